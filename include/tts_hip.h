@@ -1,0 +1,179 @@
+/*
+ * tts_hip.h — C ABI of the MI355X (gfx950) compute shim underneath TTS.cpp's
+ * tts_generation_runner API.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * What this replaces in the reference (file:line under /root/reference):
+ *   - the ggml graph build + backend-sched execution inside
+ *       parler_tts_runner::decode            src/models/parler/model.cpp:648-693
+ *       parler_tts_runner::build_parler_graph                      :520-614
+ *       parler_tts_model::prep_cross_key_values                    :110-173
+ *       parler_kv_cache_init / parler_build_kv_store               :339-385, :420-439
+ *       dac_runner::run / build_dac_graph    src/decoder/dac_model.cpp:146-212
+ *   - the weight buffer owned by tts_model (tts_model::set_tensor, src/tts_model.cpp:157-164)
+ *   - runner_context's device/backend state (src/tts_model.h:16-44)
+ * The host C++ runner (tts.cpp_amd/host) keeps tokenisation, the AR loop, sampling and the
+ * delay pattern exactly where the reference has them and calls into this ABI once per
+ * decode step and once per codec decode.
+ *
+ * Conventions: every int-returning call returns 0 on success, non-zero on failure and
+ * leaves a message retrievable by tts_hip_last_error().  The reference has no error codes
+ * (TTS_ABORT -> abort(), src/util.cpp:14-22); the C++ wrapper aborts on non-zero to match.
+ * A context is single-threaded from the caller's point of view (one HIP stream + one device
+ * per context), mirroring "one runner per worker thread" (examples/server/server.cpp:316-321).
+ */
+#ifndef TTS_HIP_H
+#define TTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ggml tensor type ids as they appear in GGUF tensor infos (examples/quantize/README.md:48-55) */
+enum tts_hip_type {
+    TTS_HIP_F32  = 0,
+    TTS_HIP_F16  = 1,
+    TTS_HIP_Q4_0 = 2,
+    TTS_HIP_Q5_0 = 6,
+    TTS_HIP_Q8_0 = 8,
+};
+
+#define TTS_HIP_MAX_DAC_BLOCKS 8
+
+/* Hyper-parameters that the reference reads from GGUF KV pairs
+ * (parler_tts_model::prep_constants model.cpp:51-108, dac_model::prep_constants/prep_layers
+ * dac_model.cpp:15-55).  Shapes that the reference takes from tensor shapes (FFN width,
+ * prompt vocab, DAC channel counts) are inferred from the uploaded tensors at finalize. */
+typedef struct tts_hip_desc {
+    uint32_t struct_size;         /* sizeof(tts_hip_desc), ABI guard */
+    /* Parler decoder */
+    uint32_t hidden_size;         /* parler-tts.decoder.hidden_size          (1024) */
+    uint32_t n_layers;            /* parler-tts.decoder.num_hidden_layers    (24)   */
+    uint32_t n_attn_heads;        /* parler-tts.decoder.attention.head_count (16)   */
+    uint32_t n_output_heads;      /* parler-tts.decoder.output_heads         (9)    */
+    uint32_t output_vocab_size;   /* parler-tts.decoder.out_vocab_size       (1088) */
+    uint32_t max_ctx_length;      /* parler-tts.decoder.context_length       (4096) */
+    uint32_t n_encode_length;     /* parler-tts.decoder.encode_length (voice prompt tokens) */
+    uint32_t use_cross_attn;      /* generation_configuration.use_cross_attn (common.h:59) */
+    /* DAC */
+    uint32_t dac_n_blocks;        /* 4 (dac_model.h:33) */
+    uint32_t dac_stride[TTS_HIP_MAX_DAC_BLOCKS];   /* dac.dac_layer_stride_i  */
+    uint32_t dac_padding[TTS_HIP_MAX_DAC_BLOCKS];  /* dac.dac_layer_padding_i */
+    uint32_t dac_max_frames;      /* parler-tts.decoder.max_generation (2580) */
+    /* engine knobs (extensions; the reference is max_seqs=1, kv F32) */
+    uint32_t max_seqs;            /* utterances decoded in lock-step on this device */
+    uint32_t kv_type;             /* TTS_HIP_F32 (reference, model.h:138-139) or TTS_HIP_F16 */
+    uint32_t gelu_mode;           /* 1 = ggml CPU's fp16-table GELU semantics, 0 = fp32 tanh GELU */
+    uint32_t flags;               /* TTS_HIP_FLAG_* */
+} tts_hip_desc;
+
+#define TTS_HIP_FLAG_NO_GRAPH   1u  /* launch kernels eagerly instead of replaying a captured hipGraph */
+#define TTS_HIP_FLAG_VALU_GEMM  2u  /* use the scalar-FMA reference GEMV kernels instead of MFMA (debug/parity) */
+#define TTS_HIP_FLAG_NO_DAC     4u  /* context carries no audio codec */
+#define TTS_HIP_FLAG_NO_PARLER  8u  /* context carries only the audio codec */
+
+typedef struct tts_hip_ctx tts_hip_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int          tts_hip_device_count(void);
+tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc);  /* NULL on failure */
+void         tts_hip_destroy(tts_hip_ctx *ctx);
+const char  *tts_hip_last_error(void);
+const char  *tts_hip_version(void);
+
+/* ---- weights -----------------------------------------------------------------------------
+ * One call per GGUF tensor, with the tensor's GGUF name, e.g.
+ * "decoder.layers.3.self_attn.q_proj.weight", "audio_encoder.decoder_block.2.residual_unit.0.res.initial.weight"
+ * (== runner->assign_weight(name, tensor), src/models/loaders.cpp:79-88, parler/model.cpp:500-508).
+ * ne[] is the GGUF order (ne[0] fastest).  host_data may be NULL: the tensor is then only
+ * declared (its bytes arrive later through the arena, see tts_hip_arena_*). Unknown names are
+ * ignored with return value 0 and a warning, like the reference (model.cpp:506). */
+int tts_hip_upload(tts_hip_ctx *ctx, const char *name, int type, int n_dims, const int64_t *ne,
+                   const void *host_data);
+
+/* Lays the weight arena out (fusing q/k/v and the lm heads into single matrices), moves the
+ * uploaded tensors into it, allocates KV cache + workspaces, and — when weights are present —
+ * runs prep_cross_key_values (model.cpp:110-173).  `external_arena` may be NULL (the shim
+ * allocates) or a device pointer of at least tts_hip_arena_bytes() bytes owned by the caller
+ * (e.g. a torch uint8 tensor that is then broadcast with RCCL). */
+size_t tts_hip_arena_bytes(tts_hip_ctx *ctx); /* valid after all uploads, before or after finalize */
+int    tts_hip_finalize(tts_hip_ctx *ctx, void *external_arena);
+void  *tts_hip_arena_ptr(tts_hip_ctx *ctx);
+/* After the arena of a declare-only context was filled by a collective: mark weights present.
+ * (cross K/V live inside the arena, so they arrive with the broadcast.) */
+int    tts_hip_arena_filled(tts_hip_ctx *ctx);
+/* update_conditional_prompt (model.cpp:510-518): replace the voice-prompt encoding
+ * [n_tokens][hidden] (fp32, host) and recompute the cross K/V. n_tokens <= n_encode_length cap given at create. */
+int    tts_hip_parler_set_text_encoding(tts_hip_ctx *ctx, const float *enc, uint32_t n_tokens);
+
+/* ---- Parler decoder -------------------------------------------------------------------- */
+/* pctx->reset + cache reuse (model.cpp:312-322,848-856): forget all sequences' positions. */
+int tts_hip_parler_reset(tts_hip_ctx *ctx);
+/* decode() with audio_generation=false (model.cpp:648-693 on a batch_from_sentence batch :473-498):
+ * run `n` text-prompt ids of sequence `seq` at positions pos0..pos0+n-1 and append their K/V.
+ * The prompt logits are never consumed by the reference (sampler only runs on audio steps,
+ * model.cpp:774-776), so none are produced. */
+int tts_hip_parler_prefill(tts_hip_ctx *ctx, uint32_t seq, const uint32_t *text_ids, uint32_t n, uint32_t pos0);
+/* decode() with audio_generation=true for n_seqs sequences in lock-step:
+ *   ids   [n_seqs][n_output_heads]  codebook ids fed this step (model.cpp:394-403,778-785)
+ *   pos   [n_seqs]                  absolute position of each sequence (model.cpp:784)
+ *   seqs  [n_seqs] or NULL          cache slot of each row (NULL = 0..n_seqs-1)
+ *   logits_out [n_seqs][n_output_heads][output_vocab_size] fp32 host memory (model.cpp:455-456,682-683)
+ * Blocks until the logits are in logits_out. */
+int tts_hip_parler_step(tts_hip_ctx *ctx, uint32_t n_seqs, const uint32_t *ids, const uint32_t *pos,
+                        const uint32_t *seqs, float *logits_out);
+/* Same step, but sampler::max (src/sampler.cpp:185-204, first maximum wins, no repetition
+ * penalty) is evaluated on the device; tokens_out [n_seqs][n_output_heads]. */
+int tts_hip_parler_step_greedy(tts_hip_ctx *ctx, uint32_t n_seqs, const uint32_t *ids, const uint32_t *pos,
+                               const uint32_t *seqs, uint32_t *tokens_out);
+/* Device-resident greedy generation of `n_steps` audio steps for n_seqs sequences whose prompts
+ * were prefetched with tts_hip_parler_prefill: the delay-pattern feed (model.cpp:778-785) and the
+ * EOS bookkeeping (check_stopping :715-732) run on the device, the host synchronises once.
+ *   start_pos [n_seqs]: position of the first audio step (prompt length)
+ *   tokens_out [n_steps][n_seqs][n_output_heads] sampled ids, still delayed (pctx->output_tokens)
+ *   steps_done [n_seqs] (may be NULL): number of steps executed before all heads saw EOS
+ * bos/eos: audio.bos_token_id / audio.eos_token_id. */
+int tts_hip_parler_generate_greedy(tts_hip_ctx *ctx, uint32_t n_seqs, const uint32_t *start_pos,
+                                   uint32_t n_steps, uint32_t bos, uint32_t eos, uint32_t *tokens_out,
+                                   uint32_t *steps_done);
+
+/* ---- DAC codec --------------------------------------------------------------------------- */
+/* dac_runner::run (dac_model.cpp:172-212): codes [frames][n_output_heads] (frame-major),
+ * pcm_out: frames * prod(strides) fp32 samples in host memory.  Blocks until done. */
+int tts_hip_dac_decode(tts_hip_ctx *ctx, const uint32_t *codes, uint32_t frames, float *pcm_out);
+
+/* ---- introspection (tests, bench) -------------------------------------------------------- */
+/* Copy an internal buffer to the host.  what: "hidden" (final-normed hidden of the last forward,
+ * [rows][H]), "k:<layer>:<seq>" / "v:<layer>:<seq>" (cache rows [n_pos][H] as fp32),
+ * "dac:<stage>" (activation after DAC stage, see oracle stage numbering; requires
+ * tts_hip_set_debug(ctx,1) before the decode).  Returns number of floats written or <0. */
+int64_t tts_hip_debug_read(tts_hip_ctx *ctx, const char *what, float *out, size_t max_floats);
+int     tts_hip_set_debug(tts_hip_ctx *ctx, int on);
+
+/* Per-kernel-class timing with HIP events on the context's stream.  While enabled, forwards are
+ * launched eagerly and every launch of every class is bracketed by an event pair. */
+enum tts_hip_kclass {
+    TTS_HIP_K_EMBED = 0, TTS_HIP_K_GEMM_LN = 1, TTS_HIP_K_GEMM = 2, TTS_HIP_K_ATTN = 3,
+    TTS_HIP_K_ATTN_CROSS = 4, TTS_HIP_K_HEADS = 5, TTS_HIP_K_DAC_EMBED = 6, TTS_HIP_K_DAC_CONV = 7,
+    TTS_HIP_K_DAC_CONVT = 8, TTS_HIP_K_SAMPLE = 9, TTS_HIP_K_COUNT = 10
+};
+typedef struct tts_hip_kstat {
+    double   ms_total;      /* summed event-elapsed time */
+    uint64_t launches;
+    double   bytes_total;   /* ALGORITHMIC bytes (weights + activations + cache rows each launch must touch) */
+    double   flops_total;   /* algorithmic flops */
+} tts_hip_kstat;
+int tts_hip_profile(tts_hip_ctx *ctx, int enable);        /* enable also clears the counters */
+int tts_hip_profile_get(tts_hip_ctx *ctx, int kclass, tts_hip_kstat *out);
+const char *tts_hip_kclass_name(int kclass);
+
+/* stream / device handles for callers that need to order their own work (torch interop) */
+void *tts_hip_stream(tts_hip_ctx *ctx);
+int   tts_hip_synchronize(tts_hip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTS_HIP_H */

@@ -1,0 +1,351 @@
+"""ctypes wrapper of oracle/liboracle.so and oracle/_ref/libref_sampler.so.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg — never by the product path (tts.cpp_amd/).  See tts_oracle.h for the parity status
+("parity unpinned" for tensor arithmetic; sampler pinned against the real reference).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_LAYERS, MAX_HEADS = 64, 16
+F32, F16, Q4_0, Q5_0, Q8_0 = 0, 1, 2, 6, 8
+
+
+class W(C.Structure):
+    _fields_ = [("type", C.c_int), ("data", C.c_void_p)]
+
+
+fp = C.POINTER(C.c_float)
+
+
+class Layer(C.Structure):
+    _fields_ = [("q", W), ("k", W), ("v", W), ("o", W), ("sa_ln_w", fp), ("sa_ln_b", fp),
+                ("cq", W), ("ck", W), ("cv", W), ("co", W), ("ca_ln_w", fp), ("ca_ln_b", fp),
+                ("fc1", W), ("fc2", W), ("f_ln_w", fp), ("f_ln_b", fp)]
+
+
+class ParlerModel(C.Structure):
+    _fields_ = [("H", C.c_int32), ("L", C.c_int32), ("n_heads", C.c_int32), ("F", C.c_int32), ("V", C.c_int32),
+                ("n_out", C.c_int32), ("n_ctx", C.c_int32), ("E", C.c_int32), ("use_cross", C.c_int32),
+                ("act_mode", C.c_int32), ("gelu_mode", C.c_int32),
+                ("embed_prompts", W), ("embed_tokens", W * MAX_HEADS), ("lm_heads", W * MAX_HEADS),
+                ("pos_embed", fp), ("text_encoding", fp), ("ln_w", fp), ("ln_b", fp),
+                ("layers", Layer * MAX_LAYERS)]
+
+
+class Sampler(C.Structure):
+    _fields_ = [("n_output_heads", C.c_uint32), ("vocab_size", C.c_uint32), ("top_k", C.c_uint32),
+                ("temperature", C.c_float), ("top_p", C.c_float), ("repetition_penalty", C.c_float),
+                ("do_sample", C.c_int), ("last_token_ids", C.c_int32 * MAX_HEADS),
+                ("repetition_counts", C.c_uint32 * MAX_HEADS), ("rep_initialised", C.c_int)]
+
+
+class DacRes(C.Structure):
+    _fields_ = [("in_alpha", fp), ("in_w", fp), ("in_b", fp), ("out_alpha", fp), ("out_w", fp), ("out_b", fp)]
+
+
+class DacBlock(C.Structure):
+    _fields_ = [("stride", C.c_int32), ("padding", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("alpha", fp), ("w", fp), ("b", fp), ("res", DacRes * 3)]
+
+
+class DacModel(C.Structure):
+    _fields_ = [("n_codebooks", C.c_int32), ("codebook_dim", C.c_int32), ("codebook_size", C.c_int32), ("latent", C.c_int32),
+                ("codebook", fp * MAX_HEADS), ("out_proj_w", fp * MAX_HEADS), ("out_proj_b", fp * MAX_HEADS),
+                ("c0", C.c_int32), ("init_w", fp), ("init_b", fp), ("n_blocks", C.c_int32), ("blocks", DacBlock * 8),
+                ("final_alpha", fp), ("final_w", fp), ("final_b", fp)]
+
+
+class RefSamplerCfg(C.Structure):
+    _fields_ = [("n_output_heads", C.c_uint32), ("vocab_size", C.c_uint32), ("top_k", C.c_uint32),
+                ("temperature", C.c_float), ("top_p", C.c_float), ("repetition_penalty", C.c_float), ("do_sample", C.c_int)]
+
+
+_lib = None
+_ref = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", HERE], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        p = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(p):
+            build()
+        L = C.CDLL(p)
+        L.orc_h2f.restype = C.c_float
+        L.orc_h2f.argtypes = [C.c_uint16]
+        L.orc_f2h.restype = C.c_uint16
+        L.orc_f2h.argtypes = [C.c_float]
+        L.orc_row_bytes.restype = C.c_size_t
+        L.orc_row_bytes.argtypes = [C.c_int, C.c_int64]
+        L.orc_dequantize.argtypes = [C.c_int, C.c_void_p, fp, C.c_int64]
+        L.orc_quantize.argtypes = [C.c_int, fp, C.c_void_p, C.c_int64]
+        L.orc_mul_mat.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, fp, C.c_int64, fp, C.c_int]
+        L.orc_mul_mat.restype = None
+        L.orc_parler_state_new.restype = C.c_void_p
+        L.orc_parler_state_new.argtypes = [C.POINTER(ParlerModel)]
+        L.orc_parler_state_free.argtypes = [C.c_void_p]
+        L.orc_parler_state_free.restype = None
+        L.orc_parler_prep_cross.argtypes = [C.POINTER(ParlerModel), C.c_void_p]
+        L.orc_parler_prep_cross.restype = None
+        L.orc_parler_decode.argtypes = [C.POINTER(ParlerModel), C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_int,
+                                        C.c_uint32, fp, fp]
+        L.orc_parler_decode.restype = None
+        L.orc_parler_get_kv.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, fp]
+        L.orc_parler_get_kv.restype = None
+        L.orc_parler_next_ids.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.c_uint32,
+                                          C.c_uint32, C.POINTER(C.c_uint32)]
+        L.orc_parler_next_ids.restype = None
+        L.orc_parler_adjust_output_tokens.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.c_uint32, C.c_uint32,
+                                                      C.POINTER(C.c_uint32)]
+        L.orc_parler_adjust_output_tokens.restype = C.c_size_t
+        L.orc_sampler_init.argtypes = [C.POINTER(Sampler), C.c_uint32, C.c_uint32]
+        L.orc_sampler_reset.argtypes = [C.POINTER(Sampler)]
+        L.orc_sampler_max.argtypes = [C.POINTER(Sampler), fp, C.POINTER(C.c_uint32)]
+        L.orc_sampler_sample.argtypes = [C.POINTER(Sampler), fp, fp, C.POINTER(C.c_uint32)]
+        L.orc_dac_decode.argtypes = [C.POINTER(DacModel), C.POINTER(C.c_uint32), C.c_int, fp, C.c_int, fp]
+        L.orc_dac_decode.restype = C.c_int64
+        L.orc_conv1d.argtypes = [fp, C.c_int, C.c_int64, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.orc_conv1d.restype = None
+        L.orc_conv_transpose1d.argtypes = [fp, C.c_int, C.c_int64, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.orc_conv_transpose1d.restype = None
+        L.orc_snake.argtypes = [fp, C.c_int, C.c_int64, fp]
+        L.orc_snake.restype = None
+        L.orc_layer_norm.argtypes = [fp, C.c_int, fp, fp, fp]
+        L.orc_layer_norm.restype = None
+        L.orc_gelu.argtypes = [C.c_float, C.c_int]
+        L.orc_gelu.restype = C.c_float
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def ref_sampler_lib():
+    """The REAL reference sampler (oracle/_ref/libref_sampler.so); None if it was never built."""
+    global _ref
+    if _ref is None:
+        p = os.path.join(HERE, "_ref", "libref_sampler.so")
+        if not os.path.exists(p):
+            if os.path.exists("/root/reference/src/sampler.cpp"):
+                build()
+            if not os.path.exists(p):
+                return None
+        R = C.CDLL(p)
+        u32p = C.POINTER(C.c_uint32)
+        R.ref_sampler_max.argtypes = [C.POINTER(RefSamplerCfg), C.POINTER(C.c_int32), u32p, fp, u32p]
+        R.ref_sampler_max.restype = None
+        R.ref_sampler_sample_greedy.argtypes = [C.POINTER(RefSamplerCfg), fp, u32p]
+        R.ref_sampler_sample_greedy.restype = None
+        R.ref_sampler_distribution.argtypes = [C.POINTER(RefSamplerCfg), C.POINTER(C.c_int32), u32p, fp, u32p, u32p, fp]
+        R.ref_sampler_distribution.restype = C.c_int
+        _ref = R
+    return _ref
+
+
+def f32p(a):
+    return a.ctypes.data_as(fp)
+
+
+def u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def dequantize(ttype, raw, n):
+    raw = np.frombuffer(bytes(raw), dtype=np.uint8)
+    out = np.empty(n, dtype=np.float32)
+    assert lib().orc_dequantize(ttype, raw.ctypes.data_as(C.c_void_p), f32p(out), n) == 0
+    return out
+
+
+def quantize(ttype, arr):
+    arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+    out = np.zeros(lib().orc_row_bytes(ttype, arr.size), dtype=np.uint8)
+    assert lib().orc_quantize(ttype, f32p(arr), out.ctypes.data_as(C.c_void_p), arr.size) == 0
+    return out
+
+
+def mul_mat(ttype, raw, K, N, x, act_mode=0):
+    raw = np.frombuffer(bytes(raw), dtype=np.uint8)
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, K)
+    y = np.empty((x.shape[0], N), dtype=np.float32)
+    lib().orc_mul_mat(ttype, raw.ctypes.data_as(C.c_void_p), K, N, f32p(x), x.shape[0], f32p(y), act_mode)
+    return y
+
+
+class ParlerOracle:
+    """Oracle twin of a tts_cpp_amd.synth.SynthModel (any object with .cfg and .by_name of GGUF tensors)."""
+
+    def __init__(self, model, act_mode=1, gelu_mode=1, use_cross=True):
+        self.L = lib()
+        cfg = model.cfg
+        self.cfg = cfg
+        self.keep = []
+        m = ParlerModel()
+        m.H, m.L, m.n_heads, m.F, m.V = cfg.hidden, cfg.layers, cfg.heads, cfg.ffn, cfg.out_vocab
+        m.n_out, m.n_ctx, m.E, m.use_cross = cfg.n_out, cfg.ctx, cfg.enc_len, 1 if use_cross else 0
+        m.act_mode, m.gelu_mode = act_mode, gelu_mode
+        t = model.by_name
+
+        def w(name):
+            raw = np.frombuffer(bytes(t[name].raw()), dtype=np.uint8)
+            self.keep.append(raw)
+            return W(t[name].type, raw.ctypes.data_as(C.c_void_p).value)
+
+        def f(name):
+            a = np.ascontiguousarray(t[name].to_f32().reshape(-1))
+            self.keep.append(a)
+            return f32p(a)
+
+        m.embed_prompts = w("decoder.embed_prompts")
+        m.pos_embed = f("decoder.positional_embed")
+        m.text_encoding = f("decoder.text_encoding")
+        m.ln_w, m.ln_b = f("decoder.layer_norm.weight"), f("decoder.layer_norm.bias")
+        for i in range(cfg.n_out):
+            m.embed_tokens[i] = w(f"decoder.embed_tokens.{i}.weight")
+            m.lm_heads[i] = w(f"decoder.lm_heads.{i}.weight.head")
+        for l in range(cfg.layers):
+            p = f"decoder.layers.{l}."
+            y = m.layers[l]
+            y.q, y.k, y.v, y.o = (w(p + f"self_attn.{n}_proj.weight") for n in ("q", "k", "v", "out"))
+            y.sa_ln_w, y.sa_ln_b = f(p + "self_attn_layer_norm.weight"), f(p + "self_attn_layer_norm.bias")
+            y.cq, y.ck, y.cv, y.co = (w(p + f"encoder_attn.{n}_proj.weight") for n in ("q", "k", "v", "out"))
+            y.ca_ln_w, y.ca_ln_b = f(p + "encoder_attn_layer_norm.weight"), f(p + "encoder_attn_layer_norm.bias")
+            y.fc1, y.fc2 = w(p + "fc1.weight"), w(p + "fc2.weight")
+            y.f_ln_w, y.f_ln_b = f(p + "final_layer_norm.weight"), f(p + "final_layer_norm.bias")
+        self.m = m
+        self.state = None
+        self.reset()
+
+    def reset(self):
+        if self.state:
+            self.L.orc_parler_state_free(self.state)
+        self.state = self.L.orc_parler_state_new(C.byref(self.m))
+        self.L.orc_parler_prep_cross(C.byref(self.m), self.state)
+
+    def set_text_encoding(self, enc):
+        enc = np.ascontiguousarray(enc, dtype=np.float32)
+        self.keep.append(enc)
+        self.m.text_encoding = f32p(enc)
+        self.m.E = enc.shape[0]
+        self.reset()
+
+    def __del__(self):
+        try:
+            if self.state:
+                self.L.orc_parler_state_free(self.state)
+        except Exception:
+            pass
+
+    def decode(self, tokens, pos0, audio, want_logits=True, want_hidden=False):
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        S = 1 if audio else tokens.size
+        logits = np.empty((self.cfg.n_out, S, self.cfg.out_vocab), dtype=np.float32) if want_logits else None
+        hidden = np.empty((S, self.cfg.hidden), dtype=np.float32) if want_hidden else None
+        self.L.orc_parler_decode(C.byref(self.m), self.state, 1 if audio else 0, u32p(tokens), S, pos0,
+                                 f32p(logits) if want_logits else None, f32p(hidden) if want_hidden else None)
+        return logits, hidden
+
+    def get_kv(self, layer, n_pos):
+        k = np.empty((n_pos, self.cfg.hidden), dtype=np.float32)
+        v = np.empty((n_pos, self.cfg.hidden), dtype=np.float32)
+        self.L.orc_parler_get_kv(self.state, layer, n_pos, f32p(k), f32p(v))
+        return k, v
+
+    def generate_greedy(self, prompt_ids, n_steps):
+        """The reference's generate_from_batch loop (model.cpp:762-792) under greedy sampling, for a
+        fixed number of audio steps.  Returns (tokens [n_steps][n_out], logits [n_steps][n_out][V])."""
+        cfg = self.cfg
+        self.reset()
+        self.decode(prompt_ids, 0, audio=False, want_logits=False)
+        pos = len(prompt_ids)
+        ids = np.full(cfg.n_out, cfg.bos, dtype=np.uint32)
+        eos_seen = np.zeros(cfg.n_out, dtype=np.uint8)
+        smp = Sampler()
+        self.L.orc_sampler_init(C.byref(smp), cfg.n_out, cfg.out_vocab)
+        smp.do_sample = 0
+        toks_all, logits_all = [], []
+        for step in range(1, n_steps + 1):
+            logits, _ = self.decode(ids, pos, audio=True)
+            lg = np.ascontiguousarray(logits[:, 0, :])
+            toks = np.empty(cfg.n_out, dtype=np.uint32)
+            self.L.orc_sampler_sample(C.byref(smp), f32p(lg.copy()), None, u32p(toks))
+            toks_all.append(toks.copy())
+            logits_all.append(lg)
+            pos += 1
+            eos_seen |= (toks == cfg.eos).astype(np.uint8)  # what the next check_stopping() records
+            nxt = np.empty(cfg.n_out, dtype=np.uint32)
+            # the reference evaluates eos_seen from the *previous* check_stopping; feeding eos when the
+            # token just sampled IS eos gives the same id (model.cpp:781)
+            self.L.orc_parler_next_ids(cfg.n_out, step, u32p(toks), eos_seen.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                       cfg.bos, cfg.eos, u32p(nxt))
+            ids = nxt
+        return np.stack(toks_all), np.stack(logits_all)
+
+
+class DacOracle:
+    def __init__(self, model):
+        self.L = lib()
+        cfg = model.cfg
+        self.cfg = cfg
+        self.keep = []
+        t = model.by_name
+
+        def f(name):
+            a = np.ascontiguousarray(t[name].to_f32().reshape(-1))
+            self.keep.append(a)
+            return f32p(a)
+
+        m = DacModel()
+        m.n_codebooks, m.codebook_dim, m.codebook_size, m.latent = cfg.n_out, cfg.cb_dim, cfg.cb_size, cfg.latent
+        for i in range(cfg.n_out):
+            p = f"audio_encoder.quantizers.{i}."
+            m.codebook[i], m.out_proj_w[i], m.out_proj_b[i] = f(p + "codebook.weight"), f(p + "out_proj.weight"), f(p + "out_proj.bias")
+        m.c0 = cfg.c0
+        m.init_w, m.init_b = f("audio_encoder.initial.weight"), f("audio_encoder.initial.bias")
+        m.n_blocks = len(cfg.strides)
+        c = cfg.c0
+        for bi, (s, pd) in enumerate(zip(cfg.strides, cfg.paddings)):
+            p = f"audio_encoder.decoder_block.{bi + 1}."
+            b = m.blocks[bi]
+            b.stride, b.padding, b.cin, b.cout = s, pd, c, c // 2
+            b.alpha, b.w, b.b = f(p + "final.alpha"), f(p + "final.weight"), f(p + "final.bias")
+            for r in range(3):
+                q = p + f"residual_unit.{r}.res."
+                rr = b.res[r]
+                rr.in_alpha, rr.in_w, rr.in_b = f(q + "initial.alpha"), f(q + "initial.weight"), f(q + "initial.bias")
+                rr.out_alpha, rr.out_w, rr.out_b = f(q + "final.alpha"), f(q + "final.weight"), f(q + "final.bias")
+            c //= 2
+        m.final_alpha, m.final_w, m.final_b = f("audio_encoder.final.alpha"), f("audio_encoder.final.weight"), f("audio_encoder.final.bias")
+        self.m = m
+
+    def stage_shape(self, stage, frames):
+        cfg = self.cfg
+        if stage == 0:
+            return (cfg.latent, frames)
+        if stage == 1:
+            return (cfg.c0, frames)
+        c, L = cfg.c0, frames
+        for s in cfg.strides[:stage - 1]:
+            c //= 2
+            L *= s
+        return (c, L)
+
+    def decode(self, codes, stage=-1):
+        codes = np.ascontiguousarray(codes, dtype=np.uint32).reshape(-1, self.cfg.n_out)
+        frames = codes.shape[0]
+        pcm = np.empty(frames * self.cfg.hop, dtype=np.float32)
+        st = None
+        if stage >= 0:
+            st = np.empty(self.stage_shape(stage, frames), dtype=np.float32)
+        n = self.L.orc_dac_decode(C.byref(self.m), u32p(codes), frames, f32p(pcm), stage, f32p(st) if st is not None else None)
+        assert n == pcm.size
+        return (pcm, st) if stage >= 0 else pcm

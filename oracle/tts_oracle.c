@@ -1,0 +1,800 @@
+/*
+ * tts_oracle.c — CPU restatement of the TTS.cpp Parler-TTS decoder step, sampler, delay
+ * pattern and DAC decoder.  TEST INFRASTRUCTURE ONLY (see tts_oracle.h header comment):
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * "parity unpinned" for tensor arithmetic (ggml fork absent, no reference golden vectors);
+ * sampler pinned against the real reference sampler.cpp via oracle/_ref (see Makefile).
+ *
+ * Citations are file:line under /root/reference.
+ */
+#include "tts_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ======================================================================================
+ * fp16 <-> fp32 (IEEE binary16, round-to-nearest-even) — what GGML_FP32_TO_FP16 does on
+ * every platform (F16C / NEON / the portable bit-twiddling fallback all implement RNE).
+ * ==================================================================================== */
+float orc_h2f(uint16_t h) {
+    uint32_t sign = (uint32_t) (h & 0x8000u) << 16;
+    uint32_t exp  = (h >> 10) & 0x1Fu;
+    uint32_t man  = h & 0x3FFu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else { /* subnormal */
+            int e = -1;
+            do { e++; man <<= 1; } while ((man & 0x400u) == 0);
+            man &= 0x3FFu;
+            bits = sign | ((uint32_t) (127 - 15 - e) << 23) | (man << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7F800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 112u) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+uint16_t orc_f2h(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t absx = x & 0x7FFFFFFFu;
+    if (absx >= 0x7F800000u) { /* inf / nan */
+        return (uint16_t) (sign | 0x7C00u | ((absx > 0x7F800000u) ? 0x200u : 0));
+    }
+    if (absx >= 0x477FF000u) { /* rounds to >= 65520 -> inf */
+        return (uint16_t) (sign | 0x7C00u);
+    }
+    if (absx < 0x38800000u) { /* subnormal half or zero */
+        if (absx < 0x33000000u) return (uint16_t) sign; /* < 2^-25 -> 0 */
+        uint32_t e = absx >> 23;
+        uint32_t m = (absx & 0x7FFFFFu) | 0x800000u;
+        uint32_t shift = 126 - e; /* 14..24 */
+        uint32_t r = m >> shift;
+        uint32_t rem = m & ((1u << shift) - 1u);
+        uint32_t half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1u))) r++;
+        return (uint16_t) (sign | r);
+    }
+    uint32_t e = (absx >> 23) - 112u;
+    uint32_t m = absx & 0x7FFFFFu;
+    uint32_t r = (e << 10) | (m >> 13);
+    uint32_t rem = m & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++;
+    return (uint16_t) (sign | r);
+}
+
+/* ======================================================================================
+ * ggml block formats.  Layouts per SURVEY.md A.3 (upstream ggml-common.h knowledge):
+ *   Q4_0: { fp16 d; u8 qs[16] }          Q5_0: { fp16 d; u8 qh[4]; u8 qs[16] }
+ *   Q8_0: { fp16 d; i8 qs[32] }
+ * Quantizers restate upstream quantize_row_q{4_0,5_0,8_0}_ref (ggml-quants.c).
+ * ==================================================================================== */
+#define QK 32
+
+size_t orc_row_bytes(int type, int64_t n) {
+    switch (type) {
+        case ORC_F32:  return (size_t) n * 4;
+        case ORC_F16:  return (size_t) n * 2;
+        case ORC_Q4_0: return (size_t) (n / QK) * 18;
+        case ORC_Q5_0: return (size_t) (n / QK) * 22;
+        case ORC_Q8_0: return (size_t) (n / QK) * 34;
+        default: return 0;
+    }
+}
+
+int orc_dequantize(int type, const void *src, float *dst, int64_t n) {
+    const uint8_t *p = (const uint8_t *) src;
+    switch (type) {
+        case ORC_F32:
+            memcpy(dst, src, (size_t) n * 4);
+            return 0;
+        case ORC_F16: {
+            const uint16_t *h = (const uint16_t *) src;
+            for (int64_t i = 0; i < n; i++) dst[i] = orc_h2f(h[i]);
+            return 0;
+        }
+        case ORC_Q4_0:
+            for (int64_t b = 0; b < n / QK; b++, p += 18, dst += QK) {
+                uint16_t dh; memcpy(&dh, p, 2);
+                float d = orc_h2f(dh);
+                const uint8_t *qs = p + 2;
+                for (int j = 0; j < 16; j++) {
+                    dst[j]      = (float) ((int) (qs[j] & 0x0F) - 8) * d;
+                    dst[j + 16] = (float) ((int) (qs[j] >> 4) - 8) * d;
+                }
+            }
+            return 0;
+        case ORC_Q5_0:
+            for (int64_t b = 0; b < n / QK; b++, p += 22, dst += QK) {
+                uint16_t dh; memcpy(&dh, p, 2);
+                float d = orc_h2f(dh);
+                uint32_t qh; memcpy(&qh, p + 2, 4);
+                const uint8_t *qs = p + 6;
+                for (int j = 0; j < 16; j++) {
+                    uint8_t xh0 = (uint8_t) (((qh >> (j + 0)) << 4) & 0x10);
+                    uint8_t xh1 = (uint8_t) ((qh >> (j + 12)) & 0x10);
+                    dst[j]      = (float) ((int) ((qs[j] & 0x0F) | xh0) - 16) * d;
+                    dst[j + 16] = (float) ((int) ((qs[j] >> 4) | xh1) - 16) * d;
+                }
+            }
+            return 0;
+        case ORC_Q8_0:
+            for (int64_t b = 0; b < n / QK; b++, p += 34, dst += QK) {
+                uint16_t dh; memcpy(&dh, p, 2);
+                float d = orc_h2f(dh);
+                const int8_t *qs = (const int8_t *) (p + 2);
+                for (int j = 0; j < QK; j++) dst[j] = (float) qs[j] * d;
+            }
+            return 0;
+        default:
+            return -1;
+    }
+}
+
+static void quant_q8_0_block(const float *x, uint8_t *p) {
+    float amax = 0.0f;
+    for (int j = 0; j < QK; j++) { float v = fabsf(x[j]); if (v > amax) amax = v; }
+    const float d  = amax / 127.0f;
+    const float id = d ? 1.0f / d : 0.0f;
+    uint16_t dh = orc_f2h(d);
+    memcpy(p, &dh, 2);
+    int8_t *qs = (int8_t *) (p + 2);
+    for (int j = 0; j < QK; j++) qs[j] = (int8_t) roundf(x[j] * id);
+}
+
+int orc_quantize(int type, const float *src, void *dst, int64_t n) {
+    uint8_t *p = (uint8_t *) dst;
+    switch (type) {
+        case ORC_F32:
+            memcpy(dst, src, (size_t) n * 4);
+            return 0;
+        case ORC_F16: {
+            uint16_t *h = (uint16_t *) dst;
+            for (int64_t i = 0; i < n; i++) h[i] = orc_f2h(src[i]);
+            return 0;
+        }
+        case ORC_Q4_0:
+            for (int64_t b = 0; b < n / QK; b++, p += 18, src += QK) {
+                float amax = 0.0f, max = 0.0f;
+                for (int j = 0; j < QK; j++) { float v = src[j]; if (amax < fabsf(v)) { amax = fabsf(v); max = v; } }
+                const float d  = max / -8.0f;
+                const float id = d ? 1.0f / d : 0.0f;
+                uint16_t dh = orc_f2h(d);
+                memcpy(p, &dh, 2);
+                uint8_t *qs = p + 2;
+                for (int j = 0; j < 16; j++) {
+                    float x0 = src[j] * id, x1 = src[j + 16] * id;
+                    uint8_t xi0 = (uint8_t) (int8_t) (x0 + 8.5f); if (xi0 > 15) xi0 = 15;
+                    uint8_t xi1 = (uint8_t) (int8_t) (x1 + 8.5f); if (xi1 > 15) xi1 = 15;
+                    qs[j] = (uint8_t) (xi0 | (xi1 << 4));
+                }
+            }
+            return 0;
+        case ORC_Q5_0:
+            for (int64_t b = 0; b < n / QK; b++, p += 22, src += QK) {
+                float amax = 0.0f, max = 0.0f;
+                for (int j = 0; j < QK; j++) { float v = src[j]; if (amax < fabsf(v)) { amax = fabsf(v); max = v; } }
+                const float d  = max / -16.0f;
+                const float id = d ? 1.0f / d : 0.0f;
+                uint16_t dh = orc_f2h(d);
+                memcpy(p, &dh, 2);
+                uint32_t qh = 0;
+                uint8_t *qs = p + 6;
+                for (int j = 0; j < 16; j++) {
+                    float x0 = src[j] * id, x1 = src[j + 16] * id;
+                    uint8_t xi0 = (uint8_t) (int8_t) (x0 + 16.5f); if (xi0 > 31) xi0 = 31;
+                    uint8_t xi1 = (uint8_t) (int8_t) (x1 + 16.5f); if (xi1 > 31) xi1 = 31;
+                    qs[j] = (uint8_t) ((xi0 & 0x0F) | ((xi1 & 0x0F) << 4));
+                    qh |= ((uint32_t) ((xi0 & 0x10u) >> 4)) << (j + 0);
+                    qh |= ((uint32_t) ((xi1 & 0x10u) >> 4)) << (j + 16);
+                }
+                memcpy(p + 2, &qh, 4);
+            }
+            return 0;
+        case ORC_Q8_0:
+            for (int64_t b = 0; b < n / QK; b++, p += 34, src += QK) quant_q8_0_block(src, p);
+            return 0;
+        default:
+            return -1;
+    }
+}
+
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void) n;
+    return 1;
+#endif
+}
+
+/* ======================================================================================
+ * mul_mat.  ggml_mul_mat(W, x) with W ne=[K,N] (N rows of K), x ne=[K,R] -> y ne=[N,R].
+ * Dot products accumulate in double (ggml accumulates in fp32 SIMD lanes in an
+ * implementation-defined order; double is the order-independent statement of the same sum).
+ * act_mode 1 restates ggml_compute_forward_mul_mat's conversion of src1 to the weight
+ * type's vec_dot_type (upstream ggml knowledge; SURVEY.md §7 "Hard parts").
+ * ==================================================================================== */
+static double dot_q_q8(int type, const uint8_t *w, const uint8_t *a, int64_t K) {
+    /* integer block dot like ggml_vec_dot_q{4_0,5_0,8_0}_q8_0 */
+    double sum = 0.0;
+    for (int64_t b = 0; b < K / QK; b++) {
+        const uint8_t *ab = a + b * 34;
+        uint16_t adh; memcpy(&adh, ab, 2);
+        const int8_t *aq = (const int8_t *) (ab + 2);
+        int32_t sumi = 0;
+        float wd;
+        if (type == ORC_Q4_0) {
+            const uint8_t *wb = w + b * 18;
+            uint16_t dh; memcpy(&dh, wb, 2); wd = orc_h2f(dh);
+            const uint8_t *qs = wb + 2;
+            for (int j = 0; j < 16; j++) {
+                sumi += ((int) (qs[j] & 0x0F) - 8) * aq[j] + ((int) (qs[j] >> 4) - 8) * aq[j + 16];
+            }
+        } else if (type == ORC_Q5_0) {
+            const uint8_t *wb = w + b * 22;
+            uint16_t dh; memcpy(&dh, wb, 2); wd = orc_h2f(dh);
+            uint32_t qh; memcpy(&qh, wb + 2, 4);
+            const uint8_t *qs = wb + 6;
+            for (int j = 0; j < 16; j++) {
+                uint8_t xh0 = (uint8_t) (((qh >> (j + 0)) << 4) & 0x10);
+                uint8_t xh1 = (uint8_t) ((qh >> (j + 12)) & 0x10);
+                sumi += ((int) ((qs[j] & 0x0F) | xh0) - 16) * aq[j] + ((int) ((qs[j] >> 4) | xh1) - 16) * aq[j + 16];
+            }
+        } else { /* Q8_0 */
+            const uint8_t *wb = w + b * 34;
+            uint16_t dh; memcpy(&dh, wb, 2); wd = orc_h2f(dh);
+            const int8_t *qs = (const int8_t *) (wb + 2);
+            for (int j = 0; j < QK; j++) sumi += (int) qs[j] * aq[j];
+        }
+        sum += (double) ((float) sumi * (wd * orc_h2f(adh)));
+    }
+    return sum;
+}
+
+void orc_mul_mat(int type, const void *W, int64_t K, int64_t N, const float *x, int64_t R,
+                 float *y, int act_mode) {
+    const size_t rb = orc_row_bytes(type, K);
+    const uint8_t *wp = (const uint8_t *) W;
+    const int quant = (type == ORC_Q4_0 || type == ORC_Q5_0 || type == ORC_Q8_0);
+
+    if (quant && act_mode == 1) {
+        uint8_t *aq = (uint8_t *) malloc((size_t) R * (size_t) (K / QK) * 34);
+        for (int64_t r = 0; r < R; r++)
+            for (int64_t b = 0; b < K / QK; b++) quant_q8_0_block(x + r * K + b * QK, aq + (r * (K / QK) + b) * 34);
+#pragma omp parallel for schedule(static)
+        for (int64_t n = 0; n < N; n++)
+            for (int64_t r = 0; r < R; r++)
+                y[r * N + n] = (float) dot_q_q8(type, wp + (size_t) n * rb, aq + (size_t) r * (size_t) (K / QK) * 34, K);
+        free(aq);
+        return;
+    }
+
+    float *xa = NULL;
+    const float *xs = x;
+    if (type == ORC_F16 && act_mode == 1) { /* activations rounded to fp16 (vec_dot_type F16) */
+        xa = (float *) malloc((size_t) R * (size_t) K * 4);
+        for (int64_t i = 0; i < R * K; i++) xa[i] = orc_h2f(orc_f2h(x[i]));
+        xs = xa;
+    }
+#pragma omp parallel
+    {
+        float *row = (float *) malloc((size_t) K * 4);
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; n++) {
+            const float *wr;
+            if (type == ORC_F32) {
+                wr = (const float *) (wp + (size_t) n * rb);
+            } else {
+                orc_dequantize(type, wp + (size_t) n * rb, row, K);
+                wr = row;
+            }
+            for (int64_t r = 0; r < R; r++) {
+                const float *xr = xs + r * K;
+                double acc = 0.0;
+                for (int64_t k = 0; k < K; k++) acc += (double) wr[k] * (double) xr[k];
+                y[r * N + n] = (float) acc;
+            }
+        }
+        free(row);
+    }
+    free(xa);
+}
+
+/* ======================================================================================
+ * elementwise pieces
+ * ==================================================================================== */
+/* parler_build_layer_norm (model.cpp:412-418): ggml_norm eps=1e-5, * weight, + bias.
+ * ggml_norm: mean and variance in double (ggml_float), scale = 1/sqrtf(var + eps). */
+void orc_layer_norm(const float *x, int H, const float *w, const float *b, float *y) {
+    double sum = 0.0;
+    for (int i = 0; i < H; i++) sum += (double) x[i];
+    float mean = (float) (sum / H);
+    double sum2 = 0.0;
+    for (int i = 0; i < H; i++) { float v = x[i] - mean; y[i] = v; sum2 += (double) (v * v); }
+    float variance = (float) (sum2 / H);
+    const float scale = 1.0f / sqrtf(variance + 1e-5f);
+    for (int i = 0; i < H; i++) y[i] = y[i] * scale * w[i] + b[i];
+}
+
+/* ggml_gelu (model.cpp:602).  mode 0: fp32 tanh approximation.  mode 1: ggml CPU's fp16
+ * lookup table (ggml_vec_gelu_f32 with GGML_GELU_FP16; upstream knowledge): the input is
+ * rounded to fp16, gelu evaluated in fp32 and the result rounded to fp16 again; |x|>=10 bypass. */
+static float gelu_f32(float x) {
+    const float GELU_COEF_A = 0.044715f, SQRT_2_OVER_PI = 0.79788456080286535587989211986876f;
+    return 0.5f * x * (1.0f + tanhf(SQRT_2_OVER_PI * x * (1.0f + GELU_COEF_A * x * x)));
+}
+float orc_gelu(float x, int mode) {
+    if (mode == 0) return gelu_f32(x);
+    if (x <= -10.0f) return 0.0f;
+    if (x >= 10.0f) return x;
+    return orc_h2f(orc_f2h(gelu_f32(orc_h2f(orc_f2h(x)))));
+}
+
+/* ======================================================================================
+ * Parler decoder
+ * ==================================================================================== */
+struct orc_parler_state {
+    int H, L, n_ctx, E;
+    float *k, *v;   /* [L][n_ctx][H]  (the reference stores V transposed, model.cpp:432-436;
+                       layout is free as long as the arithmetic is the same) */
+    float *ck, *cv; /* [L][E][H] */
+};
+
+orc_parler_state *orc_parler_state_new(const orc_parler_model *m) {
+    orc_parler_state *s = (orc_parler_state *) calloc(1, sizeof(*s));
+    s->H = m->H; s->L = m->L; s->n_ctx = m->n_ctx; s->E = m->E;
+    size_t n = (size_t) m->L * m->n_ctx * m->H;
+    s->k = (float *) calloc(n, 4);
+    s->v = (float *) calloc(n, 4);
+    size_t nc = (size_t) m->L * (m->E > 0 ? m->E : 1) * m->H;
+    s->ck = (float *) calloc(nc, 4);
+    s->cv = (float *) calloc(nc, 4);
+    return s;
+}
+void orc_parler_state_free(orc_parler_state *s) {
+    if (!s) return;
+    free(s->k); free(s->v); free(s->ck); free(s->cv); free(s);
+}
+
+void orc_parler_prep_cross(const orc_parler_model *m, orc_parler_state *s) {
+    if (!m->use_cross) return;
+    for (int l = 0; l < m->L; l++) { /* model.cpp:138-140 */
+        orc_mul_mat(m->layers[l].ck.type, m->layers[l].ck.data, m->H, m->H, m->text_encoding, m->E,
+                    s->ck + (size_t) l * m->E * m->H, m->act_mode);
+        orc_mul_mat(m->layers[l].cv.type, m->layers[l].cv.data, m->H, m->H, m->text_encoding, m->E,
+                    s->cv + (size_t) l * m->E * m->H, m->act_mode);
+    }
+}
+
+void orc_parler_get_kv(const orc_parler_state *s, int layer, int n_pos, float *k_out, float *v_out) {
+    memcpy(k_out, s->k + (size_t) layer * s->n_ctx * s->H, (size_t) n_pos * s->H * 4);
+    memcpy(v_out, s->v + (size_t) layer * s->n_ctx * s->H, (size_t) n_pos * s->H * 4);
+}
+
+static void get_row(const orc_w *w, int64_t row, int H, float *dst) {
+    const uint8_t *p = (const uint8_t *) w->data + (size_t) row * orc_row_bytes(w->type, H);
+    orc_dequantize(w->type, p, dst, H);
+}
+
+/* softmax(scale*x [+ mask]) over n (ggml_soft_max_ext, model.cpp:567,589): max, expf(x-max),
+ * double sum, scale by 1/sum. */
+static void softmax_scaled(float *x, int n, float scale) {
+    float mx = -INFINITY;
+    for (int i = 0; i < n; i++) { x[i] *= scale; if (x[i] > mx) mx = x[i]; }
+    double sum = 0.0;
+    for (int i = 0; i < n; i++) { x[i] = expf(x[i] - mx); sum += (double) x[i]; }
+    const float inv = (float) (1.0 / sum);
+    for (int i = 0; i < n; i++) x[i] *= inv;
+}
+
+/* attention of one query row against n_keys rows of K,V ([n][H] position-major), per head */
+static void attend(const float *q, const float *K, const float *V, int n_keys, int H, int n_heads,
+                   float *out, float *scores) {
+    const int d = H / n_heads;
+    const float scale = 1.0f / sqrtf((float) d);
+    for (int h = 0; h < n_heads; h++) {
+        for (int t = 0; t < n_keys; t++) {
+            double acc = 0.0;
+            const float *kr = K + (size_t) t * H + h * d;
+            for (int c = 0; c < d; c++) acc += (double) kr[c] * (double) q[h * d + c];
+            scores[t] = (float) acc;
+        }
+        softmax_scaled(scores, n_keys, scale);
+        for (int c = 0; c < d; c++) {
+            double acc = 0.0;
+            for (int t = 0; t < n_keys; t++) acc += (double) scores[t] * (double) V[(size_t) t * H + h * d + c];
+            out[h * d + c] = (float) acc;
+        }
+    }
+}
+
+void orc_parler_decode(const orc_parler_model *m, orc_parler_state *s, int audio,
+                       const uint32_t *tokens, int S, uint32_t pos0, float *logits_out,
+                       float *hidden_out) {
+    const int H = m->H, F = m->F;
+    float *x   = (float *) malloc((size_t) S * H * 4);
+    float *cur = (float *) malloc((size_t) S * H * 4);
+    float *q   = (float *) malloc((size_t) S * H * 4);
+    float *kk  = (float *) malloc((size_t) S * H * 4);
+    float *vv  = (float *) malloc((size_t) S * H * 4);
+    float *att = (float *) malloc((size_t) S * H * 4);
+    float *tmp = (float *) malloc((size_t) S * H * 4);
+    float *ff  = (float *) malloc((size_t) S * F * 4);
+    float *row = (float *) malloc((size_t) H * 4);
+    float *scores = (float *) malloc((size_t) (m->n_ctx > m->E ? m->n_ctx : m->E) * 4);
+
+    /* parler_build_inp_embd (model.cpp:387-410) */
+    for (int sidx = 0; sidx < S; sidx++) {
+        float *xr = x + (size_t) sidx * H;
+        if (audio) {
+            for (int i = 0; i < m->n_out; i++) {
+                get_row(&m->embed_tokens[i], tokens[i], H, row);
+                if (i == 0) memcpy(xr, row, (size_t) H * 4);
+                else for (int c = 0; c < H; c++) xr[c] = row[c] + xr[c];
+            }
+        } else {
+            get_row(&m->embed_prompts, tokens[sidx], H, xr);
+        }
+        const float *pe = m->pos_embed + (size_t) (pos0 + sidx) * H;
+        for (int c = 0; c < H; c++) xr[c] = xr[c] + pe[c];
+    }
+
+    for (int l = 0; l < m->L; l++) {
+        const orc_parler_layer *ly = &m->layers[l];
+        float *Kl = s->k + (size_t) l * s->n_ctx * H;
+        float *Vl = s->v + (size_t) l * s->n_ctx * H;
+        /* self attention (model.cpp:538-574) */
+        for (int i = 0; i < S; i++) orc_layer_norm(x + (size_t) i * H, H, ly->sa_ln_w, ly->sa_ln_b, cur + (size_t) i * H);
+        orc_mul_mat(ly->q.type, ly->q.data, H, H, cur, S, q, m->act_mode);
+        orc_mul_mat(ly->k.type, ly->k.data, H, H, cur, S, kk, m->act_mode);
+        orc_mul_mat(ly->v.type, ly->v.data, H, H, cur, S, vv, m->act_mode);
+        memcpy(Kl + (size_t) pos0 * H, kk, (size_t) S * H * 4); /* parler_build_kv_store :420-439 */
+        memcpy(Vl + (size_t) pos0 * H, vv, (size_t) S * H * 4);
+        for (int i = 0; i < S; i++) /* causal mask: key <= pos (model.cpp:623-631) */
+            attend(q + (size_t) i * H, Kl, Vl, (int) pos0 + i + 1, H, m->n_heads, att + (size_t) i * H, scores);
+        orc_mul_mat(ly->o.type, ly->o.data, H, H, att, S, tmp, m->act_mode);
+        for (size_t i = 0; i < (size_t) S * H; i++) x[i] = tmp[i] + x[i];
+
+        if (m->use_cross) { /* model.cpp:576-596 */
+            for (int i = 0; i < S; i++) orc_layer_norm(x + (size_t) i * H, H, ly->ca_ln_w, ly->ca_ln_b, cur + (size_t) i * H);
+            orc_mul_mat(ly->cq.type, ly->cq.data, H, H, cur, S, q, m->act_mode);
+            for (int i = 0; i < S; i++)
+                attend(q + (size_t) i * H, s->ck + (size_t) l * m->E * H, s->cv + (size_t) l * m->E * H, m->E, H,
+                       m->n_heads, att + (size_t) i * H, scores);
+            orc_mul_mat(ly->co.type, ly->co.data, H, H, att, S, tmp, m->act_mode);
+            for (size_t i = 0; i < (size_t) S * H; i++) x[i] = tmp[i] + x[i];
+        }
+
+        /* FFN (model.cpp:598-604) */
+        for (int i = 0; i < S; i++) orc_layer_norm(x + (size_t) i * H, H, ly->f_ln_w, ly->f_ln_b, cur + (size_t) i * H);
+        orc_mul_mat(ly->fc1.type, ly->fc1.data, H, F, cur, S, ff, m->act_mode);
+        for (size_t i = 0; i < (size_t) S * F; i++) ff[i] = orc_gelu(ff[i], m->gelu_mode);
+        orc_mul_mat(ly->fc2.type, ly->fc2.data, F, H, ff, S, tmp, m->act_mode);
+        for (size_t i = 0; i < (size_t) S * H; i++) x[i] = tmp[i] + x[i];
+    }
+
+    /* final norm + heads (model.cpp:608-609, 441-457) */
+    for (int i = 0; i < S; i++) orc_layer_norm(x + (size_t) i * H, H, m->ln_w, m->ln_b, cur + (size_t) i * H);
+    if (hidden_out) memcpy(hidden_out, cur, (size_t) S * H * 4);
+    if (logits_out) {
+        for (int i = 0; i < m->n_out; i++)
+            orc_mul_mat(m->lm_heads[i].type, m->lm_heads[i].data, H, m->V, cur, S,
+                        logits_out + (size_t) i * S * m->V, m->act_mode);
+    }
+    free(x); free(cur); free(q); free(kk); free(vv); free(att); free(tmp); free(ff); free(row); free(scores);
+}
+
+/* model.cpp:778-785: head i is fed BOS until `step > i`, then its last output, EOS once seen.
+ * `step` is batch.current_step of the decode that just ran (0 for the text prompt). */
+void orc_parler_next_ids(int n_out, int step, const uint32_t *last_outputs, const uint8_t *eos_seen,
+                         uint32_t bos, uint32_t eos, uint32_t *next_ids) {
+    for (int i = 0; i < n_out; i++)
+        next_ids[i] = step > i ? (eos_seen[i] ? eos : last_outputs[i]) : bos;
+}
+
+/* adjust_output_tokens (model.cpp:734-760).  Quirks kept: the bound check is
+ * `next_index > size` (off by one: next_index == size reads one past the end in the reference;
+ * here that element is treated as "out of range -> remove", the only defined behaviour). */
+size_t orc_parler_adjust_output_tokens(const uint32_t *tokens, size_t size, int n_out,
+                                       uint32_t audio_vocab, uint32_t eos, uint32_t *filtered) {
+    size_t w = 0;
+    for (size_t i = 0; i < size / (size_t) n_out; i++) {
+        int remove = 0;
+        for (int ii = 0; ii < n_out; ii++) {
+            size_t next_index = i * n_out + (size_t) ii * n_out + ii;
+            if (next_index >= size || tokens[next_index] >= audio_vocab) { remove = 1; break; }
+        }
+        if (!remove) {
+            for (int ii = 0; ii < n_out; ii++) {
+                size_t next_index = i * n_out + (size_t) ii * n_out + ii;
+                filtered[w++] = next_index > size ? eos : tokens[next_index];
+            }
+        }
+    }
+    return w;
+}
+
+/* ======================================================================================
+ * sampler (src/sampler.cpp)
+ * ==================================================================================== */
+void orc_sampler_init(orc_sampler *s, uint32_t n_heads, uint32_t vocab) {
+    memset(s, 0, sizeof(*s));
+    s->n_output_heads = n_heads; s->vocab_size = vocab;
+    s->temperature = 1.0f; s->top_p = 1.0f; s->repetition_penalty = 1.0f; s->top_k = 0; s->do_sample = 1;
+}
+void orc_sampler_reset(orc_sampler *s) { /* sampler.cpp:71-80 */
+    if (s->repetition_penalty != 1.0f) {
+        for (uint32_t i = 0; i < s->n_output_heads; i++) { s->last_token_ids[i] = -1; s->repetition_counts[i] = 0; }
+        s->rep_initialised = 1;
+    }
+}
+static float rep_div(const orc_sampler *s, float v, uint32_t head) {
+    /* v /= pow(repetition_penalty, repetition_counts[i])  — pow promotes to double */
+    return (float) ((double) v / pow((double) s->repetition_penalty, (double) s->repetition_counts[head]));
+}
+void orc_sampler_max(const orc_sampler *s, const float *logits, uint32_t *out) { /* sampler.cpp:185-204 */
+    const int has_rep = s->repetition_penalty != 1.0f;
+    for (uint32_t i = 0; i < s->n_output_heads; i++) {
+        float mx = -INFINITY; uint32_t id = 0;
+        for (uint32_t ii = 0; ii < s->vocab_size; ii++) {
+            float v = logits[i * s->vocab_size + ii];
+            if (has_rep && s->last_token_ids[i] == (int32_t) ii) v = rep_div(s, v, i);
+            if (v > mx) { mx = v; id = ii; }
+        }
+        out[i] = id;
+    }
+}
+
+typedef struct { float v; uint32_t idx; } vi_pair;
+static int cmp_desc(const void *a, const void *b) {
+    const vi_pair *x = (const vi_pair *) a, *y = (const vi_pair *) b;
+    if (x->v > y->v) return -1;
+    if (x->v < y->v) return 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx); /* ties: std::sort order is unspecified in the reference */
+}
+
+/* sampler.cpp:82-116.  picks==NULL -> whole vocab. */
+static void sampler_softmax(const orc_sampler *s, float *logits, uint32_t *const *picks, const uint32_t *n_picks,
+                            const uint32_t *max_idx) {
+    const int has_rep = s->repetition_penalty != 1.0f, has_temp = s->temperature != 1.0f;
+    const uint32_t V = s->vocab_size;
+    for (uint32_t i = 0; i < s->n_output_heads; i++) {
+        float cumsum = 0.0f;
+        float max_val = logits[i * V + max_idx[i]];
+        if (has_rep && s->last_token_ids[i] == (int32_t) max_idx[i]) max_val = rep_div(s, max_val, i);
+        if (has_temp) max_val /= s->temperature;
+        const uint32_t n = picks ? n_picks[i] : V;
+        for (uint32_t j = 0; j < n; j++) {
+            uint32_t ii = picks ? picks[i][j] : j;
+            float v = logits[i * V + ii];
+            if (has_rep && s->last_token_ids[i] == (int32_t) ii) v = rep_div(s, v, i);
+            if (has_temp) v /= s->temperature;
+            v = expf(v - max_val);
+            cumsum += v;
+            logits[i * V + ii] = v;
+        }
+        for (uint32_t j = 0; j < n; j++) {
+            uint32_t ii = picks ? picks[i][j] : j;
+            logits[i * V + ii] = logits[i * V + ii] / cumsum;
+        }
+    }
+}
+
+void orc_sampler_sample(orc_sampler *s, float *logits, const float *uniforms, uint32_t *out) {
+    const uint32_t V = s->vocab_size, NH = s->n_output_heads;
+    if (!s->do_sample) { orc_sampler_max(s, logits, out); return; } /* sampler.cpp:5-7 */
+    uint32_t max_vals[ORC_MAX_HEADS];
+    float max_head_probs[ORC_MAX_HEADS];
+    uint32_t *picks[ORC_MAX_HEADS] = {0};
+    uint32_t n_picks[ORC_MAX_HEADS] = {0};
+    int have_picks = 0, use_nucleus = 0, performed_softmax = 0;
+    const int has_rep = s->repetition_penalty != 1.0f;
+    vi_pair *tmp = (vi_pair *) malloc((size_t) V * sizeof(vi_pair));
+
+    orc_sampler_max(s, logits, max_vals);                                   /* :18 */
+    if (s->top_p < 1.0f) { sampler_softmax(s, logits, NULL, NULL, max_vals); performed_softmax = 1; } /* :24-29 */
+    if (s->top_k > 0 && s->top_k < V) {                                      /* :30-33, topk :152-183 */
+        for (uint32_t i = 0; i < NH; i++) {
+            for (uint32_t j = 0; j < V; j++) {
+                float v = logits[i * V + j];
+                if (!performed_softmax && has_rep && s->last_token_ids[i] == (int32_t) j) v = rep_div(s, v, i);
+                tmp[j].v = v; tmp[j].idx = j;
+            }
+            qsort(tmp, V, sizeof(vi_pair), cmp_desc);
+            picks[i] = (uint32_t *) malloc((size_t) V * 4);
+            n_picks[i] = s->top_k;
+            for (uint32_t j = 0; j < s->top_k; j++) picks[i][j] = tmp[j].idx;
+        }
+        have_picks = 1; use_nucleus = 1;
+    }
+    if (s->top_p >= 1.0f) { /* :35-38 */
+        sampler_softmax(s, logits, have_picks ? picks : NULL, n_picks, max_vals);
+        performed_softmax = 1;
+    }
+    if (s->top_p < 1.0f) { /* topp :118-150 */
+        if (!have_picks) {
+            for (uint32_t i = 0; i < NH; i++) {
+                for (uint32_t j = 0; j < V; j++) { tmp[j].v = logits[i * V + j]; tmp[j].idx = j; }
+                qsort(tmp, V, sizeof(vi_pair), cmp_desc);
+                picks[i] = (uint32_t *) malloc((size_t) V * 4);
+                n_picks[i] = V;
+                for (uint32_t j = 0; j < V; j++) picks[i][j] = tmp[j].idx;
+            }
+            have_picks = 1;
+        }
+        for (uint32_t i = 0; i < NH; i++) {
+            float prob_sum = 0.0f; int trim_to = -1;
+            for (uint32_t ii = 0; ii < n_picks[i]; ii++) {
+                prob_sum += logits[i * V + picks[i][ii]];
+                if (prob_sum >= s->top_p) { trim_to = (int) ii + 1; break; }
+            }
+            max_head_probs[i] = prob_sum < s->top_p ? prob_sum : s->top_p;
+            if (trim_to > 0) n_picks[i] = (uint32_t) trim_to;
+        }
+        use_nucleus = 1;
+    }
+    if (has_rep && !s->rep_initialised) orc_sampler_reset(s); /* :43-46 */
+
+    for (uint32_t i = 0; i < NH; i++) { /* :49-68 */
+        float assignment = s->top_p < 1.0f ? uniforms[i] * max_head_probs[i] : uniforms[i];
+        float cumulative = 0.0f;
+        const uint32_t n = use_nucleus ? n_picks[i] : V;
+        uint32_t chosen = 0; int found = 0;
+        for (uint32_t j = 0; j < n; j++) {
+            uint32_t ii = use_nucleus ? picks[i][j] : j;
+            cumulative += logits[i * V + ii];
+            /* third clause reads picks[i].size() even when picks is empty in the reference (UB when
+             * top_k==0 && top_p>=1); restated as "last candidate" which is its evident intent. */
+            if (assignment <= cumulative || ii >= V + 1 || j >= n - 1) { chosen = ii; found = 1; break; }
+        }
+        if (!found) chosen = 0;
+        if (has_rep) {
+            if (s->last_token_ids[i] != (int32_t) chosen) s->repetition_counts[i] = 0;
+            s->last_token_ids[i] = (int32_t) chosen;
+            s->repetition_counts[i] += 1;
+        }
+        out[i] = chosen;
+    }
+    for (uint32_t i = 0; i < NH; i++) free(picks[i]);
+    free(tmp);
+}
+
+/* ======================================================================================
+ * DAC decoder.  Activations are [C][L] (length fastest), weights in PyTorch order
+ * (Conv1d [Cout][Cin][K], ConvTranspose1d [Cin][Cout][K]) which is what the GGUF stores
+ * with ne reversed.  fp32 accumulation, input-channel-major.
+ * ==================================================================================== */
+void orc_conv1d(const float *x, int cin, int64_t L, const float *w, const float *b, int cout, int K,
+                int pad, int dil, float *y) {
+    /* ggml_conv_1d(kernel, x, stride 1, pad, dil) + bias (dac_model.cpp:158-159) ; L_out = L for "same" pads */
+    const int64_t Lout = L + 2 * pad - (int64_t) dil * (K - 1);
+#pragma omp parallel for schedule(static)
+    for (int co = 0; co < cout; co++) {
+        float *yr = y + (size_t) co * Lout;
+        for (int64_t t = 0; t < Lout; t++) yr[t] = b ? b[co] : 0.0f;
+        for (int ci = 0; ci < cin; ci++) {
+            const float *xr = x + (size_t) ci * L;
+            for (int k = 0; k < K; k++) {
+                const float wv = w[((size_t) co * cin + ci) * K + k];
+                const int64_t off = (int64_t) k * dil - pad;
+                int64_t t0 = off < 0 ? -off : 0;
+                int64_t t1 = Lout;
+                if (t1 + off > L) t1 = L - off;
+                for (int64_t t = t0; t < t1; t++) yr[t] += wv * xr[t + off];
+            }
+        }
+    }
+}
+
+void orc_conv_transpose1d(const float *x, int cin, int64_t L, const float *w, const float *b, int cout,
+                          int K, int stride, int pad, float *y) {
+    /* fork's ggml_conv_transpose_1d(kernel, x, stride, padding, 1, 0, 1)
+     * (general_neural_audio_codec.cpp:153) == torch ConvTranspose1d(stride, padding):
+     * y[co][ti*stride + k - pad] += x[ci][ti] * w[ci][co][k];  L_out = (L-1)*stride - 2*pad + K */
+    const int64_t Lout = (L - 1) * stride - 2 * (int64_t) pad + K;
+#pragma omp parallel for schedule(static)
+    for (int co = 0; co < cout; co++) {
+        float *yr = y + (size_t) co * Lout;
+        for (int64_t t = 0; t < Lout; t++) yr[t] = b ? b[co] : 0.0f;
+        for (int ci = 0; ci < cin; ci++) {
+            const float *xr = x + (size_t) ci * L;
+            const float *wr = w + ((size_t) ci * cout + co) * K;
+            for (int64_t ti = 0; ti < L; ti++) {
+                const float xv = xr[ti];
+                const int64_t base = ti * stride - pad;
+                for (int k = 0; k < K; k++) {
+                    int64_t to = base + k;
+                    if (to >= 0 && to < Lout) yr[to] += xv * wr[k];
+                }
+            }
+        }
+    }
+}
+
+/* snake_1d (util.cpp:96-101): a + sin(a*alpha)^2 * (1/alpha), no epsilon. */
+void orc_snake(float *x, int C, int64_t L, const float *alpha) {
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < C; c++) {
+        const float a = alpha[c];
+        const float ra = 1.0f / a;
+        float *xr = x + (size_t) c * L;
+        for (int64_t t = 0; t < L; t++) {
+            float sn = sinf(xr[t] * a);
+            xr[t] = xr[t] + (sn * sn) * ra;
+        }
+    }
+}
+
+int64_t orc_dac_decode(const orc_dac_model *m, const uint32_t *codes, int frames, float *pcm_out,
+                       int stage, float *stage_out) {
+    int64_t L = frames;
+    int C = m->latent;
+    /* quantizer: dac_build_audio_inputs (dac_model.cpp:100-123) + build_quantize_layer
+     * (general_neural_audio_codec.cpp:166-172): sum_i (out_proj_i * codebook_i[tok] + bias_i) */
+    float *cur = (float *) malloc((size_t) C * L * 4);
+    for (int i = 0; i < m->n_codebooks; i++) {
+#pragma omp parallel for schedule(static)
+        for (int c = 0; c < C; c++) {
+            for (int64_t t = 0; t < L; t++) {
+                const float *cb = m->codebook[i] + (size_t) codes[t * m->n_codebooks + i] * m->codebook_dim;
+                float acc = 0.0f;
+                for (int d = 0; d < m->codebook_dim; d++) acc += m->out_proj_w[i][(size_t) c * m->codebook_dim + d] * cb[d];
+                acc += m->out_proj_b[i][c];
+                if (i == 0) cur[(size_t) c * L + t] = acc;
+                else cur[(size_t) c * L + t] = cur[(size_t) c * L + t] + acc;
+            }
+        }
+    }
+    if (stage == 0 && stage_out) memcpy(stage_out, cur, (size_t) C * L * 4);
+
+    /* initial conv k7 pad 3 (dac_model.cpp:158-159) */
+    float *nxt = (float *) malloc((size_t) m->c0 * L * 4);
+    orc_conv1d(cur, C, L, m->init_w, m->init_b, m->c0, 7, 3, 1, nxt);
+    free(cur); cur = nxt; C = m->c0;
+    if (stage == 1 && stage_out) memcpy(stage_out, cur, (size_t) C * L * 4);
+
+    for (int bi = 0; bi < m->n_blocks; bi++) { /* build_layer (general_neural_audio_codec.cpp:151-164) */
+        const orc_dac_block *b = &m->blocks[bi];
+        orc_snake(cur, C, L, b->alpha);
+        const int K = 2 * b->stride;
+        const int64_t L2 = (L - 1) * b->stride - 2 * (int64_t) b->padding + K;
+        nxt = (float *) malloc((size_t) b->cout * L2 * 4);
+        orc_conv_transpose1d(cur, C, L, b->w, b->b, b->cout, K, b->stride, b->padding, nxt);
+        free(cur); cur = nxt; C = b->cout; L = L2;
+        float *t1 = (float *) malloc((size_t) C * L * 4);
+        float *t2 = (float *) malloc((size_t) C * L * 4);
+        for (int r = 0; r < 3; r++) { /* build_residual_unit :133-149; pad=3^(r+1)?? no: pad 3^r*3, dil 3^r (header :44-48) */
+            int dil = 1; for (int e = 0; e < r; e++) dil *= 3;
+            const int pad = dil * 3;
+            memcpy(t1, cur, (size_t) C * L * 4);
+            orc_snake(t1, C, L, b->res[r].in_alpha);
+            orc_conv1d(t1, C, L, b->res[r].in_w, b->res[r].in_b, C, 7, pad, dil, t2);
+            orc_snake(t2, C, L, b->res[r].out_alpha);
+            orc_conv1d(t2, C, L, b->res[r].out_w, b->res[r].out_b, C, 1, 0, 1, t1);
+            for (size_t i = 0; i < (size_t) C * L; i++) cur[i] = t1[i] + cur[i];
+        }
+        free(t1); free(t2);
+        if (stage == 2 + bi && stage_out) memcpy(stage_out, cur, (size_t) C * L * 4);
+    }
+    /* final snake, conv k7 -> 1 channel, tanh (dac_model.cpp:163-166) */
+    orc_snake(cur, C, L, m->final_alpha);
+    float *pcm = (float *) malloc((size_t) L * 4);
+    orc_conv1d(cur, C, L, m->final_w, m->final_b, 1, 7, 3, 1, pcm);
+    for (int64_t t = 0; t < L; t++) pcm_out[t] = tanhf(pcm[t]);
+    free(pcm); free(cur);
+    return L;
+}

@@ -1,0 +1,151 @@
+"""Generate tests/golden/*.npz — golden vectors for the oracle.
+
+The reference cannot be built or imported here (its arithmetic lives in the absent ggml submodule,
+SURVEY.md §0.1) and it ships no golden vectors (§0.2), so these vectors come from a SECOND,
+independent restatement of the same path written with PyTorch CPU primitives in float64
+(F.layer_norm / F.linear / softmax / tanh-GELU / F.conv1d / F.conv_transpose1d), on seeded synthetic
+weights (tts.cpp_amd/synth.py).  They pin the C oracle against PyTorch's definitions of each
+primitive; they do NOT pin it against ggml ("parity unpinned").
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as Fn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import tts_cpp_amd  # noqa: E402
+from tts_cpp_amd import gguf, synth  # noqa: E402
+
+D = torch.float64
+
+
+def T(model, name):
+    return torch.from_numpy(model.by_name[name].to_f32().astype(np.float64))
+
+
+class TorchParler:
+    """Parler decoder (src/models/parler/model.cpp:520-614) in float64 torch."""
+
+    def __init__(self, model):
+        self.m, self.cfg = model, model.cfg
+        c = self.cfg
+        self.k = [torch.zeros(0, c.hidden, dtype=D) for _ in range(c.layers)]
+        self.v = [torch.zeros(0, c.hidden, dtype=D) for _ in range(c.layers)]
+        enc = T(model, "decoder.text_encoding")
+        self.ck = [Fn.linear(enc, T(model, f"decoder.layers.{l}.encoder_attn.k_proj.weight")) for l in range(c.layers)]
+        self.cv = [Fn.linear(enc, T(model, f"decoder.layers.{l}.encoder_attn.v_proj.weight")) for l in range(c.layers)]
+
+    def attend(self, q, K, V, causal_from=None):
+        c = self.cfg
+        d = c.hidden // c.heads
+        S, Tn = q.shape[0], K.shape[0]
+        qh = q.view(S, c.heads, d).transpose(0, 1)
+        kh = K.view(Tn, c.heads, d).transpose(0, 1)
+        vh = V.view(Tn, c.heads, d).transpose(0, 1)
+        s = qh @ kh.transpose(1, 2) / d ** 0.5
+        if causal_from is not None:
+            pos = causal_from + torch.arange(S)
+            mask = torch.arange(Tn)[None, :] > pos[:, None]
+            s = s.masked_fill(mask[None], float("-inf"))
+        p = torch.softmax(s, dim=-1)
+        return (p @ vh).transpose(0, 1).reshape(S, c.hidden)
+
+    def decode(self, tokens, pos0, audio):
+        c, m = self.cfg, self.m
+        if audio:
+            x = sum(T(m, f"decoder.embed_tokens.{i}.weight")[int(tokens[i])] for i in range(c.n_out))[None]
+        else:
+            x = T(m, "decoder.embed_prompts")[torch.as_tensor(np.asarray(tokens, dtype=np.int64))]
+        S = x.shape[0]
+        x = x + T(m, "decoder.positional_embed")[pos0:pos0 + S]
+        for l in range(c.layers):
+            p = f"decoder.layers.{l}."
+            h = Fn.layer_norm(x, (c.hidden,), T(m, p + "self_attn_layer_norm.weight"), T(m, p + "self_attn_layer_norm.bias"), 1e-5)
+            q = Fn.linear(h, T(m, p + "self_attn.q_proj.weight"))
+            self.k[l] = torch.cat([self.k[l][:pos0], Fn.linear(h, T(m, p + "self_attn.k_proj.weight"))])
+            self.v[l] = torch.cat([self.v[l][:pos0], Fn.linear(h, T(m, p + "self_attn.v_proj.weight"))])
+            x = x + Fn.linear(self.attend(q, self.k[l], self.v[l], causal_from=pos0), T(m, p + "self_attn.out_proj.weight"))
+            h = Fn.layer_norm(x, (c.hidden,), T(m, p + "encoder_attn_layer_norm.weight"), T(m, p + "encoder_attn_layer_norm.bias"), 1e-5)
+            q = Fn.linear(h, T(m, p + "encoder_attn.q_proj.weight"))
+            x = x + Fn.linear(self.attend(q, self.ck[l], self.cv[l]), T(m, p + "encoder_attn.out_proj.weight"))
+            h = Fn.layer_norm(x, (c.hidden,), T(m, p + "final_layer_norm.weight"), T(m, p + "final_layer_norm.bias"), 1e-5)
+            h = Fn.gelu(Fn.linear(h, T(m, p + "fc1.weight")), approximate="tanh")
+            x = x + Fn.linear(h, T(m, p + "fc2.weight"))
+        h = Fn.layer_norm(x, (c.hidden,), T(m, "decoder.layer_norm.weight"), T(m, "decoder.layer_norm.bias"), 1e-5)
+        logits = torch.stack([Fn.linear(h, T(m, f"decoder.lm_heads.{i}.weight.head")) for i in range(c.n_out)])  # [n_out][S][V]
+        return logits, h
+
+
+def snake(x, alpha):
+    a = alpha.reshape(-1, 1)
+    return x + torch.sin(a * x) ** 2 / a
+
+
+def torch_dac(model, codes, stages=False):
+    """DAC decoder (src/decoder/dac_model.cpp:146-170) in float64 torch. codes [frames][n_out]."""
+    c = model.cfg
+    codes = torch.as_tensor(np.asarray(codes, dtype=np.int64)).reshape(-1, c.n_out)
+    x = 0
+    for i in range(c.n_out):
+        p = f"audio_encoder.quantizers.{i}."
+        e = T(model, p + "codebook.weight")[codes[:, i]].t()[None]  # [1][dim][T]
+        x = x + Fn.conv1d(e, T(model, p + "out_proj.weight"), T(model, p + "out_proj.bias"))
+    outs = [x[0]]
+    x = Fn.conv1d(x, T(model, "audio_encoder.initial.weight"), T(model, "audio_encoder.initial.bias"), padding=3)
+    outs.append(x[0])
+    for bi, (s, pd) in enumerate(zip(c.strides, c.paddings)):
+        p = f"audio_encoder.decoder_block.{bi + 1}."
+        x = snake(x[0], T(model, p + "final.alpha"))[None]
+        x = Fn.conv_transpose1d(x, T(model, p + "final.weight"), T(model, p + "final.bias"), stride=s, padding=pd)
+        for r in range(3):
+            q = p + f"residual_unit.{r}.res."
+            dil = 3 ** r
+            y = snake(x[0], T(model, q + "initial.alpha"))[None]
+            y = Fn.conv1d(y, T(model, q + "initial.weight"), T(model, q + "initial.bias"), padding=3 * dil, dilation=dil)
+            y = snake(y[0], T(model, q + "final.alpha"))[None]
+            y = Fn.conv1d(y, T(model, q + "final.weight"), T(model, q + "final.bias"))
+            x = x + y
+        outs.append(x[0])
+    x = snake(x[0], T(model, "audio_encoder.final.alpha"))[None]
+    x = torch.tanh(Fn.conv1d(x, T(model, "audio_encoder.final.weight"), T(model, "audio_encoder.final.bias"), padding=3))
+    return (x[0, 0], outs) if stages else x[0, 0]
+
+
+def main():
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    cfg = synth.tiny(weight_type=gguf.F32)
+    model = synth.build(cfg)
+    rng = np.random.default_rng(1234)
+    prompt = rng.integers(3, cfg.prompt_vocab, 7).astype(np.uint32)
+    n_steps = 5
+    audio_ids = rng.integers(0, cfg.audio_vocab, (n_steps, cfg.n_out)).astype(np.uint32)
+    tp = TorchParler(model)
+    with torch.no_grad():
+        _, h0 = tp.decode(prompt, 0, audio=False)
+        logits, hidden = [], []
+        for s in range(n_steps):
+            lg, h = tp.decode(audio_ids[s], len(prompt) + s, audio=True)
+            logits.append(lg[:, 0, :].numpy())
+            hidden.append(h[0].numpy())
+        k0 = tp.k[0].numpy()
+        v1 = tp.v[cfg.layers - 1].numpy()
+        codes = rng.integers(0, cfg.cb_size, (9, cfg.n_out)).astype(np.uint32)
+        pcm, stages = torch_dac(model, codes, stages=True)
+    np.savez_compressed(
+        os.path.join(out_dir, "tiny_f32.npz"),
+        prompt=prompt, audio_ids=audio_ids, prompt_hidden=h0.numpy().astype(np.float32),
+        logits=np.stack(logits).astype(np.float32), hidden=np.stack(hidden).astype(np.float32),
+        k_layer0=k0.astype(np.float32), v_last=v1.astype(np.float32),
+        codes=codes, pcm=pcm.numpy().astype(np.float32),
+        **{f"dac_stage{i}": s.numpy().astype(np.float32) for i, s in enumerate(stages)},
+    )
+    print("wrote tiny_f32.npz", {k: v.shape for k, v in np.load(os.path.join(out_dir, "tiny_f32.npz")).items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+"""CPU tests of the oracle: golden vectors (independent float64 torch restatement), PyTorch primitive
+semantics, block formats.  The oracle is the checker for the HIP path, so it is pinned first."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+import oracle as orc
+from tts_cpp_amd import gguf, synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "tiny_f32.npz")
+
+
+def relerr(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def tiny_f32():
+    return synth.build(synth.tiny(weight_type=gguf.F32))
+
+
+def test_golden_parler_decode(tiny_f32):
+    g = np.load(GOLD)
+    cfg = tiny_f32.cfg
+    o = orc.ParlerOracle(tiny_f32, act_mode=0, gelu_mode=0)
+    _, h0 = o.decode(g["prompt"], 0, audio=False, want_logits=False, want_hidden=True)
+    assert relerr(h0, g["prompt_hidden"]) < 2e-5
+    for s in range(g["audio_ids"].shape[0]):
+        lg, h = o.decode(g["audio_ids"][s], len(g["prompt"]) + s, audio=True, want_hidden=True)
+        assert relerr(lg[:, 0, :], g["logits"][s]) < 2e-5, s
+        assert relerr(h[0], g["hidden"][s]) < 2e-5, s
+        assert (lg[:, 0, :].argmax(-1) == g["logits"][s].argmax(-1)).all()
+    n_pos = g["k_layer0"].shape[0]
+    k0, _ = o.get_kv(0, n_pos)
+    _, v1 = o.get_kv(cfg.layers - 1, n_pos)
+    assert relerr(k0, g["k_layer0"]) < 2e-5
+    assert relerr(v1, g["v_last"]) < 2e-5
+
+
+def test_golden_dac(tiny_f32):
+    g = np.load(GOLD)
+    d = orc.DacOracle(tiny_f32)
+    pcm = d.decode(g["codes"])
+    assert pcm.shape == g["pcm"].shape
+    assert np.abs(pcm - g["pcm"]).max() < 2e-5
+    for st in range(2 + len(tiny_f32.cfg.strides)):
+        _, act = d.decode(g["codes"], stage=st)
+        assert relerr(act, g[f"dac_stage{st}"]) < 2e-5, st
+
+
+@pytest.mark.parametrize("K,pad,dil", [(7, 3, 1), (7, 9, 3), (7, 27, 9), (1, 0, 1)])
+def test_conv1d_vs_torch(K, pad, dil):
+    rng = np.random.default_rng(K * 100 + dil)
+    cin, cout, L = 5, 6, 50
+    x = rng.standard_normal((cin, L)).astype(np.float32)
+    w = rng.standard_normal((cout, cin, K)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    y = np.empty((cout, L), dtype=np.float32)
+    orc.lib().orc_conv1d(orc.f32p(x), cin, L, orc.f32p(w), orc.f32p(b), cout, K, pad, dil, orc.f32p(y))
+    ref = Fn.conv1d(torch.from_numpy(x)[None].double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=pad, dilation=dil)[0].numpy()
+    assert np.abs(y - ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("stride,pad", [(8, 4), (4, 2), (2, 1), (5, 3)])
+def test_conv_transpose1d_vs_torch(stride, pad):
+    rng = np.random.default_rng(stride)
+    cin, cout, L, K = 6, 4, 11, 2 * stride
+    x = rng.standard_normal((cin, L)).astype(np.float32)
+    w = rng.standard_normal((cin, cout, K)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    Lout = (L - 1) * stride - 2 * pad + K
+    y = np.empty((cout, Lout), dtype=np.float32)
+    orc.lib().orc_conv_transpose1d(orc.f32p(x), cin, L, orc.f32p(w), orc.f32p(b), cout, K, stride, pad, orc.f32p(y))
+    ref = Fn.conv_transpose1d(torch.from_numpy(x)[None].double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=stride, padding=pad)[0].numpy()
+    assert ref.shape == y.shape
+    assert np.abs(y - ref).max() < 1e-4
+    if stride % 2 == 0 and pad == stride // 2:
+        assert Lout == L * stride  # DAC blocks upsample by exactly their stride
+
+
+def test_layer_norm_and_gelu_vs_torch():
+    rng = np.random.default_rng(3)
+    H = 256
+    x = (rng.standard_normal(H) * 3 + 1).astype(np.float32)
+    w = rng.standard_normal(H).astype(np.float32)
+    b = rng.standard_normal(H).astype(np.float32)
+    y = np.empty(H, dtype=np.float32)
+    orc.lib().orc_layer_norm(orc.f32p(x), H, orc.f32p(w), orc.f32p(b), orc.f32p(y))
+    ref = Fn.layer_norm(torch.from_numpy(x).double(), (H,), torch.from_numpy(w).double(), torch.from_numpy(b).double(), 1e-5).numpy()
+    assert np.abs(y - ref).max() < 1e-5
+    xs = np.linspace(-12, 12, 4001).astype(np.float32)
+    g0 = np.array([orc.lib().orc_gelu(float(v), 0) for v in xs], dtype=np.float32)
+    refg = Fn.gelu(torch.from_numpy(xs).double(), approximate="tanh").numpy()
+    assert np.abs(g0 - refg).max() < 2e-6
+    # ggml fp16-table mode: fp16-precision of the same function, identity/zero outside (-10, 10)
+    g1 = np.array([orc.lib().orc_gelu(float(v), 1) for v in xs], dtype=np.float32)
+    inside = np.abs(xs) < 10
+    assert np.abs(g1[inside] - refg[inside]).max() < 6e-3
+    assert (g1[xs >= 10] == xs[xs >= 10]).all() and (g1[xs <= -10] == 0).all()
+    assert (g1[inside] == g1[inside].astype(np.float16).astype(np.float32)).all()  # table entries are fp16
+
+
+def test_fp16_conversion_matches_numpy():
+    L = orc.lib()
+    bits = np.arange(0, 65536, dtype=np.uint16)
+    vals = bits.view(np.float16).astype(np.float32)
+    mine = np.array([L.orc_h2f(int(b)) for b in bits[::7]], dtype=np.float32)
+    ref = vals[::7]
+    ok = (mine == ref) | (np.isnan(mine) & np.isnan(ref))
+    assert ok.all()
+    rng = np.random.default_rng(0)
+    f = np.concatenate([rng.standard_normal(5000).astype(np.float32) * s for s in (1e-8, 1e-5, 1e-3, 1, 1e3, 7e4)])
+    f = np.concatenate([f, np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e9, -1e9, 2.0 ** -24, 2.0 ** -25, 1.5 * 2.0 ** -25], dtype=np.float32)])
+    with np.errstate(over="ignore"):
+        ref16 = f.astype(np.float16).view(np.uint16)
+    mine16 = np.array([L.orc_f2h(float(v)) for v in f], dtype=np.uint16)
+    assert (mine16 == ref16).all()
+
+
+@pytest.mark.parametrize("ttype", [gguf.Q4_0, gguf.Q5_0, gguf.Q8_0, gguf.F16])
+def test_block_formats(ttype):
+    rng = np.random.default_rng(ttype)
+    x = (rng.standard_normal(32 * 64) * rng.uniform(0.01, 3, 32 * 64)).astype(np.float32)
+    q_c = orc.quantize(ttype, x)
+    if ttype != gguf.F16:
+        q_np = synth.quantize(x, ttype)
+        assert (q_c == q_np).all(), "numpy quantiser (synth) and oracle quantiser disagree"
+    dq = orc.dequantize(ttype, q_c, x.size)
+    tol = {gguf.Q4_0: 0.13, gguf.Q5_0: 0.065, gguf.Q8_0: 0.005, gguf.F16: 0.0006}[ttype]  # one quantisation step (clamped end included)
+    blk = np.abs(x).reshape(-1, 32).max(axis=1).repeat(32)
+    assert (np.abs(dq - x) <= tol * blk + 1e-7).all()
+    # dequantised values re-quantise to themselves (formats are idempotent)
+    assert (orc.quantize(ttype, dq) == q_c).all() or ttype in (gguf.Q4_0, gguf.Q5_0)
+
+
+def test_mul_mat_modes():
+    rng = np.random.default_rng(11)
+    K, N, R = 256, 48, 3
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    x = rng.standard_normal((R, K)).astype(np.float32)
+    exact = x.astype(np.float64) @ w.astype(np.float64).T
+    y = orc.mul_mat(gguf.F32, w.tobytes(), K, N, x)
+    assert np.abs(y - exact).max() < 1e-5
+    w16 = w.astype(np.float16)
+    y0 = orc.mul_mat(gguf.F16, w16.tobytes(), K, N, x, act_mode=0)
+    assert np.abs(y0 - x.astype(np.float64) @ w16.astype(np.float64).T).max() < 1e-5
+    y1 = orc.mul_mat(gguf.F16, w16.tobytes(), K, N, x, act_mode=1)
+    x16 = x.astype(np.float16).astype(np.float64)
+    assert np.abs(y1 - x16 @ w16.astype(np.float64).T).max() < 1e-5
+    for t in (gguf.Q4_0, gguf.Q5_0, gguf.Q8_0):
+        q = orc.quantize(t, w)
+        wd = orc.dequantize(t, q, w.size).reshape(N, K).astype(np.float64)
+        ya = orc.mul_mat(t, q, K, N, x, act_mode=0)
+        assert np.abs(ya - x.astype(np.float64) @ wd.T).max() < 1e-5
+        yb = orc.mul_mat(t, q, K, N, x, act_mode=1)  # Q8_0 activations: close to, not equal to, the fp32-activation result
+        assert np.abs(yb - ya).max() < 0.05 * np.abs(ya).max()
+
+
+def test_generation_bookkeeping():
+    L = orc.lib()
+    n_out, bos, eos = 4, 65, 64
+    last = np.array([5, 6, 7, 8], dtype=np.uint32)
+    seen = np.array([0, 0, 1, 0], dtype=np.uint8)
+    nxt = np.empty(4, dtype=np.uint32)
+    import ctypes as C
+    for step, exp in [(0, [65, 65, 65, 65]), (1, [5, 65, 65, 65]), (3, [5, 6, 64, 65]), (9, [5, 6, 64, 8])]:
+        L.orc_parler_next_ids(n_out, step, orc.u32p(last), seen.ctypes.data_as(C.POINTER(C.c_uint8)), bos, eos, orc.u32p(nxt))
+        assert nxt.tolist() == exp
+    # un-delay: frame i, head k <- token at step i+k; frames with a special id are dropped
+    steps = 7
+    toks = (np.arange(steps * n_out) % 50).astype(np.uint32).reshape(steps, n_out)
+    toks[2, 1] = eos  # step 2 head 1 -> poisons frame 1
+    flat = toks.reshape(-1).copy()
+    out = np.empty_like(flat)
+    n = L.orc_parler_adjust_output_tokens(orc.u32p(flat), flat.size, n_out, 64, eos, orc.u32p(out))
+    frames = out[:n].reshape(-1, n_out)
+    expect = [[toks[i + k, k] for k in range(n_out)] for i in range(steps - n_out + 1) if i != 1]
+    assert frames.tolist() == [[int(v) for v in r] for r in expect]

@@ -1,0 +1,543 @@
+// parler_kernels.h — gfx950 (CDNA4) kernels for the Parler-TTS decoder step.
+//
+// One forward over R "rows" (R = utterances decoded in lock-step, or the S tokens of one text
+// prompt) replaces the ggml graph that parler_tts_runner::build_parler_graph
+// (/root/reference/src/models/parler/model.cpp:520-614) rebuilds every step.  Kernel ↔ reference:
+//   embed_rows_kernel   parler_build_inp_embd            model.cpp:387-410
+//   gemm16_kernel<PRO_LN,...>  parler_build_layer_norm + ggml_mul_mat   :412-418, :544-546, :583, :601
+//        EPI_QKV        parler_build_kv_store            :420-439   (cache append in the epilogue)
+//        EPI_GELU       ggml_gelu                        :602
+//        EPI_RESID      ggml_add(residual)               :574, :595, :604
+//   attn_kernel         mul_mat(K,q) -> soft_max_ext -> mul_mat(kq,V)   :549-570 / :583-595
+//   argmax_kernel       sampler::max                     src/sampler.cpp:185-204
+//   feed_kernel         delay-pattern feed + EOS flags   model.cpp:715-732, :778-785
+//
+// Design notes (MI355X): a decode step is pure weight streaming (≈725 MB of fp16 weights per
+// step, 0.7 GFLOP per row), so the GEMMs are shaped for HBM, not for MFMA peak: one workgroup
+// owns 16 output features, its waves split K in 256-wide slices, every lane issues all of its
+// weight loads (64 B contiguous per lane, whole 128/256 B lines per row across a 16-lane group)
+// before the LayerNorm prologue runs, so HBM latency overlaps the prologue.  MFMA is used because
+// a 16x16 tile gives up to 16 rows for free at the same weight traffic (lock-step utterances /
+// prompt tokens), not because the op is compute bound.  K is visited in a lane-permuted order
+// (same permutation for A and B fragments), which is legal for a dot product and is what makes
+// the 64-B-per-lane loads possible.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+#define LN_EPS 1e-5f  // model.cpp:414 "parler always uses default eps"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ggml_gelu.  mode 1 restates ggml's CPU path, which evaluates GELU through a table indexed by the
+// fp16 bits of x and holding fp16 results (upstream ggml_vec_gelu_f32 / GGML_GELU_FP16): a table is
+// memoisation, so rounding x to fp16, evaluating in fp32 and rounding the result to fp16 is the
+// same function.
+__device__ __forceinline__ float gelu_tanh_f32(float x) {
+    const float A = 0.044715f, S = 0.79788456080286535587989211986876f;
+    return 0.5f * x * (1.0f + tanhf(S * x * (1.0f + A * x * x)));
+}
+__device__ __forceinline__ float gelu_apply(float x, int mode) {
+    if (mode == 0) return gelu_tanh_f32(x);
+    if (x <= -10.0f) return 0.0f;
+    if (x >= 10.0f) return x;
+    const float xr = (float) (_Float16) x;
+    return (float) (_Float16) gelu_tanh_f32(xr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// embeddings: x[r] = (audio ? sum_i Emb_i[ids[r][i]] : EmbPrompt[ids[r]]) + Pos[pos[r]]
+// ------------------------------------------------------------------------------------------------
+struct EmbedArgs {
+    const void *tab;        // [n_tabs][rows][H] (audio) or [rows][H] (text)
+    int         tab_f16;    // element type of tab
+    int64_t     tab_stride; // elements between consecutive tables
+    int         n_tabs;     // n_output_heads (audio) or 1 (text)
+    const uint32_t *ids;    // [R][n_tabs]
+    const float *pos_embed; // [n_pos][H] fp32
+    const uint32_t *row_pos;
+    float      *x;          // [R][H]
+    int         H;
+};
+
+__global__ void embed_rows_kernel(EmbedArgs a) {
+    const int r = blockIdx.x;
+    const uint32_t pos = a.row_pos[r];
+    for (int c = threadIdx.x; c < a.H; c += blockDim.x) {
+        float acc = 0.0f;
+        for (int i = 0; i < a.n_tabs; i++) {
+            const uint32_t id = a.ids[r * a.n_tabs + i];
+            const int64_t off = (int64_t) i * a.tab_stride + (int64_t) id * a.H + c;
+            const float v = a.tab_f16 ? (float) ((const _Float16 *) a.tab)[off] : ((const float *) a.tab)[off];
+            acc = (i == 0) ? v : (v + acc);  // ggml_add(get_rows(i), input_embs), model.cpp:401
+        }
+        a.x[(int64_t) r * a.H + c] = acc + a.pos_embed[(int64_t) pos * a.H + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM  y[r][n] = sum_k W[n][k] * act[r][k]   for R <= 16*RB rows, 16 features per workgroup
+// ------------------------------------------------------------------------------------------------
+enum { PRO_F32 = 0, PRO_LN = 1, PRO_F16 = 2 };
+enum { EPI_STORE = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3 };
+
+struct GemmArgs {
+    const void *W;      // [N][K], fp16 or fp32 (ggml ne=[K,N])
+    int K, N, R;
+    const void *A;      // activations [R][lda] fp32 (PRO_F32 / PRO_LN) or fp16 (PRO_F16)
+    int lda;
+    const float *ln_w, *ln_b;  // PRO_LN (K == hidden size)
+    float *out;         // EPI_STORE / EPI_RESID / EPI_GELU(fp32): [R][ldo]
+    _Float16 *out16;    // EPI_GELU with fp16 activations
+    int ldo;
+    // EPI_QKV: n in [0,H) -> q, [H,2H) -> K cache, [2H,3H) -> V cache
+    float *q;           // [R][H]
+    void *kc, *vc;      // this layer's cache base [seq][n_ctx][H]
+    int kv_f16;
+    int64_t seq_stride; // elements between sequences in the cache
+    const uint32_t *row_seq, *row_pos;
+    int H;
+    int gelu_mode;
+};
+
+__device__ __forceinline__ void gemm_epilogue4(const GemmArgs &a, int EPI, int r, int n, float4v v) {
+    if (EPI == EPI_STORE) {
+        *(float4v *) (a.out + (int64_t) r * a.ldo + n) = v;
+    } else if (EPI == EPI_RESID) {
+        float4v *p = (float4v *) (a.out + (int64_t) r * a.ldo + n);
+        float4v o = *p;
+        o += v;  // ggml_add(cur, residual)
+        *p = o;
+    } else if (EPI == EPI_GELU) {
+        float4v g;
+#pragma unroll
+        for (int e = 0; e < 4; e++) g[e] = gelu_apply(v[e], a.gelu_mode);
+        if (a.out16) {
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; e++) h[e] = (_Float16) g[e];
+            *(half4 *) (a.out16 + (int64_t) r * a.ldo + n) = h;
+        } else {
+            *(float4v *) (a.out + (int64_t) r * a.ldo + n) = g;
+        }
+    } else {  // EPI_QKV
+        const int which = n / a.H;
+        const int c = n - which * a.H;
+        if (which == 0) {
+            *(float4v *) (a.q + (int64_t) r * a.H + c) = v;
+        } else {
+            const int64_t off = (int64_t) a.row_seq[r] * a.seq_stride + (int64_t) a.row_pos[r] * a.H + c;
+            void *base = which == 1 ? a.kc : a.vc;
+            if (a.kv_f16) {
+                half4 h;
+#pragma unroll
+                for (int e = 0; e < 4; e++) h[e] = (_Float16) v[e];
+                *(half4 *) ((_Float16 *) base + off) = h;
+            } else {
+                *(float4v *) ((float *) base + off) = v;
+            }
+        }
+    }
+}
+
+// WT: 0 = fp32 weights (exact-fp32 MFMA 16x16x4), 1 = fp16 weights (MFMA 16x16x32, activations rounded
+// to fp16 like ggml's vec_dot_type conversion).  blockDim.x = 64 * K/256.
+template <int WT, int PRO, int EPI, int RB>
+__global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int li = lane & 15, g = lane >> 4;
+    const int K = a.K;
+
+    // ---- 1. issue every weight load of this lane (HBM latency overlaps the prologue) -------------
+    half8   wh[2][4];
+    float4v wf[4][4];
+    if (WT == 1) {
+        const _Float16 *wp = (const _Float16 *) a.W + (int64_t) (n0 + li) * K + w * 256 + g * 32;
+#pragma unroll
+        for (int ss = 0; ss < 2; ss++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) wh[ss][c] = __builtin_nontemporal_load((const half8 *) (wp + ss * 128 + c * 8));
+    } else {
+        const float *wp = (const float *) a.W + (int64_t) (n0 + li) * K + w * 256 + g * 16;
+#pragma unroll
+        for (int ss = 0; ss < 4; ss++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) wf[ss][c] = __builtin_nontemporal_load((const float4v *) (wp + ss * 64 + c * 4));
+    }
+
+    // ---- 2. prologue: LayerNorm of the R rows into LDS (fp16 for WT=1, fp32 for WT=0) -----------
+    const int ldx = K + (WT == 1 ? 8 : 4);  // +16 B per row: spreads rows over LDS banks
+    _Float16 *xs16 = (_Float16 *) smem;
+    float    *xs32 = (float *) smem;
+    size_t    red_off = 0;
+    if (PRO == PRO_LN) {
+        const float *A = (const float *) a.A;
+        for (int r = w; r < RB * 16; r += nw) {
+            const int rr = r < a.R ? r : a.R - 1;
+            const float *xr = A + (int64_t) rr * a.lda;
+            float s = 0.0f;
+            for (int k = lane * 4; k < K; k += 256) {
+                const float4v v = *(const float4v *) (xr + k);
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            const float mean = wave_sum(s) / (float) K;
+            float s2 = 0.0f;
+            for (int k = lane * 4; k < K; k += 256) {
+                const float4v v = *(const float4v *) (xr + k);
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const float d = v[e] - mean; s2 += d * d; }
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float) K + LN_EPS);
+            for (int k = lane * 4; k < K; k += 256) {
+                const float4v v  = *(const float4v *) (xr + k);
+                const float4v lw = *(const float4v *) (a.ln_w + k);
+                const float4v lb = *(const float4v *) (a.ln_b + k);
+                float4v y;
+#pragma unroll
+                for (int e = 0; e < 4; e++) y[e] = (v[e] - mean) * rstd * lw[e] + lb[e];
+                if (WT == 1) {
+                    half4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) h[e] = (_Float16) y[e];
+                    *(half4 *) (xs16 + (size_t) r * ldx + k) = h;
+                } else {
+                    *(float4v *) (xs32 + (size_t) r * ldx + k) = y;
+                }
+            }
+        }
+        red_off = (size_t) RB * 16 * ldx * (WT == 1 ? 2 : 4);
+        red_off = (red_off + 15) & ~(size_t) 15;
+        __syncthreads();
+    }
+
+    // ---- 3. MFMA over this wave's 256-wide K slice ---------------------------------------------
+    float4v acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++) acc[rb] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++) {
+        const int r  = rb * 16 + li;
+        const int rr = r < a.R ? r : a.R - 1;
+        if (WT == 1) {
+            const int kb = w * 256 + g * 32;
+#pragma unroll
+            for (int ss = 0; ss < 2; ss++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    half8 b;
+                    const int k = kb + ss * 128 + c * 8;
+                    if (PRO == PRO_LN) {
+                        b = *(const half8 *) (xs16 + (size_t) r * ldx + k);
+                    } else if (PRO == PRO_F16) {
+                        b = *(const half8 *) ((const _Float16 *) a.A + (int64_t) rr * a.lda + k);
+                    } else {
+                        const float *p = (const float *) a.A + (int64_t) rr * a.lda + k;
+                        const float4v f0 = *(const float4v *) p, f1 = *(const float4v *) (p + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { b[e] = (_Float16) f0[e]; b[4 + e] = (_Float16) f1[e]; }
+                    }
+                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ss][c], b, acc[rb], 0, 0, 0);
+                }
+        } else {
+            const int kb = w * 256 + g * 16;
+#pragma unroll
+            for (int ss = 0; ss < 4; ss++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float4v b;
+                    const int k = kb + ss * 64 + c * 4;
+                    if (PRO == PRO_LN) b = *(const float4v *) (xs32 + (size_t) r * ldx + k);
+                    else               b = *(const float4v *) ((const float *) a.A + (int64_t) rr * a.lda + k);
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ss][c][e], b[e], acc[rb], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- 4. reduce the K slices across waves (fixed order: deterministic) -----------------------
+    if (nw > 1) {
+        float *red = (float *) (smem + red_off);  // [nw][RB][4][64]
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) red[((w * RB + rb) * 4 + e) * 64 + lane] = acc[rb][e];
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float s = red[((0 * RB + rb) * 4 + e) * 64 + lane];
+                    for (int ww = 1; ww < nw; ww++) s += red[((ww * RB + rb) * 4 + e) * 64 + lane];
+                    acc[rb][e] = s;
+                }
+        }
+    }
+
+    // ---- 5. epilogue: D[feature = g*4+e][row = li] ---------------------------------------------
+    if (w == 0) {
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) {
+            const int r = rb * 16 + li;
+            if (r < a.R) gemm_epilogue4(a, EPI, r, n0 + g * 4, acc[rb]);
+        }
+    }
+}
+
+// Scalar-FMA reference GEMV (debug / parity cross-check on the device, and shapes with K % 256 != 0).
+// One wave per output feature; activations already normalised by ln_rows_kernel when needed.
+template <int WT>
+__global__ void gemv_valu_kernel(GemmArgs a, int EPI, int act_f16_src) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = blockIdx.x * (blockDim.x >> 6) + w;
+    if (n >= a.N) return;
+    for (int r = 0; r < a.R; r++) {
+        float acc = 0.0f;
+        for (int k = lane; k < a.K; k += 64) {
+            float wv, xv;
+            if (WT == 1) wv = (float) ((const _Float16 *) a.W)[(int64_t) n * a.K + k];
+            else         wv = ((const float *) a.W)[(int64_t) n * a.K + k];
+            if (act_f16_src) xv = (float) ((const _Float16 *) a.A)[(int64_t) r * a.lda + k];
+            else {
+                xv = ((const float *) a.A)[(int64_t) r * a.lda + k];
+                if (WT == 1) xv = (float) (_Float16) xv;  // vec_dot_type conversion of src1
+            }
+            acc += wv * xv;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            if (EPI == EPI_STORE) a.out[(int64_t) r * a.ldo + n] = acc;
+            else if (EPI == EPI_RESID) a.out[(int64_t) r * a.ldo + n] += acc;
+            else if (EPI == EPI_GELU) {
+                const float gl = gelu_apply(acc, a.gelu_mode);
+                if (a.out16) a.out16[(int64_t) r * a.ldo + n] = (_Float16) gl;
+                else a.out[(int64_t) r * a.ldo + n] = gl;
+            } else {
+                const int which = n / a.H, c = n - which * a.H;
+                if (which == 0) a.q[(int64_t) r * a.H + c] = acc;
+                else {
+                    const int64_t off = (int64_t) a.row_seq[r] * a.seq_stride + (int64_t) a.row_pos[r] * a.H + c;
+                    void *base = which == 1 ? a.kc : a.vc;
+                    if (a.kv_f16) ((_Float16 *) base)[off] = (_Float16) acc;
+                    else ((float *) base)[off] = acc;
+                }
+            }
+        }
+    }
+}
+
+// LayerNorm of R rows (debug "hidden" read-back and the VALU GEMV path)
+__global__ void ln_rows_kernel(const float *x, int H, const float *lw, const float *lb, float *y) {
+    __shared__ float sh[32];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const float *xr = x + (int64_t) r * H;
+    float s = 0.0f;
+    for (int k = tid; k < H; k += blockDim.x) s += xr[k];
+    s = wave_sum(s);
+    if (lane == 0) sh[w] = s;
+    __syncthreads();
+    float tot = 0.0f;
+    for (int i = 0; i < nw; i++) tot += sh[i];
+    const float mean = tot / (float) H;
+    __syncthreads();
+    float s2 = 0.0f;
+    for (int k = tid; k < H; k += blockDim.x) { const float d = xr[k] - mean; s2 += d * d; }
+    s2 = wave_sum(s2);
+    if (lane == 0) sh[w] = s2;
+    __syncthreads();
+    tot = 0.0f;
+    for (int i = 0; i < nw; i++) tot += sh[i];
+    const float rstd = 1.0f / sqrtf(tot / (float) H + LN_EPS);
+    for (int k = tid; k < H; k += blockDim.x) y[(int64_t) r * H + k] = (xr[k] - mean) * rstd * lw[k] + lb[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention for one query row per (head, row): softmax(q·K^T / sqrt(d)) · V over T cached positions.
+// head_dim is 64 (Parler-Mini/Large).  16 lanes own one key (4 channels each, one 256-B line per
+// key per head), 16 keys in flight per workgroup pass; the causal mask of model.cpp:623-631 is
+// implicit in T = pos+1, the all-zero cross mask (:633-641) in T = n_encode_length.
+// Split-T: blockIdx.z owns keys [z*chunk, (z+1)*chunk); partial (max, sum, acc[64]) are merged by
+// attn_combine_kernel when gridDim.z > 1.
+// ------------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const float *q;        // [R][H]
+    const void *kc, *vc;   // [seq][n_ctx][H]  (or [E][H] for cross)
+    int kv_f16;
+    int64_t seq_stride;    // 0 for cross attention
+    const uint32_t *row_seq, *row_pos;  // NULL for cross attention
+    int T_fixed;           // cross: n_encode_length
+    int H, n_heads;
+    float scale;
+    float *out;            // [R][H]
+    float *part;           // [R][n_heads][nsplit][66]  (max, sum, acc[64]) when nsplit > 1
+    int max_T;             // LDS score capacity
+};
+
+__device__ __forceinline__ float4v load_kv4(const void *base, int kv_f16, int64_t off) {
+    if (kv_f16) {
+        const half4 h = *(const half4 *) ((const _Float16 *) base + off);
+        return (float4v){(float) h[0], (float) h[1], (float) h[2], (float) h[3]};
+    }
+    return *(const float4v *) ((const float *) base + off);
+}
+
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sc  = (float *) smem;                 // [chunk]
+    float *red = sc + a.max_T;                   // [16][64] + [16] + [16]
+    const int h = blockIdx.x, r = blockIdx.y, z = blockIdx.z, nz = gridDim.z;
+    const int tid = threadIdx.x, kg = tid >> 4, cl = tid & 15, c4 = cl * 4;
+    const int T = a.row_pos ? (int) a.row_pos[r] + 1 : a.T_fixed;
+    const int64_t sb = a.row_seq ? (int64_t) a.row_seq[r] * a.seq_stride : 0;
+    const int chunk = (T + nz - 1) / nz;
+    const int t0 = z * chunk, t1 = min(T, t0 + chunk);
+    const int64_t hb = sb + h * 64 + c4;
+    const float4v q4 = *(const float4v *) (a.q + (int64_t) r * a.H + h * 64 + c4);
+
+    // pass 1: scores + running max
+    float lmax = -INFINITY;
+    for (int t = t0 + kg; t < t1; t += 16) {
+        const float4v k4 = load_kv4(a.kc, a.kv_f16, hb + (int64_t) t * a.H);
+        float d = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
+        d += __shfl_xor(d, 8); d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
+        d *= a.scale;  // soft_max_ext(kq, mask, 1/sqrt(d), 0)
+        if (cl == 0) sc[t - t0] = d;
+        lmax = fmaxf(lmax, d);
+    }
+    lmax = wave_max(lmax);
+    if ((tid & 63) == 0) red[tid >> 6] = lmax;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+
+    // pass 2: p = exp(s - max), acc += p * V
+    float4v acc = {0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.0f;
+    for (int t = t0 + kg; t < t1; t += 16) {
+        const float p = expf(sc[t - t0] - mx);
+        const float4v v4 = load_kv4(a.vc, a.kv_f16, hb + (int64_t) t * a.H);
+        lsum += p;
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[e] += p * v4[e];
+    }
+    // reduce over the 16 key groups
+    *(float4v *) (red + kg * 64 + c4) = acc;
+    if (cl == 0) red[1024 + kg] = lsum;
+    __syncthreads();
+    if (tid < 64) {
+        float o = 0.0f, s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { o += red[i * 64 + tid]; s += red[1024 + i]; }
+        if (nz == 1) {
+            a.out[(int64_t) r * a.H + h * 64 + tid] = o / s;
+        } else {
+            float *p = a.part + (((int64_t) r * a.n_heads + h) * nz + z) * 66;
+            if (tid == 0) { p[0] = mx; p[1] = s; }
+            p[2 + tid] = o;
+        }
+    }
+}
+
+__global__ void attn_combine_kernel(const float *part, int nz, int H, int n_heads, float *out) {
+    const int h = blockIdx.x, r = blockIdx.y, c = threadIdx.x;  // 64 threads
+    const float *p = part + ((int64_t) r * n_heads + h) * nz * 66;
+    float mx = -INFINITY;
+    for (int z = 0; z < nz; z++) mx = fmaxf(mx, p[z * 66]);
+    float o = 0.0f, s = 0.0f;
+    for (int z = 0; z < nz; z++) {
+        const float m = p[z * 66];
+        if (m == -INFINITY) continue;  // empty chunk
+        const float f = expf(m - mx);
+        o += f * p[z * 66 + 2 + c];
+        s += f * p[z * 66 + 1];
+    }
+    out[(int64_t) r * H + h * 64 + c] = o / s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampler::max on the device (src/sampler.cpp:185-204): first maximum wins (v > max).
+// ------------------------------------------------------------------------------------------------
+__global__ void argmax_kernel(const float *logits, int V, uint32_t *tokens) {
+    __shared__ float bv[4];
+    __shared__ uint32_t bi[4];
+    const int idx = blockIdx.x;  // r * n_out + head
+    const float *lg = logits + (int64_t) idx * V;
+    float best = -INFINITY;
+    uint32_t besti = 0;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        const float v = lg[i];
+        if (v > best) { best = v; besti = (uint32_t) i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const uint32_t oi = __shfl_xor(besti, o);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { bv[w] = best; bi[w] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int) (blockDim.x >> 6); i++)
+            if (bv[i] > best || (bv[i] == best && bi[i] < besti)) { best = bv[i]; besti = bi[i]; }
+        tokens[idx] = besti;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-resident AR loop bookkeeping for greedy generation:
+//   record the sampled tokens, update eos_seen (check_stopping, model.cpp:715-732), build the next
+//   input ids with the delay pattern (model.cpp:778-785) and advance positions.
+// ------------------------------------------------------------------------------------------------
+struct FeedArgs {
+    const uint32_t *tokens;   // [R][n_out] argmax of this step
+    uint32_t *ids;            // [R][n_out] next step's input ids (in/out)
+    uint32_t *row_pos;        // [R]
+    uint32_t *step;           // [1] current_step of the step that just ran (>= 1), incremented here
+    uint8_t  *eos_seen;       // [R][n_out]
+    uint32_t *steps_done;     // [R] number of audio steps after which check_stopping() would return true (0 = not yet)
+    uint32_t *tokens_out;     // [n_steps][R][n_out]
+    int R, n_out;
+    uint32_t bos, eos;
+};
+
+__global__ void feed_kernel(FeedArgs a) {
+    __shared__ int all_seen[64];
+    const uint32_t step = *a.step;
+    const int tid = threadIdx.x;
+    if (tid < a.R) all_seen[tid] = 1;
+    __syncthreads();
+    if (tid < a.R * a.n_out) {
+        const int r = tid / a.n_out, hd = tid - r * a.n_out;
+        const uint32_t tok = a.tokens[tid];
+        a.tokens_out[((int64_t) (step - 1) * a.R + r) * a.n_out + hd] = tok;
+        const uint8_t seen = a.eos_seen[tid] | (tok == a.eos ? 1 : 0);
+        a.eos_seen[tid] = seen;
+        a.ids[tid] = ((int) step > hd) ? (seen ? a.eos : tok) : a.bos;
+        if (!seen) atomicAnd(&all_seen[r], 0);
+    }
+    __syncthreads();
+    if (tid < a.R) {
+        a.row_pos[tid] += 1;
+        if (all_seen[tid] && a.steps_done[tid] == 0) a.steps_done[tid] = step;
+    }
+    __syncthreads();
+    if (tid == 0) *a.step = step + 1;
+}

@@ -1,0 +1,1235 @@
+// tts_hip.hip — implementation of include/tts_hip.h for MI355X (gfx950).
+//
+// Owns: the device weight arena (tts_model's backend buffer, /root/reference/src/tts_model.cpp:157-169),
+// the self-attention KV cache (parler_kv_cache, src/models/parler/model.cpp:339-385), the cross K/V
+// (prep_cross_key_values :110-173), one HIP stream, and the captured hipGraphs that replace the
+// per-step ggml graph rebuild (build_parler_graph :520-614 + ggml_backend_sched_alloc_graph :674).
+// No CPU fallback: every entry point fails if the device is unavailable.
+#include "../../include/tts_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "dac_kernels.h"
+#include "parler_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+static int set_err(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return -1;
+}
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return set_err("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+    } while (0)
+#define CHK(expr)                       \
+    do {                                \
+        int _r = (expr);                \
+        if (_r != 0) return _r;         \
+    } while (0)
+
+extern "C" const char *tts_hip_last_error(void) { return g_err; }
+extern "C" const char *tts_hip_version(void) { return "tts_hip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------
+// host-side format helpers (GGUF block formats)
+// ------------------------------------------------------------------------------------------------
+static float h2f_host(uint16_t h) {
+    const uint32_t sign = (uint32_t) (h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1F, man = h & 0x3FF, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {
+            exp = 113;
+            while ((man & 0x400) == 0) { man <<= 1; exp--; }
+            bits = sign | (exp << 23) | ((man & 0x3FF) << 13);
+        }
+    } else if (exp == 31) bits = sign | 0x7F800000u | (man << 13);
+    else bits = sign | ((exp + 112) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+static size_t type_row_bytes(int type, int64_t n) {
+    switch (type) {
+        case TTS_HIP_F32: return (size_t) n * 4;
+        case TTS_HIP_F16: return (size_t) n * 2;
+        case TTS_HIP_Q4_0: return (size_t) (n / 32) * 18;
+        case TTS_HIP_Q5_0: return (size_t) (n / 32) * 22;
+        case TTS_HIP_Q8_0: return (size_t) (n / 32) * 34;
+        default: return 0;
+    }
+}
+
+// exact dequantisation of a GGUF tensor to fp32 on the host (round-1 handling of Q4_0/Q5_0/Q8_0 and
+// of fp16 tensors that the kernels want in fp32)
+static int dequant_to_f32(int type, const void *src, float *dst, int64_t n) {
+    const uint8_t *p = (const uint8_t *) src;
+    if (type == TTS_HIP_F32) { memcpy(dst, src, (size_t) n * 4); return 0; }
+    if (type == TTS_HIP_F16) {
+        const uint16_t *h = (const uint16_t *) src;
+        for (int64_t i = 0; i < n; i++) dst[i] = h2f_host(h[i]);
+        return 0;
+    }
+    if (n % 32) return -1;
+    for (int64_t b = 0; b < n / 32; b++, dst += 32) {
+        uint16_t dh;
+        memcpy(&dh, p, 2);
+        const float d = h2f_host(dh);
+        if (type == TTS_HIP_Q4_0) {
+            const uint8_t *qs = p + 2;
+            for (int j = 0; j < 16; j++) {
+                dst[j] = (float) ((int) (qs[j] & 0xF) - 8) * d;
+                dst[j + 16] = (float) ((int) (qs[j] >> 4) - 8) * d;
+            }
+            p += 18;
+        } else if (type == TTS_HIP_Q5_0) {
+            uint32_t qh;
+            memcpy(&qh, p + 2, 4);
+            const uint8_t *qs = p + 6;
+            for (int j = 0; j < 16; j++) {
+                const int b0 = (qh >> j) & 1, b1 = (qh >> (j + 16)) & 1;
+                dst[j] = (float) ((int) ((qs[j] & 0xF) | (b0 << 4)) - 16) * d;
+                dst[j + 16] = (float) ((int) ((qs[j] >> 4) | (b1 << 4)) - 16) * d;
+            }
+            p += 22;
+        } else if (type == TTS_HIP_Q8_0) {
+            const int8_t *qs = (const int8_t *) (p + 2);
+            for (int j = 0; j < 32; j++) dst[j] = (float) qs[j] * d;
+            p += 34;
+        } else return -1;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct Tensor {
+    int type = 0;  // type as stored on the device (F32 or F16)
+    int n_dims = 0;
+    int64_t ne[4] = {1, 1, 1, 1};
+    size_t nbytes = 0;
+    void *tmp = nullptr;  // device staging copy until finalize
+    bool has_data = false;
+    int64_t nelem() const { return ne[0] * ne[1] * ne[2] * ne[3]; }
+};
+
+struct W {  // a matrix living in the arena
+    size_t off = 0;
+    int type = 0;
+    int64_t K = 0, N = 0;
+};
+
+struct PLayer {
+    W qkv, o, cq, ck, cv, co, fc1, fc2;
+    size_t sa_w = 0, sa_b = 0, ca_w = 0, ca_b = 0, f_w = 0, f_b = 0;
+};
+
+struct DRes { size_t in_alpha, in_w, in_b, out_alpha, out_w, out_b; };
+struct DBlock { int stride, padding, cin, cout; size_t alpha, w, b; DRes res[3]; };
+
+struct CopyItem { size_t dst; std::string src; };
+
+struct ProfEv { hipEvent_t a, b; int kclass; };
+
+struct tts_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    tts_hip_desc d{};
+    std::map<std::string, Tensor> tensors;
+    bool planned = false, finalized = false, weights_present = false;
+    bool has_parler = false, has_dac = false;
+
+    // arena
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    bool arena_external = false;
+    std::vector<CopyItem> copies;
+
+    // parler model
+    int H = 0, L = 0, NH = 0, F = 0, V = 0, NO = 0, NCTX = 0, E = 0, ECAP = 0, PV = 0, EROWS = 0, NPOS = 0;
+    W embed_prompts, embed_tokens, heads;
+    size_t pos_embed = 0, text_enc = 0, ln_w = 0, ln_b = 0, cross_kv = 0;
+    std::vector<PLayer> layers;
+
+    // dac model
+    int d_ncb = 0, d_cbsize = 0, d_cbdim = 0, d_latent = 0, d_c0 = 0, d_clast = 0, d_up = 1;
+    size_t d_codebook = 0, d_projw = 0, d_projb = 0, d_initw = 0, d_initb = 0, d_falpha = 0, d_fw = 0, d_fb = 0;
+    std::vector<DBlock> dblocks;
+
+    // runtime buffers
+    int RMAX = 0;
+    void *kcache = nullptr, *vcache = nullptr;  // [L][max_seqs][NCTX][H]
+    float *x = nullptr, *q = nullptr, *att = nullptr, *u32 = nullptr, *logits = nullptr, *part = nullptr, *dbg = nullptr;
+    _Float16 *u16 = nullptr;
+    uint32_t *d_ids = nullptr, *d_pos = nullptr, *d_seq = nullptr, *d_tok = nullptr, *d_step = nullptr, *d_steps_done = nullptr;
+    uint32_t *d_tokens_out = nullptr;
+    size_t tokens_out_cap = 0;
+    uint8_t *d_eos = nullptr;
+    // pinned staging
+    uint32_t *h_ids = nullptr, *h_pos = nullptr, *h_seq = nullptr, *h_tok = nullptr;
+    float *h_logits = nullptr;
+    std::vector<uint32_t> host_pos;  // positions per row of the forward being enqueued (for byte accounting)
+
+    // dac buffers
+    float *dbuf[3] = {nullptr, nullptr, nullptr};
+    size_t dbuf_elems = 0;
+    uint32_t *d_codes = nullptr;
+    float *h_pcm = nullptr;
+    bool debug = false;
+    std::map<int, std::vector<float>> dac_dbg;
+
+    // graphs
+    std::map<int, hipGraphExec_t> graphs;
+
+    // profiling
+    bool prof = false;
+    std::vector<ProfEv> prof_events;
+    tts_hip_kstat kstat[TTS_HIP_K_COUNT]{};
+    int attn_nsplit_override = 0;
+};
+
+static const char *KNAMES[TTS_HIP_K_COUNT] = {"embed", "gemm_ln", "gemm", "attn", "attn_cross", "heads",
+                                              "dac_embed", "dac_conv", "dac_convt", "sample"};
+extern "C" const char *tts_hip_kclass_name(int k) { return (k >= 0 && k < TTS_HIP_K_COUNT) ? KNAMES[k] : "?"; }
+
+extern "C" int tts_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { set_err("hipGetDeviceCount failed (no ROCm device visible)"); return 0; }
+    return n;
+}
+
+extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
+    if (!desc || desc->struct_size != sizeof(tts_hip_desc)) { set_err("tts_hip_create: bad desc (struct_size mismatch)"); return nullptr; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_err("tts_hip_create: no HIP device available; this library has no CPU fallback"); return nullptr; }
+    if (device < 0 || device >= n) { set_err("tts_hip_create: device %d out of range (%d devices)", device, n); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); return nullptr; }
+    tts_hip_ctx *c = new tts_hip_ctx;
+    c->device = device;
+    c->d = *desc;
+    if (c->d.max_seqs == 0) c->d.max_seqs = 1;
+    if (c->d.kv_type != TTS_HIP_F16) c->d.kv_type = TTS_HIP_F32;
+    c->has_parler = !(desc->flags & TTS_HIP_FLAG_NO_PARLER);
+    c->has_dac = !(desc->flags & TTS_HIP_FLAG_NO_DAC);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); delete c; return nullptr; }
+    const char *ns = getenv("TTS_HIP_ATTN_NSPLIT");
+    if (ns) c->attn_nsplit_override = atoi(ns);
+    return c;
+}
+
+static void free_dev(void *p) { if (p) (void) hipFree(p); }
+
+extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
+    if (!c) return;
+    (void) hipSetDevice(c->device);
+    (void) hipStreamSynchronize(c->stream);
+    for (auto &g : c->graphs) (void) hipGraphExecDestroy(g.second);
+    for (auto &t : c->tensors) free_dev(t.second.tmp);
+    if (!c->arena_external) free_dev(c->arena);
+    free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
+    free_dev(c->u16); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
+    free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
+    free_dev(c->d_eos); free_dev(c->d_codes);
+    for (int i = 0; i < 3; i++) free_dev(c->dbuf[i]);
+    if (c->h_ids) (void) hipHostFree(c->h_ids);
+    if (c->h_pos) (void) hipHostFree(c->h_pos);
+    if (c->h_seq) (void) hipHostFree(c->h_seq);
+    if (c->h_tok) (void) hipHostFree(c->h_tok);
+    if (c->h_logits) (void) hipHostFree(c->h_logits);
+    if (c->h_pcm) (void) hipHostFree(c->h_pcm);
+    for (auto &e : c->prof_events) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
+    (void) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// upload
+// ------------------------------------------------------------------------------------------------
+static bool ends_with(const std::string &s, const char *suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+static bool starts_with(const std::string &s, const char *pre) { return s.compare(0, strlen(pre), pre) == 0; }
+
+// Which uploaded tensors stay fp16 on the device: the big decoder matrices and embedding tables.
+// Norm vectors, positional table, text encoding and the whole DAC are kept fp32.
+static bool keeps_f16(const std::string &name) {
+    if (!starts_with(name, "decoder.")) return false;
+    if (name.find("layer_norm") != std::string::npos) return false;
+    if (name == "decoder.positional_embed" || name == "decoder.text_encoding") return false;
+    return true;
+}
+
+extern "C" int tts_hip_upload(tts_hip_ctx *c, const char *name_c, int type, int n_dims, const int64_t *ne, const void *host) {
+    if (!c || !name_c || !ne) return set_err("tts_hip_upload: null argument");
+    if (c->finalized) return set_err("tts_hip_upload(%s): context already finalized", name_c);
+    HIPCHK(hipSetDevice(c->device));
+    std::string name(name_c);
+    if (!starts_with(name, "decoder.") && !starts_with(name, "audio_encoder.")) {
+        fprintf(stderr, "tts_hip: ignoring unhandled tensor '%s'\n", name_c);  // model.cpp:506
+        return 0;
+    }
+    if (starts_with(name, "decoder.") && !c->has_parler) return 0;
+    if (starts_with(name, "audio_encoder.") && !c->has_dac) return 0;
+    if (name.find(".in_proj") != std::string::npos) return 0;  // unused quantizer input projection (gnac.cpp:126-130)
+    if (n_dims < 1 || n_dims > 4) return set_err("tts_hip_upload(%s): n_dims=%d", name_c, n_dims);
+    Tensor t;
+    t.n_dims = n_dims;
+    for (int i = 0; i < n_dims; i++) t.ne[i] = ne[i];
+    const int64_t n = t.nelem();
+    const size_t src_bytes = type_row_bytes(type, t.ne[0]) * (size_t) (n / t.ne[0]);
+    if (src_bytes == 0) return set_err("tts_hip_upload(%s): unsupported ggml type %d", name_c, type);
+    const bool keep16 = (type == TTS_HIP_F16) && keeps_f16(name);
+    t.type = keep16 ? TTS_HIP_F16 : TTS_HIP_F32;
+    t.nbytes = (size_t) n * (keep16 ? 2 : 4);
+    t.has_data = host != nullptr;
+    if (host) {
+        HIPCHK(hipMalloc(&t.tmp, t.nbytes));
+        if (keep16 || type == TTS_HIP_F32) {
+            HIPCHK(hipMemcpy(t.tmp, host, t.nbytes, hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> f((size_t) n);
+            if (dequant_to_f32(type, host, f.data(), n) != 0) return set_err("tts_hip_upload(%s): dequantisation failed", name_c);
+            HIPCHK(hipMemcpy(t.tmp, f.data(), t.nbytes, hipMemcpyHostToDevice));
+        }
+    }
+    auto it = c->tensors.find(name);
+    if (it != c->tensors.end()) free_dev(it->second.tmp);
+    c->tensors[name] = t;
+    c->planned = false;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// arena planning
+// ------------------------------------------------------------------------------------------------
+struct Planner {
+    tts_hip_ctx *c;
+    size_t cur = 0;
+    std::string err;
+    size_t alloc(size_t bytes) {
+        cur = (cur + 255) & ~(size_t) 255;
+        const size_t o = cur;
+        cur += bytes;
+        return o;
+    }
+    const Tensor *get(const std::string &n) {
+        auto it = c->tensors.find(n);
+        if (it == c->tensors.end()) { if (err.empty()) err = "missing tensor '" + n + "'"; return nullptr; }
+        return &it->second;
+    }
+    size_t place(const std::string &n) {
+        const Tensor *t = get(n);
+        if (!t) return 0;
+        const size_t o = alloc(t->nbytes);
+        c->copies.push_back({o, n});
+        return o;
+    }
+    size_t place_f32(const std::string &n) {
+        const Tensor *t = get(n);
+        if (t && t->type != TTS_HIP_F32 && err.empty()) err = "tensor '" + n + "' must be fp32";
+        return place(n);
+    }
+    W mat(const std::string &n) {
+        W w;
+        const Tensor *t = get(n);
+        if (!t) return w;
+        w.type = t->type; w.K = t->ne[0]; w.N = t->nelem() / t->ne[0];
+        w.off = place(n);
+        return w;
+    }
+    // several same-shaped matrices stacked along N
+    W fused(const std::vector<std::string> &names) {
+        W w;
+        for (size_t i = 0; i < names.size(); i++) {
+            const Tensor *t = get(names[i]);
+            if (!t) return w;
+            if (i == 0) {
+                w.type = t->type; w.K = t->ne[0]; w.N = 0;
+                cur = (cur + 255) & ~(size_t) 255;
+                w.off = cur;
+            } else if (t->type != w.type || t->ne[0] != w.K) {
+                if (err.empty()) err = "tensors fused with '" + names[0] + "' differ in type/shape: '" + names[i] + "'";
+                return w;
+            }
+            c->copies.push_back({cur, names[i]});
+            cur += t->nbytes;
+            w.N += t->nelem() / t->ne[0];
+        }
+        return w;
+    }
+};
+
+static int plan(tts_hip_ctx *c) {
+    if (c->planned) return 0;
+    Planner P{c};
+    c->copies.clear();
+    const tts_hip_desc &d = c->d;
+    if (c->has_parler) {
+        c->H = d.hidden_size; c->L = d.n_layers; c->NH = d.n_attn_heads; c->NO = d.n_output_heads;
+        c->V = d.output_vocab_size; c->NCTX = d.max_ctx_length; c->E = d.n_encode_length;
+        if (c->H <= 0 || c->L <= 0 || c->NH <= 0 || c->NO <= 0 || c->V <= 0 || c->NCTX <= 0) return set_err("plan: incomplete Parler hyper-parameters in desc");
+        if (c->H / c->NH != 64 || c->H % c->NH) return set_err("plan: head size %d unsupported (kernels are specialised for 64, Parler-Mini/Large)", c->H / c->NH);
+        if (c->H % 16 || c->V % 16) return set_err("plan: hidden size and vocab must be multiples of 16");
+        if (c->NO > 16) return set_err("plan: at most 16 output heads");
+        c->ECAP = std::max(c->E, 512);  // max_encode_length, model.h:69
+        c->embed_prompts = P.mat("decoder.embed_prompts");
+        c->PV = (int) c->embed_prompts.N;
+        { const Tensor *t = P.get("decoder.positional_embed"); c->NPOS = t ? (int) (t->nelem() / t->ne[0]) : 0; }
+        c->pos_embed = P.place_f32("decoder.positional_embed");
+        c->ln_w = P.place_f32("decoder.layer_norm.weight");
+        c->ln_b = P.place_f32("decoder.layer_norm.bias");
+        std::vector<std::string> en, hn;
+        for (int i = 0; i < c->NO; i++) {
+            en.push_back("decoder.embed_tokens." + std::to_string(i) + ".weight");
+            hn.push_back("decoder.lm_heads." + std::to_string(i) + ".weight.head");
+        }
+        c->embed_tokens = P.fused(en);
+        c->EROWS = (int) (c->embed_tokens.N / c->NO);
+        c->heads = P.fused(hn);
+        c->layers.assign(c->L, PLayer{});
+        for (int l = 0; l < c->L; l++) {
+            const std::string p = "decoder.layers." + std::to_string(l) + ".";
+            PLayer &y = c->layers[l];
+            y.sa_w = P.place_f32(p + "self_attn_layer_norm.weight");
+            y.sa_b = P.place_f32(p + "self_attn_layer_norm.bias");
+            y.qkv = P.fused({p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"});
+            y.o = P.mat(p + "self_attn.out_proj.weight");
+            if (d.use_cross_attn) {
+                y.ca_w = P.place_f32(p + "encoder_attn_layer_norm.weight");
+                y.ca_b = P.place_f32(p + "encoder_attn_layer_norm.bias");
+                y.cq = P.mat(p + "encoder_attn.q_proj.weight");
+                y.ck = P.mat(p + "encoder_attn.k_proj.weight");
+                y.cv = P.mat(p + "encoder_attn.v_proj.weight");
+                y.co = P.mat(p + "encoder_attn.out_proj.weight");
+            }
+            y.f_w = P.place_f32(p + "final_layer_norm.weight");
+            y.f_b = P.place_f32(p + "final_layer_norm.bias");
+            y.fc1 = P.mat(p + "fc1.weight");
+            y.fc2 = P.mat(p + "fc2.weight");
+        }
+        c->F = c->layers.empty() ? 0 : (int) c->layers[0].fc1.N;
+        if (d.use_cross_attn) {
+            // voice-prompt encoding gets ECAP rows so that update_conditional_prompt fits (model.cpp:129-136)
+            const Tensor *t = P.get("decoder.text_encoding");
+            if (t) {
+                if ((int) (t->nelem() / t->ne[0]) != c->E && P.err.empty()) P.err = "decoder.text_encoding rows != n_encode_length";
+                c->text_enc = P.alloc((size_t) c->ECAP * c->H * 4);
+                c->copies.push_back({c->text_enc, "decoder.text_encoding"});
+            }
+            c->cross_kv = P.alloc((size_t) c->L * 2 * c->ECAP * c->H * 4);
+        }
+    }
+    if (c->has_dac) {
+        std::vector<std::string> cb, pw, pb;
+        int ncb = 0;
+        while (c->tensors.count("audio_encoder.quantizers." + std::to_string(ncb) + ".codebook.weight")) ncb++;
+        if (ncb == 0) return set_err("plan: no audio_encoder.quantizers.*.codebook.weight tensors");
+        if (c->has_parler && ncb < c->NO) return set_err("plan: %d DAC codebooks < %d output heads", ncb, c->NO);
+        if (c->has_parler) ncb = c->NO;  // dac_model::prep_constants: n_heads = output_heads (dac_model.cpp:16-19)
+        for (int i = 0; i < ncb; i++) {
+            const std::string p = "audio_encoder.quantizers." + std::to_string(i) + ".";
+            cb.push_back(p + "codebook.weight"); pw.push_back(p + "out_proj.weight"); pb.push_back(p + "out_proj.bias");
+        }
+        c->d_ncb = ncb;
+        const Tensor *t0 = P.get(cb[0]);
+        const Tensor *w0 = P.get(pw[0]);
+        if (t0 && w0) {
+            c->d_cbdim = (int) t0->ne[0]; c->d_cbsize = (int) t0->ne[1];
+            c->d_latent = (int) (w0->nelem() / c->d_cbdim);
+        }
+        c->d_codebook = P.fused(cb).off;
+        c->d_projw = P.fused(pw).off;
+        c->d_projb = P.fused(pb).off;
+        { const Tensor *t = P.get("audio_encoder.initial.weight"); c->d_c0 = t ? (int) t->ne[2] : 0; }
+        c->d_initw = P.place_f32("audio_encoder.initial.weight");
+        c->d_initb = P.place_f32("audio_encoder.initial.bias");
+        c->dblocks.assign(d.dac_n_blocks, DBlock{});
+        c->d_up = 1;
+        int C = c->d_c0;
+        for (uint32_t i = 0; i < d.dac_n_blocks; i++) {
+            const std::string p = "audio_encoder.decoder_block." + std::to_string(i + 1) + ".";
+            DBlock &b = c->dblocks[i];
+            b.stride = (int) d.dac_stride[i]; b.padding = (int) d.dac_padding[i];
+            const Tensor *t = P.get(p + "final.weight");  // ne = [K, Cout, Cin]
+            if (t) {
+                b.cin = (int) t->ne[2]; b.cout = (int) t->ne[1];
+                if ((int) t->ne[0] != 2 * b.stride && P.err.empty()) P.err = "DAC block kernel size != 2*stride: " + p;
+                if (b.cin != C && P.err.empty()) P.err = "DAC block channel mismatch: " + p;
+                if (((int) t->ne[0] - 2 * b.padding) != b.stride && P.err.empty()) P.err = "DAC block does not upsample by exactly its stride: " + p;
+            }
+            b.alpha = P.place_f32(p + "final.alpha");
+            b.w = P.place_f32(p + "final.weight");
+            b.b = P.place_f32(p + "final.bias");
+            for (int r = 0; r < 3; r++) {
+                const std::string q = p + "residual_unit." + std::to_string(r) + ".res.";
+                b.res[r].in_alpha = P.place_f32(q + "initial.alpha");
+                b.res[r].in_w = P.place_f32(q + "initial.weight");
+                b.res[r].in_b = P.place_f32(q + "initial.bias");
+                b.res[r].out_alpha = P.place_f32(q + "final.alpha");
+                b.res[r].out_w = P.place_f32(q + "final.weight");
+                b.res[r].out_b = P.place_f32(q + "final.bias");
+            }
+            C = b.cout;
+            c->d_up *= b.stride;
+        }
+        c->d_clast = C;
+        c->d_falpha = P.place_f32("audio_encoder.final.alpha");
+        c->d_fw = P.place_f32("audio_encoder.final.weight");
+        c->d_fb = P.place_f32("audio_encoder.final.bias");
+    }
+    if (!P.err.empty()) return set_err("plan: %s", P.err.c_str());
+    c->arena_bytes = (P.cur + 255) & ~(size_t) 255;
+    c->planned = true;
+    return 0;
+}
+
+extern "C" size_t tts_hip_arena_bytes(tts_hip_ctx *c) {
+    if (!c) return 0;
+    if (plan(c) != 0) return 0;
+    return c->arena_bytes;
+}
+extern "C" void *tts_hip_arena_ptr(tts_hip_ctx *c) { return c ? c->arena : nullptr; }
+extern "C" void *tts_hip_stream(tts_hip_ctx *c) { return c ? (void *) c->stream : nullptr; }
+extern "C" int tts_hip_synchronize(tts_hip_ctx *c) {
+    if (!c) return set_err("null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel launch plumbing (+ optional per-class event timing)
+// ------------------------------------------------------------------------------------------------
+static int prof_begin(tts_hip_ctx *c, int kclass, double bytes, double flops) {
+    if (!c->prof) return 0;
+    ProfEv e;
+    HIPCHK(hipEventCreate(&e.a));
+    HIPCHK(hipEventCreate(&e.b));
+    e.kclass = kclass;
+    HIPCHK(hipEventRecord(e.a, c->stream));
+    c->prof_events.push_back(e);
+    c->kstat[kclass].launches++;
+    c->kstat[kclass].bytes_total += bytes;
+    c->kstat[kclass].flops_total += flops;
+    return 0;
+}
+static int prof_end(tts_hip_ctx *c) {
+    if (!c->prof) return 0;
+    HIPCHK(hipEventRecord(c->prof_events.back().b, c->stream));
+    return 0;
+}
+static int prof_collect(tts_hip_ctx *c) {
+    if (c->prof_events.empty()) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &e : c->prof_events) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+        c->kstat[e.kclass].ms_total += ms;
+        (void) hipEventDestroy(e.a);
+        (void) hipEventDestroy(e.b);
+    }
+    c->prof_events.clear();
+    return 0;
+}
+
+extern "C" int tts_hip_profile(tts_hip_ctx *c, int enable) {
+    if (!c) return set_err("null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    CHK(prof_collect(c));
+    c->prof = enable != 0;
+    if (enable) memset(c->kstat, 0, sizeof(c->kstat));
+    return 0;
+}
+extern "C" int tts_hip_profile_get(tts_hip_ctx *c, int k, tts_hip_kstat *out) {
+    if (!c || !out || k < 0 || k >= TTS_HIP_K_COUNT) return set_err("tts_hip_profile_get: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    CHK(prof_collect(c));
+    *out = c->kstat[k];
+    return 0;
+}
+
+template <int WT, int PRO, int EPI, int RB>
+static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
+    const int nw = a.K / 256;
+    size_t lds = 0;
+    if (PRO == PRO_LN) {
+        lds = (size_t) RB * 16 * (a.K + (WT == 1 ? 8 : 4)) * (WT == 1 ? 2 : 4);
+        lds = (lds + 15) & ~(size_t) 15;
+    }
+    if (nw > 1) lds += (size_t) nw * RB * 4 * 64 * 4;
+    static size_t attr_set = 0;
+    if (lds > attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *) gemm16_kernel<WT, PRO, EPI, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = 160 * 1024;
+    }
+    if (lds > 160 * 1024) return set_err("gemm16: LDS request %zu exceeds 160 KiB", lds);
+    hipLaunchKernelGGL((gemm16_kernel<WT, PRO, EPI, RB>), dim3(a.N / 16), dim3(nw * 64), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <int WT, int PRO, int EPI>
+static int launch_gemm16_rb(tts_hip_ctx *c, const GemmArgs &a) {
+    if (a.R <= 16) return launch_gemm16<WT, PRO, EPI, 1>(c, a);
+    if (a.R <= 32) return launch_gemm16<WT, PRO, EPI, 2>(c, a);
+    if (WT == 1 || PRO != PRO_LN) {
+        if (a.R <= 64) return launch_gemm16<WT, PRO, EPI, 4>(c, a);
+    }
+    return set_err("gemm16: %d rows exceed the per-launch maximum", a.R);
+}
+
+static int max_rows_for(const tts_hip_ctx *c) {
+    // fp32 LN tiles of 64 rows do not fit LDS; fp16 ones do
+    bool any_f32 = false;
+    for (auto &l : c->layers) if (l.qkv.type == TTS_HIP_F32 || l.fc1.type == TTS_HIP_F32) any_f32 = true;
+    if (c->heads.type == TTS_HIP_F32) any_f32 = true;
+    return any_f32 ? 32 : 64;
+}
+
+// one GEMM of the forward: picks MFMA or the scalar reference path
+static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi) {
+    a.W = c->arena + w.off;
+    a.K = (int) w.K;
+    a.N = (int) w.N;
+    const double wbytes = (double) w.K * w.N * (w.type == TTS_HIP_F16 ? 2 : 4);
+    const double bytes = wbytes + (double) a.R * a.K * 4 + (double) a.R * a.N * 4;
+    const double flops = 2.0 * a.R * (double) w.K * w.N;
+    const bool valu = (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) || (a.K % 256) || (a.N % 16);
+    if (valu) {
+        // scalar path: LayerNorm materialised first
+        GemmArgs b = a;
+        if (pro == PRO_LN) {
+            CHK(prof_begin(c, kclass, 0, 0));
+            hipLaunchKernelGGL(ln_rows_kernel, dim3(a.R), dim3(256), 0, c->stream, (const float *) a.A, a.K, a.ln_w, a.ln_b, c->dbg);
+            HIPCHK(hipGetLastError());
+            CHK(prof_end(c));
+            b.A = c->dbg;
+            b.lda = a.K;
+        }
+        CHK(prof_begin(c, kclass, bytes, flops));
+        const int wpb = 4;
+        if (w.type == TTS_HIP_F16) hipLaunchKernelGGL(gemv_valu_kernel<1>, dim3((a.N + wpb - 1) / wpb), dim3(wpb * 64), 0, c->stream, b, epi, pro == PRO_F16 ? 1 : 0);
+        else hipLaunchKernelGGL(gemv_valu_kernel<0>, dim3((a.N + wpb - 1) / wpb), dim3(wpb * 64), 0, c->stream, b, epi, pro == PRO_F16 ? 1 : 0);
+        HIPCHK(hipGetLastError());
+        return prof_end(c);
+    }
+    CHK(prof_begin(c, kclass, bytes, flops));
+    int rc = -1;
+#define GEMM_CASE(WTv, PROv, EPIv) \
+    if ((w.type == TTS_HIP_F16 ? 1 : 0) == WTv && pro == PROv && epi == EPIv) rc = launch_gemm16_rb<WTv, PROv, EPIv>(c, a); else
+    GEMM_CASE(1, PRO_LN, EPI_QKV) GEMM_CASE(0, PRO_LN, EPI_QKV)
+    GEMM_CASE(1, PRO_LN, EPI_STORE) GEMM_CASE(0, PRO_LN, EPI_STORE)
+    GEMM_CASE(1, PRO_LN, EPI_GELU) GEMM_CASE(0, PRO_LN, EPI_GELU)
+    GEMM_CASE(1, PRO_F32, EPI_RESID) GEMM_CASE(0, PRO_F32, EPI_RESID)
+    GEMM_CASE(1, PRO_F32, EPI_STORE) GEMM_CASE(0, PRO_F32, EPI_STORE)
+    GEMM_CASE(1, PRO_F16, EPI_RESID)
+    { rc = set_err("run_gemm: no kernel for type=%d pro=%d epi=%d", w.type, pro, epi); }
+#undef GEMM_CASE
+    CHK(rc);
+    return prof_end(c);
+}
+
+static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, double kv_bytes) {
+    a.max_T = (nsplit > 1) ? (c->NCTX + nsplit - 1) / nsplit + 1 : std::max(c->NCTX, c->ECAP);
+    const size_t lds = ((size_t) a.max_T + 1024 + 16) * 4;
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void *) attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    CHK(prof_begin(c, kclass, kv_bytes + 2.0 * R * c->H * 4, 0));
+    hipLaunchKernelGGL(attn_kernel, dim3(c->NH, R, nsplit), dim3(256), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    if (nsplit > 1) {
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(c->NH, R), dim3(64), 0, c->stream, (const float *) a.part, nsplit, c->H, c->NH, a.out);
+        HIPCHK(hipGetLastError());
+    }
+    return prof_end(c);
+}
+
+static int attn_nsplit(const tts_hip_ctx *c, int R, bool same_seq) {
+    if (c->attn_nsplit_override > 0) return std::min(c->attn_nsplit_override, 16);
+    if (same_seq) return 1;  // prompt rows: short T
+    int ns = (512 + c->NH * R - 1) / (c->NH * R);
+    return std::max(1, std::min(ns, 16));
+}
+
+// ------------------------------------------------------------------------------------------------
+// the decoder forward over R rows (ids / positions / cache slots already in d_ids / d_pos / d_seq)
+// ------------------------------------------------------------------------------------------------
+static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, bool same_seq) {
+    const int H = c->H;
+    const int64_t seq_stride = (int64_t) c->NCTX * H;
+    const size_t kv_esz = c->d.kv_type == TTS_HIP_F16 ? 2 : 4;
+    const size_t layer_kv_bytes = (size_t) c->d.max_seqs * seq_stride * kv_esz;
+
+    EmbedArgs ea{};
+    const W &tab = audio ? c->embed_tokens : c->embed_prompts;
+    ea.tab = c->arena + tab.off;
+    ea.tab_f16 = tab.type == TTS_HIP_F16;
+    ea.tab_stride = audio ? (int64_t) c->EROWS * H : 0;
+    ea.n_tabs = audio ? c->NO : 1;
+    ea.ids = c->d_ids;
+    ea.pos_embed = (const float *) (c->arena + c->pos_embed);
+    ea.row_pos = c->d_pos;
+    ea.x = c->x;
+    ea.H = H;
+    CHK(prof_begin(c, TTS_HIP_K_EMBED, (double) R * (ea.n_tabs + 2) * H * 4, 0));
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(R), dim3(256), 0, c->stream, ea);
+    HIPCHK(hipGetLastError());
+    CHK(prof_end(c));
+
+    double self_kv_bytes = 0;
+    for (int r = 0; r < R && r < (int) c->host_pos.size(); r++) self_kv_bytes += 2.0 * (c->host_pos[r] + 1) * H * kv_esz;
+    const int nsplit = attn_nsplit(c, R, same_seq);
+
+    for (int l = 0; l < c->L; l++) {
+        const PLayer &y = c->layers[l];
+        GemmArgs g{};
+        g.R = R; g.H = H; g.gelu_mode = (int) c->d.gelu_mode;
+        // self attention -------------------------------------------------------------------
+        g.A = c->x; g.lda = H;
+        g.ln_w = (const float *) (c->arena + y.sa_w); g.ln_b = (const float *) (c->arena + y.sa_b);
+        g.q = c->q;
+        g.kc = (char *) c->kcache + (size_t) l * layer_kv_bytes;
+        g.vc = (char *) c->vcache + (size_t) l * layer_kv_bytes;
+        g.kv_f16 = c->d.kv_type == TTS_HIP_F16;
+        g.seq_stride = seq_stride; g.row_seq = c->d_seq; g.row_pos = c->d_pos;
+        CHK(run_gemm(c, TTS_HIP_K_GEMM_LN, y.qkv, g, PRO_LN, EPI_QKV));
+
+        AttnArgs at{};
+        at.q = c->q; at.kc = g.kc; at.vc = g.vc; at.kv_f16 = g.kv_f16; at.seq_stride = seq_stride;
+        at.row_seq = c->d_seq; at.row_pos = c->d_pos; at.H = H; at.n_heads = c->NH;
+        at.scale = 1.0f / sqrtf(64.0f); at.out = c->att; at.part = c->part;
+        CHK(run_attn(c, TTS_HIP_K_ATTN, at, R, nsplit, self_kv_bytes));
+
+        GemmArgs go{};
+        go.R = R; go.H = H; go.A = c->att; go.lda = H; go.out = c->x; go.ldo = H;
+        CHK(run_gemm(c, TTS_HIP_K_GEMM, y.o, go, PRO_F32, EPI_RESID));
+
+        // cross attention ------------------------------------------------------------------
+        if (c->d.use_cross_attn) {
+            GemmArgs gq{};
+            gq.R = R; gq.H = H; gq.A = c->x; gq.lda = H;
+            gq.ln_w = (const float *) (c->arena + y.ca_w); gq.ln_b = (const float *) (c->arena + y.ca_b);
+            gq.out = c->q; gq.ldo = H;
+            CHK(run_gemm(c, TTS_HIP_K_GEMM_LN, y.cq, gq, PRO_LN, EPI_STORE));
+            AttnArgs ac{};
+            ac.q = c->q;
+            ac.kc = c->arena + c->cross_kv + ((size_t) l * 2 + 0) * c->ECAP * H * 4;
+            ac.vc = c->arena + c->cross_kv + ((size_t) l * 2 + 1) * c->ECAP * H * 4;
+            ac.kv_f16 = 0; ac.seq_stride = 0; ac.row_seq = nullptr; ac.row_pos = nullptr; ac.T_fixed = c->E;
+            ac.H = H; ac.n_heads = c->NH; ac.scale = at.scale; ac.out = c->att; ac.part = c->part;
+            CHK(run_attn(c, TTS_HIP_K_ATTN_CROSS, ac, R, 1, 2.0 * c->E * H * 4));
+            GemmArgs gc = go;
+            CHK(run_gemm(c, TTS_HIP_K_GEMM, y.co, gc, PRO_F32, EPI_RESID));
+        }
+
+        // FFN ------------------------------------------------------------------------------
+        GemmArgs g1{};
+        g1.R = R; g1.H = H; g1.gelu_mode = (int) c->d.gelu_mode; g1.A = c->x; g1.lda = H;
+        g1.ln_w = (const float *) (c->arena + y.f_w); g1.ln_b = (const float *) (c->arena + y.f_b);
+        const bool u_half = (y.fc2.type == TTS_HIP_F16) && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM) && (c->F % 256 == 0);
+        g1.out = c->u32; g1.out16 = u_half ? c->u16 : nullptr; g1.ldo = c->F;
+        CHK(run_gemm(c, TTS_HIP_K_GEMM_LN, y.fc1, g1, PRO_LN, EPI_GELU));
+        GemmArgs g2{};
+        g2.R = R; g2.H = H; g2.A = u_half ? (const void *) c->u16 : (const void *) c->u32; g2.lda = c->F;
+        g2.out = c->x; g2.ldo = H;
+        CHK(run_gemm(c, TTS_HIP_K_GEMM, y.fc2, g2, u_half ? PRO_F16 : PRO_F32, EPI_RESID));
+    }
+
+    if (want_logits) {
+        GemmArgs gh{};
+        gh.R = R; gh.H = H; gh.A = c->x; gh.lda = H;
+        gh.ln_w = (const float *) (c->arena + c->ln_w); gh.ln_b = (const float *) (c->arena + c->ln_b);
+        gh.out = c->logits; gh.ldo = c->NO * c->V;
+        CHK(run_gemm(c, TTS_HIP_K_HEADS, c->heads, gh, PRO_LN, EPI_STORE));
+    }
+    return 0;
+}
+
+// prep_cross_key_values (model.cpp:110-173): K_c / V_c = W_k / W_v · text_encoding, per layer
+static int compute_cross_kv(tts_hip_ctx *c) {
+    if (!c->has_parler || !c->d.use_cross_attn) return 0;
+    const int H = c->H, step = 32;
+    for (int l = 0; l < c->L; l++) {
+        for (int kv = 0; kv < 2; kv++) {
+            for (int e0 = 0; e0 < c->E; e0 += step) {
+                GemmArgs g{};
+                g.R = std::min(step, c->E - e0); g.H = H;
+                g.A = (const float *) (c->arena + c->text_enc) + (size_t) e0 * H; g.lda = H;
+                g.out = (float *) (c->arena + c->cross_kv + ((size_t) l * 2 + kv) * c->ECAP * H * 4) + (size_t) e0 * H;
+                g.ldo = H;
+                CHK(run_gemm(c, TTS_HIP_K_GEMM, kv == 0 ? c->layers[l].ck : c->layers[l].cv, g, PRO_F32, EPI_STORE));
+            }
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static int dmalloc(T **p, size_t n) {
+    HIPCHK(hipMalloc((void **) p, n * sizeof(T)));
+    HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
+    return 0;
+}
+
+extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
+    if (!c) return set_err("null ctx");
+    if (c->finalized) return set_err("tts_hip_finalize: already finalized");
+    HIPCHK(hipSetDevice(c->device));
+    CHK(plan(c));
+    if (external_arena) { c->arena = (char *) external_arena; c->arena_external = true; }
+    else HIPCHK(hipMalloc((void **) &c->arena, c->arena_bytes));
+    bool all = true, any = false;
+    for (auto &ci : c->copies) {
+        Tensor &t = c->tensors[ci.src];
+        if (t.has_data) { any = true; HIPCHK(hipMemcpy(c->arena + ci.dst, t.tmp, t.nbytes, hipMemcpyDeviceToDevice)); }
+        else all = false;
+    }
+    if (any && !all) return set_err("tts_hip_finalize: some tensors were uploaded with data and some without");
+    for (auto &t : c->tensors) { free_dev(t.second.tmp); t.second.tmp = nullptr; }
+    c->weights_present = all;
+
+    if (c->has_parler) {
+        const int H = c->H;
+        c->RMAX = std::max(max_rows_for(c), 1);
+        if ((int) c->d.max_seqs > c->RMAX) return set_err("max_seqs=%u exceeds the %d rows one forward can carry with these weight types", c->d.max_seqs, c->RMAX);
+        if ((int) c->d.max_seqs > 64) return set_err("max_seqs > 64 unsupported");
+        const size_t kv_esz = c->d.kv_type == TTS_HIP_F16 ? 2 : 4;
+        const size_t kvb = (size_t) c->L * c->d.max_seqs * c->NCTX * H * kv_esz;
+        HIPCHK(hipMalloc(&c->kcache, kvb));
+        HIPCHK(hipMalloc(&c->vcache, kvb));
+        HIPCHK(hipMemset(c->kcache, 0, kvb));  // ggml_backend_buffer_clear(buf, 0), model.cpp:381
+        HIPCHK(hipMemset(c->vcache, 0, kvb));
+        const int R = c->RMAX;
+        CHK(dmalloc(&c->x, (size_t) R * H));
+        CHK(dmalloc(&c->q, (size_t) R * H));
+        CHK(dmalloc(&c->att, (size_t) R * H));
+        CHK(dmalloc(&c->dbg, (size_t) R * std::max(H, c->F)));
+        CHK(dmalloc(&c->u32, (size_t) R * c->F));
+        CHK(dmalloc(&c->u16, (size_t) R * c->F));
+        CHK(dmalloc(&c->logits, (size_t) R * c->NO * c->V));
+        CHK(dmalloc(&c->part, (size_t) R * c->NH * 16 * 66));
+        CHK(dmalloc(&c->d_ids, (size_t) R * c->NO));
+        CHK(dmalloc(&c->d_pos, (size_t) R));
+        CHK(dmalloc(&c->d_seq, (size_t) R));
+        CHK(dmalloc(&c->d_tok, (size_t) R * c->NO));
+        CHK(dmalloc(&c->d_step, (size_t) 1));
+        CHK(dmalloc(&c->d_steps_done, (size_t) R));
+        CHK(dmalloc(&c->d_eos, (size_t) R * c->NO));
+        HIPCHK(hipHostMalloc((void **) &c->h_ids, (size_t) R * c->NO * 4));
+        HIPCHK(hipHostMalloc((void **) &c->h_pos, (size_t) R * 4));
+        HIPCHK(hipHostMalloc((void **) &c->h_seq, (size_t) R * 4));
+        HIPCHK(hipHostMalloc((void **) &c->h_tok, (size_t) R * c->NO * 4));
+        HIPCHK(hipHostMalloc((void **) &c->h_logits, (size_t) R * c->NO * c->V * 4));
+    }
+    if (c->has_dac) {
+        // largest activation: C * L over all stages, for dac_max_frames frames
+        const size_t T = std::max<uint32_t>(c->d.dac_max_frames, 1);
+        size_t mx = (size_t) std::max(c->d_latent, c->d_c0) * T;
+        size_t Lc = T;
+        for (auto &b : c->dblocks) { Lc *= b.stride; mx = std::max(mx, (size_t) b.cout * Lc); mx = std::max(mx, (size_t) b.cin * (Lc / b.stride)); }
+        c->dbuf_elems = mx;
+        for (int i = 0; i < 3; i++) HIPCHK(hipMalloc((void **) &c->dbuf[i], mx * 4));
+        HIPCHK(hipMalloc((void **) &c->d_codes, T * c->d_ncb * 4));
+        HIPCHK(hipHostMalloc((void **) &c->h_pcm, T * c->d_up * 4));
+    }
+    c->finalized = true;
+    if (c->weights_present) CHK(compute_cross_kv(c));
+    return 0;
+}
+
+extern "C" int tts_hip_arena_filled(tts_hip_ctx *c) {
+    if (!c || !c->finalized) return set_err("tts_hip_arena_filled: context not finalized");
+    c->weights_present = true;
+    return 0;
+}
+
+extern "C" int tts_hip_parler_set_text_encoding(tts_hip_ctx *c, const float *enc, uint32_t n_tokens) {
+    if (!c || !c->finalized || !c->has_parler) return set_err("set_text_encoding: context not ready");
+    if (!c->d.use_cross_attn) return set_err("set_text_encoding: cross attention disabled");
+    if ((int) n_tokens > c->ECAP || n_tokens == 0) return set_err("set_text_encoding: %u tokens outside 1..%d", n_tokens, c->ECAP);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(c->arena + c->text_enc, enc, (size_t) n_tokens * c->H * 4, hipMemcpyHostToDevice));
+    c->E = (int) n_tokens;  // n_encode_length = conditional_prompt->n_outputs (model.cpp:135)
+    for (auto &g : c->graphs) (void) hipGraphExecDestroy(g.second);  // E is baked into captured launches
+    c->graphs.clear();
+    return compute_cross_kv(c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Parler entry points
+// ------------------------------------------------------------------------------------------------
+static int ready(tts_hip_ctx *c, const char *who) {
+    if (!c) return set_err("%s: null ctx", who);
+    if (!c->finalized) return set_err("%s: context not finalized", who);
+    if (!c->weights_present) return set_err("%s: weights not present (declare-only context: fill the arena, then tts_hip_arena_filled)", who);
+    if (!c->has_parler) return set_err("%s: context has no Parler decoder", who);
+    HIPCHK(hipSetDevice(c->device));
+    return 0;
+}
+
+extern "C" int tts_hip_parler_reset(tts_hip_ctx *c) {
+    CHK(ready(c, "tts_hip_parler_reset"));
+    return 0;  // positions are caller-supplied; the cache is overwritten position by position like the reference's
+}
+
+extern "C" int tts_hip_parler_prefill(tts_hip_ctx *c, uint32_t seq, const uint32_t *ids, uint32_t n, uint32_t pos0) {
+    CHK(ready(c, "tts_hip_parler_prefill"));
+    if (seq >= c->d.max_seqs) return set_err("prefill: seq %u >= max_seqs %u", seq, c->d.max_seqs);
+    if (pos0 + n > (uint32_t) c->NCTX || pos0 + n > (uint32_t) c->NPOS) return set_err("prefill: positions %u..%u exceed context %d", pos0, pos0 + n, c->NCTX);
+    for (uint32_t i = 0; i < n; i++) if (ids[i] >= (uint32_t) c->PV) return set_err("prefill: text id %u >= prompt vocab %d", ids[i], c->PV);
+    for (uint32_t o = 0; o < n; o += c->RMAX) {
+        const int R = (int) std::min<uint32_t>(c->RMAX, n - o);
+        c->host_pos.resize(R);
+        for (int r = 0; r < R; r++) {
+            c->h_ids[r] = ids[o + r];
+            c->h_pos[r] = pos0 + o + r;
+            c->h_seq[r] = seq;
+            c->host_pos[r] = pos0 + o + r;
+        }
+        HIPCHK(hipMemcpyAsync(c->d_ids, c->h_ids, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_pos, c->h_pos, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_seq, c->h_seq, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+        CHK(enqueue_forward(c, R, /*audio=*/false, /*logits=*/false, /*same_seq=*/true));
+        HIPCHK(hipStreamSynchronize(c->stream));  // staging buffers are reused by the next chunk
+    }
+    return 0;
+}
+
+enum { MODE_LOGITS = 0, MODE_GREEDY = 1, MODE_GEN = 2 };
+
+static int stage_step_inputs(tts_hip_ctx *c, uint32_t n, const uint32_t *ids, const uint32_t *pos, const uint32_t *seqs) {
+    if (n == 0 || (int) n > c->RMAX || n > c->d.max_seqs) return set_err("step: n_seqs=%u outside 1..%u", n, std::min<uint32_t>(c->RMAX, c->d.max_seqs));
+    c->host_pos.resize(n);
+    for (uint32_t r = 0; r < n; r++) {
+        const uint32_t s = seqs ? seqs[r] : r;
+        if (s >= c->d.max_seqs) return set_err("step: seq %u >= max_seqs %u", s, c->d.max_seqs);
+        if (pos[r] >= (uint32_t) c->NCTX || pos[r] >= (uint32_t) c->NPOS) return set_err("step: position %u exceeds context %d", pos[r], c->NCTX);
+        for (int i = 0; i < c->NO; i++) {
+            const uint32_t id = ids[r * c->NO + i];
+            if (id >= (uint32_t) c->EROWS) return set_err("step: audio id %u >= embedding rows %d", id, c->EROWS);
+            c->h_ids[r * c->NO + i] = id;
+        }
+        c->h_pos[r] = pos[r];
+        c->h_seq[r] = s;
+        c->host_pos[r] = pos[r];
+    }
+    return 0;
+}
+
+// enqueue (or replay) one audio step for R rows in the given mode
+static int enqueue_step_body(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint32_t eos) {
+    if (mode != MODE_GEN) {
+        HIPCHK(hipMemcpyAsync(c->d_ids, c->h_ids, (size_t) R * c->NO * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_pos, c->h_pos, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_seq, c->h_seq, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    CHK(enqueue_forward(c, R, true, true, false));
+    if (mode == MODE_LOGITS) {
+        HIPCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t) R * c->NO * c->V * 4, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        CHK(prof_begin(c, TTS_HIP_K_SAMPLE, (double) R * c->NO * c->V * 4, 0));
+        hipLaunchKernelGGL(argmax_kernel, dim3(R * c->NO), dim3(256), 0, c->stream, (const float *) c->logits, c->V, c->d_tok);
+        HIPCHK(hipGetLastError());
+        if (mode == MODE_GEN) {
+            FeedArgs f{};
+            f.tokens = c->d_tok; f.ids = c->d_ids; f.row_pos = c->d_pos; f.step = c->d_step; f.eos_seen = c->d_eos;
+            f.steps_done = c->d_steps_done; f.tokens_out = c->d_tokens_out; f.R = R; f.n_out = c->NO; f.bos = bos; f.eos = eos;
+            hipLaunchKernelGGL(feed_kernel, dim3(1), dim3(1024), 0, c->stream, f);
+            HIPCHK(hipGetLastError());
+        }
+        CHK(prof_end(c));
+        if (mode == MODE_GREEDY) HIPCHK(hipMemcpyAsync(c->h_tok, c->d_tok, (size_t) R * c->NO * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    return 0;
+}
+
+static int run_step(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint32_t eos) {
+    const bool use_graph = !(c->d.flags & TTS_HIP_FLAG_NO_GRAPH) && !c->prof;
+    if (!use_graph) return enqueue_step_body(c, R, mode, bos, eos);
+    const int key = mode * 1000 + R;
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_step_body(c, R, mode, bos, eos);
+        const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        if (rc != 0) { if (graph) (void) hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return set_err("hipStreamEndCapture: %s", hipGetErrorString(e));
+        hipGraphExec_t exec = nullptr;
+        HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void) hipGraphDestroy(graph);
+        it = c->graphs.emplace(key, exec).first;
+    }
+    HIPCHK(hipGraphLaunch(it->second, c->stream));
+    return 0;
+}
+
+extern "C" int tts_hip_parler_step(tts_hip_ctx *c, uint32_t n, const uint32_t *ids, const uint32_t *pos,
+                                   const uint32_t *seqs, float *logits_out) {
+    CHK(ready(c, "tts_hip_parler_step"));
+    if (!ids || !pos || !logits_out) return set_err("step: null argument");
+    CHK(stage_step_inputs(c, n, ids, pos, seqs));
+    CHK(run_step(c, (int) n, MODE_LOGITS, 0, 0));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(logits_out, c->h_logits, (size_t) n * c->NO * c->V * 4);
+    return 0;
+}
+
+extern "C" int tts_hip_parler_step_greedy(tts_hip_ctx *c, uint32_t n, const uint32_t *ids, const uint32_t *pos,
+                                          const uint32_t *seqs, uint32_t *tokens_out) {
+    CHK(ready(c, "tts_hip_parler_step_greedy"));
+    if (!ids || !pos || !tokens_out) return set_err("step_greedy: null argument");
+    CHK(stage_step_inputs(c, n, ids, pos, seqs));
+    CHK(run_step(c, (int) n, MODE_GREEDY, 0, 0));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(tokens_out, c->h_tok, (size_t) n * c->NO * 4);
+    return 0;
+}
+
+extern "C" int tts_hip_parler_generate_greedy(tts_hip_ctx *c, uint32_t n, const uint32_t *start_pos, uint32_t n_steps,
+                                              uint32_t bos, uint32_t eos, uint32_t *tokens_out, uint32_t *steps_done) {
+    CHK(ready(c, "tts_hip_parler_generate_greedy"));
+    if (!start_pos || !tokens_out) return set_err("generate_greedy: null argument");
+    if (n == 0 || (int) n > c->RMAX || n > c->d.max_seqs) return set_err("generate_greedy: n_seqs=%u out of range", n);
+    if (bos >= (uint32_t) c->EROWS || eos >= (uint32_t) c->EROWS) return set_err("generate_greedy: bos/eos outside the embedding table");
+    c->host_pos.resize(n);
+    for (uint32_t r = 0; r < n; r++) {
+        if (start_pos[r] + n_steps > (uint32_t) c->NCTX || start_pos[r] + n_steps > (uint32_t) c->NPOS)
+            return set_err("generate_greedy: sequence %u would exceed the context (%u + %u > %d)", r, start_pos[r], n_steps, c->NCTX);
+        for (int i = 0; i < c->NO; i++) c->h_ids[r * c->NO + i] = bos;  // model.cpp:781 with current_step == 0
+        c->h_pos[r] = start_pos[r];
+        c->h_seq[r] = r;
+        c->host_pos[r] = start_pos[r];
+    }
+    const size_t need = (size_t) n_steps * n * c->NO;
+    if (need > c->tokens_out_cap) {
+        free_dev(c->d_tokens_out);
+        c->d_tokens_out = nullptr;
+        HIPCHK(hipMalloc((void **) &c->d_tokens_out, need * 4));
+        c->tokens_out_cap = need;
+        // the captured graph baked the old pointer in
+        auto it = c->graphs.find(MODE_GEN * 1000 + (int) n);
+        for (auto g = c->graphs.begin(); g != c->graphs.end();) {
+            if (g->first / 1000 == MODE_GEN) { (void) hipGraphExecDestroy(g->second); g = c->graphs.erase(g); } else ++g;
+        }
+        (void) it;
+    }
+    const uint32_t one = 1;
+    HIPCHK(hipMemcpyAsync(c->d_ids, c->h_ids, (size_t) n * c->NO * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_pos, c->h_pos, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_seq, c->h_seq, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_step, &one, 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_eos, 0, (size_t) n * c->NO, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_steps_done, 0, (size_t) n * 4, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // bos/eos are baked into the captured feed kernel: key the graph on them too
+    static uint32_t g_bos = 0xFFFFFFFFu, g_eos = 0xFFFFFFFFu;
+    if (g_bos != bos || g_eos != eos) {
+        for (auto g = c->graphs.begin(); g != c->graphs.end();) {
+            if (g->first / 1000 == MODE_GEN) { (void) hipGraphExecDestroy(g->second); g = c->graphs.erase(g); } else ++g;
+        }
+        g_bos = bos; g_eos = eos;
+    }
+    for (uint32_t s = 0; s < n_steps; s++) {
+        for (uint32_t r = 0; r < n; r++) c->host_pos[r] = start_pos[r] + s;
+        CHK(run_step(c, (int) n, MODE_GEN, bos, eos));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(tokens_out, c->d_tokens_out, need * 4, hipMemcpyDeviceToHost));
+    if (steps_done) HIPCHK(hipMemcpy(steps_done, c->d_steps_done, (size_t) n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DAC
+// ------------------------------------------------------------------------------------------------
+static int dac_snapshot(tts_hip_ctx *c, int stage, const float *dev, size_t n) {
+    if (!c->debug) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<float> &v = c->dac_dbg[stage];
+    v.resize(n);
+    HIPCHK(hipMemcpy(v.data(), dev, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int launch_conv(tts_hip_ctx *c, const float *x, int cin, int L, size_t w, size_t b, size_t alpha, bool has_alpha,
+                       int cout, int K, int pad, int dil, const float *resid, bool do_tanh, float *y) {
+    ConvArgs a{};
+    a.x = x; a.w = (const float *) (c->arena + w); a.b = (const float *) (c->arena + b);
+    a.alpha = has_alpha ? (const float *) (c->arena + alpha) : nullptr;
+    a.resid = resid; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.dil = dil; a.pad = pad; a.do_tanh = do_tanh;
+    const dim3 grid((L + CV_T - 1) / CV_T, (cout + CV_CO - 1) / CV_CO);
+    const size_t lds = ((size_t) CV_CI * (CV_T + (K - 1) * dil) + (size_t) CV_CI * K * CV_CO) * 4;
+    const double bytes = ((double) cin * L + (double) cout * L * (resid ? 2 : 1) + (double) cout * cin * K) * 4;
+    CHK(prof_begin(c, TTS_HIP_K_DAC_CONV, bytes, 2.0 * cout * (double) cin * K * L));
+    if (K == 7) hipLaunchKernelGGL(conv1d_kernel<7>, grid, dim3(256), lds, c->stream, a);
+    else if (K == 1) hipLaunchKernelGGL(conv1d_kernel<1>, grid, dim3(256), lds, c->stream, a);
+    else return set_err("conv1d: kernel size %d unsupported", K);
+    HIPCHK(hipGetLastError());
+    return prof_end(c);
+}
+
+extern "C" int tts_hip_dac_decode(tts_hip_ctx *c, const uint32_t *codes, uint32_t frames, float *pcm_out) {
+    if (!c || !c->finalized || !c->has_dac) return set_err("tts_hip_dac_decode: context has no finalized DAC");
+    if (!c->weights_present) return set_err("tts_hip_dac_decode: weights not present");
+    if (!codes || !pcm_out) return set_err("tts_hip_dac_decode: null argument");
+    if (frames == 0) return 0;  // empty response (cli.cpp:87-90 treats n_outputs==0 as the soft failure)
+    if (frames > c->d.dac_max_frames) return set_err("tts_hip_dac_decode: %u frames > max %u", frames, c->d.dac_max_frames);
+    HIPCHK(hipSetDevice(c->device));
+    for (size_t i = 0; i < (size_t) frames * c->d_ncb; i++)
+        if (codes[i] >= (uint32_t) c->d_cbsize) return set_err("tts_hip_dac_decode: code %u >= codebook size %d", codes[i], c->d_cbsize);
+    c->dac_dbg.clear();
+    HIPCHK(hipMemcpyAsync(c->d_codes, codes, (size_t) frames * c->d_ncb * 4, hipMemcpyHostToDevice, c->stream));
+    int L = (int) frames;
+    float *cur = c->dbuf[0], *t1 = c->dbuf[1], *t2 = c->dbuf[2];
+
+    DacEmbedArgs ea{};
+    ea.codes = c->d_codes; ea.codebook = (const float *) (c->arena + c->d_codebook); ea.proj_w = (const float *) (c->arena + c->d_projw);
+    ea.proj_b = (const float *) (c->arena + c->d_projb); ea.n_cb = c->d_ncb; ea.cb_size = c->d_cbsize; ea.cb_dim = c->d_cbdim;
+    ea.latent = c->d_latent; ea.T = L; ea.out = cur;
+    CHK(prof_begin(c, TTS_HIP_K_DAC_EMBED, (double) c->d_latent * L * 4, 2.0 * c->d_latent * L * c->d_ncb * c->d_cbdim));
+    hipLaunchKernelGGL(dac_embed_kernel, dim3((L + 63) / 64, c->d_latent), dim3(64), 0, c->stream, ea);
+    HIPCHK(hipGetLastError());
+    CHK(prof_end(c));
+    CHK(dac_snapshot(c, 0, cur, (size_t) c->d_latent * L));
+
+    CHK(launch_conv(c, cur, c->d_latent, L, c->d_initw, c->d_initb, 0, false, c->d_c0, 7, 3, 1, nullptr, false, t1));
+    std::swap(cur, t1);
+    CHK(dac_snapshot(c, 1, cur, (size_t) c->d_c0 * L));
+
+    int C = c->d_c0;
+    for (size_t bi = 0; bi < c->dblocks.size(); bi++) {
+        const DBlock &b = c->dblocks[bi];
+        ConvTArgs ta{};
+        ta.x = cur; ta.w = (const float *) (c->arena + b.w); ta.b = (const float *) (c->arena + b.b);
+        ta.alpha = (const float *) (c->arena + b.alpha); ta.y = t1; ta.cin = b.cin; ta.cout = b.cout; ta.L = L;
+        ta.Lout = (L - 1) * b.stride - 2 * b.padding + 2 * b.stride; ta.stride = b.stride; ta.pad = b.padding;
+        const dim3 grid((ta.Lout + CV_T - 1) / CV_T, (b.cout + CV_CO - 1) / CV_CO);
+        const size_t lds = ((size_t) CT_CI * ((CV_T + b.stride - 1) / b.stride + 2) + (size_t) CT_CI * 2 * b.stride * CV_CO) * 4;
+        CHK(prof_begin(c, TTS_HIP_K_DAC_CONVT, ((double) b.cin * L + (double) b.cout * ta.Lout + (double) b.cin * b.cout * 2 * b.stride) * 4,
+                       2.0 * b.cin * (double) b.cout * 2 * ta.Lout));
+        hipLaunchKernelGGL(convt1d_kernel, grid, dim3(256), lds, c->stream, ta);
+        HIPCHK(hipGetLastError());
+        CHK(prof_end(c));
+        std::swap(cur, t1);
+        L = ta.Lout; C = b.cout;
+        for (int r = 0; r < 3; r++) {  // build_residual_unit: dilation 3^r, padding 3^(r+1) (gnac.h:44-48)
+            int dil = 1;
+            for (int e = 0; e < r; e++) dil *= 3;
+            CHK(launch_conv(c, cur, C, L, b.res[r].in_w, b.res[r].in_b, b.res[r].in_alpha, true, C, 7, 3 * dil, dil, nullptr, false, t1));
+            CHK(launch_conv(c, t1, C, L, b.res[r].out_w, b.res[r].out_b, b.res[r].out_alpha, true, C, 1, 0, 1, cur, false, t2));
+            std::swap(cur, t2);
+        }
+        CHK(dac_snapshot(c, 2 + (int) bi, cur, (size_t) C * L));
+    }
+    CHK(launch_conv(c, cur, C, L, c->d_fw, c->d_fb, c->d_falpha, true, 1, 7, 3, 1, nullptr, true, t1));
+    HIPCHK(hipMemcpyAsync(c->h_pcm, t1, (size_t) L * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(pcm_out, c->h_pcm, (size_t) L * 4);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// introspection
+// ------------------------------------------------------------------------------------------------
+extern "C" int tts_hip_set_debug(tts_hip_ctx *c, int on) {
+    if (!c) return set_err("null ctx");
+    c->debug = on != 0;
+    return 0;
+}
+
+__global__ void half_to_float_kernel(const _Float16 *in, float *out, size_t n) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float) in[i];
+}
+
+extern "C" int64_t tts_hip_debug_read(tts_hip_ctx *c, const char *what, float *out, size_t max_floats) {
+    if (!c || !what || !out || !c->finalized) { set_err("tts_hip_debug_read: bad argument"); return -1; }
+    if (hipSetDevice(c->device) != hipSuccess) { set_err("hipSetDevice failed"); return -1; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { set_err("sync failed"); return -1; }
+    std::string w(what);
+    if (w == "hidden") {
+        const size_t R = c->host_pos.size();
+        if (R == 0 || R * c->H > max_floats) { set_err("debug_read(hidden): no forward yet or buffer too small"); return -1; }
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned) R), dim3(256), 0, c->stream, (const float *) c->x, c->H,
+                           (const float *) (c->arena + c->ln_w), (const float *) (c->arena + c->ln_b), c->dbg);
+        if (hipMemcpyAsync(out, c->dbg, R * c->H * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { set_err("debug_read(hidden): copy failed"); return -1; }
+        return (int64_t) (R * c->H);
+    }
+    if (w == "x") {
+        const size_t R = c->host_pos.size();
+        if (R == 0 || R * c->H > max_floats) { set_err("debug_read(x): no forward yet or buffer too small"); return -1; }
+        if (hipMemcpy(out, c->x, R * c->H * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("copy failed"); return -1; }
+        return (int64_t) (R * c->H);
+    }
+    if (w.size() > 2 && (w[0] == 'k' || w[0] == 'v') && w[1] == ':') {
+        int layer = 0, seq = 0;
+        if (sscanf(w.c_str() + 2, "%d:%d", &layer, &seq) != 2 || layer < 0 || layer >= c->L || seq < 0 || seq >= (int) c->d.max_seqs) {
+            set_err("debug_read(%s): bad layer/seq", what);
+            return -1;
+        }
+        const size_t n = std::min(max_floats / c->H, (size_t) c->NCTX) * c->H;
+        const size_t kv_esz = c->d.kv_type == TTS_HIP_F16 ? 2 : 4;
+        const char *base = (const char *) (w[0] == 'k' ? c->kcache : c->vcache) +
+                           ((size_t) layer * c->d.max_seqs + seq) * (size_t) c->NCTX * c->H * kv_esz;
+        if (kv_esz == 4) {
+            if (hipMemcpy(out, base, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("copy failed"); return -1; }
+        } else {
+            float *tmp = nullptr;
+            if (hipMalloc((void **) &tmp, n * 4) != hipSuccess) { set_err("alloc failed"); return -1; }
+            hipLaunchKernelGGL(half_to_float_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, c->stream, (const _Float16 *) base, tmp, n);
+            (void) hipStreamSynchronize(c->stream);
+            const hipError_t e = hipMemcpy(out, tmp, n * 4, hipMemcpyDeviceToHost);
+            (void) hipFree(tmp);
+            if (e != hipSuccess) { set_err("copy failed"); return -1; }
+        }
+        return (int64_t) n;
+    }
+    if (starts_with(w, "cross:")) {  // cross:<layer>:<0|1>  -> [E][H]
+        int layer = 0, kv = 0;
+        if (sscanf(w.c_str() + 6, "%d:%d", &layer, &kv) != 2 || layer < 0 || layer >= c->L || kv < 0 || kv > 1) { set_err("bad cross spec"); return -1; }
+        const size_t n = (size_t) c->E * c->H;
+        if (n > max_floats) { set_err("buffer too small"); return -1; }
+        if (hipMemcpy(out, c->arena + c->cross_kv + ((size_t) layer * 2 + kv) * c->ECAP * c->H * 4, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("copy failed"); return -1; }
+        return (int64_t) n;
+    }
+    if (starts_with(w, "dac:")) {
+        const int stage = atoi(w.c_str() + 4);
+        auto it = c->dac_dbg.find(stage);
+        if (it == c->dac_dbg.end()) { set_err("debug_read(%s): no snapshot (enable tts_hip_set_debug before decode)", what); return -1; }
+        if (it->second.size() > max_floats) { set_err("buffer too small"); return -1; }
+        memcpy(out, it->second.data(), it->second.size() * 4);
+        return (int64_t) it->second.size();
+    }
+    set_err("tts_hip_debug_read: unknown item '%s'", what);
+    return -1;
+}

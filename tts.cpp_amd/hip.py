@@ -1,0 +1,253 @@
+"""ctypes binding of the C ABI in include/tts_hip.h (libtts_hip.so).
+
+Fails loudly when the library is missing or no MI355X is visible — there is no CPU fallback
+in the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import gguf
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+MAX_DAC_BLOCKS = 8
+
+FLAG_NO_GRAPH, FLAG_VALU_GEMM, FLAG_NO_DAC, FLAG_NO_PARLER = 1, 2, 4, 8
+KCLASSES = ["embed", "gemm_ln", "gemm", "attn", "attn_cross", "heads", "dac_embed", "dac_conv", "dac_convt", "sample"]
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class Desc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("hidden_size", C.c_uint32), ("n_layers", C.c_uint32), ("n_attn_heads", C.c_uint32),
+        ("n_output_heads", C.c_uint32), ("output_vocab_size", C.c_uint32), ("max_ctx_length", C.c_uint32),
+        ("n_encode_length", C.c_uint32), ("use_cross_attn", C.c_uint32),
+        ("dac_n_blocks", C.c_uint32),
+        ("dac_stride", C.c_uint32 * MAX_DAC_BLOCKS), ("dac_padding", C.c_uint32 * MAX_DAC_BLOCKS),
+        ("dac_max_frames", C.c_uint32),
+        ("max_seqs", C.c_uint32), ("kv_type", C.c_uint32), ("gelu_mode", C.c_uint32), ("flags", C.c_uint32),
+    ]
+
+
+class KStat(C.Structure):
+    _fields_ = [("ms_total", C.c_double), ("launches", C.c_uint64), ("bytes_total", C.c_double), ("flops_total", C.c_double)]
+
+
+EXPORTS = [
+    "tts_hip_device_count", "tts_hip_create", "tts_hip_destroy", "tts_hip_last_error", "tts_hip_version",
+    "tts_hip_upload", "tts_hip_arena_bytes", "tts_hip_finalize", "tts_hip_arena_ptr", "tts_hip_arena_filled",
+    "tts_hip_parler_set_text_encoding", "tts_hip_parler_reset", "tts_hip_parler_prefill", "tts_hip_parler_step",
+    "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_dac_decode", "tts_hip_debug_read",
+    "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
+    "tts_hip_synchronize",
+]
+
+_lib = None
+
+
+def lib_path():
+    return os.path.join(PKG_DIR, "libtts_hip.so")
+
+
+def load_lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise HipError(f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950)")
+    L = C.CDLL(p)
+    u32p, f32p, vp = C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.c_void_p
+    L.tts_hip_device_count.restype = C.c_int
+    L.tts_hip_create.restype = vp
+    L.tts_hip_create.argtypes = [C.c_int, C.POINTER(Desc)]
+    L.tts_hip_destroy.argtypes = [vp]
+    L.tts_hip_destroy.restype = None
+    L.tts_hip_last_error.restype = C.c_char_p
+    L.tts_hip_version.restype = C.c_char_p
+    L.tts_hip_upload.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int64), vp]
+    L.tts_hip_arena_bytes.argtypes = [vp]
+    L.tts_hip_arena_bytes.restype = C.c_size_t
+    L.tts_hip_finalize.argtypes = [vp, vp]
+    L.tts_hip_arena_ptr.argtypes = [vp]
+    L.tts_hip_arena_ptr.restype = vp
+    L.tts_hip_arena_filled.argtypes = [vp]
+    L.tts_hip_parler_set_text_encoding.argtypes = [vp, f32p, C.c_uint32]
+    L.tts_hip_parler_reset.argtypes = [vp]
+    L.tts_hip_parler_prefill.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32]
+    L.tts_hip_parler_step.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, f32p]
+    L.tts_hip_parler_step_greedy.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, u32p]
+    L.tts_hip_parler_generate_greedy.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
+    L.tts_hip_dac_decode.argtypes = [vp, u32p, C.c_uint32, f32p]
+    L.tts_hip_debug_read.argtypes = [vp, C.c_char_p, f32p, C.c_size_t]
+    L.tts_hip_debug_read.restype = C.c_int64
+    L.tts_hip_set_debug.argtypes = [vp, C.c_int]
+    L.tts_hip_profile.argtypes = [vp, C.c_int]
+    L.tts_hip_profile_get.argtypes = [vp, C.c_int, C.POINTER(KStat)]
+    L.tts_hip_kclass_name.argtypes = [C.c_int]
+    L.tts_hip_kclass_name.restype = C.c_char_p
+    L.tts_hip_stream.argtypes = [vp]
+    L.tts_hip_stream.restype = vp
+    L.tts_hip_synchronize.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _u32(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class HipEngine:
+    """One device context holding a Parler decoder and/or a DAC codec."""
+
+    def __init__(self, cfg, device=0, max_seqs=1, kv_type=gguf.F32, gelu_mode=1, flags=0, use_cross_attn=True,
+                 n_encode_length=None):
+        self.L = load_lib()
+        self.cfg = cfg
+        d = Desc()
+        d.struct_size = C.sizeof(Desc)
+        d.hidden_size, d.n_layers, d.n_attn_heads = cfg.hidden, cfg.layers, cfg.heads
+        d.n_output_heads, d.output_vocab_size, d.max_ctx_length = cfg.n_out, cfg.out_vocab, cfg.ctx
+        d.n_encode_length = cfg.enc_len if n_encode_length is None else n_encode_length
+        d.use_cross_attn = 1 if use_cross_attn else 0
+        d.dac_n_blocks = len(cfg.strides)
+        for i, (s, p) in enumerate(zip(cfg.strides, cfg.paddings)):
+            d.dac_stride[i], d.dac_padding[i] = s, p
+        d.dac_max_frames = cfg.max_gen
+        d.max_seqs, d.kv_type, d.gelu_mode, d.flags = max_seqs, kv_type, gelu_mode, flags
+        self.desc = d
+        self.max_seqs = max_seqs
+        self.ctx = self.L.tts_hip_create(device, C.byref(d))
+        if not self.ctx:
+            raise HipError(self.err())
+        self.finalized = False
+
+    def err(self):
+        return self.L.tts_hip_last_error().decode("utf-8", "replace")
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HipError(self.err())
+
+    def close(self):
+        if self.ctx:
+            self.L.tts_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ------------------------------------------------------------------------------
+    def upload(self, t: gguf.Tensor, declare_only=False):
+        ne = (C.c_int64 * 4)(*(t.ne + [1] * (4 - len(t.ne))))
+        raw = None if declare_only else np.frombuffer(bytes(t.raw()), dtype=np.uint8)
+        ptr = None if declare_only else raw.ctypes.data_as(C.c_void_p)
+        self._chk(self.L.tts_hip_upload(self.ctx, t.name.encode(), t.type, len(t.ne), ne, ptr))
+
+    def load(self, model, declare_only=False, external_arena=None):
+        for t in model.tensors:
+            self.upload(t, declare_only)
+        self.finalize(external_arena)
+
+    def arena_bytes(self):
+        n = self.L.tts_hip_arena_bytes(self.ctx)
+        if n == 0:
+            raise HipError(self.err())
+        return n
+
+    def finalize(self, external_arena=None):
+        self._chk(self.L.tts_hip_finalize(self.ctx, external_arena))
+        self.finalized = True
+
+    def arena_ptr(self):
+        return self.L.tts_hip_arena_ptr(self.ctx)
+
+    def arena_filled(self):
+        self._chk(self.L.tts_hip_arena_filled(self.ctx))
+
+    def set_text_encoding(self, enc):
+        enc = np.ascontiguousarray(enc, dtype=np.float32)
+        self._chk(self.L.tts_hip_parler_set_text_encoding(self.ctx, enc.ctypes.data_as(C.POINTER(C.c_float)), enc.shape[0]))
+
+    # ---- parler -------------------------------------------------------------------------------
+    def reset(self):
+        self._chk(self.L.tts_hip_parler_reset(self.ctx))
+
+    def prefill(self, seq, ids, pos0=0):
+        a, p = _u32(ids)
+        self._chk(self.L.tts_hip_parler_prefill(self.ctx, seq, p, len(a), pos0))
+
+    def step(self, ids, pos, seqs=None):
+        """ids [n][n_out], pos [n] -> logits [n][n_out][V]"""
+        a, ap = _u32(ids)
+        b, bp = _u32(pos)
+        n = len(b)
+        sp = None
+        if seqs is not None:
+            s, sp = _u32(seqs)
+        out = np.empty((n, self.cfg.n_out, self.cfg.out_vocab), dtype=np.float32)
+        self._chk(self.L.tts_hip_parler_step(self.ctx, n, ap, bp, sp, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def step_greedy(self, ids, pos, seqs=None):
+        a, ap = _u32(ids)
+        b, bp = _u32(pos)
+        n = len(b)
+        sp = None
+        if seqs is not None:
+            s, sp = _u32(seqs)
+        out = np.empty((n, self.cfg.n_out), dtype=np.uint32)
+        self._chk(self.L.tts_hip_parler_step_greedy(self.ctx, n, ap, bp, sp, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def generate_greedy(self, start_pos, n_steps, bos=None, eos=None):
+        b, bp = _u32(start_pos)
+        n = len(b)
+        out = np.empty((n_steps, n, self.cfg.n_out), dtype=np.uint32)
+        done = np.zeros(n, dtype=np.uint32)
+        self._chk(self.L.tts_hip_parler_generate_greedy(
+            self.ctx, n, bp, n_steps, self.cfg.bos if bos is None else bos, self.cfg.eos if eos is None else eos,
+            out.ctypes.data_as(C.POINTER(C.c_uint32)), done.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out, done
+
+    # ---- dac ----------------------------------------------------------------------------------
+    def dac_decode(self, codes):
+        a, ap = _u32(codes)
+        frames = a.size // self.cfg.n_out
+        out = np.empty(frames * self.cfg.hop, dtype=np.float32)
+        self._chk(self.L.tts_hip_dac_decode(self.ctx, ap, frames, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    # ---- introspection ------------------------------------------------------------------------
+    def set_debug(self, on=True):
+        self._chk(self.L.tts_hip_set_debug(self.ctx, 1 if on else 0))
+
+    def debug_read(self, what, max_floats):
+        out = np.empty(max_floats, dtype=np.float32)
+        n = self.L.tts_hip_debug_read(self.ctx, what.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), max_floats)
+        if n < 0:
+            raise HipError(self.err())
+        return out[:n].copy()
+
+    def profile(self, enable):
+        self._chk(self.L.tts_hip_profile(self.ctx, 1 if enable else 0))
+
+    def profile_get(self):
+        res = {}
+        for k, name in enumerate(KCLASSES):
+            st = KStat()
+            self._chk(self.L.tts_hip_profile_get(self.ctx, k, C.byref(st)))
+            res[name] = dict(ms_total=st.ms_total, launches=int(st.launches), bytes_total=st.bytes_total, flops_total=st.flops_total)
+        return res
+
+    def synchronize(self):
+        self._chk(self.L.tts_hip_synchronize(self.ctx))

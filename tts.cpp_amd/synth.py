@@ -1,0 +1,277 @@
+"""Synthetic Parler-TTS + DAC models with the reference's exact GGUF tensor names and KV keys.
+
+There are no real checkpoints in the build/bench environment (no network), so tests and bench run
+on seeded random weights of the right architecture.  Names/keys follow
+py-gguf/tts_encoders/parler_tts_gguf_encoder.py:85-180 and dac_gguf_encoder.py:7-110 and what the
+C++ loaders look up (src/models/parler/model.cpp:4-28,51-108; src/decoder/dac_model.cpp:7-55).
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import gguf
+
+
+@dataclass
+class Config:
+    hidden: int = 1024
+    layers: int = 24
+    heads: int = 16
+    ffn: int = 4096
+    out_vocab: int = 1088
+    audio_vocab: int = 1024
+    n_out: int = 9
+    ctx: int = 4096
+    max_gen: int = 2580
+    enc_len: int = 8
+    prompt_vocab: int = 32128
+    eos: int = 1024
+    bos: int = 1025
+    # DAC 44 kHz
+    latent: int = 1024
+    cb_dim: int = 8
+    cb_size: int = 1024
+    c0: int = 1536
+    strides: tuple = (8, 8, 4, 2)
+    seed: int = 0xC0FFEE
+    weight_type: int = gguf.F16  # type of the quantisable decoder tensors
+    dac_f16: bool = False
+    paddings: tuple = field(default=None)
+
+    def __post_init__(self):
+        if self.paddings is None:
+            self.paddings = tuple(math.ceil(s / 2) for s in self.strides)
+
+    @property
+    def hop(self):
+        return int(np.prod(self.strides))
+
+
+def parler_mini(**kw):
+    return Config(**kw)
+
+
+def tiny(**kw):
+    base = dict(hidden=256, layers=2, heads=4, ffn=512, out_vocab=80, audio_vocab=64, n_out=4, ctx=128,
+                max_gen=96, enc_len=6, prompt_vocab=160, eos=64, bos=65, latent=64, cb_dim=8, cb_size=64,
+                c0=96, strides=(4, 2))
+    base.update(kw)
+    return Config(**base)
+
+
+def small(**kw):
+    """Mid-size twin: real head/vocab/codebook structure (9 heads, V=1088, 4 DAC blocks), thin layers."""
+    base = dict(hidden=512, layers=3, heads=8, ffn=1024, ctx=512, max_gen=256, enc_len=8, prompt_vocab=512,
+                latent=128, c0=192, strides=(8, 8, 4, 2))
+    base.update(kw)
+    return Config(**base)
+
+
+# --------------------------------------------------------------------------------------------------
+# numpy block quantisers (same formats as ggml's quantize_row_q{4_0,5_0,8_0}_ref).
+# Used only to mint quantised test models; tests cross-check them against oracle/orc_quantize.
+# --------------------------------------------------------------------------------------------------
+def _f16_bits(x):
+    return x.astype("<f2").view("<u2")
+
+
+def quantize(arr, ttype):
+    a = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1, 32)
+    nb = a.shape[0]
+    if ttype == gguf.Q8_0:
+        amax = np.abs(a).max(axis=1)
+        d = (amax / np.float32(127.0)).astype(np.float32)
+        idv = np.where(d != 0, np.float32(1.0) / np.where(d != 0, d, 1), 0).astype(np.float32)
+        x = a * idv[:, None]
+        q = np.where(x >= 0, np.floor(x + np.float32(0.5)), np.ceil(x - np.float32(0.5))).astype(np.int8)  # roundf
+        out = np.zeros((nb, 34), dtype=np.uint8)
+        out[:, 0:2] = _f16_bits(d).reshape(-1, 1).view(np.uint8)
+        out[:, 2:] = q.view(np.uint8)
+        return out.reshape(-1)
+    idx = np.abs(a).argmax(axis=1)
+    mx = a[np.arange(nb), idx]
+    if ttype == gguf.Q4_0:
+        d = (mx / np.float32(-8.0)).astype(np.float32)
+        idv = np.where(d != 0, np.float32(1.0) / np.where(d != 0, d, 1), 0).astype(np.float32)
+        x = a * idv[:, None]
+        q = np.minimum(15, (x + np.float32(8.5)).astype(np.int32).astype(np.int8).astype(np.uint8)).astype(np.uint8)
+        out = np.zeros((nb, 18), dtype=np.uint8)
+        out[:, 0:2] = _f16_bits(d).reshape(-1, 1).view(np.uint8)
+        out[:, 2:] = q[:, :16] | (q[:, 16:] << 4)
+        return out.reshape(-1)
+    if ttype == gguf.Q5_0:
+        d = (mx / np.float32(-16.0)).astype(np.float32)
+        idv = np.where(d != 0, np.float32(1.0) / np.where(d != 0, d, 1), 0).astype(np.float32)
+        x = a * idv[:, None]
+        q = np.minimum(31, (x + np.float32(16.5)).astype(np.int32).astype(np.int8).astype(np.uint8)).astype(np.uint32)
+        qh = np.zeros(nb, dtype=np.uint32)
+        for j in range(16):
+            qh |= ((q[:, j] & 0x10) >> 4) << j
+            qh |= ((q[:, j + 16] & 0x10) >> 4) << (j + 16)
+        out = np.zeros((nb, 22), dtype=np.uint8)
+        out[:, 0:2] = _f16_bits(d).reshape(-1, 1).view(np.uint8)
+        out[:, 2:6] = qh.astype("<u4").reshape(-1, 1).view(np.uint8)
+        out[:, 6:] = ((q[:, :16] & 0x0F) | ((q[:, 16:] & 0x0F) << 4)).astype(np.uint8)
+        return out.reshape(-1)
+    raise ValueError(ttype)
+
+
+def _quantizable(name):
+    """parler_is_quanitizable with --quantize-output-heads/-text-embedding/-cross-attn-kv all on
+    (examples/quantize/quantize_impl.cpp:51-67)."""
+    return not (name.startswith("audio_encoder") or name.endswith("norm.weight") or name.endswith("text_encoding")
+                or name.endswith("positional_embed") or name.endswith("norm.bias"))
+
+
+def _sinusoid(n_pos, dim):
+    half = dim // 2
+    freq = np.exp(np.arange(half, dtype=np.float64) * -(math.log(10000.0) / half))
+    ang = np.arange(n_pos, dtype=np.float64)[:, None] * freq[None, :]
+    return np.concatenate([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32)
+
+
+def _vocab(n, rng):
+    """Synthetic unigram vocabulary: specials, printable single characters, then random 2-4 grams."""
+    toks = ["<pad>", "</s>", "<unk>"]
+    singles = [" "] + [chr(c) for c in range(ord("a"), ord("z") + 1)] + list(".,'!?-") + [chr(c) for c in range(ord("A"), ord("Z") + 1)]
+    toks += singles
+    seen = set(toks)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    while len(toks) < n:
+        ln = int(rng.integers(2, 5))
+        s = "".join(letters[int(i)] for i in rng.integers(0, 26, ln))
+        if rng.random() < 0.4:
+            s = " " + s
+        if s not in seen:
+            seen.add(s)
+            toks.append(s)
+    toks = toks[:n]
+    scores = np.zeros(n, dtype=np.float32)
+    for i, t in enumerate(toks):
+        scores[i] = 0.0 if i < 3 else -(2.0 + 1.5 * len(t)) + float(rng.random())
+    scores[2] = -20.0  # <unk>
+    return toks, scores
+
+
+class SynthModel:
+    """tensors: list[gguf.Tensor] in file order; kv: list of (key, type, value); cfg: Config."""
+
+    def __init__(self, cfg: Config):
+        self.cfg = cfg
+        rng = np.random.Generator(np.random.Philox(cfg.seed))
+        self.rng = rng
+        self.tensors = []
+        self.f32 = {}  # name -> fp32 array in PyTorch order, AFTER rounding to the stored type where exact
+        H, F = cfg.hidden, cfg.ffn
+
+        def normal(shape, std=0.02, mean=0.0):
+            return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std) + np.float32(mean)).astype(np.float32)
+
+        def add(name, arr):
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            ttype = gguf.F32
+            if _quantizable(name):
+                ttype = cfg.weight_type
+            elif name.startswith("audio_encoder") and cfg.dac_f16 and not name.endswith("alpha"):
+                ttype = gguf.F16  # --convert-dac-to-f16 keeps alpha F32 (quantize_impl.cpp:264-266)
+            ne = list(reversed(arr.shape))
+            if ttype in (gguf.Q4_0, gguf.Q5_0, gguf.Q8_0):
+                self.tensors.append(gguf.Tensor(name, ttype, ne, quantize(arr, ttype).tobytes()))
+            else:
+                self.tensors.append(gguf.Tensor.from_array(name, arr, ttype))
+
+        # ---- voice prompt encoding + DAC (prepare_text_encoding_tensors / prepare_dac_audio_encoder_tensors)
+        add("decoder.text_encoding", normal((cfg.enc_len, H), std=0.5))
+        chans = [cfg.c0]
+        for _ in cfg.strides:
+            chans.append(chans[-1] // 2)
+
+        def conv_w(cout, cin, k):
+            b = 1.0 / math.sqrt(cin * k)
+            return rng.uniform(-b, b, (cout, cin, k)).astype(np.float32)
+
+        add("audio_encoder.initial.bias", rng.uniform(-0.05, 0.05, (cfg.c0,)).astype(np.float32))
+        add("audio_encoder.initial.weight", conv_w(cfg.c0, cfg.latent, 7))
+        for bi, s in enumerate(cfg.strides):
+            cin, cout = chans[bi], chans[bi + 1]
+            p = f"audio_encoder.decoder_block.{bi + 1}."
+            add(p + "final.alpha", rng.uniform(0.5, 2.0, (1, cin, 1)).astype(np.float32))
+            add(p + "final.bias", rng.uniform(-0.05, 0.05, (cout,)).astype(np.float32))
+            bnd = 1.0 / math.sqrt(cin * 2)
+            add(p + "final.weight", rng.uniform(-bnd, bnd, (cin, cout, 2 * s)).astype(np.float32))
+            for r in range(3):
+                q = p + f"residual_unit.{r}.res."
+                add(q + "initial.alpha", rng.uniform(0.5, 2.0, (1, cout, 1)).astype(np.float32))
+                add(q + "initial.bias", rng.uniform(-0.05, 0.05, (cout,)).astype(np.float32))
+                add(q + "initial.weight", conv_w(cout, cout, 7))
+                add(q + "final.alpha", rng.uniform(0.5, 2.0, (1, cout, 1)).astype(np.float32))
+                add(q + "final.bias", rng.uniform(-0.05, 0.05, (cout,)).astype(np.float32))
+                add(q + "final.weight", conv_w(cout, cout, 1) * np.float32(0.5))
+        add("audio_encoder.final.alpha", rng.uniform(0.5, 2.0, (1, chans[-1], 1)).astype(np.float32))
+        add("audio_encoder.final.bias", rng.uniform(-0.05, 0.05, (1,)).astype(np.float32))
+        add("audio_encoder.final.weight", conv_w(1, chans[-1], 7))
+        for i in range(cfg.n_out):
+            p = f"audio_encoder.quantizers.{i}."
+            add(p + "codebook.weight", normal((cfg.cb_size, cfg.cb_dim), std=1.0))
+            add(p + "out_proj.bias", rng.uniform(-0.05, 0.05, (cfg.latent,)).astype(np.float32))
+            add(p + "out_proj.weight", conv_w(cfg.latent, cfg.cb_dim, 1))
+
+        # ---- decoder (prepare_decoder_tensors)
+        add("decoder.embed_prompts", normal((cfg.prompt_vocab, H), std=0.02) * np.float32(1.0))
+        add("decoder.positional_embed", _sinusoid(cfg.ctx, H) * np.float32(0.02))
+        for i in range(cfg.n_out):
+            add(f"decoder.embed_tokens.{i}.weight", normal((cfg.out_vocab + 1, H), std=0.02))
+        for l in range(cfg.layers):
+            p = f"decoder.layers.{l}."
+            for blk in ("self_attn", "encoder_attn"):
+                for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                    add(p + f"{blk}.{proj}.weight", normal((H, H)))
+                add(p + f"{blk}_layer_norm.weight", normal((H,), mean=1.0))
+                add(p + f"{blk}_layer_norm.bias", normal((H,)))
+            add(p + "fc1.weight", normal((F, H)))
+            add(p + "fc2.weight", normal((H, F)))
+            add(p + "final_layer_norm.weight", normal((H,), mean=1.0))
+            add(p + "final_layer_norm.bias", normal((H,)))
+        add("decoder.layer_norm.weight", normal((H,), mean=1.0))
+        add("decoder.layer_norm.bias", normal((H,)))
+        for i in range(cfg.n_out):
+            add(f"decoder.lm_heads.{i}.weight.head", normal((cfg.out_vocab, H), std=0.05))
+
+        toks, scores = _vocab(cfg.prompt_vocab, rng)
+        self.vocab, self.scores = toks, scores
+        U32, STR, ARR, F32T = gguf.T_U32, gguf.T_STR, gguf.T_ARR, gguf.T_F32
+        self.kv = [
+            ("general.architecture", STR, "parler-tts"),
+            ("general.name", STR, "synthetic-parler"),
+            ("parler-tts.decoder.encode_length", U32, cfg.enc_len),
+            ("dac.up_scaling_factor", U32, cfg.hop),  # written but never read
+        ]
+        for i, (s, p) in enumerate(zip(cfg.strides, cfg.paddings)):
+            self.kv.append((f"dac.dac_layer_stride_{i}", U32, int(s)))
+            self.kv.append((f"dac.dac_layer_padding_{i}", U32, int(p)))
+        self.kv += [
+            ("audio.bos_token_id", U32, cfg.bos),
+            ("audio.eos_token_id", U32, cfg.eos),
+            ("parler-tts.decoder.hidden_size", U32, H),
+            ("parler-tts.decoder.output_heads", U32, cfg.n_out),
+            ("parler-tts.decoder.context_length", U32, cfg.ctx),
+            ("parler-tts.decoder.attention.head_count", U32, cfg.heads),
+            ("parler-tts.decoder.max_generation", U32, cfg.max_gen),
+            ("parler-tts.decoder.out_vocab_size", U32, cfg.out_vocab),
+            ("parler-tts.decoder.audio_vocab_size", U32, cfg.audio_vocab),
+            ("parler-tts.decoder.num_hidden_layers", U32, cfg.layers),
+            ("tokenizer.ggml.tokens", ARR, (STR, toks)),
+            ("tokenizer.ggml.scores", ARR, (F32T, scores)),
+            ("tokenizer.ggml.eos_token_id", U32, 1),
+            ("tokenizer.ggml.unknown_token_id", U32, 2),
+        ]
+        self.by_name = {t.name: t for t in self.tensors}
+
+    def write_gguf(self, path):
+        gguf.write(path, self.kv, self.tensors)
+        return path
+
+
+def build(cfg: Config) -> SynthModel:
+    return SynthModel(cfg)
