@@ -1,0 +1,366 @@
+"""GPU parity: the HIP Parler decoder (through the C ABI) against the oracle, same seeded inputs.
+
+Tolerances (relative to max|oracle| of the compared tensor):
+  F32 weights                      : 2e-4   (fp32 MFMA / FMA chains vs the oracle's double accumulation)
+  F16 weights (act rounded to f16) : 2e-3   (both sides round activations to fp16 before each matmul, so
+                                             a 1-ulp fp32 difference can flip an fp16 rounding: 1e-3 class)
+  F16 KV cache (extension)         : 1e-2
+Greedy token ids must be identical wherever the oracle's top-2 logit margin exceeds the tolerance.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from tts_cpp_amd import gguf, hip, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = {gguf.F32: 2e-4, gguf.F16: 2e-3, gguf.Q8_0: 2e-4, gguf.Q4_0: 2e-4, gguf.Q5_0: 2e-4}
+
+
+def relerr(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - b).max() / (np.abs(b).max() + 1e-30))
+
+
+_models = {}
+
+
+def get_model(kind, wtype):
+    key = (kind, wtype)
+    if key not in _models:
+        cfg = {"tiny": synth.tiny, "small": synth.small, "mini": synth.parler_mini}[kind](weight_type=wtype)
+        _models[key] = synth.build(cfg)
+    return _models[key]
+
+
+def check_tokens(lg_gpu, lg_ref, tol):
+    """argmax must agree unless the oracle's own margin is inside the tolerance band"""
+    a, b = lg_gpu.argmax(-1), lg_ref.argmax(-1)
+    srt = np.sort(lg_ref, axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
+    band = tol * np.abs(lg_ref).max() * 2
+    bad = (a != b) & (margin > band)
+    assert not bad.any(), f"greedy ids differ outside the tolerance band: gpu {a[bad]} ref {b[bad]} margin {margin[bad]}"
+
+
+@pytest.mark.parametrize("kind,wtype,flags", [
+    ("tiny", gguf.F32, 0),
+    ("tiny", gguf.F32, hip.FLAG_VALU_GEMM),
+    ("tiny", gguf.F16, 0),
+    ("tiny", gguf.F16, hip.FLAG_VALU_GEMM),
+    ("small", gguf.F16, 0),
+    ("small", gguf.F32, hip.FLAG_NO_GRAPH),
+])
+def test_prefill_and_steps_match_oracle(kind, wtype, flags):
+    model = get_model(kind, wtype)
+    cfg = model.cfg
+    tol = TOL[wtype]
+    eng = hip.HipEngine(cfg, max_seqs=1, flags=flags)
+    eng.load(model)
+    o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+    rng = np.random.default_rng(5)
+    prompt = rng.integers(3, cfg.prompt_vocab, 9).astype(np.uint32)
+
+    # cross K/V computed at finalize (prep_cross_key_values)
+    ck = eng.debug_read("cross:0:0", cfg.enc_len * cfg.hidden).reshape(cfg.enc_len, cfg.hidden)
+    ref_ck = orc.mul_mat(model.by_name["decoder.layers.0.encoder_attn.k_proj.weight"].type,
+                         model.by_name["decoder.layers.0.encoder_attn.k_proj.weight"].raw(), cfg.hidden, cfg.hidden,
+                         model.by_name["decoder.text_encoding"].to_f32(), act_mode=1)
+    assert relerr(ck, ref_ck) < tol
+
+    eng.prefill(0, prompt)
+    _, h_ref = o.decode(prompt, 0, audio=False, want_logits=False, want_hidden=True)
+    h = eng.debug_read("hidden", len(prompt) * cfg.hidden).reshape(len(prompt), cfg.hidden)
+    assert relerr(h, h_ref) < tol, "prompt hidden states"
+
+    ids = np.full(cfg.n_out, cfg.bos, dtype=np.uint32)
+    for step in range(1, 7):
+        pos = len(prompt) + step - 1
+        lg = eng.step(ids[None], [pos])[0]
+        ref, _ = o.decode(ids, pos, audio=True)
+        ref = ref[:, 0, :]
+        assert np.isfinite(lg).all()
+        assert relerr(lg, ref) < tol, f"step {step}"
+        check_tokens(lg, ref, tol)
+        toks = ref.argmax(-1).astype(np.uint32)  # teacher forcing with the oracle's ids
+        ids = np.array([toks[i] if step > i else cfg.bos for i in range(cfg.n_out)], dtype=np.uint32)
+
+    n_pos = len(prompt) + 6
+    for layer in (0, cfg.layers - 1):
+        k_ref, v_ref = o.get_kv(layer, n_pos)
+        k = eng.debug_read(f"k:{layer}:0", n_pos * cfg.hidden).reshape(n_pos, cfg.hidden)
+        v = eng.debug_read(f"v:{layer}:0", n_pos * cfg.hidden).reshape(n_pos, cfg.hidden)
+        assert relerr(k, k_ref) < tol and relerr(v, v_ref) < tol, f"cache layer {layer}"
+    eng.close()
+
+
+def test_lockstep_sequences_are_independent():
+    """3 utterances with different prompt lengths decoded in one batch == 3 single-utterance oracles."""
+    model = get_model("tiny", gguf.F16)
+    cfg = model.cfg
+    eng = hip.HipEngine(cfg, max_seqs=3)
+    eng.load(model)
+    rng = np.random.default_rng(8)
+    prompts = [rng.integers(3, cfg.prompt_vocab, n).astype(np.uint32) for n in (4, 11, 7)]
+    oracles = [orc.ParlerOracle(model, act_mode=1, gelu_mode=1) for _ in prompts]
+    for s, (p, o) in enumerate(zip(prompts, oracles)):
+        eng.prefill(s, p)
+        o.decode(p, 0, audio=False, want_logits=False)
+    ids = np.full((3, cfg.n_out), cfg.bos, dtype=np.uint32)
+    for step in range(1, 5):
+        pos = [len(p) + step - 1 for p in prompts]
+        lg = eng.step(ids, pos)
+        for s, o in enumerate(oracles):
+            ref, _ = o.decode(ids[s], pos[s], audio=True)
+            assert relerr(lg[s], ref[:, 0, :]) < TOL[gguf.F16], (step, s)
+            toks = ref[:, 0, :].argmax(-1)
+            ids[s] = [toks[i] if step > i else cfg.bos for i in range(cfg.n_out)]
+    # a permuted slot mapping gives the same logits for the same sequence
+    lg_a = eng.step(ids[[2, 0]], [len(prompts[2]) + 4, len(prompts[0]) + 4], seqs=[2, 0])
+    lg_b = eng.step(ids[[0]], [len(prompts[0]) + 4], seqs=[0])
+    assert relerr(lg_a[1], lg_b[0]) < 1e-5
+    eng.close()
+
+
+def test_graph_replay_equals_eager_and_greedy_equals_argmax():
+    model = get_model("tiny", gguf.F16)
+    cfg = model.cfg
+    prompt = np.array([7, 8, 9, 10, 1], dtype=np.uint32)
+    outs = []
+    for flags in (0, hip.FLAG_NO_GRAPH):
+        eng = hip.HipEngine(cfg, max_seqs=2, flags=flags)
+        eng.load(model)
+        eng.prefill(0, prompt)
+        eng.prefill(1, prompt[:3])
+        ids = np.full((2, cfg.n_out), cfg.bos, dtype=np.uint32)
+        seq = []
+        for step in range(4):
+            lg = eng.step(ids, [5 + step, 3 + step])
+            tk = eng.step_greedy(ids, [5 + step, 3 + step])  # same positions: rewrites identical K/V
+            assert (tk == lg.argmax(-1)).all()
+            seq.append(lg)
+            ids = lg.argmax(-1).astype(np.uint32)
+        outs.append(np.stack(seq))
+        eng.close()
+    assert np.array_equal(outs[0], outs[1]), "hipGraph replay must be bit-identical to eager launches"
+
+
+@pytest.mark.parametrize("nsplit", [1, 4, 16])
+def test_long_context_split_attention(nsplit):
+    """fill most of the context, with the split-T attention path forced"""
+    os.environ["TTS_HIP_ATTN_NSPLIT"] = str(nsplit)
+    try:
+        model = get_model("tiny", gguf.F32)
+        cfg = model.cfg
+        eng = hip.HipEngine(cfg, max_seqs=1)
+        eng.load(model)
+    finally:
+        del os.environ["TTS_HIP_ATTN_NSPLIT"]
+    o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+    rng = np.random.default_rng(nsplit)
+    prompt = rng.integers(3, cfg.prompt_vocab, 100).astype(np.uint32)  # > 64 rows: chunked prefill
+    eng.prefill(0, prompt)
+    o.decode(prompt, 0, audio=False, want_logits=False)
+    ids = rng.integers(0, cfg.audio_vocab, cfg.n_out).astype(np.uint32)
+    for pos in range(100, 110):
+        lg = eng.step(ids[None], [pos])[0]
+        ref, _ = o.decode(ids, pos, audio=True)
+        assert relerr(lg, ref[:, 0, :]) < TOL[gguf.F32], pos
+        ids = ref[:, 0, :].argmax(-1).astype(np.uint32)
+    eng.close()
+
+
+def test_device_resident_greedy_generation_matches_reference_loop():
+    """tts_hip_parler_generate_greedy (delay pattern + EOS flags on the device, one host sync) against
+    the reference loop restated in the oracle (model.cpp:762-792)."""
+    model = get_model("tiny", gguf.F32)
+    cfg = model.cfg
+    n_steps = 24
+    prompts = [np.array([5, 6, 7, 1], dtype=np.uint32), np.array([9, 3, 44, 12, 13, 1], dtype=np.uint32)]
+    eng = hip.HipEngine(cfg, max_seqs=2)
+    eng.load(model)
+    for s, p in enumerate(prompts):
+        eng.prefill(s, p)
+    toks, done = eng.generate_greedy([len(p) for p in prompts], n_steps)
+    assert toks.shape == (n_steps, 2, cfg.n_out)
+    for s, p in enumerate(prompts):
+        o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+        ref_toks, ref_logits = o.generate_greedy(p, n_steps)
+        mism = np.argwhere(toks[:, s, :] != ref_toks)
+        if len(mism):
+            st, hd = mism[0]
+            srt = np.sort(ref_logits[st, hd])
+            margin = srt[-1] - srt[-2]
+            assert margin < TOL[gguf.F32] * 2 * np.abs(ref_logits[st]).max(), \
+                f"seq {s}: first divergence at step {st} head {hd} with oracle margin {margin}"
+        else:
+            assert np.array_equal(toks[:, s, :], ref_toks)
+    # running the host-driven loop over the same prompts gives the same ids as the device loop
+    eng2 = hip.HipEngine(cfg, max_seqs=2)
+    eng2.load(model)
+    for s, p in enumerate(prompts):
+        eng2.prefill(s, p)
+    ids = np.full((2, cfg.n_out), cfg.bos, dtype=np.uint32)
+    eos_seen = np.zeros((2, cfg.n_out), dtype=bool)
+    for step in range(1, n_steps + 1):
+        tk = eng2.step_greedy(ids, [len(p) + step - 1 for p in prompts])
+        assert np.array_equal(tk, toks[step - 1]), step
+        eos_seen |= tk == cfg.eos
+        for s in range(2):
+            ids[s] = [(cfg.eos if eos_seen[s, i] else tk[s, i]) if step > i else cfg.bos for i in range(cfg.n_out)]
+    eng.close()
+    eng2.close()
+
+
+def replace_tensors(model, repl):
+    import copy
+    m2 = copy.copy(model)
+    m2.tensors = list(model.tensors)
+    m2.by_name = dict(model.by_name)
+    names = [x.name for x in m2.tensors]
+    for name, arr in repl.items():
+        t = gguf.Tensor.from_array(name, arr, gguf.F32)
+        m2.by_name[name] = t
+        m2.tensors[names.index(name)] = t
+    return m2
+
+
+def test_eos_bookkeeping_on_device():
+    """Force EOS: with a zero final-LayerNorm weight the final hidden state is the LN bias, so a head row
+    aligned with it wins every arg-max.  All heads emit EOS at audio step 1 -> check_stopping
+    (model.cpp:715-732) turns true before step 2 (steps_done == 1) and every later input id is EOS."""
+    model = get_model("tiny", gguf.F32)
+    cfg = model.cfg
+    lnb = model.by_name["decoder.layer_norm.bias"].to_f32()
+    repl = {"decoder.layer_norm.weight": np.zeros_like(lnb)}
+    for i in range(cfg.n_out):
+        name = f"decoder.lm_heads.{i}.weight.head"
+        w = model.by_name[name].to_f32().copy()
+        w[cfg.eos] = 10.0 * lnb / float((lnb * lnb).sum())
+        repl[name] = w
+    m2 = replace_tensors(model, repl)
+    eng = hip.HipEngine(cfg, max_seqs=1)
+    eng.load(m2)
+    prompt = np.array([4, 5, 1], dtype=np.uint32)
+    eng.prefill(0, prompt)
+    toks, done = eng.generate_greedy([3], 6)
+    assert (toks == cfg.eos).all()
+    assert done[0] == 1
+    o = orc.ParlerOracle(m2, act_mode=1, gelu_mode=1)
+    ref_toks, _ = o.generate_greedy(prompt, 6)
+    assert np.array_equal(toks[:, 0, :], ref_toks)
+    eng.close()
+
+
+def test_fp16_kv_cache_extension():
+    model = get_model("tiny", gguf.F16)
+    cfg = model.cfg
+    eng = hip.HipEngine(cfg, max_seqs=1, kv_type=gguf.F16)
+    eng.load(model)
+    o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+    prompt = np.array([11, 12, 13, 14, 15, 1], dtype=np.uint32)
+    eng.prefill(0, prompt)
+    o.decode(prompt, 0, audio=False, want_logits=False)
+    ids = np.full(cfg.n_out, cfg.bos, dtype=np.uint32)
+    for pos in range(6, 10):
+        lg = eng.step(ids[None], [pos])[0]
+        ref, _ = o.decode(ids, pos, audio=True)
+        assert relerr(lg, ref[:, 0, :]) < 1e-2
+        ids = ref[:, 0, :].argmax(-1).astype(np.uint32)
+    eng.close()
+
+
+@pytest.mark.parametrize("wtype", [gguf.Q8_0, gguf.Q5_0, gguf.Q4_0])
+def test_quantised_gguf_tensors_are_decoded_exactly(wtype):
+    """Round 1 dequantises Q4_0/Q5_0/Q8_0 blocks to fp32 at upload: must equal the oracle run on the
+    same blocks with fp32 activations (act_mode 0)."""
+    model = get_model("tiny", wtype)
+    cfg = model.cfg
+    eng = hip.HipEngine(cfg, max_seqs=1)
+    eng.load(model)
+    o = orc.ParlerOracle(model, act_mode=0, gelu_mode=1)
+    prompt = np.array([21, 22, 23, 1], dtype=np.uint32)
+    eng.prefill(0, prompt)
+    o.decode(prompt, 0, audio=False, want_logits=False)
+    ids = np.full(cfg.n_out, cfg.bos, dtype=np.uint32)
+    lg = eng.step(ids[None], [4])[0]
+    ref, _ = o.decode(ids, 4, audio=True)
+    assert relerr(lg, ref[:, 0, :]) < TOL[wtype]
+    eng.close()
+
+
+def test_update_conditional_prompt():
+    model = get_model("tiny", gguf.F32)
+    cfg = model.cfg
+    eng = hip.HipEngine(cfg, max_seqs=1)
+    eng.load(model)
+    o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+    enc = (np.random.default_rng(3).standard_normal((11, cfg.hidden)) * 0.5).astype(np.float32)
+    eng.set_text_encoding(enc)
+    o.set_text_encoding(enc)
+    prompt = np.array([5, 6, 1], dtype=np.uint32)
+    eng.prefill(0, prompt)
+    o.decode(prompt, 0, audio=False, want_logits=False)
+    ids = np.full(cfg.n_out, cfg.bos, dtype=np.uint32)
+    lg = eng.step(ids[None], [3])[0]
+    ref, _ = o.decode(ids, 3, audio=True)
+    assert relerr(lg, ref[:, 0, :]) < TOL[gguf.F32]
+    eng.close()
+
+
+def test_no_cross_attention_mode():
+    model = get_model("tiny", gguf.F32)
+    cfg = model.cfg
+    eng = hip.HipEngine(cfg, max_seqs=1, use_cross_attn=False)
+    eng.load(model)
+    o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1, use_cross=False)
+    prompt = np.array([5, 6, 7, 1], dtype=np.uint32)
+    eng.prefill(0, prompt)
+    o.decode(prompt, 0, audio=False, want_logits=False)
+    ids = np.full(cfg.n_out, cfg.bos, dtype=np.uint32)
+    lg = eng.step(ids[None], [4])[0]
+    ref, _ = o.decode(ids, 4, audio=True)
+    assert relerr(lg, ref[:, 0, :]) < TOL[gguf.F32]
+    eng.close()
+
+
+def test_argument_errors_are_reported():
+    model = get_model("tiny", gguf.F32)
+    cfg = model.cfg
+    eng = hip.HipEngine(cfg, max_seqs=1)
+    with pytest.raises(hip.HipError):
+        eng.step(np.zeros((1, cfg.n_out)), [0])  # not finalized
+    eng.load(model)
+    with pytest.raises(hip.HipError):
+        eng.step(np.full((1, cfg.n_out), cfg.out_vocab + 5), [0])  # id outside the embedding table
+    with pytest.raises(hip.HipError):
+        eng.step(np.zeros((1, cfg.n_out)), [cfg.ctx])  # position outside the context
+    with pytest.raises(hip.HipError):
+        eng.prefill(3, [1, 2])  # sequence slot out of range
+    with pytest.raises(hip.HipError):
+        eng.step(np.zeros((2, cfg.n_out)), [0, 0])  # more rows than max_seqs
+    eng.close()
+
+
+def test_parler_mini_full_size_step():
+    """BASELINE config dims (H=1024, 24 layers, 9x1088 heads, fp16 weights): prefill + 2 steps."""
+    model = get_model("mini", gguf.F16)
+    cfg = model.cfg
+    eng = hip.HipEngine(cfg, max_seqs=2)
+    eng.load(model)
+    o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+    prompt = np.random.default_rng(0).integers(3, cfg.prompt_vocab, 6).astype(np.uint32)
+    eng.prefill(0, prompt)
+    eng.prefill(1, prompt[:4])
+    o.decode(prompt, 0, audio=False, want_logits=False)
+    ids = np.full((2, cfg.n_out), cfg.bos, dtype=np.uint32)
+    for step in range(2):
+        lg = eng.step(ids, [6 + step, 4 + step])
+        ref, _ = o.decode(ids[0], 6 + step, audio=True)
+        assert relerr(lg[0], ref[:, 0, :]) < TOL[gguf.F16]
+        check_tokens(lg[0], ref[:, 0, :], TOL[gguf.F16])
+        ids[0] = ref[:, 0, :].argmax(-1)
+        ids[1] = lg[1].argmax(-1)
+    eng.close()
