@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py — audio-seconds/sec of the Parler-TTS-Mini hot path (AR decoder + DAC) on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic utterances:
+  text-prompt prefill -> N greedy audio steps (device-resident delay-pattern loop) -> un-delay ->
+  DAC decode to 44.1 kHz PCM, for `--batch` utterances per GPU decoded in lock-step.
+Inputs (weights, prompts) are resident in HBM before the timed region; sampled ids and PCM come back
+to the host inside it, exactly as tts_generation_runner::generate() returns them.
+
+Multi-GPU (launched by torch.distributed.run): rank 0 mints the synthetic GGUF tensors and uploads them,
+the other ranks only declare shapes; the finished weight arena (incl. precomputed cross K/V) is
+broadcast once with RCCL; afterwards utterances are independent, no data-path collective
+ -> "scaling": "weak".
+
+Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit + roofline + cpu_baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import tts_cpp_amd  # noqa: E402,F401
+from tts_cpp_amd import gguf, hip, synth  # noqa: E402
+from tts_cpp_amd.pattern import undelay  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+F32_PEAK_TFLOPS = 157.3   # fp32 vector == fp32-input MFMA peak
+SAMPLE_RATE = 44100.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_prompts(cfg, batch, prompt_len, rank):
+    rng = np.random.default_rng(1000 + rank)
+    return [np.concatenate([rng.integers(3, cfg.prompt_vocab, prompt_len - 1), [1]]).astype(np.uint32) for _ in range(batch)]
+
+
+def run_utterance_batch(eng, cfg, prompts, n_audio, timings=None):
+    """one bench step; returns total PCM samples produced"""
+    t0 = time.perf_counter()
+    for s, p in enumerate(prompts):
+        eng.prefill(s, p)
+    t1 = time.perf_counter()
+    toks, _ = eng.generate_greedy([len(p) for p in prompts], n_audio)
+    t2 = time.perf_counter()
+    n_samples = 0
+    for s in range(len(prompts)):
+        frames = undelay(toks[:, s, :], cfg.audio_vocab)
+        if len(frames):
+            pcm = eng.dac_decode(frames)
+            n_samples += pcm.size
+    t3 = time.perf_counter()
+    if timings is not None:
+        timings.append((t1 - t0, t2 - t1, t3 - t2))
+    return n_samples
+
+
+def cpu_baseline(model, cfg, prompt, threads):
+    """The oracle ("port": restated CPU path, ggml unavailable) on the host cores, bounded sample:
+    prompt prefill + a few audio steps + a few DAC frames, extrapolated per frame."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["ORACLE_THREADS"] = str(threads)
+    import oracle as orc
+
+    orc.lib().orc_set_threads(threads)
+    o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+    o.decode(prompt, 0, audio=False, want_logits=False)
+    ids = np.full(cfg.n_out, cfg.bos, dtype=np.uint32)
+    n_steps = 12
+    t0 = time.perf_counter()
+    for s in range(n_steps):
+        lg, _ = o.decode(ids, len(prompt) + s, audio=True)
+        ids = lg[:, 0, :].argmax(-1).astype(np.uint32)
+    t_step = (time.perf_counter() - t0) / n_steps
+    d = orc.DacOracle(model)
+    n_frames = 4
+    codes = np.random.default_rng(0).integers(0, cfg.cb_size, (n_frames, cfg.n_out)).astype(np.uint32)
+    t0 = time.perf_counter()
+    d.decode(codes)
+    t_frame = (time.perf_counter() - t0) / n_frames
+    frame_s = cfg.hop / SAMPLE_RATE
+    return {
+        "value": round(frame_s / (t_step + t_frame), 4),
+        "unit": "audio-seconds/sec",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle (restated CPU path; ggml absent): {n_steps} decoder steps at T~{len(prompt)}..{len(prompt) + n_steps} "
+                  f"+ DAC on {n_frames} frames, batch 1, extrapolated per 11.6 ms frame",
+        "ms_per_decode_step": round(t_step * 1e3, 3),
+        "dac_ms_per_frame": round(t_frame * 1e3, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TTS_BENCH_BATCH", "8")), help="utterances per GPU decoded in lock-step")
+    ap.add_argument("--audio-steps", type=int, default=256, help="AR audio steps per utterance (random weights never emit EOS)")
+    ap.add_argument("--prompt-len", type=int, default=16)
+    ap.add_argument("--kv", choices=["f32", "f16"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--model", choices=["mini", "small", "tiny"], default="mini")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    import torch
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    cfg = {"mini": synth.parler_mini, "small": synth.small, "tiny": synth.tiny}[args.model](weight_type=gguf.F16)
+    n_audio = min(args.audio_steps, cfg.max_gen - args.prompt_len, cfg.ctx - args.prompt_len)
+    kv_type = gguf.F16 if args.kv == "f16" else gguf.F32
+
+    # ---- weights: rank 0 generates + uploads, everyone else receives the arena over RCCL ------
+    t_load = time.perf_counter()
+    model = synth.build(cfg, shapes_only=(rank != 0))
+    eng = hip.HipEngine(cfg, device=local_rank, max_seqs=args.batch, kv_type=kv_type)
+    for t in model.tensors:
+        eng.upload(t, declare_only=(rank != 0))
+    arena = None
+    if world > 1:
+        arena = torch.empty(eng.arena_bytes(), dtype=torch.uint8, device=f"cuda:{local_rank}")
+        eng.finalize(external_arena=arena.data_ptr())
+        torch.cuda.synchronize()
+        dist.broadcast(arena, src=0)   # RCCL over xGMI: the one collective of the path
+        torch.cuda.synchronize()
+        eng.arena_filled()
+    else:
+        eng.finalize()
+    log(f"[rank {rank}] weights ready in {time.perf_counter() - t_load:.1f}s, arena {eng.arena_bytes() / 1e6:.0f} MB")
+
+    prompts = make_prompts(cfg, args.batch, args.prompt_len, rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_utterance_batch(eng, cfg, prompts, n_audio)
+    barrier()
+    timings = []
+    t0 = time.perf_counter()
+    n_samples = 0
+    for _ in range(args.steps):
+        n_samples += run_utterance_batch(eng, cfg, prompts, n_audio, timings)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        ns = torch.tensor([n_samples], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(ns, op=dist.ReduceOp.SUM)
+        n_samples = float(ns.item())
+
+    audio_seconds = n_samples / SAMPLE_RATE
+    value = audio_seconds / elapsed
+    tm = np.array(timings)
+    out = {
+        "metric": "audio-seconds/sec (Parler-TTS-Mini fp16, greedy decode + DAC to 44.1 kHz PCM)",
+        "value": round(value, 3),
+        "unit": "audio-seconds/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f16 weights / f32 accumulate (fp16 MFMA inputs, fp32 residual stream; DAC fp32)",
+        "data": "synthetic (seeded random weights of the Parler-TTS-Mini + DAC-44k architecture; fixed-length greedy generation)",
+        "config": {
+            "workload": f"configs[1]: Parler-TTS-Mini fp16 on MI355X, greedy decode + DAC codec; {args.batch} utterances/GPU in lock-step, "
+                        f"{args.prompt_len}-id prompt, {n_audio} audio steps (={n_audio - cfg.n_out + 1} frames, "
+                        f"{(n_audio - cfg.n_out + 1) * cfg.hop / SAMPLE_RATE:.2f} s audio) per utterance",
+            "utterances_per_gpu": args.batch, "audio_steps": n_audio, "prompt_len": args.prompt_len,
+            "kv_cache": args.kv, "parallelism": f"dp{world} (one process per GPU, RCCL weight broadcast, no per-step collective)",
+        },
+        "real_time_factor": round(elapsed / audio_seconds, 6),
+        "x_real_time_per_gpu": round(value / world, 3),
+        "ms_per_decode_step": round(float(tm[:, 1].mean()) / n_audio * 1e3, 4),
+        "phase_ms": {"prefill": round(float(tm[:, 0].mean()) * 1e3, 3), "ar_loop": round(float(tm[:, 1].mean()) * 1e3, 3),
+                     "dac": round(float(tm[:, 2].mean()) * 1e3, 3)},
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            # per-kernel-class HIP-event timing of the same workload (eager launches, shortened AR loop)
+            prof_steps = min(n_audio, 48)
+            eng.profile(True)
+            run_utterance_batch(eng, cfg, prompts, prof_steps)
+            stats = eng.profile_get()
+            eng.profile(False)
+            tot = sum(v["ms_total"] for v in stats.values()) or 1.0
+            dom = max(stats, key=lambda k: stats[k]["ms_total"])
+            st = stats[dom]
+            per_launch_ms = st["ms_total"] / max(st["launches"], 1)
+            if dom in ("dac_conv", "dac_convt"):
+                ach = st["flops_total"] / (st["ms_total"] * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / F32_PEAK_TFLOPS, 4), "traffic": None,
+                        "note": "fp32 conv: peak = fp32 vector/fp32-input-MFMA peak (exact-fp32 numerics)"}
+            else:
+                ach = st["bytes_total"] / (st["ms_total"] * 1e-3) / 1e9
+                roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+            roof.update({"kernel": dom, "avg_launch_us": round(per_launch_ms * 1e3, 3), "launches": st["launches"],
+                         "share_of_kernel_time": round(st["ms_total"] / tot, 3),
+                         "algorithmic_bytes_per_launch": round(st["bytes_total"] / max(st["launches"], 1), 1)})
+            out["roofline"] = roof
+            out["kernel_classes"] = {
+                k: {"ms": round(v["ms_total"], 3), "launches": v["launches"],
+                    "GBps": round(v["bytes_total"] / max(v["ms_total"], 1e-9) / 1e6, 1),
+                    "TFLOPs": round(v["flops_total"] / max(v["ms_total"], 1e-9) / 1e9, 3)}
+                for k, v in stats.items() if v["launches"]}
+        if not args.no_cpu_baseline:
+            threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 32)
+            out["cpu_baseline"] = cpu_baseline(model, cfg, prompts[0], threads)
+    eng.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,9 +73,23 @@ def build():
     subprocess.check_call(["make", "-C", HERE], stdout=subprocess.DEVNULL)
 
 
+def default_threads():
+    """OpenMP threads for the oracle: bounded, because the GPU box reports hundreds of cores while the
+    container may be CPU-limited (oversubscribed spinning OpenMP teams are catastrophically slow)."""
+    if "ORACLE_THREADS" in os.environ:
+        return max(1, int(os.environ["ORACLE_THREADS"]))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def lib():
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+        os.environ.setdefault("OMP_NUM_THREADS", str(default_threads()))
         p = os.path.join(HERE, "liboracle.so")
         if not os.path.exists(p):
             build()
@@ -125,6 +139,7 @@ def lib():
         L.orc_gelu.restype = C.c_float
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_set_threads.restype = C.c_int
+        L.orc_set_threads(default_threads())
         _lib = L
     return _lib
 

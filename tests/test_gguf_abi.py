@@ -81,3 +81,16 @@ def test_product_package_does_not_touch_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", ".c")) or f == "Makefile":
                 src = open(os.path.join(base, f), errors="replace").read()
                 assert "liboracle" not in src and "tts_oracle.h" not in src and "import oracle" not in src, os.path.join(base, f)
+
+
+def test_undelay_matches_oracle_adjust_output_tokens():
+    import oracle as orc
+    from tts_cpp_amd.pattern import undelay
+    rng = np.random.default_rng(0)
+    for trial in range(30):
+        steps, n_out = int(rng.integers(1, 40)), int(rng.integers(1, 10))
+        t = rng.integers(0, 70, (steps, n_out)).astype(np.uint32)
+        flat = t.reshape(-1).copy()
+        out = np.empty_like(flat)
+        n = orc.lib().orc_parler_adjust_output_tokens(orc.u32p(flat), flat.size, n_out, 64, 64, orc.u32p(out))
+        assert np.array_equal(out[:n].reshape(-1, n_out), undelay(t, 64)), trial

@@ -37,6 +37,7 @@ class Config:
     seed: int = 0xC0FFEE
     weight_type: int = gguf.F16  # type of the quantisable decoder tensors
     dac_f16: bool = False
+    suppress_special: bool = True
     paddings: tuple = field(default=None)
 
     def __post_init__(self):
@@ -154,21 +155,63 @@ def _vocab(n, rng):
     return toks, scores
 
 
-class SynthModel:
-    """tensors: list[gguf.Tensor] in file order; kv: list of (key, type, value); cfg: Config."""
+class TensorDecl:
+    """shape-only stand-in for gguf.Tensor (ranks that receive the weights by RCCL broadcast)"""
 
-    def __init__(self, cfg: Config):
+    def __init__(self, name, ttype, ne):
+        self.name, self.type, self.ne = name, int(ttype), [int(x) for x in ne]
+
+
+class SynthModel:
+    """tensors: list[gguf.Tensor] in file order; kv: list of (key, type, value); cfg: Config.
+    shapes_only=True builds TensorDecl entries without generating any data."""
+
+    def __init__(self, cfg: Config, shapes_only=False):
         self.cfg = cfg
+        self.shapes_only = shapes_only
         rng = np.random.Generator(np.random.Philox(cfg.seed))
         self.rng = rng
         self.tensors = []
         self.f32 = {}  # name -> fp32 array in PyTorch order, AFTER rounding to the stored type where exact
         H, F = cfg.hidden, cfg.ffn
 
+        class _Shape:  # array stand-in that only carries a shape
+            def __init__(self, shape):
+                self.shape = tuple(shape)
+
+            def __mul__(self, other):
+                return self
+
+            __rmul__ = __mul__
+
+            def astype(self, dt):
+                return self
+
+            def __setitem__(self, k, v):
+                pass
+
+        if shapes_only:
+            class _R:
+                def standard_normal(self, shape, dtype=None): return _Shape(shape if isinstance(shape, tuple) else (shape,))
+                def uniform(self, a, b, shape): return _Shape(shape)
+                def integers(self, *a, **k): return np.random.default_rng(0).integers(*a, **k)
+                def random(self): return 0.5
+            rng = _R()
+
         def normal(shape, std=0.02, mean=0.0):
+            if shapes_only:
+                return _Shape(shape)
             return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std) + np.float32(mean)).astype(np.float32)
 
         def add(name, arr):
+            if shapes_only:
+                ttype = gguf.F32
+                if _quantizable(name):
+                    ttype = cfg.weight_type
+                elif name.startswith("audio_encoder") and cfg.dac_f16 and not name.endswith("alpha"):
+                    ttype = gguf.F16
+                self.tensors.append(TensorDecl(name, ttype, list(reversed(arr.shape))))
+                return
             arr = np.ascontiguousarray(arr, dtype=np.float32)
             ttype = gguf.F32
             if _quantizable(name):
@@ -236,9 +279,14 @@ class SynthModel:
         add("decoder.layer_norm.weight", normal((H,), mean=1.0))
         add("decoder.layer_norm.bias", normal((H,)))
         for i in range(cfg.n_out):
-            add(f"decoder.lm_heads.{i}.weight.head", normal((cfg.out_vocab, H), std=0.05))
+            hw = normal((cfg.out_vocab, H), std=0.05)
+            if cfg.suppress_special:
+                # rows of the special ids (EOS/BOS/pad, >= audio_vocab) are zero: random weights then never
+                # emit them, so synthetic generation has a fixed length and every id is a valid DAC code
+                hw[cfg.audio_vocab:] = 0.0
+            add(f"decoder.lm_heads.{i}.weight.head", hw)
 
-        toks, scores = _vocab(cfg.prompt_vocab, rng)
+        toks, scores = _vocab(cfg.prompt_vocab, np.random.Generator(np.random.Philox(cfg.seed + 1)))
         self.vocab, self.scores = toks, scores
         U32, STR, ARR, F32T = gguf.T_U32, gguf.T_STR, gguf.T_ARR, gguf.T_F32
         self.kv = [
@@ -273,5 +321,5 @@ class SynthModel:
         return path
 
 
-def build(cfg: Config) -> SynthModel:
-    return SynthModel(cfg)
+def build(cfg: Config, shapes_only=False) -> SynthModel:
+    return SynthModel(cfg, shapes_only=shapes_only)
