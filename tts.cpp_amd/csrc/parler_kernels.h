@@ -15,12 +15,10 @@
 // Design notes (MI355X): a decode step is pure weight streaming (≈725 MB of fp16 weights per
 // step, 0.7 GFLOP per row), so the GEMMs are shaped for HBM, not for MFMA peak: one workgroup
 // owns 16 output features, its waves split K in 256-wide slices, every lane issues all of its
-// weight loads (64 B contiguous per lane, whole 128/256 B lines per row across a 16-lane group)
-// before the LayerNorm prologue runs, so HBM latency overlaps the prologue.  MFMA is used because
-// a 16x16 tile gives up to 16 rows for free at the same weight traffic (lock-step utterances /
-// prompt tokens), not because the op is compute bound.  K is visited in a lane-permuted order
-// (same permutation for A and B fragments), which is legal for a dot product and is what makes
-// the 64-B-per-lane loads possible.
+// weight loads (16 rows x one 64-byte sector per wave instruction) before the LayerNorm prologue
+// runs, so HBM latency overlaps the prologue.  MFMA is used because a 16x16 tile gives up to 16
+// rows for free at the same weight traffic (lock-step utterances / prompt tokens), not because
+// the op is compute bound.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -76,15 +74,24 @@ struct EmbedArgs {
 __global__ void embed_rows_kernel(EmbedArgs a) {
     const int r = blockIdx.x;
     const uint32_t pos = a.row_pos[r];
+    uint32_t id[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) id[i] = i < a.n_tabs ? a.ids[r * a.n_tabs + i] : 0;  // all id loads in flight at once
     for (int c = threadIdx.x; c < a.H; c += blockDim.x) {
-        float acc = 0.0f;
-        for (int i = 0; i < a.n_tabs; i++) {
-            const uint32_t id = a.ids[r * a.n_tabs + i];
-            const int64_t off = (int64_t) i * a.tab_stride + (int64_t) id * a.H + c;
-            const float v = a.tab_f16 ? (float) ((const _Float16 *) a.tab)[off] : ((const float *) a.tab)[off];
-            acc = (i == 0) ? v : (v + acc);  // ggml_add(get_rows(i), input_embs), model.cpp:401
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (i < a.n_tabs) {
+                const int64_t off = (int64_t) i * a.tab_stride + (int64_t) id[i] * a.H + c;
+                v[i] = a.tab_f16 ? (float) ((const _Float16 *) a.tab)[off] : ((const float *) a.tab)[off];
+            }
         }
-        a.x[(int64_t) r * a.H + c] = acc + a.pos_embed[(int64_t) pos * a.H + c];
+        const float pe = a.pos_embed[(int64_t) pos * a.H + c];
+        float acc = v[0];
+#pragma unroll
+        for (int i = 1; i < 16; i++)
+            if (i < a.n_tabs) acc = v[i] + acc;  // ggml_add(get_rows(i), input_embs), model.cpp:401
+        a.x[(int64_t) r * a.H + c] = acc + pe;
     }
 }
 
@@ -164,59 +171,68 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
     const int K = a.K;
 
     // ---- 1. issue every weight load of this lane (HBM latency overlaps the prologue) -------------
-    half8   wh[2][4];
-    float4v wf[4][4];
+    // MFMA-natural K order: for load c, the 4 lanes (g = 0..3) that share a weight row read one
+    // contiguous 64-byte sector of it, so a wave instruction touches 16 rows x 64 B (whole sectors).
+    half8   wh[8];
+    float4v wf[16];
     if (WT == 1) {
-        const _Float16 *wp = (const _Float16 *) a.W + (int64_t) (n0 + li) * K + w * 256 + g * 32;
+        const _Float16 *wp = (const _Float16 *) a.W + (int64_t) (n0 + li) * K + w * 256 + g * 8;
 #pragma unroll
-        for (int ss = 0; ss < 2; ss++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) wh[ss][c] = __builtin_nontemporal_load((const half8 *) (wp + ss * 128 + c * 8));
+        for (int c = 0; c < 8; c++) wh[c] = __builtin_nontemporal_load((const half8 *) (wp + c * 32));
     } else {
-        const float *wp = (const float *) a.W + (int64_t) (n0 + li) * K + w * 256 + g * 16;
+        const float *wp = (const float *) a.W + (int64_t) (n0 + li) * K + w * 256 + g * 4;
 #pragma unroll
-        for (int ss = 0; ss < 4; ss++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) wf[ss][c] = __builtin_nontemporal_load((const float4v *) (wp + ss * 64 + c * 4));
+        for (int c = 0; c < 16; c++) wf[c] = __builtin_nontemporal_load((const float4v *) (wp + c * 16));
     }
 
     // ---- 2. prologue: LayerNorm of the R rows into LDS (fp16 for WT=1, fp32 for WT=0) -----------
+    // One pass: the row (K <= 2048) is held in registers; rows >= R are not computed (their MFMA
+    // columns are never stored).
     const int ldx = K + (WT == 1 ? 8 : 4);  // +16 B per row: spreads rows over LDS banks
     _Float16 *xs16 = (_Float16 *) smem;
     float    *xs32 = (float *) smem;
     size_t    red_off = 0;
     if (PRO == PRO_LN) {
         const float *A = (const float *) a.A;
-        for (int r = w; r < RB * 16; r += nw) {
-            const int rr = r < a.R ? r : a.R - 1;
-            const float *xr = A + (int64_t) rr * a.lda;
+        for (int r = w; r < a.R; r += nw) {
+            const float *xr = A + (int64_t) r * a.lda;
+            float4v v[8];
             float s = 0.0f;
-            for (int k = lane * 4; k < K; k += 256) {
-                const float4v v = *(const float4v *) (xr + k);
-                s += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int k = i * 256 + lane * 4;
+                if (k < K) {
+                    v[i] = *(const float4v *) (xr + k);
+                    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+                }
             }
             const float mean = wave_sum(s) / (float) K;
             float s2 = 0.0f;
-            for (int k = lane * 4; k < K; k += 256) {
-                const float4v v = *(const float4v *) (xr + k);
 #pragma unroll
-                for (int e = 0; e < 4; e++) { const float d = v[e] - mean; s2 += d * d; }
+            for (int i = 0; i < 8; i++) {
+                if (i * 256 + lane * 4 < K) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { const float d = v[i][e] - mean; s2 += d * d; }
+                }
             }
             const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float) K + LN_EPS);
-            for (int k = lane * 4; k < K; k += 256) {
-                const float4v v  = *(const float4v *) (xr + k);
-                const float4v lw = *(const float4v *) (a.ln_w + k);
-                const float4v lb = *(const float4v *) (a.ln_b + k);
-                float4v y;
 #pragma unroll
-                for (int e = 0; e < 4; e++) y[e] = (v[e] - mean) * rstd * lw[e] + lb[e];
-                if (WT == 1) {
-                    half4 h;
+            for (int i = 0; i < 8; i++) {
+                const int k = i * 256 + lane * 4;
+                if (k < K) {
+                    const float4v lw = *(const float4v *) (a.ln_w + k);
+                    const float4v lb = *(const float4v *) (a.ln_b + k);
+                    float4v y;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) h[e] = (_Float16) y[e];
-                    *(half4 *) (xs16 + (size_t) r * ldx + k) = h;
-                } else {
-                    *(float4v *) (xs32 + (size_t) r * ldx + k) = y;
+                    for (int e = 0; e < 4; e++) y[e] = (v[i][e] - mean) * rstd * lw[e] + lb[e];
+                    if (WT == 1) {
+                        half4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) h[e] = (_Float16) y[e];
+                        *(half4 *) (xs16 + (size_t) r * ldx + k) = h;
+                    } else {
+                        *(float4v *) (xs32 + (size_t) r * ldx + k) = y;
+                    }
                 }
             }
         }
@@ -235,39 +251,35 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
         const int r  = rb * 16 + li;
         const int rr = r < a.R ? r : a.R - 1;
         if (WT == 1) {
-            const int kb = w * 256 + g * 32;
+            const int kb = w * 256 + g * 8;
 #pragma unroll
-            for (int ss = 0; ss < 2; ss++)
+            for (int c = 0; c < 8; c++) {
+                half8 b;
+                const int k = kb + c * 32;
+                if (PRO == PRO_LN) {
+                    b = *(const half8 *) (xs16 + (size_t) r * ldx + k);
+                } else if (PRO == PRO_F16) {
+                    b = *(const half8 *) ((const _Float16 *) a.A + (int64_t) rr * a.lda + k);
+                } else {
+                    const float *p = (const float *) a.A + (int64_t) rr * a.lda + k;
+                    const float4v f0 = *(const float4v *) p, f1 = *(const float4v *) (p + 4);
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    half8 b;
-                    const int k = kb + ss * 128 + c * 8;
-                    if (PRO == PRO_LN) {
-                        b = *(const half8 *) (xs16 + (size_t) r * ldx + k);
-                    } else if (PRO == PRO_F16) {
-                        b = *(const half8 *) ((const _Float16 *) a.A + (int64_t) rr * a.lda + k);
-                    } else {
-                        const float *p = (const float *) a.A + (int64_t) rr * a.lda + k;
-                        const float4v f0 = *(const float4v *) p, f1 = *(const float4v *) (p + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) { b[e] = (_Float16) f0[e]; b[4 + e] = (_Float16) f1[e]; }
-                    }
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ss][c], b, acc[rb], 0, 0, 0);
+                    for (int e = 0; e < 4; e++) { b[e] = (_Float16) f0[e]; b[4 + e] = (_Float16) f1[e]; }
                 }
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], b, acc[rb], 0, 0, 0);
+            }
         } else {
-            const int kb = w * 256 + g * 16;
+            const int kb = w * 256 + g * 4;
 #pragma unroll
-            for (int ss = 0; ss < 4; ss++)
+            for (int c = 0; c < 16; c++) {
+                float4v b;
+                const int k = kb + c * 16;
+                if (PRO == PRO_LN) b = *(const float4v *) (xs32 + (size_t) r * ldx + k);
+                else               b = *(const float4v *) ((const float *) a.A + (int64_t) rr * a.lda + k);
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    float4v b;
-                    const int k = kb + ss * 64 + c * 4;
-                    if (PRO == PRO_LN) b = *(const float4v *) (xs32 + (size_t) r * ldx + k);
-                    else               b = *(const float4v *) ((const float *) a.A + (int64_t) rr * a.lda + k);
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ss][c][e], b[e], acc[rb], 0, 0, 0);
-                }
+                for (int e = 0; e < 4; e++)
+                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], b[e], acc[rb], 0, 0, 0);
+            }
         }
     }
 
@@ -411,15 +423,23 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int64_t hb = sb + h * 64 + c4;
     const float4v q4 = *(const float4v *) (a.q + (int64_t) r * a.H + h * 64 + c4);
 
-    // pass 1: scores + running max
+    // pass 1: scores + running max (4 keys per lane group in flight)
     float lmax = -INFINITY;
-    for (int t = t0 + kg; t < t1; t += 16) {
-        const float4v k4 = load_kv4(a.kc, a.kv_f16, hb + (int64_t) t * a.H);
-        float d = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
-        d += __shfl_xor(d, 8); d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
-        d *= a.scale;  // soft_max_ext(kq, mask, 1/sqrt(d), 0)
-        if (cl == 0) sc[t - t0] = d;
-        lmax = fmaxf(lmax, d);
+    for (int t = t0 + kg; t < t1; t += 64) {
+        float4v k4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (t + u * 16 < t1) k4[u] = load_kv4(a.kc, a.kv_f16, hb + (int64_t) (t + u * 16) * a.H);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (t + u * 16 < t1) {
+                float d = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
+                d += __shfl_xor(d, 8); d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
+                d *= a.scale;  // soft_max_ext(kq, mask, 1/sqrt(d), 0)
+                if (cl == 0) sc[t + u * 16 - t0] = d;
+                lmax = fmaxf(lmax, d);
+            }
+        }
     }
     lmax = wave_max(lmax);
     if ((tid & 63) == 0) red[tid >> 6] = lmax;
@@ -430,12 +450,20 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     // pass 2: p = exp(s - max), acc += p * V
     float4v acc = {0.f, 0.f, 0.f, 0.f};
     float lsum = 0.0f;
-    for (int t = t0 + kg; t < t1; t += 16) {
-        const float p = expf(sc[t - t0] - mx);
-        const float4v v4 = load_kv4(a.vc, a.kv_f16, hb + (int64_t) t * a.H);
-        lsum += p;
+    for (int t = t0 + kg; t < t1; t += 64) {
+        float4v v4[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) acc[e] += p * v4[e];
+        for (int u = 0; u < 4; u++)
+            if (t + u * 16 < t1) v4[u] = load_kv4(a.vc, a.kv_f16, hb + (int64_t) (t + u * 16) * a.H);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (t + u * 16 < t1) {
+                const float p = expf(sc[t + u * 16 - t0] - mx);
+                lsum += p;
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] += p * v4[u][e];
+            }
+        }
     }
     // reduce over the 16 key groups
     *(float4v *) (red + kg * 64 + c4) = acc;
@@ -456,19 +484,26 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 }
 
 __global__ void attn_combine_kernel(const float *part, int nz, int H, int n_heads, float *out) {
-    const int h = blockIdx.x, r = blockIdx.y, c = threadIdx.x;  // 64 threads
+    const int h = blockIdx.x, r = blockIdx.y, c = threadIdx.x;  // 64 threads; nz <= 16
     const float *p = part + ((int64_t) r * n_heads + h) * nz * 66;
-    float mx = -INFINITY;
-    for (int z = 0; z < nz; z++) mx = fmaxf(mx, p[z * 66]);
-    float o = 0.0f, s = 0.0f;
-    for (int z = 0; z < nz; z++) {
-        const float m = p[z * 66];
-        if (m == -INFINITY) continue;  // empty chunk
-        const float f = expf(m - mx);
-        o += f * p[z * 66 + 2 + c];
-        s += f * p[z * 66 + 1];
+    float m[16], s[16], o[16];
+#pragma unroll
+    for (int z = 0; z < 16; z++) {  // every load issued before any use
+        if (z < nz) { m[z] = p[z * 66]; s[z] = p[z * 66 + 1]; o[z] = p[z * 66 + 2 + c]; }
     }
-    out[(int64_t) r * H + h * 64 + c] = o / s;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int z = 0; z < 16; z++) if (z < nz) mx = fmaxf(mx, m[z]);
+    float oo = 0.0f, ss = 0.0f;
+#pragma unroll
+    for (int z = 0; z < 16; z++) {
+        if (z < nz && m[z] != -INFINITY) {  // -inf marks an empty chunk
+            const float f = expf(m[z] - mx);
+            oo += f * o[z];
+            ss += f * s[z];
+        }
+    }
+    out[(int64_t) r * H + h * 64 + c] = oo / ss;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -583,6 +583,7 @@ static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
         attr_set = 160 * 1024;
     }
     if (lds > 160 * 1024) return set_err("gemm16: LDS request %zu exceeds 160 KiB", lds);
+    if (PRO == PRO_LN && a.K > 2048) return set_err("gemm16: LayerNorm prologue supports hidden sizes up to 2048 (got %d)", a.K);
     hipLaunchKernelGGL((gemm16_kernel<WT, PRO, EPI, RB>), dim3(a.N / 16), dim3(nw * 64), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
@@ -670,8 +671,8 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
 static int attn_nsplit(const tts_hip_ctx *c, int R, bool same_seq) {
     if (c->attn_nsplit_override > 0) return std::min(c->attn_nsplit_override, 16);
     if (same_seq) return 1;  // prompt rows: short T
-    int ns = (512 + c->NH * R - 1) / (c->NH * R);
-    return std::max(1, std::min(ns, 16));
+    int ns = 128 / (c->NH * R);  // enough workgroups to cover half the chip; more splits only add combine work
+    return std::max(1, std::min(ns, 8));
 }
 
 // ------------------------------------------------------------------------------------------------
