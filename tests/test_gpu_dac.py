@@ -54,6 +54,33 @@ def test_small_dac_matches_oracle(frames):
     eng.close()
 
 
+@pytest.mark.parametrize("frames", [3, 37])
+def test_mfma_conv_paths_match_oracle_and_valu(frames):
+    """Channel counts that exercise every MFMA tile shape (conv 128/64/96-channel tiles, convT strides
+    8/4/2) at a size the oracle finishes quickly; the scalar-FMA kernels must agree too."""
+    cfg = synth.small(weight_type=gguf.F32, latent=64, c0=768, strides=(8, 4, 2), max_gen=64)
+    model = synth.build(cfg)
+    codes = np.random.default_rng(frames).integers(0, cfg.cb_size, (frames, cfg.n_out)).astype(np.uint32)
+    ref = orc.DacOracle(model).decode(codes)
+    outs = []
+    for flags in (hip.FLAG_NO_PARLER, hip.FLAG_NO_PARLER | hip.FLAG_VALU_GEMM):
+        eng = hip.HipEngine(cfg, flags=flags)
+        eng.load(model)
+        eng.set_debug(True)
+        pcm = eng.dac_decode(codes)
+        assert pcm.shape == ref.shape
+        assert np.abs(pcm - ref).max() < 1e-4, flags
+        if flags & hip.FLAG_VALU_GEMM == 0:
+            d = orc.DacOracle(model)
+            for st in range(2 + len(cfg.strides)):
+                _, r = d.decode(codes, stage=st)
+                act = eng.debug_read(f"dac:{st}", r.size).reshape(r.shape)
+                assert relerr(act, r) < 1e-4, f"stage {st}"
+        outs.append(pcm)
+        eng.close()
+    assert np.abs(outs[0] - outs[1]).max() < 1e-5
+
+
 def test_f16_dac_tensors_and_empty_input():
     model = synth.build(synth.tiny(weight_type=gguf.F32, dac_f16=True))
     cfg = model.cfg

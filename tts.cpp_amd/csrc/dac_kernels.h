@@ -236,3 +236,218 @@ __global__ __launch_bounds__(256) void convt1d_kernel(ConvTArgs a) {
         }
     }
 }
+
+// ================================================================================================
+// MFMA paths.  v_mfma_f32_32x32x2_f32 is exact fp32 (bitwise an fmaf chain in k order) at the fp32
+// vector rate, so the codec keeps the reference's fp32 numerics while the contraction runs on the
+// matrix pipe.  Fragment maps (cdna_hip_programming.md §3): A[i = lane&31][k = lane>>5],
+// B[k = lane>>5][j = lane&31], D col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// ================================================================================================
+typedef float float16d __attribute__((ext_vector_type(16)));
+
+// conv1d as an implicit GEMM: M = cout, N = positions, K = (tap, ci).  Workgroup tile
+// (32*MI*WM) channels x (32*NI*WN) positions; input channels staged through LDS CI_T at a time
+// with snake applied on the way in; weights staged transposed as [tap][ci][co] so A-fragment reads
+// are lane-contiguous.
+template <int KT, int MI, int NI, int WM, int WN, int CI_T>
+__global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
+    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, NT = 64 * WM * WN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int halo = (KT - 1) * a.dil;
+    const int xw = T_T + halo;
+    float *xs = (float *) smem;                 // [CI_T][xw]
+    constexpr int WS = CO_T + 1;                // padded row: the transposed staging writes hit distinct banks
+    float *ws = xs + ((CI_T * xw + 3) & ~3);    // [KT*CI_T][WS]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T;
+    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * a.L;
+    float *yg = a.y + (int64_t) blockIdx.z * a.cout * a.L;
+    const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * a.L : nullptr;
+
+    float16d acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NI; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    for (int ci0 = 0; ci0 < a.cin; ci0 += CI_T) {
+        __syncthreads();
+        for (int i = tid; i < CI_T * xw; i += NT) {
+            const int ci = i / xw, p = i - ci * xw;
+            const int t = t0 + p - a.pad, cig = ci0 + ci;
+            float v = 0.0f;
+            if (cig < a.cin && t >= 0 && t < a.L) {
+                v = xg[(int64_t) cig * a.L + t];
+                if (a.alpha) { const float al = a.alpha[cig]; v = snake_f(v, al, 1.0f / al); }
+            }
+            xs[i] = v;
+        }
+        // weights: global [co][ci][k] -> LDS [(k*CI_T + ci)][co]; consecutive threads walk (ci,k) of one co row
+        for (int i = tid; i < CO_T * CI_T * KT; i += NT) {
+            const int co = i / (CI_T * KT), rem = i - co * (CI_T * KT);
+            const int ci = rem / KT, k = rem - ci * KT;
+            const int cog = co0 + co, cig = ci0 + ci;
+            float v = 0.0f;
+            if (cog < a.cout && cig < a.cin) v = a.w[((int64_t) cog * a.cin + cig) * KT + k];
+            ws[(k * CI_T + ci) * WS + co] = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int kk = 0; kk < KT * CI_T; kk += 2) {
+            const int kq = kk + hi;              // this half-wave's k index
+            const int tap = kq / CI_T, ci = kq - tap * CI_T;
+            float af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; i++) af[i] = ws[kq * WS + (wm * MI + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < NI; j++) bf[j] = xs[ci * xw + (wn * NI + j) * 32 + l31 + tap * a.dil];
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int j = 0; j < NI; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int co = co0 + (wm * MI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (co >= a.cout) continue;
+            const float bias = a.b ? a.b[co] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < NI; j++) {
+                const int t = t0 + (wn * NI + j) * 32 + l31;
+                if (t >= a.L) continue;
+                float v = acc[i][j][e] + bias;
+                if (rg) v = v + rg[(int64_t) co * a.L + t];
+                if (a.do_tanh) v = tanhf(v);
+                yg[(int64_t) co * a.L + t] = v;
+            }
+        }
+    }
+}
+
+// ConvTranspose1d(stride S, kernel 2S) on the matrix pipe: for output phase phi = (to+p) mod S,
+//   y[co][ti*S + phi - p] = b[co] + sum_ci ( f(x[ci][ti]) w[ci][co][phi] + f(x[ci][ti-1]) w[ci][co][phi+S] )
+// i.e. S small GEMMs (M = cout, N = ti, K = 2*cin) that share one B operand: per input channel one
+// MFMA k-step whose two k slots are the taps (ti, ti-1).  A wave owns 32*MI channels x 32 ti x S phases.
+template <int S, int MI, int WM, int WN, int CI_T>
+__global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma_kernel(ConvTArgs a) {
+    constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN, NT = 64 * WM * WN, K2 = 2 * S;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int xw = TI_T + 1;
+    float *xs = (float *) smem;                    // [CI_T][xw]   positions ti0-1 .. ti0+TI_T-1
+    constexpr int WS = CO_T + 1;
+    float *ws = xs + ((CI_T * xw + 3) & ~3);       // [CI_T][K2][WS]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ti0 = blockIdx.x * TI_T, co0 = blockIdx.y * CO_T;
+    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * a.L;
+    float *yg = a.y + (int64_t) blockIdx.z * a.cout * a.Lout;
+
+    float16d acc[MI][S];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int ph = 0; ph < S; ph++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][ph][e] = 0.0f;
+
+    for (int ci0 = 0; ci0 < a.cin; ci0 += CI_T) {
+        __syncthreads();
+        for (int i = tid; i < CI_T * xw; i += NT) {
+            const int ci = i / xw, p = i - ci * xw;
+            const int ti = ti0 - 1 + p, cig = ci0 + ci;
+            float v = 0.0f;
+            if (cig < a.cin && ti >= 0 && ti < a.L) {
+                v = xg[(int64_t) cig * a.L + ti];
+                if (a.alpha) { const float al = a.alpha[cig]; v = snake_f(v, al, 1.0f / al); }
+            }
+            xs[i] = v;
+        }
+        // weights: global [ci][co][k] -> LDS [ci][k][co]
+        for (int i = tid; i < CI_T * CO_T * K2; i += NT) {
+            const int ci = i / (CO_T * K2), rem = i - ci * (CO_T * K2);
+            const int co = rem / K2, k = rem - co * K2;
+            const int cog = co0 + co, cig = ci0 + ci;
+            float v = 0.0f;
+            if (cog < a.cout && cig < a.cin) v = a.w[((int64_t) cig * a.cout + cog) * K2 + k];
+            ws[(ci * K2 + k) * WS + co] = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ci = 0; ci < CI_T; ci++) {
+            // k slot 0 (lanes 0-31): x[ti];  k slot 1 (lanes 32-63): x[ti-1]
+            const float bf = xs[ci * xw + wn * 32 + l31 + 1 - hi];
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int ph = 0; ph < S; ph++) {
+                    const float af = ws[(ci * K2 + ph + hi * S) * WS + (wm * MI + i) * 32 + l31];
+                    acc[i][ph] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[i][ph], 0, 0, 0);
+                }
+        }
+    }
+    const int ti = ti0 + wn * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int co = co0 + (wm * MI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (co >= a.cout) continue;
+            const float bias = a.b ? a.b[co] : 0.0f;
+#pragma unroll
+            for (int ph = 0; ph < S; ph++) {
+                const int to = ti * S + ph - a.pad;
+                if (to >= 0 && to < a.Lout) yg[(int64_t) co * a.Lout + to] = acc[i][ph][e] + bias;
+            }
+        }
+    }
+}
+
+// final conv: Cout = 1, k = 7 (dac_model.cpp:163-166: snake -> conv -> + bias -> tanh).  One output per
+// thread; a 1-channel output gives the matrix pipe nothing to do, so this is a staged dot product.
+#define C1_T 256
+#define C1_CI 16
+__global__ __launch_bounds__(256) void conv1d_cout1_kernel(ConvArgs a) {
+    __shared__ float xs[C1_CI][C1_T + 8];
+    __shared__ float wsm[C1_CI][8];
+    const int tid = threadIdx.x, t0 = blockIdx.x * C1_T;
+    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * a.L;
+    float *yg = a.y + (int64_t) blockIdx.z * a.L;
+    float acc = 0.0f;
+    for (int ci0 = 0; ci0 < a.cin; ci0 += C1_CI) {
+        __syncthreads();
+        for (int i = tid; i < C1_CI * (C1_T + 6); i += 256) {
+            const int ci = i / (C1_T + 6), p = i - ci * (C1_T + 6);
+            const int t = t0 + p - a.pad, cig = ci0 + ci;
+            float v = 0.0f;
+            if (cig < a.cin && t >= 0 && t < a.L) {
+                v = xg[(int64_t) cig * a.L + t];
+                if (a.alpha) { const float al = a.alpha[cig]; v = snake_f(v, al, 1.0f / al); }
+            }
+            xs[ci][p] = v;
+        }
+        if (tid < C1_CI * 7) {
+            const int ci = tid / 7, k = tid - ci * 7;
+            wsm[ci][k] = (ci0 + ci < a.cin) ? a.w[(int64_t) (ci0 + ci) * 7 + k] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ci = 0; ci < C1_CI; ci++)
+#pragma unroll
+            for (int k = 0; k < 7; k++) acc += wsm[ci][k] * xs[ci][tid + k];
+    }
+    const int t = t0 + tid;
+    if (t < a.L) {
+        float v = acc + (a.b ? a.b[0] : 0.0f);
+        if (a.do_tanh) v = tanhf(v);
+        yg[t] = v;
+    }
+}

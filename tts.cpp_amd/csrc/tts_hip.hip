@@ -1081,21 +1081,84 @@ static int dac_snapshot(tts_hip_ctx *c, int stage, const float *dev, size_t n) {
     return 0;
 }
 
+template <int KT, int MI, int NI, int WM, int WN, int CI_T>
+static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a) {
+    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN;
+    const int xw = T_T + (KT - 1) * a.dil;
+    const size_t lds = ((size_t) ((CI_T * xw + 3) & ~3) + (size_t) KT * CI_T * (CO_T + 1)) * 4;
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void *) conv1d_mfma_kernel<KT, MI, NI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const dim3 grid((a.L + T_T - 1) / T_T, (a.cout + CO_T - 1) / CO_T, 1);
+    hipLaunchKernelGGL((conv1d_mfma_kernel<KT, MI, NI, WM, WN, CI_T>), grid, dim3(64 * WM * WN), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int launch_conv(tts_hip_ctx *c, const float *x, int cin, int L, size_t w, size_t b, size_t alpha, bool has_alpha,
                        int cout, int K, int pad, int dil, const float *resid, bool do_tanh, float *y) {
     ConvArgs a{};
     a.x = x; a.w = (const float *) (c->arena + w); a.b = (const float *) (c->arena + b);
     a.alpha = has_alpha ? (const float *) (c->arena + alpha) : nullptr;
     a.resid = resid; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.dil = dil; a.pad = pad; a.do_tanh = do_tanh;
-    const dim3 grid((L + CV_T - 1) / CV_T, (cout + CV_CO - 1) / CV_CO);
-    const size_t lds = ((size_t) CV_CI * (CV_T + (K - 1) * dil) + (size_t) CV_CI * K * CV_CO) * 4;
     const double bytes = ((double) cin * L + (double) cout * L * (resid ? 2 : 1) + (double) cout * cin * K) * 4;
     CHK(prof_begin(c, TTS_HIP_K_DAC_CONV, bytes, 2.0 * cout * (double) cin * K * L));
-    if (K == 7) hipLaunchKernelGGL(conv1d_kernel<7>, grid, dim3(256), lds, c->stream, a);
-    else if (K == 1) hipLaunchKernelGGL(conv1d_kernel<1>, grid, dim3(256), lds, c->stream, a);
-    else return set_err("conv1d: kernel size %d unsupported", K);
-    HIPCHK(hipGetLastError());
+    const bool valu = (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) != 0;
+    if (!valu && cout == 1 && K == 7) {
+        hipLaunchKernelGGL(conv1d_cout1_kernel, dim3((L + C1_T - 1) / C1_T, 1, 1), dim3(256), 0, c->stream, a);
+        HIPCHK(hipGetLastError());
+    } else if (!valu && K == 7 && cout % 128 == 0) {
+        CHK((launch_conv_mfma<7, 2, 2, 2, 2, 8>(c, a)));
+    } else if (!valu && K == 7 && cout % 96 == 0 && cout % 64 != 0) {
+        CHK((launch_conv_mfma<7, 3, 2, 1, 4, 8>(c, a)));
+    } else if (!valu && K == 7 && cout % 64 == 0) {
+        CHK((launch_conv_mfma<7, 2, 2, 1, 4, 8>(c, a)));
+    } else if (!valu && K == 1 && cout % 128 == 0) {
+        CHK((launch_conv_mfma<1, 2, 2, 2, 2, 32>(c, a)));
+    } else if (!valu && K == 1 && cout % 96 == 0 && cout % 64 != 0) {
+        CHK((launch_conv_mfma<1, 3, 2, 1, 4, 32>(c, a)));
+    } else if (!valu && K == 1 && cout % 64 == 0) {
+        CHK((launch_conv_mfma<1, 2, 2, 1, 4, 32>(c, a)));
+    } else {
+        const dim3 grid((L + CV_T - 1) / CV_T, (cout + CV_CO - 1) / CV_CO);
+        const size_t lds = ((size_t) CV_CI * (CV_T + (K - 1) * dil) + (size_t) CV_CI * K * CV_CO) * 4;
+        if (K == 7) hipLaunchKernelGGL(conv1d_kernel<7>, grid, dim3(256), lds, c->stream, a);
+        else if (K == 1) hipLaunchKernelGGL(conv1d_kernel<1>, grid, dim3(256), lds, c->stream, a);
+        else return set_err("conv1d: kernel size %d unsupported", K);
+        HIPCHK(hipGetLastError());
+    }
     return prof_end(c);
+}
+
+template <int S, int MI, int WM, int WN, int CI_T>
+static int launch_convt_mfma(tts_hip_ctx *c, const ConvTArgs &a) {
+    constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN;
+    const size_t lds = ((size_t) ((CI_T * (TI_T + 1) + 3) & ~3) + (size_t) CI_T * 2 * S * (CO_T + 1)) * 4;
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void *) convt1d_mfma_kernel<S, MI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const dim3 grid((a.L + 1 + TI_T - 1) / TI_T, (a.cout + CO_T - 1) / CO_T, 1);  // ti runs 0..L inclusive
+    hipLaunchKernelGGL((convt1d_mfma_kernel<S, MI, WM, WN, CI_T>), grid, dim3(64 * WM * WN), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int launch_convt(tts_hip_ctx *c, const ConvTArgs &ta) {
+    const bool valu = (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) != 0;
+    const int s = ta.stride;
+    if (!valu && s == 8 && ta.cout % 64 == 0) return launch_convt_mfma<8, 1, 2, 2, 8>(c, ta);
+    if (!valu && s == 4 && ta.cout % 64 == 0) return launch_convt_mfma<4, 2, 1, 4, 8>(c, ta);
+    if (!valu && s == 2 && ta.cout % 96 == 0) return launch_convt_mfma<2, 3, 1, 4, 8>(c, ta);
+    if (!valu && s == 2 && ta.cout % 64 == 0) return launch_convt_mfma<2, 2, 1, 4, 8>(c, ta);
+    const dim3 grid((ta.Lout + CV_T - 1) / CV_T, (ta.cout + CV_CO - 1) / CV_CO);
+    const size_t lds = ((size_t) CT_CI * ((CV_T + s - 1) / s + 2) + (size_t) CT_CI * 2 * s * CV_CO) * 4;
+    hipLaunchKernelGGL(convt1d_kernel, grid, dim3(256), lds, c->stream, ta);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 extern "C" int tts_hip_dac_decode(tts_hip_ctx *c, const uint32_t *codes, uint32_t frames, float *pcm_out) {
@@ -1133,12 +1196,9 @@ extern "C" int tts_hip_dac_decode(tts_hip_ctx *c, const uint32_t *codes, uint32_
         ta.x = cur; ta.w = (const float *) (c->arena + b.w); ta.b = (const float *) (c->arena + b.b);
         ta.alpha = (const float *) (c->arena + b.alpha); ta.y = t1; ta.cin = b.cin; ta.cout = b.cout; ta.L = L;
         ta.Lout = (L - 1) * b.stride - 2 * b.padding + 2 * b.stride; ta.stride = b.stride; ta.pad = b.padding;
-        const dim3 grid((ta.Lout + CV_T - 1) / CV_T, (b.cout + CV_CO - 1) / CV_CO);
-        const size_t lds = ((size_t) CT_CI * ((CV_T + b.stride - 1) / b.stride + 2) + (size_t) CT_CI * 2 * b.stride * CV_CO) * 4;
         CHK(prof_begin(c, TTS_HIP_K_DAC_CONVT, ((double) b.cin * L + (double) b.cout * ta.Lout + (double) b.cin * b.cout * 2 * b.stride) * 4,
                        2.0 * b.cin * (double) b.cout * 2 * ta.Lout));
-        hipLaunchKernelGGL(convt1d_kernel, grid, dim3(256), lds, c->stream, ta);
-        HIPCHK(hipGetLastError());
+        CHK(launch_convt(c, ta));
         CHK(prof_end(c));
         std::swap(cur, t1);
         L = ta.Lout; C = b.cout;
