@@ -7,14 +7,17 @@ from collections import defaultdict
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+        name = r["Kernel_Name"]
+        if "--grid" in sys.argv:
+            name = f'{name[:48]} g=({r["Grid_Size_X"]},{r["Grid_Size_Y"]},{r["Grid_Size_Z"]}) wg={r["Workgroup_Size_X"]} lds={r["LDS_Block_Size"]} v={r["VGPR_Count"]}+{r["Accum_VGPR_Count"]}'
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 rows.sort()
 dur = defaultdict(list)
 for s, e, n in rows:
     dur[n].append(e - s)
-print(f"{'kernel':70s} {'calls':>7s} {'avg_us':>8s} {'min_us':>8s} {'total_ms':>9s}")
+print(f"{'kernel':110s} {'calls':>7s} {'avg_us':>8s} {'min_us':>8s} {'total_ms':>9s}")
 for n, d in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-    print(f"{n[:70]:70s} {len(d):7d} {sum(d)/len(d)/1e3:8.2f} {min(d)/1e3:8.2f} {sum(d)/1e6:9.2f}")
+    print(f"{n[:110]:110s} {len(d):7d} {sum(d)/len(d)/1e3:8.2f} {min(d)/1e3:8.2f} {sum(d)/1e6:9.2f}")
 # gaps between consecutive kernels (only short ones = back-to-back graph nodes)
 gaps = [rows[i + 1][0] - rows[i][1] for i in range(len(rows) - 1)]
 short = [g for g in gaps if -5000 < g < 20000]

@@ -245,26 +245,67 @@ __global__ __launch_bounds__(256) void convt1d_kernel(ConvTArgs a) {
 // ================================================================================================
 typedef float float16d __attribute__((ext_vector_type(16)));
 
+// Weight pre-packing (once, after the weights are resident): each (channel tile, input-channel chunk)
+// of a conv weight is rewritten as the exact LDS image the MFMA kernels consume, zero padded, so
+// staging is a straight contiguous float4 copy.
+//   conv1d   src [cout][cin][KT]  -> dst [co_tile][chunk][(k*CI_T + ci)][CO_T]
+//   convT1d  src [cin][cout][K2]  -> dst [co_tile][chunk][ci][k][CO_T]
+__global__ void pack_conv_w_kernel(const float *src, float *dst, int cout, int cin, int KT, int CO_T, int CI_T, int n_chunks,
+                                   int transposed_src) {
+    const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * KT * CI_T * CO_T;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        const int col = (int) (i % CO_T);
+        int64_t r = i / CO_T;
+        int k, cil;
+        if (!transposed_src) { cil = (int) (r % CI_T); r /= CI_T; k = (int) (r % KT); r /= KT; }
+        else                 { k = (int) (r % KT); r /= KT; cil = (int) (r % CI_T); r /= CI_T; }
+        const int ch = (int) (r % n_chunks);
+        const int ct = (int) (r / n_chunks);
+        const int co = ct * CO_T + col, ci = ch * CI_T + cil;
+        float v = 0.0f;
+        if (co < cout && ci < cin)
+            v = transposed_src ? src[((int64_t) ci * cout + co) * KT + k] : src[((int64_t) co * cin + ci) * KT + k];
+        dst[i] = v;
+    }
+}
+
 // conv1d as an implicit GEMM: M = cout, N = positions, K = (tap, ci).  Workgroup tile
-// (32*MI*WM) channels x (32*NI*WN) positions; input channels staged through LDS CI_T at a time
-// with snake applied on the way in; weights staged transposed as [tap][ci][co] so A-fragment reads
-// are lane-contiguous.
+// (32*MI*WM) channels x (32*NI*WN) positions.  Input channels go through LDS CI_T at a time with
+// snake applied on the way in; a.w is the PACKED weight (see pack_conv_w_kernel).  Two LDS buffers:
+// the global loads of chunk c+1 are issued before the MFMA loop of chunk c and land in registers
+// while the matrix pipe works; one barrier per chunk.
 template <int KT, int MI, int NI, int WM, int WN, int CI_T>
 __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, NT = 64 * WM * WN;
+    constexpr int WCH = KT * CI_T * CO_T;                    // floats per packed weight chunk
+    constexpr int WV = (WCH / 4 + NT - 1) / NT;              // float4 per thread per chunk
+    constexpr int XMAX = CI_T * (T_T + (KT - 1) * 9);        // dilation <= 9 (3^2)
+    constexpr int XV = (XMAX + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int halo = (KT - 1) * a.dil;
     const int xw = T_T + halo;
-    float *xs = (float *) smem;                 // [CI_T][xw]
-    constexpr int WS = CO_T + 1;                // padded row: the transposed staging writes hit distinct banks
-    float *ws = xs + ((CI_T * xw + 3) & ~3);    // [KT*CI_T][WS]
+    const int xsz = (CI_T * xw + 3) & ~3;
+    float *wsb = (float *) smem;                // [2][WCH]
+    float *xsb = wsb + 2 * WCH;                 // [2][xsz]
+    float *als = xsb + 2 * xsz;                 // [cin_pad] alpha, then [cin_pad] 1/alpha
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
     const int l31 = lane & 31, hi = lane >> 5;
     const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T;
+    const int n_chunks = (a.cin + CI_T - 1) / CI_T;
+    const int cin_pad = n_chunks * CI_T;
     const float *xg = a.x + (int64_t) blockIdx.z * a.cin * a.L;
     float *yg = a.y + (int64_t) blockIdx.z * a.cout * a.L;
     const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * a.L : nullptr;
+    const float4d *wg = (const float4d *) (a.w + (int64_t) blockIdx.y * n_chunks * WCH);
+
+    if (a.alpha) {
+        for (int i = tid; i < cin_pad; i += NT) {
+            const float al = i < a.cin ? a.alpha[i] : 1.0f;
+            als[i] = al;
+            als[cin_pad + i] = 1.0f / al;
+        }
+    }
 
     float16d acc[MI][NI];
 #pragma unroll
@@ -274,35 +315,65 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
-    for (int ci0 = 0; ci0 < a.cin; ci0 += CI_T) {
-        __syncthreads();
-        for (int i = tid; i < CI_T * xw; i += NT) {
-            const int ci = i / xw, p = i - ci * xw;
-            const int t = t0 + p - a.pad, cig = ci0 + ci;
+    float4d wreg[WV];
+    float xreg[XV];
+    auto prefetch = [&](int c) {
+        const float4d *wp = wg + (int64_t) c * (WCH / 4);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < WCH / 4) wreg[j] = wp[i];
+        }
+#pragma unroll
+        for (int j = 0; j < XV; j++) {
+            const int i = tid + j * NT;
             float v = 0.0f;
-            if (cig < a.cin && t >= 0 && t < a.L) {
-                v = xg[(int64_t) cig * a.L + t];
-                if (a.alpha) { const float al = a.alpha[cig]; v = snake_f(v, al, 1.0f / al); }
+            if (i < CI_T * xw) {
+                const int ci = i / xw, p = i - ci * xw;
+                const int t = t0 + p - a.pad, cig = c * CI_T + ci;
+                if (cig < a.cin && t >= 0 && t < a.L) v = xg[(int64_t) cig * a.L + t];
             }
-            xs[i] = v;
+            xreg[j] = v;
         }
-        // weights: global [co][ci][k] -> LDS [(k*CI_T + ci)][co]; consecutive threads walk (ci,k) of one co row
-        for (int i = tid; i < CO_T * CI_T * KT; i += NT) {
-            const int co = i / (CI_T * KT), rem = i - co * (CI_T * KT);
-            const int ci = rem / KT, k = rem - ci * KT;
-            const int cog = co0 + co, cig = ci0 + ci;
-            float v = 0.0f;
-            if (cog < a.cout && cig < a.cin) v = a.w[((int64_t) cog * a.cin + cig) * KT + k];
-            ws[(k * CI_T + ci) * WS + co] = v;
+    };
+    auto commit = [&](int c, int buf) {
+        float4d *wd = (float4d *) (wsb + buf * WCH);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < WCH / 4) wd[i] = wreg[j];
         }
-        __syncthreads();
-#pragma unroll 2
+        float *xd = xsb + buf * xsz;
+#pragma unroll
+        for (int j = 0; j < XV; j++) {
+            const int i = tid + j * NT;
+            if (i < CI_T * xw) {
+                float v = xreg[j];
+                if (a.alpha) {
+                    const int cig = c * CI_T + i / xw;
+                    v = snake_f(v, als[cig], als[cin_pad + cig]);  // snake(0) == 0: zero padding is preserved
+                }
+                xd[i] = v;
+            }
+        }
+    };
+
+    prefetch(0);
+    __syncthreads();  // alpha table visible
+    commit(0, 0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) prefetch(c + 1);
+        const float *ws = wsb + buf * WCH;
+        const float *xs = xsb + buf * xsz;
+#pragma unroll 4
         for (int kk = 0; kk < KT * CI_T; kk += 2) {
             const int kq = kk + hi;              // this half-wave's k index
             const int tap = kq / CI_T, ci = kq - tap * CI_T;
             float af[MI], bf[NI];
 #pragma unroll
-            for (int i = 0; i < MI; i++) af[i] = ws[kq * WS + (wm * MI + i) * 32 + l31];
+            for (int i = 0; i < MI; i++) af[i] = ws[kq * CO_T + (wm * MI + i) * 32 + l31];
 #pragma unroll
             for (int j = 0; j < NI; j++) bf[j] = xs[ci * xw + (wn * NI + j) * 32 + l31 + tap * a.dil];
 #pragma unroll
@@ -311,6 +382,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
                 for (int j = 0; j < NI; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        if (c + 1 < n_chunks) commit(c + 1, buf ^ 1);
+        __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < MI; i++) {
@@ -336,20 +409,36 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
 //   y[co][ti*S + phi - p] = b[co] + sum_ci ( f(x[ci][ti]) w[ci][co][phi] + f(x[ci][ti-1]) w[ci][co][phi+S] )
 // i.e. S small GEMMs (M = cout, N = ti, K = 2*cin) that share one B operand: per input channel one
 // MFMA k-step whose two k slots are the taps (ti, ti-1).  A wave owns 32*MI channels x 32 ti x S phases.
+// a.w is the PACKED weight; same two-buffer / register-prefetch structure as conv1d_mfma_kernel.
 template <int S, int MI, int WM, int WN, int CI_T>
 __global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma_kernel(ConvTArgs a) {
     constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN, NT = 64 * WM * WN, K2 = 2 * S;
+    constexpr int WCH = CI_T * K2 * CO_T;
+    constexpr int WV = (WCH / 4 + NT - 1) / NT;
+    constexpr int xw = TI_T + 1;                   // positions ti0-1 .. ti0+TI_T-1
+    constexpr int xsz = (CI_T * xw + 3) & ~3;
+    constexpr int XV = (CI_T * xw + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int xw = TI_T + 1;
-    float *xs = (float *) smem;                    // [CI_T][xw]   positions ti0-1 .. ti0+TI_T-1
-    constexpr int WS = CO_T + 1;
-    float *ws = xs + ((CI_T * xw + 3) & ~3);       // [CI_T][K2][WS]
+    float *wsb = (float *) smem;                   // [2][WCH]
+    float *xsb = wsb + 2 * WCH;                    // [2][xsz]
+    float *als = xsb + 2 * xsz;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
     const int l31 = lane & 31, hi = lane >> 5;
     const int ti0 = blockIdx.x * TI_T, co0 = blockIdx.y * CO_T;
+    const int n_chunks = (a.cin + CI_T - 1) / CI_T;
+    const int cin_pad = n_chunks * CI_T;
     const float *xg = a.x + (int64_t) blockIdx.z * a.cin * a.L;
     float *yg = a.y + (int64_t) blockIdx.z * a.cout * a.Lout;
+    const float4d *wg = (const float4d *) (a.w + (int64_t) blockIdx.y * n_chunks * WCH);
+
+    if (a.alpha) {
+        for (int i = tid; i < cin_pad; i += NT) {
+            const float al = i < a.cin ? a.alpha[i] : 1.0f;
+            als[i] = al;
+            als[cin_pad + i] = 1.0f / al;
+        }
+    }
 
     float16d acc[MI][S];
 #pragma unroll
@@ -359,28 +448,58 @@ __global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma_kernel(ConvTArgs a)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][ph][e] = 0.0f;
 
-    for (int ci0 = 0; ci0 < a.cin; ci0 += CI_T) {
-        __syncthreads();
-        for (int i = tid; i < CI_T * xw; i += NT) {
-            const int ci = i / xw, p = i - ci * xw;
-            const int ti = ti0 - 1 + p, cig = ci0 + ci;
+    float4d wreg[WV];
+    float xreg[XV];
+    auto prefetch = [&](int c) {
+        const float4d *wp = wg + (int64_t) c * (WCH / 4);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < WCH / 4) wreg[j] = wp[i];
+        }
+#pragma unroll
+        for (int j = 0; j < XV; j++) {
+            const int i = tid + j * NT;
             float v = 0.0f;
-            if (cig < a.cin && ti >= 0 && ti < a.L) {
-                v = xg[(int64_t) cig * a.L + ti];
-                if (a.alpha) { const float al = a.alpha[cig]; v = snake_f(v, al, 1.0f / al); }
+            if (i < CI_T * xw) {
+                const int ci = i / xw, p = i - ci * xw;
+                const int ti = ti0 - 1 + p, cig = c * CI_T + ci;
+                if (cig < a.cin && ti >= 0 && ti < a.L) v = xg[(int64_t) cig * a.L + ti];
             }
-            xs[i] = v;
+            xreg[j] = v;
         }
-        // weights: global [ci][co][k] -> LDS [ci][k][co]
-        for (int i = tid; i < CI_T * CO_T * K2; i += NT) {
-            const int ci = i / (CO_T * K2), rem = i - ci * (CO_T * K2);
-            const int co = rem / K2, k = rem - co * K2;
-            const int cog = co0 + co, cig = ci0 + ci;
-            float v = 0.0f;
-            if (cog < a.cout && cig < a.cin) v = a.w[((int64_t) cig * a.cout + cog) * K2 + k];
-            ws[(ci * K2 + k) * WS + co] = v;
+    };
+    auto commit = [&](int c, int buf) {
+        float4d *wd = (float4d *) (wsb + buf * WCH);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < WCH / 4) wd[i] = wreg[j];
         }
-        __syncthreads();
+        float *xd = xsb + buf * xsz;
+#pragma unroll
+        for (int j = 0; j < XV; j++) {
+            const int i = tid + j * NT;
+            if (i < CI_T * xw) {
+                float v = xreg[j];
+                if (a.alpha) {
+                    const int cig = c * CI_T + i / xw;
+                    v = snake_f(v, als[cig], als[cin_pad + cig]);
+                }
+                xd[i] = v;
+            }
+        }
+    };
+
+    prefetch(0);
+    __syncthreads();
+    commit(0, 0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) prefetch(c + 1);
+        const float *ws = wsb + buf * WCH;
+        const float *xs = xsb + buf * xsz;
 #pragma unroll 2
         for (int ci = 0; ci < CI_T; ci++) {
             // k slot 0 (lanes 0-31): x[ti];  k slot 1 (lanes 32-63): x[ti-1]
@@ -389,10 +508,12 @@ __global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma_kernel(ConvTArgs a)
             for (int i = 0; i < MI; i++)
 #pragma unroll
                 for (int ph = 0; ph < S; ph++) {
-                    const float af = ws[(ci * K2 + ph + hi * S) * WS + (wm * MI + i) * 32 + l31];
+                    const float af = ws[(ci * K2 + ph + hi * S) * CO_T + (wm * MI + i) * 32 + l31];
                     acc[i][ph] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[i][ph], 0, 0, 0);
                 }
         }
+        if (c + 1 < n_chunks) commit(c + 1, buf ^ 1);
+        __syncthreads();
     }
     const int ti = ti0 + wn * 32 + l31;
 #pragma unroll

@@ -196,6 +196,8 @@ struct tts_hip_ctx {
     float *h_pcm = nullptr;
     bool debug = false;
     std::map<int, std::vector<float>> dac_dbg;
+    std::map<size_t, float *> packed;  // arena offset of a conv weight -> its MFMA-tile-packed copy
+    bool dac_packed = false;
 
     // graphs
     std::map<int, hipGraphExec_t> graphs;
@@ -250,6 +252,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
     free_dev(c->d_eos); free_dev(c->d_codes);
     for (int i = 0; i < 3; i++) free_dev(c->dbuf[i]);
+    for (auto &pw : c->packed) free_dev(pw.second);
     if (c->h_ids) (void) hipHostFree(c->h_ids);
     if (c->h_pos) (void) hipHostFree(c->h_pos);
     if (c->h_seq) (void) hipHostFree(c->h_seq);
@@ -1081,11 +1084,60 @@ static int dac_snapshot(tts_hip_ctx *c, int stage, const float *dev, size_t n) {
     return 0;
 }
 
+// ---- MFMA tile selection (shared by the packer and the launchers) ---------------------------------
+static int conv_tile(int cout, int K, int *CO_T, int *CI_T) {
+    if (K != 7 && K != 1) return -1;
+    *CI_T = K == 7 ? 8 : 32;
+    if (cout % 128 == 0) { *CO_T = 128; return 0; }
+    if (cout % 96 == 0 && cout % 64 != 0) { *CO_T = 96; return 1; }
+    if (cout % 64 == 0) { *CO_T = 64; return 2; }
+    return -1;
+}
+static int convt_tile(int cout, int s, int *CO_T) {
+    if (s == 8 && cout % 64 == 0) { *CO_T = 64; return 0; }
+    if (s == 4 && cout % 64 == 0) { *CO_T = 64; return 1; }
+    if (s == 2 && cout % 96 == 0) { *CO_T = 96; return 2; }
+    if (s == 2 && cout % 64 == 0) { *CO_T = 64; return 3; }
+    return -1;
+}
+
+static int pack_one(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT, int CO_T, int CI_T, bool transposed) {
+    const int n_chunks = (cin + CI_T - 1) / CI_T;
+    const size_t n = (size_t) ((cout + CO_T - 1) / CO_T) * n_chunks * KT * CI_T * CO_T;
+    float *dst = nullptr;
+    HIPCHK(hipMalloc((void **) &dst, n * 4));
+    hipLaunchKernelGGL(pack_conv_w_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + w_off), dst, cout, cin, KT,
+                       CO_T, CI_T, n_chunks, transposed ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    c->packed[w_off] = dst;
+    return 0;
+}
+
+// one-time re-layout of the DAC conv weights into MFMA LDS images (after the arena holds the weights,
+// i.e. also after an RCCL broadcast filled it)
+static int ensure_packed(tts_hip_ctx *c) {
+    if (c->dac_packed || (c->d.flags & TTS_HIP_FLAG_VALU_GEMM)) return 0;
+    int CO_T = 0, CI_T = 0;
+    if (conv_tile(c->d_c0, 7, &CO_T, &CI_T) >= 0) CHK(pack_one(c, c->d_initw, c->d_c0, c->d_latent, 7, CO_T, CI_T, false));
+    for (auto &b : c->dblocks) {
+        if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, 8, true));
+        for (int r = 0; r < 3; r++) {
+            if (conv_tile(b.cout, 7, &CO_T, &CI_T) >= 0) CHK(pack_one(c, b.res[r].in_w, b.cout, b.cout, 7, CO_T, CI_T, false));
+            if (conv_tile(b.cout, 1, &CO_T, &CI_T) >= 0) CHK(pack_one(c, b.res[r].out_w, b.cout, b.cout, 1, CO_T, CI_T, false));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->dac_packed = true;
+    return 0;
+}
+
 template <int KT, int MI, int NI, int WM, int WN, int CI_T>
 static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a) {
-    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN;
+    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WCH = KT * CI_T * CO_T;
     const int xw = T_T + (KT - 1) * a.dil;
-    const size_t lds = ((size_t) ((CI_T * xw + 3) & ~3) + (size_t) KT * CI_T * (CO_T + 1)) * 4;
+    const int cin_pad = (a.cin + CI_T - 1) / CI_T * CI_T;
+    const size_t lds = ((size_t) 2 * WCH + 2 * (size_t) ((CI_T * xw + 3) & ~3) + (a.alpha ? 2 * (size_t) cin_pad : 0)) * 4;
+    if (a.dil > 9) return set_err("conv1d_mfma: dilation %d > 9 unsupported", a.dil);
     static bool attr = false;
     if (!attr) {
         HIPCHK(hipFuncSetAttribute((const void *) conv1d_mfma_kernel<KT, MI, NI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1106,21 +1158,20 @@ static int launch_conv(tts_hip_ctx *c, const float *x, int cin, int L, size_t w,
     const double bytes = ((double) cin * L + (double) cout * L * (resid ? 2 : 1) + (double) cout * cin * K) * 4;
     CHK(prof_begin(c, TTS_HIP_K_DAC_CONV, bytes, 2.0 * cout * (double) cin * K * L));
     const bool valu = (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) != 0;
+    int CO_T = 0, CI_T = 0;
+    const int cfg = valu ? -1 : conv_tile(cout, K, &CO_T, &CI_T);
+    auto pk = c->packed.find(w);
     if (!valu && cout == 1 && K == 7) {
         hipLaunchKernelGGL(conv1d_cout1_kernel, dim3((L + C1_T - 1) / C1_T, 1, 1), dim3(256), 0, c->stream, a);
         HIPCHK(hipGetLastError());
-    } else if (!valu && K == 7 && cout % 128 == 0) {
-        CHK((launch_conv_mfma<7, 2, 2, 2, 2, 8>(c, a)));
-    } else if (!valu && K == 7 && cout % 96 == 0 && cout % 64 != 0) {
-        CHK((launch_conv_mfma<7, 3, 2, 1, 4, 8>(c, a)));
-    } else if (!valu && K == 7 && cout % 64 == 0) {
-        CHK((launch_conv_mfma<7, 2, 2, 1, 4, 8>(c, a)));
-    } else if (!valu && K == 1 && cout % 128 == 0) {
-        CHK((launch_conv_mfma<1, 2, 2, 2, 2, 32>(c, a)));
-    } else if (!valu && K == 1 && cout % 96 == 0 && cout % 64 != 0) {
-        CHK((launch_conv_mfma<1, 3, 2, 1, 4, 32>(c, a)));
-    } else if (!valu && K == 1 && cout % 64 == 0) {
-        CHK((launch_conv_mfma<1, 2, 2, 1, 4, 32>(c, a)));
+    } else if (cfg >= 0 && pk != c->packed.end()) {
+        a.w = pk->second;
+        if (K == 7 && cfg == 0) CHK((launch_conv_mfma<7, 2, 2, 2, 2, 8>(c, a)));
+        else if (K == 7 && cfg == 1) CHK((launch_conv_mfma<7, 3, 2, 1, 4, 8>(c, a)));
+        else if (K == 7 && cfg == 2) CHK((launch_conv_mfma<7, 2, 2, 1, 4, 8>(c, a)));
+        else if (K == 1 && cfg == 0) CHK((launch_conv_mfma<1, 2, 2, 2, 2, 32>(c, a)));
+        else if (K == 1 && cfg == 1) CHK((launch_conv_mfma<1, 3, 2, 1, 4, 32>(c, a)));
+        else CHK((launch_conv_mfma<1, 2, 2, 1, 4, 32>(c, a)));
     } else {
         const dim3 grid((L + CV_T - 1) / CV_T, (cout + CV_CO - 1) / CV_CO);
         const size_t lds = ((size_t) CV_CI * (CV_T + (K - 1) * dil) + (size_t) CV_CI * K * CV_CO) * 4;
@@ -1134,8 +1185,9 @@ static int launch_conv(tts_hip_ctx *c, const float *x, int cin, int L, size_t w,
 
 template <int S, int MI, int WM, int WN, int CI_T>
 static int launch_convt_mfma(tts_hip_ctx *c, const ConvTArgs &a) {
-    constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN;
-    const size_t lds = ((size_t) ((CI_T * (TI_T + 1) + 3) & ~3) + (size_t) CI_T * 2 * S * (CO_T + 1)) * 4;
+    constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN, WCH = CI_T * 2 * S * CO_T;
+    const int cin_pad = (a.cin + CI_T - 1) / CI_T * CI_T;
+    const size_t lds = ((size_t) 2 * WCH + 2 * (size_t) ((CI_T * (TI_T + 1) + 3) & ~3) + (a.alpha ? 2 * (size_t) cin_pad : 0)) * 4;
     static bool attr = false;
     if (!attr) {
         HIPCHK(hipFuncSetAttribute((const void *) convt1d_mfma_kernel<S, MI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1147,13 +1199,19 @@ static int launch_convt_mfma(tts_hip_ctx *c, const ConvTArgs &a) {
     return 0;
 }
 
-static int launch_convt(tts_hip_ctx *c, const ConvTArgs &ta) {
+static int launch_convt(tts_hip_ctx *c, ConvTArgs ta, size_t w_off) {
     const bool valu = (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) != 0;
     const int s = ta.stride;
-    if (!valu && s == 8 && ta.cout % 64 == 0) return launch_convt_mfma<8, 1, 2, 2, 8>(c, ta);
-    if (!valu && s == 4 && ta.cout % 64 == 0) return launch_convt_mfma<4, 2, 1, 4, 8>(c, ta);
-    if (!valu && s == 2 && ta.cout % 96 == 0) return launch_convt_mfma<2, 3, 1, 4, 8>(c, ta);
-    if (!valu && s == 2 && ta.cout % 64 == 0) return launch_convt_mfma<2, 2, 1, 4, 8>(c, ta);
+    int CO_T = 0;
+    const int cfg = valu ? -1 : convt_tile(ta.cout, s, &CO_T);
+    auto pk = c->packed.find(w_off);
+    if (cfg >= 0 && pk != c->packed.end()) {
+        ta.w = pk->second;
+        if (cfg == 0) return launch_convt_mfma<8, 1, 2, 2, 8>(c, ta);
+        if (cfg == 1) return launch_convt_mfma<4, 2, 1, 4, 8>(c, ta);
+        if (cfg == 2) return launch_convt_mfma<2, 3, 1, 4, 8>(c, ta);
+        return launch_convt_mfma<2, 2, 1, 4, 8>(c, ta);
+    }
     const dim3 grid((ta.Lout + CV_T - 1) / CV_T, (ta.cout + CV_CO - 1) / CV_CO);
     const size_t lds = ((size_t) CT_CI * ((CV_T + s - 1) / s + 2) + (size_t) CT_CI * 2 * s * CV_CO) * 4;
     hipLaunchKernelGGL(convt1d_kernel, grid, dim3(256), lds, c->stream, ta);
@@ -1171,6 +1229,7 @@ extern "C" int tts_hip_dac_decode(tts_hip_ctx *c, const uint32_t *codes, uint32_
     for (size_t i = 0; i < (size_t) frames * c->d_ncb; i++)
         if (codes[i] >= (uint32_t) c->d_cbsize) return set_err("tts_hip_dac_decode: code %u >= codebook size %d", codes[i], c->d_cbsize);
     c->dac_dbg.clear();
+    CHK(ensure_packed(c));
     HIPCHK(hipMemcpyAsync(c->d_codes, codes, (size_t) frames * c->d_ncb * 4, hipMemcpyHostToDevice, c->stream));
     int L = (int) frames;
     float *cur = c->dbuf[0], *t1 = c->dbuf[1], *t2 = c->dbuf[2];
@@ -1198,7 +1257,7 @@ extern "C" int tts_hip_dac_decode(tts_hip_ctx *c, const uint32_t *codes, uint32_
         ta.Lout = (L - 1) * b.stride - 2 * b.padding + 2 * b.stride; ta.stride = b.stride; ta.pad = b.padding;
         CHK(prof_begin(c, TTS_HIP_K_DAC_CONVT, ((double) b.cin * L + (double) b.cout * ta.Lout + (double) b.cin * b.cout * 2 * b.stride) * 4,
                        2.0 * b.cin * (double) b.cout * 2 * ta.Lout));
-        CHK(launch_convt(c, ta));
+        CHK(launch_convt(c, ta, b.w));
         CHK(prof_end(c));
         std::swap(cur, t1);
         L = ta.Lout; C = b.cout;
