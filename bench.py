@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TTS_BENCH_BATCH", "8")), help="utterances per GPU decoded in lock-step")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("TTS_BENCH_STREAMS", "1")),
+                    help="independent contexts (HIP streams) per GPU sharing one weight arena; each decodes --batch utterances")
     ap.add_argument("--audio-steps", type=int, default=256, help="AR audio steps per utterance (random weights never emit EOS)")
     ap.add_argument("--prompt-len", type=int, default=16)
     ap.add_argument("--kv", choices=["f32", "f16"], default="f32")
@@ -149,9 +151,33 @@ def main():
         eng.arena_filled()
     else:
         eng.finalize()
-    log(f"[rank {rank}] weights ready in {time.perf_counter() - t_load:.1f}s, arena {eng.arena_bytes() / 1e6:.0f} MB")
+    # extra contexts on the same GPU share the finished arena (weights + cross K/V): own stream, own KV cache
+    engines = [eng]
+    for _ in range(1, args.streams):
+        e2 = hip.HipEngine(cfg, device=local_rank, max_seqs=args.batch, kv_type=kv_type)
+        for t in model.tensors:
+            e2.upload(t, declare_only=True)
+        e2.finalize(external_arena=eng.arena_ptr())
+        e2.arena_filled()
+        engines.append(e2)
+    log(f"[rank {rank}] weights ready in {time.perf_counter() - t_load:.1f}s, arena {eng.arena_bytes() / 1e6:.0f} MB, {len(engines)} context(s)")
 
-    prompts = make_prompts(cfg, args.batch, args.prompt_len, rank)
+    all_prompts = [make_prompts(cfg, args.batch, args.prompt_len, rank * 64 + i) for i in range(args.streams)]
+    prompts = all_prompts[0]
+    if args.streams > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=args.streams)
+
+        def run_all(n_audio_, timings_=None):
+            tl = [[] for _ in engines]
+            futs = [pool.submit(run_utterance_batch, e, cfg, p, n_audio_, t) for e, p, t in zip(engines, all_prompts, tl)]
+            tot = sum(f.result() for f in futs)
+            if timings_ is not None:
+                timings_.append(tuple(np.mean([t[0][i] for t in tl]) for i in range(3)))
+            return tot
+    else:
+        def run_all(n_audio_, timings_=None):
+            return run_utterance_batch(eng, cfg, prompts, n_audio_, timings_)
 
     def barrier():
         torch.cuda.synchronize()
@@ -160,13 +186,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        run_utterance_batch(eng, cfg, prompts, n_audio)
+        run_all(n_audio)
     barrier()
     timings = []
     t0 = time.perf_counter()
     n_samples = 0
     for _ in range(args.steps):
-        n_samples += run_utterance_batch(eng, cfg, prompts, n_audio, timings)
+        n_samples += run_all(n_audio, timings)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -194,10 +220,10 @@ def main():
         "dtype": "f16 weights / f32 accumulate (fp16 MFMA inputs, fp32 residual stream; DAC fp32)",
         "data": "synthetic (seeded random weights of the Parler-TTS-Mini + DAC-44k architecture; fixed-length greedy generation)",
         "config": {
-            "workload": f"configs[1]: Parler-TTS-Mini fp16 on MI355X, greedy decode + DAC codec; {args.batch} utterances/GPU in lock-step, "
+            "workload": f"configs[1]: Parler-TTS-Mini fp16 on MI355X, greedy decode + DAC codec; {args.streams} context(s) x {args.batch} utterances/GPU in lock-step, "
                         f"{args.prompt_len}-id prompt, {n_audio} audio steps (={n_audio - cfg.n_out + 1} frames, "
                         f"{(n_audio - cfg.n_out + 1) * cfg.hop / SAMPLE_RATE:.2f} s audio) per utterance",
-            "utterances_per_gpu": args.batch, "audio_steps": n_audio, "prompt_len": args.prompt_len,
+            "utterances_per_gpu": args.batch * args.streams, "contexts_per_gpu": args.streams, "lockstep_batch": args.batch, "audio_steps": n_audio, "prompt_len": args.prompt_len,
             "kv_cache": args.kv, "parallelism": f"dp{world} (one process per GPU, RCCL weight broadcast, no per-step collective)",
         },
         "real_time_factor": round(elapsed / audio_seconds, 6),
@@ -240,6 +266,8 @@ def main():
         if not args.no_cpu_baseline:
             threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 32)
             out["cpu_baseline"] = cpu_baseline(model, cfg, prompts[0], threads)
+    for e in engines[1:]:
+        e.close()
     eng.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
