@@ -124,6 +124,33 @@ def test_lockstep_sequences_are_independent():
     eng.close()
 
 
+@pytest.mark.parametrize("wtype", [gguf.F16, gguf.F32])
+def test_many_lockstep_sequences_split_layernorm_path(wtype):
+    """more than 8 rows per forward: LayerNorm runs as its own kernel and the GEMMs read the normalised
+    rows from memory (other template instantiations than the small-batch path)"""
+    model = get_model("tiny", wtype)
+    cfg = model.cfg
+    n = 12
+    eng = hip.HipEngine(cfg, max_seqs=n)
+    eng.load(model)
+    rng = np.random.default_rng(21)
+    prompts = [rng.integers(3, cfg.prompt_vocab, 3 + (i % 5)).astype(np.uint32) for i in range(n)]
+    oracles = [orc.ParlerOracle(model, act_mode=1, gelu_mode=1) for _ in prompts]
+    for s, (p, o) in enumerate(zip(prompts, oracles)):
+        eng.prefill(s, p)
+        o.decode(p, 0, audio=False, want_logits=False)
+    ids = np.full((n, cfg.n_out), cfg.bos, dtype=np.uint32)
+    for step in range(1, 4):
+        pos = [len(p) + step - 1 for p in prompts]
+        lg = eng.step(ids, pos)
+        for s, o in enumerate(oracles):
+            ref, _ = o.decode(ids[s], pos[s], audio=True)
+            assert relerr(lg[s], ref[:, 0, :]) < TOL[wtype], (step, s)
+            toks = ref[:, 0, :].argmax(-1)
+            ids[s] = [toks[i] if step > i else cfg.bos for i in range(cfg.n_out)]
+    eng.close()
+
+
 def test_graph_replay_equals_eager_and_greedy_equals_argmax():
     model = get_model("tiny", gguf.F16)
     cfg = model.cfg

@@ -355,29 +355,63 @@ __global__ void gemv_valu_kernel(GemmArgs a, int EPI, int act_f16_src) {
     }
 }
 
-// LayerNorm of R rows (debug "hidden" read-back and the VALU GEMV path)
-__global__ void ln_rows_kernel(const float *x, int H, const float *lw, const float *lb, float *y) {
-    __shared__ float sh[32];
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+// LayerNorm of R rows, one wave per row, row held in registers (H <= 2048 on this path, any H on the
+// looped fallback).  Used when R is large enough that re-normalising every row inside every GEMM
+// workgroup would dominate (and for the debug "hidden" read-back / scalar GEMV path).
+// y32 and/or y16 may be NULL.
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float *x, int H, const float *lw, const float *lb, float *y32,
+                                                      _Float16 *y16, int R) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;
     const float *xr = x + (int64_t) r * H;
-    float s = 0.0f;
-    for (int k = tid; k < H; k += blockDim.x) s += xr[k];
-    s = wave_sum(s);
-    if (lane == 0) sh[w] = s;
-    __syncthreads();
-    float tot = 0.0f;
-    for (int i = 0; i < nw; i++) tot += sh[i];
-    const float mean = tot / (float) H;
-    __syncthreads();
-    float s2 = 0.0f;
-    for (int k = tid; k < H; k += blockDim.x) { const float d = xr[k] - mean; s2 += d * d; }
-    s2 = wave_sum(s2);
-    if (lane == 0) sh[w] = s2;
-    __syncthreads();
-    tot = 0.0f;
-    for (int i = 0; i < nw; i++) tot += sh[i];
-    const float rstd = 1.0f / sqrtf(tot / (float) H + LN_EPS);
-    for (int k = tid; k < H; k += blockDim.x) y[(int64_t) r * H + k] = (xr[k] - mean) * rstd * lw[k] + lb[k];
+    if (H <= 2048 && (H & 3) == 0) {
+        float4v v[8];
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int k = i * 256 + lane * 4;
+            if (k < H) { v[i] = *(const float4v *) (xr + k); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+        }
+        const float mean = wave_sum(s) / (float) H;
+        float s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (i * 256 + lane * 4 < H) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const float d = v[i][e] - mean; s2 += d * d; }
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float) H + LN_EPS);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int k = i * 256 + lane * 4;
+            if (k < H) {
+                const float4v w4 = *(const float4v *) (lw + k), b4 = *(const float4v *) (lb + k);
+                float4v y;
+#pragma unroll
+                for (int e = 0; e < 4; e++) y[e] = (v[i][e] - mean) * rstd * w4[e] + b4[e];
+                if (y32) *(float4v *) (y32 + (int64_t) r * H + k) = y;
+                if (y16) {
+                    half4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) h[e] = (_Float16) y[e];
+                    *(half4 *) (y16 + (int64_t) r * H + k) = h;
+                }
+            }
+        }
+    } else {
+        float s = 0.0f;
+        for (int k = lane; k < H; k += 64) s += xr[k];
+        const float mean = wave_sum(s) / (float) H;
+        float s2 = 0.0f;
+        for (int k = lane; k < H; k += 64) { const float d = xr[k] - mean; s2 += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float) H + LN_EPS);
+        for (int k = lane; k < H; k += 64) {
+            const float y = (xr[k] - mean) * rstd * lw[k] + lb[k];
+            if (y32) y32[(int64_t) r * H + k] = y;
+            if (y16) y16[(int64_t) r * H + k] = (_Float16) y;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

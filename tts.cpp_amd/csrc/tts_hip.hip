@@ -179,7 +179,8 @@ struct tts_hip_ctx {
     int RMAX = 0;
     void *kcache = nullptr, *vcache = nullptr;  // [L][max_seqs][NCTX][H]
     float *x = nullptr, *q = nullptr, *att = nullptr, *u32 = nullptr, *logits = nullptr, *part = nullptr, *dbg = nullptr;
-    _Float16 *u16 = nullptr;
+    _Float16 *u16 = nullptr, *xn16 = nullptr;
+    int ln_fuse_max = 8;  // rows up to which LayerNorm stays fused in the GEMM prologue
     uint32_t *d_ids = nullptr, *d_pos = nullptr, *d_seq = nullptr, *d_tok = nullptr, *d_step = nullptr, *d_steps_done = nullptr;
     uint32_t *d_tokens_out = nullptr;
     size_t tokens_out_cap = 0;
@@ -235,6 +236,8 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); delete c; return nullptr; }
     const char *ns = getenv("TTS_HIP_ATTN_NSPLIT");
     if (ns) c->attn_nsplit_override = atoi(ns);
+    const char *lf = getenv("TTS_HIP_LN_FUSE_MAX");
+    if (lf) c->ln_fuse_max = atoi(lf);
     return c;
 }
 
@@ -248,7 +251,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (auto &t : c->tensors) free_dev(t.second.tmp);
     if (!c->arena_external) free_dev(c->arena);
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
-    free_dev(c->u16); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
+    free_dev(c->u16); free_dev(c->xn16); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
     free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
     free_dev(c->d_eos); free_dev(c->d_codes);
     for (int i = 0; i < 3; i++) free_dev(c->dbuf[i]);
@@ -624,7 +627,8 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
         GemmArgs b = a;
         if (pro == PRO_LN) {
             CHK(prof_begin(c, kclass, 0, 0));
-            hipLaunchKernelGGL(ln_rows_kernel, dim3(a.R), dim3(256), 0, c->stream, (const float *) a.A, a.K, a.ln_w, a.ln_b, c->dbg);
+            hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, (const float *) a.A, a.K, a.ln_w, a.ln_b, c->dbg,
+                               (_Float16 *) nullptr, a.R);
             HIPCHK(hipGetLastError());
             CHK(prof_end(c));
             b.A = c->dbg;
@@ -637,6 +641,18 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
         HIPCHK(hipGetLastError());
         return prof_end(c);
     }
+    if (pro == PRO_LN && a.R > c->ln_fuse_max) {
+        // many rows: normalise once (one wave per row) instead of once per GEMM workgroup
+        const bool h16 = w.type == TTS_HIP_F16;
+        CHK(prof_begin(c, kclass, (double) a.R * a.K * (h16 ? 6 : 8), 0));
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, (const float *) a.A, a.K, a.ln_w, a.ln_b,
+                           h16 ? (float *) nullptr : c->dbg, h16 ? c->xn16 : (_Float16 *) nullptr, a.R);
+        HIPCHK(hipGetLastError());
+        CHK(prof_end(c));
+        a.A = h16 ? (const void *) c->xn16 : (const void *) c->dbg;
+        a.lda = a.K;
+        pro = h16 ? PRO_F16 : PRO_F32;
+    }
     CHK(prof_begin(c, kclass, bytes, flops));
     int rc = -1;
 #define GEMM_CASE(WTv, PROv, EPIv) \
@@ -647,6 +663,8 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
     GEMM_CASE(1, PRO_F32, EPI_RESID) GEMM_CASE(0, PRO_F32, EPI_RESID)
     GEMM_CASE(1, PRO_F32, EPI_STORE) GEMM_CASE(0, PRO_F32, EPI_STORE)
     GEMM_CASE(1, PRO_F16, EPI_RESID)
+    GEMM_CASE(1, PRO_F16, EPI_QKV) GEMM_CASE(1, PRO_F16, EPI_STORE) GEMM_CASE(1, PRO_F16, EPI_GELU)
+    GEMM_CASE(0, PRO_F32, EPI_QKV) GEMM_CASE(0, PRO_F32, EPI_GELU)
     { rc = set_err("run_gemm: no kernel for type=%d pro=%d epi=%d", w.type, pro, epi); }
 #undef GEMM_CASE
     CHK(rc);
@@ -837,6 +855,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->dbg, (size_t) R * std::max(H, c->F)));
         CHK(dmalloc(&c->u32, (size_t) R * c->F));
         CHK(dmalloc(&c->u16, (size_t) R * c->F));
+        CHK(dmalloc(&c->xn16, (size_t) R * H));
         CHK(dmalloc(&c->logits, (size_t) R * c->NO * c->V));
         CHK(dmalloc(&c->part, (size_t) R * c->NH * 16 * 66));
         CHK(dmalloc(&c->d_ids, (size_t) R * c->NO));
@@ -1299,8 +1318,8 @@ extern "C" int64_t tts_hip_debug_read(tts_hip_ctx *c, const char *what, float *o
     if (w == "hidden") {
         const size_t R = c->host_pos.size();
         if (R == 0 || R * c->H > max_floats) { set_err("debug_read(hidden): no forward yet or buffer too small"); return -1; }
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned) R), dim3(256), 0, c->stream, (const float *) c->x, c->H,
-                           (const float *) (c->arena + c->ln_w), (const float *) (c->arena + c->ln_b), c->dbg);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned) (R + 3) / 4), dim3(256), 0, c->stream, (const float *) c->x, c->H,
+                           (const float *) (c->arena + c->ln_w), (const float *) (c->arena + c->ln_b), c->dbg, (_Float16 *) nullptr, (int) R);
         if (hipMemcpyAsync(out, c->dbg, R * c->H * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { set_err("debug_read(hidden): copy failed"); return -1; }
         return (int64_t) (R * c->H);
