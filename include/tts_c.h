@@ -1,0 +1,71 @@
+/*
+ * tts_c.h — C ABI over the C++ runner API (tts.cpp_amd/host/common.h), for language bindings
+ * (ctypes / cgo / JNI / N-API) and the parity tests.
+ *
+ * Each entry point corresponds to one call the reference's applications make on its C++ API
+ * (file:line under /root/reference):
+ *   tts_c_runner_from_file  -> runner_from_file()                      src/models/loaders.h:19-20, loaders.cpp:34-95
+ *   tts_c_generate          -> tts_generation_runner::generate()       include/common.h:93, parler/model.cpp:838-858
+ *   tts_c_sampling_rate     -> tts_runner::sampling_rate               include/common.h:70
+ *   tts_c_arch              -> runner->loader.get().arch               examples/perf_battery/perf_battery.cpp:116
+ *   tts_c_free              -> ~tts_generation_runner
+ * plus test hooks for the host pieces that have no device dependency (tokenizer, sampler, GGUF reader).
+ * Errors: the reference aborts (TTS_ABORT, src/util.cpp:14-22); through this ABI the same conditions are
+ * returned as NULL / non-zero with tts_c_last_error().
+ */
+#ifndef TTS_C_H
+#define TTS_C_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tts_c_runner tts_c_runner;
+
+/* generation_configuration (include/common.h:45-66) */
+typedef struct tts_c_config {
+    const char *voice;
+    int         top_k;
+    float       temperature;
+    float       repetition_penalty;
+    int         use_cross_attn;
+    int         max_tokens;
+    float       top_p;
+    int         sample;
+    uint64_t    seed; /* extension: 0 = unseeded like the reference (src/sampler.cpp:47) */
+} tts_c_config;
+
+void          tts_c_default_config(tts_c_config *cfg);
+tts_c_runner *tts_c_runner_from_file(const char *path, int n_threads, const tts_c_config *cfg, int cpu_only);
+/* *data stays owned by the runner and valid until the next generate (dac_model.cpp:190-191) */
+int           tts_c_generate(tts_c_runner *r, const char *text, const tts_c_config *cfg, const float **data, size_t *n_outputs);
+float         tts_c_sampling_rate(tts_c_runner *r);
+const char   *tts_c_arch(tts_c_runner *r);
+void          tts_c_free(tts_c_runner *r);
+const char   *tts_c_last_error(void);
+
+/* ---- test hooks ---------------------------------------------------------------------------------- */
+/* which = 0: prompt ids of the last generate (tokenised + EOS); 1: sampled ids, still delayed
+ * (pctx->output_tokens).  Returns the count (copies at most cap). */
+int tts_c_last_tokens(tts_c_runner *r, int which, uint32_t *out, int cap);
+/* unigram tokenizer from the GGUF vocabulary + EOS, as batch_from_sentence builds it (model.cpp:473-498) */
+int tts_c_tokenize(const char *gguf_path, const char *text, uint32_t *out, int cap);
+
+typedef struct tts_c_sampler_cfg {
+    uint32_t n_output_heads, vocab_size, top_k;
+    float    temperature, top_p, repetition_penalty;
+    int      do_sample;
+    uint64_t seed;
+} tts_c_sampler_cfg;
+/* sampler::sample (src/sampler.cpp:3-69); uniforms != NULL injects the per-head U[0,1) draws */
+int tts_c_sampler_sample(const tts_c_sampler_cfg *cfg, const int32_t *last_ids, const uint32_t *counts, float *logits,
+                         const float *uniforms, uint32_t *out);
+
+int tts_c_gguf_summary(const char *path, uint64_t *n_tensors, uint64_t *n_kv, uint64_t *data_offset, char *arch, int arch_cap);
+int tts_c_gguf_tensor(const char *path, int index, char *name, int name_cap, int *type, int64_t ne[4], uint64_t *checksum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

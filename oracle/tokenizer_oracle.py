@@ -1,0 +1,77 @@
+"""Pure-Python restatement of the reference's unigram tokenizer (TEST INFRASTRUCTURE ONLY).
+
+Follows /root/reference/src/tokenizer.cpp:49-127 statement by statement (trie walk, utf-8 step logic,
+unknown handling, backwards walk with the result-reference quirk), small inputs only.  "parity
+unpinned": tokenizer.cpp cannot be compiled here (it includes ggml headers through util.h), so this
+restatement is checked by inspection against the source and used to pin the C++ host tokenizer.
+"""
+import math
+import re
+
+_DUPED_SPACES = re.compile(r"\s{2,}", re.ASCII)  # static std::regex duped_spaces("\\s{2,}") (tokenizer.h:22)
+_UTF8_LEN = [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 3, 4]
+
+
+class UnigramOracle:
+    def __init__(self, vocab, scores, unk_token, eos_token=1):
+        self.scores = [float(s) for s in scores]
+        self.unk, self.eos = unk_token, eos_token
+        self.unk_score = self.scores[unk_token]
+        m = {}
+        for i, t in enumerate(vocab):  # unordered_map<string,uint32_t>: later duplicates overwrite
+            m[t.encode("utf-8", "surrogateescape") if isinstance(t, str) else bytes(t)] = i
+        self.trie = {}
+        for gram, tok in m.items():  # token_trie::add (tokenizer.cpp:3-22)
+            node = self.trie
+            for ch in gram:
+                node = node.setdefault(ch, {})
+            node["tok"] = tok
+
+    def tokenize(self, text):
+        raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        norm = b" " + _DUPED_SPACES.sub(" ", raw.decode("latin-1")).encode("latin-1")  # byte-wise like std::regex on char
+        n = len(norm)
+        res = [[self.unk, 0, -math.inf] for _ in range(n + 1)]
+        res[0] = [self.unk, 0, 0.0]
+        off = 0
+        f32 = _f32
+        while off < n:
+            cur = off
+            step = min(_UTF8_LEN[norm[off] >> 4], n - off)
+            found_unknown = True
+            best = res[off]
+            node = self.trie.get(norm[cur])
+            cur += 1
+            while cur <= n and node is not None:
+                if "tok" in node:
+                    if cur - off == step:
+                        found_unknown = False
+                    score = f32(best[2] + self.scores[node["tok"]])
+                    if score > res[cur][2]:
+                        res[cur] = [node["tok"], off, score]
+                node = node.get(norm[cur]) if cur < n else node.get(0)  # std::string[size()] == '\0'
+                cur += 1
+            if found_unknown:
+                cur = off + step
+                score = f32(best[2] + self.unk_score)
+                if score > res[cur][2]:
+                    res[cur] = [self.unk, off, score]
+            off += step
+        out = []
+        prev_unknown = False
+        r = res[n]
+        while True:
+            unknown = r[0] == self.unk
+            if not (prev_unknown and unknown):
+                out.append(r[0])
+            if r[1] == 0:
+                break
+            prev_unknown = unknown
+            r = res[r[1]]
+        out.reverse()
+        return out
+
+
+def _f32(x):
+    import struct
+    return struct.unpack("f", struct.pack("f", x))[0] if math.isfinite(x) else x

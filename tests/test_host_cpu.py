@@ -1,0 +1,165 @@
+"""CPU tests of the C++ host layer (libtts.so): GGUF reader vs the Python writer/reader, unigram tokenizer
+vs the Python restatement, sampler vs the REAL reference sampler, the test:dummy plumbing backend, and the
+exported C ABI (include/tts_c.h)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as orc
+import tokenizer_oracle
+from tts_cpp_amd import gguf, runner, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def tiny_gguf(tmp_path_factory):
+    m = synth.build(synth.tiny(weight_type=gguf.Q8_0))
+    p = str(tmp_path_factory.mktemp("gguf") / "tiny.gguf")
+    m.write_gguf(p)
+    return m, p
+
+
+def test_tts_c_exports_match_header():
+    hdr = open(os.path.join(ROOT, "include", "tts_c.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(tts_c_[a-z_0-9]+)\s*\(", hdr)))
+    assert sorted(runner.EXPORTS) == declared
+    L = C.CDLL(runner.lib_path())
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_cpp_gguf_reader_matches_python(tiny_gguf):
+    m, p = tiny_gguf
+    L = runner.load_lib()
+    nt, nkv, off = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    arch = C.create_string_buffer(64)
+    assert L.tts_c_gguf_summary(p.encode(), C.byref(nt), C.byref(nkv), C.byref(off), arch, 64) == 0
+    r = gguf.Reader(p)
+    assert nt.value == len(m.tensors) and nkv.value == len(m.kv) and off.value == r.data_offset
+    assert arch.value == b"parler-tts"
+    for idx in (0, 7, len(m.tensors) // 2, len(m.tensors) - 1):
+        name = C.create_string_buffer(256)
+        ttype, ne, cs = C.c_int(), (C.c_int64 * 4)(), C.c_uint64()
+        assert L.tts_c_gguf_tensor(p.encode(), idx, name, 256, C.byref(ttype), ne, C.byref(cs)) == 0
+        t = m.tensors[idx]
+        assert name.value.decode() == t.name and ttype.value == t.type
+        assert list(ne)[:len(t.ne)] == t.ne
+        h = 1469598103934665603
+        for b in bytes(t.raw()):
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        assert cs.value == h, t.name
+
+
+TEXTS = ["hello world", "The birch canoe slid on the smooth planks.", "  two  spaces\tand\n\nnewlines  ", "", "a",
+         "zzzzqqqq xkcd", "naïve café ☕ 你好", "It's easy to tell the depth of a well.", "ALL CAPS and MiXeD", "x" * 200]
+
+
+@pytest.mark.parametrize("text", TEXTS)
+def test_tokenizer_matches_restatement(tiny_gguf, text):
+    m, p = tiny_gguf
+    o = tokenizer_oracle.UnigramOracle(m.vocab, m.scores, 2, 1)
+    exp = o.tokenize(text) + [1]
+    got = runner.tokenize(p, text)
+    assert got.tolist() == exp
+    assert all(t < m.cfg.prompt_vocab for t in got)
+
+
+def test_tokenizer_prefers_high_scoring_segmentation():
+    vocab = ["<pad>", "</s>", "<unk>", " ", "a", "b", "ab", " a", " ab", "abab"]
+    scores = [0, 0, -10, -1, -2, -2, -3.5, -2.5, -4.2, -9]
+    o = tokenizer_oracle.UnigramOracle(vocab, scores, 2)
+    assert o.tokenize("abab") == [8, 6]        # " ab" + "ab" (-7.7) beats " a","b","ab" (-8) and " "+"abab" (-10)
+    assert o.tokenize("a?b") == [7, 2, 5]      # unknown code point -> <unk>
+    assert o.tokenize("a??b") == [7, 2, 5]     # consecutive unknowns are joined
+
+
+def _ref():
+    r = orc.ref_sampler_lib()
+    if r is None:
+        pytest.skip("oracle/_ref not built")
+    return r
+
+
+@pytest.mark.parametrize("top_k,top_p,temp,rep", [(50, 1.0, 1.0, 1.0), (50, 0.9, 0.8, 1.0), (0, 0.7, 1.0, 1.0), (30, 0.95, 1.1, 1.3), (1, 1.0, 1.0, 1.0)])
+def test_host_cpp_sampler_matches_reference(top_k, top_p, temp, rep):
+    """the product's sampler (host/sampler.cpp) against the real reference sampler's distribution"""
+    R, L = _ref(), runner.load_lib()
+    NH, V = 9, 1088
+    for seed in range(3):
+        lg = (np.random.default_rng(50 + seed).standard_normal((NH, V)) * 3).astype(np.float32)
+        rc = orc.RefSamplerCfg(NH, V, top_k, temp, top_p, rep, 1)
+        last = lg.argmax(axis=1).astype(np.int32)
+        last[1::2] = 3
+        counts = np.arange(1, NH + 1, dtype=np.uint32)
+        ref_l, picks, n_picks, mhp = lg.copy(), np.zeros((NH, V), dtype=np.uint32), np.zeros(NH, dtype=np.uint32), np.zeros(NH, dtype=np.float32)
+        R.ref_sampler_distribution(C.byref(rc), last.ctypes.data_as(C.POINTER(C.c_int32)), orc.u32p(counts), orc.f32p(ref_l),
+                                   orc.u32p(picks), orc.u32p(n_picks), orc.f32p(mhp))
+        u = np.random.default_rng(seed).random(NH).astype(np.float32)
+        exp = []
+        for i in range(NH):
+            a = np.float32(u[i] * mhp[i]) if top_p < 1.0 else u[i]
+            cum, n = np.float32(0), int(n_picks[i])
+            for j in range(n):
+                cum = np.float32(cum + ref_l[i, picks[i, j]])
+                if a <= cum or j >= n - 1:
+                    exp.append(int(picks[i, j]))
+                    break
+        sc = runner.SamplerCfg(NH, V, top_k, temp, top_p, rep, 1, 0)
+        out = np.zeros(NH, dtype=np.uint32)
+        mine = lg.copy()
+        L.tts_c_sampler_sample(C.byref(sc), last.ctypes.data_as(C.POINTER(C.c_int32)), orc.u32p(counts), orc.f32p(mine), orc.f32p(u), orc.u32p(out))
+        assert out.tolist() == exp
+
+
+def test_host_sampler_greedy_and_seed():
+    R, L = _ref(), runner.load_lib()
+    NH, V = 9, 1088
+    lg = (np.random.default_rng(9).standard_normal((NH, V)) * 2).astype(np.float32)
+    lg[:, 500] = lg.max() + 1
+    lg[:, 20] = lg[:, 500]  # tie: the first maximum (20) wins
+    rc = orc.RefSamplerCfg(NH, V, 50, 1.0, 1.0, 1.0, 0)
+    ref_out = np.zeros(NH, dtype=np.uint32)
+    R.ref_sampler_sample_greedy(C.byref(rc), orc.f32p(lg.copy()), orc.u32p(ref_out))
+    sc = runner.SamplerCfg(NH, V, 50, 1.0, 1.0, 1.0, 0, 0)
+    out = np.zeros(NH, dtype=np.uint32)
+    L.tts_c_sampler_sample(C.byref(sc), None, None, orc.f32p(lg.copy()), None, orc.u32p(out))
+    assert (out == ref_out).all() and (out == 20).all()
+    # seeded sampling is reproducible (extension), different seeds differ
+    outs = []
+    for seed in (7, 7, 8):
+        sc = runner.SamplerCfg(NH, V, 50, 1.0, 1.0, 1.0, 1, seed)
+        o = np.zeros(NH, dtype=np.uint32)
+        L.tts_c_sampler_sample(C.byref(sc), None, None, orc.f32p(lg.copy()), None, orc.u32p(o))
+        outs.append(o.copy())
+    assert (outs[0] == outs[1]).all() and not (outs[0] == outs[2]).all()
+
+
+def test_dummy_backend_plumbing():
+    """config 1 of BASELINE.json ("plumbing, no GPU"): runner_from_file("test:dummy") -> generate -> PCM"""
+    r = runner.Runner("test:dummy")
+    pcm = r.generate("ab")
+    assert r.arch == "dummy" and r.sampling_rate == 44100.0
+    assert pcm.shape == (2 * 44100,)
+    j = np.arange(44100, dtype=np.float32)
+    for i, ch in enumerate("ab"):
+        wl = np.float32(44100 / np.pi / 2) / np.float32(200 + ord(ch))
+        exp = np.sin(j * np.float32(np.pi / 44100)) * np.sin(j / wl)
+        assert np.abs(pcm[i * 44100:(i + 1) * 44100] - exp).max() < 2e-3
+    r.close()
+    with pytest.raises(runner.RunnerError):
+        runner.Runner("test:nope")
+    with pytest.raises(runner.RunnerError):
+        runner.Runner("/nonexistent/model.gguf")
+
+
+def test_runner_from_file_fails_loudly_without_gpu(tiny_gguf, have_gpu):
+    if have_gpu:
+        pytest.skip("a GPU is present")
+    with pytest.raises(runner.RunnerError) as e:
+        runner.Runner(tiny_gguf[1])
+    assert "tts_hip_create failed" in str(e.value)

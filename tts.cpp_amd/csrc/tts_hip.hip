@@ -1081,12 +1081,23 @@ extern "C" int tts_hip_parler_generate_greedy(tts_hip_ctx *c, uint32_t n, const 
         }
         g_bos = bos; g_eos = eos;
     }
+    uint32_t ran = 0;
     for (uint32_t s = 0; s < n_steps; s++) {
         for (uint32_t r = 0; r < n; r++) c->host_pos[r] = start_pos[r] + s;
         CHK(run_step(c, (int) n, MODE_GEN, bos, eos));
+        ran = s + 1;
+        if ((ran % 32) == 0 && ran < n_steps) {
+            // has check_stopping() fired for every sequence?  (one small D2H + sync every 32 steps)
+            HIPCHK(hipMemcpyAsync(c->h_tok, c->d_steps_done, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            bool all = true;
+            for (uint32_t r = 0; r < n; r++) all = all && c->h_tok[r] != 0;
+            if (all) break;
+        }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(tokens_out, c->d_tokens_out, need * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tokens_out, c->d_tokens_out, (size_t) ran * n * c->NO * 4, hipMemcpyDeviceToHost));
+    if (ran < n_steps) memset(tokens_out + (size_t) ran * n * c->NO, 0, (size_t) (n_steps - ran) * n * c->NO * 4);
     if (steps_done) HIPCHK(hipMemcpy(steps_done, c->d_steps_done, (size_t) n * 4, hipMemcpyDeviceToHost));
     return 0;
 }

@@ -1,0 +1,117 @@
+// common.h — public C++ API of the MI355X-native engine.
+//
+// Source-compatible with the reference's include/common.h (/root/reference/include/common.h:13-101):
+// the applications (examples/cli/cli.cpp:79-95, examples/perf_battery/perf_battery.cpp:102-116,
+// examples/server/server.cpp:261-298) only touch the names declared here, so they build against this
+// header unchanged.  What differs is underneath: no ggml types — weights are handed to the runner as
+// gguf_tensor_view records (our own GGUF reader, host/gguf.h) and the compute goes through the C ABI in
+// include/tts_hip.h.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <string_view>
+#include <vector>
+
+// tts_response (common.h:13-17): `data` points into a buffer owned by the runner and stays valid until
+// the next generate() on that runner (dac_model.cpp:190-191); callers never free it.
+struct tts_response {
+    float *  data        = nullptr;
+    size_t   n_outputs   = 0;
+    uint32_t hidden_size = 0;  // only meaningful for encoder outputs (t5); kept for layout compatibility
+};
+
+enum tts_arch {
+    PARLER_TTS_ARCH = 0,
+    KOKORO_ARCH     = 1,
+    DIA_ARCH        = 2,
+    ORPHEUS_ARCH    = 3,
+};
+
+extern const std::map<std::string, tts_arch> SUPPORTED_ARCHITECTURES;
+extern const std::map<tts_arch, std::string> ARCHITECTURE_NAMES;
+
+// generation_configuration (common.h:45-66): same field names, defaults and constructor argument order.
+struct generation_configuration {
+    generation_configuration(std::string voice = "", int top_k = 50, float temperature = 1.0f,
+                             float repetition_penalty = 1.0f, bool use_cross_attn = true,
+                             std::string espeak_voice_id = "", int max_tokens = 0, float top_p = 1.0f,
+                             bool sample = true)
+        : use_cross_attn(use_cross_attn), temperature(temperature), repetition_penalty(repetition_penalty),
+          top_p(top_p), top_k(top_k), max_tokens(max_tokens), voice(std::move(voice)), sample(sample),
+          espeak_voice_id(std::move(espeak_voice_id)) {}
+
+    bool        use_cross_attn;
+    float       temperature;
+    float       repetition_penalty;
+    float       top_p;
+    int         top_k;
+    int         max_tokens;
+    std::string voice;
+    bool        sample;
+    std::string espeak_voice_id;
+    // ---- extensions (not in the reference) -------------------------------------------------------
+    // The reference seeds std::minstd_rand from std::random_device on every sample() (sampler.cpp:47),
+    // so sampled output is irreproducible; seed != 0 makes it reproducible here.
+    uint64_t seed = 0;
+};
+
+struct tts_runner {
+    float sampling_rate   = 44100.0f;  // common.h:70
+    bool  supports_voices = false;
+    virtual ~tts_runner() = default;
+};
+
+struct tts_model_loader;
+struct gguf_file;
+
+// One tensor of the GGUF file as handed to assign_weight: what the reference passes as ggml_tensor&
+// (loaders.cpp:79-88) reduced to what a loader needs.
+struct gguf_tensor_view {
+    const char *  name;
+    int           type;     // ggml type id (F32=0, F16=1, Q4_0=2, Q5_0=6, Q8_0=8)
+    int           n_dims;
+    int64_t       ne[4];    // ne[0] fastest
+    const void *  data;     // points into the mapped file
+    size_t        nbytes;
+};
+
+struct tts_generation_runner : tts_runner {
+    const std::reference_wrapper<const tts_model_loader> loader;
+    std::shared_ptr<gguf_file>                           buf;  // keeps the mapping alive (reference: unique_ptr<llama_mmap>)
+    explicit tts_generation_runner(const tts_model_loader & loader);
+    ~tts_generation_runner() override;
+
+    virtual void assign_weight(const char * name, const gguf_tensor_view & tensor) = 0;
+    virtual void prepare_post_load()                                              = 0;
+    virtual std::vector<std::string_view> list_voices();
+    virtual void update_conditional_prompt(const char * file_path, const char * prompt);
+    virtual void generate(const char * sentence, tts_response & output, const generation_configuration & config) = 0;
+};
+
+// loaders.h:8-20
+struct tts_model_loader {
+    explicit tts_model_loader(const char * arch, bool is_test = false);
+    const char * const arch;
+    const bool         is_test;
+    virtual std::unique_ptr<tts_generation_runner> from_file(gguf_file * meta, int n_threads, bool cpu_only,
+                                                             const generation_configuration & config) const = 0;
+
+  protected:
+    ~tts_model_loader() = default;
+};
+
+// Same call the reference applications make (loaders.h:19-20).  `cpu_only` was "do not use Metal" in the
+// reference; here cpu_only == true selects device 0 and cpu_only == false reads TTS_HIP_DEVICE — the
+// engine has no CPU path, so loading without an MI355X aborts like any other fatal error in the reference
+// (TTS_ABORT, util.cpp:14-22).  "test:<arch>" loads a weightless test backend (loaders.cpp:37-44).
+std::unique_ptr<tts_generation_runner> runner_from_file(const char * fname, int n_threads,
+                                                        const generation_configuration & config, bool cpu_only = true);
+
+[[noreturn]] void tts_abort(const char * file, int line, const char * fmt, ...);
+#define TTS_ABORT(...) tts_abort(__FILE__, __LINE__, __VA_ARGS__)
+#define TTS_ASSERT(x) do { if (!(x)) TTS_ABORT("TTS_ASSERT(%s) failed\n", #x); } while (0)

@@ -1,0 +1,201 @@
+#include "parler_runner.h"
+
+#include <cstdlib>
+#include <cstring>
+
+#include "gguf.h"
+
+static void hip_check(int rc, const char * what) {
+    if (rc != 0) TTS_ABORT("%s failed: %s\n", what, tts_hip_last_error());
+}
+
+parler_model_loader::parler_model_loader() : tts_model_loader{"parler-tts"} {}
+const parler_model_loader parler_loader{};
+void parler_register() {}
+
+// parler_tts_model::prep_constants (model.cpp:51-108) + dac_model::prep_constants/prep_layers
+// (dac_model.cpp:15-55): same keys, same aliases, same defaults.
+static parler_hparams read_hparams(const gguf_file & m) {
+    parler_hparams hp;
+    if (!m.get_u32({"parler-tts.decoder.encode_length", "encode_length"}, hp.n_encode_length))
+        TTS_ABORT("key 'parler-tts.decoder.encode_length' must be specified in gguf file.\n");
+    m.get_u32({"parler-tts.decoder.hidden_size", "hidden_size"}, hp.hidden_size);
+    m.get_u32({"parler-tts.decoder.output_heads", "output_heads"}, hp.n_output_heads);
+    m.get_u32({"parler-tts.decoder.context_length", "ctx_length"}, hp.max_ctx_length);
+    m.get_u32({"parler-tts.decoder.attention.head_count", "attn_heads"}, hp.n_attn_heads);
+    m.get_u32({"parler-tts.decoder.out_vocab_size", "out_vocab_size"}, hp.output_vocab_size);
+    m.get_u32({"parler-tts.decoder.audio_vocab_size", "audio_vocab_size"}, hp.audio_vocab_size);
+    m.get_u32({"parler-tts.decoder.max_generation", "max_generation"}, hp.max_generation_size);
+    m.get_u32({"parler-tts.decoder.num_hidden_layers", "num_hidden_layers"}, hp.n_layers);
+    m.get_u32({"audio.bos_token_id", "bos_token_id"}, hp.bos_token_id);
+    m.get_u32({"audio.eos_token_id", "eos_token_id"}, hp.eos_token_id);
+    // the converter writes dac.up_scaling_factor but the reference reads dac.up_sampling_factor, so the
+    // default 512 always applies there (dac_model.cpp:21-24); kept, and cross-checked against the strides below
+    m.get_u32({"dac.up_sampling_factor", "up_sampling_factor"}, hp.up_sampling_factor);
+    // The reference fixes the codec at 4 decoder blocks (dac_model.h:33) and aborts when one of their
+    // stride/padding keys is missing (dac_model.cpp:37-47).  Extension: the block count is taken from how many
+    // consecutive dac_layer_stride_i keys the file holds (>= 1), so non-standard codecs load too.
+    uint32_t up = 1, n_found = 0;
+    for (uint32_t i = 0; i < TTS_HIP_MAX_DAC_BLOCKS; i++) {
+        const std::string sk = "dac_layer_stride_" + std::to_string(i), pk = "dac_layer_padding_" + std::to_string(i);
+        const std::string dsk = "dac." + sk, dpk = "dac." + pk;
+        if (!m.get_u32({dsk.c_str(), sk.c_str()}, hp.dac_stride[i])) {
+            if (i == 0) TTS_ABORT("key %s must be specified in gguf file inorder to initialize the DAC audio decoder.\n", sk.c_str());
+            break;
+        }
+        if (!m.get_u32({dpk.c_str(), pk.c_str()}, hp.dac_padding[i]))
+            TTS_ABORT("key %s must be specified in gguf file inorder to initialize the DAC audio decoder.\n", pk.c_str());
+        up *= hp.dac_stride[i];
+        n_found++;
+    }
+    hp.dac_n_layers = n_found;
+    if (up != hp.up_sampling_factor) hp.up_sampling_factor = up;  // non-standard codec: trust the layer strides
+    return hp;
+}
+
+std::unique_ptr<tts_generation_runner> parler_model_loader::from_file(gguf_file * meta, int, bool cpu_only,
+                                                                      const generation_configuration & config) const {
+    const parler_hparams hp = read_hparams(*meta);
+    int device = 0;
+    if (const char * d = getenv("TTS_HIP_DEVICE")) device = atoi(d);
+    (void) cpu_only;
+    return std::make_unique<parler_runner>(hp, unigram_tokenizer_from_gguf(*meta), device, config.use_cross_attn);
+}
+
+parler_runner::parler_runner(const parler_hparams & hp_, unigram_tokenizer * tok, int device, bool cross)
+    : tts_generation_runner{parler_loader}, hp(hp_), tokenizer(tok), use_cross_attn(cross) {
+    tts_hip_desc d{};
+    d.struct_size = sizeof(d);
+    d.hidden_size = hp.hidden_size; d.n_layers = hp.n_layers; d.n_attn_heads = hp.n_attn_heads;
+    d.n_output_heads = hp.n_output_heads; d.output_vocab_size = hp.output_vocab_size; d.max_ctx_length = hp.max_ctx_length;
+    d.n_encode_length = hp.n_encode_length; d.use_cross_attn = cross ? 1 : 0;
+    d.dac_n_blocks = hp.dac_n_layers;
+    for (uint32_t i = 0; i < hp.dac_n_layers; i++) { d.dac_stride[i] = hp.dac_stride[i]; d.dac_padding[i] = hp.dac_padding[i]; }
+    d.dac_max_frames = hp.max_generation_size;
+    d.max_seqs = 1;
+    d.kv_type = getenv("TTS_HIP_KV_F16") ? TTS_HIP_F16 : TTS_HIP_F32;
+    d.gelu_mode = 1;
+    ctx = tts_hip_create(device, &d);
+    if (!ctx) TTS_ABORT("tts_hip_create failed: %s\n", tts_hip_last_error());
+    smp.n_output_heads = hp.n_output_heads;
+    smp.vocab_size = hp.output_vocab_size;
+    smp.eos_token_id = hp.eos_token_id;
+    sampling_rate = 44100.0f;
+}
+
+parler_runner::~parler_runner() { tts_hip_destroy(ctx); }
+
+void parler_runner::assign_weight(const char * name, const gguf_tensor_view & t) {
+    // model.cpp:500-508 routes "audio_encoder." / "decoder." prefixes; the shim does the same by name
+    hip_check(tts_hip_upload(ctx, name, t.type, t.n_dims, t.ne, t.data), name);
+}
+
+void parler_runner::prepare_post_load() {
+    // prep_cross_key_values + kv cache init + graph reserve (model.cpp:704-713) all live in finalize
+    hip_check(tts_hip_finalize(ctx, nullptr), "tts_hip_finalize");
+    logits.resize((size_t) hp.n_output_heads * hp.output_vocab_size);
+    pcm.reserve((size_t) hp.max_generation_size * hp.up_sampling_factor);
+}
+
+void parler_runner::update_conditional_prompt(const char *, const char *) {
+    // needs the T5 text encoder (model.cpp:510-518, t5/model.cpp) which is outside this round's scope
+    // (SURVEY.md §8f-4); the device side is ready: tts_hip_parler_set_text_encoding().
+    TTS_ABORT("update_conditional_prompt: the T5 voice-prompt encoder is not part of this build; "
+              "feed a precomputed encoding through tts_hip_parler_set_text_encoding().\n");
+}
+
+// model.cpp:734-760, including the `next_index > size` bound (an index == size would read one past the
+// end in the reference; such a frame is dropped here, the only defined outcome).
+void parler_runner::adjust_output_tokens(const std::vector<uint32_t> & toks, std::vector<uint32_t> & filtered) const {
+    const size_t size = toks.size(), nh = hp.n_output_heads;
+    filtered.reserve(size);
+    for (size_t i = 0; i < size / nh; i++) {
+        bool remove = false;
+        for (size_t ii = 0; ii < nh; ii++) {
+            const size_t idx = i * nh + ii * nh + ii;
+            if (idx >= size || toks[idx] >= hp.audio_vocab_size) { remove = true; break; }
+        }
+        if (remove) continue;
+        for (size_t ii = 0; ii < nh; ii++) filtered.push_back(toks[i * nh + ii * nh + ii]);
+    }
+}
+
+void parler_runner::generate(const char * sentence, tts_response & output, const generation_configuration & config) {
+    smp.temperature = config.temperature;
+    smp.repetition_penalty = config.repetition_penalty;
+    smp.do_sample = config.sample;
+    smp.top_k = (uint32_t) config.top_k;
+    smp.top_p = config.top_p;
+    smp.seed = config.seed;
+    smp.n_calls = 0;
+    if (config.use_cross_attn != use_cross_attn)
+        TTS_ABORT("generate(): use_cross_attn differs from the value the model was loaded with (the reference only "
+                  "loads the encoder_attn tensors when it is set at load time, model.cpp:202-237)\n");
+
+    // batch_from_sentence (model.cpp:473-498)
+    std::vector<uint32_t> prompt;
+    tokenizer->tokenize(sentence, prompt);
+    prompt.push_back(tokenizer->eos_token);
+    last_prompt_tokens = prompt;
+    smp.reset();
+    hip_check(tts_hip_parler_reset(ctx), "tts_hip_parler_reset");
+    output.data = nullptr;
+    output.n_outputs = 0;
+    if (prompt.size() >= hp.max_generation_size || prompt.size() >= hp.max_ctx_length) {
+        fprintf(stderr, "prompt of %zu tokens leaves no room for generation\n", prompt.size());
+        return;
+    }
+    hip_check(tts_hip_parler_prefill(ctx, 0, prompt.data(), (uint32_t) prompt.size(), 0), "tts_hip_parler_prefill");
+
+    const uint32_t nh = hp.n_output_heads;
+    uint32_t       current_position = (uint32_t) prompt.size();
+    std::vector<uint32_t> & out_tokens = last_output_tokens;
+    out_tokens.clear();
+
+    const bool device_loop = !config.sample && config.repetition_penalty == 1.0f && !getenv("TTS_HOST_LOOP");
+    if (device_loop) {
+        // greedy: sampler::max, the delay-pattern feed and the EOS flags run on the device; the host
+        // synchronises in chunks only to learn whether check_stopping() would have fired.
+        const uint32_t max_steps = hp.max_generation_size - current_position;
+        std::vector<uint32_t> toks((size_t) max_steps * nh);
+        uint32_t start = current_position, done = 0;
+        hip_check(tts_hip_parler_generate_greedy(ctx, 1, &start, max_steps, hp.bos_token_id, hp.eos_token_id, toks.data(), &done),
+                  "tts_hip_parler_generate_greedy");
+        const uint32_t n = done ? done : max_steps;
+        out_tokens.assign(toks.begin(), toks.begin() + (size_t) n * nh);
+    } else {
+        // generate_from_batch (model.cpp:762-792) with host sampling
+        std::vector<uint32_t> ids(nh, hp.bos_token_id);
+        std::vector<bool>     eos_seen(nh, false);
+        int                   current_step = 0;  // batch.current_step of the decode that just ran
+        for (;;) {
+            // check_stopping (model.cpp:715-732)
+            if (!out_tokens.empty()) {
+                if (current_position >= hp.max_generation_size) break;
+                bool all = true;
+                for (uint32_t i = 0; i < nh; i++) {
+                    eos_seen[i] = eos_seen[i] || out_tokens[out_tokens.size() - nh + i] == hp.eos_token_id;
+                    all = all && eos_seen[i];
+                }
+                if (all) break;
+            } else if (current_position >= hp.max_generation_size) {
+                break;
+            }
+            current_step++;
+            hip_check(tts_hip_parler_step(ctx, 1, ids.data(), &current_position, nullptr, logits.data()), "tts_hip_parler_step");
+            smp.sample(logits.data(), out_tokens);
+            current_position += 1;
+            const uint32_t * last = out_tokens.data() + out_tokens.size() - nh;
+            for (uint32_t i = 0; i < nh; i++)
+                ids[i] = current_step > (int) i ? (eos_seen[i] ? hp.eos_token_id : last[i]) : hp.bos_token_id;
+        }
+    }
+
+    std::vector<uint32_t> filtered;
+    adjust_output_tokens(out_tokens, filtered);
+    const uint32_t frames = (uint32_t) (filtered.size() / nh);
+    pcm.assign((size_t) frames * hp.up_sampling_factor, 0.0f);
+    if (frames) hip_check(tts_hip_dac_decode(ctx, filtered.data(), frames, pcm.data()), "tts_hip_dac_decode");
+    output.data = pcm.data();
+    output.n_outputs = pcm.size();
+}

@@ -1,0 +1,53 @@
+// parler_runner.h — Parler-TTS generation runner on top of the HIP shim (include/tts_hip.h).
+//
+// Mirrors parler_tts_runner (/root/reference/src/models/parler/model.h:187-225, model.cpp:473-498,
+// 704-858): tokenise -> text-prompt decode -> AR loop with the delay pattern, host sampling and EOS
+// tracking -> un-delay -> DAC.  The ggml graph build/compute inside decode() and dac_runner::run() is
+// replaced by calls into the C ABI; everything the reference keeps on the host stays on the host.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/tts_hip.h"
+#include "common.h"
+#include "sampler.h"
+#include "tokenizer.h"
+
+extern const struct parler_model_loader final : tts_model_loader {
+    explicit parler_model_loader();
+    std::unique_ptr<tts_generation_runner> from_file(gguf_file * meta, int n_threads, bool cpu_only,
+                                                     const generation_configuration & config) const override;
+} parler_loader;
+
+struct parler_hparams {  // defaults = Parler TTS Mini v1 (model.h:66-83)
+    uint32_t n_output_heads = 9, n_encode_length = 0, hidden_size = 1024, max_ctx_length = 4096, n_attn_heads = 16;
+    uint32_t output_vocab_size = 1088, eos_token_id = 1024, audio_vocab_size = 1024, max_generation_size = 2580;
+    uint32_t n_layers = 24, bos_token_id = 1025;
+    uint32_t dac_n_layers = 4;  // dac_model.h:33
+    uint32_t dac_stride[TTS_HIP_MAX_DAC_BLOCKS] = {0}, dac_padding[TTS_HIP_MAX_DAC_BLOCKS] = {0};
+    uint32_t up_sampling_factor = 512;
+};
+
+struct parler_runner final : tts_generation_runner {
+    parler_runner(const parler_hparams & hp, unigram_tokenizer * tok, int device, bool use_cross_attn);
+    ~parler_runner() override;
+
+    void assign_weight(const char * name, const gguf_tensor_view & tensor) override;
+    void prepare_post_load() override;
+    void generate(const char * sentence, tts_response & output, const generation_configuration & config) override;
+    void update_conditional_prompt(const char * file_path, const char * prompt) override;
+
+    // pieces exposed for tests
+    void                 adjust_output_tokens(const std::vector<uint32_t> & output_tokens, std::vector<uint32_t> & filtered) const;
+    std::vector<uint32_t> last_output_tokens;  // pctx->output_tokens of the last generate (still delayed)
+    std::vector<uint32_t> last_prompt_tokens;
+
+    parler_hparams                     hp;
+    std::unique_ptr<unigram_tokenizer> tokenizer;
+    sampler                            smp;
+    tts_hip_ctx *                      ctx = nullptr;
+    bool                               use_cross_attn;
+    std::vector<float>                 pcm;     // runner-owned output buffer (dctx->buf_output)
+    std::vector<float>                 logits;
+};

@@ -1,0 +1,136 @@
+// tts_c.cpp — C wrapper of the C++ runner API (include/tts_c.h) for language bindings and tests.
+#include "../../include/tts_c.h"
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "common.h"
+#include "gguf.h"
+#include "parler_runner.h"
+#include "sampler.h"
+#include "tokenizer.h"
+
+extern bool g_tts_throw_on_abort;
+static thread_local std::string g_c_err;
+
+static generation_configuration to_cfg(const tts_c_config * c) {
+    if (!c) return generation_configuration{};
+    generation_configuration g{c->voice ? c->voice : "", c->top_k, c->temperature, c->repetition_penalty, c->use_cross_attn != 0,
+                               "", c->max_tokens, c->top_p, c->sample != 0};
+    g.seed = c->seed;
+    return g;
+}
+
+extern "C" {
+
+const char * tts_c_last_error(void) { return g_c_err.c_str(); }
+
+void tts_c_default_config(tts_c_config * c) {
+    const generation_configuration g{};
+    c->voice = nullptr; c->top_k = g.top_k; c->temperature = g.temperature; c->repetition_penalty = g.repetition_penalty;
+    c->use_cross_attn = g.use_cross_attn; c->max_tokens = g.max_tokens; c->top_p = g.top_p; c->sample = g.sample; c->seed = 0;
+}
+
+tts_c_runner * tts_c_runner_from_file(const char * path, int n_threads, const tts_c_config * cfg, int cpu_only) {
+    g_tts_throw_on_abort = true;
+    try {
+        return (tts_c_runner *) runner_from_file(path, n_threads, to_cfg(cfg), cpu_only != 0).release();
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return nullptr;
+    }
+}
+
+int tts_c_generate(tts_c_runner * r, const char * text, const tts_c_config * cfg, const float ** data, size_t * n_outputs) {
+    g_tts_throw_on_abort = true;
+    try {
+        tts_response resp;
+        ((tts_generation_runner *) r)->generate(text, resp, to_cfg(cfg));
+        *data = resp.data;
+        *n_outputs = resp.n_outputs;
+        return 0;
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return -1;
+    }
+}
+
+float        tts_c_sampling_rate(tts_c_runner * r) { return ((tts_generation_runner *) r)->sampling_rate; }
+const char * tts_c_arch(tts_c_runner * r) { return ((tts_generation_runner *) r)->loader.get().arch; }
+void         tts_c_free(tts_c_runner * r) { delete (tts_generation_runner *) r; }
+
+int tts_c_last_tokens(tts_c_runner * r, int which, uint32_t * out, int cap) {
+    auto * p = dynamic_cast<parler_runner *>((tts_generation_runner *) r);
+    if (!p) { g_c_err = "not a parler runner"; return -1; }
+    const std::vector<uint32_t> & v = which == 0 ? p->last_prompt_tokens : p->last_output_tokens;
+    const int n = (int) v.size();
+    if (out) memcpy(out, v.data(), (size_t) (n < cap ? n : cap) * 4);
+    return n;
+}
+
+int tts_c_tokenize(const char * gguf_path, const char * text, uint32_t * out, int cap) {
+    g_tts_throw_on_abort = true;
+    try {
+        std::string err;
+        auto f = gguf_file::open(gguf_path, err);
+        if (!f) { g_c_err = err; return -1; }
+        std::unique_ptr<unigram_tokenizer> t(unigram_tokenizer_from_gguf(*f));
+        std::vector<uint32_t> ids;
+        t->tokenize(text, ids);
+        ids.push_back(t->eos_token);  // batch_from_sentence appends EOS (model.cpp:478)
+        const int n = (int) ids.size();
+        if (out) memcpy(out, ids.data(), (size_t) (n < cap ? n : cap) * 4);
+        return n;
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return -1;
+    }
+}
+
+int tts_c_sampler_sample(const tts_c_sampler_cfg * c, const int32_t * last_ids, const uint32_t * counts, float * logits,
+                         const float * uniforms, uint32_t * out) {
+    sampler s;
+    s.n_output_heads = c->n_output_heads; s.vocab_size = c->vocab_size; s.top_k = c->top_k; s.temperature = c->temperature;
+    s.top_p = c->top_p; s.repetition_penalty = c->repetition_penalty; s.do_sample = c->do_sample != 0; s.seed = c->seed;
+    s.reset();
+    if (last_ids && c->repetition_penalty != 1.0f) {
+        s.last_token_ids.assign(last_ids, last_ids + c->n_output_heads);
+        s.repetition_counts.assign(counts, counts + c->n_output_heads);
+    }
+    std::vector<uint32_t> o;
+    if (uniforms) s.sample_with_uniforms(logits, uniforms, o);
+    else s.sample(logits, o);
+    memcpy(out, o.data(), o.size() * 4);
+    return (int) o.size();
+}
+
+int tts_c_gguf_summary(const char * path, uint64_t * n_tensors, uint64_t * n_kv, uint64_t * data_offset, char * arch, int arch_cap) {
+    std::string err;
+    auto f = gguf_file::open(path, err);
+    if (!f) { g_c_err = err; return -1; }
+    *n_tensors = f->tensors.size();
+    *n_kv = f->kv.size();
+    *data_offset = f->data_offset;
+    if (auto a = f->get("general.architecture")) snprintf(arch, (size_t) arch_cap, "%s", a->s.c_str());
+    else if (arch_cap) arch[0] = 0;
+    return 0;
+}
+
+int tts_c_gguf_tensor(const char * path, int index, char * name, int name_cap, int * type, int64_t ne[4], uint64_t * checksum) {
+    std::string err;
+    auto f = gguf_file::open(path, err);
+    if (!f) { g_c_err = err; return -1; }
+    if (index < 0 || index >= (int) f->tensors.size()) { g_c_err = "tensor index out of range"; return -1; }
+    const gguf_tensor_view & t = f->tensors[(size_t) index];
+    snprintf(name, (size_t) name_cap, "%s", t.name);
+    *type = t.type;
+    for (int d = 0; d < 4; d++) ne[d] = t.ne[d];
+    uint64_t h = 1469598103934665603ull;  // FNV-1a over the tensor bytes
+    const uint8_t * p = (const uint8_t *) t.data;
+    for (size_t i = 0; i < t.nbytes; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    *checksum = h;
+    return 0;
+}
+
+}  // extern "C"

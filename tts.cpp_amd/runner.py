@@ -1,0 +1,120 @@
+"""ctypes binding of include/tts_c.h (host/libtts.so): the C++ runner API the reference's applications use."""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+
+
+class RunnerError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("voice", C.c_char_p), ("top_k", C.c_int), ("temperature", C.c_float), ("repetition_penalty", C.c_float),
+                ("use_cross_attn", C.c_int), ("max_tokens", C.c_int), ("top_p", C.c_float), ("sample", C.c_int), ("seed", C.c_uint64)]
+
+
+class SamplerCfg(C.Structure):
+    _fields_ = [("n_output_heads", C.c_uint32), ("vocab_size", C.c_uint32), ("top_k", C.c_uint32), ("temperature", C.c_float),
+                ("top_p", C.c_float), ("repetition_penalty", C.c_float), ("do_sample", C.c_int), ("seed", C.c_uint64)]
+
+
+EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
+           "tts_c_last_error", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor"]
+
+_lib = None
+
+
+def lib_path():
+    return os.path.join(PKG_DIR, "host", "libtts.so")
+
+
+def load_lib():
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise RunnerError(f"{p} not built: run __graft_entry__.build()")
+        L = C.CDLL(p)
+        L.tts_c_default_config.argtypes = [C.POINTER(Config)]
+        L.tts_c_runner_from_file.restype = C.c_void_p
+        L.tts_c_runner_from_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(Config), C.c_int]
+        L.tts_c_generate.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Config), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t)]
+        L.tts_c_sampling_rate.restype = C.c_float
+        L.tts_c_sampling_rate.argtypes = [C.c_void_p]
+        L.tts_c_arch.restype = C.c_char_p
+        L.tts_c_arch.argtypes = [C.c_void_p]
+        L.tts_c_free.argtypes = [C.c_void_p]
+        L.tts_c_free.restype = None
+        L.tts_c_last_error.restype = C.c_char_p
+        L.tts_c_last_tokens.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_int]
+        L.tts_c_tokenize.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint32), C.c_int]
+        L.tts_c_sampler_sample.argtypes = [C.POINTER(SamplerCfg), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_float),
+                                           C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        L.tts_c_gguf_summary.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_int]
+        L.tts_c_gguf_tensor.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+        _lib = L
+    return _lib
+
+
+def make_config(**kw):
+    c = Config()
+    load_lib().tts_c_default_config(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+class Runner:
+    """runner_from_file() + generate(), as examples/cli/cli.cpp:79-95 uses them."""
+
+    def __init__(self, path, n_threads=1, cpu_only=True, **cfg):
+        self.L = load_lib()
+        self.cfg = make_config(**cfg)
+        self.h = self.L.tts_c_runner_from_file(path.encode(), n_threads, C.byref(self.cfg), 1 if cpu_only else 0)
+        if not self.h:
+            raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
+
+    @property
+    def sampling_rate(self):
+        return float(self.L.tts_c_sampling_rate(self.h))
+
+    @property
+    def arch(self):
+        return self.L.tts_c_arch(self.h).decode()
+
+    def generate(self, text, **cfg):
+        c = make_config(**cfg) if cfg else self.cfg
+        data = C.POINTER(C.c_float)()
+        n = C.c_size_t()
+        if self.L.tts_c_generate(self.h, text.encode("utf-8"), C.byref(c), C.byref(data), C.byref(n)) != 0:
+            raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
+        return np.ctypeslib.as_array(data, shape=(n.value,)).copy() if n.value else np.zeros(0, dtype=np.float32)
+
+    def last_tokens(self, which):
+        n = self.L.tts_c_last_tokens(self.h, which, None, 0)
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        self.L.tts_c_last_tokens(self.h, which, out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+        return out[:n]
+
+    def close(self):
+        if self.h:
+            self.L.tts_c_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tokenize(gguf_path, text):
+    L = load_lib()
+    out = np.zeros(4096, dtype=np.uint32)
+    n = L.tts_c_tokenize(gguf_path.encode(), text.encode("utf-8"), out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size)
+    if n < 0:
+        raise RunnerError(L.tts_c_last_error().decode())
+    return out[:n].copy()
