@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import tts_cpp_amd  # noqa: E402,F401
+from tts_cpp_amd import dist as tdist  # noqa: E402
 from tts_cpp_amd import gguf, hip, synth  # noqa: E402
 from tts_cpp_amd.pattern import undelay  # noqa: E402
 
@@ -128,8 +129,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        tdist.init("nccl", rank, world, device=torch.device("cuda", local_rank))
 
     cfg = {"mini": synth.parler_mini, "small": synth.small, "tiny": synth.tiny}[args.model](weight_type=gguf.F16)
     n_audio = min(args.audio_steps, cfg.max_gen - args.prompt_len, cfg.ctx - args.prompt_len)
@@ -146,7 +146,7 @@ def main():
         arena = torch.empty(eng.arena_bytes(), dtype=torch.uint8, device=f"cuda:{local_rank}")
         eng.finalize(external_arena=arena.data_ptr())
         torch.cuda.synchronize()
-        dist.broadcast(arena, src=0)   # RCCL over xGMI: the one collective of the path
+        tdist.broadcast_arena(arena, src=0)   # RCCL over xGMI: the one collective of the path
         torch.cuda.synchronize()
         eng.arena_filled()
     else:
@@ -196,12 +196,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        ns = torch.tensor([n_samples], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(ns, op=dist.ReduceOp.SUM)
-        n_samples = float(ns.item())
+        elapsed, n_samples = tdist.reduce_timing(elapsed, n_samples, device=f"cuda:{local_rank}")
 
     audio_seconds = n_samples / SAMPLE_RATE
     value = audio_seconds / elapsed

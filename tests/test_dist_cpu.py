@@ -1,0 +1,55 @@
+"""world_size-2 gloo tests of the multi-GPU plumbing (weight-arena broadcast, utterance sharding, timing
+reduction) — the N>1 path of bench.py minus the device work."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tts_cpp_amd import dist as tdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init("gloo", rank, world)
+    n = 5_000_003  # not a multiple of the chunk size
+    arena = torch.zeros(n, dtype=torch.uint8)
+    if rank == 0:
+        arena = (torch.arange(n, dtype=torch.int64) * 2654435761 % 251).to(torch.uint8)
+    tdist.broadcast_arena(arena, src=0, chunk_bytes=1 << 20)
+    expect = (torch.arange(n, dtype=torch.int64) * 2654435761 % 251).to(torch.uint8)
+    ok_arena = bool(torch.equal(arena, expect))
+    mine = tdist.shard_utterances(11, rank, world)
+    t, u = tdist.reduce_timing(1.0 + rank, len(mine))
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([ok_arena, t, u] + mine, dtype=np.float64))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_broadcast_shard_reduce(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    seen = []
+    for r in range(world):
+        a = np.load(tmp_path / f"r{r}.npy")
+        assert a[0] == 1.0, "arena differs after broadcast"
+        assert a[1] == 2.0, "timing must be the MAX over ranks"
+        assert a[2] == 11.0, "work units must SUM over ranks"
+        seen += [int(x) for x in a[3:]]
+    assert sorted(seen) == list(range(11)), "utterances must be partitioned exactly once"
+
+
+def test_shard_is_round_robin():
+    assert tdist.shard_utterances(10, 1, 4) == [1, 5, 9]
+    assert sum(len(tdist.shard_utterances(32, r, 8)) for r in range(8)) == 32
