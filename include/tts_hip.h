@@ -155,9 +155,25 @@ int     tts_hip_set_debug(tts_hip_ctx *ctx, int on);
 /* Per-kernel-class timing with HIP events on the context's stream.  While enabled, forwards are
  * launched eagerly and every launch of every class is bracketed by an event pair. */
 enum tts_hip_kclass {
-    TTS_HIP_K_EMBED = 0, TTS_HIP_K_GEMM_LN = 1, TTS_HIP_K_GEMM = 2, TTS_HIP_K_ATTN = 3,
-    TTS_HIP_K_ATTN_CROSS = 4, TTS_HIP_K_HEADS = 5, TTS_HIP_K_DAC_EMBED = 6, TTS_HIP_K_DAC_CONV = 7,
-    TTS_HIP_K_DAC_CONVT = 8, TTS_HIP_K_SAMPLE = 9, TTS_HIP_K_COUNT = 10
+    TTS_HIP_K_EMBED = 0,        /* embed_rows_kernel */
+    TTS_HIP_K_LN = 1,           /* ln_rows_kernel (LayerNorm as its own launch, > 8 rows) */
+    TTS_HIP_K_GEMM_QKV = 2,     /* [LN +] fused q/k/v projection + KV-cache append */
+    TTS_HIP_K_ATTN_SELF = 3,    /* attn_kernel (+ attn_combine_kernel) over the self-attention cache */
+    TTS_HIP_K_GEMM_ATTN_OUT = 4,/* self_attn.out_proj + residual */
+    TTS_HIP_K_GEMM_CROSS_Q = 5, /* [LN +] encoder_attn.q_proj */
+    TTS_HIP_K_ATTN_CROSS = 6,   /* attn_kernel over the voice-prompt K/V */
+    TTS_HIP_K_GEMM_CROSS_OUT = 7,/* encoder_attn.out_proj + residual */
+    TTS_HIP_K_GEMM_FC1 = 8,     /* [LN +] fc1 + GELU */
+    TTS_HIP_K_GEMM_FC2 = 9,     /* fc2 + residual */
+    TTS_HIP_K_GEMM_HEADS = 10,  /* [LN +] 9 lm heads */
+    TTS_HIP_K_SAMPLE = 11,      /* argmax_kernel + feed_kernel */
+    TTS_HIP_K_GEMM_OTHER = 12,  /* cross K/V precompute */
+    TTS_HIP_K_DAC_EMBED = 13,   /* dac_embed_kernel */
+    TTS_HIP_K_DAC_CONV7 = 14,   /* conv1d k=7 (initial + residual units) */
+    TTS_HIP_K_DAC_CONV1 = 15,   /* conv1d k=1 (+ residual add) */
+    TTS_HIP_K_DAC_CONVT = 16,   /* ConvTranspose1d upsampling */
+    TTS_HIP_K_DAC_FINAL = 17,   /* final Cout=1 conv + tanh */
+    TTS_HIP_K_COUNT = 18
 };
 typedef struct tts_hip_kstat {
     double   ms_total;      /* summed event-elapsed time */

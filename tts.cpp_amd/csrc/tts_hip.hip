@@ -210,8 +210,9 @@ struct tts_hip_ctx {
     int attn_nsplit_override = 0;
 };
 
-static const char *KNAMES[TTS_HIP_K_COUNT] = {"embed", "gemm_ln", "gemm", "attn", "attn_cross", "heads",
-                                              "dac_embed", "dac_conv", "dac_convt", "sample"};
+static const char *KNAMES[TTS_HIP_K_COUNT] = {"embed", "ln", "gemm_qkv", "attn_self", "gemm_attn_out", "gemm_cross_q", "attn_cross",
+                                              "gemm_cross_out", "gemm_fc1", "gemm_fc2", "gemm_heads", "sample", "gemm_other",
+                                              "dac_embed", "dac_conv7", "dac_conv1", "dac_convt", "dac_final"};
 extern "C" const char *tts_hip_kclass_name(int k) { return (k >= 0 && k < TTS_HIP_K_COUNT) ? KNAMES[k] : "?"; }
 
 extern "C" int tts_hip_device_count(void) {
@@ -626,7 +627,7 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
         // scalar path: LayerNorm materialised first
         GemmArgs b = a;
         if (pro == PRO_LN) {
-            CHK(prof_begin(c, kclass, 0, 0));
+            CHK(prof_begin(c, TTS_HIP_K_LN, (double) a.R * a.K * 8, 0));
             hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, (const float *) a.A, a.K, a.ln_w, a.ln_b, c->dbg,
                                (_Float16 *) nullptr, a.R);
             HIPCHK(hipGetLastError());
@@ -644,7 +645,7 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
     if (pro == PRO_LN && a.R > c->ln_fuse_max) {
         // many rows: normalise once (one wave per row) instead of once per GEMM workgroup
         const bool h16 = w.type == TTS_HIP_F16;
-        CHK(prof_begin(c, kclass, (double) a.R * a.K * (h16 ? 6 : 8), 0));
+        CHK(prof_begin(c, TTS_HIP_K_LN, (double) a.R * a.K * (h16 ? 6 : 8), 0));
         hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, (const float *) a.A, a.K, a.ln_w, a.ln_b,
                            h16 ? (float *) nullptr : c->dbg, h16 ? c->xn16 : (_Float16 *) nullptr, a.R);
         HIPCHK(hipGetLastError());
@@ -737,17 +738,17 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
         g.vc = (char *) c->vcache + (size_t) l * layer_kv_bytes;
         g.kv_f16 = c->d.kv_type == TTS_HIP_F16;
         g.seq_stride = seq_stride; g.row_seq = c->d_seq; g.row_pos = c->d_pos;
-        CHK(run_gemm(c, TTS_HIP_K_GEMM_LN, y.qkv, g, PRO_LN, EPI_QKV));
+        CHK(run_gemm(c, TTS_HIP_K_GEMM_QKV, y.qkv, g, PRO_LN, EPI_QKV));
 
         AttnArgs at{};
         at.q = c->q; at.kc = g.kc; at.vc = g.vc; at.kv_f16 = g.kv_f16; at.seq_stride = seq_stride;
         at.row_seq = c->d_seq; at.row_pos = c->d_pos; at.H = H; at.n_heads = c->NH;
         at.scale = 1.0f / sqrtf(64.0f); at.out = c->att; at.part = c->part;
-        CHK(run_attn(c, TTS_HIP_K_ATTN, at, R, nsplit, self_kv_bytes));
+        CHK(run_attn(c, TTS_HIP_K_ATTN_SELF, at, R, nsplit, self_kv_bytes));
 
         GemmArgs go{};
         go.R = R; go.H = H; go.A = c->att; go.lda = H; go.out = c->x; go.ldo = H;
-        CHK(run_gemm(c, TTS_HIP_K_GEMM, y.o, go, PRO_F32, EPI_RESID));
+        CHK(run_gemm(c, TTS_HIP_K_GEMM_ATTN_OUT, y.o, go, PRO_F32, EPI_RESID));
 
         // cross attention ------------------------------------------------------------------
         if (c->d.use_cross_attn) {
@@ -755,7 +756,7 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
             gq.R = R; gq.H = H; gq.A = c->x; gq.lda = H;
             gq.ln_w = (const float *) (c->arena + y.ca_w); gq.ln_b = (const float *) (c->arena + y.ca_b);
             gq.out = c->q; gq.ldo = H;
-            CHK(run_gemm(c, TTS_HIP_K_GEMM_LN, y.cq, gq, PRO_LN, EPI_STORE));
+            CHK(run_gemm(c, TTS_HIP_K_GEMM_CROSS_Q, y.cq, gq, PRO_LN, EPI_STORE));
             AttnArgs ac{};
             ac.q = c->q;
             ac.kc = c->arena + c->cross_kv + ((size_t) l * 2 + 0) * c->ECAP * H * 4;
@@ -764,7 +765,7 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
             ac.H = H; ac.n_heads = c->NH; ac.scale = at.scale; ac.out = c->att; ac.part = c->part;
             CHK(run_attn(c, TTS_HIP_K_ATTN_CROSS, ac, R, 1, 2.0 * c->E * H * 4));
             GemmArgs gc = go;
-            CHK(run_gemm(c, TTS_HIP_K_GEMM, y.co, gc, PRO_F32, EPI_RESID));
+            CHK(run_gemm(c, TTS_HIP_K_GEMM_CROSS_OUT, y.co, gc, PRO_F32, EPI_RESID));
         }
 
         // FFN ------------------------------------------------------------------------------
@@ -773,11 +774,11 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
         g1.ln_w = (const float *) (c->arena + y.f_w); g1.ln_b = (const float *) (c->arena + y.f_b);
         const bool u_half = (y.fc2.type == TTS_HIP_F16) && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM) && (c->F % 256 == 0);
         g1.out = c->u32; g1.out16 = u_half ? c->u16 : nullptr; g1.ldo = c->F;
-        CHK(run_gemm(c, TTS_HIP_K_GEMM_LN, y.fc1, g1, PRO_LN, EPI_GELU));
+        CHK(run_gemm(c, TTS_HIP_K_GEMM_FC1, y.fc1, g1, PRO_LN, EPI_GELU));
         GemmArgs g2{};
         g2.R = R; g2.H = H; g2.A = u_half ? (const void *) c->u16 : (const void *) c->u32; g2.lda = c->F;
         g2.out = c->x; g2.ldo = H;
-        CHK(run_gemm(c, TTS_HIP_K_GEMM, y.fc2, g2, u_half ? PRO_F16 : PRO_F32, EPI_RESID));
+        CHK(run_gemm(c, TTS_HIP_K_GEMM_FC2, y.fc2, g2, u_half ? PRO_F16 : PRO_F32, EPI_RESID));
     }
 
     if (want_logits) {
@@ -785,7 +786,7 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
         gh.R = R; gh.H = H; gh.A = c->x; gh.lda = H;
         gh.ln_w = (const float *) (c->arena + c->ln_w); gh.ln_b = (const float *) (c->arena + c->ln_b);
         gh.out = c->logits; gh.ldo = c->NO * c->V;
-        CHK(run_gemm(c, TTS_HIP_K_HEADS, c->heads, gh, PRO_LN, EPI_STORE));
+        CHK(run_gemm(c, TTS_HIP_K_GEMM_HEADS, c->heads, gh, PRO_LN, EPI_STORE));
     }
     return 0;
 }
@@ -802,7 +803,7 @@ static int compute_cross_kv(tts_hip_ctx *c) {
                 g.A = (const float *) (c->arena + c->text_enc) + (size_t) e0 * H; g.lda = H;
                 g.out = (float *) (c->arena + c->cross_kv + ((size_t) l * 2 + kv) * c->ECAP * H * 4) + (size_t) e0 * H;
                 g.ldo = H;
-                CHK(run_gemm(c, TTS_HIP_K_GEMM, kv == 0 ? c->layers[l].ck : c->layers[l].cv, g, PRO_F32, EPI_STORE));
+                CHK(run_gemm(c, TTS_HIP_K_GEMM_OTHER, kv == 0 ? c->layers[l].ck : c->layers[l].cv, g, PRO_F32, EPI_STORE));
             }
         }
     }
@@ -1186,7 +1187,7 @@ static int launch_conv(tts_hip_ctx *c, const float *x, int cin, int L, size_t w,
     a.alpha = has_alpha ? (const float *) (c->arena + alpha) : nullptr;
     a.resid = resid; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.dil = dil; a.pad = pad; a.do_tanh = do_tanh;
     const double bytes = ((double) cin * L + (double) cout * L * (resid ? 2 : 1) + (double) cout * cin * K) * 4;
-    CHK(prof_begin(c, TTS_HIP_K_DAC_CONV, bytes, 2.0 * cout * (double) cin * K * L));
+    CHK(prof_begin(c, cout == 1 ? TTS_HIP_K_DAC_FINAL : (K == 7 ? TTS_HIP_K_DAC_CONV7 : TTS_HIP_K_DAC_CONV1), bytes, 2.0 * cout * (double) cin * K * L));
     const bool valu = (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) != 0;
     int CO_T = 0, CI_T = 0;
     const int cfg = valu ? -1 : conv_tile(cout, K, &CO_T, &CI_T);
