@@ -444,10 +444,13 @@ __device__ __forceinline__ float4v load_kv4(const void *base, int kv_f16, int64_
     return *(const float4v *) ((const float *) base + off);
 }
 
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+// blockDim.x = 16 * NKG threads (NKG key groups of 16 lanes; 16 for 256 threads, 64 for 1024 threads: the
+// wide form keeps a single workgroup per (head,row) fast enough that small batches need no split-T pass).
+__global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NKG = blockDim.x >> 4, NW = blockDim.x >> 6;
     float *sc  = (float *) smem;                 // [chunk]
-    float *red = sc + a.max_T;                   // [16][64] + [16] + [16]
+    float *red = sc + a.max_T;                   // [NKG][64] + [NKG]
     const int h = blockIdx.x, r = blockIdx.y, z = blockIdx.z, nz = gridDim.z;
     const int tid = threadIdx.x, kg = tid >> 4, cl = tid & 15, c4 = cl * 4;
     const int T = a.row_pos ? (int) a.row_pos[r] + 1 : a.T_fixed;
@@ -456,21 +459,22 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int t0 = z * chunk, t1 = min(T, t0 + chunk);
     const int64_t hb = sb + h * 64 + c4;
     const float4v q4 = *(const float4v *) (a.q + (int64_t) r * a.H + h * 64 + c4);
+    const int step = NKG * 4;
 
     // pass 1: scores + running max (4 keys per lane group in flight)
     float lmax = -INFINITY;
-    for (int t = t0 + kg; t < t1; t += 64) {
+    for (int t = t0 + kg; t < t1; t += step) {
         float4v k4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (t + u * 16 < t1) k4[u] = load_kv4(a.kc, a.kv_f16, hb + (int64_t) (t + u * 16) * a.H);
+            if (t + u * NKG < t1) k4[u] = load_kv4(a.kc, a.kv_f16, hb + (int64_t) (t + u * NKG) * a.H);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            if (t + u * 16 < t1) {
+            if (t + u * NKG < t1) {
                 float d = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
                 d += __shfl_xor(d, 8); d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
                 d *= a.scale;  // soft_max_ext(kq, mask, 1/sqrt(d), 0)
-                if (cl == 0) sc[t + u * 16 - t0] = d;
+                if (cl == 0) sc[t + u * NKG - t0] = d;
                 lmax = fmaxf(lmax, d);
             }
         }
@@ -478,35 +482,35 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     lmax = wave_max(lmax);
     if ((tid & 63) == 0) red[tid >> 6] = lmax;
     __syncthreads();
-    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float mx = red[0];
+    for (int i = 1; i < NW; i++) mx = fmaxf(mx, red[i]);
     __syncthreads();
 
     // pass 2: p = exp(s - max), acc += p * V
     float4v acc = {0.f, 0.f, 0.f, 0.f};
     float lsum = 0.0f;
-    for (int t = t0 + kg; t < t1; t += 64) {
+    for (int t = t0 + kg; t < t1; t += step) {
         float4v v4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (t + u * 16 < t1) v4[u] = load_kv4(a.vc, a.kv_f16, hb + (int64_t) (t + u * 16) * a.H);
+            if (t + u * NKG < t1) v4[u] = load_kv4(a.vc, a.kv_f16, hb + (int64_t) (t + u * NKG) * a.H);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            if (t + u * 16 < t1) {
-                const float p = expf(sc[t + u * 16 - t0] - mx);
+            if (t + u * NKG < t1) {
+                const float p = expf(sc[t + u * NKG - t0] - mx);
                 lsum += p;
 #pragma unroll
                 for (int e = 0; e < 4; e++) acc[e] += p * v4[u][e];
             }
         }
     }
-    // reduce over the 16 key groups
+    // reduce over the key groups (fixed order)
     *(float4v *) (red + kg * 64 + c4) = acc;
-    if (cl == 0) red[1024 + kg] = lsum;
+    if (cl == 0) red[NKG * 64 + kg] = lsum;
     __syncthreads();
     if (tid < 64) {
         float o = 0.0f, s = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; i++) { o += red[i * 64 + tid]; s += red[1024 + i]; }
+        for (int i = 0; i < NKG; i++) { o += red[i * 64 + tid]; s += red[NKG * 64 + i]; }
         if (nz == 1) {
             a.out[(int64_t) r * a.H + h * 64 + tid] = o / s;
         } else {

@@ -674,14 +674,17 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
 
 static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, double kv_bytes) {
     a.max_T = (nsplit > 1) ? (c->NCTX + nsplit - 1) / nsplit + 1 : std::max(c->NCTX, c->ECAP);
-    const size_t lds = ((size_t) a.max_T + 1024 + 16) * 4;
+    // few (head,row) pairs: 1024-thread workgroups (64 key groups) instead of a split-T pass + combine launch
+    const bool wide = nsplit == 1 && c->NH * R < 128 && a.row_pos != nullptr;
+    const int threads = wide ? 1024 : 256;
+    const size_t lds = ((size_t) a.max_T + (threads / 16) * 65 + 16) * 4;
     static bool attr = false;
     if (!attr) {
         HIPCHK(hipFuncSetAttribute((const void *) attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     CHK(prof_begin(c, kclass, kv_bytes + 2.0 * R * c->H * 4, 0));
-    hipLaunchKernelGGL(attn_kernel, dim3(c->NH, R, nsplit), dim3(256), lds, c->stream, a);
+    hipLaunchKernelGGL(attn_kernel, dim3(c->NH, R, nsplit), dim3(threads), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     if (nsplit > 1) {
         hipLaunchKernelGGL(attn_combine_kernel, dim3(c->NH, R), dim3(64), 0, c->stream, (const float *) a.part, nsplit, c->H, c->NH, a.out);
@@ -692,9 +695,8 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
 
 static int attn_nsplit(const tts_hip_ctx *c, int R, bool same_seq) {
     if (c->attn_nsplit_override > 0) return std::min(c->attn_nsplit_override, 16);
-    if (same_seq) return 1;  // prompt rows: short T
-    int ns = 128 / (c->NH * R);  // enough workgroups to cover half the chip; more splits only add combine work
-    return std::max(1, std::min(ns, 8));
+    (void) R; (void) same_seq;
+    return 1;  // small batches use 1024-thread workgroups instead (run_attn); split-T stays available via TTS_HIP_ATTN_NSPLIT
 }
 
 // ------------------------------------------------------------------------------------------------
