@@ -446,11 +446,14 @@ __device__ __forceinline__ float4v load_kv4(const void *base, int kv_f16, int64_
 
 // blockDim.x = 16 * NKG threads (NKG key groups of 16 lanes; 16 for 256 threads, 64 for 1024 threads: the
 // wide form keeps a single workgroup per (head,row) fast enough that small batches need no split-T pass).
+// Single pass: the K and V rows of a key are loaded together (one HBM round trip per 4*NKG keys instead of
+// two dependent passes) and folded with a running max / sum per key group; the groups are merged through
+// LDS in a fixed order.  Mathematically soft_max_ext + mul_mat; rounding differs from the two-pass form
+// only in the order of fp32 operations.
 __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int NKG = blockDim.x >> 4, NW = blockDim.x >> 6;
-    float *sc  = (float *) smem;                 // [chunk]
-    float *red = sc + a.max_T;                   // [NKG][64] + [NKG]
+    const int NKG = blockDim.x >> 4;
+    float *red = (float *) smem;                 // [NKG][64] acc, [NKG] max, [NKG] sum
     const int h = blockIdx.x, r = blockIdx.y, z = blockIdx.z, nz = gridDim.z;
     const int tid = threadIdx.x, kg = tid >> 4, cl = tid & 15, c4 = cl * 4;
     const int T = a.row_pos ? (int) a.row_pos[r] + 1 : a.T_fixed;
@@ -461,56 +464,47 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
     const float4v q4 = *(const float4v *) (a.q + (int64_t) r * a.H + h * 64 + c4);
     const int step = NKG * 4;
 
-    // pass 1: scores + running max (4 keys per lane group in flight)
-    float lmax = -INFINITY;
+    float m = -INFINITY, l = 0.0f;
+    float4v acc = {0.f, 0.f, 0.f, 0.f};
     for (int t = t0 + kg; t < t1; t += step) {
-        float4v k4[4];
+        float4v k4[4], v4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (t + u * NKG < t1) k4[u] = load_kv4(a.kc, a.kv_f16, hb + (int64_t) (t + u * NKG) * a.H);
+            if (t + u * NKG < t1) {
+                const int64_t off = hb + (int64_t) (t + u * NKG) * a.H;
+                k4[u] = load_kv4(a.kc, a.kv_f16, off);
+                v4[u] = load_kv4(a.vc, a.kv_f16, off);
+            }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (t + u * NKG < t1) {
                 float d = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
                 d += __shfl_xor(d, 8); d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
                 d *= a.scale;  // soft_max_ext(kq, mask, 1/sqrt(d), 0)
-                if (cl == 0) sc[t + u * NKG - t0] = d;
-                lmax = fmaxf(lmax, d);
+                const float mn = fmaxf(m, d);
+                const float f = expf(m - mn);   // 0 on the first key (m = -inf)
+                const float p = expf(d - mn);
+                l = l * f + p;
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] = acc[e] * f + p * v4[u][e];
+                m = mn;
             }
         }
     }
-    lmax = wave_max(lmax);
-    if ((tid & 63) == 0) red[tid >> 6] = lmax;
+    // merge the key groups
+    if (cl == 0) red[NKG * 64 + kg] = m;
     __syncthreads();
-    float mx = red[0];
-    for (int i = 1; i < NW; i++) mx = fmaxf(mx, red[i]);
-    __syncthreads();
-
-    // pass 2: p = exp(s - max), acc += p * V
-    float4v acc = {0.f, 0.f, 0.f, 0.f};
-    float lsum = 0.0f;
-    for (int t = t0 + kg; t < t1; t += step) {
-        float4v v4[4];
+    float mx = -INFINITY;
+    for (int i = 0; i < NKG; i++) mx = fmaxf(mx, red[NKG * 64 + i]);
+    const float f = (m == -INFINITY) ? 0.0f : expf(m - mx);
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (t + u * NKG < t1) v4[u] = load_kv4(a.vc, a.kv_f16, hb + (int64_t) (t + u * NKG) * a.H);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (t + u * NKG < t1) {
-                const float p = expf(sc[t + u * NKG - t0] - mx);
-                lsum += p;
-#pragma unroll
-                for (int e = 0; e < 4; e++) acc[e] += p * v4[u][e];
-            }
-        }
-    }
-    // reduce over the key groups (fixed order)
+    for (int e = 0; e < 4; e++) acc[e] *= f;
     *(float4v *) (red + kg * 64 + c4) = acc;
-    if (cl == 0) red[NKG * 64 + kg] = lsum;
+    if (cl == 0) red[NKG * 65 + kg] = l * f;
     __syncthreads();
     if (tid < 64) {
         float o = 0.0f, s = 0.0f;
-        for (int i = 0; i < NKG; i++) { o += red[i * 64 + tid]; s += red[NKG * 64 + i]; }
+        for (int i = 0; i < NKG; i++) { o += red[i * 64 + tid]; s += red[NKG * 65 + i]; }
         if (nz == 1) {
             a.out[(int64_t) r * a.H + h * 64 + tid] = o / s;
         } else {

@@ -677,7 +677,7 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
     // few (head,row) pairs: 1024-thread workgroups (64 key groups) instead of a split-T pass + combine launch
     const bool wide = nsplit == 1 && c->NH * R < 128 && a.row_pos != nullptr;
     const int threads = wide ? 1024 : 256;
-    const size_t lds = ((size_t) a.max_T + (threads / 16) * 65 + 16) * 4;
+    const size_t lds = ((size_t) (threads / 16) * 66 + 16) * 4;
     static bool attr = false;
     if (!attr) {
         HIPCHK(hipFuncSetAttribute((const void *) attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
