@@ -138,7 +138,8 @@ def main():
     # ---- weights: rank 0 generates + uploads, everyone else receives the arena over RCCL ------
     t_load = time.perf_counter()
     model = synth.build(cfg, shapes_only=(rank != 0))
-    eng = hip.HipEngine(cfg, device=local_rank, max_seqs=args.batch, kv_type=kv_type)
+    kv_pos = min(cfg.ctx, cfg.max_gen)  # generation stops at position max_generation (check_stopping, model.cpp:720-722)
+    eng = hip.HipEngine(cfg, device=local_rank, max_seqs=args.batch, kv_type=kv_type, kv_positions=kv_pos)
     for t in model.tensors:
         eng.upload(t, declare_only=(rank != 0))
     arena = None
@@ -154,7 +155,7 @@ def main():
     # extra contexts on the same GPU share the finished arena (weights + cross K/V): own stream, own KV cache
     engines = [eng]
     for _ in range(1, args.streams):
-        e2 = hip.HipEngine(cfg, device=local_rank, max_seqs=args.batch, kv_type=kv_type)
+        e2 = hip.HipEngine(cfg, device=local_rank, max_seqs=args.batch, kv_type=kv_type, kv_positions=kv_pos)
         for t in model.tensors:
             e2.upload(t, declare_only=True)
         e2.finalize(external_arena=eng.arena_ptr())

@@ -67,6 +67,9 @@ typedef struct tts_hip_desc {
     uint32_t kv_type;             /* TTS_HIP_F32 (reference, model.h:138-139) or TTS_HIP_F16 */
     uint32_t gelu_mode;           /* 1 = ggml CPU's fp16-table GELU semantics, 0 = fp32 tanh GELU */
     uint32_t flags;               /* TTS_HIP_FLAG_* */
+    uint32_t kv_positions;        /* positions kept per sequence in the self-attention cache; 0 = max_ctx_length
+                                     (reference, model.cpp:368-369).  Generation stops at position
+                                     max_generation (check_stopping, model.cpp:720-722), so max_generation suffices. */
 } tts_hip_desc;
 
 #define TTS_HIP_FLAG_NO_GRAPH   1u  /* launch kernels eagerly instead of replaying a captured hipGraph */

@@ -63,7 +63,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} not exported"
     assert hip.load_lib().tts_hip_version().startswith(b"tts_hip")
-    assert C.sizeof(hip.Desc) == 4 * (1 + 8 + 1 + 16 + 1 + 4)
+    assert C.sizeof(hip.Desc) == 4 * (1 + 8 + 1 + 16 + 1 + 4 + 1)
 
 
 def test_product_path_fails_loudly_without_gpu(have_gpu):

@@ -151,6 +151,32 @@ def test_many_lockstep_sequences_split_layernorm_path(wtype):
     eng.close()
 
 
+def test_large_lockstep_batch_and_kv_position_cap():
+    """80 utterances in one forward: the GEMM walks the rows in groups of 64 with the weights held in
+    registers; device-resident generation == per-sequence oracles; the cache holds kv_positions rows."""
+    model = get_model("tiny", gguf.F16)
+    cfg = model.cfg
+    n, n_steps = 80, 6
+    eng = hip.HipEngine(cfg, max_seqs=n, kv_positions=40)
+    eng.load(model)
+    rng = np.random.default_rng(77)
+    prompts = [rng.integers(3, cfg.prompt_vocab, 2 + (i % 7)).astype(np.uint32) for i in range(n)]
+    for s, p in enumerate(prompts):
+        eng.prefill(s, p)
+    toks, done = eng.generate_greedy([len(p) for p in prompts], n_steps)
+    for s in (0, 15, 16, 63, 64, 79):
+        o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+        ref_toks, ref_logits = o.generate_greedy(prompts[s], n_steps)
+        mism = np.argwhere(toks[:, s, :] != ref_toks)
+        if len(mism):
+            st, hd = mism[0]
+            srt = np.sort(ref_logits[st, hd])
+            assert srt[-1] - srt[-2] < TOL[gguf.F16] * 2 * np.abs(ref_logits[st]).max(), (s, st, hd)
+    with pytest.raises(hip.HipError):
+        eng.step(np.zeros((1, cfg.n_out)), [40])  # beyond the cached positions
+    eng.close()
+
+
 def test_graph_replay_equals_eager_and_greedy_equals_argmax():
     model = get_model("tiny", gguf.F16)
     cfg = model.cfg

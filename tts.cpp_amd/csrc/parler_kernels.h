@@ -241,74 +241,79 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
         __syncthreads();
     }
 
-    // ---- 3. MFMA over this wave's 256-wide K slice ---------------------------------------------
-    float4v acc[RB];
+    // ---- 3-5. for every group of 16*RB rows: MFMA over this wave's 256-wide K slice, reduce the K slices
+    //           across waves, epilogue.  The weight fragments stay in registers across row groups, so many
+    //           lock-step utterances cost one pass over the weights.
+    for (int rg = 0; rg < a.R; rg += 16 * RB) {
+        float4v acc[RB];
 #pragma unroll
-    for (int rb = 0; rb < RB; rb++) acc[rb] = (float4v){0.f, 0.f, 0.f, 0.f};
+        for (int rb = 0; rb < RB; rb++) acc[rb] = (float4v){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-    for (int rb = 0; rb < RB; rb++) {
-        const int r  = rb * 16 + li;
-        const int rr = r < a.R ? r : a.R - 1;
-        if (WT == 1) {
-            const int kb = w * 256 + g * 8;
+        for (int rb = 0; rb < RB; rb++) {
+            const int r  = rg + rb * 16 + li;
+            const int rr = r < a.R ? r : a.R - 1;
+            if (WT == 1) {
+                const int kb = w * 256 + g * 8;
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                half8 b;
-                const int k = kb + c * 32;
-                if (PRO == PRO_LN) {
-                    b = *(const half8 *) (xs16 + (size_t) r * ldx + k);
-                } else if (PRO == PRO_F16) {
-                    b = *(const half8 *) ((const _Float16 *) a.A + (int64_t) rr * a.lda + k);
-                } else {
-                    const float *p = (const float *) a.A + (int64_t) rr * a.lda + k;
-                    const float4v f0 = *(const float4v *) p, f1 = *(const float4v *) (p + 4);
+                for (int c = 0; c < 8; c++) {
+                    half8 b;
+                    const int k = kb + c * 32;
+                    if (PRO == PRO_LN) {
+                        b = *(const half8 *) (xs16 + (size_t) r * ldx + k);
+                    } else if (PRO == PRO_F16) {
+                        b = *(const half8 *) ((const _Float16 *) a.A + (int64_t) rr * a.lda + k);
+                    } else {
+                        const float *p = (const float *) a.A + (int64_t) rr * a.lda + k;
+                        const float4v f0 = *(const float4v *) p, f1 = *(const float4v *) (p + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; e++) { b[e] = (_Float16) f0[e]; b[4 + e] = (_Float16) f1[e]; }
+                        for (int e = 0; e < 4; e++) { b[e] = (_Float16) f0[e]; b[4 + e] = (_Float16) f1[e]; }
+                    }
+                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], b, acc[rb], 0, 0, 0);
                 }
-                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], b, acc[rb], 0, 0, 0);
-            }
-        } else {
-            const int kb = w * 256 + g * 4;
+            } else {
+                const int kb = w * 256 + g * 4;
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                float4v b;
-                const int k = kb + c * 16;
-                if (PRO == PRO_LN) b = *(const float4v *) (xs32 + (size_t) r * ldx + k);
-                else               b = *(const float4v *) ((const float *) a.A + (int64_t) rr * a.lda + k);
+                for (int c = 0; c < 16; c++) {
+                    float4v b;
+                    const int k = kb + c * 16;
+                    if (PRO == PRO_LN) b = *(const float4v *) (xs32 + (size_t) r * ldx + k);
+                    else               b = *(const float4v *) ((const float *) a.A + (int64_t) rr * a.lda + k);
 #pragma unroll
-                for (int e = 0; e < 4; e++)
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], b[e], acc[rb], 0, 0, 0);
+                    for (int e = 0; e < 4; e++)
+                        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][e], b[e], acc[rb], 0, 0, 0);
+                }
             }
         }
-    }
 
-    // ---- 4. reduce the K slices across waves (fixed order: deterministic) -----------------------
-    if (nw > 1) {
-        float *red = (float *) (smem + red_off);  // [nw][RB][4][64]
-#pragma unroll
-        for (int rb = 0; rb < RB; rb++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) red[((w * RB + rb) * 4 + e) * 64 + lane] = acc[rb][e];
-        __syncthreads();
-        if (w == 0) {
+        // reduce the K slices across waves (fixed order: deterministic)
+        if (nw > 1) {
+            float *red = (float *) (smem + red_off);  // [nw][RB][4][64]
+            if (rg > 0) __syncthreads();              // previous group's partials have been consumed
 #pragma unroll
             for (int rb = 0; rb < RB; rb++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float s = red[((0 * RB + rb) * 4 + e) * 64 + lane];
-                    for (int ww = 1; ww < nw; ww++) s += red[((ww * RB + rb) * 4 + e) * 64 + lane];
-                    acc[rb][e] = s;
-                }
-        }
-    }
-
-    // ---- 5. epilogue: D[feature = g*4+e][row = li] ---------------------------------------------
-    if (w == 0) {
+                for (int e = 0; e < 4; e++) red[((w * RB + rb) * 4 + e) * 64 + lane] = acc[rb][e];
+            __syncthreads();
+            if (w == 0) {
 #pragma unroll
-        for (int rb = 0; rb < RB; rb++) {
-            const int r = rb * 16 + li;
-            if (r < a.R) gemm_epilogue4(a, EPI, r, n0 + g * 4, acc[rb]);
+                for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float s = red[((0 * RB + rb) * 4 + e) * 64 + lane];
+                        for (int ww = 1; ww < nw; ww++) s += red[((ww * RB + rb) * 4 + e) * 64 + lane];
+                        acc[rb][e] = s;
+                    }
+            }
+        }
+
+        // epilogue: D[feature = g*4+e][row = li]
+        if (w == 0) {
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) {
+                const int r = rg + rb * 16 + li;
+                if (r < a.R) gemm_epilogue4(a, EPI, r, n0 + g * 4, acc[rb]);
+            }
         }
     }
 }
@@ -577,7 +582,7 @@ struct FeedArgs {
     const uint32_t *tokens;   // [R][n_out] argmax of this step
     uint32_t *ids;            // [R][n_out] next step's input ids (in/out)
     uint32_t *row_pos;        // [R]
-    uint32_t *step;           // [1] current_step of the step that just ran (>= 1), incremented here
+    uint32_t *row_step;       // [R] current_step of the step that just ran (>= 1), incremented here
     uint8_t  *eos_seen;       // [R][n_out]
     uint32_t *steps_done;     // [R] number of audio steps after which check_stopping() would return true (0 = not yet)
     uint32_t *tokens_out;     // [n_steps][R][n_out]
@@ -585,26 +590,26 @@ struct FeedArgs {
     uint32_t bos, eos;
 };
 
+// one 64-thread workgroup per row
 __global__ void feed_kernel(FeedArgs a) {
-    __shared__ int all_seen[64];
-    const uint32_t step = *a.step;
-    const int tid = threadIdx.x;
-    if (tid < a.R) all_seen[tid] = 1;
+    __shared__ int not_seen;
+    const int r = blockIdx.x, hd = threadIdx.x;
+    const uint32_t step = a.row_step[r];
+    if (hd == 0) not_seen = 0;
     __syncthreads();
-    if (tid < a.R * a.n_out) {
-        const int r = tid / a.n_out, hd = tid - r * a.n_out;
-        const uint32_t tok = a.tokens[tid];
+    if (hd < a.n_out) {
+        const int idx = r * a.n_out + hd;
+        const uint32_t tok = a.tokens[idx];
         a.tokens_out[((int64_t) (step - 1) * a.R + r) * a.n_out + hd] = tok;
-        const uint8_t seen = a.eos_seen[tid] | (tok == a.eos ? 1 : 0);
-        a.eos_seen[tid] = seen;
-        a.ids[tid] = ((int) step > hd) ? (seen ? a.eos : tok) : a.bos;
-        if (!seen) atomicAnd(&all_seen[r], 0);
+        const uint8_t seen = a.eos_seen[idx] | (tok == a.eos ? 1 : 0);
+        a.eos_seen[idx] = seen;
+        a.ids[idx] = ((int) step > hd) ? (seen ? a.eos : tok) : a.bos;
+        if (!seen) atomicOr(&not_seen, 1);
     }
     __syncthreads();
-    if (tid < a.R) {
-        a.row_pos[tid] += 1;
-        if (all_seen[tid] && a.steps_done[tid] == 0) a.steps_done[tid] = step;
+    if (hd == 0) {
+        a.row_pos[r] += 1;
+        a.row_step[r] = step + 1;
+        if (!not_seen && a.steps_done[r] == 0) a.steps_done[r] = step;
     }
-    __syncthreads();
-    if (tid == 0) *a.step = step + 1;
 }

@@ -165,7 +165,7 @@ struct tts_hip_ctx {
     std::vector<CopyItem> copies;
 
     // parler model
-    int H = 0, L = 0, NH = 0, F = 0, V = 0, NO = 0, NCTX = 0, E = 0, ECAP = 0, PV = 0, EROWS = 0, NPOS = 0;
+    int H = 0, L = 0, NH = 0, F = 0, V = 0, NO = 0, NCTX = 0, E = 0, ECAP = 0, PV = 0, EROWS = 0, NPOS = 0, KVPOS = 0;
     W embed_prompts, embed_tokens, heads;
     size_t pos_embed = 0, text_enc = 0, ln_w = 0, ln_b = 0, cross_kv = 0;
     std::vector<PLayer> layers;
@@ -394,6 +394,7 @@ static int plan(tts_hip_ctx *c) {
     if (c->has_parler) {
         c->H = d.hidden_size; c->L = d.n_layers; c->NH = d.n_attn_heads; c->NO = d.n_output_heads;
         c->V = d.output_vocab_size; c->NCTX = d.max_ctx_length; c->E = d.n_encode_length;
+        c->KVPOS = d.kv_positions ? (int) std::min<uint32_t>(d.kv_positions, d.max_ctx_length) : (int) d.max_ctx_length;
         if (c->H <= 0 || c->L <= 0 || c->NH <= 0 || c->NO <= 0 || c->V <= 0 || c->NCTX <= 0) return set_err("plan: incomplete Parler hyper-parameters in desc");
         if (c->H / c->NH != 64 || c->H % c->NH) return set_err("plan: head size %d unsupported (kernels are specialised for 64, Parler-Mini/Large)", c->H / c->NH);
         if (c->H % 16 || c->V % 16) return set_err("plan: hidden size and vocab must be multiples of 16");
@@ -600,19 +601,11 @@ template <int WT, int PRO, int EPI>
 static int launch_gemm16_rb(tts_hip_ctx *c, const GemmArgs &a) {
     if (a.R <= 16) return launch_gemm16<WT, PRO, EPI, 1>(c, a);
     if (a.R <= 32) return launch_gemm16<WT, PRO, EPI, 2>(c, a);
-    if (WT == 1 || PRO != PRO_LN) {
-        if (a.R <= 64) return launch_gemm16<WT, PRO, EPI, 4>(c, a);
-    }
-    return set_err("gemm16: %d rows exceed the per-launch maximum", a.R);
+    if (PRO == PRO_LN && (WT == 0 || a.R > 64)) return set_err("gemm16: %d rows with a fused LayerNorm prologue do not fit LDS", a.R);
+    return launch_gemm16<WT, PRO, EPI, 4>(c, a);  // loops over groups of 64 rows, weights stay in registers
 }
 
-static int max_rows_for(const tts_hip_ctx *c) {
-    // fp32 LN tiles of 64 rows do not fit LDS; fp16 ones do
-    bool any_f32 = false;
-    for (auto &l : c->layers) if (l.qkv.type == TTS_HIP_F32 || l.fc1.type == TTS_HIP_F32) any_f32 = true;
-    if (c->heads.type == TTS_HIP_F32) any_f32 = true;
-    return any_f32 ? 32 : 64;
-}
+static int max_rows_for(const tts_hip_ctx *) { return 256; }
 
 // one GEMM of the forward: picks MFMA or the scalar reference path
 static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi) {
@@ -642,7 +635,7 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
         HIPCHK(hipGetLastError());
         return prof_end(c);
     }
-    if (pro == PRO_LN && a.R > c->ln_fuse_max) {
+    if (pro == PRO_LN && (a.R > c->ln_fuse_max || (w.type != TTS_HIP_F16 && a.R > 32) || a.R > 64)) {
         // many rows: normalise once (one wave per row) instead of once per GEMM workgroup
         const bool h16 = w.type == TTS_HIP_F16;
         CHK(prof_begin(c, TTS_HIP_K_LN, (double) a.R * a.K * (h16 ? 6 : 8), 0));
@@ -704,7 +697,7 @@ static int attn_nsplit(const tts_hip_ctx *c, int R, bool same_seq) {
 // ------------------------------------------------------------------------------------------------
 static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, bool same_seq) {
     const int H = c->H;
-    const int64_t seq_stride = (int64_t) c->NCTX * H;
+    const int64_t seq_stride = (int64_t) c->KVPOS * H;
     const size_t kv_esz = c->d.kv_type == TTS_HIP_F16 ? 2 : 4;
     const size_t layer_kv_bytes = (size_t) c->d.max_seqs * seq_stride * kv_esz;
 
@@ -844,9 +837,9 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         const int H = c->H;
         c->RMAX = std::max(max_rows_for(c), 1);
         if ((int) c->d.max_seqs > c->RMAX) return set_err("max_seqs=%u exceeds the %d rows one forward can carry with these weight types", c->d.max_seqs, c->RMAX);
-        if ((int) c->d.max_seqs > 64) return set_err("max_seqs > 64 unsupported");
+        if ((int) c->d.max_seqs > 256) return set_err("max_seqs > 256 unsupported");
         const size_t kv_esz = c->d.kv_type == TTS_HIP_F16 ? 2 : 4;
-        const size_t kvb = (size_t) c->L * c->d.max_seqs * c->NCTX * H * kv_esz;
+        const size_t kvb = (size_t) c->L * c->d.max_seqs * c->KVPOS * H * kv_esz;
         HIPCHK(hipMalloc(&c->kcache, kvb));
         HIPCHK(hipMalloc(&c->vcache, kvb));
         HIPCHK(hipMemset(c->kcache, 0, kvb));  // ggml_backend_buffer_clear(buf, 0), model.cpp:381
@@ -865,7 +858,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->d_pos, (size_t) R));
         CHK(dmalloc(&c->d_seq, (size_t) R));
         CHK(dmalloc(&c->d_tok, (size_t) R * c->NO));
-        CHK(dmalloc(&c->d_step, (size_t) 1));
+        CHK(dmalloc(&c->d_step, (size_t) R));
         CHK(dmalloc(&c->d_steps_done, (size_t) R));
         CHK(dmalloc(&c->d_eos, (size_t) R * c->NO));
         HIPCHK(hipHostMalloc((void **) &c->h_ids, (size_t) R * c->NO * 4));
@@ -929,7 +922,7 @@ extern "C" int tts_hip_parler_reset(tts_hip_ctx *c) {
 extern "C" int tts_hip_parler_prefill(tts_hip_ctx *c, uint32_t seq, const uint32_t *ids, uint32_t n, uint32_t pos0) {
     CHK(ready(c, "tts_hip_parler_prefill"));
     if (seq >= c->d.max_seqs) return set_err("prefill: seq %u >= max_seqs %u", seq, c->d.max_seqs);
-    if (pos0 + n > (uint32_t) c->NCTX || pos0 + n > (uint32_t) c->NPOS) return set_err("prefill: positions %u..%u exceed context %d", pos0, pos0 + n, c->NCTX);
+    if (pos0 + n > (uint32_t) c->KVPOS || pos0 + n > (uint32_t) c->NPOS) return set_err("prefill: positions %u..%u exceed the %d cached positions", pos0, pos0 + n, c->KVPOS);
     for (uint32_t i = 0; i < n; i++) if (ids[i] >= (uint32_t) c->PV) return set_err("prefill: text id %u >= prompt vocab %d", ids[i], c->PV);
     for (uint32_t o = 0; o < n; o += c->RMAX) {
         const int R = (int) std::min<uint32_t>(c->RMAX, n - o);
@@ -957,7 +950,7 @@ static int stage_step_inputs(tts_hip_ctx *c, uint32_t n, const uint32_t *ids, co
     for (uint32_t r = 0; r < n; r++) {
         const uint32_t s = seqs ? seqs[r] : r;
         if (s >= c->d.max_seqs) return set_err("step: seq %u >= max_seqs %u", s, c->d.max_seqs);
-        if (pos[r] >= (uint32_t) c->NCTX || pos[r] >= (uint32_t) c->NPOS) return set_err("step: position %u exceeds context %d", pos[r], c->NCTX);
+        if (pos[r] >= (uint32_t) c->KVPOS || pos[r] >= (uint32_t) c->NPOS) return set_err("step: position %u exceeds the %d cached positions", pos[r], c->KVPOS);
         for (int i = 0; i < c->NO; i++) {
             const uint32_t id = ids[r * c->NO + i];
             if (id >= (uint32_t) c->EROWS) return set_err("step: audio id %u >= embedding rows %d", id, c->EROWS);
@@ -986,9 +979,9 @@ static int enqueue_step_body(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint
         HIPCHK(hipGetLastError());
         if (mode == MODE_GEN) {
             FeedArgs f{};
-            f.tokens = c->d_tok; f.ids = c->d_ids; f.row_pos = c->d_pos; f.step = c->d_step; f.eos_seen = c->d_eos;
+            f.tokens = c->d_tok; f.ids = c->d_ids; f.row_pos = c->d_pos; f.row_step = c->d_step; f.eos_seen = c->d_eos;
             f.steps_done = c->d_steps_done; f.tokens_out = c->d_tokens_out; f.R = R; f.n_out = c->NO; f.bos = bos; f.eos = eos;
-            hipLaunchKernelGGL(feed_kernel, dim3(1), dim3(1024), 0, c->stream, f);
+            hipLaunchKernelGGL(feed_kernel, dim3(R), dim3(64), 0, c->stream, f);
             HIPCHK(hipGetLastError());
         }
         CHK(prof_end(c));
@@ -1048,8 +1041,8 @@ extern "C" int tts_hip_parler_generate_greedy(tts_hip_ctx *c, uint32_t n, const 
     if (bos >= (uint32_t) c->EROWS || eos >= (uint32_t) c->EROWS) return set_err("generate_greedy: bos/eos outside the embedding table");
     c->host_pos.resize(n);
     for (uint32_t r = 0; r < n; r++) {
-        if (start_pos[r] + n_steps > (uint32_t) c->NCTX || start_pos[r] + n_steps > (uint32_t) c->NPOS)
-            return set_err("generate_greedy: sequence %u would exceed the context (%u + %u > %d)", r, start_pos[r], n_steps, c->NCTX);
+        if (start_pos[r] + n_steps > (uint32_t) c->KVPOS || start_pos[r] + n_steps > (uint32_t) c->NPOS)
+            return set_err("generate_greedy: sequence %u would exceed the cached positions (%u + %u > %d)", r, start_pos[r], n_steps, c->KVPOS);
         for (int i = 0; i < c->NO; i++) c->h_ids[r * c->NO + i] = bos;  // model.cpp:781 with current_step == 0
         c->h_pos[r] = start_pos[r];
         c->h_seq[r] = r;
@@ -1068,11 +1061,11 @@ extern "C" int tts_hip_parler_generate_greedy(tts_hip_ctx *c, uint32_t n, const 
         }
         (void) it;
     }
-    const uint32_t one = 1;
+    for (uint32_t r = 0; r < n; r++) c->h_tok[r] = 1;  // current_step of the first audio decode (model.cpp:783-785)
     HIPCHK(hipMemcpyAsync(c->d_ids, c->h_ids, (size_t) n * c->NO * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_pos, c->h_pos, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_seq, c->h_seq, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_step, &one, 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_step, c->h_tok, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->d_eos, 0, (size_t) n * c->NO, c->stream));
     HIPCHK(hipMemsetAsync(c->d_steps_done, 0, (size_t) n * 4, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1350,10 +1343,10 @@ extern "C" int64_t tts_hip_debug_read(tts_hip_ctx *c, const char *what, float *o
             set_err("debug_read(%s): bad layer/seq", what);
             return -1;
         }
-        const size_t n = std::min(max_floats / c->H, (size_t) c->NCTX) * c->H;
+        const size_t n = std::min(max_floats / c->H, (size_t) c->KVPOS) * c->H;
         const size_t kv_esz = c->d.kv_type == TTS_HIP_F16 ? 2 : 4;
         const char *base = (const char *) (w[0] == 'k' ? c->kcache : c->vcache) +
-                           ((size_t) layer * c->d.max_seqs + seq) * (size_t) c->NCTX * c->H * kv_esz;
+                           ((size_t) layer * c->d.max_seqs + seq) * (size_t) c->KVPOS * c->H * kv_esz;
         if (kv_esz == 4) {
             if (hipMemcpy(out, base, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("copy failed"); return -1; }
         } else {

@@ -32,6 +32,7 @@ class Desc(C.Structure):
         ("dac_stride", C.c_uint32 * MAX_DAC_BLOCKS), ("dac_padding", C.c_uint32 * MAX_DAC_BLOCKS),
         ("dac_max_frames", C.c_uint32),
         ("max_seqs", C.c_uint32), ("kv_type", C.c_uint32), ("gelu_mode", C.c_uint32), ("flags", C.c_uint32),
+        ("kv_positions", C.c_uint32),
     ]
 
 
@@ -108,7 +109,7 @@ class HipEngine:
     """One device context holding a Parler decoder and/or a DAC codec."""
 
     def __init__(self, cfg, device=0, max_seqs=1, kv_type=gguf.F32, gelu_mode=1, flags=0, use_cross_attn=True,
-                 n_encode_length=None):
+                 n_encode_length=None, kv_positions=0):
         self.L = load_lib()
         self.cfg = cfg
         d = Desc()
@@ -122,6 +123,7 @@ class HipEngine:
             d.dac_stride[i], d.dac_padding[i] = s, p
         d.dac_max_frames = cfg.max_gen
         d.max_seqs, d.kv_type, d.gelu_mode, d.flags = max_seqs, kv_type, gelu_mode, flags
+        d.kv_positions = kv_positions
         self.desc = d
         self.max_seqs = max_seqs
         self.ctx = self.L.tts_hip_create(device, C.byref(d))

@@ -75,6 +75,7 @@ parler_runner::parler_runner(const parler_hparams & hp_, unigram_tokenizer * tok
     d.max_seqs = 1;
     d.kv_type = getenv("TTS_HIP_KV_F16") ? TTS_HIP_F16 : TTS_HIP_F32;
     d.gelu_mode = 1;
+    d.kv_positions = 0;  // reference layout: max_ctx_length positions (model.cpp:368-369)
     ctx = tts_hip_create(device, &d);
     if (!ctx) TTS_ABORT("tts_hip_create failed: %s\n", tts_hip_last_error());
     smp.n_output_heads = hp.n_output_heads;
