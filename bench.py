@@ -44,19 +44,18 @@ def make_prompts(cfg, batch, prompt_len, rank):
     return [np.concatenate([rng.integers(3, cfg.prompt_vocab, prompt_len - 1), [1]]).astype(np.uint32) for _ in range(batch)]
 
 
-def run_utterance_batch(eng, cfg, prompts, n_audio, timings=None):
+def run_utterance_batch(eng, cfg, prompts, n_audio, timings=None, dac_group=16):
     """one bench step; returns total PCM samples produced"""
     t0 = time.perf_counter()
-    for s, p in enumerate(prompts):
-        eng.prefill(s, p)
+    eng.prefill_batch(prompts)
     t1 = time.perf_counter()
     toks, _ = eng.generate_greedy([len(p) for p in prompts], n_audio)
     t2 = time.perf_counter()
+    frames = [undelay(toks[:, s, :], cfg.audio_vocab) for s in range(len(prompts))]
     n_samples = 0
-    for s in range(len(prompts)):
-        frames = undelay(toks[:, s, :], cfg.audio_vocab)
-        if len(frames):
-            pcm = eng.dac_decode(frames)
+    group = max(1, dac_group)
+    for g in range(0, len(frames), group):  # DAC for `group` utterances per pass (bounds the activation buffers)
+        for pcm in eng.dac_decode_batch(frames[g:g + group]):
             n_samples += pcm.size
     t3 = time.perf_counter()
     if timings is not None:

@@ -119,6 +119,10 @@ int tts_hip_parler_reset(tts_hip_ctx *ctx);
  * The prompt logits are never consumed by the reference (sampler only runs on audio steps,
  * model.cpp:774-776), so none are produced. */
 int tts_hip_parler_prefill(tts_hip_ctx *ctx, uint32_t seq, const uint32_t *text_ids, uint32_t n, uint32_t pos0);
+/* The same for n sequences in as few forwards as possible (extension): ids = the prompts concatenated, lens[n];
+ * seqs[n] (NULL = 0..n-1) and pos0[n] (NULL = all 0).  Equivalent to n tts_hip_parler_prefill calls. */
+int tts_hip_parler_prefill_batch(tts_hip_ctx *ctx, uint32_t n, const uint32_t *seqs, const uint32_t *text_ids,
+                                 const uint32_t *lens, const uint32_t *pos0);
 /* decode() with audio_generation=true for n_seqs sequences in lock-step:
  *   ids   [n_seqs][n_output_heads]  codebook ids fed this step (model.cpp:394-403,778-785)
  *   pos   [n_seqs]                  absolute position of each sequence (model.cpp:784)
@@ -146,6 +150,10 @@ int tts_hip_parler_generate_greedy(tts_hip_ctx *ctx, uint32_t n_seqs, const uint
 /* dac_runner::run (dac_model.cpp:172-212): codes [frames][n_output_heads] (frame-major),
  * pcm_out: frames * prod(strides) fp32 samples in host memory.  Blocks until done. */
 int tts_hip_dac_decode(tts_hip_ctx *ctx, const uint32_t *codes, uint32_t frames, float *pcm_out);
+/* The same for n utterances in one pass (extension; the reference decodes one utterance per dac_runner::run).
+ * codes: the utterances' code frames concatenated [sum(frames)][n_output_heads]; frames[n]; pcm_out: the PCM of
+ * the utterances concatenated (frames[i] * prod(strides) samples each).  Results are identical to n single calls. */
+int tts_hip_dac_decode_batch(tts_hip_ctx *ctx, const uint32_t *codes, const uint32_t *frames, uint32_t n, float *pcm_out);
 
 /* ---- introspection (tests, bench) -------------------------------------------------------- */
 /* Copy an internal buffer to the host.  what: "hidden" (final-normed hidden of the last forward,

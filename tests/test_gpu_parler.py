@@ -177,6 +177,26 @@ def test_large_lockstep_batch_and_kv_position_cap():
     eng.close()
 
 
+def test_batched_prefill_equals_sequential_prefill():
+    model = get_model("tiny", gguf.F16)
+    cfg = model.cfg
+    rng = np.random.default_rng(31)
+    prompts = [rng.integers(3, cfg.prompt_vocab, 1 + (i * 5) % 13).astype(np.uint32) for i in range(9)]
+    outs = []
+    for batched in (True, False):
+        eng = hip.HipEngine(cfg, max_seqs=len(prompts))
+        eng.load(model)
+        if batched:
+            eng.prefill_batch(prompts)
+        else:
+            for s, p in enumerate(prompts):
+                eng.prefill(s, p)
+        ids = np.full((len(prompts), cfg.n_out), cfg.bos, dtype=np.uint32)
+        outs.append(eng.step(ids, [len(p) for p in prompts]))
+        eng.close()
+    assert relerr(outs[0], outs[1]) < 1e-5
+
+
 def test_graph_replay_equals_eager_and_greedy_equals_argmax():
     model = get_model("tiny", gguf.F16)
     cfg = model.cfg

@@ -27,7 +27,8 @@ __device__ __forceinline__ float snake_f(float x, float alpha, float ralpha) {
 // quantizer: out[c][t] = sum_i ( b_i[c] + sum_d W_i[c][d] * codebook_i[code[t][i]][d] )
 // ------------------------------------------------------------------------------------------------
 struct DacEmbedArgs {
-    const uint32_t *codes;  // [T][n_cb]
+    const uint32_t *frames; // [n] valid frames per utterance (grid.z), or NULL
+    const uint32_t *codes;  // [n][T][n_cb]
     const float *codebook;  // [n_cb][cb_size][cb_dim]
     const float *proj_w;    // [n_cb][latent][cb_dim]
     const float *proj_b;    // [n_cb][latent]
@@ -37,11 +38,12 @@ struct DacEmbedArgs {
 
 __global__ void dac_embed_kernel(DacEmbedArgs a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = blockIdx.y;
-    if (t >= a.T) return;
+    const int c = blockIdx.y, z = blockIdx.z;
+    const int Tz = a.frames ? (int) a.frames[z] : a.T;
+    if (t >= Tz) return;
     float total = 0.0f;
     for (int i = 0; i < a.n_cb; i++) {
-        const uint32_t code = a.codes[(int64_t) t * a.n_cb + i];
+        const uint32_t code = a.codes[((int64_t) z * a.T + t) * a.n_cb + i];
         const float *cb = a.codebook + ((int64_t) i * a.cb_size + code) * a.cb_dim;
         const float *w = a.proj_w + ((int64_t) i * a.latent + c) * a.cb_dim;
         float acc = 0.0f;
@@ -49,7 +51,7 @@ __global__ void dac_embed_kernel(DacEmbedArgs a) {
         acc += a.proj_b[i * a.latent + c];
         total = (i == 0) ? acc : (total + acc);
     }
-    a.out[(int64_t) c * a.T + t] = total;
+    a.out[((int64_t) z * a.latent + c) * a.T + t] = total;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -59,14 +61,21 @@ __global__ void dac_embed_kernel(DacEmbedArgs a) {
 // input channels staged through LDS 8 at a time.
 // ------------------------------------------------------------------------------------------------
 struct ConvArgs {
-    const float *x;      // [cin][L]
+    const float *x;      // [n][cin][L]
     const float *w;      // [cout][cin][K]
     const float *b;      // [cout]
     const float *alpha;  // [cin] snake on the input, or NULL
-    const float *resid;  // [cout][L] or NULL
-    float *y;            // [cout][L]
-    int cin, cout, L, dil, pad, do_tanh;
+    const float *resid;  // [n][cout][L] or NULL
+    float *y;            // [n][cout][L]
+    int cin, cout, L, dil, pad, do_tanh;   // L = row stride (longest utterance of the batch at this stage)
+    const uint32_t *frames;  // [n] valid frames per utterance (grid.z) or NULL; valid length = frames[z] * mult
+    int mult;
+    const float *alpha_out;  // [cout] snake applied to the OUTPUT (the next layer's snake_1d, fused here), or NULL
 };
+
+__device__ __forceinline__ int valid_len(const uint32_t *frames, int mult, int L) {
+    return frames ? (int) frames[blockIdx.z] * mult : L;
+}
 
 #define CV_CO 64
 #define CV_T  64
@@ -82,6 +91,11 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * CV_T, co0 = blockIdx.y * CV_CO;
     const int tt = (tid & 15) * 4, tc = (tid >> 4) * 4;  // thread's 4 positions / 4 channels
+    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    if (t0 >= L) return;
+    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * LS;
+    float *yg = a.y + (int64_t) blockIdx.z * a.cout * LS;
+    const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * LS : nullptr;
 
     float acc[4][4];
 #pragma unroll
@@ -97,8 +111,8 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
             const int t = t0 + p - a.pad;
             const int cig = ci0 + ci;
             float v = 0.0f;
-            if (cig < a.cin && t >= 0 && t < a.L) {
-                v = a.x[(int64_t) cig * a.L + t];
+            if (cig < a.cin && t >= 0 && t < L) {
+                v = xg[(int64_t) cig * LS + t];
                 if (a.alpha) { const float al = a.alpha[cig]; v = snake_f(v, al, 1.0f / al); }
             }
             xs[i] = v;
@@ -138,11 +152,12 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int t = t0 + tt + j;
-            if (t >= a.L) continue;
+            if (t >= L) continue;
             float v = acc[i][j] + bias;
-            if (a.resid) v = v + a.resid[(int64_t) co * a.L + t];
+            if (rg) v = v + rg[(int64_t) co * LS + t];
+            if (a.alpha_out) { const float al = a.alpha_out[co]; v = snake_f(v, al, 1.0f / al); }
             if (a.do_tanh) v = tanhf(v);
-            a.y[(int64_t) co * a.L + t] = v;
+            yg[(int64_t) co * LS + t] = v;
         }
     }
 }
@@ -154,12 +169,14 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
 // Tile: 64 output channels x 64 output positions per workgroup, 4x4 per thread.
 // ------------------------------------------------------------------------------------------------
 struct ConvTArgs {
-    const float *x;      // [cin][L]
+    const float *x;      // [n][cin][L]
     const float *w;      // [cin][cout][2s]
     const float *b;      // [cout]
     const float *alpha;  // [cin] snake on the input
-    float *y;            // [cout][Lout]
-    int cin, cout, L, Lout, stride, pad;
+    float *y;            // [n][cout][Lout]
+    int cin, cout, L, Lout, stride, pad;   // L / Lout = row strides
+    const uint32_t *frames;  // per-utterance frames (grid.z) or NULL; valid input length = frames[z] * mult
+    int mult;
 };
 
 #define CT_CI 8
@@ -174,6 +191,11 @@ __global__ __launch_bounds__(256) void convt1d_kernel(ConvTArgs a) {
     float *ws = xs + CT_CI * xw;                        // [CT_CI][K][CV_CO]
     const int tid = threadIdx.x;
     const int tt = (tid & 15) * 4, tc = (tid >> 4) * 4;
+    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    const int LoS = a.Lout, Lout = a.frames ? (L - 1) * s - 2 * a.pad + K : a.Lout;
+    if (to0 >= Lout) return;
+    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * LS;
+    float *yg = a.y + (int64_t) blockIdx.z * a.cout * LoS;
 
     float acc[4][4];
 #pragma unroll
@@ -195,8 +217,8 @@ __global__ __launch_bounds__(256) void convt1d_kernel(ConvTArgs a) {
             const int ci = i / xw, p = i - ci * xw;
             const int ti = ti_lo + p, cig = ci0 + ci;
             float v = 0.0f;
-            if (cig < a.cin && ti >= 0 && ti < a.L) {
-                v = a.x[(int64_t) cig * a.L + ti];
+            if (cig < a.cin && ti >= 0 && ti < L) {
+                v = xg[(int64_t) cig * LS + ti];
                 if (a.alpha) { const float al = a.alpha[cig]; v = snake_f(v, al, 1.0f / al); }
             }
             xs[i] = v;
@@ -231,8 +253,8 @@ __global__ __launch_bounds__(256) void convt1d_kernel(ConvTArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int to = to0 + tt + j;
-            if (to >= a.Lout) continue;
-            a.y[(int64_t) co * a.Lout + to] = acc[i][j] + bias;
+            if (to >= Lout) continue;
+            yg[(int64_t) co * LoS + to] = acc[i][j] + bias;
         }
     }
 }
@@ -294,9 +316,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
     const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T;
     const int n_chunks = (a.cin + CI_T - 1) / CI_T;
     const int cin_pad = n_chunks * CI_T;
-    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * a.L;
-    float *yg = a.y + (int64_t) blockIdx.z * a.cout * a.L;
-    const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * a.L : nullptr;
+    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    if (t0 >= L) return;  // whole workgroup past the end of this (shorter) utterance
+    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * LS;
+    float *yg = a.y + (int64_t) blockIdx.z * a.cout * LS;
+    const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * LS : nullptr;
     const float4d *wg = (const float4d *) (a.w + (int64_t) blockIdx.y * n_chunks * WCH);
 
     if (a.alpha) {
@@ -331,7 +355,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
             if (i < CI_T * xw) {
                 const int ci = i / xw, p = i - ci * xw;
                 const int t = t0 + p - a.pad, cig = c * CI_T + ci;
-                if (cig < a.cin && t >= 0 && t < a.L) v = xg[(int64_t) cig * a.L + t];
+                if (cig < a.cin && t >= 0 && t < L) v = xg[(int64_t) cig * LS + t];
             }
             xreg[j] = v;
         }
@@ -392,14 +416,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
             const int co = co0 + (wm * MI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
             if (co >= a.cout) continue;
             const float bias = a.b ? a.b[co] : 0.0f;
+            const float al_o = a.alpha_out ? a.alpha_out[co] : 1.0f, ral_o = 1.0f / al_o;
 #pragma unroll
             for (int j = 0; j < NI; j++) {
                 const int t = t0 + (wn * NI + j) * 32 + l31;
-                if (t >= a.L) continue;
+                if (t >= L) continue;
                 float v = acc[i][j][e] + bias;
-                if (rg) v = v + rg[(int64_t) co * a.L + t];
+                if (rg) v = v + rg[(int64_t) co * LS + t];
+                if (a.alpha_out) v = snake_f(v, al_o, ral_o);
                 if (a.do_tanh) v = tanhf(v);
-                yg[(int64_t) co * a.L + t] = v;
+                yg[(int64_t) co * LS + t] = v;
             }
         }
     }
@@ -428,8 +454,11 @@ __global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma_kernel(ConvTArgs a)
     const int ti0 = blockIdx.x * TI_T, co0 = blockIdx.y * CO_T;
     const int n_chunks = (a.cin + CI_T - 1) / CI_T;
     const int cin_pad = n_chunks * CI_T;
-    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * a.L;
-    float *yg = a.y + (int64_t) blockIdx.z * a.cout * a.Lout;
+    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    const int LoS = a.Lout, Lout = a.frames ? (L - 1) * S - 2 * a.pad + K2 : a.Lout;
+    if (ti0 > L) return;  // ti runs 0..L inclusive
+    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * LS;
+    float *yg = a.y + (int64_t) blockIdx.z * a.cout * LoS;
     const float4d *wg = (const float4d *) (a.w + (int64_t) blockIdx.y * n_chunks * WCH);
 
     if (a.alpha) {
@@ -464,7 +493,7 @@ __global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma_kernel(ConvTArgs a)
             if (i < CI_T * xw) {
                 const int ci = i / xw, p = i - ci * xw;
                 const int ti = ti0 - 1 + p, cig = c * CI_T + ci;
-                if (cig < a.cin && ti >= 0 && ti < a.L) v = xg[(int64_t) cig * a.L + ti];
+                if (cig < a.cin && ti >= 0 && ti < L) v = xg[(int64_t) cig * LS + ti];
             }
             xreg[j] = v;
         }
@@ -526,7 +555,7 @@ __global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma_kernel(ConvTArgs a)
 #pragma unroll
             for (int ph = 0; ph < S; ph++) {
                 const int to = ti * S + ph - a.pad;
-                if (to >= 0 && to < a.Lout) yg[(int64_t) co * a.Lout + to] = acc[i][ph][e] + bias;
+                if (to >= 0 && to < Lout) yg[(int64_t) co * LoS + to] = acc[i][ph][e] + bias;
             }
         }
     }
@@ -540,8 +569,10 @@ __global__ __launch_bounds__(256) void conv1d_cout1_kernel(ConvArgs a) {
     __shared__ float xs[C1_CI][C1_T + 8];
     __shared__ float wsm[C1_CI][8];
     const int tid = threadIdx.x, t0 = blockIdx.x * C1_T;
-    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * a.L;
-    float *yg = a.y + (int64_t) blockIdx.z * a.L;
+    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    if (t0 >= L) return;
+    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * LS;
+    float *yg = a.y + (int64_t) blockIdx.z * LS;
     float acc = 0.0f;
     for (int ci0 = 0; ci0 < a.cin; ci0 += C1_CI) {
         __syncthreads();
@@ -549,8 +580,8 @@ __global__ __launch_bounds__(256) void conv1d_cout1_kernel(ConvArgs a) {
             const int ci = i / (C1_T + 6), p = i - ci * (C1_T + 6);
             const int t = t0 + p - a.pad, cig = ci0 + ci;
             float v = 0.0f;
-            if (cig < a.cin && t >= 0 && t < a.L) {
-                v = xg[(int64_t) cig * a.L + t];
+            if (cig < a.cin && t >= 0 && t < L) {
+                v = xg[(int64_t) cig * LS + t];
                 if (a.alpha) { const float al = a.alpha[cig]; v = snake_f(v, al, 1.0f / al); }
             }
             xs[ci][p] = v;
@@ -566,7 +597,7 @@ __global__ __launch_bounds__(256) void conv1d_cout1_kernel(ConvArgs a) {
             for (int k = 0; k < 7; k++) acc += wsm[ci][k] * xs[ci][tid + k];
     }
     const int t = t0 + tid;
-    if (t < a.L) {
+    if (t < L) {
         float v = acc + (a.b ? a.b[0] : 0.0f);
         if (a.do_tanh) v = tanhf(v);
         yg[t] = v;

@@ -192,8 +192,11 @@ struct tts_hip_ctx {
 
     // dac buffers
     float *dbuf[3] = {nullptr, nullptr, nullptr};
-    size_t dbuf_elems = 0;
-    uint32_t *d_codes = nullptr;
+    size_t dbuf_elems = 0;       // capacity of each buffer in floats
+    size_t dac_frame_elems = 0;  // largest activation per frame over all stages (C * L / frames)
+    size_t dac_cap_frames = 0;   // frames (summed over a batch, padded to the longest) the buffers hold
+    uint32_t *d_codes = nullptr, *d_frames = nullptr;
+    size_t d_frames_cap = 0;
     float *h_pcm = nullptr;
     bool debug = false;
     std::map<int, std::vector<float>> dac_dbg;
@@ -254,7 +257,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
     free_dev(c->u16); free_dev(c->xn16); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
     free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
-    free_dev(c->d_eos); free_dev(c->d_codes);
+    free_dev(c->d_eos); free_dev(c->d_codes); free_dev(c->d_frames);
     for (int i = 0; i < 3; i++) free_dev(c->dbuf[i]);
     for (auto &pw : c->packed) free_dev(pw.second);
     if (c->h_ids) (void) hipHostFree(c->h_ids);
@@ -868,15 +871,10 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         HIPCHK(hipHostMalloc((void **) &c->h_logits, (size_t) R * c->NO * c->V * 4));
     }
     if (c->has_dac) {
-        // largest activation: C * L over all stages, for dac_max_frames frames
-        const size_t T = std::max<uint32_t>(c->d.dac_max_frames, 1);
-        size_t mx = (size_t) std::max(c->d_latent, c->d_c0) * T;
-        size_t Lc = T;
-        for (auto &b : c->dblocks) { Lc *= b.stride; mx = std::max(mx, (size_t) b.cout * Lc); mx = std::max(mx, (size_t) b.cin * (Lc / b.stride)); }
-        c->dbuf_elems = mx;
-        for (int i = 0; i < 3; i++) HIPCHK(hipMalloc((void **) &c->dbuf[i], mx * 4));
-        HIPCHK(hipMalloc((void **) &c->d_codes, T * c->d_ncb * 4));
-        HIPCHK(hipHostMalloc((void **) &c->h_pcm, T * c->d_up * 4));
+        // largest activation per frame over all stages (C * L / frames)
+        size_t mx = (size_t) std::max(c->d_latent, c->d_c0), up = 1;
+        for (auto &b : c->dblocks) { mx = std::max(mx, (size_t) b.cin * up); up *= b.stride; mx = std::max(mx, (size_t) b.cout * up); }
+        c->dac_frame_elems = mx;
     }
     c->finalized = true;
     if (c->weights_present) CHK(compute_cross_kv(c));
@@ -938,6 +936,39 @@ extern "C" int tts_hip_parler_prefill(tts_hip_ctx *c, uint32_t seq, const uint32
         HIPCHK(hipMemcpyAsync(c->d_seq, c->h_seq, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
         CHK(enqueue_forward(c, R, /*audio=*/false, /*logits=*/false, /*same_seq=*/true));
         HIPCHK(hipStreamSynchronize(c->stream));  // staging buffers are reused by the next chunk
+    }
+    return 0;
+}
+
+extern "C" int tts_hip_parler_prefill_batch(tts_hip_ctx *c, uint32_t n, const uint32_t *seqs, const uint32_t *ids,
+                                            const uint32_t *lens, const uint32_t *pos0) {
+    CHK(ready(c, "tts_hip_parler_prefill_batch"));
+    if (!ids || !lens) return set_err("prefill_batch: null argument");
+    // flatten to rows (seq, position, id); rows of one sequence stay in order, a forward carries up to RMAX rows
+    std::vector<uint32_t> rs, rp, ri;
+    size_t off = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t s = seqs ? seqs[i] : i, p0 = pos0 ? pos0[i] : 0;
+        if (s >= c->d.max_seqs) return set_err("prefill_batch: seq %u >= max_seqs %u", s, c->d.max_seqs);
+        if (p0 + lens[i] > (uint32_t) c->KVPOS || p0 + lens[i] > (uint32_t) c->NPOS)
+            return set_err("prefill_batch: positions %u..%u exceed the %d cached positions", p0, p0 + lens[i], c->KVPOS);
+        for (uint32_t j = 0; j < lens[i]; j++) {
+            if (ids[off + j] >= (uint32_t) c->PV) return set_err("prefill_batch: text id %u >= prompt vocab %d", ids[off + j], c->PV);
+            rs.push_back(s); rp.push_back(p0 + j); ri.push_back(ids[off + j]);
+        }
+        off += lens[i];
+    }
+    for (size_t o = 0; o < rs.size(); o += (size_t) c->RMAX) {
+        const int R = (int) std::min<size_t>((size_t) c->RMAX, rs.size() - o);
+        c->host_pos.resize(R);
+        for (int r = 0; r < R; r++) {
+            c->h_ids[r] = ri[o + r]; c->h_pos[r] = rp[o + r]; c->h_seq[r] = rs[o + r]; c->host_pos[r] = rp[o + r];
+        }
+        HIPCHK(hipMemcpyAsync(c->d_ids, c->h_ids, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_pos, c->h_pos, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_seq, c->h_seq, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+        CHK(enqueue_forward(c, R, /*audio=*/false, /*logits=*/false, /*same_seq=*/false));
+        HIPCHK(hipStreamSynchronize(c->stream));
     }
     return 0;
 }
@@ -1158,7 +1189,7 @@ static int ensure_packed(tts_hip_ctx *c) {
 }
 
 template <int KT, int MI, int NI, int WM, int WN, int CI_T>
-static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a) {
+static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a, int nz) {
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WCH = KT * CI_T * CO_T;
     const int xw = T_T + (KT - 1) * a.dil;
     const int cin_pad = (a.cin + CI_T - 1) / CI_T * CI_T;
@@ -1169,37 +1200,48 @@ static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a) {
         HIPCHK(hipFuncSetAttribute((const void *) conv1d_mfma_kernel<KT, MI, NI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    const dim3 grid((a.L + T_T - 1) / T_T, (a.cout + CO_T - 1) / CO_T, 1);
+    const dim3 grid((a.L + T_T - 1) / T_T, (a.cout + CO_T - 1) / CO_T, nz);
     hipLaunchKernelGGL((conv1d_mfma_kernel<KT, MI, NI, WM, WN, CI_T>), grid, dim3(64 * WM * WN), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-static int launch_conv(tts_hip_ctx *c, const float *x, int cin, int L, size_t w, size_t b, size_t alpha, bool has_alpha,
-                       int cout, int K, int pad, int dil, const float *resid, bool do_tanh, float *y) {
+struct DacBatch {
+    int n = 1;                  // utterances (grid.z)
+    const uint32_t *frames = nullptr;  // device [n]
+    int mult = 1;               // valid length at this stage = frames[z] * mult
+    double tot_frames = 0;      // sum of frames (for flop/byte accounting)
+};
+
+static int launch_conv(tts_hip_ctx *c, const DacBatch &bt, const float *x, int cin, int L, size_t w, size_t b, size_t alpha, bool has_alpha,
+                       int cout, int K, int pad, int dil, const float *resid, bool do_tanh, float *y, size_t alpha_out = 0,
+                       bool has_alpha_out = false) {
     ConvArgs a{};
     a.x = x; a.w = (const float *) (c->arena + w); a.b = (const float *) (c->arena + b);
     a.alpha = has_alpha ? (const float *) (c->arena + alpha) : nullptr;
+    a.alpha_out = has_alpha_out ? (const float *) (c->arena + alpha_out) : nullptr;
     a.resid = resid; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.dil = dil; a.pad = pad; a.do_tanh = do_tanh;
-    const double bytes = ((double) cin * L + (double) cout * L * (resid ? 2 : 1) + (double) cout * cin * K) * 4;
-    CHK(prof_begin(c, cout == 1 ? TTS_HIP_K_DAC_FINAL : (K == 7 ? TTS_HIP_K_DAC_CONV7 : TTS_HIP_K_DAC_CONV1), bytes, 2.0 * cout * (double) cin * K * L));
+    a.frames = bt.frames; a.mult = bt.mult;
+    const double Lv = bt.tot_frames * bt.mult;  // valid positions over the batch
+    const double bytes = ((double) cin * Lv + (double) cout * Lv * (resid ? 2 : 1) + (double) cout * cin * K) * 4;
+    CHK(prof_begin(c, cout == 1 ? TTS_HIP_K_DAC_FINAL : (K == 7 ? TTS_HIP_K_DAC_CONV7 : TTS_HIP_K_DAC_CONV1), bytes, 2.0 * cout * (double) cin * K * Lv));
     const bool valu = (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) != 0;
     int CO_T = 0, CI_T = 0;
     const int cfg = valu ? -1 : conv_tile(cout, K, &CO_T, &CI_T);
     auto pk = c->packed.find(w);
     if (!valu && cout == 1 && K == 7) {
-        hipLaunchKernelGGL(conv1d_cout1_kernel, dim3((L + C1_T - 1) / C1_T, 1, 1), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(conv1d_cout1_kernel, dim3((L + C1_T - 1) / C1_T, 1, bt.n), dim3(256), 0, c->stream, a);
         HIPCHK(hipGetLastError());
     } else if (cfg >= 0 && pk != c->packed.end()) {
         a.w = pk->second;
-        if (K == 7 && cfg == 0) CHK((launch_conv_mfma<7, 2, 2, 2, 2, 8>(c, a)));
-        else if (K == 7 && cfg == 1) CHK((launch_conv_mfma<7, 3, 2, 1, 4, 8>(c, a)));
-        else if (K == 7 && cfg == 2) CHK((launch_conv_mfma<7, 2, 2, 1, 4, 8>(c, a)));
-        else if (K == 1 && cfg == 0) CHK((launch_conv_mfma<1, 2, 2, 2, 2, 32>(c, a)));
-        else if (K == 1 && cfg == 1) CHK((launch_conv_mfma<1, 3, 2, 1, 4, 32>(c, a)));
-        else CHK((launch_conv_mfma<1, 2, 2, 1, 4, 32>(c, a)));
+        if (K == 7 && cfg == 0) CHK((launch_conv_mfma<7, 2, 2, 2, 2, 8>(c, a, bt.n)));
+        else if (K == 7 && cfg == 1) CHK((launch_conv_mfma<7, 3, 2, 1, 4, 8>(c, a, bt.n)));
+        else if (K == 7 && cfg == 2) CHK((launch_conv_mfma<7, 2, 2, 1, 4, 8>(c, a, bt.n)));
+        else if (K == 1 && cfg == 0) CHK((launch_conv_mfma<1, 2, 2, 2, 2, 32>(c, a, bt.n)));
+        else if (K == 1 && cfg == 1) CHK((launch_conv_mfma<1, 3, 2, 1, 4, 32>(c, a, bt.n)));
+        else CHK((launch_conv_mfma<1, 2, 2, 1, 4, 32>(c, a, bt.n)));
     } else {
-        const dim3 grid((L + CV_T - 1) / CV_T, (cout + CV_CO - 1) / CV_CO);
+        const dim3 grid((L + CV_T - 1) / CV_T, (cout + CV_CO - 1) / CV_CO, bt.n);
         const size_t lds = ((size_t) CV_CI * (CV_T + (K - 1) * dil) + (size_t) CV_CI * K * CV_CO) * 4;
         if (K == 7) hipLaunchKernelGGL(conv1d_kernel<7>, grid, dim3(256), lds, c->stream, a);
         else if (K == 1) hipLaunchKernelGGL(conv1d_kernel<1>, grid, dim3(256), lds, c->stream, a);
@@ -1210,7 +1252,7 @@ static int launch_conv(tts_hip_ctx *c, const float *x, int cin, int L, size_t w,
 }
 
 template <int S, int MI, int WM, int WN, int CI_T>
-static int launch_convt_mfma(tts_hip_ctx *c, const ConvTArgs &a) {
+static int launch_convt_mfma(tts_hip_ctx *c, const ConvTArgs &a, int nz) {
     constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN, WCH = CI_T * 2 * S * CO_T;
     const int cin_pad = (a.cin + CI_T - 1) / CI_T * CI_T;
     const size_t lds = ((size_t) 2 * WCH + 2 * (size_t) ((CI_T * (TI_T + 1) + 3) & ~3) + (a.alpha ? 2 * (size_t) cin_pad : 0)) * 4;
@@ -1219,13 +1261,13 @@ static int launch_convt_mfma(tts_hip_ctx *c, const ConvTArgs &a) {
         HIPCHK(hipFuncSetAttribute((const void *) convt1d_mfma_kernel<S, MI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    const dim3 grid((a.L + 1 + TI_T - 1) / TI_T, (a.cout + CO_T - 1) / CO_T, 1);  // ti runs 0..L inclusive
+    const dim3 grid((a.L + 1 + TI_T - 1) / TI_T, (a.cout + CO_T - 1) / CO_T, nz);  // ti runs 0..L inclusive
     hipLaunchKernelGGL((convt1d_mfma_kernel<S, MI, WM, WN, CI_T>), grid, dim3(64 * WM * WN), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-static int launch_convt(tts_hip_ctx *c, ConvTArgs ta, size_t w_off) {
+static int launch_convt(tts_hip_ctx *c, ConvTArgs ta, size_t w_off, int nz) {
     const bool valu = (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) != 0;
     const int s = ta.stride;
     int CO_T = 0;
@@ -1233,46 +1275,83 @@ static int launch_convt(tts_hip_ctx *c, ConvTArgs ta, size_t w_off) {
     auto pk = c->packed.find(w_off);
     if (cfg >= 0 && pk != c->packed.end()) {
         ta.w = pk->second;
-        if (cfg == 0) return launch_convt_mfma<8, 1, 2, 2, 8>(c, ta);
-        if (cfg == 1) return launch_convt_mfma<4, 2, 1, 4, 8>(c, ta);
-        if (cfg == 2) return launch_convt_mfma<2, 3, 1, 4, 8>(c, ta);
-        return launch_convt_mfma<2, 2, 1, 4, 8>(c, ta);
+        if (cfg == 0) return launch_convt_mfma<8, 1, 2, 2, 8>(c, ta, nz);
+        if (cfg == 1) return launch_convt_mfma<4, 2, 1, 4, 8>(c, ta, nz);
+        if (cfg == 2) return launch_convt_mfma<2, 3, 1, 4, 8>(c, ta, nz);
+        return launch_convt_mfma<2, 2, 1, 4, 8>(c, ta, nz);
     }
-    const dim3 grid((ta.Lout + CV_T - 1) / CV_T, (ta.cout + CV_CO - 1) / CV_CO);
+    const dim3 grid((ta.Lout + CV_T - 1) / CV_T, (ta.cout + CV_CO - 1) / CV_CO, nz);
     const size_t lds = ((size_t) CT_CI * ((CV_T + s - 1) / s + 2) + (size_t) CT_CI * 2 * s * CV_CO) * 4;
     hipLaunchKernelGGL(convt1d_kernel, grid, dim3(256), lds, c->stream, ta);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-extern "C" int tts_hip_dac_decode(tts_hip_ctx *c, const uint32_t *codes, uint32_t frames, float *pcm_out) {
+// dac_runner::run for n utterances at once (grid.z = utterance, per-utterance lengths): the early blocks have
+// few positions per utterance, so batching is what fills the 256 CUs there.
+static int dac_decode_batch(tts_hip_ctx *c, const uint32_t *codes, const uint32_t *frames, uint32_t n, float *pcm_out) {
     if (!c || !c->finalized || !c->has_dac) return set_err("tts_hip_dac_decode: context has no finalized DAC");
     if (!c->weights_present) return set_err("tts_hip_dac_decode: weights not present");
-    if (!codes || !pcm_out) return set_err("tts_hip_dac_decode: null argument");
-    if (frames == 0) return 0;  // empty response (cli.cpp:87-90 treats n_outputs==0 as the soft failure)
-    if (frames > c->d.dac_max_frames) return set_err("tts_hip_dac_decode: %u frames > max %u", frames, c->d.dac_max_frames);
+    if (!codes || !pcm_out || !frames) return set_err("tts_hip_dac_decode: null argument");
     HIPCHK(hipSetDevice(c->device));
-    for (size_t i = 0; i < (size_t) frames * c->d_ncb; i++)
+    uint32_t Fmax = 0;
+    size_t tot = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (frames[i] > c->d.dac_max_frames) return set_err("tts_hip_dac_decode: %u frames > max %u", frames[i], c->d.dac_max_frames);
+        Fmax = std::max(Fmax, frames[i]);
+        tot += frames[i];
+    }
+    if (Fmax == 0) return 0;  // empty response (cli.cpp:87-90 treats n_outputs==0 as the soft failure)
+    for (size_t i = 0; i < tot * c->d_ncb; i++)
         if (codes[i] >= (uint32_t) c->d_cbsize) return set_err("tts_hip_dac_decode: code %u >= codebook size %d", codes[i], c->d_cbsize);
     c->dac_dbg.clear();
     CHK(ensure_packed(c));
-    HIPCHK(hipMemcpyAsync(c->d_codes, codes, (size_t) frames * c->d_ncb * 4, hipMemcpyHostToDevice, c->stream));
-    int L = (int) frames;
+    // buffers: n utterances padded to the longest
+    const size_t need_frames = (size_t) n * Fmax;
+    if (need_frames > c->dac_cap_frames) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < 3; i++) { free_dev(c->dbuf[i]); c->dbuf[i] = nullptr; }
+        free_dev(c->d_codes); c->d_codes = nullptr;
+        if (c->h_pcm) { (void) hipHostFree(c->h_pcm); c->h_pcm = nullptr; }
+        c->dbuf_elems = c->dac_frame_elems * need_frames;
+        for (int i = 0; i < 3; i++) HIPCHK(hipMalloc((void **) &c->dbuf[i], c->dbuf_elems * 4));
+        HIPCHK(hipMalloc((void **) &c->d_codes, need_frames * c->d_ncb * 4));
+        HIPCHK(hipHostMalloc((void **) &c->h_pcm, need_frames * c->d_up * 4));
+        c->dac_cap_frames = need_frames;
+    }
+    if (n > c->d_frames_cap) {
+        free_dev(c->d_frames);
+        HIPCHK(hipMalloc((void **) &c->d_frames, (size_t) n * 4));
+        c->d_frames_cap = n;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_frames, frames, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+    {   // codes padded to [n][Fmax][n_cb]
+        size_t off = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            if (frames[i]) HIPCHK(hipMemcpyAsync(c->d_codes + (size_t) i * Fmax * c->d_ncb, codes + off * c->d_ncb, (size_t) frames[i] * c->d_ncb * 4,
+                                                 hipMemcpyHostToDevice, c->stream));
+            off += frames[i];
+        }
+    }
+    DacBatch bt;
+    bt.n = (int) n; bt.frames = c->d_frames; bt.mult = 1; bt.tot_frames = (double) tot;
+    int L = (int) Fmax;
     float *cur = c->dbuf[0], *t1 = c->dbuf[1], *t2 = c->dbuf[2];
 
     DacEmbedArgs ea{};
+    ea.frames = c->d_frames;
     ea.codes = c->d_codes; ea.codebook = (const float *) (c->arena + c->d_codebook); ea.proj_w = (const float *) (c->arena + c->d_projw);
     ea.proj_b = (const float *) (c->arena + c->d_projb); ea.n_cb = c->d_ncb; ea.cb_size = c->d_cbsize; ea.cb_dim = c->d_cbdim;
     ea.latent = c->d_latent; ea.T = L; ea.out = cur;
-    CHK(prof_begin(c, TTS_HIP_K_DAC_EMBED, (double) c->d_latent * L * 4, 2.0 * c->d_latent * L * c->d_ncb * c->d_cbdim));
-    hipLaunchKernelGGL(dac_embed_kernel, dim3((L + 63) / 64, c->d_latent), dim3(64), 0, c->stream, ea);
+    CHK(prof_begin(c, TTS_HIP_K_DAC_EMBED, (double) c->d_latent * tot * 4, 2.0 * c->d_latent * tot * c->d_ncb * c->d_cbdim));
+    hipLaunchKernelGGL(dac_embed_kernel, dim3((L + 63) / 64, c->d_latent, n), dim3(64), 0, c->stream, ea);
     HIPCHK(hipGetLastError());
     CHK(prof_end(c));
-    CHK(dac_snapshot(c, 0, cur, (size_t) c->d_latent * L));
+    if (n == 1) CHK(dac_snapshot(c, 0, cur, (size_t) c->d_latent * L));
 
-    CHK(launch_conv(c, cur, c->d_latent, L, c->d_initw, c->d_initb, 0, false, c->d_c0, 7, 3, 1, nullptr, false, t1));
+    CHK(launch_conv(c, bt, cur, c->d_latent, L, c->d_initw, c->d_initb, 0, false, c->d_c0, 7, 3, 1, nullptr, false, t1));
     std::swap(cur, t1);
-    CHK(dac_snapshot(c, 1, cur, (size_t) c->d_c0 * L));
+    if (n == 1) CHK(dac_snapshot(c, 1, cur, (size_t) c->d_c0 * L));
 
     int C = c->d_c0;
     for (size_t bi = 0; bi < c->dblocks.size(); bi++) {
@@ -1281,26 +1360,45 @@ extern "C" int tts_hip_dac_decode(tts_hip_ctx *c, const uint32_t *codes, uint32_
         ta.x = cur; ta.w = (const float *) (c->arena + b.w); ta.b = (const float *) (c->arena + b.b);
         ta.alpha = (const float *) (c->arena + b.alpha); ta.y = t1; ta.cin = b.cin; ta.cout = b.cout; ta.L = L;
         ta.Lout = (L - 1) * b.stride - 2 * b.padding + 2 * b.stride; ta.stride = b.stride; ta.pad = b.padding;
-        CHK(prof_begin(c, TTS_HIP_K_DAC_CONVT, ((double) b.cin * L + (double) b.cout * ta.Lout + (double) b.cin * b.cout * 2 * b.stride) * 4,
-                       2.0 * b.cin * (double) b.cout * 2 * ta.Lout));
-        CHK(launch_convt(c, ta, b.w));
+        ta.frames = c->d_frames; ta.mult = bt.mult;
+        const double Lov = bt.tot_frames * bt.mult * b.stride;
+        CHK(prof_begin(c, TTS_HIP_K_DAC_CONVT, ((double) b.cin * bt.tot_frames * bt.mult + (double) b.cout * Lov + (double) b.cin * b.cout * 2 * b.stride) * 4,
+                       2.0 * b.cin * (double) b.cout * 2 * Lov));
+        CHK(launch_convt(c, ta, b.w, (int) n));
         CHK(prof_end(c));
         std::swap(cur, t1);
         L = ta.Lout; C = b.cout;
+        bt.mult *= b.stride;
         for (int r = 0; r < 3; r++) {  // build_residual_unit: dilation 3^r, padding 3^(r+1) (gnac.h:44-48)
             int dil = 1;
             for (int e = 0; e < r; e++) dil *= 3;
-            CHK(launch_conv(c, cur, C, L, b.res[r].in_w, b.res[r].in_b, b.res[r].in_alpha, true, C, 7, 3 * dil, dil, nullptr, false, t1));
-            CHK(launch_conv(c, t1, C, L, b.res[r].out_w, b.res[r].out_b, b.res[r].out_alpha, true, C, 1, 0, 1, cur, false, t2));
+            // snake(out_alpha) of the k=1 conv's input is applied in the k=7 conv's epilogue (same arithmetic, once
+            // per element instead of once per output-channel tile)
+            CHK(launch_conv(c, bt, cur, C, L, b.res[r].in_w, b.res[r].in_b, b.res[r].in_alpha, true, C, 7, 3 * dil, dil, nullptr, false, t1,
+                            b.res[r].out_alpha, true));
+            CHK(launch_conv(c, bt, t1, C, L, b.res[r].out_w, b.res[r].out_b, 0, false, C, 1, 0, 1, cur, false, t2));
             std::swap(cur, t2);
         }
-        CHK(dac_snapshot(c, 2 + (int) bi, cur, (size_t) C * L));
+        if (n == 1) CHK(dac_snapshot(c, 2 + (int) bi, cur, (size_t) C * L));
     }
-    CHK(launch_conv(c, cur, C, L, c->d_fw, c->d_fb, c->d_falpha, true, 1, 7, 3, 1, nullptr, true, t1));
-    HIPCHK(hipMemcpyAsync(c->h_pcm, t1, (size_t) L * 4, hipMemcpyDeviceToHost, c->stream));
+    CHK(launch_conv(c, bt, cur, C, L, c->d_fw, c->d_fb, c->d_falpha, true, 1, 7, 3, 1, nullptr, true, t1));
+    HIPCHK(hipMemcpyAsync(c->h_pcm, t1, (size_t) n * L * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    memcpy(pcm_out, c->h_pcm, (size_t) L * 4);
+    size_t off = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        memcpy(pcm_out + off, c->h_pcm + (size_t) i * L, (size_t) frames[i] * c->d_up * 4);
+        off += (size_t) frames[i] * c->d_up;
+    }
     return 0;
+}
+
+extern "C" int tts_hip_dac_decode(tts_hip_ctx *c, const uint32_t *codes, uint32_t frames, float *pcm_out) {
+    return dac_decode_batch(c, codes, &frames, 1, pcm_out);
+}
+
+extern "C" int tts_hip_dac_decode_batch(tts_hip_ctx *c, const uint32_t *codes, const uint32_t *frames, uint32_t n, float *pcm_out) {
+    if (n == 0) return 0;
+    return dac_decode_batch(c, codes, frames, n, pcm_out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -43,8 +43,8 @@ class KStat(C.Structure):
 EXPORTS = [
     "tts_hip_device_count", "tts_hip_create", "tts_hip_destroy", "tts_hip_last_error", "tts_hip_version",
     "tts_hip_upload", "tts_hip_arena_bytes", "tts_hip_finalize", "tts_hip_arena_ptr", "tts_hip_arena_filled",
-    "tts_hip_parler_set_text_encoding", "tts_hip_parler_reset", "tts_hip_parler_prefill", "tts_hip_parler_step",
-    "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_dac_decode", "tts_hip_debug_read",
+    "tts_hip_parler_set_text_encoding", "tts_hip_parler_reset", "tts_hip_parler_prefill", "tts_hip_parler_prefill_batch", "tts_hip_parler_step",
+    "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
     "tts_hip_synchronize",
 ]
@@ -82,10 +82,12 @@ def load_lib():
     L.tts_hip_parler_set_text_encoding.argtypes = [vp, f32p, C.c_uint32]
     L.tts_hip_parler_reset.argtypes = [vp]
     L.tts_hip_parler_prefill.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32]
+    L.tts_hip_parler_prefill_batch.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, u32p]
     L.tts_hip_parler_step.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, f32p]
     L.tts_hip_parler_step_greedy.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, u32p]
     L.tts_hip_parler_generate_greedy.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
     L.tts_hip_dac_decode.argtypes = [vp, u32p, C.c_uint32, f32p]
+    L.tts_hip_dac_decode_batch.argtypes = [vp, u32p, u32p, C.c_uint32, f32p]
     L.tts_hip_debug_read.argtypes = [vp, C.c_char_p, f32p, C.c_size_t]
     L.tts_hip_debug_read.restype = C.c_int64
     L.tts_hip_set_debug.argtypes = [vp, C.c_int]
@@ -189,6 +191,13 @@ class HipEngine:
         a, p = _u32(ids)
         self._chk(self.L.tts_hip_parler_prefill(self.ctx, seq, p, len(a), pos0))
 
+    def prefill_batch(self, prompts):
+        """prompts: list of id arrays, sequence i -> cache slot i, positions from 0"""
+        lens = np.array([len(p) for p in prompts], dtype=np.uint32)
+        cat, cp = _u32(np.concatenate([np.asarray(p, dtype=np.uint32) for p in prompts]))
+        l, lp = _u32(lens)
+        self._chk(self.L.tts_hip_parler_prefill_batch(self.ctx, len(prompts), None, cp, lp, None))
+
     def step(self, ids, pos, seqs=None):
         """ids [n][n_out], pos [n] -> logits [n][n_out][V]"""
         a, ap = _u32(ids)
@@ -229,6 +238,19 @@ class HipEngine:
         out = np.empty(frames * self.cfg.hop, dtype=np.float32)
         self._chk(self.L.tts_hip_dac_decode(self.ctx, ap, frames, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
+
+    def dac_decode_batch(self, codes_list):
+        """codes_list: list of [frames_i][n_out] arrays -> list of PCM arrays"""
+        frames = np.array([len(np.asarray(c).reshape(-1, self.cfg.n_out)) for c in codes_list], dtype=np.uint32)
+        if frames.sum() == 0:
+            return [np.zeros(0, dtype=np.float32) for _ in codes_list]
+        cat = np.concatenate([np.asarray(c, dtype=np.uint32).reshape(-1, self.cfg.n_out) for c in codes_list])
+        a, ap = _u32(cat)
+        f, fp = _u32(frames)
+        out = np.empty(int(frames.sum()) * self.cfg.hop, dtype=np.float32)
+        self._chk(self.L.tts_hip_dac_decode_batch(self.ctx, ap, fp, len(frames), out.ctypes.data_as(C.POINTER(C.c_float))))
+        offs = np.concatenate([[0], np.cumsum(frames.astype(np.int64) * self.cfg.hop)])
+        return [out[offs[i]:offs[i + 1]] for i in range(len(frames))]
 
     # ---- introspection ------------------------------------------------------------------------
     def set_debug(self, on=True):
