@@ -286,7 +286,9 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
             }
         }
 
-        // reduce the K slices across waves (fixed order: deterministic)
+        // reduce the K slices across waves (fixed order: deterministic) and run the epilogue; the row blocks
+        // of the group are spread over the waves (wave w owns row blocks w, w+nw, ...) so that neither the
+        // reduction nor the scattered epilogue stores serialise on one wave
         if (nw > 1) {
             float *red = (float *) (smem + red_off);  // [nw][RB][4][64]
             if (rg > 0) __syncthreads();              // previous group's partials have been consumed
@@ -295,20 +297,20 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) red[((w * RB + rb) * 4 + e) * 64 + lane] = acc[rb][e];
             __syncthreads();
-            if (w == 0) {
 #pragma unroll
-                for (int rb = 0; rb < RB; rb++)
+            for (int rb = 0; rb < RB; rb++) {
+                if ((rb % nw) != w) continue;
+                float4v t;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        float s = red[((0 * RB + rb) * 4 + e) * 64 + lane];
-                        for (int ww = 1; ww < nw; ww++) s += red[((ww * RB + rb) * 4 + e) * 64 + lane];
-                        acc[rb][e] = s;
-                    }
+                for (int e = 0; e < 4; e++) {
+                    float sum = red[((0 * RB + rb) * 4 + e) * 64 + lane];
+                    for (int ww = 1; ww < nw; ww++) sum += red[((ww * RB + rb) * 4 + e) * 64 + lane];
+                    t[e] = sum;
+                }
+                const int r = rg + rb * 16 + li;
+                if (r < a.R) gemm_epilogue4(a, EPI, r, n0 + g * 4, t);
             }
-        }
-
-        // epilogue: D[feature = g*4+e][row = li]
-        if (w == 0) {
+        } else {
 #pragma unroll
             for (int rb = 0; rb < RB; rb++) {
                 const int r = rg + rb * 16 + li;
@@ -437,6 +439,7 @@ struct AttnArgs {
     int H, n_heads;
     float scale;
     float *out;            // [R][H]
+    _Float16 *out16;       // [R][H] fp16 copy for an fp16-weight out_proj (same rounding the GEMM would apply), or NULL
     float *part;           // [R][n_heads][nsplit][66]  (max, sum, acc[64]) when nsplit > 1
     int max_T;             // LDS score capacity
 };
@@ -511,7 +514,9 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
         float o = 0.0f, s = 0.0f;
         for (int i = 0; i < NKG; i++) { o += red[i * 64 + tid]; s += red[NKG * 65 + i]; }
         if (nz == 1) {
-            a.out[(int64_t) r * a.H + h * 64 + tid] = o / s;
+            const float res = o / s;
+            if (a.out16) a.out16[(int64_t) r * a.H + h * 64 + tid] = (_Float16) res;
+            else a.out[(int64_t) r * a.H + h * 64 + tid] = res;
         } else {
             float *p = a.part + (((int64_t) r * a.n_heads + h) * nz + z) * 66;
             if (tid == 0) { p[0] = mx; p[1] = s; }
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
     }
 }
 
-__global__ void attn_combine_kernel(const float *part, int nz, int H, int n_heads, float *out) {
+__global__ void attn_combine_kernel(const float *part, int nz, int H, int n_heads, float *out, _Float16 *out16) {
     const int h = blockIdx.x, r = blockIdx.y, c = threadIdx.x;  // 64 threads; nz <= 16
     const float *p = part + ((int64_t) r * n_heads + h) * nz * 66;
     float m[16], s[16], o[16];
@@ -540,7 +545,9 @@ __global__ void attn_combine_kernel(const float *part, int nz, int H, int n_head
             ss += f * s[z];
         }
     }
-    out[(int64_t) r * H + h * 64 + c] = oo / ss;
+    const float res = oo / ss;
+    if (out16) out16[(int64_t) r * H + h * 64 + c] = (_Float16) res;
+    else out[(int64_t) r * H + h * 64 + c] = res;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -179,7 +179,7 @@ struct tts_hip_ctx {
     int RMAX = 0;
     void *kcache = nullptr, *vcache = nullptr;  // [L][max_seqs][NCTX][H]
     float *x = nullptr, *q = nullptr, *att = nullptr, *u32 = nullptr, *logits = nullptr, *part = nullptr, *dbg = nullptr;
-    _Float16 *u16 = nullptr, *xn16 = nullptr;
+    _Float16 *u16 = nullptr, *xn16 = nullptr, *att16 = nullptr;
     int ln_fuse_max = 8;  // rows up to which LayerNorm stays fused in the GEMM prologue
     uint32_t *d_ids = nullptr, *d_pos = nullptr, *d_seq = nullptr, *d_tok = nullptr, *d_step = nullptr, *d_steps_done = nullptr;
     uint32_t *d_tokens_out = nullptr;
@@ -255,7 +255,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (auto &t : c->tensors) free_dev(t.second.tmp);
     if (!c->arena_external) free_dev(c->arena);
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
-    free_dev(c->u16); free_dev(c->xn16); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
+    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
     free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
     free_dev(c->d_eos); free_dev(c->d_codes); free_dev(c->d_frames);
     for (int i = 0; i < 3; i++) free_dev(c->dbuf[i]);
@@ -683,7 +683,7 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
     hipLaunchKernelGGL(attn_kernel, dim3(c->NH, R, nsplit), dim3(threads), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     if (nsplit > 1) {
-        hipLaunchKernelGGL(attn_combine_kernel, dim3(c->NH, R), dim3(64), 0, c->stream, (const float *) a.part, nsplit, c->H, c->NH, a.out);
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(c->NH, R), dim3(64), 0, c->stream, (const float *) a.part, nsplit, c->H, c->NH, a.out, a.out16);
         HIPCHK(hipGetLastError());
     }
     return prof_end(c);
@@ -741,12 +741,15 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
         AttnArgs at{};
         at.q = c->q; at.kc = g.kc; at.vc = g.vc; at.kv_f16 = g.kv_f16; at.seq_stride = seq_stride;
         at.row_seq = c->d_seq; at.row_pos = c->d_pos; at.H = H; at.n_heads = c->NH;
-        at.scale = 1.0f / sqrtf(64.0f); at.out = c->att; at.part = c->part;
+        // an fp16-weight out_proj rounds its input to fp16 anyway: let the attention kernel store fp16
+        const bool valu_mode = (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) != 0;
+        const bool o_half = y.o.type == TTS_HIP_F16 && !valu_mode && (H % 256 == 0);
+        at.scale = 1.0f / sqrtf(64.0f); at.out = c->att; at.out16 = o_half ? c->att16 : nullptr; at.part = c->part;
         CHK(run_attn(c, TTS_HIP_K_ATTN_SELF, at, R, nsplit, self_kv_bytes));
 
         GemmArgs go{};
-        go.R = R; go.H = H; go.A = c->att; go.lda = H; go.out = c->x; go.ldo = H;
-        CHK(run_gemm(c, TTS_HIP_K_GEMM_ATTN_OUT, y.o, go, PRO_F32, EPI_RESID));
+        go.R = R; go.H = H; go.A = o_half ? (const void *) c->att16 : (const void *) c->att; go.lda = H; go.out = c->x; go.ldo = H;
+        CHK(run_gemm(c, TTS_HIP_K_GEMM_ATTN_OUT, y.o, go, o_half ? PRO_F16 : PRO_F32, EPI_RESID));
 
         // cross attention ------------------------------------------------------------------
         if (c->d.use_cross_attn) {
@@ -760,10 +763,12 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
             ac.kc = c->arena + c->cross_kv + ((size_t) l * 2 + 0) * c->ECAP * H * 4;
             ac.vc = c->arena + c->cross_kv + ((size_t) l * 2 + 1) * c->ECAP * H * 4;
             ac.kv_f16 = 0; ac.seq_stride = 0; ac.row_seq = nullptr; ac.row_pos = nullptr; ac.T_fixed = c->E;
-            ac.H = H; ac.n_heads = c->NH; ac.scale = at.scale; ac.out = c->att; ac.part = c->part;
+            const bool co_half = y.co.type == TTS_HIP_F16 && !valu_mode && (H % 256 == 0);
+            ac.H = H; ac.n_heads = c->NH; ac.scale = at.scale; ac.out = c->att; ac.out16 = co_half ? c->att16 : nullptr; ac.part = c->part;
             CHK(run_attn(c, TTS_HIP_K_ATTN_CROSS, ac, R, 1, 2.0 * c->E * H * 4));
             GemmArgs gc = go;
-            CHK(run_gemm(c, TTS_HIP_K_GEMM_CROSS_OUT, y.co, gc, PRO_F32, EPI_RESID));
+            gc.A = co_half ? (const void *) c->att16 : (const void *) c->att;
+            CHK(run_gemm(c, TTS_HIP_K_GEMM_CROSS_OUT, y.co, gc, co_half ? PRO_F16 : PRO_F32, EPI_RESID));
         }
 
         // FFN ------------------------------------------------------------------------------
@@ -855,6 +860,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->u32, (size_t) R * c->F));
         CHK(dmalloc(&c->u16, (size_t) R * c->F));
         CHK(dmalloc(&c->xn16, (size_t) R * H));
+        CHK(dmalloc(&c->att16, (size_t) R * H));
         CHK(dmalloc(&c->logits, (size_t) R * c->NO * c->V));
         CHK(dmalloc(&c->part, (size_t) R * c->NH * 16 * 66));
         CHK(dmalloc(&c->d_ids, (size_t) R * c->NO));
