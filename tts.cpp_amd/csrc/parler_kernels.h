@@ -118,11 +118,15 @@ struct GemmArgs {
     const uint32_t *row_seq, *row_pos;
     int H;
     int gelu_mode;
+    // split-K over workgroups (blockIdx.y = K slice of `kchunk` columns): EPI_STORE writes slab blockIdx.y of
+    // `out` (slab_stride floats apart); the consumer (ln_rows_kernel) adds the slabs in a fixed order.
+    int kchunk;
+    int64_t slab_stride;
 };
 
 __device__ __forceinline__ void gemm_epilogue4(const GemmArgs &a, int EPI, int r, int n, float4v v) {
     if (EPI == EPI_STORE) {
-        *(float4v *) (a.out + (int64_t) r * a.ldo + n) = v;
+        *(float4v *) (a.out + (int64_t) blockIdx.y * a.slab_stride + (int64_t) r * a.ldo + n) = v;
     } else if (EPI == EPI_RESID) {
         float4v *p = (float4v *) (a.out + (int64_t) r * a.ldo + n);
         float4v o = *p;
@@ -169,6 +173,7 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
     const int n0 = blockIdx.x * 16;
     const int li = lane & 15, g = lane >> 4;
     const int K = a.K;
+    const int kz = blockIdx.y * a.kchunk;  // 0 unless K is split over workgroups
 
     // ---- 1. issue every weight load of this lane (HBM latency overlaps the prologue) -------------
     // MFMA-natural K order: for load c, the 4 lanes (g = 0..3) that share a weight row read one
@@ -176,11 +181,11 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
     half8   wh[8];
     float4v wf[16];
     if (WT == 1) {
-        const _Float16 *wp = (const _Float16 *) a.W + (int64_t) (n0 + li) * K + w * 256 + g * 8;
+        const _Float16 *wp = (const _Float16 *) a.W + (int64_t) (n0 + li) * K + kz + w * 256 + g * 8;
 #pragma unroll
         for (int c = 0; c < 8; c++) wh[c] = __builtin_nontemporal_load((const half8 *) (wp + c * 32));
     } else {
-        const float *wp = (const float *) a.W + (int64_t) (n0 + li) * K + w * 256 + g * 4;
+        const float *wp = (const float *) a.W + (int64_t) (n0 + li) * K + kz + w * 256 + g * 4;
 #pragma unroll
         for (int c = 0; c < 16; c++) wf[c] = __builtin_nontemporal_load((const float4v *) (wp + c * 16));
     }
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
             const int r  = rg + rb * 16 + li;
             const int rr = r < a.R ? r : a.R - 1;
             if (WT == 1) {
-                const int kb = w * 256 + g * 8;
+                const int kb = kz + w * 256 + g * 8;
 #pragma unroll
                 for (int c = 0; c < 8; c++) {
                     half8 b;
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
                     acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], b, acc[rb], 0, 0, 0);
                 }
             } else {
-                const int kb = w * 256 + g * 4;
+                const int kb = kz + w * 256 + g * 4;
 #pragma unroll
                 for (int c = 0; c < 16; c++) {
                     float4v b;
@@ -366,19 +371,31 @@ __global__ void gemv_valu_kernel(GemmArgs a, int EPI, int act_f16_src) {
 // looped fallback).  Used when R is large enough that re-normalising every row inside every GEMM
 // workgroup would dominate (and for the debug "hidden" read-back / scalar GEMV path).
 // y32 and/or y16 may be NULL.
-__global__ __launch_bounds__(256) void ln_rows_kernel(const float *x, int H, const float *lw, const float *lb, float *y32,
-                                                      _Float16 *y16, int R) {
+//
+// Residual hand-off: when `parts` != NULL the preceding out_proj / fc2 GEMM ran split-K and left n_parts fp32
+// slabs [n_parts][R][H]; this kernel performs the reference's ggml_add(cur, residual): x[r] += sum_s parts[s][r]
+// (fixed order), stores the new residual stream in place (x is written by the wave that owns the row) and
+// normalises it.  Requires H <= 2048.
+__global__ __launch_bounds__(256) void ln_rows_kernel(float *x, int H, const float *lw, const float *lb, float *y32,
+                                                      _Float16 *y16, int R, const float *parts, int n_parts, int64_t slab_stride) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= R) return;
-    const float *xr = x + (int64_t) r * H;
+    float *xr = x + (int64_t) r * H;
     if (H <= 2048 && (H & 3) == 0) {
         float4v v[8];
         float s = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int k = i * 256 + lane * 4;
-            if (k < H) { v[i] = *(const float4v *) (xr + k); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+            if (k < H) {
+                v[i] = *(const float4v *) (xr + k);
+                if (parts) {
+                    for (int sp = 0; sp < n_parts; sp++) v[i] += *(const float4v *) (parts + sp * slab_stride + (int64_t) r * H + k);
+                    *(float4v *) (xr + k) = v[i];
+                }
+                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            }
         }
         const float mean = wave_sum(s) / (float) H;
         float s2 = 0.0f;

@@ -181,6 +181,8 @@ struct tts_hip_ctx {
     float *x = nullptr, *q = nullptr, *att = nullptr, *u32 = nullptr, *logits = nullptr, *part = nullptr, *dbg = nullptr;
     _Float16 *u16 = nullptr, *xn16 = nullptr, *att16 = nullptr;
     int ln_fuse_max = 8;  // rows up to which LayerNorm stays fused in the GEMM prologue
+    float *partials = nullptr;  // [8][RMAX][H] split-K slabs of the residual GEMMs
+    int pending_parts = 0;      // slabs waiting to be folded into x by the next LayerNorm launch
     uint32_t *d_ids = nullptr, *d_pos = nullptr, *d_seq = nullptr, *d_tok = nullptr, *d_step = nullptr, *d_steps_done = nullptr;
     uint32_t *d_tokens_out = nullptr;
     size_t tokens_out_cap = 0;
@@ -241,7 +243,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     const char *ns = getenv("TTS_HIP_ATTN_NSPLIT");
     if (ns) c->attn_nsplit_override = atoi(ns);
     const char *lf = getenv("TTS_HIP_LN_FUSE_MAX");
-    if (lf) c->ln_fuse_max = atoi(lf);
+    if (lf) c->ln_fuse_max = std::max(0, std::min(32, atoi(lf)));
     return c;
 }
 
@@ -255,7 +257,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (auto &t : c->tensors) free_dev(t.second.tmp);
     if (!c->arena_external) free_dev(c->arena);
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
-    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
+    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
     free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
     free_dev(c->d_eos); free_dev(c->d_codes); free_dev(c->d_frames);
     for (int i = 0; i < 3; i++) free_dev(c->dbuf[i]);
@@ -581,7 +583,8 @@ extern "C" int tts_hip_profile_get(tts_hip_ctx *c, int k, tts_hip_kstat *out) {
 
 template <int WT, int PRO, int EPI, int RB>
 static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
-    const int nw = a.K / 256;
+    const int ksplit = a.kchunk ? a.K / a.kchunk : 1;
+    const int nw = (a.kchunk ? a.kchunk : a.K) / 256;
     size_t lds = 0;
     if (PRO == PRO_LN) {
         lds = (size_t) RB * 16 * (a.K + (WT == 1 ? 8 : 4)) * (WT == 1 ? 2 : 4);
@@ -595,7 +598,7 @@ static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
     }
     if (lds > 160 * 1024) return set_err("gemm16: LDS request %zu exceeds 160 KiB", lds);
     if (PRO == PRO_LN && a.K > 2048) return set_err("gemm16: LayerNorm prologue supports hidden sizes up to 2048 (got %d)", a.K);
-    hipLaunchKernelGGL((gemm16_kernel<WT, PRO, EPI, RB>), dim3(a.N / 16), dim3(nw * 64), lds, c->stream, a);
+    hipLaunchKernelGGL((gemm16_kernel<WT, PRO, EPI, RB>), dim3(a.N / 16, ksplit), dim3(nw * 64), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -624,8 +627,8 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
         GemmArgs b = a;
         if (pro == PRO_LN) {
             CHK(prof_begin(c, TTS_HIP_K_LN, (double) a.R * a.K * 8, 0));
-            hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, (const float *) a.A, a.K, a.ln_w, a.ln_b, c->dbg,
-                               (_Float16 *) nullptr, a.R);
+            hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, (float *) a.A, a.K, a.ln_w, a.ln_b, c->dbg,
+                               (_Float16 *) nullptr, a.R, (const float *) nullptr, 0, (int64_t) 0);
             HIPCHK(hipGetLastError());
             CHK(prof_end(c));
             b.A = c->dbg;
@@ -642,13 +645,27 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
         // many rows: normalise once (one wave per row) instead of once per GEMM workgroup
         const bool h16 = w.type == TTS_HIP_F16;
         CHK(prof_begin(c, TTS_HIP_K_LN, (double) a.R * a.K * (h16 ? 6 : 8), 0));
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, (const float *) a.A, a.K, a.ln_w, a.ln_b,
-                           h16 ? (float *) nullptr : c->dbg, h16 ? c->xn16 : (_Float16 *) nullptr, a.R);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, (float *) a.A, a.K, a.ln_w, a.ln_b,
+                           h16 ? (float *) nullptr : c->dbg, h16 ? c->xn16 : (_Float16 *) nullptr, a.R,
+                           c->pending_parts ? (const float *) c->partials : (const float *) nullptr, c->pending_parts,
+                           (int64_t) c->RMAX * c->H);
+        c->pending_parts = 0;
         HIPCHK(hipGetLastError());
         CHK(prof_end(c));
         a.A = h16 ? (const void *) c->xn16 : (const void *) c->dbg;
         a.lda = a.K;
         pro = h16 ? PRO_F16 : PRO_F32;
+    }
+    if (epi == EPI_RESID && a.R > c->ln_fuse_max && a.H <= 2048 && a.N == a.H && a.out == c->x) {
+        // many rows: spread K over 4-8x more workgroups; the partial slabs are folded into x by the next LayerNorm
+        const int ks = a.K >= 4096 ? 8 : 4;
+        if (a.K % (ks * 256) == 0) {
+            a.kchunk = a.K / ks;
+            a.slab_stride = (int64_t) c->RMAX * c->H;
+            a.out = c->partials;
+            epi = EPI_STORE;
+            c->pending_parts = ks;
+        }
     }
     CHK(prof_begin(c, kclass, bytes, flops));
     int rc = -1;
@@ -704,6 +721,7 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
     const size_t kv_esz = c->d.kv_type == TTS_HIP_F16 ? 2 : 4;
     const size_t layer_kv_bytes = (size_t) c->d.max_seqs * seq_stride * kv_esz;
 
+    c->pending_parts = 0;
     EmbedArgs ea{};
     const W &tab = audio ? c->embed_tokens : c->embed_prompts;
     ea.tab = c->arena + tab.off;
@@ -861,6 +879,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->u16, (size_t) R * c->F));
         CHK(dmalloc(&c->xn16, (size_t) R * H));
         CHK(dmalloc(&c->att16, (size_t) R * H));
+        CHK(dmalloc(&c->partials, (size_t) 8 * R * H));
         CHK(dmalloc(&c->logits, (size_t) R * c->NO * c->V));
         CHK(dmalloc(&c->part, (size_t) R * c->NH * 16 * 66));
         CHK(dmalloc(&c->d_ids, (size_t) R * c->NO));
@@ -1429,8 +1448,10 @@ extern "C" int64_t tts_hip_debug_read(tts_hip_ctx *c, const char *what, float *o
     if (w == "hidden") {
         const size_t R = c->host_pos.size();
         if (R == 0 || R * c->H > max_floats) { set_err("debug_read(hidden): no forward yet or buffer too small"); return -1; }
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned) (R + 3) / 4), dim3(256), 0, c->stream, (const float *) c->x, c->H,
-                           (const float *) (c->arena + c->ln_w), (const float *) (c->arena + c->ln_b), c->dbg, (_Float16 *) nullptr, (int) R);
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned) (R + 3) / 4), dim3(256), 0, c->stream, c->x, c->H,
+                           (const float *) (c->arena + c->ln_w), (const float *) (c->arena + c->ln_b), c->dbg, (_Float16 *) nullptr, (int) R,
+                           c->pending_parts ? (const float *) c->partials : (const float *) nullptr, c->pending_parts, (int64_t) c->RMAX * c->H);
+        c->pending_parts = 0;
         if (hipMemcpyAsync(out, c->dbg, R * c->H * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { set_err("debug_read(hidden): copy failed"); return -1; }
         return (int64_t) (R * c->H);
