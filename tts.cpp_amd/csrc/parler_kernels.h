@@ -169,7 +169,13 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs &a, int EPI, int r
 template <int WT, int PRO, int EPI, int RB>
 __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // nw waves split this workgroup's K range in 256-wide slices; when the forward carries several groups of
+    // 16*RB rows the workgroup holds `ngs` such wave sets and the row groups are dealt round-robin to them,
+    // so groups are processed in parallel instead of one after the other.
+    const int nw = (a.kchunk ? a.kchunk : a.K) >> 8;
+    const int ngs = (blockDim.x >> 6) / nw;
+    const int w = wave % nw, gs = wave / nw;
     const int n0 = blockIdx.x * 16;
     const int li = lane & 15, g = lane >> 4;
     const int K = a.K;
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
     size_t    red_off = 0;
     if (PRO == PRO_LN) {
         const float *A = (const float *) a.A;
-        for (int r = w; r < a.R; r += nw) {
+        for (int r = wave; r < a.R; r += nw * ngs) {
             const float *xr = A + (int64_t) r * a.lda;
             float4v v[8];
             float s = 0.0f;
@@ -249,7 +255,10 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
     // ---- 3-5. for every group of 16*RB rows: MFMA over this wave's 256-wide K slice, reduce the K slices
     //           across waves, epilogue.  The weight fragments stay in registers across row groups, so many
     //           lock-step utterances cost one pass over the weights.
-    for (int rg = 0; rg < a.R; rg += 16 * RB) {
+    const int n_groups = (a.R + 16 * RB - 1) / (16 * RB);
+    const int n_rounds = (n_groups + ngs - 1) / ngs;   // uniform trip count: every wave reaches every barrier
+    for (int rd = 0; rd < n_rounds; rd++) {
+        const int rg = (rd * ngs + gs) * 16 * RB;      // may lie beyond R for the last round: nothing is stored then
         float4v acc[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) acc[rb] = (float4v){0.f, 0.f, 0.f, 0.f};
@@ -295,8 +304,8 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
         // of the group are spread over the waves (wave w owns row blocks w, w+nw, ...) so that neither the
         // reduction nor the scattered epilogue stores serialise on one wave
         if (nw > 1) {
-            float *red = (float *) (smem + red_off);  // [nw][RB][4][64]
-            if (rg > 0) __syncthreads();              // previous group's partials have been consumed
+            float *red = (float *) (smem + red_off) + (size_t) gs * nw * RB * 256;  // [ngs][nw][RB][4][64]
+            if (rd > 0) __syncthreads();              // previous round's partials have been consumed
 #pragma unroll
             for (int rb = 0; rb < RB; rb++)
 #pragma unroll
