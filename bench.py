@@ -44,7 +44,11 @@ def make_prompts(cfg, batch, prompt_len, rank):
     return [np.concatenate([rng.integers(3, cfg.prompt_vocab, prompt_len - 1), [1]]).astype(np.uint32) for _ in range(batch)]
 
 
-def run_utterance_batch(eng, cfg, prompts, n_audio, timings=None, dac_group=16):
+DAC_GROUP = int(os.environ.get("TTS_BENCH_DAC_GROUP", "16"))
+
+
+def run_utterance_batch(eng, cfg, prompts, n_audio, timings=None, dac_group=None):
+    dac_group = dac_group or DAC_GROUP
     """one bench step; returns total PCM samples produced"""
     t0 = time.perf_counter()
     eng.prefill_batch(prompts)

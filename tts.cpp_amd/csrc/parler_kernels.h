@@ -207,16 +207,20 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
         const float *A = (const float *) a.A;
         for (int r = wave; r < a.R; r += nw * ngs) {
             const float *xr = A + (int64_t) r * a.lda;
-            float4v v[8];
+            float4v v[8], lwv[8], lbv[8];
             float s = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < 8; i++) {  // x row and the affine parameters in one round trip
                 const int k = i * 256 + lane * 4;
                 if (k < K) {
                     v[i] = *(const float4v *) (xr + k);
-                    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+                    lwv[i] = *(const float4v *) (a.ln_w + k);
+                    lbv[i] = *(const float4v *) (a.ln_b + k);
                 }
             }
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (i * 256 + lane * 4 < K) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             const float mean = wave_sum(s) / (float) K;
             float s2 = 0.0f;
 #pragma unroll
@@ -231,8 +235,7 @@ __global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
             for (int i = 0; i < 8; i++) {
                 const int k = i * 256 + lane * 4;
                 if (k < K) {
-                    const float4v lw = *(const float4v *) (a.ln_w + k);
-                    const float4v lb = *(const float4v *) (a.ln_b + k);
+                    const float4v lw = lwv[i], lb = lbv[i];
                     float4v y;
 #pragma unroll
                     for (int e = 0; e < 4; e++) y[e] = (v[i][e] - mean) * rstd * lw[e] + lb[e];
@@ -392,8 +395,13 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(float *x, int H, const flo
     if (r >= R) return;
     float *xr = x + (int64_t) r * H;
     if (H <= 2048 && (H & 3) == 0) {
-        float4v v[8];
+        float4v v[8], lwv[8], lbv[8];
         float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int k = i * 256 + lane * 4;
+            if (k < H) { lwv[i] = *(const float4v *) (lw + k); lbv[i] = *(const float4v *) (lb + k); }
+        }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int k = i * 256 + lane * 4;
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(float *x, int H, const flo
         for (int i = 0; i < 8; i++) {
             const int k = i * 256 + lane * 4;
             if (k < H) {
-                const float4v w4 = *(const float4v *) (lw + k), b4 = *(const float4v *) (lb + k);
+                const float4v w4 = lwv[i], b4 = lbv[i];
                 float4v y;
 #pragma unroll
                 for (int e = 0; e < 4; e++) y[e] = (v[i][e] - mean) * rstd * w4[e] + b4[e];
