@@ -167,7 +167,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs &a, int EPI, int r
 // WT: 0 = fp32 weights (exact-fp32 MFMA 16x16x4), 1 = fp16 weights (MFMA 16x16x32, activations rounded
 // to fp16 like ggml's vec_dot_type conversion).  blockDim.x = 64 * K/256.
 template <int WT, int PRO, int EPI, int RB>
-__global__ __launch_bounds__(1024) void gemm16_kernel(GemmArgs a) {
+__global__ __launch_bounds__(PRO == PRO_LN ? 512 : 1024) void gemm16_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // nw waves split this workgroup's K range in 256-wide slices; when the forward carries several groups of
@@ -395,13 +395,8 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(float *x, int H, const flo
     if (r >= R) return;
     float *xr = x + (int64_t) r * H;
     if (H <= 2048 && (H & 3) == 0) {
-        float4v v[8], lwv[8], lbv[8];
+        float4v v[8];
         float s = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int k = i * 256 + lane * 4;
-            if (k < H) { lwv[i] = *(const float4v *) (lw + k); lbv[i] = *(const float4v *) (lb + k); }
-        }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int k = i * 256 + lane * 4;
@@ -427,7 +422,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(float *x, int H, const flo
         for (int i = 0; i < 8; i++) {
             const int k = i * 256 + lane * 4;
             if (k < H) {
-                const float4v w4 = lwv[i], b4 = lbv[i];
+                const float4v w4 = *(const float4v *) (lw + k), b4 = *(const float4v *) (lb + k);
                 float4v y;
 #pragma unroll
                 for (int e = 0; e < 4; e++) y[e] = (v[i][e] - mean) * rstd * w4[e] + b4[e];

@@ -587,7 +587,7 @@ static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
     const int nw = (a.kchunk ? a.kchunk : a.K) / 256;
     // wave sets working on different row groups in parallel (up to 16 waves per workgroup)
     const int n_groups = (a.R + 16 * RB - 1) / (16 * RB);
-    const int ngs = std::max(1, std::min(n_groups, 16 / nw));
+    const int ngs = PRO == PRO_LN ? 1 : std::max(1, std::min(n_groups, 16 / nw));
     size_t lds = 0;
     if (PRO == PRO_LN) {
         lds = (size_t) RB * 16 * (a.K + (WT == 1 ? 8 : 4)) * (WT == 1 ? 2 : 4);
@@ -601,6 +601,7 @@ static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
     }
     if (lds > 160 * 1024) return set_err("gemm16: LDS request %zu exceeds 160 KiB", lds);
     if (PRO == PRO_LN && a.K > 2048) return set_err("gemm16: LayerNorm prologue supports hidden sizes up to 2048 (got %d)", a.K);
+    if (PRO == PRO_LN && ngs * nw > 8) return set_err("gemm16: fused-LayerNorm launch wants %d waves (> 8)", ngs * nw);
     hipLaunchKernelGGL((gemm16_kernel<WT, PRO, EPI, RB>), dim3(a.N / 16, ksplit), dim3(ngs * nw * 64), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
