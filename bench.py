@@ -44,7 +44,7 @@ def make_prompts(cfg, batch, prompt_len, rank):
     return [np.concatenate([rng.integers(3, cfg.prompt_vocab, prompt_len - 1), [1]]).astype(np.uint32) for _ in range(batch)]
 
 
-DAC_GROUP = int(os.environ.get("TTS_BENCH_DAC_GROUP", "16"))
+DAC_GROUP = int(os.environ.get("TTS_BENCH_DAC_GROUP", "32"))
 
 
 def run_utterance_batch(eng, cfg, prompts, n_audio, timings=None, dac_group=None):
@@ -65,6 +65,21 @@ def run_utterance_batch(eng, cfg, prompts, n_audio, timings=None, dac_group=None
     if timings is not None:
         timings.append((t1 - t0, t2 - t1, t3 - t2))
     return n_samples
+
+
+def pmc_traffic(kclass, args, n_audio):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM);
+    None when the committed measurement was taken on a different workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    w = t.get("workload", {})
+    if w.get("batch") != args.batch or w.get("audio_steps") != n_audio or w.get("dac_group") != DAC_GROUP:
+        return None
+    v = t.get("kernels", {}).get(kclass)
+    return None if v is None else round(v["hbm_bytes_per_launch"], 1)
 
 
 def cpu_baseline(model, cfg, prompt, threads):
@@ -108,8 +123,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TTS_BENCH_BATCH", "8")), help="utterances per GPU decoded in lock-step")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("TTS_BENCH_STREAMS", "1")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TTS_BENCH_BATCH", "128")), help="utterances per context decoded in lock-step")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("TTS_BENCH_STREAMS", "2")),
                     help="independent contexts (HIP streams) per GPU sharing one weight arena; each decodes --batch utterances")
     ap.add_argument("--audio-steps", type=int, default=256, help="AR audio steps per utterance (random weights never emit EOS)")
     ap.add_argument("--prompt-len", type=int, default=16)
@@ -254,6 +269,7 @@ def main():
                 ach = st["bytes_total"] / (st["ms_total"] * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+            roof["traffic"] = pmc_traffic(dom, args, n_audio)
             roof.update({"kernel": dom, "avg_launch_us": round(per_launch_ms * 1e3, 3), "launches": st["launches"],
                          "share_of_kernel_time": round(st["ms_total"] / tot, 3),
                          "algorithmic_bytes_per_launch": round(st["bytes_total"] / max(st["launches"], 1), 1)})
