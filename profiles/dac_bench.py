@@ -13,15 +13,21 @@ cfg = synth.parler_mini(layers=1, prompt_vocab=64, ctx=64)
 model = synth.build(cfg)
 eng = hip.HipEngine(cfg, flags=flags)
 eng.load(model)
-codes = np.random.default_rng(0).integers(0, cfg.cb_size, (frames, cfg.n_out)).astype(np.uint32)
-eng.dac_decode(codes)
+batch = 1
+for a in sys.argv:
+    if a.startswith("--batch="):
+        batch = int(a.split("=")[1])
+rng = np.random.default_rng(0)
+codes = [rng.integers(0, cfg.cb_size, (frames, cfg.n_out)).astype(np.uint32) for _ in range(batch)]
+if "--no-warmup" not in sys.argv:
+    eng.dac_decode_batch(codes)
 t0 = time.perf_counter()
 for _ in range(reps):
-    eng.dac_decode(codes)
+    eng.dac_decode_batch(codes)
 dt = (time.perf_counter() - t0) / reps
-print(f"frames={frames} {dt*1e3:.2f} ms/decode  {1.608e9*frames/dt/1e12:.1f} TFLOP/s  {frames*512/44100/dt:.1f}x real-time")
+print(f"batch={batch} frames={frames} {dt*1e3:.2f} ms/decode  {1.608e9*frames*batch/dt/1e12:.1f} TFLOP/s  {batch*frames*512/44100/dt:.1f}x real-time")
 if "--prof" in sys.argv:
-    eng.profile(True); eng.dac_decode(codes); st = eng.profile_get(); eng.profile(False)
+    eng.profile(True); eng.dac_decode_batch(codes); st = eng.profile_get(); eng.profile(False)
     for k, v in st.items():
         if v["launches"]:
             print(k, v["launches"], f'{v["ms_total"]:.3f} ms', f'{v["flops_total"]/max(v["ms_total"],1e-9)/1e9:.2f} TF')
