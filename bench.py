@@ -145,12 +145,16 @@ def main():
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     import torch
 
+    # test hooks: run the multi-rank flow on a single-GPU box (all ranks on one device, gloo instead of RCCL)
+    if os.environ.get("TTS_BENCH_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["TTS_BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("TTS_BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        tdist.init("nccl", rank, world, device=torch.device("cuda", local_rank))
+        tdist.init(backend, rank, world, device=torch.device("cuda", local_rank))
 
     cfg = {"mini": synth.parler_mini, "small": synth.small, "tiny": synth.tiny}[args.model](weight_type=gguf.F16)
     n_audio = min(args.audio_steps, cfg.max_gen - args.prompt_len, cfg.ctx - args.prompt_len)

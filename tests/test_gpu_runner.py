@@ -125,3 +125,51 @@ def test_cli_writes_wav(tmp_path):
     r = runner.Runner(path, sample=0)
     assert n == r.generate("a short test").size and n > 0
     r.close()
+
+
+def test_two_rank_bench_flow_on_one_gpu(tmp_path):
+    """bench.py's N>1 path end to end with two processes (both on cuda:0, gloo transport): rank 1 only declares
+    tensors, receives the weight arena by broadcast and must produce audio like rank 0."""
+    import json
+    import socket
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, TTS_BENCH_FORCE_DEVICE="0", TTS_BENCH_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--model", "small",
+           "--batch", "3", "--streams", "2", "--audio-steps", "40", "--prompt-len", "6", "--no-cpu-baseline", "--no-roofline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    frames = 40 - 9 + 1
+    expect_audio_s = 2 * 2 * 3 * frames * 512 / 44100.0   # ranks x contexts x utterances
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - expect_audio_s) < 1e-3 * expect_audio_s
+
+
+def test_maximum_size_generation_and_decode():
+    """Parler-Mini dims, one utterance to max_generation (2580 positions) on the device-resident loop, then the
+    DAC on every frame: positions/caches/buffers at their maximum sizes; finite PCM in [-1, 1]."""
+    cfg = synth.parler_mini(weight_type=gguf.F16)
+    model = synth.build(cfg)
+    from tts_cpp_amd import hip
+    eng = hip.HipEngine(cfg, max_seqs=1, kv_positions=cfg.max_gen)
+    eng.load(model)
+    prompt = np.arange(3, 19, dtype=np.uint32)
+    eng.prefill(0, prompt)
+    n_steps = cfg.max_gen - len(prompt)
+    toks, done = eng.generate_greedy([len(prompt)], n_steps)
+    assert toks.shape == (n_steps, 1, cfg.n_out) and (toks < cfg.audio_vocab).all()
+    with pytest.raises(hip.HipError):
+        eng.step(np.zeros((1, cfg.n_out)), [cfg.max_gen])  # one past the last cached position
+    frames = undelay(toks[:, 0, :], cfg.audio_vocab)
+    assert len(frames) == n_steps - cfg.n_out + 1
+    pcm = eng.dac_decode(frames)
+    assert pcm.size == len(frames) * 512 and np.isfinite(pcm).all() and np.abs(pcm).max() <= 1.0
+    # the last steps attend over ~2.5k cached positions: spot-check one late step against the argmax of its logits
+    ids = np.full((1, cfg.n_out), cfg.bos, dtype=np.uint32)
+    ids[0] = toks[-2, 0, :]
+    tk = eng.step_greedy(ids, [cfg.max_gen - 1])
+    assert np.array_equal(tk[0], toks[-1, 0, :])
+    eng.close()
