@@ -348,16 +348,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
             const int i = tid + j * NT;
             if (i < WCH / 4) wreg[j] = wp[i];
         }
+        if constexpr (KT == 1) {
+            // k = 1: no halo, tiles and rows are 16-byte aligned (T_T, L and the row stride are multiples of 4):
+            // stage the input with 16-byte loads
 #pragma unroll
-        for (int j = 0; j < XV; j++) {
-            const int i = tid + j * NT;
-            float v = 0.0f;
-            if (i < CI_T * xw) {
-                const int ci = i / xw, p = i - ci * xw;
-                const int t = t0 + p - a.pad, cig = c * CI_T + ci;
-                if (cig < a.cin && t >= 0 && t < L) v = xg[(int64_t) cig * LS + t];
+            for (int j = 0; j < XV / 4; j++) {
+                const int i4 = tid + j * NT;  // float4 index in the [CI_T][T_T] tile
+                const int ci = (i4 * 4) / T_T, p = (i4 * 4) - ci * T_T;
+                const int t = t0 + p, cig = c * CI_T + ci;
+                float4d v = {0.f, 0.f, 0.f, 0.f};
+                if (cig < a.cin && t < L) v = *(const float4d *) (xg + (int64_t) cig * LS + t);
+                xreg[4 * j] = v[0]; xreg[4 * j + 1] = v[1]; xreg[4 * j + 2] = v[2]; xreg[4 * j + 3] = v[3];
             }
-            xreg[j] = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < XV; j++) {
+                const int i = tid + j * NT;
+                float v = 0.0f;
+                if (i < CI_T * xw) {
+                    const int ci = i / xw, p = i - ci * xw;
+                    const int t = t0 + p - a.pad, cig = c * CI_T + ci;
+                    if (cig < a.cin && t >= 0 && t < L) v = xg[(int64_t) cig * LS + t];
+                }
+                xreg[j] = v;
+            }
         }
     };
     auto commit = [&](int c, int buf) {
@@ -368,16 +382,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
             if (i < WCH / 4) wd[i] = wreg[j];
         }
         float *xd = xsb + buf * xsz;
+        if constexpr (KT == 1) {
 #pragma unroll
-        for (int j = 0; j < XV; j++) {
-            const int i = tid + j * NT;
-            if (i < CI_T * xw) {
-                float v = xreg[j];
+            for (int j = 0; j < XV / 4; j++) {
+                const int i4 = tid + j * NT;
+                float4d v = {xreg[4 * j], xreg[4 * j + 1], xreg[4 * j + 2], xreg[4 * j + 3]};
                 if (a.alpha) {
-                    const int cig = c * CI_T + i / xw;
-                    v = snake_f(v, als[cig], als[cin_pad + cig]);  // snake(0) == 0: zero padding is preserved
+                    const int cig = c * CI_T + (i4 * 4) / T_T;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = snake_f(v[e], als[cig], als[cin_pad + cig]);
                 }
-                xd[i] = v;
+                *(float4d *) (xd + i4 * 4) = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < XV; j++) {
+                const int i = tid + j * NT;
+                if (i < CI_T * xw) {
+                    float v = xreg[j];
+                    if (a.alpha) {
+                        const int cig = c * CI_T + i / xw;
+                        v = snake_f(v, als[cig], als[cin_pad + cig]);  // snake(0) == 0: zero padding is preserved
+                    }
+                    xd[i] = v;
+                }
             }
         }
     };
