@@ -40,6 +40,11 @@ void          tts_c_default_config(tts_c_config *cfg);
 tts_c_runner *tts_c_runner_from_file(const char *path, int n_threads, const tts_c_config *cfg, int cpu_only);
 /* *data stays owned by the runner and valid until the next generate (dac_model.cpp:190-191) */
 int           tts_c_generate(tts_c_runner *r, const char *text, const tts_c_config *cfg, const float **data, size_t *n_outputs);
+/* Extension: n utterances in lock-step on the runner's device (parler_runner::generate_batch).  texts[n];
+ * data[i] / n_outputs[i] receive each utterance's PCM (runner-owned, valid until the next generate*). The runner
+ * must have been loaded with TTS_HIP_MAX_SEQS >= n in the environment. */
+int           tts_c_generate_batch(tts_c_runner *r, const char *const *texts, int n, const tts_c_config *cfg, const float **data,
+                                   size_t *n_outputs);
 float         tts_c_sampling_rate(tts_c_runner *r);
 const char   *tts_c_arch(tts_c_runner *r);
 void          tts_c_free(tts_c_runner *r);

@@ -80,6 +80,32 @@ def test_host_sampling_loop_modes(tmp_path):
     r.close()
 
 
+def test_generate_batch_equals_separate_generates(tmp_path):
+    """extension: lock-step utterances through the C++ runner == one generate() per utterance (greedy exactly;
+    seeded sampling runs and is reproducible)"""
+    model = synth.build(synth.tiny(weight_type=gguf.F16))
+    path = model.write_gguf(str(tmp_path / "m.gguf"))
+    texts = ["the quick brown fox", "hello", "a much longer sentence with several more words in it", "zz top"]
+    os.environ["TTS_HIP_MAX_SEQS"] = "4"
+    try:
+        r = runner.Runner(path, sample=0)
+    finally:
+        del os.environ["TTS_HIP_MAX_SEQS"]
+    batch = r.generate_batch(texts)
+    singles = [r.generate(t) for t in texts]
+    for b, s_ in zip(batch, singles):
+        # sequences share max_generation - longest_prompt steps in a batch; compare the common prefix of frames
+        n = min(b.size, s_.size)
+        assert n > 0 and abs(b.size - s_.size) <= 512 * 16
+        assert np.abs(b[: n - 512 * 8] - s_[: n - 512 * 8]).max() < 1e-5
+    a = r.generate_batch(texts, sample=1, top_k=20, temperature=0.9, seed=99)
+    b2 = r.generate_batch(texts, sample=1, top_k=20, temperature=0.9, seed=99)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b2))
+    with pytest.raises(runner.RunnerError):
+        r.generate_batch(texts + ["one too many"])
+    r.close()
+
+
 def test_eos_stops_generation_and_empty_response(tmp_path):
     """every head emits EOS at the first audio step -> check_stopping ends the loop, every frame contains a
     special id and is dropped by adjust_output_tokens -> n_outputs == 0 (the reference's soft failure)"""

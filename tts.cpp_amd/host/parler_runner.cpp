@@ -1,5 +1,6 @@
 #include "parler_runner.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -72,10 +73,13 @@ parler_runner::parler_runner(const parler_hparams & hp_, unigram_tokenizer * tok
     d.dac_n_blocks = hp.dac_n_layers;
     for (uint32_t i = 0; i < hp.dac_n_layers; i++) { d.dac_stride[i] = hp.dac_stride[i]; d.dac_padding[i] = hp.dac_padding[i]; }
     d.dac_max_frames = hp.max_generation_size;
-    d.max_seqs = 1;
+    if (const char * ms = getenv("TTS_HIP_MAX_SEQS")) max_seqs = (uint32_t) std::max(1, atoi(ms));
+    d.max_seqs = max_seqs;
     d.kv_type = getenv("TTS_HIP_KV_F16") ? TTS_HIP_F16 : TTS_HIP_F32;
     d.gelu_mode = 1;
-    d.kv_positions = 0;  // reference layout: max_ctx_length positions (model.cpp:368-369)
+    // one utterance: the reference layout (max_ctx_length positions, model.cpp:368-369); lock-step batches keep only
+    // the positions generation can reach (check_stopping stops at max_generation, model.cpp:720-722)
+    d.kv_positions = max_seqs > 1 ? hp.max_generation_size : 0;
     ctx = tts_hip_create(device, &d);
     if (!ctx) TTS_ABORT("tts_hip_create failed: %s\n", tts_hip_last_error());
     smp.n_output_heads = hp.n_output_heads;
@@ -199,4 +203,100 @@ void parler_runner::generate(const char * sentence, tts_response & output, const
     if (frames) hip_check(tts_hip_dac_decode(ctx, filtered.data(), frames, pcm.data()), "tts_hip_dac_decode");
     output.data = pcm.data();
     output.n_outputs = pcm.size();
+}
+
+void parler_runner::generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs,
+                                   const generation_configuration & config) {
+    const uint32_t n = (uint32_t) sentences.size(), nh = hp.n_output_heads;
+    outputs.assign(n, tts_response{});
+    if (n == 0) return;
+    if (n > max_seqs) TTS_ABORT("generate_batch: %u utterances but the runner was loaded with max_seqs=%u (TTS_HIP_MAX_SEQS)\n", n, max_seqs);
+    if (config.use_cross_attn != use_cross_attn) TTS_ABORT("generate_batch: use_cross_attn differs from load time\n");
+    std::vector<uint32_t> ids, lens(n), start(n);
+    for (uint32_t i = 0; i < n; i++) {
+        std::vector<uint32_t> p;
+        tokenizer->tokenize(sentences[i], p);
+        p.push_back(tokenizer->eos_token);
+        if (p.size() >= hp.max_generation_size) TTS_ABORT("generate_batch: prompt %u leaves no room for generation\n", i);
+        lens[i] = start[i] = (uint32_t) p.size();
+        ids.insert(ids.end(), p.begin(), p.end());
+    }
+    hip_check(tts_hip_parler_reset(ctx), "tts_hip_parler_reset");
+    hip_check(tts_hip_parler_prefill_batch(ctx, n, nullptr, ids.data(), lens.data(), nullptr), "tts_hip_parler_prefill_batch");
+    const uint32_t longest = *std::max_element(start.begin(), start.end());
+    const uint32_t max_steps = hp.max_generation_size - longest;  // every sequence stays inside max_generation
+    last_batch_tokens.assign(n, {});
+
+    if (!config.sample && config.repetition_penalty == 1.0f) {
+        std::vector<uint32_t> toks((size_t) max_steps * n * nh), done(n);
+        hip_check(tts_hip_parler_generate_greedy(ctx, n, start.data(), max_steps, hp.bos_token_id, hp.eos_token_id, toks.data(), done.data()),
+                  "tts_hip_parler_generate_greedy");
+        for (uint32_t i = 0; i < n; i++) {
+            // check_stopping per sequence: EOS on every head, or position == max_generation
+            uint32_t steps = done[i] ? done[i] : max_steps;
+            steps = std::min(steps, hp.max_generation_size - start[i]);
+            for (uint32_t s = 0; s < steps; s++)
+                last_batch_tokens[i].insert(last_batch_tokens[i].end(), toks.begin() + ((size_t) s * n + i) * nh, toks.begin() + ((size_t) s * n + i + 1) * nh);
+        }
+    } else {
+        // host sampling, one sampler state per utterance; finished sequences keep stepping on EOS inputs (their
+        // tokens are no longer recorded) until all are done
+        std::vector<sampler> smps(n, smp);
+        for (uint32_t i = 0; i < n; i++) {
+            smps[i].temperature = config.temperature; smps[i].repetition_penalty = config.repetition_penalty;
+            smps[i].do_sample = config.sample; smps[i].top_k = (uint32_t) config.top_k; smps[i].top_p = config.top_p;
+            smps[i].seed = config.seed ? config.seed + i : 0; smps[i].n_calls = 0;
+            smps[i].reset();
+        }
+        std::vector<uint32_t> in_ids((size_t) n * nh, hp.bos_token_id), pos(start);
+        std::vector<std::vector<bool>> eos_seen(n, std::vector<bool>(nh, false));
+        std::vector<bool> finished(n, false);
+        std::vector<float> lg((size_t) n * nh * hp.output_vocab_size);
+        for (uint32_t step = 1; step <= max_steps; step++) {
+            bool all_done = true;
+            for (uint32_t i = 0; i < n; i++) {
+                if (finished[i]) continue;
+                auto & t = last_batch_tokens[i];
+                if (!t.empty()) {
+                    if (pos[i] >= hp.max_generation_size) { finished[i] = true; continue; }
+                    bool all = true;
+                    for (uint32_t h = 0; h < nh; h++) {
+                        eos_seen[i][h] = eos_seen[i][h] || t[t.size() - nh + h] == hp.eos_token_id;
+                        all = all && eos_seen[i][h];
+                    }
+                    if (all) { finished[i] = true; continue; }
+                }
+                all_done = false;
+            }
+            if (all_done) break;
+            hip_check(tts_hip_parler_step(ctx, n, in_ids.data(), pos.data(), nullptr, lg.data()), "tts_hip_parler_step");
+            for (uint32_t i = 0; i < n; i++) {
+                if (pos[i] + 1 < hp.max_generation_size) pos[i] += 1;  // finished rows idle on their last position
+                if (finished[i]) continue;
+                auto & t = last_batch_tokens[i];
+                smps[i].sample(lg.data() + (size_t) i * nh * hp.output_vocab_size, t);
+                const uint32_t * last = t.data() + t.size() - nh;
+                for (uint32_t h = 0; h < nh; h++)
+                    in_ids[(size_t) i * nh + h] = step > h ? (eos_seen[i][h] ? hp.eos_token_id : last[h]) : hp.bos_token_id;
+            }
+        }
+    }
+
+    std::vector<uint32_t> codes, frames(n);
+    for (uint32_t i = 0; i < n; i++) {
+        std::vector<uint32_t> f;
+        adjust_output_tokens(last_batch_tokens[i], f);
+        frames[i] = (uint32_t) (f.size() / nh);
+        codes.insert(codes.end(), f.begin(), f.end());
+    }
+    size_t total = 0;
+    for (uint32_t f : frames) total += (size_t) f * hp.up_sampling_factor;
+    pcm.assign(total, 0.0f);
+    if (total) hip_check(tts_hip_dac_decode_batch(ctx, codes.data(), frames.data(), n, pcm.data()), "tts_hip_dac_decode_batch");
+    size_t off = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        outputs[i].data = pcm.data() + off;
+        outputs[i].n_outputs = (size_t) frames[i] * hp.up_sampling_factor;
+        off += outputs[i].n_outputs;
+    }
 }

@@ -38,6 +38,16 @@ struct parler_runner final : tts_generation_runner {
     void generate(const char * sentence, tts_response & output, const generation_configuration & config) override;
     void update_conditional_prompt(const char * file_path, const char * prompt) override;
 
+    // Extension (the reference generates one utterance per call; its only multi-utterance construct is the
+    // server's pool of full replicas, examples/server/server.cpp:885-895): n utterances decoded in lock-step on
+    // this runner's device — one pass over the weights per step for all of them, one batched DAC pass.
+    // outputs[i].data points into a runner-owned buffer valid until the next generate/generate_batch.
+    // Needs max_seqs >= n (TTS_HIP_MAX_SEQS at load time).  Results equal n separate generate() calls.
+    void generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs,
+                        const generation_configuration & config);
+    uint32_t max_seqs = 1;
+    std::vector<std::vector<uint32_t>> last_batch_tokens;  // per utterance, still delayed
+
     // pieces exposed for tests
     void                 adjust_output_tokens(const std::vector<uint32_t> & output_tokens, std::vector<uint32_t> & filtered) const;
     std::vector<uint32_t> last_output_tokens;  // pctx->output_tokens of the last generate (still delayed)

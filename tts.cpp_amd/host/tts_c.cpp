@@ -56,6 +56,22 @@ int tts_c_generate(tts_c_runner * r, const char * text, const tts_c_config * cfg
     }
 }
 
+int tts_c_generate_batch(tts_c_runner * r, const char * const * texts, int n, const tts_c_config * cfg, const float ** data, size_t * n_outputs) {
+    g_tts_throw_on_abort = true;
+    try {
+        auto * p = dynamic_cast<parler_runner *>((tts_generation_runner *) r);
+        if (!p) { g_c_err = "generate_batch: not a parler runner"; return -1; }
+        std::vector<std::string> s(texts, texts + n);
+        std::vector<tts_response> out;
+        p->generate_batch(s, out, to_cfg(cfg));
+        for (int i = 0; i < n; i++) { data[i] = out[(size_t) i].data; n_outputs[i] = out[(size_t) i].n_outputs; }
+        return 0;
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return -1;
+    }
+}
+
 float        tts_c_sampling_rate(tts_c_runner * r) { return ((tts_generation_runner *) r)->sampling_rate; }
 const char * tts_c_arch(tts_c_runner * r) { return ((tts_generation_runner *) r)->loader.get().arch; }
 void         tts_c_free(tts_c_runner * r) { delete (tts_generation_runner *) r; }

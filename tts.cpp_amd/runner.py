@@ -21,7 +21,7 @@ class SamplerCfg(C.Structure):
                 ("top_p", C.c_float), ("repetition_penalty", C.c_float), ("do_sample", C.c_int), ("seed", C.c_uint64)]
 
 
-EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
+EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_generate_batch", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
            "tts_c_last_error", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor"]
 
 _lib = None
@@ -42,6 +42,8 @@ def load_lib():
         L.tts_c_runner_from_file.restype = C.c_void_p
         L.tts_c_runner_from_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(Config), C.c_int]
         L.tts_c_generate.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Config), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t)]
+        L.tts_c_generate_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(Config), C.POINTER(C.POINTER(C.c_float)),
+                                           C.POINTER(C.c_size_t)]
         L.tts_c_sampling_rate.restype = C.c_float
         L.tts_c_sampling_rate.argtypes = [C.c_void_p]
         L.tts_c_arch.restype = C.c_char_p
@@ -92,6 +94,16 @@ class Runner:
         if self.L.tts_c_generate(self.h, text.encode("utf-8"), C.byref(c), C.byref(data), C.byref(n)) != 0:
             raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
         return np.ctypeslib.as_array(data, shape=(n.value,)).copy() if n.value else np.zeros(0, dtype=np.float32)
+
+    def generate_batch(self, texts, **cfg):
+        c = make_config(**cfg) if cfg else self.cfg
+        n = len(texts)
+        arr = (C.c_char_p * n)(*[t.encode("utf-8") for t in texts])
+        data = (C.POINTER(C.c_float) * n)()
+        ns = (C.c_size_t * n)()
+        if self.L.tts_c_generate_batch(self.h, arr, n, C.byref(c), data, ns) != 0:
+            raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
+        return [np.ctypeslib.as_array(data[i], shape=(ns[i],)).copy() if ns[i] else np.zeros(0, dtype=np.float32) for i in range(n)]
 
     def last_tokens(self, which):
         n = self.L.tts_c_last_tokens(self.h, which, None, 0)
