@@ -97,9 +97,10 @@ def test_generate_batch_equals_separate_generates(tmp_path):
     for b, s_ in zip(batch, singles):
         # in a batch every sequence runs max_generation - longest_prompt steps, alone it runs to max_generation: the
         # frames they have in common must agree (minus the codec's receptive field at the shorter one's end)
+        # (tiny codec: 3 frames for the first conv + (3+9+27) samples per residual stack at 4 and 8 samples/frame ~ 18 frames)
         n = min(b.size, s_.size)
-        assert n > 16 * hop and b.size <= s_.size
-        assert np.abs(b[: n - 8 * hop] - s_[: n - 8 * hop]).max() < 1e-5
+        assert n > 30 * hop and b.size <= s_.size
+        assert np.abs(b[: n - 24 * hop] - s_[: n - 24 * hop]).max() < 1e-5
     a = r.generate_batch(texts, sample=1, top_k=20, temperature=0.9, seed=99)
     b2 = r.generate_batch(texts, sample=1, top_k=20, temperature=0.9, seed=99)
     assert all(np.array_equal(x, y) for x, y in zip(a, b2))
