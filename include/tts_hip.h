@@ -192,7 +192,9 @@ typedef struct tts_hip_kstat {
     double   bytes_total;   /* ALGORITHMIC bytes (weights + activations + cache rows each launch must touch) */
     double   flops_total;   /* algorithmic flops */
 } tts_hip_kstat;
-int tts_hip_profile(tts_hip_ctx *ctx, int enable);        /* enable also clears the counters */
+int tts_hip_profile(tts_hip_ctx *ctx, int enable);        /* 1: every launch, forwards run eagerly; 2: only the launches that are
+                                                              never graph-captured (the DAC), decoder steps keep replaying their
+                                                              hipGraph; 0: off.  Enabling clears the counters. */
 int tts_hip_profile_get(tts_hip_ctx *ctx, int kclass, tts_hip_kstat *out);
 const char *tts_hip_kclass_name(int kclass);
 

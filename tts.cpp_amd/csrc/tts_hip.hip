@@ -209,8 +209,10 @@ struct tts_hip_ctx {
     std::map<int, hipGraphExec_t> graphs;
 
     // profiling
-    bool prof = false;
+    bool prof = false;       // full per-launch event timing: forwards run eagerly
+    bool prof_light = false; // event pairs only around launches that are never graph-captured (the DAC)
     std::vector<ProfEv> prof_events;
+    bool prof_cur = false;
     tts_hip_kstat kstat[TTS_HIP_K_COUNT]{};
     int attn_nsplit_override = 0;
 };
@@ -533,8 +535,12 @@ extern "C" int tts_hip_synchronize(tts_hip_ctx *c) {
 // ------------------------------------------------------------------------------------------------
 // kernel launch plumbing (+ optional per-class event timing)
 // ------------------------------------------------------------------------------------------------
+static bool prof_on(const tts_hip_ctx *c, int kclass) {
+    return c->prof || (c->prof_light && kclass >= TTS_HIP_K_DAC_EMBED);
+}
 static int prof_begin(tts_hip_ctx *c, int kclass, double bytes, double flops) {
-    if (!c->prof) return 0;
+    c->prof_cur = prof_on(c, kclass);
+    if (!c->prof_cur) return 0;
     ProfEv e;
     HIPCHK(hipEventCreate(&e.a));
     HIPCHK(hipEventCreate(&e.b));
@@ -547,7 +553,8 @@ static int prof_begin(tts_hip_ctx *c, int kclass, double bytes, double flops) {
     return 0;
 }
 static int prof_end(tts_hip_ctx *c) {
-    if (!c->prof) return 0;
+    if (!c->prof_cur) return 0;
+    c->prof_cur = false;
     HIPCHK(hipEventRecord(c->prof_events.back().b, c->stream));
     return 0;
 }
@@ -569,7 +576,8 @@ extern "C" int tts_hip_profile(tts_hip_ctx *c, int enable) {
     if (!c) return set_err("null ctx");
     HIPCHK(hipSetDevice(c->device));
     CHK(prof_collect(c));
-    c->prof = enable != 0;
+    c->prof = enable == 1;
+    c->prof_light = enable == 2;
     if (enable) memset(c->kstat, 0, sizeof(c->kstat));
     return 0;
 }

@@ -264,7 +264,8 @@ class HipEngine:
         return out[:n].copy()
 
     def profile(self, enable):
-        self._chk(self.L.tts_hip_profile(self.ctx, 1 if enable else 0))
+        """True/1: every launch (eager forwards); 2: DAC launches only (usable inside a timed region); False/0: off"""
+        self._chk(self.L.tts_hip_profile(self.ctx, int(enable)))
 
     def profile_get(self):
         res = {}
