@@ -284,6 +284,7 @@ def main():
             dom = max(stats, key=lambda k: stats[k]["ms_total"])
             st = stats[dom]
             src = "separate eager pass of the same workload on context 0 (decoder launches live inside hipGraphs in the timed region)"
+            share = st["ms_total"] / tot
             if live.get(dom, {}).get("launches"):
                 st = live[dom]   # the dominant kernel was bracketed live in the timed region
                 src = "HIP events around every launch of this kernel in the timed region (all contexts)"
@@ -299,7 +300,7 @@ def main():
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
             roof["traffic"] = pmc_traffic(dom, args, n_audio)
             roof.update({"kernel": dom, "timing_source": src, "avg_launch_us": round(per_launch_ms * 1e3, 3), "launches": st["launches"],
-                         "share_of_kernel_time": round(st["ms_total"] / tot, 3),
+                         "share_of_kernel_time": round(share, 3),
                          "algorithmic_bytes_per_launch": round(st["bytes_total"] / max(st["launches"], 1), 1)})
             out["roofline"] = roof
             out["kernel_classes"] = {
