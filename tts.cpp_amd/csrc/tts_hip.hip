@@ -183,6 +183,8 @@ struct tts_hip_ctx {
     int ln_fuse_max = 8;  // rows up to which LayerNorm stays fused in the GEMM prologue
     float *partials = nullptr;  // [8][RMAX][H] split-K slabs of the residual GEMMs
     int pending_parts = 0;      // slabs waiting to be folded into x by the next LayerNorm launch
+    int ln_waves = 1;           // rows (waves) per LayerNorm workgroup
+    int ksplit_big = 8;         // K slices for K >= 4096 residual GEMMs
     uint32_t *d_ids = nullptr, *d_pos = nullptr, *d_seq = nullptr, *d_tok = nullptr, *d_step = nullptr, *d_steps_done = nullptr;
     uint32_t *d_tokens_out = nullptr;
     size_t tokens_out_cap = 0;
@@ -246,6 +248,8 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (ns) c->attn_nsplit_override = atoi(ns);
     const char *lf = getenv("TTS_HIP_LN_FUSE_MAX");
     if (lf) c->ln_fuse_max = std::max(0, std::min(32, atoi(lf)));
+    if (const char *e = getenv("TTS_HIP_LN_WAVES")) c->ln_waves = std::max(1, std::min(4, atoi(e)));
+    if (const char *e = getenv("TTS_HIP_KSPLIT_BIG")) c->ksplit_big = std::max(1, std::min(8, atoi(e)));
     return c;
 }
 
@@ -657,8 +661,8 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
         // many rows: normalise once (one wave per row) instead of once per GEMM workgroup
         const bool h16 = w.type == TTS_HIP_F16;
         CHK(prof_begin(c, TTS_HIP_K_LN, (double) a.R * a.K * (h16 ? 6 : 8), 0));
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, (float *) a.A, a.K, a.ln_w, a.ln_b,
-                           h16 ? (float *) nullptr : c->dbg, h16 ? c->xn16 : (_Float16 *) nullptr, a.R,
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + c->ln_waves - 1) / c->ln_waves), dim3(64 * c->ln_waves), 0, c->stream, (float *) a.A, a.K,
+                           a.ln_w, a.ln_b, h16 ? (float *) nullptr : c->dbg, h16 ? c->xn16 : (_Float16 *) nullptr, a.R,
                            c->pending_parts ? (const float *) c->partials : (const float *) nullptr, c->pending_parts,
                            (int64_t) c->RMAX * c->H);
         c->pending_parts = 0;
@@ -670,7 +674,7 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
     }
     if (epi == EPI_RESID && a.R > c->ln_fuse_max && a.H <= 2048 && a.N == a.H && a.out == c->x) {
         // many rows: spread K over 4-8x more workgroups; the partial slabs are folded into x by the next LayerNorm
-        const int ks = a.K >= 4096 ? 8 : 4;
+        const int ks = a.K >= 4096 ? c->ksplit_big : 4;
         if (a.K % (ks * 256) == 0) {
             a.kchunk = a.K / ks;
             a.slab_stride = (int64_t) c->RMAX * c->H;
