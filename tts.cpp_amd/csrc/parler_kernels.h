@@ -649,3 +649,106 @@ __global__ void feed_kernel(FeedArgs a) {
         if (!not_seen && a.steps_done[r] == 0) a.steps_done[r] = step;
     }
 }
+
+// ================================================================================================
+// Quantised weights (GGUF Q4_0 / Q5_0 / Q8_0) with ggml's CPU semantics (upstream ggml knowledge, SURVEY.md
+// A.3): ggml_compute_forward_mul_mat converts the activation row to Q8_0 blocks (d = max|x|/127 per 32
+// values, q = roundf(x/d), d kept as fp16) and each 32-wide block contributes
+//       (fp16 d_w * fp16 d_a) * sum_j q_w[j] * q_a[j]        with the integer dot exact.
+// On the device the block integers are held as int8 (Q4_0: nibble-8, Q5_0: 5-bit value-16, Q8_0: as stored;
+// expanded once at upload, the scales stay fp16), a 32-wide block is exactly one v_mfma_i32_16x16x32_i8, and
+// the per-block scaling/accumulation runs in fp32 like ggml_vec_dot_q*_q8_0.
+// ================================================================================================
+typedef int int4v __attribute__((ext_vector_type(4)));
+
+// activation rows -> Q8_0 blocks: q int8 [R][K], d (fp16-rounded, stored as float) [R][K/32]
+__global__ void quant_rows_q8_kernel(const float *x, int lda, int K, int8_t *q, float *d, int R) {
+    const int r = blockIdx.y;
+    const int b = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);  // 32 threads per block of 32 values
+    const int j = threadIdx.x & 31;
+    if (r >= R || b >= K / 32) return;
+    const float v = x[(int64_t) r * lda + b * 32 + j];
+    float amax = fabsf(v);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float dd = amax / 127.0f;
+    const float id = dd ? 1.0f / dd : 0.0f;
+    q[(int64_t) r * K + b * 32 + j] = (int8_t) roundf(v * id);
+    if (j == 0) d[(int64_t) r * (K / 32) + b] = (float) (_Float16) dd;
+}
+
+struct QGemmArgs {
+    GemmArgs g;             // K, N, R, epilogue fields (out/ldo/q/kc/vc/...); g.W = int8 weights [N][K]
+    const _Float16 *wd;     // weight block scales [N][K/32]
+    const int8_t *aq;       // quantised activations [R][K]
+    const float *ad;        // activation block scales [R][K/32]
+};
+
+template <int EPI, int RB>
+__global__ __launch_bounds__(1024) void qgemm16_kernel(QGemmArgs qa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GemmArgs &a = qa.g;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int li = lane & 15, g = lane >> 4;
+    const int K = a.K, nb = K / 32;
+    const int kb = w * 256 + g * 8;  // this lane's 8 consecutive k inside each 32-wide block
+
+    // weights: 8 blocks x 8 int8 (one 64-bit load each); scales: 8 fp16 per owned output row
+    long wq[8];
+    const int8_t *wp = (const int8_t *) a.W + (int64_t) (n0 + li) * K + kb;
+#pragma unroll
+    for (int c = 0; c < 8; c++) wq[c] = *(const long *) (wp + c * 32);
+    half8 wds[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) wds[e] = *(const half8 *) (qa.wd + (int64_t) (n0 + g * 4 + e) * nb + w * 8);
+
+    for (int rg = 0; rg < a.R; rg += 16 * RB) {
+        float4v acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) {
+            acc[rb] = (float4v){0.f, 0.f, 0.f, 0.f};
+            const int r = rg + rb * 16 + li;
+            const int rr = r < a.R ? r : a.R - 1;
+            const int8_t *ap = qa.aq + (int64_t) rr * K + kb;
+            const float *adp = qa.ad + (int64_t) rr * nb + w * 8;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const long bq = *(const long *) (ap + c * 32);
+                int4v z = {0, 0, 0, 0};
+                z = __builtin_amdgcn_mfma_i32_16x16x32_i8(wq[c], bq, z, 0, 0, 0);  // exact block dot
+                const float da = adp[c];
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[rb][e] += (float) z[e] * ((float) wds[e][c] * da);
+            }
+        }
+        if (nw > 1) {
+            float *red = (float *) smem;  // [nw][RB][4][64]
+            if (rg > 0) __syncthreads();
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) red[((w * RB + rb) * 4 + e) * 64 + lane] = acc[rb][e];
+            __syncthreads();
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) {
+                if ((rb % nw) != w) continue;
+                float4v t;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float sum = red[((0 * RB + rb) * 4 + e) * 64 + lane];
+                    for (int ww = 1; ww < nw; ww++) sum += red[((ww * RB + rb) * 4 + e) * 64 + lane];
+                    t[e] = sum;
+                }
+                const int r = rg + rb * 16 + li;
+                if (r < a.R) gemm_epilogue4(a, EPI, r, n0 + g * 4, t);
+            }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) {
+                const int r = rg + rb * 16 + li;
+                if (r < a.R) gemm_epilogue4(a, EPI, r, n0 + g * 4, acc[rb]);
+            }
+        }
+    }
+}

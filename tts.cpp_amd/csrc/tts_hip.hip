@@ -122,8 +122,10 @@ static int dequant_to_f32(int type, const void *src, float *dst, int64_t n) {
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
+#define TTS_HIP_Q8I 100  // device-side: int8 block integers [N][K] followed by fp16 block scales [N][K/32]
+
 struct Tensor {
-    int type = 0;  // type as stored on the device (F32 or F16)
+    int type = 0;  // type as stored on the device (F32, F16 or TTS_HIP_Q8I)
     int n_dims = 0;
     int64_t ne[4] = {1, 1, 1, 1};
     size_t nbytes = 0;
@@ -134,6 +136,7 @@ struct Tensor {
 
 struct W {  // a matrix living in the arena
     size_t off = 0;
+    size_t soff = 0;  // TTS_HIP_Q8I: block scales
     int type = 0;
     int64_t K = 0, N = 0;
 };
@@ -146,7 +149,7 @@ struct PLayer {
 struct DRes { size_t in_alpha, in_w, in_b, out_alpha, out_w, out_b; };
 struct DBlock { int stride, padding, cin, cout; size_t alpha, w, b; DRes res[3]; };
 
-struct CopyItem { size_t dst; std::string src; };
+struct CopyItem { size_t dst; std::string src; size_t src_off = 0; size_t bytes = 0; };  // bytes == 0: the whole tensor
 
 struct ProfEv { hipEvent_t a, b; int kclass; };
 
@@ -182,9 +185,11 @@ struct tts_hip_ctx {
     _Float16 *u16 = nullptr, *xn16 = nullptr, *att16 = nullptr;
     int ln_fuse_max = 8;  // rows up to which LayerNorm stays fused in the GEMM prologue
     float *partials = nullptr;  // [8][RMAX][H] split-K slabs of the residual GEMMs
+    int8_t *aq = nullptr;       // Q8_0-quantised activation rows [RMAX][max(H,F)]
+    float *ad = nullptr;        // their block scales
     int pending_parts = 0;      // slabs waiting to be folded into x by the next LayerNorm launch
     int ln_waves = 1;           // rows (waves) per LayerNorm workgroup
-    int ksplit_big = 8;         // K slices for K >= 4096 residual GEMMs
+    int ksplit_big = 4;         // K slices for K >= 4096 residual GEMMs
     uint32_t *d_ids = nullptr, *d_pos = nullptr, *d_seq = nullptr, *d_tok = nullptr, *d_step = nullptr, *d_steps_done = nullptr;
     uint32_t *d_tokens_out = nullptr;
     size_t tokens_out_cap = 0;
@@ -263,7 +268,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (auto &t : c->tensors) free_dev(t.second.tmp);
     if (!c->arena_external) free_dev(c->arena);
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
-    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
+    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
     free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
     free_dev(c->d_eos); free_dev(c->d_codes); free_dev(c->d_frames);
     for (int i = 0; i < 3; i++) free_dev(c->dbuf[i]);
@@ -290,6 +295,38 @@ static bool starts_with(const std::string &s, const char *pre) { return s.compar
 
 // Which uploaded tensors stay fp16 on the device: the big decoder matrices and embedding tables.
 // Norm vectors, positional table, text encoding and the whole DAC are kept fp32.
+// decoder matrices that are only ever used through mul_mat (not get_rows): eligible for the integer path
+static bool is_matmul_weight(const std::string &name) {
+    return starts_with(name, "decoder.") && (ends_with(name, "_proj.weight") || ends_with(name, "fc1.weight") ||
+                                              ends_with(name, "fc2.weight") || ends_with(name, "weight.head"));
+}
+
+// Q4_0 / Q5_0 / Q8_0 blocks -> int8 block integers + fp16 scales (exact: the integers of the block formats)
+static int expand_q_to_i8(int type, const void *src, int64_t n, int8_t *q, uint16_t *d) {
+    const uint8_t *p = (const uint8_t *) src;
+    for (int64_t b = 0; b < n / 32; b++, q += 32) {
+        memcpy(&d[b], p, 2);
+        if (type == TTS_HIP_Q4_0) {
+            const uint8_t *qs = p + 2;
+            for (int j = 0; j < 16; j++) { q[j] = (int8_t) ((int) (qs[j] & 0xF) - 8); q[j + 16] = (int8_t) ((int) (qs[j] >> 4) - 8); }
+            p += 18;
+        } else if (type == TTS_HIP_Q5_0) {
+            uint32_t qh;
+            memcpy(&qh, p + 2, 4);
+            const uint8_t *qs = p + 6;
+            for (int j = 0; j < 16; j++) {
+                q[j] = (int8_t) ((int) ((qs[j] & 0xF) | (((qh >> j) & 1) << 4)) - 16);
+                q[j + 16] = (int8_t) ((int) ((qs[j] >> 4) | (((qh >> (j + 16)) & 1) << 4)) - 16);
+            }
+            p += 22;
+        } else if (type == TTS_HIP_Q8_0) {
+            memcpy(q, p + 2, 32);
+            p += 34;
+        } else return -1;
+    }
+    return 0;
+}
+
 static bool keeps_f16(const std::string &name) {
     if (!starts_with(name, "decoder.")) return false;
     if (name.find("layer_norm") != std::string::npos) return false;
@@ -317,12 +354,21 @@ extern "C" int tts_hip_upload(tts_hip_ctx *c, const char *name_c, int type, int 
     const size_t src_bytes = type_row_bytes(type, t.ne[0]) * (size_t) (n / t.ne[0]);
     if (src_bytes == 0) return set_err("tts_hip_upload(%s): unsupported ggml type %d", name_c, type);
     const bool keep16 = (type == TTS_HIP_F16) && keeps_f16(name);
-    t.type = keep16 ? TTS_HIP_F16 : TTS_HIP_F32;
-    t.nbytes = (size_t) n * (keep16 ? 2 : 4);
+    const bool quant = type == TTS_HIP_Q4_0 || type == TTS_HIP_Q5_0 || type == TTS_HIP_Q8_0;
+    const bool q8i = quant && is_matmul_weight(name) && n_dims == 2 && (t.ne[0] % 256 == 0) && !(c->d.flags & TTS_HIP_FLAG_DEQUANT_Q) &&
+                     !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM);
+    t.type = q8i ? TTS_HIP_Q8I : (keep16 ? TTS_HIP_F16 : TTS_HIP_F32);
+    t.nbytes = q8i ? (size_t) n + (size_t) (n / 32) * 2 : (size_t) n * (keep16 ? 2 : 4);
     t.has_data = host != nullptr;
     if (host) {
         HIPCHK(hipMalloc(&t.tmp, t.nbytes));
-        if (keep16 || type == TTS_HIP_F32) {
+        if (q8i) {
+            std::vector<int8_t> q((size_t) n);
+            std::vector<uint16_t> d((size_t) (n / 32));
+            if (expand_q_to_i8(type, host, n, q.data(), d.data()) != 0) return set_err("tts_hip_upload(%s): block expansion failed", name_c);
+            HIPCHK(hipMemcpy(t.tmp, q.data(), (size_t) n, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy((char *) t.tmp + n, d.data(), (size_t) (n / 32) * 2, hipMemcpyHostToDevice));
+        } else if (keep16 || type == TTS_HIP_F32) {
             HIPCHK(hipMemcpy(t.tmp, host, t.nbytes, hipMemcpyHostToDevice));
         } else {
             std::vector<float> f((size_t) n);
@@ -367,14 +413,7 @@ struct Planner {
         if (t && t->type != TTS_HIP_F32 && err.empty()) err = "tensor '" + n + "' must be fp32";
         return place(n);
     }
-    W mat(const std::string &n) {
-        W w;
-        const Tensor *t = get(n);
-        if (!t) return w;
-        w.type = t->type; w.K = t->ne[0]; w.N = t->nelem() / t->ne[0];
-        w.off = place(n);
-        return w;
-    }
+    W mat(const std::string &n) { return fused({n}); }
     // several same-shaped matrices stacked along N
     W fused(const std::vector<std::string> &names) {
         W w;
@@ -389,9 +428,20 @@ struct Planner {
                 if (err.empty()) err = "tensors fused with '" + names[0] + "' differ in type/shape: '" + names[i] + "'";
                 return w;
             }
-            c->copies.push_back({cur, names[i]});
-            cur += t->nbytes;
+            const size_t main_bytes = t->type == TTS_HIP_Q8I ? (size_t) t->nelem() : t->nbytes;
+            c->copies.push_back({cur, names[i], 0, main_bytes});
+            cur += main_bytes;
             w.N += t->nelem() / t->ne[0];
+        }
+        if (w.type == TTS_HIP_Q8I) {  // the block scales of the stacked matrices, [N_total][K/32] fp16
+            cur = (cur + 255) & ~(size_t) 255;
+            w.soff = cur;
+            for (auto &nm : names) {
+                const Tensor *t = get(nm);
+                const size_t sb = (size_t) (t->nelem() / 32) * 2;
+                c->copies.push_back({cur, nm, (size_t) t->nelem(), sb});
+                cur += sb;
+            }
         }
         return w;
     }
@@ -629,11 +679,66 @@ static int launch_gemm16_rb(tts_hip_ctx *c, const GemmArgs &a) {
 
 static int max_rows_for(const tts_hip_ctx *) { return 256; }
 
+template <int EPI, int RB>
+static int launch_qgemm16(tts_hip_ctx *c, const QGemmArgs &qa) {
+    const int nw = qa.g.K / 256;
+    const size_t lds = nw > 1 ? (size_t) nw * RB * 4 * 64 * 4 : 0;
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void *) qgemm16_kernel<EPI, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL((qgemm16_kernel<EPI, RB>), dim3(qa.g.N / 16), dim3(nw * 64), lds, c->stream, qa);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <int EPI>
+static int launch_qgemm16_rb(tts_hip_ctx *c, const QGemmArgs &qa) {
+    if (qa.g.R <= 16) return launch_qgemm16<EPI, 1>(c, qa);
+    if (qa.g.R <= 32) return launch_qgemm16<EPI, 2>(c, qa);
+    return launch_qgemm16<EPI, 4>(c, qa);
+}
+
+// GGUF-quantised matrix: LayerNorm (if any) -> Q8_0-quantise the activation rows -> integer block GEMM
+static int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi) {
+    if (pro == PRO_F16) return set_err("run_qgemm: fp16 activations are never produced for a quantised consumer");
+    const float *src = (const float *) a.A;
+    int lda = a.lda;
+    if (pro == PRO_LN) {
+        CHK(prof_begin(c, TTS_HIP_K_LN, (double) a.R * a.K * 8, 0));
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + c->ln_waves - 1) / c->ln_waves), dim3(64 * c->ln_waves), 0, c->stream, (float *) a.A, a.K,
+                           a.ln_w, a.ln_b, c->dbg, (_Float16 *) nullptr, a.R,
+                           c->pending_parts ? (const float *) c->partials : (const float *) nullptr, c->pending_parts, (int64_t) c->RMAX * c->H);
+        HIPCHK(hipGetLastError());
+        c->pending_parts = 0;
+        CHK(prof_end(c));
+        src = c->dbg;
+        lda = a.K;
+    }
+    const double wbytes = (double) w.K * w.N * (1.0 + 2.0 / 32);
+    CHK(prof_begin(c, kclass, wbytes + (double) a.R * a.K * 5 + (double) a.R * a.N * 4, 2.0 * a.R * (double) w.K * w.N));
+    hipLaunchKernelGGL(quant_rows_q8_kernel, dim3((a.K / 32 + 7) / 8, a.R), dim3(256), 0, c->stream, src, lda, a.K, c->aq, c->ad, a.R);
+    HIPCHK(hipGetLastError());
+    QGemmArgs qa{};
+    qa.g = a;
+    qa.wd = (const _Float16 *) (c->arena + w.soff);
+    qa.aq = c->aq;
+    qa.ad = c->ad;
+    int rc;
+    if (epi == EPI_STORE) rc = launch_qgemm16_rb<EPI_STORE>(c, qa);
+    else if (epi == EPI_QKV) rc = launch_qgemm16_rb<EPI_QKV>(c, qa);
+    else if (epi == EPI_RESID) rc = launch_qgemm16_rb<EPI_RESID>(c, qa);
+    else rc = launch_qgemm16_rb<EPI_GELU>(c, qa);
+    CHK(rc);
+    return prof_end(c);
+}
+
 // one GEMM of the forward: picks MFMA or the scalar reference path
 static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi) {
     a.W = c->arena + w.off;
     a.K = (int) w.K;
     a.N = (int) w.N;
+    if (w.type == TTS_HIP_Q8I) return run_qgemm(c, kclass, w, a, pro, epi);
     const double wbytes = (double) w.K * w.N * (w.type == TTS_HIP_F16 ? 2 : 4);
     const double bytes = wbytes + (double) a.R * a.K * 4 + (double) a.R * a.N * 4;
     const double flops = 2.0 * a.R * (double) w.K * w.N;
@@ -868,7 +973,10 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
     bool all = true, any = false;
     for (auto &ci : c->copies) {
         Tensor &t = c->tensors[ci.src];
-        if (t.has_data) { any = true; HIPCHK(hipMemcpy(c->arena + ci.dst, t.tmp, t.nbytes, hipMemcpyDeviceToDevice)); }
+        if (t.has_data) {
+            any = true;
+            HIPCHK(hipMemcpy(c->arena + ci.dst, (const char *) t.tmp + ci.src_off, ci.bytes ? ci.bytes : t.nbytes, hipMemcpyDeviceToDevice));
+        }
         else all = false;
     }
     if (any && !all) return set_err("tts_hip_finalize: some tensors were uploaded with data and some without");
@@ -896,6 +1004,8 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->xn16, (size_t) R * H));
         CHK(dmalloc(&c->att16, (size_t) R * H));
         CHK(dmalloc(&c->partials, (size_t) 8 * R * H));
+        CHK(dmalloc(&c->aq, (size_t) R * std::max(H, c->F)));
+        CHK(dmalloc(&c->ad, (size_t) R * std::max(H, c->F) / 32));
         CHK(dmalloc(&c->logits, (size_t) R * c->NO * c->V));
         CHK(dmalloc(&c->part, (size_t) R * c->NH * 16 * 66));
         CHK(dmalloc(&c->d_ids, (size_t) R * c->NO));
