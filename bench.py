@@ -92,6 +92,16 @@ def pmc_traffic(kclass, args, n_audio):
     return None if v is None else round(v["hbm_bytes_per_launch"], 1)
 
 
+_TAIL = "f32 accumulate and residual stream; KV cache f32; DAC codec f32 (exact-f32 MFMA)"
+DTYPE_DETAIL = {
+    "f16": "decoder: f16 weights, f16 MFMA inputs, " + _TAIL,
+    "f32": "decoder: f32 weights and activations (exact-f32 MFMA), " + _TAIL,
+    "q8_0": "decoder: Q8_0 weights x Q8_0-quantised activations, int8 MFMA block dots, fp16 block scales, " + _TAIL,
+    "q5_0": "decoder: Q5_0 weights x Q8_0-quantised activations, int8 MFMA block dots, fp16 block scales, " + _TAIL,
+    "q4_0": "decoder: Q4_0 weights x Q8_0-quantised activations, int8 MFMA block dots, fp16 block scales, " + _TAIL,
+}
+
+
 def cpu_baseline(model, cfg, prompt, threads):
     """The oracle ("port": restated CPU path, ggml unavailable) on the host cores, bounded sample:
     prompt prefill + a few audio steps + a few DAC frames, extrapolated per frame."""
@@ -143,6 +153,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--model", choices=["mini", "small", "tiny"], default="mini")
+    ap.add_argument("--wtype", choices=["f16", "f32", "q8_0", "q5_0", "q4_0"], default="f16",
+                    help="GGUF type of the decoder matrices (headline: f16; q*: integer path with Q8_0 activations)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -163,7 +175,9 @@ def main():
 
         tdist.init(backend, rank, world, device=torch.device("cuda", local_rank))
 
-    cfg = {"mini": synth.parler_mini, "small": synth.small, "tiny": synth.tiny}[args.model](weight_type=gguf.F16)
+    cfg = {"mini": synth.parler_mini, "small": synth.small, "tiny": synth.tiny}[args.model](
+        weight_type={"f16": gguf.F16, "f32": gguf.F32, "q8_0": gguf.Q8_0, "q5_0": gguf.Q5_0, "q4_0": gguf.Q4_0}[args.wtype])
+    WNAME = dict(f16="fp16", f32="fp32").get(args.wtype, args.wtype)
     n_audio = min(args.audio_steps, cfg.max_gen - args.prompt_len, cfg.ctx - args.prompt_len)
     kv_type = gguf.F16 if args.kv == "f16" else gguf.F32
 
@@ -254,11 +268,11 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f16",
-        "dtype_detail": "decoder: f16 weights, f16 MFMA inputs, f32 accumulate and residual stream; KV cache f32; DAC codec f32 (exact-f32 MFMA)",
+        "dtype": {"f16": "f16", "f32": "f32"}.get(args.wtype, "i8"),
+        "dtype_detail": DTYPE_DETAIL[args.wtype],
         "data": "synthetic (seeded random weights of the Parler-TTS-Mini + DAC-44k architecture; fixed-length greedy generation)",
         "config": {
-            "workload": f"configs[1]: Parler-TTS-Mini fp16 on MI355X, greedy decode + DAC codec; {args.streams} context(s) x {args.batch} utterances/GPU in lock-step, "
+            "workload": f"configs[1]: Parler-TTS-Mini {WNAME} on MI355X, greedy decode + DAC codec; {args.streams} context(s) x {args.batch} utterances/GPU in lock-step, "
                         f"{args.prompt_len}-id prompt, {n_audio} audio steps (={n_audio - cfg.n_out + 1} frames, "
                         f"{(n_audio - cfg.n_out + 1) * cfg.hop / SAMPLE_RATE:.2f} s audio) per utterance",
             "utterances_per_gpu": args.batch * args.streams, "contexts_per_gpu": args.streams, "lockstep_batch": args.batch, "audio_steps": n_audio, "prompt_len": args.prompt_len,

@@ -431,6 +431,35 @@ def test_integer_path_is_closer_to_ggml_semantics_than_dequantised_weights():
     assert relerr(res["integer"], refs[1]) < relerr(res["integer"], refs[0]) or relerr(res["integer"], refs[1]) < 1e-5
 
 
+@pytest.mark.parametrize("rows", [1, 3, 20, 40])
+def test_integer_path_full_width_shapes(rows):
+    """Parler-Mini's matrix shapes (H=1024, F=4096; one layer): split-K slabs of the residual GEMMs (K=1024 -> 4x256,
+    K=4096 -> 4x1024 with 4 waves), folded by the next LayerNorm; rows <= 16 quantise inside the GEMM workgroups,
+    more rows through quant_rows_q8_kernel with 2 / 4 row blocks per wave."""
+    key = ("wide1", gguf.Q5_0)
+    if key not in _models:
+        _models[key] = synth.build(synth.tiny(hidden=1024, heads=16, ffn=4096, layers=1, weight_type=gguf.Q5_0))
+    model = _models[key]
+    cfg = model.cfg
+    eng = hip.HipEngine(cfg, max_seqs=rows)
+    eng.load(model)
+    rng = np.random.default_rng(rows)
+    prompts = [rng.integers(3, cfg.prompt_vocab, 2 + (i % 3)).astype(np.uint32) for i in range(rows)]
+    eng.prefill_batch(prompts)
+    ids = np.full((rows, cfg.n_out), cfg.bos, dtype=np.uint32)
+    lg = eng.step(ids, [len(p) for p in prompts])
+    exact = 0
+    for s in range(min(rows, 6)):
+        o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+        o.decode(prompts[s], 0, audio=False, want_logits=False)
+        ref, _ = o.decode(ids[s], len(prompts[s]), audio=True)
+        e = relerr(lg[s], ref[:, 0, :])
+        assert e < Q_FLIP_TOL, (s, e)
+        exact += e < 1e-5
+    assert exact >= min(rows, 6) - 2   # most utterances see no flipped activation at all
+    eng.close()
+
+
 def test_update_conditional_prompt():
     model = get_model("tiny", gguf.F32)
     cfg = model.cfg

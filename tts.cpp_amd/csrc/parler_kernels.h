@@ -684,24 +684,118 @@ struct QGemmArgs {
     const float *ad;        // activation block scales [R][K/32]
 };
 
-template <int EPI, int RB>
-__global__ __launch_bounds__(1024) void qgemm16_kernel(QGemmArgs qa) {
+// 4 consecutive values of a Q8_0 block held by each of 8 neighbouring lanes -> the lane's 4 int8 (packed) and the
+// block scale; same arithmetic as quant_rows_q8_kernel / ggml's quantize_row_q8_0_ref.
+__device__ __forceinline__ unsigned quant4_q8(float4v y, float &d_out) {
+    float amax = fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3])));
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    amax = fmaxf(amax, __shfl_xor(amax, 4));
+    const float dd = amax / 127.0f;
+    const float id = dd ? 1.0f / dd : 0.0f;
+    unsigned q = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) q |= ((unsigned) (int) roundf(y[e] * id) & 0xFFu) << (8 * e);
+    d_out = (float) (_Float16) dd;
+    return q;
+}
+
+// QPRO 0: activations pre-quantised by quant_rows_q8_kernel (qa.aq / qa.ad).
+// QPRO 1: (R <= 16) the workgroup quantises the fp32 rows itself: every wave its own 256-column slice of each row,
+//         4 values per lane, into LDS (int8 + block scales); the MFMA operands are then read from LDS.
+// QPRO 2: (R <= 8, no split-K, K <= 2048) LayerNorm first: wave r % nw holds row r in registers (as gemm16_kernel's
+//         PRO_LN), normalises and quantises it into LDS.
+// split-K like gemm16_kernel: blockIdx.y owns `kchunk` columns, EPI_STORE writes slab blockIdx.y.
+template <int EPI, int RB, int QPRO>
+__global__ __launch_bounds__(QPRO == 2 ? 512 : 1024) void qgemm16_kernel(QGemmArgs qa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemmArgs &a = qa.g;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const int n0 = blockIdx.x * 16;
     const int li = lane & 15, g = lane >> 4;
     const int K = a.K, nb = K / 32;
-    const int kb = w * 256 + g * 8;  // this lane's 8 consecutive k inside each 32-wide block
+    const int k0 = a.kchunk ? blockIdx.y * a.kchunk : 0;
+    const int kb = k0 + w * 256 + g * 8;  // this lane's 8 consecutive k inside each 32-wide block
+    const int b0 = (k0 >> 5) + w * 8;     // first of this wave's 8 blocks
 
     // weights: 8 blocks x 8 int8 (one 64-bit load each); scales: 8 fp16 per owned output row
     long wq[8];
     const int8_t *wp = (const int8_t *) a.W + (int64_t) (n0 + li) * K + kb;
 #pragma unroll
-    for (int c = 0; c < 8; c++) wq[c] = *(const long *) (wp + c * 32);
+    for (int c = 0; c < 8; c++) wq[c] = __builtin_nontemporal_load((const long *) (wp + c * 32));
     half8 wds[4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) wds[e] = *(const half8 *) (qa.wd + (int64_t) (n0 + g * 4 + e) * nb + w * 8);
+    for (int e = 0; e < 4; e++) wds[e] = *(const half8 *) (qa.wd + (int64_t) (n0 + g * 4 + e) * nb + b0);
+
+    // LDS: qs int8 [R][Kc] | ds float [R][Kc/32] | red   (Kc = the K range of this workgroup)
+    const int Kc = nw * 256;
+    int8_t *qs = (int8_t *) smem;
+    float *ds = (float *) (smem + (((size_t) a.R * Kc + 15) & ~(size_t) 15));
+    size_t red_off = 0;
+    if (QPRO >= 1) {
+        red_off = (((size_t) a.R * Kc + 15) & ~(size_t) 15) + (((size_t) a.R * (Kc / 32) * 4 + 15) & ~(size_t) 15);
+        const float *A = (const float *) a.A;
+        if (QPRO == 2) {
+            for (int r = w; r < a.R; r += nw) {
+                const float *xr = A + (int64_t) r * a.lda;
+                float4v v[8], lwv[8], lbv[8];
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int k = i * 256 + lane * 4;
+                    if (k < K) {
+                        v[i] = *(const float4v *) (xr + k);
+                        lwv[i] = *(const float4v *) (a.ln_w + k);
+                        lbv[i] = *(const float4v *) (a.ln_b + k);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (i * 256 + lane * 4 < K) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+                const float mean = wave_sum(s) / (float) K;
+                float s2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (i * 256 + lane * 4 < K) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { const float d = v[i][e] - mean; s2 += d * d; }
+                    }
+                }
+                const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float) K + LN_EPS);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int k = i * 256 + lane * 4;
+                    if (k < K) {
+                        float4v y;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) y[e] = (v[i][e] - mean) * rstd * lwv[i][e] + lbv[i][e];
+                        float dd;
+                        const unsigned q = quant4_q8(y, dd);
+                        *(unsigned *) (qs + (size_t) r * Kc + k) = q;
+                        if ((lane & 7) == 0) ds[r * (Kc / 32) + (k >> 5)] = dd;
+                    }
+                }
+            }
+        } else {
+            const int kk = w * 256 + lane * 4;  // inside this workgroup's K range
+            for (int r0 = 0; r0 < a.R; r0 += 4) {
+                float4v x[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (r0 + j < a.R) x[j] = *(const float4v *) (A + (int64_t) (r0 + j) * a.lda + k0 + kk);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (r0 + j < a.R) {
+                        float dd;
+                        const unsigned q = quant4_q8(x[j], dd);
+                        *(unsigned *) (qs + (size_t) (r0 + j) * Kc + kk) = q;
+                        if ((lane & 7) == 0) ds[(r0 + j) * (Kc / 32) + (kk >> 5)] = dd;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
 
     for (int rg = 0; rg < a.R; rg += 16 * RB) {
         float4v acc[RB];
@@ -710,20 +804,34 @@ __global__ __launch_bounds__(1024) void qgemm16_kernel(QGemmArgs qa) {
             acc[rb] = (float4v){0.f, 0.f, 0.f, 0.f};
             const int r = rg + rb * 16 + li;
             const int rr = r < a.R ? r : a.R - 1;
-            const int8_t *ap = qa.aq + (int64_t) rr * K + kb;
-            const float *adp = qa.ad + (int64_t) rr * nb + w * 8;
+            if (QPRO >= 1) {
+                const int8_t *ap = qs + (size_t) rr * Kc + w * 256 + g * 8;
+                const float *adp = ds + rr * (Kc / 32) + w * 8;
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const long bq = *(const long *) (ap + c * 32);
-                int4v z = {0, 0, 0, 0};
-                z = __builtin_amdgcn_mfma_i32_16x16x32_i8(wq[c], bq, z, 0, 0, 0);  // exact block dot
-                const float da = adp[c];
+                for (int c = 0; c < 8; c++) {
+                    const long bq = *(const long *) (ap + c * 32);
+                    int4v z = {0, 0, 0, 0};
+                    z = __builtin_amdgcn_mfma_i32_16x16x32_i8(wq[c], bq, z, 0, 0, 0);
+                    const float da = adp[c];
 #pragma unroll
-                for (int e = 0; e < 4; e++) acc[rb][e] += (float) z[e] * ((float) wds[e][c] * da);
+                    for (int e = 0; e < 4; e++) acc[rb][e] += (float) z[e] * ((float) wds[e][c] * da);
+                }
+            } else {
+                const int8_t *ap = qa.aq + (int64_t) rr * K + kb;
+                const float *adp = qa.ad + (int64_t) rr * nb + b0;
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const long bq = *(const long *) (ap + c * 32);
+                    int4v z = {0, 0, 0, 0};
+                    z = __builtin_amdgcn_mfma_i32_16x16x32_i8(wq[c], bq, z, 0, 0, 0);  // exact block dot
+                    const float da = adp[c];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[rb][e] += (float) z[e] * ((float) wds[e][c] * da);
+                }
             }
         }
         if (nw > 1) {
-            float *red = (float *) smem;  // [nw][RB][4][64]
+            float *red = (float *) (smem + red_off);  // [nw][RB][4][64]
             if (rg > 0) __syncthreads();
 #pragma unroll
             for (int rb = 0; rb < RB; rb++)

@@ -187,6 +187,8 @@ struct tts_hip_ctx {
     float *partials = nullptr;  // [8][RMAX][H] split-K slabs of the residual GEMMs
     int8_t *aq = nullptr;       // Q8_0-quantised activation rows [RMAX][max(H,F)]
     float *ad = nullptr;        // their block scales
+    bool all_q8i = false;       // every decoder matrix is on the integer path (all GEMMs go through run_qgemm)
+    int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
     int pending_parts = 0;      // slabs waiting to be folded into x by the next LayerNorm launch
     int ln_waves = 1;           // rows (waves) per LayerNorm workgroup
     int ksplit_big = 4;         // K slices for K >= 4096 residual GEMMs
@@ -255,6 +257,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (lf) c->ln_fuse_max = std::max(0, std::min(32, atoi(lf)));
     if (const char *e = getenv("TTS_HIP_LN_WAVES")) c->ln_waves = std::max(1, std::min(4, atoi(e)));
     if (const char *e = getenv("TTS_HIP_KSPLIT_BIG")) c->ksplit_big = std::max(1, std::min(8, atoi(e)));
+    if (const char *e = getenv("TTS_HIP_Q_FUSE_MAX")) c->q_fuse_max = std::max(0, std::min(16, atoi(e)));
     return c;
 }
 
@@ -497,6 +500,11 @@ static int plan(tts_hip_ctx *c) {
             y.fc2 = P.mat(p + "fc2.weight");
         }
         c->F = c->layers.empty() ? 0 : (int) c->layers[0].fc1.N;
+        c->all_q8i = c->heads.type == TTS_HIP_Q8I;
+        for (const PLayer &y : c->layers) {
+            c->all_q8i = c->all_q8i && y.qkv.type == TTS_HIP_Q8I && y.o.type == TTS_HIP_Q8I && y.fc1.type == TTS_HIP_Q8I && y.fc2.type == TTS_HIP_Q8I;
+            if (d.use_cross_attn) c->all_q8i = c->all_q8i && y.cq.type == TTS_HIP_Q8I && y.co.type == TTS_HIP_Q8I;
+        }
         if (d.use_cross_attn) {
             // voice-prompt encoding gets ECAP rows so that update_conditional_prompt fits (model.cpp:129-136)
             const Tensor *t = P.get("decoder.text_encoding");
@@ -679,32 +687,36 @@ static int launch_gemm16_rb(tts_hip_ctx *c, const GemmArgs &a) {
 
 static int max_rows_for(const tts_hip_ctx *) { return 256; }
 
-template <int EPI, int RB>
+template <int EPI, int RB, int QPRO>
 static int launch_qgemm16(tts_hip_ctx *c, const QGemmArgs &qa) {
-    const int nw = qa.g.K / 256;
-    const size_t lds = nw > 1 ? (size_t) nw * RB * 4 * 64 * 4 : 0;
+    const int kc = qa.g.kchunk ? qa.g.kchunk : qa.g.K;
+    const int nw = kc / 256;
+    size_t lds = nw > 1 ? (size_t) nw * RB * 4 * 64 * 4 : 0;
+    if (QPRO >= 1) lds += (((size_t) qa.g.R * kc + 15) & ~(size_t) 15) + (((size_t) qa.g.R * (kc / 32) * 4 + 15) & ~(size_t) 15);
     static bool attr = false;
     if (!attr) {
-        HIPCHK(hipFuncSetAttribute((const void *) qgemm16_kernel<EPI, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) qgemm16_kernel<EPI, RB, QPRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL((qgemm16_kernel<EPI, RB>), dim3(qa.g.N / 16), dim3(nw * 64), lds, c->stream, qa);
+    hipLaunchKernelGGL((qgemm16_kernel<EPI, RB, QPRO>), dim3(qa.g.N / 16, qa.g.K / kc), dim3(nw * 64), lds, c->stream, qa);
     HIPCHK(hipGetLastError());
     return 0;
 }
 template <int EPI>
-static int launch_qgemm16_rb(tts_hip_ctx *c, const QGemmArgs &qa) {
-    if (qa.g.R <= 16) return launch_qgemm16<EPI, 1>(c, qa);
-    if (qa.g.R <= 32) return launch_qgemm16<EPI, 2>(c, qa);
-    return launch_qgemm16<EPI, 4>(c, qa);
+static int launch_qgemm16_rb(tts_hip_ctx *c, const QGemmArgs &qa, bool fused_quant, bool fused_ln) {
+    if (fused_ln) return launch_qgemm16<EPI, 1, 2>(c, qa);
+    if (fused_quant) return launch_qgemm16<EPI, 1, 1>(c, qa);
+    if (qa.g.R <= 16) return launch_qgemm16<EPI, 1, 0>(c, qa);
+    if (qa.g.R <= 32) return launch_qgemm16<EPI, 2, 0>(c, qa);
+    return launch_qgemm16<EPI, 4, 0>(c, qa);
 }
 
 // GGUF-quantised matrix: LayerNorm (if any) -> Q8_0-quantise the activation rows -> integer block GEMM
 static int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi) {
     if (pro == PRO_F16) return set_err("run_qgemm: fp16 activations are never produced for a quantised consumer");
-    const float *src = (const float *) a.A;
-    int lda = a.lda;
-    if (pro == PRO_LN) {
+    // few rows: LayerNorm + quantisation inside every GEMM workgroup (one launch instead of three)
+    const bool fused_ln = pro == PRO_LN && a.R <= std::min(c->ln_fuse_max, 8) && a.K <= 2048 && !c->pending_parts && c->q_fuse_max > 0;
+    if (pro == PRO_LN && !fused_ln) {
         CHK(prof_begin(c, TTS_HIP_K_LN, (double) a.R * a.K * 8, 0));
         hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + c->ln_waves - 1) / c->ln_waves), dim3(64 * c->ln_waves), 0, c->stream, (float *) a.A, a.K,
                            a.ln_w, a.ln_b, c->dbg, (_Float16 *) nullptr, a.R,
@@ -712,23 +724,37 @@ static int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro
         HIPCHK(hipGetLastError());
         c->pending_parts = 0;
         CHK(prof_end(c));
-        src = c->dbg;
-        lda = a.K;
+        a.A = c->dbg;
+        a.lda = a.K;
+    }
+    const bool fused_quant = fused_ln || a.R <= c->q_fuse_max;  // up to 16 rows: each workgroup quantises them itself
+    if (epi == EPI_RESID && a.R > c->ln_fuse_max && a.H <= 2048 && a.N == a.H && a.out == c->x) {
+        // N = H only gives H/16 workgroups: spread K over 4x more; the slabs are folded into x by the next LayerNorm
+        const int ks = a.K >= 4096 ? c->ksplit_big : 4;
+        if (a.K % (ks * 256) == 0) {
+            a.kchunk = a.K / ks;
+            a.slab_stride = (int64_t) c->RMAX * c->H;
+            a.out = c->partials;
+            epi = EPI_STORE;
+            c->pending_parts = ks;
+        }
     }
     const double wbytes = (double) w.K * w.N * (1.0 + 2.0 / 32);
     CHK(prof_begin(c, kclass, wbytes + (double) a.R * a.K * 5 + (double) a.R * a.N * 4, 2.0 * a.R * (double) w.K * w.N));
-    hipLaunchKernelGGL(quant_rows_q8_kernel, dim3((a.K / 32 + 7) / 8, a.R), dim3(256), 0, c->stream, src, lda, a.K, c->aq, c->ad, a.R);
-    HIPCHK(hipGetLastError());
+    if (!fused_quant) {
+        hipLaunchKernelGGL(quant_rows_q8_kernel, dim3((a.K / 32 + 7) / 8, a.R), dim3(256), 0, c->stream, (const float *) a.A, a.lda, a.K, c->aq, c->ad, a.R);
+        HIPCHK(hipGetLastError());
+    }
     QGemmArgs qa{};
     qa.g = a;
     qa.wd = (const _Float16 *) (c->arena + w.soff);
     qa.aq = c->aq;
     qa.ad = c->ad;
     int rc;
-    if (epi == EPI_STORE) rc = launch_qgemm16_rb<EPI_STORE>(c, qa);
-    else if (epi == EPI_QKV) rc = launch_qgemm16_rb<EPI_QKV>(c, qa);
-    else if (epi == EPI_RESID) rc = launch_qgemm16_rb<EPI_RESID>(c, qa);
-    else rc = launch_qgemm16_rb<EPI_GELU>(c, qa);
+    if (epi == EPI_STORE) rc = launch_qgemm16_rb<EPI_STORE>(c, qa, fused_quant, fused_ln);
+    else if (epi == EPI_QKV) rc = launch_qgemm16_rb<EPI_QKV>(c, qa, fused_quant, fused_ln);
+    else if (epi == EPI_RESID) rc = launch_qgemm16_rb<EPI_RESID>(c, qa, fused_quant, fused_ln);
+    else rc = launch_qgemm16_rb<EPI_GELU>(c, qa, fused_quant, fused_ln);
     CHK(rc);
     return prof_end(c);
 }
