@@ -76,6 +76,8 @@ typedef struct tts_hip_desc {
 #define TTS_HIP_FLAG_VALU_GEMM  2u  /* use the scalar-FMA reference GEMV kernels instead of MFMA (debug/parity) */
 #define TTS_HIP_FLAG_NO_DAC     4u  /* context carries no audio codec */
 #define TTS_HIP_FLAG_NO_PARLER  8u  /* context carries only the audio codec */
+#define TTS_HIP_FLAG_DAC_F32    32u /* F16 codec tensors: compute with fp32 activations (exact-fp32 MFMA) instead of ggml's
+                                       fp16 im2col x fp16 kernel semantics */
 #define TTS_HIP_FLAG_DEQUANT_Q  16u /* decode Q4_0/Q5_0/Q8_0 matrices to fp32 at upload (fp32 activations) instead of
                                        the integer path with Q8_0-quantised activations (ggml's CPU semantics) */
 

@@ -57,7 +57,7 @@ class DacModel(C.Structure):
     _fields_ = [("n_codebooks", C.c_int32), ("codebook_dim", C.c_int32), ("codebook_size", C.c_int32), ("latent", C.c_int32),
                 ("codebook", fp * MAX_HEADS), ("out_proj_w", fp * MAX_HEADS), ("out_proj_b", fp * MAX_HEADS),
                 ("c0", C.c_int32), ("init_w", fp), ("init_b", fp), ("n_blocks", C.c_int32), ("blocks", DacBlock * 8),
-                ("final_alpha", fp), ("final_w", fp), ("final_b", fp)]
+                ("final_alpha", fp), ("final_w", fp), ("final_b", fp), ("f16_conv", C.c_int32)]
 
 
 class RefSamplerCfg(C.Structure):
@@ -307,7 +307,8 @@ class ParlerOracle:
 
 
 class DacOracle:
-    def __init__(self, model):
+    def __init__(self, model, f16_conv=None):
+        """f16_conv: None = follow the GGUF (F16 conv kernels -> ggml's fp16 im2col semantics), or force 0/1"""
         self.L = lib()
         cfg = model.cfg
         self.cfg = cfg
@@ -340,6 +341,9 @@ class DacOracle:
                 rr.out_alpha, rr.out_w, rr.out_b = f(q + "final.alpha"), f(q + "final.weight"), f(q + "final.bias")
             c //= 2
         m.final_alpha, m.final_w, m.final_b = f("audio_encoder.final.alpha"), f("audio_encoder.final.weight"), f("audio_encoder.final.bias")
+        if f16_conv is None:
+            f16_conv = all(x.type == 1 for n, x in t.items() if n.startswith("audio_encoder.") and n.endswith(".weight") and ".in_proj" not in n and len(x.ne) == 3)
+        m.f16_conv = 1 if f16_conv else 0
         self.m = m
 
     def stage_shape(self, stage, frames):

@@ -739,9 +739,15 @@ void orc_snake(float *x, int C, int64_t L, const float *alpha) {
     }
 }
 
+static void round_buf_f16(float *x, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t) n; i++) x[i] = orc_h2f(orc_f2h(x[i]));
+}
+
 int64_t orc_dac_decode(const orc_dac_model *m, const uint32_t *codes, int frames, float *pcm_out,
                        int stage, float *stage_out) {
     int64_t L = frames;
+    const int h = m->f16_conv;
     int C = m->latent;
     /* quantizer: dac_build_audio_inputs (dac_model.cpp:100-123) + build_quantize_layer
      * (general_neural_audio_codec.cpp:166-172): sum_i (out_proj_i * codebook_i[tok] + bias_i) */
@@ -752,7 +758,8 @@ int64_t orc_dac_decode(const orc_dac_model *m, const uint32_t *codes, int frames
             for (int64_t t = 0; t < L; t++) {
                 const float *cb = m->codebook[i] + (size_t) codes[t * m->n_codebooks + i] * m->codebook_dim;
                 float acc = 0.0f;
-                for (int d = 0; d < m->codebook_dim; d++) acc += m->out_proj_w[i][(size_t) c * m->codebook_dim + d] * cb[d];
+                for (int d = 0; d < m->codebook_dim; d++)
+                    acc += m->out_proj_w[i][(size_t) c * m->codebook_dim + d] * (h ? orc_h2f(orc_f2h(cb[d])) : cb[d]);
                 acc += m->out_proj_b[i][c];
                 if (i == 0) cur[(size_t) c * L + t] = acc;
                 else cur[(size_t) c * L + t] = cur[(size_t) c * L + t] + acc;
@@ -763,6 +770,7 @@ int64_t orc_dac_decode(const orc_dac_model *m, const uint32_t *codes, int frames
 
     /* initial conv k7 pad 3 (dac_model.cpp:158-159) */
     float *nxt = (float *) malloc((size_t) m->c0 * L * 4);
+    if (h) round_buf_f16(cur, (size_t) C * L);
     orc_conv1d(cur, C, L, m->init_w, m->init_b, m->c0, 7, 3, 1, nxt);
     free(cur); cur = nxt; C = m->c0;
     if (stage == 1 && stage_out) memcpy(stage_out, cur, (size_t) C * L * 4);
@@ -773,6 +781,7 @@ int64_t orc_dac_decode(const orc_dac_model *m, const uint32_t *codes, int frames
         const int K = 2 * b->stride;
         const int64_t L2 = (L - 1) * b->stride - 2 * (int64_t) b->padding + K;
         nxt = (float *) malloc((size_t) b->cout * L2 * 4);
+        if (h) round_buf_f16(cur, (size_t) C * L);
         orc_conv_transpose1d(cur, C, L, b->w, b->b, b->cout, K, b->stride, b->padding, nxt);
         free(cur); cur = nxt; C = b->cout; L = L2;
         float *t1 = (float *) malloc((size_t) C * L * 4);
@@ -782,8 +791,10 @@ int64_t orc_dac_decode(const orc_dac_model *m, const uint32_t *codes, int frames
             const int pad = dil * 3;
             memcpy(t1, cur, (size_t) C * L * 4);
             orc_snake(t1, C, L, b->res[r].in_alpha);
+            if (h) round_buf_f16(t1, (size_t) C * L);
             orc_conv1d(t1, C, L, b->res[r].in_w, b->res[r].in_b, C, 7, pad, dil, t2);
             orc_snake(t2, C, L, b->res[r].out_alpha);
+            if (h) round_buf_f16(t2, (size_t) C * L);
             orc_conv1d(t2, C, L, b->res[r].out_w, b->res[r].out_b, C, 1, 0, 1, t1);
             for (size_t i = 0; i < (size_t) C * L; i++) cur[i] = t1[i] + cur[i];
         }
@@ -793,6 +804,7 @@ int64_t orc_dac_decode(const orc_dac_model *m, const uint32_t *codes, int frames
     /* final snake, conv k7 -> 1 channel, tanh (dac_model.cpp:163-166) */
     orc_snake(cur, C, L, m->final_alpha);
     float *pcm = (float *) malloc((size_t) L * 4);
+    if (h) round_buf_f16(cur, (size_t) C * L);
     orc_conv1d(cur, C, L, m->final_w, m->final_b, 1, 7, 3, 1, pcm);
     for (int64_t t = 0; t < L; t++) pcm_out[t] = tanhf(pcm[t]);
     free(pcm); free(cur);

@@ -9,7 +9,7 @@ from tts_cpp_amd import gguf, hip, synth
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 248
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 flags = hip.FLAG_NO_PARLER | (hip.FLAG_VALU_GEMM if "--valu" in sys.argv else 0)
-cfg = synth.parler_mini(layers=1, prompt_vocab=64, ctx=64)
+cfg = synth.parler_mini(layers=1, prompt_vocab=64, ctx=64, dac_f16="--f16" in sys.argv)
 model = synth.build(cfg)
 eng = hip.HipEngine(cfg, flags=flags)
 eng.load(model)

@@ -98,32 +98,65 @@ def test_batched_dac_equals_single_decodes():
     eng.close()
 
 
+# fp16-im2col noise floor.  Rounding a conv input to fp16 turns a relative difference eps between two fp32
+# implementations (summation order) into flips of 1 fp16 ulp (2^-10) with probability eps*2^10 per element, i.e. an
+# output difference of about 2^-10*sqrt(eps*2^10); iterating eps -> 0.03*sqrt(eps) over the 6 roundings per block
+# converges to ~5e-4 whatever the starting point (measured: 2.5e-7 after the first conv, 3e-5 / 1.3e-4 / 4e-4 after
+# blocks 1 / 2 / 4).  ggml run with another thread count differs from itself by the same amount.  So: the first
+# convs are checked at rounding level (that is where fp16 vs fp32 im2col differ 1000x), the end at the floor.
+F16_DAC_TOL = 1e-3
+
+
 def test_f16_dac_tensors_and_empty_input():
+    """--convert-dac-to-f16 GGUFs (quantize_impl.cpp:264-266): ggml's conv_1d / conv_transpose_1d round their input to
+    fp16 when the kernel is F16 (fp16 im2col), accumulate in fp32."""
     model = synth.build(synth.tiny(weight_type=gguf.F32, dac_f16=True))
     cfg = model.cfg
     eng = dac_engine(cfg, model)
     codes = np.random.default_rng(1).integers(0, cfg.cb_size, (5, cfg.n_out)).astype(np.uint32)
+    eng.set_debug(True)
     pcm = eng.dac_decode(codes)
-    ref = orc.DacOracle(model).decode(codes)  # oracle sees the same fp16-rounded weights
-    assert np.abs(pcm - ref).max() < 1e-4
+    o16, o32 = orc.DacOracle(model), orc.DacOracle(model, f16_conv=0)  # default follows the GGUF types: fp16 im2col
+    assert o16.m.f16_conv == 1
+    for stage in range(0, 2 + len(cfg.strides)):
+        _, st_ref = o16.decode(codes, stage=stage)
+        _, st_32 = o32.decode(codes, stage=stage)
+        st = eng.debug_read(f"dac:{stage}", st_ref.size).reshape(st_ref.shape)
+        if stage <= 1:
+            assert relerr(st, st_ref) < 1e-5, f"stage {stage}"          # quantizer + first conv: exact semantics
+        else:
+            assert relerr(st, st_ref) < F16_DAC_TOL, f"stage {stage}"
+        if stage in (1, 2):
+            assert relerr(st, st_ref) * 5 < relerr(st, st_32), f"stage {stage}: not the fp16-im2col result"
+    assert np.abs(pcm - o16.decode(codes)).max() < F16_DAC_TOL
+    # fp32 activations on the same F16 tensors (TTS_HIP_FLAG_DAC_F32)
+    eng32 = hip.HipEngine(cfg, flags=hip.FLAG_NO_PARLER | hip.FLAG_DAC_F32)
+    eng32.load(model)
+    assert np.abs(eng32.dac_decode(codes) - o32.decode(codes)).max() < 1e-4
+    eng32.close()
     assert eng.dac_decode(np.zeros((0, cfg.n_out), dtype=np.uint32)).size == 0
     with pytest.raises(hip.HipError):
         eng.dac_decode(np.full((2, cfg.n_out), cfg.cb_size, dtype=np.uint32))  # code outside the codebook
     eng.close()
 
 
-def test_full_size_dac_and_locality():
-    """DAC 44 kHz dims (1536->96 channels, x512).  Parity on 3 frames; at 40 frames, size-independent
-    properties: determinism, and locality — the decoder is a finite-receptive-field convolution stack,
-    so PCM far from an edited frame is unchanged bit for bit."""
-    model = synth.build(synth.parler_mini(layers=1, prompt_vocab=64, ctx=64))  # decoder part irrelevant here
+@pytest.mark.parametrize("dac_f16", [False, True])
+def test_full_size_dac_and_locality(dac_f16):
+    """DAC 44 kHz dims (1536->96 channels, x512), F32 tensors (exact-fp32 MFMA) and F16 tensors (fp16 MFMA, fp16
+    im2col).  Parity on 3 frames; at 40 frames, size-independent properties: determinism, and locality — the decoder
+    is a finite-receptive-field convolution stack, so PCM far from an edited frame is unchanged bit for bit."""
+    model = synth.build(synth.parler_mini(layers=1, prompt_vocab=64, ctx=64, dac_f16=dac_f16))  # decoder part irrelevant here
     cfg = model.cfg
     eng = dac_engine(cfg, model)
     rng = np.random.default_rng(2)
     codes = rng.integers(0, cfg.cb_size, (3, cfg.n_out)).astype(np.uint32)
+    eng.set_debug(True)
     pcm = eng.dac_decode(codes)
+    eng.set_debug(False)
     ref = orc.DacOracle(model).decode(codes)
-    assert np.abs(pcm - ref).max() < 2e-4
+    assert np.abs(pcm - ref).max() < (F16_DAC_TOL if dac_f16 else 2e-4)
+    _, st_ref = orc.DacOracle(model).decode(codes, stage=1)       # every 128-channel k7 tile, K = 7 x 1024
+    assert relerr(eng.debug_read("dac:1", st_ref.size).reshape(st_ref.shape), st_ref) < 1e-5
     big = rng.integers(0, cfg.cb_size, (40, cfg.n_out)).astype(np.uint32)
     a = eng.dac_decode(big)
     b = eng.dac_decode(big)

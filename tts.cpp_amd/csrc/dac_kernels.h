@@ -34,6 +34,7 @@ struct DacEmbedArgs {
     const float *proj_b;    // [n_cb][latent]
     int n_cb, cb_size, cb_dim, latent, T;
     float *out;             // [latent][T]
+    int x_f16;              // F16 conv kernels: the conv input (codebook row) goes through an fp16 im2col
 };
 
 __global__ void dac_embed_kernel(DacEmbedArgs a) {
@@ -47,7 +48,7 @@ __global__ void dac_embed_kernel(DacEmbedArgs a) {
         const float *cb = a.codebook + ((int64_t) i * a.cb_size + code) * a.cb_dim;
         const float *w = a.proj_w + ((int64_t) i * a.latent + c) * a.cb_dim;
         float acc = 0.0f;
-        for (int d = 0; d < a.cb_dim; d++) acc += w[d] * cb[d];
+        for (int d = 0; d < a.cb_dim; d++) acc += w[d] * (a.x_f16 ? (float) (_Float16) cb[d] : cb[d]);
         acc += a.proj_b[i * a.latent + c];
         total = (i == 0) ? acc : (total + acc);
     }
@@ -71,6 +72,7 @@ struct ConvArgs {
     const uint32_t *frames;  // [n] valid frames per utterance (grid.z) or NULL; valid length = frames[z] * mult
     int mult;
     const float *alpha_out;  // [cout] snake applied to the OUTPUT (the next layer's snake_1d, fused here), or NULL
+    int x_f16;               // F16 conv kernel: inputs are rounded to fp16 on the way in (ggml's fp16 im2col)
 };
 
 __device__ __forceinline__ int valid_len(const uint32_t *frames, int mult, int L) {
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
             if (cig < a.cin && t >= 0 && t < L) {
                 v = xg[(int64_t) cig * LS + t];
                 if (a.alpha) { const float al = a.alpha[cig]; v = snake_f(v, al, 1.0f / al); }
+                if (a.x_f16) v = (float) (_Float16) v;
             }
             xs[i] = v;
         }
@@ -177,6 +180,7 @@ struct ConvTArgs {
     int cin, cout, L, Lout, stride, pad;   // L / Lout = row strides
     const uint32_t *frames;  // per-utterance frames (grid.z) or NULL; valid input length = frames[z] * mult
     int mult;
+    int x_f16;               // F16 kernel: inputs rounded to fp16 (ggml_compute_forward_conv_transpose_1d_f16_f32)
 };
 
 #define CT_CI 8
@@ -220,6 +224,7 @@ __global__ __launch_bounds__(256) void convt1d_kernel(ConvTArgs a) {
             if (cig < a.cin && ti >= 0 && ti < L) {
                 v = xg[(int64_t) cig * LS + ti];
                 if (a.alpha) { const float al = a.alpha[cig]; v = snake_f(v, al, 1.0f / al); }
+                if (a.x_f16) v = (float) (_Float16) v;
             }
             xs[i] = v;
         }
@@ -611,6 +616,7 @@ __global__ __launch_bounds__(256) void conv1d_cout1_kernel(ConvArgs a) {
             if (cig < a.cin && t >= 0 && t < L) {
                 v = xg[(int64_t) cig * LS + t];
                 if (a.alpha) { const float al = a.alpha[cig]; v = snake_f(v, al, 1.0f / al); }
+                if (a.x_f16) v = (float) (_Float16) v;
             }
             xs[ci][p] = v;
         }
@@ -629,5 +635,322 @@ __global__ __launch_bounds__(256) void conv1d_cout1_kernel(ConvArgs a) {
         float v = acc + (a.b ? a.b[0] : 0.0f);
         if (a.do_tanh) v = tanhf(v);
         yg[t] = v;
+    }
+}
+
+
+// ================================================================================================
+// fp16 MFMA paths for F16 codec weights (quantize --convert-dac-to-f16, quantize_impl.cpp:264-266).
+// ggml lowers conv_1d to im2col(F16) x kernel(F16) and conv_transpose_1d_f16_f32 converts its source to fp16
+// (upstream ggml): inputs are rounded to fp16 AFTER snake, products accumulate in fp32.
+// v_mfma_f32_32x32x16_f16 does exactly that: fp16 x fp16 products are exact in fp32.
+// Fragment maps: A[i = lane&31][k = 8*(lane>>5) + 0..7], B[k = 8*(lane>>5) + 0..7][j = lane&31], D as above.
+// LDS images:  weights [k-step][lane>>5][channel][8 k]  (pre-packed, straight 16-byte copies; conflict-free reads)
+//              inputs  [position][CI_T + 8] fp16        (channel-contiguous: one 16-byte read per B fragment)
+// ================================================================================================
+typedef _Float16 half8d __attribute__((ext_vector_type(8)));
+
+//   conv1d   src [cout][cin][KT]  -> dst [co_tile][chunk][k][cg][hi][CO_T][8]   (ci = chunk*CI_T + cg*16 + hi*8 + j)
+//   convT1d  src [cin][cout][K2]  -> same with k = 0..K2-1
+__global__ void pack_conv_w16_kernel(const float *src, _Float16 *dst, int cout, int cin, int KT, int CO_T, int CI_T, int n_chunks,
+                                     int transposed_src) {
+    const int NCG = CI_T / 16;
+    const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * KT * CI_T * CO_T;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        const int j = (int) (i % 8);
+        int64_t r = i / 8;
+        const int col = (int) (r % CO_T); r /= CO_T;
+        const int hi = (int) (r % 2); r /= 2;
+        const int cg = (int) (r % NCG); r /= NCG;
+        const int k = (int) (r % KT); r /= KT;
+        const int ch = (int) (r % n_chunks);
+        const int ct = (int) (r / n_chunks);
+        const int co = ct * CO_T + col, ci = ch * CI_T + cg * 16 + hi * 8 + j;
+        float v = 0.0f;
+        if (co < cout && ci < cin)
+            v = transposed_src ? src[((int64_t) ci * cout + co) * KT + k] : src[((int64_t) co * cin + ci) * KT + k];
+        dst[i] = (_Float16) v;  // exact: the tensor was stored as F16
+    }
+}
+
+template <int KT, int MI, int NI, int WM, int WN, int CI_T>
+__global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma16_kernel(ConvArgs a) {
+    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, NT = 64 * WM * WN;
+    constexpr int NCG = CI_T / 16, QG = CI_T / 8, XS = CI_T + 8;
+    constexpr int WCH = KT * CI_T * CO_T;                     // halves per packed weight chunk
+    constexpr int WV = (WCH / 8 + NT - 1) / NT;               // 16-byte vectors per thread per chunk
+    constexpr int XU = ((T_T + (KT - 1) * 9) * QG + NT - 1) / NT;  // (position, 8-channel group) units per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int halo = (KT - 1) * a.dil;
+    const int xw = T_T + halo;
+    const int xsz = xw * XS;                                  // halves (XS is a multiple of 8)
+    _Float16 *wsb = (_Float16 *) smem;                        // [2][WCH]
+    _Float16 *xsb = wsb + 2 * WCH;                            // [2][xsz]
+    float *als = (float *) (xsb + 2 * xsz);                   // [cin_pad] alpha, then [cin_pad] 1/alpha
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T;
+    const int n_chunks = (a.cin + CI_T - 1) / CI_T;
+    const int cin_pad = n_chunks * CI_T;
+    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    if (t0 >= L) return;
+    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * LS;
+    float *yg = a.y + (int64_t) blockIdx.z * a.cout * LS;
+    const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * LS : nullptr;
+    const half8d *wg = (const half8d *) ((const _Float16 *) a.w + (int64_t) blockIdx.y * n_chunks * WCH);
+
+    if (a.alpha) {
+        for (int i = tid; i < cin_pad; i += NT) {
+            const float al = i < a.cin ? a.alpha[i] : 1.0f;
+            als[i] = al;
+            als[cin_pad + i] = 1.0f / al;
+        }
+    }
+
+    float16d acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NI; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    half8d wreg[WV];
+    float xreg[XU][8];
+    auto prefetch = [&](int c) {
+        const half8d *wp = wg + (int64_t) c * (WCH / 8);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < WCH / 8) wreg[j] = wp[i];
+        }
+#pragma unroll
+        for (int j = 0; j < XU; j++) {
+            const int u = tid + j * NT;
+            const int q = u / xw, p = u - q * xw;   // lanes run along positions: coalesced rows
+            const int t = t0 + p - a.pad;
+            const bool ok = q < QG && t >= 0 && t < L;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int cig = c * CI_T + q * 8 + e;
+                xreg[j][e] = (ok && cig < a.cin) ? xg[(int64_t) cig * LS + t] : 0.0f;
+            }
+        }
+    };
+    auto commit = [&](int c, int buf) {
+        half8d *wd = (half8d *) (wsb + buf * WCH);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < WCH / 8) wd[i] = wreg[j];
+        }
+        _Float16 *xd = xsb + buf * xsz;
+#pragma unroll
+        for (int j = 0; j < XU; j++) {
+            const int u = tid + j * NT;
+            const int q = u / xw, p = u - q * xw;
+            if (q < QG) {
+                half8d h;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float v = xreg[j][e];
+                    if (a.alpha) {
+                        const int cig = c * CI_T + q * 8 + e;
+                        v = snake_f(v, als[cig], als[cin_pad + cig]);  // snake(0) == 0: zero padding is preserved
+                    }
+                    h[e] = (_Float16) v;                               // the fp16 im2col
+                }
+                *(half8d *) (xd + p * XS + q * 8) = h;
+            }
+        }
+    };
+
+    prefetch(0);
+    __syncthreads();  // alpha table visible
+    commit(0, 0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) prefetch(c + 1);
+        const _Float16 *ws = wsb + buf * WCH;
+        const _Float16 *xs = xsb + buf * xsz;
+#pragma unroll
+        for (int tap = 0; tap < KT; tap++) {
+#pragma unroll
+            for (int cg = 0; cg < NCG; cg++) {
+                half8d af[MI], bf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+                    af[i] = *(const half8d *) (ws + ((((tap * NCG + cg) * 2 + hi) * CO_T) + (wm * MI + i) * 32 + l31) * 8);
+#pragma unroll
+                for (int j = 0; j < NI; j++)
+                    bf[j] = *(const half8d *) (xs + ((wn * NI + j) * 32 + l31 + tap * a.dil) * XS + cg * 16 + hi * 8);
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+#pragma unroll
+                    for (int j = 0; j < NI; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (c + 1 < n_chunks) commit(c + 1, buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int co = co0 + (wm * MI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (co >= a.cout) continue;
+            const float bias = a.b ? a.b[co] : 0.0f;
+            const float al_o = a.alpha_out ? a.alpha_out[co] : 1.0f, ral_o = 1.0f / al_o;
+#pragma unroll
+            for (int j = 0; j < NI; j++) {
+                const int t = t0 + (wn * NI + j) * 32 + l31;
+                if (t >= L) continue;
+                float v = acc[i][j][e] + bias;
+                if (rg) v = v + rg[(int64_t) co * LS + t];
+                if (a.alpha_out) v = snake_f(v, al_o, ral_o);
+                if (a.do_tanh) v = tanhf(v);
+                yg[(int64_t) co * LS + t] = v;
+            }
+        }
+    }
+}
+
+// ConvTranspose1d, phase-decomposed as convt1d_mfma_kernel; one k-step = 16 input channels of one tap slot
+// (slot 0: x[ti] with w[..][phi], slot 1: x[ti-1] with w[..][phi+S]).
+template <int S, int MI, int WM, int WN, int CI_T>
+__global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma16_kernel(ConvTArgs a) {
+    constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN, NT = 64 * WM * WN, K2 = 2 * S;
+    constexpr int NCG = CI_T / 16, QG = CI_T / 8, XS = CI_T + 8;
+    constexpr int WCH = CI_T * K2 * CO_T;
+    constexpr int WV = (WCH / 8 + NT - 1) / NT;
+    constexpr int xw = TI_T + 1;                   // positions ti0-1 .. ti0+TI_T-1
+    constexpr int xsz = xw * XS;
+    constexpr int XU = (xw * QG + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16 *wsb = (_Float16 *) smem;             // [2][WCH]
+    _Float16 *xsb = wsb + 2 * WCH;                 // [2][xsz]
+    float *als = (float *) (xsb + 2 * xsz);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ti0 = blockIdx.x * TI_T, co0 = blockIdx.y * CO_T;
+    const int n_chunks = (a.cin + CI_T - 1) / CI_T;
+    const int cin_pad = n_chunks * CI_T;
+    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    const int LoS = a.Lout, Lout = a.frames ? (L - 1) * S - 2 * a.pad + K2 : a.Lout;
+    if (ti0 > L) return;  // ti runs 0..L inclusive
+    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * LS;
+    float *yg = a.y + (int64_t) blockIdx.z * a.cout * LoS;
+    const half8d *wg = (const half8d *) ((const _Float16 *) a.w + (int64_t) blockIdx.y * n_chunks * WCH);
+
+    if (a.alpha) {
+        for (int i = tid; i < cin_pad; i += NT) {
+            const float al = i < a.cin ? a.alpha[i] : 1.0f;
+            als[i] = al;
+            als[cin_pad + i] = 1.0f / al;
+        }
+    }
+
+    float16d acc[MI][S];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int ph = 0; ph < S; ph++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][ph][e] = 0.0f;
+
+    half8d wreg[WV];
+    float xreg[XU][8];
+    auto prefetch = [&](int c) {
+        const half8d *wp = wg + (int64_t) c * (WCH / 8);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < WCH / 8) wreg[j] = wp[i];
+        }
+#pragma unroll
+        for (int j = 0; j < XU; j++) {
+            const int u = tid + j * NT;
+            const int q = u / xw, p = u - q * xw;
+            const int ti = ti0 - 1 + p;
+            const bool ok = q < QG && ti >= 0 && ti < L;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int cig = c * CI_T + q * 8 + e;
+                xreg[j][e] = (ok && cig < a.cin) ? xg[(int64_t) cig * LS + ti] : 0.0f;
+            }
+        }
+    };
+    auto commit = [&](int c, int buf) {
+        half8d *wd = (half8d *) (wsb + buf * WCH);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < WCH / 8) wd[i] = wreg[j];
+        }
+        _Float16 *xd = xsb + buf * xsz;
+#pragma unroll
+        for (int j = 0; j < XU; j++) {
+            const int u = tid + j * NT;
+            const int q = u / xw, p = u - q * xw;
+            if (q < QG) {
+                half8d h;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float v = xreg[j][e];
+                    if (a.alpha) {
+                        const int cig = c * CI_T + q * 8 + e;
+                        v = snake_f(v, als[cig], als[cin_pad + cig]);
+                    }
+                    h[e] = (_Float16) v;
+                }
+                *(half8d *) (xd + p * XS + q * 8) = h;
+            }
+        }
+    };
+
+    prefetch(0);
+    __syncthreads();
+    commit(0, 0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) prefetch(c + 1);
+        const _Float16 *ws = wsb + buf * WCH;
+        const _Float16 *xs = xsb + buf * xsz;
+#pragma unroll
+        for (int ts = 0; ts < 2; ts++) {
+#pragma unroll
+            for (int cg = 0; cg < NCG; cg++) {
+                const half8d bf = *(const half8d *) (xs + (wn * 32 + l31 + 1 - ts) * XS + cg * 16 + hi * 8);
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+#pragma unroll
+                    for (int ph = 0; ph < S; ph++) {
+                        const half8d af = *(const half8d *) (ws + (((((ph + ts * S) * NCG + cg) * 2 + hi) * CO_T) + (wm * MI + i) * 32 + l31) * 8);
+                        acc[i][ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[i][ph], 0, 0, 0);
+                    }
+            }
+        }
+        if (c + 1 < n_chunks) commit(c + 1, buf ^ 1);
+        __syncthreads();
+    }
+    const int ti = ti0 + wn * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int co = co0 + (wm * MI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (co >= a.cout) continue;
+            const float bias = a.b ? a.b[co] : 0.0f;
+#pragma unroll
+            for (int ph = 0; ph < S; ph++) {
+                const int to = ti * S + ph - a.pad;
+                if (to >= 0 && to < Lout) yg[(int64_t) co * LoS + to] = acc[i][ph][e] + bias;
+            }
+        }
     }
 }

@@ -388,6 +388,72 @@ __global__ void gemv_valu_kernel(GemmArgs a, int EPI, int act_f16_src) {
 // slabs [n_parts][R][H]; this kernel performs the reference's ggml_add(cur, residual): x[r] += sum_s parts[s][r]
 // (fixed order), stores the new residual stream in place (x is written by the wave that owns the row) and
 // normalises it.  Requires H <= 2048.
+// One wave normalises one row held in registers (NI float4 per lane: H <= 1024 for NI = 4, <= 2048 for NI = 8).
+// NP >= 0: that many split-K slabs are added to x in slab order first, with every load in flight at once
+// (the slab loop with a run-time trip count serialised 4 dependent round trips per float4: 13.8 us -> see DESIGN.md);
+// NP < 0: run-time slab count.
+template <int NI, int NP>
+__device__ __forceinline__ void ln_row_regs(float *xr, int H, int lane, const float *lw, const float *lb, float *yr32, _Float16 *yr16,
+                                            const float *pr, int n_parts, int64_t slab_stride) {
+    float4v v[NI], w4[NI], b4[NI];
+    float4v p[NP > 0 ? NP : 1][NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const int k = i * 256 + lane * 4;
+        if (k < H) {
+            v[i] = *(const float4v *) (xr + k);
+#pragma unroll
+            for (int sp = 0; sp < NP; sp++) p[sp][i] = *(const float4v *) (pr + sp * slab_stride + k);
+            w4[i] = *(const float4v *) (lw + k);
+            b4[i] = *(const float4v *) (lb + k);
+        }
+    }
+    if (NP != 0) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int k = i * 256 + lane * 4;
+            if (k < H) {
+                if (NP > 0) {
+#pragma unroll
+                    for (int sp = 0; sp < NP; sp++) v[i] += p[sp][i];
+                } else {
+                    for (int sp = 0; sp < n_parts; sp++) v[i] += *(const float4v *) (pr + sp * slab_stride + k);
+                }
+                *(float4v *) (xr + k) = v[i];
+            }
+        }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+        if (i * 256 + lane * 4 < H) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float) H;
+    float s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+        if (i * 256 + lane * 4 < H) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const float d = v[i][e] - mean; s2 += d * d; }
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float) H + LN_EPS);
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const int k = i * 256 + lane * 4;
+        if (k < H) {
+            float4v y;
+#pragma unroll
+            for (int e = 0; e < 4; e++) y[e] = (v[i][e] - mean) * rstd * w4[i][e] + b4[i][e];
+            if (yr32) *(float4v *) (yr32 + k) = y;
+            if (yr16) {
+                half4 h;
+#pragma unroll
+                for (int e = 0; e < 4; e++) h[e] = (_Float16) y[e];
+                *(half4 *) (yr16 + k) = h;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void ln_rows_kernel(float *x, int H, const float *lw, const float *lb, float *y32,
                                                       _Float16 *y16, int R, const float *parts, int n_parts, int64_t slab_stride) {
     const int lane = threadIdx.x & 63;
@@ -395,45 +461,18 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(float *x, int H, const flo
     if (r >= R) return;
     float *xr = x + (int64_t) r * H;
     if (H <= 2048 && (H & 3) == 0) {
-        float4v v[8];
-        float s = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int k = i * 256 + lane * 4;
-            if (k < H) {
-                v[i] = *(const float4v *) (xr + k);
-                if (parts) {
-                    for (int sp = 0; sp < n_parts; sp++) v[i] += *(const float4v *) (parts + sp * slab_stride + (int64_t) r * H + k);
-                    *(float4v *) (xr + k) = v[i];
-                }
-                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-            }
-        }
-        const float mean = wave_sum(s) / (float) H;
-        float s2 = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-            if (i * 256 + lane * 4 < H) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) { const float d = v[i][e] - mean; s2 += d * d; }
-            }
-        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float) H + LN_EPS);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int k = i * 256 + lane * 4;
-            if (k < H) {
-                const float4v w4 = *(const float4v *) (lw + k), b4 = *(const float4v *) (lb + k);
-                float4v y;
-#pragma unroll
-                for (int e = 0; e < 4; e++) y[e] = (v[i][e] - mean) * rstd * w4[e] + b4[e];
-                if (y32) *(float4v *) (y32 + (int64_t) r * H + k) = y;
-                if (y16) {
-                    half4 h;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) h[e] = (_Float16) y[e];
-                    *(half4 *) (y16 + (int64_t) r * H + k) = h;
-                }
-            }
+        const float *pr = parts ? parts + (int64_t) r * H : nullptr;
+        float *yr32 = y32 ? y32 + (int64_t) r * H : nullptr;
+        _Float16 *yr16 = y16 ? y16 + (int64_t) r * H : nullptr;
+        const int np = parts ? n_parts : 0;
+        if (H <= 1024) {
+            if (np == 0) ln_row_regs<4, 0>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
+            else if (np == 4) ln_row_regs<4, 4>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
+            else if (np == 2) ln_row_regs<4, 2>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
+            else ln_row_regs<4, -1>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
+        } else {
+            if (np == 0) ln_row_regs<8, 0>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
+            else ln_row_regs<8, -1>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
         }
     } else {
         float s = 0.0f;

@@ -129,6 +129,7 @@ struct Tensor {
     int n_dims = 0;
     int64_t ne[4] = {1, 1, 1, 1};
     size_t nbytes = 0;
+    int src_type = 0;  // ggml type the tensor had in the GGUF
     void *tmp = nullptr;  // device staging copy until finalize
     bool has_data = false;
     int64_t nelem() const { return ne[0] * ne[1] * ne[2] * ne[3]; }
@@ -212,6 +213,8 @@ struct tts_hip_ctx {
     bool debug = false;
     std::map<int, std::vector<float>> dac_dbg;
     std::map<size_t, float *> packed;  // arena offset of a conv weight -> its MFMA-tile-packed copy
+    std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
+    bool dac_f16 = false;      // every codec conv kernel arrived as F16: fp16 im2col x fp16 kernel, fp32 accumulate (ggml)
     bool dac_packed = false;
 
     // graphs
@@ -276,6 +279,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     free_dev(c->d_eos); free_dev(c->d_codes); free_dev(c->d_frames);
     for (int i = 0; i < 3; i++) free_dev(c->dbuf[i]);
     for (auto &pw : c->packed) free_dev(pw.second);
+    for (auto &pw : c->packed16) free_dev(pw.second);
     if (c->h_ids) (void) hipHostFree(c->h_ids);
     if (c->h_pos) (void) hipHostFree(c->h_pos);
     if (c->h_seq) (void) hipHostFree(c->h_seq);
@@ -362,6 +366,7 @@ extern "C" int tts_hip_upload(tts_hip_ctx *c, const char *name_c, int type, int 
                      !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM);
     t.type = q8i ? TTS_HIP_Q8I : (keep16 ? TTS_HIP_F16 : TTS_HIP_F32);
     t.nbytes = q8i ? (size_t) n + (size_t) (n / 32) * 2 : (size_t) n * (keep16 ? 2 : 4);
+    t.src_type = type;
     t.has_data = host != nullptr;
     if (host) {
         HIPCHK(hipMalloc(&t.tmp, t.nbytes));
@@ -573,6 +578,13 @@ static int plan(tts_hip_ctx *c) {
         c->d_falpha = P.place_f32("audio_encoder.final.alpha");
         c->d_fw = P.place_f32("audio_encoder.final.weight");
         c->d_fb = P.place_f32("audio_encoder.final.bias");
+        // --convert-dac-to-f16 turns every audio_encoder tensor except the snake alphas into F16 (quantize_impl.cpp:264-266)
+        c->dac_f16 = !(d.flags & TTS_HIP_FLAG_DAC_F32);
+        for (auto &kv : c->tensors) {
+            const std::string &nm = kv.first;
+            if (starts_with(nm, "audio_encoder.") && ends_with(nm, ".weight") && kv.second.n_dims == 3 && nm.find(".in_proj") == std::string::npos)
+                c->dac_f16 = c->dac_f16 && kv.second.src_type == TTS_HIP_F16;
+        }
     }
     if (!P.err.empty()) return set_err("plan: %s", P.err.c_str());
     c->arena_bytes = (P.cur + 255) & ~(size_t) 255;
@@ -1349,9 +1361,37 @@ static int pack_one(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT, int
 
 // one-time re-layout of the DAC conv weights into MFMA LDS images (after the arena holds the weights,
 // i.e. also after an RCCL broadcast filled it)
+static int pack_one16(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT, int CO_T, int CI_T, bool transposed) {
+    const int n_chunks = (cin + CI_T - 1) / CI_T;
+    const size_t n = (size_t) ((cout + CO_T - 1) / CO_T) * n_chunks * KT * CI_T * CO_T;
+    _Float16 *dst = nullptr;
+    HIPCHK(hipMalloc((void **) &dst, n * 2));
+    hipLaunchKernelGGL(pack_conv_w16_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + w_off), dst, cout, cin, KT,
+                       CO_T, CI_T, n_chunks, transposed ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    c->packed16[w_off] = dst;
+    return 0;
+}
+#define CI16_K7 16
+#define CI16_K1 32
+#define CI16_T  16
+
 static int ensure_packed(tts_hip_ctx *c) {
     if (c->dac_packed || (c->d.flags & TTS_HIP_FLAG_VALU_GEMM)) return 0;
     int CO_T = 0, CI_T = 0;
+    if (c->dac_f16) {
+        if (conv_tile(c->d_c0, 7, &CO_T, &CI_T) >= 0) CHK(pack_one16(c, c->d_initw, c->d_c0, c->d_latent, 7, CO_T, CI16_K7, false));
+        for (auto &b : c->dblocks) {
+            if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one16(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, CI16_T, true));
+            for (int r = 0; r < 3; r++) {
+                if (conv_tile(b.cout, 7, &CO_T, &CI_T) >= 0) CHK(pack_one16(c, b.res[r].in_w, b.cout, b.cout, 7, CO_T, CI16_K7, false));
+                if (conv_tile(b.cout, 1, &CO_T, &CI_T) >= 0) CHK(pack_one16(c, b.res[r].out_w, b.cout, b.cout, 1, CO_T, CI16_K1, false));
+            }
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->dac_packed = true;
+        return 0;
+    }
     if (conv_tile(c->d_c0, 7, &CO_T, &CI_T) >= 0) CHK(pack_one(c, c->d_initw, c->d_c0, c->d_latent, 7, CO_T, CI_T, false));
     for (auto &b : c->dblocks) {
         if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, 8, true));
@@ -1383,6 +1423,40 @@ static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a, int nz) {
     return 0;
 }
 
+template <int KT, int MI, int NI, int WM, int WN, int CI_T>
+static int launch_conv_mfma16(tts_hip_ctx *c, const ConvArgs &a, int nz) {
+    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WCH = KT * CI_T * CO_T, XS = CI_T + 8;
+    const int xw = T_T + (KT - 1) * a.dil;
+    const int cin_pad = (a.cin + CI_T - 1) / CI_T * CI_T;
+    const size_t lds = ((size_t) 2 * WCH + 2 * (size_t) xw * XS) * 2 + (a.alpha ? 2 * (size_t) cin_pad : 0) * 4;
+    if (a.dil > 9) return set_err("conv1d_mfma16: dilation %d > 9 unsupported", a.dil);
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void *) conv1d_mfma16_kernel<KT, MI, NI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const dim3 grid((a.L + T_T - 1) / T_T, (a.cout + CO_T - 1) / CO_T, nz);
+    hipLaunchKernelGGL((conv1d_mfma16_kernel<KT, MI, NI, WM, WN, CI_T>), grid, dim3(64 * WM * WN), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <int S, int MI, int WM, int WN, int CI_T>
+static int launch_convt_mfma16(tts_hip_ctx *c, const ConvTArgs &a, int nz) {
+    constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN, WCH = CI_T * 2 * S * CO_T, XS = CI_T + 8;
+    const int cin_pad = (a.cin + CI_T - 1) / CI_T * CI_T;
+    const size_t lds = ((size_t) 2 * WCH + 2 * (size_t) (TI_T + 1) * XS) * 2 + (a.alpha ? 2 * (size_t) cin_pad : 0) * 4;
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute((const void *) convt1d_mfma16_kernel<S, MI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const dim3 grid((a.L + 1 + TI_T - 1) / TI_T, (a.cout + CO_T - 1) / CO_T, nz);  // ti runs 0..L inclusive
+    hipLaunchKernelGGL((convt1d_mfma16_kernel<S, MI, WM, WN, CI_T>), grid, dim3(64 * WM * WN), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 struct DacBatch {
     int n = 1;                  // utterances (grid.z)
     const uint32_t *frames = nullptr;  // device [n]
@@ -1399,6 +1473,7 @@ static int launch_conv(tts_hip_ctx *c, const DacBatch &bt, const float *x, int c
     a.alpha_out = has_alpha_out ? (const float *) (c->arena + alpha_out) : nullptr;
     a.resid = resid; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.dil = dil; a.pad = pad; a.do_tanh = do_tanh;
     a.frames = bt.frames; a.mult = bt.mult;
+    a.x_f16 = c->dac_f16 ? 1 : 0;
     const double Lv = bt.tot_frames * bt.mult;  // valid positions over the batch
     const double bytes = ((double) cin * Lv + (double) cout * Lv * (resid ? 2 : 1) + (double) cout * cin * K) * 4;
     CHK(prof_begin(c, cout == 1 ? TTS_HIP_K_DAC_FINAL : (K == 7 ? TTS_HIP_K_DAC_CONV7 : TTS_HIP_K_DAC_CONV1), bytes, 2.0 * cout * (double) cin * K * Lv));
@@ -1406,9 +1481,18 @@ static int launch_conv(tts_hip_ctx *c, const DacBatch &bt, const float *x, int c
     int CO_T = 0, CI_T = 0;
     const int cfg = valu ? -1 : conv_tile(cout, K, &CO_T, &CI_T);
     auto pk = c->packed.find(w);
+    auto pk16 = c->packed16.find(w);
     if (!valu && cout == 1 && K == 7) {
         hipLaunchKernelGGL(conv1d_cout1_kernel, dim3((L + C1_T - 1) / C1_T, 1, bt.n), dim3(256), 0, c->stream, a);
         HIPCHK(hipGetLastError());
+    } else if (cfg >= 0 && c->dac_f16 && pk16 != c->packed16.end()) {
+        a.w = (const float *) pk16->second;  // fp16 LDS images
+        if (K == 7 && cfg == 0) CHK((launch_conv_mfma16<7, 2, 2, 2, 2, CI16_K7>(c, a, bt.n)));
+        else if (K == 7 && cfg == 1) CHK((launch_conv_mfma16<7, 3, 2, 1, 4, CI16_K7>(c, a, bt.n)));
+        else if (K == 7 && cfg == 2) CHK((launch_conv_mfma16<7, 2, 2, 1, 4, CI16_K7>(c, a, bt.n)));
+        else if (K == 1 && cfg == 0) CHK((launch_conv_mfma16<1, 2, 2, 2, 2, CI16_K1>(c, a, bt.n)));
+        else if (K == 1 && cfg == 1) CHK((launch_conv_mfma16<1, 3, 2, 1, 4, CI16_K1>(c, a, bt.n)));
+        else CHK((launch_conv_mfma16<1, 2, 2, 1, 4, CI16_K1>(c, a, bt.n)));
     } else if (cfg >= 0 && pk != c->packed.end()) {
         a.w = pk->second;
         if (K == 7 && cfg == 0) CHK((launch_conv_mfma<7, 2, 2, 2, 2, 8>(c, a, bt.n)));
@@ -1449,6 +1533,15 @@ static int launch_convt(tts_hip_ctx *c, ConvTArgs ta, size_t w_off, int nz) {
     const int s = ta.stride;
     int CO_T = 0;
     const int cfg = valu ? -1 : convt_tile(ta.cout, s, &CO_T);
+    ta.x_f16 = c->dac_f16 ? 1 : 0;
+    auto pk16 = c->packed16.find(w_off);
+    if (cfg >= 0 && c->dac_f16 && pk16 != c->packed16.end()) {
+        ta.w = (const float *) pk16->second;
+        if (cfg == 0) return launch_convt_mfma16<8, 1, 2, 2, CI16_T>(c, ta, nz);
+        if (cfg == 1) return launch_convt_mfma16<4, 2, 1, 4, CI16_T>(c, ta, nz);
+        if (cfg == 2) return launch_convt_mfma16<2, 3, 1, 4, CI16_T>(c, ta, nz);
+        return launch_convt_mfma16<2, 2, 1, 4, CI16_T>(c, ta, nz);
+    }
     auto pk = c->packed.find(w_off);
     if (cfg >= 0 && pk != c->packed.end()) {
         ta.w = pk->second;
@@ -1519,7 +1612,7 @@ static int dac_decode_batch(tts_hip_ctx *c, const uint32_t *codes, const uint32_
     ea.frames = c->d_frames;
     ea.codes = c->d_codes; ea.codebook = (const float *) (c->arena + c->d_codebook); ea.proj_w = (const float *) (c->arena + c->d_projw);
     ea.proj_b = (const float *) (c->arena + c->d_projb); ea.n_cb = c->d_ncb; ea.cb_size = c->d_cbsize; ea.cb_dim = c->d_cbdim;
-    ea.latent = c->d_latent; ea.T = L; ea.out = cur;
+    ea.latent = c->d_latent; ea.T = L; ea.out = cur; ea.x_f16 = c->dac_f16 ? 1 : 0;
     CHK(prof_begin(c, TTS_HIP_K_DAC_EMBED, (double) c->d_latent * tot * 4, 2.0 * c->d_latent * tot * c->d_ncb * c->d_cbdim));
     hipLaunchKernelGGL(dac_embed_kernel, dim3((L + 63) / 64, c->d_latent, n), dim3(64), 0, c->stream, ea);
     HIPCHK(hipGetLastError());
