@@ -32,6 +32,7 @@ from tts_cpp_amd.pattern import undelay  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 F32_PEAK_TFLOPS = 157.3   # fp32 vector == fp32-input MFMA peak
+F16_PEAK_TFLOPS = 2516.8  # dense fp16 MFMA = 16 x the fp32 matrix rate (MI355X_MICROARCH.md)
 SAMPLE_RATE = 44100.0
 
 
@@ -84,6 +85,8 @@ def pmc_traffic(kclass, args, n_audio):
     t = json.load(open(path))
     w = t.get("workload", {})
     if kclass.startswith("dac_"):  # DAC launches depend only on the group size and the frame count
+        if args.dac_wtype != "f32":
+            return None
         if w.get("audio_steps") != n_audio or w.get("dac_group") != DAC_GROUP:
             return None
     elif w.get("batch") != args.batch or w.get("audio_steps") != n_audio:
@@ -144,7 +147,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TTS_BENCH_BATCH", "128")), help="utterances per context decoded in lock-step")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("TTS_BENCH_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("TTS_BENCH_STREAMS", "3")),
                     help="independent contexts (HIP streams) per GPU sharing one weight arena; each decodes --batch utterances")
     ap.add_argument("--audio-steps", type=int, default=256, help="AR audio steps per utterance (random weights never emit EOS)")
     ap.add_argument("--prompt-len", type=int, default=16)
@@ -153,6 +156,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--model", choices=["mini", "small", "tiny"], default="mini")
+    ap.add_argument("--dac-wtype", choices=["f32", "f16"], default="f32",
+                    help="GGUF type of the codec tensors: f32 (quantize default) or f16 (--convert-dac-to-f16: fp16 im2col, fp16 MFMA)")
     ap.add_argument("--wtype", choices=["f16", "f32", "q8_0", "q5_0", "q4_0"], default="f16",
                     help="GGUF type of the decoder matrices (headline: f16; q*: integer path with Q8_0 activations)")
     args = ap.parse_args()
@@ -176,7 +181,8 @@ def main():
         tdist.init(backend, rank, world, device=torch.device("cuda", local_rank))
 
     cfg = {"mini": synth.parler_mini, "small": synth.small, "tiny": synth.tiny}[args.model](
-        weight_type={"f16": gguf.F16, "f32": gguf.F32, "q8_0": gguf.Q8_0, "q5_0": gguf.Q5_0, "q4_0": gguf.Q4_0}[args.wtype])
+        weight_type={"f16": gguf.F16, "f32": gguf.F32, "q8_0": gguf.Q8_0, "q5_0": gguf.Q5_0, "q4_0": gguf.Q4_0}[args.wtype],
+        dac_f16=args.dac_wtype == "f16")
     WNAME = dict(f16="fp16", f32="fp32").get(args.wtype, args.wtype)
     n_audio = min(args.audio_steps, cfg.max_gen - args.prompt_len, cfg.ctx - args.prompt_len)
     kv_type = gguf.F16 if args.kv == "f16" else gguf.F32
@@ -269,10 +275,11 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": {"f16": "f16", "f32": "f32"}.get(args.wtype, "i8"),
-        "dtype_detail": DTYPE_DETAIL[args.wtype],
+        "dtype_detail": DTYPE_DETAIL[args.wtype] if args.dac_wtype == "f32" else
+                        DTYPE_DETAIL[args.wtype].replace("DAC codec f32 (exact-f32 MFMA)", "DAC codec F16 tensors (fp16 im2col x fp16 kernels, fp16 MFMA, f32 accumulate)"),
         "data": "synthetic (seeded random weights of the Parler-TTS-Mini + DAC-44k architecture; fixed-length greedy generation)",
         "config": {
-            "workload": f"configs[1]: Parler-TTS-Mini {WNAME} on MI355X, greedy decode + DAC codec; {args.streams} context(s) x {args.batch} utterances/GPU in lock-step, "
+            "workload": f"configs[1]: Parler-TTS-Mini {WNAME} on MI355X, greedy decode + DAC codec ({args.dac_wtype} tensors); {args.streams} context(s) x {args.batch} utterances/GPU in lock-step, "
                         f"{args.prompt_len}-id prompt, {n_audio} audio steps (={n_audio - cfg.n_out + 1} frames, "
                         f"{(n_audio - cfg.n_out + 1) * cfg.hop / SAMPLE_RATE:.2f} s audio) per utterance",
             "utterances_per_gpu": args.batch * args.streams, "contexts_per_gpu": args.streams, "lockstep_batch": args.batch, "audio_steps": n_audio, "prompt_len": args.prompt_len,
@@ -305,9 +312,11 @@ def main():
             per_launch_ms = st["ms_total"] / max(st["launches"], 1)
             if dom.startswith("dac_conv"):
                 ach = st["flops_total"] / (st["ms_total"] * 1e-3) / 1e12
-                roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / F32_PEAK_TFLOPS, 4), "traffic": None,
-                        "note": "fp32 conv: peak = fp32 vector/fp32-input-MFMA peak (exact-fp32 numerics)"}
+                peak = F16_PEAK_TFLOPS if args.dac_wtype == "f16" else F32_PEAK_TFLOPS
+                roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": None,
+                        "note": "fp16 conv (F16 tensors, fp16 im2col): dense fp16 MFMA peak" if args.dac_wtype == "f16" else
+                                "fp32 conv: peak = fp32 vector/fp32-input-MFMA peak (exact-fp32 numerics)"}
             else:
                 ach = st["bytes_total"] / (st["ms_total"] * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

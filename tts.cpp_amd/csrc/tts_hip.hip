@@ -157,6 +157,7 @@ struct ProfEv { hipEvent_t a, b; int kclass; };
 struct tts_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t dac_stream = nullptr;  // low-priority queue for the codec (NULL: same stream)
     tts_hip_desc d{};
     std::map<std::string, Tensor> tensors;
     bool planned = false, finalized = false, weights_present = false;
@@ -253,7 +254,17 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (c->d.kv_type != TTS_HIP_F16) c->d.kv_type = TTS_HIP_F32;
     c->has_parler = !(desc->flags & TTS_HIP_FLAG_NO_PARLER);
     c->has_dac = !(desc->flags & TTS_HIP_FLAG_NO_DAC);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); delete c; return nullptr; }
+    {
+        // the decoder's short dependent kernels get the high-priority queue, the codec's chip-filling convolutions the
+        // low one: when contexts share a GPU, one context's step is not held up behind another's conv workgroups
+        int least = 0, greatest = 0;
+        const char *e = getenv("TTS_HIP_STREAM_PRIO");
+        const bool prio = !(e && atoi(e) == 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
+        hipError_t rc = prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest)
+                             : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (rc != hipSuccess) { set_err("hipStreamCreate failed"); delete c; return nullptr; }
+        if (prio && hipStreamCreateWithPriority(&c->dac_stream, hipStreamNonBlocking, least) != hipSuccess) c->dac_stream = nullptr;
+    }
     const char *ns = getenv("TTS_HIP_ATTN_NSPLIT");
     if (ns) c->attn_nsplit_override = atoi(ns);
     const char *lf = getenv("TTS_HIP_LN_FUSE_MAX");
@@ -288,6 +299,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     if (c->h_pcm) (void) hipHostFree(c->h_pcm);
     for (auto &e : c->prof_events) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
     (void) hipStreamDestroy(c->stream);
+    if (c->dac_stream) (void) hipStreamDestroy(c->dac_stream);
     delete c;
 }
 
@@ -1559,8 +1571,19 @@ static int launch_convt(tts_hip_ctx *c, ConvTArgs ta, size_t w_off, int nz) {
 
 // dac_runner::run for n utterances at once (grid.z = utterance, per-utterance lengths): the early blocks have
 // few positions per utterance, so batching is what fills the 256 CUs there.
+static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint32_t *frames, uint32_t n, float *pcm_out);
 static int dac_decode_batch(tts_hip_ctx *c, const uint32_t *codes, const uint32_t *frames, uint32_t n, float *pcm_out) {
     if (!c || !c->finalized || !c->has_dac) return set_err("tts_hip_dac_decode: context has no finalized DAC");
+    if (!c->dac_stream) return dac_decode_batch_on(c, codes, frames, n, pcm_out);
+    // the decoder stream is idle here (every decoder entry point synchronises before it returns)
+    hipStream_t ar = c->stream;
+    c->stream = c->dac_stream;
+    const int rc = dac_decode_batch_on(c, codes, frames, n, pcm_out);
+    c->stream = ar;
+    return rc;
+}
+
+static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint32_t *frames, uint32_t n, float *pcm_out) {
     if (!c->weights_present) return set_err("tts_hip_dac_decode: weights not present");
     if (!codes || !pcm_out || !frames) return set_err("tts_hip_dac_decode: null argument");
     HIPCHK(hipSetDevice(c->device));
