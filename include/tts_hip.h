@@ -150,6 +150,25 @@ int tts_hip_parler_generate_greedy(tts_hip_ctx *ctx, uint32_t n_seqs, const uint
                                    uint32_t n_steps, uint32_t bos, uint32_t eos, uint32_t *tokens_out,
                                    uint32_t *steps_done);
 
+/* sampler::sample on the device (src/sampler.cpp:3-69: softmax :82-116, topk :152-183, topp :118-150) for
+ * repetition_penalty == 1 and output_vocab_size <= 2048.  top_k == 0 or >= vocab disables top-k, top_p >= 1
+ * disables top-p; the order of the fp32 sums follows the reference (see sample_kernel).  The U[0,1) draws are the
+ * caller's (the reference draws them from std::minstd_rand, sampler.cpp:47-48). */
+typedef struct tts_hip_sampling {
+    uint32_t top_k;
+    float    top_p;
+    float    temperature;
+} tts_hip_sampling;
+/* tts_hip_parler_generate_greedy with sampler::sample instead of sampler::max.
+ *   uniforms [n_steps][n_seqs][n_output_heads]: draw for head h of sequence s at its k-th sampler call */
+int tts_hip_parler_generate_sampled(tts_hip_ctx *ctx, uint32_t n_seqs, const uint32_t *start_pos,
+                                    uint32_t n_steps, uint32_t bos, uint32_t eos, const tts_hip_sampling *sampling,
+                                    const float *uniforms, uint32_t *tokens_out, uint32_t *steps_done);
+/* The device sampler alone on caller-supplied logits [n_rows][n_output_heads][output_vocab_size]
+ * (uniforms [n_rows][n_output_heads]) -> tokens_out [n_rows][n_output_heads]; for parity tests. */
+int tts_hip_sample_logits(tts_hip_ctx *ctx, uint32_t n_rows, const float *logits, const tts_hip_sampling *sampling,
+                          const float *uniforms, uint32_t *tokens_out);
+
 /* ---- DAC codec --------------------------------------------------------------------------- */
 /* dac_runner::run (dac_model.cpp:172-212): codes [frames][n_output_heads] (frame-major),
  * pcm_out: frames * prod(strides) fp32 samples in host memory.  Blocks until done. */

@@ -80,6 +80,29 @@ def test_host_sampling_loop_modes(tmp_path):
     r.close()
 
 
+def test_device_sampler_loop_equals_host_sampler_loop(tmp_path):
+    """seeded sampling: sampler::sample on the device (tts_hip_parler_generate_sampled, uniforms drawn ahead with the
+    same std::minstd_rand sequence) == the per-step host loop (logits D2H + sampler::sample on the host).
+    The model keeps its special-id head rows: the suppressed variant has 16 exactly equal logits per head, and the
+    order of equal keys is where the device (index order) and the reference's std::sort (unspecified) may differ."""
+    model = synth.build(synth.tiny(weight_type=gguf.F32, suppress_special=False))
+    path = model.write_gguf(str(tmp_path / "m.gguf"))
+    text = "hello there"
+    r = runner.Runner(path, sample=0)
+    for kw in (dict(top_k=50, temperature=1.0, seed=1234), dict(top_k=0, top_p=0.85, temperature=1.2, seed=77),
+               dict(top_k=12, top_p=0.9, temperature=0.8, seed=5)):
+        dev = r.generate(text, sample=1, max_tokens=40, **kw)
+        td = r.last_tokens(1).copy()
+        os.environ["TTS_HOST_LOOP"] = "1"
+        try:
+            hst = r.generate(text, sample=1, max_tokens=40, **kw)
+        finally:
+            del os.environ["TTS_HOST_LOOP"]
+        assert len(td) > 0 and np.array_equal(td, r.last_tokens(1)), kw
+        assert np.array_equal(dev, hst), kw
+    r.close()
+
+
 def test_generate_batch_equals_separate_generates(tmp_path):
     """extension: lock-step utterances through the C++ runner == one generate() per utterance (greedy exactly;
     seeded sampling runs and is reproducible)"""

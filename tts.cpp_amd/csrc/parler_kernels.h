@@ -10,6 +10,7 @@
 //        EPI_RESID      ggml_add(residual)               :574, :595, :604
 //   attn_kernel         mul_mat(K,q) -> soft_max_ext -> mul_mat(kq,V)   :549-570 / :583-595
 //   argmax_kernel       sampler::max                     src/sampler.cpp:185-204
+//   sample_kernel       sampler::sample (softmax/topk/topp/inverse CDF)   src/sampler.cpp:3-69,82-183
 //   feed_kernel         delay-pattern feed + EOS flags   model.cpp:715-732, :778-785
 //
 // Design notes (MI355X): a decode step is pure weight streaming (≈725 MB of fp16 weights per
@@ -645,6 +646,152 @@ __global__ void argmax_kernel(const float *logits, int V, uint32_t *tokens) {
         for (int i = 1; i < (int) (blockDim.x >> 6); i++)
             if (bv[i] > best || (bv[i] == best && bi[i] < besti)) { best = bv[i]; besti = bi[i]; }
         tokens[idx] = besti;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampler::sample on the device (src/sampler.cpp:3-69 with softmax :82-116, topk :152-183, topp :118-150) for
+// repetition_penalty == 1: one workgroup per (row, head).  Everything whose result depends on the order of fp32
+// operations follows the reference's order: the softmax denominator and the inverse-CDF scan are sequential sums
+// over the candidates in candidate order (one thread), probabilities are exp(v/T - top)/total with the same
+// operation sequence; only the embarrassingly parallel parts (exp, rank counting) use the whole workgroup.
+// Candidate order = descending value; equal values are ordered by index (the reference's std::sort leaves the
+// order of equal keys unspecified).  The uniform draws come from the host (std::minstd_rand, sampler.cpp:47-48).
+// ------------------------------------------------------------------------------------------------
+#define SMP_VMAX 2048
+struct SampleArgs {
+    const float *logits;       // [R][n_out][V]
+    int V, n_out, R;
+    uint32_t top_k;
+    float top_p, temperature;
+    const float *uniforms;     // [calls][R][n_out]
+    const uint32_t *row_step;  // [R] 1-based index of the sampler call this step is (NULL: call 1)
+    uint32_t *out;             // [R][n_out]
+};
+
+// picks[rank] = index for every element whose rank (descending value, then ascending index) is < k
+__device__ __forceinline__ void smp_rank_select(const float *val, int V, int k, unsigned short *picks) {
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        const float vi = val[i];
+        int rank = 0;
+        for (int j = 0; j < V; j++) {
+            const float vj = val[j];
+            rank += (vj > vi || (vj == vi && j < i)) ? 1 : 0;
+        }
+        if (rank < k) picks[rank] = (unsigned short) i;
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
+    __shared__ float val[SMP_VMAX];
+    __shared__ float tmp[SMP_VMAX];
+    __shared__ unsigned short picks[SMP_VMAX];
+    __shared__ float bv[4];
+    __shared__ uint32_t bi[4];
+    __shared__ float s_top, s_total, s_mhp;
+    __shared__ int s_n;
+    const int h = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, V = a.V;
+    const float *row = a.logits + ((int64_t) r * a.n_out + h) * V;
+    const bool temp = a.temperature != 1.0f;
+    const bool use_topk = a.top_k > 0 && a.top_k < (uint32_t) V;
+    const bool use_topp = a.top_p < 1.0f;
+
+    // sampler::max (first maximum wins)
+    float best = -INFINITY;
+    uint32_t besti = 0;
+    for (int i = tid; i < V; i += 256) {
+        const float v = row[i];
+        val[i] = v;
+        if (v > best) { best = v; besti = (uint32_t) i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const uint32_t oi = __shfl_xor(besti, o);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 4; i++)
+            if (bv[i] > best || (bv[i] == best && bi[i] < besti)) { best = bv[i]; besti = bi[i]; }
+        float top = val[besti];
+        if (temp) top /= a.temperature;
+        s_top = top;
+    }
+    __syncthreads();
+    const float top = s_top;
+    int n = V;
+    bool nucleus = false;
+
+    if (use_topp) {  // softmax over the whole vocabulary first (sampler.cpp:20-23)
+        for (int i = tid; i < V; i += 256) {
+            float v = val[i];
+            if (temp) v /= a.temperature;
+            tmp[i] = expf(v - top);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float total = 0.0f;
+            for (int i = 0; i < V; i++) total += tmp[i];
+            s_total = total;
+        }
+        __syncthreads();
+        for (int i = tid; i < V; i += 256) val[i] = tmp[i] / s_total;
+        __syncthreads();
+    }
+    if (use_topk) {  // on logits, or on probabilities when the softmax already ran
+        smp_rank_select(val, V, (int) a.top_k, picks);
+        n = (int) a.top_k;
+        nucleus = true;
+        __syncthreads();
+    }
+    if (!use_topp) {  // softmax over the candidates, in candidate order
+        for (int j = tid; j < n; j += 256) {
+            float v = val[nucleus ? picks[j] : j];
+            if (temp) v /= a.temperature;
+            tmp[j] = expf(v - top);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float total = 0.0f;
+            for (int j = 0; j < n; j++) total += tmp[j];
+            s_total = total;
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += 256) val[nucleus ? picks[j] : j] = tmp[j] / s_total;
+        __syncthreads();
+    } else {
+        if (!nucleus) {  // topp sorts the whole vocabulary by probability (sampler.cpp:119-131)
+            smp_rank_select(val, V, V, picks);
+            nucleus = true;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            float mass = 0.0f;
+            int keep = -1;
+            for (int j = 0; j < n; j++) {
+                mass += val[picks[j]];
+                if (mass >= a.top_p) { keep = j + 1; break; }
+            }
+            s_mhp = fminf(mass, a.top_p);
+            s_n = keep > 0 ? keep : n;
+        }
+        __syncthreads();
+        n = s_n;
+    }
+    if (tid == 0) {
+        const uint32_t call = a.row_step ? a.row_step[r] - 1 : 0;
+        const float u = a.uniforms[((int64_t) call * a.R + r) * a.n_out + h];
+        const float target = use_topp ? u * s_mhp : u;
+        float cum = 0.0f;
+        int chosen = n ? (nucleus ? (int) picks[n - 1] : n - 1) : 0;
+        for (int j = 0; j < n; j++) {
+            const int i = nucleus ? (int) picks[j] : j;
+            cum += val[i];
+            if (target <= cum || j + 1 >= n) { chosen = i; break; }
+        }
+        a.out[r * a.n_out + h] = (uint32_t) chosen;
     }
 }
 

@@ -191,6 +191,10 @@ struct tts_hip_ctx {
     float *ad = nullptr;        // their block scales
     bool all_q8i = false;       // every decoder matrix is on the integer path (all GEMMs go through run_qgemm)
     int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
+    tts_hip_sampling smp{};     // parameters baked into the captured MODE_GEN_SAMPLE graphs
+    float *d_uniforms = nullptr;  // [calls][R][n_out] host-drawn U[0,1) for sample_kernel
+    size_t uniforms_cap = 0;
+    uint32_t g_bos = 0xFFFFFFFFu, g_eos = 0xFFFFFFFFu;  // ids baked into the captured feed kernel
     int pending_parts = 0;      // slabs waiting to be folded into x by the next LayerNorm launch
     int ln_waves = 1;           // rows (waves) per LayerNorm workgroup
     int ksplit_big = 4;         // K slices for K >= 4096 residual GEMMs
@@ -285,7 +289,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (auto &t : c->tensors) free_dev(t.second.tmp);
     if (!c->arena_external) free_dev(c->arena);
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
-    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
+    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
     free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
     free_dev(c->d_eos); free_dev(c->d_codes); free_dev(c->d_frames);
     for (int i = 0; i < 3; i++) free_dev(c->dbuf[i]);
@@ -1174,7 +1178,7 @@ extern "C" int tts_hip_parler_prefill_batch(tts_hip_ctx *c, uint32_t n, const ui
     return 0;
 }
 
-enum { MODE_LOGITS = 0, MODE_GREEDY = 1, MODE_GEN = 2 };
+enum { MODE_LOGITS = 0, MODE_GREEDY = 1, MODE_GEN = 2, MODE_GEN_SAMPLE = 3 };
 
 static int stage_step_inputs(tts_hip_ctx *c, uint32_t n, const uint32_t *ids, const uint32_t *pos, const uint32_t *seqs) {
     if (n == 0 || (int) n > c->RMAX || n > c->d.max_seqs) return set_err("step: n_seqs=%u outside 1..%u", n, std::min<uint32_t>(c->RMAX, c->d.max_seqs));
@@ -1197,7 +1201,7 @@ static int stage_step_inputs(tts_hip_ctx *c, uint32_t n, const uint32_t *ids, co
 
 // enqueue (or replay) one audio step for R rows in the given mode
 static int enqueue_step_body(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint32_t eos) {
-    if (mode != MODE_GEN) {
+    if (mode != MODE_GEN && mode != MODE_GEN_SAMPLE) {
         HIPCHK(hipMemcpyAsync(c->d_ids, c->h_ids, (size_t) R * c->NO * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_pos, c->h_pos, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_seq, c->h_seq, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
@@ -1207,9 +1211,17 @@ static int enqueue_step_body(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint
         HIPCHK(hipMemcpyAsync(c->h_logits, c->logits, (size_t) R * c->NO * c->V * 4, hipMemcpyDeviceToHost, c->stream));
     } else {
         CHK(prof_begin(c, TTS_HIP_K_SAMPLE, (double) R * c->NO * c->V * 4, 0));
-        hipLaunchKernelGGL(argmax_kernel, dim3(R * c->NO), dim3(256), 0, c->stream, (const float *) c->logits, c->V, c->d_tok);
+        if (mode == MODE_GEN_SAMPLE) {
+            SampleArgs sa{};
+            sa.logits = c->logits; sa.V = c->V; sa.n_out = c->NO; sa.R = R;
+            sa.top_k = c->smp.top_k; sa.top_p = c->smp.top_p; sa.temperature = c->smp.temperature;
+            sa.uniforms = c->d_uniforms; sa.row_step = c->d_step; sa.out = c->d_tok;
+            hipLaunchKernelGGL(sample_kernel, dim3(c->NO, R), dim3(256), 0, c->stream, sa);
+        } else {
+            hipLaunchKernelGGL(argmax_kernel, dim3(R * c->NO), dim3(256), 0, c->stream, (const float *) c->logits, c->V, c->d_tok);
+        }
         HIPCHK(hipGetLastError());
-        if (mode == MODE_GEN) {
+        if (mode == MODE_GEN || mode == MODE_GEN_SAMPLE) {
             FeedArgs f{};
             f.tokens = c->d_tok; f.ids = c->d_ids; f.row_pos = c->d_pos; f.row_step = c->d_step; f.eos_seen = c->d_eos;
             f.steps_done = c->d_steps_done; f.tokens_out = c->d_tokens_out; f.R = R; f.n_out = c->NO; f.bos = bos; f.eos = eos;
@@ -1265,9 +1277,15 @@ extern "C" int tts_hip_parler_step_greedy(tts_hip_ctx *c, uint32_t n, const uint
     return 0;
 }
 
-extern "C" int tts_hip_parler_generate_greedy(tts_hip_ctx *c, uint32_t n, const uint32_t *start_pos, uint32_t n_steps,
-                                              uint32_t bos, uint32_t eos, uint32_t *tokens_out, uint32_t *steps_done) {
-    CHK(ready(c, "tts_hip_parler_generate_greedy"));
+static void drop_gen_graphs(tts_hip_ctx *c) {
+    for (auto g = c->graphs.begin(); g != c->graphs.end();) {
+        if (g->first / 1000 == MODE_GEN || g->first / 1000 == MODE_GEN_SAMPLE) { (void) hipGraphExecDestroy(g->second); g = c->graphs.erase(g); } else ++g;
+    }
+}
+
+// the device-resident generation loop; mode MODE_GEN (sampler::max) or MODE_GEN_SAMPLE (sample_kernel, c->smp / c->d_uniforms)
+static int generate_loop(tts_hip_ctx *c, int mode, uint32_t n, const uint32_t *start_pos, uint32_t n_steps,
+                         uint32_t bos, uint32_t eos, uint32_t *tokens_out, uint32_t *steps_done) {
     if (!start_pos || !tokens_out) return set_err("generate_greedy: null argument");
     if (n == 0 || (int) n > c->RMAX || n > c->d.max_seqs) return set_err("generate_greedy: n_seqs=%u out of range", n);
     if (bos >= (uint32_t) c->EROWS || eos >= (uint32_t) c->EROWS) return set_err("generate_greedy: bos/eos outside the embedding table");
@@ -1286,12 +1304,7 @@ extern "C" int tts_hip_parler_generate_greedy(tts_hip_ctx *c, uint32_t n, const 
         c->d_tokens_out = nullptr;
         HIPCHK(hipMalloc((void **) &c->d_tokens_out, need * 4));
         c->tokens_out_cap = need;
-        // the captured graph baked the old pointer in
-        auto it = c->graphs.find(MODE_GEN * 1000 + (int) n);
-        for (auto g = c->graphs.begin(); g != c->graphs.end();) {
-            if (g->first / 1000 == MODE_GEN) { (void) hipGraphExecDestroy(g->second); g = c->graphs.erase(g); } else ++g;
-        }
-        (void) it;
+        drop_gen_graphs(c);  // the captured graphs baked the old pointer in
     }
     for (uint32_t r = 0; r < n; r++) c->h_tok[r] = 1;  // current_step of the first audio decode (model.cpp:783-785)
     HIPCHK(hipMemcpyAsync(c->d_ids, c->h_ids, (size_t) n * c->NO * 4, hipMemcpyHostToDevice, c->stream));
@@ -1302,17 +1315,14 @@ extern "C" int tts_hip_parler_generate_greedy(tts_hip_ctx *c, uint32_t n, const 
     HIPCHK(hipMemsetAsync(c->d_steps_done, 0, (size_t) n * 4, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     // bos/eos are baked into the captured feed kernel: key the graph on them too
-    static uint32_t g_bos = 0xFFFFFFFFu, g_eos = 0xFFFFFFFFu;
-    if (g_bos != bos || g_eos != eos) {
-        for (auto g = c->graphs.begin(); g != c->graphs.end();) {
-            if (g->first / 1000 == MODE_GEN) { (void) hipGraphExecDestroy(g->second); g = c->graphs.erase(g); } else ++g;
-        }
-        g_bos = bos; g_eos = eos;
+    if (c->g_bos != bos || c->g_eos != eos) {
+        drop_gen_graphs(c);
+        c->g_bos = bos; c->g_eos = eos;
     }
     uint32_t ran = 0;
     for (uint32_t s = 0; s < n_steps; s++) {
         for (uint32_t r = 0; r < n; r++) c->host_pos[r] = start_pos[r] + s;
-        CHK(run_step(c, (int) n, MODE_GEN, bos, eos));
+        CHK(run_step(c, (int) n, mode, bos, eos));
         ran = s + 1;
         if ((ran % 32) == 0 && ran < n_steps) {
             // has check_stopping() fired for every sequence?  (one small D2H + sync every 32 steps)
@@ -1329,6 +1339,67 @@ extern "C" int tts_hip_parler_generate_greedy(tts_hip_ctx *c, uint32_t n, const 
     if (steps_done) HIPCHK(hipMemcpy(steps_done, c->d_steps_done, (size_t) n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
+
+extern "C" int tts_hip_parler_generate_greedy(tts_hip_ctx *c, uint32_t n, const uint32_t *start_pos, uint32_t n_steps,
+                                              uint32_t bos, uint32_t eos, uint32_t *tokens_out, uint32_t *steps_done) {
+    CHK(ready(c, "tts_hip_parler_generate_greedy"));
+    return generate_loop(c, MODE_GEN, n, start_pos, n_steps, bos, eos, tokens_out, steps_done);
+}
+
+static int check_sampling(const tts_hip_ctx *c, const tts_hip_sampling *sp, const char *what) {
+    if (!sp) return set_err("%s: null sampling parameters", what);
+    if (c->V > SMP_VMAX) return set_err("%s: output vocabulary %d > %d (sample on the host from tts_hip_parler_step)", what, c->V, SMP_VMAX);
+    if (!(sp->temperature > 0.0f)) return set_err("%s: temperature must be > 0", what);
+    if (!(sp->top_p > 0.0f)) return set_err("%s: top_p must be > 0", what);
+    return 0;
+}
+
+static int stage_uniforms(tts_hip_ctx *c, const float *uniforms, size_t count) {
+    if (count > c->uniforms_cap) {
+        free_dev(c->d_uniforms);
+        c->d_uniforms = nullptr;
+        HIPCHK(hipMalloc((void **) &c->d_uniforms, count * 4));
+        c->uniforms_cap = count;
+        drop_gen_graphs(c);
+    }
+    HIPCHK(hipMemcpy(c->d_uniforms, uniforms, count * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int tts_hip_parler_generate_sampled(tts_hip_ctx *c, uint32_t n, const uint32_t *start_pos, uint32_t n_steps,
+                                               uint32_t bos, uint32_t eos, const tts_hip_sampling *sp, const float *uniforms,
+                                               uint32_t *tokens_out, uint32_t *steps_done) {
+    CHK(ready(c, "tts_hip_parler_generate_sampled"));
+    CHK(check_sampling(c, sp, "tts_hip_parler_generate_sampled"));
+    if (!uniforms) return set_err("tts_hip_parler_generate_sampled: null uniforms");
+    if (n == 0 || (int) n > c->RMAX || n > c->d.max_seqs) return set_err("generate_sampled: n_seqs=%u out of range", n);
+    if (sp->top_k != c->smp.top_k || sp->top_p != c->smp.top_p || sp->temperature != c->smp.temperature) {
+        drop_gen_graphs(c);  // parameters are baked into the captured sample_kernel launch
+        c->smp = *sp;
+    }
+    CHK(stage_uniforms(c, uniforms, (size_t) n_steps * n * c->NO));
+    return generate_loop(c, MODE_GEN_SAMPLE, n, start_pos, n_steps, bos, eos, tokens_out, steps_done);
+}
+
+extern "C" int tts_hip_sample_logits(tts_hip_ctx *c, uint32_t n_rows, const float *logits, const tts_hip_sampling *sp,
+                                     const float *uniforms, uint32_t *tokens_out) {
+    CHK(ready(c, "tts_hip_sample_logits"));
+    CHK(check_sampling(c, sp, "tts_hip_sample_logits"));
+    if (!logits || !uniforms || !tokens_out) return set_err("tts_hip_sample_logits: null argument");
+    if (n_rows == 0 || (int) n_rows > c->RMAX) return set_err("tts_hip_sample_logits: n_rows=%u outside 1..%d", n_rows, c->RMAX);
+    CHK(stage_uniforms(c, uniforms, (size_t) n_rows * c->NO));
+    HIPCHK(hipMemcpyAsync(c->logits, logits, (size_t) n_rows * c->NO * c->V * 4, hipMemcpyHostToDevice, c->stream));
+    SampleArgs sa{};
+    sa.logits = c->logits; sa.V = c->V; sa.n_out = c->NO; sa.R = (int) n_rows;
+    sa.top_k = sp->top_k; sa.top_p = sp->top_p; sa.temperature = sp->temperature;
+    sa.uniforms = c->d_uniforms; sa.row_step = nullptr; sa.out = c->d_tok;
+    hipLaunchKernelGGL(sample_kernel, dim3(c->NO, n_rows), dim3(256), 0, c->stream, sa);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(tokens_out, c->d_tok, (size_t) n_rows * c->NO * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // DAC

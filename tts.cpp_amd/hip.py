@@ -44,10 +44,15 @@ EXPORTS = [
     "tts_hip_device_count", "tts_hip_create", "tts_hip_destroy", "tts_hip_last_error", "tts_hip_version",
     "tts_hip_upload", "tts_hip_arena_bytes", "tts_hip_finalize", "tts_hip_arena_ptr", "tts_hip_arena_filled",
     "tts_hip_parler_set_text_encoding", "tts_hip_parler_reset", "tts_hip_parler_prefill", "tts_hip_parler_prefill_batch", "tts_hip_parler_step",
-    "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
+    "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
     "tts_hip_synchronize",
 ]
+
+class Sampling(C.Structure):
+    """tts_hip_sampling (include/tts_hip.h)"""
+    _fields_ = [("top_k", C.c_uint32), ("top_p", C.c_float), ("temperature", C.c_float)]
+
 
 _lib = None
 
@@ -86,6 +91,8 @@ def load_lib():
     L.tts_hip_parler_step.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, f32p]
     L.tts_hip_parler_step_greedy.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, u32p]
     L.tts_hip_parler_generate_greedy.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
+    L.tts_hip_parler_generate_sampled.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Sampling), f32p, u32p, u32p]
+    L.tts_hip_sample_logits.argtypes = [vp, C.c_uint32, f32p, C.POINTER(Sampling), f32p, u32p]
     L.tts_hip_dac_decode.argtypes = [vp, u32p, C.c_uint32, f32p]
     L.tts_hip_dac_decode_batch.argtypes = [vp, u32p, u32p, C.c_uint32, f32p]
     L.tts_hip_debug_read.argtypes = [vp, C.c_char_p, f32p, C.c_size_t]
@@ -230,6 +237,29 @@ class HipEngine:
             self.ctx, n, bp, n_steps, self.cfg.bos if bos is None else bos, self.cfg.eos if eos is None else eos,
             out.ctypes.data_as(C.POINTER(C.c_uint32)), done.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out, done
+
+    def generate_sampled(self, start_pos, n_steps, uniforms, top_k=50, top_p=1.0, temperature=1.0, bos=None, eos=None):
+        """uniforms [n_steps][n][n_out] -> (tokens [n_steps][n][n_out], steps_done [n])"""
+        b, bp = _u32(start_pos)
+        n = len(b)
+        u = np.ascontiguousarray(uniforms, dtype=np.float32).reshape(n_steps, n, self.cfg.n_out)
+        out = np.empty((n_steps, n, self.cfg.n_out), dtype=np.uint32)
+        done = np.zeros(n, dtype=np.uint32)
+        sp = Sampling(top_k, top_p, temperature)
+        self._chk(self.L.tts_hip_parler_generate_sampled(
+            self.ctx, n, bp, n_steps, self.cfg.bos if bos is None else bos, self.cfg.eos if eos is None else eos, C.byref(sp),
+            u.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_uint32)), done.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out, done
+
+    def sample_logits(self, logits, uniforms, top_k=50, top_p=1.0, temperature=1.0):
+        """the device sampler alone: logits [n][n_out][V], uniforms [n][n_out] -> ids [n][n_out]"""
+        lg = np.ascontiguousarray(logits, dtype=np.float32).reshape(-1, self.cfg.n_out, self.cfg.out_vocab)
+        u = np.ascontiguousarray(uniforms, dtype=np.float32).reshape(lg.shape[0], self.cfg.n_out)
+        out = np.empty((lg.shape[0], self.cfg.n_out), dtype=np.uint32)
+        sp = Sampling(top_k, top_p, temperature)
+        self._chk(self.L.tts_hip_sample_logits(self.ctx, lg.shape[0], lg.ctypes.data_as(C.POINTER(C.c_float)), C.byref(sp),
+                                                u.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
 
     # ---- dac ----------------------------------------------------------------------------------
     def dac_decode(self, codes):

@@ -157,13 +157,22 @@ void parler_runner::generate(const char * sentence, tts_response & output, const
     std::vector<uint32_t> & out_tokens = last_output_tokens;
     out_tokens.clear();
 
-    const bool device_loop = !config.sample && config.repetition_penalty == 1.0f && !getenv("TTS_HOST_LOOP");
+    // the sampler runs on the device unless it needs the repetition-penalty state (or more than 2048 logits per head)
+    const bool device_loop = config.repetition_penalty == 1.0f && !getenv("TTS_HOST_LOOP") && (!config.sample || hp.output_vocab_size <= 2048);
     if (device_loop) {
-        // greedy: sampler::max, the delay-pattern feed and the EOS flags run on the device; the host
+        // sampler::max / sampler::sample, the delay-pattern feed and the EOS flags run on the device; the host
         // synchronises in chunks only to learn whether check_stopping() would have fired.
         const uint32_t max_steps = hp.max_generation_size - current_position;
         std::vector<uint32_t> toks((size_t) max_steps * nh);
         uint32_t start = current_position, done = 0;
+        if (config.sample) {
+            // the U[0,1) draws sample() would make, call by call (sampler.cpp:47-50), drawn ahead
+            std::vector<float> u((size_t) max_steps * nh);
+            for (uint32_t s = 0; s < max_steps; s++) smp.draw_uniforms(u.data() + (size_t) s * nh);
+            const tts_hip_sampling sp{smp.top_k, smp.top_p, smp.temperature};
+            hip_check(tts_hip_parler_generate_sampled(ctx, 1, &start, max_steps, hp.bos_token_id, hp.eos_token_id, &sp, u.data(), toks.data(), &done),
+                      "tts_hip_parler_generate_sampled");
+        } else
         hip_check(tts_hip_parler_generate_greedy(ctx, 1, &start, max_steps, hp.bos_token_id, hp.eos_token_id, toks.data(), &done),
                   "tts_hip_parler_generate_greedy");
         const uint32_t n = done ? done : max_steps;
@@ -227,8 +236,20 @@ void parler_runner::generate_batch(const std::vector<std::string> & sentences, s
     const uint32_t max_steps = hp.max_generation_size - longest;  // every sequence stays inside max_generation
     last_batch_tokens.assign(n, {});
 
-    if (!config.sample && config.repetition_penalty == 1.0f) {
+    if (config.repetition_penalty == 1.0f && !getenv("TTS_HOST_LOOP") && (!config.sample || hp.output_vocab_size <= 2048)) {
         std::vector<uint32_t> toks((size_t) max_steps * n * nh), done(n);
+        if (config.sample) {
+            // one sampler state per utterance, seeded like the host loop below: uniforms [step][utterance][head]
+            std::vector<float> u((size_t) max_steps * n * nh);
+            for (uint32_t i = 0; i < n; i++) {
+                sampler si = smp;
+                si.seed = config.seed ? config.seed + i : 0; si.n_calls = 0;
+                for (uint32_t s = 0; s < max_steps; s++) si.draw_uniforms(u.data() + ((size_t) s * n + i) * nh);
+            }
+            const tts_hip_sampling sp{(uint32_t) config.top_k, config.top_p, config.temperature};
+            hip_check(tts_hip_parler_generate_sampled(ctx, n, start.data(), max_steps, hp.bos_token_id, hp.eos_token_id, &sp, u.data(), toks.data(), done.data()),
+                      "tts_hip_parler_generate_sampled");
+        } else
         hip_check(tts_hip_parler_generate_greedy(ctx, n, start.data(), max_steps, hp.bos_token_id, hp.eos_token_id, toks.data(), done.data()),
                   "tts_hip_parler_generate_greedy");
         for (uint32_t i = 0; i < n; i++) {

@@ -138,11 +138,15 @@ void sampler::sample_with_uniforms(float * logits, const float * uniforms, std::
     }
 }
 
-void sampler::sample(float * logits, std::vector<uint32_t> & output_tokens) {
-    if (!do_sample) { max(logits, output_tokens); return; }
+void sampler::draw_uniforms(float * u) {
     std::minstd_rand gen(seed ? (std::minstd_rand::result_type) (seed * 0x9E3779B97F4A7C15ull + ++n_calls) : std::random_device{}());
     std::uniform_real_distribution<float> dist(0.0f, 1.0f);
+    for (uint32_t h = 0; h < n_output_heads; h++) u[h] = dist(gen);
+}
+
+void sampler::sample(float * logits, std::vector<uint32_t> & output_tokens) {
+    if (!do_sample) { max(logits, output_tokens); return; }
     std::vector<float> u(n_output_heads);
-    for (auto & x : u) x = dist(gen);
+    draw_uniforms(u.data());
     sample_with_uniforms(logits, u.data(), output_tokens);
 }

@@ -24,6 +24,10 @@ struct sampler {
 
     void reset();
     void sample(float * logits, std::vector<uint32_t> & output_tokens);
+    // the n_output_heads U[0,1) draws of the next sample() call (std::minstd_rand + uniform_real_distribution as
+    // sampler.cpp:47-50); advances n_calls exactly like sample() does, so a caller can draw ahead for a
+    // device-resident loop and get the token stream sample() would have produced
+    void draw_uniforms(float * u);
     // test hook: same as sample() but the per-head uniform draws are supplied
     void sample_with_uniforms(float * logits, const float * uniforms, std::vector<uint32_t> & output_tokens);
     void max(const float * logits, std::vector<uint32_t> & out) const;
