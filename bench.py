@@ -53,13 +53,20 @@ import threading  # noqa: E402
 DAC_LOCK = threading.Lock()
 
 
+SAMPLE_UNIFORMS = None  # [steps][batch][heads] U[0,1) draws when --sample
+
+
 def run_utterance_batch(eng, cfg, prompts, n_audio, timings=None, dac_group=None):
     dac_group = dac_group or DAC_GROUP
     """one bench step; returns total PCM samples produced"""
     t0 = time.perf_counter()
     eng.prefill_batch(prompts)
     t1 = time.perf_counter()
-    toks, _ = eng.generate_greedy([len(p) for p in prompts], n_audio)
+    if SAMPLE_UNIFORMS is not None:   # --sample: sampler::sample on the device, the reference's default parameters
+        u = SAMPLE_UNIFORMS[:n_audio, :len(prompts)]
+        toks, _ = eng.generate_sampled([len(p) for p in prompts], n_audio, u, top_k=50, top_p=1.0, temperature=1.0)
+    else:
+        toks, _ = eng.generate_greedy([len(p) for p in prompts], n_audio)
     t2 = time.perf_counter()
     frames = [undelay(toks[:, s, :], cfg.audio_vocab) for s in range(len(prompts))]
     n_samples = 0
@@ -156,6 +163,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--model", choices=["mini", "small", "tiny"], default="mini")
+    ap.add_argument("--sample", action="store_true",
+                    help="sampler::sample on the device (top_k 50, temperature 1, top_p 1: the reference's defaults) instead of greedy")
     ap.add_argument("--dac-wtype", choices=["f32", "f16"], default="f32",
                     help="GGUF type of the codec tensors: f32 (quantize default) or f16 (--convert-dac-to-f16: fp16 im2col, fp16 MFMA)")
     ap.add_argument("--wtype", choices=["f16", "f32", "q8_0", "q5_0", "q4_0"], default="f16",
@@ -184,6 +193,10 @@ def main():
         weight_type={"f16": gguf.F16, "f32": gguf.F32, "q8_0": gguf.Q8_0, "q5_0": gguf.Q5_0, "q4_0": gguf.Q4_0}[args.wtype],
         dac_f16=args.dac_wtype == "f16")
     WNAME = dict(f16="fp16", f32="fp32").get(args.wtype, args.wtype)
+    DECODE = "top-k 50 sampling" if args.sample else "greedy decode"
+    if args.sample:
+        global SAMPLE_UNIFORMS
+        SAMPLE_UNIFORMS = np.random.default_rng(1234 + rank).random((args.audio_steps, args.batch, cfg.n_out), dtype=np.float32)
     n_audio = min(args.audio_steps, cfg.max_gen - args.prompt_len, cfg.ctx - args.prompt_len)
     kv_type = gguf.F16 if args.kv == "f16" else gguf.F32
 
@@ -279,7 +292,7 @@ def main():
                         DTYPE_DETAIL[args.wtype].replace("DAC codec f32 (exact-f32 MFMA)", "DAC codec F16 tensors (fp16 im2col x fp16 kernels, fp16 MFMA, f32 accumulate)"),
         "data": "synthetic (seeded random weights of the Parler-TTS-Mini + DAC-44k architecture; fixed-length greedy generation)",
         "config": {
-            "workload": f"configs[1]: Parler-TTS-Mini {WNAME} on MI355X, greedy decode + DAC codec ({args.dac_wtype} tensors); {args.streams} context(s) x {args.batch} utterances/GPU in lock-step, "
+            "workload": f"configs[1]: Parler-TTS-Mini {WNAME} on MI355X, {DECODE} + DAC codec ({args.dac_wtype} tensors); {args.streams} context(s) x {args.batch} utterances/GPU in lock-step, "
                         f"{args.prompt_len}-id prompt, {n_audio} audio steps (={n_audio - cfg.n_out + 1} frames, "
                         f"{(n_audio - cfg.n_out + 1) * cfg.hop / SAMPLE_RATE:.2f} s audio) per utterance",
             "utterances_per_gpu": args.batch * args.streams, "contexts_per_gpu": args.streams, "lockstep_batch": args.batch, "audio_steps": n_audio, "prompt_len": args.prompt_len,

@@ -67,6 +67,21 @@ typedef struct tts_c_sampler_cfg {
 int tts_c_sampler_sample(const tts_c_sampler_cfg *cfg, const int32_t *last_ids, const uint32_t *counts, float *logits,
                          const float *uniforms, uint32_t *out);
 
+/* ---- device pool: the server's worker pool (examples/server/server.cpp:126-330,885-895) with one worker per device
+ * and dynamic lock-step batching of the queued requests (tts.cpp_amd/host/device_pool.h).  No HTTP. -------------- */
+typedef struct tts_c_pool tts_c_pool;
+/* n_workers workers (server --n-parallelism), worker w on devices[w % n_devices] (NULL: device 0); each worker decodes
+ * up to max_batch compatible queued requests together, waiting batch_window_ms for more after the first. */
+tts_c_pool *tts_c_pool_create(const char *model_path, int n_workers, const int *devices, int n_devices, int max_batch,
+                              int batch_window_ms, const tts_c_config *load_cfg);
+int  tts_c_pool_submit(tts_c_pool *pool, const char *text, const tts_c_config *cfg);   /* task id, < 0 on error */
+/* blocks until the task is done (timeout_ms < 0: forever).  0 = audio in data[0..n_outputs), valid until
+ * tts_c_pool_release(id); 1 = finished without audio (tts_c_last_error says why); -1 = not finished */
+int  tts_c_pool_wait(tts_c_pool *pool, int id, int timeout_ms, const float **data, size_t *n_outputs, int *batch_size, int *worker);
+void tts_c_pool_release(tts_c_pool *pool, int id);
+void tts_c_pool_stats(tts_c_pool *pool, uint64_t *tasks, uint64_t *batches, uint64_t *largest_batch, uint64_t *timed_out);
+void tts_c_pool_free(tts_c_pool *pool);
+
 int tts_c_gguf_summary(const char *path, uint64_t *n_tensors, uint64_t *n_kv, uint64_t *data_offset, char *arch, int arch_cap);
 int tts_c_gguf_tensor(const char *path, int index, char *name, int name_cap, int *type, int64_t ne[4], uint64_t *checksum);
 

@@ -132,6 +132,33 @@ def test_generate_batch_equals_separate_generates(tmp_path):
     r.close()
 
 
+def test_device_pool_batches_queued_requests_on_the_gpu(tmp_path):
+    """device_pool on a real runner: 6 queued greedy requests, one worker with 4 KV slots -> decoded in lock-step
+    passes; every response equals a stand-alone generate() of the same text."""
+    model = synth.build(synth.tiny(weight_type=gguf.F32))
+    path = model.write_gguf(str(tmp_path / "m.gguf"))
+    texts = ["hello there", "a much longer sentence to say", "hi", "one two three", "hello there", "the last one"]
+    r = runner.Runner(path, sample=0)
+    expect = [r.generate(t) for t in texts]
+    r.close()
+    pool = runner.Pool(path, n_workers=1, max_batch=4, batch_window_ms=200, sample=0)
+    ids = [pool.submit(t) for t in texts]
+    sizes = []
+    for i, t in zip(ids, expect):
+        audio, bs, wk, err = pool.wait(i, timeout_ms=60000)
+        assert err == "" and wk == 0
+        # as in test_generate_batch_equals_separate_generates: in a batch every sequence runs max_generation -
+        # longest_prompt steps (random weights never emit EOS); the common frames agree, minus the codec's receptive field
+        n = min(audio.size, t.size)
+        hop = model.cfg.hop
+        assert n > 30 * hop and audio.size <= t.size
+        assert np.abs(audio[: n - 24 * hop] - t[: n - 24 * hop]).max() < 1e-5
+        sizes.append(bs)
+    st = pool.stats()
+    assert st["tasks"] == 6 and st["largest_batch"] == 4 and st["batches"] == 2, (st, sizes)
+    pool.close()
+
+
 def test_eos_stops_generation_and_empty_response(tmp_path):
     """every head emits EOS at the first audio step -> check_stopping ends the loop, every frame contains a
     special id and is dropped by adjust_output_tokens -> n_outputs == 0 (the reference's soft failure)"""

@@ -163,3 +163,59 @@ def test_runner_from_file_fails_loudly_without_gpu(tiny_gguf, have_gpu):
     with pytest.raises(runner.RunnerError) as e:
         runner.Runner(tiny_gguf[1])
     assert "tts_hip_create failed" in str(e.value)
+
+
+def test_device_pool_queue_batching_and_responses():
+    """device_pool (host/device_pool.h ~ examples/server/server.cpp:126-330): tasks pushed from several threads,
+    pulled by 2 workers, compatible queued tasks decoded together, responses fetched by id.  Runs on the weightless
+    test:dummy backend (its generate_batch is the base-class loop), so this is the queue/batch/response logic alone."""
+    import threading
+
+    ref = runner.Runner("test:dummy")
+    pool = runner.Pool("test:dummy", n_workers=2, max_batch=4, batch_window_ms=30)
+    texts = [f"utterance number {i}" for i in range(13)]
+    ids = {}
+    lock = threading.Lock()
+
+    def producer(lo, hi):
+        for i in range(lo, hi):
+            t = pool.submit(texts[i])
+            with lock:
+                ids[i] = t
+
+    th = [threading.Thread(target=producer, args=(a, b)) for a, b in ((0, 5), (5, 9), (9, 13))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert len(set(ids.values())) == 13
+    workers, sizes = set(), []
+    for i in range(13):
+        audio, bs, wk, err = pool.wait(ids[i], timeout_ms=20000)
+        assert err == "" and np.array_equal(audio, ref.generate(texts[i])), i
+        assert 1 <= bs <= 4
+        workers.add(wk)
+        sizes.append(bs)
+    st = pool.stats()
+    assert st["tasks"] == 13 and st["timed_out"] == 0
+    assert st["batches"] < 13 and 2 <= st["largest_batch"] <= 4, st   # requests did share passes
+    assert workers <= {0, 1}
+    # a different generation_configuration is not batched with the others
+    a = pool.submit("same text", top_k=5)
+    b = pool.submit("same text", top_k=7)
+    ra, rb = pool.wait(a, 20000), pool.wait(b, 20000)
+    assert ra[1] == 1 and rb[1] == 1 and np.array_equal(ra[0], rb[0])
+    # an empty prompt gives an empty response: finished, success == false (server.cpp:258)
+    e = pool.submit("")
+    audio, bs, wk, err = pool.wait(e, 20000)
+    assert audio.size == 0 and err != ""
+    # unknown id: wait times out
+    with pytest.raises(runner.RunnerError):
+        pool.wait(10 ** 6, timeout_ms=50)
+    pool.close()
+    ref.close()
+
+
+def test_device_pool_reports_load_failure():
+    with pytest.raises(runner.RunnerError):
+        runner.Pool("/nonexistent/model.gguf", n_workers=2, max_batch=2)

@@ -91,6 +91,17 @@ struct tts_generation_runner : tts_runner {
     virtual std::vector<std::string_view> list_voices();
     virtual void update_conditional_prompt(const char * file_path, const char * prompt);
     virtual void generate(const char * sentence, tts_response & output, const generation_configuration & config) = 0;
+
+    // ---- extension (not in the reference, which generates one utterance per call) -----------------------------
+    // n utterances in one call; outputs[i].data stays valid until the next generate/generate_batch on this runner.
+    // The default decodes them one after the other; a runner that can decode in lock-step on its device overrides
+    // it (parler_runner) and reports how many utterances one call may carry.
+    virtual void     generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs,
+                                    const generation_configuration & config);
+    virtual uint32_t batch_capacity() const { return UINT32_MAX; }
+
+  protected:
+    std::vector<std::vector<float>> batch_store_;  // audio of the default generate_batch
 };
 
 // loaders.h:8-20

@@ -1,0 +1,195 @@
+#include "device_pool.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <stdexcept>
+
+extern bool g_tts_throw_on_abort;
+
+bool pool_configs_compatible(const generation_configuration & a, const generation_configuration & b) {
+    return a.use_cross_attn == b.use_cross_attn && a.temperature == b.temperature && a.repetition_penalty == b.repetition_penalty &&
+           a.top_p == b.top_p && a.top_k == b.top_k && a.max_tokens == b.max_tokens && a.voice == b.voice && a.sample == b.sample &&
+           a.espeak_voice_id == b.espeak_voice_id && a.seed == b.seed;
+}
+
+struct device_pool::worker_state {
+    std::map<std::string, std::unique_ptr<tts_generation_runner>> runners;  // worker::runners (:240)
+};
+
+device_pool::device_pool(const std::map<std::string, std::string> & model_paths, const generation_configuration & load_config,
+                         const pool_options & opts)
+    : model_paths_(model_paths), load_config_(load_config), opts_(opts) {
+    if (opts_.n_workers < 1) opts_.n_workers = 1;
+    if (opts_.max_batch < 1) opts_.max_batch = 1;
+    if (opts_.devices.empty()) opts_.devices.push_back(0);
+    for (int w = 0; w < opts_.n_workers; w++) threads_.emplace_back(&device_pool::worker_main, this, w);
+    std::unique_lock<std::mutex> lock(load_mutex_);
+    load_cv_.wait(lock, [&] { return loaded_ == opts_.n_workers; });
+    if (!error_.empty()) {
+        lock.unlock();
+        terminate();
+    }
+}
+
+device_pool::~device_pool() {
+    terminate();
+    for (auto & t : threads_)
+        if (t.joinable()) t.join();
+}
+
+void device_pool::terminate() {
+    {
+        std::lock_guard<std::mutex> lock(q_mutex_);
+        running_ = false;
+    }
+    q_cv_.notify_all();
+    {
+        std::lock_guard<std::mutex> lock(r_mutex_);
+    }
+    r_cv_.notify_all();
+}
+
+int device_pool::submit(const std::string & model, const std::string & prompt, const generation_configuration & config) {
+    auto t = std::make_shared<pool_task>();
+    t->id = next_id_.fetch_add(1);
+    t->model = model;
+    t->prompt = prompt;
+    t->gen_config = config;
+    {
+        std::lock_guard<std::mutex> lock(q_mutex_);
+        if (!running_) return -1;
+        queue_.push_back(t);
+    }
+    q_cv_.notify_one();
+    return t->id;
+}
+
+std::shared_ptr<pool_task> device_pool::wait(int id, int timeout_ms) {
+    std::unique_lock<std::mutex> lock(r_mutex_);
+    auto ready = [&] { return completed_.count(id) != 0 || !running_; };
+    if (timeout_ms < 0) r_cv_.wait(lock, ready);
+    else if (!r_cv_.wait_for(lock, std::chrono::milliseconds(timeout_ms), ready)) return nullptr;
+    auto it = completed_.find(id);
+    return it == completed_.end() ? nullptr : it->second;
+}
+
+void device_pool::release(int id) {
+    std::lock_guard<std::mutex> lock(r_mutex_);
+    completed_.erase(id);
+}
+
+pool_stats device_pool::stats() const {
+    std::lock_guard<std::mutex> lock(s_mutex_);
+    return stats_;
+}
+
+// simple_task_queue::get_next (:132-145) widened to a batch: the oldest task plus every queued task compatible
+// with it (queue order preserved among the others), up to `cap`
+std::vector<std::shared_ptr<pool_task>> device_pool::next_batch(int cap) {
+    std::vector<std::shared_ptr<pool_task>> batch;
+    std::unique_lock<std::mutex> lock(q_mutex_);
+    q_cv_.wait(lock, [&] { return !queue_.empty() || !running_; });
+    if (!running_) return batch;
+    batch.push_back(queue_.front());
+    queue_.pop_front();
+    auto collect = [&] {
+        for (auto it = queue_.begin(); it != queue_.end() && (int) batch.size() < cap;) {
+            if ((*it)->model == batch[0]->model && pool_configs_compatible((*it)->gen_config, batch[0]->gen_config)) {
+                batch.push_back(*it);
+                it = queue_.erase(it);
+            } else ++it;
+        }
+    };
+    collect();
+    if (opts_.batch_window_ms > 0 && (int) batch.size() < cap) {
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(opts_.batch_window_ms);
+        while (running_ && (int) batch.size() < cap) {
+            if (q_cv_.wait_until(lock, deadline) == std::cv_status::timeout) { collect(); break; }
+            collect();
+        }
+    }
+    return batch;
+}
+
+void device_pool::worker_main(int w) {
+    worker_state ws;
+    g_tts_throw_on_abort = true;  // a failed load must not abort() the whole server
+    {
+        // init_worker (:309-314).  The runner reads its device and KV-slot count from the environment at load time;
+        // loads are serialised so every worker sees its own values.
+        std::lock_guard<std::mutex> lock(load_mutex_);
+        const int dev = opts_.devices[(size_t) w % opts_.devices.size()];
+        setenv("TTS_HIP_DEVICE", std::to_string(dev).c_str(), 1);
+        setenv("TTS_HIP_MAX_SEQS", std::to_string(opts_.max_batch).c_str(), 1);
+        try {
+            for (const auto & [id, path] : model_paths_) ws.runners[id] = runner_from_file(path.c_str(), opts_.n_threads, load_config_, false);
+        } catch (const std::exception & e) {
+            if (error_.empty()) error_ = std::string("worker ") + std::to_string(w) + ": " + e.what();
+        }
+        loaded_++;
+    }
+    load_cv_.notify_all();
+    while (true) {
+        std::vector<std::shared_ptr<pool_task>> batch = next_batch(opts_.max_batch);
+        if (batch.empty()) break;
+        process(w, batch, ws);
+    }
+}
+
+void device_pool::process(int w, std::vector<std::shared_ptr<pool_task>> & batch, worker_state & ws) {
+    std::vector<std::shared_ptr<pool_task>> live;
+    uint64_t expired = 0;
+    for (auto & t : batch) {
+        t->worker = w;
+        if (t->timed_out(opts_.task_timeout_s)) {  // worker::process_task :247-249 drops it silently; here it is answered
+            t->message = "timed out in the queue";
+            expired++;
+        } else live.push_back(t);
+    }
+    if (!live.empty()) {
+        auto found = ws.runners.find(live[0]->model);
+        if (found == ws.runners.end() || !found->second) {
+            for (auto & t : live) t->message = "unknown model '" + t->model + "'";
+        } else {
+            tts_generation_runner & runner = *found->second;
+            const size_t cap = std::max<size_t>(1, std::min<size_t>(live.size(), runner.batch_capacity()));
+            for (size_t off = 0; off < live.size(); off += cap) {
+                const size_t n = std::min(cap, live.size() - off);
+                try {
+                    std::vector<std::string> prompts;
+                    for (size_t i = 0; i < n; i++) prompts.push_back(live[off + i]->prompt);
+                    std::vector<tts_response> out;
+                    if (n == 1) {
+                        out.resize(1);
+                        runner.generate(prompts[0].c_str(), out[0], live[off]->gen_config);
+                    } else {
+                        runner.generate_batch(prompts, out, live[off]->gen_config);
+                    }
+                    for (size_t i = 0; i < n; i++) {
+                        pool_task & t = *live[off + i];
+                        t.audio.assign(out[i].data, out[i].data + out[i].n_outputs);  // the runner reuses its buffer on the next call
+                        t.sample_rate = runner.sampling_rate;
+                        t.success = out[i].n_outputs != 0;                            // :258
+                        t.batch_size = (int) n;
+                    }
+                } catch (const std::exception & e) {
+                    for (size_t i = 0; i < n; i++) { live[off + i]->success = false; live[off + i]->message = e.what(); }
+                }
+            }
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lock(s_mutex_);
+        stats_.tasks += batch.size();
+        stats_.timed_out += expired;
+        if (!live.empty()) {
+            stats_.batches += 1;
+            stats_.largest_batch = std::max<uint64_t>(stats_.largest_batch, live.size());
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lock(r_mutex_);
+        for (auto & t : batch) completed_[t->id] = t;
+    }
+    r_cv_.notify_all();
+}

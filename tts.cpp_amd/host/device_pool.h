@@ -1,0 +1,110 @@
+// device_pool.h — the reference server's worker pool re-shaped for GPUs: one worker per device, dynamic
+// lock-step batching of the queued requests.
+//
+// Mirrors examples/server/server.cpp (/root/reference): simple_server_task :100-123, simple_task_queue :126-158,
+// simple_response_map :160-219, worker :225-307, init_worker :309-314, the pool start-up/terminate :316-330,885-895.
+// Same flow — callers push tasks on one queue, workers pull, finished tasks land in a response map keyed by task
+// id and a caller blocks on its id — with two changes that the hardware asks for:
+//   * a worker owns a DEVICE (worker w -> devices[w mod G]) instead of a set of CPU threads, and
+//   * a worker drains up to `max_batch` compatible tasks (same model, same generation_configuration) that are
+//     already queued — optionally waiting `batch_window_ms` for more — and decodes them in lock-step with
+//     tts_generation_runner::generate_batch (one pass over the weights per step for all of them).  The reference
+//     processes one task per worker at a time (:246-262).
+// No HTTP here: the transport (cpp-httplib in the reference) stays with the application.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+struct pool_task {  // simple_server_task (:100-123); the audio is copied out of the runner-owned buffer
+    int                      id = 0;
+    std::string              model;
+    std::string              prompt;
+    generation_configuration gen_config;
+    std::vector<float>       audio;
+    float                    sample_rate = 44100.0f;
+    bool                     success = false;
+    std::string              message;
+    std::chrono::steady_clock::time_point time = std::chrono::steady_clock::now();
+    int                      batch_size = 0;  // how many tasks were decoded together with this one
+    int                      worker = -1;
+    bool timed_out(int seconds) const {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - time).count() > seconds;
+    }
+};
+
+struct pool_options {
+    int              n_workers = 1;        // --n-parallelism (:885): here one per device/context
+    std::vector<int> devices;              // worker w runs on devices[w % size]; empty = {0}
+    int              max_batch = 1;        // lock-step utterances per worker (runners are loaded with this many KV slots)
+    int              batch_window_ms = 0;  // after the first task, wait this long for more before decoding
+    int              n_threads = 1;
+    int              task_timeout_s = 300; // :231, tasks older than this are answered with success == false
+};
+
+struct pool_stats {
+    uint64_t tasks = 0, batches = 0, largest_batch = 0, timed_out = 0;
+};
+
+// generation parameters that must agree for two tasks to share a lock-step batch
+bool pool_configs_compatible(const generation_configuration & a, const generation_configuration & b);
+
+class device_pool {
+  public:
+    // model_paths: id -> GGUF path (or "test:<arch>"), every worker loads every model (init_worker :309-314).
+    // Blocks until all workers have loaded (or one of them failed: then ok() is false and error() says why).
+    device_pool(const std::map<std::string, std::string> & model_paths, const generation_configuration & load_config,
+                const pool_options & opts);
+    ~device_pool();
+    device_pool(const device_pool &) = delete;
+    device_pool & operator=(const device_pool &) = delete;
+
+    bool                ok() const { return error_.empty(); }
+    const std::string & error() const { return error_; }
+
+    // enqueue one TTS request; returns its id (the reference uses rand(), :102; ids here are sequential)
+    int submit(const std::string & model, const std::string & prompt, const generation_configuration & config);
+    // block until task `id` is finished (simple_response_map::get :203-218); nullptr after terminate()/timeout
+    std::shared_ptr<pool_task> wait(int id, int timeout_ms = -1);
+    void       release(int id);  // drop a finished task from the response map (the reference's cleanup thread, :168-189)
+    void       terminate();      // :316-330
+    pool_stats stats() const;
+
+  private:
+    struct worker_state;
+    void worker_main(int w);
+    void process(int w, std::vector<std::shared_ptr<pool_task>> & batch, worker_state & ws);
+    std::vector<std::shared_ptr<pool_task>> next_batch(int cap);
+
+    std::map<std::string, std::string> model_paths_;
+    generation_configuration           load_config_;
+    pool_options                       opts_;
+    std::string                        error_;
+
+    std::mutex                              q_mutex_;
+    std::condition_variable                 q_cv_;
+    std::deque<std::shared_ptr<pool_task>>  queue_;
+    bool                                    running_ = true;
+
+    mutable std::mutex                          r_mutex_;
+    std::condition_variable                     r_cv_;
+    std::map<int, std::shared_ptr<pool_task>>   completed_;
+
+    std::mutex              load_mutex_;
+    std::condition_variable load_cv_;
+    int                     loaded_ = 0;
+
+    std::atomic<int>         next_id_{1};
+    mutable std::mutex       s_mutex_;
+    pool_stats               stats_;
+    std::vector<std::thread> threads_;
+};

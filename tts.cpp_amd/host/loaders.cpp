@@ -49,6 +49,19 @@ void tts_generation_runner::update_conditional_prompt(const char *, const char *
     TTS_ABORT("The architecture '%s' does not support update_conditional_prompt.\n", loader.get().arch);
 }
 
+void tts_generation_runner::generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs,
+                                           const generation_configuration & config) {
+    batch_store_.assign(sentences.size(), {});
+    outputs.assign(sentences.size(), tts_response{});
+    for (size_t i = 0; i < sentences.size(); i++) {
+        tts_response r;
+        generate(sentences[i].c_str(), r, config);
+        batch_store_[i].assign(r.data, r.data + r.n_outputs);
+        outputs[i].data = batch_store_[i].data();
+        outputs[i].n_outputs = r.n_outputs;
+    }
+}
+
 // ---- "test:dummy": weightless plumbing backend (src/models/dummy/model.cpp:6-19) ----------------------
 namespace {
 struct dummy_loader_t final : tts_model_loader {

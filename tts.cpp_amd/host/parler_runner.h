@@ -44,7 +44,8 @@ struct parler_runner final : tts_generation_runner {
     // outputs[i].data points into a runner-owned buffer valid until the next generate/generate_batch.
     // Needs max_seqs >= n (TTS_HIP_MAX_SEQS at load time).  Results equal n separate generate() calls.
     void generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs,
-                        const generation_configuration & config);
+                        const generation_configuration & config) override;
+    uint32_t batch_capacity() const override { return max_seqs; }
     uint32_t max_seqs = 1;
     std::vector<std::vector<uint32_t>> last_batch_tokens;  // per utterance, still delayed
 

@@ -59,8 +59,7 @@ int tts_c_generate(tts_c_runner * r, const char * text, const tts_c_config * cfg
 int tts_c_generate_batch(tts_c_runner * r, const char * const * texts, int n, const tts_c_config * cfg, const float ** data, size_t * n_outputs) {
     g_tts_throw_on_abort = true;
     try {
-        auto * p = dynamic_cast<parler_runner *>((tts_generation_runner *) r);
-        if (!p) { g_c_err = "generate_batch: not a parler runner"; return -1; }
+        auto * p = (tts_generation_runner *) r;
         std::vector<std::string> s(texts, texts + n);
         std::vector<tts_response> out;
         p->generate_batch(s, out, to_cfg(cfg));
@@ -150,3 +149,69 @@ int tts_c_gguf_tensor(const char * path, int index, char * name, int name_cap, i
 }
 
 }  // extern "C"
+
+// ---- device pool (host/device_pool.h) ------------------------------------------------------------------------
+#include "device_pool.h"
+
+struct tts_c_pool {
+    std::unique_ptr<device_pool> pool;
+    std::map<int, std::shared_ptr<pool_task>> held;  // tasks whose audio the caller still reads
+    std::mutex mutex;
+};
+
+tts_c_pool * tts_c_pool_create(const char * model_path, int n_workers, const int * devices, int n_devices, int max_batch,
+                               int batch_window_ms, const tts_c_config * load_cfg) {
+    try {
+        pool_options o;
+        o.n_workers = n_workers;
+        for (int i = 0; devices && i < n_devices; i++) o.devices.push_back(devices[i]);
+        o.max_batch = max_batch;
+        o.batch_window_ms = batch_window_ms;
+        auto p = std::make_unique<tts_c_pool>();
+        p->pool = std::make_unique<device_pool>(std::map<std::string, std::string>{{"default", model_path}}, to_cfg(load_cfg), o);
+        if (!p->pool->ok()) { g_c_err = p->pool->error(); return nullptr; }
+        return p.release();
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return nullptr;
+    }
+}
+
+int tts_c_pool_submit(tts_c_pool * p, const char * text, const tts_c_config * cfg) {
+    const int id = p->pool->submit("default", text, to_cfg(cfg));
+    if (id < 0) g_c_err = "pool is terminated";
+    return id;
+}
+
+int tts_c_pool_wait(tts_c_pool * p, int id, int timeout_ms, const float ** data, size_t * n_outputs, int * batch_size, int * worker) {
+    std::shared_ptr<pool_task> t = p->pool->wait(id, timeout_ms);
+    if (!t) { g_c_err = "task not finished (timeout or pool terminated)"; return -1; }
+    {
+        std::lock_guard<std::mutex> lock(p->mutex);
+        p->held[id] = t;
+    }
+    if (data) *data = t->audio.data();
+    if (n_outputs) *n_outputs = t->audio.size();
+    if (batch_size) *batch_size = t->batch_size;
+    if (worker) *worker = t->worker;
+    if (!t->success) { g_c_err = t->message.empty() ? "empty response" : t->message; return 1; }
+    return 0;
+}
+
+void tts_c_pool_release(tts_c_pool * p, int id) {
+    {
+        std::lock_guard<std::mutex> lock(p->mutex);
+        p->held.erase(id);
+    }
+    p->pool->release(id);
+}
+
+void tts_c_pool_stats(tts_c_pool * p, uint64_t * tasks, uint64_t * batches, uint64_t * largest_batch, uint64_t * timed_out) {
+    const pool_stats s = p->pool->stats();
+    if (tasks) *tasks = s.tasks;
+    if (batches) *batches = s.batches;
+    if (largest_batch) *largest_batch = s.largest_batch;
+    if (timed_out) *timed_out = s.timed_out;
+}
+
+void tts_c_pool_free(tts_c_pool * p) { delete p; }

@@ -22,7 +22,8 @@ class SamplerCfg(C.Structure):
 
 
 EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_generate_batch", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
-           "tts_c_last_error", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor"]
+           "tts_c_last_error", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor",
+           "tts_c_pool_create", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_free"]
 
 _lib = None
 
@@ -57,6 +58,16 @@ def load_lib():
                                            C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.tts_c_gguf_summary.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_int]
         L.tts_c_gguf_tensor.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+        L.tts_c_pool_create.restype = C.c_void_p
+        L.tts_c_pool_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(Config)]
+        L.tts_c_pool_submit.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Config)]
+        L.tts_c_pool_wait.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.tts_c_pool_release.argtypes = [C.c_void_p, C.c_int]
+        L.tts_c_pool_release.restype = None
+        L.tts_c_pool_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 4
+        L.tts_c_pool_stats.restype = None
+        L.tts_c_pool_free.argtypes = [C.c_void_p]
+        L.tts_c_pool_free.restype = None
         _lib = L
     return _lib
 
@@ -130,3 +141,50 @@ def tokenize(gguf_path, text):
     if n < 0:
         raise RunnerError(L.tts_c_last_error().decode())
     return out[:n].copy()
+
+
+class Pool:
+    """device_pool (host/device_pool.h): the reference server's worker pool with one worker per device and dynamic
+    lock-step batching.  submit() -> id; wait(id) -> (audio, batch_size, worker)."""
+
+    def __init__(self, path, n_workers=1, devices=None, max_batch=1, batch_window_ms=0, **cfg):
+        self.L = load_lib()
+        self.cfg = make_config(**cfg)
+        dev = (C.c_int * len(devices))(*devices) if devices else None
+        self.h = self.L.tts_c_pool_create(path.encode(), n_workers, dev, len(devices) if devices else 0, max_batch, batch_window_ms, C.byref(self.cfg))
+        if not self.h:
+            raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
+
+    def submit(self, text, **cfg):
+        c = make_config(**cfg) if cfg else self.cfg
+        i = self.L.tts_c_pool_submit(self.h, text.encode("utf-8"), C.byref(c))
+        if i < 0:
+            raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
+        return i
+
+    def wait(self, task_id, timeout_ms=-1):
+        data = C.POINTER(C.c_float)()
+        n, bs, wk = C.c_size_t(), C.c_int(), C.c_int()
+        rc = self.L.tts_c_pool_wait(self.h, task_id, timeout_ms, C.byref(data), C.byref(n), C.byref(bs), C.byref(wk))
+        if rc < 0:
+            raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
+        audio = np.ctypeslib.as_array(data, shape=(n.value,)).copy() if n.value else np.zeros(0, dtype=np.float32)
+        err = self.L.tts_c_last_error().decode("utf-8", "replace") if rc == 1 else ""
+        self.L.tts_c_pool_release(self.h, task_id)
+        return audio, bs.value, wk.value, err
+
+    def stats(self):
+        v = [C.c_uint64() for _ in range(4)]
+        self.L.tts_c_pool_stats(self.h, *[C.byref(x) for x in v])
+        return dict(zip(("tasks", "batches", "largest_batch", "timed_out"), [x.value for x in v]))
+
+    def close(self):
+        if self.h:
+            self.L.tts_c_pool_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
