@@ -22,6 +22,12 @@ __device__ __forceinline__ float snake_f(float x, float alpha, float ralpha) {
     const float s = sinf(x * alpha);
     return x + (s * s) * ralpha;
 }
+// snake with alpha from the LDS table (alpha, then 1/alpha, cin_pad entries each) or straight from memory; same arithmetic
+__device__ __forceinline__ float snake_ch(float x, int cig, int cin, int cin_pad, const float *als, const float *alpha, int tab) {
+    if (tab) return snake_f(x, als[cig], als[cin_pad + cig]);
+    const float al = cig < cin ? alpha[cig] : 1.0f;
+    return snake_f(x, al, 1.0f / al);
+}
 
 // ------------------------------------------------------------------------------------------------
 // quantizer: out[c][t] = sum_i ( b_i[c] + sum_d W_i[c][d] * codebook_i[code[t][i]][d] )
@@ -73,6 +79,7 @@ struct ConvArgs {
     int mult;
     const float *alpha_out;  // [cout] snake applied to the OUTPUT (the next layer's snake_1d, fused here), or NULL
     int x_f16;               // F16 conv kernel: inputs are rounded to fp16 on the way in (ggml's fp16 im2col)
+    int alpha_tab;           // MFMA kernels: 1 = alpha and 1/alpha of every input channel staged in LDS, 0 = read from memory
 };
 
 __device__ __forceinline__ int valid_len(const uint32_t *frames, int mult, int L) {
@@ -181,6 +188,7 @@ struct ConvTArgs {
     const uint32_t *frames;  // per-utterance frames (grid.z) or NULL; valid input length = frames[z] * mult
     int mult;
     int x_f16;               // F16 kernel: inputs rounded to fp16 (ggml_compute_forward_conv_transpose_1d_f16_f32)
+    int alpha_tab;           // as ConvArgs
 };
 
 #define CT_CI 8
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
     const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * LS : nullptr;
     const float4d *wg = (const float4d *) (a.w + (int64_t) blockIdx.y * n_chunks * WCH);
 
-    if (a.alpha) {
+    if (a.alpha && a.alpha_tab) {
         for (int i = tid; i < cin_pad; i += NT) {
             const float al = i < a.cin ? a.alpha[i] : 1.0f;
             als[i] = al;
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
                 if (a.alpha) {
                     const int cig = c * CI_T + (i4 * 4) / T_T;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = snake_f(v[e], als[cig], als[cin_pad + cig]);
+                    for (int e = 0; e < 4; e++) v[e] = snake_ch(v[e], cig, a.cin, cin_pad, als, a.alpha, a.alpha_tab);
                 }
                 *(float4d *) (xd + i4 * 4) = v;
             }
@@ -407,7 +415,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
                     float v = xreg[j];
                     if (a.alpha) {
                         const int cig = c * CI_T + i / xw;
-                        v = snake_f(v, als[cig], als[cin_pad + cig]);  // snake(0) == 0: zero padding is preserved
+                        v = snake_ch(v, cig, a.cin, cin_pad, als, a.alpha, a.alpha_tab);  // snake(0) == 0: zero padding is preserved
                     }
                     xd[i] = v;
                 }
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma_kernel(ConvTArgs a)
     float *yg = a.y + (int64_t) blockIdx.z * a.cout * LoS;
     const float4d *wg = (const float4d *) (a.w + (int64_t) blockIdx.y * n_chunks * WCH);
 
-    if (a.alpha) {
+    if (a.alpha && a.alpha_tab) {
         for (int i = tid; i < cin_pad; i += NT) {
             const float al = i < a.cin ? a.alpha[i] : 1.0f;
             als[i] = al;
@@ -546,7 +554,7 @@ __global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma_kernel(ConvTArgs a)
                 float v = xreg[j];
                 if (a.alpha) {
                     const int cig = c * CI_T + i / xw;
-                    v = snake_f(v, als[cig], als[cin_pad + cig]);
+                    v = snake_ch(v, cig, a.cin, cin_pad, als, a.alpha, a.alpha_tab);
                 }
                 xd[i] = v;
             }
@@ -700,7 +708,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma16_kernel(ConvArgs a)
     const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * LS : nullptr;
     const half8d *wg = (const half8d *) ((const _Float16 *) a.w + (int64_t) blockIdx.y * n_chunks * WCH);
 
-    if (a.alpha) {
+    if (a.alpha && a.alpha_tab) {
         for (int i = tid; i < cin_pad; i += NT) {
             const float al = i < a.cin ? a.alpha[i] : 1.0f;
             als[i] = al;
@@ -757,7 +765,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma16_kernel(ConvArgs a)
                     float v = xreg[j][e];
                     if (a.alpha) {
                         const int cig = c * CI_T + q * 8 + e;
-                        v = snake_f(v, als[cig], als[cin_pad + cig]);  // snake(0) == 0: zero padding is preserved
+                        v = snake_ch(v, cig, a.cin, cin_pad, als, a.alpha, a.alpha_tab);  // snake(0) == 0: zero padding is preserved
                     }
                     h[e] = (_Float16) v;                               // the fp16 im2col
                 }
@@ -846,7 +854,7 @@ __global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma16_kernel(ConvTArgs 
     float *yg = a.y + (int64_t) blockIdx.z * a.cout * LoS;
     const half8d *wg = (const half8d *) ((const _Float16 *) a.w + (int64_t) blockIdx.y * n_chunks * WCH);
 
-    if (a.alpha) {
+    if (a.alpha && a.alpha_tab) {
         for (int i = tid; i < cin_pad; i += NT) {
             const float al = i < a.cin ? a.alpha[i] : 1.0f;
             als[i] = al;
@@ -903,7 +911,7 @@ __global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma16_kernel(ConvTArgs 
                     float v = xreg[j][e];
                     if (a.alpha) {
                         const int cig = c * CI_T + q * 8 + e;
-                        v = snake_f(v, als[cig], als[cin_pad + cig]);
+                        v = snake_ch(v, cig, a.cin, cin_pad, als, a.alpha, a.alpha_tab);
                     }
                     h[e] = (_Float16) v;
                 }

@@ -654,7 +654,7 @@ __global__ void argmax_kernel(const float *logits, int V, uint32_t *tokens) {
 // repetition_penalty == 1: one workgroup per (row, head).  Everything whose result depends on the order of fp32
 // operations follows the reference's order: the softmax denominator and the inverse-CDF scan are sequential sums
 // over the candidates in candidate order (one thread), probabilities are exp(v/T - top)/total with the same
-// operation sequence; only the embarrassingly parallel parts (exp, rank counting) use the whole workgroup.
+// operation sequence; only the embarrassingly parallel parts (exp, the candidate sort) use the whole workgroup.
 // Candidate order = descending value; equal values are ordered by index (the reference's std::sort leaves the
 // order of equal keys unspecified).  The uniform draws come from the host (std::minstd_rand, sampler.cpp:47-48).
 // ------------------------------------------------------------------------------------------------
@@ -669,23 +669,39 @@ struct SampleArgs {
     uint32_t *out;             // [R][n_out]
 };
 
-// picks[rank] = index for every element whose rank (descending value, then ascending index) is < k
-__device__ __forceinline__ void smp_rank_select(const float *val, int V, int k, unsigned short *picks) {
-    for (int i = threadIdx.x; i < V; i += blockDim.x) {
-        const float vi = val[i];
-        int rank = 0;
-        for (int j = 0; j < V; j++) {
-            const float vj = val[j];
-            rank += (vj > vi || (vj == vi && j < i)) ? 1 : 0;
+// Candidate order = descending value, equal values by ascending index: a total order, so a bitonic sort of the
+// 64-bit keys (~monotone(value) << 32 | index) over the vocabulary padded to a power of two gives it directly.
+__device__ __forceinline__ unsigned long long smp_key(float v, int i) {
+    unsigned u = __float_as_uint(v == 0.0f ? 0.0f : v);  // -0 == +0
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // monotone: larger float -> larger unsigned
+    return ((unsigned long long) (~u) << 32) | (unsigned) i;  // ascending key == descending value, ascending index
+}
+
+// keys[0..P) sorted ascending (P = power of two >= V, padding keys = ~0); then picks[rank] = index for rank < k
+__device__ __forceinline__ void smp_rank_select(const float *val, int V, int k, unsigned short *picks, unsigned long long *keys) {
+    int P = 1;
+    while (P < V) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) keys[i] = i < V ? smp_key(val[i], i) : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+                const int lo = ((t / stride) * (stride << 1)) + (t % stride), hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
         }
-        if (rank < k) picks[rank] = (unsigned short) i;
     }
+    for (int j = threadIdx.x; j < k; j += blockDim.x) picks[j] = (unsigned short) (keys[j] & 0xFFFFu);
 }
 
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     __shared__ float val[SMP_VMAX];
     __shared__ float tmp[SMP_VMAX];
     __shared__ unsigned short picks[SMP_VMAX];
+    __shared__ unsigned long long keys[SMP_VMAX];
     __shared__ float bv[4];
     __shared__ uint32_t bi[4];
     __shared__ float s_top, s_total, s_mhp;
@@ -741,7 +757,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         __syncthreads();
     }
     if (use_topk) {  // on logits, or on probabilities when the softmax already ran
-        smp_rank_select(val, V, (int) a.top_k, picks);
+        smp_rank_select(val, V, (int) a.top_k, picks, keys);
         n = (int) a.top_k;
         nucleus = true;
         __syncthreads();
@@ -763,7 +779,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         __syncthreads();
     } else {
         if (!nucleus) {  // topp sorts the whole vocabulary by probability (sampler.cpp:119-131)
-            smp_rank_select(val, V, V, picks);
+            smp_rank_select(val, V, V, picks, keys);
             nucleus = true;
             __syncthreads();
         }

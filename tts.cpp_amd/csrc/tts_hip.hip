@@ -219,6 +219,8 @@ struct tts_hip_ctx {
     std::map<int, std::vector<float>> dac_dbg;
     std::map<size_t, float *> packed;  // arena offset of a conv weight -> its MFMA-tile-packed copy
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
+    int dac_lds_reserve_kb = 0; // LDS the codec kernels leave free per CU for another context's decoder workgroups
+    int gemm_ngs_max = 16;      // cap on parallel row-group wave sets per GEMM workgroup (LDS = 4 KB x waves x RB)
     bool dac_f16 = false;      // every codec conv kernel arrived as F16: fp16 im2col x fp16 kernel, fp32 accumulate (ggml)
     bool dac_packed = false;
 
@@ -275,6 +277,8 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (lf) c->ln_fuse_max = std::max(0, std::min(32, atoi(lf)));
     if (const char *e = getenv("TTS_HIP_LN_WAVES")) c->ln_waves = std::max(1, std::min(4, atoi(e)));
     if (const char *e = getenv("TTS_HIP_KSPLIT_BIG")) c->ksplit_big = std::max(1, std::min(8, atoi(e)));
+    if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
+    if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
     if (const char *e = getenv("TTS_HIP_Q_FUSE_MAX")) c->q_fuse_max = std::max(0, std::min(16, atoi(e)));
     return c;
 }
@@ -685,7 +689,7 @@ static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
     const int nw = (a.kchunk ? a.kchunk : a.K) / 256;
     // wave sets working on different row groups in parallel (up to 16 waves per workgroup)
     const int n_groups = (a.R + 16 * RB - 1) / (16 * RB);
-    const int ngs = PRO == PRO_LN ? 1 : std::max(1, std::min(n_groups, 16 / nw));
+    const int ngs = PRO == PRO_LN ? 1 : std::max(1, std::min(std::min(n_groups, 16 / nw), c->gemm_ngs_max));
     size_t lds = 0;
     if (PRO == PRO_LN) {
         lds = (size_t) RB * 16 * (a.K + (WT == 1 ? 8 : 4)) * (WT == 1 ? 2 : 4);
@@ -1098,7 +1102,9 @@ extern "C" int tts_hip_parler_set_text_encoding(tts_hip_ctx *c, const float *enc
     if ((int) n_tokens > c->ECAP || n_tokens == 0) return set_err("set_text_encoding: %u tokens outside 1..%d", n_tokens, c->ECAP);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(c->arena + c->text_enc, enc, (size_t) n_tokens * c->H * 4, hipMemcpyHostToDevice));
+    // (stream copies, not hipMemcpy: the legacy stream may not be used while another context captures a graph)
+    HIPCHK(hipMemcpyAsync(c->arena + c->text_enc, enc, (size_t) n_tokens * c->H * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     c->E = (int) n_tokens;  // n_encode_length = conditional_prompt->n_outputs (model.cpp:135)
     for (auto &g : c->graphs) (void) hipGraphExecDestroy(g.second);  // E is baked into captured launches
     c->graphs.clear();
@@ -1334,9 +1340,10 @@ static int generate_loop(tts_hip_ctx *c, int mode, uint32_t n, const uint32_t *s
         }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(tokens_out, c->d_tokens_out, (size_t) ran * n * c->NO * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(tokens_out, c->d_tokens_out, (size_t) ran * n * c->NO * 4, hipMemcpyDeviceToHost, c->stream));
     if (ran < n_steps) memset(tokens_out + (size_t) ran * n * c->NO, 0, (size_t) (n_steps - ran) * n * c->NO * 4);
-    if (steps_done) HIPCHK(hipMemcpy(steps_done, c->d_steps_done, (size_t) n * 4, hipMemcpyDeviceToHost));
+    if (steps_done) HIPCHK(hipMemcpyAsync(steps_done, c->d_steps_done, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -1362,7 +1369,8 @@ static int stage_uniforms(tts_hip_ctx *c, const float *uniforms, size_t count) {
         c->uniforms_cap = count;
         drop_gen_graphs(c);
     }
-    HIPCHK(hipMemcpy(c->d_uniforms, uniforms, count * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(c->d_uniforms, uniforms, count * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -1409,7 +1417,8 @@ static int dac_snapshot(tts_hip_ctx *c, int stage, const float *dev, size_t n) {
     HIPCHK(hipStreamSynchronize(c->stream));
     std::vector<float> &v = c->dac_dbg[stage];
     v.resize(n);
-    HIPCHK(hipMemcpy(v.data(), dev, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(v.data(), dev, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -1488,12 +1497,33 @@ static int ensure_packed(tts_hip_ctx *c) {
     return 0;
 }
 
+// LDS request of a codec kernel.  With `dac_lds_reserve` > 0 (contexts sharing a GPU) the codec leaves that much LDS
+// free on every CU so that another context's decoder workgroups (<= 32 KB) can be resident next to the codec's:
+// the alpha table is dropped when that is what it takes, and the request is padded so that one workgroup fewer fits
+// when the natural size would fill the CU.
+static size_t dac_lds_request(const tts_hip_ctx *c, size_t base, size_t table, int *use_table) {
+    const size_t CU = 160 * 1024, reserve = (size_t) c->dac_lds_reserve_kb * 1024;
+    *use_table = table ? 1 : 0;
+    size_t natural = base + table;
+    if (!reserve) return natural;
+    auto leaves = [&](size_t req) { const size_t n = CU / req; return CU - n * req; };
+    if (leaves(natural) >= reserve) return natural;
+    if (table && leaves(base) >= reserve) { *use_table = 0; return base; }
+    if (table) { *use_table = 0; natural = base; }
+    for (size_t n = CU / natural; n >= 1; n--) {       // pad so that exactly n fit and `reserve` stays free
+        const size_t req = std::max(natural, CU / (n + 1) + 16);
+        if (n * req + reserve <= CU && CU / req == n) return req;
+    }
+    return natural;
+}
+
 template <int KT, int MI, int NI, int WM, int WN, int CI_T>
-static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a, int nz) {
+static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a_in, int nz) {
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WCH = KT * CI_T * CO_T;
-    const int xw = T_T + (KT - 1) * a.dil;
-    const int cin_pad = (a.cin + CI_T - 1) / CI_T * CI_T;
-    const size_t lds = ((size_t) 2 * WCH + 2 * (size_t) ((CI_T * xw + 3) & ~3) + (a.alpha ? 2 * (size_t) cin_pad : 0)) * 4;
+    const int xw = T_T + (KT - 1) * a_in.dil;
+    const int cin_pad = (a_in.cin + CI_T - 1) / CI_T * CI_T;
+    ConvArgs a = a_in;
+    const size_t lds = dac_lds_request(c, ((size_t) 2 * WCH + 2 * (size_t) ((CI_T * xw + 3) & ~3)) * 4, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab);
     if (a.dil > 9) return set_err("conv1d_mfma: dilation %d > 9 unsupported", a.dil);
     static bool attr = false;
     if (!attr) {
@@ -1507,11 +1537,12 @@ static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a, int nz) {
 }
 
 template <int KT, int MI, int NI, int WM, int WN, int CI_T>
-static int launch_conv_mfma16(tts_hip_ctx *c, const ConvArgs &a, int nz) {
+static int launch_conv_mfma16(tts_hip_ctx *c, const ConvArgs &a_in, int nz) {
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WCH = KT * CI_T * CO_T, XS = CI_T + 8;
-    const int xw = T_T + (KT - 1) * a.dil;
-    const int cin_pad = (a.cin + CI_T - 1) / CI_T * CI_T;
-    const size_t lds = ((size_t) 2 * WCH + 2 * (size_t) xw * XS) * 2 + (a.alpha ? 2 * (size_t) cin_pad : 0) * 4;
+    const int xw = T_T + (KT - 1) * a_in.dil;
+    const int cin_pad = (a_in.cin + CI_T - 1) / CI_T * CI_T;
+    ConvArgs a = a_in;
+    const size_t lds = dac_lds_request(c, ((size_t) 2 * WCH + 2 * (size_t) xw * XS) * 2, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab);
     if (a.dil > 9) return set_err("conv1d_mfma16: dilation %d > 9 unsupported", a.dil);
     static bool attr = false;
     if (!attr) {
@@ -1525,10 +1556,11 @@ static int launch_conv_mfma16(tts_hip_ctx *c, const ConvArgs &a, int nz) {
 }
 
 template <int S, int MI, int WM, int WN, int CI_T>
-static int launch_convt_mfma16(tts_hip_ctx *c, const ConvTArgs &a, int nz) {
+static int launch_convt_mfma16(tts_hip_ctx *c, const ConvTArgs &a_in, int nz) {
     constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN, WCH = CI_T * 2 * S * CO_T, XS = CI_T + 8;
-    const int cin_pad = (a.cin + CI_T - 1) / CI_T * CI_T;
-    const size_t lds = ((size_t) 2 * WCH + 2 * (size_t) (TI_T + 1) * XS) * 2 + (a.alpha ? 2 * (size_t) cin_pad : 0) * 4;
+    const int cin_pad = (a_in.cin + CI_T - 1) / CI_T * CI_T;
+    ConvTArgs a = a_in;
+    const size_t lds = dac_lds_request(c, ((size_t) 2 * WCH + 2 * (size_t) (TI_T + 1) * XS) * 2, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab);
     static bool attr = false;
     if (!attr) {
         HIPCHK(hipFuncSetAttribute((const void *) convt1d_mfma16_kernel<S, MI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1596,10 +1628,11 @@ static int launch_conv(tts_hip_ctx *c, const DacBatch &bt, const float *x, int c
 }
 
 template <int S, int MI, int WM, int WN, int CI_T>
-static int launch_convt_mfma(tts_hip_ctx *c, const ConvTArgs &a, int nz) {
+static int launch_convt_mfma(tts_hip_ctx *c, const ConvTArgs &a_in, int nz) {
     constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN, WCH = CI_T * 2 * S * CO_T;
-    const int cin_pad = (a.cin + CI_T - 1) / CI_T * CI_T;
-    const size_t lds = ((size_t) 2 * WCH + 2 * (size_t) ((CI_T * (TI_T + 1) + 3) & ~3) + (a.alpha ? 2 * (size_t) cin_pad : 0)) * 4;
+    const int cin_pad = (a_in.cin + CI_T - 1) / CI_T * CI_T;
+    ConvTArgs a = a_in;
+    const size_t lds = dac_lds_request(c, ((size_t) 2 * WCH + 2 * (size_t) ((CI_T * (TI_T + 1) + 3) & ~3)) * 4, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab);
     static bool attr = false;
     if (!attr) {
         HIPCHK(hipFuncSetAttribute((const void *) convt1d_mfma_kernel<S, MI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
