@@ -123,6 +123,9 @@ struct GemmArgs {
     // `out` (slab_stride floats apart); the consumer (ln_rows_kernel) adds the slabs in a fixed order.
     int kchunk;
     int64_t slab_stride;
+    // rows split over workgroups too (blockIdx.z owns rows [z*rows_per_z, (z+1)*rows_per_z)); 0 = one workgroup
+    // walks all rows.  Many lock-step rows: more resident workgroups per CU hide the L2 latency of the activation loads.
+    int rows_per_z;
 };
 
 __device__ __forceinline__ void gemm_epilogue4(const GemmArgs &a, int EPI, int r, int n, float4v v) {
@@ -259,10 +262,12 @@ __global__ __launch_bounds__(PRO == PRO_LN ? 512 : 1024) void gemm16_kernel(Gemm
     // ---- 3-5. for every group of 16*RB rows: MFMA over this wave's 256-wide K slice, reduce the K slices
     //           across waves, epilogue.  The weight fragments stay in registers across row groups, so many
     //           lock-step utterances cost one pass over the weights.
-    const int n_groups = (a.R + 16 * RB - 1) / (16 * RB);
+    const int r_lo = a.rows_per_z ? (int) blockIdx.z * a.rows_per_z : 0;
+    const int r_hi = a.rows_per_z ? min(a.R, r_lo + a.rows_per_z) : a.R;
+    const int n_groups = (r_hi - r_lo + 16 * RB - 1) / (16 * RB);
     const int n_rounds = (n_groups + ngs - 1) / ngs;   // uniform trip count: every wave reaches every barrier
     for (int rd = 0; rd < n_rounds; rd++) {
-        const int rg = (rd * ngs + gs) * 16 * RB;      // may lie beyond R for the last round: nothing is stored then
+        const int rg = r_lo + (rd * ngs + gs) * 16 * RB;      // may lie beyond R for the last round: nothing is stored then
         float4v acc[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) acc[rb] = (float4v){0.f, 0.f, 0.f, 0.f};
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(PRO == PRO_LN ? 512 : 1024) void gemm16_kernel(Gemm
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) {
             const int r  = rg + rb * 16 + li;
-            const int rr = r < a.R ? r : a.R - 1;
+            const int rr = r < r_hi ? r : r_hi - 1;
             if (WT == 1) {
                 const int kb = kz + w * 256 + g * 8;
 #pragma unroll
@@ -326,13 +331,13 @@ __global__ __launch_bounds__(PRO == PRO_LN ? 512 : 1024) void gemm16_kernel(Gemm
                     t[e] = sum;
                 }
                 const int r = rg + rb * 16 + li;
-                if (r < a.R) gemm_epilogue4(a, EPI, r, n0 + g * 4, t);
+                if (r < r_hi) gemm_epilogue4(a, EPI, r, n0 + g * 4, t);
             }
         } else {
 #pragma unroll
             for (int rb = 0; rb < RB; rb++) {
                 const int r = rg + rb * 16 + li;
-                if (r < a.R) gemm_epilogue4(a, EPI, r, n0 + g * 4, acc[rb]);
+                if (r < r_hi) gemm_epilogue4(a, EPI, r, n0 + g * 4, acc[rb]);
             }
         }
     }

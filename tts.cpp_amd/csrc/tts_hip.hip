@@ -220,6 +220,7 @@ struct tts_hip_ctx {
     std::map<size_t, float *> packed;  // arena offset of a conv weight -> its MFMA-tile-packed copy
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
     int dac_lds_reserve_kb = 0; // LDS the codec kernels leave free per CU for another context's decoder workgroups
+    int gemm_rows_per_wg = 0;   // > 0: forwards with more rows split them over workgroups of this many rows (16/32/64)
     int gemm_ngs_max = 16;      // cap on parallel row-group wave sets per GEMM workgroup (LDS = 4 KB x waves x RB)
     bool dac_f16 = false;      // every codec conv kernel arrived as F16: fp16 im2col x fp16 kernel, fp32 accumulate (ggml)
     bool dac_packed = false;
@@ -278,6 +279,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_LN_WAVES")) c->ln_waves = std::max(1, std::min(4, atoi(e)));
     if (const char *e = getenv("TTS_HIP_KSPLIT_BIG")) c->ksplit_big = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
+    if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
     if (const char *e = getenv("TTS_HIP_Q_FUSE_MAX")) c->q_fuse_max = std::max(0, std::min(16, atoi(e)));
     return c;
@@ -688,7 +690,8 @@ static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
     const int ksplit = a.kchunk ? a.K / a.kchunk : 1;
     const int nw = (a.kchunk ? a.kchunk : a.K) / 256;
     // wave sets working on different row groups in parallel (up to 16 waves per workgroup)
-    const int n_groups = (a.R + 16 * RB - 1) / (16 * RB);
+    const int rows_wg = a.rows_per_z ? std::min(a.rows_per_z, a.R) : a.R;
+    const int n_groups = (rows_wg + 16 * RB - 1) / (16 * RB);
     const int ngs = PRO == PRO_LN ? 1 : std::max(1, std::min(std::min(n_groups, 16 / nw), c->gemm_ngs_max));
     size_t lds = 0;
     if (PRO == PRO_LN) {
@@ -704,13 +707,21 @@ static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
     if (lds > 160 * 1024) return set_err("gemm16: LDS request %zu exceeds 160 KiB", lds);
     if (PRO == PRO_LN && a.K > 2048) return set_err("gemm16: LayerNorm prologue supports hidden sizes up to 2048 (got %d)", a.K);
     if (PRO == PRO_LN && ngs * nw > 8) return set_err("gemm16: fused-LayerNorm launch wants %d waves (> 8)", ngs * nw);
-    hipLaunchKernelGGL((gemm16_kernel<WT, PRO, EPI, RB>), dim3(a.N / 16, ksplit), dim3(ngs * nw * 64), lds, c->stream, a);
+    const int nz = a.rows_per_z ? (a.R + a.rows_per_z - 1) / a.rows_per_z : 1;
+    hipLaunchKernelGGL((gemm16_kernel<WT, PRO, EPI, RB>), dim3(a.N / 16, ksplit, nz), dim3(ngs * nw * 64), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
 template <int WT, int PRO, int EPI>
-static int launch_gemm16_rb(tts_hip_ctx *c, const GemmArgs &a) {
+static int launch_gemm16_rb(tts_hip_ctx *c, const GemmArgs &a_in) {
+    GemmArgs a = a_in;
+    if (PRO != PRO_LN && c->gemm_rows_per_wg > 0 && a.R > c->gemm_rows_per_wg) {
+        a.rows_per_z = c->gemm_rows_per_wg;
+        if (a.rows_per_z <= 16) return launch_gemm16<WT, PRO, EPI, 1>(c, a);
+        if (a.rows_per_z <= 32) return launch_gemm16<WT, PRO, EPI, 2>(c, a);
+        return launch_gemm16<WT, PRO, EPI, 4>(c, a);
+    }
     if (a.R <= 16) return launch_gemm16<WT, PRO, EPI, 1>(c, a);
     if (a.R <= 32) return launch_gemm16<WT, PRO, EPI, 2>(c, a);
     if (PRO == PRO_LN && (WT == 0 || a.R > 64)) return set_err("gemm16: %d rows with a fused LayerNorm prologue do not fit LDS", a.R);
@@ -1423,9 +1434,17 @@ static int dac_snapshot(tts_hip_ctx *c, int stage, const float *dev, size_t n) {
 }
 
 // ---- MFMA tile selection (shared by the packer and the launchers) ---------------------------------
+// input channels per LDS chunk of the fp32 k=1 kernels: 16 keeps the footprint at 40-45 KB (3-4 workgroups per CU);
+// with 32 the 96- and 64-channel tiles needed 80-90 KB = ONE workgroup per CU, and a k=1 conv has only C/32 chunks to
+// pipeline over, so its residual loads and stores ran with nothing to overlap (0.88 TB/s)
+#define CI32_K1 16
+// k=7: 4 channels per chunk (40 KB, 4 workgroups per CU) measured 3.7 % faster than 8 (75 KB, 2 per CU)
+#ifndef CI32_K7
+#define CI32_K7 4
+#endif
 static int conv_tile(int cout, int K, int *CO_T, int *CI_T) {
     if (K != 7 && K != 1) return -1;
-    *CI_T = K == 7 ? 8 : 32;
+    *CI_T = K == 7 ? CI32_K7 : CI32_K1;
     if (cout % 128 == 0) { *CO_T = 128; return 0; }
     if (cout % 96 == 0 && cout % 64 != 0) { *CO_T = 96; return 1; }
     if (cout % 64 == 0) { *CO_T = 64; return 2; }
@@ -1610,12 +1629,12 @@ static int launch_conv(tts_hip_ctx *c, const DacBatch &bt, const float *x, int c
         else CHK((launch_conv_mfma16<1, 2, 2, 1, 4, CI16_K1>(c, a, bt.n)));
     } else if (cfg >= 0 && pk != c->packed.end()) {
         a.w = pk->second;
-        if (K == 7 && cfg == 0) CHK((launch_conv_mfma<7, 2, 2, 2, 2, 8>(c, a, bt.n)));
-        else if (K == 7 && cfg == 1) CHK((launch_conv_mfma<7, 3, 2, 1, 4, 8>(c, a, bt.n)));
-        else if (K == 7 && cfg == 2) CHK((launch_conv_mfma<7, 2, 2, 1, 4, 8>(c, a, bt.n)));
-        else if (K == 1 && cfg == 0) CHK((launch_conv_mfma<1, 2, 2, 2, 2, 32>(c, a, bt.n)));
-        else if (K == 1 && cfg == 1) CHK((launch_conv_mfma<1, 3, 2, 1, 4, 32>(c, a, bt.n)));
-        else CHK((launch_conv_mfma<1, 2, 2, 1, 4, 32>(c, a, bt.n)));
+        if (K == 7 && cfg == 0) CHK((launch_conv_mfma<7, 2, 2, 2, 2, CI32_K7>(c, a, bt.n)));
+        else if (K == 7 && cfg == 1) CHK((launch_conv_mfma<7, 3, 2, 1, 4, CI32_K7>(c, a, bt.n)));
+        else if (K == 7 && cfg == 2) CHK((launch_conv_mfma<7, 2, 2, 1, 4, CI32_K7>(c, a, bt.n)));
+        else if (K == 1 && cfg == 0) CHK((launch_conv_mfma<1, 2, 2, 2, 2, CI32_K1>(c, a, bt.n)));
+        else if (K == 1 && cfg == 1) CHK((launch_conv_mfma<1, 3, 2, 1, 4, CI32_K1>(c, a, bt.n)));
+        else CHK((launch_conv_mfma<1, 2, 2, 1, 4, CI32_K1>(c, a, bt.n)));
     } else {
         const dim3 grid((L + CV_T - 1) / CV_T, (cout + CV_CO - 1) / CV_CO, bt.n);
         const size_t lds = ((size_t) CV_CI * (CV_T + (K - 1) * dil) + (size_t) CV_CI * K * CV_CO) * 4;
