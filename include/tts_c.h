@@ -67,6 +67,11 @@ typedef struct tts_c_sampler_cfg {
 int tts_c_sampler_sample(const tts_c_sampler_cfg *cfg, const int32_t *last_ids, const uint32_t *counts, float *logits,
                          const float *uniforms, uint32_t *out);
 
+/* tts_generation_runner::update_conditional_prompt (common.h:91; parler/model.cpp:510-518): encode `prompt` with the
+ * T5 encoder GGUF at text_encoder_path and make it the voice prompt of every later generate().  which == 2 in
+ * tts_c_last_tokens returns the ids it was encoded from. */
+int tts_c_update_conditional_prompt(tts_c_runner *r, const char *text_encoder_path, const char *prompt);
+
 /* ---- device pool: the server's worker pool (examples/server/server.cpp:126-330,885-895) with one worker per device
  * and dynamic lock-step batching of the queued requests (tts.cpp_amd/host/device_pool.h).  No HTTP. -------------- */
 typedef struct tts_c_pool tts_c_pool;

@@ -169,6 +169,28 @@ int tts_hip_parler_generate_sampled(tts_hip_ctx *ctx, uint32_t n_seqs, const uin
 int tts_hip_sample_logits(tts_hip_ctx *ctx, uint32_t n_rows, const float *logits, const tts_hip_sampling *sampling,
                           const float *uniforms, uint32_t *tokens_out);
 
+/* ---- T5 voice-prompt encoder (src/models/parler/t5/model.cpp) ---------------------------------
+ * What parler_tts_runner::update_conditional_prompt runs (model.cpp:510-518): text_encoder_from_file ->
+ * t5_runner::generate -> prep_cross_key_values.  A T5 context is its own tts_hip_ctx: create, tts_hip_upload
+ * every "t5encoder.*" tensor of the encoder GGUF (names: t5/model.cpp:3-18), tts_hip_finalize(ctx, NULL),
+ * tts_hip_t5_encode, then hand the result to the decoder context with tts_hip_parler_set_text_encoding. */
+typedef struct tts_hip_t5_desc {
+    uint32_t struct_size;      /* sizeof(tts_hip_t5_desc) */
+    uint32_t hidden_size;      /* t5encoder.embedding_length      (t5/model.cpp:129-132) */
+    uint32_t n_layers;         /* t5encoder.block_count           (:124-127) */
+    uint32_t n_attn_heads;     /* t5encoder.attention.head_count  (:134-137); head size is 64 (t5/model.h:46) */
+    uint32_t max_ctx_length;   /* t5encoder.context_length        (:139-142) */
+    uint32_t n_buckets;        /* relative_attn_buckets, 32 (t5/model.h:48); 0 = 32 */
+    uint32_t output_size;      /* t5encoder.output_size (:160-163), 0 = take it from the tensors */
+    uint32_t gelu_mode;        /* as tts_hip_desc */
+    uint32_t flags;            /* TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q */
+} tts_hip_t5_desc;
+tts_hip_ctx *tts_hip_t5_create(int device, const tts_hip_t5_desc *desc);
+/* t5_runner::run (t5/model.cpp:321-357): ids [n_tokens] (the caller appends EOS, :361-362) ->
+ * out [n_tokens][output size] fp32 (final rms norm, then down_proj + bias when the GGUF has them) */
+int tts_hip_t5_encode(tts_hip_ctx *ctx, const uint32_t *ids, uint32_t n_tokens, float *out);
+int tts_hip_t5_output_size(tts_hip_ctx *ctx);   /* after tts_hip_finalize / tts_hip_arena_bytes; < 0 on error */
+
 /* ---- DAC codec --------------------------------------------------------------------------- */
 /* dac_runner::run (dac_model.cpp:172-212): codes [frames][n_output_heads] (frame-major),
  * pcm_out: frames * prod(strides) fp32 samples in host memory.  Blocks until done. */

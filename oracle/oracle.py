@@ -60,6 +60,16 @@ class DacModel(C.Structure):
                 ("final_alpha", fp), ("final_w", fp), ("final_b", fp), ("f16_conv", C.c_int32)]
 
 
+class T5Layer(C.Structure):
+    _fields_ = [("q", W), ("k", W), ("v", W), ("o", W), ("attn_norm", fp), ("wi_0", W), ("wi_1", W), ("wo", W), ("mlp_norm", fp)]
+
+
+class T5Model(C.Structure):
+    _fields_ = [("H", C.c_int32), ("L", C.c_int32), ("n_heads", C.c_int32), ("F", C.c_int32), ("n_buckets", C.c_int32),
+                ("out_size", C.c_int32), ("act_mode", C.c_int32), ("gelu_mode", C.c_int32), ("embd", W), ("rel_bias", fp),
+                ("out_norm", fp), ("down_proj", W), ("down_proj_bias", fp), ("layers", T5Layer * MAX_LAYERS)]
+
+
 class RefSamplerCfg(C.Structure):
     _fields_ = [("n_output_heads", C.c_uint32), ("vocab_size", C.c_uint32), ("top_k", C.c_uint32),
                 ("temperature", C.c_float), ("top_p", C.c_float), ("repetition_penalty", C.c_float), ("do_sample", C.c_int)]
@@ -304,6 +314,57 @@ class ParlerOracle:
                                        cfg.bos, cfg.eos, u32p(nxt))
             ids = nxt
         return np.stack(toks_all), np.stack(logits_all)
+
+
+class T5Oracle:
+    """Oracle twin of a tts_cpp_amd.synth.SynthT5 (src/models/parler/t5/model.cpp restated in tts_oracle.c)."""
+
+    def __init__(self, model, act_mode=1, gelu_mode=1):
+        self.L = lib()
+        self.L.orc_t5_encode.argtypes = [C.POINTER(T5Model), C.POINTER(C.c_uint32), C.c_int, fp]
+        self.L.orc_t5_encode.restype = None
+        self.L.orc_t5_bucket.argtypes = [C.c_int, C.c_int, C.c_int]
+        self.L.orc_t5_bucket.restype = C.c_uint32
+        cfg = model.cfg
+        self.cfg = cfg
+        self.keep = []
+        t = model.by_name
+
+        def w(name):
+            raw = np.frombuffer(bytes(t[name].raw()), dtype=np.uint8)
+            self.keep.append(raw)
+            return W(t[name].type, raw.ctypes.data_as(C.c_void_p).value)
+
+        def f(name):
+            a = np.ascontiguousarray(t[name].to_f32().reshape(-1))
+            self.keep.append(a)
+            return f32p(a)
+
+        m = T5Model()
+        m.H, m.L, m.n_heads, m.F, m.n_buckets, m.out_size = cfg.hidden, cfg.layers, cfg.heads, cfg.ffn, cfg.buckets, cfg.output_size
+        m.act_mode, m.gelu_mode = act_mode, gelu_mode
+        m.embd = w("t5encoder.token_embd")
+        m.rel_bias = f("t5encoder.enc.blk.0.attn_rel_b")
+        m.out_norm = f("t5encoder.enc.final_layer_norm")
+        if "t5encoder.down_proj" in t:
+            m.down_proj = w("t5encoder.down_proj")
+            m.down_proj_bias = f("t5encoder.down_proj_bias")
+        for l in range(cfg.layers):
+            p = f"t5encoder.enc.blk.{l}."
+            y = m.layers[l]
+            y.q, y.k, y.v, y.o = w(p + "attn_q"), w(p + "attn_k"), w(p + "attn_v"), w(p + "attn_o")
+            y.attn_norm, y.mlp_norm = f(p + "attn_norm"), f(p + "ffn_norm")
+            y.wi_0, y.wi_1, y.wo = w(p + "ffn_up"), w(p + "ffn_gate"), w(p + "ffn_down")
+        self.m = m
+
+    def encode(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out = np.empty((ids.size, self.cfg.output_size), dtype=np.float32)
+        self.L.orc_t5_encode(C.byref(self.m), u32p(ids), ids.size, f32p(out))
+        return out
+
+    def bucket(self, key, query):
+        return int(self.L.orc_t5_bucket(key, query, self.cfg.buckets))
 
 
 class DacOracle:

@@ -506,6 +506,92 @@ void orc_parler_next_ids(int n_out, int step, const uint32_t *last_outputs, cons
         next_ids[i] = step > i ? (eos_seen[i] ? eos : last_outputs[i]) : bos;
 }
 
+/* ======================================================================================
+ * T5 encoder (src/models/parler/t5/model.cpp).  rms norm eps 1e-6 (:181), no attention scale
+ * (soft_max_ext(kq, mask, 1.0f, 0) :258 with an all-zero mask :311), relative position bias added to
+ * kq before the softmax (:256), gated GELU MLP gelu(wi_0 x) * (wi_1 x) (:272-275).
+ * ==================================================================================== */
+uint32_t orc_t5_bucket(int i, int ii, int n_buckets_total) {
+    /* :303-316.  pos_bucket[i*n + ii] is added to kq[key = ii?]: the tensor is [ne0 = n, ne1 = n] with data index
+     * i*n + ii, and build_t5_pos_bias permutes it so that (i, ii) lands on kq's (ne0 = key, ne1 = query) = (i, ii):
+     * i is the KEY position, ii the QUERY position, rpos = key - query (HF: memory - context). */
+    const int n_buckets = n_buckets_total / 2;
+    const int max_exact = n_buckets / 2;
+    const float logarithmic_denominator = (float) log(128.0 / max_exact);
+    const int ab_rpos = abs(i - ii);
+    const int rpos = i - ii;
+    int v;
+    if (ab_rpos < max_exact) v = ab_rpos;
+    else {
+        /* log((ab_rpos / max_exact)) with INTEGER division, as written (:314) */
+        const int big = max_exact + (int) ((log((double) (ab_rpos / max_exact)) / logarithmic_denominator) * max_exact);
+        v = big < n_buckets - 1 ? big : n_buckets - 1;
+    }
+    return (uint32_t) (rpos > 0 ? n_buckets : 0) + (uint32_t) v;
+}
+
+static void t5_rms_norm(const float *x, int H, const float *w, float *y) {
+    /* ggml_rms_norm(eps 1e-6) * weight (:179-185): mean of squares in double like ggml's ggml_float */
+    double sum = 0.0;
+    for (int i = 0; i < H; i++) sum += (double) (x[i] * x[i]);
+    const float mean = (float) (sum / H);
+    const float scale = 1.0f / sqrtf(mean + 1e-6f);
+    for (int i = 0; i < H; i++) y[i] = x[i] * scale * w[i];
+}
+
+void orc_t5_encode(const orc_t5_model *m, const uint32_t *ids, int n, float *out) {
+    const int H = m->H, F = m->F, NH = m->n_heads, D = H / NH;
+    float *x = (float *) malloc((size_t) n * H * 4), *cur = (float *) malloc((size_t) n * H * 4);
+    float *q = (float *) malloc((size_t) n * H * 4), *k = (float *) malloc((size_t) n * H * 4), *v = (float *) malloc((size_t) n * H * 4);
+    float *att = (float *) malloc((size_t) n * H * 4), *tmp = (float *) malloc((size_t) n * H * 4);
+    float *up = (float *) malloc((size_t) n * F * 4), *gate = (float *) malloc((size_t) n * F * 4);
+    float *sc = (float *) malloc((size_t) n * 4);
+    for (int t = 0; t < n; t++) get_row(&m->embd, ids[t], H, x + (size_t) t * H);
+    for (int l = 0; l < m->L; l++) {
+        const orc_t5_layer *ly = &m->layers[l];
+        for (int t = 0; t < n; t++) t5_rms_norm(x + (size_t) t * H, H, ly->attn_norm, cur + (size_t) t * H);
+        orc_mul_mat(ly->q.type, ly->q.data, H, H, cur, n, q, m->act_mode);
+        orc_mul_mat(ly->k.type, ly->k.data, H, H, cur, n, k, m->act_mode);
+        orc_mul_mat(ly->v.type, ly->v.data, H, H, cur, n, v, m->act_mode);
+        for (int h = 0; h < NH; h++) {
+            for (int qi = 0; qi < n; qi++) {
+                const float *qv = q + (size_t) qi * H + h * D;
+                for (int ki = 0; ki < n; ki++) {
+                    const float *kv = k + (size_t) ki * H + h * D;
+                    double d = 0.0;
+                    for (int e = 0; e < D; e++) d += (double) qv[e] * (double) kv[e];
+                    sc[ki] = (float) d + m->rel_bias[(size_t) orc_t5_bucket(ki, qi, m->n_buckets) * NH + h];
+                }
+                softmax_scaled(sc, n, 1.0f);
+                float *o = att + (size_t) qi * H + h * D;
+                for (int e = 0; e < D; e++) {
+                    double a = 0.0;
+                    for (int ki = 0; ki < n; ki++) a += (double) sc[ki] * (double) v[(size_t) ki * H + h * D + e];
+                    o[e] = (float) a;
+                }
+            }
+        }
+        orc_mul_mat(ly->o.type, ly->o.data, H, H, att, n, tmp, m->act_mode);
+        for (size_t i = 0; i < (size_t) n * H; i++) x[i] = tmp[i] + x[i];          /* ggml_add(attn_out, residual) :267 */
+        for (int t = 0; t < n; t++) t5_rms_norm(x + (size_t) t * H, H, ly->mlp_norm, cur + (size_t) t * H);
+        orc_mul_mat(ly->wi_1.type, ly->wi_1.data, H, F, cur, n, gate, m->act_mode);
+        orc_mul_mat(ly->wi_0.type, ly->wi_0.data, H, F, cur, n, up, m->act_mode);
+        for (size_t i = 0; i < (size_t) n * F; i++) up[i] = orc_gelu(up[i], m->gelu_mode) * gate[i];  /* :274 */
+        orc_mul_mat(ly->wo.type, ly->wo.data, F, H, up, n, tmp, m->act_mode);
+        for (size_t i = 0; i < (size_t) n * H; i++) x[i] = tmp[i] + x[i];          /* :278 */
+    }
+    for (int t = 0; t < n; t++) t5_rms_norm(x + (size_t) t * H, H, m->out_norm, cur + (size_t) t * H);
+    if (m->down_proj.data) {
+        orc_mul_mat(m->down_proj.type, m->down_proj.data, H, m->out_size, cur, n, out, m->act_mode);
+        if (m->down_proj_bias)
+            for (int t = 0; t < n; t++)
+                for (int i = 0; i < m->out_size; i++) out[(size_t) t * m->out_size + i] += m->down_proj_bias[i];
+    } else {
+        memcpy(out, cur, (size_t) n * H * 4);
+    }
+    free(x); free(cur); free(q); free(k); free(v); free(att); free(tmp); free(up); free(gate); free(sc);
+}
+
 /* adjust_output_tokens (model.cpp:734-760).  Quirks kept: the bound check is
  * `next_index > size` (off by one: next_index == size reads one past the end in the reference;
  * here that element is treated as "out of range -> remove", the only defined behaviour). */

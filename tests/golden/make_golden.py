@@ -116,8 +116,60 @@ def torch_dac(model, codes, stages=False):
     return (x[0, 0], outs) if stages else x[0, 0]
 
 
+def t5_bucket(key, query, n_buckets_total=32):
+    """t5_runner::set_inputs (src/models/parler/t5/model.cpp:303-316), integer division inside the log included"""
+    import math
+    n_buckets = n_buckets_total // 2
+    max_exact = n_buckets // 2
+    den = float(np.float32(math.log(128.0 / max_exact)))  # `float logarithmic_denominator` (:309), used in double arithmetic
+    rpos, ab = key - query, abs(key - query)
+    if ab < max_exact:
+        v = ab
+    else:
+        v = min(n_buckets - 1, max_exact + int((math.log(ab // max_exact) / den) * max_exact))
+    return (n_buckets if rpos > 0 else 0) + v
+
+
+def torch_t5(model, ids):
+    """T5 encoder (t5/model.cpp:216-295) in float64 torch: rms norm eps 1e-6, unscaled attention + relative bias,
+    gated tanh-GELU MLP, final norm, optional down projection."""
+    c = model.cfg
+    n, H, NH = len(ids), c.hidden, c.heads
+    d = H // NH
+    x = T(model, "t5encoder.token_embd")[torch.from_numpy(np.asarray(ids, dtype=np.int64))]
+    relb = T(model, "t5encoder.enc.blk.0.attn_rel_b")  # [buckets][heads]
+    bucket = torch.tensor([[t5_bucket(k, q, c.buckets) for k in range(n)] for q in range(n)])  # [query][key]
+    bias = relb[bucket].permute(2, 0, 1)  # [heads][query][key]
+
+    def rms(v, w):
+        return v * torch.rsqrt((v * v).mean(-1, keepdim=True) + 1e-6) * w
+
+    for l in range(c.layers):
+        p = f"t5encoder.enc.blk.{l}."
+        cur = rms(x, T(model, p + "attn_norm"))
+        q = Fn.linear(cur, T(model, p + "attn_q")).view(n, NH, d).transpose(0, 1)
+        k = Fn.linear(cur, T(model, p + "attn_k")).view(n, NH, d).transpose(0, 1)
+        v = Fn.linear(cur, T(model, p + "attn_v")).view(n, NH, d).transpose(0, 1)
+        att = torch.softmax(q @ k.transpose(1, 2) + bias, dim=-1) @ v
+        x = x + Fn.linear(att.transpose(0, 1).reshape(n, H), T(model, p + "attn_o"))
+        cur = rms(x, T(model, p + "ffn_norm"))
+        up = Fn.gelu(Fn.linear(cur, T(model, p + "ffn_up")), approximate="tanh") * Fn.linear(cur, T(model, p + "ffn_gate"))
+        x = x + Fn.linear(up, T(model, p + "ffn_down"))
+    x = rms(x, T(model, "t5encoder.enc.final_layer_norm"))
+    if "t5encoder.down_proj" in model.by_name:
+        x = Fn.linear(x, T(model, "t5encoder.down_proj"), T(model, "t5encoder.down_proj_bias"))
+    return x
+
+
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    t5 = synth.build_t5(synth.t5_tiny())
+    t5p = synth.build_t5(synth.t5_tiny(output_size=192, seed=0x76))  # with the down projection
+    ids = np.random.default_rng(77).integers(3, 160, 40).astype(np.uint32)
+    with torch.no_grad():
+        np.savez_compressed(os.path.join(out_dir, "tiny_t5.npz"), ids=ids, out=torch_t5(t5, ids).numpy().astype(np.float32),
+                            out_proj=torch_t5(t5p, ids[:23]).numpy().astype(np.float32))
+    print("wrote tiny_t5.npz")
     cfg = synth.tiny(weight_type=gguf.F32)
     model = synth.build(cfg)
     rng = np.random.default_rng(1234)

@@ -159,6 +159,43 @@ def test_device_pool_batches_queued_requests_on_the_gpu(tmp_path):
     pool.close()
 
 
+def test_update_conditional_prompt_runs_the_t5_encoder(tmp_path):
+    """update_conditional_prompt (model.cpp:510-518): T5 GGUF -> encode the voice prompt with the runner's tokenizer ->
+    new cross K/V.  The greedy token stream afterwards equals the oracle pipeline fed with the oracle T5 encoding."""
+    cfg = synth.tiny(weight_type=gguf.F32)
+    model = synth.build(cfg)
+    path = model.write_gguf(str(tmp_path / "m.gguf"))
+    t5 = synth.build_t5(synth.t5_tiny(vocab=cfg.prompt_vocab, output_size=cfg.hidden))
+    t5_path = t5.write_gguf(str(tmp_path / "t5.gguf"))
+    r = runner.Runner(path, sample=0)
+    text = "hello there"
+    before = r.generate(text)
+    toks_before = r.last_tokens(1).copy()
+    r.update_conditional_prompt(t5_path, "a calm low voice speaking slowly")
+    after = r.generate(text)
+    toks_after = r.last_tokens(1).copy()
+    assert not np.array_equal(toks_before, toks_after) and after.size > 0 and before.size > 0
+    voice_ids = r.last_tokens(2)
+    tok = tokenizer_oracle.UnigramOracle(model.vocab, model.scores, 2, 1)
+    assert voice_ids.tolist() == tok.tokenize("a calm low voice speaking slowly") + [1]
+    enc = orc.T5Oracle(t5).encode(voice_ids)
+    o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+    o.set_text_encoding(enc)
+    prompt_ids = r.last_tokens(0)
+    ref_toks, ref_logits = o.generate_greedy(prompt_ids, 12)
+    got = toks_after.reshape(-1, cfg.n_out)[:12]
+    for s_ in range(12):
+        if not np.array_equal(got[s_], ref_toks[s_]):
+            srt = np.sort(ref_logits[s_], axis=-1)
+            assert (srt[..., -1] - srt[..., -2]).min() < 4e-4 * np.abs(ref_logits[s_]).max(), f"step {s_} diverged outside an oracle near-tie"
+            break
+    # a T5 whose output size is not the decoder's hidden size is refused
+    bad = synth.build_t5(synth.t5_tiny(vocab=cfg.prompt_vocab, output_size=192)).write_gguf(str(tmp_path / "bad.gguf"))
+    with pytest.raises(runner.RunnerError):
+        r.update_conditional_prompt(bad, "x")
+    r.close()
+
+
 def test_eos_stops_generation_and_empty_response(tmp_path):
     """every head emits EOS at the first audio step -> check_stopping ends the loop, every frame contains a
     special id and is dropped by adjust_output_tokens -> n_outputs == 0 (the reference's soft failure)"""

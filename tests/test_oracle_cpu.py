@@ -179,3 +179,29 @@ def test_generation_bookkeeping():
     frames = out[:n].reshape(-1, n_out)
     expect = [[toks[i + k, k] for k in range(n_out)] for i in range(steps - n_out + 1) if i != 1]
     assert frames.tolist() == [[int(v) for v in r] for r in expect]
+
+
+def test_t5_encoder_oracle_matches_torch_golden_and_bucket_quirk():
+    """orc_t5_encode (src/models/parler/t5/model.cpp:216-320 restated) against tests/golden/tiny_t5.npz (float64 torch:
+    rms norm, unscaled attention + relative bias, gated tanh-GELU, final norm, down projection), and the relative
+    position buckets against the formula as the reference writes it — integer division inside the log (:314)."""
+    import math
+    from tts_cpp_amd import synth as sy
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_t5.npz"))
+    o = orc.T5Oracle(sy.build_t5(sy.t5_tiny()), act_mode=0, gelu_mode=0)
+    assert np.abs(o.encode(g["ids"]) - g["out"]).max() < 2e-5
+    o2 = orc.T5Oracle(sy.build_t5(sy.t5_tiny(output_size=192, seed=0x76)), act_mode=0, gelu_mode=0)
+    assert np.abs(o2.encode(g["ids"][:23]) - g["out_proj"]).max() < 2e-5
+    den = float(np.float32(math.log(128.0 / 8)))
+    for key in range(0, 200, 7):
+        for query in (0, 3, 50, 199):
+            ab = abs(key - query)
+            v = ab if ab < 8 else min(15, 8 + int((math.log(ab // 8) / den) * 8))
+            assert o.bucket(key, query) == (16 if key > query else 0) + v
+    assert o.bucket(12, 0) == 16 + 8      # HF's float division would give 9: the reference's quirk is kept
+    # F16 / quantised weights run (ggml activation conversion) and stay close to the F32 model they were made from
+    ids = g["ids"][:11]
+    ref = orc.T5Oracle(sy.build_t5(sy.t5_tiny())).encode(ids)
+    for wt, tol in ((gguf.F16, 5e-3), (gguf.Q8_0, 3e-2)):
+        out = orc.T5Oracle(sy.build_t5(sy.t5_tiny(weight_type=wt))).encode(ids)
+        assert np.abs(out - ref).max() / np.abs(ref).max() < tol

@@ -21,6 +21,7 @@
 
 #include "dac_kernels.h"
 #include "parler_kernels.h"
+#include "t5_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -191,6 +192,18 @@ struct tts_hip_ctx {
     float *ad = nullptr;        // their block scales
     bool all_q8i = false;       // every decoder matrix is on the integer path (all GEMMs go through run_qgemm)
     int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
+    // ---- T5 voice-prompt encoder context (tts_hip_t5_create) ----
+    bool has_t5 = false;
+    tts_hip_t5_desc t5{};
+    struct T5Layer { size_t attn_norm = 0, mlp_norm = 0; W qkv, o, wi, wo; };
+    std::vector<T5Layer> t5_layers;
+    size_t t5_embd = 0, t5_relb = 0, t5_out_norm = 0, t5_down_b = 0;
+    W t5_down;
+    bool t5_has_down = false, t5_has_down_b = false;
+    int t5_vocab = 0, t5_out = 0;
+    int *t5_bucket = nullptr;          // bucket of (key - query) + (n_ctx - 1), host-computed with the reference's arithmetic
+    float *t5_x = nullptr, *t5_qkv = nullptr, *t5_att = nullptr, *t5_ug = nullptr, *t5_g = nullptr, *t5_y = nullptr;
+    uint32_t *t5_ids = nullptr;
     tts_hip_sampling smp{};     // parameters baked into the captured MODE_GEN_SAMPLE graphs
     float *d_uniforms = nullptr;  // [calls][R][n_out] host-drawn U[0,1) for sample_kernel
     size_t uniforms_cap = 0;
@@ -295,7 +308,8 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (auto &t : c->tensors) free_dev(t.second.tmp);
     if (!c->arena_external) free_dev(c->arena);
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
-    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
+    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms);
+    free_dev(c->t5_bucket); free_dev(c->t5_x); free_dev(c->t5_qkv); free_dev(c->t5_att); free_dev(c->t5_ug); free_dev(c->t5_g); free_dev(c->t5_y); free_dev(c->t5_ids); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
     free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
     free_dev(c->d_eos); free_dev(c->d_codes); free_dev(c->d_frames);
     for (int i = 0; i < 3; i++) free_dev(c->dbuf[i]);
@@ -325,7 +339,13 @@ static bool starts_with(const std::string &s, const char *pre) { return s.compar
 // Which uploaded tensors stay fp16 on the device: the big decoder matrices and embedding tables.
 // Norm vectors, positional table, text encoding and the whole DAC are kept fp32.
 // decoder matrices that are only ever used through mul_mat (not get_rows): eligible for the integer path
+static bool is_t5_matmul(const std::string &name) {
+    return starts_with(name, "t5encoder.") && (ends_with(name, ".attn_q") || ends_with(name, ".attn_k") || ends_with(name, ".attn_v") ||
+                                                ends_with(name, ".attn_o") || ends_with(name, ".ffn_up") || ends_with(name, ".ffn_gate") ||
+                                                ends_with(name, ".ffn_down") || name == "t5encoder.down_proj");
+}
 static bool is_matmul_weight(const std::string &name) {
+    if (is_t5_matmul(name)) return true;
     return starts_with(name, "decoder.") && (ends_with(name, "_proj.weight") || ends_with(name, "fc1.weight") ||
                                               ends_with(name, "fc2.weight") || ends_with(name, "weight.head"));
 }
@@ -357,6 +377,7 @@ static int expand_q_to_i8(int type, const void *src, int64_t n, int8_t *q, uint1
 }
 
 static bool keeps_f16(const std::string &name) {
+    if (is_t5_matmul(name)) return true;
     if (!starts_with(name, "decoder.")) return false;
     if (name.find("layer_norm") != std::string::npos) return false;
     if (name == "decoder.positional_embed" || name == "decoder.text_encoding") return false;
@@ -368,7 +389,9 @@ extern "C" int tts_hip_upload(tts_hip_ctx *c, const char *name_c, int type, int 
     if (c->finalized) return set_err("tts_hip_upload(%s): context already finalized", name_c);
     HIPCHK(hipSetDevice(c->device));
     std::string name(name_c);
-    if (!starts_with(name, "decoder.") && !starts_with(name, "audio_encoder.")) {
+    if (c->has_t5) {
+        if (!starts_with(name, "t5encoder.")) return 0;  // assign_to_t5_encoder ignores other top levels (t5/model.cpp:107-109)
+    } else if (!starts_with(name, "decoder.") && !starts_with(name, "audio_encoder.")) {
         fprintf(stderr, "tts_hip: ignoring unhandled tensor '%s'\n", name_c);  // model.cpp:506
         return 0;
     }
@@ -384,6 +407,7 @@ extern "C" int tts_hip_upload(tts_hip_ctx *c, const char *name_c, int type, int 
     if (src_bytes == 0) return set_err("tts_hip_upload(%s): unsupported ggml type %d", name_c, type);
     const bool keep16 = (type == TTS_HIP_F16) && keeps_f16(name);
     const bool quant = type == TTS_HIP_Q4_0 || type == TTS_HIP_Q5_0 || type == TTS_HIP_Q8_0;
+    if (c->has_t5 && starts_with(name, "t5encoder.")) { /* falls through to the common storage rules */ }
     const bool q8i = quant && is_matmul_weight(name) && n_dims == 2 && (t.ne[0] % 256 == 0) && !(c->d.flags & TTS_HIP_FLAG_DEQUANT_Q) &&
                      !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM);
     t.type = q8i ? TTS_HIP_Q8I : (keep16 ? TTS_HIP_F16 : TTS_HIP_F32);
@@ -542,6 +566,39 @@ static int plan(tts_hip_ctx *c) {
             }
             c->cross_kv = P.alloc((size_t) c->L * 2 * c->ECAP * c->H * 4);
         }
+    }
+    if (c->has_t5) {
+        // t5_encoder (t5/model.h:39-60, tensor names t5/model.cpp:3-18, py-gguf t5_encoder_gguf_encoder.py:73-90)
+        c->H = (int) c->t5.hidden_size; c->L = (int) c->t5.n_layers; c->NH = (int) c->t5.n_attn_heads;
+        if (c->H <= 0 || c->L <= 0 || c->NH <= 0 || c->t5.max_ctx_length == 0) return set_err("plan: incomplete T5 hyper-parameters");
+        if (c->H / c->NH != 64 || c->H % c->NH) return set_err("plan: T5 head size %d unsupported (64, t5/model.h:46)", c->H / c->NH);
+        const Tensor *te = P.get("t5encoder.token_embd");
+        if (!te) return set_err("plan: t5encoder.token_embd missing");
+        c->t5_vocab = (int) (te->nelem() / te->ne[0]);
+        c->t5_embd = P.place_f32("t5encoder.token_embd");
+        c->t5_out_norm = P.place_f32("t5encoder.enc.final_layer_norm");
+        c->t5_relb = P.place_f32("t5encoder.enc.blk.0.attn_rel_b");
+        { const Tensor *rb = P.get("t5encoder.enc.blk.0.attn_rel_b");
+          if (rb && ((int) rb->ne[0] != c->NH || (uint32_t) (rb->nelem() / rb->ne[0]) != c->t5.n_buckets) && P.err.empty())
+              P.err = "t5 relative attention bias is not [n_buckets][n_heads]"; }
+        c->t5_has_down = c->tensors.count("t5encoder.down_proj") != 0;
+        c->t5_has_down_b = c->tensors.count("t5encoder.down_proj_bias") != 0;
+        if (c->t5_has_down) c->t5_down = P.mat("t5encoder.down_proj");
+        if (c->t5_has_down_b) c->t5_down_b = P.place_f32("t5encoder.down_proj_bias");
+        c->t5_out = c->t5_has_down ? (int) c->t5_down.N : c->H;
+        if (c->t5.output_size && (int) c->t5.output_size != c->t5_out && P.err.empty()) P.err = "t5encoder.output_size disagrees with the tensors";
+        c->t5_layers.assign(c->L, tts_hip_ctx::T5Layer{});
+        for (int l = 0; l < c->L; l++) {
+            const std::string p = "t5encoder.enc.blk." + std::to_string(l) + ".";
+            auto &y = c->t5_layers[l];
+            y.attn_norm = P.place_f32(p + "attn_norm");
+            y.qkv = P.fused({p + "attn_q", p + "attn_k", p + "attn_v"});
+            y.o = P.mat(p + "attn_o");
+            y.mlp_norm = P.place_f32(p + "ffn_norm");
+            y.wi = P.fused({p + "ffn_up", p + "ffn_gate"});   // wi_0 | wi_1
+            y.wo = P.mat(p + "ffn_down");
+        }
+        c->F = c->t5_layers.empty() ? 0 : (int) (c->t5_layers[0].wi.N / 2);
     }
     if (c->has_dac) {
         std::vector<std::string> cb, pw, pb;
@@ -1090,6 +1147,33 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         HIPCHK(hipHostMalloc((void **) &c->h_tok, (size_t) R * c->NO * 4));
         HIPCHK(hipHostMalloc((void **) &c->h_logits, (size_t) R * c->NO * c->V * 4));
     }
+    if (c->has_t5) {
+        const int H = c->H, F = c->F, S = (int) c->t5.max_ctx_length;
+        c->RMAX = 256;
+        CHK(dmalloc(&c->t5_x, (size_t) S * H));
+        CHK(dmalloc(&c->t5_qkv, (size_t) S * 3 * H));
+        CHK(dmalloc(&c->t5_att, (size_t) S * H));
+        CHK(dmalloc(&c->t5_ug, (size_t) S * 2 * F));
+        CHK(dmalloc(&c->t5_g, (size_t) S * F));
+        CHK(dmalloc(&c->t5_y, (size_t) S * std::max(H, c->t5_out)));
+        CHK(dmalloc(&c->dbg, (size_t) S * std::max(H, F)));
+        CHK(dmalloc(&c->aq, (size_t) c->RMAX * std::max(H, F)));
+        CHK(dmalloc(&c->ad, (size_t) c->RMAX * std::max(H, F) / 32 + 1));
+        CHK(dmalloc(&c->t5_ids, (size_t) S));
+        // relative position buckets, t5_runner::set_inputs (t5/model.cpp:303-316) — a function of key - query only;
+        // evaluated here with the reference's arithmetic (float denominator, integer division inside the log, double log)
+        std::vector<int> tab((size_t) 2 * S - 1);
+        const int n_buckets = (int) c->t5.n_buckets / 2, max_exact = n_buckets / 2;
+        const float logarithmic_denominator = (float) log(128.0 / max_exact);
+        for (int delta = -(S - 1); delta <= S - 1; delta++) {
+            const int ab_rpos = abs(delta);
+            int v = ab_rpos;
+            if (ab_rpos >= max_exact) v = std::min(n_buckets - 1, max_exact + (int) ((log((double) (ab_rpos / max_exact)) / logarithmic_denominator) * max_exact));
+            tab[(size_t) (delta + S - 1)] = (delta > 0 ? n_buckets : 0) + v;
+        }
+        HIPCHK(hipMalloc((void **) &c->t5_bucket, tab.size() * 4));
+        HIPCHK(hipMemcpy(c->t5_bucket, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    }
     if (c->has_dac) {
         // largest activation per frame over all stages (C * L / frames)
         size_t mx = (size_t) std::max(c->d_latent, c->d_c0), up = 1;
@@ -1421,6 +1505,88 @@ extern "C" int tts_hip_sample_logits(tts_hip_ctx *c, uint32_t n_rows, const floa
 
 
 // ------------------------------------------------------------------------------------------------
+// T5 voice-prompt encoder (src/models/parler/t5/model.cpp:216-357)
+// ------------------------------------------------------------------------------------------------
+extern "C" tts_hip_ctx *tts_hip_t5_create(int device, const tts_hip_t5_desc *td) {
+    if (!td || td->struct_size != sizeof(tts_hip_t5_desc)) { set_err("tts_hip_t5_create: bad desc (struct_size mismatch)"); return nullptr; }
+    tts_hip_desc d{};
+    d.struct_size = sizeof(d);
+    d.hidden_size = td->hidden_size; d.n_layers = td->n_layers; d.n_attn_heads = td->n_attn_heads; d.max_ctx_length = td->max_ctx_length;
+    d.max_seqs = 1; d.gelu_mode = td->gelu_mode;
+    d.flags = (td->flags & (TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q | TTS_HIP_FLAG_NO_GRAPH)) | TTS_HIP_FLAG_NO_PARLER | TTS_HIP_FLAG_NO_DAC;
+    tts_hip_ctx *c = tts_hip_create(device, &d);
+    if (!c) return nullptr;
+    c->has_t5 = true;
+    c->t5 = *td;
+    if (c->t5.n_buckets == 0) c->t5.n_buckets = 32;  // t5/model.h:48
+    return c;
+}
+
+static int t5_gemm(tts_hip_ctx *c, const W &w, const float *A, int lda, float *out, int ldo, int n, int epi) {
+    for (int r0 = 0; r0 < n; r0 += c->RMAX) {  // the activation-quantisation scratch holds RMAX rows
+        GemmArgs g{};
+        g.R = std::min(c->RMAX, n - r0); g.H = c->H; g.gelu_mode = (int) c->d.gelu_mode;
+        g.A = A + (size_t) r0 * lda; g.lda = lda;
+        g.out = out + (size_t) r0 * ldo; g.ldo = ldo;
+        CHK(run_gemm(c, TTS_HIP_K_GEMM_OTHER, w, g, PRO_F32, epi));
+    }
+    return 0;
+}
+
+extern "C" int tts_hip_t5_encode(tts_hip_ctx *c, const uint32_t *ids, uint32_t n_tokens, float *out) {
+    if (!c || !c->has_t5) return set_err("tts_hip_t5_encode: not a T5 context (tts_hip_t5_create)");
+    if (!c->finalized || !c->weights_present) return set_err("tts_hip_t5_encode: context not finalized");
+    if (!ids || !out) return set_err("tts_hip_t5_encode: null argument");
+    if (n_tokens == 0 || n_tokens > c->t5.max_ctx_length) return set_err("tts_hip_t5_encode: %u tokens outside 1..%u (t5encoder.context_length)", n_tokens, c->t5.max_ctx_length);
+    for (uint32_t i = 0; i < n_tokens; i++)
+        if (ids[i] >= (uint32_t) c->t5_vocab) return set_err("tts_hip_t5_encode: token id %u >= vocabulary %d", ids[i], c->t5_vocab);
+    HIPCHK(hipSetDevice(c->device));
+    const int n = (int) n_tokens, H = c->H, F = c->F, S = (int) c->t5.max_ctx_length;
+    auto f32 = [&](size_t off) { return (const float *) (c->arena + off); };
+    HIPCHK(hipMemcpyAsync(c->t5_ids, ids, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(t5_embed_kernel, dim3(n), dim3(256), 0, c->stream, f32(c->t5_embd), (const uint32_t *) c->t5_ids, H, c->t5_x);
+    HIPCHK(hipGetLastError());
+    auto rms = [&](const float *x, size_t w_off, float *y) {
+        hipLaunchKernelGGL(t5_rms_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, c->stream, x, H, f32(w_off), y, n);
+        return hipGetLastError() == hipSuccess ? 0 : set_err("t5_rms_rows_kernel launch failed");
+    };
+    for (int l = 0; l < c->L; l++) {
+        const auto &y = c->t5_layers[l];
+        CHK(rms(c->t5_x, y.attn_norm, c->dbg));
+        CHK(t5_gemm(c, y.qkv, c->dbg, H, c->t5_qkv, 3 * H, n, EPI_STORE));
+        hipLaunchKernelGGL(t5_attn_kernel, dim3(c->NH, n), dim3(64), (size_t) (64 + n) * 4, c->stream, (const float *) c->t5_qkv, n, H, c->NH,
+                           (const int *) c->t5_bucket, S, f32(c->t5_relb), c->t5_att);
+        HIPCHK(hipGetLastError());
+        CHK(t5_gemm(c, y.o, c->t5_att, H, c->t5_x, H, n, EPI_RESID));          // ggml_add(attn_out, residual) :267
+        CHK(rms(c->t5_x, y.mlp_norm, c->dbg));
+        CHK(t5_gemm(c, y.wi, c->dbg, H, c->t5_ug, 2 * F, n, EPI_STORE));
+        hipLaunchKernelGGL(t5_gated_gelu_kernel, dim3((unsigned) (((size_t) n * F + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->t5_ug, F, n,
+                           (int) c->d.gelu_mode, c->t5_g);
+        HIPCHK(hipGetLastError());
+        CHK(t5_gemm(c, y.wo, c->t5_g, F, c->t5_x, H, n, EPI_RESID));           // :278
+    }
+    float *result = c->dbg;
+    CHK(rms(c->t5_x, c->t5_out_norm, c->dbg));
+    if (c->t5_has_down) {
+        CHK(t5_gemm(c, c->t5_down, c->dbg, H, c->t5_y, c->t5_out, n, EPI_STORE));
+        if (c->t5_has_down_b) {
+            hipLaunchKernelGGL(t5_add_bias_kernel, dim3((unsigned) (((size_t) n * c->t5_out + 255) / 256)), dim3(256), 0, c->stream, c->t5_y, f32(c->t5_down_b),
+                               c->t5_out, n);
+            HIPCHK(hipGetLastError());
+        }
+        result = c->t5_y;
+    }
+    HIPCHK(hipMemcpyAsync(out, result, (size_t) n * c->t5_out * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int tts_hip_t5_output_size(tts_hip_ctx *c) {
+    if (!c || !c->has_t5 || !c->planned) { set_err("tts_hip_t5_output_size: not a planned T5 context"); return -1; }
+    return c->t5_out;
+}
+
+// ------------------------------------------------------------------------------------------------
 // DAC
 // ------------------------------------------------------------------------------------------------
 static int dac_snapshot(tts_hip_ctx *c, int stage, const float *dev, size_t n) {
@@ -1439,6 +1605,9 @@ static int dac_snapshot(tts_hip_ctx *c, int stage, const float *dev, size_t n) {
 // pipeline over, so its residual loads and stores ran with nothing to overlap (0.88 TB/s)
 #define CI32_K1 16
 // k=7: 4 channels per chunk (40 KB, 4 workgroups per CU) measured 3.7 % faster than 8 (75 KB, 2 per CU)
+#ifndef CI32_T
+#define CI32_T 8
+#endif
 #ifndef CI32_K7
 #define CI32_K7 4
 #endif
@@ -1505,7 +1674,7 @@ static int ensure_packed(tts_hip_ctx *c) {
     }
     if (conv_tile(c->d_c0, 7, &CO_T, &CI_T) >= 0) CHK(pack_one(c, c->d_initw, c->d_c0, c->d_latent, 7, CO_T, CI_T, false));
     for (auto &b : c->dblocks) {
-        if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, 8, true));
+        if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, CI32_T, true));
         for (int r = 0; r < 3; r++) {
             if (conv_tile(b.cout, 7, &CO_T, &CI_T) >= 0) CHK(pack_one(c, b.res[r].in_w, b.cout, b.cout, 7, CO_T, CI_T, false));
             if (conv_tile(b.cout, 1, &CO_T, &CI_T) >= 0) CHK(pack_one(c, b.res[r].out_w, b.cout, b.cout, 1, CO_T, CI_T, false));
@@ -1680,10 +1849,10 @@ static int launch_convt(tts_hip_ctx *c, ConvTArgs ta, size_t w_off, int nz) {
     auto pk = c->packed.find(w_off);
     if (cfg >= 0 && pk != c->packed.end()) {
         ta.w = pk->second;
-        if (cfg == 0) return launch_convt_mfma<8, 1, 2, 2, 8>(c, ta, nz);
-        if (cfg == 1) return launch_convt_mfma<4, 2, 1, 4, 8>(c, ta, nz);
-        if (cfg == 2) return launch_convt_mfma<2, 3, 1, 4, 8>(c, ta, nz);
-        return launch_convt_mfma<2, 2, 1, 4, 8>(c, ta, nz);
+        if (cfg == 0) return launch_convt_mfma<8, 1, 2, 2, CI32_T>(c, ta, nz);
+        if (cfg == 1) return launch_convt_mfma<4, 2, 1, 4, CI32_T>(c, ta, nz);
+        if (cfg == 2) return launch_convt_mfma<2, 3, 1, 4, CI32_T>(c, ta, nz);
+        return launch_convt_mfma<2, 2, 1, 4, CI32_T>(c, ta, nz);
     }
     const dim3 grid((ta.Lout + CV_T - 1) / CV_T, (ta.cout + CV_CO - 1) / CV_CO, nz);
     const size_t lds = ((size_t) CT_CI * ((CV_T + s - 1) / s + 2) + (size_t) CT_CI * 2 * s * CV_CO) * 4;

@@ -36,6 +36,13 @@ class Desc(C.Structure):
     ]
 
 
+class T5Desc(C.Structure):
+    """tts_hip_t5_desc (include/tts_hip.h)"""
+    _fields_ = [("struct_size", C.c_uint32), ("hidden_size", C.c_uint32), ("n_layers", C.c_uint32), ("n_attn_heads", C.c_uint32),
+                ("max_ctx_length", C.c_uint32), ("n_buckets", C.c_uint32), ("output_size", C.c_uint32), ("gelu_mode", C.c_uint32),
+                ("flags", C.c_uint32)]
+
+
 class KStat(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("launches", C.c_uint64), ("bytes_total", C.c_double), ("flops_total", C.c_double)]
 
@@ -44,7 +51,8 @@ EXPORTS = [
     "tts_hip_device_count", "tts_hip_create", "tts_hip_destroy", "tts_hip_last_error", "tts_hip_version",
     "tts_hip_upload", "tts_hip_arena_bytes", "tts_hip_finalize", "tts_hip_arena_ptr", "tts_hip_arena_filled",
     "tts_hip_parler_set_text_encoding", "tts_hip_parler_reset", "tts_hip_parler_prefill", "tts_hip_parler_prefill_batch", "tts_hip_parler_step",
-    "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
+    "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits",
+    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
     "tts_hip_synchronize",
 ]
@@ -93,6 +101,10 @@ def load_lib():
     L.tts_hip_parler_generate_greedy.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
     L.tts_hip_parler_generate_sampled.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Sampling), f32p, u32p, u32p]
     L.tts_hip_sample_logits.argtypes = [vp, C.c_uint32, f32p, C.POINTER(Sampling), f32p, u32p]
+    L.tts_hip_t5_create.restype = vp
+    L.tts_hip_t5_create.argtypes = [C.c_int, C.POINTER(T5Desc)]
+    L.tts_hip_t5_encode.argtypes = [vp, u32p, C.c_uint32, f32p]
+    L.tts_hip_t5_output_size.argtypes = [vp]
     L.tts_hip_dac_decode.argtypes = [vp, u32p, C.c_uint32, f32p]
     L.tts_hip_dac_decode_batch.argtypes = [vp, u32p, u32p, C.c_uint32, f32p]
     L.tts_hip_debug_read.argtypes = [vp, C.c_char_p, f32p, C.c_size_t]
@@ -307,3 +319,49 @@ class HipEngine:
 
     def synchronize(self):
         self._chk(self.L.tts_hip_synchronize(self.ctx))
+
+
+class T5Engine:
+    """A T5 voice-prompt encoder context (tts_hip_t5_create): load a synth.SynthT5 / GGUF tensor list, encode ids."""
+
+    def __init__(self, cfg, device=0, gelu_mode=1, flags=0):
+        self.L = load_lib()
+        self.cfg = cfg
+        d = T5Desc()
+        d.struct_size = C.sizeof(T5Desc)
+        d.hidden_size, d.n_layers, d.n_attn_heads, d.max_ctx_length = cfg.hidden, cfg.layers, cfg.heads, cfg.ctx
+        d.n_buckets, d.output_size, d.gelu_mode, d.flags = cfg.buckets, cfg.output_size, gelu_mode, flags
+        self.ctx = self.L.tts_hip_t5_create(device, C.byref(d))
+        if not self.ctx:
+            raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
+
+    def load(self, model):
+        for t in model.tensors:
+            ne = (C.c_int64 * 4)(*(t.ne + [1] * (4 - len(t.ne))))
+            raw = np.frombuffer(bytes(t.raw()), dtype=np.uint8)
+            self._chk(self.L.tts_hip_upload(self.ctx, t.name.encode(), t.type, len(t.ne), ne, raw.ctypes.data_as(C.c_void_p)))
+        self._chk(self.L.tts_hip_finalize(self.ctx, None))
+
+    def encode(self, ids):
+        a, ap = _u32(ids)
+        n_out = self.L.tts_hip_t5_output_size(self.ctx)
+        if n_out < 0:
+            raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
+        out = np.empty((a.size, n_out), dtype=np.float32)
+        self._chk(self.L.tts_hip_t5_encode(self.ctx, ap, a.size, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def close(self):
+        if self.ctx:
+            self.L.tts_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -64,7 +64,7 @@ std::unique_ptr<tts_generation_runner> parler_model_loader::from_file(gguf_file 
 }
 
 parler_runner::parler_runner(const parler_hparams & hp_, unigram_tokenizer * tok, int device, bool cross)
-    : tts_generation_runner{parler_loader}, hp(hp_), tokenizer(tok), use_cross_attn(cross) {
+    : tts_generation_runner{parler_loader}, hp(hp_), tokenizer(tok), use_cross_attn(cross), device_id(device) {
     tts_hip_desc d{};
     d.struct_size = sizeof(d);
     d.hidden_size = hp.hidden_size; d.n_layers = hp.n_layers; d.n_attn_heads = hp.n_attn_heads;
@@ -102,11 +102,47 @@ void parler_runner::prepare_post_load() {
     pcm.reserve((size_t) hp.max_generation_size * hp.up_sampling_factor);
 }
 
-void parler_runner::update_conditional_prompt(const char *, const char *) {
-    // needs the T5 text encoder (model.cpp:510-518, t5/model.cpp) which is outside this round's scope
-    // (SURVEY.md §8f-4); the device side is ready: tts_hip_parler_set_text_encoding().
-    TTS_ABORT("update_conditional_prompt: the T5 voice-prompt encoder is not part of this build; "
-              "feed a precomputed encoding through tts_hip_parler_set_text_encoding().\n");
+// model.cpp:510-518: text_encoder_from_file (t5/model.cpp:365-402) with THIS runner's tokenizer, t5_runner::generate
+// (:359-364: tokenize + EOS, run), then prep_cross_key_values with the response.  The encoder lives in its own device
+// context for the duration of the call, as the reference builds and deletes a t5_runner per call.
+void parler_runner::update_conditional_prompt(const char * file_path, const char * prompt) {
+    std::string err;
+    std::shared_ptr<gguf_file> meta = gguf_file::open(file_path, err);
+    if (!meta) TTS_ABORT("text_encoder_from_file failed for file %s: %s\n", file_path, err.c_str());
+    // t5_encoder::prep_constants (t5/model.cpp:123-164); defaults t5/model.h:43-52
+    tts_hip_t5_desc td{};
+    td.struct_size = sizeof(td);
+    td.n_layers = 24; td.n_attn_heads = 32; td.hidden_size = 2048; td.max_ctx_length = 512; td.n_buckets = 32; td.output_size = 1536;
+    uint32_t eos = 1, vocab = 0;
+    meta->get_u32({"t5encoder.block_count"}, td.n_layers);
+    meta->get_u32({"t5encoder.embedding_length"}, td.hidden_size);
+    meta->get_u32({"t5encoder.attention.head_count"}, td.n_attn_heads);
+    meta->get_u32({"t5encoder.context_length"}, td.max_ctx_length);
+    meta->get_u32({"tokenizer.ggml.eos_token_id"}, eos);
+    if (!meta->get_u32({"t5encoder.vocab_size"}, vocab)) TTS_ABORT("key 't5encoder.vocab_size' must be specified in gguf file.\n");
+    meta->get_u32({"t5encoder.output_size"}, td.output_size);
+    td.gelu_mode = 1;
+    if (td.output_size != hp.hidden_size)
+        TTS_ABORT("update_conditional_prompt: the encoder's output size %u differs from the decoder's hidden size %u\n", td.output_size, hp.hidden_size);
+
+    tts_hip_ctx * t5 = tts_hip_t5_create(device_id, &td);
+    if (!t5) TTS_ABORT("tts_hip_t5_create failed: %s\n", tts_hip_last_error());
+    struct guard { tts_hip_ctx * c; ~guard() { tts_hip_destroy(c); } } g{t5};
+    for (const gguf_tensor_view & t : meta->tensors) {
+        if (!t.data || !*t.name) continue;
+        hip_check(tts_hip_upload(t5, t.name, t.type, t.n_dims, t.ne, t.data), t.name);  // assign_to_t5_encoder keeps "t5encoder.*"
+    }
+    hip_check(tts_hip_finalize(t5, nullptr), "tts_hip_finalize(t5)");
+
+    std::vector<uint32_t> tokens;
+    tokenizer->tokenize(prompt, tokens);
+    tokens.push_back(eos);
+    if (tokens.size() > td.max_ctx_length || tokens.size() > 512)   // max_encode_length, model.h:69
+        TTS_ABORT("update_conditional_prompt: %zu prompt tokens exceed the encoder context %u\n", tokens.size(), td.max_ctx_length);
+    std::vector<float> enc(tokens.size() * (size_t) td.output_size);
+    hip_check(tts_hip_t5_encode(t5, tokens.data(), (uint32_t) tokens.size(), enc.data()), "tts_hip_t5_encode");
+    hip_check(tts_hip_parler_set_text_encoding(ctx, enc.data(), (uint32_t) tokens.size()), "tts_hip_parler_set_text_encoding");
+    last_conditional_tokens = tokens;
 }
 
 // model.cpp:734-760, including the `next_index > size` bound (an index == size would read one past the

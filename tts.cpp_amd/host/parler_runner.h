@@ -59,6 +59,8 @@ struct parler_runner final : tts_generation_runner {
     sampler                            smp;
     tts_hip_ctx *                      ctx = nullptr;
     bool                               use_cross_attn;
+    int                                device_id = 0;
+    std::vector<uint32_t>              last_conditional_tokens;  // ids the voice prompt was encoded from (tests)
     std::vector<float>                 pcm;     // runner-owned output buffer (dctx->buf_output)
     std::vector<float>                 logits;
 };

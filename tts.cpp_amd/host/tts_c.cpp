@@ -71,6 +71,17 @@ int tts_c_generate_batch(tts_c_runner * r, const char * const * texts, int n, co
     }
 }
 
+int tts_c_update_conditional_prompt(tts_c_runner * r, const char * text_encoder_path, const char * prompt) {
+    g_tts_throw_on_abort = true;
+    try {
+        ((tts_generation_runner *) r)->update_conditional_prompt(text_encoder_path, prompt);
+        return 0;
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return -1;
+    }
+}
+
 float        tts_c_sampling_rate(tts_c_runner * r) { return ((tts_generation_runner *) r)->sampling_rate; }
 const char * tts_c_arch(tts_c_runner * r) { return ((tts_generation_runner *) r)->loader.get().arch; }
 void         tts_c_free(tts_c_runner * r) { delete (tts_generation_runner *) r; }
@@ -78,7 +89,7 @@ void         tts_c_free(tts_c_runner * r) { delete (tts_generation_runner *) r; 
 int tts_c_last_tokens(tts_c_runner * r, int which, uint32_t * out, int cap) {
     auto * p = dynamic_cast<parler_runner *>((tts_generation_runner *) r);
     if (!p) { g_c_err = "not a parler runner"; return -1; }
-    const std::vector<uint32_t> & v = which == 0 ? p->last_prompt_tokens : p->last_output_tokens;
+    const std::vector<uint32_t> & v = which == 0 ? p->last_prompt_tokens : (which == 2 ? p->last_conditional_tokens : p->last_output_tokens);
     const int n = (int) v.size();
     if (out) memcpy(out, v.data(), (size_t) (n < cap ? n : cap) * 4);
     return n;

@@ -22,7 +22,7 @@ class SamplerCfg(C.Structure):
 
 
 EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_generate_batch", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
-           "tts_c_last_error", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor",
+           "tts_c_last_error", "tts_c_update_conditional_prompt", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor",
            "tts_c_pool_create", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_free"]
 
 _lib = None
@@ -58,6 +58,7 @@ def load_lib():
                                            C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.tts_c_gguf_summary.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_int]
         L.tts_c_gguf_tensor.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+        L.tts_c_update_conditional_prompt.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         L.tts_c_pool_create.restype = C.c_void_p
         L.tts_c_pool_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(Config)]
         L.tts_c_pool_submit.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Config)]
@@ -115,6 +116,10 @@ class Runner:
         if self.L.tts_c_generate_batch(self.h, arr, n, C.byref(c), data, ns) != 0:
             raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
         return [np.ctypeslib.as_array(data[i], shape=(ns[i],)).copy() if ns[i] else np.zeros(0, dtype=np.float32) for i in range(n)]
+
+    def update_conditional_prompt(self, text_encoder_path, prompt):
+        if self.L.tts_c_update_conditional_prompt(self.h, text_encoder_path.encode(), prompt.encode("utf-8")) != 0:
+            raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
 
     def last_tokens(self, which):
         n = self.L.tts_c_last_tokens(self.h, which, None, 0)

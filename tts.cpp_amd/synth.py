@@ -323,3 +323,92 @@ class SynthModel:
 
 def build(cfg: Config, shapes_only=False) -> SynthModel:
     return SynthModel(cfg, shapes_only=shapes_only)
+
+
+# --------------------------------------------------------------------------------------------------
+# T5 voice-prompt encoder (the model update_conditional_prompt loads; src/models/parler/t5/model.cpp).
+# Tensor names / keys as py-gguf/tts_encoders/t5_encoder_gguf_encoder.py:73-90 writes them.
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class T5Config:
+    hidden: int = 256
+    layers: int = 2
+    heads: int = 4           # head size is 64 like flan-t5 (t5/model.h:46)
+    ffn: int = 512
+    vocab: int = 160         # == the decoder's prompt vocabulary: the Parler runner's tokenizer is reused (model.cpp:513)
+    ctx: int = 64            # t5encoder.context_length
+    buckets: int = 32        # relative_attn_buckets (t5/model.h:48)
+    output_size: int = 256   # == decoder hidden size; a down projection is stored when it differs from `hidden`
+    weight_type: int = gguf.F32
+    seed: int = 0x75
+
+
+def t5_tiny(**kw):
+    return T5Config(**kw)
+
+
+def t5_flan_large(**kw):
+    """the encoder of parler-tts-mini-v1 (google/flan-t5-large: 24 layers, d_model 1024, 16 heads, d_ff 2816)"""
+    base = dict(hidden=1024, layers=24, heads=16, ffn=2816, vocab=32128, ctx=512, output_size=1024)
+    base.update(kw)
+    return T5Config(**base)
+
+
+class SynthT5:
+    def __init__(self, cfg: T5Config):
+        self.cfg = cfg
+        rng = np.random.Generator(np.random.Philox(cfg.seed))
+        self.tensors = []
+        H, F = cfg.hidden, cfg.ffn
+
+        def normal(shape, std):
+            return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+        def add(name, arr, quantizable=True):
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            ttype = cfg.weight_type if quantizable else gguf.F32
+            ne = list(reversed(arr.shape))
+            if ttype in (gguf.Q4_0, gguf.Q5_0, gguf.Q8_0):
+                self.tensors.append(gguf.Tensor(name, ttype, ne, quantize(arr, ttype).tobytes()))
+            else:
+                self.tensors.append(gguf.Tensor.from_array(name, arr, ttype))
+
+        if cfg.output_size != H:
+            add("t5encoder.down_proj", normal((cfg.output_size, H), 1.0 / math.sqrt(H)))
+            add("t5encoder.down_proj_bias", normal((cfg.output_size,), 0.02), quantizable=False)
+        add("t5encoder.token_embd", normal((cfg.vocab, H), 1.0))
+        add("t5encoder.enc.final_layer_norm", 1.0 + normal((H,), 0.05), quantizable=False)
+        for i in range(cfg.layers):
+            p = f"t5encoder.enc.blk.{i}."
+            if i == 0:
+                add(p + "attn_rel_b", normal((cfg.buckets, cfg.heads), 0.5), quantizable=False)
+            for nm in ("attn_q", "attn_k", "attn_v", "attn_o"):
+                # T5 attention has no 1/sqrt(d) (t5/model.cpp:258: soft_max_ext scale 1.0): keep the logits tame
+                add(p + nm, normal((H, H), 0.3 / math.sqrt(H) if nm in ("attn_q", "attn_k") else 1.0 / math.sqrt(H)))
+            add(p + "attn_norm", 1.0 + normal((H,), 0.05), quantizable=False)
+            add(p + "ffn_up", normal((F, H), 1.0 / math.sqrt(H)))
+            add(p + "ffn_gate", normal((F, H), 1.0 / math.sqrt(H)))
+            add(p + "ffn_down", normal((H, F), 1.0 / math.sqrt(F)))
+            add(p + "ffn_norm", 1.0 + normal((H,), 0.05), quantizable=False)
+        U32, STR = gguf.T_U32, gguf.T_STR
+        self.kv = [
+            ("general.architecture", STR, "t5encoder"),
+            ("general.name", STR, "synthetic-t5-encoder"),
+            ("t5encoder.block_count", U32, cfg.layers),
+            ("t5encoder.embedding_length", U32, H),
+            ("t5encoder.attention.head_count", U32, cfg.heads),
+            ("t5encoder.context_length", U32, cfg.ctx),
+            ("t5encoder.vocab_size", U32, cfg.vocab),
+            ("t5encoder.output_size", U32, cfg.output_size),
+            ("tokenizer.ggml.bos_token_id", U32, 0),
+            ("tokenizer.ggml.eos_token_id", U32, 1),
+        ]
+        self.by_name = {t.name: t for t in self.tensors}
+
+    def write_gguf(self, path):
+        gguf.write(path, self.kv, self.tensors)
+        return path
+
+
+def build_t5(cfg: T5Config) -> SynthT5:
+    return SynthT5(cfg)
