@@ -151,13 +151,15 @@ int tts_hip_parler_generate_greedy(tts_hip_ctx *ctx, uint32_t n_seqs, const uint
                                    uint32_t *steps_done);
 
 /* sampler::sample on the device (src/sampler.cpp:3-69: softmax :82-116, topk :152-183, topp :118-150) for
- * repetition_penalty == 1 and output_vocab_size <= 2048.  top_k == 0 or >= vocab disables top-k, top_p >= 1
+ * output_vocab_size <= 2048.  repetition_penalty != 1 keeps sampler::last_token_ids / repetition_counts per
+ * (sequence, head) on the device (reset at the start of a generation, sampler.cpp:71-80).  top_k == 0 or >= vocab disables top-k, top_p >= 1
  * disables top-p; the order of the fp32 sums follows the reference (see sample_kernel).  The U[0,1) draws are the
  * caller's (the reference draws them from std::minstd_rand, sampler.cpp:47-48). */
 typedef struct tts_hip_sampling {
     uint32_t top_k;
     float    top_p;
     float    temperature;
+    float    repetition_penalty;   /* 1 = off */
 } tts_hip_sampling;
 /* tts_hip_parler_generate_greedy with sampler::sample instead of sampler::max.
  *   uniforms [n_steps][n_seqs][n_output_heads]: draw for head h of sequence s at its k-th sampler call */
@@ -165,9 +167,11 @@ int tts_hip_parler_generate_sampled(tts_hip_ctx *ctx, uint32_t n_seqs, const uin
                                     uint32_t n_steps, uint32_t bos, uint32_t eos, const tts_hip_sampling *sampling,
                                     const float *uniforms, uint32_t *tokens_out, uint32_t *steps_done);
 /* The device sampler alone on caller-supplied logits [n_rows][n_output_heads][output_vocab_size]
- * (uniforms [n_rows][n_output_heads]) -> tokens_out [n_rows][n_output_heads]; for parity tests. */
+ * (uniforms [n_rows][n_output_heads]) -> tokens_out [n_rows][n_output_heads]; for parity tests.
+ * last_ids / rep_counts [n_rows][n_output_heads]: the repetition state, read and updated in place (may be NULL when
+ * repetition_penalty == 1). */
 int tts_hip_sample_logits(tts_hip_ctx *ctx, uint32_t n_rows, const float *logits, const tts_hip_sampling *sampling,
-                          const float *uniforms, uint32_t *tokens_out);
+                          const float *uniforms, int32_t *last_ids, uint32_t *rep_counts, uint32_t *tokens_out);
 
 /* ---- T5 voice-prompt encoder (src/models/parler/t5/model.cpp) ---------------------------------
  * What parler_tts_runner::update_conditional_prompt runs (model.cpp:510-518): text_encoder_from_file ->

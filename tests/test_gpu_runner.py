@@ -90,7 +90,8 @@ def test_device_sampler_loop_equals_host_sampler_loop(tmp_path):
     text = "hello there"
     r = runner.Runner(path, sample=0)
     for kw in (dict(top_k=50, temperature=1.0, seed=1234), dict(top_k=0, top_p=0.85, temperature=1.2, seed=77),
-               dict(top_k=12, top_p=0.9, temperature=0.8, seed=5)):
+               dict(top_k=12, top_p=0.9, temperature=0.8, seed=5), dict(top_k=30, temperature=1.1, repetition_penalty=1.4, seed=9),
+               dict(top_k=0, top_p=0.9, repetition_penalty=1.2, seed=11)):
         dev = r.generate(text, sample=1, max_tokens=40, **kw)
         td = r.last_tokens(1).copy()
         os.environ["TTS_HOST_LOOP"] = "1"

@@ -70,6 +70,48 @@ def test_device_sampler_matches_reference_sampler(top_k, top_p, temp):
         assert len(np.unique(got)) > 50  # it does sample
 
 
+@pytest.mark.parametrize("top_k,top_p,temp,rep", [(50, 1.0, 1.0, 1.3), (0, 0.8, 1.3, 1.5), (20, 0.95, 0.9, 1.2), (0, 1.0, 1.0, 2.0)])
+def test_device_sampler_repetition_penalty_state(top_k, top_p, temp, rep):
+    """v /= pow(penalty, count) for the token sampled last (sampler.cpp:89-90,99-100,172-175), in max, softmax and the
+    top-k comparator, and the state update :57-63 — against the oracle sampler carrying the same state, 3 calls deep."""
+    eng, model = engine("small")
+    cfg = model.cfg
+    nh, v = cfg.n_out, cfg.out_vocab
+    rng = np.random.default_rng(int(rep * 100) + top_k)
+    rows = 8
+    last = rng.integers(-1, v, (rows, nh)).astype(np.int32)
+    counts = rng.integers(1, 6, (rows, nh)).astype(np.uint32)
+    samplers = []
+    for r in range(rows):
+        s = orc.Sampler()
+        orc.lib().orc_sampler_init(C.byref(s), nh, v)
+        s.top_k, s.temperature, s.top_p, s.repetition_penalty, s.do_sample = top_k, temp, top_p, rep, 1
+        orc.lib().orc_sampler_reset(C.byref(s))
+        for h in range(nh):
+            s.last_token_ids[h], s.repetition_counts[h] = int(last[r, h]), int(counts[r, h])
+        samplers.append(s)
+    for call in range(3):
+        lg = (rng.standard_normal((rows, nh, v)) * 3.0).astype(np.float32)
+        if call == 1:   # make the last token the arg-max so that its penalised value decides the maximum
+            for r in range(rows):
+                for h in range(nh):
+                    if last[r, h] >= 0:
+                        lg[r, h, last[r, h]] = 9.0
+        u = rng.random((rows, nh)).astype(np.float32)
+        got = eng.sample_logits(lg, u, top_k=top_k, top_p=top_p, temperature=temp, repetition_penalty=rep, last_ids=last, rep_counts=counts)
+        ref = np.zeros((rows, nh), dtype=np.uint32)
+        for r in range(rows):
+            l = np.ascontiguousarray(lg[r].copy())
+            orc.lib().orc_sampler_sample(C.byref(samplers[r]), orc.f32p(l), orc.f32p(np.ascontiguousarray(u[r])), orc.u32p(ref[r]))
+        assert (got != ref).sum() <= 1, (call, np.argwhere(got != ref))
+        if (got != ref).sum() == 0:
+            for r in range(rows):
+                assert [samplers[r].last_token_ids[h] for h in range(nh)] == last[r].tolist()
+                assert [samplers[r].repetition_counts[h] for h in range(nh)] == counts[r].tolist()
+        else:
+            pytest.skip("one draw on a CDF boundary: states legitimately diverge after it")
+
+
 def test_device_resident_sampled_generation_matches_host_driven_loop():
     """tts_hip_parler_generate_sampled (sampler + delay-pattern feed + EOS flags on the device, one graph per step)
     == tts_hip_parler_step + oracle sampler + the reference's feed rule on the host, same uniform draws."""

@@ -672,6 +672,12 @@ struct SampleArgs {
     const float *uniforms;     // [calls][R][n_out]
     const uint32_t *row_step;  // [R] 1-based index of the sampler call this step is (NULL: call 1)
     uint32_t *out;             // [R][n_out]
+    // repetition penalty (sampler.cpp:89-90,99-100,172-175,194-195: v /= pow(penalty, count) for the token sampled last,
+    // in double): pen_table[c] = pow(penalty, c) evaluated on the host, NULL when the penalty is 1
+    const double *pen_table;
+    int pen_len;
+    int32_t *last_ids;         // [R][n_out] sampler::last_token_ids (-1 after reset)
+    uint32_t *rep_counts;      // [R][n_out] sampler::repetition_counts
 };
 
 // Candidate order = descending value, equal values by ascending index: a total order, so a bitonic sort of the
@@ -717,11 +723,18 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     const bool use_topk = a.top_k > 0 && a.top_k < (uint32_t) V;
     const bool use_topp = a.top_p < 1.0f;
 
+    // the token sampled last enters every comparison and the softmax with its penalised value
+    const int last = a.pen_table ? a.last_ids[r * a.n_out + h] : -1;
+    float pen_v = 0.0f;
+    if (last >= 0 && last < V) {
+        const uint32_t cnt = a.rep_counts[r * a.n_out + h];
+        pen_v = (float) ((double) row[last] / a.pen_table[cnt < (uint32_t) a.pen_len ? cnt : (uint32_t) a.pen_len - 1]);
+    }
     // sampler::max (first maximum wins)
     float best = -INFINITY;
     uint32_t besti = 0;
     for (int i = tid; i < V; i += 256) {
-        const float v = row[i];
+        const float v = i == last ? pen_v : row[i];
         val[i] = v;
         if (v > best) { best = v; besti = (uint32_t) i; }
     }
@@ -813,6 +826,12 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             if (target <= cum || j + 1 >= n) { chosen = i; break; }
         }
         a.out[r * a.n_out + h] = (uint32_t) chosen;
+        if (a.pen_table) {  // sampler.cpp:57-63
+            uint32_t cnt = a.rep_counts[r * a.n_out + h];
+            if (last != chosen) cnt = 0;
+            a.last_ids[r * a.n_out + h] = chosen;
+            a.rep_counts[r * a.n_out + h] = cnt + 1;
+        }
     }
 }
 

@@ -206,6 +206,10 @@ struct tts_hip_ctx {
     uint32_t *t5_ids = nullptr;
     tts_hip_sampling smp{};     // parameters baked into the captured MODE_GEN_SAMPLE graphs
     float *d_uniforms = nullptr;  // [calls][R][n_out] host-drawn U[0,1) for sample_kernel
+    double *d_pen = nullptr;      // pow(repetition_penalty, count) table (host-evaluated)
+    int pen_len = 0;
+    int32_t *d_last = nullptr;    // [RMAX][n_out] sampler::last_token_ids
+    uint32_t *d_repc = nullptr;   // [RMAX][n_out] sampler::repetition_counts
     size_t uniforms_cap = 0;
     uint32_t g_bos = 0xFFFFFFFFu, g_eos = 0xFFFFFFFFu;  // ids baked into the captured feed kernel
     int pending_parts = 0;      // slabs waiting to be folded into x by the next LayerNorm launch
@@ -308,7 +312,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (auto &t : c->tensors) free_dev(t.second.tmp);
     if (!c->arena_external) free_dev(c->arena);
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
-    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms);
+    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms); free_dev(c->d_pen); free_dev(c->d_last); free_dev(c->d_repc);
     free_dev(c->t5_bucket); free_dev(c->t5_x); free_dev(c->t5_qkv); free_dev(c->t5_att); free_dev(c->t5_ug); free_dev(c->t5_g); free_dev(c->t5_y); free_dev(c->t5_ids); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
     free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
     free_dev(c->d_eos); free_dev(c->d_codes); free_dev(c->d_frames);
@@ -1141,6 +1145,8 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->d_step, (size_t) R));
         CHK(dmalloc(&c->d_steps_done, (size_t) R));
         CHK(dmalloc(&c->d_eos, (size_t) R * c->NO));
+        CHK(dmalloc(&c->d_last, (size_t) R * c->NO));
+        CHK(dmalloc(&c->d_repc, (size_t) R * c->NO));
         HIPCHK(hipHostMalloc((void **) &c->h_ids, (size_t) R * c->NO * 4));
         HIPCHK(hipHostMalloc((void **) &c->h_pos, (size_t) R * 4));
         HIPCHK(hipHostMalloc((void **) &c->h_seq, (size_t) R * 4));
@@ -1317,6 +1323,8 @@ static int enqueue_step_body(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint
             sa.logits = c->logits; sa.V = c->V; sa.n_out = c->NO; sa.R = R;
             sa.top_k = c->smp.top_k; sa.top_p = c->smp.top_p; sa.temperature = c->smp.temperature;
             sa.uniforms = c->d_uniforms; sa.row_step = c->d_step; sa.out = c->d_tok;
+            sa.pen_table = c->smp.repetition_penalty != 1.0f ? c->d_pen : nullptr; sa.pen_len = c->pen_len;
+            sa.last_ids = c->d_last; sa.rep_counts = c->d_repc;
             hipLaunchKernelGGL(sample_kernel, dim3(c->NO, R), dim3(256), 0, c->stream, sa);
         } else {
             hipLaunchKernelGGL(argmax_kernel, dim3(R * c->NO), dim3(256), 0, c->stream, (const float *) c->logits, c->V, c->d_tok);
@@ -1453,6 +1461,7 @@ static int check_sampling(const tts_hip_ctx *c, const tts_hip_sampling *sp, cons
     if (c->V > SMP_VMAX) return set_err("%s: output vocabulary %d > %d (sample on the host from tts_hip_parler_step)", what, c->V, SMP_VMAX);
     if (!(sp->temperature > 0.0f)) return set_err("%s: temperature must be > 0", what);
     if (!(sp->top_p > 0.0f)) return set_err("%s: top_p must be > 0", what);
+    if (!(sp->repetition_penalty > 0.0f)) return set_err("%s: repetition_penalty must be > 0 (1 = off)", what);
     return 0;
 }
 
@@ -1469,6 +1478,23 @@ static int stage_uniforms(tts_hip_ctx *c, const float *uniforms, size_t count) {
     return 0;
 }
 
+// pow(penalty, count) for count = 0..n: evaluated here with the host libm, the arithmetic sampler.cpp:90 performs
+static int stage_penalty(tts_hip_ctx *c, float penalty, int n) {
+    if (penalty == 1.0f) return 0;
+    if (n + 1 > c->pen_len) {
+        free_dev(c->d_pen);
+        c->d_pen = nullptr;
+        HIPCHK(hipMalloc((void **) &c->d_pen, (size_t) (n + 1) * 8));
+        c->pen_len = n + 1;
+        drop_gen_graphs(c);
+    }
+    std::vector<double> t((size_t) c->pen_len);
+    for (int i = 0; i < c->pen_len; i++) t[(size_t) i] = pow((double) penalty, (double) i);
+    HIPCHK(hipMemcpyAsync(c->d_pen, t.data(), t.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 extern "C" int tts_hip_parler_generate_sampled(tts_hip_ctx *c, uint32_t n, const uint32_t *start_pos, uint32_t n_steps,
                                                uint32_t bos, uint32_t eos, const tts_hip_sampling *sp, const float *uniforms,
                                                uint32_t *tokens_out, uint32_t *steps_done) {
@@ -1476,16 +1502,22 @@ extern "C" int tts_hip_parler_generate_sampled(tts_hip_ctx *c, uint32_t n, const
     CHK(check_sampling(c, sp, "tts_hip_parler_generate_sampled"));
     if (!uniforms) return set_err("tts_hip_parler_generate_sampled: null uniforms");
     if (n == 0 || (int) n > c->RMAX || n > c->d.max_seqs) return set_err("generate_sampled: n_seqs=%u out of range", n);
-    if (sp->top_k != c->smp.top_k || sp->top_p != c->smp.top_p || sp->temperature != c->smp.temperature) {
+    if (sp->top_k != c->smp.top_k || sp->top_p != c->smp.top_p || sp->temperature != c->smp.temperature ||
+        (sp->repetition_penalty != 1.0f) != (c->smp.repetition_penalty != 1.0f)) {
         drop_gen_graphs(c);  // parameters are baked into the captured sample_kernel launch
-        c->smp = *sp;
     }
+    c->smp = *sp;
     CHK(stage_uniforms(c, uniforms, (size_t) n_steps * n * c->NO));
+    CHK(stage_penalty(c, sp->repetition_penalty, (int) n_steps));
+    if (sp->repetition_penalty != 1.0f) {  // sampler::reset (sampler.cpp:71-80)
+        HIPCHK(hipMemsetAsync(c->d_last, 0xFF, (size_t) n * c->NO * 4, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_repc, 0, (size_t) n * c->NO * 4, c->stream));
+    }
     return generate_loop(c, MODE_GEN_SAMPLE, n, start_pos, n_steps, bos, eos, tokens_out, steps_done);
 }
 
 extern "C" int tts_hip_sample_logits(tts_hip_ctx *c, uint32_t n_rows, const float *logits, const tts_hip_sampling *sp,
-                                     const float *uniforms, uint32_t *tokens_out) {
+                                     const float *uniforms, int32_t *last_ids, uint32_t *rep_counts, uint32_t *tokens_out) {
     CHK(ready(c, "tts_hip_sample_logits"));
     CHK(check_sampling(c, sp, "tts_hip_sample_logits"));
     if (!logits || !uniforms || !tokens_out) return set_err("tts_hip_sample_logits: null argument");
@@ -1496,8 +1528,22 @@ extern "C" int tts_hip_sample_logits(tts_hip_ctx *c, uint32_t n_rows, const floa
     sa.logits = c->logits; sa.V = c->V; sa.n_out = c->NO; sa.R = (int) n_rows;
     sa.top_k = sp->top_k; sa.top_p = sp->top_p; sa.temperature = sp->temperature;
     sa.uniforms = c->d_uniforms; sa.row_step = nullptr; sa.out = c->d_tok;
+    const bool rep = sp->repetition_penalty != 1.0f;
+    if (rep) {
+        if (!last_ids || !rep_counts) return set_err("tts_hip_sample_logits: repetition penalty needs last_ids and rep_counts");
+        uint32_t mx = 0;
+        for (size_t i = 0; i < (size_t) n_rows * c->NO; i++) mx = std::max(mx, rep_counts[i]);
+        CHK(stage_penalty(c, sp->repetition_penalty, (int) std::min<uint32_t>(mx + 2, 1u << 20)));
+        HIPCHK(hipMemcpyAsync(c->d_last, last_ids, (size_t) n_rows * c->NO * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_repc, rep_counts, (size_t) n_rows * c->NO * 4, hipMemcpyHostToDevice, c->stream));
+        sa.pen_table = c->d_pen; sa.pen_len = c->pen_len; sa.last_ids = c->d_last; sa.rep_counts = c->d_repc;
+    }
     hipLaunchKernelGGL(sample_kernel, dim3(c->NO, n_rows), dim3(256), 0, c->stream, sa);
     HIPCHK(hipGetLastError());
+    if (rep) {
+        HIPCHK(hipMemcpyAsync(last_ids, c->d_last, (size_t) n_rows * c->NO * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(rep_counts, c->d_repc, (size_t) n_rows * c->NO * 4, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(hipMemcpyAsync(tokens_out, c->d_tok, (size_t) n_rows * c->NO * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;

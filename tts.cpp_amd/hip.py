@@ -59,7 +59,7 @@ EXPORTS = [
 
 class Sampling(C.Structure):
     """tts_hip_sampling (include/tts_hip.h)"""
-    _fields_ = [("top_k", C.c_uint32), ("top_p", C.c_float), ("temperature", C.c_float)]
+    _fields_ = [("top_k", C.c_uint32), ("top_p", C.c_float), ("temperature", C.c_float), ("repetition_penalty", C.c_float)]
 
 
 _lib = None
@@ -100,7 +100,7 @@ def load_lib():
     L.tts_hip_parler_step_greedy.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, u32p]
     L.tts_hip_parler_generate_greedy.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
     L.tts_hip_parler_generate_sampled.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Sampling), f32p, u32p, u32p]
-    L.tts_hip_sample_logits.argtypes = [vp, C.c_uint32, f32p, C.POINTER(Sampling), f32p, u32p]
+    L.tts_hip_sample_logits.argtypes = [vp, C.c_uint32, f32p, C.POINTER(Sampling), f32p, C.POINTER(C.c_int32), u32p, u32p]
     L.tts_hip_t5_create.restype = vp
     L.tts_hip_t5_create.argtypes = [C.c_int, C.POINTER(T5Desc)]
     L.tts_hip_t5_encode.argtypes = [vp, u32p, C.c_uint32, f32p]
@@ -250,27 +250,31 @@ class HipEngine:
             out.ctypes.data_as(C.POINTER(C.c_uint32)), done.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out, done
 
-    def generate_sampled(self, start_pos, n_steps, uniforms, top_k=50, top_p=1.0, temperature=1.0, bos=None, eos=None):
+    def generate_sampled(self, start_pos, n_steps, uniforms, top_k=50, top_p=1.0, temperature=1.0, bos=None, eos=None,
+                         repetition_penalty=1.0):
         """uniforms [n_steps][n][n_out] -> (tokens [n_steps][n][n_out], steps_done [n])"""
         b, bp = _u32(start_pos)
         n = len(b)
         u = np.ascontiguousarray(uniforms, dtype=np.float32).reshape(n_steps, n, self.cfg.n_out)
         out = np.empty((n_steps, n, self.cfg.n_out), dtype=np.uint32)
         done = np.zeros(n, dtype=np.uint32)
-        sp = Sampling(top_k, top_p, temperature)
+        sp = Sampling(top_k, top_p, temperature, repetition_penalty)
         self._chk(self.L.tts_hip_parler_generate_sampled(
             self.ctx, n, bp, n_steps, self.cfg.bos if bos is None else bos, self.cfg.eos if eos is None else eos, C.byref(sp),
             u.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_uint32)), done.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out, done
 
-    def sample_logits(self, logits, uniforms, top_k=50, top_p=1.0, temperature=1.0):
-        """the device sampler alone: logits [n][n_out][V], uniforms [n][n_out] -> ids [n][n_out]"""
+    def sample_logits(self, logits, uniforms, top_k=50, top_p=1.0, temperature=1.0, repetition_penalty=1.0, last_ids=None, rep_counts=None):
+        """the device sampler alone: logits [n][n_out][V], uniforms [n][n_out] -> ids [n][n_out];
+        last_ids (int32) / rep_counts (uint32) [n][n_out] are updated in place when repetition_penalty != 1"""
         lg = np.ascontiguousarray(logits, dtype=np.float32).reshape(-1, self.cfg.n_out, self.cfg.out_vocab)
         u = np.ascontiguousarray(uniforms, dtype=np.float32).reshape(lg.shape[0], self.cfg.n_out)
         out = np.empty((lg.shape[0], self.cfg.n_out), dtype=np.uint32)
-        sp = Sampling(top_k, top_p, temperature)
+        sp = Sampling(top_k, top_p, temperature, repetition_penalty)
+        lp = last_ids.ctypes.data_as(C.POINTER(C.c_int32)) if last_ids is not None else None
+        cp = rep_counts.ctypes.data_as(C.POINTER(C.c_uint32)) if rep_counts is not None else None
         self._chk(self.L.tts_hip_sample_logits(self.ctx, lg.shape[0], lg.ctypes.data_as(C.POINTER(C.c_float)), C.byref(sp),
-                                                u.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_uint32))))
+                                                u.ctypes.data_as(C.POINTER(C.c_float)), lp, cp, out.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out
 
     # ---- dac ----------------------------------------------------------------------------------

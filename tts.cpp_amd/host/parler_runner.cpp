@@ -193,8 +193,9 @@ void parler_runner::generate(const char * sentence, tts_response & output, const
     std::vector<uint32_t> & out_tokens = last_output_tokens;
     out_tokens.clear();
 
-    // the sampler runs on the device unless it needs the repetition-penalty state (or more than 2048 logits per head)
-    const bool device_loop = config.repetition_penalty == 1.0f && !getenv("TTS_HOST_LOOP") && (!config.sample || hp.output_vocab_size <= 2048);
+    // the sampler runs on the device (unless a head has more than 2048 logits).  Greedy never sees the repetition
+    // penalty: sampler::max only reads last_token_ids, which stay -1 after reset() (sampler.cpp:71-80,185-204)
+    const bool device_loop = !getenv("TTS_HOST_LOOP") && (!config.sample || hp.output_vocab_size <= 2048);
     if (device_loop) {
         // sampler::max / sampler::sample, the delay-pattern feed and the EOS flags run on the device; the host
         // synchronises in chunks only to learn whether check_stopping() would have fired.
@@ -205,7 +206,7 @@ void parler_runner::generate(const char * sentence, tts_response & output, const
             // the U[0,1) draws sample() would make, call by call (sampler.cpp:47-50), drawn ahead
             std::vector<float> u((size_t) max_steps * nh);
             for (uint32_t s = 0; s < max_steps; s++) smp.draw_uniforms(u.data() + (size_t) s * nh);
-            const tts_hip_sampling sp{smp.top_k, smp.top_p, smp.temperature};
+            const tts_hip_sampling sp{smp.top_k, smp.top_p, smp.temperature, smp.repetition_penalty};
             hip_check(tts_hip_parler_generate_sampled(ctx, 1, &start, max_steps, hp.bos_token_id, hp.eos_token_id, &sp, u.data(), toks.data(), &done),
                       "tts_hip_parler_generate_sampled");
         } else
@@ -272,7 +273,7 @@ void parler_runner::generate_batch(const std::vector<std::string> & sentences, s
     const uint32_t max_steps = hp.max_generation_size - longest;  // every sequence stays inside max_generation
     last_batch_tokens.assign(n, {});
 
-    if (config.repetition_penalty == 1.0f && !getenv("TTS_HOST_LOOP") && (!config.sample || hp.output_vocab_size <= 2048)) {
+    if (!getenv("TTS_HOST_LOOP") && (!config.sample || hp.output_vocab_size <= 2048)) {
         std::vector<uint32_t> toks((size_t) max_steps * n * nh), done(n);
         if (config.sample) {
             // one sampler state per utterance, seeded like the host loop below: uniforms [step][utterance][head]
@@ -282,7 +283,7 @@ void parler_runner::generate_batch(const std::vector<std::string> & sentences, s
                 si.seed = config.seed ? config.seed + i : 0; si.n_calls = 0;
                 for (uint32_t s = 0; s < max_steps; s++) si.draw_uniforms(u.data() + ((size_t) s * n + i) * nh);
             }
-            const tts_hip_sampling sp{(uint32_t) config.top_k, config.top_p, config.temperature};
+            const tts_hip_sampling sp{(uint32_t) config.top_k, config.top_p, config.temperature, config.repetition_penalty};
             hip_check(tts_hip_parler_generate_sampled(ctx, n, start.data(), max_steps, hp.bos_token_id, hp.eos_token_id, &sp, u.data(), toks.data(), done.data()),
                       "tts_hip_parler_generate_sampled");
         } else
