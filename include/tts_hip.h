@@ -195,6 +195,27 @@ tts_hip_ctx *tts_hip_t5_create(int device, const tts_hip_t5_desc *desc);
 int tts_hip_t5_encode(tts_hip_ctx *ctx, const uint32_t *ids, uint32_t n_tokens, float *out);
 int tts_hip_t5_output_size(tts_hip_ctx *ctx);   /* after tts_hip_finalize / tts_hip_arena_bytes; < 0 on error */
 
+/* ---- SNAC codec (src/decoder/snac_model.cpp; Orpheus' audio decoder) -------------------------------
+ * A SNAC context is its own tts_hip_ctx: create, tts_hip_upload every "snac.*" tensor (names:
+ * py-gguf/tts_encoders/orpheus_gguf_encoder.py:89-142), tts_hip_finalize(ctx, NULL), tts_hip_snac_decode. */
+typedef struct tts_hip_snac_desc {
+    uint32_t struct_size;
+    uint32_t n_blocks;                          /* snac_model::n_layers (4) */
+    uint32_t stride[TTS_HIP_MAX_DAC_BLOCKS];    /* snac.snac_layer_stride_i   (snac_model.cpp:26-48) */
+    uint32_t padding[TTS_HIP_MAX_DAC_BLOCKS];   /* snac.snac_layer_padding_i  */
+    uint32_t groups[TTS_HIP_MAX_DAC_BLOCKS];    /* snac.snac_layer_grouping_i: must equal the layer's channel count (depthwise, gnac.cpp:136-140) */
+    uint32_t n_codebooks;                       /* snac.audio_token_channels (3) */
+    uint32_t repeats[4];                        /* 4, 2, 1 (snac_model.h:17) */
+    uint32_t max_frames;                        /* snac.max_generation_size: finest-level tokens per call */
+    uint32_t flags;                             /* TTS_HIP_FLAG_VALU_GEMM */
+} tts_hip_snac_desc;
+tts_hip_ctx *tts_hip_snac_create(int device, const tts_hip_snac_desc *desc);
+/* snac_runner::run (snac_model.cpp:180-208).  codes: level-major ids as set_inputs lays them out (:161-178): T/repeats[0]
+ * of level 0, T/repeats[1] of level 1, ...; noise: per layer l, T * prod(stride_0..l) floats, concatenated (:131-137) —
+ * the reference draws them from an unseeded normal generator (:177), here they are the caller's; NULL = no noise;
+ * pcm_out: T * prod(strides) fp32 samples. */
+int tts_hip_snac_decode(tts_hip_ctx *ctx, const uint32_t *codes, uint32_t T, const float *noise, float *pcm_out);
+
 /* ---- DAC codec --------------------------------------------------------------------------- */
 /* dac_runner::run (dac_model.cpp:172-212): codes [frames][n_output_heads] (frame-major),
  * pcm_out: frames * prod(strides) fp32 samples in host memory.  Blocks until done. */

@@ -70,6 +70,22 @@ class T5Model(C.Structure):
                 ("out_norm", fp), ("down_proj", W), ("down_proj_bias", fp), ("layers", T5Layer * MAX_LAYERS)]
 
 
+class SnacRes(C.Structure):
+    _fields_ = [("in_alpha", fp), ("in_w", fp), ("in_b", fp), ("out_alpha", fp), ("out_w", fp), ("out_b", fp)]
+
+
+class SnacBlock(C.Structure):
+    _fields_ = [("stride", C.c_int32), ("padding", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("alpha", fp), ("w", fp), ("b", fp), ("noise_w", fp), ("res", SnacRes * 3)]
+
+
+class SnacModel(C.Structure):
+    _fields_ = [("n_codebooks", C.c_int32), ("codebook_dim", C.c_int32), ("codebook_size", C.c_int32), ("latent", C.c_int32),
+                ("repeats", C.c_int32 * 4), ("codebook", fp * 4), ("out_proj_w", fp * 4), ("out_proj_b", fp * 4),
+                ("in_w", fp), ("in_b", fp), ("c0", C.c_int32), ("up_w", fp), ("up_b", fp), ("n_blocks", C.c_int32),
+                ("blocks", SnacBlock * 8), ("final_alpha", fp), ("final_w", fp), ("final_b", fp)]
+
+
 class RefSamplerCfg(C.Structure):
     _fields_ = [("n_output_heads", C.c_uint32), ("vocab_size", C.c_uint32), ("top_k", C.c_uint32),
                 ("temperature", C.c_float), ("top_p", C.c_float), ("repetition_penalty", C.c_float), ("do_sample", C.c_int)]
@@ -429,3 +445,64 @@ class DacOracle:
         n = self.L.orc_dac_decode(C.byref(self.m), u32p(codes), frames, f32p(pcm), stage, f32p(st) if st is not None else None)
         assert n == pcm.size
         return (pcm, st) if stage >= 0 else pcm
+
+
+class SnacOracle:
+    """Oracle twin of a tts_cpp_amd.synth.SynthSnac (src/decoder/snac_model.cpp restated in tts_oracle.c)."""
+
+    def __init__(self, model):
+        self.L = lib()
+        self.L.orc_snac_decode.argtypes = [C.POINTER(SnacModel), C.POINTER(C.c_uint32), C.c_int, fp, fp]
+        self.L.orc_snac_decode.restype = C.c_int64
+        cfg = model.cfg
+        self.cfg = cfg
+        self.keep = []
+        t = model.by_name
+
+        def f(name):
+            a = np.ascontiguousarray(t["snac." + name].to_f32().reshape(-1))
+            self.keep.append(a)
+            return f32p(a)
+
+        m = SnacModel()
+        m.n_codebooks, m.codebook_dim, m.codebook_size, m.latent = len(cfg.repeats), cfg.cb_dim, cfg.cb_size, cfg.latent
+        for i, r in enumerate(cfg.repeats):
+            m.repeats[i] = r
+            p = f"quantizers.{i}."
+            m.codebook[i], m.out_proj_w[i], m.out_proj_b[i] = f(p + "codebook.weight"), f(p + "out_proj.weight"), f(p + "out_proj.bias")
+        m.in_w, m.in_b, m.c0, m.up_w, m.up_b = f("in.weight"), f("in.bias"), cfg.c0, f("up.weight"), f("up.bias")
+        m.n_blocks = len(cfg.strides)
+        c = cfg.c0
+        for bi, (s, pd) in enumerate(zip(cfg.strides, cfg.paddings)):
+            p = f"layers.{bi}."
+            b = m.blocks[bi]
+            b.stride, b.padding, b.cin, b.cout = s, pd, c, c // 2
+            b.alpha, b.w, b.b, b.noise_w = f(p + "alpha"), f(p + "weight"), f(p + "bias"), f(p + "noise_weight")
+            for r in range(3):
+                q = p + f"residual_unit.{r}.res."
+                rr = b.res[r]
+                rr.in_alpha, rr.in_w, rr.in_b = f(q + "initial.alpha"), f(q + "initial.weight"), f(q + "initial.bias")
+                rr.out_alpha, rr.out_w, rr.out_b = f(q + "final.alpha"), f(q + "final.weight"), f(q + "final.bias")
+            c //= 2
+        m.final_alpha, m.final_w, m.final_b = f("alpha_out"), f("final.weight"), f("final.bias")
+        self.m = m
+
+    def noise_len(self, T):
+        n, L = 0, T
+        for s in self.cfg.strides:
+            L *= s
+            n += L
+        return n
+
+    def decode(self, codes, T, noise=None):
+        """codes: level-major flat ids (T/4 + T/2 + T for repeats 4,2,1); noise: noise_len(T) floats or None"""
+        codes = np.ascontiguousarray(codes, dtype=np.uint32)
+        assert codes.size == sum(T // r for r in self.cfg.repeats)
+        pcm = np.empty(T * self.cfg.hop, dtype=np.float32)
+        nz = None
+        if noise is not None:
+            nz = np.ascontiguousarray(noise, dtype=np.float32)
+            assert nz.size == self.noise_len(T)
+        n = self.L.orc_snac_decode(C.byref(self.m), u32p(codes), T, f32p(nz) if nz is not None else None, f32p(pcm))
+        assert n == pcm.size
+        return pcm

@@ -896,3 +896,85 @@ int64_t orc_dac_decode(const orc_dac_model *m, const uint32_t *codes, int frames
     free(pcm); free(cur);
     return L;
 }
+
+
+/* ======================================================================================
+ * SNAC decoder (src/decoder/snac_model.cpp:86-159).
+ * ==================================================================================== */
+void orc_conv1d_dw(const float *x, int C, int64_t L, const float *w, const float *b, int K, int pad, int dil, float *y) {
+    /* ggml_conv_1d_dw(kernel [K,1,C], x, stride 1, pad, dil) + bias: y[c][t] = b[c] + sum_k w[c][k] x[c][t + k*dil - pad] */
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < C; c++) {
+        for (int64_t t = 0; t < L; t++) {
+            float acc = b ? b[c] : 0.0f;
+            for (int k = 0; k < K; k++) {
+                const int64_t ti = t + (int64_t) k * dil - pad;
+                if (ti >= 0 && ti < L) acc += w[(size_t) c * K + k] * x[(size_t) c * L + ti];
+            }
+            y[(size_t) c * L + t] = acc;
+        }
+    }
+}
+
+int64_t orc_snac_decode(const orc_snac_model *m, const uint32_t *codes, int T, const float *noise, float *pcm_out) {
+    int64_t L = T;
+    int C = m->latent;
+    float *cur = (float *) calloc((size_t) C * L, 4);
+    /* snac_build_audio_inputs (:86-108): per level quantize layer on T/repeat ids, repeat_interleave up to T, summed */
+    size_t off = 0;
+    for (int i = 0; i < m->n_codebooks; i++) {
+        const int rep = m->repeats[i], n = T / rep;
+        for (int c = 0; c < C; c++) {
+            for (int j = 0; j < n; j++) {
+                const float *cb = m->codebook[i] + (size_t) codes[off + j] * m->codebook_dim;
+                float acc = 0.0f;
+                for (int d = 0; d < m->codebook_dim; d++) acc += m->out_proj_w[i][(size_t) c * m->codebook_dim + d] * cb[d];
+                acc += m->out_proj_b[i][c];
+                for (int rr = 0; rr < rep; rr++) {
+                    float *dst = &cur[(size_t) c * L + (size_t) j * rep + rr];
+                    *dst = (i == 0) ? acc : (*dst + acc);
+                }
+            }
+        }
+        off += (size_t) n;
+    }
+    float *nxt = (float *) malloc((size_t) C * L * 4);
+    orc_conv1d_dw(cur, C, L, m->in_w, m->in_b, 7, 3, 1, nxt);                         /* :141-142 */
+    free(cur); cur = nxt;
+    nxt = (float *) malloc((size_t) m->c0 * L * 4);
+    orc_conv1d(cur, C, L, m->up_w, m->up_b, m->c0, 1, 0, 1, nxt);                     /* :143-144 */
+    free(cur); cur = nxt; C = m->c0;
+    size_t noise_off = 0;
+    for (int bi = 0; bi < m->n_blocks; bi++) {                                        /* build_layer, gnac.cpp:151-164 */
+        const orc_snac_block *b = &m->blocks[bi];
+        orc_snake(cur, C, L, b->alpha);
+        const int K = 2 * b->stride;
+        const int64_t L2 = (L - 1) * b->stride - 2 * (int64_t) b->padding + K;
+        nxt = (float *) malloc((size_t) b->cout * L2 * 4);
+        orc_conv_transpose1d(cur, C, L, b->w, b->b, b->cout, K, b->stride, b->padding, nxt);
+        free(cur); cur = nxt; C = b->cout; L = L2;
+        float *t1 = (float *) malloc((size_t) C * L * 4), *t2 = (float *) malloc((size_t) C * L * 4);
+        if (b->noise_w && noise) {                                                    /* :155-159 */
+            orc_conv1d(cur, C, L, b->noise_w, NULL, C, 1, 0, 1, t1);
+            for (int c = 0; c < C; c++)
+                for (int64_t t = 0; t < L; t++) cur[(size_t) c * L + t] = cur[(size_t) c * L + t] + t1[(size_t) c * L + t] * noise[noise_off + (size_t) t];
+        }
+        noise_off += (size_t) L;
+        for (int r = 0; r < 3; r++) {                                                 /* build_residual_unit :133-149, groups > 1 */
+            int dil = 1; for (int e = 0; e < r; e++) dil *= 3;
+            memcpy(t1, cur, (size_t) C * L * 4);
+            orc_snake(t1, C, L, b->res[r].in_alpha);
+            orc_conv1d_dw(t1, C, L, b->res[r].in_w, b->res[r].in_b, 7, 3 * dil, dil, t2);
+            orc_snake(t2, C, L, b->res[r].out_alpha);
+            orc_conv1d(t2, C, L, b->res[r].out_w, b->res[r].out_b, C, 1, 0, 1, t1);
+            for (size_t i = 0; i < (size_t) C * L; i++) cur[i] = t1[i] + cur[i];
+        }
+        free(t1); free(t2);
+    }
+    orc_snake(cur, C, L, m->final_alpha);                                             /* :152-155 */
+    float *pcm = (float *) malloc((size_t) L * 4);
+    orc_conv1d(cur, C, L, m->final_w, m->final_b, 1, 7, 3, 1, pcm);
+    for (int64_t t = 0; t < L; t++) pcm_out[t] = tanhf(pcm[t]);
+    free(pcm); free(cur);
+    return L;
+}

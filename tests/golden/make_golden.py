@@ -161,8 +161,73 @@ def torch_t5(model, ids):
     return x
 
 
+def torch_snac(model, codes, T, noise):
+    """SNAC decoder (src/decoder/snac_model.cpp:86-159) in float64 torch: repeat_interleave'd codebook levels, depthwise /
+    pointwise convs, ConvTranspose1d, noise block x + noise * conv1x1(x), snake, tanh."""
+    c = model.cfg
+
+    def P(name):
+        return T_(model, "snac." + name)
+
+    def snake(x, a):
+        a = a.reshape(1, -1, 1)
+        return x + torch.sin(a * x) ** 2 / a
+
+    x = None
+    off = 0
+    for i, rep in enumerate(c.repeats):
+        n = T // rep
+        ids = torch.from_numpy(np.asarray(codes[off:off + n], dtype=np.int64))
+        off += n
+        z = P(f"quantizers.{i}.codebook.weight")[ids].t()[None]                    # [1][cb_dim][n]
+        z = Fn.conv1d(z, P(f"quantizers.{i}.out_proj.weight"), P(f"quantizers.{i}.out_proj.bias"))
+        z = torch.repeat_interleave(z, rep, dim=-1)
+        x = z if x is None else x + z
+    x = Fn.conv1d(x, P("in.weight"), P("in.bias"), padding=3, groups=c.latent)
+    x = Fn.conv1d(x, P("up.weight"), P("up.bias"))
+    noff = 0
+    for li, (s, pd) in enumerate(zip(c.strides, c.paddings)):
+        p = f"layers.{li}."
+        x = snake(x, P(p + "alpha"))
+        x = Fn.conv_transpose1d(x, P(p + "weight"), P(p + "bias"), stride=s, padding=pd)
+        L = x.shape[-1]
+        if noise is not None:
+            nz = torch.from_numpy(np.asarray(noise[noff:noff + L], dtype=np.float64))[None, None]
+            x = x + nz * Fn.conv1d(x, P(p + "noise_weight"))
+        noff += L
+        ch = x.shape[1]
+        for r in range(3):
+            q = p + f"residual_unit.{r}.res."
+            dil = 3 ** r
+            y = snake(x, P(q + "initial.alpha"))
+            y = Fn.conv1d(y, P(q + "initial.weight"), P(q + "initial.bias"), padding=3 * dil, dilation=dil, groups=ch)
+            y = snake(y, P(q + "final.alpha"))
+            y = Fn.conv1d(y, P(q + "final.weight"), P(q + "final.bias"))
+            x = x + y
+    x = snake(x, P("alpha_out"))
+    return torch.tanh(Fn.conv1d(x, P("final.weight"), P("final.bias"), padding=3))[0, 0]
+
+
+def T_(model, name):
+    return torch.from_numpy(model.by_name[name].to_f32().astype(np.float64))
+
+
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    sn = synth.build_snac(synth.snac_tiny())
+    rs = np.random.default_rng(99)
+    Tn = 12
+    sn_codes = np.concatenate([rs.integers(0, sn.cfg.cb_size, Tn // r) for r in sn.cfg.repeats]).astype(np.uint32)
+    nlen, L = 0, Tn
+    for s_ in sn.cfg.strides:
+        L *= s_
+        nlen += L
+    sn_noise = rs.standard_normal(nlen).astype(np.float32)
+    with torch.no_grad():
+        np.savez_compressed(os.path.join(out_dir, "tiny_snac.npz"), codes=sn_codes, T=np.int32(Tn), noise=sn_noise,
+                            pcm_noise=torch_snac(sn, sn_codes, Tn, sn_noise).numpy().astype(np.float32),
+                            pcm_clean=torch_snac(sn, sn_codes, Tn, None).numpy().astype(np.float32))
+    print("wrote tiny_snac.npz")
     t5 = synth.build_t5(synth.t5_tiny())
     t5p = synth.build_t5(synth.t5_tiny(output_size=192, seed=0x76))  # with the down projection
     ids = np.random.default_rng(77).integers(3, 160, 40).astype(np.uint32)

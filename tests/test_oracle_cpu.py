@@ -1,5 +1,6 @@
 """CPU tests of the oracle: golden vectors (independent float64 torch restatement), PyTorch primitive
 semantics, block formats.  The oracle is the checker for the HIP path, so it is pinned first."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -205,3 +206,26 @@ def test_t5_encoder_oracle_matches_torch_golden_and_bucket_quirk():
     for wt, tol in ((gguf.F16, 5e-3), (gguf.Q8_0, 3e-2)):
         out = orc.T5Oracle(sy.build_t5(sy.t5_tiny(weight_type=wt))).encode(ids)
         assert np.abs(out - ref).max() / np.abs(ref).max() < tol
+
+
+def test_snac_decoder_oracle_matches_torch_golden():
+    """orc_snac_decode (src/decoder/snac_model.cpp:86-159 restated) against tests/golden/tiny_snac.npz (float64 torch:
+    repeat_interleave'd codebook levels, depthwise + pointwise convs, ConvTranspose1d, noise block, snake, tanh)."""
+    from tts_cpp_amd import synth as sy
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_snac.npz"))
+    o = orc.SnacOracle(sy.build_snac(sy.snac_tiny()))
+    T = int(g["T"])
+    assert np.abs(o.decode(g["codes"], T, g["noise"]) - g["pcm_noise"]).max() < 2e-6
+    assert np.abs(o.decode(g["codes"], T, None) - g["pcm_clean"]).max() < 2e-6
+    # depthwise conv primitive against torch
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((5, 40)).astype(np.float32)
+    w = rng.standard_normal((5, 1, 7)).astype(np.float32)
+    b = rng.standard_normal(5).astype(np.float32)
+    for dil in (1, 3, 9):
+        y = np.empty_like(x)
+        orc.lib().orc_conv1d_dw.argtypes = [orc.fp, C.c_int, C.c_int64, orc.fp, orc.fp, C.c_int, C.c_int, C.c_int, orc.fp]
+        orc.lib().orc_conv1d_dw.restype = None
+        orc.lib().orc_conv1d_dw(orc.f32p(x), 5, 40, orc.f32p(w), orc.f32p(b), 7, 3 * dil, dil, orc.f32p(y))
+        ref = Fn.conv1d(torch.from_numpy(x)[None].double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=3 * dil, dilation=dil, groups=5)[0]
+        assert np.abs(y - ref.numpy()).max() < 1e-5

@@ -272,6 +272,70 @@ __global__ __launch_bounds__(256) void convt1d_kernel(ConvTArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// SNAC (src/decoder/snac_model.cpp): the pieces the DAC kernels do not cover.
+//   snac_embed_kernel   snac_build_audio_inputs :86-108 — codebook levels at 1/4, 1/2, 1x the latent rate,
+//                       quantize layer per level (gnac.cpp:166-172), repeat_interleave, sum
+//   dwconv7_kernel      snake_1d + ggml_conv_1d_dw (groups = channels) + bias [+ the next snake]  :141-142, gnac.cpp:135-145
+//   noise_fma_kernel    x + noise * conv1x1(x)   gnac.cpp:155-159 (the 1x1 conv is a conv1d launch)
+// ------------------------------------------------------------------------------------------------
+struct SnacEmbedArgs {
+    const uint32_t *codes;   // level-major: T/rep[0] ids, then T/rep[1], ... (snac_runner::set_inputs :161-178)
+    const float *codebook;   // [n_cb][cb_size][cb_dim]
+    const float *proj_w;     // [n_cb][latent][cb_dim]
+    const float *proj_b;     // [n_cb][latent]
+    int n_cb, cb_size, cb_dim, latent, T;
+    int rep[4];
+    float *out;              // [latent][T]
+};
+
+__global__ void snac_embed_kernel(SnacEmbedArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (t >= a.T) return;
+    float total = 0.0f;
+    int off = 0;
+    for (int i = 0; i < a.n_cb; i++) {
+        const uint32_t code = a.codes[off + t / a.rep[i]];
+        off += a.T / a.rep[i];
+        const float *cb = a.codebook + ((int64_t) i * a.cb_size + code) * a.cb_dim;
+        const float *w = a.proj_w + ((int64_t) i * a.latent + c) * a.cb_dim;
+        float acc = 0.0f;
+        for (int d = 0; d < a.cb_dim; d++) acc += w[d] * cb[d];
+        acc += a.proj_b[i * a.latent + c];
+        total = (i == 0) ? acc : (total + acc);
+    }
+    a.out[(int64_t) c * a.T + t] = total;
+}
+
+// depthwise k = 7: one output per thread (memory-shaped: 1 read + 1 write per element, 7 taps from L1/L2)
+__global__ __launch_bounds__(256) void dwconv7_kernel(const float *x, const float *w, const float *b, const float *alpha_in,
+                                                      const float *alpha_out, float *y, int C, int L, int pad, int dil) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (t >= L) return;
+    const float *xr = x + (int64_t) c * L;
+    const float al = alpha_in ? alpha_in[c] : 1.0f, ral = 1.0f / al;
+    float acc = b ? b[c] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const int ti = t + k * dil - pad;
+        if (ti >= 0 && ti < L) {
+            float v = xr[ti];
+            if (alpha_in) v = snake_f(v, al, ral);
+            acc += w[c * 7 + k] * v;
+        }
+    }
+    if (alpha_out) { const float ao = alpha_out[c]; acc = snake_f(acc, ao, 1.0f / ao); }
+    y[(int64_t) c * L + t] = acc;
+}
+
+__global__ void noise_fma_kernel(float *x, const float *h, const float *noise, int C, int L) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t) C * L) return;
+    x[i] = x[i] + h[i] * noise[i % L];
+}
+
 // ================================================================================================
 // MFMA paths.  v_mfma_f32_32x32x2_f32 is exact fp32 (bitwise an fmaf chain in k order) at the fp32
 // vector rate, so the codec keeps the reference's fp32 numerics while the contraction runs on the

@@ -192,6 +192,18 @@ struct tts_hip_ctx {
     float *ad = nullptr;        // their block scales
     bool all_q8i = false;       // every decoder matrix is on the integer path (all GEMMs go through run_qgemm)
     int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
+    // ---- SNAC codec context (tts_hip_snac_create) ----
+    bool has_snac = false;
+    tts_hip_snac_desc snac{};
+    struct SRes { size_t in_alpha = 0, in_w = 0, in_b = 0, out_alpha = 0, out_w = 0, out_b = 0; };
+    struct SBlock { int stride = 0, padding = 0, cin = 0, cout = 0; size_t alpha = 0, w = 0, b = 0, noise_w = 0; SRes res[3]; };
+    std::vector<SBlock> sblocks;
+    size_t s_codebook = 0, s_projw = 0, s_projb = 0, s_inw = 0, s_inb = 0, s_upw = 0, s_upb = 0, s_falpha = 0, s_fw = 0, s_fb = 0;
+    int s_latent = 0, s_c0 = 0, s_cbdim = 0, s_cbsize = 0, s_up = 1, s_clast = 0;
+    float *sbuf[3] = {nullptr, nullptr, nullptr};
+    float *s_noise = nullptr;
+    uint32_t *s_codes = nullptr;
+    bool snac_packed = false;
     // ---- T5 voice-prompt encoder context (tts_hip_t5_create) ----
     bool has_t5 = false;
     tts_hip_t5_desc t5{};
@@ -315,6 +327,8 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     if (!c->arena_external) free_dev(c->arena);
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
     free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms); free_dev(c->d_pen); free_dev(c->d_last); free_dev(c->d_repc);
+    for (int i = 0; i < 3; i++) free_dev(c->sbuf[i]);
+    free_dev(c->s_noise); free_dev(c->s_codes);
     free_dev(c->t5_bucket); free_dev(c->t5_x); free_dev(c->t5_qkv); free_dev(c->t5_att); free_dev(c->t5_ug); free_dev(c->t5_g); free_dev(c->t5_y); free_dev(c->t5_ids); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
     free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
     free_dev(c->d_eos); free_dev(c->d_codes); free_dev(c->d_frames);
@@ -395,7 +409,10 @@ extern "C" int tts_hip_upload(tts_hip_ctx *c, const char *name_c, int type, int 
     if (c->finalized) return set_err("tts_hip_upload(%s): context already finalized", name_c);
     HIPCHK(hipSetDevice(c->device));
     std::string name(name_c);
-    if (c->has_t5) {
+    if (c->has_snac) {
+        if (!starts_with(name, "snac.")) return 0;       // the Orpheus GGUF also carries "orpheus.*" (orpheus/model.cpp)
+        if (name.find(".in_proj") != std::string::npos) return 0;
+    } else if (c->has_t5) {
         if (!starts_with(name, "t5encoder.")) return 0;  // assign_to_t5_encoder ignores other top levels (t5/model.cpp:107-109)
     } else if (!starts_with(name, "decoder.") && !starts_with(name, "audio_encoder.")) {
         fprintf(stderr, "tts_hip: ignoring unhandled tensor '%s'\n", name_c);  // model.cpp:506
@@ -572,6 +589,53 @@ static int plan(tts_hip_ctx *c) {
             }
             c->cross_kv = P.alloc((size_t) c->L * 2 * c->ECAP * c->H * 4);
         }
+    }
+    if (c->has_snac) {
+        // snac_model (snac_model.h:10-40, assign_weight snac_model.cpp:50-84, layer tensors gnac.cpp:9-34)
+        const tts_hip_snac_desc &sd = c->snac;
+        std::vector<std::string> cb, pw, pb;
+        for (uint32_t i = 0; i < sd.n_codebooks; i++) {
+            const std::string p = "snac.quantizers." + std::to_string(i) + ".";
+            cb.push_back(p + "codebook.weight"); pw.push_back(p + "out_proj.weight"); pb.push_back(p + "out_proj.bias");
+        }
+        const Tensor *t0 = P.get(cb[0]);
+        const Tensor *w0 = P.get(pw[0]);
+        if (t0 && w0) {
+            c->s_cbdim = (int) t0->ne[0]; c->s_cbsize = (int) t0->ne[1];
+            c->s_latent = (int) (w0->nelem() / c->s_cbdim);
+        }
+        c->s_codebook = P.fused(cb).off; c->s_projw = P.fused(pw).off; c->s_projb = P.fused(pb).off;
+        c->s_inw = P.place_f32("snac.in.weight"); c->s_inb = P.place_f32("snac.in.bias");
+        { const Tensor *t = P.get("snac.up.weight"); c->s_c0 = t ? (int) t->ne[2] : 0; }
+        c->s_upw = P.place_f32("snac.up.weight"); c->s_upb = P.place_f32("snac.up.bias");
+        c->sblocks.assign(sd.n_blocks, tts_hip_ctx::SBlock{});
+        c->s_up = 1;
+        int C = c->s_c0;
+        for (uint32_t i = 0; i < sd.n_blocks; i++) {
+            const std::string p = "snac.layers." + std::to_string(i) + ".";
+            auto &b = c->sblocks[i];
+            b.stride = (int) sd.stride[i]; b.padding = (int) sd.padding[i];
+            const Tensor *t = P.get(p + "weight");  // ne = [K, Cout, Cin]
+            if (t) {
+                b.cin = (int) t->ne[2]; b.cout = (int) t->ne[1];
+                if ((int) t->ne[0] != 2 * b.stride && P.err.empty()) P.err = "SNAC layer kernel size != 2*stride: " + p;
+                if (b.cin != C && P.err.empty()) P.err = "SNAC layer channel mismatch: " + p;
+                if (((int) t->ne[0] - 2 * b.padding) != b.stride && P.err.empty()) P.err = "SNAC layer does not upsample by exactly its stride: " + p;
+                if ((int) sd.groups[i] != b.cout && P.err.empty()) P.err = "SNAC layer grouping != channels (only depthwise residual units are supported): " + p;
+            }
+            b.alpha = P.place_f32(p + "alpha"); b.w = P.place_f32(p + "weight"); b.b = P.place_f32(p + "bias");
+            b.noise_w = P.place_f32(p + "noise_weight");
+            for (int r = 0; r < 3; r++) {
+                const std::string q = p + "residual_unit." + std::to_string(r) + ".res.";
+                b.res[r].in_alpha = P.place_f32(q + "initial.alpha"); b.res[r].in_w = P.place_f32(q + "initial.weight");
+                b.res[r].in_b = P.place_f32(q + "initial.bias"); b.res[r].out_alpha = P.place_f32(q + "final.alpha");
+                b.res[r].out_w = P.place_f32(q + "final.weight"); b.res[r].out_b = P.place_f32(q + "final.bias");
+            }
+            C = b.cout;
+            c->s_up *= b.stride;
+        }
+        c->s_clast = C;
+        c->s_falpha = P.place_f32("snac.alpha_out"); c->s_fw = P.place_f32("snac.final.weight"); c->s_fb = P.place_f32("snac.final.bias");
     }
     if (c->has_t5) {
         // t5_encoder (t5/model.h:39-60, tensor names t5/model.cpp:3-18, py-gguf t5_encoder_gguf_encoder.py:73-90)
@@ -1818,9 +1882,9 @@ struct DacBatch {
 
 static int launch_conv(tts_hip_ctx *c, const DacBatch &bt, const float *x, int cin, int L, size_t w, size_t b, size_t alpha, bool has_alpha,
                        int cout, int K, int pad, int dil, const float *resid, bool do_tanh, float *y, size_t alpha_out = 0,
-                       bool has_alpha_out = false) {
+                       bool has_alpha_out = false, bool has_bias = true) {
     ConvArgs a{};
-    a.x = x; a.w = (const float *) (c->arena + w); a.b = (const float *) (c->arena + b);
+    a.x = x; a.w = (const float *) (c->arena + w); a.b = has_bias ? (const float *) (c->arena + b) : nullptr;
     a.alpha = has_alpha ? (const float *) (c->arena + alpha) : nullptr;
     a.alpha_out = has_alpha_out ? (const float *) (c->arena + alpha_out) : nullptr;
     a.resid = resid; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.dil = dil; a.pad = pad; a.do_tanh = do_tanh;
@@ -2033,6 +2097,128 @@ extern "C" int tts_hip_dac_decode(tts_hip_ctx *c, const uint32_t *codes, uint32_
 extern "C" int tts_hip_dac_decode_batch(tts_hip_ctx *c, const uint32_t *codes, const uint32_t *frames, uint32_t n, float *pcm_out) {
     if (n == 0) return 0;
     return dac_decode_batch(c, codes, frames, n, pcm_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SNAC codec (src/decoder/snac_model.cpp:110-208)
+// ------------------------------------------------------------------------------------------------
+extern "C" tts_hip_ctx *tts_hip_snac_create(int device, const tts_hip_snac_desc *sd) {
+    if (!sd || sd->struct_size != sizeof(tts_hip_snac_desc)) { set_err("tts_hip_snac_create: bad desc (struct_size mismatch)"); return nullptr; }
+    if (sd->n_blocks == 0 || sd->n_blocks > TTS_HIP_MAX_DAC_BLOCKS || sd->n_codebooks == 0 || sd->n_codebooks > 4) { set_err("tts_hip_snac_create: n_blocks / n_codebooks out of range"); return nullptr; }
+    tts_hip_desc d{};
+    d.struct_size = sizeof(d);
+    d.max_seqs = 1;
+    d.flags = (sd->flags & TTS_HIP_FLAG_VALU_GEMM) | TTS_HIP_FLAG_NO_PARLER | TTS_HIP_FLAG_NO_DAC;
+    tts_hip_ctx *c = tts_hip_create(device, &d);
+    if (!c) return nullptr;
+    c->has_snac = true;
+    c->snac = *sd;
+    for (uint32_t i = 0; i < sd->n_codebooks; i++)
+        if (c->snac.repeats[i] == 0) c->snac.repeats[i] = 1;
+    return c;
+}
+
+static int ensure_packed_snac(tts_hip_ctx *c) {
+    if (c->snac_packed || (c->d.flags & TTS_HIP_FLAG_VALU_GEMM)) return 0;
+    int CO_T = 0, CI_T = 0;
+    if (conv_tile(c->s_c0, 1, &CO_T, &CI_T) >= 0) CHK(pack_one(c, c->s_upw, c->s_c0, c->s_latent, 1, CO_T, CI_T, false));
+    for (auto &b : c->sblocks) {
+        if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, CI32_T, true));
+        if (conv_tile(b.cout, 1, &CO_T, &CI_T) >= 0) {
+            CHK(pack_one(c, b.noise_w, b.cout, b.cout, 1, CO_T, CI_T, false));
+            for (int r = 0; r < 3; r++) CHK(pack_one(c, b.res[r].out_w, b.cout, b.cout, 1, CO_T, CI_T, false));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->snac_packed = true;
+    return 0;
+}
+
+extern "C" int tts_hip_snac_decode(tts_hip_ctx *c, const uint32_t *codes, uint32_t T_, const float *noise, float *pcm_out) {
+    if (!c || !c->has_snac) return set_err("tts_hip_snac_decode: not a SNAC context (tts_hip_snac_create)");
+    if (!c->finalized || !c->weights_present) return set_err("tts_hip_snac_decode: context not finalized");
+    if (!codes || !pcm_out) return set_err("tts_hip_snac_decode: null argument");
+    if (T_ == 0) return 0;
+    const tts_hip_snac_desc &sd = c->snac;
+    if (sd.max_frames && T_ > sd.max_frames) return set_err("tts_hip_snac_decode: %u tokens exceed snac.max_generation_size %u", T_, sd.max_frames);
+    size_t n_codes = 0;
+    for (uint32_t i = 0; i < sd.n_codebooks; i++) {
+        if (T_ % sd.repeats[i]) return set_err("tts_hip_snac_decode: T=%u is not a multiple of the level-%u repeat %u", T_, i, sd.repeats[i]);
+        n_codes += T_ / sd.repeats[i];
+    }
+    for (size_t i = 0; i < n_codes; i++)
+        if (codes[i] >= (uint32_t) c->s_cbsize) return set_err("tts_hip_snac_decode: code %u >= codebook size %d", codes[i], c->s_cbsize);
+    HIPCHK(hipSetDevice(c->device));
+    CHK(ensure_packed_snac(c));
+    const int T = (int) T_;
+    // buffers sized for max_frames (or this call): largest activation = max over stages of C * L
+    const size_t Tcap = std::max<size_t>(sd.max_frames, T_);
+    if (!c->sbuf[0] || Tcap > c->dac_cap_frames) {
+        size_t mx = (size_t) std::max(c->s_latent, c->s_c0), up = 1, noise_len = 0;
+        for (auto &b : c->sblocks) { mx = std::max(mx, (size_t) b.cin * up); up *= b.stride; mx = std::max(mx, (size_t) b.cout * up); noise_len += up; }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < 3; i++) { free_dev(c->sbuf[i]); c->sbuf[i] = nullptr; HIPCHK(hipMalloc((void **) &c->sbuf[i], mx * Tcap * 4)); }
+        free_dev(c->s_noise); c->s_noise = nullptr;
+        HIPCHK(hipMalloc((void **) &c->s_noise, noise_len * Tcap * 4));
+        free_dev(c->s_codes); c->s_codes = nullptr;
+        HIPCHK(hipMalloc((void **) &c->s_codes, Tcap * sd.n_codebooks * 4));
+        c->dac_cap_frames = Tcap;
+    }
+    auto f32 = [&](size_t off) { return (const float *) (c->arena + off); };
+    HIPCHK(hipMemcpyAsync(c->s_codes, codes, n_codes * 4, hipMemcpyHostToDevice, c->stream));
+    size_t noise_len = 0;
+    { size_t up = 1; for (auto &b : c->sblocks) { up *= b.stride; noise_len += up * (size_t) T; } }
+    if (noise) HIPCHK(hipMemcpyAsync(c->s_noise, noise, noise_len * 4, hipMemcpyHostToDevice, c->stream));
+
+    float *cur = c->sbuf[0], *t1 = c->sbuf[1], *t2 = c->sbuf[2];
+    int L = T;
+    SnacEmbedArgs ea{};
+    ea.codes = c->s_codes; ea.codebook = f32(c->s_codebook); ea.proj_w = f32(c->s_projw); ea.proj_b = f32(c->s_projb);
+    ea.n_cb = (int) sd.n_codebooks; ea.cb_size = c->s_cbsize; ea.cb_dim = c->s_cbdim; ea.latent = c->s_latent; ea.T = T; ea.out = cur;
+    for (uint32_t i = 0; i < 4; i++) ea.rep[i] = i < sd.n_codebooks ? (int) sd.repeats[i] : 1;
+    hipLaunchKernelGGL(snac_embed_kernel, dim3((T + 63) / 64, c->s_latent), dim3(64), 0, c->stream, ea);
+    HIPCHK(hipGetLastError());
+    auto dw = [&](const float *x, size_t w, size_t b, const float *ain, const float *aout, float *y, int C, int Ln, int pad, int dil) {
+        hipLaunchKernelGGL(dwconv7_kernel, dim3((Ln + 255) / 256, C), dim3(256), 0, c->stream, x, f32(w), f32(b), ain, aout, y, C, Ln, pad, dil);
+        return hipGetLastError() == hipSuccess ? 0 : set_err("dwconv7_kernel launch failed");
+    };
+    DacBatch bt;
+    bt.n = 1; bt.frames = nullptr; bt.mult = 1; bt.tot_frames = (double) T;
+    CHK(dw(cur, c->s_inw, c->s_inb, nullptr, nullptr, t1, c->s_latent, L, 3, 1));                                 // :141-142
+    CHK(launch_conv(c, bt, t1, c->s_latent, L, c->s_upw, c->s_upb, 0, false, c->s_c0, 1, 0, 1, nullptr, false, cur));   // :143-144
+    int C = c->s_c0;
+    size_t noise_off = 0;
+    for (auto &b : c->sblocks) {                                                                                  // build_layer, gnac.cpp:151-164
+        ConvTArgs ta{};
+        ta.x = cur; ta.w = f32(b.w); ta.b = f32(b.b); ta.alpha = f32(b.alpha); ta.y = t1; ta.cin = b.cin; ta.cout = b.cout; ta.L = L;
+        ta.Lout = (L - 1) * b.stride - 2 * b.padding + 2 * b.stride; ta.stride = b.stride; ta.pad = b.padding;
+        ta.frames = nullptr; ta.mult = 1;
+        CHK(prof_begin(c, TTS_HIP_K_DAC_CONVT, 0, 2.0 * b.cin * (double) b.cout * 2 * ta.Lout));
+        CHK(launch_convt(c, ta, b.w, 1));
+        CHK(prof_end(c));
+        std::swap(cur, t1);
+        L = ta.Lout; C = b.cout;
+        bt.tot_frames = (double) L;   // launch_conv's accounting: valid positions = tot_frames * mult
+        if (noise) {                                                                                              // gnac.cpp:155-159
+            CHK(launch_conv(c, bt, cur, C, L, b.noise_w, 0, 0, false, C, 1, 0, 1, nullptr, false, t1, 0, false, false));
+            hipLaunchKernelGGL(noise_fma_kernel, dim3((unsigned) (((size_t) C * L + 255) / 256)), dim3(256), 0, c->stream, cur, (const float *) t1,
+                               (const float *) (c->s_noise + noise_off), C, L);
+            HIPCHK(hipGetLastError());
+        }
+        noise_off += (size_t) L;
+        for (int r = 0; r < 3; r++) {                                                                             // build_residual_unit, groups > 1
+            int dil = 1;
+            for (int e = 0; e < r; e++) dil *= 3;
+            // snake(in_alpha) on the way in, depthwise k7, bias, and the pointwise conv's snake(out_alpha) on the way out
+            CHK(dw(cur, b.res[r].in_w, b.res[r].in_b, f32(b.res[r].in_alpha), f32(b.res[r].out_alpha), t1, C, L, 3 * dil, dil));
+            CHK(launch_conv(c, bt, t1, C, L, b.res[r].out_w, b.res[r].out_b, 0, false, C, 1, 0, 1, cur, false, t2));
+            std::swap(cur, t2);
+        }
+    }
+    CHK(launch_conv(c, bt, cur, C, L, c->s_fw, c->s_fb, c->s_falpha, true, 1, 7, 3, 1, nullptr, true, t1));        // :152-155
+    HIPCHK(hipMemcpyAsync(pcm_out, t1, (size_t) L * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

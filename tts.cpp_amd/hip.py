@@ -43,6 +43,13 @@ class T5Desc(C.Structure):
                 ("flags", C.c_uint32)]
 
 
+class SnacDesc(C.Structure):
+    """tts_hip_snac_desc (include/tts_hip.h)"""
+    _fields_ = [("struct_size", C.c_uint32), ("n_blocks", C.c_uint32), ("stride", C.c_uint32 * MAX_DAC_BLOCKS),
+                ("padding", C.c_uint32 * MAX_DAC_BLOCKS), ("groups", C.c_uint32 * MAX_DAC_BLOCKS), ("n_codebooks", C.c_uint32),
+                ("repeats", C.c_uint32 * 4), ("max_frames", C.c_uint32), ("flags", C.c_uint32)]
+
+
 class KStat(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("launches", C.c_uint64), ("bytes_total", C.c_double), ("flops_total", C.c_double)]
 
@@ -52,7 +59,7 @@ EXPORTS = [
     "tts_hip_upload", "tts_hip_arena_bytes", "tts_hip_finalize", "tts_hip_arena_ptr", "tts_hip_arena_filled",
     "tts_hip_parler_set_text_encoding", "tts_hip_parler_reset", "tts_hip_parler_prefill", "tts_hip_parler_prefill_batch", "tts_hip_parler_step",
     "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits",
-    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
+    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
     "tts_hip_synchronize",
 ]
@@ -101,6 +108,9 @@ def load_lib():
     L.tts_hip_parler_generate_greedy.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
     L.tts_hip_parler_generate_sampled.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Sampling), f32p, u32p, u32p]
     L.tts_hip_sample_logits.argtypes = [vp, C.c_uint32, f32p, C.POINTER(Sampling), f32p, C.POINTER(C.c_int32), u32p, u32p]
+    L.tts_hip_snac_create.restype = vp
+    L.tts_hip_snac_create.argtypes = [C.c_int, C.POINTER(SnacDesc)]
+    L.tts_hip_snac_decode.argtypes = [vp, u32p, C.c_uint32, f32p, f32p]
     L.tts_hip_t5_create.restype = vp
     L.tts_hip_t5_create.argtypes = [C.c_int, C.POINTER(T5Desc)]
     L.tts_hip_t5_encode.argtypes = [vp, u32p, C.c_uint32, f32p]
@@ -357,6 +367,58 @@ class T5Engine:
             raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
         out = np.empty((a.size, n_out), dtype=np.float32)
         self._chk(self.L.tts_hip_t5_encode(self.ctx, ap, a.size, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def close(self):
+        if self.ctx:
+            self.L.tts_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SnacEngine:
+    """A SNAC codec context (tts_hip_snac_create): load a synth.SynthSnac / the snac.* tensors of an Orpheus GGUF, decode."""
+
+    def __init__(self, cfg, device=0, flags=0):
+        self.L = load_lib()
+        self.cfg = cfg
+        d = SnacDesc()
+        d.struct_size = C.sizeof(SnacDesc)
+        d.n_blocks = len(cfg.strides)
+        c = cfg.c0
+        for i, (s, p) in enumerate(zip(cfg.strides, cfg.paddings)):
+            c //= 2
+            d.stride[i], d.padding[i], d.groups[i] = s, p, c
+        d.n_codebooks = len(cfg.repeats)
+        for i, r in enumerate(cfg.repeats):
+            d.repeats[i] = r
+        d.max_frames, d.flags = cfg.max_frames, flags
+        self.ctx = self.L.tts_hip_snac_create(device, C.byref(d))
+        if not self.ctx:
+            raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
+
+    def load(self, model):
+        for t in model.tensors:
+            ne = (C.c_int64 * 4)(*(t.ne + [1] * (4 - len(t.ne))))
+            raw = np.frombuffer(bytes(t.raw()), dtype=np.uint8)
+            self._chk(self.L.tts_hip_upload(self.ctx, t.name.encode(), t.type, len(t.ne), ne, raw.ctypes.data_as(C.c_void_p)))
+        self._chk(self.L.tts_hip_finalize(self.ctx, None))
+
+    def decode(self, codes, T, noise=None):
+        a, ap = _u32(codes)
+        out = np.empty(T * self.cfg.hop, dtype=np.float32)
+        nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.float32)
+        self._chk(self.L.tts_hip_snac_decode(self.ctx, ap, T, None if nz is None else nz.ctypes.data_as(C.POINTER(C.c_float)),
+                                             out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
     def close(self):

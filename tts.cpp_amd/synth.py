@@ -412,3 +412,105 @@ class SynthT5:
 
 def build_t5(cfg: T5Config) -> SynthT5:
     return SynthT5(cfg)
+
+
+# --------------------------------------------------------------------------------------------------
+# SNAC codec (Orpheus' audio decoder; src/decoder/snac_model.cpp).  Tensor names as
+# py-gguf/tts_encoders/orpheus_gguf_encoder.py:89-142 writes them ("snac." + simplify_snac_name), KV keys :214-220.
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class SnacConfig:
+    latent: int = 64          # snac_model::embd (768)
+    c0: int = 96              # channels after the `up` conv (1024)
+    strides: tuple = (4, 2)   # 8, 8, 4, 2
+    cb_dim: int = 8
+    cb_size: int = 64         # 4096
+    repeats: tuple = (4, 2, 1)
+    max_frames: int = 64      # snac.max_generation_size (finest-scale tokens)
+    seed: int = 0x5AC
+
+    @property
+    def paddings(self):
+        return tuple((s + 1) // 2 for s in self.strides)   # SNAC DecoderBlock: ConvTranspose1d(k=2s, stride s, padding ceil(s/2))
+
+    @property
+    def hop(self):
+        return int(np.prod(self.strides))
+
+
+def snac_tiny(**kw):
+    return SnacConfig(**kw)
+
+
+def snac_24khz(**kw):
+    base = dict(latent=768, c0=1024, strides=(8, 8, 4, 2), cb_dim=8, cb_size=4096, max_frames=2580)
+    base.update(kw)
+    return SnacConfig(**base)
+
+
+class SynthSnac:
+    def __init__(self, cfg: SnacConfig):
+        self.cfg = cfg
+        rng = np.random.Generator(np.random.Philox(cfg.seed))
+        self.tensors = []
+
+        def add(name, arr):
+            self.tensors.append(gguf.Tensor.from_array("snac." + name, np.ascontiguousarray(arr, dtype=np.float32), gguf.F32))
+
+        def conv_w(cout, cin, k):
+            b = 1.0 / math.sqrt(cin * k)
+            return rng.uniform(-b, b, (cout, cin, k)).astype(np.float32)
+
+        def bias(n):
+            return rng.uniform(-0.05, 0.05, (n,)).astype(np.float32)
+
+        def alpha(n):
+            return rng.uniform(0.5, 2.0, (1, n, 1)).astype(np.float32)
+
+        for i in range(len(cfg.repeats)):
+            p = f"quantizers.{i}."
+            add(p + "codebook.weight", (rng.standard_normal((cfg.cb_size, cfg.cb_dim), dtype=np.float32)).astype(np.float32))
+            add(p + "out_proj.bias", bias(cfg.latent))
+            add(p + "out_proj.weight", conv_w(cfg.latent, cfg.cb_dim, 1))
+        add("in.weight", conv_w(cfg.latent, 1, 7))          # depthwise: [C][1][7]
+        add("in.bias", bias(cfg.latent))
+        add("up.weight", conv_w(cfg.c0, cfg.latent, 1))
+        add("up.bias", bias(cfg.c0))
+        c = cfg.c0
+        for li, s in enumerate(cfg.strides):
+            cout = c // 2
+            p = f"layers.{li}."
+            add(p + "alpha", alpha(c))
+            bnd = 1.0 / math.sqrt(c * 2)
+            add(p + "weight", rng.uniform(-bnd, bnd, (c, cout, 2 * s)).astype(np.float32))
+            add(p + "bias", bias(cout))
+            add(p + "noise_weight", conv_w(cout, cout, 1) * np.float32(0.3))
+            for r in range(3):
+                q = p + f"residual_unit.{r}.res."
+                add(q + "initial.alpha", alpha(cout))
+                add(q + "initial.bias", bias(cout))
+                add(q + "initial.weight", conv_w(cout, 1, 7))   # depthwise (groups = channels)
+                add(q + "final.alpha", alpha(cout))
+                add(q + "final.bias", bias(cout))
+                add(q + "final.weight", conv_w(cout, cout, 1) * np.float32(0.5))
+            c = cout
+        add("alpha_out", alpha(c))
+        add("final.weight", conv_w(1, c, 7))
+        add("final.bias", bias(1))
+        self.c_last = c
+        U32 = gguf.T_U32
+        self.kv = [("general.architecture", gguf.T_STR, "orpheus"), ("snac.audio_token_channels", U32, len(cfg.repeats)),
+                   ("snac.up_sampling_factor", U32, cfg.hop), ("snac.max_generation_size", U32, cfg.max_frames)]
+        c = cfg.c0
+        for i, (s, pd) in enumerate(zip(cfg.strides, cfg.paddings)):
+            c //= 2
+            self.kv += [(f"snac.snac_layer_stride_{i}", U32, s), (f"snac.snac_layer_padding_{i}", U32, pd), (f"snac.snac_layer_grouping_{i}", U32, c)]
+        self.by_name = {t.name: t for t in self.tensors}
+
+    def write_gguf(self, path):
+        gguf.write(path, self.kv, self.tensors)
+        return path
+
+
+def build_snac(cfg: SnacConfig) -> SynthSnac:
+    return SynthSnac(cfg)
