@@ -79,7 +79,13 @@ typedef struct tts_c_pool tts_c_pool;
  * up to max_batch compatible queued requests together, waiting batch_window_ms for more after the first. */
 tts_c_pool *tts_c_pool_create(const char *model_path, int n_workers, const int *devices, int n_devices, int max_batch,
                               int batch_window_ms, const tts_c_config *load_cfg);
+/* server --text-encoder-path: the T5 GGUF that CONDITIONAL_PROMPT tasks use; applies to pools created afterwards by
+ * this thread (NULL / "" = none) */
+void tts_c_pool_set_text_encoder(const char *path);
 int  tts_c_pool_submit(tts_c_pool *pool, const char *text, const tts_c_config *cfg);   /* task id, < 0 on error */
+/* CONDITIONAL_PROMPT task (server.cpp:263-271) fanned out to every worker; wait on the id like any task (no audio:
+ * tts_c_pool_wait returns 0 with n_outputs == 0 on success, 1 + tts_c_last_error() otherwise) */
+int  tts_c_pool_conditional_prompt(tts_c_pool *pool, const char *prompt);
 /* blocks until the task is done (timeout_ms < 0: forever).  0 = audio in data[0..n_outputs), valid until
  * tts_c_pool_release(id); 1 = finished without audio (tts_c_last_error says why); -1 = not finished */
 int  tts_c_pool_wait(tts_c_pool *pool, int id, int timeout_ms, const float **data, size_t *n_outputs, int *batch_size, int *worker);

@@ -197,6 +197,26 @@ def test_update_conditional_prompt_runs_the_t5_encoder(tmp_path):
     r.close()
 
 
+def test_device_pool_conditional_prompt_changes_every_worker(tmp_path):
+    """CONDITIONAL_PROMPT through the pool == update_conditional_prompt on a stand-alone runner: same greedy audio after."""
+    cfg = synth.tiny(weight_type=gguf.F32)
+    path = synth.build(cfg).write_gguf(str(tmp_path / "m.gguf"))
+    t5_path = synth.build_t5(synth.t5_tiny(vocab=cfg.prompt_vocab, output_size=cfg.hidden)).write_gguf(str(tmp_path / "t5.gguf"))
+    r = runner.Runner(path, sample=0)
+    before = r.generate("hello there")
+    r.update_conditional_prompt(t5_path, "a calm low voice")
+    after = r.generate("hello there")
+    r.close()
+    pool = runner.Pool(path, n_workers=2, max_batch=1, text_encoder_path=t5_path, sample=0)
+    assert np.array_equal(pool.wait(pool.submit("hello there"), 60000)[0], before)
+    audio, bs, wk, err = pool.wait(pool.conditional_prompt("a calm low voice"), 60000)
+    assert err == "" and audio.size == 0
+    outs = [pool.wait(pool.submit("hello there"), 60000) for _ in range(4)]
+    assert all(np.array_equal(o[0], after) for o in outs)
+    assert not np.array_equal(before, after)
+    pool.close()
+
+
 def test_eos_stops_generation_and_empty_response(tmp_path):
     """every head emits EOS at the first audio step -> check_stopping ends the loop, every frame contains a
     special id and is dropped by adjust_output_tokens -> n_outputs == 0 (the reference's soft failure)"""

@@ -216,6 +216,21 @@ def test_device_pool_queue_batching_and_responses():
     ref.close()
 
 
+def test_device_pool_conditional_prompt_task():
+    """CONDITIONAL_PROMPT (server.cpp:263-271): without --text-encoder-path the task is answered with the reference's
+    message; with one, every worker applies it (here the dummy backend refuses, as any non-Parler architecture does)."""
+    pool = runner.Pool("test:dummy", n_workers=2, max_batch=2)
+    audio, bs, wk, err = pool.wait(pool.conditional_prompt("a calm voice"), 20000)
+    assert audio.size == 0 and "text encoder path must be specified" in err
+    pool.close()
+    pool = runner.Pool("test:dummy", n_workers=2, max_batch=2, text_encoder_path="/nonexistent/t5.gguf")
+    audio, bs, wk, err = pool.wait(pool.conditional_prompt("a calm voice"), 20000)
+    assert audio.size == 0 and "does not support update_conditional_prompt" in err
+    t = pool.submit("still serving")          # TTS tasks keep flowing after a failed control task
+    assert pool.wait(t, 20000)[0].size > 0
+    pool.close()
+
+
 def test_device_pool_reports_load_failure():
     with pytest.raises(runner.RunnerError):
         runner.Pool("/nonexistent/model.gguf", n_workers=2, max_batch=2)

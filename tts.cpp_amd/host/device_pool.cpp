@@ -22,6 +22,7 @@ device_pool::device_pool(const std::map<std::string, std::string> & model_paths,
     if (opts_.n_workers < 1) opts_.n_workers = 1;
     if (opts_.max_batch < 1) opts_.max_batch = 1;
     if (opts_.devices.empty()) opts_.devices.push_back(0);
+    per_worker_.resize((size_t) opts_.n_workers);
     for (int w = 0; w < opts_.n_workers; w++) threads_.emplace_back(&device_pool::worker_main, this, w);
     std::unique_lock<std::mutex> lock(load_mutex_);
     load_cv_.wait(lock, [&] { return loaded_ == opts_.n_workers; });
@@ -64,6 +65,38 @@ int device_pool::submit(const std::string & model, const std::string & prompt, c
     return t->id;
 }
 
+int device_pool::submit_conditional_prompt(const std::string & model, const std::string & prompt) {
+    auto parent = std::make_shared<pool_task>();
+    parent->task = POOL_CONDITIONAL_PROMPT;
+    parent->id = next_id_.fetch_add(1);
+    parent->model = model;
+    parent->prompt = prompt;
+    {
+        std::lock_guard<std::mutex> lock(q_mutex_);
+        if (!running_) return -1;
+        fanouts_[parent->id] = fanout{parent, opts_.n_workers, true, ""};
+        for (int w = 0; w < opts_.n_workers; w++) {
+            auto t = std::make_shared<pool_task>(*parent);   // same id: the copies report into the fan-out record
+            per_worker_[(size_t) w].push_back(t);
+        }
+    }
+    q_cv_.notify_all();
+    return parent->id;
+}
+
+int device_pool::submit_voices() {
+    auto t = std::make_shared<pool_task>();
+    t->task = POOL_VOICES;
+    t->id = next_id_.fetch_add(1);
+    {
+        std::lock_guard<std::mutex> lock(q_mutex_);
+        if (!running_) return -1;
+        queue_.push_back(t);
+    }
+    q_cv_.notify_one();
+    return t->id;
+}
+
 std::shared_ptr<pool_task> device_pool::wait(int id, int timeout_ms) {
     std::unique_lock<std::mutex> lock(r_mutex_);
     auto ready = [&] { return completed_.count(id) != 0 || !running_; };
@@ -85,16 +118,23 @@ pool_stats device_pool::stats() const {
 
 // simple_task_queue::get_next (:132-145) widened to a batch: the oldest task plus every queued task compatible
 // with it (queue order preserved among the others), up to `cap`
-std::vector<std::shared_ptr<pool_task>> device_pool::next_batch(int cap) {
+std::vector<std::shared_ptr<pool_task>> device_pool::next_batch(int w, int cap) {
     std::vector<std::shared_ptr<pool_task>> batch;
     std::unique_lock<std::mutex> lock(q_mutex_);
-    q_cv_.wait(lock, [&] { return !queue_.empty() || !running_; });
+    auto & mine = per_worker_[(size_t) w];
+    q_cv_.wait(lock, [&] { return !queue_.empty() || !mine.empty() || !running_; });
     if (!running_) return batch;
+    if (!mine.empty()) {  // control tasks addressed to this worker go first, one at a time
+        batch.push_back(mine.front());
+        mine.pop_front();
+        return batch;
+    }
     batch.push_back(queue_.front());
     queue_.pop_front();
+    if (batch[0]->task != POOL_TTS) return batch;
     auto collect = [&] {
         for (auto it = queue_.begin(); it != queue_.end() && (int) batch.size() < cap;) {
-            if ((*it)->model == batch[0]->model && pool_configs_compatible((*it)->gen_config, batch[0]->gen_config)) {
+            if ((*it)->task == POOL_TTS && (*it)->model == batch[0]->model && pool_configs_compatible((*it)->gen_config, batch[0]->gen_config)) {
                 batch.push_back(*it);
                 it = queue_.erase(it);
             } else ++it;
@@ -130,9 +170,69 @@ void device_pool::worker_main(int w) {
     }
     load_cv_.notify_all();
     while (true) {
-        std::vector<std::shared_ptr<pool_task>> batch = next_batch(opts_.max_batch);
+        std::vector<std::shared_ptr<pool_task>> batch = next_batch(w, opts_.max_batch);
         if (batch.empty()) break;
+        if (batch[0]->task != POOL_TTS) {
+            control(w, *batch[0], ws);
+            if (batch[0]->task == POOL_CONDITIONAL_PROMPT) {
+                std::shared_ptr<pool_task> done;
+                {
+                    std::lock_guard<std::mutex> lock(q_mutex_);
+                    auto it = fanouts_.find(batch[0]->id);
+                    if (it != fanouts_.end()) {
+                        it->second.ok = it->second.ok && batch[0]->success;
+                        if (!batch[0]->success && it->second.message.empty()) it->second.message = batch[0]->message;
+                        if (--it->second.remaining == 0) {
+                            done = it->second.parent;
+                            done->success = it->second.ok;
+                            done->message = it->second.message;
+                            fanouts_.erase(it);
+                        }
+                    }
+                }
+                if (done) {
+                    { std::lock_guard<std::mutex> lock(r_mutex_); completed_[done->id] = done; }
+                    r_cv_.notify_all();
+                }
+            } else {
+                { std::lock_guard<std::mutex> lock(r_mutex_); completed_[batch[0]->id] = batch[0]; }
+                r_cv_.notify_all();
+            }
+            continue;
+        }
         process(w, batch, ws);
+    }
+}
+
+// worker::process_task, the non-TTS cases (server.cpp:263-306)
+void device_pool::control(int w, pool_task & t, worker_state & ws) {
+    t.worker = w;
+    try {
+        if (t.task == POOL_CONDITIONAL_PROMPT) {
+            if (opts_.text_encoder_path.empty()) {
+                t.message = "A text encoder path must be specified on server initialization in order to support conditional prompting.";  // :264-266
+                return;
+            }
+            auto found = ws.runners.find(t.model);
+            if (found == ws.runners.end() || !found->second) { t.message = "unknown model '" + t.model + "'"; return; }
+            found->second->update_conditional_prompt(opts_.text_encoder_path.c_str(), t.prompt.c_str());
+            t.success = true;
+        } else {  // VOICES
+            for (const auto & [id, runner] : ws.runners) {
+                if (!runner || !runner->supports_voices) continue;
+                std::string voices;
+                for (const auto v : runner->list_voices()) {
+                    if (!voices.empty()) voices += ",";
+                    voices += v;
+                }
+                if (!t.message.empty()) t.message += ";";
+                t.message += id + "/" + voices;
+            }
+            t.success = true;
+        }
+    } catch (const std::exception & e) {
+        t.success = false;
+        t.message = e.what();
     }
 }
 

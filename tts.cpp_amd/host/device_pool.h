@@ -25,7 +25,10 @@
 
 #include "common.h"
 
+enum pool_task_type { POOL_TTS = 0, POOL_CONDITIONAL_PROMPT = 1, POOL_VOICES = 2 };  // task_type (server.cpp:94-98)
+
 struct pool_task {  // simple_server_task (:100-123); the audio is copied out of the runner-owned buffer
+    pool_task_type           task = POOL_TTS;
     int                      id = 0;
     std::string              model;
     std::string              prompt;
@@ -49,6 +52,7 @@ struct pool_options {
     int              batch_window_ms = 0;  // after the first task, wait this long for more before decoding
     int              n_threads = 1;
     int              task_timeout_s = 300; // :231, tasks older than this are answered with success == false
+    std::string      text_encoder_path;    // T5 GGUF for CONDITIONAL_PROMPT tasks (server --text-encoder-path, :263-271)
 };
 
 struct pool_stats {
@@ -73,6 +77,11 @@ class device_pool {
 
     // enqueue one TTS request; returns its id (the reference uses rand(), :102; ids here are sequential)
     int submit(const std::string & model, const std::string & prompt, const generation_configuration & config);
+    // CONDITIONAL_PROMPT (:263-271): every worker re-encodes its runner's voice prompt (the reference hands the task to ONE
+    // worker, so only that worker's replica changes voice; here the task is fanned out and the returned id completes when
+    // the last worker has applied it).  VOICES (:272-306): "model/voice,voice;model/..." in pool_task::message.
+    int submit_conditional_prompt(const std::string & model, const std::string & prompt);
+    int submit_voices();
     // block until task `id` is finished (simple_response_map::get :203-218); nullptr after terminate()/timeout
     std::shared_ptr<pool_task> wait(int id, int timeout_ms = -1);
     void       release(int id);  // drop a finished task from the response map (the reference's cleanup thread, :168-189)
@@ -83,7 +92,11 @@ class device_pool {
     struct worker_state;
     void worker_main(int w);
     void process(int w, std::vector<std::shared_ptr<pool_task>> & batch, worker_state & ws);
-    std::vector<std::shared_ptr<pool_task>> next_batch(int cap);
+    std::vector<std::shared_ptr<pool_task>> next_batch(int w, int cap);
+    void control(int w, pool_task & t, worker_state & ws);
+    struct fanout { std::shared_ptr<pool_task> parent; int remaining = 0; bool ok = true; std::string message; };
+    std::map<int, fanout>                  fanouts_;     // parent id -> state (guarded by q_mutex_)
+    std::vector<std::deque<std::shared_ptr<pool_task>>> per_worker_;  // control tasks addressed to one worker
 
     std::map<std::string, std::string> model_paths_;
     generation_configuration           load_config_;

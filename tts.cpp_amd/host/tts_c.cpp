@@ -170,10 +170,20 @@ struct tts_c_pool {
     std::mutex mutex;
 };
 
+static thread_local std::string g_pool_text_encoder;
+void tts_c_pool_set_text_encoder(const char * path) { g_pool_text_encoder = path ? path : ""; }
+
+int tts_c_pool_conditional_prompt(tts_c_pool * p, const char * prompt) {
+    const int id = p->pool->submit_conditional_prompt("default", prompt);
+    if (id < 0) g_c_err = "pool is terminated";
+    return id;
+}
+
 tts_c_pool * tts_c_pool_create(const char * model_path, int n_workers, const int * devices, int n_devices, int max_batch,
                                int batch_window_ms, const tts_c_config * load_cfg) {
     try {
         pool_options o;
+        o.text_encoder_path = g_pool_text_encoder;
         o.n_workers = n_workers;
         for (int i = 0; devices && i < n_devices; i++) o.devices.push_back(devices[i]);
         o.max_batch = max_batch;

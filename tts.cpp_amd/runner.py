@@ -23,7 +23,7 @@ class SamplerCfg(C.Structure):
 
 EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_generate_batch", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
            "tts_c_last_error", "tts_c_update_conditional_prompt", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor",
-           "tts_c_pool_create", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_free"]
+           "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_free"]
 
 _lib = None
 
@@ -62,6 +62,9 @@ def load_lib():
         L.tts_c_pool_create.restype = C.c_void_p
         L.tts_c_pool_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(Config)]
         L.tts_c_pool_submit.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Config)]
+        L.tts_c_pool_set_text_encoder.argtypes = [C.c_char_p]
+        L.tts_c_pool_set_text_encoder.restype = None
+        L.tts_c_pool_conditional_prompt.argtypes = [C.c_void_p, C.c_char_p]
         L.tts_c_pool_wait.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.tts_c_pool_release.argtypes = [C.c_void_p, C.c_int]
         L.tts_c_pool_release.restype = None
@@ -152,9 +155,10 @@ class Pool:
     """device_pool (host/device_pool.h): the reference server's worker pool with one worker per device and dynamic
     lock-step batching.  submit() -> id; wait(id) -> (audio, batch_size, worker)."""
 
-    def __init__(self, path, n_workers=1, devices=None, max_batch=1, batch_window_ms=0, **cfg):
+    def __init__(self, path, n_workers=1, devices=None, max_batch=1, batch_window_ms=0, text_encoder_path=None, **cfg):
         self.L = load_lib()
         self.cfg = make_config(**cfg)
+        self.L.tts_c_pool_set_text_encoder(text_encoder_path.encode() if text_encoder_path else None)
         dev = (C.c_int * len(devices))(*devices) if devices else None
         self.h = self.L.tts_c_pool_create(path.encode(), n_workers, dev, len(devices) if devices else 0, max_batch, batch_window_ms, C.byref(self.cfg))
         if not self.h:
@@ -163,6 +167,12 @@ class Pool:
     def submit(self, text, **cfg):
         c = make_config(**cfg) if cfg else self.cfg
         i = self.L.tts_c_pool_submit(self.h, text.encode("utf-8"), C.byref(c))
+        if i < 0:
+            raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
+        return i
+
+    def conditional_prompt(self, prompt):
+        i = self.L.tts_c_pool_conditional_prompt(self.h, prompt.encode("utf-8"))
         if i < 0:
             raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
         return i
