@@ -70,6 +70,16 @@ class T5Model(C.Structure):
                 ("out_norm", fp), ("down_proj", W), ("down_proj_bias", fp), ("layers", T5Layer * MAX_LAYERS)]
 
 
+class OrpheusLayer(C.Structure):
+    _fields_ = [("q", W), ("k", W), ("v", W), ("o", W), ("gate", W), ("up", W), ("down", W), ("input_norm", fp), ("post_norm", fp)]
+
+
+class OrpheusModel(C.Structure):
+    _fields_ = [("H", C.c_int32), ("L", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32), ("head_dim", C.c_int32),
+                ("F", C.c_int32), ("V", C.c_int32), ("n_ctx", C.c_int32), ("act_mode", C.c_int32), ("embd", W), ("head", W),
+                ("out_norm", fp), ("rope_freqs", fp), ("layers", OrpheusLayer * MAX_LAYERS)]
+
+
 class SnacRes(C.Structure):
     _fields_ = [("in_alpha", fp), ("in_w", fp), ("in_b", fp), ("out_alpha", fp), ("out_w", fp), ("out_b", fp)]
 
@@ -506,3 +516,59 @@ class SnacOracle:
         n = self.L.orc_snac_decode(C.byref(self.m), u32p(codes), T, f32p(nz) if nz is not None else None, f32p(pcm))
         assert n == pcm.size
         return pcm
+
+
+class OrpheusOracle:
+    """Oracle twin of a tts_cpp_amd.synth.SynthOrpheus (src/models/orpheus/model.cpp:186-325 restated in tts_oracle.c)."""
+
+    def __init__(self, model, act_mode=1):
+        self.L = lib()
+        self.L.orc_orpheus_state_new.restype = C.c_void_p
+        self.L.orc_orpheus_state_new.argtypes = [C.POINTER(OrpheusModel)]
+        self.L.orc_orpheus_state_free.argtypes = [C.c_void_p]
+        self.L.orc_orpheus_decode.argtypes = [C.POINTER(OrpheusModel), C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_uint32, fp, fp]
+        self.L.orc_orpheus_decode.restype = None
+        cfg = model.cfg
+        self.cfg = cfg
+        self.keep = []
+        t = model.by_name
+
+        def w(name):
+            raw = np.frombuffer(bytes(t["orpheus." + name].raw()), dtype=np.uint8)
+            self.keep.append(raw)
+            return W(t["orpheus." + name].type, raw.ctypes.data_as(C.c_void_p).value)
+
+        def f(name):
+            a = np.ascontiguousarray(t["orpheus." + name].to_f32().reshape(-1))
+            self.keep.append(a)
+            return f32p(a)
+
+        m = OrpheusModel()
+        m.H, m.L, m.n_heads, m.n_kv_heads, m.head_dim = cfg.hidden, cfg.layers, cfg.heads, cfg.kv_heads, cfg.head_dim
+        m.F, m.V, m.n_ctx, m.act_mode = cfg.ffn, cfg.vocab, cfg.ctx, act_mode
+        m.embd, m.head, m.out_norm, m.rope_freqs = w("embed_tokens"), w("lm_head"), f("norm"), f("rope_frequencies")
+        for l in range(cfg.layers):
+            p = f"layers.{l}."
+            y = m.layers[l]
+            y.q, y.k, y.v, y.o = w(p + "self_attn.q_proj"), w(p + "self_attn.k_proj"), w(p + "self_attn.v_proj"), w(p + "self_attn.o_proj")
+            y.gate, y.up, y.down = w(p + "mlp.gate_proj"), w(p + "mlp.up_proj"), w(p + "mlp.down_proj")
+            y.input_norm, y.post_norm = f(p + "input_layernorm"), f(p + "post_attention_layernorm")
+        self.m = m
+        self.state = self.L.orc_orpheus_state_new(C.byref(m))
+
+    def reset(self):
+        self.L.orc_orpheus_state_free(self.state)
+        self.state = self.L.orc_orpheus_state_new(C.byref(self.m))
+
+    def decode(self, tokens, pos0, want_hidden=False):
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        logits = np.empty(self.cfg.vocab, dtype=np.float32)
+        hid = np.empty((tokens.size, self.cfg.hidden), dtype=np.float32) if want_hidden else None
+        self.L.orc_orpheus_decode(C.byref(self.m), self.state, u32p(tokens), tokens.size, pos0, f32p(logits), f32p(hid) if want_hidden else None)
+        return (logits, hid) if want_hidden else logits
+
+    def __del__(self):
+        try:
+            self.L.orc_orpheus_state_free(self.state)
+        except Exception:
+            pass

@@ -978,3 +978,105 @@ int64_t orc_snac_decode(const orc_snac_model *m, const uint32_t *codes, int T, c
     free(pcm); free(cur);
     return L;
 }
+
+
+/* ======================================================================================
+ * Orpheus decoder (Llama-3 blocks, src/models/orpheus/model.cpp:186-296)
+ * ==================================================================================== */
+struct orc_orpheus_state {
+    int L, n_ctx, kvH;
+    float *k, *v; /* [L][n_ctx][kvH], un-repeated (the reference's repeat-interleaved copy is the same data 3x) */
+};
+
+orc_orpheus_state *orc_orpheus_state_new(const orc_orpheus_model *m) {
+    orc_orpheus_state *s = (orc_orpheus_state *) calloc(1, sizeof(*s));
+    s->L = m->L; s->n_ctx = m->n_ctx; s->kvH = m->n_kv_heads * m->head_dim;
+    s->k = (float *) calloc((size_t) s->L * s->n_ctx * s->kvH, 4);
+    s->v = (float *) calloc((size_t) s->L * s->n_ctx * s->kvH, 4);
+    return s;
+}
+void orc_orpheus_state_free(orc_orpheus_state *s) { if (s) { free(s->k); free(s->v); free(s); } }
+
+static void llama_rms_norm(const float *x, int H, const float *w, float *y) { /* :122-125, eps 1e-5 */
+    double sum = 0.0;
+    for (int i = 0; i < H; i++) sum += (double) (x[i] * x[i]);
+    const float scale = 1.0f / sqrtf((float) (sum / H) + 1e-5f);
+    for (int i = 0; i < H; i++) y[i] = x[i] * scale * w[i];
+}
+
+/* ggml_rope_ext(x, pos, freq_factors, n_dims = head_dim, mode 2 (NEOX pairs i, i + n/2), n_ctx_orig 0, freq_base 500000,
+ * freq_scale 1, ext_factor 0, attn_factor 1, beta 0/0): upstream ggml_rope_cache_init walks theta = pos, theta *=
+ * powf(base, -2/n) in fp32 and evaluates cosf/sinf of theta / freq_factor. */
+static void llama_rope(float *x, int n_heads, int hd, uint32_t pos, const float *ff) {
+    const float theta_scale = powf(500000.0f, -2.0f / (float) hd);
+    for (int h = 0; h < n_heads; h++) {
+        float *v = x + (size_t) h * hd;
+        float theta = (float) pos;
+        for (int i = 0; i < hd / 2; i++) {
+            const float ang = theta / (ff ? ff[i] : 1.0f);
+            const float c = cosf(ang), sn = sinf(ang);
+            const float x0 = v[i], x1 = v[i + hd / 2];
+            v[i] = x0 * c - x1 * sn;
+            v[i + hd / 2] = x0 * sn + x1 * c;
+            theta *= theta_scale;
+        }
+    }
+}
+
+void orc_orpheus_decode(const orc_orpheus_model *m, orc_orpheus_state *s, const uint32_t *tokens, int n, uint32_t pos0,
+                        float *logits_out, float *hidden_out) {
+    const int H = m->H, F = m->F, NH = m->n_heads, NKV = m->n_kv_heads, hd = m->head_dim, kvH = NKV * hd, rep = NH / NKV;
+    float *x = (float *) malloc((size_t) n * H * 4), *cur = (float *) malloc((size_t) n * H * 4);
+    float *q = (float *) malloc((size_t) n * NH * hd * 4), *k = (float *) malloc((size_t) n * kvH * 4), *v = (float *) malloc((size_t) n * kvH * 4);
+    float *att = (float *) malloc((size_t) n * NH * hd * 4), *tmp = (float *) malloc((size_t) n * H * 4);
+    float *gate = (float *) malloc((size_t) n * F * 4), *up = (float *) malloc((size_t) n * F * 4);
+    float *sc = (float *) malloc((size_t) (pos0 + n) * 4);
+    const float scale = 1.0f / sqrtf((float) hd);
+    for (int t = 0; t < n; t++) get_row(&m->embd, tokens[t], H, x + (size_t) t * H);
+    for (int l = 0; l < m->L; l++) {
+        const orc_orpheus_layer *ly = &m->layers[l];
+        float *kc = s->k + (size_t) l * s->n_ctx * kvH, *vc = s->v + (size_t) l * s->n_ctx * kvH;
+        for (int t = 0; t < n; t++) llama_rms_norm(x + (size_t) t * H, H, ly->input_norm, cur + (size_t) t * H);
+        orc_mul_mat(ly->q.type, ly->q.data, H, NH * hd, cur, n, q, m->act_mode);
+        orc_mul_mat(ly->k.type, ly->k.data, H, kvH, cur, n, k, m->act_mode);
+        orc_mul_mat(ly->v.type, ly->v.data, H, kvH, cur, n, v, m->act_mode);
+        for (int t = 0; t < n; t++) {
+            llama_rope(q + (size_t) t * NH * hd, NH, hd, pos0 + t, m->rope_freqs);
+            llama_rope(k + (size_t) t * kvH, NKV, hd, pos0 + t, m->rope_freqs);
+            memcpy(kc + (size_t) (pos0 + t) * kvH, k + (size_t) t * kvH, (size_t) kvH * 4);
+            memcpy(vc + (size_t) (pos0 + t) * kvH, v + (size_t) t * kvH, (size_t) kvH * 4);
+        }
+        for (int t = 0; t < n; t++) {
+            const int T = (int) pos0 + t + 1; /* causal mask :329-337 */
+            for (int h = 0; h < NH; h++) {
+                const float *qv = q + ((size_t) t * NH + h) * hd;
+                const int kh = h / rep;
+                for (int j = 0; j < T; j++) {
+                    const float *kv = kc + (size_t) j * kvH + kh * hd;
+                    double d = 0.0;
+                    for (int e = 0; e < hd; e++) d += (double) qv[e] * (double) kv[e];
+                    sc[j] = (float) d;
+                }
+                softmax_scaled(sc, T, scale);
+                float *o = att + ((size_t) t * NH + h) * hd;
+                for (int e = 0; e < hd; e++) {
+                    double a = 0.0;
+                    for (int j = 0; j < T; j++) a += (double) sc[j] * (double) vc[(size_t) j * kvH + kh * hd + e];
+                    o[e] = (float) a;
+                }
+            }
+        }
+        orc_mul_mat(ly->o.type, ly->o.data, NH * hd, H, att, n, tmp, m->act_mode);
+        for (size_t i = 0; i < (size_t) n * H; i++) x[i] = tmp[i] + x[i];
+        for (int t = 0; t < n; t++) llama_rms_norm(x + (size_t) t * H, H, ly->post_norm, cur + (size_t) t * H);
+        orc_mul_mat(ly->gate.type, ly->gate.data, H, F, cur, n, gate, m->act_mode);
+        orc_mul_mat(ly->up.type, ly->up.data, H, F, cur, n, up, m->act_mode);
+        for (size_t i = 0; i < (size_t) n * F; i++) gate[i] = (gate[i] / (1.0f + expf(-gate[i]))) * up[i]; /* ggml_silu, fp32 (:279) */
+        orc_mul_mat(ly->down.type, ly->down.data, F, H, gate, n, tmp, m->act_mode);
+        for (size_t i = 0; i < (size_t) n * H; i++) x[i] = tmp[i] + x[i];
+    }
+    for (int t = 0; t < n; t++) llama_rms_norm(x + (size_t) t * H, H, m->out_norm, cur + (size_t) t * H);
+    if (hidden_out) memcpy(hidden_out, cur, (size_t) n * H * 4);
+    if (logits_out) orc_mul_mat(m->head.type, m->head.data, H, m->V, cur + (size_t) (n - 1) * H, 1, logits_out, m->act_mode);
+    free(x); free(cur); free(q); free(k); free(v); free(att); free(tmp); free(gate); free(up); free(sc);
+}

@@ -208,12 +208,74 @@ def torch_snac(model, codes, T, noise):
     return torch.tanh(Fn.conv1d(x, P("final.weight"), P("final.bias"), padding=3))[0, 0]
 
 
+def torch_orpheus(model, prompt, steps):
+    """Llama-3 blocks (src/models/orpheus/model.cpp:186-296) in float64 torch with the HF formulation of rotary
+    embeddings (inv_freq / llama3 factors, rotate_half) — an independent route to the same numbers as ggml's NEOX rope
+    with frequency factors.  Returns last-token logits after the prompt and after each greedy step, and the tokens."""
+    c = model.cfg
+    H, NH, NKV, hd = c.hidden, c.heads, c.kv_heads, c.head_dim
+
+    def P(name):
+        return T_(model, "orpheus." + name)
+
+    inv_freq = 1.0 / (500000.0 ** (torch.arange(0, hd, 2, dtype=D) / hd)) / P("rope_frequencies")
+
+    def rope(x, pos):  # x [n][heads][hd]
+        ang = pos[:, None].to(D) * inv_freq[None, :]
+        cos, sin = torch.cos(ang)[:, None, :], torch.sin(ang)[:, None, :]
+        x0, x1 = x[..., : hd // 2], x[..., hd // 2:]
+        return torch.cat([x0 * cos - x1 * sin, x0 * sin + x1 * cos], dim=-1)
+
+    def rms(v, w):
+        return v * torch.rsqrt((v * v).mean(-1, keepdim=True) + 1e-5) * w
+
+    ks = [torch.zeros(0, NKV, hd, dtype=D) for _ in range(c.layers)]
+    vs = [torch.zeros(0, NKV, hd, dtype=D) for _ in range(c.layers)]
+
+    def forward(ids, pos0):
+        n = len(ids)
+        pos = torch.arange(pos0, pos0 + n)
+        x = P("embed_tokens")[torch.tensor(ids, dtype=torch.long)]
+        for l in range(c.layers):
+            p = f"layers.{l}."
+            cur = rms(x, P(p + "input_layernorm"))
+            q = rope(Fn.linear(cur, P(p + "self_attn.q_proj")).view(n, NH, hd), pos)
+            k = rope(Fn.linear(cur, P(p + "self_attn.k_proj")).view(n, NKV, hd), pos)
+            v = Fn.linear(cur, P(p + "self_attn.v_proj")).view(n, NKV, hd)
+            ks[l] = torch.cat([ks[l], k]); vs[l] = torch.cat([vs[l], v])
+            kk = ks[l].repeat_interleave(NH // NKV, dim=1)
+            vv = vs[l].repeat_interleave(NH // NKV, dim=1)
+            sc = torch.einsum("nhd,thd->hnt", q, kk) / hd ** 0.5
+            mask = torch.arange(kk.shape[0])[None, :] > pos[:, None]
+            sc = sc.masked_fill(mask[None], float("-inf"))
+            att = torch.einsum("hnt,thd->nhd", torch.softmax(sc, -1), vv).reshape(n, NH * hd)
+            x = x + Fn.linear(att, P(p + "self_attn.o_proj"))
+            cur = rms(x, P(p + "post_attention_layernorm"))
+            x = x + Fn.linear(Fn.silu(Fn.linear(cur, P(p + "mlp.gate_proj"))) * Fn.linear(cur, P(p + "mlp.up_proj")), P(p + "mlp.down_proj"))
+        return Fn.linear(rms(x[-1], P("norm")), P("lm_head"))
+
+    logits = [forward(list(prompt), 0)]
+    toks = []
+    pos = len(prompt)
+    for _ in range(steps):
+        toks.append(int(logits[-1].argmax()))
+        logits.append(forward([toks[-1]], pos))
+        pos += 1
+    return torch.stack(logits), toks
+
+
 def T_(model, name):
     return torch.from_numpy(model.by_name[name].to_f32().astype(np.float64))
 
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    om = synth.build_orpheus(synth.orpheus_tiny())
+    op = np.random.default_rng(5).integers(0, om.cfg.vocab, 9).astype(np.uint32)
+    with torch.no_grad():
+        olog, otoks = torch_orpheus(om, op, 6)
+    np.savez_compressed(os.path.join(out_dir, "tiny_orpheus.npz"), prompt=op, logits=olog.numpy().astype(np.float32), tokens=np.array(otoks, dtype=np.uint32))
+    print("wrote tiny_orpheus.npz")
     sn = synth.build_snac(synth.snac_tiny())
     rs = np.random.default_rng(99)
     Tn = 12

@@ -229,3 +229,29 @@ def test_snac_decoder_oracle_matches_torch_golden():
         orc.lib().orc_conv1d_dw(orc.f32p(x), 5, 40, orc.f32p(w), orc.f32p(b), 7, 3 * dil, dil, orc.f32p(y))
         ref = Fn.conv1d(torch.from_numpy(x)[None].double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=3 * dil, dilation=dil, groups=5)[0]
         assert np.abs(y - ref.numpy()).max() < 1e-5
+
+
+def test_orpheus_decoder_oracle_matches_torch_golden():
+    """orc_orpheus_decode (Llama-3 blocks, src/models/orpheus/model.cpp:186-325 restated with ggml's NEOX rope + frequency
+    factors, iterated fp32 theta) against tests/golden/tiny_orpheus.npz (float64 torch with the HF rotary formulation):
+    prompt logits, 6 greedy steps through the KV cache, token ids."""
+    from tts_cpp_amd import synth as sy
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_orpheus.npz"))
+    model = sy.build_orpheus(sy.orpheus_tiny())
+    o = orc.OrpheusOracle(model, act_mode=0)
+    lg = o.decode(g["prompt"], 0)
+    assert np.abs(lg - g["logits"][0]).max() < 5e-6
+    pos = len(g["prompt"])
+    for s_, t in enumerate(g["tokens"]):
+        assert int(lg.argmax()) == int(t)
+        lg = o.decode([t], pos)
+        pos += 1
+        assert np.abs(lg - g["logits"][s_ + 1]).max() < 5e-6
+    # prefill in two pieces == one piece (cache semantics)
+    o.reset()
+    o.decode(g["prompt"][:4], 0)
+    lg2 = o.decode(g["prompt"][4:], 4)
+    assert np.abs(lg2 - g["logits"][0]).max() < 5e-6
+    # Q4_0 weights (BASELINE config 4) run through the integer mul_mat
+    q = orc.OrpheusOracle(sy.build_orpheus(sy.orpheus_tiny(weight_type=gguf.Q4_0)))
+    assert np.isfinite(q.decode(g["prompt"], 0)).all()

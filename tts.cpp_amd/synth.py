@@ -514,3 +514,97 @@ class SynthSnac:
 
 def build_snac(cfg: SnacConfig) -> SynthSnac:
     return SynthSnac(cfg)
+
+
+# --------------------------------------------------------------------------------------------------
+# Orpheus decoder (Llama-3 blocks; src/models/orpheus/model.cpp).  Tensor names as
+# py-gguf/tts_encoders/orpheus_gguf_encoder.py:118-122,173 writes them, KV keys :190-212.
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class OrpheusConfig:
+    hidden: int = 256
+    layers: int = 2
+    heads: int = 2            # head_dim is 128 (orpheus/model.h:28)
+    kv_heads: int = 1
+    head_dim: int = 128
+    ffn: int = 512
+    vocab: int = 200
+    ctx: int = 96             # max_context_length + max_generation_size positions of KV cache
+    weight_type: int = gguf.F32
+    seed: int = 0x0A9
+
+
+def orpheus_tiny(**kw):
+    return OrpheusConfig(**kw)
+
+
+def orpheus_3b(**kw):
+    """canopylabs/orpheus-3b: 28 layers, hidden 3072, 24 heads / 8 kv heads x 128, ffn 8192, vocab 156940"""
+    base = dict(hidden=3072, layers=28, heads=24, kv_heads=8, ffn=8192, vocab=156940, ctx=3124)
+    base.update(kw)
+    return OrpheusConfig(**base)
+
+
+def llama3_rope_factors(head_dim, base=500000.0, factor=8.0, low=1.0, high=4.0, old_ctx=8192):
+    """orpheus_gguf_encoder.py:145-173 (prepare_rope_frequencies)"""
+    out = []
+    for i in range(0, head_dim, 2):
+        freq = 1.0 / (base ** (i / head_dim))
+        wavelen = 2 * math.pi / freq
+        if wavelen < old_ctx / high:
+            out.append(1.0)
+        elif wavelen > old_ctx / low:
+            out.append(factor)
+        else:
+            smooth = (old_ctx / wavelen - low) / (high - low)
+            out.append(1 / ((1 - smooth) / factor + smooth))
+    return np.array(out, dtype=np.float32)
+
+
+class SynthOrpheus:
+    def __init__(self, cfg: OrpheusConfig):
+        self.cfg = cfg
+        rng = np.random.Generator(np.random.Philox(cfg.seed))
+        self.tensors = []
+        H, F, kvH = cfg.hidden, cfg.ffn, cfg.kv_heads * cfg.head_dim
+
+        def normal(shape, std):
+            return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+        def add(name, arr, quantizable=True):
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            ttype = cfg.weight_type if quantizable else gguf.F32
+            ne = list(reversed(arr.shape))
+            if ttype in (gguf.Q4_0, gguf.Q5_0, gguf.Q8_0):
+                self.tensors.append(gguf.Tensor("orpheus." + name, ttype, ne, quantize(arr, ttype).tobytes()))
+            else:
+                self.tensors.append(gguf.Tensor.from_array("orpheus." + name, arr, ttype))
+
+        add("embed_tokens", normal((cfg.vocab, H), 1.0))
+        for l in range(cfg.layers):
+            p = f"layers.{l}."
+            add(p + "self_attn.q_proj", normal((cfg.heads * cfg.head_dim, H), 1.0 / math.sqrt(H)))
+            add(p + "self_attn.k_proj", normal((kvH, H), 1.0 / math.sqrt(H)))
+            add(p + "self_attn.v_proj", normal((kvH, H), 1.0 / math.sqrt(H)))
+            add(p + "self_attn.o_proj", normal((H, cfg.heads * cfg.head_dim), 1.0 / math.sqrt(H)))
+            add(p + "mlp.gate_proj", normal((F, H), 1.0 / math.sqrt(H)))
+            add(p + "mlp.up_proj", normal((F, H), 1.0 / math.sqrt(H)))
+            add(p + "mlp.down_proj", normal((H, F), 1.0 / math.sqrt(F)))
+            add(p + "input_layernorm", 1.0 + normal((H,), 0.05), quantizable=False)
+            add(p + "post_attention_layernorm", 1.0 + normal((H,), 0.05), quantizable=False)
+        add("norm", 1.0 + normal((H,), 0.05), quantizable=False)
+        add("lm_head", normal((cfg.vocab, H), 1.0 / math.sqrt(H)))
+        add("rope_frequencies", llama3_rope_factors(cfg.head_dim), quantizable=False)
+        U32 = gguf.T_U32
+        self.kv = [("general.architecture", gguf.T_STR, "orpheus"), ("orpheus.layers", U32, cfg.layers), ("orpheus.hidden_size", U32, H),
+                   ("orpheus.vocab_size", U32, cfg.vocab), ("orpheus.attn_heads", U32, cfg.heads), ("orpheus.kv_attn_heads", U32, cfg.kv_heads),
+                   ("orpheus.head_dim", U32, cfg.head_dim), ("orpheus.kv_hidden_size", U32, kvH), ("orpheus.stopping_token_id", U32, cfg.vocab - 1)]
+        self.by_name = {t.name: t for t in self.tensors}
+
+    def write_gguf(self, path):
+        gguf.write(path, self.kv, self.tensors)
+        return path
+
+
+def build_orpheus(cfg: OrpheusConfig) -> SynthOrpheus:
+    return SynthOrpheus(cfg)
