@@ -195,6 +195,32 @@ tts_hip_ctx *tts_hip_t5_create(int device, const tts_hip_t5_desc *desc);
 int tts_hip_t5_encode(tts_hip_ctx *ctx, const uint32_t *ids, uint32_t n_tokens, float *out);
 int tts_hip_t5_output_size(tts_hip_ctx *ctx);   /* after tts_hip_finalize / tts_hip_arena_bytes; < 0 on error */
 
+/* ---- Orpheus decoder: Llama-3 blocks (src/models/orpheus/model.cpp) --------------------------------------
+ * Device side of orpheus_runner::decode (:298-325): create, tts_hip_upload every "orpheus.*" tensor (names :11-60),
+ * tts_hip_finalize(ctx, NULL), then tts_hip_orpheus_decode per call of decode() — the prompt batch first, one token
+ * per step after.  Tokenizer (BPE), prompt framing (:341-356), sampler and the 7-ids-per-frame -> SNAC level mapping
+ * (:358-376) stay with the host. */
+typedef struct tts_hip_orpheus_desc {
+    uint32_t struct_size;
+    uint32_t hidden_size;      /* orpheus.hidden_size (3072)   */
+    uint32_t n_layers;         /* orpheus.layers (28)          */
+    uint32_t n_attn_heads;     /* orpheus.attn_heads (24)      */
+    uint32_t n_kv_heads;       /* orpheus.kv_attn_heads (8)    */
+    uint32_t head_dim;         /* orpheus.head_dim (128)       */
+    uint32_t vocab_size;       /* orpheus.vocab_size (156940)  */
+    uint32_t n_ctx;            /* KV positions: max_context_length + max_generation_size (1024 + 2100, :176-177) */
+    float    rope_base;        /* 500000 (:190,250); 0 = that  */
+    uint32_t flags;            /* TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q */
+} tts_hip_orpheus_desc;
+tts_hip_ctx *tts_hip_orpheus_create(int device, const tts_hip_orpheus_desc *desc);
+/* n tokens at positions pos0 .. pos0+n-1 (KV cache appended); logits_out [vocab_size] of the LAST token (:287-290).
+ * tokens_out (may be NULL): sampler::max of those logits (first maximum wins), evaluated on the device. */
+int tts_hip_orpheus_decode(tts_hip_ctx *ctx, const uint32_t *ids, uint32_t n, uint32_t pos0, float *logits_out, uint32_t *token_out);
+/* greedy generate_from_batch (:378-392 with sampler::max): decode the prompt, then feed back the arg-max until
+ * stop_id or max_new ids; returns the count in *n_out */
+int tts_hip_orpheus_generate_greedy(tts_hip_ctx *ctx, const uint32_t *prompt, uint32_t n_prompt, uint32_t max_new, uint32_t stop_id,
+                                    uint32_t *tokens_out, uint32_t *n_out);
+
 /* ---- SNAC codec (src/decoder/snac_model.cpp; Orpheus' audio decoder) -------------------------------
  * A SNAC context is its own tts_hip_ctx: create, tts_hip_upload every "snac.*" tensor (names:
  * py-gguf/tts_encoders/orpheus_gguf_encoder.py:89-142), tts_hip_finalize(ctx, NULL), tts_hip_snac_decode. */

@@ -22,6 +22,7 @@
 #include "dac_kernels.h"
 #include "parler_kernels.h"
 #include "t5_kernels.h"
+#include "llama_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -192,6 +193,18 @@ struct tts_hip_ctx {
     float *ad = nullptr;        // their block scales
     bool all_q8i = false;       // every decoder matrix is on the integer path (all GEMMs go through run_qgemm)
     int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
+    // ---- Orpheus decoder context (tts_hip_orpheus_create) ----
+    bool has_llama = false;
+    tts_hip_orpheus_desc lm{};
+    struct LLayer { size_t in_norm = 0, post_norm = 0; W qkv, o, gu, down; };
+    std::vector<LLayer> l_layers;
+    size_t l_embd = 0, l_out_norm = 0, l_ropef = 0;
+    W l_head;
+    int l_V = 0, l_Vpad = 0, l_kvH = 0, l_ksplit = 1;
+    float *l_x = nullptr, *l_xn = nullptr, *l_qkv = nullptr, *l_att = nullptr, *l_gu = nullptr, *l_g = nullptr, *l_logits = nullptr, *l_parts = nullptr;
+    float *l_kc = nullptr, *l_vc = nullptr;
+    uint32_t *l_ids = nullptr, *l_pos = nullptr, *l_tok = nullptr;
+    int l_pending = 0;
     // ---- SNAC codec context (tts_hip_snac_create) ----
     bool has_snac = false;
     tts_hip_snac_desc snac{};
@@ -327,6 +340,8 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     if (!c->arena_external) free_dev(c->arena);
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
     free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms); free_dev(c->d_pen); free_dev(c->d_last); free_dev(c->d_repc);
+    free_dev(c->l_x); free_dev(c->l_xn); free_dev(c->l_qkv); free_dev(c->l_att); free_dev(c->l_gu); free_dev(c->l_g); free_dev(c->l_logits); free_dev(c->l_parts);
+    free_dev(c->l_kc); free_dev(c->l_vc); free_dev(c->l_ids); free_dev(c->l_pos); free_dev(c->l_tok);
     for (int i = 0; i < 3; i++) free_dev(c->sbuf[i]);
     free_dev(c->s_noise); free_dev(c->s_codes);
     free_dev(c->t5_bucket); free_dev(c->t5_x); free_dev(c->t5_qkv); free_dev(c->t5_att); free_dev(c->t5_ug); free_dev(c->t5_g); free_dev(c->t5_y); free_dev(c->t5_ids); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
@@ -364,8 +379,11 @@ static bool is_t5_matmul(const std::string &name) {
                                                 ends_with(name, ".attn_o") || ends_with(name, ".ffn_up") || ends_with(name, ".ffn_gate") ||
                                                 ends_with(name, ".ffn_down") || name == "t5encoder.down_proj");
 }
+static bool is_llama_matmul(const std::string &name) {
+    return starts_with(name, "orpheus.") && (ends_with(name, "_proj") || name == "orpheus.lm_head");
+}
 static bool is_matmul_weight(const std::string &name) {
-    if (is_t5_matmul(name)) return true;
+    if (is_t5_matmul(name) || is_llama_matmul(name)) return true;
     return starts_with(name, "decoder.") && (ends_with(name, "_proj.weight") || ends_with(name, "fc1.weight") ||
                                               ends_with(name, "fc2.weight") || ends_with(name, "weight.head"));
 }
@@ -397,7 +415,7 @@ static int expand_q_to_i8(int type, const void *src, int64_t n, int8_t *q, uint1
 }
 
 static bool keeps_f16(const std::string &name) {
-    if (is_t5_matmul(name)) return true;
+    if (is_t5_matmul(name) || is_llama_matmul(name)) return true;
     if (!starts_with(name, "decoder.")) return false;
     if (name.find("layer_norm") != std::string::npos) return false;
     if (name == "decoder.positional_embed" || name == "decoder.text_encoding") return false;
@@ -409,7 +427,9 @@ extern "C" int tts_hip_upload(tts_hip_ctx *c, const char *name_c, int type, int 
     if (c->finalized) return set_err("tts_hip_upload(%s): context already finalized", name_c);
     HIPCHK(hipSetDevice(c->device));
     std::string name(name_c);
-    if (c->has_snac) {
+    if (c->has_llama) {
+        if (!starts_with(name, "orpheus.")) return 0;    // "snac.*" belongs to the codec context (orpheus/model.cpp:430-438)
+    } else if (c->has_snac) {
         if (!starts_with(name, "snac.")) return 0;       // the Orpheus GGUF also carries "orpheus.*" (orpheus/model.cpp)
         if (name.find(".in_proj") != std::string::npos) return 0;
     } else if (c->has_t5) {
@@ -492,7 +512,7 @@ struct Planner {
     }
     W mat(const std::string &n) { return fused({n}); }
     // several same-shaped matrices stacked along N
-    W fused(const std::vector<std::string> &names) {
+    W fused(const std::vector<std::string> &names, int pad_rows_to = 1) {
         W w;
         for (size_t i = 0; i < names.size(); i++) {
             const Tensor *t = get(names[i]);
@@ -510,6 +530,9 @@ struct Planner {
             cur += main_bytes;
             w.N += t->nelem() / t->ne[0];
         }
+        // rows up to a multiple of pad_rows_to exist in the arena (uninitialised: their outputs are never read)
+        const int64_t n_pad = (w.N + pad_rows_to - 1) / pad_rows_to * pad_rows_to - w.N;
+        if (n_pad) cur += (size_t) n_pad * w.K * (w.type == TTS_HIP_Q8I ? 1 : (w.type == TTS_HIP_F16 ? 2 : 4));
         if (w.type == TTS_HIP_Q8I) {  // the block scales of the stacked matrices, [N_total][K/32] fp16
             cur = (cur + 255) & ~(size_t) 255;
             w.soff = cur;
@@ -519,7 +542,9 @@ struct Planner {
                 c->copies.push_back({cur, nm, (size_t) t->nelem(), sb});
                 cur += sb;
             }
+            cur += (size_t) n_pad * (w.K / 32) * 2;
         }
+        w.N += n_pad;
         return w;
     }
 };
@@ -589,6 +614,36 @@ static int plan(tts_hip_ctx *c) {
             }
             c->cross_kv = P.alloc((size_t) c->L * 2 * c->ECAP * c->H * 4);
         }
+    }
+    if (c->has_llama) {
+        // orpheus_model (orpheus/model.h:24-52, tensor names orpheus/model.cpp:11-60)
+        const tts_hip_orpheus_desc &ld = c->lm;
+        c->H = (int) ld.hidden_size; c->L = (int) ld.n_layers; c->NH = (int) ld.n_attn_heads;
+        if (c->H <= 0 || c->L <= 0 || c->NH <= 0 || ld.n_kv_heads == 0 || ld.n_ctx == 0) return set_err("plan: incomplete Orpheus hyper-parameters");
+        if (ld.head_dim != 128) return set_err("plan: Orpheus head_dim %u unsupported (128, orpheus/model.h:28)", ld.head_dim);
+        if (c->NH % (int) ld.n_kv_heads) return set_err("plan: attn_heads %% kv_attn_heads != 0");
+        c->l_kvH = (int) (ld.n_kv_heads * ld.head_dim);
+        c->l_embd = P.place_f32("orpheus.embed_tokens");
+        c->l_out_norm = P.place_f32("orpheus.norm");
+        c->l_ropef = P.place_f32("orpheus.rope_frequencies");
+        { const Tensor *t = P.get("orpheus.lm_head"); c->l_V = t ? (int) (t->nelem() / t->ne[0]) : 0; }
+        if (ld.vocab_size && (int) ld.vocab_size != c->l_V && P.err.empty()) P.err = "orpheus.vocab_size disagrees with lm_head";
+        c->l_head = P.fused({"orpheus.lm_head"}, 16);
+        c->l_Vpad = (int) c->l_head.N;
+        c->l_layers.assign(c->L, tts_hip_ctx::LLayer{});
+        for (int l = 0; l < c->L; l++) {
+            const std::string p = "orpheus.layers." + std::to_string(l) + ".";
+            auto &y = c->l_layers[l];
+            y.in_norm = P.place_f32(p + "input_layernorm");
+            y.qkv = P.fused({p + "self_attn.q_proj", p + "self_attn.k_proj", p + "self_attn.v_proj"});
+            y.o = P.mat(p + "self_attn.o_proj");
+            y.post_norm = P.place_f32(p + "post_attention_layernorm");
+            y.gu = P.fused({p + "mlp.gate_proj", p + "mlp.up_proj"});
+            y.down = P.mat(p + "mlp.down_proj");
+        }
+        c->F = c->l_layers.empty() ? 0 : (int) (c->l_layers[0].gu.N / 2);
+        if (!c->l_layers.empty() && (int) c->l_layers[0].qkv.N != (c->NH + 2 * (int) ld.n_kv_heads) * (int) ld.head_dim && P.err.empty())
+            P.err = "orpheus q/k/v projection shapes disagree with attn_heads / kv_attn_heads / head_dim";
     }
     if (c->has_snac) {
         // snac_model (snac_model.h:10-40, assign_weight snac_model.cpp:50-84, layer tensors gnac.cpp:9-34)
@@ -1218,6 +1273,32 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         HIPCHK(hipHostMalloc((void **) &c->h_seq, (size_t) R * 4));
         HIPCHK(hipHostMalloc((void **) &c->h_tok, (size_t) R * c->NO * 4));
         HIPCHK(hipHostMalloc((void **) &c->h_logits, (size_t) R * c->NO * c->V * 4));
+    }
+    if (c->has_llama) {
+        const int H = c->H, F = c->F, NCTX = (int) c->lm.n_ctx, QKV = (c->NH + 2 * (int) c->lm.n_kv_heads) * (int) c->lm.head_dim;
+        c->RMAX = 256;
+        // down_proj: K = F columns in slices of at most 4096 (16 waves x 256) per workgroup
+        c->l_ksplit = 1;
+        while (F / c->l_ksplit > 4096 || (F % c->l_ksplit)) c->l_ksplit++;
+        if ((F / c->l_ksplit) % 256) c->l_ksplit = 1;
+        const size_t kvb = (size_t) c->L * NCTX * c->l_kvH;
+        CHK(dmalloc(&c->l_kc, kvb));   // ggml_backend_buffer_clear(buf, 0), orpheus/model.cpp:181
+        CHK(dmalloc(&c->l_vc, kvb));
+        const int R = c->RMAX;
+        CHK(dmalloc(&c->l_x, (size_t) R * H));
+        CHK(dmalloc(&c->l_xn, (size_t) R * H));
+        CHK(dmalloc(&c->l_qkv, (size_t) R * QKV));
+        CHK(dmalloc(&c->l_att, (size_t) R * c->NH * c->lm.head_dim));
+        CHK(dmalloc(&c->l_gu, (size_t) R * 2 * F));
+        CHK(dmalloc(&c->l_g, (size_t) R * F));
+        CHK(dmalloc(&c->l_parts, (size_t) 8 * R * H));
+        CHK(dmalloc(&c->l_logits, (size_t) c->l_Vpad));
+        CHK(dmalloc(&c->dbg, (size_t) R * std::max(H, F)));
+        CHK(dmalloc(&c->aq, (size_t) R * std::max(std::max(H, F), c->NH * (int) c->lm.head_dim)));
+        CHK(dmalloc(&c->ad, (size_t) R * std::max(std::max(H, F), c->NH * (int) c->lm.head_dim) / 32 + 1));
+        CHK(dmalloc(&c->l_ids, (size_t) R));
+        CHK(dmalloc(&c->l_pos, (size_t) R));
+        CHK(dmalloc(&c->l_tok, (size_t) 1));
     }
     if (c->has_t5) {
         const int H = c->H, F = c->F, S = (int) c->t5.max_ctx_length;
@@ -2097,6 +2178,132 @@ extern "C" int tts_hip_dac_decode(tts_hip_ctx *c, const uint32_t *codes, uint32_
 extern "C" int tts_hip_dac_decode_batch(tts_hip_ctx *c, const uint32_t *codes, const uint32_t *frames, uint32_t n, float *pcm_out) {
     if (n == 0) return 0;
     return dac_decode_batch(c, codes, frames, n, pcm_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Orpheus decoder (src/models/orpheus/model.cpp:186-325)
+// ------------------------------------------------------------------------------------------------
+extern "C" tts_hip_ctx *tts_hip_orpheus_create(int device, const tts_hip_orpheus_desc *ld) {
+    if (!ld || ld->struct_size != sizeof(tts_hip_orpheus_desc)) { set_err("tts_hip_orpheus_create: bad desc (struct_size mismatch)"); return nullptr; }
+    tts_hip_desc d{};
+    d.struct_size = sizeof(d);
+    d.hidden_size = ld->hidden_size; d.n_layers = ld->n_layers; d.n_attn_heads = ld->n_attn_heads; d.max_ctx_length = ld->n_ctx;
+    d.max_seqs = 1;
+    d.flags = (ld->flags & (TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q)) | TTS_HIP_FLAG_NO_PARLER | TTS_HIP_FLAG_NO_DAC;
+    tts_hip_ctx *c = tts_hip_create(device, &d);
+    if (!c) return nullptr;
+    c->has_llama = true;
+    c->lm = *ld;
+    if (c->lm.rope_base == 0.0f) c->lm.rope_base = 500000.0f;
+    return c;
+}
+
+static int llama_gemm(tts_hip_ctx *c, const W &w, const float *A, int lda, float *out, int ldo, int n, int epi, int ksplit = 1) {
+    for (int r0 = 0; r0 < n; r0 += c->RMAX) {
+        GemmArgs g{};
+        g.R = std::min(c->RMAX, n - r0); g.H = c->H;
+        g.A = A + (size_t) r0 * lda; g.lda = lda;
+        g.out = out + (size_t) r0 * ldo; g.ldo = ldo;
+        if (ksplit > 1) {  // slabs [ksplit][RMAX][ldo], folded into the residual stream by the next rms_fold_rows_kernel
+            g.kchunk = (int) w.K / ksplit;
+            g.slab_stride = (int64_t) c->RMAX * ldo;
+        }
+        CHK(run_gemm(c, TTS_HIP_K_GEMM_OTHER, w, g, PRO_F32, epi));
+    }
+    return 0;
+}
+
+// one call of orpheus_runner::decode: n rows (<= RMAX) at pos0..; leaves the final-normed last row's logits in l_logits
+static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t pos0) {
+    const int H = c->H, F = c->F, NH = c->NH, NKV = (int) c->lm.n_kv_heads, HD = (int) c->lm.head_dim;
+    const int QKV = (NH + 2 * NKV) * HD, NCTX = (int) c->lm.n_ctx;
+    if (n < 1 || n > c->RMAX) return set_err("tts_hip_orpheus_decode: %d tokens per call outside 1..%d", n, c->RMAX);
+    if (pos0 + (uint32_t) n > (uint32_t) NCTX) return set_err("tts_hip_orpheus_decode: positions up to %u exceed the %d cached positions", pos0 + n, NCTX);
+    std::vector<uint32_t> hp((size_t) n);
+    for (int i = 0; i < n; i++) {
+        if (ids[i] >= (uint32_t) c->l_V) return set_err("tts_hip_orpheus_decode: token id %u >= vocabulary %d", ids[i], c->l_V);
+        hp[(size_t) i] = pos0 + (uint32_t) i;
+    }
+    auto f32 = [&](size_t off) { return (const float *) (c->arena + off); };
+    HIPCHK(hipMemcpyAsync(c->l_ids, ids, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->l_pos, hp.data(), (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // hp is a local
+    hipLaunchKernelGGL(t5_embed_kernel, dim3(n), dim3(256), 0, c->stream, f32(c->l_embd), (const uint32_t *) c->l_ids, H, c->l_x);
+    HIPCHK(hipGetLastError());
+    const float theta_scale = powf(c->lm.rope_base, -2.0f / (float) HD);
+    c->l_pending = 0;
+    auto rms = [&](size_t w_off, int rows, float *x, float *y) {
+        hipLaunchKernelGGL(rms_fold_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, c->stream, x, H, f32(w_off), y, rows, 1e-5f,
+                           c->l_pending ? (const float *) c->l_parts : (const float *) nullptr, c->l_pending, (int64_t) c->RMAX * H);
+        c->l_pending = 0;
+        return hipGetLastError() == hipSuccess ? 0 : set_err("rms_fold_rows_kernel launch failed");
+    };
+    for (int l = 0; l < c->L; l++) {
+        const auto &y = c->l_layers[l];
+        float *kc = c->l_kc + (size_t) l * NCTX * c->l_kvH, *vc = c->l_vc + (size_t) l * NCTX * c->l_kvH;
+        CHK(rms(y.in_norm, n, c->l_x, c->l_xn));
+        CHK(llama_gemm(c, y.qkv, c->l_xn, H, c->l_qkv, QKV, n, EPI_STORE));
+        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n), dim3(256), 0, c->stream, c->l_qkv, (const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, HD, kc, vc);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, n), dim3(64), (size_t) (128 + pos0 + n) * 4, c->stream, (const float *) c->l_qkv, QKV, (const uint32_t *) c->l_pos,
+                           (const float *) kc, (const float *) vc, NH, NKV, 1.0f / sqrtf((float) HD), c->l_att);
+        HIPCHK(hipGetLastError());
+        CHK(llama_gemm(c, y.o, c->l_att, NH * HD, c->l_x, H, n, EPI_RESID));
+        CHK(rms(y.post_norm, n, c->l_x, c->l_xn));
+        CHK(llama_gemm(c, y.gu, c->l_xn, H, c->l_gu, 2 * F, n, EPI_STORE));
+        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) n * F + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->l_gu, F, n, c->l_g);
+        HIPCHK(hipGetLastError());
+        if (c->l_ksplit > 1) {
+            CHK(llama_gemm(c, y.down, c->l_g, F, c->l_parts, H, n, EPI_STORE, c->l_ksplit));
+            c->l_pending = c->l_ksplit;
+        } else {
+            CHK(llama_gemm(c, y.down, c->l_g, F, c->l_x, H, n, EPI_RESID));
+        }
+    }
+    // lm_head on the last token only (:287-290)
+    CHK(rms(c->l_out_norm, n, c->l_x, c->l_xn));
+    GemmArgs g{};
+    g.R = 1; g.H = H; g.A = c->l_xn + (size_t) (n - 1) * H; g.lda = H; g.out = c->l_logits; g.ldo = c->l_Vpad;
+    CHK(run_gemm(c, TTS_HIP_K_GEMM_HEADS, c->l_head, g, PRO_F32, EPI_STORE));
+    return 0;
+}
+
+extern "C" int tts_hip_orpheus_decode(tts_hip_ctx *c, const uint32_t *ids, uint32_t n, uint32_t pos0, float *logits_out, uint32_t *token_out) {
+    if (!c || !c->has_llama) return set_err("tts_hip_orpheus_decode: not an Orpheus context (tts_hip_orpheus_create)");
+    if (!c->finalized || !c->weights_present) return set_err("tts_hip_orpheus_decode: context not finalized");
+    if (!ids || n == 0) return set_err("tts_hip_orpheus_decode: no tokens");
+    HIPCHK(hipSetDevice(c->device));
+    uint32_t done = 0;
+    while (done < n) {   // a long prompt goes through in pieces of RMAX rows (same cache semantics as one call)
+        const uint32_t m = std::min<uint32_t>((uint32_t) c->RMAX, n - done);
+        CHK(llama_forward(c, ids + done, (int) m, pos0 + done));
+        done += m;
+    }
+    if (token_out) {
+        hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(256), 0, c->stream, (const float *) c->l_logits, c->l_V, c->l_tok);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(token_out, c->l_tok, 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (logits_out) HIPCHK(hipMemcpyAsync(logits_out, c->l_logits, (size_t) c->l_V * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int tts_hip_orpheus_generate_greedy(tts_hip_ctx *c, const uint32_t *prompt, uint32_t n_prompt, uint32_t max_new, uint32_t stop_id,
+                                               uint32_t *tokens_out, uint32_t *n_out) {
+    if (!tokens_out || !n_out) return set_err("tts_hip_orpheus_generate_greedy: null argument");
+    *n_out = 0;
+    uint32_t tok = 0, pos = n_prompt;
+    CHK(tts_hip_orpheus_decode(c, prompt, n_prompt, 0, nullptr, &tok));
+    // generate_from_batch (:378-392): stop once the last token is the stopping token or max_generation_size ids exist
+    while (*n_out < max_new) {
+        tokens_out[(*n_out)++] = tok;
+        if (tok == stop_id || *n_out >= max_new) break;
+        if (pos >= c->lm.n_ctx) break;
+        CHK(tts_hip_orpheus_decode(c, &tok, 1, pos, nullptr, &tok));
+        pos++;
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -50,6 +50,13 @@ class SnacDesc(C.Structure):
                 ("repeats", C.c_uint32 * 4), ("max_frames", C.c_uint32), ("flags", C.c_uint32)]
 
 
+class OrpheusDesc(C.Structure):
+    """tts_hip_orpheus_desc (include/tts_hip.h)"""
+    _fields_ = [("struct_size", C.c_uint32), ("hidden_size", C.c_uint32), ("n_layers", C.c_uint32), ("n_attn_heads", C.c_uint32),
+                ("n_kv_heads", C.c_uint32), ("head_dim", C.c_uint32), ("vocab_size", C.c_uint32), ("n_ctx", C.c_uint32),
+                ("rope_base", C.c_float), ("flags", C.c_uint32)]
+
+
 class KStat(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("launches", C.c_uint64), ("bytes_total", C.c_double), ("flops_total", C.c_double)]
 
@@ -59,7 +66,7 @@ EXPORTS = [
     "tts_hip_upload", "tts_hip_arena_bytes", "tts_hip_finalize", "tts_hip_arena_ptr", "tts_hip_arena_filled",
     "tts_hip_parler_set_text_encoding", "tts_hip_parler_reset", "tts_hip_parler_prefill", "tts_hip_parler_prefill_batch", "tts_hip_parler_step",
     "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits",
-    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
+    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
     "tts_hip_synchronize",
 ]
@@ -108,6 +115,10 @@ def load_lib():
     L.tts_hip_parler_generate_greedy.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
     L.tts_hip_parler_generate_sampled.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Sampling), f32p, u32p, u32p]
     L.tts_hip_sample_logits.argtypes = [vp, C.c_uint32, f32p, C.POINTER(Sampling), f32p, C.POINTER(C.c_int32), u32p, u32p]
+    L.tts_hip_orpheus_create.restype = vp
+    L.tts_hip_orpheus_create.argtypes = [C.c_int, C.POINTER(OrpheusDesc)]
+    L.tts_hip_orpheus_decode.argtypes = [vp, u32p, C.c_uint32, C.c_uint32, f32p, u32p]
+    L.tts_hip_orpheus_generate_greedy.argtypes = [vp, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
     L.tts_hip_snac_create.restype = vp
     L.tts_hip_snac_create.argtypes = [C.c_int, C.POINTER(SnacDesc)]
     L.tts_hip_snac_decode.argtypes = [vp, u32p, C.c_uint32, f32p, f32p]
@@ -420,6 +431,58 @@ class SnacEngine:
         self._chk(self.L.tts_hip_snac_decode(self.ctx, ap, T, None if nz is None else nz.ctypes.data_as(C.POINTER(C.c_float)),
                                              out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
+
+    def close(self):
+        if self.ctx:
+            self.L.tts_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OrpheusEngine:
+    """An Orpheus decoder context (tts_hip_orpheus_create): Llama-3 blocks, one sequence."""
+
+    def __init__(self, cfg, device=0, flags=0):
+        self.L = load_lib()
+        self.cfg = cfg
+        d = OrpheusDesc()
+        d.struct_size = C.sizeof(OrpheusDesc)
+        d.hidden_size, d.n_layers, d.n_attn_heads, d.n_kv_heads, d.head_dim = cfg.hidden, cfg.layers, cfg.heads, cfg.kv_heads, cfg.head_dim
+        d.vocab_size, d.n_ctx, d.rope_base, d.flags = cfg.vocab, cfg.ctx, 0.0, flags
+        self.ctx = self.L.tts_hip_orpheus_create(device, C.byref(d))
+        if not self.ctx:
+            raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
+
+    def load(self, model):
+        for t in model.tensors:
+            ne = (C.c_int64 * 4)(*(t.ne + [1] * (4 - len(t.ne))))
+            raw = np.frombuffer(bytes(t.raw()), dtype=np.uint8)
+            self._chk(self.L.tts_hip_upload(self.ctx, t.name.encode(), t.type, len(t.ne), ne, raw.ctypes.data_as(C.c_void_p)))
+        self._chk(self.L.tts_hip_finalize(self.ctx, None))
+
+    def decode(self, ids, pos0):
+        """-> (logits [vocab] of the last token, its arg-max)"""
+        a, ap = _u32(ids)
+        lg = np.empty(self.cfg.vocab, dtype=np.float32)
+        tok = C.c_uint32()
+        self._chk(self.L.tts_hip_orpheus_decode(self.ctx, ap, a.size, pos0, lg.ctypes.data_as(C.POINTER(C.c_float)), C.byref(tok)))
+        return lg, tok.value
+
+    def generate_greedy(self, prompt, max_new, stop_id):
+        a, ap = _u32(prompt)
+        out = np.zeros(max_new, dtype=np.uint32)
+        n = C.c_uint32()
+        self._chk(self.L.tts_hip_orpheus_generate_greedy(self.ctx, ap, a.size, max_new, stop_id, out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n)))
+        return out[:n.value]
 
     def close(self):
         if self.ctx:
