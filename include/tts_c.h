@@ -54,7 +54,8 @@ const char   *tts_c_last_error(void);
 /* which = 0: prompt ids of the last generate (tokenised + EOS); 1: sampled ids, still delayed
  * (pctx->output_tokens).  Returns the count (copies at most cap). */
 int tts_c_last_tokens(tts_c_runner *r, int which, uint32_t *out, int cap);
-/* unigram tokenizer from the GGUF vocabulary + EOS, as batch_from_sentence builds it (model.cpp:473-498) */
+/* unigram tokenizer from the GGUF vocabulary + EOS, as batch_from_sentence builds it (model.cpp:473-498); a GGUF with
+ * tokenizer.ggml.merges gets the byte-pair tokenizer instead (src/tokenizer.cpp:265-296; ids only, no framing) */
 int tts_c_tokenize(const char *gguf_path, const char *text, uint32_t *out, int cap);
 
 typedef struct tts_c_sampler_cfg {

@@ -75,3 +75,90 @@ class UnigramOracle:
 def _f32(x):
     import struct
     return struct.unpack("f", struct.pack("f", x))[0] if math.isfinite(x) else x
+
+
+class BpeOracle:
+    """Pure-Python restatement of the reference's byte-pair tokenizer (src/tokenizer.cpp:209-296), written from its
+    priority-queue formulation: pieces cut at spaces, "Ġ" prefix once a space has been seen, whole-piece lookup, then merges
+    popped lowest (rank, left position) first and re-checked for staleness the way bpe_merge's size test does."""
+
+    def __init__(self, vocab, merges):
+        self.ids = {}
+        for i, t in enumerate(vocab):
+            self.ids[t] = i
+        self.ranks = {}
+        for i, m in enumerate(merges):
+            a, b = m.split(" ")
+            self.ranks[(a, b)] = i
+
+    def tokenize(self, text):
+        out = []
+        space_prior = False
+        for chunk in _split_keep(text, " "):
+            if chunk != " ":
+                self._piece(("Ġ" + chunk) if space_prior else chunk, out)
+            else:
+                space_prior = True
+        return out
+
+    def _piece(self, chunk, out):
+        import heapq
+        if chunk in self.ids:
+            out.append(self.ids[chunk])
+            return
+        raw = chunk.encode("utf-8")
+        parts = []  # [pos, size, prev, next]
+        i = 0
+        while i < len(raw):
+            n = 1
+            while i + n < len(raw) and (raw[i + n] & 0xC0) == 0x80:
+                n += 1
+            parts.append([i, n, len(parts) - 1, -1])
+            i += n
+        for k in range(len(parts) - 1):
+            parts[k][3] = k + 1
+
+        def s(k):
+            return raw[parts[k][0]:parts[k][0] + parts[k][1]].decode("utf-8")
+
+        heap = []
+
+        def push(a, b):
+            r = self.ranks.get((s(a), s(b)))
+            if r is not None:
+                heapq.heappush(heap, (r, parts[a][0], a, b, parts[a][1] + parts[b][1]))
+
+        for k in range(len(parts) - 1):   # add_merges(only_forward = true)
+            push(k, k + 1)
+        while heap:
+            r, _, a, b, new_size = heapq.heappop(heap)
+            if parts[a][1] > 0 and parts[b][1] > 0 and new_size == parts[a][1] + parts[b][1] and parts[a][3] == b:
+                parts[a][1] += parts[b][1]
+                parts[b][1] = -1
+                parts[a][3] = parts[b][3]
+                if parts[a][3] >= 0:
+                    parts[parts[a][3]][2] = a
+                if parts[a][2] >= 0:
+                    push(parts[a][2], a)
+                if parts[a][3] >= 0:
+                    push(a, parts[a][3])
+        k = 0
+        while k >= 0:
+            out.append(self.ids.get(s(k), 0))
+            k = parts[k][3]
+
+
+def _split_keep(text, sep):
+    """split(text, " ", true) of the reference's util: pieces and the separators between them, empty pieces dropped"""
+    out, cur = [], ""
+    for ch in text:
+        if ch == sep:
+            if cur:
+                out.append(cur)
+                cur = ""
+            out.append(sep)
+        else:
+            cur += ch
+    if cur:
+        out.append(cur)
+    return out

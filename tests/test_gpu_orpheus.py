@@ -77,3 +77,52 @@ def test_orpheus_3b_layer_shapes():
     lg2, _ = eng.decode([int(ref.argmax())], 20)
     assert relerr(lg2, o.decode([int(ref.argmax())], 20)) < 2e-3
     eng.close()
+
+
+def test_orpheus_runner_generates_through_both_contexts(tmp_path):
+    """runner_from_file on an Orpheus GGUF (orpheus.* + snac.* + byte-pair vocabulary): prompt framing (model.cpp:341-356),
+    greedy generate_from_batch (:378-392), 7 ids -> 3 SNAC levels (:358-376), SNAC decode — equal to the oracle pipeline."""
+    import os
+    import tokenizer_oracle
+    from tts_cpp_amd import runner
+    full = synth.SynthOrpheusFull(max_gen=28)
+    path = full.write_gguf(str(tmp_path / "orpheus.gguf"))
+    os.environ["TTS_SNAC_NO_NOISE"] = "1"     # the reference's noise comes from a process-wide engine; parity runs without it
+    try:
+        r = runner.Runner(path, sample=0)
+        assert r.arch == "orpheus" and r.sampling_rate == 24000.0
+        pcm = r.generate("hello the zebra", voice=b"zoe", sample=0)
+    finally:
+        del os.environ["TTS_SNAC_NO_NOISE"]
+    tok = tokenizer_oracle.BpeOracle(full.vocab_tokens, full.merges)
+    prompt = full.specials["pre"] + tok.tokenize("zoe: hello the zebra") + full.specials["app"]
+    assert r.last_tokens(0).tolist() == prompt
+    o = orc.OrpheusOracle(full.orpheus)
+    lg = o.decode(prompt, 0)
+    toks, pos = [], len(prompt)
+    while len(toks) < full.max_gen:
+        toks.append(int(lg.argmax()))
+        if toks[-1] == full.specials["stop"] or len(toks) >= full.max_gen:
+            break
+        lg = o.decode([toks[-1]], pos)
+        pos += 1
+    got = r.last_tokens(1).tolist()
+    assert got == toks
+    heads = [0, 1, 2, 2, 1, 2, 2]
+    levels = [[], [], []]
+    for i in range(len(toks) // 7):
+        for ii in range(7):
+            levels[heads[ii]].append(toks[i * 7 + ii] - full.audio_offset)
+    T = len(levels[2])
+    ref = orc.SnacOracle(full.snac).decode(np.array(levels[0] + levels[1] + levels[2], dtype=np.uint32), T, None)
+    assert pcm.shape == ref.shape == (T * full.scfg.hop,)
+    assert np.abs(pcm - ref).max() < 1e-4
+    # with the noise block active the audio differs and stays a tanh output
+    noisy = r.generate("hello the zebra", voice=b"zoe", sample=0)
+    assert noisy.shape == pcm.shape and np.abs(noisy).max() <= 1.0 and not np.array_equal(noisy, pcm)
+    # sampling goes through the host sampler (156 940 logits in the real model; the device sampler stops at 2048)
+    sampled = r.generate("hello the zebra", voice=b"zoe", sample=1, top_k=8, seed=3)
+    assert sampled.size % full.scfg.hop == 0 and np.isfinite(sampled).all()
+    with pytest.raises(runner.RunnerError):
+        r.generate("hello", voice=b"nobody", sample=0)
+    r.close()

@@ -234,3 +234,27 @@ def test_device_pool_conditional_prompt_task():
 def test_device_pool_reports_load_failure():
     with pytest.raises(runner.RunnerError):
         runner.Pool("/nonexistent/model.gguf", n_workers=2, max_batch=2)
+
+
+def test_bpe_tokenizer_matches_python_restatement(tmp_path):
+    """host/tokenizer.cpp bpe_tokenizer (Orpheus; src/tokenizer.cpp:209-296) against oracle/tokenizer_oracle.BpeOracle on a
+    synthetic merge table: whole-piece hits, rank order, equal-rank position ties, the sticky "Ġ" prefix, UTF-8 symbols,
+    unknown symbols -> id 0."""
+    import ctypes as C
+    import tokenizer_oracle
+    from tts_cpp_amd import gguf as gg
+    vocab = ["<unk>", "a", "b", "c", "d", "e", "Ġ", "ab", "abc", "bc", "cd", "Ġa", "Ġab", "é", "éa", "hello", "Ġhello", "de", "cde", "dd", "ddd"]
+    merges = ["a b", "ab c", "b c", "c d", "Ġ a", "Ġa b", "é a", "d e", "c de", "d d", "dd d"]
+    path = str(tmp_path / "bpe.gguf")
+    gg.write(path, [("general.architecture", gg.T_STR, "orpheus"), ("tokenizer.ggml.tokens", gg.T_ARR, (gg.T_STR, vocab)),
+                    ("tokenizer.ggml.merges", gg.T_ARR, (gg.T_STR, merges)), ("tokenizer.ggml.bos_token_id", gg.T_U32, 0),
+                    ("tokenizer.ggml.eos_token_id", gg.T_U32, 1)], [])
+    o = tokenizer_oracle.BpeOracle(vocab, merges)
+    L = runner.load_lib()
+    for text in ["abc", "ab cd", "hello hello", "abcd abcd", "éab x", "a  b", " a", "dddd cde", "bcde", "", "zzz", "dédé abc"]:
+        out = (C.c_uint32 * 64)()
+        n = L.tts_c_tokenize(path.encode(), text.encode("utf-8"), out, 64)
+        assert n >= 0, L.tts_c_last_error()
+        assert list(out[:n]) == o.tokenize(text), text
+    assert o.tokenize("abc") == [8]                 # whole-piece hit
+    assert o.tokenize("hello hello") == [15, 16]    # "Ġ" prefix after the first space

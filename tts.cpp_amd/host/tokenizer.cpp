@@ -107,3 +107,78 @@ unigram_tokenizer * unigram_tokenizer_from_gguf(const gguf_file & meta) {
     if (auto e = meta.get("tokenizer.ggml.eos_token_id")) t->eos_token = (uint32_t) e->u;
     return t;
 }
+
+// ---- byte-pair tokenizer (Orpheus) ---------------------------------------------------------------------------
+void bpe_tokenizer::tokenize(const std::string & text, std::vector<uint32_t> & token_ids) const {
+    bool   space_prior = false;
+    size_t i = 0;
+    while (i < text.size()) {
+        if (text[i] == ' ') { space_prior = true; i++; continue; }
+        size_t j = text.find(' ', i);
+        if (j == std::string::npos) j = text.size();
+        const std::string chunk = text.substr(i, j - i);
+        piece(space_prior ? "\xC4\xA0" + chunk : chunk, token_ids);   // "Ġ"
+        i = j;
+    }
+}
+
+void bpe_tokenizer::piece(const std::string & chunk, std::vector<uint32_t> & token_ids) const {
+    auto whole = tokens_to_ids.find(chunk);
+    if (whole != tokens_to_ids.end()) { token_ids.push_back(whole->second); return; }
+    // symbols = UTF-8 characters; links make merged-away symbols skippable
+    struct sym { size_t pos, size; int prev, next; bool live; };
+    std::vector<sym> syms;
+    for (size_t i = 0; i < chunk.size();) {
+        size_t n = 1;
+        while (i + n < chunk.size() && ((unsigned char) chunk[i + n] & 0xC0) == 0x80) n++;
+        syms.push_back({i, n, (int) syms.size() - 1, -1, true});
+        i += n;
+    }
+    for (size_t k = 0; k + 1 < syms.size(); k++) syms[k].next = (int) k + 1;
+    auto str = [&](int k) { return chunk.substr(syms[(size_t) k].pos, syms[(size_t) k].size); };
+    // lowest rank first; equal ranks: the pair whose left symbol starts first (bpe_merge_comp, tokenizer.cpp:231-233)
+    for (;;) {
+        int best = -1, best_rank = 0;
+        for (int k = 0; k >= 0 && k < (int) syms.size(); k = syms[(size_t) k].next) {
+            const int nx = syms[(size_t) k].next;
+            if (nx < 0) break;
+            auto r = ranks.find(str(k) + " " + str(nx));
+            if (r != ranks.end() && (best < 0 || r->second < best_rank)) { best = k; best_rank = r->second; }
+        }
+        if (best < 0) break;
+        sym & a = syms[(size_t) best];
+        sym & b = syms[(size_t) a.next];
+        a.size += b.size;
+        b.live = false;
+        a.next = b.next;
+        if (a.next >= 0) syms[(size_t) a.next].prev = best;
+    }
+    for (int k = 0; k >= 0 && k < (int) syms.size(); k = syms[(size_t) k].next) {
+        auto it = tokens_to_ids.find(str(k));
+        token_ids.push_back(it == tokens_to_ids.end() ? 0u : it->second);
+        if (syms[(size_t) k].next < 0) break;
+    }
+}
+
+bpe_tokenizer * bpe_tokenizer_from_gguf(const gguf_file & meta) {
+    const gguf_value * toks = meta.get("tokenizer.ggml.tokens");
+    const gguf_value * merges = meta.get("tokenizer.ggml.merges");
+    const gguf_value * eos = meta.get("tokenizer.ggml.eos_token_id");
+    const gguf_value * bos = meta.get("tokenizer.ggml.bos_token_id");
+    if (!toks) TTS_ABORT("The 'tokenizer.ggml.tokens' key must be set in order to support BPE tokenization.\n");
+    if (!merges) TTS_ABORT("The 'tokenizer.ggml.merges' key must be set in order to support BPE tokenization.\n");
+    if (!eos) TTS_ABORT("The 'tokenizer.ggml.eos_token_id' key must be set in order to support BPE tokenization.\n");
+    if (!bos) TTS_ABORT("The 'tokenizer.ggml.bos_token_id' key must be set in order to support BPE tokenization.\n");
+    auto * t = new bpe_tokenizer;
+    t->bos_token_id = (uint32_t) bos->u;
+    t->eos_token_id = (uint32_t) eos->u;
+    for (size_t i = 0; i < toks->arr_s.size(); i++) t->tokens_to_ids[toks->arr_s[i]] = (uint32_t) i;
+    for (size_t i = 0; i < merges->arr_s.size(); i++) {
+        const std::string & m = merges->arr_s[i];
+        const size_t sp = m.find(' ');
+        if (sp == std::string::npos || m.find(' ', sp + 1) != std::string::npos)
+            TTS_ABORT("Invalid pair, '%s', found in BPE merges, 'tokenizer.ggml.merges', at index %zu.\n", m.c_str(), i);
+        t->ranks[m] = (int) i;
+    }
+    return t;
+}

@@ -29,3 +29,22 @@ struct unigram_tokenizer {
 };
 
 unigram_tokenizer * unigram_tokenizer_from_gguf(const gguf_file & meta);
+
+// Byte-pair tokenizer used by Orpheus (reference: bpe_tokenizer, /root/reference/src/tokenizer.h:141-150,
+// tokenizer.cpp:209-296).  Behaviour: the text is cut at single spaces; every piece after the first space is
+// prefixed with "Ġ" (the flag is never cleared, tokenizer.cpp:265-275); a piece that is a vocabulary entry is emitted
+// whole; otherwise it is split into UTF-8 characters and adjacent pairs are merged lowest rank first, ties by
+// position (tokenizer.cpp:231-263); a symbol that is not in the vocabulary maps to id 0 (operator[] on the map, :286).
+struct bpe_tokenizer {
+    std::unordered_map<std::string, uint32_t> tokens_to_ids;
+    std::unordered_map<std::string, int>      ranks;   // "left right" -> merge rank
+    uint32_t bos_token_id = 0, eos_token_id = 0;
+
+    void tokenize(const std::string & text, std::vector<uint32_t> & token_ids) const;
+
+  private:
+    void piece(const std::string & chunk, std::vector<uint32_t> & token_ids) const;
+};
+
+// tokenizer.ggml.{tokens,merges,bos_token_id,eos_token_id} (tokenizer.cpp:298-331); every key is required
+bpe_tokenizer * bpe_tokenizer_from_gguf(const gguf_file & meta);

@@ -7,6 +7,7 @@
 
 #include "common.h"
 #include "gguf.h"
+#include "orpheus_runner.h"
 #include "parler_runner.h"
 #include "sampler.h"
 #include "tokenizer.h"
@@ -87,9 +88,14 @@ const char * tts_c_arch(tts_c_runner * r) { return ((tts_generation_runner *) r)
 void         tts_c_free(tts_c_runner * r) { delete (tts_generation_runner *) r; }
 
 int tts_c_last_tokens(tts_c_runner * r, int which, uint32_t * out, int cap) {
-    auto * p = dynamic_cast<parler_runner *>((tts_generation_runner *) r);
-    if (!p) { g_c_err = "not a parler runner"; return -1; }
-    const std::vector<uint32_t> & v = which == 0 ? p->last_prompt_tokens : (which == 2 ? p->last_conditional_tokens : p->last_output_tokens);
+    static const std::vector<uint32_t> none;
+    const std::vector<uint32_t> * vp = nullptr;
+    if (auto * p = dynamic_cast<parler_runner *>((tts_generation_runner *) r))
+        vp = which == 0 ? &p->last_prompt_tokens : (which == 2 ? &p->last_conditional_tokens : &p->last_output_tokens);
+    else if (auto * o = dynamic_cast<orpheus_runner *>((tts_generation_runner *) r))
+        vp = which == 0 ? &o->last_prompt_tokens : (which == 1 ? &o->last_output_tokens : &none);
+    if (!vp) { g_c_err = "runner keeps no token record"; return -1; }
+    const std::vector<uint32_t> & v = *vp;
     const int n = (int) v.size();
     if (out) memcpy(out, v.data(), (size_t) (n < cap ? n : cap) * 4);
     return n;
@@ -101,10 +107,15 @@ int tts_c_tokenize(const char * gguf_path, const char * text, uint32_t * out, in
         std::string err;
         auto f = gguf_file::open(gguf_path, err);
         if (!f) { g_c_err = err; return -1; }
-        std::unique_ptr<unigram_tokenizer> t(unigram_tokenizer_from_gguf(*f));
         std::vector<uint32_t> ids;
-        t->tokenize(text, ids);
-        ids.push_back(t->eos_token);  // batch_from_sentence appends EOS (model.cpp:478)
+        if (f->get("tokenizer.ggml.merges")) {   // byte-pair vocabulary (Orpheus): the bare token ids, no framing
+            std::unique_ptr<bpe_tokenizer> t(bpe_tokenizer_from_gguf(*f));
+            t->tokenize(text, ids);
+        } else {
+            std::unique_ptr<unigram_tokenizer> t(unigram_tokenizer_from_gguf(*f));
+            t->tokenize(text, ids);
+            ids.push_back(t->eos_token);  // batch_from_sentence appends EOS (model.cpp:478)
+        }
         const int n = (int) ids.size();
         if (out) memcpy(out, ids.data(), (size_t) (n < cap ? n : cap) * 4);
         return n;

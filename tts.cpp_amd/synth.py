@@ -608,3 +608,52 @@ class SynthOrpheus:
 
 def build_orpheus(cfg: OrpheusConfig) -> SynthOrpheus:
     return SynthOrpheus(cfg)
+
+
+class SynthOrpheusFull:
+    """One GGUF as the Orpheus converter writes it: orpheus.* + snac.* tensors, byte-pair vocabulary, and the framing
+    constants as extension keys so that a small synthetic vocabulary can carry them (the reference hard-codes
+    128259 / 128000 / ... / 128266 / 4096, orpheus/model.cpp:8-9,371).  lm_head rows outside the audio-token range are
+    zero, so greedy decoding always lands on a valid SNAC code."""
+
+    def __init__(self, ocfg: OrpheusConfig = None, scfg: SnacConfig = None, max_gen=28):
+        scfg = scfg or snac_tiny()
+        letters = list("abcdefghijklmnopqrstuvwxyz")
+        text_vocab = ["<unk>"] + letters + ["Ġ", ":", "th", "he", "the", "Ġthe", "Ġa", "lo", "hel", "hello", "Ġhello", "zo", "zoe"]
+        merges = ["t h", "h e", "th e", "Ġ the", "Ġ a", "l o", "he l", "hel lo", "Ġ hello", "z o", "zo e"]
+        n_text = len(text_vocab)
+        self.specials = dict(pre=[n_text, n_text + 1], app=[n_text + 2, n_text + 3, n_text + 4, n_text + 5], stop=n_text + 6)
+        self.audio_offset = n_text + 8
+        vocab = self.audio_offset + scfg.cb_size + 3
+        ocfg = ocfg or orpheus_tiny(vocab=vocab, ctx=64 + max_gen)
+        assert ocfg.vocab == vocab
+        self.cfg, self.scfg, self.max_gen = ocfg, scfg, max_gen
+        self.orpheus = SynthOrpheus(ocfg)
+        head = self.orpheus.by_name["orpheus.lm_head"].to_f32().copy()
+        head[: self.audio_offset] = 0.0
+        head[self.audio_offset + scfg.cb_size:] = 0.0
+        ne = self.orpheus.by_name["orpheus.lm_head"].ne
+        if ocfg.weight_type in (gguf.Q4_0, gguf.Q5_0, gguf.Q8_0):
+            new_head = gguf.Tensor("orpheus.lm_head", ocfg.weight_type, ne, quantize(head, ocfg.weight_type).tobytes())
+        else:
+            new_head = gguf.Tensor.from_array("orpheus.lm_head", head, ocfg.weight_type)
+        self.orpheus.tensors = [new_head if t.name == "orpheus.lm_head" else t for t in self.orpheus.tensors]
+        self.orpheus.by_name = {t.name: t for t in self.orpheus.tensors}
+        self.snac = SynthSnac(scfg)
+        self.tensors = self.orpheus.tensors + self.snac.tensors
+        self.vocab_tokens = text_vocab + [f"<s{i}>" for i in range(vocab - n_text)]
+        self.merges = merges
+        U32, STR, ARR = gguf.T_U32, gguf.T_STR, gguf.T_ARR
+        self.kv = [kv for kv in self.orpheus.kv if kv[0] != "orpheus.stopping_token_id"] + [kv for kv in self.snac.kv if kv[0] != "general.architecture"] + [
+            ("orpheus.stopping_token_id", U32, self.specials["stop"]),
+            ("orpheus.max_context_length", U32, 64), ("orpheus.max_generation_size", U32, max_gen),
+            ("orpheus.audio_token_offset", U32, self.audio_offset), ("orpheus.audio_token_stride", U32, 0),
+            ("orpheus.prepended_tokens", ARR, (U32, self.specials["pre"])), ("orpheus.appended_tokens", ARR, (U32, self.specials["app"])),
+            ("tokenizer.ggml.tokens", ARR, (STR, self.vocab_tokens)), ("tokenizer.ggml.merges", ARR, (STR, merges)),
+            ("tokenizer.ggml.bos_token_id", U32, n_text + 1), ("tokenizer.ggml.eos_token_id", U32, n_text + 7),
+        ]
+        self.by_name = {t.name: t for t in self.tensors}
+
+    def write_gguf(self, path):
+        gguf.write(path, self.kv, self.tensors)
+        return path
