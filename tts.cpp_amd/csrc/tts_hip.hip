@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -813,6 +814,15 @@ extern "C" int tts_hip_synchronize(tts_hip_ctx *c) {
 // ------------------------------------------------------------------------------------------------
 // kernel launch plumbing (+ optional per-class event timing)
 // ------------------------------------------------------------------------------------------------
+// hipFuncSetAttribute applies to the current device: remember per device (a host may drive several GPUs from one
+// process, e.g. device_pool), not per process
+static bool attr_needed(std::atomic<uint64_t> &done, int device) {
+    const uint64_t bit = 1ull << (device & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return false;
+    done.fetch_or(bit, std::memory_order_relaxed);
+    return true;
+}
+
 static bool prof_on(const tts_hip_ctx *c, int kclass) {
     return c->prof || (c->prof_light && kclass >= TTS_HIP_K_DAC_EMBED);
 }
@@ -881,10 +891,9 @@ static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
         lds = (lds + 15) & ~(size_t) 15;
     }
     if (nw > 1) lds += (size_t) ngs * nw * RB * 4 * 64 * 4;
-    static size_t attr_set = 0;
-    if (lds > attr_set) {
+    static std::atomic<uint64_t> attr{0};
+    if (lds > 48 * 1024 && attr_needed(attr, c->device)) {
         HIPCHK(hipFuncSetAttribute((const void *) gemm16_kernel<WT, PRO, EPI, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = 160 * 1024;
     }
     if (lds > 160 * 1024) return set_err("gemm16: LDS request %zu exceeds 160 KiB", lds);
     if (PRO == PRO_LN && a.K > 2048) return set_err("gemm16: LayerNorm prologue supports hidden sizes up to 2048 (got %d)", a.K);
@@ -918,10 +927,9 @@ static int launch_qgemm16(tts_hip_ctx *c, const QGemmArgs &qa) {
     const int nw = kc / 256;
     size_t lds = nw > 1 ? (size_t) nw * RB * 4 * 64 * 4 : 0;
     if (QPRO >= 1) lds += (((size_t) qa.g.R * kc + 15) & ~(size_t) 15) + (((size_t) qa.g.R * (kc / 32) * 4 + 15) & ~(size_t) 15);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};
+    if (attr_needed(attr, c->device)) {
         HIPCHK(hipFuncSetAttribute((const void *) qgemm16_kernel<EPI, RB, QPRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     hipLaunchKernelGGL((qgemm16_kernel<EPI, RB, QPRO>), dim3(qa.g.N / 16, qa.g.K / kc), dim3(nw * 64), lds, c->stream, qa);
     HIPCHK(hipGetLastError());
@@ -1063,10 +1071,9 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
     const bool wide = nsplit == 1 && c->NH * R < 128 && a.row_pos != nullptr;
     const int threads = wide ? 1024 : 256;
     const size_t lds = ((size_t) (threads / 16) * 66 + 16) * 4;
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};
+    if (attr_needed(attr, c->device)) {
         HIPCHK(hipFuncSetAttribute((const void *) attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     CHK(prof_begin(c, kclass, kv_bytes + 2.0 * R * c->H * 4, 0));
     hipLaunchKernelGGL(attn_kernel, dim3(c->NH, R, nsplit), dim3(threads), lds, c->stream, a);
@@ -1907,10 +1914,9 @@ static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a_in, int nz) {
     ConvArgs a = a_in;
     const size_t lds = dac_lds_request(c, ((size_t) 2 * WCH + 2 * (size_t) ((CI_T * xw + 3) & ~3)) * 4, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab);
     if (a.dil > 9) return set_err("conv1d_mfma: dilation %d > 9 unsupported", a.dil);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};
+    if (attr_needed(attr, c->device)) {
         HIPCHK(hipFuncSetAttribute((const void *) conv1d_mfma_kernel<KT, MI, NI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     const dim3 grid((a.L + T_T - 1) / T_T, (a.cout + CO_T - 1) / CO_T, nz);
     hipLaunchKernelGGL((conv1d_mfma_kernel<KT, MI, NI, WM, WN, CI_T>), grid, dim3(64 * WM * WN), lds, c->stream, a);
@@ -1926,10 +1932,9 @@ static int launch_conv_mfma16(tts_hip_ctx *c, const ConvArgs &a_in, int nz) {
     ConvArgs a = a_in;
     const size_t lds = dac_lds_request(c, ((size_t) 2 * WCH + 2 * (size_t) xw * XS) * 2, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab);
     if (a.dil > 9) return set_err("conv1d_mfma16: dilation %d > 9 unsupported", a.dil);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};
+    if (attr_needed(attr, c->device)) {
         HIPCHK(hipFuncSetAttribute((const void *) conv1d_mfma16_kernel<KT, MI, NI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     const dim3 grid((a.L + T_T - 1) / T_T, (a.cout + CO_T - 1) / CO_T, nz);
     hipLaunchKernelGGL((conv1d_mfma16_kernel<KT, MI, NI, WM, WN, CI_T>), grid, dim3(64 * WM * WN), lds, c->stream, a);
@@ -1943,10 +1948,9 @@ static int launch_convt_mfma16(tts_hip_ctx *c, const ConvTArgs &a_in, int nz) {
     const int cin_pad = (a_in.cin + CI_T - 1) / CI_T * CI_T;
     ConvTArgs a = a_in;
     const size_t lds = dac_lds_request(c, ((size_t) 2 * WCH + 2 * (size_t) (TI_T + 1) * XS) * 2, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};
+    if (attr_needed(attr, c->device)) {
         HIPCHK(hipFuncSetAttribute((const void *) convt1d_mfma16_kernel<S, MI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     const dim3 grid((a.L + 1 + TI_T - 1) / TI_T, (a.cout + CO_T - 1) / CO_T, nz);  // ti runs 0..L inclusive
     hipLaunchKernelGGL((convt1d_mfma16_kernel<S, MI, WM, WN, CI_T>), grid, dim3(64 * WM * WN), lds, c->stream, a);
@@ -2015,10 +2019,9 @@ static int launch_convt_mfma(tts_hip_ctx *c, const ConvTArgs &a_in, int nz) {
     const int cin_pad = (a_in.cin + CI_T - 1) / CI_T * CI_T;
     ConvTArgs a = a_in;
     const size_t lds = dac_lds_request(c, ((size_t) 2 * WCH + 2 * (size_t) ((CI_T * (TI_T + 1) + 3) & ~3)) * 4, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};
+    if (attr_needed(attr, c->device)) {
         HIPCHK(hipFuncSetAttribute((const void *) convt1d_mfma_kernel<S, MI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     const dim3 grid((a.L + 1 + TI_T - 1) / TI_T, (a.cout + CO_T - 1) / CO_T, nz);  // ti runs 0..L inclusive
     hipLaunchKernelGGL((convt1d_mfma_kernel<S, MI, WM, WN, CI_T>), grid, dim3(64 * WM * WN), lds, c->stream, a);
