@@ -97,6 +97,23 @@ void tts_c_pool_free(tts_c_pool *pool);
 int tts_c_gguf_summary(const char *path, uint64_t *n_tensors, uint64_t *n_kv, uint64_t *data_offset, char *arch, int arch_cap);
 int tts_c_gguf_tensor(const char *path, int index, char *name, int name_cap, int *type, int64_t ne[4], uint64_t *checksum);
 
+/* ---- the quantize tool (examples/quantize/quantize_impl.h:5-15: quantization_params + quantize_gguf) ------------
+ * Host only.  quantize_type is the ggml type number (F16 1, Q4_0 2, Q5_0 6, Q8_0 8; quantize.cpp:11-20). */
+typedef struct tts_c_quantization_params {
+    uint32_t n_threads;
+    int      quantize_type;
+    int      quantize_output_heads;
+    int      quantize_text_embeddings;
+    int      quantize_cross_attn_kv;
+    int      convert_dac_to_f16;
+    int      convert_non_quantizable_to_f16;
+} tts_c_quantization_params;
+int tts_c_quantize_gguf(const char *ifile, const char *ofile, const tts_c_quantization_params *params);  /* 0 / -1 */
+/* the allow-list decision for one tensor name: 0 copied, 1 quantised to quantize_type, 2 converted to F16, -1 error */
+int tts_c_quantize_decision(const char *arch, const char *tensor_name, int n_dims, const tts_c_quantization_params *params);
+/* one call of the row quantisers (n values, n % 32 == 0 for the block types); returns bytes written or -1 */
+int64_t tts_c_quantize_rows(int type, const float *src, void *dst, int64_t n_per_row, int64_t nrows, uint32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

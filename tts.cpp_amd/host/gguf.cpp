@@ -107,8 +107,9 @@ std::shared_ptr<gguf_file> gguf_file::open(const char * path, std::string & err)
     const uint64_t n_tensors = c.rd<uint64_t>();
     const uint64_t n_kv = c.rd<uint64_t>();
     for (uint64_t i = 0; i < n_kv && c.ok; i++) {
-        std::string key = c.str();
-        gguf_value  v;
+        const size_t rec_begin = (size_t) (c.p - base);
+        std::string  key = c.str();
+        gguf_value   v;
         v.type = (gguf_vtype) c.rd<uint32_t>();
         if (v.type == GGUF_STR) {
             v.s = c.str();
@@ -127,6 +128,7 @@ std::shared_ptr<gguf_file> gguf_file::open(const char * path, std::string & err)
         } else if (!read_scalar(c, v.type, v)) {
             c.ok = false;
         }
+        f->kv_order.push_back({key, rec_begin, (size_t) (c.p - base)});
         f->kv.emplace(std::move(key), std::move(v));
     }
     if (!c.ok) { err = "truncated or corrupt GGUF metadata"; return nullptr; }

@@ -31,11 +31,14 @@ struct gguf_file {
     std::vector<uint8_t>                        owned;  // OLLAMA_NO_MMAP: file read into memory instead (loaders.cpp:45)
     uint32_t                                    version = 0;
     std::unordered_map<std::string, gguf_value> kv;
+    struct kv_span { std::string key; size_t begin, end; };  // byte range of one key/value record in the file
+    std::vector<kv_span>                        kv_order;      // file order (a rewriter copies records verbatim)
     std::vector<gguf_tensor_view>               tensors;
     std::vector<std::string>                    tensor_names;  // owns the name strings
     size_t                                      data_offset = 0;
 
     ~gguf_file();
+    const uint8_t * base() const { return map ? (const uint8_t *) map : owned.data(); }
     static std::shared_ptr<gguf_file> open(const char * path, std::string & err);
 
     int find_key(const std::string & key) const { return kv.count(key) ? 1 : -1; }

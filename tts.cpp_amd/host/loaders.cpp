@@ -1,34 +1,12 @@
 // loaders.cpp — architecture registry + runner_from_file (mirrors /root/reference/src/models/loaders.cpp:13-95)
 #include <cmath>
-#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <stdexcept>
 #include <unordered_map>
 
 #include "common.h"
 #include "gguf.h"
-
-const std::map<std::string, tts_arch> SUPPORTED_ARCHITECTURES = {
-    {"parler-tts", PARLER_TTS_ARCH}, {"kokoro", KOKORO_ARCH}, {"dia", DIA_ARCH}, {"orpheus", ORPHEUS_ARCH}};
-const std::map<tts_arch, std::string> ARCHITECTURE_NAMES = {
-    {PARLER_TTS_ARCH, "parler-tts"}, {KOKORO_ARCH, "kokoro"}, {DIA_ARCH, "dia"}, {ORPHEUS_ARCH, "orpheus"}};
-
-bool g_tts_throw_on_abort = false;  // set by the C wrapper so that language bindings get an error instead of abort()
-
-void tts_abort(const char * file, int line, const char * fmt, ...) {
-    char    msg[2048];
-    va_list ap;
-    va_start(ap, fmt);
-    const int n = snprintf(msg, sizeof(msg), "%s:%d: ", file, line);
-    vsnprintf(msg + n, sizeof(msg) - (size_t) n, fmt, ap);
-    va_end(ap);
-    if (g_tts_throw_on_abort) throw std::runtime_error(msg);
-    fflush(stdout);
-    fputs(msg, stderr);
-    abort();  // util.cpp:14-22
-}
 
 static std::unordered_map<std::string, std::reference_wrapper<const tts_model_loader>> & registry() {
     static std::unordered_map<std::string, std::reference_wrapper<const tts_model_loader>> r;

@@ -172,6 +172,52 @@ int tts_c_gguf_tensor(const char * path, int index, char * name, int name_cap, i
 
 }  // extern "C"
 
+// ---- quantize tool (host/quantize.h) -------------------------------------------------------------------------
+#include "quantize.h"
+
+static quantization_params to_qp(const tts_c_quantization_params * p) {
+    quantization_params q;
+    q.n_threads = p->n_threads ? p->n_threads : 1;
+    q.quantize_type = p->quantize_type;
+    q.quantize_output_heads = p->quantize_output_heads != 0;
+    q.quantize_text_embeddings = p->quantize_text_embeddings != 0;
+    q.quantize_cross_attn_kv = p->quantize_cross_attn_kv != 0;
+    q.convert_dac_to_f16 = p->convert_dac_to_f16 != 0;
+    q.convert_non_quantizable_to_f16 = p->convert_non_quantizable_to_f16 != 0;
+    return q;
+}
+
+extern "C" int tts_c_quantize_gguf(const char * ifile, const char * ofile, const tts_c_quantization_params * params) {
+    g_tts_throw_on_abort = true;
+    try {
+        quantize_gguf(ifile, ofile, to_qp(params));
+        return 0;
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return -1;
+    }
+}
+
+extern "C" int tts_c_quantize_decision(const char * arch, const char * tensor_name, int n_dims, const tts_c_quantization_params * params) {
+    g_tts_throw_on_abort = true;
+    try {
+        return quantize_decision(arch, tensor_name, n_dims, to_qp(params));
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return -1;
+    }
+}
+
+extern "C" int64_t tts_c_quantize_rows(int type, const float * src, void * dst, int64_t n_per_row, int64_t nrows, uint32_t n_threads) {
+    g_tts_throw_on_abort = true;
+    try {
+        return (int64_t) quantize_rows(type, src, dst, n_per_row, nrows, n_threads ? n_threads : 1);
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return -1;
+    }
+}
+
 // ---- device pool (host/device_pool.h) ------------------------------------------------------------------------
 #include "device_pool.h"
 

@@ -16,6 +16,11 @@ class Config(C.Structure):
                 ("use_cross_attn", C.c_int), ("max_tokens", C.c_int), ("top_p", C.c_float), ("sample", C.c_int), ("seed", C.c_uint64)]
 
 
+class QuantizationParams(C.Structure):
+    _fields_ = [("n_threads", C.c_uint32), ("quantize_type", C.c_int), ("quantize_output_heads", C.c_int), ("quantize_text_embeddings", C.c_int),
+                ("quantize_cross_attn_kv", C.c_int), ("convert_dac_to_f16", C.c_int), ("convert_non_quantizable_to_f16", C.c_int)]
+
+
 class SamplerCfg(C.Structure):
     _fields_ = [("n_output_heads", C.c_uint32), ("vocab_size", C.c_uint32), ("top_k", C.c_uint32), ("temperature", C.c_float),
                 ("top_p", C.c_float), ("repetition_penalty", C.c_float), ("do_sample", C.c_int), ("seed", C.c_uint64)]
@@ -23,7 +28,8 @@ class SamplerCfg(C.Structure):
 
 EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_generate_batch", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
            "tts_c_last_error", "tts_c_update_conditional_prompt", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor",
-           "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_free"]
+           "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_free",
+           "tts_c_quantize_gguf", "tts_c_quantize_decision", "tts_c_quantize_rows"]
 
 _lib = None
 
@@ -59,6 +65,10 @@ def load_lib():
         L.tts_c_gguf_summary.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_int]
         L.tts_c_gguf_tensor.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
         L.tts_c_update_conditional_prompt.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.tts_c_quantize_gguf.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(QuantizationParams)]
+        L.tts_c_quantize_decision.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(QuantizationParams)]
+        L.tts_c_quantize_rows.restype = C.c_int64
+        L.tts_c_quantize_rows.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_int64, C.c_int64, C.c_uint32]
         L.tts_c_pool_create.restype = C.c_void_p
         L.tts_c_pool_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(Config)]
         L.tts_c_pool_submit.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Config)]
@@ -149,6 +159,40 @@ def tokenize(gguf_path, text):
     if n < 0:
         raise RunnerError(L.tts_c_last_error().decode())
     return out[:n].copy()
+
+
+def _qparams(qtype, n_threads=1, output_heads=False, text_embeddings=False, cross_attn_kv=False, dac_f16=False, non_quantizable_f16=False):
+    return QuantizationParams(n_threads, qtype, int(output_heads), int(text_embeddings), int(cross_attn_kv), int(dac_f16), int(non_quantizable_f16))
+
+
+def quantize_gguf(ifile, ofile, qtype, **flags):
+    """The quantize tool (examples/quantize): rewrites `ifile` with the allow-listed F32 tensors converted to `qtype`."""
+    L = load_lib()
+    p = _qparams(qtype, **flags)
+    if L.tts_c_quantize_gguf(str(ifile).encode(), str(ofile).encode(), C.byref(p)) != 0:
+        raise RunnerError(L.tts_c_last_error().decode("utf-8", "replace"))
+
+
+def quantize_decision(arch, name, n_dims, qtype, **flags):
+    L = load_lib()
+    p = _qparams(qtype, **flags)
+    r = L.tts_c_quantize_decision(arch.encode(), name.encode(), n_dims, C.byref(p))
+    if r < 0:
+        raise RunnerError(L.tts_c_last_error().decode("utf-8", "replace"))
+    return r
+
+
+def quantize_rows(qtype, arr, n_threads=1):
+    from . import gguf
+    L = load_lib()
+    a = np.ascontiguousarray(arr, dtype=np.float32)
+    a2 = a.reshape(-1, a.shape[-1])
+    out = np.zeros(gguf.nbytes(qtype, [a2.shape[1], a2.shape[0]]), dtype=np.uint8)
+    n = L.tts_c_quantize_rows(qtype, a2.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.c_void_p), a2.shape[1], a2.shape[0], n_threads)
+    if n < 0:
+        raise RunnerError(L.tts_c_last_error().decode("utf-8", "replace"))
+    assert n == out.size
+    return out
 
 
 class Pool:
