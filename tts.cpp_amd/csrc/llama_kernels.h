@@ -6,18 +6,19 @@
 //   llama_rope_kv_kernel   ggml_rope_ext(NEOX, frequency factors) on q and k, K/V cache append :186-221,248-251
 //   attn_gqa_kernel        mul_mat(k, q) -> soft_max_ext(causal, 1/sqrt(d)) -> mul_mat(kq, v), kv head = q head / rep :228-259
 //   silu_mul_kernel        silu(gate x) * (up x) :279
-// First version: one wave per row / per (head, row); written for parity, not yet for a roofline.
+//   argmax_parts/fold      sampler::max over the 156 940-logit vocabulary, two stages
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-__global__ void rms_fold_rows_kernel(float *x, int H, const float *w, float *y, int R, float eps, const float *parts, int n_parts, int64_t slab_stride) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (r >= R) return;
+// one workgroup (4 waves) per row
+__global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int H, const float *w, float *y, int R, float eps, const float *parts, int n_parts,
+                                                            int64_t slab_stride) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
     float *xr = x + (int64_t) r * H;
     float s = 0.0f;
-    for (int i = lane; i < H; i += 64) {
+    for (int i = threadIdx.x; i < H; i += 256) {
         float v = xr[i];
         if (parts) {
             for (int p = 0; p < n_parts; p++) v += parts[p * slab_stride + (int64_t) r * H + i];
@@ -26,27 +27,30 @@ __global__ void rms_fold_rows_kernel(float *x, int H, const float *w, float *y, 
         s += v * v;
     }
     s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
     const float scale = 1.0f / sqrtf(s / (float) H + eps);
-    for (int i = lane; i < H; i += 64) y[(int64_t) r * H + i] = xr[i] * scale * w[i];
+    for (int i = threadIdx.x; i < H; i += 256) y[(int64_t) r * H + i] = xr[i] * scale * w[i];   // xr[i] was written by this thread
 }
 
-// qkv [R][(NH + 2 NKV) * HD] (q | k | v).  One workgroup per row; thread = (head, pair i).
+// qkv [R][(NH + 2 NKV) * HD] (q | k | v).  One wave per (row, q or k head); lane = pair i (and i + 64, ... for HD > 128).
 // theta walks pos, pos*s, (pos*s)*s, ... in fp32 exactly like ggml_rope_cache_init (theta *= theta_scale), theta_scale =
-// powf(base, -2/HD) from the host; angle = theta / freq_factor[i]; NEOX pairing (i, i + HD/2).
-__global__ __launch_bounds__(256) void llama_rope_kv_kernel(float *qkv, const uint32_t *pos, const float *ff, float theta_scale, int NH, int NKV, int HD,
-                                                            float *kcache, float *vcache) {
-    const int r = blockIdx.x;
+// powf(base, -2/HD) from the host; angle = theta / freq_factor[i]; NEOX pairing (i, i + HD/2).  The k-head waves write the
+// rotated key into the cache and copy their head's slice of v next to it.
+__global__ __launch_bounds__(64) void llama_rope_kv_kernel(float *qkv, const uint32_t *pos, const float *ff, float theta_scale, int NH, int NKV, int HD,
+                                                           float *kcache, float *vcache) {
+    const int r = blockIdx.x, h = blockIdx.y;
     const int half = HD >> 1;
     const int ld = (NH + 2 * NKV) * HD, kvH = NKV * HD;
     float *row = qkv + (int64_t) r * ld;
     const uint32_t p = pos[r];
-    for (int idx = threadIdx.x; idx < (NH + NKV) * half; idx += blockDim.x) {
-        const int h = idx / half, i = idx - h * half;
+    float *v = row + (int64_t) h * HD;      // heads NH.. are the k heads (they follow q in the row)
+    for (int i = threadIdx.x; i < half; i += 64) {
         float theta = (float) p;
         for (int j = 0; j < i; j++) theta *= theta_scale;
         const float ang = theta / (ff ? ff[i] : 1.0f);
         const float cs = cosf(ang), sn = sinf(ang);
-        float *v = row + (int64_t) h * HD;      // heads NH.. are the k heads (they follow q in the row)
         const float x0 = v[i], x1 = v[i + half];
         const float y0 = x0 * cs - x1 * sn, y1 = x0 * sn + x1 * cs;
         if (h < NH) { v[i] = y0; v[i + half] = y1; }
@@ -55,46 +59,118 @@ __global__ __launch_bounds__(256) void llama_rope_kv_kernel(float *qkv, const ui
             kc[i] = y0; kc[i + half] = y1;
         }
     }
-    const float *vsrc = row + (int64_t) (NH + NKV) * HD;
-    for (int i = threadIdx.x; i < kvH; i += blockDim.x) vcache[(int64_t) p * kvH + i] = vsrc[i];
+    if (h >= NH) {
+        const float *vsrc = row + (int64_t) (NH + NKV) * HD + (int64_t) (h - NH) * HD;
+        float *vdst = vcache + (int64_t) p * kvH + (h - NH) * HD;
+        for (int i = threadIdx.x; i < HD; i += 64) vdst[i] = vsrc[i];
+    }
 }
 
-// one wave per (q head, row): lanes over keys for the scores, lanes over the head dims for the output
+// One workgroup (4 waves) per (q head, row).  Scores: 16 lanes per key, each lane 8 of the 128 dims (two 16-byte loads, a
+// key row is read as one contiguous 512 bytes), 16 keys per pass.  Softmax statistics over the block.  P.V: 8 groups of
+// 32 lanes walk the keys, a lane owns 4 consecutive output dims (16-byte loads, 512 contiguous bytes per key and group).
+extern __shared__ __align__(16) float attn_gqa_sm[];
 template <int HD>
-__global__ __launch_bounds__(64) void attn_gqa_kernel(const float *qkv, int ld, const uint32_t *pos, const float *kcache, const float *vcache, int NH, int NKV,
-                                                      float scale, float *out) {
-    extern __shared__ float sm[];   // [HD] q, then [T] probabilities
-    float *qs = sm, *ps = sm + HD;
-    const int h = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld, const uint32_t *pos, const float *kcache, const float *vcache, int NH, int NKV,
+                                                       float scale, float *out) {
+    static_assert(HD == 128, "lane mapping below is written for head_dim 128 (orpheus/model.h:28)");
+    __shared__ float red[8];
+    __shared__ float4 accs[8][HD / 4];
+    float *qs = attn_gqa_sm, *ps = attn_gqa_sm + HD;   // [HD] q, then [T] scores -> probabilities
+    const int h = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = (int) pos[r] + 1;
     const int kvH = NKV * HD, kh = h / (NH / NKV);
-    for (int e = lane; e < HD; e += 64) qs[e] = qkv[(int64_t) r * ld + h * HD + e];
+    if (tid < HD) qs[tid] = qkv[(int64_t) r * ld + h * HD + tid];
+    __syncthreads();
+    {
+        const int g = tid >> 4, sub = tid & 15;
+        const float4 q0 = *(const float4 *) (qs + sub * 4), q1 = *(const float4 *) (qs + 64 + sub * 4);
+        for (int j0 = 0; j0 < T; j0 += 16) {   // uniform trip count: every lane takes part in the shuffles
+            const int j = j0 + g;
+            float d = 0.0f;
+            if (j < T) {
+                const float4 *kr = (const float4 *) (kcache + (int64_t) j * kvH + kh * HD);
+                const float4 a = kr[sub], b = kr[16 + sub];
+                d = (a.x * q0.x + a.y * q0.y + a.z * q0.z + a.w * q0.w) + (b.x * q1.x + b.y * q1.y + b.z * q1.z + b.w * q1.w);
+            }
+            d += __shfl_xor(d, 8);
+            d += __shfl_xor(d, 4);
+            d += __shfl_xor(d, 2);
+            d += __shfl_xor(d, 1);
+            if (sub == 0 && j < T) ps[j] = d * scale;
+        }
+    }
     __syncthreads();
     float mx = -INFINITY;
-    for (int j = lane; j < T; j += 64) {
-        const float *kr = kcache + (int64_t) j * kvH + kh * HD;
-        float d = 0.0f;
-#pragma unroll 8
-        for (int e = 0; e < HD; e++) d += qs[e] * kr[e];
-        d *= scale;
-        ps[j] = d;
-        mx = fmaxf(mx, d);
-    }
+    for (int j = tid; j < T; j += 256) mx = fmaxf(mx, ps[j]);
     mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.0f;
-    for (int j = lane; j < T; j += 64) {
+    for (int j = tid; j < T; j += 256) {
         const float p = expf(ps[j] - mx);
         ps[j] = p;
         sum += p;
     }
     sum = wave_sum(sum);
-    __syncthreads();
-    const float inv = 1.0f / sum;
-    for (int e = lane; e < HD; e += 64) {
-        float acc = 0.0f;
-        for (int j = 0; j < T; j++) acc += (ps[j] * inv) * vcache[(int64_t) j * kvH + kh * HD + e];
-        out[(int64_t) r * NH * HD + h * HD + e] = acc;
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();   // probabilities and the four partial sums are in LDS
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    {
+        const int grp = tid >> 5, e4 = tid & 31;
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int j = grp; j < T; j += 8) {
+            const float p = ps[j];
+            const float4 v = *(const float4 *) (vcache + (int64_t) j * kvH + kh * HD + e4 * 4);
+            acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w;
+        }
+        accs[grp][e4] = acc;
     }
+    __syncthreads();
+    if (tid < HD) {
+        const float *a = (const float *) &accs[0][0];
+        float o = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 8; g++) o += a[g * HD + tid];
+        out[(int64_t) r * NH * HD + h * HD + tid] = o * inv;
+    }
+}
+
+// arg-max over a large vocabulary (156 940 logits), sampler::max semantics (src/sampler.cpp:185-204: the first maximum
+// wins).  Stage 1: ARGMAX_PARTS workgroups over contiguous chunks; stage 2: one wave folds the partial results.
+#define ARGMAX_PARTS 128
+__device__ __forceinline__ void argmax_merge(float &best, uint32_t &besti, float ov, uint32_t oi) {
+    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+}
+__global__ __launch_bounds__(256) void argmax_parts_kernel(const float *logits, int V, float *pv, uint32_t *pi) {
+    __shared__ float bv[4];
+    __shared__ uint32_t bi[4];
+    const int chunk = (V + ARGMAX_PARTS - 1) / ARGMAX_PARTS;
+    const int i0 = blockIdx.x * chunk, i1 = min(V, i0 + chunk);
+    float best = -INFINITY;
+    uint32_t besti = 0xffffffffu;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float v = logits[i];
+        if (v > best) { best = v; besti = (uint32_t) i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_merge(best, besti, __shfl_xor(best, o), __shfl_xor(besti, o));
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) argmax_merge(best, besti, bv[w], bi[w]);
+        pv[blockIdx.x] = best;
+        pi[blockIdx.x] = besti;
+    }
+}
+__global__ __launch_bounds__(64) void argmax_fold_kernel(const float *pv, const uint32_t *pi, uint32_t *token) {
+    float best = -INFINITY;
+    uint32_t besti = 0xffffffffu;
+    for (int i = threadIdx.x; i < ARGMAX_PARTS; i += 64) argmax_merge(best, besti, pv[i], pi[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_merge(best, besti, __shfl_xor(best, o), __shfl_xor(besti, o));
+    if (threadIdx.x == 0) token[0] = besti == 0xffffffffu ? 0u : besti;   // all -inf / NaN: index 0 like sampler::max
 }
 
 // gu [R][2F] (gate | up) -> g [R][F] = silu(gate) * up

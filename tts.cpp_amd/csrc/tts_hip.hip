@@ -1305,7 +1305,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->ad, (size_t) R * std::max(std::max(H, F), c->NH * (int) c->lm.head_dim) / 32 + 1));
         CHK(dmalloc(&c->l_ids, (size_t) R));
         CHK(dmalloc(&c->l_pos, (size_t) R));
-        CHK(dmalloc(&c->l_tok, (size_t) 1));
+        CHK(dmalloc(&c->l_tok, (size_t) 1 + 2 * ARGMAX_PARTS));
     }
     if (c->has_t5) {
         const int H = c->H, F = c->F, S = (int) c->t5.max_ctx_length;
@@ -2236,7 +2236,7 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
     const float theta_scale = powf(c->lm.rope_base, -2.0f / (float) HD);
     c->l_pending = 0;
     auto rms = [&](size_t w_off, int rows, float *x, float *y) {
-        hipLaunchKernelGGL(rms_fold_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, c->stream, x, H, f32(w_off), y, rows, 1e-5f,
+        hipLaunchKernelGGL(rms_fold_rows_kernel, dim3(rows), dim3(256), 0, c->stream, x, H, f32(w_off), y, rows, 1e-5f,
                            c->l_pending ? (const float *) c->l_parts : (const float *) nullptr, c->l_pending, (int64_t) c->RMAX * H);
         c->l_pending = 0;
         return hipGetLastError() == hipSuccess ? 0 : set_err("rms_fold_rows_kernel launch failed");
@@ -2246,9 +2246,9 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
         float *kc = c->l_kc + (size_t) l * NCTX * c->l_kvH, *vc = c->l_vc + (size_t) l * NCTX * c->l_kvH;
         CHK(rms(y.in_norm, n, c->l_x, c->l_xn));
         CHK(llama_gemm(c, y.qkv, c->l_xn, H, c->l_qkv, QKV, n, EPI_STORE));
-        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n), dim3(256), 0, c->stream, c->l_qkv, (const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, HD, kc, vc);
+        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH + NKV), dim3(64), 0, c->stream, c->l_qkv, (const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, HD, kc, vc);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, n), dim3(64), (size_t) (128 + pos0 + n) * 4, c->stream, (const float *) c->l_qkv, QKV, (const uint32_t *) c->l_pos,
+        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, n), dim3(256), (size_t) (128 + pos0 + n) * 4, c->stream, (const float *) c->l_qkv, QKV, (const uint32_t *) c->l_pos,
                            (const float *) kc, (const float *) vc, NH, NKV, 1.0f / sqrtf((float) HD), c->l_att);
         HIPCHK(hipGetLastError());
         CHK(llama_gemm(c, y.o, c->l_att, NH * HD, c->l_x, H, n, EPI_RESID));
@@ -2283,7 +2283,12 @@ extern "C" int tts_hip_orpheus_decode(tts_hip_ctx *c, const uint32_t *ids, uint3
         done += m;
     }
     if (token_out) {
-        hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(256), 0, c->stream, (const float *) c->l_logits, c->l_V, c->l_tok);
+        // l_tok: [0] the token, [1..] stage-1 indices, then stage-1 maxima
+        uint32_t *pi = c->l_tok + 1;
+        float *pv = (float *) (c->l_tok + 1 + ARGMAX_PARTS);
+        hipLaunchKernelGGL(argmax_parts_kernel, dim3(ARGMAX_PARTS), dim3(256), 0, c->stream, (const float *) c->l_logits, c->l_V, pv, pi);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(argmax_fold_kernel, dim3(1), dim3(64), 0, c->stream, (const float *) pv, (const uint32_t *) pi, c->l_tok);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(token_out, c->l_tok, 4, hipMemcpyDeviceToHost, c->stream));
     }
