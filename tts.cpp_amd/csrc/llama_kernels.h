@@ -164,13 +164,20 @@ __global__ __launch_bounds__(256) void argmax_parts_kernel(const float *logits, 
         pi[blockIdx.x] = besti;
     }
 }
-__global__ __launch_bounds__(64) void argmax_fold_kernel(const float *pv, const uint32_t *pi, uint32_t *token) {
+// hist / next_id / next_pos (optional): the device-resident greedy loop feeds the token straight back as the next input
+__global__ __launch_bounds__(64) void argmax_fold_kernel(const float *pv, const uint32_t *pi, uint32_t *token, uint32_t *hist, uint32_t *next_id,
+                                                         uint32_t *next_pos) {
     float best = -INFINITY;
     uint32_t besti = 0xffffffffu;
     for (int i = threadIdx.x; i < ARGMAX_PARTS; i += 64) argmax_merge(best, besti, pv[i], pi[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) argmax_merge(best, besti, __shfl_xor(best, o), __shfl_xor(besti, o));
-    if (threadIdx.x == 0) token[0] = besti == 0xffffffffu ? 0u : besti;   // all -inf / NaN: index 0 like sampler::max
+    if (threadIdx.x == 0) {
+        const uint32_t t = besti == 0xffffffffu ? 0u : besti;   // all -inf / NaN: index 0 like sampler::max
+        token[0] = t;
+        if (hist) hist[0] = t;
+        if (next_id) { next_id[0] = t; next_pos[0] += 1; }
+    }
 }
 
 // gu [R][2F] (gate | up) -> g [R][F] = silu(gate) * up

@@ -24,6 +24,7 @@
 #include "parler_kernels.h"
 #include "t5_kernels.h"
 #include "llama_kernels.h"
+#define LLAMA_GREEDY_CHUNK 8
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -1305,7 +1306,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->ad, (size_t) R * std::max(std::max(H, F), c->NH * (int) c->lm.head_dim) / 32 + 1));
         CHK(dmalloc(&c->l_ids, (size_t) R));
         CHK(dmalloc(&c->l_pos, (size_t) R));
-        CHK(dmalloc(&c->l_tok, (size_t) 1 + 2 * ARGMAX_PARTS));
+        CHK(dmalloc(&c->l_tok, (size_t) 1 + 2 * ARGMAX_PARTS + LLAMA_GREEDY_CHUNK));
     }
     if (c->has_t5) {
         const int H = c->H, F = c->F, S = (int) c->t5.max_ctx_length;
@@ -2217,20 +2218,25 @@ static int llama_gemm(tts_hip_ctx *c, const W &w, const float *A, int lda, float
 }
 
 // one call of orpheus_runner::decode: n rows (<= RMAX) at pos0..; leaves the final-normed last row's logits in l_logits
+// ids == nullptr: one row whose token id and position are already in l_ids[0] / l_pos[0] (the device-resident greedy loop)
 static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t pos0) {
     const int H = c->H, F = c->F, NH = c->NH, NKV = (int) c->lm.n_kv_heads, HD = (int) c->lm.head_dim;
     const int QKV = (NH + 2 * NKV) * HD, NCTX = (int) c->lm.n_ctx;
     if (n < 1 || n > c->RMAX) return set_err("tts_hip_orpheus_decode: %d tokens per call outside 1..%d", n, c->RMAX);
     if (pos0 + (uint32_t) n > (uint32_t) NCTX) return set_err("tts_hip_orpheus_decode: positions up to %u exceed the %d cached positions", pos0 + n, NCTX);
-    std::vector<uint32_t> hp((size_t) n);
-    for (int i = 0; i < n; i++) {
-        if (ids[i] >= (uint32_t) c->l_V) return set_err("tts_hip_orpheus_decode: token id %u >= vocabulary %d", ids[i], c->l_V);
-        hp[(size_t) i] = pos0 + (uint32_t) i;
-    }
     auto f32 = [&](size_t off) { return (const float *) (c->arena + off); };
-    HIPCHK(hipMemcpyAsync(c->l_ids, ids, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->l_pos, hp.data(), (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));  // hp is a local
+    if (ids) {
+        std::vector<uint32_t> hp((size_t) n);
+        for (int i = 0; i < n; i++) {
+            if (ids[i] >= (uint32_t) c->l_V) return set_err("tts_hip_orpheus_decode: token id %u >= vocabulary %d", ids[i], c->l_V);
+            hp[(size_t) i] = pos0 + (uint32_t) i;
+        }
+        HIPCHK(hipMemcpyAsync(c->l_ids, ids, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->l_pos, hp.data(), (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));  // hp is a local
+    } else if (n != 1) {
+        return set_err("llama_forward: device-resident inputs carry one row");
+    }
     hipLaunchKernelGGL(t5_embed_kernel, dim3(n), dim3(256), 0, c->stream, f32(c->l_embd), (const uint32_t *) c->l_ids, H, c->l_x);
     HIPCHK(hipGetLastError());
     const float theta_scale = powf(c->lm.rope_base, -2.0f / (float) HD);
@@ -2288,7 +2294,8 @@ extern "C" int tts_hip_orpheus_decode(tts_hip_ctx *c, const uint32_t *ids, uint3
         float *pv = (float *) (c->l_tok + 1 + ARGMAX_PARTS);
         hipLaunchKernelGGL(argmax_parts_kernel, dim3(ARGMAX_PARTS), dim3(256), 0, c->stream, (const float *) c->l_logits, c->l_V, pv, pi);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(argmax_fold_kernel, dim3(1), dim3(64), 0, c->stream, (const float *) pv, (const uint32_t *) pi, c->l_tok);
+        hipLaunchKernelGGL(argmax_fold_kernel, dim3(1), dim3(64), 0, c->stream, (const float *) pv, (const uint32_t *) pi, c->l_tok, (uint32_t *) nullptr,
+                           (uint32_t *) nullptr, (uint32_t *) nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(token_out, c->l_tok, 4, hipMemcpyDeviceToHost, c->stream));
     }
@@ -2303,13 +2310,38 @@ extern "C" int tts_hip_orpheus_generate_greedy(tts_hip_ctx *c, const uint32_t *p
     *n_out = 0;
     uint32_t tok = 0, pos = n_prompt;
     CHK(tts_hip_orpheus_decode(c, prompt, n_prompt, 0, nullptr, &tok));
-    // generate_from_batch (:378-392): stop once the last token is the stopping token or max_generation_size ids exist
+    // generate_from_batch (:378-392): stop once the last token is the stopping token or max_generation_size ids exist.
+    // The token never leaves the device inside a chunk of LLAMA_GREEDY_CHUNK steps (arg-max writes it back as the next
+    // input and bumps the position); the host looks at a chunk's tokens at once, so at most CHUNK-1 steps run past the
+    // stopping token (their cache rows are never read: the next call starts at position 0).
+    uint32_t *pi = c->l_tok + 1, *hist = c->l_tok + 1 + 2 * ARGMAX_PARTS;
+    float *pv = (float *) (c->l_tok + 1 + ARGMAX_PARTS);
+    uint32_t host_hist[LLAMA_GREEDY_CHUNK];
     while (*n_out < max_new) {
         tokens_out[(*n_out)++] = tok;
         if (tok == stop_id || *n_out >= max_new) break;
         if (pos >= c->lm.n_ctx) break;
-        CHK(tts_hip_orpheus_decode(c, &tok, 1, pos, nullptr, &tok));
-        pos++;
+        const uint32_t chunk = std::min<uint32_t>(std::min<uint32_t>(LLAMA_GREEDY_CHUNK, max_new - *n_out), c->lm.n_ctx - pos);
+        HIPCHK(hipMemcpyAsync(c->l_ids, &tok, 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->l_pos, &pos, 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));  // tok / pos are reused below
+        for (uint32_t s = 0; s < chunk; s++) {
+            CHK(llama_forward(c, nullptr, 1, pos + s));
+            hipLaunchKernelGGL(argmax_parts_kernel, dim3(ARGMAX_PARTS), dim3(256), 0, c->stream, (const float *) c->l_logits, c->l_V, pv, pi);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(argmax_fold_kernel, dim3(1), dim3(64), 0, c->stream, (const float *) pv, (const uint32_t *) pi, c->l_tok, hist + s, c->l_ids, c->l_pos);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(host_hist, hist, (size_t) chunk * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        pos += chunk;
+        // all but the chunk's last token are final here; the last one goes through the loop head like any other
+        uint32_t s = 0;
+        for (; s + 1 < chunk; s++) {
+            tokens_out[(*n_out)++] = host_hist[s];
+            if (host_hist[s] == stop_id || *n_out >= max_new) return 0;
+        }
+        tok = host_hist[s];
     }
     return 0;
 }
