@@ -80,6 +80,21 @@ class OrpheusModel(C.Structure):
                 ("out_norm", fp), ("rope_freqs", fp), ("layers", OrpheusLayer * MAX_LAYERS)]
 
 
+class DiaEncLayer(C.Structure):
+    _fields_ = [(n, W) for n in ("q", "k", "v", "o", "gate", "up", "out")] + [("sa_norm", fp), ("mlp_norm", fp)]
+
+
+class DiaDecLayer(C.Structure):
+    _fields_ = [(n, W) for n in ("sq", "sk", "sv", "so", "cq", "ck", "cv", "co", "gate", "up", "out")] + [("sa_norm", fp), ("ca_norm", fp), ("mlp_norm", fp)]
+
+
+class DiaModel(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("enc_H", "enc_L", "enc_heads", "enc_F", "dec_H", "dec_L", "dec_heads", "dec_kv_heads", "dec_F",
+                                          "head_dim", "n_out", "V", "max_ctx", "max_gen", "act_mode")] + [
+        ("cfg_scale", C.c_float), ("enc_embd", W), ("enc_norm", fp), ("dec_norm", fp), ("dec_embd", W * MAX_HEADS), ("heads", W * MAX_HEADS),
+        ("enc", DiaEncLayer * MAX_LAYERS), ("dec", DiaDecLayer * MAX_LAYERS)]
+
+
 class SnacRes(C.Structure):
     _fields_ = [("in_alpha", fp), ("in_w", fp), ("in_b", fp), ("out_alpha", fp), ("out_w", fp), ("out_b", fp)]
 
@@ -570,5 +585,134 @@ class OrpheusOracle:
     def __del__(self):
         try:
             self.L.orc_orpheus_state_free(self.state)
+        except Exception:
+            pass
+
+
+DIA_DELAY_PATTERN = (0, 8, 9, 10, 11, 12, 13, 14, 15)   # src/models/dia/model.h:84
+
+
+def dia_tokenize(sentence, max_ctx):
+    """dia_runner::tokenize_sentence (src/models/dia/model.cpp:661-705): byte tokens, [S1]/[S2] -> 1/2, zero padding.
+    Returns (tokens [max_ctx], sentence_length)."""
+    s = sentence.strip(" ")        # strip() in src/util.cpp trims spaces
+    if s[:4] not in ("[S1]", "[S2]"):
+        s = "[S1] " + s
+    if s[-1] != ".":
+        s += "."
+    b = s.encode("utf-8").replace(b"[S1]", b"\x01").replace(b"[S2]", b"\x02")
+    assert len(b) <= max_ctx
+    toks = np.zeros(max_ctx, dtype=np.uint32)
+    toks[:len(b)] = np.frombuffer(b, dtype=np.uint8)
+    return toks, len(b)
+
+
+class DiaOracle:
+    """Oracle twin of a tts_cpp_amd.synth.SynthDia (src/models/dia/model.cpp restated in tts_oracle.c)."""
+
+    def __init__(self, model, act_mode=1, cfg_scale=3.0):
+        self.L = lib()
+        L = self.L
+        L.orc_dia_state_new.restype = C.c_void_p
+        L.orc_dia_state_new.argtypes = [C.POINTER(DiaModel)]
+        L.orc_dia_state_free.argtypes = [C.c_void_p]
+        L.orc_dia_encode.argtypes = [C.POINTER(DiaModel), C.c_void_p, C.POINTER(C.c_uint32), C.c_int, fp]
+        L.orc_dia_encode.restype = None
+        L.orc_dia_step.argtypes = [C.POINTER(DiaModel), C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, fp, fp]
+        L.orc_dia_step.restype = None
+        L.orc_dia_check_stopping.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.POINTER(C.c_int)]
+        L.orc_dia_adjust_output_tokens.restype = C.c_size_t
+        L.orc_dia_adjust_output_tokens.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        cfg = model.cfg
+        self.cfg, self.model = cfg, model
+        self.keep = []
+        t = model.by_name
+
+        def w(name):
+            raw = np.frombuffer(bytes(t["dia." + name].raw()), dtype=np.uint8)
+            self.keep.append(raw)
+            return W(t["dia." + name].type, raw.ctypes.data_as(C.c_void_p).value)
+
+        def f(name):
+            a = np.ascontiguousarray(t["dia." + name].to_f32().reshape(-1))
+            self.keep.append(a)
+            return f32p(a)
+
+        m = DiaModel()
+        m.enc_H, m.enc_L, m.enc_heads, m.enc_F = cfg.enc_hidden, cfg.enc_layers, cfg.enc_heads, cfg.enc_ffn
+        m.dec_H, m.dec_L, m.dec_heads, m.dec_kv_heads, m.dec_F = cfg.dec_hidden, cfg.dec_layers, cfg.dec_heads, cfg.dec_kv_heads, cfg.dec_ffn
+        m.head_dim, m.n_out, m.V, m.max_ctx, m.max_gen, m.act_mode, m.cfg_scale = cfg.head_dim, cfg.n_out, cfg.out_vocab, cfg.max_ctx, cfg.max_gen, act_mode, cfg_scale
+        m.enc_embd, m.enc_norm, m.dec_norm = w("encoder.embedding"), f("encoder.norm"), f("decoder.norm")
+        for i in range(cfg.n_out):
+            m.dec_embd[i], m.heads[i] = w(f"decoder.embeddings.{i}"), w(f"decoder.heads.{i}")
+        for l in range(cfg.enc_layers):
+            p, y = f"encoder.layers.{l}.", m.enc[l]
+            y.q, y.k, y.v, y.o = w(p + "q_proj"), w(p + "k_proj"), w(p + "v_proj"), w(p + "o_proj")
+            y.gate, y.up, y.out, y.sa_norm, y.mlp_norm = w(p + "gate"), w(p + "up"), w(p + "wo"), f(p + "pre_sa_norm"), f(p + "post_sa_norm")
+        for l in range(cfg.dec_layers):
+            p, y = f"decoder.layers.{l}.", m.dec[l]
+            y.sq, y.sk, y.sv, y.so = w(p + "self_q_proj"), w(p + "self_k_proj"), w(p + "self_v_proj"), w(p + "self_o_proj")
+            y.cq, y.ck, y.cv, y.co = w(p + "cross_q_proj"), w(p + "cross_k_proj"), w(p + "cross_v_proj"), w(p + "cross_o_proj")
+            y.gate, y.up, y.out = w(p + "gate"), w(p + "up"), w(p + "wo")
+            y.sa_norm, y.ca_norm, y.mlp_norm = f(p + "pre_sa_norm"), f(p + "pre_ca_norm"), f(p + "pre_mlp_norm")
+        self.m = m
+        self.state = L.orc_dia_state_new(C.byref(m))
+        self.delay = np.array(DIA_DELAY_PATTERN[:cfg.n_out], dtype=np.uint32)
+
+    def encode(self, tokens, sentence_len, want_states=False):
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        assert tokens.size == self.cfg.max_ctx
+        out = np.empty((2, self.cfg.max_ctx, self.cfg.enc_hidden), dtype=np.float32) if want_states else None
+        self.L.orc_dia_encode(C.byref(self.m), self.state, u32p(tokens), sentence_len, f32p(out) if want_states else None)
+        return out
+
+    def step(self, ids, pos, want_raw=False):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        lg = np.empty((self.cfg.n_out, self.cfg.out_vocab), dtype=np.float32)
+        raw = np.empty((2, self.cfg.n_out, self.cfg.out_vocab), dtype=np.float32) if want_raw else None
+        self.L.orc_dia_step(C.byref(self.m), self.state, u32p(ids), pos, f32p(lg), f32p(raw) if want_raw else None)
+        return (lg, raw) if want_raw else lg
+
+    def check_stopping(self, ids, position, max_generation_size, delay_steps):
+        """-> (stop, ids', delay_steps')"""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32).copy()
+        d = C.c_int(delay_steps)
+        stop = self.L.orc_dia_check_stopping(u32p(ids), self.cfg.n_out, u32p(self.delay), self.cfg.max_delay, self.cfg.eos, self.cfg.pad, position,
+                                             max_generation_size, C.byref(d))
+        return bool(stop), ids, d.value
+
+    def adjust_output_tokens(self, tokens):
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32).reshape(-1)
+        out = np.empty(tokens.size, dtype=np.uint32)
+        n = self.L.orc_dia_adjust_output_tokens(u32p(tokens), tokens.size, self.cfg.n_out, u32p(self.delay), self.cfg.max_delay, self.cfg.audio_vocab, u32p(out))
+        return out[:n].reshape(-1, self.cfg.n_out)
+
+    def generate(self, sentence, max_tokens=0, pick=None):
+        """dia_runner::generate + generate_from_batch (:810-858) with greedy picks (or pick(logits) -> ids).
+        Returns (output_tokens [steps][n_out], frames [frames][n_out])."""
+        cfg = self.cfg
+        max_gen = max_tokens if max_tokens > cfg.max_delay else cfg.max_gen
+        toks, n = dia_tokenize(sentence, cfg.max_ctx)
+        self.L.orc_dia_state_free(self.state)
+        self.state = self.L.orc_dia_state_new(C.byref(self.m))
+        self.encode(toks, n)
+        ids = np.full(cfg.n_out, cfg.bos, dtype=np.uint32)
+        pos, delay_steps, outs = 0, -1, []
+        while True:
+            stop, ids, delay_steps = self.check_stopping(ids, pos, max_gen, delay_steps)
+            if stop:
+                break
+            lg = self.step(ids, pos)
+            new = (pick(lg) if pick else lg.argmax(-1)).astype(np.uint32)
+            outs.append(new)
+            pos += 1
+            ids = np.array([new[i] if pos > i else cfg.bos for i in range(cfg.n_out)], dtype=np.uint32)
+        outs = np.array(outs, dtype=np.uint32).reshape(-1, cfg.n_out)
+        return outs, self.adjust_output_tokens(outs)
+
+    def __del__(self):
+        try:
+            self.L.orc_dia_state_free(self.state)
         except Exception:
             pass

@@ -1007,8 +1007,8 @@ static void llama_rms_norm(const float *x, int H, const float *w, float *y) { /*
 /* ggml_rope_ext(x, pos, freq_factors, n_dims = head_dim, mode 2 (NEOX pairs i, i + n/2), n_ctx_orig 0, freq_base 500000,
  * freq_scale 1, ext_factor 0, attn_factor 1, beta 0/0): upstream ggml_rope_cache_init walks theta = pos, theta *=
  * powf(base, -2/n) in fp32 and evaluates cosf/sinf of theta / freq_factor. */
-static void llama_rope(float *x, int n_heads, int hd, uint32_t pos, const float *ff) {
-    const float theta_scale = powf(500000.0f, -2.0f / (float) hd);
+static void neox_rope(float *x, int n_heads, int hd, uint32_t pos, const float *ff, float base) {
+    const float theta_scale = powf(base, -2.0f / (float) hd);
     for (int h = 0; h < n_heads; h++) {
         float *v = x + (size_t) h * hd;
         float theta = (float) pos;
@@ -1022,6 +1022,7 @@ static void llama_rope(float *x, int n_heads, int hd, uint32_t pos, const float 
         }
     }
 }
+static void llama_rope(float *x, int n_heads, int hd, uint32_t pos, const float *ff) { neox_rope(x, n_heads, hd, pos, ff, 500000.0f); }
 
 void orc_orpheus_decode(const orc_orpheus_model *m, orc_orpheus_state *s, const uint32_t *tokens, int n, uint32_t pos0,
                         float *logits_out, float *hidden_out) {
@@ -1079,4 +1080,204 @@ void orc_orpheus_decode(const orc_orpheus_model *m, orc_orpheus_state *s, const 
     if (hidden_out) memcpy(hidden_out, cur, (size_t) n * H * 4);
     if (logits_out) orc_mul_mat(m->head.type, m->head.data, H, m->V, cur + (size_t) (n - 1) * H, 1, logits_out, m->act_mode);
     free(x); free(cur); free(q); free(k); free(v); free(att); free(tmp); free(gate); free(up); free(sc);
+}
+
+
+/* ======================================================================================
+ * Dia (src/models/dia/model.cpp)
+ * ==================================================================================== */
+struct orc_dia_state {
+    int L, max_ctx, max_gen, A, kvH;
+    float *ck, *cv; /* cross K/V [L][2][max_ctx][A]; K rows >= prompt_size stay zero (:505-541) */
+    float *k, *v;   /* self K/V [L][2][max_gen][kvH], un-repeated (the reference stores each group repeat-interleaved, :454-503) */
+};
+
+orc_dia_state *orc_dia_state_new(const orc_dia_model *m) {
+    orc_dia_state *s = (orc_dia_state *) calloc(1, sizeof(*s));
+    s->L = m->dec_L; s->max_ctx = m->max_ctx; s->max_gen = m->max_gen;
+    s->A = m->dec_heads * m->head_dim; s->kvH = m->dec_kv_heads * m->head_dim;
+    s->ck = (float *) calloc((size_t) s->L * 2 * s->max_ctx * s->A, 4);
+    s->cv = (float *) calloc((size_t) s->L * 2 * s->max_ctx * s->A, 4);
+    s->k = (float *) calloc((size_t) s->L * 2 * s->max_gen * s->kvH, 4);
+    s->v = (float *) calloc((size_t) s->L * 2 * s->max_gen * s->kvH, 4);
+    return s;
+}
+void orc_dia_state_free(orc_dia_state *s) { if (s) { free(s->ck); free(s->cv); free(s->k); free(s->v); free(s); } }
+
+/* one query against n_keys rows of K/V ([n][ld] position-major), heads of hd, kv head = head / rep, scale 1.0, optional
+ * additive mask row (:403, :586, :630) */
+static void dia_attend(const float *q, const float *K, const float *V, int n_keys, int ld, int n_heads, int rep, int hd, const float *mask,
+                       float *out, float *scores) {
+    for (int h = 0; h < n_heads; h++) {
+        const int kh = h / rep;
+        for (int t = 0; t < n_keys; t++) {
+            double acc = 0.0;
+            const float *kr = K + (size_t) t * ld + kh * hd;
+            for (int c = 0; c < hd; c++) acc += (double) kr[c] * (double) q[h * hd + c];
+            scores[t] = (float) acc + (mask ? mask[t] : 0.0f);
+        }
+        softmax_scaled(scores, n_keys, 1.0f);
+        for (int c = 0; c < hd; c++) {
+            double acc = 0.0;
+            for (int t = 0; t < n_keys; t++) acc += (double) scores[t] * (double) V[(size_t) t * ld + kh * hd + c];
+            out[h * hd + c] = (float) acc;
+        }
+    }
+}
+
+static void silu_mul(float *gate, const float *up, size_t n) {
+    for (size_t i = 0; i < n; i++) gate[i] = (gate[i] / (1.0f + expf(-gate[i]))) * up[i];
+}
+
+void orc_dia_encode(const orc_dia_model *m, orc_dia_state *s, const uint32_t *tokens, int sentence_len, float *enc_out) {
+    const int H = m->enc_H, S = m->max_ctx, NH = m->enc_heads, hd = m->head_dim, A = NH * hd, F = m->enc_F, n = 2 * S;
+    float *x = (float *) malloc((size_t) n * H * 4), *cur = (float *) malloc((size_t) n * H * 4), *tmp = (float *) malloc((size_t) n * H * 4);
+    float *q = (float *) malloc((size_t) n * A * 4), *k = (float *) malloc((size_t) n * A * 4), *v = (float *) malloc((size_t) n * A * 4);
+    float *att = (float *) malloc((size_t) n * A * 4);
+    float *gate = (float *) malloc((size_t) n * F * 4), *up = (float *) malloc((size_t) n * F * 4);
+    float *mask = (float *) malloc((size_t) S * S * 4);
+    for (int i = 0; i < S; i++)   /* set_inputs :712-721 */
+        for (int j = 0; j < S; j++)
+            mask[(size_t) i * S + j] = (i < sentence_len) == (j < sentence_len) ? 0.0f : -INFINITY;
+    for (int t = 0; t < S; t++) {
+        get_row(&m->enc_embd, tokens[t], H, x + (size_t) t * H);  /* stream 0: the text */
+        get_row(&m->enc_embd, 0, H, x + (size_t) (S + t) * H);    /* stream 1: all zeros (:700-703) */
+    }
+    for (int l = 0; l < m->enc_L; l++) {
+        const orc_dia_enc_layer *ly = &m->enc[l];
+        for (int t = 0; t < n; t++) llama_rms_norm(x + (size_t) t * H, H, ly->sa_norm, cur + (size_t) t * H);
+        orc_mul_mat(ly->q.type, ly->q.data, H, A, cur, n, q, m->act_mode);
+        orc_mul_mat(ly->k.type, ly->k.data, H, A, cur, n, k, m->act_mode);
+        orc_mul_mat(ly->v.type, ly->v.data, H, A, cur, n, v, m->act_mode);
+        for (int t = 0; t < n; t++) {
+            neox_rope(q + (size_t) t * A, NH, hd, (uint32_t) (t % S), NULL, 10000.0f);
+            neox_rope(k + (size_t) t * A, NH, hd, (uint32_t) (t % S), NULL, 10000.0f);
+        }
+#pragma omp parallel for schedule(static)
+        for (int t = 0; t < n; t++) {
+            float *sc = (float *) malloc((size_t) S * 4);
+            const int b = t / S;
+            dia_attend(q + (size_t) t * A, k + (size_t) b * S * A, v + (size_t) b * S * A, S, A, NH, 1, hd, mask + (size_t) (t % S) * S,
+                       att + (size_t) t * A, sc);
+            free(sc);
+        }
+        orc_mul_mat(ly->o.type, ly->o.data, A, H, att, n, tmp, m->act_mode);
+        for (size_t i = 0; i < (size_t) n * H; i++) x[i] = tmp[i] + x[i];
+        for (int t = 0; t < n; t++) llama_rms_norm(x + (size_t) t * H, H, ly->mlp_norm, cur + (size_t) t * H);
+        orc_mul_mat(ly->gate.type, ly->gate.data, H, F, cur, n, gate, m->act_mode);
+        orc_mul_mat(ly->up.type, ly->up.data, H, F, cur, n, up, m->act_mode);
+        silu_mul(gate, up, (size_t) n * F);
+        orc_mul_mat(ly->out.type, ly->out.data, F, H, gate, n, tmp, m->act_mode);
+        for (size_t i = 0; i < (size_t) n * H; i++) x[i] = tmp[i] + x[i];
+    }
+    for (int t = 0; t < n; t++) llama_rms_norm(x + (size_t) t * H, H, m->enc_norm, cur + (size_t) t * H);
+    if (enc_out) memcpy(enc_out, cur, (size_t) n * H * 4);
+    /* cross K/V for every decoder layer (build_dia_cross_kv_store :505-541) */
+    const int DA = s->A;
+    float *kk = (float *) malloc((size_t) n * DA * 4);
+    memset(s->ck, 0, (size_t) s->L * 2 * S * DA * 4);
+    for (int l = 0; l < m->dec_L; l++) {
+        const orc_dia_dec_layer *ly = &m->dec[l];
+        float *ck = s->ck + (size_t) l * 2 * S * DA, *cv = s->cv + (size_t) l * 2 * S * DA;
+        orc_mul_mat(ly->ck.type, ly->ck.data, H, DA, cur, n, kk, m->act_mode);
+        for (int b = 0; b < 2; b++)
+            for (int t = 0; t < sentence_len; t++) {
+                float *row = kk + ((size_t) b * S + t) * DA;
+                neox_rope(row, m->dec_heads, hd, (uint32_t) t, NULL, 10000.0f);
+                memcpy(ck + ((size_t) b * S + t) * DA, row, (size_t) DA * 4);
+            }
+        orc_mul_mat(ly->cv.type, ly->cv.data, H, DA, cur, n, cv, m->act_mode);
+    }
+    free(kk);
+    free(x); free(cur); free(tmp); free(q); free(k); free(v); free(att); free(gate); free(up); free(mask);
+}
+
+void orc_dia_step(const orc_dia_model *m, orc_dia_state *s, const uint32_t *ids, uint32_t pos, float *logits_out, float *raw_out) {
+    const int H = m->dec_H, NH = m->dec_heads, NKV = m->dec_kv_heads, hd = m->head_dim, A = NH * hd, kvH = NKV * hd, rep = NH / NKV;
+    const int F = m->dec_F, S = m->max_ctx, G = m->max_gen, V = m->V, NO = m->n_out, n = 2;
+    float *x = (float *) calloc((size_t) n * H, 4), *cur = (float *) malloc((size_t) n * H * 4), *tmp = (float *) malloc((size_t) n * H * 4);
+    float *row = (float *) malloc((size_t) H * 4);
+    float *q = (float *) malloc((size_t) n * A * 4), *k = (float *) malloc((size_t) n * kvH * 4), *v = (float *) malloc((size_t) n * kvH * 4);
+    float *att = (float *) malloc((size_t) n * A * 4);
+    float *gate = (float *) malloc((size_t) n * F * 4), *up = (float *) malloc((size_t) n * F * 4);
+    float *sc = (float *) malloc((size_t) (S > (int) pos + 1 ? S : (int) pos + 1) * 4);
+    float *raw = (float *) malloc((size_t) n * NO * V * 4), *hl = (float *) malloc((size_t) n * V * 4);
+    /* build_dia_decoder_inp_embd :337-350: embds[0] first, then embds[i] + running; both streams get the same ids (:724-726) */
+    for (int i = 0; i < NO; i++) {
+        get_row(&m->dec_embd[i], ids[i], H, row);
+        for (int e = 0; e < H; e++) x[e] = i == 0 ? row[e] : row[e] + x[e];
+    }
+    memcpy(x + H, x, (size_t) H * 4);
+    for (int l = 0; l < m->dec_L; l++) {
+        const orc_dia_dec_layer *ly = &m->dec[l];
+        for (int t = 0; t < n; t++) llama_rms_norm(x + (size_t) t * H, H, ly->sa_norm, cur + (size_t) t * H);
+        orc_mul_mat(ly->sq.type, ly->sq.data, H, A, cur, n, q, m->act_mode);
+        orc_mul_mat(ly->sk.type, ly->sk.data, H, kvH, cur, n, k, m->act_mode);
+        orc_mul_mat(ly->sv.type, ly->sv.data, H, kvH, cur, n, v, m->act_mode);
+        for (int b = 0; b < n; b++) {
+            float *kc = s->k + ((size_t) l * 2 + b) * G * kvH, *vc = s->v + ((size_t) l * 2 + b) * G * kvH;
+            neox_rope(q + (size_t) b * A, NH, hd, pos, NULL, 10000.0f);
+            neox_rope(k + (size_t) b * kvH, NKV, hd, pos, NULL, 10000.0f);
+            memcpy(kc + (size_t) pos * kvH, k + (size_t) b * kvH, (size_t) kvH * 4);
+            memcpy(vc + (size_t) pos * kvH, v + (size_t) b * kvH, (size_t) kvH * 4);
+            dia_attend(q + (size_t) b * A, kc, vc, (int) pos + 1, kvH, NH, rep, hd, NULL, att + (size_t) b * A, sc);
+        }
+        orc_mul_mat(ly->so.type, ly->so.data, A, H, att, n, tmp, m->act_mode);
+        for (size_t i = 0; i < (size_t) n * H; i++) x[i] = tmp[i] + x[i];
+        for (int t = 0; t < n; t++) llama_rms_norm(x + (size_t) t * H, H, ly->ca_norm, cur + (size_t) t * H);
+        orc_mul_mat(ly->cq.type, ly->cq.data, H, A, cur, n, q, m->act_mode);
+        for (int b = 0; b < n; b++) {
+            const float *ck = s->ck + ((size_t) l * 2 + b) * S * A, *cv = s->cv + ((size_t) l * 2 + b) * S * A;
+            neox_rope(q + (size_t) b * A, NH, hd, pos, NULL, 10000.0f);
+            dia_attend(q + (size_t) b * A, ck, cv, S, A, NH, 1, hd, NULL, att + (size_t) b * A, sc);
+        }
+        orc_mul_mat(ly->co.type, ly->co.data, A, H, att, n, tmp, m->act_mode);
+        for (size_t i = 0; i < (size_t) n * H; i++) x[i] = tmp[i] + x[i];
+        for (int t = 0; t < n; t++) llama_rms_norm(x + (size_t) t * H, H, ly->mlp_norm, cur + (size_t) t * H);
+        orc_mul_mat(ly->gate.type, ly->gate.data, H, F, cur, n, gate, m->act_mode);
+        orc_mul_mat(ly->up.type, ly->up.data, H, F, cur, n, up, m->act_mode);
+        silu_mul(gate, up, (size_t) n * F);
+        orc_mul_mat(ly->out.type, ly->out.data, F, H, gate, n, tmp, m->act_mode);
+        for (size_t i = 0; i < (size_t) n * H; i++) x[i] = tmp[i] + x[i];
+    }
+    for (int t = 0; t < n; t++) llama_rms_norm(x + (size_t) t * H, H, m->dec_norm, cur + (size_t) t * H);
+    for (int i = 0; i < NO; i++) {
+        orc_mul_mat(m->heads[i].type, m->heads[i].data, H, V, cur, n, hl, m->act_mode);   /* build_dia_head_outputs :366-380 */
+        for (int b = 0; b < n; b++) memcpy(raw + ((size_t) b * NO + i) * V, hl + (size_t) b * V, (size_t) V * 4);
+    }
+    for (size_t i = 0; i < (size_t) NO * V; i++) {   /* cfg_scale, util.cpp:194-196 */
+        const float cr = raw[i], ur = raw[(size_t) NO * V + i];
+        logits_out[i] = cr + m->cfg_scale * (cr - ur);
+    }
+    if (raw_out) memcpy(raw_out, raw, (size_t) n * NO * V * 4);
+    free(x); free(cur); free(tmp); free(row); free(q); free(k); free(v); free(att); free(gate); free(up); free(sc); free(raw); free(hl);
+}
+
+int orc_dia_check_stopping(uint32_t *ids, int n_out, const uint32_t *delay_pattern, uint32_t max_delay, uint32_t eos, uint32_t pad,
+                           uint32_t current_position, uint32_t max_generation_size, int *delay_steps) {
+    if (*delay_steps == -1 && (ids[0] == eos || current_position >= max_generation_size - max_delay)) *delay_steps = (int) max_delay;
+    if (*delay_steps > 0) {
+        const int step_after_eos = (int) max_delay - *delay_steps;
+        for (int i = 0; i < n_out; i++) {
+            if (step_after_eos == (int) delay_pattern[i]) ids[i] = eos;
+            else if (step_after_eos > (int) delay_pattern[i]) ids[i] = pad;
+        }
+        *delay_steps -= 1;
+    }
+    return *delay_steps == 0;
+}
+
+size_t orc_dia_adjust_output_tokens(const uint32_t *tokens, size_t size, int n_out, const uint32_t *delay_pattern, uint32_t max_delay,
+                                    uint32_t audio_vocab, uint32_t *filtered) {
+    size_t n = 0;
+    for (int i = 0; i < (int) (size / (size_t) n_out) - (int) max_delay; i++) {
+        int skip = 0;
+        for (int ii = 0; ii < n_out; ii++) {
+            const size_t next = (size_t) i * n_out + (size_t) delay_pattern[ii] * n_out + ii;
+            if (next > size || tokens[next] >= audio_vocab) { skip = 1; break; }
+        }
+        if (skip) continue;
+        for (int ii = 0; ii < n_out; ii++) filtered[n++] = tokens[(size_t) i * n_out + (size_t) delay_pattern[ii] * n_out + ii];
+    }
+    return n;
 }

@@ -264,12 +264,105 @@ def torch_orpheus(model, prompt, steps):
     return torch.stack(logits), toks
 
 
+def torch_dia(model, tokens, sentence_len, ids_seq, cfg_scale=3.0):
+    """Dia (src/models/dia/model.cpp:383-659) in float64 torch, batched over the two streams (text / all-zero), with the HF
+    formulation of rotary embeddings (closed-form inv_freq, rotate_half) and boolean masks — an independent route to the
+    numbers of the C oracle.  tokens [max_ctx] (zero padded); ids_seq [steps][n_out] decoder inputs.
+    Returns encoder states [2][S][EH], guided logits [steps][n_out][V] and raw logits [steps][2][n_out][V]."""
+    c = model.cfg
+    S, hd, NH, NKV, rep, NO = c.max_ctx, c.head_dim, c.dec_heads, c.dec_kv_heads, c.dec_repeat, c.n_out
+
+    def P(name):
+        return T_(model, "dia." + name)
+
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=D) / hd))
+
+    def rope(x, pos):  # x [..., n, heads, hd], pos [n]
+        ang = pos.to(D)[:, None] * inv_freq[None, :]
+        cos, sin = torch.cos(ang)[:, None, :], torch.sin(ang)[:, None, :]
+        x0, x1 = x[..., : hd // 2], x[..., hd // 2:]
+        return torch.cat([x0 * cos - x1 * sin, x0 * sin + x1 * cos], dim=-1)
+
+    def rms(v, w):
+        return v * torch.rsqrt((v * v).mean(-1, keepdim=True) + 1e-5) * w
+
+    def mlp(cur, p):
+        return Fn.linear(Fn.silu(Fn.linear(cur, P(p + "gate"))) * Fn.linear(cur, P(p + "up")), P(p + "wo"))
+
+    # ---- encoder: [2][S][EH]
+    ids = torch.stack([torch.tensor(tokens.astype(np.int64)), torch.zeros(S, dtype=torch.long)])
+    x = P("encoder.embedding")[ids]
+    real = torch.arange(S) < sentence_len
+    allowed = real[:, None] == real[None, :]                      # real sees real, pad sees pad (set_inputs :712-721)
+    pos = torch.arange(S)
+    for l in range(c.enc_layers):
+        p = f"encoder.layers.{l}."
+        cur = rms(x, P(p + "pre_sa_norm"))
+        q = rope(Fn.linear(cur, P(p + "q_proj")).view(2, S, c.enc_heads, hd), pos)
+        k = rope(Fn.linear(cur, P(p + "k_proj")).view(2, S, c.enc_heads, hd), pos)
+        v = Fn.linear(cur, P(p + "v_proj")).view(2, S, c.enc_heads, hd)
+        sc = torch.einsum("bnhd,bthd->bhnt", q, k).masked_fill(~allowed[None, None], float("-inf"))   # no 1/sqrt(d) in Dia
+        att = torch.einsum("bhnt,bthd->bnhd", torch.softmax(sc, -1), v).reshape(2, S, c.enc_heads * hd)
+        x = x + Fn.linear(att, P(p + "o_proj"))
+        x = x + mlp(rms(x, P(p + "post_sa_norm")), p)
+    enc = rms(x, P("encoder.norm"))
+
+    # ---- cross K/V: keys only for the sentence (the other cache rows are zero), values for every position
+    ck, cv = [], []
+    for l in range(c.dec_layers):
+        p = f"decoder.layers.{l}."
+        k = rope(Fn.linear(enc, P(p + "cross_k_proj")).view(2, S, NH, hd), pos)
+        ck.append(k * real[None, :, None, None].to(D))
+        cv.append(Fn.linear(enc, P(p + "cross_v_proj")).view(2, S, NH, hd))
+
+    ks = [torch.zeros(2, 0, NKV, hd, dtype=D) for _ in range(c.dec_layers)]
+    vs = [torch.zeros(2, 0, NKV, hd, dtype=D) for _ in range(c.dec_layers)]
+    guided, raws = [], []
+    for step, ids_t in enumerate(ids_seq):
+        pt = torch.tensor([step])
+        x = sum(P(f"decoder.embeddings.{i}")[int(ids_t[i])] for i in range(NO))[None, None, :].repeat(2, 1, 1)   # [2][1][DH]
+        for l in range(c.dec_layers):
+            p = f"decoder.layers.{l}."
+            cur = rms(x, P(p + "pre_sa_norm"))
+            q = rope(Fn.linear(cur, P(p + "self_q_proj")).view(2, 1, NH, hd), pt)
+            k = rope(Fn.linear(cur, P(p + "self_k_proj")).view(2, 1, NKV, hd), pt)
+            v = Fn.linear(cur, P(p + "self_v_proj")).view(2, 1, NKV, hd)
+            ks[l] = torch.cat([ks[l], k], dim=1); vs[l] = torch.cat([vs[l], v], dim=1)
+            kk, vv = ks[l].repeat_interleave(rep, dim=2), vs[l].repeat_interleave(rep, dim=2)
+            sc = torch.einsum("bnhd,bthd->bhnt", q, kk)
+            att = torch.einsum("bhnt,bthd->bnhd", torch.softmax(sc, -1), vv).reshape(2, 1, NH * hd)
+            x = x + Fn.linear(att, P(p + "self_o_proj"))
+            cur = rms(x, P(p + "pre_ca_norm"))
+            q = rope(Fn.linear(cur, P(p + "cross_q_proj")).view(2, 1, NH, hd), pt)
+            sc = torch.einsum("bnhd,bthd->bhnt", q, ck[l])                        # all S positions, no mask
+            att = torch.einsum("bhnt,bthd->bnhd", torch.softmax(sc, -1), cv[l]).reshape(2, 1, NH * hd)
+            x = x + Fn.linear(att, P(p + "cross_o_proj"))
+            x = x + mlp(rms(x, P(p + "pre_mlp_norm")), p)
+        h = rms(x[:, 0], P("decoder.norm"))
+        raw = torch.stack([Fn.linear(h, P(f"decoder.heads.{i}")) for i in range(NO)], dim=1)   # [2][NO][V]
+        raws.append(raw)
+        guided.append(raw[0] + cfg_scale * (raw[0] - raw[1]))
+    return enc, torch.stack(guided), torch.stack(raws)
+
+
 def T_(model, name):
     return torch.from_numpy(model.by_name[name].to_f32().astype(np.float64))
 
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    dm = synth.build_dia(synth.dia_tiny())
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import dia_tokenize
+    dtoks, dn = dia_tokenize("[S1] Hi there [S2] ok", dm.cfg.max_ctx)
+    rd = np.random.default_rng(11)
+    dids = rd.integers(0, dm.cfg.audio_vocab, (5, dm.cfg.n_out)).astype(np.uint32)
+    dids[0] = dm.cfg.bos
+    with torch.no_grad():
+        denc, dguided, draw = torch_dia(dm, dtoks, dn, dids)
+    np.savez_compressed(os.path.join(out_dir, "tiny_dia.npz"), tokens=dtoks, sentence_len=np.int32(dn), ids=dids, enc=denc.numpy().astype(np.float32),
+                        logits=dguided.numpy().astype(np.float32), raw=draw.numpy().astype(np.float32))
+    print("wrote tiny_dia.npz")
     om = synth.build_orpheus(synth.orpheus_tiny())
     op = np.random.default_rng(5).integers(0, om.cfg.vocab, 9).astype(np.uint32)
     with torch.no_grad():

@@ -255,3 +255,95 @@ def test_orpheus_decoder_oracle_matches_torch_golden():
     # Q4_0 weights (BASELINE config 4) run through the integer mul_mat
     q = orc.OrpheusOracle(sy.build_orpheus(sy.orpheus_tiny(weight_type=gguf.Q4_0)))
     assert np.isfinite(q.decode(g["prompt"], 0)).all()
+
+
+# ---- Dia (src/models/dia/model.cpp) -------------------------------------------------------------------------------
+def test_dia_oracle_matches_torch_golden():
+    """orc_dia_encode / orc_dia_step (encoder with the real|pad block mask, cross K only for the sentence, GQA self-attention,
+    unscaled softmax, NEOX rope base 10000 with iterated fp32 theta, cfg_scale map) against tests/golden/tiny_dia.npz (float64
+    torch, batched, HF rotary formulation, boolean masks)."""
+    from tts_cpp_amd import synth as sy
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_dia.npz"))
+    model = sy.build_dia(sy.dia_tiny())
+    o = orc.DiaOracle(model, act_mode=0)
+    enc = o.encode(g["tokens"], int(g["sentence_len"]), want_states=True)
+    assert np.abs(enc - g["enc"]).max() < 1e-5
+    for s_ in range(len(g["ids"])):
+        lg, raw = o.step(g["ids"][s_], s_, want_raw=True)
+        assert np.abs(raw - g["raw"][s_]).max() < 1e-5
+        assert np.abs(lg - g["logits"][s_]).max() < 2e-5
+        assert np.array_equal(lg, raw[0] + np.float32(3.0) * (raw[0] - raw[1]))   # util.cpp:194-196, nothing masked
+    # the unconditional stream does not depend on the text; the conditional one does
+    o2 = orc.DiaOracle(model, act_mode=0)
+    toks2, n2 = orc.dia_tokenize("[S2] something else", model.cfg.max_ctx)
+    o2.encode(toks2, n2)
+    _, raw2 = o2.step(g["ids"][0], 0, want_raw=True)
+    assert np.abs(raw2[0] - g["raw"][0][0]).max() > 1e-2
+    # pad positions see only pad positions, so the all-zero stream splits the same way: its rows >= n differ between the two texts
+    q = orc.DiaOracle(sy.build_dia(sy.dia_tiny(weight_type=gguf.Q8_0)))
+    q.encode(g["tokens"], int(g["sentence_len"]))
+    assert np.isfinite(q.step(g["ids"][0], 0)).all()
+
+
+def test_dia_tokenize():
+    """tokenize_sentence :661-705"""
+    t, n = orc.dia_tokenize("  hello world ", 32)
+    assert bytes(t[:n].astype(np.uint8)) == b"\x01 hello world." and (t[n:] == 0).all() and t.size == 32
+    t, n = orc.dia_tokenize("[S2] a [S1] b.", 32)
+    assert bytes(t[:n].astype(np.uint8)) == b"\x02 a \x01 b."
+    t, n = orc.dia_tokenize("[S1]x", 8)
+    assert bytes(t[:n].astype(np.uint8)) == b"\x01x."
+
+
+def test_dia_stopping_and_delay_pattern():
+    """check_stopping :767-785 and adjust_output_tokens :787-808 on hand-made sequences"""
+    from tts_cpp_amd import synth as sy
+    cfg = sy.dia_tiny()
+    o = orc.DiaOracle(sy.build_dia(cfg))
+    NO, D = cfg.n_out, orc.DIA_DELAY_PATTERN
+    # EOS on head 0 at position 5: the next 15 calls force eos / pad per head, the 15th stops
+    ids = np.arange(NO, dtype=np.uint32)
+    stop, out, d = o.check_stopping(ids, 4, 1000, -1)
+    assert not stop and d == -1 and np.array_equal(out, ids)
+    ids[0] = cfg.eos
+    d = -1
+    for k in range(15):
+        stop, out, d = o.check_stopping(ids, 5 + k, 1000, d)
+        for h in range(NO):
+            want = cfg.eos if k == D[h] else (cfg.pad if k > D[h] else ids[h])
+            assert out[h] == want, (k, h)
+        assert d == 14 - k and stop == (k == 14)
+    # the length limit triggers the same countdown at max_generation_size - max_delay
+    stop, out, d = o.check_stopping(np.zeros(NO, dtype=np.uint32), 100 - 15, 100, -1)
+    assert d == 14 and out[0] == cfg.eos and not stop
+    stop, _, d = o.check_stopping(np.zeros(NO, dtype=np.uint32), 100 - 16, 100, -1)
+    assert d == -1
+    # un-delay: frame i takes head h from step i + delay[h]; a frame with any id >= audio_vocab is dropped; the last
+    # max_delay steps only feed earlier frames
+    steps = 20
+    toks = np.zeros((steps, NO), dtype=np.uint32)
+    for s_ in range(steps):
+        for h in range(NO):
+            toks[s_, h] = (s_ - D[h]) % cfg.audio_vocab if s_ >= D[h] else cfg.bos   # frame index carried by every head
+    toks[2 + D[3], 3] = cfg.pad                                                       # spoils frame 2
+    frames = o.adjust_output_tokens(toks)
+    assert frames.shape == (steps - 15 - 1, NO)
+    assert [int(f[0]) for f in frames] == [0, 1, 3, 4] and all((f == f[0]).all() for f in frames)
+
+
+def test_dia_generate_loop_and_codec():
+    """generate_from_batch :810-833 end to end on the oracle: fixed length from the generation limit, 9-head delay pattern,
+    DAC on the un-delayed frames"""
+    from tts_cpp_amd import synth as sy
+    model = sy.build_dia(sy.dia_tiny(), suppress_special=True)
+    o = orc.DiaOracle(model)
+    outs, frames = o.generate("[S1] Hi there [S2] ok")
+    cfg = model.cfg
+    assert outs.shape == (cfg.max_gen - 1, cfg.n_out)               # limit hit at max_gen - 15, then 14 more decodes
+    assert frames.shape == (cfg.max_gen - 1 - cfg.max_delay, cfg.n_out) and frames.max() < cfg.audio_vocab
+    for h, dl in enumerate(orc.DIA_DELAY_PATTERN):
+        assert np.array_equal(frames[:, h], outs[dl:dl + len(frames), h])
+    outs2, _ = o.generate("[S1] Hi there [S2] ok", max_tokens=24)    # config.max_tokens (:812-818)
+    assert outs2.shape == (23, cfg.n_out) and np.array_equal(outs2[:8], outs[:8])
+    pcm = orc.DacOracle(model.dac).decode(frames)
+    assert pcm.shape == (len(frames) * cfg.hop,) and np.isfinite(pcm).all() and np.abs(pcm).max() <= 1.0

@@ -657,3 +657,156 @@ class SynthOrpheusFull:
     def write_gguf(self, path):
         gguf.write(path, self.kv, self.tensors)
         return path
+
+
+# --------------------------------------------------------------------------------------------------
+# Dia (src/models/dia/model.cpp).  Tensor names / keys as py-gguf/tts_encoders/dia_gguf_encoder.py:72-190 writes them:
+# dia.encoder.{embedding,norm,layers.N.{q,k,v,o}_proj,pre_sa_norm,post_sa_norm,gate,up,wo}, dia.decoder.{embeddings.N,
+# heads.N,norm,layers.N.{self,cross}_{q,k,v,o}_proj,pre_{sa,ca,mlp}_norm,gate,up,wo}, audio_encoder.* (the DAC codec).
+# "dia.decoder.attn_heads" is the number of query heads and "dia.decoder.query_heads" the repeat count of each k/v
+# group (the converter writes gqa_query_heads / kv_heads, :169-170; the model uses attn_heads / query_heads groups,
+# model.cpp:463,468).  The encoder's hidden size has no key (model.h:68 default 1024); it is the embedding's width.
+# --------------------------------------------------------------------------------------------------
+DIA_DELAY_PATTERN = (0, 8, 9, 10, 11, 12, 13, 14, 15)   # model.h:84: not stored in the GGUF
+
+
+@dataclass
+class DiaConfig:
+    enc_hidden: int = 128
+    enc_layers: int = 2
+    enc_heads: int = 2          # enc_heads * head_dim == dec_hidden (model.cpp:410)
+    enc_ffn: int = 256
+    enc_vocab: int = 256        # byte tokens
+    dec_hidden: int = 256
+    dec_layers: int = 2
+    dec_heads: int = 2          # "attn_heads": query heads
+    dec_repeat: int = 2         # "query_heads": how many query heads share one k/v group
+    dec_ffn: int = 512
+    head_dim: int = 128
+    n_out: int = 9
+    audio_vocab: int = 64       # eos = audio_vocab, pad = +1, bos = +2, output vocab = +4 (model.h:75-79 with 1024)
+    max_ctx: int = 24           # dia.encoder.max_context_length
+    max_gen: int = 48           # dia.decoder.max_generation_size
+    max_delay: int = 15
+    weight_type: int = gguf.F32
+    seed: int = 0xD1A
+    # codec (the Parler generator's DAC builder): latent / codebooks sized for the tiny tests
+    latent: int = 64
+    cb_dim: int = 8
+    c0: int = 64
+    strides: tuple = (4, 2)
+
+    @property
+    def eos(self): return self.audio_vocab
+    @property
+    def pad(self): return self.audio_vocab + 1
+    @property
+    def bos(self): return self.audio_vocab + 2
+    @property
+    def out_vocab(self): return self.audio_vocab + 4
+    @property
+    def dec_kv_heads(self): return self.dec_heads // self.dec_repeat
+    @property
+    def hop(self): return int(np.prod(self.strides))
+
+
+def dia_tiny(**kw):
+    return DiaConfig(**kw)
+
+
+def dia_1_6b(**kw):
+    """nari-labs/Dia-1.6B (model.h:64-84): encoder 12 x 1024 (16 x 128 heads, ffn 4096), decoder 18 x 2048 (16 query heads on
+    4 k/v groups x 128, ffn 8192), 9 heads x 1028 logits, 1024 text positions, 3072 audio steps"""
+    base = dict(enc_hidden=1024, enc_layers=12, enc_heads=16, enc_ffn=4096, dec_hidden=2048, dec_layers=18, dec_heads=16, dec_repeat=4,
+                dec_ffn=8192, audio_vocab=1024, max_ctx=1024, max_gen=3072, latent=1024, c0=1536, strides=(8, 8, 4, 2))
+    base.update(kw)
+    return DiaConfig(**base)
+
+
+class SynthDia:
+    def __init__(self, cfg: DiaConfig, suppress_special=False):
+        self.cfg = cfg
+        assert cfg.enc_heads * cfg.head_dim == cfg.dec_hidden and cfg.dec_heads * cfg.head_dim == cfg.dec_hidden
+        rng = np.random.Generator(np.random.Philox(cfg.seed))
+        self.tensors = []
+        EH, DH, A, kvH = cfg.enc_hidden, cfg.dec_hidden, cfg.dec_heads * cfg.head_dim, cfg.dec_kv_heads * cfg.head_dim
+
+        def normal(shape, std):
+            return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+        def add(name, arr, quantizable=True):
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            ttype = cfg.weight_type if quantizable else gguf.F32
+            ne = list(reversed(arr.shape))
+            if ttype in (gguf.Q4_0, gguf.Q5_0, gguf.Q8_0):
+                self.tensors.append(gguf.Tensor(name, ttype, ne, quantize(arr, ttype).tobytes()))
+            else:
+                self.tensors.append(gguf.Tensor.from_array(name, arr, ttype))
+
+        # attention logits are not scaled by 1/sqrt(d) in Dia (soft_max_ext(..., 1.0f, 0), model.cpp:403,586,630): keep
+        # q and k small so that the synthetic softmax is not one-hot
+        qs = 0.35
+        for i in range(cfg.n_out):
+            add(f"dia.decoder.embeddings.{i}", normal((cfg.out_vocab, DH), 0.5))
+        add("dia.decoder.norm", 1.0 + normal((DH,), 0.05), quantizable=False)
+        for i in range(cfg.n_out):
+            hw = normal((cfg.out_vocab, DH), 1.0 / math.sqrt(DH))
+            if suppress_special:
+                hw[cfg.audio_vocab:] = 0.0
+            add(f"dia.decoder.heads.{i}", hw)
+        for l in range(cfg.dec_layers):
+            p = f"dia.decoder.layers.{l}."
+            add(p + "pre_sa_norm", 1.0 + normal((DH,), 0.05), quantizable=False)
+            add(p + "self_q_proj", normal((A, DH), qs / math.sqrt(DH)))
+            add(p + "self_k_proj", normal((kvH, DH), qs / math.sqrt(DH)))
+            add(p + "self_v_proj", normal((kvH, DH), 1.0 / math.sqrt(DH)))
+            add(p + "self_o_proj", normal((DH, A), 1.0 / math.sqrt(A)))
+            add(p + "pre_ca_norm", 1.0 + normal((DH,), 0.05), quantizable=False)
+            add(p + "cross_q_proj", normal((A, DH), qs / math.sqrt(DH)))
+            add(p + "cross_k_proj", normal((A, EH), qs / math.sqrt(EH)))
+            add(p + "cross_v_proj", normal((A, EH), 1.0 / math.sqrt(EH)))
+            add(p + "cross_o_proj", normal((DH, A), 1.0 / math.sqrt(A)))
+            add(p + "pre_mlp_norm", 1.0 + normal((DH,), 0.05), quantizable=False)
+            add(p + "gate", normal((cfg.dec_ffn, DH), 1.0 / math.sqrt(DH)))
+            add(p + "up", normal((cfg.dec_ffn, DH), 1.0 / math.sqrt(DH)))
+            add(p + "wo", normal((DH, cfg.dec_ffn), 1.0 / math.sqrt(cfg.dec_ffn)))
+        add("dia.encoder.embedding", normal((cfg.enc_vocab, EH), 1.0))
+        add("dia.encoder.norm", 1.0 + normal((EH,), 0.05), quantizable=False)
+        for l in range(cfg.enc_layers):
+            p = f"dia.encoder.layers.{l}."
+            add(p + "pre_sa_norm", 1.0 + normal((EH,), 0.05), quantizable=False)
+            add(p + "q_proj", normal((A, EH), qs / math.sqrt(EH)))
+            add(p + "k_proj", normal((A, EH), qs / math.sqrt(EH)))
+            add(p + "v_proj", normal((A, EH), 1.0 / math.sqrt(EH)))
+            add(p + "o_proj", normal((EH, A), 1.0 / math.sqrt(A)))
+            add(p + "post_sa_norm", 1.0 + normal((EH,), 0.05), quantizable=False)
+            add(p + "gate", normal((cfg.enc_ffn, EH), 1.0 / math.sqrt(EH)))
+            add(p + "up", normal((cfg.enc_ffn, EH), 1.0 / math.sqrt(EH)))
+            add(p + "wo", normal((EH, cfg.enc_ffn), 1.0 / math.sqrt(cfg.enc_ffn)))
+        # the codec: the Parler generator's DAC tensors and keys (same converter base class, DACEncoder)
+        pc = Config(hidden=64, layers=1, heads=1, ffn=64, out_vocab=cfg.out_vocab, audio_vocab=cfg.audio_vocab, n_out=cfg.n_out, ctx=32, max_gen=16,
+                    enc_len=2, prompt_vocab=8, eos=cfg.eos, bos=cfg.bos, latent=cfg.latent, cb_dim=cfg.cb_dim, cb_size=cfg.audio_vocab, c0=cfg.c0,
+                    strides=cfg.strides, seed=cfg.seed + 1, weight_type=gguf.F32)
+        self.dac = SynthModel(pc)
+        self.tensors += [t for t in self.dac.tensors if t.name.startswith("audio_encoder.")]
+        U32, STR = gguf.T_U32, gguf.T_STR
+        self.kv = [("general.architecture", STR, "dia"), ("general.name", STR, "synthetic-dia")]
+        self.kv += [kv for kv in self.dac.kv if kv[0].startswith("dac.") or kv[0].startswith("audio.")]
+        self.kv += [
+            ("dia.attn_head_size", U32, cfg.head_dim), ("dia.eos_token_id", U32, cfg.eos), ("dia.bos_token_id", U32, cfg.bos),
+            ("dia.pad_token_id", U32, cfg.pad), ("dia.max_delay", U32, cfg.max_delay),
+            ("dia.encoder.max_context_length", U32, cfg.max_ctx), ("dia.encoder.attn_heads", U32, cfg.enc_heads), ("dia.encoder.layers", U32, cfg.enc_layers),
+            ("dia.decoder.hidden_size", U32, DH), ("dia.decoder.layers", U32, cfg.dec_layers), ("dia.decoder.output_heads", U32, cfg.n_out),
+            ("dia.decoder.attn_heads", U32, cfg.dec_heads), ("dia.decoder.query_heads", U32, cfg.dec_repeat),
+            ("dia.decoder.output_vocab_size", U32, cfg.out_vocab), ("dia.decoder.audio_vocab_size", U32, cfg.audio_vocab),
+            ("dia.decoder.max_generation_size", U32, cfg.max_gen),
+        ]
+        self.by_name = {t.name: t for t in self.tensors}
+
+    def write_gguf(self, path):
+        gguf.write(path, self.kv, self.tensors)
+        return path
+
+
+def build_dia(cfg: DiaConfig, **kw) -> SynthDia:
+    return SynthDia(cfg, **kw)
