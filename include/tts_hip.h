@@ -221,6 +221,40 @@ int tts_hip_orpheus_decode(tts_hip_ctx *ctx, const uint32_t *ids, uint32_t n, ui
 int tts_hip_orpheus_generate_greedy(tts_hip_ctx *ctx, const uint32_t *prompt, uint32_t n_prompt, uint32_t max_new, uint32_t stop_id,
                                     uint32_t *tokens_out, uint32_t *n_out);
 
+/* ---- Dia encoder + decoder step (src/models/dia/model.cpp) --------------------------------------------------------
+ * Device side of dia_runner::decode (:730-757): create, tts_hip_upload every "dia.*" tensor (names
+ * py-gguf/tts_encoders/dia_gguf_encoder.py:72-131), tts_hip_finalize(ctx, NULL), tts_hip_dia_encode once per sentence
+ * (build_dia_encoder :383-440 + build_dia_cross_kv_store :505-541, both streams), then tts_hip_dia_step per token.
+ * Tokenisation (:661-705), the sampler, check_stopping / the delay pattern (:767-808) stay with the host; the codec is
+ * the DAC context (tts_hip_create with TTS_HIP_FLAG_NO_PARLER, "audio_encoder.*"). */
+typedef struct tts_hip_dia_desc {
+    uint32_t struct_size;
+    uint32_t enc_hidden_size;   /* width of dia.encoder.embedding (1024; model.h:68, no GGUF key)        */
+    uint32_t enc_layers;        /* dia.encoder.layers (12)                                               */
+    uint32_t enc_attn_heads;    /* dia.encoder.attn_heads (16): heads x head_dim == dec_hidden_size       */
+    uint32_t dec_hidden_size;   /* dia.decoder.hidden_size (2048)                                        */
+    uint32_t dec_layers;        /* dia.decoder.layers (18)                                               */
+    uint32_t dec_attn_heads;    /* dia.decoder.attn_heads (16) query heads                               */
+    uint32_t dec_kv_heads;      /* attn_heads / dia.decoder.query_heads (16 / 4 = 4 k/v groups, :463,468) */
+    uint32_t head_dim;          /* dia.attn_head_size (128)                                              */
+    uint32_t n_output_heads;    /* dia.decoder.output_heads (9)                                          */
+    uint32_t output_vocab_size; /* dia.decoder.output_vocab_size (1028)                                  */
+    uint32_t max_ctx;           /* dia.encoder.max_context_length (1024): the encoder always runs all of it */
+    uint32_t max_gen;           /* dia.decoder.max_generation_size (3072) self-attention cache positions  */
+    float    cfg_scale;         /* dia.cfg_scale (3.0, model.h:82); 0 = that                             */
+    uint32_t flags;             /* TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q */
+} tts_hip_dia_desc;
+tts_hip_ctx *tts_hip_dia_create(int device, const tts_hip_dia_desc *desc);
+/* tokens [max_ctx]: the sentence bytes then zeros; the all-zero second stream is added here (:700-703).  Fills the cross
+ * K/V of every decoder layer (K only for the first sentence_len positions, the rest zero as in a freshly cleared cache)
+ * and resets nothing else: self-attention cache rows are overwritten as positions are decoded.
+ * enc_out (may be NULL): [2][max_ctx][enc_hidden_size] final-normed encoder states. */
+int tts_hip_dia_encode(tts_hip_ctx *ctx, const uint32_t *tokens, uint32_t sentence_len, float *enc_out);
+/* one decoder step at position pos with the n_output_heads ids of the previous step (both streams get the same ids).
+ * logits_out [n_output_heads][output_vocab_size]: cond + cfg_scale * (cond - uncond) (util.cpp:194-196);
+ * raw_out (may be NULL): [2][n_output_heads][output_vocab_size] conditional, unconditional. */
+int tts_hip_dia_step(tts_hip_ctx *ctx, const uint32_t *ids, uint32_t pos, float *logits_out, float *raw_out);
+
 /* ---- SNAC codec (src/decoder/snac_model.cpp; Orpheus' audio decoder) -------------------------------
  * A SNAC context is its own tts_hip_ctx: create, tts_hip_upload every "snac.*" tensor (names:
  * py-gguf/tts_encoders/orpheus_gguf_encoder.py:89-142), tts_hip_finalize(ctx, NULL), tts_hip_snac_decode. */

@@ -38,9 +38,11 @@ __global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int H, con
 // theta walks pos, pos*s, (pos*s)*s, ... in fp32 exactly like ggml_rope_cache_init (theta *= theta_scale), theta_scale =
 // powf(base, -2/HD) from the host; angle = theta / freq_factor[i]; NEOX pairing (i, i + HD/2).  The k-head waves write the
 // rotated key into the cache and copy their head's slice of v next to it.
+// row_seq (optional): row r appends to the cache of sequence row_seq[r], seq_stride floats apart (Dia's two streams).
 __global__ __launch_bounds__(64) void llama_rope_kv_kernel(float *qkv, const uint32_t *pos, const float *ff, float theta_scale, int NH, int NKV, int HD,
-                                                           float *kcache, float *vcache) {
+                                                           float *kcache, float *vcache, const uint32_t *row_seq, int64_t seq_stride) {
     const int r = blockIdx.x, h = blockIdx.y;
+    if (row_seq) { kcache += (int64_t) row_seq[r] * seq_stride; vcache += (int64_t) row_seq[r] * seq_stride; }
     const int half = HD >> 1;
     const int ld = (NH + 2 * NKV) * HD, kvH = NKV * HD;
     float *row = qkv + (int64_t) r * ld;
@@ -70,16 +72,22 @@ __global__ __launch_bounds__(64) void llama_rope_kv_kernel(float *qkv, const uin
 // key row is read as one contiguous 512 bytes), 16 keys per pass.  Softmax statistics over the block.  P.V: 8 groups of
 // 32 lanes walk the keys, a lane owns 4 consecutive output dims (16-byte loads, 512 contiguous bytes per key and group).
 extern __shared__ __align__(16) float attn_gqa_sm[];
+// Keys [kbeg[r], kend[r]) of the row's sequence (defaults: 0 and pos[r] + 1 = causal over the cache); row_seq / seq_stride as above.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld, const uint32_t *pos, const float *kcache, const float *vcache, int NH, int NKV,
-                                                       float scale, float *out) {
+                                                       float scale, float *out, const uint32_t *kbeg, const uint32_t *kend, const uint32_t *row_seq,
+                                                       int64_t seq_stride) {
     static_assert(HD == 128, "lane mapping below is written for head_dim 128 (orpheus/model.h:28)");
     __shared__ float red[8];
     __shared__ float4 accs[8][HD / 4];
     float *qs = attn_gqa_sm, *ps = attn_gqa_sm + HD;   // [HD] q, then [T] scores -> probabilities
     const int h = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int T = (int) pos[r] + 1;
+    const int k0 = kbeg ? (int) kbeg[r] : 0;
+    const int T = (kend ? (int) kend[r] : (int) pos[r] + 1) - k0;
     const int kvH = NKV * HD, kh = h / (NH / NKV);
+    if (row_seq) { kcache += (int64_t) row_seq[r] * seq_stride; vcache += (int64_t) row_seq[r] * seq_stride; }
+    kcache += (int64_t) k0 * kvH;
+    vcache += (int64_t) k0 * kvH;
     if (tid < HD) qs[tid] = qkv[(int64_t) r * ld + h * HD + tid];
     __syncthreads();
     {

@@ -24,6 +24,7 @@
 #include "parler_kernels.h"
 #include "t5_kernels.h"
 #include "llama_kernels.h"
+#include "dia_kernels.h"
 #define LLAMA_GREEDY_CHUNK 8
 
 // ------------------------------------------------------------------------------------------------
@@ -207,6 +208,23 @@ struct tts_hip_ctx {
     float *l_kc = nullptr, *l_vc = nullptr;
     uint32_t *l_ids = nullptr, *l_pos = nullptr, *l_tok = nullptr;
     int l_pending = 0;
+    // ---- Dia context (tts_hip_dia_create) ----
+    bool has_dia = false;
+    tts_hip_dia_desc dia{};
+    struct DiaEnc { size_t sa_norm = 0, mlp_norm = 0; W qkv, o, gu, out; };
+    struct DiaDec { size_t sa_norm = 0, ca_norm = 0, mlp_norm = 0; W sqkv, so, cq, ckv, co, gu, out; };
+    std::vector<DiaEnc> di_enc;
+    std::vector<DiaDec> di_dec;
+    size_t di_enc_embd = 0, di_enc_norm = 0, di_dec_norm = 0, di_embd[16] = {0};
+    W di_heads;
+    int di_EH = 0, di_EF = 0, di_DF = 0, di_A = 0, di_kvH = 0, di_V = 0, di_Vpad = 0, di_ksplit = 1, di_pending = 0, di_evocab = 0;
+    float *di_ex = nullptr, *di_exn = nullptr, *di_eqkv = nullptr, *di_eatt = nullptr, *di_egu = nullptr, *di_eg = nullptr, *di_ek = nullptr, *di_ev = nullptr;
+    float *di_ckv = nullptr, *di_ck = nullptr, *di_cv = nullptr, *di_k = nullptr, *di_v = nullptr;
+    float *di_x = nullptr, *di_xn = nullptr, *di_qkv = nullptr, *di_q = nullptr, *di_att = nullptr, *di_gu = nullptr, *di_g = nullptr, *di_parts = nullptr;
+    float *di_logits = nullptr, *di_guided = nullptr;
+    uint32_t *di_tok = nullptr, *di_epos = nullptr, *di_eseq = nullptr, *di_kbeg = nullptr, *di_kend = nullptr;
+    uint32_t *di_ids = nullptr, *di_pos = nullptr, *di_seq = nullptr, *di_cend = nullptr;
+    bool di_encoded = false;
     // ---- SNAC codec context (tts_hip_snac_create) ----
     bool has_snac = false;
     tts_hip_snac_desc snac{};
@@ -344,6 +362,10 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms); free_dev(c->d_pen); free_dev(c->d_last); free_dev(c->d_repc);
     free_dev(c->l_x); free_dev(c->l_xn); free_dev(c->l_qkv); free_dev(c->l_att); free_dev(c->l_gu); free_dev(c->l_g); free_dev(c->l_logits); free_dev(c->l_parts);
     free_dev(c->l_kc); free_dev(c->l_vc); free_dev(c->l_ids); free_dev(c->l_pos); free_dev(c->l_tok);
+    for (float *p : {c->di_ex, c->di_exn, c->di_eqkv, c->di_eatt, c->di_egu, c->di_eg, c->di_ek, c->di_ev, c->di_ckv, c->di_ck, c->di_cv, c->di_k, c->di_v, c->di_x,
+                     c->di_xn, c->di_qkv, c->di_q, c->di_att, c->di_gu, c->di_g, c->di_parts, c->di_logits, c->di_guided})
+        free_dev(p);
+    for (uint32_t *p : {c->di_tok, c->di_epos, c->di_eseq, c->di_kbeg, c->di_kend, c->di_ids, c->di_pos, c->di_seq, c->di_cend}) free_dev(p);
     for (int i = 0; i < 3; i++) free_dev(c->sbuf[i]);
     free_dev(c->s_noise); free_dev(c->s_codes);
     free_dev(c->t5_bucket); free_dev(c->t5_x); free_dev(c->t5_qkv); free_dev(c->t5_att); free_dev(c->t5_ug); free_dev(c->t5_g); free_dev(c->t5_y); free_dev(c->t5_ids); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
@@ -384,8 +406,12 @@ static bool is_t5_matmul(const std::string &name) {
 static bool is_llama_matmul(const std::string &name) {
     return starts_with(name, "orpheus.") && (ends_with(name, "_proj") || name == "orpheus.lm_head");
 }
+static bool is_dia_matmul(const std::string &name) {
+    return starts_with(name, "dia.") && (ends_with(name, "_proj") || ends_with(name, ".gate") || ends_with(name, ".up") || ends_with(name, ".wo") ||
+                                         name.find(".heads.") != std::string::npos);
+}
 static bool is_matmul_weight(const std::string &name) {
-    if (is_t5_matmul(name) || is_llama_matmul(name)) return true;
+    if (is_t5_matmul(name) || is_llama_matmul(name) || is_dia_matmul(name)) return true;
     return starts_with(name, "decoder.") && (ends_with(name, "_proj.weight") || ends_with(name, "fc1.weight") ||
                                               ends_with(name, "fc2.weight") || ends_with(name, "weight.head"));
 }
@@ -417,7 +443,7 @@ static int expand_q_to_i8(int type, const void *src, int64_t n, int8_t *q, uint1
 }
 
 static bool keeps_f16(const std::string &name) {
-    if (is_t5_matmul(name) || is_llama_matmul(name)) return true;
+    if (is_t5_matmul(name) || is_llama_matmul(name) || is_dia_matmul(name)) return true;
     if (!starts_with(name, "decoder.")) return false;
     if (name.find("layer_norm") != std::string::npos) return false;
     if (name == "decoder.positional_embed" || name == "decoder.text_encoding") return false;
@@ -429,7 +455,9 @@ extern "C" int tts_hip_upload(tts_hip_ctx *c, const char *name_c, int type, int 
     if (c->finalized) return set_err("tts_hip_upload(%s): context already finalized", name_c);
     HIPCHK(hipSetDevice(c->device));
     std::string name(name_c);
-    if (c->has_llama) {
+    if (c->has_dia) {
+        if (!starts_with(name, "dia.")) return 0;        // "audio_encoder.*" belongs to the codec context (dia/model.cpp:892-898)
+    } else if (c->has_llama) {
         if (!starts_with(name, "orpheus.")) return 0;    // "snac.*" belongs to the codec context (orpheus/model.cpp:430-438)
     } else if (c->has_snac) {
         if (!starts_with(name, "snac.")) return 0;       // the Orpheus GGUF also carries "orpheus.*" (orpheus/model.cpp)
@@ -646,6 +674,69 @@ static int plan(tts_hip_ctx *c) {
         c->F = c->l_layers.empty() ? 0 : (int) (c->l_layers[0].gu.N / 2);
         if (!c->l_layers.empty() && (int) c->l_layers[0].qkv.N != (c->NH + 2 * (int) ld.n_kv_heads) * (int) ld.head_dim && P.err.empty())
             P.err = "orpheus q/k/v projection shapes disagree with attn_heads / kv_attn_heads / head_dim";
+    }
+    if (c->has_dia) {
+        // dia_model (dia/model.h:16-84, assign_weight dia/model.cpp:3-139)
+        const tts_hip_dia_desc &dd = c->dia;
+        const int HD = (int) dd.head_dim;
+        c->H = (int) dd.dec_hidden_size; c->L = (int) dd.dec_layers; c->NH = (int) dd.dec_attn_heads; c->NO = (int) dd.n_output_heads;
+        c->di_EH = (int) dd.enc_hidden_size; c->di_A = c->NH * HD; c->di_kvH = (int) dd.dec_kv_heads * HD;
+        if (c->H <= 0 || c->L <= 0 || c->NH <= 0 || dd.dec_kv_heads == 0 || dd.enc_layers == 0 || dd.enc_attn_heads == 0 || dd.max_ctx == 0 || dd.max_gen == 0 ||
+            c->NO <= 0 || c->NO > 16 || dd.output_vocab_size == 0)
+            return set_err("plan: incomplete Dia hyper-parameters");
+        if (HD != 128) return set_err("plan: Dia head size %d unsupported (128, dia/model.h:74)", HD);
+        if (c->NH % (int) dd.dec_kv_heads) return set_err("plan: Dia attn_heads %% k/v groups != 0");
+        if ((int) dd.enc_attn_heads * HD != c->H || c->di_A != c->H)
+            return set_err("plan: Dia attention width (heads x head size) must equal the decoder hidden size (dia/model.cpp:410,593)");
+        c->di_enc_embd = P.place_f32("dia.encoder.embedding");
+        { const Tensor *t = P.get("dia.encoder.embedding"); c->di_evocab = t ? (int) (t->nelem() / t->ne[0]) : 0;
+          if (t && (int) t->ne[0] != c->di_EH && P.err.empty()) P.err = "dia.encoder.embedding width != enc_hidden_size"; }
+        c->di_enc_norm = P.place_f32("dia.encoder.norm");
+        c->di_dec_norm = P.place_f32("dia.decoder.norm");
+        std::vector<std::string> hn;
+        for (int i = 0; i < c->NO; i++) {
+            c->di_embd[i] = P.place_f32("dia.decoder.embeddings." + std::to_string(i));
+            hn.push_back("dia.decoder.heads." + std::to_string(i));
+        }
+        { const Tensor *t = P.get(hn[0]); c->di_V = t ? (int) (t->nelem() / t->ne[0]) : 0; }
+        if (c->di_V != (int) dd.output_vocab_size && P.err.empty()) P.err = "dia.decoder.output_vocab_size disagrees with dia.decoder.heads.0";
+        c->di_heads = P.fused(hn, 16);
+        c->di_Vpad = (int) c->di_heads.N;
+        c->di_enc.assign(dd.enc_layers, tts_hip_ctx::DiaEnc{});
+        for (uint32_t l = 0; l < dd.enc_layers; l++) {
+            const std::string p = "dia.encoder.layers." + std::to_string(l) + ".";
+            auto &y = c->di_enc[l];
+            y.sa_norm = P.place_f32(p + "pre_sa_norm");
+            y.qkv = P.fused({p + "q_proj", p + "k_proj", p + "v_proj"});
+            y.o = P.mat(p + "o_proj");
+            y.mlp_norm = P.place_f32(p + "post_sa_norm");
+            y.gu = P.fused({p + "gate", p + "up"});
+            y.out = P.mat(p + "wo");
+        }
+        c->di_dec.assign(dd.dec_layers, tts_hip_ctx::DiaDec{});
+        for (uint32_t l = 0; l < dd.dec_layers; l++) {
+            const std::string p = "dia.decoder.layers." + std::to_string(l) + ".";
+            auto &y = c->di_dec[l];
+            y.sa_norm = P.place_f32(p + "pre_sa_norm");
+            y.sqkv = P.fused({p + "self_q_proj", p + "self_k_proj", p + "self_v_proj"});
+            y.so = P.mat(p + "self_o_proj");
+            y.ca_norm = P.place_f32(p + "pre_ca_norm");
+            y.cq = P.mat(p + "cross_q_proj");
+            y.ckv = P.fused({p + "cross_k_proj", p + "cross_v_proj"});
+            y.co = P.mat(p + "cross_o_proj");
+            y.mlp_norm = P.place_f32(p + "pre_mlp_norm");
+            y.gu = P.fused({p + "gate", p + "up"});
+            y.out = P.mat(p + "wo");
+        }
+        c->di_EF = c->di_enc.empty() ? 0 : (int) (c->di_enc[0].gu.N / 2);
+        c->di_DF = c->di_dec.empty() ? 0 : (int) (c->di_dec[0].gu.N / 2);
+        c->F = c->di_DF;
+        if (P.err.empty() && !c->di_enc.empty() && !c->di_dec.empty()) {
+            if ((int) c->di_enc[0].qkv.N != 3 * c->di_A || (int) c->di_enc[0].qkv.K != c->di_EH) P.err = "dia encoder q/k/v projection shapes disagree with the hyper-parameters";
+            else if ((int) c->di_dec[0].sqkv.N != c->di_A + 2 * c->di_kvH) P.err = "dia decoder self q/k/v projection shapes disagree with attn_heads / query_heads / head size";
+            else if ((int) c->di_dec[0].ckv.N != 2 * c->di_A || (int) c->di_dec[0].ckv.K != c->di_EH) P.err = "dia decoder cross k/v projection shapes disagree with the hyper-parameters";
+            else if (c->di_EF > 4096 && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM)) P.err = "dia encoder feed-forward width above 4096 is not supported";
+        }
     }
     if (c->has_snac) {
         // snac_model (snac_model.h:10-40, assign_weight snac_model.cpp:50-84, layer tensors gnac.cpp:9-34)
@@ -1307,6 +1398,36 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->l_ids, (size_t) R));
         CHK(dmalloc(&c->l_pos, (size_t) R));
         CHK(dmalloc(&c->l_tok, (size_t) 1 + 2 * ARGMAX_PARTS + LLAMA_GREEDY_CHUNK));
+    }
+    if (c->has_dia) {
+        const tts_hip_dia_desc &dd = c->dia;
+        const int S = (int) dd.max_ctx, G = (int) dd.max_gen, EH = c->di_EH, EF = c->di_EF, DH = c->H, DF = c->di_DF, A = c->di_A, kvH = c->di_kvH;
+        const size_t n = (size_t) 2 * S;
+        c->RMAX = 256;
+        // decoder wo: K = DF columns in slices of at most 4096 (16 waves x 256) per workgroup, folded by the next rms norm
+        c->di_ksplit = 1;
+        while (DF / c->di_ksplit > 4096 || (DF % c->di_ksplit)) c->di_ksplit++;
+        if ((DF / c->di_ksplit) % 256 || (c->d.flags & TTS_HIP_FLAG_VALU_GEMM)) c->di_ksplit = 1;
+        CHK(dmalloc(&c->di_ex, n * EH)); CHK(dmalloc(&c->di_exn, n * EH)); CHK(dmalloc(&c->di_eqkv, n * 3 * A)); CHK(dmalloc(&c->di_eatt, n * A));
+        CHK(dmalloc(&c->di_egu, n * 2 * EF)); CHK(dmalloc(&c->di_eg, n * EF)); CHK(dmalloc(&c->di_ek, n * A)); CHK(dmalloc(&c->di_ev, n * A));
+        CHK(dmalloc(&c->di_ckv, n * 2 * A));
+        CHK(dmalloc(&c->di_ck, (size_t) c->L * n * A));   // zero like the reference's cleared cache (dia/model.cpp:329)
+        CHK(dmalloc(&c->di_cv, (size_t) c->L * n * A));
+        CHK(dmalloc(&c->di_k, (size_t) c->L * 2 * G * kvH));
+        CHK(dmalloc(&c->di_v, (size_t) c->L * 2 * G * kvH));
+        CHK(dmalloc(&c->di_x, (size_t) 2 * DH)); CHK(dmalloc(&c->di_xn, (size_t) 2 * DH)); CHK(dmalloc(&c->di_qkv, (size_t) 2 * (A + 2 * kvH)));
+        CHK(dmalloc(&c->di_q, (size_t) 2 * A)); CHK(dmalloc(&c->di_att, (size_t) 2 * A)); CHK(dmalloc(&c->di_gu, (size_t) 2 * 2 * DF)); CHK(dmalloc(&c->di_g, (size_t) 2 * DF));
+        CHK(dmalloc(&c->di_parts, (size_t) 8 * c->RMAX * DH));
+        CHK(dmalloc(&c->di_logits, (size_t) 2 * c->di_Vpad)); CHK(dmalloc(&c->di_guided, (size_t) c->NO * c->di_V));
+        const int maxK = std::max(std::max(EH, EF), std::max(std::max(DH, DF), A));
+        CHK(dmalloc(&c->dbg, (size_t) c->RMAX * maxK));
+        CHK(dmalloc(&c->aq, (size_t) c->RMAX * maxK));
+        CHK(dmalloc(&c->ad, (size_t) c->RMAX * maxK / 32 + 1));
+        CHK(dmalloc(&c->di_tok, n)); CHK(dmalloc(&c->di_epos, n)); CHK(dmalloc(&c->di_eseq, n)); CHK(dmalloc(&c->di_kbeg, n)); CHK(dmalloc(&c->di_kend, n));
+        CHK(dmalloc(&c->di_ids, (size_t) 16)); CHK(dmalloc(&c->di_pos, (size_t) 2)); CHK(dmalloc(&c->di_seq, (size_t) 2)); CHK(dmalloc(&c->di_cend, (size_t) 2));
+        const uint32_t seq01[2] = {0u, 1u}, cend[2] = {(uint32_t) S, (uint32_t) S};
+        HIPCHK(hipMemcpy(c->di_seq, seq01, 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->di_cend, cend, 8, hipMemcpyHostToDevice));
     }
     if (c->has_t5) {
         const int H = c->H, F = c->F, S = (int) c->t5.max_ctx_length;
@@ -2252,10 +2373,12 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
         float *kc = c->l_kc + (size_t) l * NCTX * c->l_kvH, *vc = c->l_vc + (size_t) l * NCTX * c->l_kvH;
         CHK(rms(y.in_norm, n, c->l_x, c->l_xn));
         CHK(llama_gemm(c, y.qkv, c->l_xn, H, c->l_qkv, QKV, n, EPI_STORE));
-        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH + NKV), dim3(64), 0, c->stream, c->l_qkv, (const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, HD, kc, vc);
+        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH + NKV), dim3(64), 0, c->stream, c->l_qkv, (const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, HD, kc, vc,
+                           (const uint32_t *) nullptr, (int64_t) 0);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, n), dim3(256), (size_t) (128 + pos0 + n) * 4, c->stream, (const float *) c->l_qkv, QKV, (const uint32_t *) c->l_pos,
-                           (const float *) kc, (const float *) vc, NH, NKV, 1.0f / sqrtf((float) HD), c->l_att);
+                           (const float *) kc, (const float *) vc, NH, NKV, 1.0f / sqrtf((float) HD), c->l_att,
+                           (const uint32_t *) nullptr, (const uint32_t *) nullptr, (const uint32_t *) nullptr, (int64_t) 0);
         HIPCHK(hipGetLastError());
         CHK(llama_gemm(c, y.o, c->l_att, NH * HD, c->l_x, H, n, EPI_RESID));
         CHK(rms(y.post_norm, n, c->l_x, c->l_xn));
@@ -2343,6 +2466,195 @@ extern "C" int tts_hip_orpheus_generate_greedy(tts_hip_ctx *c, const uint32_t *p
         }
         tok = host_hist[s];
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dia (src/models/dia/model.cpp:383-659)
+// ------------------------------------------------------------------------------------------------
+extern "C" tts_hip_ctx *tts_hip_dia_create(int device, const tts_hip_dia_desc *dd) {
+    if (!dd || dd->struct_size != sizeof(tts_hip_dia_desc)) { set_err("tts_hip_dia_create: bad desc (struct_size mismatch)"); return nullptr; }
+    tts_hip_desc d{};
+    d.struct_size = sizeof(d);
+    d.hidden_size = dd->dec_hidden_size; d.n_layers = dd->dec_layers; d.n_attn_heads = dd->dec_attn_heads; d.max_ctx_length = dd->max_gen;
+    d.max_seqs = 1;
+    d.flags = (dd->flags & (TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q)) | TTS_HIP_FLAG_NO_PARLER | TTS_HIP_FLAG_NO_DAC;
+    tts_hip_ctx *c = tts_hip_create(device, &d);
+    if (!c) return nullptr;
+    c->has_dia = true;
+    c->dia = *dd;
+    if (c->dia.cfg_scale == 0.0f) c->dia.cfg_scale = 3.0f;
+    return c;
+}
+
+// rows in pieces of RMAX (the activation-quantisation scratch holds RMAX rows); ksplit > 1 only with n <= RMAX
+static int dia_gemm(tts_hip_ctx *c, const W &w, const float *A, int lda, float *out, int ldo, int n, int epi, int ksplit = 1) {
+    if (ksplit > 1 && n > c->RMAX) return set_err("dia_gemm: split-K needs all rows in one piece");
+    for (int r0 = 0; r0 < n; r0 += c->RMAX) {
+        GemmArgs g{};
+        g.R = std::min(c->RMAX, n - r0); g.H = c->H;
+        g.A = A + (size_t) r0 * lda; g.lda = lda;
+        g.out = out + (size_t) r0 * ldo; g.ldo = ldo;
+        if (ksplit > 1) {
+            g.kchunk = (int) w.K / ksplit;
+            g.slab_stride = (int64_t) c->RMAX * ldo;
+        }
+        CHK(run_gemm(c, TTS_HIP_K_GEMM_OTHER, w, g, PRO_F32, epi));
+    }
+    return 0;
+}
+
+static int dia_rms(tts_hip_ctx *c, size_t w_off, int rows, int H, float *x, float *y, bool fold) {
+    const int pend = fold ? c->di_pending : 0;
+    hipLaunchKernelGGL(rms_fold_rows_kernel, dim3(rows), dim3(256), 0, c->stream, x, H, (const float *) (c->arena + w_off), y, rows, 1e-5f,
+                       pend ? (const float *) c->di_parts : (const float *) nullptr, pend, (int64_t) c->RMAX * H);
+    if (fold) c->di_pending = 0;
+    return hipGetLastError() == hipSuccess ? 0 : set_err("rms_fold_rows_kernel launch failed");
+}
+
+extern "C" int tts_hip_dia_encode(tts_hip_ctx *c, const uint32_t *tokens, uint32_t sentence_len, float *enc_out) {
+    if (!c || !c->has_dia) return set_err("tts_hip_dia_encode: not a Dia context (tts_hip_dia_create)");
+    if (!c->finalized || !c->weights_present) return set_err("tts_hip_dia_encode: context not finalized");
+    if (!tokens) return set_err("tts_hip_dia_encode: null argument");
+    const int S = (int) c->dia.max_ctx, EH = c->di_EH, EF = c->di_EF, A = c->di_A, HD = (int) c->dia.head_dim, ENH = (int) c->dia.enc_attn_heads;
+    const int NH = c->NH, n = 2 * S;
+    if (sentence_len == 0 || sentence_len > (uint32_t) S) return set_err("tts_hip_dia_encode: sentence length %u outside 1..%d", sentence_len, S);
+    std::vector<uint32_t> tok((size_t) n, 0u), epos((size_t) n), eseq((size_t) n), kbeg((size_t) n), kend((size_t) n);
+    for (int t = 0; t < S; t++) {
+        if (tokens[t] >= (uint32_t) c->di_evocab) return set_err("tts_hip_dia_encode: token %u >= encoder vocabulary %d", tokens[t], c->di_evocab);
+        tok[(size_t) t] = tokens[t];
+    }
+    for (int t = 0; t < n; t++) {   // set_inputs :712-721: real positions see real positions, pad positions see pad positions
+        const uint32_t p = (uint32_t) (t % S);
+        epos[(size_t) t] = p; eseq[(size_t) t] = (uint32_t) (t / S);
+        kbeg[(size_t) t] = p < sentence_len ? 0u : sentence_len;
+        kend[(size_t) t] = p < sentence_len ? sentence_len : (uint32_t) S;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nb = (size_t) n * 4;
+    HIPCHK(hipMemcpyAsync(c->di_tok, tok.data(), nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->di_epos, epos.data(), nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->di_eseq, eseq.data(), nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->di_kbeg, kbeg.data(), nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->di_kend, kend.data(), nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // the vectors are locals
+    auto f32 = [&](size_t off) { return (const float *) (c->arena + off); };
+    const float theta_scale = powf(10000.0f, -2.0f / (float) HD);   // ggml_rope(..., head_size, 2): default base
+    const size_t attn_lds = (size_t) (128 + S) * 4;
+    static std::atomic<uint64_t> attr{0};
+    if (attn_lds > 48 * 1024 && attr_needed(attr, c->device))
+        HIPCHK(hipFuncSetAttribute((const void *) attn_gqa_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192));
+    hipLaunchKernelGGL(t5_embed_kernel, dim3(n), dim3(256), 0, c->stream, f32(c->di_enc_embd), (const uint32_t *) c->di_tok, EH, c->di_ex);
+    HIPCHK(hipGetLastError());
+    for (const auto &y : c->di_enc) {
+        CHK(dia_rms(c, y.sa_norm, n, EH, c->di_ex, c->di_exn, false));
+        CHK(dia_gemm(c, y.qkv, c->di_exn, EH, c->di_eqkv, 3 * A, n, EPI_STORE));
+        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, 2 * ENH), dim3(64), 0, c->stream, c->di_eqkv, (const uint32_t *) c->di_epos, (const float *) nullptr, theta_scale,
+                           ENH, ENH, HD, c->di_ek, c->di_ev, (const uint32_t *) c->di_eseq, (int64_t) S * A);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(ENH, n), dim3(256), attn_lds, c->stream, (const float *) c->di_eqkv, 3 * A, (const uint32_t *) c->di_epos,
+                           (const float *) c->di_ek, (const float *) c->di_ev, ENH, ENH, 1.0f, c->di_eatt, (const uint32_t *) c->di_kbeg, (const uint32_t *) c->di_kend,
+                           (const uint32_t *) c->di_eseq, (int64_t) S * A);
+        HIPCHK(hipGetLastError());
+        CHK(dia_gemm(c, y.o, c->di_eatt, A, c->di_ex, EH, n, EPI_RESID));
+        CHK(dia_rms(c, y.mlp_norm, n, EH, c->di_ex, c->di_exn, false));
+        CHK(dia_gemm(c, y.gu, c->di_exn, EH, c->di_egu, 2 * EF, n, EPI_STORE));
+        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) n * EF + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->di_egu, EF, n, c->di_eg);
+        HIPCHK(hipGetLastError());
+        CHK(dia_gemm(c, y.out, c->di_eg, EF, c->di_ex, EH, n, EPI_RESID));
+    }
+    CHK(dia_rms(c, c->di_enc_norm, n, EH, c->di_ex, c->di_exn, false));
+    // cross K/V of every decoder layer (build_dia_cross_kv_store :505-541): V for all positions, K (rope'd with the encoder
+    // positions) only for the sentence; the other K rows are zero as in the freshly cleared cache
+    for (int l = 0; l < c->L; l++) {
+        const auto &y = c->di_dec[(size_t) l];
+        float *ck = c->di_ck + (size_t) l * n * A, *cv = c->di_cv + (size_t) l * n * A;
+        CHK(dia_gemm(c, y.ckv, c->di_exn, EH, c->di_ckv, 2 * A, n, EPI_STORE));
+        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH), dim3(64), 0, c->stream, c->di_ckv, (const uint32_t *) c->di_epos, (const float *) nullptr, theta_scale, 0, NH,
+                           HD, ck, cv, (const uint32_t *) c->di_eseq, (int64_t) S * A);
+        HIPCHK(hipGetLastError());
+        if ((int) sentence_len < S)
+            for (int b = 0; b < 2; b++)
+                HIPCHK(hipMemsetAsync(ck + ((size_t) b * S + sentence_len) * A, 0, (size_t) (S - (int) sentence_len) * A * 4, c->stream));
+    }
+    if (enc_out) HIPCHK(hipMemcpyAsync(enc_out, c->di_exn, (size_t) n * EH * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->di_encoded = true;
+    return 0;
+}
+
+extern "C" int tts_hip_dia_step(tts_hip_ctx *c, const uint32_t *ids, uint32_t pos, float *logits_out, float *raw_out) {
+    if (!c || !c->has_dia) return set_err("tts_hip_dia_step: not a Dia context (tts_hip_dia_create)");
+    if (!c->finalized || !c->weights_present) return set_err("tts_hip_dia_step: context not finalized");
+    if (!c->di_encoded) return set_err("tts_hip_dia_step: tts_hip_dia_encode has not run");
+    if (!ids || !logits_out) return set_err("tts_hip_dia_step: null argument");
+    const int S = (int) c->dia.max_ctx, G = (int) c->dia.max_gen, DH = c->H, DF = c->di_DF, A = c->di_A, kvH = c->di_kvH, HD = (int) c->dia.head_dim;
+    const int NH = c->NH, NKV = (int) c->dia.dec_kv_heads, NO = c->NO, V = c->di_V, QKV = A + 2 * kvH;
+    if (pos >= (uint32_t) G) return set_err("tts_hip_dia_step: position %u outside the %d cached positions", pos, G);
+    for (int i = 0; i < NO; i++)
+        if (ids[i] >= (uint32_t) V) return set_err("tts_hip_dia_step: id %u >= output vocabulary %d", ids[i], V);
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t pp[2] = {pos, pos};
+    HIPCHK(hipMemcpyAsync(c->di_ids, ids, (size_t) NO * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->di_pos, pp, 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // pp is a local
+    auto f32 = [&](size_t off) { return (const float *) (c->arena + off); };
+    const float theta_scale = powf(10000.0f, -2.0f / (float) HD);
+    static std::atomic<uint64_t> attr{0};
+    if ((size_t) (128 + std::max(S, G)) * 4 > 48 * 1024 && attr_needed(attr, c->device))
+        HIPCHK(hipFuncSetAttribute((const void *) attn_gqa_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192));
+    DiaEmbedArgs ea{};
+    for (int i = 0; i < NO; i++) ea.table[i] = f32(c->di_embd[i]);
+    ea.ids = c->di_ids; ea.n_out = NO; ea.H = DH; ea.x = c->di_x;
+    hipLaunchKernelGGL(dia_embed_kernel, dim3((DH + 255) / 256), dim3(256), 0, c->stream, ea);
+    HIPCHK(hipGetLastError());
+    c->di_pending = 0;
+    const uint32_t *nul = nullptr;
+    for (int l = 0; l < c->L; l++) {
+        const auto &y = c->di_dec[(size_t) l];
+        float *kc = c->di_k + (size_t) l * 2 * G * kvH, *vc = c->di_v + (size_t) l * 2 * G * kvH;
+        const float *ck = c->di_ck + (size_t) l * 2 * S * A, *cv = c->di_cv + (size_t) l * 2 * S * A;
+        CHK(dia_rms(c, y.sa_norm, 2, DH, c->di_x, c->di_xn, true));
+        CHK(dia_gemm(c, y.sqkv, c->di_xn, DH, c->di_qkv, QKV, 2, EPI_STORE));
+        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(2, NH + NKV), dim3(64), 0, c->stream, c->di_qkv, (const uint32_t *) c->di_pos, (const float *) nullptr, theta_scale, NH,
+                           NKV, HD, kc, vc, (const uint32_t *) c->di_seq, (int64_t) G * kvH);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, 2), dim3(256), (size_t) (128 + pos + 1) * 4, c->stream, (const float *) c->di_qkv, QKV,
+                           (const uint32_t *) c->di_pos, (const float *) kc, (const float *) vc, NH, NKV, 1.0f, c->di_att, nul, nul, (const uint32_t *) c->di_seq,
+                           (int64_t) G * kvH);
+        HIPCHK(hipGetLastError());
+        CHK(dia_gemm(c, y.so, c->di_att, A, c->di_x, DH, 2, EPI_RESID));
+        CHK(dia_rms(c, y.ca_norm, 2, DH, c->di_x, c->di_xn, false));
+        CHK(dia_gemm(c, y.cq, c->di_xn, DH, c->di_q, A, 2, EPI_STORE));
+        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(2, NH), dim3(64), 0, c->stream, c->di_q, (const uint32_t *) c->di_pos, (const float *) nullptr, theta_scale, NH, 0, HD,
+                           (float *) nullptr, (float *) nullptr, nul, (int64_t) 0);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, 2), dim3(256), (size_t) (128 + S) * 4, c->stream, (const float *) c->di_q, A, (const uint32_t *) c->di_pos, ck, cv,
+                           NH, NH, 1.0f, c->di_att, nul, (const uint32_t *) c->di_cend, (const uint32_t *) c->di_seq, (int64_t) S * A);
+        HIPCHK(hipGetLastError());
+        CHK(dia_gemm(c, y.co, c->di_att, A, c->di_x, DH, 2, EPI_RESID));
+        CHK(dia_rms(c, y.mlp_norm, 2, DH, c->di_x, c->di_xn, false));
+        CHK(dia_gemm(c, y.gu, c->di_xn, DH, c->di_gu, 2 * DF, 2, EPI_STORE));
+        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) 2 * DF + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->di_gu, DF, 2, c->di_g);
+        HIPCHK(hipGetLastError());
+        if (c->di_ksplit > 1) {
+            CHK(dia_gemm(c, y.out, c->di_g, DF, c->di_parts, DH, 2, EPI_STORE, c->di_ksplit));
+            c->di_pending = c->di_ksplit;
+        } else {
+            CHK(dia_gemm(c, y.out, c->di_g, DF, c->di_x, DH, 2, EPI_RESID));
+        }
+    }
+    CHK(dia_rms(c, c->di_dec_norm, 2, DH, c->di_x, c->di_xn, true));
+    GemmArgs g{};
+    g.R = 2; g.H = DH; g.A = c->di_xn; g.lda = DH; g.out = c->di_logits; g.ldo = c->di_Vpad;
+    CHK(run_gemm(c, TTS_HIP_K_GEMM_HEADS, c->di_heads, g, PRO_F32, EPI_STORE));
+    hipLaunchKernelGGL(dia_cfg_kernel, dim3((NO * V + 255) / 256), dim3(256), 0, c->stream, (const float *) c->di_logits, c->di_Vpad, NO * V, c->dia.cfg_scale, c->di_guided);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(logits_out, c->di_guided, (size_t) NO * V * 4, hipMemcpyDeviceToHost, c->stream));
+    if (raw_out)
+        for (int b = 0; b < 2; b++)
+            HIPCHK(hipMemcpyAsync(raw_out + (size_t) b * NO * V, c->di_logits + (size_t) b * c->di_Vpad, (size_t) NO * V * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

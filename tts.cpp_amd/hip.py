@@ -57,6 +57,13 @@ class OrpheusDesc(C.Structure):
                 ("rope_base", C.c_float), ("flags", C.c_uint32)]
 
 
+class DiaDesc(C.Structure):
+    """tts_hip_dia_desc (include/tts_hip.h)"""
+    _fields_ = [(n, C.c_uint32) for n in ("struct_size", "enc_hidden_size", "enc_layers", "enc_attn_heads", "dec_hidden_size", "dec_layers", "dec_attn_heads",
+                                          "dec_kv_heads", "head_dim", "n_output_heads", "output_vocab_size", "max_ctx", "max_gen")] + [
+        ("cfg_scale", C.c_float), ("flags", C.c_uint32)]
+
+
 class KStat(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("launches", C.c_uint64), ("bytes_total", C.c_double), ("flops_total", C.c_double)]
 
@@ -66,7 +73,7 @@ EXPORTS = [
     "tts_hip_upload", "tts_hip_arena_bytes", "tts_hip_finalize", "tts_hip_arena_ptr", "tts_hip_arena_filled",
     "tts_hip_parler_set_text_encoding", "tts_hip_parler_reset", "tts_hip_parler_prefill", "tts_hip_parler_prefill_batch", "tts_hip_parler_step",
     "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits",
-    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
+    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
     "tts_hip_synchronize",
 ]
@@ -119,6 +126,10 @@ def load_lib():
     L.tts_hip_orpheus_create.argtypes = [C.c_int, C.POINTER(OrpheusDesc)]
     L.tts_hip_orpheus_decode.argtypes = [vp, u32p, C.c_uint32, C.c_uint32, f32p, u32p]
     L.tts_hip_orpheus_generate_greedy.argtypes = [vp, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
+    L.tts_hip_dia_create.restype = vp
+    L.tts_hip_dia_create.argtypes = [C.c_int, C.POINTER(DiaDesc)]
+    L.tts_hip_dia_encode.argtypes = [vp, u32p, C.c_uint32, f32p]
+    L.tts_hip_dia_step.argtypes = [vp, u32p, C.c_uint32, f32p, f32p]
     L.tts_hip_snac_create.restype = vp
     L.tts_hip_snac_create.argtypes = [C.c_int, C.POINTER(SnacDesc)]
     L.tts_hip_snac_decode.argtypes = [vp, u32p, C.c_uint32, f32p, f32p]
@@ -483,6 +494,60 @@ class OrpheusEngine:
         n = C.c_uint32()
         self._chk(self.L.tts_hip_orpheus_generate_greedy(self.ctx, ap, a.size, max_new, stop_id, out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n)))
         return out[:n.value]
+
+    def close(self):
+        if self.ctx:
+            self.L.tts_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DiaEngine:
+    """A Dia context (tts_hip_dia_create): encoder + cross K/V once per sentence, then one decoder step per call."""
+
+    def __init__(self, cfg, device=0, flags=0, cfg_scale=0.0):
+        self.L = load_lib()
+        self.cfg = cfg
+        d = DiaDesc()
+        d.struct_size = C.sizeof(DiaDesc)
+        d.enc_hidden_size, d.enc_layers, d.enc_attn_heads = cfg.enc_hidden, cfg.enc_layers, cfg.enc_heads
+        d.dec_hidden_size, d.dec_layers, d.dec_attn_heads, d.dec_kv_heads = cfg.dec_hidden, cfg.dec_layers, cfg.dec_heads, cfg.dec_kv_heads
+        d.head_dim, d.n_output_heads, d.output_vocab_size, d.max_ctx, d.max_gen = cfg.head_dim, cfg.n_out, cfg.out_vocab, cfg.max_ctx, cfg.max_gen
+        d.cfg_scale, d.flags = cfg_scale, flags
+        self.ctx = self.L.tts_hip_dia_create(device, C.byref(d))
+        if not self.ctx:
+            raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
+
+    def load(self, model):
+        for t in model.tensors:
+            ne = (C.c_int64 * 4)(*(t.ne + [1] * (4 - len(t.ne))))
+            raw = np.frombuffer(bytes(t.raw()), dtype=np.uint8)
+            self._chk(self.L.tts_hip_upload(self.ctx, t.name.encode(), t.type, len(t.ne), ne, raw.ctypes.data_as(C.c_void_p)))
+        self._chk(self.L.tts_hip_finalize(self.ctx, None))
+
+    def encode(self, tokens, sentence_len, want_states=False):
+        a, ap = _u32(tokens)
+        assert a.size == self.cfg.max_ctx
+        out = np.empty((2, self.cfg.max_ctx, self.cfg.enc_hidden), dtype=np.float32) if want_states else None
+        self._chk(self.L.tts_hip_dia_encode(self.ctx, ap, sentence_len, out.ctypes.data_as(C.POINTER(C.c_float)) if want_states else None))
+        return out
+
+    def step(self, ids, pos, want_raw=False):
+        a, ap = _u32(ids)
+        lg = np.empty((self.cfg.n_out, self.cfg.out_vocab), dtype=np.float32)
+        raw = np.empty((2, self.cfg.n_out, self.cfg.out_vocab), dtype=np.float32) if want_raw else None
+        self._chk(self.L.tts_hip_dia_step(self.ctx, ap, pos, lg.ctypes.data_as(C.POINTER(C.c_float)),
+                                          raw.ctypes.data_as(C.POINTER(C.c_float)) if want_raw else None))
+        return (lg, raw) if want_raw else lg
 
     def close(self):
         if self.ctx:
