@@ -69,3 +69,36 @@ def test_dia_second_sentence_and_errors():
     with pytest.raises(hip.HipError):
         eng.encode(short_t, 0)
     eng.close()
+
+
+def test_dia_runner_generates_through_both_contexts(tmp_path):
+    """runner_from_file on a Dia GGUF (dia.* + audio_encoder.*): byte tokenisation with speaker tags (model.cpp:661-705),
+    greedy generate_from_batch with the end-of-sequence countdown (:767-833), un-delay (:787-808), DAC — equal to the oracle
+    pipeline."""
+    from tts_cpp_amd import runner
+    model = synth.build_dia(synth.dia_tiny(), suppress_special=True)
+    cfg = model.cfg
+    path = model.write_gguf(str(tmp_path / "dia.gguf"))
+    r = runner.Runner(path, sample=0)
+    assert r.arch == "dia" and r.sampling_rate == 44100.0
+    text = " Hi there [S2] ok"
+    pcm = r.generate(text, sample=0)
+    toks, n = orc.dia_tokenize(text, cfg.max_ctx)
+    assert r.last_tokens(0).tolist() == toks.tolist()
+    o = orc.DiaOracle(model, act_mode=1)
+    outs, frames = o.generate(text)
+    got = r.last_tokens(1).reshape(-1, cfg.n_out)
+    assert got.shape == outs.shape == (cfg.max_gen - 1, cfg.n_out)
+    assert np.array_equal(got, outs)
+    ref = orc.DacOracle(model.dac).decode(frames)
+    assert pcm.shape == ref.shape == (len(frames) * cfg.hop,)
+    assert np.abs(pcm - ref).max() < 1e-4
+    short = r.generate(text, sample=0, max_tokens=24)               # config.max_tokens bounds the loop (:812-818): the countdown starts at step 9
+    outs_s, frames_s = o.generate(text, max_tokens=24)
+    assert np.array_equal(r.last_tokens(1).reshape(-1, cfg.n_out), outs_s) and len(outs_s) == 23
+    assert np.abs(short - orc.DacOracle(model.dac).decode(frames_s)).max() < 1e-4
+    sampled = r.generate(text, sample=1, top_k=8, seed=5)
+    assert sampled.size % cfg.hop == 0 and np.isfinite(sampled).all()
+    with pytest.raises(runner.RunnerError):
+        r.generate(text, sample=0, max_tokens=7)                    # GGML_ASSERT(max_tokens == 0 || max_tokens > max_delay)
+    r.close()

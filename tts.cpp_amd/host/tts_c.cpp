@@ -7,6 +7,7 @@
 
 #include "common.h"
 #include "gguf.h"
+#include "dia_runner.h"
 #include "orpheus_runner.h"
 #include "parler_runner.h"
 #include "sampler.h"
@@ -94,6 +95,8 @@ int tts_c_last_tokens(tts_c_runner * r, int which, uint32_t * out, int cap) {
         vp = which == 0 ? &p->last_prompt_tokens : (which == 2 ? &p->last_conditional_tokens : &p->last_output_tokens);
     else if (auto * o = dynamic_cast<orpheus_runner *>((tts_generation_runner *) r))
         vp = which == 0 ? &o->last_prompt_tokens : (which == 1 ? &o->last_output_tokens : &none);
+    else if (auto * d = dynamic_cast<dia_runner *>((tts_generation_runner *) r))
+        vp = which == 0 ? &d->last_prompt_tokens : (which == 1 ? &d->last_output_tokens : &none);
     if (!vp) { g_c_err = "runner keeps no token record"; return -1; }
     const std::vector<uint32_t> & v = *vp;
     const int n = (int) v.size();
