@@ -97,6 +97,15 @@ void tts_c_pool_free(tts_c_pool *pool);
 int tts_c_gguf_summary(const char *path, uint64_t *n_tensors, uint64_t *n_kv, uint64_t *data_offset, char *arch, int arch_cap);
 int tts_c_gguf_tensor(const char *path, int index, char *name, int name_cap, int *type, int64_t ne[4], uint64_t *checksum);
 
+/* ---- Dia host logic, callable without a device (host/dia_runner.h; reference src/models/dia/model.cpp) -------------
+ * tokenize_sentence :661-705: out[max_ctx] = the sentence bytes ([S1]/[S2] -> 1/2) then zeros; returns the sentence length or -1 */
+int tts_c_dia_tokenize(const char *sentence, uint32_t max_ctx, uint32_t *out);
+/* check_stopping :767-785 with the default 9-head delay pattern; ids[9] may be rewritten; returns 1 when generation stops */
+int tts_c_dia_check_stopping(uint32_t *ids, uint32_t eos, uint32_t pad, uint32_t max_delay, uint32_t current_position, uint32_t max_generation_size,
+                             int *delay_steps);
+/* adjust_output_tokens :787-808: tokens[n_steps][9] -> filtered frames [..][9]; returns the number of ids written */
+int64_t tts_c_dia_adjust_output_tokens(const uint32_t *tokens, uint64_t n_ids, uint32_t audio_vocab, uint32_t max_delay, uint32_t *filtered);
+
 /* ---- the quantize tool (examples/quantize/quantize_impl.h:5-15: quantization_params + quantize_gguf) ------------
  * Host only.  quantize_type is the ggml type number (F16 1, Q4_0 2, Q5_0 6, Q8_0 8; quantize.cpp:11-20). */
 typedef struct tts_c_quantization_params {

@@ -258,3 +258,36 @@ def test_bpe_tokenizer_matches_python_restatement(tmp_path):
         assert list(out[:n]) == o.tokenize(text), text
     assert o.tokenize("abc") == [8]                 # whole-piece hit
     assert o.tokenize("hello hello") == [15, 16]    # "Ġ" prefix after the first space
+
+
+# ---- Dia host logic (host/dia_runner.cpp) against the oracle's restatement of src/models/dia/model.cpp:661-808 --------------
+def test_dia_host_tokenizer_matches_oracle():
+    import oracle as orc
+    for text in ["hello world", "  [S2] spaced out.  ", "[S1] a [S2] b [S1] c", "no tag, with comma", "x", "[S1]", "café naïve"]:
+        want, n = orc.dia_tokenize(text, 48)
+        got, m = runner.dia_tokenize(text, 48)
+        assert m == n and np.array_equal(got, want), text
+    assert runner.dia_tokenize("café", 16)[0].max() < 256          # UTF-8 bytes stay byte values (see DESIGN: the reference sign-extends)
+    with pytest.raises(runner.RunnerError):
+        runner.dia_tokenize("a" * 60, 48)                                # longer than the encoder context (model.cpp:689-691)
+
+
+def test_dia_host_stopping_and_undelay_match_oracle():
+    import oracle as orc
+    from tts_cpp_amd import synth
+    cfg = synth.dia_tiny()
+    o = orc.DiaOracle(synth.build_dia(cfg))
+    rng = np.random.default_rng(4)
+    # every (position, countdown state) the loop can be in, with and without an EOS on head 0
+    for max_gen in (40, 100):
+        for pos in range(0, max_gen):
+            for d in (-1, 15, 9, 1):
+                ids = rng.integers(0, cfg.audio_vocab, cfg.n_out).astype(np.uint32)
+                if pos % 7 == 3:
+                    ids[0] = cfg.eos
+                want = o.check_stopping(ids, pos, max_gen, d)
+                got = runner.dia_check_stopping(ids, cfg.eos, cfg.pad, cfg.max_delay, pos, max_gen, d)
+                assert got[0] == want[0] and np.array_equal(got[1], want[1]) and got[2] == want[2], (max_gen, pos, d)
+    for steps in (10, 16, 17, 40):
+        toks = rng.integers(0, cfg.audio_vocab + 3, (steps, cfg.n_out)).astype(np.uint32)   # a few specials: frames get dropped
+        assert np.array_equal(runner.dia_adjust_output_tokens(toks, cfg.audio_vocab, cfg.max_delay), o.adjust_output_tokens(toks)), steps

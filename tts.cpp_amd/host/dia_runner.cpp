@@ -109,7 +109,7 @@ void dia_runner::prepare_post_load() {
     logits.resize((size_t) hp.n_output_heads * hp.output_vocab_size);
 }
 
-uint32_t dia_runner::tokenize_sentence(std::string sentence, std::vector<uint32_t> & tokens) const {
+uint32_t dia_tokenize_sentence(const dia_hparams & hp, std::string sentence, std::vector<uint32_t> & tokens) {
     const size_t b = sentence.find_first_not_of(' '), e = sentence.find_last_not_of(' ');   // strip(), util.cpp:273-281
     sentence = b == std::string::npos ? std::string() : sentence.substr(b, e - b + 1);
     const std::string start = sentence.substr(0, 4);
@@ -128,7 +128,7 @@ uint32_t dia_runner::tokenize_sentence(std::string sentence, std::vector<uint32_
     return (uint32_t) sentence.size();
 }
 
-bool dia_runner::check_stopping(std::vector<uint32_t> & audio_tokens, uint32_t current_position, uint32_t max_generation_size, int & delay_steps) const {
+bool dia_check_stopping(const dia_hparams & hp, std::vector<uint32_t> & audio_tokens, uint32_t current_position, uint32_t max_generation_size, int & delay_steps) {
     if (delay_steps == -1 && (audio_tokens[0] == hp.eos_token_id || current_position >= max_generation_size - hp.max_delay)) delay_steps = (int) hp.max_delay;
     if (delay_steps > 0) {
         const int step_after_eos = (int) hp.max_delay - delay_steps;
@@ -141,7 +141,7 @@ bool dia_runner::check_stopping(std::vector<uint32_t> & audio_tokens, uint32_t c
     return delay_steps == 0;
 }
 
-void dia_runner::adjust_output_tokens(const std::vector<uint32_t> & output_tokens, std::vector<uint32_t> & filtered) const {
+void dia_adjust_output_tokens(const dia_hparams & hp, const std::vector<uint32_t> & output_tokens, std::vector<uint32_t> & filtered) {
     const size_t size = output_tokens.size(), nh = hp.n_output_heads;
     filtered.clear();
     filtered.reserve(size);
@@ -170,7 +170,7 @@ void dia_runner::generate(const char * sentence, tts_response & output, const ge
     output.data = nullptr;
     output.n_outputs = 0;
 
-    const uint32_t sentence_length = tokenize_sentence(sentence, last_prompt_tokens);
+    const uint32_t sentence_length = dia_tokenize_sentence(hp, sentence, last_prompt_tokens);
     smp.reset();
     hip_check(tts_hip_dia_encode(lm, last_prompt_tokens.data(), sentence_length, nullptr), "tts_hip_dia_encode");
 
@@ -182,7 +182,7 @@ void dia_runner::generate(const char * sentence, tts_response & output, const ge
     std::vector<uint32_t> audio_tokens(nh, hp.bos_token_id);
     uint32_t current_position = 0;
     int      delay_steps = -1;
-    while (!check_stopping(audio_tokens, current_position, max_gen, delay_steps)) {
+    while (!dia_check_stopping(hp, audio_tokens, current_position, max_gen, delay_steps)) {
         hip_check(tts_hip_dia_step(lm, audio_tokens.data(), current_position, logits.data(), nullptr), "tts_hip_dia_step");
         smp.sample(logits.data(), out);
         current_position += 1;
@@ -191,7 +191,7 @@ void dia_runner::generate(const char * sentence, tts_response & output, const ge
     }
 
     std::vector<uint32_t> filtered;
-    adjust_output_tokens(out, filtered);
+    dia_adjust_output_tokens(hp, out, filtered);
     const uint32_t frames = (uint32_t) (filtered.size() / nh);
     if (frames == 0) return;
     pcm.assign((size_t) frames * hp.up_sampling_factor, 0.0f);

@@ -32,6 +32,12 @@ struct dia_hparams {  // defaults = nari-labs/Dia-1.6B (dia/model.h:64-84)
     uint32_t up_sampling_factor = 512;
 };
 
+// host logic of the runner as free functions of the hyper-parameters (no device behind them; the runner and the CPU tests call these)
+uint32_t dia_tokenize_sentence(const dia_hparams & hp, std::string sentence, std::vector<uint32_t> & tokens);                               // model.cpp:661-705
+bool     dia_check_stopping(const dia_hparams & hp, std::vector<uint32_t> & audio_tokens, uint32_t current_position, uint32_t max_generation_size,
+                            int & delay_steps);                                                                                             // :767-785
+void     dia_adjust_output_tokens(const dia_hparams & hp, const std::vector<uint32_t> & output_tokens, std::vector<uint32_t> & filtered);   // :787-808
+
 struct dia_runner final : tts_generation_runner {
     dia_runner(const dia_hparams & hp, int device);
     ~dia_runner() override;
@@ -40,10 +46,6 @@ struct dia_runner final : tts_generation_runner {
     void prepare_post_load() override;
     void generate(const char * sentence, tts_response & output, const generation_configuration & config) override;
 
-    // pieces exposed for tests
-    uint32_t tokenize_sentence(std::string sentence, std::vector<uint32_t> & tokens) const;                                    // model.cpp:661-705
-    bool     check_stopping(std::vector<uint32_t> & audio_tokens, uint32_t current_position, uint32_t max_generation_size, int & delay_steps) const;  // :767-785
-    void     adjust_output_tokens(const std::vector<uint32_t> & output_tokens, std::vector<uint32_t> & filtered) const;         // :787-808
     std::vector<uint32_t> last_prompt_tokens, last_output_tokens;
 
     dia_hparams        hp;

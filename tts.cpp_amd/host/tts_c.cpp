@@ -175,6 +175,41 @@ int tts_c_gguf_tensor(const char * path, int index, char * name, int name_cap, i
 
 }  // extern "C"
 
+// ---- Dia host logic (host/dia_runner.h) -----------------------------------------------------------------------
+extern "C" int tts_c_dia_tokenize(const char * sentence, uint32_t max_ctx, uint32_t * out) {
+    g_tts_throw_on_abort = true;
+    try {
+        dia_hparams hp;
+        hp.max_encoder_context_length = max_ctx;
+        std::vector<uint32_t> t;
+        const uint32_t n = dia_tokenize_sentence(hp, sentence, t);
+        memcpy(out, t.data(), (size_t) max_ctx * 4);
+        return (int) n;
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return -1;
+    }
+}
+
+extern "C" int tts_c_dia_check_stopping(uint32_t * ids, uint32_t eos, uint32_t pad, uint32_t max_delay, uint32_t current_position,
+                                        uint32_t max_generation_size, int * delay_steps) {
+    dia_hparams hp;
+    hp.eos_token_id = eos; hp.pad_token_id = pad; hp.max_delay = max_delay;
+    std::vector<uint32_t> v(ids, ids + hp.delay_pattern.size());
+    const bool stop = dia_check_stopping(hp, v, current_position, max_generation_size, *delay_steps);
+    memcpy(ids, v.data(), v.size() * 4);
+    return stop ? 1 : 0;
+}
+
+extern "C" int64_t tts_c_dia_adjust_output_tokens(const uint32_t * tokens, uint64_t n_ids, uint32_t audio_vocab, uint32_t max_delay, uint32_t * filtered) {
+    dia_hparams hp;
+    hp.audio_vocab_size = audio_vocab; hp.max_delay = max_delay;
+    std::vector<uint32_t> in(tokens, tokens + n_ids), out;
+    dia_adjust_output_tokens(hp, in, out);
+    memcpy(filtered, out.data(), out.size() * 4);
+    return (int64_t) out.size();
+}
+
 // ---- quantize tool (host/quantize.h) -------------------------------------------------------------------------
 #include "quantize.h"
 

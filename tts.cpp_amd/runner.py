@@ -29,7 +29,8 @@ class SamplerCfg(C.Structure):
 EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_generate_batch", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
            "tts_c_last_error", "tts_c_update_conditional_prompt", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor",
            "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_free",
-           "tts_c_quantize_gguf", "tts_c_quantize_decision", "tts_c_quantize_rows"]
+           "tts_c_quantize_gguf", "tts_c_quantize_decision", "tts_c_quantize_rows",
+           "tts_c_dia_tokenize", "tts_c_dia_check_stopping", "tts_c_dia_adjust_output_tokens"]
 
 _lib = None
 
@@ -65,6 +66,10 @@ def load_lib():
         L.tts_c_gguf_summary.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_int]
         L.tts_c_gguf_tensor.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
         L.tts_c_update_conditional_prompt.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.tts_c_dia_tokenize.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.tts_c_dia_check_stopping.argtypes = [C.POINTER(C.c_uint32)] + [C.c_uint32] * 5 + [C.POINTER(C.c_int)]
+        L.tts_c_dia_adjust_output_tokens.restype = C.c_int64
+        L.tts_c_dia_adjust_output_tokens.argtypes = [C.POINTER(C.c_uint32), C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         L.tts_c_quantize_gguf.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(QuantizationParams)]
         L.tts_c_quantize_decision.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(QuantizationParams)]
         L.tts_c_quantize_rows.restype = C.c_int64
@@ -159,6 +164,29 @@ def tokenize(gguf_path, text):
     if n < 0:
         raise RunnerError(L.tts_c_last_error().decode())
     return out[:n].copy()
+
+
+def dia_tokenize(sentence, max_ctx):
+    L = load_lib()
+    out = np.zeros(max_ctx, dtype=np.uint32)
+    n = L.tts_c_dia_tokenize(sentence.encode("utf-8") if isinstance(sentence, str) else sentence, max_ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if n < 0:
+        raise RunnerError(L.tts_c_last_error().decode("utf-8", "replace"))
+    return out, n
+
+
+def dia_check_stopping(ids, eos, pad, max_delay, position, max_generation_size, delay_steps):
+    a = np.ascontiguousarray(ids, dtype=np.uint32).copy()
+    d = C.c_int(delay_steps)
+    stop = load_lib().tts_c_dia_check_stopping(a.ctypes.data_as(C.POINTER(C.c_uint32)), eos, pad, max_delay, position, max_generation_size, C.byref(d))
+    return bool(stop), a, d.value
+
+
+def dia_adjust_output_tokens(tokens, audio_vocab, max_delay):
+    a = np.ascontiguousarray(tokens, dtype=np.uint32).reshape(-1)
+    out = np.zeros(a.size, dtype=np.uint32)
+    n = load_lib().tts_c_dia_adjust_output_tokens(a.ctypes.data_as(C.POINTER(C.c_uint32)), a.size, audio_vocab, max_delay, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out[:n].reshape(-1, 9)
 
 
 def _qparams(qtype, n_threads=1, output_heads=False, text_embeddings=False, cross_attn_kv=False, dac_f16=False, non_quantizable_f16=False):
