@@ -1,0 +1,78 @@
+"""Opt-in: the streaming 1..4-row GEMV kernels (csrc/gemv_kernels.h, TTS_HIP_GEMV_ROWS=1) against the oracle through the Orpheus
+and Dia steps.  Written without GPU time left in the round, so it only runs when asked for (TTS_TEST_EXPERIMENTAL=1); the
+default path (MFMA workgroups) is what every other test exercises.  First thing to run next round:
+    TTS_TEST_EXPERIMENTAL=1 python -m pytest tests/test_gpu_gemv_rows.py -q
+    TTS_HIP_GEMV_ROWS=1 python profiles/orpheus_bench.py ; TTS_HIP_GEMV_ROWS=1 python profiles/dia_bench.py"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from tts_cpp_amd import gguf, hip, synth
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("TTS_TEST_EXPERIMENTAL") != "1", reason="opt-in kernels (TTS_TEST_EXPERIMENTAL=1)")]
+HERE = os.path.dirname(__file__)
+
+
+def relerr(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(autouse=True)
+def _knob():
+    os.environ["TTS_HIP_GEMV_ROWS"] = "1"     # read when a context is created
+    yield
+    del os.environ["TTS_HIP_GEMV_ROWS"]
+
+
+@pytest.mark.parametrize("wtype,tol", [(gguf.F32, 2e-4), (gguf.F16, 2e-3), (gguf.Q4_0, 3e-2), (gguf.Q8_0, 3e-2)])
+def test_orpheus_steps_through_the_row_kernels(wtype, tol):
+    model = synth.build_orpheus(synth.orpheus_tiny(weight_type=wtype))
+    eng = hip.OrpheusEngine(model.cfg)
+    eng.load(model)
+    o = orc.OrpheusOracle(model, act_mode=1)
+    g = np.load(os.path.join(HERE, "golden", "tiny_orpheus.npz"))
+    prompt = g["prompt"]
+    ref = o.decode(prompt[:3], 0)                    # 3 rows: the row kernels; the 9-token prompt would take the MFMA path
+    lg, _ = eng.decode(prompt[:3], 0)
+    assert relerr(lg, ref) < tol
+    pos = 3
+    for step in range(6):
+        t = int(ref.argmax())
+        lg, _ = eng.decode([t], pos)
+        ref = o.decode([t], pos)
+        assert relerr(lg, ref) < tol, step
+        pos += 1
+    eng.close()
+
+
+@pytest.mark.parametrize("wtype,tol", [(gguf.F32, 2e-4), (gguf.F16, 2e-3), (gguf.Q8_0, 3e-2)])
+def test_dia_steps_through_the_row_kernels(wtype, tol):
+    kw = dict(enc_hidden=256) if wtype == gguf.Q8_0 else {}
+    model = synth.build_dia(synth.dia_tiny(weight_type=wtype, **kw))
+    eng = hip.DiaEngine(model.cfg)
+    eng.load(model)
+    o = orc.DiaOracle(model, act_mode=1)
+    g = np.load(os.path.join(HERE, "golden", "tiny_dia.npz"))
+    n = int(g["sentence_len"])
+    eng.encode(g["tokens"], n)
+    o.encode(g["tokens"], n)
+    for s_ in range(len(g["ids"])):
+        lg, raw = eng.step(g["ids"][s_], s_, want_raw=True)
+        ref, ref_raw = o.step(g["ids"][s_], s_, want_raw=True)
+        assert relerr(raw, ref_raw) < tol, s_
+        assert relerr(lg, ref) < 4 * tol, s_
+    eng.close()
+
+
+def test_wide_feed_forward_without_split_k():
+    """ffn 8192: the MFMA path splits K in two slabs folded by the next rms norm; the row kernels walk all of K — same numbers"""
+    cfg = synth.orpheus_tiny(ffn=8192, layers=1)
+    model = synth.build_orpheus(cfg)
+    o = orc.OrpheusOracle(model, act_mode=1)
+    eng = hip.OrpheusEngine(cfg)
+    eng.load(model)
+    lg, _ = eng.decode([5, 7], 0)
+    assert relerr(lg, o.decode([5, 7], 0)) < 2e-4
+    eng.close()

@@ -1,0 +1,115 @@
+// gemv_kernels.h — streaming matrix-vector kernels for 1..4 activation rows (the batch-1 / two-stream steps of the Orpheus and
+// Dia decoders: mul_mat of [N][K] weights with 1-2 rows, orpheus/model.cpp:240-283, dia/model.cpp:557-648).
+//
+// The 16-feature MFMA workgroups of gemm16_kernel / qgemm16_kernel are shaped for lock-step batches (the MFMA tile gives up to 16
+// rows for free); with one or two rows and matrices of 2048..16384 features they leave few, large workgroups with a long
+// dependent chain each (measured: 1.3 TB/s on the Orpheus-3B matrices, profiles/r01/kernel_stats_orpheus_3b_q4_0_first_version.csv).
+// Here one wave owns one output feature: every lane streams 16-byte pieces of that weight row (all loads of a row are independent
+// and issued back to back), the activation rows are tiny and stay in L2/L1, and a wave-wide sum finishes the feature.  N waves
+// (thousands) fill the chip; no LDS, no barriers.
+//   gemv_rows_kernel<WT, NR>    F32 / F16 weights; F16: activations rounded to fp16 first (ggml's vec_dot_type conversion), fp32 accumulate
+//   gemv_q8_rows_kernel<NR>     int8 block integers + fp16 block scales (Q4_0/Q5_0/Q8_0 expanded at upload) x Q8_0-quantised activations:
+//                               exact integer block dots (v_dot4_i32_i8), scaled by d_w * d_a and summed in fp32 (ggml's vec_dot_q*_q8_0)
+// Opt-in (TTS_HIP_GEMV_ROWS=1) until measured against the MFMA path on the GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+template <int WT, int NR>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(GemmArgs a, int epi) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    const int K = a.K;
+    float acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) acc[r] = 0.0f;
+    if (WT == 1) {
+        const _Float16 *w = (const _Float16 *) a.W + (int64_t) n * K;
+#pragma unroll 4
+        for (int k = lane * 8; k < K; k += 512) {   // K % 256 == 0 on this path: a lane's 8 columns never straddle the end
+            const half8 wv = *(const half8 *) (w + k);
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                if (r < a.R) {
+                    const float *x = (const float *) a.A + (int64_t) r * a.lda + k;
+                    const float4v x0 = *(const float4v *) x, x1 = *(const float4v *) (x + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        acc[r] += (float) wv[e] * (float) (_Float16) x0[e];
+                        acc[r] += (float) wv[4 + e] * (float) (_Float16) x1[e];
+                    }
+                }
+            }
+        }
+    } else {
+        const float *w = (const float *) a.W + (int64_t) n * K;
+#pragma unroll 4
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4v wv = *(const float4v *) (w + k);
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                if (r < a.R) {
+                    const float4v x0 = *(const float4v *) ((const float *) a.A + (int64_t) r * a.lda + k);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[r] += wv[e] * x0[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        if (r < a.R) {
+            const float s = wave_sum(acc[r]);
+            if (lane == 0) {
+                float *o = a.out + (int64_t) r * a.ldo + n;
+                if (epi == EPI_RESID) *o += s;
+                else *o = s;
+            }
+        }
+    }
+}
+
+template <int NR>
+__global__ __launch_bounds__(256) void gemv_q8_rows_kernel(QGemmArgs qa, int epi) {
+    const GemmArgs &a = qa.g;
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    const int K = a.K, nb = K >> 5;
+    const int8_t *w = (const int8_t *) a.W + (int64_t) n * K;
+    const _Float16 *wd = qa.wd + (int64_t) n * nb;
+    float acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) acc[r] = 0.0f;
+#pragma unroll 2
+    for (int b = lane; b < nb; b += 64) {   // one 32-value block per lane and pass: two 16-byte loads
+        const int4v w0 = *(const int4v *) (w + b * 32), w1 = *(const int4v *) (w + b * 32 + 16);
+        const float dw = (float) wd[b];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            if (r < a.R) {
+                const int8_t *xq = qa.aq + (int64_t) r * K + b * 32;
+                const int4v x0 = *(const int4v *) xq, x1 = *(const int4v *) (xq + 16);
+                int s = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    s = __builtin_amdgcn_sdot4(w0[e], x0[e], s, false);
+                    s = __builtin_amdgcn_sdot4(w1[e], x1[e], s, false);
+                }
+                acc[r] += (float) s * (dw * qa.ad[(int64_t) r * nb + b]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        if (r < a.R) {
+            const float s = wave_sum(acc[r]);
+            if (lane == 0) {
+                float *o = a.out + (int64_t) r * a.ldo + n;
+                if (epi == EPI_RESID) *o += s;
+                else *o = s;
+            }
+        }
+    }
+}

@@ -25,6 +25,7 @@
 #include "t5_kernels.h"
 #include "llama_kernels.h"
 #include "dia_kernels.h"
+#include "gemv_kernels.h"
 #define LLAMA_GREEDY_CHUNK 8
 
 // ------------------------------------------------------------------------------------------------
@@ -196,6 +197,7 @@ struct tts_hip_ctx {
     float *ad = nullptr;        // their block scales
     bool all_q8i = false;       // every decoder matrix is on the integer path (all GEMMs go through run_qgemm)
     int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
+    bool gemv_rows = false;     // TTS_HIP_GEMV_ROWS=1: 1..4 rows go through the streaming one-wave-per-feature kernels (gemv_kernels.h)
     // ---- Orpheus decoder context (tts_hip_orpheus_create) ----
     bool has_llama = false;
     tts_hip_orpheus_desc lm{};
@@ -346,6 +348,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
     if (const char *e = getenv("TTS_HIP_Q_FUSE_MAX")) c->q_fuse_max = std::max(0, std::min(16, atoi(e)));
+    if (const char *e = getenv("TTS_HIP_GEMV_ROWS")) c->gemv_rows = atoi(e) != 0;
     return c;
 }
 
@@ -1039,6 +1042,19 @@ static int launch_qgemm16_rb(tts_hip_ctx *c, const QGemmArgs &qa, bool fused_qua
 // GGUF-quantised matrix: LayerNorm (if any) -> Q8_0-quantise the activation rows -> integer block GEMM
 static int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi) {
     if (pro == PRO_F16) return set_err("run_qgemm: fp16 activations are never produced for a quantised consumer");
+    if (c->gemv_rows && a.R <= 4 && pro == PRO_F32 && (epi == EPI_STORE || epi == EPI_RESID) && !a.kchunk) {
+        CHK(prof_begin(c, kclass, (double) w.K * w.N * (1.0 + 2.0 / 32) + (double) a.R * a.K * 5 + (double) a.R * a.N * 4, 2.0 * a.R * (double) w.K * w.N));
+        hipLaunchKernelGGL(quant_rows_q8_kernel, dim3((a.K / 32 + 7) / 8, a.R), dim3(256), 0, c->stream, (const float *) a.A, a.lda, a.K, c->aq, c->ad, a.R);
+        HIPCHK(hipGetLastError());
+        QGemmArgs qa{};
+        qa.g = a;
+        qa.wd = (const _Float16 *) (c->arena + w.soff);
+        qa.aq = c->aq;
+        qa.ad = c->ad;
+        hipLaunchKernelGGL(gemv_q8_rows_kernel<4>, dim3((a.N + 3) / 4), dim3(256), 0, c->stream, qa, epi);
+        HIPCHK(hipGetLastError());
+        return prof_end(c);
+    }
     // few rows: LayerNorm + quantisation inside every GEMM workgroup (one launch instead of three)
     const bool fused_ln = pro == PRO_LN && a.R <= std::min(c->ln_fuse_max, 8) && a.K <= 2048 && !c->pending_parts && c->q_fuse_max > 0;
     if (pro == PRO_LN && !fused_ln) {
@@ -1110,6 +1126,13 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
         const int wpb = 4;
         if (w.type == TTS_HIP_F16) hipLaunchKernelGGL(gemv_valu_kernel<1>, dim3((a.N + wpb - 1) / wpb), dim3(wpb * 64), 0, c->stream, b, epi, pro == PRO_F16 ? 1 : 0);
         else hipLaunchKernelGGL(gemv_valu_kernel<0>, dim3((a.N + wpb - 1) / wpb), dim3(wpb * 64), 0, c->stream, b, epi, pro == PRO_F16 ? 1 : 0);
+        HIPCHK(hipGetLastError());
+        return prof_end(c);
+    }
+    if (c->gemv_rows && a.R <= 4 && pro == PRO_F32 && (epi == EPI_STORE || epi == EPI_RESID) && !a.kchunk) {
+        CHK(prof_begin(c, kclass, bytes, flops));
+        if (w.type == TTS_HIP_F16) hipLaunchKernelGGL((gemv_rows_kernel<1, 4>), dim3((a.N + 3) / 4), dim3(256), 0, c->stream, a, epi);
+        else hipLaunchKernelGGL((gemv_rows_kernel<0, 4>), dim3((a.N + 3) / 4), dim3(256), 0, c->stream, a, epi);
         HIPCHK(hipGetLastError());
         return prof_end(c);
     }
@@ -1407,7 +1430,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         // decoder wo: K = DF columns in slices of at most 4096 (16 waves x 256) per workgroup, folded by the next rms norm
         c->di_ksplit = 1;
         while (DF / c->di_ksplit > 4096 || (DF % c->di_ksplit)) c->di_ksplit++;
-        if ((DF / c->di_ksplit) % 256 || (c->d.flags & TTS_HIP_FLAG_VALU_GEMM)) c->di_ksplit = 1;
+        if ((DF / c->di_ksplit) % 256 || (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) || c->gemv_rows) c->di_ksplit = 1;
         CHK(dmalloc(&c->di_ex, n * EH)); CHK(dmalloc(&c->di_exn, n * EH)); CHK(dmalloc(&c->di_eqkv, n * 3 * A)); CHK(dmalloc(&c->di_eatt, n * A));
         CHK(dmalloc(&c->di_egu, n * 2 * EF)); CHK(dmalloc(&c->di_eg, n * EF)); CHK(dmalloc(&c->di_ek, n * A)); CHK(dmalloc(&c->di_ev, n * A));
         CHK(dmalloc(&c->di_ckv, n * 2 * A));
@@ -2385,9 +2408,10 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
         CHK(llama_gemm(c, y.gu, c->l_xn, H, c->l_gu, 2 * F, n, EPI_STORE));
         hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) n * F + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->l_gu, F, n, c->l_g);
         HIPCHK(hipGetLastError());
-        if (c->l_ksplit > 1) {
-            CHK(llama_gemm(c, y.down, c->l_g, F, c->l_parts, H, n, EPI_STORE, c->l_ksplit));
-            c->l_pending = c->l_ksplit;
+        const int ks = (c->gemv_rows && n <= 4) ? 1 : c->l_ksplit;   // the streaming kernels walk all of K themselves
+        if (ks > 1) {
+            CHK(llama_gemm(c, y.down, c->l_g, F, c->l_parts, H, n, EPI_STORE, ks));
+            c->l_pending = ks;
         } else {
             CHK(llama_gemm(c, y.down, c->l_g, F, c->l_x, H, n, EPI_RESID));
         }
