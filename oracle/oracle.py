@@ -716,3 +716,92 @@ class DiaOracle:
             self.L.orc_dia_state_free(self.state)
         except Exception:
             pass
+
+
+class KokoroModelC(C.Structure):
+    _fields_ = [("n_tensors", C.c_int32), ("names", C.POINTER(C.c_char_p)), ("data", C.POINTER(fp)), ("ne", C.POINTER(C.c_int64))] + [
+        (n, C.c_int32) for n in ("n_heads", "n_recurrence", "n_dp_layers", "f0_n_blocks", "n_conv_layers", "n_decoder_blocks", "n_upsamples", "n_kernels",
+                                 "n_fft", "hop", "harmonic_num", "up_sampling_factor", "out_conv_padding")] + [
+        (n, C.c_float) for n in ("attn_scale", "upsample_scale", "sample_rate", "sin_amp", "noise_std", "voice_threshold")] + [
+        ("up_stride", C.c_int32 * 4), ("up_padding", C.c_int32 * 4), ("noise_stride", C.c_int32 * 4), ("noise_padding", C.c_int32 * 4),
+        ("res_padding", (C.c_int32 * 3) * 16), ("res_dilation", (C.c_int32 * 3) * 16), ("noise_res_padding", (C.c_int32 * 3) * 4),
+        ("noise_res_dilation", (C.c_int32 * 3) * 4)]
+
+
+class KokoroOracle:
+    """Oracle twin of a tts_cpp_amd.synth.SynthKokoro (src/models/kokoro/model.cpp restated in kokoro_oracle.c; PARITY UNPINNED,
+    see that file's header).  The phonemizer is outside: inputs are phoneme ids with the bos / eos ids around them."""
+
+    def __init__(self, model, attn_scale=0.125):
+        self.L = lib()
+        L = self.L
+        L.orc_kokoro_durations.argtypes = [C.POINTER(KokoroModelC), C.POINTER(C.c_uint32), C.c_int, fp, fp, fp]
+        L.orc_kokoro_durations.restype = None
+        L.orc_kokoro_generate.argtypes = [C.POINTER(KokoroModelC), C.POINTER(C.c_uint32), C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp]
+        L.orc_kokoro_generate.restype = C.c_int64
+        cfg = model.cfg
+        self.cfg, self.model = cfg, model
+        ts = model.tensors
+        self.arrs = [np.ascontiguousarray(t.to_f32().reshape(-1)) for t in ts]
+        self.names = (C.c_char_p * len(ts))(*[t.name.encode() for t in ts])
+        self.ptrs = (fp * len(ts))(*[f32p(a) for a in self.arrs])
+        self.ne = np.array([t.ne + [1] * (4 - len(t.ne)) for t in ts], dtype=np.int64)
+        m = KokoroModelC()
+        m.n_tensors, m.names, m.data, m.ne = len(ts), self.names, self.ptrs, self.ne.ctypes.data_as(C.POINTER(C.c_int64))
+        m.n_heads, m.n_recurrence, m.n_dp_layers, m.f0_n_blocks, m.n_conv_layers = cfg.heads, cfg.recurrence, cfg.dp_layers, cfg.f0_blocks, cfg.conv_layers
+        m.n_decoder_blocks, m.n_upsamples, m.n_kernels = cfg.decoder_blocks, len(cfg.up_rates), len(cfg.res_kernels)
+        m.n_fft, m.hop, m.harmonic_num, m.up_sampling_factor, m.out_conv_padding = cfg.n_fft, cfg.hop, cfg.harmonic_num, cfg.up_sampling_factor, 3
+        # model.h:196,195,219-222 defaults
+        m.attn_scale, m.upsample_scale, m.sample_rate, m.sin_amp, m.noise_std, m.voice_threshold = attn_scale, float(np.prod(cfg.up_rates) * cfg.hop), 24000.0, 0.1, 0.003, 10.0
+        g = model.geometry
+        for i, (st, pd) in enumerate(g["up"]):
+            m.up_stride[i], m.up_padding[i] = st, pd
+        for i, (st, pd) in enumerate(g["noise"]):
+            m.noise_stride[i], m.noise_padding[i] = st, pd
+        for i, blk in enumerate(g["res"]):
+            for ii, (pd, dl) in enumerate(blk):
+                m.res_padding[i][ii], m.res_dilation[i][ii] = pd, dl
+        for i, blk in enumerate(g["noise_res"]):
+            for ii, (pd, dl) in enumerate(blk):
+                m.noise_res_padding[i][ii], m.noise_res_dilation[i][ii] = pd, dl
+        self.m = m
+
+    def voice(self, name):
+        return np.ascontiguousarray(self.model.by_name["kokoro.voice_tensors." + name].to_f32())
+
+    def durations(self, tokens, voice):
+        """-> (lengths [n], hidden states [n][D + S])"""
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        v = self.voice(voice)
+        lens = np.empty(tokens.size, dtype=np.float32)
+        hid = np.empty((tokens.size, self.cfg.dp_hidden + self.cfg.style_half), dtype=np.float32)
+        self.L.orc_kokoro_durations(C.byref(self.m), u32p(tokens), tokens.size, f32p(v), f32p(lens), f32p(hid))
+        return lens, hid
+
+    def noise_len(self, total):
+        return (self.cfg.harmonic_num + 1) * total * self.cfg.up_sampling_factor
+
+    def stft_shape(self, total):
+        return (2 * (self.cfg.n_fft // 2 + 1), 2 * total * int(np.prod(self.cfg.up_rates)) + 1)
+
+    def generate(self, tokens, lens, hidden, voice, noise, want_curves=False, hsrc_in=None):
+        """want_curves: also return the F0 / N curves and the STFT conditioning; hsrc_in: use this conditioning instead (see kokoro_oracle.c)"""
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        lens = np.ascontiguousarray(lens, dtype=np.float32)
+        hidden = np.ascontiguousarray(hidden, dtype=np.float32)
+        total = int(lens.sum())
+        noise = np.ascontiguousarray(noise, dtype=np.float32)
+        assert noise.size == self.noise_len(total)
+        v = self.voice(voice)
+        pcm = np.empty(total * self.cfg.up_sampling_factor, dtype=np.float32)
+        f0 = np.empty(2 * total, dtype=np.float32)
+        nn = np.empty(2 * total, dtype=np.float32)
+        hs = np.empty(self.stft_shape(total), dtype=np.float32)
+        hin = None
+        if hsrc_in is not None:
+            hin = np.ascontiguousarray(hsrc_in, dtype=np.float32)
+            assert hin.shape == hs.shape
+        n = self.L.orc_kokoro_generate(C.byref(self.m), u32p(tokens), tokens.size, f32p(lens), f32p(hidden), f32p(v), f32p(noise), f32p(pcm), f32p(f0), f32p(nn),
+                                       f32p(hs), f32p(hin) if hin is not None else None)
+        assert n == pcm.size
+        return (pcm, f0, nn, hs) if want_curves else pcm

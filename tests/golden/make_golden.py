@@ -9,6 +9,7 @@ primitive; they do NOT pin it against ggml ("parity unpinned", DESIGN.md §oracl
 
 Run from the repo root:  python tests/golden/make_golden.py
 """
+import math
 import os
 import sys
 
@@ -22,6 +23,7 @@ import tts_cpp_amd  # noqa: E402
 from tts_cpp_amd import gguf, synth  # noqa: E402
 
 D = torch.float64
+D_ = torch.float64
 
 
 def T(model, name):
@@ -345,12 +347,201 @@ def torch_dia(model, tokens, sentence_len, ids_seq, cfg_scale=3.0):
     return enc, torch.stack(guided), torch.stack(raws)
 
 
+def torch_kokoro(model, tokens, voice_name, noise, attn_scale=0.125, only_durations=False, dbg=None, hsrc_in=None):
+    """Kokoro (src/models/kokoro/model.cpp) in float64 torch through library modules — nn.LSTM, F.layer_norm, F.instance_norm,
+    F.conv1d / conv_transpose1d (groups, output_padding), F.interpolate (nearest, linear), torch.stft / torch.istft — i.e. the
+    PyTorch definitions the C oracle restates by hand.  Returns lengths, duration hidden states, F0 / N curves and the audio."""
+    c = model.cfg
+    E, H, D, S = c.albert_embd, c.hidden, c.dp_hidden, c.style_half
+
+    def P(name):
+        return T_(model, "kokoro." + name)
+
+    def make_lstm(base, inp, hid):
+        l = torch.nn.LSTM(inp, hid, batch_first=True, bidirectional=True).double()
+        with torch.no_grad():
+            for sfx, wn, bn in (("", "weights", "biases"), ("_reverse", "reverse_weights", "reverse_biases")):
+                getattr(l, "weight_ih_l0" + sfx).copy_(torch.cat([P(f"{base}.0.{wn}.{2 * j}") for j in range(4)]))
+                getattr(l, "weight_hh_l0" + sfx).copy_(torch.cat([P(f"{base}.0.{wn}.{2 * j + 1}") for j in range(4)]))
+                getattr(l, "bias_ih_l0" + sfx).copy_(torch.cat([P(f"{base}.0.{bn}.{2 * j}") for j in range(4)]))
+                getattr(l, "bias_hh_l0" + sfx).copy_(torch.cat([P(f"{base}.0.{bn}.{2 * j + 1}") for j in range(4)]))
+        return l
+
+    n = len(tokens)
+    ids = torch.tensor(np.asarray(tokens, dtype=np.int64))
+    voice = P("voice_tensors." + voice_name)
+    style_p, style_d = voice[n - 3, S:], voice[n - 3, :S]
+    # ---- ALBERT
+    x = P("albert.token_embd")[ids] + P("albert.position_embd")[:n] + P("albert.token_type_embd")
+    x = Fn.layer_norm(x, (E,), P("albert.norm"), P("albert.norm_bias"), eps=1e-12)
+    x = Fn.linear(x, P("albert.embd"), P("albert.embd_bias"))
+    L0 = "albert.layer.0."
+    hs = H // c.heads
+    for _ in range(c.recurrence):
+        q = Fn.linear(x, P(L0 + "q"), P(L0 + "q_bias")).view(n, c.heads, hs)
+        k = Fn.linear(x, P(L0 + "k"), P(L0 + "k_bias")).view(n, c.heads, hs)
+        v = Fn.linear(x, P(L0 + "v"), P(L0 + "v_bias")).view(n, c.heads, hs)
+        att = torch.einsum("hnt,thd->nhd", torch.softmax(torch.einsum("nhd,thd->hnt", q, k) * attn_scale, -1), v).reshape(n, H)
+        x = Fn.layer_norm(Fn.linear(att, P(L0 + "o"), P(L0 + "o_bias")) + x, (H,), P(L0 + "ffn_norm"), P(L0 + "ffn_norm_bias"), eps=1e-12)
+        ff = Fn.linear(Fn.gelu(Fn.linear(x, P(L0 + "ffn"), P(L0 + "ffn_bias")), approximate="tanh"), P(L0 + "ffn_out"), P(L0 + "ffn_out_bias"))
+        x = Fn.layer_norm(ff + x, (H,), P(L0 + "attn_norm"), P(L0 + "attn_norm_bias"), eps=1e-12)
+    # ---- prosody predictor
+    dp = "duration_predictor."
+    cur = torch.cat([Fn.linear(x, P(dp + "encode"), P(dp + "encode_bias")), style_p.expand(n, S)], dim=1)
+    for l in range(c.dp_layers):
+        y, _ = make_lstm(f"{dp}layers.{2 * l}.lstm", D + S, D // 2)(cur[None])
+        gamma = Fn.linear(style_p, P(f"{dp}layers.{2 * l + 1}.gamma_weight"), P(f"{dp}layers.{2 * l + 1}.gamma_bias"))
+        beta = Fn.linear(style_p, P(f"{dp}layers.{2 * l + 1}.beta_weight"), P(f"{dp}layers.{2 * l + 1}.beta_bias"))
+        y = Fn.layer_norm(y[0], (D,), eps=1e-5)
+        cur = torch.cat([(1 + gamma) * y + beta, style_p.expand(n, S)], dim=1)
+    hidden = cur
+    y, _ = make_lstm(dp + "duration_lstm", D + S, D // 2)(cur[None])
+    dur = torch.sigmoid(Fn.linear(y[0], P(dp + "duration_proj"), P(dp + "duration_proj_bias"))).sum(-1)
+    lens = torch.clamp(torch.floor(dur + 0.5), 1, 50)     # roundf for positive sums
+    if only_durations:
+        return lens, hidden
+    # ---- alignment + F0 / N
+    tok_of = torch.repeat_interleave(torch.arange(n), lens.long())
+    T = len(tok_of)
+    en = hidden[tok_of]
+    sh, _ = make_lstm(dp + "shared_lstm", D + S, D // 2)(en[None])
+    sh = sh[0].t()[None]                                   # [1][D][T]
+
+    def adain(x_, style, base, k):
+        g = Fn.linear(style, P(f"{base}.{k}_gamma_weight"), P(f"{base}.{k}_gamma_bias"))
+        b = Fn.linear(style, P(f"{base}.{k}_beta_weight"), P(f"{base}.{k}_beta_bias"))
+        return (1 + g)[None, :, None] * Fn.instance_norm(x_, eps=1e-5) + b[None, :, None]
+
+    def ada_block(x_, style, base):
+        up = ("kokoro." + base + ".pool_weight") in model.by_name
+        y_ = Fn.leaky_relu(adain(x_, style, base, "norm1"), 0.2)
+        if up:
+            y_ = Fn.conv_transpose1d(y_, P(base + ".pool_weight"), P(base + ".pool_bias"), stride=2, padding=1, output_padding=1, groups=y_.shape[1])
+        y_ = Fn.conv1d(y_, P(base + ".conv1_weight"), P(base + ".conv1_bias"), padding=1)
+        y_ = Fn.leaky_relu(adain(y_, style, base, "norm2"), 0.2)
+        y_ = Fn.conv1d(y_, P(base + ".conv2_weight"), P(base + ".conv2_bias"), padding=1)
+        s_ = x_
+        if ("kokoro." + base + ".conv1x1_weight") in model.by_name:
+            if up:
+                s_ = Fn.interpolate(s_, scale_factor=2, mode="nearest")
+            s_ = Fn.conv1d(s_, P(base + ".conv1x1_weight"))
+        return (y_ + s_) / math.sqrt(2.0)
+
+    curves = []
+    for br in ("f0", "n"):
+        cur = sh
+        for i in range(c.f0_blocks):
+            cur = ada_block(cur, style_p, f"{dp}{br}_blocks.{i}")
+        curves.append(Fn.conv1d(cur, P(f"{dp}{br}_proj_kernel"), P(f"{dp}{br}_proj_bias"))[0, 0])
+    f0c, nc = curves
+    # ---- text encoder
+    t = P("text_encoder.embedding_weight")[ids].t()[None]
+    for l in range(c.conv_layers):
+        t = Fn.conv1d(t, P(f"text_encoder.layers.{l}.weight"), P(f"text_encoder.layers.{l}.bias"), padding=2)
+        t = Fn.layer_norm(t.transpose(1, 2), (t.shape[1],), P(f"text_encoder.layers.{l}.gamma"), P(f"text_encoder.layers.{l}.beta"), eps=1e-5).transpose(1, 2)
+        t = Fn.leaky_relu(t, 0.2)
+    tl, _ = make_lstm("text_encoder.lstm", D, D // 2)(t.transpose(1, 2))
+    asr = tl[0][tok_of].t()[None]                          # [1][C][T]
+    # ---- decoder
+    de = "decoder."
+    f0d = Fn.conv1d(f0c[None, None], P(de + "f0_conv_weight"), P(de + "f0_conv_bias"), stride=2, padding=1)
+    nd = Fn.conv1d(nc[None, None], P(de + "n_conv_weight"), P(de + "n_conv_bias"), stride=2, padding=1)
+    cur = ada_block(torch.cat([asr, f0d, nd], dim=1), style_d, de + "encoder_block")
+    asr_res = Fn.conv1d(asr, P(de + "asr_conv_weight"), P(de + "asr_conv_bias"))
+    for i in range(c.decoder_blocks):
+        cur = ada_block(torch.cat([cur, asr_res, f0d, nd], dim=1), style_d, f"{de}decoder_blocks.{i}")
+    if dbg is not None:
+        dbg["asr"], dbg["dec_out"] = asr[0], cur[0]
+    # ---- generator: harmonic source
+    g = de + "generator."
+    up = int(np.prod(c.up_rates)) * c.hop
+    NHm, L2 = c.harmonic_num + 1, f0c.shape[0]
+    LS = L2 * up
+    harm = torch.arange(1, NHm + 1, dtype=D_)[:, None]
+    rad = torch.remainder(f0c[None, :] * harm / 24000.0, 1.0)
+    phase = torch.cumsum(rad, dim=1) * (up * 2 * math.pi)
+    phase = Fn.interpolate(phase[None], scale_factor=up, mode="linear", align_corners=False)[0]
+    f0u = Fn.interpolate(f0c[None, None], scale_factor=up, mode="nearest")[0, 0]
+    voiced = f0u > 10.0
+    nz = torch.from_numpy(np.asarray(noise, dtype=np.float64)).view(NHm, LS)
+    sine = torch.sin(phase) * (voiced * 0.1)[None] + torch.where(voiced, torch.tensor(0.003, dtype=D_), torch.tensor(0.1 / 3.0, dtype=D_))[None] * nz
+    har = torch.tanh(Fn.linear(sine.t(), P(g + "m_source_weight"), P(g + "m_source_bias"))[:, 0])
+    N, hop = c.n_fft, c.hop
+    win = torch.sin(math.pi * torch.arange(N, dtype=D_) / N) ** 2
+    spec = torch.stft(har, N, hop, N, window=win, center=True, pad_mode="reflect", return_complex=True)     # [11][F]
+    hsrc = torch.cat([spec.abs(), spec.angle()], dim=0)[None]
+    hsrc_own = hsrc[0]
+    if hsrc_in is not None:
+        hsrc = torch.from_numpy(np.asarray(hsrc_in, dtype=np.float64))[None]
+    if dbg is not None:
+        dbg["sine"], dbg["har"], dbg["hsrc"] = sine, har, hsrc[0]
+
+    def gen_res(x_, base, pads, dils):
+        for j in range(3):
+            def ad(y_, a):
+                gm = Fn.linear(style_d, P(f"{base}.{j}.gamma{a}_weight"), P(f"{base}.{j}.gamma{a}_bias"))
+                bt = Fn.linear(style_d, P(f"{base}.{j}.beta{a}_weight"), P(f"{base}.{j}.beta{a}_bias"))
+                y_ = (1 + gm)[None, :, None] * Fn.instance_norm(y_, eps=1e-5) + bt[None, :, None]
+                al = P(f"{base}.{j}.alpha{a}")
+                return y_ + torch.sin(al * y_) ** 2 / al
+            y_ = Fn.conv1d(ad(x_, "1"), P(f"{base}.{j}.convs1_weight"), P(f"{base}.{j}.convs1_bias"), padding=pads[j], dilation=dils[j])
+            y_ = Fn.conv1d(ad(y_, "2"), P(f"{base}.{j}.convs2_weight"), P(f"{base}.{j}.convs2_bias"), padding=pads[0])
+            x_ = x_ + y_
+        return x_
+
+    geo = model.geometry
+    nk = len(c.res_kernels)
+    for i in range(len(c.up_rates)):
+        cur = Fn.leaky_relu(cur, 0.1)
+        cur = Fn.conv_transpose1d(cur, P(f"{g}ups.{i}.weight"), P(f"{g}ups.{i}.bias"), stride=geo["up"][i][0], padding=geo["up"][i][1])
+        if i == len(c.up_rates) - 1:
+            cur = Fn.pad(cur, (1, 0), mode="reflect")
+        xs = Fn.conv1d(hsrc, P(f"{g}noise_blocks.{i}.conv_weight"), P(f"{g}noise_blocks.{i}.conv_bias"), stride=geo["noise"][i][0], padding=geo["noise"][i][1])
+        xs = gen_res(xs, f"{g}noise_blocks.{i}.resblock", [p_ for p_, _ in geo["noise_res"][i]], [d_ for _, d_ in geo["noise_res"][i]])
+        cur = cur + xs
+        cur = sum(gen_res(cur, f"{g}resblocks.{i * nk + ii}", [p_ for p_, _ in geo["res"][i * nk + ii]], [d_ for _, d_ in geo["res"][i * nk + ii]]) for ii in range(nk)) / nk
+        if dbg is not None:
+            dbg[f"gen_stage{i}"] = cur[0]
+    cur = Fn.conv1d(Fn.leaky_relu(cur, 0.01), P(g + "conv_post_weight"), P(g + "conv_post_bias"), padding=3)[0]
+    nb = N // 2 + 1
+    mag, ph = torch.exp(cur[:nb]), torch.sin(cur[nb:])
+    if dbg is not None:
+        dbg["post"] = torch.cat([mag, ph])
+    out_len = T * c.up_sampling_factor
+    y = torch.istft(torch.polar(mag, ph), N, hop, N, window=win, center=True, length=out_len)
+    # torch divides by the window envelope of its F frames; the reference by compute_window_squared_sum (util.cpp:203-217), which
+    # adds out_len / hop + N / 2 / hop frames: rescale
+    Fr = mag.shape[1]
+    w2 = (win ** 2).numpy()
+    env_t, env_r = np.zeros(out_len + 2 * N), np.zeros(out_len + 2 * N)
+    for f in range(Fr):
+        env_t[f * hop:f * hop + N] += w2
+    for f in range(out_len // hop + (N // 2) // hop):
+        env_r[f * hop:f * hop + N] += w2
+    half = N // 2
+    y = y * torch.from_numpy(env_t[half:half + out_len] / env_r[half:half + out_len])
+    return lens, hidden, f0c, nc, y, hsrc_own
+
+
 def T_(model, name):
     return torch.from_numpy(model.by_name[name].to_f32().astype(np.float64))
 
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    km = synth.build_kokoro(synth.kokoro_tiny())
+    ktoks = np.array([0, 5, 9, 3, 16, 7, 21, 0], dtype=np.uint32)
+    knoise = np.random.default_rng(21).random(9 * 50 * km.cfg.up_sampling_factor, dtype=np.float32)   # the tests draw the same stream (seed 21) instead of storing it
+    with torch.no_grad():
+        klens, _ = torch_kokoro(km, ktoks, "af_test", None, only_durations=True)   # lengths first: they size the noise
+        kn = knoise[:9 * int(klens.sum()) * km.cfg.up_sampling_factor]
+        _, _, _, _, _, khs = torch_kokoro(km, ktoks, "af_test", kn)
+        # the audio is computed from the fp32-rounded conditioning that is stored, so that an implementation fed the same
+        # conditioning can be compared sample for sample (the phase channels are discontinuous at +-pi)
+        klens, khid, kf0, kn_, kpcm, _ = torch_kokoro(km, ktoks, "af_test", kn, hsrc_in=khs.numpy().astype(np.float32))
+    np.savez_compressed(os.path.join(out_dir, "tiny_kokoro.npz"), tokens=ktoks, noise_seed=np.int32(21), lens=klens.numpy().astype(np.float32), hidden=khid.numpy().astype(np.float32),
+                        f0=kf0.numpy().astype(np.float32), n=kn_.numpy().astype(np.float32), pcm=kpcm.numpy().astype(np.float32), hsrc=khs.numpy().astype(np.float32))
+    print("wrote tiny_kokoro.npz", "lens", klens.numpy())
     dm = synth.build_dia(synth.dia_tiny())
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import dia_tokenize

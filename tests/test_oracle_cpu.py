@@ -347,3 +347,59 @@ def test_dia_generate_loop_and_codec():
     assert outs2.shape == (23, cfg.n_out) and np.array_equal(outs2[:8], outs[:8])
     pcm = orc.DacOracle(model.dac).decode(frames)
     assert pcm.shape == (len(frames) * cfg.hop,) and np.isfinite(pcm).all() and np.abs(pcm).max() <= 1.0
+
+
+# ---- Kokoro (src/models/kokoro/model.cpp; oracle/kokoro_oracle.c, parity unpinned: see its header) -------------------------
+def _kokoro_case():
+    from tts_cpp_amd import synth as sy
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_kokoro.npz"))
+    model = sy.build_kokoro(sy.kokoro_tiny())
+    o = orc.KokoroOracle(model)
+    total = int(g["lens"].sum())
+    noise = np.random.default_rng(int(g["noise_seed"])).random(9 * 50 * model.cfg.up_sampling_factor, dtype=np.float32)[:o.noise_len(total)]
+    return g, model, o, noise
+
+
+def test_kokoro_duration_graph_matches_torch_golden():
+    """ALBERT (one shared layer applied `recurrence` times, eps 1e-12 norms, fixed 0.125 softmax scale), the prosody predictor's
+    bidirectional LSTM + AdaLayerNorm stack and the duration head against float64 torch (nn.LSTM, F.layer_norm)."""
+    g, model, o, _ = _kokoro_case()
+    lens, hid = o.durations(g["tokens"], "af_test")
+    assert np.array_equal(lens, g["lens"]) and len(set(lens.tolist())) > 1
+    assert np.abs(hid - g["hidden"]).max() < 2e-5
+    lens_b, hid_b = o.durations(g["tokens"], "bm_test")           # the voice row (n_tokens - 3) conditions the predictor
+    assert np.abs(hid_b - hid).max() > 1e-2
+
+
+def test_kokoro_generation_graph_matches_torch_golden():
+    """alignment, shared LSTM, F0 / N branches (AdaIN residual blocks with the depthwise transposed-conv pool and the nearest-
+    neighbour shortcut), text encoder, decoder blocks, harmonic source, STFT conditioning, generator and iSTFT head against float64
+    torch (F.instance_norm, F.conv_transpose1d(groups, output_padding), F.interpolate, torch.stft / istft)."""
+    g, model, o, noise = _kokoro_case()
+    cfg = model.cfg
+    pcm, f0, nn_, hs = o.generate(g["tokens"], g["lens"], g["hidden"], "af_test", noise, want_curves=True, hsrc_in=g["hsrc"])
+    assert np.abs(f0 - g["f0"]).max() < 1e-4 * np.abs(g["f0"]).max() and np.abs(nn_ - g["n"]).max() < 1e-4
+    assert (g["f0"] > 10).any() and (g["f0"] <= 10).any()       # voiced and unvoiced stretches both occur
+    # the oracle's own STFT conditioning: fp32 phases of ~1e4 rad limit the source to ~1e-3, compared as complex numbers because the
+    # phase channels wrap at +-pi
+    nb = cfg.n_fft // 2 + 1
+    za, zb = hs[:nb] * np.exp(1j * hs[nb:]), g["hsrc"][:nb] * np.exp(1j * g["hsrc"][nb:])
+    assert np.abs(za - zb).max() < 1e-2 * np.abs(zb).max()
+    # everything after the conditioning, sample for sample
+    assert pcm.shape == g["pcm"].shape == (int(g["lens"].sum()) * cfg.up_sampling_factor,)
+    assert np.abs(pcm - g["pcm"]).max() < 5e-5 * np.abs(g["pcm"]).max()
+
+
+def test_kokoro_forced_durations_and_noise():
+    """BASELINE's Kokoro configuration forces the durations for shape determinism: any integer lengths drive the same graph"""
+    g, model, o, _ = _kokoro_case()
+    cfg = model.cfg
+    lens = np.array([1, 4, 2, 1, 3, 2, 5, 1], dtype=np.float32)
+    total = int(lens.sum())
+    rng = np.random.default_rng(3)
+    n1, n2 = rng.random(o.noise_len(total), dtype=np.float32), rng.random(o.noise_len(total), dtype=np.float32)
+    a = o.generate(g["tokens"], lens, g["hidden"], "af_test", n1)
+    b = o.generate(g["tokens"], lens, g["hidden"], "af_test", n2)
+    assert a.shape == (total * cfg.up_sampling_factor,) and np.isfinite(a).all()
+    assert 1e-6 < np.abs(a - b).max()                            # the source noise reaches the audio
+    assert np.array_equal(a, o.generate(g["tokens"], lens, g["hidden"], "af_test", n1))

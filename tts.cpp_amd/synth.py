@@ -810,3 +810,220 @@ class SynthDia:
 
 def build_dia(cfg: DiaConfig, **kw) -> SynthDia:
     return SynthDia(cfg, **kw)
+
+
+# --------------------------------------------------------------------------------------------------
+# Kokoro (src/models/kokoro/model.cpp).  Tensor names / keys as py-gguf/tts_encoders/kokoro_gguf_encoder.py writes them
+# (ALBERT_PARTS :14-38, prepare_lstm_tensor :287-307, prepare_adain_res_block_tensor :309-327, set_gguf_parameters :412-470).
+# The phonemizer tables are left out: the acoustic path starts at phoneme ids.
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class KokoroConfig:
+    vocab: int = 32
+    albert_embd: int = 16        # 128
+    hidden: int = 64             # 768
+    heads: int = 4               # 12 (the reference's softmax scale stays 0.125 whatever the head size, model.h:196)
+    ffn: int = 128               # 2048
+    recurrence: int = 2          # 12
+    max_ctx: int = 32            # 512
+    dp_hidden: int = 32          # 512: duration predictor, text encoder and shared LSTM width
+    style_half: int = 8          # 128
+    dp_layers: int = 3
+    f0_blocks: int = 3
+    n_durations: int = 6         # 50 duration bins (sum of sigmoids = the predicted length)
+    conv_layers: int = 3
+    enc_channels: int = 48       # 1024
+    asr_channels: int = 8        # 64
+    gen_channels: int = 24       # 512
+    decoder_blocks: int = 4
+    up_rates: tuple = (10, 6)
+    up_kernels: tuple = (20, 12)
+    res_kernels: tuple = (3, 7, 11)
+    res_dilations: tuple = (1, 3, 5)
+    n_fft: int = 20
+    hop: int = 5
+    harmonic_num: int = 8
+    voices: tuple = ("af_test", "bm_test")
+    seed: int = 0xC0C0
+
+    @property
+    def up_sampling_factor(self):
+        return 2 * int(np.prod(self.up_rates)) * self.hop      # 600 in the reference's file (kokoro_gguf_encoder.py:441)
+
+
+def kokoro_tiny(**kw):
+    return KokoroConfig(**kw)
+
+
+def kokoro_82m(**kw):
+    base = dict(vocab=178, albert_embd=128, hidden=768, heads=12, ffn=2048, recurrence=12, max_ctx=512, dp_hidden=512, style_half=128, n_durations=50,
+                enc_channels=1024, asr_channels=64, gen_channels=512)
+    base.update(kw)
+    return KokoroConfig(**base)
+
+
+class SynthKokoro:
+    def __init__(self, cfg: KokoroConfig):
+        self.cfg = cfg
+        rng = np.random.Generator(np.random.Philox(cfg.seed))
+        self.tensors = []
+        E, H, F, D, S, C = cfg.albert_embd, cfg.hidden, cfg.ffn, cfg.dp_hidden, cfg.style_half, cfg.dp_hidden
+
+        def normal(shape, std):
+            return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+        def add(name, arr):
+            self.tensors.append(gguf.Tensor.from_array("kokoro." + name, np.ascontiguousarray(arr, dtype=np.float32)))
+
+        def lin(name, out, inp, bias_name=None, std=None):
+            add(name, normal((out, inp), std if std is not None else 1.0 / math.sqrt(inp)))
+            add(bias_name or name + "_bias", normal((out,), 0.05))
+
+        def norm(name, n, bias_name=None):
+            add(name, 1.0 + normal((n,), 0.05))
+            add(bias_name or name + "_bias", normal((n,), 0.05))
+
+        def lstm(base, inp, hid):
+            for d in ("weights", "reverse_weights"):
+                for j in range(4):
+                    add(f"{base}.0.{d}.{2 * j}", normal((hid, inp), 1.0 / math.sqrt(inp)))
+                    add(f"{base}.0.{d}.{2 * j + 1}", normal((hid, hid), 1.0 / math.sqrt(hid)))
+            for d in ("biases", "reverse_biases"):
+                for j in range(8):
+                    add(f"{base}.0.{d}.{j}", normal((hid,), 0.1))
+
+        def adain_block(base, cin, cout, upsample):
+            for k, c in (("norm1", cin), ("norm2", cout)):
+                for gb in ("gamma", "beta"):
+                    add(f"{base}.{k}_{gb}_weight", normal((c, S), 0.3 / math.sqrt(S)))
+                    add(f"{base}.{k}_{gb}_bias", normal((c,), 0.1))
+            add(f"{base}.conv1_weight", normal((cout, cin, 3), 1.0 / math.sqrt(3 * cin)))
+            add(f"{base}.conv1_bias", normal((cout,), 0.05))
+            add(f"{base}.conv2_weight", normal((cout, cout, 3), 1.0 / math.sqrt(3 * cout)))
+            add(f"{base}.conv2_bias", normal((cout,), 0.05))
+            if upsample:
+                add(f"{base}.pool_weight", normal((cin, 1, 3), 0.6))
+                add(f"{base}.pool_bias", normal((cin,), 0.05))
+            if upsample or cin != cout:
+                add(f"{base}.conv1x1_weight", normal((cout, cin, 1), 1.0 / math.sqrt(cin)))
+
+        def gen_res(base, c, k):
+            for j in range(3):
+                for a in ("1", "2"):
+                    for gb in ("gamma", "beta"):
+                        add(f"{base}.{j}.{gb}{a}_weight", normal((c, S), 0.3 / math.sqrt(S)))
+                        add(f"{base}.{j}.{gb}{a}_bias", normal((c,), 0.1))
+                    add(f"{base}.{j}.alpha{a}", rng.uniform(0.5, 2.0, (1, c, 1)).astype(np.float32))
+                    add(f"{base}.{j}.convs{a}_weight", normal((c, c, k), 0.7 / math.sqrt(k * c)))
+                    add(f"{base}.{j}.convs{a}_bias", normal((c,), 0.05))
+
+        # ---- ALBERT
+        add("albert.token_embd", normal((cfg.vocab, E), 1.0))
+        add("albert.position_embd", normal((cfg.max_ctx, E), 0.5))
+        add("albert.token_type_embd", normal((E,), 0.5))
+        norm("albert.norm", E)
+        lin("albert.embd", H, E)
+        p = "albert.layer.0."
+        for nm in ("q", "k", "v", "o"):
+            lin(p + nm, H, H)
+        lin(p + "ffn", F, H)
+        lin(p + "ffn_out", H, F)
+        norm(p + "attn_norm", H)
+        norm(p + "ffn_norm", H)
+        # ---- duration / prosody predictor
+        dp = "duration_predictor."
+        lin(dp + "encode", D, H)
+        for l in range(cfg.dp_layers):
+            lstm(f"{dp}layers.{2 * l}.lstm", D + S, D // 2)
+            for gb in ("gamma", "beta"):
+                add(f"{dp}layers.{2 * l + 1}.{gb}_weight", normal((D, S), 0.3 / math.sqrt(S)))
+                add(f"{dp}layers.{2 * l + 1}.{gb}_bias", normal((D,), 0.1))
+        lstm(dp + "duration_lstm", D + S, D // 2)
+        lin(dp + "duration_proj", cfg.n_durations, D, std=8.0)   # wide: the tiny model then predicts a spread of lengths
+        lstm(dp + "shared_lstm", D + S, D // 2)
+        dims = [(D, D, False), (D, D // 2, True), (D // 2, D // 2, False)][:cfg.f0_blocks]
+        for br in ("f0", "n"):
+            for i, (ci, co, up) in enumerate(dims):
+                adain_block(f"{dp}{br}_blocks.{i}", ci, co, up)
+            add(f"{dp}{br}_proj_kernel", normal((1, dims[-1][1], 1), (60.0 if br == "f0" else 1.0) / math.sqrt(dims[-1][1])))   # f0 in Hz-like units: some frames voiced (> 10)
+            add(f"{dp}{br}_proj_bias", normal((1,), 0.1))
+        # ---- text encoder
+        add("text_encoder.embedding_weight", normal((cfg.vocab, C), 1.0))
+        for l in range(cfg.conv_layers):
+            add(f"text_encoder.layers.{l}.weight", normal((C, C, 5), 1.0 / math.sqrt(5 * C)))
+            add(f"text_encoder.layers.{l}.bias", normal((C,), 0.05))
+            add(f"text_encoder.layers.{l}.gamma", 1.0 + normal((C,), 0.05))
+            add(f"text_encoder.layers.{l}.beta", normal((C,), 0.05))
+        lstm("text_encoder.lstm", C, C // 2)
+        # ---- decoder
+        de = "decoder."
+        for br in ("f0", "n"):
+            add(f"{de}{br}_conv_weight", normal((1, 1, 3), 0.5))
+            add(f"{de}{br}_conv_bias", normal((1,), 0.05))
+        add(de + "asr_conv_weight", normal((cfg.asr_channels, C, 1), 1.0 / math.sqrt(C)))
+        add(de + "asr_conv_bias", normal((cfg.asr_channels,), 0.05))
+        CE, CA, CG = cfg.enc_channels, cfg.asr_channels, cfg.gen_channels
+        adain_block(de + "encoder_block", C + 2, CE, False)
+        for i in range(cfg.decoder_blocks):
+            last = i == cfg.decoder_blocks - 1
+            adain_block(f"{de}decoder_blocks.{i}", CE + CA + 2, CG if last else CE, last)
+        g = de + "generator."
+        add(g + "m_source_weight", normal((1, cfg.harmonic_num + 1), 1.0))
+        add(g + "m_source_bias", normal((1,), 0.05))
+        c = CG
+        nb = cfg.n_fft // 2 + 1
+        self.geometry = dict(up=[], noise=[], res=[], noise_res=[])
+        for i, (u, k) in enumerate(zip(cfg.up_rates, cfg.up_kernels)):
+            co = c // 2
+            add(f"{g}ups.{i}.weight", normal((c, co, k), 1.0 / math.sqrt(c * k / u)))
+            add(f"{g}ups.{i}.bias", normal((co,), 0.05))
+            self.geometry["up"].append((u, (k - u) // 2))
+            c = co
+            if i + 1 < len(cfg.up_rates):
+                sf = int(np.prod(cfg.up_rates[i + 1:]))
+                nk, ns, npad, rk = sf * 2, sf, (sf + 1) // 2, 7
+            else:
+                nk, ns, npad, rk = 1, 1, 0, 11
+            add(f"{g}noise_blocks.{i}.conv_weight", normal((c, 2 * nb, nk), 0.3 / math.sqrt(2 * nb * nk)))
+            add(f"{g}noise_blocks.{i}.conv_bias", normal((c,), 0.05))
+            self.geometry["noise"].append((ns, npad))
+            gen_res(f"{g}noise_blocks.{i}.resblock", c, rk)
+            self.geometry["noise_res"].append([((rk * d - d) // 2, d) for d in cfg.res_dilations])
+            for ii, rk2 in enumerate(cfg.res_kernels):
+                gen_res(f"{g}resblocks.{i * len(cfg.res_kernels) + ii}", c, rk2)
+                self.geometry["res"].append([((rk2 * d - d) // 2, d) for d in cfg.res_dilations])
+        add(g + "conv_post_weight", normal((2 * nb, c, 7), 0.5 / math.sqrt(7 * c)))
+        add(g + "conv_post_bias", normal((2 * nb,), 0.05))
+        for vname in cfg.voices:
+            add(f"voice_tensors.{vname}", normal((cfg.max_ctx, 2 * S), 1.0))
+        U32, STR, ARR = gguf.T_U32, gguf.T_STR, gguf.T_ARR
+        a = "kokoro.duration_predictor.albert."
+        gk = "kokoro.decoder.generator."
+        self.kv = [("general.architecture", STR, "kokoro"), ("general.name", STR, "synthetic-kokoro"),
+                   (a + "context_length", U32, cfg.max_ctx), (a + "layers", U32, 1), (a + "attn_heads", U32, cfg.heads), (a + "hidden_size", U32, H),
+                   (a + "recurrence", U32, cfg.recurrence),
+                   ("kokoro.duration_predictor.hidden_size", U32, D), ("kokoro.duration_predictor.layers", U32, cfg.dp_layers),
+                   ("kokoro.duration_predictor.f0_n_blocks", U32, cfg.f0_blocks), ("kokoro.text_encoder.layers", U32, cfg.conv_layers),
+                   (gk + "up_sampling_factor", U32, cfg.up_sampling_factor), (gk + "kernels", U32, len(cfg.res_kernels)), (gk + "upsamples", U32, len(cfg.up_rates)),
+                   (gk + "layers", U32, cfg.decoder_blocks), (gk + "padding", U32, 3), (gk + "n_fft", U32, cfg.n_fft), (gk + "hop", U32, cfg.hop)]
+        for i, blk in enumerate(self.geometry["noise_res"]):
+            for ii, (pd, dl) in enumerate(blk):
+                self.kv += [(f"{gk}noise_blocks.{i}.res_block.{ii}.padding", U32, pd), (f"{gk}noise_blocks.{i}.res_block.{ii}.dilation", U32, dl)]
+        for i, (st, pd) in enumerate(self.geometry["noise"]):
+            self.kv += [(f"{gk}noise_blocks.{i}.stride", U32, st), (f"{gk}noise_blocks.{i}.padding", U32, pd)]
+        for i, blk in enumerate(self.geometry["res"]):
+            for ii, (pd, dl) in enumerate(blk):
+                self.kv += [(f"{gk}res_blocks.{i}.{ii}.padding", U32, pd), (f"{gk}res_blocks.{i}.{ii}.dilation", U32, dl)]
+        for i, (st, pd) in enumerate(self.geometry["up"]):
+            self.kv += [(f"{gk}up_convs.{i}.padding", U32, pd), (f"{gk}up_convs.{i}.stride", U32, st)]
+        self.kv += [("kokoro.voices", ARR, (STR, list(cfg.voices))), ("tokenizer.ggml.tokens", ARR, (STR, [""] + [chr(0x61 + i % 26) for i in range(cfg.vocab - 1)])),
+                    ("tokenizer.ggml.eos_token_id", U32, 0), ("tokenizer.ggml.padding_token_id", U32, 0)]
+        self.by_name = {t.name: t for t in self.tensors}
+
+    def write_gguf(self, path):
+        gguf.write(path, self.kv, self.tensors)
+        return path
+
+
+def build_kokoro(cfg: KokoroConfig) -> SynthKokoro:
+    return SynthKokoro(cfg)
