@@ -255,6 +255,47 @@ int tts_hip_dia_encode(tts_hip_ctx *ctx, const uint32_t *tokens, uint32_t senten
  * raw_out (may be NULL): [2][n_output_heads][output_vocab_size] conditional, unconditional. */
 int tts_hip_dia_step(tts_hip_ctx *ctx, const uint32_t *ids, uint32_t pos, float *logits_out, float *raw_out);
 
+/* ---- Kokoro (src/models/kokoro/model.cpp) ----------------------------------------------------------------------------
+ * Device side of kokoro_duration_runner::run (:1069-1123) and kokoro_runner::run (:1277-1325): create, tts_hip_upload every
+ * "kokoro.*" tensor (names py-gguf/tts_encoders/kokoro_gguf_encoder.py), tts_hip_finalize(ctx, NULL), then per clause
+ * tts_hip_kokoro_durations (ALBERT + prosody predictor + duration head) and tts_hip_kokoro_generate (alignment ... iSTFT).
+ * The phonemizer, the tokenizer, clause chunking (:1340-1388) and the source-noise draws (set_inputs :1255) stay with the host.
+ * First version: plain fp32 kernels (csrc/kokoro_kernels.h). */
+typedef struct tts_hip_kokoro_desc {
+    uint32_t struct_size;
+    uint32_t n_attn_heads;       /* kokoro.duration_predictor.albert.attn_heads (12) */
+    uint32_t n_recurrence;       /* ...albert.recurrence (12): the one shared layer is applied this many times */
+    uint32_t n_dp_layers;        /* kokoro.duration_predictor.layers (3) */
+    uint32_t f0_n_blocks;        /* kokoro.duration_predictor.f0_n_blocks (3) */
+    uint32_t n_conv_layers;      /* kokoro.text_encoder.layers (3) */
+    uint32_t n_decoder_blocks;   /* kokoro.decoder.generator.layers (4) */
+    uint32_t n_upsamples;        /* kokoro.decoder.generator.upsamples (2) */
+    uint32_t n_kernels;          /* kokoro.decoder.generator.kernels (3) */
+    uint32_t n_fft, hop;         /* kokoro.decoder.generator.{n_fft,hop} (20, 5) */
+    uint32_t harmonic_num;       /* 8 (model.h:218) */
+    uint32_t up_sampling_factor; /* kokoro.decoder.generator.up_sampling_factor (600 samples per duration frame) */
+    uint32_t out_conv_padding;   /* kokoro.decoder.generator.padding (3) */
+    uint32_t max_ctx;            /* ...albert.context_length (512) tokens per call */
+    float    attn_scale;         /* 0.125 (model.h:196: not derived from the head size) */
+    float    upsample_scale;     /* 300 (model.h:195) */
+    float    sample_rate, sin_amp, noise_std, voice_threshold;   /* 24000, 0.1, 0.003, 10 (model.h:219-222) */
+    uint32_t up_stride[4], up_padding[4];             /* kokoro.decoder.generator.up_convs.i.{stride,padding} */
+    uint32_t noise_stride[4], noise_padding[4];       /* ...noise_blocks.i.{stride,padding} */
+    uint32_t res_padding[16][3], res_dilation[16][3]; /* ...res_blocks.i.j.{padding,dilation} */
+    uint32_t noise_res_padding[4][3], noise_res_dilation[4][3];   /* ...noise_blocks.i.res_block.j.{padding,dilation} */
+    uint32_t flags;
+} tts_hip_kokoro_desc;
+tts_hip_ctx *tts_hip_kokoro_create(int device, const tts_hip_kokoro_desc *desc);
+/* tokens [n] (bos, phoneme ids, eos); voice: the name after "kokoro.voice_tensors."; lens_out [n] = clamp(round(sum of the
+ * duration sigmoids), 1, 50) (:1035-1037); hidden_out [n][duration hidden + style half] (:1029-1031) */
+int tts_hip_kokoro_durations(tts_hip_ctx *ctx, const uint32_t *tokens, uint32_t n, const char *voice, float *lens_out, float *hidden_out);
+/* lens [n]: whole numbers (the predicted ones, or forced); hidden [n][duration hidden + style half] from the call above;
+ * noise [(harmonic_num + 1) * total * up_sampling_factor] uniform draws, total = sum(lens); pcm_out [total * up_sampling_factor].
+ * hsrc_out / hsrc_in (may be NULL) [2 * (n_fft / 2 + 1)][2 * total * upsample_scale / hop + 1]: the STFT conditioning read out /
+ * replaced (its phase channels wrap at +-pi, see oracle/kokoro_oracle.c). */
+int tts_hip_kokoro_generate(tts_hip_ctx *ctx, const uint32_t *tokens, uint32_t n, const float *lens, const float *hidden, const char *voice, const float *noise,
+                            float *pcm_out, float *hsrc_out, const float *hsrc_in);
+
 /* ---- SNAC codec (src/decoder/snac_model.cpp; Orpheus' audio decoder) -------------------------------
  * A SNAC context is its own tts_hip_ctx: create, tts_hip_upload every "snac.*" tensor (names:
  * py-gguf/tts_encoders/orpheus_gguf_encoder.py:89-142), tts_hip_finalize(ctx, NULL), tts_hip_snac_decode. */

@@ -1,7 +1,6 @@
-"""Opt-in: the streaming 1..4-row GEMV kernels (csrc/gemv_kernels.h, TTS_HIP_GEMV_ROWS=1) against the oracle through the Orpheus
-and Dia steps.  Written without GPU time left in the round, so it only runs when asked for (TTS_TEST_EXPERIMENTAL=1); the
-default path (MFMA workgroups) is what every other test exercises.  First thing to run next round:
-    TTS_TEST_EXPERIMENTAL=1 python -m pytest tests/test_gpu_gemv_rows.py -q
+"""GPU parity: the streaming 1..4-row GEMV kernels (csrc/gemv_kernels.h, TTS_HIP_GEMV_ROWS=1) against the oracle through the Orpheus
+and Dia steps.  Their numbers are verified here; their speed against the default MFMA workgroups is not measured yet (the round's
+GPU minutes ended with this test), so the knob stays off by default.  To measure:
     TTS_HIP_GEMV_ROWS=1 python profiles/orpheus_bench.py ; TTS_HIP_GEMV_ROWS=1 python profiles/dia_bench.py"""
 import os
 
@@ -11,7 +10,7 @@ import pytest
 import oracle as orc
 from tts_cpp_amd import gguf, hip, synth
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("TTS_TEST_EXPERIMENTAL") != "1", reason="opt-in kernels (TTS_TEST_EXPERIMENTAL=1)")]
+pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(__file__)
 
 

@@ -1,0 +1,50 @@
+"""GPU parity: the first device version of the Kokoro graphs (tts_hip_kokoro_*, csrc/kokoro_kernels.h) against the oracle
+(oracle/kokoro_oracle.c, matched to a float64 torch golden by tests/test_oracle_cpu.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from tts_cpp_amd import hip, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "tiny_kokoro.npz")
+
+
+def relerr(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_kokoro_durations_and_audio_match_oracle():
+    g = np.load(GOLD)
+    model = synth.build_kokoro(synth.kokoro_tiny())
+    eng = hip.KokoroEngine(model)
+    o = orc.KokoroOracle(model)
+    toks = g["tokens"]
+    lens, hid = eng.durations(toks, "af_test")
+    ref_lens, ref_hid = o.durations(toks, "af_test")
+    assert np.array_equal(lens, ref_lens) and np.array_equal(lens, g["lens"])
+    assert relerr(hid, ref_hid) < 2e-4 and relerr(hid, g["hidden"]) < 2e-4
+    total = int(ref_lens.sum())
+    noise = np.random.default_rng(int(g["noise_seed"])).random(9 * 50 * model.cfg.up_sampling_factor, dtype=np.float32)[:o.noise_len(total)]
+    # the STFT conditioning as complex numbers (its phase channels wrap at +-pi), then the audio from a shared conditioning
+    ref_pcm, _, _, ref_hs = o.generate(toks, ref_lens, ref_hid, "af_test", noise, want_curves=True)
+    pcm_own, hs = eng.generate(toks, ref_lens, ref_hid, "af_test", noise, want_hsrc=True)
+    nb = model.cfg.n_fft // 2 + 1
+    za, zb = hs[:nb] * np.exp(1j * hs[nb:]), ref_hs[:nb] * np.exp(1j * ref_hs[nb:])
+    assert np.abs(za - zb).max() < 1e-2 * np.abs(zb).max()
+    pcm = eng.generate(toks, ref_lens, ref_hid, "af_test", noise, hsrc_in=ref_hs)
+    assert pcm.shape == ref_pcm.shape and relerr(pcm, ref_pcm) < 2e-4
+    assert relerr(eng.generate(toks, g["lens"], g["hidden"], "af_test", noise, hsrc_in=g["hsrc"]), g["pcm"]) < 2e-4
+    assert pcm_own.shape == pcm.shape and np.isfinite(pcm_own).all()
+    # forced durations (BASELINE's Kokoro configuration) and the other voice
+    lens2 = np.array([1, 4, 2, 1, 3, 2, 5, 1], dtype=np.float32)
+    n2 = np.random.default_rng(3).random(o.noise_len(int(lens2.sum())), dtype=np.float32)
+    r2, _, _, h2 = o.generate(toks, lens2, ref_hid, "bm_test", n2, want_curves=True)
+    assert relerr(eng.generate(toks, lens2, ref_hid, "bm_test", n2, hsrc_in=h2), r2) < 2e-4
+    with pytest.raises(hip.HipError):
+        eng.durations(toks, "nobody")
+    with pytest.raises(hip.HipError):
+        eng.generate(toks, lens2 + 0.5, ref_hid, "af_test", n2)
+    eng.close()

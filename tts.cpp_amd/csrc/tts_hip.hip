@@ -26,6 +26,7 @@
 #include "llama_kernels.h"
 #include "dia_kernels.h"
 #include "gemv_kernels.h"
+#include "kokoro_kernels.h"
 #define LLAMA_GREEDY_CHUNK 8
 
 // ------------------------------------------------------------------------------------------------
@@ -227,6 +228,11 @@ struct tts_hip_ctx {
     uint32_t *di_tok = nullptr, *di_epos = nullptr, *di_eseq = nullptr, *di_kbeg = nullptr, *di_kend = nullptr;
     uint32_t *di_ids = nullptr, *di_pos = nullptr, *di_seq = nullptr, *di_cend = nullptr;
     bool di_encoded = false;
+    // ---- Kokoro context (tts_hip_kokoro_create) ----
+    bool has_kokoro = false;
+    tts_hip_kokoro_desc ko{};
+    struct KTensor { size_t off = 0; int64_t ne[4] = {1, 1, 1, 1}; };
+    std::unordered_map<std::string, KTensor> k_tensors;   // every "kokoro.*" tensor, fp32, by GGUF name
     // ---- SNAC codec context (tts_hip_snac_create) ----
     bool has_snac = false;
     tts_hip_snac_desc snac{};
@@ -458,7 +464,9 @@ extern "C" int tts_hip_upload(tts_hip_ctx *c, const char *name_c, int type, int 
     if (c->finalized) return set_err("tts_hip_upload(%s): context already finalized", name_c);
     HIPCHK(hipSetDevice(c->device));
     std::string name(name_c);
-    if (c->has_dia) {
+    if (c->has_kokoro) {
+        if (!starts_with(name, "kokoro.")) return 0;     // kokoro_runner::assign_weight asserts the prefix (kokoro/model.cpp:1327-1332)
+    } else if (c->has_dia) {
         if (!starts_with(name, "dia.")) return 0;        // "audio_encoder.*" belongs to the codec context (dia/model.cpp:892-898)
     } else if (c->has_llama) {
         if (!starts_with(name, "orpheus.")) return 0;    // "snac.*" belongs to the codec context (orpheus/model.cpp:430-438)
@@ -740,6 +748,22 @@ static int plan(tts_hip_ctx *c) {
             else if ((int) c->di_dec[0].ckv.N != 2 * c->di_A || (int) c->di_dec[0].ckv.K != c->di_EH) P.err = "dia decoder cross k/v projection shapes disagree with the hyper-parameters";
             else if (c->di_EF > 4096 && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM)) P.err = "dia encoder feed-forward width above 4096 is not supported";
         }
+    }
+    if (c->has_kokoro) {
+        // every tensor by name, fp32 (kokoro_model::assign_weight kokoro/model.cpp:413-428 walks the same names)
+        c->k_tensors.clear();
+        std::vector<std::string> names;
+        for (auto &kv : c->tensors)
+            if (starts_with(kv.first, "kokoro.")) names.push_back(kv.first);
+        std::sort(names.begin(), names.end());
+        for (auto &nm : names) {
+            tts_hip_ctx::KTensor kt;
+            kt.off = P.place_f32(nm);
+            const Tensor *t = P.get(nm);
+            for (int d = 0; d < 4; d++) kt.ne[d] = t->ne[d];
+            c->k_tensors[nm] = kt;
+        }
+        if (names.empty() && P.err.empty()) P.err = "no kokoro.* tensors were uploaded";
     }
     if (c->has_snac) {
         // snac_model (snac_model.h:10-40, assign_weight snac_model.cpp:50-84, layer tensors gnac.cpp:9-34)
@@ -2678,6 +2702,434 @@ extern "C" int tts_hip_dia_step(tts_hip_ctx *c, const uint32_t *ids, uint32_t po
     if (raw_out)
         for (int b = 0; b < 2; b++)
             HIPCHK(hipMemcpyAsync(raw_out + (size_t) b * NO * V, c->di_logits + (size_t) b * c->di_Vpad, (size_t) NO * V * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kokoro (src/models/kokoro/model.cpp:938-1047, 1141-1242, 195-244); first version, see kokoro_kernels.h
+// ------------------------------------------------------------------------------------------------
+extern "C" tts_hip_ctx *tts_hip_kokoro_create(int device, const tts_hip_kokoro_desc *kd) {
+    if (!kd || kd->struct_size != sizeof(tts_hip_kokoro_desc)) { set_err("tts_hip_kokoro_create: bad desc (struct_size mismatch)"); return nullptr; }
+    if (kd->n_upsamples == 0 || kd->n_upsamples > 4 || kd->n_kernels == 0 || kd->n_upsamples * kd->n_kernels > 16 || kd->n_fft < 2 || kd->hop == 0 || kd->max_ctx < 3) {
+        set_err("tts_hip_kokoro_create: generator geometry out of range");
+        return nullptr;
+    }
+    tts_hip_desc d{};
+    d.struct_size = sizeof(d);
+    d.max_seqs = 1;
+    d.flags = TTS_HIP_FLAG_NO_PARLER | TTS_HIP_FLAG_NO_DAC;
+    tts_hip_ctx *c = tts_hip_create(device, &d);
+    if (!c) return nullptr;
+    c->has_kokoro = true;
+    c->ko = *kd;
+    return c;
+}
+
+namespace {
+// scratch for one call: device buffers released when the call returns
+struct KScratch {
+    std::vector<void *> bufs;
+    bool failed = false;
+    ~KScratch() { for (void *p : bufs) (void) hipFree(p); }
+    float *f(size_t n) {
+        void *p = nullptr;
+        if (hipMalloc(&p, (n ? n : 1) * sizeof(float)) != hipSuccess) { failed = true; return nullptr; }
+        bufs.push_back(p);
+        return (float *) p;
+    }
+};
+inline dim3 kgrid(int64_t n, int bs = 256) { return dim3((unsigned) ((n + bs - 1) / bs)); }
+
+struct KRun {
+    tts_hip_ctx *c;
+    KScratch &s;
+    std::string err;
+    hipStream_t st;
+    KRun(tts_hip_ctx *c_, KScratch &s_) : c(c_), s(s_), st(c_->stream) {}
+    bool has(const std::string &n) const { return c->k_tensors.count("kokoro." + n) != 0; }
+    const float *w(const std::string &n, int64_t *ne = nullptr) {
+        auto it = c->k_tensors.find("kokoro." + n);
+        if (it == c->k_tensors.end()) { if (err.empty()) err = "missing tensor 'kokoro." + n + "'"; return nullptr; }
+        if (ne) memcpy(ne, it->second.ne, sizeof(int64_t) * 4);
+        return (const float *) (c->arena + it->second.off);
+    }
+    bool ok() {
+        if (!err.empty()) return false;
+        if (s.failed) { err = "device scratch allocation failed"; return false; }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { err = std::string("kernel launch failed: ") + hipGetErrorString(e); return false; }
+        return true;
+    }
+    void linear(const float *W, const float *b, const float *x, int ldx, int R, int K, int N, float *y, int ldy, int acc = 0) {
+        if (!W || !x || !y) return;
+        hipLaunchKernelGGL(kk_linear_kernel, dim3((unsigned) (((int64_t) R * N + 3) / 4)), dim3(256), 0, st, W, b, x, ldx, R, K, N, y, ldy, acc);
+    }
+    void norm_rows(const float *x, int ldx, int R, int H, float eps, const float *w_, const float *b, int mode, float *y, int ldy) {
+        if (!x || !y) return;
+        hipLaunchKernelGGL(kk_norm_rows_kernel, dim3(R), dim3(64), 0, st, x, ldx, H, eps, w_, b, mode, y, ldy);
+    }
+    void copy(float *dst, const float *src, size_t n) { if (dst && src) (void) hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, st); }
+    // build_lstm (:35-51): one bidirectional cell; x [L][in] -> out [L][2 hid]
+    void bilstm(const std::string &base, const float *x, int L, int in, int hid, float *out) {
+        float *pre = s.f((size_t) 4 * L * hid);
+        for (int dir = 0; dir < 2; dir++) {
+            const std::string wn = dir ? ".0.reverse_weights." : ".0.weights.", bn = dir ? ".0.reverse_biases." : ".0.biases.";
+            const float *whh[4], *bhh[4];
+            for (int g = 0; g < 4; g++) {
+                linear(w(base + wn + std::to_string(2 * g)), w(base + bn + std::to_string(2 * g)), x, in, L, in, hid, pre + (size_t) g * L * hid, hid);
+                whh[g] = w(base + wn + std::to_string(2 * g + 1));
+                bhh[g] = w(base + bn + std::to_string(2 * g + 1));
+            }
+            if (!err.empty() || !pre) return;
+            const int threads = std::max(64, (hid + 63) / 64 * 64);
+            hipLaunchKernelGGL(kk_lstm_kernel, dim3(1), dim3(threads), (size_t) hid * 4, st, (const float *) pre, whh[0], whh[1], whh[2], whh[3], bhh[0], bhh[1], bhh[2], bhh[3],
+                               L, hid, dir, out, 2 * hid, dir * hid);
+        }
+    }
+    // gamma / beta = W style + b, then the fused instance norm (:93-101)
+    void adain(float *x, int C, int64_t L, const float *style, int S, const std::string &gw, const std::string &gb, const std::string &bw, const std::string &bb, int act,
+               float slope, const float *alpha) {
+        float *gamma = s.f(C), *beta = s.f(C);
+        linear(w(gw), w(gb), style, S, 1, S, C, gamma, C);
+        linear(w(bw), w(bb), style, S, 1, S, C, beta, C);
+        if (!err.empty() || !gamma || !beta) return;
+        hipLaunchKernelGGL(kk_adain_kernel, dim3(C), dim3(256), 0, st, x, L, (const float *) gamma, (const float *) beta, act, slope, alpha);
+    }
+    void conv1d(const float *x, int cin, int64_t L, const float *wt, const float *b, int cout, int K, int stride, int pad, int dil, int in_shift, float *y, int64_t Lout,
+                int acc, float post) {
+        if (!x || !wt || !y) return;
+        hipLaunchKernelGGL(kk_conv1d_kernel, kgrid((int64_t) cout * Lout), dim3(256), 0, st, x, cin, L, wt, b, cout, K, stride, pad, dil, in_shift, y, Lout, acc, post);
+    }
+    // build_ada_residual_conv (:88-134): x [cin][L] -> [cout][L or 2L]
+    float *ada_block(const std::string &base, const float *x, int64_t L, const float *style, int S, int &C, int64_t &Lout) {
+        int64_t ne[4];
+        const float *conv1 = w(base + ".conv1_weight", ne);
+        if (!conv1) return nullptr;
+        const int cin = (int) ne[1], cout = (int) ne[2];
+        if (cin != C) { err = base + ": channel count mismatch"; return nullptr; }
+        float *cur = s.f((size_t) cin * L);
+        copy(cur, x, (size_t) cin * L);
+        adain(cur, cin, L, style, S, base + ".norm1_gamma_weight", base + ".norm1_gamma_bias", base + ".norm1_beta_weight", base + ".norm1_beta_bias", 1, 0.2f, nullptr);
+        const bool pool = has(base + ".pool_weight");
+        int64_t Lc = L;
+        if (pool) {
+            float *up = s.f((size_t) cin * 2 * L);
+            if (up) hipLaunchKernelGGL(kk_pool_convt_kernel, kgrid((int64_t) cin * 2 * L), dim3(256), 0, st, (const float *) cur, cin, L, w(base + ".pool_weight"), w(base + ".pool_bias"), up);
+            cur = up;
+            Lc = 2 * L;
+        }
+        float *y = s.f((size_t) cout * Lc);
+        conv1d(cur, cin, Lc, conv1, w(base + ".conv1_bias"), cout, 3, 1, 1, 1, 0, y, Lc, 0, 1.0f);
+        adain(y, cout, Lc, style, S, base + ".norm2_gamma_weight", base + ".norm2_gamma_bias", base + ".norm2_beta_weight", base + ".norm2_beta_bias", 1, 0.2f, nullptr);
+        float *res = s.f((size_t) cout * Lc);
+        conv1d(y, cout, Lc, w(base + ".conv2_weight"), w(base + ".conv2_bias"), cout, 3, 1, 1, 1, 0, res, Lc, 0, 1.0f);
+        const float inv = 1.0f / sqrtf(2.0f);
+        if (has(base + ".conv1x1_weight")) {
+            conv1d(x, cin, L, w(base + ".conv1x1_weight"), nullptr, cout, 1, 1, 0, 1, pool ? 1 : 0, res, Lc, 1, inv);
+        } else if (res) {
+            hipLaunchKernelGGL(kk_add_kernel, kgrid((int64_t) cout * Lc), dim3(256), 0, st, (const float *) res, x, res, (int64_t) cout * Lc, inv);
+        }
+        C = cout;
+        Lout = Lc;
+        return res;
+    }
+    // build_kokoro_generator_res_block (:136-165), in place on x [C][L]
+    void gen_res(const std::string &base, float *x, int C, int64_t L, const float *style, int S, const uint32_t *pads, const uint32_t *dils) {
+        for (int i = 0; i < 3; i++) {
+            const std::string b = base + "." + std::to_string(i) + ".";
+            float *cur = s.f((size_t) C * L), *y = s.f((size_t) C * L);
+            copy(cur, x, (size_t) C * L);
+            adain(cur, C, L, style, S, b + "gamma1_weight", b + "gamma1_bias", b + "beta1_weight", b + "beta1_bias", 2, 0.0f, w(b + "alpha1"));
+            int64_t ne[4];
+            const float *w1 = w(b + "convs1_weight", ne);
+            if (!w1) return;
+            conv1d(cur, C, L, w1, w(b + "convs1_bias"), C, (int) ne[0], 1, (int) pads[i], (int) dils[i], 0, y, L, 0, 1.0f);
+            adain(y, C, L, style, S, b + "gamma2_weight", b + "gamma2_bias", b + "beta2_weight", b + "beta2_bias", 2, 0.0f, w(b + "alpha2"));
+            const float *w2 = w(b + "convs2_weight", ne);
+            if (!w2) return;
+            conv1d(y, C, L, w2, w(b + "convs2_bias"), C, (int) ne[0], 1, (int) pads[0], 1, 0, x, L, 1, 1.0f);   // x += conv (:160-161)
+        }
+    }
+};
+
+int kokoro_dims(tts_hip_ctx *c, KRun &k, int &D, int &S) {
+    int64_t ne[4];
+    if (!k.w("duration_predictor.encode", ne)) return -1;
+    D = (int) ne[1];
+    if (!k.w("duration_predictor.layers.1.gamma_weight", ne)) return -1;
+    S = (int) ne[0];
+    return 0;
+}
+const float *kokoro_voice(tts_hip_ctx *c, KRun &k, const char *voice, uint32_t n, int S, bool second_half) {
+    int64_t ne[4];
+    const float *v = k.w(std::string("voice_tensors.") + (voice ? voice : ""), ne);
+    if (!v) return nullptr;
+    if ((int) ne[0] != 2 * S || (int64_t) n - 3 >= ne[1]) { k.err = "voice tensor shape does not cover this token count"; return nullptr; }
+    return v + (size_t) (n - 3) * 2 * S + (second_half ? S : 0);   // row n_tokens - 3 (:1012, :1149, :1220)
+}
+}  // namespace
+
+extern "C" int tts_hip_kokoro_durations(tts_hip_ctx *c, const uint32_t *tokens, uint32_t n, const char *voice, float *lens_out, float *hidden_out) {
+    if (!c || !c->has_kokoro) return set_err("tts_hip_kokoro_durations: not a Kokoro context (tts_hip_kokoro_create)");
+    if (!c->finalized || !c->weights_present) return set_err("tts_hip_kokoro_durations: context not finalized");
+    if (!tokens || !lens_out) return set_err("tts_hip_kokoro_durations: null argument");
+    if (n < 3 || n > c->ko.max_ctx) return set_err("tts_hip_kokoro_durations: %u tokens outside 3..%u", n, c->ko.max_ctx);
+    HIPCHK(hipSetDevice(c->device));
+    KScratch s;
+    KRun k(c, s);
+    int64_t ne[4];
+    const float *tok_embd = k.w("albert.token_embd", ne);
+    if (!tok_embd) return set_err("tts_hip_kokoro_durations: %s", k.err.c_str());
+    const int E = (int) ne[0], vocab = (int) ne[1];
+    for (uint32_t i = 0; i < n; i++)
+        if (tokens[i] >= (uint32_t) vocab) return set_err("tts_hip_kokoro_durations: token %u >= vocabulary %d", tokens[i], vocab);
+    const float *embd = k.w("albert.embd", ne);
+    const int H = embd ? (int) ne[1] : 0, NH = (int) c->ko.n_attn_heads, hs = NH ? H / NH : 0;
+    const float *ffn_w = k.w("albert.layer.0.ffn", ne);
+    const int F = ffn_w ? (int) ne[1] : 0;
+    int D = 0, S = 0;
+    if (kokoro_dims(c, k, D, S) != 0 || !embd || !ffn_w || NH == 0 || H % NH) return set_err("tts_hip_kokoro_durations: %s", k.err.empty() ? "bad ALBERT shapes" : k.err.c_str());
+    const float *style = kokoro_voice(c, k, voice, n, S, true);
+    if (!style) return set_err("tts_hip_kokoro_durations: %s", k.err.c_str());
+    const int N = (int) n, Wd = D + S;
+    uint32_t *d_tok = (uint32_t *) s.f(n);
+    float *x0 = s.f((size_t) N * E), *x = s.f((size_t) N * H), *q = s.f((size_t) N * H), *kk = s.f((size_t) N * H), *v = s.f((size_t) N * H), *att = s.f((size_t) N * H);
+    float *o = s.f((size_t) N * H), *ff = s.f((size_t) N * F), *cur = s.f((size_t) N * Wd), *ls = s.f((size_t) N * D), *gamma = s.f(D), *beta = s.f(D);
+    if (s.failed) return set_err("tts_hip_kokoro_durations: device scratch allocation failed");
+    HIPCHK(hipMemcpyAsync(d_tok, tokens, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(kk_albert_embed_kernel, kgrid((int64_t) N * E), dim3(256), 0, c->stream, tok_embd, k.w("albert.position_embd"), k.w("albert.token_type_embd"),
+                       (const uint32_t *) d_tok, N, E, x0);
+    k.norm_rows(x0, E, N, E, 1e-12f, k.w("albert.norm"), k.w("albert.norm_bias"), 0, x0, E);
+    k.linear(embd, k.w("albert.embd_bias"), x0, E, N, E, H, x, H);
+    const std::string L0 = "albert.layer.0.";
+    for (uint32_t r = 0; r < c->ko.n_recurrence; r++) {
+        k.linear(k.w(L0 + "q"), k.w(L0 + "q_bias"), x, H, N, H, H, q, H);
+        k.linear(k.w(L0 + "k"), k.w(L0 + "k_bias"), x, H, N, H, H, kk, H);
+        k.linear(k.w(L0 + "v"), k.w(L0 + "v_bias"), x, H, N, H, H, v, H);
+        hipLaunchKernelGGL(kk_albert_attn_kernel, dim3(NH, N), dim3(64), (size_t) N * 4, c->stream, (const float *) q, (const float *) kk, (const float *) v, N, H, hs,
+                           c->ko.attn_scale, att);
+        k.linear(k.w(L0 + "o"), k.w(L0 + "o_bias"), att, H, N, H, H, o, H);
+        hipLaunchKernelGGL(kk_add_kernel, kgrid((int64_t) N * H), dim3(256), 0, c->stream, (const float *) o, (const float *) x, o, (int64_t) N * H, 1.0f);
+        k.norm_rows(o, H, N, H, 1e-12f, k.w(L0 + "ffn_norm"), k.w(L0 + "ffn_norm_bias"), 0, x, H);
+        k.linear(ffn_w, k.w(L0 + "ffn_bias"), x, H, N, H, F, ff, F);
+        hipLaunchKernelGGL(kk_gelu_kernel, kgrid((int64_t) N * F), dim3(256), 0, c->stream, ff, (int64_t) N * F);
+        k.linear(k.w(L0 + "ffn_out"), k.w(L0 + "ffn_out_bias"), ff, F, N, F, H, o, H);
+        hipLaunchKernelGGL(kk_add_kernel, kgrid((int64_t) N * H), dim3(256), 0, c->stream, (const float *) o, (const float *) x, o, (int64_t) N * H, 1.0f);
+        k.norm_rows(o, H, N, H, 1e-12f, k.w(L0 + "attn_norm"), k.w(L0 + "attn_norm_bias"), 0, x, H);
+        if (!k.ok()) return set_err("tts_hip_kokoro_durations: %s", k.err.c_str());
+    }
+    const std::string dp = "duration_predictor.";
+    k.linear(k.w(dp + "encode"), k.w(dp + "encode_bias"), x, H, N, H, D, cur, Wd);
+    hipLaunchKernelGGL(kk_fill_cols_kernel, kgrid((int64_t) N * S), dim3(256), 0, c->stream, cur, N, Wd, D, style, S);
+    for (uint32_t l = 0; l < c->ko.n_dp_layers; l++) {
+        const std::string lb = dp + "layers." + std::to_string(2 * l + 1) + ".";
+        k.bilstm(dp + "layers." + std::to_string(2 * l) + ".lstm", cur, N, Wd, D / 2, ls);
+        k.linear(k.w(lb + "gamma_weight"), k.w(lb + "gamma_bias"), style, S, 1, S, D, gamma, D);
+        k.linear(k.w(lb + "beta_weight"), k.w(lb + "beta_bias"), style, S, 1, S, D, beta, D);
+        k.norm_rows(ls, D, N, D, 1e-5f, gamma, beta, 1, cur, Wd);   // the style columns of cur stay in place
+        if (!k.ok()) return set_err("tts_hip_kokoro_durations: %s", k.err.c_str());
+    }
+    if (hidden_out) HIPCHK(hipMemcpyAsync(hidden_out, cur, (size_t) N * Wd * 4, hipMemcpyDeviceToHost, c->stream));
+    k.bilstm(dp + "duration_lstm", cur, N, Wd, D / 2, ls);
+    const float *dpw = k.w(dp + "duration_proj", ne);
+    const int ND = dpw ? (int) ne[1] : 0;
+    float *dur = s.f((size_t) N * ND), *lens = s.f(n);
+    k.linear(dpw, k.w(dp + "duration_proj_bias"), ls, D, N, D, ND, dur, ND);
+    if (dur && lens) hipLaunchKernelGGL(kk_duration_kernel, kgrid(N, 64), dim3(64), 0, c->stream, (const float *) dur, N, ND, lens);
+    if (!k.ok()) return set_err("tts_hip_kokoro_durations: %s", k.err.c_str());
+    HIPCHK(hipMemcpyAsync(lens_out, lens, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int tts_hip_kokoro_generate(tts_hip_ctx *c, const uint32_t *tokens, uint32_t n, const float *lens, const float *hidden, const char *voice, const float *noise,
+                                       float *pcm_out, float *hsrc_out, const float *hsrc_in) {
+    if (!c || !c->has_kokoro) return set_err("tts_hip_kokoro_generate: not a Kokoro context (tts_hip_kokoro_create)");
+    if (!c->finalized || !c->weights_present) return set_err("tts_hip_kokoro_generate: context not finalized");
+    if (!tokens || !lens || !hidden || !noise || !pcm_out) return set_err("tts_hip_kokoro_generate: null argument");
+    if (n < 3 || n > c->ko.max_ctx) return set_err("tts_hip_kokoro_generate: %u tokens outside 3..%u", n, c->ko.max_ctx);
+    HIPCHK(hipSetDevice(c->device));
+    const tts_hip_kokoro_desc &kd = c->ko;
+    KScratch s;
+    KRun k(c, s);
+    int D = 0, S = 0;
+    if (kokoro_dims(c, k, D, S) != 0) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+    const int N = (int) n, Wd = D + S;
+    std::vector<int> tok_of;
+    for (int i = 0; i < N; i++) {
+        if (!(lens[i] >= 1.0f) || lens[i] > 50.0f || lens[i] != floorf(lens[i])) return set_err("tts_hip_kokoro_generate: length %g of token %d is not a whole number in 1..50", lens[i], i);
+        for (int r = 0; r < (int) lens[i]; r++) tok_of.push_back(i);
+    }
+    const int64_t T = (int64_t) tok_of.size();
+    const float *style_p = kokoro_voice(c, k, voice, n, S, true), *style_d = kokoro_voice(c, k, voice, n, S, false);
+    if (!style_p || !style_d) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+    int64_t ne[4];
+    const float *te = k.w("text_encoder.embedding_weight", ne);
+    if (!te) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+    const int C = (int) ne[0], vocab = (int) ne[1];
+    for (uint32_t i = 0; i < n; i++)
+        if (tokens[i] >= (uint32_t) vocab) return set_err("tts_hip_kokoro_generate: token %u >= vocabulary %d", tokens[i], vocab);
+    const int NHm = (int) kd.harmonic_num + 1, up = (int) kd.upsample_scale;
+    const int64_t L2 = 2 * T, LS = L2 * up, out_len = T * kd.up_sampling_factor;
+    const int Nf = (int) kd.n_fft, hop = (int) kd.hop, nbins = Nf / 2 + 1;
+    const int64_t F = LS / hop + 1;
+
+    uint32_t *d_tok = (uint32_t *) s.f(n);
+    int *d_idx = (int *) s.f((size_t) T);
+    float *d_hidden = s.f((size_t) N * Wd), *d_noise = s.f((size_t) NHm * LS);
+    if (s.failed) return set_err("tts_hip_kokoro_generate: device scratch allocation failed");
+    HIPCHK(hipMemcpyAsync(d_tok, tokens, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_idx, tok_of.data(), (size_t) T * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_hidden, hidden, (size_t) N * Wd * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_noise, noise, (size_t) NHm * LS * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // tok_of is a local
+
+    // alignment + shared LSTM (:1157-1166)
+    float *en = s.f((size_t) T * Wd), *sh = s.f((size_t) T * D), *shc = s.f((size_t) D * T);
+    if (s.failed) return set_err("tts_hip_kokoro_generate: device scratch allocation failed");
+    hipLaunchKernelGGL(kk_gather_rows_kernel, kgrid(T * Wd), dim3(256), 0, c->stream, (const float *) d_hidden, (const int *) d_idx, (int) T, Wd, en);
+    k.bilstm("duration_predictor.shared_lstm", en, (int) T, Wd, D / 2, sh);
+    hipLaunchKernelGGL(kk_transpose_kernel, kgrid(T * D), dim3(256), 0, c->stream, (const float *) sh, (int) T, D, shc);
+    // F0 / N branches (:1169-1192)
+    float *curves[2] = {nullptr, nullptr};
+    const char *branch[2] = {"f0", "n"};
+    for (int b = 0; b < 2; b++) {
+        float *cur = shc;
+        int Cb = D;
+        int64_t L = T;
+        for (uint32_t i = 0; i < kd.f0_n_blocks; i++) {
+            cur = k.ada_block(std::string("duration_predictor.") + branch[b] + "_blocks." + std::to_string(i), cur, L, style_p, S, Cb, L);
+            if (!cur || !k.ok()) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+        }
+        if (L != L2) return set_err("tts_hip_kokoro_generate: the %s branch does not double the frame count", branch[b]);
+        curves[b] = s.f((size_t) L2);
+        k.conv1d(cur, Cb, L, k.w(std::string("duration_predictor.") + branch[b] + "_proj_kernel"), k.w(std::string("duration_predictor.") + branch[b] + "_proj_bias"), 1, 1, 1,
+                 0, 1, 0, curves[b], L2, 0, 1.0f);
+    }
+    // text encoder (:1196-1210)
+    float *tx = s.f((size_t) C * N);
+    hipLaunchKernelGGL(kk_embed_cols_kernel, kgrid((int64_t) N * C), dim3(256), 0, c->stream, te, (const uint32_t *) d_tok, N, C, tx);
+    for (uint32_t l = 0; l < kd.n_conv_layers; l++) {
+        const std::string lb = "text_encoder.layers." + std::to_string(l) + ".";
+        const float *cw = k.w(lb + "weight", ne);
+        if (!cw) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+        float *y = s.f((size_t) C * N);
+        k.conv1d(tx, C, N, cw, k.w(lb + "bias"), C, (int) ne[0], 1, 2, 1, 0, y, N, 0, 1.0f);
+        if (y) hipLaunchKernelGGL(kk_chan_norm_kernel, dim3(N), dim3(64), 0, c->stream, y, C, (int64_t) N, k.w(lb + "gamma"), k.w(lb + "beta"), 0.2f);
+        tx = y;
+    }
+    float *txr = s.f((size_t) N * C), *tl = s.f((size_t) N * C), *asr = s.f((size_t) C * T);
+    if (s.failed) return set_err("tts_hip_kokoro_generate: device scratch allocation failed");
+    hipLaunchKernelGGL(kk_transpose_kernel, kgrid((int64_t) C * N), dim3(256), 0, c->stream, (const float *) tx, C, N, txr);
+    k.bilstm("text_encoder.lstm", txr, N, C, C / 2, tl);
+    hipLaunchKernelGGL(kk_gather_cols_kernel, kgrid((int64_t) C * T), dim3(256), 0, c->stream, (const float *) tl, (const int *) d_idx, (int) T, C, asr);
+    if (!k.ok()) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+    // decoder (:1222-1241)
+    float *f0d = s.f((size_t) T), *nd = s.f((size_t) T);
+    k.conv1d(curves[0], 1, L2, k.w("decoder.f0_conv_weight"), k.w("decoder.f0_conv_bias"), 1, 3, 2, 1, 1, 0, f0d, T, 0, 1.0f);
+    k.conv1d(curves[1], 1, L2, k.w("decoder.n_conv_weight"), k.w("decoder.n_conv_bias"), 1, 3, 2, 1, 1, 0, nd, T, 0, 1.0f);
+    int Cc = C + 2;
+    float *cat0 = s.f((size_t) Cc * T);
+    k.copy(cat0, asr, (size_t) C * T);
+    k.copy(cat0 + (size_t) C * T, f0d, (size_t) T);
+    k.copy(cat0 + (size_t) (C + 1) * T, nd, (size_t) T);
+    int64_t Lc = T;
+    float *cur = k.ada_block("decoder.encoder_block", cat0, T, style_d, S, Cc, Lc);
+    const float *aw = k.w("decoder.asr_conv_weight", ne);
+    if (!cur || !aw) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+    const int CA = (int) ne[2];
+    float *asr_res = s.f((size_t) CA * T);
+    k.conv1d(asr, C, T, aw, k.w("decoder.asr_conv_bias"), CA, 1, 1, 0, 1, 0, asr_res, T, 0, 1.0f);
+    for (uint32_t i = 0; i < kd.n_decoder_blocks; i++) {
+        int Cin = Cc + CA + 2;
+        float *cat = s.f((size_t) Cin * T);
+        k.copy(cat, cur, (size_t) Cc * T);
+        k.copy(cat + (size_t) Cc * T, asr_res, (size_t) CA * T);
+        k.copy(cat + (size_t) (Cc + CA) * T, f0d, (size_t) T);
+        k.copy(cat + (size_t) (Cc + CA + 1) * T, nd, (size_t) T);
+        cur = k.ada_block("decoder.decoder_blocks." + std::to_string(i), cat, T, style_d, S, Cin, Lc);
+        if (!cur || !k.ok()) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+        Cc = Cin;
+    }
+    if (Lc != L2) return set_err("tts_hip_kokoro_generate: the decoder does not end at twice the frame count");
+    // harmonic source + STFT conditioning (:173-206)
+    float *phase = s.f((size_t) NHm * L2), *sine = s.f((size_t) NHm * LS), *har = s.f((size_t) LS), *win = s.f(Nf), *hs = s.f((size_t) 2 * nbins * F);
+    if (s.failed) return set_err("tts_hip_kokoro_generate: device scratch allocation failed");
+    {
+        std::vector<float> hw((size_t) Nf);
+        for (int i = 0; i < Nf; i++) hw[(size_t) i] = (float) pow(sin(M_PI * (double) i / (double) Nf), 2.0);   // hann_window, util.cpp:134-139
+        HIPCHK(hipMemcpyAsync(win, hw.data(), (size_t) Nf * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    hipLaunchKernelGGL(kk_sine_phase_kernel, kgrid(NHm, 64), dim3(64), 0, c->stream, (const float *) curves[0], L2, NHm, kd.sample_rate, kd.upsample_scale * 2.0f * (float) M_PI, phase);
+    hipLaunchKernelGGL(kk_sine_source_kernel, kgrid((int64_t) NHm * LS), dim3(256), 0, c->stream, (const float *) phase, (const float *) curves[0], L2, NHm, up, kd.voice_threshold,
+                       kd.sin_amp, kd.noise_std, (const float *) d_noise, sine);
+    hipLaunchKernelGGL(kk_source_merge_kernel, kgrid(LS), dim3(256), 0, c->stream, (const float *) sine, NHm, LS, k.w("decoder.generator.m_source_weight"),
+                       k.w("decoder.generator.m_source_bias"), har);
+    hipLaunchKernelGGL(kk_stft_kernel, kgrid((int64_t) nbins * F), dim3(256), 0, c->stream, (const float *) har, LS, (const float *) win, Nf, hop, F, hs);
+    if (!k.ok()) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+    if (hsrc_out) HIPCHK(hipMemcpyAsync(hsrc_out, hs, (size_t) 2 * nbins * F * 4, hipMemcpyDeviceToHost, c->stream));
+    if (hsrc_in) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpyAsync(hs, hsrc_in, (size_t) 2 * nbins * F * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    // generator (:208-241)
+    float *g = cur;
+    int Cg = Cc;
+    int64_t Lg = Lc;
+    const std::string gb = "decoder.generator.";
+    for (uint32_t i = 0; i < kd.n_upsamples; i++) {
+        hipLaunchKernelGGL(kk_leaky_kernel, kgrid((int64_t) Cg * Lg), dim3(256), 0, c->stream, g, (int64_t) Cg * Lg, 0.1f);
+        const float *uw = k.w(gb + "ups." + std::to_string(i) + ".weight", ne);
+        if (!uw) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+        const int K = (int) ne[0], Co = (int) ne[1];
+        const int64_t Lo = (Lg - 1) * kd.up_stride[i] - 2 * (int64_t) kd.up_padding[i] + K;
+        float *y = s.f((size_t) Co * Lo);
+        if (y) hipLaunchKernelGGL(kk_convt1d_kernel, kgrid((int64_t) Co * Lo), dim3(256), 0, c->stream, (const float *) g, Cg, Lg, uw, k.w(gb + "ups." + std::to_string(i) + ".bias"), Co, K,
+                                  (int) kd.up_stride[i], (int) kd.up_padding[i], y, Lo);
+        g = y; Cg = Co; Lg = Lo;
+        if (i == kd.n_upsamples - 1) {
+            float *p = s.f((size_t) Cg * (Lg + 1));
+            if (p) hipLaunchKernelGGL(kk_pad_front_kernel, kgrid((int64_t) Cg * (Lg + 1)), dim3(256), 0, c->stream, (const float *) g, Cg, Lg, p);
+            g = p; Lg += 1;
+        }
+        const std::string nbk = gb + "noise_blocks." + std::to_string(i) + ".";
+        const float *nw = k.w(nbk + "conv_weight", ne);
+        if (!nw) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+        const int NK = (int) ne[0];
+        const int64_t Ls = (F + 2 * (int64_t) kd.noise_padding[i] - (NK - 1) - 1) / kd.noise_stride[i] + 1;
+        if (Ls != Lg) return set_err("tts_hip_kokoro_generate: source length %lld != %lld at stage %u", (long long) Ls, (long long) Lg, i);
+        float *xs = s.f((size_t) Cg * Lg);
+        k.conv1d(hs, 2 * nbins, F, nw, k.w(nbk + "conv_bias"), Cg, NK, (int) kd.noise_stride[i], (int) kd.noise_padding[i], 1, 0, xs, Lg, 0, 1.0f);
+        k.gen_res(nbk + "resblock", xs, Cg, Lg, style_d, S, kd.noise_res_padding[i], kd.noise_res_dilation[i]);
+        if (g && xs) hipLaunchKernelGGL(kk_add_kernel, kgrid((int64_t) Cg * Lg), dim3(256), 0, c->stream, (const float *) g, (const float *) xs, g, (int64_t) Cg * Lg, 1.0f);
+        float *sum = s.f((size_t) Cg * Lg), *br = s.f((size_t) Cg * Lg);
+        for (uint32_t ii = 0; ii < kd.n_kernels; ii++) {
+            float *dst = ii == 0 ? sum : br;
+            k.copy(dst, g, (size_t) Cg * Lg);
+            const uint32_t ri = i * kd.n_kernels + ii;
+            k.gen_res(gb + "resblocks." + std::to_string(ri), dst, Cg, Lg, style_d, S, kd.res_padding[ri], kd.res_dilation[ri]);
+            if (ii > 0 && sum && br)
+                hipLaunchKernelGGL(kk_add_kernel, kgrid((int64_t) Cg * Lg), dim3(256), 0, c->stream, (const float *) sum, (const float *) br, sum, (int64_t) Cg * Lg,
+                                   ii == kd.n_kernels - 1 ? 1.0f / (float) kd.n_kernels : 1.0f);
+        }
+        if (kd.n_kernels == 1 && sum) hipLaunchKernelGGL(kk_leaky_kernel, kgrid(1), dim3(1), 0, c->stream, sum, (int64_t) 0, 1.0f);   // nothing to average
+        g = sum;
+        if (!k.ok()) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+    }
+    hipLaunchKernelGGL(kk_leaky_kernel, kgrid((int64_t) Cg * Lg), dim3(256), 0, c->stream, g, (int64_t) Cg * Lg, 0.01f);
+    const float *pw = k.w(gb + "conv_post_weight", ne);
+    if (!pw) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+    if (Lg != F) return set_err("tts_hip_kokoro_generate: generator length %lld != STFT frames %lld", (long long) Lg, (long long) F);
+    float *post = s.f((size_t) 2 * nbins * Lg), *pcm = s.f((size_t) out_len);
+    k.conv1d(g, Cg, Lg, pw, k.w(gb + "conv_post_bias"), 2 * nbins, (int) ne[0], 1, (int) kd.out_conv_padding, 1, 0, post, Lg, 0, 1.0f);
+    if (post && pcm) {
+        hipLaunchKernelGGL(kk_spec_phase_kernel, kgrid((int64_t) 2 * nbins * Lg), dim3(256), 0, c->stream, post, nbins, Lg);
+        hipLaunchKernelGGL(kk_istft_kernel, kgrid(out_len), dim3(256), 0, c->stream, (const float *) post, Lg, (const float *) win, Nf, hop, pcm, out_len);
+    }
+    if (!k.ok()) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
+    HIPCHK(hipMemcpyAsync(pcm_out, pcm, (size_t) out_len * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }

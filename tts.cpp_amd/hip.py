@@ -64,6 +64,16 @@ class DiaDesc(C.Structure):
         ("cfg_scale", C.c_float), ("flags", C.c_uint32)]
 
 
+class KokoroDesc(C.Structure):
+    """tts_hip_kokoro_desc (include/tts_hip.h)"""
+    _fields_ = [(n, C.c_uint32) for n in ("struct_size", "n_attn_heads", "n_recurrence", "n_dp_layers", "f0_n_blocks", "n_conv_layers", "n_decoder_blocks", "n_upsamples",
+                                          "n_kernels", "n_fft", "hop", "harmonic_num", "up_sampling_factor", "out_conv_padding", "max_ctx")] + [
+        (n, C.c_float) for n in ("attn_scale", "upsample_scale", "sample_rate", "sin_amp", "noise_std", "voice_threshold")] + [
+        ("up_stride", C.c_uint32 * 4), ("up_padding", C.c_uint32 * 4), ("noise_stride", C.c_uint32 * 4), ("noise_padding", C.c_uint32 * 4),
+        ("res_padding", (C.c_uint32 * 3) * 16), ("res_dilation", (C.c_uint32 * 3) * 16), ("noise_res_padding", (C.c_uint32 * 3) * 4),
+        ("noise_res_dilation", (C.c_uint32 * 3) * 4), ("flags", C.c_uint32)]
+
+
 class KStat(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("launches", C.c_uint64), ("bytes_total", C.c_double), ("flops_total", C.c_double)]
 
@@ -73,7 +83,7 @@ EXPORTS = [
     "tts_hip_upload", "tts_hip_arena_bytes", "tts_hip_finalize", "tts_hip_arena_ptr", "tts_hip_arena_filled",
     "tts_hip_parler_set_text_encoding", "tts_hip_parler_reset", "tts_hip_parler_prefill", "tts_hip_parler_prefill_batch", "tts_hip_parler_step",
     "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits",
-    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
+    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_kokoro_create", "tts_hip_kokoro_durations", "tts_hip_kokoro_generate", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
     "tts_hip_synchronize",
 ]
@@ -126,6 +136,10 @@ def load_lib():
     L.tts_hip_orpheus_create.argtypes = [C.c_int, C.POINTER(OrpheusDesc)]
     L.tts_hip_orpheus_decode.argtypes = [vp, u32p, C.c_uint32, C.c_uint32, f32p, u32p]
     L.tts_hip_orpheus_generate_greedy.argtypes = [vp, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
+    L.tts_hip_kokoro_create.restype = vp
+    L.tts_hip_kokoro_create.argtypes = [C.c_int, C.POINTER(KokoroDesc)]
+    L.tts_hip_kokoro_durations.argtypes = [vp, u32p, C.c_uint32, C.c_char_p, f32p, f32p]
+    L.tts_hip_kokoro_generate.argtypes = [vp, u32p, C.c_uint32, f32p, f32p, C.c_char_p, f32p, f32p, f32p, f32p]
     L.tts_hip_dia_create.restype = vp
     L.tts_hip_dia_create.argtypes = [C.c_int, C.POINTER(DiaDesc)]
     L.tts_hip_dia_encode.argtypes = [vp, u32p, C.c_uint32, f32p]
@@ -548,6 +562,78 @@ class DiaEngine:
         self._chk(self.L.tts_hip_dia_step(self.ctx, ap, pos, lg.ctypes.data_as(C.POINTER(C.c_float)),
                                           raw.ctypes.data_as(C.POINTER(C.c_float)) if want_raw else None))
         return (lg, raw) if want_raw else lg
+
+    def close(self):
+        if self.ctx:
+            self.L.tts_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class KokoroEngine:
+    """A Kokoro context (tts_hip_kokoro_create): duration graph, then generation graph, per clause."""
+
+    def __init__(self, model, device=0, attn_scale=0.125):
+        self.L = load_lib()
+        cfg = model.cfg
+        self.cfg = cfg
+        d = KokoroDesc()
+        d.struct_size = C.sizeof(KokoroDesc)
+        d.n_attn_heads, d.n_recurrence, d.n_dp_layers, d.f0_n_blocks, d.n_conv_layers = cfg.heads, cfg.recurrence, cfg.dp_layers, cfg.f0_blocks, cfg.conv_layers
+        d.n_decoder_blocks, d.n_upsamples, d.n_kernels = cfg.decoder_blocks, len(cfg.up_rates), len(cfg.res_kernels)
+        d.n_fft, d.hop, d.harmonic_num, d.up_sampling_factor, d.out_conv_padding, d.max_ctx = cfg.n_fft, cfg.hop, cfg.harmonic_num, cfg.up_sampling_factor, 3, cfg.max_ctx
+        d.attn_scale, d.upsample_scale = attn_scale, float(np.prod(cfg.up_rates) * cfg.hop)
+        d.sample_rate, d.sin_amp, d.noise_std, d.voice_threshold = 24000.0, 0.1, 0.003, 10.0     # kokoro/model.h:219-222
+        g = model.geometry
+        for i, (st, pd) in enumerate(g["up"]):
+            d.up_stride[i], d.up_padding[i] = st, pd
+        for i, (st, pd) in enumerate(g["noise"]):
+            d.noise_stride[i], d.noise_padding[i] = st, pd
+        for i, blk in enumerate(g["res"]):
+            for ii, (pd, dl) in enumerate(blk):
+                d.res_padding[i][ii], d.res_dilation[i][ii] = pd, dl
+        for i, blk in enumerate(g["noise_res"]):
+            for ii, (pd, dl) in enumerate(blk):
+                d.noise_res_padding[i][ii], d.noise_res_dilation[i][ii] = pd, dl
+        self.ctx = self.L.tts_hip_kokoro_create(device, C.byref(d))
+        if not self.ctx:
+            raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
+        for t in model.tensors:
+            ne = (C.c_int64 * 4)(*(t.ne + [1] * (4 - len(t.ne))))
+            raw = np.frombuffer(bytes(t.raw()), dtype=np.uint8)
+            self._chk(self.L.tts_hip_upload(self.ctx, t.name.encode(), t.type, len(t.ne), ne, raw.ctypes.data_as(C.c_void_p)))
+        self._chk(self.L.tts_hip_finalize(self.ctx, None))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
+
+    def durations(self, tokens, voice):
+        a, ap = _u32(tokens)
+        lens = np.empty(a.size, dtype=np.float32)
+        hid = np.empty((a.size, self.cfg.dp_hidden + self.cfg.style_half), dtype=np.float32)
+        fpt = C.POINTER(C.c_float)
+        self._chk(self.L.tts_hip_kokoro_durations(self.ctx, ap, a.size, voice.encode(), lens.ctypes.data_as(fpt), hid.ctypes.data_as(fpt)))
+        return lens, hid
+
+    def generate(self, tokens, lens, hidden, voice, noise, hsrc_in=None, want_hsrc=False):
+        a, ap = _u32(tokens)
+        fpt = C.POINTER(C.c_float)
+        lens = np.ascontiguousarray(lens, dtype=np.float32)
+        hidden = np.ascontiguousarray(hidden, dtype=np.float32)
+        noise = np.ascontiguousarray(noise, dtype=np.float32)
+        total = int(lens.sum())
+        pcm = np.empty(total * self.cfg.up_sampling_factor, dtype=np.float32)
+        hs = np.empty((2 * (self.cfg.n_fft // 2 + 1), 2 * total * int(np.prod(self.cfg.up_rates)) + 1), dtype=np.float32)
+        hin = None if hsrc_in is None else np.ascontiguousarray(hsrc_in, dtype=np.float32)
+        self._chk(self.L.tts_hip_kokoro_generate(self.ctx, ap, a.size, lens.ctypes.data_as(fpt), hidden.ctypes.data_as(fpt), voice.encode(), noise.ctypes.data_as(fpt),
+                                                 pcm.ctypes.data_as(fpt), hs.ctypes.data_as(fpt), hin.ctypes.data_as(fpt) if hin is not None else None))
+        return (pcm, hs) if want_hsrc else pcm
 
     def close(self):
         if self.ctx:
