@@ -106,6 +106,14 @@ int tts_c_dia_check_stopping(uint32_t *ids, uint32_t eos, uint32_t pad, uint32_t
 /* adjust_output_tokens :787-808: tokens[n_steps][9] -> filtered frames [..][9]; returns the number of ids written */
 int64_t tts_c_dia_adjust_output_tokens(const uint32_t *tokens, uint64_t n_ids, uint32_t audio_vocab, uint32_t max_delay, uint32_t *filtered);
 
+/* ---- Kokoro host logic, callable without a device (host/kokoro_runner.h; reference src/tokenizer.cpp:159-177,
+ * src/models/kokoro/model.cpp:1340-1388) ------------------------------------------------------------------------------
+ * single_pass_tokenizer::tokenize over the given vocabulary; returns the number of ids (out may be NULL to count) */
+int tts_c_single_pass_tokenize(const char *const *vocab, int n_vocab, const char *text, uint32_t *out, int cap);
+/* the clause / chunk split of kokoro_runner::generate (:1420-1446) for a phoneme string: out receives, per chunk, its length
+ * followed by its ids (bos ... eos); returns the number of uint32 written (or needed, when larger than cap) */
+int tts_c_kokoro_chunks(const char *const *vocab, int n_vocab, const char *phonemes, uint32_t max_ctx, uint32_t space_token_id, uint32_t *out, int cap);
+
 /* ---- the quantize tool (examples/quantize/quantize_impl.h:5-15: quantization_params + quantize_gguf) ------------
  * Host only.  quantize_type is the ggml type number (F16 1, Q4_0 2, Q5_0 6, Q8_0 8; quantize.cpp:11-20). */
 typedef struct tts_c_quantization_params {

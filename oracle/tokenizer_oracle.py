@@ -162,3 +162,76 @@ def _split_keep(text, sep):
     if cur:
         out.append(cur)
     return out
+
+
+# ---- Kokoro: single-pass tokenizer and clause chunking (TEST INFRASTRUCTURE) -------------------------------------------
+class SinglePassOracle:
+    """single_pass_tokenizer::tokenize (/root/reference/src/tokenizer.cpp:159-177): at each position, prefixes of 1, 2, ... bytes
+    (up to the longest vocabulary entry) are looked up in order and the first hit wins; no hit -> id 0, one byte skipped."""
+
+    def __init__(self, tokens):
+        self.tokens = [t.encode("utf-8") if isinstance(t, str) else t for t in tokens]
+        self.max_size = max((len(t) for t in self.tokens), default=0)
+
+    def tokenize(self, text, out=None):
+        rem = text.encode("utf-8") if isinstance(text, str) else text
+        ids = [] if out is None else out
+        while rem:
+            tid = 0
+            for i in range(1, min(len(rem) + 1, self.max_size + 1)):
+                part = rem[:i]
+                if part in self.tokens:
+                    tid = self.tokens.index(part)
+                    rem = rem[i:]
+                    break
+            if tid == 0:
+                rem = rem[1:]
+            ids.append(tid)
+        return ids
+
+
+def kokoro_chunks(tok, phonemes, max_ctx, space_id=16, bos=0, eos=0):
+    """kokoro_runner::generate's split (src/models/kokoro/model.cpp:1420-1446) with tokenize_chunks (:1340-1388).  The
+    reference reads chunks.back() of an empty list when the first clause is too long; that case counts as zero here."""
+    p = (phonemes.encode("utf-8") if isinstance(phonemes, str) else phonemes).replace(b"\n", b" ")
+    if len(p) < max_ctx - 2:
+        for ch in b".!?":
+            p = p.replace(bytes([ch]), b"")
+        p = p.strip(b" ")
+        if not p:
+            return []
+        return [[bos] + tok.tokenize(p) + [eos]]
+    clauses, cur = [], b""
+    for ch in p:
+        if ch in b".!?":
+            if cur:
+                clauses.append(cur)
+            cur = b""
+        else:
+            cur += bytes([ch])
+    if cur:
+        clauses.append(cur)
+    chunks = []
+    for clause in clauses:
+        clause = clause.strip(b" ")
+        if not clause:
+            continue
+        tokens = [bos] + tok.tokenize(clause)
+        if len(tokens) > max_ctx - 2:
+            last_space, last_split = 1, 1
+            for i in range(1, len(tokens)):
+                if tokens[i] == space_id:
+                    last_space = i
+                prev = len(chunks[-1]) if chunks else 0
+                if (i - last_split) + prev >= max_ctx - 1:
+                    if last_space > last_split:
+                        chunks.append([bos] + tokens[last_split:last_space] + [eos])
+                        last_split = last_space
+                    else:
+                        chunks.append([bos] + tokens[last_split:i + 1] + [eos])
+                        last_split = i + 1
+            if last_split + 1 < len(tokens):
+                chunks.append([bos] + tokens[last_split:] + [eos])
+        else:
+            chunks.append(tokens + [eos])
+    return chunks

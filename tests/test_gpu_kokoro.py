@@ -48,3 +48,46 @@ def test_kokoro_durations_and_audio_match_oracle():
     with pytest.raises(hip.HipError):
         eng.generate(toks, lens2 + 0.5, ref_hid, "af_test", n2)
     eng.close()
+
+
+def _minstd0_uniform(n, state=1):
+    """std::default_random_engine (minstd_rand0) through std::uniform_real_distribution<float>(0, 1) as libstdc++ evaluates it:
+    one engine call per draw, (x - 1) / 2147483646 in float, a result of 1.0 replaced by the float below it"""
+    out = np.empty(n, dtype=np.float32)
+    x = state
+    for i in range(n):
+        x = (x * 16807) % 2147483647
+        v = np.float32(x - 1) / np.float32(2147483646.0)
+        out[i] = v if v < 1.0 else np.nextafter(np.float32(1.0), np.float32(0.0))
+    return out, x
+
+
+@pytest.mark.skipif(os.environ.get("TTS_TEST_EXPERIMENTAL") != "1", reason="runner path written after the round's GPU minutes were spent (TTS_TEST_EXPERIMENTAL=1)")
+def test_kokoro_runner_from_file(tmp_path):
+    """runner_from_file on a Kokoro GGUF: phoneme string -> clause chunks -> durations -> source noise -> audio (kokoro/model.cpp:1277-1446).
+    The reference phonemizes first; the runner is handed the phonemes (host/kokoro_runner.h)."""
+    import tokenizer_oracle
+    from tts_cpp_amd import gguf, runner
+    model = synth.build_kokoro(synth.kokoro_tiny())
+    cfg = model.cfg
+    path = model.write_gguf(str(tmp_path / "kokoro.gguf"))
+    vocab = gguf.Reader(path).kv["tokenizer.ggml.tokens"]
+    r = runner.Runner(path, voice=b"af_test")
+    assert r.arch == "kokoro" and r.sampling_rate == 24000.0
+    text = "abc de. fgh"
+    pcm = r.generate(text, voice=b"af_test")
+    tok = tokenizer_oracle.SinglePassOracle(vocab)
+    chunks = tokenizer_oracle.kokoro_chunks(tok, text, cfg.max_ctx)
+    assert r.last_tokens(0).tolist() == [t for ch in chunks for t in ch]
+    o = orc.KokoroOracle(model)
+    eng = hip.KokoroEngine(model)
+    state, want = 1, []
+    for ch in chunks:
+        lens, hid = o.durations(ch, "af_test")
+        noise, state = _minstd0_uniform(o.noise_len(int(lens.sum())), state)
+        want.append(eng.generate(ch, lens, hid, "af_test", noise))     # same device kernels, same noise stream: bit-equal audio
+    want = np.concatenate(want)
+    assert pcm.shape == want.shape and np.array_equal(pcm, want)
+    with pytest.raises(runner.RunnerError):
+        r.generate(text, voice=b"nobody")
+    r.close()

@@ -291,3 +291,39 @@ def test_dia_host_stopping_and_undelay_match_oracle():
     for steps in (10, 16, 17, 40):
         toks = rng.integers(0, cfg.audio_vocab + 3, (steps, cfg.n_out)).astype(np.uint32)   # a few specials: frames get dropped
         assert np.array_equal(runner.dia_adjust_output_tokens(toks, cfg.audio_vocab, cfg.max_delay), o.adjust_output_tokens(toks)), steps
+
+
+# ---- Kokoro host logic (host/kokoro_runner.cpp) against the restatement in oracle/tokenizer_oracle.py ---------------------------
+KOKORO_VOCAB = ["", "a", "b", "ab", "ʃ", "ə", "ˈ", "t", "h", "e", "l", "o", "w", "r", "d", "k", " ", ",", "ɪ", "n", "ŋ"]   # id 16 is the space (model.h:185)
+
+
+def test_kokoro_single_pass_tokenizer_matches_oracle():
+    tok = tokenizer_oracle.SinglePassOracle(KOKORO_VOCAB)
+    for text in ["hello world", "ab abba", "ˈʃə təl", "xyz", "", "a?b", "həˈloʊ wɜːld", "ŋŋ nn ɪ"]:
+        assert runner.single_pass_tokenize(KOKORO_VOCAB, text).tolist() == tok.tokenize(text), text
+    # the shortest matching entry wins: "ab" is never produced while "a" is in the vocabulary (tokenizer.cpp:163-170)
+    assert runner.single_pass_tokenize(KOKORO_VOCAB, "ab").tolist() == [1, 2]
+    # a multi-byte symbol outside the vocabulary costs one unknown id per byte
+    assert runner.single_pass_tokenize(KOKORO_VOCAB, "é").tolist() == [0, 0]
+
+
+def test_kokoro_clause_chunking_matches_oracle():
+    tok = tokenizer_oracle.SinglePassOracle(KOKORO_VOCAB)
+    rng = np.random.default_rng(8)
+    words = ["hello", "world", "talk", "ˈʃə", "ten", "doll", "loaned", "a"]
+    for max_ctx, n_words in ((64, 5), (24, 12), (24, 40), (16, 30), (12, 25)):
+        for trial in range(6):
+            parts = []
+            for i in range(n_words):
+                parts.append(words[int(rng.integers(len(words)))])
+                parts.append(rng.choice([" ", " ", " ", ". ", "! ", "? ", "\n"]))
+            text = "".join(parts)
+            want = tokenizer_oracle.kokoro_chunks(tok, text, max_ctx)
+            got = runner.kokoro_chunks(KOKORO_VOCAB, text, max_ctx)
+            assert got == want, (max_ctx, text)
+            assert all(c[0] == 0 and c[-1] == 0 for c in got)
+    assert runner.kokoro_chunks(KOKORO_VOCAB, " . ! ", 64) == []
+    # a clause longer than the context without any space is cut mid-word
+    long_word = "hello" * 10
+    got = runner.kokoro_chunks(KOKORO_VOCAB, long_word, 16)
+    assert got == tokenizer_oracle.kokoro_chunks(tok, long_word, 16) and len(got) > 1

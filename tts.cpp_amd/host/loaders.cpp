@@ -76,7 +76,8 @@ std::unique_ptr<tts_generation_runner> dummy_loader_t::from_file(gguf_file *, in
 void parler_register();
 void orpheus_register();
 void dia_register();
-[[maybe_unused]] static const bool loaders_registered = [] { parler_register(); orpheus_register(); dia_register(); return true; }();
+void kokoro_register();
+[[maybe_unused]] static const bool loaders_registered = [] { parler_register(); orpheus_register(); dia_register(); kokoro_register(); return true; }();
 
 std::unique_ptr<tts_generation_runner> runner_from_file(const char * fname, int n_threads,
                                                         const generation_configuration & config, bool cpu_only) {

@@ -8,6 +8,7 @@
 #include "common.h"
 #include "gguf.h"
 #include "dia_runner.h"
+#include "kokoro_runner.h"
 #include "orpheus_runner.h"
 #include "parler_runner.h"
 #include "sampler.h"
@@ -97,6 +98,8 @@ int tts_c_last_tokens(tts_c_runner * r, int which, uint32_t * out, int cap) {
         vp = which == 0 ? &o->last_prompt_tokens : (which == 1 ? &o->last_output_tokens : &none);
     else if (auto * d = dynamic_cast<dia_runner *>((tts_generation_runner *) r))
         vp = which == 0 ? &d->last_prompt_tokens : (which == 1 ? &d->last_output_tokens : &none);
+    else if (auto * k = dynamic_cast<kokoro_runner *>((tts_generation_runner *) r))
+        vp = which == 0 ? &k->last_prompt_tokens : &none;
     if (!vp) { g_c_err = "runner keeps no token record"; return -1; }
     const std::vector<uint32_t> & v = *vp;
     const int n = (int) v.size();
@@ -208,6 +211,31 @@ extern "C" int64_t tts_c_dia_adjust_output_tokens(const uint32_t * tokens, uint6
     dia_adjust_output_tokens(hp, in, out);
     memcpy(filtered, out.data(), out.size() * 4);
     return (int64_t) out.size();
+}
+
+// ---- Kokoro host logic (host/kokoro_runner.h) -------------------------------------------------------------------
+std::vector<std::vector<uint32_t>> kokoro_clause_chunks(const kokoro_hparams & hp, const single_pass_tokenizer & tok, const std::string & phonemes);
+
+extern "C" int tts_c_single_pass_tokenize(const char * const * vocab, int n_vocab, const char * text, uint32_t * out, int cap) {
+    single_pass_tokenizer t(std::vector<std::string>(vocab, vocab + n_vocab));
+    std::vector<uint32_t> ids;
+    t.tokenize(text, ids);
+    if (out) memcpy(out, ids.data(), (size_t) std::min<int>((int) ids.size(), cap) * 4);
+    return (int) ids.size();
+}
+
+extern "C" int tts_c_kokoro_chunks(const char * const * vocab, int n_vocab, const char * phonemes, uint32_t max_ctx, uint32_t space_token_id, uint32_t * out, int cap) {
+    single_pass_tokenizer t(std::vector<std::string>(vocab, vocab + n_vocab));
+    kokoro_hparams hp;
+    hp.max_context_length = max_ctx;
+    hp.space_token_id = space_token_id;
+    std::vector<uint32_t> flat;
+    for (const auto & ch : kokoro_clause_chunks(hp, t, phonemes)) {
+        flat.push_back((uint32_t) ch.size());
+        flat.insert(flat.end(), ch.begin(), ch.end());
+    }
+    if (out) memcpy(out, flat.data(), (size_t) std::min<int>((int) flat.size(), cap) * 4);
+    return (int) flat.size();
 }
 
 // ---- quantize tool (host/quantize.h) -------------------------------------------------------------------------

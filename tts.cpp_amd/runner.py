@@ -30,7 +30,7 @@ EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "
            "tts_c_last_error", "tts_c_update_conditional_prompt", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor",
            "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_free",
            "tts_c_quantize_gguf", "tts_c_quantize_decision", "tts_c_quantize_rows",
-           "tts_c_dia_tokenize", "tts_c_dia_check_stopping", "tts_c_dia_adjust_output_tokens"]
+           "tts_c_dia_tokenize", "tts_c_dia_check_stopping", "tts_c_dia_adjust_output_tokens", "tts_c_single_pass_tokenize", "tts_c_kokoro_chunks"]
 
 _lib = None
 
@@ -66,6 +66,8 @@ def load_lib():
         L.tts_c_gguf_summary.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_int]
         L.tts_c_gguf_tensor.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
         L.tts_c_update_conditional_prompt.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.tts_c_single_pass_tokenize.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.POINTER(C.c_uint32), C.c_int]
+        L.tts_c_kokoro_chunks.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int]
         L.tts_c_dia_tokenize.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.tts_c_dia_check_stopping.argtypes = [C.POINTER(C.c_uint32)] + [C.c_uint32] * 5 + [C.POINTER(C.c_int)]
         L.tts_c_dia_adjust_output_tokens.restype = C.c_int64
@@ -164,6 +166,35 @@ def tokenize(gguf_path, text):
     if n < 0:
         raise RunnerError(L.tts_c_last_error().decode())
     return out[:n].copy()
+
+
+def _vocab_array(vocab):
+    return (C.c_char_p * len(vocab))(*[v.encode("utf-8") if isinstance(v, str) else v for v in vocab])
+
+
+def single_pass_tokenize(vocab, text):
+    L = load_lib()
+    va = _vocab_array(vocab)
+    t = text.encode("utf-8") if isinstance(text, str) else text
+    n = L.tts_c_single_pass_tokenize(va, len(vocab), t, None, 0)
+    out = np.zeros(max(n, 1), dtype=np.uint32)
+    L.tts_c_single_pass_tokenize(va, len(vocab), t, out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+    return out[:n]
+
+
+def kokoro_chunks(vocab, phonemes, max_ctx, space_token_id=16):
+    L = load_lib()
+    va = _vocab_array(vocab)
+    t = phonemes.encode("utf-8") if isinstance(phonemes, str) else phonemes
+    n = L.tts_c_kokoro_chunks(va, len(vocab), t, max_ctx, space_token_id, None, 0)
+    flat = np.zeros(max(n, 1), dtype=np.uint32)
+    L.tts_c_kokoro_chunks(va, len(vocab), t, max_ctx, space_token_id, flat.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+    out, i = [], 0
+    while i < n:
+        k = int(flat[i])
+        out.append(flat[i + 1:i + 1 + k].tolist())
+        i += 1 + k
+    return out
 
 
 def dia_tokenize(sentence, max_ctx):
