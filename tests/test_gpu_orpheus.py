@@ -126,3 +126,20 @@ def test_orpheus_runner_generates_through_both_contexts(tmp_path):
     with pytest.raises(runner.RunnerError):
         r.generate("hello", voice=b"nobody", sample=0)
     r.close()
+
+
+@pytest.mark.skipif(os.environ.get("TTS_TEST_EXPERIMENTAL") != "1", reason="captured-step path written after the round's GPU minutes were spent (TTS_TEST_EXPERIMENTAL=1)")
+def test_orpheus_greedy_through_the_captured_step():
+    """TTS_HIP_LLAMA_GRAPH=1: the greedy step (forward + arg-max + feedback) as one hipGraph replayed per position — same ids as the eager loop"""
+    model = synth.build_orpheus(synth.orpheus_tiny())
+    g = np.load(GOLD)
+    os.environ["TTS_HIP_LLAMA_GRAPH"] = "1"
+    try:
+        eng = hip.OrpheusEngine(model.cfg)
+    finally:
+        del os.environ["TTS_HIP_LLAMA_GRAPH"]
+    eng.load(model)
+    assert eng.generate_greedy(g["prompt"], 6, stop_id=model.cfg.vocab + 5).tolist() == g["tokens"].tolist()
+    assert eng.generate_greedy(g["prompt"], 40, stop_id=model.cfg.vocab + 5).tolist()[:6] == g["tokens"].tolist()   # several chunks of 8 replays
+    assert eng.generate_greedy(g["prompt"], 6, stop_id=int(g["tokens"][2])).tolist() == g["tokens"][:3].tolist()
+    eng.close()

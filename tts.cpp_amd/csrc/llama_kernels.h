@@ -188,6 +188,24 @@ __global__ __launch_bounds__(64) void argmax_fold_kernel(const float *pv, const 
     }
 }
 
+// the same fold for a captured step (one graph replayed for every position): the history slot comes from a device counter
+__global__ __launch_bounds__(64) void argmax_fold_graph_kernel(const float *pv, const uint32_t *pi, uint32_t *token, uint32_t *hist, uint32_t *hist_idx, uint32_t *next_id,
+                                                               uint32_t *next_pos) {
+    float best = -INFINITY;
+    uint32_t besti = 0xffffffffu;
+    for (int i = threadIdx.x; i < ARGMAX_PARTS; i += 64) argmax_merge(best, besti, pv[i], pi[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_merge(best, besti, __shfl_xor(best, o), __shfl_xor(besti, o));
+    if (threadIdx.x == 0) {
+        const uint32_t t = besti == 0xffffffffu ? 0u : besti;
+        token[0] = t;
+        hist[hist_idx[0]] = t;
+        hist_idx[0] += 1;
+        next_id[0] = t;
+        next_pos[0] += 1;
+    }
+}
+
 // gu [R][2F] (gate | up) -> g [R][F] = silu(gate) * up
 __global__ void silu_mul_kernel(const float *gu, int F, int R, float *g) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;

@@ -198,6 +198,7 @@ struct tts_hip_ctx {
     float *ad = nullptr;        // their block scales
     bool all_q8i = false;       // every decoder matrix is on the integer path (all GEMMs go through run_qgemm)
     int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
+    bool llama_graph = false;   // TTS_HIP_LLAMA_GRAPH=1: the Orpheus greedy step as one captured graph (written, not yet run on a GPU)
     bool gemv_rows = false;     // TTS_HIP_GEMV_ROWS=1: 1..4 rows go through the streaming one-wave-per-feature kernels (gemv_kernels.h)
     // ---- Orpheus decoder context (tts_hip_orpheus_create) ----
     bool has_llama = false;
@@ -355,6 +356,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
     if (const char *e = getenv("TTS_HIP_Q_FUSE_MAX")) c->q_fuse_max = std::max(0, std::min(16, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMV_ROWS")) c->gemv_rows = atoi(e) != 0;
+    if (const char *e = getenv("TTS_HIP_LLAMA_GRAPH")) c->llama_graph = atoi(e) != 0;
     return c;
 }
 
@@ -1444,7 +1446,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->ad, (size_t) R * std::max(std::max(H, F), c->NH * (int) c->lm.head_dim) / 32 + 1));
         CHK(dmalloc(&c->l_ids, (size_t) R));
         CHK(dmalloc(&c->l_pos, (size_t) R));
-        CHK(dmalloc(&c->l_tok, (size_t) 1 + 2 * ARGMAX_PARTS + LLAMA_GREEDY_CHUNK));
+        CHK(dmalloc(&c->l_tok, (size_t) 1 + 2 * ARGMAX_PARTS + LLAMA_GREEDY_CHUNK + 1));
     }
     if (c->has_dia) {
         const tts_hip_dia_desc &dd = c->dia;
@@ -2387,7 +2389,9 @@ static int llama_gemm(tts_hip_ctx *c, const W &w, const float *A, int lda, float
 
 // one call of orpheus_runner::decode: n rows (<= RMAX) at pos0..; leaves the final-normed last row's logits in l_logits
 // ids == nullptr: one row whose token id and position are already in l_ids[0] / l_pos[0] (the device-resident greedy loop)
-static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t pos0) {
+// attn_positions != 0: size the attention scratch for that many cached positions instead of pos0 + n (a captured step is replayed
+// at every position)
+static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t pos0, int attn_positions = 0) {
     const int H = c->H, F = c->F, NH = c->NH, NKV = (int) c->lm.n_kv_heads, HD = (int) c->lm.head_dim;
     const int QKV = (NH + 2 * NKV) * HD, NCTX = (int) c->lm.n_ctx;
     if (n < 1 || n > c->RMAX) return set_err("tts_hip_orpheus_decode: %d tokens per call outside 1..%d", n, c->RMAX);
@@ -2423,7 +2427,7 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
         hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH + NKV), dim3(64), 0, c->stream, c->l_qkv, (const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, HD, kc, vc,
                            (const uint32_t *) nullptr, (int64_t) 0);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, n), dim3(256), (size_t) (128 + pos0 + n) * 4, c->stream, (const float *) c->l_qkv, QKV, (const uint32_t *) c->l_pos,
+        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, n), dim3(256), (size_t) (128 + (attn_positions ? (uint32_t) attn_positions : pos0 + n)) * 4, c->stream, (const float *) c->l_qkv, QKV, (const uint32_t *) c->l_pos,
                            (const float *) kc, (const float *) vc, NH, NKV, 1.0f / sqrtf((float) HD), c->l_att,
                            (const uint32_t *) nullptr, (const uint32_t *) nullptr, (const uint32_t *) nullptr, (int64_t) 0);
         HIPCHK(hipGetLastError());
@@ -2496,12 +2500,43 @@ extern "C" int tts_hip_orpheus_generate_greedy(tts_hip_ctx *c, const uint32_t *p
         HIPCHK(hipMemcpyAsync(c->l_ids, &tok, 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->l_pos, &pos, 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));  // tok / pos are reused below
-        for (uint32_t s = 0; s < chunk; s++) {
-            CHK(llama_forward(c, nullptr, 1, pos + s));
-            hipLaunchKernelGGL(argmax_parts_kernel, dim3(ARGMAX_PARTS), dim3(256), 0, c->stream, (const float *) c->l_logits, c->l_V, pv, pi);
-            HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(argmax_fold_kernel, dim3(1), dim3(64), 0, c->stream, (const float *) pv, (const uint32_t *) pi, c->l_tok, hist + s, c->l_ids, c->l_pos);
-            HIPCHK(hipGetLastError());
+        if (c->llama_graph && !c->prof) {
+            // one captured step (forward + arg-max + feedback) replayed `chunk` times; the history slot is a device counter
+            uint32_t *hist_idx = hist + LLAMA_GREEDY_CHUNK;
+            HIPCHK(hipMemsetAsync(hist_idx, 0, 4, c->stream));
+            if (pos + chunk > c->lm.n_ctx) return set_err("tts_hip_orpheus_generate_greedy: positions exceed the cache");
+            const int key = 9000001;
+            auto it = c->graphs.find(key);
+            if (it == c->graphs.end()) {
+                // one eager pass first: per-kernel attributes are set outside the capture (it rewrites the cache row of `pos`
+                // with the values the first replay writes again, nothing else)
+                CHK(llama_forward(c, nullptr, 1, pos, (int) c->lm.n_ctx));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                hipGraph_t graph = nullptr;
+                HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                int rc = llama_forward(c, nullptr, 1, 0, (int) c->lm.n_ctx);
+                if (rc == 0) {
+                    hipLaunchKernelGGL(argmax_parts_kernel, dim3(ARGMAX_PARTS), dim3(256), 0, c->stream, (const float *) c->l_logits, c->l_V, pv, pi);
+                    hipLaunchKernelGGL(argmax_fold_graph_kernel, dim3(1), dim3(64), 0, c->stream, (const float *) pv, (const uint32_t *) pi, c->l_tok, hist, hist_idx, c->l_ids,
+                                       c->l_pos);
+                }
+                const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+                if (rc != 0) { if (graph) (void) hipGraphDestroy(graph); return rc; }
+                if (e != hipSuccess) return set_err("hipStreamEndCapture: %s", hipGetErrorString(e));
+                hipGraphExec_t exec = nullptr;
+                HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                (void) hipGraphDestroy(graph);
+                it = c->graphs.emplace(key, exec).first;
+            }
+            for (uint32_t s = 0; s < chunk; s++) HIPCHK(hipGraphLaunch(it->second, c->stream));
+        } else {
+            for (uint32_t s = 0; s < chunk; s++) {
+                CHK(llama_forward(c, nullptr, 1, pos + s));
+                hipLaunchKernelGGL(argmax_parts_kernel, dim3(ARGMAX_PARTS), dim3(256), 0, c->stream, (const float *) c->l_logits, c->l_V, pv, pi);
+                HIPCHK(hipGetLastError());
+                hipLaunchKernelGGL(argmax_fold_kernel, dim3(1), dim3(64), 0, c->stream, (const float *) pv, (const uint32_t *) pi, c->l_tok, hist + s, c->l_ids, c->l_pos);
+                HIPCHK(hipGetLastError());
+            }
         }
         HIPCHK(hipMemcpyAsync(host_hist, hist, (size_t) chunk * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
