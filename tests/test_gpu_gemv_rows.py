@@ -75,3 +75,31 @@ def test_wide_feed_forward_without_split_k():
     lg, _ = eng.decode([5, 7], 0)
     assert relerr(lg, o.decode([5, 7], 0)) < 2e-4
     eng.close()
+
+
+@pytest.mark.skipif(os.environ.get("TTS_TEST_EXPERIMENTAL") != "1", reason="4-bit path written after the round's GPU minutes were spent (TTS_TEST_EXPERIMENTAL=1)")
+def test_orpheus_q4_0_matrices_read_as_4_bit_codes():
+    """TTS_HIP_Q4_NATIVE=1: the streaming kernel reads the Q4_0 codes (half the bytes of the int8 expansion); sum (n - 8) x is the same
+    integer, so the logits equal the int8 streaming path bit for bit"""
+    model = synth.build_orpheus(synth.orpheus_tiny(weight_type=gguf.Q4_0))
+    g = np.load(os.path.join(HERE, "golden", "tiny_orpheus.npz"))
+    base = hip.OrpheusEngine(model.cfg)            # TTS_HIP_GEMV_ROWS=1 from the fixture: int8 streaming kernels
+    base.load(model)
+    os.environ["TTS_HIP_Q4_NATIVE"] = "1"
+    try:
+        eng = hip.OrpheusEngine(model.cfg)
+    finally:
+        del os.environ["TTS_HIP_Q4_NATIVE"]
+    eng.load(model)
+    o = orc.OrpheusOracle(model, act_mode=1)
+    ref = o.decode(g["prompt"][:3], 0)
+    a, _ = base.decode(g["prompt"][:3], 0)
+    b, _ = eng.decode(g["prompt"][:3], 0)
+    assert np.array_equal(a, b) and relerr(b, ref) < 3e-2
+    for pos in range(3, 8):
+        t = int(ref.argmax())
+        a, _ = base.decode([t], pos)
+        b, _ = eng.decode([t], pos)
+        ref = o.decode([t], pos)
+        assert np.array_equal(a, b) and relerr(b, ref) < 3e-2
+    base.close(); eng.close()

@@ -10,7 +10,10 @@
 //   gemv_rows_kernel<WT, NR>    F32 / F16 weights; F16: activations rounded to fp16 first (ggml's vec_dot_type conversion), fp32 accumulate
 //   gemv_q8_rows_kernel<NR>     int8 block integers + fp16 block scales (Q4_0/Q5_0/Q8_0 expanded at upload) x Q8_0-quantised activations:
 //                               exact integer block dots (v_dot4_i32_i8), scaled by d_w * d_a and summed in fp32 (ggml's vec_dot_q*_q8_0)
-// Opt-in (TTS_HIP_GEMV_ROWS=1) until measured against the MFMA path on the GPU.
+//   gemv_q4_rows_kernel<NR>     the same for matrices whose GGUF type is Q4_0, reading the 4-bit codes themselves (16 bytes per block of 32
+//                               instead of the 32 of the int8 expansion): sum (n - 8) x = sum n x - 8 sum x, both by dot4 on unpacked nibbles
+//   repack_i8_to_q4_kernel      int8 expansion [N][K] -> nibble blocks [N][K/32][16] (ggml's Q4_0 packing: code j | code j+16 << 4)
+// Opt-in (TTS_HIP_GEMV_ROWS=1, TTS_HIP_Q4_NATIVE=1) until measured against the MFMA path on the GPU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -109,6 +112,63 @@ __global__ __launch_bounds__(256) void gemv_q8_rows_kernel(QGemmArgs qa, int epi
                 float *o = a.out + (int64_t) r * a.ldo + n;
                 if (epi == EPI_RESID) *o += s;
                 else *o = s;
+            }
+        }
+    }
+}
+
+
+__global__ void repack_i8_to_q4_kernel(const int8_t *q, uint8_t *out, int64_t n_bytes) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bytes) return;
+    const int64_t b = i >> 4;
+    const int j = (int) (i & 15);
+    const unsigned lo = (unsigned) (q[b * 32 + j] + 8) & 0xFu, hi = (unsigned) (q[b * 32 + 16 + j] + 8) & 0xFu;
+    out[i] = (uint8_t) (lo | (hi << 4));
+}
+
+template <int NR>
+__global__ __launch_bounds__(256) void gemv_q4_rows_kernel(QGemmArgs qa, const uint8_t *w4, int epi) {
+    const GemmArgs &a = qa.g;
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    const int K = a.K, nb = K >> 5;
+    const uint8_t *w = w4 + (int64_t) n * (K >> 1);
+    const _Float16 *wd = qa.wd + (int64_t) n * nb;
+    float acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) acc[r] = 0.0f;
+#pragma unroll 2
+    for (int b = lane; b < nb; b += 64) {   // one block of 32 codes per lane and pass: one 16-byte load
+        const int4v wn = *(const int4v *) (w + b * 16);
+        const float dw = (float) wd[b];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            if (r < a.R) {
+                const int8_t *xq = qa.aq + (int64_t) r * K + b * 32;
+                const int4v x0 = *(const int4v *) xq, x1 = *(const int4v *) (xq + 16);
+                int s = 0, sx = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int lo = wn[e] & 0x0F0F0F0F, hi = (wn[e] >> 4) & 0x0F0F0F0F;   // codes 4e..4e+3 and 16+4e..16+4e+3 as bytes 0..15
+                    s = __builtin_amdgcn_sdot4(lo, x0[e], s, false);
+                    s = __builtin_amdgcn_sdot4(hi, x1[e], s, false);
+                    sx = __builtin_amdgcn_sdot4(0x01010101, x0[e], sx, false);
+                    sx = __builtin_amdgcn_sdot4(0x01010101, x1[e], sx, false);
+                }
+                acc[r] += (float) (s - 8 * sx) * (dw * qa.ad[(int64_t) r * nb + b]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        if (r < a.R) {
+            const float sm_ = wave_sum(acc[r]);
+            if (lane == 0) {
+                float *o = a.out + (int64_t) r * a.ldo + n;
+                if (epi == EPI_RESID) *o += sm_;
+                else *o = sm_;
             }
         }
     }

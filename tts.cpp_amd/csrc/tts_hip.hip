@@ -147,6 +147,8 @@ struct W {  // a matrix living in the arena
     size_t soff = 0;  // TTS_HIP_Q8I: block scales
     int type = 0;
     int64_t K = 0, N = 0;
+    bool src_q4 = false;            // every stacked source tensor was Q4_0 in the GGUF
+    const uint8_t *q4 = nullptr;    // TTS_HIP_Q4_NATIVE: the 4-bit codes repacked next to the int8 expansion (gemv_q4_rows_kernel)
 };
 
 struct PLayer {
@@ -198,6 +200,8 @@ struct tts_hip_ctx {
     float *ad = nullptr;        // their block scales
     bool all_q8i = false;       // every decoder matrix is on the integer path (all GEMMs go through run_qgemm)
     int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
+    bool q4_native = false;     // TTS_HIP_Q4_NATIVE=1 (with TTS_HIP_GEMV_ROWS): Q4_0 matrices of the Orpheus decoder are read as 4-bit codes
+    std::vector<void *> q4_bufs;
     bool llama_graph = false;   // TTS_HIP_LLAMA_GRAPH=1: the Orpheus greedy step as one captured graph (written, not yet run on a GPU)
     bool gemv_rows = false;     // TTS_HIP_GEMV_ROWS=1: 1..4 rows go through the streaming one-wave-per-feature kernels (gemv_kernels.h)
     // ---- Orpheus decoder context (tts_hip_orpheus_create) ----
@@ -357,6 +361,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_Q_FUSE_MAX")) c->q_fuse_max = std::max(0, std::min(16, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMV_ROWS")) c->gemv_rows = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_LLAMA_GRAPH")) c->llama_graph = atoi(e) != 0;
+    if (const char *e = getenv("TTS_HIP_Q4_NATIVE")) c->q4_native = atoi(e) != 0;
     return c;
 }
 
@@ -373,6 +378,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms); free_dev(c->d_pen); free_dev(c->d_last); free_dev(c->d_repc);
     free_dev(c->l_x); free_dev(c->l_xn); free_dev(c->l_qkv); free_dev(c->l_att); free_dev(c->l_gu); free_dev(c->l_g); free_dev(c->l_logits); free_dev(c->l_parts);
     free_dev(c->l_kc); free_dev(c->l_vc); free_dev(c->l_ids); free_dev(c->l_pos); free_dev(c->l_tok);
+    for (void *p : c->q4_bufs) free_dev(p);
     for (float *p : {c->di_ex, c->di_exn, c->di_eqkv, c->di_eatt, c->di_egu, c->di_eg, c->di_ek, c->di_ev, c->di_ckv, c->di_ck, c->di_cv, c->di_k, c->di_v, c->di_x,
                      c->di_xn, c->di_qkv, c->di_q, c->di_att, c->di_gu, c->di_g, c->di_parts, c->di_logits, c->di_guided})
         free_dev(p);
@@ -562,6 +568,7 @@ struct Planner {
             if (!t) return w;
             if (i == 0) {
                 w.type = t->type; w.K = t->ne[0]; w.N = 0;
+                w.src_q4 = true;
                 cur = (cur + 255) & ~(size_t) 255;
                 w.off = cur;
             } else if (t->type != w.type || t->ne[0] != w.K) {
@@ -569,6 +576,7 @@ struct Planner {
                 return w;
             }
             const size_t main_bytes = t->type == TTS_HIP_Q8I ? (size_t) t->nelem() : t->nbytes;
+            w.src_q4 = w.src_q4 && t->src_type == TTS_HIP_Q4_0;
             c->copies.push_back({cur, names[i], 0, main_bytes});
             cur += main_bytes;
             w.N += t->nelem() / t->ne[0];
@@ -1077,7 +1085,8 @@ static int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro
         qa.wd = (const _Float16 *) (c->arena + w.soff);
         qa.aq = c->aq;
         qa.ad = c->ad;
-        hipLaunchKernelGGL(gemv_q8_rows_kernel<4>, dim3((a.N + 3) / 4), dim3(256), 0, c->stream, qa, epi);
+        if (w.q4) hipLaunchKernelGGL(gemv_q4_rows_kernel<4>, dim3((a.N + 3) / 4), dim3(256), 0, c->stream, qa, w.q4, epi);
+        else hipLaunchKernelGGL(gemv_q8_rows_kernel<4>, dim3((a.N + 3) / 4), dim3(256), 0, c->stream, qa, epi);
         HIPCHK(hipGetLastError());
         return prof_end(c);
     }
@@ -1421,6 +1430,23 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         HIPCHK(hipHostMalloc((void **) &c->h_seq, (size_t) R * 4));
         HIPCHK(hipHostMalloc((void **) &c->h_tok, (size_t) R * c->NO * 4));
         HIPCHK(hipHostMalloc((void **) &c->h_logits, (size_t) R * c->NO * c->V * 4));
+    }
+    if (c->has_llama && c->q4_native && c->gemv_rows && c->weights_present) {
+        // the 4-bit codes of the Q4_0 matrices, repacked from the int8 expansion that the many-row MFMA path keeps using
+        auto repack = [&](W &w) -> int {
+            if (w.type != TTS_HIP_Q8I || !w.src_q4) return 0;
+            const int64_t nbytes = w.N * w.K / 2;
+            uint8_t *buf = nullptr;
+            HIPCHK(hipMalloc((void **) &buf, (size_t) nbytes));
+            c->q4_bufs.push_back(buf);
+            hipLaunchKernelGGL(repack_i8_to_q4_kernel, dim3((unsigned) ((nbytes + 255) / 256)), dim3(256), 0, c->stream, (const int8_t *) (c->arena + w.off), buf, nbytes);
+            HIPCHK(hipGetLastError());
+            w.q4 = buf;
+            return 0;
+        };
+        for (auto &y : c->l_layers) { CHK(repack(y.qkv)); CHK(repack(y.o)); CHK(repack(y.gu)); CHK(repack(y.down)); }
+        CHK(repack(c->l_head));
+        HIPCHK(hipStreamSynchronize(c->stream));
     }
     if (c->has_llama) {
         const int H = c->H, F = c->F, NCTX = (int) c->lm.n_ctx, QKV = (c->NH + 2 * (int) c->lm.n_kv_heads) * (int) c->lm.head_dim;
