@@ -3175,7 +3175,6 @@ extern "C" int tts_hip_kokoro_generate(tts_hip_ctx *c, const uint32_t *tokens, u
                 hipLaunchKernelGGL(kk_add_kernel, kgrid((int64_t) Cg * Lg), dim3(256), 0, c->stream, (const float *) sum, (const float *) br, sum, (int64_t) Cg * Lg,
                                    ii == kd.n_kernels - 1 ? 1.0f / (float) kd.n_kernels : 1.0f);
         }
-        if (kd.n_kernels == 1 && sum) hipLaunchKernelGGL(kk_leaky_kernel, kgrid(1), dim3(1), 0, c->stream, sum, (int64_t) 0, 1.0f);   // nothing to average
         g = sum;
         if (!k.ok()) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
     }
