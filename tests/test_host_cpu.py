@@ -327,3 +327,34 @@ def test_kokoro_clause_chunking_matches_oracle():
     long_word = "hello" * 10
     got = runner.kokoro_chunks(KOKORO_VOCAB, long_word, 16)
     assert got == tokenizer_oracle.kokoro_chunks(tok, long_word, 16) and len(got) > 1
+
+
+def test_a_caller_written_against_the_reference_api_builds_and_runs(tmp_path):
+    """The reference's applications and its one test (tests/aPaleBlueDot/main.cpp) only use `generation_configuration`'s positional
+    constructor, `runner_from_file(path, n_threads, config, cpu_only)`, `runner->generate(text, response, config)` and the
+    `tts_response` / `sampling_rate` fields.  A translation unit written against exactly that surface compiles against host/common.h
+    and runs on the weightless backend (BASELINE config 1: plumbing, no GPU)."""
+    import subprocess
+    host = os.path.join(ROOT, "tts.cpp_amd", "host")
+    src = tmp_path / "caller.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <memory>
+#include "common.h"
+int main() {
+    generation_configuration config("", 30, 1.0f, 1.1f, false, "", 256, 0.95f, true);   // voice, top_k, temperature, repetition_penalty,
+                                                                                         // use_cross_attn, espeak_voice_id, max_tokens, top_p, sample
+    std::unique_ptr<tts_generation_runner> runner{runner_from_file("test:dummy", 4, config, true)};
+    tts_response response{};
+    runner->generate("Hello", response, config);
+    std::printf("%zu %.0f %s %d\n", response.n_outputs, runner->sampling_rate, runner->loader.get().arch, (int) runner->supports_voices);
+    return response.data && response.n_outputs == 5 * 44100 ? 0 : 1;
+}
+''')
+    exe = tmp_path / "caller"
+    cc = subprocess.run(["g++", "-std=c++20", "-O1", "-I", host, str(src), "-o", str(exe), "-L", host, "-ltts", "-L", os.path.join(ROOT, "tts.cpp_amd"), "-ltts_hip",
+                         f"-Wl,-rpath,{host}", f"-Wl,-rpath,{os.path.join(ROOT, 'tts.cpp_amd')}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True, timeout=300)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert run.stdout.split() == ["220500", "44100", "dummy", "0"]
