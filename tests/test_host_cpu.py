@@ -358,3 +358,76 @@ int main() {
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
     assert run.stdout.split() == ["220500", "44100", "dummy", "0"]
+
+
+def test_gguf_reader_survives_damaged_files(tiny_gguf, tmp_path):
+    """Truncations at every structural boundary region and random byte flips in the metadata: the mmap reader (host/gguf.cpp) must
+    answer with an error or a consistent parse, never read outside the mapping (run in a child process so that a crash is a failure,
+    not the end of the test session)."""
+    import subprocess
+    import sys
+    path = tiny_gguf[1] if isinstance(tiny_gguf, tuple) else tiny_gguf
+    data = open(path, "rb").read()
+    r = gguf.Reader(path)
+    meta_end = r.data_offset
+    rng = np.random.default_rng(12)
+    cases = []
+    for cut in sorted(set([0, 3, 4, 8, 16, 23, 24, 40] + rng.integers(24, meta_end, 60).tolist() + [meta_end - 1, meta_end, meta_end + 1, len(data) - 1])):
+        cases.append(data[:cut])
+    for _ in range(120):
+        b = bytearray(data[:meta_end + 4096])
+        for pos in rng.integers(0, meta_end, int(rng.integers(1, 6))):
+            b[int(pos)] = int(rng.integers(0, 256))
+        cases.append(bytes(b) + data[meta_end + 4096:])
+    paths = []
+    for i, c in enumerate(cases):
+        p = tmp_path / f"d{i}.gguf"
+        p.write_bytes(c)
+        paths.append(str(p))
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import tts_cpp_amd
+from tts_cpp_amd import runner
+L = runner.load_lib()
+ok = bad = 0
+for p in sys.argv[1:]:
+    nt, nkv, off = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    arch = C.create_string_buffer(64)
+    rc = L.tts_c_gguf_summary(p.encode(), C.byref(nt), C.byref(nkv), C.byref(off), arch, 64)
+    if rc == 0:
+        ok += 1
+        name = C.create_string_buffer(256); tt = C.c_int(); ne = (C.c_int64 * 4)(); cs = C.c_uint64()
+        for idx in range(min(int(nt.value), 4)):
+            L.tts_c_gguf_tensor(p.encode(), idx, name, 256, C.byref(tt), ne, C.byref(cs))
+    else:
+        bad += 1
+print(ok, bad)
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code] + paths, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ok, bad = map(int, out.stdout.split())
+    assert ok + bad == len(cases) and bad >= 40        # every truncation inside the metadata is refused
+
+
+def test_gguf_reader_refuses_hostile_lengths(tmp_path):
+    """length fields chosen to wrap pointer / size arithmetic: string length, array count, tensor dimensions, data offset"""
+    import struct
+    L = runner.load_lib()
+
+    def summary(b):
+        p = tmp_path / "x.gguf"
+        p.write_bytes(b)
+        nt, nkv, off = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        return L.tts_c_gguf_summary(str(p).encode(), C.byref(nt), C.byref(nkv), C.byref(off), C.create_string_buffer(64), 64), L.tts_c_last_error().decode()
+
+    hdr = b"GGUF" + struct.pack("<IQQ", 3, 1, 1)
+    big = 0xFFFFFFFFFFFFFFF0
+    kv = struct.pack("<Q", 1) + b"k" + struct.pack("<II", 4, 7)
+    tensor = lambda dims, off: struct.pack("<Q", 1) + b"t" + struct.pack("<I", len(dims)) + b"".join(struct.pack("<Q", d) for d in dims) + struct.pack("<IQ", 0, off)
+    assert summary(hdr + struct.pack("<Q", big) + b"abc") == (-1, "truncated or corrupt GGUF metadata")
+    assert summary(hdr + struct.pack("<Q", 1) + b"k" + struct.pack("<II", 9, 4) + struct.pack("<Q", big) + b"\0" * 64)[0] == -1
+    assert "impossible dimensions" in summary(hdr + kv + tensor([1 << 62, 1 << 62], 0) + b"\0" * 64)[1]
+    assert "impossible dimensions" in summary(hdr + kv + tensor([0, 4], 0) + b"\0" * 64)[1]
+    assert "past the end" in summary(hdr + kv + tensor([8], big) + b"\0" * 96)[1]
+    assert summary(hdr + kv + tensor([8], 0) + b"\0" * 96)[0] == 0           # the well-formed twin loads

@@ -31,14 +31,14 @@ struct cursor {
     bool            ok = true;
     template <typename T> T rd() {
         T v{};
-        if (p + sizeof(T) > end) { ok = false; return v; }
+        if ((size_t) (end - p) < sizeof(T)) { ok = false; return v; }
         memcpy(&v, p, sizeof(T));
         p += sizeof(T);
         return v;
     }
     std::string str() {
         const uint64_t n = rd<uint64_t>();
-        if (!ok || p + n > end) { ok = false; return {}; }
+        if (!ok || n > (uint64_t) (end - p)) { ok = false; return {}; }   // compared as sizes: a hostile length must not wrap the pointer
         std::string s((const char *) p, (size_t) n);
         p += n;
         return s;
@@ -121,7 +121,7 @@ std::shared_ptr<gguf_file> gguf_file::open(const char * path, std::string & err)
                 for (uint64_t j = 0; j < v.arr_n && c.ok; j++) v.arr_s.push_back(c.str());
             } else {
                 const size_t es = scalar_size(v.elem_type);
-                if (es == 0 || c.p + es * v.arr_n > c.end) { c.ok = false; break; }
+                if (es == 0 || v.arr_n > (uint64_t) (c.end - c.p) / es) { c.ok = false; break; }
                 v.arr_data = c.p;
                 c.p += es * v.arr_n;
             }
@@ -159,10 +159,19 @@ std::shared_ptr<gguf_file> gguf_file::open(const char * path, std::string & err)
         v.type = t.type;
         v.n_dims = t.n_dims;
         int64_t rows = 1;
-        for (int d = 0; d < 4; d++) { v.ne[d] = t.ne[d]; if (d > 0) rows *= t.ne[d]; }
-        v.nbytes = gguf_type_row_bytes(t.type, t.ne[0]) * (size_t) rows;
+        bool    dims_ok = true;
+        for (int d = 0; d < 4; d++) {
+            v.ne[d] = t.ne[d];
+            // no tensor of the file can hold more elements than the file has bits; products are checked, not trusted
+            if (t.ne[d] <= 0 || t.ne[d] > (int64_t) st.st_size * 8) dims_ok = false;
+            else if (d > 0 && __builtin_mul_overflow(rows, t.ne[d], &rows)) dims_ok = false;
+        }
+        size_t row_bytes = dims_ok ? gguf_type_row_bytes(t.type, t.ne[0]) : 0;
+        if (dims_ok && row_bytes && __builtin_mul_overflow(row_bytes, (size_t) rows, &v.nbytes)) dims_ok = false;
+        if (!dims_ok) { err = "tensor '" + t.name + "' has impossible dimensions"; return nullptr; }
+        v.nbytes = row_bytes * (size_t) rows;
         if (v.nbytes == 0) { err = "tensor '" + t.name + "' has unsupported type " + std::to_string(t.type); return nullptr; }
-        if (f->data_offset + t.off + v.nbytes > (size_t) st.st_size) { err = "tensor '" + t.name + "' runs past the end of the file"; return nullptr; }
+        if (f->data_offset > (size_t) st.st_size || t.off > (size_t) st.st_size - f->data_offset || v.nbytes > (size_t) st.st_size - f->data_offset - t.off) { err = "tensor '" + t.name + "' runs past the end of the file"; return nullptr; }
         v.data = base + f->data_offset + t.off;
         f->tensors.push_back(v);
     }
