@@ -242,7 +242,18 @@ void kokoro_runner::generate(const char * prompt, tts_response & output, const g
     last_prompt_tokens.clear();
     last_lengths.clear();
     // the reference phonemizes here (:1415-1417); this runner is handed the phonemes.  Its newline normalisation is kept.
-    for (const auto & tokens : kokoro_clause_chunks(hp, *tokenizer, prompt)) run(tokens);
+    for (const auto & tokens : kokoro_clause_chunks(hp, *tokenizer, prompt)) {
+        // the reference's split lets a chunk reach max_context_length + 2 ids (bos + max_context_length + eos, model.cpp:1359-1372),
+        // past what its own graphs are sized for; such a chunk is cut once more here so that every call fits the context
+        const size_t inner_max = hp.max_context_length - 2;
+        if (tokens.size() <= hp.max_context_length) { run(tokens); continue; }
+        for (size_t at = 1; at + 1 < tokens.size(); at += inner_max) {
+            std::vector<uint32_t> piece{hp.bos_token_id};
+            piece.insert(piece.end(), tokens.begin() + (long) at, tokens.begin() + (long) std::min(at + inner_max, tokens.size() - 1));
+            piece.push_back(hp.eos_token_id);
+            run(piece);
+        }
+    }
     if (pcm.empty()) return;
     output.data = pcm.data();
     output.n_outputs = pcm.size();
