@@ -17,6 +17,11 @@
 extern bool g_tts_throw_on_abort;
 static thread_local std::string g_c_err;
 
+// memcpy with a zero count still requires valid pointers (an empty vector's data() may be null)
+static void copy_u32(uint32_t * dst, const uint32_t * src, size_t n) {
+    if (dst && src && n) memcpy(dst, src, n * 4);
+}
+
 static generation_configuration to_cfg(const tts_c_config * c) {
     if (!c) return generation_configuration{};
     generation_configuration g{c->voice ? c->voice : "", c->top_k, c->temperature, c->repetition_penalty, c->use_cross_attn != 0,
@@ -103,7 +108,7 @@ int tts_c_last_tokens(tts_c_runner * r, int which, uint32_t * out, int cap) {
     if (!vp) { g_c_err = "runner keeps no token record"; return -1; }
     const std::vector<uint32_t> & v = *vp;
     const int n = (int) v.size();
-    if (out) memcpy(out, v.data(), (size_t) (n < cap ? n : cap) * 4);
+    copy_u32(out, v.data(), (size_t) (n < cap ? n : cap));
     return n;
 }
 
@@ -123,7 +128,7 @@ int tts_c_tokenize(const char * gguf_path, const char * text, uint32_t * out, in
             ids.push_back(t->eos_token);  // batch_from_sentence appends EOS (model.cpp:478)
         }
         const int n = (int) ids.size();
-        if (out) memcpy(out, ids.data(), (size_t) (n < cap ? n : cap) * 4);
+        copy_u32(out, ids.data(), (size_t) (n < cap ? n : cap));
         return n;
     } catch (const std::exception & e) {
         g_c_err = e.what();
@@ -144,7 +149,7 @@ int tts_c_sampler_sample(const tts_c_sampler_cfg * c, const int32_t * last_ids, 
     std::vector<uint32_t> o;
     if (uniforms) s.sample_with_uniforms(logits, uniforms, o);
     else s.sample(logits, o);
-    memcpy(out, o.data(), o.size() * 4);
+    copy_u32(out, o.data(), o.size());
     return (int) o.size();
 }
 
@@ -186,7 +191,7 @@ extern "C" int tts_c_dia_tokenize(const char * sentence, uint32_t max_ctx, uint3
         hp.max_encoder_context_length = max_ctx;
         std::vector<uint32_t> t;
         const uint32_t n = dia_tokenize_sentence(hp, sentence, t);
-        memcpy(out, t.data(), (size_t) max_ctx * 4);
+        copy_u32(out, t.data(), (size_t) max_ctx);
         return (int) n;
     } catch (const std::exception & e) {
         g_c_err = e.what();
@@ -200,7 +205,7 @@ extern "C" int tts_c_dia_check_stopping(uint32_t * ids, uint32_t eos, uint32_t p
     hp.eos_token_id = eos; hp.pad_token_id = pad; hp.max_delay = max_delay;
     std::vector<uint32_t> v(ids, ids + hp.delay_pattern.size());
     const bool stop = dia_check_stopping(hp, v, current_position, max_generation_size, *delay_steps);
-    memcpy(ids, v.data(), v.size() * 4);
+    copy_u32(ids, v.data(), v.size());
     return stop ? 1 : 0;
 }
 
@@ -209,7 +214,7 @@ extern "C" int64_t tts_c_dia_adjust_output_tokens(const uint32_t * tokens, uint6
     hp.audio_vocab_size = audio_vocab; hp.max_delay = max_delay;
     std::vector<uint32_t> in(tokens, tokens + n_ids), out;
     dia_adjust_output_tokens(hp, in, out);
-    memcpy(filtered, out.data(), out.size() * 4);
+    copy_u32(filtered, out.data(), out.size());
     return (int64_t) out.size();
 }
 
@@ -220,7 +225,7 @@ extern "C" int tts_c_single_pass_tokenize(const char * const * vocab, int n_voca
     single_pass_tokenizer t(std::vector<std::string>(vocab, vocab + n_vocab));
     std::vector<uint32_t> ids;
     t.tokenize(text, ids);
-    if (out) memcpy(out, ids.data(), (size_t) std::min<int>((int) ids.size(), cap) * 4);
+    copy_u32(out, ids.data(), (size_t) std::min<int>((int) ids.size(), cap));
     return (int) ids.size();
 }
 
@@ -234,7 +239,7 @@ extern "C" int tts_c_kokoro_chunks(const char * const * vocab, int n_vocab, cons
         flat.push_back((uint32_t) ch.size());
         flat.insert(flat.end(), ch.begin(), ch.end());
     }
-    if (out) memcpy(out, flat.data(), (size_t) std::min<int>((int) flat.size(), cap) * 4);
+    copy_u32(out, flat.data(), (size_t) std::min<int>((int) flat.size(), cap));
     return (int) flat.size();
 }
 
