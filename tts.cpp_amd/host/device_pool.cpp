@@ -4,7 +4,8 @@
 #include <cstdlib>
 #include <stdexcept>
 
-extern bool g_tts_throw_on_abort;
+#include <atomic>
+extern std::atomic<bool> g_tts_throw_on_abort;
 
 bool pool_configs_compatible(const generation_configuration & a, const generation_configuration & b) {
     return a.use_cross_attn == b.use_cross_attn && a.temperature == b.temperature && a.repetition_penalty == b.repetition_penalty &&

@@ -106,7 +106,7 @@ class device_pool {
     std::mutex                              q_mutex_;
     std::condition_variable                 q_cv_;
     std::deque<std::shared_ptr<pool_task>>  queue_;
-    bool                                    running_ = true;
+    std::atomic<bool>                       running_{true};   // read under either mutex (wait() holds r_mutex_, the queue side q_mutex_)
 
     mutable std::mutex                          r_mutex_;
     std::condition_variable                     r_cv_;

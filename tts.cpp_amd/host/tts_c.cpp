@@ -14,7 +14,8 @@
 #include "sampler.h"
 #include "tokenizer.h"
 
-extern bool g_tts_throw_on_abort;
+#include <atomic>
+extern std::atomic<bool> g_tts_throw_on_abort;
 static thread_local std::string g_c_err;
 
 // memcpy with a zero count still requires valid pointers (an empty vector's data() may be null)

@@ -1,5 +1,6 @@
 // util.cpp — the architecture table (src/models/loaders.cpp / include/common.h:19-43) and TTS_ABORT (src/util.cpp:14-22): print file:line + message and abort(); the C wrappers flip
 // g_tts_throw_on_abort so that a language binding gets an error string instead of losing the process.
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -12,7 +13,7 @@ const std::map<std::string, tts_arch> SUPPORTED_ARCHITECTURES = {
 const std::map<tts_arch, std::string> ARCHITECTURE_NAMES = {
     {PARLER_TTS_ARCH, "parler-tts"}, {KOKORO_ARCH, "kokoro"}, {DIA_ARCH, "dia"}, {ORPHEUS_ARCH, "orpheus"}};
 
-bool g_tts_throw_on_abort = false;  // set by the C wrapper so that language bindings get an error instead of abort()
+std::atomic<bool> g_tts_throw_on_abort{false};  // set by the C wrapper so that language bindings get an error instead of abort()
 
 void tts_abort(const char * file, int line, const char * fmt, ...) {
     char    msg[2048];
