@@ -50,23 +50,12 @@ def test_kokoro_durations_and_audio_match_oracle():
     eng.close()
 
 
-def _minstd0_uniform(n, state=1):
-    """std::default_random_engine (minstd_rand0) through std::uniform_real_distribution<float>(0, 1) as libstdc++ evaluates it:
-    one engine call per draw, (x - 1) / 2147483646 in float, a result of 1.0 replaced by the float below it"""
-    out = np.empty(n, dtype=np.float32)
-    x = state
-    for i in range(n):
-        x = (x * 16807) % 2147483647
-        v = np.float32(x - 1) / np.float32(2147483646.0)
-        out[i] = v if v < 1.0 else np.nextafter(np.float32(1.0), np.float32(0.0))
-    return out, x
-
-
 @pytest.mark.skipif(os.environ.get("TTS_TEST_EXPERIMENTAL") != "1", reason="runner path written after the round's GPU minutes were spent (TTS_TEST_EXPERIMENTAL=1)")
 def test_kokoro_runner_from_file(tmp_path):
     """runner_from_file on a Kokoro GGUF: phoneme string -> clause chunks -> durations -> source noise -> audio (kokoro/model.cpp:1277-1446).
     The reference phonemizes first; the runner is handed the phonemes (host/kokoro_runner.h)."""
     import tokenizer_oracle
+    from rng_oracle import minstd0_uniform
     from tts_cpp_amd import gguf, runner
     model = synth.build_kokoro(synth.kokoro_tiny())
     cfg = model.cfg
@@ -84,7 +73,7 @@ def test_kokoro_runner_from_file(tmp_path):
     state, want = 1, []
     for ch in chunks:
         lens, hid = o.durations(ch, "af_test")
-        noise, state = _minstd0_uniform(o.noise_len(int(lens.sum())), state)
+        noise, state = minstd0_uniform(o.noise_len(int(lens.sum())), state)
         want.append(eng.generate(ch, lens, hid, "af_test", noise))     # same device kernels, same noise stream: bit-equal audio
     want = np.concatenate(want)
     assert pcm.shape == want.shape and np.array_equal(pcm, want)

@@ -431,3 +431,20 @@ def test_gguf_reader_refuses_hostile_lengths(tmp_path):
     assert "impossible dimensions" in summary(hdr + kv + tensor([0, 4], 0) + b"\0" * 64)[1]
     assert "past the end" in summary(hdr + kv + tensor([8], big) + b"\0" * 96)[1]
     assert summary(hdr + kv + tensor([8], 0) + b"\0" * 96)[0] == 0           # the well-formed twin loads
+
+
+def test_noise_stream_restatement_matches_the_local_standard_library(tmp_path):
+    """The Kokoro runner draws its source noise like the reference (std::default_random_engine + uniform_real_distribution<float>,
+    util.cpp:65-71); oracle/rng_oracle.py restates that stream for the runner parity test.  Checked against a program built here."""
+    import subprocess
+    from rng_oracle import minstd0_uniform
+    src = tmp_path / "rng.cpp"
+    src.write_text('#include <cstdio>\n#include <random>\nint main() { std::default_random_engine e; std::uniform_real_distribution<float> d(0.0f, 1.0f);\n'
+                   '  for (int i = 0; i < 3000; i++) std::printf("%.9g\\n", d(e)); }\n')
+    exe = tmp_path / "rng"
+    assert subprocess.run(["g++", "-O2", str(src), "-o", str(exe)], capture_output=True, text=True, timeout=120).returncode == 0
+    want = np.array([float(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, timeout=60).stdout.split()], dtype=np.float32)
+    got, state = minstd0_uniform(3000)
+    assert np.array_equal(got, want)
+    more, _ = minstd0_uniform(10, state)                         # the state carries over between clauses
+    assert np.array_equal(np.concatenate([got, more])[-10:], more) and 0.0 <= got.min() and got.max() < 1.0
