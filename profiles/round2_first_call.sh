@@ -18,3 +18,7 @@ run dia_default 40 python profiles/dia_bench.py
 TTS_HIP_GEMV_ROWS=1 run dia_gemv 40 python profiles/dia_bench.py
 # 4. Kokoro-82M, first measurement (parity-only kernels)
 run kokoro 90 python profiles/kokoro_bench.py
+# 5. headline workload: larger lock-step batches per context (never measured: 1 x 256, 2 x 256 with the fp16 cache, 2 x 192)
+run parler_1x256 150 python bench.py --batch 256 --streams 1 --no-cpu-baseline
+run parler_2x256_kvf16 200 python bench.py --batch 256 --streams 2 --kv f16 --no-cpu-baseline
+run parler_2x192 200 python bench.py --batch 192 --streams 2 --no-cpu-baseline
