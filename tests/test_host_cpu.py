@@ -448,3 +448,28 @@ def test_noise_stream_restatement_matches_the_local_standard_library(tmp_path):
     assert np.array_equal(got, want)
     more, _ = minstd0_uniform(10, state)                         # the state carries over between clauses
     assert np.array_equal(np.concatenate([got, more])[-10:], more) and 0.0 <= got.min() and got.max() < 1.0
+
+
+@pytest.mark.parametrize("kind", ["dia", "kokoro", "orpheus"])
+def test_cpp_gguf_reader_on_the_other_architectures(tmp_path, kind):
+    """the C++ reader sees every tensor (name, type, shape, bytes) and key of the Dia / Kokoro / Orpheus files the generators mint"""
+    model = {"dia": lambda: synth.build_dia(synth.dia_tiny()), "kokoro": lambda: synth.build_kokoro(synth.kokoro_tiny()),
+             "orpheus": lambda: synth.SynthOrpheusFull(max_gen=28)}[kind]()
+    p = model.write_gguf(str(tmp_path / f"{kind}.gguf"))
+    L = runner.load_lib()
+    nt, nkv, off = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    arch = C.create_string_buffer(64)
+    assert L.tts_c_gguf_summary(p.encode(), C.byref(nt), C.byref(nkv), C.byref(off), arch, 64) == 0
+    assert arch.value.decode() == kind and nt.value == len(model.tensors) and nkv.value == len(model.kv)
+    r = gguf.Reader(p)
+    assert off.value == r.data_offset
+    name = C.create_string_buffer(256)
+    ttype, ne, cs = C.c_int(), (C.c_int64 * 4)(), C.c_uint64()
+    for idx in sorted(set(np.linspace(0, len(model.tensors) - 1, 25).astype(int).tolist())):
+        assert L.tts_c_gguf_tensor(p.encode(), idx, name, 256, C.byref(ttype), ne, C.byref(cs)) == 0
+        t = model.tensors[idx]
+        assert name.value.decode() == t.name and ttype.value == t.type and list(ne)[:len(t.ne)] == t.ne
+        h = 1469598103934665603
+        for b in bytes(t.raw()):
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        assert cs.value == h, t.name
