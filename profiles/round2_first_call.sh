@@ -7,7 +7,7 @@ mkdir -p gpurun_out/r2
 cd "$(dirname "$0")/.."
 run() { name=$1; shift; t=$1; shift; ( timeout "$t" "$@" > "gpurun_out/r2/$name.log" 2>&1; echo "rc=$?" >> "gpurun_out/r2/$name.log" ); tail -3 "gpurun_out/r2/$name.log"; }
 # 1. the paths behind knobs / gates: parity first
-TTS_TEST_EXPERIMENTAL=1 run gated_tests 90 python -m pytest tests/test_gpu_orpheus.py tests/test_gpu_kokoro.py tests/test_gpu_gemv_rows.py -q -k "captured or runner_from_file or 4_bit"
+TTS_TEST_EXPERIMENTAL=1 run gated_tests 90 python -m pytest tests/test_gpu_orpheus.py tests/test_gpu_kokoro.py tests/test_gpu_gemv_rows.py -q -k "captured or runner_from_file or 4_bit or noise_block"
 # 2. Orpheus-3B Q4_0 step: default, streaming GEMV rows, + captured step
 run orpheus_default 60 python profiles/orpheus_bench.py
 TTS_HIP_GEMV_ROWS=1 run orpheus_gemv 60 python profiles/orpheus_bench.py

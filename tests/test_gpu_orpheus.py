@@ -143,3 +143,33 @@ def test_orpheus_greedy_through_the_captured_step():
     assert eng.generate_greedy(g["prompt"], 40, stop_id=model.cfg.vocab + 5).tolist()[:6] == g["tokens"].tolist()   # several chunks of 8 replays
     assert eng.generate_greedy(g["prompt"], 6, stop_id=int(g["tokens"][2])).tolist() == g["tokens"][:3].tolist()
     eng.close()
+
+
+@pytest.mark.skipif(os.environ.get("TTS_TEST_EXPERIMENTAL") != "1", reason="written after the round's GPU minutes were spent (TTS_TEST_EXPERIMENTAL=1)")
+def test_orpheus_runner_with_the_noise_block(tmp_path):
+    """The SNAC noise block draws from a never-reseeded std::default_random_engine through std::normal_distribution<float>
+    (util.cpp:73-79); oracle/rng_oracle.py restates that stream, so the first generate of a fresh runner is comparable with the
+    noise active (the other runner test switches it off)."""
+    import tokenizer_oracle
+    from rng_oracle import minstd0_normal
+    from tts_cpp_amd import runner
+    full = synth.SynthOrpheusFull(max_gen=28)
+    path = full.write_gguf(str(tmp_path / "orpheus.gguf"))
+    r = runner.Runner(path, sample=0)
+    pcm = r.generate("hello the zebra", voice=b"zoe", sample=0)
+    toks = r.last_tokens(1).tolist()
+    heads = [0, 1, 2, 2, 1, 2, 2]
+    levels = [[], [], []]
+    for i in range(len(toks) // 7):
+        for ii in range(7):
+            levels[heads[ii]].append(toks[i * 7 + ii] - full.audio_offset)
+    T = len(levels[2])
+    so = orc.SnacOracle(full.snac)
+    noise, state, saved = minstd0_normal(so.noise_len(T))
+    ref = so.decode(np.array(levels[0] + levels[1] + levels[2], dtype=np.uint32), T, noise)
+    assert pcm.shape == ref.shape and np.abs(pcm - ref).max() < 1e-4
+    # the second generate continues the stream where the first stopped
+    pcm2 = r.generate("hello the zebra", voice=b"zoe", sample=0)
+    noise2, _, _ = minstd0_normal(so.noise_len(T), state, saved)
+    assert np.abs(pcm2 - so.decode(np.array(levels[0] + levels[1] + levels[2], dtype=np.uint32), T, noise2)).max() < 1e-4
+    r.close()

@@ -448,6 +448,15 @@ def test_noise_stream_restatement_matches_the_local_standard_library(tmp_path):
     assert np.array_equal(got, want)
     more, _ = minstd0_uniform(10, state)                         # the state carries over between clauses
     assert np.array_equal(np.concatenate([got, more])[-10:], more) and 0.0 <= got.min() and got.max() < 1.0
+    # the SNAC noise block's stream (random_normal_gen, util.cpp:73-79)
+    from rng_oracle import minstd0_normal
+    src.write_text('#include <cstdio>\n#include <random>\nint main() { std::default_random_engine e; std::normal_distribution<float> d(0.0f, 1.0f);\n'
+                   '  for (int i = 0; i < 2001; i++) std::printf("%.9g\\n", d(e)); }\n')
+    assert subprocess.run(["g++", "-O2", str(src), "-o", str(exe)], capture_output=True, text=True, timeout=120).returncode == 0
+    want = np.array([float(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, timeout=60).stdout.split()], dtype=np.float32)
+    a, st, sv = minstd0_normal(1001)                             # an odd count leaves the pair's second value saved
+    b, _, _ = minstd0_normal(1000, st, sv)
+    assert np.array_equal(np.concatenate([a, b]), want)
 
 
 @pytest.mark.parametrize("kind", ["dia", "kokoro", "orpheus"])
