@@ -533,3 +533,76 @@ def test_parler_mini_full_size_step():
         ids[0] = ref[:, 0, :].argmax(-1)
         ids[1] = lg[1].argmax(-1)
     eng.close()
+
+
+SAMPLE_ROWS = {128: (0, 15, 16, 63, 64, 127), 384: (0, 31, 32, 127, 128, 255, 256, 383)}
+
+
+@pytest.mark.parametrize("rows", [128, 384])
+def test_parler_mini_full_size_many_rows(rows):
+    """The measured configuration (bench.py: H=1024, 24 layers, fp16 weights, 128..384 lock-step rows): the LDS-tiled GEMM
+    path (gemm_tile_kernels.h: every tile shape the cost model picks at these sizes, split-K slabs folded by the next
+    LayerNorm, KV append from the tile epilogue), 4 steps, a sample of rows at the tile / wave / row-group boundaries against
+    per-row oracles.  Each row feeds its own arg-max back, like the device loop does."""
+    model = get_model("mini", gguf.F16)
+    cfg = model.cfg
+    eng = hip.HipEngine(cfg, max_seqs=rows, kv_positions=32)
+    eng.load(model)
+    rng = np.random.default_rng(rows)
+    prompts = [rng.integers(3, cfg.prompt_vocab, 3 + (i % 4)).astype(np.uint32) for i in range(rows)]
+    eng.prefill_batch(prompts)
+    sample = SAMPLE_ROWS[rows]
+    oracles = {}
+    for r in sample:
+        o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+        o.decode(prompts[r], 0, audio=False, want_logits=False)
+        oracles[r] = o
+    ids = np.full((rows, cfg.n_out), cfg.bos, dtype=np.uint32)
+    worst = 0.0
+    for step in range(4):
+        lg = eng.step(ids, [len(p) + step for p in prompts])
+        for r in sample:
+            ref, _ = oracles[r].decode(ids[r], len(prompts[r]) + step, audio=True)
+            e = relerr(lg[r], ref[:, 0, :])
+            worst = max(worst, e)
+            assert e < TOL[gguf.F16], (rows, r, step, e)
+            check_tokens(lg[r], ref[:, 0, :], TOL[gguf.F16])
+            ids[r] = ref[:, 0, :].argmax(-1)   # the oracle's token keeps both sides on one trajectory
+        for r in range(rows):
+            if r not in sample:
+                ids[r] = lg[r].argmax(-1)
+    print(f"rows={rows}: worst relative logit error over {len(sample)} rows x 4 steps = {worst:.2e}")
+    eng.close()
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("rows", [40, 100, 200])
+def test_tiled_gemm_every_tile_shape(rows, shape, monkeypatch):
+    """every tile shape of gemm_tile_kernel forced onto every GEMM of a Parler-Mini-width layer (H=1024, F=4096, fp16), ragged
+    row counts (rows % tile != 0), split-K 1/2/4/8 on the residual GEMMs."""
+    monkeypatch.setenv("TTS_HIP_TILE_FORCE", str(shape))
+    monkeypatch.setenv("TTS_HIP_TILE_KS", str((1, 2, 4, 8, 1, 2)[shape]))
+    key = ("wide1", gguf.F16)
+    if key not in _models:
+        _models[key] = synth.build(synth.tiny(hidden=1024, heads=16, ffn=4096, layers=1, weight_type=gguf.F16))
+    model = _models[key]
+    cfg = model.cfg
+    eng = hip.HipEngine(cfg, max_seqs=rows, kv_positions=16)
+    eng.load(model)
+    rng = np.random.default_rng(rows * 8 + shape)
+    prompts = [rng.integers(3, cfg.prompt_vocab, 2 + (i % 3)).astype(np.uint32) for i in range(rows)]
+    eng.prefill_batch(prompts)
+    ids = np.full((rows, cfg.n_out), cfg.bos, dtype=np.uint32)
+    sample = sorted({0, 15, 16, 31, 32, rows // 2, rows - 1})
+    oracles = {}
+    for r in sample:
+        o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+        o.decode(prompts[r], 0, audio=False, want_logits=False)
+        oracles[r] = o
+    for step in range(2):
+        lg = eng.step(ids, [len(p) + step for p in prompts])
+        for r in sample:
+            ref, _ = oracles[r].decode(ids[r], len(prompts[r]) + step, audio=True)
+            assert relerr(lg[r], ref[:, 0, :]) < TOL[gguf.F16], (rows, shape, r, step)
+        ids = lg.argmax(-1).astype(np.uint32)
+    eng.close()

@@ -128,9 +128,9 @@ struct GemmArgs {
     int rows_per_z;
 };
 
-__device__ __forceinline__ void gemm_epilogue4(const GemmArgs &a, int EPI, int r, int n, float4v v) {
+__device__ __forceinline__ void gemm_epilogue4(const GemmArgs &a, int EPI, int r, int n, float4v v, int slab) {
     if (EPI == EPI_STORE) {
-        *(float4v *) (a.out + (int64_t) blockIdx.y * a.slab_stride + (int64_t) r * a.ldo + n) = v;
+        *(float4v *) (a.out + (int64_t) slab * a.slab_stride + (int64_t) r * a.ldo + n) = v;
     } else if (EPI == EPI_RESID) {
         float4v *p = (float4v *) (a.out + (int64_t) r * a.ldo + n);
         float4v o = *p;
@@ -331,13 +331,13 @@ __global__ __launch_bounds__(PRO == PRO_LN ? 512 : 1024) void gemm16_kernel(Gemm
                     t[e] = sum;
                 }
                 const int r = rg + rb * 16 + li;
-                if (r < r_hi) gemm_epilogue4(a, EPI, r, n0 + g * 4, t);
+                if (r < r_hi) gemm_epilogue4(a, EPI, r, n0 + g * 4, t, blockIdx.y);
             }
         } else {
 #pragma unroll
             for (int rb = 0; rb < RB; rb++) {
                 const int r = rg + rb * 16 + li;
-                if (r < r_hi) gemm_epilogue4(a, EPI, r, n0 + g * 4, acc[rb]);
+                if (r < r_hi) gemm_epilogue4(a, EPI, r, n0 + g * 4, acc[rb], blockIdx.y);
             }
         }
     }
@@ -475,6 +475,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(float *x, int H, const flo
             if (np == 0) ln_row_regs<4, 0>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
             else if (np == 4) ln_row_regs<4, 4>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
             else if (np == 2) ln_row_regs<4, 2>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
+            else if (np == 8) ln_row_regs<4, 8>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
             else ln_row_regs<4, -1>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
         } else {
             if (np == 0) ln_row_regs<8, 0>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
@@ -1075,13 +1076,13 @@ __global__ __launch_bounds__(QPRO == 2 ? 512 : 1024) void qgemm16_kernel(QGemmAr
                     t[e] = sum;
                 }
                 const int r = rg + rb * 16 + li;
-                if (r < a.R) gemm_epilogue4(a, EPI, r, n0 + g * 4, t);
+                if (r < a.R) gemm_epilogue4(a, EPI, r, n0 + g * 4, t, blockIdx.y);
             }
         } else {
 #pragma unroll
             for (int rb = 0; rb < RB; rb++) {
                 const int r = rg + rb * 16 + li;
-                if (r < a.R) gemm_epilogue4(a, EPI, r, n0 + g * 4, acc[rb]);
+                if (r < a.R) gemm_epilogue4(a, EPI, r, n0 + g * 4, acc[rb], blockIdx.y);
             }
         }
     }

@@ -22,6 +22,7 @@
 
 #include "dac_kernels.h"
 #include "parler_kernels.h"
+#include "gemm_tile_kernels.h"
 #include "t5_kernels.h"
 #include "llama_kernels.h"
 #include "dia_kernels.h"
@@ -298,6 +299,9 @@ struct tts_hip_ctx {
     int dac_lds_reserve_kb = 0; // LDS the codec kernels leave free per CU for another context's decoder workgroups
     int gemm_rows_per_wg = 0;   // > 0: forwards with more rows split them over workgroups of this many rows (16/32/64)
     int gemm_ngs_max = 16;      // cap on parallel row-group wave sets per GEMM workgroup (LDS = 4 KB x waves x RB)
+    int tile_min_rows = 33;     // forwards with at least this many rows take the LDS-tiled GEMM (gemm_tile_kernels.h); 0 = never
+    int tile_force = -1;        // TTS_HIP_TILE_FORCE: tile shape index for every tiled GEMM (tuning)
+    int tile_force_ks = 0;      // TTS_HIP_TILE_KS: k slices for the residual GEMMs (tuning)
     bool dac_f16 = false;      // every codec conv kernel arrived as F16: fp16 im2col x fp16 kernel, fp32 accumulate (ggml)
     bool dac_packed = false;
 
@@ -358,6 +362,9 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
+    if (const char *e = getenv("TTS_HIP_TILE_MIN_ROWS")) c->tile_min_rows = std::max(0, atoi(e));
+    if (const char *e = getenv("TTS_HIP_TILE_FORCE")) c->tile_force = atoi(e);
+    if (const char *e = getenv("TTS_HIP_TILE_KS")) c->tile_force_ks = atoi(e);
     if (const char *e = getenv("TTS_HIP_Q_FUSE_MAX")) c->q_fuse_max = std::max(0, std::min(16, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMV_ROWS")) c->gemv_rows = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_LLAMA_GRAPH")) c->llama_graph = atoi(e) != 0;
@@ -1048,7 +1055,14 @@ static int launch_gemm16_rb(tts_hip_ctx *c, const GemmArgs &a_in) {
     return launch_gemm16<WT, PRO, EPI, 4>(c, a);  // loops over groups of 64 rows, weights stay in registers
 }
 
-static int max_rows_for(const tts_hip_ctx *) { return 256; }
+// rows one forward can carry: 256 through the 16-feature workgroups, 512 when every decoder matrix is fp16 (LDS-tiled GEMM)
+static int max_rows_for(const tts_hip_ctx *c) {
+    if (c->tile_min_rows <= 0) return 256;
+    for (const PLayer &y : c->layers)
+        for (const W *w : {&y.qkv, &y.o, &y.cq, &y.co, &y.fc1, &y.fc2})
+            if (w->type != TTS_HIP_F16 && w->N) return 256;
+    return c->heads.type == TTS_HIP_F16 ? 512 : 256;
+}
 
 template <int EPI, int RB, int QPRO>
 static int launch_qgemm16(tts_hip_ctx *c, const QGemmArgs &qa) {
@@ -1071,6 +1085,77 @@ static int launch_qgemm16_rb(tts_hip_ctx *c, const QGemmArgs &qa, bool fused_qua
     if (qa.g.R <= 16) return launch_qgemm16<EPI, 1, 0>(c, qa);
     if (qa.g.R <= 32) return launch_qgemm16<EPI, 2, 0>(c, qa);
     return launch_qgemm16<EPI, 4, 0>(c, qa);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled GEMM for many rows (gemm_tile_kernels.h): shape choice + launch
+// ------------------------------------------------------------------------------------------------
+struct TileShape { int BM, BN, threads; };
+static const TileShape TILE_SHAPES[] = {{32, 32, 128}, {32, 64, 256}, {64, 32, 256}, {64, 64, 512}, {128, 64, 512}, {128, 128, 512}};
+enum { N_TILE_SHAPES = 6 };
+
+template <int BM, int BN, int WM, int WN, int EPI>
+static int launch_tile_shape(tts_hip_ctx *c, const GemmArgs &a, const TileMap &tm, bool deep) {
+    // deep: 128-wide k-tiles, 3 LDS buffers — fewer barriers for a single wave of workgroups; otherwise 64-wide k-tiles,
+    // 4 buffers (half the LDS: two workgroups per CU when the grid exceeds the CU count)
+    constexpr bool can_deep = (BM + BN) * 256 * 3 <= 160 * 1024;
+    const int total = tm.m_tiles * tm.n_tiles * tm.k_slices;
+    const int grid = (total + 7) / 8 * 8;
+    const int kc = a.kchunk ? a.kchunk : a.K;
+    if (can_deep && deep && kc % 128 == 0) {
+        const size_t lds = (size_t) 3 * (BM + BN) * 256;
+        static std::atomic<uint64_t> attr{0};
+        if (attr_needed(attr, c->device))
+            HIPCHK(hipFuncSetAttribute((const void *) gemm_tile_kernel<BM, BN, WM, WN, 128, 3, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN, 128, 3, EPI>), dim3(grid), dim3(WM * WN * 64), lds, c->stream, a, tm);
+    } else {
+        const size_t lds = (size_t) 4 * (BM + BN) * 128;
+        static std::atomic<uint64_t> attr{0};
+        if (attr_needed(attr, c->device))
+            HIPCHK(hipFuncSetAttribute((const void *) gemm_tile_kernel<BM, BN, WM, WN, 64, 4, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN, 64, 4, EPI>), dim3(grid), dim3(WM * WN * 64), lds, c->stream, a, tm);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <int EPI>
+static int launch_tile(tts_hip_ctx *c, const GemmArgs &a, int shape, int ks) {
+    const TileShape &t = TILE_SHAPES[shape];
+    TileMap tm{(a.R + t.BM - 1) / t.BM, (a.N + t.BN - 1) / t.BN, ks};
+    const bool deep = tm.m_tiles * tm.n_tiles * tm.k_slices <= 320;
+    switch (shape) {
+        case 0: return launch_tile_shape<32, 32, 1, 2, EPI>(c, a, tm, deep);
+        case 1: return launch_tile_shape<32, 64, 1, 4, EPI>(c, a, tm, deep);
+        case 2: return launch_tile_shape<64, 32, 2, 2, EPI>(c, a, tm, deep);
+        case 3: return launch_tile_shape<64, 64, 2, 4, EPI>(c, a, tm, deep);
+        case 4: return launch_tile_shape<128, 64, 4, 2, EPI>(c, a, tm, deep);
+        default: return launch_tile_shape<128, 128, 2, 4, EPI>(c, a, tm, deep);
+    }
+}
+
+// Cost model fitted to profiles/r02/gemm_tile_sweep.log: a launch costs ~ (fixed + bytes one workgroup stages) per wave of
+// workgroups (a CU pulls ~28 B/clk of mixed L2 / HBM traffic whatever the tile), so the best shape is the largest tile that
+// still gives about one workgroup per CU; residual GEMMs (N = hidden size) may split K to get there.
+static void choose_tile(const tts_hip_ctx *c, int R, int N, int K, bool may_split, int *shape_out, int *ks_out) {
+    double best = 1e30;
+    int bs = 0, bk = 1;
+    for (int s = 0; s < N_TILE_SHAPES; s++) {
+        const TileShape &t = TILE_SHAPES[s];
+        if (t.BM >= 2 * R && s > 0) continue;   // mostly padding rows
+        for (int ks = 1; ks <= (may_split ? 8 : 1); ks *= 2) {
+            if (K % (ks * 128) || K / ks < 256) continue;
+            const double blocks = (double) ((R + t.BM - 1) / t.BM) * ((N + t.BN - 1) / t.BN) * ks;
+            const double bytes = (double) (t.BM + t.BN) * (K / ks) * 2.0;
+            double cost = std::max(1.0, blocks / 256.0) * (96.0 * 1024 + bytes);
+            if (ks > 1) cost += 4096.0 * ks;   // slab write + fold traffic
+            if (cost < best) { best = cost; bs = s; bk = ks; }
+        }
+    }
+    if (c->tile_force >= 0 && c->tile_force < N_TILE_SHAPES) bs = c->tile_force;
+    if (c->tile_force_ks > 0 && may_split && K % (c->tile_force_ks * 128) == 0) bk = c->tile_force_ks;
+    *shape_out = bs;
+    *ks_out = bk;
 }
 
 // GGUF-quantised matrix: LayerNorm (if any) -> Q8_0-quantise the activation rows -> integer block GEMM
@@ -1185,6 +1270,27 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
         a.A = h16 ? (const void *) c->xn16 : (const void *) c->dbg;
         a.lda = a.K;
         pro = h16 ? PRO_F16 : PRO_F32;
+    }
+    if (w.type == TTS_HIP_F16 && pro == PRO_F16 && c->tile_min_rows > 0 && a.R >= c->tile_min_rows && a.K % 128 == 0 && a.N % 16 == 0) {
+        // many rows: LDS-tiled MFMA GEMM; a residual GEMM may split K into fp32 slabs that the next LayerNorm folds into x
+        const bool may_split = epi == EPI_RESID && a.H <= 2048 && a.N == a.H && a.out == c->x;
+        int shape = 0, ks = 1;
+        choose_tile(c, a.R, a.N, a.K, may_split, &shape, &ks);
+        if (ks > 1) {
+            a.kchunk = a.K / ks;
+            a.slab_stride = (int64_t) c->RMAX * c->H;
+            a.out = c->partials;
+            epi = EPI_STORE;
+            c->pending_parts = ks;
+        }
+        CHK(prof_begin(c, kclass, bytes, flops));
+        int rc;
+        if (epi == EPI_STORE) rc = launch_tile<EPI_STORE>(c, a, shape, ks);
+        else if (epi == EPI_QKV) rc = launch_tile<EPI_QKV>(c, a, shape, ks);
+        else if (epi == EPI_RESID) rc = launch_tile<EPI_RESID>(c, a, shape, ks);
+        else rc = launch_tile<EPI_GELU>(c, a, shape, ks);
+        CHK(rc);
+        return prof_end(c);
     }
     if (epi == EPI_RESID && a.R > c->ln_fuse_max && a.H <= 2048 && a.N == a.H && a.out == c->x) {
         // many rows: spread K over 4-8x more workgroups; the partial slabs are folded into x by the next LayerNorm
@@ -1395,7 +1501,6 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         const int H = c->H;
         c->RMAX = std::max(max_rows_for(c), 1);
         if ((int) c->d.max_seqs > c->RMAX) return set_err("max_seqs=%u exceeds the %d rows one forward can carry with these weight types", c->d.max_seqs, c->RMAX);
-        if ((int) c->d.max_seqs > 256) return set_err("max_seqs > 256 unsupported");
         const size_t kv_esz = c->d.kv_type == TTS_HIP_F16 ? 2 : 4;
         const size_t kvb = (size_t) c->L * c->d.max_seqs * c->KVPOS * H * kv_esz;
         HIPCHK(hipMalloc(&c->kcache, kvb));
