@@ -92,6 +92,9 @@ int  tts_c_pool_conditional_prompt(tts_c_pool *pool, const char *prompt);
 int  tts_c_pool_wait(tts_c_pool *pool, int id, int timeout_ms, const float **data, size_t *n_outputs, int *batch_size, int *worker);
 void tts_c_pool_release(tts_c_pool *pool, int id);
 void tts_c_pool_stats(tts_c_pool *pool, uint64_t *tasks, uint64_t *batches, uint64_t *largest_batch, uint64_t *timed_out);
+/* how the pool loaded its models: RCCL weight broadcasts performed (one per model when the workers span more than one device) and
+ * workers that use their device's existing weight arena instead of uploading the file again */
+void tts_c_pool_load_stats(tts_c_pool *pool, int *weight_broadcasts, int *shared_arena_loads);
 void tts_c_pool_free(tts_c_pool *pool);
 
 int tts_c_gguf_summary(const char *path, uint64_t *n_tensors, uint64_t *n_kv, uint64_t *data_offset, char *arch, int arch_cap);

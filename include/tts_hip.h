@@ -111,6 +111,20 @@ void  *tts_hip_arena_ptr(tts_hip_ctx *ctx);
 /* After the arena of a declare-only context was filled by a collective: mark weights present.
  * (cross K/V live inside the arena, so they arrive with the broadcast.) */
 int    tts_hip_arena_filled(tts_hip_ctx *ctx);
+
+/* The one collective of the path: RCCL broadcast of the finished weight arena (weights + precomputed cross
+ * K/V) from ctxs[root] to every other context, so that a host serving G devices parses and uploads the GGUF once — where the
+ * reference's server re-parses the file for every worker (examples/server/server.cpp:316-321).  All n contexts belong to this
+ * process, one per DISTINCT device, each finalized with its own arena of the same tts_hip_arena_bytes(); the non-root contexts
+ * were filled declare-only (tts_hip_upload with host_data == NULL) and are marked ready here (tts_hip_arena_filled).
+ * Single process: ncclCommInitAll over the contexts' devices, ncclGroupStart, one ncclBroadcast(uint8, arena bytes) per context on
+ * its own stream, ncclGroupEnd, stream syncs, communicators destroyed.  n == 1 is a no-op that only validates.  librccl.so is
+ * opened on first use (it is not a load-time dependency of this library). */
+int    tts_hip_broadcast_weights(tts_hip_ctx **ctxs, int n, int root);
+/* One-process-per-GPU form of the same broadcast: rank 0 obtains a 128-byte id (tts_hip_comm_unique_id) and hands it to the other
+ * ranks by whatever the launcher offers (bench.py: torch.distributed); every rank then calls tts_hip_broadcast_weights_rank. */
+int    tts_hip_comm_unique_id(void *id128);
+int    tts_hip_broadcast_weights_rank(tts_hip_ctx *ctx, const void *id128, int rank, int world, int root);
 /* update_conditional_prompt (model.cpp:510-518): replace the voice-prompt encoding
  * [n_tokens][hidden] (fp32, host) and recompute the cross K/V. n_tokens <= n_encode_length cap given at create. */
 int    tts_hip_parler_set_text_encoding(tts_hip_ctx *ctx, const float *enc, uint32_t n_tokens);

@@ -50,7 +50,6 @@ def test_kokoro_durations_and_audio_match_oracle():
     eng.close()
 
 
-@pytest.mark.skipif(os.environ.get("TTS_TEST_EXPERIMENTAL") != "1", reason="runner path written after the round's GPU minutes were spent (TTS_TEST_EXPERIMENTAL=1)")
 def test_kokoro_runner_from_file(tmp_path):
     """runner_from_file on a Kokoro GGUF: phoneme string -> clause chunks -> durations -> source noise -> audio (kokoro/model.cpp:1277-1446).
     The reference phonemizes first; the runner is handed the phonemes (host/kokoro_runner.h)."""
@@ -72,9 +71,10 @@ def test_kokoro_runner_from_file(tmp_path):
     eng = hip.KokoroEngine(model)
     state, want = 1, []
     for ch in chunks:
-        lens, hid = o.durations(ch, "af_test")
+        lens, hid = eng.durations(ch, "af_test")                           # the runner's own two device calls, same noise stream: bit-equal audio
+        assert np.array_equal(lens, o.durations(ch, "af_test")[0])
         noise, state = minstd0_uniform(o.noise_len(int(lens.sum())), state)
-        want.append(eng.generate(ch, lens, hid, "af_test", noise))     # same device kernels, same noise stream: bit-equal audio
+        want.append(eng.generate(ch, lens, hid, "af_test", noise))
     want = np.concatenate(want)
     assert pcm.shape == want.shape and np.array_equal(pcm, want)
     with pytest.raises(runner.RunnerError):

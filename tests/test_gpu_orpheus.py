@@ -128,7 +128,6 @@ def test_orpheus_runner_generates_through_both_contexts(tmp_path):
     r.close()
 
 
-@pytest.mark.skipif(os.environ.get("TTS_TEST_EXPERIMENTAL") != "1", reason="captured-step path written after the round's GPU minutes were spent (TTS_TEST_EXPERIMENTAL=1)")
 def test_orpheus_greedy_through_the_captured_step():
     """TTS_HIP_LLAMA_GRAPH=1: the greedy step (forward + arg-max + feedback) as one hipGraph replayed per position — same ids as the eager loop"""
     model = synth.build_orpheus(synth.orpheus_tiny())
@@ -145,7 +144,6 @@ def test_orpheus_greedy_through_the_captured_step():
     eng.close()
 
 
-@pytest.mark.skipif(os.environ.get("TTS_TEST_EXPERIMENTAL") != "1", reason="written after the round's GPU minutes were spent (TTS_TEST_EXPERIMENTAL=1)")
 def test_orpheus_runner_with_the_noise_block(tmp_path):
     """The SNAC noise block draws from a never-reseeded std::default_random_engine through std::normal_distribution<float>
     (util.cpp:73-79); oracle/rng_oracle.py restates that stream, so the first generate of a fresh runner is comparable with the

@@ -194,7 +194,9 @@ def test_batched_prefill_equals_sequential_prefill():
         ids = np.full((len(prompts), cfg.n_out), cfg.bos, dtype=np.uint32)
         outs.append(eng.step(ids, [len(p) for p in prompts]))
         eng.close()
-    assert relerr(outs[0], outs[1]) < 1e-5
+    # the batched prefill carries enough rows for the LDS-tiled GEMM (fc2: K = 128), the sequential one stays on the 16-feature
+    # workgroups: same products, different fp32 summation order
+    assert relerr(outs[0], outs[1]) < 1e-4
 
 
 def test_graph_replay_equals_eager_and_greedy_equals_argmax():

@@ -360,6 +360,44 @@ int main() {
     assert run.stdout.split() == ["220500", "44100", "dummy", "0"]
 
 
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "examples", "cli")), reason="needs the reference checkout (absent on the GPU box)")
+def test_reference_cli_and_perf_battery_build_unchanged_against_the_overlay(tmp_path):
+    """The reference's OWN examples/cli/cli.cpp (+ playback / vad / write_file / src/args.cpp) and examples/perf_battery/perf_battery.cpp,
+    compiled from where they lie with compat/'s three headers in place of include/common.h, src/models/loaders.h and ggml.h
+    (compat/make_overlay.py), link against libtts.so and run on the weightless backend (BASELINE configs[0])."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "compat"))
+    from make_overlay import make_overlay
+    ovl = make_overlay(REFERENCE, str(tmp_path / "ovl"))
+    # the application sources are links into the checkout, not copies
+    assert os.path.realpath(os.path.join(ovl, "examples/cli/cli.cpp")) == os.path.join(REFERENCE, "examples/cli/cli.cpp")
+    host = os.path.join(ROOT, "tts.cpp_amd", "host")
+    link = ["-L", host, "-ltts", "-L", os.path.join(ROOT, "tts.cpp_amd"), "-ltts_hip", f"-Wl,-rpath,{host}",
+            f"-Wl,-rpath,{os.path.join(ROOT, 'tts.cpp_amd')}", "-Wl,-rpath,/opt/rocm/lib"]
+    builds = {
+        "tts-cli": ["examples/cli/cli.cpp", "examples/cli/playback.cpp", "examples/cli/vad.cpp", "examples/cli/write_file.cpp", "src/args.cpp"],
+        "perf_battery": ["examples/perf_battery/perf_battery.cpp", "src/args.cpp"],
+    }
+    for exe, srcs in builds.items():
+        cc = subprocess.run(["g++", "-std=c++20", "-O1", "-I", "include", *srcs, "-o", exe, *link], cwd=ovl, capture_output=True, text=True, timeout=600)
+        assert cc.returncode == 0, cc.stderr[-4000:]
+    wav = tmp_path / "out.wav"
+    run = subprocess.run(["./tts-cli", "--model-path", "test:dummy", "--prompt", "Hello", "--save-path", str(wav)], cwd=ovl, capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "total time" in run.stdout                       # cli.cpp:10-20 through compat/include/ggml.h
+    assert wav.stat().st_size == 44 + 2 * 5 * 44100          # "Hello" -> 5 s of 16-bit mono at 44.1 kHz (test runner: 1 s per character)
+    run = subprocess.run(["./perf_battery", "--model-path", "test:dummy"], cwd=ovl, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "Mean Stats for arch dummy" in run.stdout and "Generation Real Time Factor" in run.stdout
+    # no ggml anywhere in what was linked
+    ldd = subprocess.run(["ldd", os.path.join(ovl, "tts-cli")], capture_output=True, text=True).stdout
+    assert "libtts.so" in ldd and "ggml" not in ldd
+
+
 def test_gguf_reader_survives_damaged_files(tiny_gguf, tmp_path):
     """Truncations at every structural boundary region and random byte flips in the metadata: the mmap reader (host/gguf.cpp) must
     answer with an error or a consistent parse, never read outside the mapping (run in a child process so that a crash is a failure,

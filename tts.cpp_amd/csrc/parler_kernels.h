@@ -600,6 +600,37 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
     }
 }
 
+// Cross-attention over a short voice prompt (T_fixed <= 32 encoder positions; Parler-Mini: 8..40): the general kernel
+// spends its time in workgroup merges and idle key groups there (18 us per layer at 384 rows).  One wave per (row, head):
+// lane = channel of the 64-wide head, every K / V row is one coalesced 256-B load, the score of a key is a wave reduction,
+// softmax runs redundantly in every lane (no LDS, no barrier).  Same mathematics as soft_max_ext + mul_mat (model.cpp:586-593).
+__global__ __launch_bounds__(256) void attn_short_kernel(AttnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), r = blockIdx.y;
+    if (h >= a.n_heads) return;
+    const int T = a.T_fixed;
+    const int64_t hb = h * 64 + lane;
+    const float qv = a.q[(int64_t) r * a.H + hb];
+    float kv[32], sc[32];
+#pragma unroll
+    for (int t = 0; t < 32; t++)
+        if (t < T) kv[t] = a.kv_f16 ? (float) ((const _Float16 *) a.kc)[hb + (int64_t) t * a.H] : ((const float *) a.kc)[hb + (int64_t) t * a.H];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 32; t++)
+        if (t < T) { sc[t] = wave_sum(qv * kv[t]) * a.scale; m = fmaxf(m, sc[t]); }
+#pragma unroll
+    for (int t = 0; t < 32; t++)
+        if (t < T) kv[t] = a.kv_f16 ? (float) ((const _Float16 *) a.vc)[hb + (int64_t) t * a.H] : ((const float *) a.vc)[hb + (int64_t) t * a.H];
+    float l = 0.0f, o = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 32; t++)
+        if (t < T) { const float p = expf(sc[t] - m); l += p; o += p * kv[t]; }
+    const float res = o / l;
+    if (a.out16) a.out16[(int64_t) r * a.H + hb] = (_Float16) res;
+    else a.out[(int64_t) r * a.H + hb] = res;
+}
+
 __global__ void attn_combine_kernel(const float *part, int nz, int H, int n_heads, float *out, _Float16 *out16) {
     const int h = blockIdx.x, r = blockIdx.y, c = threadIdx.x;  // 64 threads; nz <= 16
     const float *p = part + ((int64_t) r * n_heads + h) * nz * 66;
@@ -851,6 +882,8 @@ struct FeedArgs {
     uint32_t *tokens_out;     // [n_steps][R][n_out]
     int R, n_out;
     uint32_t bos, eos;
+    uint32_t max_pos;         // a row whose next position would reach this has finished (check_stopping's current_position >= max_generation_size,
+                              // model.cpp:720-722, with max_generation = the cached positions of a lock-step context); it idles on its last position
 };
 
 // one 64-thread workgroup per row
@@ -871,9 +904,10 @@ __global__ void feed_kernel(FeedArgs a) {
     }
     __syncthreads();
     if (hd == 0) {
-        a.row_pos[r] += 1;
+        const uint32_t np = a.row_pos[r] + 1;
+        if (np < a.max_pos) a.row_pos[r] = np;
         a.row_step[r] = step + 1;
-        if (!not_seen && a.steps_done[r] == 0) a.steps_done[r] = step;
+        if ((!not_seen || np >= a.max_pos) && a.steps_done[r] == 0) a.steps_done[r] = step;
     }
 }
 

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -201,10 +202,10 @@ struct tts_hip_ctx {
     float *ad = nullptr;        // their block scales
     bool all_q8i = false;       // every decoder matrix is on the integer path (all GEMMs go through run_qgemm)
     int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
-    bool q4_native = false;     // TTS_HIP_Q4_NATIVE=1 (with TTS_HIP_GEMV_ROWS): Q4_0 matrices of the Orpheus decoder are read as 4-bit codes
+    bool q4_native = false;     // TTS_HIP_Q4_NATIVE (with TTS_HIP_GEMV_ROWS; default on for Orpheus contexts): Q4_0 matrices are read as 4-bit codes
     std::vector<void *> q4_bufs;
-    bool llama_graph = false;   // TTS_HIP_LLAMA_GRAPH=1: the Orpheus greedy step as one captured graph (written, not yet run on a GPU)
-    bool gemv_rows = false;     // TTS_HIP_GEMV_ROWS=1: 1..4 rows go through the streaming one-wave-per-feature kernels (gemv_kernels.h)
+    bool llama_graph = false;   // TTS_HIP_LLAMA_GRAPH (default on for Orpheus contexts): the greedy step as one captured graph
+    bool gemv_rows = false;     // TTS_HIP_GEMV_ROWS (default on for Orpheus contexts): 1..4 rows go through the streaming one-wave-per-feature kernels (gemv_kernels.h)
     // ---- Orpheus decoder context (tts_hip_orpheus_create) ----
     bool has_llama = false;
     tts_hip_orpheus_desc lm{};
@@ -299,6 +300,7 @@ struct tts_hip_ctx {
     int dac_lds_reserve_kb = 0; // LDS the codec kernels leave free per CU for another context's decoder workgroups
     int gemm_rows_per_wg = 0;   // > 0: forwards with more rows split them over workgroups of this many rows (16/32/64)
     int gemm_ngs_max = 16;      // cap on parallel row-group wave sets per GEMM workgroup (LDS = 4 KB x waves x RB)
+    bool attn_short = true;     // TTS_HIP_ATTN_SHORT=0: cross-attention through the general kernel
     int tile_min_rows = 33;     // forwards with at least this many rows take the LDS-tiled GEMM (gemm_tile_kernels.h); 0 = never
     int tile_force = -1;        // TTS_HIP_TILE_FORCE: tile shape index for every tiled GEMM (tuning)
     int tile_force_ks = 0;      // TTS_HIP_TILE_KS: k slices for the residual GEMMs (tuning)
@@ -362,6 +364,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
+    if (const char *e = getenv("TTS_HIP_ATTN_SHORT")) c->attn_short = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_TILE_MIN_ROWS")) c->tile_min_rows = std::max(0, atoi(e));
     if (const char *e = getenv("TTS_HIP_TILE_FORCE")) c->tile_force = atoi(e);
     if (const char *e = getenv("TTS_HIP_TILE_KS")) c->tile_force_ks = atoi(e);
@@ -515,6 +518,8 @@ extern "C" int tts_hip_upload(tts_hip_ctx *c, const char *name_c, int type, int 
     t.has_data = host != nullptr;
     if (host) {
         HIPCHK(hipMalloc(&t.tmp, t.nbytes));
+        // every failure below releases the staging allocation (a server that retries loads must not accumulate device memory)
+        struct TmpGuard { void *&p; bool armed = true; ~TmpGuard() { if (armed) { free_dev(p); p = nullptr; } } } guard{t.tmp};
         if (q8i) {
             std::vector<int8_t> q((size_t) n);
             std::vector<uint16_t> d((size_t) (n / 32));
@@ -528,6 +533,7 @@ extern "C" int tts_hip_upload(tts_hip_ctx *c, const char *name_c, int type, int 
             if (dequant_to_f32(type, host, f.data(), n) != 0) return set_err("tts_hip_upload(%s): dequantisation failed", name_c);
             HIPCHK(hipMemcpy(t.tmp, f.data(), t.nbytes, hipMemcpyHostToDevice));
         }
+        guard.armed = false;
     }
     auto it = c->tensors.find(name);
     if (it != c->tensors.end()) free_dev(it->second.tmp);
@@ -1148,7 +1154,7 @@ static void choose_tile(const tts_hip_ctx *c, int R, int N, int K, bool may_spli
             const double blocks = (double) ((R + t.BM - 1) / t.BM) * ((N + t.BN - 1) / t.BN) * ks;
             const double bytes = (double) (t.BM + t.BN) * (K / ks) * 2.0;
             double cost = std::max(1.0, blocks / 256.0) * (96.0 * 1024 + bytes);
-            if (ks > 1) cost += 4096.0 * ks;   // slab write + fold traffic
+            if (ks > 1) cost += 0.18 * ks * (double) R * N;   // slab write by this launch + read by the folding LayerNorm (~1 us per 1.5 MB slab)
             if (cost < best) { best = cost; bs = s; bk = ks; }
         }
     }
@@ -1332,6 +1338,12 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
         HIPCHK(hipFuncSetAttribute((const void *) attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     CHK(prof_begin(c, kclass, kv_bytes + 2.0 * R * c->H * 4, 0));
+    if (!a.row_pos && a.T_fixed <= 32 && nsplit == 1 && c->attn_short) {
+        // cross-attention over a short voice prompt: one wave per (row, head), no merges
+        hipLaunchKernelGGL(attn_short_kernel, dim3((c->NH + 3) / 4, R), dim3(256), 0, c->stream, a);
+        HIPCHK(hipGetLastError());
+        return prof_end(c);
+    }
     hipLaunchKernelGGL(attn_kernel, dim3(c->NH, R, nsplit), dim3(threads), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     if (nsplit > 1) {
@@ -1653,6 +1665,133 @@ extern "C" int tts_hip_arena_filled(tts_hip_ctx *c) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// RCCL weight broadcast (the path's only collective).  librccl is opened lazily: 570 MB that a single-GPU user never maps.
+// ------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi *rccl() {
+    static RcclApi api;
+    static std::atomic<int> state{0};   // 0 untried, 1 ready, -1 failed
+    static std::mutex m;
+    if (state.load() == 1) return &api;
+    std::lock_guard<std::mutex> lock(m);
+    if (state.load() == 1) return &api;
+    if (state.load() == -1) return nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.h) break;
+    }
+    if (!api.h) { state = -1; return nullptr; }
+#define RCCL_SYM(field, sym) api.field = (decltype(api.field)) dlsym(api.h, sym); if (!api.field) { state = -1; return nullptr; }
+    RCCL_SYM(GetUniqueId, "ncclGetUniqueId") RCCL_SYM(CommInitRank, "ncclCommInitRank") RCCL_SYM(CommInitAll, "ncclCommInitAll")
+    RCCL_SYM(CommDestroy, "ncclCommDestroy") RCCL_SYM(Broadcast, "ncclBroadcast") RCCL_SYM(GroupStart, "ncclGroupStart")
+    RCCL_SYM(GroupEnd, "ncclGroupEnd") RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+    state = 1;
+    return &api;
+}
+#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return set_err("%s failed: %s", #x, api->GetErrorString(r_)); } while (0)
+
+int check_broadcast_ctx(tts_hip_ctx *c, int i, size_t bytes) {
+    if (!c) return set_err("tts_hip_broadcast_weights: context %d is NULL", i);
+    if (!c->finalized || !c->arena) return set_err("tts_hip_broadcast_weights: context %d is not finalized", i);
+    if (c->arena_bytes != bytes) return set_err("tts_hip_broadcast_weights: context %d has an arena of %zu bytes, the root %zu (different models?)", i, c->arena_bytes, bytes);
+    return 0;
+}
+}  // namespace
+
+extern "C" int tts_hip_broadcast_weights(tts_hip_ctx **ctxs, int n, int root) {
+    if (!ctxs || n < 1) return set_err("tts_hip_broadcast_weights: no contexts");
+    if (root < 0 || root >= n) return set_err("tts_hip_broadcast_weights: root %d outside 0..%d", root, n - 1);
+    if (!ctxs[root]) return set_err("tts_hip_broadcast_weights: root context is NULL");
+    const size_t bytes = ctxs[root]->arena_bytes;
+    for (int i = 0; i < n; i++) CHK(check_broadcast_ctx(ctxs[i], i, bytes));
+    if (!ctxs[root]->weights_present) return set_err("tts_hip_broadcast_weights: the root context holds no weights (declare-only)");
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++)
+            if (ctxs[i]->device == ctxs[j]->device)
+                return set_err("tts_hip_broadcast_weights: contexts %d and %d share device %d (contexts of one device share the arena: tts_hip_finalize(ctx, tts_hip_arena_ptr(other)))", i, j, ctxs[i]->device);
+    if (n == 1) return 0;
+    RcclApi *api = rccl();
+    if (!api) return set_err("tts_hip_broadcast_weights: librccl.so could not be opened (%s)", dlerror() ? dlerror() : "symbols missing");
+    std::vector<int> devs((size_t) n);
+    for (int i = 0; i < n; i++) devs[(size_t) i] = ctxs[i]->device;
+    std::vector<ncclComm_t> comms((size_t) n, nullptr);
+    NCCLCHK(api->CommInitAll(comms.data(), n, devs.data()));
+    int rc = 0;
+    // <= 1 GiB pieces: one launch per piece and device, all devices of a piece inside one group
+    const size_t piece = (size_t) 1 << 30;
+    for (size_t off = 0; off < bytes && rc == 0; off += piece) {
+        const size_t cnt = std::min(piece, bytes - off);
+        ncclResult_t r = api->GroupStart();
+        for (int i = 0; i < n && r == ncclSuccess; i++) {
+            (void) hipSetDevice(ctxs[i]->device);
+            r = api->Broadcast(ctxs[root]->arena + off, ctxs[i]->arena + off, cnt, ncclUint8, root, comms[(size_t) i], ctxs[i]->stream);
+        }
+        const ncclResult_t e = api->GroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) rc = set_err("ncclBroadcast failed: %s", api->GetErrorString(r));
+    }
+    for (int i = 0; i < n; i++) {
+        (void) hipSetDevice(ctxs[i]->device);
+        if (hipStreamSynchronize(ctxs[i]->stream) != hipSuccess && rc == 0) rc = set_err("tts_hip_broadcast_weights: stream sync failed on device %d", ctxs[i]->device);
+    }
+    for (ncclComm_t cm : comms) if (cm) (void) api->CommDestroy(cm);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) if (i != root) ctxs[i]->weights_present = true;
+    return 0;
+}
+
+extern "C" int tts_hip_comm_unique_id(void *id128) {
+    if (!id128) return set_err("tts_hip_comm_unique_id: null buffer");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    RcclApi *api = rccl();
+    if (!api) return set_err("tts_hip_comm_unique_id: librccl.so could not be opened");
+    ncclUniqueId id;
+    NCCLCHK(api->GetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return 0;
+}
+
+extern "C" int tts_hip_broadcast_weights_rank(tts_hip_ctx *c, const void *id128, int rank, int world, int root) {
+    if (!c || !id128) return set_err("tts_hip_broadcast_weights_rank: null argument");
+    if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world) return set_err("tts_hip_broadcast_weights_rank: rank %d / root %d outside world %d", rank, root, world);
+    if (!c->finalized || !c->arena) return set_err("tts_hip_broadcast_weights_rank: context is not finalized");
+    if (rank == root && !c->weights_present) return set_err("tts_hip_broadcast_weights_rank: the root rank holds no weights");
+    if (world == 1) return 0;
+    RcclApi *api = rccl();
+    if (!api) return set_err("tts_hip_broadcast_weights_rank: librccl.so could not be opened");
+    HIPCHK(hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t comm = nullptr;
+    NCCLCHK(api->CommInitRank(&comm, world, id, rank));
+    int rc = 0;
+    const size_t piece = (size_t) 1 << 30;
+    for (size_t off = 0; off < c->arena_bytes && rc == 0; off += piece) {
+        const ncclResult_t r = api->Broadcast(c->arena + off, c->arena + off, std::min(piece, c->arena_bytes - off), ncclUint8, root, comm, c->stream);
+        if (r != ncclSuccess) rc = set_err("ncclBroadcast failed: %s", api->GetErrorString(r));
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == 0) rc = set_err("tts_hip_broadcast_weights_rank: stream sync failed");
+    (void) api->CommDestroy(comm);
+    if (rc) return rc;
+    if (rank != root) c->weights_present = true;
+    return 0;
+}
+
 extern "C" int tts_hip_parler_set_text_encoding(tts_hip_ctx *c, const float *enc, uint32_t n_tokens) {
     if (!c || !c->finalized || !c->has_parler) return set_err("set_text_encoding: context not ready");
     if (!c->d.use_cross_attn) return set_err("set_text_encoding: cross attention disabled");
@@ -1790,6 +1929,7 @@ static int enqueue_step_body(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint
             FeedArgs f{};
             f.tokens = c->d_tok; f.ids = c->d_ids; f.row_pos = c->d_pos; f.row_step = c->d_step; f.eos_seen = c->d_eos;
             f.steps_done = c->d_steps_done; f.tokens_out = c->d_tokens_out; f.R = R; f.n_out = c->NO; f.bos = bos; f.eos = eos;
+            f.max_pos = (uint32_t) std::min(c->KVPOS, c->NPOS);
             hipLaunchKernelGGL(feed_kernel, dim3(R), dim3(64), 0, c->stream, f);
             HIPCHK(hipGetLastError());
         }
@@ -1856,8 +1996,10 @@ static int generate_loop(tts_hip_ctx *c, int mode, uint32_t n, const uint32_t *s
     if (bos >= (uint32_t) c->EROWS || eos >= (uint32_t) c->EROWS) return set_err("generate_greedy: bos/eos outside the embedding table");
     c->host_pos.resize(n);
     for (uint32_t r = 0; r < n; r++) {
-        if (start_pos[r] + n_steps > (uint32_t) c->KVPOS || start_pos[r] + n_steps > (uint32_t) c->NPOS)
-            return set_err("generate_greedy: sequence %u would exceed the cached positions (%u + %u > %d)", r, start_pos[r], n_steps, c->KVPOS);
+        // a row may be asked for more steps than its cache holds: it finishes when its position reaches the end of the cache
+        // (steps_done says after how many steps) and idles there while the other rows go on
+        if (start_pos[r] >= (uint32_t) c->KVPOS || start_pos[r] >= (uint32_t) c->NPOS)
+            return set_err("generate_greedy: sequence %u starts outside the cached positions (%u >= %d)", r, start_pos[r], c->KVPOS);
         for (int i = 0; i < c->NO; i++) c->h_ids[r * c->NO + i] = bos;  // model.cpp:781 with current_step == 0
         c->h_pos[r] = start_pos[r];
         c->h_seq[r] = r;
@@ -2499,6 +2641,12 @@ extern "C" tts_hip_ctx *tts_hip_orpheus_create(int device, const tts_hip_orpheus
     if (!c) return nullptr;
     c->has_llama = true;
     c->lm = *ld;
+    // measured on MI355X at the orpheus-3b Q4_0 shapes (profiles/r02/first_call_orpheus_*.log): 3.84 ms/step through the
+    // lock-step workgroups, 2.98 with the streaming 1-4 row kernels, 2.84 reading the Q4_0 codes themselves, 2.80 with the
+    // step captured in one hipGraph -> all three are the default here; TTS_HIP_GEMV_ROWS / _Q4_NATIVE / _LLAMA_GRAPH=0 turn them off
+    if (!getenv("TTS_HIP_GEMV_ROWS")) c->gemv_rows = true;
+    if (!getenv("TTS_HIP_Q4_NATIVE")) c->q4_native = true;
+    if (!getenv("TTS_HIP_LLAMA_GRAPH")) c->llama_graph = true;
     if (c->lm.rope_base == 0.0f) c->lm.rope_base = 500000.0f;
     return c;
 }

@@ -85,7 +85,7 @@ EXPORTS = [
     "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits",
     "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_kokoro_create", "tts_hip_kokoro_durations", "tts_hip_kokoro_generate", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
-    "tts_hip_synchronize",
+    "tts_hip_synchronize", "tts_hip_broadcast_weights", "tts_hip_comm_unique_id", "tts_hip_broadcast_weights_rank",
 ]
 
 class Sampling(C.Structure):
@@ -123,6 +123,9 @@ def load_lib():
     L.tts_hip_arena_ptr.argtypes = [vp]
     L.tts_hip_arena_ptr.restype = vp
     L.tts_hip_arena_filled.argtypes = [vp]
+    L.tts_hip_broadcast_weights.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
+    L.tts_hip_comm_unique_id.argtypes = [vp]
+    L.tts_hip_broadcast_weights_rank.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
     L.tts_hip_parler_set_text_encoding.argtypes = [vp, f32p, C.c_uint32]
     L.tts_hip_parler_reset.argtypes = [vp]
     L.tts_hip_parler_prefill.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_uint32]
@@ -243,6 +246,14 @@ class HipEngine:
 
     def arena_filled(self):
         self._chk(self.L.tts_hip_arena_filled(self.ctx))
+
+    @staticmethod
+    def broadcast_weights(engines, root=0):
+        """tts_hip_broadcast_weights: RCCL broadcast of engines[root]'s arena to the other engines (one per distinct device, one process)"""
+        L = load_lib()
+        arr = (C.c_void_p * len(engines))(*[e.ctx for e in engines])
+        if L.tts_hip_broadcast_weights(arr, len(engines), root) != 0:
+            raise HipError(L.tts_hip_last_error().decode())
 
     def set_text_encoding(self, enc):
         enc = np.ascontiguousarray(enc, dtype=np.float32)

@@ -99,6 +99,9 @@ struct tts_generation_runner : tts_runner {
     virtual void     generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs,
                                     const generation_configuration & config);
     virtual uint32_t batch_capacity() const { return UINT32_MAX; }
+    // the device context (tts_hip_ctx*) that holds this runner's weight arena, or nullptr when the runner cannot hand its weights to
+    // another runner (tts_load_options::share_with / tts_hip_broadcast_weights)
+    virtual void *   device_context() const { return nullptr; }
 
   protected:
     std::vector<std::vector<float>> batch_store_;  // audio of the default generate_batch
@@ -122,6 +125,23 @@ struct tts_model_loader {
 // (TTS_ABORT, util.cpp:14-22).  "test:<arch>" loads a weightless test backend (loaders.cpp:37-44).
 std::unique_ptr<tts_generation_runner> runner_from_file(const char * fname, int n_threads,
                                                         const generation_configuration & config, bool cpu_only = true);
+
+// ---- extension: where and how the NEXT runner_from_file on the calling thread places its model.  The reference has one runner per
+// process-wide backend; a host that serves several devices (device_pool) needs per-load placement, and the process environment is
+// not a channel for it (setenv races with every getenv in the process).  Unset fields fall back to TTS_HIP_DEVICE /
+// TTS_HIP_MAX_SEQS as read at load time, then to device 0 / one sequence.
+struct tts_load_options {
+    int  device       = -1;
+    int  max_seqs     = 0;
+    // declare_only: the tensors' shapes are declared to the device and the arena is laid out, but no bytes are uploaded: the weights
+    // arrive by tts_hip_broadcast_weights (RCCL) from the runner that parsed the file.
+    bool declare_only = false;
+    // share_with: a loaded runner of the same model on the same device; this runner uses its weight arena (own KV cache, own stream).
+    const tts_generation_runner * share_with = nullptr;
+};
+tts_load_options & tts_thread_load_options();   // thread_local; runner_from_file reads it, the caller resets it afterwards
+int      tts_load_device();                     // resolved values for the loaders
+uint32_t tts_load_max_seqs();
 
 [[noreturn]] void tts_abort(const char * file, int line, const char * fmt, ...);
 #define TTS_ABORT(...) tts_abort(__FILE__, __LINE__, __VA_ARGS__)

@@ -1,5 +1,7 @@
 #include "device_pool.h"
 
+#include "../../include/tts_hip.h"
+
 #include <algorithm>
 #include <cstdlib>
 #include <stdexcept>
@@ -24,12 +26,67 @@ device_pool::device_pool(const std::map<std::string, std::string> & model_paths,
     if (opts_.max_batch < 1) opts_.max_batch = 1;
     if (opts_.devices.empty()) opts_.devices.push_back(0);
     per_worker_.resize((size_t) opts_.n_workers);
+    for (int w = 0; w < opts_.n_workers; w++) states_.push_back(std::make_unique<worker_state>());
+    load_all();
+    if (!error_.empty()) { running_ = false; return; }
     for (int w = 0; w < opts_.n_workers; w++) threads_.emplace_back(&device_pool::worker_main, this, w);
-    std::unique_lock<std::mutex> lock(load_mutex_);
-    load_cv_.wait(lock, [&] { return loaded_ == opts_.n_workers; });
-    if (!error_.empty()) {
-        lock.unlock();
-        terminate();
+}
+
+// init_worker (server.cpp:309-321) for every worker, with the file parsed and uploaded ONCE per model where the runner can hand its
+// weights on (device_context() != nullptr): the first worker of the first device loads, the first worker of every other device is
+// laid out declare-only and receives the finished arena by RCCL (tts_hip_broadcast_weights, the path's one collective), further
+// workers of a device share their device's arena.  Other runners (and the weightless test backend) load per worker as the reference.
+// Placement goes through tts_thread_load_options(), not the environment.
+void device_pool::load_all() {
+    g_tts_throw_on_abort = true;  // a failed load must not abort() the whole server
+    const int nw = opts_.n_workers, nd = (int) opts_.devices.size();
+    auto device_of = [&](int w) { return opts_.devices[(size_t) w % (size_t) nd]; };
+    auto load = [&](int w, const std::string & path, bool declare, const tts_generation_runner * share) {
+        tts_load_options & lo = tts_thread_load_options();
+        lo = tts_load_options{};
+        lo.device = device_of(w);
+        lo.max_seqs = opts_.max_batch;
+        lo.declare_only = declare;
+        lo.share_with = share;
+        std::unique_ptr<tts_generation_runner> r;
+        try {
+            r = runner_from_file(path.c_str(), opts_.n_threads, load_config_, false);
+        } catch (...) {
+            lo = tts_load_options{};
+            throw;
+        }
+        lo = tts_load_options{};
+        return r;
+    };
+    try {
+        for (const auto & [id, path] : model_paths_) {
+            // owners: the first worker on each distinct device
+            std::map<int, int> owner;   // device -> worker
+            for (int w = 0; w < nw; w++) owner.emplace(device_of(w), w);
+            const int root_w = 0;   // worker 0 is the first worker of its device
+            states_[(size_t) root_w]->runners[id] = load(root_w, path, false, nullptr);
+            tts_generation_runner * root = states_[(size_t) root_w]->runners[id].get();
+            const bool can_share = opts_.share_weights && root->device_context() != nullptr;
+            std::vector<void *> ctxs{root->device_context()};
+            for (const auto & [dev, w] : owner) {
+                if (w == root_w) continue;
+                states_[(size_t) w]->runners[id] = load(w, path, can_share, nullptr);
+                if (can_share) ctxs.push_back(states_[(size_t) w]->runners[id]->device_context());
+            }
+            if (can_share && ctxs.size() > 1) {
+                if (tts_hip_broadcast_weights((tts_hip_ctx **) ctxs.data(), (int) ctxs.size(), 0) != 0)
+                    throw std::runtime_error(std::string("tts_hip_broadcast_weights: ") + tts_hip_last_error());
+                broadcasts_++;
+            }
+            for (int w = 0; w < nw; w++) {
+                if (states_[(size_t) w]->runners.count(id)) continue;
+                const tts_generation_runner * own = states_[(size_t) owner.at(device_of(w))]->runners[id].get();
+                states_[(size_t) w]->runners[id] = load(w, path, false, can_share ? own : nullptr);
+                if (can_share) shared_loads_++;
+            }
+        }
+    } catch (const std::exception & e) {
+        error_ = std::string("load: ") + e.what();
     }
 }
 
@@ -153,23 +210,8 @@ std::vector<std::shared_ptr<pool_task>> device_pool::next_batch(int w, int cap) 
 }
 
 void device_pool::worker_main(int w) {
-    worker_state ws;
-    g_tts_throw_on_abort = true;  // a failed load must not abort() the whole server
-    {
-        // init_worker (:309-314).  The runner reads its device and KV-slot count from the environment at load time;
-        // loads are serialised so every worker sees its own values.
-        std::lock_guard<std::mutex> lock(load_mutex_);
-        const int dev = opts_.devices[(size_t) w % opts_.devices.size()];
-        setenv("TTS_HIP_DEVICE", std::to_string(dev).c_str(), 1);
-        setenv("TTS_HIP_MAX_SEQS", std::to_string(opts_.max_batch).c_str(), 1);
-        try {
-            for (const auto & [id, path] : model_paths_) ws.runners[id] = runner_from_file(path.c_str(), opts_.n_threads, load_config_, false);
-        } catch (const std::exception & e) {
-            if (error_.empty()) error_ = std::string("worker ") + std::to_string(w) + ": " + e.what();
-        }
-        loaded_++;
-    }
-    load_cv_.notify_all();
+    worker_state & ws = *states_[(size_t) w];
+    g_tts_throw_on_abort = true;
     while (true) {
         std::vector<std::shared_ptr<pool_task>> batch = next_batch(w, opts_.max_batch);
         if (batch.empty()) break;

@@ -53,6 +53,7 @@ struct pool_options {
     int              n_threads = 1;
     int              task_timeout_s = 300; // :231, tasks older than this are answered with success == false
     std::string      text_encoder_path;    // T5 GGUF for CONDITIONAL_PROMPT tasks (server --text-encoder-path, :263-271)
+    bool             share_weights = true; // parse + upload each model once: RCCL broadcast across devices, one arena per device
 };
 
 struct pool_stats {
@@ -87,9 +88,12 @@ class device_pool {
     void       release(int id);  // drop a finished task from the response map (the reference's cleanup thread, :168-189)
     void       terminate();      // :316-330
     pool_stats stats() const;
+    int        weight_broadcasts() const { return broadcasts_; }   // RCCL broadcasts performed at load (one per model with > 1 device)
+    int        shared_arena_loads() const { return shared_loads_; } // workers that reuse their device's arena instead of uploading
 
   private:
     struct worker_state;
+    void load_all();
     void worker_main(int w);
     void process(int w, std::vector<std::shared_ptr<pool_task>> & batch, worker_state & ws);
     std::vector<std::shared_ptr<pool_task>> next_batch(int w, int cap);
@@ -112,9 +116,8 @@ class device_pool {
     std::condition_variable                     r_cv_;
     std::map<int, std::shared_ptr<pool_task>>   completed_;
 
-    std::mutex              load_mutex_;
-    std::condition_variable load_cv_;
-    int                     loaded_ = 0;
+    std::vector<std::unique_ptr<worker_state>> states_;   // loaded by the constructor, then owned by worker w's thread
+    int                     broadcasts_ = 0, shared_loads_ = 0;
 
     std::atomic<int>         next_id_{1};
     mutable std::mutex       s_mutex_;

@@ -61,8 +61,7 @@ static dia_hparams read_hparams(const gguf_file & m) {
 
 std::unique_ptr<tts_generation_runner> dia_model_loader::from_file(gguf_file * meta, int, bool, const generation_configuration &) const {
     const dia_hparams hp = read_hparams(*meta);
-    int device = 0;
-    if (const char * d = getenv("TTS_HIP_DEVICE")) device = atoi(d);
+    const int device = tts_load_device();
     return std::make_unique<dia_runner>(hp, device);
 }
 
@@ -84,7 +83,12 @@ dia_runner::dia_runner(const dia_hparams & hp_, int device) : tts_generation_run
     a.max_seqs = 1;
     a.flags = TTS_HIP_FLAG_NO_PARLER;
     dac = tts_hip_create(device, &a);
-    if (!dac) TTS_ABORT("tts_hip_create (codec) failed: %s\n", tts_hip_last_error());
+    if (!dac) {
+        // the destructor does not run for a constructor that throws (TTS_ABORT under g_tts_throw_on_abort): release the model context
+        tts_hip_destroy(lm);
+        lm = nullptr;
+        TTS_ABORT("tts_hip_create (codec) failed: %s\n", tts_hip_last_error());
+    }
     sampling_rate = 44100.0f;
     smp.n_output_heads = hp.n_output_heads;
     smp.vocab_size = hp.output_vocab_size;   // model.h:191

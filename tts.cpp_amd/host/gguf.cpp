@@ -75,7 +75,18 @@ bool read_scalar(cursor & c, gguf_vtype t, gguf_value & v) {
 }
 }  // namespace
 
+static std::shared_ptr<gguf_file> gguf_open_impl(const char * path, std::string & err);
+
 std::shared_ptr<gguf_file> gguf_file::open(const char * path, std::string & err) {
+    try {
+        return gguf_open_impl(path, err);
+    } catch (const std::exception & e) {   // bad_alloc / length_error from a hostile count that passed the size checks
+        err = std::string("GGUF parse failed: ") + e.what();
+        return nullptr;
+    }
+}
+
+static std::shared_ptr<gguf_file> gguf_open_impl(const char * path, std::string & err) {
     auto f = std::make_shared<gguf_file>();
     f->path = path;
     const int fd = ::open(path, O_RDONLY);
@@ -117,6 +128,8 @@ std::shared_ptr<gguf_file> gguf_file::open(const char * path, std::string & err)
             v.elem_type = (gguf_vtype) c.rd<uint32_t>();
             v.arr_n = c.rd<uint64_t>();
             if (v.elem_type == GGUF_STR) {
+                // a string is at least its 8-byte length: a count the rest of the file cannot hold is corrupt (and must not reach reserve)
+                if (v.arr_n > (uint64_t) (c.end - c.p) / 8) { c.ok = false; break; }
                 v.arr_s.reserve((size_t) v.arr_n);
                 for (uint64_t j = 0; j < v.arr_n && c.ok; j++) v.arr_s.push_back(c.str());
             } else {
@@ -134,6 +147,8 @@ std::shared_ptr<gguf_file> gguf_file::open(const char * path, std::string & err)
     if (!c.ok) { err = "truncated or corrupt GGUF metadata"; return nullptr; }
     struct info { std::string name; int n_dims; int64_t ne[4]; int type; uint64_t off; };
     std::vector<info> infos;
+    // a tensor record is at least 8 (name length) + 4 (n_dims) + 8 (one dimension) + 4 (type) + 8 (offset) bytes
+    if (n_tensors > (uint64_t) (c.end - c.p) / 32) { err = "truncated or corrupt GGUF tensor table"; return nullptr; }
     infos.reserve((size_t) n_tensors);
     for (uint64_t i = 0; i < n_tensors && c.ok; i++) {
         info t{};
@@ -165,6 +180,11 @@ std::shared_ptr<gguf_file> gguf_file::open(const char * path, std::string & err)
             // no tensor of the file can hold more elements than the file has bits; products are checked, not trusted
             if (t.ne[d] <= 0 || t.ne[d] > (int64_t) st.st_size * 8) dims_ok = false;
             else if (d > 0 && __builtin_mul_overflow(rows, t.ne[d], &rows)) dims_ok = false;
+        }
+        // block formats hold 32 consecutive elements of ne[0] per block (Q4_0 / Q5_0 / Q8_0): a ragged row has no encoding
+        if (dims_ok && (t.type == 2 || t.type == 6 || t.type == 8) && t.ne[0] % 32 != 0) {
+            err = "tensor '" + t.name + "' has a quantised type with ne[0] = " + std::to_string(t.ne[0]) + " not a multiple of 32";
+            return nullptr;
         }
         size_t row_bytes = dims_ok ? gguf_type_row_bytes(t.type, t.ne[0]) : 0;
         if (dims_ok && row_bytes && __builtin_mul_overflow(row_bytes, (size_t) rows, &v.nbytes)) dims_ok = false;

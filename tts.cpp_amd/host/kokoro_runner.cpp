@@ -153,8 +153,7 @@ std::unique_ptr<tts_generation_runner> kokoro_model_loader::from_file(gguf_file 
     const kokoro_hparams hp = read_hparams(*meta);
     const gguf_value *   toks = meta->get("tokenizer.ggml.tokens");
     if (!toks) TTS_ABORT("The '%s' key must be set in order to support single pass tokenization.", "tokenizer.ggml.tokens");
-    int device = 0;
-    if (const char * d = getenv("TTS_HIP_DEVICE")) device = atoi(d);
+    const int device = tts_load_device();
     return std::make_unique<kokoro_runner>(hp, new single_pass_tokenizer(toks->arr_s), device, config.voice);
 }
 
@@ -241,8 +240,23 @@ void kokoro_runner::generate(const char * prompt, tts_response & output, const g
     pcm.clear();
     last_prompt_tokens.clear();
     last_lengths.clear();
-    // the reference phonemizes here (:1415-1417); this runner is handed the phonemes.  Its newline normalisation is kept.
-    for (const auto & tokens : kokoro_clause_chunks(hp, *tokenizer, prompt)) {
+    // the reference phonemizes here (:1415-1417: phonemizer.cpp rule tables or espeak); this runner is handed the phonemes.  A caller
+    // written for the reference passes plain text, which would be read as if it were IPA: say so loudly instead of quietly
+    // synthesising nonsense — once per runner as a notice (TTS_KOKORO_INPUT_IS_PHONEMES=1 acknowledges it), and on every call that
+    // contains characters outside the phoneme vocabulary.
+    if (!phoneme_notice_given && !getenv("TTS_KOKORO_INPUT_IS_PHONEMES")) {
+        phoneme_notice_given = true;
+        fprintf(stderr, "kokoro: NOTE this engine has no phonemizer: the prompt is read as IPA phonemes (the reference phonemizes text first, "
+                        "kokoro/model.cpp:1415-1417).  Set TTS_KOKORO_INPUT_IS_PHONEMES=1 to silence this notice.\n");
+    }
+    const auto chunks = kokoro_clause_chunks(hp, *tokenizer, prompt);
+    size_t unknown = 0, total_ids = 0;
+    for (const auto & tokens : chunks)
+        for (uint32_t id : tokens) { total_ids++; unknown += id == tokenizer->unknown_id; }
+    if (unknown)
+        fprintf(stderr, "kokoro: WARNING %zu of %zu symbols of the prompt are not in the phoneme vocabulary (plain text instead of phonemes?); "
+                        "they are synthesised as the unknown token\n", unknown, total_ids);
+    for (const auto & tokens : chunks) {
         // the reference's split lets a chunk reach max_context_length + 2 ids (bos + max_context_length + eos, model.cpp:1359-1372),
         // past what its own graphs are sized for; such a chunk is cut once more here so that every call fits the context
         const size_t inner_max = hp.max_context_length - 2;

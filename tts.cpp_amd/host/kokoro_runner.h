@@ -60,6 +60,7 @@ struct kokoro_runner final : tts_generation_runner {
 
     std::vector<uint32_t> last_prompt_tokens;   // every clause's ids of the last generate, concatenated
     std::vector<float>    last_lengths;
+    bool                  phoneme_notice_given = false;
 
     kokoro_hparams                         hp;
     std::unique_ptr<single_pass_tokenizer> tokenizer;

@@ -1,3 +1,5 @@
+#include <algorithm>
+#include <cstdlib>
 // loaders.cpp — architecture registry + runner_from_file (mirrors /root/reference/src/models/loaders.cpp:13-95)
 #include <cmath>
 #include <cstdio>
@@ -19,6 +21,23 @@ tts_model_loader::tts_model_loader(const char * arch, bool is_test) : arch{arch}
 
 tts_generation_runner::tts_generation_runner(const tts_model_loader & loader) : loader{std::ref(loader)} {}
 tts_generation_runner::~tts_generation_runner() = default;
+
+tts_load_options & tts_thread_load_options() {
+    static thread_local tts_load_options o;
+    return o;
+}
+int tts_load_device() {
+    const tts_load_options & o = tts_thread_load_options();
+    if (o.device >= 0) return o.device;
+    if (const char * d = getenv("TTS_HIP_DEVICE")) return atoi(d);
+    return 0;
+}
+uint32_t tts_load_max_seqs() {
+    const tts_load_options & o = tts_thread_load_options();
+    if (o.max_seqs > 0) return (uint32_t) o.max_seqs;
+    if (const char * ms = getenv("TTS_HIP_MAX_SEQS")) return (uint32_t) std::max(1, atoi(ms));
+    return 1;
+}
 
 std::vector<std::string_view> tts_generation_runner::list_voices() {
     TTS_ABORT("The architecture '%s' does not support #list_voices.\n", loader.get().arch);

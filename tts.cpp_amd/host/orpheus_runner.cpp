@@ -70,8 +70,7 @@ static orpheus_hparams read_hparams(const gguf_file & m) {
 
 std::unique_ptr<tts_generation_runner> orpheus_model_loader::from_file(gguf_file * meta, int, bool, const generation_configuration &) const {
     const orpheus_hparams hp = read_hparams(*meta);
-    int device = 0;
-    if (const char * d = getenv("TTS_HIP_DEVICE")) device = atoi(d);
+    const int device = tts_load_device();
     return std::make_unique<orpheus_runner>(hp, bpe_tokenizer_from_gguf(*meta), device);
 }
 
@@ -92,7 +91,12 @@ orpheus_runner::orpheus_runner(const orpheus_hparams & hp_, bpe_tokenizer * tok,
     for (uint32_t i = 0; i < 3; i++) s.repeats[i] = hp.snac_repeats[i];
     s.max_frames = hp.snac_max_generation;
     snac = tts_hip_snac_create(device, &s);
-    if (!snac) TTS_ABORT("tts_hip_snac_create failed: %s\n", tts_hip_last_error());
+    if (!snac) {
+        // the destructor does not run for a constructor that throws (TTS_ABORT under g_tts_throw_on_abort): release the decoder context
+        tts_hip_destroy(lm);
+        lm = nullptr;
+        TTS_ABORT("tts_hip_snac_create failed: %s\n", tts_hip_last_error());
+    }
     sampling_rate = 24000.0f;           // model.h:112
     supports_voices = true;
     smp.n_output_heads = 1;             // model.h:113-115

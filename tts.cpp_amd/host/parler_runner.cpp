@@ -57,8 +57,7 @@ static parler_hparams read_hparams(const gguf_file & m) {
 std::unique_ptr<tts_generation_runner> parler_model_loader::from_file(gguf_file * meta, int, bool cpu_only,
                                                                       const generation_configuration & config) const {
     const parler_hparams hp = read_hparams(*meta);
-    int device = 0;
-    if (const char * d = getenv("TTS_HIP_DEVICE")) device = atoi(d);
+    const int device = tts_load_device();
     (void) cpu_only;
     return std::make_unique<parler_runner>(hp, unigram_tokenizer_from_gguf(*meta), device, config.use_cross_attn);
 }
@@ -73,8 +72,16 @@ parler_runner::parler_runner(const parler_hparams & hp_, unigram_tokenizer * tok
     d.dac_n_blocks = hp.dac_n_layers;
     for (uint32_t i = 0; i < hp.dac_n_layers; i++) { d.dac_stride[i] = hp.dac_stride[i]; d.dac_padding[i] = hp.dac_padding[i]; }
     d.dac_max_frames = hp.max_generation_size;
-    if (const char * ms = getenv("TTS_HIP_MAX_SEQS")) max_seqs = (uint32_t) std::max(1, atoi(ms));
+    max_seqs = tts_load_max_seqs();
     d.max_seqs = max_seqs;
+    {
+        const tts_load_options & lo = tts_thread_load_options();
+        if (lo.share_with) {
+            share_ctx = (tts_hip_ctx *) lo.share_with->device_context();
+            if (!share_ctx) TTS_ABORT("load: share_with names a runner that cannot share its weights\n");
+        }
+        declare_only = lo.declare_only || share_ctx != nullptr;
+    }
     d.kv_type = getenv("TTS_HIP_KV_F16") ? TTS_HIP_F16 : TTS_HIP_F32;
     d.gelu_mode = 1;
     // one utterance: the reference layout (max_ctx_length positions, model.cpp:368-369); lock-step batches keep only
@@ -92,11 +99,18 @@ parler_runner::~parler_runner() { tts_hip_destroy(ctx); }
 
 void parler_runner::assign_weight(const char * name, const gguf_tensor_view & t) {
     // model.cpp:500-508 routes "audio_encoder." / "decoder." prefixes; the shim does the same by name
-    hip_check(tts_hip_upload(ctx, name, t.type, t.n_dims, t.ne, t.data), name);
+    // declare-only: the shape is all the device needs to lay its arena out; the bytes come from another context
+    hip_check(tts_hip_upload(ctx, name, t.type, t.n_dims, t.ne, declare_only ? nullptr : t.data), name);
 }
 
 void parler_runner::prepare_post_load() {
     // prep_cross_key_values + kv cache init + graph reserve (model.cpp:704-713) all live in finalize
+    if (share_ctx) {
+        // same model, same device: use the loaded runner's arena (weights + precomputed cross K/V); own KV cache and stream
+        if (tts_hip_arena_bytes(ctx) != tts_hip_arena_bytes(share_ctx)) TTS_ABORT("load: the runner to share weights with holds a different model\n");
+        hip_check(tts_hip_finalize(ctx, tts_hip_arena_ptr(share_ctx)), "tts_hip_finalize(shared arena)");
+        hip_check(tts_hip_arena_filled(ctx), "tts_hip_arena_filled");
+    } else
     hip_check(tts_hip_finalize(ctx, nullptr), "tts_hip_finalize");
     logits.resize((size_t) hp.n_output_heads * hp.output_vocab_size);
     pcm.reserve((size_t) hp.max_generation_size * hp.up_sampling_factor);
@@ -253,25 +267,36 @@ void parler_runner::generate(const char * sentence, tts_response & output, const
 
 void parler_runner::generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs,
                                    const generation_configuration & config) {
-    const uint32_t n = (uint32_t) sentences.size(), nh = hp.n_output_heads;
-    outputs.assign(n, tts_response{});
-    if (n == 0) return;
-    if (n > max_seqs) TTS_ABORT("generate_batch: %u utterances but the runner was loaded with max_seqs=%u (TTS_HIP_MAX_SEQS)\n", n, max_seqs);
+    const uint32_t n_all = (uint32_t) sentences.size(), nh = hp.n_output_heads;
+    outputs.assign(n_all, tts_response{});
+    if (n_all == 0) return;
+    if (n_all > max_seqs) TTS_ABORT("generate_batch: %u utterances but the runner was loaded with max_seqs=%u (TTS_HIP_MAX_SEQS)\n", n_all, max_seqs);
     if (config.use_cross_attn != use_cross_attn) TTS_ABORT("generate_batch: use_cross_attn differs from load time\n");
-    std::vector<uint32_t> ids, lens(n), start(n);
-    for (uint32_t i = 0; i < n; i++) {
+    // batch_from_sentence per utterance; an utterance whose prompt leaves no room gets an empty response, exactly as generate() does
+    std::vector<uint32_t> ids, lens, start, row_of;
+    for (uint32_t i = 0; i < n_all; i++) {
         std::vector<uint32_t> p;
         tokenizer->tokenize(sentences[i], p);
         p.push_back(tokenizer->eos_token);
-        if (p.size() >= hp.max_generation_size) TTS_ABORT("generate_batch: prompt %u leaves no room for generation\n", i);
-        lens[i] = start[i] = (uint32_t) p.size();
+        if (p.size() >= hp.max_generation_size || p.size() >= hp.max_ctx_length) {
+            fprintf(stderr, "prompt %u of %zu tokens leaves no room for generation\n", i, p.size());
+            continue;
+        }
+        row_of.push_back(i);
+        lens.push_back((uint32_t) p.size());
+        start.push_back((uint32_t) p.size());
         ids.insert(ids.end(), p.begin(), p.end());
     }
+    const uint32_t n = (uint32_t) row_of.size();
+    last_batch_tokens.assign(n_all, {});
+    if (n == 0) return;
     hip_check(tts_hip_parler_reset(ctx), "tts_hip_parler_reset");
     hip_check(tts_hip_parler_prefill_batch(ctx, n, nullptr, ids.data(), lens.data(), nullptr), "tts_hip_parler_prefill_batch");
-    const uint32_t longest = *std::max_element(start.begin(), start.end());
-    const uint32_t max_steps = hp.max_generation_size - longest;  // every sequence stays inside max_generation
-    last_batch_tokens.assign(n, {});
+    // every utterance gets the steps generate() would give it alone (max_generation - its own prompt): the loop runs as long as the
+    // shortest prompt needs; the device marks a row finished when its position reaches max_generation and lets it idle there
+    const uint32_t shortest = *std::min_element(start.begin(), start.end());
+    const uint32_t max_steps = hp.max_generation_size - shortest;
+    std::vector<std::vector<uint32_t>> row_tokens(n);
 
     if (!getenv("TTS_HOST_LOOP") && (!config.sample || hp.output_vocab_size <= 2048)) {
         std::vector<uint32_t> toks((size_t) max_steps * n * nh), done(n);
@@ -280,7 +305,7 @@ void parler_runner::generate_batch(const std::vector<std::string> & sentences, s
             std::vector<float> u((size_t) max_steps * n * nh);
             for (uint32_t i = 0; i < n; i++) {
                 sampler si = smp;
-                si.seed = config.seed ? config.seed + i : 0; si.n_calls = 0;
+                si.seed = config.seed; si.n_calls = 0;   // n separate generate() calls would each seed with config.seed
                 for (uint32_t s = 0; s < max_steps; s++) si.draw_uniforms(u.data() + ((size_t) s * n + i) * nh);
             }
             const tts_hip_sampling sp{(uint32_t) config.top_k, config.top_p, config.temperature, config.repetition_penalty};
@@ -294,7 +319,7 @@ void parler_runner::generate_batch(const std::vector<std::string> & sentences, s
             uint32_t steps = done[i] ? done[i] : max_steps;
             steps = std::min(steps, hp.max_generation_size - start[i]);
             for (uint32_t s = 0; s < steps; s++)
-                last_batch_tokens[i].insert(last_batch_tokens[i].end(), toks.begin() + ((size_t) s * n + i) * nh, toks.begin() + ((size_t) s * n + i + 1) * nh);
+                row_tokens[i].insert(row_tokens[i].end(), toks.begin() + ((size_t) s * n + i) * nh, toks.begin() + ((size_t) s * n + i + 1) * nh);
         }
     } else {
         // host sampling, one sampler state per utterance; finished sequences keep stepping on EOS inputs (their
@@ -303,7 +328,7 @@ void parler_runner::generate_batch(const std::vector<std::string> & sentences, s
         for (uint32_t i = 0; i < n; i++) {
             smps[i].temperature = config.temperature; smps[i].repetition_penalty = config.repetition_penalty;
             smps[i].do_sample = config.sample; smps[i].top_k = (uint32_t) config.top_k; smps[i].top_p = config.top_p;
-            smps[i].seed = config.seed ? config.seed + i : 0; smps[i].n_calls = 0;
+            smps[i].seed = config.seed; smps[i].n_calls = 0;
             smps[i].reset();
         }
         std::vector<uint32_t> in_ids((size_t) n * nh, hp.bos_token_id), pos(start);
@@ -314,7 +339,7 @@ void parler_runner::generate_batch(const std::vector<std::string> & sentences, s
             bool all_done = true;
             for (uint32_t i = 0; i < n; i++) {
                 if (finished[i]) continue;
-                auto & t = last_batch_tokens[i];
+                auto & t = row_tokens[i];
                 if (!t.empty()) {
                     if (pos[i] >= hp.max_generation_size) { finished[i] = true; continue; }
                     bool all = true;
@@ -331,7 +356,7 @@ void parler_runner::generate_batch(const std::vector<std::string> & sentences, s
             for (uint32_t i = 0; i < n; i++) {
                 if (pos[i] + 1 < hp.max_generation_size) pos[i] += 1;  // finished rows idle on their last position
                 if (finished[i]) continue;
-                auto & t = last_batch_tokens[i];
+                auto & t = row_tokens[i];
                 smps[i].sample(lg.data() + (size_t) i * nh * hp.output_vocab_size, t);
                 const uint32_t * last = t.data() + t.size() - nh;
                 for (uint32_t h = 0; h < nh; h++)
@@ -343,9 +368,10 @@ void parler_runner::generate_batch(const std::vector<std::string> & sentences, s
     std::vector<uint32_t> codes, frames(n);
     for (uint32_t i = 0; i < n; i++) {
         std::vector<uint32_t> f;
-        adjust_output_tokens(last_batch_tokens[i], f);
+        adjust_output_tokens(row_tokens[i], f);
         frames[i] = (uint32_t) (f.size() / nh);
         codes.insert(codes.end(), f.begin(), f.end());
+        last_batch_tokens[row_of[i]] = std::move(row_tokens[i]);
     }
     size_t total = 0;
     for (uint32_t f : frames) total += (size_t) f * hp.up_sampling_factor;
@@ -353,8 +379,8 @@ void parler_runner::generate_batch(const std::vector<std::string> & sentences, s
     if (total) hip_check(tts_hip_dac_decode_batch(ctx, codes.data(), frames.data(), n, pcm.data()), "tts_hip_dac_decode_batch");
     size_t off = 0;
     for (uint32_t i = 0; i < n; i++) {
-        outputs[i].data = pcm.data() + off;
-        outputs[i].n_outputs = (size_t) frames[i] * hp.up_sampling_factor;
-        off += outputs[i].n_outputs;
+        outputs[row_of[i]].data = pcm.data() + off;
+        outputs[row_of[i]].n_outputs = (size_t) frames[i] * hp.up_sampling_factor;
+        off += outputs[row_of[i]].n_outputs;
     }
 }

@@ -46,6 +46,9 @@ struct parler_runner final : tts_generation_runner {
     void generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs,
                         const generation_configuration & config) override;
     uint32_t batch_capacity() const override { return max_seqs; }
+    void *   device_context() const override { return ctx; }
+    bool          declare_only = false;   // tts_load_options at load time: no weight bytes uploaded by this runner
+    tts_hip_ctx * share_ctx = nullptr;    // ... and whose arena it uses instead (same device)
     uint32_t max_seqs = 1;
     std::vector<std::vector<uint32_t>> last_batch_tokens;  // per utterance, still delayed
 

@@ -139,6 +139,7 @@ int tts_c_tokenize(const char * gguf_path, const char * text, uint32_t * out, in
 
 int tts_c_sampler_sample(const tts_c_sampler_cfg * c, const int32_t * last_ids, const uint32_t * counts, float * logits,
                          const float * uniforms, uint32_t * out) {
+    try {
     sampler s;
     s.n_output_heads = c->n_output_heads; s.vocab_size = c->vocab_size; s.top_k = c->top_k; s.temperature = c->temperature;
     s.top_p = c->top_p; s.repetition_penalty = c->repetition_penalty; s.do_sample = c->do_sample != 0; s.seed = c->seed;
@@ -152,9 +153,14 @@ int tts_c_sampler_sample(const tts_c_sampler_cfg * c, const int32_t * last_ids, 
     else s.sample(logits, o);
     copy_u32(out, o.data(), o.size());
     return (int) o.size();
+    } catch (const std::exception & e) {   // no exception may cross the C boundary
+        g_c_err = e.what();
+        return -1;
+    }
 }
 
 int tts_c_gguf_summary(const char * path, uint64_t * n_tensors, uint64_t * n_kv, uint64_t * data_offset, char * arch, int arch_cap) {
+    try {
     std::string err;
     auto f = gguf_file::open(path, err);
     if (!f) { g_c_err = err; return -1; }
@@ -164,9 +170,14 @@ int tts_c_gguf_summary(const char * path, uint64_t * n_tensors, uint64_t * n_kv,
     if (auto a = f->get("general.architecture")) snprintf(arch, (size_t) arch_cap, "%s", a->s.c_str());
     else if (arch_cap) arch[0] = 0;
     return 0;
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return -1;
+    }
 }
 
 int tts_c_gguf_tensor(const char * path, int index, char * name, int name_cap, int * type, int64_t ne[4], uint64_t * checksum) {
+    try {
     std::string err;
     auto f = gguf_file::open(path, err);
     if (!f) { g_c_err = err; return -1; }
@@ -180,6 +191,10 @@ int tts_c_gguf_tensor(const char * path, int index, char * name, int name_cap, i
     for (size_t i = 0; i < t.nbytes; i++) { h ^= p[i]; h *= 1099511628211ull; }
     *checksum = h;
     return 0;
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return -1;
+    }
 }
 
 }  // extern "C"
@@ -364,4 +379,8 @@ void tts_c_pool_stats(tts_c_pool * p, uint64_t * tasks, uint64_t * batches, uint
     if (timed_out) *timed_out = s.timed_out;
 }
 
+void tts_c_pool_load_stats(tts_c_pool * p, int * weight_broadcasts, int * shared_arena_loads) {
+    if (weight_broadcasts) *weight_broadcasts = p->pool->weight_broadcasts();
+    if (shared_arena_loads) *shared_arena_loads = p->pool->shared_arena_loads();
+}
 void tts_c_pool_free(tts_c_pool * p) { delete p; }

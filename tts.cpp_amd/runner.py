@@ -28,7 +28,7 @@ class SamplerCfg(C.Structure):
 
 EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_generate_batch", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
            "tts_c_last_error", "tts_c_update_conditional_prompt", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor",
-           "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_free",
+           "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_load_stats", "tts_c_pool_free",
            "tts_c_quantize_gguf", "tts_c_quantize_decision", "tts_c_quantize_rows",
            "tts_c_dia_tokenize", "tts_c_dia_check_stopping", "tts_c_dia_adjust_output_tokens", "tts_c_single_pass_tokenize", "tts_c_kokoro_chunks"]
 
@@ -87,6 +87,8 @@ def load_lib():
         L.tts_c_pool_release.restype = None
         L.tts_c_pool_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 4
         L.tts_c_pool_stats.restype = None
+        L.tts_c_pool_load_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.tts_c_pool_load_stats.restype = None
         L.tts_c_pool_free.argtypes = [C.c_void_p]
         L.tts_c_pool_free.restype = None
         _lib = L
@@ -290,6 +292,11 @@ class Pool:
         err = self.L.tts_c_last_error().decode("utf-8", "replace") if rc == 1 else ""
         self.L.tts_c_pool_release(self.h, task_id)
         return audio, bs.value, wk.value, err
+
+    def load_stats(self):
+        a, b = C.c_int(), C.c_int()
+        self.L.tts_c_pool_load_stats(self.h, C.byref(a), C.byref(b))
+        return {"weight_broadcasts": a.value, "shared_arena_loads": b.value}
 
     def stats(self):
         v = [C.c_uint64() for _ in range(4)]
