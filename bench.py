@@ -1,23 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py — audio-seconds/sec of the Parler-TTS-Mini hot path (AR decoder + DAC) on MI355X.
+"""bench.py — audio-seconds/sec of the Parler-TTS-Mini hot path (AR decoder + DAC) on MI355X, through the product path.
 
-A "step" is one pass of the hot path over one batch of synthetic utterances:
-  text-prompt prefill -> N greedy audio steps (device-resident delay-pattern loop) -> un-delay ->
-  DAC decode to 44.1 kHz PCM, for `--batch` utterances per GPU decoded in lock-step.
-Inputs (weights, prompts) are resident in HBM before the timed region; sampled ids and PCM come back
-to the host inside it, exactly as tts_generation_runner::generate() returns them.
+A "step" is one pass of the hot path over one batch of synthetic utterances, driven exactly as an application drives it:
+  tts_c_runner_from_file(GGUF)  (C++ loader: GGUF reader, weight upload, cross K/V, KV cache)        -- before the timed region
+  tts_c_generate_batch(texts)   (C++ runner: unigram tokenizer -> text-prompt prefill -> N greedy audio steps in the device-resident
+                                 delay-pattern loop -> adjust_output_tokens -> DAC decode to 44.1 kHz PCM)   -- the timed region
+for `--batch` utterances per context decoded in lock-step (`--streams` contexts per GPU).  Python only writes the synthetic GGUF,
+picks the sentences and reads the clock: tokenizer, loop control, un-delay and the codec call are the C++ host's
+(tts.cpp_amd/host/parler_runner.cpp), the compute is the HIP library's (include/tts_hip.h).
 
-Multi-GPU (launched by torch.distributed.run): rank 0 mints the synthetic GGUF tensors and uploads them,
-the other ranks only declare shapes; the finished weight arena (incl. precomputed cross K/V) is
-broadcast once with RCCL; afterwards utterances are independent, no data-path collective
- -> "scaling": "weak".
+Multi-GPU (launched by torch.distributed.run): rank 0's runner parses and uploads the file, the other ranks load it declare-only
+(tts_load_options) and receive the finished weight arena (incl. precomputed cross K/V) by ONE RCCL broadcast; afterwards utterances
+are independent, no data-path collective -> "scaling": "weak".
 
-Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit + roofline + cpu_baseline.
+Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit + roofline + cpu_baseline, plus SURVEY §8(d)'s second metric
+(batch-1 ms per decode step at T ~ 128 / 512 / 1024 / 2580, a 1024-step utterance).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -27,78 +32,78 @@ sys.path.insert(0, ROOT)
 
 import tts_cpp_amd  # noqa: E402,F401
 from tts_cpp_amd import dist as tdist  # noqa: E402
-from tts_cpp_amd import gguf, hip, synth  # noqa: E402
-from tts_cpp_amd.pattern import undelay  # noqa: E402
+from tts_cpp_amd import gguf, hip, runner, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 F32_PEAK_TFLOPS = 157.3   # fp32 vector == fp32-input MFMA peak
 F16_PEAK_TFLOPS = 2516.8  # dense fp16 MFMA = 16 x the fp32 matrix rate (MI355X_MICROARCH.md)
 SAMPLE_RATE = 44100.0
 
+# kernel families as rocprofv3 groups them by symbol (profiles/r02/kernel_stats_*.csv): the per-class HIP-event statistics of the shim
+# (tts_hip_profile) are summed per family, so "dominant" means what it means in the rocprof table
+FAMILIES = {
+    "gemm_tile_kernel (decoder GEMMs: qkv, out_proj, cross q/out, fc1, fc2, heads)":
+        ["gemm_qkv", "gemm_attn_out", "gemm_cross_q", "gemm_cross_out", "gemm_fc1", "gemm_fc2", "gemm_heads", "gemm_other"],
+    "attn_kernel (self-attention over the fp32 KV cache)": ["attn_self"],
+    "attn_short_kernel (cross-attention over the voice prompt)": ["attn_cross"],
+    "ln_rows_kernel (LayerNorm + split-K fold)": ["ln"],
+    "conv1d_mfma_kernel<7,...> (DAC k=7 residual convs)": ["dac_conv7"],
+    "conv1d_mfma_kernel<1,...> (DAC k=1 convs + residual)": ["dac_conv1"],
+    "convt1d_mfma_kernel (DAC transposed convs)": ["dac_convt"],
+    "other (embed, sampler/feed, DAC quantizer + final conv)": ["embed", "sample", "dac_embed", "dac_final"],
+}
+MFMA_FP16 = {"gemm_tile_kernel (decoder GEMMs: qkv, out_proj, cross q/out, fc1, fc2, heads)"}
+MFMA_FP32 = {"conv1d_mfma_kernel<7,...> (DAC k=7 residual convs)", "conv1d_mfma_kernel<1,...> (DAC k=1 convs + residual)",
+             "convt1d_mfma_kernel (DAC transposed convs)"}
+
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_prompts(cfg, batch, prompt_len, rank):
-    rng = np.random.default_rng(1000 + rank)
-    return [np.concatenate([rng.integers(3, cfg.prompt_vocab, prompt_len - 1), [1]]).astype(np.uint32) for _ in range(batch)]
+class ArenaView:
+    """a runner's weight arena as a CUDA array (for torch.as_tensor): the RCCL broadcast writes straight into it"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-DAC_GROUP = int(os.environ.get("TTS_BENCH_DAC_GROUP", "32"))
-import threading  # noqa: E402
-
-# One DAC pass fills the chip (compute-bound MFMA convs); passes of different contexts are serialised so that they
-# overlap the other context's latency-bound decoder loop instead of each other.
-DAC_LOCK = threading.Lock()
-
-
-SAMPLE_UNIFORMS = None  # [steps][batch][heads] U[0,1) draws when --sample
-
-
-def run_utterance_batch(eng, cfg, prompts, n_audio, timings=None, dac_group=None):
-    dac_group = dac_group or DAC_GROUP
-    """one bench step; returns total PCM samples produced"""
-    t0 = time.perf_counter()
-    eng.prefill_batch(prompts)
-    t1 = time.perf_counter()
-    if SAMPLE_UNIFORMS is not None:   # --sample: sampler::sample on the device, the reference's default parameters
-        u = SAMPLE_UNIFORMS[:n_audio, :len(prompts)]
-        toks, _ = eng.generate_sampled([len(p) for p in prompts], n_audio, u, top_k=50, top_p=1.0, temperature=1.0)
-    else:
-        toks, _ = eng.generate_greedy([len(p) for p in prompts], n_audio)
-    t2 = time.perf_counter()
-    frames = [undelay(toks[:, s, :], cfg.audio_vocab) for s in range(len(prompts))]
-    n_samples = 0
-    group = max(1, dac_group)
-    for g in range(0, len(frames), group):  # DAC for `group` utterances per pass (bounds the activation buffers)
-        with DAC_LOCK:
-            pcms = eng.dac_decode_batch(frames[g:g + group])
-        for pcm in pcms:
-            n_samples += pcm.size
-    t3 = time.perf_counter()
-    if timings is not None:
-        timings.append((t1 - t0, t2 - t1, t3 - t2))
-    return n_samples
+def make_sentences(rn, n, target_ids, seed):
+    """`n` distinct pseudo-sentences that the runner's own tokenizer (batch_from_sentence: ids + EOS) turns into exactly
+    `target_ids` ids, so every utterance of a lock-step batch runs the same number of audio steps"""
+    rng = np.random.default_rng(seed)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    out, tries = [], 0
+    while len(out) < n:
+        tries += 1
+        if tries > 200000:
+            raise RuntimeError("could not find sentences of the requested token length")
+        words = ["".join(rng.choice(list(letters), size=int(rng.integers(2, 7)))) for _ in range(int(rng.integers(2, 3 + target_ids // 2)))]
+        text = " ".join(words)
+        k = len(rn.tokenize(text))
+        while k > target_ids and len(text) > 1:   # trim characters until the count fits
+            text = text[:-1].rstrip()
+            k = len(rn.tokenize(text)) if text else 0
+        if k == target_ids and text not in out:
+            out.append(text)
+    return out
 
 
-def pmc_traffic(kclass, args, n_audio):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM);
-    None when the committed measurement was taken on a different workload."""
+def pmc_traffic(family, args, n_audio):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    runs, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); None when the committed measurement was taken on a different workload."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
     t = json.load(open(path))
     w = t.get("workload", {})
-    if kclass.startswith("dac_"):  # DAC launches depend only on the group size and the frame count
-        if args.dac_wtype != "f32":
-            return None
-        if w.get("audio_steps") != n_audio or w.get("dac_group") != DAC_GROUP:
+    key = FAMILIES[family][0]
+    if key.startswith("dac_"):  # DAC launches depend only on the group size (32 utterances per pass) and the frame count
+        if args.dac_wtype != "f32" or w.get("audio_steps") != n_audio:
             return None
     elif w.get("batch") != args.batch or w.get("audio_steps") != n_audio:
         return None
-    v = t.get("kernels", {}).get(kclass)
+    v = t.get("kernels", {}).get(key)
     return None if v is None else round(v["hbm_bytes_per_launch"], 1)
 
 
@@ -148,19 +153,58 @@ def cpu_baseline(model, cfg, prompt, threads):
     }
 
 
+def decode_step_sweep(cfg_full, model, arena_ptr, device):
+    """SURVEY §8(d) metric 2: batch 1, ms per decode step as the cache grows (device-resident greedy loop, one hipGraph replay per
+    step) + a 1024-step utterance.  A one-sequence context with the full 2580-position cache on the resident weights."""
+    e = hip.HipEngine(cfg_full, device=device, max_seqs=1, kv_positions=cfg_full.max_gen)
+    for t in model.tensors:
+        e.upload(t, declare_only=True)
+    e.finalize(external_arena=arena_ptr)
+    e.arena_filled()
+    prompt = np.arange(3, 19, dtype=np.uint32)
+    out = {}
+    e.prefill(0, prompt)
+    e.generate_greedy([len(prompt)], 8)   # graph capture outside the clock
+    e.reset()
+    e.prefill(0, prompt)
+    pos = len(prompt)
+    for label, upto in (("T~128", 128), ("T~512", 512), ("T~1024", 1024), ("T~2580", 2580)):
+        upto = min(upto, cfg_full.max_gen)
+        n = upto - pos
+        if n <= 0:
+            continue
+        t0 = time.perf_counter()
+        e.generate_greedy([pos], n)
+        out[label] = round((time.perf_counter() - t0) / n * 1e3, 4)
+        pos = upto
+    e.reset()
+    e.prefill(0, prompt)
+    n_long = min(1024, cfg_full.max_gen - len(prompt))
+    t0 = time.perf_counter()
+    e.generate_greedy([len(prompt)], n_long)
+    t1024 = time.perf_counter() - t0
+    e.close()
+    return {"ms_per_step_by_cached_positions": out,
+            "steps_1024": {"steps": n_long, "ms_total": round(t1024 * 1e3, 2), "ms_per_step": round(t1024 / n_long * 1e3, 4),
+                           "x_real_time": round((n_long - cfg_full.n_out + 1) * cfg_full.hop / SAMPLE_RATE / t1024, 2)},
+            "note": "batch 1, fp16 weights, fp32 KV cache, cross-attention on, greedy, device-resident loop (tts_hip_parler_generate_greedy); "
+                    "each interval continues the same utterance from the previous one"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TTS_BENCH_BATCH", "128")), help="utterances per context decoded in lock-step")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("TTS_BENCH_STREAMS", "3")),
-                    help="independent contexts (HIP streams) per GPU sharing one weight arena; each decodes --batch utterances")
-    ap.add_argument("--audio-steps", type=int, default=256, help="AR audio steps per utterance (random weights never emit EOS)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TTS_BENCH_BATCH", "384")), help="utterances per context decoded in lock-step")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("TTS_BENCH_STREAMS", "1")),
+                    help="independent runners (contexts, HIP streams) per GPU; each decodes --batch utterances per step")
+    ap.add_argument("--audio-steps", type=int, default=256, help="AR audio steps per utterance (random weights never emit EOS: max_generation = prompt + this)")
     ap.add_argument("--prompt-len", type=int, default=16)
     ap.add_argument("--kv", choices=["f32", "f16"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-step-sweep", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--model", choices=["mini", "small", "tiny"], default="mini")
     ap.add_argument("--sample", action="store_true",
@@ -189,61 +233,69 @@ def main():
 
         tdist.init(backend, rank, world, device=torch.device("cuda", local_rank))
 
-    cfg = {"mini": synth.parler_mini, "small": synth.small, "tiny": synth.tiny}[args.model](
-        weight_type={"f16": gguf.F16, "f32": gguf.F32, "q8_0": gguf.Q8_0, "q5_0": gguf.Q5_0, "q4_0": gguf.Q4_0}[args.wtype],
-        dac_f16=args.dac_wtype == "f16")
+    mk = {"mini": synth.parler_mini, "small": synth.small, "tiny": synth.tiny}[args.model]
+    wt = {"f16": gguf.F16, "f32": gguf.F32, "q8_0": gguf.Q8_0, "q5_0": gguf.Q5_0, "q4_0": gguf.Q4_0}[args.wtype]
+    cfg_full = mk(weight_type=wt, dac_f16=args.dac_wtype == "f16")
+    n_audio = min(args.audio_steps, cfg_full.max_gen - args.prompt_len, cfg_full.ctx - args.prompt_len)
+    # the file the runners load: same tensors, max_generation = prompt + audio steps (check_stopping ends every utterance there,
+    # model.cpp:720-722; random weights never emit EOS)
+    cfg = mk(weight_type=wt, dac_f16=args.dac_wtype == "f16", max_gen=args.prompt_len + n_audio)
     WNAME = dict(f16="fp16", f32="fp32").get(args.wtype, args.wtype)
     DECODE = "top-k 50 sampling" if args.sample else "greedy decode"
-    if args.sample:
-        global SAMPLE_UNIFORMS
-        SAMPLE_UNIFORMS = np.random.default_rng(1234 + rank).random((args.audio_steps, args.batch, cfg.n_out), dtype=np.float32)
-    n_audio = min(args.audio_steps, cfg.max_gen - args.prompt_len, cfg.ctx - args.prompt_len)
-    kv_type = gguf.F16 if args.kv == "f16" else gguf.F32
+    if args.kv == "f16":
+        os.environ["TTS_HIP_KV_F16"] = "1"
 
-    # ---- weights: rank 0 generates + uploads, everyone else receives the arena over RCCL ------
+    # ---- the model file: rank 0 mints the synthetic GGUF; the others only need its metadata (they load declare-only) ------------
     t_load = time.perf_counter()
-    model = synth.build(cfg, shapes_only=(rank != 0))
-    kv_pos = min(cfg.ctx, cfg.max_gen)  # generation stops at position max_generation (check_stopping, model.cpp:720-722)
-    eng = hip.HipEngine(cfg, device=local_rank, max_seqs=args.batch, kv_type=kv_type, kv_positions=kv_pos)
-    for t in model.tensors:
-        eng.upload(t, declare_only=(rank != 0))
-    arena = None
-    if world > 1:
-        arena = torch.empty(eng.arena_bytes(), dtype=torch.uint8, device=f"cuda:{local_rank}")
-        eng.finalize(external_arena=arena.data_ptr())
-        torch.cuda.synchronize()
-        tdist.broadcast_arena(arena, src=0)   # RCCL over xGMI: the one collective of the path
-        torch.cuda.synchronize()
-        eng.arena_filled()
-    else:
-        eng.finalize()
-    # extra contexts on the same GPU share the finished arena (weights + cross K/V): own stream, own KV cache
-    engines = [eng]
-    for _ in range(1, args.streams):
-        e2 = hip.HipEngine(cfg, device=local_rank, max_seqs=args.batch, kv_type=kv_type, kv_positions=kv_pos)
-        for t in model.tensors:
-            e2.upload(t, declare_only=True)
-        e2.finalize(external_arena=eng.arena_ptr())
-        e2.arena_filled()
-        engines.append(e2)
-    log(f"[rank {rank}] weights ready in {time.perf_counter() - t_load:.1f}s, arena {eng.arena_bytes() / 1e6:.0f} MB, {len(engines)} context(s)")
+    path = os.path.join(tempfile.gettempdir(), f"tts_bench_{args.model}_{args.wtype}_{args.dac_wtype}_{args.prompt_len + n_audio}_{os.environ.get('MASTER_PORT', '0')}.gguf")
+    model = synth.build(cfg, shapes_only=(rank != 0 and args.no_cpu_baseline))
+    if rank == 0:
+        model.write_gguf(path)
+    if dist is not None:
+        dist.barrier()
+    gen_cfg = dict(sample=1 if args.sample else 0, top_k=50, top_p=1.0, temperature=1.0, seed=1234 + rank)
+    runners = []
+    for s in range(args.streams):
+        rn = runner.Runner(path, device=local_rank, max_seqs=args.batch, declare_only=(rank != 0), **gen_cfg)
+        ctx = rn.device_context()
+        if world > 1:
+            L = hip.load_lib()
+            arena = torch.as_tensor(ArenaView(L.tts_hip_arena_ptr(ctx), L.tts_hip_arena_bytes(ctx)), device=f"cuda:{local_rank}")
+            torch.cuda.synchronize()
+            tdist.broadcast_arena(arena, src=0)   # RCCL over xGMI: the one collective of the path
+            torch.cuda.synchronize()
+            if rank != 0 and L.tts_hip_arena_filled(ctx) != 0:
+                raise RuntimeError(L.tts_hip_last_error().decode())
+        runners.append(rn)
+    L = hip.load_lib()
+    arena_bytes = L.tts_hip_arena_bytes(runners[0].device_context())
+    log(f"[rank {rank}] {len(runners)} runner(s) ready in {time.perf_counter() - t_load:.1f}s, arena {arena_bytes / 1e6:.0f} MB each")
+    if dist is not None:
+        dist.barrier()
+    if rank == 0 and not os.environ.get("TTS_BENCH_KEEP_GGUF"):
+        os.unlink(path)   # mapped by the runners; the name is no longer needed
 
-    all_prompts = [make_prompts(cfg, args.batch, args.prompt_len, rank * 64 + i) for i in range(args.streams)]
-    prompts = all_prompts[0]
-    if args.streams > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=args.streams)
+    all_texts = [make_sentences(runners[0], args.batch, args.prompt_len, 1000 + rank * 64 + i) for i in range(args.streams)]
 
-        def run_all(n_audio_, timings_=None):
-            tl = [[] for _ in engines]
-            futs = [pool.submit(run_utterance_batch, e, cfg, p, n_audio_, t) for e, p, t in zip(engines, all_prompts, tl)]
-            tot = sum(f.result() for f in futs)
-            if timings_ is not None:
-                timings_.append(tuple(np.mean([t[0][i] for t in tl]) for i in range(3)))
-            return tot
-    else:
-        def run_all(n_audio_, timings_=None):
-            return run_utterance_batch(eng, cfg, prompts, n_audio_, timings_)
+    def run_all(timings_=None):
+        res = [None] * len(runners)
+
+        def work(i):
+            t0 = time.perf_counter()
+            sizes = runners[i].generate_batch_sizes(all_texts[i])
+            res[i] = (sum(sizes), time.perf_counter() - t0)
+
+        if len(runners) == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(i,)) for i in range(len(runners))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        if timings_ is not None:
+            timings_.append(float(np.mean([r[1] for r in res])))
+        return sum(r[0] for r in res)
 
     def barrier():
         torch.cuda.synchronize()
@@ -251,31 +303,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def profile(mode):
+        for rn in runners:
+            if L.tts_hip_profile(rn.device_context(), mode) != 0:
+                raise RuntimeError(L.tts_hip_last_error().decode())
+
+    def profile_get(rn):
+        out = {}
+        for k in range(64):
+            name = L.tts_hip_kclass_name(k).decode()
+            if name == "?":
+                break
+            st = hip.KStat()
+            if L.tts_hip_profile_get(rn.device_context(), k, C.byref(st)) == 0:
+                out[name] = dict(ms_total=st.ms_total, launches=st.launches, bytes_total=st.bytes_total, flops_total=st.flops_total)
+        return out
+
     for _ in range(args.warmup):
-        run_all(n_audio)
+        run_all()
     barrier()
-    for e in engines:
-        e.profile(2)   # HIP-event pairs around the (never graph-captured) DAC launches, live in the timed region
+    profile(2)   # HIP-event pairs around the (never graph-captured) DAC launches, live in the timed region
     timings = []
     t0 = time.perf_counter()
     n_samples = 0
     for _ in range(args.steps):
-        n_samples += run_all(n_audio, timings)
+        n_samples += run_all(timings)
     barrier()
     elapsed = time.perf_counter() - t0
     live = {}
-    for e in engines:
-        for k, v in e.profile_get().items():
+    for rn in runners:
+        for k, v in profile_get(rn).items():
             a = live.setdefault(k, dict(ms_total=0.0, launches=0, bytes_total=0.0, flops_total=0.0))
             for f in a:
                 a[f] += v[f]
-        e.profile(0)
+    profile(0)
     if dist is not None:
         elapsed, n_samples = tdist.reduce_timing(elapsed, n_samples, device=f"cuda:{local_rank}")
 
     audio_seconds = n_samples / SAMPLE_RATE
     value = audio_seconds / elapsed
-    tm = np.array(timings)
+    frames = n_audio - cfg.n_out + 1
     out = {
         "metric": "audio-seconds/sec (Parler-TTS-Mini fp16, greedy decode + DAC to 44.1 kHz PCM)",
         "value": round(value, 3),
@@ -290,66 +357,88 @@ def main():
         "dtype": {"f16": "f16", "f32": "f32"}.get(args.wtype, "i8"),
         "dtype_detail": DTYPE_DETAIL[args.wtype] if args.dac_wtype == "f32" else
                         DTYPE_DETAIL[args.wtype].replace("DAC codec f32 (exact-f32 MFMA)", "DAC codec F16 tensors (fp16 im2col x fp16 kernels, fp16 MFMA, f32 accumulate)"),
-        "data": "synthetic (seeded random weights of the Parler-TTS-Mini + DAC-44k architecture; fixed-length greedy generation)",
+        "data": "synthetic (seeded random weights of the Parler-TTS-Mini + DAC-44k architecture written as a GGUF file; fixed-length greedy generation)",
         "config": {
-            "workload": f"configs[1]: Parler-TTS-Mini {WNAME} on MI355X, {DECODE} + DAC codec ({args.dac_wtype} tensors); {args.streams} context(s) x {args.batch} utterances/GPU in lock-step, "
-                        f"{args.prompt_len}-id prompt, {n_audio} audio steps (={n_audio - cfg.n_out + 1} frames, "
-                        f"{(n_audio - cfg.n_out + 1) * cfg.hop / SAMPLE_RATE:.2f} s audio) per utterance",
-            "utterances_per_gpu": args.batch * args.streams, "contexts_per_gpu": args.streams, "lockstep_batch": args.batch, "audio_steps": n_audio, "prompt_len": args.prompt_len,
-            "kv_cache": args.kv, "parallelism": f"dp{world} (one process per GPU, RCCL weight broadcast, no per-step collective)",
+            "workload": f"configs[1]: Parler-TTS-Mini {WNAME} on MI355X, {DECODE} + DAC codec ({args.dac_wtype} tensors), through the C++ runner "
+                        f"(tts_c_generate_batch: tokenizer, device-resident AR loop, un-delay, DAC); {args.streams} runner(s) x {args.batch} utterances/GPU "
+                        f"in lock-step, {args.prompt_len}-id prompts, {n_audio} audio steps (={frames} frames, {frames * cfg.hop / SAMPLE_RATE:.2f} s audio) per utterance",
+            "utterances_per_gpu": args.batch * args.streams, "contexts_per_gpu": args.streams, "lockstep_batch": args.batch, "audio_steps": n_audio,
+            "prompt_len": args.prompt_len, "kv_cache": args.kv,
+            "parallelism": f"dp{world} (one process per GPU, RCCL weight broadcast, no per-step collective)",
         },
         "real_time_factor": round(elapsed / audio_seconds, 6),
         "x_real_time_per_gpu": round(value / world, 3),
-        "ms_per_decode_step": round(float(tm[:, 1].mean()) / n_audio * 1e3, 4),
-        "phase_ms": {"prefill": round(float(tm[:, 0].mean()) * 1e3, 3), "ar_loop": round(float(tm[:, 1].mean()) * 1e3, 3),
-                     "dac": round(float(tm[:, 2].mean()) * 1e3, 3)},
+        "rccl_ranks": world,
+        "ms_per_generate_batch": round(float(np.mean(timings)) * 1e3, 3),
     }
 
     if rank == 0 and world == 1:
         if not args.no_roofline:
-            # per-kernel-class HIP-event timing of the same workload on context 0 (eager launches, every launch
-            # of every class bracketed by an event pair on the context's stream)
-            prof_steps = n_audio
-            eng.profile(True)
-            run_utterance_batch(eng, cfg, prompts, prof_steps)
-            stats = eng.profile_get()
-            eng.profile(False)
-            tot = sum(v["ms_total"] for v in stats.values()) or 1.0
-            dom = max(stats, key=lambda k: stats[k]["ms_total"])
-            st = stats[dom]
-            src = "separate eager pass of the same workload on context 0 (decoder launches live inside hipGraphs in the timed region)"
-            share = st["ms_total"] / tot
-            if live.get(dom, {}).get("launches"):
-                st = live[dom]   # the dominant kernel was bracketed live in the timed region
-                src = "HIP events around every launch of this kernel in the timed region (all contexts)"
-            per_launch_ms = st["ms_total"] / max(st["launches"], 1)
-            if dom.startswith("dac_conv"):
-                ach = st["flops_total"] / (st["ms_total"] * 1e-3) / 1e12
-                peak = F16_PEAK_TFLOPS if args.dac_wtype == "f16" else F32_PEAK_TFLOPS
-                roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": None,
-                        "note": "fp16 conv (F16 tensors, fp16 im2col): dense fp16 MFMA peak" if args.dac_wtype == "f16" else
-                                "fp32 conv: peak = fp32 vector/fp32-input-MFMA peak (exact-fp32 numerics)"}
-            else:
-                ach = st["bytes_total"] / (st["ms_total"] * 1e-3) / 1e9
-                roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+            # per-kernel-class HIP-event timing of the same call on runner 0 (eager launches, every launch bracketed by an event pair on
+            # the context's stream); classes are summed per rocprof symbol family
+            rn = runners[0]
+            L.tts_hip_profile(rn.device_context(), 1)
+            rn.generate_batch_sizes(all_texts[0])
+            stats = profile_get(rn)
+            L.tts_hip_profile(rn.device_context(), 0)
+            fam = {}
+            for name, keys in FAMILIES.items():
+                a = dict(ms_total=0.0, launches=0, bytes_total=0.0, flops_total=0.0)
+                for k in keys:
+                    for f in a:
+                        a[f] += stats.get(k, {}).get(f, 0)
+                if a["launches"]:
+                    fam[name] = a
+            tot = sum(v["ms_total"] for v in fam.values()) or 1.0
+            dom = max(fam, key=lambda k: fam[k]["ms_total"])
+
+            def roof_of(name, st, src):
+                per_launch_ms = st["ms_total"] / max(st["launches"], 1)
+                tf = st["flops_total"] / max(st["ms_total"], 1e-9) / 1e9
+                gb = st["bytes_total"] / max(st["ms_total"], 1e-9) / 1e6
+                if name in MFMA_FP32 or name in MFMA_FP16:
+                    peak = F16_PEAK_TFLOPS if (name in MFMA_FP16 or args.dac_wtype == "f16") else F32_PEAK_TFLOPS
+                    r = {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                         "hbm_GBps": round(gb, 1), "hbm_frac": round(gb / HBM_PEAK_GBS, 4)}
+                else:
+                    r = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 4)}
+                r.update({"kernel": name, "timing_source": src, "avg_launch_us": round(per_launch_ms * 1e3, 3), "launches": st["launches"],
+                          "share_of_kernel_time": round(st["ms_total"] / tot, 3),
+                          "algorithmic_bytes_per_launch": round(st["bytes_total"] / max(st["launches"], 1), 1),
+                          "algorithmic_flops_per_launch": round(st["flops_total"] / max(st["launches"], 1), 1)})
+                return r
+
+            src = "separate eager pass of the same tts_c_generate_batch call on runner 0 (decoder launches live inside hipGraphs in the timed region)"
+            st = fam[dom]
+            keys = FAMILIES[dom]
+            if all(live.get(k, {}).get("launches") for k in keys if stats.get(k, {}).get("launches")):
+                st = dict(ms_total=0.0, launches=0, bytes_total=0.0, flops_total=0.0)
+                for k in keys:
+                    for f in st:
+                        st[f] += live.get(k, {}).get(f, 0)
+                src = "HIP events around every launch of this kernel family in the timed region (all runners)"
+            roof = roof_of(dom, st, src)
+            roof["share_of_kernel_time"] = round(fam[dom]["ms_total"] / tot, 3)
             roof["traffic"] = pmc_traffic(dom, args, n_audio)
-            roof.update({"kernel": dom, "timing_source": src, "avg_launch_us": round(per_launch_ms * 1e3, 3), "launches": st["launches"],
-                         "share_of_kernel_time": round(share, 3),
-                         "algorithmic_bytes_per_launch": round(st["bytes_total"] / max(st["launches"], 1), 1)})
+            if roof["bound"] == "mfma" and dom in MFMA_FP32:
+                roof["note"] = "fp32 conv: peak = fp32 vector / fp32-input-MFMA peak (exact-fp32 numerics)"
             out["roofline"] = roof
+            out["roofline_families"] = [dict(roof_of(n, v, "eager pass (launch-by-launch HIP events: short kernels read ~1-2 us long)"), traffic=None)
+                                        for n, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_total"]) if n != dom]
             out["kernel_classes"] = {
                 k: {"ms": round(v["ms_total"], 3), "launches": v["launches"],
                     "GBps": round(v["bytes_total"] / max(v["ms_total"], 1e-9) / 1e6, 1),
                     "TFLOPs": round(v["flops_total"] / max(v["ms_total"], 1e-9) / 1e9, 3)}
                 for k, v in stats.items() if v["launches"]}
+        if not args.no_step_sweep and args.wtype in ("f16", "f32"):
+            full_model = synth.build(cfg_full, shapes_only=True)
+            out["decode_step_batch1"] = decode_step_sweep(cfg_full, full_model, L.tts_hip_arena_ptr(runners[0].device_context()), local_rank)
         if not args.no_cpu_baseline:
             threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 32)
-            out["cpu_baseline"] = cpu_baseline(model, cfg, prompts[0], threads)
-    for e in engines[1:]:
-        e.close()
-    eng.close()
+            prompt = runners[0].tokenize(all_texts[0][0])
+            out["cpu_baseline"] = cpu_baseline(model, cfg, prompt, threads)
+    for rn in runners:
+        rn.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -45,6 +45,14 @@ int           tts_c_generate(tts_c_runner *r, const char *text, const tts_c_conf
  * must have been loaded with TTS_HIP_MAX_SEQS >= n in the environment. */
 int           tts_c_generate_batch(tts_c_runner *r, const char *const *texts, int n, const tts_c_config *cfg, const float **data,
                                    size_t *n_outputs);
+/* Placement of the NEXT tts_c_runner_from_file on the calling thread (host/common.h tts_load_options): device (< 0: TTS_HIP_DEVICE or
+ * 0), lock-step KV slots (0: TTS_HIP_MAX_SEQS or 1), declare_only != 0: lay the model out without uploading its bytes — the weights
+ * then arrive in tts_hip_arena_ptr(tts_c_runner_device_context(r)) by a collective and tts_hip_arena_filled() marks them present. */
+void          tts_c_set_load_options(int device, int max_seqs, int declare_only);
+/* the runner's tts_hip_ctx* (include/tts_hip.h: arena, profiling), or NULL when the architecture keeps several contexts */
+void         *tts_c_runner_device_context(tts_c_runner *r);
+/* the loaded runner's own tokenizer (Parler: unigram ids + EOS as batch_from_sentence builds them); returns the id count */
+int           tts_c_runner_tokenize(tts_c_runner *r, const char *text, uint32_t *out, int cap);
 float         tts_c_sampling_rate(tts_c_runner *r);
 const char   *tts_c_arch(tts_c_runner *r);
 void          tts_c_free(tts_c_runner *r);

@@ -91,6 +91,30 @@ int tts_c_update_conditional_prompt(tts_c_runner * r, const char * text_encoder_
     }
 }
 
+void tts_c_set_load_options(int device, int max_seqs, int declare_only) {
+    tts_load_options & o = tts_thread_load_options();
+    o = tts_load_options{};
+    o.device = device;
+    o.max_seqs = max_seqs;
+    o.declare_only = declare_only != 0;
+}
+void * tts_c_runner_device_context(tts_c_runner * r) { return r ? ((tts_generation_runner *) r)->device_context() : nullptr; }
+int tts_c_runner_tokenize(tts_c_runner * r, const char * text, uint32_t * out, int cap) {
+    g_tts_throw_on_abort = true;
+    try {
+        auto * p = dynamic_cast<parler_runner *>((tts_generation_runner *) r);
+        if (!p) { g_c_err = "tts_c_runner_tokenize: only the Parler runner exposes its tokenizer"; return -1; }
+        std::vector<uint32_t> ids;
+        p->tokenizer->tokenize(text, ids);
+        ids.push_back(p->tokenizer->eos_token);
+        const int n = (int) ids.size();
+        copy_u32(out, ids.data(), (size_t) (n < cap ? n : cap));
+        return n;
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return -1;
+    }
+}
 float        tts_c_sampling_rate(tts_c_runner * r) { return ((tts_generation_runner *) r)->sampling_rate; }
 const char * tts_c_arch(tts_c_runner * r) { return ((tts_generation_runner *) r)->loader.get().arch; }
 void         tts_c_free(tts_c_runner * r) { delete (tts_generation_runner *) r; }

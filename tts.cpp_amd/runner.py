@@ -28,7 +28,7 @@ class SamplerCfg(C.Structure):
 
 EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_generate_batch", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
            "tts_c_last_error", "tts_c_update_conditional_prompt", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor",
-           "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_load_stats", "tts_c_pool_free",
+           "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_load_stats", "tts_c_pool_free", "tts_c_set_load_options", "tts_c_runner_device_context", "tts_c_runner_tokenize",
            "tts_c_quantize_gguf", "tts_c_quantize_decision", "tts_c_quantize_rows",
            "tts_c_dia_tokenize", "tts_c_dia_check_stopping", "tts_c_dia_adjust_output_tokens", "tts_c_single_pass_tokenize", "tts_c_kokoro_chunks"]
 
@@ -90,6 +90,11 @@ def load_lib():
         L.tts_c_pool_load_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.tts_c_pool_load_stats.restype = None
         L.tts_c_pool_free.argtypes = [C.c_void_p]
+        L.tts_c_set_load_options.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.tts_c_set_load_options.restype = None
+        L.tts_c_runner_device_context.argtypes = [C.c_void_p]
+        L.tts_c_runner_device_context.restype = C.c_void_p
+        L.tts_c_runner_tokenize.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.c_int]
         L.tts_c_pool_free.restype = None
         _lib = L
     return _lib
@@ -106,10 +111,15 @@ def make_config(**kw):
 class Runner:
     """runner_from_file() + generate(), as examples/cli/cli.cpp:79-95 uses them."""
 
-    def __init__(self, path, n_threads=1, cpu_only=True, **cfg):
+    def __init__(self, path, n_threads=1, cpu_only=True, device=-1, max_seqs=0, declare_only=False, **cfg):
         self.L = load_lib()
         self.cfg = make_config(**cfg)
-        self.h = self.L.tts_c_runner_from_file(path.encode(), n_threads, C.byref(self.cfg), 1 if cpu_only else 0)
+        if device >= 0 or max_seqs > 0 or declare_only:
+            self.L.tts_c_set_load_options(device, max_seqs, 1 if declare_only else 0)   # tts_load_options of this thread, for this load
+        try:
+            self.h = self.L.tts_c_runner_from_file(path.encode(), n_threads, C.byref(self.cfg), 1 if cpu_only else 0)
+        finally:
+            self.L.tts_c_set_load_options(-1, 0, 0)
         if not self.h:
             raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
 
@@ -138,6 +148,28 @@ class Runner:
         if self.L.tts_c_generate_batch(self.h, arr, n, C.byref(c), data, ns) != 0:
             raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
         return [np.ctypeslib.as_array(data[i], shape=(ns[i],)).copy() if ns[i] else np.zeros(0, dtype=np.float32) for i in range(n)]
+
+    def generate_batch_sizes(self, texts, **cfg):
+        """tts_c_generate_batch without copying the audio out of the runner-owned buffer: samples per utterance"""
+        c = make_config(**cfg) if cfg else self.cfg
+        n = len(texts)
+        arr = (C.c_char_p * n)(*[t.encode("utf-8") for t in texts])
+        data = (C.POINTER(C.c_float) * n)()
+        ns = (C.c_size_t * n)()
+        if self.L.tts_c_generate_batch(self.h, arr, n, C.byref(c), data, ns) != 0:
+            raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
+        return [int(ns[i]) for i in range(n)]
+
+    def tokenize(self, text):
+        n = self.L.tts_c_runner_tokenize(self.h, text.encode("utf-8"), None, 0)
+        if n < 0:
+            raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        self.L.tts_c_runner_tokenize(self.h, text.encode("utf-8"), out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+        return out[:n]
+
+    def device_context(self):
+        return self.L.tts_c_runner_device_context(self.h)
 
     def update_conditional_prompt(self, text_encoder_path, prompt):
         if self.L.tts_c_update_conditional_prompt(self.h, text_encoder_path.encode(), prompt.encode("utf-8")) != 0:
