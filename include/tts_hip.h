@@ -257,6 +257,8 @@ typedef struct tts_hip_dia_desc {
     uint32_t max_gen;           /* dia.decoder.max_generation_size (3072) self-attention cache positions  */
     float    cfg_scale;         /* dia.cfg_scale (3.0, model.h:82); 0 = that                             */
     uint32_t flags;             /* TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q */
+    uint32_t max_utterances;    /* extension: utterances decoded in lock-step (each is the reference's batch of 2 guidance streams,
+                                   dia/model.cpp:330-341); 0 = 1.  Rows of a step = 2 x utterances */
 } tts_hip_dia_desc;
 tts_hip_ctx *tts_hip_dia_create(int device, const tts_hip_dia_desc *desc);
 /* tokens [max_ctx]: the sentence bytes then zeros; the all-zero second stream is added here (:700-703).  Fills the cross
@@ -268,6 +270,15 @@ int tts_hip_dia_encode(tts_hip_ctx *ctx, const uint32_t *tokens, uint32_t senten
  * logits_out [n_output_heads][output_vocab_size]: cond + cfg_scale * (cond - uncond) (util.cpp:194-196);
  * raw_out (may be NULL): [2][n_output_heads][output_vocab_size] conditional, unconditional. */
 int tts_hip_dia_step(tts_hip_ctx *ctx, const uint32_t *ids, uint32_t pos, float *logits_out, float *raw_out);
+/* Lock-step utterances (BASELINE config 3: batch 32 = 4 utterances per GPU x 8 GPUs; SURVEY.md §8e: M = 8 rows per GPU).  The
+ * reference decodes one utterance = 2 guidance rows per graph (:330-341, :705-721); here utterance slot u owns rows 2u (text) and
+ * 2u+1 (all-zero twin) of every cache, tts_hip_dia_encode_slot fills its cross K/V, and one step carries the rows of n_utt slots:
+ * ids [n_utt][n_output_heads], pos [n_utt] (a slot that has finished keeps stepping on its last position; its rows are ignored by
+ * the host), slots [n_utt] or NULL (= 0..n_utt-1), logits_out [n_utt][n_output_heads][vocab] guided, raw_out (may be NULL)
+ * [n_utt][2][n_output_heads][vocab].  tts_hip_dia_encode / _step are the slot-0, one-utterance forms. */
+int tts_hip_dia_encode_slot(tts_hip_ctx *ctx, uint32_t slot, const uint32_t *tokens, uint32_t sentence_len, float *enc_out);
+int tts_hip_dia_step_batch(tts_hip_ctx *ctx, uint32_t n_utt, const uint32_t *slots, const uint32_t *ids, const uint32_t *pos,
+                           float *logits_out, float *raw_out);
 
 /* ---- Kokoro (src/models/kokoro/model.cpp) ----------------------------------------------------------------------------
  * Device side of kokoro_duration_runner::run (:1069-1123) and kokoro_runner::run (:1277-1325): create, tts_hip_upload every

@@ -62,7 +62,8 @@ class M:
 
 
 m = M(); m.cfg = cfg; m.tensors = tensors
-eng = hip.DiaEngine(cfg)
+U = int(os.environ.get('DIA_BENCH_UTTERANCES', '4'))   # BASELINE config 3: 4 utterances per GPU (x 2 guidance rows)
+eng = hip.DiaEngine(cfg, max_utterances=U)
 t0 = time.perf_counter()
 eng.load(m)
 print(f"loaded {sum(len(t.raw()) for t in tensors) / 1e9:.2f} GB in {time.perf_counter() - t0:.1f}s", flush=True)
@@ -86,3 +87,18 @@ print(f"encode (2 x {cfg.max_ctx} positions, 12 layers + cross K/V of {cfg.dec_l
 print(f"decoder step at positions 4..{4 + steps}: {step * 1e3:.3f} ms = {1 / step:.0f} steps/s = {1 / step / 86.13:.2f}x real time (86.13 frames/s)")
 print(f"bytes per step: fp16 matrices {w_bytes / 1e9:.3f} GB + cross K/V {ckv_bytes / 1e9:.3f} GB -> {(w_bytes + ckv_bytes) / step / 1e9:.0f} GB/s "
       f"({(w_bytes + ckv_bytes) / step / 8e12 * 100:.1f}% of 8 TB/s; floor {(w_bytes + ckv_bytes) / 8e12 * 1e3:.3f} ms/step)")
+
+# ---- lock-step utterances (BASELINE config 3: 32 utterances over 8 GPUs = 4 per GPU, M = 8 rows per step) ----
+for u in range(U):
+    eng.encode_slot(u, toks, 200)
+idsb = np.full((U, cfg.n_out), cfg.bos, dtype=np.uint32)
+for s in range(4):
+    eng.step_batch(idsb, np.full(U, s, dtype=np.uint32))
+t0 = time.perf_counter()
+for s in range(4, 4 + steps):
+    eng.step_batch(idsb, np.full(U, s, dtype=np.uint32))
+stepb = (time.perf_counter() - t0) / steps
+tot = w_bytes + U * ckv_bytes
+print(f"{U} utterances in lock-step ({2 * U} rows): {stepb * 1e3:.3f} ms per step = {U / stepb:.0f} utterance-steps/s = {U / stepb / 86.13:.2f}x real time per GPU")
+print(f"bytes per step: fp16 matrices {w_bytes / 1e9:.3f} GB + {U} x cross K/V {ckv_bytes / 1e9:.3f} GB -> {tot / stepb / 1e9:.0f} GB/s "
+      f"({tot / stepb / 8e12 * 100:.1f}% of 8 TB/s; floor {tot / 8e12 * 1e3:.3f} ms/step)")

@@ -102,3 +102,91 @@ def test_dia_runner_generates_through_both_contexts(tmp_path):
     with pytest.raises(runner.RunnerError):
         r.generate(text, sample=0, max_tokens=7)                    # GGML_ASSERT(max_tokens == 0 || max_tokens > max_delay)
     r.close()
+
+
+@pytest.mark.parametrize("wtype,tol", [(gguf.F32, 2e-4), (gguf.F16, 2e-3)])
+def test_dia_lockstep_batch_of_4_equals_4_single_oracles(wtype, tol):
+    """BASELINE config 3's per-GPU unit: 4 utterances x 2 guidance rows in one step (tts_hip_dia_step_batch), each utterance with
+    its own sentence (cross K/V slot), ids and position; every utterance must equal a stand-alone oracle of that utterance.
+    Utterance 2 starts two steps late (its position lags), utterance 3 sits in a non-contiguous slot order."""
+    model = synth.build_dia(synth.dia_tiny(weight_type=wtype))
+    cfg = model.cfg
+    eng = hip.DiaEngine(cfg, max_utterances=4)
+    eng.load(model)
+    texts = ["[S1] first one.", "[S2] the second is long.", "[S1] hi.", "[S1] a [S2] b [S1] c."]   # <= 24 characters (tiny max_ctx) once the tags are single bytes
+    slots = [0, 1, 3, 2]
+    oracles, rng = [], np.random.default_rng(11)
+    for s, t in zip(slots, texts):
+        toks, n = orc.dia_tokenize(t, cfg.max_ctx)
+        eng.encode_slot(s, toks, n)
+        o = orc.DiaOracle(model, act_mode=1)
+        o.encode(toks, n)
+        oracles.append(o)
+    pos = np.zeros(4, dtype=np.uint32)
+    ids = np.full((4, cfg.n_out), cfg.bos, dtype=np.uint32)
+    for step in range(6):
+        active = [u for u in range(4) if not (u == 2 and step < 2)]      # utterance 2 joins at step 2
+        lg, raw = eng.step_batch(ids[active], pos[active], slots=[slots[u] for u in active], want_raw=True)
+        for k, u in enumerate(active):
+            ref, ref_raw = oracles[u].step(ids[u], int(pos[u]), want_raw=True)
+            assert relerr(raw[k], ref_raw) < tol, (step, u)
+            assert relerr(lg[k], ref) < 4 * tol, (step, u)
+            ids[u] = rng.integers(0, cfg.audio_vocab, cfg.n_out)        # the same (arbitrary) ids on both sides
+            pos[u] += 1
+    with pytest.raises(hip.HipError):
+        eng.step_batch(ids[:1], pos[:1], slots=[4])                     # slot outside max_utterances
+    eng.close()
+    one = hip.DiaEngine(cfg)                                            # a one-utterance context refuses a second slot
+    one.load(model)
+    with pytest.raises(hip.HipError):
+        one.encode_slot(1, *orc.dia_tokenize(texts[0], cfg.max_ctx))
+    one.close()
+
+
+def test_dia_runner_generate_batch_equals_separate_generates(tmp_path):
+    """dia_runner::generate_batch (4 utterances in lock-step, per-utterance countdown and un-delay) == 4 generate() calls, greedy:
+    token streams identical, audio equal"""
+    from tts_cpp_amd import runner
+    model = synth.build_dia(synth.dia_tiny(), suppress_special=True)
+    cfg = model.cfg
+    path = model.write_gguf(str(tmp_path / "dia.gguf"))
+    texts = [" Hi there [S2] ok", "[S1] another one.", "[S2] short", "[S1] the fourth one."]
+    r = runner.Runner(path, sample=0, max_seqs=4)
+    singles, toks = [], []
+    for t in texts:
+        singles.append(r.generate(t, sample=0, max_tokens=30))
+        toks.append(r.last_tokens(1).copy())
+    batch = r.generate_batch(texts, sample=0, max_tokens=30)
+    for b, s_ in zip(batch, singles):
+        assert b.shape == s_.shape and b.size > 0 and np.abs(b - s_).max() < 1e-5
+    with pytest.raises(runner.RunnerError):
+        r.generate_batch(texts + ["one too many"], sample=0, max_tokens=30)
+    r.close()
+
+
+def test_dia_1_6b_layer_shapes():
+    """one encoder and one decoder layer at nari-labs/Dia-1.6B's widths (encoder 1024 / ffn 4096 over 2 x 1024 positions, decoder
+    2048 with 16 query heads on 4 k/v groups x 128, ffn 8192, 9 x 1028 logits), fp16 matrices: BASELINE config 3's shapes,
+    two utterances in lock-step against per-utterance oracles"""
+    model = synth.build_dia(synth.dia_1_6b(enc_layers=1, dec_layers=1, max_gen=32, weight_type=gguf.F16))
+    cfg = model.cfg
+    eng = hip.DiaEngine(cfg, max_utterances=2)
+    eng.load(model)
+    texts = ["[S1] The birch canoe slid on the smooth planks.", "[S2] Glue the sheet to the dark blue background."]
+    oracles = []
+    for u, t in enumerate(texts):
+        toks, n = orc.dia_tokenize(t, cfg.max_ctx)
+        eng.encode_slot(u, toks, n)
+        o = orc.DiaOracle(model, act_mode=1)
+        o.encode(toks, n)
+        oracles.append(o)
+    ids = np.full((2, cfg.n_out), cfg.bos, dtype=np.uint32)
+    rng = np.random.default_rng(5)
+    for step in range(3):
+        lg, raw = eng.step_batch(ids, np.full(2, step, dtype=np.uint32), want_raw=True)
+        for u in range(2):
+            ref, ref_raw = oracles[u].step(ids[u], step, want_raw=True)
+            assert relerr(raw[u], ref_raw) < 2e-3, (step, u)
+            assert relerr(lg[u], ref) < 8e-3, (step, u)
+            ids[u] = rng.integers(0, cfg.audio_vocab, cfg.n_out)
+    eng.close()

@@ -10,27 +10,27 @@
 
 struct DiaEmbedArgs {
     const float *table[16];   // [V][H] fp32 each
-    const uint32_t *ids;      // [n_out]
+    const uint32_t *ids;      // [n_utt][n_out]
     int n_out, H;
-    float *x;                 // [2][H]
+    float *x;                 // [2 * n_utt][H]: rows 2u (text stream) and 2u+1 (all-zero twin) of utterance u get the same embedding
 };
 
 __global__ __launch_bounds__(256) void dia_embed_kernel(DiaEmbedArgs a) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.x * 256 + threadIdx.x, u = blockIdx.y;
     if (e >= a.H) return;
     float acc = 0.0f;
     for (int i = 0; i < a.n_out; i++) {   // embds[0] first, then embds[i] + running (:343-347)
-        const float v = a.table[i][(int64_t) a.ids[i] * a.H + e];
+        const float v = a.table[i][(int64_t) a.ids[u * a.n_out + i] * a.H + e];
         acc = i == 0 ? v : v + acc;
     }
-    a.x[e] = acc;
-    a.x[a.H + e] = acc;
+    a.x[(int64_t) (2 * u) * a.H + e] = acc;
+    a.x[(int64_t) (2 * u + 1) * a.H + e] = acc;
 }
 
-// raw [2][ld] (ld >= n: the fused heads are padded to a multiple of 16 rows) -> guided [n]
+// raw [2 * n_utt][ld] (ld >= n: the fused heads are padded to a multiple of 16 rows) -> guided [n_utt][n]; blockIdx.y = utterance
 __global__ __launch_bounds__(256) void dia_cfg_kernel(const float *raw, int ld, int n, float scale, float *guided) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x, u = blockIdx.y;
     if (i >= n) return;
-    const float cr = raw[i], ur = raw[ld + i];
-    guided[i] = cr + scale * (cr - ur);
+    const float cr = raw[(int64_t) (2 * u) * ld + i], ur = raw[(int64_t) (2 * u + 1) * ld + i];
+    guided[(int64_t) u * n + i] = cr + scale * (cr - ur);
 }

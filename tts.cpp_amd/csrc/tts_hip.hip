@@ -234,7 +234,9 @@ struct tts_hip_ctx {
     float *di_logits = nullptr, *di_guided = nullptr;
     uint32_t *di_tok = nullptr, *di_epos = nullptr, *di_eseq = nullptr, *di_kbeg = nullptr, *di_kend = nullptr;
     uint32_t *di_ids = nullptr, *di_pos = nullptr, *di_seq = nullptr, *di_cend = nullptr;
-    bool di_encoded = false;
+    int di_U = 1;                        // utterance slots (rows = 2 per slot)
+    std::vector<uint8_t> di_slot_encoded;   // tts_hip_dia_encode_slot has run for the slot
+    uint32_t *h_di = nullptr;            // pinned staging: ids / pos / seq of a step
     // ---- Kokoro context (tts_hip_kokoro_create) ----
     bool has_kokoro = false;
     tts_hip_kokoro_desc ko{};
@@ -407,6 +409,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     if (c->h_tok) (void) hipHostFree(c->h_tok);
     if (c->h_logits) (void) hipHostFree(c->h_logits);
     if (c->h_pcm) (void) hipHostFree(c->h_pcm);
+    if (c->h_di) (void) hipHostFree(c->h_di);
     for (auto &e : c->prof_events) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
     (void) hipStreamDestroy(c->stream);
     if (c->dac_stream) (void) hipStreamDestroy(c->dac_stream);
@@ -1603,23 +1606,26 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->di_ex, n * EH)); CHK(dmalloc(&c->di_exn, n * EH)); CHK(dmalloc(&c->di_eqkv, n * 3 * A)); CHK(dmalloc(&c->di_eatt, n * A));
         CHK(dmalloc(&c->di_egu, n * 2 * EF)); CHK(dmalloc(&c->di_eg, n * EF)); CHK(dmalloc(&c->di_ek, n * A)); CHK(dmalloc(&c->di_ev, n * A));
         CHK(dmalloc(&c->di_ckv, n * 2 * A));
-        CHK(dmalloc(&c->di_ck, (size_t) c->L * n * A));   // zero like the reference's cleared cache (dia/model.cpp:329)
-        CHK(dmalloc(&c->di_cv, (size_t) c->L * n * A));
-        CHK(dmalloc(&c->di_k, (size_t) c->L * 2 * G * kvH));
-        CHK(dmalloc(&c->di_v, (size_t) c->L * 2 * G * kvH));
-        CHK(dmalloc(&c->di_x, (size_t) 2 * DH)); CHK(dmalloc(&c->di_xn, (size_t) 2 * DH)); CHK(dmalloc(&c->di_qkv, (size_t) 2 * (A + 2 * kvH)));
-        CHK(dmalloc(&c->di_q, (size_t) 2 * A)); CHK(dmalloc(&c->di_att, (size_t) 2 * A)); CHK(dmalloc(&c->di_gu, (size_t) 2 * 2 * DF)); CHK(dmalloc(&c->di_g, (size_t) 2 * DF));
+        const int U = std::max(1, std::min((int) dd.max_utterances, 64)), R = 2 * U;
+        c->di_U = U;
+        c->di_slot_encoded.assign((size_t) U, 0);
+        CHK(dmalloc(&c->di_ck, (size_t) c->L * U * n * A));   // [L][2U][S][A], zero like the reference's cleared cache (dia/model.cpp:329)
+        CHK(dmalloc(&c->di_cv, (size_t) c->L * U * n * A));
+        CHK(dmalloc(&c->di_k, (size_t) c->L * R * G * kvH));  // [L][2U][G][kvH]
+        CHK(dmalloc(&c->di_v, (size_t) c->L * R * G * kvH));
+        CHK(dmalloc(&c->di_x, (size_t) R * DH)); CHK(dmalloc(&c->di_xn, (size_t) R * DH)); CHK(dmalloc(&c->di_qkv, (size_t) R * (A + 2 * kvH)));
+        CHK(dmalloc(&c->di_q, (size_t) R * A)); CHK(dmalloc(&c->di_att, (size_t) R * A)); CHK(dmalloc(&c->di_gu, (size_t) R * 2 * DF)); CHK(dmalloc(&c->di_g, (size_t) R * DF));
         CHK(dmalloc(&c->di_parts, (size_t) 8 * c->RMAX * DH));
-        CHK(dmalloc(&c->di_logits, (size_t) 2 * c->di_Vpad)); CHK(dmalloc(&c->di_guided, (size_t) c->NO * c->di_V));
+        CHK(dmalloc(&c->di_logits, (size_t) R * c->di_Vpad)); CHK(dmalloc(&c->di_guided, (size_t) U * c->NO * c->di_V));
         const int maxK = std::max(std::max(EH, EF), std::max(std::max(DH, DF), A));
         CHK(dmalloc(&c->dbg, (size_t) c->RMAX * maxK));
         CHK(dmalloc(&c->aq, (size_t) c->RMAX * maxK));
         CHK(dmalloc(&c->ad, (size_t) c->RMAX * maxK / 32 + 1));
         CHK(dmalloc(&c->di_tok, n)); CHK(dmalloc(&c->di_epos, n)); CHK(dmalloc(&c->di_eseq, n)); CHK(dmalloc(&c->di_kbeg, n)); CHK(dmalloc(&c->di_kend, n));
-        CHK(dmalloc(&c->di_ids, (size_t) 16)); CHK(dmalloc(&c->di_pos, (size_t) 2)); CHK(dmalloc(&c->di_seq, (size_t) 2)); CHK(dmalloc(&c->di_cend, (size_t) 2));
-        const uint32_t seq01[2] = {0u, 1u}, cend[2] = {(uint32_t) S, (uint32_t) S};
-        HIPCHK(hipMemcpy(c->di_seq, seq01, 8, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(c->di_cend, cend, 8, hipMemcpyHostToDevice));
+        CHK(dmalloc(&c->di_ids, (size_t) U * 16)); CHK(dmalloc(&c->di_pos, (size_t) R)); CHK(dmalloc(&c->di_seq, (size_t) R)); CHK(dmalloc(&c->di_cend, (size_t) R));
+        HIPCHK(hipHostMalloc((void **) &c->h_di, ((size_t) U * 16 + 2 * (size_t) R) * 4));
+        std::vector<uint32_t> cend((size_t) R, (uint32_t) S);
+        HIPCHK(hipMemcpy(c->di_cend, cend.data(), (size_t) R * 4, hipMemcpyHostToDevice));
     }
     if (c->has_t5) {
         const int H = c->H, F = c->F, S = (int) c->t5.max_ctx_length;
@@ -2874,8 +2880,9 @@ static int dia_rms(tts_hip_ctx *c, size_t w_off, int rows, int H, float *x, floa
     return hipGetLastError() == hipSuccess ? 0 : set_err("rms_fold_rows_kernel launch failed");
 }
 
-extern "C" int tts_hip_dia_encode(tts_hip_ctx *c, const uint32_t *tokens, uint32_t sentence_len, float *enc_out) {
+extern "C" int tts_hip_dia_encode_slot(tts_hip_ctx *c, uint32_t slot, const uint32_t *tokens, uint32_t sentence_len, float *enc_out) {
     if (!c || !c->has_dia) return set_err("tts_hip_dia_encode: not a Dia context (tts_hip_dia_create)");
+    if (slot >= (uint32_t) c->di_U) return set_err("tts_hip_dia_encode_slot: slot %u outside the %d utterance slots of this context (max_utterances)", slot, c->di_U);
     if (!c->finalized || !c->weights_present) return set_err("tts_hip_dia_encode: context not finalized");
     if (!tokens) return set_err("tts_hip_dia_encode: null argument");
     const int S = (int) c->dia.max_ctx, EH = c->di_EH, EF = c->di_EF, A = c->di_A, HD = (int) c->dia.head_dim, ENH = (int) c->dia.enc_attn_heads;
@@ -2930,7 +2937,7 @@ extern "C" int tts_hip_dia_encode(tts_hip_ctx *c, const uint32_t *tokens, uint32
     // positions) only for the sentence; the other K rows are zero as in the freshly cleared cache
     for (int l = 0; l < c->L; l++) {
         const auto &y = c->di_dec[(size_t) l];
-        float *ck = c->di_ck + (size_t) l * n * A, *cv = c->di_cv + (size_t) l * n * A;
+        float *ck = c->di_ck + ((size_t) l * c->di_U + slot) * n * A, *cv = c->di_cv + ((size_t) l * c->di_U + slot) * n * A;   // rows 2*slot, 2*slot+1
         CHK(dia_gemm(c, y.ckv, c->di_exn, EH, c->di_ckv, 2 * A, n, EPI_STORE));
         hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH), dim3(64), 0, c->stream, c->di_ckv, (const uint32_t *) c->di_epos, (const float *) nullptr, theta_scale, 0, NH,
                            HD, ck, cv, (const uint32_t *) c->di_eseq, (int64_t) S * A);
@@ -2941,25 +2948,42 @@ extern "C" int tts_hip_dia_encode(tts_hip_ctx *c, const uint32_t *tokens, uint32
     }
     if (enc_out) HIPCHK(hipMemcpyAsync(enc_out, c->di_exn, (size_t) n * EH * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->di_encoded = true;
+    c->di_slot_encoded[slot] = 1;
     return 0;
 }
 
-extern "C" int tts_hip_dia_step(tts_hip_ctx *c, const uint32_t *ids, uint32_t pos, float *logits_out, float *raw_out) {
+extern "C" int tts_hip_dia_encode(tts_hip_ctx *c, const uint32_t *tokens, uint32_t sentence_len, float *enc_out) {
+    return tts_hip_dia_encode_slot(c, 0, tokens, sentence_len, enc_out);
+}
+
+extern "C" int tts_hip_dia_step_batch(tts_hip_ctx *c, uint32_t n_utt, const uint32_t *slots, const uint32_t *ids, const uint32_t *pos, float *logits_out,
+                                      float *raw_out) {
     if (!c || !c->has_dia) return set_err("tts_hip_dia_step: not a Dia context (tts_hip_dia_create)");
     if (!c->finalized || !c->weights_present) return set_err("tts_hip_dia_step: context not finalized");
-    if (!c->di_encoded) return set_err("tts_hip_dia_step: tts_hip_dia_encode has not run");
-    if (!ids || !logits_out) return set_err("tts_hip_dia_step: null argument");
+    if (!ids || !pos || !logits_out) return set_err("tts_hip_dia_step: null argument");
+    if (n_utt == 0 || n_utt > (uint32_t) c->di_U) return set_err("tts_hip_dia_step_batch: %u utterances outside 1..%d (max_utterances)", n_utt, c->di_U);
     const int S = (int) c->dia.max_ctx, G = (int) c->dia.max_gen, DH = c->H, DF = c->di_DF, A = c->di_A, kvH = c->di_kvH, HD = (int) c->dia.head_dim;
     const int NH = c->NH, NKV = (int) c->dia.dec_kv_heads, NO = c->NO, V = c->di_V, QKV = A + 2 * kvH;
-    if (pos >= (uint32_t) G) return set_err("tts_hip_dia_step: position %u outside the %d cached positions", pos, G);
-    for (int i = 0; i < NO; i++)
-        if (ids[i] >= (uint32_t) V) return set_err("tts_hip_dia_step: id %u >= output vocabulary %d", ids[i], V);
+    const int U = (int) n_utt, R = 2 * U, RS = 2 * c->di_U;   // rows of this step, row slots of the caches
+    uint32_t max_pos = 0;
+    uint32_t *h_ids = c->h_di, *h_pos = c->h_di + (size_t) c->di_U * 16, *h_seq = h_pos + RS;
+    for (int u = 0; u < U; u++) {
+        const uint32_t slot = slots ? slots[u] : (uint32_t) u;
+        if (slot >= (uint32_t) c->di_U) return set_err("tts_hip_dia_step_batch: slot %u outside the %d utterance slots", slot, c->di_U);
+        if (!c->di_slot_encoded[slot]) return set_err("tts_hip_dia_step: tts_hip_dia_encode has not run%s", c->di_U > 1 ? " for this slot" : "");
+        if (pos[u] >= (uint32_t) G) return set_err("tts_hip_dia_step: position %u outside the %d cached positions", pos[u], G);
+        for (int i = 0; i < NO; i++) {
+            if (ids[u * NO + i] >= (uint32_t) V) return set_err("tts_hip_dia_step: id %u >= output vocabulary %d", ids[u * NO + i], V);
+            h_ids[u * NO + i] = ids[u * NO + i];
+        }
+        h_pos[2 * u] = h_pos[2 * u + 1] = pos[u];
+        h_seq[2 * u] = 2 * slot; h_seq[2 * u + 1] = 2 * slot + 1;
+        max_pos = std::max(max_pos, pos[u]);
+    }
     HIPCHK(hipSetDevice(c->device));
-    const uint32_t pp[2] = {pos, pos};
-    HIPCHK(hipMemcpyAsync(c->di_ids, ids, (size_t) NO * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->di_pos, pp, 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));  // pp is a local
+    HIPCHK(hipMemcpyAsync(c->di_ids, h_ids, (size_t) U * NO * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->di_pos, h_pos, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->di_seq, h_seq, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
     auto f32 = [&](size_t off) { return (const float *) (c->arena + off); };
     const float theta_scale = powf(10000.0f, -2.0f / (float) HD);
     static std::atomic<uint64_t> attr{0};
@@ -2968,56 +2992,60 @@ extern "C" int tts_hip_dia_step(tts_hip_ctx *c, const uint32_t *ids, uint32_t po
     DiaEmbedArgs ea{};
     for (int i = 0; i < NO; i++) ea.table[i] = f32(c->di_embd[i]);
     ea.ids = c->di_ids; ea.n_out = NO; ea.H = DH; ea.x = c->di_x;
-    hipLaunchKernelGGL(dia_embed_kernel, dim3((DH + 255) / 256), dim3(256), 0, c->stream, ea);
+    hipLaunchKernelGGL(dia_embed_kernel, dim3((DH + 255) / 256, U), dim3(256), 0, c->stream, ea);
     HIPCHK(hipGetLastError());
     c->di_pending = 0;
     const uint32_t *nul = nullptr;
     for (int l = 0; l < c->L; l++) {
         const auto &y = c->di_dec[(size_t) l];
-        float *kc = c->di_k + (size_t) l * 2 * G * kvH, *vc = c->di_v + (size_t) l * 2 * G * kvH;
-        const float *ck = c->di_ck + (size_t) l * 2 * S * A, *cv = c->di_cv + (size_t) l * 2 * S * A;
-        CHK(dia_rms(c, y.sa_norm, 2, DH, c->di_x, c->di_xn, true));
-        CHK(dia_gemm(c, y.sqkv, c->di_xn, DH, c->di_qkv, QKV, 2, EPI_STORE));
-        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(2, NH + NKV), dim3(64), 0, c->stream, c->di_qkv, (const uint32_t *) c->di_pos, (const float *) nullptr, theta_scale, NH,
+        float *kc = c->di_k + (size_t) l * RS * G * kvH, *vc = c->di_v + (size_t) l * RS * G * kvH;
+        const float *ck = c->di_ck + (size_t) l * RS * S * A, *cv = c->di_cv + (size_t) l * RS * S * A;
+        CHK(dia_rms(c, y.sa_norm, R, DH, c->di_x, c->di_xn, true));
+        CHK(dia_gemm(c, y.sqkv, c->di_xn, DH, c->di_qkv, QKV, R, EPI_STORE));
+        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(R, NH + NKV), dim3(64), 0, c->stream, c->di_qkv, (const uint32_t *) c->di_pos, (const float *) nullptr, theta_scale, NH,
                            NKV, HD, kc, vc, (const uint32_t *) c->di_seq, (int64_t) G * kvH);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, 2), dim3(256), (size_t) (128 + pos + 1) * 4, c->stream, (const float *) c->di_qkv, QKV,
+        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, R), dim3(256), (size_t) (128 + max_pos + 1) * 4, c->stream, (const float *) c->di_qkv, QKV,
                            (const uint32_t *) c->di_pos, (const float *) kc, (const float *) vc, NH, NKV, 1.0f, c->di_att, nul, nul, (const uint32_t *) c->di_seq,
                            (int64_t) G * kvH);
         HIPCHK(hipGetLastError());
-        CHK(dia_gemm(c, y.so, c->di_att, A, c->di_x, DH, 2, EPI_RESID));
-        CHK(dia_rms(c, y.ca_norm, 2, DH, c->di_x, c->di_xn, false));
-        CHK(dia_gemm(c, y.cq, c->di_xn, DH, c->di_q, A, 2, EPI_STORE));
-        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(2, NH), dim3(64), 0, c->stream, c->di_q, (const uint32_t *) c->di_pos, (const float *) nullptr, theta_scale, NH, 0, HD,
+        CHK(dia_gemm(c, y.so, c->di_att, A, c->di_x, DH, R, EPI_RESID));
+        CHK(dia_rms(c, y.ca_norm, R, DH, c->di_x, c->di_xn, false));
+        CHK(dia_gemm(c, y.cq, c->di_xn, DH, c->di_q, A, R, EPI_STORE));
+        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(R, NH), dim3(64), 0, c->stream, c->di_q, (const uint32_t *) c->di_pos, (const float *) nullptr, theta_scale, NH, 0, HD,
                            (float *) nullptr, (float *) nullptr, nul, (int64_t) 0);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, 2), dim3(256), (size_t) (128 + S) * 4, c->stream, (const float *) c->di_q, A, (const uint32_t *) c->di_pos, ck, cv,
+        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, R), dim3(256), (size_t) (128 + S) * 4, c->stream, (const float *) c->di_q, A, (const uint32_t *) c->di_pos, ck, cv,
                            NH, NH, 1.0f, c->di_att, nul, (const uint32_t *) c->di_cend, (const uint32_t *) c->di_seq, (int64_t) S * A);
         HIPCHK(hipGetLastError());
-        CHK(dia_gemm(c, y.co, c->di_att, A, c->di_x, DH, 2, EPI_RESID));
-        CHK(dia_rms(c, y.mlp_norm, 2, DH, c->di_x, c->di_xn, false));
-        CHK(dia_gemm(c, y.gu, c->di_xn, DH, c->di_gu, 2 * DF, 2, EPI_STORE));
-        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) 2 * DF + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->di_gu, DF, 2, c->di_g);
+        CHK(dia_gemm(c, y.co, c->di_att, A, c->di_x, DH, R, EPI_RESID));
+        CHK(dia_rms(c, y.mlp_norm, R, DH, c->di_x, c->di_xn, false));
+        CHK(dia_gemm(c, y.gu, c->di_xn, DH, c->di_gu, 2 * DF, R, EPI_STORE));
+        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) R * DF + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->di_gu, DF, R, c->di_g);
         HIPCHK(hipGetLastError());
         if (c->di_ksplit > 1) {
-            CHK(dia_gemm(c, y.out, c->di_g, DF, c->di_parts, DH, 2, EPI_STORE, c->di_ksplit));
+            CHK(dia_gemm(c, y.out, c->di_g, DF, c->di_parts, DH, R, EPI_STORE, c->di_ksplit));
             c->di_pending = c->di_ksplit;
         } else {
-            CHK(dia_gemm(c, y.out, c->di_g, DF, c->di_x, DH, 2, EPI_RESID));
+            CHK(dia_gemm(c, y.out, c->di_g, DF, c->di_x, DH, R, EPI_RESID));
         }
     }
-    CHK(dia_rms(c, c->di_dec_norm, 2, DH, c->di_x, c->di_xn, true));
+    CHK(dia_rms(c, c->di_dec_norm, R, DH, c->di_x, c->di_xn, true));
     GemmArgs g{};
-    g.R = 2; g.H = DH; g.A = c->di_xn; g.lda = DH; g.out = c->di_logits; g.ldo = c->di_Vpad;
+    g.R = R; g.H = DH; g.A = c->di_xn; g.lda = DH; g.out = c->di_logits; g.ldo = c->di_Vpad;
     CHK(run_gemm(c, TTS_HIP_K_GEMM_HEADS, c->di_heads, g, PRO_F32, EPI_STORE));
-    hipLaunchKernelGGL(dia_cfg_kernel, dim3((NO * V + 255) / 256), dim3(256), 0, c->stream, (const float *) c->di_logits, c->di_Vpad, NO * V, c->dia.cfg_scale, c->di_guided);
+    hipLaunchKernelGGL(dia_cfg_kernel, dim3((NO * V + 255) / 256, U), dim3(256), 0, c->stream, (const float *) c->di_logits, c->di_Vpad, NO * V, c->dia.cfg_scale, c->di_guided);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(logits_out, c->di_guided, (size_t) NO * V * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(logits_out, c->di_guided, (size_t) U * NO * V * 4, hipMemcpyDeviceToHost, c->stream));
     if (raw_out)
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < R; b++)
             HIPCHK(hipMemcpyAsync(raw_out + (size_t) b * NO * V, c->di_logits + (size_t) b * c->di_Vpad, (size_t) NO * V * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+extern "C" int tts_hip_dia_step(tts_hip_ctx *c, const uint32_t *ids, uint32_t pos, float *logits_out, float *raw_out) {
+    return tts_hip_dia_step_batch(c, 1, nullptr, ids, &pos, logits_out, raw_out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -61,7 +61,7 @@ class DiaDesc(C.Structure):
     """tts_hip_dia_desc (include/tts_hip.h)"""
     _fields_ = [(n, C.c_uint32) for n in ("struct_size", "enc_hidden_size", "enc_layers", "enc_attn_heads", "dec_hidden_size", "dec_layers", "dec_attn_heads",
                                           "dec_kv_heads", "head_dim", "n_output_heads", "output_vocab_size", "max_ctx", "max_gen")] + [
-        ("cfg_scale", C.c_float), ("flags", C.c_uint32)]
+        ("cfg_scale", C.c_float), ("flags", C.c_uint32), ("max_utterances", C.c_uint32)]
 
 
 class KokoroDesc(C.Structure):
@@ -83,7 +83,7 @@ EXPORTS = [
     "tts_hip_upload", "tts_hip_arena_bytes", "tts_hip_finalize", "tts_hip_arena_ptr", "tts_hip_arena_filled",
     "tts_hip_parler_set_text_encoding", "tts_hip_parler_reset", "tts_hip_parler_prefill", "tts_hip_parler_prefill_batch", "tts_hip_parler_step",
     "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits",
-    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_kokoro_create", "tts_hip_kokoro_durations", "tts_hip_kokoro_generate", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
+    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_dia_encode_slot", "tts_hip_dia_step_batch", "tts_hip_kokoro_create", "tts_hip_kokoro_durations", "tts_hip_kokoro_generate", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
     "tts_hip_synchronize", "tts_hip_broadcast_weights", "tts_hip_comm_unique_id", "tts_hip_broadcast_weights_rank",
 ]
@@ -147,6 +147,8 @@ def load_lib():
     L.tts_hip_dia_create.argtypes = [C.c_int, C.POINTER(DiaDesc)]
     L.tts_hip_dia_encode.argtypes = [vp, u32p, C.c_uint32, f32p]
     L.tts_hip_dia_step.argtypes = [vp, u32p, C.c_uint32, f32p, f32p]
+    L.tts_hip_dia_encode_slot.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, f32p]
+    L.tts_hip_dia_step_batch.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, f32p, f32p]
     L.tts_hip_snac_create.restype = vp
     L.tts_hip_snac_create.argtypes = [C.c_int, C.POINTER(SnacDesc)]
     L.tts_hip_snac_decode.argtypes = [vp, u32p, C.c_uint32, f32p, f32p]
@@ -535,10 +537,11 @@ class OrpheusEngine:
 class DiaEngine:
     """A Dia context (tts_hip_dia_create): encoder + cross K/V once per sentence, then one decoder step per call."""
 
-    def __init__(self, cfg, device=0, flags=0, cfg_scale=0.0):
+    def __init__(self, cfg, device=0, flags=0, cfg_scale=0.0, max_utterances=1):
         self.L = load_lib()
         self.cfg = cfg
         d = DiaDesc()
+        d.max_utterances = max_utterances
         d.struct_size = C.sizeof(DiaDesc)
         d.enc_hidden_size, d.enc_layers, d.enc_attn_heads = cfg.enc_hidden, cfg.enc_layers, cfg.enc_heads
         d.dec_hidden_size, d.dec_layers, d.dec_attn_heads, d.dec_kv_heads = cfg.dec_hidden, cfg.dec_layers, cfg.dec_heads, cfg.dec_kv_heads
@@ -565,6 +568,23 @@ class DiaEngine:
         out = np.empty((2, self.cfg.max_ctx, self.cfg.enc_hidden), dtype=np.float32) if want_states else None
         self._chk(self.L.tts_hip_dia_encode(self.ctx, ap, sentence_len, out.ctypes.data_as(C.POINTER(C.c_float)) if want_states else None))
         return out
+
+    def encode_slot(self, slot, tokens, sentence_len):
+        a, ap = _u32(tokens)
+        assert a.size == self.cfg.max_ctx
+        self._chk(self.L.tts_hip_dia_encode_slot(self.ctx, slot, ap, sentence_len, None))
+
+    def step_batch(self, ids, pos, slots=None, want_raw=False):
+        """ids [n_utt][n_out], pos [n_utt] -> guided logits [n_utt][n_out][vocab] (and raw [n_utt][2][n_out][vocab])"""
+        a, ap = _u32(np.asarray(ids).reshape(-1))
+        p, pp = _u32(pos)
+        n = p.size
+        sl = _u32(slots)[1] if slots is not None else None
+        lg = np.empty((n, self.cfg.n_out, self.cfg.out_vocab), dtype=np.float32)
+        raw = np.empty((n, 2, self.cfg.n_out, self.cfg.out_vocab), dtype=np.float32) if want_raw else None
+        self._chk(self.L.tts_hip_dia_step_batch(self.ctx, n, sl, ap, pp, lg.ctypes.data_as(C.POINTER(C.c_float)),
+                                                raw.ctypes.data_as(C.POINTER(C.c_float)) if want_raw else None))
+        return (lg, raw) if want_raw else lg
 
     def step(self, ids, pos, want_raw=False):
         a, ap = _u32(ids)

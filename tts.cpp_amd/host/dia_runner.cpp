@@ -73,6 +73,8 @@ dia_runner::dia_runner(const dia_hparams & hp_, int device) : tts_generation_run
     d.dec_kv_heads = hp.decoder_attn_heads / hp.decoder_query_heads;   // model.cpp:463: k/v are projected to attn_heads / query_heads groups
     d.head_dim = hp.head_size; d.n_output_heads = hp.n_output_heads; d.output_vocab_size = hp.output_vocab_size;
     d.max_ctx = hp.max_encoder_context_length; d.max_gen = hp.max_generation_size; d.cfg_scale = hp.cfg_scale;
+    max_seqs = tts_load_max_seqs();
+    d.max_utterances = max_seqs;
     lm = tts_hip_dia_create(device, &d);
     if (!lm) TTS_ABORT("tts_hip_dia_create failed: %s\n", tts_hip_last_error());
     tts_hip_desc a{};
@@ -202,4 +204,72 @@ void dia_runner::generate(const char * sentence, tts_response & output, const ge
     hip_check(tts_hip_dac_decode(dac, filtered.data(), frames, pcm.data()), "tts_hip_dac_decode");
     output.data = pcm.data();
     output.n_outputs = pcm.size();
+}
+
+void dia_runner::generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs, const generation_configuration & config) {
+    const uint32_t n = (uint32_t) sentences.size(), nh = hp.n_output_heads;
+    outputs.assign(n, tts_response{});
+    if (n == 0) return;
+    if (n > max_seqs) TTS_ABORT("generate_batch: %u utterances but the runner was loaded with max_seqs=%u (TTS_HIP_MAX_SEQS)\n", n, max_seqs);
+    if (!(config.max_tokens == 0 || config.max_tokens > (int) hp.max_delay)) TTS_ABORT("TTS_ASSERT(config.max_tokens == 0 || config.max_tokens > model->max_delay) failed\n");
+    uint32_t max_gen = config.max_tokens > (int) hp.max_delay ? (uint32_t) config.max_tokens : hp.max_generation_size;
+    if (max_gen > hp.max_generation_size) max_gen = hp.max_generation_size;
+
+    // per utterance: its own sampler state (n separate generate() calls would each reset and seed theirs), tokens, countdown
+    std::vector<sampler> smps(n, smp);
+    std::vector<std::vector<uint32_t>> prompts(n);
+    for (uint32_t u = 0; u < n; u++) {
+        sampler & s = smps[u];
+        s.temperature = config.temperature; s.repetition_penalty = config.repetition_penalty; s.do_sample = config.sample;
+        s.top_k = (uint32_t) config.top_k; s.top_p = config.top_p; s.seed = config.seed; s.n_calls = 0;
+        s.reset();
+        const uint32_t len = dia_tokenize_sentence(hp, sentences[u], prompts[u]);
+        hip_check(tts_hip_dia_encode_slot(lm, u, prompts[u].data(), len, nullptr), "tts_hip_dia_encode_slot");
+    }
+    last_batch_tokens.assign(n, {});
+    std::vector<std::vector<uint32_t>> audio(n, std::vector<uint32_t>(nh, hp.bos_token_id));
+    std::vector<uint32_t> pos(n, 0), ids((size_t) n * nh);
+    std::vector<int>      delay(n, -1);
+    std::vector<bool>     done(n, false);
+    std::vector<float>    lg((size_t) n * nh * hp.output_vocab_size);
+    for (;;) {
+        // check_stopping (:767-785) per utterance before each decode, as generate_from_batch's while condition (:817)
+        bool any = false;
+        for (uint32_t u = 0; u < n; u++) {
+            if (!done[u] && dia_check_stopping(hp, audio[u], pos[u], max_gen, delay[u])) done[u] = true;
+            any = any || !done[u];
+        }
+        if (!any) break;
+        for (uint32_t u = 0; u < n; u++) std::copy(audio[u].begin(), audio[u].end(), ids.begin() + (size_t) u * nh);
+        // a finished utterance keeps its rows in the step (lock-step shapes stay fixed); its logits are ignored and its position stays
+        hip_check(tts_hip_dia_step_batch(lm, n, nullptr, ids.data(), pos.data(), lg.data(), nullptr), "tts_hip_dia_step_batch");
+        for (uint32_t u = 0; u < n; u++) {
+            if (done[u]) continue;
+            std::vector<uint32_t> & out = last_batch_tokens[u];
+            smps[u].sample(lg.data() + (size_t) u * nh * hp.output_vocab_size, out);
+            pos[u] += 1;
+            const uint32_t * last = out.data() + out.size() - nh;
+            for (uint32_t i = 0; i < nh; i++) audio[u][i] = pos[u] > i ? last[i] : hp.bos_token_id;
+        }
+    }
+
+    std::vector<uint32_t> codes, frames(n);
+    for (uint32_t u = 0; u < n; u++) {
+        std::vector<uint32_t> f;
+        dia_adjust_output_tokens(hp, last_batch_tokens[u], f);
+        frames[u] = (uint32_t) (f.size() / nh);
+        codes.insert(codes.end(), f.begin(), f.end());
+    }
+    size_t total = 0;
+    for (uint32_t f : frames) total += (size_t) f * hp.up_sampling_factor;
+    pcm.assign(total, 0.0f);
+    // the codec context decodes the utterances one after the other into the shared buffer (its batch entry needs max_seqs slots)
+    size_t off = 0, coff = 0;
+    for (uint32_t u = 0; u < n; u++) {
+        if (frames[u]) hip_check(tts_hip_dac_decode(dac, codes.data() + coff, frames[u], pcm.data() + off), "tts_hip_dac_decode");
+        outputs[u].data = frames[u] ? pcm.data() + off : nullptr;
+        outputs[u].n_outputs = (size_t) frames[u] * hp.up_sampling_factor;
+        off += outputs[u].n_outputs;
+        coff += (size_t) frames[u] * nh;
+    }
 }

@@ -45,6 +45,14 @@ struct dia_runner final : tts_generation_runner {
     void assign_weight(const char * name, const gguf_tensor_view & tensor) override;
     void prepare_post_load() override;
     void generate(const char * sentence, tts_response & output, const generation_configuration & config) override;
+    // extension (BASELINE config 3: 4 utterances per GPU): n utterances in lock-step, each the reference's batch of two guidance streams
+    // (model.cpp:330-341); per-utterance sampler, check_stopping countdown and un-delay; one batched DAC pass.  Needs max_seqs >= n at
+    // load time (tts_load_options / TTS_HIP_MAX_SEQS).  Greedy results equal n separate generate() calls.
+    void generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs,
+                        const generation_configuration & config) override;
+    uint32_t batch_capacity() const override { return max_seqs; }
+    uint32_t max_seqs = 1;
+    std::vector<std::vector<uint32_t>> last_batch_tokens;
 
     std::vector<uint32_t> last_prompt_tokens, last_output_tokens;
 
