@@ -207,6 +207,9 @@ def main():
     ap.add_argument("--no-step-sweep", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--model", choices=["mini", "small", "tiny"], default="mini")
+    ap.add_argument("--workload", choices=["parler", "dia", "orpheus", "kokoro"], default="parler",
+                    help="parler (default) = BASELINE configs[1], the headline; dia / orpheus / kokoro = configs[3] / [4] / [2] at one GPU's share "
+                         "(profiles/secondary_bench.py: same JSON contract, measured through the C ABI engines)")
     ap.add_argument("--sample", action="store_true",
                     help="sampler::sample on the device (top_k 50, temperature 1, top_p 1: the reference's defaults) instead of greedy")
     ap.add_argument("--dac-wtype", choices=["f32", "f16"], default="f32",
@@ -215,6 +218,13 @@ def main():
                     help="GGUF type of the decoder matrices (headline: f16; q*: integer path with Q8_0 activations)")
     args = ap.parse_args()
 
+    if args.workload != "parler":
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        import secondary_bench
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise SystemExit("--workload dia/orpheus/kokoro measure one GPU's share; run them with --gpus 1")
+        print(json.dumps(secondary_bench.RUNNERS[args.workload](args)), flush=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

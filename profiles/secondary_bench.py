@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Bench lines for BASELINE configs 2-4 (`python bench.py --workload dia|orpheus|kokoro`): the same JSON contract as the headline
+workload (metric / value / unit / roofline / cpu_baseline), measured through the C ABI engines at the real model shapes with
+synthetic weights.  Timing does not depend on the weight values, so the big matrices are slices of small random pools (minting
+billions of normals in numpy would cost more box time than the runs).
+
+roofline here is the HBM roofline of the WHOLE decoder step (a step is a chain of ~250-350 short launches that stream the model once):
+achieved = algorithmic bytes one step must read / measured step time.  cpu_baseline = the oracle on a reduced number of layers,
+extrapolated linearly in the layer count (stated in `sample`)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tts_cpp_amd  # noqa: E402,F401
+from tts_cpp_amd import gguf, hip, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+
+
+class _Model:
+    def __init__(self, cfg, tensors):
+        self.cfg, self.tensors = cfg, tensors
+        self.by_name = {t.name: t for t in tensors}
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    return orc
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Dia-1.6B fp16 (configs[3]: 32 utterances over 8 GPUs = 4 per GPU in lock-step, 2 guidance rows each)
+# ------------------------------------------------------------------------------------------------------------------------------
+def dia_tensors(cfg, rng):
+    pool16 = (rng.standard_normal(1 << 25, dtype=np.float32) * np.float32(0.02)).astype(np.float16).view(np.uint8)
+    pool32 = (rng.standard_normal(1 << 22, dtype=np.float32) * np.float32(0.5)).view(np.uint8)
+    EH, DH, A, kvH = cfg.enc_hidden, cfg.dec_hidden, cfg.dec_heads * cfg.head_dim, cfg.dec_kv_heads * cfg.head_dim
+    tensors, n_dec = [], [0]
+
+    def mat(name, rows, cols):
+        n = rows * cols
+        tensors.append(gguf.Tensor(name, gguf.F16, [cols, rows], pool16[: n * 2]))
+        if ".decoder.layers." in name or ".heads." in name:
+            n_dec[0] += n
+
+    def vec(name, n):
+        tensors.append(gguf.Tensor.from_array(name, np.ones(n, dtype=np.float32)))
+
+    def table(name, rows, cols):
+        tensors.append(gguf.Tensor(name, gguf.F32, [cols, rows], pool32[: rows * cols * 4]))
+
+    for i in range(cfg.n_out):
+        table(f"dia.decoder.embeddings.{i}", cfg.out_vocab, DH)
+        mat(f"dia.decoder.heads.{i}", cfg.out_vocab, DH)
+    vec("dia.decoder.norm", DH)
+    for l in range(cfg.dec_layers):
+        p = f"dia.decoder.layers.{l}."
+        for nm in ("pre_sa_norm", "pre_ca_norm", "pre_mlp_norm"):
+            vec(p + nm, DH)
+        for nm, r, c in (("self_q_proj", A, DH), ("self_k_proj", kvH, DH), ("self_v_proj", kvH, DH), ("self_o_proj", DH, A), ("cross_q_proj", A, DH),
+                         ("cross_k_proj", A, EH), ("cross_v_proj", A, EH), ("cross_o_proj", DH, A), ("gate", cfg.dec_ffn, DH), ("up", cfg.dec_ffn, DH),
+                         ("wo", DH, cfg.dec_ffn)):
+            mat(p + nm, r, c)
+    table("dia.encoder.embedding", cfg.enc_vocab, EH)
+    vec("dia.encoder.norm", EH)
+    for l in range(cfg.enc_layers):
+        p = f"dia.encoder.layers.{l}."
+        vec(p + "pre_sa_norm", EH)
+        vec(p + "post_sa_norm", EH)
+        for nm, r, c in (("q_proj", A, EH), ("k_proj", A, EH), ("v_proj", A, EH), ("o_proj", EH, A), ("gate", cfg.enc_ffn, EH), ("up", cfg.enc_ffn, EH), ("wo", EH, cfg.enc_ffn)):
+            mat(p + nm, r, c)
+    return tensors, n_dec[0]
+
+
+def run_dia(args):
+    U = 4
+    steps = max(32, int(os.environ.get("TTS_BENCH_DIA_STEPS", "512")))
+    cfg = synth.dia_1_6b(weight_type=gguf.F16)
+    rng = np.random.default_rng(3)
+    tensors, n_dec = dia_tensors(cfg, rng)
+    eng = hip.DiaEngine(cfg, device=0, max_utterances=U)
+    eng.load(_Model(cfg, tensors))
+    toks = np.zeros(cfg.max_ctx, dtype=np.uint32)
+    toks[:200] = rng.integers(32, 127, 200)
+    A = cfg.dec_heads * cfg.head_dim
+    # the codec: Dia decodes through the same 44.1 kHz DAC as Parler (dia/model.cpp:892-898); a codec-only context
+    pm = synth.build(synth.parler_mini())
+    dac = hip.HipEngine(pm.cfg, device=0, max_seqs=1, flags=hip.FLAG_NO_PARLER)
+    for t in pm.tensors:
+        if t.name.startswith("audio_encoder."):
+            dac.upload(t)
+    dac.finalize()
+    delay = np.array([0, 8, 9, 10, 11, 12, 13, 14, 15])   # dia/model.h:84
+
+    def one_pass(n_steps):
+        """4 sentences -> encoder + cross K/V per slot -> n_steps guided decoder steps with the host arg-max (sampler::max) feeding back"""
+        t0 = time.perf_counter()
+        for u in range(U):
+            eng.encode_slot(u, toks, 200)
+        t1 = time.perf_counter()
+        ids = np.full((U, cfg.n_out), cfg.bos, dtype=np.uint32)
+        hist = np.empty((n_steps, U, cfg.n_out), dtype=np.uint32)
+        for s in range(n_steps):
+            lg = eng.step_batch(ids, np.full(U, s, dtype=np.uint32))
+            nxt = lg[:, :, :cfg.audio_vocab].argmax(-1).astype(np.uint32)
+            hist[s] = nxt
+            ids = np.where(np.arange(cfg.n_out)[None, :] <= s, nxt, cfg.bos).astype(np.uint32)
+        t2 = time.perf_counter()
+        # adjust_output_tokens (:787-808): frame i takes head h from step i + delay[h]; then one batched DAC pass
+        nf = n_steps - 15
+        codes = [np.stack([hist[np.arange(nf) + delay[h], u, h] for h in range(cfg.n_out)], axis=1) for u in range(U)]
+        pcm = dac.dac_decode_batch(codes)
+        assert sum(p.size for p in pcm) == U * nf * 512
+        return t1 - t0, t2 - t1, time.perf_counter() - t2
+
+    for _ in range(args.warmup):
+        one_pass(24)
+    enc_s, dec_s, dac_s = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        e, d, k = one_pass(steps)
+        enc_s.append(e)
+        dec_s.append(d)
+        dac_s.append(k)
+    elapsed = time.perf_counter() - t0
+    step_ms = float(np.mean(dec_s)) / steps * 1e3
+    frames = steps - 15                      # un-delay drops max_delay steps (dia/model.cpp:787-808)
+    audio_s = U * frames * 512 / 44100.0 * args.steps
+    w_bytes = n_dec * 2
+    ckv_bytes = cfg.dec_layers * 2 * cfg.max_ctx * A * 4 * 2
+    tot = w_bytes + U * ckv_bytes
+    out = {
+        "metric": "audio-seconds/sec (Dia-1.6B fp16: encoder + guided decoder + DAC to 44.1 kHz PCM, lock-step utterances)",
+        "value": round(audio_s / elapsed, 3), "unit": "audio-seconds/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+        "data": "synthetic (fp16 matrices = slices of one random pool; shapes of nari-labs/Dia-1.6B)",
+        "config": {"workload": f"configs[3]: Dia-1.6B fp16, the per-GPU share of batch 32 over 8 GPUs = {U} utterances in lock-step x 2 guidance rows, "
+                               f"200-character sentences (encoder over 2 x 1024 positions + cross K/V per utterance), {steps} guided decoder steps with the host "
+                               "arg-max, un-delay, one batched DAC pass to PCM",
+                   "utterances_per_gpu": U, "rows_per_step": 2 * U, "decoder_steps": steps, "parallelism": "dp1 of dp8 (utterances are independent)"},
+        "ms_per_decode_step": round(step_ms, 4), "encode_ms_per_utterance": round(float(np.mean(enc_s)) / U * 1e3, 2),
+        "dac_ms_per_pass": round(float(np.mean(dac_s)) * 1e3, 2),
+        "x_real_time_per_gpu": round(U / (step_ms * 1e-3) / 86.13, 2),
+        "roofline": {"bound": "hbm", "achieved": round(tot / (step_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(tot / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "whole decoder step (18 layers x 14 launches: gemm16_kernel, attn_gqa_kernel<128>, rms_fold_rows_kernel, ...)",
+                     "algorithmic_bytes_per_launch": tot, "note": f"fp16 matrices {w_bytes / 1e9:.3f} GB + {U} x fp32 cross K/V {ckv_bytes / 1e9:.3f} GB per step"},
+    }
+    eng.close()
+    dac.close()
+    if not args.no_cpu_baseline:
+        orc = _oracle()
+        threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 32)
+        orc.lib().orc_set_threads(threads)
+        t = {}
+        for nl in (1, 2):
+            c2 = synth.dia_1_6b(weight_type=gguf.F16, dec_layers=nl, enc_layers=1, max_ctx=64, max_gen=16)
+            ts, _ = dia_tensors(c2, np.random.default_rng(3))
+            o = orc.DiaOracle(_Model(c2, ts), act_mode=1)
+            tk = np.zeros(c2.max_ctx, dtype=np.uint32)
+            tk[:40] = 65
+            o.encode(tk, 40)
+            ids = np.full(c2.n_out, c2.bos, dtype=np.uint32)
+            o.step(ids, 0)
+            t0 = time.perf_counter()
+            for s in range(1, 4):
+                o.step(ids, s)
+            t[nl] = (time.perf_counter() - t0) / 3
+        t_layer = max(t[2] - t[1], 1e-6)
+        t_full = (t[1] - t_layer) + cfg.dec_layers * t_layer
+        out["cpu_baseline"] = {"value": round(512 / 44100.0 / t_full, 4), "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
+                               "sample": "oracle decoder steps (one utterance = 2 guidance rows) at the 1.6B widths with 1 and 2 decoder layers and a 64-position "
+                                         f"encoder context, extrapolated linearly to {cfg.dec_layers} layers; encoder pass and codec excluded",
+                               "ms_per_decode_step": round(t_full * 1e3, 2)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Orpheus-3B Q4_0 (configs[4]); the SNAC codec is measured separately by tests/profiles (7 tokens per 2048-sample frame)
+# ------------------------------------------------------------------------------------------------------------------------------
+def orpheus_tensors(cfg, rng):
+    def q4(name, rows, cols):
+        nb = rows * cols // 32
+        b = rng.integers(0, 256, size=(nb, 18), dtype=np.uint8)
+        b[:, 0], b[:, 1] = 0x00, 0x1C          # d = 2^-8 as fp16
+        return gguf.Tensor("orpheus." + name, gguf.Q4_0, [cols, rows], b.reshape(-1))
+
+    def f32(name, arr):
+        return gguf.Tensor.from_array("orpheus." + name, np.asarray(arr, dtype=np.float32))
+
+    H, F, QH, KVH = cfg.hidden, cfg.ffn, cfg.heads * cfg.head_dim, cfg.kv_heads * cfg.head_dim
+    tensors = [q4("embed_tokens", cfg.vocab, H)]
+    per_layer = 0
+    for l in range(cfg.layers):
+        p = f"layers.{l}."
+        for nm, r, c in (("self_attn.q_proj", QH, H), ("self_attn.k_proj", KVH, H), ("self_attn.v_proj", KVH, H), ("self_attn.o_proj", H, QH),
+                         ("mlp.gate_proj", F, H), ("mlp.up_proj", F, H), ("mlp.down_proj", H, F)):
+            tensors.append(q4(p + nm, r, c))
+            per_layer += r * c if l == 0 else 0
+        tensors += [f32(p + "input_layernorm", np.ones(H)), f32(p + "post_attention_layernorm", np.ones(H))]
+    tensors += [f32("norm", np.ones(H)), q4("lm_head", cfg.vocab, H), f32("rope_frequencies", synth.llama3_rope_factors(cfg.head_dim))]
+    return tensors, per_layer
+
+
+def run_orpheus(args):
+    cfg = synth.orpheus_3b(ctx=1024, weight_type=gguf.Q4_0)
+    rng = np.random.default_rng(7)
+    tensors, per_layer = orpheus_tensors(cfg, rng)
+    eng = hip.OrpheusEngine(cfg)
+    eng.load(_Model(cfg, tensors))
+    prompt = rng.integers(0, cfg.vocab, 32).astype(np.uint32)
+    NO_STOP = 0xFFFFFFFF
+    n_tok = 448
+    for _ in range(max(1, args.warmup)):
+        eng.generate_greedy(prompt, 16, NO_STOP)
+    t0 = time.perf_counter()
+    ts = []
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        out_ids = eng.generate_greedy(prompt, n_tok, NO_STOP)
+        ts.append(time.perf_counter() - t1)
+        assert len(out_ids) == n_tok
+    elapsed = time.perf_counter() - t0
+    t64 = time.perf_counter()
+    eng.generate_greedy(prompt, 64, NO_STOP)
+    t64 = time.perf_counter() - t64
+    step = (float(np.mean(ts)) - t64) / (n_tok - 64)
+    params = cfg.layers * per_layer + cfg.vocab * cfg.hidden
+    q4_bytes = params / 32 * 18
+    audio_s = n_tok / 7 * 2048 / 24000.0 * args.steps
+    out = {
+        "metric": "audio-seconds/sec (Orpheus-3B Q4_0 decoder, greedy; SNAC codec not included)",
+        "value": round(audio_s / elapsed, 3), "unit": "audio-seconds/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8",
+        "dtype_detail": "Q4_0 matrices x Q8_0-quantised activations (ggml's vec_dot_q4_0_q8_0 semantics), integer block dots, fp16 block scales, f32 accumulate",
+        "data": "synthetic (random Q4_0 blocks with a fixed scale; shapes of canopylabs/orpheus-3b)",
+        "config": {"workload": f"configs[4]: Orpheus (Llama-3-3B backbone) Q4_0 on 1 x MI355X, one utterance: 32-token prompt (prefill) + {n_tok} greedy tokens "
+                               "(= 64 SNAC frames of 2048 samples at 24 kHz) through tts_hip_orpheus_generate_greedy (captured step, streaming Q4_0 GEMV kernels)",
+                   "tokens": n_tok, "parallelism": "dp1"},
+        "ms_per_decode_step": round(step * 1e3, 4), "x_real_time_per_gpu": round(1 / step / 7 * 2048 / 24000, 2),
+        "roofline": {"bound": "hbm", "achieved": round(q4_bytes / step / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(q4_bytes / step / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel": "whole decoder step (28 layers: gemv_q4_rows_kernel, rms norm, rope, attn_gqa_kernel<128>, arg-max over 156 940 logits)",
+                     "algorithmic_bytes_per_launch": q4_bytes, "note": "Q4_0 bytes of every matrix one step reads (lm_head included, one embedding row excluded)"},
+    }
+    eng.close()
+    if not args.no_cpu_baseline:
+        orc = _oracle()
+        threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 32)
+        orc.lib().orc_set_threads(threads)
+        t = {}
+        for nl in (1, 2):
+            c2 = synth.orpheus_3b(layers=nl, ctx=64, vocab=cfg.vocab, weight_type=gguf.Q4_0)
+            ts2, _ = orpheus_tensors(c2, np.random.default_rng(7))
+            o = orc.OrpheusOracle(_Model(c2, ts2), act_mode=1)
+            o.decode([5, 6, 7], 0)
+            t0 = time.perf_counter()
+            for s in range(3, 6):
+                o.decode([9], s)
+            t[nl] = (time.perf_counter() - t0) / 3
+        t_layer = max(t[2] - t[1], 1e-6)
+        t_full = (t[1] - t_layer) + cfg.layers * t_layer
+        out["cpu_baseline"] = {"value": round(2048 / 24000.0 / (7 * t_full), 4), "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
+                               "sample": f"oracle decode steps at the 3B widths with 1 and 2 layers (full 156 940-row lm_head), extrapolated linearly to {cfg.layers} layers; codec excluded",
+                               "ms_per_decode_step": round(t_full * 1e3, 2)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Kokoro-82M (configs[2]): duration graph + generation graph, forced durations for shape determinism
+# ------------------------------------------------------------------------------------------------------------------------------
+def run_kokoro(args):
+    model = synth.build_kokoro(synth.kokoro_82m())
+    eng = hip.KokoroEngine(model)
+    cfg = model.cfg
+    rng = np.random.default_rng(1)
+    res = {}
+    t_all0 = time.perf_counter()
+    audio_total = 0.0
+    timed = 0.0
+    for n_ids in (64, 400):
+        toks = np.concatenate([[0], rng.integers(1, cfg.vocab, n_ids), [0]]).astype(np.uint32)
+        forced = np.full(toks.size, 3.0, dtype=np.float32)
+        noise = rng.random((cfg.harmonic_num + 1) * int(forced.sum()) * cfg.up_sampling_factor, dtype=np.float32)
+        for _ in range(max(1, args.warmup)):
+            lens, hid = eng.durations(toks, cfg.voices[0])
+            eng.generate(toks, forced, hid, cfg.voices[0], noise)
+        td, tg = [], []
+        for _ in range(args.steps):
+            t0 = time.perf_counter()
+            lens, hid = eng.durations(toks, cfg.voices[0])
+            t1 = time.perf_counter()
+            pcm = eng.generate(toks, forced, hid, cfg.voices[0], noise)
+            t2 = time.perf_counter()
+            td.append(t1 - t0)
+            tg.append(t2 - t1)
+            audio_total += pcm.size / 24000.0
+            timed += t2 - t0
+        res[f"{n_ids}_ids"] = {"durations_ms": round(float(np.mean(td)) * 1e3, 2), "generation_ms": round(float(np.mean(tg)) * 1e3, 2),
+                               "audio_s": round(pcm.size / 24000.0, 2), "x_real_time": round(pcm.size / 24000.0 / (np.mean(td) + np.mean(tg)), 2)}
+    out = {
+        "metric": "audio-seconds/sec (Kokoro-82M: duration predictor + iSTFT vocoder path)",
+        "value": round(audio_total / timed, 3), "unit": "audio-seconds/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(timed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (seeded random weights at the shapes of hexgrad/Kokoro-82M)",
+        "config": {"workload": "configs[2]: Kokoro-82M on 1 x MI355X, 64 and 400 phoneme ids, durations forced to 3 frames per id for shape determinism; "
+                               "tts_hip_kokoro_durations + tts_hip_kokoro_generate (plain fp32 kernels: first device version)", "parallelism": "dp1"},
+        "by_length": res,
+        "roofline": None, "roofline_note": "no per-kernel roofline yet: the Kokoro kernels are the parity-first version (one thread per output), DESIGN.md §7",
+    }
+    eng.close()
+    if not args.no_cpu_baseline:
+        orc = _oracle()
+        o = orc.KokoroOracle(model)
+        toks = np.concatenate([[0], rng.integers(1, cfg.vocab, 16), [0]]).astype(np.uint32)
+        t0 = time.perf_counter()
+        lens, hid = o.durations(toks, cfg.voices[0])
+        forced = np.full(toks.size, 3.0, dtype=np.float32)
+        noise = rng.random(o.noise_len(int(forced.sum())), dtype=np.float32)
+        pcm = o.generate(toks, forced, hid, cfg.voices[0], noise)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(pcm.size / 24000.0 / dt, 4), "unit": "audio-seconds/sec", "cores": 1, "kind": "port",
+                               "sample": "oracle (oracle/kokoro_oracle.c, scalar C) on 16 phoneme ids x 3 frames, both graphs"}
+    return out
+
+
+RUNNERS = {"dia": run_dia, "orpheus": run_orpheus, "kokoro": run_kokoro}
+
+if __name__ == "__main__":
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workload", choices=sorted(RUNNERS))
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    a = ap.parse_args()
+    print(json.dumps(RUNNERS[a.workload](a)), flush=True)

@@ -263,13 +263,11 @@ void dia_runner::generate_batch(const std::vector<std::string> & sentences, std:
     size_t total = 0;
     for (uint32_t f : frames) total += (size_t) f * hp.up_sampling_factor;
     pcm.assign(total, 0.0f);
-    // the codec context decodes the utterances one after the other into the shared buffer (its batch entry needs max_seqs slots)
-    size_t off = 0, coff = 0;
+    if (total) hip_check(tts_hip_dac_decode_batch(dac, codes.data(), frames.data(), n, pcm.data()), "tts_hip_dac_decode_batch");   // one batched codec pass
+    size_t off = 0;
     for (uint32_t u = 0; u < n; u++) {
-        if (frames[u]) hip_check(tts_hip_dac_decode(dac, codes.data() + coff, frames[u], pcm.data() + off), "tts_hip_dac_decode");
         outputs[u].data = frames[u] ? pcm.data() + off : nullptr;
         outputs[u].n_outputs = (size_t) frames[u] * hp.up_sampling_factor;
         off += outputs[u].n_outputs;
-        coff += (size_t) frames[u] * nh;
     }
 }
