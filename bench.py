@@ -197,7 +197,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TTS_BENCH_BATCH", "384")), help="utterances per context decoded in lock-step")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("TTS_BENCH_STREAMS", "1")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("TTS_BENCH_STREAMS", "3")),
                     help="independent runners (contexts, HIP streams) per GPU; each decodes --batch utterances per step")
     ap.add_argument("--audio-steps", type=int, default=256, help="AR audio steps per utterance (random weights never emit EOS: max_generation = prompt + this)")
     ap.add_argument("--prompt-len", type=int, default=16)
@@ -291,9 +291,12 @@ def main():
         res = [None] * len(runners)
 
         def work(i):
-            t0 = time.perf_counter()
-            sizes = runners[i].generate_batch_sizes(all_texts[i])
-            res[i] = (sum(sizes), time.perf_counter() - t0)
+            try:
+                t0 = time.perf_counter()
+                sizes = runners[i].generate_batch_sizes(all_texts[i])
+                res[i] = (sum(sizes), time.perf_counter() - t0)
+            except Exception as e:   # surfaced by the caller: a worker thread must not fail silently
+                res[i] = e
 
         if len(runners) == 1:
             work(0)
@@ -303,6 +306,9 @@ def main():
                 t.start()
             for t in th:
                 t.join()
+        for r in res:
+            if isinstance(r, Exception):
+                raise r
         if timings_ is not None:
             timings_.append(float(np.mean([r[1] for r in res])))
         return sum(r[0] for r in res)

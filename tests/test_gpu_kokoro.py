@@ -98,3 +98,25 @@ def test_kokoro_runner_from_file(tmp_path):
     with pytest.raises(runner.RunnerError):
         r.generate(text, voice=b"nobody")
     r.close()
+
+
+def test_kokoro_82m_shapes_match_oracle():
+    """BASELINE config 2's dimensions (hexgrad/Kokoro-82M: ALBERT 768 x 12 recurrences, predictor / text encoder 512, decoder 1024,
+    generator 512 -> 256 -> 128, (10, 6) upsampling, n_fft 20 / hop 5) with seeded weights, 10 phoneme ids: durations identical,
+    duration states, and the audio from the oracle's conditioning sample for sample"""
+    model = synth.build_kokoro(synth.kokoro_82m())
+    cfg = model.cfg
+    eng = hip.KokoroEngine(model)
+    o = orc.KokoroOracle(model)
+    rng = np.random.default_rng(82)
+    toks = np.concatenate([[0], rng.integers(1, cfg.vocab, 10), [0]]).astype(np.uint32)
+    lens, hid = eng.durations(toks, cfg.voices[0])
+    ref_lens, ref_hid = o.durations(toks, cfg.voices[0])
+    assert np.array_equal(lens, ref_lens) and relerr(hid, ref_hid) < 2e-4   # measured 9e-7
+    forced = np.full(toks.size, 2.0, dtype=np.float32)       # forced durations: shape determinism (SURVEY §8d), and both sides see the same alignment
+    noise = rng.random(o.noise_len(int(forced.sum())), dtype=np.float32)
+    ref_pcm, _, _, ref_hs = o.generate(toks, forced, ref_hid, cfg.voices[0], noise, want_curves=True)
+    pcm = eng.generate(toks, forced, ref_hid, cfg.voices[0], noise, hsrc_in=ref_hs)
+    print(f"kokoro-82m: duration states {relerr(hid, ref_hid):.2e}, predicted lengths equal: {np.array_equal(lens, ref_lens)}, audio {relerr(pcm, ref_pcm):.2e}")
+    assert pcm.shape == ref_pcm.shape and relerr(pcm, ref_pcm) < 2e-4          # measured 2.8e-6
+    eng.close()

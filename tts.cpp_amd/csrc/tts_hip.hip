@@ -306,6 +306,7 @@ struct tts_hip_ctx {
     int tile_min_rows = 33;     // forwards with at least this many rows take the LDS-tiled GEMM (gemm_tile_kernels.h); 0 = never
     int tile_force = -1;        // TTS_HIP_TILE_FORCE: tile shape index for every tiled GEMM (tuning)
     int tile_force_ks = 0;      // TTS_HIP_TILE_KS: k slices for the residual GEMMs (tuning)
+    int tile_deep = 1;          // TTS_HIP_TILE_DEEP=0: always the 64-wide k-tiles / 4 buffers form (half the LDS per workgroup)
     bool dac_f16 = false;      // every codec conv kernel arrived as F16: fp16 im2col x fp16 kernel, fp32 accumulate (ggml)
     bool dac_packed = false;
 
@@ -370,6 +371,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_TILE_MIN_ROWS")) c->tile_min_rows = std::max(0, atoi(e));
     if (const char *e = getenv("TTS_HIP_TILE_FORCE")) c->tile_force = atoi(e);
     if (const char *e = getenv("TTS_HIP_TILE_KS")) c->tile_force_ks = atoi(e);
+    if (const char *e = getenv("TTS_HIP_TILE_DEEP")) c->tile_deep = atoi(e);
     if (const char *e = getenv("TTS_HIP_Q_FUSE_MAX")) c->q_fuse_max = std::max(0, std::min(16, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMV_ROWS")) c->gemv_rows = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_LLAMA_GRAPH")) c->llama_graph = atoi(e) != 0;
@@ -1132,7 +1134,7 @@ template <int EPI>
 static int launch_tile(tts_hip_ctx *c, const GemmArgs &a, int shape, int ks) {
     const TileShape &t = TILE_SHAPES[shape];
     TileMap tm{(a.R + t.BM - 1) / t.BM, (a.N + t.BN - 1) / t.BN, ks};
-    const bool deep = tm.m_tiles * tm.n_tiles * tm.k_slices <= 320;
+    const bool deep = c->tile_deep && tm.m_tiles * tm.n_tiles * tm.k_slices <= 320;
     switch (shape) {
         case 0: return launch_tile_shape<32, 32, 1, 2, EPI>(c, a, tm, deep);
         case 1: return launch_tile_shape<32, 64, 1, 4, EPI>(c, a, tm, deep);
