@@ -11,14 +11,70 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// one workgroup (4 waves) per row
+// Q8_0 block of 32 consecutive values held one per lane by 32 neighbouring lanes (ggml's quantize_row_q8_0_ref: d = amax / 127 kept
+// as fp16, q = roundf(x / d)) — the same arithmetic as quant_rows_q8_kernel, for producers that quantise their own output row.
+__device__ __forceinline__ void q8_block_store(float v, int64_t idx, int8_t *aq, float *ad) {
+    float amax = fabsf(v);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float dd = amax / 127.0f;
+    const float id = dd ? 1.0f / dd : 0.0f;
+    aq[idx] = (int8_t) roundf(v * id);
+    if ((idx & 31) == 0) ad[idx >> 5] = (float) (_Float16) dd;
+}
+
+// one workgroup (4 waves) per row; the row (H <= 4096) is held in registers: every load of the row, the slabs and the weight is in
+// flight at once (the first version walked the row twice with dependent loads: 9.4 us for one 3072-wide row).
+// aq / ad (optional): the normalised row is also written as Q8_0 blocks (aq int8 [R][H], ad [R][H/32]) for an integer GEMV that
+// follows immediately (saves that GEMV's quant_rows_q8_kernel launch).
 __global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int H, const float *w, float *y, int R, float eps, const float *parts, int n_parts,
-                                                            int64_t slab_stride) {
+                                                            int64_t slab_stride, int8_t *aq, float *ad) {
     __shared__ float red[4];
-    const int r = blockIdx.x;
+    const int r = blockIdx.x, tid = threadIdx.x;
     float *xr = x + (int64_t) r * H;
+    if (H <= 4096) {
+        float v[16], wv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = tid + k * 256;
+            if (i < H) { v[k] = xr[i]; wv[k] = w[i]; }
+        }
+        if (parts) {
+            for (int p = 0; p < n_parts; p++) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int i = tid + k * 256;
+                    if (i < H) v[k] += parts[p * slab_stride + (int64_t) r * H + i];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int i = tid + k * 256;
+                if (i < H) xr[i] = v[k];
+            }
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (tid + k * 256 < H) s += v[k] * v[k];
+        s = wave_sum(s);
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        s = (red[0] + red[1]) + (red[2] + red[3]);
+        const float scale = 1.0f / sqrtf(s / (float) H + eps);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = tid + k * 256;
+            if (i < H) {   // H is a multiple of 32 whenever aq is given: a wave's 32-lane halves are whole blocks
+                const float o = v[k] * scale * wv[k];
+                y[(int64_t) r * H + i] = o;
+                if (aq) q8_block_store(o, (int64_t) r * H + i, aq, ad);
+            }
+        }
+        return;
+    }
     float s = 0.0f;
-    for (int i = threadIdx.x; i < H; i += 256) {
+    for (int i = tid; i < H; i += 256) {
         float v = xr[i];
         if (parts) {
             for (int p = 0; p < n_parts; p++) v += parts[p * slab_stride + (int64_t) r * H + i];
@@ -27,11 +83,15 @@ __global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int H, con
         s += v * v;
     }
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
     s = (red[0] + red[1]) + (red[2] + red[3]);
     const float scale = 1.0f / sqrtf(s / (float) H + eps);
-    for (int i = threadIdx.x; i < H; i += 256) y[(int64_t) r * H + i] = xr[i] * scale * w[i];   // xr[i] was written by this thread
+    for (int i = tid; i < H; i += 256) {
+        const float o = xr[i] * scale * w[i];   // xr[i] was written by this thread
+        y[(int64_t) r * H + i] = o;
+        if (aq) q8_block_store(o, (int64_t) r * H + i, aq, ad);
+    }
 }
 
 // qkv [R][(NH + 2 NKV) * HD] (q | k | v).  One wave per (row, q or k head); lane = pair i (and i + 64, ... for HD > 128).
@@ -145,6 +205,110 @@ __global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld,
     }
 }
 
+// Decode-time form of attn_gqa_kernel for few (head, row) pairs and many keys: one workgroup can pull only ~1/256 of the HBM
+// bandwidth (a CU's load path), so 24 workgroups reading 0.5 MB each take 20 us whatever the chip could do.  The keys of a row are
+// split over gridDim.z workgroups; each leaves (max, sum, unnormalised out[128]) and attn_gqa_combine_kernel merges them — the same
+// softmax, associated differently.  An empty split (short sequences under a graph captured for long ones) leaves max = -inf.
+#define ATTN_PART 130   // floats per partial: max, sum, out[128]
+template <int HD>
+__global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, int ld, const uint32_t *pos, const float *kcache, const float *vcache, int NH, int NKV,
+                                                             float scale, float *part, const uint32_t *kbeg, const uint32_t *kend, const uint32_t *row_seq,
+                                                             int64_t seq_stride) {
+    static_assert(HD == 128, "lane mapping below is written for head_dim 128");
+    __shared__ float red[8];
+    __shared__ float4 accs[8][HD / 4];
+    float *qs = attn_gqa_sm, *ps = attn_gqa_sm + HD;
+    const int h = blockIdx.x, r = blockIdx.y, z = blockIdx.z, nz = gridDim.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kb = kbeg ? (int) kbeg[r] : 0;
+    const int Tall = (kend ? (int) kend[r] : (int) pos[r] + 1) - kb;
+    const int chunk = (Tall + nz - 1) / nz;
+    const int k0 = kb + z * chunk;
+    const int T = max(0, min(chunk, Tall - z * chunk));
+    float *pz = part + (((int64_t) r * NH + h) * nz + z) * ATTN_PART;
+    if (T <= 0) {
+        if (tid == 0) { pz[0] = -INFINITY; pz[1] = 0.0f; }
+        return;
+    }
+    const int kvH = NKV * HD, kh = h / (NH / NKV);
+    if (row_seq) { kcache += (int64_t) row_seq[r] * seq_stride; vcache += (int64_t) row_seq[r] * seq_stride; }
+    kcache += (int64_t) k0 * kvH;
+    vcache += (int64_t) k0 * kvH;
+    if (tid < HD) qs[tid] = qkv[(int64_t) r * ld + h * HD + tid];
+    __syncthreads();
+    {
+        const int g = tid >> 4, sub = tid & 15;
+        const float4 q0 = *(const float4 *) (qs + sub * 4), q1 = *(const float4 *) (qs + 64 + sub * 4);
+        for (int j0 = 0; j0 < T; j0 += 16) {
+            const int j = j0 + g;
+            float d = 0.0f;
+            if (j < T) {
+                const float4 *kr = (const float4 *) (kcache + (int64_t) j * kvH + kh * HD);
+                const float4 a = kr[sub], b = kr[16 + sub];
+                d = (a.x * q0.x + a.y * q0.y + a.z * q0.z + a.w * q0.w) + (b.x * q1.x + b.y * q1.y + b.z * q1.z + b.w * q1.w);
+            }
+            d += __shfl_xor(d, 8);
+            d += __shfl_xor(d, 4);
+            d += __shfl_xor(d, 2);
+            d += __shfl_xor(d, 1);
+            if (sub == 0 && j < T) ps[j] = d * scale;
+        }
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = tid; j < T; j += 256) mx = fmaxf(mx, ps[j]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.0f;
+    for (int j = tid; j < T; j += 256) {
+        const float p = expf(ps[j] - mx);
+        ps[j] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    {
+        const int grp = tid >> 5, e4 = tid & 31;
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int j = grp; j < T; j += 8) {
+            const float p = ps[j];
+            const float4 v = *(const float4 *) (vcache + (int64_t) j * kvH + kh * HD + e4 * 4);
+            acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w;
+        }
+        accs[grp][e4] = acc;
+    }
+    __syncthreads();
+    if (tid < HD) {
+        const float *a = (const float *) &accs[0][0];
+        float o = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 8; g++) o += a[g * HD + tid];
+        pz[2 + tid] = o;
+    }
+    if (tid == 0) { pz[0] = mx; pz[1] = (red[4] + red[5]) + (red[6] + red[7]); }
+}
+
+// one 128-thread workgroup per (head, row): out = sum_z e^(m_z - m) o_z / sum_z e^(m_z - m) l_z, splits in order
+__global__ __launch_bounds__(128) void attn_gqa_combine_kernel(const float *part, int nz, int NH, float *out, int8_t *aq, float *ad) {
+    const int h = blockIdx.x, r = blockIdx.y, t = threadIdx.x;
+    const float *p = part + ((int64_t) r * NH + h) * nz * ATTN_PART;
+    float m = -INFINITY;
+    for (int z = 0; z < nz; z++) m = fmaxf(m, p[z * ATTN_PART]);
+    float o = 0.0f, l = 0.0f;
+    for (int z = 0; z < nz; z++) {
+        const float mz = p[z * ATTN_PART];
+        if (mz == -INFINITY) continue;
+        const float f = expf(mz - m);
+        o += f * p[z * ATTN_PART + 2 + t];
+        l += f * p[z * ATTN_PART + 1];
+    }
+    const float res = o / l;
+    out[(int64_t) r * NH * 128 + h * 128 + t] = res;
+    if (aq) q8_block_store(res, (int64_t) r * NH * 128 + h * 128 + t, aq, ad);   // the o projection's activation blocks
+}
+
 // arg-max over a large vocabulary (156 940 logits), sampler::max semantics (src/sampler.cpp:185-204: the first maximum
 // wins).  Stage 1: ARGMAX_PARTS workgroups over contiguous chunks; stage 2: one wave folds the partial results.
 #define ARGMAX_PARTS 128
@@ -206,11 +370,13 @@ __global__ __launch_bounds__(64) void argmax_fold_graph_kernel(const float *pv, 
     }
 }
 
-// gu [R][2F] (gate | up) -> g [R][F] = silu(gate) * up
-__global__ void silu_mul_kernel(const float *gu, int F, int R, float *g) {
+// gu [R][2F] (gate | up) -> g [R][F] = silu(gate) * up; aq / ad (optional, F % 32 == 0): g also as Q8_0 blocks for the down projection
+__global__ void silu_mul_kernel(const float *gu, int F, int R, float *g, int8_t *aq, float *ad) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) R * F) return;
     const int64_t r = i / F, c = i - r * F;
     const float x = gu[r * 2 * F + c];
-    g[i] = (x / (1.0f + expf(-x))) * gu[r * 2 * F + F + c];
+    const float o = (x / (1.0f + expf(-x))) * gu[r * 2 * F + F + c];
+    g[i] = o;
+    if (aq) q8_block_store(o, i, aq, ad);
 }

@@ -306,6 +306,10 @@ struct tts_hip_ctx {
     int tile_min_rows = 33;     // forwards with at least this many rows take the LDS-tiled GEMM (gemm_tile_kernels.h); 0 = never
     int tile_force = -1;        // TTS_HIP_TILE_FORCE: tile shape index for every tiled GEMM (tuning)
     int tile_force_ks = 0;      // TTS_HIP_TILE_KS: k slices for the residual GEMMs (tuning)
+    const void *aq_src = nullptr;  // activation rows whose Q8_0 blocks already sit in aq / ad (written by the producing kernel)
+    int attn_split_max = 8;     // TTS_HIP_ATTN_SPLIT: key splits of the decode attention of the Llama / Dia steps (1 = off)
+    float *attn_part = nullptr; // [rows][heads][splits][130] partial softmax results
+    size_t attn_part_cap = 0;   // in (row, head, split) triples
     int tile_deep = 1;          // TTS_HIP_TILE_DEEP=0: always the 64-wide k-tiles / 4 buffers form (half the LDS per workgroup)
     bool dac_f16 = false;      // every codec conv kernel arrived as F16: fp16 im2col x fp16 kernel, fp32 accumulate (ggml)
     bool dac_packed = false;
@@ -372,6 +376,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_TILE_FORCE")) c->tile_force = atoi(e);
     if (const char *e = getenv("TTS_HIP_TILE_KS")) c->tile_force_ks = atoi(e);
     if (const char *e = getenv("TTS_HIP_TILE_DEEP")) c->tile_deep = atoi(e);
+    if (const char *e = getenv("TTS_HIP_ATTN_SPLIT")) c->attn_split_max = std::max(1, std::min(16, atoi(e)));
     if (const char *e = getenv("TTS_HIP_Q_FUSE_MAX")) c->q_fuse_max = std::max(0, std::min(16, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMV_ROWS")) c->gemv_rows = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_LLAMA_GRAPH")) c->llama_graph = atoi(e) != 0;
@@ -391,6 +396,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
     free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms); free_dev(c->d_pen); free_dev(c->d_last); free_dev(c->d_repc);
     free_dev(c->l_x); free_dev(c->l_xn); free_dev(c->l_qkv); free_dev(c->l_att); free_dev(c->l_gu); free_dev(c->l_g); free_dev(c->l_logits); free_dev(c->l_parts);
+    free_dev(c->attn_part);
     free_dev(c->l_kc); free_dev(c->l_vc); free_dev(c->l_ids); free_dev(c->l_pos); free_dev(c->l_tok);
     for (void *p : c->q4_bufs) free_dev(p);
     for (float *p : {c->di_ex, c->di_exn, c->di_eqkv, c->di_eatt, c->di_egu, c->di_eg, c->di_ek, c->di_ev, c->di_ckv, c->di_ck, c->di_cv, c->di_k, c->di_v, c->di_x,
@@ -1172,10 +1178,14 @@ static void choose_tile(const tts_hip_ctx *c, int R, int N, int K, bool may_spli
 // GGUF-quantised matrix: LayerNorm (if any) -> Q8_0-quantise the activation rows -> integer block GEMM
 static int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi) {
     if (pro == PRO_F16) return set_err("run_qgemm: fp16 activations are never produced for a quantised consumer");
+    const bool have_q = c->aq_src != nullptr && c->aq_src == a.A && a.lda == a.K;
+    c->aq_src = nullptr;
     if (c->gemv_rows && a.R <= 4 && pro == PRO_F32 && (epi == EPI_STORE || epi == EPI_RESID) && !a.kchunk) {
         CHK(prof_begin(c, kclass, (double) w.K * w.N * (1.0 + 2.0 / 32) + (double) a.R * a.K * 5 + (double) a.R * a.N * 4, 2.0 * a.R * (double) w.K * w.N));
-        hipLaunchKernelGGL(quant_rows_q8_kernel, dim3((a.K / 32 + 7) / 8, a.R), dim3(256), 0, c->stream, (const float *) a.A, a.lda, a.K, c->aq, c->ad, a.R);
-        HIPCHK(hipGetLastError());
+        if (!have_q) {   // otherwise the producing kernel (rms norm, silu*up, attention combine) left the Q8_0 blocks in aq / ad
+            hipLaunchKernelGGL(quant_rows_q8_kernel, dim3((a.K / 32 + 7) / 8, a.R), dim3(256), 0, c->stream, (const float *) a.A, a.lda, a.K, c->aq, c->ad, a.R);
+            HIPCHK(hipGetLastError());
+        }
         QGemmArgs qa{};
         qa.g = a;
         qa.wd = (const _Float16 *) (c->arena + w.soff);
@@ -1578,6 +1588,8 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         while (F / c->l_ksplit > 4096 || (F % c->l_ksplit)) c->l_ksplit++;
         if ((F / c->l_ksplit) % 256) c->l_ksplit = 1;
         const size_t kvb = (size_t) c->L * NCTX * c->l_kvH;
+        c->attn_part_cap = (size_t) 4 * c->NH * 16;   // up to 4 rows x heads x 16 splits (more rows take the unsplit kernel)
+        CHK(dmalloc(&c->attn_part, c->attn_part_cap * ATTN_PART));
         CHK(dmalloc(&c->l_kc, kvb));   // ggml_backend_buffer_clear(buf, 0), orpheus/model.cpp:181
         CHK(dmalloc(&c->l_vc, kvb));
         const int R = c->RMAX;
@@ -1611,6 +1623,8 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         const int U = std::max(1, std::min((int) dd.max_utterances, 64)), R = 2 * U;
         c->di_U = U;
         c->di_slot_encoded.assign((size_t) U, 0);
+        c->attn_part_cap = (size_t) R * c->NH * 16;
+        CHK(dmalloc(&c->attn_part, c->attn_part_cap * ATTN_PART));
         CHK(dmalloc(&c->di_ck, (size_t) c->L * U * n * A));   // [L][2U][S][A], zero like the reference's cleared cache (dia/model.cpp:329)
         CHK(dmalloc(&c->di_cv, (size_t) c->L * U * n * A));
         CHK(dmalloc(&c->di_k, (size_t) c->L * R * G * kvH));  // [L][2U][G][kvH]
@@ -2659,6 +2673,32 @@ extern "C" tts_hip_ctx *tts_hip_orpheus_create(int device, const tts_hip_orpheus
     return c;
 }
 
+// attention of the Llama / Dia steps: one workgroup per (head, row), or — few rows, many keys — the keys split over `nz` workgroups
+// plus a combine launch (attn_gqa_split_kernel).  max_keys bounds the LDS score buffer.
+static int launch_attn_gqa(tts_hip_ctx *c, int NHq, int rows, int max_keys, const float *qkv, int ld, const uint32_t *pos, const float *kc, const float *vc, int NKV,
+                           float scale, float *out, const uint32_t *kbeg, const uint32_t *kend, const uint32_t *row_seq, int64_t seq_stride, bool fixed_split, bool q_out = false) {
+    int nz = 1;
+    if (c->attn_split_max > 1 && NHq * rows <= 256) {
+        // a graph captured once replays for every position: the split count must not depend on the position then
+        nz = fixed_split ? c->attn_split_max : std::min(c->attn_split_max, std::max(1, max_keys / 128));
+        while (nz > 1 && (size_t) rows * NHq * nz > c->attn_part_cap) nz--;
+    }
+    if (nz <= 1) {
+        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NHq, rows), dim3(256), (size_t) (128 + max_keys) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, out, kbeg, kend,
+                           row_seq, seq_stride);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    const int chunk = (max_keys + nz - 1) / nz;
+    hipLaunchKernelGGL(attn_gqa_split_kernel<128>, dim3(NHq, rows, nz), dim3(256), (size_t) (128 + chunk + 1) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part,
+                       kbeg, kend, row_seq, seq_stride);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(attn_gqa_combine_kernel, dim3(NHq, rows), dim3(128), 0, c->stream, (const float *) c->attn_part, nz, NHq, out, q_out ? c->aq : (int8_t *) nullptr, q_out ? c->ad : (float *) nullptr);
+    if (q_out) c->aq_src = out;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int llama_gemm(tts_hip_ctx *c, const W &w, const float *A, int lda, float *out, int ldo, int n, int epi, int ksplit = 1) {
     for (int r0 = 0; r0 < n; r0 += c->RMAX) {
         GemmArgs g{};
@@ -2700,30 +2740,39 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
     HIPCHK(hipGetLastError());
     const float theta_scale = powf(c->lm.rope_base, -2.0f / (float) HD);
     c->l_pending = 0;
-    auto rms = [&](size_t w_off, int rows, float *x, float *y) {
+    // the streaming integer GEMV of 1..4 rows takes its Q8_0 activation blocks from the producing kernel where there is one
+    auto q_for = [&](const W &w, int rows) {
+        return c->gemv_rows && rows <= 4 && w.type == TTS_HIP_Q8I && !(c->d.flags & (TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q)) && w.K % 32 == 0;
+    };
+    auto rms = [&](size_t w_off, int rows, float *x, float *y, const W *next) {
+        const bool q = next && q_for(*next, rows);
         hipLaunchKernelGGL(rms_fold_rows_kernel, dim3(rows), dim3(256), 0, c->stream, x, H, f32(w_off), y, rows, 1e-5f,
-                           c->l_pending ? (const float *) c->l_parts : (const float *) nullptr, c->l_pending, (int64_t) c->RMAX * H);
+                           c->l_pending ? (const float *) c->l_parts : (const float *) nullptr, c->l_pending, (int64_t) c->RMAX * H,
+                           q ? c->aq : (int8_t *) nullptr, q ? c->ad : (float *) nullptr);
         c->l_pending = 0;
+        c->aq_src = q ? y : nullptr;
         return hipGetLastError() == hipSuccess ? 0 : set_err("rms_fold_rows_kernel launch failed");
     };
     for (int l = 0; l < c->L; l++) {
         const auto &y = c->l_layers[l];
         float *kc = c->l_kc + (size_t) l * NCTX * c->l_kvH, *vc = c->l_vc + (size_t) l * NCTX * c->l_kvH;
-        CHK(rms(y.in_norm, n, c->l_x, c->l_xn));
+        CHK(rms(y.in_norm, n, c->l_x, c->l_xn, &y.qkv));
         CHK(llama_gemm(c, y.qkv, c->l_xn, H, c->l_qkv, QKV, n, EPI_STORE));
         hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH + NKV), dim3(64), 0, c->stream, c->l_qkv, (const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, HD, kc, vc,
                            (const uint32_t *) nullptr, (int64_t) 0);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, n), dim3(256), (size_t) (128 + (attn_positions ? (uint32_t) attn_positions : pos0 + n)) * 4, c->stream, (const float *) c->l_qkv, QKV, (const uint32_t *) c->l_pos,
-                           (const float *) kc, (const float *) vc, NH, NKV, 1.0f / sqrtf((float) HD), c->l_att,
-                           (const uint32_t *) nullptr, (const uint32_t *) nullptr, (const uint32_t *) nullptr, (int64_t) 0);
-        HIPCHK(hipGetLastError());
+        CHK(launch_attn_gqa(c, NH, n, (int) (attn_positions ? (uint32_t) attn_positions : pos0 + n), (const float *) c->l_qkv, QKV, (const uint32_t *) c->l_pos,
+                            (const float *) kc, (const float *) vc, NKV, 1.0f / sqrtf((float) HD), c->l_att, nullptr, nullptr, nullptr, (int64_t) 0, attn_positions != 0,
+                            q_for(y.o, n)));
         CHK(llama_gemm(c, y.o, c->l_att, NH * HD, c->l_x, H, n, EPI_RESID));
-        CHK(rms(y.post_norm, n, c->l_x, c->l_xn));
+        CHK(rms(y.post_norm, n, c->l_x, c->l_xn, &y.gu));
         CHK(llama_gemm(c, y.gu, c->l_xn, H, c->l_gu, 2 * F, n, EPI_STORE));
-        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) n * F + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->l_gu, F, n, c->l_g);
-        HIPCHK(hipGetLastError());
         const int ks = (c->gemv_rows && n <= 4) ? 1 : c->l_ksplit;   // the streaming kernels walk all of K themselves
+        const bool qd = ks == 1 && q_for(y.down, n);
+        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) n * F + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->l_gu, F, n, c->l_g,
+                           qd ? c->aq : (int8_t *) nullptr, qd ? c->ad : (float *) nullptr);
+        HIPCHK(hipGetLastError());
+        c->aq_src = qd ? c->l_g : nullptr;
         if (ks > 1) {
             CHK(llama_gemm(c, y.down, c->l_g, F, c->l_parts, H, n, EPI_STORE, ks));
             c->l_pending = ks;
@@ -2732,7 +2781,7 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
         }
     }
     // lm_head on the last token only (:287-290)
-    CHK(rms(c->l_out_norm, n, c->l_x, c->l_xn));
+    CHK(rms(c->l_out_norm, n, c->l_x, c->l_xn, nullptr));
     GemmArgs g{};
     g.R = 1; g.H = H; g.A = c->l_xn + (size_t) (n - 1) * H; g.lda = H; g.out = c->l_logits; g.ldo = c->l_Vpad;
     CHK(run_gemm(c, TTS_HIP_K_GEMM_HEADS, c->l_head, g, PRO_F32, EPI_STORE));
@@ -2877,7 +2926,7 @@ static int dia_gemm(tts_hip_ctx *c, const W &w, const float *A, int lda, float *
 static int dia_rms(tts_hip_ctx *c, size_t w_off, int rows, int H, float *x, float *y, bool fold) {
     const int pend = fold ? c->di_pending : 0;
     hipLaunchKernelGGL(rms_fold_rows_kernel, dim3(rows), dim3(256), 0, c->stream, x, H, (const float *) (c->arena + w_off), y, rows, 1e-5f,
-                       pend ? (const float *) c->di_parts : (const float *) nullptr, pend, (int64_t) c->RMAX * H);
+                       pend ? (const float *) c->di_parts : (const float *) nullptr, pend, (int64_t) c->RMAX * H, (int8_t *) nullptr, (float *) nullptr);
     if (fold) c->di_pending = 0;
     return hipGetLastError() == hipSuccess ? 0 : set_err("rms_fold_rows_kernel launch failed");
 }
@@ -2930,7 +2979,7 @@ extern "C" int tts_hip_dia_encode_slot(tts_hip_ctx *c, uint32_t slot, const uint
         CHK(dia_gemm(c, y.o, c->di_eatt, A, c->di_ex, EH, n, EPI_RESID));
         CHK(dia_rms(c, y.mlp_norm, n, EH, c->di_ex, c->di_exn, false));
         CHK(dia_gemm(c, y.gu, c->di_exn, EH, c->di_egu, 2 * EF, n, EPI_STORE));
-        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) n * EF + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->di_egu, EF, n, c->di_eg);
+        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) n * EF + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->di_egu, EF, n, c->di_eg, (int8_t *) nullptr, (float *) nullptr);
         HIPCHK(hipGetLastError());
         CHK(dia_gemm(c, y.out, c->di_eg, EF, c->di_ex, EH, n, EPI_RESID));
     }
@@ -3007,23 +3056,20 @@ extern "C" int tts_hip_dia_step_batch(tts_hip_ctx *c, uint32_t n_utt, const uint
         hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(R, NH + NKV), dim3(64), 0, c->stream, c->di_qkv, (const uint32_t *) c->di_pos, (const float *) nullptr, theta_scale, NH,
                            NKV, HD, kc, vc, (const uint32_t *) c->di_seq, (int64_t) G * kvH);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, R), dim3(256), (size_t) (128 + max_pos + 1) * 4, c->stream, (const float *) c->di_qkv, QKV,
-                           (const uint32_t *) c->di_pos, (const float *) kc, (const float *) vc, NH, NKV, 1.0f, c->di_att, nul, nul, (const uint32_t *) c->di_seq,
-                           (int64_t) G * kvH);
-        HIPCHK(hipGetLastError());
+        CHK(launch_attn_gqa(c, NH, R, (int) max_pos + 1, (const float *) c->di_qkv, QKV, (const uint32_t *) c->di_pos, (const float *) kc, (const float *) vc, NKV, 1.0f,
+                            c->di_att, nul, nul, (const uint32_t *) c->di_seq, (int64_t) G * kvH, false));
         CHK(dia_gemm(c, y.so, c->di_att, A, c->di_x, DH, R, EPI_RESID));
         CHK(dia_rms(c, y.ca_norm, R, DH, c->di_x, c->di_xn, false));
         CHK(dia_gemm(c, y.cq, c->di_xn, DH, c->di_q, A, R, EPI_STORE));
         hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(R, NH), dim3(64), 0, c->stream, c->di_q, (const uint32_t *) c->di_pos, (const float *) nullptr, theta_scale, NH, 0, HD,
                            (float *) nullptr, (float *) nullptr, nul, (int64_t) 0);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NH, R), dim3(256), (size_t) (128 + S) * 4, c->stream, (const float *) c->di_q, A, (const uint32_t *) c->di_pos, ck, cv,
-                           NH, NH, 1.0f, c->di_att, nul, (const uint32_t *) c->di_cend, (const uint32_t *) c->di_seq, (int64_t) S * A);
-        HIPCHK(hipGetLastError());
+        CHK(launch_attn_gqa(c, NH, R, S, (const float *) c->di_q, A, (const uint32_t *) c->di_pos, ck, cv, NH, 1.0f, c->di_att, nul, (const uint32_t *) c->di_cend,
+                            (const uint32_t *) c->di_seq, (int64_t) S * A, false));
         CHK(dia_gemm(c, y.co, c->di_att, A, c->di_x, DH, R, EPI_RESID));
         CHK(dia_rms(c, y.mlp_norm, R, DH, c->di_x, c->di_xn, false));
         CHK(dia_gemm(c, y.gu, c->di_xn, DH, c->di_gu, 2 * DF, R, EPI_STORE));
-        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) R * DF + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->di_gu, DF, R, c->di_g);
+        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) R * DF + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->di_gu, DF, R, c->di_g, (int8_t *) nullptr, (float *) nullptr);
         HIPCHK(hipGetLastError());
         if (c->di_ksplit > 1) {
             CHK(dia_gemm(c, y.out, c->di_g, DF, c->di_parts, DH, R, EPI_STORE, c->di_ksplit));
