@@ -298,6 +298,7 @@ struct tts_hip_ctx {
     std::map<int, std::vector<float>> dac_dbg;
     std::map<size_t, float *> packed;  // arena offset of a conv weight -> its MFMA-tile-packed copy
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
+    int dac_variant = 20;       // TTS_HIP_DAC_VARIANT (tuning; 20 = 96-channel class on 128-position tiles, the one variant that measured faster): position-tile variant of the k = 7 conv kernel per channel-tile class
     int dac_alpha_tab = 1;      // 0: the codec kernels read snake's alpha from memory instead of an LDS table (smaller footprint)
     int dac_lds_reserve_kb = 0; // LDS the codec kernels leave free per CU for another context's decoder workgroups
     int gemm_rows_per_wg = 0;   // > 0: forwards with more rows split them over workgroups of this many rows (16/32/64)
@@ -367,6 +368,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (lf) c->ln_fuse_max = std::max(0, std::min(32, atoi(lf)));
     if (const char *e = getenv("TTS_HIP_LN_WAVES")) c->ln_waves = std::max(1, std::min(4, atoi(e)));
     if (const char *e = getenv("TTS_HIP_KSPLIT_BIG")) c->ksplit_big = std::max(1, std::min(8, atoi(e)));
+    if (const char *e = getenv("TTS_HIP_DAC_VARIANT")) c->dac_variant = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_ALPHA_TAB")) c->dac_alpha_tab = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
@@ -2462,8 +2464,23 @@ static int launch_conv(tts_hip_ctx *c, const DacBatch &bt, const float *x, int c
         else CHK((launch_conv_mfma16<1, 2, 2, 1, 4, CI16_K1>(c, a, bt.n)));
     } else if (cfg >= 0 && pk != c->packed.end()) {
         a.w = pk->second;
-        if (K == 7 && cfg == 0) CHK((launch_conv_mfma<7, 2, 2, 2, 2, CI32_K7>(c, a, bt.n)));
+        // position-tile variants of the k = 7 kernel (same packed weights: the image depends on CO_T and CI_T only); TTS_HIP_DAC_VARIANT picks
+        // per channel-tile class (decimal digits: class 0 / 1 / 2), measured in profiles/r02/dac_variants.log
+        const int v0 = c->dac_variant % 10, v1 = (c->dac_variant / 10) % 10, v2 = (c->dac_variant / 100) % 10;
+        if (K == 7 && cfg == 0 && v0 == 1) CHK((launch_conv_mfma<7, 2, 4, 2, 2, CI32_K7>(c, a, bt.n)));        // 128 ch x 256 pos, wave 64 x 128
+        else if (K == 7 && cfg == 0 && v0 == 2) CHK((launch_conv_mfma<7, 4, 2, 1, 4, CI32_K7>(c, a, bt.n)));   // 128 ch x 256 pos, wave 128 x 64
+        else if (K == 7 && cfg == 0 && v0 == 3) CHK((launch_conv_mfma<7, 2, 1, 2, 2, CI32_K7>(c, a, bt.n)));   // 128 ch x 64 pos
+        else if (K == 7 && cfg == 0 && v0 == 4) CHK((launch_conv_mfma<7, 1, 2, 4, 1, CI32_K7>(c, a, bt.n)));   // 128 ch x 64 pos, wave 32 x 64
+        else if (K == 7 && cfg == 0 && v0 == 5) CHK((launch_conv_mfma<7, 2, 2, 2, 4, CI32_K7>(c, a, bt.n)));   // 128 ch x 256 pos, 8 waves
+        else if (K == 7 && cfg == 0) CHK((launch_conv_mfma<7, 2, 2, 2, 2, CI32_K7>(c, a, bt.n)));
+        else if (K == 7 && cfg == 1 && v1 == 1) CHK((launch_conv_mfma<7, 3, 4, 1, 4, CI32_K7>(c, a, bt.n)));   // 96 ch x 512 pos
+        else if (K == 7 && cfg == 1 && v1 == 2) CHK((launch_conv_mfma<7, 3, 1, 1, 4, CI32_K7>(c, a, bt.n)));   // 96 ch x 128 pos
+        else if (K == 7 && cfg == 1 && v1 == 3) CHK((launch_conv_mfma<7, 3, 2, 1, 2, CI32_K7>(c, a, bt.n)));   // 96 ch x 128 pos, 2 waves
         else if (K == 7 && cfg == 1) CHK((launch_conv_mfma<7, 3, 2, 1, 4, CI32_K7>(c, a, bt.n)));
+        else if (K == 7 && cfg == 2 && v2 == 1) CHK((launch_conv_mfma<7, 2, 4, 1, 4, CI32_K7>(c, a, bt.n)));   // 64 ch x 512 pos
+        else if (K == 7 && cfg == 2 && v2 == 2) CHK((launch_conv_mfma<7, 2, 2, 1, 8, CI32_K7>(c, a, bt.n)));   // 64 ch x 512 pos, 8 waves
+        else if (K == 7 && cfg == 2 && v2 == 3) CHK((launch_conv_mfma<7, 2, 1, 1, 4, CI32_K7>(c, a, bt.n)));   // 64 ch x 128 pos
+        else if (K == 7 && cfg == 2 && v2 == 4) CHK((launch_conv_mfma<7, 2, 2, 1, 2, CI32_K7>(c, a, bt.n)));   // 64 ch x 128 pos, 2 waves
         else if (K == 7 && cfg == 2) CHK((launch_conv_mfma<7, 2, 2, 1, 4, CI32_K7>(c, a, bt.n)));
         else if (K == 1 && cfg == 0) CHK((launch_conv_mfma<1, 2, 2, 2, 2, CI32_K1>(c, a, bt.n)));
         else if (K == 1 && cfg == 1) CHK((launch_conv_mfma<1, 3, 2, 1, 4, CI32_K1>(c, a, bt.n)));
