@@ -403,3 +403,33 @@ def test_kokoro_forced_durations_and_noise():
     assert a.shape == (total * cfg.up_sampling_factor,) and np.isfinite(a).all()
     assert 1e-6 < np.abs(a - b).max()                            # the source noise reaches the audio
     assert np.array_equal(a, o.generate(g["tokens"], lens, g["hidden"], "af_test", n1))
+
+
+def test_snake_sine_polynomial_is_libm_accurate():
+    """csrc/dac_kernels.h snake_sin (4-term Cody-Waite reduction by pi + degree-9 odd polynomial, |x| < 125) restated in numpy float32
+    with exact fused multiply-adds: against float64 sin its error stays within 2 ulp / 1.5e-7 absolute — the class of libm's sinf, which
+    the reference's snake_1d calls (src/util.cpp:96-101)."""
+    f = np.float32
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+    def snake_sin(x):
+        q = np.rint((x * f(0.318309886183790671537767526745028724)).astype(f)).astype(f)
+        r = x
+        for cst in (-3.140625, -0.0009670257568359375, -6.2771141529083251953e-07, -1.2154201256553420762e-10):
+            r = fma(q, np.full_like(x, f(cst)), r)
+        s = (r * r).astype(f)
+        r = np.where(q.astype(np.int64) & 1, -r, r).astype(f)
+        u = np.full_like(x, f(2.6083159809786593541503e-06))
+        for cst in (-0.0001981069071916863322258, 0.00833307858556509017944336, -0.166666597127914428710938):
+            u = fma(u, s, np.full_like(x, f(cst)))
+        return fma(s, (u * r).astype(f), r)
+
+    rng = np.random.default_rng(0)
+    for lo, hi in ((-125, 125), (-10, 10), (-1, 1)):
+        x = rng.uniform(lo, hi, 1_000_000).astype(f)
+        ref = np.sin(x.astype(np.float64))
+        err = np.abs(snake_sin(x).astype(np.float64) - ref)
+        assert err.max() < 1.5e-7
+        assert (err / np.spacing(np.abs(ref).astype(f)).astype(np.float64)).max() < 2.5

@@ -18,8 +18,29 @@
 
 typedef float float4d __attribute__((ext_vector_type(4)));
 
+// sin for snake's argument range.  libm's sinf spends ~250 instructions (branches, a Payne-Hanek path for huge arguments) and the
+// staging of every conv input tile evaluates it once per element: 7.5 % of the codec's time (profiles/r02/dac_sin_experiment.log).
+// |x| < 125: 4-term Cody-Waite reduction by pi (every product exact, so the reduced argument is correct to < 1 ulp) and the degree-9
+// odd minimax polynomial on [-pi/2, pi/2].  Checked against float64 sin on 12 M random arguments (tests/test_oracle_cpu.py restates it in
+// numpy): max abs error 1.3e-7, <= 2 ulp — libm's own float result is within 1.4 ulp on the same points; larger arguments go to sinf.
+__device__ __forceinline__ float snake_sin(float x) {
+    if (!(fabsf(x) < 125.0f)) return sinf(x);
+    const float q = rintf(x * 0.318309886183790671537767526745028724f);
+    float r = fmaf(q, -3.140625f, x);
+    r = fmaf(q, -0.0009670257568359375f, r);
+    r = fmaf(q, -6.2771141529083251953e-07f, r);
+    r = fmaf(q, -1.2154201256553420762e-10f, r);
+    const float s = r * r;
+    if (((int) q) & 1) r = -r;
+    float u = 2.6083159809786593541503e-06f;
+    u = fmaf(u, s, -0.0001981069071916863322258f);
+    u = fmaf(u, s, 0.00833307858556509017944336f);
+    u = fmaf(u, s, -0.166666597127914428710938f);
+    return fmaf(s, u * r, r);
+}
+
 __device__ __forceinline__ float snake_f(float x, float alpha, float ralpha) {
-    const float s = sinf(x * alpha);
+    const float s = snake_sin(x * alpha);
     return x + (s * s) * ralpha;
 }
 // snake with alpha from the LDS table (alpha, then 1/alpha, cin_pad entries each) or straight from memory; same arithmetic
