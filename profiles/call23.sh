@@ -1,0 +1,6 @@
+mkdir -p gpurun_out/r2
+timeout 900 python bench.py > gpurun_out/r2/bench_final.json 2> gpurun_out/r2/bench_final.log; echo rc=$?; tail -2 gpurun_out/r2/bench_final.log
+export TMPDIR=/tmp
+R=$PWD
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/proffinal -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-step-sweep > $R/gpurun_out/r2/prof_final.log 2>&1
+cd $R; f=$(find /tmp/proffinal -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r2/kernel_stats_bench_default_b384_s3.csv; head -5 gpurun_out/r2/kernel_stats_bench_default_b384_s3.csv | cut -c1-120

@@ -298,6 +298,7 @@ struct tts_hip_ctx {
     std::map<int, std::vector<float>> dac_dbg;
     std::map<size_t, float *> packed;  // arena offset of a conv weight -> its MFMA-tile-packed copy
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
+    int dac_group = 64;         // TTS_HIP_DAC_GROUP: utterances per codec pass (16: 451, 32: 458, 64: 461, 128: 460, 384: 462 audio-s/s at 3 x 384)
     int dac_variant = 20;       // TTS_HIP_DAC_VARIANT (tuning; 20 = 96-channel class on 128-position tiles, the one variant that measured faster): position-tile variant of the k = 7 conv kernel per channel-tile class
     int dac_alpha_tab = 1;      // 0: the codec kernels read snake's alpha from memory instead of an LDS table (smaller footprint)
     int dac_lds_reserve_kb = 0; // LDS the codec kernels leave free per CU for another context's decoder workgroups
@@ -369,6 +370,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_LN_WAVES")) c->ln_waves = std::max(1, std::min(4, atoi(e)));
     if (const char *e = getenv("TTS_HIP_KSPLIT_BIG")) c->ksplit_big = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("TTS_HIP_DAC_VARIANT")) c->dac_variant = atoi(e);
+    if (const char *e = getenv("TTS_HIP_DAC_GROUP")) c->dac_group = std::max(1, atoi(e));
     if (const char *e = getenv("TTS_HIP_DAC_ALPHA_TAB")) c->dac_alpha_tab = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
@@ -2544,15 +2546,38 @@ static int launch_convt(tts_hip_ctx *c, ConvTArgs ta, size_t w_off, int nz) {
 // dac_runner::run for n utterances at once (grid.z = utterance, per-utterance lengths): the early blocks have
 // few positions per utterance, so batching is what fills the 256 CUs there.
 static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint32_t *frames, uint32_t n, float *pcm_out);
+// One codec pass carries at most `dac_group` utterances (TTS_HIP_DAC_GROUP, default 64): the activation buffers are sized for a group
+// (3 x 197 KB per frame: 9.4 GB for 64 x 248 frames instead of 56 GB for a 384-utterance batch), and passes of different contexts on
+// one device take turns (a per-device mutex): a pass fills the chip with compute-bound convolutions, two of them interleaved only
+// stretch each other, while another context's latency-bound decoder loop does fit next to one.
+static std::mutex g_dac_pass_mutex[64];
 static int dac_decode_batch(tts_hip_ctx *c, const uint32_t *codes, const uint32_t *frames, uint32_t n, float *pcm_out) {
     if (!c || !c->finalized || !c->has_dac) return set_err("tts_hip_dac_decode: context has no finalized DAC");
-    if (!c->dac_stream) return dac_decode_batch_on(c, codes, frames, n, pcm_out);
-    // the decoder stream is idle here (every decoder entry point synchronises before it returns)
-    hipStream_t ar = c->stream;
-    c->stream = c->dac_stream;
-    const int rc = dac_decode_batch_on(c, codes, frames, n, pcm_out);
-    c->stream = ar;
-    return rc;
+    if (!frames || !codes || !pcm_out) return set_err("tts_hip_dac_decode: null argument");
+    const uint32_t G = (uint32_t) std::max(1, c->dac_group);
+    size_t code_off = 0, pcm_off = 0;
+    for (uint32_t g0 = 0; g0 < n; g0 += G) {
+        const uint32_t m = std::min(G, n - g0);
+        size_t fr = 0;
+        for (uint32_t i = 0; i < m; i++) fr += frames[g0 + i];
+        int rc;
+        {
+            std::lock_guard<std::mutex> lock(g_dac_pass_mutex[(unsigned) c->device % 64]);
+            if (!c->dac_stream) {
+                rc = dac_decode_batch_on(c, codes + code_off * c->d_ncb, frames + g0, m, pcm_out + pcm_off);
+            } else {
+                // the decoder stream is idle here (every decoder entry point synchronises before it returns)
+                hipStream_t ar = c->stream;
+                c->stream = c->dac_stream;
+                rc = dac_decode_batch_on(c, codes + code_off * c->d_ncb, frames + g0, m, pcm_out + pcm_off);
+                c->stream = ar;
+            }
+        }
+        if (rc) return rc;
+        code_off += fr;
+        pcm_off += fr * (size_t) c->d_up;
+    }
+    return 0;
 }
 
 static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint32_t *frames, uint32_t n, float *pcm_out) {
