@@ -98,8 +98,8 @@ def pmc_traffic(family, args, n_audio):
     t = json.load(open(path))
     w = t.get("workload", {})
     key = FAMILIES[family][0]
-    if key.startswith("dac_"):  # DAC launches depend only on the group size (32 utterances per pass) and the frame count
-        if args.dac_wtype != "f32" or w.get("audio_steps") != n_audio:
+    if key.startswith("dac_"):  # DAC launches depend only on the utterances per codec pass and the frame count
+        if args.dac_wtype != "f32" or w.get("audio_steps") != n_audio or w.get("dac_group") != int(os.environ.get("TTS_HIP_DAC_GROUP", "64")):
             return None
     elif w.get("batch") != args.batch or w.get("audio_steps") != n_audio:
         return None
