@@ -298,6 +298,7 @@ struct tts_hip_ctx {
     std::map<int, std::vector<float>> dac_dbg;
     std::map<size_t, float *> packed;  // arena offset of a conv weight -> its MFMA-tile-packed copy
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
+    bool kk_mfma = true;        // TTS_HIP_KOKORO_MFMA=0: every Kokoro convolution through the one-thread-per-output kernel
     int dac_group = 64;         // TTS_HIP_DAC_GROUP: utterances per codec pass (16: 451, 32: 458, 64: 461, 128: 460, 384: 462 audio-s/s at 3 x 384)
     int dac_variant = 20;       // TTS_HIP_DAC_VARIANT (tuning; 20 = 96-channel class on 128-position tiles, the one variant that measured faster): position-tile variant of the k = 7 conv kernel per channel-tile class
     int dac_alpha_tab = 1;      // 0: the codec kernels read snake's alpha from memory instead of an LDS table (smaller footprint)
@@ -370,6 +371,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_LN_WAVES")) c->ln_waves = std::max(1, std::min(4, atoi(e)));
     if (const char *e = getenv("TTS_HIP_KSPLIT_BIG")) c->ksplit_big = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("TTS_HIP_DAC_VARIANT")) c->dac_variant = atoi(e);
+    if (const char *e = getenv("TTS_HIP_KOKORO_MFMA")) c->kk_mfma = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_DAC_GROUP")) c->dac_group = std::max(1, atoi(e));
     if (const char *e = getenv("TTS_HIP_DAC_ALPHA_TAB")) c->dac_alpha_tab = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
@@ -3228,9 +3230,33 @@ struct KRun {
         if (!err.empty() || !gamma || !beta) return;
         hipLaunchKernelGGL(kk_adain_kernel, dim3(C), dim3(256), 0, st, x, L, (const float *) gamma, (const float *) beta, act, slope, alpha);
     }
+    // Stride-1 "same" convolutions with enough channels (the generator's residual blocks k = 3 / 7 / 11 with dilations 1 / 3 / 5, the
+    // AdaIN residual blocks k = 3, the text encoder k = 5, conv_post k = 7: 59 % of the model's kernel time through the one-thread-per-
+    // output kernel, profiles/r02/kernel_stats_kokoro_82m.csv) go through the codec's exact-fp32 MFMA conv kernel (conv1d_mfma_kernel: input
+    // channels staged through LDS, weights pre-packed once per tensor into its LDS image); `acc` becomes its residual input (y += conv).
+    // Everything else (stride 2, nearest-2x input, one output channel, the scaled shortcut) stays on kk_conv1d_kernel.
+    template <int KT, int CI_T>
+    bool conv_mfma(const float *x, int cin, int64_t L, const float *wt, const float *b, int cout, int pad, int dil, float *y, int acc) {
+        const size_t w_off = (size_t) ((const char *) wt - c->arena);
+        const int CO_T = cout % 128 == 0 ? 128 : 64;
+        if (c->packed.find(w_off) == c->packed.end() && pack_one(c, w_off, cout, cin, KT, CO_T, CI_T, false) != 0) { err = tts_hip_last_error(); return true; }
+        ConvArgs a{};
+        a.x = x; a.w = c->packed[w_off]; a.b = b; a.alpha = nullptr; a.alpha_out = nullptr; a.resid = acc ? y : nullptr; a.y = y;
+        a.cin = cin; a.cout = cout; a.L = (int) L; a.dil = dil; a.pad = pad; a.do_tanh = 0; a.frames = nullptr; a.mult = 1; a.x_f16 = 0;
+        const int rc = CO_T == 128 ? launch_conv_mfma<KT, 2, 2, 2, 2, CI_T>(c, a, 1) : launch_conv_mfma<KT, 2, 2, 1, 4, CI_T>(c, a, 1);
+        if (rc != 0) err = tts_hip_last_error();
+        return true;
+    }
     void conv1d(const float *x, int cin, int64_t L, const float *wt, const float *b, int cout, int K, int stride, int pad, int dil, int in_shift, float *y, int64_t Lout,
                 int acc, float post) {
         if (!x || !wt || !y) return;
+        const bool same = stride == 1 && !in_shift && Lout == L && pad * 2 == dil * (K - 1) && post == 1.0f && dil <= 9;
+        if (same && c->kk_mfma && cout % 64 == 0 && cin >= 16 && L < (1 << 30) && (const char *) wt >= c->arena && (const char *) wt < c->arena + c->arena_bytes) {
+            if (K == 3 && conv_mfma<3, 8>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
+            if (K == 5 && conv_mfma<5, 4>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
+            if (K == 7 && conv_mfma<7, 4>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
+            if (K == 11 && conv_mfma<11, 4>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
+        }
         hipLaunchKernelGGL(kk_conv1d_kernel, kgrid((int64_t) cout * Lout), dim3(256), 0, st, x, cin, L, wt, b, cout, K, stride, pad, dil, in_shift, y, Lout, acc, post);
     }
     // build_ada_residual_conv (:88-134): x [cin][L] -> [cout][L or 2L]
