@@ -124,6 +124,82 @@ __global__ void kk_embed_cols_kernel(const float *embd, const uint32_t *tok, int
 
 // One direction of an LSTM cell over L positions.  pre [4][L][hid]: the input part of the gates i, f, g, o for every position
 // (W_ih x + b_ih); whh [4][hid][hid], bhh [4][hid].  One workgroup of `hid` threads (hid <= 1024); h lives in LDS.
+// The recurrence spread over hid/16 workgroups per direction.  One workgroup re-reads the whole recurrent matrix (4 x hid x hid floats:
+// 1 MB at hid = 256) from L2 at every time step, and one CU's load path caps that at ~7.5 us per step (kk_lstm_kernel below: 9 ms per
+// call at 1200 steps).  Here a workgroup owns 16 hidden units: thread (unit u, gate g, part p) keeps a quarter (CP = hid/4 columns) of
+// row (g, u) of W_hh in registers for the whole sequence, so a step reads nothing but the previous hidden state; the workgroups
+// exchange their 16 new h values through 8-byte {value, step tag} granules written with one device-scope store each and polled with
+// device-scope loads (a granule is published by a single naturally aligned store, so a reader that sees the tag sees the value: no
+// fences, no barrier; MI355X_MICROARCH.md "handoff-1to1").  Spins are bounded: a workgroup that is never scheduled next to its peers
+// raises *stuck instead of hanging the device.  blockIdx.y = direction (0 forward, 1 reversed), each with its own pre-activations.
+// Same arithmetic as kk_lstm_kernel up to the summation order of the 256-term dot products (4 partial sums of CP terms).
+struct LstmArgs {
+    const float *pre[2];        // [4][L][hid] input pre-activations (x W_ih^T + b_ih) per direction
+    const float *whh[2][4];     // [hid][hid] per gate (i, f, g, o)
+    const float *bhh[2][4];     // [hid]
+    unsigned long long *xch;    // [2 dirs][2 parities][hid] granules, zeroed before the launch
+    float *out;                 // [L][out_stride]
+    int L, hid, out_stride;
+    int *stuck;
+};
+
+template <int CP>
+__global__ __launch_bounds__(256) void kk_lstm_split_kernel(LstmArgs a) {
+    extern __shared__ float kk_h[];   // [hid] previous hidden state
+    const int tid = threadIdx.x, dir = blockIdx.y;
+    const int u = tid >> 4, g = (tid >> 2) & 3, p = tid & 3;
+    const int unit = blockIdx.x * 16 + u, hid = a.hid, L = a.L;
+    float w[CP];
+    {
+        const float *wr = a.whh[dir][g] + (int64_t) unit * hid + p * CP;
+#pragma unroll
+        for (int j = 0; j < CP; j++) w[j] = wr[j];
+    }
+    const float bias = a.bhh[dir][g][unit];
+    const float *pre = a.pre[dir] + (int64_t) g * L * hid + unit;
+    unsigned long long *xch = a.xch + (int64_t) dir * 2 * hid;
+    float c = 0.0f;
+    for (int idx = 0; idx < L; idx++) {
+        const int t = dir ? L - 1 - idx : idx;
+        const float pv = pre[(int64_t) t * hid];            // issued before the wait: the input term does not depend on the exchange
+        if (idx == 0) {
+            for (int j = tid; j < hid; j += 256) kk_h[j] = 0.0f;
+        } else {
+            const unsigned long long *slot = xch + (int64_t) ((idx - 1) & 1) * hid;
+            for (int j = tid; j < hid; j += 256) {
+                unsigned long long v = 0;
+                int spins = 0;
+                for (;;) {
+                    v = __hip_atomic_load(slot + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned) (v >> 32) == (unsigned) idx) break;
+                    if (++spins > (1 << 22)) { *a.stuck = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                kk_h[j] = __uint_as_float((unsigned) v);
+            }
+        }
+        __syncthreads();
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < CP; j++) acc += w[j] * kk_h[p * CP + j];
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);                          // the four parts of row (g, unit)
+        const float gate = pv + (acc + bias);
+        const int base = (tid & 63) & ~15;                  // lane of (u, gate 0, part 0) inside the wave
+        const float gi = __shfl(gate, base), gf = __shfl(gate, base + 4), gg_ = __shfl(gate, base + 8), go = __shfl(gate, base + 12);
+        if ((tid & 15) == 0) {
+            const float ig = 1.0f / (1.0f + expf(-gi)), fg = 1.0f / (1.0f + expf(-gf)), gg = tanhf(gg_), og = 1.0f / (1.0f + expf(-go));
+            c = fg * c + ig * gg;
+            const float h = tanhf(c) * og;
+            a.out[(int64_t) t * a.out_stride + dir * hid + unit] = h;
+            if (idx + 1 < L)
+                __hip_atomic_store(xch + (int64_t) (idx & 1) * hid + unit, ((unsigned long long) (unsigned) (idx + 1) << 32) | __float_as_uint(h), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();   // kk_h is rewritten by the next step
+    }
+}
+
 __global__ __launch_bounds__(1024) void kk_lstm_kernel(const float *pre, const float *whh0, const float *whh1, const float *whh2, const float *whh3, const float *bhh0,
                                                        const float *bhh1, const float *bhh2, const float *bhh3, int L, int hid, int reversed, float *out, int out_stride,
                                                        int out_off) {

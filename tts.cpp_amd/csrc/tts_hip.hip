@@ -298,6 +298,8 @@ struct tts_hip_ctx {
     std::map<int, std::vector<float>> dac_dbg;
     std::map<size_t, float *> packed;  // arena offset of a conv weight -> its MFMA-tile-packed copy
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
+    bool kk_lstm_split = true;  // TTS_HIP_KOKORO_LSTM_SPLIT=0: the bidirectional LSTMs through the one-workgroup-per-direction kernel
+    int *kk_stuck = nullptr;    // set by kk_lstm_split_kernel when a granule never arrives (bounded spin)
     bool kk_mfma = true;        // TTS_HIP_KOKORO_MFMA=0: every Kokoro convolution through the one-thread-per-output kernel
     int dac_group = 64;         // TTS_HIP_DAC_GROUP: utterances per codec pass (16: 451, 32: 458, 64: 461, 128: 460, 384: 462 audio-s/s at 3 x 384)
     int dac_variant = 20;       // TTS_HIP_DAC_VARIANT (tuning; 20 = 96-channel class on 128-position tiles, the one variant that measured faster): position-tile variant of the k = 7 conv kernel per channel-tile class
@@ -372,6 +374,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_KSPLIT_BIG")) c->ksplit_big = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("TTS_HIP_DAC_VARIANT")) c->dac_variant = atoi(e);
     if (const char *e = getenv("TTS_HIP_KOKORO_MFMA")) c->kk_mfma = atoi(e) != 0;
+    if (const char *e = getenv("TTS_HIP_KOKORO_LSTM_SPLIT")) c->kk_lstm_split = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_DAC_GROUP")) c->dac_group = std::max(1, atoi(e));
     if (const char *e = getenv("TTS_HIP_DAC_ALPHA_TAB")) c->dac_alpha_tab = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
@@ -402,7 +405,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
     free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms); free_dev(c->d_pen); free_dev(c->d_last); free_dev(c->d_repc);
     free_dev(c->l_x); free_dev(c->l_xn); free_dev(c->l_qkv); free_dev(c->l_att); free_dev(c->l_gu); free_dev(c->l_g); free_dev(c->l_logits); free_dev(c->l_parts);
-    free_dev(c->attn_part);
+    free_dev(c->attn_part); free_dev(c->kk_stuck);
     free_dev(c->l_kc); free_dev(c->l_vc); free_dev(c->l_ids); free_dev(c->l_pos); free_dev(c->l_tok);
     for (void *p : c->q4_bufs) free_dev(p);
     for (float *p : {c->di_ex, c->di_exn, c->di_eqkv, c->di_eatt, c->di_egu, c->di_eg, c->di_ek, c->di_ev, c->di_ckv, c->di_ck, c->di_cv, c->di_k, c->di_v, c->di_x,
@@ -3157,6 +3160,7 @@ extern "C" tts_hip_ctx *tts_hip_kokoro_create(int device, const tts_hip_kokoro_d
     if (!c) return nullptr;
     c->has_kokoro = true;
     c->ko = *kd;
+    if (hipMalloc((void **) &c->kk_stuck, 4) != hipSuccess || hipMemset(c->kk_stuck, 0, 4) != hipSuccess) { set_err("tts_hip_kokoro_create: hipMalloc failed"); tts_hip_destroy(c); return nullptr; }
     return c;
 }
 
@@ -3206,7 +3210,39 @@ struct KRun {
     void copy(float *dst, const float *src, size_t n) { if (dst && src) (void) hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, st); }
     // build_lstm (:35-51): one bidirectional cell; x [L][in] -> out [L][2 hid]
     void bilstm(const std::string &base, const float *x, int L, int in, int hid, float *out) {
-        float *pre = s.f((size_t) 4 * L * hid);
+        const int cp = hid / 4;
+        const bool split = c->kk_lstm_split && hid % 16 == 0 && (cp == 4 || cp == 8 || cp == 16 || cp == 32 || cp == 64 || cp == 128) && L > 1;
+        float *pre = s.f((size_t) 8 * L * hid);   // both directions' input pre-activations
+        if (split) {
+            // the recurrence of both directions in one launch over hid/16 workgroups each (kk_lstm_split_kernel)
+            LstmArgs la{};
+            for (int dir = 0; dir < 2; dir++) {
+                const std::string wn = dir ? ".0.reverse_weights." : ".0.weights.", bn = dir ? ".0.reverse_biases." : ".0.biases.";
+                float *pd = pre ? pre + (size_t) dir * 4 * L * hid : nullptr;
+                for (int g = 0; g < 4; g++) {
+                    linear(w(base + wn + std::to_string(2 * g)), w(base + bn + std::to_string(2 * g)), x, in, L, in, hid, pd ? pd + (size_t) g * L * hid : nullptr, hid);
+                    la.whh[dir][g] = w(base + wn + std::to_string(2 * g + 1));
+                    la.bhh[dir][g] = w(base + bn + std::to_string(2 * g + 1));
+                }
+                la.pre[dir] = pd;
+            }
+            float *xch = s.f((size_t) 2 * 2 * hid * 2);   // 8-byte granules
+            if (!err.empty() || !pre || !xch) return;
+            (void) hipMemsetAsync(xch, 0, (size_t) 2 * 2 * hid * 8, st);
+            (void) hipMemsetAsync(c->kk_stuck, 0, 4, st);
+            la.xch = (unsigned long long *) xch; la.out = out; la.L = L; la.hid = hid; la.out_stride = 2 * hid; la.stuck = c->kk_stuck;
+            const dim3 grid(hid / 16, 2);
+            const size_t lds = (size_t) hid * 4;
+            switch (cp) {
+                case 4: hipLaunchKernelGGL(kk_lstm_split_kernel<4>, grid, dim3(256), lds, st, la); break;
+                case 8: hipLaunchKernelGGL(kk_lstm_split_kernel<8>, grid, dim3(256), lds, st, la); break;
+                case 16: hipLaunchKernelGGL(kk_lstm_split_kernel<16>, grid, dim3(256), lds, st, la); break;
+                case 32: hipLaunchKernelGGL(kk_lstm_split_kernel<32>, grid, dim3(256), lds, st, la); break;
+                case 64: hipLaunchKernelGGL(kk_lstm_split_kernel<64>, grid, dim3(256), lds, st, la); break;
+                default: hipLaunchKernelGGL(kk_lstm_split_kernel<128>, grid, dim3(256), lds, st, la); break;
+            }
+            return;
+        }
         for (int dir = 0; dir < 2; dir++) {
             const std::string wn = dir ? ".0.reverse_weights." : ".0.weights.", bn = dir ? ".0.reverse_biases." : ".0.biases.";
             const float *whh[4], *bhh[4];
@@ -3328,6 +3364,18 @@ const float *kokoro_voice(tts_hip_ctx *c, KRun &k, const char *voice, uint32_t n
 }
 }  // namespace
 
+// after a synchronised Kokoro call: did a bounded spin of kk_lstm_split_kernel give up?
+static int kokoro_check_stuck(tts_hip_ctx *c, const char *who) {
+    int stuck = 0;
+    HIPCHK(hipMemcpy(&stuck, c->kk_stuck, 4, hipMemcpyDeviceToHost));
+    if (stuck) {
+        (void) hipMemset(c->kk_stuck, 0, 4);
+        return set_err("%s: the workgroups of a split LSTM recurrence never saw each other's hidden state (device oversubscribed?); "
+                       "TTS_HIP_KOKORO_LSTM_SPLIT=0 selects the single-workgroup kernel", who);
+    }
+    return 0;
+}
+
 extern "C" int tts_hip_kokoro_durations(tts_hip_ctx *c, const uint32_t *tokens, uint32_t n, const char *voice, float *lens_out, float *hidden_out) {
     if (!c || !c->has_kokoro) return set_err("tts_hip_kokoro_durations: not a Kokoro context (tts_hip_kokoro_create)");
     if (!c->finalized || !c->weights_present) return set_err("tts_hip_kokoro_durations: context not finalized");
@@ -3398,7 +3446,7 @@ extern "C" int tts_hip_kokoro_durations(tts_hip_ctx *c, const uint32_t *tokens, 
     if (!k.ok()) return set_err("tts_hip_kokoro_durations: %s", k.err.c_str());
     HIPCHK(hipMemcpyAsync(lens_out, lens, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return kokoro_check_stuck(c, "tts_hip_kokoro_durations");
 }
 
 extern "C" int tts_hip_kokoro_generate(tts_hip_ctx *c, const uint32_t *tokens, uint32_t n, const float *lens, const float *hidden, const char *voice, const float *noise,
@@ -3544,6 +3592,19 @@ extern "C" int tts_hip_kokoro_generate(tts_hip_ctx *c, const uint32_t *tokens, u
         const int K = (int) ne[0], Co = (int) ne[1];
         const int64_t Lo = (Lg - 1) * kd.up_stride[i] - 2 * (int64_t) kd.up_padding[i] + K;
         float *y = s.f((size_t) Co * Lo);
+        const int S_ = (int) kd.up_stride[i];
+        const bool mfma_up = c->kk_mfma && K == 2 * S_ && (S_ == 10 || S_ == 6) && Co % 64 == 0 && 2 * (int) kd.up_padding[i] == K - S_ && Lo == Lg * S_;
+        if (y && mfma_up) {
+            // the generator's ConvTranspose1d (stride 10 / 6, kernel = 2 x stride: every output touches two taps) on the codec's
+            // phase-decomposed MFMA kernel; the one-thread-per-output kernel spent 18 ms per launch here
+            const size_t w_off = (size_t) ((const char *) uw - c->arena);
+            if (c->packed.find(w_off) == c->packed.end()) CHK(pack_one(c, w_off, Co, Cg, K, 64, CI32_T, true));
+            ConvTArgs ta{};
+            ta.x = g; ta.w = c->packed[w_off]; ta.b = k.w(gb + "ups." + std::to_string(i) + ".bias"); ta.alpha = nullptr; ta.y = y;
+            ta.cin = Cg; ta.cout = Co; ta.L = (int) Lg; ta.Lout = (int) Lo; ta.stride = S_; ta.pad = (int) kd.up_padding[i]; ta.frames = nullptr; ta.mult = 1;
+            if (S_ == 10) CHK((launch_convt_mfma<10, 1, 2, 2, CI32_T>(c, ta, 1)));
+            else CHK((launch_convt_mfma<6, 1, 2, 2, CI32_T>(c, ta, 1)));
+        } else
         if (y) hipLaunchKernelGGL(kk_convt1d_kernel, kgrid((int64_t) Co * Lo), dim3(256), 0, c->stream, (const float *) g, Cg, Lg, uw, k.w(gb + "ups." + std::to_string(i) + ".bias"), Co, K,
                                   (int) kd.up_stride[i], (int) kd.up_padding[i], y, Lo);
         g = y; Cg = Co; Lg = Lo;
@@ -3588,7 +3649,7 @@ extern "C" int tts_hip_kokoro_generate(tts_hip_ctx *c, const uint32_t *tokens, u
     if (!k.ok()) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
     HIPCHK(hipMemcpyAsync(pcm_out, pcm, (size_t) out_len * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return kokoro_check_stuck(c, "tts_hip_kokoro_generate");
 }
 
 // ------------------------------------------------------------------------------------------------
