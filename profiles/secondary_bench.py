@@ -308,9 +308,9 @@ def run_kokoro(args):
         "ms_per_step": round(timed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (seeded random weights at the shapes of hexgrad/Kokoro-82M)",
         "config": {"workload": "configs[2]: Kokoro-82M on 1 x MI355X, 64 and 400 phoneme ids, durations forced to 3 frames per id for shape determinism; "
-                               "tts_hip_kokoro_durations + tts_hip_kokoro_generate (plain fp32 kernels: first device version)", "parallelism": "dp1"},
+                               "tts_hip_kokoro_durations + tts_hip_kokoro_generate (exact-fp32 MFMA convolutions, workgroup-split LSTM recurrence)", "parallelism": "dp1"},
         "by_length": res,
-        "roofline": None, "roofline_note": "no per-kernel roofline yet: the Kokoro kernels are the parity-first version (one thread per output), DESIGN.md §7",
+        "roofline": None, "roofline_note": "no single bounding kernel: the time is spread over ~20 short kernel families (profiles/r02/kernel_stats_kokoro_82m_round2_final.csv), DESIGN.md §5",
     }
     eng.close()
     if not args.no_cpu_baseline:

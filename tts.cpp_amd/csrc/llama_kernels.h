@@ -40,7 +40,25 @@ __global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int H, con
             if (i < H) { v[k] = xr[i]; wv[k] = w[i]; }
         }
         if (parts) {
-            for (int p = 0; p < n_parts; p++) {
+            int p = 0;
+            if (H <= 2048) {   // four slabs per round trip (8 values each): the adds still run in slab order
+                for (; p + 4 <= n_parts; p += 4) {
+                    float t[4][8];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const int i = tid + k * 256;
+                            if (i < H) t[q][k] = parts[(p + q) * slab_stride + (int64_t) r * H + i];
+                        }
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                            if (tid + k * 256 < H) v[k] += t[q][k];
+                }
+            }
+            for (; p < n_parts; p++) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int i = tid + k * 256;
@@ -99,8 +117,11 @@ __global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int H, con
 // powf(base, -2/HD) from the host; angle = theta / freq_factor[i]; NEOX pairing (i, i + HD/2).  The k-head waves write the
 // rotated key into the cache and copy their head's slice of v next to it.
 // row_seq (optional): row r appends to the cache of sequence row_seq[r], seq_stride floats apart (Dia's two streams).
+// n_parts > 1: qkv holds n_parts fp32 slabs (part_stride floats apart, K slices of the projection written by gemv_stream_kernel); they are
+// summed in slab order on the way in and the rotated q lands in slab 0, where the attention kernels read it.
 __global__ __launch_bounds__(64) void llama_rope_kv_kernel(float *qkv, const uint32_t *pos, const float *ff, float theta_scale, int NH, int NKV, int HD,
-                                                           float *kcache, float *vcache, const uint32_t *row_seq, int64_t seq_stride) {
+                                                           float *kcache, float *vcache, const uint32_t *row_seq, int64_t seq_stride, int n_parts = 1,
+                                                           int64_t part_stride = 0) {
     const int r = blockIdx.x, h = blockIdx.y;
     if (row_seq) { kcache += (int64_t) row_seq[r] * seq_stride; vcache += (int64_t) row_seq[r] * seq_stride; }
     const int half = HD >> 1;
@@ -113,7 +134,17 @@ __global__ __launch_bounds__(64) void llama_rope_kv_kernel(float *qkv, const uin
         for (int j = 0; j < i; j++) theta *= theta_scale;
         const float ang = theta / (ff ? ff[i] : 1.0f);
         const float cs = cosf(ang), sn = sinf(ang);
-        const float x0 = v[i], x1 = v[i + half];
+        float x0 = v[i], x1 = v[i + half];
+        {   // slabs 1..7 in flight together, added in slab order
+            float t0[7], t1[7];
+#pragma unroll
+            for (int q = 1; q < 8; q++)
+                if (q < n_parts) { t0[q - 1] = v[q * part_stride + i]; t1[q - 1] = v[q * part_stride + i + half]; }
+#pragma unroll
+            for (int q = 1; q < 8; q++)
+                if (q < n_parts) { x0 += t0[q - 1]; x1 += t1[q - 1]; }
+            for (int q = 8; q < n_parts; q++) { x0 += v[q * part_stride + i]; x1 += v[q * part_stride + i + half]; }
+        }
         const float y0 = x0 * cs - x1 * sn, y1 = x0 * sn + x1 * cs;
         if (h < NH) { v[i] = y0; v[i + half] = y1; }
         else {
@@ -124,7 +155,17 @@ __global__ __launch_bounds__(64) void llama_rope_kv_kernel(float *qkv, const uin
     if (h >= NH) {
         const float *vsrc = row + (int64_t) (NH + NKV) * HD + (int64_t) (h - NH) * HD;
         float *vdst = vcache + (int64_t) p * kvH + (h - NH) * HD;
-        for (int i = threadIdx.x; i < HD; i += 64) vdst[i] = vsrc[i];
+        for (int i = threadIdx.x; i < HD; i += 64) {
+            float t = vsrc[i], tp[7];
+#pragma unroll
+            for (int q = 1; q < 8; q++)
+                if (q < n_parts) tp[q - 1] = vsrc[q * part_stride + i];
+#pragma unroll
+            for (int q = 1; q < 8; q++)
+                if (q < n_parts) t += tp[q - 1];
+            for (int q = 8; q < n_parts; q++) t += vsrc[q * part_stride + i];
+            vdst[i] = t;
+        }
     }
 }
 
@@ -132,11 +173,50 @@ __global__ __launch_bounds__(64) void llama_rope_kv_kernel(float *qkv, const uin
 // key row is read as one contiguous 512 bytes), 16 keys per pass.  Softmax statistics over the block.  P.V: 8 groups of
 // 32 lanes walk the keys, a lane owns 4 consecutive output dims (16-byte loads, 512 contiguous bytes per key and group).
 extern __shared__ __align__(16) float attn_gqa_sm[];
+
+// Optional work on the query as an attention workgroup loads it (saves the llama_rope_kv_kernel launch of a projection that has no
+// k/v to append — Dia's cross-attention q, dia/model.cpp:609-633): fold n_parts K-slice slabs (gemv_stream_kernels.h) in slab order,
+// then ggml_rope NEOX at rope_pos[r] with the same iterated theta as llama_rope_kv_kernel.
+struct QPre {
+    int n_parts = 1;
+    int64_t part_stride = 0;
+    const uint32_t *rope_pos = nullptr;
+    float theta_scale = 0.0f;
+};
+template <int HD>
+__device__ __forceinline__ void attn_load_q(float *qs, const float *q, int r, const QPre &qp, int tid) {
+    if (tid < HD) {
+        float t[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++)
+            if (p < qp.n_parts) t[p] = q[p * qp.part_stride + tid];
+        float x = t[0];
+#pragma unroll
+        for (int p = 1; p < 8; p++)
+            if (p < qp.n_parts) x += t[p];
+        for (int p = 8; p < qp.n_parts; p++) x += q[p * qp.part_stride + tid];
+        qs[tid] = x;
+    }
+    __syncthreads();
+    if (qp.rope_pos) {
+        float y0 = 0.0f, y1 = 0.0f;
+        if (tid < HD / 2) {
+            float theta = (float) qp.rope_pos[r];
+            for (int j = 0; j < tid; j++) theta *= qp.theta_scale;
+            const float cs = cosf(theta), sn = sinf(theta);
+            const float x0 = qs[tid], x1 = qs[tid + HD / 2];
+            y0 = x0 * cs - x1 * sn; y1 = x0 * sn + x1 * cs;
+        }
+        __syncthreads();
+        if (tid < HD / 2) { qs[tid] = y0; qs[tid + HD / 2] = y1; }
+        __syncthreads();
+    }
+}
 // Keys [kbeg[r], kend[r]) of the row's sequence (defaults: 0 and pos[r] + 1 = causal over the cache); row_seq / seq_stride as above.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld, const uint32_t *pos, const float *kcache, const float *vcache, int NH, int NKV,
                                                        float scale, float *out, const uint32_t *kbeg, const uint32_t *kend, const uint32_t *row_seq,
-                                                       int64_t seq_stride) {
+                                                       int64_t seq_stride, QPre qp = QPre{}) {
     static_assert(HD == 128, "lane mapping below is written for head_dim 128 (orpheus/model.h:28)");
     __shared__ float red[8];
     __shared__ float4 accs[8][HD / 4];
@@ -148,8 +228,7 @@ __global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld,
     if (row_seq) { kcache += (int64_t) row_seq[r] * seq_stride; vcache += (int64_t) row_seq[r] * seq_stride; }
     kcache += (int64_t) k0 * kvH;
     vcache += (int64_t) k0 * kvH;
-    if (tid < HD) qs[tid] = qkv[(int64_t) r * ld + h * HD + tid];
-    __syncthreads();
+    attn_load_q<HD>(qs, qkv + (int64_t) r * ld + h * HD, r, qp, tid);
     {
         const int g = tid >> 4, sub = tid & 15;
         const float4 q0 = *(const float4 *) (qs + sub * 4), q1 = *(const float4 *) (qs + 64 + sub * 4);
@@ -213,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld,
 template <int HD>
 __global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, int ld, const uint32_t *pos, const float *kcache, const float *vcache, int NH, int NKV,
                                                              float scale, float *part, const uint32_t *kbeg, const uint32_t *kend, const uint32_t *row_seq,
-                                                             int64_t seq_stride) {
+                                                             int64_t seq_stride, QPre qp = QPre{}) {
     static_assert(HD == 128, "lane mapping below is written for head_dim 128");
     __shared__ float red[8];
     __shared__ float4 accs[8][HD / 4];
@@ -233,8 +312,7 @@ __global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, i
     if (row_seq) { kcache += (int64_t) row_seq[r] * seq_stride; vcache += (int64_t) row_seq[r] * seq_stride; }
     kcache += (int64_t) k0 * kvH;
     vcache += (int64_t) k0 * kvH;
-    if (tid < HD) qs[tid] = qkv[(int64_t) r * ld + h * HD + tid];
-    __syncthreads();
+    attn_load_q<HD>(qs, qkv + (int64_t) r * ld + h * HD, r, qp, tid);
     {
         const int g = tid >> 4, sub = tid & 15;
         const float4 q0 = *(const float4 *) (qs + sub * 4), q1 = *(const float4 *) (qs + 64 + sub * 4);
@@ -371,12 +449,14 @@ __global__ __launch_bounds__(64) void argmax_fold_graph_kernel(const float *pv, 
 }
 
 // gu [R][2F] (gate | up) -> g [R][F] = silu(gate) * up; aq / ad (optional, F % 32 == 0): g also as Q8_0 blocks for the down projection
-__global__ void silu_mul_kernel(const float *gu, int F, int R, float *g, int8_t *aq, float *ad) {
+// n_parts > 1: gu holds n_parts fp32 slabs part_stride floats apart (gemv_stream_kernel), summed in slab order on the way in
+__global__ void silu_mul_kernel(const float *gu, int F, int R, float *g, int8_t *aq, float *ad, int n_parts = 1, int64_t part_stride = 0) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) R * F) return;
     const int64_t r = i / F, c = i - r * F;
-    const float x = gu[r * 2 * F + c];
-    const float o = (x / (1.0f + expf(-x))) * gu[r * 2 * F + F + c];
+    float x = gu[r * 2 * F + c], u = gu[r * 2 * F + F + c];
+    for (int q = 1; q < n_parts; q++) { x += gu[q * part_stride + r * 2 * F + c]; u += gu[q * part_stride + r * 2 * F + F + c]; }
+    const float o = (x / (1.0f + expf(-x))) * u;
     g[i] = o;
     if (aq) q8_block_store(o, i, aq, ad);
 }

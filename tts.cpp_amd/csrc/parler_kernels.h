@@ -126,6 +126,9 @@ struct GemmArgs {
     // rows split over workgroups too (blockIdx.z owns rows [z*rows_per_z, (z+1)*rows_per_z)); 0 = one workgroup
     // walks all rows.  Many lock-step rows: more resident workgroups per CU hide the L2 latency of the activation loads.
     int rows_per_z;
+    // host-side hint, not read by any kernel: the caller has room for K-slice slabs and a consumer that folds them ->
+    // run_gemm may take gemv_stream_kernel (gemv_stream_kernels.h) for <= 16 rows
+    int stream;
 };
 
 __device__ __forceinline__ void gemm_epilogue4(const GemmArgs &a, int EPI, int r, int n, float4v v, int slab) {

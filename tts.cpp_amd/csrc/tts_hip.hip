@@ -24,6 +24,7 @@
 #include "dac_kernels.h"
 #include "parler_kernels.h"
 #include "gemm_tile_kernels.h"
+#include "gemv_stream_kernels.h"
 #include "t5_kernels.h"
 #include "llama_kernels.h"
 #include "dia_kernels.h"
@@ -204,6 +205,7 @@ struct tts_hip_ctx {
     int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
     bool q4_native = false;     // TTS_HIP_Q4_NATIVE (with TTS_HIP_GEMV_ROWS; default on for Orpheus contexts): Q4_0 matrices are read as 4-bit codes
     std::vector<void *> q4_bufs;
+    bool gemv_stream = true;    // TTS_HIP_GEMV_STREAM=0: <= 16-row F16 GEMMs of the Dia step stay on gemm16_kernel (gemv_stream_kernels.h otherwise)
     bool llama_graph = false;   // TTS_HIP_LLAMA_GRAPH (default on for Orpheus contexts): the greedy step as one captured graph
     bool gemv_rows = false;     // TTS_HIP_GEMV_ROWS (default on for Orpheus contexts): 1..4 rows go through the streaming one-wave-per-feature kernels (gemv_kernels.h)
     // ---- Orpheus decoder context (tts_hip_orpheus_create) ----
@@ -389,6 +391,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_Q_FUSE_MAX")) c->q_fuse_max = std::max(0, std::min(16, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMV_ROWS")) c->gemv_rows = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_LLAMA_GRAPH")) c->llama_graph = atoi(e) != 0;
+    if (const char *e = getenv("TTS_HIP_GEMV_STREAM")) c->gemv_stream = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_Q4_NATIVE")) c->q4_native = atoi(e) != 0;
     return c;
 }
@@ -1185,6 +1188,48 @@ static void choose_tile(const tts_hip_ctx *c, int R, int N, int K, bool may_spli
 }
 
 // GGUF-quantised matrix: LayerNorm (if any) -> Q8_0-quantise the activation rows -> integer block GEMM
+// ------------------------------------------------------------------------------------------------
+// weight-streaming GEMM for <= 16 rows (gemv_stream_kernels.h): K slices -> fp32 slabs the consumer folds
+// ------------------------------------------------------------------------------------------------
+// K slices for an [N][K] fp16 matrix: as many 256-column chunks as give every wave one (feature tile, slice) item, up to ~4096
+// items (one per wave slot of the chip) and the consumer's slab budget; 0 = the shape does not go through gemv_stream_kernel.
+// Measured on MI355X at 8 rows (profiles/r02/gemv_bench_r8.log): Dia gate|up 24.9 -> 14.2 us, wo 15.2 -> 9.6, self qkv 8.4 -> 6.0,
+// o / cross q / cross o 8.1 -> 4.3.
+enum { DIA_STREAM_SLABS = 8 };   // slab budget of the Dia step buffers (di_qkv, di_q, di_gu, di_parts)
+static int stream_slices(const tts_hip_ctx *c, const W &w, int R, int max_slabs) {
+    if (!c->gemv_stream || w.type != TTS_HIP_F16 || R > 16 || w.K % 256 || w.N % 16 || (c->d.flags & TTS_HIP_FLAG_VALU_GEMM)) return 0;
+    const int tiles = (int) w.N / 16;
+    int ks = 1;
+    while (ks * 2 <= max_slabs && (int) w.K % (ks * 2 * 256) == 0 && tiles * ks * 2 <= 4096) ks *= 2;
+    if ((size_t) 16 * (w.K / ks + 32) * 2 > 96 * 1024) return 0;   // the slice of the rows must fit LDS
+    return ks;
+}
+
+template <int NWV, int PRO, int EPI>
+static int launch_stream_one(tts_hip_ctx *c, const GemmArgs &a, StreamMap sm, int grid, size_t lds) {
+    static std::atomic<uint64_t> attr{0};
+    if (lds > 48 * 1024 && attr_needed(attr, c->device))
+        HIPCHK(hipFuncSetAttribute((const void *) gemv_stream_kernel<NWV, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((gemv_stream_kernel<NWV, PRO, EPI>), dim3(grid), dim3(NWV * 64), lds, c->stream, a, sm);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int launch_stream(tts_hip_ctx *c, const GemmArgs &a, int pro, int epi) {
+    const int ks = a.kchunk ? a.K / a.kchunk : 1;
+    if (ks > 1 && epi != EPI_STORE) return set_err("gemv_stream: K slices need the slab epilogue");
+    if (epi != EPI_STORE && epi != EPI_RESID) return set_err("gemv_stream: no kernel for epilogue %d", epi);
+    const StreamMap sm{ks, a.K / ks};
+    const int items = a.N / 16 * ks;
+    const int nwv = items >= 4096 ? 16 : 4;
+    const int grid = ((items + nwv - 1) / nwv + ks - 1) / ks * ks;
+    const size_t lds = (size_t) (a.R <= 8 ? 8 : 16) * (sm.kslice + 32) * 2;
+#define STREAM_CASE(NWVv, PROv, EPIv) if (nwv == NWVv && pro == PROv && epi == EPIv) return launch_stream_one<NWVv, PROv, EPIv>(c, a, sm, grid, lds);
+    STREAM_CASE(4, PRO_F32, EPI_STORE) STREAM_CASE(16, PRO_F32, EPI_STORE) STREAM_CASE(4, PRO_F32, EPI_RESID) STREAM_CASE(16, PRO_F32, EPI_RESID)
+    STREAM_CASE(4, PRO_F16, EPI_STORE) STREAM_CASE(16, PRO_F16, EPI_STORE)
+#undef STREAM_CASE
+    return set_err("gemv_stream: no kernel for pro=%d epi=%d", pro, epi);
+}
+
 static int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi) {
     if (pro == PRO_F16) return set_err("run_qgemm: fp16 activations are never produced for a quantised consumer");
     const bool have_q = c->aq_src != nullptr && c->aq_src == a.A && a.lda == a.K;
@@ -1277,6 +1322,11 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
         if (w.type == TTS_HIP_F16) hipLaunchKernelGGL(gemv_valu_kernel<1>, dim3((a.N + wpb - 1) / wpb), dim3(wpb * 64), 0, c->stream, b, epi, pro == PRO_F16 ? 1 : 0);
         else hipLaunchKernelGGL(gemv_valu_kernel<0>, dim3((a.N + wpb - 1) / wpb), dim3(wpb * 64), 0, c->stream, b, epi, pro == PRO_F16 ? 1 : 0);
         HIPCHK(hipGetLastError());
+        return prof_end(c);
+    }
+    if (a.stream && w.type == TTS_HIP_F16 && a.R <= 16 && pro != PRO_LN) {
+        CHK(prof_begin(c, kclass, bytes, flops));
+        CHK(launch_stream(c, a, pro, epi));
         return prof_end(c);
     }
     if (c->gemv_rows && a.R <= 4 && pro == PRO_F32 && (epi == EPI_STORE || epi == EPI_RESID) && !a.kchunk) {
@@ -1638,8 +1688,11 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->di_cv, (size_t) c->L * U * n * A));
         CHK(dmalloc(&c->di_k, (size_t) c->L * R * G * kvH));  // [L][2U][G][kvH]
         CHK(dmalloc(&c->di_v, (size_t) c->L * R * G * kvH));
-        CHK(dmalloc(&c->di_x, (size_t) R * DH)); CHK(dmalloc(&c->di_xn, (size_t) R * DH)); CHK(dmalloc(&c->di_qkv, (size_t) R * (A + 2 * kvH)));
-        CHK(dmalloc(&c->di_q, (size_t) R * A)); CHK(dmalloc(&c->di_att, (size_t) R * A)); CHK(dmalloc(&c->di_gu, (size_t) R * 2 * DF)); CHK(dmalloc(&c->di_g, (size_t) R * DF));
+        CHK(dmalloc(&c->di_x, (size_t) R * DH)); CHK(dmalloc(&c->di_xn, (size_t) R * DH)); 
+        // the projections of a step with <= 16 rows may arrive as up to DIA_STREAM_SLABS K-slice slabs of 16 rows (gemv_stream_kernels.h)
+        const size_t RSL = std::max((size_t) R, (size_t) DIA_STREAM_SLABS * 16);
+        CHK(dmalloc(&c->di_qkv, RSL * (A + 2 * kvH)));
+        CHK(dmalloc(&c->di_q, RSL * A)); CHK(dmalloc(&c->di_att, (size_t) R * A)); CHK(dmalloc(&c->di_gu, RSL * 2 * DF)); CHK(dmalloc(&c->di_g, (size_t) R * DF));
         CHK(dmalloc(&c->di_parts, (size_t) 8 * c->RMAX * DH));
         CHK(dmalloc(&c->di_logits, (size_t) R * c->di_Vpad)); CHK(dmalloc(&c->di_guided, (size_t) U * c->NO * c->di_V));
         const int maxK = std::max(std::max(EH, EF), std::max(std::max(DH, DF), A));
@@ -2723,7 +2776,8 @@ extern "C" tts_hip_ctx *tts_hip_orpheus_create(int device, const tts_hip_orpheus
 // attention of the Llama / Dia steps: one workgroup per (head, row), or — few rows, many keys — the keys split over `nz` workgroups
 // plus a combine launch (attn_gqa_split_kernel).  max_keys bounds the LDS score buffer.
 static int launch_attn_gqa(tts_hip_ctx *c, int NHq, int rows, int max_keys, const float *qkv, int ld, const uint32_t *pos, const float *kc, const float *vc, int NKV,
-                           float scale, float *out, const uint32_t *kbeg, const uint32_t *kend, const uint32_t *row_seq, int64_t seq_stride, bool fixed_split, bool q_out = false) {
+                           float scale, float *out, const uint32_t *kbeg, const uint32_t *kend, const uint32_t *row_seq, int64_t seq_stride, bool fixed_split, bool q_out = false,
+                           QPre qp = QPre{}) {
     int nz = 1;
     if (c->attn_split_max > 1 && NHq * rows <= 256) {
         // a graph captured once replays for every position: the split count must not depend on the position then
@@ -2732,13 +2786,13 @@ static int launch_attn_gqa(tts_hip_ctx *c, int NHq, int rows, int max_keys, cons
     }
     if (nz <= 1) {
         hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NHq, rows), dim3(256), (size_t) (128 + max_keys) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, out, kbeg, kend,
-                           row_seq, seq_stride);
+                           row_seq, seq_stride, qp);
         HIPCHK(hipGetLastError());
         return 0;
     }
     const int chunk = (max_keys + nz - 1) / nz;
     hipLaunchKernelGGL(attn_gqa_split_kernel<128>, dim3(NHq, rows, nz), dim3(256), (size_t) (128 + chunk + 1) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part,
-                       kbeg, kend, row_seq, seq_stride);
+                       kbeg, kend, row_seq, seq_stride, qp);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(attn_gqa_combine_kernel, dim3(NHq, rows), dim3(128), 0, c->stream, (const float *) c->attn_part, nz, NHq, out, q_out ? c->aq : (int8_t *) nullptr, q_out ? c->ad : (float *) nullptr);
     if (q_out) c->aq_src = out;
@@ -2970,6 +3024,22 @@ static int dia_gemm(tts_hip_ctx *c, const W &w, const float *A, int lda, float *
     return 0;
 }
 
+// <= 16 rows through gemv_stream_kernel: `out` receives *slabs K-slice slabs 16 * ldo floats apart (the consumer folds them);
+// *slabs = 0: the shape does not qualify and nothing was launched
+static int dia_gemm_stream(tts_hip_ctx *c, const W &w, const float *A, int lda, float *out, int ldo, int n, int max_slabs, int64_t slab_stride, int *slabs) {
+    const int ks = stream_slices(c, w, n, max_slabs);
+    *slabs = ks;
+    if (!ks) return 0;
+    GemmArgs g{};
+    g.R = n; g.H = c->H;
+    g.A = A; g.lda = lda;
+    g.out = out; g.ldo = ldo;
+    g.stream = 1;
+    g.kchunk = ks > 1 ? (int) w.K / ks : 0;
+    g.slab_stride = slab_stride;
+    return run_gemm(c, TTS_HIP_K_GEMM_OTHER, w, g, PRO_F32, EPI_STORE);
+}
+
 static int dia_rms(tts_hip_ctx *c, size_t w_off, int rows, int H, float *x, float *y, bool fold) {
     const int pend = fold ? c->di_pending : 0;
     hipLaunchKernelGGL(rms_fold_rows_kernel, dim3(rows), dim3(256), 0, c->stream, x, H, (const float *) (c->arena + w_off), y, rows, 1e-5f,
@@ -3098,27 +3168,41 @@ extern "C" int tts_hip_dia_step_batch(tts_hip_ctx *c, uint32_t n_utt, const uint
         const auto &y = c->di_dec[(size_t) l];
         float *kc = c->di_k + (size_t) l * RS * G * kvH, *vc = c->di_v + (size_t) l * RS * G * kvH;
         const float *ck = c->di_ck + (size_t) l * RS * S * A, *cv = c->di_cv + (size_t) l * RS * S * A;
+        // every projection: gemv_stream_kernel slabs folded by its consumer when the step has <= 16 rows and fp16 matrices
+        // (sl = slabs written, 0 = shape does not qualify -> gemm16_kernel as before)
+        int sl = 0;
+        const int64_t st16 = 16;   // slab stride in rows
         CHK(dia_rms(c, y.sa_norm, R, DH, c->di_x, c->di_xn, true));
-        CHK(dia_gemm(c, y.sqkv, c->di_xn, DH, c->di_qkv, QKV, R, EPI_STORE));
+        CHK(dia_gemm_stream(c, y.sqkv, c->di_xn, DH, c->di_qkv, QKV, R, DIA_STREAM_SLABS, st16 * QKV, &sl));
+        if (!sl) CHK(dia_gemm(c, y.sqkv, c->di_xn, DH, c->di_qkv, QKV, R, EPI_STORE));
         hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(R, NH + NKV), dim3(64), 0, c->stream, c->di_qkv, (const uint32_t *) c->di_pos, (const float *) nullptr, theta_scale, NH,
-                           NKV, HD, kc, vc, (const uint32_t *) c->di_seq, (int64_t) G * kvH);
+                           NKV, HD, kc, vc, (const uint32_t *) c->di_seq, (int64_t) G * kvH, std::max(sl, 1), st16 * QKV);
         HIPCHK(hipGetLastError());
         CHK(launch_attn_gqa(c, NH, R, (int) max_pos + 1, (const float *) c->di_qkv, QKV, (const uint32_t *) c->di_pos, (const float *) kc, (const float *) vc, NKV, 1.0f,
                             c->di_att, nul, nul, (const uint32_t *) c->di_seq, (int64_t) G * kvH, false));
-        CHK(dia_gemm(c, y.so, c->di_att, A, c->di_x, DH, R, EPI_RESID));
-        CHK(dia_rms(c, y.ca_norm, R, DH, c->di_x, c->di_xn, false));
-        CHK(dia_gemm(c, y.cq, c->di_xn, DH, c->di_q, A, R, EPI_STORE));
-        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(R, NH), dim3(64), 0, c->stream, c->di_q, (const uint32_t *) c->di_pos, (const float *) nullptr, theta_scale, NH, 0, HD,
-                           (float *) nullptr, (float *) nullptr, nul, (int64_t) 0);
-        HIPCHK(hipGetLastError());
+        CHK(dia_gemm_stream(c, y.so, c->di_att, A, c->di_parts, DH, R, DIA_STREAM_SLABS, (int64_t) c->RMAX * DH, &sl));
+        if (sl) c->di_pending = sl;
+        else CHK(dia_gemm(c, y.so, c->di_att, A, c->di_x, DH, R, EPI_RESID));
+        CHK(dia_rms(c, y.ca_norm, R, DH, c->di_x, c->di_xn, true));
+        CHK(dia_gemm_stream(c, y.cq, c->di_xn, DH, c->di_q, A, R, DIA_STREAM_SLABS, st16 * A, &sl));
+        if (!sl) CHK(dia_gemm(c, y.cq, c->di_xn, DH, c->di_q, A, R, EPI_STORE));
+        QPre qp;   // slab fold + rope of the cross-attention query happen as the attention workgroups load it
+        qp.n_parts = std::max(sl, 1); qp.part_stride = st16 * A; qp.rope_pos = c->di_pos; qp.theta_scale = theta_scale;
         CHK(launch_attn_gqa(c, NH, R, S, (const float *) c->di_q, A, (const uint32_t *) c->di_pos, ck, cv, NH, 1.0f, c->di_att, nul, (const uint32_t *) c->di_cend,
-                            (const uint32_t *) c->di_seq, (int64_t) S * A, false));
-        CHK(dia_gemm(c, y.co, c->di_att, A, c->di_x, DH, R, EPI_RESID));
-        CHK(dia_rms(c, y.mlp_norm, R, DH, c->di_x, c->di_xn, false));
-        CHK(dia_gemm(c, y.gu, c->di_xn, DH, c->di_gu, 2 * DF, R, EPI_STORE));
-        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) R * DF + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->di_gu, DF, R, c->di_g, (int8_t *) nullptr, (float *) nullptr);
+                            (const uint32_t *) c->di_seq, (int64_t) S * A, false, false, qp));
+        CHK(dia_gemm_stream(c, y.co, c->di_att, A, c->di_parts, DH, R, DIA_STREAM_SLABS, (int64_t) c->RMAX * DH, &sl));
+        if (sl) c->di_pending = sl;
+        else CHK(dia_gemm(c, y.co, c->di_att, A, c->di_x, DH, R, EPI_RESID));
+        CHK(dia_rms(c, y.mlp_norm, R, DH, c->di_x, c->di_xn, true));
+        CHK(dia_gemm_stream(c, y.gu, c->di_xn, DH, c->di_gu, 2 * DF, R, DIA_STREAM_SLABS, st16 * 2 * DF, &sl));
+        if (!sl) CHK(dia_gemm(c, y.gu, c->di_xn, DH, c->di_gu, 2 * DF, R, EPI_STORE));
+        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) R * DF + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->di_gu, DF, R, c->di_g, (int8_t *) nullptr,
+                           (float *) nullptr, std::max(sl, 1), st16 * 2 * DF);
         HIPCHK(hipGetLastError());
-        if (c->di_ksplit > 1) {
+        CHK(dia_gemm_stream(c, y.out, c->di_g, DF, c->di_parts, DH, R, DIA_STREAM_SLABS, (int64_t) c->RMAX * DH, &sl));
+        if (sl) {
+            c->di_pending = sl;
+        } else if (c->di_ksplit > 1) {
             CHK(dia_gemm(c, y.out, c->di_g, DF, c->di_parts, DH, R, EPI_STORE, c->di_ksplit));
             c->di_pending = c->di_ksplit;
         } else {
