@@ -37,6 +37,9 @@ typedef struct {
     /* generator geometry (kokoro.decoder.generator.{up_convs,noise_blocks,res_blocks}.*) */
     int32_t up_stride[4], up_padding[4], noise_stride[4], noise_padding[4];
     int32_t res_padding[16][3], res_dilation[16][3], noise_res_padding[4][3], noise_res_dilation[4][3];
+    /* ALBERT's ggml_gelu (model.cpp:1000): 1 = ggml's CPU path, tanh-GELU through its fp16-indexed table (round x to fp16, result
+     * rounded to fp16; orc_gelu in tts_oracle.c); 0 = fp32 tanh-GELU, for the comparison with the float64 torch fixture */
+    int32_t gelu_mode;
 } orc_kokoro_model;
 
 static const float *kt(const orc_kokoro_model *m, const char *name, int64_t *ne) {
@@ -333,7 +336,7 @@ void orc_kokoro_durations(const orc_kokoro_model *m, const uint32_t *tokens, int
             norm_vec(o + (size_t) t * H, H, 1e-12f, kt(m, nm, NULL), kt(m, nb, NULL), x + (size_t) t * H);
         }
         AL("ffn", "ffn_bias"); lin_rows(ffn_w, kt(m, nb, NULL), x, n, H, F, ff);
-        for (size_t i = 0; i < (size_t) n * F; i++) ff[i] = orc_gelu(ff[i], 0);
+        for (size_t i = 0; i < (size_t) n * F; i++) ff[i] = orc_gelu(ff[i], m->gelu_mode);
         AL("ffn_out", "ffn_out_bias"); lin_rows(kt(m, nm, NULL), kt(m, nb, NULL), ff, n, F, H, o);
         AL("attn_norm", "attn_norm_bias");   /* full_layer_layer_norm (:742-747) */
         for (int t = 0; t < n; t++) {

@@ -725,14 +725,15 @@ class KokoroModelC(C.Structure):
         (n, C.c_float) for n in ("attn_scale", "upsample_scale", "sample_rate", "sin_amp", "noise_std", "voice_threshold")] + [
         ("up_stride", C.c_int32 * 4), ("up_padding", C.c_int32 * 4), ("noise_stride", C.c_int32 * 4), ("noise_padding", C.c_int32 * 4),
         ("res_padding", (C.c_int32 * 3) * 16), ("res_dilation", (C.c_int32 * 3) * 16), ("noise_res_padding", (C.c_int32 * 3) * 4),
-        ("noise_res_dilation", (C.c_int32 * 3) * 4)]
+        ("noise_res_dilation", (C.c_int32 * 3) * 4), ("gelu_mode", C.c_int32)]
 
 
 class KokoroOracle:
     """Oracle twin of a tts_cpp_amd.synth.SynthKokoro (src/models/kokoro/model.cpp restated in kokoro_oracle.c; PARITY UNPINNED,
     see that file's header).  The phonemizer is outside: inputs are phoneme ids with the bos / eos ids around them."""
 
-    def __init__(self, model, attn_scale=0.125):
+    def __init__(self, model, attn_scale=0.125, gelu_mode=1):
+        """gelu_mode 1: ALBERT's GELU through ggml's fp16 table like the reference's CPU path; 0: fp32 (the torch fixture)"""
         self.L = lib()
         L = self.L
         L.orc_kokoro_durations.argtypes = [C.POINTER(KokoroModelC), C.POINTER(C.c_uint32), C.c_int, fp, fp, fp]
@@ -752,6 +753,7 @@ class KokoroOracle:
         m.n_decoder_blocks, m.n_upsamples, m.n_kernels = cfg.decoder_blocks, len(cfg.up_rates), len(cfg.res_kernels)
         m.n_fft, m.hop, m.harmonic_num, m.up_sampling_factor, m.out_conv_padding = cfg.n_fft, cfg.hop, cfg.harmonic_num, cfg.up_sampling_factor, 3
         # model.h:196,195,219-222 defaults
+        m.gelu_mode = int(gelu_mode)
         m.attn_scale, m.upsample_scale, m.sample_rate, m.sin_amp, m.noise_std, m.voice_threshold = attn_scale, float(np.prod(cfg.up_rates) * cfg.hop), 24000.0, 0.1, 0.003, 10.0
         g = model.geometry
         for i, (st, pd) in enumerate(g["up"]):

@@ -114,7 +114,9 @@ def test_kokoro_82m_shapes_match_oracle():
     toks = np.concatenate([[0], rng.integers(1, cfg.vocab, 10), [0]]).astype(np.uint32)
     lens, hid = eng.durations(toks, cfg.voices[0])
     ref_lens, ref_hid = o.durations(toks, cfg.voices[0])
-    assert np.array_equal(lens, ref_lens) and relerr(hid, ref_hid) < 2e-4   # measured 9e-7
+    # ALBERT's GELU goes through ggml's fp16 table on both sides (kokoro/model.cpp:1000): an x within fp32 rounding distance of an fp16
+    # boundary lands in the neighbouring entry (1e-3 of that element) -> measured 3.4e-4 over the states (9e-7 with an fp32 GELU)
+    assert np.array_equal(lens, ref_lens) and relerr(hid, ref_hid) < 2e-3
     forced = np.full(toks.size, 2.0, dtype=np.float32)       # forced durations: shape determinism, and both sides see the same alignment
     noise = rng.random(o.noise_len(int(forced.sum())), dtype=np.float32)
     ref_pcm, _, _, ref_hs = o.generate(toks, forced, ref_hid, cfg.voices[0], noise, want_curves=True)

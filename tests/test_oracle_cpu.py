@@ -350,11 +350,12 @@ def test_dia_generate_loop_and_codec():
 
 
 # ---- Kokoro (src/models/kokoro/model.cpp; oracle/kokoro_oracle.c, parity unpinned: see its header) -------------------------
-def _kokoro_case():
+def _kokoro_case(gelu_mode=0):
+    """gelu_mode 0: fp32 tanh-GELU like the float64 torch fixture (the product semantics, ggml's fp16 table, is mode 1)"""
     from tts_cpp_amd import synth as sy
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_kokoro.npz"))
     model = sy.build_kokoro(sy.kokoro_tiny())
-    o = orc.KokoroOracle(model)
+    o = orc.KokoroOracle(model, gelu_mode=gelu_mode)
     total = int(g["lens"].sum())
     noise = np.random.default_rng(int(g["noise_seed"])).random(9 * 50 * model.cfg.up_sampling_factor, dtype=np.float32)[:o.noise_len(total)]
     return g, model, o, noise
@@ -388,6 +389,17 @@ def test_kokoro_generation_graph_matches_torch_golden():
     # everything after the conditioning, sample for sample
     assert pcm.shape == g["pcm"].shape == (int(g["lens"].sum()) * cfg.up_sampling_factor,)
     assert np.abs(pcm - g["pcm"]).max() < 5e-5 * np.abs(g["pcm"]).max()
+
+
+def test_kokoro_albert_gelu_through_the_fp16_table():
+    """ggml_gelu on the CPU goes through a table indexed by the fp16 bits of x (kokoro/model.cpp:1000): the default oracle mode follows it —
+    close to, but not equal to, the fp32 evaluation"""
+    g, model, o0, _ = _kokoro_case(0)
+    _, _, o1, _ = _kokoro_case(1)
+    l0, h0 = o0.durations(g["tokens"], "af_test")
+    l1, h1 = o1.durations(g["tokens"], "af_test")
+    d = np.abs(h1 - h0).max()
+    assert 0 < d < 5e-3 * np.abs(h0).max()
 
 
 def test_kokoro_forced_durations_and_noise():

@@ -75,11 +75,20 @@ __global__ __launch_bounds__(64) void kk_albert_attn_kernel(const float *q, cons
     }
 }
 
-__global__ void kk_gelu_kernel(float *x, int64_t n) {   // ggml_gelu (tanh form)
+// ggml_gelu as the reference's CPU path evaluates it (kokoro/model.cpp:1000): tanh form through the table indexed by the fp16 bits of x,
+// i.e. x rounded to fp16 and the result rounded to fp16, 0 / x outside (-10, 10) — the same arithmetic as gelu_apply(mode 1), parler_kernels.h
+__global__ void kk_gelu_kernel(float *x, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = x[i];
-    x[i] = 0.5f * v * (1.0f + tanhf(0.79788456080286535587989211986876f * v * (1.0f + 0.044715f * v * v)));
+    float o;
+    if (v <= -10.0f) o = 0.0f;
+    else if (v >= 10.0f) o = v;
+    else {
+        const float vr = (float) (_Float16) v;
+        o = (float) (_Float16) (0.5f * vr * (1.0f + tanhf(0.79788456080286535587989211986876f * vr * (1.0f + 0.044715f * vr * vr))));
+    }
+    x[i] = o;
 }
 
 // out[i] = (a[i] + b[i]) * scale
