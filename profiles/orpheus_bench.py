@@ -66,3 +66,26 @@ print(f"layers={cfg.layers} prompt 32 + 64 tokens {res[64]*1e3:.1f} ms, + 448 to
       f"({1/step:.0f} tokens/s = {1/step/7*2048/24000:.2f}x real time: 7 tokens per 2048-sample SNAC frame at 24 kHz)")
 print(f"Q4_0 bytes per step {q4_bytes/1e9:.3f} GB -> {q4_bytes/step/1e9:.0f} GB/s algorithmic ({q4_bytes/step/8e12*100:.1f}% of 8 TB/s); "
       f"HBM floor {q4_bytes/8e12*1e3:.3f} ms/step")
+
+# the default generation_configuration samples (top_k 50, temperature 1, top_p 1): sampler::sample over the 156 940 logits on the device
+u = rng.random(448, dtype=np.float32)
+eng.generate_sampled(prompt, 16, NO_STOP, u[:16], top_k=50, repetition_penalty=1.1)
+rs = {}
+for n in (64, 448):
+    t0 = time.perf_counter()
+    out = eng.generate_sampled(prompt, n, NO_STOP, u[:n], top_k=50, temperature=0.6, repetition_penalty=1.1)
+    rs[n] = time.perf_counter() - t0
+    assert len(out) == n
+sstep = (rs[448] - rs[64]) / (448 - 64)
+print(f"sampled on the device (top_k 50, temperature 0.6, repetition penalty 1.1): {sstep*1e3:.3f} ms/step ({(sstep - step)*1e6:+.0f} us vs the arg-max loop)")
+# the per-step host loop it replaces: logits D2H (628 KB) + a full sort of 156 940 values per step
+import ctypes as C
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+t0 = time.perf_counter()
+lg, _ = eng.decode(prompt, 0)
+pos = len(prompt)
+for s in range(16):
+    order = np.argsort(-lg, kind="stable")[:50]        # stand-in for the host sampler's sort: the cost is the point here
+    lg, _ = eng.decode([int(order[0])], pos)
+    pos += 1
+print(f"per-step host loop (decode + logits D2H + numpy sort of the vocabulary): {(time.perf_counter() - t0) / 16 * 1e3:.2f} ms/step")

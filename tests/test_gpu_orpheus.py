@@ -123,9 +123,35 @@ def test_orpheus_runner_generates_through_both_contexts(tmp_path):
     # with the noise block active the audio differs and stays a tanh output
     noisy = r.generate("hello the zebra", voice=b"zoe", sample=0)
     assert noisy.shape == pcm.shape and np.abs(noisy).max() <= 1.0 and not np.array_equal(noisy, pcm)
-    # sampling goes through the host sampler (156 940 logits in the real model; the device sampler stops at 2048)
-    sampled = r.generate("hello the zebra", voice=b"zoe", sample=1, top_k=8, seed=3)
-    assert sampled.size % full.scfg.hop == 0 and np.isfinite(sampled).all()
+    # seeded sampling: the device sampler loop (tts_hip_orpheus_generate_sampled; top_k 1..64, top_p 1) == the per-step host loop
+    # (logits D2H + sampler::sample on the host), token for token; other configurations take the host loop
+    os.environ["TTS_SNAC_NO_NOISE"] = "1"
+    try:
+        def run(**kw):   # random weights may sample a text id where an audio id belongs: the SNAC context refuses it, the ids are still there
+            try:
+                pcm_ = r.generate("hello the zebra", voice=b"zoe", sample=1, **kw)
+            except runner.RunnerError as e:
+                assert "codebook size" in str(e)
+                pcm_ = None
+            return pcm_, r.last_tokens(1).copy()
+        # top_k stays below the number of distinct logits: this synthetic model has a block of exactly equal logits (untrained text rows),
+        # and the order of equal keys is where the device (index order) and std::sort (unspecified, sampler.cpp:167) may differ
+        for kw in (dict(top_k=8, seed=3), dict(top_k=16, temperature=0.8, seed=11), dict(top_k=20, temperature=1.3, repetition_penalty=1.3, seed=5)):
+            sampled, dev_toks = run(**kw)
+            os.environ["TTS_HOST_LOOP"] = "1"
+            try:
+                hst, hst_toks = run(**kw)
+            finally:
+                del os.environ["TTS_HOST_LOOP"]
+            assert len(dev_toks) > 0 and np.array_equal(dev_toks, hst_toks), kw
+            assert (sampled is None) == (hst is None)
+            if sampled is not None:
+                assert np.array_equal(sampled, hst) and sampled.size % full.scfg.hop == 0 and np.isfinite(sampled).all()
+        assert not np.array_equal(dev_toks, np.array(toks[:len(dev_toks)]))     # it does sample
+        nucleus, ntoks = run(top_k=0, top_p=0.9, seed=3)   # host loop
+        assert len(ntoks) > 0 and (nucleus is None or (nucleus.size % full.scfg.hop == 0 and np.isfinite(nucleus).all()))
+    finally:
+        del os.environ["TTS_SNAC_NO_NOISE"]
     with pytest.raises(runner.RunnerError):
         r.generate("hello", voice=b"nobody", sample=0)
     r.close()
@@ -174,3 +200,91 @@ def test_orpheus_runner_with_the_noise_block(tmp_path):
     noise2, _, _ = minstd0_normal(so.noise_len(T), state, saved)
     assert np.abs(pcm2 - so.decode(np.array(levels[0] + levels[1] + levels[2], dtype=np.uint32), T, noise2)).max() < 1e-4
     r.close()
+
+
+def _oracle_sampler(v, top_k, temp, rep):
+    import ctypes as C
+    smp = orc.Sampler()
+    orc.lib().orc_sampler_init(C.byref(smp), 1, v)
+    smp.top_k, smp.temperature, smp.top_p, smp.repetition_penalty, smp.do_sample = top_k, temp, 1.0, rep, 1
+    orc.lib().orc_sampler_reset(C.byref(smp))
+    return smp
+
+
+@pytest.mark.parametrize("top_k,temp,rep", [(50, 1.0, 1.0), (50, 0.6, 1.1), (64, 1.4, 1.0), (1, 1.0, 1.0), (7, 0.9, 1.5)])
+def test_orpheus_device_sampler_over_the_full_vocabulary(top_k, temp, rep):
+    """sampler::sample over 156 940 logits (orpheus/model.cpp:389-398): topk_parts_kernel + topk_sample_kernel against the oracle sampler
+    (pinned to the compiled src/sampler.cpp by tests/test_sampler.py), same logits, same uniform draw, same repetition state, three calls
+    deep.  Bar: identical ids; a draw within a few ulp of a CDF boundary may land on the neighbouring candidate (device expf vs libm)."""
+    import ctypes as C
+    cfg = synth.orpheus_tiny(vocab=156940)
+    model = synth.build_orpheus(cfg)
+    eng = hip.OrpheusEngine(cfg)
+    eng.load(model)
+    V = cfg.vocab
+    rng = np.random.default_rng(top_k * 31 + int(temp * 10))
+    bad = 0
+    for case in range(6):
+        last, cnt = (int(rng.integers(0, V)), int(rng.integers(1, 5))) if rep != 1.0 else (-1, 0)
+        smp = _oracle_sampler(V, top_k, temp, rep)
+        if rep != 1.0:
+            smp.last_token_ids[0], smp.repetition_counts[0] = last, cnt
+        for call in range(3):
+            lg = (rng.standard_normal(V) * 3.0).astype(np.float32)
+            if rep != 1.0 and call == 1 and last >= 0:
+                lg[last] = 20.0     # the token sampled last is the arg-max: its penalised value decides the softmax maximum
+            u = float(np.float32([0.0, 0.99999994][case]) if case < 2 and call == 0 else rng.random(dtype=np.float32))
+            tok, last, cnt = eng.sample_logits(lg, u, top_k=top_k, temperature=temp, repetition_penalty=rep, last_id=last, rep_count=cnt)
+            ref = np.zeros(1, dtype=np.uint32)
+            orc.lib().orc_sampler_sample(C.byref(smp), orc.f32p(lg.copy()), orc.f32p(np.float32([u])), orc.u32p(ref))
+            if tok != int(ref[0]):
+                bad += 1
+                break   # the states have diverged
+            if rep != 1.0:
+                assert (smp.last_token_ids[0], smp.repetition_counts[0]) == (last, cnt)
+            if top_k == 1:
+                pen = lg.copy()
+                assert tok == int(pen.argmax()) or rep != 1.0
+    assert bad <= 1, bad
+    with pytest.raises(hip.HipError):
+        eng.sample_logits(np.zeros(V, dtype=np.float32), 0.5, top_k=65)       # beyond the device sampler: host loop
+    with pytest.raises(hip.HipError):
+        eng.sample_logits(np.zeros(V, dtype=np.float32), 0.5, top_k=50, top_p=0.9)
+    eng.close()
+
+
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_orpheus_sampled_generation_equals_the_per_step_host_loop(graph):
+    """tts_hip_orpheus_generate_sampled (eager steps and the captured step) == decode + logits D2H + the oracle sampler per step with the same
+    uniform draws: the ids, the stop on the stopping token, several chunks of 8 replays"""
+    import ctypes as C
+    model = synth.build_orpheus(synth.orpheus_tiny())
+    cfg = model.cfg
+    os.environ["TTS_HIP_LLAMA_GRAPH"] = graph
+    try:
+        eng = hip.OrpheusEngine(cfg)
+    finally:
+        del os.environ["TTS_HIP_LLAMA_GRAPH"]
+    eng.load(model)
+    g = np.load(GOLD)
+    prompt = g["prompt"]
+    for top_k, temp, rep, seed in ((8, 1.0, 1.0, 1), (50, 0.8, 1.2, 2), (3, 1.5, 1.0, 3)):
+        n = 30
+        u = np.random.default_rng(seed).random(n, dtype=np.float32)
+        got = eng.generate_sampled(prompt, n, stop_id=cfg.vocab + 5, uniforms=u, top_k=top_k, temperature=temp, repetition_penalty=rep)
+        smp = _oracle_sampler(cfg.vocab, top_k, temp, rep)
+        ref, pos = [], len(prompt)
+        lg, _ = eng.decode(prompt, 0)
+        for s in range(n):
+            t = np.zeros(1, dtype=np.uint32)
+            orc.lib().orc_sampler_sample(C.byref(smp), orc.f32p(lg.copy()), orc.f32p(u[s:s + 1].copy()), orc.u32p(t))
+            ref.append(int(t[0]))
+            if s + 1 < n:
+                lg, _ = eng.decode([ref[-1]], pos)
+                pos += 1
+        assert got.tolist() == ref, (top_k, temp, rep)
+        stop = ref[4]
+        first = ref.index(stop)
+        assert eng.generate_sampled(prompt, n, stop_id=stop, uniforms=u, top_k=top_k, temperature=temp, repetition_penalty=rep).tolist() == ref[:first + 1]
+    assert len(set(ref)) > 1
+    eng.close()

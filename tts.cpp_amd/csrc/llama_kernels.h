@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "parler_kernels.h"   // smp_key: the candidate order of the device samplers
 
 // Q8_0 block of 32 consecutive values held one per lane by 32 neighbouring lanes (ggml's quantize_row_q8_0_ref: d = amax / 127 kept
 // as fp16, q = roundf(x / d)) — the same arithmetic as quant_rows_q8_kernel, for producers that quantise their own output row.
@@ -445,6 +446,113 @@ __global__ __launch_bounds__(64) void argmax_fold_graph_kernel(const float *pv, 
         hist_idx[0] += 1;
         next_id[0] = t;
         next_pos[0] += 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampler::sample over the 156 940-logit vocabulary (orpheus/model.cpp:389-398, sampler.cpp:3-69 with topk :152-183 and softmax :82-116)
+// for the default shape of a generation configuration: top_k in 1..TOPK_MAXK, top_p >= 1.  The reference sorts all 156 940 indices by
+// (penalised) value on the host at every step; only the first top_k of that order are ever read, so two stages find them:
+//   topk_parts_kernel   TOPK_PARTS workgroups, each sorts its slice of the vocabulary (bitonic, 64-bit keys = value descending, index
+//                       ascending — the total order of sample_kernel / smp_key) and keeps its first k keys;
+//   topk_sample_kernel  one workgroup sorts the TOPK_PARTS * k survivors, takes the first k (the reference's `picks`), and runs the
+//                       rest of sampler::sample exactly as sample_kernel does: softmax over the picks in pick order (sequential fp32
+//                       sum, exp(v / T - top) with top = the penalised maximum / T), inverse-CDF scan against the host-drawn uniform,
+//                       repetition state update (sampler.cpp:57-63); it then feeds the token back like argmax_fold_*_kernel.
+// The token sampled last takes part with v / pow(penalty, count) evaluated in double (sampler.cpp:89-90,172-175); pen_table[c] =
+// pow(penalty, c) comes from the host libm.
+// ------------------------------------------------------------------------------------------------
+#define TOPK_PARTS 64
+#define TOPK_SLICE 4096   // keys one part sorts: vocabularies up to TOPK_PARTS * TOPK_SLICE = 262 144
+#define TOPK_MAXK 64
+
+__device__ __forceinline__ void bitonic_sort_keys(unsigned long long *keys, int P) {
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+                const int lo = ((t / stride) * (stride << 1)) + (t % stride), hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+__device__ __forceinline__ float smp_key_value(unsigned long long key) {   // inverse of smp_key's value field
+    const unsigned u = ~(unsigned) (key >> 32);
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ __launch_bounds__(512) void topk_parts_kernel(const float *logits, int V, int k, const double *pen_table, int pen_len, const int32_t *last_id,
+                                                         const uint32_t *rep_count, unsigned long long *cand) {
+    __shared__ unsigned long long keys[TOPK_SLICE];
+    const int chunk = (V + TOPK_PARTS - 1) / TOPK_PARTS;
+    const int i0 = (int) blockIdx.x * chunk;
+    const int last = pen_table ? last_id[0] : -1;
+    for (int j = threadIdx.x; j < TOPK_SLICE; j += blockDim.x) {
+        const int i = i0 + j;
+        unsigned long long key = ~0ull;
+        if (j < chunk && i < V) {
+            float v = logits[i];
+            if (i == last) {
+                const uint32_t cnt = rep_count[0];
+                v = (float) ((double) v / pen_table[cnt < (uint32_t) pen_len ? cnt : (uint32_t) pen_len - 1]);
+            }
+            key = smp_key(v, i);
+        }
+        keys[j] = key;
+    }
+    __syncthreads();
+    bitonic_sort_keys(keys, TOPK_SLICE);
+    for (int j = threadIdx.x; j < k; j += blockDim.x) cand[(int) blockIdx.x * TOPK_MAXK + j] = keys[j];
+}
+
+// uniforms[call[0]] is this call's draw; call[0] advances.  hist_idx != NULL: captured step, the history slot is hist[hist_idx[0]++];
+// otherwise hist (may be NULL) is the slot itself.  next_id / next_pos (may be NULL): the token goes straight back as the next input.
+__global__ __launch_bounds__(1024) void topk_sample_kernel(const unsigned long long *cand, int k, float temperature, const float *uniforms, uint32_t *call,
+                                                           const double *pen_table, int32_t *last_id, uint32_t *rep_count, uint32_t *token, uint32_t *hist,
+                                                           uint32_t *hist_idx, uint32_t *next_id, uint32_t *next_pos) {
+    __shared__ unsigned long long keys[TOPK_PARTS * TOPK_MAXK];
+    __shared__ float prob[TOPK_MAXK];
+    const int n = TOPK_PARTS * k;
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int j = threadIdx.x; j < P; j += blockDim.x) keys[j] = j < n ? cand[(j / k) * TOPK_MAXK + (j % k)] : ~0ull;
+    __syncthreads();
+    bitonic_sort_keys(keys, P);
+    const bool temp = temperature != 1.0f;
+    float top = smp_key_value(keys[0]);     // sampler::max over the penalised values: first maximum wins = smallest key
+    if (temp) top /= temperature;
+    if ((int) threadIdx.x < k) {
+        float v = smp_key_value(keys[threadIdx.x]);
+        if (temp) v /= temperature;
+        prob[threadIdx.x] = keys[threadIdx.x] == ~0ull ? 0.0f : expf(v - top);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int m = k;                            // fewer than k real candidates only when the vocabulary is smaller than k
+        while (m > 1 && keys[m - 1] == ~0ull) m--;
+        float total = 0.0f;
+        for (int j = 0; j < m; j++) total += prob[j];
+        const float target = uniforms[call[0]];
+        call[0] += 1;
+        float cum = 0.0f;
+        int chosen = (int) (unsigned) keys[m - 1];
+        for (int j = 0; j < m; j++) {
+            cum += prob[j] / total;
+            if (target <= cum || j + 1 >= m) { chosen = (int) (unsigned) keys[j]; break; }
+        }
+        if (pen_table) {
+            uint32_t cnt = rep_count[0];
+            if (last_id[0] != chosen) cnt = 0;
+            last_id[0] = chosen;
+            rep_count[0] = cnt + 1;
+        }
+        token[0] = (uint32_t) chosen;
+        if (hist_idx) { hist[hist_idx[0]] = (uint32_t) chosen; hist_idx[0] += 1; }
+        else if (hist) hist[0] = (uint32_t) chosen;
+        if (next_id) { next_id[0] = (uint32_t) chosen; next_pos[0] += 1; }
     }
 }
 

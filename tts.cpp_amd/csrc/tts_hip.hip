@@ -270,6 +270,9 @@ struct tts_hip_ctx {
     uint32_t *t5_ids = nullptr;
     tts_hip_sampling smp{};     // parameters baked into the captured MODE_GEN_SAMPLE graphs
     float *d_uniforms = nullptr;  // [calls][R][n_out] host-drawn U[0,1) for sample_kernel
+    unsigned long long *l_cand = nullptr;   // Orpheus sampler: [TOPK_PARTS][TOPK_MAXK] stage-1 survivors
+    uint32_t *l_smp = nullptr;              // Orpheus sampler: [0] last token (int32), [1] repetition count, [2] sampler call index
+    struct { const void *uni = nullptr, *pen = nullptr; uint32_t k = 0; float temp = 0; } l_smp_baked;   // what the captured sampled step holds
     double *d_pen = nullptr;      // pow(repetition_penalty, count) table (host-evaluated)
     int pen_len = 0;
     int32_t *d_last = nullptr;    // [RMAX][n_out] sampler::last_token_ids
@@ -406,7 +409,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (auto &t : c->tensors) free_dev(t.second.tmp);
     if (!c->arena_external) free_dev(c->arena);
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
-    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms); free_dev(c->d_pen); free_dev(c->d_last); free_dev(c->d_repc);
+    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms); free_dev(c->l_cand); free_dev(c->l_smp); free_dev(c->d_pen); free_dev(c->d_last); free_dev(c->d_repc);
     free_dev(c->l_x); free_dev(c->l_xn); free_dev(c->l_qkv); free_dev(c->l_att); free_dev(c->l_gu); free_dev(c->l_g); free_dev(c->l_logits); free_dev(c->l_parts);
     free_dev(c->attn_part); free_dev(c->kk_stuck);
     free_dev(c->l_kc); free_dev(c->l_vc); free_dev(c->l_ids); free_dev(c->l_pos); free_dev(c->l_tok);
@@ -1666,6 +1669,8 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->l_ids, (size_t) R));
         CHK(dmalloc(&c->l_pos, (size_t) R));
         CHK(dmalloc(&c->l_tok, (size_t) 1 + 2 * ARGMAX_PARTS + LLAMA_GREEDY_CHUNK + 1));
+        HIPCHK(hipMalloc((void **) &c->l_cand, (size_t) TOPK_PARTS * TOPK_MAXK * 8));
+        CHK(dmalloc(&c->l_smp, (size_t) 4));
     }
     if (c->has_dia) {
         const tts_hip_dia_desc &dd = c->dia;
@@ -2916,18 +2921,89 @@ extern "C" int tts_hip_orpheus_decode(tts_hip_ctx *c, const uint32_t *ids, uint3
     return 0;
 }
 
-extern "C" int tts_hip_orpheus_generate_greedy(tts_hip_ctx *c, const uint32_t *prompt, uint32_t n_prompt, uint32_t max_new, uint32_t stop_id,
-                                               uint32_t *tokens_out, uint32_t *n_out) {
-    if (!tokens_out || !n_out) return set_err("tts_hip_orpheus_generate_greedy: null argument");
-    *n_out = 0;
-    uint32_t tok = 0, pos = n_prompt;
-    CHK(tts_hip_orpheus_decode(c, prompt, n_prompt, 0, nullptr, &tok));
-    // generate_from_batch (:378-392): stop once the last token is the stopping token or max_generation_size ids exist.
-    // The token never leaves the device inside a chunk of LLAMA_GREEDY_CHUNK steps (arg-max writes it back as the next
-    // input and bumps the position); the host looks at a chunk's tokens at once, so at most CHUNK-1 steps run past the
-    // stopping token (their cache rows are never read: the next call starts at position 0).
-    uint32_t *pi = c->l_tok + 1, *hist = c->l_tok + 1 + 2 * ARGMAX_PARTS;
+// sampler::max or sampler::sample of l_logits -> l_tok[0]; captured: the history slot and the uniform come from device counters and the
+// token is fed back; eager: hist_slot (may be NULL) receives the token, feed says whether it goes back as the next input
+static int llama_select(tts_hip_ctx *c, const tts_hip_sampling *sp, bool captured, uint32_t *hist_slot, bool feed) {
+    uint32_t *pi = c->l_tok + 1, *hist = c->l_tok + 1 + 2 * ARGMAX_PARTS, *hist_idx = hist + LLAMA_GREEDY_CHUNK;
     float *pv = (float *) (c->l_tok + 1 + ARGMAX_PARTS);
+    if (!sp) {
+        hipLaunchKernelGGL(argmax_parts_kernel, dim3(ARGMAX_PARTS), dim3(256), 0, c->stream, (const float *) c->l_logits, c->l_V, pv, pi);
+        HIPCHK(hipGetLastError());
+        if (captured)
+            hipLaunchKernelGGL(argmax_fold_graph_kernel, dim3(1), dim3(64), 0, c->stream, (const float *) pv, (const uint32_t *) pi, c->l_tok, hist, hist_idx, c->l_ids, c->l_pos);
+        else
+            hipLaunchKernelGGL(argmax_fold_kernel, dim3(1), dim3(64), 0, c->stream, (const float *) pv, (const uint32_t *) pi, c->l_tok, hist_slot,
+                               feed ? c->l_ids : (uint32_t *) nullptr, feed ? c->l_pos : (uint32_t *) nullptr);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    const double *pen = sp->repetition_penalty != 1.0f ? c->d_pen : nullptr;
+    int32_t *last = (int32_t *) c->l_smp;
+    uint32_t *repc = c->l_smp + 1, *call = c->l_smp + 2;
+    hipLaunchKernelGGL(topk_parts_kernel, dim3(TOPK_PARTS), dim3(512), 0, c->stream, (const float *) c->l_logits, c->l_V, (int) sp->top_k, pen, c->pen_len, (const int32_t *) last,
+                       (const uint32_t *) repc, c->l_cand);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(topk_sample_kernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long *) c->l_cand, (int) sp->top_k, sp->temperature, (const float *) c->d_uniforms,
+                       call, pen, last, repc, c->l_tok, captured ? hist : hist_slot, captured ? hist_idx : (uint32_t *) nullptr,
+                       (captured || feed) ? c->l_ids : (uint32_t *) nullptr, (captured || feed) ? c->l_pos : (uint32_t *) nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// what the two-stage device sampler covers (topk_parts_kernel / topk_sample_kernel, llama_kernels.h); anything else: sample on the host
+// from tts_hip_orpheus_decode's logits
+static int check_llama_sampling(const tts_hip_ctx *c, const tts_hip_sampling *sp, const char *what) {
+    if (!sp) return set_err("%s: null sampling parameters", what);
+    if (!(sp->temperature > 0.0f)) return set_err("%s: temperature must be > 0", what);
+    if (!(sp->repetition_penalty > 0.0f)) return set_err("%s: repetition_penalty must be > 0 (1 = off)", what);
+    if (sp->top_p < 1.0f) return set_err("%s: top_p < 1 needs the softmax over the whole vocabulary in index order: sample on the host", what);
+    if (sp->top_k == 0 || sp->top_k > TOPK_MAXK || (int) sp->top_k >= c->l_V)
+        return set_err("%s: the device sampler takes top_k in 1..%d (got %u): sample on the host", what, TOPK_MAXK, sp->top_k);
+    if (c->l_V > TOPK_PARTS * TOPK_SLICE) return set_err("%s: vocabulary %d > %d", what, c->l_V, TOPK_PARTS * TOPK_SLICE);
+    return 0;
+}
+
+// generate_from_batch (:378-392) with sampler::max (sp == NULL) or sampler::sample (sp, uniforms[max_new])
+static int orpheus_generate(tts_hip_ctx *c, const char *what, const uint32_t *prompt, uint32_t n_prompt, uint32_t max_new, uint32_t stop_id, const tts_hip_sampling *sp,
+                            const float *uniforms, uint32_t *tokens_out, uint32_t *n_out) {
+    if (!c || !c->has_llama) return set_err("%s: not an Orpheus context (tts_hip_orpheus_create)", what);
+    if (!c->finalized || !c->weights_present) return set_err("%s: context not finalized", what);
+    if (!prompt || n_prompt == 0 || !tokens_out || !n_out) return set_err("%s: null argument", what);
+    *n_out = 0;
+    HIPCHK(hipSetDevice(c->device));
+    if (sp) {
+        CHK(check_llama_sampling(c, sp, what));
+        if (!uniforms) return set_err("%s: null uniforms", what);
+        if (max_new == 0) return 0;
+        CHK(stage_uniforms(c, uniforms, (size_t) max_new));   // one sampler call per token, at most max_new tokens
+        CHK(stage_penalty(c, sp->repetition_penalty, (int) max_new));
+        const uint32_t init[3] = {0xFFFFFFFFu, 0u, 0u};   // sampler::reset (sampler.cpp:71-80): last token -1, count 0; call index 0
+        HIPCHK(hipMemcpyAsync(c->l_smp, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const void *pen = sp->repetition_penalty != 1.0f ? (const void *) c->d_pen : nullptr;
+        if (c->l_smp_baked.uni != c->d_uniforms || c->l_smp_baked.pen != pen || c->l_smp_baked.k != sp->top_k || c->l_smp_baked.temp != sp->temperature) {
+            auto it = c->graphs.find(9000002);
+            if (it != c->graphs.end()) { (void) hipGraphExecDestroy(it->second); c->graphs.erase(it); }
+            c->l_smp_baked.uni = c->d_uniforms; c->l_smp_baked.pen = pen; c->l_smp_baked.k = sp->top_k; c->l_smp_baked.temp = sp->temperature;
+        }
+    }
+    uint32_t tok = 0, pos = n_prompt;
+    {   // the prompt (pieces of RMAX rows), then the first selection
+        uint32_t done = 0;
+        while (done < n_prompt) {
+            const uint32_t m = std::min<uint32_t>((uint32_t) c->RMAX, n_prompt - done);
+            CHK(llama_forward(c, prompt + done, (int) m, done));
+            done += m;
+        }
+        CHK(llama_select(c, sp, false, nullptr, false));
+        HIPCHK(hipMemcpyAsync(&tok, c->l_tok, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    // stop once the last token is the stopping token or max_generation_size ids exist.  The token never leaves the device inside a
+    // chunk of LLAMA_GREEDY_CHUNK steps (the selection writes it back as the next input and bumps the position); the host looks at
+    // a chunk's tokens at once, so at most CHUNK-1 steps run past the stopping token (their cache rows are never read: the next
+    // call starts at position 0; the sampler draws they consume belong to no token).
+    uint32_t *hist = c->l_tok + 1 + 2 * ARGMAX_PARTS;
     uint32_t host_hist[LLAMA_GREEDY_CHUNK];
     while (*n_out < max_new) {
         tokens_out[(*n_out)++] = tok;
@@ -2938,11 +3014,11 @@ extern "C" int tts_hip_orpheus_generate_greedy(tts_hip_ctx *c, const uint32_t *p
         HIPCHK(hipMemcpyAsync(c->l_pos, &pos, 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));  // tok / pos are reused below
         if (c->llama_graph && !c->prof) {
-            // one captured step (forward + arg-max + feedback) replayed `chunk` times; the history slot is a device counter
+            // one captured step (forward + selection + feedback) replayed `chunk` times; the history slot is a device counter
             uint32_t *hist_idx = hist + LLAMA_GREEDY_CHUNK;
             HIPCHK(hipMemsetAsync(hist_idx, 0, 4, c->stream));
-            if (pos + chunk > c->lm.n_ctx) return set_err("tts_hip_orpheus_generate_greedy: positions exceed the cache");
-            const int key = 9000001;
+            if (pos + chunk > c->lm.n_ctx) return set_err("%s: positions exceed the cache", what);
+            const int key = sp ? 9000002 : 9000001;
             auto it = c->graphs.find(key);
             if (it == c->graphs.end()) {
                 // one eager pass first: per-kernel attributes are set outside the capture (it rewrites the cache row of `pos`
@@ -2952,11 +3028,7 @@ extern "C" int tts_hip_orpheus_generate_greedy(tts_hip_ctx *c, const uint32_t *p
                 hipGraph_t graph = nullptr;
                 HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
                 int rc = llama_forward(c, nullptr, 1, 0, (int) c->lm.n_ctx);
-                if (rc == 0) {
-                    hipLaunchKernelGGL(argmax_parts_kernel, dim3(ARGMAX_PARTS), dim3(256), 0, c->stream, (const float *) c->l_logits, c->l_V, pv, pi);
-                    hipLaunchKernelGGL(argmax_fold_graph_kernel, dim3(1), dim3(64), 0, c->stream, (const float *) pv, (const uint32_t *) pi, c->l_tok, hist, hist_idx, c->l_ids,
-                                       c->l_pos);
-                }
+                if (rc == 0) rc = llama_select(c, sp, true, nullptr, true);
                 const hipError_t e = hipStreamEndCapture(c->stream, &graph);
                 if (rc != 0) { if (graph) (void) hipGraphDestroy(graph); return rc; }
                 if (e != hipSuccess) return set_err("hipStreamEndCapture: %s", hipGetErrorString(e));
@@ -2969,10 +3041,7 @@ extern "C" int tts_hip_orpheus_generate_greedy(tts_hip_ctx *c, const uint32_t *p
         } else {
             for (uint32_t s = 0; s < chunk; s++) {
                 CHK(llama_forward(c, nullptr, 1, pos + s));
-                hipLaunchKernelGGL(argmax_parts_kernel, dim3(ARGMAX_PARTS), dim3(256), 0, c->stream, (const float *) c->l_logits, c->l_V, pv, pi);
-                HIPCHK(hipGetLastError());
-                hipLaunchKernelGGL(argmax_fold_kernel, dim3(1), dim3(64), 0, c->stream, (const float *) pv, (const uint32_t *) pi, c->l_tok, hist + s, c->l_ids, c->l_pos);
-                HIPCHK(hipGetLastError());
+                CHK(llama_select(c, sp, false, hist + s, true));
             }
         }
         HIPCHK(hipMemcpyAsync(host_hist, hist, (size_t) chunk * 4, hipMemcpyDeviceToHost, c->stream));
@@ -2986,6 +3055,40 @@ extern "C" int tts_hip_orpheus_generate_greedy(tts_hip_ctx *c, const uint32_t *p
         }
         tok = host_hist[s];
     }
+    return 0;
+}
+
+extern "C" int tts_hip_orpheus_generate_greedy(tts_hip_ctx *c, const uint32_t *prompt, uint32_t n_prompt, uint32_t max_new, uint32_t stop_id,
+                                               uint32_t *tokens_out, uint32_t *n_out) {
+    return orpheus_generate(c, "tts_hip_orpheus_generate_greedy", prompt, n_prompt, max_new, stop_id, nullptr, nullptr, tokens_out, n_out);
+}
+
+extern "C" int tts_hip_orpheus_generate_sampled(tts_hip_ctx *c, const uint32_t *prompt, uint32_t n_prompt, uint32_t max_new, uint32_t stop_id,
+                                                const tts_hip_sampling *sampling, const float *uniforms, uint32_t *tokens_out, uint32_t *n_out) {
+    if (!sampling) return set_err("tts_hip_orpheus_generate_sampled: null sampling parameters");
+    return orpheus_generate(c, "tts_hip_orpheus_generate_sampled", prompt, n_prompt, max_new, stop_id, sampling, uniforms, tokens_out, n_out);
+}
+
+extern "C" int tts_hip_orpheus_sample_logits(tts_hip_ctx *c, const float *logits, const tts_hip_sampling *sp, float uniform, int32_t *last_id, uint32_t *rep_count,
+                                             uint32_t *token_out) {
+    if (!c || !c->has_llama) return set_err("tts_hip_orpheus_sample_logits: not an Orpheus context (tts_hip_orpheus_create)");
+    if (!c->finalized) return set_err("tts_hip_orpheus_sample_logits: context not finalized");
+    if (!logits || !token_out) return set_err("tts_hip_orpheus_sample_logits: null argument");
+    CHK(check_llama_sampling(c, sp, "tts_hip_orpheus_sample_logits"));
+    HIPCHK(hipSetDevice(c->device));
+    const bool rep = sp->repetition_penalty != 1.0f;
+    if (rep && (!last_id || !rep_count)) return set_err("tts_hip_orpheus_sample_logits: repetition penalty needs last_id and rep_count");
+    CHK(stage_uniforms(c, &uniform, 1));
+    if (rep) CHK(stage_penalty(c, sp->repetition_penalty, (int) std::min<uint32_t>(*rep_count + 2, 1u << 20)));
+    const uint32_t init[3] = {rep ? (uint32_t) *last_id : 0xFFFFFFFFu, rep ? *rep_count : 0u, 0u};
+    HIPCHK(hipMemcpyAsync(c->l_smp, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->l_logits, logits, (size_t) c->l_V * 4, hipMemcpyHostToDevice, c->stream));
+    CHK(llama_select(c, sp, false, nullptr, false));
+    uint32_t back[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(token_out, c->l_tok, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(back, c->l_smp, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (rep) { *last_id = (int32_t) back[0]; *rep_count = back[1]; }
     return 0;
 }
 

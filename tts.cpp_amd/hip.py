@@ -83,7 +83,7 @@ EXPORTS = [
     "tts_hip_upload", "tts_hip_arena_bytes", "tts_hip_finalize", "tts_hip_arena_ptr", "tts_hip_arena_filled",
     "tts_hip_parler_set_text_encoding", "tts_hip_parler_reset", "tts_hip_parler_prefill", "tts_hip_parler_prefill_batch", "tts_hip_parler_step",
     "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits",
-    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_dia_encode_slot", "tts_hip_dia_step_batch", "tts_hip_kokoro_create", "tts_hip_kokoro_durations", "tts_hip_kokoro_generate", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
+    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_orpheus_generate_sampled", "tts_hip_orpheus_sample_logits", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_dia_encode_slot", "tts_hip_dia_step_batch", "tts_hip_kokoro_create", "tts_hip_kokoro_durations", "tts_hip_kokoro_generate", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
     "tts_hip_synchronize", "tts_hip_broadcast_weights", "tts_hip_comm_unique_id", "tts_hip_broadcast_weights_rank",
 ]
@@ -139,6 +139,8 @@ def load_lib():
     L.tts_hip_orpheus_create.argtypes = [C.c_int, C.POINTER(OrpheusDesc)]
     L.tts_hip_orpheus_decode.argtypes = [vp, u32p, C.c_uint32, C.c_uint32, f32p, u32p]
     L.tts_hip_orpheus_generate_greedy.argtypes = [vp, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
+    L.tts_hip_orpheus_generate_sampled.argtypes = [vp, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Sampling), C.POINTER(C.c_float), u32p, u32p]
+    L.tts_hip_orpheus_sample_logits.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(Sampling), C.c_float, C.POINTER(C.c_int32), u32p, u32p]
     L.tts_hip_kokoro_create.restype = vp
     L.tts_hip_kokoro_create.argtypes = [C.c_int, C.POINTER(KokoroDesc)]
     L.tts_hip_kokoro_durations.argtypes = [vp, u32p, C.c_uint32, C.c_char_p, f32p, f32p]
@@ -521,6 +523,27 @@ class OrpheusEngine:
         n = C.c_uint32()
         self._chk(self.L.tts_hip_orpheus_generate_greedy(self.ctx, ap, a.size, max_new, stop_id, out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n)))
         return out[:n.value]
+
+    def generate_sampled(self, prompt, max_new, stop_id, uniforms, top_k=50, temperature=1.0, repetition_penalty=1.0, top_p=1.0):
+        """sampler::sample on the device (top_k 1..64, top_p >= 1); uniforms [max_new]: the draw of the k-th sampler call"""
+        a, ap = _u32(prompt)
+        u = np.ascontiguousarray(uniforms, dtype=np.float32)
+        assert u.size >= max_new
+        out = np.zeros(max_new, dtype=np.uint32)
+        n = C.c_uint32()
+        sp = Sampling(top_k, top_p, temperature, repetition_penalty)
+        self._chk(self.L.tts_hip_orpheus_generate_sampled(self.ctx, ap, a.size, max_new, stop_id, C.byref(sp), u.ctypes.data_as(C.POINTER(C.c_float)),
+                                                          out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n)))
+        return out[:n.value]
+
+    def sample_logits(self, logits, uniform, top_k=50, temperature=1.0, repetition_penalty=1.0, top_p=1.0, last_id=-1, rep_count=0):
+        """the device sampler on caller-supplied logits [vocab] -> (token, last_id, rep_count)"""
+        lg = np.ascontiguousarray(logits, dtype=np.float32)
+        assert lg.size == self.cfg.vocab
+        sp = Sampling(top_k, top_p, temperature, repetition_penalty)
+        li, rc, tok = C.c_int32(last_id), C.c_uint32(rep_count), C.c_uint32()
+        self._chk(self.L.tts_hip_orpheus_sample_logits(self.ctx, lg.ctypes.data_as(C.POINTER(C.c_float)), C.byref(sp), uniform, C.byref(li), C.byref(rc), C.byref(tok)))
+        return tok.value, li.value, rc.value
 
     def close(self):
         if self.ctx:

@@ -169,8 +169,20 @@ void orpheus_runner::generate(const char * sentence, tts_response & output, cons
         hip_check(tts_hip_orpheus_generate_greedy(lm, prompt.data(), (uint32_t) prompt.size(), hp.max_generation_size, hp.stopping_token_id, out.data(), &n),
                   "tts_hip_orpheus_generate_greedy");
         out.resize(n);
+    } else if (!getenv("TTS_HOST_LOOP") && config.top_p >= 1.0f && config.top_k >= 1 && config.top_k <= 64 && (uint32_t) config.top_k < hp.vocab_size) {
+        // the default shape of a generation_configuration (top_k 50, top_p 1): sampler::sample runs on the device, two kernels pick the
+        // top_k candidates out of the 156 940 logits; the U[0,1) draws are made here, one generator per call as sampler.cpp:47-48
+        std::vector<float> u(hp.max_generation_size);
+        for (auto & v : u) smp.draw_uniforms(&v);
+        tts_hip_sampling sp{(uint32_t) config.top_k, config.top_p, config.temperature, config.repetition_penalty};
+        out.resize(hp.max_generation_size);
+        uint32_t n = 0;
+        hip_check(tts_hip_orpheus_generate_sampled(lm, prompt.data(), (uint32_t) prompt.size(), hp.max_generation_size, hp.stopping_token_id, &sp, u.data(), out.data(), &n),
+                  "tts_hip_orpheus_generate_sampled");
+        out.resize(n);
     } else {
-        // the vocabulary (156 940 logits) is beyond the on-device sampler's 2048: logits come back, sampler::sample runs here
+        // top_p < 1 (softmax over the whole vocabulary in index order) or a top_k the device sampler does not take: logits come back,
+        // sampler::sample runs here
         std::vector<uint32_t> batch = prompt;
         uint32_t pos = 0;
         while ((out.empty() || out.back() != hp.stopping_token_id) && out.size() < hp.max_generation_size) {
