@@ -291,6 +291,20 @@ int tts_hip_dia_step(tts_hip_ctx *ctx, const uint32_t *ids, uint32_t pos, float 
 int tts_hip_dia_encode_slot(tts_hip_ctx *ctx, uint32_t slot, const uint32_t *tokens, uint32_t sentence_len, float *enc_out);
 int tts_hip_dia_step_batch(tts_hip_ctx *ctx, uint32_t n_utt, const uint32_t *slots, const uint32_t *ids, const uint32_t *pos,
                            float *logits_out, float *raw_out);
+/* The whole generate_from_batch loop (dia/model.cpp:806-870) on the device for utterance slots 0..n_utt-1 (encoded with
+ * tts_hip_dia_encode_slot): per step check_stopping (:767-785: EOS on head 0 or position max_gen - max_delay starts the countdown that
+ * forces EOS / PAD into the delayed heads), the decoder step, guidance, sampler::sample (sampling != NULL; sample_kernel, any top_k /
+ * top_p / temperature / repetition penalty at this vocabulary) or sampler::max (NULL), and the delay-pattern feedback (:795-803) run
+ * as one captured graph; the host looks at the done flags every few steps.  uniforms [max_gen][n_utt][n_output_heads]: the draw for
+ * head h of utterance u at its k-th sampler call (ignored for sampler::max).  tokens_out [n_utt][max_gen][n_output_heads]: the
+ * sampled ids in generation order (the runner's output_tokens before adjust_output_tokens); steps_out [n_utt]: sampler calls made. */
+typedef struct tts_hip_dia_codes {
+    uint32_t bos, eos, pad;        /* dia.bos_token_id 1026, eos 1024, pad 1025 (model.h:70-72) */
+    uint32_t max_delay;            /* model.h:74 (15) */
+    uint32_t delay_pattern[16];    /* per output head (model.h:66: 0,8,9,...,15) */
+} tts_hip_dia_codes;
+int tts_hip_dia_generate(tts_hip_ctx *ctx, uint32_t n_utt, uint32_t max_gen, const tts_hip_dia_codes *codes, const tts_hip_sampling *sampling,
+                         const float *uniforms, uint32_t *tokens_out, uint32_t *steps_out);
 
 /* ---- Kokoro (src/models/kokoro/model.cpp) ----------------------------------------------------------------------------
  * Device side of kokoro_duration_runner::run (:1069-1123) and kokoro_runner::run (:1277-1325): create, tts_hip_upload every

@@ -54,9 +54,15 @@ def dia_tensors(cfg, rng):
     def table(name, rows, cols):
         tensors.append(gguf.Tensor(name, gguf.F32, [cols, rows], pool32[: rows * cols * 4]))
 
+    # the rows of the special ids (EOS / PAD / BOS, >= audio_vocab) of every head are zero: random weights then never pick one and
+    # every utterance runs the full max_gen steps
+    head = np.frombuffer(pool16[: cfg.out_vocab * DH * 2].tobytes(), dtype=np.float16).reshape(cfg.out_vocab, DH).copy()
+    head[cfg.audio_vocab:] = 0
+    head = head.reshape(-1).view(np.uint8)
     for i in range(cfg.n_out):
         table(f"dia.decoder.embeddings.{i}", cfg.out_vocab, DH)
-        mat(f"dia.decoder.heads.{i}", cfg.out_vocab, DH)
+        tensors.append(gguf.Tensor(f"dia.decoder.heads.{i}", gguf.F16, [DH, cfg.out_vocab], head))
+        n_dec[0] += cfg.out_vocab * DH
     vec("dia.decoder.norm", DH)
     for l in range(cfg.dec_layers):
         p = f"dia.decoder.layers.{l}."
@@ -97,23 +103,23 @@ def run_dia(args):
     dac.finalize()
     delay = np.array([0, 8, 9, 10, 11, 12, 13, 14, 15])   # dia/model.h:84
 
+    urng = np.random.default_rng(11)
+
     def one_pass(n_steps):
-        """4 sentences -> encoder + cross K/V per slot -> n_steps guided decoder steps with the host arg-max (sampler::max) feeding back"""
+        """4 sentences -> encoder + cross K/V per slot -> the generation loop on the device (tts_hip_dia_generate: check_stopping, guided step,
+        sampler::sample with the reference's default top_k 50, delay-pattern feedback as one captured graph; max_gen = n_steps, so the
+        countdown starts at position n_steps - 15 and n_steps - 1 sampler calls are made) -> un-delay -> one batched DAC pass"""
         t0 = time.perf_counter()
         for u in range(U):
             eng.encode_slot(u, toks, 200)
         t1 = time.perf_counter()
-        ids = np.full((U, cfg.n_out), cfg.bos, dtype=np.uint32)
-        hist = np.empty((n_steps, U, cfg.n_out), dtype=np.uint32)
-        for s in range(n_steps):
-            lg = eng.step_batch(ids, np.full(U, s, dtype=np.uint32))
-            nxt = lg[:, :, :cfg.audio_vocab].argmax(-1).astype(np.uint32)
-            hist[s] = nxt
-            ids = np.where(np.arange(cfg.n_out)[None, :] <= s, nxt, cfg.bos).astype(np.uint32)
+        uni = urng.random((n_steps, U, cfg.n_out), dtype=np.float32)
+        hist = eng.generate(U, n_steps, delay, cfg.bos, cfg.eos, cfg.pad, 15, uniforms=uni, top_k=50)
         t2 = time.perf_counter()
+        assert all(h.shape == (n_steps - 1, cfg.n_out) and int(h.max()) < cfg.audio_vocab for h in hist)
         # adjust_output_tokens (:787-808): frame i takes head h from step i + delay[h]; then one batched DAC pass
-        nf = n_steps - 15
-        codes = [np.stack([hist[np.arange(nf) + delay[h], u, h] for h in range(cfg.n_out)], axis=1) for u in range(U)]
+        nf = n_steps - 1 - 15
+        codes = [np.stack([hist[u][np.arange(nf) + delay[h], h] for h in range(cfg.n_out)], axis=1) for u in range(U)]
         pcm = dac.dac_decode_batch(codes)
         assert sum(p.size for p in pcm) == U * nf * 512
         return t1 - t0, t2 - t1, time.perf_counter() - t2
@@ -128,8 +134,8 @@ def run_dia(args):
         dec_s.append(d)
         dac_s.append(k)
     elapsed = time.perf_counter() - t0
-    step_ms = float(np.mean(dec_s)) / steps * 1e3
-    frames = steps - 15                      # un-delay drops max_delay steps (dia/model.cpp:787-808)
+    step_ms = float(np.mean(dec_s)) / (steps - 1) * 1e3
+    frames = steps - 1 - 15                  # max_gen = steps -> steps - 1 sampler calls; un-delay drops max_delay steps (dia/model.cpp:787-808)
     audio_s = U * frames * 512 / 44100.0 * args.steps
     w_bytes = n_dec * 2
     ckv_bytes = cfg.dec_layers * 2 * cfg.max_ctx * A * 4 * 2
@@ -140,15 +146,16 @@ def run_dia(args):
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
         "data": "synthetic (fp16 matrices = slices of one random pool; shapes of nari-labs/Dia-1.6B)",
         "config": {"workload": f"configs[3]: Dia-1.6B fp16, the per-GPU share of batch 32 over 8 GPUs = {U} utterances in lock-step x 2 guidance rows, "
-                               f"200-character sentences (encoder over 2 x 1024 positions + cross K/V per utterance), {steps} guided decoder steps with the host "
-                               "arg-max, un-delay, one batched DAC pass to PCM",
+                               f"200-character sentences (encoder over 2 x 1024 positions + cross K/V per utterance), max_generation_size {steps}: {steps - 1} guided decoder "
+                               "steps with check_stopping, sampler::sample (top_k 50) and the delay-pattern feedback on the device (tts_hip_dia_generate), "
+                               "un-delay, one batched DAC pass to PCM",
                    "utterances_per_gpu": U, "rows_per_step": 2 * U, "decoder_steps": steps, "parallelism": "dp1 of dp8 (utterances are independent)"},
         "ms_per_decode_step": round(step_ms, 4), "encode_ms_per_utterance": round(float(np.mean(enc_s)) / U * 1e3, 2),
         "dac_ms_per_pass": round(float(np.mean(dac_s)) * 1e3, 2),
         "x_real_time_per_gpu": round(U / (step_ms * 1e-3) / 86.13, 2),
         "roofline": {"bound": "hbm", "achieved": round(tot / (step_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(tot / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "whole decoder step (18 layers x 14 launches: gemm16_kernel, attn_gqa_kernel<128>, rms_fold_rows_kernel, ...)",
+                     "kernel": "whole decoder step (18 layers x 14 launches: gemv_stream_kernel, attn_gqa_split_kernel<128>, rms_fold_rows_kernel, ... + sample_kernel)",
                      "algorithmic_bytes_per_launch": tot, "note": f"fp16 matrices {w_bytes / 1e9:.3f} GB + {U} x fp32 cross K/V {ckv_bytes / 1e9:.3f} GB per step"},
     }
     eng.close()

@@ -164,6 +164,65 @@ def test_dia_runner_generate_batch_equals_separate_generates(tmp_path):
     r.close()
 
 
+def test_dia_device_loop_equals_the_per_step_host_loop(tmp_path):
+    """tts_hip_dia_generate (check_stopping, step, guidance, sampler::sample / sampler::max and the delay-pattern feedback replayed as one
+    captured graph) == the reference-shaped host loop (TTS_HOST_LOOP=1: logits D2H + sampler::sample + check_stopping on the host every
+    step): ids identical under a fixed seed, audio equal; one utterance and three in lock-step.  The model keeps its special-id head
+    rows (no block of exactly equal logits: the order of equal keys is where index order and std::sort may differ)."""
+    import os
+    from tts_cpp_amd import runner
+    model = synth.build_dia(synth.dia_tiny(), suppress_special=False)
+    path = model.write_gguf(str(tmp_path / "dia.gguf"))
+    text = " Hi there [S2] ok"
+    r = runner.Runner(path, sample=0, max_seqs=3)
+
+    def host(fn):
+        os.environ["TTS_HOST_LOOP"] = "1"
+        try:
+            return fn()
+        finally:
+            del os.environ["TTS_HOST_LOOP"]
+    for kw in (dict(sample=1, top_k=8, seed=5), dict(sample=1, top_k=0, top_p=0.9, temperature=1.2, seed=7), dict(sample=1, top_k=20, repetition_penalty=1.3, seed=9),
+               dict(sample=1, top_k=12, top_p=0.8, temperature=0.7, seed=11), dict(sample=0)):
+        dev = r.generate(text, max_tokens=40, **kw)
+        dt = r.last_tokens(1).copy()
+        hst = host(lambda: r.generate(text, max_tokens=40, **kw))
+        assert len(dt) > 0 and np.array_equal(dt, r.last_tokens(1)), kw
+        assert np.array_equal(dev, hst), kw
+    texts = [" Hi there [S2] ok", "[S1] another one.", "[S2] short"]
+    for kw in (dict(sample=1, top_k=10, seed=4), dict(sample=0)):
+        dev = r.generate_batch(texts, max_tokens=36, **kw)
+        hst = host(lambda: r.generate_batch(texts, max_tokens=36, **kw))
+        assert len(dev) == len(hst) == 3
+        for a, b in zip(dev, hst):
+            assert a.shape == b.shape and np.array_equal(a, b), kw
+    r.close()
+
+
+def test_dia_generate_entry_point_checks():
+    model = synth.build_dia(synth.dia_tiny())
+    cfg = model.cfg
+    eng = hip.DiaEngine(cfg, max_utterances=2)
+    eng.load(model)
+    args = dict(delay_pattern=[0, 8, 9, 10, 11, 12, 13, 14, 15], bos=cfg.bos, eos=cfg.eos, pad=cfg.pad, max_delay=cfg.max_delay)
+    with pytest.raises(hip.HipError):
+        eng.generate(1, 24, **args)                       # slot 0 not encoded
+    toks, n = orc.dia_tokenize("[S1] hi", cfg.max_ctx)
+    eng.encode_slot(0, toks, n)
+    with pytest.raises(hip.HipError):
+        eng.generate(2, 24, **args)                       # slot 1 not encoded
+    with pytest.raises(hip.HipError):
+        eng.generate(1, cfg.max_gen + 1, **args)          # beyond the self-attention cache
+    with pytest.raises(hip.HipError):
+        eng.generate(1, cfg.max_delay, **args)            # max_gen must exceed max_delay
+    out = eng.generate(1, 24, **args)                     # greedy: the countdown starts at position 24 - 15 and ends the loop at 23 ids
+    assert len(out) == 1 and out[0].shape == (23, cfg.n_out)
+    o = orc.DiaOracle(model, act_mode=1)
+    outs, _ = o.generate("[S1] hi", max_tokens=24)
+    assert np.array_equal(out[0], outs)
+    eng.close()
+
+
 def test_dia_1_6b_layer_shapes():
     """one encoder and one decoder layer at nari-labs/Dia-1.6B's widths (encoder 1024 / ffn 4096 over 2 x 1024 positions, decoder
     2048 with 16 query heads on 4 k/v groups x 128, ffn 8192, 9 x 1028 logits), fp16 matrices: BASELINE config 3's shapes,

@@ -236,6 +236,10 @@ struct tts_hip_ctx {
     float *di_logits = nullptr, *di_guided = nullptr;
     uint32_t *di_tok = nullptr, *di_epos = nullptr, *di_eseq = nullptr, *di_kbeg = nullptr, *di_kend = nullptr;
     uint32_t *di_ids = nullptr, *di_pos = nullptr, *di_seq = nullptr, *di_cend = nullptr;
+    // device-resident generation loop (tts_hip_dia_generate): sampled ids [U][NO], countdown [U] / done [U] / sampler call [U], history [U][G][NO]
+    uint32_t *di_stok = nullptr, *di_loop = nullptr, *di_hist = nullptr;
+    _Float16 *di_e16 = nullptr;   // [2 * max_ctx][max(EH, A, EF)] the encoder activations rounded to fp16 for gemm_tile_kernel
+    struct { const void *uni = nullptr, *pen = nullptr; tts_hip_sampling sp{}; int mode = -1; uint32_t U = 0, max_gen = 0; tts_hip_dia_codes codes{}; } di_baked;
     int di_U = 1;                        // utterance slots (rows = 2 per slot)
     std::vector<uint8_t> di_slot_encoded;   // tts_hip_dia_encode_slot has run for the slot
     uint32_t *h_di = nullptr;            // pinned staging: ids / pos / seq of a step
@@ -417,7 +421,8 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (float *p : {c->di_ex, c->di_exn, c->di_eqkv, c->di_eatt, c->di_egu, c->di_eg, c->di_ek, c->di_ev, c->di_ckv, c->di_ck, c->di_cv, c->di_k, c->di_v, c->di_x,
                      c->di_xn, c->di_qkv, c->di_q, c->di_att, c->di_gu, c->di_g, c->di_parts, c->di_logits, c->di_guided})
         free_dev(p);
-    for (uint32_t *p : {c->di_tok, c->di_epos, c->di_eseq, c->di_kbeg, c->di_kend, c->di_ids, c->di_pos, c->di_seq, c->di_cend}) free_dev(p);
+    for (uint32_t *p : {c->di_tok, c->di_epos, c->di_eseq, c->di_kbeg, c->di_kend, c->di_ids, c->di_pos, c->di_seq, c->di_cend, c->di_stok, c->di_loop, c->di_hist}) free_dev(p);
+    free_dev(c->di_e16);
     for (int i = 0; i < 3; i++) free_dev(c->sbuf[i]);
     free_dev(c->s_noise); free_dev(c->s_codes);
     free_dev(c->t5_bucket); free_dev(c->t5_x); free_dev(c->t5_qkv); free_dev(c->t5_att); free_dev(c->t5_ug); free_dev(c->t5_g); free_dev(c->t5_y); free_dev(c->t5_ids); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
@@ -1684,6 +1689,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->di_ex, n * EH)); CHK(dmalloc(&c->di_exn, n * EH)); CHK(dmalloc(&c->di_eqkv, n * 3 * A)); CHK(dmalloc(&c->di_eatt, n * A));
         CHK(dmalloc(&c->di_egu, n * 2 * EF)); CHK(dmalloc(&c->di_eg, n * EF)); CHK(dmalloc(&c->di_ek, n * A)); CHK(dmalloc(&c->di_ev, n * A));
         CHK(dmalloc(&c->di_ckv, n * 2 * A));
+        HIPCHK(hipMalloc((void **) &c->di_e16, n * (size_t) std::max(std::max(EH, EF), A) * 2));
         const int U = std::max(1, std::min((int) dd.max_utterances, 64)), R = 2 * U;
         c->di_U = U;
         c->di_slot_encoded.assign((size_t) U, 0);
@@ -1706,6 +1712,8 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->ad, (size_t) c->RMAX * maxK / 32 + 1));
         CHK(dmalloc(&c->di_tok, n)); CHK(dmalloc(&c->di_epos, n)); CHK(dmalloc(&c->di_eseq, n)); CHK(dmalloc(&c->di_kbeg, n)); CHK(dmalloc(&c->di_kend, n));
         CHK(dmalloc(&c->di_ids, (size_t) U * 16)); CHK(dmalloc(&c->di_pos, (size_t) R)); CHK(dmalloc(&c->di_seq, (size_t) R)); CHK(dmalloc(&c->di_cend, (size_t) R));
+        CHK(dmalloc(&c->di_stok, (size_t) U * 16)); CHK(dmalloc(&c->di_loop, (size_t) 3 * U)); CHK(dmalloc(&c->di_hist, (size_t) U * G * c->NO));
+        CHK(dmalloc(&c->d_last, (size_t) U * c->NO)); CHK(dmalloc(&c->d_repc, (size_t) U * c->NO));
         HIPCHK(hipHostMalloc((void **) &c->h_di, ((size_t) U * 16 + 2 * (size_t) R) * 4));
         std::vector<uint32_t> cend((size_t) R, (uint32_t) S);
         HIPCHK(hipMemcpy(c->di_cend, cend.data(), (size_t) R * 4, hipMemcpyHostToDevice));
@@ -3127,6 +3135,21 @@ static int dia_gemm(tts_hip_ctx *c, const W &w, const float *A, int lda, float *
     return 0;
 }
 
+// the encoder's GEMMs (2 x max_ctx rows): fp16 matrices take gemm_tile_kernel with all rows in one launch — the activations are rounded
+// to fp16 once (what ggml_mul_mat does with them for an F16 weight), every matrix leaves HBM once instead of once per RMAX rows
+static int dia_gemm_rows(tts_hip_ctx *c, const W &w, const float *A, int lda, float *out, int ldo, int n, int epi) {
+    if (w.type != TTS_HIP_F16 || c->tile_min_rows <= 0 || n < c->tile_min_rows || w.K % 128 || w.N % 16 || (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) || c->prof)
+        return dia_gemm(c, w, A, lda, out, ldo, n, epi);
+    const int64_t n8 = (int64_t) n * (int64_t) (w.K / 8);
+    hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned) ((n8 + 255) / 256)), dim3(256), 0, c->stream, A, lda, (int) w.K, n8, c->di_e16);
+    HIPCHK(hipGetLastError());
+    GemmArgs g{};
+    g.R = n; g.H = c->H;
+    g.A = c->di_e16; g.lda = (int) w.K;
+    g.out = out; g.ldo = ldo;
+    return run_gemm(c, TTS_HIP_K_GEMM_OTHER, w, g, PRO_F16, epi);
+}
+
 // <= 16 rows through gemv_stream_kernel: `out` receives *slabs K-slice slabs 16 * ldo floats apart (the consumer folds them);
 // *slabs = 0: the shape does not qualify and nothing was launched
 static int dia_gemm_stream(tts_hip_ctx *c, const W &w, const float *A, int lda, float *out, int ldo, int n, int max_slabs, int64_t slab_stride, int *slabs) {
@@ -3188,7 +3211,7 @@ extern "C" int tts_hip_dia_encode_slot(tts_hip_ctx *c, uint32_t slot, const uint
     HIPCHK(hipGetLastError());
     for (const auto &y : c->di_enc) {
         CHK(dia_rms(c, y.sa_norm, n, EH, c->di_ex, c->di_exn, false));
-        CHK(dia_gemm(c, y.qkv, c->di_exn, EH, c->di_eqkv, 3 * A, n, EPI_STORE));
+        CHK(dia_gemm_rows(c, y.qkv, c->di_exn, EH, c->di_eqkv, 3 * A, n, EPI_STORE));
         hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, 2 * ENH), dim3(64), 0, c->stream, c->di_eqkv, (const uint32_t *) c->di_epos, (const float *) nullptr, theta_scale,
                            ENH, ENH, HD, c->di_ek, c->di_ev, (const uint32_t *) c->di_eseq, (int64_t) S * A);
         HIPCHK(hipGetLastError());
@@ -3196,12 +3219,12 @@ extern "C" int tts_hip_dia_encode_slot(tts_hip_ctx *c, uint32_t slot, const uint
                            (const float *) c->di_ek, (const float *) c->di_ev, ENH, ENH, 1.0f, c->di_eatt, (const uint32_t *) c->di_kbeg, (const uint32_t *) c->di_kend,
                            (const uint32_t *) c->di_eseq, (int64_t) S * A);
         HIPCHK(hipGetLastError());
-        CHK(dia_gemm(c, y.o, c->di_eatt, A, c->di_ex, EH, n, EPI_RESID));
+        CHK(dia_gemm_rows(c, y.o, c->di_eatt, A, c->di_ex, EH, n, EPI_RESID));
         CHK(dia_rms(c, y.mlp_norm, n, EH, c->di_ex, c->di_exn, false));
-        CHK(dia_gemm(c, y.gu, c->di_exn, EH, c->di_egu, 2 * EF, n, EPI_STORE));
+        CHK(dia_gemm_rows(c, y.gu, c->di_exn, EH, c->di_egu, 2 * EF, n, EPI_STORE));
         hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) n * EF + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->di_egu, EF, n, c->di_eg, (int8_t *) nullptr, (float *) nullptr);
         HIPCHK(hipGetLastError());
-        CHK(dia_gemm(c, y.out, c->di_eg, EF, c->di_ex, EH, n, EPI_RESID));
+        CHK(dia_gemm_rows(c, y.out, c->di_eg, EF, c->di_ex, EH, n, EPI_RESID));
     }
     CHK(dia_rms(c, c->di_enc_norm, n, EH, c->di_ex, c->di_exn, false));
     // cross K/V of every decoder layer (build_dia_cross_kv_store :505-541): V for all positions, K (rope'd with the encoder
@@ -3209,7 +3232,7 @@ extern "C" int tts_hip_dia_encode_slot(tts_hip_ctx *c, uint32_t slot, const uint
     for (int l = 0; l < c->L; l++) {
         const auto &y = c->di_dec[(size_t) l];
         float *ck = c->di_ck + ((size_t) l * c->di_U + slot) * n * A, *cv = c->di_cv + ((size_t) l * c->di_U + slot) * n * A;   // rows 2*slot, 2*slot+1
-        CHK(dia_gemm(c, y.ckv, c->di_exn, EH, c->di_ckv, 2 * A, n, EPI_STORE));
+        CHK(dia_gemm_rows(c, y.ckv, c->di_exn, EH, c->di_ckv, 2 * A, n, EPI_STORE));
         hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH), dim3(64), 0, c->stream, c->di_ckv, (const uint32_t *) c->di_epos, (const float *) nullptr, theta_scale, 0, NH,
                            HD, ck, cv, (const uint32_t *) c->di_eseq, (int64_t) S * A);
         HIPCHK(hipGetLastError());
@@ -3227,34 +3250,13 @@ extern "C" int tts_hip_dia_encode(tts_hip_ctx *c, const uint32_t *tokens, uint32
     return tts_hip_dia_encode_slot(c, 0, tokens, sentence_len, enc_out);
 }
 
-extern "C" int tts_hip_dia_step_batch(tts_hip_ctx *c, uint32_t n_utt, const uint32_t *slots, const uint32_t *ids, const uint32_t *pos, float *logits_out,
-                                      float *raw_out) {
-    if (!c || !c->has_dia) return set_err("tts_hip_dia_step: not a Dia context (tts_hip_dia_create)");
-    if (!c->finalized || !c->weights_present) return set_err("tts_hip_dia_step: context not finalized");
-    if (!ids || !pos || !logits_out) return set_err("tts_hip_dia_step: null argument");
-    if (n_utt == 0 || n_utt > (uint32_t) c->di_U) return set_err("tts_hip_dia_step_batch: %u utterances outside 1..%d (max_utterances)", n_utt, c->di_U);
+// the decoder step for the U utterances whose input ids / positions / cache rows are in di_ids / di_pos / di_seq; leaves the guided
+// logits in di_guided.  self_keys sizes the self-attention scratch; fixed_split: a captured step is replayed at every position, so the
+// key-split count must not depend on it (the kernels read the true extent from di_pos)
+static int dia_forward(tts_hip_ctx *c, int U, int self_keys, bool fixed_split) {
     const int S = (int) c->dia.max_ctx, G = (int) c->dia.max_gen, DH = c->H, DF = c->di_DF, A = c->di_A, kvH = c->di_kvH, HD = (int) c->dia.head_dim;
     const int NH = c->NH, NKV = (int) c->dia.dec_kv_heads, NO = c->NO, V = c->di_V, QKV = A + 2 * kvH;
-    const int U = (int) n_utt, R = 2 * U, RS = 2 * c->di_U;   // rows of this step, row slots of the caches
-    uint32_t max_pos = 0;
-    uint32_t *h_ids = c->h_di, *h_pos = c->h_di + (size_t) c->di_U * 16, *h_seq = h_pos + RS;
-    for (int u = 0; u < U; u++) {
-        const uint32_t slot = slots ? slots[u] : (uint32_t) u;
-        if (slot >= (uint32_t) c->di_U) return set_err("tts_hip_dia_step_batch: slot %u outside the %d utterance slots", slot, c->di_U);
-        if (!c->di_slot_encoded[slot]) return set_err("tts_hip_dia_step: tts_hip_dia_encode has not run%s", c->di_U > 1 ? " for this slot" : "");
-        if (pos[u] >= (uint32_t) G) return set_err("tts_hip_dia_step: position %u outside the %d cached positions", pos[u], G);
-        for (int i = 0; i < NO; i++) {
-            if (ids[u * NO + i] >= (uint32_t) V) return set_err("tts_hip_dia_step: id %u >= output vocabulary %d", ids[u * NO + i], V);
-            h_ids[u * NO + i] = ids[u * NO + i];
-        }
-        h_pos[2 * u] = h_pos[2 * u + 1] = pos[u];
-        h_seq[2 * u] = 2 * slot; h_seq[2 * u + 1] = 2 * slot + 1;
-        max_pos = std::max(max_pos, pos[u]);
-    }
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(c->di_ids, h_ids, (size_t) U * NO * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->di_pos, h_pos, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->di_seq, h_seq, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+    const int R = 2 * U, RS = 2 * c->di_U;
     auto f32 = [&](size_t off) { return (const float *) (c->arena + off); };
     const float theta_scale = powf(10000.0f, -2.0f / (float) HD);
     static std::atomic<uint64_t> attr{0};
@@ -3281,8 +3283,8 @@ extern "C" int tts_hip_dia_step_batch(tts_hip_ctx *c, uint32_t n_utt, const uint
         hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(R, NH + NKV), dim3(64), 0, c->stream, c->di_qkv, (const uint32_t *) c->di_pos, (const float *) nullptr, theta_scale, NH,
                            NKV, HD, kc, vc, (const uint32_t *) c->di_seq, (int64_t) G * kvH, std::max(sl, 1), st16 * QKV);
         HIPCHK(hipGetLastError());
-        CHK(launch_attn_gqa(c, NH, R, (int) max_pos + 1, (const float *) c->di_qkv, QKV, (const uint32_t *) c->di_pos, (const float *) kc, (const float *) vc, NKV, 1.0f,
-                            c->di_att, nul, nul, (const uint32_t *) c->di_seq, (int64_t) G * kvH, false));
+        CHK(launch_attn_gqa(c, NH, R, self_keys, (const float *) c->di_qkv, QKV, (const uint32_t *) c->di_pos, (const float *) kc, (const float *) vc, NKV, 1.0f,
+                            c->di_att, nul, nul, (const uint32_t *) c->di_seq, (int64_t) G * kvH, fixed_split));
         CHK(dia_gemm_stream(c, y.so, c->di_att, A, c->di_parts, DH, R, DIA_STREAM_SLABS, (int64_t) c->RMAX * DH, &sl));
         if (sl) c->di_pending = sl;
         else CHK(dia_gemm(c, y.so, c->di_att, A, c->di_x, DH, R, EPI_RESID));
@@ -3318,11 +3320,162 @@ extern "C" int tts_hip_dia_step_batch(tts_hip_ctx *c, uint32_t n_utt, const uint
     CHK(run_gemm(c, TTS_HIP_K_GEMM_HEADS, c->di_heads, g, PRO_F32, EPI_STORE));
     hipLaunchKernelGGL(dia_cfg_kernel, dim3((NO * V + 255) / 256, U), dim3(256), 0, c->stream, (const float *) c->di_logits, c->di_Vpad, NO * V, c->dia.cfg_scale, c->di_guided);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int tts_hip_dia_step_batch(tts_hip_ctx *c, uint32_t n_utt, const uint32_t *slots, const uint32_t *ids, const uint32_t *pos, float *logits_out,
+                                      float *raw_out) {
+    if (!c || !c->has_dia) return set_err("tts_hip_dia_step: not a Dia context (tts_hip_dia_create)");
+    if (!c->finalized || !c->weights_present) return set_err("tts_hip_dia_step: context not finalized");
+    if (!ids || !pos || !logits_out) return set_err("tts_hip_dia_step: null argument");
+    if (n_utt == 0 || n_utt > (uint32_t) c->di_U) return set_err("tts_hip_dia_step_batch: %u utterances outside 1..%d (max_utterances)", n_utt, c->di_U);
+    const int G = (int) c->dia.max_gen, NO = c->NO, V = c->di_V;
+    const int U = (int) n_utt, R = 2 * U, RS = 2 * c->di_U;   // rows of this step, row slots of the caches
+    uint32_t max_pos = 0;
+    uint32_t *h_ids = c->h_di, *h_pos = c->h_di + (size_t) c->di_U * 16, *h_seq = h_pos + RS;
+    for (int u = 0; u < U; u++) {
+        const uint32_t slot = slots ? slots[u] : (uint32_t) u;
+        if (slot >= (uint32_t) c->di_U) return set_err("tts_hip_dia_step_batch: slot %u outside the %d utterance slots", slot, c->di_U);
+        if (!c->di_slot_encoded[slot]) return set_err("tts_hip_dia_step: tts_hip_dia_encode has not run%s", c->di_U > 1 ? " for this slot" : "");
+        if (pos[u] >= (uint32_t) G) return set_err("tts_hip_dia_step: position %u outside the %d cached positions", pos[u], G);
+        for (int i = 0; i < NO; i++) {
+            if (ids[u * NO + i] >= (uint32_t) V) return set_err("tts_hip_dia_step: id %u >= output vocabulary %d", ids[u * NO + i], V);
+            h_ids[u * NO + i] = ids[u * NO + i];
+        }
+        h_pos[2 * u] = h_pos[2 * u + 1] = pos[u];
+        h_seq[2 * u] = 2 * slot; h_seq[2 * u + 1] = 2 * slot + 1;
+        max_pos = std::max(max_pos, pos[u]);
+    }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->di_ids, h_ids, (size_t) U * NO * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->di_pos, h_pos, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->di_seq, h_seq, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+    CHK(dia_forward(c, U, (int) max_pos + 1, false));
     HIPCHK(hipMemcpyAsync(logits_out, c->di_guided, (size_t) U * NO * V * 4, hipMemcpyDeviceToHost, c->stream));
     if (raw_out)
         for (int b = 0; b < R; b++)
             HIPCHK(hipMemcpyAsync(raw_out + (size_t) b * NO * V, c->di_logits + (size_t) b * c->di_Vpad, (size_t) NO * V * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+#define DIA_LOOP_CHUNK 16
+extern "C" int tts_hip_dia_generate(tts_hip_ctx *c, uint32_t n_utt, uint32_t max_gen, const tts_hip_dia_codes *codes, const tts_hip_sampling *sp, const float *uniforms,
+                                    uint32_t *tokens_out, uint32_t *steps_out) {
+    if (!c || !c->has_dia) return set_err("tts_hip_dia_generate: not a Dia context (tts_hip_dia_create)");
+    if (!c->finalized || !c->weights_present) return set_err("tts_hip_dia_generate: context not finalized");
+    if (!codes || !tokens_out || !steps_out) return set_err("tts_hip_dia_generate: null argument");
+    if (n_utt == 0 || n_utt > (uint32_t) c->di_U) return set_err("tts_hip_dia_generate: %u utterances outside 1..%d (max_utterances)", n_utt, c->di_U);
+    const int G = (int) c->dia.max_gen, NO = c->NO, V = c->di_V, U = (int) n_utt;
+    if (max_gen == 0 || max_gen > (uint32_t) G) return set_err("tts_hip_dia_generate: max_gen %u outside 1..%d cached positions", max_gen, G);
+    if (codes->max_delay >= max_gen) return set_err("tts_hip_dia_generate: max_gen %u must exceed max_delay %u", max_gen, codes->max_delay);
+    if (codes->bos >= (uint32_t) V || codes->eos >= (uint32_t) V || codes->pad >= (uint32_t) V) return set_err("tts_hip_dia_generate: special ids outside the vocabulary %d", V);
+    for (int u = 0; u < U; u++)
+        if (!c->di_slot_encoded[(size_t) u]) return set_err("tts_hip_dia_generate: slot %d has not been encoded (tts_hip_dia_encode_slot)", u);
+    if (sp) {
+        if (V > SMP_VMAX) return set_err("tts_hip_dia_generate: output vocabulary %d > %d", V, SMP_VMAX);
+        if (!(sp->temperature > 0.0f) || !(sp->top_p > 0.0f) || !(sp->repetition_penalty > 0.0f)) return set_err("tts_hip_dia_generate: temperature, top_p, repetition_penalty must be > 0");
+        if (!uniforms) return set_err("tts_hip_dia_generate: null uniforms");
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const bool rep = sp && sp->repetition_penalty != 1.0f;
+    if (sp) {
+        CHK(stage_uniforms(c, uniforms, (size_t) max_gen * U * NO));
+        CHK(stage_penalty(c, sp->repetition_penalty, (int) max_gen));
+    }
+    // loop state: ids = BOS everywhere, positions 0, countdown -1, nothing done; sampler::reset (sampler.cpp:71-80)
+    {
+        std::vector<uint32_t> ids((size_t) U * NO, codes->bos), zero((size_t) 3 * c->di_U, 0u), seq((size_t) 2 * U);
+        for (int u = 0; u < U; u++) { zero[(size_t) u] = 0xFFFFFFFFu; seq[(size_t) 2 * u] = 2 * u; seq[(size_t) 2 * u + 1] = 2 * u + 1; }
+        HIPCHK(hipMemcpyAsync(c->di_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemsetAsync(c->di_pos, 0, (size_t) 2 * U * 4, c->stream));
+        HIPCHK(hipMemcpyAsync(c->di_seq, seq.data(), seq.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->di_loop, zero.data(), zero.size() * 4, hipMemcpyHostToDevice, c->stream));
+        if (rep) {
+            HIPCHK(hipMemsetAsync(c->d_last, 0xFF, (size_t) U * NO * 4, c->stream));
+            HIPCHK(hipMemsetAsync(c->d_repc, 0, (size_t) U * NO * 4, c->stream));
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));   // the vectors are locals
+    }
+    DiaLoopArgs la{};
+    la.n_utt = U; la.n_out = NO;
+    la.bos = codes->bos; la.eos = codes->eos; la.pad = codes->pad; la.max_delay = codes->max_delay; la.max_gen = max_gen;
+    for (int i = 0; i < 16; i++) la.delay_pattern[i] = codes->delay_pattern[i];
+    la.ids = c->di_ids; la.pos = c->di_pos;
+    la.delay = (int32_t *) c->di_loop; la.done = c->di_loop + c->di_U; la.call = c->di_loop + 2 * c->di_U;
+    la.tok = c->di_stok; la.hist = c->di_hist;
+    auto one_step = [&](bool captured) -> int {
+        hipLaunchKernelGGL(dia_prestep_kernel, dim3((U + 63) / 64), dim3(64), 0, c->stream, la);
+        HIPCHK(hipGetLastError());
+        CHK(dia_forward(c, U, G, captured));
+        if (sp) {
+            SampleArgs sa{};
+            sa.logits = c->di_guided; sa.V = V; sa.n_out = NO; sa.R = U;
+            sa.top_k = sp->top_k; sa.top_p = sp->top_p; sa.temperature = sp->temperature;
+            sa.uniforms = c->d_uniforms; sa.row_step = la.call; sa.out = c->di_stok;
+            if (rep) { sa.pen_table = c->d_pen; sa.pen_len = c->pen_len; sa.last_ids = c->d_last; sa.rep_counts = c->d_repc; }
+            hipLaunchKernelGGL(sample_kernel, dim3(NO, U), dim3(256), 0, c->stream, sa);
+        } else {
+            hipLaunchKernelGGL(argmax_kernel, dim3(U * NO), dim3(256), 0, c->stream, (const float *) c->di_guided, V, c->di_stok);
+        }
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(dia_poststep_kernel, dim3((U + 63) / 64), dim3(64), 0, c->stream, la);
+        HIPCHK(hipGetLastError());
+        return 0;
+    };
+    // everything the captured launches hold by value: a change drops the graph
+    const int mode = sp ? 1 : 0;
+    const void *pen = rep ? (const void *) c->d_pen : nullptr;
+    const tts_hip_sampling spv = sp ? *sp : tts_hip_sampling{};
+    auto &bk = c->di_baked;
+    const bool same = bk.mode == mode && bk.U == n_utt && bk.max_gen == max_gen && memcmp(&bk.codes, codes, sizeof(*codes)) == 0 &&
+                      (!sp || (bk.uni == c->d_uniforms && bk.pen == pen && memcmp(&bk.sp, &spv, sizeof(spv)) == 0));
+    const int key = 9100001;
+    if (!same) {
+        auto it = c->graphs.find(key);
+        if (it != c->graphs.end()) { (void) hipGraphExecDestroy(it->second); c->graphs.erase(it); }
+        bk.mode = mode; bk.U = n_utt; bk.max_gen = max_gen; bk.codes = *codes; bk.uni = c->d_uniforms; bk.pen = pen; bk.sp = spv;
+    }
+    const bool use_graph = !(c->d.flags & TTS_HIP_FLAG_NO_GRAPH) && !c->prof;
+    std::vector<uint32_t> done((size_t) U);
+    uint32_t ran = 0;
+    while (ran < max_gen + 1) {   // at most max_gen sampler calls, then one pre-step that ends the countdown
+        const uint32_t chunk = std::min<uint32_t>(DIA_LOOP_CHUNK, max_gen + 1 - ran);
+        if (use_graph) {
+            auto it = c->graphs.find(key);
+            if (it == c->graphs.end()) {
+                // the first step runs eagerly (per-kernel attributes are set outside a capture), the capture follows
+                CHK(one_step(false));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                hipGraph_t graph = nullptr;
+                HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                const int rc = one_step(true);
+                const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+                if (rc != 0) { if (graph) (void) hipGraphDestroy(graph); return rc; }
+                if (e != hipSuccess) return set_err("hipStreamEndCapture: %s", hipGetErrorString(e));
+                hipGraphExec_t exec = nullptr;
+                HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                (void) hipGraphDestroy(graph);
+                it = c->graphs.emplace(key, exec).first;
+                for (uint32_t s = 1; s < chunk; s++) HIPCHK(hipGraphLaunch(it->second, c->stream));
+            } else {
+                for (uint32_t s = 0; s < chunk; s++) HIPCHK(hipGraphLaunch(it->second, c->stream));
+            }
+        } else {
+            for (uint32_t s = 0; s < chunk; s++) CHK(one_step(false));
+        }
+        ran += chunk;
+        HIPCHK(hipMemcpyAsync(done.data(), la.done, (size_t) U * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        bool all = true;
+        for (int u = 0; u < U; u++) all = all && done[(size_t) u] != 0;
+        if (all) break;
+    }
+    std::vector<uint32_t> pos((size_t) 2 * U);
+    HIPCHK(hipMemcpyAsync(pos.data(), c->di_pos, pos.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(tokens_out, c->di_hist, (size_t) U * max_gen * NO * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int u = 0; u < U; u++) steps_out[u] = pos[(size_t) 2 * u];
     return 0;
 }
 

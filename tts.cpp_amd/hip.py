@@ -83,7 +83,7 @@ EXPORTS = [
     "tts_hip_upload", "tts_hip_arena_bytes", "tts_hip_finalize", "tts_hip_arena_ptr", "tts_hip_arena_filled",
     "tts_hip_parler_set_text_encoding", "tts_hip_parler_reset", "tts_hip_parler_prefill", "tts_hip_parler_prefill_batch", "tts_hip_parler_step",
     "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits",
-    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_orpheus_generate_sampled", "tts_hip_orpheus_sample_logits", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_dia_encode_slot", "tts_hip_dia_step_batch", "tts_hip_kokoro_create", "tts_hip_kokoro_durations", "tts_hip_kokoro_generate", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
+    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_orpheus_generate_sampled", "tts_hip_orpheus_sample_logits", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_dia_encode_slot", "tts_hip_dia_step_batch", "tts_hip_dia_generate", "tts_hip_kokoro_create", "tts_hip_kokoro_durations", "tts_hip_kokoro_generate", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
     "tts_hip_synchronize", "tts_hip_broadcast_weights", "tts_hip_comm_unique_id", "tts_hip_broadcast_weights_rank",
 ]
@@ -151,6 +151,7 @@ def load_lib():
     L.tts_hip_dia_step.argtypes = [vp, u32p, C.c_uint32, f32p, f32p]
     L.tts_hip_dia_encode_slot.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, f32p]
     L.tts_hip_dia_step_batch.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, f32p, f32p]
+    L.tts_hip_dia_generate.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(DiaCodes), C.POINTER(Sampling), f32p, u32p, u32p]
     L.tts_hip_snac_create.restype = vp
     L.tts_hip_snac_create.argtypes = [C.c_int, C.POINTER(SnacDesc)]
     L.tts_hip_snac_decode.argtypes = [vp, u32p, C.c_uint32, f32p, f32p]
@@ -557,6 +558,11 @@ class OrpheusEngine:
             pass
 
 
+class DiaCodes(C.Structure):
+    """tts_hip_dia_codes (include/tts_hip.h)"""
+    _fields_ = [("bos", C.c_uint32), ("eos", C.c_uint32), ("pad", C.c_uint32), ("max_delay", C.c_uint32), ("delay_pattern", C.c_uint32 * 16)]
+
+
 class DiaEngine:
     """A Dia context (tts_hip_dia_create): encoder + cross K/V once per sentence, then one decoder step per call."""
 
@@ -608,6 +614,23 @@ class DiaEngine:
         self._chk(self.L.tts_hip_dia_step_batch(self.ctx, n, sl, ap, pp, lg.ctypes.data_as(C.POINTER(C.c_float)),
                                                 raw.ctypes.data_as(C.POINTER(C.c_float)) if want_raw else None))
         return (lg, raw) if want_raw else lg
+
+    def generate(self, n_utt, max_gen, delay_pattern, bos, eos, pad, max_delay, uniforms=None, top_k=50, top_p=1.0, temperature=1.0, repetition_penalty=1.0):
+        """the whole generation loop on the device (tts_hip_dia_generate) for the encoded slots 0..n_utt-1; uniforms None: sampler::max.
+        -> list of [steps][n_out] id arrays (generation order, before adjust_output_tokens)"""
+        codes = DiaCodes(bos, eos, pad, max_delay)
+        for i, d in enumerate(delay_pattern):
+            codes.delay_pattern[i] = int(d)
+        out = np.zeros((n_utt, max_gen, self.cfg.n_out), dtype=np.uint32)
+        steps = np.zeros(n_utt, dtype=np.uint32)
+        sp, up = None, None
+        if uniforms is not None:
+            u = np.ascontiguousarray(uniforms, dtype=np.float32)
+            assert u.size >= max_gen * n_utt * self.cfg.n_out
+            sp, up = C.byref(Sampling(top_k, top_p, temperature, repetition_penalty)), u.ctypes.data_as(C.POINTER(C.c_float))
+        self._chk(self.L.tts_hip_dia_generate(self.ctx, n_utt, max_gen, C.byref(codes), sp, up, out.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                              steps.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return [out[u, :int(steps[u])].copy() for u in range(n_utt)]
 
     def step(self, ids, pos, want_raw=False):
         a, ap = _u32(ids)

@@ -162,6 +162,33 @@ void dia_adjust_output_tokens(const dia_hparams & hp, const std::vector<uint32_t
     }
 }
 
+// the generation loop on the device (tts_hip_dia_generate): one sampler per utterance, each seeded like a separate generate() call
+// would seed its own, so the U[0,1) draws of call k are the same for every utterance
+static void dia_device_loop(tts_hip_ctx * lm, const dia_hparams & hp, sampler & proto, uint32_t n, uint32_t max_gen, const generation_configuration & config,
+                            std::vector<std::vector<uint32_t>> & tokens) {
+    const uint32_t nh = hp.n_output_heads;
+    tts_hip_dia_codes codes{};
+    codes.bos = hp.bos_token_id; codes.eos = hp.eos_token_id; codes.pad = hp.pad_token_id; codes.max_delay = hp.max_delay;
+    for (size_t i = 0; i < hp.delay_pattern.size() && i < 16; i++) codes.delay_pattern[i] = hp.delay_pattern[i];
+    std::vector<uint32_t> toks((size_t) n * max_gen * nh), steps(n);
+    std::vector<float> u;
+    tts_hip_sampling sp{(uint32_t) config.top_k, config.top_p, config.temperature, config.repetition_penalty};
+    if (config.sample) {
+        u.resize((size_t) max_gen * n * nh);
+        std::vector<float> draw(nh);
+        sampler s = proto;
+        s.seed = config.seed; s.n_calls = 0;
+        for (uint32_t k = 0; k < max_gen; k++) {
+            s.draw_uniforms(draw.data());
+            for (uint32_t i = 0; i < n; i++) std::copy(draw.begin(), draw.end(), u.begin() + ((size_t) k * n + i) * nh);
+        }
+    }
+    if (tts_hip_dia_generate(lm, n, max_gen, &codes, config.sample ? &sp : nullptr, config.sample ? u.data() : nullptr, toks.data(), steps.data()) != 0)
+        TTS_ABORT("tts_hip_dia_generate failed: %s\n", tts_hip_last_error());
+    tokens.assign(n, {});
+    for (uint32_t i = 0; i < n; i++) tokens[i].assign(toks.begin() + (size_t) i * max_gen * nh, toks.begin() + ((size_t) i * max_gen + steps[i]) * nh);
+}
+
 void dia_runner::generate(const char * sentence, tts_response & output, const generation_configuration & config) {
     if (!(config.max_tokens == 0 || config.max_tokens > (int) hp.max_delay)) TTS_ABORT("TTS_ASSERT(config.max_tokens == 0 || config.max_tokens > model->max_delay) failed\n");
     smp.temperature = config.temperature;
@@ -188,7 +215,15 @@ void dia_runner::generate(const char * sentence, tts_response & output, const ge
     std::vector<uint32_t> audio_tokens(nh, hp.bos_token_id);
     uint32_t current_position = 0;
     int      delay_steps = -1;
-    while (!dia_check_stopping(hp, audio_tokens, current_position, max_gen, delay_steps)) {
+    if (!getenv("TTS_HOST_LOOP")) {
+        // check_stopping, the step, the sampler and the delay-pattern feedback replay as one captured graph; the host loop below is
+        // the reference's shape (logits back every step, sampler::sample here) and stays for TTS_HOST_LOOP=1
+        std::vector<std::vector<uint32_t>> t;
+        dia_device_loop(lm, hp, smp, 1, max_gen, config, t);
+        out = t[0];
+        delay_steps = 0;
+    }
+    while (delay_steps != 0 && !dia_check_stopping(hp, audio_tokens, current_position, max_gen, delay_steps)) {
         hip_check(tts_hip_dia_step(lm, audio_tokens.data(), current_position, logits.data(), nullptr), "tts_hip_dia_step");
         smp.sample(logits.data(), out);
         current_position += 1;
@@ -232,7 +267,9 @@ void dia_runner::generate_batch(const std::vector<std::string> & sentences, std:
     std::vector<int>      delay(n, -1);
     std::vector<bool>     done(n, false);
     std::vector<float>    lg((size_t) n * nh * hp.output_vocab_size);
-    for (;;) {
+    const bool device_loop = !getenv("TTS_HOST_LOOP");
+    if (device_loop) dia_device_loop(lm, hp, smp, n, max_gen, config, last_batch_tokens);
+    for (; !device_loop;) {
         // check_stopping (:767-785) per utterance before each decode, as generate_from_batch's while condition (:817)
         bool any = false;
         for (uint32_t u = 0; u < n; u++) {
