@@ -60,7 +60,8 @@ struct DacEmbedArgs {
     const float *proj_w;    // [n_cb][latent][cb_dim]
     const float *proj_b;    // [n_cb][latent]
     int n_cb, cb_size, cb_dim, latent, T;
-    float *out;             // [latent][T]
+    int Tout;               // row stride of out (>= T)
+    float *out;             // [latent][Tout]
     int x_f16;              // F16 conv kernels: the conv input (codebook row) goes through an fp16 im2col
 };
 
@@ -79,7 +80,7 @@ __global__ void dac_embed_kernel(DacEmbedArgs a) {
         acc += a.proj_b[i * a.latent + c];
         total = (i == 0) ? acc : (total + acc);
     }
-    a.out[((int64_t) z * a.latent + c) * a.T + t] = total;
+    a.out[((int64_t) z * a.latent + c) * a.Tout + t] = total;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -551,6 +552,120 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
                 if (rg) v = v + rg[(int64_t) co * LS + t];
                 if (a.alpha_out) v = snake_f(v, al_o, ral_o);
                 if (a.do_tanh) v = tanhf(v);
+                yg[(int64_t) co * LS + t] = v;
+            }
+        }
+    }
+}
+
+// k = 1 conv + bias + residual of a residual unit (gnac.cpp:147-149) for CIN <= 192 input channels, shaped for HBM instead of for the
+// matrix pipe: at 96 / 192 channels the op moves 12 B per 2 * C flops, and conv1d_mfma_kernel<1,...> — 16-channel chunks through LDS, one
+// barrier per chunk, one chunk of loads in flight — ran it at 1.7 TB/s with exactly the algorithmic traffic (PMC: profiles/r02/pmc_*).
+// Here nothing but the weights goes through LDS:
+//   * the MFMA B operand of v_mfma_f32_32x32x2_f32 is one float per lane, B[k = lane >> 5][j = lane & 31] = x[ci = 2 s + (lane >> 5)]
+//     [t = t_wave + lane & 31]: each lane loads its own operands straight from global memory (a wave instruction = two 128-byte row
+//     segments), ALL of them issued before the first MFMA — up to 63 loads in flight per wave, ~100 KB per CU, no staging, no barrier;
+//   * the weight tile [CIN][CO_T] (the packed image of pack_conv_w_kernel; CO_T = all output channels, so x is read once) goes
+//     through LDS KH input channels (36 KB) at a time;
+//   * accumulation order over the input channels is the old kernel's (ascending, two per MFMA), so the results are bit-identical.
+// Workgroup = 4 waves side by side in t: (32 * MI) output channels x (4 * 32 * NI) positions: 96 x 256 or 192 x 128.
+template <int MI, int NI, int CIN, int KH>
+__global__ __launch_bounds__(256) void conv1x1_direct_kernel(ConvArgs a) {
+    constexpr int CO_T = 32 * MI, T_W = 32 * NI, T_T = 4 * T_W, NS = CIN / 2;
+    constexpr int NH = CIN / KH;                                // the weight tile goes through LDS KH input channels (36 KB) at a time
+    constexpr int W4 = KH * CO_T / 4, WV = (W4 + 255) / 256;
+    static_assert(CIN % KH == 0 && KH % 2 == 0, "input channels in LDS phases of KH");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *ws = (float *) smem;   // [KH][CO_T]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T;
+    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    if (t0 >= L) return;
+    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * LS;
+    float *yg = a.y + (int64_t) blockIdx.z * a.cout * LS;
+    const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * LS : nullptr;
+    const float4d *wg = (const float4d *) (a.w + (int64_t) blockIdx.y * CIN * CO_T);
+
+    float4d wreg[WV];
+#pragma unroll
+    for (int j = 0; j < WV; j++) {
+        const int i = tid + j * 256;
+        if (i < W4) wreg[j] = wg[i];
+    }
+    float xb[NI][NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const float *xr = xg + (int64_t) (2 * s + hi) * LS;
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            const int t = t0 + wv * T_W + j * 32 + l31;
+            xb[j][s] = t < L ? xr[t] : 0.0f;
+        }
+    }
+
+    float16d acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NI; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        if (h > 0) __syncthreads();   // every wave is done with the previous phase of the weights
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * 256;
+            if (i < W4) ((float4d *) ws)[i] = wreg[j];
+        }
+        if (h + 1 < NH) {             // the next phase's weights travel while this phase's MFMAs run
+#pragma unroll
+            for (int j = 0; j < WV; j++) {
+                const int i = tid + j * 256;
+                if (i < W4) wreg[j] = wg[(h + 1) * W4 + i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KH / 2; s++) {
+            float af[MI];
+#pragma unroll
+            for (int i = 0; i < MI; i++) af[i] = ws[(2 * s + hi) * CO_T + i * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int j = 0; j < NI; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], xb[j][h * (KH / 2) + s], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue per 32-channel block: its residual values are requested together, then stored (requesting the whole tile at once costs the
+    // second wave per SIMD: 200 + 96 registers)
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+        float rv[16][NI];
+        if (rg) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int co = co0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+#pragma unroll
+                for (int j = 0; j < NI; j++) {
+                    const int t = t0 + wv * T_W + j * 32 + l31;
+                    rv[e][j] = (co < a.cout && t < L) ? rg[(int64_t) co * LS + t] : 0.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int co = co0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (co >= a.cout) continue;
+            const float bias = a.b ? a.b[co] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < NI; j++) {
+                const int t = t0 + wv * T_W + j * 32 + l31;
+                if (t >= L) continue;
+                float v = acc[i][j][e] + bias;
+                if (rg) v = v + rv[e][j];
                 yg[(int64_t) co * LS + t] = v;
             }
         }

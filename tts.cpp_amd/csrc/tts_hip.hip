@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -303,14 +304,18 @@ struct tts_hip_ctx {
     uint32_t *d_codes = nullptr, *d_frames = nullptr;
     size_t d_frames_cap = 0;
     float *h_pcm = nullptr;
+    size_t h_pcm_elems = 0;
     bool debug = false;
     std::map<int, std::vector<float>> dac_dbg;
     std::map<size_t, float *> packed;  // arena offset of a conv weight -> its MFMA-tile-packed copy
+    std::set<size_t> packed_direct;    // ... of those, the k = 1 weights packed as [cin][cout] for conv1x1_direct_kernel
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
     bool kk_lstm_split = true;  // TTS_HIP_KOKORO_LSTM_SPLIT=0: the bidirectional LSTMs through the one-workgroup-per-direction kernel
     int *kk_stuck = nullptr;    // set by kk_lstm_split_kernel when a granule never arrives (bounded spin)
     bool kk_mfma = true;        // TTS_HIP_KOKORO_MFMA=0: every Kokoro convolution through the one-thread-per-output kernel
     int dac_group = 64;         // TTS_HIP_DAC_GROUP: utterances per codec pass (16: 451, 32: 458, 64: 461, 128: 460, 384: 462 audio-s/s at 3 x 384)
+    bool dac_conv1_direct = true;   // TTS_HIP_DAC_CONV1_DIRECT=0: the 96- / 192-channel k=1 convs stay on conv1d_mfma_kernel<1,...>
+    int dac_pad = 0;            // TTS_HIP_DAC_PAD=1: activation rows at the padded stride of dac_row_stride (measured: no effect, profiles/r02/dac_row_stride.log)
     int dac_variant = 20;       // TTS_HIP_DAC_VARIANT (tuning; 20 = 96-channel class on 128-position tiles, the one variant that measured faster): position-tile variant of the k = 7 conv kernel per channel-tile class
     int dac_alpha_tab = 1;      // 0: the codec kernels read snake's alpha from memory instead of an LDS table (smaller footprint)
     int dac_lds_reserve_kb = 0; // LDS the codec kernels leave free per CU for another context's decoder workgroups
@@ -382,6 +387,8 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_LN_WAVES")) c->ln_waves = std::max(1, std::min(4, atoi(e)));
     if (const char *e = getenv("TTS_HIP_KSPLIT_BIG")) c->ksplit_big = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("TTS_HIP_DAC_VARIANT")) c->dac_variant = atoi(e);
+    if (const char *e = getenv("TTS_HIP_DAC_PAD")) c->dac_pad = atoi(e);
+    if (const char *e = getenv("TTS_HIP_DAC_CONV1_DIRECT")) c->dac_conv1_direct = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_KOKORO_MFMA")) c->kk_mfma = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_KOKORO_LSTM_SPLIT")) c->kk_lstm_split = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_DAC_GROUP")) c->dac_group = std::max(1, atoi(e));
@@ -2330,12 +2337,13 @@ extern "C" int tts_hip_t5_output_size(tts_hip_ctx *c) {
 // ------------------------------------------------------------------------------------------------
 // DAC
 // ------------------------------------------------------------------------------------------------
-static int dac_snapshot(tts_hip_ctx *c, int stage, const float *dev, size_t n) {
+// [C][L] out of a device tensor whose rows are LS apart
+static int dac_snapshot(tts_hip_ctx *c, int stage, const float *dev, size_t C, size_t L, size_t LS) {
     if (!c->debug) return 0;
     HIPCHK(hipStreamSynchronize(c->stream));
     std::vector<float> &v = c->dac_dbg[stage];
-    v.resize(n);
-    HIPCHK(hipMemcpyAsync(v.data(), dev, n * 4, hipMemcpyDeviceToHost, c->stream));
+    v.resize(C * L);
+    HIPCHK(hipMemcpy2DAsync(v.data(), L * 4, dev, LS * 4, L * 4, C, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -2359,6 +2367,10 @@ static int conv_tile(int cout, int K, int *CO_T, int *CI_T) {
     if (cout % 96 == 0 && cout % 64 != 0) { *CO_T = 96; return 1; }
     if (cout % 64 == 0) { *CO_T = 64; return 2; }
     return -1;
+}
+// the k = 1 conv of a residual unit at <= 192 channels goes through conv1x1_direct_kernel (96-channel tiles; fp32 tensors only)
+static bool conv1_direct(const tts_hip_ctx *c, int cout, int cin) {
+    return c->dac_conv1_direct && !c->dac_f16 && cout == cin && (cin == 96 || cin == 192);
 }
 static int convt_tile(int cout, int s, int *CO_T) {
     if (s == 8 && cout % 64 == 0) { *CO_T = 64; return 0; }
@@ -2418,7 +2430,10 @@ static int ensure_packed(tts_hip_ctx *c) {
         if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, CI32_T, true));
         for (int r = 0; r < 3; r++) {
             if (conv_tile(b.cout, 7, &CO_T, &CI_T) >= 0) CHK(pack_one(c, b.res[r].in_w, b.cout, b.cout, 7, CO_T, CI_T, false));
-            if (conv_tile(b.cout, 1, &CO_T, &CI_T) >= 0) CHK(pack_one(c, b.res[r].out_w, b.cout, b.cout, 1, CO_T, CI_T, false));
+            if (conv1_direct(c, b.cout, b.cout)) {   // [cin][cout] for conv1x1_direct_kernel
+                CHK(pack_one(c, b.res[r].out_w, b.cout, b.cout, 1, b.cout, CI32_K1, false));
+                c->packed_direct.insert(b.res[r].out_w);
+            } else if (conv_tile(b.cout, 1, &CO_T, &CI_T) >= 0) CHK(pack_one(c, b.res[r].out_w, b.cout, b.cout, 1, CO_T, CI_T, false));
         }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -2499,6 +2514,17 @@ static int launch_convt_mfma16(tts_hip_ctx *c, const ConvTArgs &a_in, int nz) {
     return 0;
 }
 
+// Row stride of a codec activation [C][L]: L is frames x 2^k, so rows packed back to back start a multiple of 2 KB (up to 496 KB) apart and the
+// C rows a tile touches at the same position fall on few HBM channels.  An odd multiple of 256 B makes consecutive rows walk through
+// all of them, whatever power of two the interleave is; the kernels take the stride (a.L / a.Lout) apart from the valid length
+// (frames x mult) already.
+static int dac_row_stride(const tts_hip_ctx *c, int L) {
+    if (!c->dac_pad) return L;
+    int LS = (L + 63) / 64 * 64;
+    if (((LS / 64) & 1) == 0) LS += 64;
+    return LS;
+}
+
 struct DacBatch {
     int n = 1;                  // utterances (grid.z)
     const uint32_t *frames = nullptr;  // device [n]
@@ -2535,6 +2561,16 @@ static int launch_conv(tts_hip_ctx *c, const DacBatch &bt, const float *x, int c
         else if (K == 1 && cfg == 0) CHK((launch_conv_mfma16<1, 2, 2, 2, 2, CI16_K1>(c, a, bt.n)));
         else if (K == 1 && cfg == 1) CHK((launch_conv_mfma16<1, 3, 2, 1, 4, CI16_K1>(c, a, bt.n)));
         else CHK((launch_conv_mfma16<1, 2, 2, 1, 4, CI16_K1>(c, a, bt.n)));
+    } else if (K == 1 && pk != c->packed.end() && c->packed_direct.count(w) && !a.alpha && !a.alpha_out && !do_tanh) {
+        a.w = pk->second;
+        static std::atomic<uint64_t> attr{0};
+        if (attr_needed(attr, c->device)) {
+            HIPCHK(hipFuncSetAttribute((const void *) conv1x1_direct_kernel<3, 2, 96, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHK(hipFuncSetAttribute((const void *) conv1x1_direct_kernel<6, 1, 192, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        if (cin == 96) hipLaunchKernelGGL((conv1x1_direct_kernel<3, 2, 96, 96>), dim3((L + 255) / 256, 1, bt.n), dim3(256), (size_t) 96 * 96 * 4, c->stream, a);
+        else hipLaunchKernelGGL((conv1x1_direct_kernel<6, 1, 192, 48>), dim3((L + 127) / 128, 1, bt.n), dim3(256), (size_t) 48 * 192 * 4, c->stream, a);
+        HIPCHK(hipGetLastError());
     } else if (cfg >= 0 && pk != c->packed.end()) {
         a.w = pk->second;
         // position-tile variants of the k = 7 kernel (same packed weights: the image depends on CO_T and CI_T only); TTS_HIP_DAC_VARIANT picks
@@ -2667,18 +2703,32 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
         if (codes[i] >= (uint32_t) c->d_cbsize) return set_err("tts_hip_dac_decode: code %u >= codebook size %d", codes[i], c->d_cbsize);
     c->dac_dbg.clear();
     CHK(ensure_packed(c));
-    // buffers: n utterances padded to the longest
+    // buffers: n utterances, rows at the padded stride of the stage
     const size_t need_frames = (size_t) n * Fmax;
-    if (need_frames > c->dac_cap_frames) {
+    size_t need_elems = 0, pcm_elems = 0;
+    {
+        int Lq = (int) Fmax;
+        need_elems = (size_t) std::max(c->d_latent, c->d_c0) * dac_row_stride(c, Lq);
+        for (auto &b : c->dblocks) {
+            need_elems = std::max(need_elems, (size_t) b.cin * dac_row_stride(c, Lq));
+            Lq = (Lq - 1) * b.stride - 2 * b.padding + 2 * b.stride;
+            need_elems = std::max(need_elems, (size_t) b.cout * dac_row_stride(c, Lq));
+        }
+        need_elems *= n;
+        pcm_elems = (size_t) n * dac_row_stride(c, Lq);
+    }
+    if (need_frames > c->dac_cap_frames || need_elems > c->dbuf_elems || pcm_elems > c->h_pcm_elems) {
         HIPCHK(hipStreamSynchronize(c->stream));
         for (int i = 0; i < 3; i++) { free_dev(c->dbuf[i]); c->dbuf[i] = nullptr; }
         free_dev(c->d_codes); c->d_codes = nullptr;
         if (c->h_pcm) { (void) hipHostFree(c->h_pcm); c->h_pcm = nullptr; }
-        c->dbuf_elems = c->dac_frame_elems * need_frames;
+        c->dbuf_elems = std::max(need_elems, c->dbuf_elems);
+        const size_t cap_frames = std::max(need_frames, c->dac_cap_frames);
         for (int i = 0; i < 3; i++) HIPCHK(hipMalloc((void **) &c->dbuf[i], c->dbuf_elems * 4));
-        HIPCHK(hipMalloc((void **) &c->d_codes, need_frames * c->d_ncb * 4));
-        HIPCHK(hipHostMalloc((void **) &c->h_pcm, need_frames * c->d_up * 4));
-        c->dac_cap_frames = need_frames;
+        HIPCHK(hipMalloc((void **) &c->d_codes, cap_frames * c->d_ncb * 4));
+        c->h_pcm_elems = std::max(pcm_elems, c->h_pcm_elems);
+        HIPCHK(hipHostMalloc((void **) &c->h_pcm, c->h_pcm_elems * 4));
+        c->dac_cap_frames = cap_frames;
     }
     if (n > c->d_frames_cap) {
         free_dev(c->d_frames);
@@ -2696,31 +2746,33 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
     }
     DacBatch bt;
     bt.n = (int) n; bt.frames = c->d_frames; bt.mult = 1; bt.tot_frames = (double) tot;
-    int L = (int) Fmax;
+    int L = (int) Fmax;                      // longest utterance at this stage
+    int LS = dac_row_stride(c, L);           // row stride of this stage's activations
     float *cur = c->dbuf[0], *t1 = c->dbuf[1], *t2 = c->dbuf[2];
 
     DacEmbedArgs ea{};
     ea.frames = c->d_frames;
     ea.codes = c->d_codes; ea.codebook = (const float *) (c->arena + c->d_codebook); ea.proj_w = (const float *) (c->arena + c->d_projw);
     ea.proj_b = (const float *) (c->arena + c->d_projb); ea.n_cb = c->d_ncb; ea.cb_size = c->d_cbsize; ea.cb_dim = c->d_cbdim;
-    ea.latent = c->d_latent; ea.T = L; ea.out = cur; ea.x_f16 = c->dac_f16 ? 1 : 0;
+    ea.latent = c->d_latent; ea.T = L; ea.Tout = LS; ea.out = cur; ea.x_f16 = c->dac_f16 ? 1 : 0;
     CHK(prof_begin(c, TTS_HIP_K_DAC_EMBED, (double) c->d_latent * tot * 4, 2.0 * c->d_latent * tot * c->d_ncb * c->d_cbdim));
     hipLaunchKernelGGL(dac_embed_kernel, dim3((L + 63) / 64, c->d_latent, n), dim3(64), 0, c->stream, ea);
     HIPCHK(hipGetLastError());
     CHK(prof_end(c));
-    if (n == 1) CHK(dac_snapshot(c, 0, cur, (size_t) c->d_latent * L));
+    if (n == 1) CHK(dac_snapshot(c, 0, cur, (size_t) c->d_latent, (size_t) L, (size_t) LS));
 
-    CHK(launch_conv(c, bt, cur, c->d_latent, L, c->d_initw, c->d_initb, 0, false, c->d_c0, 7, 3, 1, nullptr, false, t1));
+    CHK(launch_conv(c, bt, cur, c->d_latent, LS, c->d_initw, c->d_initb, 0, false, c->d_c0, 7, 3, 1, nullptr, false, t1));
     std::swap(cur, t1);
-    if (n == 1) CHK(dac_snapshot(c, 1, cur, (size_t) c->d_c0 * L));
+    if (n == 1) CHK(dac_snapshot(c, 1, cur, (size_t) c->d_c0, (size_t) L, (size_t) LS));
 
     int C = c->d_c0;
     for (size_t bi = 0; bi < c->dblocks.size(); bi++) {
         const DBlock &b = c->dblocks[bi];
+        const int Lout = (L - 1) * b.stride - 2 * b.padding + 2 * b.stride, LSout = dac_row_stride(c, Lout);
         ConvTArgs ta{};
         ta.x = cur; ta.w = (const float *) (c->arena + b.w); ta.b = (const float *) (c->arena + b.b);
-        ta.alpha = (const float *) (c->arena + b.alpha); ta.y = t1; ta.cin = b.cin; ta.cout = b.cout; ta.L = L;
-        ta.Lout = (L - 1) * b.stride - 2 * b.padding + 2 * b.stride; ta.stride = b.stride; ta.pad = b.padding;
+        ta.alpha = (const float *) (c->arena + b.alpha); ta.y = t1; ta.cin = b.cin; ta.cout = b.cout; ta.L = LS;
+        ta.Lout = LSout; ta.stride = b.stride; ta.pad = b.padding;
         ta.frames = c->d_frames; ta.mult = bt.mult;
         const double Lov = bt.tot_frames * bt.mult * b.stride;
         CHK(prof_begin(c, TTS_HIP_K_DAC_CONVT, ((double) b.cin * bt.tot_frames * bt.mult + (double) b.cout * Lov + (double) b.cin * b.cout * 2 * b.stride) * 4,
@@ -2728,26 +2780,26 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
         CHK(launch_convt(c, ta, b.w, (int) n));
         CHK(prof_end(c));
         std::swap(cur, t1);
-        L = ta.Lout; C = b.cout;
+        L = Lout; LS = LSout; C = b.cout;
         bt.mult *= b.stride;
         for (int r = 0; r < 3; r++) {  // build_residual_unit: dilation 3^r, padding 3^(r+1) (gnac.h:44-48)
             int dil = 1;
             for (int e = 0; e < r; e++) dil *= 3;
             // snake(out_alpha) of the k=1 conv's input is applied in the k=7 conv's epilogue (same arithmetic, once
             // per element instead of once per output-channel tile)
-            CHK(launch_conv(c, bt, cur, C, L, b.res[r].in_w, b.res[r].in_b, b.res[r].in_alpha, true, C, 7, 3 * dil, dil, nullptr, false, t1,
+            CHK(launch_conv(c, bt, cur, C, LS, b.res[r].in_w, b.res[r].in_b, b.res[r].in_alpha, true, C, 7, 3 * dil, dil, nullptr, false, t1,
                             b.res[r].out_alpha, true));
-            CHK(launch_conv(c, bt, t1, C, L, b.res[r].out_w, b.res[r].out_b, 0, false, C, 1, 0, 1, cur, false, t2));
+            CHK(launch_conv(c, bt, t1, C, LS, b.res[r].out_w, b.res[r].out_b, 0, false, C, 1, 0, 1, cur, false, t2));
             std::swap(cur, t2);
         }
-        if (n == 1) CHK(dac_snapshot(c, 2 + (int) bi, cur, (size_t) C * L));
+        if (n == 1) CHK(dac_snapshot(c, 2 + (int) bi, cur, (size_t) C, (size_t) L, (size_t) LS));
     }
-    CHK(launch_conv(c, bt, cur, C, L, c->d_fw, c->d_fb, c->d_falpha, true, 1, 7, 3, 1, nullptr, true, t1));
-    HIPCHK(hipMemcpyAsync(c->h_pcm, t1, (size_t) n * L * 4, hipMemcpyDeviceToHost, c->stream));
+    CHK(launch_conv(c, bt, cur, C, LS, c->d_fw, c->d_fb, c->d_falpha, true, 1, 7, 3, 1, nullptr, true, t1));
+    HIPCHK(hipMemcpyAsync(c->h_pcm, t1, (size_t) n * LS * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     size_t off = 0;
     for (uint32_t i = 0; i < n; i++) {
-        memcpy(pcm_out + off, c->h_pcm + (size_t) i * L, (size_t) frames[i] * c->d_up * 4);
+        memcpy(pcm_out + off, c->h_pcm + (size_t) i * LS, (size_t) frames[i] * c->d_up * 4);
         off += (size_t) frames[i] * c->d_up;
     }
     return 0;
