@@ -195,8 +195,9 @@ def test_batched_prefill_equals_sequential_prefill():
         outs.append(eng.step(ids, [len(p) for p in prompts]))
         eng.close()
     # the batched prefill carries enough rows for the LDS-tiled GEMM (fc2: K = 128), the sequential one stays on the 16-feature
-    # workgroups: same products, different fp32 summation order
-    assert relerr(outs[0], outs[1]) < 1e-4
+    # workgroups, and forwards of up to 4 rows slice the keys of a (row, head) over 8 workgroups whose partial softmax results are
+    # merged by the last one to finish (attn_kernel): same products, different fp32 summation order (measured 1.7e-4)
+    assert relerr(outs[0], outs[1]) < 4e-4
 
 
 def test_graph_replay_equals_eager_and_greedy_equals_argmax():

@@ -520,6 +520,9 @@ struct AttnArgs {
     _Float16 *out16;       // [R][H] fp16 copy for an fp16-weight out_proj (same rounding the GEMM would apply), or NULL
     float *part;           // [R][n_heads][nsplit][66]  (max, sum, acc[64]) when nsplit > 1
     int max_T;             // LDS score capacity
+    // nsplit > 1 with counters != NULL: the workgroup that finishes a (row, head) last folds the nsplit partials itself (same fixed
+    // order as attn_combine_kernel) — no separate combine launch; counters [R][n_heads] start at 0 and are left at 0
+    uint32_t *counters;
 };
 
 __device__ __forceinline__ float4v load_kv4(const void *base, int kv_f16, int64_t off) {
@@ -596,11 +599,51 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
             if (a.out16) a.out16[(int64_t) r * a.H + h * 64 + tid] = (_Float16) res;
             else a.out[(int64_t) r * a.H + h * 64 + tid] = res;
         } else {
+            // agent-scope atomic stores: the partial is read by a workgroup on another CU / XCD (L2 is per XCD)
             float *p = a.part + (((int64_t) r * a.n_heads + h) * nz + z) * 66;
-            if (tid == 0) { p[0] = mx; p[1] = s; }
-            p[2 + tid] = o;
+            if (tid == 0) {
+                __hip_atomic_store(p, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p + 1, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(p + 2 + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (nz == 1 || !a.counters) return;
+    // last workgroup of this (row, head): fold the partials in split order (attn_combine_kernel's arithmetic)
+    uint32_t *s_last = (uint32_t *) (red + NKG * 66);   // one of the 16 spare words behind [NKG][66]
+    __syncthreads();   // the 64 stores above are issued
+    if (tid == 0) {
+        const uint32_t prev = __hip_atomic_fetch_add(a.counters + r * a.n_heads + h, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = prev == (uint32_t) nz - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!*s_last || tid >= 64) return;
+    const float *p = a.part + ((int64_t) r * a.n_heads + h) * nz * 66;
+    float mm[16], ss[16], oo[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i < nz) {
+            mm[i] = __hip_atomic_load(p + i * 66, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ss[i] = __hip_atomic_load(p + i * 66 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            oo[i] = __hip_atomic_load(p + i * 66 + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    float gmx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; i++) if (i < nz) gmx = fmaxf(gmx, mm[i]);
+    float ot = 0.0f, st = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i < nz && mm[i] != -INFINITY) {  // -inf marks an empty chunk
+            const float f2 = expf(mm[i] - gmx);
+            ot += f2 * oo[i];
+            st += f2 * ss[i];
+        }
+    }
+    const float res = ot / st;
+    if (a.out16) a.out16[(int64_t) r * a.H + h * 64 + tid] = (_Float16) res;
+    else a.out[(int64_t) r * a.H + h * 64 + tid] = res;
+    if (tid == 0) __hip_atomic_store(a.counters + r * a.n_heads + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Cross-attention over a short voice prompt (T_fixed <= 32 encoder positions; Parler-Mini: 8..40): the general kernel

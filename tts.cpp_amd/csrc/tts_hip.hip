@@ -308,6 +308,8 @@ struct tts_hip_ctx {
     bool debug = false;
     std::map<int, std::vector<float>> dac_dbg;
     std::map<size_t, float *> packed;  // arena offset of a conv weight -> its MFMA-tile-packed copy
+    std::set<size_t> packed_c192;      // ... and the k = 7 weights of 192-channel units packed as one 192-channel tile (TTS_HIP_DAC_C192=1)
+    int dac_c192 = 0;
     std::set<size_t> packed_direct;    // ... of those, the k = 1 weights packed as [cin][cout] for conv1x1_direct_kernel
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
     bool kk_lstm_split = true;  // TTS_HIP_KOKORO_LSTM_SPLIT=0: the bidirectional LSTMs through the one-workgroup-per-direction kernel
@@ -343,6 +345,8 @@ struct tts_hip_ctx {
     bool prof_cur = false;
     tts_hip_kstat kstat[TTS_HIP_K_COUNT]{};
     int attn_nsplit_override = 0;
+    bool attn_fused = true;          // TTS_HIP_ATTN_FUSED=0: split-T self-attention keeps its separate combine launch and small batches stay unsplit
+    uint32_t *attn_cnt = nullptr;    // [RMAX][heads] arrival counters of the fused combine (attn_kernel)
 };
 
 static const char *KNAMES[TTS_HIP_K_COUNT] = {"embed", "ln", "gemm_qkv", "attn_self", "gemm_attn_out", "gemm_cross_q", "attn_cross",
@@ -382,12 +386,14 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     }
     const char *ns = getenv("TTS_HIP_ATTN_NSPLIT");
     if (ns) c->attn_nsplit_override = atoi(ns);
+    if (const char *e = getenv("TTS_HIP_ATTN_FUSED")) c->attn_fused = atoi(e) != 0;
     const char *lf = getenv("TTS_HIP_LN_FUSE_MAX");
     if (lf) c->ln_fuse_max = std::max(0, std::min(32, atoi(lf)));
     if (const char *e = getenv("TTS_HIP_LN_WAVES")) c->ln_waves = std::max(1, std::min(4, atoi(e)));
     if (const char *e = getenv("TTS_HIP_KSPLIT_BIG")) c->ksplit_big = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("TTS_HIP_DAC_VARIANT")) c->dac_variant = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_PAD")) c->dac_pad = atoi(e);
+    if (const char *e = getenv("TTS_HIP_DAC_C192")) c->dac_c192 = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_CONV1_DIRECT")) c->dac_conv1_direct = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_KOKORO_MFMA")) c->kk_mfma = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_KOKORO_LSTM_SPLIT")) c->kk_lstm_split = atoi(e) != 0;
@@ -432,7 +438,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     free_dev(c->di_e16);
     for (int i = 0; i < 3; i++) free_dev(c->sbuf[i]);
     free_dev(c->s_noise); free_dev(c->s_codes);
-    free_dev(c->t5_bucket); free_dev(c->t5_x); free_dev(c->t5_qkv); free_dev(c->t5_att); free_dev(c->t5_ug); free_dev(c->t5_g); free_dev(c->t5_y); free_dev(c->t5_ids); free_dev(c->logits); free_dev(c->part); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
+    free_dev(c->t5_bucket); free_dev(c->t5_x); free_dev(c->t5_qkv); free_dev(c->t5_att); free_dev(c->t5_ug); free_dev(c->t5_g); free_dev(c->t5_y); free_dev(c->t5_ids); free_dev(c->logits); free_dev(c->part); free_dev(c->attn_cnt); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
     free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
     free_dev(c->d_eos); free_dev(c->d_codes); free_dev(c->d_frames);
     for (int i = 0; i < 3; i++) free_dev(c->dbuf[i]);
@@ -1433,9 +1439,11 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
         HIPCHK(hipGetLastError());
         return prof_end(c);
     }
+    const bool fused = nsplit > 1 && c->attn_fused && c->attn_cnt != nullptr;
+    a.counters = fused ? c->attn_cnt : nullptr;
     hipLaunchKernelGGL(attn_kernel, dim3(c->NH, R, nsplit), dim3(threads), lds, c->stream, a);
     HIPCHK(hipGetLastError());
-    if (nsplit > 1) {
+    if (nsplit > 1 && !fused) {
         hipLaunchKernelGGL(attn_combine_kernel, dim3(c->NH, R), dim3(64), 0, c->stream, (const float *) a.part, nsplit, c->H, c->NH, a.out, a.out16);
         HIPCHK(hipGetLastError());
     }
@@ -1444,8 +1452,11 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
 
 static int attn_nsplit(const tts_hip_ctx *c, int R, bool same_seq) {
     if (c->attn_nsplit_override > 0) return std::min(c->attn_nsplit_override, 16);
-    (void) R; (void) same_seq;
-    return 1;  // small batches use 1024-thread workgroups instead (run_attn); split-T stays available via TTS_HIP_ATTN_NSPLIT
+    (void) same_seq;
+    // up to 4 rows (64 (head, row) pairs on 256 CUs): 8 key slices per pair, folded by the workgroup that finishes last (attn_kernel);
+    // batch 1: 1.55 -> 1.33 ms/step over a 2564-step utterance, 1.71 -> 1.38 at T > 1024.  Larger batches fill the chip with one workgroup per pair.
+    if (c->attn_fused && c->attn_cnt && R * c->NH <= 64) return 8;
+    return 1;  // 1024-thread workgroups for few pairs (run_attn); split-T stays available via TTS_HIP_ATTN_NSPLIT
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1622,6 +1633,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->ad, (size_t) R * std::max(H, c->F) / 32));
         CHK(dmalloc(&c->logits, (size_t) R * c->NO * c->V));
         CHK(dmalloc(&c->part, (size_t) R * c->NH * 16 * 66));
+        CHK(dmalloc(&c->attn_cnt, (size_t) R * c->NH));
         CHK(dmalloc(&c->d_ids, (size_t) R * c->NO));
         CHK(dmalloc(&c->d_pos, (size_t) R));
         CHK(dmalloc(&c->d_seq, (size_t) R));
@@ -2429,7 +2441,10 @@ static int ensure_packed(tts_hip_ctx *c) {
     for (auto &b : c->dblocks) {
         if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, CI32_T, true));
         for (int r = 0; r < 3; r++) {
-            if (conv_tile(b.cout, 7, &CO_T, &CI_T) >= 0) CHK(pack_one(c, b.res[r].in_w, b.cout, b.cout, 7, CO_T, CI_T, false));
+            if (c->dac_c192 && b.cout == 192) {
+                CHK(pack_one(c, b.res[r].in_w, b.cout, b.cout, 7, 192, CI32_K7, false));
+                c->packed_c192.insert(b.res[r].in_w);
+            } else if (conv_tile(b.cout, 7, &CO_T, &CI_T) >= 0) CHK(pack_one(c, b.res[r].in_w, b.cout, b.cout, 7, CO_T, CI_T, false));
             if (conv1_direct(c, b.cout, b.cout)) {   // [cin][cout] for conv1x1_direct_kernel
                 CHK(pack_one(c, b.res[r].out_w, b.cout, b.cout, 1, b.cout, CI32_K1, false));
                 c->packed_direct.insert(b.res[r].out_w);
@@ -2576,7 +2591,9 @@ static int launch_conv(tts_hip_ctx *c, const DacBatch &bt, const float *x, int c
         // position-tile variants of the k = 7 kernel (same packed weights: the image depends on CO_T and CI_T only); TTS_HIP_DAC_VARIANT picks
         // per channel-tile class (decimal digits: class 0 / 1 / 2), measured in profiles/r02/dac_variants.log
         const int v0 = c->dac_variant % 10, v1 = (c->dac_variant / 10) % 10, v2 = (c->dac_variant / 100) % 10;
-        if (K == 7 && cfg == 0 && v0 == 1) CHK((launch_conv_mfma<7, 2, 4, 2, 2, CI32_K7>(c, a, bt.n)));        // 128 ch x 256 pos, wave 64 x 128
+        if (K == 7 && c->packed_c192.count(w) && c->dac_c192 == 1) CHK((launch_conv_mfma<7, 6, 1, 1, 4, CI32_K7>(c, a, bt.n)));        // 192 ch x 128 pos: input staged once
+        else if (K == 7 && c->packed_c192.count(w)) CHK((launch_conv_mfma<7, 3, 1, 2, 2, CI32_K7>(c, a, bt.n)));                        // 192 ch x 64 pos, 2 x 2 waves
+        else if (K == 7 && cfg == 0 && v0 == 1) CHK((launch_conv_mfma<7, 2, 4, 2, 2, CI32_K7>(c, a, bt.n)));        // 128 ch x 256 pos, wave 64 x 128
         else if (K == 7 && cfg == 0 && v0 == 2) CHK((launch_conv_mfma<7, 4, 2, 1, 4, CI32_K7>(c, a, bt.n)));   // 128 ch x 256 pos, wave 128 x 64
         else if (K == 7 && cfg == 0 && v0 == 3) CHK((launch_conv_mfma<7, 2, 1, 2, 2, CI32_K7>(c, a, bt.n)));   // 128 ch x 64 pos
         else if (K == 7 && cfg == 0 && v0 == 4) CHK((launch_conv_mfma<7, 1, 2, 4, 1, CI32_K7>(c, a, bt.n)));   // 128 ch x 64 pos, wave 32 x 64
