@@ -1481,7 +1481,7 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
     ea.x = c->x;
     ea.H = H;
     CHK(prof_begin(c, TTS_HIP_K_EMBED, (double) R * (ea.n_tabs + 2) * H * 4, 0));
-    hipLaunchKernelGGL(embed_rows_kernel, dim3(R), dim3(256), 0, c->stream, ea);
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(R, R <= 64 ? (H + 255) / 256 : 1), dim3(256), 0, c->stream, ea);
     HIPCHK(hipGetLastError());
     CHK(prof_end(c));
 
