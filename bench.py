@@ -177,6 +177,20 @@ def decode_step_sweep(cfg_full, model, arena_ptr, device):
         e.generate_greedy([pos], n)
         out[label] = round((time.perf_counter() - t0) / n * 1e3, 4)
         pos = upto
+    # the reference's shape of a step (decode() + get_ggml_node_data + sampler::max on the host, parler/model.cpp:648-693): one call per
+    # token, the 39 KB of logits copied back, arg-max here — 64 steps around T = 128 and T = 512
+    per_call = {}
+    for label, T in (("T~128", 128), ("T~512", 512)):
+        e.reset()
+        e.prefill(0, prompt)
+        e.generate_greedy([len(prompt)], T - 32 - len(prompt))
+        ids = np.full((1, cfg_full.n_out), cfg_full.bos, dtype=np.uint32)
+        for s in range(4):
+            ids = e.step(ids, [T - 32 - 4 + s]).argmax(-1).astype(np.uint32)
+        t0 = time.perf_counter()
+        for s in range(64):
+            ids = e.step(ids, [T - 32 + s]).argmax(-1).astype(np.uint32)
+        per_call[label] = round((time.perf_counter() - t0) / 64 * 1e3, 4)
     e.reset()
     e.prefill(0, prompt)
     n_long = min(1024, cfg_full.max_gen - len(prompt))
@@ -184,11 +198,11 @@ def decode_step_sweep(cfg_full, model, arena_ptr, device):
     e.generate_greedy([len(prompt)], n_long)
     t1024 = time.perf_counter() - t0
     e.close()
-    return {"ms_per_step_by_cached_positions": out,
+    return {"ms_per_step_by_cached_positions": out, "ms_per_step_per_call_with_logits_d2h": per_call,
             "steps_1024": {"steps": n_long, "ms_total": round(t1024 * 1e3, 2), "ms_per_step": round(t1024 / n_long * 1e3, 4),
                            "x_real_time": round((n_long - cfg_full.n_out + 1) * cfg_full.hop / SAMPLE_RATE / t1024, 2)},
             "note": "batch 1, fp16 weights, fp32 KV cache, cross-attention on, greedy, device-resident loop (tts_hip_parler_generate_greedy); "
-                    "each interval continues the same utterance from the previous one"}
+                    "each interval continues the same utterance from the previous one; per_call: tts_hip_parler_step per token + logits D2H + host arg-max"}
 
 
 def main():
