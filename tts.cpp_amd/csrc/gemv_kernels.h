@@ -173,3 +173,80 @@ __global__ __launch_bounds__(256) void gemv_q4_rows_kernel(QGemmArgs qa, const u
         }
     }
 }
+
+
+// The same Q4_0 x Q8_0 row products as gemv_q4_rows_kernel (identical per-feature arithmetic: lane -> block mapping, fp32 accumulation order,
+// wave reduction), scheduled for the load path: that kernel issues five load instructions per 16 bytes of weights (codes, block scale,
+// two activation vectors, activation scale — the last three are the same for every feature but still go through the CU's address /
+// L1 path), and one feature per wave leaves one or two 16-byte loads in flight per lane.  Here the Q8_0 activation rows and their
+// scales are staged in LDS once per workgroup, a wave owns FPW consecutive features and requests the codes and scales of all of them
+// for a block column before the first integer dot.
+template <int NR, int FPW>
+__global__ __launch_bounds__(256) void gemv_q4_rows_lds_kernel(QGemmArgs qa, const uint8_t *w4, int epi) {
+    extern __shared__ __attribute__((aligned(16))) char gq_sm[];
+    const GemmArgs &a = qa.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, nb = K >> 5, R = a.R;
+    int8_t *sx = (int8_t *) gq_sm;                       // [R][K]
+    float *sd = (float *) (gq_sm + (size_t) R * K);      // [R][nb]
+    for (int i = tid; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
+    for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
+    __syncthreads();
+    const int n0 = ((int) blockIdx.x * 4 + wave) * FPW;
+    if (n0 >= a.N) return;
+    float acc[FPW][NR];
+#pragma unroll
+    for (int f = 0; f < FPW; f++)
+#pragma unroll
+        for (int r = 0; r < NR; r++) acc[f][r] = 0.0f;
+#pragma unroll 2
+    for (int b = lane; b < nb; b += 64) {
+        int4v wn[FPW];
+        float dw[FPW];
+#pragma unroll
+        for (int f = 0; f < FPW; f++) {
+            const int n = min(n0 + f, a.N - 1);
+            wn[f] = *(const int4v *) (w4 + (int64_t) n * (K >> 1) + b * 16);
+            dw[f] = (float) qa.wd[(int64_t) n * nb + b];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            if (r < R) {
+                const int4v x0 = *(const int4v *) (sx + (size_t) r * K + b * 32), x1 = *(const int4v *) (sx + (size_t) r * K + b * 32 + 16);
+                const float da = sd[r * nb + b];
+                int sxs = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    sxs = __builtin_amdgcn_sdot4(0x01010101, x0[e], sxs, false);
+                    sxs = __builtin_amdgcn_sdot4(0x01010101, x1[e], sxs, false);
+                }
+#pragma unroll
+                for (int f = 0; f < FPW; f++) {
+                    int s = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int lo = wn[f][e] & 0x0F0F0F0F, hi = (wn[f][e] >> 4) & 0x0F0F0F0F;
+                        s = __builtin_amdgcn_sdot4(lo, x0[e], s, false);
+                        s = __builtin_amdgcn_sdot4(hi, x1[e], s, false);
+                    }
+                    acc[f][r] += (float) (s - 8 * sxs) * (dw[f] * da);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < FPW; f++) {
+        const int n = n0 + f;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            if (r < R) {
+                const float sm_ = wave_sum(acc[f][r]);
+                if (lane == 0 && n < a.N) {
+                    float *o = a.out + (int64_t) r * a.ldo + n;
+                    if (epi == EPI_RESID) *o += sm_;
+                    else *o = sm_;
+                }
+            }
+        }
+    }
+}

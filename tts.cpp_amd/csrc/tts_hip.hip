@@ -206,6 +206,7 @@ struct tts_hip_ctx {
     int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
     bool q4_native = false;     // TTS_HIP_Q4_NATIVE (with TTS_HIP_GEMV_ROWS; default on for Orpheus contexts): Q4_0 matrices are read as 4-bit codes
     std::vector<void *> q4_bufs;
+    bool q4_lds = true;         // TTS_HIP_Q4_LDS=0: Q4_0 row products stay on gemv_q4_rows_kernel (one feature per wave, activations from L2)
     bool gemv_stream = true;    // TTS_HIP_GEMV_STREAM=0: <= 16-row F16 GEMMs of the Dia step stay on gemm16_kernel (gemv_stream_kernels.h otherwise)
     bool llama_graph = false;   // TTS_HIP_LLAMA_GRAPH (default on for Orpheus contexts): the greedy step as one captured graph
     bool gemv_rows = false;     // TTS_HIP_GEMV_ROWS (default on for Orpheus contexts): 1..4 rows go through the streaming one-wave-per-feature kernels (gemv_kernels.h)
@@ -412,6 +413,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_GEMV_ROWS")) c->gemv_rows = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_LLAMA_GRAPH")) c->llama_graph = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_GEMV_STREAM")) c->gemv_stream = atoi(e) != 0;
+    if (const char *e = getenv("TTS_HIP_Q4_LDS")) c->q4_lds = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_Q4_NATIVE")) c->q4_native = atoi(e) != 0;
     return c;
 }
@@ -1266,7 +1268,12 @@ static int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro
         qa.wd = (const _Float16 *) (c->arena + w.soff);
         qa.aq = c->aq;
         qa.ad = c->ad;
-        if (w.q4) hipLaunchKernelGGL(gemv_q4_rows_kernel<4>, dim3((a.N + 3) / 4), dim3(256), 0, c->stream, qa, w.q4, epi);
+        const size_t q4_lds = (size_t) a.R * a.K + (size_t) a.R * (a.K / 32) * 4;
+        if (w.q4 && c->q4_lds && q4_lds <= 64 * 1024 && a.K % 512 == 0) {
+            // activations in LDS, 2 or 4 features per wave (gemv_q4_rows_lds_kernel): fewer load instructions per weight byte
+            if (a.N >= 8192) hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 4>), dim3((a.N + 15) / 16), dim3(256), q4_lds, c->stream, qa, w.q4, epi);
+            else hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 2>), dim3((a.N + 7) / 8), dim3(256), q4_lds, c->stream, qa, w.q4, epi);
+        } else if (w.q4) hipLaunchKernelGGL(gemv_q4_rows_kernel<4>, dim3((a.N + 3) / 4), dim3(256), 0, c->stream, qa, w.q4, epi);
         else hipLaunchKernelGGL(gemv_q8_rows_kernel<4>, dim3((a.N + 3) / 4), dim3(256), 0, c->stream, qa, epi);
         HIPCHK(hipGetLastError());
         return prof_end(c);
