@@ -119,7 +119,8 @@ DTYPE_DETAIL = {
 
 def cpu_baseline(model, cfg, prompt, threads):
     """The oracle ("port": restated CPU path, ggml unavailable) on the host cores, bounded sample:
-    prompt prefill + a few audio steps + a few DAC frames, extrapolated per frame."""
+    prompt prefill + 128 audio steps (one greedy utterance up to T ~ 144) + the DAC on 64 frames — about 10-15 s of CPU work —
+    extrapolated per frame."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ["ORACLE_THREADS"] = str(threads)
     import oracle as orc
@@ -128,14 +129,14 @@ def cpu_baseline(model, cfg, prompt, threads):
     o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
     o.decode(prompt, 0, audio=False, want_logits=False)
     ids = np.full(cfg.n_out, cfg.bos, dtype=np.uint32)
-    n_steps = 12
+    n_steps = min(128, max(1, cfg.max_gen - len(prompt) - 1))
     t0 = time.perf_counter()
     for s in range(n_steps):
         lg, _ = o.decode(ids, len(prompt) + s, audio=True)
         ids = lg[:, 0, :].argmax(-1).astype(np.uint32)
     t_step = (time.perf_counter() - t0) / n_steps
     d = orc.DacOracle(model)
-    n_frames = 4
+    n_frames = 64
     codes = np.random.default_rng(0).integers(0, cfg.cb_size, (n_frames, cfg.n_out)).astype(np.uint32)
     t0 = time.perf_counter()
     d.decode(codes)
