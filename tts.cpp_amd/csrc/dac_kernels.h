@@ -395,8 +395,11 @@ __global__ void pack_conv_w_kernel(const float *src, float *dst, int cout, int c
 // snake applied on the way in; a.w is the PACKED weight (see pack_conv_w_kernel).  Two LDS buffers:
 // the global loads of chunk c+1 are issued before the MFMA loop of chunk c and land in registers
 // while the matrix pipe works; one barrier per chunk.
+#ifndef CONV7_MIN_WAVES
+#define CONV7_MIN_WAVES 1   // 4 (= 128 registers per wave, accumulators out of the AGPRs, 11-21 spills) measured 12 % slower: profiles/r02/dac_conv7_occupancy_ab.log
+#endif
 template <int KT, int MI, int NI, int WM, int WN, int CI_T>
-__global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (KT == 7 && MI * NI <= 4) ? CONV7_MIN_WAVES : 1) void conv1d_mfma_kernel(ConvArgs a) {
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, NT = 64 * WM * WN;
     constexpr int WCH = KT * CI_T * CO_T;                    // floats per packed weight chunk
     constexpr int WV = (WCH / 4 + NT - 1) / NT;              // float4 per thread per chunk
