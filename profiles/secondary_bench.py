@@ -139,7 +139,10 @@ def run_dia(args):
     audio_s = U * frames * 512 / 44100.0 * args.steps
     w_bytes = n_dec * 2
     ckv_bytes = cfg.dec_layers * 2 * cfg.max_ctx * A * 4 * 2
-    tot = w_bytes + U * ckv_bytes
+    # self-attention cache rows a step reads: fp32 K and V of the 4 k/v groups, positions 0..t of both guidance rows, t averaged over the loop
+    kvH = cfg.dec_kv_heads * cfg.head_dim
+    skv_bytes = cfg.dec_layers * 2 * 2 * (steps / 2.0) * kvH * 4
+    tot = w_bytes + U * (ckv_bytes + skv_bytes)
     out = {
         "metric": "audio-seconds/sec (Dia-1.6B fp16: encoder + guided decoder + DAC to 44.1 kHz PCM, lock-step utterances)",
         "value": round(audio_s / elapsed, 3), "unit": "audio-seconds/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -156,7 +159,7 @@ def run_dia(args):
         "roofline": {"bound": "hbm", "achieved": round(tot / (step_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(tot / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel": "whole decoder step (18 layers x 14 launches: gemv_stream_kernel, attn_gqa_split_kernel<128>, rms_fold_rows_kernel, ... + sample_kernel)",
-                     "algorithmic_bytes_per_launch": tot, "note": f"fp16 matrices {w_bytes / 1e9:.3f} GB + {U} x fp32 cross K/V {ckv_bytes / 1e9:.3f} GB per step"},
+                     "algorithmic_bytes_per_launch": tot, "note": f"fp16 matrices {w_bytes / 1e9:.3f} GB + {U} x (fp32 cross K/V {ckv_bytes / 1e9:.3f} GB + self-attention K/V at the mean position {skv_bytes / 1e9:.3f} GB) per step"},
     }
     eng.close()
     dac.close()
