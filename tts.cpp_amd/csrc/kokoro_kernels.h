@@ -29,6 +29,56 @@ __global__ __launch_bounds__(256) void kk_linear_kernel(const float *W, const fl
     }
 }
 
+// The same product for many rows (ALBERT over the whole phoneme sequence: 402 rows x 768 -> 3072) on the exact-fp32 matrix pipe:
+// kk_linear_kernel gives a wave to every output and re-reads a weight row and an activation row from L2 for each (7 GB of L2 reads for
+// one FFN projection).  Here a workgroup owns 64 rows x 64 features; 16-column slices of both operands are transposed into LDS
+// ([k][row], [k][feature]) so that v_mfma_f32_32x32x2_f32 reads one float per lane (A[i = row][k], B[k][j = feature]); the next slice's
+// global loads travel under the MFMAs of the current one.  fp32 products, accumulation over k ascending as an fma chain.
+// Requires K % 16 == 0, ldx % 4 == 0 and 16-byte aligned x / W (the caller checks); b may be NULL.
+__global__ __launch_bounds__(256) void kk_linear_mfma_kernel(const float *W, const float *b, const float *x, int ldx, int R, int K, int N, float *y, int ldy, int accumulate) {
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    constexpr int KC = 16, LD = 68;
+    __shared__ float xs[2][KC][LD], ws[2][KC][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 1, wn = wv & 1;
+    const int r0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int si = tid >> 2, k4 = (tid & 3) * 4;   // staging: row / feature si, columns k4..k4+3 of the slice
+    const bool xok = r0 + si < R, wok = n0 + si < N;
+    const float *xp = x + (int64_t) (r0 + si) * ldx + k4, *wp = W + (int64_t) (n0 + si) * K + k4;
+    f4v xa = {0.f, 0.f, 0.f, 0.f}, wa = {0.f, 0.f, 0.f, 0.f};
+    if (xok) xa = *(const f4v *) xp;
+    if (wok) wa = *(const f4v *) wp;
+    f16v acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+    const int nc = K / KC;
+    for (int c = 0; c < nc; c++) {
+        const int buf = c & 1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { xs[buf][k4 + e][si] = xa[e]; ws[buf][k4 + e][si] = wa[e]; }
+        if (c + 1 < nc) {
+            if (xok) xa = *(const f4v *) (xp + (c + 1) * KC);
+            if (wok) wa = *(const f4v *) (wp + (c + 1) * KC);
+        }
+        __syncthreads();   // slice c is in LDS; the other buffer was last read before the previous barrier
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[buf][kk + hi][wm * 32 + l31], ws[buf][kk + hi][wn * 32 + l31], acc, 0, 0, 0);
+    }
+    const int n = n0 + wn * 32 + l31;
+    if (n >= N) return;
+    const float bias = b ? b[n] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int r = r0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        if (r >= R) continue;
+        float *p = y + (int64_t) r * ldy + n;
+        const float v = acc[e] + bias;
+        *p = accumulate ? *p + v : v;
+    }
+}
+
 // mode 0: y = norm(x) * w + b (w may be NULL: plain norm); mode 1 (AdaLayerNorm): y = n + n * gamma + beta with gamma = w, beta = b
 __global__ __launch_bounds__(64) void kk_norm_rows_kernel(const float *x, int ldx, int H, float eps, const float *w, const float *b, int mode, float *y, int ldy) {
     const int r = blockIdx.x, lane = threadIdx.x;

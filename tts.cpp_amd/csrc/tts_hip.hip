@@ -3617,6 +3617,11 @@ struct KRun {
     }
     void linear(const float *W, const float *b, const float *x, int ldx, int R, int K, int N, float *y, int ldy, int acc = 0) {
         if (!W || !x || !y) return;
+        if (c->kk_mfma && R >= 32 && K % 16 == 0 && ldx % 4 == 0 && ((uintptr_t) W & 15) == 0 && ((uintptr_t) x & 15) == 0) {
+            // many rows (ALBERT and the predictor over the whole sequence): 64 x 64 tiles on the exact-fp32 matrix pipe
+            hipLaunchKernelGGL(kk_linear_mfma_kernel, dim3((unsigned) ((N + 63) / 64), (unsigned) ((R + 63) / 64)), dim3(256), 0, st, W, b, x, ldx, R, K, N, y, ldy, acc);
+            return;
+        }
         hipLaunchKernelGGL(kk_linear_kernel, dim3((unsigned) (((int64_t) R * N + 3) / 4)), dim3(256), 0, st, W, b, x, ldx, R, K, N, y, ldy, acc);
     }
     void norm_rows(const float *x, int ldx, int R, int H, float eps, const float *w_, const float *b, int mode, float *y, int ldy) {
