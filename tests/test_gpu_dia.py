@@ -143,6 +143,30 @@ def test_dia_lockstep_batch_of_4_equals_4_single_oracles(wtype, tol):
     one.close()
 
 
+def test_dia_seven_utterances_take_the_16_row_streaming_gemm():
+    """7 utterances = 14 rows: gemv_stream_kernel keeps 16 rows of the activation slice in LDS (8 up to 4 utterances), slabs folded by the
+    consumers — every utterance against its own oracle, fp16 matrices"""
+    model = synth.build_dia(synth.dia_tiny(weight_type=gguf.F16))
+    cfg = model.cfg
+    eng = hip.DiaEngine(cfg, max_utterances=7)
+    eng.load(model)
+    texts = ["[S1] one.", "[S2] two two.", "[S1] three.", "[S2] four.", "[S1] five five.", "[S2] six.", "[S1] seven."]
+    oracles, rng = [], np.random.default_rng(7)
+    for u, t in enumerate(texts):
+        toks, n = orc.dia_tokenize(t, cfg.max_ctx)
+        eng.encode_slot(u, toks, n)
+        o = orc.DiaOracle(model, act_mode=1)
+        o.encode(toks, n)
+        oracles.append(o)
+    ids = np.full((7, cfg.n_out), cfg.bos, dtype=np.uint32)
+    for step in range(3):
+        lg = eng.step_batch(ids, np.full(7, step, dtype=np.uint32))
+        for u in range(7):
+            assert relerr(lg[u], oracles[u].step(ids[u], step)) < 8e-3, (step, u)
+            ids[u] = rng.integers(0, cfg.audio_vocab, cfg.n_out)
+    eng.close()
+
+
 def test_dia_runner_generate_batch_equals_separate_generates(tmp_path):
     """dia_runner::generate_batch (4 utterances in lock-step, per-utterance countdown and un-delay) == 4 generate() calls, greedy:
     token streams identical, audio equal"""

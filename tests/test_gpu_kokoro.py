@@ -124,3 +124,19 @@ def test_kokoro_82m_shapes_match_oracle():
     print(f"kokoro-82m: duration states {relerr(hid, ref_hid):.2e}, predicted lengths equal: {np.array_equal(lens, ref_lens)}, audio {relerr(pcm, ref_pcm):.2e}")
     assert pcm.shape == ref_pcm.shape and relerr(pcm, ref_pcm) < 2e-4          # measured 2.8e-6
     eng.close()
+
+
+def test_kokoro_82m_projections_over_a_long_sequence():
+    """40 phoneme ids at the 82M widths: from 32 rows on, ALBERT's and the predictor's projections run on kk_linear_mfma_kernel (64 x 64
+    tiles of the exact-fp32 MFMA) instead of one wave per output — durations identical, duration states against the oracle"""
+    model = synth.build_kokoro(synth.kokoro_82m())
+    cfg = model.cfg
+    eng = hip.KokoroEngine(model)
+    o = orc.KokoroOracle(model)
+    rng = np.random.default_rng(40)
+    toks = np.concatenate([[0], rng.integers(1, cfg.vocab, 40), [0]]).astype(np.uint32)
+    lens, hid = eng.durations(toks, cfg.voices[0])
+    ref_lens, ref_hid = o.durations(toks, cfg.voices[0])
+    print(f"kokoro-82m, 42 rows: duration states {relerr(hid, ref_hid):.2e}")
+    assert np.array_equal(lens, ref_lens) and relerr(hid, ref_hid) < 2e-3     # fp16-table GELU on both sides (see the 82M test above)
+    eng.close()
