@@ -250,3 +250,99 @@ __global__ __launch_bounds__(256) void gemv_q4_rows_lds_kernel(QGemmArgs qa, con
         }
     }
 }
+
+
+// The q/k/v projection of a Llama decode step (orpheus/model.cpp:194-221) with ggml_rope_ext (NeoX pairs i, i + 64 of a 128-wide head,
+// frequency factors) and the K/V cache append in the epilogue: gemv_q4_rows_lds_kernel with a wave owning features i and i + 64 of one head,
+// so that lane 0 holds a rotation pair once the wave sums are done — the arithmetic of llama_rope_kv_kernel (iterated theta, cosf / sinf),
+// one launch less per layer.  q goes to `out` (the attention kernels read it there), rotated k and plain v go straight to the cache rows
+// of pos[r].
+struct RopeEpi {
+    const uint32_t *pos;   // [R]
+    const float *ff;       // [64] frequency factors or NULL
+    float theta_scale;
+    int NH, NKV;
+    float *kcache, *vcache;   // this layer: [n_ctx][NKV * 128]
+};
+template <int NR>
+__global__ __launch_bounds__(256) void gemv_q4_qkv_rope_kernel(QGemmArgs qa, const uint8_t *w4, RopeEpi re) {
+    extern __shared__ __attribute__((aligned(16))) char gq_sm[];
+    const GemmArgs &a = qa.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, nb = K >> 5, R = a.R;
+    int8_t *sx = (int8_t *) gq_sm;
+    float *sd = (float *) (gq_sm + (size_t) R * K);
+    for (int i = tid; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
+    for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
+    __syncthreads();
+    const int p = (int) blockIdx.x * 4 + wave;      // rotation pair
+    if (p * 2 >= a.N) return;
+    const int head = p >> 6, i = p & 63;
+    const int nf[2] = {head * 128 + i, head * 128 + i + 64};
+    float acc[2][NR];
+#pragma unroll
+    for (int f = 0; f < 2; f++)
+#pragma unroll
+        for (int r = 0; r < NR; r++) acc[f][r] = 0.0f;
+#pragma unroll 2
+    for (int b = lane; b < nb; b += 64) {
+        int4v wn[2];
+        float dw[2];
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            wn[f] = *(const int4v *) (w4 + (int64_t) nf[f] * (K >> 1) + b * 16);
+            dw[f] = (float) qa.wd[(int64_t) nf[f] * nb + b];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            if (r < R) {
+                const int4v x0 = *(const int4v *) (sx + (size_t) r * K + b * 32), x1 = *(const int4v *) (sx + (size_t) r * K + b * 32 + 16);
+                const float da = sd[r * nb + b];
+                int sxs = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    sxs = __builtin_amdgcn_sdot4(0x01010101, x0[e], sxs, false);
+                    sxs = __builtin_amdgcn_sdot4(0x01010101, x1[e], sxs, false);
+                }
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    int s = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int lo = wn[f][e] & 0x0F0F0F0F, hi = (wn[f][e] >> 4) & 0x0F0F0F0F;
+                        s = __builtin_amdgcn_sdot4(lo, x0[e], s, false);
+                        s = __builtin_amdgcn_sdot4(hi, x1[e], s, false);
+                    }
+                    acc[f][r] += (float) (s - 8 * sxs) * (dw[f] * da);
+                }
+            }
+        }
+    }
+    const int kvH = re.NKV * 128;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        if (r < R) {
+            const float x0 = wave_sum(acc[0][r]), x1 = wave_sum(acc[1][r]);
+            if (lane == 0) {
+                const uint32_t ps = re.pos[r];
+                if (head < re.NH + re.NKV) {
+                    float theta = (float) ps;
+                    for (int j = 0; j < i; j++) theta *= re.theta_scale;
+                    const float ang = theta / (re.ff ? re.ff[i] : 1.0f);
+                    const float cs = cosf(ang), sn = sinf(ang);
+                    const float y0 = x0 * cs - x1 * sn, y1 = x0 * sn + x1 * cs;
+                    if (head < re.NH) {
+                        float *o = a.out + (int64_t) r * a.ldo + nf[0];
+                        o[0] = y0; o[64] = y1;
+                    } else {
+                        float *kc = re.kcache + (int64_t) ps * kvH + (head - re.NH) * 128 + i;
+                        kc[0] = y0; kc[64] = y1;
+                    }
+                } else {
+                    float *vd = re.vcache + (int64_t) ps * kvH + (head - re.NH - re.NKV) * 128 + i;
+                    vd[0] = x0; vd[64] = x1;
+                }
+            }
+        }
+    }
+}

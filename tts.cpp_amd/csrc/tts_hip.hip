@@ -206,6 +206,7 @@ struct tts_hip_ctx {
     int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
     bool q4_native = false;     // TTS_HIP_Q4_NATIVE (with TTS_HIP_GEMV_ROWS; default on for Orpheus contexts): Q4_0 matrices are read as 4-bit codes
     std::vector<void *> q4_bufs;
+    bool q4_rope = true;        // TTS_HIP_Q4_ROPE=0: the Llama q/k/v projection keeps its separate rope + cache-append launch
     bool q4_lds = true;         // TTS_HIP_Q4_LDS=0: Q4_0 row products stay on gemv_q4_rows_kernel (one feature per wave, activations from L2)
     bool gemv_stream = true;    // TTS_HIP_GEMV_STREAM=0: <= 16-row F16 GEMMs of the Dia step stay on gemm16_kernel (gemv_stream_kernels.h otherwise)
     bool llama_graph = false;   // TTS_HIP_LLAMA_GRAPH (default on for Orpheus contexts): the greedy step as one captured graph
@@ -414,6 +415,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_LLAMA_GRAPH")) c->llama_graph = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_GEMV_STREAM")) c->gemv_stream = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_Q4_LDS")) c->q4_lds = atoi(e) != 0;
+    if (const char *e = getenv("TTS_HIP_Q4_ROPE")) c->q4_rope = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_Q4_NATIVE")) c->q4_native = atoi(e) != 0;
     return c;
 }
@@ -2947,10 +2949,22 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
         const auto &y = c->l_layers[l];
         float *kc = c->l_kc + (size_t) l * NCTX * c->l_kvH, *vc = c->l_vc + (size_t) l * NCTX * c->l_kvH;
         CHK(rms(y.in_norm, n, c->l_x, c->l_xn, &y.qkv));
-        CHK(llama_gemm(c, y.qkv, c->l_xn, H, c->l_qkv, QKV, n, EPI_STORE));
-        hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH + NKV), dim3(64), 0, c->stream, c->l_qkv, (const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, HD, kc, vc,
-                           (const uint32_t *) nullptr, (int64_t) 0);
-        HIPCHK(hipGetLastError());
+        const size_t qkv_lds = (size_t) n * H + (size_t) n * (H / 32) * 4;
+        if (c->q4_rope && c->q4_lds && y.qkv.q4 && q_for(y.qkv, n) && c->aq_src == c->l_xn && HD == 128 && H % 512 == 0 && qkv_lds <= 64 * 1024 && !c->prof) {
+            // the projection, the rope of q and k and the cache append in one launch (gemv_q4_qkv_rope_kernel)
+            QGemmArgs qa{};
+            qa.g.W = c->arena + y.qkv.off; qa.g.K = H; qa.g.N = QKV; qa.g.R = n; qa.g.out = c->l_qkv; qa.g.ldo = QKV;
+            qa.wd = (const _Float16 *) (c->arena + y.qkv.soff); qa.aq = c->aq; qa.ad = c->ad;
+            RopeEpi re{(const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, kc, vc};
+            hipLaunchKernelGGL(gemv_q4_qkv_rope_kernel<4>, dim3((QKV / 2 + 3) / 4), dim3(256), qkv_lds, c->stream, qa, y.qkv.q4, re);
+            HIPCHK(hipGetLastError());
+            c->aq_src = nullptr;
+        } else {
+            CHK(llama_gemm(c, y.qkv, c->l_xn, H, c->l_qkv, QKV, n, EPI_STORE));
+            hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH + NKV), dim3(64), 0, c->stream, c->l_qkv, (const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, HD, kc, vc,
+                               (const uint32_t *) nullptr, (int64_t) 0);
+            HIPCHK(hipGetLastError());
+        }
         CHK(launch_attn_gqa(c, NH, n, (int) (attn_positions ? (uint32_t) attn_positions : pos0 + n), (const float *) c->l_qkv, QKV, (const uint32_t *) c->l_pos,
                             (const float *) kc, (const float *) vc, NKV, 1.0f / sqrtf((float) HD), c->l_att, nullptr, nullptr, nullptr, (int64_t) 0, attn_positions != 0,
                             q_for(y.o, n)));
