@@ -9,7 +9,7 @@ from tts_cpp_amd import gguf, hip, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 cfg = synth.parler_mini(weight_type=gguf.F16)
 model = synth.build(cfg)
-eng = hip.HipEngine(cfg, device=0, max_seqs=1, kv_type=gguf.F32, kv_positions=min(cfg.ctx, cfg.max_gen))
+eng = hip.HipEngine(cfg, device=0, max_seqs=1, kv_type=gguf.F32, kv_positions=min(cfg.ctx, cfg.max_gen), flags=hip.FLAG_NO_GRAPH if os.environ.get('B1_NO_GRAPH') else 0)
 eng.load(model)
 prompt = np.random.default_rng(3).integers(3, cfg.prompt_vocab, 16).astype(np.uint32)
 eng.prefill_batch([prompt]); eng.generate_greedy([len(prompt)], 32)
