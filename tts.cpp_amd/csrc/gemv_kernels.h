@@ -181,7 +181,10 @@ __global__ __launch_bounds__(256) void gemv_q4_rows_kernel(QGemmArgs qa, const u
 // L1 path), and one feature per wave leaves one or two 16-byte loads in flight per lane.  Here the Q8_0 activation rows and their
 // scales are staged in LDS once per workgroup, a wave owns FPW consecutive features and requests the codes and scales of all of them
 // for a block column before the first integer dot.
-template <int NR, int FPW>
+// QSRC 1: the activations arrive as fp32 rows (a.A, lda == K) and are Q8_0-quantised while they are staged — ggml's quantize_row_q8_0_ref
+// arithmetic, identical to quant_rows_q8_kernel / q8_block_store (d = amax / 127 kept as fp16, q = roundf(x / d)) — one 32-value block per
+// thread and pass; saves the producer a separate quantisation (the silu * up product of gemv_q4_gateup_silu_kernel feeds the down projection).
+template <int NR, int FPW, int QSRC = 0>
 __global__ __launch_bounds__(256) void gemv_q4_rows_lds_kernel(QGemmArgs qa, const uint8_t *w4, int epi) {
     extern __shared__ __attribute__((aligned(16))) char gq_sm[];
     const GemmArgs &a = qa.g;
@@ -189,8 +192,36 @@ __global__ __launch_bounds__(256) void gemv_q4_rows_lds_kernel(QGemmArgs qa, con
     const int K = a.K, nb = K >> 5, R = a.R;
     int8_t *sx = (int8_t *) gq_sm;                       // [R][K]
     float *sd = (float *) (gq_sm + (size_t) R * K);      // [R][nb]
-    for (int i = tid; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
-    for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
+    if (QSRC == 0) {
+        for (int i = tid; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
+        for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
+    } else {
+        for (int i = tid; i < R * nb; i += 256) {
+            const int r = i / nb, b = i - r * nb;
+            const float4v *src = (const float4v *) ((const float *) a.A + (int64_t) r * a.lda + b * 32);
+            float4v v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = src[j];
+            float amax = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) amax = fmaxf(amax, fabsf(v[j][e]));
+            const float dd = amax / 127.0f;
+            const float id = dd ? 1.0f / dd : 0.0f;
+            int4v q[2];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                unsigned pk = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) pk |= ((unsigned) (int) (int8_t) roundf(v[j][e] * id) & 0xFFu) << (8 * e);
+                q[j >> 2][j & 3] = (int) pk;
+            }
+            *(int4v *) (sx + (size_t) r * K + b * 32) = q[0];
+            *(int4v *) (sx + (size_t) r * K + b * 32 + 16) = q[1];
+            sd[i] = (float) (_Float16) dd;
+        }
+    }
     __syncthreads();
     const int n0 = ((int) blockIdx.x * 4 + wave) * FPW;
     if (n0 >= a.N) return;
@@ -342,6 +373,77 @@ __global__ __launch_bounds__(256) void gemv_q4_qkv_rope_kernel(QGemmArgs qa, con
                     float *vd = re.vcache + (int64_t) ps * kvH + (head - re.NH - re.NKV) * 128 + i;
                     vd[0] = x0; vd[64] = x1;
                 }
+            }
+        }
+    }
+}
+
+
+// gate and up projections of a Llama FFN with silu(gate) * up in the epilogue (orpheus/model.cpp:274-279): gemv_q4_rows_lds_kernel with a
+// wave owning rows i, i + 1 of gate and rows F + i, F + i + 1 of up (the stacked [gate; up] matrix), so that lane 0 holds both factors of
+// two outputs once the wave sums are done; g [R][F] fp32 goes to the down projection, which quantises it while staging (QSRC 1) —
+// silu_mul_kernel's arithmetic, one launch less per layer.
+template <int NR>
+__global__ __launch_bounds__(256) void gemv_q4_gateup_silu_kernel(QGemmArgs qa, const uint8_t *w4, int F, float *gout) {
+    extern __shared__ __attribute__((aligned(16))) char gq_sm[];
+    const GemmArgs &a = qa.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, nb = K >> 5, R = a.R;
+    int8_t *sx = (int8_t *) gq_sm;
+    float *sd = (float *) (gq_sm + (size_t) R * K);
+    for (int i = tid; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
+    for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
+    __syncthreads();
+    const int i0 = ((int) blockIdx.x * 4 + wave) * 2;
+    if (i0 >= F) return;
+    const int i1 = min(i0 + 1, F - 1);
+    const int nf[4] = {i0, i1, F + i0, F + i1};
+    float acc[4][NR];
+#pragma unroll
+    for (int f = 0; f < 4; f++)
+#pragma unroll
+        for (int r = 0; r < NR; r++) acc[f][r] = 0.0f;
+#pragma unroll 2
+    for (int b = lane; b < nb; b += 64) {
+        int4v wn[4];
+        float dw[4];
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            wn[f] = *(const int4v *) (w4 + (int64_t) nf[f] * (K >> 1) + b * 16);
+            dw[f] = (float) qa.wd[(int64_t) nf[f] * nb + b];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            if (r < R) {
+                const int4v x0 = *(const int4v *) (sx + (size_t) r * K + b * 32), x1 = *(const int4v *) (sx + (size_t) r * K + b * 32 + 16);
+                const float da = sd[r * nb + b];
+                int sxs = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    sxs = __builtin_amdgcn_sdot4(0x01010101, x0[e], sxs, false);
+                    sxs = __builtin_amdgcn_sdot4(0x01010101, x1[e], sxs, false);
+                }
+#pragma unroll
+                for (int f = 0; f < 4; f++) {
+                    int s = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int lo = wn[f][e] & 0x0F0F0F0F, hi = (wn[f][e] >> 4) & 0x0F0F0F0F;
+                        s = __builtin_amdgcn_sdot4(lo, x0[e], s, false);
+                        s = __builtin_amdgcn_sdot4(hi, x1[e], s, false);
+                    }
+                    acc[f][r] += (float) (s - 8 * sxs) * (dw[f] * da);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        if (r < R) {
+            const float g0 = wave_sum(acc[0][r]), g1 = wave_sum(acc[1][r]), u0 = wave_sum(acc[2][r]), u1 = wave_sum(acc[3][r]);
+            if (lane == 0) {
+                gout[(int64_t) r * F + i0] = (g0 / (1.0f + expf(-g0))) * u0;
+                if (i0 + 1 < F) gout[(int64_t) r * F + i0 + 1] = (g1 / (1.0f + expf(-g1))) * u1;
             }
         }
     }

@@ -206,6 +206,7 @@ struct tts_hip_ctx {
     int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
     bool q4_native = false;     // TTS_HIP_Q4_NATIVE (with TTS_HIP_GEMV_ROWS; default on for Orpheus contexts): Q4_0 matrices are read as 4-bit codes
     std::vector<void *> q4_bufs;
+    bool q4_silu = true;        // TTS_HIP_Q4_SILU=0: gate|up, silu * up and the down projection stay three launches
     bool q4_rope = true;        // TTS_HIP_Q4_ROPE=0: the Llama q/k/v projection keeps its separate rope + cache-append launch
     bool q4_lds = true;         // TTS_HIP_Q4_LDS=0: Q4_0 row products stay on gemv_q4_rows_kernel (one feature per wave, activations from L2)
     bool gemv_stream = true;    // TTS_HIP_GEMV_STREAM=0: <= 16-row F16 GEMMs of the Dia step stay on gemm16_kernel (gemv_stream_kernels.h otherwise)
@@ -416,6 +417,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_GEMV_STREAM")) c->gemv_stream = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_Q4_LDS")) c->q4_lds = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_Q4_ROPE")) c->q4_rope = atoi(e) != 0;
+    if (const char *e = getenv("TTS_HIP_Q4_SILU")) c->q4_silu = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_Q4_NATIVE")) c->q4_native = atoi(e) != 0;
     return c;
 }
@@ -2970,6 +2972,27 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
                             q_for(y.o, n)));
         CHK(llama_gemm(c, y.o, c->l_att, NH * HD, c->l_x, H, n, EPI_RESID));
         CHK(rms(y.post_norm, n, c->l_x, c->l_xn, &y.gu));
+        const size_t gu_lds = (size_t) n * H + (size_t) n * (H / 32) * 4, dn_lds = (size_t) n * F + (size_t) n * (F / 32) * 4;
+        if (c->q4_silu && c->q4_lds && y.gu.q4 && y.down.q4 && q_for(y.gu, n) && q_for(y.down, n) && c->aq_src == c->l_xn && H % 512 == 0 && F % 512 == 0 &&
+            gu_lds <= 64 * 1024 && dn_lds <= 64 * 1024 && (int) y.gu.N == 2 * F && !c->prof) {
+            // gate | up with silu * up in the epilogue, then the down projection quantising that product while it stages it: two launches
+            // instead of three (gemv_q4_gateup_silu_kernel, gemv_q4_rows_lds_kernel<.., QSRC 1>)
+            QGemmArgs qa{};
+            qa.g.W = c->arena + y.gu.off; qa.g.K = H; qa.g.N = 2 * F; qa.g.R = n;
+            qa.wd = (const _Float16 *) (c->arena + y.gu.soff); qa.aq = c->aq; qa.ad = c->ad;
+            hipLaunchKernelGGL(gemv_q4_gateup_silu_kernel<4>, dim3((F / 2 + 3) / 4), dim3(256), gu_lds, c->stream, qa, y.gu.q4, F, c->l_g);
+            HIPCHK(hipGetLastError());
+            c->aq_src = nullptr;
+            QGemmArgs qd{};
+            qd.g.W = c->arena + y.down.off; qd.g.K = F; qd.g.N = H; qd.g.R = n; qd.g.A = c->l_g; qd.g.lda = F; qd.g.out = c->l_x; qd.g.ldo = H;
+            qd.wd = (const _Float16 *) (c->arena + y.down.soff);
+            static std::atomic<uint64_t> attr{0};
+            if (attr_needed(attr, c->device))
+                HIPCHK(hipFuncSetAttribute((const void *) gemv_q4_rows_lds_kernel<4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 2, 1>), dim3((H + 7) / 8), dim3(256), dn_lds, c->stream, qd, y.down.q4, (int) EPI_RESID);
+            HIPCHK(hipGetLastError());
+            continue;
+        }
         CHK(llama_gemm(c, y.gu, c->l_xn, H, c->l_gu, 2 * F, n, EPI_STORE));
         const int ks = (c->gemv_rows && n <= 4) ? 1 : c->l_ksplit;   // the streaming kernels walk all of K themselves
         const bool qd = ks == 1 && q_for(y.down, n);
