@@ -288,6 +288,43 @@ __global__ __launch_bounds__(256) void gemv_q4_rows_lds_kernel(QGemmArgs qa, con
 // so that lane 0 holds a rotation pair once the wave sums are done — the arithmetic of llama_rope_kv_kernel (iterated theta, cosf / sinf),
 // one launch less per layer.  q goes to `out` (the attention kernels read it there), rotated k and plain v go straight to the cache rows
 // of pos[r].
+// Staging variant for the two projections that follow an rms norm (orpheus/model.cpp:122-125): the workgroup normalises the R rows itself —
+// rms_fold_rows_kernel's arithmetic to the letter (thread t holds elements t + 256 k, per-thread sums, wave sums, (w0 + w1) + (w2 + w3),
+// o = x * scale * weight, Q8_0 blocks by q8_block_store) — and leaves the Q8_0 rows in LDS: the norm needs no launch of its own, at the price
+// of every workgroup reading the 12 KB row and its weight from L2.
+struct RmsSrc {
+    const float *x;   // [R][H] the residual stream
+    const float *w;   // [H]
+    float eps;
+};
+__device__ __forceinline__ void stage_rms_q8(const RmsSrc &rs, int R, int H, int8_t *sx, float *sd, float *red) {
+    const int tid = threadIdx.x;
+    for (int r = 0; r < R; r++) {
+        const float *xr = rs.x + (int64_t) r * H;
+        float v[16], wv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = tid + k * 256;
+            if (i < H) { v[k] = xr[i]; wv[k] = rs.w[i]; }
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (tid + k * 256 < H) s += v[k] * v[k];
+        s = wave_sum(s);
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        s = (red[0] + red[1]) + (red[2] + red[3]);
+        const float scale = 1.0f / sqrtf(s / (float) H + rs.eps);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = tid + k * 256;
+            if (i < H) q8_block_store(v[k] * scale * wv[k], (int64_t) r * H + i, sx, sd);
+        }
+        __syncthreads();   // red is reused by the next row; the blocks are visible
+    }
+}
+
 struct RopeEpi {
     const uint32_t *pos;   // [R]
     const float *ff;       // [64] frequency factors or NULL
@@ -295,17 +332,21 @@ struct RopeEpi {
     int NH, NKV;
     float *kcache, *vcache;   // this layer: [n_ctx][NKV * 128]
 };
-template <int NR>
-__global__ __launch_bounds__(256) void gemv_q4_qkv_rope_kernel(QGemmArgs qa, const uint8_t *w4, RopeEpi re) {
+template <int NR, int QSRC = 0>
+__global__ __launch_bounds__(256) void gemv_q4_qkv_rope_kernel(QGemmArgs qa, const uint8_t *w4, RopeEpi re, RmsSrc rs = RmsSrc{}) {
     extern __shared__ __attribute__((aligned(16))) char gq_sm[];
     const GemmArgs &a = qa.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, nb = K >> 5, R = a.R;
     int8_t *sx = (int8_t *) gq_sm;
     float *sd = (float *) (gq_sm + (size_t) R * K);
-    for (int i = tid; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
-    for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
-    __syncthreads();
+    if (QSRC == 2) {
+        stage_rms_q8(rs, R, K, sx, sd, sd + (size_t) R * nb);
+    } else {
+        for (int i = tid; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
+        for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
+        __syncthreads();
+    }
     const int p = (int) blockIdx.x * 4 + wave;      // rotation pair
     if (p * 2 >= a.N) return;
     const int head = p >> 6, i = p & 63;
@@ -383,17 +424,21 @@ __global__ __launch_bounds__(256) void gemv_q4_qkv_rope_kernel(QGemmArgs qa, con
 // wave owning rows i, i + 1 of gate and rows F + i, F + i + 1 of up (the stacked [gate; up] matrix), so that lane 0 holds both factors of
 // two outputs once the wave sums are done; g [R][F] fp32 goes to the down projection, which quantises it while staging (QSRC 1) —
 // silu_mul_kernel's arithmetic, one launch less per layer.
-template <int NR>
-__global__ __launch_bounds__(256) void gemv_q4_gateup_silu_kernel(QGemmArgs qa, const uint8_t *w4, int F, float *gout) {
+template <int NR, int QSRC = 0>
+__global__ __launch_bounds__(256) void gemv_q4_gateup_silu_kernel(QGemmArgs qa, const uint8_t *w4, int F, float *gout, RmsSrc rs = RmsSrc{}) {
     extern __shared__ __attribute__((aligned(16))) char gq_sm[];
     const GemmArgs &a = qa.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, nb = K >> 5, R = a.R;
     int8_t *sx = (int8_t *) gq_sm;
     float *sd = (float *) (gq_sm + (size_t) R * K);
-    for (int i = tid; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
-    for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
-    __syncthreads();
+    if (QSRC == 2) {
+        stage_rms_q8(rs, R, K, sx, sd, sd + (size_t) R * nb);
+    } else {
+        for (int i = tid; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
+        for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
+        __syncthreads();
+    }
     const int i0 = ((int) blockIdx.x * 4 + wave) * 2;
     if (i0 >= F) return;
     const int i1 = min(i0 + 1, F - 1);

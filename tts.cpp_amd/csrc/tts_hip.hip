@@ -206,6 +206,7 @@ struct tts_hip_ctx {
     int q_fuse_max = 16;        // rows up to which the integer GEMM quantises its own activations
     bool q4_native = false;     // TTS_HIP_Q4_NATIVE (with TTS_HIP_GEMV_ROWS; default on for Orpheus contexts): Q4_0 matrices are read as 4-bit codes
     std::vector<void *> q4_bufs;
+    bool q4_rms = true;         // TTS_HIP_Q4_RMS=0: the rms norms in front of the q/k/v and gate|up projections keep their own launches
     bool q4_silu = true;        // TTS_HIP_Q4_SILU=0: gate|up, silu * up and the down projection stay three launches
     bool q4_rope = true;        // TTS_HIP_Q4_ROPE=0: the Llama q/k/v projection keeps its separate rope + cache-append launch
     bool q4_lds = true;         // TTS_HIP_Q4_LDS=0: Q4_0 row products stay on gemv_q4_rows_kernel (one feature per wave, activations from L2)
@@ -418,6 +419,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_Q4_LDS")) c->q4_lds = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_Q4_ROPE")) c->q4_rope = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_Q4_SILU")) c->q4_silu = atoi(e) != 0;
+    if (const char *e = getenv("TTS_HIP_Q4_RMS")) c->q4_rms = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_Q4_NATIVE")) c->q4_native = atoi(e) != 0;
     return c;
 }
@@ -2950,9 +2952,21 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
     for (int l = 0; l < c->L; l++) {
         const auto &y = c->l_layers[l];
         float *kc = c->l_kc + (size_t) l * NCTX * c->l_kvH, *vc = c->l_vc + (size_t) l * NCTX * c->l_kvH;
-        CHK(rms(y.in_norm, n, c->l_x, c->l_xn, &y.qkv));
         const size_t qkv_lds = (size_t) n * H + (size_t) n * (H / 32) * 4;
-        if (c->q4_rope && c->q4_lds && y.qkv.q4 && q_for(y.qkv, n) && c->aq_src == c->l_xn && HD == 128 && H % 512 == 0 && qkv_lds <= 64 * 1024 && !c->prof) {
+        const bool qkv_fused = c->q4_rope && c->q4_lds && y.qkv.q4 && q_for(y.qkv, n) && HD == 128 && H % 512 == 0 && qkv_lds <= 64 * 1024 && !c->prof;
+        // the rms norm inside the consuming projection's staging (stage_rms_q8): no slabs may be pending, the row is held in registers
+        const bool rms_fused = c->q4_rms && !c->l_pending && H <= 4096;
+        if (qkv_fused && rms_fused) {
+            QGemmArgs qa{};
+            qa.g.W = c->arena + y.qkv.off; qa.g.K = H; qa.g.N = QKV; qa.g.R = n; qa.g.out = c->l_qkv; qa.g.ldo = QKV;
+            qa.wd = (const _Float16 *) (c->arena + y.qkv.soff);
+            RopeEpi re{(const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, kc, vc};
+            RmsSrc rs{c->l_x, f32(y.in_norm), 1e-5f};
+            hipLaunchKernelGGL((gemv_q4_qkv_rope_kernel<4, 2>), dim3((QKV / 2 + 3) / 4), dim3(256), qkv_lds + 16, c->stream, qa, y.qkv.q4, re, rs);
+            HIPCHK(hipGetLastError());
+            c->aq_src = nullptr;
+        } else if (qkv_fused) {
+            CHK(rms(y.in_norm, n, c->l_x, c->l_xn, &y.qkv));
             // the projection, the rope of q and k and the cache append in one launch (gemv_q4_qkv_rope_kernel)
             QGemmArgs qa{};
             qa.g.W = c->arena + y.qkv.off; qa.g.K = H; qa.g.N = QKV; qa.g.R = n; qa.g.out = c->l_qkv; qa.g.ldo = QKV;
@@ -2962,6 +2976,7 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
             HIPCHK(hipGetLastError());
             c->aq_src = nullptr;
         } else {
+            CHK(rms(y.in_norm, n, c->l_x, c->l_xn, &y.qkv));
             CHK(llama_gemm(c, y.qkv, c->l_xn, H, c->l_qkv, QKV, n, EPI_STORE));
             hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH + NKV), dim3(64), 0, c->stream, c->l_qkv, (const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, HD, kc, vc,
                                (const uint32_t *) nullptr, (int64_t) 0);
@@ -2971,16 +2986,22 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
                             (const float *) kc, (const float *) vc, NKV, 1.0f / sqrtf((float) HD), c->l_att, nullptr, nullptr, nullptr, (int64_t) 0, attn_positions != 0,
                             q_for(y.o, n)));
         CHK(llama_gemm(c, y.o, c->l_att, NH * HD, c->l_x, H, n, EPI_RESID));
-        CHK(rms(y.post_norm, n, c->l_x, c->l_xn, &y.gu));
         const size_t gu_lds = (size_t) n * H + (size_t) n * (H / 32) * 4, dn_lds = (size_t) n * F + (size_t) n * (F / 32) * 4;
-        if (c->q4_silu && c->q4_lds && y.gu.q4 && y.down.q4 && q_for(y.gu, n) && q_for(y.down, n) && c->aq_src == c->l_xn && H % 512 == 0 && F % 512 == 0 &&
-            gu_lds <= 64 * 1024 && dn_lds <= 64 * 1024 && (int) y.gu.N == 2 * F && !c->prof) {
+        const bool gu_fused = c->q4_silu && c->q4_lds && y.gu.q4 && y.down.q4 && q_for(y.gu, n) && q_for(y.down, n) && H % 512 == 0 && F % 512 == 0 &&
+                              gu_lds <= 64 * 1024 && dn_lds <= 64 * 1024 && (int) y.gu.N == 2 * F && !c->prof;
+        if (!(gu_fused && rms_fused)) CHK(rms(y.post_norm, n, c->l_x, c->l_xn, &y.gu));
+        if (gu_fused) {
             // gate | up with silu * up in the epilogue, then the down projection quantising that product while it stages it: two launches
             // instead of three (gemv_q4_gateup_silu_kernel, gemv_q4_rows_lds_kernel<.., QSRC 1>)
             QGemmArgs qa{};
             qa.g.W = c->arena + y.gu.off; qa.g.K = H; qa.g.N = 2 * F; qa.g.R = n;
             qa.wd = (const _Float16 *) (c->arena + y.gu.soff); qa.aq = c->aq; qa.ad = c->ad;
-            hipLaunchKernelGGL(gemv_q4_gateup_silu_kernel<4>, dim3((F / 2 + 3) / 4), dim3(256), gu_lds, c->stream, qa, y.gu.q4, F, c->l_g);
+            if (rms_fused) {
+                RmsSrc rs{c->l_x, f32(y.post_norm), 1e-5f};
+                hipLaunchKernelGGL((gemv_q4_gateup_silu_kernel<4, 2>), dim3((F / 2 + 3) / 4), dim3(256), gu_lds + 16, c->stream, qa, y.gu.q4, F, c->l_g, rs);
+            } else {
+                hipLaunchKernelGGL(gemv_q4_gateup_silu_kernel<4>, dim3((F / 2 + 3) / 4), dim3(256), gu_lds, c->stream, qa, y.gu.q4, F, c->l_g);
+            }
             HIPCHK(hipGetLastError());
             c->aq_src = nullptr;
             QGemmArgs qd{};
