@@ -87,6 +87,24 @@ def test_orpheus_3b_layer_shapes(wtype, tol):
     eng.close()
 
 
+def test_orpheus_3b_shapes_few_row_calls_take_the_fused_projections():
+    """decode() calls of 2-4 tokens at the 3B widths (Q4_0): every row has its own position in the fused launches — rms norm inside the
+    staging, q/k/v + rope + cache append, gate|up + silu, down with on-the-fly Q8_0 — and the cache rows they append are read by the next
+    call; against the oracle fed the same pieces"""
+    model = synth.build_orpheus(synth.orpheus_3b(layers=2, vocab=5001, ctx=64, weight_type=gguf.Q4_0))
+    eng = hip.OrpheusEngine(model.cfg)
+    eng.load(model)
+    o = orc.OrpheusOracle(model, act_mode=1)
+    ids = np.random.default_rng(4).integers(0, 5001, 9).astype(np.uint32)
+    pos = 0
+    for piece in (ids[:3], ids[3:7], ids[7:9]):
+        lg, _ = eng.decode(piece, pos)
+        ref = o.decode(piece, pos)
+        assert relerr(lg, ref) < 3e-2, pos
+        pos += len(piece)
+    eng.close()
+
+
 def test_orpheus_runner_generates_through_both_contexts(tmp_path):
     """runner_from_file on an Orpheus GGUF (orpheus.* + snac.* + byte-pair vocabulary): prompt framing (model.cpp:341-356),
     greedy generate_from_batch (:378-392), 7 ids -> 3 SNAC levels (:358-376), SNAC decode — equal to the oracle pipeline."""
