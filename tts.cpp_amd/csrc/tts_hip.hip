@@ -3753,7 +3753,7 @@ struct KRun {
     template <int KT, int CI_T>
     bool conv_mfma(const float *x, int cin, int64_t L, const float *wt, const float *b, int cout, int pad, int dil, float *y, int acc) {
         const size_t w_off = (size_t) ((const char *) wt - c->arena);
-        const int CO_T = cout % 128 == 0 ? 128 : 64;
+        const int CO_T = cout % 128 == 0 ? 128 : 64;   // other widths (conv_post: 22 channels): 64-channel tiles, zero-padded weights, stores masked
         if (c->packed.find(w_off) == c->packed.end() && pack_one(c, w_off, cout, cin, KT, CO_T, CI_T, false) != 0) { err = tts_hip_last_error(); return true; }
         ConvArgs a{};
         a.x = x; a.w = c->packed[w_off]; a.b = b; a.alpha = nullptr; a.alpha_out = nullptr; a.resid = acc ? y : nullptr; a.y = y;
@@ -3766,7 +3766,8 @@ struct KRun {
                 int acc, float post) {
         if (!x || !wt || !y) return;
         const bool same = stride == 1 && !in_shift && Lout == L && pad * 2 == dil * (K - 1) && post == 1.0f && dil <= 9;
-        if (same && c->kk_mfma && cout % 64 == 0 && cin >= 16 && L < (1 << 30) && (const char *) wt >= c->arena && (const char *) wt < c->arena + c->arena_bytes) {
+        if (same && c->kk_mfma && cout >= 16 && cin >= 16 && L < (1 << 30) && (const char *) wt >= c->arena && (const char *) wt < c->arena + c->arena_bytes) {
+            if (K == 1 && (L & 3) == 0 && (((uintptr_t) x | (uintptr_t) y) & 15) == 0 && conv_mfma<1, 16>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;   // k = 1 stages 16-byte pieces
             if (K == 3 && conv_mfma<3, 8>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
             if (K == 5 && conv_mfma<5, 4>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
             if (K == 7 && conv_mfma<7, 4>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
