@@ -388,6 +388,64 @@ __global__ void kk_conv1d_kernel(const float *x, int cin, int64_t L, const float
     y[i] = v * post_scale;
 }
 
+// The k = 1 convolutions kk_conv1d_kernel was left with (the shortcuts of the AdaIN residual blocks: 1090 -> 1024 channels, optionally through
+// the nearest-neighbour 2x input, accumulated into the block's output and scaled by 1/sqrt 2; row lengths that are no multiple of 4) as a
+// 64-channel x 64-position tile GEMM on the exact-fp32 matrix pipe: y[co][t] = ((y[co][t] +) b[co] + sum_ci w[co][ci] x[ci][t >> in_shift]) * post.
+// A = w (transposed into LDS as [ci][co]), B = x rows as they lie ([ci][t]); any cin, scalar loads (nothing here is 16-byte aligned).
+__global__ __launch_bounds__(256) void kk_conv1x1_mfma_kernel(const float *x, int cin, int64_t L, const float *w, const float *b, int cout, int in_shift, float *y, int64_t Lout,
+                                                              int accumulate, float post_scale) {
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    constexpr int KC = 16, LD = 68;
+    __shared__ float ws[2][KC][LD], xs[2][KC][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 1, wn = wv & 1;
+    const int co0 = blockIdx.y * 64;
+    const int64_t t0 = (int64_t) blockIdx.x * 64;
+    const int wi = tid >> 2, wk = (tid & 3) * 4;      // weights: channel wi, slice columns wk..wk+3
+    const int xk = tid >> 4, xt = (tid & 15) * 4;     // input: slice row xk, positions xt..xt+3
+    const bool wok = co0 + wi < cout;
+    float wa[4], xa[4];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int ci = c * KC + wk + e;
+            wa[e] = (wok && ci < cin) ? w[(int64_t) (co0 + wi) * cin + ci] : 0.0f;
+        }
+        const int cix = c * KC + xk;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int64_t t = t0 + xt + e;
+            xa[e] = (cix < cin && t < Lout) ? x[(int64_t) cix * L + (in_shift ? t >> 1 : t)] : 0.0f;
+        }
+    };
+    fetch(0);
+    f16v acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+    const int nc = (cin + KC - 1) / KC;
+    for (int c = 0; c < nc; c++) {
+        const int buf = c & 1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { ws[buf][wk + e][wi] = wa[e]; xs[buf][xk][xt + e] = xa[e]; }
+        if (c + 1 < nc) fetch(c + 1);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[buf][kk + hi][wm * 32 + l31], xs[buf][kk + hi][wn * 32 + l31], acc, 0, 0, 0);
+    }
+    const int64_t t = t0 + wn * 32 + l31;
+    if (t >= Lout) return;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int co = co0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        if (co >= cout) continue;
+        float *p = y + (int64_t) co * Lout + t;
+        float v = acc[e] + (b ? b[co] : 0.0f);
+        if (accumulate) v = *p + v;
+        *p = v * post_scale;
+    }
+}
+
 // dense ConvTranspose1d, weight [Cin][Cout][K]: y[co][to] = b[co] + sum over (ci, ti, k) with ti * stride + k - pad == to
 __global__ void kk_convt1d_kernel(const float *x, int cin, int64_t L, const float *w, const float *b, int cout, int K, int stride, int pad, float *y, int64_t Lout) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;

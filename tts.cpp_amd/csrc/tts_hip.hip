@@ -3773,6 +3773,11 @@ struct KRun {
             if (K == 7 && conv_mfma<7, 4>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
             if (K == 11 && conv_mfma<11, 4>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
         }
+        if (c->kk_mfma && K == 1 && stride == 1 && pad == 0 && dil == 1 && cin >= 16 && cout >= 16 && Lout == (in_shift ? 2 * L : L)) {
+            // the k = 1 shortcuts (any channel count, nearest-2x input, accumulate + 1/sqrt 2): 64 x 64 tiles on the exact-fp32 matrix pipe
+            hipLaunchKernelGGL(kk_conv1x1_mfma_kernel, dim3((unsigned) ((Lout + 63) / 64), (unsigned) ((cout + 63) / 64)), dim3(256), 0, st, x, cin, L, wt, b, cout, in_shift, y, Lout, acc, post);
+            return;
+        }
         hipLaunchKernelGGL(kk_conv1d_kernel, kgrid((int64_t) cout * Lout), dim3(256), 0, st, x, cin, L, wt, b, cout, K, stride, pad, dil, in_shift, y, Lout, acc, post);
     }
     // build_ada_residual_conv (:88-134): x [cin][L] -> [cout][L or 2L]
