@@ -345,6 +345,48 @@ __global__ __launch_bounds__(256) void kk_adain_kernel(float *x, int64_t L, cons
     }
 }
 
+// The same instance norm for long rows (the generator's AdaIN blocks: 128 channels x 144 721 positions): one workgroup per channel leaves half
+// the chip idle and walks 580 KB three times.  The row is cut into gridDim.y slices; phase 0 writes slice sums, phase 1 the slice sums of
+// (x - mean)^2 with the mean folded from phase 0 in slice order, phase 2 folds both and applies — the two-pass statistics of kk_adain_kernel,
+// summed slice by slice.  part: [2][C][S].
+__global__ __launch_bounds__(256) void kk_adain_split_kernel(float *x, int64_t L, const float *gamma, const float *beta, int act, float slope, const float *alpha, float *part,
+                                                             int phase) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, sl = blockIdx.y, S = gridDim.y, C = gridDim.x, tid = threadIdx.x;
+    const int64_t chunk = ((L + S - 1) / S + 3) & ~(int64_t) 3;
+    const int64_t t_lo = (int64_t) sl * chunk, t_hi = t_lo + chunk < L ? t_lo + chunk : L;
+    float *xr = x + (int64_t) c * L;
+    const float *psum = part + (int64_t) c * S, *pvar = part + (int64_t) C * S + (int64_t) c * S;
+    float mean = 0.0f;
+    if (phase >= 1) {
+        float tot = 0.0f;
+        for (int i = 0; i < S; i++) tot += psum[i];
+        mean = tot / (float) L;
+    }
+    if (phase <= 1) {
+        float s = 0.0f;
+        if (phase == 0) for (int64_t t = t_lo + tid; t < t_hi; t += 256) s += xr[t];
+        else for (int64_t t = t_lo + tid; t < t_hi; t += 256) { const float d = xr[t] - mean; s += d * d; }
+        s = wave_sum(s);
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) part[(int64_t) phase * C * S + (int64_t) c * S + sl] = (red[0] + red[1]) + (red[2] + red[3]);
+        return;
+    }
+    float var = 0.0f;
+    for (int i = 0; i < S; i++) var += pvar[i];
+    const float scale = 1.0f / sqrtf(var / (float) L + 1e-5f);
+    const float g = gamma[c], b = beta[c];
+    const float al = act == 2 ? alpha[c] : 1.0f;
+    for (int64_t t = t_lo + tid; t < t_hi; t += 256) {
+        const float n = (xr[t] - mean) * scale;
+        float o = (n + n * g) + b;
+        if (act == 1) o = o > 0.0f ? o : o * slope;
+        else if (act == 2) { const float sn = sinf(o * al); o = o + (sn * sn) * (1.0f / al); }
+        xr[t] = o;
+    }
+}
+
 __global__ void kk_leaky_kernel(float *x, int64_t n, float slope) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const float v = x[i]; x[i] = v > 0.0f ? v : v * slope; }

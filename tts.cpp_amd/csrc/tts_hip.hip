@@ -3743,6 +3743,14 @@ struct KRun {
         linear(w(gw), w(gb), style, S, 1, S, C, gamma, C);
         linear(w(bw), w(bb), style, S, 1, S, C, beta, C);
         if (!err.empty() || !gamma || !beta) return;
+        if (c->kk_mfma && L >= 8192) {   // long rows: slices over workgroups, three phases (kk_adain_split_kernel)
+            const int S = (int) std::min<int64_t>(32, std::max<int64_t>(2, (int64_t) 2048 / C));
+            float *part = s.f((size_t) 2 * C * S);
+            if (!part) return;
+            for (int phase = 0; phase < 3; phase++)
+                hipLaunchKernelGGL(kk_adain_split_kernel, dim3(C, S), dim3(256), 0, st, x, L, (const float *) gamma, (const float *) beta, act, slope, alpha, part, phase);
+            return;
+        }
         hipLaunchKernelGGL(kk_adain_kernel, dim3(C), dim3(256), 0, st, x, L, (const float *) gamma, (const float *) beta, act, slope, alpha);
     }
     // Stride-1 "same" convolutions with enough channels (the generator's residual blocks k = 3 / 7 / 11 with dilations 1 / 3 / 5, the
