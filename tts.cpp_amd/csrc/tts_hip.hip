@@ -317,6 +317,8 @@ struct tts_hip_ctx {
     std::set<size_t> packed_direct;    // ... of those, the k = 1 weights packed as [cin][cout] for conv1x1_direct_kernel
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
     bool kk_lstm_split = true;  // TTS_HIP_KOKORO_LSTM_SPLIT=0: the bidirectional LSTMs through the one-workgroup-per-direction kernel
+    char *kk_pool = nullptr;    // Kokoro scratch pool (KScratch): grows to the largest call
+    size_t kk_pool_cap = 0, kk_pool_next = 0;
     int *kk_stuck = nullptr;    // set by kk_lstm_split_kernel when a granule never arrives (bounded spin)
     bool kk_mfma = true;        // TTS_HIP_KOKORO_MFMA=0: every Kokoro convolution through the one-thread-per-output kernel
     int dac_group = 64;         // TTS_HIP_DAC_GROUP: utterances per codec pass (16: 451, 32: 458, 64: 461, 128: 460, 384: 462 audio-s/s at 3 x 384)
@@ -436,7 +438,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
     free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms); free_dev(c->l_cand); free_dev(c->l_smp); free_dev(c->d_pen); free_dev(c->d_last); free_dev(c->d_repc);
     free_dev(c->l_x); free_dev(c->l_xn); free_dev(c->l_qkv); free_dev(c->l_att); free_dev(c->l_gu); free_dev(c->l_g); free_dev(c->l_logits); free_dev(c->l_parts);
-    free_dev(c->attn_part); free_dev(c->kk_stuck);
+    free_dev(c->attn_part); free_dev(c->kk_stuck); free_dev(c->kk_pool);
     free_dev(c->l_kc); free_dev(c->l_vc); free_dev(c->l_ids); free_dev(c->l_pos); free_dev(c->l_tok);
     for (void *p : c->q4_bufs) free_dev(p);
     for (float *p : {c->di_ex, c->di_exn, c->di_eqkv, c->di_eatt, c->di_egu, c->di_eg, c->di_ek, c->di_ev, c->di_ckv, c->di_ck, c->di_cv, c->di_k, c->di_v, c->di_x,
@@ -3639,15 +3641,38 @@ extern "C" tts_hip_ctx *tts_hip_kokoro_create(int device, const tts_hip_kokoro_d
 }
 
 namespace {
-// scratch for one call: device buffers released when the call returns
+// scratch for one call: pieces of a context-owned pool that grows to the largest call seen (a synthesis asks for ~100 buffers: one
+// hipMalloc / hipFree pair each cost more host time than the kernels they fed); what does not fit yet is allocated for this call alone
 struct KScratch {
-    std::vector<void *> bufs;
+    tts_hip_ctx *c;
+    size_t off = 0, want = 0;
+    std::vector<void *> extra;
     bool failed = false;
-    ~KScratch() { for (void *p : bufs) (void) hipFree(p); }
+    explicit KScratch(tts_hip_ctx *c_) : c(c_) {
+        if (c->kk_pool_next > c->kk_pool_cap) {
+            (void) hipStreamSynchronize(c->stream);
+            if (c->kk_pool) (void) hipFree(c->kk_pool);
+            c->kk_pool = nullptr; c->kk_pool_cap = 0;
+            const size_t cap = c->kk_pool_next + c->kk_pool_next / 4;
+            if (hipMalloc((void **) &c->kk_pool, cap) == hipSuccess) c->kk_pool_cap = cap;
+        }
+    }
+    ~KScratch() {
+        if (!extra.empty()) (void) hipStreamSynchronize(c->stream);
+        for (void *p : extra) (void) hipFree(p);
+        if (want > c->kk_pool_cap) c->kk_pool_next = std::max(c->kk_pool_next, want);
+    }
     float *f(size_t n) {
+        const size_t bytes = ((n ? n : 1) * sizeof(float) + 255) & ~(size_t) 255;
+        want += bytes;
+        if (c->kk_pool && off + bytes <= c->kk_pool_cap) {
+            float *p = (float *) (c->kk_pool + off);
+            off += bytes;
+            return p;
+        }
         void *p = nullptr;
-        if (hipMalloc(&p, (n ? n : 1) * sizeof(float)) != hipSuccess) { failed = true; return nullptr; }
-        bufs.push_back(p);
+        if (hipMalloc(&p, bytes) != hipSuccess) { failed = true; return nullptr; }
+        extra.push_back(p);
         return (float *) p;
     }
 };
@@ -3875,7 +3900,7 @@ extern "C" int tts_hip_kokoro_durations(tts_hip_ctx *c, const uint32_t *tokens, 
     if (!tokens || !lens_out) return set_err("tts_hip_kokoro_durations: null argument");
     if (n < 3 || n > c->ko.max_ctx) return set_err("tts_hip_kokoro_durations: %u tokens outside 3..%u", n, c->ko.max_ctx);
     HIPCHK(hipSetDevice(c->device));
-    KScratch s;
+    KScratch s(c);
     KRun k(c, s);
     int64_t ne[4];
     const float *tok_embd = k.w("albert.token_embd", ne);
@@ -3950,7 +3975,7 @@ extern "C" int tts_hip_kokoro_generate(tts_hip_ctx *c, const uint32_t *tokens, u
     if (n < 3 || n > c->ko.max_ctx) return set_err("tts_hip_kokoro_generate: %u tokens outside 3..%u", n, c->ko.max_ctx);
     HIPCHK(hipSetDevice(c->device));
     const tts_hip_kokoro_desc &kd = c->ko;
-    KScratch s;
+    KScratch s(c);
     KRun k(c, s);
     int D = 0, S = 0;
     if (kokoro_dims(c, k, D, S) != 0) return set_err("tts_hip_kokoro_generate: %s", k.err.c_str());
