@@ -445,3 +445,33 @@ def test_snake_sine_polynomial_is_libm_accurate():
         err = np.abs(snake_sin(x).astype(np.float64) - ref)
         assert err.max() < 1.5e-7
         assert (err / np.spacing(np.abs(ref).astype(f)).astype(np.float64)).max() < 2.5
+
+
+def test_device_sampler_key_order_restatement():
+    """numpy restatement of smp_key / smp_key_value (csrc/parler_kernels.h, llama_kernels.h): the 64-bit keys the device samplers sort —
+    ~monotone(value) << 32 | index — order candidates by value descending, equal values by index ascending (the total order the tests
+    hold the reference's std::sort to wherever it is specified), -0 and +0 compare equal, and the value field inverts exactly."""
+    rng = np.random.default_rng(5)
+    v = (rng.standard_normal(5000) * 7).astype(np.float32)
+    v[:50] = np.float32([0.0, -0.0] * 25)
+    v[50:60] = v[60:70]                      # exact ties
+    v[70], v[71] = np.float32(np.inf), np.float32(-np.inf)
+    idx = np.arange(v.size, dtype=np.uint64)
+
+    def key(val, i):
+        val = np.where(val == 0.0, np.float32(0.0), val).astype(np.float32)
+        u = val.view(np.uint32).astype(np.uint64)
+        u = np.where(u & 0x80000000, (~u) & 0xFFFFFFFF, u | 0x80000000)
+        return (((~u) & 0xFFFFFFFF) << np.uint64(32)) | i
+
+    def value(k):
+        u = (~(k >> np.uint64(32))) & np.uint64(0xFFFFFFFF)
+        bits = np.where(u & 0x80000000, u & 0x7FFFFFFF, (~u) & 0xFFFFFFFF).astype(np.uint32)
+        return bits.view(np.float32)
+
+    k = key(v, idx)
+    order = np.argsort(k, kind="stable")
+    ref = np.lexsort((idx, -np.where(v == 0.0, np.float32(0.0), v).astype(np.float64)))
+    assert np.array_equal(order, ref)
+    back = value(k)
+    assert np.array_equal(back, np.where(v == 0.0, np.float32(0.0), v))
