@@ -465,39 +465,43 @@ __device__ __forceinline__ void ln_row_regs(float *xr, int H, int lane, const fl
     }
 }
 
+// One kernel per (row width class, slab count): a single kernel that branches over the variants is allocated the registers of the
+// largest one (256 VGPRs + 96 AGPRs: one wave per SIMD, and next to the codec's workgroups a launch waited for two thirds of a
+// SIMD's register file to drain — 29.7 us per launch with three runners against 7.5 alone).  NI: float4 pieces per lane (4: H <= 1024,
+// 8: H <= 2048); NP: slabs folded (-1: any count, looped).
+template <int NI, int NP>
+__global__ __launch_bounds__(256) void ln_rows_t_kernel(float *x, int H, const float *lw, const float *lb, float *y32, _Float16 *y16, int R, const float *parts, int n_parts,
+                                                        int64_t slab_stride) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float *pr = parts ? parts + (int64_t) r * H : nullptr;
+    ln_row_regs<NI, NP>(x + (int64_t) r * H, H, lane, lw, lb, y32 ? y32 + (int64_t) r * H : nullptr, y16 ? y16 + (int64_t) r * H : nullptr, pr, parts ? n_parts : 0, slab_stride);
+}
+
+// any H: three passes over the row
 __global__ __launch_bounds__(256) void ln_rows_kernel(float *x, int H, const float *lw, const float *lb, float *y32,
                                                       _Float16 *y16, int R, const float *parts, int n_parts, int64_t slab_stride) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= R) return;
     float *xr = x + (int64_t) r * H;
-    if (H <= 2048 && (H & 3) == 0) {
-        const float *pr = parts ? parts + (int64_t) r * H : nullptr;
-        float *yr32 = y32 ? y32 + (int64_t) r * H : nullptr;
-        _Float16 *yr16 = y16 ? y16 + (int64_t) r * H : nullptr;
-        const int np = parts ? n_parts : 0;
-        if (H <= 1024) {
-            if (np == 0) ln_row_regs<4, 0>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
-            else if (np == 4) ln_row_regs<4, 4>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
-            else if (np == 2) ln_row_regs<4, 2>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
-            else if (np == 8) ln_row_regs<4, 8>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
-            else ln_row_regs<4, -1>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
-        } else {
-            if (np == 0) ln_row_regs<8, 0>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
-            else ln_row_regs<8, -1>(xr, H, lane, lw, lb, yr32, yr16, pr, np, slab_stride);
-        }
-    } else {
-        float s = 0.0f;
-        for (int k = lane; k < H; k += 64) s += xr[k];
-        const float mean = wave_sum(s) / (float) H;
-        float s2 = 0.0f;
-        for (int k = lane; k < H; k += 64) { const float d = xr[k] - mean; s2 += d * d; }
-        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float) H + LN_EPS);
+    if (parts)
         for (int k = lane; k < H; k += 64) {
-            const float y = (xr[k] - mean) * rstd * lw[k] + lb[k];
-            if (y32) y32[(int64_t) r * H + k] = y;
-            if (y16) y16[(int64_t) r * H + k] = (_Float16) y;
+            float v = xr[k];
+            for (int sp = 0; sp < n_parts; sp++) v += parts[sp * slab_stride + (int64_t) r * H + k];
+            xr[k] = v;
         }
+    float s = 0.0f;
+    for (int k = lane; k < H; k += 64) s += xr[k];
+    const float mean = wave_sum(s) / (float) H;
+    float s2 = 0.0f;
+    for (int k = lane; k < H; k += 64) { const float d = xr[k] - mean; s2 += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float) H + LN_EPS);
+    for (int k = lane; k < H; k += 64) {
+        const float y = (xr[k] - mean) * rstd * lw[k] + lb[k];
+        if (y32) y32[(int64_t) r * H + k] = y;
+        if (y16) y16[(int64_t) r * H + k] = (_Float16) y;
     }
 }
 

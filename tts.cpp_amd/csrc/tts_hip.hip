@@ -1219,6 +1219,30 @@ static void choose_tile(const tts_hip_ctx *c, int R, int N, int K, bool may_spli
 }
 
 // GGUF-quantised matrix: LayerNorm (if any) -> Q8_0-quantise the activation rows -> integer block GEMM
+// LayerNorm of R rows (+ slab fold): the kernel instantiated for this row width and slab count (ln_rows_t_kernel), so that a launch
+// carries the registers of its own variant only
+static void launch_ln_rows(tts_hip_ctx *c, int rows_per_wg, float *x, int H, const float *lw, const float *lb, float *y32, _Float16 *y16, int R, const float *parts, int n_parts,
+                           int64_t slab_stride) {
+    const dim3 grid((unsigned) ((R + rows_per_wg - 1) / rows_per_wg)), block((unsigned) (64 * rows_per_wg));
+    const int np = parts ? n_parts : 0;
+#define LN_CASE(NIv, NPv) hipLaunchKernelGGL((ln_rows_t_kernel<NIv, NPv>), grid, block, 0, c->stream, x, H, lw, lb, y32, y16, R, parts, n_parts, slab_stride)
+    if (H <= 2048 && (H & 3) == 0) {
+        if (H <= 1024) {
+            if (np == 0) LN_CASE(4, 0);
+            else if (np == 4) LN_CASE(4, 4);
+            else if (np == 2) LN_CASE(4, 2);
+            else if (np == 8) LN_CASE(4, 8);
+            else LN_CASE(4, -1);
+        } else {
+            if (np == 0) LN_CASE(8, 0);
+            else LN_CASE(8, -1);
+        }
+    } else {
+        hipLaunchKernelGGL(ln_rows_kernel, grid, block, 0, c->stream, x, H, lw, lb, y32, y16, R, parts, n_parts, slab_stride);
+    }
+#undef LN_CASE
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight-streaming GEMM for <= 16 rows (gemv_stream_kernels.h): K slices -> fp32 slabs the consumer folds
 // ------------------------------------------------------------------------------------------------
@@ -1290,9 +1314,8 @@ static int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro
     const bool fused_ln = pro == PRO_LN && a.R <= std::min(c->ln_fuse_max, 8) && a.K <= 2048 && !c->pending_parts && c->q_fuse_max > 0;
     if (pro == PRO_LN && !fused_ln) {
         CHK(prof_begin(c, TTS_HIP_K_LN, (double) a.R * a.K * 8, 0));
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + c->ln_waves - 1) / c->ln_waves), dim3(64 * c->ln_waves), 0, c->stream, (float *) a.A, a.K,
-                           a.ln_w, a.ln_b, c->dbg, (_Float16 *) nullptr, a.R,
-                           c->pending_parts ? (const float *) c->partials : (const float *) nullptr, c->pending_parts, (int64_t) c->RMAX * c->H);
+        launch_ln_rows(c, c->ln_waves, (float *) a.A, a.K, a.ln_w, a.ln_b, c->dbg, (_Float16 *) nullptr, a.R,
+                       c->pending_parts ? (const float *) c->partials : (const float *) nullptr, c->pending_parts, (int64_t) c->RMAX * c->H);
         HIPCHK(hipGetLastError());
         c->pending_parts = 0;
         CHK(prof_end(c));
@@ -1346,8 +1369,7 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
         GemmArgs b = a;
         if (pro == PRO_LN) {
             CHK(prof_begin(c, TTS_HIP_K_LN, (double) a.R * a.K * 8, 0));
-            hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + 3) / 4), dim3(256), 0, c->stream, (float *) a.A, a.K, a.ln_w, a.ln_b, c->dbg,
-                               (_Float16 *) nullptr, a.R, (const float *) nullptr, 0, (int64_t) 0);
+            launch_ln_rows(c, 4, (float *) a.A, a.K, a.ln_w, a.ln_b, c->dbg, (_Float16 *) nullptr, a.R, (const float *) nullptr, 0, (int64_t) 0);
             HIPCHK(hipGetLastError());
             CHK(prof_end(c));
             b.A = c->dbg;
@@ -1376,10 +1398,8 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
         // many rows: normalise once (one wave per row) instead of once per GEMM workgroup
         const bool h16 = w.type == TTS_HIP_F16;
         CHK(prof_begin(c, TTS_HIP_K_LN, (double) a.R * a.K * (h16 ? 6 : 8), 0));
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((a.R + c->ln_waves - 1) / c->ln_waves), dim3(64 * c->ln_waves), 0, c->stream, (float *) a.A, a.K,
-                           a.ln_w, a.ln_b, h16 ? (float *) nullptr : c->dbg, h16 ? c->xn16 : (_Float16 *) nullptr, a.R,
-                           c->pending_parts ? (const float *) c->partials : (const float *) nullptr, c->pending_parts,
-                           (int64_t) c->RMAX * c->H);
+        launch_ln_rows(c, c->ln_waves, (float *) a.A, a.K, a.ln_w, a.ln_b, h16 ? (float *) nullptr : c->dbg, h16 ? c->xn16 : (_Float16 *) nullptr, a.R,
+                       c->pending_parts ? (const float *) c->partials : (const float *) nullptr, c->pending_parts, (int64_t) c->RMAX * c->H);
         c->pending_parts = 0;
         HIPCHK(hipGetLastError());
         CHK(prof_end(c));
@@ -4314,9 +4334,8 @@ extern "C" int64_t tts_hip_debug_read(tts_hip_ctx *c, const char *what, float *o
     if (w == "hidden") {
         const size_t R = c->host_pos.size();
         if (R == 0 || R * c->H > max_floats) { set_err("debug_read(hidden): no forward yet or buffer too small"); return -1; }
-        hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned) (R + 3) / 4), dim3(256), 0, c->stream, c->x, c->H,
-                           (const float *) (c->arena + c->ln_w), (const float *) (c->arena + c->ln_b), c->dbg, (_Float16 *) nullptr, (int) R,
-                           c->pending_parts ? (const float *) c->partials : (const float *) nullptr, c->pending_parts, (int64_t) c->RMAX * c->H);
+        launch_ln_rows(c, 4, c->x, c->H, (const float *) (c->arena + c->ln_w), (const float *) (c->arena + c->ln_b), c->dbg, (_Float16 *) nullptr, (int) R,
+                       c->pending_parts ? (const float *) c->partials : (const float *) nullptr, c->pending_parts, (int64_t) c->RMAX * c->H);
         c->pending_parts = 0;
         if (hipMemcpyAsync(out, c->dbg, R * c->H * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { set_err("debug_read(hidden): copy failed"); return -1; }
