@@ -680,8 +680,11 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(ConvArgs a) {
 // i.e. S small GEMMs (M = cout, N = ti, K = 2*cin) that share one B operand: per input channel one
 // MFMA k-step whose two k slots are the taps (ti, ti-1).  A wave owns 32*MI channels x 32 ti x S phases.
 // a.w is the PACKED weight; same two-buffer / register-prefetch structure as conv1d_mfma_kernel.
+#ifndef CONVT_MIN_WAVES
+#define CONVT_MIN_WAVES 2   // the stride-8 and stride-4 instantiations came out at 264 / 265 registers: 8 over what lets a second wave onto the SIMD
+#endif
 template <int S, int MI, int WM, int WN, int CI_T>
-__global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma_kernel(ConvTArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, CONVT_MIN_WAVES) void convt1d_mfma_kernel(ConvTArgs a) {
     constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN, NT = 64 * WM * WN, K2 = 2 * S;
     constexpr int WCH = CI_T * K2 * CO_T;
     constexpr int WV = (WCH / 4 + NT - 1) / NT;
@@ -1032,7 +1035,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma16_kernel(ConvArgs a)
 // ConvTranspose1d, phase-decomposed as convt1d_mfma_kernel; one k-step = 16 input channels of one tap slot
 // (slot 0: x[ti] with w[..][phi], slot 1: x[ti-1] with w[..][phi+S]).
 template <int S, int MI, int WM, int WN, int CI_T>
-__global__ __launch_bounds__(64 * WM * WN) void convt1d_mfma16_kernel(ConvTArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, CONVT_MIN_WAVES) void convt1d_mfma16_kernel(ConvTArgs a) {
     constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN, NT = 64 * WM * WN, K2 = 2 * S;
     constexpr int NCG = CI_T / 16, QG = CI_T / 8, XS = CI_T + 8;
     constexpr int WCH = CI_T * K2 * CO_T;

@@ -325,7 +325,7 @@ struct tts_hip_ctx {
     bool dac_conv1_direct = true;   // TTS_HIP_DAC_CONV1_DIRECT=0: the 96- / 192-channel k=1 convs stay on conv1d_mfma_kernel<1,...>
     int dac_pad = 0;            // TTS_HIP_DAC_PAD=1: activation rows at the padded stride of dac_row_stride (measured: no effect, profiles/r02/dac_row_stride.log)
     int dac_variant = 20;       // TTS_HIP_DAC_VARIANT (tuning; 20 = 96-channel class on 128-position tiles, the one variant that measured faster): position-tile variant of the k = 7 conv kernel per channel-tile class
-    int dac_alpha_tab = 1;      // 0: the codec kernels read snake's alpha from memory instead of an LDS table (smaller footprint)
+    int dac_alpha_tab = 1;      // 0: the codec kernels read snake's alpha from memory instead of an LDS table (smaller footprint); 2: table unless it costs a resident workgroup
     int dac_lds_reserve_kb = 0; // LDS the codec kernels leave free per CU for another context's decoder workgroups
     int gemm_rows_per_wg = 0;   // > 0: forwards with more rows split them over workgroups of this many rows (16/32/64)
     int gemm_ngs_max = 16;      // cap on parallel row-group wave sets per GEMM workgroup (LDS = 4 KB x waves x RB)
@@ -404,7 +404,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_KOKORO_MFMA")) c->kk_mfma = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_KOKORO_LSTM_SPLIT")) c->kk_lstm_split = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_DAC_GROUP")) c->dac_group = std::max(1, atoi(e));
-    if (const char *e = getenv("TTS_HIP_DAC_ALPHA_TAB")) c->dac_alpha_tab = atoi(e) != 0;
+    if (const char *e = getenv("TTS_HIP_DAC_ALPHA_TAB")) c->dac_alpha_tab = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
@@ -2495,11 +2495,12 @@ static int ensure_packed(tts_hip_ctx *c) {
 // free on every CU so that another context's decoder workgroups (<= 32 KB) can be resident next to the codec's:
 // the alpha table is dropped when that is what it takes, and the request is padded so that one workgroup fewer fits
 // when the natural size would fill the CU.
-static size_t dac_lds_request(const tts_hip_ctx *c, size_t base, size_t table, int *use_table) {
+static size_t dac_lds_request(const tts_hip_ctx *c, size_t base, size_t table, int *use_table, bool keep_residency = false) {
     const size_t CU = 160 * 1024, reserve = (size_t) c->dac_lds_reserve_kb * 1024;
     *use_table = table ? 1 : 0;
     size_t natural = base + table;
     if (table && !c->dac_alpha_tab) { *use_table = 0; natural = base; }
+    if (table && *use_table && (keep_residency || c->dac_alpha_tab == 2) && CU / (base + table) < CU / base) { *use_table = 0; natural = base; }  // the table would cost a resident workgroup
     if (!reserve) return natural;
     auto leaves = [&](size_t req) { const size_t n = CU / req; return CU - n * req; };
     if (leaves(natural) >= reserve) return natural;
@@ -2553,7 +2554,7 @@ static int launch_convt_mfma16(tts_hip_ctx *c, const ConvTArgs &a_in, int nz) {
     constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN, WCH = CI_T * 2 * S * CO_T, XS = CI_T + 8;
     const int cin_pad = (a_in.cin + CI_T - 1) / CI_T * CI_T;
     ConvTArgs a = a_in;
-    const size_t lds = dac_lds_request(c, ((size_t) 2 * WCH + 2 * (size_t) (TI_T + 1) * XS) * 2, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab);
+    const size_t lds = dac_lds_request(c, ((size_t) 2 * WCH + 2 * (size_t) (TI_T + 1) * XS) * 2, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab, true);
     static std::atomic<uint64_t> attr{0};
     if (attr_needed(attr, c->device)) {
         HIPCHK(hipFuncSetAttribute((const void *) convt1d_mfma16_kernel<S, MI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2662,7 +2663,7 @@ static int launch_convt_mfma(tts_hip_ctx *c, const ConvTArgs &a_in, int nz) {
     constexpr int CO_T = 32 * MI * WM, TI_T = 32 * WN, WCH = CI_T * 2 * S * CO_T;
     const int cin_pad = (a_in.cin + CI_T - 1) / CI_T * CI_T;
     ConvTArgs a = a_in;
-    const size_t lds = dac_lds_request(c, ((size_t) 2 * WCH + 2 * (size_t) ((CI_T * (TI_T + 1) + 3) & ~3)) * 4, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab);
+    const size_t lds = dac_lds_request(c, ((size_t) 2 * WCH + 2 * (size_t) ((CI_T * (TI_T + 1) + 3) & ~3)) * 4, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab, true);   // two resident workgroups matter more to the transposed convs than the table
     static std::atomic<uint64_t> attr{0};
     if (attr_needed(attr, c->device)) {
         HIPCHK(hipFuncSetAttribute((const void *) convt1d_mfma_kernel<S, MI, WM, WN, CI_T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
