@@ -168,3 +168,24 @@ def test_full_size_dac_and_locality(dac_f16):
     assert np.array_equal(a[: 20 * 512], c[: 20 * 512])
     assert not np.array_equal(a[34 * 512: 36 * 512], c[34 * 512: 36 * 512])
     eng.close()
+
+
+def test_full_size_quantizer_embedding_tile_kernel():
+    """9 codebooks x 8 dims -> 1024 channels (dac_embed_tile_kernel): stage 0 against the oracle, and utterances of
+    0 / 1 / 70 / 129 frames in one pass (the kernel works on 64-frame tiles) equal to one decode each."""
+    model = synth.build(synth.parler_mini(layers=1, prompt_vocab=64, ctx=64))
+    cfg = model.cfg
+    eng = dac_engine(cfg, model)
+    rng = np.random.default_rng(9)
+    codes = rng.integers(0, cfg.cb_size, (70, cfg.n_out)).astype(np.uint32)
+    eng.set_debug(True)
+    pcm = eng.dac_decode(codes)
+    eng.set_debug(False)
+    _, st0 = orc.DacOracle(model).decode(codes, stage=0)
+    assert relerr(eng.debug_read("dac:0", st0.size).reshape(st0.shape), st0) < 1e-6
+    ragged = [rng.integers(0, cfg.cb_size, (f, cfg.n_out)).astype(np.uint32) for f in (1, 129, 0)] + [codes]
+    batch = eng.dac_decode_batch(ragged)
+    assert np.array_equal(batch[3], pcm)
+    for c, out in zip(ragged[:3], batch[:3]):
+        assert np.array_equal(out, eng.dac_decode(c))
+    eng.close()

@@ -83,6 +83,52 @@ __global__ void dac_embed_kernel(DacEmbedArgs a) {
     a.out[((int64_t) z * a.latent + c) * a.Tout + t] = total;
 }
 
+// The same sum with the work shaped for the chip: one lane per frame holds the NCB gathered codebook rows (NCB x D
+// registers) and each wave walks EMB_CH output channels, whose projection rows are wave-uniform (scalar loads). The
+// per-thread form above gathers the rows again for every one of the 1024 channels and runs 262 144 single-wave
+// workgroups of two dependent loads each (2.9 ms per 64-utterance pass against ~65 MB written).
+// Same operation order per output: D products summed in order, + bias, codebooks summed in order.
+#define EMB_CH 32
+template <int NCB, int D>
+__global__ __launch_bounds__(256) void dac_embed_tile_kernel(DacEmbedArgs a) {
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), z = blockIdx.z;
+    const int Tz = a.frames ? (int) a.frames[z] : a.T;
+    if (t >= Tz) return;
+    float v[NCB][D];
+#pragma unroll
+    for (int i = 0; i < NCB; i++) {
+        const uint32_t code = a.codes[((int64_t) z * a.T + t) * NCB + i];
+        const float4 *cb = (const float4 *) (a.codebook + ((int64_t) i * a.cb_size + code) * D);
+#pragma unroll
+        for (int q = 0; q < D / 4; q++) {
+            const float4 r = cb[q];
+            v[i][q * 4] = r.x; v[i][q * 4 + 1] = r.y; v[i][q * 4 + 2] = r.z; v[i][q * 4 + 3] = r.w;
+        }
+        if (a.x_f16) {
+#pragma unroll
+            for (int d = 0; d < D; d++) v[i][d] = (float) (_Float16) v[i][d];
+        }
+    }
+    const int c0 = (blockIdx.y * 4 + wv) * EMB_CH;
+#pragma unroll 2
+    for (int cc = 0; cc < EMB_CH; cc++) {
+        const int c = c0 + cc;
+        if (c >= a.latent) break;
+        float total = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NCB; i++) {
+            const float *w = a.proj_w + ((int64_t) i * a.latent + c) * D;
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < D; d++) acc += w[d] * v[i][d];
+            acc += a.proj_b[i * a.latent + c];
+            total = (i == 0) ? acc : (total + acc);
+        }
+        a.out[((int64_t) z * a.latent + c) * a.Tout + t] = total;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // conv1d, stride 1, "same" padding: y[co][t] = b[co] + sum_ci sum_k w[co][ci][k] * f(x[ci][t + k*dil - pad])
 //   f = snake (per input channel alpha) or identity;  epilogue: + residual[co][t], tanh.

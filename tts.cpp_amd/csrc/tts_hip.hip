@@ -2809,7 +2809,10 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
     ea.proj_b = (const float *) (c->arena + c->d_projb); ea.n_cb = c->d_ncb; ea.cb_size = c->d_cbsize; ea.cb_dim = c->d_cbdim;
     ea.latent = c->d_latent; ea.T = L; ea.Tout = LS; ea.out = cur; ea.x_f16 = c->dac_f16 ? 1 : 0;
     CHK(prof_begin(c, TTS_HIP_K_DAC_EMBED, (double) c->d_latent * tot * 4, 2.0 * c->d_latent * tot * c->d_ncb * c->d_cbdim));
-    hipLaunchKernelGGL(dac_embed_kernel, dim3((L + 63) / 64, c->d_latent, n), dim3(64), 0, c->stream, ea);
+    if (c->d_ncb == 9 && c->d_cbdim == 8 && !getenv("TTS_HIP_DAC_EMBED_SIMPLE"))
+        hipLaunchKernelGGL((dac_embed_tile_kernel<9, 8>), dim3((L + 63) / 64, (c->d_latent + 4 * EMB_CH - 1) / (4 * EMB_CH), n), dim3(256), 0, c->stream, ea);
+    else
+        hipLaunchKernelGGL(dac_embed_kernel, dim3((L + 63) / 64, c->d_latent, n), dim3(64), 0, c->stream, ea);
     HIPCHK(hipGetLastError());
     CHK(prof_end(c));
     if (n == 1) CHK(dac_snapshot(c, 0, cur, (size_t) c->d_latent, (size_t) L, (size_t) LS));
