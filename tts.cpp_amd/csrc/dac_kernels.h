@@ -148,6 +148,7 @@ struct ConvArgs {
     const float *alpha_out;  // [cout] snake applied to the OUTPUT (the next layer's snake_1d, fused here), or NULL
     int x_f16;               // F16 conv kernel: inputs are rounded to fp16 on the way in (ggml's fp16 im2col)
     int alpha_tab;           // MFMA kernels: 1 = alpha and 1/alpha of every input channel staged in LDS, 0 = read from memory
+    int prio;                // conv1d_mfma_kernel: 1 = waves raise their issue priority for the MFMA phase of a chunk, 2 = for the staging phase
 };
 
 __device__ __forceinline__ int valid_len(const uint32_t *frames, int mult, int L) {
@@ -470,6 +471,12 @@ __global__ __launch_bounds__(64 * WM * WN, (KT == 7 && MI * NI <= 4) ? CONV7_MIN
     float *yg = a.y + (int64_t) blockIdx.z * a.cout * LS;
     const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * LS : nullptr;
     const float4d *wg = (const float4d *) (a.w + (int64_t) blockIdx.y * n_chunks * WCH);
+    if (a.prio >= 3) {   // experiment: workgroups sharing a SIMD at different static priorities, so that their MFMA phases do not line up
+        const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned pr = (a.prio == 3 ? bid / 256u : bid) % 3u;
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    }
 
     if (a.alpha && a.alpha_tab) {
         for (int i = tid; i < cin_pad; i += NT) {
@@ -567,6 +574,8 @@ __global__ __launch_bounds__(64 * WM * WN, (KT == 7 && MI * NI <= 4) ? CONV7_MIN
         if (c + 1 < n_chunks) prefetch(c + 1);
         const float *ws = wsb + buf * WCH;
         const float *xs = xsb + buf * xsz;
+        if (a.prio == 1) __builtin_amdgcn_s_setprio(2);
+        else if (a.prio == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll 4
         for (int kk = 0; kk < KT * CI_T; kk += 2) {
             const int kq = kk + hi;              // this half-wave's k index
@@ -582,9 +591,12 @@ __global__ __launch_bounds__(64 * WM * WN, (KT == 7 && MI * NI <= 4) ? CONV7_MIN
                 for (int j = 0; j < NI; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        if (a.prio == 1) __builtin_amdgcn_s_setprio(0);
+        else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
         if (c + 1 < n_chunks) commit(c + 1, buf ^ 1);
         __syncthreads();
     }
+    if (a.prio == 1 || a.prio == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int i = 0; i < MI; i++) {
 #pragma unroll

@@ -326,6 +326,7 @@ struct tts_hip_ctx {
     int dac_pad = 0;            // TTS_HIP_DAC_PAD=1: activation rows at the padded stride of dac_row_stride (measured: no effect, profiles/r02/dac_row_stride.log)
     int dac_variant = 20;       // TTS_HIP_DAC_VARIANT (tuning; 20 = 96-channel class on 128-position tiles, the one variant that measured faster): position-tile variant of the k = 7 conv kernel per channel-tile class
     int dac_alpha_tab = 1;      // 0: the codec kernels read snake's alpha from memory instead of an LDS table (smaller footprint); 2: table unless it costs a resident workgroup
+    int dac_prio = 2;           // TTS_HIP_DAC_PRIO: waves of the k = 7 conv raise their issue priority for the staging phase of a chunk (2, measured 1.2 % faster twice), for the MFMA phase (1, slower), static per workgroup (3 / 4, neutral / slower), 0 = never
     int dac_lds_reserve_kb = 0; // LDS the codec kernels leave free per CU for another context's decoder workgroups
     int gemm_rows_per_wg = 0;   // > 0: forwards with more rows split them over workgroups of this many rows (16/32/64)
     int gemm_ngs_max = 16;      // cap on parallel row-group wave sets per GEMM workgroup (LDS = 4 KB x waves x RB)
@@ -405,6 +406,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_KOKORO_LSTM_SPLIT")) c->kk_lstm_split = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_DAC_GROUP")) c->dac_group = std::max(1, atoi(e));
     if (const char *e = getenv("TTS_HIP_DAC_ALPHA_TAB")) c->dac_alpha_tab = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = getenv("TTS_HIP_DAC_PRIO")) c->dac_prio = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
@@ -2593,6 +2595,7 @@ static int launch_conv(tts_hip_ctx *c, const DacBatch &bt, const float *x, int c
     a.resid = resid; a.y = y; a.cin = cin; a.cout = cout; a.L = L; a.dil = dil; a.pad = pad; a.do_tanh = do_tanh;
     a.frames = bt.frames; a.mult = bt.mult;
     a.x_f16 = c->dac_f16 ? 1 : 0;
+    a.prio = K == 7 ? c->dac_prio : 0;
     const double Lv = bt.tot_frames * bt.mult;  // valid positions over the batch
     const double bytes = ((double) cin * Lv + (double) cout * Lv * (resid ? 2 : 1) + (double) cout * cin * K) * 4;
     CHK(prof_begin(c, cout == 1 ? TTS_HIP_K_DAC_FINAL : (K == 7 ? TTS_HIP_K_DAC_CONV7 : TTS_HIP_K_DAC_CONV1), bytes, 2.0 * cout * (double) cin * K * Lv));
