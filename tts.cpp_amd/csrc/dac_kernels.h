@@ -946,7 +946,7 @@ __global__ void pack_conv_w16_kernel(const float *src, _Float16 *dst, int cout, 
 }
 
 template <int KT, int MI, int NI, int WM, int WN, int CI_T>
-__global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma16_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (KT == 1 && MI == 3) ? 2 : 1) void conv1d_mfma16_kernel(ConvArgs a) {   // the 96-channel k = 1 tile came out at 264 registers: 8 over what a second wave per SIMD allows
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, NT = 64 * WM * WN;
     constexpr int NCG = CI_T / 16, QG = CI_T / 8, XS = CI_T + 8;
     constexpr int WCH = KT * CI_T * CO_T;                     // halves per packed weight chunk
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma16_kernel(ConvArgs a)
 
     half8d wreg[WV];
     float xreg[XU][8];
-    auto prefetch = [&](int c) {
+    auto prefetch = [&](int c) __attribute__((always_inline)) {
         const half8d *wp = wg + (int64_t) c * (WCH / 8);
 #pragma unroll
         for (int j = 0; j < WV; j++) {
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma16_kernel(ConvArgs a)
             }
         }
     };
-    auto commit = [&](int c, int buf) {
+    auto commit = [&](int c, int buf) __attribute__((always_inline)) {   // left out of line by the inliner in two k = 1 instantiations: every captured array went through scratch (28.9 TFLOP/s)
         half8d *wd = (half8d *) (wsb + buf * WCH);
 #pragma unroll
         for (int j = 0; j < WV; j++) {
