@@ -189,3 +189,27 @@ def test_full_size_quantizer_embedding_tile_kernel():
     for c, out in zip(ragged[:3], batch[:3]):
         assert np.array_equal(out, eng.dac_decode(c))
     eng.close()
+
+
+def test_bf16x3_conv_experiment_matches_oracle(monkeypatch):
+    """TTS_HIP_DAC_BF16X3=1 (off by default): the k = 7 convs with >= 64-channel tiles as six bf16 MFMAs per fp32
+    product (conv1d_mfma_b3_kernel).  Same tolerances as the exact-fp32 path at the DAC-44k dims: the split keeps 24
+    mantissa bits per operand, the error is that of the fp32 accumulation (measured: PCM 1.0e-6 against 6.7e-7,
+    stages 2.8e-6 against 1.8e-6; profiles/r02/dac_bf16x3_experiment.txt)."""
+    monkeypatch.setenv("TTS_HIP_DAC_BF16X3", "1")
+    model = synth.build(synth.parler_mini(layers=1, prompt_vocab=64, ctx=64))
+    cfg = model.cfg
+    eng = dac_engine(cfg, model)
+    codes = np.random.default_rng(2).integers(0, cfg.cb_size, (3, cfg.n_out)).astype(np.uint32)
+    eng.set_debug(True)
+    pcm = eng.dac_decode(codes)
+    eng.set_debug(False)
+    o = orc.DacOracle(model)
+    assert np.abs(pcm - o.decode(codes)).max() < 2e-4
+    for st in range(2 + len(cfg.strides)):
+        _, ref = o.decode(codes, stage=st)
+        assert relerr(eng.debug_read(f"dac:{st}", ref.size).reshape(ref.shape), ref) < 1e-5, f"stage {st}"
+    ragged = [np.random.default_rng(f).integers(0, cfg.cb_size, (f, cfg.n_out)).astype(np.uint32) for f in (1, 5)] + [codes]
+    batch = eng.dac_decode_batch(ragged)
+    assert np.array_equal(batch[2], pcm)
+    eng.close()

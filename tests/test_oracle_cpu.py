@@ -475,3 +475,102 @@ def test_device_sampler_key_order_restatement():
     assert np.array_equal(order, ref)
     back = value(k)
     assert np.array_equal(back, np.where(v == 0.0, np.float32(0.0), v))
+
+
+def _bf16_rne(x):
+    """float32 -> bf16 (round to nearest even), returned as float32 (what v_cvt_pk_bf16_f32 does)"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return ((u + (((u >> 16) & 1) + 0x7FFF)) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+
+
+def _split_bf16x3(x):
+    x = np.asarray(x, dtype=np.float32)
+    h1 = _bf16_rne(x)
+    r1 = x - h1
+    h2 = _bf16_rne(r1)
+    h3 = _bf16_rne(r1 - h2)
+    return h1, h2, h3
+
+
+def test_bf16x3_split_is_fp32_accurate():
+    """The arithmetic of the off-by-default conv1d_mfma_b3_kernel (csrc/dac_kernels.h): fp32 operands as three bf16
+    terms, six products, fp32 accumulation per 16-deep MFMA step.  The split itself is exact to 24 bits, the six
+    terms leave 1e-8, and the sum's error is that of an fp32 accumulation — not larger than the fp32 MFMA chain's."""
+    rng = np.random.default_rng(0)
+    K = 7 * 192
+    A = (rng.standard_normal((64, K)) * 0.05).astype(np.float32)
+    B = rng.standard_normal((K, 128)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    a, b = _split_bf16x3(A), _split_bf16x3(B)
+    assert np.array_equal((a[0].astype(np.float64) + a[1] + a[2]).astype(np.float32), A)
+    terms = [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)]
+    exact6 = sum(a[i].astype(np.float64) @ b[j].astype(np.float64) for i, j in terms)
+    assert np.abs(exact6 - ref).max() / np.abs(ref).max() < 5e-8
+    acc = np.zeros((64, 128), np.float32)
+    chain = np.zeros((64, 128), np.float32)
+    for k in range(0, K, 16):
+        for i, j in terms:      # one 32x32x16 bf16 MFMA each: exact products, fp32 accumulate
+            acc = acc + (a[i][:, k:k + 16].astype(np.float64) @ b[j][k:k + 16].astype(np.float64)).astype(np.float32)
+    for k in range(0, K, 2):    # the 32x32x2 fp32 MFMA chain of conv1d_mfma_kernel
+        chain = chain + (A[:, k:k + 2].astype(np.float64) @ B[k:k + 2].astype(np.float64)).astype(np.float32)
+    e_b3 = np.abs(acc - ref).max() / np.abs(ref).max()
+    e_f32 = np.abs(chain - ref).max() / np.abs(ref).max()
+    assert e_b3 < 2e-6 and e_b3 < 2 * e_f32, (e_b3, e_f32)
+
+
+def test_bf16x3_conv_layout_restatement():
+    """Index arithmetic of conv1d_mfma_b3_kernel / pack_conv_w_b3_kernel restated in numpy: packed weight image
+    [chunk][plane][s][hi][co][8], input image [plane][position][8], half-wave hi takes tap 2s + hi (the eighth tap has
+    zero weights and reads tap 6's rows), MFMA fragments A[i = lane & 31][k = 8 hi + e], B[k][j = lane & 31]."""
+    rng = np.random.default_rng(1)
+    cout, cin, L, dil, CO_T, T_T = 64, 24, 150, 3, 64, 64
+    pad = 3 * dil
+    w = (rng.standard_normal((cout, cin, 7)) * 0.1).astype(np.float32)
+    x = rng.standard_normal((cin, L)).astype(np.float32)
+    n_chunks = (cin + 7) // 8
+    packed = np.zeros((n_chunks, 3, 4, 2, CO_T, 8), np.float32)       # pack_conv_w_b3_kernel (one co tile)
+    for ch in range(n_chunks):
+        for st in range(4):
+            for hi in range(2):
+                tap = 2 * st + hi
+                for j in range(8):
+                    ci = ch * 8 + j
+                    v = w[:, ci, tap] if (ci < cin and tap < 7) else np.zeros(cout, np.float32)
+                    for pl, h in enumerate(_split_bf16x3(v)):
+                        packed[ch, pl, st, hi, :, j] = h
+    xw = T_T + 6 * dil
+    out = np.zeros((cout, L), np.float64)
+    for t0 in range(0, L, T_T):
+        acc = np.zeros((CO_T // 32, T_T // 32, 32, 32), np.float64)
+        for ch in range(n_chunks):
+            img = np.zeros((3, xw, 8), np.float32)                    # commit(): [plane][position][8 channels]
+            for p in range(xw):
+                t = t0 + p - pad
+                for e in range(8):
+                    ci = ch * 8 + e
+                    v = x[ci, t] if (ci < cin and 0 <= t < L) else np.float32(0)
+                    for pl, h in enumerate(_split_bf16x3(np.array([v], np.float32))):
+                        img[pl, p, e] = h[0]
+            for st in range(4):
+                for i in range(CO_T // 32):
+                    for jt in range(T_T // 32):
+                        A = np.zeros((3, 32, 16), np.float32)
+                        B = np.zeros((3, 16, 32), np.float32)
+                        for hi in range(2):
+                            tap = min(2 * st + hi, 6)
+                            for l31 in range(32):
+                                for pl in range(3):
+                                    A[pl, l31, 8 * hi:8 * hi + 8] = packed[ch, pl, st, hi, i * 32 + l31]
+                                    B[pl, 8 * hi:8 * hi + 8, l31] = img[pl, jt * 32 + l31 + tap * dil]
+                        for pa, pb in [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)]:
+                            acc[i, jt] += A[pa].astype(np.float64) @ B[pb].astype(np.float64)
+        for i in range(CO_T // 32):
+            for jt in range(T_T // 32):
+                t_lo = t0 + jt * 32
+                n = max(0, min(32, L - t_lo))
+                out[i * 32:(i + 1) * 32, t_lo:t_lo + n] = acc[i, jt][:, :n]
+    ref = np.zeros((cout, L), np.float64)
+    xp = np.pad(x.astype(np.float64), ((0, 0), (pad, pad)))
+    for k in range(7):
+        ref += np.einsum("oc,cl->ol", w[:, :, k].astype(np.float64), xp[:, k * dil:k * dil + L])
+    assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-7

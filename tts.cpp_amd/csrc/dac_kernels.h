@@ -945,6 +945,206 @@ __global__ void pack_conv_w16_kernel(const float *src, _Float16 *dst, int cout, 
     }
 }
 
+// ================================================================================================
+// EXPERIMENT (off by default, TTS_HIP_DAC_BF16X3=1): the k = 7 conv of F32 tensors with every fp32 operand split into
+// three bf16 terms, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24 mantissa bits, the
+// subtractions are exact), and the six products of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+//   w*x ~= w1*x1 + w1*x2 + w2*x1 + w1*x3 + w2*x2 + w3*x1          (dropped: 2^-24 and below)
+// bf16 x bf16 products are exact in fp32, so the error is the dropped terms (measured 6e-9 relative on K = 1344 sums,
+// tests/test_oracle_cpu.py) under the fp32 accumulation's own rounding (7.5e-7 against 8.9e-7 for the 32x32x2 fp32 chain).
+// 6 MFMAs at 16x the fp32 rate = a 2.7x higher matrix ceiling.
+// One k step of the MFMA = 16 values of the reduction: the half-wave `hi` takes tap 2s + hi, 8 input channels each;
+// the eighth tap (s = 3, hi = 1) has zero weights and reads tap 6's rows.  Chunk = 8 input channels x 7 taps.
+// LDS images per plane:  weights [s][hi][channel co][8 ci] (16-byte rows, pre-packed: straight copies)
+//                        inputs  [position][8 ci]          (16-byte rows: one read per B fragment, conflict-free)
+// ================================================================================================
+typedef __bf16 bf16x8d __attribute__((ext_vector_type(8)));
+typedef unsigned int uint4d __attribute__((ext_vector_type(4)));
+
+// x = h1 + h2 + h3 with bf16 terms (round-to-nearest-even conversions; the remainders are exact in fp32)
+__device__ __forceinline__ void split_bf16x3(float x, __bf16 &h1, __bf16 &h2, __bf16 &h3) {
+    h1 = (__bf16) x;
+    const float r1 = x - (float) h1;
+    h2 = (__bf16) r1;
+    h3 = (__bf16) (r1 - (float) h2);
+}
+
+//   conv1d  src [cout][cin][7]  ->  dst [co_tile][chunk][plane][s][hi][CO_T][8]   (ci = chunk*8 + j, tap = 2s + hi, tap 7 = 0)
+__global__ void pack_conv_w_b3_kernel(const float *src, __bf16 *dst, int cout, int cin, int CO_T, int n_chunks) {
+    const int64_t plane_sz = (int64_t) 8 * CO_T * 8;                                  // 4 steps x 2 halves x CO_T x 8
+    const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * plane_sz;  // one thread per (element, all planes)
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        const int j = (int) (i % 8);
+        int64_t r = i / 8;
+        const int col = (int) (r % CO_T); r /= CO_T;
+        const int hi = (int) (r % 2); r /= 2;
+        const int st = (int) (r % 4); r /= 4;
+        const int ch = (int) (r % n_chunks);
+        const int ct = (int) (r / n_chunks);
+        const int co = ct * CO_T + col, ci = ch * 8 + j, tap = 2 * st + hi;
+        float v = 0.0f;
+        if (co < cout && ci < cin && tap < 7) v = src[((int64_t) co * cin + ci) * 7 + tap];
+        __bf16 h1, h2, h3;
+        split_bf16x3(v, h1, h2, h3);
+        const int64_t base = ((int64_t) ct * n_chunks + ch) * 3 * plane_sz + (i % plane_sz);
+        dst[base] = h1;
+        dst[base + plane_sz] = h2;
+        dst[base + 2 * plane_sz] = h3;
+    }
+}
+
+template <int MI, int NI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_b3_kernel(ConvArgs a) {
+    constexpr int KT = 7, CI_T = 8;
+    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, NT = 64 * WM * WN;
+    constexpr int WPL = 8 * CO_T * 8;                        // bf16 per weight plane of a chunk
+    constexpr int WV = (3 * WPL / 8 + NT - 1) / NT;          // 16-byte vectors per thread per chunk (all planes)
+    constexpr int XU = (T_T + (KT - 1) * 9 + NT - 1) / NT;   // positions per thread per chunk (8 channels each), dilation <= 9
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int halo = (KT - 1) * a.dil;
+    const int xw = T_T + halo;
+    const int xpl = xw * 8;                                  // bf16 per input plane
+    __bf16 *wsb = (__bf16 *) smem;                           // [2][3][WPL]
+    __bf16 *xsb = wsb + 2 * 3 * WPL;                         // [2][3][xpl]
+    float *als = (float *) (xsb + 2 * 3 * xpl);              // [cin_pad] alpha, then [cin_pad] 1/alpha   (xpl * 2 B is a multiple of 16)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T;
+    const int n_chunks = (a.cin + CI_T - 1) / CI_T;
+    const int cin_pad = n_chunks * CI_T;
+    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    if (t0 >= L) return;
+    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * LS;
+    float *yg = a.y + (int64_t) blockIdx.z * a.cout * LS;
+    const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * LS : nullptr;
+    const uint4d *wg = (const uint4d *) ((const __bf16 *) a.w + (int64_t) blockIdx.y * n_chunks * 3 * WPL);
+
+    if (a.alpha && a.alpha_tab) {
+        for (int i = tid; i < cin_pad; i += NT) {
+            const float al = i < a.cin ? a.alpha[i] : 1.0f;
+            als[i] = al;
+            als[cin_pad + i] = 1.0f / al;
+        }
+    }
+
+    float16d acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NI; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    uint4d wreg[WV];
+    float xreg[XU][8];
+    auto prefetch = [&](int c) __attribute__((always_inline)) {
+        const uint4d *wp = wg + (int64_t) c * (3 * WPL / 8);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < 3 * WPL / 8) wreg[j] = wp[i];
+        }
+#pragma unroll
+        for (int j = 0; j < XU; j++) {
+            const int p = tid + j * NT;            // lanes run along positions: coalesced rows
+            const int t = t0 + p - a.pad;
+            const bool ok = p < xw && t >= 0 && t < L;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int cig = c * CI_T + e;
+                xreg[j][e] = (ok && cig < a.cin) ? xg[(int64_t) cig * LS + t] : 0.0f;
+            }
+        }
+    };
+    auto commit = [&](int c, int buf) __attribute__((always_inline)) {
+        uint4d *wd = (uint4d *) (wsb + buf * 3 * WPL);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < 3 * WPL / 8) wd[i] = wreg[j];
+        }
+        __bf16 *xd = xsb + buf * 3 * xpl;
+#pragma unroll
+        for (int j = 0; j < XU; j++) {
+            const int p = tid + j * NT;
+            if (p < xw) {
+                bf16x8d h1, h2, h3;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float v = xreg[j][e];
+                    if (a.alpha) {
+                        const int cig = c * CI_T + e;
+                        v = snake_ch(v, cig, a.cin, cin_pad, als, a.alpha, a.alpha_tab);  // snake(0) == 0: zero padding is preserved
+                    }
+                    __bf16 b1, b2, b3;
+                    split_bf16x3(v, b1, b2, b3);
+                    h1[e] = b1; h2[e] = b2; h3[e] = b3;
+                }
+                *(bf16x8d *) (xd + p * 8) = h1;
+                *(bf16x8d *) (xd + xpl + p * 8) = h2;
+                *(bf16x8d *) (xd + 2 * xpl + p * 8) = h3;
+            }
+        }
+    };
+
+    prefetch(0);
+    __syncthreads();  // alpha table visible
+    commit(0, 0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) prefetch(c + 1);
+        const __bf16 *ws = wsb + buf * 3 * WPL;
+        const __bf16 *xs = xsb + buf * 3 * xpl;
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+            const int tap = (2 * st + hi < KT) ? 2 * st + hi : KT - 1;   // the eighth tap: zero weights, any valid rows
+            bf16x8d af[3][MI], bf[3][NI];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+                    af[pl][i] = *(const bf16x8d *) (ws + pl * WPL + (((st * 2 + hi) * CO_T) + (wm * MI + i) * 32 + l31) * 8);
+#pragma unroll
+                for (int j = 0; j < NI; j++)
+                    bf[pl][j] = *(const bf16x8d *) (xs + pl * xpl + ((wn * NI + j) * 32 + l31 + tap * a.dil) * 8);
+            }
+            // the six terms, smallest first; term-major so that consecutive MFMAs write different accumulators
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int tm = 0; tm < 6; tm++)
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+#pragma unroll
+                    for (int j = 0; j < NI; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[tm]][i], bf[TB[tm]][j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < n_chunks) commit(c + 1, buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int co = co0 + (wm * MI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (co >= a.cout) continue;
+            const float bias = a.b ? a.b[co] : 0.0f;
+            const float al_o = a.alpha_out ? a.alpha_out[co] : 1.0f, ral_o = 1.0f / al_o;
+#pragma unroll
+            for (int j = 0; j < NI; j++) {
+                const int t = t0 + (wn * NI + j) * 32 + l31;
+                if (t >= L) continue;
+                float v = acc[i][j][e] + bias;
+                if (rg) v = v + rg[(int64_t) co * LS + t];
+                if (a.alpha_out) v = snake_f(v, al_o, ral_o);
+                if (a.do_tanh) v = tanhf(v);
+                yg[(int64_t) co * LS + t] = v;
+            }
+        }
+    }
+}
+
 template <int KT, int MI, int NI, int WM, int WN, int CI_T>
 __global__ __launch_bounds__(64 * WM * WN, (KT == 1 && MI == 3) ? 2 : 1) void conv1d_mfma16_kernel(ConvArgs a) {   // the 96-channel k = 1 tile came out at 264 registers: 8 over what a second wave per SIMD allows
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, NT = 64 * WM * WN;

@@ -316,6 +316,8 @@ struct tts_hip_ctx {
     int dac_c192 = 0;
     std::set<size_t> packed_direct;    // ... of those, the k = 1 weights packed as [cin][cout] for conv1x1_direct_kernel
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
+    std::map<size_t, __bf16 *> packed_b3;   // k = 7 conv weights as three bf16 planes (dac_b3, experiment)
+    int dac_b3 = 0;             // TTS_HIP_DAC_BF16X3 (experiment, off): k = 7 convs of F32 tensors as six bf16 MFMAs per product (conv1d_mfma_b3_kernel)
     bool kk_lstm_split = true;  // TTS_HIP_KOKORO_LSTM_SPLIT=0: the bidirectional LSTMs through the one-workgroup-per-direction kernel
     char *kk_pool = nullptr;    // Kokoro scratch pool (KScratch): grows to the largest call
     size_t kk_pool_cap = 0, kk_pool_next = 0;
@@ -407,6 +409,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_DAC_GROUP")) c->dac_group = std::max(1, atoi(e));
     if (const char *e = getenv("TTS_HIP_DAC_ALPHA_TAB")) c->dac_alpha_tab = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("TTS_HIP_DAC_PRIO")) c->dac_prio = atoi(e);
+    if (const char *e = getenv("TTS_HIP_DAC_BF16X3")) c->dac_b3 = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
@@ -456,6 +459,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (int i = 0; i < 3; i++) free_dev(c->dbuf[i]);
     for (auto &pw : c->packed) free_dev(pw.second);
     for (auto &pw : c->packed16) free_dev(pw.second);
+    for (auto &pw : c->packed_b3) free_dev(pw.second);
     if (c->h_ids) (void) hipHostFree(c->h_ids);
     if (c->h_pos) (void) hipHostFree(c->h_pos);
     if (c->h_seq) (void) hipHostFree(c->h_seq);
@@ -2454,6 +2458,16 @@ static int pack_one16(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT, i
     c->packed16[w_off] = dst;
     return 0;
 }
+static int pack_one_b3(tts_hip_ctx *c, size_t w_off, int cout, int cin) {   // k = 7, 64-channel tiles, 8 input channels per chunk
+    const int n_chunks = (cin + 7) / 8, CO_T = 64;
+    const size_t n = (size_t) ((cout + CO_T - 1) / CO_T) * n_chunks * 3 * 8 * CO_T * 8;
+    __bf16 *dst = nullptr;
+    HIPCHK(hipMalloc((void **) &dst, n * 2));
+    hipLaunchKernelGGL(pack_conv_w_b3_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + w_off), dst, cout, cin, CO_T, n_chunks);
+    HIPCHK(hipGetLastError());
+    c->packed_b3[w_off] = dst;
+    return 0;
+}
 #define CI16_K7 16
 #define CI16_K1 32
 #define CI16_T  16
@@ -2475,9 +2489,11 @@ static int ensure_packed(tts_hip_ctx *c) {
         return 0;
     }
     if (conv_tile(c->d_c0, 7, &CO_T, &CI_T) >= 0) CHK(pack_one(c, c->d_initw, c->d_c0, c->d_latent, 7, CO_T, CI_T, false));
+    if (c->dac_b3 && c->d_c0 % 64 == 0) CHK(pack_one_b3(c, c->d_initw, c->d_c0, c->d_latent));
     for (auto &b : c->dblocks) {
         if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, CI32_T, true));
         for (int r = 0; r < 3; r++) {
+            if (c->dac_b3 && b.cout % 64 == 0) CHK(pack_one_b3(c, b.res[r].in_w, b.cout, b.cout));
             if (c->dac_c192 && b.cout == 192) {
                 CHK(pack_one(c, b.res[r].in_w, b.cout, b.cout, 7, 192, CI32_K7, false));
                 c->packed_c192.insert(b.res[r].in_w);
@@ -2529,6 +2545,23 @@ static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a_in, int nz) {
     }
     const dim3 grid((a.L + T_T - 1) / T_T, (a.cout + CO_T - 1) / CO_T, nz);
     hipLaunchKernelGGL((conv1d_mfma_kernel<KT, MI, NI, WM, WN, CI_T>), grid, dim3(64 * WM * WN), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// k = 7 conv as six bf16 MFMAs per product (experiment): 64 channels x 256 positions per workgroup of 4 waves
+static int launch_conv_b3(tts_hip_ctx *c, const ConvArgs &a_in, int nz) {
+    constexpr int MI = 2, NI = 2, WM = 1, WN = 4, CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WPL = 8 * CO_T * 8;
+    const int xw = T_T + 6 * a_in.dil;
+    const int cin_pad = (a_in.cin + 7) / 8 * 8;
+    ConvArgs a = a_in;
+    const size_t lds = dac_lds_request(c, ((size_t) 6 * WPL + 6 * (size_t) xw * 8) * 2, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab, true);
+    static std::atomic<uint64_t> attr{0};
+    if (attr_needed(attr, c->device)) {
+        HIPCHK(hipFuncSetAttribute((const void *) conv1d_mfma_b3_kernel<MI, NI, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    const dim3 grid((a.L + T_T - 1) / T_T, (a.cout + CO_T - 1) / CO_T, nz);
+    hipLaunchKernelGGL((conv1d_mfma_b3_kernel<MI, NI, WM, WN>), grid, dim3(64 * WM * WN), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2607,6 +2640,9 @@ static int launch_conv(tts_hip_ctx *c, const DacBatch &bt, const float *x, int c
     if (!valu && cout == 1 && K == 7) {
         hipLaunchKernelGGL(conv1d_cout1_kernel, dim3((L + C1_T - 1) / C1_T, 1, bt.n), dim3(256), 0, c->stream, a);
         HIPCHK(hipGetLastError());
+    } else if (!valu && K == 7 && c->dac_b3 && !c->dac_f16 && c->packed_b3.count(w) && dil <= 9) {
+        a.w = (const float *) c->packed_b3[w];   // three bf16 planes (experiment)
+        CHK(launch_conv_b3(c, a, bt.n));
     } else if (cfg >= 0 && c->dac_f16 && pk16 != c->packed16.end()) {
         a.w = (const float *) pk16->second;  // fp16 LDS images
         if (K == 7 && cfg == 0) CHK((launch_conv_mfma16<7, 2, 2, 2, 2, CI16_K7>(c, a, bt.n)));
