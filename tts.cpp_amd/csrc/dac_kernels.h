@@ -994,7 +994,7 @@ __global__ void pack_conv_w_b3_kernel(const float *src, __bf16 *dst, int cout, i
 }
 
 template <int MI, int NI, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_mfma_b3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, WM * WN >= 8 ? 1 : 2) void conv1d_mfma_b3_kernel(ConvArgs a) {   // 2 waves per SIMD either way
     constexpr int KT = 7, CI_T = 8;
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, NT = 64 * WM * WN;
     constexpr int WPL = 8 * CO_T * 8;                        // bf16 per weight plane of a chunk

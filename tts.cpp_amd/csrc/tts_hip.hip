@@ -317,7 +317,7 @@ struct tts_hip_ctx {
     std::set<size_t> packed_direct;    // ... of those, the k = 1 weights packed as [cin][cout] for conv1x1_direct_kernel
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
     std::map<size_t, __bf16 *> packed_b3;   // k = 7 conv weights as three bf16 planes (dac_b3, experiment)
-    int dac_b3 = 0;             // TTS_HIP_DAC_BF16X3 (experiment, off): k = 7 convs of F32 tensors as six bf16 MFMAs per product (conv1d_mfma_b3_kernel)
+    int dac_b3 = 0;             // TTS_HIP_DAC_BF16X3 (experiment, off): k = 7 convs of F32 tensors as six bf16 MFMAs per product (conv1d_mfma_b3_kernel); 1 = the layers with 64-channel tiles (measured, tested), 2 = also the 96-channel tile (written after the GPU budget of round 2 was spent: never run)
     bool kk_lstm_split = true;  // TTS_HIP_KOKORO_LSTM_SPLIT=0: the bidirectional LSTMs through the one-workgroup-per-direction kernel
     char *kk_pool = nullptr;    // Kokoro scratch pool (KScratch): grows to the largest call
     size_t kk_pool_cap = 0, kk_pool_next = 0;
@@ -409,7 +409,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_DAC_GROUP")) c->dac_group = std::max(1, atoi(e));
     if (const char *e = getenv("TTS_HIP_DAC_ALPHA_TAB")) c->dac_alpha_tab = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("TTS_HIP_DAC_PRIO")) c->dac_prio = atoi(e);
-    if (const char *e = getenv("TTS_HIP_DAC_BF16X3")) c->dac_b3 = atoi(e) != 0;
+    if (const char *e = getenv("TTS_HIP_DAC_BF16X3")) c->dac_b3 = std::max(0, atoi(e));
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
@@ -2458,8 +2458,8 @@ static int pack_one16(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT, i
     c->packed16[w_off] = dst;
     return 0;
 }
-static int pack_one_b3(tts_hip_ctx *c, size_t w_off, int cout, int cin) {   // k = 7, 64-channel tiles, 8 input channels per chunk
-    const int n_chunks = (cin + 7) / 8, CO_T = 64;
+static int pack_one_b3(tts_hip_ctx *c, size_t w_off, int cout, int cin, int CO_T) {   // k = 7, 64- or 96-channel tiles, 8 input channels per chunk
+    const int n_chunks = (cin + 7) / 8;
     const size_t n = (size_t) ((cout + CO_T - 1) / CO_T) * n_chunks * 3 * 8 * CO_T * 8;
     __bf16 *dst = nullptr;
     HIPCHK(hipMalloc((void **) &dst, n * 2));
@@ -2489,11 +2489,12 @@ static int ensure_packed(tts_hip_ctx *c) {
         return 0;
     }
     if (conv_tile(c->d_c0, 7, &CO_T, &CI_T) >= 0) CHK(pack_one(c, c->d_initw, c->d_c0, c->d_latent, 7, CO_T, CI_T, false));
-    if (c->dac_b3 && c->d_c0 % 64 == 0) CHK(pack_one_b3(c, c->d_initw, c->d_c0, c->d_latent));
+    if (c->dac_b3 && c->d_c0 % 64 == 0) CHK(pack_one_b3(c, c->d_initw, c->d_c0, c->d_latent, 64));
     for (auto &b : c->dblocks) {
         if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, CI32_T, true));
         for (int r = 0; r < 3; r++) {
-            if (c->dac_b3 && b.cout % 64 == 0) CHK(pack_one_b3(c, b.res[r].in_w, b.cout, b.cout));
+            if (c->dac_b3 && b.cout % 64 == 0) CHK(pack_one_b3(c, b.res[r].in_w, b.cout, b.cout, 64));
+            else if (c->dac_b3 >= 2 && b.cout % 96 == 0) CHK(pack_one_b3(c, b.res[r].in_w, b.cout, b.cout, 96));   // not run on a GPU yet
             if (c->dac_c192 && b.cout == 192) {
                 CHK(pack_one(c, b.res[r].in_w, b.cout, b.cout, 7, 192, CI32_K7, false));
                 c->packed_c192.insert(b.res[r].in_w);
@@ -2549,9 +2550,11 @@ static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a_in, int nz) {
     return 0;
 }
 
-// k = 7 conv as six bf16 MFMAs per product (experiment): 64 channels x 256 positions per workgroup of 4 waves
+// k = 7 conv as six bf16 MFMAs per product (experiment): 64 channels x 256 positions per workgroup of 4 waves,
+// or 96 channels x 256 positions per workgroup of 8 waves
+template <int MI, int NI, int WM, int WN>
 static int launch_conv_b3(tts_hip_ctx *c, const ConvArgs &a_in, int nz) {
-    constexpr int MI = 2, NI = 2, WM = 1, WN = 4, CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WPL = 8 * CO_T * 8;
+    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WPL = 8 * CO_T * 8;
     const int xw = T_T + 6 * a_in.dil;
     const int cin_pad = (a_in.cin + 7) / 8 * 8;
     ConvArgs a = a_in;
@@ -2642,7 +2645,8 @@ static int launch_conv(tts_hip_ctx *c, const DacBatch &bt, const float *x, int c
         HIPCHK(hipGetLastError());
     } else if (!valu && K == 7 && c->dac_b3 && !c->dac_f16 && c->packed_b3.count(w) && dil <= 9) {
         a.w = (const float *) c->packed_b3[w];   // three bf16 planes (experiment)
-        CHK(launch_conv_b3(c, a, bt.n));
+        if (cout % 64 == 0) CHK((launch_conv_b3<2, 2, 1, 4>(c, a, bt.n)));
+        else CHK((launch_conv_b3<3, 1, 1, 8>(c, a, bt.n)));
     } else if (cfg >= 0 && c->dac_f16 && pk16 != c->packed16.end()) {
         a.w = (const float *) pk16->second;  // fp16 LDS images
         if (K == 7 && cfg == 0) CHK((launch_conv_mfma16<7, 2, 2, 2, 2, CI16_K7>(c, a, bt.n)));
