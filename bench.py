@@ -453,6 +453,15 @@ def main():
             roof["traffic"] = pmc_traffic(dom, args, n_audio)
             if roof["bound"] == "mfma" and dom in MFMA_FP32:
                 roof["note"] = "fp32 conv: peak = fp32 vector / fp32-input-MFMA peak (exact-fp32 numerics)"
+            if int(os.environ.get("TTS_HIP_DAC_BF16X3", "0") or 0) and dom.startswith("conv1d_mfma_kernel<7") and args.dac_wtype == "f32":
+                # experiment: the k = 7 convs issue six bf16 MFMAs per fp32 product (and 8 tap slots for 7 taps): price the
+                # family against the bf16 pipe with the flops it issues, keep the fp32-equivalent rate beside it
+                issued = roof["achieved"] * 6.0 * 8.0 / 7.0
+                roof.update({"fp32_equivalent_TFLOPs": roof["achieved"], "achieved": round(issued, 3), "peak": F16_PEAK_TFLOPS,
+                             "frac": round(issued / F16_PEAK_TFLOPS, 4),
+                             "note": "TTS_HIP_DAC_BF16X3: fp32 operands as three bf16 terms, six bf16 MFMAs per product, fp32 accumulate; achieved = issued "
+                                     "flops (6 x 8/7 x algorithmic) against the dense bf16 peak; layers still on the fp32 kernel (96-channel tiles with knob 1) "
+                                     "are counted the same way, which overstates the issued rate for them"})
             out["roofline"] = roof
             out["roofline_families"] = [dict(roof_of(n, v, "eager pass (launch-by-launch HIP events: short kernels read ~1-2 us long)"), traffic=None)
                                         for n, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_total"]) if n != dom]
