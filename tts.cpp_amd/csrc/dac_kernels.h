@@ -3,10 +3,17 @@
 // Replaces the ggml graph of dac_runner::build_dac_graph
 // (/root/reference/src/decoder/dac_model.cpp:146-170) and the layer builders in
 // /root/reference/src/decoder/general_neural_audio_codec.cpp:133-172.  Kernel ↔ reference:
-//   dac_embed_kernel   dac_build_audio_inputs + build_quantize_layer   dac_model.cpp:100-123, gnac.cpp:166-172
-//   conv1d_kernel      ggml_conv_1d + ggml_add(bias) [+ snake_1d in front] [+ residual add] [+ tanh]
-//                      dac_model.cpp:158-166, gnac.cpp:133-149
-//   convt1d_kernel     snake_1d + fork's ggml_conv_transpose_1d + bias               gnac.cpp:151-154
+//   dac_embed_tile_kernel / dac_embed_kernel   dac_build_audio_inputs + build_quantize_layer   dac_model.cpp:100-123, gnac.cpp:166-172
+//   conv1d_mfma_kernel<KT,...>   ggml_conv_1d + ggml_add(bias) [+ snake_1d in front] [+ residual add] [+ tanh], exact fp32 on
+//                      v_mfma_f32_32x32x2_f32                                        dac_model.cpp:158-166, gnac.cpp:133-149
+//   conv1x1_direct_kernel        the k = 1 conv + bias + residual of a residual unit at 96 / 192 channels        gnac.cpp:147-149
+//   convt1d_mfma_kernel<S,...>   snake_1d + fork's ggml_conv_transpose_1d + bias, phase-decomposed             gnac.cpp:151-154
+//   conv1d_cout1_kernel          final snake + conv (1 output channel) + tanh                                  dac_model.cpp:163-166
+//   conv1d_mfma16_kernel / convt1d_mfma16_kernel   the same layers with F16 tensors (fp16 im2col, v_mfma_f32_32x32x16_f16)
+//   conv1d_mfma_b3_kernel        experiment, off by default: k = 7 conv with fp32 operands as three bf16 terms (v_mfma_f32_32x32x16_bf16)
+//   conv1d_kernel / convt1d_kernel   the same layers without the matrix pipe (TTS_HIP_FLAG_VALU_GEMM: cross-check in the tests)
+//   pack_conv_w_kernel / pack_conv_w16_kernel / pack_conv_w_b3_kernel   one-time re-layout of the weights into the LDS images
+//   snac_embed_kernel, dwconv7_kernel, noise_fma_kernel   SNAC's quantizer, depthwise conv and noise block (snac_model.cpp)
 // Activations are [C][L] fp32 with L fastest (ggml ne=[L,C]); weights keep the GGUF/PyTorch memory
 // order (Conv1d [Cout][Cin][K], ConvTranspose1d [Cin][Cout][K]).
 //
