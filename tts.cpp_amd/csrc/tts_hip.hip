@@ -317,6 +317,7 @@ struct tts_hip_ctx {
     std::set<size_t> packed_direct;    // ... of those, the k = 1 weights packed as [cin][cout] for conv1x1_direct_kernel
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
     std::map<size_t, __bf16 *> packed_b3;   // k = 7 conv weights as three bf16 planes (dac_b3, experiment)
+    int dac_b3_variant = 0;     // TTS_HIP_DAC_B3_VARIANT: tile shape of the 64-channel class of the experiment
     int dac_b3 = 0;             // TTS_HIP_DAC_BF16X3 (experiment, off): k = 7 convs of F32 tensors as six bf16 MFMAs per product (conv1d_mfma_b3_kernel); 1 = the layers with 64-channel tiles (measured, tested), 2 = also the 96-channel tile (written after the GPU budget of round 2 was spent: never run)
     bool kk_lstm_split = true;  // TTS_HIP_KOKORO_LSTM_SPLIT=0: the bidirectional LSTMs through the one-workgroup-per-direction kernel
     char *kk_pool = nullptr;    // Kokoro scratch pool (KScratch): grows to the largest call
@@ -410,6 +411,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_DAC_ALPHA_TAB")) c->dac_alpha_tab = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("TTS_HIP_DAC_PRIO")) c->dac_prio = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_BF16X3")) c->dac_b3 = std::max(0, atoi(e));
+    if (const char *e = getenv("TTS_HIP_DAC_B3_VARIANT")) c->dac_b3_variant = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
@@ -2645,8 +2647,12 @@ static int launch_conv(tts_hip_ctx *c, const DacBatch &bt, const float *x, int c
         HIPCHK(hipGetLastError());
     } else if (!valu && K == 7 && c->dac_b3 && !c->dac_f16 && c->packed_b3.count(w) && dil <= 9) {
         a.w = (const float *) c->packed_b3[w];   // three bf16 planes (experiment)
-        if (cout % 64 == 0) CHK((launch_conv_b3<2, 2, 1, 4>(c, a, bt.n)));
-        else CHK((launch_conv_b3<3, 1, 1, 8>(c, a, bt.n)));
+        // tile variants of the 64-channel class for the sweep of round 3 (only 0 has run on a GPU)
+        if (cout % 64 == 0 && c->dac_b3_variant == 1) CHK((launch_conv_b3<2, 1, 1, 4>(c, a, bt.n)));        // 64 ch x 128 pos, 4 waves
+        else if (cout % 64 == 0 && c->dac_b3_variant == 2) CHK((launch_conv_b3<2, 1, 1, 8>(c, a, bt.n)));   // 64 ch x 256 pos, 8 waves
+        else if (cout % 64 == 0 && c->dac_b3_variant == 3) CHK((launch_conv_b3<1, 2, 2, 2>(c, a, bt.n)));   // 64 ch x 128 pos, waves 32 x 64
+        else if (cout % 64 == 0) CHK((launch_conv_b3<2, 2, 1, 4>(c, a, bt.n)));                             // 64 ch x 256 pos, 4 waves
+        else CHK((launch_conv_b3<3, 1, 1, 8>(c, a, bt.n)));                                                  // 96 ch x 256 pos, 8 waves
     } else if (cfg >= 0 && c->dac_f16 && pk16 != c->packed16.end()) {
         a.w = (const float *) pk16->second;  // fp16 LDS images
         if (K == 7 && cfg == 0) CHK((launch_conv_mfma16<7, 2, 2, 2, 2, CI16_K7>(c, a, bt.n)));
