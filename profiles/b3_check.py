@@ -18,7 +18,7 @@ codes = np.random.default_rng(2).integers(0, cfg.cb_size, (3, cfg.n_out)).astype
 o = orc.DacOracle(model)
 ref = o.decode(codes)
 stages = [o.decode(codes, stage=s)[1] for s in range(2 + len(cfg.strides))]
-for knob in ("1", "0"):
+for knob in os.environ.get("B3_KNOBS", "1 0").split():   # B3_KNOBS="2" checks the 96-channel tile as well
     os.environ["TTS_HIP_DAC_BF16X3"] = knob
     eng = hip.HipEngine(cfg, flags=hip.FLAG_NO_PARLER)
     eng.load(model)
