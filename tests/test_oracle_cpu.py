@@ -574,3 +574,36 @@ def test_bf16x3_conv_layout_restatement():
     for k in range(7):
         ref += np.einsum("oc,cl->ol", w[:, :, k].astype(np.float64), xp[:, k * dil:k * dil + L])
     assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-7
+
+
+def test_accumulators_as_b_fragments_restatement():
+    """Design check for DESIGN §8 'round 3' item 2 (the k = 1 conv of a 96-channel residual unit inside the k = 7
+    kernel's epilogue): with v_mfma_f32_32x32x2_f32 the result D[row][col] of tile i sits in lane (col, hi), register e
+    with row = (e & 3) + 8 (e >> 2) + 4 hi; taking the reduction step of the second GEMM as (i, e) and its two k values
+    as hi, every lane's own register IS its B fragment (B[k = hi][j = col]) and the weights only need the matching
+    permutation.  No cross-lane movement: checked here against a plain matrix product."""
+    rng = np.random.default_rng(3)
+    C, T = 96, 32
+    s1 = rng.standard_normal((C, T)).astype(np.float32)           # snake(conv7 + bias): what the accumulators hold
+    w2 = (rng.standard_normal((C, C)) * 0.1).astype(np.float32)   # k = 1 conv weights [co][ci]
+    # accumulator image: acc[i][lane = (col, hi)][e]
+    acc = np.zeros((C // 32, 32, 2, 16), np.float32)
+    for i in range(C // 32):
+        for e in range(16):
+            for hi in range(2):
+                acc[i, :, hi, e] = s1[32 * i + (e & 3) + 8 * (e >> 2) + 4 * hi, :]
+    out = np.zeros((C, T), np.float64)
+    for i2 in range(C // 32):                                      # output tile of the second GEMM
+        D = np.zeros((32, 32), np.float64)
+        for i in range(C // 32):
+            for e in range(16):                                    # one MFMA: K = 2 (hi = 0, 1)
+                A = np.zeros((32, 2), np.float32)
+                B = np.zeros((2, 32), np.float32)
+                for hi in range(2):
+                    ci = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hi
+                    A[:, hi] = w2[32 * i2:32 * i2 + 32, ci]        # lane (row, hi) reads the permuted weight image
+                    B[hi, :] = acc[i, :, hi, e]                    # the lane's own register
+                D += A.astype(np.float64) @ B.astype(np.float64)
+        out[32 * i2:32 * i2 + 32] = D
+    ref = w2.astype(np.float64) @ s1.astype(np.float64)
+    assert np.abs(out - ref).max() < 1e-12
