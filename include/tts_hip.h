@@ -406,7 +406,8 @@ enum tts_hip_kclass {
     TTS_HIP_K_DAC_CONV1 = 15,   /* conv1d k=1 (+ residual add) */
     TTS_HIP_K_DAC_CONVT = 16,   /* ConvTranspose1d upsampling */
     TTS_HIP_K_DAC_FINAL = 17,   /* final Cout=1 conv + tanh */
-    TTS_HIP_K_COUNT = 18
+    TTS_HIP_K_DAC_RESUNIT = 18, /* resunit_b3_kernel: one residual unit (snake, k=7 conv, snake, k=1 conv, + x) in one launch */
+    TTS_HIP_K_COUNT = 19
 };
 typedef struct tts_hip_kstat {
     double   ms_total;      /* summed event-elapsed time */

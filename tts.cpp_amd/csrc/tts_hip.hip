@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "dac_kernels.h"
+#include "dac_b3_kernels.h"
 #include "parler_kernels.h"
 #include "gemm_tile_kernels.h"
 #include "gemv_stream_kernels.h"
@@ -317,6 +318,8 @@ struct tts_hip_ctx {
     std::set<size_t> packed_direct;    // ... of those, the k = 1 weights packed as [cin][cout] for conv1x1_direct_kernel
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
     std::map<size_t, __bf16 *> packed_b3;   // k = 7 conv weights as three bf16 planes (dac_b3, experiment)
+    std::map<size_t, __bf16 *> packed_ru;   // residual unit (keyed by its k = 7 weight) -> stage stream of resunit_b3_kernel
+    int dac_fuse = 1;           // TTS_HIP_DAC_FUSE=0: residual units at 96 / 192 channels stay two launches (k = 7 conv, k = 1 conv + residual)
     int dac_b3_variant = 0;     // TTS_HIP_DAC_B3_VARIANT: tile shape of the 64-channel class of the experiment
     int dac_b3 = 0;             // TTS_HIP_DAC_BF16X3 (experiment, off): k = 7 convs of F32 tensors as six bf16 MFMAs per product (conv1d_mfma_b3_kernel); 1 = the layers with 64-channel tiles (measured, tested), 2 = also the 96-channel tile (written after the GPU budget of round 2 was spent: never run)
     bool kk_lstm_split = true;  // TTS_HIP_KOKORO_LSTM_SPLIT=0: the bidirectional LSTMs through the one-workgroup-per-direction kernel
@@ -361,7 +364,7 @@ struct tts_hip_ctx {
 
 static const char *KNAMES[TTS_HIP_K_COUNT] = {"embed", "ln", "gemm_qkv", "attn_self", "gemm_attn_out", "gemm_cross_q", "attn_cross",
                                               "gemm_cross_out", "gemm_fc1", "gemm_fc2", "gemm_heads", "sample", "gemm_other",
-                                              "dac_embed", "dac_conv7", "dac_conv1", "dac_convt", "dac_final"};
+                                              "dac_embed", "dac_conv7", "dac_conv1", "dac_convt", "dac_final", "dac_resunit"};
 extern "C" const char *tts_hip_kclass_name(int k) { return (k >= 0 && k < TTS_HIP_K_COUNT) ? KNAMES[k] : "?"; }
 
 extern "C" int tts_hip_device_count(void) {
@@ -412,6 +415,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_DAC_PRIO")) c->dac_prio = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_BF16X3")) c->dac_b3 = std::max(0, atoi(e));
     if (const char *e = getenv("TTS_HIP_DAC_B3_VARIANT")) c->dac_b3_variant = atoi(e);
+    if (const char *e = getenv("TTS_HIP_DAC_FUSE")) c->dac_fuse = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
@@ -462,6 +466,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (auto &pw : c->packed) free_dev(pw.second);
     for (auto &pw : c->packed16) free_dev(pw.second);
     for (auto &pw : c->packed_b3) free_dev(pw.second);
+    for (auto &pw : c->packed_ru) free_dev(pw.second);
     if (c->h_ids) (void) hipHostFree(c->h_ids);
     if (c->h_pos) (void) hipHostFree(c->h_pos);
     if (c->h_seq) (void) hipHostFree(c->h_seq);
@@ -2470,6 +2475,25 @@ static int pack_one_b3(tts_hip_ctx *c, size_t w_off, int cout, int cin, int CO_T
     c->packed_b3[w_off] = dst;
     return 0;
 }
+// residual units of 96 / 192 channels as one launch (resunit_b3_kernel): k-steps per stage of the k = 7 / k = 1 part
+static bool resunit_shape(int C, int *KS, int *KS2) {
+    if (C == 96) { *KS = 4; *KS2 = 3; return true; }
+    if (C == 192) { *KS = 2; *KS2 = 4; return true; }
+    return false;
+}
+static int pack_resunit(tts_hip_ctx *c, const DRes &r, int C) {
+    int KS = 0, KS2 = 0;
+    if (!resunit_shape(C, &KS, &KS2)) return 0;
+    const ResUnitGeom g = resunit_geom(C, KS, KS2);
+    const size_t n = (size_t) (g.n7 + g.n1 + 1) * g.WST;   // + 1: the prefetch of the stage after the last one stays inside the buffer
+    __bf16 *dst = nullptr;
+    HIPCHK(hipMalloc((void **) &dst, n * 2));
+    HIPCHK(hipMemsetAsync(dst, 0, n * 2, c->stream));
+    hipLaunchKernelGGL(pack_resunit_b3_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + r.in_w), (const float *) (c->arena + r.out_w), dst, C, KS, KS2);
+    HIPCHK(hipGetLastError());
+    c->packed_ru[r.in_w] = dst;
+    return 0;
+}
 #define CI16_K7 16
 #define CI16_K1 32
 #define CI16_T  16
@@ -2495,6 +2519,7 @@ static int ensure_packed(tts_hip_ctx *c) {
     for (auto &b : c->dblocks) {
         if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, CI32_T, true));
         for (int r = 0; r < 3; r++) {
+            if (c->dac_fuse) CHK(pack_resunit(c, b.res[r], b.cout));
             if (c->dac_b3 && b.cout % 64 == 0) CHK(pack_one_b3(c, b.res[r].in_w, b.cout, b.cout, 64));
             else if (c->dac_b3 >= 2 && b.cout % 96 == 0) CHK(pack_one_b3(c, b.res[r].in_w, b.cout, b.cout, 96));   // not run on a GPU yet
             if (c->dac_c192 && b.cout == 192) {
@@ -2752,6 +2777,37 @@ static int launch_convt(tts_hip_ctx *c, ConvTArgs ta, size_t w_off, int nz) {
     return 0;
 }
 
+// one residual unit (gnac.cpp:133-149) as one launch
+template <int MI, int KS, int KS2>
+static int launch_resunit_t(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
+    constexpr int C = 32 * MI;
+    const ResUnitGeom g = resunit_geom(C, KS, KS2);
+    const int xw = 256 + 6 * a.dil;
+    const size_t lds = (size_t) 2 * g.WST * 2 + (size_t) 6 * xw * 8 * 2 + (size_t) C * 24;
+    static std::atomic<uint64_t> attr{0};
+    if (attr_needed(attr, c->device)) {
+        HIPCHK(hipFuncSetAttribute((const void *) resunit_b3_kernel<MI, KS, KS2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    hipLaunchKernelGGL((resunit_b3_kernel<MI, KS, KS2>), dim3((a.L + 255) / 256, 1, nz), dim3(512), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static bool resunit_fused(const tts_hip_ctx *c, const DRes &r, int dil) {
+    return c->dac_fuse && !c->dac_f16 && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM) && dil <= 9 && c->packed_ru.count(r.in_w);
+}
+static int launch_resunit(tts_hip_ctx *c, const DacBatch &bt, const DRes &r, int C, int LS, int dil, const float *x, float *y) {
+    ResUnitArgs a{};
+    a.x = x; a.y = y; a.w = c->packed_ru.at(r.in_w);
+    a.b7 = (const float *) (c->arena + r.in_b); a.b1 = (const float *) (c->arena + r.out_b);
+    a.alpha_in = (const float *) (c->arena + r.in_alpha); a.alpha_mid = (const float *) (c->arena + r.out_alpha);
+    a.L = LS; a.dil = dil; a.pad = 3 * dil; a.frames = bt.frames; a.mult = bt.mult;
+    const double Lv = bt.tot_frames * bt.mult;
+    CHK(prof_begin(c, TTS_HIP_K_DAC_RESUNIT, (2.0 * C * Lv + 8.0 * C * C) * 4, 2.0 * C * (double) C * 8 * Lv));
+    if (C == 96) CHK((launch_resunit_t<3, 4, 3>(c, a, bt.n)));
+    else CHK((launch_resunit_t<6, 2, 4>(c, a, bt.n)));
+    return prof_end(c);
+}
+
 // dac_runner::run for n utterances at once (grid.z = utterance, per-utterance lengths): the early blocks have
 // few positions per utterance, so batching is what fills the 256 CUs there.
 static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint32_t *frames, uint32_t n, float *pcm_out);
@@ -2892,6 +2948,11 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
             for (int e = 0; e < r; e++) dil *= 3;
             // snake(out_alpha) of the k=1 conv's input is applied in the k=7 conv's epilogue (same arithmetic, once
             // per element instead of once per output-channel tile)
+            if (resunit_fused(c, b.res[r], dil)) {
+                CHK(launch_resunit(c, bt, b.res[r], C, LS, dil, cur, t1));
+                std::swap(cur, t1);
+                continue;
+            }
             CHK(launch_conv(c, bt, cur, C, LS, b.res[r].in_w, b.res[r].in_b, b.res[r].in_alpha, true, C, 7, 3 * dil, dil, nullptr, false, t1,
                             b.res[r].out_alpha, true));
             CHK(launch_conv(c, bt, t1, C, LS, b.res[r].out_w, b.res[r].out_b, 0, false, C, 1, 0, 1, cur, false, t2));

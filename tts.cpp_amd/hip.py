@@ -15,7 +15,7 @@ MAX_DAC_BLOCKS = 8
 
 FLAG_NO_GRAPH, FLAG_VALU_GEMM, FLAG_NO_DAC, FLAG_NO_PARLER, FLAG_DEQUANT_Q, FLAG_DAC_F32 = 1, 2, 4, 8, 16, 32
 KCLASSES = ["embed", "ln", "gemm_qkv", "attn_self", "gemm_attn_out", "gemm_cross_q", "attn_cross", "gemm_cross_out", "gemm_fc1",
-            "gemm_fc2", "gemm_heads", "sample", "gemm_other", "dac_embed", "dac_conv7", "dac_conv1", "dac_convt", "dac_final"]
+            "gemm_fc2", "gemm_heads", "sample", "gemm_other", "dac_embed", "dac_conv7", "dac_conv1", "dac_convt", "dac_final", "dac_resunit"]
 
 
 class HipError(RuntimeError):
