@@ -96,9 +96,15 @@ struct ResUnitArgs {
     int L, dil, pad;         // L = row stride
     const uint32_t *frames;  // per-utterance frames (grid.z) or NULL; valid length = frames[z] * mult
     int mult;
+    long long *stamps;       // profiling (profiles/ru_bench.hip): 5 cycle-counter stamps per workgroup, or NULL
 };
+#define RU_STAMP(k) do { if (a.stamps && tid == 0) a.stamps[((int64_t) blockIdx.z * gridDim.x + blockIdx.x) * 5 + (k)] = (long long) __builtin_readcyclecounter(); } while (0)
 
-template <int MI, int KS, int KS2>
+// SCHED: 0 = fragments read just in time (the compiler's order), 1 = double-buffered fragment sets, 2 = double-buffered and the reads of
+// group q + 1 pinned between the MFMAs of group q (sched_group_barrier)
+// ABL (timing experiments only, results invalid): 1 = no snake / split in the input staging, 2 = no weight streaming, 4 = no barriers,
+// 8 = fragments read once instead of per group
+template <int MI, int KS, int KS2, int SCHED = 1, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void resunit_b3_kernel(ResUnitArgs a) {
     constexpr int C = 32 * MI, WN = 8, NT = 512, T_T = 32 * WN;
     constexpr int SPC = 4 / KS;                               // k = 7 stages per 8-channel chunk
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(512, 2) void resunit_b3_kernel(ResUnitArgs a) {
     float *yg = a.y + (int64_t) blockIdx.z * C * LS;
     const uint4d *wg = (const uint4d *) a.w;
 
+    RU_STAMP(0);
     for (int i = tid; i < C; i += NT) {
         const float am = a.alpha_mid[i], ai = a.alpha_in[i];
         tab[i] = make_float4(a.b7[i], am, 1.0f / am, a.b1[i]);
@@ -163,12 +170,14 @@ __global__ __launch_bounds__(512, 2) void resunit_b3_kernel(ResUnitArgs a) {
     auto commit_x = [&](int c, int buf) __attribute__((always_inline)) {
         if (xp < xw) {
             bf16x8d h1, h2, h3;
+            float v[8], al[8], ral[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float2 t2 = tin[c * 8 + e]; v[e] = xreg[e]; al[e] = t2.x; ral[e] = t2.y; }
+            if (!(ABL & 1)) snake_vec<8>(v, al, ral);   // snake(0) == 0: zero padding is preserved
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const float2 al = tin[c * 8 + e];
-                const float v = snake_f(xreg[e], al.x, al.y);   // snake(0) == 0: zero padding is preserved
                 __bf16 b1, b2, b3;
-                split_bf16x3(v, b1, b2, b3);
+                split_bf16x3(v[e], b1, b2, b3);
                 h1[e] = b1; h2[e] = b2; h3[e] = b3;
             }
             __bf16 *xd = xsb + buf * 3 * xpl + xp * 8;
@@ -184,43 +193,79 @@ __global__ __launch_bounds__(512, 2) void resunit_b3_kernel(ResUnitArgs a) {
     commit_w(0);
     commit_x(0, 0);
     __syncthreads();
+    RU_STAMP(1);
 
     // ---- k = 7 conv: N7 stages --------------------------------------------------------------------------------------------------
     for (int g = 0; g < N7; g++) {
         const int c = g / SPC, sub = g - c * SPC;
-        prefetch_w(g + 1);                                     // the stream continues into the k = 1 stages
-        if (sub == 0 && c + 1 < NCH) prefetch_x(c + 1);
+        if (!(ABL & 2)) prefetch_w(g + 1);                     // the stream continues into the k = 1 stages
+        if (!(ABL & 16) && sub == 0 && c + 1 < NCH) prefetch_x(c + 1);
         const __bf16 *ws = wsb + (g & 1) * WST;
         const __bf16 *xs = xsb + (c & 1) * 3 * xpl;
-#pragma unroll
-        for (int s = 0; s < KS; s++) {
+        // fragments of group q + 1 (three 32-channel blocks of one k-step) are requested before the MFMAs of group q: with two waves per
+        // SIMD a just-in-time ds_read + wait in front of every few MFMAs left the matrix pipe 53 % idle (profiles/r03/pmc_busy_dac_b64_fused.txt)
+        constexpr int GPS = MI / 3, NG = KS * GPS;
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};   // the six partial products, smallest first; term-major over
+                                                                                // the three accumulators: consecutive MFMAs write different registers
+        auto load_b = [&](bf16x8d (&bf)[3], int s) __attribute__((always_inline)) {
             const int st = sub * KS + s;
             const int tap = (2 * st + hi < 7) ? 2 * st + hi : 6;   // the eighth tap: zero weights, any valid rows
-            bf16x8d bf[3];
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) bf[pl] = *(const bf16x8d *) (xs + pl * xpl + (wn * 32 + l31 + tap * a.dil) * 8);
+        };
+        auto load_a = [&](bf16x8d (&af)[3][3], int s, int ig) __attribute__((always_inline)) {
 #pragma unroll
-            for (int ig = 0; ig < MI; ig += 3) {
-                bf16x8d af[3][3];
+            for (int ii = 0; ii < 3; ii++)
 #pragma unroll
-                for (int ii = 0; ii < 3; ii++)
-#pragma unroll
-                    for (int pl = 0; pl < 3; pl++)
-                        af[ii][pl] = *(const bf16x8d *) (ws + pl * WPL7 + (((s * 2 + hi) * C) + (ig + ii) * 32 + l31) * 8);
-                // term-major over the three accumulators: consecutive MFMAs write different registers
-                constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+                for (int pl = 0; pl < 3; pl++)
+                    af[ii][pl] = *(const bf16x8d *) (ws + pl * WPL7 + (((s * 2 + hi) * C) + (ig + ii) * 32 + l31) * 8);
+        };
+        if constexpr (SCHED == 0) {
+            static_for<NG>([&](auto Q) __attribute__((always_inline)) {
+                constexpr int q = decltype(Q)::value, s = q / GPS, ig = 3 * (q % GPS);
+                bf16x8d af[3][3], bf[3];
+                load_b(bf, s);
+                load_a(af, s, ig);
 #pragma unroll
                 for (int tm = 0; tm < 6; tm++)
 #pragma unroll
                     for (int ii = 0; ii < 3; ii++)
                         acc[ig + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ii][TA[tm]], bf[TB[tm]], acc[ig + ii], 0, 0, 0);
-            }
+            });
+        } else {
+            bf16x8d afs[2][3][3], bfs[2][3];
+            load_b(bfs[0], 0);
+            load_a(afs[0], 0, 0);
+            if constexpr ((ABL & 8) != 0) { load_b(bfs[1], 1); load_a(afs[1], 1, 0); }
+            static_for<NG>([&](auto Q) __attribute__((always_inline)) {
+                constexpr int q = decltype(Q)::value, s = q / GPS, ig = 3 * (q % GPS);
+                constexpr int s1 = (q + 1) / GPS, ig1 = 3 * ((q + 1) % GPS);
+                constexpr int nrd = q + 1 < NG ? (ig1 == 0 ? 12 : 9) : 0;
+                if constexpr (q + 1 < NG && !(ABL & 8)) {
+                    if constexpr (ig1 == 0) load_b(bfs[s1 & 1], s1);
+                    load_a(afs[(q + 1) & 1], s1, ig1);
+                }
+#pragma unroll
+                for (int tm = 0; tm < 6; tm++)
+#pragma unroll
+                    for (int ii = 0; ii < 3; ii++)
+                        acc[ig + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afs[q & 1][ii][TA[tm]], bfs[s & 1][TB[tm]], acc[ig + ii], 0, 0, 0);
+                if constexpr (SCHED == 2 && nrd > 0) {   // 2 reads behind every MFMA until the next group's reads are out, then the rest of the MFMAs
+#pragma unroll
+                    for (int k = 0; k < (nrd + 1) / 2; k++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 18 - (nrd + 1) / 2, 0);
+                }
+            });
         }
-        commit_w((g + 1) & 1);
-        if (sub == SPC - 1 && c + 1 < NCH) commit_x(c + 1, (c + 1) & 1);
-        __syncthreads();
+        if (!(ABL & 2)) commit_w((g + 1) & 1);
+        if (!(ABL & 16) && sub == SPC - 1 && c + 1 < NCH) commit_x(c + 1, (c + 1) & 1);
+        if (!(ABL & 4)) __syncthreads();
     }
 
+    RU_STAMP(2);
     // ---- k = 1 conv: the accumulators (bias, snake, split) are its B fragments; 96 output channels per pass --------------------------
     // (static_for: the stage index must be a compile-time constant, it selects accumulator registers)
     const int t = t0 + wn * 32 + l31;
@@ -235,17 +280,22 @@ __global__ __launch_bounds__(512, 2) void resunit_b3_kernel(ResUnitArgs a) {
         }
         if constexpr (g2 + 1 < N1) prefetch_w(N7 + g2 + 1);
         const __bf16 *ws = wsb + ((N7 + g2) & 1) * WST;
-        static_for<KS2>([&](auto S) __attribute__((always_inline)) {
+        static_for<(ABL & 32) ? 0 : KS2>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value, ks = q * KS2 + s, ib = ks / 2, qq = ks % 2;
             bf16x8d bf[3];
+            float hv[8], al[8], ral[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int e = 8 * qq + m;
                 const int ch = 32 * ib + (e & 3) + 8 * (e >> 2) + 4 * hi;
                 const float4 tb = tab[ch];
-                const float v = snake_f(acc[ib][e] + tb.x, tb.y, tb.z);
+                hv[m] = acc[ib][e] + tb.x; al[m] = tb.y; ral[m] = tb.z;
+            }
+            snake_vec<8>(hv, al, ral);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
                 __bf16 b1, b2, b3;
-                split_bf16x3(v, b1, b2, b3);
+                split_bf16x3(hv[m], b1, b2, b3);
                 bf[0][m] = b1; bf[1][m] = b2; bf[2][m] = b3;
             }
             bf16x8d af[3][3];
@@ -266,6 +316,7 @@ __global__ __launch_bounds__(512, 2) void resunit_b3_kernel(ResUnitArgs a) {
             __syncthreads();
         }
         if constexpr (q == NS1 - 1) {   // + bias + x
+            if constexpr (p == NP - 1) RU_STAMP(3);
             if (t < L) {
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
@@ -284,4 +335,443 @@ __global__ __launch_bounds__(512, 2) void resunit_b3_kernel(ResUnitArgs a) {
             }
         }
     });
+    RU_STAMP(4);
+}
+
+// ================================================================================================================================
+// Split planes in memory.  For the wide classes (768 / 384 / 1536 channels) an output-channel tile cannot hold all channels, so a
+// conv kernel that stages fp32 inputs applies snake + split once per OUTPUT-CHANNEL TILE (12 x per element at 768 channels) and the
+// matrix pipe waits for the vector pipe.  There the activation a conv consumes is kept in memory already snaked and split:
+//     planes [n][3][C / 8][L][8] bf16       (plane, 8-channel group, position, channel in group)
+// — one 16-byte row per (plane, group, position), consecutive positions consecutive rows, i.e. exactly the LDS image of a chunk:
+// staging is a straight 16-byte copy and the B fragment of v_mfma_f32_32x32x16_bf16 one ds_read_b128.  The producer's epilogue
+// writes the planes (snake with the CONSUMER's alpha, then the split), plus the fp32 tensor where a residual add needs it.
+//   snake_split_kernel      fp32 [n][C][L] -> planes (for producers that are not plane-aware)
+//   conv_b3p_kernel<KT,...> k = 7 / k = 1 conv: planes in; fp32 and / or planes out; bias, residual, snake for the consumer fused
+//   pack_conv_w_b3p_kernel  weights as bf16 planes in stage order
+// ================================================================================================================================
+struct SplitArgs {
+    const float *x;          // [n][C][L]
+    const float *alpha;      // [C] snake before the split, or NULL
+    __bf16 *yp;              // [n][3][C/8][L][8]
+    int C, L;
+    const uint32_t *frames; int mult;
+};
+
+__global__ __launch_bounds__(256) void snake_split_kernel(SplitArgs a) {
+    const int t = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, z = blockIdx.z;
+    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    if (t >= L) return;
+    const int CG = a.C / 8;
+    const float *xg = a.x + ((int64_t) z * a.C + cg * 8) * LS + t;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = xg[(int64_t) e * LS];
+    bf16x8d h1, h2, h3;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        float s = v[e];
+        if (a.alpha) { const float al = a.alpha[cg * 8 + e]; s = snake_f(s, al, 1.0f / al); }
+        __bf16 b1, b2, b3;
+        split_bf16x3(s, b1, b2, b3);
+        h1[e] = b1; h2[e] = b2; h3[e] = b3;
+    }
+    const int64_t pst = (int64_t) CG * LS * 8;
+    __bf16 *yp = a.yp + (int64_t) z * 3 * pst + ((int64_t) cg * LS + t) * 8;
+    *(bf16x8d *) yp = h1;
+    *(bf16x8d *) (yp + pst) = h2;
+    *(bf16x8d *) (yp + 2 * pst) = h3;
+}
+
+//   src [cout][cin][KT] -> dst [co_tile][chunk][plane][s < NS][hi][CO_T][8]
+//   KT = 7 (NS = 4): ci = 8 chunk + j, tap = 2 s + hi (tap 7: zero);   KT = 1: ci = 16 NS chunk + 8 (2 s + hi) + j
+__global__ void pack_conv_w_b3p_kernel(const float *src, __bf16 *dst, int cout, int cin, int KT, int CO_T, int NS, int n_chunks) {
+    const int64_t plane_sz = (int64_t) NS * 2 * CO_T * 8;
+    const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * plane_sz;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        const int j = (int) (i % 8);
+        int64_t r = i / 8;
+        const int col = (int) (r % CO_T); r /= CO_T;
+        const int hi = (int) (r % 2); r /= 2;
+        const int st = (int) (r % NS); r /= NS;
+        const int ch = (int) (r % n_chunks);
+        const int ct = (int) (r / n_chunks);
+        const int co = ct * CO_T + col;
+        int ci, tap;
+        if (KT == 7) { ci = ch * 8 + j; tap = 2 * st + hi; }
+        else { ci = ch * 16 * NS + 8 * (2 * st + hi) + j; tap = 0; }
+        float v = 0.0f;
+        if (co < cout && ci < cin && tap < KT) v = src[((int64_t) co * cin + ci) * KT + tap];
+        __bf16 h1, h2, h3;
+        split_bf16x3(v, h1, h2, h3);
+        const int64_t base = ((int64_t) ct * n_chunks + ch) * 3 * plane_sz + (i % plane_sz);
+        dst[base] = h1;
+        dst[base + plane_sz] = h2;
+        dst[base + 2 * plane_sz] = h3;
+    }
+}
+
+struct PConvArgs {
+    const __bf16 *xp;        // input planes [n][3][cin/8][L][8]
+    const __bf16 *w;         // packed weights (pack_conv_w_b3p_kernel)
+    const float *b;          // [cout]
+    const float *resid;      // fp32 [n][cout][L] or NULL
+    float *y;                // fp32 out [n][cout][L] or NULL
+    __bf16 *yp;              // planes out [n][3][cout/8][L][8] or NULL
+    const float *alpha_out;  // snake applied before the split of yp, or NULL
+    int cin, cout, L, dil, pad;   // L = row stride
+    const uint32_t *frames; int mult;
+};
+
+// one lane's 4 consecutive channels of one position: bias (+ residual) -> fp32 out and / or snake + split -> planes out
+__device__ __forceinline__ void b3p_store4(const PConvArgs &a, float v0, float v1, float v2, float v3, int co, int t, int LS, const float *rg, float *yg,
+                                           __bf16 *ypz, int64_t pst) {
+    float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        v[r] += a.b ? a.b[co + r] : 0.0f;
+        if (rg) v[r] = v[r] + rg[(int64_t) (co + r) * LS + t];
+        if (yg) yg[(int64_t) (co + r) * LS + t] = v[r];
+    }
+    if (ypz) {
+        typedef __bf16 bf16x4d __attribute__((ext_vector_type(4)));
+        bf16x4d h1, h2, h3;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float s = v[r];
+            if (a.alpha_out) { const float al = a.alpha_out[co + r]; s = snake_f(s, al, 1.0f / al); }
+            __bf16 b1, b2, b3;
+            split_bf16x3(s, b1, b2, b3);
+            h1[r] = b1; h2[r] = b2; h3[r] = b3;
+        }
+        __bf16 *p = ypz + ((int64_t) (co >> 3) * LS + t) * 8 + (co & 7);   // co is a multiple of 4: the lower or upper half of a 16-byte row
+        *(bf16x4d *) p = h1;
+        *(bf16x4d *) (p + pst) = h2;
+        *(bf16x4d *) (p + 2 * pst) = h3;
+    }
+}
+
+template <int KT, int MI, int NI, int WM, int WN, int NS, int MINW>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs a) {
+    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, NT = 64 * WM * WN;
+    constexpr int NCG = KT == 7 ? 1 : 2 * NS;                // 8-channel groups per chunk
+    constexpr int WPL = NS * 2 * CO_T * 8;                   // bf16 per weight plane of a chunk
+    constexpr int WV = (3 * WPL / 8 + NT - 1) / NT;          // 16-byte vectors per thread per chunk (all planes)
+    constexpr int XP = (T_T + (KT - 1) * 9 + NT - 1) / NT;   // position rows per thread per (plane, group), dilation <= 9
+    static_assert(KT == 1 || NS == 4, "k = 7: four k-steps (tap pairs) per 8-channel chunk");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int xw = T_T + (KT - 1) * a.dil;
+    const int xsz = 3 * NCG * xw * 8;                        // bf16 per input chunk image [plane][group][position][8]
+    __bf16 *wsb = (__bf16 *) smem;                           // [2][3][WPL]
+    __bf16 *xsb = wsb + 2 * 3 * WPL;                         // [2][xsz]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T;
+    const int CGI = a.cin / 8;
+    const int n_chunks = CGI / NCG;
+    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    if (t0 >= L) return;
+    const int64_t psti = (int64_t) CGI * LS * 8;             // bf16 per input plane
+    const __bf16 *xg = a.xp + (int64_t) blockIdx.z * 3 * psti;
+    const uint4d *wg = (const uint4d *) (a.w + (int64_t) blockIdx.y * n_chunks * 3 * WPL);
+
+    float16d acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NI; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    uint4d wreg[WV];
+    uint4d xreg[3 * NCG * XP];
+    auto prefetch = [&](int c) __attribute__((always_inline)) {
+        const uint4d *wp = wg + (int64_t) c * (3 * WPL / 8);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < 3 * WPL / 8) wreg[j] = wp[i];
+        }
+#pragma unroll
+        for (int q = 0; q < XP; q++) {
+            const int p = tid + q * NT;
+            const int t = t0 + p - a.pad;
+            const bool ok = p < xw && t >= 0 && t < L;
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+                for (int g = 0; g < NCG; g++) {
+                    const uint4d zero = {0u, 0u, 0u, 0u};
+                    xreg[(q * 3 + pl) * NCG + g] = ok ? *(const uint4d *) (xg + pl * psti + ((int64_t) (c * NCG + g) * LS + t) * 8) : zero;
+                }
+        }
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+        uint4d *wd = (uint4d *) (wsb + buf * 3 * WPL);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < 3 * WPL / 8) wd[i] = wreg[j];
+        }
+        __bf16 *xd = xsb + buf * xsz;
+#pragma unroll
+        for (int q = 0; q < XP; q++) {
+            const int p = tid + q * NT;
+            if (p < xw) {
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+                    for (int g = 0; g < NCG; g++) *(uint4d *) (xd + ((pl * NCG + g) * xw + p) * 8) = xreg[(q * 3 + pl) * NCG + g];
+            }
+        }
+    };
+
+    prefetch(0);
+    commit(0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) prefetch(c + 1);
+        const __bf16 *ws = wsb + buf * 3 * WPL;
+        const __bf16 *xs = xsb + buf * xsz;
+#pragma unroll
+        for (int st = 0; st < NS; st++) {
+            int xoff;   // bf16 offset of this half-wave's B rows inside a plane image
+            if constexpr (KT == 7) {
+                const int tap = (2 * st + hi < KT) ? 2 * st + hi : KT - 1;   // the eighth tap: zero weights, any valid rows
+                xoff = tap * a.dil * 8;
+            } else {
+                xoff = (2 * st + hi) * xw * 8;
+            }
+            bf16x8d af[3][MI], bf[3][NI];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+                    af[pl][i] = *(const bf16x8d *) (ws + pl * WPL + (((st * 2 + hi) * CO_T) + (wm * MI + i) * 32 + l31) * 8);
+#pragma unroll
+                for (int j = 0; j < NI; j++)
+                    bf[pl][j] = *(const bf16x8d *) (xs + pl * NCG * xw * 8 + xoff + ((wn * NI + j) * 32 + l31) * 8);
+            }
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int tm = 0; tm < 6; tm++)
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+#pragma unroll
+                    for (int j = 0; j < NI; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[tm]][i], bf[TB[tm]][j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < n_chunks) commit(buf ^ 1);
+        __syncthreads();
+    }
+
+    const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * LS : nullptr;
+    float *yg = a.y ? a.y + (int64_t) blockIdx.z * a.cout * LS : nullptr;
+    const int64_t psto = (int64_t) (a.cout / 8) * LS * 8;
+    __bf16 *ypz = a.yp ? a.yp + (int64_t) blockIdx.z * 3 * psto : nullptr;
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int co = co0 + (wm * MI + i) * 32 + 8 * q + 4 * hi;
+            if (co >= a.cout) continue;
+#pragma unroll
+            for (int j = 0; j < NI; j++) {
+                const int t = t0 + (wn * NI + j) * 32 + l31;
+                if (t >= L) continue;
+                b3p_store4(a, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3], co, t, LS, rg, yg, ypz, psto);
+            }
+        }
+}
+
+// ================================================================================================================================
+// ConvTranspose1d(stride S, kernel 2 S) as bf16 x 3 products, phase-decomposed like convt1d_mfma_kernel (dac_kernels.h):
+//   y[co][ti S + ph - p] = b[co] + sum_ci ( f(x[ci][ti]) w[ci][co][ph] + f(x[ci][ti - 1]) w[ci][co][ph + S] ),   f = snake
+// One MFMA k-step = 8 input channels x the two tap slots (half-wave hi = 0: x[ti], hi = 1: x[ti - 1]); the S phases share the B operand.
+// Workgroup = 8 waves side by side in ti: (32 MI) output channels x 256 ti x S phases; chunk = 16 input channels (two k-steps).
+// The fp32 input is staged once per workgroup and chunk: snake (snake_vec) + split -> LDS planes [plane][group][ti0 - 1 + r][8].
+//   pack_convt_w_b3_kernel   src [cin][cout][2 S] -> dst [co_tile][chunk][plane][ks < 2][ph < S][hi][CO_T][8]  (ci = 16 chunk + 8 ks + j, k = ph + hi S)
+// ================================================================================================================================
+__global__ void pack_convt_w_b3_kernel(const float *src, __bf16 *dst, int cout, int cin, int S, int CO_T, int n_chunks) {
+    const int64_t plane_sz = (int64_t) 2 * S * 2 * CO_T * 8;
+    const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * plane_sz;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        const int j = (int) (i % 8);
+        int64_t r = i / 8;
+        const int col = (int) (r % CO_T); r /= CO_T;
+        const int hi = (int) (r % 2); r /= 2;
+        const int ph = (int) (r % S); r /= S;
+        const int ks = (int) (r % 2); r /= 2;
+        const int ch = (int) (r % n_chunks);
+        const int ct = (int) (r / n_chunks);
+        const int co = ct * CO_T + col, ci = ch * 16 + ks * 8 + j, k = ph + hi * S;
+        float v = 0.0f;
+        if (co < cout && ci < cin) v = src[((int64_t) ci * cout + co) * 2 * S + k];
+        __bf16 h1, h2, h3;
+        split_bf16x3(v, h1, h2, h3);
+        const int64_t base = ((int64_t) ct * n_chunks + ch) * 3 * plane_sz + (i % plane_sz);
+        dst[base] = h1;
+        dst[base + plane_sz] = h2;
+        dst[base + 2 * plane_sz] = h3;
+    }
+}
+
+template <int S, int MI>
+__global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
+    constexpr int CO_T = 32 * MI, WN = 8, TI_T = 32 * WN, NT = 64 * WN, K2 = 2 * S;
+    constexpr int WPL = 2 * S * 2 * CO_T * 8;                // bf16 per weight plane of a chunk
+    constexpr int WV = (3 * WPL / 8 + NT - 1) / NT;          // 16-byte vectors per thread per chunk
+    constexpr int xw = TI_T + 1;                             // rows ti0 - 1 .. ti0 + TI_T - 1
+    constexpr int XR = (2 * xw + NT - 1) / NT;               // (group, row) units per thread per chunk
+    constexpr int xpl = 2 * xw * 8;                          // bf16 per input plane of a chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16 *wsb = (__bf16 *) smem;                           // [2][3][WPL]
+    __bf16 *xsb = wsb + 2 * 3 * WPL;                         // [2][3][xpl]
+    float2 *tin = (float2 *) (xsb + 2 * 3 * xpl);            // [cin] {alpha, 1 / alpha}
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ti0 = blockIdx.x * TI_T, co0 = blockIdx.y * CO_T;
+    const int n_chunks = a.cin / 16;
+    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    const int LoS = a.Lout, Lout = a.frames ? (L - 1) * S - 2 * a.pad + K2 : a.Lout;
+    if (ti0 > L) return;  // ti runs 0..L inclusive
+    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * LS;
+    float *yg = a.y + (int64_t) blockIdx.z * a.cout * LoS;
+    const uint4d *wg = (const uint4d *) ((const __bf16 *) a.w + (int64_t) blockIdx.y * n_chunks * 3 * WPL);
+
+    for (int i = tid; i < a.cin; i += NT) {
+        const float al = a.alpha ? a.alpha[i] : 1.0f;
+        tin[i] = make_float2(al, 1.0f / al);
+    }
+
+    float16d acc[MI][S];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int ph = 0; ph < S; ph++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][ph][e] = 0.0f;
+
+    uint4d wreg[WV];
+    float xreg[XR][8];
+    auto prefetch = [&](int c) __attribute__((always_inline)) {
+        const uint4d *wp = wg + (int64_t) c * (3 * WPL / 8);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < 3 * WPL / 8) wreg[j] = wp[i];
+        }
+#pragma unroll
+        for (int q = 0; q < XR; q++) {
+            const int u = tid + q * NT;
+            const int g = u / xw, r = u - g * xw;           // lanes run along positions: coalesced rows
+            const int ti = ti0 - 1 + r;
+            const bool ok = g < 2 && ti >= 0 && ti < L;
+#pragma unroll
+            for (int e = 0; e < 8; e++) xreg[q][e] = ok ? xg[(int64_t) (c * 16 + g * 8 + e) * LS + ti] : 0.0f;
+        }
+    };
+    auto commit = [&](int c, int buf) __attribute__((always_inline)) {
+        uint4d *wd = (uint4d *) (wsb + buf * 3 * WPL);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < 3 * WPL / 8) wd[i] = wreg[j];
+        }
+        __bf16 *xd = xsb + buf * 3 * xpl;
+#pragma unroll
+        for (int q = 0; q < XR; q++) {
+            const int u = tid + q * NT;
+            const int g = u / xw, r = u - g * xw;
+            if (g < 2) {
+                if (a.alpha) {
+                    float al[8], ral[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { const float2 t2 = tin[c * 16 + g * 8 + e]; al[e] = t2.x; ral[e] = t2.y; }
+                    snake_vec<8>(xreg[q], al, ral);          // snake(0) == 0: zero padding is preserved
+                }
+                bf16x8d h1, h2, h3;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    __bf16 b1, b2, b3;
+                    split_bf16x3(xreg[q][e], b1, b2, b3);
+                    h1[e] = b1; h2[e] = b2; h3[e] = b3;
+                }
+                __bf16 *p = xd + (g * xw + r) * 8;
+                *(bf16x8d *) p = h1;
+                *(bf16x8d *) (p + xpl) = h2;
+                *(bf16x8d *) (p + 2 * xpl) = h3;
+            }
+        }
+    };
+
+    prefetch(0);
+    __syncthreads();   // alpha table visible
+    commit(0, 0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) prefetch(c + 1);
+        const __bf16 *ws = wsb + buf * 3 * WPL;
+        const __bf16 *xs = xsb + buf * 3 * xpl;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8d bf[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) bf[pl] = *(const bf16x8d *) (xs + pl * xpl + (ks * xw + wn * 32 + l31 + 1 - hi) * 8);
+#pragma unroll
+            for (int ph = 0; ph < S; ph++) {
+                bf16x8d af[MI][3];
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++)
+                        af[i][pl] = *(const bf16x8d *) (ws + pl * WPL + ((((ks * S + ph) * 2 + hi) * CO_T) + i * 32 + l31) * 8);
+                constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int tm = 0; tm < 6; tm++)
+#pragma unroll
+                    for (int i = 0; i < MI; i++)
+                        acc[i][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[tm]], bf[TB[tm]], acc[i][ph], 0, 0, 0);
+            }
+        }
+        if (c + 1 < n_chunks) commit(c + 1, buf ^ 1);
+        __syncthreads();
+    }
+
+    // a lane holds the S consecutive outputs to = ti S - p .. ti S - p + S - 1 of every channel it owns: stored as wide as the alignment allows
+    const int ti = ti0 + wn * 32 + l31;
+    const int tob = ti * S - a.pad;
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int co = co0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (co >= a.cout) continue;
+            const float bias = a.b ? a.b[co] : 0.0f;
+            float *row = yg + (int64_t) co * LoS;
+            if ((S % 4) == 0 && (a.pad % 4) == 0 && (LoS % 4) == 0) {
+#pragma unroll
+                for (int p4 = 0; p4 < S / 4; p4++) {
+                    const int to = tob + 4 * p4;
+                    if (to >= 0 && to + 3 < Lout) {
+                        float4d v = {acc[i][4 * p4][e] + bias, acc[i][4 * p4 + 1][e] + bias, acc[i][4 * p4 + 2][e] + bias, acc[i][4 * p4 + 3][e] + bias};
+                        *(float4d *) (row + to) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (to + r >= 0 && to + r < Lout) row[to + r] = acc[i][4 * p4 + r][e] + bias;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ph = 0; ph < S; ph++) {
+                    const int to = tob + ph;
+                    if (to >= 0 && to < Lout) row[to] = acc[i][ph][e] + bias;
+                }
+            }
+        }
+    }
 }

@@ -30,8 +30,7 @@ typedef float float4d __attribute__((ext_vector_type(4)));
 // |x| < 125: 4-term Cody-Waite reduction by pi (every product exact, so the reduced argument is correct to < 1 ulp) and the degree-9
 // odd minimax polynomial on [-pi/2, pi/2].  Checked against float64 sin on 12 M random arguments (tests/test_oracle_cpu.py restates it in
 // numpy): max abs error 1.3e-7, <= 2 ulp — libm's own float result is within 1.4 ulp on the same points; larger arguments go to sinf.
-__device__ __forceinline__ float snake_sin(float x) {
-    if (!(fabsf(x) < 125.0f)) return sinf(x);
+__device__ __forceinline__ float snake_sin_poly(float x) {   // |x| < 125
     const float q = rintf(x * 0.318309886183790671537767526745028724f);
     float r = fmaf(q, -3.140625f, x);
     r = fmaf(q, -0.0009670257568359375f, r);
@@ -45,10 +44,33 @@ __device__ __forceinline__ float snake_sin(float x) {
     u = fmaf(u, s, -0.166666597127914428710938f);
     return fmaf(s, u * r, r);
 }
+__device__ __forceinline__ float snake_sin(float x) {
+    if (!(fabsf(x) < 125.0f)) return sinf(x);
+    return snake_sin_poly(x);
+}
 
 __device__ __forceinline__ float snake_f(float x, float alpha, float ralpha) {
     const float s = snake_sin(x * alpha);
     return x + (s * s) * ralpha;
+}
+// N values at once.  snake_f's range test is a divergent branch per element: N calls in a row are N separate control-flow regions, i.e. N
+// dependent chains of ~20 operations one after the other (measured: ~190 cycles per element, profiles/r03/ru_bench_3.txt — the staging
+// and conversion phases of the codec kernels were bound by it).  Here the test is made once for the group and wave-uniformly: the
+// common case is N interleavable straight-line chains; if any lane holds an argument beyond the polynomial's range the whole wave takes
+// the per-element form.  Same function per element either way (bit-identical to snake_f).
+template <int N>
+__device__ __forceinline__ void snake_vec(float (&v)[N], const float (&al)[N], const float (&ral)[N]) {
+    float arg[N];
+    bool big = false;
+#pragma unroll
+    for (int e = 0; e < N; e++) { arg[e] = v[e] * al[e]; big = big || !(fabsf(arg[e]) < 125.0f); }
+    if (__builtin_amdgcn_ballot_w64(big) != 0) {
+#pragma unroll
+        for (int e = 0; e < N; e++) { const float s = snake_sin(arg[e]); v[e] = v[e] + (s * s) * ral[e]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; e++) { const float s = snake_sin_poly(arg[e]); v[e] = v[e] + (s * s) * ral[e]; }
+    }
 }
 // snake with alpha from the LDS table (alpha, then 1/alpha, cin_pad entries each) or straight from memory; same arithmetic
 __device__ __forceinline__ float snake_ch(float x, int cig, int cin, int cin_pad, const float *als, const float *alpha, int tab) {
@@ -544,30 +566,31 @@ __global__ __launch_bounds__(64 * WM * WN, (KT == 7 && MI * NI <= 4) ? CONV7_MIN
             if (i < WCH / 4) wd[i] = wreg[j];
         }
         float *xd = xsb + buf * xsz;
+        // snake on all of a thread's staged values at once (snake_vec: one wave-uniform range test instead of a divergent branch per value)
+        if (a.alpha) {
+            float al[XV], ral[XV];
+#pragma unroll
+            for (int j = 0; j < XV; j++) {
+                int cig;
+                if constexpr (KT == 1) cig = c * CI_T + ((tid + (j / 4) * NT) * 4) / T_T;
+                else { const int i = tid + j * NT; cig = c * CI_T + (i < CI_T * xw ? i / xw : 0); }
+                if (a.alpha_tab) { al[j] = als[cig]; ral[j] = als[cin_pad + cig]; }
+                else { al[j] = cig < a.cin ? a.alpha[cig] : 1.0f; ral[j] = 1.0f / al[j]; }
+            }
+            snake_vec<XV>(xreg, al, ral);   // snake(0) == 0: zero padding is preserved
+        }
         if constexpr (KT == 1) {
 #pragma unroll
             for (int j = 0; j < XV / 4; j++) {
                 const int i4 = tid + j * NT;
                 float4d v = {xreg[4 * j], xreg[4 * j + 1], xreg[4 * j + 2], xreg[4 * j + 3]};
-                if (a.alpha) {
-                    const int cig = c * CI_T + (i4 * 4) / T_T;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = snake_ch(v[e], cig, a.cin, cin_pad, als, a.alpha, a.alpha_tab);
-                }
                 *(float4d *) (xd + i4 * 4) = v;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < XV; j++) {
                 const int i = tid + j * NT;
-                if (i < CI_T * xw) {
-                    float v = xreg[j];
-                    if (a.alpha) {
-                        const int cig = c * CI_T + i / xw;
-                        v = snake_ch(v, cig, a.cin, cin_pad, als, a.alpha, a.alpha_tab);  // snake(0) == 0: zero padding is preserved
-                    }
-                    xd[i] = v;
-                }
+                if (i < CI_T * xw) xd[i] = xreg[j];
             }
         }
     };
@@ -818,17 +841,21 @@ __global__ __launch_bounds__(64 * WM * WN, CONVT_MIN_WAVES) void convt1d_mfma_ke
             if (i < WCH / 4) wd[i] = wreg[j];
         }
         float *xd = xsb + buf * xsz;
+        if (a.alpha) {
+            float al[XV], ral[XV];
+#pragma unroll
+            for (int j = 0; j < XV; j++) {
+                const int i = tid + j * NT;
+                const int cig = c * CI_T + (i < CI_T * xw ? i / xw : 0);
+                if (a.alpha_tab) { al[j] = als[cig]; ral[j] = als[cin_pad + cig]; }
+                else { al[j] = cig < a.cin ? a.alpha[cig] : 1.0f; ral[j] = 1.0f / al[j]; }
+            }
+            snake_vec<XV>(xreg, al, ral);
+        }
 #pragma unroll
         for (int j = 0; j < XV; j++) {
             const int i = tid + j * NT;
-            if (i < CI_T * xw) {
-                float v = xreg[j];
-                if (a.alpha) {
-                    const int cig = c * CI_T + i / xw;
-                    v = snake_ch(v, cig, a.cin, cin_pad, als, a.alpha, a.alpha_tab);
-                }
-                xd[i] = v;
-            }
+            if (i < CI_T * xw) xd[i] = xreg[j];
         }
     };
 
@@ -1077,15 +1104,20 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN >= 8 ? 1 : 2) void conv1d_mfm
             const int p = tid + j * NT;
             if (p < xw) {
                 bf16x8d h1, h2, h3;
+                if (a.alpha) {
+                    float al[8], ral[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int cig = c * CI_T + e;
+                        if (a.alpha_tab) { al[e] = als[cig]; ral[e] = als[cin_pad + cig]; }
+                        else { al[e] = cig < a.cin ? a.alpha[cig] : 1.0f; ral[e] = 1.0f / al[e]; }
+                    }
+                    snake_vec<8>(xreg[j], al, ral);  // snake(0) == 0: zero padding is preserved
+                }
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    float v = xreg[j][e];
-                    if (a.alpha) {
-                        const int cig = c * CI_T + e;
-                        v = snake_ch(v, cig, a.cin, cin_pad, als, a.alpha, a.alpha_tab);  // snake(0) == 0: zero padding is preserved
-                    }
                     __bf16 b1, b2, b3;
-                    split_bf16x3(v, b1, b2, b3);
+                    split_bf16x3(xreg[j][e], b1, b2, b3);
                     h1[e] = b1; h2[e] = b2; h3[e] = b3;
                 }
                 *(bf16x8d *) (xd + p * 8) = h1;
@@ -1231,15 +1263,18 @@ __global__ __launch_bounds__(64 * WM * WN, (KT == 1 && MI == 3) ? 2 : 1) void co
             const int q = u / xw, p = u - q * xw;
             if (q < QG) {
                 half8d h;
+                if (a.alpha) {
+                    float al[8], ral[8];
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    float v = xreg[j][e];
-                    if (a.alpha) {
+                    for (int e = 0; e < 8; e++) {
                         const int cig = c * CI_T + q * 8 + e;
-                        v = snake_ch(v, cig, a.cin, cin_pad, als, a.alpha, a.alpha_tab);  // snake(0) == 0: zero padding is preserved
+                        if (a.alpha_tab) { al[e] = als[cig]; ral[e] = als[cin_pad + cig]; }
+                        else { al[e] = cig < a.cin ? a.alpha[cig] : 1.0f; ral[e] = 1.0f / al[e]; }
                     }
-                    h[e] = (_Float16) v;                               // the fp16 im2col
+                    snake_vec<8>(xreg[j], al, ral);  // snake(0) == 0: zero padding is preserved
                 }
+#pragma unroll
+                for (int e = 0; e < 8; e++) h[e] = (_Float16) xreg[j][e];   // the fp16 im2col
                 *(half8d *) (xd + p * XS + q * 8) = h;
             }
         }
@@ -1377,15 +1412,18 @@ __global__ __launch_bounds__(64 * WM * WN, CONVT_MIN_WAVES) void convt1d_mfma16_
             const int q = u / xw, p = u - q * xw;
             if (q < QG) {
                 half8d h;
+                if (a.alpha) {
+                    float al[8], ral[8];
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    float v = xreg[j][e];
-                    if (a.alpha) {
+                    for (int e = 0; e < 8; e++) {
                         const int cig = c * CI_T + q * 8 + e;
-                        v = snake_ch(v, cig, a.cin, cin_pad, als, a.alpha, a.alpha_tab);
+                        if (a.alpha_tab) { al[e] = als[cig]; ral[e] = als[cin_pad + cig]; }
+                        else { al[e] = cig < a.cin ? a.alpha[cig] : 1.0f; ral[e] = 1.0f / al[e]; }
                     }
-                    h[e] = (_Float16) v;
+                    snake_vec<8>(xreg[j], al, ral);
                 }
+#pragma unroll
+                for (int e = 0; e < 8; e++) h[e] = (_Float16) xreg[j][e];
                 *(half8d *) (xd + p * XS + q * 8) = h;
             }
         }

@@ -319,9 +319,11 @@ struct tts_hip_ctx {
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
     std::map<size_t, __bf16 *> packed_b3;   // k = 7 conv weights as three bf16 planes (dac_b3, experiment)
     std::map<size_t, __bf16 *> packed_ru;   // residual unit (keyed by its k = 7 weight) -> stage stream of resunit_b3_kernel
+    std::map<size_t, __bf16 *> packed_ct;   // transposed conv weight -> bf16 planes of convt_b3_kernel
+    int dac_convt_b3 = 1;       // TTS_HIP_DAC_CONVT_B3=0: the transposed convs stay on the exact-fp32 MFMA kernel
     int dac_fuse = 1;           // TTS_HIP_DAC_FUSE=0: residual units at 96 / 192 channels stay two launches (k = 7 conv, k = 1 conv + residual)
-    int dac_b3_variant = 0;     // TTS_HIP_DAC_B3_VARIANT: tile shape of the 64-channel class of the experiment
-    int dac_b3 = 0;             // TTS_HIP_DAC_BF16X3 (experiment, off): k = 7 convs of F32 tensors as six bf16 MFMAs per product (conv1d_mfma_b3_kernel); 1 = the layers with 64-channel tiles (measured, tested), 2 = also the 96-channel tile (written after the GPU budget of round 2 was spent: never run)
+    int dac_b3_variant = 2;     // TTS_HIP_DAC_B3_VARIANT: tile shape of the 64-channel class of the experiment
+    int dac_b3 = 2;             // TTS_HIP_DAC_BF16X3 (default 2 since round 3; 0 = exact-fp32 MFMA convs): k = 7 convs of F32 tensors as six bf16 MFMAs per product (conv1d_mfma_b3_kernel); 1 = the layers with 64-channel tiles (measured, tested), 2 = also the 96-channel tile (written after the GPU budget of round 2 was spent: never run)
     bool kk_lstm_split = true;  // TTS_HIP_KOKORO_LSTM_SPLIT=0: the bidirectional LSTMs through the one-workgroup-per-direction kernel
     char *kk_pool = nullptr;    // Kokoro scratch pool (KScratch): grows to the largest call
     size_t kk_pool_cap = 0, kk_pool_next = 0;
@@ -416,6 +418,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_DAC_BF16X3")) c->dac_b3 = std::max(0, atoi(e));
     if (const char *e = getenv("TTS_HIP_DAC_B3_VARIANT")) c->dac_b3_variant = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_FUSE")) c->dac_fuse = atoi(e);
+    if (const char *e = getenv("TTS_HIP_DAC_CONVT_B3")) c->dac_convt_b3 = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
@@ -467,6 +470,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (auto &pw : c->packed16) free_dev(pw.second);
     for (auto &pw : c->packed_b3) free_dev(pw.second);
     for (auto &pw : c->packed_ru) free_dev(pw.second);
+    for (auto &pw : c->packed_ct) free_dev(pw.second);
     if (c->h_ids) (void) hipHostFree(c->h_ids);
     if (c->h_pos) (void) hipHostFree(c->h_pos);
     if (c->h_seq) (void) hipHostFree(c->h_seq);
@@ -2494,6 +2498,26 @@ static int pack_resunit(tts_hip_ctx *c, const DRes &r, int C) {
     c->packed_ru[r.in_w] = dst;
     return 0;
 }
+// transposed convs as bf16 x 3 products (convt_b3_kernel): 32 MI output channels per workgroup
+static int convt_b3_tile(int cout, int cin, int s) {
+    if (cin % 16) return 0;
+    if (s == 8 && cout % 32 == 0) return 32;
+    if (s == 4 && cout % 64 == 0) return 64;
+    if (s == 2 && cout % 96 == 0) return 96;
+    return 0;
+}
+static int pack_convt_b3(tts_hip_ctx *c, const DBlock &b) {
+    const int CO_T = convt_b3_tile(b.cout, b.cin, b.stride);
+    if (!CO_T) return 0;
+    const int n_chunks = b.cin / 16;
+    const size_t n = (size_t) (b.cout / CO_T) * n_chunks * 3 * 2 * b.stride * 2 * CO_T * 8;
+    __bf16 *dst = nullptr;
+    HIPCHK(hipMalloc((void **) &dst, n * 2));
+    hipLaunchKernelGGL(pack_convt_w_b3_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + b.w), dst, b.cout, b.cin, b.stride, CO_T, n_chunks);
+    HIPCHK(hipGetLastError());
+    c->packed_ct[b.w] = dst;
+    return 0;
+}
 #define CI16_K7 16
 #define CI16_K1 32
 #define CI16_T  16
@@ -2518,6 +2542,7 @@ static int ensure_packed(tts_hip_ctx *c) {
     if (c->dac_b3 && c->d_c0 % 64 == 0) CHK(pack_one_b3(c, c->d_initw, c->d_c0, c->d_latent, 64));
     for (auto &b : c->dblocks) {
         if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, CI32_T, true));
+        if (c->dac_convt_b3) CHK(pack_convt_b3(c, b));
         for (int r = 0; r < 3; r++) {
             if (c->dac_fuse) CHK(pack_resunit(c, b.res[r], b.cout));
             if (c->dac_b3 && b.cout % 64 == 0) CHK(pack_one_b3(c, b.res[r].in_w, b.cout, b.cout, 64));
@@ -2748,9 +2773,32 @@ static int launch_convt_mfma(tts_hip_ctx *c, const ConvTArgs &a_in, int nz) {
     return 0;
 }
 
+template <int S, int MI>
+static int launch_convt_b3(tts_hip_ctx *c, const ConvTArgs &a, int nz) {
+    constexpr int CO_T = 32 * MI, WPL = 2 * S * 2 * CO_T * 8, xpl = 2 * 257 * 8;
+    const size_t lds = (size_t) 6 * WPL * 2 + (size_t) 6 * xpl * 2 + (size_t) a.cin * 8;
+    if (lds > 160 * 1024) return set_err("convt_b3: %d input channels need %zu bytes of LDS", a.cin, lds);
+    static std::atomic<uint64_t> attr{0};
+    if (attr_needed(attr, c->device)) {
+        HIPCHK(hipFuncSetAttribute((const void *) convt_b3_kernel<S, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    const dim3 grid((a.L + 1 + 255) / 256, a.cout / CO_T, nz);  // ti runs 0..L inclusive
+    hipLaunchKernelGGL((convt_b3_kernel<S, MI>), grid, dim3(512), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int launch_convt(tts_hip_ctx *c, ConvTArgs ta, size_t w_off, int nz) {
     const bool valu = (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) != 0;
     const int s = ta.stride;
+    auto pct = c->packed_ct.find(w_off);
+    if (!valu && !c->dac_f16 && c->dac_convt_b3 && pct != c->packed_ct.end() && (size_t) 6 * (2 * s * 2 * convt_b3_tile(ta.cout, ta.cin, s) * 8) * 2 + 6 * 2 * 257 * 8 * 2 + (size_t) ta.cin * 8 <= 160 * 1024) {
+        ta.w = (const float *) pct->second;
+        ta.x_f16 = 0;
+        if (s == 8) return launch_convt_b3<8, 1>(c, ta, nz);
+        if (s == 4) return launch_convt_b3<4, 2>(c, ta, nz);
+        return launch_convt_b3<2, 3>(c, ta, nz);
+    }
     int CO_T = 0;
     const int cfg = valu ? -1 : convt_tile(ta.cout, s, &CO_T);
     ta.x_f16 = c->dac_f16 ? 1 : 0;
