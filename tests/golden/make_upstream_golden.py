@@ -1,0 +1,346 @@
+#!/usr/bin/env python3
+"""Golden vectors from implementations this repository did NOT write (build container only; the .npz files are committed, this
+script never travels to a GPU box and nothing under tests/ imports transformers or /root/reference at test time).
+
+The oracle (oracle/*.c) restates the reference's graphs; its float results were so far pinned only to tests/golden/make_golden.py, a
+second restatement by the same author.  Here every model family is instantiated from the library the reference's converters
+(/root/reference/py-gguf/tts_encoders/*.py) convert FROM — Hugging Face `transformers` — with tiny seeded dimensions, run in float64,
+and its weights are exported under the converters' tensor names and layout rules into the same container the GGUF writer takes.
+tests/test_upstream_golden.py feeds those tensors to the oracle and compares.
+
+  family            upstream class (the converter's source)                      converter rules followed (file:line)
+  orpheus           transformers LlamaForCausalLM, llama3 rope scaling            orpheus_gguf_encoder.py:118-122 (names), :145-173 (rope factors)
+  t5 encoder        transformers T5EncoderModel (gated-gelu = flan)               t5_encoder_gguf_encoder.py:62-80
+  dac               transformers DacModel decoder + residual VQ from_codes        dac_gguf_encoder.py:7-35 (names), :43-110; weight norm folded by the
+                                                                                  reference's own tensor_util.get_regularized_weight (imported from
+                                                                                  /root/reference/py-gguf/tts_encoders/tensor_util.py, torch only)
+  parler decoder    transformers MusicgenForCausalLM (Parler-TTS' decoder is a    parler_tts_gguf_encoder.py:112-130
+                    fork of it: same modules and parameter names; parler_tts
+                    itself is not installed here)
+
+Intentional divergences of the REFERENCE from these upstream models, each visible in the numbers this script prints and stored in the
+fixtures (the tests assert them):
+  * T5 relative position buckets: t5/model.cpp:303-316 takes log of the INTEGER quotient |d| / max_exact, HF of the float quotient — equal
+    for |d| < 8 and at |d| = 8, 16, 32, 64, different elsewhere.  The fixture holds HF's output for a 7-token input (identical buckets),
+    and for a 24-token input both HF's own output and HF's output with the reference's bucket formula patched in.
+  * GELU: the reference evaluates tanh-GELU (ggml_gelu) where Parler-TTS' config asks for erf-GELU; the Musicgen twin is configured with
+    gelu_pytorch_tanh so that the comparison isolates everything else, and the erf variant's distance is recorded.
+  * snake: HF's Snake1d divides by (alpha + 1e-9), snake_1d (src/util.cpp:96-101) by alpha: 1e-9 relative, below fp32 resolution.
+Run:  python tests/golden/make_upstream_golden.py        (writes tests/golden/upstream_*.npz)
+"""
+import importlib.util
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_UTIL = "/root/reference/py-gguf/tts_encoders/tensor_util.py"
+
+
+def npy(t):
+    return t.detach().to(torch.float64).cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KB)")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def make_orpheus():
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(1001)
+    kw = dict(vocab_size=200, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+              head_dim=128, max_position_embeddings=131072, rms_norm_eps=1e-5, attention_bias=False, mlp_bias=False, tie_word_embeddings=False)
+    rope = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192, rope_theta=500000.0)
+    try:
+        cfg = LlamaConfig(**kw, rope_parameters=rope)
+    except TypeError:
+        cfg = LlamaConfig(**kw, rope_theta=500000.0, rope_scaling={k: v for k, v in rope.items() if k != "rope_theta"})
+    model = LlamaForCausalLM(cfg).double().eval()
+    with torch.no_grad():   # norms away from 1 so that their placement matters
+        for n, p in model.named_parameters():
+            if "norm" in n:
+                p.copy_(1.0 + 0.1 * torch.randn_like(p))
+    tensors = {}
+    for name, param in model.model.named_parameters():              # orpheus_gguf_encoder.py:118-121
+        tensors[f"orpheus.{name[:-7]}"] = npy(param).astype(np.float32)
+    tensors["orpheus.lm_head"] = npy(model.lm_head.weight).astype(np.float32)   # :122
+    # :145-173 prepare_rope_frequencies, as written there
+    base, dim = 500000.0, 128
+    freqs = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+    factor, low, high, old = 8.0, 1.0, 4.0, 8192
+    lw, hw = old / low, old / high
+    rf = []
+    for f in freqs:
+        wl = 2 * math.pi / f
+        if wl < hw:
+            rf.append(1)
+        elif wl > lw:
+            rf.append(factor)
+        else:
+            smooth = (old / wl - low) / (high - low)
+            rf.append(1 / ((1 - smooth) / factor + smooth))
+    tensors["orpheus.rope_frequencies"] = np.array([float(x) for x in rf], dtype=np.float32)
+
+    # the converter exports fp32: run the upstream model on the fp32-rounded weights, in float64
+    with torch.no_grad():
+        for name, param in model.named_parameters():
+            param.copy_(param.to(torch.float32).to(torch.float64))
+    rng = np.random.default_rng(7)
+    n = 2304   # beyond 2048 positions: the llama3 low-frequency scaling is visible in the logits
+    ids = rng.integers(0, 200, n)
+    with torch.no_grad():
+        out = model(torch.tensor(ids[None]), output_hidden_states=True)
+    logits = npy(out.logits[0])
+    hidden = npy(out.hidden_states[-1][0])   # after the final norm
+    save("upstream_orpheus.npz", ids=ids.astype(np.uint32), logits_last=logits[-1], logits_at_40=logits[40], hidden_rows=hidden[[0, 40, n - 1]],
+         hidden_row_index=np.array([0, 40, n - 1]), cfg=np.array([64, 2, 2, 1, 128, 128, 200]),
+         **{"t:" + k: v for k, v in tensors.items()})
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def reference_bucket(rel, n_buckets_total=32):
+    """t5/model.cpp:303-316 as written (rpos = i - ii = key - query)"""
+    n_buckets = n_buckets_total // 2
+    max_exact = n_buckets // 2
+    den = float(np.float32(math.log(128.0 / max_exact)))   # `float logarithmic_denominator` (:309): at |d| = 16..23 the quotient
+    out = np.zeros_like(rel)                                # log(2) / den * 8 = 1.99999999 truncates to 1, not 2
+    for idx, r in np.ndenumerate(rel):
+        ab = abs(int(r))
+        v = ab if ab < max_exact else min(n_buckets - 1, max_exact + int((math.log(ab // max_exact) / den) * max_exact))
+        out[idx] = (n_buckets if r > 0 else 0) + v
+    return out
+
+
+def make_t5():
+    from transformers import T5Config, T5EncoderModel
+    from transformers.models.t5 import modeling_t5
+
+    torch.manual_seed(1002)
+    cfg = T5Config(vocab_size=120, d_model=64, d_kv=16, d_ff=128, num_layers=2, num_heads=4, relative_attention_num_buckets=32,
+                   relative_attention_max_distance=128, feed_forward_proj="gated-gelu", layer_norm_epsilon=1e-6, dropout_rate=0.0)
+    model = T5EncoderModel(cfg).double().eval()
+    proj = torch.nn.Linear(64, 48).double()   # enc_to_dec_proj (t5_encoder_gguf_encoder.py:63-65)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "layer_norm" in n:
+                p.copy_(1.0 + 0.1 * torch.randn_like(p))
+            if "relative_attention_bias" in n:
+                p.copy_(torch.randn_like(p))
+        for p in list(model.parameters()) + list(proj.parameters()):
+            p.copy_(p.to(torch.float32).to(torch.float64))
+    enc = model.encoder
+    t = {"t5encoder.down_proj": proj.weight, "t5encoder.down_proj_bias": proj.bias, "t5encoder.token_embd": enc.embed_tokens.weight,
+         "t5encoder.enc.final_layer_norm": enc.final_layer_norm.weight}
+    for i, layer in enumerate(enc.block):                                                             # :66-80
+        if i == 0:
+            t[f"t5encoder.enc.blk.{i}.attn_rel_b"] = layer.layer[0].SelfAttention.relative_attention_bias.weight
+        sa, ff = layer.layer[0].SelfAttention, layer.layer[1].DenseReluDense
+        t[f"t5encoder.enc.blk.{i}.attn_q"], t[f"t5encoder.enc.blk.{i}.attn_k"] = sa.q.weight, sa.k.weight
+        t[f"t5encoder.enc.blk.{i}.attn_v"], t[f"t5encoder.enc.blk.{i}.attn_o"] = sa.v.weight, sa.o.weight
+        t[f"t5encoder.enc.blk.{i}.attn_norm"] = layer.layer[0].layer_norm.weight
+        t[f"t5encoder.enc.blk.{i}.ffn_up"], t[f"t5encoder.enc.blk.{i}.ffn_gate"] = ff.wi_0.weight, ff.wi_1.weight
+        t[f"t5encoder.enc.blk.{i}.ffn_down"] = ff.wo.weight
+        t[f"t5encoder.enc.blk.{i}.ffn_norm"] = layer.layer[1].layer_norm.weight
+    tensors = {k: npy(v).astype(np.float32) for k, v in t.items()}
+
+    def run(ids):
+        with torch.no_grad():
+            h = model(torch.tensor(ids[None])).last_hidden_state
+            return npy(proj(h)[0])
+
+    rng = np.random.default_rng(8)
+    ids7, ids24 = rng.integers(3, 120, 7), rng.integers(3, 120, 24)
+    out7, out24_hf = run(ids7), run(ids24)
+    # the same upstream model with the reference's bucket formula patched in (everything else HF's)
+    attn = modeling_t5.T5Attention
+    orig = attn._relative_position_bucket
+
+    def patched(relative_position, bidirectional=True, num_buckets=32, max_distance=128):
+        # HF: relative_position = memory_position - query_position (key - query).  The reference's rpos = i - ii with i the KEY and ii the
+        # QUERY position (pos_bucket[i * n + ii] lands on kq's (ne0 = key, ne1 = query) after build_t5_pos_bias' permute): the same sign
+        rel = relative_position.cpu().numpy()
+        return torch.tensor(reference_bucket(rel, num_buckets), dtype=torch.long)
+
+    attn._relative_position_bucket = staticmethod(patched)
+    try:
+        out24_ref = run(ids24)
+        out7_ref = run(ids7)
+    finally:
+        attn._relative_position_bucket = orig
+    print(f"t5: |HF - HF with reference buckets| 7 tokens {np.abs(out7 - out7_ref).max():.2e}, 24 tokens {np.abs(out24_hf - out24_ref).max():.2e} "
+          f"(max |out| {np.abs(out24_hf).max():.2f})")
+    save("upstream_t5.npz", ids7=ids7.astype(np.uint32), ids24=ids24.astype(np.uint32), out7=out7, out24_hf=out24_hf, out24_refbuckets=out24_ref,
+         cfg=np.array([120, 64, 16, 128, 2, 4, 48]), **{"t:" + k: v for k, v in tensors.items()})
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def make_dac():
+    from transformers import DacConfig, DacModel
+
+    spec = importlib.util.spec_from_file_location("ref_tensor_util", REF_UTIL)   # the reference's own weight-norm folding (torch only)
+    ref_util = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_util)
+
+    torch.manual_seed(1003)
+    strides = [4, 2]
+    cfg = DacConfig(encoder_hidden_size=8, downsampling_ratios=[2, 4], decoder_hidden_size=96, upsampling_ratios=strides, n_codebooks=4,
+                    codebook_size=64, codebook_dim=8, hidden_size=64, sampling_rate=44100)
+    model = DacModel(cfg).double().eval()
+    dec, qz = model.decoder, model.quantizer
+    # descript-audio-codec checkpoints (what dac_gguf_encoder.py reads) carry weight_g / weight_v: old-style weight norm on every conv
+    convs = [dec.conv1, dec.conv2] + [q.out_proj for q in qz.quantizers]
+    for blk in dec.block:
+        convs += [blk.conv_t1] + [c for ru in (blk.res_unit1, blk.res_unit2, blk.res_unit3) for c in (ru.conv1, ru.conv2)]
+    for c in convs:
+        torch.nn.utils.weight_norm(c)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("weight_g"):
+                p.mul_(0.5 + torch.rand_like(p))        # g != |v|: the fold matters
+            if n.endswith("alpha"):
+                p.copy_(0.5 + 1.5 * torch.rand_like(p))
+            if n.endswith("bias"):
+                p.copy_(0.1 * torch.randn_like(p))
+    # tensor names: the converter's part maps (dac_gguf_encoder.py:7-35) applied to the same ROLES in HF's module tree
+    t = {}
+
+    def folded(module, prefix, modules):
+        return ref_util.get_regularized_weight(modules, prefix + ".weight_g")   # dac_gguf_encoder.py:53-56
+
+    mods = {n: m for n, m in dec.named_modules()}
+    t["audio_encoder.initial.weight"], t["audio_encoder.initial.bias"] = folded(dec.conv1, "conv1", mods), dec.conv1.bias
+    for bi, blk in enumerate(dec.block):
+        p = f"audio_encoder.decoder_block.{bi + 1}."
+        t[p + "final.alpha"] = blk.snake1.alpha
+        t[p + "final.weight"], t[p + "final.bias"] = folded(blk.conv_t1, f"block.{bi}.conv_t1", mods), blk.conv_t1.bias
+        for r, ru in enumerate((blk.res_unit1, blk.res_unit2, blk.res_unit3)):
+            q = p + f"residual_unit.{r}.res."
+            t[q + "initial.alpha"], t[q + "final.alpha"] = ru.snake1.alpha, ru.snake2.alpha
+            t[q + "initial.weight"], t[q + "initial.bias"] = folded(ru.conv1, f"block.{bi}.res_unit{r + 1}.conv1", mods), ru.conv1.bias
+            t[q + "final.weight"], t[q + "final.bias"] = folded(ru.conv2, f"block.{bi}.res_unit{r + 1}.conv2", mods), ru.conv2.bias
+    t["audio_encoder.final.alpha"] = dec.snake1.alpha
+    t["audio_encoder.final.weight"], t["audio_encoder.final.bias"] = folded(dec.conv2, "conv2", mods), dec.conv2.bias
+    qmods = {n: m for n, m in qz.named_modules()}
+    for i, q in enumerate(qz.quantizers):                                      # dac_gguf_encoder.py:82-97: audio_encoder.<quantizer name>
+        p = f"audio_encoder.quantizers.{i}."
+        t[p + "codebook.weight"] = q.codebook.weight
+        t[p + "out_proj.weight"], t[p + "out_proj.bias"] = folded(q.out_proj, f"quantizers.{i}.out_proj", qmods), q.out_proj.bias
+    tensors = {k: npy(v).astype(np.float32) for k, v in t.items()}
+    # upstream forward on the exported (fp32-rounded, folded) weights: remove the weight norm and write them back
+    for c in convs:
+        torch.nn.utils.remove_weight_norm(c)
+    with torch.no_grad():
+        for p_ in model.parameters():
+            p_.copy_(p_.to(torch.float32).to(torch.float64))
+    rng = np.random.default_rng(9)
+    frames = 11
+    codes = rng.integers(0, 64, (frames, 4))
+    stages = {}
+    with torch.no_grad():
+        z = qz.from_codes(torch.tensor(codes.T[None]))[0]
+        stages["stage0"] = npy(z[0])
+        h = dec.conv1(z)
+        stages["stage1"] = npy(h[0])
+        for bi, blk in enumerate(dec.block):
+            h = blk(h)
+            stages[f"stage{2 + bi}"] = npy(h[0])
+        pcm = npy(dec.tanh(dec.conv2(dec.snake1(h)))[0, 0])
+        pcm_api = npy(model.decode(audio_codes=torch.tensor(codes.T[None])).audio_values.reshape(-1))
+    assert np.abs(pcm - pcm_api).max() < 1e-12, "stage-by-stage walk differs from DacModel.decode"
+    save("upstream_dac.npz", codes=codes.astype(np.uint32), pcm=pcm, strides=np.array(strides), cfg=np.array([64, 8, 64, 96, 4]), **stages,
+         **{"t:" + k: v for k, v in tensors.items()})
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def make_parler():
+    from transformers import MusicgenDecoderConfig, MusicgenForCausalLM
+
+    torch.manual_seed(1004)
+    H, NCB, V, L, F, HEADS, ENC, PV = 64, 4, 80, 2, 128, 4, 6, 160
+
+    def build(act):
+        torch.manual_seed(1004)
+        cfg = MusicgenDecoderConfig(vocab_size=V, hidden_size=H, num_hidden_layers=L, ffn_dim=F, num_attention_heads=HEADS, num_codebooks=NCB,
+                                    max_position_embeddings=128, activation_function=act, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
+                                    layerdrop=0.0, scale_embedding=False, audio_channels=1, pad_token_id=V, bos_token_id=V + 1, tie_word_embeddings=False)
+        m = MusicgenForCausalLM(cfg).double().eval()
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if "layer_norm" in n and n.endswith("weight"):
+                    p.copy_(1.0 + 0.1 * torch.randn_like(p))
+                elif "layer_norm" in n:
+                    p.copy_(0.1 * torch.randn_like(p))
+                else:
+                    p.copy_(0.08 * torch.randn_like(p))
+            for p in m.parameters():
+                p.copy_(p.to(torch.float32).to(torch.float64))
+        return m
+
+    model = build("gelu_pytorch_tanh")
+    dec = model.model.decoder
+    gen = torch.Generator().manual_seed(5)
+    embed_prompts = (0.05 * torch.randn(PV, H, generator=gen, dtype=torch.float64)).to(torch.float32).to(torch.float64)
+    text_enc = (0.5 * torch.randn(ENC, H, generator=gen, dtype=torch.float64)).to(torch.float32).to(torch.float64)
+    t = {"decoder.embed_prompts": embed_prompts, "decoder.text_encoding": text_enc}
+    t["decoder.positional_embed"] = dec.embed_positions.weights                       # parler_tts_gguf_encoder.py:116-117
+    for name, param in dec.named_parameters():                                      # :118-120
+        t[f"decoder.{name}"] = param
+    for name, param in model.lm_heads.named_parameters():                           # :121-128
+        t[f"decoder.lm_heads.{name}.head"] = param
+    tensors = {k: npy(v).astype(np.float32) for k, v in t.items()}
+
+    rng = np.random.default_rng(10)
+    prompt = rng.integers(3, PV, 5)
+    steps = 6
+    audio = rng.integers(0, 64, (steps, NCB))       # ids fed at every audio step (teacher forcing; no delay pattern here: the graph only)
+
+    def run(m):
+        """prompt embeddings in front of the summed codebook embeddings, positions 0 .. n - 1 over the whole sequence (what Parler-TTS'
+        forward does with prompt_hidden_states).  MusicgenDecoder.forward cannot express that (with inputs_embeds it gives every token
+        position 0), so the embedding sum and the position add are done here and everything after them — the decoder layers, the final
+        LayerNorm, the heads — is upstream's code."""
+        d = m.model.decoder
+        with torch.no_grad():
+            pe = embed_prompts[torch.tensor(prompt)]
+            ae = sum(d.embed_tokens[c](torch.tensor(audio[:, c])) for c in range(NCB))
+            x = torch.cat([pe, ae], 0)[None]
+            T = x.shape[1]
+            x = x + d.embed_positions.weights[:T].to(x.dtype)[None]
+            mask = torch.full((T, T), float("-inf"), dtype=x.dtype).triu(1)[None, None]
+            for layer in d.layers:
+                x = layer(x, attention_mask=mask, encoder_hidden_states=text_enc[None])
+                x = x[0] if isinstance(x, tuple) else x
+            hid = d.layer_norm(x)[0]
+            logits = torch.stack([head(hid) for head in m.lm_heads], 0)            # [NCB][T][V]
+        return npy(hid), npy(logits)
+
+    def run_api(m):
+        """audio ids only, through MusicgenForCausalLM's own forward (embedding sum and positions upstream's too)"""
+        with torch.no_grad():
+            ids = torch.tensor(audio.T.reshape(1 * NCB, -1))       # (batch * codebooks, T)
+            out = m(input_ids=ids, encoder_hidden_states=text_enc[None])
+        return npy(out.logits.reshape(1, NCB, audio.shape[0], V)[0])               # [NCB][T][V]
+
+    hid, logits = run(model)
+    # distance of the erf-GELU variant (what the Parler-TTS config asks for) from the tanh-GELU the reference evaluates
+    m2 = build("gelu")
+    m2.load_state_dict(model.state_dict())
+    _, logits_erf = run(m2)
+    print(f"parler twin: |tanh-GELU - erf-GELU| logits {np.abs(logits - logits_erf).max():.2e} (max |logit| {np.abs(logits).max():.2f})")
+    logits_api = run_api(model)
+    save("upstream_parler.npz", prompt=prompt.astype(np.uint32), audio=audio.astype(np.uint32), hidden=hid, logits=logits, logits_erf_gelu=logits_erf,
+         logits_audio_only_api=logits_api,
+         cfg=np.array([H, L, HEADS, F, V, NCB, ENC, PV]), **{"t:" + k: v for k, v in tensors.items()})
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["orpheus", "t5", "dac", "parler"]
+    for w in which:
+        {"orpheus": make_orpheus, "t5": make_t5, "dac": make_dac, "parler": make_parler}[w]()
