@@ -49,6 +49,10 @@ int           tts_c_generate_batch(tts_c_runner *r, const char *const *texts, in
  * 0), lock-step KV slots (0: TTS_HIP_MAX_SEQS or 1), declare_only != 0: lay the model out without uploading its bytes — the weights
  * then arrive in tts_hip_arena_ptr(tts_c_runner_device_context(r)) by a collective and tts_hip_arena_filled() marks them present. */
 void          tts_c_set_load_options(int device, int max_seqs, int declare_only);
+/* the same plus share_with (tts_load_options::share_with): a loaded runner of the same model on the same device whose weight arena the
+ * next runner uses instead of uploading its own (own KV cache, own stream, own voice prompt once it is updated); the reference's server
+ * loads the file once per worker (examples/server/server.cpp:316-321) */
+void          tts_c_set_load_options_ex(int device, int max_seqs, int declare_only, tts_c_runner *share_with);
 /* the runner's tts_hip_ctx* (include/tts_hip.h: arena, profiling), or NULL when the architecture keeps several contexts */
 void         *tts_c_runner_device_context(tts_c_runner *r);
 /* the loaded runner's own tokenizer (Parler: unigram ids + EOS as batch_from_sentence builds them); returns the id count */

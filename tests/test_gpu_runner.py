@@ -9,7 +9,7 @@ import pytest
 
 import oracle as orc
 import tokenizer_oracle
-from tts_cpp_amd import gguf, runner, synth
+from tts_cpp_amd import gguf, hip, runner, synth
 from tts_cpp_amd.pattern import undelay
 
 pytestmark = pytest.mark.gpu
@@ -230,6 +230,42 @@ def test_update_conditional_prompt_runs_the_t5_encoder(tmp_path):
     with pytest.raises(runner.RunnerError):
         r.update_conditional_prompt(bad, "x")
     r.close()
+
+
+def test_shared_arena_runners_keep_their_own_voice_prompt(tmp_path):
+    """Runners of one device share ONE weight arena (tts_load_options::share_with); the voice prompt and the cross K/V computed from it
+    are per runner once updated: a new prompt on one runner leaves its siblings' audio — also of a generation already under way — on the
+    prompt they started with, as the reference's one-model-per-worker server does (server.cpp:316-321).  Round 2 kept both inside the
+    shared arena (ADVICE: a sibling mid-generation would have read a mix of old and new cross K/V)."""
+    import threading
+    cfg = synth.tiny(weight_type=gguf.F32)
+    path = synth.build(cfg).write_gguf(str(tmp_path / "m.gguf"))
+    t5_path = synth.build_t5(synth.t5_tiny(vocab=cfg.prompt_vocab, output_size=cfg.hidden)).write_gguf(str(tmp_path / "t5.gguf"))
+    a = runner.Runner(path, sample=0)
+    b = runner.Runner(path, sample=0, share_with=a)
+    L = hip.load_lib()
+    assert L.tts_hip_arena_ptr(a.device_context()) == L.tts_hip_arena_ptr(b.device_context())
+    text = "hello there"
+    before = a.generate(text)
+    assert np.array_equal(b.generate(text), before)
+    b.update_conditional_prompt(t5_path, "a calm low voice")
+    after_b = b.generate(text)
+    assert not np.array_equal(after_b, before)
+    assert np.array_equal(a.generate(text), before), "the owner of the arena must not see its sibling's new prompt"
+    # the owner changes its prompt too: the sharer keeps its own
+    a.update_conditional_prompt(t5_path, "a bright fast voice")
+    after_a = a.generate(text)
+    assert not np.array_equal(after_a, before) and not np.array_equal(after_a, after_b)
+    assert np.array_equal(b.generate(text), after_b)
+    # an update on one runner while the other generates: the generation under way is unaffected
+    res = {}
+    th = threading.Thread(target=lambda: res.setdefault("a", a.generate_batch([text] * 1)[0]))
+    th.start()
+    b.update_conditional_prompt(t5_path, "yet another voice")
+    th.join()
+    assert np.array_equal(res["a"], after_a)
+    b.close()
+    a.close()
 
 
 def test_device_pool_conditional_prompt_changes_every_worker(tmp_path):

@@ -231,12 +231,16 @@ __global__ __launch_bounds__(256) void kk_lstm_split_kernel(LstmArgs a) {
                 for (;;) {
                     v = __hip_atomic_load(slot + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((unsigned) (v >> 32) == (unsigned) idx) break;
-                    if (++spins > (1 << 22)) { *a.stuck = 1; break; }
+                    // a peer that is never co-resident: give up once, for the whole launch — every workgroup sees the flag in its own spin
+                    // and leaves, instead of spinning out 2^22 polls per granule and time step (minutes) with a garbage state
+                    if (++spins > (1 << 22)) { __hip_atomic_store(a.stuck, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if ((spins & 1023) == 0 && __hip_atomic_load(a.stuck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
                 kk_h[j] = __uint_as_float((unsigned) v);
             }
         }
+        if (idx > 0 && __syncthreads_or(__hip_atomic_load(a.stuck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) return;   // fail fast (the host reports kk_stuck)
         __syncthreads();
         float acc = 0.0f;
 #pragma unroll

@@ -187,6 +187,13 @@ struct tts_hip_ctx {
     int H = 0, L = 0, NH = 0, F = 0, V = 0, NO = 0, NCTX = 0, E = 0, ECAP = 0, PV = 0, EROWS = 0, NPOS = 0, KVPOS = 0;
     W embed_prompts, embed_tokens, heads;
     size_t pos_embed = 0, text_enc = 0, ln_w = 0, ln_b = 0, cross_kv = 0;
+    // The voice-prompt encoding and the cross K/V computed from it are the only arena entries that change after load
+    // (tts_hip_parler_set_text_encoding).  Contexts of one device may share an arena (tts_hip_finalize(ctx, arena of another context)),
+    // so a context that gets a new prompt moves both into allocations of its own and the arena stays immutable: a sibling in the middle
+    // of a generation keeps reading the prompt it started with (the reference keeps a whole model per worker, server.cpp:316-321).
+    char *cond_text_enc = nullptr, *cond_cross_kv = nullptr;   // private copies, or NULL = the arena's
+    char *text_enc_ptr() const { return cond_text_enc ? cond_text_enc : arena + text_enc; }
+    char *cross_kv_ptr() const { return cond_cross_kv ? cond_cross_kv : arena + cross_kv; }
     std::vector<PLayer> layers;
 
     // dac model
@@ -469,6 +476,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (auto &pw : c->packed) free_dev(pw.second);
     for (auto &pw : c->packed16) free_dev(pw.second);
     for (auto &pw : c->packed_b3) free_dev(pw.second);
+    free_dev(c->cond_text_enc); free_dev(c->cond_cross_kv);
     for (auto &pw : c->packed_ru) free_dev(pw.second);
     for (auto &pw : c->packed_ct) free_dev(pw.second);
     if (c->h_ids) (void) hipHostFree(c->h_ids);
@@ -1577,8 +1585,8 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
             CHK(run_gemm(c, TTS_HIP_K_GEMM_CROSS_Q, y.cq, gq, PRO_LN, EPI_STORE));
             AttnArgs ac{};
             ac.q = c->q;
-            ac.kc = c->arena + c->cross_kv + ((size_t) l * 2 + 0) * c->ECAP * H * 4;
-            ac.vc = c->arena + c->cross_kv + ((size_t) l * 2 + 1) * c->ECAP * H * 4;
+            ac.kc = c->cross_kv_ptr() + ((size_t) l * 2 + 0) * c->ECAP * H * 4;
+            ac.vc = c->cross_kv_ptr() + ((size_t) l * 2 + 1) * c->ECAP * H * 4;
             ac.kv_f16 = 0; ac.seq_stride = 0; ac.row_seq = nullptr; ac.row_pos = nullptr; ac.T_fixed = c->E;
             const bool co_half = y.co.type == TTS_HIP_F16 && !valu_mode && (H % 256 == 0);
             ac.H = H; ac.n_heads = c->NH; ac.scale = at.scale; ac.out = c->att; ac.out16 = co_half ? c->att16 : nullptr; ac.part = c->part;
@@ -1620,8 +1628,8 @@ static int compute_cross_kv(tts_hip_ctx *c) {
             for (int e0 = 0; e0 < c->E; e0 += step) {
                 GemmArgs g{};
                 g.R = std::min(step, c->E - e0); g.H = H;
-                g.A = (const float *) (c->arena + c->text_enc) + (size_t) e0 * H; g.lda = H;
-                g.out = (float *) (c->arena + c->cross_kv + ((size_t) l * 2 + kv) * c->ECAP * H * 4) + (size_t) e0 * H;
+                g.A = (const float *) c->text_enc_ptr() + (size_t) e0 * H; g.lda = H;
+                g.out = (float *) (c->cross_kv_ptr() + ((size_t) l * 2 + kv) * c->ECAP * H * 4) + (size_t) e0 * H;
                 g.ldo = H;
                 CHK(run_gemm(c, TTS_HIP_K_GEMM_OTHER, kv == 0 ? c->layers[l].ck : c->layers[l].cv, g, PRO_F32, EPI_STORE));
             }
@@ -1967,7 +1975,13 @@ extern "C" int tts_hip_parler_set_text_encoding(tts_hip_ctx *c, const float *enc
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     // (stream copies, not hipMemcpy: the legacy stream may not be used while another context captures a graph)
-    HIPCHK(hipMemcpyAsync(c->arena + c->text_enc, enc, (size_t) n_tokens * c->H * 4, hipMemcpyHostToDevice, c->stream));
+    if (!c->cond_text_enc) {   // first new prompt of this context: its own copies from here on, the (possibly shared) arena is never written
+        HIPCHK(hipMalloc((void **) &c->cond_text_enc, (size_t) c->ECAP * c->H * 4));
+        HIPCHK(hipMalloc((void **) &c->cond_cross_kv, (size_t) c->L * 2 * c->ECAP * c->H * 4));
+        HIPCHK(hipMemsetAsync(c->cond_text_enc, 0, (size_t) c->ECAP * c->H * 4, c->stream));
+        HIPCHK(hipMemsetAsync(c->cond_cross_kv, 0, (size_t) c->L * 2 * c->ECAP * c->H * 4, c->stream));
+    }
+    HIPCHK(hipMemcpyAsync(c->text_enc_ptr(), enc, (size_t) n_tokens * c->H * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->E = (int) n_tokens;  // n_encode_length = conditional_prompt->n_outputs (model.cpp:135)
     for (auto &g : c->graphs) (void) hipGraphExecDestroy(g.second);  // E is baked into captured launches
@@ -4537,7 +4551,7 @@ extern "C" int64_t tts_hip_debug_read(tts_hip_ctx *c, const char *what, float *o
         if (sscanf(w.c_str() + 6, "%d:%d", &layer, &kv) != 2 || layer < 0 || layer >= c->L || kv < 0 || kv > 1) { set_err("bad cross spec"); return -1; }
         const size_t n = (size_t) c->E * c->H;
         if (n > max_floats) { set_err("buffer too small"); return -1; }
-        if (hipMemcpy(out, c->arena + c->cross_kv + ((size_t) layer * 2 + kv) * c->ECAP * c->H * 4, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("copy failed"); return -1; }
+        if (hipMemcpy(out, c->cross_kv_ptr() + ((size_t) layer * 2 + kv) * c->ECAP * c->H * 4, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("copy failed"); return -1; }
         return (int64_t) n;
     }
     if (starts_with(w, "dac:")) {

@@ -3,6 +3,7 @@
 #include "../../include/tts_hip.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
 
@@ -38,7 +39,13 @@ device_pool::device_pool(const std::map<std::string, std::string> & model_paths,
 // workers of a device share their device's arena.  Other runners (and the weightless test backend) load per worker as the reference.
 // Placement goes through tts_thread_load_options(), not the environment.
 void device_pool::load_all() {
-    g_tts_throw_on_abort = true;  // a failed load must not abort() the whole server
+    // a failed load must not abort() the whole server; the switch is the embedding application's again once the loads are done
+    // (this runs on the constructing caller's thread)
+    struct abort_guard {
+        bool prev = g_tts_throw_on_abort;
+        abort_guard() { g_tts_throw_on_abort = true; }
+        ~abort_guard() { g_tts_throw_on_abort = prev; }
+    } guard;
     const int nw = opts_.n_workers, nd = (int) opts_.devices.size();
     auto device_of = [&](int w) { return opts_.devices[(size_t) w % (size_t) nd]; };
     auto load = [&](int w, const std::string & path, bool declare, const tts_generation_runner * share) {
@@ -74,9 +81,17 @@ void device_pool::load_all() {
                 if (can_share) ctxs.push_back(states_[(size_t) w]->runners[id]->device_context());
             }
             if (can_share && ctxs.size() > 1) {
-                if (tts_hip_broadcast_weights((tts_hip_ctx **) ctxs.data(), (int) ctxs.size(), 0) != 0)
-                    throw std::runtime_error(std::string("tts_hip_broadcast_weights: ") + tts_hip_last_error());
-                broadcasts_++;
+                if (tts_hip_broadcast_weights((tts_hip_ctx **) ctxs.data(), (int) ctxs.size(), 0) != 0) {
+                    // no usable RCCL on this host (librccl missing, ncclCommInitAll failed, peer access off): every other device parses and
+                    // uploads the file itself, as the reference's server does per worker (server.cpp:316-321)
+                    fprintf(stderr, "device_pool: weight broadcast failed (%s); loading the file once per device instead\n", tts_hip_last_error());
+                    for (const auto & [dev, w] : owner) {
+                        if (w == root_w) continue;
+                        states_[(size_t) w]->runners.erase(id);
+                        states_[(size_t) w]->runners[id] = load(w, path, false, nullptr);
+                    }
+                } else
+                    broadcasts_++;
             }
             for (int w = 0; w < nw; w++) {
                 if (states_[(size_t) w]->runners.count(id)) continue;

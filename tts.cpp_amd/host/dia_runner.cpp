@@ -162,8 +162,10 @@ void dia_adjust_output_tokens(const dia_hparams & hp, const std::vector<uint32_t
     }
 }
 
-// the generation loop on the device (tts_hip_dia_generate): one sampler per utterance, each seeded like a separate generate() call
-// would seed its own, so the U[0,1) draws of call k are the same for every utterance
+// the generation loop on the device (tts_hip_dia_generate).  With a fixed seed every utterance gets the draws a separate generate()
+// call would make (each call seeds its own sampler the same way, so call k draws the same U[0,1) values for every utterance); with
+// seed == 0 (std::random_device per call, the reference's behaviour) separate calls are independently random, so every utterance of the
+// batch draws its own values — as the host loop's per-utterance samplers and the Parler batch path do
 static void dia_device_loop(tts_hip_ctx * lm, const dia_hparams & hp, sampler & proto, uint32_t n, uint32_t max_gen, const generation_configuration & config,
                             std::vector<std::vector<uint32_t>> & tokens) {
     const uint32_t nh = hp.n_output_heads;
@@ -179,8 +181,12 @@ static void dia_device_loop(tts_hip_ctx * lm, const dia_hparams & hp, sampler & 
         sampler s = proto;
         s.seed = config.seed; s.n_calls = 0;
         for (uint32_t k = 0; k < max_gen; k++) {
-            s.draw_uniforms(draw.data());
-            for (uint32_t i = 0; i < n; i++) std::copy(draw.begin(), draw.end(), u.begin() + ((size_t) k * n + i) * nh);
+            if (config.seed != 0) {
+                s.draw_uniforms(draw.data());
+                for (uint32_t i = 0; i < n; i++) std::copy(draw.begin(), draw.end(), u.begin() + ((size_t) k * n + i) * nh);
+            } else {
+                for (uint32_t i = 0; i < n; i++) s.draw_uniforms(u.data() + ((size_t) k * n + i) * nh);   // a fresh random_device draw per utterance
+            }
         }
     }
     if (tts_hip_dia_generate(lm, n, max_gen, &codes, config.sample ? &sp : nullptr, config.sample ? u.data() : nullptr, toks.data(), steps.data()) != 0)

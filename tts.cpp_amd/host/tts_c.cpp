@@ -98,6 +98,10 @@ void tts_c_set_load_options(int device, int max_seqs, int declare_only) {
     o.max_seqs = max_seqs;
     o.declare_only = declare_only != 0;
 }
+void tts_c_set_load_options_ex(int device, int max_seqs, int declare_only, tts_c_runner * share_with) {
+    tts_c_set_load_options(device, max_seqs, declare_only);
+    tts_thread_load_options().share_with = (const tts_generation_runner *) share_with;
+}
 void * tts_c_runner_device_context(tts_c_runner * r) { return r ? ((tts_generation_runner *) r)->device_context() : nullptr; }
 int tts_c_runner_tokenize(tts_c_runner * r, const char * text, uint32_t * out, int cap) {
     g_tts_throw_on_abort = true;

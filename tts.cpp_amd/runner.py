@@ -28,7 +28,7 @@ class SamplerCfg(C.Structure):
 
 EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_generate_batch", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
            "tts_c_last_error", "tts_c_update_conditional_prompt", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor",
-           "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_load_stats", "tts_c_pool_free", "tts_c_set_load_options", "tts_c_runner_device_context", "tts_c_runner_tokenize",
+           "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_load_stats", "tts_c_pool_free", "tts_c_set_load_options", "tts_c_set_load_options_ex", "tts_c_runner_device_context", "tts_c_runner_tokenize",
            "tts_c_quantize_gguf", "tts_c_quantize_decision", "tts_c_quantize_rows",
            "tts_c_dia_tokenize", "tts_c_dia_check_stopping", "tts_c_dia_adjust_output_tokens", "tts_c_single_pass_tokenize", "tts_c_kokoro_chunks"]
 
@@ -92,6 +92,8 @@ def load_lib():
         L.tts_c_pool_free.argtypes = [C.c_void_p]
         L.tts_c_set_load_options.argtypes = [C.c_int, C.c_int, C.c_int]
         L.tts_c_set_load_options.restype = None
+        L.tts_c_set_load_options_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.tts_c_set_load_options_ex.restype = None
         L.tts_c_runner_device_context.argtypes = [C.c_void_p]
         L.tts_c_runner_device_context.restype = C.c_void_p
         L.tts_c_runner_tokenize.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.c_int]
@@ -111,10 +113,12 @@ def make_config(**kw):
 class Runner:
     """runner_from_file() + generate(), as examples/cli/cli.cpp:79-95 uses them."""
 
-    def __init__(self, path, n_threads=1, cpu_only=True, device=-1, max_seqs=0, declare_only=False, **cfg):
+    def __init__(self, path, n_threads=1, cpu_only=True, device=-1, max_seqs=0, declare_only=False, share_with=None, **cfg):
         self.L = load_lib()
         self.cfg = make_config(**cfg)
-        if device >= 0 or max_seqs > 0 or declare_only:
+        if share_with is not None:
+            self.L.tts_c_set_load_options_ex(device, max_seqs, 1 if declare_only else 0, share_with.h)   # use that runner's weight arena
+        elif device >= 0 or max_seqs > 0 or declare_only:
             self.L.tts_c_set_load_options(device, max_seqs, 1 if declare_only else 0)   # tts_load_options of this thread, for this load
         try:
             self.h = self.L.tts_c_runner_from_file(path.encode(), n_threads, C.byref(self.cfg), 1 if cpu_only else 0)
