@@ -9,12 +9,16 @@ for `--batch` utterances per context decoded in lock-step (`--streams` contexts 
 picks the sentences and reads the clock: tokenizer, loop control, un-delay and the codec call are the C++ host's
 (tts.cpp_amd/host/parler_runner.cpp), the compute is the HIP library's (include/tts_hip.h).
 
-Multi-GPU (launched by torch.distributed.run): rank 0's runner parses and uploads the file, the other ranks load it declare-only
-(tts_load_options) and receive the finished weight arena (incl. precomputed cross K/V) by ONE RCCL broadcast; afterwards utterances
+Multi-GPU: `python bench.py --gpus N` starts N ranks itself (re-exec under torch.distributed.run; a launcher that already set WORLD_SIZE is
+used as is) and fails loudly when fewer devices exist.  Rank 0's first runner parses and uploads the file, the first runner of every
+other rank is laid out declare-only (tts_load_options) and receives the finished weight arena (incl. precomputed cross K/V) by ONE RCCL
+broadcast through the C ABI (tts_hip_comm_unique_id + tts_hip_broadcast_weights_rank; examples/server/server.cpp:885-895 is the
+reference's per-worker load), further runners of a rank share their rank's arena (tts_load_options::share_with); afterwards utterances
 are independent, no data-path collective -> "scaling": "weak".
 
 Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit + roofline + cpu_baseline, plus SURVEY §8(d)'s second metric
-(batch-1 ms per decode step at T ~ 128 / 512 / 1024 / 2580, a 1024-step utterance).
+(batch-1 ms per decode step at T ~ 128 / 512 / 1024 / 2580, a 1024-step utterance), `long_utterances` (1024 audio steps per utterance,
+uniform and ragged batches) and `secondary` (short runs of BASELINE configs 2-4).
 """
 import argparse
 import ctypes as C
@@ -36,7 +40,8 @@ from tts_cpp_amd import gguf, hip, runner, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 F32_PEAK_TFLOPS = 157.3   # fp32 vector == fp32-input MFMA peak
-F16_PEAK_TFLOPS = 2516.8  # dense fp16 MFMA = 16 x the fp32 matrix rate (MI355X_MICROARCH.md)
+F16_PEAK_TFLOPS = 2516.8  # dense fp16 / bf16 MFMA = 16 x the fp32 matrix rate (MI355X_MICROARCH.md); with random operands the chip sustains
+                          # 1830 TFLOP/s of v_mfma_f32_32x32x16_bf16 (power-limited clock, profiles/r03/mfma_rate.txt)
 SAMPLE_RATE = 44100.0
 
 # kernel families as rocprofv3 groups them by symbol (profiles/r02/kernel_stats_*.csv): the per-class HIP-event statistics of the shim
@@ -47,14 +52,22 @@ FAMILIES = {
     "attn_kernel (self-attention over the fp32 KV cache)": ["attn_self"],
     "attn_short_kernel (cross-attention over the voice prompt)": ["attn_cross"],
     "ln_rows_kernel (LayerNorm + split-K fold)": ["ln"],
-    "conv1d_mfma_kernel<7,...> (DAC k=7 residual convs)": ["dac_conv7"],
-    "conv1d_mfma_kernel<1,...> (DAC k=1 convs + residual)": ["dac_conv1"],
-    "convt1d_mfma_kernel (DAC transposed convs)": ["dac_convt"],
+    "resunit_b3_kernel (DAC residual units at 96 / 192 channels, one launch each)": ["dac_resunit"],
+    "conv1d_mfma_b3_kernel / conv1d_mfma_kernel<7,...> (DAC k=7 convs of the wide classes)": ["dac_conv7"],
+    "conv1d_mfma_kernel<1,...> (DAC k=1 convs + residual of the wide classes)": ["dac_conv1"],
+    "convt_b3_kernel / convt1d_mfma_kernel (DAC transposed convs)": ["dac_convt"],
     "other (embed, sampler/feed, DAC quantizer + final conv)": ["embed", "sample", "dac_embed", "dac_final"],
 }
 MFMA_FP16 = {"gemm_tile_kernel (decoder GEMMs: qkv, out_proj, cross q/out, fc1, fc2, heads)"}
-MFMA_FP32 = {"conv1d_mfma_kernel<7,...> (DAC k=7 residual convs)", "conv1d_mfma_kernel<1,...> (DAC k=1 convs + residual)",
-             "convt1d_mfma_kernel (DAC transposed convs)"}
+MFMA_FP32 = {"conv1d_mfma_kernel<1,...> (DAC k=1 convs + residual of the wide classes)"}
+# families that run fp32 convolutions as bf16 x 3 split products when the codec arithmetic is on (tts_hip_dac_arith): issued bf16 flops per
+# algorithmic flop = six products, and the k = 7 kernels pad their 7 taps to 8 k-slots
+B3_ISSUE = {"resunit_b3_kernel (DAC residual units at 96 / 192 channels, one launch each)": (6.0 * 8.0 + 6.0) / 8.0,     # 7 of 8 flops in the k = 7 conv
+            "conv1d_mfma_b3_kernel / conv1d_mfma_kernel<7,...> (DAC k=7 convs of the wide classes)": 6.0 * 8.0 / 7.0,
+            "convt_b3_kernel / convt1d_mfma_kernel (DAC transposed convs)": 6.0}
+B3_BIT = {"resunit_b3_kernel (DAC residual units at 96 / 192 channels, one launch each)": 2,
+          "conv1d_mfma_b3_kernel / conv1d_mfma_kernel<7,...> (DAC k=7 convs of the wide classes)": 1,
+          "convt_b3_kernel / convt1d_mfma_kernel (DAC transposed convs)": 4}
 
 
 def log(*a):
@@ -89,7 +102,7 @@ def make_sentences(rn, n, target_ids, seed):
     return out
 
 
-def pmc_traffic(family, args, n_audio):
+def pmc_traffic(family, args, n_audio, arith=0):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     runs, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); None when the committed measurement was taken on a different workload."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -101,6 +114,8 @@ def pmc_traffic(family, args, n_audio):
     if key.startswith("dac_"):  # DAC launches depend only on the utterances per codec pass and the frame count
         if args.dac_wtype != "f32" or w.get("audio_steps") != n_audio or w.get("dac_group") != int(os.environ.get("TTS_HIP_DAC_GROUP", "64")):
             return None
+        if w.get("codec_arith", 0) != arith:   # measured with other codec kernels than the ones this run used
+            return None
     elif w.get("batch") != args.batch or w.get("audio_steps") != n_audio:
         return None
     v = t.get("kernels", {}).get(key)
@@ -108,6 +123,8 @@ def pmc_traffic(family, args, n_audio):
 
 
 _TAIL = "f32 accumulate and residual stream; KV cache f32; DAC codec f32 (exact-f32 MFMA)"
+_B3 = ("DAC codec: F32 tensors, every fp32 operand carried as three bf16 terms and every product as six v_mfma_f32_32x32x16_bf16 partial products "
+       "with fp32 accumulation (fp32-level error, the suite's fp32 tolerances); the k=1 convs of the 768 / 384-channel classes and the final conv on exact-f32 MFMA / VALU")
 DTYPE_DETAIL = {
     "f16": "decoder: f16 weights, f16 MFMA inputs, " + _TAIL,
     "f32": "decoder: f32 weights and activations (exact-f32 MFMA), " + _TAIL,
@@ -206,6 +223,222 @@ def decode_step_sweep(cfg_full, model, arena_ptr, device):
                     "each interval continues the same utterance from the previous one; per_call: tts_hip_parler_step per token + logits D2H + host arg-max"}
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (torch.distributed.run, one process per GPU, rendezvous on
+    127.0.0.1).  Fails loudly when the box has fewer devices (the test hook TTS_BENCH_FORCE_DEVICE puts every rank on one device)."""
+    import torch
+    have = torch.cuda.device_count()
+    if os.environ.get("TTS_BENCH_FORCE_DEVICE") is None and have < n:
+        raise SystemExit(f"bench.py --gpus {n}: this box has {have} GPU(s); refusing to report an n_gpus={n} line from fewer devices")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: starting", n, "ranks:", " ".join(cmd))
+    os.execv(sys.executable, cmd)
+
+
+def load_runners(path, args, rank, world, local_rank, backend, dist, torch, gen_cfg, batch):
+    """`--streams` runners on this rank's device with ONE weight arena per rank: the first runner loads the file (rank 0) or is laid out
+    declare-only and filled by the RCCL broadcast (other ranks); the others share its arena."""
+    L = hip.load_lib()
+    info = None
+    first = runner.Runner(path, device=local_rank, max_seqs=batch, declare_only=(rank != 0), **gen_cfg)
+    if world > 1:
+        ctx = first.device_context()
+        nbytes = int(L.tts_hip_arena_bytes(ctx))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if backend == "nccl":
+            # the C ABI's collective: rank 0 mints the communicator id, every rank joins with its own context
+            ident = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0 and L.tts_hip_comm_unique_id(ident.numpy().ctypes.data_as(C.c_void_p)) != 0:
+                raise RuntimeError(L.tts_hip_last_error().decode())
+            ident = ident.cuda(local_rank)
+            dist.broadcast(ident, src=0)
+            ident = ident.cpu()
+            if L.tts_hip_broadcast_weights_rank(ctx, ident.numpy().ctypes.data_as(C.c_void_p), rank, world, 0) != 0:
+                raise RuntimeError(L.tts_hip_last_error().decode())
+            via = "tts_hip_comm_unique_id + tts_hip_broadcast_weights_rank (RCCL, C ABI)"
+        else:   # CPU-collective test hook (gloo; several ranks on one device, where RCCL cannot form a communicator)
+            arena = torch.as_tensor(ArenaView(L.tts_hip_arena_ptr(ctx), nbytes), device=f"cuda:{local_rank}")
+            tdist.broadcast_arena(arena, src=0)
+            torch.cuda.synchronize()
+            if rank != 0 and L.tts_hip_arena_filled(ctx) != 0:
+                raise RuntimeError(L.tts_hip_last_error().decode())
+            via = f"torch.distributed.broadcast ({backend})"
+        torch.cuda.synchronize()
+        dist.barrier()
+        info = {"bytes": nbytes, "ms": round((time.perf_counter() - t0) * 1e3, 2), "via": via}
+    runners = [first]
+    for _ in range(1, args.streams):
+        runners.append(runner.Runner(path, device=local_rank, max_seqs=batch, share_with=first, **gen_cfg))
+    return runners, info
+
+
+def run_all(runners, texts, timings_=None):
+    res = [None] * len(runners)
+
+    def work(i):
+        try:
+            t0 = time.perf_counter()
+            sizes = runners[i].generate_batch_sizes(texts[i])
+            res[i] = (sum(sizes), time.perf_counter() - t0)
+        except Exception as e:   # surfaced by the caller: a worker thread must not fail silently
+            res[i] = e
+
+    if len(runners) == 1:
+        work(0)
+    else:
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(runners))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    for r in res:
+        if isinstance(r, Exception):
+            raise r
+    if timings_ is not None:
+        timings_.append(float(np.mean([r[1] for r in res])))
+    return sum(r[0] for r in res)
+
+
+def profile_get(L, rn):
+    out = {}
+    for k in range(64):
+        name = L.tts_hip_kclass_name(k).decode()
+        if name == "?":
+            break
+        st = hip.KStat()
+        if L.tts_hip_profile_get(rn.device_context(), k, C.byref(st)) == 0:
+            out[name] = dict(ms_total=st.ms_total, launches=st.launches, bytes_total=st.bytes_total, flops_total=st.flops_total)
+    return out
+
+
+def family_stats(stats):
+    fam = {}
+    for name, keys in FAMILIES.items():
+        a = dict(ms_total=0.0, launches=0, bytes_total=0.0, flops_total=0.0)
+        for k in keys:
+            for f in a:
+                a[f] += stats.get(k, {}).get(f, 0)
+        if a["launches"]:
+            fam[name] = a
+    return fam
+
+
+def roof_of(name, st, src, tot, arith, dac_wtype):
+    """one family against the roofline that bounds it; bf16 x 3 families are priced with the flops they ISSUE against the bf16 pipe,
+    the fp32-equivalent (algorithmic) rate beside it"""
+    per_launch_ms = st["ms_total"] / max(st["launches"], 1)
+    tf = st["flops_total"] / max(st["ms_total"], 1e-9) / 1e9
+    gb = st["bytes_total"] / max(st["ms_total"], 1e-9) / 1e6
+    b3 = name in B3_ISSUE and dac_wtype == "f32" and (arith & B3_BIT[name]) and not (arith & 24)
+    if b3:
+        issued = tf * B3_ISSUE[name]
+        r = {"bound": "mfma", "achieved": round(issued, 3), "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(issued / F16_PEAK_TFLOPS, 4),
+             "fp32_equivalent_TFLOPs": round(tf, 3), "hbm_GBps": round(gb, 1), "hbm_frac": round(gb / HBM_PEAK_GBS, 4),
+             "note": f"fp32 operands as three bf16 terms, six bf16 MFMAs per product, fp32 accumulate: achieved = issued bf16 flops ({B3_ISSUE[name]:.2f} x "
+                     "algorithmic) against the dense bf16 peak; with random operands the pipe sustains 1830 TFLOP/s (power-limited clock, profiles/r03/mfma_rate.txt)"}
+    elif name in MFMA_FP32 or name in MFMA_FP16 or name in B3_ISSUE:
+        peak = F16_PEAK_TFLOPS if (name in MFMA_FP16 or dac_wtype == "f16") else F32_PEAK_TFLOPS
+        r = {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+             "hbm_GBps": round(gb, 1), "hbm_frac": round(gb / HBM_PEAK_GBS, 4)}
+        if peak == F32_PEAK_TFLOPS:
+            r["note"] = "fp32 conv: peak = fp32 vector / fp32-input-MFMA peak (exact-fp32 numerics)"
+    else:
+        r = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 4)}
+    r.update({"kernel": name, "timing_source": src, "avg_launch_us": round(per_launch_ms * 1e3, 3), "launches": st["launches"],
+              "share_of_kernel_time": round(st["ms_total"] / tot, 3),
+              "algorithmic_bytes_per_launch": round(st["bytes_total"] / max(st["launches"], 1), 1),
+              "algorithmic_flops_per_launch": round(st["flops_total"] / max(st["launches"], 1), 1)})
+    return r
+
+
+def long_sentences(rn, n, lo, hi, seed):
+    """`n` pseudo-sentences whose id counts (the runner's tokenizer, + EOS) spread evenly over lo..hi"""
+    rng = np.random.default_rng(seed)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    out = []
+    for i in range(n):
+        target = lo + (hi - lo) * i // max(n - 1, 1)
+        words = []
+        while True:
+            words.append("".join(rng.choice(list(letters), size=int(rng.integers(2, 7)))))
+            if len(words) % 16 == 0 or len(words) * 2 >= target:
+                if len(rn.tokenize(" ".join(words))) >= target:
+                    break
+        text = " ".join(words)
+        while len(rn.tokenize(text)) > target and len(text) > 1:
+            text = text[:-1].rstrip()
+        out.append(text)
+    return out
+
+
+def long_utterances(args, mk, wt, local_rank, gen_cfg, torch, L):
+    """SURVEY §8(d)'s long workload: 1024 audio steps per utterance (11.7 s of audio; the reference's perf_battery sentences average
+    10.8 s), the largest 3-runner lock-step batch whose fp32 KV cache fits, then a ragged batch (prompts of 16 .. 784 ids, so that the
+    rows stop — reach max_generation — at different steps, 1024 down to 256)."""
+    n_steps = args.long_steps
+    cfg = mk(weight_type=wt, dac_f16=args.dac_wtype == "f16", max_gen=args.prompt_len + n_steps)
+    free_b, _ = torch.cuda.mem_get_info(local_rank)
+    kv_per_seq = cfg.layers * 2 * (args.prompt_len + n_steps) * cfg.hidden * (2 if args.kv == "f16" else 4)
+    frame_elems = max(cfg.latent, cfg.c0, max((cfg.c0 >> (i + 1)) * int(np.prod(cfg.strides[:i + 1])) for i in range(len(cfg.strides))))
+    codec = 4 * 64 * (n_steps - cfg.n_out + 1) * frame_elems * 4        # the device's codec buffers: three activation buffers + planes of a 64-utterance pass
+    budget = 0.85 * free_b - codec - 6e9
+    batch = int(min(args.batch, budget // (args.streams * kv_per_seq))) // 32 * 32
+    if batch < 32:
+        return {"skipped": f"not enough free memory for {args.streams} x 32 sequences of {n_steps} steps ({free_b / 1e9:.0f} GB free)"}
+    path = os.path.join(tempfile.gettempdir(), f"tts_bench_long_{os.getpid()}.gguf")
+    model = synth.build(cfg)
+    model.write_gguf(path)
+    first = runner.Runner(path, device=local_rank, max_seqs=batch, **gen_cfg)
+    runners = [first] + [runner.Runner(path, device=local_rank, max_seqs=batch, share_with=first, **gen_cfg) for _ in range(1, args.streams)]
+    os.unlink(path)
+    out = {"audio_steps": n_steps, "lockstep_batch": batch, "contexts_per_gpu": args.streams, "kv_cache": args.kv,
+           "kv_cache_GB": round(args.streams * batch * kv_per_seq / 1e9, 1)}
+    frames = n_steps - cfg.n_out + 1
+    try:
+        texts = [make_sentences(first, batch, args.prompt_len, 5000 + i) for i in range(args.streams)]
+        run_all(runners, texts)                                   # warm-up: graph capture, codec buffers
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_samples = run_all(runners, texts)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["uniform"] = {"audio_seconds_per_sec": round(n_samples / SAMPLE_RATE / dt, 2), "seconds": round(dt, 3),
+                          "utterances": batch * args.streams, "audio_s_per_utterance": round(frames * cfg.hop / SAMPLE_RATE, 2)}
+        # the attention family over the long cache: eager, event-timed pass of one runner
+        L.tts_hip_profile(first.device_context(), 1)
+        first.generate_batch_sizes(texts[0])
+        st = profile_get(L, first).get("attn_self", {})
+        L.tts_hip_profile(first.device_context(), 0)
+        if st.get("launches"):
+            out["uniform"]["attn_self"] = {"GBps": round(st["bytes_total"] / st["ms_total"] / 1e6, 1), "frac_of_hbm_peak": round(st["bytes_total"] / st["ms_total"] / 1e6 / HBM_PEAK_GBS, 4),
+                                           "avg_launch_us": round(st["ms_total"] / st["launches"] * 1e3, 2), "mean_cached_positions": args.prompt_len + n_steps // 2}
+        # ragged: prompt lengths spread over 16 .. 784 ids -> rows run 1024 .. 256 steps; a finished row idles at its last position
+        hi = args.prompt_len + (3 * n_steps) // 4
+        rag = [long_sentences(first, batch, args.prompt_len, hi, 7000 + i) for i in range(args.streams)]
+        run_all(runners, rag)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_samples = run_all(runners, rag)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["ragged"] = {"audio_seconds_per_sec": round(n_samples / SAMPLE_RATE / dt, 2), "seconds": round(dt, 3), "utterances": batch * args.streams,
+                         "prompt_ids": [args.prompt_len, hi], "audio_steps_per_utterance": [n_steps - (hi - args.prompt_len), n_steps],
+                         "note": "lock-step: the loop runs as long as the longest row; rows that reached max_generation idle (their tokens are not recorded)"}
+    finally:
+        for rn in reversed(runners):
+            rn.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,11 +448,14 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TTS_BENCH_STREAMS", "3")),
                     help="independent runners (contexts, HIP streams) per GPU; each decodes --batch utterances per step")
     ap.add_argument("--audio-steps", type=int, default=256, help="AR audio steps per utterance (random weights never emit EOS: max_generation = prompt + this)")
+    ap.add_argument("--long-steps", type=int, default=1024, help="audio steps per utterance of the long_utterances section")
     ap.add_argument("--prompt-len", type=int, default=16)
     ap.add_argument("--kv", choices=["f32", "f16"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-step-sweep", action="store_true")
+    ap.add_argument("--no-long", action="store_true", help="skip the long_utterances section (1024 audio steps, uniform + ragged)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE configs 2-4 (secondary)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--model", choices=["mini", "small", "tiny"], default="mini")
     ap.add_argument("--workload", choices=["parler", "dia", "orpheus", "kokoro"], default="parler",
@@ -236,20 +472,34 @@ def main():
     if args.workload != "parler":
         sys.path.insert(0, os.path.join(ROOT, "profiles"))
         import secondary_bench
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus > 1:
             raise SystemExit("--workload dia/orpheus/kokoro measure one GPU's share; run them with --gpus 1")
         print(json.dumps(secondary_bench.RUNNERS[args.workload](args)), flush=True)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+        raise SystemExit(f"bench.py: the launcher started WORLD_SIZE={world} ranks but --gpus {args.gpus} was asked for")
     import torch
 
+    if os.environ.get("TTS_BENCH_LAUNCH_ONLY"):   # CPU test hook: prove that the ranks start and meet, without touching a device
+        import torch.distributed as dist
+        tdist.init(os.environ.get("TTS_BENCH_DIST_BACKEND", "gloo"), rank, world)
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launched_ranks": world, "rank_sum": t.item(), "n_gpus": args.gpus}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # test hooks: run the multi-rank flow on a single-GPU box (all ranks on one device, gloo instead of RCCL)
     if os.environ.get("TTS_BENCH_FORCE_DEVICE") is not None:
         local_rank = int(os.environ["TTS_BENCH_FORCE_DEVICE"])
+    elif world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) on this box")
     backend = os.environ.get("TTS_BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
@@ -279,54 +529,17 @@ def main():
     if dist is not None:
         dist.barrier()
     gen_cfg = dict(sample=1 if args.sample else 0, top_k=50, top_p=1.0, temperature=1.0, seed=1234 + rank)
-    runners = []
-    for s in range(args.streams):
-        rn = runner.Runner(path, device=local_rank, max_seqs=args.batch, declare_only=(rank != 0), **gen_cfg)
-        ctx = rn.device_context()
-        if world > 1:
-            L = hip.load_lib()
-            arena = torch.as_tensor(ArenaView(L.tts_hip_arena_ptr(ctx), L.tts_hip_arena_bytes(ctx)), device=f"cuda:{local_rank}")
-            torch.cuda.synchronize()
-            tdist.broadcast_arena(arena, src=0)   # RCCL over xGMI: the one collective of the path
-            torch.cuda.synchronize()
-            if rank != 0 and L.tts_hip_arena_filled(ctx) != 0:
-                raise RuntimeError(L.tts_hip_last_error().decode())
-        runners.append(rn)
     L = hip.load_lib()
+    runners, bcast = load_runners(path, args, rank, world, local_rank, backend, dist, torch, gen_cfg, args.batch)
     arena_bytes = L.tts_hip_arena_bytes(runners[0].device_context())
-    log(f"[rank {rank}] {len(runners)} runner(s) ready in {time.perf_counter() - t_load:.1f}s, arena {arena_bytes / 1e6:.0f} MB each")
+    arith = int(L.tts_hip_dac_arith(runners[0].device_context()))
+    log(f"[rank {rank}] {len(runners)} runner(s) ready in {time.perf_counter() - t_load:.1f}s, one arena of {arena_bytes / 1e6:.0f} MB per rank")
     if dist is not None:
         dist.barrier()
     if rank == 0 and not os.environ.get("TTS_BENCH_KEEP_GGUF"):
         os.unlink(path)   # mapped by the runners; the name is no longer needed
 
     all_texts = [make_sentences(runners[0], args.batch, args.prompt_len, 1000 + rank * 64 + i) for i in range(args.streams)]
-
-    def run_all(timings_=None):
-        res = [None] * len(runners)
-
-        def work(i):
-            try:
-                t0 = time.perf_counter()
-                sizes = runners[i].generate_batch_sizes(all_texts[i])
-                res[i] = (sum(sizes), time.perf_counter() - t0)
-            except Exception as e:   # surfaced by the caller: a worker thread must not fail silently
-                res[i] = e
-
-        if len(runners) == 1:
-            work(0)
-        else:
-            th = [threading.Thread(target=work, args=(i,)) for i in range(len(runners))]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-        for r in res:
-            if isinstance(r, Exception):
-                raise r
-        if timings_ is not None:
-            timings_.append(float(np.mean([r[1] for r in res])))
-        return sum(r[0] for r in res)
 
     def barrier():
         torch.cuda.synchronize()
@@ -339,31 +552,20 @@ def main():
             if L.tts_hip_profile(rn.device_context(), mode) != 0:
                 raise RuntimeError(L.tts_hip_last_error().decode())
 
-    def profile_get(rn):
-        out = {}
-        for k in range(64):
-            name = L.tts_hip_kclass_name(k).decode()
-            if name == "?":
-                break
-            st = hip.KStat()
-            if L.tts_hip_profile_get(rn.device_context(), k, C.byref(st)) == 0:
-                out[name] = dict(ms_total=st.ms_total, launches=st.launches, bytes_total=st.bytes_total, flops_total=st.flops_total)
-        return out
-
     for _ in range(args.warmup):
-        run_all()
+        run_all(runners, all_texts)
     barrier()
     profile(2)   # HIP-event pairs around the (never graph-captured) DAC launches, live in the timed region
     timings = []
     t0 = time.perf_counter()
     n_samples = 0
     for _ in range(args.steps):
-        n_samples += run_all(timings)
+        n_samples += run_all(runners, all_texts, timings)
     barrier()
     elapsed = time.perf_counter() - t0
     live = {}
     for rn in runners:
-        for k, v in profile_get(rn).items():
+        for k, v in profile_get(L, rn).items():
             a = live.setdefault(k, dict(ms_total=0.0, launches=0, bytes_total=0.0, flops_total=0.0))
             for f in a:
                 a[f] += v[f]
@@ -374,6 +576,12 @@ def main():
     audio_seconds = n_samples / SAMPLE_RATE
     value = audio_seconds / elapsed
     frames = n_audio - cfg.n_out + 1
+    b3_on = args.dac_wtype == "f32" and (arith & 7) and not (arith & 24)
+    detail = DTYPE_DETAIL[args.wtype]
+    if args.dac_wtype == "f16":
+        detail = detail.replace("DAC codec f32 (exact-f32 MFMA)", "DAC codec F16 tensors (fp16 im2col x fp16 kernels, fp16 MFMA, f32 accumulate)")
+    elif b3_on:
+        detail = detail.replace("DAC codec f32 (exact-f32 MFMA)", _B3)
     out = {
         "metric": "audio-seconds/sec (Parler-TTS-Mini fp16, greedy decode + DAC to 44.1 kHz PCM)",
         "value": round(value, 3),
@@ -386,59 +594,37 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": {"f16": "f16", "f32": "f32"}.get(args.wtype, "i8"),
-        "dtype_detail": DTYPE_DETAIL[args.wtype] if args.dac_wtype == "f32" else
-                        DTYPE_DETAIL[args.wtype].replace("DAC codec f32 (exact-f32 MFMA)", "DAC codec F16 tensors (fp16 im2col x fp16 kernels, fp16 MFMA, f32 accumulate)"),
+        "dtype_detail": detail,
         "data": "synthetic (seeded random weights of the Parler-TTS-Mini + DAC-44k architecture written as a GGUF file; fixed-length greedy generation)",
         "config": {
             "workload": f"configs[1]: Parler-TTS-Mini {WNAME} on MI355X, {DECODE} + DAC codec ({args.dac_wtype} tensors), through the C++ runner "
                         f"(tts_c_generate_batch: tokenizer, device-resident AR loop, un-delay, DAC); {args.streams} runner(s) x {args.batch} utterances/GPU "
                         f"in lock-step, {args.prompt_len}-id prompts, {n_audio} audio steps (={frames} frames, {frames * cfg.hop / SAMPLE_RATE:.2f} s audio) per utterance",
             "utterances_per_gpu": args.batch * args.streams, "contexts_per_gpu": args.streams, "lockstep_batch": args.batch, "audio_steps": n_audio,
-            "prompt_len": args.prompt_len, "kv_cache": args.kv,
-            "parallelism": f"dp{world} (one process per GPU, RCCL weight broadcast, no per-step collective)",
+            "prompt_len": args.prompt_len, "kv_cache": args.kv, "codec_arithmetic_bits": arith,
+            "parallelism": f"dp{world} (one process per GPU, one weight arena per GPU shared by its runners, RCCL weight broadcast, no per-step collective)",
         },
         "real_time_factor": round(elapsed / audio_seconds, 6),
         "x_real_time_per_gpu": round(value / world, 3),
         "rccl_ranks": world,
+        "weight_broadcast": bcast,
         "ms_per_generate_batch": round(float(np.mean(timings)) * 1e3, 3),
+        "ms_per_generate_batch_note": "mean wall time of one runner's tts_c_generate_batch call; ms_per_step is the wall time until ALL runners of the "
+                                      "step are done (runners wait for each other's turn at the per-device codec mutex: one 64-utterance codec pass at a time)",
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0:
         if not args.no_roofline:
             # per-kernel-class HIP-event timing of the same call on runner 0 (eager launches, every launch bracketed by an event pair on
             # the context's stream); classes are summed per rocprof symbol family
             rn = runners[0]
             L.tts_hip_profile(rn.device_context(), 1)
             rn.generate_batch_sizes(all_texts[0])
-            stats = profile_get(rn)
+            stats = profile_get(L, rn)
             L.tts_hip_profile(rn.device_context(), 0)
-            fam = {}
-            for name, keys in FAMILIES.items():
-                a = dict(ms_total=0.0, launches=0, bytes_total=0.0, flops_total=0.0)
-                for k in keys:
-                    for f in a:
-                        a[f] += stats.get(k, {}).get(f, 0)
-                if a["launches"]:
-                    fam[name] = a
+            fam = family_stats(stats)
             tot = sum(v["ms_total"] for v in fam.values()) or 1.0
             dom = max(fam, key=lambda k: fam[k]["ms_total"])
-
-            def roof_of(name, st, src):
-                per_launch_ms = st["ms_total"] / max(st["launches"], 1)
-                tf = st["flops_total"] / max(st["ms_total"], 1e-9) / 1e9
-                gb = st["bytes_total"] / max(st["ms_total"], 1e-9) / 1e6
-                if name in MFMA_FP32 or name in MFMA_FP16:
-                    peak = F16_PEAK_TFLOPS if (name in MFMA_FP16 or args.dac_wtype == "f16") else F32_PEAK_TFLOPS
-                    r = {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                         "hbm_GBps": round(gb, 1), "hbm_frac": round(gb / HBM_PEAK_GBS, 4)}
-                else:
-                    r = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 4)}
-                r.update({"kernel": name, "timing_source": src, "avg_launch_us": round(per_launch_ms * 1e3, 3), "launches": st["launches"],
-                          "share_of_kernel_time": round(st["ms_total"] / tot, 3),
-                          "algorithmic_bytes_per_launch": round(st["bytes_total"] / max(st["launches"], 1), 1),
-                          "algorithmic_flops_per_launch": round(st["flops_total"] / max(st["launches"], 1), 1)})
-                return r
-
             src = "separate eager pass of the same tts_c_generate_batch call on runner 0 (decoder launches live inside hipGraphs in the timed region)"
             st = fam[dom]
             keys = FAMILIES[dom]
@@ -447,23 +633,13 @@ def main():
                 for k in keys:
                     for f in st:
                         st[f] += live.get(k, {}).get(f, 0)
-                src = "HIP events around every launch of this kernel family in the timed region (all runners)"
-            roof = roof_of(dom, st, src)
+                src = "HIP events around every launch of this kernel family in the timed region (all runners of rank 0)"
+            roof = roof_of(dom, st, src, tot, arith, args.dac_wtype)
             roof["share_of_kernel_time"] = round(fam[dom]["ms_total"] / tot, 3)
-            roof["traffic"] = pmc_traffic(dom, args, n_audio)
-            if roof["bound"] == "mfma" and dom in MFMA_FP32:
-                roof["note"] = "fp32 conv: peak = fp32 vector / fp32-input-MFMA peak (exact-fp32 numerics)"
-            if int(os.environ.get("TTS_HIP_DAC_BF16X3", "0") or 0) and dom.startswith("conv1d_mfma_kernel<7") and args.dac_wtype == "f32":
-                # experiment: the k = 7 convs issue six bf16 MFMAs per fp32 product (and 8 tap slots for 7 taps): price the
-                # family against the bf16 pipe with the flops it issues, keep the fp32-equivalent rate beside it
-                issued = roof["achieved"] * 6.0 * 8.0 / 7.0
-                roof.update({"fp32_equivalent_TFLOPs": roof["achieved"], "achieved": round(issued, 3), "peak": F16_PEAK_TFLOPS,
-                             "frac": round(issued / F16_PEAK_TFLOPS, 4),
-                             "note": "TTS_HIP_DAC_BF16X3: fp32 operands as three bf16 terms, six bf16 MFMAs per product, fp32 accumulate; achieved = issued "
-                                     "flops (6 x 8/7 x algorithmic) against the dense bf16 peak; layers still on the fp32 kernel (96-channel tiles with knob 1) "
-                                     "are counted the same way, which overstates the issued rate for them"})
+            roof["traffic"] = pmc_traffic(dom, args, n_audio, arith)
             out["roofline"] = roof
-            out["roofline_families"] = [dict(roof_of(n, v, "eager pass (launch-by-launch HIP events: short kernels read ~1-2 us long)"), traffic=None)
+            out["roofline_families"] = [dict(roof_of(n, v, "eager pass (launch-by-launch HIP events: short kernels read ~1-2 us long)", tot, arith, args.dac_wtype),
+                                             traffic=pmc_traffic(n, args, n_audio, arith))
                                         for n, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_total"]) if n != dom]
             out["kernel_classes"] = {
                 k: {"ms": round(v["ms_total"], 3), "launches": v["launches"],
@@ -477,8 +653,25 @@ def main():
             threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 32)
             prompt = runners[0].tokenize(all_texts[0][0])
             out["cpu_baseline"] = cpu_baseline(model, cfg, prompt, threads)
-    for rn in runners:
+    for rn in reversed(runners):
         rn.close()
+    if rank == 0 and world == 1 and args.model == "mini":
+        if not args.no_long:
+            try:
+                out["long_utterances"] = long_utterances(args, mk, wt, local_rank, gen_cfg, torch, L)
+            except Exception as e:   # the headline must survive a failure of an extra section
+                out["long_utterances"] = {"error": str(e)[:300]}
+        if not args.no_secondary:
+            sys.path.insert(0, os.path.join(ROOT, "profiles"))
+            import secondary_bench
+            sec = {}
+            sargs = argparse.Namespace(steps=1, warmup=1, no_cpu_baseline=True, cpu_threads=0)
+            for name in ("kokoro", "dia", "orpheus"):
+                try:
+                    sec[name] = secondary_bench.RUNNERS[name](sargs)
+                except Exception as e:
+                    sec[name] = {"error": str(e)[:300]}
+            out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

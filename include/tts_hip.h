@@ -407,13 +407,19 @@ enum tts_hip_kclass {
     TTS_HIP_K_DAC_CONVT = 16,   /* ConvTranspose1d upsampling */
     TTS_HIP_K_DAC_FINAL = 17,   /* final Cout=1 conv + tanh */
     TTS_HIP_K_DAC_RESUNIT = 18, /* resunit_b3_kernel: one residual unit (snake, k=7 conv, snake, k=1 conv, + x) in one launch */
-    TTS_HIP_K_COUNT = 19
+    TTS_HIP_K_KOKORO_CONV = 19, /* Kokoro's stride-1 "same" convolutions on conv1d_mfma_kernel (exact-fp32 MFMA) */
+    TTS_HIP_K_COUNT = 20
 };
 typedef struct tts_hip_kstat {
     double   ms_total;      /* summed event-elapsed time */
     uint64_t launches;
     double   bytes_total;   /* ALGORITHMIC bytes (weights + activations + cache rows each launch must touch) */
-    double   flops_total;   /* algorithmic flops */
+    double   flops_total;   /* Arithmetic of the codec convolutions of this context (bench.py prices each kernel family against the pipe it runs on): bit 0 = the
+ * k = 7 convs of the wide classes as bf16 x 3 split products (TTS_HIP_DAC_BF16X3), bit 1 = residual units of 96 / 192 channels as one
+ * launch, bf16 x 3 (TTS_HIP_DAC_FUSE), bit 2 = transposed convs as bf16 x 3 (TTS_HIP_DAC_CONVT_B3); 8 = F16 tensors (fp16 im2col, fp16
+ * MFMA); 16 = scalar-FMA cross-check kernels; 0 = exact-fp32 MFMA throughout or no codec. */
+int tts_hip_dac_arith(tts_hip_ctx *ctx);
+/* algorithmic flops */
 } tts_hip_kstat;
 int tts_hip_profile(tts_hip_ctx *ctx, int enable);        /* 1: every launch, forwards run eagerly; 2: only the launches that are
                                                               never graph-captured (the DAC), decoder steps keep replaying their

@@ -191,7 +191,8 @@ def run_dia(args):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
-# Orpheus-3B Q4_0 (configs[4]); the SNAC codec is measured separately by tests/profiles (7 tokens per 2048-sample frame)
+# Orpheus-3B Q4_0 + SNAC (configs[4]): 7 tokens per 2048-sample frame (orpheus/model.cpp:389-405), the 24 kHz SNAC decoder
+# (snac_model.cpp:86-159) inside the timed region
 # ------------------------------------------------------------------------------------------------------------------------------
 def orpheus_tensors(cfg, rng):
     def q4(name, rows, cols):
@@ -226,14 +227,32 @@ def run_orpheus(args):
     prompt = rng.integers(0, cfg.vocab, 32).astype(np.uint32)
     NO_STOP = 0xFFFFFFFF
     n_tok = 448
+    # the codec of this config: SNAC 24 kHz at its real shapes (synthetic weights), 7 ids per frame -> 1 / 2 / 4 codes on its three levels
+    # (orpheus/model.cpp:389-405); random codes of the right layout stand in for the ids' payload (timing does not depend on their values)
+    scfg = synth.snac_24khz(max_frames=4 * (n_tok // 7))
+    snac = hip.SnacEngine(scfg)
+    snac.load(synth.build_snac(scfg))
+    frames = n_tok // 7
+    T = 4 * frames
+
+    def codec():
+        codes = np.concatenate([rng.integers(0, scfg.cb_size, T // r) for r in scfg.repeats]).astype(np.uint32)   # level-major (snac_runner::set_inputs :161-178)
+        pcm = snac.decode(codes, T)
+        assert pcm.size == frames * 2048
+        return pcm
+
     for _ in range(max(1, args.warmup)):
         eng.generate_greedy(prompt, 16, NO_STOP)
+        codec()
     t0 = time.perf_counter()
-    ts = []
+    ts, tc = [], []
     for _ in range(args.steps):
         t1 = time.perf_counter()
         out_ids = eng.generate_greedy(prompt, n_tok, NO_STOP)
-        ts.append(time.perf_counter() - t1)
+        t2 = time.perf_counter()
+        codec()
+        tc.append(time.perf_counter() - t2)
+        ts.append(t2 - t1)
         assert len(out_ids) == n_tok
     elapsed = time.perf_counter() - t0
     t64 = time.perf_counter()
@@ -244,20 +263,25 @@ def run_orpheus(args):
     q4_bytes = params / 32 * 18
     audio_s = n_tok / 7 * 2048 / 24000.0 * args.steps
     out = {
-        "metric": "audio-seconds/sec (Orpheus-3B Q4_0 decoder, greedy; SNAC codec not included)",
+        "metric": "audio-seconds/sec (Orpheus-3B Q4_0 decoder, greedy, + SNAC codec to 24 kHz PCM)",
         "value": round(audio_s / elapsed, 3), "unit": "audio-seconds/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8",
         "dtype_detail": "Q4_0 matrices x Q8_0-quantised activations (ggml's vec_dot_q4_0_q8_0 semantics), integer block dots, fp16 block scales, f32 accumulate",
         "data": "synthetic (random Q4_0 blocks with a fixed scale; shapes of canopylabs/orpheus-3b)",
         "config": {"workload": f"configs[4]: Orpheus (Llama-3-3B backbone) Q4_0 on 1 x MI355X, one utterance: 32-token prompt (prefill) + {n_tok} greedy tokens "
-                               "(= 64 SNAC frames of 2048 samples at 24 kHz) through tts_hip_orpheus_generate_greedy (captured step, streaming Q4_0 GEMV kernels)",
+                               "(= 64 SNAC frames of 2048 samples at 24 kHz) through tts_hip_orpheus_generate_greedy (captured step, streaming Q4_0 GEMV kernels), "
+                               "then tts_hip_snac_decode of the 64 frames (SNAC 24 kHz shapes), both inside the timed region",
                    "tokens": n_tok, "parallelism": "dp1"},
-        "ms_per_decode_step": round(step * 1e3, 4), "x_real_time_per_gpu": round(1 / step / 7 * 2048 / 24000, 2),
+        "ms_per_decode_step": round(step * 1e3, 4), "snac_ms_per_64_frames": round(float(np.mean(tc)) * 1e3, 3),
+        "snac_share_of_step": round(float(np.mean(tc)) / (float(np.mean(ts)) + float(np.mean(tc))), 4),
+        "x_real_time_per_gpu": round(audio_s / elapsed, 2),
         "roofline": {"bound": "hbm", "achieved": round(q4_bytes / step / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(q4_bytes / step / 1e9 / HBM_PEAK_GBS, 4),
                      "traffic": None, "kernel": "whole decoder step (28 layers: gemv_q4_rows_kernel, rms norm, rope, attn_gqa_kernel<128>, arg-max over 156 940 logits)",
-                     "algorithmic_bytes_per_launch": q4_bytes, "note": "Q4_0 bytes of every matrix one step reads (lm_head included, one embedding row excluded)"},
+                     "algorithmic_bytes_per_launch": q4_bytes, "note": "Q4_0 bytes of every matrix one step reads (lm_head included, one embedding row excluded); "
+                     "the decoder steps are the dominant part of the timed region (snac_share_of_step is the codec's)"},
     }
     eng.close()
+    snac.close() if hasattr(snac, "close") else None
     if not args.no_cpu_baseline:
         orc = _oracle()
         threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 32)
@@ -289,7 +313,6 @@ def run_kokoro(args):
     cfg = model.cfg
     rng = np.random.default_rng(1)
     res = {}
-    t_all0 = time.perf_counter()
     audio_total = 0.0
     timed = 0.0
     for n_ids in (64, 400):
@@ -320,8 +343,27 @@ def run_kokoro(args):
         "config": {"workload": "configs[2]: Kokoro-82M on 1 x MI355X, 64 and 400 phoneme ids, durations forced to 3 frames per id for shape determinism; "
                                "tts_hip_kokoro_durations + tts_hip_kokoro_generate (exact-fp32 MFMA convolutions, workgroup-split LSTM recurrence)", "parallelism": "dp1"},
         "by_length": res,
-        "roofline": None, "roofline_note": "no single bounding kernel: the time is spread over ~20 short kernel families (profiles/r02/kernel_stats_kokoro_82m_round2_final.csv), DESIGN.md §5",
     }
+    # the dominant family (the stride-1 "same" convolutions on conv1d_mfma_kernel, exact-fp32 MFMA: kokoro/model.cpp:1141-1242) from an
+    # event-timed pass of the 400-id synthesis
+    hip.engine_profile(eng, 1)
+    t0 = time.perf_counter()
+    lens, hid = eng.durations(toks, cfg.voices[0])
+    eng.generate(toks, forced, hid, cfg.voices[0], noise)
+    wall = time.perf_counter() - t0
+    st = hip.engine_profile_get(eng)["kokoro_conv_mfma"]
+    hip.engine_profile(eng, 0)
+    if st["launches"]:
+        tf = st["flops_total"] / st["ms_total"] / 1e9
+        out["roofline"] = {"bound": "mfma", "achieved": round(tf, 3), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": None,
+                           "kernel": "conv1d_mfma_kernel<3 / 5 / 7 / 11,...> (generator + AdaIN + text-encoder convolutions, exact-fp32 MFMA)",
+                           "avg_launch_us": round(st["ms_total"] / st["launches"] * 1e3, 2), "launches": st["launches"],
+                           "share_of_wall_time": round(st["ms_total"] * 1e-3 / wall, 3),
+                           "algorithmic_flops_per_launch": round(st["flops_total"] / st["launches"], 1),
+                           "hbm_GBps": round(st["bytes_total"] / st["ms_total"] / 1e6, 1),
+                           "note": "400 phoneme ids, one synthesis, HIP events around every launch of the family (eager pass); short sequences: few workgroups per launch"}
+    else:
+        out["roofline"] = None
     eng.close()
     if not args.no_cpu_baseline:
         orc = _oracle()

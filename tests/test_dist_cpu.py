@@ -53,3 +53,24 @@ def test_two_rank_broadcast_shard_reduce(tmp_path):
 def test_shard_is_round_robin():
     assert tdist.shard_utterances(10, 1, 4) == [1, 5, 9]
     assert sum(len(tdist.shard_utterances(32, r, 8)) for r in range(8)) == 32
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (rendezvous on 127.0.0.1); without the
+    single-device test hook it refuses to produce an n_gpus = 2 line on a box with fewer GPUs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TTS_BENCH_LAUNCH_ONLY="1", TTS_BENCH_DIST_BACKEND="gloo", TTS_BENCH_FORCE_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d == {"launched_ranks": 2, "rank_sum": 1.0, "n_gpus": 2}
+    import torch
+    if torch.cuda.device_count() < 2:
+        env.pop("TTS_BENCH_FORCE_DEVICE")
+        bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)

@@ -336,21 +336,23 @@ def test_cli_writes_wav(tmp_path):
 
 
 def test_two_rank_bench_flow_on_one_gpu(tmp_path):
-    """bench.py's N>1 path end to end with two processes (both on cuda:0, gloo transport): rank 1 only declares
-    tensors, receives the weight arena by broadcast and must produce audio like rank 0."""
+    """`python bench.py --gpus 2` with NO launcher: bench.py starts the two ranks itself (both on cuda:0 through the test hooks, gloo
+    transport: RCCL cannot form a communicator of two ranks on one device).  Rank 1 only declares tensors, receives the weight arena by
+    broadcast and must produce audio like rank 0; the runners of a rank share one arena; the rank-0 line still carries the roofline."""
     import json
-    import socket
     import sys
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, TTS_BENCH_FORCE_DEVICE="0", TTS_BENCH_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--model", "small",
-           "--batch", "3", "--streams", "2", "--audio-steps", "40", "--prompt-len", "6", "--no-cpu-baseline", "--no-roofline"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--model", "small",
+           "--batch", "3", "--streams", "2", "--audio-steps", "40", "--prompt-len", "6", "--no-cpu-baseline", "--no-step-sweep"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak"
+    assert d["weight_broadcast"]["bytes"] > 0 and d["weight_broadcast"]["ms"] > 0
+    assert "roofline" in d and d["roofline"]["launches"] > 0, "the N > 1 line carries rank 0's roofline too"
     frames = 40 - 9 + 1
     expect_audio_s = 2 * 2 * 3 * frames * 512 / 44100.0   # ranks x contexts x utterances
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - expect_audio_s) < 1e-3 * expect_audio_s

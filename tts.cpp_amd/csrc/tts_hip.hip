@@ -168,6 +168,21 @@ struct CopyItem { size_t dst; std::string src; size_t src_off = 0; size_t bytes 
 
 struct ProfEv { hipEvent_t a, b; int kclass; };
 
+// Codec activation buffers of a device.  Codec passes of one device take turns (g_dac_pass_mutex: a pass fills the chip), so every
+// context of the device works in the same buffers instead of holding its own three activation buffers (197 KB per frame and utterance of
+// a pass each: 12.6 GB per context for 64 x 248 frames, 38.6 GB at 1016 frames); they are freed when the device's last codec context goes.
+struct DacBuffers {
+    float *dbuf[3] = {nullptr, nullptr, nullptr};
+    size_t dbuf_elems = 0;       // capacity of each buffer in floats
+    size_t cap_codes = 0;        // ids d_codes holds (frames summed over a batch, padded to the longest, x codebooks)
+    float *dplanes = nullptr;    // second planes buffer of the wide classes (the first lives in dbuf[2])
+    uint32_t *d_codes = nullptr;
+    float *h_pcm = nullptr;
+    size_t h_pcm_elems = 0;
+    int users = 0;
+};
+static DacBuffers g_dac_buffers[64];
+
 struct tts_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -308,15 +323,11 @@ struct tts_hip_ctx {
     float *h_logits = nullptr;
     std::vector<uint32_t> host_pos;  // positions per row of the forward being enqueued (for byte accounting)
 
-    // dac buffers
-    float *dbuf[3] = {nullptr, nullptr, nullptr};
-    size_t dbuf_elems = 0;       // capacity of each buffer in floats
+    // dac: the activation buffers are the device's (g_dac_buffers)
     size_t dac_frame_elems = 0;  // largest activation per frame over all stages (C * L / frames)
-    size_t dac_cap_frames = 0;   // frames (summed over a batch, padded to the longest) the buffers hold
-    uint32_t *d_codes = nullptr, *d_frames = nullptr;
+    size_t dac_cap_frames = 0;   // SNAC: frames its own buffers hold
+    uint32_t *d_frames = nullptr;
     size_t d_frames_cap = 0;
-    float *h_pcm = nullptr;
-    size_t h_pcm_elems = 0;
     bool debug = false;
     std::map<int, std::vector<float>> dac_dbg;
     std::map<size_t, float *> packed;  // arena offset of a conv weight -> its MFMA-tile-packed copy
@@ -326,6 +337,9 @@ struct tts_hip_ctx {
     std::map<size_t, _Float16 *> packed16;  // same, fp16 images (dac_f16)
     std::map<size_t, __bf16 *> packed_b3;   // k = 7 conv weights as three bf16 planes (dac_b3, experiment)
     std::map<size_t, __bf16 *> packed_ru;   // residual unit (keyed by its k = 7 weight) -> stage stream of resunit_b3_kernel
+    std::map<size_t, __bf16 *> packed_p;    // conv weight -> bf16 planes in stage order for conv_b3p_kernel (k = 7: 64-channel tiles, k = 1: 128-channel tiles)
+    int dac_planes = 1;         // TTS_HIP_DAC_PLANES=0: the wide classes (channels % 128 == 0, no fused unit) keep fp32 activations and stage snake + split per tile
+    bool dac_buf_user = false;  // counted in g_dac_buffers[device].users
     std::map<size_t, __bf16 *> packed_ct;   // transposed conv weight -> bf16 planes of convt_b3_kernel
     int dac_convt_b3 = 1;       // TTS_HIP_DAC_CONVT_B3=0: the transposed convs stay on the exact-fp32 MFMA kernel
     int dac_fuse = 1;           // TTS_HIP_DAC_FUSE=0: residual units at 96 / 192 channels stay two launches (k = 7 conv, k = 1 conv + residual)
@@ -373,7 +387,7 @@ struct tts_hip_ctx {
 
 static const char *KNAMES[TTS_HIP_K_COUNT] = {"embed", "ln", "gemm_qkv", "attn_self", "gemm_attn_out", "gemm_cross_q", "attn_cross",
                                               "gemm_cross_out", "gemm_fc1", "gemm_fc2", "gemm_heads", "sample", "gemm_other",
-                                              "dac_embed", "dac_conv7", "dac_conv1", "dac_convt", "dac_final", "dac_resunit"};
+                                              "dac_embed", "dac_conv7", "dac_conv1", "dac_convt", "dac_final", "dac_resunit", "kokoro_conv_mfma"};
 extern "C" const char *tts_hip_kclass_name(int k) { return (k >= 0 && k < TTS_HIP_K_COUNT) ? KNAMES[k] : "?"; }
 
 extern "C" int tts_hip_device_count(void) {
@@ -426,6 +440,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_DAC_B3_VARIANT")) c->dac_b3_variant = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_FUSE")) c->dac_fuse = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_CONVT_B3")) c->dac_convt_b3 = atoi(e);
+    if (const char *e = getenv("TTS_HIP_DAC_PLANES")) c->dac_planes = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
@@ -448,6 +463,20 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
 }
 
 static void free_dev(void *p) { if (p) (void) hipFree(p); }
+static std::mutex g_dac_pass_mutex[64];
+static void dac_buffers_release(tts_hip_ctx *c) {
+    if (!c->dac_buf_user) return;
+    std::lock_guard<std::mutex> lock(g_dac_pass_mutex[(unsigned) c->device % 64]);
+    DacBuffers &B = g_dac_buffers[(unsigned) c->device % 64];
+    c->dac_buf_user = false;
+    if (--B.users > 0) return;
+    for (int i = 0; i < 3; i++) { free_dev(B.dbuf[i]); B.dbuf[i] = nullptr; }
+    free_dev(B.dplanes); B.dplanes = nullptr;
+    free_dev(B.d_codes); B.d_codes = nullptr;
+    if (B.h_pcm) { (void) hipHostFree(B.h_pcm); B.h_pcm = nullptr; }
+    B.dbuf_elems = B.cap_codes = B.h_pcm_elems = 0;
+    B.users = 0;
+}
 
 extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     if (!c) return;
@@ -471,20 +500,20 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     free_dev(c->s_noise); free_dev(c->s_codes);
     free_dev(c->t5_bucket); free_dev(c->t5_x); free_dev(c->t5_qkv); free_dev(c->t5_att); free_dev(c->t5_ug); free_dev(c->t5_g); free_dev(c->t5_y); free_dev(c->t5_ids); free_dev(c->logits); free_dev(c->part); free_dev(c->attn_cnt); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
     free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
-    free_dev(c->d_eos); free_dev(c->d_codes); free_dev(c->d_frames);
-    for (int i = 0; i < 3; i++) free_dev(c->dbuf[i]);
+    free_dev(c->d_eos); free_dev(c->d_frames);
+    dac_buffers_release(c);
     for (auto &pw : c->packed) free_dev(pw.second);
     for (auto &pw : c->packed16) free_dev(pw.second);
     for (auto &pw : c->packed_b3) free_dev(pw.second);
     free_dev(c->cond_text_enc); free_dev(c->cond_cross_kv);
     for (auto &pw : c->packed_ru) free_dev(pw.second);
     for (auto &pw : c->packed_ct) free_dev(pw.second);
+    for (auto &pw : c->packed_p) free_dev(pw.second);
     if (c->h_ids) (void) hipHostFree(c->h_ids);
     if (c->h_pos) (void) hipHostFree(c->h_pos);
     if (c->h_seq) (void) hipHostFree(c->h_seq);
     if (c->h_tok) (void) hipHostFree(c->h_tok);
     if (c->h_logits) (void) hipHostFree(c->h_logits);
-    if (c->h_pcm) (void) hipHostFree(c->h_pcm);
     if (c->h_di) (void) hipHostFree(c->h_di);
     for (auto &e : c->prof_events) { (void) hipEventDestroy(e.a); (void) hipEventDestroy(e.b); }
     (void) hipStreamDestroy(c->stream);
@@ -1081,6 +1110,12 @@ static int prof_collect(tts_hip_ctx *c) {
     return 0;
 }
 
+extern "C" int tts_hip_dac_arith(tts_hip_ctx *c) {
+    if (!c || !c->has_dac) return 0;
+    if (c->dac_f16) return 8;
+    if (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) return 16;
+    return (c->dac_b3 ? 1 : 0) | (c->dac_fuse ? 2 : 0) | (c->dac_convt_b3 ? 4 : 0);
+}
 extern "C" int tts_hip_profile(tts_hip_ctx *c, int enable) {
     if (!c) return set_err("null ctx");
     HIPCHK(hipSetDevice(c->device));
@@ -1146,7 +1181,9 @@ static int max_rows_for(const tts_hip_ctx *c) {
     for (const PLayer &y : c->layers)
         for (const W *w : {&y.qkv, &y.o, &y.cq, &y.co, &y.fc1, &y.fc2})
             if (w->type != TTS_HIP_F16 && w->N) return 256;
-    return c->heads.type == TTS_HIP_F16 ? 512 : 256;
+    if (c->heads.type != TTS_HIP_F16) return 256;
+    if (const char *e = getenv("TTS_HIP_MAX_ROWS")) return std::max(256, atoi(e));   // experiment: lock-step forwards of more than 512 rows
+    return 512;
 }
 
 template <int EPI, int RB, int QPRO>
@@ -2532,6 +2569,23 @@ static int pack_convt_b3(tts_hip_ctx *c, const DBlock &b) {
     c->packed_ct[b.w] = dst;
     return 0;
 }
+// wide classes on split planes (conv_b3p_kernel): k = 7 in 64-channel tiles (four k-steps per 8-channel chunk), k = 1 in 128-channel
+// tiles (one k-step = 16 channels per chunk)
+static bool planes_class(const tts_hip_ctx *c, int ch) {
+    int ks = 0, ks2 = 0;
+    return c->dac_planes && c->dac_b3 && !c->dac_f16 && ch % 128 == 0 && !(c->dac_fuse && resunit_shape(ch, &ks, &ks2));
+}
+static int pack_planes(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT) {
+    const int CO_T = KT == 7 ? 64 : 128, NS = KT == 7 ? 4 : 1;
+    const int n_chunks = KT == 7 ? cin / 8 : cin / 16;
+    const size_t n = (size_t) (cout / CO_T) * n_chunks * 3 * NS * 2 * CO_T * 8;
+    __bf16 *dst = nullptr;
+    HIPCHK(hipMalloc((void **) &dst, n * 2));
+    hipLaunchKernelGGL(pack_conv_w_b3p_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + w_off), dst, cout, cin, KT, CO_T, NS, n_chunks);
+    HIPCHK(hipGetLastError());
+    c->packed_p[w_off] = dst;
+    return 0;
+}
 #define CI16_K7 16
 #define CI16_K1 32
 #define CI16_T  16
@@ -2554,10 +2608,15 @@ static int ensure_packed(tts_hip_ctx *c) {
     }
     if (conv_tile(c->d_c0, 7, &CO_T, &CI_T) >= 0) CHK(pack_one(c, c->d_initw, c->d_c0, c->d_latent, 7, CO_T, CI_T, false));
     if (c->dac_b3 && c->d_c0 % 64 == 0) CHK(pack_one_b3(c, c->d_initw, c->d_c0, c->d_latent, 64));
+    if (planes_class(c, c->d_c0) && c->d_latent % 8 == 0) CHK(pack_planes(c, c->d_initw, c->d_c0, c->d_latent, 7));
     for (auto &b : c->dblocks) {
         if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, CI32_T, true));
         if (c->dac_convt_b3) CHK(pack_convt_b3(c, b));
         for (int r = 0; r < 3; r++) {
+            if (planes_class(c, b.cout)) {
+                CHK(pack_planes(c, b.res[r].in_w, b.cout, b.cout, 7));
+                CHK(pack_planes(c, b.res[r].out_w, b.cout, b.cout, 1));
+            }
             if (c->dac_fuse) CHK(pack_resunit(c, b.res[r], b.cout));
             if (c->dac_b3 && b.cout % 64 == 0) CHK(pack_one_b3(c, b.res[r].in_w, b.cout, b.cout, 64));
             else if (c->dac_b3 >= 2 && b.cout % 96 == 0) CHK(pack_one_b3(c, b.res[r].in_w, b.cout, b.cout, 96));   // not run on a GPU yet
@@ -2839,6 +2898,48 @@ static int launch_convt(tts_hip_ctx *c, ConvTArgs ta, size_t w_off, int nz) {
     return 0;
 }
 
+// ---- wide classes on split planes --------------------------------------------------------------------------------------------------
+static int launch_split(tts_hip_ctx *c, const DacBatch &bt, const float *x, int C, int LS, size_t alpha, bool has_alpha, __bf16 *yp) {
+    SplitArgs a{};
+    a.x = x; a.alpha = has_alpha ? (const float *) (c->arena + alpha) : nullptr; a.yp = yp; a.C = C; a.L = LS; a.frames = bt.frames; a.mult = bt.mult;
+    const double Lv = bt.tot_frames * bt.mult;
+    CHK(prof_begin(c, TTS_HIP_K_DAC_CONV1, (double) C * Lv * 10, 0));
+    hipLaunchKernelGGL(snake_split_kernel, dim3((LS + 255) / 256, C / 8, bt.n), dim3(256), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return prof_end(c);
+}
+template <int KT, int MI, int NI, int WM, int WN, int NS, int MINW>
+static int launch_conv_b3p_t(tts_hip_ctx *c, const PConvArgs &a, int nz) {
+    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WPL = NS * 2 * CO_T * 8, NCG = KT == 7 ? 1 : 2 * NS;
+    const int xw = T_T + (KT - 1) * a.dil;
+    const size_t lds = (size_t) 2 * 3 * WPL * 2 + (size_t) 2 * 3 * NCG * xw * 8 * 2;
+    static std::atomic<uint64_t> attr{0};
+    if (attr_needed(attr, c->device)) {
+        HIPCHK(hipFuncSetAttribute((const void *) conv_b3p_kernel<KT, MI, NI, WM, WN, NS, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    hipLaunchKernelGGL((conv_b3p_kernel<KT, MI, NI, WM, WN, NS, MINW>), dim3((a.L + T_T - 1) / T_T, a.cout / CO_T, nz), dim3(64 * WM * WN), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// conv on planes: y (fp32, may be NULL) and / or yp (planes with the consumer's snake, may be NULL)
+static int launch_conv_planes(tts_hip_ctx *c, const DacBatch &bt, const __bf16 *xp, int cin, int LS, size_t w, size_t b, int cout, int K, int dil, const float *resid,
+                              float *y, __bf16 *yp, size_t alpha_out, bool has_alpha_out) {
+    PConvArgs a{};
+    a.xp = xp; a.w = c->packed_p.at(w); a.b = (const float *) (c->arena + b); a.resid = resid; a.y = y; a.yp = yp;
+    a.alpha_out = has_alpha_out ? (const float *) (c->arena + alpha_out) : nullptr;
+    a.cin = cin; a.cout = cout; a.L = LS; a.dil = dil; a.pad = K == 7 ? 3 * dil : 0; a.frames = bt.frames; a.mult = bt.mult;
+    const double Lv = bt.tot_frames * bt.mult;
+    const double bytes = ((double) cin * Lv * 6 + (double) cout * Lv * ((resid ? 4 : 0) + (y ? 4 : 0) + (yp ? 6 : 0)) + (double) cout * cin * K * 6);
+    CHK(prof_begin(c, K == 7 ? TTS_HIP_K_DAC_CONV7 : TTS_HIP_K_DAC_CONV1, bytes, 2.0 * cout * (double) cin * K * Lv));
+    if (K == 7) {
+        if (c->dac_b3_variant == 0) CHK((launch_conv_b3p_t<7, 2, 2, 1, 4, 4, 2>(c, a, bt.n)));      // 64 ch x 256 pos, 4 waves
+        else CHK((launch_conv_b3p_t<7, 2, 1, 1, 8, 4, 4>(c, a, bt.n)));                             // 64 ch x 256 pos, 8 waves, two workgroups per CU
+    } else {
+        CHK((launch_conv_b3p_t<1, 2, 2, 2, 4, 1, 2>(c, a, bt.n)));                                  // 128 ch x 256 pos, 8 waves
+    }
+    return prof_end(c);
+}
+
 // one residual unit (gnac.cpp:133-149) as one launch
 template <int MI, int KS, int KS2>
 static int launch_resunit_t(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
@@ -2877,7 +2978,6 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
 // (3 x 197 KB per frame: 9.4 GB for 64 x 248 frames instead of 56 GB for a 384-utterance batch), and passes of different contexts on
 // one device take turns (a per-device mutex): a pass fills the chip with compute-bound convolutions, two of them interleaved only
 // stretch each other, while another context's latency-bound decoder loop does fit next to one.
-static std::mutex g_dac_pass_mutex[64];
 static int dac_decode_batch(tts_hip_ctx *c, const uint32_t *codes, const uint32_t *frames, uint32_t n, float *pcm_out) {
     if (!c || !c->finalized || !c->has_dac) return set_err("tts_hip_dac_decode: context has no finalized DAC");
     if (!frames || !codes || !pcm_out) return set_err("tts_hip_dac_decode: null argument");
@@ -2929,26 +3029,34 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
     {
         int Lq = (int) Fmax;
         need_elems = (size_t) std::max(c->d_latent, c->d_c0) * dac_row_stride(c, Lq);
+        // split planes (6 bytes per element) of the wide classes live in these buffers too
+        if (c->packed_p.count(c->d_initw)) need_elems = std::max(need_elems, ((size_t) c->d_latent * dac_row_stride(c, Lq) * 3 + 1) / 2);
         for (auto &b : c->dblocks) {
             need_elems = std::max(need_elems, (size_t) b.cin * dac_row_stride(c, Lq));
             Lq = (Lq - 1) * b.stride - 2 * b.padding + 2 * b.stride;
             need_elems = std::max(need_elems, (size_t) b.cout * dac_row_stride(c, Lq));
+            if (c->packed_p.count(b.res[0].in_w)) need_elems = std::max(need_elems, ((size_t) b.cout * dac_row_stride(c, Lq) * 3 + 1) / 2);
         }
         need_elems *= n;
         pcm_elems = (size_t) n * dac_row_stride(c, Lq);
     }
-    if (need_frames > c->dac_cap_frames || need_elems > c->dbuf_elems || pcm_elems > c->h_pcm_elems) {
+    // the device's codec buffers (the caller holds the device's pass lock)
+    DacBuffers &B = g_dac_buffers[(unsigned) c->device % 64];
+    if (!c->dac_buf_user) { c->dac_buf_user = true; B.users++; }
+    if (need_frames * c->d_ncb > B.cap_codes || need_elems > B.dbuf_elems || pcm_elems > B.h_pcm_elems || (!c->packed_p.empty() && !B.dplanes)) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        for (int i = 0; i < 3; i++) { free_dev(c->dbuf[i]); c->dbuf[i] = nullptr; }
-        free_dev(c->d_codes); c->d_codes = nullptr;
-        if (c->h_pcm) { (void) hipHostFree(c->h_pcm); c->h_pcm = nullptr; }
-        c->dbuf_elems = std::max(need_elems, c->dbuf_elems);
-        const size_t cap_frames = std::max(need_frames, c->dac_cap_frames);
-        for (int i = 0; i < 3; i++) HIPCHK(hipMalloc((void **) &c->dbuf[i], c->dbuf_elems * 4));
-        HIPCHK(hipMalloc((void **) &c->d_codes, cap_frames * c->d_ncb * 4));
-        c->h_pcm_elems = std::max(pcm_elems, c->h_pcm_elems);
-        HIPCHK(hipHostMalloc((void **) &c->h_pcm, c->h_pcm_elems * 4));
-        c->dac_cap_frames = cap_frames;
+        for (int i = 0; i < 3; i++) { free_dev(B.dbuf[i]); B.dbuf[i] = nullptr; }
+        free_dev(B.dplanes); B.dplanes = nullptr;
+        free_dev(B.d_codes); B.d_codes = nullptr;
+        if (B.h_pcm) { (void) hipHostFree(B.h_pcm); B.h_pcm = nullptr; }
+        B.dbuf_elems = std::max(need_elems, B.dbuf_elems);
+        const size_t cap_codes = std::max(need_frames * c->d_ncb, B.cap_codes);
+        for (int i = 0; i < 3; i++) HIPCHK(hipMalloc((void **) &B.dbuf[i], B.dbuf_elems * 4));
+        if (!c->packed_p.empty()) HIPCHK(hipMalloc((void **) &B.dplanes, B.dbuf_elems * 4));   // 6 bytes per element of the widest planes class <= a dbuf
+        HIPCHK(hipMalloc((void **) &B.d_codes, cap_codes * 4));
+        B.h_pcm_elems = std::max(pcm_elems, B.h_pcm_elems);
+        HIPCHK(hipHostMalloc((void **) &B.h_pcm, B.h_pcm_elems * 4));
+        B.cap_codes = cap_codes;
     }
     if (n > c->d_frames_cap) {
         free_dev(c->d_frames);
@@ -2959,7 +3067,7 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
     {   // codes padded to [n][Fmax][n_cb]
         size_t off = 0;
         for (uint32_t i = 0; i < n; i++) {
-            if (frames[i]) HIPCHK(hipMemcpyAsync(c->d_codes + (size_t) i * Fmax * c->d_ncb, codes + off * c->d_ncb, (size_t) frames[i] * c->d_ncb * 4,
+            if (frames[i]) HIPCHK(hipMemcpyAsync(B.d_codes + (size_t) i * Fmax * c->d_ncb, codes + off * c->d_ncb, (size_t) frames[i] * c->d_ncb * 4,
                                                  hipMemcpyHostToDevice, c->stream));
             off += frames[i];
         }
@@ -2968,11 +3076,11 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
     bt.n = (int) n; bt.frames = c->d_frames; bt.mult = 1; bt.tot_frames = (double) tot;
     int L = (int) Fmax;                      // longest utterance at this stage
     int LS = dac_row_stride(c, L);           // row stride of this stage's activations
-    float *cur = c->dbuf[0], *t1 = c->dbuf[1], *t2 = c->dbuf[2];
+    float *cur = B.dbuf[0], *t1 = B.dbuf[1], *t2 = B.dbuf[2];
 
     DacEmbedArgs ea{};
     ea.frames = c->d_frames;
-    ea.codes = c->d_codes; ea.codebook = (const float *) (c->arena + c->d_codebook); ea.proj_w = (const float *) (c->arena + c->d_projw);
+    ea.codes = B.d_codes; ea.codebook = (const float *) (c->arena + c->d_codebook); ea.proj_w = (const float *) (c->arena + c->d_projw);
     ea.proj_b = (const float *) (c->arena + c->d_projb); ea.n_cb = c->d_ncb; ea.cb_size = c->d_cbsize; ea.cb_dim = c->d_cbdim;
     ea.latent = c->d_latent; ea.T = L; ea.Tout = LS; ea.out = cur; ea.x_f16 = c->dac_f16 ? 1 : 0;
     CHK(prof_begin(c, TTS_HIP_K_DAC_EMBED, (double) c->d_latent * tot * 4, 2.0 * c->d_latent * tot * c->d_ncb * c->d_cbdim));
@@ -2984,6 +3092,11 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
     CHK(prof_end(c));
     if (n == 1) CHK(dac_snapshot(c, 0, cur, (size_t) c->d_latent, (size_t) L, (size_t) LS));
 
+    if (c->packed_p.count(c->d_initw) && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM)) {
+        // quantizer output -> split planes (no snake in front of the first conv) -> k = 7 conv on planes -> fp32 for the first transposed conv
+        CHK(launch_split(c, bt, cur, c->d_latent, LS, 0, false, (__bf16 *) t2));
+        CHK(launch_conv_planes(c, bt, (const __bf16 *) t2, c->d_latent, LS, c->d_initw, c->d_initb, c->d_c0, 7, 1, nullptr, t1, nullptr, 0, false));
+    } else
     CHK(launch_conv(c, bt, cur, c->d_latent, LS, c->d_initw, c->d_initb, 0, false, c->d_c0, 7, 3, 1, nullptr, false, t1));
     std::swap(cur, t1);
     if (n == 1) CHK(dac_snapshot(c, 1, cur, (size_t) c->d_c0, (size_t) L, (size_t) LS));
@@ -3005,6 +3118,23 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
         std::swap(cur, t1);
         L = Lout; LS = LSout; C = b.cout;
         bt.mult *= b.stride;
+        if (c->packed_p.count(b.res[0].in_w) && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM)) {
+            // a wide class on split planes: the activation a conv consumes is written by its producer already snaked (the consumer's alpha)
+            // and split; the fp32 tensor exists only where the residual add and the next transposed conv need it.
+            //   X (cur, fp32) --split(snake in_alpha 0)--> PA ;  k7(PA) -> PB = split(snake out_alpha) ;  k1(PB) + X -> X' (fp32) [+ PA for the next unit]
+            __bf16 *PA = (__bf16 *) t2, *PB = (__bf16 *) B.dplanes;
+            CHK(launch_split(c, bt, cur, C, LS, b.res[0].in_alpha, true, PA));
+            for (int r = 0; r < 3; r++) {
+                int dil = 1;
+                for (int e = 0; e < r; e++) dil *= 3;
+                CHK(launch_conv_planes(c, bt, PA, C, LS, b.res[r].in_w, b.res[r].in_b, C, 7, dil, nullptr, nullptr, PB, b.res[r].out_alpha, true));
+                CHK(launch_conv_planes(c, bt, PB, C, LS, b.res[r].out_w, b.res[r].out_b, C, 1, 1, cur, t1, r < 2 ? PA : nullptr,
+                                       r < 2 ? b.res[r + 1].in_alpha : 0, r < 2));
+                std::swap(cur, t1);
+            }
+            if (n == 1) CHK(dac_snapshot(c, 2 + (int) bi, cur, (size_t) C, (size_t) L, (size_t) LS));
+            continue;
+        }
         for (int r = 0; r < 3; r++) {  // build_residual_unit: dilation 3^r, padding 3^(r+1) (gnac.h:44-48)
             int dil = 1;
             for (int e = 0; e < r; e++) dil *= 3;
@@ -3023,11 +3153,11 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
         if (n == 1) CHK(dac_snapshot(c, 2 + (int) bi, cur, (size_t) C, (size_t) L, (size_t) LS));
     }
     CHK(launch_conv(c, bt, cur, C, LS, c->d_fw, c->d_fb, c->d_falpha, true, 1, 7, 3, 1, nullptr, true, t1));
-    HIPCHK(hipMemcpyAsync(c->h_pcm, t1, (size_t) n * LS * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(B.h_pcm, t1, (size_t) n * LS * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     size_t off = 0;
     for (uint32_t i = 0; i < n; i++) {
-        memcpy(pcm_out + off, c->h_pcm + (size_t) i * LS, (size_t) frames[i] * c->d_up * 4);
+        memcpy(pcm_out + off, B.h_pcm + (size_t) i * LS, (size_t) frames[i] * c->d_up * 4);
         off += (size_t) frames[i] * c->d_up;
     }
     return 0;
@@ -3987,8 +4117,9 @@ struct KRun {
         ConvArgs a{};
         a.x = x; a.w = c->packed[w_off]; a.b = b; a.alpha = nullptr; a.alpha_out = nullptr; a.resid = acc ? y : nullptr; a.y = y;
         a.cin = cin; a.cout = cout; a.L = (int) L; a.dil = dil; a.pad = pad; a.do_tanh = 0; a.frames = nullptr; a.mult = 1; a.x_f16 = 0;
+        if (prof_begin(c, TTS_HIP_K_KOKORO_CONV, ((double) cin * L + (double) cout * L * (acc ? 2 : 1) + (double) cout * cin * KT) * 4, 2.0 * cout * (double) cin * KT * L) != 0) { err = tts_hip_last_error(); return true; }
         const int rc = CO_T == 128 ? launch_conv_mfma<KT, 2, 2, 2, 2, CI_T>(c, a, 1) : launch_conv_mfma<KT, 2, 2, 1, 4, CI_T>(c, a, 1);
-        if (rc != 0) err = tts_hip_last_error();
+        if (rc != 0 || prof_end(c) != 0) err = tts_hip_last_error();
         return true;
     }
     void conv1d(const float *x, int cin, int64_t L, const float *wt, const float *b, int cout, int K, int stride, int pad, int dil, int in_shift, float *y, int64_t Lout,

@@ -15,7 +15,7 @@ MAX_DAC_BLOCKS = 8
 
 FLAG_NO_GRAPH, FLAG_VALU_GEMM, FLAG_NO_DAC, FLAG_NO_PARLER, FLAG_DEQUANT_Q, FLAG_DAC_F32 = 1, 2, 4, 8, 16, 32
 KCLASSES = ["embed", "ln", "gemm_qkv", "attn_self", "gemm_attn_out", "gemm_cross_q", "attn_cross", "gemm_cross_out", "gemm_fc1",
-            "gemm_fc2", "gemm_heads", "sample", "gemm_other", "dac_embed", "dac_conv7", "dac_conv1", "dac_convt", "dac_final", "dac_resunit"]
+            "gemm_fc2", "gemm_heads", "sample", "gemm_other", "dac_embed", "dac_conv7", "dac_conv1", "dac_convt", "dac_final", "dac_resunit", "kokoro_conv_mfma"]
 
 
 class HipError(RuntimeError):
@@ -85,7 +85,7 @@ EXPORTS = [
     "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits",
     "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_orpheus_generate_sampled", "tts_hip_orpheus_sample_logits", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_dia_encode_slot", "tts_hip_dia_step_batch", "tts_hip_dia_generate", "tts_hip_kokoro_create", "tts_hip_kokoro_durations", "tts_hip_kokoro_generate", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
-    "tts_hip_synchronize", "tts_hip_broadcast_weights", "tts_hip_comm_unique_id", "tts_hip_broadcast_weights_rank",
+    "tts_hip_synchronize", "tts_hip_dac_arith", "tts_hip_broadcast_weights", "tts_hip_comm_unique_id", "tts_hip_broadcast_weights_rank",
 ]
 
 class Sampling(C.Structure):
@@ -124,6 +124,7 @@ def load_lib():
     L.tts_hip_arena_ptr.restype = vp
     L.tts_hip_arena_filled.argtypes = [vp]
     L.tts_hip_broadcast_weights.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
+    L.tts_hip_dac_arith.argtypes = [vp]
     L.tts_hip_comm_unique_id.argtypes = [vp]
     L.tts_hip_broadcast_weights_rank.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
     L.tts_hip_parler_set_text_encoding.argtypes = [vp, f32p, C.c_uint32]
@@ -431,6 +432,22 @@ class T5Engine:
             self.close()
         except Exception:
             pass
+
+
+def engine_profile(engine, enable):
+    """tts_hip_profile on any engine's context (1: every launch, 2: codec launches only, 0: off)"""
+    if engine.L.tts_hip_profile(engine.ctx, int(enable)) != 0:
+        raise HipError(engine.L.tts_hip_last_error().decode())
+
+
+def engine_profile_get(engine):
+    res = {}
+    for k, name in enumerate(KCLASSES):
+        st = KStat()
+        if engine.L.tts_hip_profile_get(engine.ctx, k, C.byref(st)) != 0:
+            raise HipError(engine.L.tts_hip_last_error().decode())
+        res[name] = dict(ms_total=st.ms_total, launches=int(st.launches), bytes_total=st.bytes_total, flops_total=st.flops_total)
+    return res
 
 
 class SnacEngine:
