@@ -444,7 +444,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TTS_BENCH_BATCH", "384")), help="utterances per context decoded in lock-step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TTS_BENCH_BATCH", "1024")),
+                    help="utterances per context decoded in lock-step (1024: every decoder GEMM is whole rounds of tiles over the 256 CUs; 3 x 384 was the round-2 default)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TTS_BENCH_STREAMS", "3")),
                     help="independent runners (contexts, HIP streams) per GPU; each decodes --batch utterances per step")
     ap.add_argument("--audio-steps", type=int, default=256, help="AR audio steps per utterance (random weights never emit EOS: max_generation = prompt + this)")

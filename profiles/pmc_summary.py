@@ -26,8 +26,11 @@ for name, cs in sorted(acc.items(), key=lambda kv: -sum(v[0] for v in kv[1].valu
 
 # ---- optional: per-kernel-class JSON for bench.py's roofline.traffic ---------------------------------------
 import json, os
-CLASS = [("conv1d_mfma_kernel<7", "dac_conv7"), ("conv1d_mfma_kernel<1", "dac_conv1"), ("convt1d_mfma_kernel", "dac_convt"),
-         ("conv1d_cout1_kernel", "dac_final"), ("dac_embed_kernel", "dac_embed"), ("ln_rows_kernel", "ln"), ("embed_rows_kernel", "embed")]
+CLASS = [("attn_short_kernel", "attn_cross"), ("attn_kernel", "attn_self"), ("attn_combine", "attn_self"), ("gemm_tile_kernel", "gemm_qkv"), ("gemm16_kernel", "gemm_qkv"),
+         ("ln_rows", "ln"), ("resunit_b3_kernel", "dac_resunit"), ("conv_b3p_kernel<7", "dac_conv7"), ("conv1d_mfma_b3_kernel", "dac_conv7"),
+         ("conv1d_mfma_kernel<7", "dac_conv7"), ("conv_b3p_kernel<1", "dac_conv1"), ("snake_split_kernel", "dac_conv1"), ("conv1d_mfma_kernel<1", "dac_conv1"),
+         ("conv1x1_direct_kernel", "dac_conv1"), ("convt_b3_kernel", "dac_convt"), ("convt1d_mfma_kernel", "dac_convt"),
+         ("conv1d_cout1_kernel", "dac_final"), ("dac_embed", "dac_embed"), ("embed_rows_kernel", "embed")]   # first match wins
 if os.environ.get("PMC_JSON_OUT"):
     agg = {}
     for name, cs in acc.items():
@@ -38,6 +41,7 @@ if os.environ.get("PMC_JSON_OUT"):
                     if cn in a:
                         a[cn][0] += tot
                         a[cn][1] += n
+                break
     out = {"workload": json.loads(os.environ.get("PMC_WORKLOAD", "{}")), "kernels": {},
            "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 "
                      "(FETCH_SIZE counts half the bytes of wide coalesced reads on gfx950, MI355X_MICROARCH.md)"}

@@ -538,12 +538,13 @@ def test_parler_mini_full_size_step():
     eng.close()
 
 
-SAMPLE_ROWS = {128: (0, 15, 16, 63, 64, 127), 384: (0, 31, 32, 127, 128, 255, 256, 383), 1152: (0, 127, 128, 511, 512, 640, 1023, 1024, 1151)}
+SAMPLE_ROWS = {128: (0, 15, 16, 63, 64, 127), 384: (0, 31, 32, 127, 128, 255, 256, 383), 1024: (0, 127, 128, 511, 512, 640, 895, 896, 1023),
+               1152: (0, 127, 128, 511, 512, 640, 1023, 1024, 1151)}
 
 
-@pytest.mark.parametrize("rows", [128, 384] + ([1152] if int(os.environ.get("TTS_HIP_MAX_ROWS", "0")) >= 1152 else []))
+@pytest.mark.parametrize("rows", [128, 384, 1024] + ([1152] if int(os.environ.get("TTS_HIP_MAX_ROWS", "0")) >= 1152 else []))
 def test_parler_mini_full_size_many_rows(rows):
-    """The measured configuration (bench.py: H=1024, 24 layers, fp16 weights, 128..384 lock-step rows): the LDS-tiled GEMM
+    """The measured configuration (bench.py: H=1024, 24 layers, fp16 weights, 128..1024 lock-step rows): the LDS-tiled GEMM
     path (gemm_tile_kernels.h: every tile shape the cost model picks at these sizes, split-K slabs folded by the next
     LayerNorm, KV append from the tile epilogue), 4 steps, a sample of rows at the tile / wave / row-group boundaries against
     per-row oracles.  Each row feeds its own arg-max back, like the device loop does."""

@@ -1182,8 +1182,11 @@ static int max_rows_for(const tts_hip_ctx *c) {
         for (const W *w : {&y.qkv, &y.o, &y.cq, &y.co, &y.fc1, &y.fc2})
             if (w->type != TTS_HIP_F16 && w->N) return 256;
     if (c->heads.type != TTS_HIP_F16) return 256;
-    if (const char *e = getenv("TTS_HIP_MAX_ROWS")) return std::max(256, atoi(e));   // experiment: lock-step forwards of more than 512 rows
-    return 512;
+    // 1024 rows per forward: every GEMM of a Parler-Mini layer is a whole number of rounds of 128 x 128 (N = 4096, 3072) or 64 x 64 (N = 1024)
+    // tiles over the 256 CUs; at 1152 rows the ninth row tile costs a second, nearly empty round (146 vs 101 us of GEMMs per layer,
+    // profiles/r03/rows1152_classes.txt / rows1024_classes.txt).  TTS_HIP_MAX_ROWS raises or lowers the cap.
+    if (const char *e = getenv("TTS_HIP_MAX_ROWS")) return std::max(256, atoi(e));
+    return 1024;
 }
 
 template <int EPI, int RB, int QPRO>
