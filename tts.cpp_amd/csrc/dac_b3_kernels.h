@@ -411,6 +411,34 @@ __global__ void pack_conv_w_b3p_kernel(const float *src, __bf16 *dst, int cout, 
     }
 }
 
+// XCD-aware tile order.  Workgroup ids go round-robin over the 8 XCDs (each with its own L2).  With the plain (position tile, channel tile,
+// utterance) grid the channel tiles of one position tile are dispatched far apart, each on another XCD, and every one of them pulls the input
+// tile from memory again: 5 x the algorithmic traffic on the k = 7 convs of the wide classes, 4.5 x on the stride-8 transposed convs
+// (profiles/r03/pmc_fetch_write_round3.txt).  Here the grid is one-dimensional, 8 * ceil(columns / 8) * nco workgroups, and workgroup g is
+// item w = g / 8 of XCD g % 8: its channel tile is w % nco and its column (position tile, utterance) is (w / nco) * 8 + g % 8, so the nco
+// channel tiles of a column are consecutive items of ONE XCD: the input tile leaves memory once, the other channel tiles take it from that L2.
+// When the layer's weights outweigh its input (few positions per utterance: the first conv, the first transposed conv) the plain order —
+// channel tile slowest, so that the workgroups in flight share one weight tile — moves less (nco < 0 selects it).
+struct TileId { int pos, co, z; bool valid; };
+__device__ __forceinline__ TileId xcd_tile(int npos, int nco_signed, int nz) {
+    const unsigned g = blockIdx.x, xcd = g & 7u, w = g >> 3;
+    const unsigned nco = (unsigned) (nco_signed < 0 ? -nco_signed : nco_signed), ncols = (unsigned) npos * (unsigned) nz;
+    TileId t;
+    unsigned col;
+    if (nco_signed < 0) { col = g % ncols; t.co = (int) (g / ncols); t.valid = g < ncols * nco; }
+    else { col = (w / nco) * 8u + xcd; t.co = (int) (w % nco); t.valid = col < ncols; }
+    t.z = (int) (col / (unsigned) npos);
+    t.pos = (int) (col % (unsigned) npos);
+    return t;
+}
+// weights_outweigh: 4 x the weight bytes >= the input bytes of the launch -> plain order
+__host__ inline int xcd_order(int nco, double input_bytes, double weight_bytes) { return 4.0 * weight_bytes >= input_bytes ? -nco : nco; }
+__host__ inline unsigned xcd_grid(int npos, int nco, int nz) {
+    const unsigned cols = (unsigned) npos * (unsigned) nz;
+    return 8u * ((cols + 7u) / 8u) * (unsigned) nco;
+}
+__device__ __forceinline__ int valid_len_z(const uint32_t *frames, int mult, int L, int z) { return frames ? (int) frames[z] * mult : L; }
+
 struct PConvArgs {
     const __bf16 *xp;        // input planes [n][3][cin/8][L][8]
     const __bf16 *w;         // packed weights (pack_conv_w_b3p_kernel)
@@ -421,6 +449,7 @@ struct PConvArgs {
     const float *alpha_out;  // snake applied before the split of yp, or NULL
     int cin, cout, L, dil, pad;   // L = row stride
     const uint32_t *frames; int mult;
+    int npos, nco, nz;       // tiles along positions / output channels, utterances (xcd_tile)
 };
 
 // one lane's 4 consecutive channels of one position: bias (+ residual) -> fp32 out and / or snake + split -> planes out
@@ -467,14 +496,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T;
+    const TileId tile = xcd_tile(a.npos, a.nco, a.nz);
+    if (!tile.valid) return;
+    const int t0 = tile.pos * T_T, co0 = tile.co * CO_T;
     const int CGI = a.cin / 8;
     const int n_chunks = CGI / NCG;
-    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    const int LS = a.L, L = valid_len_z(a.frames, a.mult, a.L, tile.z);
     if (t0 >= L) return;
     const int64_t psti = (int64_t) CGI * LS * 8;             // bf16 per input plane
-    const __bf16 *xg = a.xp + (int64_t) blockIdx.z * 3 * psti;
-    const uint4d *wg = (const uint4d *) (a.w + (int64_t) blockIdx.y * n_chunks * 3 * WPL);
+    const __bf16 *xg = a.xp + (int64_t) tile.z * 3 * psti;
+    const uint4d *wg = (const uint4d *) (a.w + (int64_t) tile.co * n_chunks * 3 * WPL);
 
     float16d acc[MI][NI];
 #pragma unroll
@@ -567,10 +598,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
         __syncthreads();
     }
 
-    const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * LS : nullptr;
-    float *yg = a.y ? a.y + (int64_t) blockIdx.z * a.cout * LS : nullptr;
+    const float *rg = a.resid ? a.resid + (int64_t) tile.z * a.cout * LS : nullptr;
+    float *yg = a.y ? a.y + (int64_t) tile.z * a.cout * LS : nullptr;
     const int64_t psto = (int64_t) (a.cout / 8) * LS * 8;
-    __bf16 *ypz = a.yp ? a.yp + (int64_t) blockIdx.z * 3 * psto : nullptr;
+    __bf16 *ypz = a.yp ? a.yp + (int64_t) tile.z * 3 * psto : nullptr;
 #pragma unroll
     for (int i = 0; i < MI; i++)
 #pragma unroll
@@ -632,14 +663,16 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
     float2 *tin = (float2 *) (xsb + 2 * 3 * xpl);            // [cin] {alpha, 1 / alpha}
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int ti0 = blockIdx.x * TI_T, co0 = blockIdx.y * CO_T;
+    const TileId tile = xcd_tile(a.npos, a.nco, a.nz);
+    if (!tile.valid) return;
+    const int ti0 = tile.pos * TI_T, co0 = tile.co * CO_T;
     const int n_chunks = a.cin / 16;
-    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    const int LS = a.L, L = valid_len_z(a.frames, a.mult, a.L, tile.z);
     const int LoS = a.Lout, Lout = a.frames ? (L - 1) * S - 2 * a.pad + K2 : a.Lout;
     if (ti0 > L) return;  // ti runs 0..L inclusive
-    const float *xg = a.x + (int64_t) blockIdx.z * a.cin * LS;
-    float *yg = a.y + (int64_t) blockIdx.z * a.cout * LoS;
-    const uint4d *wg = (const uint4d *) ((const __bf16 *) a.w + (int64_t) blockIdx.y * n_chunks * 3 * WPL);
+    const float *xg = a.x + (int64_t) tile.z * a.cin * LS;
+    float *yg = a.y + (int64_t) tile.z * a.cout * LoS;
+    const uint4d *wg = (const uint4d *) ((const __bf16 *) a.w + (int64_t) tile.co * n_chunks * 3 * WPL);
 
     for (int i = tid; i < a.cin; i += NT) {
         const float al = a.alpha ? a.alpha[i] : 1.0f;

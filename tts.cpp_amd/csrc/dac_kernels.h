@@ -287,6 +287,7 @@ struct ConvTArgs {
     int mult;
     int x_f16;               // F16 kernel: inputs rounded to fp16 (ggml_compute_forward_conv_transpose_1d_f16_f32)
     int alpha_tab;           // as ConvArgs
+    int npos, nco, nz;       // convt_b3_kernel: tiles along ti / output channels, utterances (xcd_tile in dac_b3_kernels.h)
 };
 
 #define CT_CI 8

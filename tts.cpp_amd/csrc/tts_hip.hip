@@ -2858,8 +2858,10 @@ static int launch_convt_b3(tts_hip_ctx *c, const ConvTArgs &a, int nz) {
     if (attr_needed(attr, c->device)) {
         HIPCHK(hipFuncSetAttribute((const void *) convt_b3_kernel<S, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    const dim3 grid((a.L + 1 + 255) / 256, a.cout / CO_T, nz);  // ti runs 0..L inclusive
-    hipLaunchKernelGGL((convt_b3_kernel<S, MI>), grid, dim3(512), lds, c->stream, a);
+    ConvTArgs b = a;
+    b.npos = (a.L + 1 + 255) / 256; b.nz = nz;   // ti runs 0..L inclusive
+    b.nco = xcd_order(a.cout / CO_T, (double) a.cin * a.L * nz * 4, (double) a.cout * a.cin * 2 * S * 6);
+    hipLaunchKernelGGL((convt_b3_kernel<S, MI>), dim3(xcd_grid(b.npos, a.cout / CO_T, b.nz)), dim3(512), lds, c->stream, b);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2920,7 +2922,10 @@ static int launch_conv_b3p_t(tts_hip_ctx *c, const PConvArgs &a, int nz) {
     if (attr_needed(attr, c->device)) {
         HIPCHK(hipFuncSetAttribute((const void *) conv_b3p_kernel<KT, MI, NI, WM, WN, NS, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    hipLaunchKernelGGL((conv_b3p_kernel<KT, MI, NI, WM, WN, NS, MINW>), dim3((a.L + T_T - 1) / T_T, a.cout / CO_T, nz), dim3(64 * WM * WN), lds, c->stream, a);
+    PConvArgs b = a;
+    b.npos = (a.L + T_T - 1) / T_T; b.nz = nz;
+    b.nco = xcd_order(a.cout / CO_T, (double) a.cin * a.L * nz * 6, (double) a.cout * a.cin * KT * 6);
+    hipLaunchKernelGGL((conv_b3p_kernel<KT, MI, NI, WM, WN, NS, MINW>), dim3(xcd_grid(b.npos, a.cout / CO_T, b.nz)), dim3(64 * WM * WN), lds, c->stream, b);
     HIPCHK(hipGetLastError());
     return 0;
 }
