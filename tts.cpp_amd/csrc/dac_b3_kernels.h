@@ -384,7 +384,8 @@ __global__ __launch_bounds__(256) void snake_split_kernel(SplitArgs a) {
 }
 
 //   src [cout][cin][KT] -> dst [co_tile][chunk][plane][s < NS][hi][CO_T][8]
-//   KT = 7 (NS = 4): ci = 8 chunk + j, tap = 2 s + hi (tap 7: zero);   KT = 1: ci = 16 NS chunk + 8 (2 s + hi) + j
+//   KT = 7, NS = 4: ci = 8 chunk + j, tap = 2 s + hi (tap 7: zero);   KT = 7, NS = 7: ci = 16 chunk + 8 hi + j, tap = s;
+//   KT = 1: ci = 16 NS chunk + 8 (2 s + hi) + j
 __global__ void pack_conv_w_b3p_kernel(const float *src, __bf16 *dst, int cout, int cin, int KT, int CO_T, int NS, int n_chunks) {
     const int64_t plane_sz = (int64_t) NS * 2 * CO_T * 8;
     const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * plane_sz;
@@ -398,7 +399,8 @@ __global__ void pack_conv_w_b3p_kernel(const float *src, __bf16 *dst, int cout, 
         const int ct = (int) (r / n_chunks);
         const int co = ct * CO_T + col;
         int ci, tap;
-        if (KT == 7) { ci = ch * 8 + j; tap = 2 * st + hi; }
+        if (KT == 7 && NS == 7) { ci = ch * 16 + 8 * hi + j; tap = st; }
+        else if (KT == 7) { ci = ch * 8 + j; tap = 2 * st + hi; }
         else { ci = ch * 16 * NS + 8 * (2 * st + hi) + j; tap = 0; }
         float v = 0.0f;
         if (co < cout && ci < cin && tap < KT) v = src[((int64_t) co * cin + ci) * KT + tap];
@@ -480,19 +482,25 @@ __device__ __forceinline__ void b3p_store4(const PConvArgs &a, float v0, float v
     }
 }
 
-template <int KT, int MI, int NI, int WM, int WN, int NS, int MINW>
+// k = 7, NS = 7 (round 3, "tap per k-step"): chunk = 16 input channels, k-step s = tap s, the half-wave takes 8-channel group hi — 7 k-steps per
+// 16 channels where the NS = 4 form (chunk = 8 channels, half-wave = tap parity) spends 8 with the eighth tap slot on zero weights.
+// NB = 1: one LDS buffer, the next chunk waits in registers and is committed between two barriers; with two workgroups per CU the other one
+// computes meanwhile (NB = 2: the next chunk is committed into the other buffer while the workgroup's own waves still compute).
+template <int KT, int MI, int NI, int WM, int WN, int NS, int MINW, int NB = 2>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs a) {
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, NT = 64 * WM * WN;
-    constexpr int NCG = KT == 7 ? 1 : 2 * NS;                // 8-channel groups per chunk
+    constexpr bool TAPK = KT == 7 && NS == 7;
+    constexpr int NCG = KT == 7 ? (TAPK ? 2 : 1) : 2 * NS;   // 8-channel groups per chunk
     constexpr int WPL = NS * 2 * CO_T * 8;                   // bf16 per weight plane of a chunk
     constexpr int WV = (3 * WPL / 8 + NT - 1) / NT;          // 16-byte vectors per thread per chunk (all planes)
     constexpr int XP = (T_T + (KT - 1) * 9 + NT - 1) / NT;   // position rows per thread per (plane, group), dilation <= 9
-    static_assert(KT == 1 || NS == 4, "k = 7: four k-steps (tap pairs) per 8-channel chunk");
+    static_assert(KT == 1 || NS == 4 || NS == 7, "k = 7: four k-steps (tap pairs) per 8-channel chunk, or seven (taps) per 16-channel chunk");
+    static_assert(NB == 1 || NB == 2, "LDS buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int xw = T_T + (KT - 1) * a.dil;
     const int xsz = 3 * NCG * xw * 8;                        // bf16 per input chunk image [plane][group][position][8]
-    __bf16 *wsb = (__bf16 *) smem;                           // [2][3][WPL]
-    __bf16 *xsb = wsb + 2 * 3 * WPL;                         // [2][xsz]
+    __bf16 *wsb = (__bf16 *) smem;                           // [NB][3][WPL]
+    __bf16 *xsb = wsb + NB * 3 * WPL;                        // [NB][xsz]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -562,14 +570,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
     commit(0);
     __syncthreads();
     for (int c = 0; c < n_chunks; c++) {
-        const int buf = c & 1;
+        const int buf = NB == 2 ? (c & 1) : 0;
         if (c + 1 < n_chunks) prefetch(c + 1);
         const __bf16 *ws = wsb + buf * 3 * WPL;
         const __bf16 *xs = xsb + buf * xsz;
 #pragma unroll
         for (int st = 0; st < NS; st++) {
             int xoff;   // bf16 offset of this half-wave's B rows inside a plane image
-            if constexpr (KT == 7) {
+            if constexpr (TAPK) {
+                xoff = (hi * xw + st * a.dil) * 8;                           // group hi, tap st
+            } else if constexpr (KT == 7) {
                 const int tap = (2 * st + hi < KT) ? 2 * st + hi : KT - 1;   // the eighth tap: zero weights, any valid rows
                 xoff = tap * a.dil * 8;
             } else {
@@ -594,8 +604,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
                     for (int j = 0; j < NI; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[tm]][i], bf[TB[tm]][j], acc[i][j], 0, 0, 0);
         }
-        if (c + 1 < n_chunks) commit(buf ^ 1);
-        __syncthreads();
+        if constexpr (NB == 2) {
+            if (c + 1 < n_chunks) commit(buf ^ 1);
+            __syncthreads();
+        } else {
+            __syncthreads();                     // every wave is done with the buffer
+            if (c + 1 < n_chunks) {
+                commit(0);
+                __syncthreads();
+            }
+        }
     }
 
     const float *rg = a.resid ? a.resid + (int64_t) tile.z * a.cout * LS : nullptr;

@@ -338,6 +338,8 @@ struct tts_hip_ctx {
     std::map<size_t, __bf16 *> packed_b3;   // k = 7 conv weights as three bf16 planes (dac_b3, experiment)
     std::map<size_t, __bf16 *> packed_ru;   // residual unit (keyed by its k = 7 weight) -> stage stream of resunit_b3_kernel
     std::map<size_t, __bf16 *> packed_p;    // conv weight -> bf16 planes in stage order for conv_b3p_kernel (k = 7: 64-channel tiles, k = 1: 128-channel tiles)
+    int dac_p_variant = 0;      // TTS_HIP_DAC_P_VARIANT: tile shape of the k = 7 convs on planes (0 = 4 waves, one LDS buffer, two workgroups per CU: measured best, profiles/r03/tap7_call16.txt)
+    int dac_tap7 = 1;           // TTS_HIP_DAC_TAP7=0: the k = 7 convs on planes keep the tap-pair k-steps (8 slots for 7 taps) instead of one tap per k-step
     int dac_planes = 1;         // TTS_HIP_DAC_PLANES=0: the wide classes (channels % 128 == 0, no fused unit) keep fp32 activations and stage snake + split per tile
     bool dac_buf_user = false;  // counted in g_dac_buffers[device].users
     std::map<size_t, __bf16 *> packed_ct;   // transposed conv weight -> bf16 planes of convt_b3_kernel
@@ -441,6 +443,8 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_DAC_FUSE")) c->dac_fuse = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_CONVT_B3")) c->dac_convt_b3 = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_PLANES")) c->dac_planes = atoi(e);
+    if (const char *e = getenv("TTS_HIP_DAC_TAP7")) c->dac_tap7 = atoi(e);
+    if (const char *e = getenv("TTS_HIP_DAC_P_VARIANT")) c->dac_p_variant = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
@@ -2579,8 +2583,9 @@ static bool planes_class(const tts_hip_ctx *c, int ch) {
     return c->dac_planes && c->dac_b3 && !c->dac_f16 && ch % 128 == 0 && !(c->dac_fuse && resunit_shape(ch, &ks, &ks2));
 }
 static int pack_planes(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT) {
-    const int CO_T = KT == 7 ? 64 : 128, NS = KT == 7 ? 4 : 1;
-    const int n_chunks = KT == 7 ? cin / 8 : cin / 16;
+    const bool tapk = KT == 7 && c->dac_tap7 && cin % 16 == 0;
+    const int CO_T = KT == 7 ? 64 : 128, NS = KT == 7 ? (tapk ? 7 : 4) : 1;
+    const int n_chunks = KT == 7 && !tapk ? cin / 8 : cin / 16;
     const size_t n = (size_t) (cout / CO_T) * n_chunks * 3 * NS * 2 * CO_T * 8;
     __bf16 *dst = nullptr;
     HIPCHK(hipMalloc((void **) &dst, n * 2));
@@ -2913,19 +2918,19 @@ static int launch_split(tts_hip_ctx *c, const DacBatch &bt, const float *x, int 
     HIPCHK(hipGetLastError());
     return prof_end(c);
 }
-template <int KT, int MI, int NI, int WM, int WN, int NS, int MINW>
+template <int KT, int MI, int NI, int WM, int WN, int NS, int MINW, int NB = 2>
 static int launch_conv_b3p_t(tts_hip_ctx *c, const PConvArgs &a, int nz) {
-    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WPL = NS * 2 * CO_T * 8, NCG = KT == 7 ? 1 : 2 * NS;
+    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WPL = NS * 2 * CO_T * 8, NCG = KT == 7 ? (NS == 7 ? 2 : 1) : 2 * NS;
     const int xw = T_T + (KT - 1) * a.dil;
-    const size_t lds = (size_t) 2 * 3 * WPL * 2 + (size_t) 2 * 3 * NCG * xw * 8 * 2;
+    const size_t lds = (size_t) NB * (3 * WPL * 2 + (size_t) 3 * NCG * xw * 8 * 2);
     static std::atomic<uint64_t> attr{0};
     if (attr_needed(attr, c->device)) {
-        HIPCHK(hipFuncSetAttribute((const void *) conv_b3p_kernel<KT, MI, NI, WM, WN, NS, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) conv_b3p_kernel<KT, MI, NI, WM, WN, NS, MINW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     PConvArgs b = a;
     b.npos = (a.L + T_T - 1) / T_T; b.nz = nz;
     b.nco = xcd_order(a.cout / CO_T, (double) a.cin * a.L * nz * 6, (double) a.cout * a.cin * KT * 6);
-    hipLaunchKernelGGL((conv_b3p_kernel<KT, MI, NI, WM, WN, NS, MINW>), dim3(xcd_grid(b.npos, a.cout / CO_T, b.nz)), dim3(64 * WM * WN), lds, c->stream, b);
+    hipLaunchKernelGGL((conv_b3p_kernel<KT, MI, NI, WM, WN, NS, MINW, NB>), dim3(xcd_grid(b.npos, a.cout / CO_T, b.nz)), dim3(64 * WM * WN), lds, c->stream, b);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2940,7 +2945,15 @@ static int launch_conv_planes(tts_hip_ctx *c, const DacBatch &bt, const __bf16 *
     const double bytes = ((double) cin * Lv * 6 + (double) cout * Lv * ((resid ? 4 : 0) + (y ? 4 : 0) + (yp ? 6 : 0)) + (double) cout * cin * K * 6);
     CHK(prof_begin(c, K == 7 ? TTS_HIP_K_DAC_CONV7 : TTS_HIP_K_DAC_CONV1, bytes, 2.0 * cout * (double) cin * K * Lv));
     if (K == 7) {
-        if (c->dac_b3_variant == 0) CHK((launch_conv_b3p_t<7, 2, 2, 1, 4, 4, 2>(c, a, bt.n)));      // 64 ch x 256 pos, 4 waves
+        const bool tapk = c->dac_tap7 && cin % 16 == 0;
+        // TTS_HIP_DAC_P_VARIANT: 0 / 2 = 4 / 8 waves; with one tap per k-step: one LDS buffer (73 KB, two workgroups per CU), +10 = two buffers.
+        // 64-utterance pass, k = 7 family: 45.7 (0) / 49.9 (2: 128 registers, spills) / 53.5 (10) / 48.6 (12) ms; tap pairs 50.3 ms
+        const int pv = c->dac_p_variant;
+        if (tapk && pv == 0) CHK((launch_conv_b3p_t<7, 2, 2, 1, 4, 7, 2, 1>(c, a, bt.n)));
+        else if (tapk && pv == 10) CHK((launch_conv_b3p_t<7, 2, 2, 1, 4, 7, 2, 2>(c, a, bt.n)));
+        else if (tapk && pv == 12) CHK((launch_conv_b3p_t<7, 2, 1, 1, 8, 7, 2, 2>(c, a, bt.n)));
+        else if (tapk) CHK((launch_conv_b3p_t<7, 2, 1, 1, 8, 7, 4, 1>(c, a, bt.n)));
+        else if (pv == 0) CHK((launch_conv_b3p_t<7, 2, 2, 1, 4, 4, 2>(c, a, bt.n)));      // 64 ch x 256 pos, 4 waves
         else CHK((launch_conv_b3p_t<7, 2, 1, 1, 8, 4, 4>(c, a, bt.n)));                             // 64 ch x 256 pos, 8 waves, two workgroups per CU
     } else {
         CHK((launch_conv_b3p_t<1, 2, 2, 2, 4, 1, 2>(c, a, bt.n)));                                  // 128 ch x 256 pos, 8 waves
