@@ -62,7 +62,7 @@ MFMA_FP16 = {"gemm_tile_kernel (decoder GEMMs: qkv, out_proj, cross q/out, fc1, 
 MFMA_FP32 = {"conv1d_mfma_kernel<1,...> (DAC k=1 convs + residual of the wide classes)"}
 # families that run fp32 convolutions as bf16 x 3 split products when the codec arithmetic is on (tts_hip_dac_arith): issued bf16 flops per
 # algorithmic flop = six products, and the k = 7 kernels pad their 7 taps to 8 k-slots
-B3_ISSUE = {"resunit_b3_kernel (DAC residual units at 96 / 192 channels, one launch each)": (6.0 * 8.0 + 6.0) / 8.0,     # 7 of 8 flops in the k = 7 conv
+B3_ISSUE = {"resunit_b3_kernel (DAC residual units at 96 / 192 channels, one launch each)": 6.0,     # resunit_t7_kernel: one tap per k-step, no padded slot
             "conv1d_mfma_b3_kernel / conv1d_mfma_kernel<7,...> (DAC k=7 convs of the wide classes)": 6.0,   # conv_b3p_kernel, one tap per k-step: no padded slot
             "convt_b3_kernel / convt1d_mfma_kernel (DAC transposed convs)": 6.0}
 B3_BIT = {"resunit_b3_kernel (DAC residual units at 96 / 192 channels, one launch each)": 2,

@@ -826,3 +826,269 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
         }
     }
 }
+
+// ================================================================================================================================
+// resunit_t7_kernel: resunit_b3_kernel with ONE TAP PER K-STEP in the k = 7 conv.  The 8-channel chunk of resunit_b3_kernel pairs taps
+// (2 s, 2 s + 1) in a k-step, i.e. 8 slots for 7 taps: an eighth of the k = 7 MFMAs multiply zero weights.  Here a chunk is 16 input
+// channels, k-step s is tap s and the half-wave takes 8-channel group hi: 7 k-steps per 16 channels.  The weight stream keeps 36.9 KB
+// stages, now of unequal k-step counts per chunk: 96 channels {4, 3}, 192 channels {2, 2, 2, 1}.  The k = 1 phase, the epilogue and the
+// packing of the k = 1 weights are resunit_b3_kernel's.
+//   stage g = chunk * SPC + sub:  [plane][s < CNT[sub]][hi][co < C][j < 8] = plane of w7[co][ci = 16 chunk + 8 hi + j][tap = FIRST[sub] + s]
+// ================================================================================================================================
+template <int MI> struct ResT7 {
+    static constexpr int SPC = MI == 3 ? 2 : 4;
+    static constexpr int cnt(int sub) { return MI == 3 ? (sub == 0 ? 4 : 3) : (sub == 3 ? 1 : 2); }
+    static constexpr int first(int sub) { return MI == 3 ? (sub == 0 ? 0 : 4) : 2 * sub; }
+    static constexpr int MAXCNT = MI == 3 ? 4 : 2;
+};
+
+__global__ void pack_resunit_t7_kernel(const float *w7, const float *w1, __bf16 *dst, int C, int KS2) {
+    const int MI = C / 32, SPC = MI == 3 ? 2 : 4, MAXCNT = MI == 3 ? 4 : 2;
+    const int64_t WST = (int64_t) 3 * MAXCNT * 2 * C * 8;
+    const int n7 = (C / 16) * SPC, ns1 = (C / 16) / KS2, n1 = (C / 96) * ns1;
+    const int64_t per1 = (int64_t) KS2 * 2 * 96 * 8;
+    // k = 7 part: one thread per (stage, slot s < MAXCNT, hi, co, j); slots beyond the stage's k-step count are skipped
+    const int64_t slot7 = (int64_t) MAXCNT * 2 * C * 8;
+    const int64_t total = (int64_t) n7 * slot7 + (int64_t) n1 * per1;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        int64_t base, plane_sz;
+        if (i < (int64_t) n7 * slot7) {
+            const int st = (int) (i / slot7);
+            int64_t r = i % slot7;
+            const int j = (int) (r % 8); r /= 8;
+            const int co = (int) (r % C); r /= C;
+            const int hi = (int) (r % 2); r /= 2;
+            const int s = (int) r;
+            const int chunk = st / SPC, sub = st % SPC;
+            const int cnt = MI == 3 ? (sub == 0 ? 4 : 3) : (sub == 3 ? 1 : 2), first = MI == 3 ? (sub == 0 ? 0 : 4) : 2 * sub;
+            if (s >= cnt) continue;
+            v = w7[((int64_t) co * C + chunk * 16 + hi * 8 + j) * 7 + first + s];
+            plane_sz = (int64_t) cnt * 2 * C * 8;
+            base = (int64_t) st * WST + ((int64_t) (s * 2 + hi) * C + co) * 8 + j;
+        } else {
+            const int64_t i1 = i - (int64_t) n7 * slot7;
+            const int st = (int) (i1 / per1);
+            int64_t r = i1 % per1;
+            const int m = (int) (r % 8); r /= 8;
+            const int col = (int) (r % 96); r /= 96;
+            const int hi = (int) (r % 2); r /= 2;
+            const int s = (int) r;
+            const int pass = st / ns1, q = st % ns1;
+            const int ks = q * KS2 + s, ib = ks / 2, qq = ks % 2;
+            const int ch = 32 * ib + 16 * qq + (m < 4 ? 4 * hi + m : 8 + 4 * hi + m - 4);
+            v = w1[(int64_t) (96 * pass + col) * C + ch];
+            plane_sz = per1;
+            base = (int64_t) (n7 + st) * WST + (i1 % per1);
+        }
+        __bf16 h1, h2, h3;
+        split_bf16x3(v, h1, h2, h3);
+        dst[base] = h1;
+        dst[base + plane_sz] = h2;
+        dst[base + 2 * plane_sz] = h3;
+    }
+}
+
+template <int MI, int KS2>
+__global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
+    using G = ResT7<MI>;
+    constexpr int C = 32 * MI, WN = 8, NT = 512, T_T = 32 * WN;
+    constexpr int SPC = G::SPC, NCH = C / 16, N7 = NCH * SPC;
+    constexpr int WPL1 = KS2 * 2 * 96 * 8;
+    constexpr int WST = 3 * G::MAXCNT * 2 * C * 8;            // bf16 per stage (stream stride and LDS buffer) >= 3 * WPL1
+    constexpr int NP = MI / 3, NS1 = (C / 16) / KS2, N1 = NP * NS1;
+    constexpr int WV = (WST / 8 + NT - 1) / NT;               // 16-byte vectors per thread per stage
+    static_assert(3 * WPL1 <= WST && (C / 16) % KS2 == 0 && MI % 3 == 0, "stage shapes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int xw = T_T + 6 * a.dil;
+    const int xpl = 2 * xw * 8;                               // bf16 per input plane of a chunk: [group 2][position][8]
+    __bf16 *wsb = (__bf16 *) smem;                            // [2][WST]
+    __bf16 *xsb = wsb + 2 * WST;                              // [2][3][xpl]
+    float4 *tab = (float4 *) (xsb + 2 * 3 * xpl);             // [C] {b7, alpha_mid, 1/alpha_mid, b1}
+    float2 *tin = (float2 *) (tab + C);                       // [C] {alpha_in, 1/alpha_in}
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int t0 = blockIdx.x * T_T;
+    const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
+    if (t0 >= L) return;
+    const float *xg = a.x + (int64_t) blockIdx.z * C * LS;
+    float *yg = a.y + (int64_t) blockIdx.z * C * LS;
+    const uint4d *wg = (const uint4d *) a.w;
+
+    for (int i = tid; i < C; i += NT) {
+        const float am = a.alpha_mid[i], ai = a.alpha_in[i];
+        tab[i] = make_float4(a.b7[i], am, 1.0f / am, a.b1[i]);
+        tin[i] = make_float2(ai, 1.0f / ai);
+    }
+
+    float16d acc[MI];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[i][e] = 0.0f;
+
+    uint4d wreg[WV];
+    float xreg[2][8];                                         // (group, position) units u = tid, tid + 512 of the 2 * xw <= 620 of a chunk
+    auto prefetch_w = [&](int g) __attribute__((always_inline)) {
+        const uint4d *wp = wg + (int64_t) g * (WST / 8);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < WST / 8) wreg[j] = wp[i];
+        }
+    };
+    auto commit_w = [&](int buf) __attribute__((always_inline)) {
+        uint4d *wd = (uint4d *) (wsb + buf * WST);
+#pragma unroll
+        for (int j = 0; j < WV; j++) {
+            const int i = tid + j * NT;
+            if (i < WST / 8) wd[i] = wreg[j];
+        }
+    };
+    auto prefetch_x = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int u = tid + q * NT;
+            const int g = u >= xw ? 1 : 0, p = u - g * xw;   // lanes run along positions: coalesced rows
+            const int t = t0 + p - a.pad;
+            const bool ok = u < 2 * xw && t >= 0 && t < L;
+#pragma unroll
+            for (int e = 0; e < 8; e++) xreg[q][e] = ok ? xg[(int64_t) (c * 16 + g * 8 + e) * LS + t] : 0.0f;
+        }
+    };
+    auto commit_x = [&](int c, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int u = tid + q * NT;
+            if (u < 2 * xw) {
+                const int g = u >= xw ? 1 : 0;
+                float al[8], ral[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) { const float2 t2 = tin[c * 16 + g * 8 + e]; al[e] = t2.x; ral[e] = t2.y; }
+                snake_vec<8>(xreg[q], al, ral);               // snake(0) == 0: zero padding is preserved
+                bf16x8d h1, h2, h3;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    __bf16 b1, b2, b3;
+                    split_bf16x3(xreg[q][e], b1, b2, b3);
+                    h1[e] = b1; h2[e] = b2; h3[e] = b3;
+                }
+                __bf16 *xd = xsb + buf * 3 * xpl + u * 8;     // u = g * xw + p: the [group][position] order of the image
+                *(bf16x8d *) xd = h1;
+                *(bf16x8d *) (xd + xpl) = h2;
+                *(bf16x8d *) (xd + 2 * xpl) = h3;
+            }
+        }
+    };
+
+    prefetch_w(0);
+    prefetch_x(0);
+    __syncthreads();   // tables visible
+    commit_w(0);
+    commit_x(0, 0);
+    __syncthreads();
+
+    // ---- k = 7 conv: NCH chunks of 16 input channels, SPC stages each -----------------------------------------------------------------
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};   // the six partial products, smallest first; term-major over the
+                                                                            // three accumulators: consecutive MFMAs write different registers
+    for (int c = 0; c < NCH; c++) {
+        const __bf16 *xs = xsb + (c & 1) * 3 * xpl;
+        static_for<SPC>([&](auto SUB) __attribute__((always_inline)) {
+            constexpr int sub = decltype(SUB)::value, CNT = G::cnt(sub), FIRST = G::first(sub), WPL7 = CNT * 2 * C * 8;
+            const int g = c * SPC + sub;
+            prefetch_w(g + 1);                                   // the stream continues into the k = 1 stages
+            if (sub == 0 && c + 1 < NCH) prefetch_x(c + 1);
+            const __bf16 *ws = wsb + (g & 1) * WST;
+            static_for<CNT>([&](auto S) __attribute__((always_inline)) {
+                constexpr int s = decltype(S)::value;
+                bf16x8d bf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) bf[pl] = *(const bf16x8d *) (xs + pl * xpl + (hi * xw + wn * 32 + l31 + (FIRST + s) * a.dil) * 8);
+#pragma unroll
+                for (int ig = 0; ig < MI; ig += 3) {
+                    bf16x8d af[3][3];
+#pragma unroll
+                    for (int ii = 0; ii < 3; ii++)
+#pragma unroll
+                        for (int pl = 0; pl < 3; pl++)
+                            af[ii][pl] = *(const bf16x8d *) (ws + pl * WPL7 + (((s * 2 + hi) * C) + (ig + ii) * 32 + l31) * 8);
+#pragma unroll
+                    for (int tm = 0; tm < 6; tm++)
+#pragma unroll
+                        for (int ii = 0; ii < 3; ii++)
+                            acc[ig + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ii][TA[tm]], bf[TB[tm]], acc[ig + ii], 0, 0, 0);
+                }
+            });
+            commit_w((g + 1) & 1);
+            if (sub == SPC - 1 && c + 1 < NCH) commit_x(c + 1, (c + 1) & 1);
+            __syncthreads();
+        });
+    }
+
+    // ---- k = 1 conv: the accumulators (bias, snake, split) are its B fragments; 96 output channels per pass --------------------------
+    const int t = t0 + wn * 32 + l31;
+    float16d acc2[3];
+    static_for<N1>([&](auto G2) __attribute__((always_inline)) {
+        constexpr int g2 = decltype(G2)::value, p = g2 / NS1, q = g2 % NS1;
+        if constexpr (q == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc2[i][e] = 0.0f;
+        }
+        if constexpr (g2 + 1 < N1) prefetch_w(N7 + g2 + 1);
+        const __bf16 *ws = wsb + ((N7 + g2) & 1) * WST;
+        static_for<KS2>([&](auto S) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value, ks = q * KS2 + s, ib = ks / 2, qq = ks % 2;
+            bf16x8d bf[3];
+            float hv[8], al[8], ral[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int e = 8 * qq + m;
+                const int ch = 32 * ib + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                const float4 tb = tab[ch];
+                hv[m] = acc[ib][e] + tb.x; al[m] = tb.y; ral[m] = tb.z;
+            }
+            snake_vec<8>(hv, al, ral);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                __bf16 b1, b2, b3;
+                split_bf16x3(hv[m], b1, b2, b3);
+                bf[0][m] = b1; bf[1][m] = b2; bf[2][m] = b3;
+            }
+            bf16x8d af[3][3];
+#pragma unroll
+            for (int ii = 0; ii < 3; ii++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    af[ii][pl] = *(const bf16x8d *) (ws + pl * WPL1 + (((s * 2 + hi) * 96) + ii * 32 + l31) * 8);
+#pragma unroll
+            for (int tm = 0; tm < 6; tm++)
+#pragma unroll
+                for (int ii = 0; ii < 3; ii++)
+                    acc2[ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ii][TA[tm]], bf[TB[tm]], acc2[ii], 0, 0, 0);
+        });
+        if constexpr (g2 + 1 < N1) {
+            commit_w((N7 + g2 + 1) & 1);
+            __syncthreads();
+        }
+        if constexpr (q == NS1 - 1) {   // + bias + x
+            if (t < L) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    float rv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int co = 96 * p + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                        rv[e] = xg[(int64_t) co * LS + t];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int co = 96 * p + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                        yg[(int64_t) co * LS + t] = (acc2[i][e] + tab[co].w) + rv[e];
+                    }
+                }
+            }
+        }
+    });
+}

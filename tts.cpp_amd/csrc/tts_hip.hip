@@ -2546,12 +2546,21 @@ static bool resunit_shape(int C, int *KS, int *KS2) {
 static int pack_resunit(tts_hip_ctx *c, const DRes &r, int C) {
     int KS = 0, KS2 = 0;
     if (!resunit_shape(C, &KS, &KS2)) return 0;
-    const ResUnitGeom g = resunit_geom(C, KS, KS2);
-    const size_t n = (size_t) (g.n7 + g.n1 + 1) * g.WST;   // + 1: the prefetch of the stage after the last one stays inside the buffer
     __bf16 *dst = nullptr;
-    HIPCHK(hipMalloc((void **) &dst, n * 2));
-    HIPCHK(hipMemsetAsync(dst, 0, n * 2, c->stream));
-    hipLaunchKernelGGL(pack_resunit_b3_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + r.in_w), (const float *) (c->arena + r.out_w), dst, C, KS, KS2);
+    if (c->dac_tap7) {   // resunit_t7_kernel: one tap per k-step, stages of {4, 3} / {2, 2, 2, 1} k-steps per 16-channel chunk
+        const int MI = C / 32, SPC = MI == 3 ? 2 : 4, MAXCNT = MI == 3 ? 4 : 2;
+        const size_t WST = (size_t) 3 * MAXCNT * 2 * C * 8;
+        const size_t n = (size_t) ((C / 16) * SPC + (C / 96) * ((C / 16) / KS2) + 1) * WST;
+        HIPCHK(hipMalloc((void **) &dst, n * 2));
+        HIPCHK(hipMemsetAsync(dst, 0, n * 2, c->stream));
+        hipLaunchKernelGGL(pack_resunit_t7_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + r.in_w), (const float *) (c->arena + r.out_w), dst, C, KS2);
+    } else {
+        const ResUnitGeom g = resunit_geom(C, KS, KS2);
+        const size_t n = (size_t) (g.n7 + g.n1 + 1) * g.WST;   // + 1: the prefetch of the stage after the last one stays inside the buffer
+        HIPCHK(hipMalloc((void **) &dst, n * 2));
+        HIPCHK(hipMemsetAsync(dst, 0, n * 2, c->stream));
+        hipLaunchKernelGGL(pack_resunit_b3_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + r.in_w), (const float *) (c->arena + r.out_w), dst, C, KS, KS2);
+    }
     HIPCHK(hipGetLastError());
     c->packed_ru[r.in_w] = dst;
     return 0;
@@ -2976,6 +2985,20 @@ static int launch_resunit_t(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
     HIPCHK(hipGetLastError());
     return 0;
 }
+template <int MI, int KS2>
+static int launch_resunit_t7(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
+    constexpr int C = 32 * MI;
+    const int xw = 256 + 6 * a.dil;
+    const size_t WST = (size_t) 3 * ResT7<MI>::MAXCNT * 2 * C * 8;
+    const size_t lds = 2 * WST * 2 + (size_t) 6 * 2 * xw * 8 * 2 + (size_t) C * 24;
+    static std::atomic<uint64_t> attr{0};
+    if (attr_needed(attr, c->device)) {
+        HIPCHK(hipFuncSetAttribute((const void *) resunit_t7_kernel<MI, KS2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    hipLaunchKernelGGL((resunit_t7_kernel<MI, KS2>), dim3((a.L + 255) / 256, 1, nz), dim3(512), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 static bool resunit_fused(const tts_hip_ctx *c, const DRes &r, int dil) {
     return c->dac_fuse && !c->dac_f16 && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM) && dil <= 9 && c->packed_ru.count(r.in_w);
 }
@@ -2987,7 +3010,10 @@ static int launch_resunit(tts_hip_ctx *c, const DacBatch &bt, const DRes &r, int
     a.L = LS; a.dil = dil; a.pad = 3 * dil; a.frames = bt.frames; a.mult = bt.mult;
     const double Lv = bt.tot_frames * bt.mult;
     CHK(prof_begin(c, TTS_HIP_K_DAC_RESUNIT, (2.0 * C * Lv + 8.0 * C * C) * 4, 2.0 * C * (double) C * 8 * Lv));
-    if (C == 96) CHK((launch_resunit_t<3, 4, 3>(c, a, bt.n)));
+    if (c->dac_tap7) {
+        if (C == 96) CHK((launch_resunit_t7<3, 3>(c, a, bt.n)));
+        else CHK((launch_resunit_t7<6, 4>(c, a, bt.n)));
+    } else if (C == 96) CHK((launch_resunit_t<3, 4, 3>(c, a, bt.n)));
     else CHK((launch_resunit_t<6, 2, 4>(c, a, bt.n)));
     return prof_end(c);
 }
