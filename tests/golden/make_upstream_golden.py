@@ -181,17 +181,19 @@ def make_t5():
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-def make_dac():
+def make_dac(name="upstream_dac.npz", hidden=96, strides=(4, 2), latent=64, seed=1003, frames=11):
+    """hidden 96 / strides (4, 2): thin, every layer on the generic kernels.  hidden 192 / strides (2, 2) (upstream_dac_b3.npz): a
+    96-channel class, i.e. the device's fused bf16 x 3 residual unit and bf16 x 3 transposed conv, against upstream directly."""
     from transformers import DacConfig, DacModel
 
     spec = importlib.util.spec_from_file_location("ref_tensor_util", REF_UTIL)   # the reference's own weight-norm folding (torch only)
     ref_util = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ref_util)
 
-    torch.manual_seed(1003)
-    strides = [4, 2]
-    cfg = DacConfig(encoder_hidden_size=8, downsampling_ratios=[2, 4], decoder_hidden_size=96, upsampling_ratios=strides, n_codebooks=4,
-                    codebook_size=64, codebook_dim=8, hidden_size=64, sampling_rate=44100)
+    torch.manual_seed(seed)
+    strides = list(strides)
+    cfg = DacConfig(encoder_hidden_size=8, downsampling_ratios=[2, 4], decoder_hidden_size=hidden, upsampling_ratios=strides, n_codebooks=4,
+                    codebook_size=64, codebook_dim=8, hidden_size=latent, sampling_rate=44100)
     model = DacModel(cfg).double().eval()
     dec, qz = model.decoder, model.quantizer
     # descript-audio-codec checkpoints (what dac_gguf_encoder.py reads) carry weight_g / weight_v: old-style weight norm on every conv
@@ -240,7 +242,6 @@ def make_dac():
         for p_ in model.parameters():
             p_.copy_(p_.to(torch.float32).to(torch.float64))
     rng = np.random.default_rng(9)
-    frames = 11
     codes = rng.integers(0, 64, (frames, 4))
     stages = {}
     with torch.no_grad():
@@ -254,7 +255,9 @@ def make_dac():
         pcm = npy(dec.tanh(dec.conv2(dec.snake1(h)))[0, 0])
         pcm_api = npy(model.decode(audio_codes=torch.tensor(codes.T[None])).audio_values.reshape(-1))
     assert np.abs(pcm - pcm_api).max() < 1e-12, "stage-by-stage walk differs from DacModel.decode"
-    save("upstream_dac.npz", codes=codes.astype(np.uint32), pcm=pcm, strides=np.array(strides), cfg=np.array([64, 8, 64, 96, 4]), **stages,
+    if frames > 64:   # the long fixture: stages in fp32 (they are compared at 1e-5 of their range)
+        stages = {k: v.astype(np.float32) for k, v in stages.items()}
+    save(name, codes=codes.astype(np.uint32), pcm=pcm, strides=np.array(strides), cfg=np.array([latent, 8, 64, hidden, 4]), **stages,
          **{"t:" + k: v for k, v in tensors.items()})
 
 
@@ -341,6 +344,7 @@ def make_parler():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["orpheus", "t5", "dac", "parler"]
+    which = sys.argv[1:] or ["orpheus", "t5", "dac", "dac_b3", "parler"]
     for w in which:
-        {"orpheus": make_orpheus, "t5": make_t5, "dac": make_dac, "parler": make_parler}[w]()
+        {"orpheus": make_orpheus, "t5": make_t5, "dac": make_dac, "parler": make_parler,
+         "dac_b3": lambda: make_dac("upstream_dac_b3.npz", hidden=192, strides=(2, 2), seed=1005, frames=300)}[w]()

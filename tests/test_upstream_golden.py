@@ -74,13 +74,14 @@ def test_t5_encoder_against_transformers_t5():
     assert o.bucket(0, 12) == 8 and o.bucket(0, 16) == 9   # 16: log(2) / (float) log(16) * 8 = 1.99999999 -> 1 (HF: 10)
 
 
-def test_dac_decoder_against_transformers_dac():
+@pytest.mark.parametrize("fixture", ["upstream_dac.npz", "upstream_dac_b3.npz"])
+def test_dac_decoder_against_transformers_dac(fixture):
     """DacModel decoder + residual VQ (dac_model.cpp:100-170, general_neural_audio_codec.cpp:133-172; dac_gguf_encoder.py), weight norm folded by
     the reference's own tensor_util"""
-    z, by_name = load("upstream_dac.npz")
+    z, by_name = load(fixture)
     latent, cb_dim, cb_size, c0, n_cb = (int(x) for x in z["cfg"])
     strides = tuple(int(s) for s in z["strides"])
-    cfg = synth.tiny(latent=latent, cb_dim=cb_dim, cb_size=cb_size, c0=c0, n_out=n_cb, strides=strides, weight_type=gguf.F32)
+    cfg = synth.tiny(latent=latent, cb_dim=cb_dim, cb_size=cb_size, c0=c0, n_out=n_cb, strides=strides, weight_type=gguf.F32, max_gen=max(96, len(z["codes"]) + 8))
     o = orc.DacOracle(types.SimpleNamespace(cfg=cfg, by_name=by_name))
     pcm = o.decode(z["codes"])
     assert np.abs(pcm - z["pcm"]).max() < 2e-5

@@ -338,6 +338,7 @@ struct tts_hip_ctx {
     std::map<size_t, __bf16 *> packed_b3;   // k = 7 conv weights as three bf16 planes (dac_b3, experiment)
     std::map<size_t, __bf16 *> packed_ru;   // residual unit (keyed by its k = 7 weight) -> stage stream of resunit_b3_kernel
     std::map<size_t, __bf16 *> packed_p;    // conv weight -> bf16 planes in stage order for conv_b3p_kernel (k = 7: 64-channel tiles, k = 1: 128-channel tiles)
+    int dac_k1_variant = 1;     // TTS_HIP_DAC_K1_VARIANT: tiles of the k = 1 convs on planes: 0 = 128 ch x 256 pos (21.9 ms per pass); 1 = 256 x 256 where the channels divide by 256, 128 x 512 elsewhere (20.4 ms: fewer re-reads of the operands from L2)
     int dac_p_variant = 0;      // TTS_HIP_DAC_P_VARIANT: tile shape of the k = 7 convs on planes (0 = 4 waves, one LDS buffer, two workgroups per CU: measured best, profiles/r03/tap7_call16.txt)
     int dac_tap7 = 1;           // TTS_HIP_DAC_TAP7=0: the k = 7 convs on planes keep the tap-pair k-steps (8 slots for 7 taps) instead of one tap per k-step
     int dac_planes = 1;         // TTS_HIP_DAC_PLANES=0: the wide classes (channels % 128 == 0, no fused unit) keep fp32 activations and stage snake + split per tile
@@ -445,6 +446,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_DAC_PLANES")) c->dac_planes = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_TAP7")) c->dac_tap7 = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_P_VARIANT")) c->dac_p_variant = atoi(e);
+    if (const char *e = getenv("TTS_HIP_DAC_K1_VARIANT")) c->dac_k1_variant = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
     if (const char *e = getenv("TTS_HIP_GEMM_ROWS_PER_WG")) { const int v = atoi(e); c->gemm_rows_per_wg = v <= 0 ? 0 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
     if (const char *e = getenv("TTS_HIP_GEMM_NGS_MAX")) c->gemm_ngs_max = std::max(1, std::min(16, atoi(e)));
@@ -2593,7 +2595,7 @@ static bool planes_class(const tts_hip_ctx *c, int ch) {
 }
 static int pack_planes(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT) {
     const bool tapk = KT == 7 && c->dac_tap7 && cin % 16 == 0;
-    const int CO_T = KT == 7 ? 64 : 128, NS = KT == 7 ? (tapk ? 7 : 4) : 1;
+    const int CO_T = KT == 7 ? 64 : ((c->dac_k1_variant == 1 && cout % 256 == 0) ? 256 : 128), NS = KT == 7 ? (tapk ? 7 : 4) : 1;
     const int n_chunks = KT == 7 && !tapk ? cin / 8 : cin / 16;
     const size_t n = (size_t) (cout / CO_T) * n_chunks * 3 * NS * 2 * CO_T * 8;
     __bf16 *dst = nullptr;
@@ -2964,6 +2966,10 @@ static int launch_conv_planes(tts_hip_ctx *c, const DacBatch &bt, const __bf16 *
         else if (tapk) CHK((launch_conv_b3p_t<7, 2, 1, 1, 8, 7, 4, 1>(c, a, bt.n)));
         else if (pv == 0) CHK((launch_conv_b3p_t<7, 2, 2, 1, 4, 4, 2>(c, a, bt.n)));      // 64 ch x 256 pos, 4 waves
         else CHK((launch_conv_b3p_t<7, 2, 1, 1, 8, 4, 4>(c, a, bt.n)));                             // 64 ch x 256 pos, 8 waves, two workgroups per CU
+    } else if (c->dac_k1_variant == 1 && cout % 256 == 0) {
+        CHK((launch_conv_b3p_t<1, 4, 2, 2, 4, 1, 2>(c, a, bt.n)));                                  // 256 ch x 256 pos, 8 waves
+    } else if (c->dac_k1_variant == 1) {
+        CHK((launch_conv_b3p_t<1, 2, 4, 2, 4, 1, 2>(c, a, bt.n)));                                  // 128 ch x 512 pos, 8 waves
     } else {
         CHK((launch_conv_b3p_t<1, 2, 2, 2, 4, 1, 2>(c, a, bt.n)));                                  // 128 ch x 256 pos, 8 waves
     }
