@@ -123,10 +123,10 @@ def make_t5():
     from transformers.models.t5 import modeling_t5
 
     torch.manual_seed(1002)
-    cfg = T5Config(vocab_size=120, d_model=64, d_kv=16, d_ff=128, num_layers=2, num_heads=4, relative_attention_num_buckets=32,
+    cfg = T5Config(vocab_size=120, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2, relative_attention_num_buckets=32,   # head size 64 (flan-t5)
                    relative_attention_max_distance=128, feed_forward_proj="gated-gelu", layer_norm_epsilon=1e-6, dropout_rate=0.0)
     model = T5EncoderModel(cfg).double().eval()
-    proj = torch.nn.Linear(64, 48).double()   # enc_to_dec_proj (t5_encoder_gguf_encoder.py:63-65)
+    proj = torch.nn.Linear(128, 64).double()   # enc_to_dec_proj (t5_encoder_gguf_encoder.py:63-65)
     with torch.no_grad():
         for n, p in model.named_parameters():
             if "layer_norm" in n:
@@ -177,7 +177,7 @@ def make_t5():
     print(f"t5: |HF - HF with reference buckets| 7 tokens {np.abs(out7 - out7_ref).max():.2e}, 24 tokens {np.abs(out24_hf - out24_ref).max():.2e} "
           f"(max |out| {np.abs(out24_hf).max():.2f})")
     save("upstream_t5.npz", ids7=ids7.astype(np.uint32), ids24=ids24.astype(np.uint32), out7=out7, out24_hf=out24_hf, out24_refbuckets=out24_ref,
-         cfg=np.array([120, 64, 16, 128, 2, 4, 48]), **{"t:" + k: v for k, v in tensors.items()})
+         cfg=np.array([120, 128, 64, 256, 2, 2, 64]), **{"t:" + k: v for k, v in tensors.items()})
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -266,7 +266,7 @@ def make_parler():
     from transformers import MusicgenDecoderConfig, MusicgenForCausalLM
 
     torch.manual_seed(1004)
-    H, NCB, V, L, F, HEADS, ENC, PV = 64, 4, 80, 2, 128, 4, 6, 160
+    H, NCB, V, L, F, HEADS, ENC, PV = 128, 4, 80, 2, 256, 2, 6, 160   # head size 64: what the device kernels are specialised for
 
     def build(act):
         torch.manual_seed(1004)
