@@ -610,3 +610,39 @@ def test_tiled_gemm_every_tile_shape(rows, shape, monkeypatch):
             assert relerr(lg[r], ref[:, 0, :]) < TOL[gguf.F16], (rows, shape, r, step)
         ids = lg.argmax(-1).astype(np.uint32)
     eng.close()
+
+
+@pytest.mark.parametrize("sampled", [False, True])
+def test_row_compaction_keeps_every_utterance_token_for_token(sampled, monkeypatch):
+    """A ragged lock-step batch: 200 utterances whose prompts leave 20 ... 76 steps before their position reaches max_generation
+    (check_stopping, model.cpp:720-722).  generate_loop drops finished utterances from the forward every 32 steps (row compaction: live rows
+    gathered to the front, the rest of the loop state indexed by utterance).  Every utterance must get exactly the tokens and the step count
+    it gets when finished rows keep idling in the forward (TTS_HIP_GEN_COMPACT=0), greedy and with the device sampler (uniforms, repetition
+    penalty state per utterance)."""
+    cfg = synth.small(weight_type=gguf.F16, ctx=80, max_gen=80)
+    model = synth.build(cfg)
+    rng = np.random.default_rng(11)
+    n, cap = 200, 80
+    lens = rng.integers(4, 61, n)
+    prompts = [rng.integers(3, cfg.prompt_vocab, int(l)).astype(np.uint32) for l in lens]
+    n_steps = int(cap - lens.min())
+    uni = rng.random((n_steps, n, cfg.n_out), dtype=np.float32)
+    res = []
+    for compact in ("1", "0"):
+        monkeypatch.setenv("TTS_HIP_GEN_COMPACT", compact)
+        eng = hip.HipEngine(cfg, max_seqs=n, kv_positions=cap, flags=hip.FLAG_NO_DAC)
+        eng.load(model)
+        eng.prefill_batch(prompts)
+        if sampled:
+            toks, done = eng.generate_sampled(lens, n_steps, uni, top_k=20, temperature=0.9, repetition_penalty=1.1)
+        else:
+            toks, done = eng.generate_greedy(lens, n_steps)
+        res.append((toks, done))
+        eng.close()
+    (ta, da), (tb, db) = res
+    assert np.array_equal(da, db)
+    assert sorted(set(da.tolist()))[0] < 32 < da.max(), "some utterances must finish before and some after the first compaction point"
+    for u in range(n):
+        k = int(da[u]) if da[u] else n_steps
+        assert k == cap - lens[u] or da[u] == 0 or k < cap - lens[u]
+        assert np.array_equal(ta[:k, u], tb[:k, u]), f"utterance {u}"

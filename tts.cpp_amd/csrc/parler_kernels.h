@@ -762,6 +762,10 @@ struct SampleArgs {
     int pen_len;
     int32_t *last_ids;         // [R][n_out] sampler::last_token_ids (-1 after reset)
     uint32_t *rep_counts;      // [R][n_out] sampler::repetition_counts
+    // generation loop with row compaction: row r of this forward is utterance orig[r] of R_total; the uniforms and the sampler state stay
+    // indexed by utterance (NULL: row == utterance, R_total == R)
+    const uint32_t *orig;
+    int R_total;
 };
 
 // Candidate order = descending value, equal values by ascending index: a total order, so a bitonic sort of the
@@ -808,10 +812,11 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     const bool use_topp = a.top_p < 1.0f;
 
     // the token sampled last enters every comparison and the softmax with its penalised value
-    const int last = a.pen_table ? a.last_ids[r * a.n_out + h] : -1;
+    const int ro = a.orig ? (int) a.orig[r] : r;   // utterance of this row
+    const int last = a.pen_table ? a.last_ids[ro * a.n_out + h] : -1;
     float pen_v = 0.0f;
     if (last >= 0 && last < V) {
-        const uint32_t cnt = a.rep_counts[r * a.n_out + h];
+        const uint32_t cnt = a.rep_counts[ro * a.n_out + h];
         pen_v = (float) ((double) row[last] / a.pen_table[cnt < (uint32_t) a.pen_len ? cnt : (uint32_t) a.pen_len - 1]);
     }
     // sampler::max (first maximum wins)
@@ -900,7 +905,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     }
     if (tid == 0) {
         const uint32_t call = a.row_step ? a.row_step[r] - 1 : 0;
-        const float u = a.uniforms[((int64_t) call * a.R + r) * a.n_out + h];
+        const float u = a.uniforms[((int64_t) call * (a.orig ? a.R_total : a.R) + ro) * a.n_out + h];
         const float target = use_topp ? u * s_mhp : u;
         float cum = 0.0f;
         int chosen = n ? (nucleus ? (int) picks[n - 1] : n - 1) : 0;
@@ -911,10 +916,10 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         }
         a.out[r * a.n_out + h] = (uint32_t) chosen;
         if (a.pen_table) {  // sampler.cpp:57-63
-            uint32_t cnt = a.rep_counts[r * a.n_out + h];
+            uint32_t cnt = a.rep_counts[ro * a.n_out + h];
             if (last != chosen) cnt = 0;
-            a.last_ids[r * a.n_out + h] = chosen;
-            a.rep_counts[r * a.n_out + h] = cnt + 1;
+            a.last_ids[ro * a.n_out + h] = chosen;
+            a.rep_counts[ro * a.n_out + h] = cnt + 1;
         }
     }
 }
@@ -936,21 +941,47 @@ struct FeedArgs {
     uint32_t bos, eos;
     uint32_t max_pos;         // a row whose next position would reach this has finished (check_stopping's current_position >= max_generation_size,
                               // model.cpp:720-722, with max_generation = the cached positions of a lock-step context); it idles on its last position
+    // row compaction (generate_loop drops finished utterances from the lock-step forward): row r is utterance orig[r] of R_total; eos_seen,
+    // steps_done and tokens_out stay indexed by utterance, ids / row_pos / row_step by row (NULL: row == utterance)
+    const uint32_t *orig;
+    int R_total;
 };
+
+// rows dst[r] = src[map[r]] of the per-row loop state (ids, position, cache slot, step counter): the compaction of generate_loop, in two
+// launches through a scratch copy (rows move towards lower indices while other workgroups still read them)
+struct GatherArgs {
+    const uint32_t *map;      // [R2] old row of new row r
+    uint32_t *ids, *pos, *seq, *step;          // live arrays
+    uint32_t *s_ids, *s_pos, *s_seq, *s_step;  // scratch
+    int R2, n_out;
+};
+__global__ void gather_rows_kernel(GatherArgs a, int phase) {
+    const int r = blockIdx.x, t = threadIdx.x;
+    if (r >= a.R2) return;
+    if (phase == 0) {
+        const int o = (int) a.map[r];
+        if (t < a.n_out) a.s_ids[r * a.n_out + t] = a.ids[o * a.n_out + t];
+        if (t == 0) { a.s_pos[r] = a.pos[o]; a.s_seq[r] = a.seq[o]; a.s_step[r] = a.step[o]; }
+    } else {
+        if (t < a.n_out) a.ids[r * a.n_out + t] = a.s_ids[r * a.n_out + t];
+        if (t == 0) { a.pos[r] = a.s_pos[r]; a.seq[r] = a.s_seq[r]; a.step[r] = a.s_step[r]; }
+    }
+}
 
 // one 64-thread workgroup per row
 __global__ void feed_kernel(FeedArgs a) {
     __shared__ int not_seen;
     const int r = blockIdx.x, hd = threadIdx.x;
+    const int ro = a.orig ? (int) a.orig[r] : r, RT = a.orig ? a.R_total : a.R;
     const uint32_t step = a.row_step[r];
     if (hd == 0) not_seen = 0;
     __syncthreads();
     if (hd < a.n_out) {
-        const int idx = r * a.n_out + hd;
+        const int idx = r * a.n_out + hd, io = ro * a.n_out + hd;
         const uint32_t tok = a.tokens[idx];
-        a.tokens_out[((int64_t) (step - 1) * a.R + r) * a.n_out + hd] = tok;
-        const uint8_t seen = a.eos_seen[idx] | (tok == a.eos ? 1 : 0);
-        a.eos_seen[idx] = seen;
+        a.tokens_out[((int64_t) (step - 1) * RT + ro) * a.n_out + hd] = tok;
+        const uint8_t seen = a.eos_seen[io] | (tok == a.eos ? 1 : 0);
+        a.eos_seen[io] = seen;
         a.ids[idx] = ((int) step > hd) ? (seen ? a.eos : tok) : a.bos;
         if (!seen) atomicOr(&not_seen, 1);
     }
@@ -959,7 +990,7 @@ __global__ void feed_kernel(FeedArgs a) {
         const uint32_t np = a.row_pos[r] + 1;
         if (np < a.max_pos) a.row_pos[r] = np;
         a.row_step[r] = step + 1;
-        if ((!not_seen || np >= a.max_pos) && a.steps_done[r] == 0) a.steps_done[r] = step;
+        if ((!not_seen || np >= a.max_pos) && a.steps_done[ro] == 0) a.steps_done[ro] = step;
     }
 }
 

@@ -315,6 +315,9 @@ struct tts_hip_ctx {
     int ln_waves = 1;           // rows (waves) per LayerNorm workgroup
     int ksplit_big = 4;         // K slices for K >= 4096 residual GEMMs
     uint32_t *d_ids = nullptr, *d_pos = nullptr, *d_seq = nullptr, *d_tok = nullptr, *d_step = nullptr, *d_steps_done = nullptr;
+    uint32_t *d_gather = nullptr;   // scratch of the row compaction: map [R] + ids [R][n_out] + pos / seq / step [R] each
+    int gen_total = 0;              // utterances of the generation loop under way (rows of the forward <= this after a compaction)
+    bool gen_compact = true;        // TTS_HIP_GEN_COMPACT=0: finished utterances keep idling in the lock-step forward
     uint32_t *d_tokens_out = nullptr;
     size_t tokens_out_cap = 0;
     uint8_t *d_eos = nullptr;
@@ -445,6 +448,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_DAC_CONVT_B3")) c->dac_convt_b3 = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_PLANES")) c->dac_planes = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_TAP7")) c->dac_tap7 = atoi(e);
+    if (const char *e = getenv("TTS_HIP_GEN_COMPACT")) c->gen_compact = atoi(e) != 0;
     if (const char *e = getenv("TTS_HIP_DAC_P_VARIANT")) c->dac_p_variant = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_K1_VARIANT")) c->dac_k1_variant = atoi(e);
     if (const char *e = getenv("TTS_HIP_DAC_LDS_RESERVE_KB")) c->dac_lds_reserve_kb = std::max(0, std::min(96, atoi(e)));
@@ -505,7 +509,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (int i = 0; i < 3; i++) free_dev(c->sbuf[i]);
     free_dev(c->s_noise); free_dev(c->s_codes);
     free_dev(c->t5_bucket); free_dev(c->t5_x); free_dev(c->t5_qkv); free_dev(c->t5_att); free_dev(c->t5_ug); free_dev(c->t5_g); free_dev(c->t5_y); free_dev(c->t5_ids); free_dev(c->logits); free_dev(c->part); free_dev(c->attn_cnt); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
-    free_dev(c->d_seq); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
+    free_dev(c->d_seq); free_dev(c->d_gather); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
     free_dev(c->d_eos); free_dev(c->d_frames);
     dac_buffers_release(c);
     for (auto &pw : c->packed) free_dev(pw.second);
@@ -1743,6 +1747,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->d_ids, (size_t) R * c->NO));
         CHK(dmalloc(&c->d_pos, (size_t) R));
         CHK(dmalloc(&c->d_seq, (size_t) R));
+        CHK(dmalloc(&c->d_gather, (size_t) R * (c->NO + 4)));
         CHK(dmalloc(&c->d_tok, (size_t) R * c->NO));
         CHK(dmalloc(&c->d_step, (size_t) R));
         CHK(dmalloc(&c->d_steps_done, (size_t) R));
@@ -2148,6 +2153,7 @@ static int enqueue_step_body(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint
             sa.uniforms = c->d_uniforms; sa.row_step = c->d_step; sa.out = c->d_tok;
             sa.pen_table = c->smp.repetition_penalty != 1.0f ? c->d_pen : nullptr; sa.pen_len = c->pen_len;
             sa.last_ids = c->d_last; sa.rep_counts = c->d_repc;
+            sa.orig = c->d_seq; sa.R_total = c->gen_total;   // the loop's rows sit in cache slot = utterance index
             hipLaunchKernelGGL(sample_kernel, dim3(c->NO, R), dim3(256), 0, c->stream, sa);
         } else {
             hipLaunchKernelGGL(argmax_kernel, dim3(R * c->NO), dim3(256), 0, c->stream, (const float *) c->logits, c->V, c->d_tok);
@@ -2158,6 +2164,7 @@ static int enqueue_step_body(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint
             f.tokens = c->d_tok; f.ids = c->d_ids; f.row_pos = c->d_pos; f.row_step = c->d_step; f.eos_seen = c->d_eos;
             f.steps_done = c->d_steps_done; f.tokens_out = c->d_tokens_out; f.R = R; f.n_out = c->NO; f.bos = bos; f.eos = eos;
             f.max_pos = (uint32_t) std::min(c->KVPOS, c->NPOS);
+            f.orig = c->d_seq; f.R_total = c->gen_total;
             hipLaunchKernelGGL(feed_kernel, dim3(R), dim3(64), 0, c->stream, f);
             HIPCHK(hipGetLastError());
         }
@@ -2170,7 +2177,7 @@ static int enqueue_step_body(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint
 static int run_step(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint32_t eos) {
     const bool use_graph = !(c->d.flags & TTS_HIP_FLAG_NO_GRAPH) && !c->prof;
     if (!use_graph) return enqueue_step_body(c, R, mode, bos, eos);
-    const int key = mode * 1000 + R;
+    const int key = mode * 8192 + R;   // R <= TTS_HIP_MAX_ROWS (1024 by default)
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -2254,18 +2261,50 @@ static int generate_loop(tts_hip_ctx *c, int mode, uint32_t n, const uint32_t *s
         drop_gen_graphs(c);
         c->g_bos = bos; c->g_eos = eos;
     }
-    uint32_t ran = 0;
+    if (c->gen_total != (int) n) {   // the utterance count is baked into the captured sampler / feed launches (tokens_out stride)
+        drop_gen_graphs(c);
+        c->gen_total = (int) n;
+    }
+    // Row compaction.  Every 32 steps the host looks at steps_done (one small D2H + sync) to see whether check_stopping() has fired for every
+    // utterance; utterances that have finished (EOS on every head, or their position reached max_generation) used to idle in the lock-step
+    // forward until the last one was done — a ragged batch paid for its longest row (165 against 323 audio-s/s at 1024 steps).  Now the
+    // finished rows are dropped from the forward: the live rows are gathered to the front (ids, position, cache slot, step counter; everything
+    // else is indexed by utterance) and the loop goes on with R' = the live count rounded up to a multiple of 128 (64 below 256) — finished
+    // rows fill the remainder, so that a forward keeps whole row tiles and only a handful of row counts are ever captured as graphs.
+    std::vector<uint32_t> row_utt(n);            // utterance of row r
+    for (uint32_t r = 0; r < n; r++) row_utt[r] = r;
+    uint32_t R = n, ran = 0;
     for (uint32_t s = 0; s < n_steps; s++) {
-        for (uint32_t r = 0; r < n; r++) c->host_pos[r] = start_pos[r] + s;
-        CHK(run_step(c, (int) n, mode, bos, eos));
+        for (uint32_t r = 0; r < R; r++) c->host_pos[r] = std::min<uint32_t>(start_pos[row_utt[r]] + s, (uint32_t) std::min(c->KVPOS, c->NPOS) - 1);
+        CHK(run_step(c, (int) R, mode, bos, eos));
         ran = s + 1;
         if ((ran % 32) == 0 && ran < n_steps) {
-            // has check_stopping() fired for every sequence?  (one small D2H + sync every 32 steps)
             HIPCHK(hipMemcpyAsync(c->h_tok, c->d_steps_done, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
-            bool all = true;
-            for (uint32_t r = 0; r < n; r++) all = all && c->h_tok[r] != 0;
-            if (all) break;
+            uint32_t live = 0;
+            for (uint32_t r = 0; r < R; r++) live += c->h_tok[row_utt[r]] == 0;
+            if (live == 0) break;
+            const uint32_t q = live >= 256 ? 128 : 64;
+            const uint32_t R2 = std::min(R, (live + q - 1) / q * q);
+            if (c->gen_compact && R2 < R) {
+                std::vector<uint32_t> map, fill;
+                for (uint32_t r = 0; r < R; r++) (c->h_tok[row_utt[r]] == 0 ? map : fill).push_back(r);
+                for (uint32_t i = 0; map.size() < R2; i++) map.push_back(fill[i]);
+                std::sort(map.begin(), map.end());   // keep the row order: rows only move towards lower indices
+                std::vector<uint32_t> utt2(R2);
+                for (uint32_t r = 0; r < R2; r++) utt2[r] = row_utt[map[r]];
+                GatherArgs ga{};
+                ga.map = c->d_gather; ga.R2 = (int) R2; ga.n_out = c->NO;
+                ga.ids = c->d_ids; ga.pos = c->d_pos; ga.seq = c->d_seq; ga.step = c->d_step;
+                ga.s_ids = c->d_gather + c->RMAX; ga.s_pos = ga.s_ids + (size_t) c->RMAX * c->NO; ga.s_seq = ga.s_pos + c->RMAX; ga.s_step = ga.s_seq + c->RMAX;
+                HIPCHK(hipMemcpyAsync(c->d_gather, map.data(), (size_t) R2 * 4, hipMemcpyHostToDevice, c->stream));
+                hipLaunchKernelGGL(gather_rows_kernel, dim3(R2), dim3(64), 0, c->stream, ga, 0);
+                hipLaunchKernelGGL(gather_rows_kernel, dim3(R2), dim3(64), 0, c->stream, ga, 1);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(c->stream));   // map lives on the host stack
+                row_utt.swap(utt2);
+                R = R2;
+            }
         }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
