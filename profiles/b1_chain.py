@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Batch-1 Parler-TTS-Mini chain (fp16 weights, fp32 KV): ms per step of the device-resident greedy loop under the knobs of the
+variants below, the tokens of every variant against the plain chain, the logits of one step against it, and (TTS_HIP_B1_STAMPS=1)
+the in-kernel timeline of the last graph-replayed step (s_memrealtime stamps of the first and the last workgroup of every launch).
+
+  python profiles/b1_chain.py            # all variants, each in its own process (the knobs are read at context creation)
+  python profiles/b1_chain.py --one      # this process' environment only
+"""
+import os, subprocess, sys, time, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+N = 1024
+
+
+def one():
+    import tts_cpp_amd  # noqa: F401
+    from tts_cpp_amd import gguf, hip, synth
+    cfg = synth.parler_mini(weight_type=gguf.F16)
+    model = synth.build(cfg)
+    eng = hip.HipEngine(cfg, device=0, max_seqs=1, kv_type=gguf.F32, kv_positions=min(cfg.ctx, cfg.max_gen))
+    eng.load(model)
+    prompt = np.random.default_rng(3).integers(3, cfg.prompt_vocab, 16).astype(np.uint32)
+    eng.prefill_batch([prompt]); eng.generate_greedy([len(prompt)], 32)
+    best = 1e9
+    for rep in range(2):
+        eng.reset(); eng.prefill_batch([prompt])
+        t0 = time.perf_counter()
+        toks, _ = eng.generate_greedy([len(prompt)], N)
+        best = min(best, time.perf_counter() - t0)
+    res = {"ms_per_step": best / N * 1e3, "x_real_time": 1 / (best / N) / 86.13, "tokens_crc": int(np.bitwise_xor.reduce(toks.astype(np.uint64).ravel() * np.arange(1, toks.size + 1, dtype=np.uint64)))}
+    if os.environ.get("TTS_HIP_B1_STAMPS"):
+        # the last replayed step left its stamps behind (every node writes its own slot)
+        st = eng.debug_read("stamps", 16 * 2 * (cfg.layers * 8 + 8)).view(np.int64).reshape(-1, 16)
+        rows = []
+        for i, s in enumerate(st):
+            a, b = s[:8], s[8:]
+            rows.append([int(v) for v in a[:5]] + [int(v) for v in b[:5]])
+        res["stamps"] = rows
+    # logits of one more step (eager call): the variants are compared on it
+    ids = np.full((1, cfg.n_out), cfg.bos, dtype=np.uint32)
+    lg = eng.step(ids, [len(prompt) + N])
+    np.save(os.environ.get("B1_LOGITS", "/tmp/b1_logits.npy"), np.asarray(lg))
+    np.save(os.environ.get("B1_TOKENS", "/tmp/b1_tokens.npy"), toks)
+    print(json.dumps(res))
+
+
+def analyse(rows, per_layer):
+    """rows: per launch, 5 stamps of the first workgroup + 5 of the last (10 ns ticks).  Prints the mean timeline of a layer."""
+    rows = np.array(rows, dtype=np.int64)
+    L = (len(rows)) // per_layer
+    r = rows[per_layer:L * per_layer].reshape(L - 1, per_layer, 10)      # drop layer 0
+    print(f"  stamps: {per_layer} launches per layer, mean over {L - 1} layers, us (first workgroup | last workgroup)")
+    prev_end = None
+    for k in range(per_layer):
+        a = r[:, k, :5].astype(float); b = r[:, k, 5:].astype(float)
+        def seg(x):
+            x = np.where(x > 0, x, np.nan)
+            start = x[:, 0]
+            pts = [np.nanmean(x[:, j] - start) / 100 for j in range(1, 5)]
+            return pts
+        start_k = np.minimum(np.where(a[:, 0] > 0, a[:, 0], np.inf), np.where(b[:, 0] > 0, b[:, 0], np.inf))
+        end_k = np.nanmax(np.concatenate([a, b], axis=1), axis=1)
+        gap = "" if prev_end is None else f"gap {np.mean(start_k - prev_end) / 100:5.2f}"
+        print(f"    launch {k}: {gap:10s} span {np.mean(end_k - start_k) / 100:5.2f}  first wg {' '.join('%5.2f' % p for p in seg(a))}  | last wg (+{np.nanmean(b[:, 0] - a[:, 0]) / 100:4.2f}) {' '.join('%5.2f' % p for p in seg(b))}")
+        prev_end = end_k
+    layer_span = (r[1:, 0, 0] - r[:-1, 0, 0]).astype(float)
+    print(f"    layer to layer: {np.mean(layer_span) / 100:.2f} us")
+
+
+def main():
+    if "--one" in sys.argv:
+        return one()
+    variants = [
+        ("round-2 chain", {"TTS_HIP_B1_FC2_SPLIT": "0", "TTS_HIP_B1_DEFER_COMBINE": "0"}, False),
+        ("fc2 as 256 workgroups + slabs", {"TTS_HIP_B1_FC2_SPLIT": "1", "TTS_HIP_B1_DEFER_COMBINE": "0"}, False),
+        ("combine in out_proj's prologue", {"TTS_HIP_B1_FC2_SPLIT": "0", "TTS_HIP_B1_DEFER_COMBINE": "1"}, False),
+        ("both (default)", {}, True),
+    ]
+    base_lg = base_tok = None
+    for i, (name, env, stamps) in enumerate(variants):
+        e = dict(os.environ); e.update(env)
+        e["B1_LOGITS"] = f"/tmp/b1_logits_{i}.npy"; e["B1_TOKENS"] = f"/tmp/b1_tokens_{i}.npy"
+        if stamps: e["TTS_HIP_B1_STAMPS"] = "1"
+        p = subprocess.run([sys.executable, __file__, "--one"], env=e, capture_output=True, text=True, timeout=600)
+        if p.returncode != 0:
+            print(f"{name}: FAILED\n{p.stdout[-2000:]}\n{p.stderr[-3000:]}"); continue
+        r = json.loads(p.stdout.strip().split("\n")[-1])
+        lg = np.load(e["B1_LOGITS"]); tok = np.load(e["B1_TOKENS"])
+        if base_lg is None: base_lg, base_tok = lg, tok
+        same = int((tok == base_tok).all())
+        first_diff = -1 if same else int(np.argwhere((tok != base_tok).any(axis=(1, 2)))[0][0])
+        print(f"{name:32s}{' [stamps]' if stamps else '':9s} {r['ms_per_step']:.4f} ms/step = {r['x_real_time']:.2f} x real time;  tokens equal to plain: {same}"
+              f"{'' if same else ' (first difference at step %d)' % first_diff};  logits max |diff| {np.abs(lg - base_lg).max():.3e} (max |logit| {np.abs(base_lg).max():.2f})")
+        if stamps: analyse(r["stamps"], 8)
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -30,15 +31,40 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 
 #define LN_EPS 1e-5f  // model.cpp:414 "parler always uses default eps"
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Cross-lane reductions without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0): six dependent LDS round
+// trips per wave_sum, which is most of a LayerNorm's time at batch 1 (profiles/r03/b1_chain.txt).  The xor butterfly 32, 16, 8, 4, 2, 1 is
+// reproduced bit for bit: v_permlane32_swap / v_permlane16_swap of (v, v) leave lane i's value in one result and lane (i ^ 32) / (i ^ 16)'s in the
+// other (fp add and max commute); inside a row of 16 lanes the value has period 8 after the xor-8 step, period 4 after the xor-4 step ..., so
+// rotating the row by 8, 4, 2, 1 (DPP row_ror) pairs every lane with the same partner value the xor would (profiles/wave_sum_check.hip).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {   // == v += __shfl_xor(v, 8); ... 4; 2; 1 for aligned groups of 16 lanes
+    v += dpp_f<0x128>(v); v += dpp_f<0x124>(v); v += dpp_f<0x122>(v); v += dpp_f<0x121>(v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<0x128>(v)); v = fmaxf(v, dpp_f<0x124>(v)); v = fmaxf(v, dpp_f<0x122>(v)); v = fmaxf(v, dpp_f<0x121>(v));
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned) a[0]) + __builtin_bit_cast(float, (unsigned) a[1]);
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+    v = __builtin_bit_cast(float, (unsigned) b[0]) + __builtin_bit_cast(float, (unsigned) b[1]);
+    return row16_sum(v);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = fmaxf(__builtin_bit_cast(float, (unsigned) a[0]), __builtin_bit_cast(float, (unsigned) a[1]));
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+    v = fmaxf(__builtin_bit_cast(float, (unsigned) b[0]), __builtin_bit_cast(float, (unsigned) b[1]));
+    return row16_max(v);
 }
 
 // ggml_gelu.  mode 1 restates ggml's CPU path, which evaluates GELU through a table indexed by the
@@ -101,7 +127,11 @@ __global__ void embed_rows_kernel(EmbedArgs a) {
 // ------------------------------------------------------------------------------------------------
 // GEMM  y[r][n] = sum_k W[n][k] * act[r][k]   for R <= 16*RB rows, 16 features per workgroup
 // ------------------------------------------------------------------------------------------------
-enum { PRO_F32 = 0, PRO_LN = 1, PRO_F16 = 2 };
+// PRO_ATTN: the activations are the split-T self-attention's partials (attn_kernel with nsplit > 1 and no in-kernel combine); the
+// workgroup folds them — attn_combine_kernel's arithmetic — into the fp16 rows its MFMAs read (batch-1 chain)
+enum { PRO_F32 = 0, PRO_LN = 1, PRO_F16 = 2, PRO_ATTN = 3 };
+// key-split partials of one (row, head): [nsplit][ATT_PS] floats = max, sum, pad, pad, acc[64] (acc 16-byte aligned)
+constexpr int ATT_PS = 68, ATT_PO = 4;
 enum { EPI_STORE = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3 };
 
 struct GemmArgs {
@@ -131,7 +161,21 @@ struct GemmArgs {
     // host-side hint, not read by any kernel: the caller has room for K-slice slabs and a consumer that folds them ->
     // run_gemm may take gemv_stream_kernel (gemv_stream_kernels.h) for <= 16 rows
     int stream;
+    // <= 4 rows: the preceding fc2 ran split-K (four times the workgroups, a quarter of the weight bytes each) and left n_parts fp32
+    // slabs [n_parts][rows][H]: a PRO_LN prologue normalises x + slabs (x is not written: other workgroups still read it), the next
+    // EPI_RESID epilogue stores x + slabs + its own result (every element of x has one owner there).  Fixed slab order in both.
+    const float *parts;
+    int n_parts;
+    int64_t parts_stride;
+    // PRO_ATTN: partials [R][att_heads][att_nz][ATT_PS]
+    const float *att_part;
+    int att_nz, att_heads;
+    // debug (TTS_HIP_B1_STAMPS=1): s_memrealtime stamps (100 MHz) written by the first and the last workgroup of the launch, 8 slots each
+    long long *stamps;
 };
+
+#define B1_STAMP(st, i) do { if ((st) != nullptr && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) \
+    (st)[(blockIdx.x ? 8 : 0) + (i)] = (long long) __builtin_amdgcn_s_memrealtime(); } while (0)
 
 __device__ __forceinline__ void gemm_epilogue4(const GemmArgs &a, int EPI, int r, int n, float4v v, int slab) {
     if (EPI == EPI_STORE) {
@@ -139,6 +183,13 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs &a, int EPI, int r
     } else if (EPI == EPI_RESID) {
         float4v *p = (float4v *) (a.out + (int64_t) r * a.ldo + n);
         float4v o = *p;
+        if (a.n_parts == 4) {   // the residual stream still lacks the previous fc2's four K-slice slabs
+            float4v pv[4];
+#pragma unroll
+            for (int sp = 0; sp < 4; sp++) pv[sp] = *(const float4v *) (a.parts + sp * a.parts_stride + (int64_t) r * a.ldo + n);
+#pragma unroll
+            for (int sp = 0; sp < 4; sp++) o += pv[sp];
+        }
         o += v;  // ggml_add(cur, residual)
         *p = o;
     } else if (EPI == EPI_GELU) {
@@ -176,7 +227,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs &a, int EPI, int r
 // WT: 0 = fp32 weights (exact-fp32 MFMA 16x16x4), 1 = fp16 weights (MFMA 16x16x32, activations rounded
 // to fp16 like ggml's vec_dot_type conversion).  blockDim.x = 64 * K/256.
 template <int WT, int PRO, int EPI, int RB>
-__global__ __launch_bounds__(PRO == PRO_LN ? 512 : 1024) void gemm16_kernel(GemmArgs a) {
+__global__ __launch_bounds__(PRO == PRO_LN || PRO == PRO_ATTN ? 512 : 1024) void gemm16_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // nw waves split this workgroup's K range in 256-wide slices; when the forward carries several groups of
@@ -189,6 +240,7 @@ __global__ __launch_bounds__(PRO == PRO_LN ? 512 : 1024) void gemm16_kernel(Gemm
     const int li = lane & 15, g = lane >> 4;
     const int K = a.K;
     const int kz = blockIdx.y * a.kchunk;  // 0 unless K is split over workgroups
+    B1_STAMP(a.stamps, 0);
 
     // ---- 1. issue every weight load of this lane (HBM latency overlaps the prologue) -------------
     // MFMA-natural K order: for load c, the 4 lanes (g = 0..3) that share a weight row read one
@@ -214,36 +266,51 @@ __global__ __launch_bounds__(PRO == PRO_LN ? 512 : 1024) void gemm16_kernel(Gemm
     size_t    red_off = 0;
     if (PRO == PRO_LN) {
         const float *A = (const float *) a.A;
-        for (int r = wave; r < a.R; r += nw * ngs) {
+        const int nk = K >> 8;   // chunks of 256 columns in a row (K % 256 == 0 on this path); wave-uniform
+        // NI = chunks held in registers: 4 for K <= 1024 (leaves room for the slab fold), 8 up to K = 2048
+        auto ln_row = [&](int r, auto ni_c) {
+            constexpr int NI = decltype(ni_c)::value;
             const float *xr = A + (int64_t) r * a.lda;
-            float4v v[8], lwv[8], lbv[8];
+            float4v v[NI], lwv[NI], lbv[NI];
             float s = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {  // x row and the affine parameters in one round trip
-                const int k = i * 256 + lane * 4;
-                if (k < K) {
-                    v[i] = *(const float4v *) (xr + k);
-                    lwv[i] = *(const float4v *) (a.ln_w + k);
-                    lbv[i] = *(const float4v *) (a.ln_b + k);
-                }
+            for (int i = 0; i < NI; i++) {  // x row and the affine parameters in one round trip
+                // straight-line loads: a chunk beyond the row (i >= nk, wave-uniform) re-reads chunk 0 and is never used.  Loads predicated on
+                // `k < K` became one basic block each and hipcc put an s_waitcnt between them: the row arrived in four dependent round trips.
+                const int k = (i < nk ? i * 256 : 0) + lane * 4;
+                v[i] = *(const float4v *) (xr + k);
+                lwv[i] = *(const float4v *) (a.ln_w + k);
+                lbv[i] = *(const float4v *) (a.ln_b + k);
+            }
+            if (WT == 1 && NI == 4 && a.n_parts == 4) {   // (the host splits fc2 only when every matrix is fp16)   // x + the previous fc2's slabs in slab order; same round trip (K <= 1024: i < 4)
+                float4v pp[4][4];
+#pragma unroll
+                for (int sp = 0; sp < 4; sp++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        pp[sp][i] = *(const float4v *) (a.parts + sp * a.parts_stride + (int64_t) r * a.lda + (i < nk ? i * 256 : 0) + lane * 4);
+#pragma unroll
+                for (int sp = 0; sp < 4; sp++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] += pp[sp][i];
             }
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (i * 256 + lane * 4 < K) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            for (int i = 0; i < NI; i++)
+                if (i < nk) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             const float mean = wave_sum(s) / (float) K;
             float s2 = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (i * 256 + lane * 4 < K) {
+            for (int i = 0; i < NI; i++) {
+                if (i < nk) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) { const float d = v[i][e] - mean; s2 += d * d; }
                 }
             }
             const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float) K + LN_EPS);
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < NI; i++) {
                 const int k = i * 256 + lane * 4;
-                if (k < K) {
+                if (i < nk) {
                     const float4v lw = lwv[i], lb = lbv[i];
                     float4v y;
 #pragma unroll
@@ -258,11 +325,51 @@ __global__ __launch_bounds__(PRO == PRO_LN ? 512 : 1024) void gemm16_kernel(Gemm
                     }
                 }
             }
+        };
+        for (int r = wave; r < a.R; r += nw * ngs) {
+            if (K <= 1024) ln_row(r, std::integral_constant<int, 4>{});
+            else ln_row(r, std::integral_constant<int, 8>{});
         }
         red_off = (size_t) RB * 16 * ldx * (WT == 1 ? 2 : 4);
         red_off = (red_off + 15) & ~(size_t) 15;
         __syncthreads();
     }
+    if (PRO == PRO_ATTN) {   // WT == 1
+        const int nq = K >> 2, nz = a.att_nz;   // K = att_heads * 64
+        for (int idx = tid; idx < a.R * nq; idx += blockDim.x) {
+            const int r = idx / nq, c4 = (idx - r * nq) * 4, h = c4 >> 6, d = c4 & 63;
+            const float *p = a.att_part + ((int64_t) r * a.att_heads + h) * nz * ATT_PS;
+            float mm[16], ss[16];
+            float4v oo[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {   // straight-line loads (a split beyond nz re-reads the last one, see the LayerNorm prologue)
+                const int ic = i < nz ? i : nz - 1;
+                mm[i] = p[ic * ATT_PS]; ss[i] = p[ic * ATT_PS + 1]; oo[i] = *(const float4v *) (p + ic * ATT_PS + ATT_PO + d);
+            }
+            float gmx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; i++) if (i < nz) gmx = fmaxf(gmx, mm[i]);
+            float4v ot = {0.f, 0.f, 0.f, 0.f};
+            float st = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (i < nz && mm[i] != -INFINITY) {  // -inf marks an empty chunk
+                    const float f2 = expf(mm[i] - gmx);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) ot[e] += f2 * oo[i][e];
+                    st += f2 * ss[i];
+                }
+            }
+            half4 hh;
+#pragma unroll
+            for (int e = 0; e < 4; e++) hh[e] = (_Float16) (ot[e] / st);
+            *(half4 *) (xs16 + (size_t) r * ldx + c4) = hh;
+        }
+        red_off = (size_t) RB * 16 * ldx * 2;
+        red_off = (red_off + 15) & ~(size_t) 15;
+        __syncthreads();
+    }
+    B1_STAMP(a.stamps, 1);
 
     // ---- 3-5. for every group of 16*RB rows: MFMA over this wave's 256-wide K slice, reduce the K slices
     //           across waves, epilogue.  The weight fragments stay in registers across row groups, so many
@@ -287,7 +394,7 @@ __global__ __launch_bounds__(PRO == PRO_LN ? 512 : 1024) void gemm16_kernel(Gemm
                 for (int c = 0; c < 8; c++) {
                     half8 b;
                     const int k = kb + c * 32;
-                    if (PRO == PRO_LN) {
+                    if (PRO == PRO_LN || PRO == PRO_ATTN) {
                         b = *(const half8 *) (xs16 + (size_t) r * ldx + k);
                     } else if (PRO == PRO_F16) {
                         b = *(const half8 *) ((const _Float16 *) a.A + (int64_t) rr * a.lda + k);
@@ -314,6 +421,7 @@ __global__ __launch_bounds__(PRO == PRO_LN ? 512 : 1024) void gemm16_kernel(Gemm
             }
         }
 
+        if (a.stamps != nullptr) { asm volatile("" :: "v"(acc[0][0])); B1_STAMP(a.stamps, 2); }
         // reduce the K slices across waves (fixed order: deterministic) and run the epilogue; the row blocks
         // of the group are spread over the waves (wave w owns row blocks w, w+nw, ...) so that neither the
         // reduction nor the scattered epilogue stores serialise on one wave
@@ -346,6 +454,7 @@ __global__ __launch_bounds__(PRO == PRO_LN ? 512 : 1024) void gemm16_kernel(Gemm
             }
         }
     }
+    B1_STAMP(a.stamps, 3);
 }
 
 // Scalar-FMA reference GEMV (debug / parity cross-check on the device, and shapes with K % 256 != 0).
@@ -524,11 +633,12 @@ struct AttnArgs {
     float scale;
     float *out;            // [R][H]
     _Float16 *out16;       // [R][H] fp16 copy for an fp16-weight out_proj (same rounding the GEMM would apply), or NULL
-    float *part;           // [R][n_heads][nsplit][66]  (max, sum, acc[64]) when nsplit > 1
+    float *part;           // [R][n_heads][nsplit][ATT_PS] when nsplit > 1
     int max_T;             // LDS score capacity
     // nsplit > 1 with counters != NULL: the workgroup that finishes a (row, head) last folds the nsplit partials itself (same fixed
     // order as attn_combine_kernel) — no separate combine launch; counters [R][n_heads] start at 0 and are left at 0
     uint32_t *counters;
+    long long *stamps;     // debug, as GemmArgs
 };
 
 __device__ __forceinline__ float4v load_kv4(const void *base, int kv_f16, int64_t off) {
@@ -551,6 +661,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
     float *red = (float *) smem;                 // [NKG][64] acc, [NKG] max, [NKG] sum
     const int h = blockIdx.x, r = blockIdx.y, z = blockIdx.z, nz = gridDim.z;
     const int tid = threadIdx.x, kg = tid >> 4, cl = tid & 15, c4 = cl * 4;
+    B1_STAMP(a.stamps, 0);
     const int T = a.row_pos ? (int) a.row_pos[r] + 1 : a.T_fixed;
     const int64_t sb = a.row_seq ? (int64_t) a.row_seq[r] * a.seq_stride : 0;
     const int chunk = (T + nz - 1) / nz;
@@ -574,7 +685,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
         for (int u = 0; u < 4; u++) {
             if (t + u * NKG < t1) {
                 float d = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
-                d += __shfl_xor(d, 8); d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
+                d = row16_sum(d);
                 d *= a.scale;  // soft_max_ext(kq, mask, 1/sqrt(d), 0)
                 const float mn = fmaxf(m, d);
                 const float f = expf(m - mn);   // 0 on the first key (m = -inf)
@@ -586,6 +697,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
             }
         }
     }
+    if (a.stamps != nullptr) { asm volatile("" :: "v"(acc[0])); B1_STAMP(a.stamps, 1); }
     // merge the key groups
     if (cl == 0) red[NKG * 64 + kg] = m;
     __syncthreads();
@@ -606,14 +718,15 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
             else a.out[(int64_t) r * a.H + h * 64 + tid] = res;
         } else {
             // agent-scope atomic stores: the partial is read by a workgroup on another CU / XCD (L2 is per XCD)
-            float *p = a.part + (((int64_t) r * a.n_heads + h) * nz + z) * 66;
+            float *p = a.part + (((int64_t) r * a.n_heads + h) * nz + z) * ATT_PS;
             if (tid == 0) {
                 __hip_atomic_store(p, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(p + 1, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __hip_atomic_store(p + 2 + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p + ATT_PO + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    B1_STAMP(a.stamps, 2);
     if (nz == 1 || !a.counters) return;
     // last workgroup of this (row, head): fold the partials in split order (attn_combine_kernel's arithmetic)
     uint32_t *s_last = (uint32_t *) (red + NKG * 66);   // one of the 16 spare words behind [NKG][66]
@@ -624,14 +737,14 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
     }
     __syncthreads();
     if (!*s_last || tid >= 64) return;
-    const float *p = a.part + ((int64_t) r * a.n_heads + h) * nz * 66;
+    const float *p = a.part + ((int64_t) r * a.n_heads + h) * nz * ATT_PS;
     float mm[16], ss[16], oo[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         if (i < nz) {
-            mm[i] = __hip_atomic_load(p + i * 66, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ss[i] = __hip_atomic_load(p + i * 66 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            oo[i] = __hip_atomic_load(p + i * 66 + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mm[i] = __hip_atomic_load(p + i * ATT_PS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ss[i] = __hip_atomic_load(p + i * ATT_PS + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            oo[i] = __hip_atomic_load(p + i * ATT_PS + ATT_PO + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     float gmx = -INFINITY;
@@ -650,6 +763,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
     if (a.out16) a.out16[(int64_t) r * a.H + h * 64 + tid] = (_Float16) res;
     else a.out[(int64_t) r * a.H + h * 64 + tid] = res;
     if (tid == 0) __hip_atomic_store(a.counters + r * a.n_heads + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.stamps != nullptr && tid == 0 && (h == 0 || h == (int) gridDim.x - 1) && r == 0) a.stamps[(h ? 8 : 0) + 3] = (long long) __builtin_amdgcn_s_memrealtime();
 }
 
 // Cross-attention over a short voice prompt (T_fixed <= 32 encoder positions; Parler-Mini: 8..40): the general kernel
@@ -660,6 +774,7 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), r = blockIdx.y;
     if (h >= a.n_heads) return;
+    B1_STAMP(a.stamps, 0);
     const int T = a.T_fixed;
     const int64_t hb = h * 64 + lane;
     const float qv = a.q[(int64_t) r * a.H + hb];
@@ -681,15 +796,16 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnArgs a) {
     const float res = o / l;
     if (a.out16) a.out16[(int64_t) r * a.H + hb] = (_Float16) res;
     else a.out[(int64_t) r * a.H + hb] = res;
+    B1_STAMP(a.stamps, 3);
 }
 
 __global__ void attn_combine_kernel(const float *part, int nz, int H, int n_heads, float *out, _Float16 *out16) {
     const int h = blockIdx.x, r = blockIdx.y, c = threadIdx.x;  // 64 threads; nz <= 16
-    const float *p = part + ((int64_t) r * n_heads + h) * nz * 66;
+    const float *p = part + ((int64_t) r * n_heads + h) * nz * ATT_PS;
     float m[16], s[16], o[16];
 #pragma unroll
     for (int z = 0; z < 16; z++) {  // every load issued before any use
-        if (z < nz) { m[z] = p[z * 66]; s[z] = p[z * 66 + 1]; o[z] = p[z * 66 + 2 + c]; }
+        if (z < nz) { m[z] = p[z * ATT_PS]; s[z] = p[z * ATT_PS + 1]; o[z] = p[z * ATT_PS + ATT_PO + c]; }
     }
     float mx = -INFINITY;
 #pragma unroll

@@ -387,6 +387,11 @@ struct tts_hip_ctx {
     bool prof_cur = false;
     tts_hip_kstat kstat[TTS_HIP_K_COUNT]{};
     int attn_nsplit_override = 0;
+    // batch-1 chain (<= 4 rows; timeline in profiles/r03/b1_chain.txt):
+    bool b1_fc2_split = true;        // TTS_HIP_B1_FC2_SPLIT=0: fc2 stays 64 workgroups x 128 KB of weights (7.4 us) instead of 256 x 32 KB writing four K-slice slabs
+    bool b1_defer_combine = true;    // TTS_HIP_B1_DEFER_COMBINE=0: the split-T self-attention folds its partials itself (last workgroup, +3.3 us) instead of out_proj's prologue
+    long long *b1_stamps = nullptr;  // TTS_HIP_B1_STAMPS=1: 16 s_memrealtime stamps per launch of a <= 4-row forward (debug_read "stamps", profiles/b1_chain.py)
+    int b1_stamp_slot = 0;
     bool attn_fused = true;          // TTS_HIP_ATTN_FUSED=0: split-T self-attention keeps its separate combine launch and small batches stay unsplit
     uint32_t *attn_cnt = nullptr;    // [RMAX][heads] arrival counters of the fused combine (attn_kernel)
 };
@@ -429,6 +434,8 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     const char *ns = getenv("TTS_HIP_ATTN_NSPLIT");
     if (ns) c->attn_nsplit_override = atoi(ns);
     if (const char *e = getenv("TTS_HIP_ATTN_FUSED")) c->attn_fused = atoi(e) != 0;
+    if (const char *e = getenv("TTS_HIP_B1_FC2_SPLIT")) c->b1_fc2_split = atoi(e) != 0;
+    if (const char *e = getenv("TTS_HIP_B1_DEFER_COMBINE")) c->b1_defer_combine = atoi(e) != 0;
     const char *lf = getenv("TTS_HIP_LN_FUSE_MAX");
     if (lf) c->ln_fuse_max = std::max(0, std::min(32, atoi(lf)));
     if (const char *e = getenv("TTS_HIP_LN_WAVES")) c->ln_waves = std::max(1, std::min(4, atoi(e)));
@@ -508,7 +515,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     free_dev(c->di_e16);
     for (int i = 0; i < 3; i++) free_dev(c->sbuf[i]);
     free_dev(c->s_noise); free_dev(c->s_codes);
-    free_dev(c->t5_bucket); free_dev(c->t5_x); free_dev(c->t5_qkv); free_dev(c->t5_att); free_dev(c->t5_ug); free_dev(c->t5_g); free_dev(c->t5_y); free_dev(c->t5_ids); free_dev(c->logits); free_dev(c->part); free_dev(c->attn_cnt); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
+    free_dev(c->t5_bucket); free_dev(c->t5_x); free_dev(c->t5_qkv); free_dev(c->t5_att); free_dev(c->t5_ug); free_dev(c->t5_g); free_dev(c->t5_y); free_dev(c->t5_ids); free_dev(c->logits); free_dev(c->part); free_dev(c->attn_cnt); free_dev(c->b1_stamps); free_dev(c->dbg); free_dev(c->d_ids); free_dev(c->d_pos);
     free_dev(c->d_seq); free_dev(c->d_gather); free_dev(c->d_tok); free_dev(c->d_step); free_dev(c->d_steps_done); free_dev(c->d_tokens_out);
     free_dev(c->d_eos); free_dev(c->d_frames);
     dac_buffers_release(c);
@@ -1150,9 +1157,9 @@ static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
     // wave sets working on different row groups in parallel (up to 16 waves per workgroup)
     const int rows_wg = a.rows_per_z ? std::min(a.rows_per_z, a.R) : a.R;
     const int n_groups = (rows_wg + 16 * RB - 1) / (16 * RB);
-    const int ngs = PRO == PRO_LN ? 1 : std::max(1, std::min(std::min(n_groups, 16 / nw), c->gemm_ngs_max));
+    const int ngs = PRO == PRO_LN || PRO == PRO_ATTN ? 1 : std::max(1, std::min(std::min(n_groups, 16 / nw), c->gemm_ngs_max));
     size_t lds = 0;
-    if (PRO == PRO_LN) {
+    if (PRO == PRO_LN || PRO == PRO_ATTN) {
         lds = (size_t) RB * 16 * (a.K + (WT == 1 ? 8 : 4)) * (WT == 1 ? 2 : 4);
         lds = (lds + 15) & ~(size_t) 15;
     }
@@ -1163,7 +1170,7 @@ static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
     }
     if (lds > 160 * 1024) return set_err("gemm16: LDS request %zu exceeds 160 KiB", lds);
     if (PRO == PRO_LN && a.K > 2048) return set_err("gemm16: LayerNorm prologue supports hidden sizes up to 2048 (got %d)", a.K);
-    if (PRO == PRO_LN && ngs * nw > 8) return set_err("gemm16: fused-LayerNorm launch wants %d waves (> 8)", ngs * nw);
+    if ((PRO == PRO_LN || PRO == PRO_ATTN) && ngs * nw > 8) return set_err("gemm16: fused-prologue launch wants %d waves (> 8)", ngs * nw);
     const int nz = a.rows_per_z ? (a.R + a.rows_per_z - 1) / a.rows_per_z : 1;
     hipLaunchKernelGGL((gemm16_kernel<WT, PRO, EPI, RB>), dim3(a.N / 16, ksplit, nz), dim3(ngs * nw * 64), lds, c->stream, a);
     HIPCHK(hipGetLastError());
@@ -1173,7 +1180,7 @@ static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
 template <int WT, int PRO, int EPI>
 static int launch_gemm16_rb(tts_hip_ctx *c, const GemmArgs &a_in) {
     GemmArgs a = a_in;
-    if (PRO != PRO_LN && c->gemm_rows_per_wg > 0 && a.R > c->gemm_rows_per_wg) {
+    if (PRO != PRO_LN && PRO != PRO_ATTN && c->gemm_rows_per_wg > 0 && a.R > c->gemm_rows_per_wg) {
         a.rows_per_z = c->gemm_rows_per_wg;
         if (a.rows_per_z <= 16) return launch_gemm16<WT, PRO, EPI, 1>(c, a);
         if (a.rows_per_z <= 32) return launch_gemm16<WT, PRO, EPI, 2>(c, a);
@@ -1430,6 +1437,15 @@ static int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro
 }
 
 // one GEMM of the forward: picks MFMA or the scalar reference path
+// every matrix the <= 4-row forward touches goes through gemm16_kernel<1, ...> (the only consumer that folds fc2's K-slice slabs)
+static bool chain_all_f16(const tts_hip_ctx *c) {
+    if ((c->d.flags & TTS_HIP_FLAG_VALU_GEMM) || c->gemv_rows || c->H % 256) return false;
+    for (const PLayer &y : c->layers)
+        for (const W *m : {&y.qkv, &y.o, &y.cq, &y.co, &y.fc1, &y.fc2})
+            if (m->N && m->type != TTS_HIP_F16) return false;
+    return c->heads.type == TTS_HIP_F16;
+}
+
 static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi) {
     a.W = c->arena + w.off;
     a.K = (int) w.K;
@@ -1514,6 +1530,16 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
             c->pending_parts = ks;
         }
     }
+    if (epi == EPI_RESID && pro == PRO_F16 && w.type == TTS_HIP_F16 && a.R <= 4 && c->b1_fc2_split && a.K >= 4096 && a.K % 1024 == 0 && a.N == a.H && a.H <= 1024 &&
+        a.out == c->x && !a.n_parts && chain_all_f16(c)) {
+        // batch-1 chain: 64 workgroups streaming 128 KB of fc2 each and reducing 16 K slices through LDS take 7.4 us; 256 workgroups of 32 KB take what
+        // out_proj takes (3 us).  The four K-slice slabs are folded by the consumers: the next LayerNorm prologue and the next residual epilogue.
+        a.kchunk = a.K / 4;
+        a.slab_stride = (int64_t) c->RMAX * c->H;
+        a.out = c->partials;
+        epi = EPI_STORE;
+        c->pending_parts = 4;
+    }
     CHK(prof_begin(c, kclass, bytes, flops));
     int rc = -1;
 #define GEMM_CASE(WTv, PROv, EPIv) \
@@ -1523,7 +1549,7 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
     GEMM_CASE(1, PRO_LN, EPI_GELU) GEMM_CASE(0, PRO_LN, EPI_GELU)
     GEMM_CASE(1, PRO_F32, EPI_RESID) GEMM_CASE(0, PRO_F32, EPI_RESID)
     GEMM_CASE(1, PRO_F32, EPI_STORE) GEMM_CASE(0, PRO_F32, EPI_STORE)
-    GEMM_CASE(1, PRO_F16, EPI_RESID)
+    GEMM_CASE(1, PRO_F16, EPI_RESID) GEMM_CASE(1, PRO_ATTN, EPI_RESID)
     GEMM_CASE(1, PRO_F16, EPI_QKV) GEMM_CASE(1, PRO_F16, EPI_STORE) GEMM_CASE(1, PRO_F16, EPI_GELU)
     GEMM_CASE(0, PRO_F32, EPI_QKV) GEMM_CASE(0, PRO_F32, EPI_GELU)
     { rc = set_err("run_gemm: no kernel for type=%d pro=%d epi=%d", w.type, pro, epi); }
@@ -1532,7 +1558,7 @@ static int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro,
     return prof_end(c);
 }
 
-static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, double kv_bytes) {
+static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, double kv_bytes, bool defer_combine = false) {
     a.max_T = (nsplit > 1) ? (c->NCTX + nsplit - 1) / nsplit + 1 : std::max(c->NCTX, c->ECAP);
     // few (head,row) pairs: 1024-thread workgroups (64 key groups) instead of a split-T pass + combine launch
     const bool wide = nsplit == 1 && c->NH * R < 128 && a.row_pos != nullptr;
@@ -1549,11 +1575,11 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
         HIPCHK(hipGetLastError());
         return prof_end(c);
     }
-    const bool fused = nsplit > 1 && c->attn_fused && c->attn_cnt != nullptr;
+    const bool fused = nsplit > 1 && c->attn_fused && c->attn_cnt != nullptr && !defer_combine;
     a.counters = fused ? c->attn_cnt : nullptr;
     hipLaunchKernelGGL(attn_kernel, dim3(c->NH, R, nsplit), dim3(threads), lds, c->stream, a);
     HIPCHK(hipGetLastError());
-    if (nsplit > 1 && !fused) {
+    if (nsplit > 1 && !fused && !defer_combine) {
         hipLaunchKernelGGL(attn_combine_kernel, dim3(c->NH, R), dim3(64), 0, c->stream, (const float *) a.part, nsplit, c->H, c->NH, a.out, a.out16);
         HIPCHK(hipGetLastError());
     }
@@ -1599,10 +1625,16 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
     for (int r = 0; r < R && r < (int) c->host_pos.size(); r++) self_kv_bytes += 2.0 * (c->host_pos[r] + 1) * H * kv_esz;
     const int nsplit = attn_nsplit(c, R, same_seq);
 
+    // debug timeline of the batch-1 chain: every launch of a <= 4-row forward gets its own 16-stamp record (graph replays rewrite it)
+    const bool stamped = c->b1_stamps != nullptr && R <= 4;
+    if (stamped) c->b1_stamp_slot = 0;
+    auto stamp_slot = [&]() -> long long * { return stamped ? c->b1_stamps + 16 * (size_t) (c->b1_stamp_slot++) : nullptr; };
     for (int l = 0; l < c->L; l++) {
         const PLayer &y = c->layers[l];
         GemmArgs g{};
         g.R = R; g.H = H; g.gelu_mode = (int) c->d.gelu_mode;
+        g.stamps = stamp_slot();
+        if (c->pending_parts && R <= 4) { g.parts = c->partials; g.n_parts = c->pending_parts; g.parts_stride = (int64_t) c->RMAX * H; }   // the previous layer's fc2 slabs
         // self attention -------------------------------------------------------------------
         g.A = c->x; g.lda = H;
         g.ln_w = (const float *) (c->arena + y.sa_w); g.ln_b = (const float *) (c->arena + y.sa_b);
@@ -1620,11 +1652,19 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
         const bool valu_mode = (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) != 0;
         const bool o_half = y.o.type == TTS_HIP_F16 && !valu_mode && (H % 256 == 0);
         at.scale = 1.0f / sqrtf(64.0f); at.out = c->att; at.out16 = o_half ? c->att16 : nullptr; at.part = c->part;
-        CHK(run_attn(c, TTS_HIP_K_ATTN_SELF, at, R, nsplit, self_kv_bytes));
+        at.stamps = stamp_slot();
+        // <= 4 rows: the key-split partials are folded by out_proj's workgroups as they load them (one kernel boundary instead of an arrival
+        // counter + a dependent read-back inside the attention launch: 9.6 -> 6.3 us per layer at T ~ 1000)
+        const bool defer = R <= 4 && nsplit > 1 && o_half && c->b1_defer_combine && H <= 2048 && H == c->NH * 64 && (int) y.o.K == H && c->attn_nsplit_override <= 0;
+        CHK(run_attn(c, TTS_HIP_K_ATTN_SELF, at, R, nsplit, self_kv_bytes, defer));
 
         GemmArgs go{};
         go.R = R; go.H = H; go.A = o_half ? (const void *) c->att16 : (const void *) c->att; go.lda = H; go.out = c->x; go.ldo = H;
-        CHK(run_gemm(c, TTS_HIP_K_GEMM_ATTN_OUT, y.o, go, o_half ? PRO_F16 : PRO_F32, EPI_RESID));
+        go.stamps = stamp_slot();
+        if (defer) { go.att_part = c->part; go.att_nz = nsplit; go.att_heads = c->NH; }
+        if (c->pending_parts && R <= 4) { go.parts = c->partials; go.n_parts = c->pending_parts; go.parts_stride = (int64_t) c->RMAX * H; }
+        CHK(run_gemm(c, TTS_HIP_K_GEMM_ATTN_OUT, y.o, go, defer ? PRO_ATTN : (o_half ? PRO_F16 : PRO_F32), EPI_RESID));
+        if (go.n_parts) { c->pending_parts = 0; go.parts = nullptr; go.n_parts = 0; }   // x is whole again
 
         // cross attention ------------------------------------------------------------------
         if (c->d.use_cross_attn) {
@@ -1632,6 +1672,7 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
             gq.R = R; gq.H = H; gq.A = c->x; gq.lda = H;
             gq.ln_w = (const float *) (c->arena + y.ca_w); gq.ln_b = (const float *) (c->arena + y.ca_b);
             gq.out = c->q; gq.ldo = H;
+            gq.stamps = stamp_slot();
             CHK(run_gemm(c, TTS_HIP_K_GEMM_CROSS_Q, y.cq, gq, PRO_LN, EPI_STORE));
             AttnArgs ac{};
             ac.q = c->q;
@@ -1640,8 +1681,10 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
             ac.kv_f16 = 0; ac.seq_stride = 0; ac.row_seq = nullptr; ac.row_pos = nullptr; ac.T_fixed = c->E;
             const bool co_half = y.co.type == TTS_HIP_F16 && !valu_mode && (H % 256 == 0);
             ac.H = H; ac.n_heads = c->NH; ac.scale = at.scale; ac.out = c->att; ac.out16 = co_half ? c->att16 : nullptr; ac.part = c->part;
+            ac.stamps = stamp_slot();
             CHK(run_attn(c, TTS_HIP_K_ATTN_CROSS, ac, R, 1, 2.0 * c->E * H * 4));
             GemmArgs gc = go;
+            gc.stamps = stamp_slot();
             gc.A = co_half ? (const void *) c->att16 : (const void *) c->att;
             CHK(run_gemm(c, TTS_HIP_K_GEMM_CROSS_OUT, y.co, gc, co_half ? PRO_F16 : PRO_F32, EPI_RESID));
         }
@@ -1652,10 +1695,12 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
         g1.ln_w = (const float *) (c->arena + y.f_w); g1.ln_b = (const float *) (c->arena + y.f_b);
         const bool u_half = (y.fc2.type == TTS_HIP_F16) && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM) && (c->F % 256 == 0);
         g1.out = c->u32; g1.out16 = u_half ? c->u16 : nullptr; g1.ldo = c->F;
+        g1.stamps = stamp_slot();
         CHK(run_gemm(c, TTS_HIP_K_GEMM_FC1, y.fc1, g1, PRO_LN, EPI_GELU));
         GemmArgs g2{};
         g2.R = R; g2.H = H; g2.A = u_half ? (const void *) c->u16 : (const void *) c->u32; g2.lda = c->F;
         g2.out = c->x; g2.ldo = H;
+        g2.stamps = stamp_slot();
         CHK(run_gemm(c, TTS_HIP_K_GEMM_FC2, y.fc2, g2, u_half ? PRO_F16 : PRO_F32, EPI_RESID));
     }
 
@@ -1664,6 +1709,7 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
         gh.R = R; gh.H = H; gh.A = c->x; gh.lda = H;
         gh.ln_w = (const float *) (c->arena + c->ln_w); gh.ln_b = (const float *) (c->arena + c->ln_b);
         gh.out = c->logits; gh.ldo = c->NO * c->V;
+        if (c->pending_parts && R <= 4) { gh.parts = c->partials; gh.n_parts = c->pending_parts; gh.parts_stride = (int64_t) c->RMAX * H; }
         CHK(run_gemm(c, TTS_HIP_K_GEMM_HEADS, c->heads, gh, PRO_LN, EPI_STORE));
     }
     return 0;
@@ -1742,8 +1788,9 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->aq, (size_t) R * std::max(H, c->F)));
         CHK(dmalloc(&c->ad, (size_t) R * std::max(H, c->F) / 32));
         CHK(dmalloc(&c->logits, (size_t) R * c->NO * c->V));
-        CHK(dmalloc(&c->part, (size_t) R * c->NH * 16 * 66));
+        CHK(dmalloc(&c->part, (size_t) R * c->NH * 16 * ATT_PS));
         CHK(dmalloc(&c->attn_cnt, (size_t) R * c->NH));
+        if (getenv("TTS_HIP_B1_STAMPS") && atoi(getenv("TTS_HIP_B1_STAMPS"))) CHK(dmalloc(&c->b1_stamps, (size_t) 16 * (c->L * 8 + 8)));
         CHK(dmalloc(&c->d_ids, (size_t) R * c->NO));
         CHK(dmalloc(&c->d_pos, (size_t) R));
         CHK(dmalloc(&c->d_seq, (size_t) R));
@@ -4743,6 +4790,12 @@ extern "C" int64_t tts_hip_debug_read(tts_hip_ctx *c, const char *what, float *o
     if (w == "x") {
         const size_t R = c->host_pos.size();
         if (R == 0 || R * c->H > max_floats) { set_err("debug_read(x): no forward yet or buffer too small"); return -1; }
+        if (c->pending_parts) {   // the last fc2 left K-slice slabs: fold them into x (the LayerNorm output goes to scratch)
+            launch_ln_rows(c, 4, c->x, c->H, (const float *) (c->arena + c->ln_w), (const float *) (c->arena + c->ln_b), c->dbg, (_Float16 *) nullptr, (int) R,
+                           (const float *) c->partials, c->pending_parts, (int64_t) c->RMAX * c->H);
+            c->pending_parts = 0;
+            if (hipStreamSynchronize(c->stream) != hipSuccess) { set_err("debug_read(x): fold failed"); return -1; }
+        }
         if (hipMemcpy(out, c->x, R * c->H * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("copy failed"); return -1; }
         return (int64_t) (R * c->H);
     }
@@ -4767,6 +4820,13 @@ extern "C" int64_t tts_hip_debug_read(tts_hip_ctx *c, const char *what, float *o
             (void) hipFree(tmp);
             if (e != hipSuccess) { set_err("copy failed"); return -1; }
         }
+        return (int64_t) n;
+    }
+    if (w == "stamps") {  // TTS_HIP_B1_STAMPS=1: [launch][16] int64 s_memrealtime stamps of the last <= 4-row forward, two floats per stamp
+        if (!c->b1_stamps) { set_err("debug_read(stamps): set TTS_HIP_B1_STAMPS=1 before tts_hip_finalize"); return -1; }
+        const size_t n = (size_t) 16 * c->b1_stamp_slot * 2;
+        if (n > max_floats) { set_err("buffer too small"); return -1; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, c->b1_stamps, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("copy failed"); return -1; }
         return (int64_t) n;
     }
     if (starts_with(w, "cross:")) {  // cross:<layer>:<0|1>  -> [E][H]
