@@ -76,6 +76,8 @@ def main():
         ("fc2 as 256 workgroups + slabs", {"TTS_HIP_B1_FC2_SPLIT": "1", "TTS_HIP_B1_DEFER_COMBINE": "0"}, False),
         ("combine in out_proj's prologue", {"TTS_HIP_B1_FC2_SPLIT": "0", "TTS_HIP_B1_DEFER_COMBINE": "1"}, False),
         ("both (default)", {}, True),
+        ("... in 16 key splits", {"TTS_HIP_ATTN_NSPLIT": "16"}, False),
+        ("... in 4 key splits", {"TTS_HIP_ATTN_NSPLIT": "4"}, False),
     ]
     base_lg = base_tok = None
     for i, (name, env, stamps) in enumerate(variants):
@@ -90,7 +92,7 @@ def main():
         if base_lg is None: base_lg, base_tok = lg, tok
         same = int((tok == base_tok).all())
         first_diff = -1 if same else int(np.argwhere((tok != base_tok).any(axis=(1, 2)))[0][0])
-        print(f"{name:32s}{' [stamps]' if stamps else '':9s} {r['ms_per_step']:.4f} ms/step = {r['x_real_time']:.2f} x real time;  tokens equal to plain: {same}"
+        print(f"{name:36s}{' [stamps]' if stamps else '':9s} {r['ms_per_step']:.4f} ms/step = {r['x_real_time']:.2f} x real time;  tokens equal to plain: {same}"
               f"{'' if same else ' (first difference at step %d)' % first_diff};  logits max |diff| {np.abs(lg - base_lg).max():.3e} (max |logit| {np.abs(base_lg).max():.2f})")
         if stamps: analyse(r["stamps"], 8)
 

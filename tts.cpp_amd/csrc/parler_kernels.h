@@ -655,7 +655,9 @@ __device__ __forceinline__ float4v load_kv4(const void *base, int kv_f16, int64_
 // two dependent passes) and folded with a running max / sum per key group; the groups are merged through
 // LDS in a fixed order.  Mathematically soft_max_ext + mul_mat; rounding differs from the two-pass form
 // only in the order of fp32 operations.
-__global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
+// (8 keys per lane group and pass instead of 4 — 128 keys per workgroup and round trip — was measured for the batch-1 chain: 183 VGPRs and
+// twice the loads in flight per CU made the key pass slower, 3.7 -> 6.0 us at T ~ 1000, profiles/r03/b1_chain_attn_variants.txt.)
+__global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {   // U = 8 is launched with 256 threads only (nsplit > 1)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NKG = blockDim.x >> 4;
     float *red = (float *) smem;                 // [NKG][64] acc, [NKG] max, [NKG] sum
@@ -717,13 +719,18 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {
             if (a.out16) a.out16[(int64_t) r * a.H + h * 64 + tid] = (_Float16) res;
             else a.out[(int64_t) r * a.H + h * 64 + tid] = res;
         } else {
-            // agent-scope atomic stores: the partial is read by a workgroup on another CU / XCD (L2 is per XCD)
             float *p = a.part + (((int64_t) r * a.n_heads + h) * nz + z) * ATT_PS;
-            if (tid == 0) {
-                __hip_atomic_store(p, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p + 1, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.counters) {
+                // agent-scope atomic stores: the partial is read inside this launch by a workgroup on another CU / XCD (L2 is per XCD)
+                if (tid == 0) {
+                    __hip_atomic_store(p, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p + 1, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __hip_atomic_store(p + ATT_PO + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {   // read by a later launch (attn_combine_kernel or out_proj's PRO_ATTN prologue)
+                if (tid == 0) { p[0] = mx; p[1] = s; }
+                p[ATT_PO + tid] = o;
             }
-            __hip_atomic_store(p + ATT_PO + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     B1_STAMP(a.stamps, 2);

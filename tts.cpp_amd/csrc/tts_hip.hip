@@ -1655,7 +1655,7 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
         at.stamps = stamp_slot();
         // <= 4 rows: the key-split partials are folded by out_proj's workgroups as they load them (one kernel boundary instead of an arrival
         // counter + a dependent read-back inside the attention launch: 9.6 -> 6.3 us per layer at T ~ 1000)
-        const bool defer = R <= 4 && nsplit > 1 && o_half && c->b1_defer_combine && H <= 2048 && H == c->NH * 64 && (int) y.o.K == H && c->attn_nsplit_override <= 0;
+        const bool defer = R <= 4 && nsplit > 1 && o_half && c->b1_defer_combine && H <= 2048 && H == c->NH * 64 && (int) y.o.K == H;
         CHK(run_attn(c, TTS_HIP_K_ATTN_SELF, at, R, nsplit, self_kv_bytes, defer));
 
         GemmArgs go{};
