@@ -367,13 +367,20 @@ __global__ __launch_bounds__(256) void snake_split_kernel(SplitArgs a) {
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) v[e] = xg[(int64_t) e * LS];
+    if (a.alpha) {   // one wave-uniform range test for the eight values (snake_vec) instead of a divergent branch per value
+        const float4d a0 = *(const float4d *) (a.alpha + cg * 8), a1 = *(const float4d *) (a.alpha + cg * 8 + 4);
+        float al[8], ral[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { al[e] = a0[e]; al[4 + e] = a1[e]; }
+#pragma unroll
+        for (int e = 0; e < 8; e++) ral[e] = 1.0f / al[e];
+        snake_vec<8>(v, al, ral);
+    }
     bf16x8d h1, h2, h3;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-        float s = v[e];
-        if (a.alpha) { const float al = a.alpha[cg * 8 + e]; s = snake_f(s, al, 1.0f / al); }
         __bf16 b1, b2, b3;
-        split_bf16x3(s, b1, b2, b3);
+        split_bf16x3(v[e], b1, b2, b3);
         h1[e] = b1; h2[e] = b2; h3[e] = b3;
     }
     const int64_t pst = (int64_t) CG * LS * 8;
@@ -454,33 +461,6 @@ struct PConvArgs {
     int npos, nco, nz;       // tiles along positions / output channels, utterances (xcd_tile)
 };
 
-// one lane's 4 consecutive channels of one position: bias (+ residual) -> fp32 out and / or snake + split -> planes out
-__device__ __forceinline__ void b3p_store4(const PConvArgs &a, float v0, float v1, float v2, float v3, int co, int t, int LS, const float *rg, float *yg,
-                                           __bf16 *ypz, int64_t pst) {
-    float v[4] = {v0, v1, v2, v3};
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        v[r] += a.b ? a.b[co + r] : 0.0f;
-        if (rg) v[r] = v[r] + rg[(int64_t) (co + r) * LS + t];
-        if (yg) yg[(int64_t) (co + r) * LS + t] = v[r];
-    }
-    if (ypz) {
-        typedef __bf16 bf16x4d __attribute__((ext_vector_type(4)));
-        bf16x4d h1, h2, h3;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float s = v[r];
-            if (a.alpha_out) { const float al = a.alpha_out[co + r]; s = snake_f(s, al, 1.0f / al); }
-            __bf16 b1, b2, b3;
-            split_bf16x3(s, b1, b2, b3);
-            h1[r] = b1; h2[r] = b2; h3[r] = b3;
-        }
-        __bf16 *p = ypz + ((int64_t) (co >> 3) * LS + t) * 8 + (co & 7);   // co is a multiple of 4: the lower or upper half of a 16-byte row
-        *(bf16x4d *) p = h1;
-        *(bf16x4d *) (p + pst) = h2;
-        *(bf16x4d *) (p + 2 * pst) = h3;
-    }
-}
 
 // k = 7, NS = 7 (round 3, "tap per k-step"): chunk = 16 input channels, k-step s = tap s, the half-wave takes 8-channel group hi — 7 k-steps per
 // 16 channels where the NS = 4 form (chunk = 8 channels, half-wave = tap parity) spends 8 with the eighth tap slot on zero weights.
@@ -620,17 +600,68 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
     float *yg = a.y ? a.y + (int64_t) tile.z * a.cout * LS : nullptr;
     const int64_t psto = (int64_t) (a.cout / 8) * LS * 8;
     __bf16 *ypz = a.yp ? a.yp + (int64_t) tile.z * 3 * psto : nullptr;
+    // Epilogue in phases per (row tile, quad of 4 channels): every load of the phase is issued before anything waits (bias / alpha as one
+    // 16-byte load each, the NI x 4 residual values with clamped indices), then the arithmetic for all lanes, then predicated stores.  The
+    // per-value form — `if (t < L)`, `if (resid)`, `if (alpha)` around single loads — compiled to load, s_waitcnt vmcnt(0), store per value:
+    // 128 dependent round trips per lane on a 256 x 256 tile (profiles/tools/isa_serial_loads.py).
+    typedef __bf16 bf16x4d __attribute__((ext_vector_type(4)));
+    const bool has_b = a.b != nullptr, has_al = a.alpha_out != nullptr;
 #pragma unroll
     for (int i = 0; i < MI; i++)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int co = co0 + (wm * MI + i) * 32 + 8 * q + 4 * hi;
-            if (co >= a.cout) continue;
+            const int co = co0 + (wm * MI + i) * 32 + 8 * q + 4 * hi;   // a multiple of 4; cout is a multiple of 8
+            const bool co_ok = co < a.cout;
+            const int coc = co_ok ? co : 0;
+            float4d b4 = {0.f, 0.f, 0.f, 0.f}, al4 = {1.f, 1.f, 1.f, 1.f};
+            if (has_b) b4 = *(const float4d *) (a.b + coc);
+            if (has_al) al4 = *(const float4d *) (a.alpha_out + coc);
+            float rv[NI][4];
+            if (rg) {
+#pragma unroll
+                for (int j = 0; j < NI; j++) {
+                    const int tc = min(t0 + (wn * NI + j) * 32 + l31, L - 1);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) rv[j][r] = rg[(int64_t) (coc + r) * LS + tc];
+                }
+            }
+            float al[4], ral[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { al[r] = al4[r]; ral[r] = 1.0f / al4[r]; }
 #pragma unroll
             for (int j = 0; j < NI; j++) {
                 const int t = t0 + (wn * NI + j) * 32 + l31;
-                if (t >= L) continue;
-                b3p_store4(a, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3], co, t, LS, rg, yg, ypz, psto);
+                const bool ok = co_ok && t < L;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    v[r] = acc[i][j][4 * q + r] + (has_b ? b4[r] : 0.0f);
+                    if (rg) v[r] = v[r] + rv[j][r];
+                }
+                if (yg && ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) yg[(int64_t) (co + r) * LS + t] = v[r];
+                }
+                if (ypz) {
+                    if (has_al) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) if (!ok) v[r] = 0.0f;   // lanes outside the tensor must not drag the wave into the slow sine
+                        snake_vec<4>(v, al, ral);
+                    }
+                    bf16x4d h1, h2, h3;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        __bf16 b1, b2, b3;
+                        split_bf16x3(v[r], b1, b2, b3);
+                        h1[r] = b1; h2[r] = b2; h3[r] = b3;
+                    }
+                    if (ok) {
+                        __bf16 *p = ypz + ((int64_t) (co >> 3) * LS + t) * 8 + (co & 7);   // co is a multiple of 4: the lower or upper half of a 16-byte row
+                        *(bf16x4d *) p = h1;
+                        *(bf16x4d *) (p + psto) = h2;
+                        *(bf16x4d *) (p + 2 * psto) = h3;
+                    }
+                }
             }
         }
 }

@@ -138,13 +138,73 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tile_kernel(GemmArgs a, Til
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------
+    // Loads first, then stores.  The per-fragment form (gemm_epilogue4 under `if (r < R && n < N)`) compiled to load, s_waitcnt vmcnt(0),
+    // store for each of the NI * MI fragments: the residual read-modify-write and the KV-cache append (row_seq / row_pos) were eight
+    // dependent round trips at the end of a 10-20 us kernel (profiles/tools/isa_serial_loads.py).
+    if constexpr (EPI == EPI_RESID) {
+        float4v xo[NI][MI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ni++) {
-        const int n = n0 + wn * (BN / WN) + ni * 16 + fq * 4;
+        for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                const int n = min(n0 + wn * (BN / WN) + ni * 16 + fq * 4, a.N - 4);
+                const int r = min(r0 + wm * (BM / WM) + mi * 16 + fl, a.R - 1);
+                xo[ni][mi] = *(const float4v *) (a.out + (int64_t) r * a.ldo + n);
+            }
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {
+            const int n = n0 + wn * (BN / WN) + ni * 16 + fq * 4;
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                const int r = r0 + wm * (BM / WM) + mi * 16 + fl;
+                if (r < a.R && n < a.N) {
+                    float4v o = xo[ni][mi];
+                    o += acc[ni][mi];  // ggml_add(cur, residual)
+                    *(float4v *) (a.out + (int64_t) r * a.ldo + n) = o;
+                }
+            }
+        }
+    } else if constexpr (EPI == EPI_QKV) {
+        int64_t rowoff[MI];   // this lane's rows in the cache: sequence and position
 #pragma unroll
         for (int mi = 0; mi < MI; mi++) {
-            const int r = r0 + wm * (BM / WM) + mi * 16 + fl;
-            if (r < a.R && n < a.N) gemm_epilogue4(a, EPI, r, n, acc[ni][mi], kz);
+            const int r = min(r0 + wm * (BM / WM) + mi * 16 + fl, a.R - 1);
+            rowoff[mi] = (int64_t) a.row_seq[r] * a.seq_stride + (int64_t) a.row_pos[r] * a.H;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {
+            const int n = n0 + wn * (BN / WN) + ni * 16 + fq * 4;
+            const int which = n / a.H, c = n - which * a.H;   // wave-uniform per ni up to fq: a feature quad never straddles q / k / v (H % 4 == 0)
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                const int r = r0 + wm * (BM / WM) + mi * 16 + fl;
+                if (r < a.R && n < a.N) {
+                    const float4v v = acc[ni][mi];
+                    if (which == 0) {
+                        *(float4v *) (a.q + (int64_t) r * a.H + c) = v;
+                    } else {
+                        void *base = which == 1 ? a.kc : a.vc;
+                        if (a.kv_f16) {
+                            half4 h;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) h[e] = (_Float16) v[e];
+                            *(half4 *) ((_Float16 *) base + rowoff[mi] + c) = h;
+                        } else {
+                            *(float4v *) ((float *) base + rowoff[mi] + c) = v;
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {
+            const int n = n0 + wn * (BN / WN) + ni * 16 + fq * 4;
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                const int r = r0 + wm * (BM / WM) + mi * 16 + fl;
+                if (r < a.R && n < a.N) gemm_epilogue4(a, EPI, r, n, acc[ni][mi], kz);
+            }
         }
     }
 }

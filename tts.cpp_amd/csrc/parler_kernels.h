@@ -103,17 +103,19 @@ __global__ void embed_rows_kernel(EmbedArgs a) {
     const uint32_t pos = a.row_pos[r];
     uint32_t id[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) id[i] = i < a.n_tabs ? a.ids[r * a.n_tabs + i] : 0;  // all id loads in flight at once
+    for (int i = 0; i < 16; i++) id[i] = a.ids[r * a.n_tabs + min(i, a.n_tabs - 1)];  // all id loads in flight at once (straight-line: a table beyond n_tabs repeats the last)
     // gridDim.y column blocks: every thread does one column per table, all of its loads in one round trip (one workgroup walking the
     // row in 4 dependent passes took 17 us at batch 1)
     for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < a.H; c += gridDim.y * blockDim.x) {
         float v[16];
+        if (a.tab_f16) {   // the element type is tested once, not around every load (each test was its own basic block with a wait)
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            if (i < a.n_tabs) {
-                const int64_t off = (int64_t) i * a.tab_stride + (int64_t) id[i] * a.H + c;
-                v[i] = a.tab_f16 ? (float) ((const _Float16 *) a.tab)[off] : ((const float *) a.tab)[off];
-            }
+            for (int i = 0; i < 16; i++)
+                v[i] = (float) ((const _Float16 *) a.tab)[(int64_t) min(i, a.n_tabs - 1) * a.tab_stride + (int64_t) id[i] * a.H + c];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                v[i] = ((const float *) a.tab)[(int64_t) min(i, a.n_tabs - 1) * a.tab_stride + (int64_t) id[i] * a.H + c];
         }
         const float pe = a.pos_embed[(int64_t) pos * a.H + c];
         float acc = v[0];
@@ -786,12 +788,13 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnArgs a) {
     const int64_t hb = h * 64 + lane;
     const float qv = a.q[(int64_t) r * a.H + hb];
     float kv[32], vv[32], sc[32];
+    const float *kc = (const float *) a.kc, *vc = (const float *) a.vc;   // the cross K / V are fp32 (compute_cross_kv); the launcher refuses kv_f16
 #pragma unroll
-    for (int t = 0; t < 32; t++)   // K and V rows requested together: one round trip
-        if (t < T) {
-            kv[t] = a.kv_f16 ? (float) ((const _Float16 *) a.kc)[hb + (int64_t) t * a.H] : ((const float *) a.kc)[hb + (int64_t) t * a.H];
-            vv[t] = a.kv_f16 ? (float) ((const _Float16 *) a.vc)[hb + (int64_t) t * a.H] : ((const float *) a.vc)[hb + (int64_t) t * a.H];
-        }
+    for (int t = 0; t < 32; t++) {   // K and V rows requested together, straight-line: one round trip (a position beyond T re-reads the last row)
+        const int64_t off = hb + (int64_t) min(t, T - 1) * a.H;
+        kv[t] = kc[off];
+        vv[t] = vc[off];
+    }
     float m = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 32; t++)

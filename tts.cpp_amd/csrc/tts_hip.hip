@@ -1569,7 +1569,7 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
         HIPCHK(hipFuncSetAttribute((const void *) attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     CHK(prof_begin(c, kclass, kv_bytes + 2.0 * R * c->H * 4, 0));
-    if (!a.row_pos && a.T_fixed <= 32 && nsplit == 1 && c->attn_short) {
+    if (!a.row_pos && a.T_fixed <= 32 && a.T_fixed >= 1 && nsplit == 1 && c->attn_short && !a.kv_f16) {
         // cross-attention over a short voice prompt: one wave per (row, head), no merges
         hipLaunchKernelGGL(attn_short_kernel, dim3((c->NH + 3) / 4, R), dim3(256), 0, c->stream, a);
         HIPCHK(hipGetLastError());
