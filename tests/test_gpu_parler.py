@@ -652,3 +652,37 @@ def test_row_compaction_keeps_every_utterance_token_for_token(sampled, monkeypat
         k = int(da[u]) if da[u] else n_steps
         assert k == cap - lens[u] or da[u] == 0 or k < cap - lens[u]
         assert np.array_equal(ta[:k, u], tb[:k, u]), f"utterance {u}"
+
+
+def test_generation_graphs_follow_reallocated_outputs_and_sampling_parameters():
+    """The captured generation step bakes the tokens_out pointer and the sampling parameters in; both may change between calls on one
+    context (a longer request reallocates tokens_out, a request may sample differently).  Round 3 keyed the graphs in units of 8192 rows
+    and dropped them in units of 1000: stale graphs wrote through a freed pointer (memory access fault in the 3-runner bench) and sampled
+    with the first call's top_k (tests/test_gpu_runner.py::test_host_sampling_loop_modes)."""
+    model = get_model("small", gguf.F16)
+    cfg = model.cfg
+    prompt = np.random.default_rng(21).integers(3, cfg.prompt_vocab, 12).astype(np.uint32)
+
+    def fresh(n_steps, sampled=None):
+        eng = hip.HipEngine(cfg, max_seqs=2)
+        eng.load(model)
+        eng.prefill_batch([prompt, prompt[:7]])
+        out = run(eng, n_steps, sampled)
+        eng.close()
+        return out
+
+    def run(eng, n_steps, sampled):
+        start = [len(prompt), 7]
+        if sampled is None:
+            return eng.generate_greedy(start, n_steps)[0]
+        u = np.random.default_rng(5).random((n_steps, 2, cfg.n_out), dtype=np.float32)
+        return eng.generate_sampled(start, n_steps, u, top_k=sampled, temperature=1.0)[0]
+
+    eng = hip.HipEngine(cfg, max_seqs=2)
+    eng.load(model)
+    for n_steps, sampled in [(6, None), (40, None), (40, 1), (40, 30), (64, 30), (64, None)]:   # growing outputs, changing sampler
+        eng.reset(); eng.prefill_batch([prompt, prompt[:7]])
+        got = run(eng, n_steps, sampled)
+        assert np.array_equal(got, fresh(n_steps, sampled)), (n_steps, sampled)
+    eng.close()
+    assert not np.array_equal(fresh(40, 30), fresh(40, None))

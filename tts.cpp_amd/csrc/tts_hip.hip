@@ -171,6 +171,8 @@ struct ProfEv { hipEvent_t a, b; int kclass; };
 // Codec activation buffers of a device.  Codec passes of one device take turns (g_dac_pass_mutex: a pass fills the chip), so every
 // context of the device works in the same buffers instead of holding its own three activation buffers (197 KB per frame and utterance of
 // a pass each: 12.6 GB per context for 64 x 248 frames, 38.6 GB at 1016 frames); they are freed when the device's last codec context goes.
+constexpr int GRAPH_KEY_ROWS = 8192;   // captured decode steps are keyed mode * GRAPH_KEY_ROWS + rows (run_step, drop_gen_graphs)
+
 struct DacBuffers {
     float *dbuf[3] = {nullptr, nullptr, nullptr};
     size_t dbuf_elems = 0;       // capacity of each buffer in floats
@@ -1202,7 +1204,7 @@ static int max_rows_for(const tts_hip_ctx *c) {
     // 1024 rows per forward: every GEMM of a Parler-Mini layer is a whole number of rounds of 128 x 128 (N = 4096, 3072) or 64 x 64 (N = 1024)
     // tiles over the 256 CUs; at 1152 rows the ninth row tile costs a second, nearly empty round (146 vs 101 us of GEMMs per layer,
     // profiles/r03/rows1152_classes.txt / rows1024_classes.txt).  TTS_HIP_MAX_ROWS raises or lowers the cap.
-    if (const char *e = getenv("TTS_HIP_MAX_ROWS")) return std::max(256, atoi(e));
+    if (const char *e = getenv("TTS_HIP_MAX_ROWS")) return std::min(GRAPH_KEY_ROWS - 1, std::max(256, atoi(e)));
     return 1024;
 }
 
@@ -2161,6 +2163,10 @@ extern "C" int tts_hip_parler_prefill_batch(tts_hip_ctx *c, uint32_t n, const ui
 }
 
 enum { MODE_LOGITS = 0, MODE_GREEDY = 1, MODE_GEN = 2, MODE_GEN_SAMPLE = 3 };
+// captured steps are keyed mode * GRAPH_KEY_ROWS + rows (rows <= TTS_HIP_MAX_ROWS, 1024 by default); drop_gen_graphs() recovers the mode from the
+// key — with the two sites out of step (keys in units of 8192, the drop in units of 1000) the generation graphs were never dropped and a
+// replay used whatever sampling parameters / tokens_out pointer its capture had baked in
+
 
 static int stage_step_inputs(tts_hip_ctx *c, uint32_t n, const uint32_t *ids, const uint32_t *pos, const uint32_t *seqs) {
     if (n == 0 || (int) n > c->RMAX || n > c->d.max_seqs) return set_err("step: n_seqs=%u outside 1..%u", n, std::min<uint32_t>(c->RMAX, c->d.max_seqs));
@@ -2224,7 +2230,7 @@ static int enqueue_step_body(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint
 static int run_step(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint32_t eos) {
     const bool use_graph = !(c->d.flags & TTS_HIP_FLAG_NO_GRAPH) && !c->prof;
     if (!use_graph) return enqueue_step_body(c, R, mode, bos, eos);
-    const int key = mode * 8192 + R;   // R <= TTS_HIP_MAX_ROWS (1024 by default)
+    const int key = mode * GRAPH_KEY_ROWS + R;
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -2266,7 +2272,8 @@ extern "C" int tts_hip_parler_step_greedy(tts_hip_ctx *c, uint32_t n, const uint
 
 static void drop_gen_graphs(tts_hip_ctx *c) {
     for (auto g = c->graphs.begin(); g != c->graphs.end();) {
-        if (g->first / 1000 == MODE_GEN || g->first / 1000 == MODE_GEN_SAMPLE) { (void) hipGraphExecDestroy(g->second); g = c->graphs.erase(g); } else ++g;
+        const int mode = g->first / GRAPH_KEY_ROWS;   // run_step's key
+        if (mode == MODE_GEN || mode == MODE_GEN_SAMPLE) { (void) hipGraphExecDestroy(g->second); g = c->graphs.erase(g); } else ++g;
     }
 }
 
