@@ -52,22 +52,24 @@ FAMILIES = {
     "attn_kernel (self-attention over the fp32 KV cache)": ["attn_self"],
     "attn_short_kernel (cross-attention over the voice prompt)": ["attn_cross"],
     "ln_rows_kernel (LayerNorm + split-K fold)": ["ln"],
-    "resunit_b3_kernel (DAC residual units at 96 / 192 channels, one launch each)": ["dac_resunit"],
-    "conv1d_mfma_b3_kernel / conv1d_mfma_kernel<7,...> (DAC k=7 convs of the wide classes)": ["dac_conv7"],
-    "conv1d_mfma_kernel<1,...> (DAC k=1 convs + residual of the wide classes)": ["dac_conv1"],
-    "convt_b3_kernel / convt1d_mfma_kernel (DAC transposed convs)": ["dac_convt"],
+    "resunit_t7_kernel (DAC residual units at 96 / 192 channels, one launch each)": ["dac_resunit"],
+    "conv_b3p_kernel<7,...> (DAC k=7 convs of the wide classes, split planes)": ["dac_conv7"],
+    "conv_b3p_kernel<1,...> + snake_split_kernel (DAC k=1 convs + residual of the wide classes)": ["dac_conv1"],
+    "convt_b3_kernel (DAC transposed convs)": ["dac_convt"],
     "other (embed, sampler/feed, DAC quantizer + final conv)": ["embed", "sample", "dac_embed", "dac_final"],
 }
 MFMA_FP16 = {"gemm_tile_kernel (decoder GEMMs: qkv, out_proj, cross q/out, fc1, fc2, heads)"}
-MFMA_FP32 = {"conv1d_mfma_kernel<1,...> (DAC k=1 convs + residual of the wide classes)"}
+MFMA_FP32 = {"conv_b3p_kernel<1,...> + snake_split_kernel (DAC k=1 convs + residual of the wide classes)"}
 # families that run fp32 convolutions as bf16 x 3 split products when the codec arithmetic is on (tts_hip_dac_arith): issued bf16 flops per
 # algorithmic flop = six products, and the k = 7 kernels pad their 7 taps to 8 k-slots
-B3_ISSUE = {"resunit_b3_kernel (DAC residual units at 96 / 192 channels, one launch each)": 6.0,     # resunit_t7_kernel: one tap per k-step, no padded slot
-            "conv1d_mfma_b3_kernel / conv1d_mfma_kernel<7,...> (DAC k=7 convs of the wide classes)": 6.0,   # conv_b3p_kernel, one tap per k-step: no padded slot
-            "convt_b3_kernel / convt1d_mfma_kernel (DAC transposed convs)": 6.0}
-B3_BIT = {"resunit_b3_kernel (DAC residual units at 96 / 192 channels, one launch each)": 2,
-          "conv1d_mfma_b3_kernel / conv1d_mfma_kernel<7,...> (DAC k=7 convs of the wide classes)": 1,
-          "convt_b3_kernel / convt1d_mfma_kernel (DAC transposed convs)": 4}
+B3_ISSUE = {"resunit_t7_kernel (DAC residual units at 96 / 192 channels, one launch each)": 6.0,     # resunit_t7_kernel: one tap per k-step, no padded slot
+            "conv_b3p_kernel<7,...> (DAC k=7 convs of the wide classes, split planes)": 6.0,   # conv_b3p_kernel, one tap per k-step: no padded slot
+            "convt_b3_kernel (DAC transposed convs)": 6.0,
+            "conv_b3p_kernel<1,...> + snake_split_kernel (DAC k=1 convs + residual of the wide classes)": 6.0}
+B3_BIT = {"conv_b3p_kernel<1,...> + snake_split_kernel (DAC k=1 convs + residual of the wide classes)": 32,
+          "resunit_t7_kernel (DAC residual units at 96 / 192 channels, one launch each)": 2,
+          "conv_b3p_kernel<7,...> (DAC k=7 convs of the wide classes, split planes)": 1,
+          "convt_b3_kernel (DAC transposed convs)": 4}
 
 
 def log(*a):
@@ -114,7 +116,7 @@ def pmc_traffic(family, args, n_audio, arith=0):
     if key.startswith("dac_"):  # DAC launches depend only on the utterances per codec pass and the frame count
         if args.dac_wtype != "f32" or w.get("audio_steps") != n_audio or w.get("dac_group") != int(os.environ.get("TTS_HIP_DAC_GROUP", "64")):
             return None
-        if w.get("codec_arith", 0) != arith:   # measured with other codec kernels than the ones this run used
+        if w.get("codec_arith", 0) != (arith & 31):   # measured with other codec kernels than the ones this run used
             return None
     elif w.get("batch") != args.batch or w.get("audio_steps") != n_audio:
         return None
@@ -124,7 +126,7 @@ def pmc_traffic(family, args, n_audio, arith=0):
 
 _TAIL = "f32 accumulate and residual stream; KV cache f32; DAC codec f32 (exact-f32 MFMA)"
 _B3 = ("DAC codec: F32 tensors, every fp32 operand carried as three bf16 terms and every product as six v_mfma_f32_32x32x16_bf16 partial products "
-       "with fp32 accumulation (fp32-level error, the suite's fp32 tolerances); the k=1 convs of the 768 / 384-channel classes and the final conv on exact-f32 MFMA / VALU")
+       "with fp32 accumulation (fp32-level error, the suite's fp32 tolerances); the one-channel final conv on fp32 VALU")
 DTYPE_DETAIL = {
     "f16": "decoder: f16 weights, f16 MFMA inputs, " + _TAIL,
     "f32": "decoder: f32 weights and activations (exact-f32 MFMA), " + _TAIL,

@@ -416,7 +416,8 @@ typedef struct tts_hip_kstat {
     double   bytes_total;   /* ALGORITHMIC bytes (weights + activations + cache rows each launch must touch) */
     double   flops_total;   /* Arithmetic of the codec convolutions of this context (bench.py prices each kernel family against the pipe it runs on): bit 0 = the
  * k = 7 convs of the wide classes as bf16 x 3 split products (TTS_HIP_DAC_BF16X3), bit 1 = residual units of 96 / 192 channels as one
- * launch, bf16 x 3 (TTS_HIP_DAC_FUSE), bit 2 = transposed convs as bf16 x 3 (TTS_HIP_DAC_CONVT_B3); 8 = F16 tensors (fp16 im2col, fp16
+ * launch, bf16 x 3 (TTS_HIP_DAC_FUSE), bit 2 = transposed convs as bf16 x 3 (TTS_HIP_DAC_CONVT_B3), bit 5 (32) = the wide classes keep their activations as bf16 x 3 split planes, so
+ * their k = 1 convs are bf16 x 3 products too (TTS_HIP_DAC_PLANES; otherwise exact-fp32 MFMA); 8 = F16 tensors (fp16 im2col, fp16
  * MFMA); 16 = scalar-FMA cross-check kernels; 0 = exact-fp32 MFMA throughout or no codec. */
 int tts_hip_dac_arith(tts_hip_ctx *ctx);
 /* algorithmic flops */
