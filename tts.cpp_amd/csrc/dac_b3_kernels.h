@@ -826,13 +826,23 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
     // a lane holds the S consecutive outputs to = ti S - p .. ti S - p + S - 1 of every channel it owns: stored as wide as the alignment allows
     const int ti = ti0 + wn * 32 + l31;
     const int tob = ti * S - a.pad;
+    // the lane's biases first, as 16-byte loads (one per quad of channels): a scalar load per value sat in front of every store group
+    float4d b4[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int cq = co0 + i * 32 + 8 * q + 4 * hi;   // a multiple of 4; cout is a multiple of 8
+            b4[i][q] = (float4d){0.f, 0.f, 0.f, 0.f};
+            if (a.b) b4[i][q] = *(const float4d *) (a.b + (cq < a.cout ? cq : 0));
+        }
 #pragma unroll
     for (int i = 0; i < MI; i++) {
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int co = co0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
             if (co >= a.cout) continue;
-            const float bias = a.b ? a.b[co] : 0.0f;
+            const float bias = b4[i][e >> 2][e & 3];
             float *row = yg + (int64_t) co * LoS;
             if ((S % 4) == 0 && (a.pad % 4) == 0 && (LoS % 4) == 0) {
 #pragma unroll

@@ -779,6 +779,8 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {   // U = 8 is 
 // spends its time in workgroup merges and idle key groups there (18 us per layer at 384 rows).  One wave per (row, head):
 // lane = channel of the 64-wide head, every K / V row is one coalesced 256-B load, the score of a key is a wave reduction,
 // softmax runs redundantly in every lane (no LDS, no barrier).  Same mathematics as soft_max_ext + mul_mat (model.cpp:586-593).
+// (Keeping a head's K / V in registers for 8 consecutive rows of a 1024-row forward — an eighth of the L2 reads — measured slower, 18.3 -> 22.6 us per
+// launch: a row is ~2 us of dependent cross-lane reductions and wants its own wave, profiles/r03/attn_short_rows_rejected.txt.)
 __global__ __launch_bounds__(256) void attn_short_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), r = blockIdx.y;
