@@ -781,35 +781,46 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {   // U = 8 is 
 // softmax runs redundantly in every lane (no LDS, no barrier).  Same mathematics as soft_max_ext + mul_mat (model.cpp:586-593).
 // (Keeping a head's K / V in registers for 8 consecutive rows of a 1024-row forward — an eighth of the L2 reads — measured slower, 18.3 -> 22.6 us per
 // launch: a row is ~2 us of dependent cross-lane reductions and wants its own wave, profiles/r03/attn_short_rows_rejected.txt.)
-__global__ __launch_bounds__(256) void attn_short_kernel(AttnArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), r = blockIdx.y;
-    if (h >= a.n_heads) return;
-    B1_STAMP(a.stamps, 0);
-    const int T = a.T_fixed;
+// TN = the prompt length rounded up to 8 / 16 / 32 (compile time): the K / V rows and the scores live in registers, TN loads per array
+template <int TN>
+__device__ __forceinline__ void attn_short_body(const AttnArgs &a, int r, int h, int lane, int T) {
     const int64_t hb = h * 64 + lane;
     const float qv = a.q[(int64_t) r * a.H + hb];
-    float kv[32], vv[32], sc[32];
+    float kv[TN], vv[TN], sc[TN];
     const float *kc = (const float *) a.kc, *vc = (const float *) a.vc;   // the cross K / V are fp32 (compute_cross_kv); the launcher refuses kv_f16
 #pragma unroll
-    for (int t = 0; t < 32; t++) {   // K and V rows requested together, straight-line: one round trip (a position beyond T re-reads the last row)
+    for (int t = 0; t < TN; t++) {   // K and V rows requested together, straight-line: one round trip (a position beyond T re-reads the last row)
         const int64_t off = hb + (int64_t) min(t, T - 1) * a.H;
         kv[t] = kc[off];
         vv[t] = vc[off];
     }
     float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 32; t++)
+    for (int t = 0; t < TN; t++)
         if (t < T) { sc[t] = wave_sum(qv * kv[t]) * a.scale; m = fmaxf(m, sc[t]); }
     float l = 0.0f, o = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 32; t++)
+    for (int t = 0; t < TN; t++)
         if (t < T) { const float p = expf(sc[t] - m); l += p; o += p * vv[t]; }
     const float res = o / l;
     if (a.out16) a.out16[(int64_t) r * a.H + hb] = (_Float16) res;
     else a.out[(int64_t) r * a.H + hb] = res;
+}
+__global__ __launch_bounds__(256) void attn_short_kernel(AttnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), r = blockIdx.y;
+    if (h >= a.n_heads) return;
+    B1_STAMP(a.stamps, 0);
+    const int T = a.T_fixed;
+    if (T <= 8) attn_short_body<8>(a, r, h, lane, T);
+    else if (T <= 16) attn_short_body<16>(a, r, h, lane, T);
+    else attn_short_body<32>(a, r, h, lane, T);
     B1_STAMP(a.stamps, 3);
 }
+
+// (A second lane layout — key = lane / 4, a quarter of the head's channels per lane: all scores from 16 FMAs and two quad steps, 14 cross-lane steps
+// per row instead of six per key — measured 14.8 us per launch at 1024 rows against 13.7 for this kernel with its compile-time prompt bound:
+// the launch is bound by the latency of its loads, not by the reductions; profiles/r03/attn_short16_rejected.txt.)
 
 __global__ void attn_combine_kernel(const float *part, int nz, int H, int n_heads, float *out, _Float16 *out16) {
     const int h = blockIdx.x, r = blockIdx.y, c = threadIdx.x;  // 64 threads; nz <= 16
