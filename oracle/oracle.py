@@ -92,7 +92,7 @@ class DiaModel(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("enc_H", "enc_L", "enc_heads", "enc_F", "dec_H", "dec_L", "dec_heads", "dec_kv_heads", "dec_F",
                                           "head_dim", "n_out", "V", "max_ctx", "max_gen", "act_mode")] + [
         ("cfg_scale", C.c_float), ("enc_embd", W), ("enc_norm", fp), ("dec_norm", fp), ("dec_embd", W * MAX_HEADS), ("heads", W * MAX_HEADS),
-        ("enc", DiaEncLayer * MAX_LAYERS), ("dec", DiaDecLayer * MAX_LAYERS)]
+        ("enc", DiaEncLayer * MAX_LAYERS), ("dec", DiaDecLayer * MAX_LAYERS), ("no_cross_rope", C.c_int32)]
 
 
 class SnacRes(C.Structure):
@@ -610,7 +610,8 @@ def dia_tokenize(sentence, max_ctx):
 class DiaOracle:
     """Oracle twin of a tts_cpp_amd.synth.SynthDia (src/models/dia/model.cpp restated in tts_oracle.c)."""
 
-    def __init__(self, model, act_mode=1, cfg_scale=3.0):
+    def __init__(self, model, act_mode=1, cfg_scale=3.0, cross_rope=True):
+        """cross_rope=False: no rope in cross-attention (Hugging Face's DiaModel; the reference ropes the cross query and keys, tts_oracle.h)"""
         self.L = lib()
         L = self.L
         L.orc_dia_state_new.restype = C.c_void_p
@@ -656,6 +657,7 @@ class DiaOracle:
             y.cq, y.ck, y.cv, y.co = w(p + "cross_q_proj"), w(p + "cross_k_proj"), w(p + "cross_v_proj"), w(p + "cross_o_proj")
             y.gate, y.up, y.out = w(p + "gate"), w(p + "up"), w(p + "wo")
             y.sa_norm, y.ca_norm, y.mlp_norm = f(p + "pre_sa_norm"), f(p + "pre_ca_norm"), f(p + "pre_mlp_norm")
+        m.no_cross_rope = 0 if cross_rope else 1
         self.m = m
         self.state = L.orc_dia_state_new(C.byref(m))
         self.delay = np.array(DIA_DELAY_PATTERN[:cfg.n_out], dtype=np.uint32)

@@ -1183,7 +1183,7 @@ void orc_dia_encode(const orc_dia_model *m, orc_dia_state *s, const uint32_t *to
         for (int b = 0; b < 2; b++)
             for (int t = 0; t < sentence_len; t++) {
                 float *row = kk + ((size_t) b * S + t) * DA;
-                neox_rope(row, m->dec_heads, hd, (uint32_t) t, NULL, 10000.0f);
+                if (!m->no_cross_rope) neox_rope(row, m->dec_heads, hd, (uint32_t) t, NULL, 10000.0f);
                 memcpy(ck + ((size_t) b * S + t) * DA, row, (size_t) DA * 4);
             }
         orc_mul_mat(ly->cv.type, ly->cv.data, H, DA, cur, n, cv, m->act_mode);
@@ -1228,7 +1228,7 @@ void orc_dia_step(const orc_dia_model *m, orc_dia_state *s, const uint32_t *ids,
         orc_mul_mat(ly->cq.type, ly->cq.data, H, A, cur, n, q, m->act_mode);
         for (int b = 0; b < n; b++) {
             const float *ck = s->ck + ((size_t) l * 2 + b) * S * A, *cv = s->cv + ((size_t) l * 2 + b) * S * A;
-            neox_rope(q + (size_t) b * A, NH, hd, pos, NULL, 10000.0f);
+            if (!m->no_cross_rope) neox_rope(q + (size_t) b * A, NH, hd, pos, NULL, 10000.0f);
             dia_attend(q + (size_t) b * A, ck, cv, S, A, NH, 1, hd, NULL, att + (size_t) b * A, sc);
         }
         orc_mul_mat(ly->co.type, ly->co.data, A, H, att, n, tmp, m->act_mode);

@@ -14,6 +14,8 @@ tests/test_upstream_golden.py feeds those tensors to the oracle and compares.
   dac               transformers DacModel decoder + residual VQ from_codes        dac_gguf_encoder.py:7-35 (names), :43-110; weight norm folded by the
                                                                                   reference's own tensor_util.get_regularized_weight (imported from
                                                                                   /root/reference/py-gguf/tts_encoders/tensor_util.py, torch only)
+  dia               transformers DiaForConditionalGeneration (encoder, decoder,  dia_gguf_encoder.py:74-129
+                    logits_dense)
   parler decoder    transformers MusicgenForCausalLM (Parler-TTS' decoder is a    parler_tts_gguf_encoder.py:112-130
                     fork of it: same modules and parameter names; parler_tts
                     itself is not installed here)
@@ -25,6 +27,9 @@ fixtures (the tests assert them):
     and for a 24-token input both HF's own output and HF's output with the reference's bucket formula patched in.
   * GELU: the reference evaluates tanh-GELU (ggml_gelu) where Parler-TTS' config asks for erf-GELU; the Musicgen twin is configured with
     gelu_pytorch_tanh so that the comparison isolates everything else, and the erf variant's distance is recorded.
+  * Dia cross-attention: the reference ropes the cross-attention query (decoder position, dia/model.cpp:606) and keys (encoder position, :489) —
+    what the `dia` package its converter imports did; transformers' DiaCrossAttention applies no rope.  The oracle has a switch for it
+    (orc_dia_model.no_cross_rope): with the switch it equals transformers to 2e-5, without it (the reference's graph) it does not.
   * snake: HF's Snake1d divides by (alpha + 1e-9), snake_1d (src/util.cpp:96-101) by alpha: 1e-9 relative, below fp32 resolution.
 Run:  python tests/golden/make_upstream_golden.py        (writes tests/golden/upstream_*.npz)
 """
@@ -343,8 +348,86 @@ def make_parler():
          cfg=np.array([H, L, HEADS, F, V, NCB, ENC, PV]), **{"t:" + k: v for k, v in tensors.items()})
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+def make_dia():
+    """transformers DiaForConditionalGeneration (encoder, decoder, logits_dense) at tiny dims (2 + 2 layers, 2 query heads on 1 k/v group in the decoder), float64.
+    Both encoder streams of the reference's classifier-free-guidance batch (the text, all zeros) with NO padding (sentence length =
+    max_context_length): there the reference's block mask (model.cpp:712-721) and upstream's padding mask are both "everything sees
+    everything".  The decoder is run teacher-forced over T steps (causal mask = the incremental cache path), both streams with the same ids."""
+    from transformers import DiaConfig, DiaDecoderConfig, DiaEncoderConfig, DiaForConditionalGeneration
+
+    torch.manual_seed(1007)
+    # head size 64 keeps the fixture at ~1.5 MB; the graph is the same at 128 (tiny_dia.npz and the GPU tests run the device's 128)
+    EH, EL, ENH, EF, DH, DL, DNH, DKV, DF, HD, NO, AV, S, G = 64, 2, 2, 128, 128, 2, 2, 1, 192, 64, 9, 48, 24, 48
+    V = AV + 4
+    enc = DiaEncoderConfig(max_position_embeddings=S, num_hidden_layers=EL, hidden_size=EH, num_attention_heads=ENH, num_key_value_heads=ENH, head_dim=HD,
+                           intermediate_size=EF, norm_eps=1e-5, vocab_size=256, hidden_act="silu")
+    dec = DiaDecoderConfig(max_position_embeddings=G, num_hidden_layers=DL, hidden_size=DH, intermediate_size=DF, num_attention_heads=DNH,
+                           num_key_value_heads=DKV, head_dim=HD, cross_num_attention_heads=DNH, cross_head_dim=HD, cross_num_key_value_heads=DNH,
+                           cross_hidden_size=EH, norm_eps=1e-5, vocab_size=V, hidden_act="silu", num_channels=NO,
+                           pad_token_id=AV + 1, eos_token_id=AV, bos_token_id=AV + 2)
+    cfg = DiaConfig(encoder_config=enc, decoder_config=dec, pad_token_id=AV + 1, eos_token_id=AV, bos_token_id=AV + 2,
+                    delay_pattern=[0, 8, 9, 10, 11, 12, 13, 14, 15])
+    model = DiaForConditionalGeneration(cfg).double().eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "norm" in n:                                  # away from 1: their placement matters
+                p.copy_(1.0 + 0.1 * torch.randn_like(p))
+            elif "embed" in n:
+                p.copy_(0.5 * torch.randn_like(p))
+            elif "q_proj" in n or "k_proj" in n:             # attention logits are not scaled by 1/sqrt(d) in Dia: keep the softmax soft
+                p.copy_(0.35 / math.sqrt(p.shape[1]) * torch.randn_like(p))
+            else:
+                p.copy_(torch.randn_like(p) / math.sqrt(p.shape[1]))
+        for p in model.parameters():                         # the converter exports fp32: upstream runs on the fp32-rounded weights, in float64
+            p.copy_(p.to(torch.float32).to(torch.float64))
+    sd = {k: npy(v).astype(np.float32) for k, v in model.state_dict().items()}
+    t = {}
+    # dia_gguf_encoder.py:108-129 (encoder), :74-106 (decoder).  The converter reads the `dia` package's DenseGeneral tensors [in, heads, head_dim]
+    # and writes reshape(in, -1).T = [heads * head_dim][in]: exactly a torch Linear weight, which is what the transformers port stores.
+    t["dia.encoder.embedding"] = sd["model.encoder.embedding.weight"]
+    t["dia.encoder.norm"] = sd["model.encoder.norm.weight"]
+    for l in range(EL):
+        a, b = f"model.encoder.layers.{l}.", f"dia.encoder.layers.{l}."
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            t[b + n] = sd[a + f"self_attention.{n}.weight"]
+        t[b + "pre_sa_norm"], t[b + "post_sa_norm"] = sd[a + "pre_sa_norm.weight"], sd[a + "post_sa_norm.weight"]
+        gu = sd[a + "mlp.gate_up_proj.weight"]              # wi_fused[:, 0] = gate, [:, 1] = up (:116-121); the port chunks the output the same way
+        t[b + "gate"], t[b + "up"], t[b + "wo"] = gu[:EF], gu[EF:], sd[a + "mlp.down_proj.weight"]
+    emb = sd["model.decoder.embeddings.embed.weight"]       # one table with per-channel offsets = the package's nine embeddings stacked
+    for i in range(NO):
+        t[f"dia.decoder.embeddings.{i}"] = emb[i * V:(i + 1) * V]
+        t[f"dia.decoder.heads.{i}"] = sd["logits_dense.weight"][i * V:(i + 1) * V]     # logits_dense[:, i].T (:83-87)
+    t["dia.decoder.norm"] = sd["model.decoder.norm.weight"]
+    for l in range(DL):
+        a, b = f"model.decoder.layers.{l}.", f"dia.decoder.layers.{l}."
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            t[b + "self_" + n] = sd[a + f"self_attention.{n}.weight"]
+            t[b + "cross_" + n] = sd[a + f"cross_attention.{n}.weight"]
+        for n in ("pre_sa_norm", "pre_ca_norm", "pre_mlp_norm"):
+            t[b + n] = sd[a + n + ".weight"]
+        gu = sd[a + "mlp.gate_up_proj.weight"]
+        t[b + "gate"], t[b + "up"], t[b + "wo"] = gu[:DF], gu[DF:], sd[a + "mlp.down_proj.weight"]
+
+    rng = np.random.default_rng(11)
+    text = rng.integers(1, 256, S)                           # S byte tokens, none of them the pad id 0
+    T = 20
+    ids = rng.integers(0, AV, (T, NO))
+    ids[0, :] = AV + 2                                       # step 0: bos on every channel (model.cpp:724-726 feeds both streams the same ids)
+    with torch.no_grad():
+        enc_in = torch.tensor(np.stack([text, np.zeros(S, dtype=np.int64)]))
+        enc_out = model.model.encoder(input_ids=enc_in, attention_mask=torch.ones(2, S, dtype=torch.long)).last_hidden_state
+        dec_in = torch.tensor(np.stack([ids, ids]))
+        dec_out = model.model.decoder(input_ids=dec_in, encoder_hidden_states=enc_out,
+                                      encoder_attention_mask=torch.ones(2, S, dtype=torch.long)).last_hidden_state
+        raw = model.logits_dense(dec_out).view(2, T, NO, V)
+    save("upstream_dia.npz", text=text.astype(np.uint32), ids=ids.astype(np.uint32), enc_out=npy(enc_out), raw_logits=npy(raw).transpose(1, 0, 2, 3),
+         cfg=np.array([EH, EL, ENH, EF, DH, DL, DNH, DNH // DKV, DF, HD, NO, AV, S, G]), **{"t:" + k: v for k, v in t.items()})
+    print("dia: encoder", tuple(enc_out.shape), "raw logits", tuple(raw.shape), "max |logit|", float(raw.abs().max()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["orpheus", "t5", "dac", "dac_b3", "parler"]
+    which = sys.argv[1:] or ["orpheus", "t5", "dac", "dac_b3", "parler", "dia"]
     for w in which:
-        {"orpheus": make_orpheus, "t5": make_t5, "dac": make_dac, "parler": make_parler,
+        {"orpheus": make_orpheus, "t5": make_t5, "dac": make_dac, "parler": make_parler, "dia": make_dia,
          "dac_b3": lambda: make_dac("upstream_dac_b3.npz", hidden=192, strides=(2, 2), seed=1005, frames=300)}[w]()

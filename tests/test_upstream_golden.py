@@ -112,3 +112,37 @@ def test_parler_decoder_against_transformers_musicgen():
         assert rel(logits[:, 0, :], z["logits_audio_only_api"][:, t, :]) < 2e-5, f"api step {t}"
     # the erf-GELU Parler-TTS' config names is a different function from the tanh-GELU the reference evaluates (ggml_gelu): recorded distance
     assert 1e-5 < rel(z["logits_erf_gelu"], z["logits"]) < 1e-2
+
+
+def test_dia_against_transformers_dia():
+    """DiaForConditionalGeneration: both encoder streams of the guidance batch, 20 teacher-forced decoder steps (dia/model.cpp:337-659;
+    dia_gguf_encoder.py:74-129).  transformers' cross-attention applies no rope, the reference ropes the cross query and keys: with the oracle's
+    switch for that (orc_dia_model.no_cross_rope) everything else — RMS norms, unscaled attention, NEOX rope on the self-attention, grouped k / v
+    heads, the fused gate / up split, the summed codebook embeddings, the nine heads — equals upstream; without it the oracle is the reference."""
+    z, by_name = load("upstream_dia.npz")
+    EH, EL, ENH, EF, DH, DL, DNH, REP, DF, HD, NO, AV, S, G = (int(x) for x in z["cfg"])
+    cfg = synth.DiaConfig(enc_hidden=EH, enc_layers=EL, enc_heads=ENH, enc_ffn=EF, dec_hidden=DH, dec_layers=DL, dec_heads=DNH, dec_repeat=REP,
+                          dec_ffn=DF, head_dim=HD, n_out=NO, audio_vocab=AV, max_ctx=S, max_gen=G, weight_type=gguf.F32)
+    assert cfg.out_vocab == z["raw_logits"].shape[-1]
+    model = types.SimpleNamespace(cfg=cfg, by_name=by_name)
+    text, ids = z["text"], z["ids"]
+
+    def run(cross_rope):
+        o = orc.DiaOracle(model, act_mode=0, cross_rope=cross_rope)
+        enc = o.encode(text, S, want_states=True)
+        raw = np.stack([o.step(ids[s], s, want_raw=True)[1] for s in range(ids.shape[0])])
+        return enc, raw
+
+    enc, raw = run(cross_rope=False)
+    assert rel(enc, z["enc_out"]) < 2e-5, "encoder states, both streams"
+    assert rel(raw, z["raw_logits"]) < 2e-5, "conditional / unconditional logits of every step and head"
+    assert np.array_equal(raw.argmax(-1), z["raw_logits"].argmax(-1))
+    # the reference's own graph (rope in cross-attention): same encoder, different logits — an intentional divergence from the transformers port
+    enc_ref, raw_ref = run(cross_rope=True)
+    assert np.array_equal(enc_ref, enc)
+    assert rel(raw_ref, z["raw_logits"]) > 1e-3
+    # classifier-free guidance as the reference combines it (util.cpp:194-196): cond + scale * (cond - uncond)
+    o = orc.DiaOracle(model, act_mode=0, cfg_scale=3.0, cross_rope=False)
+    o.encode(text, S)
+    lg, r = o.step(ids[0], 0, want_raw=True)
+    assert np.allclose(lg, r[0] + 3.0 * (r[0] - r[1]), rtol=0, atol=1e-5)
