@@ -1,9 +1,13 @@
 """Pure-Python restatement of the reference's unigram tokenizer (TEST INFRASTRUCTURE ONLY).
 
 Follows /root/reference/src/tokenizer.cpp:49-127 statement by statement (trie walk, utf-8 step logic,
-unknown handling, backwards walk with the result-reference quirk), small inputs only.  "parity
-unpinned": tokenizer.cpp cannot be compiled here (it includes ggml headers through util.h), so this
-restatement is checked by inspection against the source and used to pin the C++ host tokenizer.
+unknown handling, backwards walk with the result-reference quirk), small inputs only.  tokenizer.cpp
+cannot be compiled here (it includes ggml headers through util.h); the restatement is pinned instead to
+the implementation the reference's converter reads the vocabulary FROM — Hugging Face `tokenizers`:
+`models.Unigram` behind T5's pre-tokenizer for UnigramOracle (tests/golden/upstream_unigram.npz: 43 sentences
+with doubled spaces and characters outside the vocabulary, identical ids), `models.BPE` with the byte-level
+pre-tokenizer for BpeOracle (upstream_bpe.npz; a doubled space is the one stated divergence) —
+tests/test_upstream_golden.py — and is what pins the C++ host tokenizers (tests/test_host_cpu.py).
 """
 import math
 import re

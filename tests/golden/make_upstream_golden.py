@@ -16,6 +16,8 @@ tests/test_upstream_golden.py feeds those tensors to the oracle and compares.
                                                                                   /root/reference/py-gguf/tts_encoders/tensor_util.py, torch only)
   dia               transformers DiaForConditionalGeneration (encoder, decoder,  dia_gguf_encoder.py:74-129
                     logits_dense)
+  prompt tokenizer  tokenizers.models.Unigram behind T5's pre-tokenizer           parler_tts_gguf_encoder.py:187-202
+  orpheus tokenizer tokenizers.models.BPE, byte-level                             orpheus_gguf_encoder.py:231-242
   parler decoder    transformers MusicgenForCausalLM (Parler-TTS' decoder is a    parler_tts_gguf_encoder.py:112-130
                     fork of it: same modules and parameter names; parler_tts
                     itself is not installed here)
@@ -30,6 +32,8 @@ fixtures (the tests assert them):
   * Dia cross-attention: the reference ropes the cross-attention query (decoder position, dia/model.cpp:606) and keys (encoder position, :489) —
     what the `dia` package its converter imports did; transformers' DiaCrossAttention applies no rope.  The oracle has a switch for it
     (orc_dia_model.no_cross_rope): with the switch it equals transformers to 2e-5, without it (the reference's graph) it does not.
+  * BPE prompts with doubled spaces: upstream emits the extra space as its own token, the reference drops it (tokenizer.cpp:209-296 splits at
+    spaces and discards empty pieces).
   * snake: HF's Snake1d divides by (alpha + 1e-9), snake_1d (src/util.cpp:96-101) by alpha: 1e-9 relative, below fp32 resolution.
 Run:  python tests/golden/make_upstream_golden.py        (writes tests/golden/upstream_*.npz)
 """
@@ -426,8 +430,88 @@ def make_dia():
     print("dia: encoder", tuple(enc_out.shape), "raw logits", tuple(raw.shape), "max |logit|", float(raw.abs().max()))
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+def make_unigram():
+    """The prompt tokenizer.  parler_tts_gguf_encoder.py:187-202 converts FROM a Hugging Face `tokenizers` Unigram model (the T5 fast
+    tokenizer of the Parler-TTS repositories): pieces with U+2581 replaced by a space, scores from the tokenizer's JSON, unk / eos ids.  The twin
+    here is a seeded 300-piece Unigram model behind T5's pre-tokenizer (WhitespaceSplit + Metaspace, prefix space always); its ids for a set of
+    sentences are the fixture, the vocabulary is exported by the converter's rules."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+
+    rng = np.random.default_rng(5)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    sp = "\u2581"
+    vocab = [("<pad>", 0.0), ("</s>", 0.0), ("<unk>", 0.0), (sp, -2.5)]
+    vocab += [(ch, float(-4 - 3 * rng.random())) for ch in letters] + [(sp + ch, float(-3.5 - 3 * rng.random())) for ch in letters]
+    seen = {p for p, _ in vocab}
+    while len(vocab) < 300:
+        w = "".join(rng.choice(list(letters), int(rng.integers(2, 6))))
+        if rng.random() < 0.5:
+            w = sp + w
+        if w not in seen:
+            seen.add(w)
+            vocab.append((w, float(-5 - 6 * rng.random())))
+    tok = Tokenizer(models.Unigram(vocab, unk_id=2, byte_fallback=False))
+    tok.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.WhitespaceSplit(), pre_tokenizers.Metaspace(replacement=sp, prepend_scheme="always")])
+    pieces = [p for p, _ in vocab]
+    texts = []
+    for i in range(40):                                  # words biased towards the multi-letter pieces so that the segmentation has choices
+        words = []
+        for _ in range(int(rng.integers(1, 9))):
+            w = ""
+            while len(w) < int(rng.integers(1, 10)):
+                w += (pieces[int(rng.integers(4, 300))].replace(sp, "") if rng.random() < 0.6 else letters[int(rng.integers(0, 26))])
+            words.append(w)
+        texts.append((" " if i % 5 else "  ").join(words))    # every fifth sentence with doubled spaces (the reference collapses them, tokenizer.h:22)
+    texts += ["a?b", "zz!!zz", "caf\u00e9 ab"]            # characters outside the vocabulary: <unk>, consecutive ones fused
+    ids = [tok.encode(t).ids for t in texts]
+    flat = np.array([x for row in ids for x in row], dtype=np.uint32)
+    save("upstream_unigram.npz", pieces=np.array([p.replace(sp, " ") for p in pieces]),      # :193-194
+         scores=np.array([sc for _, sc in vocab], dtype=np.float32), unk=np.array(2), eos=np.array(1),   # :195-200
+         texts=np.array(texts), ids_flat=flat, ids_len=np.array([len(r) for r in ids], dtype=np.int64))
+    print("unigram:", len(texts), "sentences,", flat.size, "ids; e.g.", texts[0], "->", tok.encode(texts[0]).tokens)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def make_bpe():
+    """Orpheus' prompt tokenizer.  orpheus_gguf_encoder.py:231-242 copies `model.vocab` (in id order) and `model.merges` out of a Hugging Face
+    byte-level BPE tokenizer.json.  The twin: a 400-token byte-level BPE trained by `tokenizers` on seeded pseudo-words; its ids for sentences
+    of letters and single spaces are the fixture.  (The reference cuts a prompt at spaces only, tokenizer.cpp:209-296, where Llama-3's
+    pre-tokenizer regex also cuts at digits and punctuation: sentences with those are outside what the two share.)"""
+    import json
+
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
+
+    rng = np.random.default_rng(9)
+    syll = ["ka", "to", "mi", "re", "sun", "lo", "ve", "da", "ri", "no", "ta", "shi", "be", "qu", "zo", "el", "an", "ing", "er", "st"]
+
+    def word():
+        return "".join(syll[int(rng.integers(0, len(syll)))] for _ in range(int(rng.integers(1, 5))))
+
+    corpus = [" ".join(word() for _ in range(int(rng.integers(3, 12)))) for _ in range(400)]
+    tok = Tokenizer(models.BPE())
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=True)
+    tok.decoder = decoders.ByteLevel()
+    tok.train_from_iterator(corpus, trainers.BpeTrainer(vocab_size=400, initial_alphabet=pre_tokenizers.ByteLevel.alphabet(), show_progress=False))
+    model = json.loads(tok.to_str())["model"]
+    tokens = list(model["vocab"].keys())                                            # :238
+    assert [model["vocab"][t] for t in tokens] == list(range(len(tokens)))
+    merges = [" ".join(pair) if not isinstance(pair, str) else pair for pair in model["merges"]]   # :240
+    texts = [" ".join(word() for _ in range(int(rng.integers(1, 10)))) for _ in range(40)]
+    texts += ["k", "zzzz qqq"]                       # a single byte, letters the merges never saw together
+    ids = [tok.encode(t).ids for t in texts]
+    flat = np.array([x for row in ids for x in row], dtype=np.uint32)
+    # a doubled space: upstream keeps the first space as a token of its own ("Ġ"), the reference's split drops empty pieces — a divergence of the
+    # reference, stored with upstream's ids so that the test can state it
+    dbl = "sunlo  vedari"
+    save("upstream_bpe.npz", tokens=np.array(tokens), merges=np.array(merges), texts=np.array(texts), ids_flat=flat,
+         ids_len=np.array([len(r) for r in ids], dtype=np.int64), doubled_space_text=np.array(dbl),
+         doubled_space_ids=np.array(tok.encode(dbl).ids, dtype=np.uint32), space_id=np.array(tok.token_to_id("\u0120")))
+    print("bpe:", len(tokens), "tokens,", len(merges), "merges; e.g.", texts[0], "->", tok.encode(texts[0]).tokens)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["orpheus", "t5", "dac", "dac_b3", "parler", "dia"]
+    which = sys.argv[1:] or ["orpheus", "t5", "dac", "dac_b3", "parler", "dia", "unigram", "bpe"]
     for w in which:
-        {"orpheus": make_orpheus, "t5": make_t5, "dac": make_dac, "parler": make_parler, "dia": make_dia,
+        {"orpheus": make_orpheus, "t5": make_t5, "dac": make_dac, "parler": make_parler, "dia": make_dia, "unigram": make_unigram, "bpe": make_bpe,
          "dac_b3": lambda: make_dac("upstream_dac_b3.npz", hidden=192, strides=(2, 2), seed=1005, frames=300)}[w]()

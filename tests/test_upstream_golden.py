@@ -146,3 +146,38 @@ def test_dia_against_transformers_dia():
     o.encode(text, S)
     lg, r = o.step(ids[0], 0, want_raw=True)
     assert np.allclose(lg, r[0] + 3.0 * (r[0] - r[1]), rtol=0, atol=1e-5)
+
+
+def test_unigram_tokenizer_against_hf_tokenizers():
+    """The reference's unigram tokenizer (src/tokenizer.cpp:49-127, restated in oracle/tokenizer_oracle.py and pinned to the C++ host tokenizer by
+    tests/test_host_cpu.py) against `tokenizers.models.Unigram` — the model its converter reads (parler_tts_gguf_encoder.py:187-202): Viterbi over
+    the same pieces and scores, prefix space, doubled spaces, characters outside the vocabulary."""
+    import tokenizer_oracle
+    z = np.load(os.path.join(GOLD, "upstream_unigram.npz"))
+    o = tokenizer_oracle.UnigramOracle([str(p) for p in z["pieces"]], z["scores"], int(z["unk"]), int(z["eos"]))
+    off = 0
+    n_multi = 0
+    for text, n in zip(z["texts"], z["ids_len"]):
+        want = z["ids_flat"][off:off + n].tolist()
+        off += n
+        assert o.tokenize(str(text)) == want, text
+        n_multi += sum(len(str(z["pieces"][i]).strip()) > 1 for i in want)
+    assert n_multi > 100, "the sentences must exercise multi-character pieces"
+
+
+def test_bpe_tokenizer_against_hf_tokenizers():
+    """The reference's byte-pair tokenizer (src/tokenizer.cpp:209-296, restated in oracle/tokenizer_oracle.py) against `tokenizers.models.BPE` with
+    the byte-level pre-tokenizer — the tokenizer.json its converter copies vocabulary and merges from (orpheus_gguf_encoder.py:231-242) — on
+    sentences of letters and spaces (the reference cuts at spaces only; Llama-3's regex also cuts at digits and punctuation)."""
+    import tokenizer_oracle
+    z = np.load(os.path.join(GOLD, "upstream_bpe.npz"))
+    o = tokenizer_oracle.BpeOracle([str(t) for t in z["tokens"]], [str(m) for m in z["merges"]])
+    off = 0
+    for text, n in zip(z["texts"], z["ids_len"]):
+        want = z["ids_flat"][off:off + n].tolist()
+        off += n
+        assert o.tokenize(str(text)) == want, text
+    # intentional divergence: a doubled space is one separator for the reference, a separator and a token for upstream
+    hf = z["doubled_space_ids"].tolist()
+    ours = o.tokenize(str(z["doubled_space_text"]))
+    assert ours != hf and ours == [t for t in hf if t != int(z["space_id"])]
