@@ -18,6 +18,7 @@ tests/test_upstream_golden.py feeds those tensors to the oracle and compares.
                     logits_dense)
   prompt tokenizer  tokenizers.models.Unigram behind T5's pre-tokenizer           parler_tts_gguf_encoder.py:187-202
   orpheus tokenizer tokenizers.models.BPE, byte-level                             orpheus_gguf_encoder.py:231-242
+  delay pattern     MusicgenForCausalLM.build / apply_delay_pattern_mask          (no converter rule: generation logic, model.cpp:734-785)
   parler decoder    transformers MusicgenForCausalLM (Parler-TTS' decoder is a    parler_tts_gguf_encoder.py:112-130
                     fork of it: same modules and parameter names; parler_tts
                     itself is not installed here)
@@ -34,6 +35,8 @@ fixtures (the tests assert them):
     (orc_dia_model.no_cross_rope): with the switch it equals transformers to 2e-5, without it (the reference's graph) it does not.
   * BPE prompts with doubled spaces: upstream emits the extra space as its own token, the reference drops it (tokenizer.cpp:209-296 splits at
     spaces and discards empty pieces).
+  * delay pattern at the END of a generation: upstream knows max_length in advance and feeds pad to codebook k for its last 8 - k positions; the
+    reference keeps feeding what it sampled (it stops on EOS / max_generation instead).  The frames both keep are the same.
   * snake: HF's Snake1d divides by (alpha + 1e-9), snake_1d (src/util.cpp:96-101) by alpha: 1e-9 relative, below fp32 resolution.
 Run:  python tests/golden/make_upstream_golden.py        (writes tests/golden/upstream_*.npz)
 """
@@ -510,8 +513,34 @@ def make_bpe():
     print("bpe:", len(tokens), "tokens,", len(merges), "merges; e.g.", texts[0], "->", tok.encode(texts[0]).tokens)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+def make_delay():
+    """The delay pattern of the nine codebooks and its undoing — index logic, so the comparison is exact.  Upstream:
+    MusicgenForCausalLM.build_delay_pattern_mask / apply_delay_pattern_mask (Parler-TTS inherits both) and generate()'s final
+    `output_ids[output_ids != pad]` reshape.  Reference: the ids fed per step (parler/model.cpp:778-785) and adjust_output_tokens (:734-760).
+    A seeded stream of "sampled" tokens stands for the model."""
+    from transformers import MusicgenDecoderConfig, MusicgenForCausalLM
+
+    K, AV = 9, 64
+    bos = AV + 2
+    cfg = MusicgenDecoderConfig(vocab_size=AV + 4, hidden_size=16, num_hidden_layers=1, ffn_dim=16, num_attention_heads=1, num_codebooks=K,
+                                max_position_embeddings=64, audio_channels=1, pad_token_id=bos, bos_token_id=bos, tie_word_embeddings=False)
+    m = MusicgenForCausalLM(cfg)
+    steps = 30
+    rng = np.random.default_rng(13)
+    samples = rng.integers(0, AV, (steps, K))                       # what the sampler returned after step s (1-based s = row s - 1)
+    start = torch.full((K, 1), bos, dtype=torch.long)
+    _, mask = m.build_delay_pattern_mask(start, pad_token_id=bos, max_length=steps + 1)
+    seq = torch.cat([start, torch.tensor(samples.T)], 1)            # position 0 = the bos column, position s = the sample of step s
+    fed = m.apply_delay_pattern_mask(seq, mask)                     # what generate() feeds back, position by position
+    frames = fed[fed != bos].reshape(K, -1)                         # generate()'s un-delay: drop every pad / bos
+    save("upstream_delay.npz", samples=samples.astype(np.uint32), fed=fed.numpy().T.astype(np.uint32), mask=mask.numpy().T.astype(np.int64),
+         frames=frames.numpy().T.astype(np.uint32), cfg=np.array([K, AV, bos, steps]))
+    print("delay:", tuple(fed.shape), "->", tuple(frames.shape))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["orpheus", "t5", "dac", "dac_b3", "parler", "dia", "unigram", "bpe"]
+    which = sys.argv[1:] or ["orpheus", "t5", "dac", "dac_b3", "parler", "dia", "unigram", "bpe", "delay"]
     for w in which:
-        {"orpheus": make_orpheus, "t5": make_t5, "dac": make_dac, "parler": make_parler, "dia": make_dia, "unigram": make_unigram, "bpe": make_bpe,
+        {"orpheus": make_orpheus, "t5": make_t5, "dac": make_dac, "parler": make_parler, "dia": make_dia, "unigram": make_unigram, "bpe": make_bpe, "delay": make_delay,
          "dac_b3": lambda: make_dac("upstream_dac_b3.npz", hidden=192, strides=(2, 2), seed=1005, frames=300)}[w]()

@@ -181,3 +181,30 @@ def test_bpe_tokenizer_against_hf_tokenizers():
     hf = z["doubled_space_ids"].tolist()
     ours = o.tokenize(str(z["doubled_space_text"]))
     assert ours != hf and ours == [t for t in hf if t != int(z["space_id"])]
+
+
+def test_delay_pattern_against_transformers_musicgen():
+    """Index logic, exact: the ids the reference feeds per step (parler/model.cpp:778-785, orc_parler_next_ids) and its un-delay
+    (adjust_output_tokens :734-760) against MusicgenForCausalLM.build_delay_pattern_mask / apply_delay_pattern_mask and generate()'s pad filter
+    (Parler-TTS inherits them) on one seeded stream of sampled tokens."""
+    z = np.load(os.path.join(GOLD, "upstream_delay.npz"))
+    K, AV, bos, steps = (int(x) for x in z["cfg"])
+    L = orc.lib()
+    samples, fed, mask = z["samples"], z["fed"], z["mask"]
+    seen = np.zeros(K, dtype=np.uint8)
+    tail = 0
+    for s in range(1, steps):                      # the ids fed AFTER step s = upstream's sequence position s
+        nxt = np.empty(K, dtype=np.uint32)
+        L.orc_parler_next_ids(K, s, orc.u32p(np.ascontiguousarray(samples[s - 1])), seen.ctypes.data_as(orc.C.POINTER(orc.C.c_uint8)), bos, AV, orc.u32p(nxt))
+        free = mask[s] == -1                       # positions upstream leaves to the model
+        head = np.arange(K) >= s                   # codebook k still delayed: both feed bos
+        assert np.array_equal(nxt[free], fed[s][free]) and np.array_equal(nxt[head], fed[s][head]) and (nxt[head] == bos).all()
+        # the divergence: upstream pads the tail of the low codebooks because it knows max_length, the reference feeds its samples
+        t = ~free & ~head
+        tail += int(t.sum())
+        assert (fed[s][t] == bos).all() and np.array_equal(nxt[t], samples[s - 1][t])
+    assert tail == sum(range(K)) - (K - 1), "the last K - 1 positions, minus the final one that is never fed"
+    flat = np.ascontiguousarray(samples.reshape(-1))
+    out = np.empty(flat.size, dtype=np.uint32)
+    n = L.orc_parler_adjust_output_tokens(orc.u32p(flat), flat.size, K, AV, AV, orc.u32p(out))
+    assert np.array_equal(out[:n].reshape(-1, K), z["frames"]) and n // K == steps - (K - 1)
