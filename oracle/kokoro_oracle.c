@@ -12,7 +12,9 @@
  * semantics of the module the reference converts from (hexgrad/Kokoro-82M, StyleTTS2 iSTFTNet): torch.stft / istft with
  * center = True and reflect padding, F.interpolate(mode = "linear", align_corners = False), ConvTranspose1d(groups = C,
  * output_padding = 1), nearest-neighbour 2x upsampling, roundf.  tests/golden/tiny_kokoro.npz (float64 torch) pins this file to
- * those definitions, not to ggml.
+ * those definitions, not to ggml.  The one part with an upstream implementation installed here is pinned to it: the ALBERT stage
+ * against transformers' AlbertModel (the class kokoro's `bert` is and the converter walks, kokoro_gguf_encoder.py:14-37, :274-287):
+ * 1.7e-7 on a 19-token input, tests/golden/upstream_albert.npz, tests/test_upstream_golden.py.
  *
  * Tensors are looked up by their GGUF names (py-gguf/tts_encoders/kokoro_gguf_encoder.py), all fp32. */
 #define _GNU_SOURCE
@@ -345,6 +347,7 @@ void orc_kokoro_durations(const orc_kokoro_model *m, const uint32_t *tokens, int
         }
     }
 #undef AL
+    kdump("albert", x, (size_t) n * H);   /* ORC_KOKORO_DUMP: the ALBERT output, compared with transformers' AlbertModel in tests/test_upstream_golden.py */
     /* prosody predictor (:1009-1041) */
     const float *enc_w = kt(m, "kokoro.duration_predictor.encode", ne);
     const int D = (int) ne[1];

@@ -19,6 +19,7 @@ tests/test_upstream_golden.py feeds those tensors to the oracle and compares.
   prompt tokenizer  tokenizers.models.Unigram behind T5's pre-tokenizer           parler_tts_gguf_encoder.py:187-202
   orpheus tokenizer tokenizers.models.BPE, byte-level                             orpheus_gguf_encoder.py:231-242
   delay pattern     MusicgenForCausalLM.build / apply_delay_pattern_mask          (no converter rule: generation logic, model.cpp:734-785)
+  kokoro albert     transformers AlbertModel (kokoro's `bert` is one)             kokoro_gguf_encoder.py:14-37, :274-287
   parler decoder    transformers MusicgenForCausalLM (Parler-TTS' decoder is a    parler_tts_gguf_encoder.py:112-130
                     fork of it: same modules and parameter names; parler_tts
                     itself is not installed here)
@@ -539,8 +540,60 @@ def make_delay():
     print("delay:", tuple(fed.shape), "->", tuple(frames.shape))
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+def make_albert():
+    """Kokoro's text model.  kokoro_gguf_encoder.py:274-287 walks `model.bert` — a transformers AlbertModel — with the names of ALBERT_PARTS
+    (:14-37): one shared layer applied num_hidden_layers times.  The twin has the dims of tts_cpp_amd.synth.kokoro_tiny (so that the fixture's
+    tensors can replace the synthetic ones of that model) and transformers' own softmax scale 1/sqrt(head size) — the reference hard-codes
+    0.125 = 1/sqrt(64), Kokoro-82M's head size (model.h:196), which the oracle takes as a parameter."""
+    from transformers import AlbertConfig, AlbertModel
+
+    torch.manual_seed(1011)
+    V, E, H, NH, F, REC, CTX = 32, 16, 64, 4, 128, 2, 32
+    cfg = AlbertConfig(vocab_size=V, embedding_size=E, hidden_size=H, num_hidden_layers=REC, num_hidden_groups=1, num_attention_heads=NH,
+                       intermediate_size=F, inner_group_num=1, hidden_act="gelu_new", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                       max_position_embeddings=CTX, type_vocab_size=2, layer_norm_eps=1e-12)
+    model = AlbertModel(cfg, add_pooling_layer=False).double().eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "LayerNorm.weight" in n or "layer_norm.weight" in n:
+                p.copy_(1.0 + 0.1 * torch.randn_like(p))
+            elif n.endswith("bias"):
+                p.copy_(0.1 * torch.randn_like(p))
+            elif "embeddings" in n:
+                p.copy_(0.7 * torch.randn_like(p))
+            else:
+                p.copy_(torch.randn_like(p) / math.sqrt(p.shape[1]))
+        for p in model.parameters():
+            p.copy_(p.to(torch.float32).to(torch.float64))
+    parts = {"embeddings.word_embeddings.weight": "token_embd", "embeddings.position_embeddings.weight": "position_embd",          # ALBERT_PARTS :14-37
+             "embeddings.LayerNorm.weight": "norm", "embeddings.LayerNorm.bias": "norm_bias", "encoder.embedding_hidden_mapping_in.weight": "embd",
+             "encoder.embedding_hidden_mapping_in.bias": "embd_bias", "full_layer_layer_norm.weight": "attn_norm", "full_layer_layer_norm.bias": "attn_norm_bias",
+             "attention.query.weight": "q", "attention.query.bias": "q_bias", "attention.key.weight": "k", "attention.key.bias": "k_bias",
+             "attention.value.weight": "v", "attention.value.bias": "v_bias", "attention.dense.weight": "o", "attention.dense.bias": "o_bias",
+             "attention.LayerNorm.weight": "ffn_norm", "attention.LayerNorm.bias": "ffn_norm_bias", "ffn.weight": "ffn", "ffn.bias": "ffn_bias",
+             "ffn_output.weight": "ffn_out", "ffn_output.bias": "ffn_out_bias"}
+    layer = "encoder.albert_layer_groups.0.albert_layers.0."
+    t = {}
+    for name, param in model.named_parameters():                                                  # :279-287
+        if name in parts:
+            t["kokoro.albert." + parts[name]] = npy(param).astype(np.float32)
+        elif layer in name and name[len(layer):] in parts:
+            t["kokoro.albert.layer.0." + parts[name[len(layer):]]] = npy(param).astype(np.float32)
+        elif name == "embeddings.token_type_embeddings.weight":
+            t["kokoro.albert.token_type_embd"] = npy(param).astype(np.float32)[0, :]
+    assert len(t) == 23, sorted(t)
+    rng = np.random.default_rng(17)
+    ids = rng.integers(0, V, 19)
+    with torch.no_grad():
+        out = model(input_ids=torch.tensor(ids[None]), attention_mask=torch.ones(1, ids.size, dtype=torch.long),
+                    token_type_ids=torch.zeros(1, ids.size, dtype=torch.long)).last_hidden_state[0]
+    save("upstream_albert.npz", ids=ids.astype(np.uint32), out=npy(out), cfg=np.array([V, E, H, NH, F, REC, CTX]), **{"t:" + k: v for k, v in t.items()})
+    print("albert:", tuple(out.shape), "max |out|", float(out.abs().max()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["orpheus", "t5", "dac", "dac_b3", "parler", "dia", "unigram", "bpe", "delay"]
+    which = sys.argv[1:] or ["orpheus", "t5", "dac", "dac_b3", "parler", "dia", "unigram", "bpe", "delay", "albert"]
     for w in which:
-        {"orpheus": make_orpheus, "t5": make_t5, "dac": make_dac, "parler": make_parler, "dia": make_dia, "unigram": make_unigram, "bpe": make_bpe, "delay": make_delay,
+        {"orpheus": make_orpheus, "t5": make_t5, "dac": make_dac, "parler": make_parler, "dia": make_dia, "unigram": make_unigram, "bpe": make_bpe, "delay": make_delay, "albert": make_albert,
          "dac_b3": lambda: make_dac("upstream_dac_b3.npz", hidden=192, strides=(2, 2), seed=1005, frames=300)}[w]()

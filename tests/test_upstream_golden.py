@@ -208,3 +208,33 @@ def test_delay_pattern_against_transformers_musicgen():
     out = np.empty(flat.size, dtype=np.uint32)
     n = L.orc_parler_adjust_output_tokens(orc.u32p(flat), flat.size, K, AV, AV, orc.u32p(out))
     assert np.array_equal(out[:n].reshape(-1, K), z["frames"]) and n // K == steps - (K - 1)
+
+
+def test_kokoro_albert_against_transformers_albert(tmp_path, monkeypatch):
+    """Kokoro's text model is a transformers AlbertModel (kokoro_gguf_encoder.py:14-37, :274-287 walk its parameter names): embeddings + LayerNorm
+    (eps 1e-12) + embedding_hidden_mapping_in, then ONE shared layer applied num_hidden_layers times — attention, dense + residual + LayerNorm,
+    ffn / gelu_new / ffn_output + residual + LayerNorm (kokoro/model.cpp:10-23, :966-1007).  The fixture's tensors replace the ALBERT tensors of the
+    synthetic tiny model; the oracle's ALBERT output (ORC_KOKORO_DUMP) is compared with upstream's last_hidden_state.  The softmax scale is the
+    one place the reference does not follow the config: it hard-codes 0.125 = 1/sqrt(64) (model.h:196), right for Kokoro-82M's head size only."""
+    z, by_name = load("upstream_albert.npz")
+    V, E, H, NH, F, REC, CTX = (int(x) for x in z["cfg"])
+    cfg = synth.kokoro_tiny()
+    assert (cfg.vocab, cfg.albert_embd, cfg.hidden, cfg.heads, cfg.ffn, cfg.recurrence, cfg.max_ctx) == (V, E, H, NH, F, REC, CTX)
+    model = synth.build_kokoro(cfg)
+    n_rep = 0
+    for i, t in enumerate(model.tensors):
+        if t.name in by_name:
+            assert list(t.ne) == list(by_name[t.name].ne), t.name
+            model.tensors[i] = by_name[t.name]
+            n_rep += 1
+    assert n_rep == len(by_name) == 23
+    monkeypatch.setenv("ORC_KOKORO_DUMP", str(tmp_path))
+
+    def albert(scale):
+        o = orc.KokoroOracle(model, attn_scale=scale, gelu_mode=0)
+        o.durations(z["ids"], "af_test")
+        return np.fromfile(tmp_path / "albert.bin", dtype=np.float32).reshape(-1, H)
+
+    out = albert(1.0 / np.sqrt(H // NH))
+    assert rel(out, z["out"]) < 2e-5
+    assert rel(albert(0.125), z["out"]) > 1e-3   # the reference's constant at a head size other than 64
