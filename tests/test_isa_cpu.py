@@ -1,0 +1,79 @@
+"""Device code checked at the ISA level, without a GPU (hipcc cross-compiles gfx950): the hot kernels of the batch-1 chain and the epilogues
+restructured in round 3 must stay free of scratch and of serialized load chains.  Both were found the slow way — a predicate around a load
+became its own basic block with an `s_waitcnt vmcnt(0)` behind it (4 dependent round trips in a LayerNorm prologue, 384 in the planes convs'
+epilogue, 8 at the end of every tiled decoder GEMM: DESIGN.md §5) — so the scanner that found them now guards them."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+PARLER_TU = """
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include "{root}/tts.cpp_amd/csrc/gemm_tile_kernels.h"
+template __global__ void gemm16_kernel<1, PRO_LN, EPI_STORE, 1>(GemmArgs);
+template __global__ void gemm16_kernel<1, PRO_LN, EPI_QKV, 1>(GemmArgs);
+template __global__ void gemm16_kernel<1, PRO_ATTN, EPI_RESID, 1>(GemmArgs);
+template __global__ void gemm16_kernel<1, PRO_F16, EPI_STORE, 1>(GemmArgs);
+template __global__ void gemm_tile_kernel<128, 128, 2, 4, 64, 4, EPI_QKV>(GemmArgs, TileMap);
+template __global__ void gemm_tile_kernel<128, 128, 2, 4, 64, 4, EPI_RESID>(GemmArgs, TileMap);
+template __global__ void gemm_tile_kernel<64, 64, 2, 4, 128, 3, EPI_RESID>(GemmArgs, TileMap);
+"""
+DAC_TU = """
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+#include "{root}/tts.cpp_amd/csrc/dac_kernels.h"
+#include "{root}/tts.cpp_amd/csrc/dac_b3_kernels.h"
+template __global__ void conv_b3p_kernel<1, 4, 2, 2, 4, 1, 2, 2>(PConvArgs);
+template __global__ void conv_b3p_kernel<1, 2, 4, 2, 4, 1, 2, 2>(PConvArgs);
+"""
+# dependent load groups a kernel may show in profiles/tools/isa_serial_loads.py (measured at the end of round 3, one of slack)
+LIMITS = {
+    r"gemm16_kernel<1, 1, 0, 1>": 4, r"gemm16_kernel<1, 1, 1, 1>": 4, r"gemm16_kernel<1, 3, 2, 1>": 3, r"gemm16_kernel<1, 2, 0, 1>": 3,
+    r"gemm_tile_kernel<128, 128, 2, 4, 64, 4, 1>": 3, r"gemm_tile_kernel<128, 128, 2, 4, 64, 4, 2>": 3, r"gemm_tile_kernel<64, 64, 2, 4, 128, 3, 2>": 3,
+    r"attn_short_kernel": 4, r"embed_rows_kernel": 4,
+    r"conv_b3p_kernel<1, 4, 2, 2, 4, 1, 2, 2>": 17, r"conv_b3p_kernel<1, 2, 4, 2, 4, 1, 2, 2>": 10,
+}
+
+
+def _compile(tmp_path, name, src):
+    cu = tmp_path / f"{name}.hip"
+    cu.write_text(src.format(root=ROOT))
+    asm = tmp_path / f"{name}.s"
+    p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+                        "-o", str(asm), str(cu)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return asm, p.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_hot_kernels_have_no_scratch_and_no_serialized_load_chains(tmp_path):
+    seen = {}
+    for name, src in (("parler", PARLER_TU), ("dac", DAC_TU)):
+        asm, remarks = _compile(tmp_path, name, src)
+        scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", remarks)]
+        assert scratch and max(scratch) == 0, f"{name}: a kernel spills ({scratch})"
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "tools", "isa_serial_loads.py"), str(asm), "1"],
+                             capture_output=True, text=True, check=True).stdout
+        filt = subprocess.run(["c++filt"], input=out, capture_output=True, text=True).stdout if shutil.which("c++filt") else out
+        for line in filt.splitlines():
+            m = re.match(r"\s*(\d+) dependent load groups\s+(.*)", line)
+            if m:
+                seen[m.group(2)] = int(m.group(1))
+    checked = 0
+    for pat, limit in LIMITS.items():
+        hits = [(k, v) for k, v in seen.items() if pat in k]
+        for k, v in hits:
+            assert v <= limit, f"{k}: {v} dependent load groups (limit {limit}): a predicate crept back around a load?"
+            checked += 1
+    if shutil.which("c++filt"):
+        assert checked >= 8, sorted(seen)
