@@ -1,8 +1,8 @@
 """ctypes wrapper of oracle/liboracle.so and oracle/_ref/libref_sampler.so.
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
-leg — never by the product path (tts.cpp_amd/).  See tts_oracle.h for the parity status
-("parity unpinned" for tensor arithmetic; sampler pinned against the real reference).
+leg — never by the product path (tts.cpp_amd/).  See tts_oracle.h for the parity status (sampler pinned against the real
+reference, graph arithmetic against the upstream models of tests/golden/upstream_*.npz, ggml's kernel-level rounding unpinned).
 """
 import ctypes as C
 import os
@@ -731,7 +731,7 @@ class KokoroModelC(C.Structure):
 
 
 class KokoroOracle:
-    """Oracle twin of a tts_cpp_amd.synth.SynthKokoro (src/models/kokoro/model.cpp restated in kokoro_oracle.c; PARITY UNPINNED,
+    """Oracle twin of a tts_cpp_amd.synth.SynthKokoro (src/models/kokoro/model.cpp restated in kokoro_oracle.c; PARITY UNPINNED beyond the ALBERT stage,
     see that file's header).  The phonemizer is outside: inputs are phoneme ids with the bos / eos ids around them."""
 
     def __init__(self, model, attn_scale=0.125, gelu_mode=1):

@@ -3,8 +3,9 @@
  * pattern and DAC decoder.  TEST INFRASTRUCTURE ONLY (see tts_oracle.h header comment):
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
  *
- * "parity unpinned" for tensor arithmetic (ggml fork absent, no reference golden vectors);
- * sampler pinned against the real reference sampler.cpp via oracle/_ref (see Makefile).
+ * Parity status in tts_oracle.h: sampler pinned to the real reference sampler.cpp (oracle/_ref), graph arithmetic pinned to
+ * the upstream models the reference converts from (tests/golden/upstream_*.npz); ggml's kernel-level rounding unpinned
+ * (fork absent, no reference golden vectors).
  *
  * Citations are file:line under /root/reference.
  */

@@ -5,14 +5,23 @@
  * link or call this.  Allowed users: tests/, __graft_entry__.smoke(), bench.py's
  * cpu_baseline leg.
  *
- * PARITY STATUS: "parity unpinned" for the tensor arithmetic.  The reference's numerics
- * live in the un-vendored ggml fork (github.com/mmwillet/ggml, branch support-for-tts,
- * commit pin unknown; /root/reference/ggml is empty) and the reference ships no golden
- * vectors.  What IS pinned:
- *   - the sampler restatement is checked against the real reference src/sampler.cpp,
- *     compiled from where it lies into oracle/_ref/ (oracle/Makefile, tests/test_sampler.py);
- *   - every tensor primitive here is cross-checked against PyTorch CPU primitives
- *     (the .npz files under tests/golden, generated by tests/golden/make_golden.py).
+ * PARITY STATUS.  The reference's kernels live in the un-vendored ggml fork (github.com/mmwillet/ggml, branch
+ * support-for-tts, commit pin unknown; /root/reference/ggml is empty) and the reference ships no golden vectors
+ * (SURVEY.md §0.1, §0.2), so nothing here can be checked against the reference's own floats.  What IS pinned, and to what:
+ *   - the sampler restatement against the real reference src/sampler.cpp, compiled from where it lies into
+ *     oracle/_ref/ (oracle/Makefile, tests/test_sampler.py): bit-exact;
+ *   - the arithmetic of every graph whose upstream model is importable in the build container, against that model in
+ *     float64 — the implementations the reference's converters convert FROM, weights exported under the converters'
+ *     naming and layout rules (tests/golden/make_upstream_golden.py -> tests/golden/upstream_*.npz,
+ *     tests/test_upstream_golden.py): transformers' LlamaForCausalLM (Orpheus), T5EncoderModel, DacModel (weight norm
+ *     folded by the reference's own tensor_util.py), MusicgenForCausalLM (Parler's decoder; delay pattern and un-delay
+ *     exact), DiaForConditionalGeneration, AlbertModel (Kokoro's text model), and `tokenizers` Unigram / BPE for the
+ *     prompt tokenizers; every place where the REFERENCE departs from those upstreams is asserted as such (T5 buckets,
+ *     tanh-GELU, Dia's rope in cross-attention, Kokoro's fixed softmax scale, doubled spaces in BPE prompts);
+ *   - every tensor primitive against PyTorch CPU primitives (tests/golden/tiny_*.npz, tests/golden/make_golden.py).
+ * "parity unpinned" remains true of: ggml's kernel-level rounding (fp16 rounding of activations in front of F16
+ * weights, the fp16-indexed GELU table — stated as upstream knowledge), the fork's own ops behind Kokoro's vocoder
+ * (kokoro_oracle.c's header), SNAC, and Kokoro beyond its ALBERT stage.
  *
  * All file:line citations are relative to /root/reference.
  */
