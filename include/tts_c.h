@@ -51,7 +51,9 @@ int           tts_c_generate_batch(tts_c_runner *r, const char *const *texts, in
 void          tts_c_set_load_options(int device, int max_seqs, int declare_only);
 /* the same plus share_with (tts_load_options::share_with): a loaded runner of the same model on the same device whose weight arena the
  * next runner uses instead of uploading its own (own KV cache, own stream, own voice prompt once it is updated); the reference's server
- * loads the file once per worker (examples/server/server.cpp:316-321) */
+ * loads the file once per worker (examples/server/server.cpp:316-321).  Lifetime: the arena is reference counted in the device library, so
+ * the runners may be freed in any order — the memory goes with the last of them.  Both calls apply to ONE load: tts_c_runner_from_file
+ * resets the thread's options to the defaults when it returns. */
 void          tts_c_set_load_options_ex(int device, int max_seqs, int declare_only, tts_c_runner *share_with);
 /* the runner's tts_hip_ctx* (include/tts_hip.h: arena, profiling), or NULL when the architecture keeps several contexts */
 void         *tts_c_runner_device_context(tts_c_runner *r);

@@ -414,19 +414,23 @@ typedef struct tts_hip_kstat {
     double   ms_total;      /* summed event-elapsed time */
     uint64_t launches;
     double   bytes_total;   /* ALGORITHMIC bytes (weights + activations + cache rows each launch must touch) */
-    double   flops_total;   /* Arithmetic of the codec convolutions of this context (bench.py prices each kernel family against the pipe it runs on): bit 0 = the
+    double   flops_total;   /* algorithmic flops */
+} tts_hip_kstat;
+/* Arithmetic of the codec convolutions of this context (bench.py prices each kernel family against the pipe it runs on): bit 0 = the
  * k = 7 convs of the wide classes as bf16 x 3 split products (TTS_HIP_DAC_BF16X3), bit 1 = residual units of 96 / 192 channels as one
  * launch, bf16 x 3 (TTS_HIP_DAC_FUSE), bit 2 = transposed convs as bf16 x 3 (TTS_HIP_DAC_CONVT_B3), bit 5 (32) = the wide classes keep their activations as bf16 x 3 split planes, so
  * their k = 1 convs are bf16 x 3 products too (TTS_HIP_DAC_PLANES; otherwise exact-fp32 MFMA); 8 = F16 tensors (fp16 im2col, fp16
  * MFMA); 16 = scalar-FMA cross-check kernels; 0 = exact-fp32 MFMA throughout or no codec. */
 int tts_hip_dac_arith(tts_hip_ctx *ctx);
-/* algorithmic flops */
-} tts_hip_kstat;
 int tts_hip_profile(tts_hip_ctx *ctx, int enable);        /* 1: every launch, forwards run eagerly; 2: only the launches that are
                                                               never graph-captured (the DAC), decoder steps keep replaying their
                                                               hipGraph; 0: off.  Enabling clears the counters. */
 int tts_hip_profile_get(tts_hip_ctx *ctx, int kclass, tts_hip_kstat *out);
 const char *tts_hip_kclass_name(int kclass);
+
+/* Tuning and fallback switches by name (profiles/ harnesses and the fallback parity test; call between tts_hip_create and the first
+ * launch).  Unknown key: -1.  Not an environment variable on purpose: a deployment cannot flip a kernel path by accident. */
+int tts_hip_tune(tts_hip_ctx *ctx, const char *key, int value);
 
 /* stream / device handles for callers that need to order their own work (torch interop) */
 void *tts_hip_stream(tts_hip_ctx *ctx);

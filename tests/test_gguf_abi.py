@@ -51,6 +51,16 @@ def test_synth_shapes_match_reference_layout():
     assert t["audio_encoder.decoder_block.2.final.alpha"].ne == [1, c.c0 // 2, 1]
 
 
+@pytest.mark.parametrize("header", ["tts_hip.h", "tts_c.h"])
+@pytest.mark.parametrize("compiler,lang", [("gcc", "c"), ("g++", "c++")])
+def test_public_headers_compile_as_c_and_cpp(header, compiler, lang):
+    """The boundary headers are a C ABI: both must parse as plain C (and as C++) on their own, warnings as errors."""
+    import subprocess
+    r = subprocess.run([compiler, "-fsyntax-only", "-x", lang, "-Wall", "-Werror", os.path.join(ROOT, "include", header)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_c_abi_exports_every_declared_symbol():
     """include/tts_hip.h is the boundary: the built library must export each function it declares."""
     hdr = open(os.path.join(ROOT, "include", "tts_hip.h")).read()

@@ -191,15 +191,31 @@ def test_full_size_quantizer_embedding_tile_kernel():
     eng.close()
 
 
-def test_bf16x3_conv_experiment_matches_oracle(monkeypatch):
-    """TTS_HIP_DAC_BF16X3=1 (off by default): the k = 7 convs with >= 64-channel tiles as six bf16 MFMAs per fp32
-    product (conv1d_mfma_b3_kernel).  Same tolerances as the exact-fp32 path at the DAC-44k dims: the split keeps 24
-    mantissa bits per operand, the error is that of the fp32 accumulation (measured: PCM 1.0e-6 against 6.7e-7,
-    stages 2.8e-6 against 1.8e-6; profiles/r02/dac_bf16x3_experiment.txt)."""
-    monkeypatch.setenv("TTS_HIP_DAC_BF16X3", "1")
+ARITH_CASES = [
+    # (id, environment, tts_hip_tune keys, tts_hip_dac_arith bits expected)
+    ("default_bf16x3", {}, {}, 1 | 2 | 4 | 32),                       # the product default: every conv as bf16 x 3 split products
+    ("exact_fp32", {"TTS_HIP_DAC_BF16X3": "0"}, {}, 0),              # the exact-fp32 MFMA pipe the default is held against
+    ("units_unfused", {}, {"dac_fuse": 0}, 1 | 4 | 32),               # residual units at 96 / 192 channels as two launches
+    ("convt_fp32", {}, {"dac_convt_b3": 0}, 1 | 2 | 32),              # transposed convs on the exact-fp32 kernel
+    ("no_planes", {}, {"dac_planes": 0}, 1 | 2 | 4),                  # wide classes keep fp32 activations (conv1d_mfma_b3_kernel + fp32 k = 1)
+    ("tap_pairs", {}, {"dac_tap7": 0}, 1 | 2 | 4 | 32),               # k = 7 convs with tap-pair k-steps (8 slots for 7 taps)
+]
+
+
+@pytest.mark.parametrize("case", ARITH_CASES, ids=[c[0] for c in ARITH_CASES])
+def test_codec_arithmetic_default_and_every_fallback_match_oracle(case, monkeypatch):
+    """The DAC-44k stage check under the product default (bf16 x 3 split products on v_mfma_f32_32x32x16_bf16, fused residual units,
+    split planes) and under every switch that survives as a fallback — one bar for all: PCM 2e-4, stages 1e-5 relative (the split keeps 24
+    mantissa bits per operand; measured PCM 1.0e-6 / stages 2.0-3.5e-6 for the default, 6.3e-7 / 1.2-1.9e-6 for the exact-fp32 pipe).
+    A fallback nobody runs is a second product nobody verifies: the switches this test does not name were deleted in round 4."""
+    _, env, tune, arith = case
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     model = synth.build(synth.parler_mini(layers=1, prompt_vocab=64, ctx=64))
     cfg = model.cfg
-    eng = dac_engine(cfg, model)
+    eng = hip.HipEngine(cfg, flags=hip.FLAG_NO_PARLER, tune=tune)
+    eng.load(model)
+    assert eng.L.tts_hip_dac_arith(eng.ctx) == arith
     codes = np.random.default_rng(2).integers(0, cfg.cb_size, (3, cfg.n_out)).astype(np.uint32)
     eng.set_debug(True)
     pcm = eng.dac_decode(codes)
@@ -212,4 +228,42 @@ def test_bf16x3_conv_experiment_matches_oracle(monkeypatch):
     ragged = [np.random.default_rng(f).integers(0, cfg.cb_size, (f, cfg.n_out)).astype(np.uint32) for f in (1, 5)] + [codes]
     batch = eng.dac_decode_batch(ragged)
     assert np.array_equal(batch[2], pcm)
+    eng.close()
+
+
+def test_unknown_tuning_key_is_refused():
+    model = synth.build(synth.tiny(weight_type=gguf.F32))
+    eng = hip.HipEngine(model.cfg, flags=hip.FLAG_NO_PARLER)
+    with pytest.raises(hip.HipError, match="unknown key"):
+        eng.tune("dac_variant", 3)
+    eng.close()
+
+
+def test_measured_codec_shape_windows_match_oracle():
+    """The shape bench.py measures: ONE codec pass of 64 utterances x 248 frames at the DAC-44k dims.  The decoder is a stack of finite
+    receptive-field convolutions (< 8 frames on either side, test_full_size_dac_and_locality), so a 2-frame window of any utterance
+    equals the same window of an oracle decode of the surrounding +-8 frames: three random windows per utterance for eight utterances spread
+    over the pass (first, last, tile boundaries of grid.z) at the full-size tolerance, plus every utterance against its own single decode
+    bit for bit for four of them."""
+    model = synth.build(synth.parler_mini(layers=1, prompt_vocab=64, ctx=64))
+    cfg = model.cfg
+    eng = dac_engine(cfg, model)
+    rng = np.random.default_rng(64248)
+    U, F, HALO, hop = 64, 248, 8, 512
+    utts = [rng.integers(0, cfg.cb_size, (F, cfg.n_out)).astype(np.uint32) for _ in range(U)]
+    out = eng.dac_decode_batch(utts)
+    assert len(out) == U and all(o.shape == (F * hop,) for o in out)
+    o = orc.DacOracle(model)
+    worst = 0.0
+    for u in (0, 1, 15, 16, 31, 32, 62, 63):
+        for f0 in [0, F - 2] + list(rng.integers(HALO, F - HALO - 2, 1)):
+            lo, hi = max(0, int(f0) - HALO), min(F, int(f0) + 2 + HALO)
+            ref = o.decode(utts[u][lo:hi])
+            w = slice((int(f0) - lo) * hop, (int(f0) - lo + 2) * hop)
+            err = float(np.abs(out[u][int(f0) * hop:(int(f0) + 2) * hop] - ref[w]).max())
+            worst = max(worst, err)
+            assert err < 2e-4, f"utterance {u}, frames {int(f0)}..{int(f0) + 1}: {err:.2e}"
+    for u in (0, 17, 40, 63):
+        assert np.array_equal(out[u], eng.dac_decode(utts[u])), f"utterance {u}: batched pass differs from its own decode"
+    print(f"64 x 248 frames: worst window error {worst:.2e}")
     eng.close()

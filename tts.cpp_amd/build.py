@@ -16,14 +16,32 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+UNITS = ["shim_core", "shim_decoder", "shim_codec", "shim_llama"]
+
+
 def build_hip(force=False, verbose=True):
-    """libtts_hip.so: the C-ABI HIP shim (include/tts_hip.h)."""
+    """libtts_hip.so: the C-ABI HIP shim (include/tts_hip.h).  The translation units under csrc/ compile in parallel into
+    csrc/obj/*.o (each rebuilt only when it or a header is newer), then link."""
     csrc = os.path.join(PKG_DIR, "csrc")
-    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(REPO_ROOT, "include", "tts_hip.h")]
+    objdir = os.path.join(csrc, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.join(REPO_ROOT, "include", "tts_hip.h")]
     out = os.path.join(PKG_DIR, "libtts_hip.so")
-    if force or _newer(out, srcs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-function", "-o", out, os.path.join(csrc, "tts_hip.hip")]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    jobs = []
+    for u in UNITS:
+        src, obj = os.path.join(csrc, u + ".hip"), os.path.join(objdir, u + ".o")
+        if force or _newer(obj, [src] + headers):
+            cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    objs = [os.path.join(objdir, u + ".o") for u in UNITS]
+    if force or jobs or _newer(out, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -36,7 +36,7 @@ __host__ __device__ inline ResUnitGeom resunit_geom(int C, int KS, int KS2) {
     return g;
 }
 
-__global__ void pack_resunit_b3_kernel(const float *w7, const float *w1, __bf16 *dst, int C, int KS, int KS2) {
+static __global__ void pack_resunit_b3_kernel(const float *w7, const float *w1, __bf16 *dst, int C, int KS, int KS2) {
     const ResUnitGeom g = resunit_geom(C, KS, KS2);
     const int64_t per7 = (int64_t) KS * 2 * C * 8, per1 = (int64_t) KS2 * 2 * 96 * 8;
     const int64_t total = (int64_t) g.n7 * per7 + (int64_t) g.n1 * per1;
@@ -358,7 +358,7 @@ struct SplitArgs {
     const uint32_t *frames; int mult;
 };
 
-__global__ __launch_bounds__(256) void snake_split_kernel(SplitArgs a) {
+static __global__ __launch_bounds__(256) void snake_split_kernel(SplitArgs a) {
     const int t = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, z = blockIdx.z;
     const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
     if (t >= L) return;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void snake_split_kernel(SplitArgs a) {
 //   src [cout][cin][KT] -> dst [co_tile][chunk][plane][s < NS][hi][CO_T][8]
 //   KT = 7, NS = 4: ci = 8 chunk + j, tap = 2 s + hi (tap 7: zero);   KT = 7, NS = 7: ci = 16 chunk + 8 hi + j, tap = s;
 //   KT = 1: ci = 16 NS chunk + 8 (2 s + hi) + j
-__global__ void pack_conv_w_b3p_kernel(const float *src, __bf16 *dst, int cout, int cin, int KT, int CO_T, int NS, int n_chunks) {
+static __global__ void pack_conv_w_b3p_kernel(const float *src, __bf16 *dst, int cout, int cin, int KT, int CO_T, int NS, int n_chunks) {
     const int64_t plane_sz = (int64_t) NS * 2 * CO_T * 8;
     const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * plane_sz;
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
 // The fp32 input is staged once per workgroup and chunk: snake (snake_vec) + split -> LDS planes [plane][group][ti0 - 1 + r][8].
 //   pack_convt_w_b3_kernel   src [cin][cout][2 S] -> dst [co_tile][chunk][plane][ks < 2][ph < S][hi][CO_T][8]  (ci = 16 chunk + 8 ks + j, k = ph + hi S)
 // ================================================================================================================================
-__global__ void pack_convt_w_b3_kernel(const float *src, __bf16 *dst, int cout, int cin, int S, int CO_T, int n_chunks) {
+static __global__ void pack_convt_w_b3_kernel(const float *src, __bf16 *dst, int cout, int cin, int S, int CO_T, int n_chunks) {
     const int64_t plane_sz = (int64_t) 2 * S * 2 * CO_T * 8;
     const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * plane_sz;
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
@@ -883,7 +883,7 @@ template <int MI> struct ResT7 {
     static constexpr int MAXCNT = MI == 3 ? 4 : 2;
 };
 
-__global__ void pack_resunit_t7_kernel(const float *w7, const float *w1, __bf16 *dst, int C, int KS2) {
+static __global__ void pack_resunit_t7_kernel(const float *w7, const float *w1, __bf16 *dst, int C, int KS2) {
     const int MI = C / 32, SPC = MI == 3 ? 2 : 4, MAXCNT = MI == 3 ? 4 : 2;
     const int64_t WST = (int64_t) 3 * MAXCNT * 2 * C * 8;
     const int n7 = (C / 16) * SPC, ns1 = (C / 16) / KS2, n1 = (C / 96) * ns1;

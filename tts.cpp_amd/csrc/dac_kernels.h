@@ -94,7 +94,7 @@ struct DacEmbedArgs {
     int x_f16;              // F16 conv kernels: the conv input (codebook row) goes through an fp16 im2col
 };
 
-__global__ void dac_embed_kernel(DacEmbedArgs a) {
+static __global__ void dac_embed_kernel(DacEmbedArgs a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y, z = blockIdx.z;
     const int Tz = a.frames ? (int) a.frames[z] : a.T;
@@ -292,7 +292,7 @@ struct ConvTArgs {
 
 #define CT_CI 8
 
-__global__ __launch_bounds__(256) void convt1d_kernel(ConvTArgs a) {
+static __global__ __launch_bounds__(256) void convt1d_kernel(ConvTArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int s = a.stride, K = 2 * s;
     const int to0 = blockIdx.x * CV_T, co0 = blockIdx.y * CV_CO;
@@ -388,7 +388,7 @@ struct SnacEmbedArgs {
     float *out;              // [latent][T]
 };
 
-__global__ void snac_embed_kernel(SnacEmbedArgs a) {
+static __global__ void snac_embed_kernel(SnacEmbedArgs a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     if (t >= a.T) return;
@@ -408,7 +408,7 @@ __global__ void snac_embed_kernel(SnacEmbedArgs a) {
 }
 
 // depthwise k = 7: one output per thread (memory-shaped: 1 read + 1 write per element, 7 taps from L1/L2)
-__global__ __launch_bounds__(256) void dwconv7_kernel(const float *x, const float *w, const float *b, const float *alpha_in,
+static __global__ __launch_bounds__(256) void dwconv7_kernel(const float *x, const float *w, const float *b, const float *alpha_in,
                                                       const float *alpha_out, float *y, int C, int L, int pad, int dil) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const float *x, const floa
     y[(int64_t) c * L + t] = acc;
 }
 
-__global__ void noise_fma_kernel(float *x, const float *h, const float *noise, int C, int L) {
+static __global__ void noise_fma_kernel(float *x, const float *h, const float *noise, int C, int L) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) C * L) return;
     x[i] = x[i] + h[i] * noise[i % L];
@@ -448,7 +448,7 @@ typedef float float16d __attribute__((ext_vector_type(16)));
 // staging is a straight contiguous float4 copy.
 //   conv1d   src [cout][cin][KT]  -> dst [co_tile][chunk][(k*CI_T + ci)][CO_T]
 //   convT1d  src [cin][cout][K2]  -> dst [co_tile][chunk][ci][k][CO_T]
-__global__ void pack_conv_w_kernel(const float *src, float *dst, int cout, int cin, int KT, int CO_T, int CI_T, int n_chunks,
+static __global__ void pack_conv_w_kernel(const float *src, float *dst, int cout, int cin, int KT, int CO_T, int CI_T, int n_chunks,
                                    int transposed_src) {
     const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * KT * CI_T * CO_T;
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(64 * WM * WN, CONVT_MIN_WAVES) void convt1d_mfma_ke
 // thread; a 1-channel output gives the matrix pipe nothing to do, so this is a staged dot product.
 #define C1_T 256
 #define C1_CI 16
-__global__ __launch_bounds__(256) void conv1d_cout1_kernel(ConvArgs a) {
+static __global__ __launch_bounds__(256) void conv1d_cout1_kernel(ConvArgs a) {
     __shared__ float xs[C1_CI][C1_T + 8];
     __shared__ float wsm[C1_CI][8];
     const int tid = threadIdx.x, t0 = blockIdx.x * C1_T;
@@ -959,7 +959,7 @@ typedef _Float16 half8d __attribute__((ext_vector_type(8)));
 
 //   conv1d   src [cout][cin][KT]  -> dst [co_tile][chunk][k][cg][hi][CO_T][8]   (ci = chunk*CI_T + cg*16 + hi*8 + j)
 //   convT1d  src [cin][cout][K2]  -> same with k = 0..K2-1
-__global__ void pack_conv_w16_kernel(const float *src, _Float16 *dst, int cout, int cin, int KT, int CO_T, int CI_T, int n_chunks,
+static __global__ void pack_conv_w16_kernel(const float *src, _Float16 *dst, int cout, int cin, int KT, int CO_T, int CI_T, int n_chunks,
                                      int transposed_src) {
     const int NCG = CI_T / 16;
     const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * KT * CI_T * CO_T;
@@ -1005,7 +1005,7 @@ __device__ __forceinline__ void split_bf16x3(float x, __bf16 &h1, __bf16 &h2, __
 }
 
 //   conv1d  src [cout][cin][7]  ->  dst [co_tile][chunk][plane][s][hi][CO_T][8]   (ci = chunk*8 + j, tap = 2s + hi, tap 7 = 0)
-__global__ void pack_conv_w_b3_kernel(const float *src, __bf16 *dst, int cout, int cin, int CO_T, int n_chunks) {
+static __global__ void pack_conv_w_b3_kernel(const float *src, __bf16 *dst, int cout, int cin, int CO_T, int n_chunks) {
     const int64_t plane_sz = (int64_t) 8 * CO_T * 8;                                  // 4 steps x 2 halves x CO_T x 8
     const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * plane_sz;  // one thread per (element, all planes)
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {

@@ -15,7 +15,7 @@ struct DiaEmbedArgs {
     float *x;                 // [2 * n_utt][H]: rows 2u (text stream) and 2u+1 (all-zero twin) of utterance u get the same embedding
 };
 
-__global__ __launch_bounds__(256) void dia_embed_kernel(DiaEmbedArgs a) {
+static __global__ __launch_bounds__(256) void dia_embed_kernel(DiaEmbedArgs a) {
     const int e = blockIdx.x * 256 + threadIdx.x, u = blockIdx.y;
     if (e >= a.H) return;
     float acc = 0.0f;
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void dia_embed_kernel(DiaEmbedArgs a) {
 }
 
 // raw [2 * n_utt][ld] (ld >= n: the fused heads are padded to a multiple of 16 rows) -> guided [n_utt][n]; blockIdx.y = utterance
-__global__ __launch_bounds__(256) void dia_cfg_kernel(const float *raw, int ld, int n, float scale, float *guided) {
+static __global__ __launch_bounds__(256) void dia_cfg_kernel(const float *raw, int ld, int n, float scale, float *guided) {
     const int i = blockIdx.x * 256 + threadIdx.x, u = blockIdx.y;
     if (i >= n) return;
     const float cr = raw[(int64_t) (2 * u) * ld + i], ur = raw[(int64_t) (2 * u + 1) * ld + i];
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void dia_cfg_kernel(const float *raw, int ld, 
 
 // [R][ld] fp32 -> [R][K] fp16 (round to nearest even): the rounding ggml_mul_mat applies to the activations of an F16-weight product
 // (vec_dot_type conversion of src1), done once here so that the encoder's 2 x 1024 rows can go through gemm_tile_kernel
-__global__ __launch_bounds__(256) void rows_to_f16_kernel(const float *x, int ld, int K, int64_t n8, _Float16 *y) {
+static __global__ __launch_bounds__(256) void rows_to_f16_kernel(const float *x, int ld, int K, int64_t n8, _Float16 *y) {
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;   // one thread = 8 consecutive values
     if (i >= n8) return;
     const int64_t r = i / (K >> 3), c8 = i - r * (K >> 3);
@@ -73,7 +73,7 @@ struct DiaLoopArgs {
     uint32_t *hist;       // [n_utt][max_gen][n_out]
 };
 
-__global__ void dia_prestep_kernel(DiaLoopArgs a) {
+static __global__ void dia_prestep_kernel(DiaLoopArgs a) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= a.n_utt || a.done[u]) return;
     uint32_t *aud = a.ids + u * a.n_out;
@@ -93,7 +93,7 @@ __global__ void dia_prestep_kernel(DiaLoopArgs a) {
     a.call[u] = p + 1;
 }
 
-__global__ void dia_poststep_kernel(DiaLoopArgs a) {
+static __global__ void dia_poststep_kernel(DiaLoopArgs a) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= a.n_utt || a.done[u]) return;
     const uint32_t p = a.pos[2 * u];

@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "llama_kernels.h"   // q8_block_store
 
 template <int WT, int NR>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(GemmArgs a, int epi) {
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void gemv_q8_rows_kernel(QGemmArgs qa, int epi
 }
 
 
-__global__ void repack_i8_to_q4_kernel(const int8_t *q, uint8_t *out, int64_t n_bytes) {
+static __global__ void repack_i8_to_q4_kernel(const int8_t *q, uint8_t *out, int64_t n_bytes) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_bytes) return;
     const int64_t b = i >> 4;

@@ -12,9 +12,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "wave_ops.h"
 
 // y[r][n] = sum_k W[n][k] x[r][k] + b[n]; one wave per output
-__global__ __launch_bounds__(256) void kk_linear_kernel(const float *W, const float *b, const float *x, int ldx, int R, int K, int N, float *y, int ldy, int accumulate) {
+static __global__ __launch_bounds__(256) void kk_linear_kernel(const float *W, const float *b, const float *x, int ldx, int R, int K, int N, float *y, int ldy, int accumulate) {
     const int lane = threadIdx.x & 63;
     const int64_t o = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o >= (int64_t) R * N) return;
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void kk_linear_kernel(const float *W, const fl
 // ([k][row], [k][feature]) so that v_mfma_f32_32x32x2_f32 reads one float per lane (A[i = row][k], B[k][j = feature]); the next slice's
 // global loads travel under the MFMAs of the current one.  fp32 products, accumulation over k ascending as an fma chain.
 // Requires K % 16 == 0, ldx % 4 == 0 and 16-byte aligned x / W (the caller checks); b may be NULL.
-__global__ __launch_bounds__(256) void kk_linear_mfma_kernel(const float *W, const float *b, const float *x, int ldx, int R, int K, int N, float *y, int ldy, int accumulate) {
+static __global__ __launch_bounds__(256) void kk_linear_mfma_kernel(const float *W, const float *b, const float *x, int ldx, int R, int K, int N, float *y, int ldy, int accumulate) {
     typedef float f16v __attribute__((ext_vector_type(16)));
     typedef float f4v __attribute__((ext_vector_type(4)));
     constexpr int KC = 16, LD = 68;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void kk_linear_mfma_kernel(const float *W, con
 }
 
 // mode 0: y = norm(x) * w + b (w may be NULL: plain norm); mode 1 (AdaLayerNorm): y = n + n * gamma + beta with gamma = w, beta = b
-__global__ __launch_bounds__(64) void kk_norm_rows_kernel(const float *x, int ldx, int H, float eps, const float *w, const float *b, int mode, float *y, int ldy) {
+static __global__ __launch_bounds__(64) void kk_norm_rows_kernel(const float *x, int ldx, int H, float eps, const float *w, const float *b, int mode, float *y, int ldy) {
     const int r = blockIdx.x, lane = threadIdx.x;
     const float *xr = x + (int64_t) r * ldx;
     float s = 0.0f;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(64) void kk_norm_rows_kernel(const float *x, int ld
 }
 
 // q, k, v [n][H] -> out [n][H]; grid (heads, n), 64 threads; dynamic LDS n floats
-__global__ __launch_bounds__(64) void kk_albert_attn_kernel(const float *q, const float *k, const float *v, int n, int H, int hs, float scale, float *out) {
+static __global__ __launch_bounds__(64) void kk_albert_attn_kernel(const float *q, const float *k, const float *v, int n, int H, int hs, float scale, float *out) {
     extern __shared__ float kk_sc[];
     const int h = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
     const float *qr = q + (int64_t) t * H + h * hs;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(64) void kk_albert_attn_kernel(const float *q, cons
 
 // ggml_gelu as the reference's CPU path evaluates it (kokoro/model.cpp:1000): tanh form through the table indexed by the fp16 bits of x,
 // i.e. x rounded to fp16 and the result rounded to fp16, 0 / x outside (-10, 10) — the same arithmetic as gelu_apply(mode 1), parler_kernels.h
-__global__ void kk_gelu_kernel(float *x, int64_t n) {
+static __global__ void kk_gelu_kernel(float *x, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = x[i];
@@ -142,13 +143,13 @@ __global__ void kk_gelu_kernel(float *x, int64_t n) {
 }
 
 // out[i] = (a[i] + b[i]) * scale
-__global__ void kk_add_kernel(const float *a, const float *b, float *out, int64_t n, float scale) {
+static __global__ void kk_add_kernel(const float *a, const float *b, float *out, int64_t n, float scale) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (a[i] + b[i]) * scale;
 }
 
 // build_albert_inputs (:10-15): x[t][e] = (token_embd[tok[t]][e] + position_embd[t][e]) + token_type[e]
-__global__ void kk_albert_embed_kernel(const float *tok_embd, const float *pos_embd, const float *type_embd, const uint32_t *tok, int n, int E, float *x) {
+static __global__ void kk_albert_embed_kernel(const float *tok_embd, const float *pos_embd, const float *type_embd, const uint32_t *tok, int n, int E, float *x) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) n * E) return;
     const int t = (int) (i / E), e = (int) (i - (int64_t) t * E);
@@ -156,7 +157,7 @@ __global__ void kk_albert_embed_kernel(const float *tok_embd, const float *pos_e
 }
 
 // x[t][off + s] = style[s] for every row (the style half concatenated to the predictor states :1014, :1027)
-__global__ void kk_fill_cols_kernel(float *x, int n, int ld, int off, const float *style, int S) {
+static __global__ void kk_fill_cols_kernel(float *x, int n, int ld, int off, const float *style, int S) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) n * S) return;
     const int t = (int) (i / S), s = (int) (i - (int64_t) t * S);
@@ -164,7 +165,7 @@ __global__ void kk_fill_cols_kernel(float *x, int n, int ld, int off, const floa
 }
 
 // lens[t] = clamp(round(sum_e sigmoid(dur[t][e])), 1, 50) (:1035-1037)
-__global__ void kk_duration_kernel(const float *dur, int n, int ND, float *lens) {
+static __global__ void kk_duration_kernel(const float *dur, int n, int ND, float *lens) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     float s = 0.0f;
@@ -174,7 +175,7 @@ __global__ void kk_duration_kernel(const float *dur, int n, int ND, float *lens)
 }
 
 // token embedding rows onto channel-major output: y[c][t] = embd[tok[t]][c]
-__global__ void kk_embed_cols_kernel(const float *embd, const uint32_t *tok, int n, int C, float *y) {
+static __global__ void kk_embed_cols_kernel(const float *embd, const uint32_t *tok, int n, int C, float *y) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) n * C) return;
     const int c = (int) (i / n), t = (int) (i - (int64_t) c * n);
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void kk_lstm_split_kernel(LstmArgs a) {
     }
 }
 
-__global__ __launch_bounds__(1024) void kk_lstm_kernel(const float *pre, const float *whh0, const float *whh1, const float *whh2, const float *whh3, const float *bhh0,
+static __global__ __launch_bounds__(1024) void kk_lstm_kernel(const float *pre, const float *whh0, const float *whh1, const float *whh2, const float *whh3, const float *bhh0,
                                                        const float *bhh1, const float *bhh2, const float *bhh3, int L, int hid, int reversed, float *out, int out_stride,
                                                        int out_off) {
     extern __shared__ float kk_h[];
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(1024) void kk_lstm_kernel(const float *pre, const f
 }
 
 // [R][C] <-> [C][R]
-__global__ void kk_transpose_kernel(const float *x, int R, int C, float *y) {
+static __global__ void kk_transpose_kernel(const float *x, int R, int C, float *y) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) R * C) return;
     const int r = (int) (i / C), c = (int) (i - (int64_t) r * C);
@@ -306,14 +307,14 @@ __global__ void kk_transpose_kernel(const float *x, int R, int C, float *y) {
 }
 
 // rows gathered by index: y[t][:] = x[idx[t]][:]  (the duration mask of set_inputs :1262-1271 as an index)
-__global__ void kk_gather_rows_kernel(const float *x, const int *idx, int T, int W, float *y) {
+static __global__ void kk_gather_rows_kernel(const float *x, const int *idx, int T, int W, float *y) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) T * W) return;
     const int t = (int) (i / W), w = (int) (i - (int64_t) t * W);
     y[i] = x[(int64_t) idx[t] * W + w];
 }
 // the same onto channel-major output: y[c][t] = x[idx[t]][c]
-__global__ void kk_gather_cols_kernel(const float *x, const int *idx, int T, int C, float *y) {
+static __global__ void kk_gather_cols_kernel(const float *x, const int *idx, int T, int C, float *y) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) T * C) return;
     const int c = (int) (i / T), t = (int) (i - (int64_t) c * T);
@@ -321,7 +322,7 @@ __global__ void kk_gather_cols_kernel(const float *x, const int *idx, int T, int
 }
 
 // instance norm over L per channel, then n + n * gamma[c] + beta[c]; act 0 none, 1 leaky relu (slope), 2 snake with alpha[c]
-__global__ __launch_bounds__(256) void kk_adain_kernel(float *x, int64_t L, const float *gamma, const float *beta, int act, float slope, const float *alpha) {
+static __global__ __launch_bounds__(256) void kk_adain_kernel(float *x, int64_t L, const float *gamma, const float *beta, int act, float slope, const float *alpha) {
     __shared__ float red[4];
     const int c = blockIdx.x, tid = threadIdx.x;
     float *xr = x + (int64_t) c * L;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256) void kk_adain_kernel(float *x, int64_t L, cons
 // the chip idle and walks 580 KB three times.  The row is cut into gridDim.y slices; phase 0 writes slice sums, phase 1 the slice sums of
 // (x - mean)^2 with the mean folded from phase 0 in slice order, phase 2 folds both and applies — the two-pass statistics of kk_adain_kernel,
 // summed slice by slice.  part: [2][C][S].
-__global__ __launch_bounds__(256) void kk_adain_split_kernel(float *x, int64_t L, const float *gamma, const float *beta, int act, float slope, const float *alpha, float *part,
+static __global__ __launch_bounds__(256) void kk_adain_split_kernel(float *x, int64_t L, const float *gamma, const float *beta, int act, float slope, const float *alpha, float *part,
                                                              int phase) {
     __shared__ float red[4];
     const int c = blockIdx.x, sl = blockIdx.y, S = gridDim.y, C = gridDim.x, tid = threadIdx.x;
@@ -391,13 +392,13 @@ __global__ __launch_bounds__(256) void kk_adain_split_kernel(float *x, int64_t L
     }
 }
 
-__global__ void kk_leaky_kernel(float *x, int64_t n, float slope) {
+static __global__ void kk_leaky_kernel(float *x, int64_t n, float slope) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const float v = x[i]; x[i] = v > 0.0f ? v : v * slope; }
 }
 
 // per-position layer norm over the channels of a [C][L] tensor (text encoder :1201-1203) + leaky relu
-__global__ __launch_bounds__(64) void kk_chan_norm_kernel(float *x, int C, int64_t L, const float *g, const float *b, float slope) {
+static __global__ __launch_bounds__(64) void kk_chan_norm_kernel(float *x, int C, int64_t L, const float *g, const float *b, float slope) {
     const int64_t t = blockIdx.x;
     const int lane = threadIdx.x;
     float s = 0.0f;
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(64) void kk_chan_norm_kernel(float *x, int C, int64
 // y[co][t] (+)= b[co] + sum_ci sum_k w[co][ci][k] * x[ci][(t * stride - pad + k * dil) >> in_shift]
 // in_shift 1: the input is read through a nearest-neighbour 2x upsample (the pooled shortcut of build_ada_residual_conv :126-128)
 // post_scale: the result (after the optional accumulate) is multiplied by it ((res + shortcut) / sqrt 2 :132, / n_kernels :229)
-__global__ void kk_conv1d_kernel(const float *x, int cin, int64_t L, const float *w, const float *b, int cout, int K, int stride, int pad, int dil, int in_shift,
+static __global__ void kk_conv1d_kernel(const float *x, int cin, int64_t L, const float *w, const float *b, int cout, int K, int stride, int pad, int dil, int in_shift,
                                  float *y, int64_t Lout, int accumulate, float post_scale) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) cout * Lout) return;
@@ -438,7 +439,7 @@ __global__ void kk_conv1d_kernel(const float *x, int cin, int64_t L, const float
 // the nearest-neighbour 2x input, accumulated into the block's output and scaled by 1/sqrt 2; row lengths that are no multiple of 4) as a
 // 64-channel x 64-position tile GEMM on the exact-fp32 matrix pipe: y[co][t] = ((y[co][t] +) b[co] + sum_ci w[co][ci] x[ci][t >> in_shift]) * post.
 // A = w (transposed into LDS as [ci][co]), B = x rows as they lie ([ci][t]); any cin, scalar loads (nothing here is 16-byte aligned).
-__global__ __launch_bounds__(256) void kk_conv1x1_mfma_kernel(const float *x, int cin, int64_t L, const float *w, const float *b, int cout, int in_shift, float *y, int64_t Lout,
+static __global__ __launch_bounds__(256) void kk_conv1x1_mfma_kernel(const float *x, int cin, int64_t L, const float *w, const float *b, int cout, int in_shift, float *y, int64_t Lout,
                                                               int accumulate, float post_scale) {
     typedef float f16v __attribute__((ext_vector_type(16)));
     constexpr int KC = 16, LD = 68;
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(256) void kk_conv1x1_mfma_kernel(const float *x, in
 }
 
 // dense ConvTranspose1d, weight [Cin][Cout][K]: y[co][to] = b[co] + sum over (ci, ti, k) with ti * stride + k - pad == to
-__global__ void kk_convt1d_kernel(const float *x, int cin, int64_t L, const float *w, const float *b, int cout, int K, int stride, int pad, float *y, int64_t Lout) {
+static __global__ void kk_convt1d_kernel(const float *x, int cin, int64_t L, const float *w, const float *b, int cout, int K, int stride, int pad, float *y, int64_t Lout) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) cout * Lout) return;
     const int co = (int) (i / Lout);
@@ -510,7 +511,7 @@ __global__ void kk_convt1d_kernel(const float *x, int cin, int64_t L, const floa
 }
 
 // depthwise ConvTranspose1d(k 3, stride 2, padding 1, output_padding 1): y[c][o] = b[c] + sum_k x[c][t] w[c][k] with 2 t + k - 1 == o; Lout = 2 L
-__global__ void kk_pool_convt_kernel(const float *x, int C, int64_t L, const float *w, const float *b, float *y) {
+static __global__ void kk_pool_convt_kernel(const float *x, int C, int64_t L, const float *w, const float *b, float *y) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) C * 2 * L) return;
     const int c = (int) (i / (2 * L));
@@ -526,7 +527,7 @@ __global__ void kk_pool_convt_kernel(const float *x, int C, int64_t L, const flo
 }
 
 // reflection pad of one sample in front of every channel (:215-220): y[c][0] = x[c][1], y[c][1 + t] = x[c][t]
-__global__ void kk_pad_front_kernel(const float *x, int C, int64_t L, float *y) {
+static __global__ void kk_pad_front_kernel(const float *x, int C, int64_t L, float *y) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) C * (L + 1)) return;
     const int c = (int) (i / (L + 1));
@@ -535,7 +536,7 @@ __global__ void kk_pad_front_kernel(const float *x, int C, int64_t L, float *y) 
 }
 
 // harmonic phases at the frame rate: phase[h][l] = cumsum_l(frac(f0[l] * (h + 1) / sr)) * (upsample_scale * 2 pi); one thread per harmonic
-__global__ void kk_sine_phase_kernel(const float *f0, int64_t L2, int NH, float sample_rate, float factor, float *phase) {
+static __global__ void kk_sine_phase_kernel(const float *f0, int64_t L2, int NH, float sample_rate, float factor, float *phase) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= NH) return;
     float run = 0.0f;
@@ -547,7 +548,7 @@ __global__ void kk_sine_phase_kernel(const float *f0, int64_t L2, int NH, float 
     }
 }
 // sine[h][j] = sin(linear_upscale(phase)[j]) * uv + noise scale * rand[h][j]   (uv_noise_compute, util.cpp:143-173)
-__global__ void kk_sine_source_kernel(const float *phase, const float *f0, int64_t L2, int NH, int up, float threshold, float sin_amp, float noise_std, const float *noise,
+static __global__ void kk_sine_source_kernel(const float *phase, const float *f0, int64_t L2, int NH, int up, float threshold, float sin_amp, float noise_std, const float *noise,
                                       float *sine) {
     const int64_t LS = L2 * up;
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -565,7 +566,7 @@ __global__ void kk_sine_source_kernel(const float *phase, const float *f0, int64
     sine[i] = sinf(ph) * (voiced ? sin_amp : 0.0f) + (voiced ? noise_std : sin_amp / 3.0f) * noise[i];
 }
 // har[j] = tanh(sum_h mw[h] sine[h][j] + mb)
-__global__ void kk_source_merge_kernel(const float *sine, int NH, int64_t LS, const float *mw, const float *mb, float *har) {
+static __global__ void kk_source_merge_kernel(const float *sine, int NH, int64_t LS, const float *mw, const float *mb, float *har) {
     const int64_t j = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= LS) return;
     float acc = 0.0f;
@@ -574,7 +575,7 @@ __global__ void kk_source_merge_kernel(const float *sine, int NH, int64_t LS, co
 }
 
 // torch.stft(center, reflect, onesided): out [2 nb][F] = magnitudes then phases; one thread per (bin, frame)
-__global__ void kk_stft_kernel(const float *x, int64_t L, const float *win, int N, int hop, int64_t F, float *out) {
+static __global__ void kk_stft_kernel(const float *x, int64_t L, const float *win, int N, int hop, int64_t F, float *out) {
     const int nb = N / 2 + 1;
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) nb * F) return;
@@ -595,7 +596,7 @@ __global__ void kk_stft_kernel(const float *x, int64_t L, const float *win, int 
 }
 
 // post [2 nb][F]: rows < nb -> exp (magnitude), rows >= nb -> sin (phase) (:234-238), in place
-__global__ void kk_spec_phase_kernel(float *post, int nb, int64_t F) {
+static __global__ void kk_spec_phase_kernel(float *post, int nb, int64_t F) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) 2 * nb * F) return;
     post[i] = i < (int64_t) nb * F ? expf(post[i]) : sinf(post[i]);
@@ -603,7 +604,7 @@ __global__ void kk_spec_phase_kernel(float *post, int nb, int64_t F) {
 
 // inverse STFT from magnitude / phase, overlap-add with the window, trimmed by N / 2, divided by the reference's window envelope
 // (compute_window_squared_sum, util.cpp:203-217 for out_len / hop frames); one thread per output sample
-__global__ void kk_istft_kernel(const float *post, int64_t F, const float *win, int N, int hop, float *out, int64_t out_len) {
+static __global__ void kk_istft_kernel(const float *post, int64_t F, const float *win, int N, int hop, float *out, int64_t out_len) {
     const int nb = N / 2 + 1, half = N / 2;
     const int64_t o = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= out_len) return;

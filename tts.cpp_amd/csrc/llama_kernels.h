@@ -28,7 +28,7 @@ __device__ __forceinline__ void q8_block_store(float v, int64_t idx, int8_t *aq,
 // flight at once (the first version walked the row twice with dependent loads: 9.4 us for one 3072-wide row).
 // aq / ad (optional): the normalised row is also written as Q8_0 blocks (aq int8 [R][H], ad [R][H/32]) for an integer GEMV that
 // follows immediately (saves that GEMV's quant_rows_q8_kernel launch).
-__global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int H, const float *w, float *y, int R, float eps, const float *parts, int n_parts,
+static __global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int H, const float *w, float *y, int R, float eps, const float *parts, int n_parts,
                                                             int64_t slab_stride, int8_t *aq, float *ad) {
     __shared__ float red[4];
     const int r = blockIdx.x, tid = threadIdx.x;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int H, con
 // row_seq (optional): row r appends to the cache of sequence row_seq[r], seq_stride floats apart (Dia's two streams).
 // n_parts > 1: qkv holds n_parts fp32 slabs (part_stride floats apart, K slices of the projection written by gemv_stream_kernel); they are
 // summed in slab order on the way in and the rotated q lands in slab 0, where the attention kernels read it.
-__global__ __launch_bounds__(64) void llama_rope_kv_kernel(float *qkv, const uint32_t *pos, const float *ff, float theta_scale, int NH, int NKV, int HD,
+static __global__ __launch_bounds__(64) void llama_rope_kv_kernel(float *qkv, const uint32_t *pos, const float *ff, float theta_scale, int NH, int NKV, int HD,
                                                            float *kcache, float *vcache, const uint32_t *row_seq, int64_t seq_stride, int n_parts = 1,
                                                            int64_t part_stride = 0) {
     const int r = blockIdx.x, h = blockIdx.y;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, i
 }
 
 // one 128-thread workgroup per (head, row): out = sum_z e^(m_z - m) o_z / sum_z e^(m_z - m) l_z, splits in order
-__global__ __launch_bounds__(128) void attn_gqa_combine_kernel(const float *part, int nz, int NH, float *out, int8_t *aq, float *ad) {
+static __global__ __launch_bounds__(128) void attn_gqa_combine_kernel(const float *part, int nz, int NH, float *out, int8_t *aq, float *ad) {
     const int h = blockIdx.x, r = blockIdx.y, t = threadIdx.x;
     const float *p = part + ((int64_t) r * NH + h) * nz * ATTN_PART;
     float m = -INFINITY;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(128) void attn_gqa_combine_kernel(const float *part
 __device__ __forceinline__ void argmax_merge(float &best, uint32_t &besti, float ov, uint32_t oi) {
     if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
 }
-__global__ __launch_bounds__(256) void argmax_parts_kernel(const float *logits, int V, float *pv, uint32_t *pi) {
+static __global__ __launch_bounds__(256) void argmax_parts_kernel(const float *logits, int V, float *pv, uint32_t *pi) {
     __shared__ float bv[4];
     __shared__ uint32_t bi[4];
     const int chunk = (V + ARGMAX_PARTS - 1) / ARGMAX_PARTS;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void argmax_parts_kernel(const float *logits, 
     }
 }
 // hist / next_id / next_pos (optional): the device-resident greedy loop feeds the token straight back as the next input
-__global__ __launch_bounds__(64) void argmax_fold_kernel(const float *pv, const uint32_t *pi, uint32_t *token, uint32_t *hist, uint32_t *next_id,
+static __global__ __launch_bounds__(64) void argmax_fold_kernel(const float *pv, const uint32_t *pi, uint32_t *token, uint32_t *hist, uint32_t *next_id,
                                                          uint32_t *next_pos) {
     float best = -INFINITY;
     uint32_t besti = 0xffffffffu;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64) void argmax_fold_kernel(const float *pv, const 
 }
 
 // the same fold for a captured step (one graph replayed for every position): the history slot comes from a device counter
-__global__ __launch_bounds__(64) void argmax_fold_graph_kernel(const float *pv, const uint32_t *pi, uint32_t *token, uint32_t *hist, uint32_t *hist_idx, uint32_t *next_id,
+static __global__ __launch_bounds__(64) void argmax_fold_graph_kernel(const float *pv, const uint32_t *pi, uint32_t *token, uint32_t *hist, uint32_t *hist_idx, uint32_t *next_id,
                                                                uint32_t *next_pos) {
     float best = -INFINITY;
     uint32_t besti = 0xffffffffu;
@@ -484,7 +484,7 @@ __device__ __forceinline__ float smp_key_value(unsigned long long key) {   // in
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-__global__ __launch_bounds__(512) void topk_parts_kernel(const float *logits, int V, int k, const double *pen_table, int pen_len, const int32_t *last_id,
+static __global__ __launch_bounds__(512) void topk_parts_kernel(const float *logits, int V, int k, const double *pen_table, int pen_len, const int32_t *last_id,
                                                          const uint32_t *rep_count, unsigned long long *cand) {
     __shared__ unsigned long long keys[TOPK_SLICE];
     const int chunk = (V + TOPK_PARTS - 1) / TOPK_PARTS;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(512) void topk_parts_kernel(const float *logits, in
 
 // uniforms[call[0]] is this call's draw; call[0] advances.  hist_idx != NULL: captured step, the history slot is hist[hist_idx[0]++];
 // otherwise hist (may be NULL) is the slot itself.  next_id / next_pos (may be NULL): the token goes straight back as the next input.
-__global__ __launch_bounds__(1024) void topk_sample_kernel(const unsigned long long *cand, int k, float temperature, const float *uniforms, uint32_t *call,
+static __global__ __launch_bounds__(1024) void topk_sample_kernel(const unsigned long long *cand, int k, float temperature, const float *uniforms, uint32_t *call,
                                                            const double *pen_table, int32_t *last_id, uint32_t *rep_count, uint32_t *token, uint32_t *hist,
                                                            uint32_t *hist_idx, uint32_t *next_id, uint32_t *next_pos) {
     __shared__ unsigned long long keys[TOPK_PARTS * TOPK_MAXK];
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(1024) void topk_sample_kernel(const unsigned long l
 
 // gu [R][2F] (gate | up) -> g [R][F] = silu(gate) * up; aq / ad (optional, F % 32 == 0): g also as Q8_0 blocks for the down projection
 // n_parts > 1: gu holds n_parts fp32 slabs part_stride floats apart (gemv_stream_kernel), summed in slab order on the way in
-__global__ void silu_mul_kernel(const float *gu, int F, int R, float *g, int8_t *aq, float *ad, int n_parts = 1, int64_t part_stride = 0) {
+static __global__ void silu_mul_kernel(const float *gu, int F, int R, float *g, int8_t *aq, float *ad, int n_parts = 1, int64_t part_stride = 0) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) R * F) return;
     const int64_t r = i / F, c = i - r * F;

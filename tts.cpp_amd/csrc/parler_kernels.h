@@ -25,63 +25,7 @@
 #include <stdint.h>
 #include <type_traits>
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float float4v __attribute__((ext_vector_type(4)));
-
-#define LN_EPS 1e-5f  // model.cpp:414 "parler always uses default eps"
-
-// Cross-lane reductions without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0): six dependent LDS round
-// trips per wave_sum, which is most of a LayerNorm's time at batch 1 (profiles/r03/b1_chain.txt).  The xor butterfly 32, 16, 8, 4, 2, 1 is
-// reproduced bit for bit: v_permlane32_swap / v_permlane16_swap of (v, v) leave lane i's value in one result and lane (i ^ 32) / (i ^ 16)'s in the
-// other (fp add and max commute); inside a row of 16 lanes the value has period 8 after the xor-8 step, period 4 after the xor-4 step ..., so
-// rotating the row by 8, 4, 2, 1 (DPP row_ror) pairs every lane with the same partner value the xor would (profiles/wave_sum_check.hip).
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row16_sum(float v) {   // == v += __shfl_xor(v, 8); ... 4; 2; 1 for aligned groups of 16 lanes
-    v += dpp_f<0x128>(v); v += dpp_f<0x124>(v); v += dpp_f<0x122>(v); v += dpp_f<0x121>(v);
-    return v;
-}
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, dpp_f<0x128>(v)); v = fmaxf(v, dpp_f<0x124>(v)); v = fmaxf(v, dpp_f<0x122>(v)); v = fmaxf(v, dpp_f<0x121>(v));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    v = __builtin_bit_cast(float, (unsigned) a[0]) + __builtin_bit_cast(float, (unsigned) a[1]);
-    const unsigned w = __builtin_bit_cast(unsigned, v);
-    const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
-    v = __builtin_bit_cast(float, (unsigned) b[0]) + __builtin_bit_cast(float, (unsigned) b[1]);
-    return row16_sum(v);
-}
-__device__ __forceinline__ float wave_max(float v) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    v = fmaxf(__builtin_bit_cast(float, (unsigned) a[0]), __builtin_bit_cast(float, (unsigned) a[1]));
-    const unsigned w = __builtin_bit_cast(unsigned, v);
-    const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
-    v = fmaxf(__builtin_bit_cast(float, (unsigned) b[0]), __builtin_bit_cast(float, (unsigned) b[1]));
-    return row16_max(v);
-}
-
-// ggml_gelu.  mode 1 restates ggml's CPU path, which evaluates GELU through a table indexed by the
-// fp16 bits of x and holding fp16 results (upstream ggml_vec_gelu_f32 / GGML_GELU_FP16): a table is
-// memoisation, so rounding x to fp16, evaluating in fp32 and rounding the result to fp16 is the
-// same function.
-__device__ __forceinline__ float gelu_tanh_f32(float x) {
-    const float A = 0.044715f, S = 0.79788456080286535587989211986876f;
-    return 0.5f * x * (1.0f + tanhf(S * x * (1.0f + A * x * x)));
-}
-__device__ __forceinline__ float gelu_apply(float x, int mode) {
-    if (mode == 0) return gelu_tanh_f32(x);
-    if (x <= -10.0f) return 0.0f;
-    if (x >= 10.0f) return x;
-    const float xr = (float) (_Float16) x;
-    return (float) (_Float16) gelu_tanh_f32(xr);
-}
+#include "wave_ops.h"
 
 // ------------------------------------------------------------------------------------------------
 // embeddings: x[r] = (audio ? sum_i Emb_i[ids[r][i]] : EmbPrompt[ids[r]]) + Pos[pos[r]]
@@ -98,7 +42,7 @@ struct EmbedArgs {
     int         H;
 };
 
-__global__ void embed_rows_kernel(EmbedArgs a) {
+static __global__ void embed_rows_kernel(EmbedArgs a) {
     const int r = blockIdx.x;
     const uint32_t pos = a.row_pos[r];
     uint32_t id[16];
@@ -591,7 +535,7 @@ __global__ __launch_bounds__(256) void ln_rows_t_kernel(float *x, int H, const f
 }
 
 // any H: three passes over the row
-__global__ __launch_bounds__(256) void ln_rows_kernel(float *x, int H, const float *lw, const float *lb, float *y32,
+static __global__ __launch_bounds__(256) void ln_rows_kernel(float *x, int H, const float *lw, const float *lb, float *y32,
                                                       _Float16 *y16, int R, const float *parts, int n_parts, int64_t slab_stride) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -659,7 +603,7 @@ __device__ __forceinline__ float4v load_kv4(const void *base, int kv_f16, int64_
 // only in the order of fp32 operations.
 // (8 keys per lane group and pass instead of 4 — 128 keys per workgroup and round trip — was measured for the batch-1 chain: 183 VGPRs and
 // twice the loads in flight per CU made the key pass slower, 3.7 -> 6.0 us at T ~ 1000, profiles/r03/b1_chain_attn_variants.txt.)
-__global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {   // U = 8 is launched with 256 threads only (nsplit > 1)
+static __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {   // U = 8 is launched with 256 threads only (nsplit > 1)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NKG = blockDim.x >> 4;
     float *red = (float *) smem;                 // [NKG][64] acc, [NKG] max, [NKG] sum
@@ -806,7 +750,7 @@ __device__ __forceinline__ void attn_short_body(const AttnArgs &a, int r, int h,
     if (a.out16) a.out16[(int64_t) r * a.H + hb] = (_Float16) res;
     else a.out[(int64_t) r * a.H + hb] = res;
 }
-__global__ __launch_bounds__(256) void attn_short_kernel(AttnArgs a) {
+static __global__ __launch_bounds__(256) void attn_short_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), r = blockIdx.y;
     if (h >= a.n_heads) return;
@@ -822,7 +766,7 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnArgs a) {
 // per row instead of six per key — measured 14.8 us per launch at 1024 rows against 13.7 for this kernel with its compile-time prompt bound:
 // the launch is bound by the latency of its loads, not by the reductions; profiles/r03/attn_short16_rejected.txt.)
 
-__global__ void attn_combine_kernel(const float *part, int nz, int H, int n_heads, float *out, _Float16 *out16) {
+static __global__ void attn_combine_kernel(const float *part, int nz, int H, int n_heads, float *out, _Float16 *out16) {
     const int h = blockIdx.x, r = blockIdx.y, c = threadIdx.x;  // 64 threads; nz <= 16
     const float *p = part + ((int64_t) r * n_heads + h) * nz * ATT_PS;
     float m[16], s[16], o[16];
@@ -850,7 +794,7 @@ __global__ void attn_combine_kernel(const float *part, int nz, int H, int n_head
 // ------------------------------------------------------------------------------------------------
 // sampler::max on the device (src/sampler.cpp:185-204): first maximum wins (v > max).
 // ------------------------------------------------------------------------------------------------
-__global__ void argmax_kernel(const float *logits, int V, uint32_t *tokens) {
+static __global__ void argmax_kernel(const float *logits, int V, uint32_t *tokens) {
     __shared__ float bv[4];
     __shared__ uint32_t bi[4];
     const int idx = blockIdx.x;  // r * n_out + head
@@ -935,7 +879,7 @@ __device__ __forceinline__ void smp_rank_select(const float *val, int V, int k, 
     for (int j = threadIdx.x; j < k; j += blockDim.x) picks[j] = (unsigned short) (keys[j] & 0xFFFFu);
 }
 
-__global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
+static __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     __shared__ float val[SMP_VMAX];
     __shared__ float tmp[SMP_VMAX];
     __shared__ unsigned short picks[SMP_VMAX];
@@ -1094,7 +1038,7 @@ struct GatherArgs {
     uint32_t *s_ids, *s_pos, *s_seq, *s_step;  // scratch
     int R2, n_out;
 };
-__global__ void gather_rows_kernel(GatherArgs a, int phase) {
+static __global__ void gather_rows_kernel(GatherArgs a, int phase) {
     const int r = blockIdx.x, t = threadIdx.x;
     if (r >= a.R2) return;
     if (phase == 0) {
@@ -1108,7 +1052,7 @@ __global__ void gather_rows_kernel(GatherArgs a, int phase) {
 }
 
 // one 64-thread workgroup per row
-__global__ void feed_kernel(FeedArgs a) {
+static __global__ void feed_kernel(FeedArgs a) {
     __shared__ int not_seen;
     const int r = blockIdx.x, hd = threadIdx.x;
     const int ro = a.orig ? (int) a.orig[r] : r, RT = a.orig ? a.R_total : a.R;
@@ -1145,7 +1089,7 @@ __global__ void feed_kernel(FeedArgs a) {
 typedef int int4v __attribute__((ext_vector_type(4)));
 
 // activation rows -> Q8_0 blocks: q int8 [R][K], d (fp16-rounded, stored as float) [R][K/32]
-__global__ void quant_rows_q8_kernel(const float *x, int lda, int K, int8_t *q, float *d, int R) {
+static __global__ void quant_rows_q8_kernel(const float *x, int lda, int K, int8_t *q, float *d, int R) {
     const int r = blockIdx.y;
     const int b = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);  // 32 threads per block of 32 values
     const int j = threadIdx.x & 31;

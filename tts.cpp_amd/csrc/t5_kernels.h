@@ -11,14 +11,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-__global__ void t5_embed_kernel(const float *table, const uint32_t *ids, int H, float *x) {
+static __global__ void t5_embed_kernel(const float *table, const uint32_t *ids, int H, float *x) {
     const int t = blockIdx.x;
     const float *row = table + (int64_t) ids[t] * H;
     for (int i = threadIdx.x; i < H; i += blockDim.x) x[(int64_t) t * H + i] = row[i];
 }
 
 // one wave per row
-__global__ void t5_rms_rows_kernel(const float *x, int H, const float *w, float *y, int R) {
+static __global__ void t5_rms_rows_kernel(const float *x, int H, const float *w, float *y, int R) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -33,7 +33,7 @@ __global__ void t5_rms_rows_kernel(const float *x, int H, const float *w, float 
 // One 64-thread workgroup per (head, query): lanes over keys for the scores, lanes over the 64 head dims for the
 // output.  qkv [n][3H] (q | k | v), bucket_of_delta[(key - query) + (n_ctx - 1)] (host table with the reference's
 // double arithmetic, t5/model.cpp:303-316), rel_bias [n_buckets][n_heads].
-__global__ __launch_bounds__(64) void t5_attn_kernel(const float *qkv, int n, int H, int n_heads, const int *bucket_of_delta, int n_ctx,
+static __global__ __launch_bounds__(64) void t5_attn_kernel(const float *qkv, int n, int H, int n_heads, const int *bucket_of_delta, int n_ctx,
                                                      const float *rel_bias, float *out) {
     extern __shared__ float sm[];   // [64] q, then [n] probabilities
     float *qs = sm, *ps = sm + 64;
@@ -67,14 +67,14 @@ __global__ __launch_bounds__(64) void t5_attn_kernel(const float *qkv, int n, in
 }
 
 // ug [n][2F] (wi_0 x | wi_1 x) -> g [n][F] = gelu(up) * gate
-__global__ void t5_gated_gelu_kernel(const float *ug, int F, int n, int gelu_mode, float *g) {
+static __global__ void t5_gated_gelu_kernel(const float *ug, int F, int n, int gelu_mode, float *g) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t) n * F) return;
     const int64_t r = i / F, c = i - r * F;
     g[i] = gelu_apply(ug[r * 2 * F + c], gelu_mode) * ug[r * 2 * F + F + c];
 }
 
-__global__ void t5_add_bias_kernel(float *y, const float *b, int N, int n) {
+static __global__ void t5_add_bias_kernel(float *y, const float *b, int N, int n) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (int64_t) n * N) y[i] += b[i % N];
 }

@@ -85,7 +85,7 @@ EXPORTS = [
     "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits",
     "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_orpheus_generate_sampled", "tts_hip_orpheus_sample_logits", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_dia_encode_slot", "tts_hip_dia_step_batch", "tts_hip_dia_generate", "tts_hip_kokoro_create", "tts_hip_kokoro_durations", "tts_hip_kokoro_generate", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
-    "tts_hip_synchronize", "tts_hip_dac_arith", "tts_hip_broadcast_weights", "tts_hip_comm_unique_id", "tts_hip_broadcast_weights_rank",
+    "tts_hip_synchronize", "tts_hip_dac_arith", "tts_hip_broadcast_weights", "tts_hip_comm_unique_id", "tts_hip_broadcast_weights_rank", "tts_hip_tune",
 ]
 
 class Sampling(C.Structure):
@@ -172,6 +172,7 @@ def load_lib():
     L.tts_hip_stream.argtypes = [vp]
     L.tts_hip_stream.restype = vp
     L.tts_hip_synchronize.argtypes = [vp]
+    L.tts_hip_tune.argtypes = [vp, C.c_char_p, C.c_int]
     _lib = L
     return L
 
@@ -185,7 +186,7 @@ class HipEngine:
     """One device context holding a Parler decoder and/or a DAC codec."""
 
     def __init__(self, cfg, device=0, max_seqs=1, kv_type=gguf.F32, gelu_mode=1, flags=0, use_cross_attn=True,
-                 n_encode_length=None, kv_positions=0):
+                 n_encode_length=None, kv_positions=0, tune=None):
         self.L = load_lib()
         self.cfg = cfg
         d = Desc()
@@ -206,6 +207,8 @@ class HipEngine:
         if not self.ctx:
             raise HipError(self.err())
         self.finalized = False
+        for k, v in (tune or {}).items():
+            self.tune(k, v)
 
     def err(self):
         return self.L.tts_hip_last_error().decode("utf-8", "replace")
@@ -213,6 +216,10 @@ class HipEngine:
     def _chk(self, rc):
         if rc != 0:
             raise HipError(self.err())
+
+    def tune(self, key, value):
+        """tts_hip_tune: a named tuning / fallback switch (before the first launch)"""
+        self._chk(self.L.tts_hip_tune(self.ctx, key.encode(), int(value)))
 
     def close(self):
         if self.ctx:

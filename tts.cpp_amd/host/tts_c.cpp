@@ -43,6 +43,9 @@ void tts_c_default_config(tts_c_config * c) {
 
 tts_c_runner * tts_c_runner_from_file(const char * path, int n_threads, const tts_c_config * cfg, int cpu_only) {
     g_tts_throw_on_abort = true;
+    // the load options are for THIS load only: whatever happens, the next load of the thread starts from the defaults again (a share_with
+    // pointer left behind would make a later, unrelated load reach into a runner that may be gone)
+    struct reset_options { ~reset_options() { tts_thread_load_options() = tts_load_options{}; } } reset;
     try {
         return (tts_c_runner *) runner_from_file(path, n_threads, to_cfg(cfg), cpu_only != 0).release();
     } catch (const std::exception & e) {
