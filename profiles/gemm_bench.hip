@@ -49,7 +49,7 @@ int main(int argc, char **argv) {
         {"qkv", 3072, 1024, false}, {"proj", 1024, 1024, true}, {"fc1", 4096, 1024, false}, {"fc2", 1024, 4096, true}, {"heads", 9792, 1024, false}};
     std::vector<int> Rs = {64, 128, 192, 256, 384, 512};
     if (argc > 1) { Rs.clear(); for (int i = 1; i < argc; i++) Rs.push_back(atoi(argv[i])); }
-    const int RMAXB = 512;
+    const int RMAXB = 1024;
     _Float16 *W, *A; float *out, *ref, *fold;
     const size_t wmax = (size_t) 9792 * 1024;  // largest matrix (elements)
     CK(hipMalloc(&W, wmax * 2 * NBUF));
