@@ -19,6 +19,16 @@ def _newer(target, sources):
 UNITS = ["shim_core", "shim_decoder", "shim_codec", "shim_llama"]
 
 
+def _deps(depfile, fallback):
+    """the headers a unit really includes (hipcc -MMD of its last build), or every header when there is no record yet"""
+    try:
+        txt = open(depfile).read().replace("\\\n", " ")
+        files = [f for f in txt.split(":", 1)[1].split() if os.path.exists(f)]
+        return files or fallback
+    except (OSError, IndexError):
+        return fallback
+
+
 def build_hip(force=False, verbose=True):
     """libtts_hip.so: the C-ABI HIP shim (include/tts_hip.h).  The translation units under csrc/ compile in parallel into
     csrc/obj/*.o (each rebuilt only when it or a header is newer), then link."""
@@ -30,9 +40,9 @@ def build_hip(force=False, verbose=True):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
     jobs = []
     for u in UNITS:
-        src, obj = os.path.join(csrc, u + ".hip"), os.path.join(objdir, u + ".o")
-        if force or _newer(obj, [src] + headers):
-            cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
+        src, obj, dep = os.path.join(csrc, u + ".hip"), os.path.join(objdir, u + ".o"), os.path.join(objdir, u + ".d")
+        if force or _newer(obj, _deps(dep, [src] + headers)):
+            cmd = [HIPCC] + flags + ["-MMD", "-MF", dep, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             jobs.append((cmd, subprocess.Popen(cmd)))

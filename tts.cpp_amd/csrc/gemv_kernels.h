@@ -176,6 +176,63 @@ __global__ __launch_bounds__(256) void gemv_q4_rows_kernel(QGemmArgs qa, const u
 }
 
 
+// The Q4_0 codes and block scales a wave needs for NF features over NP passes of 64 blocks (block b = lane + 64 p of every feature), requested
+// in one batch of non-temporal loads BEFORE the workgroup's staging prologue, so that the HBM round trip runs under the rms norm / quantisation
+// instead of after it (round 3: the loads were issued two passes at a time after the barrier — a few hundred bytes in flight per wave).  A pass
+// beyond the row re-reads the row's last block and is never used.  The consumer keeps the old order (passes ascending per lane, then the wave
+// sum): results are bit-identical to the kernels of round 2 / 3.
+template <int NF, int NP>
+struct Q4Frag {
+    int4v wn[NF][NP];
+    _Float16 dw[NF][NP];
+};
+template <int NF, int NP>
+__device__ __forceinline__ void q4_frag_load(Q4Frag<NF, NP> &fr, const uint8_t *w4, const _Float16 *wd, const int (&nf)[NF], int K, int nb, int b0, int lane) {
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const int b = min(b0 + lane + 64 * p, nb - 1);
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            fr.wn[f][p] = __builtin_nontemporal_load((const int4v *) (w4 + (int64_t) nf[f] * (K >> 1) + b * 16));
+            fr.dw[f][p] = wd[(int64_t) nf[f] * nb + b];
+        }
+    }
+}
+// acc[f][r] += the block products of pass p for every row (activations as Q8_0 rows sx [R][K] + scales sd [R][nb] in LDS)
+template <int NF, int NP, int NR>
+__device__ __forceinline__ void q4_frag_dot(const Q4Frag<NF, NP> &fr, const int8_t *sx, const float *sd, int R, int K, int nb, int b0, int lane, float (&acc)[NF][NR]) {
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const int b = b0 + lane + 64 * p;
+        if (b < nb) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                if (r < R) {
+                    const int4v x0 = *(const int4v *) (sx + (size_t) r * K + b * 32), x1 = *(const int4v *) (sx + (size_t) r * K + b * 32 + 16);
+                    const float da = sd[r * nb + b];
+                    int sxs = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        sxs = __builtin_amdgcn_sdot4(0x01010101, x0[e], sxs, false);
+                        sxs = __builtin_amdgcn_sdot4(0x01010101, x1[e], sxs, false);
+                    }
+#pragma unroll
+                    for (int f = 0; f < NF; f++) {
+                        int s = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int lo = fr.wn[f][p][e] & 0x0F0F0F0F, hi = (fr.wn[f][p][e] >> 4) & 0x0F0F0F0F;
+                            s = __builtin_amdgcn_sdot4(lo, x0[e], s, false);
+                            s = __builtin_amdgcn_sdot4(hi, x1[e], s, false);
+                        }
+                        acc[f][r] += (float) (s - 8 * sxs) * ((float) fr.dw[f][p] * da);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // The same Q4_0 x Q8_0 row products as gemv_q4_rows_kernel (identical per-feature arithmetic: lane -> block mapping, fp32 accumulation order,
 // wave reduction), scheduled for the load path: that kernel issues five load instructions per 16 bytes of weights (codes, block scale,
 // two activation vectors, activation scale — the last three are the same for every feature but still go through the CU's address /
@@ -185,12 +242,19 @@ __global__ __launch_bounds__(256) void gemv_q4_rows_kernel(QGemmArgs qa, const u
 // QSRC 1: the activations arrive as fp32 rows (a.A, lda == K) and are Q8_0-quantised while they are staged — ggml's quantize_row_q8_0_ref
 // arithmetic, identical to quant_rows_q8_kernel / q8_block_store (d = amax / 127 kept as fp16, q = roundf(x / d)) — one 32-value block per
 // thread and pass; saves the producer a separate quantisation (the silu * up product of gemv_q4_gateup_silu_kernel feeds the down projection).
-template <int NR, int FPW, int QSRC = 0>
+template <int NR, int FPW, int QSRC = 0, int NP = 2>
 __global__ __launch_bounds__(256) void gemv_q4_rows_lds_kernel(QGemmArgs qa, const uint8_t *w4, int epi) {
     extern __shared__ __attribute__((aligned(16))) char gq_sm[];
     const GemmArgs &a = qa.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, nb = K >> 5, R = a.R;
+    // this wave's weights first: the loads fly while the workgroup stages (and quantises) the activation rows
+    const int n0 = ((int) blockIdx.x * 4 + wave) * FPW;
+    int nf[FPW];
+#pragma unroll
+    for (int f = 0; f < FPW; f++) nf[f] = min(n0 + f, a.N - 1);
+    Q4Frag<FPW, NP> fr;
+    q4_frag_load<FPW, NP>(fr, w4, qa.wd, nf, K, nb, 0, lane);
     int8_t *sx = (int8_t *) gq_sm;                       // [R][K]
     float *sd = (float *) (gq_sm + (size_t) R * K);      // [R][nb]
     if (QSRC == 0) {
@@ -224,48 +288,17 @@ __global__ __launch_bounds__(256) void gemv_q4_rows_lds_kernel(QGemmArgs qa, con
         }
     }
     __syncthreads();
-    const int n0 = ((int) blockIdx.x * 4 + wave) * FPW;
-    if (n0 >= a.N) return;
     float acc[FPW][NR];
 #pragma unroll
     for (int f = 0; f < FPW; f++)
 #pragma unroll
         for (int r = 0; r < NR; r++) acc[f][r] = 0.0f;
-#pragma unroll 2
-    for (int b = lane; b < nb; b += 64) {
-        int4v wn[FPW];
-        float dw[FPW];
-#pragma unroll
-        for (int f = 0; f < FPW; f++) {
-            const int n = min(n0 + f, a.N - 1);
-            wn[f] = *(const int4v *) (w4 + (int64_t) n * (K >> 1) + b * 16);
-            dw[f] = (float) qa.wd[(int64_t) n * nb + b];
-        }
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            if (r < R) {
-                const int4v x0 = *(const int4v *) (sx + (size_t) r * K + b * 32), x1 = *(const int4v *) (sx + (size_t) r * K + b * 32 + 16);
-                const float da = sd[r * nb + b];
-                int sxs = 0;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    sxs = __builtin_amdgcn_sdot4(0x01010101, x0[e], sxs, false);
-                    sxs = __builtin_amdgcn_sdot4(0x01010101, x1[e], sxs, false);
-                }
-#pragma unroll
-                for (int f = 0; f < FPW; f++) {
-                    int s = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int lo = wn[f][e] & 0x0F0F0F0F, hi = (wn[f][e] >> 4) & 0x0F0F0F0F;
-                        s = __builtin_amdgcn_sdot4(lo, x0[e], s, false);
-                        s = __builtin_amdgcn_sdot4(hi, x1[e], s, false);
-                    }
-                    acc[f][r] += (float) (s - 8 * sxs) * (dw[f] * da);
-                }
-            }
-        }
+    q4_frag_dot<FPW, NP, NR>(fr, sx, sd, R, K, nb, 0, lane, acc);
+    for (int b0 = 64 * NP; b0 < nb; b0 += 64 * NP) {   // rows longer than 2048 NP values (none at the Orpheus shapes with the NP the host picks)
+        q4_frag_load<FPW, NP>(fr, w4, qa.wd, nf, K, nb, b0, lane);
+        q4_frag_dot<FPW, NP, NR>(fr, sx, sd, R, K, nb, b0, lane, acc);
     }
+    if (n0 >= a.N) return;
 #pragma unroll
     for (int f = 0; f < FPW; f++) {
         const int n = n0 + f;
@@ -302,11 +335,13 @@ __device__ __forceinline__ void stage_rms_q8(const RmsSrc &rs, int R, int H, int
     const int tid = threadIdx.x;
     for (int r = 0; r < R; r++) {
         const float *xr = rs.x + (int64_t) r * H;
+        // straight-line loads with clamped indices (a chunk beyond the row re-reads its last element and is never used): under `if (i < H)` every
+        // chunk was its own basic block with a full s_waitcnt in front — 12 dependent L2 round trips for a 3072-wide row, most of this prologue
         float v[16], wv[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const int i = tid + k * 256;
-            if (i < H) { v[k] = xr[i]; wv[k] = rs.w[i]; }
+            const int i = min(tid + k * 256, H - 1);
+            v[k] = xr[i]; wv[k] = rs.w[i];
         }
         float s = 0.0f;
 #pragma unroll
@@ -333,12 +368,20 @@ struct RopeEpi {
     int NH, NKV;
     float *kcache, *vcache;   // this layer: [n_ctx][NKV * 128]
 };
-template <int NR, int QSRC = 0>
+template <int NR, int QSRC = 0, int NP = 2>
 __global__ __launch_bounds__(256) void gemv_q4_qkv_rope_kernel(QGemmArgs qa, const uint8_t *w4, RopeEpi re, RmsSrc rs = RmsSrc{}) {
     extern __shared__ __attribute__((aligned(16))) char gq_sm[];
     const GemmArgs &a = qa.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, nb = K >> 5, R = a.R;
+    // this wave's weights first (rotation pair p = features i and i + 64 of one head): the loads fly under the rms norm
+    const int p = (int) blockIdx.x * 4 + wave;
+    const bool active = p * 2 < a.N;
+    const int pc = active ? p : 0;
+    const int head = pc >> 6, i = pc & 63;
+    const int nf[2] = {head * 128 + i, head * 128 + i + 64};
+    Q4Frag<2, NP> fr;
+    q4_frag_load<2, NP>(fr, w4, qa.wd, nf, K, nb, 0, lane);
     int8_t *sx = (int8_t *) gq_sm;
     float *sd = (float *) (gq_sm + (size_t) R * K);
     if (QSRC == 2) {
@@ -348,49 +391,17 @@ __global__ __launch_bounds__(256) void gemv_q4_qkv_rope_kernel(QGemmArgs qa, con
         for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
         __syncthreads();
     }
-    const int p = (int) blockIdx.x * 4 + wave;      // rotation pair
-    if (p * 2 >= a.N) return;
-    const int head = p >> 6, i = p & 63;
-    const int nf[2] = {head * 128 + i, head * 128 + i + 64};
     float acc[2][NR];
 #pragma unroll
     for (int f = 0; f < 2; f++)
 #pragma unroll
         for (int r = 0; r < NR; r++) acc[f][r] = 0.0f;
-#pragma unroll 2
-    for (int b = lane; b < nb; b += 64) {
-        int4v wn[2];
-        float dw[2];
-#pragma unroll
-        for (int f = 0; f < 2; f++) {
-            wn[f] = *(const int4v *) (w4 + (int64_t) nf[f] * (K >> 1) + b * 16);
-            dw[f] = (float) qa.wd[(int64_t) nf[f] * nb + b];
-        }
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            if (r < R) {
-                const int4v x0 = *(const int4v *) (sx + (size_t) r * K + b * 32), x1 = *(const int4v *) (sx + (size_t) r * K + b * 32 + 16);
-                const float da = sd[r * nb + b];
-                int sxs = 0;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    sxs = __builtin_amdgcn_sdot4(0x01010101, x0[e], sxs, false);
-                    sxs = __builtin_amdgcn_sdot4(0x01010101, x1[e], sxs, false);
-                }
-#pragma unroll
-                for (int f = 0; f < 2; f++) {
-                    int s = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int lo = wn[f][e] & 0x0F0F0F0F, hi = (wn[f][e] >> 4) & 0x0F0F0F0F;
-                        s = __builtin_amdgcn_sdot4(lo, x0[e], s, false);
-                        s = __builtin_amdgcn_sdot4(hi, x1[e], s, false);
-                    }
-                    acc[f][r] += (float) (s - 8 * sxs) * (dw[f] * da);
-                }
-            }
-        }
+    q4_frag_dot<2, NP, NR>(fr, sx, sd, R, K, nb, 0, lane, acc);
+    for (int b0 = 64 * NP; b0 < nb; b0 += 64 * NP) {
+        q4_frag_load<2, NP>(fr, w4, qa.wd, nf, K, nb, b0, lane);
+        q4_frag_dot<2, NP, NR>(fr, sx, sd, R, K, nb, b0, lane, acc);
     }
+    if (!active) return;
     const int kvH = re.NKV * 128;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
@@ -425,12 +436,26 @@ __global__ __launch_bounds__(256) void gemv_q4_qkv_rope_kernel(QGemmArgs qa, con
 // wave owning rows i, i + 1 of gate and rows F + i, F + i + 1 of up (the stacked [gate; up] matrix), so that lane 0 holds both factors of
 // two outputs once the wave sums are done; g [R][F] fp32 goes to the down projection, which quantises it while staging (QSRC 1) —
 // silu_mul_kernel's arithmetic, one launch less per layer.
-template <int NR, int QSRC = 0>
+template <int NR, int QSRC = 0, int NP = 2>
 __global__ __launch_bounds__(256) void gemv_q4_gateup_silu_kernel(QGemmArgs qa, const uint8_t *w4, int F, float *gout, RmsSrc rs = RmsSrc{}) {
     extern __shared__ __attribute__((aligned(16))) char gq_sm[];
     const GemmArgs &a = qa.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, nb = K >> 5, R = a.R;
+    // A wave walks items (rows i, i + 1 of gate and of up) item, item + n_waves, ...: the host launches at most two workgroups per CU, all of them
+    // resident from the start, so the staging prologue (rms norm + Q8_0 blocks: every workgroup normalises the row itself) runs once per
+    // workgroup and never in a second round of workgroups behind the first (1024 one-item workgroups at 170 registers ran as two rounds: 19.7 us).
+    // The weights of the next item are requested before the current one is consumed; the first item's fly under the prologue.
+    const int n_items = (F + 1) / 2, n_waves = (int) gridDim.x * 4;
+    int item = (int) blockIdx.x * 4 + wave;
+    auto rows_of = [&](int it, int (&nf)[4]) __attribute__((always_inline)) {
+        const int i0 = min(2 * it, F - 1), i1 = min(i0 + 1, F - 1);
+        nf[0] = i0; nf[1] = i1; nf[2] = F + i0; nf[3] = F + i1;
+    };
+    int nfa[4], nfb[4];
+    Q4Frag<4, NP> fa, fb;
+    rows_of(min(item, n_items - 1), nfa);
+    q4_frag_load<4, NP>(fa, w4, qa.wd, nfa, K, nb, 0, lane);
     int8_t *sx = (int8_t *) gq_sm;
     float *sd = (float *) (gq_sm + (size_t) R * K);
     if (QSRC == 2) {
@@ -440,57 +465,36 @@ __global__ __launch_bounds__(256) void gemv_q4_gateup_silu_kernel(QGemmArgs qa, 
         for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
         __syncthreads();
     }
-    const int i0 = ((int) blockIdx.x * 4 + wave) * 2;
-    if (i0 >= F) return;
-    const int i1 = min(i0 + 1, F - 1);
-    const int nf[4] = {i0, i1, F + i0, F + i1};
-    float acc[4][NR];
+    auto finish = [&](Q4Frag<4, NP> &fr, const int (&nf)[4], int it) __attribute__((always_inline)) {
+        float acc[4][NR];
 #pragma unroll
-    for (int f = 0; f < 4; f++)
+        for (int f = 0; f < 4; f++)
 #pragma unroll
-        for (int r = 0; r < NR; r++) acc[f][r] = 0.0f;
-#pragma unroll 2
-    for (int b = lane; b < nb; b += 64) {
-        int4v wn[4];
-        float dw[4];
-#pragma unroll
-        for (int f = 0; f < 4; f++) {
-            wn[f] = *(const int4v *) (w4 + (int64_t) nf[f] * (K >> 1) + b * 16);
-            dw[f] = (float) qa.wd[(int64_t) nf[f] * nb + b];
+            for (int r = 0; r < NR; r++) acc[f][r] = 0.0f;
+        q4_frag_dot<4, NP, NR>(fr, sx, sd, R, K, nb, 0, lane, acc);
+        for (int b0 = 64 * NP; b0 < nb; b0 += 64 * NP) {
+            q4_frag_load<4, NP>(fr, w4, qa.wd, nf, K, nb, b0, lane);
+            q4_frag_dot<4, NP, NR>(fr, sx, sd, R, K, nb, b0, lane, acc);
         }
+        const int i0 = 2 * it;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             if (r < R) {
-                const int4v x0 = *(const int4v *) (sx + (size_t) r * K + b * 32), x1 = *(const int4v *) (sx + (size_t) r * K + b * 32 + 16);
-                const float da = sd[r * nb + b];
-                int sxs = 0;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    sxs = __builtin_amdgcn_sdot4(0x01010101, x0[e], sxs, false);
-                    sxs = __builtin_amdgcn_sdot4(0x01010101, x1[e], sxs, false);
-                }
-#pragma unroll
-                for (int f = 0; f < 4; f++) {
-                    int s = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int lo = wn[f][e] & 0x0F0F0F0F, hi = (wn[f][e] >> 4) & 0x0F0F0F0F;
-                        s = __builtin_amdgcn_sdot4(lo, x0[e], s, false);
-                        s = __builtin_amdgcn_sdot4(hi, x1[e], s, false);
-                    }
-                    acc[f][r] += (float) (s - 8 * sxs) * (dw[f] * da);
+                const float g0 = wave_sum(acc[0][r]), g1 = wave_sum(acc[1][r]), u0 = wave_sum(acc[2][r]), u1 = wave_sum(acc[3][r]);
+                if (lane == 0) {
+                    gout[(int64_t) r * F + i0] = (g0 / (1.0f + expf(-g0))) * u0;
+                    if (i0 + 1 < F) gout[(int64_t) r * F + i0 + 1] = (g1 / (1.0f + expf(-g1))) * u1;
                 }
             }
         }
-    }
-#pragma unroll
-    for (int r = 0; r < NR; r++) {
-        if (r < R) {
-            const float g0 = wave_sum(acc[0][r]), g1 = wave_sum(acc[1][r]), u0 = wave_sum(acc[2][r]), u1 = wave_sum(acc[3][r]);
-            if (lane == 0) {
-                gout[(int64_t) r * F + i0] = (g0 / (1.0f + expf(-g0))) * u0;
-                if (i0 + 1 < F) gout[(int64_t) r * F + i0 + 1] = (g1 / (1.0f + expf(-g1))) * u1;
-            }
-        }
+    };
+    while (item < n_items) {
+        const int nxt = item + n_waves;
+        if (nxt < n_items) { rows_of(nxt, nfb); q4_frag_load<4, NP>(fb, w4, qa.wd, nfb, K, nb, 0, lane); }
+        finish(fa, nfa, item);
+        if (nxt >= n_items) break;
+        item = nxt + n_waves;
+        if (item < n_items) { rows_of(item, nfa); q4_frag_load<4, NP>(fa, w4, qa.wd, nfa, K, nb, 0, lane); }
+        finish(fb, nfb, nxt);
     }
 }

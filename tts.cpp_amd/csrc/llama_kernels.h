@@ -15,9 +15,7 @@
 // Q8_0 block of 32 consecutive values held one per lane by 32 neighbouring lanes (ggml's quantize_row_q8_0_ref: d = amax / 127 kept
 // as fp16, q = roundf(x / d)) — the same arithmetic as quant_rows_q8_kernel, for producers that quantise their own output row.
 __device__ __forceinline__ void q8_block_store(float v, int64_t idx, int8_t *aq, float *ad) {
-    float amax = fabsf(v);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float amax = lanes32_max(fabsf(v));
     const float dd = amax / 127.0f;
     const float id = dd ? 1.0f / dd : 0.0f;
     aq[idx] = (int8_t) roundf(v * id);
@@ -213,6 +211,59 @@ __device__ __forceinline__ void attn_load_q(float *qs, const float *q, int r, co
         __syncthreads();
     }
 }
+// The two key passes of the decode attention with their loads in batches of 64 keys: every lane requests the rows of its 4 (scores) / 8 (P.V)
+// keys of a batch back to back — clamped indices, nothing under a predicate — and only then computes.  One dependent round trip per 64 keys
+// instead of one per 16 (scores) / 8 (P.V) keys: a 40-key slice of a split took 3 + 5 round trips (15-18 us per launch at the Orpheus-3B shapes,
+// profiles/r04/kernel_stats_orpheus_baseline.csv).  Key -> lane group and the order of every sum are the ones of round 3 (key j: group j % 16 of
+// the score pass, group j % 8 of the P.V pass, keys ascending inside a group; row16_sum reproduces the xor butterfly), so results are unchanged.
+template <int HD>
+__device__ __forceinline__ void attn_v_batch(float4 (&v)[8], const float *vbase, int kvH, int T, int j0, int tid) {
+    const int grp = tid >> 5, e4 = tid & 31;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int j = max(0, min(j0 + grp + 8 * u, T - 1));
+        v[u] = *(const float4 *) (vbase + (int64_t) j * kvH + e4 * 4);
+    }
+}
+template <int HD>
+__device__ __forceinline__ void attn_scores_batched(const float *kbase, int kvH, int T, const float *qs, float scale, float *ps, int tid) {
+    const int g = tid >> 4, sub = tid & 15;
+    const float4 q0 = *(const float4 *) (qs + sub * 4), q1 = *(const float4 *) (qs + 64 + sub * 4);
+    for (int j0 = 0; j0 < T; j0 += 64) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = max(0, min(j0 + g + 16 * u, T - 1));
+            const float4 *kr = (const float4 *) (kbase + (int64_t) j * kvH);
+            a[u] = kr[sub]; b[u] = kr[16 + sub];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + g + 16 * u;
+            float d = (a[u].x * q0.x + a[u].y * q0.y + a[u].z * q0.z + a[u].w * q0.w) + (b[u].x * q1.x + b[u].y * q1.y + b[u].z * q1.z + b[u].w * q1.w);
+            d = row16_sum(d);
+            if (sub == 0 && j < T) ps[j] = d * scale;
+        }
+    }
+}
+template <int HD>
+__device__ __forceinline__ float4 attn_pv_batched(float4 (&v)[8], const float *vbase, int kvH, int T, const float *ps, int tid) {   // v: the first batch, already requested
+    const int grp = tid >> 5;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int j0 = 0; j0 < T; j0 += 64) {
+        if (j0) attn_v_batch<HD>(v, vbase, kvH, T, j0, tid);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = j0 + grp + 8 * u;
+            if (j < T) {
+                const float p = ps[j];
+                acc.x += p * v[u].x; acc.y += p * v[u].y; acc.z += p * v[u].z; acc.w += p * v[u].w;
+            }
+        }
+    }
+    return acc;
+}
+
 // Keys [kbeg[r], kend[r]) of the row's sequence (defaults: 0 and pos[r] + 1 = causal over the cache); row_seq / seq_stride as above.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld, const uint32_t *pos, const float *kcache, const float *vcache, int NH, int NKV,
@@ -229,25 +280,10 @@ __global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld,
     if (row_seq) { kcache += (int64_t) row_seq[r] * seq_stride; vcache += (int64_t) row_seq[r] * seq_stride; }
     kcache += (int64_t) k0 * kvH;
     vcache += (int64_t) k0 * kvH;
+    float4 vfirst[8];                                    // the value rows of the first 64 keys do not depend on the scores: requested up front
+    attn_v_batch<HD>(vfirst, vcache + kh * HD, kvH, T, 0, tid);
     attn_load_q<HD>(qs, qkv + (int64_t) r * ld + h * HD, r, qp, tid);
-    {
-        const int g = tid >> 4, sub = tid & 15;
-        const float4 q0 = *(const float4 *) (qs + sub * 4), q1 = *(const float4 *) (qs + 64 + sub * 4);
-        for (int j0 = 0; j0 < T; j0 += 16) {   // uniform trip count: every lane takes part in the shuffles
-            const int j = j0 + g;
-            float d = 0.0f;
-            if (j < T) {
-                const float4 *kr = (const float4 *) (kcache + (int64_t) j * kvH + kh * HD);
-                const float4 a = kr[sub], b = kr[16 + sub];
-                d = (a.x * q0.x + a.y * q0.y + a.z * q0.z + a.w * q0.w) + (b.x * q1.x + b.y * q1.y + b.z * q1.z + b.w * q1.w);
-            }
-            d += __shfl_xor(d, 8);
-            d += __shfl_xor(d, 4);
-            d += __shfl_xor(d, 2);
-            d += __shfl_xor(d, 1);
-            if (sub == 0 && j < T) ps[j] = d * scale;
-        }
-    }
+    attn_scores_batched<HD>(kcache + kh * HD, kvH, T, qs, scale, ps, tid);
     __syncthreads();
     float mx = -INFINITY;
     for (int j = tid; j < T; j += 256) mx = fmaxf(mx, ps[j]);
@@ -265,16 +301,7 @@ __global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld,
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();   // probabilities and the four partial sums are in LDS
     const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
-    {
-        const int grp = tid >> 5, e4 = tid & 31;
-        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        for (int j = grp; j < T; j += 8) {
-            const float p = ps[j];
-            const float4 v = *(const float4 *) (vcache + (int64_t) j * kvH + kh * HD + e4 * 4);
-            acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w;
-        }
-        accs[grp][e4] = acc;
-    }
+    accs[tid >> 5][tid & 31] = attn_pv_batched<HD>(vfirst, vcache + kh * HD, kvH, T, ps, tid);
     __syncthreads();
     if (tid < HD) {
         const float *a = (const float *) &accs[0][0];
@@ -313,25 +340,10 @@ __global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, i
     if (row_seq) { kcache += (int64_t) row_seq[r] * seq_stride; vcache += (int64_t) row_seq[r] * seq_stride; }
     kcache += (int64_t) k0 * kvH;
     vcache += (int64_t) k0 * kvH;
+    float4 vfirst[8];                                    // the value rows of the first 64 keys do not depend on the scores: requested up front
+    attn_v_batch<HD>(vfirst, vcache + kh * HD, kvH, T, 0, tid);
     attn_load_q<HD>(qs, qkv + (int64_t) r * ld + h * HD, r, qp, tid);
-    {
-        const int g = tid >> 4, sub = tid & 15;
-        const float4 q0 = *(const float4 *) (qs + sub * 4), q1 = *(const float4 *) (qs + 64 + sub * 4);
-        for (int j0 = 0; j0 < T; j0 += 16) {
-            const int j = j0 + g;
-            float d = 0.0f;
-            if (j < T) {
-                const float4 *kr = (const float4 *) (kcache + (int64_t) j * kvH + kh * HD);
-                const float4 a = kr[sub], b = kr[16 + sub];
-                d = (a.x * q0.x + a.y * q0.y + a.z * q0.z + a.w * q0.w) + (b.x * q1.x + b.y * q1.y + b.z * q1.z + b.w * q1.w);
-            }
-            d += __shfl_xor(d, 8);
-            d += __shfl_xor(d, 4);
-            d += __shfl_xor(d, 2);
-            d += __shfl_xor(d, 1);
-            if (sub == 0 && j < T) ps[j] = d * scale;
-        }
-    }
+    attn_scores_batched<HD>(kcache + kh * HD, kvH, T, qs, scale, ps, tid);
     __syncthreads();
     float mx = -INFINITY;
     for (int j = tid; j < T; j += 256) mx = fmaxf(mx, ps[j]);
@@ -348,16 +360,7 @@ __global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, i
     sum = wave_sum(sum);
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
-    {
-        const int grp = tid >> 5, e4 = tid & 31;
-        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        for (int j = grp; j < T; j += 8) {
-            const float p = ps[j];
-            const float4 v = *(const float4 *) (vcache + (int64_t) j * kvH + kh * HD + e4 * 4);
-            acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w;
-        }
-        accs[grp][e4] = acc;
-    }
+    accs[tid >> 5][tid & 31] = attn_pv_batched<HD>(vfirst, vcache + kh * HD, kvH, T, ps, tid);
     __syncthreads();
     if (tid < HD) {
         const float *a = (const float *) &accs[0][0];

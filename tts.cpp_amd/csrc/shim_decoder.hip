@@ -314,7 +314,9 @@ int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int e
         const size_t q4_lds = (size_t) a.R * a.K + (size_t) a.R * (a.K / 32) * 4;
         if (w.q4 && c->q4_lds && q4_lds <= 64 * 1024 && a.K % 512 == 0) {
             // activations in LDS, 2 or 4 features per wave (gemv_q4_rows_lds_kernel): fewer load instructions per weight byte
+            // NP = passes of 64 blocks a wave requests in one batch: 2 covers K <= 4096, 4 covers K <= 8192
             if (a.N >= 8192) hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 4>), dim3((a.N + 15) / 16), dim3(256), q4_lds, c->stream, qa, w.q4, epi);
+            else if (a.K > 4096) hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 2, 0, 4>), dim3((a.N + 7) / 8), dim3(256), q4_lds, c->stream, qa, w.q4, epi);
             else hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 2>), dim3((a.N + 7) / 8), dim3(256), q4_lds, c->stream, qa, w.q4, epi);
         } else if (w.q4) hipLaunchKernelGGL(gemv_q4_rows_kernel<4>, dim3((a.N + 3) / 4), dim3(256), 0, c->stream, qa, w.q4, epi);
         else hipLaunchKernelGGL(gemv_q8_rows_kernel<4>, dim3((a.N + 3) / 4), dim3(256), 0, c->stream, qa, epi);

@@ -157,14 +157,15 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
         if (gu_fused) {
             // gate | up with silu * up in the epilogue, then the down projection quantising that product while it stages it: two launches
             // instead of three (gemv_q4_gateup_silu_kernel, gemv_q4_rows_lds_kernel<.., QSRC 1>)
+            const int gu_grid = std::min((F / 2 + 3) / 4, 512);   // two resident workgroups per CU; a wave walks its items (gemv_q4_gateup_silu_kernel)
             QGemmArgs qa{};
             qa.g.W = c->arena + y.gu.off; qa.g.K = H; qa.g.N = 2 * F; qa.g.R = n;
             qa.wd = (const _Float16 *) (c->arena + y.gu.soff); qa.aq = c->aq; qa.ad = c->ad;
             if (rms_fused) {
                 RmsSrc rs{c->l_x, f32(y.post_norm), 1e-5f};
-                hipLaunchKernelGGL((gemv_q4_gateup_silu_kernel<4, 2>), dim3((F / 2 + 3) / 4), dim3(256), gu_lds + 16, c->stream, qa, y.gu.q4, F, c->l_g, rs);
+                hipLaunchKernelGGL((gemv_q4_gateup_silu_kernel<4, 2>), dim3(gu_grid), dim3(256), gu_lds + 16, c->stream, qa, y.gu.q4, F, c->l_g, rs);
             } else {
-                hipLaunchKernelGGL(gemv_q4_gateup_silu_kernel<4>, dim3((F / 2 + 3) / 4), dim3(256), gu_lds, c->stream, qa, y.gu.q4, F, c->l_g);
+                hipLaunchKernelGGL(gemv_q4_gateup_silu_kernel<4>, dim3(gu_grid), dim3(256), gu_lds, c->stream, qa, y.gu.q4, F, c->l_g);
             }
             HIPCHK(hipGetLastError());
             c->aq_src = nullptr;
@@ -172,9 +173,12 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
             qd.g.W = c->arena + y.down.off; qd.g.K = F; qd.g.N = H; qd.g.R = n; qd.g.A = c->l_g; qd.g.lda = F; qd.g.out = c->l_x; qd.g.ldo = H;
             qd.wd = (const _Float16 *) (c->arena + y.down.soff);
             static std::atomic<uint64_t> attr{0};
-            if (attr_needed(attr, c->device))
-                HIPCHK(hipFuncSetAttribute((const void *) gemv_q4_rows_lds_kernel<4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 2, 1>), dim3((H + 7) / 8), dim3(256), dn_lds, c->stream, qd, y.down.q4, (int) EPI_RESID);
+            if (attr_needed(attr, c->device)) {
+                HIPCHK(hipFuncSetAttribute((const void *) gemv_q4_rows_lds_kernel<4, 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIPCHK(hipFuncSetAttribute((const void *) gemv_q4_rows_lds_kernel<4, 2, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
+            if (F > 4096) hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 2, 1, 4>), dim3((H + 7) / 8), dim3(256), dn_lds, c->stream, qd, y.down.q4, (int) EPI_RESID);
+            else hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 2, 1, 2>), dim3((H + 7) / 8), dim3(256), dn_lds, c->stream, qd, y.down.q4, (int) EPI_RESID);
             HIPCHK(hipGetLastError());
             continue;
         }

@@ -45,6 +45,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return row16_max(v);
 }
 
+// max over aligned groups of 32 lanes (a Q8_0 block held one value per lane): the xor-16 step as v_permlane16_swap, the rest inside the rows by DPP.
+// A maximum does not depend on the order of the comparisons: the same value as the five-step __shfl_xor butterfly (five ds_bpermute round trips).
+__device__ __forceinline__ float lanes32_max(float v) {
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+    v = fmaxf(__builtin_bit_cast(float, (unsigned) b[0]), __builtin_bit_cast(float, (unsigned) b[1]));
+    return row16_max(v);
+}
+
 // ggml_gelu.  mode 1 restates ggml's CPU path, which evaluates GELU through a table indexed by the
 // fp16 bits of x and holding fp16 results (upstream ggml_vec_gelu_f32 / GGML_GELU_FP16): a table is
 // memoisation, so rounding x to fp16, evaluating in fp32 and rounding the result to fp16 is the
