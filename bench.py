@@ -245,6 +245,36 @@ def self_launch(n):
     os.execv(sys.executable, cmd)
 
 
+def broadcast_arena_ctx(L, ctx, rank, world, local_rank, backend, dist, torch):
+    """The path's one collective: rank 0's finished weight arena (weights + precomputed tables) to every rank's declare-only context, through the
+    C ABI (tts_hip_comm_unique_id + tts_hip_broadcast_weights_rank: RCCL over xGMI) — or through torch.distributed under the CPU-collective test
+    hook (several ranks on one device, where RCCL cannot form a communicator).  Any model family: the arena is just bytes."""
+    nbytes = int(L.tts_hip_arena_bytes(ctx))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if backend == "nccl":
+        # rank 0 mints the communicator id, every rank joins with its own context
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0 and L.tts_hip_comm_unique_id(ident.numpy().ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError(L.tts_hip_last_error().decode())
+        ident = ident.cuda(local_rank)
+        dist.broadcast(ident, src=0)
+        ident = ident.cpu()
+        if L.tts_hip_broadcast_weights_rank(ctx, ident.numpy().ctypes.data_as(C.c_void_p), rank, world, 0) != 0:
+            raise RuntimeError(L.tts_hip_last_error().decode())
+        via = "tts_hip_comm_unique_id + tts_hip_broadcast_weights_rank (RCCL, C ABI)"
+    else:
+        arena = torch.as_tensor(ArenaView(L.tts_hip_arena_ptr(ctx), nbytes), device=f"cuda:{local_rank}")
+        tdist.broadcast_arena(arena, src=0)
+        torch.cuda.synchronize()
+        if rank != 0 and L.tts_hip_arena_filled(ctx) != 0:
+            raise RuntimeError(L.tts_hip_last_error().decode())
+        via = f"torch.distributed.broadcast ({backend})"
+    torch.cuda.synchronize()
+    dist.barrier()
+    return {"bytes": nbytes, "ms": round((time.perf_counter() - t0) * 1e3, 2), "via": via}
+
+
 def load_runners(path, args, rank, world, local_rank, backend, dist, torch, gen_cfg, batch):
     """`--streams` runners on this rank's device with ONE weight arena per rank: the first runner loads the file (rank 0) or is laid out
     declare-only and filled by the RCCL broadcast (other ranks); the others share its arena."""
@@ -252,31 +282,7 @@ def load_runners(path, args, rank, world, local_rank, backend, dist, torch, gen_
     info = None
     first = runner.Runner(path, device=local_rank, max_seqs=batch, declare_only=(rank != 0), **gen_cfg)
     if world > 1:
-        ctx = first.device_context()
-        nbytes = int(L.tts_hip_arena_bytes(ctx))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        if backend == "nccl":
-            # the C ABI's collective: rank 0 mints the communicator id, every rank joins with its own context
-            ident = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0 and L.tts_hip_comm_unique_id(ident.numpy().ctypes.data_as(C.c_void_p)) != 0:
-                raise RuntimeError(L.tts_hip_last_error().decode())
-            ident = ident.cuda(local_rank)
-            dist.broadcast(ident, src=0)
-            ident = ident.cpu()
-            if L.tts_hip_broadcast_weights_rank(ctx, ident.numpy().ctypes.data_as(C.c_void_p), rank, world, 0) != 0:
-                raise RuntimeError(L.tts_hip_last_error().decode())
-            via = "tts_hip_comm_unique_id + tts_hip_broadcast_weights_rank (RCCL, C ABI)"
-        else:   # CPU-collective test hook (gloo; several ranks on one device, where RCCL cannot form a communicator)
-            arena = torch.as_tensor(ArenaView(L.tts_hip_arena_ptr(ctx), nbytes), device=f"cuda:{local_rank}")
-            tdist.broadcast_arena(arena, src=0)
-            torch.cuda.synchronize()
-            if rank != 0 and L.tts_hip_arena_filled(ctx) != 0:
-                raise RuntimeError(L.tts_hip_last_error().decode())
-            via = f"torch.distributed.broadcast ({backend})"
-        torch.cuda.synchronize()
-        dist.barrier()
-        info = {"bytes": nbytes, "ms": round((time.perf_counter() - t0) * 1e3, 2), "via": via}
+        info = broadcast_arena_ctx(L, first.device_context(), rank, world, local_rank, backend, dist, torch)
     runners = [first]
     for _ in range(1, args.streams):
         runners.append(runner.Runner(path, device=local_rank, max_seqs=batch, share_with=first, **gen_cfg))
@@ -473,13 +479,8 @@ def main():
                     help="GGUF type of the decoder matrices (headline: f16; q*: integer path with Q8_0 activations)")
     args = ap.parse_args()
 
-    if args.workload != "parler":
-        sys.path.insert(0, os.path.join(ROOT, "profiles"))
-        import secondary_bench
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus > 1:
-            raise SystemExit("--workload dia/orpheus/kokoro measure one GPU's share; run them with --gpus 1")
-        print(json.dumps(secondary_bench.RUNNERS[args.workload](args)), flush=True)
-        return
+    if args.workload in ("orpheus", "kokoro") and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus > 1):
+        raise SystemExit("--workload orpheus / kokoro are single-utterance configurations of BASELINE.json (configs[4] / [2]: 1 x MI355X); run them with --gpus 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
@@ -511,6 +512,24 @@ def main():
         import torch.distributed as dist
 
         tdist.init(backend, rank, world, device=torch.device("cuda", local_rank))
+
+    if args.workload != "parler":
+        # BASELINE configs[2] / [3] / [4] through the C ABI engines (profiles/secondary_bench.py: same JSON contract).  Dia is the one that shards:
+        # configs[3] = batch 32 over 8 GPUs = 4 utterances x 2 guidance rows per rank, rank 0's arena broadcast like the headline's.
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        import secondary_bench
+        ranks = None
+        if world > 1:
+            ranks = dict(rank=rank, world=world, local_rank=local_rank, backend=backend, dist=dist, torch=torch,
+                         broadcast=lambda ctx: broadcast_arena_ctx(hip.load_lib(), ctx, rank, world, local_rank, backend, dist, torch),
+                         reduce=lambda el, units: tdist.reduce_timing(el, units, device=f"cuda:{local_rank}"))
+        line = secondary_bench.RUNNERS[args.workload](args, ranks) if args.workload == "dia" else secondary_bench.RUNNERS[args.workload](args)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     mk = {"mini": synth.parler_mini, "small": synth.small, "tiny": synth.tiny}[args.model]
     wt = {"f16": gguf.F16, "f32": gguf.F32, "q8_0": gguf.Q8_0, "q5_0": gguf.Q5_0, "q4_0": gguf.Q4_0}[args.wtype]

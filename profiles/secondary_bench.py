@@ -83,27 +83,32 @@ def dia_tensors(cfg, rng):
     return tensors, n_dec[0]
 
 
-def run_dia(args):
+def run_dia(args, ranks=None):
+    """ranks (bench.py, --gpus N > 1): this process is one of N, one per GPU.  Utterance i -> rank i mod N, i.e. every rank decodes its own U
+    utterances; rank 0 uploads the matrices, the other ranks lay the same arena out declare-only and receive it by the one collective of the
+    path; timing = barrier, max over ranks; value = the utterances of all ranks / that time (weak scaling)."""
     U = 4
     steps = max(32, int(os.environ.get("TTS_BENCH_DIA_STEPS", "512")))
     cfg = synth.dia_1_6b(weight_type=gguf.F16)
     rng = np.random.default_rng(3)
     tensors, n_dec = dia_tensors(cfg, rng)
-    eng = hip.DiaEngine(cfg, device=0, max_utterances=U)
-    eng.load(_Model(cfg, tensors))
+    rank, world, dev = (ranks["rank"], ranks["world"], ranks["local_rank"]) if ranks else (0, 1, 0)
+    eng = hip.DiaEngine(cfg, device=dev, max_utterances=U)
+    eng.load(_Model(cfg, tensors), declare_only=rank != 0)
+    bcast = ranks["broadcast"](eng.ctx) if ranks else None
     toks = np.zeros(cfg.max_ctx, dtype=np.uint32)
     toks[:200] = rng.integers(32, 127, 200)
     A = cfg.dec_heads * cfg.head_dim
     # the codec: Dia decodes through the same 44.1 kHz DAC as Parler (dia/model.cpp:892-898); a codec-only context
     pm = synth.build(synth.parler_mini())
-    dac = hip.HipEngine(pm.cfg, device=0, max_seqs=1, flags=hip.FLAG_NO_PARLER)
+    dac = hip.HipEngine(pm.cfg, device=dev, max_seqs=1, flags=hip.FLAG_NO_PARLER)
     for t in pm.tensors:
         if t.name.startswith("audio_encoder."):
             dac.upload(t)
     dac.finalize()
     delay = np.array([0, 8, 9, 10, 11, 12, 13, 14, 15])   # dia/model.h:84
 
-    urng = np.random.default_rng(11)
+    urng = np.random.default_rng(11 + rank)
 
     def one_pass(n_steps):
         """4 sentences -> encoder + cross K/V per slot -> the generation loop on the device (tts_hip_dia_generate: check_stopping, guided step,
@@ -127,16 +132,27 @@ def run_dia(args):
     for _ in range(args.warmup):
         one_pass(24)
     enc_s, dec_s, dac_s = [], [], []
+
+    def barrier():
+        eng.synchronize()
+        if ranks:
+            ranks["torch"].cuda.synchronize()
+            ranks["dist"].barrier()
+
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         e, d, k = one_pass(steps)
         enc_s.append(e)
         dec_s.append(d)
         dac_s.append(k)
+    barrier()
     elapsed = time.perf_counter() - t0
     step_ms = float(np.mean(dec_s)) / (steps - 1) * 1e3
     frames = steps - 1 - 15                  # max_gen = steps -> steps - 1 sampler calls; un-delay drops max_delay steps (dia/model.cpp:787-808)
     audio_s = U * frames * 512 / 44100.0 * args.steps
+    if ranks:
+        elapsed, audio_s = ranks["reduce"](elapsed, audio_s)   # max over ranks, sum over ranks
     w_bytes = n_dec * 2
     ckv_bytes = cfg.dec_layers * 2 * cfg.max_ctx * A * 4 * 2
     # self-attention cache rows a step reads: fp32 K and V of the 4 k/v groups, positions 0..t of both guidance rows, t averaged over the loop
@@ -145,14 +161,16 @@ def run_dia(args):
     tot = w_bytes + U * (ckv_bytes + skv_bytes)
     out = {
         "metric": "audio-seconds/sec (Dia-1.6B fp16: encoder + guided decoder + DAC to 44.1 kHz PCM, lock-step utterances)",
-        "value": round(audio_s / elapsed, 3), "unit": "audio-seconds/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "value": round(audio_s / elapsed, 3), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
         "data": "synthetic (fp16 matrices = slices of one random pool; shapes of nari-labs/Dia-1.6B)",
         "config": {"workload": f"configs[3]: Dia-1.6B fp16, the per-GPU share of batch 32 over 8 GPUs = {U} utterances in lock-step x 2 guidance rows, "
                                f"200-character sentences (encoder over 2 x 1024 positions + cross K/V per utterance), max_generation_size {steps}: {steps - 1} guided decoder "
                                "steps with check_stopping, sampler::sample (top_k 50) and the delay-pattern feedback on the device (tts_hip_dia_generate), "
                                "un-delay, one batched DAC pass to PCM",
-                   "utterances_per_gpu": U, "rows_per_step": 2 * U, "decoder_steps": steps, "parallelism": "dp1 of dp8 (utterances are independent)"},
+                   "utterances_per_gpu": U, "utterances": U * world, "rows_per_step": 2 * U, "decoder_steps": steps,
+                   "parallelism": f"dp{world}" + (" of dp8" if world < 8 else "") + " (utterance i -> rank i mod N: one process per GPU, rank 0's weight arena broadcast over RCCL, no per-step collective)"},
+        "rccl_ranks": world, "weight_broadcast": bcast,
         "ms_per_decode_step": round(step_ms, 4), "encode_ms_per_utterance": round(float(np.mean(enc_s)) / U * 1e3, 2),
         "dac_ms_per_pass": round(float(np.mean(dac_s)) * 1e3, 2),
         "x_real_time_per_gpu": round(U / (step_ms * 1e-3) / 86.13, 2),

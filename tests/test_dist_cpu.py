@@ -55,9 +55,11 @@ def test_shard_is_round_robin():
     assert sum(len(tdist.shard_utterances(32, r, 8)) for r in range(8)) == 32
 
 
-def test_bench_gpus_n_starts_its_own_ranks():
+@pytest.mark.parametrize("workload", ["parler", "dia"])
+def test_bench_gpus_n_starts_its_own_ranks(workload):
     """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (rendezvous on 127.0.0.1); without the
-    single-device test hook it refuses to produce an n_gpus = 2 line on a box with fewer GPUs."""
+    single-device test hook it refuses to produce an n_gpus = 2 line on a box with fewer GPUs.  The same for `--workload dia` (BASELINE
+    configs[3]: batch 32 over 8 GPUs), which round 3 refused at N > 1; orpheus / kokoro are 1-GPU configurations and still say so."""
     import json
     import subprocess
     import sys
@@ -65,12 +67,15 @@ def test_bench_gpus_n_starts_its_own_ranks():
     env = dict(os.environ, TTS_BENCH_LAUNCH_ONLY="1", TTS_BENCH_DIST_BACKEND="gloo", TTS_BENCH_FORCE_DEVICE="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", workload]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d == {"launched_ranks": 2, "rank_sum": 1.0, "n_gpus": 2}
     import torch
     if torch.cuda.device_count() < 2:
         env.pop("TTS_BENCH_FORCE_DEVICE")
-        bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        bad = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
         assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)
+    single = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "orpheus"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert single.returncode != 0 and "--gpus 1" in (single.stderr + single.stdout)

@@ -358,6 +358,27 @@ def test_two_rank_bench_flow_on_one_gpu(tmp_path):
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - expect_audio_s) < 1e-3 * expect_audio_s
 
 
+def test_two_rank_dia_bench_flow_on_one_gpu():
+    """BASELINE configs[3] (Dia-1.6B fp16, batch 32 over 8 GPUs) must be producible at N > 1: `python bench.py --workload dia --gpus 2` with no
+    launcher starts its two ranks (both on cuda:0 through the test hooks, gloo transport), rank 1 lays the 1.6B arena out declare-only,
+    receives it by the broadcast and decodes its own four utterances; the line is the whole job's (weak scaling) and carries rank 0's roofline."""
+    import json
+    import sys
+    env = dict(os.environ, TTS_BENCH_FORCE_DEVICE="0", TTS_BENCH_DIST_BACKEND="gloo", TTS_BENCH_DIA_STEPS="32")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "dia", "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak"
+    assert d["weight_broadcast"]["bytes"] > 3e9 and d["config"]["utterances"] == 8
+    assert d["roofline"]["frac"] > 0
+    frames = 32 - 1 - 15
+    expect_audio_s = 2 * 4 * frames * 512 / 44100.0   # ranks x utterances
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - expect_audio_s) < 1e-3 * expect_audio_s
+
+
 def test_maximum_size_generation_and_decode():
     """Parler-Mini dims, one utterance to max_generation (2580 positions) on the device-resident loop, then the
     DAC on every frame: positions/caches/buffers at their maximum sizes; finite PCM in [-1, 1]."""

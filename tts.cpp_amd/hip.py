@@ -608,12 +608,16 @@ class DiaEngine:
         if rc != 0:
             raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
 
-    def load(self, model):
+    def load(self, model, declare_only=False):
+        """declare_only: lay the arena out without uploading (the bytes arrive by tts_hip_broadcast_weights_rank / tts_hip_arena_filled)"""
         for t in model.tensors:
             ne = (C.c_int64 * 4)(*(t.ne + [1] * (4 - len(t.ne))))
-            raw = np.frombuffer(bytes(t.raw()), dtype=np.uint8)
-            self._chk(self.L.tts_hip_upload(self.ctx, t.name.encode(), t.type, len(t.ne), ne, raw.ctypes.data_as(C.c_void_p)))
+            raw = None if declare_only else np.frombuffer(bytes(t.raw()), dtype=np.uint8)
+            self._chk(self.L.tts_hip_upload(self.ctx, t.name.encode(), t.type, len(t.ne), ne, None if declare_only else raw.ctypes.data_as(C.c_void_p)))
         self._chk(self.L.tts_hip_finalize(self.ctx, None))
+
+    def synchronize(self):
+        self._chk(self.L.tts_hip_synchronize(self.ctx))
 
     def encode(self, tokens, sentence_len, want_states=False):
         a, ap = _u32(tokens)
