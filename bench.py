@@ -225,6 +225,36 @@ def decode_step_sweep(cfg_full, model, arena_ptr, device):
                     "each interval continues the same utterance from the previous one; per_call: tts_hip_parler_step per token + logits D2H + host arg-max"}
 
 
+def generate_batch1_end_to_end(path, device):
+    """The reference's own protocol and harness for ONE utterance at a time (examples/perf_battery/perf_battery.cpp:100-117: the 30 Harvard
+    sentences, one generate() each = tokenizer + prefill + AR loop + un-delay + DAC, wall time per sentence; RTF = generation ms / audio ms):
+    oracle/_ref/perf_battery_ref is the reference's perf_battery.cpp compiled UNCHANGED against this engine's libtts.so through the compat/
+    overlay (oracle/Makefile; the binary travels, the source does not) — a harness, not an oracle: what it times is the product.  Falls back to
+    the engine's own host/perf_battery (same protocol) when the binary is absent.  Run on the headline's model file: every sentence generates
+    to max_generation (random weights never emit EOS), 2.8-2.9 s of audio each; the first sentence pays the graph captures."""
+    import re
+    import subprocess
+    ref = os.path.join(ROOT, "oracle", "_ref", "perf_battery_ref")
+    exe = ref if os.path.exists(ref) else os.path.join(ROOT, "tts.cpp_amd", "host", "perf_battery")
+    if not os.path.exists(exe):
+        return {"error": "no perf_battery harness built"}
+    out = {"harness": os.path.relpath(exe, ROOT) + (" (the reference's perf_battery.cpp, unchanged, linked against libtts.so)" if exe == ref else " (engine's tool, same protocol)"),
+           "protocol": "30 sentences, one tts_generation_runner::generate() each (decoder + DAC), mean over sentences; x_real_time = 1 / real-time factor"}
+    env = dict(os.environ, TTS_HIP_DEVICE=str(device), TTS_HIP_MAX_SEQS="1")
+    for label, topk in (("top_k_50", 50), ("top_k_1_greedy", 1)):
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "--model-path", path, "--topk", str(topk)], capture_output=True, text=True, timeout=600, env=env)
+        m1 = re.search(r"Generation Time \(ms\):\s+([0-9.]+)", r.stdout)
+        m2 = re.search(r"Real Time Factor \(ms\):\s+([0-9.]+)", r.stdout)
+        if r.returncode != 0 or not m1 or not m2:
+            out[label] = {"error": (r.stderr or r.stdout)[-300:]}
+            continue
+        rtf = float(m2.group(1))
+        out[label] = {"mean_generation_ms": round(float(m1.group(1)), 2), "real_time_factor": round(rtf, 5), "x_real_time": round(1.0 / rtf, 2),
+                      "wall_s": round(time.perf_counter() - t0, 1)}
+    return out
+
+
 def free_port():
     import socket
     with socket.socket() as so:
@@ -465,6 +495,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-step-sweep", action="store_true")
     ap.add_argument("--no-long", action="store_true", help="skip the long_utterances section (1024 audio steps, uniform + ragged)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip generate_batch1_end_to_end (the reference's perf_battery protocol, one utterance at a time)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE configs 2-4 (secondary)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--model", choices=["mini", "small", "tiny"], default="mini")
@@ -559,8 +590,6 @@ def main():
     log(f"[rank {rank}] {len(runners)} runner(s) ready in {time.perf_counter() - t_load:.1f}s, one arena of {arena_bytes / 1e6:.0f} MB per rank")
     if dist is not None:
         dist.barrier()
-    if rank == 0 and not os.environ.get("TTS_BENCH_KEEP_GGUF"):
-        os.unlink(path)   # mapped by the runners; the name is no longer needed
 
     all_texts = [make_sentences(runners[0], args.batch, args.prompt_len, 1000 + rank * 64 + i) for i in range(args.streams)]
 
@@ -672,12 +701,19 @@ def main():
         if not args.no_step_sweep and args.wtype in ("f16", "f32"):
             full_model = synth.build(cfg_full, shapes_only=True)
             out["decode_step_batch1"] = decode_step_sweep(cfg_full, full_model, L.tts_hip_arena_ptr(runners[0].device_context()), local_rank)
+        if not args.no_e2e and args.model == "mini" and not args.sample:
+            try:
+                out["generate_batch1_end_to_end"] = generate_batch1_end_to_end(path, local_rank)
+            except Exception as e:   # the headline must survive a failure of an extra section
+                out["generate_batch1_end_to_end"] = {"error": str(e)[:300]}
         if not args.no_cpu_baseline:
             threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 32)
             prompt = runners[0].tokenize(all_texts[0][0])
             out["cpu_baseline"] = cpu_baseline(model, cfg, prompt, threads)
     for rn in reversed(runners):
         rn.close()
+    if rank == 0 and not os.environ.get("TTS_BENCH_KEEP_GGUF"):
+        os.unlink(path)
     if rank == 0 and world == 1 and args.model == "mini":
         if not args.no_long:
             try:

@@ -7,6 +7,7 @@ billions of normals in numpy would cost more box time than the runs).
 roofline here is the HBM roofline of the WHOLE decoder step (a step is a chain of ~250-350 short launches that stream the model once):
 achieved = algorithmic bytes one step must read / measured step time.  cpu_baseline = the oracle on a reduced number of layers,
 extrapolated linearly in the layer count (stated in `sample`)."""
+import json
 import os
 import sys
 import time
@@ -26,6 +27,15 @@ class _Model:
         self.cfg, self.tensors = cfg, tensors
         self.by_name = {t.name: t for t in tensors}
 
+
+
+def _pmc(name):
+    """HBM bytes per step / launch from the committed counter passes (profiles/pmc_traffic_secondary.json, profiles/r4_pmc_secondary.sh); None if absent"""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_secondary.json")
+    try:
+        return round(json.load(open(path))[name]["hbm_bytes"], 1)
+    except (OSError, KeyError, ValueError):
+        return None
 
 def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -175,7 +185,7 @@ def run_dia(args, ranks=None):
         "dac_ms_per_pass": round(float(np.mean(dac_s)) * 1e3, 2),
         "x_real_time_per_gpu": round(U / (step_ms * 1e-3) / 86.13, 2),
         "roofline": {"bound": "hbm", "achieved": round(tot / (step_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(tot / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(tot / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": _pmc("dia_1_6b_lockstep4_step"),
                      "kernel": "whole decoder step (18 layers x 14 launches: gemv_stream_kernel, attn_gqa_split_kernel<128>, rms_fold_rows_kernel, ... + sample_kernel)",
                      "algorithmic_bytes_per_launch": tot, "note": f"fp16 matrices {w_bytes / 1e9:.3f} GB + {U} x (fp32 cross K/V {ckv_bytes / 1e9:.3f} GB + self-attention K/V at the mean position {skv_bytes / 1e9:.3f} GB) per step"},
     }
@@ -294,7 +304,7 @@ def run_orpheus(args):
         "snac_share_of_step": round(float(np.mean(tc)) / (float(np.mean(ts)) + float(np.mean(tc))), 4),
         "x_real_time_per_gpu": round(audio_s / elapsed, 2),
         "roofline": {"bound": "hbm", "achieved": round(q4_bytes / step / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(q4_bytes / step / 1e9 / HBM_PEAK_GBS, 4),
-                     "traffic": None, "kernel": "whole decoder step (28 layers: gemv_q4_rows_kernel, rms norm, rope, attn_gqa_kernel<128>, arg-max over 156 940 logits)",
+                     "traffic": _pmc("orpheus_3b_q4_0_step"), "kernel": "whole decoder step (28 layers x 6 launches: gemv_q4_qkv_rope_kernel, attn_gqa_split_kernel<128> + combine, gemv_q4_rows_lds_kernel, gemv_q4_gateup_silu_kernel; lm_head over 156 940 logits, arg-max)",
                      "algorithmic_bytes_per_launch": q4_bytes, "note": "Q4_0 bytes of every matrix one step reads (lm_head included, one embedding row excluded); "
                      "the decoder steps are the dominant part of the timed region (snac_share_of_step is the codec's)"},
     }
@@ -373,7 +383,7 @@ def run_kokoro(args):
     hip.engine_profile(eng, 0)
     if st["launches"]:
         tf = st["flops_total"] / st["ms_total"] / 1e9
-        out["roofline"] = {"bound": "mfma", "achieved": round(tf, 3), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": None,
+        out["roofline"] = {"bound": "mfma", "achieved": round(tf, 3), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": _pmc("kokoro_conv_mfma"),
                            "kernel": "conv1d_mfma_kernel<3 / 5 / 7 / 11,...> (generator + AdaIN + text-encoder convolutions, exact-fp32 MFMA)",
                            "avg_launch_us": round(st["ms_total"] / st["launches"] * 1e3, 2), "launches": st["launches"],
                            "share_of_wall_time": round(st["ms_total"] * 1e-3 / wall, 3),

@@ -32,11 +32,15 @@ static __global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int
     const int r = blockIdx.x, tid = threadIdx.x;
     float *xr = x + (int64_t) r * H;
     if (H <= 4096) {
+        // Every load of the row, its weight and the slabs is issued straight-line with a clamped index (a chunk beyond the row re-reads the row's
+        // last element and is never used); only arithmetic and stores sit under `i < H`.  Loads under that predicate were one basic block each
+        // with a full s_waitcnt in front: 18 dependent round trips for one row (profiles/r03/isa_serial_loads_final.txt), 4.7-6 us per launch of
+        // a kernel the Dia step launches three times per layer.
         float v[16], wv[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const int i = tid + k * 256;
-            if (i < H) { v[k] = xr[i]; wv[k] = w[i]; }
+            const int i = min(tid + k * 256, H - 1);
+            v[k] = xr[i]; wv[k] = w[i];
         }
         if (parts) {
             int p = 0;
@@ -46,10 +50,7 @@ static __global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int
 #pragma unroll
                     for (int q = 0; q < 4; q++)
 #pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            const int i = tid + k * 256;
-                            if (i < H) t[q][k] = parts[(p + q) * slab_stride + (int64_t) r * H + i];
-                        }
+                        for (int k = 0; k < 8; k++) t[q][k] = parts[(p + q) * slab_stride + (int64_t) r * H + min(tid + k * 256, H - 1)];
 #pragma unroll
                     for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -58,11 +59,12 @@ static __global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int
                 }
             }
             for (; p < n_parts; p++) {
+                float t[16];
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const int i = tid + k * 256;
-                    if (i < H) v[k] += parts[p * slab_stride + (int64_t) r * H + i];
-                }
+                for (int k = 0; k < 16; k++) t[k] = parts[p * slab_stride + (int64_t) r * H + min(tid + k * 256, H - 1)];
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    if (tid + k * 256 < H) v[k] += t[k];
             }
 #pragma unroll
             for (int k = 0; k < 16; k++) {
