@@ -319,13 +319,13 @@ def load_runners(path, args, rank, world, local_rank, backend, dist, torch, gen_
     return runners, info
 
 
-def run_all(runners, texts, timings_=None):
+def run_all(runners, texts, timings_=None, stream=False):
     res = [None] * len(runners)
 
     def work(i):
         try:
             t0 = time.perf_counter()
-            sizes = runners[i].generate_batch_sizes(texts[i])
+            sizes = runners[i].generate_stream(texts[i], sizes_only=True) if stream else runners[i].generate_batch_sizes(texts[i])
             res[i] = (sum(sizes), time.perf_counter() - t0)
         except Exception as e:   # surfaced by the caller: a worker thread must not fail silently
             res[i] = e
@@ -472,6 +472,24 @@ def long_utterances(args, mk, wt, local_rank, gen_cfg, torch, L):
                          "prompt_ids": [args.prompt_len, hi], "audio_steps_per_utterance": [n_steps - (hi - args.prompt_len), n_steps],
                          "note": "lock-step: the loop runs as long as the longest row; every 32 steps the rows that reached max_generation leave the forward (row compaction, "
                                  "TTS_HIP_GEN_COMPACT=0: they idle instead — 196 against 268 audio-s/s, profiles/r03/compaction_call20.txt)"}
+        # the same length mix as a STREAM of requests, three times the rows a runner holds, through one continuous-batching session per runner
+        # (tts_c_generate_stream): a row freed by an utterance that reached max_generation is refilled at the next 32-step look-in point
+        n_req = 3 * (batch - 1)
+        srag = [long_sentences(first, n_req, args.prompt_len, hi, 9000 + i) for i in range(args.streams)]
+        rngs = np.random.default_rng(17)
+        for t in srag:
+            rngs.shuffle(t)                                      # arrival order is not sorted by length
+        run_all(runners, [t[:batch - 1] for t in srag], stream=True)   # warm-up: the session's graphs
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_samples = run_all(runners, srag, stream=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["ragged_stream"] = {"audio_seconds_per_sec": round(n_samples / SAMPLE_RATE / dt, 2), "seconds": round(dt, 3), "requests": n_req * args.streams,
+                                "rows_per_runner": batch - 1, "prompt_ids": [args.prompt_len, hi],
+                                "of_uniform": round(n_samples / SAMPLE_RATE / dt / out["uniform"]["audio_seconds_per_sec"], 3),
+                                "note": "continuous batching (tts_hip_parler_stream_*): 3 x the rows of requests with the ragged length mix per runner; "
+                                        "finished utterances leave, waiting ones are prefilled as a side batch and enter the freed rows"}
     finally:
         for rn in reversed(runners):
             rn.close()

@@ -45,6 +45,11 @@ int           tts_c_generate(tts_c_runner *r, const char *text, const tts_c_conf
  * must have been loaded with TTS_HIP_MAX_SEQS >= n in the environment. */
 int           tts_c_generate_batch(tts_c_runner *r, const char *const *texts, int n, const tts_c_config *cfg, const float **data,
                                    size_t *n_outputs);
+/* Extension: any number of utterances through ONE continuous-batching session of the runner (tts_generation_runner::generate_stream): at most
+ * max_seqs - 1 generate at a time, and a row freed by an utterance that finishes is refilled from texts[] at the next look-in point (every 32
+ * decode steps) instead of idling until the longest one is done.  Same outputs as n generate() calls; data[i] valid until the next call. */
+int           tts_c_generate_stream(tts_c_runner *r, const char *const *texts, int n, const tts_c_config *cfg, const float **data,
+                                    size_t *n_outputs);
 /* Placement of the NEXT tts_c_runner_from_file on the calling thread (host/common.h tts_load_options): device (< 0: TTS_HIP_DEVICE or
  * 0), lock-step KV slots (0: TTS_HIP_MAX_SEQS or 1), declare_only != 0: lay the model out without uploading its bytes — the weights
  * then arrive in tts_hip_arena_ptr(tts_c_runner_device_context(r)) by a collective and tts_hip_arena_filled() marks them present. */
@@ -97,6 +102,11 @@ tts_c_pool *tts_c_pool_create(const char *model_path, int n_workers, const int *
 /* server --text-encoder-path: the T5 GGUF that CONDITIONAL_PROMPT tasks use; applies to pools created afterwards by
  * this thread (NULL / "" = none) */
 void tts_c_pool_set_text_encoder(const char *path);
+/* pool_options::continuous for pools created afterwards by this thread: a worker keeps one generation session per run of compatible requests
+ * and admits queued requests into rows that free up while the others are still generating (continuous batching), instead of running each
+ * batch to its end.  tts_c_pool_admitted_in_flight: how many requests entered a session that way. */
+void     tts_c_pool_set_continuous(int on);
+uint64_t tts_c_pool_admitted_in_flight(tts_c_pool *pool);
 int  tts_c_pool_submit(tts_c_pool *pool, const char *text, const tts_c_config *cfg);   /* task id, < 0 on error */
 /* CONDITIONAL_PROMPT task (server.cpp:263-271) fanned out to every worker; wait on the id like any task (no audio:
  * tts_c_pool_wait returns 0 with n_outputs == 0 on success, 1 + tts_c_last_error() otherwise) */

@@ -428,6 +428,23 @@ int tts_hip_profile(tts_hip_ctx *ctx, int enable);        /* 1: every launch, fo
 int tts_hip_profile_get(tts_hip_ctx *ctx, int kclass, tts_hip_kstat *out);
 const char *tts_hip_kclass_name(int kclass);
 
+/* ---- continuous batching: a generation that admits new utterances while others are running -----------------------------------------
+ * Replaces, for a serving loop, "form a batch from what is queued, run it to the end" (examples/server/server.cpp:126-158 is the queue this
+ * widens; parler/model.cpp:762-792 the loop).  The context needs max_seqs >= n_slots + 1: cache slot n_slots pads the lock-step forward.
+ *   begin   fixes n_slots, the per-utterance step budget max_steps (token buffer [max_steps][n_slots + 1][heads]), bos / eos and the sampler
+ *           (sp == NULL: sampler::max; else sampler::sample on the device as in tts_hip_parler_generate_sampled)
+ *   admit   n utterances into free slots: prompts concatenated in ids, lens[i] ids each (prefilled as one side batch, positions from 0);
+ *           uniforms [n][max_steps][heads] for a sampled stream (the host-drawn std::minstd_rand sequence of each utterance), else NULL
+ *   run     n_steps lock-step decode steps over the live utterances; then *n_finished slots whose check_stopping() fired (EOS on every head,
+ *           position == the cached positions, or max_steps reached) are reported with their step counts and become free
+ *   collect the tokens [steps][heads] of a finished slot (before the slot is admitted again)
+ * An utterance's tokens are those of a solo tts_hip_parler_generate_* run of the same prompt (tests/test_gpu_runner.py). */
+int tts_hip_parler_stream_begin(tts_hip_ctx *ctx, uint32_t n_slots, uint32_t max_steps, uint32_t bos, uint32_t eos, const tts_hip_sampling *sp);
+int tts_hip_parler_stream_admit(tts_hip_ctx *ctx, uint32_t n, const uint32_t *slots, const uint32_t *ids, const uint32_t *lens, const float *uniforms);
+int tts_hip_parler_stream_run(tts_hip_ctx *ctx, uint32_t n_steps, uint32_t *n_finished, uint32_t *finished_slots, uint32_t *finished_steps);
+int tts_hip_parler_stream_collect(tts_hip_ctx *ctx, uint32_t slot, uint32_t steps, uint32_t *tokens_out);
+int tts_hip_parler_stream_end(tts_hip_ctx *ctx);
+
 /* Tuning and fallback switches by name (profiles/ harnesses and the fallback parity test; call between tts_hip_create and the first
  * launch).  Unknown key: -1.  Not an environment variable on purpose: a deployment cannot flip a kernel path by accident. */
 int tts_hip_tune(tts_hip_ctx *ctx, const char *key, int value);

@@ -701,6 +701,73 @@ def test_row_compaction_keeps_every_utterance_token_for_token(sampled, monkeypat
         assert np.array_equal(ta[:k, u], tb[:k, u]), f"utterance {u}"
 
 
+@pytest.mark.parametrize("sampled", [False, True])
+def test_utterance_admitted_mid_flight_gets_the_tokens_of_its_own_run(sampled, monkeypatch):
+    """Continuous batching (tts_hip_parler_stream_*): 150 utterances through 70 rows.  The first 70 open the stream; whenever utterances
+    finish (their position reaches max_generation after 20 ... 76 steps, check_stopping model.cpp:720-722) the rows are refilled from the
+    waiting list at the next 32-step look-in point — newcomers are prefilled as a side batch while the others hold their place.  Every
+    utterance must get exactly the tokens and the step count it gets from ONE lock-step generation of all 150 (greedy, and with the device
+    sampler: its own uniforms and repetition-penalty state), whatever it shared the forward with and whenever it entered.  The GEMM tile
+    shape is pinned as in the compaction test (a forward of 64 rows otherwise sums in another order than one of 150)."""
+    monkeypatch.setenv("TTS_HIP_TILE_FORCE", "3")
+    monkeypatch.setenv("TTS_HIP_TILE_KS", "1")
+    monkeypatch.setenv("TTS_HIP_ATTN_NSPLIT", "1")
+    cfg = synth.small(weight_type=gguf.F16, ctx=80, max_gen=80)
+    model = synth.build(cfg)
+    rng = np.random.default_rng(23)
+    n, cap, slots = 150, 80, 70
+    lens = rng.integers(4, 61, n)
+    prompts = [rng.integers(3, cfg.prompt_vocab, int(l)).astype(np.uint32) for l in lens]
+    n_steps = int(cap - lens.min())
+    uni = rng.random((n_steps, n, cfg.n_out), dtype=np.float32)
+    samp = (20, 1.0, 0.9, 1.1)   # top_k, top_p, temperature, repetition penalty
+    ref = hip.HipEngine(cfg, max_seqs=n, kv_positions=cap, flags=hip.FLAG_NO_DAC)
+    ref.load(model)
+    ref.prefill_batch(prompts)
+    if sampled:
+        rt, rd = ref.generate_sampled(lens, n_steps, uni, top_k=samp[0], temperature=samp[2], repetition_penalty=samp[3])
+    else:
+        rt, rd = ref.generate_greedy(lens, n_steps)
+    ref.close()
+
+    eng = hip.HipEngine(cfg, max_seqs=slots + 1, kv_positions=cap, flags=hip.FLAG_NO_DAC)
+    eng.load(model)
+    max_steps = cap - 1
+    eng.stream_begin(slots, max_steps, sampling=samp if sampled else None)
+
+    def draws(us):
+        u = np.zeros((len(us), max_steps, cfg.n_out), dtype=np.float32)
+        for i, k in enumerate(us):
+            u[i, :n_steps] = uni[:, k]
+        return u
+
+    waiting = list(range(n))
+    slot_utt, free = {}, list(range(slots))
+    got, joined_late, rounds = {}, 0, 0
+    while waiting or slot_utt:
+        take = waiting[:len(free)]
+        if take:
+            waiting = waiting[len(take):]
+            sl = [free.pop(0) for _ in take]
+            joined_late += len(take) if slot_utt else 0
+            eng.stream_admit(sl, [prompts[k] for k in take], draws(take) if sampled else None)
+            slot_utt.update(dict(zip(sl, take)))
+        for slot, steps in eng.stream_run(32):
+            k = slot_utt.pop(slot)
+            got[k] = (steps, eng.stream_collect(slot, steps))
+            free.append(slot)
+        rounds += 1
+        assert rounds < 100
+    eng.stream_end()
+    eng.close()
+    assert len(got) == n and joined_late >= n - slots, "utterances must have entered while others were generating"
+    for k in range(n):
+        want = int(rd[k]) if rd[k] else n_steps
+        steps, toks = got[k]
+        assert steps == want == cap - lens[k], (k, steps, want)
+        assert np.array_equal(toks, rt[:want, k]), f"utterance {k} (admitted with {lens[k]} prompt ids)"
+
+
 def test_generation_graphs_follow_reallocated_outputs_and_sampling_parameters():
     """The captured generation step bakes the tokens_out pointer and the sampling parameters in; both may change between calls on one
     context (a longer request reallocates tokens_out, a request may sample differently).  Round 3 keyed the graphs in units of 8192 rows

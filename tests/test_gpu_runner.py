@@ -358,6 +358,41 @@ def test_two_rank_bench_flow_on_one_gpu(tmp_path):
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - expect_audio_s) < 1e-3 * expect_audio_s
 
 
+def test_generate_stream_and_continuous_pool_match_single_generations(tmp_path, monkeypatch):
+    """The host side of the continuous batching through the C++ runner and the device pool: 40 sentences through a runner with 15 rows
+    (tts_c_generate_stream: freed rows are refilled) give, utterance by utterance, the audio of a session that holds all 40 at once; and a
+    pool in continuous mode answers requests that arrive while others are generating out of the same session, with that same audio.
+    Greedy; the GEMM tile shape pinned (the row count otherwise selects the summation order, see the compaction test)."""
+    import time
+    monkeypatch.setenv("TTS_HIP_TILE_FORCE", "3")
+    monkeypatch.setenv("TTS_HIP_TILE_KS", "1")
+    monkeypatch.setenv("TTS_HIP_ATTN_NSPLIT", "1")
+    cfg = synth.small(weight_type=gguf.F16, ctx=96, max_gen=96)
+    model = synth.build(cfg)
+    path = model.write_gguf(str(tmp_path / "small.gguf"))
+    rng = np.random.default_rng(5)
+    texts = [" ".join("w%d" % rng.integers(0, 50) for _ in range(int(rng.integers(1, 9)))) for _ in range(40)]
+    big = runner.Runner(path, max_seqs=41, sample=0)
+    want = big.generate_stream(texts)
+    big.close()
+    assert all(w.size > 0 for w in want) and len({w.size for w in want}) > 3, "a ragged set of utterances"
+    small = runner.Runner(path, max_seqs=16, sample=0)
+    got = small.generate_stream(texts)
+    small.close()
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(a, b), f"utterance {i}"
+    pool = runner.Pool(path, n_workers=1, max_batch=16, continuous=True, sample=0)
+    ids = [pool.submit(t) for t in texts[:20]]
+    time.sleep(0.05)
+    ids += [pool.submit(t) for t in texts[20:]]       # arrive during the generation of the first twenty
+    for i, tid in enumerate(ids):
+        audio, bs, wk, err = pool.wait(tid)
+        assert err == "" and np.array_equal(audio, want[i]), f"request {i}"
+    st = pool.stats()
+    assert st["tasks"] == 40 and st["admitted_in_flight"] > 0 and st["largest_batch"] <= 15, st
+    pool.close()
+
+
 def test_two_rank_dia_bench_flow_on_one_gpu():
     """BASELINE configs[3] (Dia-1.6B fp16, batch 32 over 8 GPUs) must be producible at N > 1: `python bench.py --workload dia --gpus 2` with no
     launcher starts its two ranks (both on cuda:0 through the test hooks, gloo transport), rank 1 lays the 1.6B arena out declare-only,

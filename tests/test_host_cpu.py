@@ -216,6 +216,38 @@ def test_device_pool_queue_batching_and_responses():
     ref.close()
 
 
+def test_device_pool_continuous_batching_admits_arrivals_during_a_generation():
+    """pool_options::continuous on the weightless backend (four rows; an utterance of n characters generates for n look-in intervals of
+    10 ms): two long requests open a session, five short ones arrive while those are generating — they must enter the rows that are free
+    (and the rows that free up) of the SAME session instead of waiting for the long ones to finish, and everybody gets the audio of a
+    generate() call of their own.  generate_stream (any number of sentences through one session) is checked against generate()."""
+    import time
+    pool = runner.Pool("test:dummy", n_workers=1, max_batch=4, continuous=True)
+    t0 = time.perf_counter()
+    long_ids = [pool.submit("l" * 40) for _ in range(2)]
+    time.sleep(0.08)
+    short_ids = [pool.submit("ab") for _ in range(5)]
+    short = [pool.wait(i) for i in short_ids]
+    t_short = time.perf_counter() - t0
+    long_ = [pool.wait(i) for i in long_ids]
+    t_long = time.perf_counter() - t0
+    for audio, bs, wk, err in short:
+        assert err == "" and audio.size == 2 * 44100 and wk == 0
+    for audio, bs, wk, err in long_:
+        assert err == "" and audio.size == 40 * 44100
+    st = pool.stats()
+    assert st["tasks"] == 7 and st["batches"] == 1, st          # one session served all seven
+    assert st["admitted_in_flight"] == 5 and st["largest_batch"] == 4, st
+    assert t_short < t_long - 0.1, (t_short, t_long)               # the short requests did not wait for the long ones
+    pool.close()
+    r = runner.Runner("test:dummy")
+    texts = ["abc", "d", "efgh", "ij", "k", "lmnop", "q"]          # seven utterances through four rows
+    outs = r.generate_stream(texts)
+    for t, o in zip(texts, outs):
+        assert np.array_equal(o, r.generate(t))
+    r.close()
+
+
 def test_device_pool_conditional_prompt_task():
     """CONDITIONAL_PROMPT (server.cpp:263-271): without --text-encoder-path the task is answered with the reference's
     message; with one, every worker applies it (here the dummy backend refuses, as any non-Parler architecture does)."""

@@ -1028,6 +1028,9 @@ struct FeedArgs {
     // steps_done and tokens_out stay indexed by utterance, ids / row_pos / row_step by row (NULL: row == utterance)
     const uint32_t *orig;
     int R_total;
+    uint32_t max_steps;       // continuous batching: an utterance's step budget = planes of tokens_out (0: the loop's own n_steps bounds it); at
+                              // max_steps the utterance is marked finished and records nothing further
+    int dummy;                // continuous batching (tts_hip_parler_stream_*): rows of this cache slot are padding of the lock-step forward and record nothing (-1: none)
 };
 
 // rows dst[r] = src[map[r]] of the per-row loop state (ids, position, cache slot, step counter): the compaction of generate_loop, in two
@@ -1056,7 +1059,9 @@ static __global__ void feed_kernel(FeedArgs a) {
     __shared__ int not_seen;
     const int r = blockIdx.x, hd = threadIdx.x;
     const int ro = a.orig ? (int) a.orig[r] : r, RT = a.orig ? a.R_total : a.R;
+    if (ro == a.dummy) return;   // workgroup-uniform
     const uint32_t step = a.row_step[r];
+    if (a.max_steps && step > a.max_steps) return;   // budget spent (reported at step == max_steps below); workgroup-uniform
     if (hd == 0) not_seen = 0;
     __syncthreads();
     if (hd < a.n_out) {
@@ -1073,7 +1078,7 @@ static __global__ void feed_kernel(FeedArgs a) {
         const uint32_t np = a.row_pos[r] + 1;
         if (np < a.max_pos) a.row_pos[r] = np;
         a.row_step[r] = step + 1;
-        if ((!not_seen || np >= a.max_pos) && a.steps_done[ro] == 0) a.steps_done[ro] = step;
+        if ((!not_seen || np >= a.max_pos || (a.max_steps && step >= a.max_steps)) && a.steps_done[ro] == 0) a.steps_done[ro] = step;
     }
 }
 

@@ -1020,7 +1020,7 @@ static int enqueue_step_body(tts_hip_ctx *c, int R, int mode, uint32_t bos, uint
             f.tokens = c->d_tok; f.ids = c->d_ids; f.row_pos = c->d_pos; f.row_step = c->d_step; f.eos_seen = c->d_eos;
             f.steps_done = c->d_steps_done; f.tokens_out = c->d_tokens_out; f.R = R; f.n_out = c->NO; f.bos = bos; f.eos = eos;
             f.max_pos = (uint32_t) std::min(c->KVPOS, c->NPOS);
-            f.orig = c->d_seq; f.R_total = c->gen_total;
+            f.orig = c->d_seq; f.R_total = c->gen_total; f.dummy = c->gs.active ? (int) c->gs.n_slots : -1; f.max_steps = c->gs.active ? c->gs.max_steps : 0;
             hipLaunchKernelGGL(feed_kernel, dim3(R), dim3(64), 0, c->stream, f);
             HIPCHK(hipGetLastError());
         }
@@ -1118,10 +1118,12 @@ static int generate_loop(tts_hip_ctx *c, int mode, uint32_t n, const uint32_t *s
         drop_gen_graphs(c);
         c->g_bos = bos; c->g_eos = eos;
     }
-    if (c->gen_total != (int) n) {   // the utterance count is baked into the captured sampler / feed launches (tokens_out stride)
+    if (c->gen_total != (int) n || c->gs_graphs) {   // the utterance count (and a stream's padding slot) is baked into the captured sampler / feed launches
         drop_gen_graphs(c);
         c->gen_total = (int) n;
+        c->gs_graphs = false;
     }
+    c->gs = tts_hip_ctx::GenStream{};   // a batch generation ends any stream of this context
     // Row compaction.  Every 32 steps the host looks at steps_done (one small D2H + sync) to see whether check_stopping() has fired for every
     // utterance; utterances that have finished (EOS on every head, or their position reached max_generation) used to idle in the lock-step
     // forward until the last one was done — a ragged batch paid for its longest row (165 against 323 audio-s/s at 1024 steps).  Now the
@@ -1236,6 +1238,203 @@ extern "C" int tts_hip_parler_generate_sampled(tts_hip_ctx *c, uint32_t n, const
         HIPCHK(hipMemsetAsync(c->d_repc, 0, (size_t) n * c->NO * 4, c->stream));
     }
     return generate_loop(c, MODE_GEN_SAMPLE, n, start_pos, n_steps, bos, eos, tokens_out, steps_done);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Continuous batching (the queue of examples/server/server.cpp:126-158 widened): a generation that takes new utterances
+// into freed rows while the others keep running.  generate_loop above runs ONE batch to its end: an utterance arriving a step later waits a
+// whole generation, and a ragged batch idles (or, compacted, shrinks) instead of refilling.  Here the loop is cut at the host's 32-step
+// look-in points into calls:
+//   stream_begin(n_slots, max_steps, ...)   fixes the slot count (cache slots 0 .. n_slots-1; slot n_slots is the padding slot: the context
+//                                           needs max_seqs >= n_slots + 1), the token buffer [max_steps][n_slots + 1][heads] and the sampler
+//   stream_admit(slots, prompts ...)        prefills the newcomers as a side batch into their cache slots and enters them as rows at step 1
+//   stream_run(n_steps)                     n_steps lock-step forwards over the live rows (padded to the row counts generate_loop captures:
+//                                           multiples of 64, of 128 from 256 rows; padding rows sit on the padding slot and record nothing),
+//                                           then reports the slots whose check_stopping() fired and frees them
+//   stream_collect(slot, steps)             the finished utterance's tokens [steps][heads]
+// Per-slot state (EOS flags, steps_done, sampler history, uniforms, token column) is indexed by slot, per-row state (ids, position, step
+// counter) lives on the host between calls: the prefill of a newcomer uses the same device staging arrays as a step.
+// An utterance's tokens do not depend on when it was admitted or on its neighbours: every kernel of the forward works row by row, and the
+// GEMM tile a row count selects is pinned by the row-count rounding (tests/test_gpu_runner.py: admitted mid-flight == solo run).
+// ------------------------------------------------------------------------------------------------
+extern "C" int tts_hip_parler_stream_begin(tts_hip_ctx *c, uint32_t n_slots, uint32_t max_steps, uint32_t bos, uint32_t eos, const tts_hip_sampling *sp) {
+    CHK(ready(c, "tts_hip_parler_stream_begin"));
+    if (n_slots == 0 || n_slots + 1 > c->d.max_seqs || (int) n_slots > c->RMAX) return set_err("stream_begin: %u slots need a context with max_seqs >= %u (have %u) and <= %d rows", n_slots, n_slots + 1, c->d.max_seqs, c->RMAX);
+    if (max_steps == 0) return set_err("stream_begin: max_steps == 0");
+    if (bos >= (uint32_t) c->EROWS || eos >= (uint32_t) c->EROWS) return set_err("stream_begin: bos/eos outside the embedding table");
+    auto &g = c->gs;
+    g = tts_hip_ctx::GenStream{};
+    g.n_slots = n_slots; g.max_steps = max_steps; g.bos = bos; g.eos = eos; g.sampled = sp != nullptr;
+    const uint32_t RT = n_slots + 1;
+    if (sp) {
+        CHK(check_sampling(c, sp, "tts_hip_parler_stream_begin"));
+        if (sp->top_k != c->smp.top_k || sp->top_p != c->smp.top_p || sp->temperature != c->smp.temperature ||
+            (sp->repetition_penalty != 1.0f) != (c->smp.repetition_penalty != 1.0f))
+            drop_gen_graphs(c);
+        c->smp = *sp;
+        const size_t count = (size_t) (max_steps + 1) * RT * c->NO;   // + 1: a row that spent its budget inside a chunk still reads the plane after its last
+        if (count > c->uniforms_cap) {
+            free_dev(c->d_uniforms); c->d_uniforms = nullptr;
+            HIPCHK(hipMalloc((void **) &c->d_uniforms, count * 4));
+            c->uniforms_cap = count;
+            drop_gen_graphs(c);
+        }
+        HIPCHK(hipMemsetAsync(c->d_uniforms, 0, count * 4, c->stream));
+        CHK(stage_penalty(c, sp->repetition_penalty, (int) max_steps));
+    }
+    const size_t need = (size_t) max_steps * RT * c->NO;
+    if (need > c->tokens_out_cap) {
+        free_dev(c->d_tokens_out); c->d_tokens_out = nullptr;
+        HIPCHK(hipMalloc((void **) &c->d_tokens_out, need * 4));
+        c->tokens_out_cap = need;
+        drop_gen_graphs(c);
+    }
+    if (c->g_bos != bos || c->g_eos != eos) { drop_gen_graphs(c); c->g_bos = bos; c->g_eos = eos; }
+    if (c->gen_total != (int) RT || !c->gs_graphs || c->gs_baked_steps != max_steps) { drop_gen_graphs(c); c->gen_total = (int) RT; c->gs_graphs = true; c->gs_baked_steps = max_steps; }   // feed_kernel's padding slot is baked in too
+    HIPCHK(hipMemsetAsync(c->d_eos, 0, (size_t) RT * c->NO, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_steps_done, 0, (size_t) RT * 4, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    g.slot_live.assign(n_slots, 0);
+    g.active = true;
+    return 0;
+}
+
+extern "C" int tts_hip_parler_stream_admit(tts_hip_ctx *c, uint32_t n, const uint32_t *slots, const uint32_t *ids, const uint32_t *lens, const float *uniforms) {
+    CHK(ready(c, "tts_hip_parler_stream_admit"));
+    auto &g = c->gs;
+    if (!g.active) return set_err("stream_admit: no stream (tts_hip_parler_stream_begin)");
+    if (n == 0) return 0;
+    if (!slots || !ids || !lens) return set_err("stream_admit: null argument");
+    if (g.sampled && !uniforms) return set_err("stream_admit: a sampled stream needs the utterances' uniforms [n][max_steps][heads]");
+    const uint32_t RT = g.n_slots + 1, max_pos = (uint32_t) std::min(c->KVPOS, c->NPOS);
+    for (uint32_t i = 0; i < n; i++) {
+        if (slots[i] >= g.n_slots) return set_err("stream_admit: slot %u >= %u", slots[i], g.n_slots);
+        if (g.slot_live[slots[i]]) return set_err("stream_admit: slot %u is still generating", slots[i]);
+        for (uint32_t j = 0; j < i; j++) if (slots[j] == slots[i]) return set_err("stream_admit: slot %u named twice", slots[i]);
+        if (lens[i] == 0 || lens[i] >= max_pos) return set_err("stream_admit: prompt of %u ids leaves no room in %u cached positions", lens[i], max_pos);
+    }
+    {   // The newcomers' prompts as one side batch (prefill_batch's rows), padded with rows of the padding slot to the row counts the decode steps
+        // use (multiples of 64): a lone 5-id prompt would otherwise run through the small-batch GEMM kernels (other summation order than the
+        // tiled ones its neighbours' prompts went through), and the utterance's tokens would depend on how many others arrived with it.
+        std::vector<uint32_t> rs, rp, ri;
+        size_t off = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            for (uint32_t j = 0; j < lens[i]; j++) {
+                if (ids[off + j] >= (uint32_t) c->PV) return set_err("stream_admit: text id %u >= prompt vocab %d", ids[off + j], c->PV);
+                rs.push_back(slots[i]); rp.push_back(j); ri.push_back(ids[off + j]);
+            }
+            off += lens[i];
+        }
+        for (size_t o = 0; o < rs.size(); o += (size_t) c->RMAX) {
+            const int real = (int) std::min<size_t>((size_t) c->RMAX, rs.size() - o);
+            const int R = std::min(c->RMAX, (real + 63) / 64 * 64);
+            c->host_pos.resize(R);
+            for (int r = 0; r < R; r++) {
+                const bool pad = r >= real;
+                c->h_ids[r] = pad ? ri[o] : ri[o + r];
+                c->h_pos[r] = pad ? (uint32_t) ((r - real) % (int) max_pos) : rp[o + r];
+                c->h_seq[r] = pad ? g.n_slots : rs[o + r];
+                c->host_pos[r] = c->h_pos[r];
+            }
+            HIPCHK(hipMemcpyAsync(c->d_ids, c->h_ids, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(c->d_pos, c->h_pos, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(c->d_seq, c->h_seq, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+            CHK(enqueue_forward(c, R, /*audio=*/false, /*logits=*/false, /*same_seq=*/false));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t s = slots[i];
+        HIPCHK(hipMemsetAsync(c->d_eos + (size_t) s * c->NO, 0, (size_t) c->NO, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_steps_done + s, 0, 4, c->stream));
+        if (g.sampled) {
+            if (c->smp.repetition_penalty != 1.0f) {   // sampler::reset for this utterance
+                HIPCHK(hipMemsetAsync(c->d_last + (size_t) s * c->NO, 0xFF, (size_t) c->NO * 4, c->stream));
+                HIPCHK(hipMemsetAsync(c->d_repc + (size_t) s * c->NO, 0, (size_t) c->NO * 4, c->stream));
+            }
+            // the utterance's draws [max_steps][heads] into its column of [max_steps][slots + 1][heads]
+            HIPCHK(hipMemcpy2DAsync(c->d_uniforms + (size_t) s * c->NO, (size_t) RT * c->NO * 4, uniforms + (size_t) i * g.max_steps * c->NO, (size_t) c->NO * 4,
+                                    (size_t) c->NO * 4, g.max_steps, hipMemcpyHostToDevice, c->stream));
+        }
+        g.slot_live[s] = 1;
+        g.row_slot.push_back(s);
+        g.pos.push_back(lens[i]);
+        g.step.push_back(1);
+        for (int h = 0; h < c->NO; h++) g.ids.push_back(g.bos);
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int tts_hip_parler_stream_run(tts_hip_ctx *c, uint32_t n_steps, uint32_t *n_finished, uint32_t *finished_slots, uint32_t *finished_steps) {
+    CHK(ready(c, "tts_hip_parler_stream_run"));
+    auto &g = c->gs;
+    if (!g.active) return set_err("stream_run: no stream (tts_hip_parler_stream_begin)");
+    if (!n_finished || !finished_slots || !finished_steps) return set_err("stream_run: null argument");
+    *n_finished = 0;
+    const uint32_t live = (uint32_t) g.row_slot.size();
+    if (live == 0 || n_steps == 0) return 0;
+    const uint32_t q = live >= 256 ? 128 : 64;
+    const uint32_t R = std::min<uint32_t>((uint32_t) c->RMAX, (live + q - 1) / q * q);
+    const int NO = c->NO;
+    for (uint32_t r = 0; r < R; r++) {
+        const bool pad = r >= live;
+        for (int h = 0; h < NO; h++) c->h_ids[(size_t) r * NO + h] = pad ? g.bos : g.ids[(size_t) r * NO + h];
+        c->h_pos[r] = pad ? 0 : g.pos[r];
+        c->h_seq[r] = pad ? g.n_slots : g.row_slot[r];
+        c->h_tok[r] = pad ? 1 : g.step[r];
+    }
+    HIPCHK(hipMemcpyAsync(c->d_ids, c->h_ids, (size_t) R * NO * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_pos, c->h_pos, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_seq, c->h_seq, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_step, c->h_tok, (size_t) R * 4, hipMemcpyHostToDevice, c->stream));
+    const int mode = g.sampled ? MODE_GEN_SAMPLE : MODE_GEN;
+    c->host_pos.resize(R);
+    const uint32_t max_pos = (uint32_t) std::min(c->KVPOS, c->NPOS);
+    for (uint32_t s = 0; s < n_steps; s++) {
+        for (uint32_t r = 0; r < R; r++) c->host_pos[r] = r < live ? std::min(g.pos[r] + s, max_pos - 1) : 0;
+        CHK(run_step(c, (int) R, mode, g.bos, g.eos));
+    }
+    // the rows' state back to the host (the next admit's prefill reuses the device staging arrays), and who has finished
+    HIPCHK(hipMemcpyAsync(c->h_ids, c->d_ids, (size_t) live * NO * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_pos, c->d_pos, (size_t) live * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_seq, c->d_step, (size_t) live * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_tok, c->d_steps_done, (size_t) (g.n_slots + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> slot2, pos2, step2, ids2;
+    for (uint32_t r = 0; r < live; r++) {
+        const uint32_t sl = g.row_slot[r];
+        uint32_t done = c->h_tok[sl];
+        if (done) {
+            finished_slots[*n_finished] = sl;
+            finished_steps[*n_finished] = std::min(done, g.max_steps);
+            (*n_finished)++;
+            g.slot_live[sl] = 0;
+            continue;
+        }
+        slot2.push_back(sl); pos2.push_back(c->h_pos[r]); step2.push_back(c->h_seq[r]);
+        ids2.insert(ids2.end(), c->h_ids + (size_t) r * NO, c->h_ids + (size_t) (r + 1) * NO);
+    }
+    g.row_slot.swap(slot2); g.pos.swap(pos2); g.step.swap(step2); g.ids.swap(ids2);
+    return 0;
+}
+
+extern "C" int tts_hip_parler_stream_collect(tts_hip_ctx *c, uint32_t slot, uint32_t steps, uint32_t *tokens_out) {
+    CHK(ready(c, "tts_hip_parler_stream_collect"));
+    auto &g = c->gs;
+    if (!g.active) return set_err("stream_collect: no stream");
+    if (slot >= g.n_slots || steps > g.max_steps || !tokens_out) return set_err("stream_collect: slot %u / %u steps out of range", slot, steps);
+    if (steps == 0) return 0;
+    const size_t RT = g.n_slots + 1;
+    HIPCHK(hipMemcpy2DAsync(tokens_out, (size_t) c->NO * 4, c->d_tokens_out + (size_t) slot * c->NO, RT * c->NO * 4, (size_t) c->NO * 4, steps, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int tts_hip_parler_stream_end(tts_hip_ctx *c) {
+    if (!c) return set_err("null ctx");
+    c->gs = tts_hip_ctx::GenStream{};
+    return 0;
 }
 
 extern "C" int tts_hip_sample_logits(tts_hip_ctx *c, uint32_t n_rows, const float *logits, const tts_hip_sampling *sp,

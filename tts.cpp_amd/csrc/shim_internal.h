@@ -220,6 +220,15 @@ struct tts_hip_ctx {
     int pending_parts = 0;      // slabs waiting to be folded into x by the next LayerNorm launch
     uint32_t *d_ids = nullptr, *d_pos = nullptr, *d_seq = nullptr, *d_tok = nullptr, *d_step = nullptr, *d_steps_done = nullptr;
     uint32_t *d_gather = nullptr;   // scratch of the row compaction: map [R] + ids [R][n_out] + pos / seq / step [R] each
+    // continuous batching (tts_hip_parler_stream_*): the rows' state between two stream_run calls lives on the host
+    struct GenStream {
+        bool active = false, sampled = false;
+        uint32_t n_slots = 0, max_steps = 0, bos = 0, eos = 0;
+        std::vector<uint8_t> slot_live;
+        std::vector<uint32_t> row_slot, pos, step, ids;   // live rows: cache slot, next position, step counter, next input ids [rows][heads]
+    } gs;
+    uint32_t gs_baked_steps = 0;    // ... and the step budget they carry
+    bool gs_graphs = false;         // the captured generation graphs were made for a stream (feed_kernel's padding slot baked in)
     int gen_total = 0;              // utterances of the generation loop under way (rows of the forward <= this after a compaction)
     bool gen_compact = true;        // TTS_HIP_GEN_COMPACT=0: finished utterances keep idling in the lock-step forward
     uint32_t *d_tokens_out = nullptr;

@@ -86,6 +86,7 @@ EXPORTS = [
     "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_orpheus_generate_sampled", "tts_hip_orpheus_sample_logits", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_dia_encode_slot", "tts_hip_dia_step_batch", "tts_hip_dia_generate", "tts_hip_kokoro_create", "tts_hip_kokoro_durations", "tts_hip_kokoro_generate", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
     "tts_hip_synchronize", "tts_hip_dac_arith", "tts_hip_broadcast_weights", "tts_hip_comm_unique_id", "tts_hip_broadcast_weights_rank", "tts_hip_tune",
+    "tts_hip_parler_stream_begin", "tts_hip_parler_stream_admit", "tts_hip_parler_stream_run", "tts_hip_parler_stream_collect", "tts_hip_parler_stream_end",
 ]
 
 class Sampling(C.Structure):
@@ -173,6 +174,11 @@ def load_lib():
     L.tts_hip_stream.restype = vp
     L.tts_hip_synchronize.argtypes = [vp]
     L.tts_hip_tune.argtypes = [vp, C.c_char_p, C.c_int]
+    L.tts_hip_parler_stream_begin.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Sampling)]
+    L.tts_hip_parler_stream_admit.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, f32p]
+    L.tts_hip_parler_stream_run.argtypes = [vp, C.c_uint32, u32p, u32p, u32p]
+    L.tts_hip_parler_stream_collect.argtypes = [vp, C.c_uint32, C.c_uint32, u32p]
+    L.tts_hip_parler_stream_end.argtypes = [vp]
     _lib = L
     return L
 
@@ -319,6 +325,41 @@ class HipEngine:
             self.ctx, n, bp, n_steps, self.cfg.bos if bos is None else bos, self.cfg.eos if eos is None else eos,
             out.ctypes.data_as(C.POINTER(C.c_uint32)), done.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out, done
+
+    # ---- continuous batching (tts_hip_parler_stream_*) ----
+    def stream_begin(self, n_slots, max_steps, sampling=None, bos=None, eos=None):
+        sp = None
+        if sampling is not None:
+            sp = Sampling(*sampling)
+        self._chk(self.L.tts_hip_parler_stream_begin(self.ctx, n_slots, max_steps, self.cfg.bos if bos is None else bos, self.cfg.eos if eos is None else eos,
+                                                     C.byref(sp) if sp is not None else None))
+        self._stream_slots = n_slots
+
+    def stream_admit(self, slots, prompts, uniforms=None):
+        s, sp = _u32(slots)
+        lens, lp = _u32([len(p) for p in prompts])
+        cat, cp = _u32(np.concatenate([np.asarray(p, dtype=np.uint32) for p in prompts]))
+        up = None
+        if uniforms is not None:
+            u = np.ascontiguousarray(uniforms, dtype=np.float32)
+            up = u.ctypes.data_as(C.POINTER(C.c_float))
+        self._chk(self.L.tts_hip_parler_stream_admit(self.ctx, len(s), sp, cp, lp, up))
+
+    def stream_run(self, n_steps):
+        """-> [(slot, steps)] of the utterances that finished inside these steps"""
+        n = C.c_uint32()
+        fs = np.zeros(self._stream_slots, dtype=np.uint32)
+        fn = np.zeros(self._stream_slots, dtype=np.uint32)
+        self._chk(self.L.tts_hip_parler_stream_run(self.ctx, n_steps, C.byref(n), fs.ctypes.data_as(C.POINTER(C.c_uint32)), fn.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return [(int(fs[i]), int(fn[i])) for i in range(n.value)]
+
+    def stream_collect(self, slot, steps):
+        out = np.zeros((steps, self.cfg.n_out), dtype=np.uint32)
+        self._chk(self.L.tts_hip_parler_stream_collect(self.ctx, slot, steps, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def stream_end(self):
+        self._chk(self.L.tts_hip_parler_stream_end(self.ctx))
 
     def generate_sampled(self, start_pos, n_steps, uniforms, top_k=50, top_p=1.0, temperature=1.0, bos=None, eos=None,
                          repetition_penalty=1.0):

@@ -103,6 +103,27 @@ struct tts_generation_runner : tts_runner {
     // another runner (tts_load_options::share_with / tts_hip_broadcast_weights)
     virtual void *   device_context() const { return nullptr; }
 
+    // ---- extension: continuous batching — a session that takes utterances in while others are still generating ---------------------
+    // The reference's server hands one task at a time to a worker that owns a whole model (examples/server/server.cpp:126-158, 236-271);
+    // generate_batch widened that to "form a batch from the queue, run it to the end".  A session keeps the lock-step forward full instead:
+    // stream_submit() enters an utterance into a free row at the next look-in point (every 32 decode steps), stream_step() runs one such
+    // interval and hands back the utterances whose check_stopping() fired inside it, already decoded to audio.  An utterance's audio is that
+    // of a generate() call of its own.  A runner without the extension reports 0 capacity and the callers fall back to generate_batch.
+    struct stream_result {
+        size_t       ticket = 0;   // the caller's handle, as given to stream_submit
+        tts_response audio;        // valid until the next stream_step / stream_end of this runner
+    };
+    virtual uint32_t stream_capacity() const { return 0; }            // utterances a session can hold at once (0: not supported)
+    virtual void     stream_begin(const generation_configuration & config);
+    virtual uint32_t stream_free() const { return 0; }                // free rows right now
+    virtual uint32_t stream_live() const { return 0; }                // utterances generating or waiting for their codec pass
+    virtual void     stream_submit(size_t ticket, const std::string & sentence);
+    virtual void     stream_step(std::vector<stream_result> & finished);
+    virtual void     stream_end();
+    // any number of sentences through one session (more than batch_capacity() is fine); outputs[i].data valid until the next call on this runner
+    void             generate_stream(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs,
+                                     const generation_configuration & config);
+
   protected:
     std::vector<std::vector<float>> batch_store_;  // audio of the default generate_batch
 };

@@ -258,7 +258,100 @@ void device_pool::worker_main(int w) {
             }
             continue;
         }
-        process(w, batch, ws);
+        if (opts_.continuous) process_stream(w, batch, ws);
+        else process(w, batch, ws);
+    }
+}
+
+// queued TTS tasks compatible with `like`, up to cap, without waiting.  None while a control task addressed to this worker waits: the session
+// drains first (a CONDITIONAL_PROMPT changes the voice of everything generated after it).
+std::vector<std::shared_ptr<pool_task>> device_pool::poll_compatible(int w, const pool_task & like, size_t cap) {
+    std::vector<std::shared_ptr<pool_task>> got;
+    std::lock_guard<std::mutex> lock(q_mutex_);
+    if (!running_ || !per_worker_[(size_t) w].empty()) return got;
+    for (auto it = queue_.begin(); it != queue_.end() && got.size() < cap;) {
+        if ((*it)->task == POOL_TTS && (*it)->model == like.model && pool_configs_compatible((*it)->gen_config, like.gen_config)) {
+            got.push_back(*it);
+            it = queue_.erase(it);
+        } else ++it;
+    }
+    return got;
+}
+
+// One generation session for a run of compatible requests: the first batch opens it, later arrivals enter rows that have freed up
+// (server.cpp:126-158 is the queue; :236-271 the one-task-at-a-time worker this replaces).
+void device_pool::process_stream(int w, std::vector<std::shared_ptr<pool_task>> & first, worker_state & ws) {
+    auto found = ws.runners.find(first[0]->model);
+    if (found == ws.runners.end() || !found->second || found->second->stream_capacity() == 0) { process(w, first, ws); return; }
+    tts_generation_runner & runner = *found->second;
+    std::map<size_t, std::shared_ptr<pool_task>> inflight;
+    std::vector<std::shared_ptr<pool_task>> done, overflow;
+    size_t ticket = 0;
+    uint64_t expired = 0, served = 0, joined = 0, peak = 0;
+    const pool_task like = *first[0];
+    auto finish = [&](std::vector<std::shared_ptr<pool_task>> & v) {
+        if (v.empty()) return;
+        { std::lock_guard<std::mutex> lock(r_mutex_); for (auto & t : v) completed_[t->id] = t; }
+        r_cv_.notify_all();
+        v.clear();
+    };
+    try {
+        runner.stream_begin(like.gen_config);
+        auto admit = [&](std::vector<std::shared_ptr<pool_task>> & tasks, bool in_flight) {
+            for (auto & t : tasks) {
+                t->worker = w;
+                if (t->timed_out(opts_.task_timeout_s)) { t->message = "timed out in the queue"; expired++; done.push_back(t); continue; }
+                if (runner.stream_free() == 0) { overflow.push_back(t); continue; }
+                runner.stream_submit(ticket, t->prompt);
+                inflight[ticket++] = t;
+                served++;
+                joined += in_flight;
+            }
+            const uint32_t rows = runner.stream_capacity() - runner.stream_free();   // utterances sharing the forward from here on
+            peak = std::max<uint64_t>(peak, rows);
+            for (auto & t : tasks) if (t->batch_size == 0) t->batch_size = (int) rows;
+        };
+        admit(first, false);
+        std::vector<tts_generation_runner::stream_result> fin;
+        while (runner.stream_live() > 0) {
+            runner.stream_step(fin);
+            for (auto & f : fin) {
+                auto it = inflight.find(f.ticket);
+                if (it == inflight.end()) continue;
+                pool_task & t = *it->second;
+                t.audio.assign(f.audio.data, f.audio.data + f.audio.n_outputs);   // the runner reuses its buffer on the next step
+                t.sample_rate = runner.sampling_rate;
+                t.success = f.audio.n_outputs != 0;
+                done.push_back(it->second);
+                inflight.erase(it);
+            }
+            finish(done);
+            if (!overflow.empty()) {
+                std::vector<std::shared_ptr<pool_task>> again;
+                again.swap(overflow);
+                for (auto & t : again) t->batch_size = 0;
+                admit(again, true);
+            }
+            if (runner.stream_free() > 0) {
+                auto more = poll_compatible(w, like, runner.stream_free());
+                if (!more.empty()) admit(more, true);
+            }
+        }
+        runner.stream_end();
+    } catch (const std::exception & e) {
+        for (auto & kv : inflight) { kv.second->success = false; kv.second->message = e.what(); done.push_back(kv.second); }
+        for (auto & t : overflow) { t->success = false; t->message = e.what(); done.push_back(t); }
+        inflight.clear(); overflow.clear();
+        try { runner.stream_end(); } catch (...) {}
+    }
+    finish(done);
+    {
+        std::lock_guard<std::mutex> lock(s_mutex_);
+        stats_.tasks += served + expired;
+        stats_.timed_out += expired;
+        stats_.batches += 1;
+        stats_.largest_batch = std::max<uint64_t>(stats_.largest_batch, peak);
+        stats_.admitted_in_flight += joined;
     }
 }
 

@@ -54,10 +54,16 @@ struct pool_options {
     int              task_timeout_s = 300; // :231, tasks older than this are answered with success == false
     std::string      text_encoder_path;    // T5 GGUF for CONDITIONAL_PROMPT tasks (server --text-encoder-path, :263-271)
     bool             share_weights = true; // parse + upload each model once: RCCL broadcast across devices, one arena per device
+    // continuous batching: a worker keeps ONE generation session per run of compatible requests and admits queued requests into rows that
+    // free up while the others are still generating (tts_generation_runner::stream_*; every 32 decode steps), instead of forming a batch from
+    // what is queued and running it to the end — a request that arrives one step late no longer waits a whole generation, and a ragged
+    // batch refills instead of idling.  Runners without a session (stream_capacity() == 0) keep the batch path.
+    bool             continuous = false;
 };
 
 struct pool_stats {
     uint64_t tasks = 0, batches = 0, largest_batch = 0, timed_out = 0;
+    uint64_t admitted_in_flight = 0;   // continuous batching: requests that entered a session while other utterances were already generating
 };
 
 // generation parameters that must agree for two tasks to share a lock-step batch
@@ -96,6 +102,8 @@ class device_pool {
     void load_all();
     void worker_main(int w);
     void process(int w, std::vector<std::shared_ptr<pool_task>> & batch, worker_state & ws);
+    void process_stream(int w, std::vector<std::shared_ptr<pool_task>> & first, worker_state & ws);
+    std::vector<std::shared_ptr<pool_task>> poll_compatible(int w, const pool_task & like, size_t cap);
     std::vector<std::shared_ptr<pool_task>> next_batch(int w, int cap);
     void control(int w, pool_task & t, worker_state & ws);
     struct fanout { std::shared_ptr<pool_task> parent; int remaining = 0; bool ok = true; std::string message; };

@@ -1,4 +1,6 @@
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cstdlib>
 // loaders.cpp — architecture registry + runner_from_file (mirrors /root/reference/src/models/loaders.cpp:13-95)
 #include <cmath>
@@ -59,6 +61,48 @@ void tts_generation_runner::generate_batch(const std::vector<std::string> & sent
     }
 }
 
+// continuous batching, the defaults: a runner without a session
+void tts_generation_runner::stream_begin(const generation_configuration &) { TTS_ABORT("stream_begin: this runner has no continuous batching (stream_capacity() == 0)\n"); }
+void tts_generation_runner::stream_submit(size_t, const std::string &) { TTS_ABORT("stream_submit: this runner has no continuous batching\n"); }
+void tts_generation_runner::stream_step(std::vector<stream_result> &) { TTS_ABORT("stream_step: this runner has no continuous batching\n"); }
+void tts_generation_runner::stream_end() {}
+
+// any number of sentences through one session: rows freed by utterances that finish are refilled from the list at the next look-in point
+void tts_generation_runner::generate_stream(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs,
+                                            const generation_configuration & config) {
+    if (stream_capacity() == 0) {   // no session: batches of at most batch_capacity(), one after the other
+        batch_store_.assign(sentences.size(), {});
+        outputs.assign(sentences.size(), tts_response{});
+        const size_t cap = std::max<size_t>(1, std::min<size_t>(sentences.size(), batch_capacity()));
+        for (size_t off = 0; off < sentences.size(); off += cap) {
+            std::vector<std::string> part(sentences.begin() + off, sentences.begin() + std::min(sentences.size(), off + cap));
+            std::vector<tts_response> out;
+            generate_batch(part, out, config);
+            for (size_t i = 0; i < part.size(); i++) {
+                batch_store_[off + i].assign(out[i].data, out[i].data + out[i].n_outputs);
+                outputs[off + i].data = batch_store_[off + i].data();
+                outputs[off + i].n_outputs = out[i].n_outputs;
+            }
+        }
+        return;
+    }
+    batch_store_.assign(sentences.size(), {});
+    outputs.assign(sentences.size(), tts_response{});
+    stream_begin(config);
+    size_t next = 0;
+    std::vector<stream_result> fin;
+    while (next < sentences.size() || stream_live() > 0) {
+        while (next < sentences.size() && stream_free() > 0) { stream_submit(next, sentences[next]); next++; }
+        stream_step(fin);
+        for (auto & f : fin) {
+            batch_store_[f.ticket].assign(f.audio.data, f.audio.data + f.audio.n_outputs);
+            outputs[f.ticket].data = batch_store_[f.ticket].data();
+            outputs[f.ticket].n_outputs = f.audio.n_outputs;
+        }
+    }
+    stream_end();
+}
+
 // ---- "test:dummy": weightless plumbing backend (src/models/dummy/model.cpp:6-19) ----------------------
 namespace {
 struct dummy_loader_t final : tts_model_loader {
@@ -86,6 +130,38 @@ struct dummy_runner final : tts_generation_runner {
         output.data = out.data();
         output.n_outputs = out.size();
     }
+    // A session for the plumbing tests of the continuous batching (device_pool::process_stream, generate_stream) without a device: four rows,
+    // an utterance of n characters "generates" for n look-in intervals and then yields generate()'s audio.
+    struct row { size_t ticket; std::string text; size_t left; };
+    std::vector<row>                st_rows;
+    std::vector<std::vector<float>> st_audio;
+    bool                            st_on = false;
+    uint32_t stream_capacity() const override { return 4; }
+    void     stream_begin(const generation_configuration &) override { st_rows.clear(); st_on = true; }
+    uint32_t stream_free() const override { return st_on ? 4 - (uint32_t) st_rows.size() : 0; }
+    uint32_t stream_live() const override { return (uint32_t) st_rows.size(); }
+    void     stream_submit(size_t ticket, const std::string & sentence) override {
+        if (!st_on || st_rows.size() >= 4) TTS_ABORT("stream_submit: no free row\n");
+        st_rows.push_back(row{ticket, sentence, std::max<size_t>(1, sentence.size())});
+    }
+    void stream_step(std::vector<stream_result> & finished) override {
+        finished.clear();
+        st_audio.clear();
+        std::this_thread::sleep_for(std::chrono::milliseconds(10));   // an interval takes a while: requests do arrive during a generation
+        std::vector<row> keep;
+        for (auto & r : st_rows) {
+            if (--r.left > 0) { keep.push_back(r); continue; }
+            tts_response resp;
+            generate(r.text.c_str(), resp, generation_configuration{});
+            st_audio.emplace_back(resp.data, resp.data + resp.n_outputs);
+            stream_result f;
+            f.ticket = r.ticket;
+            finished.push_back(f);
+        }
+        for (size_t i = 0; i < finished.size(); i++) { finished[i].audio.data = st_audio[i].data(); finished[i].audio.n_outputs = st_audio[i].size(); }
+        st_rows.swap(keep);
+    }
+    void stream_end() override { st_rows.clear(); st_on = false; }
 };
 std::unique_ptr<tts_generation_runner> dummy_loader_t::from_file(gguf_file *, int, bool, const generation_configuration &) const {
     return std::make_unique<dummy_runner>();

@@ -384,3 +384,119 @@ void parler_runner::generate_batch(const std::vector<std::string> & sentences, s
         off += outputs[row_of[i]].n_outputs;
     }
 }
+
+// ---- continuous batching (common.h; tts_hip_parler_stream_* underneath) ----------------------------------------------------------------
+static constexpr uint32_t STREAM_CHUNK = 32;     // decode steps between two look-in points (what generate_loop's compaction uses)
+static constexpr size_t   STREAM_CODEC_GROUP = 64;   // finished utterances per codec pass (the device's pass size); flushed when the session drains
+
+void parler_runner::stream_begin(const generation_configuration & config) {
+    if (stream_capacity() == 0) TTS_ABORT("stream_begin: the runner was loaded with max_seqs=%u; a session needs >= 2 (TTS_HIP_MAX_SEQS)\n", max_seqs);
+    if (config.use_cross_attn != use_cross_attn) TTS_ABORT("stream_begin: use_cross_attn differs from load time\n");
+    if (config.sample && hp.output_vocab_size > 2048) TTS_ABORT("stream_begin: sampling over %u logits per head is host-only\n", hp.output_vocab_size);
+    if (st_on) stream_end();
+    const uint32_t slots = stream_capacity();
+    st_cfg = config;
+    st_max_steps = hp.max_generation_size - 1;   // an utterance ends at position max_generation (check_stopping): at most this many steps after a 1-id prompt
+    const tts_hip_sampling sp{(uint32_t) config.top_k, config.top_p, config.temperature, config.repetition_penalty};
+    hip_check(tts_hip_parler_stream_begin(ctx, slots, st_max_steps, hp.bos_token_id, hp.eos_token_id, config.sample ? &sp : nullptr), "tts_hip_parler_stream_begin");
+    st_free.clear();
+    for (uint32_t s = slots; s-- > 0;) st_free.push_back(s);   // pop_back hands out slot 0 first
+    st_ticket.assign(slots, 0);
+    st_start.assign(slots, 0);
+    st_wait.clear(); st_codec.clear(); st_pcm.clear();
+    st_live = 0;
+    st_on = true;
+}
+
+void parler_runner::stream_submit(size_t ticket, const std::string & sentence) {
+    if (!st_on) TTS_ABORT("stream_submit: no session (stream_begin)\n");
+    if (st_free.empty()) TTS_ABORT("stream_submit: no free row (stream_free() == 0)\n");
+    pending p;
+    p.ticket = ticket;
+    tokenizer->tokenize(sentence, p.prompt);
+    p.prompt.push_back(tokenizer->eos_token);
+    if (p.prompt.size() >= hp.max_generation_size || p.prompt.size() >= hp.max_ctx_length) {
+        // generate() answers such a prompt with an empty response: the session does the same at its next step
+        fprintf(stderr, "prompt of %zu tokens leaves no room for generation\n", p.prompt.size());
+        st_codec.push_back(decoded{ticket, {}});
+        return;
+    }
+    p.slot = st_free.back();
+    st_free.pop_back();
+    st_wait.push_back(std::move(p));
+    st_live++;
+}
+
+void parler_runner::stream_step(std::vector<stream_result> & finished) {
+    if (!st_on) TTS_ABORT("stream_step: no session (stream_begin)\n");
+    finished.clear();
+    const uint32_t nh = hp.n_output_heads;
+    if (!st_wait.empty()) {   // the newcomers: one prefill side batch, then rows of the lock-step forward
+        std::vector<uint32_t> slots, ids, lens;
+        std::vector<float> uni;
+        for (auto & p : st_wait) {
+            slots.push_back(p.slot);
+            lens.push_back((uint32_t) p.prompt.size());
+            ids.insert(ids.end(), p.prompt.begin(), p.prompt.end());
+            st_ticket[p.slot] = p.ticket;
+            st_start[p.slot] = (uint32_t) p.prompt.size();
+            if (st_cfg.sample) {   // the utterance's own sampler, seeded as a generate() call of its own would be
+                sampler si = smp;
+                si.seed = st_cfg.seed; si.n_calls = 0;
+                const size_t o = uni.size();
+                uni.resize(o + (size_t) st_max_steps * nh);
+                for (uint32_t s = 0; s < st_max_steps; s++) si.draw_uniforms(uni.data() + o + (size_t) s * nh);
+            }
+        }
+        hip_check(tts_hip_parler_stream_admit(ctx, (uint32_t) slots.size(), slots.data(), ids.data(), lens.data(), st_cfg.sample ? uni.data() : nullptr),
+                  "tts_hip_parler_stream_admit");
+        st_wait.clear();
+    }
+    std::vector<uint32_t> fs(stream_capacity()), fn(stream_capacity());
+    uint32_t nf = 0;
+    hip_check(tts_hip_parler_stream_run(ctx, STREAM_CHUNK, &nf, fs.data(), fn.data()), "tts_hip_parler_stream_run");
+    for (uint32_t i = 0; i < nf; i++) {
+        const uint32_t slot = fs[i];
+        const uint32_t steps = std::min(fn[i], hp.max_generation_size - st_start[slot]);   // what generate() would have run alone
+        std::vector<uint32_t> toks((size_t) steps * nh);
+        hip_check(tts_hip_parler_stream_collect(ctx, slot, steps, toks.data()), "tts_hip_parler_stream_collect");
+        decoded d;
+        d.ticket = st_ticket[slot];
+        adjust_output_tokens(toks, d.frames);
+        st_codec.push_back(std::move(d));
+        st_free.push_back(slot);
+        st_live--;
+    }
+    // the codec: whole groups as they fill, everything that is left once nothing is generating (a session never holds audio back for company)
+    const bool drain = st_live == 0;
+    size_t take = st_codec.size() >= STREAM_CODEC_GROUP ? st_codec.size() / STREAM_CODEC_GROUP * STREAM_CODEC_GROUP : (drain ? st_codec.size() : 0);
+    if (take) {
+        std::vector<uint32_t> codes, frames(take);
+        size_t total = 0;
+        for (size_t i = 0; i < take; i++) {
+            frames[i] = (uint32_t) (st_codec[i].frames.size() / nh);
+            codes.insert(codes.end(), st_codec[i].frames.begin(), st_codec[i].frames.end());
+            total += (size_t) frames[i] * hp.up_sampling_factor;
+        }
+        pcm.assign(total, 0.0f);
+        if (total) hip_check(tts_hip_dac_decode_batch(ctx, codes.data(), frames.data(), (uint32_t) take, pcm.data()), "tts_hip_dac_decode_batch");
+        size_t off = 0;
+        for (size_t i = 0; i < take; i++) {
+            stream_result r;
+            r.ticket = st_codec[i].ticket;
+            r.audio.data = pcm.data() + off;
+            r.audio.n_outputs = (size_t) frames[i] * hp.up_sampling_factor;
+            off += r.audio.n_outputs;
+            finished.push_back(r);
+        }
+        st_codec.erase(st_codec.begin(), st_codec.begin() + (std::ptrdiff_t) take);
+    }
+}
+
+void parler_runner::stream_end() {
+    if (!st_on) return;
+    (void) tts_hip_parler_stream_end(ctx);
+    st_on = false;
+    st_wait.clear(); st_codec.clear();
+    st_live = 0;
+}

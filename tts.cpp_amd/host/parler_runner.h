@@ -46,6 +46,14 @@ struct parler_runner final : tts_generation_runner {
     void generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs,
                         const generation_configuration & config) override;
     uint32_t batch_capacity() const override { return max_seqs; }
+    // continuous batching (common.h): max_seqs - 1 rows (one cache slot pads the lock-step forward), tts_hip_parler_stream_* underneath
+    uint32_t stream_capacity() const override { return max_seqs > 1 ? max_seqs - 1 : 0; }
+    void     stream_begin(const generation_configuration & config) override;
+    uint32_t stream_free() const override { return (uint32_t) st_free.size(); }
+    uint32_t stream_live() const override { return st_live + (uint32_t) st_codec.size(); }
+    void     stream_submit(size_t ticket, const std::string & sentence) override;
+    void     stream_step(std::vector<stream_result> & finished) override;
+    void     stream_end() override;
     void *   device_context() const override { return ctx; }
     bool          declare_only = false;   // tts_load_options at load time: no weight bytes uploaded by this runner
     tts_hip_ctx * share_ctx = nullptr;    // ... and whose arena it uses instead (same device)
@@ -66,4 +74,18 @@ struct parler_runner final : tts_generation_runner {
     std::vector<uint32_t>              last_conditional_tokens;  // ids the voice prompt was encoded from (tests)
     std::vector<float>                 pcm;     // runner-owned output buffer (dctx->buf_output)
     std::vector<float>                 logits;
+
+  private:
+    // session state of the continuous batching
+    struct pending { size_t ticket; uint32_t slot; std::vector<uint32_t> prompt; };
+    struct decoded { size_t ticket; std::vector<uint32_t> frames; };   // un-delayed codes waiting for a codec pass
+    bool                        st_on = false;
+    generation_configuration    st_cfg{};
+    uint32_t                    st_live = 0, st_max_steps = 0;
+    std::vector<uint32_t>       st_free;            // free cache slots
+    std::vector<size_t>         st_ticket;          // slot -> ticket
+    std::vector<uint32_t>       st_start;           // slot -> prompt length
+    std::vector<pending>        st_wait;            // submitted, not yet admitted (admitted as one side batch by the next stream_step)
+    std::vector<decoded>        st_codec;
+    std::vector<std::vector<float>> st_pcm;         // audio handed out by the last stream_step
 };

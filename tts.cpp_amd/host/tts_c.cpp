@@ -83,6 +83,21 @@ int tts_c_generate_batch(tts_c_runner * r, const char * const * texts, int n, co
     }
 }
 
+int tts_c_generate_stream(tts_c_runner * r, const char * const * texts, int n, const tts_c_config * cfg, const float ** data, size_t * n_outputs) {
+    g_tts_throw_on_abort = true;
+    try {
+        auto * p = (tts_generation_runner *) r;
+        std::vector<std::string> s(texts, texts + n);
+        std::vector<tts_response> out;
+        p->generate_stream(s, out, to_cfg(cfg));
+        for (int i = 0; i < n; i++) { data[i] = out[(size_t) i].data; n_outputs[i] = out[(size_t) i].n_outputs; }
+        return 0;
+    } catch (const std::exception & e) {
+        g_c_err = e.what();
+        return -1;
+    }
+}
+
 int tts_c_update_conditional_prompt(tts_c_runner * r, const char * text_encoder_path, const char * prompt) {
     g_tts_throw_on_abort = true;
     try {
@@ -347,6 +362,9 @@ struct tts_c_pool {
 
 static thread_local std::string g_pool_text_encoder;
 void tts_c_pool_set_text_encoder(const char * path) { g_pool_text_encoder = path ? path : ""; }
+static thread_local bool g_pool_continuous = false;
+void tts_c_pool_set_continuous(int on) { g_pool_continuous = on != 0; }
+uint64_t tts_c_pool_admitted_in_flight(tts_c_pool * p) { return p->pool->stats().admitted_in_flight; }
 
 int tts_c_pool_conditional_prompt(tts_c_pool * p, const char * prompt) {
     const int id = p->pool->submit_conditional_prompt("default", prompt);
@@ -363,6 +381,7 @@ tts_c_pool * tts_c_pool_create(const char * model_path, int n_workers, const int
         for (int i = 0; devices && i < n_devices; i++) o.devices.push_back(devices[i]);
         o.max_batch = max_batch;
         o.batch_window_ms = batch_window_ms;
+        o.continuous = g_pool_continuous;
         auto p = std::make_unique<tts_c_pool>();
         p->pool = std::make_unique<device_pool>(std::map<std::string, std::string>{{"default", model_path}}, to_cfg(load_cfg), o);
         if (!p->pool->ok()) { g_c_err = p->pool->error(); return nullptr; }

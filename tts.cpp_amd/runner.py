@@ -26,9 +26,9 @@ class SamplerCfg(C.Structure):
                 ("top_p", C.c_float), ("repetition_penalty", C.c_float), ("do_sample", C.c_int), ("seed", C.c_uint64)]
 
 
-EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_generate_batch", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
+EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_generate_batch", "tts_c_generate_stream", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
            "tts_c_last_error", "tts_c_update_conditional_prompt", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor",
-           "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_load_stats", "tts_c_pool_free", "tts_c_set_load_options", "tts_c_set_load_options_ex", "tts_c_runner_device_context", "tts_c_runner_tokenize",
+           "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_set_continuous", "tts_c_pool_admitted_in_flight", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_load_stats", "tts_c_pool_free", "tts_c_set_load_options", "tts_c_set_load_options_ex", "tts_c_runner_device_context", "tts_c_runner_tokenize",
            "tts_c_quantize_gguf", "tts_c_quantize_decision", "tts_c_quantize_rows",
            "tts_c_dia_tokenize", "tts_c_dia_check_stopping", "tts_c_dia_adjust_output_tokens", "tts_c_single_pass_tokenize", "tts_c_kokoro_chunks"]
 
@@ -52,6 +52,7 @@ def load_lib():
         L.tts_c_generate.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Config), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t)]
         L.tts_c_generate_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(Config), C.POINTER(C.POINTER(C.c_float)),
                                            C.POINTER(C.c_size_t)]
+        L.tts_c_generate_stream.argtypes = L.tts_c_generate_batch.argtypes
         L.tts_c_sampling_rate.restype = C.c_float
         L.tts_c_sampling_rate.argtypes = [C.c_void_p]
         L.tts_c_arch.restype = C.c_char_p
@@ -81,6 +82,10 @@ def load_lib():
         L.tts_c_pool_submit.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Config)]
         L.tts_c_pool_set_text_encoder.argtypes = [C.c_char_p]
         L.tts_c_pool_set_text_encoder.restype = None
+        L.tts_c_pool_set_continuous.argtypes = [C.c_int]
+        L.tts_c_pool_set_continuous.restype = None
+        L.tts_c_pool_admitted_in_flight.argtypes = [C.c_void_p]
+        L.tts_c_pool_admitted_in_flight.restype = C.c_uint64
         L.tts_c_pool_conditional_prompt.argtypes = [C.c_void_p, C.c_char_p]
         L.tts_c_pool_wait.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.tts_c_pool_release.argtypes = [C.c_void_p, C.c_int]
@@ -163,6 +168,19 @@ class Runner:
         if self.L.tts_c_generate_batch(self.h, arr, n, C.byref(c), data, ns) != 0:
             raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
         return [int(ns[i]) for i in range(n)]
+
+    def generate_stream(self, texts, sizes_only=False, **cfg):
+        """tts_c_generate_stream: any number of utterances through one continuous-batching session (rows freed by finished utterances are refilled)"""
+        c = make_config(**cfg) if cfg else self.cfg
+        n = len(texts)
+        arr = (C.c_char_p * n)(*[t.encode("utf-8") for t in texts])
+        data = (C.POINTER(C.c_float) * n)()
+        ns = (C.c_size_t * n)()
+        if self.L.tts_c_generate_stream(self.h, arr, n, C.byref(c), data, ns) != 0:
+            raise RunnerError(self.L.tts_c_last_error().decode("utf-8", "replace"))
+        if sizes_only:
+            return [int(ns[i]) for i in range(n)]
+        return [np.ctypeslib.as_array(data[i], shape=(ns[i],)).copy() if ns[i] else np.zeros(0, dtype=np.float32) for i in range(n)]
 
     def tokenize(self, text):
         n = self.L.tts_c_runner_tokenize(self.h, text.encode("utf-8"), None, 0)
@@ -296,10 +314,11 @@ class Pool:
     """device_pool (host/device_pool.h): the reference server's worker pool with one worker per device and dynamic
     lock-step batching.  submit() -> id; wait(id) -> (audio, batch_size, worker)."""
 
-    def __init__(self, path, n_workers=1, devices=None, max_batch=1, batch_window_ms=0, text_encoder_path=None, **cfg):
+    def __init__(self, path, n_workers=1, devices=None, max_batch=1, batch_window_ms=0, text_encoder_path=None, continuous=False, **cfg):
         self.L = load_lib()
         self.cfg = make_config(**cfg)
         self.L.tts_c_pool_set_text_encoder(text_encoder_path.encode() if text_encoder_path else None)
+        self.L.tts_c_pool_set_continuous(1 if continuous else 0)   # pool_options::continuous: requests join a running generation
         dev = (C.c_int * len(devices))(*devices) if devices else None
         self.h = self.L.tts_c_pool_create(path.encode(), n_workers, dev, len(devices) if devices else 0, max_batch, batch_window_ms, C.byref(self.cfg))
         if not self.h:
@@ -337,7 +356,9 @@ class Pool:
     def stats(self):
         v = [C.c_uint64() for _ in range(4)]
         self.L.tts_c_pool_stats(self.h, *[C.byref(x) for x in v])
-        return dict(zip(("tasks", "batches", "largest_batch", "timed_out"), [x.value for x in v]))
+        d = dict(zip(("tasks", "batches", "largest_batch", "timed_out"), [x.value for x in v]))
+        d["admitted_in_flight"] = int(self.L.tts_c_pool_admitted_in_flight(self.h))
+        return d
 
     def close(self):
         if self.h:
