@@ -137,10 +137,14 @@ static __global__ __launch_bounds__(64) void llama_rope_kv_kernel(float *qkv, co
         const float cs = cosf(ang), sn = sinf(ang);
         float x0 = v[i], x1 = v[i + half];
         {   // slabs 1..7 in flight together, added in slab order
+            // straight-line (a slab beyond n_parts re-reads the last one and is never added): under `if (q < n_parts)` each pair of loads was a
+            // basic block behind its own wait — seven dependent round trips for what is one round trip of data
             float t0[7], t1[7];
 #pragma unroll
-            for (int q = 1; q < 8; q++)
-                if (q < n_parts) { t0[q - 1] = v[q * part_stride + i]; t1[q - 1] = v[q * part_stride + i + half]; }
+            for (int q = 1; q < 8; q++) {
+                const int64_t qo = (int64_t) min(q, n_parts - 1) * part_stride;
+                t0[q - 1] = v[qo + i]; t1[q - 1] = v[qo + i + half];
+            }
 #pragma unroll
             for (int q = 1; q < 8; q++)
                 if (q < n_parts) { x0 += t0[q - 1]; x1 += t1[q - 1]; }
@@ -159,8 +163,7 @@ static __global__ __launch_bounds__(64) void llama_rope_kv_kernel(float *qkv, co
         for (int i = threadIdx.x; i < HD; i += 64) {
             float t = vsrc[i], tp[7];
 #pragma unroll
-            for (int q = 1; q < 8; q++)
-                if (q < n_parts) tp[q - 1] = vsrc[q * part_stride + i];
+            for (int q = 1; q < 8; q++) tp[q - 1] = vsrc[(int64_t) min(q, n_parts - 1) * part_stride + i];
 #pragma unroll
             for (int q = 1; q < 8; q++)
                 if (q < n_parts) t += tp[q - 1];
@@ -568,7 +571,18 @@ static __global__ void silu_mul_kernel(const float *gu, int F, int R, float *g, 
     if (i >= (int64_t) R * F) return;
     const int64_t r = i / F, c = i - r * F;
     float x = gu[r * 2 * F + c], u = gu[r * 2 * F + F + c];
-    for (int q = 1; q < n_parts; q++) { x += gu[q * part_stride + r * 2 * F + c]; u += gu[q * part_stride + r * 2 * F + F + c]; }
+    {   // slabs 1..7 requested together (clamped: a slab beyond n_parts re-reads the last one), added in slab order; a loop of dependent loads before
+        float tx[7], tu[7];
+#pragma unroll
+        for (int q = 1; q < 8; q++) {
+            const int64_t qo = (int64_t) min(q, n_parts - 1) * part_stride + r * 2 * F + c;
+            tx[q - 1] = gu[qo]; tu[q - 1] = gu[qo + F];
+        }
+#pragma unroll
+        for (int q = 1; q < 8; q++)
+            if (q < n_parts) { x += tx[q - 1]; u += tu[q - 1]; }
+        for (int q = 8; q < n_parts; q++) { x += gu[q * part_stride + r * 2 * F + c]; u += gu[q * part_stride + r * 2 * F + F + c]; }
+    }
     const float o = (x / (1.0f + expf(-x))) * u;
     g[i] = o;
     if (aq) q8_block_store(o, i, aq, ad);

@@ -461,18 +461,18 @@ __global__ void gemv_valu_kernel(GemmArgs a, int EPI, int act_f16_src) {
 template <int NI, int NP>
 __device__ __forceinline__ void ln_row_regs(float *xr, int H, int lane, const float *lw, const float *lb, float *yr32, _Float16 *yr16,
                                             const float *pr, int n_parts, int64_t slab_stride) {
+    // straight-line loads with clamped offsets (a piece beyond the row re-reads the row's last float4 and is never used): under `if (k < H)`
+    // every piece was its own basic block behind a full s_waitcnt — NI dependent round trips for a row that is one round trip of data
     float4v v[NI], w4[NI], b4[NI];
     float4v p[NP > 0 ? NP : 1][NI];
 #pragma unroll
     for (int i = 0; i < NI; i++) {
-        const int k = i * 256 + lane * 4;
-        if (k < H) {
-            v[i] = *(const float4v *) (xr + k);
+        const int k = min(i * 256 + lane * 4, H - 4);
+        v[i] = *(const float4v *) (xr + k);
 #pragma unroll
-            for (int sp = 0; sp < NP; sp++) p[sp][i] = *(const float4v *) (pr + sp * slab_stride + k);
-            w4[i] = *(const float4v *) (lw + k);
-            b4[i] = *(const float4v *) (lb + k);
-        }
+        for (int sp = 0; sp < NP; sp++) p[sp][i] = *(const float4v *) (pr + sp * slab_stride + k);
+        w4[i] = *(const float4v *) (lw + k);
+        b4[i] = *(const float4v *) (lb + k);
     }
     if (NP != 0) {
 #pragma unroll
@@ -595,6 +595,42 @@ __device__ __forceinline__ float4v load_kv4(const void *base, int kv_f16, int64_
     return *(const float4v *) ((const float *) base + off);
 }
 
+template <bool KVF16>
+__device__ __forceinline__ void attn_key_pass(const AttnArgs &a, int64_t hb, float4v q4, int tbeg, int t1, int step, int NKG, float &m, float &l, float4v &acc) {
+    for (int t = tbeg; t < t1; t += step) {
+        // the eight rows of a pass requested back to back (a key beyond the slice re-reads the slice's last key and is never used): under
+        // `if (t + u * NKG < t1)` each pair of loads was a basic block behind its own s_waitcnt, four dependent round trips per pass
+        float4v k4[4], v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t off = hb + (int64_t) min(t + u * NKG, t1 - 1) * a.H;
+            if (KVF16) {
+                const half4 hk = *(const half4 *) ((const _Float16 *) a.kc + off), hv = *(const half4 *) ((const _Float16 *) a.vc + off);
+                k4[u] = (float4v){(float) hk[0], (float) hk[1], (float) hk[2], (float) hk[3]};
+                v4[u] = (float4v){(float) hv[0], (float) hv[1], (float) hv[2], (float) hv[3]};
+            } else {
+                k4[u] = *(const float4v *) ((const float *) a.kc + off);
+                v4[u] = *(const float4v *) ((const float *) a.vc + off);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (t + u * NKG < t1) {
+                float d = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
+                d = row16_sum(d);
+                d *= a.scale;  // soft_max_ext(kq, mask, 1/sqrt(d), 0)
+                const float mn = fmaxf(m, d);
+                const float f = expf(m - mn);   // 0 on the first key (m = -inf)
+                const float p = expf(d - mn);
+                l = l * f + p;
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] = acc[e] * f + p * v4[u][e];
+                m = mn;
+            }
+        }
+    }
+}
+
 // blockDim.x = 16 * NKG threads (NKG key groups of 16 lanes; 16 for 256 threads, 64 for 1024 threads: the
 // wide form keeps a single workgroup per (head,row) fast enough that small batches need no split-T pass).
 // Single pass: the K and V rows of a key are loaded together (one HBM round trip per 4*NKG keys instead of
@@ -620,31 +656,10 @@ static __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {   // U 
 
     float m = -INFINITY, l = 0.0f;
     float4v acc = {0.f, 0.f, 0.f, 0.f};
-    for (int t = t0 + kg; t < t1; t += step) {
-        float4v k4[4], v4[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (t + u * NKG < t1) {
-                const int64_t off = hb + (int64_t) (t + u * NKG) * a.H;
-                k4[u] = load_kv4(a.kc, a.kv_f16, off);
-                v4[u] = load_kv4(a.vc, a.kv_f16, off);
-            }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (t + u * NKG < t1) {
-                float d = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
-                d = row16_sum(d);
-                d *= a.scale;  // soft_max_ext(kq, mask, 1/sqrt(d), 0)
-                const float mn = fmaxf(m, d);
-                const float f = expf(m - mn);   // 0 on the first key (m = -inf)
-                const float p = expf(d - mn);
-                l = l * f + p;
-#pragma unroll
-                for (int e = 0; e < 4; e++) acc[e] = acc[e] * f + p * v4[u][e];
-                m = mn;
-            }
-        }
-    }
+    // the cache type is a run-time flag of the context: one instance of the key pass per type, chosen once (a `flag ? half load : float load`
+    // inside the pass made every load its own basic block behind a wait: 11 dependent load groups in the ISA of the dominant kernel)
+    if (a.kv_f16) attn_key_pass<true>(a, hb, q4, t0 + kg, t1, step, NKG, m, l, acc);
+    else attn_key_pass<false>(a, hb, q4, t0 + kg, t1, step, NKG, m, l, acc);
     if (a.stamps != nullptr) { asm volatile("" :: "v"(acc[0])); B1_STAMP(a.stamps, 1); }
     // merge the key groups
     if (cl == 0) red[NKG * 64 + kg] = m;
@@ -717,6 +732,47 @@ static __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {   // U 
     else a.out[(int64_t) r * a.H + h * 64 + tid] = res;
     if (tid == 0) __hip_atomic_store(a.counters + r * a.n_heads + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.stamps != nullptr && tid == 0 && (h == 0 || h == (int) gridDim.x - 1) && r == 0) a.stamps[(h ? 8 : 0) + 3] = (long long) __builtin_amdgcn_s_memrealtime();
+}
+
+// The unsplit form of attn_kernel (256 threads, one (head, row) item at a time) as a workgroup that WALKS items: the grid is a fixed number of
+// workgroups per CU instead of one per item.  A 1024-row forward launches 16 384 items; as one-item workgroups they fill all 32 wave slots of
+// every CU for the whole launch, and the GEMM workgroups of another runner's step (8 waves, 128 KB of LDS) never find room beside them — two
+// decoder loops side by side gained 1.19x, no more (profiles/r04/dec_overlap_product_kernels.txt).  Six walking workgroups per CU (24 waves,
+// 336 of the 512 registers per SIMD, 26 KB of LDS) leave exactly the room a tiled GEMM workgroup needs.  Same arithmetic per item.
+static __global__ __launch_bounds__(256) void attn_walk_kernel(AttnArgs a, int n_items) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NKG = 16;
+    float *red = (float *) smem;                 // [NKG][64] acc, [NKG] max, [NKG] sum
+    const int tid = threadIdx.x, kg = tid >> 4, cl = tid & 15, c4 = cl * 4;
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int h = it % a.n_heads, r = it / a.n_heads;
+        const int T = a.row_pos ? (int) a.row_pos[r] + 1 : a.T_fixed;
+        const int64_t sb = a.row_seq ? (int64_t) a.row_seq[r] * a.seq_stride : 0;
+        const int64_t hb = sb + h * 64 + c4;
+        const float4v q4 = *(const float4v *) (a.q + (int64_t) r * a.H + h * 64 + c4);
+        float m = -INFINITY, l = 0.0f;
+        float4v acc = {0.f, 0.f, 0.f, 0.f};
+        if (a.kv_f16) attn_key_pass<true>(a, hb, q4, kg, T, NKG * 4, NKG, m, l, acc);
+        else attn_key_pass<false>(a, hb, q4, kg, T, NKG * 4, NKG, m, l, acc);
+        if (cl == 0) red[NKG * 64 + kg] = m;
+        __syncthreads();
+        float mx = -INFINITY;
+        for (int i = 0; i < NKG; i++) mx = fmaxf(mx, red[NKG * 64 + i]);
+        const float f = (m == -INFINITY) ? 0.0f : expf(m - mx);
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[e] *= f;
+        *(float4v *) (red + kg * 64 + c4) = acc;
+        if (cl == 0) red[NKG * 65 + kg] = l * f;
+        __syncthreads();
+        if (tid < 64) {
+            float o = 0.0f, sm = 0.0f;
+            for (int i = 0; i < NKG; i++) { o += red[i * 64 + tid]; sm += red[NKG * 65 + i]; }
+            const float res = o / sm;
+            if (a.out16) a.out16[(int64_t) r * a.H + h * 64 + tid] = (_Float16) res;
+            else a.out[(int64_t) r * a.H + h * 64 + tid] = res;
+        }
+        __syncthreads();   // red is reused by the next item
+    }
 }
 
 // Cross-attention over a short voice prompt (T_fixed <= 32 encoder positions; Parler-Mini: 8..40): the general kernel
