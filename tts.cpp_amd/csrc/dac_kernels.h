@@ -628,24 +628,58 @@ __global__ __launch_bounds__(64 * WM * WN, (KT == 7 && MI * NI <= 4) ? CONV7_MIN
         __syncthreads();
     }
     if (a.prio == 1 || a.prio == 2) __builtin_amdgcn_s_setprio(0);
+    // Epilogue in phases per (32-channel block, channel quad): the phase's loads first (bias, the consumer's alpha, the residual values — clamped
+    // indices, the run-time switches tested once per phase, not per value), then its arithmetic, then its predicated stores; a scheduling barrier
+    // keeps the compiler from pulling every phase's loads to the front (that cost 100+ registers and two of the three resident waves).  The
+    // per-value form (`a.b ? a.b[co] : 0`, `if (rg)`, `if (t >= L) continue` around single loads) compiled to load -> s_waitcnt -> store for each
+    // of the 16 MI (x NI) values: 100-160 dependent round trips at the end of every launch (profiles/tools/isa_serial_loads.py) — most of what
+    // Kokoro's short convolutions were.  4 MI round trips now; same arithmetic per value.
 #pragma unroll
     for (int i = 0; i < MI; i++) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int co = co0 + (wm * MI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-            if (co >= a.cout) continue;
-            const float bias = a.b ? a.b[co] : 0.0f;
-            const float al_o = a.alpha_out ? a.alpha_out[co] : 1.0f, ral_o = 1.0f / al_o;
+        for (int q = 0; q < 4; q++) {
+            float bias[4], alo[4], res[NI][4];
+            int cos[4];
 #pragma unroll
-            for (int j = 0; j < NI; j++) {
-                const int t = t0 + (wn * NI + j) * 32 + l31;
-                if (t >= L) continue;
-                float v = acc[i][j][e] + bias;
-                if (rg) v = v + rg[(int64_t) co * LS + t];
-                if (a.alpha_out) v = snake_f(v, al_o, ral_o);
-                if (a.do_tanh) v = tanhf(v);
-                yg[(int64_t) co * LS + t] = v;
+            for (int m = 0; m < 4; m++) cos[m] = min(co0 + (wm * MI + i) * 32 + m + 8 * q + 4 * hi, a.cout - 1);
+            if (a.b) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) bias[m] = a.b[cos[m]];
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; m++) bias[m] = 0.0f;
             }
+            if (a.alpha_out) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) alo[m] = a.alpha_out[cos[m]];
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; m++) alo[m] = 1.0f;
+            }
+            if (rg) {
+#pragma unroll
+                for (int j = 0; j < NI; j++) {
+                    const int t = min(t0 + (wn * NI + j) * 32 + l31, L - 1);
+#pragma unroll
+                    for (int m = 0; m < 4; m++) res[j][m] = rg[(int64_t) cos[m] * LS + t];
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int e = 4 * q + m;
+                const int co = co0 + (wm * MI + i) * 32 + m + 8 * q + 4 * hi;
+                const float ral_o = 1.0f / alo[m];
+#pragma unroll
+                for (int j = 0; j < NI; j++) {
+                    const int t = t0 + (wn * NI + j) * 32 + l31;
+                    float v = acc[i][j][e] + bias[m];
+                    if (rg) v = v + res[j][m];
+                    if (a.alpha_out) v = snake_f(v, alo[m], ral_o);
+                    if (a.do_tanh) v = tanhf(v);
+                    if (co < a.cout && t < L) yg[(int64_t) co * LS + t] = v;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
