@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Batch-1 Parler-TTS-Mini chain (fp16 weights, fp32 KV): ms per step of the device-resident greedy loop under the knobs of the
-variants below, the tokens of every variant against the plain chain, the logits of one step against it, and (TTS_HIP_B1_STAMPS=1)
+variants below, the tokens of every variant against the plain chain, the logits of one step against it, and (tune key b1_stamps)
 the in-kernel timeline of the last graph-replayed step (s_memrealtime stamps of the first and the last workgroup of every launch).
 
   python profiles/b1_chain.py            # all variants, each in its own process (the knobs are read at context creation)
@@ -18,7 +18,8 @@ def one():
     from tts_cpp_amd import gguf, hip, synth
     cfg = synth.parler_mini(weight_type=gguf.F16)
     model = synth.build(cfg)
-    eng = hip.HipEngine(cfg, device=0, max_seqs=1, kv_type=gguf.F32, kv_positions=min(cfg.ctx, cfg.max_gen))
+    tune = json.loads(os.environ.get("B1_TUNE", "{}"))   # tts_hip_tune keys of this variant (the environment switches of round 3 became tune keys)
+    eng = hip.HipEngine(cfg, device=0, max_seqs=1, kv_type=gguf.F32, kv_positions=min(cfg.ctx, cfg.max_gen), tune=tune)
     eng.load(model)
     prompt = np.random.default_rng(3).integers(3, cfg.prompt_vocab, 16).astype(np.uint32)
     eng.prefill_batch([prompt]); eng.generate_greedy([len(prompt)], 32)
@@ -29,7 +30,7 @@ def one():
         toks, _ = eng.generate_greedy([len(prompt)], N)
         best = min(best, time.perf_counter() - t0)
     res = {"ms_per_step": best / N * 1e3, "x_real_time": 1 / (best / N) / 86.13, "tokens_crc": int(np.bitwise_xor.reduce(toks.astype(np.uint64).ravel() * np.arange(1, toks.size + 1, dtype=np.uint64)))}
-    if os.environ.get("TTS_HIP_B1_STAMPS"):
+    if tune.get("b1_stamps"):
         # the last replayed step left its stamps behind (every node writes its own slot)
         st = eng.debug_read("stamps", 16 * 2 * (cfg.layers * 8 + 8)).view(np.int64).reshape(-1, 16)
         rows = []
@@ -71,19 +72,20 @@ def analyse(rows, per_layer):
 def main():
     if "--one" in sys.argv:
         return one()
-    variants = [
-        ("round-2 chain", {"TTS_HIP_B1_FC2_SPLIT": "0", "TTS_HIP_B1_DEFER_COMBINE": "0"}, False),
-        ("fc2 as 256 workgroups + slabs", {"TTS_HIP_B1_FC2_SPLIT": "1", "TTS_HIP_B1_DEFER_COMBINE": "0"}, False),
-        ("combine in out_proj's prologue", {"TTS_HIP_B1_FC2_SPLIT": "0", "TTS_HIP_B1_DEFER_COMBINE": "1"}, False),
-        ("both (default)", {}, True),
-        ("... in 16 key splits", {"TTS_HIP_ATTN_NSPLIT": "16"}, False),
-        ("... in 4 key splits", {"TTS_HIP_ATTN_NSPLIT": "4"}, False),
+    variants = [   # (name, tts_hip_tune keys, environment, stamps)
+        ("round-2 chain", {"b1_fc2_split": 0, "b1_defer_combine": 0}, {}, False),
+        ("fc2 as 256 workgroups + slabs", {"b1_fc2_split": 1, "b1_defer_combine": 0}, {}, False),
+        ("combine in out_proj's prologue", {"b1_fc2_split": 0, "b1_defer_combine": 1}, {}, False),
+        ("both (default)", {}, {}, True),
+        ("... in 16 key splits", {}, {"TTS_HIP_ATTN_NSPLIT": "16"}, False),
+        ("... in 4 key splits", {}, {"TTS_HIP_ATTN_NSPLIT": "4"}, False),
     ]
     base_lg = base_tok = None
-    for i, (name, env, stamps) in enumerate(variants):
+    for i, (name, tune, env, stamps) in enumerate(variants):
         e = dict(os.environ); e.update(env)
+        if stamps: tune = dict(tune, b1_stamps=1)
+        e["B1_TUNE"] = json.dumps(tune)
         e["B1_LOGITS"] = f"/tmp/b1_logits_{i}.npy"; e["B1_TOKENS"] = f"/tmp/b1_tokens_{i}.npy"
-        if stamps: e["TTS_HIP_B1_STAMPS"] = "1"
         p = subprocess.run([sys.executable, __file__, "--one"], env=e, capture_output=True, text=True, timeout=600)
         if p.returncode != 0:
             print(f"{name}: FAILED\n{p.stdout[-2000:]}\n{p.stderr[-3000:]}"); continue
