@@ -41,10 +41,12 @@ struct Cfg { const char *name; int BM, BN, threads, BK, S; kern_t k; };
 static Cfg cfgs[] = {
     CFGS(32, 32, 1, 2), CFG(32, 32, 1, 2, 64, 8), CFG(32, 32, 1, 2, 128, 6), CFGS(32, 64, 1, 4), CFGS(64, 32, 2, 2), CFGS(64, 64, 2, 2), CFG(64, 64, 2, 2, 64, 6),
     CFGS(64, 64, 2, 4), CFGS(64, 128, 2, 2), CFGS(128, 64, 2, 2), CFGS(128, 64, 4, 2), CFGS(128, 128, 2, 4), CFG(128, 128, 2, 4, 64, 2),
+    // round 4: 64 x 64 wave tiles (4 x 4 fragments: 8 LDS reads per 16 MFMAs instead of 6 per 8) — four waves, one per SIMD
+    CFG(128, 128, 2, 2, 64, 4), CFG(128, 128, 2, 2, 64, 3), CFG(128, 128, 2, 2, 128, 2), CFG(128, 64, 2, 1, 64, 4), CFG(64, 128, 1, 2, 64, 4), CFG(256, 128, 4, 2, 64, 3), CFG(128, 256, 2, 4, 64, 3),
 };
 
 int main(int argc, char **argv) {
-    const int NBUF = 40;
+    const int NBUF = getenv("GEMM_BENCH_NBUF") ? atoi(getenv("GEMM_BENCH_NBUF")) : 40;   // 1: the same weight copy every launch (L2 / MALL hot): separates the L2 -> CU path from HBM
     struct Shape { const char *name; int N, K; bool splitk; } shapes[] = {
         {"qkv", 3072, 1024, false}, {"proj", 1024, 1024, true}, {"fc1", 4096, 1024, false}, {"fc2", 1024, 4096, true}, {"heads", 9792, 1024, false}};
     std::vector<int> Rs = {64, 128, 192, 256, 384, 512};
