@@ -158,7 +158,6 @@ extern "C" int tts_hip_tune(tts_hip_ctx *c, const char *key, int v) {
     else if (k == "dac_tap7") c->dac_tap7 = v;                   // 0: tap-pair k-steps in the k = 7 planes convs
     else if (k == "dac_b3") c->dac_b3 = std::max(0, v);
     else if (k == "dac_conv1_direct") c->dac_conv1_direct = v != 0;
-    else if (k == "dac_slim") c->dac_slim = v;
     else if (k == "kokoro_mfma") c->kk_mfma = v != 0;
     else if (k == "kokoro_lstm_split") c->kk_lstm_split = v != 0;
     else if (k == "ln_fuse_max") c->ln_fuse_max = std::max(0, std::min(32, v));

@@ -293,7 +293,6 @@ struct tts_hip_ctx {
     bool b1_fc2_split = true;        // tune("b1_fc2_split")=0: fc2 stays 64 workgroups x 128 KB of weights (7.4 us) instead of 256 x 32 KB writing four K-slice slabs
     bool b1_defer_combine = true;    // tune("b1_defer_combine")=0: the split-T self-attention folds its partials itself (last workgroup, +3.3 us) instead of out_proj's prologue
     bool b1_stamps_want = false;     // tts_hip_tune("b1_stamps") or TTS_HIP_B1_STAMPS=1 before finalize
-    int dac_slim = 0;                // tts_hip_tune("dac_slim"): codec workgroups at half the CU footprint (section 8 overlap experiment)
     long long *b1_stamps = nullptr;  // TTS_HIP_B1_STAMPS=1: 16 s_memrealtime stamps per launch of a <= 4-row forward (debug_read "stamps", profiles/b1_chain.py)
     int b1_stamp_slot = 0;
     bool attn_fused = true;          // tune("attn_fused")=0: split-T self-attention keeps its separate combine launch and small batches stay unsplit
