@@ -11,7 +11,11 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 flags = hip.FLAG_NO_PARLER | (hip.FLAG_VALU_GEMM if "--valu" in sys.argv else 0)
 cfg = synth.parler_mini(layers=1, prompt_vocab=64, ctx=64, dac_f16="--f16" in sys.argv)
 model = synth.build(cfg)
-eng = hip.HipEngine(cfg, flags=flags)
+tune = {}
+for a in sys.argv:
+    if a.startswith("--tune="):          # --tune=dac_convt_planes=0,dac_fuse=0
+        tune.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in a[len("--tune="):].split(",")})
+eng = hip.HipEngine(cfg, flags=flags, tune=tune)
 eng.load(model)
 batch = 1
 for a in sys.argv:

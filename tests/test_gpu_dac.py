@@ -199,6 +199,7 @@ ARITH_CASES = [
     ("convt_fp32", {}, {"dac_convt_b3": 0}, 1 | 2 | 32),              # transposed convs on the exact-fp32 kernel
     ("no_planes", {}, {"dac_planes": 0}, 1 | 2 | 4),                  # wide classes keep fp32 activations (conv1d_mfma_b3_kernel + fp32 k = 1)
     ("tap_pairs", {}, {"dac_tap7": 0}, 1 | 2 | 4 | 32),               # k = 7 convs with tap-pair k-steps (8 slots for 7 taps)
+    ("convt_fp32_input", {}, {"dac_convt_planes": 0}, 1 | 2 | 4 | 32),  # bf16 x 3 transposed convs stage fp32 input themselves instead of the producer's planes
 ]
 
 

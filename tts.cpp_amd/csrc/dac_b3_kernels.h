@@ -698,7 +698,10 @@ static __global__ void pack_convt_w_b3_kernel(const float *src, __bf16 *dst, int
     }
 }
 
-template <int S, int MI>
+// PLANES: the input arrives as split planes written by its producer (snake with this layer's alpha and the bf16 x 3 split done ONCE per element);
+// the fp32 form snakes and splits the staged tile in every workgroup — 24 / 12 times per element for the stride-8 layers (cout / 32 channel
+// tiles), about as many VALU cycles per chunk as half the MFMAs of the chunk (0.40 of the bf16 peak where the k = 7 families reach 0.53).
+template <int S, int MI, bool PLANES = false>
 __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
     constexpr int CO_T = 32 * MI, WN = 8, TI_T = 32 * WN, NT = 64 * WN, K2 = 2 * S;
     constexpr int WPL = 2 * S * 2 * CO_T * 8;                // bf16 per weight plane of a chunk
@@ -720,12 +723,16 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
     const int LoS = a.Lout, Lout = a.frames ? (L - 1) * S - 2 * a.pad + K2 : a.Lout;
     if (ti0 > L) return;  // ti runs 0..L inclusive
     const float *xg = a.x + (int64_t) tile.z * a.cin * LS;
+    const int64_t psti = (int64_t) (a.cin / 8) * LS * 8;     // bf16 per input plane
+    const __bf16 *xpg = PLANES ? a.xp + (int64_t) tile.z * 3 * psti : nullptr;
     float *yg = a.y + (int64_t) tile.z * a.cout * LoS;
     const uint4d *wg = (const uint4d *) ((const __bf16 *) a.w + (int64_t) tile.co * n_chunks * 3 * WPL);
 
-    for (int i = tid; i < a.cin; i += NT) {
-        const float al = a.alpha ? a.alpha[i] : 1.0f;
-        tin[i] = make_float2(al, 1.0f / al);
+    if (!PLANES) {
+        for (int i = tid; i < a.cin; i += NT) {
+            const float al = a.alpha ? a.alpha[i] : 1.0f;
+            tin[i] = make_float2(al, 1.0f / al);
+        }
     }
 
     float16d acc[MI][S];
@@ -737,7 +744,8 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
             for (int e = 0; e < 16; e++) acc[i][ph][e] = 0.0f;
 
     uint4d wreg[WV];
-    float xreg[XR][8];
+    float xreg[PLANES ? 1 : XR][8];
+    uint4d xpreg[PLANES ? XR : 1][3];
     auto prefetch = [&](int c) __attribute__((always_inline)) {
         const uint4d *wp = wg + (int64_t) c * (3 * WPL / 8);
 #pragma unroll
@@ -751,8 +759,15 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
             const int g = u / xw, r = u - g * xw;           // lanes run along positions: coalesced rows
             const int ti = ti0 - 1 + r;
             const bool ok = g < 2 && ti >= 0 && ti < L;
+            if constexpr (PLANES) {
+                const uint4d zero = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int e = 0; e < 8; e++) xreg[q][e] = ok ? xg[(int64_t) (c * 16 + g * 8 + e) * LS + ti] : 0.0f;
+                for (int pl = 0; pl < 3; pl++)
+                    xpreg[q][pl] = ok ? *(const uint4d *) (xpg + pl * psti + ((int64_t) (c * 2 + g) * LS + ti) * 8) : zero;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) xreg[q][e] = ok ? xg[(int64_t) (c * 16 + g * 8 + e) * LS + ti] : 0.0f;
+            }
         }
     };
     auto commit = [&](int c, int buf) __attribute__((always_inline)) {
@@ -767,7 +782,14 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
         for (int q = 0; q < XR; q++) {
             const int u = tid + q * NT;
             const int g = u / xw, r = u - g * xw;
-            if (g < 2) {
+            if constexpr (PLANES) {
+                if (g < 2) {
+                    __bf16 *p = xd + (g * xw + r) * 8;
+                    *(uint4d *) p = xpreg[q][0];
+                    *(uint4d *) (p + xpl) = xpreg[q][1];
+                    *(uint4d *) (p + 2 * xpl) = xpreg[q][2];
+                }
+            } else if (g < 2) {
                 if (a.alpha) {
                     float al[8], ral[8];
 #pragma unroll

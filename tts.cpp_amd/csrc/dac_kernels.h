@@ -288,6 +288,8 @@ struct ConvTArgs {
     int x_f16;               // F16 kernel: inputs rounded to fp16 (ggml_compute_forward_conv_transpose_1d_f16_f32)
     int alpha_tab;           // as ConvArgs
     int npos, nco, nz;       // convt_b3_kernel: tiles along ti / output channels, utterances (xcd_tile in dac_b3_kernels.h)
+    const __bf16 *xp;        // convt_b3_kernel<.., true>: the input as split planes [n][3][cin/8][L][8] — already snaked with `alpha` and split by its
+                             // producer (conv_b3p_kernel's epilogue), staged as a straight copy; x / alpha are not read then
 };
 
 #define CT_CI 8

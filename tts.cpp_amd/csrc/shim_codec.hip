@@ -386,21 +386,25 @@ static int launch_convt_mfma(tts_hip_ctx *c, const ConvTArgs &a_in, int nz) {
     return 0;
 }
 
-template <int S, int MI>
-static int launch_convt_b3(tts_hip_ctx *c, const ConvTArgs &a, int nz) {
+template <int S, int MI, bool PL>
+static int launch_convt_b3_t(tts_hip_ctx *c, const ConvTArgs &a, int nz) {
     constexpr int CO_T = 32 * MI, WPL = 2 * S * 2 * CO_T * 8, xpl = 2 * 257 * 8;
     const size_t lds = (size_t) 6 * WPL * 2 + (size_t) 6 * xpl * 2 + (size_t) a.cin * 8;
     if (lds > 160 * 1024) return set_err("convt_b3: %d input channels need %zu bytes of LDS", a.cin, lds);
     static std::atomic<uint64_t> attr{0};
     if (attr_needed(attr, c->device)) {
-        HIPCHK(hipFuncSetAttribute((const void *) convt_b3_kernel<S, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) convt_b3_kernel<S, MI, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     ConvTArgs b = a;
     b.npos = (a.L + 1 + 255) / 256; b.nz = nz;   // ti runs 0..L inclusive
     b.nco = xcd_order(a.cout / CO_T, (double) a.cin * a.L * nz * 4, (double) a.cout * a.cin * 2 * S * 6);
-    hipLaunchKernelGGL((convt_b3_kernel<S, MI>), dim3(xcd_grid(b.npos, a.cout / CO_T, b.nz)), dim3(512), lds, c->stream, b);
+    hipLaunchKernelGGL((convt_b3_kernel<S, MI, PL>), dim3(xcd_grid(b.npos, a.cout / CO_T, b.nz)), dim3(512), lds, c->stream, b);
     HIPCHK(hipGetLastError());
     return 0;
+}
+template <int S, int MI>
+static int launch_convt_b3(tts_hip_ctx *c, const ConvTArgs &a, int nz) {
+    return a.xp ? launch_convt_b3_t<S, MI, true>(c, a, nz) : launch_convt_b3_t<S, MI, false>(c, a, nz);
 }
 
 static int launch_convt(tts_hip_ctx *c, ConvTArgs ta, size_t w_off, int nz) {
@@ -669,10 +673,22 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
     CHK(prof_end(c));
     if (n == 1) CHK(dac_snapshot(c, 0, cur, (size_t) c->d_latent, (size_t) L, (size_t) LS));
 
+    // A transposed conv on the bf16 x 3 kernel takes its input as split planes when the producer is a planes conv: the producer's epilogue applies
+    // this layer's snake and the split once per element, where the fp32 form redoes both in every one of the cout / 32 channel-tile workgroups.
+    auto convt_takes_planes = [&](size_t bi) {
+        if (bi >= c->dblocks.size() || !c->dac_convt_planes || (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) || c->dac_f16) return false;
+        const DBlock &nb = c->dblocks[bi];
+        return c->dac_convt_b3 && c->packed_ct.count(nb.w) != 0 && nb.cin % 16 == 0;
+    };
+    const __bf16 *convt_in = nullptr;    // planes of the next transposed conv's input, when its producer wrote them
     if (c->packed_p.count(c->d_initw) && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM)) {
-        // quantizer output -> split planes (no snake in front of the first conv) -> k = 7 conv on planes -> fp32 for the first transposed conv
+        // quantizer output -> split planes (no snake in front of the first conv) -> k = 7 conv on planes -> the first transposed conv's planes
+        // (snaked with ITS alpha), or fp32 for it
         CHK(launch_split(c, bt, cur, c->d_latent, LS, 0, false, (__bf16 *) t2));
-        CHK(launch_conv_planes(c, bt, (const __bf16 *) t2, c->d_latent, LS, c->d_initw, c->d_initb, c->d_c0, 7, 1, nullptr, t1, nullptr, 0, false));
+        const bool pl = convt_takes_planes(0);
+        CHK(launch_conv_planes(c, bt, (const __bf16 *) t2, c->d_latent, LS, c->d_initw, c->d_initb, c->d_c0, 7, 1, nullptr, (!pl || (c->debug && n == 1)) ? t1 : nullptr,
+                               pl ? (__bf16 *) B.dplanes : nullptr, pl ? c->dblocks[0].alpha : 0, pl));
+        if (pl) convt_in = (const __bf16 *) B.dplanes;
     } else
     CHK(launch_conv(c, bt, cur, c->d_latent, LS, c->d_initw, c->d_initb, 0, false, c->d_c0, 7, 3, 1, nullptr, false, t1));
     std::swap(cur, t1);
@@ -687,6 +703,8 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
         ta.alpha = (const float *) (c->arena + b.alpha); ta.y = t1; ta.cin = b.cin; ta.cout = b.cout; ta.L = LS;
         ta.Lout = LSout; ta.stride = b.stride; ta.pad = b.padding;
         ta.frames = c->d_frames; ta.mult = bt.mult;
+        ta.xp = convt_in;
+        convt_in = nullptr;
         const double Lov = bt.tot_frames * bt.mult * b.stride;
         CHK(prof_begin(c, TTS_HIP_K_DAC_CONVT, ((double) b.cin * bt.tot_frames * bt.mult + (double) b.cout * Lov + (double) b.cin * b.cout * 2 * b.stride) * 4,
                        2.0 * b.cin * (double) b.cout * 2 * Lov));
@@ -705,9 +723,14 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
                 int dil = 1;
                 for (int e = 0; e < r; e++) dil *= 3;
                 CHK(launch_conv_planes(c, bt, PA, C, LS, b.res[r].in_w, b.res[r].in_b, C, 7, dil, nullptr, nullptr, PB, b.res[r].out_alpha, true));
-                CHK(launch_conv_planes(c, bt, PB, C, LS, b.res[r].out_w, b.res[r].out_b, C, 1, 1, cur, t1, r < 2 ? PA : nullptr,
-                                       r < 2 ? b.res[r + 1].in_alpha : 0, r < 2));
-                std::swap(cur, t1);
+                // the unit's output: fp32 for the residual stream, plus the planes of whoever consumes it next — the next unit's k = 7 conv, or
+                // (last unit) the next block's transposed conv; then the fp32 tensor is written only when the debug snapshot wants it
+                const bool to_convt = r == 2 && convt_takes_planes(bi + 1);
+                const bool want_y = r < 2 || !to_convt || (c->debug && n == 1);
+                CHK(launch_conv_planes(c, bt, PB, C, LS, b.res[r].out_w, b.res[r].out_b, C, 1, 1, cur, want_y ? t1 : nullptr, (r < 2 || to_convt) ? PA : nullptr,
+                                       r < 2 ? b.res[r + 1].in_alpha : (to_convt ? c->dblocks[bi + 1].alpha : 0), r < 2 || to_convt));
+                if (to_convt) convt_in = PA;
+                if (want_y) std::swap(cur, t1);
             }
             if (n == 1) CHK(dac_snapshot(c, 2 + (int) bi, cur, (size_t) C, (size_t) L, (size_t) LS));
             continue;

@@ -154,6 +154,7 @@ extern "C" int tts_hip_tune(tts_hip_ctx *c, const char *key, int v) {
         c->dac_b3 = v ? 0 : 2; c->dac_fuse = c->dac_convt_b3 = c->dac_planes = v ? 0 : 1;
     } else if (k == "dac_fuse") c->dac_fuse = v;                 // 0: residual units at 96 / 192 channels as two launches
     else if (k == "dac_convt_b3") c->dac_convt_b3 = v;           // 0: transposed convs on the exact-fp32 MFMA kernel
+    else if (k == "dac_convt_planes") c->dac_convt_planes = v;   // 0: transposed convs stage fp32 input themselves
     else if (k == "dac_planes") c->dac_planes = v;               // 0: the wide classes keep fp32 activations
     else if (k == "dac_tap7") c->dac_tap7 = v;                   // 0: tap-pair k-steps in the k = 7 planes convs
     else if (k == "dac_b3") c->dac_b3 = std::max(0, v);

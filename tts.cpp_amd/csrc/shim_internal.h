@@ -256,6 +256,7 @@ struct tts_hip_ctx {
     int dac_planes = 1;         // tune("dac_planes")=0: the wide classes (channels % 128 == 0, no fused unit) keep fp32 activations and stage snake + split per tile
     bool dac_buf_user = false;  // counted in g_dac_buffers[device].users
     std::map<size_t, __bf16 *> packed_ct;   // transposed conv weight -> bf16 planes of convt_b3_kernel
+    int dac_convt_planes = 1;   // tune("dac_convt_planes") = 0: the bf16 x 3 transposed convs always stage fp32 input (snake + split per workgroup) instead of the producer's planes
     int dac_convt_b3 = 1;       // tune("dac_convt_b3")=0: the transposed convs stay on the exact-fp32 MFMA kernel
     int dac_fuse = 1;           // tune("dac_fuse")=0: residual units at 96 / 192 channels stay two launches (k = 7 conv, k = 1 conv + residual)
     int dac_b3 = 2;             // TTS_HIP_DAC_BF16X3 (default 2 since round 3; 0 = exact-fp32 MFMA convs): k = 7 convs of F32 tensors as six bf16 MFMAs per product (conv1d_mfma_b3_kernel); 1 = the layers with 64-channel tiles (measured, tested), 2 = also the 96-channel tile (written after the GPU budget of round 2 was spent: never run)
