@@ -734,6 +734,82 @@ static __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {   // U 
     if (a.stamps != nullptr && tid == 0 && (h == 0 || h == (int) gridDim.x - 1) && r == 0) a.stamps[(h ? 8 : 0) + 3] = (long long) __builtin_amdgcn_s_memrealtime();
 }
 
+// Self-attention of a many-row forward, one workgroup per ROW: 16 lanes per head, all heads of the row side by side (threads = 16 n_heads), the
+// keys of the row one after the other with the rows of eight keys in flight per lane.  A wave-instruction of the workgroup then reads ONE key's
+// whole K (or V) row — 4 KB contiguous for Parler-Mini — where attn_kernel's one-head workgroups read 256-byte pieces 4 KB apart and leave it to
+// the dispatcher to run the 16 heads of a row close enough in time for the DRAM pages to be shared (5.7 TB/s; a plain streaming read reaches
+// 7.1 TB/s on this chip, profiles/r04/overlap_bench_synthetic.txt).  Every 16-lane group owns its head from the first key to the last: one running
+// max / sum, no LDS, no barrier, no merge.  soft_max_ext + mul_mat as one pass in key order (attn_kernel folds sixteen interleaved key groups).
+// nz > 1: the keys of a row in nz slices (blockIdx.y), partials as attn_kernel writes them for attn_combine_kernel.
+template <bool KVF16>
+__device__ __forceinline__ void attn_row_pass(const AttnArgs &a, int64_t hb, float4v q4, int t0, int t1, float &m, float &l, float4v &acc) {
+    constexpr int U = 8;
+    for (int t = t0; t < t1; t += U) {
+        float4v k4[U], v4[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {   // straight-line: a key beyond the slice re-reads its last key and is never used
+            const int64_t off = hb + (int64_t) min(t + u, t1 - 1) * a.H;
+            if (KVF16) {
+                const half4 hk = *(const half4 *) ((const _Float16 *) a.kc + off), hv = *(const half4 *) ((const _Float16 *) a.vc + off);
+                k4[u] = (float4v){(float) hk[0], (float) hk[1], (float) hk[2], (float) hk[3]};
+                v4[u] = (float4v){(float) hv[0], (float) hv[1], (float) hv[2], (float) hv[3]};
+            } else {
+                k4[u] = __builtin_nontemporal_load((const float4v *) ((const float *) a.kc + off));
+                v4[u] = __builtin_nontemporal_load((const float4v *) ((const float *) a.vc + off));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (t + u < t1) {
+                float d = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
+                d = row16_sum(d);
+                d *= a.scale;  // soft_max_ext(kq, mask, 1/sqrt(d), 0)
+                const float mn = fmaxf(m, d);
+                const float f = expf(m - mn);   // 0 on the first key (m = -inf)
+                const float p = expf(d - mn);
+                l = l * f + p;
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] = acc[e] * f + p * v4[u][e];
+                m = mn;
+            }
+        }
+    }
+}
+static __global__ __launch_bounds__(1024) void attn_rows_kernel(AttnArgs a) {
+    const int r = blockIdx.x, z = blockIdx.y, nz = gridDim.y, tid = threadIdx.x;
+    const int h = tid >> 4, cl = tid & 15;
+    const int T = (int) a.row_pos[r] + 1;
+    const int64_t sb = (int64_t) a.row_seq[r] * a.seq_stride;
+    const int chunk = (T + nz - 1) / nz;
+    const int t0 = z * chunk, t1 = min(T, t0 + chunk);
+    const int64_t hb = sb + tid * 4;                        // head h = tid / 16, channels 4 (tid % 16) .. + 3 of it: element tid * 4 of the row
+    const float4v q4 = *(const float4v *) (a.q + (int64_t) r * a.H + tid * 4);
+    float m = -INFINITY, l = 0.0f;
+    float4v acc = {0.f, 0.f, 0.f, 0.f};
+    if (t0 < t1) {
+        if (a.kv_f16) attn_row_pass<true>(a, hb, q4, t0, t1, m, l, acc);
+        else attn_row_pass<false>(a, hb, q4, t0, t1, m, l, acc);
+    }
+    if (nz == 1) {
+        const float inv = 1.0f / l;
+        if (a.out16) {
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (_Float16) (acc[e] * inv);
+            *(half4 *) (a.out16 + (int64_t) r * a.H + tid * 4) = o;
+        } else {
+            float4v o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = acc[e] * inv;
+            *(float4v *) (a.out + (int64_t) r * a.H + tid * 4) = o;
+        }
+    } else {   // read by attn_combine_kernel: max (-inf: an empty slice), sum, unnormalised out[64] of this slice
+        float *p = a.part + (((int64_t) r * a.n_heads + h) * nz + z) * ATT_PS;
+        if (cl == 0) { p[0] = m; p[1] = l; }
+        *(float4v *) (p + ATT_PO + cl * 4) = acc;
+    }
+}
+
 // The unsplit form of attn_kernel (256 threads, one (head, row) item at a time) as a workgroup that WALKS items: the grid is a fixed number of
 // workgroups per CU instead of one per item.  A 1024-row forward launches 16 384 items; as one-item workgroups they fill all 32 wave slots of
 // every CU for the whole launch, and the GEMM workgroups of another runner's step (8 waves, 128 KB of LDS) never find room beside them — two

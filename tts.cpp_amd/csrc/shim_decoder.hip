@@ -506,6 +506,19 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
         HIPCHK(hipGetLastError());
         return prof_end(c);
     }
+    if (nsplit == 1 && a.row_pos && a.row_seq && c->attn_rows_min > 0 && R >= c->attn_rows_min && c->NH * 16 <= 1024 && c->H == c->NH * 64) {
+        // many rows: one workgroup per row reads whole K / V rows (attn_rows_kernel); below 1024 rows the keys of a row are cut into slices so
+        // that about 1024 workgroups run, and attn_combine_kernel folds the slices
+        const int nzr = std::min(16, std::max(1, 1024 / R));
+        a.part = c->part;
+        hipLaunchKernelGGL(attn_rows_kernel, dim3(R, nzr), dim3(c->NH * 16), 0, c->stream, a);
+        HIPCHK(hipGetLastError());
+        if (nzr > 1) {
+            hipLaunchKernelGGL(attn_combine_kernel, dim3(c->NH, R), dim3(64), 0, c->stream, (const float *) a.part, nzr, c->H, c->NH, a.out, a.out16);
+            HIPCHK(hipGetLastError());
+        }
+        return prof_end(c);
+    }
     if (nsplit == 1 && !wide && c->attn_walk > 0 && c->NH * R >= 4096) {
         // many (head, row) items: a fixed number of workgroups per CU walk them, so that another runner's GEMM workgroups find room on every CU
         const int grid = std::min(c->NH * R, 256 * c->attn_walk);
