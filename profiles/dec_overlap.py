@@ -64,6 +64,8 @@ a = mk(R)
 o, wall = run([a], R)
 base = o["d0"]
 print(f"one context, {R} rows: {base:.3f} ms/step")
+if os.environ.get("DEC_OVERLAP_ONE"):
+    sys.exit(0)
 b = mk(R, share=a)
 o, wall = run([a, b], R)
 print(f"two contexts x {R} rows side by side: {o['d0']:.3f} / {o['d1']:.3f} ms/step each, wall {wall / STEPS:.3f} ms per step pair = {wall / STEPS / 2:.3f} per {R} rows  ({2 * base / (wall / STEPS):.2f}x of serial)")

@@ -741,9 +741,8 @@ static __global__ __launch_bounds__(1024) void attn_kernel(AttnArgs a) {   // U 
 // 7.1 TB/s on this chip, profiles/r04/overlap_bench_synthetic.txt).  Every 16-lane group owns its head from the first key to the last: one running
 // max / sum, no LDS, no barrier, no merge.  soft_max_ext + mul_mat as one pass in key order (attn_kernel folds sixteen interleaved key groups).
 // nz > 1: the keys of a row in nz slices (blockIdx.y), partials as attn_kernel writes them for attn_combine_kernel.
-template <bool KVF16>
+template <bool KVF16, int U>
 __device__ __forceinline__ void attn_row_pass(const AttnArgs &a, int64_t hb, float4v q4, int t0, int t1, float &m, float &l, float4v &acc) {
-    constexpr int U = 8;
     for (int t = t0; t < t1; t += U) {
         float4v k4[U], v4[U];
 #pragma unroll
@@ -775,7 +774,8 @@ __device__ __forceinline__ void attn_row_pass(const AttnArgs &a, int64_t hb, flo
         }
     }
 }
-static __global__ __launch_bounds__(1024) void attn_rows_kernel(AttnArgs a) {
+template <int U>
+__global__ __launch_bounds__(1024) void attn_rows_kernel(AttnArgs a) {
     const int r = blockIdx.x, z = blockIdx.y, nz = gridDim.y, tid = threadIdx.x;
     const int h = tid >> 4, cl = tid & 15;
     const int T = (int) a.row_pos[r] + 1;
@@ -787,8 +787,8 @@ static __global__ __launch_bounds__(1024) void attn_rows_kernel(AttnArgs a) {
     float m = -INFINITY, l = 0.0f;
     float4v acc = {0.f, 0.f, 0.f, 0.f};
     if (t0 < t1) {
-        if (a.kv_f16) attn_row_pass<true>(a, hb, q4, t0, t1, m, l, acc);
-        else attn_row_pass<false>(a, hb, q4, t0, t1, m, l, acc);
+        if (a.kv_f16) attn_row_pass<true, U>(a, hb, q4, t0, t1, m, l, acc);
+        else attn_row_pass<false, U>(a, hb, q4, t0, t1, m, l, acc);
     }
     if (nz == 1) {
         const float inv = 1.0f / l;

@@ -511,7 +511,8 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
         // that about 1024 workgroups run, and attn_combine_kernel folds the slices
         const int nzr = std::min(16, std::max(1, 1024 / R));
         a.part = c->part;
-        hipLaunchKernelGGL(attn_rows_kernel, dim3(R, nzr), dim3(c->NH * 16), 0, c->stream, a);
+        // eight keys in flight per lane: 4 / 8 / 12 / 16 measured 5.19 / 5.25 / 5.28 / 5.67 ms per 1024-row step (profiles/r04/attn_rows_u_call22.txt)
+        hipLaunchKernelGGL(attn_rows_kernel<8>, dim3(R, nzr), dim3(c->NH * 16), 0, c->stream, a);
         HIPCHK(hipGetLastError());
         if (nzr > 1) {
             hipLaunchKernelGGL(attn_combine_kernel, dim3(c->NH, R), dim3(64), 0, c->stream, (const float *) a.part, nzr, c->H, c->NH, a.out, a.out16);
