@@ -49,7 +49,7 @@ SAMPLE_RATE = 44100.0
 FAMILIES = {
     "gemm_tile_kernel (decoder GEMMs: qkv, out_proj, cross q/out, fc1, fc2, heads)":
         ["gemm_qkv", "gemm_attn_out", "gemm_cross_q", "gemm_cross_out", "gemm_fc1", "gemm_fc2", "gemm_heads", "gemm_other"],
-    "attn_kernel (self-attention over the fp32 KV cache)": ["attn_self"],
+    "attn_rows_kernel / attn_kernel (self-attention over the fp32 KV cache; one workgroup per row from 1024 rows)": ["attn_self"],
     "attn_short_kernel (cross-attention over the voice prompt)": ["attn_cross"],
     "ln_rows_kernel (LayerNorm + split-K fold)": ["ln"],
     "resunit_t7_kernel (DAC residual units at 96 / 192 channels, one launch each)": ["dac_resunit"],

@@ -26,7 +26,7 @@ for name, cs in sorted(acc.items(), key=lambda kv: -sum(v[0] for v in kv[1].valu
 
 # ---- optional: per-kernel-class JSON for bench.py's roofline.traffic ---------------------------------------
 import json, os
-CLASS = [("attn_short_kernel", "attn_cross"), ("attn_kernel", "attn_self"), ("attn_combine", "attn_self"), ("gemm_tile_kernel", "gemm_qkv"), ("gemm16_kernel", "gemm_qkv"),
+CLASS = [("attn_short_kernel", "attn_cross"), ("attn_rows_kernel", "attn_self"), ("attn_walk_kernel", "attn_self"), ("attn_kernel", "attn_self"), ("attn_combine", "attn_self"), ("gemm_tile_kernel", "gemm_qkv"), ("gemm16_kernel", "gemm_qkv"),
          ("ln_rows", "ln"), ("pack_", "pack"), ("resunit_b3_kernel", "dac_resunit"), ("resunit_t7_kernel", "dac_resunit"), ("conv_b3p_kernel<7", "dac_conv7"), ("conv1d_mfma_b3_kernel", "dac_conv7"),
          ("conv1d_mfma_kernel<7", "dac_conv7"), ("conv_b3p_kernel<1", "dac_conv1"), ("snake_split_kernel", "dac_conv1"), ("conv1d_mfma_kernel<1", "dac_conv1"),
          ("conv1x1_direct_kernel", "dac_conv1"), ("convt_b3_kernel", "dac_convt"), ("convt1d_mfma_kernel", "dac_convt"),
