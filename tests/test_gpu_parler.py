@@ -672,6 +672,7 @@ def test_row_compaction_keeps_every_utterance_token_for_token(sampled, monkeypat
     monkeypatch.setenv("TTS_HIP_TILE_FORCE", "3")
     monkeypatch.setenv("TTS_HIP_TILE_KS", "1")
     monkeypatch.setenv("TTS_HIP_ATTN_NSPLIT", "1")
+    monkeypatch.setenv("TTS_HIP_ATTN_ROWS", "0")   # a >= 1024-row forward (the reference run's prefill) would take the row-major attention kernel: other summation order
     cfg = synth.small(weight_type=gguf.F16, ctx=80, max_gen=80)
     model = synth.build(cfg)
     rng = np.random.default_rng(11)
@@ -712,6 +713,7 @@ def test_utterance_admitted_mid_flight_gets_the_tokens_of_its_own_run(sampled, m
     monkeypatch.setenv("TTS_HIP_TILE_FORCE", "3")
     monkeypatch.setenv("TTS_HIP_TILE_KS", "1")
     monkeypatch.setenv("TTS_HIP_ATTN_NSPLIT", "1")
+    monkeypatch.setenv("TTS_HIP_ATTN_ROWS", "0")   # a >= 1024-row forward (the reference run's prefill) would take the row-major attention kernel: other summation order
     cfg = synth.small(weight_type=gguf.F16, ctx=80, max_gen=80)
     model = synth.build(cfg)
     rng = np.random.default_rng(23)
