@@ -11,7 +11,7 @@ CODEC = ("resunit", "conv_b3p", "convt_b3", "conv1d", "convt1d", "snake_split", 
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
-    cls = "codec" if any(k in n for k in CODEC) else "attn" if ("attn_kernel" in n or "attn_walk" in n) else "gemm" if "gemm" in n else "other"
+    cls = "codec" if any(k in n for k in CODEC) else "attn" if ("attn_kernel" in n or "attn_walk" in n or "attn_rows" in n) else "gemm" if "gemm" in n else "other"
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), cls, r.get("Queue_Id", "?"), r.get("Stream_Id", r.get("Queue_Id", "?"))))
 rows.sort()
 t0, t1 = rows[0][0], rows[-1][1]
