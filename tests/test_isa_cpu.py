@@ -25,6 +25,19 @@ template __global__ void gemm16_kernel<1, PRO_F16, EPI_STORE, 1>(GemmArgs);
 template __global__ void gemm_tile_kernel<128, 128, 2, 4, 64, 4, EPI_QKV>(GemmArgs, TileMap);
 template __global__ void gemm_tile_kernel<128, 128, 2, 4, 64, 4, EPI_RESID>(GemmArgs, TileMap);
 template __global__ void gemm_tile_kernel<64, 64, 2, 4, 128, 3, EPI_RESID>(GemmArgs, TileMap);
+template __global__ void attn_rows_kernel<8>(AttnArgs);
+template __global__ void ln_rows_t_kernel<4, 0>(float *, int, const float *, const float *, float *, _Float16 *, int, const float *, int, int64_t);
+"""
+LLAMA_TU = """
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include "{root}/tts.cpp_amd/csrc/gemv_kernels.h"
+template __global__ void gemv_q4_qkv_rope_kernel<4, 2, 2>(QGemmArgs, const uint8_t *, RopeEpi, RmsSrc);
+template __global__ void gemv_q4_gateup_silu_kernel<4, 2, 2>(QGemmArgs, const uint8_t *, int, float *, RmsSrc);
+template __global__ void gemv_q4_rows_lds_kernel<4, 2, 0, 2>(QGemmArgs, const uint8_t *, int);
+template __global__ void attn_gqa_split_kernel<128>(const float *, int, const uint32_t *, const float *, const float *, int, int, float, float *, const uint32_t *,
+                                                    const uint32_t *, const uint32_t *, int64_t, QPre);
 """
 DAC_TU = """
 #include <hip/hip_runtime.h>
@@ -35,6 +48,8 @@ DAC_TU = """
 #include "{root}/tts.cpp_amd/csrc/dac_b3_kernels.h"
 template __global__ void conv_b3p_kernel<1, 4, 2, 2, 4, 1, 2, 2>(PConvArgs);
 template __global__ void conv_b3p_kernel<1, 2, 4, 2, 4, 1, 2, 2>(PConvArgs);
+template __global__ void convt_b3_kernel<8, 1, true>(ConvTArgs);
+template __global__ void conv1d_mfma_kernel<7, 2, 2, 1, 4, 4>(ConvArgs);
 """
 # dependent load groups a kernel may show in profiles/tools/isa_serial_loads.py (measured at the end of round 3, one of slack)
 LIMITS = {
@@ -42,6 +57,10 @@ LIMITS = {
     r"gemm_tile_kernel<128, 128, 2, 4, 64, 4, 1>": 3, r"gemm_tile_kernel<128, 128, 2, 4, 64, 4, 2>": 3, r"gemm_tile_kernel<64, 64, 2, 4, 128, 3, 2>": 3,
     r"attn_short_kernel": 4, r"embed_rows_kernel": 4,
     r"conv_b3p_kernel<1, 4, 2, 2, 4, 1, 2, 2>": 17, r"conv_b3p_kernel<1, 2, 4, 2, 4, 1, 2, 2>": 10,
+    # round 4: the dominant kernel and the restructured one-sequence kernels (Orpheus / Dia)
+    r"attn_rows_kernel<8>": 4, r"attn_kernel(": 6, r"ln_rows_t_kernel<4, 0>": 2, r"ln_rows_t_kernelILi4ELi0E": 2,
+    r"gemv_q4_qkv_rope_kernel<4, 2, 2>": 5, r"gemv_q4_gateup_silu_kernel<4, 2, 2>": 6, r"gemv_q4_rows_lds_kernel<4, 2, 0, 2>": 10, r"attn_gqa_split_kernel<128>": 3,
+    r"convt_b3_kernel<8, 1, true>": 3, r"conv1d_mfma_kernel<7, 2, 2, 1, 4, 4>": 14,   # 102 before its epilogue went to load / compute / store phases
 }
 
 
@@ -58,7 +77,7 @@ def _compile(tmp_path, name, src):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_hot_kernels_have_no_scratch_and_no_serialized_load_chains(tmp_path):
     seen = {}
-    for name, src in (("parler", PARLER_TU), ("dac", DAC_TU)):
+    for name, src in (("parler", PARLER_TU), ("dac", DAC_TU), ("llama", LLAMA_TU)):
         asm, remarks = _compile(tmp_path, name, src)
         scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", remarks)]
         assert scratch and max(scratch) == 0, f"{name}: a kernel spills ({scratch})"
@@ -76,4 +95,4 @@ def test_hot_kernels_have_no_scratch_and_no_serialized_load_chains(tmp_path):
             assert v <= limit, f"{k}: {v} dependent load groups (limit {limit}): a predicate crept back around a load?"
             checked += 1
     if shutil.which("c++filt"):
-        assert checked >= 8, sorted(seen)
+        assert checked >= 14, sorted(seen)
