@@ -1041,20 +1041,21 @@ __device__ __forceinline__ void split_bf16x3(float x, __bf16 &h1, __bf16 &h2, __
 }
 
 //   conv1d  src [cout][cin][7]  ->  dst [co_tile][chunk][plane][s][hi][CO_T][8]   (ci = chunk*8 + j, tap = 2s + hi, tap 7 = 0)
-static __global__ void pack_conv_w_b3_kernel(const float *src, __bf16 *dst, int cout, int cin, int CO_T, int n_chunks) {
-    const int64_t plane_sz = (int64_t) 8 * CO_T * 8;                                  // 4 steps x 2 halves x CO_T x 8
+static __global__ void pack_conv_w_b3_kernel(const float *src, __bf16 *dst, int cout, int cin, int CO_T, int n_chunks, int KT = 7) {
+    const int NST = (KT + 1) / 2;                                                     // k-steps per chunk: tap pairs (an odd tap count leaves one zero slot)
+    const int64_t plane_sz = (int64_t) 2 * NST * CO_T * 8;                            // NST steps x 2 halves x CO_T x 8
     const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * plane_sz;  // one thread per (element, all planes)
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
         const int j = (int) (i % 8);
         int64_t r = i / 8;
         const int col = (int) (r % CO_T); r /= CO_T;
         const int hi = (int) (r % 2); r /= 2;
-        const int st = (int) (r % 4); r /= 4;
+        const int st = (int) (r % NST); r /= NST;
         const int ch = (int) (r % n_chunks);
         const int ct = (int) (r / n_chunks);
         const int co = ct * CO_T + col, ci = ch * 8 + j, tap = 2 * st + hi;
         float v = 0.0f;
-        if (co < cout && ci < cin && tap < 7) v = src[((int64_t) co * cin + ci) * 7 + tap];
+        if (co < cout && ci < cin && tap < KT) v = src[((int64_t) co * cin + ci) * KT + tap];
         __bf16 h1, h2, h3;
         split_bf16x3(v, h1, h2, h3);
         const int64_t base = ((int64_t) ct * n_chunks + ch) * 3 * plane_sz + (i % plane_sz);
@@ -1064,11 +1065,13 @@ static __global__ void pack_conv_w_b3_kernel(const float *src, __bf16 *dst, int 
     }
 }
 
-template <int MI, int NI, int WM, int WN>
+// KT (round 4): any odd tap count — (KT + 1) / 2 k-steps of tap pairs per 8-channel chunk, the odd slot on zero weights (Kokoro's k = 3 / 5 / 7 / 11
+// same-convolutions with dilations 1 / 3 / 5; the DAC's fallback k = 7).
+template <int MI, int NI, int WM, int WN, int KT = 7>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN >= 8 ? 1 : 2) void conv1d_mfma_b3_kernel(ConvArgs a) {   // 2 waves per SIMD either way
-    constexpr int KT = 7, CI_T = 8;
+    constexpr int CI_T = 8, NST = (KT + 1) / 2;
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, NT = 64 * WM * WN;
-    constexpr int WPL = 8 * CO_T * 8;                        // bf16 per weight plane of a chunk
+    constexpr int WPL = 2 * NST * CO_T * 8;                  // bf16 per weight plane of a chunk
     constexpr int WV = (3 * WPL / 8 + NT - 1) / NT;          // 16-byte vectors per thread per chunk (all planes)
     constexpr int XU = (T_T + (KT - 1) * 9 + NT - 1) / NT;   // positions per thread per chunk (8 channels each), dilation <= 9
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1174,8 +1177,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN >= 8 ? 1 : 2) void conv1d_mfm
         const __bf16 *ws = wsb + buf * 3 * WPL;
         const __bf16 *xs = xsb + buf * 3 * xpl;
 #pragma unroll
-        for (int st = 0; st < 4; st++) {
-            const int tap = (2 * st + hi < KT) ? 2 * st + hi : KT - 1;   // the eighth tap: zero weights, any valid rows
+        for (int st = 0; st < NST; st++) {
+            const int tap = (2 * st + hi < KT) ? 2 * st + hi : KT - 1;   // the slot past the last tap: zero weights, any valid rows
             bf16x8d af[3][MI], bf[3][NI];
 #pragma unroll
             for (int pl = 0; pl < 3; pl++) {

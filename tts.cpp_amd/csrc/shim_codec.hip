@@ -76,12 +76,12 @@ static int pack_one16(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT, i
     c->packed16[w_off] = dst;
     return 0;
 }
-static int pack_one_b3(tts_hip_ctx *c, size_t w_off, int cout, int cin, int CO_T) {   // k = 7, 64- or 96-channel tiles, 8 input channels per chunk
+static int pack_one_b3(tts_hip_ctx *c, size_t w_off, int cout, int cin, int CO_T, int KT = 7) {   // 64- or 96-channel tiles, 8 input channels per chunk, tap pairs
     const int n_chunks = (cin + 7) / 8;
-    const size_t n = (size_t) ((cout + CO_T - 1) / CO_T) * n_chunks * 3 * 8 * CO_T * 8;
+    const size_t n = (size_t) ((cout + CO_T - 1) / CO_T) * n_chunks * 3 * (2 * ((KT + 1) / 2)) * CO_T * 8;
     __bf16 *dst = nullptr;
     HIPCHK(hipMalloc((void **) &dst, n * 2));
-    hipLaunchKernelGGL(pack_conv_w_b3_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + w_off), dst, cout, cin, CO_T, n_chunks);
+    hipLaunchKernelGGL(pack_conv_w_b3_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + w_off), dst, cout, cin, CO_T, n_chunks, KT);
     HIPCHK(hipGetLastError());
     c->packed_b3[w_off] = dst;
     return 0;
@@ -239,19 +239,20 @@ static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a_in, int nz) {
 
 // k = 7 conv as six bf16 MFMAs per product (experiment): 64 channels x 256 positions per workgroup of 4 waves,
 // or 96 channels x 256 positions per workgroup of 8 waves
-template <int MI, int NI, int WM, int WN>
+template <int MI, int NI, int WM, int WN, int KT = 7>
 static int launch_conv_b3(tts_hip_ctx *c, const ConvArgs &a_in, int nz) {
-    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WPL = 8 * CO_T * 8;
-    const int xw = T_T + 6 * a_in.dil;
+    constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WPL = 2 * ((KT + 1) / 2) * CO_T * 8;
+    const int xw = T_T + (KT - 1) * a_in.dil;
     const int cin_pad = (a_in.cin + 7) / 8 * 8;
     ConvArgs a = a_in;
     const size_t lds = dac_lds_request(c, ((size_t) 6 * WPL + 6 * (size_t) xw * 8) * 2, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab, true);
     static std::atomic<uint64_t> attr{0};
     if (attr_needed(attr, c->device)) {
-        HIPCHK(hipFuncSetAttribute((const void *) conv1d_mfma_b3_kernel<MI, NI, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) conv1d_mfma_b3_kernel<MI, NI, WM, WN, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const dim3 grid((a.L + T_T - 1) / T_T, (a.cout + CO_T - 1) / CO_T, nz);
-    hipLaunchKernelGGL((conv1d_mfma_b3_kernel<MI, NI, WM, WN>), grid, dim3(64 * WM * WN), lds, c->stream, a);
+    if (lds > 160 * 1024) return set_err("conv1d_mfma_b3: k = %d at dilation %d needs %zu bytes of LDS", KT, a.dil, lds);
+    hipLaunchKernelGGL((conv1d_mfma_b3_kernel<MI, NI, WM, WN, KT>), grid, dim3(64 * WM * WN), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -936,6 +937,20 @@ struct KRun {
     // output kernel, profiles/r02/kernel_stats_kokoro_82m.csv) go through the codec's exact-fp32 MFMA conv kernel (conv1d_mfma_kernel: input
     // channels staged through LDS, weights pre-packed once per tensor into its LDS image); `acc` becomes its residual input (y += conv).
     // Everything else (stride 2, nearest-2x input, one output channel, the scaled shortcut) stays on kk_conv1d_kernel.
+    // The same convolutions as bf16 x 3 split products on the bf16 matrix pipe (conv1d_mfma_b3_kernel<.., KT>: fp32-level error, 2-3x the rate of the
+    // exact-fp32 MFMA at these sizes): k = 3 / 5 / 7 / 11, 64-channel tiles x 256 positions, weights packed once per tensor as three bf16 planes.
+    template <int KT>
+    bool conv_b3(const float *x, int cin, int64_t L, const float *wt, const float *b, int cout, int pad, int dil, float *y, int acc) {
+        const size_t w_off = (size_t) ((const char *) wt - c->arena);
+        if (c->packed_b3.find(w_off) == c->packed_b3.end() && pack_one_b3(c, w_off, cout, cin, 64, KT) != 0) { err = tts_hip_last_error(); return true; }
+        ConvArgs a{};
+        a.x = x; a.w = (const float *) c->packed_b3[w_off]; a.b = b; a.alpha = nullptr; a.alpha_out = nullptr; a.resid = acc ? y : nullptr; a.y = y;
+        a.cin = cin; a.cout = cout; a.L = (int) L; a.dil = dil; a.pad = pad; a.do_tanh = 0; a.frames = nullptr; a.mult = 1; a.x_f16 = 0;
+        if (prof_begin(c, TTS_HIP_K_KOKORO_CONV, ((double) cin * L + (double) cout * L * (acc ? 2 : 1) + (double) cout * cin * KT) * 4, 2.0 * cout * (double) cin * KT * L) != 0) { err = tts_hip_last_error(); return true; }
+        const int rc = launch_conv_b3<2, 1, 1, 8, KT>(c, a, 1);
+        if (rc != 0 || prof_end(c) != 0) err = tts_hip_last_error();
+        return true;
+    }
     template <int KT, int CI_T>
     bool conv_mfma(const float *x, int cin, int64_t L, const float *wt, const float *b, int cout, int pad, int dil, float *y, int acc) {
         const size_t w_off = (size_t) ((const char *) wt - c->arena);
@@ -955,6 +970,12 @@ struct KRun {
         const bool same = stride == 1 && !in_shift && Lout == L && pad * 2 == dil * (K - 1) && post == 1.0f && dil <= 9;
         if (same && c->kk_mfma && cout >= 16 && cin >= 16 && L < (1 << 30) && (const char *) wt >= c->arena && (const char *) wt < c->arena + c->arena_bytes) {
             if (K == 1 && (L & 3) == 0 && (((uintptr_t) x | (uintptr_t) y) & 15) == 0 && conv_mfma<1, 16>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;   // k = 1 stages 16-byte pieces
+            if (c->kk_b3 && dil <= 5) {   // bf16 x 3 split products (tune("kokoro_b3", 0): the exact-fp32 MFMA kernels below)
+                if (K == 3 && conv_b3<3>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
+                if (K == 5 && conv_b3<5>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
+                if (K == 7 && conv_b3<7>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
+                if (K == 11 && conv_b3<11>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
+            }
             if (K == 3 && conv_mfma<3, 8>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
             if (K == 5 && conv_mfma<5, 4>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;
             if (K == 7 && conv_mfma<7, 4>(x, cin, L, wt, b, cout, pad, dil, y, acc)) return;

@@ -161,6 +161,7 @@ extern "C" int tts_hip_tune(tts_hip_ctx *c, const char *key, int v) {
     else if (k == "dac_b3") c->dac_b3 = std::max(0, v);
     else if (k == "dac_conv1_direct") c->dac_conv1_direct = v != 0;
     else if (k == "kokoro_mfma") c->kk_mfma = v != 0;
+    else if (k == "kokoro_b3") c->kk_b3 = v != 0;
     else if (k == "kokoro_lstm_split") c->kk_lstm_split = v != 0;
     else if (k == "ln_fuse_max") c->ln_fuse_max = std::max(0, std::min(32, v));
     else if (k == "attn_short") c->attn_short = v != 0;

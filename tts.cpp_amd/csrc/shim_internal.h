@@ -264,6 +264,7 @@ struct tts_hip_ctx {
     char *kk_pool = nullptr;    // Kokoro scratch pool (KScratch): grows to the largest call
     size_t kk_pool_cap = 0, kk_pool_next = 0;
     int *kk_stuck = nullptr;    // set by kk_lstm_split_kernel when a granule never arrives (bounded spin)
+    bool kk_b3 = true;          // tune("kokoro_b3") = 0: Kokoro's k = 3 / 5 / 7 / 11 same-convolutions stay on the exact-fp32 MFMA kernel instead of bf16 x 3 split products
     bool kk_mfma = true;        // tune("kokoro_mfma")=0: every Kokoro convolution through the one-thread-per-output kernel
     int dac_group = 64;         // TTS_HIP_DAC_GROUP: utterances per codec pass (16: 451, 32: 458, 64: 461, 128: 460, 384: 462 audio-s/s at 3 x 384)
     bool dac_conv1_direct = true;   // tune("dac_conv1_direct")=0: the 96- / 192-channel k=1 convs stay on conv1d_mfma_kernel<1,...>

@@ -724,8 +724,9 @@ class DiaEngine:
 class KokoroEngine:
     """A Kokoro context (tts_hip_kokoro_create): duration graph, then generation graph, per clause."""
 
-    def __init__(self, model, device=0, attn_scale=0.125):
+    def __init__(self, model, device=0, attn_scale=0.125, tune=None):
         self.L = load_lib()
+        self._tune = dict(tune or {})
         cfg = model.cfg
         self.cfg = cfg
         d = KokoroDesc()
@@ -749,6 +750,9 @@ class KokoroEngine:
         self.ctx = self.L.tts_hip_kokoro_create(device, C.byref(d))
         if not self.ctx:
             raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
+        for kk, vv in self._tune.items():   # tts_hip_tune keys (fallback kernel paths), before the first launch
+            if self.L.tts_hip_tune(self.ctx, kk.encode(), int(vv)) != 0:
+                raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
         for t in model.tensors:
             ne = (C.c_int64 * 4)(*(t.ne + [1] * (4 - len(t.ne))))
             raw = np.frombuffer(bytes(t.raw()), dtype=np.uint8)
