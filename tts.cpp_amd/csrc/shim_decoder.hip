@@ -507,9 +507,10 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
         return prof_end(c);
     }
     if (nsplit == 1 && a.row_pos && a.row_seq && c->attn_rows_min > 0 && R >= c->attn_rows_min && c->NH * 16 <= 1024 && c->H == c->NH * 64) {
-        // many rows: one workgroup per row reads whole K / V rows (attn_rows_kernel); below 1024 rows the keys of a row are cut into slices so
-        // that about 1024 workgroups run, and attn_combine_kernel folds the slices
-        const int nzr = std::min(16, std::max(1, 1024 / R));
+        // many rows: one workgroup per row reads whole K / V rows (attn_rows_kernel); below 1024 rows the keys of a row are cut into FOUR slices
+        // (about a thousand workgroups again) that attn_combine_kernel folds — a fixed count per row-count class, so that a generation whose rows
+        // are compacted from 384 to 256 keeps its summation order
+        const int nzr = R >= 1024 ? 1 : 4;
         a.part = c->part;
         // eight keys in flight per lane: 4 / 8 / 12 / 16 measured 5.19 / 5.25 / 5.28 / 5.67 ms per 1024-row step (profiles/r04/attn_rows_u_call22.txt)
         hipLaunchKernelGGL(attn_rows_kernel<8>, dim3(R, nzr), dim3(c->NH * 16), 0, c->stream, a);

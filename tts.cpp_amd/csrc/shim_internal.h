@@ -268,7 +268,7 @@ struct tts_hip_ctx {
     bool kk_mfma = true;        // tune("kokoro_mfma")=0: every Kokoro convolution through the one-thread-per-output kernel
     int dac_group = 64;         // TTS_HIP_DAC_GROUP: utterances per codec pass (16: 451, 32: 458, 64: 461, 128: 460, 384: 462 audio-s/s at 3 x 384)
     bool dac_conv1_direct = true;   // tune("dac_conv1_direct")=0: the 96- / 192-channel k=1 convs stay on conv1d_mfma_kernel<1,...>
-    int attn_rows_min = 1024;   // tune("attn_rows_min") / TTS_HIP_ATTN_ROWS: forwards with at least this many rows run the self-attention one workgroup per ROW (attn_rows_kernel); 0 = never
+    int attn_rows_min = 256;    // tune("attn_rows_min") / TTS_HIP_ATTN_ROWS: forwards with at least this many rows run the self-attention one workgroup per ROW (attn_rows_kernel); 0 = never
     int attn_walk = 0;          // tune("attn_walk"): > 0 = the self-attention of a many-row forward as this many walking workgroups per CU (attn_walk_kernel)
     bool attn_short = true;     // tune("attn_short")=0: cross-attention through the general kernel
     int tile_min_rows = 33;     // forwards with at least this many rows take the LDS-tiled GEMM (gemm_tile_kernels.h); 0 = never
