@@ -224,7 +224,7 @@ def test_device_pool_continuous_batching_admits_arrivals_during_a_generation():
     import time
     pool = runner.Pool("test:dummy", n_workers=1, max_batch=4, continuous=True)
     t0 = time.perf_counter()
-    long_ids = [pool.submit("l" * 40) for _ in range(2)]
+    long_ids = [pool.submit("l" * 80) for _ in range(2)]             # 0.8 s of generation: a loaded CI box may stall the submitter for a while
     time.sleep(0.08)
     short_ids = [pool.submit("ab") for _ in range(5)]
     short = [pool.wait(i) for i in short_ids]
@@ -234,10 +234,11 @@ def test_device_pool_continuous_batching_admits_arrivals_during_a_generation():
     for audio, bs, wk, err in short:
         assert err == "" and audio.size == 2 * 44100 and wk == 0
     for audio, bs, wk, err in long_:
-        assert err == "" and audio.size == 40 * 44100
+        assert err == "" and audio.size == 80 * 44100
     st = pool.stats()
     assert st["tasks"] == 7 and st["batches"] == 1, st          # one session served all seven
-    assert st["admitted_in_flight"] == 5 and st["largest_batch"] == 4, st
+    # the worker may open the session on the first long request before the second is queued: then that one is an in-flight admission too
+    assert st["admitted_in_flight"] in (5, 6) and st["largest_batch"] == 4, st
     assert t_short < t_long - 0.1, (t_short, t_long)               # the short requests did not wait for the long ones
     pool.close()
     r = runner.Runner("test:dummy")
