@@ -273,7 +273,7 @@ __device__ __forceinline__ float4 attn_pv_batched(float4 (&v)[8], const float *v
 template <int HD>
 __global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld, const uint32_t *pos, const float *kcache, const float *vcache, int NH, int NKV,
                                                        float scale, float *out, const uint32_t *kbeg, const uint32_t *kend, const uint32_t *row_seq,
-                                                       int64_t seq_stride, QPre qp = QPre{}) {
+                                                       int64_t seq_stride, QPre qp = QPre{}, int8_t *aq = nullptr, float *ad = nullptr) {
     static_assert(HD == 128, "lane mapping below is written for head_dim 128 (orpheus/model.h:28)");
     __shared__ float red[8];
     __shared__ float4 accs[8][HD / 4];
@@ -313,7 +313,10 @@ __global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld,
         float o = 0.0f;
 #pragma unroll
         for (int g = 0; g < 8; g++) o += a[g * HD + tid];
-        out[(int64_t) r * NH * HD + h * HD + tid] = o * inv;
+        const float res = o * inv;
+        out[(int64_t) r * NH * HD + h * HD + tid] = res;
+        // the o projection's activation blocks (a head is four Q8_0 blocks; waves 0 and 1 are whole here): saves its quant_rows_q8_kernel launch
+        if (aq) q8_block_store(res, (int64_t) r * NH * HD + h * HD + tid, aq, ad);
     }
 }
 

@@ -45,8 +45,9 @@ static int launch_attn_gqa(tts_hip_ctx *c, int NHq, int rows, int max_keys, cons
     }
     if (nz <= 1) {
         hipLaunchKernelGGL(attn_gqa_kernel<128>, dim3(NHq, rows), dim3(256), (size_t) (128 + max_keys) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, out, kbeg, kend,
-                           row_seq, seq_stride, qp);
+                           row_seq, seq_stride, qp, q_out ? c->aq : (int8_t *) nullptr, q_out ? c->ad : (float *) nullptr);
         HIPCHK(hipGetLastError());
+        if (q_out) c->aq_src = out;
         return 0;
     }
     const int chunk = (max_keys + nz - 1) / nz;

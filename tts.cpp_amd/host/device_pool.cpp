@@ -302,7 +302,12 @@ void device_pool::process_stream(int w, std::vector<std::shared_ptr<pool_task>> 
                 t->worker = w;
                 if (t->timed_out(opts_.task_timeout_s)) { t->message = "timed out in the queue"; expired++; done.push_back(t); continue; }
                 if (runner.stream_free() == 0) { overflow.push_back(t); continue; }
-                runner.stream_submit(ticket, t->prompt);
+                try {
+                    runner.stream_submit(ticket, t->prompt);   // host work only (tokenising, taking a row): a request it rejects fails alone
+                } catch (const std::exception & e) {
+                    t->success = false; t->message = e.what(); served++; done.push_back(t);
+                    continue;
+                }
                 inflight[ticket++] = t;
                 served++;
                 joined += in_flight;
