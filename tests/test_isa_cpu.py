@@ -36,6 +36,7 @@ LLAMA_TU = """
 template __global__ void gemv_q4_qkv_rope_kernel<4, 2, 2>(QGemmArgs, const uint8_t *, RopeEpi, RmsSrc);
 template __global__ void gemv_q4_gateup_silu_kernel<4, 2, 2>(QGemmArgs, const uint8_t *, int, float *, RmsSrc);
 template __global__ void gemv_q4_rows_lds_kernel<4, 2, 0, 2>(QGemmArgs, const uint8_t *, int);
+template __global__ void gemv_q4_rows_lds_kernel<4, 2, 3, 2>(QGemmArgs, const uint8_t *, int);
 template __global__ void attn_gqa_split_kernel<128>(const float *, int, const uint32_t *, const float *, const float *, int, int, float, float *, const uint32_t *,
                                                     const uint32_t *, const uint32_t *, int64_t, QPre);
 """
@@ -59,7 +60,7 @@ LIMITS = {
     r"conv_b3p_kernel<1, 4, 2, 2, 4, 1, 2, 2>": 17, r"conv_b3p_kernel<1, 2, 4, 2, 4, 1, 2, 2>": 10,
     # round 4: the dominant kernel and the restructured one-sequence kernels (Orpheus / Dia)
     r"attn_rows_kernel<8>": 4, r"attn_kernel(": 6, r"ln_rows_t_kernel<4, 0>": 2, r"ln_rows_t_kernelILi4ELi0E": 2,
-    r"gemv_q4_qkv_rope_kernel<4, 2, 2>": 5, r"gemv_q4_gateup_silu_kernel<4, 2, 2>": 6, r"gemv_q4_rows_lds_kernel<4, 2, 0, 2>": 10, r"attn_gqa_split_kernel<128>": 3,
+    r"gemv_q4_qkv_rope_kernel<4, 2, 2>": 5, r"gemv_q4_gateup_silu_kernel<4, 2, 2>": 6, r"gemv_q4_rows_lds_kernel<4, 2, 0, 2>": 10, r"gemv_q4_rows_lds_kernel<4, 2, 3, 2>": 10, r"attn_gqa_split_kernel<128>": 3,
     r"convt_b3_kernel<8, 1, true>": 3, r"conv1d_mfma_kernel<7, 2, 2, 1, 4, 4>": 14,   # 102 before its epilogue went to load / compute / store phases
 }
 
@@ -95,4 +96,4 @@ def test_hot_kernels_have_no_scratch_and_no_serialized_load_chains(tmp_path):
             assert v <= limit, f"{k}: {v} dependent load groups (limit {limit}): a predicate crept back around a load?"
             checked += 1
     if shutil.which("c++filt"):
-        assert checked >= 14, sorted(seen)
+        assert checked >= 15, sorted(seen)

@@ -242,6 +242,12 @@ __device__ __forceinline__ void q4_frag_dot(const Q4Frag<NF, NP> &fr, const int8
 // QSRC 1: the activations arrive as fp32 rows (a.A, lda == K) and are Q8_0-quantised while they are staged — ggml's quantize_row_q8_0_ref
 // arithmetic, identical to quant_rows_q8_kernel / q8_block_store (d = amax / 127 kept as fp16, q = roundf(x / d)) — one 32-value block per
 // thread and pass; saves the producer a separate quantisation (the silu * up product of gemv_q4_gateup_silu_kernel feeds the down projection).
+// QSRC 3: the activations are the attention output of a split decode step (attn_gqa_split_kernel, Q4_FOLD_NZ key slices per (row, head)): the
+// workgroup merges the slices while it stages — attn_gqa_combine_kernel's arithmetic to the letter (running max over the slices in order,
+// o = sum f_z o_z, l = sum f_z l_z with f_z = expf(m_z - m), o / l) and q8_block_store's quantisation — eight values per thread, a 32-value
+// block per lane quad.  The o projection of a Llama step then needs no combine launch in front of it; every workgroup reads the 100 KB of
+// partials of a row from L2 instead (its weight loads are already in flight).
+#define Q4_FOLD_NZ 8
 template <int NR, int FPW, int QSRC = 0, int NP = 2>
 __global__ __launch_bounds__(256) void gemv_q4_rows_lds_kernel(QGemmArgs qa, const uint8_t *w4, int epi) {
     extern __shared__ __attribute__((aligned(16))) char gq_sm[];
@@ -260,6 +266,55 @@ __global__ __launch_bounds__(256) void gemv_q4_rows_lds_kernel(QGemmArgs qa, con
     if (QSRC == 0) {
         for (int i = tid; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
         for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
+    } else if (QSRC == 3) {
+        for (int i = tid; i < R * nb * 4; i += 256) {   // a multiple of 4 items: the four lanes of a quad are in or out together
+            const int blk = i >> 2, qt = i & 3;
+            const int r = blk / nb, b = blk - r * nb;
+            const float *p = qa.parts + ((int64_t) r * (K >> 7) + (b >> 2)) * Q4_FOLD_NZ * ATTN_PART;
+            const int t0 = (b & 3) * 32 + qt * 8;
+            float2v ml[Q4_FOLD_NZ], v[Q4_FOLD_NZ][4];
+#pragma unroll
+            for (int z = 0; z < Q4_FOLD_NZ; z++) {
+                ml[z] = *(const float2v *) (p + z * ATTN_PART);
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[z][j] = *(const float2v *) (p + z * ATTN_PART + 2 + t0 + 2 * j);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // every slice requested before the first is used (the scheduler otherwise sinks half of the loads between the exps)
+            float m = -INFINITY;
+#pragma unroll
+            for (int z = 0; z < Q4_FOLD_NZ; z++) m = fmaxf(m, ml[z][0]);
+            float o[8], l = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = 0.0f;
+#pragma unroll
+            for (int z = 0; z < Q4_FOLD_NZ; z++) {
+                // an empty slice left only (max = -inf, sum = 0) behind: it adds + 0 (selects, not a branch: a branch would pull the slice's loads
+                // into its block and make them a round trip of their own)
+                const float mz = ml[z][0];
+                const bool live = mz != -INFINITY;
+                const float f = live ? expf(mz - m) : 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] += f * (live ? v[z][e >> 1][e & 1] : 0.0f);
+                l += f * ml[z][1];
+            }
+            float amax = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) { o[e] = o[e] / l; amax = fmaxf(amax, fabsf(o[e])); }
+            amax = fmaxf(amax, __shfl_xor(amax, 1));
+            amax = fmaxf(amax, __shfl_xor(amax, 2));
+            const float dd = amax / 127.0f;
+            const float id = dd ? 1.0f / dd : 0.0f;
+            int2v q;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                unsigned pk = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) pk |= ((unsigned) (int) (int8_t) roundf(o[4 * j + e] * id) & 0xFFu) << (8 * e);
+                q[j] = (int) pk;
+            }
+            *(int2v *) (sx + (size_t) r * K + b * 32 + qt * 8) = q;
+            if (qt == 0) sd[blk] = (float) (_Float16) dd;
+        }
     } else {
         for (int i = tid; i < R * nb; i += 256) {
             const int r = i / nb, b = i - r * nb;

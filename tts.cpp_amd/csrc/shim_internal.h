@@ -275,6 +275,8 @@ struct tts_hip_ctx {
     int tile_force = -1;        // TTS_HIP_TILE_FORCE: tile shape index for every tiled GEMM (tuning)
     int tile_force_ks = 0;      // TTS_HIP_TILE_KS: k slices for the residual GEMMs (tuning)
     const void *aq_src = nullptr;  // activation rows whose Q8_0 blocks already sit in aq / ad (written by the producing kernel)
+    int attn_fold = 1;          // tune("attn_fold") = 0: the split decode attention of a Llama step keeps its combine launch (default: the o projection's workgroups merge the slices while they stage, gemv_q4_rows_lds_kernel<.., QSRC 3>)
+    int attn_fold_pending = 0;  // slices waiting in attn_part for the o projection (set by launch_attn_gqa, consumed by run_qgemm)
     int attn_split_max = 8;     // tune("attn_split"): key splits of the decode attention of the Llama / Dia steps (1 = off)
     float *attn_part = nullptr; // [rows][heads][splits][130] partial softmax results
     size_t attn_part_cap = 0;   // in (row, head, split) triples

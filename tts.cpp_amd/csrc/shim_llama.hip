@@ -54,6 +54,12 @@ static int launch_attn_gqa(tts_hip_ctx *c, int NHq, int rows, int max_keys, cons
     hipLaunchKernelGGL(attn_gqa_split_kernel<128>, dim3(NHq, rows, nz), dim3(256), (size_t) (128 + chunk + 1) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part,
                        kbeg, kend, row_seq, seq_stride, qp);
     HIPCHK(hipGetLastError());
+    if (q_out && c->attn_fold && nz == Q4_FOLD_NZ && !c->prof && !c->debug) {
+        // the consumer (run_qgemm's o projection) merges the slices while it stages its activations; `out` itself is not written
+        c->attn_fold_pending = nz;
+        c->aq_src = out;
+        return 0;
+    }
     hipLaunchKernelGGL(attn_gqa_combine_kernel, dim3(NHq, rows), dim3(128), 0, c->stream, (const float *) c->attn_part, nz, NHq, out, q_out ? c->aq : (int8_t *) nullptr, q_out ? c->ad : (float *) nullptr);
     if (q_out) c->aq_src = out;
     HIPCHK(hipGetLastError());

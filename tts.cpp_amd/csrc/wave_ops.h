@@ -6,6 +6,8 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef int int2v __attribute__((ext_vector_type(2)));
 
 #define LN_EPS 1e-5f  // model.cpp:414 "parler always uses default eps"
 

@@ -568,6 +568,10 @@ class OrpheusEngine:
         if rc != 0:
             raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
 
+    def tune(self, key, value):
+        """tts_hip_tune: a named tuning / fallback switch (before the first launch)"""
+        self._chk(self.L.tts_hip_tune(self.ctx, key.encode(), int(value)))
+
     def load(self, model):
         for t in model.tensors:
             ne = (C.c_int64 * 4)(*(t.ne + [1] * (4 - len(t.ne))))
