@@ -34,3 +34,28 @@ for f in funcs:
     if best >= min_chain: rows.append((best, name))
 for best, name in sorted(rows, reverse=True):
     print(f"{best:4d} dependent load groups  {name}")
+
+# Second pattern (round 4, gemv_stream_kernel): a PARTIAL wait in the prologue — loads issued, `s_waitcnt vmcnt(k > 0)`, more loads, all before
+# the first barrier / MFMA / loop back-edge.  A load under a predicate whose result is copied on the way out of its block (a phi) produces it:
+# the copy waits for the first load, and everything the kernel requests afterwards is a second round trip.  Inside pipelined loops the same
+# sequence is the double buffering at work, so only the straight-line head of the kernel is scanned.
+if len(sys.argv) > 3 and sys.argv[3] == "partial":
+    for f in funcs:
+        m = re.match(r'(\w+):', f)
+        if not m or 's_endpgm' not in f: continue
+        loads = waited = hits = 0
+        labels = set()
+        for ln in f.split('\n'):
+            t = ln.strip()
+            lm = re.match(r'(\.LBB\w+):', t)
+            if lm: labels.add(lm.group(1))
+            if t.startswith('global_load') or t.startswith('buffer_load'):
+                if waited: hits += 1; waited = 0
+                loads += 1
+            elif t.startswith('s_waitcnt') and re.search(r'vmcnt\((\d+)\)', t):
+                if loads and int(re.search(r'vmcnt\((\d+)\)', t).group(1)) > 0: waited = 1
+            elif t.startswith('s_barrier') or t.startswith('v_mfma'):
+                break
+            elif t.startswith('s_cbranch') and t.split()[-1] in labels:   # a back-edge: the loops start here
+                break
+        if hits: print(f"{hits:4d} partial waits in the prologue  {m.group(1)}")

@@ -273,3 +273,31 @@ def test_dia_1_6b_layer_shapes():
             assert relerr(lg[u], ref) < 8e-3, (step, u)
             ids[u] = rng.integers(0, cfg.audio_vocab, cfg.n_out)
     eng.close()
+
+
+@pytest.mark.parametrize("shapes", ["tiny_f16", "1_6b_layer"])
+def test_dia_captured_step_folds_slice_merge_and_silu_into_the_projections(shapes):
+    """The captured decoder step with fp16 matrices leaves the self- (and, over >= 1024 text positions, cross-) attention's eight key slices
+    unmerged and the gate | up slabs unmultiplied: the output / down projections do both while they stage their rows
+    (gemv_stream_kernel<.., PRO_ATTN8 / PRO_SILU, ..>, three launches fewer per layer).  Same arithmetic as the separate launches: the ids of a
+    greedy generation equal those of tune("attn_fold") = 0 exactly, for one utterance and for two in lock-step."""
+    if shapes == "tiny_f16":
+        model = synth.build_dia(synth.dia_tiny(weight_type=gguf.F16))
+        texts, steps = ["[S1] hi there", "[S2] ok"], 40
+    else:
+        model = synth.build_dia(synth.dia_1_6b(enc_layers=1, dec_layers=2, max_gen=64, weight_type=gguf.F16))
+        texts, steps = ["[S1] The birch canoe slid on the smooth planks.", "[S2] Glue the sheet."], 40
+    cfg = model.cfg
+    args = dict(delay_pattern=[0, 8, 9, 10, 11, 12, 13, 14, 15], bos=cfg.bos, eos=cfg.eos, pad=cfg.pad, max_delay=cfg.max_delay)
+    outs = {}
+    for fold in (1, 0):
+        eng = hip.DiaEngine(cfg, max_utterances=2)
+        eng.tune("attn_fold", fold)
+        eng.load(model)
+        for u, t in enumerate(texts):
+            eng.encode_slot(u, *orc.dia_tokenize(t, cfg.max_ctx))
+        outs[fold] = eng.generate(1, steps, **args) + eng.generate(2, steps, **args)
+        eng.close()
+    assert len(outs[1]) == 3 and all(len(o) > 0 for o in outs[1])
+    for a, b in zip(outs[1], outs[0]):
+        assert a.shape == b.shape and np.array_equal(a, b)

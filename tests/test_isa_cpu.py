@@ -40,6 +40,17 @@ template __global__ void gemv_q4_rows_lds_kernel<4, 2, 3, 2>(QGemmArgs, const ui
 template __global__ void attn_gqa_split_kernel<128>(const float *, int, const uint32_t *, const float *, const float *, int, int, float, float *, const uint32_t *,
                                                     const uint32_t *, const uint32_t *, int64_t, QPre);
 """
+STREAM_TU = """
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include "{root}/tts.cpp_amd/csrc/gemv_stream_kernels.h"
+template __global__ void gemv_stream_kernel<4, PRO_F32, EPI_STORE>(GemmArgs, StreamMap);
+template __global__ void gemv_stream_kernel<16, PRO_F32, EPI_STORE>(GemmArgs, StreamMap);
+template __global__ void gemv_stream_kernel<4, PRO_F16, EPI_STORE>(GemmArgs, StreamMap);
+template __global__ void gemv_stream_kernel<4, PRO_ATTN8, EPI_STORE>(GemmArgs, StreamMap);
+template __global__ void gemv_stream_kernel<4, PRO_SILU, EPI_STORE>(GemmArgs, StreamMap);
+"""
 DAC_TU = """
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -97,3 +108,17 @@ def test_hot_kernels_have_no_scratch_and_no_serialized_load_chains(tmp_path):
             checked += 1
     if shutil.which("c++filt"):
         assert checked >= 15, sorted(seen)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_streaming_gemv_requests_weights_and_rows_in_one_round_trip(tmp_path):
+    """gemv_stream_kernel (every projection of a Dia step, the MLP of a Parler batch-1 step): the first weight chunk and the staging loads of the
+    activation rows must be in flight together.  Until round 4 the weight loads sat under `if (t < tiles)`: the block's first result was copied on
+    the way out, which put an `s_waitcnt vmcnt(7)` between the two groups — two dependent round trips at the head of ~110 launches per Dia step.
+    The folding prologues (eight attention slices / silu * up) must also issue all of their loads before the first use, without scratch."""
+    asm, remarks = _compile(tmp_path, "stream", STREAM_TU)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", remarks)]
+    assert len(scratch) >= 5 and max(scratch) == 0, scratch
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "tools", "isa_serial_loads.py"), str(asm), "99", "partial"],
+                         capture_output=True, text=True, check=True).stdout
+    assert "gemv_stream_kernel" not in out, out

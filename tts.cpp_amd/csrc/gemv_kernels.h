@@ -247,7 +247,7 @@ __device__ __forceinline__ void q4_frag_dot(const Q4Frag<NF, NP> &fr, const int8
 // o = sum f_z o_z, l = sum f_z l_z with f_z = expf(m_z - m), o / l) and q8_block_store's quantisation — eight values per thread, a 32-value
 // block per lane quad.  The o projection of a Llama step then needs no combine launch in front of it; every workgroup reads the 100 KB of
 // partials of a row from L2 instead (its weight loads are already in flight).
-#define Q4_FOLD_NZ 8
+#define Q4_FOLD_NZ ATTN_FOLD_NZ
 template <int NR, int FPW, int QSRC = 0, int NP = 2>
 __global__ __launch_bounds__(256) void gemv_q4_rows_lds_kernel(QGemmArgs qa, const uint8_t *w4, int epi) {
     extern __shared__ __attribute__((aligned(16))) char gq_sm[];

@@ -45,7 +45,10 @@ __global__ __launch_bounds__(NWV * 64) void gemv_stream_kernel(GemmArgs a, Strea
 #pragma unroll
         for (int c = 0; c < 8; c++) w[c] = __builtin_nontemporal_load((const half8 *) (p + c * 32));
     };
-    if (t < tiles) loadw(w0, t, 0);   // in flight under the staging
+    // in flight under the staging.  Unconditional (a wave with no tile re-reads the last one): under `if (t < tiles)` the loads were a block of their
+    // own whose first result was copied on the way out — an s_waitcnt on the first weight load in front of the staging loads, two dependent
+    // round trips at the top of every launch.
+    loadw(w0, min(t, tiles - 1), 0);
 
     // ---- stage this slice of the R rows as fp16 ------------------------------------------------------
     const int c8n = KS >> 3;
@@ -55,6 +58,57 @@ __global__ __launch_bounds__(NWV * 64) void gemv_stream_kernel(GemmArgs a, Strea
         if (r < a.R) {
             if (PRO == PRO_F16) {
                 h = *(const half8 *) ((const _Float16 *) a.A + (int64_t) r * a.lda + k0 + c8 * 8);
+            } else if (PRO == PRO_ATTN8) {
+                // K = heads x 128: eight values of one head, merged from the key slices (attn_gqa_combine_kernel: running max in slice order,
+                // o = sum f_z o_z, l = sum f_z l_z with f_z = expf(m_z - m), o / l; an empty slice left (max = -inf, sum = 0) and adds + 0)
+                const int k = k0 + c8 * 8;
+                const float *p = a.att_part + ((int64_t) r * (a.K >> 7) + (k >> 7)) * ATTN_FOLD_NZ * ATTN_PART;
+                const int t0 = k & 127;
+                float2v ml[ATTN_FOLD_NZ], v[ATTN_FOLD_NZ][4];
+#pragma unroll
+                for (int z = 0; z < ATTN_FOLD_NZ; z++) {
+                    ml[z] = *(const float2v *) (p + z * ATTN_PART);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[z][j] = *(const float2v *) (p + z * ATTN_PART + 2 + t0 + 2 * j);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // every slice requested before the first is used
+                float m = -INFINITY;
+#pragma unroll
+                for (int z = 0; z < ATTN_FOLD_NZ; z++) m = fmaxf(m, ml[z][0]);
+                float o[8], l = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = 0.0f;
+#pragma unroll
+                for (int z = 0; z < ATTN_FOLD_NZ; z++) {
+                    const float mz = ml[z][0];
+                    const bool live = mz != -INFINITY;
+                    const float f = live ? expf(mz - m) : 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) o[e] += f * (live ? v[z][e >> 1][e & 1] : 0.0f);
+                    l += f * ml[z][1];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) h[e] = (_Float16) (o[e] / l);
+            } else if (PRO == PRO_SILU) {
+                // a.A = gate | up rows [R][2 K] as a.n_parts <= 8 slabs (a.parts_stride floats apart) of the preceding projection: slabs added in
+                // slab order (a slab beyond n_parts re-reads the last one and is never added), silu(gate) * up — silu_mul_kernel's arithmetic
+                const float *pg = (const float *) a.A + (int64_t) r * a.lda + k0 + c8 * 8;
+                float4v gx[8][2], ux[8][2];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const float *pq = pg + (int64_t) min(q, a.n_parts - 1) * a.parts_stride;
+                    gx[q][0] = *(const float4v *) pq; gx[q][1] = *(const float4v *) (pq + 4);
+                    ux[q][0] = *(const float4v *) (pq + a.K); ux[q][1] = *(const float4v *) (pq + a.K + 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float x = gx[0][e >> 2][e & 3], u = ux[0][e >> 2][e & 3];
+#pragma unroll
+                    for (int q = 1; q < 8; q++)
+                        if (q < a.n_parts) { x += gx[q][e >> 2][e & 3]; u += ux[q][e >> 2][e & 3]; }
+                    h[e] = (_Float16) ((x / (1.0f + expf(-x))) * u);
+                }
             } else {
                 const float *p = (const float *) a.A + (int64_t) r * a.lda + k0 + c8 * 8;
                 const float4v f0 = *(const float4v *) p, f1 = *(const float4v *) (p + 4);

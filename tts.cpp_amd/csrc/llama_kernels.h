@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld,
 // bandwidth (a CU's load path), so 24 workgroups reading 0.5 MB each take 20 us whatever the chip could do.  The keys of a row are
 // split over gridDim.z workgroups; each leaves (max, sum, unnormalised out[128]) and attn_gqa_combine_kernel merges them — the same
 // softmax, associated differently.  An empty split (short sequences under a graph captured for long ones) leaves max = -inf.
-#define ATTN_PART 130   // floats per partial: max, sum, out[128]
+// ATTN_PART (parler_kernels.h) floats per partial: max, sum, out[128]
 template <int HD>
 __global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, int ld, const uint32_t *pos, const float *kcache, const float *vcache, int NH, int NKV,
                                                              float scale, float *part, const uint32_t *kbeg, const uint32_t *kend, const uint32_t *row_seq,

@@ -75,7 +75,12 @@ static __global__ void embed_rows_kernel(EmbedArgs a) {
 // ------------------------------------------------------------------------------------------------
 // PRO_ATTN: the activations are the split-T self-attention's partials (attn_kernel with nsplit > 1 and no in-kernel combine); the
 // workgroup folds them — attn_combine_kernel's arithmetic — into the fp16 rows its MFMAs read (batch-1 chain)
-enum { PRO_F32 = 0, PRO_LN = 1, PRO_F16 = 2, PRO_ATTN = 3 };
+enum { PRO_F32 = 0, PRO_LN = 1, PRO_F16 = 2, PRO_ATTN = 3,
+       // gemv_stream_kernel only (Dia's step): the activations are the eight key slices of attn_gqa_split_kernel (merged while they are staged:
+       // attn_gqa_combine_kernel's arithmetic) / the gate | up slabs of the preceding projection (silu(gate) * up while staged: silu_mul_kernel's)
+       PRO_ATTN8 = 4, PRO_SILU = 5 };
+#define ATTN_PART 130     // floats per partial of attn_gqa_split_kernel: max, sum, out[128]
+#define ATTN_FOLD_NZ 8    // slices a consumer's staging prologue merges (the default split count of the captured steps)
 // key-split partials of one (row, head): [nsplit][ATT_PS] floats = max, sum, pad, pad, acc[64] (acc 16-byte aligned)
 constexpr int ATT_PS = 68, ATT_PO = 4;
 enum { EPI_STORE = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3 };

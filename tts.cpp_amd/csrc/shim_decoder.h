@@ -5,5 +5,6 @@
 
 enum { DIA_STREAM_SLABS = 8 };   // slab budget of the Dia step buffers (di_qkv, di_q, di_gu, di_parts)
 int stream_slices(const tts_hip_ctx *c, const W &w, int R, int max_slabs);
+bool stream_fold_ok(const tts_hip_ctx *c, const W &w, int R, int max_slabs);
 int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi);
 int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi);

@@ -271,6 +271,12 @@ int stream_slices(const tts_hip_ctx *c, const W &w, int R, int max_slabs) {
     return ks;
 }
 
+// a staging prologue that merges attention slices / applies silu * up exists for the four-wave instance of gemv_stream_kernel only
+bool stream_fold_ok(const tts_hip_ctx *c, const W &w, int R, int max_slabs) {
+    const int ks = stream_slices(c, w, R, max_slabs);
+    return ks > 0 && (int) w.N / 16 * ks < 4096 && R <= 8;
+}
+
 template <int NWV, int PRO, int EPI>
 static int launch_stream_one(tts_hip_ctx *c, const GemmArgs &a, StreamMap sm, int grid, size_t lds) {
     static std::atomic<uint64_t> attr{0};
@@ -292,6 +298,7 @@ static int launch_stream(tts_hip_ctx *c, const GemmArgs &a, int pro, int epi) {
 #define STREAM_CASE(NWVv, PROv, EPIv) if (nwv == NWVv && pro == PROv && epi == EPIv) return launch_stream_one<NWVv, PROv, EPIv>(c, a, sm, grid, lds);
     STREAM_CASE(4, PRO_F32, EPI_STORE) STREAM_CASE(16, PRO_F32, EPI_STORE) STREAM_CASE(4, PRO_F32, EPI_RESID) STREAM_CASE(16, PRO_F32, EPI_RESID)
     STREAM_CASE(4, PRO_F16, EPI_STORE) STREAM_CASE(16, PRO_F16, EPI_STORE)
+    STREAM_CASE(4, PRO_ATTN8, EPI_STORE) STREAM_CASE(4, PRO_SILU, EPI_STORE)   // Dia's step: four-wave workgroups only (the callers check stream_fold_ok)
 #undef STREAM_CASE
     return set_err("gemv_stream: no kernel for pro=%d epi=%d", pro, epi);
 }

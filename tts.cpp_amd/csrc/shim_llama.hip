@@ -36,8 +36,9 @@ extern "C" tts_hip_ctx *tts_hip_orpheus_create(int device, const tts_hip_orpheus
 // plus a combine launch (attn_gqa_split_kernel).  max_keys bounds the LDS score buffer.
 static int launch_attn_gqa(tts_hip_ctx *c, int NHq, int rows, int max_keys, const float *qkv, int ld, const uint32_t *pos, const float *kc, const float *vc, int NKV,
                            float scale, float *out, const uint32_t *kbeg, const uint32_t *kend, const uint32_t *row_seq, int64_t seq_stride, bool fixed_split, bool q_out = false,
-                           QPre qp = QPre{}) {
+                           QPre qp = QPre{}, int *deferred = nullptr) {
     int nz = 1;
+    if (deferred) *deferred = 0;
     if (c->attn_split_max > 1 && NHq * rows <= 256) {
         // a graph captured once replays for every position: the split count must not depend on the position then
         nz = fixed_split ? c->attn_split_max : std::min(c->attn_split_max, std::max(1, max_keys / 128));
@@ -54,6 +55,10 @@ static int launch_attn_gqa(tts_hip_ctx *c, int NHq, int rows, int max_keys, cons
     hipLaunchKernelGGL(attn_gqa_split_kernel<128>, dim3(NHq, rows, nz), dim3(256), (size_t) (128 + chunk + 1) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part,
                        kbeg, kend, row_seq, seq_stride, qp);
     HIPCHK(hipGetLastError());
+    if (deferred && c->attn_fold && nz == ATTN_FOLD_NZ && !c->prof && !c->debug) {
+        *deferred = nz;   // the caller's next projection merges the slices in its staging prologue (gemv_stream_kernel<.., PRO_ATTN8, ..>); `out` is not written
+        return 0;
+    }
     if (q_out && c->attn_fold && nz == Q4_FOLD_NZ && !c->prof && !c->debug) {
         // the consumer (run_qgemm's o projection) merges the slices while it stages its activations; `out` itself is not written
         c->attn_fold_pending = nz;
@@ -461,10 +466,13 @@ static int dia_gemm_rows(tts_hip_ctx *c, const W &w, const float *A, int lda, fl
 
 // <= 16 rows through gemv_stream_kernel: `out` receives *slabs K-slice slabs 16 * ldo floats apart (the consumer folds them);
 // *slabs = 0: the shape does not qualify and nothing was launched
-static int dia_gemm_stream(tts_hip_ctx *c, const W &w, const float *A, int lda, float *out, int ldo, int n, int max_slabs, int64_t slab_stride, int *slabs) {
+// pro: PRO_F32 (A = fp32 rows), PRO_ATTN8 (A unused: the eight key slices in c->attn_part are merged while the rows are staged) or PRO_SILU (A = the
+// gate | up rows [n][2 K] as in_parts slabs in_stride floats apart: silu(gate) * up while staged); the last two need stream_fold_ok()
+static int dia_gemm_stream(tts_hip_ctx *c, const W &w, const float *A, int lda, float *out, int ldo, int n, int max_slabs, int64_t slab_stride, int *slabs,
+                           int pro = PRO_F32, int in_parts = 1, int64_t in_stride = 0) {
     const int ks = stream_slices(c, w, n, max_slabs);
     *slabs = ks;
-    if (!ks) return 0;
+    if (!ks) return pro == PRO_F32 ? 0 : set_err("dia_gemm_stream: a folding prologue was promised to a shape the streaming kernel does not take");
     GemmArgs g{};
     g.R = n; g.H = c->H;
     g.A = A; g.lda = lda;
@@ -472,7 +480,9 @@ static int dia_gemm_stream(tts_hip_ctx *c, const W &w, const float *A, int lda, 
     g.stream = 1;
     g.kchunk = ks > 1 ? (int) w.K / ks : 0;
     g.slab_stride = slab_stride;
-    return run_gemm(c, TTS_HIP_K_GEMM_OTHER, w, g, PRO_F32, EPI_STORE);
+    if (pro == PRO_ATTN8) g.att_part = c->attn_part;
+    if (pro == PRO_SILU) { g.n_parts = std::max(in_parts, 1); g.parts_stride = in_stride; }
+    return run_gemm(c, TTS_HIP_K_GEMM_OTHER, w, g, pro, EPI_STORE);
 }
 
 static int dia_rms(tts_hip_ctx *c, size_t w_off, int rows, int H, float *x, float *y, bool fold) {
@@ -592,9 +602,11 @@ static int dia_forward(tts_hip_ctx *c, int U, int self_keys, bool fixed_split) {
         hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(R, NH + NKV), dim3(64), 0, c->stream, c->di_qkv, (const uint32_t *) c->di_pos, (const float *) nullptr, theta_scale, NH,
                            NKV, HD, kc, vc, (const uint32_t *) c->di_seq, (int64_t) G * kvH, std::max(sl, 1), st16 * QKV);
         HIPCHK(hipGetLastError());
+        int slices = 0;   // key slices the attention left unmerged for the projection's staging prologue (0: di_att holds the rows)
         CHK(launch_attn_gqa(c, NH, R, self_keys, (const float *) c->di_qkv, QKV, (const uint32_t *) c->di_pos, (const float *) kc, (const float *) vc, NKV, 1.0f,
-                            c->di_att, nul, nul, (const uint32_t *) c->di_seq, (int64_t) G * kvH, fixed_split));
-        CHK(dia_gemm_stream(c, y.so, c->di_att, A, c->di_parts, DH, R, DIA_STREAM_SLABS, (int64_t) c->RMAX * DH, &sl));
+                            c->di_att, nul, nul, (const uint32_t *) c->di_seq, (int64_t) G * kvH, fixed_split, false, QPre{},
+                            A % 128 == 0 && stream_fold_ok(c, y.so, R, DIA_STREAM_SLABS) ? &slices : nullptr));
+        CHK(dia_gemm_stream(c, y.so, c->di_att, A, c->di_parts, DH, R, DIA_STREAM_SLABS, (int64_t) c->RMAX * DH, &sl, slices ? PRO_ATTN8 : PRO_F32));
         if (sl) c->di_pending = sl;
         else CHK(dia_gemm(c, y.so, c->di_att, A, c->di_x, DH, R, EPI_RESID));
         CHK(dia_rms(c, y.ca_norm, R, DH, c->di_x, c->di_xn, true));
@@ -602,18 +614,25 @@ static int dia_forward(tts_hip_ctx *c, int U, int self_keys, bool fixed_split) {
         if (!sl) CHK(dia_gemm(c, y.cq, c->di_xn, DH, c->di_q, A, R, EPI_STORE));
         QPre qp;   // slab fold + rope of the cross-attention query happen as the attention workgroups load it
         qp.n_parts = std::max(sl, 1); qp.part_stride = st16 * A; qp.rope_pos = c->di_pos; qp.theta_scale = theta_scale;
+        slices = 0;
         CHK(launch_attn_gqa(c, NH, R, S, (const float *) c->di_q, A, (const uint32_t *) c->di_pos, ck, cv, NH, 1.0f, c->di_att, nul, (const uint32_t *) c->di_cend,
-                            (const uint32_t *) c->di_seq, (int64_t) S * A, false, false, qp));
-        CHK(dia_gemm_stream(c, y.co, c->di_att, A, c->di_parts, DH, R, DIA_STREAM_SLABS, (int64_t) c->RMAX * DH, &sl));
+                            (const uint32_t *) c->di_seq, (int64_t) S * A, false, false, qp,
+                            A % 128 == 0 && stream_fold_ok(c, y.co, R, DIA_STREAM_SLABS) ? &slices : nullptr));
+        CHK(dia_gemm_stream(c, y.co, c->di_att, A, c->di_parts, DH, R, DIA_STREAM_SLABS, (int64_t) c->RMAX * DH, &sl, slices ? PRO_ATTN8 : PRO_F32));
         if (sl) c->di_pending = sl;
         else CHK(dia_gemm(c, y.co, c->di_att, A, c->di_x, DH, R, EPI_RESID));
         CHK(dia_rms(c, y.mlp_norm, R, DH, c->di_x, c->di_xn, true));
         CHK(dia_gemm_stream(c, y.gu, c->di_xn, DH, c->di_gu, 2 * DF, R, DIA_STREAM_SLABS, st16 * 2 * DF, &sl));
         if (!sl) CHK(dia_gemm(c, y.gu, c->di_xn, DH, c->di_gu, 2 * DF, R, EPI_STORE));
-        hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) R * DF + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->di_gu, DF, R, c->di_g, (int8_t *) nullptr,
-                           (float *) nullptr, std::max(sl, 1), st16 * 2 * DF);
-        HIPCHK(hipGetLastError());
-        CHK(dia_gemm_stream(c, y.out, c->di_g, DF, c->di_parts, DH, R, DIA_STREAM_SLABS, (int64_t) c->RMAX * DH, &sl));
+        if (c->attn_fold && !c->prof && !c->debug && std::max(sl, 1) <= 8 && stream_fold_ok(c, y.out, R, DIA_STREAM_SLABS)) {
+            // silu(gate) * up while the down projection stages its rows: no launch of its own, di_g is not written
+            CHK(dia_gemm_stream(c, y.out, c->di_gu, 2 * DF, c->di_parts, DH, R, DIA_STREAM_SLABS, (int64_t) c->RMAX * DH, &sl, PRO_SILU, std::max(sl, 1), st16 * 2 * DF));
+        } else {
+            hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) R * DF + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->di_gu, DF, R, c->di_g, (int8_t *) nullptr,
+                               (float *) nullptr, std::max(sl, 1), st16 * 2 * DF);
+            HIPCHK(hipGetLastError());
+            CHK(dia_gemm_stream(c, y.out, c->di_g, DF, c->di_parts, DH, R, DIA_STREAM_SLABS, (int64_t) c->RMAX * DH, &sl));
+        }
         if (sl) {
             c->di_pending = sl;
         } else if (c->di_ksplit > 1) {

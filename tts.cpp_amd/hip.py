@@ -653,6 +653,10 @@ class DiaEngine:
         if rc != 0:
             raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
 
+    def tune(self, key, value):
+        """tts_hip_tune: a named tuning / fallback switch (before the first launch)"""
+        self._chk(self.L.tts_hip_tune(self.ctx, key.encode(), int(value)))
+
     def load(self, model, declare_only=False):
         """declare_only: lay the arena out without uploading (the bytes arrive by tts_hip_broadcast_weights_rank / tts_hip_arena_filled)"""
         for t in model.tensors:
