@@ -1,11 +1,21 @@
+# round 4, call 27: the folded one-sequence steps (Orpheus: slice merge in the o projection; Dia: slice merge + silu * up in the projections' staging;
+# gemv_stream_kernel's unconditional first weight loads) — their tests first, then the whole GPU suite, smoke(), the default bench line
 mkdir -p gpurun_out/r4
-O=$GRAFT_REPO_ROOT/gpurun_out/r4
-(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_kk -- python $GRAFT_REPO_ROOT/profiles/kokoro_bench.py > $O/kokoro_kt.log 2>&1; cp "$(find /tmp/kt_kk -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_kokoro_r4.csv)
+export HSA_DISABLE_COREDUMP_ON_EXCEPTION=1; ulimit -c 0
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4
+timeout 400 python -m pytest tests/test_gpu_orpheus.py tests/test_gpu_dia.py -q -x --tb=short 2>&1 | tail -30 > $O/gpu_tests_call27_folds.txt
+cat $O/gpu_tests_call27_folds.txt | tail -30
+if ! grep -q " passed" $O/gpu_tests_call27_folds.txt || grep -q "failed\|error" $O/gpu_tests_call27_folds.txt; then echo "FOLD TESTS NOT GREEN: stopping"; exit 0; fi
+timeout 900 python -m pytest tests -m gpu -q --deselect tests/test_gpu_orpheus.py --deselect tests/test_gpu_dia.py 2>&1 | grep -E "passed|failed|^E |^FAILED|rror" | tail -8 > $O/gpu_tests_call27_rest.txt; cat $O/gpu_tests_call27_rest.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout 1500 python bench.py > $O/bench_default_call27.json 2> $O/bench_default_call27.log
 python - <<'PY'
-import csv
-rows=list(csv.DictReader(open('gpurun_out/r4/kernel_stats_kokoro_r4.csv')))
-tot=sum(float(r['TotalDurationNs']) for r in rows)
-print('total kernel ms', tot/1e6)
-for r in rows[:18]:
-    print(f"{r['Name'][:80]:80s} calls {r['Calls']:>6s} avg {float(r['AverageNs'])/1e3:8.2f} us  {r['Percentage']}%")
+import json
+d = json.loads(open('gpurun_out/r4/bench_default_call27.json').read().strip().split('\n')[-1])
+print('value', d['value'], 'ms_per_step', d['ms_per_step'])
+print('roofline', {k: d['roofline'].get(k) for k in ('bound', 'achieved', 'frac', 'avg_launch_us')})
+print('b1', d.get('decode_step_batch1', {}).get('steps_1024'))
+print('e2e', json.dumps(d.get('generate_batch1_end_to_end'))[:400])
+print('secondary', {k: (v.get('value'), v.get('ms_per_decode_step')) for k, v in d.get('secondary', {}).items()})
+print('long', {k: (v.get('audio_seconds_per_sec') if isinstance(v, dict) else v) for k, v in d.get('long_utterances', {}).items() if k in ('uniform', 'ragged', 'ragged_stream')})
 PY
