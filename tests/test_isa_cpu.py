@@ -38,7 +38,7 @@ template __global__ void gemv_q4_gateup_silu_kernel<4, 2, 2>(QGemmArgs, const ui
 template __global__ void gemv_q4_rows_lds_kernel<4, 2, 0, 2>(QGemmArgs, const uint8_t *, int);
 template __global__ void gemv_q4_rows_lds_kernel<4, 2, 3, 2>(QGemmArgs, const uint8_t *, int);
 template __global__ void attn_gqa_split_kernel<128>(const float *, int, const uint32_t *, const float *, const float *, int, int, float, float *, const uint32_t *,
-                                                    const uint32_t *, const uint32_t *, int64_t, QPre);
+                                                    const uint32_t *, const uint32_t *, int64_t, QPre, uint32_t *, float *, int8_t *, float *);
 """
 STREAM_TU = """
 #include <hip/hip_runtime.h>

@@ -809,6 +809,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         const size_t kvb = (size_t) c->L * NCTX * c->l_kvH;
         c->attn_part_cap = (size_t) 4 * c->NH * 16;   // up to 4 rows x heads x 16 splits (more rows take the unsplit kernel)
         CHK(dmalloc(&c->attn_part, c->attn_part_cap * ATTN_PART));
+        CHK(dmalloc(&c->attn_cnt, (size_t) 256 + c->NH));   // arrival counters of the split attention's in-kernel merge (rows x heads <= 256)
         CHK(dmalloc(&c->l_kc, kvb));   // ggml_backend_buffer_clear(buf, 0), orpheus/model.cpp:181
         CHK(dmalloc(&c->l_vc, kvb));
         const int R = c->RMAX;
