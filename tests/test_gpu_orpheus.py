@@ -107,16 +107,16 @@ def test_orpheus_3b_shapes_few_row_calls_take_the_fused_projections():
 
 def test_orpheus_3b_shapes_captured_step_merges_the_attention_slices_without_a_launch():
     """The captured greedy step at the 3B widths (Q4_0) cuts the keys of every (row, head) into eight slices (attn_gqa_split_kernel; at these
-    positions most of them are empty).  Who merges them: tune("attn_fold") = 0 a combine launch, 1 (default) the last workgroup of the (row, head)
+    positions most of them are empty).  Who merges them: tune("llama_merge") = 0 (default) a combine launch, 1 the last workgroup of the (row, head)
     to arrive inside the split kernel (arrival counter, agent-scope stores), 2 the o projection's workgroups while they stage their activations
-    (gemv_q4_rows_lds_kernel<.., QSRC 3>).  Same arithmetic in all three: the ids must be equal exactly, and every id must be the oracle's
-    arg-max up to the Q8_0 activation-flip bound when the oracle is fed the same history."""
+    (gemv_q4_rows_lds_kernel<.., QSRC 3>) — measured equal, kept as switches.  Same arithmetic in all three: the ids must be equal exactly, and
+    every id must be the oracle's arg-max up to the Q8_0 activation-flip bound when the oracle is fed the same history."""
     model = synth.build_orpheus(synth.orpheus_3b(layers=2, vocab=5001, ctx=256, weight_type=gguf.Q4_0))
     ids = np.random.default_rng(7).integers(0, 5001, 20).astype(np.uint32)
     toks = {}
     for fold in (1, 2, 0):
         eng = hip.OrpheusEngine(model.cfg)
-        eng.tune("attn_fold", fold)
+        eng.tune("llama_merge", fold)
         eng.load(model)
         toks[fold] = eng.generate_greedy(ids, 40, stop_id=model.cfg.vocab + 5).tolist()
         if fold == 1:   # the arrival counters are back at zero after every launch: a second generation on the same context repeats the first
