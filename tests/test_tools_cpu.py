@@ -58,3 +58,45 @@ batched_kernel:                         ; @batched_kernel
                          capture_output=True, text=True, check=True).stdout
     assert "serial_kernel" in out and "batched_kernel" not in out
     assert out.strip().split()[0] == "3"
+
+
+def test_isa_scanner_finds_full_and_partial_waits_between_loads(tmp_path):
+    """profiles/tools/isa_serial_loads.py on hand-written gfx950 assembly: (1) `global_load ... s_waitcnt vmcnt(0) ... global_load` chains count as
+    dependent load groups; (2) mode `partial`: loads, `s_waitcnt vmcnt(k > 0)`, more loads in a kernel's straight-line head is flagged (the shape
+    gemv_stream_kernel's conditional first weight load had until round 4), the same sequence behind a loop back-edge, a barrier or an MFMA is not."""
+    import subprocess, sys
+    asm = tmp_path / "k.s"
+    asm.write_text("""
+chain_kernel: ; @chain_kernel
+	global_load_dword v1, v[2:3], off
+	s_waitcnt vmcnt(0)
+	global_load_dword v4, v[1:2], off
+	s_waitcnt vmcnt(0)
+	global_load_dword v5, v[4:5], off
+	s_waitcnt vmcnt(0)
+	s_endpgm
+head_kernel: ; @head_kernel
+	global_load_dwordx4 v[16:19], v[2:3], off
+	global_load_dwordx4 v[20:23], v[2:3], off offset:64
+	s_waitcnt vmcnt(1)
+	v_mov_b32_e32 v9, v16
+	global_load_dwordx4 v[24:27], v[4:5], off
+	s_waitcnt vmcnt(0)
+	s_barrier
+	s_endpgm
+loop_kernel: ; @loop_kernel
+	global_load_dwordx4 v[16:19], v[2:3], off
+.LBB2_1:
+	global_load_dwordx4 v[20:23], v[2:3], off offset:64
+	s_waitcnt vmcnt(1)
+	v_mfma_f32_16x16x32_f16 a[0:3], v[16:19], v[8:11], a[0:3]
+	global_load_dwordx4 v[16:19], v[2:3], off offset:128
+	s_cbranch_scc1 .LBB2_1
+	s_endpgm
+""")
+    tool = os.path.join(ROOT, "profiles", "tools", "isa_serial_loads.py")
+    full = subprocess.run([sys.executable, tool, str(asm), "2"], capture_output=True, text=True, check=True).stdout
+    assert "3 dependent load groups  chain_kernel" in full and "head_kernel" not in full and "loop_kernel" not in full, full
+    part = subprocess.run([sys.executable, tool, str(asm), "99", "partial"], capture_output=True, text=True, check=True).stdout
+    assert "1 partial waits in the prologue  head_kernel" in part and "loop_kernel" not in part and "chain_kernel" not in part, part
+
