@@ -249,6 +249,20 @@ def test_device_pool_continuous_batching_admits_arrivals_during_a_generation():
     r.close()
 
 
+def test_device_pool_under_concurrent_submitters():
+    """host/pool_stress.c: four threads submit 24 requests each to three workers and wait for them while reading the statistics, once as lock-step
+    batches and once as continuous sessions.  Every request gets its own audio, and the statistics are complete the moment the last wait returns (a
+    continuous session used to book its counters only when it ended: a waiter could read 57 of 96 tasks).  `make -C tts.cpp_amd/host sanitize` runs the
+    same driver with the host library under ThreadSanitizer and AddressSanitizer (clean at the end of round 4; about a minute to build, not part of
+    this suite)."""
+    import subprocess
+    host = os.path.join(ROOT, "tts.cpp_amd", "host")
+    subprocess.run(["make", "-C", host, "pool_stress"], check=True, capture_output=True)
+    p = subprocess.run([os.path.join(host, "pool_stress")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "lock-step: tasks 96" in p.stdout and "continuous: tasks 96" in p.stdout, p.stdout
+
+
 def test_device_pool_conditional_prompt_task():
     """CONDITIONAL_PROMPT (server.cpp:263-271): without --text-encoder-path the task is answered with the reference's
     message; with one, every worker applies it (here the dummy backend refuses, as any non-Parler architecture does)."""

@@ -289,8 +289,22 @@ void device_pool::process_stream(int w, std::vector<std::shared_ptr<pool_task>> 
     size_t ticket = 0;
     uint64_t expired = 0, served = 0, joined = 0, peak = 0;
     const pool_task like = *first[0];
+    // the counters go into the pool's statistics BEFORE the tasks they count are published (as process() does): whoever has waited for the last
+    // request of a run reads complete statistics
+    uint64_t booked_served = 0, booked_expired = 0, booked_joined = 0;
+    bool session_booked = false;
+    auto book = [&] {
+        std::lock_guard<std::mutex> lock(s_mutex_);
+        stats_.tasks += (served - booked_served) + (expired - booked_expired);
+        stats_.timed_out += expired - booked_expired;
+        stats_.admitted_in_flight += joined - booked_joined;
+        stats_.largest_batch = std::max<uint64_t>(stats_.largest_batch, peak);
+        if (!session_booked) { stats_.batches += 1; session_booked = true; }
+        booked_served = served; booked_expired = expired; booked_joined = joined;
+    };
     auto finish = [&](std::vector<std::shared_ptr<pool_task>> & v) {
         if (v.empty()) return;
+        book();
         { std::lock_guard<std::mutex> lock(r_mutex_); for (auto & t : v) completed_[t->id] = t; }
         r_cv_.notify_all();
         v.clear();
@@ -350,14 +364,7 @@ void device_pool::process_stream(int w, std::vector<std::shared_ptr<pool_task>> 
         try { runner.stream_end(); } catch (...) {}
     }
     finish(done);
-    {
-        std::lock_guard<std::mutex> lock(s_mutex_);
-        stats_.tasks += served + expired;
-        stats_.timed_out += expired;
-        stats_.batches += 1;
-        stats_.largest_batch = std::max<uint64_t>(stats_.largest_batch, peak);
-        stats_.admitted_in_flight += joined;
-    }
+    book();
 }
 
 // worker::process_task, the non-TTS cases (server.cpp:263-306)
