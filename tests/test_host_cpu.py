@@ -165,6 +165,19 @@ def test_runner_from_file_fails_loudly_without_gpu(tiny_gguf, have_gpu):
     assert "tts_hip_create failed" in str(e.value)
 
 
+def test_parler_metadata_that_cannot_describe_a_model_is_refused_at_load(tiny_gguf, tmp_path):
+    """read_hparams: zero output heads (a division further down the runner), a hidden size the heads do not divide — refused with the metadata
+    message before anything touches the device (so the check runs without a GPU too)."""
+    m, _ = tiny_gguf
+    for key, bad in (("parler-tts.decoder.output_heads", 0), ("parler-tts.decoder.attention.head_count", 7), ("parler-tts.decoder.num_hidden_layers", 0)):
+        kv = [(k, t, bad if k == key else v) for k, t, v in m.kv]
+        path = str(tmp_path / "bad.gguf")
+        gguf.write(path, kv, m.tensors)
+        with pytest.raises(runner.RunnerError) as e:
+            runner.Runner(path)
+        assert "metadata out of range" in str(e.value), (key, str(e.value))
+
+
 def test_device_pool_queue_batching_and_responses():
     """device_pool (host/device_pool.h ~ examples/server/server.cpp:126-330): tasks pushed from several threads,
     pulled by 2 workers, compatible queued tasks decoded together, responses fetched by id.  Runs on the weightless

@@ -51,6 +51,11 @@ static parler_hparams read_hparams(const gguf_file & m) {
     }
     hp.dac_n_layers = n_found;
     if (up != hp.up_sampling_factor) hp.up_sampling_factor = up;  // non-standard codec: trust the layer strides
+    // a file whose metadata cannot describe a model is refused here, not by a division further down
+    if (hp.n_output_heads == 0 || hp.output_vocab_size == 0 || hp.hidden_size == 0 || hp.n_attn_heads == 0 || hp.hidden_size % hp.n_attn_heads ||
+        hp.n_layers == 0 || hp.max_generation_size < 2 || hp.up_sampling_factor == 0)
+        TTS_ABORT("parler-tts metadata out of range: %u output heads, vocabulary %u, hidden %u over %u heads, %u layers, max_generation %u\n", hp.n_output_heads,
+                  hp.output_vocab_size, hp.hidden_size, hp.n_attn_heads, hp.n_layers, hp.max_generation_size);
     return hp;
 }
 
