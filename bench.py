@@ -18,7 +18,9 @@ are independent, no data-path collective -> "scaling": "weak".
 
 Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit + roofline + cpu_baseline, plus SURVEY §8(d)'s second metric
 (batch-1 ms per decode step at T ~ 128 / 512 / 1024 / 2580, a 1024-step utterance), `long_utterances` (1024 audio steps per utterance,
-uniform and ragged batches) and `secondary` (short runs of BASELINE configs 2-4).
+uniform and ragged batches) and `secondary` (short runs of BASELINE configs 2-4).  The extra sections share a wall-clock budget
+(`--time-budget-s`, default 480 s for the whole run; `time_budget` in the line names what was skipped): with the driver's `--steps 20 --warmup 5`
+the 25 timed steps take ~280 s on their own, and the contract's part must never be lost to an extra.
 """
 import argparse
 import ctypes as C
@@ -28,6 +30,8 @@ import sys
 import tempfile
 import threading
 import time
+
+_T_START = time.perf_counter()   # the wall-clock budget of the extra sections counts from here (the first `import torch` on a fresh box can take a minute)
 
 import numpy as np
 
@@ -418,18 +422,49 @@ def long_sentences(rn, n, lo, hi, seed):
     return out
 
 
-def long_utterances(args, mk, wt, local_rank, gen_cfg, torch, L):
+class TimeBudget:
+    """Wall-clock budget of one bench.py run.  The contract's part — warm-up, the K timed steps, the roofline pass, the CPU baseline — always runs;
+    every EXTRA section (batch-1 sweep, end-to-end harness, secondary configs, the long_utterances parts) runs only while the time already spent plus
+    the section's measured cost (seconds on an MI355X box, end of round 4) stays inside the budget, most valuable first.  The driver's round-end run
+    (`--steps 20 --warmup 5`: 25 steps of ~11.3 s) took 500 s in round 3; with this round's additions it would take ~660 s, so the default budget
+    keeps a whole run near 480 s.  `--time-budget-s 0` = no limit (how profiles/r04/bench_default_3x1024.json was produced)."""
+    COST = {"decode_step_batch1": 25, "generate_batch1_end_to_end": 25, "secondary.kokoro": 25, "secondary.dia": 25, "secondary.orpheus": 35,
+            "long_utterances.uniform": 100, "long_utterances.ragged": 70, "long_utterances.ragged_stream": 100}
+    RESERVED = 30   # the CPU baseline that still has to run after the extras of the main context
+
+    def __init__(self, budget_s):
+        self.budget, self.skipped, self.reserved = float(budget_s), [], 0.0
+
+    def elapsed(self):
+        return time.perf_counter() - _T_START
+
+    def room(self, section):
+        if self.budget <= 0 or self.elapsed() + self.reserved + self.COST[section] <= self.budget:
+            return True
+        self.skipped.append(section)
+        return False
+
+    def report(self):
+        return {"budget_s": self.budget, "elapsed_s": round(self.elapsed(), 1), "skipped": self.skipped,
+                "note": "extra sections run while elapsed + their measured cost fits the budget (--time-budget-s 0: no limit); the timed steps, "
+                        "the roofline and the CPU baseline always run"}
+
+
+def long_utterances(args, mk, wt, local_rank, gen_cfg, torch, L, budget=None):
     """SURVEY §8(d)'s long workload: 1024 audio steps per utterance (11.7 s of audio; the reference's perf_battery sentences average
     10.8 s), the largest 3-runner lock-step batch whose fp32 KV cache fits, then a ragged batch (prompts of 16 .. 784 ids, so that the
     rows stop — reach max_generation — at different steps, 1024 down to 256)."""
     n_steps = args.long_steps
+    if budget is not None and not budget.room("long_utterances.uniform"):
+        budget.skipped += ["long_utterances.ragged", "long_utterances.ragged_stream"]
+        return {"skipped": "time budget (--time-budget-s)"}
     cfg = mk(weight_type=wt, dac_f16=args.dac_wtype == "f16", max_gen=args.prompt_len + n_steps)
     free_b, _ = torch.cuda.mem_get_info(local_rank)
     kv_per_seq = cfg.layers * 2 * (args.prompt_len + n_steps) * cfg.hidden * (2 if args.kv == "f16" else 4)
     frame_elems = max(cfg.latent, cfg.c0, max((cfg.c0 >> (i + 1)) * int(np.prod(cfg.strides[:i + 1])) for i in range(len(cfg.strides))))
     codec = 4 * 64 * (n_steps - cfg.n_out + 1) * frame_elems * 4        # the device's codec buffers: three activation buffers + planes of a 64-utterance pass
-    budget = 0.85 * free_b - codec - 6e9
-    batch = int(min(args.batch, budget // (args.streams * kv_per_seq))) // 32 * 32
+    mem_budget = 0.85 * free_b - codec - 6e9
+    batch = int(min(args.batch, mem_budget // (args.streams * kv_per_seq))) // 32 * 32
     if batch < 32:
         return {"skipped": f"not enough free memory for {args.streams} x 32 sequences of {n_steps} steps ({free_b / 1e9:.0f} GB free)"}
     path = os.path.join(tempfile.gettempdir(), f"tts_bench_long_{os.getpid()}.gguf")
@@ -459,6 +494,10 @@ def long_utterances(args, mk, wt, local_rank, gen_cfg, torch, L):
         if st.get("launches"):
             out["uniform"]["attn_self"] = {"GBps": round(st["bytes_total"] / st["ms_total"] / 1e6, 1), "frac_of_hbm_peak": round(st["bytes_total"] / st["ms_total"] / 1e6 / HBM_PEAK_GBS, 4),
                                            "avg_launch_us": round(st["ms_total"] / st["launches"] * 1e3, 2), "mean_cached_positions": args.prompt_len + n_steps // 2}
+        if budget is not None and not budget.room("long_utterances.ragged"):
+            budget.skipped.append("long_utterances.ragged_stream")   # its ratios are against the two sections before it
+            out["ragged"] = out["ragged_stream"] = {"skipped": "time budget (--time-budget-s)"}
+            return out
         # ragged: prompt lengths spread over 16 .. 784 ids -> rows run 1024 .. 256 steps; a finished row idles at its last position
         hi = args.prompt_len + (3 * n_steps) // 4
         rag = [long_sentences(first, batch, args.prompt_len, hi, 7000 + i) for i in range(args.streams)]
@@ -472,6 +511,9 @@ def long_utterances(args, mk, wt, local_rank, gen_cfg, torch, L):
                          "prompt_ids": [args.prompt_len, hi], "audio_steps_per_utterance": [n_steps - (hi - args.prompt_len), n_steps],
                          "note": "lock-step: the loop runs as long as the longest row; every 32 steps the rows that reached max_generation leave the forward (row compaction, "
                                  "TTS_HIP_GEN_COMPACT=0: they idle instead — 196 against 268 audio-s/s, profiles/r03/compaction_call20.txt)"}
+        if budget is not None and not budget.room("long_utterances.ragged_stream"):
+            out["ragged_stream"] = {"skipped": "time budget (--time-budget-s)"}
+            return out
         # the same length mix as a STREAM of requests, three times the rows a runner holds, through one continuous-batching session per runner
         # (tts_c_generate_stream): a row freed by an utterance that reached max_generation is refilled at the next 32-step look-in point
         n_req = 3 * (batch - 1)
@@ -518,6 +560,8 @@ def main():
     ap.add_argument("--no-long", action="store_true", help="skip the long_utterances section (1024 audio steps, uniform + ragged)")
     ap.add_argument("--no-e2e", action="store_true", help="skip generate_batch1_end_to_end (the reference's perf_battery protocol, one utterance at a time)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE configs 2-4 (secondary)")
+    ap.add_argument("--time-budget-s", type=float, default=480.0,
+                    help="wall-clock budget of the whole run: extra sections are skipped (and named in time_budget.skipped) once they no longer fit; 0 = no limit")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--model", choices=["mini", "small", "tiny"], default="mini")
     ap.add_argument("--workload", choices=["parler", "dia", "orpheus", "kokoro"], default="parler",
@@ -530,6 +574,7 @@ def main():
     ap.add_argument("--wtype", choices=["f16", "f32", "q8_0", "q5_0", "q4_0"], default="f16",
                     help="GGUF type of the decoder matrices (headline: f16; q*: integer path with Q8_0 activations)")
     args = ap.parse_args()
+    budget = TimeBudget(args.time_budget_s)
 
     if args.workload in ("orpheus", "kokoro") and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus > 1):
         raise SystemExit("--workload orpheus / kokoro are single-utterance configurations of BASELINE.json (configs[4] / [2]: 1 x MI355X); run them with --gpus 1")
@@ -719,10 +764,11 @@ def main():
                     "GBps": round(v["bytes_total"] / max(v["ms_total"], 1e-9) / 1e6, 1),
                     "TFLOPs": round(v["flops_total"] / max(v["ms_total"], 1e-9) / 1e9, 3)}
                 for k, v in stats.items() if v["launches"]}
-        if not args.no_step_sweep and args.wtype in ("f16", "f32"):
+        budget.reserved = 0.0 if args.no_cpu_baseline else TimeBudget.RESERVED
+        if not args.no_step_sweep and args.wtype in ("f16", "f32") and budget.room("decode_step_batch1"):
             full_model = synth.build(cfg_full, shapes_only=True)
             out["decode_step_batch1"] = decode_step_sweep(cfg_full, full_model, L.tts_hip_arena_ptr(runners[0].device_context()), local_rank)
-        if not args.no_e2e and args.model == "mini" and not args.sample:
+        if not args.no_e2e and args.model == "mini" and not args.sample and budget.room("generate_batch1_end_to_end"):
             try:
                 out["generate_batch1_end_to_end"] = generate_batch1_end_to_end(path, local_rank)
             except Exception as e:   # the headline must survive a failure of an extra section
@@ -731,27 +777,33 @@ def main():
             threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 32)
             prompt = runners[0].tokenize(all_texts[0][0])
             out["cpu_baseline"] = cpu_baseline(model, cfg, prompt, threads)
+        budget.reserved = 0.0
     for rn in reversed(runners):
         rn.close()
     if rank == 0 and not os.environ.get("TTS_BENCH_KEEP_GGUF"):
         os.unlink(path)
     if rank == 0 and world == 1 and args.model == "mini":
-        if not args.no_long:
-            try:
-                out["long_utterances"] = long_utterances(args, mk, wt, local_rank, gen_cfg, torch, L)
-            except Exception as e:   # the headline must survive a failure of an extra section
-                out["long_utterances"] = {"error": str(e)[:300]}
-        if not args.no_secondary:
+        if not args.no_secondary:   # before the long section: cheaper per line of evidence when the budget is short
             sys.path.insert(0, os.path.join(ROOT, "profiles"))
             import secondary_bench
             sec = {}
             sargs = argparse.Namespace(steps=1, warmup=1, no_cpu_baseline=True, cpu_threads=0)
             for name in ("kokoro", "dia", "orpheus"):
+                if not budget.room("secondary." + name):
+                    sec[name] = {"skipped": "time budget (--time-budget-s)"}
+                    continue
                 try:
                     sec[name] = secondary_bench.RUNNERS[name](sargs)
                 except Exception as e:
                     sec[name] = {"error": str(e)[:300]}
             out["secondary"] = sec
+        if not args.no_long:
+            try:
+                out["long_utterances"] = long_utterances(args, mk, wt, local_rank, gen_cfg, torch, L, budget)
+            except Exception as e:   # the headline must survive a failure of an extra section
+                out["long_utterances"] = {"error": str(e)[:300]}
+    if rank == 0:
+        out["time_budget"] = budget.report()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

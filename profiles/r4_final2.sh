@@ -4,7 +4,7 @@ export HSA_DISABLE_COREDUMP_ON_EXCEPTION=1; ulimit -c 0
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4
 timeout 600 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|^E |^FAILED|rror" | tail -8 > $O/gpu_tests_final2.txt; cat $O/gpu_tests_final2.txt
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 900 python bench.py > $O/bench_default_final2.json 2> $O/bench_default_final2.log
+timeout 900 python bench.py --time-budget-s 0 > $O/bench_default_final2.json 2> $O/bench_default_final2.log
 python - <<'PY'
 import json
 d = json.loads(open('gpurun_out/r4/bench_default_final2.json').read().strip().split('\n')[-1])
