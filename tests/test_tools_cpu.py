@@ -100,3 +100,35 @@ loop_kernel: ; @loop_kernel
     part = subprocess.run([sys.executable, tool, str(asm), "99", "partial"], capture_output=True, text=True, check=True).stdout
     assert "1 partial waits in the prologue  head_kernel" in part and "loop_kernel" not in part and "chain_kernel" not in part, part
 
+
+def test_bench_time_budget_keeps_the_contract_and_drops_extras_in_order():
+    """bench.py's wall-clock budget: with the driver's round-end flags (25 steps of ~11.3 s already spent) the long section no longer fits and is
+    named in `skipped`, the cheaper extras still run and the whole run stays under the budget; with the default flags only `ragged_stream` drops;
+    `--time-budget-s 0` keeps everything."""
+    b = _bench()
+    extras = ["decode_step_batch1", "generate_batch1_end_to_end", "secondary.kokoro", "secondary.dia", "secondary.orpheus",
+              "long_utterances.uniform", "long_utterances.ragged", "long_utterances.ragged_stream"]
+
+    def run(spent, budget_s):
+        tb, now = b.TimeBudget(budget_s), [float(spent)]
+        tb.elapsed = lambda: now[0]
+        tb.reserved = b.TimeBudget.RESERVED          # the CPU baseline still to come while the first two extras are decided
+        ran = []
+        for i, sec in enumerate(extras):
+            if i == 2:
+                now[0] += b.TimeBudget.RESERVED
+                tb.reserved = 0.0
+            if tb.room(sec):
+                ran.append(sec)
+                now[0] += tb.COST[sec]
+        return now[0], ran, tb.skipped
+
+    total, ran, skipped = run(15 + 25 * 11.3 + 15, 480)          # imports + setup, 25 steps, the roofline pass
+    assert total <= 480 and ran == extras[:5] and skipped == extras[5:]
+    total, ran, skipped = run(15 + 4 * 11.3 + 15, 480)           # default flags
+    assert total <= 480 and skipped == ["long_utterances.ragged_stream"]
+    total, ran, skipped = run(15 + 25 * 11.3 + 15, 0)
+    assert ran == extras and skipped == []
+    rep = b.TimeBudget(480).report()
+    assert rep["budget_s"] == 480 and rep["skipped"] == [] and rep["elapsed_s"] >= 0
+
