@@ -259,7 +259,7 @@ struct tts_hip_ctx {
     int dac_convt_planes = 1;   // tune("dac_convt_planes") = 0: the bf16 x 3 transposed convs always stage fp32 input (snake + split per workgroup) instead of the producer's planes
     int dac_convt_b3 = 1;       // tune("dac_convt_b3")=0: the transposed convs stay on the exact-fp32 MFMA kernel
     int dac_fuse = 1;           // tune("dac_fuse")=0: residual units at 96 / 192 channels stay two launches (k = 7 conv, k = 1 conv + residual)
-    int dac_b3 = 2;             // TTS_HIP_DAC_BF16X3 (default 2 since round 3; 0 = exact-fp32 MFMA convs): k = 7 convs of F32 tensors as six bf16 MFMAs per product (conv1d_mfma_b3_kernel); 1 = the layers with 64-channel tiles (measured, tested), 2 = also the 96-channel tile (written after the GPU budget of round 2 was spent: never run)
+    int dac_b3 = 2;             // TTS_HIP_DAC_BF16X3 / tune("dac_exact_fp32") (default 2 since round 3; 0 = exact-fp32 MFMA convs): k = 7 convs of F32 tensors as six bf16 MFMAs per product (conv1d_mfma_b3_kernel); 1 = only the layers with 64-channel tiles, 2 = also the 96-channel tile (both measured and in the parity tests since round 3)
     bool kk_lstm_split = true;  // tune("kokoro_lstm_split")=0: the bidirectional LSTMs through the one-workgroup-per-direction kernel
     char *kk_pool = nullptr;    // Kokoro scratch pool (KScratch): grows to the largest call
     size_t kk_pool_cap = 0, kk_pool_next = 0;
