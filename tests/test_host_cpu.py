@@ -178,6 +178,16 @@ def test_parler_metadata_that_cannot_describe_a_model_is_refused_at_load(tiny_gg
         assert "metadata out of range" in str(e.value), (key, str(e.value))
 
 
+def test_malformed_gguf_files_never_crash_the_reader(have_gpu):
+    """tests/tools/fuzz_gguf.py in a subprocess (a crash must not take the suite down): truncated and bit-flipped model files through
+    tts_c_gguf_summary / tts_c_gguf_tensor / tts_c_runner_from_file — error codes, never a signal."""
+    if have_gpu:
+        pytest.skip("the loader would go on to create device contexts for the files that still parse")
+    import subprocess, sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_gguf.py"), runner.lib_path(), "7", "160"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "no crash" in p.stdout, (p.returncode, p.stdout[-300:], p.stderr[-600:])
+
+
 def test_device_pool_queue_batching_and_responses():
     """device_pool (host/device_pool.h ~ examples/server/server.cpp:126-330): tasks pushed from several threads,
     pulled by 2 workers, compatible queued tasks decoded together, responses fetched by id.  Runs on the weightless
