@@ -188,6 +188,14 @@ def test_malformed_gguf_files_never_crash_the_reader(have_gpu):
     assert p.returncode == 0 and "no crash" in p.stdout, (p.returncode, p.stdout[-300:], p.stderr[-600:])
 
 
+def test_hostile_text_never_crashes_the_tokenizers():
+    """tests/tools/fuzz_tokenizers.py in a subprocess: arbitrary bytes, invalid / truncated UTF-8, long inputs and short output buffers through the
+    unigram, Dia, single-pass and Kokoro chunking entry points of include/tts_c.h."""
+    import subprocess, sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_tokenizers.py"), runner.lib_path(), "5", "120"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "no crash" in p.stdout, (p.returncode, p.stdout[-300:], p.stderr[-600:])
+
+
 def test_device_pool_queue_batching_and_responses():
     """device_pool (host/device_pool.h ~ examples/server/server.cpp:126-330): tasks pushed from several threads,
     pulled by 2 workers, compatible queued tasks decoded together, responses fetched by id.  Runs on the weightless
