@@ -247,7 +247,7 @@ def generate_batch1_end_to_end(path, device):
     env = dict(os.environ, TTS_HIP_DEVICE=str(device), TTS_HIP_MAX_SEQS="1")
     for label, topk in (("top_k_50", 50), ("top_k_1_greedy", 1)):
         t0 = time.perf_counter()
-        r = subprocess.run([exe, "--model-path", path, "--topk", str(topk)], capture_output=True, text=True, timeout=600, env=env)
+        r = subprocess.run([exe, "--model-path", path, "--topk", str(topk)], capture_output=True, text=True, timeout=120, env=env)   # 8 s when healthy: a hang must not eat the run's time budget
         m1 = re.search(r"Generation Time \(ms\):\s+([0-9.]+)", r.stdout)
         m2 = re.search(r"Real Time Factor \(ms\):\s+([0-9.]+)", r.stdout)
         if r.returncode != 0 or not m1 or not m2:
