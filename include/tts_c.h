@@ -106,6 +106,9 @@ void tts_c_pool_set_text_encoder(const char *path);
  * and admits queued requests into rows that free up while the others are still generating (continuous batching), instead of running each
  * batch to its end.  tts_c_pool_admitted_in_flight: how many requests entered a session that way. */
 void     tts_c_pool_set_continuous(int on);
+/* pool_options::continuous_yield_ms for pools created afterwards by this thread (default 2000): a continuous session stops admitting compatible
+ * requests once a request it cannot take (another model, incompatible sampling parameters) has waited this long at the head of the queue */
+void     tts_c_pool_set_continuous_yield_ms(int ms);
 uint64_t tts_c_pool_admitted_in_flight(tts_c_pool *pool);
 int  tts_c_pool_submit(tts_c_pool *pool, const char *text, const tts_c_config *cfg);   /* task id, < 0 on error */
 /* CONDITIONAL_PROMPT task (server.cpp:263-271) fanned out to every worker; wait on the id like any task (no audio:

@@ -47,7 +47,7 @@ m.tensors += [f32("norm", np.ones(H)), q4("lm_head", cfg.vocab, H), f32("rope_fr
 print(f"{sum(len(t.raw()) for t in m.tensors) / 1e9:.2f} GB of tensors minted in {time.perf_counter() - t0:.1f}s", flush=True)
 
 eng = hip.OrpheusEngine(cfg)
-for kv in os.environ.get("ORPHEUS_TUNE", "").split(","):   # e.g. ORPHEUS_TUNE=llama_merge=1
+for kv in os.environ.get("ORPHEUS_TUNE", "").split(","):   # e.g. ORPHEUS_TUNE=attn_split=4
     if "=" in kv:
         eng.tune(kv.split("=")[0], int(kv.split("=")[1]))
 t0 = time.perf_counter()

@@ -802,3 +802,172 @@ def test_generation_graphs_follow_reallocated_outputs_and_sampling_parameters():
         assert np.array_equal(got, fresh(n_steps, sampled)), (n_steps, sampled)
     eng.close()
     assert not np.array_equal(fresh(40, 30), fresh(40, None))
+
+
+# ---- the kernel the roofline is quoted on, at the history it is measured at ----------------------------------------------------
+# bench.py runs attn_rows_kernel<8> at 1024 rows over T = 17 ... 281 cached positions (one slice per row) and `long_utterances` at 320 rows
+# over T <= 1040 (four key slices + attn_combine_kernel).  The many-rows test above only reaches T <= 10.  (parler/model.cpp:543-572)
+HISTORY_CASES = {
+    # rows: [(row, prompt length)]: the compared steps see T = length + 1 and length + 2 keys
+    1024: [(0, 6), (63, 7), (64, 15), (511, 16), (512, 136), (640, 280), (895, 99), (1022, 136), (1023, 280)],   # T = 7, 8, 9, 16, 17, 18, 100, 137, 281, 282
+    320: [(0, 4), (1, 63), (63, 527), (64, 1039), (127, 1039), (128, 527), (255, 62), (319, 3)],                   # T = 4, 5, 63, 64, 65, 528, 529, 1040, 1041
+    256: [(0, 4), (15, 31), (16, 32), (100, 263), (128, 529), (254, 2), (255, 264)],                               # slices of 1, 8, 9 keys; 66 + 66 + 66 + 67
+}
+
+
+@pytest.mark.parametrize("kv", [gguf.F32, gguf.F16])
+@pytest.mark.parametrize("rows", [1024, 320, 256])
+def test_row_major_self_attention_at_measured_history(rows, kv):
+    """attn_rows_kernel (one workgroup per row, whole K / V rows per wave-instruction set; parler_kernels.h) at the cached lengths of the
+    headline (1024 rows, one slice) and of long_utterances (320 rows, four slices + combine), fp32 and fp16 caches: Parler-Mini widths,
+    two layers, a handful of rows with long prompts among short ones, logits of those rows against per-row oracles over two steps.  The
+    prompts' prefill runs through the same kernel (every row at its own position), so the cached rows the steps read were produced by it too."""
+    key = ("mini2", gguf.F16)
+    if key not in _models:
+        _models[key] = synth.build(synth.parler_mini(layers=2, weight_type=gguf.F16))
+    model = _models[key]
+    cfg = model.cfg
+    tol = TOL[gguf.F16] if kv == gguf.F32 else 1e-2
+    cases = dict(HISTORY_CASES[rows])
+    cap = max(cases.values()) + 8
+    eng = hip.HipEngine(cfg, max_seqs=rows, kv_type=kv, kv_positions=cap)
+    eng.load(model)
+    rng = np.random.default_rng(rows + kv)
+    prompts = [rng.integers(3, cfg.prompt_vocab, cases.get(i, 3 + (i % 4))).astype(np.uint32) for i in range(rows)]
+    eng.prefill_batch(prompts)
+    oracles = {}
+    for r in cases:
+        o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+        o.decode(prompts[r], 0, audio=False, want_logits=False)
+        oracles[r] = o
+    ids = np.full((rows, cfg.n_out), cfg.bos, dtype=np.uint32)
+    worst = {}
+    for step in range(2):
+        lg = eng.step(ids, [len(p) + step for p in prompts])
+        assert np.isfinite(lg).all()
+        nxt = lg.argmax(-1).astype(np.uint32)
+        for r in cases:
+            ref, _ = oracles[r].decode(ids[r], len(prompts[r]) + step, audio=True)
+            nxt[r] = ref[:, 0, :].argmax(-1)   # the oracle's token keeps both sides on one trajectory
+            e = relerr(lg[r], ref[:, 0, :])
+            worst[len(prompts[r]) + step + 1] = max(e, worst.get(len(prompts[r]) + step + 1, 0.0))
+            assert e < tol, (rows, r, step, len(prompts[r]), e)
+            if kv == gguf.F32:
+                check_tokens(lg[r], ref[:, 0, :], tol)
+        ids = nxt
+    print(f"rows={rows} kv={'f16' if kv == gguf.F16 else 'f32'}: relative logit error by cached length " +
+          ", ".join(f"T={t}: {e:.1e}" for t, e in sorted(worst.items())))
+    eng.close()
+
+
+def test_row_major_self_attention_is_the_kernel_under_test(monkeypatch):
+    """The dispatch takes attn_rows_kernel from 256 rows on (run_attn, shim_decoder.hip): with it switched off the same forward sums its
+    scores in another order, so the two logit sets agree to rounding but not bit for bit — if they were identical the test above would be
+    exercising the one-(head, row) kernel without saying so."""
+    key = ("mini2", gguf.F16)
+    if key not in _models:
+        _models[key] = synth.build(synth.parler_mini(layers=2, weight_type=gguf.F16))
+    model = _models[key]
+    cfg = model.cfg
+    rows = 256
+    rng = np.random.default_rng(77)
+    prompts = [rng.integers(3, cfg.prompt_vocab, 40 + (i % 9)).astype(np.uint32) for i in range(rows)]
+    out = []
+    for sw in (None, "0"):
+        if sw is None:
+            monkeypatch.delenv("TTS_HIP_ATTN_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("TTS_HIP_ATTN_ROWS", sw)
+        eng = hip.HipEngine(cfg, max_seqs=rows, kv_positions=64)
+        eng.load(model)
+        eng.prefill_batch(prompts)
+        out.append(eng.step(np.full((rows, cfg.n_out), cfg.bos, dtype=np.uint32), [len(p) for p in prompts]))
+        eng.close()
+    assert relerr(out[0], out[1]) < 1e-3
+    assert not np.array_equal(out[0], out[1]), "TTS_HIP_ATTN_ROWS made no difference: which attention kernel ran?"
+
+
+@pytest.mark.parametrize("sampled", [False, True])
+def test_row_compaction_with_the_row_major_attention(sampled, monkeypatch):
+    """The compaction test above pins the self-attention to the one-(head, row) kernel to demand bit-equal streams.  Here the dispatch is
+    left alone: 400 utterances start in the row-major kernel (four key slices + combine), are compacted every 32 steps and drop below 256
+    live rows, where the other kernel takes over — a run that keeps finished rows idling never switches.  The two kernels sum in different
+    orders, so streams may part at a near-tie; a bookkeeping error (a row reading another utterance's cache after the gather) would part
+    nearly all of them at once.  Band: every utterance stops at the same step, and at least 90 % of the streams are identical."""
+    monkeypatch.setenv("TTS_HIP_TILE_FORCE", "3")
+    monkeypatch.setenv("TTS_HIP_TILE_KS", "1")
+    monkeypatch.delenv("TTS_HIP_ATTN_ROWS", raising=False)
+    cfg = synth.small(weight_type=gguf.F16, ctx=80, max_gen=80)
+    model = synth.build(cfg)
+    rng = np.random.default_rng(12)
+    n, cap = 400, 80
+    lens = rng.integers(4, 61, n)
+    prompts = [rng.integers(3, cfg.prompt_vocab, int(l)).astype(np.uint32) for l in lens]
+    n_steps = int(cap - lens.min())
+    uni = rng.random((n_steps, n, cfg.n_out), dtype=np.float32)
+    res = []
+    for compact in ("1", "0"):
+        monkeypatch.setenv("TTS_HIP_GEN_COMPACT", compact)
+        eng = hip.HipEngine(cfg, max_seqs=n, kv_positions=cap, flags=hip.FLAG_NO_DAC)
+        eng.load(model)
+        eng.prefill_batch(prompts)
+        if sampled:
+            res.append(eng.generate_sampled(lens, n_steps, uni, top_k=20, temperature=0.9, repetition_penalty=1.1))
+        else:
+            res.append(eng.generate_greedy(lens, n_steps))
+        eng.close()
+    (ta, da), (tb, db) = res
+    assert np.array_equal(da, db)
+    same = 0
+    for u in range(n):
+        k = int(da[u]) if da[u] else n_steps
+        same += bool(np.array_equal(ta[:k, u], tb[:k, u]))
+    print(f"{same} of {n} streams identical with the attention kernel changing under compaction")
+    assert same >= int(0.9 * n), same
+
+
+def test_utterance_admitted_mid_flight_with_the_row_major_attention(monkeypatch):
+    """Continuous batching with the self-attention dispatch left alone: 600 utterances through 300 rows (row-major kernel, four slices)
+    against one lock-step generation of all 600 (same kernel, other row count and neighbours).  Same band as above."""
+    monkeypatch.setenv("TTS_HIP_TILE_FORCE", "3")
+    monkeypatch.setenv("TTS_HIP_TILE_KS", "1")
+    monkeypatch.delenv("TTS_HIP_ATTN_ROWS", raising=False)
+    cfg = synth.small(weight_type=gguf.F16, ctx=80, max_gen=80)
+    model = synth.build(cfg)
+    rng = np.random.default_rng(24)
+    n, cap, slots = 600, 80, 300
+    lens = rng.integers(4, 61, n)
+    prompts = [rng.integers(3, cfg.prompt_vocab, int(l)).astype(np.uint32) for l in lens]
+    n_steps = int(cap - lens.min())
+    ref = hip.HipEngine(cfg, max_seqs=n, kv_positions=cap, flags=hip.FLAG_NO_DAC)
+    ref.load(model)
+    ref.prefill_batch(prompts)
+    rt, rd = ref.generate_greedy(lens, n_steps)
+    ref.close()
+    eng = hip.HipEngine(cfg, max_seqs=slots + 1, kv_positions=cap, flags=hip.FLAG_NO_DAC)
+    eng.load(model)
+    eng.stream_begin(slots, cap - 1)
+    waiting, slot_utt, free, got, rounds = list(range(n)), {}, list(range(slots)), {}, 0
+    while waiting or slot_utt:
+        take = waiting[:len(free)]
+        if take:
+            waiting = waiting[len(take):]
+            sl = [free.pop(0) for _ in take]
+            eng.stream_admit(sl, [prompts[k] for k in take], None)
+            slot_utt.update(dict(zip(sl, take)))
+        for slot, steps in eng.stream_run(32):
+            k = slot_utt.pop(slot)
+            got[k] = (steps, eng.stream_collect(slot, steps))
+            free.append(slot)
+        rounds += 1
+        assert rounds < 200
+    eng.stream_end()
+    eng.close()
+    same = 0
+    for k in range(n):
+        want = int(rd[k]) if rd[k] else n_steps
+        steps, toks = got[k]
+        assert steps == want == cap - lens[k], (k, steps, want)
+        same += bool(np.array_equal(toks, rt[:want, k]))
+    print(f"{same} of {n} streams identical")
+    assert same >= int(0.9 * n), same

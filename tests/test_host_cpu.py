@@ -280,6 +280,50 @@ def test_device_pool_continuous_batching_admits_arrivals_during_a_generation():
     r.close()
 
 
+def test_device_pool_continuous_session_that_cannot_open_answers_every_request():
+    """stream_begin() throws in the worker (a real runner refuses a cross-attention mismatch, a host-only sampler or a failed device
+    allocation there).  The first batch was in none of the lists the handler failed, so wait(id) never returned.  Every request of the batch
+    must come back with the message, and the pool must keep serving."""
+    pool = runner.Pool("test:dummy", n_workers=1, max_batch=4, continuous=True)
+    bad = [pool.submit("abc", voice=b"test:stream_begin-fails") for _ in range(3)]
+    for i in bad:
+        audio, bs, wk, err = pool.wait(i, 20000)
+        assert audio.size == 0 and "test:stream_begin-fails" in err, err
+    good = pool.submit("de")
+    audio, bs, wk, err = pool.wait(good, 20000)
+    assert err == "" and audio.size == 2 * 44100
+    assert pool.stats()["tasks"] == 4
+    pool.close()
+
+
+def test_device_pool_continuous_session_yields_to_an_older_incompatible_request():
+    """a continuous session admitted compatible requests from anywhere in the queue for as long as they kept coming; a request with
+    other sampling parameters (or another model) waited without bound.  With continuous_yield_ms the session stops admitting once such a request
+    has waited that long at the head of the queue, drains, and the next session serves it: it must come back before the compatible requests
+    that were submitted after the bound had passed."""
+    import time
+    pool = runner.Pool("test:dummy", n_workers=1, max_batch=4, continuous=True, continuous_yield_ms=100)
+    first = [pool.submit("a" * 20) for _ in range(2)]          # 0.2 s of generation each
+    time.sleep(0.03)
+    other = pool.submit("zz", top_k=7)                          # incompatible with the running session
+    later = []
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.6:                       # a steady stream of compatible requests
+        later.append((time.perf_counter() - t0, pool.submit("b" * 10)))
+        time.sleep(0.02)
+    audio, bs, wk, err = pool.wait(other, 20000)
+    t_other = time.perf_counter() - t0
+    assert err == "" and audio.size == 2 * 44100
+    done_late = [pool.wait(i, 20000) for _, i in later]
+    t_all = time.perf_counter() - t0
+    assert all(e == "" for _, _, _, e in done_late)
+    assert t_other < t_all - 0.1, (t_other, t_all)              # served before the stream behind it had drained
+    assert pool.stats()["batches"] >= 3                         # the session ended for it, and another one followed
+    for i in first:
+        pool.wait(i, 20000)
+    pool.close()
+
+
 def test_device_pool_under_concurrent_submitters():
     """host/pool_stress.c: four threads submit 24 requests each to three workers and wait for them while reading the statistics, once as lock-step
     batches and once as continuous sessions.  Every request gets its own audio, and the statistics are complete the moment the last wait returns (a

@@ -242,107 +242,88 @@ __device__ __forceinline__ void q4_frag_dot(const Q4Frag<NF, NP> &fr, const int8
 // QSRC 1: the activations arrive as fp32 rows (a.A, lda == K) and are Q8_0-quantised while they are staged — ggml's quantize_row_q8_0_ref
 // arithmetic, identical to quant_rows_q8_kernel / q8_block_store (d = amax / 127 kept as fp16, q = roundf(x / d)) — one 32-value block per
 // thread and pass; saves the producer a separate quantisation (the silu * up product of gemv_q4_gateup_silu_kernel feeds the down projection).
-// QSRC 3: the activations are the attention output of a split decode step (attn_gqa_split_kernel, Q4_FOLD_NZ key slices per (row, head)): the
-// workgroup merges the slices while it stages — attn_gqa_combine_kernel's arithmetic to the letter (running max over the slices in order,
-// o = sum f_z o_z, l = sum f_z l_z with f_z = expf(m_z - m), o / l) and q8_block_store's quantisation — eight values per thread, a 32-value
-// block per lane quad.  The o projection of a Llama step then needs no combine launch in front of it; every workgroup reads the 100 KB of
-// partials of a row from L2 instead (its weight loads are already in flight).
-#define Q4_FOLD_NZ ATTN_FOLD_NZ
+//
+// Order of the requests (round 5).  vmcnt retires in issue order: a wave that requests its streamed weights first and its staging inputs second
+// cannot touch the inputs before the weights have landed — the staging prologue the weights were meant to fly under started one HBM round trip
+// late in every kernel of the one-sequence chains (profiles/tools/isa_wait_order.py lists them; profiles/r05/isa_wait_order_before.txt).  So: the
+// first pass of staging inputs (L2 hits, a few hundred bytes per lane) is requested FIRST, the weights right behind it, and a pass loop only
+// handles what is left (nothing at the Orpheus / Dia shapes).
+struct StageQ8 {      // QSRC 0: item tid of the Q8_0 rows (16 codes) and of their block scales
+    int4v a0;
+    float d0;
+};
+__device__ __forceinline__ void stage_q8_load(StageQ8 &st, const QGemmArgs &qa, int R, int K, int nb, int tid) {
+    st.a0 = ((const int4v *) qa.aq)[min(tid, R * (K >> 4) - 1)];
+    st.d0 = qa.ad[min(tid, R * nb - 1)];
+}
+__device__ __forceinline__ void stage_q8_store(const StageQ8 &st, const QGemmArgs &qa, int R, int K, int nb, int tid, int8_t *sx, float *sd) {
+    if (tid < R * (K >> 4)) ((int4v *) sx)[tid] = st.a0;
+    if (tid < R * nb) sd[tid] = st.d0;
+    for (int i = tid + 256; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
+    for (int i = tid + 256; i < R * nb; i += 256) sd[i] = qa.ad[i];
+    __syncthreads();
+}
+struct StageF32 {     // QSRC 1: block item tid of the fp32 rows (32 values)
+    float4v v[8];
+};
+__device__ __forceinline__ void stage_f32_load(StageF32 &st, const GemmArgs &a, int nb, int item) {
+    const int r = item / nb, b = item - r * nb;
+    const float4v *src = (const float4v *) ((const float *) a.A + (int64_t) r * a.lda + b * 32);
+#pragma unroll
+    for (int j = 0; j < 8; j++) st.v[j] = src[j];
+}
+__device__ __forceinline__ void stage_f32_quant(const StageF32 &st, int K, int nb, int item, int8_t *sx, float *sd) {
+    const int r = item / nb, b = item - r * nb;
+    float amax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) amax = fmaxf(amax, fabsf(st.v[j][e]));
+    const float dd = amax / 127.0f;
+    const float id = dd ? 1.0f / dd : 0.0f;
+    int4v q[2];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        unsigned pk = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) pk |= ((unsigned) (int) (int8_t) roundf(st.v[j][e] * id) & 0xFFu) << (8 * e);
+        q[j >> 2][j & 3] = (int) pk;
+    }
+    *(int4v *) (sx + (size_t) r * K + b * 32) = q[0];
+    *(int4v *) (sx + (size_t) r * K + b * 32 + 16) = q[1];
+    sd[item] = (float) (_Float16) dd;
+}
 template <int NR, int FPW, int QSRC = 0, int NP = 2>
 __global__ __launch_bounds__(256) void gemv_q4_rows_lds_kernel(QGemmArgs qa, const uint8_t *w4, int epi) {
     extern __shared__ __attribute__((aligned(16))) char gq_sm[];
     const GemmArgs &a = qa.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, nb = K >> 5, R = a.R;
-    // this wave's weights first: the loads fly while the workgroup stages (and quantises) the activation rows
+    // the workgroup's staging inputs first (see above), this wave's weights right behind them
+    StageQ8 s8;
+    StageF32 s32;
+    if (QSRC == 0) stage_q8_load(s8, qa, R, K, nb, tid);
+    else stage_f32_load(s32, a, nb, min(tid, R * nb - 1));
+    __builtin_amdgcn_sched_barrier(0);
     const int n0 = ((int) blockIdx.x * 4 + wave) * FPW;
     int nf[FPW];
 #pragma unroll
     for (int f = 0; f < FPW; f++) nf[f] = min(n0 + f, a.N - 1);
     Q4Frag<FPW, NP> fr;
     q4_frag_load<FPW, NP>(fr, w4, qa.wd, nf, K, nb, 0, lane);
+    __builtin_amdgcn_sched_barrier(0);
     int8_t *sx = (int8_t *) gq_sm;                       // [R][K]
     float *sd = (float *) (gq_sm + (size_t) R * K);      // [R][nb]
     if (QSRC == 0) {
-        for (int i = tid; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
-        for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
-    } else if (QSRC == 3) {
-        for (int i = tid; i < R * nb * 4; i += 256) {   // a multiple of 4 items: the four lanes of a quad are in or out together
-            const int blk = i >> 2, qt = i & 3;
-            const int r = blk / nb, b = blk - r * nb;
-            const float *p = qa.parts + ((int64_t) r * (K >> 7) + (b >> 2)) * Q4_FOLD_NZ * ATTN_PART;
-            const int t0 = (b & 3) * 32 + qt * 8;
-            float2v ml[Q4_FOLD_NZ], v[Q4_FOLD_NZ][4];
-#pragma unroll
-            for (int z = 0; z < Q4_FOLD_NZ; z++) {
-                ml[z] = *(const float2v *) (p + z * ATTN_PART);
-#pragma unroll
-                for (int j = 0; j < 4; j++) v[z][j] = *(const float2v *) (p + z * ATTN_PART + 2 + t0 + 2 * j);
-            }
-            __builtin_amdgcn_sched_barrier(0);   // every slice requested before the first is used (the scheduler otherwise sinks half of the loads between the exps)
-            float m = -INFINITY;
-#pragma unroll
-            for (int z = 0; z < Q4_FOLD_NZ; z++) m = fmaxf(m, ml[z][0]);
-            float o[8], l = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 8; e++) o[e] = 0.0f;
-#pragma unroll
-            for (int z = 0; z < Q4_FOLD_NZ; z++) {
-                // an empty slice left only (max = -inf, sum = 0) behind: it adds + 0 (selects, not a branch: a branch would pull the slice's loads
-                // into its block and make them a round trip of their own)
-                const float mz = ml[z][0];
-                const bool live = mz != -INFINITY;
-                const float f = live ? expf(mz - m) : 0.0f;
-#pragma unroll
-                for (int e = 0; e < 8; e++) o[e] += f * (live ? v[z][e >> 1][e & 1] : 0.0f);
-                l += f * ml[z][1];
-            }
-            float amax = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 8; e++) { o[e] = o[e] / l; amax = fmaxf(amax, fabsf(o[e])); }
-            amax = fmaxf(amax, __shfl_xor(amax, 1));
-            amax = fmaxf(amax, __shfl_xor(amax, 2));
-            const float dd = amax / 127.0f;
-            const float id = dd ? 1.0f / dd : 0.0f;
-            int2v q;
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                unsigned pk = 0;
-#pragma unroll
-                for (int e = 0; e < 4; e++) pk |= ((unsigned) (int) (int8_t) roundf(o[4 * j + e] * id) & 0xFFu) << (8 * e);
-                q[j] = (int) pk;
-            }
-            *(int2v *) (sx + (size_t) r * K + b * 32 + qt * 8) = q;
-            if (qt == 0) sd[blk] = (float) (_Float16) dd;
-        }
+        stage_q8_store(s8, qa, R, K, nb, tid, sx, sd);
     } else {
-        for (int i = tid; i < R * nb; i += 256) {
-            const int r = i / nb, b = i - r * nb;
-            const float4v *src = (const float4v *) ((const float *) a.A + (int64_t) r * a.lda + b * 32);
-            float4v v[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = src[j];
-            float amax = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) amax = fmaxf(amax, fabsf(v[j][e]));
-            const float dd = amax / 127.0f;
-            const float id = dd ? 1.0f / dd : 0.0f;
-            int4v q[2];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                unsigned pk = 0;
-#pragma unroll
-                for (int e = 0; e < 4; e++) pk |= ((unsigned) (int) (int8_t) roundf(v[j][e] * id) & 0xFFu) << (8 * e);
-                q[j >> 2][j & 3] = (int) pk;
-            }
-            *(int4v *) (sx + (size_t) r * K + b * 32) = q[0];
-            *(int4v *) (sx + (size_t) r * K + b * 32 + 16) = q[1];
-            sd[i] = (float) (_Float16) dd;
+        if (tid < R * nb) stage_f32_quant(s32, K, nb, tid, sx, sd);
+        for (int i = tid + 256; i < R * nb; i += 256) {
+            stage_f32_load(s32, a, nb, i);
+            stage_f32_quant(s32, K, nb, i, sx, sd);
         }
+        __syncthreads();
     }
-    __syncthreads();
     float acc[FPW][NR];
 #pragma unroll
     for (int f = 0; f < FPW; f++)
@@ -386,33 +367,43 @@ struct RmsSrc {
     const float *w;   // [H]
     float eps;
 };
-__device__ __forceinline__ void stage_rms_q8(const RmsSrc &rs, int R, int H, int8_t *sx, float *sd, float *red) {
+struct RmsRow {       // a thread's 16 elements of one residual row and of the norm weight (element tid + 256 k)
+    float v[16], wv[16];
+};
+// straight-line loads with clamped indices (a chunk beyond the row re-reads its last element and is never used): under `if (i < H)` every
+// chunk was its own basic block with a full s_waitcnt in front — 12 dependent L2 round trips for a 3072-wide row, most of this prologue
+__device__ __forceinline__ void rms_row_load(RmsRow &row, const RmsSrc &rs, int r, int H, int tid) {
+    const float *xr = rs.x + (int64_t) r * H;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int i = min(tid + k * 256, H - 1);
+        row.v[k] = xr[i]; row.wv[k] = rs.w[i];
+    }
+}
+__device__ __forceinline__ void rms_row_stage(const RmsRow &row, const RmsSrc &rs, int r, int H, int8_t *sx, float *sd, float *red, int tid) {
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (tid + k * 256 < H) s += row.v[k] * row.v[k];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    const float scale = 1.0f / sqrtf(s / (float) H + rs.eps);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int i = tid + k * 256;
+        if (i < H) q8_block_store(row.v[k] * scale * row.wv[k], (int64_t) r * H + i, sx, sd);
+    }
+    __syncthreads();   // red is reused by the next row; the blocks are visible
+}
+// row 0 was requested before the weights (`first`); further rows (R <= 4) are requested here, behind them
+__device__ __forceinline__ void stage_rms_q8(RmsRow &first, const RmsSrc &rs, int R, int H, int8_t *sx, float *sd, float *red) {
     const int tid = threadIdx.x;
-    for (int r = 0; r < R; r++) {
-        const float *xr = rs.x + (int64_t) r * H;
-        // straight-line loads with clamped indices (a chunk beyond the row re-reads its last element and is never used): under `if (i < H)` every
-        // chunk was its own basic block with a full s_waitcnt in front — 12 dependent L2 round trips for a 3072-wide row, most of this prologue
-        float v[16], wv[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int i = min(tid + k * 256, H - 1);
-            v[k] = xr[i]; wv[k] = rs.w[i];
-        }
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            if (tid + k * 256 < H) s += v[k] * v[k];
-        s = wave_sum(s);
-        if ((tid & 63) == 0) red[tid >> 6] = s;
-        __syncthreads();
-        s = (red[0] + red[1]) + (red[2] + red[3]);
-        const float scale = 1.0f / sqrtf(s / (float) H + rs.eps);
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int i = tid + k * 256;
-            if (i < H) q8_block_store(v[k] * scale * wv[k], (int64_t) r * H + i, sx, sd);
-        }
-        __syncthreads();   // red is reused by the next row; the blocks are visible
+    rms_row_stage(first, rs, 0, H, sx, sd, red, tid);
+    for (int r = 1; r < R; r++) {
+        rms_row_load(first, rs, r, H, tid);
+        rms_row_stage(first, rs, r, H, sx, sd, red, tid);
     }
 }
 
@@ -429,22 +420,42 @@ __global__ __launch_bounds__(256) void gemv_q4_qkv_rope_kernel(QGemmArgs qa, con
     const GemmArgs &a = qa.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, nb = K >> 5, R = a.R;
-    // this wave's weights first (rotation pair p = features i and i + 64 of one head): the loads fly under the rms norm
+    // rotation pair p = features i and i + 64 of one head
     const int p = (int) blockIdx.x * 4 + wave;
     const bool active = p * 2 < a.N;
     const int pc = active ? p : 0;
     const int head = pc >> 6, i = pc & 63;
     const int nf[2] = {head * 128 + i, head * 128 + i + 64};
+    // requests in the order their consumers run (vmcnt retires in issue order, see gemv_q4_rows_lds_kernel): the staging inputs and what the
+    // epilogue needs (positions, frequency factor: they were a round trip of their own after the wave sums) first, the weights behind them
+    RmsRow row;
+    StageQ8 s8;
+    if (QSRC == 2) rms_row_load(row, rs, 0, K, tid);
+    else stage_q8_load(s8, qa, R, K, nb, tid);
+    uint32_t ps[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) ps[r] = re.pos[min(r, R - 1)];
+    const float ffi = re.ff ? re.ff[i] : 1.0f;
+    __builtin_amdgcn_sched_barrier(0);
     Q4Frag<2, NP> fr;
     q4_frag_load<2, NP>(fr, w4, qa.wd, nf, K, nb, 0, lane);
+    __builtin_amdgcn_sched_barrier(0);
     int8_t *sx = (int8_t *) gq_sm;
     float *sd = (float *) (gq_sm + (size_t) R * K);
-    if (QSRC == 2) {
-        stage_rms_q8(rs, R, K, sx, sd, sd + (size_t) R * nb);
-    } else {
-        for (int i = tid; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
-        for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
-        __syncthreads();
+    if (QSRC == 2) stage_rms_q8(row, rs, R, K, sx, sd, sd + (size_t) R * nb);
+    else stage_q8_store(s8, qa, R, K, nb, tid, sx, sd);
+    // the rotation of this wave's pair (llama_rope_kv_kernel's arithmetic: iterated theta, cosf / sinf), computed while the weights are in flight
+    float cs[NR], sn[NR];
+    if (head < re.NH + re.NKV) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            if (r < R) {
+                float theta = (float) ps[r];
+                for (int j = 0; j < i; j++) theta *= re.theta_scale;
+                const float ang = theta / ffi;
+                cs[r] = cosf(ang); sn[r] = sinf(ang);
+            }
+        }
     }
     float acc[2][NR];
 #pragma unroll
@@ -463,22 +474,17 @@ __global__ __launch_bounds__(256) void gemv_q4_qkv_rope_kernel(QGemmArgs qa, con
         if (r < R) {
             const float x0 = wave_sum(acc[0][r]), x1 = wave_sum(acc[1][r]);
             if (lane == 0) {
-                const uint32_t ps = re.pos[r];
                 if (head < re.NH + re.NKV) {
-                    float theta = (float) ps;
-                    for (int j = 0; j < i; j++) theta *= re.theta_scale;
-                    const float ang = theta / (re.ff ? re.ff[i] : 1.0f);
-                    const float cs = cosf(ang), sn = sinf(ang);
-                    const float y0 = x0 * cs - x1 * sn, y1 = x0 * sn + x1 * cs;
+                    const float y0 = x0 * cs[r] - x1 * sn[r], y1 = x0 * sn[r] + x1 * cs[r];
                     if (head < re.NH) {
                         float *o = a.out + (int64_t) r * a.ldo + nf[0];
                         o[0] = y0; o[64] = y1;
                     } else {
-                        float *kc = re.kcache + (int64_t) ps * kvH + (head - re.NH) * 128 + i;
+                        float *kc = re.kcache + (int64_t) ps[r] * kvH + (head - re.NH) * 128 + i;
                         kc[0] = y0; kc[64] = y1;
                     }
                 } else {
-                    float *vd = re.vcache + (int64_t) ps * kvH + (head - re.NH - re.NKV) * 128 + i;
+                    float *vd = re.vcache + (int64_t) ps[r] * kvH + (head - re.NH - re.NKV) * 128 + i;
                     vd[0] = x0; vd[64] = x1;
                 }
             }
@@ -510,16 +516,18 @@ __global__ __launch_bounds__(256) void gemv_q4_gateup_silu_kernel(QGemmArgs qa, 
     int nfa[4], nfb[4];
     Q4Frag<4, NP> fa, fb;
     rows_of(min(item, n_items - 1), nfa);
+    // the staging inputs first, the first item's weights behind them (vmcnt retires in issue order, see gemv_q4_rows_lds_kernel)
+    RmsRow row;
+    StageQ8 s8;
+    if (QSRC == 2) rms_row_load(row, rs, 0, K, tid);
+    else stage_q8_load(s8, qa, R, K, nb, tid);
+    __builtin_amdgcn_sched_barrier(0);
     q4_frag_load<4, NP>(fa, w4, qa.wd, nfa, K, nb, 0, lane);
+    __builtin_amdgcn_sched_barrier(0);
     int8_t *sx = (int8_t *) gq_sm;
     float *sd = (float *) (gq_sm + (size_t) R * K);
-    if (QSRC == 2) {
-        stage_rms_q8(rs, R, K, sx, sd, sd + (size_t) R * nb);
-    } else {
-        for (int i = tid; i < R * (K >> 4); i += 256) ((int4v *) sx)[i] = ((const int4v *) qa.aq)[i];
-        for (int i = tid; i < R * nb; i += 256) sd[i] = qa.ad[i];
-        __syncthreads();
-    }
+    if (QSRC == 2) stage_rms_q8(row, rs, R, K, sx, sd, sd + (size_t) R * nb);
+    else stage_q8_store(s8, qa, R, K, nb, tid, sx, sd);
     auto finish = [&](Q4Frag<4, NP> &fr, const int (&nf)[4], int it) __attribute__((always_inline)) {
         float acc[4][NR];
 #pragma unroll

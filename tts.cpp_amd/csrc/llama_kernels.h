@@ -328,12 +328,10 @@ __global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld,
 template <int HD>
 __global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, int ld, const uint32_t *pos, const float *kcache, const float *vcache, int NH, int NKV,
                                                              float scale, float *part, const uint32_t *kbeg, const uint32_t *kend, const uint32_t *row_seq,
-                                                             int64_t seq_stride, QPre qp = QPre{}, uint32_t *counters = nullptr, float *out = nullptr,
-                                                             int8_t *aq = nullptr, float *ad = nullptr) {
+                                                             int64_t seq_stride, QPre qp = QPre{}) {
     static_assert(HD == 128, "lane mapping below is written for head_dim 128");
     __shared__ float red[8];
     __shared__ float4 accs[8][HD / 4];
-    __shared__ uint32_t s_last;
     float *qs = attn_gqa_sm, *ps = attn_gqa_sm + HD;
     const int h = blockIdx.x, r = blockIdx.y, z = blockIdx.z, nz = gridDim.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kb = kbeg ? (int) kbeg[r] : 0;
@@ -342,77 +340,58 @@ __global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, i
     const int k0 = kb + z * chunk;
     const int T = max(0, min(chunk, Tall - z * chunk));
     float *pz = part + (((int64_t) r * NH + h) * nz + z) * ATTN_PART;
-    // counters != nullptr: the partial is read inside this launch by the last workgroup of the (row, head) to arrive, on another CU / XCD (L2 is
-    // per XCD): agent-scope atomic stores, as in attn_kernel's fused combine (parler_kernels.h)
-    const bool fused = counters != nullptr;
     if (T <= 0) {
-        if (tid == 0) {
-            if (fused) {
-                __hip_atomic_store(pz, -INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pz + 1, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else { pz[0] = -INFINITY; pz[1] = 0.0f; }
-        }
-        if (!fused) return;
-    } else {
-        const int kvH = NKV * HD, kh = h / (NH / NKV);
-        if (row_seq) { kcache += (int64_t) row_seq[r] * seq_stride; vcache += (int64_t) row_seq[r] * seq_stride; }
-        kcache += (int64_t) k0 * kvH;
-        vcache += (int64_t) k0 * kvH;
-        float4 vfirst[8];                                    // the value rows of the first 64 keys do not depend on the scores: requested up front
-        attn_v_batch<HD>(vfirst, vcache + kh * HD, kvH, T, 0, tid);
-        attn_load_q<HD>(qs, qkv + (int64_t) r * ld + h * HD, r, qp, tid);
-        attn_scores_batched<HD>(kcache + kh * HD, kvH, T, qs, scale, ps, tid);
-        __syncthreads();
-        float mx = -INFINITY;
-        for (int j = tid; j < T; j += 256) mx = fmaxf(mx, ps[j]);
-        mx = wave_max(mx);
-        if (lane == 0) red[wave] = mx;
-        __syncthreads();
-        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        float sum = 0.0f;
-        for (int j = tid; j < T; j += 256) {
-            const float p = expf(ps[j] - mx);
-            ps[j] = p;
-            sum += p;
-        }
-        sum = wave_sum(sum);
-        if (lane == 0) red[4 + wave] = sum;
-        __syncthreads();
-        accs[tid >> 5][tid & 31] = attn_pv_batched<HD>(vfirst, vcache + kh * HD, kvH, T, ps, tid);
-        __syncthreads();
-        if (tid < HD) {
-            const float *a = (const float *) &accs[0][0];
-            float o = 0.0f;
-#pragma unroll
-            for (int g = 0; g < 8; g++) o += a[g * HD + tid];
-            if (fused) __hip_atomic_store(pz + 2 + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else pz[2 + tid] = o;
-        }
-        if (tid == 0) {
-            const float l = (red[4] + red[5]) + (red[6] + red[7]);
-            if (fused) {
-                __hip_atomic_store(pz, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pz + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else { pz[0] = mx; pz[1] = l; }
-        }
-        if (!fused) return;
+        if (tid == 0) { pz[0] = -INFINITY; pz[1] = 0.0f; }
+        return;
     }
-    // the last workgroup of this (row, head) merges the slices in slice order — attn_gqa_combine_kernel's arithmetic, no launch of its own
-    __syncthreads();   // the stores above are issued
-    if (tid == 0) {
-        const uint32_t prev = __hip_atomic_fetch_add(counters + r * NH + h, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = prev == (uint32_t) nz - 1 ? 1u : 0u;
-    }
+    const int kvH = NKV * HD, kh = h / (NH / NKV);
+    if (row_seq) { kcache += (int64_t) row_seq[r] * seq_stride; vcache += (int64_t) row_seq[r] * seq_stride; }
+    kcache += (int64_t) k0 * kvH;
+    vcache += (int64_t) k0 * kvH;
+    float4 vfirst[8];                                    // the value rows of the first 64 keys do not depend on the scores: requested up front
+    attn_v_batch<HD>(vfirst, vcache + kh * HD, kvH, T, 0, tid);
+    attn_load_q<HD>(qs, qkv + (int64_t) r * ld + h * HD, r, qp, tid);
+    attn_scores_batched<HD>(kcache + kh * HD, kvH, T, qs, scale, ps, tid);
     __syncthreads();
-    if (!s_last || tid >= HD) return;
+    float mx = -INFINITY;
+    for (int j = tid; j < T; j += 256) mx = fmaxf(mx, ps[j]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.0f;
+    for (int j = tid; j < T; j += 256) {
+        const float p = expf(ps[j] - mx);
+        ps[j] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    accs[tid >> 5][tid & 31] = attn_pv_batched<HD>(vfirst, vcache + kh * HD, kvH, T, ps, tid);
+    __syncthreads();
+    if (tid < HD) {
+        const float *a = (const float *) &accs[0][0];
+        float o = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 8; g++) o += a[g * HD + tid];
+        pz[2 + tid] = o;
+    }
+    if (tid == 0) { pz[0] = mx; pz[1] = (red[4] + red[5]) + (red[6] + red[7]); }
+}
+
+// one 128-thread workgroup per (head, row): out = sum_z e^(m_z - m) o_z / sum_z e^(m_z - m) l_z, splits in order.
+// Every slice is requested straight-line with a clamped index (a slice beyond nz re-reads the last one and is never used): as `for (z < nz)` loops
+// with the -inf test on a loaded value this kernel was nz dependent L2 round trips — 4.9 us per launch for 24 KB of partials in the Orpheus step
+// (profiles/r04/kernel_stats_orpheus_call7.csv).  Same sums in the same order.
+static __global__ __launch_bounds__(128) void attn_gqa_combine_kernel(const float *part, int nz, int NH, float *out, int8_t *aq, float *ad) {
+    const int h = blockIdx.x, r = blockIdx.y, t = threadIdx.x;
     const float *p = part + ((int64_t) r * NH + h) * nz * ATTN_PART;
     float mm[16], ll[16], oo[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {   // clamped: a slice beyond nz re-reads the last one and is never used
+    for (int i = 0; i < 16; i++) {
         const float *pi = p + min(i, nz - 1) * ATTN_PART;
-        mm[i] = __hip_atomic_load(pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ll[i] = __hip_atomic_load(pi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        oo[i] = __hip_atomic_load(pi + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mm[i] = pi[0]; ll[i] = pi[1]; oo[i] = pi[2 + t];
     }
     float m = -INFINITY;
 #pragma unroll
@@ -425,26 +404,6 @@ __global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, i
             o += f * oo[i];
             l += f * ll[i];
         }
-    }
-    const float res = o / l;
-    out[(int64_t) r * NH * HD + h * HD + tid] = res;
-    if (aq) q8_block_store(res, (int64_t) r * NH * HD + h * HD + tid, aq, ad);   // the o projection's activation blocks (waves 0 and 1 are whole here)
-    if (tid == 0) __hip_atomic_store(counters + r * NH + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// one 128-thread workgroup per (head, row): out = sum_z e^(m_z - m) o_z / sum_z e^(m_z - m) l_z, splits in order
-static __global__ __launch_bounds__(128) void attn_gqa_combine_kernel(const float *part, int nz, int NH, float *out, int8_t *aq, float *ad) {
-    const int h = blockIdx.x, r = blockIdx.y, t = threadIdx.x;
-    const float *p = part + ((int64_t) r * NH + h) * nz * ATTN_PART;
-    float m = -INFINITY;
-    for (int z = 0; z < nz; z++) m = fmaxf(m, p[z * ATTN_PART]);
-    float o = 0.0f, l = 0.0f;
-    for (int z = 0; z < nz; z++) {
-        const float mz = p[z * ATTN_PART];
-        if (mz == -INFINITY) continue;
-        const float f = expf(mz - m);
-        o += f * p[z * ATTN_PART + 2 + t];
-        l += f * p[z * ATTN_PART + 1];
     }
     const float res = o / l;
     out[(int64_t) r * NH * 128 + h * 128 + t] = res;

@@ -1251,7 +1251,6 @@ struct QGemmArgs {
     const _Float16 *wd;     // weight block scales [N][K/32]
     const int8_t *aq;       // quantised activations [R][K]
     const float *ad;        // activation block scales [R][K/32]
-    const float *parts = nullptr;   // gemv_q4_rows_lds_kernel<.., QSRC 3>: the split attention's partial results [R][K/128][8][ATTN_PART]
 };
 
 // 4 consecutive values of a Q8_0 block held by each of 8 neighbouring lanes -> the lane's 4 int8 (packed) and the

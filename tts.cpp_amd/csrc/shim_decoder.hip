@@ -307,18 +307,6 @@ int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int e
     if (pro == PRO_F16) return set_err("run_qgemm: fp16 activations are never produced for a quantised consumer");
     const bool have_q = c->aq_src != nullptr && c->aq_src == a.A && a.lda == a.K;
     c->aq_src = nullptr;
-    int fold = c->attn_fold_pending;   // key slices of a split attention that nobody has merged yet (launch_attn_gqa): a.A holds nothing so far
-    c->attn_fold_pending = 0;
-    if (fold) {
-        const bool rows_path = c->gemv_rows && a.R <= 4 && pro == PRO_F32 && (epi == EPI_STORE || epi == EPI_RESID) && !a.kchunk;
-        const size_t lds = (size_t) a.R * a.K + (size_t) a.R * (a.K / 32) * 4;
-        const bool folds = have_q && rows_path && w.q4 && c->q4_lds && lds <= 64 * 1024 && a.K % 512 == 0 && a.N < 8192 && a.K <= 4096 && fold == Q4_FOLD_NZ;
-        if (!folds) {   // any other consumer: the combine launch after all (it also leaves the Q8_0 blocks of the rows)
-            hipLaunchKernelGGL(attn_gqa_combine_kernel, dim3(a.K / 128, a.R), dim3(128), 0, c->stream, (const float *) c->attn_part, fold, a.K / 128, (float *) a.A, c->aq, c->ad);
-            HIPCHK(hipGetLastError());
-            fold = 0;
-        }
-    }
     if (c->gemv_rows && a.R <= 4 && pro == PRO_F32 && (epi == EPI_STORE || epi == EPI_RESID) && !a.kchunk) {
         CHK(prof_begin(c, kclass, (double) w.K * w.N * (1.0 + 2.0 / 32) + (double) a.R * a.K * 5 + (double) a.R * a.N * 4, 2.0 * a.R * (double) w.K * w.N));
         if (!have_q) {   // otherwise the producing kernel (rms norm, silu*up, attention combine) left the Q8_0 blocks in aq / ad
@@ -336,10 +324,7 @@ int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int e
             // NP = passes of 64 blocks a wave requests in one batch: 2 covers K <= 4096, 4 covers K <= 8192
             if (a.N >= 8192) hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 4>), dim3((a.N + 15) / 16), dim3(256), q4_lds, c->stream, qa, w.q4, epi);
             else if (a.K > 4096) hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 2, 0, 4>), dim3((a.N + 7) / 8), dim3(256), q4_lds, c->stream, qa, w.q4, epi);
-            else if (fold) {
-                qa.parts = c->attn_part;
-                hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 2, 3>), dim3((a.N + 7) / 8), dim3(256), q4_lds, c->stream, qa, w.q4, epi);
-            } else hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 2>), dim3((a.N + 7) / 8), dim3(256), q4_lds, c->stream, qa, w.q4, epi);
+            else hipLaunchKernelGGL((gemv_q4_rows_lds_kernel<4, 2>), dim3((a.N + 7) / 8), dim3(256), q4_lds, c->stream, qa, w.q4, epi);
         } else if (w.q4) hipLaunchKernelGGL(gemv_q4_rows_kernel<4>, dim3((a.N + 3) / 4), dim3(256), 0, c->stream, qa, w.q4, epi);
         else hipLaunchKernelGGL(gemv_q8_rows_kernel<4>, dim3((a.N + 3) / 4), dim3(256), 0, c->stream, qa, epi);
         HIPCHK(hipGetLastError());

@@ -277,11 +277,6 @@ struct tts_hip_ctx {
     const void *aq_src = nullptr;  // activation rows whose Q8_0 blocks already sit in aq / ad (written by the producing kernel)
     int attn_fold = 1;          // tune("attn_fold") = 0: Dia's step keeps attn_gqa_combine_kernel and silu_mul_kernel as launches of their own.  1 (default): the consuming
                                 // projections merge the attention's key slices / apply silu * up while they stage their rows (gemv_stream_kernel<.., PRO_ATTN8 / PRO_SILU, ..>)
-    int llama_merge = 0;        // tune("llama_merge"): who merges the key slices of the split decode attention of a Llama step.  0 (default): attn_gqa_combine_kernel.
-                                // 1: the last workgroup of a (row, head) to arrive inside attn_gqa_split_kernel.  2: the o projection's workgroups while they stage
-                                // (gemv_q4_rows_lds_kernel<.., QSRC 3>).  Measured equal within 2 % (profiles/r04/orpheus_attn_fold_call28.txt): the merge costs the
-                                // same dependent round trips wherever it runs, so the plain launch stays the default
-    int attn_fold_pending = 0;  // slices waiting in attn_part for the o projection (set by launch_attn_gqa, consumed by run_qgemm)
     int attn_split_max = 8;     // tune("attn_split"): key splits of the decode attention of the Llama / Dia steps (1 = off)
     float *attn_part = nullptr; // [rows][heads][splits][130] partial softmax results
     size_t attn_part_cap = 0;   // in (row, head, split) triples

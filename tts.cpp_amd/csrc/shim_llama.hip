@@ -52,25 +52,11 @@ static int launch_attn_gqa(tts_hip_ctx *c, int NHq, int rows, int max_keys, cons
         return 0;
     }
     const int chunk = (max_keys + nz - 1) / nz;
-    if (q_out && c->llama_merge == 1 && c->attn_cnt) {
-        // the last workgroup of a (row, head) to arrive merges the slices and leaves the row (and its Q8_0 blocks) behind: no combine launch
-        hipLaunchKernelGGL(attn_gqa_split_kernel<128>, dim3(NHq, rows, nz), dim3(256), (size_t) (128 + chunk + 1) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part,
-                           kbeg, kend, row_seq, seq_stride, qp, c->attn_cnt, out, c->aq, c->ad);
-        HIPCHK(hipGetLastError());
-        c->aq_src = out;
-        return 0;
-    }
     hipLaunchKernelGGL(attn_gqa_split_kernel<128>, dim3(NHq, rows, nz), dim3(256), (size_t) (128 + chunk + 1) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part,
                        kbeg, kend, row_seq, seq_stride, qp);
     HIPCHK(hipGetLastError());
     if (deferred && c->attn_fold && nz == ATTN_FOLD_NZ && !c->prof && !c->debug) {
         *deferred = nz;   // the caller's next projection merges the slices in its staging prologue (gemv_stream_kernel<.., PRO_ATTN8, ..>); `out` is not written
-        return 0;
-    }
-    if (q_out && c->llama_merge == 2 && nz == Q4_FOLD_NZ && !c->prof && !c->debug) {
-        // the consumer (run_qgemm's o projection) merges the slices while it stages its activations; `out` itself is not written
-        c->attn_fold_pending = nz;
-        c->aq_src = out;
         return 0;
     }
     hipLaunchKernelGGL(attn_gqa_combine_kernel, dim3(NHq, rows), dim3(128), 0, c->stream, (const float *) c->attn_part, nz, NHq, out, q_out ? c->aq : (int8_t *) nullptr, q_out ? c->ad : (float *) nullptr);

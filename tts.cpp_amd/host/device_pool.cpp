@@ -269,6 +269,14 @@ std::vector<std::shared_ptr<pool_task>> device_pool::poll_compatible(int w, cons
     std::vector<std::shared_ptr<pool_task>> got;
     std::lock_guard<std::mutex> lock(q_mutex_);
     if (!running_ || !per_worker_[(size_t) w].empty()) return got;
+    // A request the session cannot take (another model, incompatible sampling parameters) that has waited longer than continuous_yield_ms at the
+    // head of the queue ends the admissions: the session drains and next_batch() serves it.  Without the bound a steady stream of compatible
+    // requests kept one session alive for ever and starved everything else (task_timeout_s is only looked at on admission).
+    for (const auto & t : queue_) {
+        if (t->task == POOL_TTS && t->model == like.model && pool_configs_compatible(t->gen_config, like.gen_config)) continue;
+        if (t->waited_s() * 1e3 > opts_.continuous_yield_ms) return got;
+        break;   // the oldest incompatible request is still young: requests behind it are younger
+    }
     for (auto it = queue_.begin(); it != queue_.end() && got.size() < cap;) {
         if ((*it)->task == POOL_TTS && (*it)->model == like.model && pool_configs_compatible((*it)->gen_config, like.gen_config)) {
             got.push_back(*it);
@@ -309,10 +317,18 @@ void device_pool::process_stream(int w, std::vector<std::shared_ptr<pool_task>> 
         r_cv_.notify_all();
         v.clear();
     };
+    // the batch admit() is working on and how far it got: if stream_begin() or anything inside admit() throws (a cross-attention mismatch, a sampler
+    // the device loop does not carry, a failed device allocation — g_tts_throw_on_abort turns every abort into an exception in a worker), the tasks
+    // that are in none of inflight / overflow / done yet are failed with the message too.  Round 4 lost them: wait(id) never returned.
+    std::vector<std::shared_ptr<pool_task>> admitting = first;
+    size_t admitted = 0;
     try {
         runner.stream_begin(like.gen_config);
         auto admit = [&](std::vector<std::shared_ptr<pool_task>> & tasks, bool in_flight) {
+            admitting = tasks;
+            admitted = 0;
             for (auto & t : tasks) {
+                admitted++;
                 t->worker = w;
                 if (t->timed_out(opts_.task_timeout_s)) { t->message = "timed out in the queue"; expired++; done.push_back(t); continue; }
                 if (runner.stream_free() == 0) { overflow.push_back(t); continue; }
@@ -329,6 +345,8 @@ void device_pool::process_stream(int w, std::vector<std::shared_ptr<pool_task>> 
             const uint32_t rows = runner.stream_capacity() - runner.stream_free();   // utterances sharing the forward from here on
             peak = std::max<uint64_t>(peak, rows);
             for (auto & t : tasks) if (t->batch_size == 0) t->batch_size = (int) rows;
+            admitting.clear();
+            admitted = 0;
         };
         admit(first, false);
         std::vector<tts_generation_runner::stream_result> fin;
@@ -360,7 +378,15 @@ void device_pool::process_stream(int w, std::vector<std::shared_ptr<pool_task>> 
     } catch (const std::exception & e) {
         for (auto & kv : inflight) { kv.second->success = false; kv.second->message = e.what(); done.push_back(kv.second); }
         for (auto & t : overflow) { t->success = false; t->message = e.what(); done.push_back(t); }
-        inflight.clear(); overflow.clear();
+        // the task admit() was working on when the exception left it is in none of the three lists either: it fails with the rest
+        for (size_t i = admitted ? admitted - 1 : 0; i < admitting.size(); i++) {
+            auto & t = admitting[i];
+            bool placed = false;
+            for (auto & d : done) placed |= d == t;
+            if (placed) continue;
+            t->worker = w; t->success = false; t->message = e.what(); served++; done.push_back(t);
+        }
+        inflight.clear(); overflow.clear(); admitting.clear();
         try { runner.stream_end(); } catch (...) {}
     }
     finish(done);

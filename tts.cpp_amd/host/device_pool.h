@@ -40,9 +40,8 @@ struct pool_task {  // simple_server_task (:100-123); the audio is copied out of
     std::chrono::steady_clock::time_point time = std::chrono::steady_clock::now();
     int                      batch_size = 0;  // how many tasks were decoded together with this one
     int                      worker = -1;
-    bool timed_out(int seconds) const {
-        return std::chrono::duration<double>(std::chrono::steady_clock::now() - time).count() > seconds;
-    }
+    double waited_s() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - time).count(); }
+    bool timed_out(int seconds) const { return waited_s() > seconds; }
 };
 
 struct pool_options {
@@ -59,6 +58,7 @@ struct pool_options {
     // what is queued and running it to the end — a request that arrives one step late no longer waits a whole generation, and a ragged
     // batch refills instead of idling.  Runners without a session (stream_capacity() == 0) keep the batch path.
     bool             continuous = false;
+    int              continuous_yield_ms = 2000;   // a session stops admitting once a request it cannot take has waited this long at the head of the queue
 };
 
 struct pool_stats {

@@ -137,7 +137,11 @@ struct dummy_runner final : tts_generation_runner {
     std::vector<std::vector<float>> st_audio;
     bool                            st_on = false;
     uint32_t stream_capacity() const override { return 4; }
-    void     stream_begin(const generation_configuration &) override { st_rows.clear(); st_on = true; }
+    void     stream_begin(const generation_configuration & config) override {
+        // test hook of the plumbing backend: a session that cannot be opened (a real runner refuses a cross-attention mismatch or a host-only sampler here)
+        if (config.voice == "test:stream_begin-fails") TTS_ABORT("stream_begin: refused (test:stream_begin-fails)\n");
+        st_rows.clear(); st_on = true;
+    }
     uint32_t stream_free() const override { return st_on ? 4 - (uint32_t) st_rows.size() : 0; }
     uint32_t stream_live() const override { return (uint32_t) st_rows.size(); }
     void     stream_submit(size_t ticket, const std::string & sentence) override {

@@ -410,6 +410,7 @@ void parler_runner::stream_begin(const generation_configuration & config) {
     st_start.assign(slots, 0);
     st_wait.clear(); st_codec.clear(); st_pcm.clear();
     st_live = 0;
+    st_codec_held = 0;
     st_on = true;
 }
 
@@ -472,9 +473,13 @@ void parler_runner::stream_step(std::vector<stream_result> & finished) {
         st_free.push_back(slot);
         st_live--;
     }
-    // the codec: whole groups as they fill, everything that is left once nothing is generating (a session never holds audio back for company)
+    // the codec: whole groups of 64 as they fill (the device's pass size); what is left goes out when nothing is generating any more, and in any case
+    // one look-in interval after it finished — a finished utterance waits at most STREAM_CHUNK decode steps for company, never for a group to fill
+    // (round 4 held a finished request's audio until 63 more utterances had finished: under steady arrivals with fewer than 64 rows, for ever)
     const bool drain = st_live == 0;
-    size_t take = st_codec.size() >= STREAM_CODEC_GROUP ? st_codec.size() / STREAM_CODEC_GROUP * STREAM_CODEC_GROUP : (drain ? st_codec.size() : 0);
+    size_t take = st_codec.size() >= STREAM_CODEC_GROUP ? st_codec.size() / STREAM_CODEC_GROUP * STREAM_CODEC_GROUP : 0;
+    if (!take && !st_codec.empty() && (drain || st_codec_held >= 1)) take = st_codec.size();
+    st_codec_held = (take < st_codec.size()) ? (take ? 0 : st_codec_held + 1) : 0;
     if (take) {
         std::vector<uint32_t> codes, frames(take);
         size_t total = 0;

@@ -364,6 +364,8 @@ static thread_local std::string g_pool_text_encoder;
 void tts_c_pool_set_text_encoder(const char * path) { g_pool_text_encoder = path ? path : ""; }
 static thread_local bool g_pool_continuous = false;
 void tts_c_pool_set_continuous(int on) { g_pool_continuous = on != 0; }
+static thread_local int g_pool_yield_ms = 2000;
+void tts_c_pool_set_continuous_yield_ms(int ms) { g_pool_yield_ms = ms < 0 ? 0 : ms; }
 uint64_t tts_c_pool_admitted_in_flight(tts_c_pool * p) { return p->pool->stats().admitted_in_flight; }
 
 int tts_c_pool_conditional_prompt(tts_c_pool * p, const char * prompt) {
@@ -382,6 +384,7 @@ tts_c_pool * tts_c_pool_create(const char * model_path, int n_workers, const int
         o.max_batch = max_batch;
         o.batch_window_ms = batch_window_ms;
         o.continuous = g_pool_continuous;
+        o.continuous_yield_ms = g_pool_yield_ms;
         auto p = std::make_unique<tts_c_pool>();
         p->pool = std::make_unique<device_pool>(std::map<std::string, std::string>{{"default", model_path}}, to_cfg(load_cfg), o);
         if (!p->pool->ok()) { g_c_err = p->pool->error(); return nullptr; }

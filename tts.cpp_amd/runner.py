@@ -28,7 +28,7 @@ class SamplerCfg(C.Structure):
 
 EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "tts_c_generate_batch", "tts_c_generate_stream", "tts_c_sampling_rate", "tts_c_arch", "tts_c_free",
            "tts_c_last_error", "tts_c_update_conditional_prompt", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor",
-           "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_set_continuous", "tts_c_pool_admitted_in_flight", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_load_stats", "tts_c_pool_free", "tts_c_set_load_options", "tts_c_set_load_options_ex", "tts_c_runner_device_context", "tts_c_runner_tokenize",
+           "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_set_continuous", "tts_c_pool_set_continuous_yield_ms", "tts_c_pool_admitted_in_flight", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_load_stats", "tts_c_pool_free", "tts_c_set_load_options", "tts_c_set_load_options_ex", "tts_c_runner_device_context", "tts_c_runner_tokenize",
            "tts_c_quantize_gguf", "tts_c_quantize_decision", "tts_c_quantize_rows",
            "tts_c_dia_tokenize", "tts_c_dia_check_stopping", "tts_c_dia_adjust_output_tokens", "tts_c_single_pass_tokenize", "tts_c_kokoro_chunks"]
 
@@ -84,6 +84,8 @@ def load_lib():
         L.tts_c_pool_set_text_encoder.restype = None
         L.tts_c_pool_set_continuous.argtypes = [C.c_int]
         L.tts_c_pool_set_continuous.restype = None
+        L.tts_c_pool_set_continuous_yield_ms.argtypes = [C.c_int]
+        L.tts_c_pool_set_continuous_yield_ms.restype = None
         L.tts_c_pool_admitted_in_flight.argtypes = [C.c_void_p]
         L.tts_c_pool_admitted_in_flight.restype = C.c_uint64
         L.tts_c_pool_conditional_prompt.argtypes = [C.c_void_p, C.c_char_p]
@@ -314,11 +316,12 @@ class Pool:
     """device_pool (host/device_pool.h): the reference server's worker pool with one worker per device and dynamic
     lock-step batching.  submit() -> id; wait(id) -> (audio, batch_size, worker)."""
 
-    def __init__(self, path, n_workers=1, devices=None, max_batch=1, batch_window_ms=0, text_encoder_path=None, continuous=False, **cfg):
+    def __init__(self, path, n_workers=1, devices=None, max_batch=1, batch_window_ms=0, text_encoder_path=None, continuous=False, continuous_yield_ms=2000, **cfg):
         self.L = load_lib()
         self.cfg = make_config(**cfg)
         self.L.tts_c_pool_set_text_encoder(text_encoder_path.encode() if text_encoder_path else None)
         self.L.tts_c_pool_set_continuous(1 if continuous else 0)   # pool_options::continuous: requests join a running generation
+        self.L.tts_c_pool_set_continuous_yield_ms(int(continuous_yield_ms))
         dev = (C.c_int * len(devices))(*devices) if devices else None
         self.h = self.L.tts_c_pool_create(path.encode(), n_workers, dev, len(devices) if devices else 0, max_batch, batch_window_ms, C.byref(self.cfg))
         if not self.h:
