@@ -425,15 +425,17 @@ def long_sentences(rn, n, lo, hi, seed):
 class TimeBudget:
     """Wall-clock budget of one bench.py run.  The contract's part — warm-up, the K timed steps, the roofline pass, the CPU baseline — always runs;
     every EXTRA section (batch-1 sweep, end-to-end harness, secondary configs, the long_utterances parts) runs only while the time already spent plus
-    the section's measured cost (seconds on an MI355X box, end of round 4) stays inside the budget, most valuable first.  The driver's round-end run
-    (`--steps 20 --warmup 5`: 25 steps of ~11.3 s) took 500 s in round 3; with this round's additions it would take ~660 s, so the default budget
-    keeps a whole run near 480 s.  `--time-budget-s 0` = no limit (how profiles/r04/bench_default_3x1024.json was produced)."""
-    COST = {"decode_step_batch1": 25, "generate_batch1_end_to_end": 25, "secondary.kokoro": 25, "secondary.dia": 25, "secondary.orpheus": 35,
-            "long_utterances.uniform": 100, "long_utterances.ragged": 70, "long_utterances.ragged_stream": 100}
-    RESERVED = 30   # the CPU baseline that still has to run after the extras of the main context
+    the section's cost (seconds on an MI355X box, measured: `time_budget.sections` of the last full line under profiles/r05/) stays inside the budget.
+    Round 4's table over-priced the short sections by 2-3 x and warmed every long part up with a full run of itself (250 of 440 s), so the driver's
+    `--steps 20 --warmup 5` line (25 steps of ~11 s = 280 s before any extra) dropped the round's own feature.  Round 5: the long parts warm up on a
+    48-step run of the same row count, the request stream is 2 x the rows instead of 3 x, the costs are the measured ones, and the order inside
+    long_utterances is uniform, ragged_stream, uniform_same_mix, ragged (most wanted first).  `--time-budget-s 0` = no limit."""
+    COST = {"decode_step_batch1": 14, "generate_batch1_end_to_end": 16, "secondary.kokoro": 10, "secondary.dia": 12, "secondary.orpheus": 18,
+            "long_utterances.uniform": 62, "long_utterances.ragged_stream": 66, "long_utterances.uniform_same_mix": 26, "long_utterances.ragged": 38}
+    RESERVED = 24   # the CPU baseline that still has to run after the extras of the main context
 
     def __init__(self, budget_s):
-        self.budget, self.skipped, self.reserved = float(budget_s), [], 0.0
+        self.budget, self.skipped, self.reserved, self.sections = float(budget_s), [], 0.0, {}
 
     def elapsed(self):
         return time.perf_counter() - _T_START
@@ -444,20 +446,28 @@ class TimeBudget:
         self.skipped.append(section)
         return False
 
+    def took(self, section, t0):
+        """book what a section really cost (so that the next COST table can be read off a line)"""
+        self.sections[section] = round(time.perf_counter() - t0, 1)
+
     def report(self):
-        return {"budget_s": self.budget, "elapsed_s": round(self.elapsed(), 1), "skipped": self.skipped,
+        return {"budget_s": self.budget, "elapsed_s": round(self.elapsed(), 1), "skipped": self.skipped, "sections": self.sections,
                 "note": "extra sections run while elapsed + their measured cost fits the budget (--time-budget-s 0: no limit); the timed steps, "
-                        "the roofline and the CPU baseline always run"}
+                        "the roofline and the CPU baseline always run; sections = seconds each extra took in this run"}
 
 
 def long_utterances(args, mk, wt, local_rank, gen_cfg, torch, L, budget=None):
     """SURVEY §8(d)'s long workload: 1024 audio steps per utterance (11.7 s of audio; the reference's perf_battery sentences average
-    10.8 s), the largest 3-runner lock-step batch whose fp32 KV cache fits, then a ragged batch (prompts of 16 .. 784 ids, so that the
-    rows stop — reach max_generation — at different steps, 1024 down to 256)."""
+    10.8 s), the largest 3-runner lock-step batch whose fp32 KV cache fits (`uniform`); then the ragged mix (prompts of 16 .. 784 ids, so that
+    the rows stop — reach max_generation — after 1024 down to 256 steps) as a STREAM of requests through continuous-batching sessions
+    (`ragged_stream`), a lock-step batch in which every utterance carries the MEAN prompt of that mix (`uniform_same_mix`: the yardstick the two
+    ragged numbers are quoted against — same ids prefilled, same steps generated, same cached positions on average, nothing ragged), and the mix as
+    one lock-step batch (`ragged`)."""
     n_steps = args.long_steps
     if budget is not None and not budget.room("long_utterances.uniform"):
-        budget.skipped += ["long_utterances.ragged", "long_utterances.ragged_stream"]
+        budget.skipped += ["long_utterances.ragged_stream", "long_utterances.uniform_same_mix", "long_utterances.ragged"]
         return {"skipped": "time budget (--time-budget-s)"}
+    t_sec = time.perf_counter()
     cfg = mk(weight_type=wt, dac_f16=args.dac_wtype == "f16", max_gen=args.prompt_len + n_steps)
     free_b, _ = torch.cuda.mem_get_info(local_rank)
     kv_per_seq = cfg.layers * 2 * (args.prompt_len + n_steps) * cfg.hidden * (2 if args.kv == "f16" else 4)
@@ -476,14 +486,21 @@ def long_utterances(args, mk, wt, local_rank, gen_cfg, torch, L, budget=None):
     out = {"audio_steps": n_steps, "lockstep_batch": batch, "contexts_per_gpu": args.streams, "kv_cache": args.kv,
            "kv_cache_GB": round(args.streams * batch * kv_per_seq / 1e9, 1)}
     frames = n_steps - cfg.n_out + 1
-    try:
-        texts = [make_sentences(first, batch, args.prompt_len, 5000 + i) for i in range(args.streams)]
-        run_all(runners, texts)                                   # warm-up: graph capture, codec buffers
+
+    def timed(texts, stream=False):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n_samples = run_all(runners, texts)
+        n = run_all(runners, texts, stream=stream)
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        return n, time.perf_counter() - t0
+
+    try:
+        # warm-up for every part: ONE utterance text of max_generation - 48 ids in every row — the same row count (the captured steps are keyed by
+        # it), the codec and session buffers, 48 decode steps instead of a whole generation (round 4 ran every part twice: 250 s of warm-up)
+        warm = long_sentences(first, 1, args.prompt_len + n_steps - 48, args.prompt_len + n_steps - 48, 4000)[0]
+        run_all(runners, [[warm] * batch for _ in range(args.streams)])
+        texts = [make_sentences(first, batch, args.prompt_len, 5000 + i) for i in range(args.streams)]
+        n_samples, dt = timed(texts)
         out["uniform"] = {"audio_seconds_per_sec": round(n_samples / SAMPLE_RATE / dt, 2), "seconds": round(dt, 3),
                           "utterances": batch * args.streams, "audio_s_per_utterance": round(frames * cfg.hop / SAMPLE_RATE, 2)}
         # the attention family over the long cache: eager, event-timed pass of one runner
@@ -494,47 +511,61 @@ def long_utterances(args, mk, wt, local_rank, gen_cfg, torch, L, budget=None):
         if st.get("launches"):
             out["uniform"]["attn_self"] = {"GBps": round(st["bytes_total"] / st["ms_total"] / 1e6, 1), "frac_of_hbm_peak": round(st["bytes_total"] / st["ms_total"] / 1e6 / HBM_PEAK_GBS, 4),
                                            "avg_launch_us": round(st["ms_total"] / st["launches"] * 1e3, 2), "mean_cached_positions": args.prompt_len + n_steps // 2}
-        if budget is not None and not budget.room("long_utterances.ragged"):
-            budget.skipped.append("long_utterances.ragged_stream")   # its ratios are against the two sections before it
-            out["ragged"] = out["ragged_stream"] = {"skipped": "time budget (--time-budget-s)"}
-            return out
-        # ragged: prompt lengths spread over 16 .. 784 ids -> rows run 1024 .. 256 steps; a finished row idles at its last position
-        hi = args.prompt_len + (3 * n_steps) // 4
-        rag = [long_sentences(first, batch, args.prompt_len, hi, 7000 + i) for i in range(args.streams)]
-        run_all(runners, rag)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n_samples = run_all(runners, rag)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out["ragged"] = {"audio_seconds_per_sec": round(n_samples / SAMPLE_RATE / dt, 2), "seconds": round(dt, 3), "utterances": batch * args.streams,
-                         "prompt_ids": [args.prompt_len, hi], "audio_steps_per_utterance": [n_steps - (hi - args.prompt_len), n_steps],
-                         "note": "lock-step: the loop runs as long as the longest row; every 32 steps the rows that reached max_generation leave the forward (row compaction, "
-                                 "TTS_HIP_GEN_COMPACT=0: they idle instead — 196 against 268 audio-s/s, profiles/r03/compaction_call20.txt)"}
-        if budget is not None and not budget.room("long_utterances.ragged_stream"):
-            out["ragged_stream"] = {"skipped": "time budget (--time-budget-s)"}
-            return out
-        # the same length mix as a STREAM of requests, three times the rows a runner holds, through one continuous-batching session per runner
+        if budget is not None:
+            budget.took("long_utterances.uniform", t_sec)
+        lo, hi = args.prompt_len, args.prompt_len + (3 * n_steps) // 4     # 16 .. 784 ids: rows run 1024 .. 256 steps
+        mid = (lo + hi) // 2
+        mix = {"prompt_ids": [lo, hi], "audio_steps_per_utterance": [n_steps - (hi - lo), n_steps], "mean_prompt_ids": mid, "mean_audio_steps": n_steps - (mid - lo)}
+
+        def part(name):
+            if budget is not None and not budget.room("long_utterances." + name):
+                out[name] = {"skipped": "time budget (--time-budget-s)"}
+                return False
+            return True
+
+        # ---- the ragged mix as a STREAM of requests: twice the rows a runner holds, one continuous-batching session per runner
         # (tts_c_generate_stream): a row freed by an utterance that reached max_generation is refilled at the next 32-step look-in point
-        n_req = 3 * (batch - 1)
-        srag = [long_sentences(first, n_req, args.prompt_len, hi, 9000 + i) for i in range(args.streams)]
-        rngs = np.random.default_rng(17)
-        for t in srag:
-            rngs.shuffle(t)                                      # arrival order is not sorted by length
-        run_all(runners, [sorted(t, key=len)[-8:] for t in srag], stream=True)   # warm-up: the session's buffers (eight of the shortest-running requests)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n_samples = run_all(runners, srag, stream=True)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out["ragged_stream"] = {"audio_seconds_per_sec": round(n_samples / SAMPLE_RATE / dt, 2), "seconds": round(dt, 3), "requests": n_req * args.streams,
-                                "rows_per_runner": batch - 1, "prompt_ids": [args.prompt_len, hi],
-                                "of_uniform": round(n_samples / SAMPLE_RATE / dt / out["uniform"]["audio_seconds_per_sec"], 3),
-                                "of_lockstep_ragged": round(n_samples / SAMPLE_RATE / dt / out["ragged"]["audio_seconds_per_sec"], 3),
-                                "workload_note": "not the uniform workload at another arrival pattern: these prompts are 16..784 ids long (prefill of ~400 ids per "
-                                                 "request, rows at a mean cached position of ~720 instead of 528), so a step costs more per audio second",
-                                "note": "continuous batching (tts_hip_parler_stream_*): 3 x the rows of requests with the ragged length mix per runner; "
-                                        "finished utterances leave, waiting ones are prefilled as a side batch and enter the freed rows"}
+        if part("ragged_stream"):
+            t_sec = time.perf_counter()
+            n_req = 2 * (batch - 1)
+            srag = [long_sentences(first, n_req, lo, hi, 9000 + i) for i in range(args.streams)]
+            rngs = np.random.default_rng(17)
+            for t in srag:
+                rngs.shuffle(t)                                      # arrival order is not sorted by length
+            run_all(runners, [sorted(t, key=len)[-8:] for t in srag], stream=True)   # warm-up: the session's buffers (eight of the shortest-running requests)
+            n_samples, dt = timed(srag, stream=True)
+            out["ragged_stream"] = dict(mix, audio_seconds_per_sec=round(n_samples / SAMPLE_RATE / dt, 2), seconds=round(dt, 3), requests=n_req * args.streams,
+                                        rows_per_runner=batch - 1,
+                                        note="continuous batching (tts_hip_parler_stream_*): 2 x the rows of requests with the ragged length mix per runner; "
+                                             "finished utterances leave, waiting ones are prefilled as a side batch and enter the freed rows")
+            budget and budget.took("long_utterances.ragged_stream", t_sec)
+        # ---- the yardstick of the mix: every utterance with the mean prompt (400 ids) and hence the mean number of steps (640), lock-step
+        if part("uniform_same_mix"):
+            t_sec = time.perf_counter()
+            same = [make_sentences(first, batch, mid, 6000 + i) for i in range(args.streams)]
+            n_samples, dt = timed(same)
+            out["uniform_same_mix"] = {"audio_seconds_per_sec": round(n_samples / SAMPLE_RATE / dt, 2), "seconds": round(dt, 3), "utterances": batch * args.streams,
+                                       "prompt_ids": mid, "audio_steps": n_steps - (mid - lo),
+                                       "note": "what the hardware does with the mix's mean utterance when nothing is ragged: the ragged numbers are quoted against this"}
+            budget and budget.took("long_utterances.uniform_same_mix", t_sec)
+        # ---- the mix as ONE lock-step batch per runner: the loop runs as long as the longest row, finished rows leave every 32 steps
+        if part("ragged"):
+            t_sec = time.perf_counter()
+            rag = [long_sentences(first, batch, lo, hi, 7000 + i) for i in range(args.streams)]
+            n_samples, dt = timed(rag)
+            out["ragged"] = dict(mix, audio_seconds_per_sec=round(n_samples / SAMPLE_RATE / dt, 2), seconds=round(dt, 3), utterances=batch * args.streams,
+                                 note="lock-step: the loop runs as long as the longest row; every 32 steps the rows that reached max_generation leave the forward (row "
+                                      "compaction, TTS_HIP_GEN_COMPACT=0: they idle instead — 196 against 268 audio-s/s, profiles/r03/compaction_call20.txt)")
+            budget and budget.took("long_utterances.ragged", t_sec)
+        ref = out.get("uniform_same_mix", {}).get("audio_seconds_per_sec")
+        for name in ("ragged_stream", "ragged"):
+            v = out.get(name, {}).get("audio_seconds_per_sec")
+            if v:
+                out[name]["of_uniform"] = round(v / out["uniform"]["audio_seconds_per_sec"], 3)
+                if ref:
+                    out[name]["of_uniform_same_mix"] = round(v / ref, 3)
+        if out.get("ragged_stream", {}).get("audio_seconds_per_sec") and out.get("ragged", {}).get("audio_seconds_per_sec"):
+            out["ragged_stream"]["of_lockstep_ragged"] = round(out["ragged_stream"]["audio_seconds_per_sec"] / out["ragged"]["audio_seconds_per_sec"], 3)
     finally:
         for rn in reversed(runners):
             rn.close()
@@ -560,7 +591,7 @@ def main():
     ap.add_argument("--no-long", action="store_true", help="skip the long_utterances section (1024 audio steps, uniform + ragged)")
     ap.add_argument("--no-e2e", action="store_true", help="skip generate_batch1_end_to_end (the reference's perf_battery protocol, one utterance at a time)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE configs 2-4 (secondary)")
-    ap.add_argument("--time-budget-s", type=float, default=480.0,
+    ap.add_argument("--time-budget-s", type=float, default=520.0,
                     help="wall-clock budget of the whole run: extra sections are skipped (and named in time_budget.skipped) once they no longer fit; 0 = no limit")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--model", choices=["mini", "small", "tiny"], default="mini")
@@ -766,17 +797,23 @@ def main():
                 for k, v in stats.items() if v["launches"]}
         budget.reserved = 0.0 if args.no_cpu_baseline else TimeBudget.RESERVED
         if not args.no_step_sweep and args.wtype in ("f16", "f32") and budget.room("decode_step_batch1"):
+            t_sec = time.perf_counter()
             full_model = synth.build(cfg_full, shapes_only=True)
             out["decode_step_batch1"] = decode_step_sweep(cfg_full, full_model, L.tts_hip_arena_ptr(runners[0].device_context()), local_rank)
+            budget.took("decode_step_batch1", t_sec)
         if not args.no_e2e and args.model == "mini" and not args.sample and budget.room("generate_batch1_end_to_end"):
+            t_sec = time.perf_counter()
             try:
                 out["generate_batch1_end_to_end"] = generate_batch1_end_to_end(path, local_rank)
             except Exception as e:   # the headline must survive a failure of an extra section
                 out["generate_batch1_end_to_end"] = {"error": str(e)[:300]}
+            budget.took("generate_batch1_end_to_end", t_sec)
         if not args.no_cpu_baseline:
+            t_sec = time.perf_counter()
             threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 32)
             prompt = runners[0].tokenize(all_texts[0][0])
             out["cpu_baseline"] = cpu_baseline(model, cfg, prompt, threads)
+            budget.took("cpu_baseline", t_sec)
         budget.reserved = 0.0
     for rn in reversed(runners):
         rn.close()
@@ -792,10 +829,12 @@ def main():
                 if not budget.room("secondary." + name):
                     sec[name] = {"skipped": "time budget (--time-budget-s)"}
                     continue
+                t_sec = time.perf_counter()
                 try:
                     sec[name] = secondary_bench.RUNNERS[name](sargs)
                 except Exception as e:
                     sec[name] = {"error": str(e)[:300]}
+                budget.took("secondary." + name, t_sec)
             out["secondary"] = sec
         if not args.no_long:
             try:

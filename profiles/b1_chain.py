@@ -80,6 +80,8 @@ def main():
         ("... in 16 key splits", {}, {"TTS_HIP_ATTN_NSPLIT": "16"}, False),
         ("... in 4 key splits", {}, {"TTS_HIP_ATTN_NSPLIT": "4"}, False),
     ]
+    if os.environ.get("B1_ONLY_DEFAULT"):   # a quick pass: the plain chain and the default
+        variants = [variants[0], variants[3]]
     base_lg = base_tok = None
     for i, (name, tune, env, stamps) in enumerate(variants):
         e = dict(os.environ); e.update(env)

@@ -45,78 +45,107 @@ __global__ __launch_bounds__(NWV * 64) void gemv_stream_kernel(GemmArgs a, Strea
 #pragma unroll
         for (int c = 0; c < 8; c++) w[c] = __builtin_nontemporal_load((const half8 *) (p + c * 32));
     };
-    // in flight under the staging.  Unconditional (a wave with no tile re-reads the last one): under `if (t < tiles)` the loads were a block of their
-    // own whose first result was copied on the way out — an s_waitcnt on the first weight load in front of the staging loads, two dependent
-    // round trips at the top of every launch.
-    loadw(w0, min(t, tiles - 1), 0);
-
     // ---- stage this slice of the R rows as fp16 ------------------------------------------------------
+    // Order of the requests (round 5): vmcnt retires in issue order, so the staging inputs (L2 hits) go out FIRST and the first weight set right
+    // behind them — with the weights in front (rounds 2-4) the staging could not touch its inputs before the weights had landed, one HBM round
+    // trip at the top of every launch (profiles/r05/isa_wait_order_before.txt).  PRE items per thread are requested ahead of the weights (all of
+    // them at Dia's and Parler's shapes for the plain prologues; one for the folding prologues, whose item is 80-128 registers), the rest behind.
     const int c8n = KS >> 3;
-    for (int i = tid; i < RS * c8n; i += NWV * 64) {
+    const int total = RS * c8n;
+    constexpr int NT = NWV * 64;
+    constexpr int PRE = (PRO == PRO_F16 || PRO == PRO_F32) ? 4 : 1;
+    constexpr int RAWQ = PRO == PRO_F16 ? 1 : PRO == PRO_SILU ? 32 : PRO == PRO_ATTN8 ? 1 : 2;   // what an item holds between its request and its use
+    constexpr int RAWD = PRO == PRO_ATTN8 ? 5 * ATTN_FOLD_NZ : 1;
+    struct Raw { float4v q[RAWQ]; float2v d[RAWD]; };
+    auto load_item = [&](int i, Raw &rw) __attribute__((always_inline)) {
+        const int r = min(i / c8n, a.R - 1), c8 = i % c8n;   // a row slot beyond R holds zeros: its loads re-read the last row and are dropped
+        if (PRO == PRO_F16) {
+            const half8 h = *(const half8 *) ((const _Float16 *) a.A + (int64_t) r * a.lda + k0 + c8 * 8);
+            rw.q[0] = __builtin_bit_cast(float4v, h);
+        } else if (PRO == PRO_ATTN8) {
+            // K = heads x 128: eight values of one head from every key slice (max, sum | 8 values): 5 x float2v per slice
+            const int k = k0 + c8 * 8;
+            const float *p = a.att_part + ((int64_t) r * (a.K >> 7) + (k >> 7)) * ATTN_FOLD_NZ * ATTN_PART;
+            const int t0 = k & 127;
+#pragma unroll
+            for (int z = 0; z < ATTN_FOLD_NZ; z++) {
+                rw.d[z * 5] = *(const float2v *) (p + z * ATTN_PART);
+#pragma unroll
+                for (int j = 0; j < 4; j++) rw.d[z * 5 + 1 + j] = *(const float2v *) (p + z * ATTN_PART + 2 + t0 + 2 * j);
+            }
+        } else if (PRO == PRO_SILU) {
+            // a.A = gate | up rows [R][2 K] as a.n_parts <= 8 slabs (a.parts_stride floats apart) of the preceding projection
+            // (a slab beyond n_parts re-reads the last one and is never added)
+            const float *pg = (const float *) a.A + (int64_t) r * a.lda + k0 + c8 * 8;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const float *pq = pg + (int64_t) min(q, a.n_parts - 1) * a.parts_stride;
+                rw.q[q * 4 + 0] = *(const float4v *) pq; rw.q[q * 4 + 1] = *(const float4v *) (pq + 4);
+                rw.q[q * 4 + 2] = *(const float4v *) (pq + a.K); rw.q[q * 4 + 3] = *(const float4v *) (pq + a.K + 4);
+            }
+        } else {
+            const float *p = (const float *) a.A + (int64_t) r * a.lda + k0 + c8 * 8;
+            rw.q[0] = *(const float4v *) p; rw.q[1] = *(const float4v *) (p + 4);
+        }
+    };
+    auto finish_item = [&](int i, const Raw &rw) __attribute__((always_inline)) {
         const int r = i / c8n, c8 = i - r * c8n;
         half8 h = {0, 0, 0, 0, 0, 0, 0, 0};
         if (r < a.R) {
             if (PRO == PRO_F16) {
-                h = *(const half8 *) ((const _Float16 *) a.A + (int64_t) r * a.lda + k0 + c8 * 8);
+                h = __builtin_bit_cast(half8, rw.q[0]);
             } else if (PRO == PRO_ATTN8) {
-                // K = heads x 128: eight values of one head, merged from the key slices (attn_gqa_combine_kernel: running max in slice order,
-                // o = sum f_z o_z, l = sum f_z l_z with f_z = expf(m_z - m), o / l; an empty slice left (max = -inf, sum = 0) and adds + 0)
-                const int k = k0 + c8 * 8;
-                const float *p = a.att_part + ((int64_t) r * (a.K >> 7) + (k >> 7)) * ATTN_FOLD_NZ * ATTN_PART;
-                const int t0 = k & 127;
-                float2v ml[ATTN_FOLD_NZ], v[ATTN_FOLD_NZ][4];
-#pragma unroll
-                for (int z = 0; z < ATTN_FOLD_NZ; z++) {
-                    ml[z] = *(const float2v *) (p + z * ATTN_PART);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) v[z][j] = *(const float2v *) (p + z * ATTN_PART + 2 + t0 + 2 * j);
-                }
-                __builtin_amdgcn_sched_barrier(0);   // every slice requested before the first is used
+                // merged from the key slices (attn_gqa_combine_kernel: running max in slice order, o = sum f_z o_z, l = sum f_z l_z with
+                // f_z = expf(m_z - m), o / l; an empty slice left (max = -inf, sum = 0) and adds + 0)
+                const float2v (&d)[RAWD] = rw.d;
                 float m = -INFINITY;
 #pragma unroll
-                for (int z = 0; z < ATTN_FOLD_NZ; z++) m = fmaxf(m, ml[z][0]);
+                for (int z = 0; z < ATTN_FOLD_NZ; z++) m = fmaxf(m, d[z * 5][0]);
                 float o[8], l = 0.0f;
 #pragma unroll
                 for (int e = 0; e < 8; e++) o[e] = 0.0f;
 #pragma unroll
                 for (int z = 0; z < ATTN_FOLD_NZ; z++) {
-                    const float mz = ml[z][0];
+                    const float mz = d[z * 5][0];
                     const bool live = mz != -INFINITY;
                     const float f = live ? expf(mz - m) : 0.0f;
 #pragma unroll
-                    for (int e = 0; e < 8; e++) o[e] += f * (live ? v[z][e >> 1][e & 1] : 0.0f);
-                    l += f * ml[z][1];
+                    for (int e = 0; e < 8; e++) o[e] += f * (live ? d[z * 5 + 1 + (e >> 1)][e & 1] : 0.0f);
+                    l += f * d[z * 5][1];
                 }
 #pragma unroll
                 for (int e = 0; e < 8; e++) h[e] = (_Float16) (o[e] / l);
             } else if (PRO == PRO_SILU) {
-                // a.A = gate | up rows [R][2 K] as a.n_parts <= 8 slabs (a.parts_stride floats apart) of the preceding projection: slabs added in
-                // slab order (a slab beyond n_parts re-reads the last one and is never added), silu(gate) * up — silu_mul_kernel's arithmetic
-                const float *pg = (const float *) a.A + (int64_t) r * a.lda + k0 + c8 * 8;
-                float4v gx[8][2], ux[8][2];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const float *pq = pg + (int64_t) min(q, a.n_parts - 1) * a.parts_stride;
-                    gx[q][0] = *(const float4v *) pq; gx[q][1] = *(const float4v *) (pq + 4);
-                    ux[q][0] = *(const float4v *) (pq + a.K); ux[q][1] = *(const float4v *) (pq + a.K + 4);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                // slabs added in slab order, silu(gate) * up — silu_mul_kernel's arithmetic
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    float x = gx[0][e >> 2][e & 3], u = ux[0][e >> 2][e & 3];
+                    float x = rw.q[0 + (e >> 2)][e & 3], u = rw.q[2 + (e >> 2)][e & 3];
 #pragma unroll
                     for (int q = 1; q < 8; q++)
-                        if (q < a.n_parts) { x += gx[q][e >> 2][e & 3]; u += ux[q][e >> 2][e & 3]; }
+                        if (q < a.n_parts) { x += rw.q[q * 4 + (e >> 2)][e & 3]; u += rw.q[q * 4 + 2 + (e >> 2)][e & 3]; }
                     h[e] = (_Float16) ((x / (1.0f + expf(-x))) * u);
                 }
             } else {
-                const float *p = (const float *) a.A + (int64_t) r * a.lda + k0 + c8 * 8;
-                const float4v f0 = *(const float4v *) p, f1 = *(const float4v *) (p + 4);
 #pragma unroll
-                for (int e = 0; e < 4; e++) { h[e] = (_Float16) f0[e]; h[4 + e] = (_Float16) f1[e]; }
+                for (int e = 0; e < 4; e++) { h[e] = (_Float16) rw.q[0][e]; h[4 + e] = (_Float16) rw.q[1][e]; }
             }
         }
         *(half8 *) (xs + (size_t) r * ldx + c8 * 8) = h;
+    };
+    Raw raw[PRE];
+#pragma unroll
+    for (int j = 0; j < PRE; j++) load_item(min(tid + j * NT, total - 1), raw[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    // the first weight set.  Unconditional (a wave with no tile re-reads the last one): under `if (t < tiles)` the loads were a block of their
+    // own whose first result was copied on the way out — an s_waitcnt on the first weight load in front of everything behind it
+    loadw(w0, min(t, tiles - 1), 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < PRE; j++)
+        if (tid + j * NT < total) finish_item(tid + j * NT, raw[j]);
+    for (int i = tid + PRE * NT; i < total; i += NT) {
+        load_item(i, raw[0]);
+        finish_item(i, raw[0]);
     }
     __syncthreads();
 

@@ -193,20 +193,28 @@ __global__ __launch_bounds__(PRO == PRO_LN || PRO == PRO_ATTN ? 512 : 1024) void
     const int kz = blockIdx.y * a.kchunk;  // 0 unless K is split over workgroups
     B1_STAMP(a.stamps, 0);
 
-    // ---- 1. issue every weight load of this lane (HBM latency overlaps the prologue) -------------
+    // ---- 1. every weight load of this lane, issued RIGHT BEHIND the first staging loads (HBM latency overlaps the prologue) -----
     // MFMA-natural K order: for load c, the 4 lanes (g = 0..3) that share a weight row read one
     // contiguous 64-byte sector of it, so a wave instruction touches 16 rows x 64 B (whole sectors).
+    // Round 5: vmcnt retires in issue order, so with the weights requested first the prologue's own inputs (the LayerNorm row, the attention
+    // partials, the activation fragments: L2 hits) could not be used before the weights had landed — every launch of the one-sequence chain
+    // started its prologue one HBM round trip late (profiles/r05/isa_wait_order_before.txt).  Each prologue now requests its first inputs,
+    // calls load_weights(), and only then computes; sched_barriers keep the compiler from merging the two groups again.
     half8   wh[8];
     float4v wf[16];
-    if (WT == 1) {
-        const _Float16 *wp = (const _Float16 *) a.W + (int64_t) (n0 + li) * K + kz + w * 256 + g * 8;
+    auto load_weights = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (WT == 1) {
+            const _Float16 *wp = (const _Float16 *) a.W + (int64_t) (n0 + li) * K + kz + w * 256 + g * 8;
 #pragma unroll
-        for (int c = 0; c < 8; c++) wh[c] = __builtin_nontemporal_load((const half8 *) (wp + c * 32));
-    } else {
-        const float *wp = (const float *) a.W + (int64_t) (n0 + li) * K + kz + w * 256 + g * 4;
+            for (int c = 0; c < 8; c++) wh[c] = __builtin_nontemporal_load((const half8 *) (wp + c * 32));
+        } else {
+            const float *wp = (const float *) a.W + (int64_t) (n0 + li) * K + kz + w * 256 + g * 4;
 #pragma unroll
-        for (int c = 0; c < 16; c++) wf[c] = __builtin_nontemporal_load((const float4v *) (wp + c * 16));
-    }
+            for (int c = 0; c < 16; c++) wf[c] = __builtin_nontemporal_load((const float4v *) (wp + c * 16));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
     // ---- 2. prologue: LayerNorm of the R rows into LDS (fp16 for WT=1, fp32 for WT=0) -----------
     // One pass: the row (K <= 2048) is held in registers; rows >= R are not computed (their MFMA
@@ -219,84 +227,100 @@ __global__ __launch_bounds__(PRO == PRO_LN || PRO == PRO_ATTN ? 512 : 1024) void
         const float *A = (const float *) a.A;
         const int nk = K >> 8;   // chunks of 256 columns in a row (K % 256 == 0 on this path); wave-uniform
         // NI = chunks held in registers: 4 for K <= 1024 (leaves room for the slab fold), 8 up to K = 2048
-        auto ln_row = [&](int r, auto ni_c) {
+        auto ln_rows = [&](auto ni_c) __attribute__((always_inline)) {
             constexpr int NI = decltype(ni_c)::value;
-            const float *xr = A + (int64_t) r * a.lda;
             float4v v[NI], lwv[NI], lbv[NI];
-            float s = 0.0f;
+            float4v pp[4][4];
+            const bool fold = WT == 1 && NI == 4 && a.n_parts == 4;   // (the host splits fc2 only when every matrix is fp16)
+            auto load = [&](int r) __attribute__((always_inline)) {
+                const float *xr = A + (int64_t) r * a.lda;
 #pragma unroll
-            for (int i = 0; i < NI; i++) {  // x row and the affine parameters in one round trip
-                // straight-line loads: a chunk beyond the row (i >= nk, wave-uniform) re-reads chunk 0 and is never used.  Loads predicated on
-                // `k < K` became one basic block each and hipcc put an s_waitcnt between them: the row arrived in four dependent round trips.
-                const int k = (i < nk ? i * 256 : 0) + lane * 4;
-                v[i] = *(const float4v *) (xr + k);
-                lwv[i] = *(const float4v *) (a.ln_w + k);
-                lbv[i] = *(const float4v *) (a.ln_b + k);
-            }
-            if (WT == 1 && NI == 4 && a.n_parts == 4) {   // (the host splits fc2 only when every matrix is fp16)   // x + the previous fc2's slabs in slab order; same round trip (K <= 1024: i < 4)
-                float4v pp[4][4];
-#pragma unroll
-                for (int sp = 0; sp < 4; sp++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        pp[sp][i] = *(const float4v *) (a.parts + sp * a.parts_stride + (int64_t) r * a.lda + (i < nk ? i * 256 : 0) + lane * 4);
-#pragma unroll
-                for (int sp = 0; sp < 4; sp++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) v[i] += pp[sp][i];
-            }
-#pragma unroll
-            for (int i = 0; i < NI; i++)
-                if (i < nk) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-            const float mean = wave_sum(s) / (float) K;
-            float s2 = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NI; i++) {
-                if (i < nk) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { const float d = v[i][e] - mean; s2 += d * d; }
+                for (int i = 0; i < NI; i++) {  // x row and the affine parameters in one round trip
+                    // straight-line loads: a chunk beyond the row (i >= nk, wave-uniform) re-reads chunk 0 and is never used.  Loads predicated on
+                    // `k < K` became one basic block each and hipcc put an s_waitcnt between them: the row arrived in four dependent round trips.
+                    const int k = (i < nk ? i * 256 : 0) + lane * 4;
+                    v[i] = *(const float4v *) (xr + k);
+                    lwv[i] = *(const float4v *) (a.ln_w + k);
+                    lbv[i] = *(const float4v *) (a.ln_b + k);
                 }
-            }
-            const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float) K + LN_EPS);
+                if (fold) {   // x + the previous fc2's slabs in slab order; same round trip (K <= 1024: i < 4)
 #pragma unroll
-            for (int i = 0; i < NI; i++) {
-                const int k = i * 256 + lane * 4;
-                if (i < nk) {
-                    const float4v lw = lwv[i], lb = lbv[i];
-                    float4v y;
+                    for (int sp = 0; sp < 4; sp++)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) y[e] = (v[i][e] - mean) * rstd * lw[e] + lb[e];
-                    if (WT == 1) {
-                        half4 h;
+                        for (int i = 0; i < 4; i++)
+                            pp[sp][i] = *(const float4v *) (a.parts + sp * a.parts_stride + (int64_t) r * a.lda + (i < nk ? i * 256 : 0) + lane * 4);
+                }
+            };
+            auto finish = [&](int r) __attribute__((always_inline)) {
+                if (fold) {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) h[e] = (_Float16) y[e];
-                        *(half4 *) (xs16 + (size_t) r * ldx + k) = h;
-                    } else {
-                        *(float4v *) (xs32 + (size_t) r * ldx + k) = y;
+                    for (int sp = 0; sp < 4; sp++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) v[i] += pp[sp][i];
+                }
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NI; i++)
+                    if (i < nk) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+                const float mean = wave_sum(s) / (float) K;
+                float s2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    if (i < nk) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { const float d = v[i][e] - mean; s2 += d * d; }
                     }
                 }
-            }
+                const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float) K + LN_EPS);
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    const int k = i * 256 + lane * 4;
+                    if (i < nk) {
+                        const float4v lw = lwv[i], lb = lbv[i];
+                        float4v y;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) y[e] = (v[i][e] - mean) * rstd * lw[e] + lb[e];
+                        if (WT == 1) {
+                            half4 h;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) h[e] = (_Float16) y[e];
+                            *(half4 *) (xs16 + (size_t) r * ldx + k) = h;
+                        } else {
+                            *(float4v *) (xs32 + (size_t) r * ldx + k) = y;
+                        }
+                    }
+                }
+            };
+            // this wave's first row (a wave without one re-reads the last row and drops it), the weights behind it, then the arithmetic
+            // (fp32 weights: 64 registers of fragments beside a 2048-wide row — the old order, or the pair spills)
+            if (WT == 0) load_weights();
+            load(min(wave, a.R - 1));
+            if (WT == 1) load_weights();
+            if (wave < a.R) finish(wave);
+            for (int r = wave + nw * ngs; r < a.R; r += nw * ngs) { load(r); finish(r); }
         };
-        for (int r = wave; r < a.R; r += nw * ngs) {
-            if (K <= 1024) ln_row(r, std::integral_constant<int, 4>{});
-            else ln_row(r, std::integral_constant<int, 8>{});
-        }
+        if (K <= 1024) ln_rows(std::integral_constant<int, 4>{});
+        else ln_rows(std::integral_constant<int, 8>{});
         red_off = (size_t) RB * 16 * ldx * (WT == 1 ? 2 : 4);
         red_off = (red_off + 15) & ~(size_t) 15;
         __syncthreads();
     }
     if (PRO == PRO_ATTN) {   // WT == 1
         const int nq = K >> 2, nz = a.att_nz;   // K = att_heads * 64
-        for (int idx = tid; idx < a.R * nq; idx += blockDim.x) {
+        const int n_items = a.R * nq;
+        float mm[16], ss[16];
+        float4v oo[16];
+        auto load = [&](int idx) __attribute__((always_inline)) {
             const int r = idx / nq, c4 = (idx - r * nq) * 4, h = c4 >> 6, d = c4 & 63;
             const float *p = a.att_part + ((int64_t) r * a.att_heads + h) * nz * ATT_PS;
-            float mm[16], ss[16];
-            float4v oo[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) {   // straight-line loads (a split beyond nz re-reads the last one, see the LayerNorm prologue)
                 const int ic = i < nz ? i : nz - 1;
                 mm[i] = p[ic * ATT_PS]; ss[i] = p[ic * ATT_PS + 1]; oo[i] = *(const float4v *) (p + ic * ATT_PS + ATT_PO + d);
             }
+        };
+        auto finish = [&](int idx) __attribute__((always_inline)) {
+            const int r = idx / nq, c4 = (idx - r * nq) * 4;
             float gmx = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 16; i++) if (i < nz) gmx = fmaxf(gmx, mm[i]);
@@ -315,18 +339,53 @@ __global__ __launch_bounds__(PRO == PRO_LN || PRO == PRO_ATTN ? 512 : 1024) void
 #pragma unroll
             for (int e = 0; e < 4; e++) hh[e] = (_Float16) (ot[e] / st);
             *(half4 *) (xs16 + (size_t) r * ldx + c4) = hh;
-        }
+        };
+        // this thread's first item (a thread without one re-reads the last item and drops it), the weights behind it, then the merge
+        load(min(tid, n_items - 1));
+        load_weights();
+        if (tid < n_items) finish(tid);
+        for (int idx = tid + (int) blockDim.x; idx < n_items; idx += blockDim.x) { load(idx); finish(idx); }
         red_off = (size_t) RB * 16 * ldx * 2;
         red_off = (red_off + 15) & ~(size_t) 15;
         __syncthreads();
+    }
+    // activations straight from memory (PRO_F16 / PRO_F32): the fragments of the first row group ahead of the weights when a group is one
+    // row block (<= 16 rows per group: the one-sequence chain and the small lock-step batches); larger groups keep the weights in front
+    const int r_lo = a.rows_per_z ? (int) blockIdx.z * a.rows_per_z : 0;
+    const int r_hi = a.rows_per_z ? min(a.R, r_lo + a.rows_per_z) : a.R;
+    constexpr bool PRELOAD = WT == 1 && RB == 1 && (PRO == PRO_F16 || PRO == PRO_F32);
+    half8 bpre[8];
+    if (PRO != PRO_LN && PRO != PRO_ATTN) {
+        if (PRELOAD) {
+            const int r = r_lo + gs * 16 + li;
+            const int rr = max(0, min(r, r_hi - 1));
+            const int kb = kz + w * 256 + g * 8;
+            if (PRO == PRO_F16) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) bpre[c] = *(const half8 *) ((const _Float16 *) a.A + (int64_t) rr * a.lda + kb + c * 32);
+                load_weights();
+            } else {
+                float4v f[16];
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const float *p = (const float *) a.A + (int64_t) rr * a.lda + kb + c * 32;
+                    f[2 * c] = *(const float4v *) p; f[2 * c + 1] = *(const float4v *) (p + 4);
+                }
+                load_weights();
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { bpre[c][e] = (_Float16) f[2 * c][e]; bpre[c][4 + e] = (_Float16) f[2 * c + 1][e]; }
+            }
+        } else {
+            load_weights();
+        }
     }
     B1_STAMP(a.stamps, 1);
 
     // ---- 3-5. for every group of 16*RB rows: MFMA over this wave's 256-wide K slice, reduce the K slices
     //           across waves, epilogue.  The weight fragments stay in registers across row groups, so many
     //           lock-step utterances cost one pass over the weights.
-    const int r_lo = a.rows_per_z ? (int) blockIdx.z * a.rows_per_z : 0;
-    const int r_hi = a.rows_per_z ? min(a.R, r_lo + a.rows_per_z) : a.R;
     const int n_groups = (r_hi - r_lo + 16 * RB - 1) / (16 * RB);
     const int n_rounds = (n_groups + ngs - 1) / ngs;   // uniform trip count: every wave reaches every barrier
     for (int rd = 0; rd < n_rounds; rd++) {
@@ -341,21 +400,26 @@ __global__ __launch_bounds__(PRO == PRO_LN || PRO == PRO_ATTN ? 512 : 1024) void
             const int rr = r < r_hi ? r : r_hi - 1;
             if (WT == 1) {
                 const int kb = kz + w * 256 + g * 8;
+                if (PRELOAD && rd == 0) {   // (wave-uniform) the first group's fragments were requested ahead of the weights
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    half8 b;
-                    const int k = kb + c * 32;
-                    if (PRO == PRO_LN || PRO == PRO_ATTN) {
-                        b = *(const half8 *) (xs16 + (size_t) r * ldx + k);
-                    } else if (PRO == PRO_F16) {
-                        b = *(const half8 *) ((const _Float16 *) a.A + (int64_t) rr * a.lda + k);
-                    } else {
-                        const float *p = (const float *) a.A + (int64_t) rr * a.lda + k;
-                        const float4v f0 = *(const float4v *) p, f1 = *(const float4v *) (p + 4);
+                    for (int c = 0; c < 8; c++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], bpre[c], acc[rb], 0, 0, 0);
+                } else {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) { b[e] = (_Float16) f0[e]; b[4 + e] = (_Float16) f1[e]; }
+                    for (int c = 0; c < 8; c++) {
+                        half8 b;
+                        const int k = kb + c * 32;
+                        if (PRO == PRO_LN || PRO == PRO_ATTN) {
+                            b = *(const half8 *) (xs16 + (size_t) r * ldx + k);
+                        } else if (PRO == PRO_F16) {
+                            b = *(const half8 *) ((const _Float16 *) a.A + (int64_t) rr * a.lda + k);
+                        } else {
+                            const float *p = (const float *) a.A + (int64_t) rr * a.lda + k;
+                            const float4v f0 = *(const float4v *) p, f1 = *(const float4v *) (p + 4);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { b[e] = (_Float16) f0[e]; b[4 + e] = (_Float16) f1[e]; }
+                        }
+                        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], b, acc[rb], 0, 0, 0);
                     }
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], b, acc[rb], 0, 0, 0);
                 }
             } else {
                 const int kb = kz + w * 256 + g * 4;
