@@ -879,47 +879,6 @@ __global__ __launch_bounds__(1024) void attn_rows_kernel(AttnArgs a) {
     }
 }
 
-// The unsplit form of attn_kernel (256 threads, one (head, row) item at a time) as a workgroup that WALKS items: the grid is a fixed number of
-// workgroups per CU instead of one per item.  A 1024-row forward launches 16 384 items; as one-item workgroups they fill all 32 wave slots of
-// every CU for the whole launch, and the GEMM workgroups of another runner's step (8 waves, 128 KB of LDS) never find room beside them — two
-// decoder loops side by side gained 1.19x, no more (profiles/r04/dec_overlap_product_kernels.txt).  Six walking workgroups per CU (24 waves,
-// 336 of the 512 registers per SIMD, 26 KB of LDS) leave exactly the room a tiled GEMM workgroup needs.  Same arithmetic per item.
-static __global__ __launch_bounds__(256) void attn_walk_kernel(AttnArgs a, int n_items) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NKG = 16;
-    float *red = (float *) smem;                 // [NKG][64] acc, [NKG] max, [NKG] sum
-    const int tid = threadIdx.x, kg = tid >> 4, cl = tid & 15, c4 = cl * 4;
-    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const int h = it % a.n_heads, r = it / a.n_heads;
-        const int T = a.row_pos ? (int) a.row_pos[r] + 1 : a.T_fixed;
-        const int64_t sb = a.row_seq ? (int64_t) a.row_seq[r] * a.seq_stride : 0;
-        const int64_t hb = sb + h * 64 + c4;
-        const float4v q4 = *(const float4v *) (a.q + (int64_t) r * a.H + h * 64 + c4);
-        float m = -INFINITY, l = 0.0f;
-        float4v acc = {0.f, 0.f, 0.f, 0.f};
-        if (a.kv_f16) attn_key_pass<true>(a, hb, q4, kg, T, NKG * 4, NKG, m, l, acc);
-        else attn_key_pass<false>(a, hb, q4, kg, T, NKG * 4, NKG, m, l, acc);
-        if (cl == 0) red[NKG * 64 + kg] = m;
-        __syncthreads();
-        float mx = -INFINITY;
-        for (int i = 0; i < NKG; i++) mx = fmaxf(mx, red[NKG * 64 + i]);
-        const float f = (m == -INFINITY) ? 0.0f : expf(m - mx);
-#pragma unroll
-        for (int e = 0; e < 4; e++) acc[e] *= f;
-        *(float4v *) (red + kg * 64 + c4) = acc;
-        if (cl == 0) red[NKG * 65 + kg] = l * f;
-        __syncthreads();
-        if (tid < 64) {
-            float o = 0.0f, sm = 0.0f;
-            for (int i = 0; i < NKG; i++) { o += red[i * 64 + tid]; sm += red[NKG * 65 + i]; }
-            const float res = o / sm;
-            if (a.out16) a.out16[(int64_t) r * a.H + h * 64 + tid] = (_Float16) res;
-            else a.out[(int64_t) r * a.H + h * 64 + tid] = res;
-        }
-        __syncthreads();   // red is reused by the next item
-    }
-}
-
 // Cross-attention over a short voice prompt (T_fixed <= 32 encoder positions; Parler-Mini: 8..40): the general kernel
 // spends its time in workgroup merges and idle key groups there (18 us per layer at 384 rows).  One wave per (row, head):
 // lane = channel of the 64-wide head, every K / V row is one coalesced 256-B load, the score of a key is a wave reduction,

@@ -135,7 +135,6 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     // tts_hip_tune() key: a harness under profiles/ can still flip it, a deployment cannot flip it by accident.
     if (const char *e = getenv("TTS_HIP_ATTN_NSPLIT")) c->attn_nsplit_override = atoi(e);
     if (const char *e = getenv("TTS_HIP_ATTN_ROWS")) c->attn_rows_min = std::max(0, atoi(e));                                                 // bench.py A/B, test_gpu_parler.py: row-major self-attention from this many rows (0: never)
-    if (const char *e = getenv("TTS_HIP_ATTN_WALK")) c->attn_walk = std::max(0, std::min(8, atoi(e)));                                          // bench.py --attn-walk                       // test_gpu_parler.py: key splits of the self-attention
     if (const char *e = getenv("TTS_HIP_DAC_GROUP")) c->dac_group = std::max(1, atoi(e));                       // test_gpu_dac.py, bench.py: utterances per codec pass
     if (const char *e = getenv("TTS_HIP_DAC_BF16X3")) (void) tts_hip_tune(c, "dac_exact_fp32", atoi(e) == 0);  // test_gpu_dac.py: 0 = the exact-fp32 MFMA codec
     if (const char *e = getenv("TTS_HIP_GEN_COMPACT")) c->gen_compact = atoi(e) != 0;                           // test_gpu_runner.py: row compaction of the generation loop
@@ -165,7 +164,6 @@ extern "C" int tts_hip_tune(tts_hip_ctx *c, const char *key, int v) {
     else if (k == "kokoro_lstm_split") c->kk_lstm_split = v != 0;
     else if (k == "ln_fuse_max") c->ln_fuse_max = std::max(0, std::min(32, v));
     else if (k == "attn_short") c->attn_short = v != 0;
-    else if (k == "attn_walk") c->attn_walk = std::max(0, std::min(8, v));
     else if (k == "attn_rows_min") c->attn_rows_min = std::max(0, v);
     else if (k == "attn_fused") c->attn_fused = v != 0;
     else if (k == "attn_split") c->attn_split_max = std::max(1, std::min(16, v));

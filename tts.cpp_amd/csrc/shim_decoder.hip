@@ -528,13 +528,6 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
         }
         return prof_end(c);
     }
-    if (nsplit == 1 && !wide && c->attn_walk > 0 && c->NH * R >= 4096) {
-        // many (head, row) items: a fixed number of workgroups per CU walk them, so that another runner's GEMM workgroups find room on every CU
-        const int grid = std::min(c->NH * R, 256 * c->attn_walk);
-        hipLaunchKernelGGL(attn_walk_kernel, dim3(grid), dim3(256), lds, c->stream, a, c->NH * R);
-        HIPCHK(hipGetLastError());
-        return prof_end(c);
-    }
     const bool fused = nsplit > 1 && c->attn_fused && c->attn_cnt != nullptr && !defer_combine;
     a.counters = fused ? c->attn_cnt : nullptr;
     hipLaunchKernelGGL(attn_kernel, dim3(c->NH, R, nsplit), dim3(threads), lds, c->stream, a);

@@ -266,11 +266,10 @@ struct tts_hip_ctx {
     int *kk_stuck = nullptr;    // set by kk_lstm_split_kernel when a granule never arrives (bounded spin)
     bool kk_b3 = true;          // tune("kokoro_b3") = 0: Kokoro's k = 3 / 5 / 7 / 11 same-convolutions stay on the exact-fp32 MFMA kernel instead of bf16 x 3 split products
     bool kk_mfma = true;        // tune("kokoro_mfma")=0: every Kokoro convolution through the one-thread-per-output kernel
+    bool attn_short = true;     // tune("attn_short")=0: cross-attention through the general kernel
     int dac_group = 64;         // TTS_HIP_DAC_GROUP: utterances per codec pass (16: 451, 32: 458, 64: 461, 128: 460, 384: 462 audio-s/s at 3 x 384)
     bool dac_conv1_direct = true;   // tune("dac_conv1_direct")=0: the 96- / 192-channel k=1 convs stay on conv1d_mfma_kernel<1,...>
     int attn_rows_min = 256;    // tune("attn_rows_min") / TTS_HIP_ATTN_ROWS: forwards with at least this many rows run the self-attention one workgroup per ROW (attn_rows_kernel); 0 = never
-    int attn_walk = 0;          // tune("attn_walk"): > 0 = the self-attention of a many-row forward as this many walking workgroups per CU (attn_walk_kernel)
-    bool attn_short = true;     // tune("attn_short")=0: cross-attention through the general kernel
     int tile_min_rows = 33;     // forwards with at least this many rows take the LDS-tiled GEMM (gemm_tile_kernels.h); 0 = never
     int tile_force = -1;        // TTS_HIP_TILE_FORCE: tile shape index for every tiled GEMM (tuning)
     int tile_force_ks = 0;      // TTS_HIP_TILE_KS: k slices for the residual GEMMs (tuning)
