@@ -380,6 +380,100 @@ __global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, i
     if (tid == 0) { pz[0] = mx; pz[1] = (red[4] + red[5]) + (red[6] + red[7]); }
 }
 
+// attn_gqa_split_kernel's job for the captured one-row step of a Llama decoder, restructured so that the launch is ONE memory round trip with
+// one workgroup barrier (round 5; the split kernel above is a chain of seven: position -> q -> K batch -> scores -> max -> exp / sum -> V -> merge,
+// 8.5 us per launch for 2.4 MB of cache at the Orpheus-3B shapes, profiles/r05/kernel_stats_orpheus_call1.csv):
+//   * the keys a (slice, wave, 16-lane group) reads do not depend on the position: key j belongs to slice (j / 16) % nz, inside the slice to group
+//     j % 16 (= wave * 4 + lane / 16) and pass j / (16 nz).  Every lane therefore requests the K and V rows of its first U passes the moment the
+//     kernel starts — together with q and the position, not behind them; keys at or beyond the position are masked afterwards (they are rows of the
+//     cache allocation: readable, never used);
+//   * a 16-lane group owns its keys from first to last with a running max / sum / output (soft_max_ext + mul_mat as one pass, as attn_rows_kernel
+//     does for Parler): no score buffer, no barrier inside the key loop;
+//   * the 4 groups of a wave merge by permlane swaps, the 4 waves through LDS with the only barrier of the kernel.
+// A lane holds dims 4 sub .. + 3 and 64 + 4 sub .. + 3 of the 128-wide head (sub = lane % 16): a K or V row is read as 512 contiguous bytes.
+// The partials have attn_gqa_split_kernel's meaning (max, sum, unnormalised out[128] of the slice's keys; an empty slice leaves -inf, 0), so
+// attn_gqa_combine_kernel follows unchanged.  Another association of the same softmax than the kernel above: results agree to rounding.
+template <int HD, int U>
+__global__ __launch_bounds__(256) void attn_gqa_wave_kernel(const float *qkv, int ld, const uint32_t *pos, const float *kcache, const float *vcache, int NH, int NKV,
+                                                            float scale, float *part, int n_ctx) {
+    static_assert(HD == 128, "lane mapping below is written for head_dim 128");
+    __shared__ float s_m[4], s_l[4];
+    __shared__ __attribute__((aligned(16))) float s_acc[4][HD];
+    const int h = blockIdx.x, r = blockIdx.y, z = blockIdx.z, nz = gridDim.z, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, sub = lane & 15, gi = wave * 4 + g;
+    const int kvH = NKV * HD, kh = h / (NH / NKV);
+    const float *kp = kcache + kh * HD + sub * 4, *vp = vcache + kh * HD + sub * 4;
+    auto key_of = [&](int p) { return 16 * (nz * p + z) + gi; };
+    float4 ka[U], kb[U], va[U], vb[U];
+    auto request = [&](int p0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t off = (int64_t) min(key_of(p0 + u), n_ctx - 1) * kvH;
+            ka[u] = *(const float4 *) (kp + off); kb[u] = *(const float4 *) (kp + off + 64);
+            va[u] = *(const float4 *) (vp + off); vb[u] = *(const float4 *) (vp + off + 64);
+        }
+    };
+    // the small inputs first (vmcnt retires in issue order: the position and q are usable while the rows below are still in flight)
+    const float *qr = qkv + (int64_t) r * ld + h * HD + sub * 4;
+    const float4 q0 = *(const float4 *) qr, q1 = *(const float4 *) (qr + 64);
+    const int T = (int) pos[r] + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    request(0);
+    __builtin_amdgcn_sched_barrier(0);
+    float m = -INFINITY, l = 0.0f;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    for (int p0 = 0; 16 * nz * p0 < T; p0 += U) {
+        if (p0) request(p0);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (key_of(p0 + u) < T) {
+                float d = (ka[u].x * q0.x + ka[u].y * q0.y + ka[u].z * q0.z + ka[u].w * q0.w) + (kb[u].x * q1.x + kb[u].y * q1.y + kb[u].z * q1.z + kb[u].w * q1.w);
+                d = row16_sum(d) * scale;
+                const float mn = fmaxf(m, d);
+                const float f = expf(m - mn);   // 0 on the group's first key (m = -inf)
+                const float pr = expf(d - mn);
+                l = l * f + pr;
+                a0.x = a0.x * f + pr * va[u].x; a0.y = a0.y * f + pr * va[u].y; a0.z = a0.z * f + pr * va[u].z; a0.w = a0.w * f + pr * va[u].w;
+                a1.x = a1.x * f + pr * vb[u].x; a1.y = a1.y * f + pr * vb[u].y; a1.z = a1.z * f + pr * vb[u].z; a1.w = a1.w * f + pr * vb[u].w;
+                m = mn;
+            }
+        }
+    }
+    // the wave's four groups (lanes sub, 16 + sub, 32 + sub, 48 + sub hold the same dims): common max, rescale, add
+    auto x16 = [](float v) { const unsigned w = __builtin_bit_cast(unsigned, v); const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+                             return make_float2(__builtin_bit_cast(float, (unsigned) b[0]), __builtin_bit_cast(float, (unsigned) b[1])); };
+    auto x32 = [](float v) { const unsigned w = __builtin_bit_cast(unsigned, v); const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+                             return make_float2(__builtin_bit_cast(float, (unsigned) b[0]), __builtin_bit_cast(float, (unsigned) b[1])); };
+    float mw;
+    { float2 t = x16(m); mw = fmaxf(t.x, t.y); t = x32(mw); mw = fmaxf(t.x, t.y); }
+    const float fg = m == -INFINITY ? 0.0f : expf(m - mw);
+    float vals[9] = {l * fg, a0.x * fg, a0.y * fg, a0.z * fg, a0.w * fg, a1.x * fg, a1.y * fg, a1.z * fg, a1.w * fg};
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        float2 t = x16(vals[i]); float v = t.x + t.y;
+        t = x32(v); vals[i] = t.x + t.y;
+    }
+    if (g == 0) {
+        *(float4 *) (&s_acc[wave][sub * 4]) = make_float4(vals[1], vals[2], vals[3], vals[4]);
+        *(float4 *) (&s_acc[wave][64 + sub * 4]) = make_float4(vals[5], vals[6], vals[7], vals[8]);
+        if (sub == 0) { s_m[wave] = mw; s_l[wave] = vals[0]; }
+    }
+    __syncthreads();
+    if (tid < HD) {
+        const float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        float o = 0.0f, L = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const float f = s_m[w] == -INFINITY ? 0.0f : expf(s_m[w] - M);
+            o += f * s_acc[w][tid];
+            L += f * s_l[w];
+        }
+        float *pz = part + (((int64_t) r * NH + h) * nz + z) * ATTN_PART;
+        pz[2 + tid] = o;
+        if (tid == 0) { pz[0] = M; pz[1] = L; }
+    }
+}
+
 // one 128-thread workgroup per (head, row): out = sum_z e^(m_z - m) o_z / sum_z e^(m_z - m) l_z, splits in order.
 // Every slice is requested straight-line with a clamped index (a slice beyond nz re-reads the last one and is never used): as `for (z < nz)` loops
 // with the -inf test on a loaded value this kernel was nz dependent L2 round trips — 4.9 us per launch for 24 KB of partials in the Orpheus step

@@ -36,7 +36,7 @@ extern "C" tts_hip_ctx *tts_hip_orpheus_create(int device, const tts_hip_orpheus
 // plus a combine launch (attn_gqa_split_kernel).  max_keys bounds the LDS score buffer.
 static int launch_attn_gqa(tts_hip_ctx *c, int NHq, int rows, int max_keys, const float *qkv, int ld, const uint32_t *pos, const float *kc, const float *vc, int NKV,
                            float scale, float *out, const uint32_t *kbeg, const uint32_t *kend, const uint32_t *row_seq, int64_t seq_stride, bool fixed_split, bool q_out = false,
-                           QPre qp = QPre{}, int *deferred = nullptr) {
+                           QPre qp = QPre{}, int *deferred = nullptr, int n_ctx_keys = 0) {
     int nz = 1;
     if (deferred) *deferred = 0;
     if (c->attn_split_max > 1 && NHq * rows <= 256) {
@@ -52,8 +52,13 @@ static int launch_attn_gqa(tts_hip_ctx *c, int NHq, int rows, int max_keys, cons
         return 0;
     }
     const int chunk = (max_keys + nz - 1) / nz;
-    hipLaunchKernelGGL(attn_gqa_split_kernel<128>, dim3(NHq, rows, nz), dim3(256), (size_t) (128 + chunk + 1) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part,
-                       kbeg, kend, row_seq, seq_stride, qp);
+    if (c->attn_wave && !kbeg && !kend && !row_seq && qp.n_parts == 1 && !qp.rope_pos && n_ctx_keys > 0) {
+        // the captured one-row step (Orpheus): every key row requested at kernel start, online softmax per 16-lane group, one barrier (attn_gqa_wave_kernel)
+        hipLaunchKernelGGL((attn_gqa_wave_kernel<128, 4>), dim3(NHq, rows, nz), dim3(256), 0, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part, n_ctx_keys);
+    } else {
+        hipLaunchKernelGGL(attn_gqa_split_kernel<128>, dim3(NHq, rows, nz), dim3(256), (size_t) (128 + chunk + 1) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part,
+                           kbeg, kend, row_seq, seq_stride, qp);
+    }
     HIPCHK(hipGetLastError());
     if (deferred && c->attn_fold && nz == ATTN_FOLD_NZ && !c->prof && !c->debug) {
         *deferred = nz;   // the caller's next projection merges the slices in its staging prologue (gemv_stream_kernel<.., PRO_ATTN8, ..>); `out` is not written
@@ -154,7 +159,7 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
         }
         CHK(launch_attn_gqa(c, NH, n, (int) (attn_positions ? (uint32_t) attn_positions : pos0 + n), (const float *) c->l_qkv, QKV, (const uint32_t *) c->l_pos,
                             (const float *) kc, (const float *) vc, NKV, 1.0f / sqrtf((float) HD), c->l_att, nullptr, nullptr, nullptr, (int64_t) 0, attn_positions != 0,
-                            q_for(y.o, n)));
+                            q_for(y.o, n), QPre{}, nullptr, NCTX));
         CHK(llama_gemm(c, y.o, c->l_att, NH * HD, c->l_x, H, n, EPI_RESID));
         const size_t gu_lds = (size_t) n * H + (size_t) n * (H / 32) * 4, dn_lds = (size_t) n * F + (size_t) n * (F / 32) * 4;
         const bool gu_fused = c->q4_silu && c->q4_lds && y.gu.q4 && y.down.q4 && q_for(y.gu, n) && q_for(y.down, n) && H % 512 == 0 && F % 512 == 0 &&
