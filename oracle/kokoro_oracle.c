@@ -675,3 +675,32 @@ int64_t orc_kokoro_generate(const orc_kokoro_model *m, const uint32_t *tokens, i
     free(curves[0]); free(curves[1]); free(shc); free(sh); free(en); free(tok_of);
     return out_len;
 }
+
+/* ---- stage entry points (test infrastructure, round 5) -------------------------------------------------------------------------------
+ * One upstream module each, so that tests/test_upstream_golden.py can hold the restatement above against PyTorch's own definitions of the
+ * stages the whole-graph fixture (tests/golden/tiny_kokoro.npz, wired by this repository's author) only covers indirectly:
+ *   orc_kk_stage_bilstm      build_lstm / build_lstm_run (kokoro/model.cpp:35-86)             <-> torch.nn.LSTM(bidirectional), weights split per
+ *                                                                                               gate as kokoro_gguf_encoder.py:289-309 writes them
+ *   orc_kk_stage_ada_block   build_ada_residual_conv (:88-134): AdaIN = instance norm + style   <-> F.instance_norm, nn.Linear, F.conv_transpose1d(groups = C,
+ *                            affine, leaky relu, depthwise transposed-conv pool, 1x1 shortcut       stride 2, padding 1, output_padding 1), F.conv1d, F.interpolate
+ *   orc_kk_stage_stft/istft  stft / istft (util.cpp:111-133) + compute_window_squared_sum       <-> torch.stft / torch.istft (center, reflect, onesided)
+ *                            (util.cpp:203-217)
+ * The tensors a stage needs are looked up by name in `m` exactly like the full graphs do. */
+void orc_kk_stage_bilstm(const orc_kokoro_model *m, const char *base, const float *x, int L, int in, int hid, float *out) {
+    bilstm(m, base, x, L, in, hid, out);
+}
+int64_t orc_kk_stage_ada_block(const orc_kokoro_model *m, const char *base, const float *x, int C, int64_t L, const float *style, int S, float *out, int32_t *C_out) {
+    int c = C;
+    int64_t lo = 0;
+    float *y = ada_res_block(m, base, x, L, style, S, &c, &lo);
+    memcpy(out, y, (size_t) c * lo * sizeof(float));
+    free(y);
+    *C_out = c;
+    return lo;
+}
+void orc_kk_stage_stft(const float *x, int64_t L, const float *win, int N, int hop, float *mag, float *ph) {
+    stft_mag_phase(x, L, win, N, hop, mag, ph, L / hop + 1);
+}
+void orc_kk_stage_istft(const float *mag, const float *ph, int64_t F, const float *win, int N, int hop, float *out, int64_t out_len) {
+    istft_mag_phase(mag, ph, F, win, N, hop, out, out_len);
+}

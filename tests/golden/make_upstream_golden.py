@@ -20,6 +20,8 @@ tests/test_upstream_golden.py feeds those tensors to the oracle and compares.
   orpheus tokenizer tokenizers.models.BPE, byte-level                             orpheus_gguf_encoder.py:231-242
   delay pattern     MusicgenForCausalLM.build / apply_delay_pattern_mask          (no converter rule: generation logic, model.cpp:734-785)
   kokoro albert     transformers AlbertModel (kokoro's `bert` is one)             kokoro_gguf_encoder.py:14-37, :274-287
+  kokoro stages     torch.nn.LSTM, F.instance_norm, F.conv_transpose1d(groups,    kokoro_gguf_encoder.py:289-309 (LSTM gate split); kokoro/model.cpp:35-134,
+  + snac depthwise  output_padding), torch.stft / istft, F.conv1d(groups)        util.cpp:111-133, 203-217; decoder/snac_model.cpp:86-110
   parler decoder    transformers MusicgenForCausalLM (Parler-TTS' decoder is a    parler_tts_gguf_encoder.py:112-130
                     fork of it: same modules and parameter names; parler_tts
                     itself is not installed here)
@@ -592,8 +594,93 @@ def make_albert():
     print("albert:", tuple(out.shape), "max |out|", float(out.abs().max()))
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+def make_kokoro_stages():
+    """Stage fixtures for the parts of the Kokoro graph beyond ALBERT and for SNAC's depthwise block, each computed by ONE PyTorch module or
+    functional in float64 (nothing of this repository in between) and stored with the tensors under the names / split rules of the converter:
+      lstm      torch.nn.LSTM(bidirectional): weight_ih / weight_hh / bias_ih / bias_hh of both directions, split into the four gate blocks
+                i, f, g, o and interleaved ih, hh as kokoro_gguf_encoder.py:289-309 (prepare_lstm_tensor) does       <-> kokoro/model.cpp:35-86
+      ada       AdainResBlk1d with upsampling, from its constituents: F.instance_norm + nn.Linear style affine (1 + gamma) x + beta, leaky relu 0.2,
+                F.conv_transpose1d(groups = C, k 3, stride 2, padding 1, output_padding 1) — the fork's ggml_conv_transpose_1d(.., 2, 1, 1, 1, C)
+                call —, F.conv1d k 3, shortcut = nearest x2 + conv1x1, (y + s) / sqrt 2                                  <-> kokoro/model.cpp:88-134
+      stft      torch.stft(center, reflect, onesided) magnitude / angle and torch.istft of (exp, sin)-shaped inputs       <-> util.cpp:111-133, 203-217
+      snac_dw   F.conv1d(groups = C, k 7, dilation d, padding 3 d): SNAC's depthwise residual conv                     <-> decoder/snac_model.cpp:86-110
+    The istft output is rescaled from torch's window envelope (its F frames) to the reference's compute_window_squared_sum (out_len / hop +
+    n_fft / 2 / hop frames), the one documented difference between the two definitions."""
+    import torch.nn.functional as Fn
+    torch.manual_seed(1013)
+    out = {}
+    # ---- lstm
+    L, IN, HID = 11, 12, 5
+    lstm = torch.nn.LSTM(IN, HID, batch_first=True, bidirectional=True).double().eval()
+    with torch.no_grad():
+        for p in lstm.parameters():
+            p.copy_((0.5 * torch.randn_like(p)).to(torch.float32).to(torch.float64))
+    x = torch.randn(L, IN, dtype=torch.float64).to(torch.float32).to(torch.float64)
+    with torch.no_grad():
+        y, _ = lstm(x[None])
+    out["lstm_x"], out["lstm_y"], out["lstm_dims"] = npy(x).astype(np.float32), npy(y[0]), np.array([L, IN, HID])
+    for name, param in lstm.named_parameters():                      # prepare_lstm_tensor, layer 0
+        data = npy(param).astype(np.float32)
+        blocks = [data[i * (data.shape[0] // 4):(i + 1) * (data.shape[0] // 4)] for i in range(4)]
+        part = ("reverse_" if "reverse" in name else "") + ("weights" if "weight" in name else "biases")
+        for i, d in enumerate(blocks):
+            out[f"t:stage.lstm.0.{part}.{i * 2 if '_ih_' in name else i * 2 + 1}"] = d
+    # ---- ada block (upsampling, with a 1x1 shortcut)
+    C, CO, S, LA = 6, 10, 7, 9
+    style = torch.randn(S, dtype=torch.float64).to(torch.float32).to(torch.float64)
+    xa = torch.randn(1, C, LA, dtype=torch.float64).to(torch.float32).to(torch.float64)
+    P = {}
+    def mk(name, *shape, scale=0.4):
+        P[name] = (scale * torch.randn(*shape, dtype=torch.float64)).to(torch.float32).to(torch.float64)
+        return P[name]
+    for k, ch in (("norm1", C), ("norm2", CO)):
+        mk(f"{k}_gamma_weight", ch, S); mk(f"{k}_gamma_bias", ch); mk(f"{k}_beta_weight", ch, S); mk(f"{k}_beta_bias", ch)
+    mk("pool_weight", C, 1, 3); mk("pool_bias", C)
+    mk("conv1_weight", CO, C, 3); mk("conv1_bias", CO); mk("conv2_weight", CO, CO, 3); mk("conv2_bias", CO); mk("conv1x1_weight", CO, C, 1)
+    def adain(v, k):
+        g = Fn.linear(style, P[f"{k}_gamma_weight"], P[f"{k}_gamma_bias"]); b = Fn.linear(style, P[f"{k}_beta_weight"], P[f"{k}_beta_bias"])
+        return (1 + g)[None, :, None] * Fn.instance_norm(v, eps=1e-5) + b[None, :, None]
+    ya = Fn.leaky_relu(adain(xa, "norm1"), 0.2)
+    ya = Fn.conv_transpose1d(ya, P["pool_weight"], P["pool_bias"], stride=2, padding=1, output_padding=1, groups=C)
+    ya = Fn.conv1d(ya, P["conv1_weight"], P["conv1_bias"], padding=1)
+    ya = Fn.conv1d(Fn.leaky_relu(adain(ya, "norm2"), 0.2), P["conv2_weight"], P["conv2_bias"], padding=1)
+    sa = Fn.conv1d(Fn.interpolate(xa, scale_factor=2, mode="nearest"), P["conv1x1_weight"])
+    out["ada_x"], out["ada_style"], out["ada_y"], out["ada_dims"] = npy(xa[0]).astype(np.float32), npy(style).astype(np.float32), npy((ya + sa)[0] / math.sqrt(2.0)), np.array([C, CO, S, LA])
+    for k, v in P.items():
+        out["t:stage.ada." + k] = npy(v).astype(np.float32)
+    # ---- stft / istft
+    N, hop, LS = 20, 5, 120
+    win = torch.sin(math.pi * torch.arange(N, dtype=torch.float64) / N) ** 2
+    sig = torch.randn(LS, dtype=torch.float64).to(torch.float32).to(torch.float64)
+    spec = torch.stft(sig, N, hop, N, window=win, center=True, pad_mode="reflect", return_complex=True)
+    out["stft_x"], out["stft_win"], out["stft_mag"], out["stft_ph"], out["stft_dims"] = npy(sig).astype(np.float32), npy(win).astype(np.float32), npy(spec.abs()), npy(spec.angle()), np.array([N, hop, LS])
+    mag = torch.exp(0.3 * torch.randn(N // 2 + 1, spec.shape[1], dtype=torch.float64)).to(torch.float32).to(torch.float64)
+    ph = torch.sin(torch.randn(N // 2 + 1, spec.shape[1], dtype=torch.float64)).to(torch.float32).to(torch.float64)
+    ph[0], ph[-1] = 0.0, 0.0                                                   # a real signal has real DC / Nyquist bins
+    out_len = LS
+    yi = torch.istft(torch.polar(mag, ph), N, hop, N, window=win, center=True, length=out_len)
+    w2 = npy(win) ** 2
+    env_t, env_r = np.zeros(out_len + 2 * N), np.zeros(out_len + 2 * N)
+    for f in range(spec.shape[1]):
+        env_t[f * hop:f * hop + N] += w2
+    for f in range(out_len // hop + (N // 2) // hop):                          # compute_window_squared_sum (util.cpp:203-217)
+        env_r[f * hop:f * hop + N] += w2
+    half = N // 2
+    out["istft_mag"], out["istft_ph"] = npy(mag).astype(np.float32), npy(ph).astype(np.float32)
+    out["istft_y"] = npy(yi) * env_t[half:half + out_len] / env_r[half:half + out_len]
+    # ---- SNAC depthwise conv
+    CD, LD, DIL = 8, 40, 3
+    wd = (0.4 * torch.randn(CD, 1, 7, dtype=torch.float64)).to(torch.float32).to(torch.float64)
+    bd = (0.4 * torch.randn(CD, dtype=torch.float64)).to(torch.float32).to(torch.float64)
+    xd = torch.randn(1, CD, LD, dtype=torch.float64).to(torch.float32).to(torch.float64)
+    out["dw_x"], out["dw_w"], out["dw_b"], out["dw_y"], out["dw_dims"] = npy(xd[0]).astype(np.float32), npy(wd[:, 0]).astype(np.float32), npy(bd).astype(np.float32), npy(Fn.conv1d(xd, wd, bd, padding=3 * DIL, dilation=DIL, groups=CD)[0]), np.array([CD, LD, DIL])
+    save("upstream_kokoro_stages.npz", **out)
+    print("kokoro stages:", {k: v.shape for k, v in out.items() if not k.startswith("t:")})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["orpheus", "t5", "dac", "dac_b3", "parler", "dia", "unigram", "bpe", "delay", "albert"]
+    which = sys.argv[1:] or ["orpheus", "t5", "dac", "dac_b3", "parler", "dia", "unigram", "bpe", "delay", "albert", "kokoro_stages"]
     for w in which:
-        {"orpheus": make_orpheus, "t5": make_t5, "dac": make_dac, "parler": make_parler, "dia": make_dia, "unigram": make_unigram, "bpe": make_bpe, "delay": make_delay, "albert": make_albert,
+        {"orpheus": make_orpheus, "t5": make_t5, "dac": make_dac, "parler": make_parler, "dia": make_dia, "unigram": make_unigram, "bpe": make_bpe, "delay": make_delay, "albert": make_albert, "kokoro_stages": make_kokoro_stages,
          "dac_b3": lambda: make_dac("upstream_dac_b3.npz", hidden=192, strides=(2, 2), seed=1005, frames=300)}[w]()

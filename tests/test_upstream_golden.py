@@ -238,3 +238,79 @@ def test_kokoro_albert_against_transformers_albert(tmp_path, monkeypatch):
     out = albert(1.0 / np.sqrt(H // NH))
     assert rel(out, z["out"]) < 2e-5
     assert rel(albert(0.125), z["out"]) > 1e-3   # the reference's constant at a head size other than 64
+
+
+def _stage_model(z, prefix):
+    """an orc_kokoro_model holding only the tensors of one stage fixture (names `stage.*`), laid out like KokoroOracle does for a whole model"""
+    import ctypes as C
+    names = [k[2:] for k in z.files if k.startswith("t:" + prefix)]
+    arrs = [np.ascontiguousarray(z["t:" + n], dtype=np.float32) for n in names]
+    m = orc.KokoroModelC()
+    keep = types.SimpleNamespace()
+    keep.arrs = [a.reshape(-1) for a in arrs]
+    keep.names = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    keep.ptrs = (orc.fp * len(names))(*[orc.f32p(a) for a in keep.arrs])
+    keep.ne = np.array([list(reversed(a.shape)) + [1] * (4 - a.ndim) for a in arrs], dtype=np.int64)
+    m.n_tensors, m.names, m.data, m.ne = len(names), keep.names, keep.ptrs, keep.ne.ctypes.data_as(C.POINTER(C.c_int64))
+    return m, keep
+
+
+def test_kokoro_stages_against_pytorch_modules():
+    """The Kokoro stages beyond ALBERT and SNAC's depthwise conv, each against ONE PyTorch module / functional run in float64 by
+    tests/golden/make_upstream_golden.py (make_kokoro_stages): torch.nn.LSTM with the converter's per-gate tensor split (kokoro/model.cpp:35-86),
+    the upsampling AdaIN residual block from F.instance_norm / F.conv_transpose1d(groups, output_padding) / F.conv1d / F.interpolate (:88-134),
+    torch.stft / torch.istft (util.cpp:111-133, 203-217) and F.conv1d(groups) (decoder/snac_model.cpp:86-110).  Until round 5 these stages were
+    pinned only through the whole-graph fixture this repository's author wired (tiny_kokoro.npz / tiny_snac.npz)."""
+    import ctypes as C
+    z = np.load(os.path.join(GOLD, "upstream_kokoro_stages.npz"))
+    L = orc.lib()
+    fp, MP = orc.fp, C.POINTER(orc.KokoroModelC)
+    L.orc_kk_stage_bilstm.argtypes = [MP, C.c_char_p, fp, C.c_int, C.c_int, C.c_int, fp]
+    L.orc_kk_stage_bilstm.restype = None
+    L.orc_kk_stage_ada_block.argtypes = [MP, C.c_char_p, fp, C.c_int, C.c_int64, fp, C.c_int, fp, C.POINTER(C.c_int32)]
+    L.orc_kk_stage_ada_block.restype = C.c_int64
+    L.orc_kk_stage_stft.argtypes = [fp, C.c_int64, fp, C.c_int, C.c_int, fp, fp]
+    L.orc_kk_stage_stft.restype = None
+    L.orc_kk_stage_istft.argtypes = [fp, fp, C.c_int64, fp, C.c_int, C.c_int, fp, C.c_int64]
+    L.orc_kk_stage_istft.restype = None
+    L.orc_conv1d_dw.argtypes = [fp, C.c_int, C.c_int64, fp, fp, C.c_int, C.c_int, C.c_int, fp]
+    L.orc_conv1d_dw.restype = None
+
+    def rel(a, b):
+        return float(np.abs(np.asarray(a, dtype=np.float64) - b).max() / np.abs(b).max())
+
+    # ---- bidirectional LSTM
+    n, inp, hid = (int(v) for v in z["lstm_dims"])
+    m, keep = _stage_model(z, "stage.lstm.")
+    x = np.ascontiguousarray(z["lstm_x"], dtype=np.float32)
+    y = np.empty((n, 2 * hid), dtype=np.float32)
+    L.orc_kk_stage_bilstm(C.byref(m), b"stage.lstm", orc.f32p(x), n, inp, hid, orc.f32p(y))
+    assert rel(y, z["lstm_y"]) < 2e-5, rel(y, z["lstm_y"])
+    # ---- AdaIN residual block with the depthwise transposed-conv pool
+    c_in, c_out, s_dim, la = (int(v) for v in z["ada_dims"])
+    m, keep = _stage_model(z, "stage.ada.")
+    xa, st = np.ascontiguousarray(z["ada_x"], dtype=np.float32), np.ascontiguousarray(z["ada_style"], dtype=np.float32)
+    ya = np.empty((c_out, 2 * la), dtype=np.float32)
+    co = C.c_int32(0)
+    lo = L.orc_kk_stage_ada_block(C.byref(m), b"stage.ada", orc.f32p(xa), c_in, la, orc.f32p(st), s_dim, orc.f32p(ya), C.byref(co))
+    assert (co.value, lo) == (c_out, 2 * la)
+    assert rel(ya, z["ada_y"]) < 2e-5, rel(ya, z["ada_y"])
+    # ---- stft (magnitude; the angle as a complex number: bins without energy have no phase) and istft
+    nfft, hop, ls = (int(v) for v in z["stft_dims"])
+    sig, win = np.ascontiguousarray(z["stft_x"], dtype=np.float32), np.ascontiguousarray(z["stft_win"], dtype=np.float32)
+    fr = ls // hop + 1
+    mag, ph = np.empty((nfft // 2 + 1, fr), dtype=np.float32), np.empty((nfft // 2 + 1, fr), dtype=np.float32)
+    L.orc_kk_stage_stft(orc.f32p(sig), ls, orc.f32p(win), nfft, hop, orc.f32p(mag), orc.f32p(ph))
+    assert mag.shape == z["stft_mag"].shape and rel(mag, z["stft_mag"]) < 2e-5
+    za, zb = mag * np.exp(1j * ph), z["stft_mag"] * np.exp(1j * z["stft_ph"])
+    assert np.abs(za - zb).max() < 2e-5 * np.abs(zb).max()
+    im, ip = np.ascontiguousarray(z["istft_mag"], dtype=np.float32), np.ascontiguousarray(z["istft_ph"], dtype=np.float32)
+    yi = np.empty(ls, dtype=np.float32)
+    L.orc_kk_stage_istft(orc.f32p(im), orc.f32p(ip), fr, orc.f32p(win), nfft, hop, orc.f32p(yi), ls)
+    assert rel(yi, z["istft_y"]) < 2e-5, rel(yi, z["istft_y"])
+    # ---- SNAC's depthwise conv
+    cd, ld, dil = (int(v) for v in z["dw_dims"])
+    xd, wd, bd = (np.ascontiguousarray(z[k], dtype=np.float32) for k in ("dw_x", "dw_w", "dw_b"))
+    yd = np.empty((cd, ld), dtype=np.float32)
+    L.orc_conv1d_dw(orc.f32p(xd), cd, ld, orc.f32p(wd), orc.f32p(bd), 7, 3 * dil, dil, orc.f32p(yd))
+    assert rel(yd, z["dw_y"]) < 2e-5
