@@ -83,6 +83,16 @@ for n in (64, 448):
     assert len(out) == n
 sstep = (rs[448] - rs[64]) / (448 - 64)
 print(f"sampled on the device (top_k 50, temperature 0.6, repetition penalty 1.1): {sstep*1e3:.3f} ms/step ({(sstep - step)*1e6:+.0f} us vs the arg-max loop)")
+# nucleus sampling (top_p < 1): + softmax_total_kernel, the full-vocabulary softmax total accumulated in index order by one thread (round 5)
+tp = float(os.environ.get("ORPHEUS_BENCH_TOP_P", "0.9"))
+eng.generate_sampled(prompt, 16, NO_STOP, u[:16], top_k=50, temperature=0.6, repetition_penalty=1.1, top_p=tp)
+rp = {}
+for n in (64, 448):
+    t0 = time.perf_counter()
+    out = eng.generate_sampled(prompt, n, NO_STOP, u[:n], top_k=50, temperature=0.6, repetition_penalty=1.1, top_p=tp)
+    rp[n] = time.perf_counter() - t0
+pstep = (rp[448] - rp[64]) / (448 - 64)
+print(f"sampled on the device with top_p {tp}: {pstep*1e3:.3f} ms/step ({(pstep - sstep)*1e6:+.0f} us vs top_p 1)")
 # the per-step host loop it replaces: logits D2H (628 KB) + a full sort of 156 940 values per step
 import ctypes as C
 sys.path.insert(0, os.path.join(ROOT, "oracle"))

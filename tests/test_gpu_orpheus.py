@@ -172,7 +172,7 @@ def test_orpheus_runner_generates_through_both_contexts(tmp_path):
     # with the noise block active the audio differs and stays a tanh output
     noisy = r.generate("hello the zebra", voice=b"zoe", sample=0)
     assert noisy.shape == pcm.shape and np.abs(noisy).max() <= 1.0 and not np.array_equal(noisy, pcm)
-    # seeded sampling: the device sampler loop (tts_hip_orpheus_generate_sampled; top_k 1..64, top_p 1) == the per-step host loop
+    # seeded sampling: the device sampler loop (tts_hip_orpheus_generate_sampled; top_k 1..64, any top_p) == the per-step host loop
     # (logits D2H + sampler::sample on the host), token for token; other configurations take the host loop
     os.environ["TTS_SNAC_NO_NOISE"] = "1"
     try:
@@ -185,7 +185,8 @@ def test_orpheus_runner_generates_through_both_contexts(tmp_path):
             return pcm_, r.last_tokens(1).copy()
         # top_k stays below the number of distinct logits: this synthetic model has a block of exactly equal logits (untrained text rows),
         # and the order of equal keys is where the device (index order) and std::sort (unspecified, sampler.cpp:167) may differ
-        for kw in (dict(top_k=8, seed=3), dict(top_k=16, temperature=0.8, seed=11), dict(top_k=20, temperature=1.3, repetition_penalty=1.3, seed=5)):
+        for kw in (dict(top_k=8, seed=3), dict(top_k=16, temperature=0.8, seed=11), dict(top_k=20, temperature=1.3, repetition_penalty=1.3, seed=5),
+                   dict(top_k=12, top_p=0.7, temperature=0.9, seed=7)):   # top_p < 1 on the device since round 5
             sampled, dev_toks = run(**kw)
             os.environ["TTS_HOST_LOOP"] = "1"
             try:
@@ -251,39 +252,42 @@ def test_orpheus_runner_with_the_noise_block(tmp_path):
     r.close()
 
 
-def _oracle_sampler(v, top_k, temp, rep):
+def _oracle_sampler(v, top_k, temp, rep, top_p=1.0):
     import ctypes as C
     smp = orc.Sampler()
     orc.lib().orc_sampler_init(C.byref(smp), 1, v)
-    smp.top_k, smp.temperature, smp.top_p, smp.repetition_penalty, smp.do_sample = top_k, temp, 1.0, rep, 1
+    smp.top_k, smp.temperature, smp.top_p, smp.repetition_penalty, smp.do_sample = top_k, temp, top_p, rep, 1
     orc.lib().orc_sampler_reset(C.byref(smp))
     return smp
 
 
-@pytest.mark.parametrize("top_k,temp,rep", [(50, 1.0, 1.0), (50, 0.6, 1.1), (64, 1.4, 1.0), (1, 1.0, 1.0), (7, 0.9, 1.5)])
-def test_orpheus_device_sampler_over_the_full_vocabulary(top_k, temp, rep):
+@pytest.mark.parametrize("top_k,temp,rep,top_p", [(50, 1.0, 1.0, 1.0), (50, 0.6, 1.1, 1.0), (64, 1.4, 1.0, 1.0), (1, 1.0, 1.0, 1.0), (7, 0.9, 1.5, 1.0),
+                                                   (50, 1.0, 1.0, 0.9), (20, 0.7, 1.2, 0.5), (64, 1.3, 1.0, 0.95), (50, 1.0, 1.0, 0.05)])
+def test_orpheus_device_sampler_over_the_full_vocabulary(top_k, temp, rep, top_p):
     """sampler::sample over 156 940 logits (orpheus/model.cpp:389-398): topk_parts_kernel + topk_sample_kernel against the oracle sampler
     (pinned to the compiled src/sampler.cpp by tests/test_sampler.py), same logits, same uniform draw, same repetition state, three calls
-    deep.  Bar: identical ids; a draw within a few ulp of a CDF boundary may land on the neighbouring candidate (device expf vs libm)."""
+    deep.  top_p < 1 (round 5: softmax_total_kernel — the softmax over the whole vocabulary before the top k, its total accumulated in index
+    order like sampler.cpp:82-116; then topp, :118-150): the logits are sharpened so that the nucleus is a handful of candidates and the trim
+    point matters.  Bar: identical ids; a draw within a few ulp of a CDF boundary may land on the neighbouring candidate (device expf vs libm)."""
     import ctypes as C
     cfg = synth.orpheus_tiny(vocab=156940)
     model = synth.build_orpheus(cfg)
     eng = hip.OrpheusEngine(cfg)
     eng.load(model)
     V = cfg.vocab
-    rng = np.random.default_rng(top_k * 31 + int(temp * 10))
+    rng = np.random.default_rng(top_k * 31 + int(temp * 10) + int(top_p * 1000))
     bad = 0
     for case in range(6):
         last, cnt = (int(rng.integers(0, V)), int(rng.integers(1, 5))) if rep != 1.0 else (-1, 0)
-        smp = _oracle_sampler(V, top_k, temp, rep)
+        smp = _oracle_sampler(V, top_k, temp, rep, top_p)
         if rep != 1.0:
             smp.last_token_ids[0], smp.repetition_counts[0] = last, cnt
         for call in range(3):
-            lg = (rng.standard_normal(V) * 3.0).astype(np.float32)
+            lg = (rng.standard_normal(V) * (3.0 if top_p >= 1.0 else 6.0)).astype(np.float32)
             if rep != 1.0 and call == 1 and last >= 0:
                 lg[last] = 20.0     # the token sampled last is the arg-max: its penalised value decides the softmax maximum
             u = float(np.float32([0.0, 0.99999994][case]) if case < 2 and call == 0 else rng.random(dtype=np.float32))
-            tok, last, cnt = eng.sample_logits(lg, u, top_k=top_k, temperature=temp, repetition_penalty=rep, last_id=last, rep_count=cnt)
+            tok, last, cnt = eng.sample_logits(lg, u, top_k=top_k, temperature=temp, repetition_penalty=rep, top_p=top_p, last_id=last, rep_count=cnt)
             ref = np.zeros(1, dtype=np.uint32)
             orc.lib().orc_sampler_sample(C.byref(smp), orc.f32p(lg.copy()), orc.f32p(np.float32([u])), orc.u32p(ref))
             if tok != int(ref[0]):
@@ -298,7 +302,7 @@ def test_orpheus_device_sampler_over_the_full_vocabulary(top_k, temp, rep):
     with pytest.raises(hip.HipError):
         eng.sample_logits(np.zeros(V, dtype=np.float32), 0.5, top_k=65)       # beyond the device sampler: host loop
     with pytest.raises(hip.HipError):
-        eng.sample_logits(np.zeros(V, dtype=np.float32), 0.5, top_k=50, top_p=0.9)
+        eng.sample_logits(np.zeros(V, dtype=np.float32), 0.5, top_k=50, top_p=0.0)
     eng.close()
 
 
@@ -317,11 +321,11 @@ def test_orpheus_sampled_generation_equals_the_per_step_host_loop(graph):
     eng.load(model)
     g = np.load(GOLD)
     prompt = g["prompt"]
-    for top_k, temp, rep, seed in ((8, 1.0, 1.0, 1), (50, 0.8, 1.2, 2), (3, 1.5, 1.0, 3)):
+    for top_k, temp, rep, seed, top_p in ((8, 1.0, 1.0, 1, 1.0), (50, 0.8, 1.2, 2, 1.0), (3, 1.5, 1.0, 3, 1.0), (20, 0.9, 1.1, 4, 0.6)):
         n = 30
         u = np.random.default_rng(seed).random(n, dtype=np.float32)
-        got = eng.generate_sampled(prompt, n, stop_id=cfg.vocab + 5, uniforms=u, top_k=top_k, temperature=temp, repetition_penalty=rep)
-        smp = _oracle_sampler(cfg.vocab, top_k, temp, rep)
+        got = eng.generate_sampled(prompt, n, stop_id=cfg.vocab + 5, uniforms=u, top_k=top_k, temperature=temp, repetition_penalty=rep, top_p=top_p)
+        smp = _oracle_sampler(cfg.vocab, top_k, temp, rep, top_p)
         ref, pos = [], len(prompt)
         lg, _ = eng.decode(prompt, 0)
         for s in range(n):
@@ -334,6 +338,6 @@ def test_orpheus_sampled_generation_equals_the_per_step_host_loop(graph):
         assert got.tolist() == ref, (top_k, temp, rep)
         stop = ref[4]
         first = ref.index(stop)
-        assert eng.generate_sampled(prompt, n, stop_id=stop, uniforms=u, top_k=top_k, temperature=temp, repetition_penalty=rep).tolist() == ref[:first + 1]
+        assert eng.generate_sampled(prompt, n, stop_id=stop, uniforms=u, top_k=top_k, temperature=temp, repetition_penalty=rep, top_p=top_p).tolist() == ref[:first + 1]
     assert len(set(ref)) > 1
     eng.close()

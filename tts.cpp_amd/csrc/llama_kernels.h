@@ -567,7 +567,7 @@ static __global__ __launch_bounds__(64) void argmax_fold_graph_kernel(const floa
 
 // ------------------------------------------------------------------------------------------------
 // sampler::sample over the 156 940-logit vocabulary (orpheus/model.cpp:389-398, sampler.cpp:3-69 with topk :152-183 and softmax :82-116)
-// for the default shape of a generation configuration: top_k in 1..TOPK_MAXK, top_p >= 1.  The reference sorts all 156 940 indices by
+// for top_k in 1..TOPK_MAXK (top_p < 1: + softmax_total_kernel, below).  The reference sorts all 156 940 indices by
 // (penalised) value on the host at every step; only the first top_k of that order are ever read, so two stages find them:
 //   topk_parts_kernel   TOPK_PARTS workgroups, each sorts its slice of the vocabulary (bitonic, 64-bit keys = value descending, index
 //                       ascending — the total order of sample_kernel / smp_key) and keeps its first k keys;
@@ -624,11 +624,64 @@ static __global__ __launch_bounds__(512) void topk_parts_kernel(const float *log
     for (int j = threadIdx.x; j < k; j += blockDim.x) cand[(int) blockIdx.x * TOPK_MAXK + j] = keys[j];
 }
 
+// top_p < 1 (sampler.cpp:22-27): the reference runs softmax over the WHOLE vocabulary before it looks for the top k — every probability is
+// exp(v / T - top) / cumsum with cumsum accumulated over the 156 940 entries in index order, in fp32.  The order of an fp32 sum is part of its
+// value, so the total is accumulated here by ONE thread in that order (the exponentials are computed by the whole workgroup, a chunk at a time,
+// into LDS): ~0.4 ms per token — the price of drawing exactly the reference's nucleus on the device instead of shipping 628 KB of logits to
+// the host and sorting them there (~10 ms per token).  `top` is the penalised maximum / T, read off the part winners of topk_parts_kernel.
+#define SOFTMAX_CHUNK 8192
+static __global__ __launch_bounds__(1024) void softmax_total_kernel(const float *logits, int V, const unsigned long long *cand, float temperature, const double *pen_table,
+                                                             int pen_len, const int32_t *last_id, const uint32_t *rep_count, float *total_out) {
+    __shared__ __attribute__((aligned(16))) float ex[SOFTMAX_CHUNK];
+    __shared__ float s_top;
+    const bool temp = temperature != 1.0f;
+    if (threadIdx.x == 0) {
+        unsigned long long best = ~0ull;
+        for (int p = 0; p < TOPK_PARTS; p++) best = cand[p * TOPK_MAXK] < best ? cand[p * TOPK_MAXK] : best;
+        float top = smp_key_value(best);
+        if (temp) top /= temperature;
+        s_top = top;
+    }
+    __syncthreads();
+    const float top = s_top;
+    const int last = pen_table ? last_id[0] : -1;
+    float total = 0.0f;
+    for (int c0 = 0; c0 < V; c0 += SOFTMAX_CHUNK) {
+        const int n = min(SOFTMAX_CHUNK, V - c0);
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            const int i = c0 + j;
+            float v = logits[i];
+            if (i == last) {
+                const uint32_t cnt = rep_count[0];
+                v = (float) ((double) v / pen_table[cnt < (uint32_t) pen_len ? cnt : (uint32_t) pen_len - 1]);
+            }
+            if (temp) v /= temperature;
+            ex[j] = expf(v - top);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int j = 0;
+            for (; j + 64 <= n; j += 64) {   // 16 LDS reads in flight, then 64 adds in index order (one read per four adds was 25 clocks per add)
+                float4 e[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) e[q] = *(const float4 *) (ex + j + 4 * q);
+#pragma unroll
+                for (int q = 0; q < 16; q++) { total += e[q].x; total += e[q].y; total += e[q].z; total += e[q].w; }
+            }
+            for (; j < n; j++) total += ex[j];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total_out[0] = total;
+}
+
 // uniforms[call[0]] is this call's draw; call[0] advances.  hist_idx != NULL: captured step, the history slot is hist[hist_idx[0]++];
 // otherwise hist (may be NULL) is the slot itself.  next_id / next_pos (may be NULL): the token goes straight back as the next input.
+// total (NULL: top_p >= 1): the full-vocabulary softmax total of softmax_total_kernel; then the picks keep their full-vocabulary probabilities
+// exp(v - top) / total, topp() trims them at top_p (sampler.cpp:118-150) and the draw is scaled by the nucleus mass (sampler.cpp:47).
 static __global__ __launch_bounds__(1024) void topk_sample_kernel(const unsigned long long *cand, int k, float temperature, const float *uniforms, uint32_t *call,
                                                            const double *pen_table, int32_t *last_id, uint32_t *rep_count, uint32_t *token, uint32_t *hist,
-                                                           uint32_t *hist_idx, uint32_t *next_id, uint32_t *next_pos) {
+                                                           uint32_t *hist_idx, uint32_t *next_id, uint32_t *next_pos, float top_p = 1.0f, const float *total_in = nullptr) {
     __shared__ unsigned long long keys[TOPK_PARTS * TOPK_MAXK];
     __shared__ float prob[TOPK_MAXK];
     const int n = TOPK_PARTS * k;
@@ -649,15 +702,35 @@ static __global__ __launch_bounds__(1024) void topk_sample_kernel(const unsigned
     if (threadIdx.x == 0) {
         int m = k;                            // fewer than k real candidates only when the vocabulary is smaller than k
         while (m > 1 && keys[m - 1] == ~0ull) m--;
-        float total = 0.0f;
-        for (int j = 0; j < m; j++) total += prob[j];
-        const float target = uniforms[call[0]];
+        float target = uniforms[call[0]];
         call[0] += 1;
         float cum = 0.0f;
-        int chosen = (int) (unsigned) keys[m - 1];
-        for (int j = 0; j < m; j++) {
-            cum += prob[j] / total;
-            if (target <= cum || j + 1 >= m) { chosen = (int) (unsigned) keys[j]; break; }
+        int chosen;
+        if (total_in) {
+            // softmax ran over the whole vocabulary (prob / total_in are the reference's logits[] after it); topp(): the first prefix of the picks
+            // whose mass reaches top_p, the draw scaled by min(mass, top_p)
+            const float total = total_in[0];
+            float mass = 0.0f;
+            int trim = -1;
+            for (int j = 0; j < m; j++) {
+                mass += prob[j] / total;
+                if (mass >= top_p) { trim = j + 1; break; }
+            }
+            if (trim > 0) m = trim;
+            target *= fminf(mass, top_p);
+            chosen = (int) (unsigned) keys[m - 1];
+            for (int j = 0; j < m; j++) {
+                cum += prob[j] / total;
+                if (target <= cum || j + 1 >= m) { chosen = (int) (unsigned) keys[j]; break; }
+            }
+        } else {
+            float total = 0.0f;
+            for (int j = 0; j < m; j++) total += prob[j];
+            chosen = (int) (unsigned) keys[m - 1];
+            for (int j = 0; j < m; j++) {
+                cum += prob[j] / total;
+                if (target <= cum || j + 1 >= m) { chosen = (int) (unsigned) keys[j]; break; }
+            }
         }
         if (pen_table) {
             uint32_t cnt = rep_count[0];

@@ -805,7 +805,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->l_ids, (size_t) R));
         CHK(dmalloc(&c->l_pos, (size_t) R));
         CHK(dmalloc(&c->l_tok, (size_t) 1 + 2 * ARGMAX_PARTS + LLAMA_GREEDY_CHUNK + 1));
-        HIPCHK(hipMalloc((void **) &c->l_cand, (size_t) TOPK_PARTS * TOPK_MAXK * 8));
+        HIPCHK(hipMalloc((void **) &c->l_cand, (size_t) TOPK_PARTS * TOPK_MAXK * 8 + 16));   // + the softmax total of a top_p < 1 step
         CHK(dmalloc(&c->l_smp, (size_t) 4));
     }
     if (c->has_dia) {

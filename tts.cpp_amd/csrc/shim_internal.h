@@ -210,7 +210,7 @@ struct tts_hip_ctx {
     float *d_uniforms = nullptr;  // [calls][R][n_out] host-drawn U[0,1) for sample_kernel
     unsigned long long *l_cand = nullptr;   // Orpheus sampler: [TOPK_PARTS][TOPK_MAXK] stage-1 survivors
     uint32_t *l_smp = nullptr;              // Orpheus sampler: [0] last token (int32), [1] repetition count, [2] sampler call index
-    struct { const void *uni = nullptr, *pen = nullptr; uint32_t k = 0; float temp = 0; } l_smp_baked;   // what the captured sampled step holds
+    struct { const void *uni = nullptr, *pen = nullptr; uint32_t k = 0; float temp = 0, top_p = 1.0f; } l_smp_baked;   // what the captured sampled step holds
     double *d_pen = nullptr;      // pow(repetition_penalty, count) table (host-evaluated)
     int pen_len = 0;
     int32_t *d_last = nullptr;    // [RMAX][n_out] sampler::last_token_ids

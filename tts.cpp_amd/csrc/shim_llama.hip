@@ -264,9 +264,16 @@ static int llama_select(tts_hip_ctx *c, const tts_hip_sampling *sp, bool capture
     hipLaunchKernelGGL(topk_parts_kernel, dim3(TOPK_PARTS), dim3(512), 0, c->stream, (const float *) c->l_logits, c->l_V, (int) sp->top_k, pen, c->pen_len, (const int32_t *) last,
                        (const uint32_t *) repc, c->l_cand);
     HIPCHK(hipGetLastError());
+    float *total = nullptr;
+    if (sp->top_p < 1.0f) {   // nucleus sampling: the softmax total over the whole vocabulary, accumulated in index order like the reference's
+        total = (float *) (c->l_cand + (size_t) TOPK_PARTS * TOPK_MAXK);
+        hipLaunchKernelGGL(softmax_total_kernel, dim3(1), dim3(1024), 0, c->stream, (const float *) c->l_logits, c->l_V, (const unsigned long long *) c->l_cand, sp->temperature, pen,
+                           c->pen_len, (const int32_t *) last, (const uint32_t *) repc, total);
+        HIPCHK(hipGetLastError());
+    }
     hipLaunchKernelGGL(topk_sample_kernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long *) c->l_cand, (int) sp->top_k, sp->temperature, (const float *) c->d_uniforms,
                        call, pen, last, repc, c->l_tok, captured ? hist : hist_slot, captured ? hist_idx : (uint32_t *) nullptr,
-                       (captured || feed) ? c->l_ids : (uint32_t *) nullptr, (captured || feed) ? c->l_pos : (uint32_t *) nullptr);
+                       (captured || feed) ? c->l_ids : (uint32_t *) nullptr, (captured || feed) ? c->l_pos : (uint32_t *) nullptr, sp->top_p, (const float *) total);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -277,7 +284,7 @@ static int check_llama_sampling(const tts_hip_ctx *c, const tts_hip_sampling *sp
     if (!sp) return set_err("%s: null sampling parameters", what);
     if (!(sp->temperature > 0.0f)) return set_err("%s: temperature must be > 0", what);
     if (!(sp->repetition_penalty > 0.0f)) return set_err("%s: repetition_penalty must be > 0 (1 = off)", what);
-    if (sp->top_p < 1.0f) return set_err("%s: top_p < 1 needs the softmax over the whole vocabulary in index order: sample on the host", what);
+    if (!(sp->top_p > 0.0f)) return set_err("%s: top_p must be > 0", what);
     if (sp->top_k == 0 || sp->top_k > TOPK_MAXK || (int) sp->top_k >= c->l_V)
         return set_err("%s: the device sampler takes top_k in 1..%d (got %u): sample on the host", what, TOPK_MAXK, sp->top_k);
     if (c->l_V > TOPK_PARTS * TOPK_SLICE) return set_err("%s: vocabulary %d > %d", what, c->l_V, TOPK_PARTS * TOPK_SLICE);
@@ -302,10 +309,10 @@ static int orpheus_generate(tts_hip_ctx *c, const char *what, const uint32_t *pr
         HIPCHK(hipMemcpyAsync(c->l_smp, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         const void *pen = sp->repetition_penalty != 1.0f ? (const void *) c->d_pen : nullptr;
-        if (c->l_smp_baked.uni != c->d_uniforms || c->l_smp_baked.pen != pen || c->l_smp_baked.k != sp->top_k || c->l_smp_baked.temp != sp->temperature) {
+        if (c->l_smp_baked.uni != c->d_uniforms || c->l_smp_baked.pen != pen || c->l_smp_baked.k != sp->top_k || c->l_smp_baked.temp != sp->temperature || c->l_smp_baked.top_p != sp->top_p) {
             auto it = c->graphs.find(9000002);
             if (it != c->graphs.end()) { (void) hipGraphExecDestroy(it->second); c->graphs.erase(it); }
-            c->l_smp_baked.uni = c->d_uniforms; c->l_smp_baked.pen = pen; c->l_smp_baked.k = sp->top_k; c->l_smp_baked.temp = sp->temperature;
+            c->l_smp_baked.uni = c->d_uniforms; c->l_smp_baked.pen = pen; c->l_smp_baked.k = sp->top_k; c->l_smp_baked.temp = sp->temperature; c->l_smp_baked.top_p = sp->top_p;
         }
     }
     uint32_t tok = 0, pos = n_prompt;

@@ -169,9 +169,10 @@ void orpheus_runner::generate(const char * sentence, tts_response & output, cons
         hip_check(tts_hip_orpheus_generate_greedy(lm, prompt.data(), (uint32_t) prompt.size(), hp.max_generation_size, hp.stopping_token_id, out.data(), &n),
                   "tts_hip_orpheus_generate_greedy");
         out.resize(n);
-    } else if (!getenv("TTS_HOST_LOOP") && config.top_p >= 1.0f && config.top_k >= 1 && config.top_k <= 64 && (uint32_t) config.top_k < hp.vocab_size) {
-        // the default shape of a generation_configuration (top_k 50, top_p 1): sampler::sample runs on the device, two kernels pick the
-        // top_k candidates out of the 156 940 logits; the U[0,1) draws are made here, one generator per call as sampler.cpp:47-48
+    } else if (!getenv("TTS_HOST_LOOP") && config.top_p > 0.0f && config.top_k >= 1 && config.top_k <= 64 && (uint32_t) config.top_k < hp.vocab_size) {
+        // top_k in 1..64 (the default generation_configuration: top_k 50, top_p 1): sampler::sample runs on the device, two kernels pick the
+        // top_k candidates out of the 156 940 logits (top_p < 1: a third accumulates the full-vocabulary softmax total in index order first,
+        // round 5); the U[0,1) draws are made here, one generator per call as sampler.cpp:47-48
         std::vector<float> u(hp.max_generation_size);
         for (auto & v : u) smp.draw_uniforms(&v);
         tts_hip_sampling sp{(uint32_t) config.top_k, config.top_p, config.temperature, config.repetition_penalty};
@@ -181,7 +182,7 @@ void orpheus_runner::generate(const char * sentence, tts_response & output, cons
                   "tts_hip_orpheus_generate_sampled");
         out.resize(n);
     } else {
-        // top_p < 1 (softmax over the whole vocabulary in index order) or a top_k the device sampler does not take: logits come back,
+        // a top_k the device sampler does not take (0 = off, or > 64: the reference sorts the whole vocabulary): logits come back,
         // sampler::sample runs here
         std::vector<uint32_t> batch = prompt;
         uint32_t pos = 0;
