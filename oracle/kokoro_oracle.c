@@ -15,6 +15,9 @@
  * those definitions, not to ggml.  The one part with an upstream implementation installed here is pinned to it: the ALBERT stage
  * against transformers' AlbertModel (the class kokoro's `bert` is and the converter walks, kokoro_gguf_encoder.py:14-37, :274-287):
  * 1.7e-7 on a 19-token input, tests/golden/upstream_albert.npz, tests/test_upstream_golden.py.
+ * Round 5: the stages (bidirectional LSTM, the upsampling AdaIN residual block with its depthwise transposed-conv pool, stft / istft) are also held
+ * against ONE PyTorch module each through the orc_kk_stage_* entry points at the end of this file (tests/golden/upstream_kokoro_stages.npz, 2e-5);
+ * what stays author-only is the order in which the graph strings them together.
  *
  * Tensors are looked up by their GGUF names (py-gguf/tts_encoders/kokoro_gguf_encoder.py), all fp32. */
 #define _GNU_SOURCE
