@@ -234,12 +234,14 @@ int tts_hip_orpheus_decode(tts_hip_ctx *ctx, const uint32_t *ids, uint32_t n, ui
  * stop_id or max_new ids; returns the count in *n_out */
 int tts_hip_orpheus_generate_greedy(tts_hip_ctx *ctx, const uint32_t *prompt, uint32_t n_prompt, uint32_t max_new, uint32_t stop_id,
                                     uint32_t *tokens_out, uint32_t *n_out);
-/* the same loop with sampler::sample (orpheus/model.cpp:389-398, src/sampler.cpp:3-69) on the device for the shape the default
- * generation_configuration has (include/common.h:45-55: top_k 50, top_p 1): top_k in 1..64, top_p >= 1, any temperature and
- * repetition penalty.  The reference sorts all 156 940 logits on the host at every step; here two kernels select the top_k
- * candidates in the reference's order (value descending; equal values by index) and run the softmax / inverse-CDF scan in the
- * reference's operation order.  uniforms [max_new]: the U[0,1) draw of the k-th sampler call (the caller's std::minstd_rand).
- * Other configurations (top_p < 1, top_k 0 or > 64) are refused: sample on the host from tts_hip_orpheus_decode's logits. */
+/* the same loop with sampler::sample (orpheus/model.cpp:389-398, src/sampler.cpp:3-69) on the device: top_k in 1..64 (the default
+ * generation_configuration, include/common.h:45-55, has top_k 50, top_p 1), any top_p > 0, temperature and repetition penalty.
+ * The reference sorts all 156 940 logits on the host at every step; here two kernels select the top_k candidates in the
+ * reference's order (value descending; equal values by index) and run the softmax / inverse-CDF scan in the reference's
+ * operation order.  top_p < 1 (nucleus sampling, sampler.cpp:22-27, 118-150): a third kernel first accumulates the softmax
+ * total over the whole vocabulary in index order, as the reference's fp32 sum is, and the picks keep their full-vocabulary
+ * probabilities (about 0.65 ms per token more).  uniforms [max_new]: the U[0,1) draw of the k-th sampler call (the caller's
+ * std::minstd_rand).  top_k 0 or > 64 is refused: sample on the host from tts_hip_orpheus_decode's logits. */
 int tts_hip_orpheus_generate_sampled(tts_hip_ctx *ctx, const uint32_t *prompt, uint32_t n_prompt, uint32_t max_new, uint32_t stop_id,
                                      const tts_hip_sampling *sampling, const float *uniforms, uint32_t *tokens_out, uint32_t *n_out);
 /* the device sampler alone on caller-supplied logits [vocab_size], for parity tests; last_id / rep_count: sampler::last_token_ids /
