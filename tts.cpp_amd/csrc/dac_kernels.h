@@ -941,7 +941,7 @@ __global__ __launch_bounds__(64 * WM * WN, CONVT_MIN_WAVES) void convt1d_mfma_ke
 // thread; a 1-channel output gives the matrix pipe nothing to do, so this is a staged dot product.
 #define C1_T 256
 #define C1_CI 16
-static __global__ __launch_bounds__(256) void conv1d_cout1_kernel(ConvArgs a) {
+static __global__ __launch_bounds__(256, 4) void conv1d_cout1_kernel(ConvArgs a) {
     __shared__ float xs[C1_CI][C1_T + 8];
     __shared__ float wsm[C1_CI][8];
     const int tid = threadIdx.x, t0 = blockIdx.x * C1_T;
@@ -949,24 +949,49 @@ static __global__ __launch_bounds__(256) void conv1d_cout1_kernel(ConvArgs a) {
     if (t0 >= L) return;
     const float *xg = a.x + (int64_t) blockIdx.z * a.cin * LS;
     float *yg = a.y + (int64_t) blockIdx.z * LS;
+    // A chunk = 16 input channels x (256 + 6) positions.  Every load of a chunk is requested before the first is used (clamped addresses, validity
+    // applied afterwards; snake on the 16 values at once: one wave-uniform range test) and the NEXT chunk's loads fly under the current chunk's dot
+    // products: the staging loop of rounds 1-4 (`for i: load, snake, store`) was 17 dependent round trips per chunk, 2.06 ms per launch at 0.19 of the
+    // HBM peak for a kernel that reads its input once (profiles/r05/bench_full_call3.json, dac_final).  Four waves per SIMD stay resident (a first
+    // version with two register sets took 348 registers, one workgroup per CU, and was 2.5 x slower: profiles/r05/dac_bench_call8.txt).
+    // Same products in the same order: bit-identical output.
+    const int tm = t0 + tid - a.pad, te = t0 + C1_T + tid - a.pad;   // this thread's position and (tid < 6) the halo position behind the tile
+    const int tmc = min(max(tm, 0), L - 1), tec = min(max(te, 0), L - 1);
+    const bool okm = tm >= 0 && tm < L, oke = te >= 0 && te < L;
+    float v[C1_CI], e[C1_CI];
+    auto request = [&](int ci0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ci = 0; ci < C1_CI; ci++) v[ci] = xg[(int64_t) min(ci0 + ci, a.cin - 1) * LS + tmc];
+        if (tid < 6) {
+#pragma unroll
+            for (int ci = 0; ci < C1_CI; ci++) e[ci] = xg[(int64_t) min(ci0 + ci, a.cin - 1) * LS + tec];
+        }
+    };
+    auto stage = [&](int ci0, float (&x)[C1_CI], bool ok, int col) __attribute__((always_inline)) {
+        if (a.alpha) {
+            float al[C1_CI], ral[C1_CI];
+#pragma unroll
+            for (int ci = 0; ci < C1_CI; ci++) { al[ci] = a.alpha[min(ci0 + ci, a.cin - 1)]; ral[ci] = 1.0f / al[ci]; }
+            snake_vec<C1_CI>(x, al, ral);
+        }
+#pragma unroll
+        for (int ci = 0; ci < C1_CI; ci++) {
+            float y = (ok && ci0 + ci < a.cin) ? x[ci] : 0.0f;
+            if (a.x_f16) y = (float) (_Float16) y;
+            xs[ci][col] = y;
+        }
+    };
+    request(0);
     float acc = 0.0f;
     for (int ci0 = 0; ci0 < a.cin; ci0 += C1_CI) {
-        __syncthreads();
-        for (int i = tid; i < C1_CI * (C1_T + 6); i += 256) {
-            const int ci = i / (C1_T + 6), p = i - ci * (C1_T + 6);
-            const int t = t0 + p - a.pad, cig = ci0 + ci;
-            float v = 0.0f;
-            if (cig < a.cin && t >= 0 && t < L) {
-                v = xg[(int64_t) cig * LS + t];
-                if (a.alpha) { const float al = a.alpha[cig]; v = snake_f(v, al, 1.0f / al); }
-                if (a.x_f16) v = (float) (_Float16) v;
-            }
-            xs[ci][p] = v;
-        }
+        __syncthreads();   // the previous chunk's tile has been consumed
+        stage(ci0, v, okm, tid);
+        if (tid < 6) stage(ci0, e, oke, C1_T + tid);
         if (tid < C1_CI * 7) {
             const int ci = tid / 7, k = tid - ci * 7;
             wsm[ci][k] = (ci0 + ci < a.cin) ? a.w[(int64_t) (ci0 + ci) * 7 + k] : 0.0f;
         }
+        if (ci0 + C1_CI < a.cin) request(ci0 + C1_CI);
         __syncthreads();
 #pragma unroll
         for (int ci = 0; ci < C1_CI; ci++)
@@ -975,9 +1000,9 @@ static __global__ __launch_bounds__(256) void conv1d_cout1_kernel(ConvArgs a) {
     }
     const int t = t0 + tid;
     if (t < L) {
-        float v = acc + (a.b ? a.b[0] : 0.0f);
-        if (a.do_tanh) v = tanhf(v);
-        yg[t] = v;
+        float vv = acc + (a.b ? a.b[0] : 0.0f);
+        if (a.do_tanh) vv = tanhf(vv);
+        yg[t] = vv;
     }
 }
 
