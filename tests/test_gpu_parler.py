@@ -971,3 +971,34 @@ def test_utterance_admitted_mid_flight_with_the_row_major_attention(monkeypatch)
         same += bool(np.array_equal(toks, rt[:want, k]))
     print(f"{same} of {n} streams identical")
     assert same >= int(0.9 * n), same
+
+
+@pytest.mark.parametrize("rows,enc", [(100, 8), (1024, 8), (200, 27)])
+def test_cross_attention_inside_the_q_projection_tiles(rows, enc, monkeypatch):
+    """Round 5: with the 64 x 64 GEMM tile a tile column of the cross-attention's q projection is one head, and the attention over the voice prompt
+    (parler/model.cpp:576-593) runs in that tile's epilogue (gemm_tile_kernel<64, 64, .., EPI_CROSS>) instead of a launch of its own.  Against the
+    oracle (ragged row counts: partial tiles; a 27-position prompt: scores beyond one 16-group), and against the same forward with the fold
+    switched off (tune cross_fold = 0: attn_short_kernel) — same mathematics, another order of the 64-term score sums."""
+    if rows != 1024:
+        monkeypatch.setenv("TTS_HIP_TILE_FORCE", "3")   # smaller forwards would pick another tile shape (and keep the launch)
+    key = ("wide1e%d" % enc, gguf.F16)
+    if key not in _models:
+        _models[key] = synth.build(synth.tiny(hidden=1024, heads=16, ffn=4096, layers=1, enc_len=enc, weight_type=gguf.F16))
+    model = _models[key]
+    cfg = model.cfg
+    rng = np.random.default_rng(rows + enc)
+    prompts = [rng.integers(3, cfg.prompt_vocab, 2 + (i % 3)).astype(np.uint32) for i in range(rows)]
+    ids = np.full((rows, cfg.n_out), cfg.bos, dtype=np.uint32)
+    out = {}
+    for fold in (1, 0):
+        eng = hip.HipEngine(cfg, max_seqs=rows, kv_positions=16, tune={"cross_fold": fold})
+        eng.load(model)
+        eng.prefill_batch(prompts)
+        out[fold] = eng.step(ids, [len(p) for p in prompts])
+        eng.close()
+    assert relerr(out[1], out[0]) < TOL[gguf.F16]
+    for r in sorted({0, 15, 16, 63, 64, rows // 2, rows - 1}):
+        o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+        o.decode(prompts[r], 0, audio=False, want_logits=False)
+        ref, _ = o.decode(ids[r], len(prompts[r]), audio=True)
+        assert relerr(out[1][r], ref[:, 0, :]) < TOL[gguf.F16], (rows, enc, r)

@@ -164,6 +164,69 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tile_kernel(GemmArgs a, Til
                 }
             }
         }
+    } else if constexpr (EPI == EPI_CROSS) {
+        // The 64 x 64 tile is ONE head's query for 64 rows (BN = 64 = the head width, n0 = 64 head).  Cross-attention over the voice prompt
+        // (cross_E <= 32 positions; soft_max_ext + mul_mat, parler/model.cpp:586-593) right here: the tile goes to LDS (it is spread over the
+        // 2 x 4 waves' accumulators), the head's K_c / V_c slices beside it, then 16 lanes per row — 4 channels each, 32 rows per pass — compute the
+        // scores (row16_sum), the softmax (redundantly per lane) and the attended channels.  attn_short_kernel's arithmetic up to the order of the
+        // 64-term score sum (a 16-lane butterfly of 4-term partial sums here, a 64-lane butterfly there); q never goes to memory and the launch
+        // between the GEMM and the out projection (10.8 us at 1024 rows, 0.08 of the HBM peak) is gone.
+        static_assert(BM == 64 && BN == 64 && WM * WN == 8, "EPI_CROSS is written for the 64 x 64 tile of 8 waves");
+        __syncthreads();                                   // every wave is done with the k-tile buffers: the LDS is reused
+        float *qs = (float *) smem;                        // [64][68] (the pad spreads the rows over the banks)
+        float *ks = qs + 64 * 68, *vs = ks + 32 * 64;      // [E][64] each
+        const int E = a.cross_E;
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+            *(float4v *) (qs + (wm * (BM / WM) + mi * 16 + fl) * 68 + wn * (BN / WN) + fq * 4) = acc[0][mi];
+        for (int i = tid; i < E * 16; i += NW * 64) {
+            const int e = i >> 4, c4 = (i & 15) * 4;
+            *(float4v *) (ks + e * 64 + c4) = *(const float4v *) (a.cross_k + (int64_t) e * a.H + n0 + c4);
+            *(float4v *) (vs + e * 64 + c4) = *(const float4v *) (a.cross_v + (int64_t) e * a.H + n0 + c4);
+        }
+        __syncthreads();
+        const int cl = tid & 15;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const int rl = pass * 32 + (tid >> 4), r = r0 + rl;
+            const float4v q4 = *(const float4v *) (qs + rl * 68 + cl * 4);
+            float sc[32];
+            float m = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 32; e++) {
+                if (e < E) {
+                    const float4v k4 = *(const float4v *) (ks + e * 64 + cl * 4);
+                    float d = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
+                    sc[e] = row16_sum(d) * a.cross_scale;
+                    m = fmaxf(m, sc[e]);
+                }
+            }
+            float l = 0.0f;
+            float4v o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 32; e++) {
+                if (e < E) {
+                    const float p = expf(sc[e] - m);
+                    const float4v v4 = *(const float4v *) (vs + e * 64 + cl * 4);
+                    l += p;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) o[j] += p * v4[j];
+                }
+            }
+            if (r < a.R) {
+                if (a.cross_out16) {
+                    half4 h;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) h[j] = (_Float16) (o[j] / l);
+                    *(half4 *) (a.cross_out16 + (int64_t) r * a.H + n0 + cl * 4) = h;
+                } else {
+                    float4v res;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) res[j] = o[j] / l;
+                    *(float4v *) (a.cross_out + (int64_t) r * a.H + n0 + cl * 4) = res;
+                }
+            }
+        }
     } else if constexpr (EPI == EPI_QKV) {
         int64_t rowoff[MI];   // this lane's rows in the cache: sequence and position
 #pragma unroll

@@ -83,7 +83,8 @@ enum { PRO_F32 = 0, PRO_LN = 1, PRO_F16 = 2, PRO_ATTN = 3,
 #define ATTN_FOLD_NZ 8    // slices a consumer's staging prologue merges (the default split count of the captured steps)
 // key-split partials of one (row, head): [nsplit][ATT_PS] floats = max, sum, pad, pad, acc[64] (acc 16-byte aligned)
 constexpr int ATT_PS = 68, ATT_PO = 4;
-enum { EPI_STORE = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3 };
+enum { EPI_STORE = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3,
+       EPI_CROSS = 4 };   // gemm_tile_kernel<64, 64, ..> only: the tile is one head's cross-attention query for 64 rows; the attention runs in the epilogue
 
 struct GemmArgs {
     const void *W;      // [N][K], fp16 or fp32 (ggml ne=[K,N])
@@ -121,6 +122,13 @@ struct GemmArgs {
     // PRO_ATTN: partials [R][att_heads][att_nz][ATT_PS]
     const float *att_part;
     int att_nz, att_heads;
+    // EPI_CROSS: cross-attention over the voice prompt inside the cross-q GEMM (parler/model.cpp:576-593): K_c / V_c [cross_E][H] fp32 of this layer,
+    // the attended rows go to cross_out (fp32 [R][H]) or cross_out16 (fp16, for an fp16 out projection); q itself is never written
+    const float *cross_k, *cross_v;
+    int cross_E;
+    float cross_scale;
+    float *cross_out;
+    _Float16 *cross_out16;
     // debug (TTS_HIP_B1_STAMPS=1): s_memrealtime stamps (100 MHz) written by the first and the last workgroup of the launch, 8 slots each
     long long *stamps;
 };

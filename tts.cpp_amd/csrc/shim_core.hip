@@ -169,6 +169,7 @@ extern "C" int tts_hip_tune(tts_hip_ctx *c, const char *key, int v) {
     else if (k == "attn_split") c->attn_split_max = std::max(1, std::min(16, v));
     else if (k == "attn_fold") c->attn_fold = v != 0;
     else if (k == "attn_wave") c->attn_wave = v != 0;
+    else if (k == "cross_fold") c->cross_fold = v != 0;
     else if (k == "tile_min_rows") c->tile_min_rows = std::max(0, v);
     else if (k == "tile_deep") c->tile_deep = v;
     else if (k == "gemv_stream") c->gemv_stream = v != 0;

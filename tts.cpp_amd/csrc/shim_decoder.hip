@@ -388,6 +388,10 @@ int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int ep
     a.W = c->arena + w.off;
     a.K = (int) w.K;
     a.N = (int) w.N;
+    // EPI_CROSS is a request: the cross-attention runs in the epilogue when this GEMM takes the 64 x 64 tile (one head per tile column); any other
+    // path stores q as before and the caller launches the attention (c->cross_folded says which)
+    const bool want_cross = epi == EPI_CROSS;
+    if (want_cross) { epi = EPI_STORE; c->cross_folded = false; }
     if (w.type == TTS_HIP_Q8I) return run_qgemm(c, kclass, w, a, pro, epi);
     const double wbytes = (double) w.K * w.N * (w.type == TTS_HIP_F16 ? 2 : 4);
     const double bytes = wbytes + (double) a.R * a.K * 4 + (double) a.R * a.N * 4;
@@ -450,6 +454,11 @@ int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int ep
         }
         CHK(prof_begin(c, kclass, bytes, flops));
         int rc;
+        if (want_cross && shape == 3 && ks == 1 && a.cross_E >= 1 && a.cross_E <= 32 && a.N == a.H && a.H % 64 == 0) {
+            TileMap tm{(a.R + 63) / 64, a.N / 64, 1};
+            rc = launch_tile_shape<64, 64, 2, 4, EPI_CROSS>(c, a, tm, c->tile_deep && tm.m_tiles * tm.n_tiles <= 320);
+            c->cross_folded = rc == 0;
+        } else
         if (epi == EPI_STORE) rc = launch_tile<EPI_STORE>(c, a, shape, ks);
         else if (epi == EPI_QKV) rc = launch_tile<EPI_QKV>(c, a, shape, ks);
         else if (epi == EPI_RESID) rc = launch_tile<EPI_RESID>(c, a, shape, ks);
@@ -626,7 +635,17 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
             gq.ln_w = (const float *) (c->arena + y.ca_w); gq.ln_b = (const float *) (c->arena + y.ca_b);
             gq.out = c->q; gq.ldo = H;
             gq.stamps = stamp_slot();
-            CHK(run_gemm(c, TTS_HIP_K_GEMM_CROSS_Q, y.cq, gq, PRO_LN, EPI_STORE));
+            const bool co_half_ = y.co.type == TTS_HIP_F16 && !valu_mode && (H % 256 == 0);
+            // many rows: the attention over the voice prompt inside the q projection's 64 x 64 tiles (gemm_tile_kernel<.., EPI_CROSS>), no launch of its own
+            const bool try_fold = c->cross_fold && c->attn_short && c->E >= 1 && c->E <= 32 && H == c->NH * 64 && !c->debug;
+            if (try_fold) {
+                gq.cross_k = (const float *) (c->cross_kv_ptr() + ((size_t) l * 2 + 0) * c->ECAP * H * 4);
+                gq.cross_v = (const float *) (c->cross_kv_ptr() + ((size_t) l * 2 + 1) * c->ECAP * H * 4);
+                gq.cross_E = c->E; gq.cross_scale = at.scale;
+                gq.cross_out = c->att; gq.cross_out16 = co_half_ ? c->att16 : nullptr;
+            }
+            CHK(run_gemm(c, TTS_HIP_K_GEMM_CROSS_Q, y.cq, gq, PRO_LN, try_fold ? EPI_CROSS : EPI_STORE));
+            const bool folded = try_fold && c->cross_folded;
             AttnArgs ac{};
             ac.q = c->q;
             ac.kc = c->cross_kv_ptr() + ((size_t) l * 2 + 0) * c->ECAP * H * 4;
@@ -635,7 +654,7 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
             const bool co_half = y.co.type == TTS_HIP_F16 && !valu_mode && (H % 256 == 0);
             ac.H = H; ac.n_heads = c->NH; ac.scale = at.scale; ac.out = c->att; ac.out16 = co_half ? c->att16 : nullptr; ac.part = c->part;
             ac.stamps = stamp_slot();
-            CHK(run_attn(c, TTS_HIP_K_ATTN_CROSS, ac, R, 1, 2.0 * c->E * H * 4));
+            if (!folded) CHK(run_attn(c, TTS_HIP_K_ATTN_CROSS, ac, R, 1, 2.0 * c->E * H * 4));
             GemmArgs gc = go;
             gc.stamps = stamp_slot();
             gc.A = co_half ? (const void *) c->att16 : (const void *) c->att;
