@@ -86,10 +86,12 @@ int main(int argc, char **argv) {
                     const int total = tm.m_tiles * tm.n_tiles * tm.k_slices;
                     const int grid = (total + 7) / 8 * 8;
                     const size_t lds = (size_t) c.S * (c.BM + c.BN) * c.BK * 2;
+                    if (lds > 160 * 1024) continue;   // does not fit a CU's LDS: the launch would fail and the check would read the previous configuration's output
                     // check (weight copy 0)
                     g.W = W;
                     CK(hipMemset(out, 0xFF, (size_t) ks * RMAXB * sh.N * 4));
                     hipLaunchKernelGGL(c.k, dim3(grid), dim3(c.threads), lds, 0, g, tm);
+                    if (hipGetLastError() != hipSuccess) { printf("%-5s R=%3d %-12s ks=%d launch failed\n", sh.name, R, c.name, ks); continue; }
                     fold_kernel<<<((size_t) R * sh.N + 255) / 256, 256>>>(out, fold, (size_t) R * sh.N, ks, (size_t) RMAXB * sh.N);
                     CK(hipDeviceSynchronize());
                     CK(hipMemcpy(h_out.data(), fold, (size_t) R * sh.N * 4, hipMemcpyDeviceToHost));
