@@ -51,7 +51,7 @@ SAMPLE_RATE = 44100.0
 # kernel families as rocprofv3 groups them by symbol (profiles/r02/kernel_stats_*.csv): the per-class HIP-event statistics of the shim
 # (tts_hip_profile) are summed per family, so "dominant" means what it means in the rocprof table
 FAMILIES = {
-    "gemm_tile_kernel (decoder GEMMs: qkv, out_proj, cross q/out, fc1, fc2, heads)":
+    "gemm_tile_kernel (decoder GEMMs: qkv, out_proj, cross q with the cross-attention in its epilogue, cross out, fc1, fc2, heads)":
         ["gemm_qkv", "gemm_attn_out", "gemm_cross_q", "gemm_cross_out", "gemm_fc1", "gemm_fc2", "gemm_heads", "gemm_other"],
     "attn_rows_kernel / attn_kernel (self-attention over the fp32 KV cache; one workgroup per row from 1024 rows)": ["attn_self"],
     "attn_short_kernel (cross-attention over the voice prompt)": ["attn_cross"],
@@ -62,7 +62,7 @@ FAMILIES = {
     "convt_b3_kernel (DAC transposed convs)": ["dac_convt"],
     "other (embed, sampler/feed, DAC quantizer + final conv)": ["embed", "sample", "dac_embed", "dac_final"],
 }
-MFMA_FP16 = {"gemm_tile_kernel (decoder GEMMs: qkv, out_proj, cross q/out, fc1, fc2, heads)"}
+MFMA_FP16 = {"gemm_tile_kernel (decoder GEMMs: qkv, out_proj, cross q with the cross-attention in its epilogue, cross out, fc1, fc2, heads)"}
 MFMA_FP32 = {"conv_b3p_kernel<1,...> + snake_split_kernel (DAC k=1 convs + residual of the wide classes)"}
 # families that run fp32 convolutions as bf16 x 3 split products when the codec arithmetic is on (tts_hip_dac_arith): issued bf16 flops per
 # algorithmic flop = six products, and the k = 7 kernels pad their 7 taps to 8 k-slots
@@ -430,10 +430,10 @@ class TimeBudget:
     Round 4's table over-priced the short sections by 2-3 x and warmed every long part up with a full run of itself (250 of 440 s), so the driver's
     `--steps 20 --warmup 5` line (25 steps of ~11 s = 280 s before any extra) dropped the round's own feature.  Round 5: the long parts warm up on a
     48-step run of the same row count, the request stream is 2 x the rows instead of 3 x, the costs are the measured ones, and the order inside
-    long_utterances is uniform, ragged_stream, ragged, uniform_same_mix (most wanted first).  With 25 steps of 11.8 s the whole line takes ~545 s.  `--time-budget-s 0` = no limit."""
-    COST = {"decode_step_batch1": 6, "generate_batch1_end_to_end": 10, "secondary.kokoro": 3, "secondary.dia": 9, "secondary.orpheus": 6,
-            "long_utterances.uniform": 62, "long_utterances.ragged_stream": 70, "long_utterances.ragged": 37, "long_utterances.uniform_same_mix": 33}
-    RESERVED = 16   # the CPU baseline that still has to run after the extras of the main context
+    long_utterances is uniform, ragged_stream, ragged, uniform_same_mix (most wanted first).  With 25 steps of 11.3 s the whole line takes 519 s (profiles/r05/bench_driver_flags.json).  `--time-budget-s 0` = no limit."""
+    COST = {"decode_step_batch1": 5, "generate_batch1_end_to_end": 8, "secondary.kokoro": 2, "secondary.dia": 8, "secondary.orpheus": 5,
+            "long_utterances.uniform": 60, "long_utterances.ragged_stream": 69, "long_utterances.ragged": 36, "long_utterances.uniform_same_mix": 30}
+    RESERVED = 12   # the CPU baseline that still has to run after the extras of the main context
 
     def __init__(self, budget_s):
         self.budget, self.skipped, self.reserved, self.sections = float(budget_s), [], 0.0, {}

@@ -304,7 +304,7 @@ def run_orpheus(args):
         "snac_share_of_step": round(float(np.mean(tc)) / (float(np.mean(ts)) + float(np.mean(tc))), 4),
         "x_real_time_per_gpu": round(audio_s / elapsed, 2),
         "roofline": {"bound": "hbm", "achieved": round(q4_bytes / step / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(q4_bytes / step / 1e9 / HBM_PEAK_GBS, 4),
-                     "traffic": _pmc("orpheus_3b_q4_0_step"), "kernel": "whole decoder step (28 layers x 6 launches: gemv_q4_qkv_rope_kernel, attn_gqa_split_kernel<128> + combine, gemv_q4_rows_lds_kernel, gemv_q4_gateup_silu_kernel; lm_head over 156 940 logits, arg-max)",
+                     "traffic": _pmc("orpheus_3b_q4_0_step"), "kernel": "whole decoder step (28 layers x 6 launches: gemv_q4_qkv_rope_kernel, attn_gqa_wave_kernel<128> + attn_gqa_combine_kernel, gemv_q4_rows_lds_kernel, gemv_q4_gateup_silu_kernel; lm_head over 156 940 logits, arg-max)",
                      "algorithmic_bytes_per_launch": q4_bytes, "note": "Q4_0 bytes of every matrix one step reads (lm_head included, one embedding row excluded); "
                      "the decoder steps are the dominant part of the timed region (snac_share_of_step is the codec's)"},
     }
@@ -369,7 +369,7 @@ def run_kokoro(args):
         "ms_per_step": round(timed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (seeded random weights at the shapes of hexgrad/Kokoro-82M)",
         "config": {"workload": "configs[2]: Kokoro-82M on 1 x MI355X, 64 and 400 phoneme ids, durations forced to 3 frames per id for shape determinism; "
-                               "tts_hip_kokoro_durations + tts_hip_kokoro_generate (exact-fp32 MFMA convolutions, workgroup-split LSTM recurrence)", "parallelism": "dp1"},
+                               "tts_hip_kokoro_durations + tts_hip_kokoro_generate (k = 3 / 5 / 7 / 11 convolutions as bf16 x 3 split products on the bf16 matrix pipe at fp32-level error, the rest exact-fp32 MFMA; workgroup-split LSTM recurrence)", "parallelism": "dp1"},
         "by_length": res,
     }
     # the dominant family (the stride-1 "same" convolutions on conv1d_mfma_kernel, exact-fp32 MFMA: kokoro/model.cpp:1141-1242) from an
