@@ -168,7 +168,7 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
         if (gu_fused) {
             // gate | up with silu * up in the epilogue, then the down projection quantising that product while it stages it: two launches
             // instead of three (gemv_q4_gateup_silu_kernel, gemv_q4_rows_lds_kernel<.., QSRC 1>)
-            const int gu_grid = std::min((F / 2 + 3) / 4, 512);   // two resident workgroups per CU; a wave walks its items (gemv_q4_gateup_silu_kernel)
+            const int gu_grid = std::min((F / 2 + 3) / 4, 512);   // 256 / 384 / 512 / 1024 workgroups: 1.24 / 1.17 / 1.14 / 1.25 ms per step (profiles/r05/orpheus_gu_grid_call12.txt)   // two resident workgroups per CU; a wave walks its items (gemv_q4_gateup_silu_kernel)
             QGemmArgs qa{};
             qa.g.W = c->arena + y.gu.off; qa.g.K = H; qa.g.N = 2 * F; qa.g.R = n;
             qa.wd = (const _Float16 *) (c->arena + y.gu.soff); qa.aq = c->aq; qa.ad = c->ad;
