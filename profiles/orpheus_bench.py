@@ -70,7 +70,7 @@ print(f"layers={cfg.layers} prompt 32 + 64 tokens {res[64]*1e3:.1f} ms, + 448 to
 print(f"Q4_0 bytes per step {q4_bytes/1e9:.3f} GB -> {q4_bytes/step/1e9:.0f} GB/s algorithmic ({q4_bytes/step/8e12*100:.1f}% of 8 TB/s); "
       f"HBM floor {q4_bytes/8e12*1e3:.3f} ms/step")
 
-if os.environ.get("ORPHEUS_BENCH_GREEDY_ONLY"):   # counter passes (profiles/r4_pmc_secondary.sh): the arg-max loop only
+if os.environ.get("ORPHEUS_BENCH_GREEDY_ONLY"):   # counter passes (profiles/r04/scripts/r4_pmc_secondary.sh): the arg-max loop only
     sys.exit(0)
 # the default generation_configuration samples (top_k 50, temperature 1, top_p 1): sampler::sample over the 156 940 logits on the device
 u = rng.random(448, dtype=np.float32)

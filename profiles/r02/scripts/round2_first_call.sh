@@ -1,6 +1,6 @@
 #!/bin/bash
 # First GPU call of the next round: everything that was written after round 1's GPU minutes ran out, in one box acquisition.
-#   gpurun --timeout 420 -- 'bash profiles/round2_first_call.sh'
+#   gpurun --timeout 420 -- 'bash profiles/r02/scripts/round2_first_call.sh'
 # Each step has its own timeout and log under gpurun_out/r2/; nothing here changes defaults.
 set -u
 mkdir -p gpurun_out/r2

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/r4
-bash profiles/r4_pmc.sh > gpurun_out/r4/pmc_main_run.txt 2>&1; tail -25 gpurun_out/r4/pmc_main_run.txt | cut -c1-170
+bash profiles/r04/scripts/r4_pmc.sh > gpurun_out/r4/pmc_main_run.txt 2>&1; tail -25 gpurun_out/r4/pmc_main_run.txt | cut -c1-170
 python - <<'PY'
 import json
 d = json.load(open('gpurun_out/r4/pmc_main/pmc_traffic.json'))

@@ -14,6 +14,6 @@ print('value', d['value'], 'attn', d['roofline']['frac'], 'b1', d['decode_step_b
 for f in d['roofline_families']: print('  ', f['kernel'][:70], f['bound'], f['achieved'], f['frac'], f['share_of_kernel_time'])
 PY
 # PMC traffic (FETCH_SIZE / WRITE_SIZE in separate passes) of the codec pass and the 1024-row decoder loop -> gpurun_out/r3/pmc/pmc_traffic.json
-bash profiles/r3_pmc.sh > gpurun_out/r4/pmc_run.txt 2>&1; tail -30 gpurun_out/r4/pmc_run.txt | cut -c1-160
+bash profiles/r03/scripts/r3_pmc.sh > gpurun_out/r4/pmc_run.txt 2>&1; tail -30 gpurun_out/r4/pmc_run.txt | cut -c1-160
 # Orpheus-3B Q4_0 step, kernel by kernel (eager: rocprofv3 cannot follow its graph replays)
 (cd /tmp && export TMPDIR=/tmp && TTS_HIP_LLAMA_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_orph -- python $GRAFT_REPO_ROOT/profiles/orpheus_bench.py > $GRAFT_REPO_ROOT/gpurun_out/r4/orpheus_kt.log 2>&1; f=$(find /tmp/kt_orph -name "*kernel_stats.csv" | head -1); cp "$f" $GRAFT_REPO_ROOT/gpurun_out/r4/kernel_stats_orpheus_first.csv; head -14 $GRAFT_REPO_ROOT/gpurun_out/r4/kernel_stats_orpheus_first.csv | cut -c1-150)

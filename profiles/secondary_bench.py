@@ -30,7 +30,7 @@ class _Model:
 
 
 def _pmc(name):
-    """HBM bytes per step / launch from the committed counter passes (profiles/pmc_traffic_secondary.json, profiles/r4_pmc_secondary.sh); None if absent"""
+    """HBM bytes per step / launch from the committed counter passes (profiles/pmc_traffic_secondary.json, profiles/r04/scripts/r4_pmc_secondary.sh); None if absent"""
     path = os.path.join(ROOT, "profiles", "pmc_traffic_secondary.json")
     try:
         return round(json.load(open(path))[name]["hbm_bytes"], 1)
