@@ -55,6 +55,9 @@ def analyse(rows, per_layer):
     prev_end = None
     for k in range(per_layer):
         a = r[:, k, :5].astype(float); b = r[:, k, 5:].astype(float)
+        if not (a[:, 0] > 0).any() and not (b[:, 0] > 0).any():
+            print(f"    launch {k}: no record (the cross-attention runs inside the next launch's prologue)")
+            continue
         def seg(x):
             x = np.where(x > 0, x, np.nan)
             start = x[:, 0]
@@ -96,8 +99,12 @@ def main():
         if base_lg is None: base_lg, base_tok = lg, tok
         same = int((tok == base_tok).all())
         first_diff = -1 if same else int(np.argwhere((tok != base_tok).any(axis=(1, 2)))[0][0])
+        # the logits are those of one step behind the N decoded ones: comparable only when the histories are the same.  A chain that sums in another
+        # order (the cross-attention inside the out projection, round 5) picks another token somewhere along a random-weight sequence.
+        cmp_lg = (f"logits max |diff| {np.abs(lg - base_lg).max():.3e} (max |logit| {np.abs(base_lg).max():.2f})" if same else
+                  "logits not compared (the histories differ from there on; the kernels' own parity tests bound the difference per launch)")
         print(f"{name:36s}{' [stamps]' if stamps else '':9s} {r['ms_per_step']:.4f} ms/step = {r['x_real_time']:.2f} x real time;  tokens equal to plain: {same}"
-              f"{'' if same else ' (first difference at step %d)' % first_diff};  logits max |diff| {np.abs(lg - base_lg).max():.3e} (max |logit| {np.abs(base_lg).max():.2f})")
+              f"{'' if same else ' (first difference at step %d)' % first_diff};  {cmp_lg}")
         if stamps: analyse(r["stamps"], 8)
 
 

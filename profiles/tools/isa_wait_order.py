@@ -10,14 +10,17 @@ For every kernel: walk the straight-line head (up to the first integer dot / MFM
 loads, and report each `s_waitcnt vmcnt(N)` that retires a non-temporal load while work that is NOT the consumer of those weights follows:
 further global loads, LDS writes or a barrier before the first dot product.
 
-  python profiles/tools/isa_wait_order.py unit.s [name-filter] [--loops]   (--loops: walk into the loops of the head too)
+  python profiles/tools/isa_wait_order.py unit.s [name-filter] [--loops] [--first-use=MNEMONIC]
+      --loops: walk into the loops of the head too
+      --first-use=v_exp_f32: the head ends at this instruction as well (a prologue whose own arithmetic is what has to start before the weights land:
+                             the attention inside gemm16_kernel<.., PRO_CROSS, ..>, whose later chunks of keys, E > 8, do wait for the weights)
 """
 import re, sys
 
 txt = open(sys.argv[1]).read()
-flt = sys.argv[2] if len(sys.argv) > 2 else ""
+flt = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else ""
 funcs = re.split(r'\n(?=_Z[\w]+:\s*;? *@)|\n(?=\w+:\s*; @)', txt)
-DOT = ("v_dot4", "v_dot2", "v_mfma", "v_dot8")
+DOT = ("v_dot4", "v_dot2", "v_mfma", "v_dot8") + tuple(a.split("=", 1)[1] for a in sys.argv if a.startswith("--first-use="))
 for f in funcs:
     m = re.match(r'(\w+):', f)
     if not m or 's_endpgm' not in f or flt not in m.group(1):

@@ -1002,3 +1002,39 @@ def test_cross_attention_inside_the_q_projection_tiles(rows, enc, monkeypatch):
         o.decode(prompts[r], 0, audio=False, want_logits=False)
         ref, _ = o.decode(ids[r], len(prompts[r]), audio=True)
         assert relerr(out[1][r], ref[:, 0, :]) < TOL[gguf.F16], (rows, enc, r)
+
+
+@pytest.mark.parametrize("rows,enc", [(1, 8), (3, 8), (4, 27)])
+def test_cross_attention_inside_the_out_projection_prologue(rows, enc):
+    """The one-sequence chain (<= 4 rows): the cross-attention over the voice prompt runs in the prologue of its own out projection
+    (gemm16_kernel<.., PRO_CROSS, ..>: every workgroup recomputes it from the q rows and K_c / V_c) instead of attn_short_kernel + a launch
+    boundary.  Against the oracle over three steps, and against the same chain with the fold switched off (tune cross_fold = 0)."""
+    key = ("wide1e%d" % enc, gguf.F16)
+    if key not in _models:
+        _models[key] = synth.build(synth.tiny(hidden=1024, heads=16, ffn=4096, layers=1, enc_len=enc, weight_type=gguf.F16))
+    model = _models[key]
+    cfg = model.cfg
+    rng = np.random.default_rng(rows * 7 + enc)
+    prompts = [rng.integers(3, cfg.prompt_vocab, 3 + i).astype(np.uint32) for i in range(rows)]
+    oracles = []
+    for p in prompts:
+        o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+        o.decode(p, 0, audio=False, want_logits=False)
+        oracles.append(o)
+    engines = []
+    for fold in (1, 0):
+        eng = hip.HipEngine(cfg, max_seqs=rows, kv_positions=16, tune={"cross_fold": fold})
+        eng.load(model)
+        eng.prefill_batch(prompts)
+        engines.append(eng)
+    ids = np.full((rows, cfg.n_out), cfg.bos, dtype=np.uint32)
+    for step in range(3):
+        pos = [len(p) + step for p in prompts]
+        a, b = engines[0].step(ids, pos), engines[1].step(ids, pos)
+        assert relerr(a, b) < TOL[gguf.F16], step
+        for r in range(rows):
+            ref, _ = oracles[r].decode(ids[r], pos[r], audio=True)
+            assert relerr(a[r], ref[:, 0, :]) < TOL[gguf.F16], (rows, enc, step, r)
+            ids[r] = ref[:, 0, :].argmax(-1)
+    for eng in engines:
+        eng.close()

@@ -22,6 +22,7 @@ template __global__ void gemm16_kernel<1, PRO_LN, EPI_STORE, 1>(GemmArgs);
 template __global__ void gemm16_kernel<1, PRO_LN, EPI_QKV, 1>(GemmArgs);
 template __global__ void gemm16_kernel<1, PRO_ATTN, EPI_RESID, 1>(GemmArgs);
 template __global__ void gemm16_kernel<1, PRO_F16, EPI_STORE, 1>(GemmArgs);
+template __global__ void gemm16_kernel<1, PRO_CROSS, EPI_RESID, 1>(GemmArgs);
 template __global__ void gemm_tile_kernel<128, 128, 2, 4, 64, 4, EPI_QKV>(GemmArgs, TileMap);
 template __global__ void gemm_tile_kernel<128, 128, 2, 4, 64, 4, EPI_RESID>(GemmArgs, TileMap);
 template __global__ void gemm_tile_kernel<64, 64, 2, 4, 128, 3, EPI_RESID>(GemmArgs, TileMap);
@@ -137,5 +138,11 @@ def test_one_sequence_kernels_request_their_staging_inputs_before_the_weights(tm
         assert must.split("<")[0] in open(asm).read()
         out = subprocess.run([sys.executable, tool, str(asm)], capture_output=True, text=True, check=True).stdout
         filt = subprocess.run(["c++filt"], input=out, capture_output=True, text=True).stdout if shutil.which("c++filt") else out
-        bad = [ln for ln in filt.splitlines() if must in ln]
+        bad = [ln for ln in filt.splitlines() if must in ln and "gemm16_kernel<1, 6," not in ln]
         assert not bad, "\n".join(bad)
+        if name == "parler_wo":
+            # PRO_CROSS (the cross-attention in the out projection's prologue): the softmax over the first eight keys must start before the weights
+            # land; the later chunks of a longer voice prompt (E > 8) are requested behind the weights and wait for them
+            out = subprocess.run([sys.executable, tool, str(asm), "gemm16_kernelILi1ELi6E", "--first-use=v_exp_f32"], capture_output=True, text=True,
+                                 check=True).stdout
+            assert "gemm16_kernel" not in out, out

@@ -78,7 +78,8 @@ static __global__ void embed_rows_kernel(EmbedArgs a) {
 enum { PRO_F32 = 0, PRO_LN = 1, PRO_F16 = 2, PRO_ATTN = 3,
        // gemv_stream_kernel only (Dia's step): the activations are the eight key slices of attn_gqa_split_kernel (merged while they are staged:
        // attn_gqa_combine_kernel's arithmetic) / the gate | up slabs of the preceding projection (silu(gate) * up while staged: silu_mul_kernel's)
-       PRO_ATTN8 = 4, PRO_SILU = 5 };
+       PRO_ATTN8 = 4, PRO_SILU = 5,
+       PRO_CROSS = 6 };   // gemm16_kernel (<= 4 rows): the activations are the cross-attention's query rows; the attention over the voice prompt runs in the prologue
 #define ATTN_PART 130     // floats per partial of attn_gqa_split_kernel: max, sum, out[128]
 #define ATTN_FOLD_NZ 8    // slices a consumer's staging prologue merges (the default split count of the captured steps)
 // key-split partials of one (row, head): [nsplit][ATT_PS] floats = max, sum, pad, pad, acc[64] (acc 16-byte aligned)
@@ -186,7 +187,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs &a, int EPI, int r
 // WT: 0 = fp32 weights (exact-fp32 MFMA 16x16x4), 1 = fp16 weights (MFMA 16x16x32, activations rounded
 // to fp16 like ggml's vec_dot_type conversion).  blockDim.x = 64 * K/256.
 template <int WT, int PRO, int EPI, int RB>
-__global__ __launch_bounds__(PRO == PRO_LN || PRO == PRO_ATTN ? 512 : 1024) void gemm16_kernel(GemmArgs a) {
+__global__ __launch_bounds__(PRO == PRO_LN || PRO == PRO_ATTN || PRO == PRO_CROSS ? 512 : 1024) void gemm16_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // nw waves split this workgroup's K range in 256-wide slices; when the forward carries several groups of
@@ -357,13 +358,85 @@ __global__ __launch_bounds__(PRO == PRO_LN || PRO == PRO_ATTN ? 512 : 1024) void
         red_off = (red_off + 15) & ~(size_t) 15;
         __syncthreads();
     }
+    if (PRO == PRO_CROSS) {   // WT == 1, no K split, <= 4 rows, blockDim.x == K / 4 == 16 lanes per 64-wide head
+        // The out projection of the cross-attention block takes the attention itself into its prologue (one-sequence chain, round 5): a.A holds the
+        // query rows (the cross-q GEMM's output), cross_k / cross_v the layer's K_c / V_c [E][H].  Thread t owns channels 4 t .. 4 t + 3 (head t / 16):
+        // score of a key = row16_sum of a 4-term partial dot, running max / sum / output per row (soft_max_ext + mul_mat as one pass over the <= 32
+        // keys; attn_short_kernel's mathematics up to the order of the sums); the attended rows go to LDS as fp16, where the MFMA loop reads them as
+        // it does a LayerNorm prologue's.  Every workgroup repeats the attention (68 KB of K_c / V_c from L2 at 8 positions): ~0.8 us of prologue
+        // against the 3 us of a launch (attn_short_kernel's span + the gap in front of it, profiles/r05/b1_chain_call2.txt).
+        const int E = a.cross_E, col = tid * 4;
+        const float *qa = (const float *) a.A;
+        float4v q4[4], kf[8], vf[8];
+#pragma unroll
+        for (int r = 0; r < 4; r++) q4[r] = *(const float4v *) (qa + (int64_t) min(r, a.R - 1) * a.lda + col);
+        auto request = [&](int e0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int64_t off = (int64_t) min(e0 + u, E - 1) * K + col;
+                kf[u] = *(const float4v *) (a.cross_k + off);
+                vf[u] = *(const float4v *) (a.cross_v + off);
+            }
+        };
+        request(0);
+        load_weights();
+        float m[4], l[4];
+        float4v acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { m[r] = -INFINITY; l[r] = 0.0f; acc[r] = (float4v){0.f, 0.f, 0.f, 0.f}; }
+        auto chunk = [&](int e0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (r < a.R) {
+                    // the eight scores of a chunk are independent of each other: one merge with the running state per chunk (per key it was a chain
+                    // of eight dependent max / exp / fma groups: 2.3 us of prologue, profiles/r05/b1_cross_fold_call13.txt)
+                    float sc[8], mc = -INFINITY;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const float d = q4[r][0] * kf[u][0] + q4[r][1] * kf[u][1] + q4[r][2] * kf[u][2] + q4[r][3] * kf[u][3];
+                        sc[u] = e0 + u < E ? row16_sum(d) * a.cross_scale : -INFINITY;
+                        mc = fmaxf(mc, sc[u]);
+                    }
+                    const float mn = fmaxf(m[r], mc);
+                    const float f = expf(m[r] - mn);   // 0 on the first chunk (m = -inf)
+                    float ls = 0.0f;
+                    float4v as = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const float p = expf(sc[u] - mn);   // 0 for a key beyond E
+                        ls += p;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) as[e] += p * vf[u][e];
+                    }
+                    l[r] = l[r] * f + ls;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[r][e] = acc[r][e] * f + as[e];
+                    m[r] = mn;
+                }
+            }
+        };
+        chunk(0);   // outside the loop: a loop header waits for every outstanding load, the weights included (profiles/tools/isa_wait_order.py)
+        for (int e0 = 8; e0 < E; e0 += 8) { request(e0); chunk(e0); }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (r < a.R) {
+                half4 hh;
+#pragma unroll
+                for (int e = 0; e < 4; e++) hh[e] = (_Float16) (acc[r][e] / l[r]);
+                *(half4 *) (xs16 + (size_t) r * ldx + col) = hh;
+            }
+        }
+        red_off = (size_t) RB * 16 * ldx * 2;
+        red_off = (red_off + 15) & ~(size_t) 15;
+        __syncthreads();
+    }
     // activations straight from memory (PRO_F16 / PRO_F32): the fragments of the first row group ahead of the weights when a group is one
     // row block (<= 16 rows per group: the one-sequence chain and the small lock-step batches); larger groups keep the weights in front
     const int r_lo = a.rows_per_z ? (int) blockIdx.z * a.rows_per_z : 0;
     const int r_hi = a.rows_per_z ? min(a.R, r_lo + a.rows_per_z) : a.R;
     constexpr bool PRELOAD = WT == 1 && RB == 1 && (PRO == PRO_F16 || PRO == PRO_F32);
     half8 bpre[8];
-    if (PRO != PRO_LN && PRO != PRO_ATTN) {
+    if (PRO != PRO_LN && PRO != PRO_ATTN && PRO != PRO_CROSS) {
         if (PRELOAD) {
             const int r = r_lo + gs * 16 + li;
             const int rr = max(0, min(r, r_hi - 1));
@@ -416,7 +489,7 @@ __global__ __launch_bounds__(PRO == PRO_LN || PRO == PRO_ATTN ? 512 : 1024) void
                     for (int c = 0; c < 8; c++) {
                         half8 b;
                         const int k = kb + c * 32;
-                        if (PRO == PRO_LN || PRO == PRO_ATTN) {
+                        if (PRO == PRO_LN || PRO == PRO_ATTN || PRO == PRO_CROSS) {
                             b = *(const half8 *) (xs16 + (size_t) r * ldx + k);
                         } else if (PRO == PRO_F16) {
                             b = *(const half8 *) ((const _Float16 *) a.A + (int64_t) rr * a.lda + k);

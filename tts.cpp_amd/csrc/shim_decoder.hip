@@ -89,9 +89,9 @@ static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
     // wave sets working on different row groups in parallel (up to 16 waves per workgroup)
     const int rows_wg = a.rows_per_z ? std::min(a.rows_per_z, a.R) : a.R;
     const int n_groups = (rows_wg + 16 * RB - 1) / (16 * RB);
-    const int ngs = PRO == PRO_LN || PRO == PRO_ATTN ? 1 : std::max(1, std::min(n_groups, 16 / nw));
+    const int ngs = PRO == PRO_LN || PRO == PRO_ATTN || PRO == PRO_CROSS ? 1 : std::max(1, std::min(n_groups, 16 / nw));
     size_t lds = 0;
-    if (PRO == PRO_LN || PRO == PRO_ATTN) {
+    if (PRO == PRO_LN || PRO == PRO_ATTN || PRO == PRO_CROSS) {
         lds = (size_t) RB * 16 * (a.K + (WT == 1 ? 8 : 4)) * (WT == 1 ? 2 : 4);
         lds = (lds + 15) & ~(size_t) 15;
     }
@@ -106,7 +106,7 @@ static int launch_gemm16(tts_hip_ctx *c, const GemmArgs &a) {
         return set_err("gemm16: %d pending K-slice slabs cannot be folded by this instance (WT %d, PRO %d, EPI %d, K %d)", a.n_parts, WT, PRO, EPI, a.K);
     if (lds > 160 * 1024) return set_err("gemm16: LDS request %zu exceeds 160 KiB", lds);
     if (PRO == PRO_LN && a.K > 2048) return set_err("gemm16: LayerNorm prologue supports hidden sizes up to 2048 (got %d)", a.K);
-    if ((PRO == PRO_LN || PRO == PRO_ATTN) && ngs * nw > 8) return set_err("gemm16: fused-prologue launch wants %d waves (> 8)", ngs * nw);
+    if ((PRO == PRO_LN || PRO == PRO_ATTN || PRO == PRO_CROSS) && ngs * nw > 8) return set_err("gemm16: fused-prologue launch wants %d waves (> 8)", ngs * nw);
     const int nz = a.rows_per_z ? (a.R + a.rows_per_z - 1) / a.rows_per_z : 1;
     hipLaunchKernelGGL((gemm16_kernel<WT, PRO, EPI, RB>), dim3(a.N / 16, ksplit, nz), dim3(ngs * nw * 64), lds, c->stream, a);
     HIPCHK(hipGetLastError());
@@ -496,7 +496,7 @@ int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int ep
     GEMM_CASE(1, PRO_LN, EPI_GELU) GEMM_CASE(0, PRO_LN, EPI_GELU)
     GEMM_CASE(1, PRO_F32, EPI_RESID) GEMM_CASE(0, PRO_F32, EPI_RESID)
     GEMM_CASE(1, PRO_F32, EPI_STORE) GEMM_CASE(0, PRO_F32, EPI_STORE)
-    GEMM_CASE(1, PRO_F16, EPI_RESID) GEMM_CASE(1, PRO_ATTN, EPI_RESID)
+    GEMM_CASE(1, PRO_F16, EPI_RESID) GEMM_CASE(1, PRO_ATTN, EPI_RESID) GEMM_CASE(1, PRO_CROSS, EPI_RESID)
     GEMM_CASE(1, PRO_F16, EPI_QKV) GEMM_CASE(1, PRO_F16, EPI_STORE) GEMM_CASE(1, PRO_F16, EPI_GELU)
     GEMM_CASE(0, PRO_F32, EPI_QKV) GEMM_CASE(0, PRO_F32, EPI_GELU)
     { rc = set_err("run_gemm: no kernel for type=%d pro=%d epi=%d", w.type, pro, epi); }
@@ -654,11 +654,18 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
             const bool co_half = y.co.type == TTS_HIP_F16 && !valu_mode && (H % 256 == 0);
             ac.H = H; ac.n_heads = c->NH; ac.scale = at.scale; ac.out = c->att; ac.out16 = co_half ? c->att16 : nullptr; ac.part = c->part;
             ac.stamps = stamp_slot();
-            if (!folded) CHK(run_attn(c, TTS_HIP_K_ATTN_CROSS, ac, R, 1, 2.0 * c->E * H * 4));
+            // one-sequence chain: the attention inside the out projection's prologue (gemm16_kernel<.., PRO_CROSS, ..>), no launch of its own
+            const bool b1_fold = !folded && c->cross_fold && c->attn_short && R <= 4 && co_half && c->E >= 1 && c->E <= 32 && H == c->NH * 64 && H <= 2048 &&
+                                 (int) y.co.K == H && !c->gemv_rows && !c->debug && !c->prof;
+            if (!folded && !b1_fold) CHK(run_attn(c, TTS_HIP_K_ATTN_CROSS, ac, R, 1, 2.0 * c->E * H * 4));
             GemmArgs gc = go;
             gc.stamps = stamp_slot();
             gc.A = co_half ? (const void *) c->att16 : (const void *) c->att;
-            CHK(run_gemm(c, TTS_HIP_K_GEMM_CROSS_OUT, y.co, gc, co_half ? PRO_F16 : PRO_F32, EPI_RESID));
+            if (b1_fold) {
+                gc.A = c->q; gc.lda = H;
+                gc.cross_k = (const float *) ac.kc; gc.cross_v = (const float *) ac.vc; gc.cross_E = c->E; gc.cross_scale = ac.scale;
+            }
+            CHK(run_gemm(c, TTS_HIP_K_GEMM_CROSS_OUT, y.co, gc, b1_fold ? PRO_CROSS : (co_half ? PRO_F16 : PRO_F32), EPI_RESID));
         }
 
         // FFN ------------------------------------------------------------------------------
