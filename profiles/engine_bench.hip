@@ -195,6 +195,121 @@ __global__ __launch_bounds__(NTH) void phase_kernel(LayerW w, Bufs b) {
     if (PH == 3) { float r[FD]; calc_plain<FD, 4>(fd, sx, F, lane, r); store_rows<FD>(b.y_down + gw * FD, r, lane); }
 }
 
+__global__ void fill_x(float *p, int n);
+// ---- E: A, and every kernel also asks for the NEXT launch's weights: into the L2 of its own XCD ------------------------------------------------
+// A launch-chain kernel starts with nothing of its own in any cache: ~1 us of HBM latency + the transfer of its share before the first dot product.
+// The previous kernel knows the addresses.  MODE 1: wave (blockIdx, w) of launch k touches every 64-byte piece of what wave (blockIdx, w) of launch
+// k + 1 will stream (plain cached loads of one dword per lane, lane stride 64 B: 4 KB per instruction and ONE register, consumed by a never-true
+// test at the end).  Workgroups go to the XCDs round-robin by blockIdx (checked by xcc_kernel below), so the lines wait in the L2 the consumer will
+// ask.  MODE 2: the same requests shifted by one workgroup (the lines land in ANOTHER XCD's L2: what the memory-side cache alone gives).
+// CAP: bytes of each region's head that are requested (gate|up is 3.1 MB per XCD in full, beside a 4 MB L2).
+template <int BYTES, int NV>
+__device__ __forceinline__ void pf_region(const void *p, int lane, unsigned (&v)[NV], int &n) {
+#pragma unroll
+    for (int i = 0; i < (BYTES + 4095) / 4096; i++) {
+        const int off = min(lane * 64 + i * 4096, BYTES - 4);
+        v[n++] = *(const unsigned *) ((const uint8_t *) p + off);
+    }
+}
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+template <int PH, int MODE, int CAP>
+__global__ __launch_bounds__(NTH) void phase_kernel_e(LayerW w, LayerW wn, Bufs b) {
+    __shared__ __attribute__((aligned(16))) int8_t sx[F];
+    const int tid = threadIdx.x, lane = tid & 63, gw = blockIdx.x * 4 + (tid >> 6);
+    const float *src = PH == 0 ? b.y_down : PH == 1 ? b.y_qkv : PH == 2 ? b.y_o : b.y_gu;
+    const float sc = PH == 0 ? S_IN : PH == 1 ? S_O : PH == 2 ? S_GU : S_DOWN;
+    constexpr int KJ = (PH == 3 ? F : H) / NTH;
+    float v[KJ];
+#pragma unroll
+    for (int j = 0; j < KJ; j++) v[j] = src[tid + j * NTH];
+    __builtin_amdgcn_sched_barrier(0);
+    Frag<FQ, 2> fq; Frag<FO, 2> fo; Frag<2 * FG, 2> fa, fb; Frag<FD, 4> fd;
+    if (PH == 0) { int nf[FQ]; rows_qkv(gw, nf); frag_load<FQ, 2>(fq, w.w4[0], w.wd[0], nf, H, lane); }
+    if (PH == 1) { int nf[FO]; rows_o(gw, nf); frag_load<FO, 2>(fo, w.w4[1], w.wd[1], nf, H, lane); }
+    if (PH == 2) {
+        int nf[2 * FG];
+        rows_gu(gw, 0, nf); frag_load<2 * FG, 2>(fa, w.w4[2], w.wd[2], nf, H, lane);
+        rows_gu(gw, 1, nf); frag_load<2 * FG, 2>(fb, w.w4[2], w.wd[2], nf, H, lane);
+    }
+    if (PH == 3) { int nf[FD]; rows_o(gw, nf); frag_load<FD, 4>(fd, w.w4[3], w.wd[3], nf, F, lane); }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next launch's share, behind this launch's own weights in the queue
+    unsigned pfv[16];
+    int npf = 0;
+    if (MODE) {
+        const int pg = MODE == 1 ? gw : (gw + 4) % NWAVES;   // MODE 2: the neighbour workgroup's share = another XCD's L2
+        if (PH == 3) {   // next: qkv of the next layer
+            pf_region<cmin(FQ * (H / 2), CAP)>(wn.w4[0] + (int64_t) pg * FQ * (H / 2), lane, pfv, npf);
+            pf_region<FQ * (H / 32) * 2>(wn.wd[0] + (int64_t) pg * FQ * (H / 32), lane, pfv, npf);
+        }
+        if (PH == 0) {
+            pf_region<cmin(FO * (H / 2), CAP)>(w.w4[1] + (int64_t) pg * FO * (H / 2), lane, pfv, npf);
+            pf_region<FO * (H / 32) * 2>(w.wd[1] + (int64_t) pg * FO * (H / 32), lane, pfv, npf);
+        }
+        if (PH == 1) {   // gate rows of both items are neighbours, so are the up rows
+            pf_region<cmin(2 * FG * (H / 2), CAP)>(w.w4[2] + (int64_t) pg * 2 * FG * (H / 2), lane, pfv, npf);
+            pf_region<cmin(2 * FG * (H / 2), CAP)>(w.w4[2] + ((int64_t) F + pg * 2 * FG) * (H / 2), lane, pfv, npf);
+            pf_region<2 * FG * (H / 32) * 2>(w.wd[2] + (int64_t) pg * 2 * FG * (H / 32), lane, pfv, npf);
+            pf_region<2 * FG * (H / 32) * 2>(w.wd[2] + ((int64_t) F + pg * 2 * FG) * (H / 32), lane, pfv, npf);
+        }
+        if (PH == 2) {
+            pf_region<cmin(FD * (F / 2), CAP)>(w.w4[3] + (int64_t) pg * FD * (F / 2), lane, pfv, npf);
+            pf_region<FD * (F / 32) * 2>(w.wd[3] + (int64_t) pg * FD * (F / 32), lane, pfv, npf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < KJ; j++) sx[tid + j * NTH] = (int8_t) fminf(fmaxf(rintf(v[j] * sc), -127.0f), 127.0f);
+    __syncthreads();
+    if (PH == 0) { float r[FQ]; calc_plain<FQ, 2>(fq, sx, H, lane, r); store_rows<FQ>(b.y_qkv + gw * FQ, r, lane); }
+    if (PH == 1) { float r[FO]; calc_plain<FO, 2>(fo, sx, H, lane, r); store_rows<FO>(b.y_o + gw * FO, r, lane); }
+    if (PH == 2) {
+        float r[FG];
+        calc_gu(fa, sx, lane, r); store_rows<FG>(b.y_gu + (gw * 2 + 0) * FG, r, lane);
+        calc_gu(fb, sx, lane, r); store_rows<FG>(b.y_gu + (gw * 2 + 1) * FG, r, lane);
+    }
+    if (PH == 3) { float r[FD]; calc_plain<FD, 4>(fd, sx, F, lane, r); store_rows<FD>(b.y_down + gw * FD, r, lane); }
+    if (MODE) {   // the requested dwords are "used": never true, and the compiler cannot know
+        unsigned any = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) if (i < npf) any |= pfv[i];
+        if (any == 0x5EEDF00Du && blockIdx.x == 0x7FFFFFFFu) b.y_qkv[0] = 1.0f;
+    }
+}
+template <int MODE, int CAP>
+static double time_chain_e(const std::vector<LayerW> &hl, Bufs b, hipStream_t st, int reps, float *result) {
+    hipGraph_t g; hipGraphExec_t ge;
+    const int L = (int) hl.size();
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int l = 0; l < L; l++) {
+        const LayerW &wn = hl[(l + 1) % L];
+        hipLaunchKernelGGL((phase_kernel_e<0, MODE, CAP>), dim3(NWG), dim3(NTH), 0, st, hl[l], wn, b);
+        hipLaunchKernelGGL((phase_kernel_e<1, MODE, CAP>), dim3(NWG), dim3(NTH), 0, st, hl[l], wn, b);
+        hipLaunchKernelGGL((phase_kernel_e<2, MODE, CAP>), dim3(NWG), dim3(NTH), 0, st, hl[l], wn, b);
+        hipLaunchKernelGGL((phase_kernel_e<3, MODE, CAP>), dim3(NWG), dim3(NTH), 0, st, hl[l], wn, b);
+    }
+    CK(hipStreamEndCapture(st, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    fill_x<<<(H + 255) / 256, 256, 0, st>>>(b.y_down, H);
+    CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(result, b.y_down, H * 4, hipMemcpyDeviceToHost));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) CK(hipGraphLaunch(ge, st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; i++) CK(hipGraphLaunch(ge, st));
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+    return ms * 1e3 / reps / L;
+}
+__global__ void xcc_kernel(unsigned *out) {   // which XCD a workgroup runs on
+    if (threadIdx.x == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        out[blockIdx.x] = x & 0xF;
+    }
+}
+
 // ---- D: the launch chain again, with the two things the product's kernels have and A does not ----------------------------------------------
 // NF = features (gate|up: output pairs) per wave and item: fewer per wave = more, smaller workgroups, each repeating the staging prologue (the product
 // launches 640 / 384 / 512 / 384 workgroups for the four phases).  RMS = the staging prologue of the product's qkv and gate|up kernels: every
@@ -459,6 +574,29 @@ int main(int argc, char **argv) {
     const double us_a = ms * 1e3 / reps / L;
     printf("A  launch chain (4 launches per layer, graph replay):      %7.2f us per layer  (%.0f GB/s)\n", us_a, layer_bytes / us_a * 1e-3);
 
+    // ---- E: the chain with every kernel warming its XCD's L2 for the next one ----
+    {
+        unsigned *xo; CK(hipMalloc(&xo, NWG * 4 * 2));
+        xcc_kernel<<<NWG, NTH, 0, st>>>(xo); xcc_kernel<<<NWG, NTH, 0, st>>>(xo + NWG);
+        std::vector<unsigned> hx(NWG * 2); CK(hipStreamSynchronize(st)); CK(hipMemcpy(hx.data(), xo, NWG * 8, hipMemcpyDeviceToHost));
+        int rr = 0, same = 0;
+        for (int i = 0; i < NWG; i++) { rr += hx[i] == (unsigned) (i % 8); same += hx[i] == hx[NWG + i]; }
+        printf("E  XCD of a workgroup: %d of %d are blockIdx %% 8, %d of %d the same in two launches (first 16: ", rr, NWG, same, NWG);
+        for (int i = 0; i < 16; i++) printf("%u", hx[i]);
+        printf(")\n");
+        std::vector<float> re(H);
+        auto line = [&](const char *name, double us) {
+            size_t diff = 0;
+            for (int i = 0; i < H; i++) diff += memcmp(&ra[i], &re[i], 4) != 0;
+            printf("E  %-58s %7.2f us per layer  (%.0f GB/s)  = %.2f x A, %zu results differ\n", name, us, layer_bytes / us * 1e-3, us / us_a, diff);
+        };
+        line("no requests for the next launch (= A again)", time_chain_e<0, 1 << 20>(hl, b, st, reps, re.data()));
+        line("next launch's share into this XCD's L2, whole", time_chain_e<1, 1 << 20>(hl, b, st, reps, re.data()));
+        line("... first 8 KB of each region", time_chain_e<1, 8192>(hl, b, st, reps, re.data()));
+        line("... first 4 KB of each region", time_chain_e<1, 4096>(hl, b, st, reps, re.data()));
+        line("the neighbour workgroup's share (another XCD's L2), whole", time_chain_e<2, 1 << 20>(hl, b, st, reps, re.data()));
+    }
+    if (getenv("ENGINE_BENCH_ONLY_E")) return 0;
     // ---- B: persistent, with and without the cross-boundary prefetch ----
     double us_b[2] = {0, 0};
     for (int pf = 1; pf >= 0; pf--) {
