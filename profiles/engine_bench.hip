@@ -19,6 +19,9 @@
 //                     sc1 loads; every spin is bounded (a timeout sets an error word and every workgroup leaves).
 //   C  barrier only:  B without any work: the price of a boundary in the persistent form.
 // Prints us per layer for A and B, us per barrier for C, and checks B's final activations against A's bit for bit.
+//   D  the chain at the product's grid shapes, with and without its rms-norm staging prologue.
+//   E  the chain with every kernel also requesting the NEXT launch's weight share into the L2 of its own XCD (ENGINE_BENCH_ONLY_E=1: only A and E):
+//      0.98 x A (profiles/r05/engine_bench_call14_l2_prefetch.txt) — a launch-chain kernel is not waiting for its first weights.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
