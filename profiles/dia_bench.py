@@ -64,6 +64,8 @@ class M:
 m = M(); m.cfg = cfg; m.tensors = tensors
 U = int(os.environ.get('DIA_BENCH_UTTERANCES', '4'))   # BASELINE config 3: 4 utterances per GPU (x 2 guidance rows)
 eng = hip.DiaEngine(cfg, max_utterances=U)
+for _k, _v in __import__('json').loads(os.environ.get('DIA_TUNE', '{}')).items():   # tts_hip_tune keys of this run
+    eng.tune(_k, _v)
 t0 = time.perf_counter()
 eng.load(m)
 print(f"loaded {sum(len(t.raw()) for t in tensors) / 1e9:.2f} GB in {time.perf_counter() - t0:.1f}s", flush=True)

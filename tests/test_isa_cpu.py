@@ -51,6 +51,7 @@ template __global__ void gemv_stream_kernel<16, PRO_F32, EPI_STORE>(GemmArgs, St
 template __global__ void gemv_stream_kernel<4, PRO_F16, EPI_STORE>(GemmArgs, StreamMap);
 template __global__ void gemv_stream_kernel<4, PRO_ATTN8, EPI_STORE>(GemmArgs, StreamMap);
 template __global__ void gemv_stream_kernel<4, PRO_SILU, EPI_STORE>(GemmArgs, StreamMap);
+template __global__ void gemv_stream_kernel<4, PRO_SILU, EPI_STORE, 4>(GemmArgs, StreamMap);
 """
 DAC_TU = """
 #include <hip/hip_runtime.h>
@@ -108,7 +109,7 @@ def test_hot_kernels_have_no_scratch_and_no_serialized_load_chains(tmp_path):
             assert v <= limit, f"{k}: {v} dependent load groups (limit {limit}): a predicate crept back around a load?"
             checked += 1
     if shutil.which("c++filt"):
-        assert checked >= 15, sorted(seen)
+        assert checked >= 14, sorted(seen)   # (attn_gqa_split_kernel left the listing in round 5: its query, K and V requests are one group now)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")

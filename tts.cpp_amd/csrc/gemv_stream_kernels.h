@@ -24,7 +24,9 @@ struct StreamMap {
     int kslice;  // columns per slice, a multiple of 256
 };
 
-template <int NWV, int PRO, int EPI>
+// NPI (PRO_SILU only): slabs of the gate | up rows an item requests (>= a.n_parts; 8 until round 5, when the launch got an instance per slab count:
+// an item of 32 16-byte loads left one item per thread in front of the weights and the other three as dependent round trips)
+template <int NWV, int PRO, int EPI, int NPI = 8>
 __global__ __launch_bounds__(NWV * 64) void gemv_stream_kernel(GemmArgs a, StreamMap sm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -53,8 +55,8 @@ __global__ __launch_bounds__(NWV * 64) void gemv_stream_kernel(GemmArgs a, Strea
     const int c8n = KS >> 3;
     const int total = RS * c8n;
     constexpr int NT = NWV * 64;
-    constexpr int PRE = (PRO == PRO_F16 || PRO == PRO_F32) ? 4 : 1;
-    constexpr int RAWQ = PRO == PRO_F16 ? 1 : PRO == PRO_SILU ? 32 : PRO == PRO_ATTN8 ? 1 : 2;   // what an item holds between its request and its use
+    constexpr int PRE = (PRO == PRO_F16 || PRO == PRO_F32) ? (NWV <= 4 ? 8 : 4) : PRO == PRO_SILU ? (NPI == 1 ? 4 : NPI == 2 ? 4 : NPI == 4 ? 2 : 1) : 1;
+    constexpr int RAWQ = PRO == PRO_F16 ? 1 : PRO == PRO_SILU ? 4 * NPI : PRO == PRO_ATTN8 ? 1 : 2;   // what an item holds between its request and its use
     constexpr int RAWD = PRO == PRO_ATTN8 ? 5 * ATTN_FOLD_NZ : 1;
     struct Raw { float4v q[RAWQ]; float2v d[RAWD]; };
     auto load_item = [&](int i, Raw &rw) __attribute__((always_inline)) {
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_stream_kernel(GemmArgs a, Strea
             // (a slab beyond n_parts re-reads the last one and is never added)
             const float *pg = (const float *) a.A + (int64_t) r * a.lda + k0 + c8 * 8;
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
+            for (int q = 0; q < NPI; q++) {
                 const float *pq = pg + (int64_t) min(q, a.n_parts - 1) * a.parts_stride;
                 rw.q[q * 4 + 0] = *(const float4v *) pq; rw.q[q * 4 + 1] = *(const float4v *) (pq + 4);
                 rw.q[q * 4 + 2] = *(const float4v *) (pq + a.K); rw.q[q * 4 + 3] = *(const float4v *) (pq + a.K + 4);
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_stream_kernel(GemmArgs a, Strea
                 for (int e = 0; e < 8; e++) {
                     float x = rw.q[0 + (e >> 2)][e & 3], u = rw.q[2 + (e >> 2)][e & 3];
 #pragma unroll
-                    for (int q = 1; q < 8; q++)
+                    for (int q = 1; q < NPI; q++)
                         if (q < a.n_parts) { x += rw.q[q * 4 + (e >> 2)][e & 3]; u += rw.q[q * 4 + 2 + (e >> 2)][e & 3]; }
                     h[e] = (_Float16) ((x / (1.0f + expf(-x))) * u);
                 }
@@ -152,6 +154,8 @@ __global__ __launch_bounds__(NWV * 64) void gemv_stream_kernel(GemmArgs a, Strea
     const _Float16 *xb = xs + (size_t) (li & (RS - 1)) * ldx + g * 8;
     float4v acc = {0.f, 0.f, 0.f, 0.f};
     // one pipeline step: issue the loads of the pair after (t, ch) into `nxt`, run the MFMAs of (t, ch) from `cur`
+    // (all four chunks of a one-item wave requested before the staging — Dia's down projection — measured equal: profiles/r05/dia_step_kernels_call17_deep_rejected.txt;
+    //  that launch is bound by its staging volume: every workgroup re-reads its slice of the gate | up slabs, 64 MB through L2 beside 33.5 MB of weights)
     auto step = [&](half8 (&cur)[8], half8 (&nxt)[8]) {
         int t2 = t, ch2 = ch + 1;
         if (ch2 == nc) { ch2 = 0; t2 = t + tstep; }

@@ -44,7 +44,21 @@ static __global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int
         }
         if (parts) {
             int p = 0;
-            if (H <= 2048) {   // four slabs per round trip (8 values each): the adds still run in slab order
+            if (H <= 2048 && n_parts <= 8) {
+                // every slab of the row in ONE round trip (round 5: two of four slabs each were two dependent trips in a kernel the Dia step launches
+                // 55 times, profiles/r05/dia_step_kernels_call15.txt); a slab beyond n_parts re-reads the last one and is never added; slab order kept
+                float t[8][8];
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) t[q][k] = parts[min(q, n_parts - 1) * slab_stride + (int64_t) r * H + min(tid + k * 256, H - 1)];
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        if (q < n_parts && tid + k * 256 < H) v[k] += t[q][k];
+                p = n_parts;
+            } else if (H <= 2048) {   // four slabs per round trip (8 values each): the adds still run in slab order
                 for (; p + 4 <= n_parts; p += 4) {
                     float t[4][8];
 #pragma unroll
@@ -128,47 +142,78 @@ static __global__ __launch_bounds__(64) void llama_rope_kv_kernel(float *qkv, co
     const int half = HD >> 1;
     const int ld = (NH + 2 * NKV) * HD, kvH = NKV * HD;
     float *row = qkv + (int64_t) r * ld;
-    const uint32_t p = pos[r];
     float *v = row + (int64_t) h * HD;      // heads NH.. are the k heads (they follow q in the row)
-    for (int i = threadIdx.x; i < half; i += 64) {
+    // Order (round 5): the slab loads of the wave's first pair (and of its v slice) do not depend on the position: they go out before pos[r] is waited
+    // for and fly under the theta chain (up to 63 dependent multiplies, ggml's iterated theta) and sincos.
+    const bool kw = h >= NH;
+    const float *vsrc = row + (int64_t) (NH + NKV) * HD + (int64_t) (h - NH) * HD;
+    auto slabs2 = [&](const float *b, int i, int j, float &a0, float &a1, float (&t0)[7], float (&t1)[7]) __attribute__((always_inline)) {
+        a0 = b[i]; a1 = b[j];
+#pragma unroll
+        for (int q = 1; q < 8; q++) {   // straight-line (a slab beyond n_parts re-reads the last one and is never added): under `if (q < n_parts)` each
+            const int64_t qo = (int64_t) min(q, n_parts - 1) * part_stride;   // pair of loads was a basic block behind its own wait
+            t0[q - 1] = b[qo + i]; t1[q - 1] = b[qo + j];
+        }
+    };
+    auto fold2 = [&](const float *b, int i, int j, float &a0, float &a1, const float (&t0)[7], const float (&t1)[7]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 1; q < 8; q++)
+            if (q < n_parts) { a0 += t0[q - 1]; a1 += t1[q - 1]; }
+        for (int q = 8; q < n_parts; q++) { a0 += b[q * part_stride + i]; a1 += b[q * part_stride + j]; }
+    };
+    const uint32_t p = pos[r];   // first in the queue: the theta chain needs nothing else
+    const int i0 = min((int) threadIdx.x, half - 1);
+    const float ff0 = ff ? ff[i0] : 1.0f;
+    float fx0, fx1, ft0[7], ft1[7], vx0 = 0.0f, vx1 = 0.0f, vt0[7], vt1[7];
+    slabs2(v, i0, i0 + half, fx0, fx1, ft0, ft1);
+    const int vi0 = min((int) threadIdx.x, HD - 1), vi1 = min((int) threadIdx.x + 64, HD - 1);
+    if (kw) slabs2(vsrc, vi0, vi1, vx0, vx1, vt0, vt1);
+    __builtin_amdgcn_sched_barrier(0);
+    auto angle = [&](int i, float fi, float &cs, float &sn) __attribute__((always_inline)) {
         float theta = (float) p;
         for (int j = 0; j < i; j++) theta *= theta_scale;
-        const float ang = theta / (ff ? ff[i] : 1.0f);
-        const float cs = cosf(ang), sn = sinf(ang);
-        float x0 = v[i], x1 = v[i + half];
-        {   // slabs 1..7 in flight together, added in slab order
-            // straight-line (a slab beyond n_parts re-reads the last one and is never added): under `if (q < n_parts)` each pair of loads was a
-            // basic block behind its own wait — seven dependent round trips for what is one round trip of data
-            float t0[7], t1[7];
-#pragma unroll
-            for (int q = 1; q < 8; q++) {
-                const int64_t qo = (int64_t) min(q, n_parts - 1) * part_stride;
-                t0[q - 1] = v[qo + i]; t1[q - 1] = v[qo + i + half];
-            }
-#pragma unroll
-            for (int q = 1; q < 8; q++)
-                if (q < n_parts) { x0 += t0[q - 1]; x1 += t1[q - 1]; }
-            for (int q = 8; q < n_parts; q++) { x0 += v[q * part_stride + i]; x1 += v[q * part_stride + i + half]; }
-        }
+        const float ang = theta / fi;
+        cs = cosf(ang); sn = sinf(ang);
+    };
+    auto rotate = [&](int i, float x0, float x1, float cs, float sn) __attribute__((always_inline)) {
         const float y0 = x0 * cs - x1 * sn, y1 = x0 * sn + x1 * cs;
         if (h < NH) { v[i] = y0; v[i + half] = y1; }
         else {
             float *kc = kcache + (int64_t) p * kvH + (h - NH) * HD;
             kc[i] = y0; kc[i + half] = y1;
         }
+    };
+    {   // the wave's first pair: its loads are in flight while the angle is computed
+        float cs, sn;
+        angle(i0, ff0, cs, sn);
+        __builtin_amdgcn_sched_barrier(0);
+        fold2(v, i0, i0 + half, fx0, fx1, ft0, ft1);
+        if ((int) threadIdx.x < half) rotate(i0, fx0, fx1, cs, sn);
     }
-    if (h >= NH) {
-        const float *vsrc = row + (int64_t) (NH + NKV) * HD + (int64_t) (h - NH) * HD;
+    for (int i = threadIdx.x + 64; i < half; i += 64) {   // HD > 128: the later pairs
+        float cs, sn, x0, x1, t0[7], t1[7];
+        slabs2(v, i, i + half, x0, x1, t0, t1);
+        angle(i, ff ? ff[i] : 1.0f, cs, sn);
+        fold2(v, i, i + half, x0, x1, t0, t1);
+        rotate(i, x0, x1, cs, sn);
+    }
+    if (kw) {
         float *vdst = vcache + (int64_t) p * kvH + (h - NH) * HD;
-        for (int i = threadIdx.x; i < HD; i += 64) {
-            float t = vsrc[i], tp[7];
+        if (HD <= 128) {
+            fold2(vsrc, vi0, vi1, vx0, vx1, vt0, vt1);
+            if ((int) threadIdx.x < HD) vdst[threadIdx.x] = vx0;
+            if ((int) threadIdx.x + 64 < HD) vdst[threadIdx.x + 64] = vx1;
+        } else {
+            for (int i = threadIdx.x; i < HD; i += 64) {
+                float t = vsrc[i], tp[7];
 #pragma unroll
-            for (int q = 1; q < 8; q++) tp[q - 1] = vsrc[(int64_t) min(q, n_parts - 1) * part_stride + i];
+                for (int q = 1; q < 8; q++) tp[q - 1] = vsrc[(int64_t) min(q, n_parts - 1) * part_stride + i];
 #pragma unroll
-            for (int q = 1; q < 8; q++)
-                if (q < n_parts) t += tp[q - 1];
-            for (int q = 8; q < n_parts; q++) t += vsrc[q * part_stride + i];
-            vdst[i] = t;
+                for (int q = 1; q < 8; q++)
+                    if (q < n_parts) t += tp[q - 1];
+                for (int q = 8; q < n_parts; q++) t += vsrc[q * part_stride + i];
+                vdst[i] = t;
+            }
         }
     }
 }
@@ -187,17 +232,27 @@ struct QPre {
     const uint32_t *rope_pos = nullptr;
     float theta_scale = 0.0f;
 };
+// Two phases (round 5): the requests go out first — ahead of the K / V rows of the first keys, which are requested right behind them and fly while the
+// query is folded and rotated (vmcnt retires in issue order: with the K rows requested behind attn_load_q's three barriers, as until round 4, a
+// 128-key slice of Dia's cross-attention was position -> q slabs -> rope position -> K -> K: five dependent round trips before the softmax).
+struct QRaw {
+    float t[8];
+    uint32_t rp;
+};
 template <int HD>
-__device__ __forceinline__ void attn_load_q(float *qs, const float *q, int r, const QPre &qp, int tid) {
-    if (tid < HD) {
-        float t[8];
+__device__ __forceinline__ void attn_q_request(QRaw &qr, const float *q, int r, const QPre &qp, int tid) {
+    const int i = min(tid, HD - 1);   // straight-line: lanes beyond the head re-read its last element, a slab beyond n_parts the last slab; neither is used
 #pragma unroll
-        for (int p = 0; p < 8; p++)
-            if (p < qp.n_parts) t[p] = q[p * qp.part_stride + tid];
-        float x = t[0];
+    for (int p = 0; p < 8; p++) qr.t[p] = q[(int64_t) min(p, qp.n_parts - 1) * qp.part_stride + i];
+    qr.rp = qp.rope_pos ? qp.rope_pos[r] : 0u;
+}
+template <int HD>
+__device__ __forceinline__ void attn_q_finish(float *qs, const QRaw &qr, const float *q, const QPre &qp, int tid) {
+    if (tid < HD) {
+        float x = qr.t[0];
 #pragma unroll
         for (int p = 1; p < 8; p++)
-            if (p < qp.n_parts) x += t[p];
+            if (p < qp.n_parts) x += qr.t[p];
         for (int p = 8; p < qp.n_parts; p++) x += q[p * qp.part_stride + tid];
         qs[tid] = x;
     }
@@ -205,7 +260,7 @@ __device__ __forceinline__ void attn_load_q(float *qs, const float *q, int r, co
     if (qp.rope_pos) {
         float y0 = 0.0f, y1 = 0.0f;
         if (tid < HD / 2) {
-            float theta = (float) qp.rope_pos[r];
+            float theta = (float) qr.rp;
             for (int j = 0; j < tid; j++) theta *= qp.theta_scale;
             const float cs = cosf(theta), sn = sinf(theta);
             const float x0 = qs[tid], x1 = qs[tid + HD / 2];
@@ -230,25 +285,40 @@ __device__ __forceinline__ void attn_v_batch(float4 (&v)[8], const float *vbase,
         v[u] = *(const float4 *) (vbase + (int64_t) j * kvH + e4 * 4);
     }
 }
+struct KBatch {   // the rows of a lane's 4 keys of a 64-key batch (its 2 x 16 bytes of each)
+    float4 a[4], b[4];
+};
 template <int HD>
-__device__ __forceinline__ void attn_scores_batched(const float *kbase, int kvH, int T, const float *qs, float scale, float *ps, int tid) {
+__device__ __forceinline__ void attn_k_request(KBatch &kb, const float *kbase, int kvH, int T, int j0, int tid) {
+    const int g = tid >> 4, sub = tid & 15;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int j = max(0, min(j0 + g + 16 * u, T - 1));
+        const float4 *kr = (const float4 *) (kbase + (int64_t) j * kvH);
+        kb.a[u] = kr[sub]; kb.b[u] = kr[16 + sub];
+    }
+}
+// kpre: the first NPRE batches, requested by the caller before the query was ready
+template <int HD, int NPRE>
+__device__ __forceinline__ void attn_scores_batched(KBatch (&kpre)[NPRE], const float *kbase, int kvH, int T, const float *qs, float scale, float *ps, int tid) {
     const int g = tid >> 4, sub = tid & 15;
     const float4 q0 = *(const float4 *) (qs + sub * 4), q1 = *(const float4 *) (qs + 64 + sub * 4);
-    for (int j0 = 0; j0 < T; j0 += 64) {
-        float4 a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = max(0, min(j0 + g + 16 * u, T - 1));
-            const float4 *kr = (const float4 *) (kbase + (int64_t) j * kvH);
-            a[u] = kr[sub]; b[u] = kr[16 + sub];
-        }
+    auto scores = [&](const KBatch &kb, int j0) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int j = j0 + g + 16 * u;
-            float d = (a[u].x * q0.x + a[u].y * q0.y + a[u].z * q0.z + a[u].w * q0.w) + (b[u].x * q1.x + b[u].y * q1.y + b[u].z * q1.z + b[u].w * q1.w);
+            float d = (kb.a[u].x * q0.x + kb.a[u].y * q0.y + kb.a[u].z * q0.z + kb.a[u].w * q0.w) + (kb.b[u].x * q1.x + kb.b[u].y * q1.y + kb.b[u].z * q1.z + kb.b[u].w * q1.w);
             d = row16_sum(d);
             if (sub == 0 && j < T) ps[j] = d * scale;
         }
+    };
+#pragma unroll
+    for (int b = 0; b < NPRE; b++)
+        if (b * 64 < T) scores(kpre[b], b * 64);
+    for (int j0 = NPRE * 64; j0 < T; j0 += 64) {
+        KBatch kb;
+        attn_k_request<HD>(kb, kbase, kvH, T, j0, tid);
+        scores(kb, j0);
     }
 }
 template <int HD>
@@ -285,10 +355,17 @@ __global__ __launch_bounds__(256) void attn_gqa_kernel(const float *qkv, int ld,
     if (row_seq) { kcache += (int64_t) row_seq[r] * seq_stride; vcache += (int64_t) row_seq[r] * seq_stride; }
     kcache += (int64_t) k0 * kvH;
     vcache += (int64_t) k0 * kvH;
-    float4 vfirst[8];                                    // the value rows of the first 64 keys do not depend on the scores: requested up front
+    // requests in the order of their use: the query (slabs, rope position), the K rows of the first 64 keys (two batches would be 140 registers: three workgroups per CU instead of four), the V rows of the first 64 (they do
+    // not depend on the scores); the query is folded and rotated under the K / V rows
+    QRaw qr;
+    attn_q_request<HD>(qr, qkv + (int64_t) r * ld + h * HD, r, qp, tid);
+    KBatch kpre[1];
+    attn_k_request<HD>(kpre[0], kcache + kh * HD, kvH, T, 0, tid);
+    float4 vfirst[8];
     attn_v_batch<HD>(vfirst, vcache + kh * HD, kvH, T, 0, tid);
-    attn_load_q<HD>(qs, qkv + (int64_t) r * ld + h * HD, r, qp, tid);
-    attn_scores_batched<HD>(kcache + kh * HD, kvH, T, qs, scale, ps, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    attn_q_finish<HD>(qs, qr, qkv + (int64_t) r * ld + h * HD, qp, tid);
+    attn_scores_batched<HD, 1>(kpre, kcache + kh * HD, kvH, T, qs, scale, ps, tid);
     __syncthreads();
     float mx = -INFINITY;
     for (int j = tid; j < T; j += 256) mx = fmaxf(mx, ps[j]);
@@ -333,7 +410,11 @@ __global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, i
     __shared__ float red[8];
     __shared__ float4 accs[8][HD / 4];
     float *qs = attn_gqa_sm, *ps = attn_gqa_sm + HD;
-    const int h = blockIdx.x, r = blockIdx.y, z = blockIdx.z, nz = gridDim.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // blockIdx.x = key slice: workgroups go to the XCDs round-robin by their linear index, so with 8 slices an XCD owns ONE slice of every head and row —
+    // whole contiguous K / V rows per XCD.  With the head in x (until round 5) an XCD saw heads x and x + 8 only: two 512-byte pieces of every 8 KB row.
+    // (Measured equal on Dia's cross-attention, 134 MB per launch: 28.9 us = 4.6 TB/s either way, as is the request order below: that launch is
+    // neither latency- nor channel-bound, profiles/r05/dia_step_kernels_call18.txt.)
+    const int z = blockIdx.x, r = blockIdx.y, h = blockIdx.z, nz = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kb = kbeg ? (int) kbeg[r] : 0;
     const int Tall = (kend ? (int) kend[r] : (int) pos[r] + 1) - kb;
     const int chunk = (Tall + nz - 1) / nz;
@@ -348,10 +429,17 @@ __global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, i
     if (row_seq) { kcache += (int64_t) row_seq[r] * seq_stride; vcache += (int64_t) row_seq[r] * seq_stride; }
     kcache += (int64_t) k0 * kvH;
     vcache += (int64_t) k0 * kvH;
-    float4 vfirst[8];                                    // the value rows of the first 64 keys do not depend on the scores: requested up front
+    // requests in the order of their use: the query (slabs, rope position), the K rows of the first 64 keys (two batches would be 140 registers: three workgroups per CU instead of four), the V rows of the first 64 (they do
+    // not depend on the scores); the query is folded and rotated under the K / V rows
+    QRaw qr;
+    attn_q_request<HD>(qr, qkv + (int64_t) r * ld + h * HD, r, qp, tid);
+    KBatch kpre[1];
+    attn_k_request<HD>(kpre[0], kcache + kh * HD, kvH, T, 0, tid);
+    float4 vfirst[8];
     attn_v_batch<HD>(vfirst, vcache + kh * HD, kvH, T, 0, tid);
-    attn_load_q<HD>(qs, qkv + (int64_t) r * ld + h * HD, r, qp, tid);
-    attn_scores_batched<HD>(kcache + kh * HD, kvH, T, qs, scale, ps, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    attn_q_finish<HD>(qs, qr, qkv + (int64_t) r * ld + h * HD, qp, tid);
+    attn_scores_batched<HD, 1>(kpre, kcache + kh * HD, kvH, T, qs, scale, ps, tid);
     __syncthreads();
     float mx = -INFINITY;
     for (int j = tid; j < T; j += 256) mx = fmaxf(mx, ps[j]);

@@ -277,12 +277,12 @@ bool stream_fold_ok(const tts_hip_ctx *c, const W &w, int R, int max_slabs) {
     return ks > 0 && (int) w.N / 16 * ks < 4096 && R <= 8;
 }
 
-template <int NWV, int PRO, int EPI>
+template <int NWV, int PRO, int EPI, int NPI = 8>
 static int launch_stream_one(tts_hip_ctx *c, const GemmArgs &a, StreamMap sm, int grid, size_t lds) {
     static std::atomic<uint64_t> attr{0};
     if (lds > 48 * 1024 && attr_needed(attr, c->device))
-        HIPCHK(hipFuncSetAttribute((const void *) gemv_stream_kernel<NWV, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((gemv_stream_kernel<NWV, PRO, EPI>), dim3(grid), dim3(NWV * 64), lds, c->stream, a, sm);
+        HIPCHK(hipFuncSetAttribute((const void *) gemv_stream_kernel<NWV, PRO, EPI, NPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((gemv_stream_kernel<NWV, PRO, EPI, NPI>), dim3(grid), dim3(NWV * 64), lds, c->stream, a, sm);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -298,7 +298,13 @@ static int launch_stream(tts_hip_ctx *c, const GemmArgs &a, int pro, int epi) {
 #define STREAM_CASE(NWVv, PROv, EPIv) if (nwv == NWVv && pro == PROv && epi == EPIv) return launch_stream_one<NWVv, PROv, EPIv>(c, a, sm, grid, lds);
     STREAM_CASE(4, PRO_F32, EPI_STORE) STREAM_CASE(16, PRO_F32, EPI_STORE) STREAM_CASE(4, PRO_F32, EPI_RESID) STREAM_CASE(16, PRO_F32, EPI_RESID)
     STREAM_CASE(4, PRO_F16, EPI_STORE) STREAM_CASE(16, PRO_F16, EPI_STORE)
-    STREAM_CASE(4, PRO_ATTN8, EPI_STORE) STREAM_CASE(4, PRO_SILU, EPI_STORE)   // Dia's step: four-wave workgroups only (the callers check stream_fold_ok)
+    STREAM_CASE(4, PRO_ATTN8, EPI_STORE)   // Dia's step: four-wave workgroups only (the callers check stream_fold_ok)
+    if (nwv == 4 && pro == PRO_SILU && epi == EPI_STORE) {   // an instance per slab count of the gate | up rows
+        if (a.n_parts <= 1) return launch_stream_one<4, PRO_SILU, EPI_STORE, 1>(c, a, sm, grid, lds);
+        if (a.n_parts <= 2) return launch_stream_one<4, PRO_SILU, EPI_STORE, 2>(c, a, sm, grid, lds);
+        if (a.n_parts <= 4) return launch_stream_one<4, PRO_SILU, EPI_STORE, 4>(c, a, sm, grid, lds);
+        return launch_stream_one<4, PRO_SILU, EPI_STORE, 8>(c, a, sm, grid, lds);
+    }
 #undef STREAM_CASE
     return set_err("gemv_stream: no kernel for pro=%d epi=%d", pro, epi);
 }

@@ -56,7 +56,7 @@ static int launch_attn_gqa(tts_hip_ctx *c, int NHq, int rows, int max_keys, cons
         // the captured one-row step (Orpheus): every key row requested at kernel start, online softmax per 16-lane group, one barrier (attn_gqa_wave_kernel)
         hipLaunchKernelGGL((attn_gqa_wave_kernel<128, 4>), dim3(NHq, rows, nz), dim3(256), 0, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part, n_ctx_keys);
     } else {
-        hipLaunchKernelGGL(attn_gqa_split_kernel<128>, dim3(NHq, rows, nz), dim3(256), (size_t) (128 + chunk + 1) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part,
+        hipLaunchKernelGGL(attn_gqa_split_kernel<128>, dim3(nz, rows, NHq), dim3(256), (size_t) (128 + chunk + 1) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part,
                            kbeg, kend, row_seq, seq_stride, qp);
     }
     HIPCHK(hipGetLastError());
