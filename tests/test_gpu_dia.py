@@ -275,6 +275,33 @@ def test_dia_1_6b_layer_shapes():
     eng.close()
 
 
+def test_dia_cross_attention_in_rolling_passes_matches_the_split_kernel():
+    """Round 5: the cross-attention of a Dia-1.6B step (16 heads x 2 rows x 8 slices of 128 text positions) runs as attn_gqa_wave_kernel<128, 3, EXT>:
+    keys of a slice interleaved 16 by 16, a running softmax per 16-lane group, eight passes through three register slots, the query's slabs folded
+    and rotated under the first rows.  Another association of the same softmax than attn_gqa_split_kernel (tune("attn_wave") = 0): guided logits
+    of three steps agree to 1e-5 of the largest logit, and both stay inside the oracle's bar (test_dia_1_6b_layer_shapes runs the default)."""
+    model = synth.build_dia(synth.dia_1_6b(enc_layers=1, dec_layers=2, max_gen=32, weight_type=gguf.F16))
+    cfg = model.cfg
+    texts = ["[S1] The birch canoe slid on the smooth planks.", "[S2] Glue the sheet to the dark blue background."]
+    res = {}
+    for wave in (1, 0):
+        eng = hip.DiaEngine(cfg, max_utterances=2)
+        eng.tune("attn_wave", wave)
+        eng.load(model)
+        for u, t in enumerate(texts):
+            eng.encode_slot(u, *orc.dia_tokenize(t, cfg.max_ctx))
+        ids = np.full((2, cfg.n_out), cfg.bos, dtype=np.uint32)
+        out = []
+        for step in range(3):
+            lg = eng.step_batch(ids, np.full(2, step, dtype=np.uint32))
+            out.append(np.array(lg, copy=True))
+            ids[:] = (np.arange(2 * cfg.n_out).reshape(2, -1) * 37 + step * 11) % cfg.audio_vocab
+        res[wave] = np.stack(out)
+        eng.close()
+    assert not np.array_equal(res[1], res[0])          # the switch reaches the kernel under test
+    assert relerr(res[1], res[0]) < 1e-5
+
+
 @pytest.mark.parametrize("shapes", ["tiny_f16", "1_6b_layer"])
 def test_dia_captured_step_folds_slice_merge_and_silu_into_the_projections(shapes):
     """The captured decoder step with fp16 matrices leaves the self- (and, over >= 1024 text positions, cross-) attention's eight key slices

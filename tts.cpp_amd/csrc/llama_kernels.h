@@ -481,50 +481,124 @@ __global__ __launch_bounds__(256) void attn_gqa_split_kernel(const float *qkv, i
 // A lane holds dims 4 sub .. + 3 and 64 + 4 sub .. + 3 of the 128-wide head (sub = lane % 16): a K or V row is read as 512 contiguous bytes.
 // The partials have attn_gqa_split_kernel's meaning (max, sum, unnormalised out[128] of the slice's keys; an empty slice leaves -inf, 0), so
 // attn_gqa_combine_kernel follows unchanged.  Another association of the same softmax than the kernel above: results agree to rounding.
-template <int HD, int U>
+// EXT (Dia's cross-attention over the 1024 text positions, 8 rows x 16 heads x 8 slices of 128 keys = U = 8 passes): the keys end at kend[r], row r reads
+// the cache of sequence row_seq[r], and the query arrives as qp.n_parts K-slice slabs to be folded and rotated (QPre) — folded by the first 128
+// threads through LDS (one more barrier, under the rows in flight), rotated in the lanes (a lane holds both halves of its NEOX pairs).
+template <int HD, int U, bool EXT = false>
 __global__ __launch_bounds__(256) void attn_gqa_wave_kernel(const float *qkv, int ld, const uint32_t *pos, const float *kcache, const float *vcache, int NH, int NKV,
-                                                            float scale, float *part, int n_ctx) {
+                                                            float scale, float *part, int n_ctx, const uint32_t *kend = nullptr, const uint32_t *row_seq = nullptr,
+                                                            int64_t seq_stride = 0, QPre qp = QPre{}) {
     static_assert(HD == 128, "lane mapping below is written for head_dim 128");
     __shared__ float s_m[4], s_l[4];
     __shared__ __attribute__((aligned(16))) float s_acc[4][HD];
+    __shared__ __attribute__((aligned(16))) float s_q[EXT ? HD : 4];
     const int h = blockIdx.x, r = blockIdx.y, z = blockIdx.z, nz = gridDim.z, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, sub = lane & 15, gi = wave * 4 + g;
     const int kvH = NKV * HD, kh = h / (NH / NKV);
-    const float *kp = kcache + kh * HD + sub * 4, *vp = vcache + kh * HD + sub * 4;
+    if (EXT && row_seq) { kcache += (int64_t) row_seq[r] * seq_stride; vcache += (int64_t) row_seq[r] * seq_stride; }
+    // wave-uniform bases + one 32-bit byte offset per row (a sequence's cache is far below 4 GB): K and V of a key share the offset register
+    const char *kp = (const char *) (kcache + kh * HD), *vp = (const char *) (vcache + kh * HD);
     auto key_of = [&](int p) { return 16 * (nz * p + z) + gi; };
     float4 ka[U], kb[U], va[U], vb[U];
+    auto request_one = [&](int u, int pass) __attribute__((always_inline)) {
+        const uint32_t off = ((uint32_t) min(key_of(pass), n_ctx - 1) * (uint32_t) kvH + (uint32_t) sub * 4u) * 4u;
+        if (EXT) {
+            // non-temporal: 2.4 GB of cross K / V per Dia step, nothing of it is met again before it has left every cache — and with plain loads the
+            // 134 MB of a launch pushed the step's small hot set (rows, slabs, partials) out of L2 / the memory-side cache: the launch itself gains
+            // 0.8 us, the step 5 % (1.90 -> 1.80 ms, same box, profiles/r05/dia_step_kernels_call21.txt)
+            auto ntl = [](const char *a) __attribute__((always_inline)) { return __builtin_bit_cast(float4, __builtin_nontemporal_load((const float4v *) a)); };
+            ka[u] = ntl(kp + off); kb[u] = ntl(kp + off + 256);
+            va[u] = ntl(vp + off); vb[u] = ntl(vp + off + 256);
+        } else {
+            ka[u] = *(const float4 *) (kp + off); kb[u] = *(const float4 *) (kp + off + 256);
+            va[u] = *(const float4 *) (vp + off); vb[u] = *(const float4 *) (vp + off + 256);
+        }
+    };
     auto request = [&](int p0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int64_t off = (int64_t) min(key_of(p0 + u), n_ctx - 1) * kvH;
-            ka[u] = *(const float4 *) (kp + off); kb[u] = *(const float4 *) (kp + off + 64);
-            va[u] = *(const float4 *) (vp + off); vb[u] = *(const float4 *) (vp + off + 64);
-        }
+        for (int u = 0; u < U; u++) request_one(u, p0 + u);
     };
     // the small inputs first (vmcnt retires in issue order: the position and q are usable while the rows below are still in flight)
     const float *qr = qkv + (int64_t) r * ld + h * HD + sub * 4;
-    const float4 q0 = *(const float4 *) qr, q1 = *(const float4 *) (qr + 64);
-    const int T = (int) pos[r] + 1;
+    float4 q0, q1;
+    float tq[4];       // EXT: threads 0-127 hold slabs 0-3 of query element tid, threads 128-255 slabs 4-7 of element tid - 128 (four registers, not eight:
+    uint32_t rp = 0;   // the kernel sits at the 128-register line of four workgroups per CU)
+    if (EXT) {
+        const float *qe = qkv + (int64_t) r * ld + h * HD + (tid & (HD - 1));
+#pragma unroll
+        for (int p = 0; p < 4; p++) tq[p] = qe[(int64_t) min((tid >> 7) * 4 + p, qp.n_parts - 1) * qp.part_stride];
+        if (qp.rope_pos) rp = qp.rope_pos[r];
+    } else { q0 = *(const float4 *) qr; q1 = *(const float4 *) (qr + 64); }
+    const int T = EXT && kend ? (int) kend[r] : (int) pos[r] + 1;
     __builtin_amdgcn_sched_barrier(0);
     request(0);
     __builtin_amdgcn_sched_barrier(0);
+    if (EXT) {
+        // attn_q_finish's arithmetic: slabs in slab order (the upper half of the workgroup continues the lower half's sum), then ggml_rope NEOX with
+        // the iterated theta (pair i, i + 64: both in this lane)
+        if (tid < HD) {
+            float x = tq[0];
+#pragma unroll
+            for (int p = 1; p < 4; p++)
+                if (p < qp.n_parts) x += tq[p];
+            s_q[tid] = x;
+        }
+        __syncthreads();
+        if (tid >= HD) {
+            float x = s_q[tid - HD];
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                if (4 + p < qp.n_parts) x += tq[p];   // (the host sends at most 8 slabs here)
+            s_q[tid - HD] = x;
+        }
+        __syncthreads();
+        q0 = *(const float4 *) (s_q + sub * 4); q1 = *(const float4 *) (s_q + 64 + sub * 4);
+        if (qp.rope_pos) {
+            float theta = (float) rp;
+            for (int j = 0; j < sub * 4; j++) theta *= qp.theta_scale;
+            float *a = (float *) &q0, *b = (float *) &q1;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float cs = cosf(theta), sn = sinf(theta);
+                const float x0 = a[e], x1 = b[e];
+                a[e] = x0 * cs - x1 * sn; b[e] = x0 * sn + x1 * cs;
+                theta *= qp.theta_scale;
+            }
+        }
+    }
     float m = -INFINITY, l = 0.0f;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    for (int p0 = 0; 16 * nz * p0 < T; p0 += U) {
-        if (p0) request(p0);
+    auto consume = [&](int u, int pass) __attribute__((always_inline)) {
+        if (key_of(pass) < T) {
+            float d = (ka[u].x * q0.x + ka[u].y * q0.y + ka[u].z * q0.z + ka[u].w * q0.w) + (kb[u].x * q1.x + kb[u].y * q1.y + kb[u].z * q1.z + kb[u].w * q1.w);
+            d = row16_sum(d) * scale;
+            const float mn = fmaxf(m, d);
+            const float f = expf(m - mn);   // 0 on the group's first key (m = -inf)
+            const float pr = expf(d - mn);
+            l = l * f + pr;
+            a0.x = a0.x * f + pr * va[u].x; a0.y = a0.y * f + pr * va[u].y; a0.z = a0.z * f + pr * va[u].z; a0.w = a0.w * f + pr * va[u].w;
+            a1.x = a1.x * f + pr * vb[u].x; a1.y = a1.y * f + pr * vb[u].y; a1.z = a1.z * f + pr * vb[u].z; a1.w = a1.w * f + pr * vb[u].w;
+            m = mn;
+        }
+    };
+    if (EXT) {
+        // eight passes (the host checks: at most 16 nz 8 keys), U register slots: a slot is requested again for pass p + U the moment pass p has been
+        // consumed, so every workgroup keeps U passes in flight from its first instruction to its last key.  Measured on Dia's cross-attention (134 MB
+        // per launch; a pure read of the same bytes: 23 us, profiles/r05/stride_read_bench_call19.txt): all eight passes requested at once (198
+        // registers, two workgroups per CU) 30.3 us, four slots (130 registers, three per CU) 27.7, three slots (112, four per CU) 26.9, the split
+        // kernel's three phases 28.1-28.9 (profiles/r05/dia_step_kernels_call20.txt, _call21.txt).
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (key_of(p0 + u) < T) {
-                float d = (ka[u].x * q0.x + ka[u].y * q0.y + ka[u].z * q0.z + ka[u].w * q0.w) + (kb[u].x * q1.x + kb[u].y * q1.y + kb[u].z * q1.z + kb[u].w * q1.w);
-                d = row16_sum(d) * scale;
-                const float mn = fmaxf(m, d);
-                const float f = expf(m - mn);   // 0 on the group's first key (m = -inf)
-                const float pr = expf(d - mn);
-                l = l * f + pr;
-                a0.x = a0.x * f + pr * va[u].x; a0.y = a0.y * f + pr * va[u].y; a0.z = a0.z * f + pr * va[u].z; a0.w = a0.w * f + pr * va[u].w;
-                a1.x = a1.x * f + pr * vb[u].x; a1.y = a1.y * f + pr * vb[u].y; a1.z = a1.z * f + pr * vb[u].z; a1.w = a1.w * f + pr * vb[u].w;
-                m = mn;
-            }
+        for (int p = 0; p < 8; p++) {
+            consume(p % U, p);
+            __builtin_amdgcn_sched_barrier(0);   // the slot's registers are free only now: a request hoisted above costs the 128-register line
+            if (p + U < 8) request_one(p % U, p + U);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        for (int p0 = 0; 16 * nz * p0 < T; p0 += U) {
+            if (p0) request(p0);
+#pragma unroll
+            for (int u = 0; u < U; u++) consume(u, p0 + u);
         }
     }
     // the wave's four groups (lanes sub, 16 + sub, 32 + sub, 48 + sub hold the same dims): common max, rescale, add

@@ -278,7 +278,7 @@ struct tts_hip_ctx {
                                 // projections merge the attention's key slices / apply silu * up while they stage their rows (gemv_stream_kernel<.., PRO_ATTN8 / PRO_SILU, ..>)
     bool cross_fold = true;     // tune("cross_fold")=0: the cross-attention of a many-row forward stays a launch of its own (attn_short_kernel) instead of the cross-q GEMM's epilogue
     bool cross_folded = false;  // set by run_gemm: the EPI_CROSS request was served by the 64 x 64 tile
-    bool attn_wave = true;      // tune("attn_wave")=0: the split decode attention of a Llama step through attn_gqa_split_kernel (rounds 2-4) instead of attn_gqa_wave_kernel
+    bool attn_wave = true;      // tune("attn_wave")=0: the split decode attention of a Llama step and the cross-attention of a Dia step through attn_gqa_split_kernel (rounds 2-4) instead of attn_gqa_wave_kernel
     int attn_split_max = 8;     // tune("attn_split"): key splits of the decode attention of the Llama / Dia steps (1 = off)
     float *attn_part = nullptr; // [rows][heads][splits][130] partial softmax results
     size_t attn_part_cap = 0;   // in (row, head, split) triples

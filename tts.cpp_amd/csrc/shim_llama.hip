@@ -55,6 +55,10 @@ static int launch_attn_gqa(tts_hip_ctx *c, int NHq, int rows, int max_keys, cons
     if (c->attn_wave && !kbeg && !kend && !row_seq && qp.n_parts == 1 && !qp.rope_pos && n_ctx_keys > 0) {
         // the captured one-row step (Orpheus): every key row requested at kernel start, online softmax per 16-lane group, one barrier (attn_gqa_wave_kernel)
         hipLaunchKernelGGL((attn_gqa_wave_kernel<128, 4>), dim3(NHq, rows, nz), dim3(256), 0, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part, n_ctx_keys);
+    } else if (c->attn_wave && !kbeg && kend && n_ctx_keys > 0 && max_keys <= 16 * nz * 8 && qp.n_parts <= 8) {
+        // Dia's cross-attention (keys end at kend[r], per-row sequences, the query as slabs to fold and rotate): the same form, 8 passes through 3 rolling register slots
+        hipLaunchKernelGGL((attn_gqa_wave_kernel<128, 3, true>), dim3(NHq, rows, nz), dim3(256), 0, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part, n_ctx_keys,
+                           kend, row_seq, seq_stride, qp);
     } else {
         hipLaunchKernelGGL(attn_gqa_split_kernel<128>, dim3(nz, rows, NHq), dim3(256), (size_t) (128 + chunk + 1) * 4, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part,
                            kbeg, kend, row_seq, seq_stride, qp);
@@ -623,7 +627,7 @@ static int dia_forward(tts_hip_ctx *c, int U, int self_keys, bool fixed_split) {
         slices = 0;
         CHK(launch_attn_gqa(c, NH, R, S, (const float *) c->di_q, A, (const uint32_t *) c->di_pos, ck, cv, NH, 1.0f, c->di_att, nul, (const uint32_t *) c->di_cend,
                             (const uint32_t *) c->di_seq, (int64_t) S * A, false, false, qp,
-                            A % 128 == 0 && stream_fold_ok(c, y.co, R, DIA_STREAM_SLABS) ? &slices : nullptr));
+                            A % 128 == 0 && stream_fold_ok(c, y.co, R, DIA_STREAM_SLABS) ? &slices : nullptr, S));
         CHK(dia_gemm_stream(c, y.co, c->di_att, A, c->di_parts, DH, R, DIA_STREAM_SLABS, (int64_t) c->RMAX * DH, &sl, slices ? PRO_ATTN8 : PRO_F32));
         if (sl) c->di_pending = sl;
         else CHK(dia_gemm(c, y.co, c->di_att, A, c->di_x, DH, R, EPI_RESID));
