@@ -186,7 +186,7 @@ def run_dia(args, ranks=None):
         "x_real_time_per_gpu": round(U / (step_ms * 1e-3) / 86.13, 2),
         "roofline": {"bound": "hbm", "achieved": round(tot / (step_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(tot / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": _pmc("dia_1_6b_lockstep4_step"),
-                     "kernel": "whole decoder step (18 layers x 14 launches: gemv_stream_kernel, attn_gqa_split_kernel<128>, rms_fold_rows_kernel, ... + sample_kernel)",
+                     "kernel": "whole decoder step (18 layers x 12 launches: gemv_stream_kernel, attn_gqa_split_kernel<128> (self) / attn_gqa_wave_kernel<128, 3, EXT> (cross), rms_fold_rows_kernel, llama_rope_kv_kernel, ... + sample_kernel)",
                      "algorithmic_bytes_per_launch": tot, "note": f"fp16 matrices {w_bytes / 1e9:.3f} GB + {U} x (fp32 cross K/V {ckv_bytes / 1e9:.3f} GB + self-attention K/V at the mean position {skv_bytes / 1e9:.3f} GB) per step"},
     }
     eng.close()

@@ -899,7 +899,7 @@ __device__ __forceinline__ void attn_row_pass(const AttnArgs &a, int64_t hb, flo
         for (int u = 0; u < U; u++) {   // straight-line: a key beyond the slice re-reads its last key and is never used
             const int64_t off = hb + (int64_t) min(t + u, t1 - 1) * a.H;
             if (KVF16) {
-                const half4 hk = *(const half4 *) ((const _Float16 *) a.kc + off), hv = *(const half4 *) ((const _Float16 *) a.vc + off);
+                const half4 hk = __builtin_nontemporal_load((const half4 *) ((const _Float16 *) a.kc + off)), hv = __builtin_nontemporal_load((const half4 *) ((const _Float16 *) a.vc + off));
                 k4[u] = (float4v){(float) hk[0], (float) hk[1], (float) hk[2], (float) hk[3]};
                 v4[u] = (float4v){(float) hv[0], (float) hv[1], (float) hv[2], (float) hv[3]};
             } else {
