@@ -11,7 +11,7 @@ import tts_cpp_amd  # noqa: F401
 from tts_cpp_amd import gguf, hip, synth
 
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 28
-cfg = synth.orpheus_3b(layers=layers, ctx=1024, weight_type=gguf.Q4_0)
+cfg = synth.orpheus_3b(layers=layers, ctx=int(os.environ.get("ORPHEUS_BENCH_CTX", "1024")), weight_type=gguf.Q4_0)
 rng = np.random.default_rng(7)
 
 
@@ -69,6 +69,14 @@ print(f"layers={cfg.layers} prompt 32 + 64 tokens {res[64]*1e3:.1f} ms, + 448 to
       f"({1/step:.0f} tokens/s = {1/step/7*2048/24000:.2f}x real time: 7 tokens per 2048-sample SNAC frame at 24 kHz)")
 print(f"Q4_0 bytes per step {q4_bytes/1e9:.3f} GB -> {q4_bytes/step/1e9:.0f} GB/s algorithmic ({q4_bytes/step/8e12*100:.1f}% of 8 TB/s); "
       f"HBM floor {q4_bytes/8e12*1e3:.3f} ms/step")
+
+if os.environ.get("ORPHEUS_BENCH_LONG"):   # the back half of a long utterance: histories beyond the first 512 keys of the decode attention
+    rl = {}
+    for n in (1088, 1536):
+        t0 = time.perf_counter()
+        out = eng.generate_greedy(prompt, n, NO_STOP)
+        rl[n] = time.perf_counter() - t0
+    print(f"long: {(rl[1536] - rl[1088]) / 448 * 1e3:.3f} ms/step at positions 1120..1568", flush=True)
 
 if os.environ.get("ORPHEUS_BENCH_GREEDY_ONLY"):   # counter passes (profiles/r04/scripts/r4_pmc_secondary.sh): the arg-max loop only
     sys.exit(0)

@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void attn_gqa_wave_kernel(const float *qkv, in
         // consumed, so every workgroup keeps U passes in flight from its first instruction to its last key.  Measured on Dia's cross-attention (134 MB
         // per launch; a pure read of the same bytes: 23 us, profiles/r05/stride_read_bench_call19.txt): all eight passes requested at once (198
         // registers, two workgroups per CU) 30.3 us, four slots (130 registers, three per CU) 27.7, three slots (112, four per CU) 26.9, the split
-        // kernel's three phases 28.1-28.9 (profiles/r05/dia_step_kernels_call20.txt, _call21.txt).
+        // kernel's three phases 28.1-28.9 (profiles/r05/dia_cross_attention_forms.txt, dia_step_kernels_call21.txt).
 #pragma unroll
         for (int p = 0; p < 8; p++) {
             consume(p % U, p);
@@ -595,6 +595,8 @@ __global__ __launch_bounds__(256) void attn_gqa_wave_kernel(const float *qkv, in
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
+        // (rolling slots here too — a history beyond the first 512 keys is one more dependent round trip per 512 keys — measured equal to this loop and
+        //  to the split kernel at positions 1120..1568 of an Orpheus-3B step: 1.33 / 1.33 / 1.32 ms, profiles/r05/orpheus_bench_call22_roll_rejected.txt)
         for (int p0 = 0; 16 * nz * p0 < T; p0 += U) {
             if (p0) request(p0);
 #pragma unroll
