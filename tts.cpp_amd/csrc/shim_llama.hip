@@ -52,10 +52,11 @@ static int launch_attn_gqa(tts_hip_ctx *c, int NHq, int rows, int max_keys, cons
         return 0;
     }
     const int chunk = (max_keys + nz - 1) / nz;
-    if (c->attn_wave && !kbeg && !kend && !row_seq && qp.n_parts == 1 && !qp.rope_pos && n_ctx_keys > 0) {
+    const bool off32 = (uint64_t) std::max(n_ctx_keys, 1) * (uint64_t) NKV * 128 * 4 < (1ull << 32);   // attn_gqa_wave_kernel addresses a sequence's rows with 32-bit byte offsets
+    if (c->attn_wave && off32 && !kbeg && !kend && !row_seq && qp.n_parts == 1 && !qp.rope_pos && n_ctx_keys > 0) {
         // the captured one-row step (Orpheus): every key row requested at kernel start, online softmax per 16-lane group, one barrier (attn_gqa_wave_kernel)
         hipLaunchKernelGGL((attn_gqa_wave_kernel<128, 4>), dim3(NHq, rows, nz), dim3(256), 0, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part, n_ctx_keys);
-    } else if (c->attn_wave && !kbeg && kend && n_ctx_keys > 0 && max_keys <= 16 * nz * 8 && qp.n_parts <= 8) {
+    } else if (c->attn_wave && off32 && !kbeg && kend && n_ctx_keys > 0 && max_keys <= 16 * nz * 8 && qp.n_parts <= 8) {
         // Dia's cross-attention (keys end at kend[r], per-row sequences, the query as slabs to fold and rotate): the same form, 8 passes through 3 rolling register slots
         hipLaunchKernelGGL((attn_gqa_wave_kernel<128, 3, true>), dim3(NHq, rows, nz), dim3(256), 0, c->stream, qkv, ld, pos, kc, vc, NHq, NKV, scale, c->attn_part, n_ctx_keys,
                            kend, row_seq, seq_stride, qp);
