@@ -194,7 +194,7 @@ __device__ __forceinline__ void q4_frag_load(Q4Frag<NF, NP> &fr, const uint8_t *
 #pragma unroll
         for (int f = 0; f < NF; f++) {
             fr.wn[f][p] = __builtin_nontemporal_load((const int4v *) (w4 + (int64_t) nf[f] * (K >> 1) + b * 16));
-            fr.dw[f][p] = wd[(int64_t) nf[f] * nb + b];
+            fr.dw[f][p] = __builtin_nontemporal_load(wd + (int64_t) nf[f] * nb + b);   // the scales are a ninth of the stream: as dead as the codes once used
         }
     }
 }
