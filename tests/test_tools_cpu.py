@@ -135,3 +135,68 @@ def test_bench_time_budget_keeps_the_contract_and_drops_extras_in_order():
     rep = b.TimeBudget(480).report()
     assert rep["budget_s"] == 480 and rep["skipped"] == [] and rep["elapsed_s"] >= 0 and rep["sections"] == {}
 
+
+
+def test_wait_order_scanner_flags_weights_retired_before_the_prologue(tmp_path):
+    """profiles/tools/isa_wait_order.py (round 5): a wait that retires a streamed (non-temporal) load while staging loads still follow is reported;
+    the same kernel with the staging loads requested first is not; --first-use ends the head at a prologue's own arithmetic."""
+    asm = tmp_path / "k.s"
+    asm.write_text("""
+weights_first_kernel:                   ; @weights_first_kernel
+\tglobal_load_dwordx4 v[2:5], v[0:1], off nt
+\tglobal_load_dword v6, v[0:1], off
+\ts_waitcnt vmcnt(0)
+\tglobal_load_dword v7, v[0:1], off
+\ts_waitcnt vmcnt(0)
+\tds_write_b32 v8, v7
+\ts_barrier
+\tv_mfma_f32_16x16x32_f16 v[0:3], v[2:5], v[2:5], v[0:3]
+\ts_endpgm
+inputs_first_kernel:                    ; @inputs_first_kernel
+\tglobal_load_dword v6, v[0:1], off
+\tglobal_load_dword v7, v[0:1], off
+\tglobal_load_dwordx4 v[2:5], v[0:1], off nt
+\ts_waitcnt vmcnt(1)
+\tds_write_b32 v8, v7
+\ts_barrier
+\ts_waitcnt vmcnt(0)
+\tv_mfma_f32_16x16x32_f16 v[0:3], v[2:5], v[2:5], v[0:3]
+\ts_endpgm
+softmax_prologue_kernel:                ; @softmax_prologue_kernel
+\tglobal_load_dword v6, v[0:1], off
+\tglobal_load_dwordx4 v[2:5], v[0:1], off nt
+\ts_waitcnt vmcnt(1)
+\tv_exp_f32_e32 v9, v6
+\ts_waitcnt vmcnt(0)
+\tglobal_load_dword v7, v[0:1], off
+\ts_waitcnt vmcnt(0)
+\tds_write_b32 v8, v7
+\ts_barrier
+\tv_mfma_f32_16x16x32_f16 v[0:3], v[2:5], v[2:5], v[0:3]
+\ts_endpgm
+""")
+    tool = os.path.join(ROOT, "profiles", "tools", "isa_wait_order.py")
+    out = subprocess.run([sys.executable, tool, str(asm)], capture_output=True, text=True, check=True).stdout
+    assert "weights_first_kernel" in out and "inputs_first_kernel" not in out
+    assert "softmax_prologue_kernel" in out            # its later chunk of keys does wait for the weights ...
+    out = subprocess.run([sys.executable, tool, str(asm), "softmax_prologue_kernel", "--first-use=v_exp_f32"], capture_output=True, text=True, check=True).stdout
+    assert "softmax_prologue_kernel" not in out        # ... but its first arithmetic starts under them
+
+
+def test_trace_steps_tool_splits_a_kernel_trace_into_steps(tmp_path):
+    """profiles/tools/trace_steps.py (round 5): the dispatches behind the N-th last launch of the marker kernel, per kernel and per step."""
+    rows = ["Kernel_Name,Start_Timestamp,End_Timestamp"]
+    t = 1000
+    for step in range(6):
+        for name, dur in (("dia_embed_kernel(DiaEmbedArgs)", 5000), ("void gemv_stream_kernel<4, 0, 0, 8>(GemmArgs, StreamMap)", 10000), ("rms_fold_rows_kernel(float*)", 4000),
+                          ("void gemv_stream_kernel<4, 0, 0, 8>(GemmArgs, StreamMap)", 10000)):
+            rows.append(f'"{name}",{t},{t + dur}')
+            t += dur + 2000
+    csvf = tmp_path / "kernel_trace.csv"
+    csvf.write_text("\n".join(rows) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "tools", "trace_steps.py"), str(csvf), "dia_embed_kernel", "4"],
+                         capture_output=True, text=True, check=True).stdout
+    head = out.splitlines()[0]
+    assert head.startswith("4 steps, 37.0 us per step, 29.0 us in kernels, 4 launches per step"), head
+    line = [ln for ln in out.splitlines() if "gemv_stream_kernel<4, 0, 0, 8>" in ln][0].split()
+    assert "2.0" in line and "10.00" in line and "20.0" in line, line
