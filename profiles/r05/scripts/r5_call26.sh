@@ -1,0 +1,17 @@
+# round 5, call 26: the quantised decoder configurations of the line (at most 256 rows per forward with quantised matrices: --batch 256, three runners)
+export HSA_DISABLE_COREDUMP_ON_EXCEPTION=1; ulimit -c 0
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5; mkdir -p $O
+cd $R
+X="--steps 2 --warmup 1 --batch 256 --no-long --no-secondary --no-e2e --no-step-sweep --no-cpu-baseline"
+for cfg in "--wtype q5_0" "--wtype q4_0" "--wtype f16"; do
+  n=$(echo $cfg | tr -d ' -' )
+  timeout 300 python bench.py $X $cfg > $O/bench_cfg_b256_$n.json 2> $O/bench_cfg_b256_$n.err; echo "[$cfg --batch 256] rc=$?"
+  python - "$O/bench_cfg_b256_$n.json" "$cfg" <<'PY'
+import json, sys
+lines = [l for l in open(sys.argv[1]) if l.startswith('{')]
+if lines:
+    d = json.loads(lines[-1])
+    r = d.get("roofline") or {}
+    print(f"[{sys.argv[2]} --batch 256] {d['value']} {d['unit']}  ms_per_step {d['ms_per_step']}  dtype {d['dtype']}  roofline {r.get('kernel','')[:50]} frac {r.get('frac')}")
+PY
+done 2>&1 | tee $O/bench_other_configs_call26.txt
