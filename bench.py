@@ -375,9 +375,10 @@ def family_stats(stats):
     return fam
 
 
-def roof_of(name, st, src, tot, arith, dac_wtype):
+def roof_of(name, st, src, tot, arith, dac_wtype, wtype="f16"):
     """one family against the roofline that bounds it; bf16 x 3 families are priced with the flops they ISSUE against the bf16 pipe,
-    the fp32-equivalent (algorithmic) rate beside it"""
+    the fp32-equivalent (algorithmic) rate beside it.  With quantised decoder matrices (--wtype q*) the decoder GEMMs are qgemm16_kernel's
+    integer block dots over Q8_0-quantised rows (at most 256 rows per forward): a weight stream, priced against HBM, not the fp16 matrix pipe."""
     per_launch_ms = st["ms_total"] / max(st["launches"], 1)
     tf = st["flops_total"] / max(st["ms_total"], 1e-9) / 1e9
     gb = st["bytes_total"] / max(st["ms_total"], 1e-9) / 1e6
@@ -388,6 +389,9 @@ def roof_of(name, st, src, tot, arith, dac_wtype):
              "fp32_equivalent_TFLOPs": round(tf, 3), "hbm_GBps": round(gb, 1), "hbm_frac": round(gb / HBM_PEAK_GBS, 4),
              "note": f"fp32 operands as three bf16 terms, six bf16 MFMAs per product, fp32 accumulate: achieved = issued bf16 flops ({B3_ISSUE[name]:.2f} x "
                      "algorithmic) against the dense bf16 peak; with random operands the pipe sustains 1830 TFLOP/s (power-limited clock, profiles/r03/mfma_rate.txt)"}
+    elif name in MFMA_FP16 and wtype.startswith("q"):
+        r = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 4), "int8_dot_TOPs": round(tf, 3)}
+        name = f"qgemm16_kernel (decoder GEMMs with {wtype} matrices: Q8_0-quantised rows, integer block dots)"
     elif name in MFMA_FP32 or name in MFMA_FP16 or name in B3_ISSUE:
         peak = F16_PEAK_TFLOPS if (name in MFMA_FP16 or dac_wtype == "f16") else F32_PEAK_TFLOPS
         r = {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
@@ -789,11 +793,11 @@ def main():
                     for f in st:
                         st[f] += live.get(k, {}).get(f, 0)
                 src = "HIP events around every launch of this kernel family in the timed region (all runners of rank 0)"
-            roof = roof_of(dom, st, src, tot, arith, args.dac_wtype)
+            roof = roof_of(dom, st, src, tot, arith, args.dac_wtype, args.wtype)
             roof["share_of_kernel_time"] = round(fam[dom]["ms_total"] / tot, 3)
             roof["traffic"] = pmc_traffic(dom, args, n_audio, arith)
             out["roofline"] = roof
-            out["roofline_families"] = [dict(roof_of(n, v, "eager pass (launch-by-launch HIP events: short kernels read ~1-2 us long)", tot, arith, args.dac_wtype),
+            out["roofline_families"] = [dict(roof_of(n, v, "eager pass (launch-by-launch HIP events: short kernels read ~1-2 us long)", tot, arith, args.dac_wtype, args.wtype),
                                              traffic=pmc_traffic(n, args, n_audio, arith))
                                         for n, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_total"]) if n != dom]
             out["kernel_classes"] = {
