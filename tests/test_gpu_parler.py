@@ -463,6 +463,98 @@ def test_integer_path_full_width_shapes(rows):
     eng.close()
 
 
+QTILE_ROWS = {65: (0, 31, 32, 63, 64), 257: (0, 63, 64, 127, 128, 255, 256), 320: (0, 31, 32, 191, 192, 256, 319), 1024: (0, 63, 64, 511, 512, 959, 960, 1023)}
+
+
+@pytest.mark.parametrize("wtype", [gguf.Q5_0, gguf.Q4_0, gguf.Q8_0])
+@pytest.mark.parametrize("rows", [65, 257, 320, 1024])
+def test_integer_tile_path_many_rows(rows, wtype):
+    """GGUF-quantised matrices with more rows than the 16-feature kernel carries: qgemm_tile_kernel (one
+    v_mfma_i32_32x32x32_i8 per quantisation block, per-block (float) sumi * (d_w * d_a) like ggml_vec_dot_q*_q8_0) at Parler-Mini's matrix
+    shapes, ragged row counts (rows % 64 != 0), split-K slabs of the residual GEMMs, the GELU output and the attended cross rows leaving
+    their GEMMs as Q8_0 blocks.  (1) layer-0 K / V rows of the prompt forward = the fused QKV GEMM on inputs that are bit-identical on both
+    sides (embedding -> LayerNorm -> Q8_0): rows without a flipped activation at 1e-5, all inside the flip bound; (2) a step end to end
+    against per-row oracles at rows on both sides of every tile boundary."""
+    key = ("wide1", wtype)
+    if key not in _models:
+        _models[key] = synth.build(synth.tiny(hidden=1024, heads=16, ffn=4096, layers=1, weight_type=wtype))
+    model = _models[key]
+    cfg = model.cfg
+    H = cfg.hidden
+    eng = hip.HipEngine(cfg, max_seqs=rows, kv_positions=16)
+    eng.load(model)
+    rng = np.random.default_rng(rows)
+    prompts = [rng.integers(3, cfg.prompt_vocab, 2 + (i % 3)).astype(np.uint32) for i in range(rows)]
+    eng.prefill_batch(prompts)   # sum(len) = 3 * rows rows in one forward: beyond 1024 the host splits it
+    sample = QTILE_ROWS[rows]
+    oracles = {}
+    exact = 0
+    for r in sample:
+        o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+        o.decode(prompts[r], 0, audio=False, want_logits=False)
+        oracles[r] = o
+        n = len(prompts[r])
+        k_ref, v_ref = o.get_kv(0, n)
+        k = eng.debug_read(f"k:0:{r}", n * H).reshape(n, H)
+        v = eng.debug_read(f"v:0:{r}", n * H).reshape(n, H)
+        e = max(np.abs(k - k_ref).max() / np.abs(k_ref).max(), np.abs(v - v_ref).max() / np.abs(v_ref).max())
+        assert e < Q_FLIP_TOL, (rows, r, e)
+        exact += e < 1e-5
+    assert exact >= len(sample) - 1, exact
+    ids = np.full((rows, cfg.n_out), cfg.bos, dtype=np.uint32)
+    worst, close = 0.0, 0
+    for step in range(2):
+        lg = eng.step(ids, [len(p) + step for p in prompts])
+        for r in sample:
+            ref, _ = oracles[r].decode(ids[r], len(prompts[r]) + step, audio=True)
+            e = relerr(lg[r], ref[:, 0, :])
+            worst = max(worst, e)
+            close += e < 1e-4
+            assert e < Q_FLIP_TOL, (rows, r, step, e)
+            ids[r] = ref[:, 0, :].argmax(-1)
+        for r in range(rows):
+            if r not in sample:
+                ids[r] = lg[r].argmax(-1)
+    assert close >= len(sample), (close, worst)   # most (row, step) pairs see no flipped activation
+    print(f"rows={rows} {wtype}: worst relative logit error {worst:.2e}, {close} of {2 * len(sample)} below 1e-4")
+    eng.close()
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2, 3])
+def test_integer_tile_path_every_tile_shape(shape):
+    """every tile shape of qgemm_tile_kernel forced onto every GEMM of a Parler-Mini-width layer, ragged rows, 1 / 2 / 4 K slices on the residual
+    GEMMs; the tiled path against the 16-feature kernel (tune qtile_min_rows = 0) on the same rows: the same block terms in another order."""
+    key = ("wide1", gguf.Q5_0)
+    if key not in _models:
+        _models[key] = synth.build(synth.tiny(hidden=1024, heads=16, ffn=4096, layers=1, weight_type=gguf.Q5_0))
+    model = _models[key]
+    cfg = model.cfg
+    rows = 200
+    rng = np.random.default_rng(shape)
+    prompts = [rng.integers(3, cfg.prompt_vocab, 2 + (i % 3)).astype(np.uint32) for i in range(rows)]
+    ids = np.full((rows, cfg.n_out), cfg.bos, dtype=np.uint32)
+    res = {}
+    for mode in ("tile", "wg16"):
+        eng = hip.HipEngine(cfg, max_seqs=rows, kv_positions=16)
+        eng.tune("qtile_min_rows", 65 if mode == "tile" else 0)
+        if mode == "tile":
+            eng.tune("qtile_shape", shape)
+            eng.tune("qtile_ks", (1, 2, 4, 2)[shape])
+        eng.load(model)
+        eng.prefill_batch(prompts)
+        res[mode] = eng.step(ids, [len(p) for p in prompts])
+        eng.close()
+    err = np.abs(res["tile"] - res["wg16"]).reshape(rows, -1).max(axis=1) / np.abs(res["wg16"]).max()
+    # a row differs only where a last-bit difference (another summation order) flips one of its ~12 000 Q8_0 activation codes of the layer: measured 14 of 200 rows
+    assert (err < 1e-5).sum() >= rows * 0.8, (shape, np.sort(err)[-10:])
+    assert err.max() < Q_FLIP_TOL
+    for r in (0, 63, 64, 199):
+        o = orc.ParlerOracle(model, act_mode=1, gelu_mode=1)
+        o.decode(prompts[r], 0, audio=False, want_logits=False)
+        ref, _ = o.decode(ids[r], len(prompts[r]), audio=True)
+        assert relerr(res["tile"][r], ref[:, 0, :]) < Q_FLIP_TOL, (shape, r)
+
+
 def test_update_conditional_prompt():
     model = get_model("tiny", gguf.F32)
     cfg = model.cfg

@@ -16,7 +16,9 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-UNITS = ["shim_core", "shim_decoder", "shim_codec", "shim_llama"]
+UNITS = ["shim_core", "shim_decoder", "shim_codec", "shim_llama", "shim_qtile"]
+# per-unit code-generation switches (the reasons are in the unit's header comment)
+UNIT_FLAGS = {"shim_qtile": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _deps(depfile, fallback):
@@ -42,7 +44,7 @@ def build_hip(force=False, verbose=True):
     for u in UNITS:
         src, obj, dep = os.path.join(csrc, u + ".hip"), os.path.join(objdir, u + ".o"), os.path.join(objdir, u + ".d")
         if force or _newer(obj, _deps(dep, [src] + headers)):
-            cmd = [HIPCC] + flags + ["-MMD", "-MF", dep, "-c", src, "-o", obj]
+            cmd = [HIPCC] + flags + UNIT_FLAGS.get(u, []) + ["-MMD", "-MF", dep, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             jobs.append((cmd, subprocess.Popen(cmd)))

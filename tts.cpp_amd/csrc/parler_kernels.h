@@ -608,9 +608,12 @@ __global__ void gemv_valu_kernel(GemmArgs a, int EPI, int act_f16_src) {
 // NP >= 0: that many split-K slabs are added to x in slab order first, with every load in flight at once
 // (the slab loop with a run-time trip count serialised 4 dependent round trips per float4: 13.8 us -> see DESIGN.md);
 // NP < 0: run-time slab count.
+__device__ __forceinline__ unsigned quant4_q8(float4v y, float &d_out);   // below (quantised weights)
+// yq / ydT != NULL: the normalised row leaves as Q8_0 blocks for a quantised consumer (qgemm_tile_kernels.h): codes yq[k], block scale ydT[(k / 32) * ldr]
+// (the caller passes the row's column of the transposed scale table).  A lane's float4 is an eighth of a block: quant4_q8, H % 32 == 0.
 template <int NI, int NP>
 __device__ __forceinline__ void ln_row_regs(float *xr, int H, int lane, const float *lw, const float *lb, float *yr32, _Float16 *yr16,
-                                            const float *pr, int n_parts, int64_t slab_stride) {
+                                            const float *pr, int n_parts, int64_t slab_stride, int8_t *yq = nullptr, float *ydT = nullptr, int ldr = 0) {
     // straight-line loads with clamped offsets (a piece beyond the row re-reads the row's last float4 and is never used): under `if (k < H)`
     // every piece was its own basic block behind a full s_waitcnt — NI dependent round trips for a row that is one round trip of data
     float4v v[NI], w4[NI], b4[NI];
@@ -666,6 +669,12 @@ __device__ __forceinline__ void ln_row_regs(float *xr, int H, int lane, const fl
                 for (int e = 0; e < 4; e++) h[e] = (_Float16) y[e];
                 *(half4 *) (yr16 + k) = h;
             }
+            if (yq) {
+                float dd;
+                const unsigned qq = quant4_q8(y, dd);
+                *(unsigned *) (yq + k) = qq;
+                if ((lane & 7) == 0) ydT[(int64_t) (k >> 5) * ldr] = dd;
+            }
         }
     }
 }
@@ -682,6 +691,17 @@ __global__ __launch_bounds__(256) void ln_rows_t_kernel(float *x, int H, const f
     if (r >= R) return;
     const float *pr = parts ? parts + (int64_t) r * H : nullptr;
     ln_row_regs<NI, NP>(x + (int64_t) r * H, H, lane, lw, lb, y32 ? y32 + (int64_t) r * H : nullptr, y16 ? y16 + (int64_t) r * H : nullptr, pr, parts ? n_parts : 0, slab_stride);
+}
+
+// the same with Q8_0 output for the tiled integer GEMM: codes q [R][H], block scales dT float [H / 32][ldr]
+template <int NI, int NP>
+__global__ __launch_bounds__(256) void ln_rows_q8t_kernel(float *x, int H, const float *lw, const float *lb, int8_t *q, float *dT, int ldr, int R, const float *parts, int n_parts,
+                                                          int64_t slab_stride) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float *pr = parts ? parts + (int64_t) r * H : nullptr;
+    ln_row_regs<NI, NP>(x + (int64_t) r * H, H, lane, lw, lb, (float *) nullptr, (_Float16 *) nullptr, pr, parts ? n_parts : 0, slab_stride, q + (int64_t) r * H, dT + r, ldr);
 }
 
 // any H: three passes over the row

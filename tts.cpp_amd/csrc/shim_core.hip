@@ -172,6 +172,10 @@ extern "C" int tts_hip_tune(tts_hip_ctx *c, const char *key, int v) {
     else if (k == "cross_fold") c->cross_fold = v != 0;
     else if (k == "tile_min_rows") c->tile_min_rows = std::max(0, v);
     else if (k == "tile_deep") c->tile_deep = v;
+    else if (k == "qtile_min_rows") c->qtile_min_rows = std::max(0, v);   // 0: quantised matrices stay on the 16-feature kernel (<= 256 rows per forward)
+    else if (k == "qtile_shape") c->qtile_shape = v;
+    else if (k == "qtile_ks") c->qtile_ks = std::max(0, v);
+    else if (k == "qtile_fuse") c->qtile_fuse = v != 0;
     else if (k == "gemv_stream") c->gemv_stream = v != 0;
     else if (k == "q_fuse_max") c->q_fuse_max = std::max(0, std::min(16, v));
     else if (k == "q4_lds") c->q4_lds = v != 0;
@@ -230,7 +234,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     for (auto &t : c->tensors) free_dev(t.second.tmp);
     arena_release(c);
     free_dev(c->kcache); free_dev(c->vcache); free_dev(c->x); free_dev(c->q); free_dev(c->att); free_dev(c->u32);
-    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->d_uniforms); free_dev(c->l_cand); free_dev(c->l_smp); free_dev(c->d_pen); free_dev(c->d_last); free_dev(c->d_repc);
+    free_dev(c->u16); free_dev(c->xn16); free_dev(c->att16); free_dev(c->partials); free_dev(c->aq); free_dev(c->ad); free_dev(c->adT); free_dev(c->aq2); free_dev(c->adT2); free_dev(c->d_uniforms); free_dev(c->l_cand); free_dev(c->l_smp); free_dev(c->d_pen); free_dev(c->d_last); free_dev(c->d_repc);
     free_dev(c->l_x); free_dev(c->l_xn); free_dev(c->l_qkv); free_dev(c->l_att); free_dev(c->l_gu); free_dev(c->l_g); free_dev(c->l_logits); free_dev(c->l_parts);
     free_dev(c->attn_part); free_dev(c->kk_stuck); free_dev(c->kk_pool);
     free_dev(c->l_kc); free_dev(c->l_vc); free_dev(c->l_ids); free_dev(c->l_pos); free_dev(c->l_tok);
@@ -461,6 +465,12 @@ struct Planner {
             cur += (size_t) n_pad * (w.K / 32) * 2;
         }
         w.N += n_pad;
+        if (w.type == TTS_HIP_Q8I && c->has_parler && w.K % 128 == 0) {
+            // the same scales transposed for the many-row kernel (qgemm_tile_kernels.h), written by tts_hip_finalize: part of the arena, so that
+            // contexts sharing it and ranks receiving it by broadcast hold them too
+            w.ldw = (int) ((w.N + 255) & ~(int64_t) 255);
+            w.stoff = alloc((size_t) (w.K / 32) * w.ldw * 2);
+        }
         return w;
     }
 };

@@ -10,6 +10,7 @@
 #include "llama_kernels.h"
 #include "dia_kernels.h"
 #include "shim_decoder.h"
+#include "shim_qtile.h"
 
 // kernel launch plumbing (+ optional per-class event timing)
 // ------------------------------------------------------------------------------------------------
@@ -122,13 +123,22 @@ static int launch_gemm16_rb(tts_hip_ctx *c, const GemmArgs &a_in) {
     return launch_gemm16<WT, PRO, EPI, 4>(c, a);  // loops over groups of 64 rows, weights stay in registers
 }
 
-// rows one forward can carry: 256 through the 16-feature workgroups, 512 when every decoder matrix is fp16 (LDS-tiled GEMM)
-static int max_rows_for(const tts_hip_ctx *c) {
-    if (c->tile_min_rows <= 0) return 256;
+// rows one forward can carry: 256 through the 16-feature workgroups, 1024 when every decoder matrix has an LDS-tiled GEMM: fp16 (gemm_tile_kernel) or a
+// GGUF-quantised one with its transposed scale table (qgemm_tile_kernel)
+static bool any_qtile(const tts_hip_ctx *c) {
+    if (c->heads.stoff) return true;
     for (const PLayer &y : c->layers)
         for (const W *w : {&y.qkv, &y.o, &y.cq, &y.co, &y.fc1, &y.fc2})
-            if (w->type != TTS_HIP_F16 && w->N) return 256;
-    if (c->heads.type != TTS_HIP_F16) return 256;
+            if (w->stoff) return true;
+    return false;
+}
+static int max_rows_for(const tts_hip_ctx *c) {
+    if (c->tile_min_rows <= 0) return 256;
+    auto tiled = [&](const W &w) { return w.type == TTS_HIP_F16 || (w.type == TTS_HIP_Q8I && w.stoff && c->qtile_min_rows > 0 && c->H <= 2048); };
+    for (const PLayer &y : c->layers)
+        for (const W *w : {&y.qkv, &y.o, &y.cq, &y.co, &y.fc1, &y.fc2})
+            if (w->N && !tiled(*w)) return 256;
+    if (!tiled(c->heads)) return 256;
     // 1024 rows per forward: every GEMM of a Parler-Mini layer is a whole number of rounds of 128 x 128 (N = 4096, 3072) or 64 x 64 (N = 1024)
     // tiles over the 256 CUs; at 1152 rows the ninth row tile costs a second, nearly empty round (146 vs 101 us of GEMMs per layer,
     // profiles/r03/rows1152_classes.txt / rows1024_classes.txt).  TTS_HIP_MAX_ROWS raises or lowers the cap.
@@ -309,8 +319,92 @@ static int launch_stream(tts_hip_ctx *c, const GemmArgs &a, int pro, int epi) {
     return set_err("gemv_stream: no kernel for pro=%d epi=%d", pro, epi);
 }
 
+// ------------------------------------------------------------------------------------------------
+// many rows on a GGUF-quantised matrix: LayerNorm (if any) -> Q8_0 blocks of the activation rows -> LDS-tiled integer block GEMM
+// (qgemm_tile_kernels.h / shim_qtile.hip).  The activations' blocks come from the producing kernel when it wrote them (c->aqt_src), from the
+// LayerNorm launch (ln_rows_q8t_kernel) or from quant_rows_q8t_kernel.
+// ------------------------------------------------------------------------------------------------
+static bool qtile_ok(const tts_hip_ctx *c, const W &w, const GemmArgs &a, int pro) {
+    return c->qtile_min_rows > 0 && a.R >= c->qtile_min_rows && w.stoff && c->adT && w.K % 128 == 0 && w.N % 16 == 0 && pro != PRO_F16 && pro != PRO_ATTN && pro != PRO_CROSS &&
+           a.R <= c->ldr && !a.kchunk && !a.n_parts && (pro != PRO_LN || (a.K <= 2048 && a.K % 32 == 0));
+}
+static void choose_qtile(const tts_hip_ctx *c, int R, int N, int K, bool may_split, int *shape_out, int *ks_out) {
+    // profiles/r06/qgemm_bench_*.txt: the launch is bound by the instruction issue of its waves (48 scaling instructions per MFMA), so the shape that
+    // gives every SIMD four waves wins: 64 x 64 tiles of four waves (wave tile 32 x 32); residual GEMMs (N = hidden size) split K until there are
+    // about four workgroups per CU
+    int shape = 0, ks = 1;
+    if (may_split) {
+        const int tiles = ((R + 63) / 64) * ((N + 63) / 64);
+        while (tiles * ks < 512 && ks < 4 && K % (ks * 2 * 256) == 0 && K / (ks * 2) >= 256) ks *= 2;
+        if (K >= 4096 && K % 1024 == 0) ks = 4;
+    }
+    if (c->qtile_shape >= 0 && c->qtile_shape < N_QTILE_SHAPES) shape = c->qtile_shape;
+    if (c->qtile_ks > 0 && may_split && K % (c->qtile_ks * 128) == 0) ks = c->qtile_ks;
+    *shape_out = shape;
+    *ks_out = ks;
+}
+static int run_qtile(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi, QTileOut qo) {
+    const bool have_q = c->aqt_src != nullptr && c->aqt_src == a.A && a.lda == a.K && pro != PRO_LN;
+    const int in_set = have_q ? c->aqt_set : 0;
+    c->aqt_src = nullptr;
+    c->aq_src = nullptr;
+    c->qtile_out = QTileOut{};
+    if (pro == PRO_LN) {
+        // LayerNorm (+ the pending split-K slabs folded into x) and the Q8_0 conversion in one launch
+        CHK(prof_begin(c, TTS_HIP_K_LN, (double) a.R * a.K * 5.2, 0));
+        const dim3 grid((unsigned) a.R), block(64);
+        const float *parts = c->pending_parts ? (const float *) c->partials : (const float *) nullptr;
+        const int np = c->pending_parts;
+        const int64_t ss = (int64_t) c->RMAX * c->H;
+#define LNQ_CASE(NIv, NPv) hipLaunchKernelGGL((ln_rows_q8t_kernel<NIv, NPv>), grid, block, 0, c->stream, (float *) a.A, a.K, a.ln_w, a.ln_b, c->aq, c->adT, c->ldr, a.R, parts, np, ss)
+        if (a.K <= 1024) {
+            if (np == 0) LNQ_CASE(4, 0); else if (np == 2) LNQ_CASE(4, 2); else if (np == 4) LNQ_CASE(4, 4); else LNQ_CASE(4, -1);
+        } else {
+            if (np == 0) LNQ_CASE(8, 0); else LNQ_CASE(8, -1);
+        }
+#undef LNQ_CASE
+        HIPCHK(hipGetLastError());
+        c->pending_parts = 0;
+        CHK(prof_end(c));
+    }
+    const bool want_cross = epi == EPI_CROSS;
+    const bool may_split = epi == EPI_RESID && a.H <= 2048 && a.N == a.H && a.out == c->x;
+    int shape = 0, ks = 1;
+    choose_qtile(c, a.R, a.N, a.K, may_split, &shape, &ks);
+    if (want_cross) {
+        const bool fold = QTILE_SHAPES[shape].BN == 64 && a.cross_E >= 1 && a.cross_E <= 32 && a.N == a.H && a.H % 64 == 0;
+        c->cross_folded = fold;
+        if (!fold) epi = EPI_STORE;
+    }
+    if (ks > 1) {
+        a.kchunk = a.K / ks;
+        a.slab_stride = (int64_t) c->RMAX * c->H;
+        a.out = c->partials;
+        epi = EPI_STORE;
+        c->pending_parts = ks;
+    }
+    const double wbytes = (double) w.K * w.N * (1.0 + 2.0 / 32);
+    CHK(prof_begin(c, kclass, wbytes + (double) a.R * a.K * 1.125 + (double) a.R * a.N * 4, 2.0 * a.R * (double) w.K * w.N));
+    if (pro != PRO_LN && !have_q) CHK(qtile_quant_rows(c, (const float *) a.A, a.lda, a.K, a.R));
+    QTileArgs qa{};
+    qa.g = a;
+    qa.wdT = (const _Float16 *) (c->arena + w.stoff);
+    qa.ldw = w.ldw;
+    qa.aq = in_set ? c->aq2 : c->aq;
+    qa.adT = in_set ? c->adT2 : c->adT;
+    qa.ldr = c->ldr;
+    const bool q_out = qo.q && (epi == EPI_GELU || epi == EPI_CROSS) && qo.q != qa.aq;
+    if (q_out) { qa.q_out = qo.q; qa.d_out = qo.dT; qa.ldq = qo.ldq; }
+    CHK(launch_qtile(c, qa, epi, shape, ks));
+    if (q_out) { c->aqt_src = qo.stands_for; c->aqt_set = qo.q == c->aq2 ? 1 : 0; }
+    return prof_end(c);
+}
+
 int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi) {
     if (pro == PRO_F16) return set_err("run_qgemm: fp16 activations are never produced for a quantised consumer");
+    if (qtile_ok(c, w, a, pro)) return run_qtile(c, kclass, w, a, pro, epi, c->qtile_out);
+    c->qtile_out = QTileOut{};
+    if (epi == EPI_CROSS) { epi = EPI_STORE; c->cross_folded = false; }
     const bool have_q = c->aq_src != nullptr && c->aq_src == a.A && a.lda == a.K;
     c->aq_src = nullptr;
     if (c->gemv_rows && a.R <= 4 && pro == PRO_F32 && (epi == EPI_STORE || epi == EPI_RESID) && !a.kchunk) {
@@ -398,7 +492,8 @@ int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int ep
     // path stores q as before and the caller launches the attention (c->cross_folded says which)
     const bool want_cross = epi == EPI_CROSS;
     if (want_cross) { epi = EPI_STORE; c->cross_folded = false; }
-    if (w.type == TTS_HIP_Q8I) return run_qgemm(c, kclass, w, a, pro, epi);
+    if (w.type == TTS_HIP_Q8I) return run_qgemm(c, kclass, w, a, pro, want_cross ? (int) EPI_CROSS : epi);
+    c->qtile_out = QTileOut{};
     const double wbytes = (double) w.K * w.N * (w.type == TTS_HIP_F16 ? 2 : 4);
     const double bytes = wbytes + (double) a.R * a.K * 4 + (double) a.R * a.N * 4;
     const double flops = 2.0 * a.R * (double) w.K * w.N;
@@ -650,6 +745,9 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
                 gq.cross_E = c->E; gq.cross_scale = at.scale;
                 gq.cross_out = c->att; gq.cross_out16 = co_half_ ? c->att16 : nullptr;
             }
+            // quantised out projection on the tiled path: the attended rows leave the fold as Q8_0 blocks (second set), not as fp32
+            const bool q_fuse = c->qtile_fuse && !c->debug && c->adT && R >= c->qtile_min_rows && c->qtile_min_rows > 0;
+            if (try_fold && q_fuse && y.co.type == TTS_HIP_Q8I && y.co.stoff && (int) y.co.K == H) c->qtile_out = QTileOut{c->aq2, c->adT2, H, c->att};
             CHK(run_gemm(c, TTS_HIP_K_GEMM_CROSS_Q, y.cq, gq, PRO_LN, try_fold ? EPI_CROSS : EPI_STORE));
             const bool folded = try_fold && c->cross_folded;
             AttnArgs ac{};
@@ -681,6 +779,8 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
         const bool u_half = (y.fc2.type == TTS_HIP_F16) && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM) && (c->F % 256 == 0);
         g1.out = c->u32; g1.out16 = u_half ? c->u16 : nullptr; g1.ldo = c->F;
         g1.stamps = stamp_slot();
+        if (c->qtile_fuse && !c->debug && c->adT && c->qtile_min_rows > 0 && R >= c->qtile_min_rows && y.fc2.type == TTS_HIP_Q8I && y.fc2.stoff && (int) y.fc2.K == c->F)
+            c->qtile_out = QTileOut{c->aq2, c->adT2, c->F, c->u32};   // fc2's input rows as Q8_0 blocks straight from the GELU epilogue
         CHK(run_gemm(c, TTS_HIP_K_GEMM_FC1, y.fc1, g1, PRO_LN, EPI_GELU));
         GemmArgs g2{};
         g2.R = R; g2.H = H; g2.A = u_half ? (const void *) c->u16 : (const void *) c->u32; g2.lda = c->F;
@@ -716,6 +816,17 @@ static int compute_cross_kv(tts_hip_ctx *c) {
             }
         }
     }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// the block scales of the Parler decoder's quantised matrices once more, transposed, for qgemm_tile_kernel (arena space reserved by the planner)
+static int derive_scale_tables(tts_hip_ctx *c) {
+    if (!c->has_parler) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    for (const PLayer &y : c->layers)
+        for (const W *w : {&y.qkv, &y.o, &y.cq, &y.ck, &y.cv, &y.co, &y.fc1, &y.fc2}) CHK(qtile_transpose_scales(c, *w));
+    CHK(qtile_transpose_scales(c, c->heads));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -772,6 +883,12 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->partials, (size_t) 8 * R * H));
         CHK(dmalloc(&c->aq, (size_t) R * std::max(H, c->F)));
         CHK(dmalloc(&c->ad, (size_t) R * std::max(H, c->F) / 32));
+        if (any_qtile(c)) {
+            c->ldr = (R + 255) & ~255;
+            CHK(dmalloc(&c->adT, (size_t) c->ldr * (std::max(H, c->F) / 32)));
+            CHK(dmalloc(&c->aq2, (size_t) R * std::max(H, c->F)));
+            CHK(dmalloc(&c->adT2, (size_t) c->ldr * (std::max(H, c->F) / 32)));
+        }
         CHK(dmalloc(&c->logits, (size_t) R * c->NO * c->V));
         CHK(dmalloc(&c->part, (size_t) R * c->NH * 16 * ATT_PS));
         CHK(dmalloc(&c->attn_cnt, (size_t) R * c->NH));
@@ -915,6 +1032,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         c->dac_frame_elems = mx;
     }
     c->finalized = true;
+    if (c->weights_present) CHK(derive_scale_tables(c));   // (a declare-only context on a shared arena finds the tables of the context that filled it)
     if (c->weights_present) CHK(compute_cross_kv(c));
     return 0;
 }
@@ -922,7 +1040,7 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
 extern "C" int tts_hip_arena_filled(tts_hip_ctx *c) {
     if (!c || !c->finalized) return set_err("tts_hip_arena_filled: context not finalized");
     c->weights_present = true;
-    return 0;
+    return 0;   // the arena image of a finalized context carries its transposed scale tables (derive_scale_tables) and cross K / V
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -56,7 +56,12 @@ struct W {  // a matrix living in the arena
     int64_t K = 0, N = 0;
     bool src_q4 = false;            // every stacked source tensor was Q4_0 in the GGUF
     const uint8_t *q4 = nullptr;    // TTS_HIP_Q4_NATIVE: the 4-bit codes repacked next to the int8 expansion (gemv_q4_rows_kernel)
+    size_t stoff = 0;               // TTS_HIP_Q8I matrices of the Parler decoder: the block scales once more, transposed (fp16 [K/32][ldw]) for qgemm_tile_kernel
+    int ldw = 0;
 };
+
+// where a tiled integer GEMM's epilogue leaves its result rows as Q8_0 blocks for the next quantised matrix (set by the caller right before run_gemm)
+struct QTileOut { int8_t *q = nullptr; float *dT = nullptr; int ldq = 0; const void *stands_for = nullptr; };   // stands_for: the fp32 buffer the consumer names as its input
 
 struct PLayer {
     W qkv, o, cq, ck, cv, co, fc1, fc2;
@@ -274,6 +279,18 @@ struct tts_hip_ctx {
     int tile_force = -1;        // TTS_HIP_TILE_FORCE: tile shape index for every tiled GEMM (tuning)
     int tile_force_ks = 0;      // TTS_HIP_TILE_KS: k slices for the residual GEMMs (tuning)
     const void *aq_src = nullptr;  // activation rows whose Q8_0 blocks already sit in aq / ad (written by the producing kernel)
+    // many rows on quantised matrices (qgemm_tile_kernels.h): activation block scales transposed, float [max(H, F) / 32][ldr]
+    float *adT = nullptr;
+    int ldr = 0;
+    int8_t *aq2 = nullptr;      // second set: blocks written by a GEMM epilogue (GELU output, attended cross rows) while that GEMM reads the first
+    float *adT2 = nullptr;
+    int aqt_set = 0;            // which set holds the blocks of aqt_src
+    int qtile_min_rows = 65;    // tune("qtile_min_rows"): forwards with at least this many rows take the LDS-tiled integer GEMM; 0 = never (the 16-feature kernel, <= 256 rows)
+    int qtile_shape = -1;       // tune("qtile_shape"): tile shape index for every tiled integer GEMM (tuning / tests)
+    int qtile_ks = 0;           // tune("qtile_ks"): k slices of the residual GEMMs (tuning / tests)
+    bool qtile_fuse = true;     // tune("qtile_fuse")=0: LayerNorm, GELU and the attentions hand fp32 rows to a quantising launch of their own instead of writing Q8_0 blocks themselves
+    const void *aqt_src = nullptr; // activation rows whose Q8_0 blocks already sit in aq / adT
+    QTileOut qtile_out;         // request for the next run_gemm: Q8_0 output (EPI_GELU / EPI_CROSS on the tiled integer path); cleared by it
     int attn_fold = 1;          // tune("attn_fold") = 0: Dia's step keeps attn_gqa_combine_kernel and silu_mul_kernel as launches of their own.  1 (default): the consuming
                                 // projections merge the attention's key slices / apply silu * up while they stage their rows (gemv_stream_kernel<.., PRO_ATTN8 / PRO_SILU, ..>)
     bool cross_fold = true;     // tune("cross_fold")=0: the cross-attention of a many-row forward stays a launch of its own (attn_short_kernel) instead of the cross-q GEMM's epilogue
@@ -320,6 +337,8 @@ int prof_end(tts_hip_ctx *c);
 int ready(tts_hip_ctx *c, const char *who);
 int stage_uniforms(tts_hip_ctx *c, const float *uniforms, size_t count);
 int stage_penalty(tts_hip_ctx *c, float penalty, int n);
+// ---- shim_qtile.hip (the tiled integer GEMM: its own unit, built without SLP vectorisation and with MFMA results in VGPRs)
+int qtile_transpose_scales(tts_hip_ctx *c, const W &w);
 // ---- shim_codec.hip
 int dac_row_stride(const tts_hip_ctx *c, int L);
 
