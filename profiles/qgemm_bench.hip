@@ -8,6 +8,7 @@
 #include <cstring>
 #include <vector>
 #include <cmath>
+#include <algorithm>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -52,16 +53,19 @@ __global__ void fold_kernel(const float *slabs, float *out, size_t n, int ks, si
 }
 
 typedef void (*kern_t)(QTileArgs, TileMap);
+#ifndef BENCH_DBG
+#define BENCH_DBG 0   // -DBENCH_DBG=1: the kernels carry the QGEMM_BENCH_DBG / QGEMM_BENCH_STAMPS switches
+#endif
 struct Cfg { const char *name; int BM, BN, threads, S; size_t lds; kern_t k; };
-#define CFG(BM, BN, WM, WN, S, WPE, PIPE) { #BM "x" #BN "/" #WM "x" #WN "/s" #S "w" #WPE "p" #PIPE, BM, BN, WM * WN * 64, S, (size_t) S * ((BM + BN) * 128 + (BN * 8 + 1023) / 1024 * 1024 + BM * 16), qgemm_tile_kernel<BM, BN, WM, WN, S, EPI_STORE, WPE, PIPE> }
+#define CFGK(BM, BN, WM, WN, S, WPE, KG) { #BM "x" #BN "/" #WM "x" #WN "/s" #S "w" #WPE "kg" #KG, BM, BN, WM * WN * KG * 64, S, std::max((size_t) S * (BM + BN) * 144, (size_t) (KG - 1) * (BM / 32) * (BN / 32) * 4096), qgemm_tile_kernel<BM, BN, WM, WN, S, EPI_STORE, WPE, false, false, KG> }
+#define CFG(BM, BN, WM, WN, S, WPE, PIPE) { #BM "x" #BN "/" #WM "x" #WN "/s" #S "w" #WPE "p" #PIPE, BM, BN, WM * WN * 64, S, (size_t) S * (BM + BN) * 144, BENCH_DBG ? (kern_t) qgemm_tile_kernel<BM, BN, WM, WN, S, EPI_STORE, WPE, PIPE, true> : (kern_t) qgemm_tile_kernel<BM, BN, WM, WN, S, EPI_STORE, WPE, PIPE, false> }
 static Cfg cfgs[] = {
-    // 16 waves per CU: two workgroups of 8 waves (wave tile 32 x 32) or four of 4
-    CFG(128, 64, 4, 2, 2, 4, false), CFG(64, 128, 2, 4, 2, 4, false), CFG(64, 64, 2, 2, 2, 4, false), CFG(64, 64, 2, 2, 3, 4, false), CFG(128, 64, 4, 2, 2, 4, true),
-    CFG(128, 128, 2, 4, 2, 4, false), CFG(128, 128, 4, 2, 2, 4, false), CFG(256, 128, 4, 4, 2, 4, false), CFG(128, 256, 4, 4, 2, 4, false), CFG(128, 128, 4, 4, 2, 4, false), CFG(128, 128, 4, 4, 3, 4, false),
-    // 8 - 12 waves per CU
-    CFG(128, 128, 2, 4, 3, 2, true), CFG(128, 128, 2, 4, 3, 2, false), CFG(128, 128, 2, 4, 2, 3, false), CFG(128, 64, 4, 2, 3, 3, false), CFG(128, 64, 4, 2, 3, 2, true),
-    CFG(64, 64, 2, 2, 4, 2, true), CFG(128, 128, 1, 4, 3, 1, true),
+    CFG(64, 64, 2, 2, 2, 4, false), CFG(64, 64, 2, 2, 3, 3, true), CFG(128, 64, 4, 2, 2, 4, false), CFG(128, 128, 4, 4, 2, 4, true), CFG(128, 128, 2, 4, 2, 3, true),
+    CFGK(64, 64, 2, 2, 2, 4, 2), CFGK(64, 64, 2, 2, 2, 4, 4), CFGK(64, 64, 2, 2, 3, 4, 4), CFGK(128, 64, 4, 2, 2, 4, 2), CFGK(128, 128, 2, 4, 2, 4, 2), CFGK(64, 128, 2, 4, 2, 4, 2),
+    CFGK(128, 128, 4, 4, 2, 4, 1),
 };
+
+
 
 int main(int argc, char **argv) {
     const int NBUF = getenv("GEMM_BENCH_NBUF") ? atoi(getenv("GEMM_BENCH_NBUF")) : 40;
@@ -72,10 +76,10 @@ int main(int argc, char **argv) {
     const int RMAXB = 1024, LDR = 1024;
     const size_t wmax = (size_t) 9792 * 1024;
     const int ldw_max = 9984;
-    int8_t *W, *aq; _Float16 *wd, *wdT; float *adT, *X, *out, *ref, *fold;
+    int8_t *W, *aq; _Float16 *wd; float *wdT, *adT, *X, *out, *ref, *fold;
     CK(hipMalloc(&W, wmax * NBUF));
     CK(hipMalloc(&wd, wmax / 32 * 2 * NBUF));
-    CK(hipMalloc(&wdT, (size_t) ldw_max * 128 * 2 * NBUF));
+    CK(hipMalloc(&wdT, (size_t) ldw_max * 128 * 4 * NBUF));
     CK(hipMalloc(&X, (size_t) RMAXB * 4096 * 4));
     CK(hipMalloc(&aq, (size_t) RMAXB * 4096));
     CK(hipMalloc(&adT, (size_t) LDR * 128 * 4));
@@ -88,6 +92,7 @@ int main(int argc, char **argv) {
     CK(hipMemset(adT, 0, (size_t) LDR * 128 * 4));
     CK(hipDeviceSynchronize());
     for (auto &c : cfgs) CK(hipFuncSetAttribute((const void *) c.k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    long long *stamps; CK(hipMalloc(&stamps, 8192 * 4 * 8)); std::vector<long long> h_st(8192 * 4);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> h_out((size_t) RMAXB * 9792), h_ref((size_t) RMAXB * 9792);
@@ -146,6 +151,16 @@ int main(int argc, char **argv) {
                     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                     const double us = ms * 1000.0 / iters, tops = 2.0 * R * sh.N * (double) sh.K / us * 1e-6;
                     const bool ok = err <= 2e-6 * refmax;
+                    if (getenv("QGEMM_BENCH_STAMPS")) {
+                        qa.stamps = stamps;
+                        launch(1); CK(hipDeviceSynchronize());
+                        CK(hipMemcpy(h_st.data(), stamps, (size_t) total * 32, hipMemcpyDeviceToHost));
+                        double w = 0, st = 0, cp = 0;
+                        for (int i = 0; i < total; i++) { w += h_st[i * 4]; st += h_st[i * 4 + 1]; cp += h_st[i * 4 + 2]; }
+                        printf("   wave 0 of a workgroup, mean shader clocks: wait+barrier %.0f, stage issue %.0f, compute %.0f (per k-tile: %.0f / %.0f / %.0f)\n", w / total, st / total, cp / total,
+                               w / total / (sh.K / ks / 128), st / total / (sh.K / ks / 128), cp / total / (sh.K / ks / 128));
+                        qa.stamps = nullptr;
+                    }
                     printf("%-6s R=%4d %-18s ks=%d wgs=%5d  %8.2f us  %7.1f Top/s  err %.2e / %.2e %s\n", sh.name, R, c.name, ks, total, us, tops, err, refmax, ok ? "ok" : "MISMATCH");
                     if (ok && us < best) { best = us; snprintf(bestname, sizeof bestname, "%s ks=%d", c.name, ks); }
                 }

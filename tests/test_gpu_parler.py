@@ -520,7 +520,7 @@ def test_integer_tile_path_many_rows(rows, wtype):
     eng.close()
 
 
-@pytest.mark.parametrize("shape", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [0, 1, 2, 3, 4])
 def test_integer_tile_path_every_tile_shape(shape):
     """every tile shape of qgemm_tile_kernel forced onto every GEMM of a Parler-Mini-width layer, ragged rows, 1 / 2 / 4 K slices on the residual
     GEMMs; the tiled path against the 16-feature kernel (tune qtile_min_rows = 0) on the same rows: the same block terms in another order."""
@@ -539,7 +539,7 @@ def test_integer_tile_path_every_tile_shape(shape):
         eng.tune("qtile_min_rows", 65 if mode == "tile" else 0)
         if mode == "tile":
             eng.tune("qtile_shape", shape)
-            eng.tune("qtile_ks", (1, 2, 4, 2)[shape])
+            eng.tune("qtile_ks", (1, 2, 4, 2, 1)[shape])
         eng.load(model)
         eng.prefill_batch(prompts)
         res[mode] = eng.step(ids, [len(p) for p in prompts])

@@ -755,6 +755,11 @@ struct AttnArgs {
     // order as attn_combine_kernel) — no separate combine launch; counters [R][n_heads] start at 0 and are left at 0
     uint32_t *counters;
     long long *stamps;     // debug, as GemmArgs
+    // attn_rows_kernel / attn_combine_kernel with a quantised out projection on the tiled path: the attended rows leave as Q8_0 blocks as well
+    // (codes out_q [R][H], block scales out_dT float [H / 32][ldr]) — ggml's quantize_row_q8_0 of the row the fp32 store holds
+    int8_t *out_q;
+    float *out_dT;
+    int ldr;
 };
 
 __device__ __forceinline__ float4v load_kv4(const void *base, int kv_f16, int64_t off) {
@@ -971,7 +976,14 @@ __global__ __launch_bounds__(1024) void attn_rows_kernel(AttnArgs a) {
             float4v o;
 #pragma unroll
             for (int e = 0; e < 4; e++) o[e] = acc[e] * inv;
-            *(float4v *) (a.out + (int64_t) r * a.H + tid * 4) = o;
+            if (a.out_q) {   // eight neighbouring threads hold one block of 32 channels
+                float dd;
+                const unsigned qq = quant4_q8(o, dd);
+                *(unsigned *) (a.out_q + (int64_t) r * a.H + tid * 4) = qq;
+                if ((tid & 7) == 0) a.out_dT[(int64_t) (tid >> 3) * a.ldr + r] = dd;
+            } else {
+                *(float4v *) (a.out + (int64_t) r * a.H + tid * 4) = o;
+            }
         }
     } else {   // read by attn_combine_kernel: max (-inf: an empty slice), sum, unnormalised out[64] of this slice
         float *p = a.part + (((int64_t) r * a.n_heads + h) * nz + z) * ATT_PS;
@@ -1027,7 +1039,7 @@ static __global__ __launch_bounds__(256) void attn_short_kernel(AttnArgs a) {
 // per row instead of six per key — measured 14.8 us per launch at 1024 rows against 13.7 for this kernel with its compile-time prompt bound:
 // the launch is bound by the latency of its loads, not by the reductions; profiles/r03/attn_short16_rejected.txt.)
 
-static __global__ void attn_combine_kernel(const float *part, int nz, int H, int n_heads, float *out, _Float16 *out16) {
+static __global__ void attn_combine_kernel(const float *part, int nz, int H, int n_heads, float *out, _Float16 *out16, int8_t *out_q = nullptr, float *out_dT = nullptr, int ldr = 0) {
     const int h = blockIdx.x, r = blockIdx.y, c = threadIdx.x;  // 64 threads; nz <= 16
     const float *p = part + ((int64_t) r * n_heads + h) * nz * ATT_PS;
     float m[16], s[16], o[16];
@@ -1048,7 +1060,13 @@ static __global__ void attn_combine_kernel(const float *part, int nz, int H, int
         }
     }
     const float res = oo / ss;
-    if (out16) out16[(int64_t) r * H + h * 64 + c] = (_Float16) res;
+    if (out_q) {   // a half-wave holds one block of 32 channels
+        const float amax = lanes32_max(fabsf(res));
+        const float dd = amax / 127.0f;
+        const float id = dd ? 1.0f / dd : 0.0f;
+        out_q[(int64_t) r * H + h * 64 + c] = (int8_t) roundf(res * id);
+        if ((c & 31) == 0) out_dT[(int64_t) (h * 2 + (c >> 5)) * ldr + r] = (float) (_Float16) dd;
+    } else if (out16) out16[(int64_t) r * H + h * 64 + c] = (_Float16) res;
     else out[(int64_t) r * H + h * 64 + c] = res;
 }
 

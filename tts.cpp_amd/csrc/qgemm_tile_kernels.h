@@ -31,11 +31,13 @@
 typedef int int16v __attribute__((ext_vector_type(16)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
-// weight block scales [N][nb] fp16 -> fp16 [nb][ldw] (ldw >= N, a multiple of 256; the pad columns are zero)
-static __global__ void transpose_scales_kernel(const _Float16 *wd, _Float16 *wdT, int N, int nb, int ldw) {
+// weight block scales [N][nb] fp16 -> float [nb][ldw] (ldw >= N, a multiple of 256; the pad columns are zero).  Floats: the scaling step is bound by
+// the vector instructions it issues, and 16 v_cvt_f32_f16 per block and 32-feature group were a sixth of them; the LDS reads the wider table costs are
+// not (profiles/r06/qgemm_bench_*.txt).
+static __global__ void transpose_scales_kernel(const _Float16 *wd, float *wdT, int N, int nb, int ldw) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (n >= ldw) return;
-    wdT[(int64_t) b * ldw + n] = n < N ? wd[(int64_t) n * nb + b] : (_Float16) 0.0f;
+    wdT[(int64_t) b * ldw + n] = n < N ? (float) wd[(int64_t) n * nb + b] : 0.0f;
 }
 
 // activation rows -> Q8_0 blocks for the tiled kernel: q int8 [R][K], d float [K/32][ldr] (the fp16-rounded scale, transposed).
@@ -53,7 +55,7 @@ static __global__ __launch_bounds__(256) void quant_rows_q8t_kernel(const float 
 
 struct QTileArgs {
     GemmArgs g;             // K, N, R, epilogue fields; g.W = int8 codes [N][K]
-    const _Float16 *wdT;    // weight block scales, fp16 [K/32][ldw]
+    const float *wdT;       // weight block scales, float [K/32][ldw]
     int ldw;
     const int8_t *aq;       // quantised activations [R][K]
     const float *adT;       // activation block scales, float [K/32][ldr]
@@ -62,6 +64,7 @@ struct QTileArgs {
     int8_t *q_out;
     float *d_out;
     int ldq;
+    long long *stamps;      // micro-benchmark only: per-phase shader-clock sums of every workgroup's wave 0 (wait + barrier, stage issue, compute, epilogue)
     int dbg;                // micro-benchmark only (profiles/qgemm_bench.hip): 1 = no k loop, 2 = no epilogue stores, 4 = no scaling, 8 = no MFMA
 };
 
@@ -94,19 +97,23 @@ __device__ __forceinline__ int4v quant16_pair(const float (&y)[16], float &d_out
 }
 
 // S: LDS buffers (S - 1 k-tiles in flight); a k-tile is 128 codes = 4 quantisation blocks = one 128-byte line per row.
-// LDS image of a k-tile: [BN rows of W codes | BM rows of activation codes | W scales fp16 [4][BN] | activation scales float [4][BM]].
+// LDS image of a k-tile: [BN rows of W codes | BM rows of activation codes | W scales float [4][BN] | activation scales float [4][BM]].
 // WPE: waves per SIMD the register allocation must allow (the scaling is issue-bound: a wave issues one vector instruction per ~4.6 cycles, the
 // SIMD executes one per ~2.4, so the vector pipe is only full with >= 2, better 4 waves per SIMD — profiles/valu_rate.hip);
 // PIPE: the MFMA of item i + 1 is issued before the scaling of item i and the LDS reads of block b + 1 before the items of block b (two result
 // sets, two operand sets) — for few waves per SIMD; with four the other waves fill those gaps and the registers are worth more.
-template <int BM, int BN, int WM, int WN, int S, int EPI, int WPE = 2, bool PIPE = true>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE > 4 ? WPE : 4))) void qgemm_tile_kernel(QTileArgs qa, TileMap tm) {
-    constexpr int NW = WM * WN;
+// KG: k groups inside the workgroup — wave (kg, wm, wn) takes the blocks b = kg (mod KG) of every k-tile for its 32 x 32 fragments and the groups' sums
+// meet in LDS at the end (in group order): four times the waves for a GEMM with few tiles (N = hidden size at 1024 rows: 256 tiles of 64 x 64)
+// without split-K slabs, i.e. with its epilogue (residual add, the cross-attention fold) still in the launch.
+template <int BM, int BN, int WM, int WN, int S, int EPI, int WPE = 2, bool PIPE = true, bool DBG = false, int KG = 1>
+__global__ __launch_bounds__(WM * WN * KG * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE > 4 ? WPE : 4))) void qgemm_tile_kernel(QTileArgs qa, TileMap tm) {
+    constexpr int NW = WM * WN * KG, NWT = WM * WN;
+    static_assert(KG == 1 || ((KG == 2 || KG == 4) && !PIPE), "k groups");
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;   // 32 x 32 fragments per wave: rows x features
     constexpr int T = MI * NI;
     constexpr int ROWB = 128;
     constexpr int DGROUPS = (BM + BN) / 8;                // 1-KiB pieces of codes: 8 rows each
-    constexpr int WSG = (BN * 8 + 1023) / 1024, ASG = BM / 64;   // 1-KiB pieces of scales (a 64-feature tile's 512 bytes are fetched twice)
+    constexpr int WSG = BN / 64, ASG = BM / 64;           // 1-KiB pieces of scales: [4][BN] / [4][BM] floats
     constexpr int GROUPS = DGROUPS + WSG + ASG;
     constexpr int GPW = (GROUPS + NW - 1) / NW, GPW_MIN = GROUPS / NW;
     constexpr int SW_OFF = (BM + BN) * ROWB, SA_OFF = SW_OFF + WSG * 1024;
@@ -126,11 +133,12 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WP
     const int kz = v / (tm.m_tiles * tm.n_tiles);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int kg = wave / NWT, wt = wave % NWT;
+    const int wm = wt / WN, wn = wt % WN;
     const int r0 = mt * BM, n0 = nt * BN;
     const int kc = a.kchunk ? a.kchunk : a.K;
     const int k0 = kz * kc;
-    const int n_kt = (qa.dbg & 1) ? 0 : kc / 128;
+    const int n_kt = (DBG && (qa.dbg & 1)) ? 0 : kc / 128;
 
     // ---- staging: wave w copies pieces w, w + NW, ... of [W codes | activation codes | W scales | activation scales] ----
     const char *src[GPW];
@@ -155,9 +163,9 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WP
             }
             inc[i] = 128;
         } else if (g < DGROUPS + WSG) {
-            const int o = ((g - DGROUPS) * 512 + lane * 8) % (4 * BN);   // fp16 index inside the [4][BN] image
+            const int o = (g - DGROUPS) * 256 + lane * 4;                // float index inside the [4][BN] image
             src[i] = (const char *) (qa.wdT + (int64_t) ((k0 >> 5) + o / BN) * qa.ldw + n0 + o % BN);
-            inc[i] = 4 * qa.ldw * 2;
+            inc[i] = 4 * qa.ldw * 4;
         } else {
             const int o = (g - DGROUPS - WSG) * 256 + lane * 4;          // float index inside the [4][BM] image
             src[i] = (const char *) (qa.adT + (int64_t) ((k0 >> 5) + o / BM) * qa.ldr + r0 + o % BM);
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WP
     // One k-tile = 4 blocks x T fragments = 4 T "items", each one MFMA followed by its 24 scaling instructions.  The MFMA of item i + 1 is
     // issued before the scaling of item i (two result sets), the LDS reads of block b + 1 before the items of block b (two operand sets): the
     // matrix pipe and the LDS work under the vector pipe's instructions, which are the bound.
-    struct Frag { int4v wf[NI], af[MI]; half8 wd[NI][2]; float ad[MI]; };
+    struct Frag { int4v wf[NI], af[MI]; float4v wd[NI][4]; float ad[MI]; };
     auto load_frag = [&](const char *base, int b, Frag &f) {
         const int coff = ((b * 2 + fh) ^ sw) * 16;
 #pragma unroll
@@ -206,15 +214,15 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WP
         for (int mi = 0; mi < MI; mi++) f.af[mi] = *(const int4v *) (base + aoff[mi] + coff);
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) {
-            const half8 *p = (const half8 *) (base + SW_OFF + (b * BN + wn * (BN / WN) + ni * 32 + 16 * fh) * 2);
-            f.wd[ni][0] = p[0];
-            f.wd[ni][1] = p[1];
+            const float4v *p = (const float4v *) (base + SW_OFF + (b * BN + wn * (BN / WN) + ni * 32 + 16 * fh) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) f.wd[ni][e] = p[e];
         }
 #pragma unroll
         for (int mi = 0; mi < MI; mi++) f.ad[mi] = *(const float *) (base + SA_OFF + (b * BM + wm * (BM / WM) + mi * 32 + fl) * 4);
     };
     auto scale_item = [&](const float16v &zz, const float (&wd)[16], float ad, float (&ac)[16]) {
-        if (qa.dbg & 4) { ac[0] += zz[0] + zz[5] + zz[15] + wd[3] + ad; return; }
+        if (DBG && (qa.dbg & 4)) { ac[0] += zz[0] + zz[5] + zz[15] + wd[3] + ad; return; }
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const float u = wd[e] * ad;                       // exact: two 11-bit significands
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WP
     };
     // 12582912 + block dot when read as floats.  (The whole vector is cast: __builtin_bit_cast(float, z[e]) on an element of an ext-vector
     // lvalue reads element 0 for every e with this compiler.)
-    auto block_dot = [&](const int4v &wf, const int4v &af) { if (qa.dbg & 8) { float16v t = __builtin_bit_cast(float16v, magic); t[0] = __builtin_bit_cast(float, wf[0] ^ af[1]); t[7] = __builtin_bit_cast(float, wf[3] ^ af[2]); return t; } return __builtin_bit_cast(float16v, __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, af, magic, 0, 0, 0)); };
+    auto block_dot = [&](const int4v &wf, const int4v &af) { if (DBG && (qa.dbg & 8)) { float16v t = __builtin_bit_cast(float16v, magic); t[0] = __builtin_bit_cast(float, wf[0] ^ af[1]); t[7] = __builtin_bit_cast(float, wf[3] ^ af[2]); return t; } return __builtin_bit_cast(float16v, __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, af, magic, 0, 0, 0)); };
     auto compute = [&](int buf) {
         const char *base = smem + buf * STAGE;
         if constexpr (PIPE) {
@@ -234,12 +242,13 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WP
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 if (b + 1 < 4) load_frag(base, b + 1, fr[(b + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);   // the reads stay here: their wait then sits in front of the first MFMA of block b + 1, a block of scaling later
                 const Frag &f = fr[b & 1];
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++) {
                     float wd[16];
 #pragma unroll
-                    for (int e = 0; e < 16; e++) wd[e] = (float) f.wd[ni][e >> 3][e & 7];
+                    for (int e = 0; e < 16; e++) wd[e] = f.wd[ni][e >> 2][e & 3];
 #pragma unroll
                     for (int mi = 0; mi < MI; mi++) {
                         const int it = b * T + ni * MI + mi;   // this item; the next one's MFMA goes first
@@ -247,20 +256,23 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WP
                             const int b2 = (it + 1) / T, ni2 = ((it + 1) % T) / MI, mi2 = (it + 1) % MI;
                             z[(it + 1) & 1] = block_dot(fr[b2 & 1].wf[ni2], fr[b2 & 1].af[mi2]);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                         scale_item(z[it & 1], wd, f.ad[mi], acc[ni][mi]);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
         } else {
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
+            for (int bb = 0; bb < 4 / KG; bb++) {
+                const int b = bb * KG + kg;
                 Frag f;
                 load_frag(base, b, f);
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++) {
                     float wd[16];
 #pragma unroll
-                    for (int e = 0; e < 16; e++) wd[e] = (float) f.wd[ni][e >> 3][e & 7];
+                    for (int e = 0; e < 16; e++) wd[e] = f.wd[ni][e >> 2][e & 3];
 #pragma unroll
                     for (int mi = 0; mi < MI; mi++) scale_item(block_dot(f.wf[ni], f.af[mi]), wd, f.ad[mi], acc[ni][mi]);
                 }
@@ -273,17 +285,47 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WP
     for (int t = 0; t < S - 1; t++)
         if (t < n_kt) stage(t, t);
     int cur = 0, nxt = S - 1;
+    long long t_wait = 0, t_stage = 0, t_comp = 0, t0 = DBG && qa.stamps ? (long long) __builtin_amdgcn_s_memtime() : 0;
     for (int kt = 0; kt < n_kt; kt++) {
         if (kt + S - 2 < n_kt) wait_vmcnt<(S - 2) * GPW_MIN>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+        if (DBG && qa.stamps) { const long long t = __builtin_amdgcn_s_memtime(); t_wait += t - t0; t0 = t; }
         if (kt + S - 1 < n_kt) stage(nxt, kt + S - 1);
+        if (DBG && qa.stamps) { const long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t0; t0 = t; }
         compute(cur);
+        if (DBG && qa.stamps) { const long long t = __builtin_amdgcn_s_memtime(); t_comp += t - t0; t0 = t; }
         cur = cur + 1 == S ? 0 : cur + 1;
         nxt = nxt + 1 == S ? 0 : nxt + 1;
     }
+    if (DBG && qa.stamps && tid == 0) { qa.stamps[v * 4 + 0] = t_wait; qa.stamps[v * 4 + 1] = t_stage; qa.stamps[v * 4 + 2] = t_comp; }
 
-    if ((qa.dbg & 2) && acc[0][0][0] != 1.2345f) return;
+    if constexpr (KG > 1) {
+        // the k groups' sums meet in LDS: groups 1 .. KG - 1 write, group 0 adds them in group order
+        __syncthreads();   // every wave is done with the k-tile buffers (and no piece is in flight: the last tile waited for vmcnt(0))
+        float *red = (float *) smem;   // [KG - 1][NWT][T * 16][64]
+        if (kg > 0) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) red[((((kg - 1) * NWT + wt) * T + ni * MI + mi) * 16 + e) * 64 + lane] = acc[ni][mi][e];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int g = 1; g < KG; g++)
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) acc[ni][mi][e] += red[((((g - 1) * NWT + wt) * T + ni * MI + mi) * 16 + e) * 64 + lane];
+        }
+        if (EPI != EPI_CROSS && kg > 0) return;
+    }
+    if (DBG && (qa.dbg & 2) && acc[0][0][0] != 1.2345f) return;
     // ---- epilogue: lane = row rr[mi], features nn[ni] .. nn[ni] + 15 -------------------------------------
     int rr[MI], nn[NI];
 #pragma unroll
@@ -367,16 +409,18 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(WP
         // the tile's 64 features are ONE head's query for BM rows: cross-attention over the voice prompt here (gemm_tile_kernel's EPI_CROSS,
         // parler/model.cpp:586-593), 16 lanes per row with 4 channels each; the attended rows leave as fp32 or as Q8_0 blocks (8 lanes = a block)
         static_assert(BN == 64, "EPI_CROSS: one head per tile column");
-        __syncthreads();
+        __syncthreads();                                   // the k-tile buffers (or the k groups' sums) have been read: the LDS is reused
         float *qs = (float *) smem;                        // [BM][68]
         float *ks = qs + BM * 68, *vs = ks + 32 * 64;      // [E][64] each
         const int E = a.cross_E;
+        if (kg == 0) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++)
+            for (int ni = 0; ni < NI; ni++)
 #pragma unroll
-            for (int mi = 0; mi < MI; mi++)
+                for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) *(float4v *) (qs + (rr[mi] - r0) * 68 + (nn[ni] - n0) + 4 * q) = quad(ni, mi, q);
+                    for (int q = 0; q < 4; q++) *(float4v *) (qs + (rr[mi] - r0) * 68 + (nn[ni] - n0) + 4 * q) = quad(ni, mi, q);
+        }
         for (int i = tid; i < E * 16; i += NW * 64) {
             const int e = i >> 4, c4 = (i & 15) * 4;
             *(float4v *) (ks + e * 64 + c4) = *(const float4v *) (a.cross_k + (int64_t) e * a.H + n0 + c4);

@@ -469,7 +469,7 @@ struct Planner {
             // the same scales transposed for the many-row kernel (qgemm_tile_kernels.h), written by tts_hip_finalize: part of the arena, so that
             // contexts sharing it and ranks receiving it by broadcast hold them too
             w.ldw = (int) ((w.N + 255) & ~(int64_t) 255);
-            w.stoff = alloc((size_t) (w.K / 32) * w.ldw * 2);
+            w.stoff = alloc((size_t) (w.K / 32) * w.ldw * 4);
         }
         return w;
     }

@@ -329,15 +329,13 @@ static bool qtile_ok(const tts_hip_ctx *c, const W &w, const GemmArgs &a, int pr
            a.R <= c->ldr && !a.kchunk && !a.n_parts && (pro != PRO_LN || (a.K <= 2048 && a.K % 32 == 0));
 }
 static void choose_qtile(const tts_hip_ctx *c, int R, int N, int K, bool may_split, int *shape_out, int *ks_out) {
-    // profiles/r06/qgemm_bench_*.txt: the launch is bound by the instruction issue of its waves (48 scaling instructions per MFMA), so the shape that
-    // gives every SIMD four waves wins: 64 x 64 tiles of four waves (wave tile 32 x 32); residual GEMMs (N = hidden size) split K until there are
-    // about four workgroups per CU
-    int shape = 0, ks = 1;
-    if (may_split) {
-        const int tiles = ((R + 63) / 64) * ((N + 63) / 64);
-        while (tiles * ks < 512 && ks < 4 && K % (ks * 2 * 256) == 0 && K / (ks * 2) >= 256) ks *= 2;
-        if (K >= 4096 && K % 1024 == 0) ks = 4;
-    }
+    // profiles/r06/qgemm_bench_*.txt: the launch is bound by the vector instructions its waves issue (48 scaling instructions per MFMA), so the shape that
+    // gives every SIMD about four waves wins: 64 x 64 tiles of four waves (wave tile 32 x 32) when there are at least two tiles per CU; with fewer (N =
+    // hidden size at 1024 rows: 256 tiles) two k groups inside the workgroup (shape 4: eight waves) — the epilogue (residual add, cross-attention fold)
+    // stays in the launch; the K = 4096 residual GEMM (fc2) additionally writes two split-K slabs the next LayerNorm folds
+    const int tiles = ((R + 63) / 64) * ((N + 63) / 64);
+    int shape = tiles >= 512 ? 0 : 4, ks = 1;
+    if (shape == 4 && may_split && K >= 2048 && K % 512 == 0) ks = 2;
     if (c->qtile_shape >= 0 && c->qtile_shape < N_QTILE_SHAPES) shape = c->qtile_shape;
     if (c->qtile_ks > 0 && may_split && K % (c->qtile_ks * 128) == 0) ks = c->qtile_ks;
     *shape_out = shape;
@@ -388,7 +386,7 @@ static int run_qtile(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro
     if (pro != PRO_LN && !have_q) CHK(qtile_quant_rows(c, (const float *) a.A, a.lda, a.K, a.R));
     QTileArgs qa{};
     qa.g = a;
-    qa.wdT = (const _Float16 *) (c->arena + w.stoff);
+    qa.wdT = (const float *) (c->arena + w.stoff);
     qa.ldw = w.ldw;
     qa.aq = in_set ? c->aq2 : c->aq;
     qa.adT = in_set ? c->adT2 : c->adT;
@@ -633,9 +631,10 @@ static int run_attn(tts_hip_ctx *c, int kclass, AttnArgs a, int R, int nsplit, d
         hipLaunchKernelGGL(attn_rows_kernel<8>, dim3(R, nzr), dim3(c->NH * 16), 0, c->stream, a);
         HIPCHK(hipGetLastError());
         if (nzr > 1) {
-            hipLaunchKernelGGL(attn_combine_kernel, dim3(c->NH, R), dim3(64), 0, c->stream, (const float *) a.part, nzr, c->H, c->NH, a.out, a.out16);
+            hipLaunchKernelGGL(attn_combine_kernel, dim3(c->NH, R), dim3(64), 0, c->stream, (const float *) a.part, nzr, c->H, c->NH, a.out, a.out16, a.out_q, a.out_dT, a.ldr);
             HIPCHK(hipGetLastError());
         }
+        if (a.out_q) { c->aqt_src = a.out; c->aqt_set = a.out_q == c->aq2 ? 1 : 0; }   // the out projection finds its input rows as Q8_0 blocks
         return prof_end(c);
     }
     const bool fused = nsplit > 1 && c->attn_fused && c->attn_cnt != nullptr && !defer_combine;
@@ -718,6 +717,10 @@ static int enqueue_forward(tts_hip_ctx *c, int R, bool audio, bool want_logits, 
         at.stamps = stamp_slot();
         // <= 4 rows: the key-split partials are folded by out_proj's workgroups as they load them (one kernel boundary instead of an arrival
         // counter + a dependent read-back inside the attention launch: 9.6 -> 6.3 us per layer at T ~ 1000)
+        // a quantised out projection on the tiled path: the attention writes the Q8_0 blocks of its rows (second set) instead of fp32
+        if (c->qtile_fuse && !c->debug && c->adT && c->qtile_min_rows > 0 && R >= c->qtile_min_rows && y.o.type == TTS_HIP_Q8I && y.o.stoff && (int) y.o.K == H) {
+            at.out_q = c->aq2; at.out_dT = c->adT2; at.ldr = c->ldr;
+        }
         const bool defer = R <= 4 && nsplit > 1 && o_half && c->b1_defer_combine && H <= 2048 && H == c->NH * 64 && (int) y.o.K == H;
         CHK(run_attn(c, TTS_HIP_K_ATTN_SELF, at, R, nsplit, self_kv_bytes, defer));
 

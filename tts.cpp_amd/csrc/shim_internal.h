@@ -56,7 +56,7 @@ struct W {  // a matrix living in the arena
     int64_t K = 0, N = 0;
     bool src_q4 = false;            // every stacked source tensor was Q4_0 in the GGUF
     const uint8_t *q4 = nullptr;    // TTS_HIP_Q4_NATIVE: the 4-bit codes repacked next to the int8 expansion (gemv_q4_rows_kernel)
-    size_t stoff = 0;               // TTS_HIP_Q8I matrices of the Parler decoder: the block scales once more, transposed (fp16 [K/32][ldw]) for qgemm_tile_kernel
+    size_t stoff = 0;               // TTS_HIP_Q8I matrices of the Parler decoder: the block scales once more, transposed (float [K/32][ldw]) for qgemm_tile_kernel
     int ldw = 0;
 };
 
