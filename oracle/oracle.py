@@ -410,15 +410,18 @@ class T5Oracle:
 
 class DacOracle:
     def __init__(self, model, f16_conv=None):
-        """f16_conv: None = follow the GGUF (F16 conv kernels -> ggml's fp16 im2col semantics), or force 0/1"""
+        """f16_conv: None = follow the GGUF (F16 conv kernels -> ggml's fp16 im2col semantics), or force 0 / 1; 2 = an F32 model read the way upstream
+        ggml_conv_1d would (F16 im2col: the inputs and the kernels of the plain convs rounded to fp16, transposed convs exact fp32)"""
         self.L = lib()
         cfg = model.cfg
         self.cfg = cfg
         self.keep = []
         t = model.by_name
 
-        def f(name):
+        def f(name, round16=False):
             a = np.ascontiguousarray(t[name].to_f32().reshape(-1))
+            if round16 and f16_conv == 2:
+                a = np.ascontiguousarray(a.astype(np.float16).astype(np.float32))   # mul_mat converts src1 (the kernel) to the F16 im2col's type
             self.keep.append(a)
             return f32p(a)
 
@@ -426,9 +429,9 @@ class DacOracle:
         m.n_codebooks, m.codebook_dim, m.codebook_size, m.latent = cfg.n_out, cfg.cb_dim, cfg.cb_size, cfg.latent
         for i in range(cfg.n_out):
             p = f"audio_encoder.quantizers.{i}."
-            m.codebook[i], m.out_proj_w[i], m.out_proj_b[i] = f(p + "codebook.weight"), f(p + "out_proj.weight"), f(p + "out_proj.bias")
+            m.codebook[i], m.out_proj_w[i], m.out_proj_b[i] = f(p + "codebook.weight"), f(p + "out_proj.weight", True), f(p + "out_proj.bias")
         m.c0 = cfg.c0
-        m.init_w, m.init_b = f("audio_encoder.initial.weight"), f("audio_encoder.initial.bias")
+        m.init_w, m.init_b = f("audio_encoder.initial.weight", True), f("audio_encoder.initial.bias")
         m.n_blocks = len(cfg.strides)
         c = cfg.c0
         for bi, (s, pd) in enumerate(zip(cfg.strides, cfg.paddings)):
@@ -439,13 +442,13 @@ class DacOracle:
             for r in range(3):
                 q = p + f"residual_unit.{r}.res."
                 rr = b.res[r]
-                rr.in_alpha, rr.in_w, rr.in_b = f(q + "initial.alpha"), f(q + "initial.weight"), f(q + "initial.bias")
-                rr.out_alpha, rr.out_w, rr.out_b = f(q + "final.alpha"), f(q + "final.weight"), f(q + "final.bias")
+                rr.in_alpha, rr.in_w, rr.in_b = f(q + "initial.alpha"), f(q + "initial.weight", True), f(q + "initial.bias")
+                rr.out_alpha, rr.out_w, rr.out_b = f(q + "final.alpha"), f(q + "final.weight", True), f(q + "final.bias")
             c //= 2
-        m.final_alpha, m.final_w, m.final_b = f("audio_encoder.final.alpha"), f("audio_encoder.final.weight"), f("audio_encoder.final.bias")
+        m.final_alpha, m.final_w, m.final_b = f("audio_encoder.final.alpha"), f("audio_encoder.final.weight", True), f("audio_encoder.final.bias")
         if f16_conv is None:
             f16_conv = all(x.type == 1 for n, x in t.items() if n.startswith("audio_encoder.") and n.endswith(".weight") and ".in_proj" not in n and len(x.ne) == 3)
-        m.f16_conv = 1 if f16_conv else 0
+        m.f16_conv = int(f16_conv) if f16_conv in (0, 1, 2) else (1 if f16_conv else 0)
         self.m = m
 
     def stage_shape(self, stage, frames):
@@ -494,7 +497,7 @@ class SnacOracle:
         for i, r in enumerate(cfg.repeats):
             m.repeats[i] = r
             p = f"quantizers.{i}."
-            m.codebook[i], m.out_proj_w[i], m.out_proj_b[i] = f(p + "codebook.weight"), f(p + "out_proj.weight"), f(p + "out_proj.bias")
+            m.codebook[i], m.out_proj_w[i], m.out_proj_b[i] = f(p + "codebook.weight"), f(p + "out_proj.weight", True), f(p + "out_proj.bias")
         m.in_w, m.in_b, m.c0, m.up_w, m.up_b = f("in.weight"), f("in.bias"), cfg.c0, f("up.weight"), f("up.bias")
         m.n_blocks = len(cfg.strides)
         c = cfg.c0
@@ -506,8 +509,8 @@ class SnacOracle:
             for r in range(3):
                 q = p + f"residual_unit.{r}.res."
                 rr = b.res[r]
-                rr.in_alpha, rr.in_w, rr.in_b = f(q + "initial.alpha"), f(q + "initial.weight"), f(q + "initial.bias")
-                rr.out_alpha, rr.out_w, rr.out_b = f(q + "final.alpha"), f(q + "final.weight"), f(q + "final.bias")
+                rr.in_alpha, rr.in_w, rr.in_b = f(q + "initial.alpha"), f(q + "initial.weight", True), f(q + "initial.bias")
+                rr.out_alpha, rr.out_w, rr.out_b = f(q + "final.alpha"), f(q + "final.weight", True), f(q + "final.bias")
             c //= 2
         m.final_alpha, m.final_w, m.final_b = f("alpha_out"), f("final.weight"), f("final.bias")
         self.m = m

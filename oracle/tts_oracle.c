@@ -834,7 +834,13 @@ static void round_buf_f16(float *x, size_t n) {
 int64_t orc_dac_decode(const orc_dac_model *m, const uint32_t *codes, int frames, float *pcm_out,
                        int stage, float *stage_out) {
     int64_t L = frames;
-    const int h = m->f16_conv;
+    /* f16_conv 0: exact fp32 (F32 codec tensors as this repository reads them); 1: F16 codec tensors — ggml_conv_1d's im2col is F16 and
+     * conv_transpose_1d_f16_f32 converts its source, so every conv input is rounded to fp16; 2: the OTHER reading of an F32 model — upstream
+     * ggml_conv_1d always builds an F16 im2col (general_neural_audio_codec.cpp:142,146, dac_model.cpp:158,164) and mul_mat then converts the
+     * F32 kernel (src1) to the im2col's type: conv inputs AND conv kernels rounded to fp16 (the caller passes kernels already rounded), while
+     * ggml_conv_transpose_1d with an F32 kernel stays exact fp32 (ht = 0) */
+    const int h = m->f16_conv != 0;
+    const int ht = m->f16_conv == 1;
     int C = m->latent;
     /* quantizer: dac_build_audio_inputs (dac_model.cpp:100-123) + build_quantize_layer
      * (general_neural_audio_codec.cpp:166-172): sum_i (out_proj_i * codebook_i[tok] + bias_i) */
@@ -868,7 +874,7 @@ int64_t orc_dac_decode(const orc_dac_model *m, const uint32_t *codes, int frames
         const int K = 2 * b->stride;
         const int64_t L2 = (L - 1) * b->stride - 2 * (int64_t) b->padding + K;
         nxt = (float *) malloc((size_t) b->cout * L2 * 4);
-        if (h) round_buf_f16(cur, (size_t) C * L);
+        if (ht) round_buf_f16(cur, (size_t) C * L);
         orc_conv_transpose1d(cur, C, L, b->w, b->b, b->cout, K, b->stride, b->padding, nxt);
         free(cur); cur = nxt; C = b->cout; L = L2;
         float *t1 = (float *) malloc((size_t) C * L * 4);

@@ -520,6 +520,63 @@ def test_reference_cli_and_perf_battery_build_unchanged_against_the_overlay(tmp_
     assert "libtts.so" in ldd and "ggml" not in ldd
 
 
+def test_reference_server_builds_unchanged_against_the_overlay_and_serves_a_wav(tmp_path):
+    """north_star: "drops in under the existing CLI/server".  The reference's OWN examples/server/server.cpp (with its vendored httplib.h / json.hpp),
+    compiled from where it lies against compat/ (common.h, loaders.h, ggml.h = timers + GGML_ASSERT, util.h = the string helpers server.cpp:809-821
+    uses) and the page header its CMake generates from public/index.html (make_overlay.py writes it the way cmake/xxd.cmake does), linked to libtts.so,
+    started on the weightless backend; POST /v1/audio/speech must come back as a RIFF / WAVE body."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    import time
+    import urllib.request
+    sys.path.insert(0, os.path.join(ROOT, "compat"))
+    from make_overlay import make_overlay
+    ovl = make_overlay(REFERENCE, str(tmp_path / "ovl"))
+    assert os.path.realpath(os.path.join(ovl, "examples/server/server.cpp")) == os.path.join(REFERENCE, "examples/server/server.cpp")
+    host = os.path.join(ROOT, "tts.cpp_amd", "host")
+    link = ["-L", host, "-ltts", "-L", os.path.join(ROOT, "tts.cpp_amd"), "-ltts_hip", f"-Wl,-rpath,{host}",
+            f"-Wl,-rpath,{os.path.join(ROOT, 'tts.cpp_amd')}", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+    # server.cpp:5 includes the C++20 header <format>; g++ 11 has none: compat/shims/format stands in ONLY then (a toolchain with <format> never sees it)
+    probe = subprocess.run(["g++", "-std=c++20", "-x", "c++", "-fsyntax-only", "-"], input="#include <format>\nint main(){}\n", capture_output=True, text=True)
+    shim = [] if probe.returncode == 0 else ["-I", os.path.join(ROOT, "compat", "shims")]
+    cc = subprocess.run(["g++", "-std=c++20", "-O1", "-I", "include", "-I", "examples/server", *shim, "examples/server/server.cpp", "src/args.cpp", "-o", "tts-server", *link],
+                        cwd=ovl, capture_output=True, text=True, timeout=900)
+    assert cc.returncode == 0, cc.stderr[-4000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    srv = subprocess.Popen(["./tts-server", "--model-path", "test:dummy", "--port", str(port)], cwd=ovl, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        base = f"http://127.0.0.1:{port}"
+        for _ in range(100):
+            try:
+                if json.loads(urllib.request.urlopen(base + "/health", timeout=2).read())["status"] == "ok":
+                    break
+            except OSError:
+                time.sleep(0.1)
+        else:
+            raise AssertionError("the server never answered /health")
+        req = urllib.request.Request(base + "/v1/audio/speech", data=json.dumps({"input": "Hi"}).encode(), headers={"Content-Type": "application/json"})
+        r = urllib.request.urlopen(req, timeout=60)
+        body = r.read()
+        assert r.status == 200 and r.headers.get("Content-Type") == "audio/wav"
+        assert body[:4] == b"RIFF" and body[8:12] == b"WAVE" and len(body) > 44 + 2 * 44100   # "Hi": 2 s of audio from the weightless runner
+        models = json.loads(urllib.request.urlopen(base + "/v1/models", timeout=5).read())
+        assert models["data"] and models["data"][0]["object"] == "model"
+        page = urllib.request.urlopen(base + "/", timeout=5).read()
+        assert page == open(os.path.join(REFERENCE, "examples/server/public/index.html"), "rb").read()   # the generated page header round-trips
+    finally:
+        srv.terminate()
+        try:
+            srv.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            srv.kill()
+    ldd = subprocess.run(["ldd", os.path.join(ovl, "tts-server")], capture_output=True, text=True).stdout
+    assert "libtts.so" in ldd and "ggml" not in ldd
+
+
 def test_gguf_reader_survives_damaged_files(tiny_gguf, tmp_path):
     """Truncations at every structural boundary region and random byte flips in the metadata: the mmap reader (host/gguf.cpp) must
     answer with an error or a consistent parse, never read outside the mapping (run in a child process so that a crash is a failure,

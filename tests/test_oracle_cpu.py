@@ -607,3 +607,26 @@ def test_accumulators_as_b_fragments_restatement():
         out[32 * i2:32 * i2 + 32] = D
     ref = w2.astype(np.float64) @ s1.astype(np.float64)
     assert np.abs(out - ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("dims", ["tiny", "dac44k"])
+def test_fp16_im2col_reading_of_an_f32_codec_model(dims):
+    """upstream ggml_conv_1d always goes through an F16 im2col (general_neural_audio_codec.cpp:142,146, dac_model.cpp:158,164), so
+    an F32 codec model can be read two ways: exact fp32 (what the HIP path and oracle reading 0 do) or with the inputs and kernels of the plain convs
+    rounded to fp16 (oracle reading 2; transposed convs with an F32 kernel stay exact).  The fork's ggml is absent, so which one it does is unknowable here;
+    this test puts the NUMBER on it: max |PCM(0) - PCM(2)| on the same model and codes, at tiny and at DAC-44k dims (DESIGN.md parity table)."""
+    if dims == "tiny":
+        model = synth.build(synth.tiny(weight_type=gguf.F32))
+        frames = 12
+    else:
+        model = synth.build(synth.tiny(weight_type=gguf.F32, n_out=9, latent=1024, cb_size=1024, c0=1536, strides=(8, 8, 4, 2), layers=1))
+        frames = 6
+    cfg = model.cfg
+    codes = np.random.default_rng(11).integers(0, cfg.cb_size, (frames, cfg.n_out)).astype(np.uint32)
+    exact = orc.DacOracle(model, f16_conv=0).decode(codes)
+    im2col16 = orc.DacOracle(model, f16_conv=2).decode(codes)
+    d = float(np.abs(exact - im2col16).max())
+    rms = float(np.sqrt(np.mean((exact - im2col16) ** 2)))
+    print(f"{dims}: max |PCM(fp32 reading) - PCM(fp16-im2col reading)| = {d:.3e} (rms {rms:.3e}), max |PCM| = {np.abs(exact).max():.3f}")
+    assert d > 1e-6          # the two readings are different functions ...
+    assert d < 5e-3, d       # ... about an fp16 rounding per conv apart: the bound DESIGN.md quotes
