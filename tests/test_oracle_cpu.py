@@ -518,6 +518,50 @@ def test_bf16x3_split_is_fp32_accurate():
     assert e_b3 < 2e-6 and e_b3 < 2 * e_f32, (e_b3, e_f32)
 
 
+def test_fp16_hi_lo_split_three_products_is_near_fp32_accurate():
+    """The arithmetic of the codec's default since round 6 (csrc/dac_kernels.h SplitH2): an fp32 operand as h = fp16(x), l = fp16(x - h) — x - h is exact
+    in fp32 and, for small x, an fp16 SUBNORMAL that v_mfma_f32_32x32x16_f16 multiplies exactly (profiles/mfma_denorm.hip) —, three products
+    h h' + h l' + l h' (each exact in fp32), fp32 accumulation per 16-deep MFMA step.  The operand is represented to 2^-22 relative (or 2^-25 absolute),
+    the dropped l l' term is 2^-22 of a product; the sum's error stays that of an fp32 accumulation (VERDICT r5 item 2's decision rule: ~2^-22 per
+    product).  fp16's exponent range ends at 2^-14 (2^-24 subnormal), so an operand below 0.25 keeps 2^-25 ABSOLUTE rather than 2^-22 relative: weights
+    of the codec's magnitude (0.05) and activations around 1 — the case the kernels meet — and, as the stress case, both spread over five decades."""
+    rng = np.random.default_rng(0)
+    K = 7 * 192
+    A = (rng.standard_normal((64, K)) * 0.05).astype(np.float32)
+    B = rng.standard_normal((K, 128)).astype(np.float32)
+    As = (A * 10.0 ** rng.uniform(-4, 0, A.shape)).astype(np.float32)
+    Bs = (B * 10.0 ** rng.uniform(-4, 1, B.shape)).astype(np.float32)
+
+    def split(x):
+        h = x.astype(np.float16)
+        l = (x - h.astype(np.float32)).astype(np.float16)
+        return h, l
+    (sh, sl), (th, tl) = split(As), split(Bs)
+    assert (np.abs(sl[np.abs(As) < 1e-3]) < 2.0 ** -14).any() and (sl != 0).any()   # fp16 subnormals are exercised
+    stress = np.abs(sum(a.astype(np.float64) @ b.astype(np.float64) for a, b in [(sl, th), (sh, tl), (sh, th)]) - As.astype(np.float64) @ Bs.astype(np.float64)).max()
+    e_stress = stress / np.abs(As.astype(np.float64) @ Bs.astype(np.float64)).max()
+    assert e_stress < 3e-6, e_stress         # five decades of operand magnitudes: still below the stage bar of the GPU tests (1e-5)
+    (ah, al), (bh, bl) = split(A), split(B)
+    rep = np.abs((ah.astype(np.float64) + al.astype(np.float64)) - A).max() / np.abs(A).max()
+    assert rep < 2.0 ** -21
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    terms = [(al, bh), (ah, bl), (ah, bh)]   # smallest first, as SplitH2::ta / tb
+    exact3 = sum(a.astype(np.float64) @ b.astype(np.float64) for a, b in terms)
+    e3 = np.abs(exact3 - ref).max() / np.abs(ref).max()
+    assert e3 < 4e-7, e3                     # the three terms alone
+    acc = np.zeros((64, 128), np.float32)
+    chain = np.zeros((64, 128), np.float32)
+    for k in range(0, K, 16):
+        for a, b in terms:      # one 32x32x16 f16 MFMA each: exact products, fp32 accumulate
+            acc = acc + (a[:, k:k + 16].astype(np.float64) @ b[k:k + 16].astype(np.float64)).astype(np.float32)
+    for k in range(0, K, 2):    # the 32x32x2 fp32 MFMA chain of conv1d_mfma_kernel
+        chain = chain + (A[:, k:k + 2].astype(np.float64) @ B[k:k + 2].astype(np.float64)).astype(np.float32)
+    e_h2 = np.abs(acc - ref).max() / np.abs(ref).max()
+    e_f32 = np.abs(chain - ref).max() / np.abs(ref).max()
+    print(f"three-term representation {e3:.2e} (operands over five decades: {e_stress:.2e}); accumulated: fp16 hi+lo {e_h2:.2e}, exact-fp32 chain {e_f32:.2e}")
+    assert e_h2 < 2e-6 and e_h2 < 3 * e_f32 + 3e-7, (e_h2, e_f32)
+
+
 def test_bf16x3_conv_layout_restatement():
     """Index arithmetic of conv1d_mfma_b3_kernel / pack_conv_w_b3_kernel restated in numpy: packed weight image
     [chunk][plane][s][hi][co][8], input image [plane][position][8], half-wave hi takes tap 2s + hi (the eighth tap has

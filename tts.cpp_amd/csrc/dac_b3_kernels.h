@@ -353,12 +353,14 @@ __global__ __launch_bounds__(512, 2) void resunit_b3_kernel(ResUnitArgs a) {
 struct SplitArgs {
     const float *x;          // [n][C][L]
     const float *alpha;      // [C] snake before the split, or NULL
-    __bf16 *yp;              // [n][3][C/8][L][8]
+    __bf16 *yp;              // [n][NPL][C/8][L][8]
     int C, L;
     const uint32_t *frames; int mult;
 };
 
-static __global__ __launch_bounds__(256) void snake_split_kernel(SplitArgs a) {
+template <typename SP = SplitB3>
+__global__ __launch_bounds__(256) void snake_split_kernel(SplitArgs a) {
+    constexpr int NPL = SP::NPL;
     const int t = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, z = blockIdx.z;
     const int LS = a.L, L = valid_len(a.frames, a.mult, a.L);
     if (t >= L) return;
@@ -376,24 +378,24 @@ static __global__ __launch_bounds__(256) void snake_split_kernel(SplitArgs a) {
         for (int e = 0; e < 8; e++) ral[e] = 1.0f / al[e];
         snake_vec<8>(v, al, ral);
     }
-    bf16x8d h1, h2, h3;
+    bf16x8d hp[NPL];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-        __bf16 b1, b2, b3;
-        split_bf16x3(v[e], b1, b2, b3);
-        h1[e] = b1; h2[e] = b2; h3[e] = b3;
+        __bf16 pv[NPL];
+        SP::split(v[e], pv);
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++) hp[pl][e] = pv[pl];
     }
     const int64_t pst = (int64_t) CG * LS * 8;
-    __bf16 *yp = a.yp + (int64_t) z * 3 * pst + ((int64_t) cg * LS + t) * 8;
-    *(bf16x8d *) yp = h1;
-    *(bf16x8d *) (yp + pst) = h2;
-    *(bf16x8d *) (yp + 2 * pst) = h3;
+    __bf16 *yp = a.yp + (int64_t) z * NPL * pst + ((int64_t) cg * LS + t) * 8;
+#pragma unroll
+    for (int pl = 0; pl < NPL; pl++) *(bf16x8d *) (yp + pl * pst) = hp[pl];
 }
 
 //   src [cout][cin][KT] -> dst [co_tile][chunk][plane][s < NS][hi][CO_T][8]
 //   KT = 7, NS = 4: ci = 8 chunk + j, tap = 2 s + hi (tap 7: zero);   KT = 7, NS = 7: ci = 16 chunk + 8 hi + j, tap = s;
 //   KT = 1: ci = 16 NS chunk + 8 (2 s + hi) + j
-static __global__ void pack_conv_w_b3p_kernel(const float *src, __bf16 *dst, int cout, int cin, int KT, int CO_T, int NS, int n_chunks) {
+static __global__ void pack_conv_w_b3p_kernel(const float *src, __bf16 *dst, int cout, int cin, int KT, int CO_T, int NS, int n_chunks, int scheme = 0) {
     const int64_t plane_sz = (int64_t) NS * 2 * CO_T * 8;
     const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * plane_sz;
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
@@ -411,12 +413,8 @@ static __global__ void pack_conv_w_b3p_kernel(const float *src, __bf16 *dst, int
         else { ci = ch * 16 * NS + 8 * (2 * st + hi) + j; tap = 0; }
         float v = 0.0f;
         if (co < cout && ci < cin && tap < KT) v = src[((int64_t) co * cin + ci) * KT + tap];
-        __bf16 h1, h2, h3;
-        split_bf16x3(v, h1, h2, h3);
-        const int64_t base = ((int64_t) ct * n_chunks + ch) * 3 * plane_sz + (i % plane_sz);
-        dst[base] = h1;
-        dst[base + plane_sz] = h2;
-        dst[base + 2 * plane_sz] = h3;
+        const int64_t base = ((int64_t) ct * n_chunks + ch) * split_planes(scheme) * plane_sz + (i % plane_sz);
+        split_store(scheme, v, dst, base, plane_sz);
     }
 }
 
@@ -466,21 +464,22 @@ struct PConvArgs {
 // 16 channels where the NS = 4 form (chunk = 8 channels, half-wave = tap parity) spends 8 with the eighth tap slot on zero weights.
 // NB = 1: one LDS buffer, the next chunk waits in registers and is committed between two barriers; with two workgroups per CU the other one
 // computes meanwhile (NB = 2: the next chunk is committed into the other buffer while the workgroup's own waves still compute).
-template <int KT, int MI, int NI, int WM, int WN, int NS, int MINW, int NB = 2>
+template <int KT, int MI, int NI, int WM, int WN, int NS, int MINW, int NB = 2, typename SP = SplitB3>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs a) {
+    constexpr int NPL = SP::NPL;
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, NT = 64 * WM * WN;
     constexpr bool TAPK = KT == 7 && NS == 7;
     constexpr int NCG = KT == 7 ? (TAPK ? 2 : 1) : 2 * NS;   // 8-channel groups per chunk
     constexpr int WPL = NS * 2 * CO_T * 8;                   // bf16 per weight plane of a chunk
-    constexpr int WV = (3 * WPL / 8 + NT - 1) / NT;          // 16-byte vectors per thread per chunk (all planes)
+    constexpr int WV = (NPL * WPL / 8 + NT - 1) / NT;        // 16-byte vectors per thread per chunk (all planes)
     constexpr int XP = (T_T + (KT - 1) * 9 + NT - 1) / NT;   // position rows per thread per (plane, group), dilation <= 9
     static_assert(KT == 1 || NS == 4 || NS == 7, "k = 7: four k-steps (tap pairs) per 8-channel chunk, or seven (taps) per 16-channel chunk");
     static_assert(NB == 1 || NB == 2, "LDS buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int xw = T_T + (KT - 1) * a.dil;
-    const int xsz = 3 * NCG * xw * 8;                        // bf16 per input chunk image [plane][group][position][8]
-    __bf16 *wsb = (__bf16 *) smem;                           // [NB][3][WPL]
-    __bf16 *xsb = wsb + NB * 3 * WPL;                        // [NB][xsz]
+    const int xsz = NPL * NCG * xw * 8;                      // 16-bit values per input chunk image [plane][group][position][8]
+    __bf16 *wsb = (__bf16 *) smem;                           // [NB][NPL][WPL]
+    __bf16 *xsb = wsb + NB * NPL * WPL;                      // [NB][xsz]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -492,8 +491,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
     const int LS = a.L, L = valid_len_z(a.frames, a.mult, a.L, tile.z);
     if (t0 >= L) return;
     const int64_t psti = (int64_t) CGI * LS * 8;             // bf16 per input plane
-    const __bf16 *xg = a.xp + (int64_t) tile.z * 3 * psti;
-    const uint4d *wg = (const uint4d *) (a.w + (int64_t) tile.co * n_chunks * 3 * WPL);
+    const __bf16 *xg = a.xp + (int64_t) tile.z * NPL * psti;
+    const uint4d *wg = (const uint4d *) (a.w + (int64_t) tile.co * n_chunks * NPL * WPL);
 
     float16d acc[MI][NI];
 #pragma unroll
@@ -504,13 +503,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
     uint4d wreg[WV];
-    uint4d xreg[3 * NCG * XP];
+    uint4d xreg[NPL * NCG * XP];
     auto prefetch = [&](int c) __attribute__((always_inline)) {
-        const uint4d *wp = wg + (int64_t) c * (3 * WPL / 8);
+        const uint4d *wp = wg + (int64_t) c * (NPL * WPL / 8);
 #pragma unroll
         for (int j = 0; j < WV; j++) {
             const int i = tid + j * NT;
-            if (i < 3 * WPL / 8) wreg[j] = wp[i];
+            if (i < NPL * WPL / 8) wreg[j] = wp[i];
         }
 #pragma unroll
         for (int q = 0; q < XP; q++) {
@@ -518,20 +517,20 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
             const int t = t0 + p - a.pad;
             const bool ok = p < xw && t >= 0 && t < L;
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++)
+            for (int pl = 0; pl < NPL; pl++)
 #pragma unroll
                 for (int g = 0; g < NCG; g++) {
                     const uint4d zero = {0u, 0u, 0u, 0u};
-                    xreg[(q * 3 + pl) * NCG + g] = ok ? *(const uint4d *) (xg + pl * psti + ((int64_t) (c * NCG + g) * LS + t) * 8) : zero;
+                    xreg[(q * NPL + pl) * NCG + g] = ok ? *(const uint4d *) (xg + pl * psti + ((int64_t) (c * NCG + g) * LS + t) * 8) : zero;
                 }
         }
     };
     auto commit = [&](int buf) __attribute__((always_inline)) {
-        uint4d *wd = (uint4d *) (wsb + buf * 3 * WPL);
+        uint4d *wd = (uint4d *) (wsb + buf * NPL * WPL);
 #pragma unroll
         for (int j = 0; j < WV; j++) {
             const int i = tid + j * NT;
-            if (i < 3 * WPL / 8) wd[i] = wreg[j];
+            if (i < NPL * WPL / 8) wd[i] = wreg[j];
         }
         __bf16 *xd = xsb + buf * xsz;
 #pragma unroll
@@ -539,9 +538,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
             const int p = tid + q * NT;
             if (p < xw) {
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
+                for (int pl = 0; pl < NPL; pl++)
 #pragma unroll
-                    for (int g = 0; g < NCG; g++) *(uint4d *) (xd + ((pl * NCG + g) * xw + p) * 8) = xreg[(q * 3 + pl) * NCG + g];
+                    for (int g = 0; g < NCG; g++) *(uint4d *) (xd + ((pl * NCG + g) * xw + p) * 8) = xreg[(q * NPL + pl) * NCG + g];
             }
         }
     };
@@ -552,7 +551,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
     for (int c = 0; c < n_chunks; c++) {
         const int buf = NB == 2 ? (c & 1) : 0;
         if (c + 1 < n_chunks) prefetch(c + 1);
-        const __bf16 *ws = wsb + buf * 3 * WPL;
+        const __bf16 *ws = wsb + buf * NPL * WPL;
         const __bf16 *xs = xsb + buf * xsz;
 #pragma unroll
         for (int st = 0; st < NS; st++) {
@@ -565,9 +564,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
             } else {
                 xoff = (2 * st + hi) * xw * 8;
             }
-            bf16x8d af[3][MI], bf[3][NI];
+            bf16x8d af[NPL][MI], bf[NPL][NI];
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
+            for (int pl = 0; pl < NPL; pl++) {
 #pragma unroll
                 for (int i = 0; i < MI; i++)
                     af[pl][i] = *(const bf16x8d *) (ws + pl * WPL + (((st * 2 + hi) * CO_T) + (wm * MI + i) * 32 + l31) * 8);
@@ -575,14 +574,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
                 for (int j = 0; j < NI; j++)
                     bf[pl][j] = *(const bf16x8d *) (xs + pl * NCG * xw * 8 + xoff + ((wn * NI + j) * 32 + l31) * 8);
             }
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int tm = 0; tm < 6; tm++)
+            for (int tm = 0; tm < SP::NT; tm++)
 #pragma unroll
                 for (int i = 0; i < MI; i++)
 #pragma unroll
                     for (int j = 0; j < NI; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[tm]][i], bf[TB[tm]][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = SP::mfma(af[SP::ta(tm)][i], bf[SP::tb(tm)][j], acc[i][j]);
         }
         if constexpr (NB == 2) {
             if (c + 1 < n_chunks) commit(buf ^ 1);
@@ -599,7 +597,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
     const float *rg = a.resid ? a.resid + (int64_t) tile.z * a.cout * LS : nullptr;
     float *yg = a.y ? a.y + (int64_t) tile.z * a.cout * LS : nullptr;
     const int64_t psto = (int64_t) (a.cout / 8) * LS * 8;
-    __bf16 *ypz = a.yp ? a.yp + (int64_t) tile.z * 3 * psto : nullptr;
+    __bf16 *ypz = a.yp ? a.yp + (int64_t) tile.z * NPL * psto : nullptr;
     // Epilogue in phases per (row tile, quad of 4 channels): every load of the phase is issued before anything waits (bias / alpha as one
     // 16-byte load each, the NI x 4 residual values with clamped indices), then the arithmetic for all lanes, then predicated stores.  The
     // per-value form — `if (t < L)`, `if (resid)`, `if (alpha)` around single loads — compiled to load, s_waitcnt vmcnt(0), store per value:
@@ -648,18 +646,18 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
                         for (int r = 0; r < 4; r++) if (!ok) v[r] = 0.0f;   // lanes outside the tensor must not drag the wave into the slow sine
                         snake_vec<4>(v, al, ral);
                     }
-                    bf16x4d h1, h2, h3;
+                    bf16x4d hp[NPL];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        __bf16 b1, b2, b3;
-                        split_bf16x3(v[r], b1, b2, b3);
-                        h1[r] = b1; h2[r] = b2; h3[r] = b3;
+                        __bf16 pv[NPL];
+                        SP::split(v[r], pv);
+#pragma unroll
+                        for (int pl = 0; pl < NPL; pl++) hp[pl][r] = pv[pl];
                     }
                     if (ok) {
                         __bf16 *p = ypz + ((int64_t) (co >> 3) * LS + t) * 8 + (co & 7);   // co is a multiple of 4: the lower or upper half of a 16-byte row
-                        *(bf16x4d *) p = h1;
-                        *(bf16x4d *) (p + psto) = h2;
-                        *(bf16x4d *) (p + 2 * psto) = h3;
+#pragma unroll
+                        for (int pl = 0; pl < NPL; pl++) *(bf16x4d *) (p + pl * psto) = hp[pl];
                     }
                 }
             }
@@ -674,7 +672,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void conv_b3p_kernel(PConvArgs 
 // The fp32 input is staged once per workgroup and chunk: snake (snake_vec) + split -> LDS planes [plane][group][ti0 - 1 + r][8].
 //   pack_convt_w_b3_kernel   src [cin][cout][2 S] -> dst [co_tile][chunk][plane][ks < 2][ph < S][hi][CO_T][8]  (ci = 16 chunk + 8 ks + j, k = ph + hi S)
 // ================================================================================================================================
-static __global__ void pack_convt_w_b3_kernel(const float *src, __bf16 *dst, int cout, int cin, int S, int CO_T, int n_chunks) {
+static __global__ void pack_convt_w_b3_kernel(const float *src, __bf16 *dst, int cout, int cin, int S, int CO_T, int n_chunks, int scheme = 0) {
     const int64_t plane_sz = (int64_t) 2 * S * 2 * CO_T * 8;
     const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * plane_sz;
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x) {
@@ -689,30 +687,27 @@ static __global__ void pack_convt_w_b3_kernel(const float *src, __bf16 *dst, int
         const int co = ct * CO_T + col, ci = ch * 16 + ks * 8 + j, k = ph + hi * S;
         float v = 0.0f;
         if (co < cout && ci < cin) v = src[((int64_t) ci * cout + co) * 2 * S + k];
-        __bf16 h1, h2, h3;
-        split_bf16x3(v, h1, h2, h3);
-        const int64_t base = ((int64_t) ct * n_chunks + ch) * 3 * plane_sz + (i % plane_sz);
-        dst[base] = h1;
-        dst[base + plane_sz] = h2;
-        dst[base + 2 * plane_sz] = h3;
+        const int64_t base = ((int64_t) ct * n_chunks + ch) * split_planes(scheme) * plane_sz + (i % plane_sz);
+        split_store(scheme, v, dst, base, plane_sz);
     }
 }
 
 // PLANES: the input arrives as split planes written by its producer (snake with this layer's alpha and the bf16 x 3 split done ONCE per element);
 // the fp32 form snakes and splits the staged tile in every workgroup — 24 / 12 times per element for the stride-8 layers (cout / 32 channel
 // tiles), about as many VALU cycles per chunk as half the MFMAs of the chunk (0.40 of the bf16 peak where the k = 7 families reach 0.53).
-template <int S, int MI, bool PLANES = false>
+template <int S, int MI, bool PLANES = false, typename SP = SplitB3>
 __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
+    constexpr int NPL = SP::NPL;
     constexpr int CO_T = 32 * MI, WN = 8, TI_T = 32 * WN, NT = 64 * WN, K2 = 2 * S;
     constexpr int WPL = 2 * S * 2 * CO_T * 8;                // bf16 per weight plane of a chunk
-    constexpr int WV = (3 * WPL / 8 + NT - 1) / NT;          // 16-byte vectors per thread per chunk
+    constexpr int WV = (NPL * WPL / 8 + NT - 1) / NT;        // 16-byte vectors per thread per chunk
     constexpr int xw = TI_T + 1;                             // rows ti0 - 1 .. ti0 + TI_T - 1
     constexpr int XR = (2 * xw + NT - 1) / NT;               // (group, row) units per thread per chunk
     constexpr int xpl = 2 * xw * 8;                          // bf16 per input plane of a chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __bf16 *wsb = (__bf16 *) smem;                           // [2][3][WPL]
-    __bf16 *xsb = wsb + 2 * 3 * WPL;                         // [2][3][xpl]
-    float2 *tin = (float2 *) (xsb + 2 * 3 * xpl);            // [cin] {alpha, 1 / alpha}
+    __bf16 *wsb = (__bf16 *) smem;                           // [2][NPL][WPL]
+    __bf16 *xsb = wsb + 2 * NPL * WPL;                       // [2][NPL][xpl]
+    float2 *tin = (float2 *) (xsb + 2 * NPL * xpl);          // [cin] {alpha, 1 / alpha}
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const TileId tile = xcd_tile(a.npos, a.nco, a.nz);
@@ -724,9 +719,9 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
     if (ti0 > L) return;  // ti runs 0..L inclusive
     const float *xg = a.x + (int64_t) tile.z * a.cin * LS;
     const int64_t psti = (int64_t) (a.cin / 8) * LS * 8;     // bf16 per input plane
-    const __bf16 *xpg = PLANES ? a.xp + (int64_t) tile.z * 3 * psti : nullptr;
+    const __bf16 *xpg = PLANES ? a.xp + (int64_t) tile.z * NPL * psti : nullptr;
     float *yg = a.y + (int64_t) tile.z * a.cout * LoS;
-    const uint4d *wg = (const uint4d *) ((const __bf16 *) a.w + (int64_t) tile.co * n_chunks * 3 * WPL);
+    const uint4d *wg = (const uint4d *) ((const __bf16 *) a.w + (int64_t) tile.co * n_chunks * NPL * WPL);
 
     if (!PLANES) {
         for (int i = tid; i < a.cin; i += NT) {
@@ -745,13 +740,13 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
 
     uint4d wreg[WV];
     float xreg[PLANES ? 1 : XR][8];
-    uint4d xpreg[PLANES ? XR : 1][3];
+    uint4d xpreg[PLANES ? XR : 1][NPL];
     auto prefetch = [&](int c) __attribute__((always_inline)) {
-        const uint4d *wp = wg + (int64_t) c * (3 * WPL / 8);
+        const uint4d *wp = wg + (int64_t) c * (NPL * WPL / 8);
 #pragma unroll
         for (int j = 0; j < WV; j++) {
             const int i = tid + j * NT;
-            if (i < 3 * WPL / 8) wreg[j] = wp[i];
+            if (i < NPL * WPL / 8) wreg[j] = wp[i];
         }
 #pragma unroll
         for (int q = 0; q < XR; q++) {
@@ -762,7 +757,7 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
             if constexpr (PLANES) {
                 const uint4d zero = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
+                for (int pl = 0; pl < NPL; pl++)
                     xpreg[q][pl] = ok ? *(const uint4d *) (xpg + pl * psti + ((int64_t) (c * 2 + g) * LS + ti) * 8) : zero;
             } else {
 #pragma unroll
@@ -771,13 +766,13 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
         }
     };
     auto commit = [&](int c, int buf) __attribute__((always_inline)) {
-        uint4d *wd = (uint4d *) (wsb + buf * 3 * WPL);
+        uint4d *wd = (uint4d *) (wsb + buf * NPL * WPL);
 #pragma unroll
         for (int j = 0; j < WV; j++) {
             const int i = tid + j * NT;
-            if (i < 3 * WPL / 8) wd[i] = wreg[j];
+            if (i < NPL * WPL / 8) wd[i] = wreg[j];
         }
-        __bf16 *xd = xsb + buf * 3 * xpl;
+        __bf16 *xd = xsb + buf * NPL * xpl;
 #pragma unroll
         for (int q = 0; q < XR; q++) {
             const int u = tid + q * NT;
@@ -785,9 +780,8 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
             if constexpr (PLANES) {
                 if (g < 2) {
                     __bf16 *p = xd + (g * xw + r) * 8;
-                    *(uint4d *) p = xpreg[q][0];
-                    *(uint4d *) (p + xpl) = xpreg[q][1];
-                    *(uint4d *) (p + 2 * xpl) = xpreg[q][2];
+#pragma unroll
+                    for (int pl = 0; pl < NPL; pl++) *(uint4d *) (p + pl * xpl) = xpreg[q][pl];
                 }
             } else if (g < 2) {
                 if (a.alpha) {
@@ -796,17 +790,17 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
                     for (int e = 0; e < 8; e++) { const float2 t2 = tin[c * 16 + g * 8 + e]; al[e] = t2.x; ral[e] = t2.y; }
                     snake_vec<8>(xreg[q], al, ral);          // snake(0) == 0: zero padding is preserved
                 }
-                bf16x8d h1, h2, h3;
+                bf16x8d hp[NPL];
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    __bf16 b1, b2, b3;
-                    split_bf16x3(xreg[q][e], b1, b2, b3);
-                    h1[e] = b1; h2[e] = b2; h3[e] = b3;
+                    __bf16 pv[NPL];
+                    SP::split(xreg[q][e], pv);
+#pragma unroll
+                    for (int pl = 0; pl < NPL; pl++) hp[pl][e] = pv[pl];
                 }
                 __bf16 *p = xd + (g * xw + r) * 8;
-                *(bf16x8d *) p = h1;
-                *(bf16x8d *) (p + xpl) = h2;
-                *(bf16x8d *) (p + 2 * xpl) = h3;
+#pragma unroll
+                for (int pl = 0; pl < NPL; pl++) *(bf16x8d *) (p + pl * xpl) = hp[pl];
             }
         }
     };
@@ -818,27 +812,26 @@ __global__ __launch_bounds__(512, 2) void convt_b3_kernel(ConvTArgs a) {
     for (int c = 0; c < n_chunks; c++) {
         const int buf = c & 1;
         if (c + 1 < n_chunks) prefetch(c + 1);
-        const __bf16 *ws = wsb + buf * 3 * WPL;
-        const __bf16 *xs = xsb + buf * 3 * xpl;
+        const __bf16 *ws = wsb + buf * NPL * WPL;
+        const __bf16 *xs = xsb + buf * NPL * xpl;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            bf16x8d bf[3];
+            bf16x8d bf[NPL];
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) bf[pl] = *(const bf16x8d *) (xs + pl * xpl + (ks * xw + wn * 32 + l31 + 1 - hi) * 8);
+            for (int pl = 0; pl < NPL; pl++) bf[pl] = *(const bf16x8d *) (xs + pl * xpl + (ks * xw + wn * 32 + l31 + 1 - hi) * 8);
 #pragma unroll
             for (int ph = 0; ph < S; ph++) {
-                bf16x8d af[MI][3];
+                bf16x8d af[MI][NPL];
 #pragma unroll
                 for (int i = 0; i < MI; i++)
 #pragma unroll
-                    for (int pl = 0; pl < 3; pl++)
+                    for (int pl = 0; pl < NPL; pl++)
                         af[i][pl] = *(const bf16x8d *) (ws + pl * WPL + ((((ks * S + ph) * 2 + hi) * CO_T) + i * 32 + l31) * 8);
-                constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int tm = 0; tm < 6; tm++)
+                for (int tm = 0; tm < SP::NT; tm++)
 #pragma unroll
                     for (int i = 0; i < MI; i++)
-                        acc[i][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[tm]], bf[TB[tm]], acc[i][ph], 0, 0, 0);
+                        acc[i][ph] = SP::mfma(af[i][SP::ta(tm)], bf[SP::tb(tm)], acc[i][ph]);
             }
         }
         if (c + 1 < n_chunks) commit(c + 1, buf ^ 1);
@@ -905,9 +898,9 @@ template <int MI> struct ResT7 {
     static constexpr int MAXCNT = MI == 3 ? 4 : 2;
 };
 
-static __global__ void pack_resunit_t7_kernel(const float *w7, const float *w1, __bf16 *dst, int C, int KS2) {
+static __global__ void pack_resunit_t7_kernel(const float *w7, const float *w1, __bf16 *dst, int C, int KS2, int scheme = 0) {
     const int MI = C / 32, SPC = MI == 3 ? 2 : 4, MAXCNT = MI == 3 ? 4 : 2;
-    const int64_t WST = (int64_t) 3 * MAXCNT * 2 * C * 8;
+    const int64_t WST = (int64_t) split_planes(scheme) * MAXCNT * 2 * C * 8;
     const int n7 = (C / 16) * SPC, ns1 = (C / 16) / KS2, n1 = (C / 96) * ns1;
     const int64_t per1 = (int64_t) KS2 * 2 * 96 * 8;
     // k = 7 part: one thread per (stage, slot s < MAXCNT, hi, co, j); slots beyond the stage's k-step count are skipped
@@ -944,30 +937,28 @@ static __global__ void pack_resunit_t7_kernel(const float *w7, const float *w1, 
             plane_sz = per1;
             base = (int64_t) (n7 + st) * WST + (i1 % per1);
         }
-        __bf16 h1, h2, h3;
-        split_bf16x3(v, h1, h2, h3);
-        dst[base] = h1;
-        dst[base + plane_sz] = h2;
-        dst[base + 2 * plane_sz] = h3;
+        split_store(scheme, v, dst, base, plane_sz);
     }
 }
 
-template <int MI, int KS2>
+// SP: the operand split (dac_kernels.h: SplitB3 = bf16 x 3 / six products, SplitH2 = fp16 hi + lo / three products, SplitH1 = fp16 / one product)
+template <int MI, int KS2, typename SP = SplitB3>
 __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
+    constexpr int NPL = SP::NPL;
     using G = ResT7<MI>;
     constexpr int C = 32 * MI, WN = 8, NT = 512, T_T = 32 * WN;
     constexpr int SPC = G::SPC, NCH = C / 16, N7 = NCH * SPC;
     constexpr int WPL1 = KS2 * 2 * 96 * 8;
-    constexpr int WST = 3 * G::MAXCNT * 2 * C * 8;            // bf16 per stage (stream stride and LDS buffer) >= 3 * WPL1
+    constexpr int WST = NPL * G::MAXCNT * 2 * C * 8;          // 16-bit values per stage (stream stride and LDS buffer) >= NPL * WPL1
     constexpr int NP = MI / 3, NS1 = (C / 16) / KS2, N1 = NP * NS1;
     constexpr int WV = (WST / 8 + NT - 1) / NT;               // 16-byte vectors per thread per stage
-    static_assert(3 * WPL1 <= WST && (C / 16) % KS2 == 0 && MI % 3 == 0, "stage shapes");
+    static_assert(NPL * WPL1 <= WST && (C / 16) % KS2 == 0 && MI % 3 == 0, "stage shapes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int xw = T_T + 6 * a.dil;
     const int xpl = 2 * xw * 8;                               // bf16 per input plane of a chunk: [group 2][position][8]
     __bf16 *wsb = (__bf16 *) smem;                            // [2][WST]
-    __bf16 *xsb = wsb + 2 * WST;                              // [2][3][xpl]
-    float4 *tab = (float4 *) (xsb + 2 * 3 * xpl);             // [C] {b7, alpha_mid, 1/alpha_mid, b1}
+    __bf16 *xsb = wsb + 2 * WST;                              // [2][NPL][xpl]
+    float4 *tab = (float4 *) (xsb + 2 * NPL * xpl);             // [C] {b7, alpha_mid, 1/alpha_mid, b1}
     float2 *tin = (float2 *) (tab + C);                       // [C] {alpha_in, 1/alpha_in}
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -1029,17 +1020,17 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; e++) { const float2 t2 = tin[c * 16 + g * 8 + e]; al[e] = t2.x; ral[e] = t2.y; }
                 snake_vec<8>(xreg[q], al, ral);               // snake(0) == 0: zero padding is preserved
-                bf16x8d h1, h2, h3;
+                bf16x8d hp[NPL];
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    __bf16 b1, b2, b3;
-                    split_bf16x3(xreg[q][e], b1, b2, b3);
-                    h1[e] = b1; h2[e] = b2; h3[e] = b3;
+                    __bf16 pv[NPL];
+                    SP::split(xreg[q][e], pv);
+#pragma unroll
+                    for (int pl = 0; pl < NPL; pl++) hp[pl][e] = pv[pl];
                 }
-                __bf16 *xd = xsb + buf * 3 * xpl + u * 8;     // u = g * xw + p: the [group][position] order of the image
-                *(bf16x8d *) xd = h1;
-                *(bf16x8d *) (xd + xpl) = h2;
-                *(bf16x8d *) (xd + 2 * xpl) = h3;
+                __bf16 *xd = xsb + buf * NPL * xpl + u * 8;   // u = g * xw + p: the [group][position] order of the image
+#pragma unroll
+                for (int pl = 0; pl < NPL; pl++) *(bf16x8d *) (xd + pl * xpl) = hp[pl];
             }
         }
     };
@@ -1052,10 +1043,8 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
     __syncthreads();
 
     // ---- k = 7 conv: NCH chunks of 16 input channels, SPC stages each -----------------------------------------------------------------
-    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};   // the six partial products, smallest first; term-major over the
-                                                                            // three accumulators: consecutive MFMAs write different registers
     for (int c = 0; c < NCH; c++) {
-        const __bf16 *xs = xsb + (c & 1) * 3 * xpl;
+        const __bf16 *xs = xsb + (c & 1) * NPL * xpl;
         static_for<SPC>([&](auto SUB) __attribute__((always_inline)) {
             constexpr int sub = decltype(SUB)::value, CNT = G::cnt(sub), FIRST = G::first(sub), WPL7 = CNT * 2 * C * 8;
             const int g = c * SPC + sub;
@@ -1064,22 +1053,22 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
             const __bf16 *ws = wsb + (g & 1) * WST;
             static_for<CNT>([&](auto S) __attribute__((always_inline)) {
                 constexpr int s = decltype(S)::value;
-                bf16x8d bf[3];
+                bf16x8d bf[NPL];
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) bf[pl] = *(const bf16x8d *) (xs + pl * xpl + (hi * xw + wn * 32 + l31 + (FIRST + s) * a.dil) * 8);
+                for (int pl = 0; pl < NPL; pl++) bf[pl] = *(const bf16x8d *) (xs + pl * xpl + (hi * xw + wn * 32 + l31 + (FIRST + s) * a.dil) * 8);
 #pragma unroll
                 for (int ig = 0; ig < MI; ig += 3) {
-                    bf16x8d af[3][3];
+                    bf16x8d af[3][NPL];
 #pragma unroll
                     for (int ii = 0; ii < 3; ii++)
 #pragma unroll
-                        for (int pl = 0; pl < 3; pl++)
+                        for (int pl = 0; pl < NPL; pl++)
                             af[ii][pl] = *(const bf16x8d *) (ws + pl * WPL7 + (((s * 2 + hi) * C) + (ig + ii) * 32 + l31) * 8);
 #pragma unroll
-                    for (int tm = 0; tm < 6; tm++)
+                    for (int tm = 0; tm < SP::NT; tm++)
 #pragma unroll
                         for (int ii = 0; ii < 3; ii++)
-                            acc[ig + ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ii][TA[tm]], bf[TB[tm]], acc[ig + ii], 0, 0, 0);
+                            acc[ig + ii] = SP::mfma(af[ii][SP::ta(tm)], bf[SP::tb(tm)], acc[ig + ii]);
                 }
             });
             commit_w((g + 1) & 1);
@@ -1103,7 +1092,7 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
         const __bf16 *ws = wsb + ((N7 + g2) & 1) * WST;
         static_for<KS2>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value, ks = q * KS2 + s, ib = ks / 2, qq = ks % 2;
-            bf16x8d bf[3];
+            bf16x8d bf[NPL];
             float hv[8], al[8], ral[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) {
@@ -1115,21 +1104,22 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
             snake_vec<8>(hv, al, ral);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                __bf16 b1, b2, b3;
-                split_bf16x3(hv[m], b1, b2, b3);
-                bf[0][m] = b1; bf[1][m] = b2; bf[2][m] = b3;
+                __bf16 pv[NPL];
+                SP::split(hv[m], pv);
+#pragma unroll
+                for (int pl = 0; pl < NPL; pl++) bf[pl][m] = pv[pl];
             }
-            bf16x8d af[3][3];
+            bf16x8d af[3][NPL];
 #pragma unroll
             for (int ii = 0; ii < 3; ii++)
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
+                for (int pl = 0; pl < NPL; pl++)
                     af[ii][pl] = *(const bf16x8d *) (ws + pl * WPL1 + (((s * 2 + hi) * 96) + ii * 32 + l31) * 8);
 #pragma unroll
-            for (int tm = 0; tm < 6; tm++)
+            for (int tm = 0; tm < SP::NT; tm++)
 #pragma unroll
                 for (int ii = 0; ii < 3; ii++)
-                    acc2[ii] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ii][TA[tm]], bf[TB[tm]], acc2[ii], 0, 0, 0);
+                    acc2[ii] = SP::mfma(af[ii][SP::ta(tm)], bf[SP::tb(tm)], acc2[ii]);
         });
         if constexpr (g2 + 1 < N1) {
             commit_w((N7 + g2 + 1) & 1);

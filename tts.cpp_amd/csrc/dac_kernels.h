@@ -1065,6 +1065,57 @@ __device__ __forceinline__ void split_bf16x3(float x, __bf16 &h1, __bf16 &h2, __
     h3 = (__bf16) (r1 - (float) h2);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Operand splits of the codec's MFMA convolutions (dac_b3_kernels.h): how an fp32 operand is carried as 16-bit planes and which
+// partial products are formed.  The 16-bit planes are stored as __bf16 containers whatever the scheme (16-byte rows are copied untyped).
+//   SplitB3  x = b1 + b2 + b3 exactly, bf16 terms; six partial products of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16 (rounds 3 - 5)
+//   SplitH2  x = h + l, fp16 terms: h = fp16(x), l = fp16(x - h) (x - h is exact in fp32 and at most 2^-11 |x|; below 2^-14 it is an fp16
+//            SUBNORMAL, which v_mfma_f32_32x32x16_f16 multiplies exactly — profiles/mfma_denorm.hip); three partial products
+//            h h' + h l' + l h' (fp16 x fp16 is exact in fp32), the dropped l l' and the split remainders are <= 2^-22 of a product:
+//            half the matrix instructions of SplitB3 for ~4 x its (fp32-level) error (tests/test_oracle_cpu.py)
+//   SplitH1  x ~ fp16(x): one plane, one product — F16 codec tensors (ggml's fp16 im2col x fp16 kernel: exact products, the reference's
+//            own arithmetic for `quantize --convert-dac-to-f16`)
+// ------------------------------------------------------------------------------------------------------------------------------------
+typedef _Float16 half8d __attribute__((ext_vector_type(8)));
+struct SplitB3 {
+    static constexpr int NPL = 3, NT = 6, ID = 0;
+    // the six partial products, smallest first; term-major over the accumulators: consecutive MFMAs write different registers
+    static __host__ __device__ constexpr int ta(int tm) { return tm == 0 ? 2 : tm == 1 ? 0 : tm == 2 ? 1 : tm == 3 ? 1 : 0; }
+    static __host__ __device__ constexpr int tb(int tm) { return tm == 0 ? 0 : tm == 1 ? 2 : tm == 2 ? 1 : tm == 3 ? 0 : tm == 4 ? 1 : 0; }
+    static __device__ __forceinline__ void split(float x, __bf16 (&p)[3]) { split_bf16x3(x, p[0], p[1], p[2]); }
+    static __device__ __forceinline__ float16d mfma(bf16x8d a, bf16x8d b, float16d c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+struct SplitH2 {
+    static constexpr int NPL = 2, NT = 3, ID = 1;
+    static __host__ __device__ constexpr int ta(int tm) { return tm == 0 ? 1 : 0; }   // l h', h l', h h'
+    static __host__ __device__ constexpr int tb(int tm) { return tm == 1 ? 1 : 0; }
+    static __device__ __forceinline__ void split(float x, __bf16 (&p)[2]) {
+        const _Float16 h = (_Float16) __builtin_fminf(__builtin_fmaxf(x, -65504.0f), 65504.0f);   // beyond fp16's range the high part saturates instead of becoming inf - inf
+        const _Float16 l = (_Float16) (x - (float) h);
+        p[0] = __builtin_bit_cast(__bf16, h);
+        p[1] = __builtin_bit_cast(__bf16, l);
+    }
+    static __device__ __forceinline__ float16d mfma(bf16x8d a, bf16x8d b, float16d c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8d, a), __builtin_bit_cast(half8d, b), c, 0, 0, 0);
+    }
+};
+struct SplitH1 {
+    static constexpr int NPL = 1, NT = 1, ID = 2;
+    static __host__ __device__ constexpr int ta(int) { return 0; }
+    static __host__ __device__ constexpr int tb(int) { return 0; }
+    static __device__ __forceinline__ void split(float x, __bf16 (&p)[1]) { p[0] = __builtin_bit_cast(__bf16, (_Float16) x); }
+    static __device__ __forceinline__ float16d mfma(bf16x8d a, bf16x8d b, float16d c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8d, a), __builtin_bit_cast(half8d, b), c, 0, 0, 0);
+    }
+};
+// a value into its planes at dst[base + pl * plane_sz] (weight packers: the scheme is a run-time argument there)
+__device__ __forceinline__ void split_store(int scheme, float v, __bf16 *dst, int64_t base, int64_t plane_sz) {
+    if (scheme == 0) { __bf16 p[3]; SplitB3::split(v, p); dst[base] = p[0]; dst[base + plane_sz] = p[1]; dst[base + 2 * plane_sz] = p[2]; }
+    else if (scheme == 1) { __bf16 p[2]; SplitH2::split(v, p); dst[base] = p[0]; dst[base + plane_sz] = p[1]; }
+    else { __bf16 p[1]; SplitH1::split(v, p); dst[base] = p[0]; }
+}
+__host__ __device__ inline int split_planes(int scheme) { return scheme == 0 ? 3 : scheme == 1 ? 2 : 1; }
+
 //   conv1d  src [cout][cin][7]  ->  dst [co_tile][chunk][plane][s][hi][CO_T][8]   (ci = chunk*8 + j, tap = 2s + hi, tap 7 = 0)
 static __global__ void pack_conv_w_b3_kernel(const float *src, __bf16 *dst, int cout, int cin, int CO_T, int n_chunks, int KT = 7) {
     const int NST = (KT + 1) / 2;                                                     // k-steps per chunk: tap pairs (an odd tap count leaves one zero slot)

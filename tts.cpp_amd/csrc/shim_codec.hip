@@ -76,6 +76,8 @@ static int pack_one16(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT, i
     c->packed16[w_off] = dst;
     return 0;
 }
+// operand split of the plane kernels (dac_kernels.h): 0 = bf16 x 3 / six products, 1 = fp16 hi + lo / three products (F32 tensors), 2 = fp16 / one product (F16 tensors)
+static int dac_scheme(const tts_hip_ctx *c) { return c->dac_f16 ? 2 : (c->dac_split ? 1 : 0); }
 static int pack_one_b3(tts_hip_ctx *c, size_t w_off, int cout, int cin, int CO_T, int KT = 7) {   // 64- or 96-channel tiles, 8 input channels per chunk, tap pairs
     const int n_chunks = (cin + 7) / 8;
     const size_t n = (size_t) ((cout + CO_T - 1) / CO_T) * n_chunks * 3 * (2 * ((KT + 1) / 2)) * CO_T * 8;
@@ -98,11 +100,11 @@ static int pack_resunit(tts_hip_ctx *c, const DRes &r, int C) {
     __bf16 *dst = nullptr;
     if (c->dac_tap7) {   // resunit_t7_kernel: one tap per k-step, stages of {4, 3} / {2, 2, 2, 1} k-steps per 16-channel chunk
         const int MI = C / 32, SPC = MI == 3 ? 2 : 4, MAXCNT = MI == 3 ? 4 : 2;
-        const size_t WST = (size_t) 3 * MAXCNT * 2 * C * 8;
+        const size_t WST = (size_t) split_planes(dac_scheme(c)) * MAXCNT * 2 * C * 8;
         const size_t n = (size_t) ((C / 16) * SPC + (C / 96) * ((C / 16) / KS2) + 1) * WST;
         HIPCHK(hipMalloc((void **) &dst, n * 2));
         HIPCHK(hipMemsetAsync(dst, 0, n * 2, c->stream));
-        hipLaunchKernelGGL(pack_resunit_t7_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + r.in_w), (const float *) (c->arena + r.out_w), dst, C, KS2);
+        hipLaunchKernelGGL(pack_resunit_t7_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + r.in_w), (const float *) (c->arena + r.out_w), dst, C, KS2, dac_scheme(c));
     } else {
         const ResUnitGeom g = resunit_geom(C, KS, KS2);
         const size_t n = (size_t) (g.n7 + g.n1 + 1) * g.WST;   // + 1: the prefetch of the stage after the last one stays inside the buffer
@@ -122,7 +124,7 @@ static int convt_b3_tile(int cout, int cin, int s) {
     if (s == 2 && cout % 96 == 0) return 96;
     return 0;
 }
-static bool convt_b3_fits(int cout, int cin, int s) {   // the kernel's LDS request (weight stages + input planes + alpha) inside a CU's 160 KB
+static bool convt_b3_fits(int cout, int cin, int s) {   // the kernel's LDS request (weight stages + input planes + alpha) inside a CU's 160 KB (three planes: the largest scheme)
     const int t = convt_b3_tile(cout, cin, s);
     return t && (size_t) 6 * (2 * s * 2 * t * 8) * 2 + 6 * 2 * 257 * 8 * 2 + (size_t) cin * 8 <= 160 * 1024;
 }
@@ -130,10 +132,10 @@ static int pack_convt_b3(tts_hip_ctx *c, const DBlock &b) {
     const int CO_T = convt_b3_tile(b.cout, b.cin, b.stride);
     if (!CO_T) return 0;
     const int n_chunks = b.cin / 16;
-    const size_t n = (size_t) (b.cout / CO_T) * n_chunks * 3 * 2 * b.stride * 2 * CO_T * 8;
+    const size_t n = (size_t) (b.cout / CO_T) * n_chunks * split_planes(dac_scheme(c)) * 2 * b.stride * 2 * CO_T * 8;
     __bf16 *dst = nullptr;
     HIPCHK(hipMalloc((void **) &dst, n * 2));
-    hipLaunchKernelGGL(pack_convt_w_b3_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + b.w), dst, b.cout, b.cin, b.stride, CO_T, n_chunks);
+    hipLaunchKernelGGL(pack_convt_w_b3_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + b.w), dst, b.cout, b.cin, b.stride, CO_T, n_chunks, dac_scheme(c));
     HIPCHK(hipGetLastError());
     c->packed_ct[b.w] = dst;
     return 0;
@@ -148,10 +150,10 @@ static int pack_planes(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT) 
     const bool tapk = KT == 7 && c->dac_tap7 && cin % 16 == 0;
     const int CO_T = KT == 7 ? 64 : (cout % 256 == 0 ? 256 : 128), NS = KT == 7 ? (tapk ? 7 : 4) : 1;
     const int n_chunks = KT == 7 && !tapk ? cin / 8 : cin / 16;
-    const size_t n = (size_t) (cout / CO_T) * n_chunks * 3 * NS * 2 * CO_T * 8;
+    const size_t n = (size_t) (cout / CO_T) * n_chunks * split_planes(dac_scheme(c)) * NS * 2 * CO_T * 8;
     __bf16 *dst = nullptr;
     HIPCHK(hipMalloc((void **) &dst, n * 2));
-    hipLaunchKernelGGL(pack_conv_w_b3p_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + w_off), dst, cout, cin, KT, CO_T, NS, n_chunks);
+    hipLaunchKernelGGL(pack_conv_w_b3p_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + w_off), dst, cout, cin, KT, CO_T, NS, n_chunks, dac_scheme(c));
     HIPCHK(hipGetLastError());
     c->packed_p[w_off] = dst;
     return 0;
@@ -387,32 +389,37 @@ static int launch_convt_mfma(tts_hip_ctx *c, const ConvTArgs &a_in, int nz) {
     return 0;
 }
 
-template <int S, int MI, bool PL>
+template <int S, int MI, bool PL, typename SP>
 static int launch_convt_b3_t(tts_hip_ctx *c, const ConvTArgs &a, int nz) {
     constexpr int CO_T = 32 * MI, WPL = 2 * S * 2 * CO_T * 8, xpl = 2 * 257 * 8;
-    const size_t lds = (size_t) 6 * WPL * 2 + (size_t) 6 * xpl * 2 + (size_t) a.cin * 8;
+    const size_t lds = (size_t) 2 * SP::NPL * WPL * 2 + (size_t) 2 * SP::NPL * xpl * 2 + (size_t) a.cin * 8;
     if (lds > 160 * 1024) return set_err("convt_b3: %d input channels need %zu bytes of LDS", a.cin, lds);
     static std::atomic<uint64_t> attr{0};
     if (attr_needed(attr, c->device)) {
-        HIPCHK(hipFuncSetAttribute((const void *) convt_b3_kernel<S, MI, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) convt_b3_kernel<S, MI, PL, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     ConvTArgs b = a;
     b.npos = (a.L + 1 + 255) / 256; b.nz = nz;   // ti runs 0..L inclusive
     b.nco = xcd_order(a.cout / CO_T, (double) a.cin * a.L * nz * 4, (double) a.cout * a.cin * 2 * S * 6);
-    hipLaunchKernelGGL((convt_b3_kernel<S, MI, PL>), dim3(xcd_grid(b.npos, a.cout / CO_T, b.nz)), dim3(512), lds, c->stream, b);
+    hipLaunchKernelGGL((convt_b3_kernel<S, MI, PL, SP>), dim3(xcd_grid(b.npos, a.cout / CO_T, b.nz)), dim3(512), lds, c->stream, b);
     HIPCHK(hipGetLastError());
     return 0;
 }
+template <int S, int MI, typename SP>
+static int launch_convt_b3_s(tts_hip_ctx *c, const ConvTArgs &a, int nz) {
+    return a.xp ? launch_convt_b3_t<S, MI, true, SP>(c, a, nz) : launch_convt_b3_t<S, MI, false, SP>(c, a, nz);
+}
 template <int S, int MI>
 static int launch_convt_b3(tts_hip_ctx *c, const ConvTArgs &a, int nz) {
-    return a.xp ? launch_convt_b3_t<S, MI, true>(c, a, nz) : launch_convt_b3_t<S, MI, false>(c, a, nz);
+    const int sc = dac_scheme(c);
+    return sc == 0 ? launch_convt_b3_s<S, MI, SplitB3>(c, a, nz) : sc == 1 ? launch_convt_b3_s<S, MI, SplitH2>(c, a, nz) : launch_convt_b3_s<S, MI, SplitH1>(c, a, nz);
 }
 
 static int launch_convt(tts_hip_ctx *c, ConvTArgs ta, size_t w_off, int nz) {
     const bool valu = (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) != 0;
     const int s = ta.stride;
     auto pct = c->packed_ct.find(w_off);
-    if (!valu && !c->dac_f16 && c->dac_convt_b3 && pct != c->packed_ct.end()) {
+    if (!valu && c->dac_convt_b3 && pct != c->packed_ct.end()) {
         ta.w = (const float *) pct->second;
         ta.x_f16 = 0;
         if (s == 8) return launch_convt_b3<8, 1>(c, ta, nz);
@@ -451,25 +458,35 @@ static int launch_split(tts_hip_ctx *c, const DacBatch &bt, const float *x, int 
     a.x = x; a.alpha = has_alpha ? (const float *) (c->arena + alpha) : nullptr; a.yp = yp; a.C = C; a.L = LS; a.frames = bt.frames; a.mult = bt.mult;
     const double Lv = bt.tot_frames * bt.mult;
     CHK(prof_begin(c, TTS_HIP_K_DAC_CONV1, (double) C * Lv * 10, 0));
-    hipLaunchKernelGGL(snake_split_kernel, dim3((LS + 255) / 256, C / 8, bt.n), dim3(256), 0, c->stream, a);
+    const int sc = dac_scheme(c);
+    if (sc == 0) hipLaunchKernelGGL(snake_split_kernel<SplitB3>, dim3((LS + 255) / 256, C / 8, bt.n), dim3(256), 0, c->stream, a);
+    else if (sc == 1) hipLaunchKernelGGL(snake_split_kernel<SplitH2>, dim3((LS + 255) / 256, C / 8, bt.n), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(snake_split_kernel<SplitH1>, dim3((LS + 255) / 256, C / 8, bt.n), dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     return prof_end(c);
 }
-template <int KT, int MI, int NI, int WM, int WN, int NS, int MINW, int NB = 2>
-static int launch_conv_b3p_t(tts_hip_ctx *c, const PConvArgs &a, int nz) {
+template <int KT, int MI, int NI, int WM, int WN, int NS, int MINW, int NB, typename SP>
+static int launch_conv_b3p_s(tts_hip_ctx *c, const PConvArgs &a, int nz) {
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WPL = NS * 2 * CO_T * 8, NCG = KT == 7 ? (NS == 7 ? 2 : 1) : 2 * NS;
     const int xw = T_T + (KT - 1) * a.dil;
-    const size_t lds = (size_t) NB * (3 * WPL * 2 + (size_t) 3 * NCG * xw * 8 * 2);
+    const size_t lds = (size_t) NB * (SP::NPL * WPL * 2 + (size_t) SP::NPL * NCG * xw * 8 * 2);
     static std::atomic<uint64_t> attr{0};
     if (attr_needed(attr, c->device)) {
-        HIPCHK(hipFuncSetAttribute((const void *) conv_b3p_kernel<KT, MI, NI, WM, WN, NS, MINW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) conv_b3p_kernel<KT, MI, NI, WM, WN, NS, MINW, NB, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     PConvArgs b = a;
     b.npos = (a.L + T_T - 1) / T_T; b.nz = nz;
     b.nco = xcd_order(a.cout / CO_T, (double) a.cin * a.L * nz * 6, (double) a.cout * a.cin * KT * 6);
-    hipLaunchKernelGGL((conv_b3p_kernel<KT, MI, NI, WM, WN, NS, MINW, NB>), dim3(xcd_grid(b.npos, a.cout / CO_T, b.nz)), dim3(64 * WM * WN), lds, c->stream, b);
+    hipLaunchKernelGGL((conv_b3p_kernel<KT, MI, NI, WM, WN, NS, MINW, NB, SP>), dim3(xcd_grid(b.npos, a.cout / CO_T, b.nz)), dim3(64 * WM * WN), lds, c->stream, b);
     HIPCHK(hipGetLastError());
     return 0;
+}
+template <int KT, int MI, int NI, int WM, int WN, int NS, int MINW, int NB = 2>
+static int launch_conv_b3p_t(tts_hip_ctx *c, const PConvArgs &a, int nz) {
+    const int sc = dac_scheme(c);
+    if (sc == 0) return launch_conv_b3p_s<KT, MI, NI, WM, WN, NS, MINW, NB, SplitB3>(c, a, nz);
+    if (sc == 1) return launch_conv_b3p_s<KT, MI, NI, WM, WN, NS, MINW, NB, SplitH2>(c, a, nz);
+    return launch_conv_b3p_s<KT, MI, NI, WM, WN, NS, MINW, NB, SplitH1>(c, a, nz);
 }
 // conv on planes: y (fp32, may be NULL) and / or yp (planes with the consumer's snake, may be NULL)
 static int launch_conv_planes(tts_hip_ctx *c, const DacBatch &bt, const __bf16 *xp, int cin, int LS, size_t w, size_t b, int cout, int K, int dil, const float *resid,
@@ -510,19 +527,24 @@ static int launch_resunit_t(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
     HIPCHK(hipGetLastError());
     return 0;
 }
-template <int MI, int KS2>
-static int launch_resunit_t7(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
+template <int MI, int KS2, typename SP>
+static int launch_resunit_t7_s(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
     constexpr int C = 32 * MI;
     const int xw = 256 + 6 * a.dil;
-    const size_t WST = (size_t) 3 * ResT7<MI>::MAXCNT * 2 * C * 8;
-    const size_t lds = 2 * WST * 2 + (size_t) 6 * 2 * xw * 8 * 2 + (size_t) C * 24;
+    const size_t WST = (size_t) SP::NPL * ResT7<MI>::MAXCNT * 2 * C * 8;
+    const size_t lds = 2 * WST * 2 + (size_t) 2 * SP::NPL * 2 * xw * 8 * 2 + (size_t) C * 24;
     static std::atomic<uint64_t> attr{0};
     if (attr_needed(attr, c->device)) {
-        HIPCHK(hipFuncSetAttribute((const void *) resunit_t7_kernel<MI, KS2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) resunit_t7_kernel<MI, KS2, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    hipLaunchKernelGGL((resunit_t7_kernel<MI, KS2>), dim3((a.L + 255) / 256, 1, nz), dim3(512), lds, c->stream, a);
+    hipLaunchKernelGGL((resunit_t7_kernel<MI, KS2, SP>), dim3((a.L + 255) / 256, 1, nz), dim3(512), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
+}
+template <int MI, int KS2>
+static int launch_resunit_t7(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
+    const int sc = dac_scheme(c);
+    return sc == 0 ? launch_resunit_t7_s<MI, KS2, SplitB3>(c, a, nz) : sc == 1 ? launch_resunit_t7_s<MI, KS2, SplitH2>(c, a, nz) : launch_resunit_t7_s<MI, KS2, SplitH1>(c, a, nz);
 }
 static bool resunit_fused(const tts_hip_ctx *c, const DRes &r, int dil) {
     return c->dac_fuse && !c->dac_f16 && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM) && dil <= 9 && c->packed_ru.count(r.in_w);

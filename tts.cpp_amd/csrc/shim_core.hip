@@ -137,6 +137,7 @@ extern "C" tts_hip_ctx *tts_hip_create(int device, const tts_hip_desc *desc) {
     if (const char *e = getenv("TTS_HIP_ATTN_ROWS")) c->attn_rows_min = std::max(0, atoi(e));                                                 // bench.py A/B, test_gpu_parler.py: row-major self-attention from this many rows (0: never)
     if (const char *e = getenv("TTS_HIP_DAC_GROUP")) c->dac_group = std::max(1, atoi(e));                       // test_gpu_dac.py, bench.py: utterances per codec pass
     if (const char *e = getenv("TTS_HIP_DAC_BF16X3")) (void) tts_hip_tune(c, "dac_exact_fp32", atoi(e) == 0);  // test_gpu_dac.py: 0 = the exact-fp32 MFMA codec
+    if (const char *e = getenv("TTS_HIP_DAC_SPLIT")) c->dac_split = atoi(e) != 0;                               // test_gpu_dac.py: 0 = bf16 x 3 products, 1 = fp16 hi + lo
     if (const char *e = getenv("TTS_HIP_GEN_COMPACT")) c->gen_compact = atoi(e) != 0;                           // test_gpu_runner.py: row compaction of the generation loop
     if (const char *e = getenv("TTS_HIP_TILE_FORCE")) c->tile_force = atoi(e);                                  // test_gpu_parler.py: every tile shape of the tiled GEMM
     if (const char *e = getenv("TTS_HIP_TILE_KS")) c->tile_force_ks = atoi(e);
@@ -156,6 +157,7 @@ extern "C" int tts_hip_tune(tts_hip_ctx *c, const char *key, int v) {
     else if (k == "dac_convt_b3") c->dac_convt_b3 = v;           // 0: transposed convs on the exact-fp32 MFMA kernel
     else if (k == "dac_convt_planes") c->dac_convt_planes = v;   // 0: transposed convs stage fp32 input themselves
     else if (k == "dac_planes") c->dac_planes = v;               // 0: the wide classes keep fp32 activations
+    else if (k == "dac_split") c->dac_split = v ? 1 : 0;         // 1: fp16 hi + lo split (three products) instead of bf16 x 3 (six)
     else if (k == "dac_tap7") c->dac_tap7 = v;                   // 0: tap-pair k-steps in the k = 7 planes convs
     else if (k == "dac_b3") c->dac_b3 = std::max(0, v);
     else if (k == "dac_conv1_direct") c->dac_conv1_direct = v != 0;

@@ -64,7 +64,7 @@ extern "C" int tts_hip_dac_arith(tts_hip_ctx *c) {
     if (!c || !c->has_dac) return 0;
     if (c->dac_f16) return 8;
     if (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) return 16;
-    return (c->dac_b3 ? 1 : 0) | (c->dac_fuse ? 2 : 0) | (c->dac_convt_b3 ? 4 : 0) | (c->dac_planes && c->dac_b3 ? 32 : 0);
+    return (c->dac_b3 ? 1 : 0) | (c->dac_fuse ? 2 : 0) | (c->dac_convt_b3 ? 4 : 0) | (c->dac_planes && c->dac_b3 ? 32 : 0) | (c->dac_split && c->dac_b3 ? 64 : 0);   // 64: fp16 hi + lo split (three products) instead of bf16 x 3 (six)
 }
 extern "C" int tts_hip_profile(tts_hip_ctx *c, int enable) {
     if (!c) return set_err("null ctx");
