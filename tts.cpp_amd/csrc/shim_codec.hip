@@ -144,7 +144,7 @@ static int pack_convt_b3(tts_hip_ctx *c, const DBlock &b) {
 // tiles (one k-step = 16 channels per chunk)
 static bool planes_class(const tts_hip_ctx *c, int ch) {
     int ks = 0, ks2 = 0;
-    return c->dac_planes && c->dac_b3 && !c->dac_f16 && ch % 128 == 0 && !(c->dac_fuse && resunit_shape(ch, &ks, &ks2));
+    return c->dac_planes && c->dac_b3 && (!c->dac_f16 || c->dac_f16_planes) && ch % 128 == 0 && !(c->dac_fuse && resunit_shape(ch, &ks, &ks2));
 }
 static int pack_planes(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT) {
     const bool tapk = KT == 7 && c->dac_tap7 && cin % 16 == 0;
@@ -165,7 +165,11 @@ static int pack_planes(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT) 
 static int ensure_packed(tts_hip_ctx *c) {
     if (c->dac_packed || (c->d.flags & TTS_HIP_FLAG_VALU_GEMM)) return 0;
     int CO_T = 0, CI_T = 0;
-    if (c->dac_f16) {
+    // F16 codec tensors (quantize --convert-dac-to-f16): since round 6 on the same plane / fused-unit / transposed kernels as F32 tensors, with one fp16
+    // plane and one product (SplitH1: ggml's fp16 im2col x fp16 kernel — the activations a conv consumes rounded to fp16, exact products, fp32
+    // accumulation); layers those kernels do not cover (other channel counts) keep the fp16 tile kernels of round 2 (packed16)
+    const bool f16p = c->dac_f16 && c->dac_f16_planes && c->dac_b3 && c->dac_tap7;
+    if (c->dac_f16 && !f16p) {
         if (conv_tile(c->d_c0, 7, &CO_T, &CI_T) >= 0) CHK(pack_one16(c, c->d_initw, c->d_c0, c->d_latent, 7, CO_T, CI16_K7, false));
         for (auto &b : c->dblocks) {
             if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one16(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, CI16_T, true));
@@ -181,10 +185,12 @@ static int ensure_packed(tts_hip_ctx *c) {
     // Every weight is packed in the ONE image the kernel that will run it stages (the images are as large as the weights: a second format per
     // tensor would be dead device memory in every context).
     if (planes_class(c, c->d_c0) && c->d_latent % 8 == 0) CHK(pack_planes(c, c->d_initw, c->d_c0, c->d_latent, 7));
+    else if (f16p) { if (conv_tile(c->d_c0, 7, &CO_T, &CI_T) >= 0) CHK(pack_one16(c, c->d_initw, c->d_c0, c->d_latent, 7, CO_T, CI16_K7, false)); }
     else if (c->dac_b3 && c->d_c0 % 64 == 0) CHK(pack_one_b3(c, c->d_initw, c->d_c0, c->d_latent, 64));
     else if (conv_tile(c->d_c0, 7, &CO_T, &CI_T) >= 0) CHK(pack_one(c, c->d_initw, c->d_c0, c->d_latent, 7, CO_T, CI_T, false));
     for (auto &b : c->dblocks) {
         if (c->dac_convt_b3 && convt_b3_fits(b.cout, b.cin, b.stride)) CHK(pack_convt_b3(c, b));
+        else if (f16p) { if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one16(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, CI16_T, true)); }
         else if (convt_tile(b.cout, b.stride, &CO_T) >= 0) CHK(pack_one(c, b.w, b.cout, b.cin, 2 * b.stride, CO_T, CI32_T, true));
         int ks = 0, ks2 = 0;
         for (int r = 0; r < 3; r++) {
@@ -195,6 +201,11 @@ static int ensure_packed(tts_hip_ctx *c) {
             }
             if (c->dac_fuse && resunit_shape(b.cout, &ks, &ks2)) {   // one launch per unit (dilations 1 / 3 / 9 all qualify)
                 CHK(pack_resunit(c, b.res[r], b.cout));
+                continue;
+            }
+            if (f16p) {
+                if (conv_tile(b.cout, 7, &CO_T, &CI_T) >= 0) CHK(pack_one16(c, b.res[r].in_w, b.cout, b.cout, 7, CO_T, CI16_K7, false));
+                if (conv_tile(b.cout, 1, &CO_T, &CI_T) >= 0) CHK(pack_one16(c, b.res[r].out_w, b.cout, b.cout, 1, CO_T, CI16_K1, false));
                 continue;
             }
             if (c->dac_b3 && b.cout % 64 == 0) CHK(pack_one_b3(c, b.res[r].in_w, b.cout, b.cout, 64));
@@ -547,7 +558,7 @@ static int launch_resunit_t7(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
     return sc == 0 ? launch_resunit_t7_s<MI, KS2, SplitB3>(c, a, nz) : sc == 1 ? launch_resunit_t7_s<MI, KS2, SplitH2>(c, a, nz) : launch_resunit_t7_s<MI, KS2, SplitH1>(c, a, nz);
 }
 static bool resunit_fused(const tts_hip_ctx *c, const DRes &r, int dil) {
-    return c->dac_fuse && !c->dac_f16 && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM) && dil <= 9 && c->packed_ru.count(r.in_w);
+    return c->dac_fuse && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM) && dil <= 9 && c->packed_ru.count(r.in_w);
 }
 static int launch_resunit(tts_hip_ctx *c, const DacBatch &bt, const DRes &r, int C, int LS, int dil, const float *x, float *y) {
     ResUnitArgs a{};
@@ -699,7 +710,7 @@ static int dac_decode_batch_on(tts_hip_ctx *c, const uint32_t *codes, const uint
     // A transposed conv on the bf16 x 3 kernel takes its input as split planes when the producer is a planes conv: the producer's epilogue applies
     // this layer's snake and the split once per element, where the fp32 form redoes both in every one of the cout / 32 channel-tile workgroups.
     auto convt_takes_planes = [&](size_t bi) {
-        if (bi >= c->dblocks.size() || !c->dac_convt_planes || (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) || c->dac_f16) return false;
+        if (bi >= c->dblocks.size() || !c->dac_convt_planes || (c->d.flags & TTS_HIP_FLAG_VALU_GEMM)) return false;
         const DBlock &nb = c->dblocks[bi];
         return c->dac_convt_b3 && c->packed_ct.count(nb.w) != 0 && nb.cin % 16 == 0;
     };

@@ -62,7 +62,7 @@ static int prof_collect(tts_hip_ctx *c) {
 
 extern "C" int tts_hip_dac_arith(tts_hip_ctx *c) {
     if (!c || !c->has_dac) return 0;
-    if (c->dac_f16) return 8;
+    if (c->dac_f16) return 8 | (c->dac_f16_planes && c->dac_b3 && c->dac_tap7 && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM) ? 128 : 0);   // 128: on the plane kernels (one fp16 plane)
     if (c->d.flags & TTS_HIP_FLAG_VALU_GEMM) return 16;
     return (c->dac_b3 ? 1 : 0) | (c->dac_fuse ? 2 : 0) | (c->dac_convt_b3 ? 4 : 0) | (c->dac_planes && c->dac_b3 ? 32 : 0) | (c->dac_split && c->dac_b3 ? 64 : 0);   // 64: fp16 hi + lo split (three products) instead of bf16 x 3 (six)
 }
