@@ -180,7 +180,7 @@ def run_dia(args, ranks=None):
                                "un-delay, one batched DAC pass to PCM",
                    "utterances_per_gpu": U, "utterances": U * world, "rows_per_step": 2 * U, "decoder_steps": steps,
                    "parallelism": f"dp{world}" + (" of dp8" if world < 8 else "") + " (utterance i -> rank i mod N: one process per GPU, rank 0's weight arena broadcast over RCCL, no per-step collective)"},
-        "rccl_ranks": world, "weight_broadcast": bcast,
+        "ranks": world, "rccl_ranks": world if (world > 1 and bcast and "RCCL" in bcast.get("via", "")) else 0, "weight_broadcast": bcast,
         "ms_per_decode_step": round(step_ms, 4), "encode_ms_per_utterance": round(float(np.mean(enc_s)) / U * 1e3, 2),
         "dac_ms_per_pass": round(float(np.mean(dac_s)) * 1e3, 2),
         "x_real_time_per_gpu": round(U / (step_ms * 1e-3) / 86.13, 2),
