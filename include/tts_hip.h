@@ -225,6 +225,7 @@ typedef struct tts_hip_orpheus_desc {
     uint32_t n_ctx;            /* KV positions: max_context_length + max_generation_size (1024 + 2100, :176-177) */
     float    rope_base;        /* 500000 (:190,250); 0 = that  */
     uint32_t flags;            /* TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q */
+    uint32_t max_seqs;         /* KV-cache slots for lock-step utterances (tts_hip_orpheus_generate_batch); 0 / 1: one sequence, as the reference's runner */
 } tts_hip_orpheus_desc;
 tts_hip_ctx *tts_hip_orpheus_create(int device, const tts_hip_orpheus_desc *desc);
 /* n tokens at positions pos0 .. pos0+n-1 (KV cache appended); logits_out [vocab_size] of the LAST token (:287-290).
@@ -244,6 +245,15 @@ int tts_hip_orpheus_generate_greedy(tts_hip_ctx *ctx, const uint32_t *prompt, ui
  * std::minstd_rand).  top_k 0 or > 64 is refused: sample on the host from tts_hip_orpheus_decode's logits. */
 int tts_hip_orpheus_generate_sampled(tts_hip_ctx *ctx, const uint32_t *prompt, uint32_t n_prompt, uint32_t max_new, uint32_t stop_id,
                                      const tts_hip_sampling *sampling, const float *uniforms, uint32_t *tokens_out, uint32_t *n_out);
+/* Lock-step utterances (the reference runs N independent workers with a model copy each, examples/server/server.cpp:225-321): one forward
+ * carries one row per live utterance, row r in cache slot slots[r] at position pos[r].  step_batch: logits_out [n][vocab_size] and / or tokens_out [n]
+ * (sampler::max per row) may be NULL.  generate_batch: generate_from_batch (orpheus/model.cpp:378-392) for n_utt utterances at once — prompts are the
+ * utterances' ids back to back (n_prompt[u] each), tokens_out [n_utt][max_new], n_out [n_utt]; sampling NULL = sampler::max, else sampler::sample with
+ * uniforms [n_utt][max_new] (utterance u's k-th sampler call draws uniforms[u * max_new + k]) and one repetition state per utterance.  Every utterance
+ * receives exactly the ids its own one-sequence generation produces; finished utterances leave the step. */
+int tts_hip_orpheus_step_batch(tts_hip_ctx *ctx, uint32_t n, const uint32_t *slots, const uint32_t *ids, const uint32_t *pos, float *logits_out, uint32_t *tokens_out);
+int tts_hip_orpheus_generate_batch(tts_hip_ctx *ctx, uint32_t n_utt, const uint32_t *prompts, const uint32_t *n_prompt, uint32_t max_new, uint32_t stop_id,
+                                   const tts_hip_sampling *sampling, const float *uniforms, uint32_t *tokens_out, uint32_t *n_out);
 /* the device sampler alone on caller-supplied logits [vocab_size], for parity tests; last_id / rep_count: sampler::last_token_ids /
  * repetition_counts, read and updated in place (may be NULL when repetition_penalty == 1) */
 int tts_hip_orpheus_sample_logits(tts_hip_ctx *ctx, const float *logits, const tts_hip_sampling *sampling, float uniform, int32_t *last_id,

@@ -487,7 +487,7 @@ class SnacOracle:
         self.keep = []
         t = model.by_name
 
-        def f(name):
+        def f(name, round16=False):   # (round16: DacOracle's fp16-im2col reading; SNAC's lines share the call shape)
             a = np.ascontiguousarray(t["snac." + name].to_f32().reshape(-1))
             self.keep.append(a)
             return f32p(a)

@@ -341,3 +341,49 @@ def test_orpheus_sampled_generation_equals_the_per_step_host_loop(graph):
         assert eng.generate_sampled(prompt, n, stop_id=stop, uniforms=u, top_k=top_k, temperature=temp, repetition_penalty=rep, top_p=top_p).tolist() == ref[:first + 1]
     assert len(set(ref)) > 1
     eng.close()
+
+
+@pytest.mark.parametrize("wtype", [gguf.F16, gguf.Q4_0])
+@pytest.mark.parametrize("n_utt", [3, 7])
+def test_orpheus_lockstep_batch_equals_single_sequence_generations(n_utt, wtype):
+    """VERDICT r5 item 5 (B utterances batched in lock-step inside a GPU; the reference's only concurrency is N independent workers,
+    server.cpp:225-321): tts_hip_orpheus_generate_batch — prompts of different lengths in their own cache slots, one row per live utterance, finished
+    utterances leaving the step — gives every utterance the ids its own one-sequence generation gives, token for token, greedy and with the device sampler
+    (own uniforms and repetition state per utterance); the first utterance's ids are also the oracle's.  3 rows take the streaming 1-4 row kernels,
+    7 rows the MFMA workgroups."""
+    model = synth.build_orpheus(synth.orpheus_tiny(weight_type=wtype))
+    cfg = model.cfg
+    rng = np.random.default_rng(10 * n_utt + wtype)
+    prompts = [rng.integers(0, cfg.vocab, 3 + 2 * (u % 4)).astype(np.uint32) for u in range(n_utt)]
+    max_new = 14
+    single = hip.OrpheusEngine(cfg)
+    single.load(model)
+    ref_greedy = [single.generate_greedy(p, max_new, stop_id=cfg.vocab + 5) for p in prompts]
+    stop = int(ref_greedy[1][5])                                  # a stopping token that some utterances meet early and others never
+    ref_stop = [single.generate_greedy(p, max_new, stop_id=stop) for p in prompts]
+    uni = rng.random((n_utt, max_new), dtype=np.float32)
+    ref_smp = [single.generate_sampled(p, max_new, stop_id=cfg.vocab + 5, uniforms=uni[u], top_k=12, temperature=0.9, repetition_penalty=1.2) for u, p in enumerate(prompts)]
+    single.close()
+    eng = hip.OrpheusEngine(cfg, max_seqs=n_utt)
+    eng.load(model)
+    got = eng.generate_batch(prompts, max_new, stop_id=cfg.vocab + 5)
+    assert [g.tolist() for g in got] == [r.tolist() for r in ref_greedy]
+    got = eng.generate_batch(prompts, max_new, stop_id=stop)
+    assert [g.tolist() for g in got] == [r.tolist() for r in ref_stop]
+    assert len({len(g) for g in got}) > 1                          # the utterances really finish at different steps
+    got = eng.generate_batch(prompts, max_new, stop_id=cfg.vocab + 5, uniforms=uni, top_k=12, temperature=0.9, repetition_penalty=1.2)
+    assert [g.tolist() for g in got] == [r.tolist() for r in ref_smp]
+    # the one-sequence entry points still work on a multi-slot context (slot 0) ...
+    assert eng.generate_greedy(prompts[0], max_new, stop_id=cfg.vocab + 5).tolist() == ref_greedy[0].tolist()
+    # ... and a step's logits are the oracle's
+    o = orc.OrpheusOracle(model, act_mode=1)
+    ref = o.decode(prompts[0], 0)
+    eng.generate_batch(prompts, 1, stop_id=cfg.vocab + 5)          # fills the slots' caches with the prompts
+    t0 = int(ref.argmax())
+    lg, tok = eng.step_batch([0, 1], [t0, int(ref_greedy[1][0])], [len(prompts[0]), len(prompts[1])])
+    ref1 = o.decode([t0], len(prompts[0]))
+    assert relerr(lg[0], ref1) < (2e-3 if wtype == gguf.F16 else 3e-2)
+    assert tok.tolist() == [int(l.argmax()) for l in lg]
+    with pytest.raises(hip.HipError, match="max_seqs"):
+        eng.generate_batch(prompts + [prompts[0]], 2, stop_id=0)
+    eng.close()

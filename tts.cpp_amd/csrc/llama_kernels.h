@@ -711,6 +711,39 @@ static __global__ __launch_bounds__(64) void argmax_fold_kernel(const float *pv,
     }
 }
 
+// the two stages for R rows of logits (lock-step utterances): blockIdx.y = row, logits rows ld floats apart; partials [R][ARGMAX_PARTS]
+static __global__ __launch_bounds__(256) void argmax_rows_parts_kernel(const float *logits, int V, int ld, float *pv, uint32_t *pi) {
+    __shared__ float bv[4];
+    __shared__ uint32_t bi[4];
+    const float *lg = logits + (int64_t) blockIdx.y * ld;
+    const int chunk = (V + ARGMAX_PARTS - 1) / ARGMAX_PARTS;
+    const int i0 = blockIdx.x * chunk, i1 = min(V, i0 + chunk);
+    float best = -INFINITY;
+    uint32_t besti = 0xffffffffu;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float v = lg[i];
+        if (v > best) { best = v; besti = (uint32_t) i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_merge(best, besti, __shfl_xor(best, o), __shfl_xor(besti, o));
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) argmax_merge(best, besti, bv[w], bi[w]);
+        pv[blockIdx.y * ARGMAX_PARTS + blockIdx.x] = best;
+        pi[blockIdx.y * ARGMAX_PARTS + blockIdx.x] = besti;
+    }
+}
+static __global__ __launch_bounds__(64) void argmax_rows_fold_kernel(const float *pv, const uint32_t *pi, uint32_t *token) {
+    const int r = blockIdx.x;
+    float best = -INFINITY;
+    uint32_t besti = 0xffffffffu;
+    for (int i = threadIdx.x; i < ARGMAX_PARTS; i += 64) argmax_merge(best, besti, pv[r * ARGMAX_PARTS + i], pi[r * ARGMAX_PARTS + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_merge(best, besti, __shfl_xor(best, o), __shfl_xor(besti, o));
+    if (threadIdx.x == 0) token[r] = besti == 0xffffffffu ? 0u : besti;
+}
+
 // the same fold for a captured step (one graph replayed for every position): the history slot comes from a device counter
 static __global__ __launch_bounds__(64) void argmax_fold_graph_kernel(const float *pv, const uint32_t *pi, uint32_t *token, uint32_t *hist, uint32_t *hist_idx, uint32_t *next_id,
                                                                uint32_t *next_pos) {

@@ -241,6 +241,7 @@ extern "C" void tts_hip_destroy(tts_hip_ctx *c) {
     free_dev(c->l_x); free_dev(c->l_xn); free_dev(c->l_qkv); free_dev(c->l_att); free_dev(c->l_gu); free_dev(c->l_g); free_dev(c->l_logits); free_dev(c->l_parts);
     free_dev(c->attn_part); free_dev(c->kk_stuck); free_dev(c->kk_pool);
     free_dev(c->l_kc); free_dev(c->l_vc); free_dev(c->l_ids); free_dev(c->l_pos); free_dev(c->l_tok);
+    free_dev(c->l_seq); free_dev(c->l_btok); free_dev(c->l_bpi); free_dev(c->l_bsmp); free_dev(c->l_bpv);
     for (void *p : c->q4_bufs) free_dev(p);
     for (float *p : {c->di_ex, c->di_exn, c->di_eqkv, c->di_eatt, c->di_egu, c->di_eg, c->di_ek, c->di_ev, c->di_ckv, c->di_ck, c->di_cv, c->di_k, c->di_v, c->di_x,
                      c->di_xn, c->di_qkv, c->di_q, c->di_att, c->di_gu, c->di_g, c->di_parts, c->di_logits, c->di_guided})

@@ -565,7 +565,7 @@ int run_gemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int ep
         CHK(rc);
         return prof_end(c);
     }
-    if (epi == EPI_RESID && a.R > c->ln_fuse_max && a.H <= 2048 && a.N == a.H && a.out == c->x) {
+    if (epi == EPI_RESID && a.R > c->ln_fuse_max && a.H <= 2048 && a.N == a.H && a.out == c->x && pro != PRO_CROSS && pro != PRO_ATTN) {   // (the staging prologues of the one-sequence chain have no K-slice form)
         // many rows: spread K over 4-8x more workgroups; the partial slabs are folded into x by the next LayerNorm
         const int ks = 4;
         if (a.K % (ks * 256) == 0) {
@@ -936,7 +936,8 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         c->l_ksplit = 1;
         while (F / c->l_ksplit > 4096 || (F % c->l_ksplit)) c->l_ksplit++;
         if ((F / c->l_ksplit) % 256) c->l_ksplit = 1;
-        const size_t kvb = (size_t) c->L * NCTX * c->l_kvH;
+        const size_t S = std::max<uint32_t>(1, c->lm.max_seqs);                 // cache slots of lock-step utterances; [slot][layer][position][kv width]
+        const size_t kvb = S * c->L * NCTX * c->l_kvH;
         c->attn_part_cap = (size_t) 4 * c->NH * 16;   // up to 4 rows x heads x 16 splits (more rows take the unsplit kernel)
         CHK(dmalloc(&c->attn_part, c->attn_part_cap * ATTN_PART));
         CHK(dmalloc(&c->attn_cnt, (size_t) 256 + c->NH));   // arrival counters of the split attention's in-kernel merge (rows x heads <= 256)
@@ -950,7 +951,12 @@ extern "C" int tts_hip_finalize(tts_hip_ctx *c, void *external_arena) {
         CHK(dmalloc(&c->l_gu, (size_t) R * 2 * F));
         CHK(dmalloc(&c->l_g, (size_t) R * F));
         CHK(dmalloc(&c->l_parts, (size_t) 8 * R * H));
-        CHK(dmalloc(&c->l_logits, (size_t) c->l_Vpad));
+        CHK(dmalloc(&c->l_logits, S * (size_t) c->l_Vpad));   // one row per utterance of a lock-step step
+        CHK(dmalloc(&c->l_seq, (size_t) R));
+        CHK(dmalloc(&c->l_btok, S));
+        CHK(dmalloc(&c->l_bpv, S * ARGMAX_PARTS));
+        CHK(dmalloc(&c->l_bpi, S * ARGMAX_PARTS));
+        CHK(dmalloc(&c->l_bsmp, S * 3));
         CHK(dmalloc(&c->dbg, (size_t) R * std::max(H, F)));
         CHK(dmalloc(&c->aq, (size_t) R * std::max(std::max(H, F), c->NH * (int) c->lm.head_dim)));
         CHK(dmalloc(&c->ad, (size_t) R * std::max(std::max(H, F), c->NH * (int) c->lm.head_dim) / 32 + 1));

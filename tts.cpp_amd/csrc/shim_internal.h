@@ -158,6 +158,8 @@ struct tts_hip_ctx {
     float *l_x = nullptr, *l_xn = nullptr, *l_qkv = nullptr, *l_att = nullptr, *l_gu = nullptr, *l_g = nullptr, *l_logits = nullptr, *l_parts = nullptr;
     float *l_kc = nullptr, *l_vc = nullptr;
     uint32_t *l_ids = nullptr, *l_pos = nullptr, *l_tok = nullptr;
+    uint32_t *l_seq = nullptr, *l_btok = nullptr, *l_bpi = nullptr, *l_bsmp = nullptr;   // lock-step utterances: row -> cache slot, selected tokens [rows], arg-max partials, sampler state [utterance][3]
+    float *l_bpv = nullptr;
     int l_pending = 0;
     // ---- Dia context (tts_hip_dia_create) ----
     bool has_dia = false;

@@ -22,6 +22,8 @@ extern "C" tts_hip_ctx *tts_hip_orpheus_create(int device, const tts_hip_orpheus
     if (!c) return nullptr;
     c->has_llama = true;
     c->lm = *ld;
+    if (c->lm.max_seqs == 0) c->lm.max_seqs = 1;
+    if (c->lm.max_seqs > 64) { set_err("tts_hip_orpheus_create: max_seqs %u > 64", c->lm.max_seqs); tts_hip_destroy(c); return nullptr; }
     // measured on MI355X at the orpheus-3b Q4_0 shapes (profiles/r02/first_call_orpheus_*.log): 3.84 ms/step through the
     // lock-step workgroups, 2.98 with the streaming 1-4 row kernels, 2.84 reading the Q4_0 codes themselves, 2.80 with the
     // step captured in one hipGraph -> all three are the default here; TTS_HIP_GEMV_ROWS / _Q4_NATIVE / _LLAMA_GRAPH=0 turn them off
@@ -94,7 +96,11 @@ static int llama_gemm(tts_hip_ctx *c, const W &w, const float *A, int lda, float
 // ids == nullptr: one row whose token id and position are already in l_ids[0] / l_pos[0] (the device-resident greedy loop)
 // attn_positions != 0: size the attention scratch for that many cached positions instead of pos0 + n (a captured step is replayed
 // at every position)
-static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t pos0, int attn_positions = 0) {
+// row_seq != NULL (lock-step utterances, tts_hip_orpheus_step_batch / _generate_batch): row r belongs to cache slot row_seq[r] (device array); ids / positions /
+// slots are already in l_ids / l_pos / l_seq (ids == NULL, any n), attn_positions bounds the keys of any row; logits_row: where the last row's logits go
+// (l_logits + logits_row * Vpad), or -1: the logits of EVERY row r to l_logits + r * Vpad.  The one-sequence kernels that append to "the" cache
+// (gemv_q4_qkv_rope_kernel) stay out of it.
+static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t pos0, int attn_positions = 0, const uint32_t *row_seq = nullptr, int logits_row = 0) {
     const int H = c->H, F = c->F, NH = c->NH, NKV = (int) c->lm.n_kv_heads, HD = (int) c->lm.head_dim;
     const int QKV = (NH + 2 * NKV) * HD, NCTX = (int) c->lm.n_ctx;
     if (n < 1 || n > c->RMAX) return set_err("tts_hip_orpheus_decode: %d tokens per call outside 1..%d", n, c->RMAX);
@@ -109,9 +115,10 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
         HIPCHK(hipMemcpyAsync(c->l_ids, ids, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->l_pos, hp.data(), (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));  // hp is a local
-    } else if (n != 1) {
+    } else if (n != 1 && !row_seq) {
         return set_err("llama_forward: device-resident inputs carry one row");
     }
+    const int64_t seq_stride = (int64_t) c->L * NCTX * c->l_kvH;   // the cache is [slot][layer][position][kv width]: slot 0 is the one-sequence context's cache
     hipLaunchKernelGGL(t5_embed_kernel, dim3(n), dim3(256), 0, c->stream, f32(c->l_embd), (const uint32_t *) c->l_ids, H, c->l_x);
     HIPCHK(hipGetLastError());
     const float theta_scale = powf(c->lm.rope_base, -2.0f / (float) HD);
@@ -133,7 +140,7 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
         const auto &y = c->l_layers[l];
         float *kc = c->l_kc + (size_t) l * NCTX * c->l_kvH, *vc = c->l_vc + (size_t) l * NCTX * c->l_kvH;
         const size_t qkv_lds = (size_t) n * H + (size_t) n * (H / 32) * 4;
-        const bool qkv_fused = c->q4_rope && c->q4_lds && y.qkv.q4 && q_for(y.qkv, n) && HD == 128 && H % 512 == 0 && qkv_lds <= 64 * 1024 && !c->prof;
+        const bool qkv_fused = !row_seq && c->q4_rope && c->q4_lds && y.qkv.q4 && q_for(y.qkv, n) && HD == 128 && H % 512 == 0 && qkv_lds <= 64 * 1024 && !c->prof;
         // the rms norm inside the consuming projection's staging (stage_rms_q8): no slabs may be pending, the row is held in registers
         const bool rms_fused = c->q4_rms && !c->l_pending && H <= 4096;
         if (qkv_fused && rms_fused) {
@@ -159,12 +166,12 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
             CHK(rms(y.in_norm, n, c->l_x, c->l_xn, &y.qkv));
             CHK(llama_gemm(c, y.qkv, c->l_xn, H, c->l_qkv, QKV, n, EPI_STORE));
             hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH + NKV), dim3(64), 0, c->stream, c->l_qkv, (const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, HD, kc, vc,
-                               (const uint32_t *) nullptr, (int64_t) 0);
+                               row_seq, row_seq ? seq_stride : (int64_t) 0);
             HIPCHK(hipGetLastError());
         }
         CHK(launch_attn_gqa(c, NH, n, (int) (attn_positions ? (uint32_t) attn_positions : pos0 + n), (const float *) c->l_qkv, QKV, (const uint32_t *) c->l_pos,
-                            (const float *) kc, (const float *) vc, NKV, 1.0f / sqrtf((float) HD), c->l_att, nullptr, nullptr, nullptr, (int64_t) 0, attn_positions != 0,
-                            q_for(y.o, n), QPre{}, nullptr, NCTX));
+                            (const float *) kc, (const float *) vc, NKV, 1.0f / sqrtf((float) HD), c->l_att, nullptr, nullptr, row_seq, row_seq ? seq_stride : (int64_t) 0,
+                            attn_positions != 0 && !row_seq, q_for(y.o, n), QPre{}, nullptr, NCTX));
         CHK(llama_gemm(c, y.o, c->l_att, NH * HD, c->l_x, H, n, EPI_RESID));
         const size_t gu_lds = (size_t) n * H + (size_t) n * (H / 32) * 4, dn_lds = (size_t) n * F + (size_t) n * (F / 32) * 4;
         const bool gu_fused = c->q4_silu && c->q4_lds && y.gu.q4 && y.down.q4 && q_for(y.gu, n) && q_for(y.down, n) && H % 512 == 0 && F % 512 == 0 &&
@@ -212,10 +219,12 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
             CHK(llama_gemm(c, y.down, c->l_g, F, c->l_x, H, n, EPI_RESID));
         }
     }
-    // lm_head on the last token only (:287-290)
+    // lm_head on the last token only (:287-290) — or, for lock-step utterances, on every row (each row is an utterance's last token)
     CHK(rms(c->l_out_norm, n, c->l_x, c->l_xn, nullptr));
     GemmArgs g{};
-    g.R = 1; g.H = H; g.A = c->l_xn + (size_t) (n - 1) * H; g.lda = H; g.out = c->l_logits; g.ldo = c->l_Vpad;
+    g.H = H; g.lda = H; g.ldo = c->l_Vpad;
+    if (logits_row < 0) { g.R = n; g.A = c->l_xn; g.out = c->l_logits; }
+    else { g.R = 1; g.A = c->l_xn + (size_t) (n - 1) * H; g.out = c->l_logits + (size_t) logits_row * c->l_Vpad; }
     CHK(run_gemm(c, TTS_HIP_K_GEMM_HEADS, c->l_head, g, PRO_F32, EPI_STORE));
     return 0;
 }
@@ -428,6 +437,159 @@ extern "C" int tts_hip_orpheus_sample_logits(tts_hip_ctx *c, const float *logits
 // ------------------------------------------------------------------------------------------------
 // Dia (src/models/dia/model.cpp:383-659)
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Lock-step utterances ("within a GPU, B utterances batched in lock-step"; the reference's only concurrency is N independent
+// workers, each with its own model copy, examples/server/server.cpp:225-321).  The cache holds lm.max_seqs slots; a step carries one row per
+// live utterance, every row with its own slot and position.
+// ------------------------------------------------------------------------------------------------
+static int llama_stage_rows(tts_hip_ctx *c, const char *what, uint32_t n, const uint32_t *slots, const uint32_t *ids, const uint32_t *pos, uint32_t *max_pos) {
+    if (n == 0 || (int) n > c->RMAX) return set_err("%s: %u rows outside 1..%d", what, n, c->RMAX);
+    *max_pos = 0;
+    for (uint32_t r = 0; r < n; r++) {
+        if (slots[r] >= c->lm.max_seqs) return set_err("%s: cache slot %u >= max_seqs %u", what, slots[r], c->lm.max_seqs);
+        if (ids[r] >= (uint32_t) c->l_V) return set_err("%s: token id %u >= vocabulary %d", what, ids[r], c->l_V);
+        if (pos[r] >= c->lm.n_ctx) return set_err("%s: position %u outside the %u cached positions", what, pos[r], c->lm.n_ctx);
+        *max_pos = std::max(*max_pos, pos[r]);
+    }
+    HIPCHK(hipMemcpyAsync(c->l_ids, ids, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->l_pos, pos, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->l_seq, slots, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// sampler::max of the logits of rows 0 .. n-1 -> l_btok[r]
+static int llama_argmax_rows(tts_hip_ctx *c, int n) {
+    hipLaunchKernelGGL(argmax_rows_parts_kernel, dim3(ARGMAX_PARTS, n), dim3(256), 0, c->stream, (const float *) c->l_logits, c->l_V, c->l_Vpad, c->l_bpv, c->l_bpi);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(argmax_rows_fold_kernel, dim3(n), dim3(64), 0, c->stream, (const float *) c->l_bpv, (const uint32_t *) c->l_bpi, c->l_btok);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int tts_hip_orpheus_step_batch(tts_hip_ctx *c, uint32_t n, const uint32_t *slots, const uint32_t *ids, const uint32_t *pos, float *logits_out, uint32_t *tokens_out) {
+    if (!c || !c->has_llama) return set_err("tts_hip_orpheus_step_batch: not an Orpheus context (tts_hip_orpheus_create)");
+    if (!c->finalized || !c->weights_present) return set_err("tts_hip_orpheus_step_batch: context not finalized");
+    if (!slots || !ids || !pos) return set_err("tts_hip_orpheus_step_batch: null argument");
+    if (n > c->lm.max_seqs) return set_err("tts_hip_orpheus_step_batch: %u rows > max_seqs %u (one row per utterance)", n, c->lm.max_seqs);
+    HIPCHK(hipSetDevice(c->device));
+    uint32_t max_pos = 0;
+    CHK(llama_stage_rows(c, "tts_hip_orpheus_step_batch", n, slots, ids, pos, &max_pos));
+    CHK(llama_forward(c, nullptr, (int) n, 0, (int) max_pos + 1, c->l_seq, -1));
+    if (tokens_out) {
+        CHK(llama_argmax_rows(c, (int) n));
+        HIPCHK(hipMemcpyAsync(tokens_out, c->l_btok, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (logits_out) HIPCHK(hipMemcpy2DAsync(logits_out, (size_t) c->l_V * 4, c->l_logits, (size_t) c->l_Vpad * 4, (size_t) c->l_V * 4, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// the prompt of one utterance into its cache slot (pieces of RMAX rows); the last row's logits land in l_logits row `slot`
+static int llama_prefill_slot(tts_hip_ctx *c, const char *what, uint32_t slot, const uint32_t *prompt, uint32_t n_prompt) {
+    std::vector<uint32_t> sl, ps;
+    uint32_t done = 0;
+    while (done < n_prompt) {
+        const uint32_t m = std::min<uint32_t>((uint32_t) c->RMAX, n_prompt - done);
+        sl.assign(m, slot);
+        ps.resize(m);
+        for (uint32_t i = 0; i < m; i++) ps[i] = done + i;
+        uint32_t max_pos = 0;
+        CHK(llama_stage_rows(c, what, m, sl.data(), prompt + done, ps.data(), &max_pos));
+        CHK(llama_forward(c, nullptr, (int) m, 0, (int) max_pos + 1, c->l_seq, (int) slot));
+        done += m;
+    }
+    return 0;
+}
+
+// generate_from_batch (orpheus/model.cpp:378-392) for n_utt utterances in lock-step: every utterance gets exactly the tokens its own one-sequence
+// generation gets (sampler::max, or sampler::sample with its own uniforms and repetition state); finished utterances leave the step.
+extern "C" int tts_hip_orpheus_generate_batch(tts_hip_ctx *c, uint32_t n_utt, const uint32_t *prompts, const uint32_t *n_prompt, uint32_t max_new, uint32_t stop_id,
+                                              const tts_hip_sampling *sp, const float *uniforms, uint32_t *tokens_out, uint32_t *n_out) {
+    const char *what = "tts_hip_orpheus_generate_batch";
+    if (!c || !c->has_llama) return set_err("%s: not an Orpheus context (tts_hip_orpheus_create)", what);
+    if (!c->finalized || !c->weights_present) return set_err("%s: context not finalized", what);
+    if (!prompts || !n_prompt || !tokens_out || !n_out) return set_err("%s: null argument", what);
+    if (n_utt == 0 || n_utt > c->lm.max_seqs) return set_err("%s: %u utterances outside 1..max_seqs = %u", what, n_utt, c->lm.max_seqs);
+    HIPCHK(hipSetDevice(c->device));
+    for (uint32_t u = 0; u < n_utt; u++) { n_out[u] = 0; if (n_prompt[u] == 0 || n_prompt[u] >= c->lm.n_ctx) return set_err("%s: utterance %u: prompt of %u ids", what, u, n_prompt[u]); }
+    if (max_new == 0) return 0;
+    if (sp) {
+        CHK(check_llama_sampling(c, sp, what));
+        if (!uniforms) return set_err("%s: null uniforms", what);
+        CHK(stage_uniforms(c, uniforms, (size_t) n_utt * max_new));   // utterance u draws uniforms[u * max_new + call]
+        CHK(stage_penalty(c, sp->repetition_penalty, (int) max_new));
+        std::vector<uint32_t> init((size_t) 3 * n_utt);
+        for (uint32_t u = 0; u < n_utt; u++) { init[3 * u] = 0xFFFFFFFFu; init[3 * u + 1] = 0; init[3 * u + 2] = 0; }   // sampler::reset per utterance
+        HIPCHK(hipMemcpyAsync(c->l_bsmp, init.data(), init.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    // select for logits row r on behalf of utterance u -> l_btok[r]
+    auto select_rows = [&](const std::vector<uint32_t> &utt) -> int {
+        const int n = (int) utt.size();
+        if (!sp) return llama_argmax_rows(c, n);
+        const double *pen = sp->repetition_penalty != 1.0f ? c->d_pen : nullptr;
+        for (int r = 0; r < n; r++) {
+            const uint32_t u = utt[(size_t) r];
+            int32_t *last = (int32_t *) (c->l_bsmp + 3 * u);
+            uint32_t *repc = c->l_bsmp + 3 * u + 1, *call = c->l_bsmp + 3 * u + 2;
+            const float *lg = c->l_logits + (size_t) r * c->l_Vpad;
+            hipLaunchKernelGGL(topk_parts_kernel, dim3(TOPK_PARTS), dim3(512), 0, c->stream, lg, c->l_V, (int) sp->top_k, pen, c->pen_len, (const int32_t *) last, (const uint32_t *) repc, c->l_cand);
+            HIPCHK(hipGetLastError());
+            float *total = nullptr;
+            if (sp->top_p < 1.0f) {
+                total = (float *) (c->l_cand + (size_t) TOPK_PARTS * TOPK_MAXK);
+                hipLaunchKernelGGL(softmax_total_kernel, dim3(1), dim3(1024), 0, c->stream, lg, c->l_V, (const unsigned long long *) c->l_cand, sp->temperature, pen, c->pen_len,
+                                   (const int32_t *) last, (const uint32_t *) repc, total);
+                HIPCHK(hipGetLastError());
+            }
+            hipLaunchKernelGGL(topk_sample_kernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long *) c->l_cand, (int) sp->top_k, sp->temperature,
+                               (const float *) c->d_uniforms + (size_t) u * max_new, call, pen, last, repc, c->l_btok + r, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr,
+                               (uint32_t *) nullptr, sp->top_p, (const float *) total);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    };
+    // prompts, then the first selection from every utterance's last prompt row (logits row u)
+    size_t off = 0;
+    std::vector<uint32_t> utt(n_utt), pos(n_utt), tok(n_utt), slots, ids, ps;
+    for (uint32_t u = 0; u < n_utt; u++) {
+        CHK(llama_prefill_slot(c, what, u, prompts + off, n_prompt[u]));
+        off += n_prompt[u];
+        utt[u] = u;
+        pos[u] = n_prompt[u];
+    }
+    CHK(select_rows(utt));
+    HIPCHK(hipMemcpyAsync(tok.data(), c->l_btok, (size_t) n_utt * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // the loop of orpheus_generate, per utterance: record the token; stop on the stopping token, at max_new ids or at the end of the cache
+    std::vector<uint32_t> live;   // utterances still generating, in utterance order (= the rows of the next step)
+    for (uint32_t u = 0; u < n_utt; u++) live.push_back(u);
+    std::vector<uint32_t> cur(n_utt);
+    for (uint32_t u = 0; u < n_utt; u++) cur[u] = tok[u];
+    while (!live.empty()) {
+        std::vector<uint32_t> next;
+        for (uint32_t u : live) {
+            tokens_out[(size_t) u * max_new + n_out[u]++] = cur[u];
+            if (cur[u] == stop_id || n_out[u] >= max_new || pos[u] >= c->lm.n_ctx) continue;
+            next.push_back(u);
+        }
+        live.swap(next);
+        if (live.empty()) break;
+        const uint32_t n = (uint32_t) live.size();
+        slots.resize(n); ids.resize(n); ps.resize(n);
+        for (uint32_t r = 0; r < n; r++) { slots[r] = live[r]; ids[r] = cur[live[r]]; ps[r] = pos[live[r]]; }
+        uint32_t max_pos = 0;
+        CHK(llama_stage_rows(c, what, n, slots.data(), ids.data(), ps.data(), &max_pos));
+        CHK(llama_forward(c, nullptr, (int) n, 0, (int) max_pos + 1, c->l_seq, -1));
+        CHK(select_rows(live));
+        HIPCHK(hipMemcpyAsync(tok.data(), c->l_btok, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (uint32_t r = 0; r < n; r++) { cur[live[r]] = tok[r]; pos[live[r]]++; }
+    }
+    return 0;
+}
+
 extern "C" tts_hip_ctx *tts_hip_dia_create(int device, const tts_hip_dia_desc *dd) {
     if (!dd || dd->struct_size != sizeof(tts_hip_dia_desc)) { set_err("tts_hip_dia_create: bad desc (struct_size mismatch)"); return nullptr; }
     tts_hip_desc d{};

@@ -54,7 +54,7 @@ class OrpheusDesc(C.Structure):
     """tts_hip_orpheus_desc (include/tts_hip.h)"""
     _fields_ = [("struct_size", C.c_uint32), ("hidden_size", C.c_uint32), ("n_layers", C.c_uint32), ("n_attn_heads", C.c_uint32),
                 ("n_kv_heads", C.c_uint32), ("head_dim", C.c_uint32), ("vocab_size", C.c_uint32), ("n_ctx", C.c_uint32),
-                ("rope_base", C.c_float), ("flags", C.c_uint32)]
+                ("rope_base", C.c_float), ("flags", C.c_uint32), ("max_seqs", C.c_uint32)]
 
 
 class DiaDesc(C.Structure):
@@ -83,7 +83,7 @@ EXPORTS = [
     "tts_hip_upload", "tts_hip_arena_bytes", "tts_hip_finalize", "tts_hip_arena_ptr", "tts_hip_arena_filled",
     "tts_hip_parler_set_text_encoding", "tts_hip_parler_reset", "tts_hip_parler_prefill", "tts_hip_parler_prefill_batch", "tts_hip_parler_step",
     "tts_hip_parler_step_greedy", "tts_hip_parler_generate_greedy", "tts_hip_parler_generate_sampled", "tts_hip_sample_logits",
-    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_generate_greedy", "tts_hip_orpheus_generate_sampled", "tts_hip_orpheus_sample_logits", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_dia_encode_slot", "tts_hip_dia_step_batch", "tts_hip_dia_generate", "tts_hip_kokoro_create", "tts_hip_kokoro_durations", "tts_hip_kokoro_generate", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
+    "tts_hip_t5_create", "tts_hip_t5_encode", "tts_hip_t5_output_size", "tts_hip_snac_create", "tts_hip_snac_decode", "tts_hip_orpheus_create", "tts_hip_orpheus_decode", "tts_hip_orpheus_step_batch", "tts_hip_orpheus_generate_batch", "tts_hip_orpheus_generate_greedy", "tts_hip_orpheus_generate_sampled", "tts_hip_orpheus_sample_logits", "tts_hip_dia_create", "tts_hip_dia_encode", "tts_hip_dia_step", "tts_hip_dia_encode_slot", "tts_hip_dia_step_batch", "tts_hip_dia_generate", "tts_hip_kokoro_create", "tts_hip_kokoro_durations", "tts_hip_kokoro_generate", "tts_hip_dac_decode", "tts_hip_dac_decode_batch", "tts_hip_debug_read",
     "tts_hip_set_debug", "tts_hip_profile", "tts_hip_profile_get", "tts_hip_kclass_name", "tts_hip_stream",
     "tts_hip_synchronize", "tts_hip_dac_arith", "tts_hip_broadcast_weights", "tts_hip_comm_unique_id", "tts_hip_broadcast_weights_rank", "tts_hip_tune",
     "tts_hip_parler_stream_begin", "tts_hip_parler_stream_admit", "tts_hip_parler_stream_run", "tts_hip_parler_stream_collect", "tts_hip_parler_stream_end",
@@ -140,6 +140,8 @@ def load_lib():
     L.tts_hip_orpheus_create.restype = vp
     L.tts_hip_orpheus_create.argtypes = [C.c_int, C.POINTER(OrpheusDesc)]
     L.tts_hip_orpheus_decode.argtypes = [vp, u32p, C.c_uint32, C.c_uint32, f32p, u32p]
+    L.tts_hip_orpheus_step_batch.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, f32p, u32p]
+    L.tts_hip_orpheus_generate_batch.argtypes = [vp, C.c_uint32, u32p, u32p, C.c_uint32, C.c_uint32, C.POINTER(Sampling), C.POINTER(C.c_float), u32p, u32p]
     L.tts_hip_orpheus_generate_greedy.argtypes = [vp, u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
     L.tts_hip_orpheus_generate_sampled.argtypes = [vp, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Sampling), C.POINTER(C.c_float), u32p, u32p]
     L.tts_hip_orpheus_sample_logits.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(Sampling), C.c_float, C.POINTER(C.c_int32), u32p, u32p]
@@ -551,15 +553,16 @@ class SnacEngine:
 
 
 class OrpheusEngine:
-    """An Orpheus decoder context (tts_hip_orpheus_create): Llama-3 blocks, one sequence."""
+    """An Orpheus decoder context (tts_hip_orpheus_create): Llama-3 blocks, one sequence or max_seqs lock-step utterances."""
 
-    def __init__(self, cfg, device=0, flags=0):
+    def __init__(self, cfg, device=0, flags=0, max_seqs=1):
         self.L = load_lib()
         self.cfg = cfg
         d = OrpheusDesc()
         d.struct_size = C.sizeof(OrpheusDesc)
         d.hidden_size, d.n_layers, d.n_attn_heads, d.n_kv_heads, d.head_dim = cfg.hidden, cfg.layers, cfg.heads, cfg.kv_heads, cfg.head_dim
         d.vocab_size, d.n_ctx, d.rope_base, d.flags = cfg.vocab, cfg.ctx, 0.0, flags
+        d.max_seqs = max_seqs
         self.ctx = self.L.tts_hip_orpheus_create(device, C.byref(d))
         if not self.ctx:
             raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
@@ -605,6 +608,34 @@ class OrpheusEngine:
         self._chk(self.L.tts_hip_orpheus_generate_sampled(self.ctx, ap, a.size, max_new, stop_id, C.byref(sp), u.ctypes.data_as(C.POINTER(C.c_float)),
                                                           out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n)))
         return out[:n.value]
+
+    def step_batch(self, slots, ids, pos, want_logits=True):
+        """one lock-step forward: row r = token ids[r] of the utterance in cache slot slots[r] at position pos[r] -> (logits [n][vocab] or None, arg-max [n])"""
+        s, sp = _u32(slots)
+        a, ap = _u32(ids)
+        b, bp = _u32(pos)
+        n = a.size
+        lg = np.empty((n, self.cfg.vocab), dtype=np.float32) if want_logits else None
+        tok = np.empty(n, dtype=np.uint32)
+        self._chk(self.L.tts_hip_orpheus_step_batch(self.ctx, n, sp, ap, bp, lg.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None,
+                                                    tok.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return lg, tok
+
+    def generate_batch(self, prompts, max_new, stop_id, uniforms=None, top_k=50, temperature=1.0, repetition_penalty=1.0, top_p=1.0):
+        """tts_hip_orpheus_generate_batch: one id list per utterance; uniforms [n_utt][max_new] selects sampler::sample, None = greedy -> list of id arrays"""
+        n = len(prompts)
+        cat, cp = _u32(np.concatenate([np.asarray(p, dtype=np.uint32) for p in prompts]))
+        lens, lp = _u32(np.array([len(p) for p in prompts], dtype=np.uint32))
+        out = np.zeros((n, max_new), dtype=np.uint32)
+        cnt = np.zeros(n, dtype=np.uint32)
+        spp, up = None, None
+        if uniforms is not None:
+            u = np.ascontiguousarray(uniforms, dtype=np.float32).reshape(n, max_new)
+            sp_ = Sampling(top_k, top_p, temperature, repetition_penalty)
+            spp, up = C.byref(sp_), u.ctypes.data_as(C.POINTER(C.c_float))
+        self._chk(self.L.tts_hip_orpheus_generate_batch(self.ctx, n, cp, lp, max_new, stop_id, spp, up, out.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                        cnt.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return [out[i, :cnt[i]].copy() for i in range(n)]
 
     def sample_logits(self, logits, uniform, top_k=50, temperature=1.0, repetition_penalty=1.0, top_p=1.0, last_id=-1, rep_count=0):
         """the device sampler on caller-supplied logits [vocab] -> (token, last_id, rep_count)"""

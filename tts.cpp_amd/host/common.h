@@ -159,6 +159,9 @@ struct tts_load_options {
     bool declare_only = false;
     // share_with: a loaded runner of the same model on the same device; this runner uses its weight arena (own KV cache, own stream).
     const tts_generation_runner * share_with = nullptr;
+    // continuous batching (generate_stream): look-in intervals a finished utterance may wait for a codec group of 64 to fill before its partial group is
+    // decoded anyway (1: latency first, the default; more: larger codec passes under steady load — a pass of 64 costs little more than a pass of 8)
+    int  stream_codec_hold = 1;
 };
 tts_load_options & tts_thread_load_options();   // thread_local; runner_from_file reads it, the caller resets it afterwards
 int      tts_load_device();                     // resolved values for the loaders

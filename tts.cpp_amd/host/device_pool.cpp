@@ -195,7 +195,9 @@ std::vector<std::shared_ptr<pool_task>> device_pool::next_batch(int w, int cap) 
     std::vector<std::shared_ptr<pool_task>> batch;
     std::unique_lock<std::mutex> lock(q_mutex_);
     auto & mine = per_worker_[(size_t) w];
+    idle_workers_++;
     q_cv_.wait(lock, [&] { return !queue_.empty() || !mine.empty() || !running_; });
+    idle_workers_--;
     if (!running_) return batch;
     if (!mine.empty()) {  // control tasks addressed to this worker go first, one at a time
         batch.push_back(mine.front());
@@ -271,10 +273,12 @@ std::vector<std::shared_ptr<pool_task>> device_pool::poll_compatible(int w, cons
     if (!running_ || !per_worker_[(size_t) w].empty()) return got;
     // A request the session cannot take (another model, incompatible sampling parameters) that has waited longer than continuous_yield_ms at the
     // head of the queue ends the admissions: the session drains and next_batch() serves it.  Without the bound a steady stream of compatible
-    // requests kept one session alive for ever and starved everything else (task_timeout_s is only looked at on admission).
+    // requests kept one session alive for ever and starved everything else (task_timeout_s is only looked at on admission).  Only when no worker is
+    // idle: an idle worker takes the stale request through next_batch() itself, and with several workers on mixed models every session draining
+    // at once for one request cost throughput.
     for (const auto & t : queue_) {
         if (t->task == POOL_TTS && t->model == like.model && pool_configs_compatible(t->gen_config, like.gen_config)) continue;
-        if (t->waited_s() * 1e3 > opts_.continuous_yield_ms) return got;
+        if (idle_workers_ == 0 && t->waited_s() * 1e3 > opts_.continuous_yield_ms) return got;
         break;   // the oldest incompatible request is still young: requests behind it are younger
     }
     for (auto it = queue_.begin(); it != queue_.end() && got.size() < cap;) {

@@ -118,6 +118,7 @@ class device_pool {
     std::mutex                              q_mutex_;
     std::condition_variable                 q_cv_;
     std::deque<std::shared_ptr<pool_task>>  queue_;
+    int                                     idle_workers_ = 0;   // workers waiting in next_batch() (under q_mutex_): one of them serves a stale incompatible request, no session has to yield for it
     std::atomic<bool>                       running_{true};   // read under either mutex (wait() holds r_mutex_, the queue side q_mutex_)
 
     mutable std::mutex                          r_mutex_;

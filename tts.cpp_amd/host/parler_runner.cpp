@@ -78,6 +78,7 @@ parler_runner::parler_runner(const parler_hparams & hp_, unigram_tokenizer * tok
     for (uint32_t i = 0; i < hp.dac_n_layers; i++) { d.dac_stride[i] = hp.dac_stride[i]; d.dac_padding[i] = hp.dac_padding[i]; }
     d.dac_max_frames = hp.max_generation_size;
     max_seqs = tts_load_max_seqs();
+    st_codec_hold = (uint32_t) std::max(1, tts_thread_load_options().stream_codec_hold);
     d.max_seqs = max_seqs;
     {
         const tts_load_options & lo = tts_thread_load_options();
@@ -478,7 +479,7 @@ void parler_runner::stream_step(std::vector<stream_result> & finished) {
     // (round 4 held a finished request's audio until 63 more utterances had finished: under steady arrivals with fewer than 64 rows, for ever)
     const bool drain = st_live == 0;
     size_t take = st_codec.size() >= STREAM_CODEC_GROUP ? st_codec.size() / STREAM_CODEC_GROUP * STREAM_CODEC_GROUP : 0;
-    if (!take && !st_codec.empty() && (drain || st_codec_held >= 1)) take = st_codec.size();
+    if (!take && !st_codec.empty() && (drain || st_codec_held >= st_codec_hold)) take = st_codec.size();
     st_codec_held = (take < st_codec.size()) ? (take ? 0 : st_codec_held + 1) : 0;
     if (take) {
         std::vector<uint32_t> codes, frames(take);

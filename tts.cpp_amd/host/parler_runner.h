@@ -82,6 +82,7 @@ struct parler_runner final : tts_generation_runner {
     bool                        st_on = false;
     generation_configuration    st_cfg{};
     uint32_t                    st_live = 0, st_max_steps = 0;
+    uint32_t                    st_codec_hold = 1;   // tts_load_options::stream_codec_hold at load time
     uint32_t                    st_codec_held = 0;   // stream_step calls the oldest undecoded finished utterance has waited for a codec group to fill
     std::vector<uint32_t>       st_free;            // free cache slots
     std::vector<size_t>         st_ticket;          // slot -> ticket
