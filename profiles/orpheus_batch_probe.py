@@ -1,0 +1,23 @@
+import os, sys, time
+import numpy as np
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/profiles")
+import tts_cpp_amd
+from tts_cpp_amd import gguf, hip, synth
+import secondary_bench as sb
+cfg = synth.orpheus_3b(ctx=1024, weight_type=gguf.Q4_0)
+rng = np.random.default_rng(7)
+tensors, per_layer = sb.orpheus_tensors(cfg, rng)
+NO_STOP = 0xFFFFFFFF
+for B in (8,):
+    for tune in ({"q_fuse_max": 4},):
+        eng = hip.OrpheusEngine(cfg, max_seqs=B)
+        for k, v in tune.items(): eng.tune(k, v)
+        eng.load(sb._Model(cfg, tensors))
+        prompts = [rng.integers(0, cfg.vocab, 32).astype(np.uint32) for _ in range(B)]
+        eng.generate_batch(prompts, 8, NO_STOP)
+        t1 = time.perf_counter(); eng.generate_batch(prompts, 16, NO_STOP); t16 = time.perf_counter() - t1
+        t1 = time.perf_counter(); eng.generate_batch(prompts, 80, NO_STOP); tn = time.perf_counter() - t1
+        print(B, tune, "ms/step", (tn - t16) / 64 * 1e3, flush=True)
+        if len(sys.argv) > 1:
+            eng.profile(True) if hasattr(eng, "profile") else None
+        eng.close()

@@ -309,6 +309,31 @@ def run_orpheus(args):
                      "the decoder steps are the dominant part of the timed region (snac_share_of_step is the codec's)"},
     }
     eng.close()
+    # lock-step utterances inside the GPU (tts_hip_orpheus_generate_batch, round 6): B cache slots, one row per utterance and step; int8 codes
+    # and fp16 scales of every matrix cross HBM once per step whatever B (the MFMA workgroups read the int8 expansion: twice the Q4_0 bytes), so the
+    # tokens of all utterances share one weight stream
+    i8_bytes = params * (1.0 + 2.0 / 32)
+    out["lockstep_batches"] = {}
+    for B in ((1, 8, 32) if not os.environ.get("TTS_BENCH_ORPHEUS_B") else tuple(int(x) for x in os.environ["TTS_BENCH_ORPHEUS_B"].split(","))):
+        engb = hip.OrpheusEngine(cfg, max_seqs=B)
+        engb.load(_Model(cfg, tensors))
+        prompts = [rng.integers(0, cfg.vocab, 32).astype(np.uint32) for _ in range(B)]
+        nb = 112   # 16 SNAC frames per utterance
+        engb.generate_batch(prompts, 8, NO_STOP)
+        t1 = time.perf_counter(); engb.generate_batch(prompts, 16, NO_STOP); t16 = time.perf_counter() - t1
+        t1 = time.perf_counter(); res = engb.generate_batch(prompts, nb, NO_STOP); tn = time.perf_counter() - t1
+        assert all(len(r) == nb for r in res)
+        stepb = (tn - t16) / (nb - 16)
+        wbytes = q4_bytes if B <= 4 else i8_bytes
+        out["lockstep_batches"][str(B)] = {"ms_per_decode_step": round(stepb * 1e3, 4), "tokens_per_s": round(B / stepb, 1),
+                                           "audio_s_per_s_decoder_only": round(B / stepb / 7 * 2048 / 24000.0, 2),
+                                           "weight_stream": "Q4_0 codes (streaming 1-4 row kernels)" if B <= 4 else "int8 expansion (MFMA workgroups)",
+                                           "hbm_frac_of_step": round(wbytes / stepb / 1e9 / HBM_PEAK_GBS, 4)}
+        engb.close()
+    b1 = out["lockstep_batches"].get("1")
+    if b1:
+        for B, v in out["lockstep_batches"].items():
+            v["throughput_vs_B1"] = round(v["tokens_per_s"] / b1["tokens_per_s"], 2)
     snac.close() if hasattr(snac, "close") else None
     if not args.no_cpu_baseline:
         orc = _oracle()

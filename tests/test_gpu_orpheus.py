@@ -387,3 +387,35 @@ def test_orpheus_lockstep_batch_equals_single_sequence_generations(n_utt, wtype)
     with pytest.raises(hip.HipError, match="max_seqs"):
         eng.generate_batch(prompts + [prompts[0]], 2, stop_id=0)
     eng.close()
+
+
+def test_orpheus_runner_generate_batch_equals_single_calls(tmp_path):
+    """orpheus_runner::generate_batch (host/orpheus_runner.cpp): runner_from_file with max_seqs slots, three sentences in lock-step through
+    tts_hip_orpheus_generate_batch, SNAC per utterance — the audio of every utterance is bit for bit the audio of a generate() call of its own,
+    greedy and with the seeded device sampler."""
+    import os
+    from tts_cpp_amd import runner
+    full = synth.SynthOrpheusFull(max_gen=28)
+    path = full.write_gguf(str(tmp_path / "orpheus.gguf"))
+    texts = ["hello the zebra", "a zebra", "the quick hello of the zebra there"]
+    os.environ["TTS_SNAC_NO_NOISE"] = "1"
+    try:
+        one = runner.Runner(path, sample=0)
+        many = runner.Runner(path, sample=0, max_seqs=4)
+        for kw in (dict(sample=0), dict(sample=1, top_k=8, seed=3)):
+            singles = []
+            for t in texts:
+                try:
+                    singles.append(one.generate(t, voice=b"zoe", **kw))
+                except runner.RunnerError as e:     # random weights may sample a text id where an audio id belongs
+                    assert "codebook size" in str(e)
+                    singles.append(None)
+            if any(s is None for s in singles):
+                continue
+            batch = many.generate_batch(texts, voice=b"zoe", **kw)
+            assert len(batch) == 3
+            for s, b in zip(singles, batch):
+                assert np.array_equal(s, b)
+        one.close(); many.close()
+    finally:
+        del os.environ["TTS_SNAC_NO_NOISE"]

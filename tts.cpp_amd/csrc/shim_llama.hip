@@ -31,6 +31,9 @@ extern "C" tts_hip_ctx *tts_hip_orpheus_create(int device, const tts_hip_orpheus
     if (!getenv("TTS_HIP_Q4_NATIVE")) c->q4_native = true;
     if (!getenv("TTS_HIP_LLAMA_GRAPH")) c->llama_graph = true;
     if (c->lm.rope_base == 0.0f) c->lm.rope_base = 500000.0f;
+    // lock-step utterances (5 .. 64 rows per step): the rows are quantised once (quant_rows_q8_kernel), not by every 16-feature workgroup again — at 8 rows
+    // of width 3072 a workgroup read 98 KB of fp32 rows beside its 49 KB of weights (4.11 -> 3.35 ms per step, profiles/r06/orpheus_batch_call2.txt)
+    if (c->lm.max_seqs > 4) c->q_fuse_max = 4;
     return c;
 }
 

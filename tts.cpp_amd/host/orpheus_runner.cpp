@@ -81,6 +81,8 @@ orpheus_runner::orpheus_runner(const orpheus_hparams & hp_, bpe_tokenizer * tok,
     d.hidden_size = hp.hidden_size; d.n_layers = hp.n_layers; d.n_attn_heads = hp.n_attn_heads; d.n_kv_heads = hp.n_kv_attn_heads;
     d.head_dim = hp.head_size; d.vocab_size = hp.vocab_size;
     d.n_ctx = hp.max_context_length + hp.max_generation_size;   // orpheus_kv_cache_init, model.cpp:176-177
+    max_seqs = std::min<uint32_t>(std::max<uint32_t>(1, tts_load_max_seqs()), 64);
+    d.max_seqs = max_seqs;
     lm = tts_hip_orpheus_create(device, &d);
     if (!lm) TTS_ABORT("tts_hip_orpheus_create failed: %s\n", tts_hip_last_error());
     tts_hip_snac_desc s{};
@@ -193,9 +195,16 @@ void orpheus_runner::generate(const char * sentence, tts_response & output, cons
             batch.assign(1, out.back());
         }
     }
+    decode_audio(out, pcm);
+    output.data = pcm.empty() ? nullptr : pcm.data();
+    output.n_outputs = pcm.size();
+}
+
+// the 7-ids-per-frame stream -> SNAC levels -> audio (model.cpp:358-376, snac_runner::run)
+void orpheus_runner::decode_audio(const std::vector<uint32_t> & out, std::vector<float> & audio) {
+    audio.clear();
     if (out.size() >= hp.max_generation_size)
         fprintf(stdout, "Warning: generation hit its max default length. The generated audio may not contain the entire prompt.\n");
-
     const std::vector<std::vector<uint32_t>> levels = prepare_output_tokens(out);
     const uint32_t T = (uint32_t) levels[2].size();   // finest level: 4 ids per 7-id chunk (snac_runner::run :181)
     if (T == 0) return;
@@ -209,8 +218,52 @@ void orpheus_runner::generate(const char * sentence, tts_response & output, cons
         noise.resize(noise_len);
         for (auto & v : noise) v = noise_dist(noise_engine);
     }
-    pcm.assign((size_t) T * hp.snac_up, 0.0f);
-    hip_check(tts_hip_snac_decode(snac, codes.data(), T, noise.empty() ? nullptr : noise.data(), pcm.data()), "tts_hip_snac_decode");
-    output.data = pcm.data();
-    output.n_outputs = pcm.size();
+    audio.assign((size_t) T * hp.snac_up, 0.0f);
+    hip_check(tts_hip_snac_decode(snac, codes.data(), T, noise.empty() ? nullptr : noise.data(), audio.data()), "tts_hip_snac_decode");
+}
+
+// n utterances in lock-step on the device: one cache slot and one row of the forward per utterance (the reference: one worker and one model copy per
+// concurrent request, examples/server/server.cpp:225-321).  Every utterance gets the ids a generate() call of its own would produce — the sampler is
+// reset per utterance exactly as generate() does, so with config.sample every utterance draws the same uniform sequence its own call would —
+// and the codec then runs utterance by utterance in order (the noise engine is never reseeded: the draws follow the order of sequential calls).
+void orpheus_runner::generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs, const generation_configuration & config) {
+    const uint32_t n = (uint32_t) sentences.size();
+    const bool dev_sample = config.sample && !getenv("TTS_HOST_LOOP") && config.top_p > 0.0f && config.top_k >= 1 && config.top_k <= 64 && (uint32_t) config.top_k < hp.vocab_size;
+    if (n <= 1 || max_seqs <= 1 || (config.sample && !dev_sample)) { tts_generation_runner::generate_batch(sentences, outputs, config); return; }
+    if (n > max_seqs) TTS_ABORT("generate_batch: %u utterances but the runner was loaded with max_seqs=%u (TTS_HIP_MAX_SEQS)\n", n, max_seqs);
+    if (!config.voice.empty() && std::find(orpheus_voices.begin(), orpheus_voices.end(), config.voice) == orpheus_voices.end())
+        TTS_ABORT("Voice '%s' is not a valid voice for Orpheus.\n", config.voice.c_str());
+    std::vector<uint32_t> prompts, lens(n);
+    for (uint32_t u = 0; u < n; u++) {
+        const std::vector<uint32_t> p = batch_from_sentence(sentences[u], config.voice);
+        if (p.size() > hp.max_context_length) TTS_ABORT("The prompt was too large for the default context window. Try splitting up or shortenning the prompt.\n");
+        lens[u] = (uint32_t) p.size();
+        prompts.insert(prompts.end(), p.begin(), p.end());
+        if (u + 1 == n) last_prompt_tokens = p;
+    }
+    const uint32_t M = hp.max_generation_size;
+    std::vector<uint32_t> toks((size_t) n * M), cnt(n);
+    std::vector<float> uni;
+    tts_hip_sampling sp{(uint32_t) config.top_k, config.top_p, config.temperature, config.repetition_penalty};
+    if (dev_sample) {
+        uni.resize((size_t) n * M);
+        for (uint32_t u = 0; u < n; u++) {   // generate() per utterance: same parameters, n_calls = 0, reset, then one draw per sampler call
+            smp.temperature = config.temperature; smp.repetition_penalty = config.repetition_penalty; smp.do_sample = true;
+            smp.top_k = (uint32_t) config.top_k; smp.top_p = config.top_p; smp.seed = config.seed; smp.n_calls = 0;
+            smp.reset();
+            for (uint32_t k = 0; k < M; k++) smp.draw_uniforms(&uni[(size_t) u * M + k]);
+        }
+    }
+    hip_check(tts_hip_orpheus_generate_batch(lm, n, prompts.data(), lens.data(), M, hp.stopping_token_id, dev_sample ? &sp : nullptr, dev_sample ? uni.data() : nullptr, toks.data(),
+                                             cnt.data()), "tts_hip_orpheus_generate_batch");
+    outputs.assign(n, tts_response{});
+    batch_store_.assign(n, {});
+    last_batch_tokens.assign(n, {});
+    for (uint32_t u = 0; u < n; u++) {
+        last_batch_tokens[u].assign(toks.begin() + (size_t) u * M, toks.begin() + (size_t) u * M + cnt[u]);
+        decode_audio(last_batch_tokens[u], batch_store_[u]);
+        outputs[u].data = batch_store_[u].empty() ? nullptr : batch_store_[u].data();
+        outputs[u].n_outputs = batch_store_[u].size();
+    }
+    last_output_tokens = last_batch_tokens[n - 1];
 }

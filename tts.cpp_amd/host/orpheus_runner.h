@@ -46,16 +46,22 @@ struct orpheus_runner final : tts_generation_runner {
     void assign_weight(const char * name, const gguf_tensor_view & tensor) override;
     void prepare_post_load() override;
     void generate(const char * sentence, tts_response & output, const generation_configuration & config) override;
+    // extension: lock-step utterances (tts_hip_orpheus_generate_batch): every utterance's audio is that of a generate() call of its own, made in order
+    void     generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs, const generation_configuration & config) override;
+    uint32_t batch_capacity() const override { return max_seqs; }
     std::vector<std::string_view> list_voices() override;
 
+    void decode_audio(const std::vector<uint32_t> & output_tokens, std::vector<float> & audio);   // prepare_output_tokens + SNAC
     // pieces exposed for tests
     std::vector<uint32_t>              batch_from_sentence(const std::string & sentence, const std::string & voice) const;  // model.cpp:341-356
     std::vector<std::vector<uint32_t>> prepare_output_tokens(const std::vector<uint32_t> & output_tokens) const;           // :358-376
     std::vector<uint32_t> last_prompt_tokens, last_output_tokens;
+    std::vector<std::vector<uint32_t>> last_batch_tokens;   // generate_batch: the ids of every utterance
 
     orpheus_hparams                hp;
     std::unique_ptr<bpe_tokenizer> tokenizer;
     sampler                        smp;
+    uint32_t                       max_seqs = 1;     // cache slots of the decoder context (tts_load_options::max_seqs, at most 64)
     tts_hip_ctx *                  lm = nullptr;     // Llama-3 decoder context
     tts_hip_ctx *                  snac = nullptr;   // SNAC codec context
     std::vector<float>             pcm, logits;
