@@ -60,10 +60,11 @@ struct Cfg { const char *name; int BM, BN, threads, S; size_t lds; kern_t k; };
 #define CFGK(BM, BN, WM, WN, S, WPE, KG) { #BM "x" #BN "/" #WM "x" #WN "/s" #S "w" #WPE "kg" #KG, BM, BN, WM * WN * KG * 64, S, std::max((size_t) S * (BM + BN) * 144, (size_t) (KG - 1) * (BM / 32) * (BN / 32) * 4096), qgemm_tile_kernel<BM, BN, WM, WN, S, EPI_STORE, WPE, false, false, KG> }
 #define CFG(BM, BN, WM, WN, S, WPE, PIPE) { #BM "x" #BN "/" #WM "x" #WN "/s" #S "w" #WPE "p" #PIPE, BM, BN, WM * WN * 64, S, (size_t) S * (BM + BN) * 144, BENCH_DBG ? (kern_t) qgemm_tile_kernel<BM, BN, WM, WN, S, EPI_STORE, WPE, PIPE, true> : (kern_t) qgemm_tile_kernel<BM, BN, WM, WN, S, EPI_STORE, WPE, PIPE, false> }
 static Cfg cfgs[] = {
-    CFG(64, 64, 2, 2, 2, 4, false), CFG(64, 64, 2, 2, 3, 3, true), CFG(128, 64, 4, 2, 2, 4, false), CFG(128, 128, 4, 4, 2, 4, true), CFG(128, 128, 2, 4, 2, 3, true),
-    CFGK(64, 64, 2, 2, 2, 4, 2), CFGK(64, 64, 2, 2, 2, 4, 4), CFGK(64, 64, 2, 2, 3, 4, 4), CFGK(128, 64, 4, 2, 2, 4, 2), CFGK(128, 128, 2, 4, 2, 4, 2), CFGK(64, 128, 2, 4, 2, 4, 2),
-    CFGK(128, 128, 4, 4, 2, 4, 1),
+    CFG(64, 64, 2, 2, 2, 4, false), CFG(64, 64, 2, 2, 3, 3, true), CFG(64, 64, 2, 2, 4, 2, true), CFG(128, 64, 4, 2, 2, 4, false), CFG(128, 128, 4, 4, 2, 4, true), CFG(128, 128, 2, 4, 2, 3, true),
+    CFG(128, 128, 2, 4, 3, 2, true), CFG(128, 128, 2, 4, 4, 2, true), CFG(256, 128, 4, 4, 2, 2, true),
+    CFGK(64, 64, 2, 2, 2, 4, 2), CFGK(64, 64, 2, 2, 2, 4, 4), CFGK(128, 128, 2, 4, 2, 4, 2),
 };
+
 
 
 

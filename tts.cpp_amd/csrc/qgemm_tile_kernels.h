@@ -65,7 +65,7 @@ struct QTileArgs {
     float *d_out;
     int ldq;
     long long *stamps;      // micro-benchmark only: per-phase shader-clock sums of every workgroup's wave 0 (wait + barrier, stage issue, compute, epilogue)
-    int dbg;                // micro-benchmark only (profiles/qgemm_bench.hip): 1 = no k loop, 2 = no epilogue stores, 4 = no scaling, 8 = no MFMA
+    int dbg;                // micro-benchmark only (profiles/qgemm_bench.hip): 1 = no k loop, 2 = no epilogue stores, 4 = no scaling, 8 = no MFMA, 16 = no LDS reads / compute at all (staging pipeline alone)
 };
 
 #define QT_MAGIC_I 0x4B400000
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64) __attribute__((amdgpu_waves_per_
         if (DBG && qa.stamps) { const long long t = __builtin_amdgcn_s_memtime(); t_wait += t - t0; t0 = t; }
         if (kt + S - 1 < n_kt) stage(nxt, kt + S - 1);
         if (DBG && qa.stamps) { const long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t0; t0 = t; }
-        compute(cur);
+        if (!(DBG && (qa.dbg & 16))) compute(cur);
         if (DBG && qa.stamps) { const long long t = __builtin_amdgcn_s_memtime(); t_comp += t - t0; t0 = t; }
         cur = cur + 1 == S ? 0 : cur + 1;
         nxt = nxt + 1 == S ? 0 : nxt + 1;

@@ -177,6 +177,7 @@ extern "C" int tts_hip_tune(tts_hip_ctx *c, const char *key, int v) {
     else if (k == "tile_deep") c->tile_deep = v;
     else if (k == "qtile_min_rows") c->qtile_min_rows = std::max(0, v);   // 0: quantised matrices stay on the 16-feature kernel (<= 256 rows per forward)
     else if (k == "qtile_shape") c->qtile_shape = v;
+    else if (k == "qtile_big") c->qtile_big = std::max(0, std::min(3, v));
     else if (k == "qtile_ks") c->qtile_ks = std::max(0, v);
     else if (k == "qtile_fuse") c->qtile_fuse = v != 0;
     else if (k == "gemv_stream") c->gemv_stream = v != 0;

@@ -334,7 +334,7 @@ static void choose_qtile(const tts_hip_ctx *c, int R, int N, int K, bool may_spl
     // hidden size at 1024 rows: 256 tiles) two k groups inside the workgroup (shape 4: eight waves) — the epilogue (residual add, cross-attention fold)
     // stays in the launch; the K = 4096 residual GEMM (fc2) additionally writes two split-K slabs the next LayerNorm folds
     const int tiles = ((R + 63) / 64) * ((N + 63) / 64);
-    int shape = tiles >= 512 ? 0 : 4, ks = 1;
+    int shape = tiles >= 512 ? c->qtile_big : 4, ks = 1;
     if (shape == 4 && may_split && K >= 2048 && K % 512 == 0) ks = 2;
     if (c->qtile_shape >= 0 && c->qtile_shape < N_QTILE_SHAPES) shape = c->qtile_shape;
     if (c->qtile_ks > 0 && may_split && K % (c->qtile_ks * 128) == 0) ks = c->qtile_ks;

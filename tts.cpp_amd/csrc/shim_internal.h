@@ -292,6 +292,7 @@ struct tts_hip_ctx {
     int aqt_set = 0;            // which set holds the blocks of aqt_src
     int qtile_min_rows = 65;    // tune("qtile_min_rows"): forwards with at least this many rows take the LDS-tiled integer GEMM; 0 = never (the 16-feature kernel, <= 256 rows)
     int qtile_shape = -1;       // tune("qtile_shape"): tile shape index for every tiled integer GEMM (tuning / tests)
+    int qtile_big = 0;          // tune("qtile_big"): tile shape of the GEMMs with at least two 64 x 64 tiles per CU (0: 64 x 64; 1: 128 x 128; 2: 128 x 64; 3: 64 x 128)
     int qtile_ks = 0;           // tune("qtile_ks"): k slices of the residual GEMMs (tuning / tests)
     bool qtile_fuse = true;     // tune("qtile_fuse")=0: LayerNorm, GELU and the attentions hand fp32 rows to a quantising launch of their own instead of writing Q8_0 blocks themselves
     const void *aqt_src = nullptr; // activation rows whose Q8_0 blocks already sit in aq / adT
