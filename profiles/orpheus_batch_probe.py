@@ -8,10 +8,12 @@ cfg = synth.orpheus_3b(ctx=1024, weight_type=gguf.Q4_0)
 rng = np.random.default_rng(7)
 tensors, per_layer = sb.orpheus_tensors(cfg, rng)
 NO_STOP = 0xFFFFFFFF
-for B in (8,):
-    for tune in ({"q_fuse_max": 4},):
+BS = [int(x) for x in os.environ.get("PROBE_B", "8,16").split(",")]
+TUNES = [dict(kv.split("=") for kv in t.split("+")) for t in os.environ.get("PROBE_TUNE", "q_stream=0,q_stream=1").split(",")]
+for B in BS:
+    for tune in TUNES:
         eng = hip.OrpheusEngine(cfg, max_seqs=B)
-        for k, v in tune.items(): eng.tune(k, v)
+        for k, v in tune.items(): eng.tune(k, int(v))
         eng.load(sb._Model(cfg, tensors))
         prompts = [rng.integers(0, cfg.vocab, 32).astype(np.uint32) for _ in range(B)]
         eng.generate_batch(prompts, 8, NO_STOP)

@@ -105,6 +105,50 @@ def test_orpheus_3b_shapes_few_row_calls_take_the_fused_projections():
     eng.close()
 
 
+@pytest.mark.parametrize("wtype", [gguf.Q4_0, gguf.Q8_0])
+def test_orpheus_3b_shapes_5_to_16_rows_take_the_weight_streaming_integer_gemm(wtype):
+    """5 .. 16 rows on GGUF-quantised matrices at the 3B widths (round 6: qgemv_stream_kernel — every projection and, for lock-step utterances, the
+    LM head with its 5001 = 312 x 16 + 9 features): K slices of 512 / 768 / 1536 columns as slabs folded by rope / silu * up / the next rms norm
+    (3072-wide rows: eight slabs per round trip), 8- and 16-row LDS images.  decode() pieces of 5, 8, 9 and 16 rows against the oracle fed the same
+    pieces, then lock-step steps of 6 and 13 utterances: every row's logits against the oracle's for that utterance's history; with
+    tune("q_stream") = 0 (qgemm16_kernel) the same calls stay inside the same bound and the arg-max tokens agree wherever the oracle's margin allows."""
+    model = synth.build_orpheus(synth.orpheus_3b(layers=2, vocab=5001, ctx=64, weight_type=wtype))
+    cfg = model.cfg
+    o = orc.OrpheusOracle(model, act_mode=1)
+    ids = np.random.default_rng(11).integers(0, 5001, 38).astype(np.uint32)
+    pieces = (ids[:5], ids[5:13], ids[13:22], ids[22:38])
+    refs, p = [], 0
+    for piece in pieces:
+        refs.append(o.decode(piece, p)); p += len(piece)
+    for qs in (31, 0):
+        eng = hip.OrpheusEngine(cfg)
+        eng.tune("q_stream", qs)
+        eng.load(model)
+        p = 0
+        for piece, ref in zip(pieces, refs):
+            lg, tok = eng.decode(piece, p)
+            assert relerr(lg, ref) < 3e-2, (qs, p)
+            assert ref[tok] >= ref.max() - 2 * 3e-2 * np.abs(ref).max(), (qs, p)
+            p += len(piece)
+        eng.close()
+    # lock-step utterances: B rows of one step, every row with its own cache slot and position
+    for B in (6, 13):
+        rng = np.random.default_rng(B)
+        prompts = [rng.integers(0, 5001, 2 + (u % 5)).astype(np.uint32) for u in range(B)]
+        eng = hip.OrpheusEngine(cfg, max_seqs=B)
+        eng.load(model)
+        first = eng.generate_batch(prompts, 1, stop_id=cfg.vocab + 5)          # fills the slots' caches, returns every utterance's first id
+        lg, tok = eng.step_batch(list(range(B)), [int(f[0]) for f in first], [len(q) for q in prompts])
+        assert lg.shape == (B, 5001)
+        for u in (0, B // 2, B - 1):
+            ob = orc.OrpheusOracle(model, act_mode=1)
+            ob.decode(prompts[u], 0)
+            ref = ob.decode([int(first[u][0])], len(prompts[u]))
+            assert relerr(lg[u], ref) < 3e-2, (B, u)
+        assert tok.tolist() == [int(l.argmax()) for l in lg]
+        eng.close()
+
+
 def test_orpheus_3b_shapes_captured_step_with_split_attention():
     """The captured greedy step at the 3B widths (Q4_0) cuts the keys of every (row, head) into eight slices (attn_gqa_split_kernel; at these
     positions most of them are empty) and attn_gqa_combine_kernel merges them with every slice requested at once (round 4 kept two more places
@@ -350,13 +394,25 @@ def test_orpheus_lockstep_batch_equals_single_sequence_generations(n_utt, wtype)
     server.cpp:225-321): tts_hip_orpheus_generate_batch — prompts of different lengths in their own cache slots, one row per live utterance, finished
     utterances leaving the step — gives every utterance the ids its own one-sequence generation gives, token for token, greedy and with the device sampler
     (own uniforms and repetition state per utterance); the first utterance's ids are also the oracle's.  3 rows take the streaming 1-4 row kernels,
-    7 rows the MFMA workgroups."""
+    7 rows the weight-streaming integer GEMM (qgemv_stream_kernel, round 6; the 5- and 7-row prompts of either engine go through it as well).
+    The reference is the one-sequence EAGER loop (TTS_HIP_LLAMA_GRAPH=0): its rows meet the same kernels as a lock-step row, so the ids are equal by
+    construction.  The captured one-sequence step attends with attn_gqa_wave_kernel, another association of the same softmax ("agrees to rounding"):
+    with Q4_0 matrices one ulp there can flip a Q8_0 code of the next activation row, so against the captured step only the greedy ids are compared
+    (equal on these seeds; captured == eager is test_orpheus_greedy_through_the_captured_step's subject)."""
     model = synth.build_orpheus(synth.orpheus_tiny(weight_type=wtype))
     cfg = model.cfg
     rng = np.random.default_rng(10 * n_utt + wtype)
     prompts = [rng.integers(0, cfg.vocab, 3 + 2 * (u % 4)).astype(np.uint32) for u in range(n_utt)]
     max_new = 14
-    single = hip.OrpheusEngine(cfg)
+    captured = hip.OrpheusEngine(cfg)
+    captured.load(model)
+    cap_greedy = [captured.generate_greedy(p, max_new, stop_id=cfg.vocab + 5) for p in prompts]
+    captured.close()
+    os.environ["TTS_HIP_LLAMA_GRAPH"] = "0"
+    try:
+        single = hip.OrpheusEngine(cfg)
+    finally:
+        del os.environ["TTS_HIP_LLAMA_GRAPH"]
     single.load(model)
     ref_greedy = [single.generate_greedy(p, max_new, stop_id=cfg.vocab + 5) for p in prompts]
     stop = int(ref_greedy[1][5])                                  # a stopping token that some utterances meet early and others never
@@ -368,6 +424,7 @@ def test_orpheus_lockstep_batch_equals_single_sequence_generations(n_utt, wtype)
     eng.load(model)
     got = eng.generate_batch(prompts, max_new, stop_id=cfg.vocab + 5)
     assert [g.tolist() for g in got] == [r.tolist() for r in ref_greedy]
+    assert [g.tolist() for g in got] == [r.tolist() for r in cap_greedy]
     got = eng.generate_batch(prompts, max_new, stop_id=stop)
     assert [g.tolist() for g in got] == [r.tolist() for r in ref_stop]
     assert len({len(g) for g in got}) > 1                          # the utterances really finish at different steps

@@ -175,3 +175,131 @@ __global__ __launch_bounds__(NWV * 64) void gemv_stream_kernel(GemmArgs a, Strea
         step(w1, w0);
     }
 }
+
+// ================================================================================================================================
+// qgemv_stream_kernel — the same schedule for GGUF-quantised matrices and 5 .. 16 rows (round 6: lock-step Orpheus utterances, orpheus/model.cpp:194-283
+// for a handful of rows).  qgemm16_kernel is one-shot per 16 features like gemm16_kernel (K / 256 waves meet in LDS) and streamed the int8 expansion of
+// the 3B matrices at ~0.15 of HBM at 8 rows (profiles/r06/orpheus_batch_call2.txt); the streaming Q4_0 kernels end at 4 rows.  Here:
+//   * a workgroup is bound to one K slice and keeps the Q8_0 rows of that slice in LDS (codes int8 [RS][KS], 16-byte pieces XOR-swizzled by the row so
+//     that the 16 rows of a fragment read land in 16 different bank groups; block scales float [RS][KS / 32]), taken from the producer's blocks
+//     (aq [R][K], ad [R][K / 32]: rms norm, attention, silu * up write them) — no conversion here;
+//   * a wave walks (16-feature tile, 256-column chunk) pairs: 4 x 16-byte code loads + 4 x 16-byte scale loads per lane and chunk — 64 contiguous bytes
+//     per matrix row and instruction, as in gemv_stream_kernel (8-byte loads, 32 bytes per row: 2.6 TB/s at best, profiles/r06/qstream_bench_r8.txt) —
+//     DEPTH - 1 pairs' loads in flight ahead of the MFMAs;
+//   * 16 bytes per lane = v_mfma_i32_16x16x64_i8, whose 64 columns are TWO quantisation blocks (lane groups 0, 1 hold block 0, groups 2, 3 block 1):
+//     two MFMAs per span, the activation operand of the other block's lane groups read from a row of zeros, give the two exact block dots;
+//     then acc += (float) sumi * (d_w * d_a) — qgemm16_kernel's arithmetic (ggml_vec_dot_q*_q8_0); accumulation across the chunks of a tile in
+//     registers, no cross-wave reduction;
+//   * K slices write fp32 slabs (slab kz of `out`, slab_stride floats apart) that the consumer folds in slab order (llama_rope_kv_kernel, silu_mul_kernel,
+//     rms_fold_rows_kernel), like gemv_stream_kernel.  N need not be a multiple of 16 (the LM head): a last tile re-reads feature N - 1 and stores nothing for it.
+// ================================================================================================================================
+template <int NWV, int DEPTH = 2>
+__global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, StreamMap sm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GemmArgs &a = qa.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int kz = (int) blockIdx.x % sm.ks, wg_in = (int) blockIdx.x / sm.ks, nwg_in = (int) gridDim.x / sm.ks;
+    const int KS = sm.kslice, k0 = kz * KS, nb = a.K >> 5, nbs = KS >> 5;
+    const int RS = a.R <= 8 ? 8 : 16;   // rows kept in LDS; B-operand columns >= RS repeat rows (never stored)
+    int8_t *xs = (int8_t *) smem;                    // [RS + 1][KS]: row RS is zeros
+    float *sd = (float *) (smem + (size_t) (RS + 1) * KS);
+
+    const int tiles = (a.N + 15) >> 4, nc = KS >> 8;
+    const int tstep = nwg_in * NWV;
+    const int8_t *wbase = (const int8_t *) a.W + k0 + g * 16;
+    struct WSet { int4v w[4]; half8 d[4]; };
+    auto loadw = [&](WSet &s, int tile, int chunk) __attribute__((always_inline)) {
+        const int8_t *p = wbase + (int64_t) min(tile * 16 + li, a.N - 1) * a.K + chunk * 256;
+#pragma unroll
+        for (int c = 0; c < 4; c++) s.w[c] = __builtin_nontemporal_load((const int4v *) (p + c * 64));
+#pragma unroll
+        for (int e = 0; e < 4; e++) s.d[e] = __builtin_nontemporal_load((const half8 *) (qa.wd + (int64_t) min(tile * 16 + g * 4 + e, a.N - 1) * nb + (k0 >> 5) + chunk * 8));
+    };
+    // ---- stage this slice of the Q8_0 rows: the staging requests first, the first weight sets right behind them (vmcnt retires in issue order) ----
+    constexpr int NTH = NWV * 64;
+    const int cvec = KS >> 4, ctot = RS * cvec, stot = RS * nbs;   // 16-byte code vectors, block scales
+    constexpr int PRE = NWV <= 4 ? 4 : 2;
+    int4v craw[PRE];
+    float sraw[PRE];
+#pragma unroll
+    for (int j = 0; j < PRE; j++) {
+        const int i = min(tid + j * NTH, ctot - 1), r = min(i / cvec, a.R - 1), cv = i % cvec;
+        craw[j] = *(const int4v *) (qa.aq + (int64_t) r * a.K + k0 + cv * 16);
+        const int is = min(tid + j * NTH, stot - 1), rs = min(is / nbs, a.R - 1), bs = is % nbs;
+        sraw[j] = qa.ad[(int64_t) rs * nb + (k0 >> 5) + bs];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the wave's (tile, chunk) pairs in order; lt / lch: the pair whose loads go out next, t / ch: the pair computed next
+    int t = wg_in * NWV + wave, ch = 0, lt = t, lch = 0;
+    auto advance = [&](int &tt, int &cc) __attribute__((always_inline)) { if (++cc == nc) { cc = 0; tt += tstep; } };
+    WSet w[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; d++) {   // DEPTH - 1 sets in flight before the first MFMA (clamped addresses past the end: never used)
+        loadw(w[d], min(lt, tiles - 1), lch);
+        advance(lt, lch);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // piece cv of row r sits at piece cv ^ (r & 15) of the row's 256-byte group
+#pragma unroll
+    for (int j = 0; j < PRE; j++) {
+        const int i = tid + j * NTH;
+        if (i < ctot) *(int4v *) (xs + (size_t) (i / cvec) * KS + (((i % cvec) ^ ((i / cvec) & 15)) << 4)) = craw[j];
+        if (i < stot) sd[i] = sraw[j];
+    }
+    for (int i = tid + PRE * NTH; i < ctot; i += NTH) {
+        const int r = min(i / cvec, a.R - 1), cv = i % cvec;
+        *(int4v *) (xs + (size_t) (i / cvec) * KS + ((cv ^ ((i / cvec) & 15)) << 4)) = *(const int4v *) (qa.aq + (int64_t) r * a.K + k0 + cv * 16);
+    }
+    for (int i = tid + PRE * NTH; i < stot; i += NTH) {
+        const int rs = min(i / nbs, a.R - 1), bs = i % nbs;
+        sd[i] = qa.ad[(int64_t) rs * nb + (k0 >> 5) + bs];
+    }
+    for (int i = tid; i < cvec; i += NTH) *(int4v *) (xs + (size_t) RS * KS + i * 16) = (int4v){0, 0, 0, 0};
+    __syncthreads();
+
+    const int row = li & (RS - 1);
+    // operand of the even block of a span (lane groups 0, 1 hold its columns) and of the odd block (groups 2, 3): the other groups read zeros
+    const int8_t *x_even = xs + (size_t) (g < 2 ? row : RS) * KS, *x_odd = xs + (size_t) (g < 2 ? RS : row) * KS;
+    int off[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) off[c] = ((c * 4 + g) ^ (row & 15)) << 4;
+    const float *sb = sd + row * nbs;
+    float4v acc = {0.f, 0.f, 0.f, 0.f};
+    auto step = [&](WSet &cur, WSet &nxt) __attribute__((always_inline)) {
+        if (lt < tiles) loadw(nxt, lt, lch);
+        advance(lt, lch);
+        const float4v da0 = *(const float4v *) (sb + ch * 8), da1 = *(const float4v *) (sb + ch * 8 + 4);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int4v zero = {0, 0, 0, 0};
+            const int4v ze = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.w[c], *(const int4v *) (x_even + ch * 256 + off[c]), zero, 0, 0, 0);   // exact block dots
+            const int4v zo = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.w[c], *(const int4v *) (x_odd + ch * 256 + off[c]), zero, 0, 0, 0);
+            const float dae = c < 2 ? da0[2 * c] : da1[2 * c - 4], dao = c < 2 ? da0[2 * c + 1] : da1[2 * c - 3];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                acc[e] += (float) ze[e] * ((float) cur.d[e][2 * c] * dae);
+                acc[e] += (float) zo[e] * ((float) cur.d[e][2 * c + 1] * dao);
+            }
+        }
+        if (ch == nc - 1) {
+            const int n0 = t * 16 + g * 4;
+            float *o = a.out + (int64_t) kz * a.slab_stride + (int64_t) li * a.ldo + n0;
+            if (li < a.R) {
+                if (n0 + 3 < a.N) *(float4v *) o = acc;
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; e++) if (n0 + e < a.N) o[e] = acc[e];
+            }
+            acc = (float4v){0.f, 0.f, 0.f, 0.f};
+        }
+        advance(t, ch);
+    };
+    while (t < tiles) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            if (d && t >= tiles) break;
+            step(w[d], w[(d + DEPTH - 1) % DEPTH]);
+        }
+    }
+}

@@ -72,6 +72,22 @@ static __global__ __launch_bounds__(256) void rms_fold_rows_kernel(float *x, int
                             if (tid + k * 256 < H) v[k] += t[q][k];
                 }
             }
+            if (H > 2048 && H <= 3072 && n_parts > 2) {
+                // eight slabs of a 3072-wide row per round trip (round 6: the integer streaming GEMM leaves up to 16 K slices of the o / down projections;
+                // one slab per trip was 8.2 us per launch, 57 launches per lock-step Orpheus step); a slab beyond n_parts re-reads the last one, never added
+                for (; p < n_parts; p += 8) {
+                    float t[8][12];
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+#pragma unroll
+                        for (int k = 0; k < 12; k++) t[q][k] = parts[min(p + q, n_parts - 1) * slab_stride + (int64_t) r * H + min(tid + k * 256, H - 1)];
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+#pragma unroll
+                        for (int k = 0; k < 12; k++)
+                            if (p + q < n_parts && tid + k * 256 < H) v[k] += t[q][k];
+                }
+            }
             for (; p < n_parts; p++) {
                 float t[16];
 #pragma unroll

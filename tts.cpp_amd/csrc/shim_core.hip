@@ -181,6 +181,7 @@ extern "C" int tts_hip_tune(tts_hip_ctx *c, const char *key, int v) {
     else if (k == "qtile_ks") c->qtile_ks = std::max(0, v);
     else if (k == "qtile_fuse") c->qtile_fuse = v != 0;
     else if (k == "gemv_stream") c->gemv_stream = v != 0;
+    else if (k == "q_stream") c->q_stream = v == 1 ? 31 : (int) v;
     else if (k == "q_fuse_max") c->q_fuse_max = std::max(0, std::min(16, v));
     else if (k == "q4_lds") c->q4_lds = v != 0;
     else if (k == "q4_rope") c->q4_rope = v != 0;

@@ -398,6 +398,49 @@ static int run_qtile(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro
     return prof_end(c);
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight-streaming integer GEMM for 5 .. 16 rows (qgemv_stream_kernel, gemv_stream_kernels.h): K slices -> fp32 slabs the consumer folds
+// ------------------------------------------------------------------------------------------------
+// K slices for an [N][K] quantised matrix: as many 256-column chunks per slice as keep about 4096 (tile, slice) items and the consumer's slab budget;
+// 0 = the shape does not go through the kernel
+static size_t qstream_lds(int R, int kslice) { return (size_t) ((R <= 8 ? 8 : 16) + 1) * kslice + (size_t) (R <= 8 ? 8 : 16) * (kslice / 32) * 4; }
+// K slices of the weight-streaming integer GEMM for R rows on w (0: the shape does not qualify).  Measured at Orpheus-3B's shapes (profiles/qstream_bench.hip,
+// profiles/r06/qstream_bench_r8d.txt): ~2000 (tile, slice) items fill the chip; a 192-tile projection prefers fewer, longer waves unless K is long.
+int qstream_slices(const tts_hip_ctx *c, const W &w, int R, int max_slabs) {
+    if (!c->q_stream || w.type != TTS_HIP_Q8I || R < 5 || R > 16 || w.K % 256 || (c->d.flags & (TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q))) return 0;
+    const int tiles = ((int) w.N + 15) / 16, chunks = (int) w.K / 256;
+    const int want = std::min(max_slabs, tiles >= 4096 ? 1 : tiles >= 1024 ? 2 : tiles >= 256 ? 6 : w.K >= 8192 ? 16 : 4);
+    int ks = 0;
+    for (int k : {1, 2, 3, 4, 6, 8, 12, 16})
+        if (k <= want && chunks % k == 0) ks = k;
+    for (int k : {2, 3, 4, 6, 8, 12, 16})   // the rows' slice must fit LDS
+        if (qstream_lds(R, (int) w.K / ks) > 64 * 1024 && k > ks && k <= max_slabs && chunks % k == 0) ks = k;
+    return qstream_lds(R, (int) w.K / ks) > 64 * 1024 ? 0 : ks;
+}
+// activations: the Q8_0 blocks in c->aq / c->ad ([R][K], [R][K / 32]); slab kz of `out` receives the partial products of K slice kz
+int launch_qstream(tts_hip_ctx *c, int kclass, const W &w, int R, float *out, int ldo, int64_t slab_stride, int ks) {
+    QGemmArgs qa{};
+    qa.g.W = c->arena + w.off; qa.g.K = (int) w.K; qa.g.N = (int) w.N; qa.g.R = R; qa.g.out = out; qa.g.ldo = ldo; qa.g.slab_stride = slab_stride;
+    qa.wd = (const _Float16 *) (c->arena + w.soff);
+    qa.aq = c->aq; qa.ad = c->ad;
+    const StreamMap sm{ks, (int) w.K / ks};
+    const int tiles = ((int) w.N + 15) / 16, items = tiles * ks;
+    const int nwv = tiles >= 256 ? 8 : 4;
+    int grid = ((items + nwv - 1) / nwv + ks - 1) / ks * ks;
+    grid = std::min(grid, 1024 / ks * ks);   // beyond four workgroups per CU the waves walk several tiles (the LM head)
+    const size_t lds = qstream_lds(R, sm.kslice);
+    CHK(prof_begin(c, kclass, (double) w.K * w.N * (1.0 + 2.0 / 32) + (double) R * w.K * 1.125 + (double) ks * R * w.N * 4, 2.0 * R * (double) w.K * w.N));
+    static std::atomic<uint64_t> attr{0};
+    if (attr_needed(attr, c->device)) {
+        HIPCHK(hipFuncSetAttribute((const void *) qgemv_stream_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) qgemv_stream_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    if (nwv == 8) hipLaunchKernelGGL((qgemv_stream_kernel<8, 2>), dim3(grid), dim3(512), lds, c->stream, qa, sm);
+    else hipLaunchKernelGGL((qgemv_stream_kernel<4, 2>), dim3(grid), dim3(256), lds, c->stream, qa, sm);
+    HIPCHK(hipGetLastError());
+    return prof_end(c);
+}
+
 int run_qgemm(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro, int epi) {
     if (pro == PRO_F16) return set_err("run_qgemm: fp16 activations are never produced for a quantised consumer");
     if (qtile_ok(c, w, a, pro)) return run_qtile(c, kclass, w, a, pro, epi, c->qtile_out);
@@ -1775,6 +1818,18 @@ extern "C" int64_t tts_hip_debug_read(tts_hip_ctx *c, const char *what, float *o
         }
         if (hipMemcpy(out, c->x, R * c->H * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("copy failed"); return -1; }
         return (int64_t) (R * c->H);
+    }
+    if (c->has_llama && w == "l_logits") {   // the logits row the last Llama step left (row 0 of l_logits)
+        const size_t n = std::min(max_floats, (size_t) c->l_V);
+        if (hipMemcpy(out, c->l_logits, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("copy failed"); return -1; }
+        return (int64_t) n;
+    }
+    if (c->has_llama && w.size() > 4 && w[0] == 'l' && w[1] == '_' && (w[2] == 'k' || w[2] == 'v') && w[3] == ':') {   // "l_k:<layer>": slot 0's cache rows of a layer
+        const int layer = atoi(w.c_str() + 4);
+        if (layer < 0 || layer >= c->L) { set_err("debug_read(%s): bad layer", what); return -1; }
+        const size_t per = (size_t) c->lm.n_ctx * c->l_kvH, n = std::min(max_floats, per);
+        if (hipMemcpy(out, (w[2] == 'k' ? c->l_kc : c->l_vc) + (size_t) layer * per, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("copy failed"); return -1; }
+        return (int64_t) n;
     }
     if (w.size() > 2 && (w[0] == 'k' || w[0] == 'v') && w[1] == ':') {
         int layer = 0, seq = 0;

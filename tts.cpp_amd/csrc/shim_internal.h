@@ -144,6 +144,8 @@ struct tts_hip_ctx {
     bool q4_silu = true;        // tune("q4_silu")=0: gate|up, silu * up and the down projection stay three launches
     bool q4_rope = true;        // tune("q4_rope")=0: the Llama q/k/v projection keeps its separate rope + cache-append launch
     bool q4_lds = true;         // tune("q4_lds")=0: Q4_0 row products stay on gemv_q4_rows_kernel (one feature per wave, activations from L2)
+    int q_stream = 31;          // tune("q_stream"): which quantised projections of a 5 .. 16 row Llama step take qgemv_stream_kernel instead of qgemm16_kernel
+                                // (bits: 1 qkv, 2 o, 4 gate|up, 8 down, 16 head; 0 none, 1 = all)
     bool gemv_stream = true;    // tune("gemv_stream")=0: <= 16-row F16 GEMMs of the Dia step stay on gemm16_kernel (gemv_stream_kernels.h otherwise)
     bool llama_graph = false;   // TTS_HIP_LLAMA_GRAPH (default on for Orpheus contexts): the greedy step as one captured graph
     bool gemv_rows = false;     // TTS_HIP_GEMV_ROWS (default on for Orpheus contexts): 1..4 rows go through the streaming one-wave-per-feature kernels (gemv_kernels.h)
@@ -161,6 +163,7 @@ struct tts_hip_ctx {
     uint32_t *l_seq = nullptr, *l_btok = nullptr, *l_bpi = nullptr, *l_bsmp = nullptr;   // lock-step utterances: row -> cache slot, selected tokens [rows], arg-max partials, sampler state [utterance][3]
     float *l_bpv = nullptr;
     int l_pending = 0;
+    int64_t l_pstride = 0;   // floats between the pending slabs (0: RMAX * H)
     // ---- Dia context (tts_hip_dia_create) ----
     bool has_dia = false;
     tts_hip_dia_desc dia{};

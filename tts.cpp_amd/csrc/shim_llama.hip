@@ -127,15 +127,31 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
     const float theta_scale = powf(c->lm.rope_base, -2.0f / (float) HD);
     c->l_pending = 0;
     // the streaming integer GEMV of 1..4 rows takes its Q8_0 activation blocks from the producing kernel where there is one
-    auto q_for = [&](const W &w, int rows) {
+    enum { QS_QKV = 1, QS_O = 2, QS_GU = 4, QS_DOWN = 8, QS_HEAD = 16 };   // bits of tune("q_stream")
+    auto slices = [&](const W &w, int bit, int rows, int max_slabs) { return (c->q_stream & bit) ? qstream_slices(c, w, rows, max_slabs) : 0; };
+    auto q_for = [&](const W &w, int rows, int bit) {
+        if (slices(w, bit, rows, 16)) return true;   // 5 .. 16 rows: the weight-streaming integer GEMM takes the producer's blocks as well
         return c->gemv_rows && rows <= 4 && w.type == TTS_HIP_Q8I && !(c->d.flags & (TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q)) && w.K % 32 == 0;
     };
-    auto rms = [&](size_t w_off, int rows, float *x, float *y, const W *next) {
-        const bool q = next && q_for(*next, rows);
+    // 5 .. 16 rows on a quantised matrix: qgemv_stream_kernel — K slices as fp32 slabs the consumer folds.  Returns the slab count (0: the shape does not
+    // qualify, the caller takes the MFMA workgroups), < 0 on error.  A: the fp32 rows whose Q8_0 blocks the producer left in aq / ad (quantised here otherwise).
+    auto qstream = [&](const W &w, int bit, const float *A, int K, float *out, int ldo, int64_t slab_stride, int max_slabs) -> int {
+        const int ks = slices(w, bit, n, max_slabs);
+        if (!ks) return 0;
+        if (c->aq_src != A) {
+            hipLaunchKernelGGL(quant_rows_q8_kernel, dim3((K / 32 + 7) / 8, n), dim3(256), 0, c->stream, A, K, K, c->aq, c->ad, n);
+            if (hipGetLastError() != hipSuccess) { set_err("quant_rows_q8_kernel launch failed"); return -1; }
+        }
+        c->aq_src = nullptr;
+        if (launch_qstream(c, TTS_HIP_K_GEMM_OTHER, w, n, out, ldo, slab_stride, ks) != 0) return -1;
+        return ks;
+    };
+    auto rms = [&](size_t w_off, int rows, float *x, float *y, const W *next, int bit = 0) {
+        const bool q = next && q_for(*next, rows, bit);
         hipLaunchKernelGGL(rms_fold_rows_kernel, dim3(rows), dim3(256), 0, c->stream, x, H, f32(w_off), y, rows, 1e-5f,
-                           c->l_pending ? (const float *) c->l_parts : (const float *) nullptr, c->l_pending, (int64_t) c->RMAX * H,
+                           c->l_pending ? (const float *) c->l_parts : (const float *) nullptr, c->l_pending, c->l_pstride ? c->l_pstride : (int64_t) c->RMAX * H,
                            q ? c->aq : (int8_t *) nullptr, q ? c->ad : (float *) nullptr);
-        c->l_pending = 0;
+        c->l_pending = 0; c->l_pstride = 0;
         c->aq_src = q ? y : nullptr;
         return hipGetLastError() == hipSuccess ? 0 : set_err("rms_fold_rows_kernel launch failed");
     };
@@ -143,7 +159,7 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
         const auto &y = c->l_layers[l];
         float *kc = c->l_kc + (size_t) l * NCTX * c->l_kvH, *vc = c->l_vc + (size_t) l * NCTX * c->l_kvH;
         const size_t qkv_lds = (size_t) n * H + (size_t) n * (H / 32) * 4;
-        const bool qkv_fused = !row_seq && c->q4_rope && c->q4_lds && y.qkv.q4 && q_for(y.qkv, n) && HD == 128 && H % 512 == 0 && qkv_lds <= 64 * 1024 && !c->prof;
+        const bool qkv_fused = !row_seq && n <= 4 && c->q4_rope && c->q4_lds && y.qkv.q4 && q_for(y.qkv, n, QS_QKV) && HD == 128 && H % 512 == 0 && qkv_lds <= 64 * 1024 && !c->prof;
         // the rms norm inside the consuming projection's staging (stage_rms_q8): no slabs may be pending, the row is held in registers
         const bool rms_fused = c->q4_rms && !c->l_pending && H <= 4096;
         if (qkv_fused && rms_fused) {
@@ -156,7 +172,7 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
             HIPCHK(hipGetLastError());
             c->aq_src = nullptr;
         } else if (qkv_fused) {
-            CHK(rms(y.in_norm, n, c->l_x, c->l_xn, &y.qkv));
+            CHK(rms(y.in_norm, n, c->l_x, c->l_xn, &y.qkv, QS_QKV));
             // the projection, the rope of q and k and the cache append in one launch (gemv_q4_qkv_rope_kernel)
             QGemmArgs qa{};
             qa.g.W = c->arena + y.qkv.off; qa.g.K = H; qa.g.N = QKV; qa.g.R = n; qa.g.out = c->l_qkv; qa.g.ldo = QKV;
@@ -166,20 +182,27 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
             HIPCHK(hipGetLastError());
             c->aq_src = nullptr;
         } else {
-            CHK(rms(y.in_norm, n, c->l_x, c->l_xn, &y.qkv));
-            CHK(llama_gemm(c, y.qkv, c->l_xn, H, c->l_qkv, QKV, n, EPI_STORE));
+            CHK(rms(y.in_norm, n, c->l_x, c->l_xn, &y.qkv, QS_QKV));
+            const int sl = qstream(y.qkv, QS_QKV, c->l_xn, H, c->l_qkv, QKV, (int64_t) 16 * QKV, 16);   // slabs of 16 rows inside l_qkv ([RMAX][QKV])
+            if (sl < 0) return -1;
+            if (!sl) CHK(llama_gemm(c, y.qkv, c->l_xn, H, c->l_qkv, QKV, n, EPI_STORE));
             hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH + NKV), dim3(64), 0, c->stream, c->l_qkv, (const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, HD, kc, vc,
-                               row_seq, row_seq ? seq_stride : (int64_t) 0);
+                               row_seq, row_seq ? seq_stride : (int64_t) 0, std::max(sl, 1), (int64_t) 16 * QKV);
             HIPCHK(hipGetLastError());
         }
         CHK(launch_attn_gqa(c, NH, n, (int) (attn_positions ? (uint32_t) attn_positions : pos0 + n), (const float *) c->l_qkv, QKV, (const uint32_t *) c->l_pos,
                             (const float *) kc, (const float *) vc, NKV, 1.0f / sqrtf((float) HD), c->l_att, nullptr, nullptr, row_seq, row_seq ? seq_stride : (int64_t) 0,
-                            attn_positions != 0 && !row_seq, q_for(y.o, n), QPre{}, nullptr, NCTX));
-        CHK(llama_gemm(c, y.o, c->l_att, NH * HD, c->l_x, H, n, EPI_RESID));
+                            attn_positions != 0 && !row_seq, q_for(y.o, n, QS_O), QPre{}, nullptr, NCTX));
+        {
+            const int sl = qstream(y.o, QS_O, c->l_att, NH * HD, c->l_parts, H, (int64_t) 16 * H, 16);   // slabs of 16 rows inside l_parts ([8][RMAX][H]), folded into the residual stream by the next rms norm
+            if (sl < 0) return -1;
+            if (sl) { c->l_pending = sl; c->l_pstride = (int64_t) 16 * H; }
+            else CHK(llama_gemm(c, y.o, c->l_att, NH * HD, c->l_x, H, n, EPI_RESID));
+        }
         const size_t gu_lds = (size_t) n * H + (size_t) n * (H / 32) * 4, dn_lds = (size_t) n * F + (size_t) n * (F / 32) * 4;
-        const bool gu_fused = c->q4_silu && c->q4_lds && y.gu.q4 && y.down.q4 && q_for(y.gu, n) && q_for(y.down, n) && H % 512 == 0 && F % 512 == 0 &&
+        const bool gu_fused = n <= 4 && c->q4_silu && c->q4_lds && y.gu.q4 && y.down.q4 && q_for(y.gu, n, QS_GU) && q_for(y.down, n, QS_DOWN) && H % 512 == 0 && F % 512 == 0 &&
                               gu_lds <= 64 * 1024 && dn_lds <= 64 * 1024 && (int) y.gu.N == 2 * F && !c->prof;
-        if (!(gu_fused && rms_fused)) CHK(rms(y.post_norm, n, c->l_x, c->l_xn, &y.gu));
+        if (!(gu_fused && rms_fused)) CHK(rms(y.post_norm, n, c->l_x, c->l_xn, &y.gu, QS_GU));
         if (gu_fused) {
             // gate | up with silu * up in the epilogue, then the down projection quantising that product while it stages it: two launches
             // instead of three (gemv_q4_gateup_silu_kernel, gemv_q4_rows_lds_kernel<.., QSRC 1>)
@@ -208,14 +231,21 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
             HIPCHK(hipGetLastError());
             continue;
         }
-        CHK(llama_gemm(c, y.gu, c->l_xn, H, c->l_gu, 2 * F, n, EPI_STORE));
-        const int ks = (c->gemv_rows && n <= 4) ? 1 : c->l_ksplit;   // the streaming kernels walk all of K themselves
-        const bool qd = ks == 1 && q_for(y.down, n);
+        const int slg = qstream(y.gu, QS_GU, c->l_xn, H, c->l_gu, 2 * F, (int64_t) 16 * 2 * F, 16);   // slabs of 16 rows inside l_gu; silu_mul_kernel folds them
+        if (slg < 0) return -1;
+        if (!slg) CHK(llama_gemm(c, y.gu, c->l_xn, H, c->l_gu, 2 * F, n, EPI_STORE));
+        const bool down_stream = slices(y.down, QS_DOWN, n, 16) != 0;
+        const int ks = ((c->gemv_rows && n <= 4) || down_stream) ? 1 : c->l_ksplit;   // the streaming kernels walk all of K themselves
+        const bool qd = ks == 1 && q_for(y.down, n, QS_DOWN);
         hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) n * F + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->l_gu, F, n, c->l_g,
-                           qd ? c->aq : (int8_t *) nullptr, qd ? c->ad : (float *) nullptr);
+                           qd ? c->aq : (int8_t *) nullptr, qd ? c->ad : (float *) nullptr, std::max(slg, 1), (int64_t) 16 * 2 * F);
         HIPCHK(hipGetLastError());
         c->aq_src = qd ? c->l_g : nullptr;
-        if (ks > 1) {
+        if (down_stream) {
+            const int sl = qstream(y.down, QS_DOWN, c->l_g, F, c->l_parts, H, (int64_t) 16 * H, 16);
+            if (sl <= 0) return sl < 0 ? -1 : set_err("llama_forward: the down projection lost its streaming form");
+            c->l_pending = sl; c->l_pstride = (int64_t) 16 * H;
+        } else if (ks > 1) {
             CHK(llama_gemm(c, y.down, c->l_g, F, c->l_parts, H, n, EPI_STORE, ks));
             c->l_pending = ks;
         } else {
@@ -223,7 +253,13 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
         }
     }
     // lm_head on the last token only (:287-290) — or, for lock-step utterances, on every row (each row is an utterance's last token)
-    CHK(rms(c->l_out_norm, n, c->l_x, c->l_xn, nullptr));
+    const bool head_stream = logits_row < 0 && slices(c->l_head, QS_HEAD, n, 1) != 0;
+    CHK(rms(c->l_out_norm, n, c->l_x, c->l_xn, head_stream ? &c->l_head : nullptr, QS_HEAD));
+    if (head_stream) {   // lock-step utterances, 5 .. 16 of them: the head streams once, whole K per wave (no slabs)
+        const int sl = qstream(c->l_head, QS_HEAD, c->l_xn, H, c->l_logits, c->l_Vpad, 0, 1);
+        if (sl < 0) return -1;
+        if (sl) return 0;
+    }
     GemmArgs g{};
     g.H = H; g.lda = H; g.ldo = c->l_Vpad;
     if (logits_row < 0) { g.R = n; g.A = c->l_xn; g.out = c->l_logits; }

@@ -571,6 +571,14 @@ class OrpheusEngine:
         if rc != 0:
             raise HipError(self.L.tts_hip_last_error().decode("utf-8", "replace"))
 
+    def debug_read(self, what, max_floats):
+        """'l_logits': the logits row the last step left; 'l_k:<layer>' / 'l_v:<layer>': slot 0's cache rows (test / debugging aid)"""
+        out = np.empty(max_floats, dtype=np.float32)
+        n = self.L.tts_hip_debug_read(self.ctx, what.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), max_floats)
+        if n < 0:
+            raise HipError(self.err())
+        return out[:n].copy()
+
     def tune(self, key, value):
         """tts_hip_tune: a named tuning / fallback switch (before the first launch)"""
         self._chk(self.L.tts_hip_tune(self.ctx, key.encode(), int(value)))
