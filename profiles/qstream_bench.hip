@@ -63,9 +63,9 @@ __global__ __launch_bounds__(256) void read_kernel(const int4v *p, size_t n16, i
 }
 
 typedef void (*kern_t)(QGemmArgs, StreamMap);
-struct Cfg { const char *name; int nwv, depth; kern_t k; };
-#define CFG(NWV, D) { "w" #NWV "d" #D, NWV, D, qgemv_stream_kernel<NWV, D> }
-static const Cfg CFGS[] = { CFG(4, 2), CFG(4, 3), CFG(4, 4), CFG(8, 2), CFG(8, 3), CFG(16, 2) };
+struct Cfg { const char *name; int nwv, depth, rt; kern_t k; };
+#define CFG(NWV, D, RT) { "w" #NWV "d" #D "rt" #RT, NWV, D, RT, qgemv_stream_kernel<NWV, D, RT> }
+static const Cfg CFGS[] = { CFG(4, 2, 1), CFG(4, 3, 1), CFG(8, 2, 1), CFG(8, 3, 1), CFG(4, 2, 2), CFG(8, 2, 2), CFG(4, 2, 4), CFG(8, 2, 4) };
 struct Shape { const char *name; int K, N; };
 static const Shape SHAPES[] = { {"qkv", 3072, 5120}, {"o", 3072, 3072}, {"gate|up", 3072, 16384}, {"down", 8192, 3072}, {"head", 3072, 156940} };
 
@@ -82,7 +82,7 @@ int main(int argc, char **argv) {
         int8_t *W; _Float16 *wd; int8_t *aq; float *ad, *out, *ref, *folded;
         CK(hipMalloc(&W, wbytes * NBUF)); CK(hipMalloc(&wd, sbytes * NBUF));
         CK(hipMalloc(&aq, (size_t) R * K)); CK(hipMalloc(&ad, (size_t) R * nb * 4));
-        CK(hipMalloc(&out, (size_t) 16 * 16 * N * 4)); CK(hipMalloc(&ref, (size_t) R * N * 4)); CK(hipMalloc(&folded, (size_t) R * N * 4));
+        CK(hipMalloc(&out, (size_t) 16 * 64 * N * 4)); CK(hipMalloc(&ref, (size_t) R * N * 4)); CK(hipMalloc(&folded, (size_t) R * N * 4));
         for (int b = 0; b < NBUF; b++) {
             fill_i8_kernel<<<(unsigned) ((wbytes + 255) / 256), 256>>>(W + b * wbytes, wbytes, 17u, -127, 127);
             fill_h_kernel<<<(unsigned) (((size_t) N * nb + 255) / 256), 256>>>(wd + (size_t) b * N * nb, (size_t) N * nb, 29u, 0.01f);
@@ -108,25 +108,26 @@ int main(int argc, char **argv) {
         for (int ks : {1, 2, 3, 4, 6, 8, 12, 16}) {
             if (K % (ks * 256)) continue;
             const int KS = K / ks;
-            const int RS = R <= 8 ? 8 : 16;
+            const int srows = R <= 16 ? 16 : R <= 32 ? 32 : 64, RS = R <= 8 ? 8 : srows;
             const size_t lds = (size_t) (RS + 1) * KS + (size_t) RS * (KS / 32) * 4;
             if (lds > 64 * 1024) continue;
             for (const Cfg &c : CFGS) {
+                if (c.rt * 16 != srows) continue;
                 const int items = tiles * ks;
                 int grid = ((items + c.nwv - 1) / c.nwv + ks - 1) / ks * ks;
                 const int maxwg = 256 * std::max(1, 16 / c.nwv) * 2;   // persistent beyond that: waves walk several tiles
                 if (grid > maxwg) grid = maxwg / ks * ks;
                 QGemmArgs qa{};
-                qa.g.K = K; qa.g.N = N; qa.g.R = R; qa.g.out = out; qa.g.ldo = N; qa.g.slab_stride = (int64_t) 16 * N;
+                qa.g.K = K; qa.g.N = N; qa.g.R = R; qa.g.out = out; qa.g.ldo = N; qa.g.slab_stride = (int64_t) 64 * N;
                 qa.aq = aq; qa.ad = ad;
                 const StreamMap sm{ks, KS};
                 auto launch = [&](int b) {
                     qa.g.W = W + (size_t) b * wbytes; qa.wd = wd + (size_t) b * N * nb;
                     hipLaunchKernelGGL(c.k, dim3(grid), dim3(c.nwv * 64), lds, 0, qa, sm);
                 };
-                CK(hipMemset(out, 0xff, (size_t) 16 * 16 * N * 4));
+                CK(hipMemset(out, 0xff, (size_t) 16 * 64 * N * 4));
                 launch(0);
-                fold_kernel<<<(unsigned) (((size_t) R * N + 255) / 256), 256>>>(out, folded, (size_t) R * N, ks, (size_t) 16 * N);
+                fold_kernel<<<(unsigned) (((size_t) R * N + 255) / 256), 256>>>(out, folded, (size_t) R * N, ks, (size_t) 64 * N);
                 CK(hipDeviceSynchronize());
                 CK(hipMemcpy(hout.data(), folded, hout.size() * 4, hipMemcpyDeviceToHost));
                 double err = 0; for (size_t i = 0; i < hout.size(); i++) { double d = fabs((double) hout[i] - href[i]); if (!(d <= err)) err = d; }

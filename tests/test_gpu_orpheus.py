@@ -106,17 +106,17 @@ def test_orpheus_3b_shapes_few_row_calls_take_the_fused_projections():
 
 
 @pytest.mark.parametrize("wtype", [gguf.Q4_0, gguf.Q8_0])
-def test_orpheus_3b_shapes_5_to_16_rows_take_the_weight_streaming_integer_gemm(wtype):
-    """5 .. 16 rows on GGUF-quantised matrices at the 3B widths (round 6: qgemv_stream_kernel — every projection and, for lock-step utterances, the
+def test_orpheus_3b_shapes_5_to_64_rows_take_the_weight_streaming_integer_gemm(wtype):
+    """5 .. 64 rows on GGUF-quantised matrices at the 3B widths (round 6: qgemv_stream_kernel — every projection and, for lock-step utterances, the
     LM head with its 5001 = 312 x 16 + 9 features): K slices of 512 / 768 / 1536 columns as slabs folded by rope / silu * up / the next rms norm
-    (3072-wide rows: eight slabs per round trip), 8- and 16-row LDS images.  decode() pieces of 5, 8, 9 and 16 rows against the oracle fed the same
-    pieces, then lock-step steps of 6 and 13 utterances: every row's logits against the oracle's for that utterance's history; with
+    (3072-wide rows: eight slabs per round trip), 8-, 16-, 32- and 64-row LDS images.  decode() pieces of 5, 8, 9, 16, 23 and 40 rows against the oracle
+    fed the same pieces, then lock-step steps of 6, 13 and 21 utterances: every row's logits against the oracle's for that utterance's history; with
     tune("q_stream") = 0 (qgemm16_kernel) the same calls stay inside the same bound and the arg-max tokens agree wherever the oracle's margin allows."""
-    model = synth.build_orpheus(synth.orpheus_3b(layers=2, vocab=5001, ctx=64, weight_type=wtype))
+    model = synth.build_orpheus(synth.orpheus_3b(layers=2, vocab=5001, ctx=128, weight_type=wtype))
     cfg = model.cfg
     o = orc.OrpheusOracle(model, act_mode=1)
-    ids = np.random.default_rng(11).integers(0, 5001, 38).astype(np.uint32)
-    pieces = (ids[:5], ids[5:13], ids[13:22], ids[22:38])
+    ids = np.random.default_rng(11).integers(0, 5001, 101).astype(np.uint32)
+    pieces = (ids[:5], ids[5:13], ids[13:22], ids[22:38], ids[38:61], ids[61:101])   # 23 and 40 rows: two and four row tiles of 16 per workgroup
     refs, p = [], 0
     for piece in pieces:
         refs.append(o.decode(piece, p)); p += len(piece)
@@ -132,7 +132,7 @@ def test_orpheus_3b_shapes_5_to_16_rows_take_the_weight_streaming_integer_gemm(w
             p += len(piece)
         eng.close()
     # lock-step utterances: B rows of one step, every row with its own cache slot and position
-    for B in (6, 13):
+    for B in (6, 13, 21):
         rng = np.random.default_rng(B)
         prompts = [rng.integers(0, 5001, 2 + (u % 5)).astype(np.uint32) for u in range(B)]
         eng = hip.OrpheusEngine(cfg, max_seqs=B)

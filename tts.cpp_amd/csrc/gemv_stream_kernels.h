@@ -177,7 +177,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_stream_kernel(GemmArgs a, Strea
 }
 
 // ================================================================================================================================
-// qgemv_stream_kernel — the same schedule for GGUF-quantised matrices and 5 .. 16 rows (round 6: lock-step Orpheus utterances, orpheus/model.cpp:194-283
+// qgemv_stream_kernel — the same schedule for GGUF-quantised matrices and 5 .. 16 RT rows (RT = 1, 2, 4 row tiles of 16; round 6: lock-step Orpheus utterances, orpheus/model.cpp:194-283
 // for a handful of rows).  qgemm16_kernel is one-shot per 16 features like gemm16_kernel (K / 256 waves meet in LDS) and streamed the int8 expansion of
 // the 3B matrices at ~0.15 of HBM at 8 rows (profiles/r06/orpheus_batch_call2.txt); the streaming Q4_0 kernels end at 4 rows.  Here:
 //   * a workgroup is bound to one K slice and keeps the Q8_0 rows of that slice in LDS (codes int8 [RS][KS], 16-byte pieces XOR-swizzled by the row so
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_stream_kernel(GemmArgs a, Strea
 //   * K slices write fp32 slabs (slab kz of `out`, slab_stride floats apart) that the consumer folds in slab order (llama_rope_kv_kernel, silu_mul_kernel,
 //     rms_fold_rows_kernel), like gemv_stream_kernel.  N need not be a multiple of 16 (the LM head): a last tile re-reads feature N - 1 and stores nothing for it.
 // ================================================================================================================================
-template <int NWV, int DEPTH = 2>
+template <int NWV, int DEPTH = 2, int RT = 1>
 __global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, StreamMap sm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemmArgs &a = qa.g;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, St
     const int li = lane & 15, g = lane >> 4;
     const int kz = (int) blockIdx.x % sm.ks, wg_in = (int) blockIdx.x / sm.ks, nwg_in = (int) gridDim.x / sm.ks;
     const int KS = sm.kslice, k0 = kz * KS, nb = a.K >> 5, nbs = KS >> 5;
-    const int RS = a.R <= 8 ? 8 : 16;   // rows kept in LDS; B-operand columns >= RS repeat rows (never stored)
+    const int RS = RT > 1 ? 16 * RT : (a.R <= 8 ? 8 : 16);   // rows kept in LDS (RT row tiles of 16); B-operand columns >= RS repeat rows (never stored)
     int8_t *xs = (int8_t *) smem;                    // [RS + 1][KS]: row RS is zeros
     float *sd = (float *) (smem + (size_t) (RS + 1) * KS);
 
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, St
     auto advance = [&](int &tt, int &cc) __attribute__((always_inline)) { if (++cc == nc) { cc = 0; tt += tstep; } };
     WSet w[DEPTH];
 #pragma unroll
-    for (int d = 0; d < DEPTH - 1; d++) {   // DEPTH - 1 sets in flight before the first MFMA (clamped addresses past the end: never used)
-        loadw(w[d], min(lt, tiles - 1), lch);
+    for (int d = 0; d < DEPTH - 1; d++) {   // DEPTH - 1 sets in flight before the first MFMA
+        if (d == 0 || lt < tiles) loadw(w[d], min(lt, tiles - 1), lch);
         advance(lt, lch);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -258,40 +258,49 @@ __global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, St
     for (int i = tid; i < cvec; i += NTH) *(int4v *) (xs + (size_t) RS * KS + i * 16) = (int4v){0, 0, 0, 0};
     __syncthreads();
 
-    const int row = li & (RS - 1);
+    const int row = li & (RS - 1);   // row tile j: row + 16 j (same swizzle key: the key is the row's low four bits)
     // operand of the even block of a span (lane groups 0, 1 hold its columns) and of the odd block (groups 2, 3): the other groups read zeros
     const int8_t *x_even = xs + (size_t) (g < 2 ? row : RS) * KS, *x_odd = xs + (size_t) (g < 2 ? RS : row) * KS;
+    const int tile_even = g < 2 ? 16 * KS : 0, tile_odd = g < 2 ? 0 : 16 * KS;   // the zero row stays where it is
     int off[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) off[c] = ((c * 4 + g) ^ (row & 15)) << 4;
     const float *sb = sd + row * nbs;
-    float4v acc = {0.f, 0.f, 0.f, 0.f};
+    float4v acc[RT];
+#pragma unroll
+    for (int j = 0; j < RT; j++) acc[j] = (float4v){0.f, 0.f, 0.f, 0.f};
     auto step = [&](WSet &cur, WSet &nxt) __attribute__((always_inline)) {
         if (lt < tiles) loadw(nxt, lt, lch);
         advance(lt, lch);
-        const float4v da0 = *(const float4v *) (sb + ch * 8), da1 = *(const float4v *) (sb + ch * 8 + 4);
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int4v zero = {0, 0, 0, 0};
-            const int4v ze = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.w[c], *(const int4v *) (x_even + ch * 256 + off[c]), zero, 0, 0, 0);   // exact block dots
-            const int4v zo = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.w[c], *(const int4v *) (x_odd + ch * 256 + off[c]), zero, 0, 0, 0);
-            const float dae = c < 2 ? da0[2 * c] : da1[2 * c - 4], dao = c < 2 ? da0[2 * c + 1] : da1[2 * c - 3];
+        for (int j = 0; j < RT; j++) {
+            const float4v da0 = *(const float4v *) (sb + j * 16 * nbs + ch * 8), da1 = *(const float4v *) (sb + j * 16 * nbs + ch * 8 + 4);
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                acc[e] += (float) ze[e] * ((float) cur.d[e][2 * c] * dae);
-                acc[e] += (float) zo[e] * ((float) cur.d[e][2 * c + 1] * dao);
+            for (int c = 0; c < 4; c++) {
+                const int4v zero = {0, 0, 0, 0};
+                const int4v ze = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.w[c], *(const int4v *) (x_even + j * tile_even + ch * 256 + off[c]), zero, 0, 0, 0);   // exact block dots
+                const int4v zo = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.w[c], *(const int4v *) (x_odd + j * tile_odd + ch * 256 + off[c]), zero, 0, 0, 0);
+                const float dae = c < 2 ? da0[2 * c] : da1[2 * c - 4], dao = c < 2 ? da0[2 * c + 1] : da1[2 * c - 3];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    acc[j][e] += (float) ze[e] * ((float) cur.d[e][2 * c] * dae);
+                    acc[j][e] += (float) zo[e] * ((float) cur.d[e][2 * c + 1] * dao);
+                }
             }
         }
         if (ch == nc - 1) {
             const int n0 = t * 16 + g * 4;
-            float *o = a.out + (int64_t) kz * a.slab_stride + (int64_t) li * a.ldo + n0;
-            if (li < a.R) {
-                if (n0 + 3 < a.N) *(float4v *) o = acc;
-                else
 #pragma unroll
-                    for (int e = 0; e < 4; e++) if (n0 + e < a.N) o[e] = acc[e];
+            for (int j = 0; j < RT; j++) {
+                float *o = a.out + (int64_t) kz * a.slab_stride + (int64_t) (li + 16 * j) * a.ldo + n0;
+                if (li + 16 * j < a.R) {
+                    if (n0 + 3 < a.N) *(float4v *) o = acc[j];
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; e++) if (n0 + e < a.N) o[e] = acc[j][e];
+                }
+                acc[j] = (float4v){0.f, 0.f, 0.f, 0.f};
             }
-            acc = (float4v){0.f, 0.f, 0.f, 0.f};
         }
         advance(t, ch);
     };

@@ -403,11 +403,16 @@ static int run_qtile(tts_hip_ctx *c, int kclass, const W &w, GemmArgs a, int pro
 // ------------------------------------------------------------------------------------------------
 // K slices for an [N][K] quantised matrix: as many 256-column chunks per slice as keep about 4096 (tile, slice) items and the consumer's slab budget;
 // 0 = the shape does not go through the kernel
-static size_t qstream_lds(int R, int kslice) { return (size_t) ((R <= 8 ? 8 : 16) + 1) * kslice + (size_t) (R <= 8 ? 8 : 16) * (kslice / 32) * 4; }
+// rows of one slab of the weight-streaming integer GEMM (= rows its workgroups keep in LDS; 8 of the 16 when R <= 8)
+int qstream_slab_rows(int R) { return R <= 16 ? 16 : R <= 32 ? 32 : 64; }
+static size_t qstream_lds(int R, int kslice) {
+    const int RS = R <= 8 ? 8 : qstream_slab_rows(R);
+    return (size_t) (RS + 1) * kslice + (size_t) RS * (kslice / 32) * 4;
+}
 // K slices of the weight-streaming integer GEMM for R rows on w (0: the shape does not qualify).  Measured at Orpheus-3B's shapes (profiles/qstream_bench.hip,
 // profiles/r06/qstream_bench_r8d.txt): ~2000 (tile, slice) items fill the chip; a 192-tile projection prefers fewer, longer waves unless K is long.
 int qstream_slices(const tts_hip_ctx *c, const W &w, int R, int max_slabs) {
-    if (!c->q_stream || w.type != TTS_HIP_Q8I || R < 5 || R > 16 || w.K % 256 || (c->d.flags & (TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q))) return 0;
+    if (!c->q_stream || w.type != TTS_HIP_Q8I || R < 5 || R > 64 || w.K % 256 || (c->d.flags & (TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q))) return 0;
     const int tiles = ((int) w.N + 15) / 16, chunks = (int) w.K / 256;
     const int want = std::min(max_slabs, tiles >= 4096 ? 1 : tiles >= 1024 ? 2 : tiles >= 256 ? 6 : w.K >= 8192 ? 16 : 4);
     int ks = 0;
@@ -425,18 +430,19 @@ int launch_qstream(tts_hip_ctx *c, int kclass, const W &w, int R, float *out, in
     qa.aq = c->aq; qa.ad = c->ad;
     const StreamMap sm{ks, (int) w.K / ks};
     const int tiles = ((int) w.N + 15) / 16, items = tiles * ks;
-    const int nwv = tiles >= 256 ? 8 : 4;
+    const int nwv = tiles >= 256 ? 8 : 4, rt = qstream_slab_rows(R) / 16;
     int grid = ((items + nwv - 1) / nwv + ks - 1) / ks * ks;
     grid = std::min(grid, 1024 / ks * ks);   // beyond four workgroups per CU the waves walk several tiles (the LM head)
     const size_t lds = qstream_lds(R, sm.kslice);
     CHK(prof_begin(c, kclass, (double) w.K * w.N * (1.0 + 2.0 / 32) + (double) R * w.K * 1.125 + (double) ks * R * w.N * 4, 2.0 * R * (double) w.K * w.N));
+    typedef void (*kern_t)(QGemmArgs, StreamMap);
+    static const kern_t kerns[2][3] = {{qgemv_stream_kernel<4, 2, 1>, qgemv_stream_kernel<4, 2, 2>, qgemv_stream_kernel<4, 2, 4>},
+                                       {qgemv_stream_kernel<8, 2, 1>, qgemv_stream_kernel<8, 2, 2>, qgemv_stream_kernel<8, 2, 4>}};
     static std::atomic<uint64_t> attr{0};
-    if (attr_needed(attr, c->device)) {
-        HIPCHK(hipFuncSetAttribute((const void *) qgemv_stream_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void *) qgemv_stream_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
-    if (nwv == 8) hipLaunchKernelGGL((qgemv_stream_kernel<8, 2>), dim3(grid), dim3(512), lds, c->stream, qa, sm);
-    else hipLaunchKernelGGL((qgemv_stream_kernel<4, 2>), dim3(grid), dim3(256), lds, c->stream, qa, sm);
+    if (attr_needed(attr, c->device))
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 3; j++) HIPCHK(hipFuncSetAttribute((const void *) kerns[i][j], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(kerns[nwv == 8][rt == 1 ? 0 : rt == 2 ? 1 : 2], dim3(grid), dim3(nwv * 64), lds, c->stream, qa, sm);
     HIPCHK(hipGetLastError());
     return prof_end(c);
 }

@@ -144,7 +144,7 @@ struct tts_hip_ctx {
     bool q4_silu = true;        // tune("q4_silu")=0: gate|up, silu * up and the down projection stay three launches
     bool q4_rope = true;        // tune("q4_rope")=0: the Llama q/k/v projection keeps its separate rope + cache-append launch
     bool q4_lds = true;         // tune("q4_lds")=0: Q4_0 row products stay on gemv_q4_rows_kernel (one feature per wave, activations from L2)
-    int q_stream = 31;          // tune("q_stream"): which quantised projections of a 5 .. 16 row Llama step take qgemv_stream_kernel instead of qgemm16_kernel
+    int q_stream = 31;          // tune("q_stream"): which quantised projections of a 5 .. 64 row Llama step take qgemv_stream_kernel instead of qgemm16_kernel
                                 // (bits: 1 qkv, 2 o, 4 gate|up, 8 down, 16 head; 0 none, 1 = all)
     bool gemv_stream = true;    // tune("gemv_stream")=0: <= 16-row F16 GEMMs of the Dia step stay on gemm16_kernel (gemv_stream_kernels.h otherwise)
     bool llama_graph = false;   // TTS_HIP_LLAMA_GRAPH (default on for Orpheus contexts): the greedy step as one captured graph

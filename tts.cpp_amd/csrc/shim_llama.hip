@@ -130,11 +130,12 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
     enum { QS_QKV = 1, QS_O = 2, QS_GU = 4, QS_DOWN = 8, QS_HEAD = 16 };   // bits of tune("q_stream")
     auto slices = [&](const W &w, int bit, int rows, int max_slabs) { return (c->q_stream & bit) ? qstream_slices(c, w, rows, max_slabs) : 0; };
     auto q_for = [&](const W &w, int rows, int bit) {
-        if (slices(w, bit, rows, 16)) return true;   // 5 .. 16 rows: the weight-streaming integer GEMM takes the producer's blocks as well
+        if (slices(w, bit, rows, std::min(16, 8 * c->RMAX / qstream_slab_rows(rows)))) return true;   // 5 .. 16 rows: the weight-streaming integer GEMM takes the producer's blocks as well
         return c->gemv_rows && rows <= 4 && w.type == TTS_HIP_Q8I && !(c->d.flags & (TTS_HIP_FLAG_VALU_GEMM | TTS_HIP_FLAG_DEQUANT_Q)) && w.K % 32 == 0;
     };
     // 5 .. 16 rows on a quantised matrix: qgemv_stream_kernel — K slices as fp32 slabs the consumer folds.  Returns the slab count (0: the shape does not
     // qualify, the caller takes the MFMA workgroups), < 0 on error.  A: the fp32 rows whose Q8_0 blocks the producer left in aq / ad (quantised here otherwise).
+    const int srows = qstream_slab_rows(n), smax = std::min(16, c->RMAX / srows), pmax = std::min(16, 8 * c->RMAX / srows);   // rows per slab of the streaming integer GEMM; slabs l_qkv / l_gu and l_parts hold
     auto qstream = [&](const W &w, int bit, const float *A, int K, float *out, int ldo, int64_t slab_stride, int max_slabs) -> int {
         const int ks = slices(w, bit, n, max_slabs);
         if (!ks) return 0;
@@ -183,20 +184,20 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
             c->aq_src = nullptr;
         } else {
             CHK(rms(y.in_norm, n, c->l_x, c->l_xn, &y.qkv, QS_QKV));
-            const int sl = qstream(y.qkv, QS_QKV, c->l_xn, H, c->l_qkv, QKV, (int64_t) 16 * QKV, 16);   // slabs of 16 rows inside l_qkv ([RMAX][QKV])
+            const int sl = qstream(y.qkv, QS_QKV, c->l_xn, H, c->l_qkv, QKV, (int64_t) srows * QKV, smax);   // slabs of srows rows inside l_qkv ([RMAX][QKV])
             if (sl < 0) return -1;
             if (!sl) CHK(llama_gemm(c, y.qkv, c->l_xn, H, c->l_qkv, QKV, n, EPI_STORE));
             hipLaunchKernelGGL(llama_rope_kv_kernel, dim3(n, NH + NKV), dim3(64), 0, c->stream, c->l_qkv, (const uint32_t *) c->l_pos, f32(c->l_ropef), theta_scale, NH, NKV, HD, kc, vc,
-                               row_seq, row_seq ? seq_stride : (int64_t) 0, std::max(sl, 1), (int64_t) 16 * QKV);
+                               row_seq, row_seq ? seq_stride : (int64_t) 0, std::max(sl, 1), (int64_t) srows * QKV);
             HIPCHK(hipGetLastError());
         }
         CHK(launch_attn_gqa(c, NH, n, (int) (attn_positions ? (uint32_t) attn_positions : pos0 + n), (const float *) c->l_qkv, QKV, (const uint32_t *) c->l_pos,
                             (const float *) kc, (const float *) vc, NKV, 1.0f / sqrtf((float) HD), c->l_att, nullptr, nullptr, row_seq, row_seq ? seq_stride : (int64_t) 0,
                             attn_positions != 0 && !row_seq, q_for(y.o, n, QS_O), QPre{}, nullptr, NCTX));
         {
-            const int sl = qstream(y.o, QS_O, c->l_att, NH * HD, c->l_parts, H, (int64_t) 16 * H, 16);   // slabs of 16 rows inside l_parts ([8][RMAX][H]), folded into the residual stream by the next rms norm
+            const int sl = qstream(y.o, QS_O, c->l_att, NH * HD, c->l_parts, H, (int64_t) srows * H, pmax);   // slabs of srows rows inside l_parts ([8][RMAX][H]), folded into the residual stream by the next rms norm
             if (sl < 0) return -1;
-            if (sl) { c->l_pending = sl; c->l_pstride = (int64_t) 16 * H; }
+            if (sl) { c->l_pending = sl; c->l_pstride = (int64_t) srows * H; }
             else CHK(llama_gemm(c, y.o, c->l_att, NH * HD, c->l_x, H, n, EPI_RESID));
         }
         const size_t gu_lds = (size_t) n * H + (size_t) n * (H / 32) * 4, dn_lds = (size_t) n * F + (size_t) n * (F / 32) * 4;
@@ -231,20 +232,20 @@ static int llama_forward(tts_hip_ctx *c, const uint32_t *ids, int n, uint32_t po
             HIPCHK(hipGetLastError());
             continue;
         }
-        const int slg = qstream(y.gu, QS_GU, c->l_xn, H, c->l_gu, 2 * F, (int64_t) 16 * 2 * F, 16);   // slabs of 16 rows inside l_gu; silu_mul_kernel folds them
+        const int slg = qstream(y.gu, QS_GU, c->l_xn, H, c->l_gu, 2 * F, (int64_t) srows * 2 * F, smax);   // slabs of srows rows inside l_gu; silu_mul_kernel folds them
         if (slg < 0) return -1;
         if (!slg) CHK(llama_gemm(c, y.gu, c->l_xn, H, c->l_gu, 2 * F, n, EPI_STORE));
-        const bool down_stream = slices(y.down, QS_DOWN, n, 16) != 0;
+        const bool down_stream = slices(y.down, QS_DOWN, n, pmax) != 0;
         const int ks = ((c->gemv_rows && n <= 4) || down_stream) ? 1 : c->l_ksplit;   // the streaming kernels walk all of K themselves
         const bool qd = ks == 1 && q_for(y.down, n, QS_DOWN);
         hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) (((size_t) n * F + 255) / 256)), dim3(256), 0, c->stream, (const float *) c->l_gu, F, n, c->l_g,
-                           qd ? c->aq : (int8_t *) nullptr, qd ? c->ad : (float *) nullptr, std::max(slg, 1), (int64_t) 16 * 2 * F);
+                           qd ? c->aq : (int8_t *) nullptr, qd ? c->ad : (float *) nullptr, std::max(slg, 1), (int64_t) srows * 2 * F);
         HIPCHK(hipGetLastError());
         c->aq_src = qd ? c->l_g : nullptr;
         if (down_stream) {
-            const int sl = qstream(y.down, QS_DOWN, c->l_g, F, c->l_parts, H, (int64_t) 16 * H, 16);
+            const int sl = qstream(y.down, QS_DOWN, c->l_g, F, c->l_parts, H, (int64_t) srows * H, pmax);
             if (sl <= 0) return sl < 0 ? -1 : set_err("llama_forward: the down projection lost its streaming form");
-            c->l_pending = sl; c->l_pstride = (int64_t) 16 * H;
+            c->l_pending = sl; c->l_pstride = (int64_t) srows * H;
         } else if (ks > 1) {
             CHK(llama_gemm(c, y.down, c->l_g, F, c->l_parts, H, n, EPI_STORE, ks));
             c->l_pending = ks;
