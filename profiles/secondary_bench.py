@@ -310,7 +310,7 @@ def run_orpheus(args):
     }
     eng.close()
     # lock-step utterances inside the GPU (tts_hip_orpheus_generate_batch, round 6): B cache slots, one row per utterance and step; int8 codes
-    # and fp16 scales of every matrix cross HBM once per step whatever B (the MFMA workgroups read the int8 expansion: twice the Q4_0 bytes), so the
+    # and fp16 scales of every matrix cross HBM once per step whatever B (from 5 rows on the kernels read the int8 expansion: twice the Q4_0 bytes), so the
     # tokens of all utterances share one weight stream
     i8_bytes = params * (1.0 + 2.0 / 32)
     out["lockstep_batches"] = {}
@@ -327,7 +327,7 @@ def run_orpheus(args):
         wbytes = q4_bytes if B <= 4 else i8_bytes
         out["lockstep_batches"][str(B)] = {"ms_per_decode_step": round(stepb * 1e3, 4), "tokens_per_s": round(B / stepb, 1),
                                            "audio_s_per_s_decoder_only": round(B / stepb / 7 * 2048 / 24000.0, 2),
-                                           "weight_stream": "Q4_0 codes (streaming 1-4 row kernels)" if B <= 4 else "int8 expansion (MFMA workgroups)",
+                                           "weight_stream": "Q4_0 codes (streaming 1-4 row kernels)" if B <= 4 else ("int8 expansion, streamed once per step (qgemv_stream_kernel, 5..64 rows)" if B <= 64 else "int8 expansion (MFMA workgroups)"),
                                            "hbm_frac_of_step": round(wbytes / stepb / 1e9 / HBM_PEAK_GBS, 4)}
         engb.close()
     b1 = out["lockstep_batches"].get("1")
