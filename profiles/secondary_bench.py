@@ -362,7 +362,8 @@ def run_orpheus(args):
 # ------------------------------------------------------------------------------------------------------------------------------
 def run_kokoro(args):
     model = synth.build_kokoro(synth.kokoro_82m())
-    eng = hip.KokoroEngine(model)
+    ktune = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in os.environ.get("TTS_BENCH_KOKORO_TUNE", "").split(",") if kv)   # e.g. kokoro_split=0: the bf16 x 3 form
+    eng = hip.KokoroEngine(model, tune=ktune)
     cfg = model.cfg
     rng = np.random.default_rng(1)
     res = {}
@@ -394,7 +395,7 @@ def run_kokoro(args):
         "ms_per_step": round(timed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (seeded random weights at the shapes of hexgrad/Kokoro-82M)",
         "config": {"workload": "configs[2]: Kokoro-82M on 1 x MI355X, 64 and 400 phoneme ids, durations forced to 3 frames per id for shape determinism; "
-                               "tts_hip_kokoro_durations + tts_hip_kokoro_generate (k = 3 / 5 / 7 / 11 convolutions as bf16 x 3 split products on the bf16 matrix pipe at fp32-level error, the rest exact-fp32 MFMA; workgroup-split LSTM recurrence)", "parallelism": "dp1"},
+                               "tts_hip_kokoro_durations + tts_hip_kokoro_generate (k = 3 / 5 / 7 / 11 convolutions as fp16 hi + lo split products (three MFMAs per product) on the fp16 matrix pipe at fp32-level error, the rest exact-fp32 MFMA; workgroup-split LSTM recurrence)", "parallelism": "dp1"},
         "by_length": res,
     }
     # the dominant family (the stride-1 "same" convolutions on conv1d_mfma_kernel, exact-fp32 MFMA: kokoro/model.cpp:1141-1242) from an

@@ -102,9 +102,10 @@ def test_kokoro_runner_from_file(tmp_path):
     r.close()
 
 
-@pytest.mark.parametrize("tune", [{}, {"kokoro_b3": 0}], ids=["bf16x3_convs", "exact_fp32_convs"])
+@pytest.mark.parametrize("tune", [{}, {"kokoro_split": 0}, {"kokoro_b3": 0}], ids=["fp16_hi_lo_convs", "bf16x3_convs", "exact_fp32_convs"])
 def test_kokoro_82m_shapes_match_oracle(tune):
-    """(default: the k = 3 / 5 / 7 / 11 same-convolutions as bf16 x 3 split products, conv1d_mfma_b3_kernel<.., KT>; fallback: the exact-fp32 MFMA kernel)
+    """(default since round 6: the k = 3 / 5 / 7 / 11 same-convolutions as fp16 hi + lo split products, three MFMAs per product,
+    conv1d_mfma_b3_kernel<.., KT, SplitH2>; tune("kokoro_split") = 0: three bf16 planes, six products; tune("kokoro_b3") = 0: the exact-fp32 MFMA kernel)
     BASELINE config 2's dimensions (hexgrad/Kokoro-82M: ALBERT 768 x 12 recurrences, predictor / text encoder 512, decoder 1024,
     generator 512 -> 256 -> 128, (10, 6) upsampling, n_fft 20 / hop 5) with seeded weights, 10 phoneme ids: durations identical,
     duration states, and the audio from the oracle's conditioning sample for sample"""

@@ -1117,7 +1117,7 @@ __device__ __forceinline__ void split_store(int scheme, float v, __bf16 *dst, in
 __host__ __device__ inline int split_planes(int scheme) { return scheme == 0 ? 3 : scheme == 1 ? 2 : 1; }
 
 //   conv1d  src [cout][cin][7]  ->  dst [co_tile][chunk][plane][s][hi][CO_T][8]   (ci = chunk*8 + j, tap = 2s + hi, tap 7 = 0)
-static __global__ void pack_conv_w_b3_kernel(const float *src, __bf16 *dst, int cout, int cin, int CO_T, int n_chunks, int KT = 7) {
+static __global__ void pack_conv_w_b3_kernel(const float *src, __bf16 *dst, int cout, int cin, int CO_T, int n_chunks, int KT = 7, int scheme = 0) {
     const int NST = (KT + 1) / 2;                                                     // k-steps per chunk: tap pairs (an odd tap count leaves one zero slot)
     const int64_t plane_sz = (int64_t) 2 * NST * CO_T * 8;                            // NST steps x 2 halves x CO_T x 8
     const int64_t total = (int64_t) ((cout + CO_T - 1) / CO_T) * n_chunks * plane_sz;  // one thread per (element, all planes)
@@ -1132,31 +1132,28 @@ static __global__ void pack_conv_w_b3_kernel(const float *src, __bf16 *dst, int 
         const int co = ct * CO_T + col, ci = ch * 8 + j, tap = 2 * st + hi;
         float v = 0.0f;
         if (co < cout && ci < cin && tap < KT) v = src[((int64_t) co * cin + ci) * KT + tap];
-        __bf16 h1, h2, h3;
-        split_bf16x3(v, h1, h2, h3);
-        const int64_t base = ((int64_t) ct * n_chunks + ch) * 3 * plane_sz + (i % plane_sz);
-        dst[base] = h1;
-        dst[base + plane_sz] = h2;
-        dst[base + 2 * plane_sz] = h3;
+        const int64_t base = ((int64_t) ct * n_chunks + ch) * split_planes(scheme) * plane_sz + (i % plane_sz);
+        split_store(scheme, v, dst, base, plane_sz);
     }
 }
 
 // KT (round 4): any odd tap count — (KT + 1) / 2 k-steps of tap pairs per 8-channel chunk, the odd slot on zero weights (Kokoro's k = 3 / 5 / 7 / 11
 // same-convolutions with dilations 1 / 3 / 5; the DAC's fallback k = 7).
-template <int MI, int NI, int WM, int WN, int KT = 7>
+// SP (round 6): the operand split — SplitB3 (three bf16 planes, six products) or SplitH2 (fp16 hi + lo, three products), as in dac_b3_kernels.h.
+template <int MI, int NI, int WM, int WN, int KT = 7, typename SP = SplitB3>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN >= 8 ? 1 : 2) void conv1d_mfma_b3_kernel(ConvArgs a) {   // 2 waves per SIMD either way
-    constexpr int CI_T = 8, NST = (KT + 1) / 2;
+    constexpr int CI_T = 8, NST = (KT + 1) / 2, NPL = SP::NPL;
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, NT = 64 * WM * WN;
     constexpr int WPL = 2 * NST * CO_T * 8;                  // bf16 per weight plane of a chunk
-    constexpr int WV = (3 * WPL / 8 + NT - 1) / NT;          // 16-byte vectors per thread per chunk (all planes)
+    constexpr int WV = (NPL * WPL / 8 + NT - 1) / NT;        // 16-byte vectors per thread per chunk (all planes)
     constexpr int XU = (T_T + (KT - 1) * 9 + NT - 1) / NT;   // positions per thread per chunk (8 channels each), dilation <= 9
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int halo = (KT - 1) * a.dil;
     const int xw = T_T + halo;
     const int xpl = xw * 8;                                  // bf16 per input plane
-    __bf16 *wsb = (__bf16 *) smem;                           // [2][3][WPL]
-    __bf16 *xsb = wsb + 2 * 3 * WPL;                         // [2][3][xpl]
-    float *als = (float *) (xsb + 2 * 3 * xpl);              // [cin_pad] alpha, then [cin_pad] 1/alpha   (xpl * 2 B is a multiple of 16)
+    __bf16 *wsb = (__bf16 *) smem;                           // [2][NPL][WPL]
+    __bf16 *xsb = wsb + 2 * NPL * WPL;                       // [2][NPL][xpl]
+    float *als = (float *) (xsb + 2 * NPL * xpl);            // [cin_pad] alpha, then [cin_pad] 1/alpha   (xpl * 2 B is a multiple of 16)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -1168,7 +1165,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN >= 8 ? 1 : 2) void conv1d_mfm
     const float *xg = a.x + (int64_t) blockIdx.z * a.cin * LS;
     float *yg = a.y + (int64_t) blockIdx.z * a.cout * LS;
     const float *rg = a.resid ? a.resid + (int64_t) blockIdx.z * a.cout * LS : nullptr;
-    const uint4d *wg = (const uint4d *) ((const __bf16 *) a.w + (int64_t) blockIdx.y * n_chunks * 3 * WPL);
+    const uint4d *wg = (const uint4d *) ((const __bf16 *) a.w + (int64_t) blockIdx.y * n_chunks * NPL * WPL);
 
     if (a.alpha && a.alpha_tab) {
         for (int i = tid; i < cin_pad; i += NT) {
@@ -1189,11 +1186,11 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN >= 8 ? 1 : 2) void conv1d_mfm
     uint4d wreg[WV];
     float xreg[XU][8];
     auto prefetch = [&](int c) __attribute__((always_inline)) {
-        const uint4d *wp = wg + (int64_t) c * (3 * WPL / 8);
+        const uint4d *wp = wg + (int64_t) c * (NPL * WPL / 8);
 #pragma unroll
         for (int j = 0; j < WV; j++) {
             const int i = tid + j * NT;
-            if (i < 3 * WPL / 8) wreg[j] = wp[i];
+            if (i < NPL * WPL / 8) wreg[j] = wp[i];
         }
 #pragma unroll
         for (int j = 0; j < XU; j++) {
@@ -1208,18 +1205,18 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN >= 8 ? 1 : 2) void conv1d_mfm
         }
     };
     auto commit = [&](int c, int buf) __attribute__((always_inline)) {
-        uint4d *wd = (uint4d *) (wsb + buf * 3 * WPL);
+        uint4d *wd = (uint4d *) (wsb + buf * NPL * WPL);
 #pragma unroll
         for (int j = 0; j < WV; j++) {
             const int i = tid + j * NT;
-            if (i < 3 * WPL / 8) wd[i] = wreg[j];
+            if (i < NPL * WPL / 8) wd[i] = wreg[j];
         }
-        __bf16 *xd = xsb + buf * 3 * xpl;
+        __bf16 *xd = xsb + buf * NPL * xpl;
 #pragma unroll
         for (int j = 0; j < XU; j++) {
             const int p = tid + j * NT;
             if (p < xw) {
-                bf16x8d h1, h2, h3;
+                bf16x8d hp[NPL];
                 if (a.alpha) {
                     float al[8], ral[8];
 #pragma unroll
@@ -1232,13 +1229,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN >= 8 ? 1 : 2) void conv1d_mfm
                 }
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    __bf16 b1, b2, b3;
-                    split_bf16x3(xreg[j][e], b1, b2, b3);
-                    h1[e] = b1; h2[e] = b2; h3[e] = b3;
+                    __bf16 bp[NPL];
+                    SP::split(xreg[j][e], bp);
+#pragma unroll
+                    for (int pl = 0; pl < NPL; pl++) hp[pl][e] = bp[pl];
                 }
-                *(bf16x8d *) (xd + p * 8) = h1;
-                *(bf16x8d *) (xd + xpl + p * 8) = h2;
-                *(bf16x8d *) (xd + 2 * xpl + p * 8) = h3;
+#pragma unroll
+                for (int pl = 0; pl < NPL; pl++) *(bf16x8d *) (xd + pl * xpl + p * 8) = hp[pl];
             }
         }
     };
@@ -1250,14 +1247,14 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN >= 8 ? 1 : 2) void conv1d_mfm
     for (int c = 0; c < n_chunks; c++) {
         const int buf = c & 1;
         if (c + 1 < n_chunks) prefetch(c + 1);
-        const __bf16 *ws = wsb + buf * 3 * WPL;
-        const __bf16 *xs = xsb + buf * 3 * xpl;
+        const __bf16 *ws = wsb + buf * NPL * WPL;
+        const __bf16 *xs = xsb + buf * NPL * xpl;
 #pragma unroll
         for (int st = 0; st < NST; st++) {
             const int tap = (2 * st + hi < KT) ? 2 * st + hi : KT - 1;   // the slot past the last tap: zero weights, any valid rows
-            bf16x8d af[3][MI], bf[3][NI];
+            bf16x8d af[NPL][MI], bf[NPL][NI];
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
+            for (int pl = 0; pl < NPL; pl++) {
 #pragma unroll
                 for (int i = 0; i < MI; i++)
                     af[pl][i] = *(const bf16x8d *) (ws + pl * WPL + (((st * 2 + hi) * CO_T) + (wm * MI + i) * 32 + l31) * 8);
@@ -1265,15 +1262,14 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN >= 8 ? 1 : 2) void conv1d_mfm
                 for (int j = 0; j < NI; j++)
                     bf[pl][j] = *(const bf16x8d *) (xs + pl * xpl + ((wn * NI + j) * 32 + l31 + tap * a.dil) * 8);
             }
-            // the six terms, smallest first; term-major so that consecutive MFMAs write different accumulators
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+            // the partial products, smallest first; term-major so that consecutive MFMAs write different accumulators
 #pragma unroll
-            for (int tm = 0; tm < 6; tm++)
+            for (int tm = 0; tm < SP::NT; tm++)
 #pragma unroll
                 for (int i = 0; i < MI; i++)
 #pragma unroll
                     for (int j = 0; j < NI; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[tm]][i], bf[TB[tm]][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = SP::mfma(af[SP::ta(tm)][i], bf[SP::tb(tm)][j], acc[i][j]);
         }
         if (c + 1 < n_chunks) commit(c + 1, buf ^ 1);
         __syncthreads();

@@ -78,12 +78,14 @@ static int pack_one16(tts_hip_ctx *c, size_t w_off, int cout, int cin, int KT, i
 }
 // operand split of the plane kernels (dac_kernels.h): 0 = bf16 x 3 / six products, 1 = fp16 hi + lo / three products (F32 tensors), 2 = fp16 / one product (F16 tensors)
 static int dac_scheme(const tts_hip_ctx *c) { return c->dac_f16 ? 2 : (c->dac_split ? 1 : 0); }
+// scheme: 0 = three bf16 planes, 1 = fp16 hi + lo (conv1d_mfma_b3_kernel<.., SplitB3 / SplitH2>)
+static int b3_scheme(const tts_hip_ctx *c) { return c->has_kokoro ? (c->kk_split ? 1 : 0) : (c->dac_split ? 1 : 0); }
 static int pack_one_b3(tts_hip_ctx *c, size_t w_off, int cout, int cin, int CO_T, int KT = 7) {   // 64- or 96-channel tiles, 8 input channels per chunk, tap pairs
-    const int n_chunks = (cin + 7) / 8;
-    const size_t n = (size_t) ((cout + CO_T - 1) / CO_T) * n_chunks * 3 * (2 * ((KT + 1) / 2)) * CO_T * 8;
+    const int n_chunks = (cin + 7) / 8, scheme = b3_scheme(c);
+    const size_t n = (size_t) ((cout + CO_T - 1) / CO_T) * n_chunks * split_planes(scheme) * (2 * ((KT + 1) / 2)) * CO_T * 8;
     __bf16 *dst = nullptr;
     HIPCHK(hipMalloc((void **) &dst, n * 2));
-    hipLaunchKernelGGL(pack_conv_w_b3_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + w_off), dst, cout, cin, CO_T, n_chunks, KT);
+    hipLaunchKernelGGL(pack_conv_w_b3_kernel, dim3(1024), dim3(256), 0, c->stream, (const float *) (c->arena + w_off), dst, cout, cin, CO_T, n_chunks, KT, scheme);
     HIPCHK(hipGetLastError());
     c->packed_b3[w_off] = dst;
     return 0;
@@ -252,22 +254,26 @@ static int launch_conv_mfma(tts_hip_ctx *c, const ConvArgs &a_in, int nz) {
 
 // k = 7 conv as six bf16 MFMAs per product (experiment): 64 channels x 256 positions per workgroup of 4 waves,
 // or 96 channels x 256 positions per workgroup of 8 waves
-template <int MI, int NI, int WM, int WN, int KT = 7>
-static int launch_conv_b3(tts_hip_ctx *c, const ConvArgs &a_in, int nz) {
+template <int MI, int NI, int WM, int WN, int KT, typename SP>
+static int launch_conv_b3_s(tts_hip_ctx *c, const ConvArgs &a_in, int nz) {
     constexpr int CO_T = 32 * MI * WM, T_T = 32 * NI * WN, WPL = 2 * ((KT + 1) / 2) * CO_T * 8;
     const int xw = T_T + (KT - 1) * a_in.dil;
     const int cin_pad = (a_in.cin + 7) / 8 * 8;
     ConvArgs a = a_in;
-    const size_t lds = dac_lds_request(c, ((size_t) 6 * WPL + 6 * (size_t) xw * 8) * 2, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab, true);
+    const size_t lds = dac_lds_request(c, ((size_t) 2 * SP::NPL * WPL + 2 * SP::NPL * (size_t) xw * 8) * 2, (a.alpha ? 2 * (size_t) cin_pad : 0) * 4, &a.alpha_tab, true);
     static std::atomic<uint64_t> attr{0};
     if (attr_needed(attr, c->device)) {
-        HIPCHK(hipFuncSetAttribute((const void *) conv1d_mfma_b3_kernel<MI, NI, WM, WN, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) conv1d_mfma_b3_kernel<MI, NI, WM, WN, KT, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const dim3 grid((a.L + T_T - 1) / T_T, (a.cout + CO_T - 1) / CO_T, nz);
     if (lds > 160 * 1024) return set_err("conv1d_mfma_b3: k = %d at dilation %d needs %zu bytes of LDS", KT, a.dil, lds);
-    hipLaunchKernelGGL((conv1d_mfma_b3_kernel<MI, NI, WM, WN, KT>), grid, dim3(64 * WM * WN), lds, c->stream, a);
+    hipLaunchKernelGGL((conv1d_mfma_b3_kernel<MI, NI, WM, WN, KT, SP>), grid, dim3(64 * WM * WN), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
+}
+template <int MI, int NI, int WM, int WN, int KT = 7>
+static int launch_conv_b3(tts_hip_ctx *c, const ConvArgs &a, int nz) {
+    return b3_scheme(c) ? launch_conv_b3_s<MI, NI, WM, WN, KT, SplitH2>(c, a, nz) : launch_conv_b3_s<MI, NI, WM, WN, KT, SplitB3>(c, a, nz);
 }
 
 template <int KT, int MI, int NI, int WM, int WN, int CI_T>
