@@ -141,7 +141,9 @@ def test_one_sequence_kernels_request_their_staging_inputs_before_the_weights(tm
         assert must.split("<")[0] in open(asm).read()
         out = subprocess.run([sys.executable, tool, str(asm)], capture_output=True, text=True, check=True).stdout
         filt = subprocess.run(["c++filt"], input=out, capture_output=True, text=True).stdout if shutil.which("c++filt") else out
-        bad = [ln for ln in filt.splitlines() if must in ln and "gemm16_kernel<1, 6," not in ln]
+        # (qgemv_stream_kernel, the 5 .. 64-row integer form of round 6, is not a one-sequence kernel: its staging goes out before the weights too, but a
+        #  slice larger than its straight-line staging is finished by loops behind the weight requests — by design, under the weights' flight)
+        bad = [ln for ln in filt.splitlines() if must in ln and "gemm16_kernel<1, 6," not in ln and "qgemv_stream_kernel" not in ln]
         assert not bad, "\n".join(bad)
         if name == "parler_wo":
             # PRO_CROSS (the cross-attention in the out projection's prologue): the softmax over the first eight keys must start before the weights
