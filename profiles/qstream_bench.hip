@@ -63,9 +63,10 @@ __global__ __launch_bounds__(256) void read_kernel(const int4v *p, size_t n16, i
 }
 
 typedef void (*kern_t)(QGemmArgs, StreamMap);
-struct Cfg { const char *name; int nwv, depth, rt; kern_t k; };
-#define CFG(NWV, D, RT) { "w" #NWV "d" #D "rt" #RT, NWV, D, RT, qgemv_stream_kernel<NWV, D, RT> }
-static const Cfg CFGS[] = { CFG(4, 2, 1), CFG(4, 3, 1), CFG(8, 2, 1), CFG(8, 3, 1), CFG(4, 2, 2), CFG(8, 2, 2), CFG(4, 2, 4), CFG(8, 2, 4) };
+struct Cfg { const char *name; int nwv, depth, rt, wl; kern_t k; };
+#define CFG(NWV, D, RT) { "w" #NWV "d" #D "rt" #RT, NWV, D, RT, 0, qgemv_stream_kernel<NWV, D, RT> }
+#define CFGL(NWV, D, RT) { "w" #NWV "d" #D "rt" #RT "lds", NWV, D, RT, 1, qgemv_stream_kernel<NWV, D, RT, true> }
+static const Cfg CFGS[] = { CFG(4, 2, 1), CFG(8, 2, 1), CFGL(4, 2, 1), CFGL(4, 3, 1), CFGL(8, 2, 1), CFGL(8, 3, 1), CFG(8, 2, 2), CFGL(8, 2, 2), CFGL(8, 3, 2) };
 struct Shape { const char *name; int K, N; };
 static const Shape SHAPES[] = { {"qkv", 3072, 5120}, {"o", 3072, 3072}, {"gate|up", 3072, 16384}, {"down", 8192, 3072}, {"head", 3072, 156940} };
 
@@ -123,7 +124,7 @@ int main(int argc, char **argv) {
                 const StreamMap sm{ks, KS};
                 auto launch = [&](int b) {
                     qa.g.W = W + (size_t) b * wbytes; qa.wd = wd + (size_t) b * N * nb;
-                    hipLaunchKernelGGL(c.k, dim3(grid), dim3(c.nwv * 64), lds, 0, qa, sm);
+                    hipLaunchKernelGGL(c.k, dim3(grid), dim3(c.nwv * 64), ((lds + 15) & ~(size_t) 15) + (c.wl ? (size_t) c.nwv * c.depth * 4096 : 0), 0, qa, sm);
                 };
                 CK(hipMemset(out, 0xff, (size_t) 16 * 64 * N * 4));
                 launch(0);

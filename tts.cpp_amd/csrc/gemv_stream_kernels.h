@@ -193,7 +193,9 @@ __global__ __launch_bounds__(NWV * 64) void gemv_stream_kernel(GemmArgs a, Strea
 //   * K slices write fp32 slabs (slab kz of `out`, slab_stride floats apart) that the consumer folds in slab order (llama_rope_kv_kernel, silu_mul_kernel,
 //     rms_fold_rows_kernel), like gemv_stream_kernel.  N need not be a multiple of 16 (the LM head): a last tile re-reads feature N - 1 and stores nothing for it.
 // ================================================================================================================================
-template <int NWV, int DEPTH = 2, int RT = 1>
+// WL (experiment, profiles/qstream_bench.hip): the weight codes go through a per-wave LDS ring (global_load_lds, 256 contiguous bytes per matrix row and
+// instruction instead of 64; XOR-swizzled by permuting the source pieces) and the fragments are read back with ds_read_b128.
+template <int NWV, int DEPTH = 2, int RT = 1, bool WL = false>
 __global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, StreamMap sm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemmArgs &a = qa.g;
@@ -208,11 +210,21 @@ __global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, St
     const int tiles = (a.N + 15) >> 4, nc = KS >> 8;
     const int tstep = nwg_in * NWV;
     const int8_t *wbase = (const int8_t *) a.W + k0 + g * 16;
-    struct WSet { int4v w[4]; half8 d[4]; };
-    auto loadw = [&](WSet &s, int tile, int chunk) __attribute__((always_inline)) {
-        const int8_t *p = wbase + (int64_t) min(tile * 16 + li, a.N - 1) * a.K + chunk * 256;
+    struct WSet { int4v w[WL ? 1 : 4]; half8 d[4]; };
+    char *const ring = smem + ((((size_t) (RS + 1) * KS + (size_t) RS * nbs * 4) + 15) & ~(size_t) 15) + (size_t) wave * DEPTH * 4096;   // WL: DEPTH x [16 rows][256 B] per wave
+    auto loadw = [&](WSet &s, int slot, int tile, int chunk) __attribute__((always_inline)) {
+        if constexpr (WL) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) s.w[c] = __builtin_nontemporal_load((const int4v *) (p + c * 64));
+            for (int j = 0; j < 4; j++) {   // rows 4 j .. 4 j + 3 of the tile: lane -> (row, slot of the row's 256 bytes), which must hold source piece slot ^ (row & 15)
+                const int r = 4 * j + (lane >> 4), piece = (lane & 15) ^ (r & 15);
+                const int8_t *p = (const int8_t *) a.W + (int64_t) min(tile * 16 + r, a.N - 1) * a.K + k0 + chunk * 256 + piece * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) p, (__attribute__((address_space(3))) void *) (ring + slot * 4096 + j * 1024), 16, 0, 0);
+            }
+        } else {
+            const int8_t *p = wbase + (int64_t) min(tile * 16 + li, a.N - 1) * a.K + chunk * 256;
+#pragma unroll
+            for (int c = 0; c < 4; c++) s.w[c] = __builtin_nontemporal_load((const int4v *) (p + c * 64));
+        }
 #pragma unroll
         for (int e = 0; e < 4; e++) s.d[e] = __builtin_nontemporal_load((const half8 *) (qa.wd + (int64_t) min(tile * 16 + g * 4 + e, a.N - 1) * nb + (k0 >> 5) + chunk * 8));
     };
@@ -234,9 +246,10 @@ __global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, St
     int t = wg_in * NWV + wave, ch = 0, lt = t, lch = 0;
     auto advance = [&](int &tt, int &cc) __attribute__((always_inline)) { if (++cc == nc) { cc = 0; tt += tstep; } };
     WSet w[DEPTH];
+    int inflight = 0;   // WL: sets requested and not yet consumed (8 vector-memory operations each: the wait before a set's LDS reads counts them)
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; d++) {   // DEPTH - 1 sets in flight before the first MFMA
-        if (d == 0 || lt < tiles) loadw(w[d], min(lt, tiles - 1), lch);
+        if (d == 0 || lt < tiles) { loadw(w[d], d, min(lt, tiles - 1), lch); inflight++; }
         advance(lt, lch);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -269,17 +282,28 @@ __global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, St
     float4v acc[RT];
 #pragma unroll
     for (int j = 0; j < RT; j++) acc[j] = (float4v){0.f, 0.f, 0.f, 0.f};
-    auto step = [&](WSet &cur, WSet &nxt) __attribute__((always_inline)) {
-        if (lt < tiles) loadw(nxt, lt, lch);
+    auto step = [&](WSet &cur, WSet &nxt, int cslot, int nslot) __attribute__((always_inline)) {
+        if (lt < tiles) { loadw(nxt, nslot, lt, lch); inflight++; }
         advance(lt, lch);
+        int4v wl[4];
+        if constexpr (WL) {
+            // the current set's DMA has landed once at most the later sets' operations are outstanding (vmcnt counts in issue order)
+            if (inflight >= 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (inflight == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            inflight--;
+#pragma unroll
+            for (int c = 0; c < 4; c++) wl[c] = *(const int4v *) (ring + cslot * 4096 + li * 256 + (((c * 4 + g) ^ li) << 4));
+        }
 #pragma unroll
         for (int j = 0; j < RT; j++) {
             const float4v da0 = *(const float4v *) (sb + j * 16 * nbs + ch * 8), da1 = *(const float4v *) (sb + j * 16 * nbs + ch * 8 + 4);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int4v zero = {0, 0, 0, 0};
-                const int4v ze = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.w[c], *(const int4v *) (x_even + j * tile_even + ch * 256 + off[c]), zero, 0, 0, 0);   // exact block dots
-                const int4v zo = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.w[c], *(const int4v *) (x_odd + j * tile_odd + ch * 256 + off[c]), zero, 0, 0, 0);
+                const int4v wc = WL ? wl[c] : cur.w[WL ? 0 : c];
+                const int4v ze = __builtin_amdgcn_mfma_i32_16x16x64_i8(wc, *(const int4v *) (x_even + j * tile_even + ch * 256 + off[c]), zero, 0, 0, 0);   // exact block dots
+                const int4v zo = __builtin_amdgcn_mfma_i32_16x16x64_i8(wc, *(const int4v *) (x_odd + j * tile_odd + ch * 256 + off[c]), zero, 0, 0, 0);
                 const float dae = c < 2 ? da0[2 * c] : da1[2 * c - 4], dao = c < 2 ? da0[2 * c + 1] : da1[2 * c - 3];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -308,7 +332,7 @@ __global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, St
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) {
             if (d && t >= tiles) break;
-            step(w[d], w[(d + DEPTH - 1) % DEPTH]);
+            step(w[d], w[(d + DEPTH - 1) % DEPTH], d, (d + DEPTH - 1) % DEPTH);
         }
     }
 }
