@@ -393,7 +393,9 @@ int tts_hip_dac_decode_batch(tts_hip_ctx *ctx, const uint32_t *codes, const uint
 /* Copy an internal buffer to the host.  what: "hidden" (final-normed hidden of the last forward,
  * [rows][H]), "k:<layer>:<seq>" / "v:<layer>:<seq>" (cache rows [n_pos][H] as fp32),
  * "dac:<stage>" (activation after DAC stage, see oracle stage numbering; requires
- * tts_hip_set_debug(ctx,1) before the decode).  Returns number of floats written or <0. */
+ * tts_hip_set_debug(ctx,1) before the decode); Orpheus contexts: "l_logits" (the logits row the last
+ * step left), "l_k:<layer>" / "l_v:<layer>" (cache slot 0 of a layer, [n_ctx][kv width]).
+ * Returns number of floats written or <0. */
 int64_t tts_hip_debug_read(tts_hip_ctx *ctx, const char *what, float *out, size_t max_floats);
 int     tts_hip_set_debug(tts_hip_ctx *ctx, int on);
 
