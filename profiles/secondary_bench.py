@@ -412,9 +412,11 @@ def run_kokoro(args):
         # round 4: the k = 3 / 5 / 7 / 11 convolutions run as bf16 x 3 split products (six v_mfma_f32_32x32x16_bf16 per product term, tap pairs per k-step):
         # priced like the DAC families — ISSUED bf16 flops (6 x the algorithmic ones; the odd tap slot adds 9-33 % on top, not counted) against the
         # 2.5 PFLOP/s dense bf16 peak, the fp32-equivalent rate beside it (the exact-fp32 MFMA kernel of round 3 reached 65 TF of 157.3)
-        out["roofline"] = {"bound": "mfma", "achieved": round(6 * tf, 3), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(6 * tf / 2500.0, 4), "traffic": _pmc("kokoro_conv_mfma"),
-                           "fp32_equivalent_TFLOPs": round(tf, 3),
-                           "kernel": "conv1d_mfma_b3_kernel<2,1,1,8, 3 / 5 / 7 / 11> (generator + AdaIN + text-encoder convolutions, bf16 x 3 split products; k = 1 stays on the exact-fp32 MFMA kernel)",
+        # round 6: fp16 hi + lo split, three products (tune kokoro_split = 0: the six-product bf16 form)
+        mult = 6 if ktune.get("kokoro_split", 1) == 0 else 3
+        out["roofline"] = {"bound": "mfma", "achieved": round(mult * tf, 3), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(mult * tf / 2500.0, 4), "traffic": _pmc("kokoro_conv_mfma"),
+                           "fp32_equivalent_TFLOPs": round(tf, 3), "products_per_fp32_product": mult,
+                           "kernel": "conv1d_mfma_b3_kernel<2,1,1,8, 3 / 5 / 7 / 11, SplitH2 | SplitB3> (generator + AdaIN + text-encoder convolutions as split products; k = 1 stays on the exact-fp32 MFMA kernel)",
                            "avg_launch_us": round(st["ms_total"] / st["launches"] * 1e3, 2), "launches": st["launches"],
                            "share_of_wall_time": round(st["ms_total"] * 1e-3 / wall, 3),
                            "algorithmic_flops_per_launch": round(st["flops_total"] / st["launches"], 1),
@@ -423,6 +425,28 @@ def run_kokoro(args):
     else:
         out["roofline"] = None
     eng.close()
+    # utterance-level concurrency, the reference's own model (N independent workers, examples/server/server.cpp:225-321): N contexts on N streams of the one
+    # GPU, a host thread each (ctypes releases the GIL inside a call), every context synthesising the 400-id utterance `steps` times.  One synthesis is a
+    # chain of short launches (LSTMs, AdaIN, iSTFT): the GPU is far from full with one context.
+    import threading
+    out["concurrent_contexts"] = {}
+    for n_ctx in tuple(int(x) for x in os.environ.get("TTS_BENCH_KOKORO_CONTEXTS", "2,4,8").split(",") if x):
+        engs = [hip.KokoroEngine(model, tune=ktune) for _ in range(n_ctx)]
+        def work(e, reps, box):
+            a = 0.0
+            for _ in range(reps):
+                lens, hid = e.durations(toks, cfg.voices[0])
+                a += e.generate(toks, forced, hid, cfg.voices[0], noise).size / 24000.0
+            box.append(a)
+        for reps in (1, max(2, args.steps)):   # warm-up, then the timed pass
+            box = []
+            th = [threading.Thread(target=work, args=(e, reps, box)) for e in engs]
+            t0 = time.perf_counter()
+            for t in th: t.start()
+            for t in th: t.join()
+            dt = time.perf_counter() - t0
+        out["concurrent_contexts"][str(n_ctx)] = {"audio_seconds_per_sec": round(sum(box) / dt, 1), "syntheses": n_ctx * max(2, args.steps), "seconds": round(dt, 3)}
+        for e in engs: e.close()
     if not args.no_cpu_baseline:
         orc = _oracle()
         o = orc.KokoroOracle(model)
