@@ -653,6 +653,74 @@ def test_accumulators_as_b_fragments_restatement():
     assert np.abs(out - ref).max() < 1e-12
 
 
+def test_streaming_integer_gemm_two_blocks_per_mfma_restatement():
+    """qgemv_stream_kernel (gemv_stream_kernels.h, round 6) restated in numpy: a lane's 16 bytes are the A operand of v_mfma_i32_16x16x64_i8, whose 64
+    columns are TWO Q8_0 blocks (lane groups 0, 1 hold the even block, groups 2, 3 the odd one).  Two MFMAs per span with the other block's lane groups
+    reading a row of zeros give the two exact block dots; the LDS image of the rows is XOR-swizzled by the row (16-byte piece p of row r at piece
+    p ^ (r & 15)), the last tile of an N that is no multiple of 16 re-reads feature N - 1, K slices leave slabs folded in slab order — and the result is
+    ggml_vec_dot_q8_0_q8_0's sum over blocks of (float) sumi * (d_w * d_a), block after block, in fp32."""
+    rng = np.random.default_rng(6)
+    R, N, K, ks = 7, 37, 1024, 2                      # 7 rows (the 8-row image), 37 features (3 tiles, the last one 5 wide), two K slices of two chunks
+    KS, nb, RS = K // ks, K // 32, 8
+    W = rng.integers(-127, 128, (N, K)).astype(np.int8)
+    wd = (rng.random((N, nb)) * 0.02 + 0.001).astype(np.float16)
+    aq = rng.integers(-127, 128, (R, K)).astype(np.int8)
+    ad = (rng.random((R, nb)) * 0.05 + 0.001).astype(np.float32)
+    # reference: block after block
+    ref = np.zeros((R, N), np.float32)
+    for b in range(nb):
+        sumi = aq[:, b * 32:(b + 1) * 32].astype(np.int32) @ W[:, b * 32:(b + 1) * 32].astype(np.int32).T
+        ref = (ref + sumi.astype(np.float32) * (ad[:, b:b + 1] * wd[:, b].astype(np.float32)[None, :]).astype(np.float32)).astype(np.float32)
+
+    def mfma_16x16x64(a_lanes, b_lanes):          # a_lanes / b_lanes [64 lanes][16 bytes]: D[i][j] = sum over lane groups g and the 16 bytes of A[i, g] * B[j, g]
+        d = np.zeros((16, 16), np.int64)
+        for g in range(4):
+            d += a_lanes[g * 16:(g + 1) * 16].astype(np.int64) @ b_lanes[g * 16:(g + 1) * 16].astype(np.int64).T
+        return d                                   # lane (li, g) ends with D[4 g + e][li], e = 0 .. 3
+
+    slabs = np.zeros((ks, 16, N), np.float32)
+    for kz in range(ks):
+        k0 = kz * KS
+        # the LDS image of this slice: [RS + 1][KS] bytes, rows >= R repeat row R - 1, row RS zeros, pieces swizzled
+        xs = np.zeros((RS + 1, KS), np.int8)
+        for r in range(RS):
+            src = aq[min(r, R - 1), k0:k0 + KS].reshape(KS // 16, 16)
+            for cv in range(KS // 16):
+                blk, pc = divmod(cv, 16)
+                xs[r, (blk * 16 + (pc ^ (r & 15))) * 16:][:16] = src[cv]
+        for t in range((N + 15) // 16):
+            acc = np.zeros((16, 16), np.float32)   # [feature of the tile][row li]
+            for ch in range(KS // 256):
+                for c in range(4):                  # a 64-column span = blocks 2 c and 2 c + 1 of the chunk
+                    a_l = np.zeros((64, 16), np.int8); be = np.zeros((64, 16), np.int8); bo = np.zeros((64, 16), np.int8)
+                    for lane in range(64):
+                        li, g = lane & 15, lane >> 4
+                        a_l[lane] = W[min(t * 16 + li, N - 1), k0 + ch * 256 + c * 64 + g * 16:][:16]
+                        row = li & (RS - 1)
+                        off = ch * 256 + (((c * 4 + g) ^ (row & 15)) << 4)
+                        be[lane] = xs[row if g < 2 else RS, off:off + 16]
+                        bo[lane] = xs[RS if g < 2 else row, off:off + 16]
+                    ze, zo = mfma_16x16x64(a_l, be), mfma_16x16x64(a_l, bo)
+                    for which, z in ((0, ze), (1, zo)):
+                        b = (k0 >> 5) + ch * 8 + 2 * c + which
+                        # the block dot is exact and only this block's
+                        feats = np.minimum(t * 16 + np.arange(16), N - 1)
+                        want = W[feats, b * 32:(b + 1) * 32].astype(np.int64) @ aq[np.minimum(np.arange(16) & (RS - 1), R - 1), b * 32:(b + 1) * 32].astype(np.int64).T
+                        assert np.array_equal(z, want)
+                        dw = wd[feats, b].astype(np.float32)[:, None]
+                        da = ad[np.minimum(np.arange(16) & (RS - 1), R - 1), b][None, :]
+                        acc = (acc + z.astype(np.float32) * (dw * da).astype(np.float32)).astype(np.float32)
+            for f in range(16):
+                if t * 16 + f < N:
+                    slabs[kz, :, t * 16 + f] = acc[f]
+    out = slabs[0].copy()
+    for kz in range(1, ks):
+        out = (out + slabs[kz]).astype(np.float32)
+    # two K slices: the same terms in k order inside a slice, associated as (slice 0) + (slice 1): equal up to the fp32 rounding of the partial sums
+    # (one slice is ggml's order exactly)
+    assert np.abs(out[:R] - ref).max() <= 4e-7 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("dims", ["tiny", "dac44k"])
 def test_fp16_im2col_reading_of_an_f32_codec_model(dims):
     """upstream ggml_conv_1d always goes through an F16 im2col (general_neural_audio_codec.cpp:142,146, dac_model.cpp:158,164), so
