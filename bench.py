@@ -327,14 +327,21 @@ def load_runners(path, args, rank, world, local_rank, backend, dist, torch, gen_
     return runners, info
 
 
-def run_all(runners, texts, timings_=None, stream=False):
+def run_all(runners, texts, timings_=None, stream=False, reps=1):
+    """Every runner (a host thread each) makes `reps` generate calls back to back; returns when all are done.  reps > 1: the runners of a GPU are not
+    joined between their calls — a runner that finishes a batch starts its next one at once, as the workers of a server do, so one runner's codec passes
+    keep falling on the others' decoder loops instead of all runners idling into a common tail after every batch."""
     res = [None] * len(runners)
 
     def work(i):
         try:
-            t0 = time.perf_counter()
-            sizes = runners[i].generate_stream(texts[i], sizes_only=True) if stream else runners[i].generate_batch_sizes(texts[i])
-            res[i] = (sum(sizes), time.perf_counter() - t0)
+            n, dt = 0, 0.0
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                sizes = runners[i].generate_stream(texts[i], sizes_only=True) if stream else runners[i].generate_batch_sizes(texts[i])
+                n += sum(sizes)
+                dt += time.perf_counter() - t0
+            res[i] = (n, dt / reps)
         except Exception as e:   # surfaced by the caller: a worker thread must not fail silently
             res[i] = e
 
@@ -594,6 +601,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--join-steps", action="store_true", help="join all runners of the GPU after every batch (rounds 1-5); default: the runners make their K calls back to back")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TTS_BENCH_BATCH", "1024")),
                     help="utterances per context decoded in lock-step (1024: every decoder GEMM is whole rounds of tiles over the 256 CUs; 3 x 384 was the round-2 default)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TTS_BENCH_STREAMS", "3")),
@@ -725,8 +733,11 @@ def main():
     timings = []
     t0 = time.perf_counter()
     n_samples = 0
-    for _ in range(args.steps):
-        n_samples += run_all(runners, all_texts, timings)
+    if args.join_steps:
+        for _ in range(args.steps):
+            n_samples += run_all(runners, all_texts, timings)
+    else:   # K steps = every runner's K batches, free-running between the two barriers (round 6; --join-steps: all runners joined after every batch)
+        n_samples += run_all(runners, all_texts, timings, reps=args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     live = {}
@@ -778,8 +789,10 @@ def main():
         "rccl_ranks": world if (world > 1 and bcast and "RCCL" in bcast.get("via", "")) else 0,
         "weight_broadcast": bcast,
         "ms_per_generate_batch": round(float(np.mean(timings)) * 1e3, 3),
-        "ms_per_generate_batch_note": "mean wall time of one runner's tts_c_generate_batch call; ms_per_step is the wall time until ALL runners of the "
-                                      "step are done (runners wait for each other's turn at the per-device codec mutex: one 64-utterance codec pass at a time)",
+        "runners_joined_per_step": bool(args.join_steps),
+        "ms_per_generate_batch_note": "mean wall time of one runner's tts_c_generate_batch call; ms_per_step is elapsed / K where K = the calls every runner makes between the two barriers "
+                                      "(runners_joined_per_step false: back to back, no join between a runner's calls; true: the wall time until ALL runners of the "
+                                      "step are done); runners take turns at the per-device codec mutex: one 64-utterance codec pass at a time",
     }
 
     if rank == 0:
