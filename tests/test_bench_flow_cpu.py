@@ -41,13 +41,13 @@ def bench(monkeypatch):
         kv = []
         def write_gguf(self, p): open(p, "w").close()
 
-    def run_all(runners, texts, timings_=None, stream=False):
+    def run_all(runners, texts, timings_=None, stream=False, reps=1):   # reps: the timed region's runners make their K calls back to back (round 6)
         n = sum(len(t) for t in texts)
         warm = len(texts[0]) > 1 and texts[0][0] == texts[0][-1] and texts[0][0].startswith("w" * 40)   # the long section's 48-step warm-up
-        clock[0] += (61.0 if n > 100 else 2.0) if stream else (11.8 if len(texts[0]) >= 1000 else 5.0 if warm else 33.0)
+        clock[0] += reps * ((61.0 if n > 100 else 2.0) if stream else (11.8 if len(texts[0]) >= 1000 else 5.0 if warm else 33.0))
         if timings_ is not None:
             timings_.append(9.7)
-        return n * 100000
+        return reps * n * 100000
 
     def costs(seconds, ret):
         def f(*a, **k):
