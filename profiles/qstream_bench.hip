@@ -66,7 +66,7 @@ typedef void (*kern_t)(QGemmArgs, StreamMap);
 struct Cfg { const char *name; int nwv, depth, rt, wl; kern_t k; };
 #define CFG(NWV, D, RT) { "w" #NWV "d" #D "rt" #RT, NWV, D, RT, 0, qgemv_stream_kernel<NWV, D, RT> }
 #define CFGL(NWV, D, RT) { "w" #NWV "d" #D "rt" #RT "lds", NWV, D, RT, 1, qgemv_stream_kernel<NWV, D, RT, true> }
-static const Cfg CFGS[] = { CFG(4, 2, 1), CFG(8, 2, 1), CFGL(4, 2, 1), CFGL(4, 3, 1), CFGL(8, 2, 1), CFGL(8, 3, 1), CFG(8, 2, 2), CFGL(8, 2, 2), CFGL(8, 3, 2) };
+static const Cfg CFGS[] = { CFG(4, 2, 1), CFG(8, 2, 1), CFGL(4, 2, 1), CFGL(8, 2, 1), CFG(4, 2, 2), CFG(8, 2, 2), CFGL(8, 2, 2), CFG(4, 2, 4), CFG(8, 2, 4) };
 struct Shape { const char *name; int K, N; };
 static const Shape SHAPES[] = { {"qkv", 3072, 5120}, {"o", 3072, 3072}, {"gate|up", 3072, 16384}, {"down", 8192, 3072}, {"head", 3072, 156940} };
 
@@ -76,7 +76,10 @@ int main(int argc, char **argv) {
     int *sink; CK(hipMalloc(&sink, 4));
     for (const Cfg &c : CFGS) CK(hipFuncSetAttribute((const void *) c.k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const char *only_shape = getenv("QSTREAM_SHAPE"), *only_cfg = getenv("QSTREAM_CFG");   // e.g. QSTREAM_SHAPE=head QSTREAM_CFG=w8d2rt1 QSTREAM_KS=1: one line (counter runs)
+    const int only_ks = getenv("QSTREAM_KS") ? atoi(getenv("QSTREAM_KS")) : 0;
     for (const Shape &sh : SHAPES) {
+        if (only_shape && strcmp(only_shape, sh.name)) continue;
         const int K = sh.K, N = sh.N, nb = K / 32;
         const size_t wbytes = (size_t) N * K, sbytes = (size_t) N * nb * 2;
         const int NBUF = (int) std::max<size_t>(2, std::min<size_t>(24, (size_t) 1200e6 / (wbytes + sbytes)));
@@ -107,13 +110,13 @@ int main(int argc, char **argv) {
         }
         const int tiles = (N + 15) / 16;
         for (int ks : {1, 2, 3, 4, 6, 8, 12, 16}) {
-            if (K % (ks * 256)) continue;
+            if (K % (ks * 256) || (only_ks && ks != only_ks)) continue;
             const int KS = K / ks;
             const int srows = R <= 16 ? 16 : R <= 32 ? 32 : 64, RS = R <= 8 ? 8 : srows;
             const size_t lds = (size_t) (RS + 1) * KS + (size_t) RS * (KS / 32) * 4;
             if (lds > 64 * 1024) continue;
             for (const Cfg &c : CFGS) {
-                if (c.rt * 16 != srows) continue;
+                if (c.rt * 16 != srows || (only_cfg && strcmp(only_cfg, c.name))) continue;
                 const int items = tiles * ks;
                 int grid = ((items + c.nwv - 1) / c.nwv + ks - 1) / ks * ks;
                 const int maxwg = 256 * std::max(1, 16 / c.nwv) * 2;   // persistent beyond that: waves walk several tiles

@@ -153,26 +153,38 @@ __global__ __launch_bounds__(NWV * 64) void gemv_stream_kernel(GemmArgs a, Strea
 
     const _Float16 *xb = xs + (size_t) (li & (RS - 1)) * ldx + g * 8;
     float4v acc = {0.f, 0.f, 0.f, 0.f};
-    // one pipeline step: issue the loads of the pair after (t, ch) into `nxt`, run the MFMAs of (t, ch) from `cur`
+    // The pipeline: the loads of the pair after (t, ch) go out UNCONDITIONALLY in the block in front of the MFMAs of (t, ch) (round 6).  Until then they sat
+    // under `if (t2 < tiles)`: at the join the compiler cannot know whether eight more loads are outstanding, so the MFMAs' waits counted down to
+    // vmcnt(0) — the set just requested had to land before the current one was finished, one memory latency per chunk whatever was in flight
+    // (profiles/r06/stream_loop_waits.txt).  The loop below decides first whether a next pair exists and only then issues + computes.
     // (all four chunks of a one-item wave requested before the staging — Dia's down projection — measured equal: profiles/r05/dia_step_kernels_call17_deep_rejected.txt;
     //  that launch is bound by its staging volume: every workgroup re-reads its slice of the gate | up slabs, 64 MB through L2 beside 33.5 MB of weights)
-    auto step = [&](half8 (&cur)[8], half8 (&nxt)[8]) {
-        int t2 = t, ch2 = ch + 1;
-        if (ch2 == nc) { ch2 = 0; t2 = t + tstep; }
-        if (t2 < tiles) loadw(nxt, t2, ch2);
+    auto compute = [&](half8 (&cur)[8]) __attribute__((always_inline)) {   // the MFMAs of (t, ch); the tile's epilogue behind its last chunk
         const _Float16 *xp = xb + ch * 256;
 #pragma unroll
         for (int c = 0; c < 8; c++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[c], *(const half8 *) (xp + c * 32), acc, 0, 0, 0);
-        if (ch2 == 0) {
+        if (ch == nc - 1) {
             if (li < a.R) gemm_epilogue4(a, EPI, li, t * 16 + g * 4, acc, kz);
             acc = (float4v){0.f, 0.f, 0.f, 0.f};
         }
-        t = t2; ch = ch2;
     };
-    while (t < tiles) {
-        step(w0, w1);
-        if (t >= tiles) break;
-        step(w1, w0);
+    if (t < tiles) {   // (a wave without a tile requested a clamped set above and leaves)
+        int t2, ch2;
+        auto next = [&]() __attribute__((always_inline)) { t2 = t; ch2 = ch + 1; if (ch2 == nc) { ch2 = 0; t2 = t + tstep; } };
+        for (;;) {     // the pending set is w0 = (t, ch) here
+            next();
+            if (t2 >= tiles) { compute(w0); break; }
+            loadw(w1, t2, ch2);
+            __builtin_amdgcn_sched_barrier(0);   // the requests first: the scheduler otherwise sinks them behind the first MFMAs, i.e. behind the wait for the current set
+            compute(w0);
+            t = t2; ch = ch2;
+            next();
+            if (t2 >= tiles) { compute(w1); break; }
+            loadw(w0, t2, ch2);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(w1);
+            t = t2; ch = ch2;
+        }
     }
 }
 
@@ -226,7 +238,9 @@ __global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, St
             for (int c = 0; c < 4; c++) s.w[c] = __builtin_nontemporal_load((const int4v *) (p + c * 64));
         }
 #pragma unroll
-        for (int e = 0; e < 4; e++) s.d[e] = __builtin_nontemporal_load((const half8 *) (qa.wd + (int64_t) min(tile * 16 + g * 4 + e, a.N - 1) * nb + (k0 >> 5) + chunk * 8));
+        // plain loads: a feature's scales of consecutive chunks share a 128-byte line; non-temporal 16-byte pieces fetched 64 bytes from HBM per chunk each
+        // (FETCH_SIZE 618 MB for 512 MB on the LM head, profiles/r06/qstream_fetch_size.txt)
+        for (int e = 0; e < 4; e++) s.d[e] = *(const half8 *) (qa.wd + (int64_t) min(tile * 16 + g * 4 + e, a.N - 1) * nb + (k0 >> 5) + chunk * 8);
     };
     // ---- stage this slice of the Q8_0 rows: the staging requests first, the first weight sets right behind them (vmcnt retires in issue order) ----
     constexpr int NTH = NWV * 64;
@@ -282,9 +296,11 @@ __global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, St
     float4v acc[RT];
 #pragma unroll
     for (int j = 0; j < RT; j++) acc[j] = (float4v){0.f, 0.f, 0.f, 0.f};
-    auto step = [&](WSet &cur, WSet &nxt, int cslot, int nslot) __attribute__((always_inline)) {
-        if (lt < tiles) { loadw(nxt, nslot, lt, lch); inflight++; }
-        advance(lt, lch);
+    // issue: the loads of the next pair, UNCONDITIONALLY in the block that precedes the MFMAs of the current one.  Under `if (lt < tiles)` the compiler cannot
+    // know at the join whether eight more loads are outstanding and waits with vmcnt(0) for the older set — i.e. for the set just requested as well: the
+    // loop then pays the full memory latency per chunk and no prefetch depth changes anything (that was the state until call 73 of round 6).
+    auto issue = [&](WSet &nxt, int nslot) __attribute__((always_inline)) { loadw(nxt, nslot, lt, lch); inflight++; advance(lt, lch); };
+    auto compute = [&](WSet &cur, int cslot) __attribute__((always_inline)) {
         int4v wl[4];
         if constexpr (WL) {
             // the current set's DMA has landed once at most the later sets' operations are outstanding (vmcnt counts in issue order)
@@ -328,11 +344,17 @@ __global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, St
         }
         advance(t, ch);
     };
-    while (t < tiles) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++) {
-            if (d && t >= tiles) break;
-            step(w[d], w[(d + DEPTH - 1) % DEPTH], d, (d + DEPTH - 1) % DEPTH);
+    static_assert(DEPTH == 2, "the loop below is written for two register sets");
+    if (t < tiles) {   // (a wave without a tile requested a clamped set above and leaves)
+        for (;;) {     // the pending set is w[0] here
+            if (lt >= tiles) { compute(w[0], 0); break; }
+            issue(w[1], 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(w[0], 0);
+            if (lt >= tiles) { compute(w[1], 1); break; }
+            issue(w[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(w[1], 1);
         }
     }
 }
