@@ -327,6 +327,7 @@ __global__ __launch_bounds__(NWV * 64) void qgemv_stream_kernel(QGemmArgs qa, St
                     acc[j][e] += (float) zo[e] * ((float) cur.d[e][2 * c + 1] * dao);
                 }
             }
+            if (RT > 2) __builtin_amdgcn_sched_barrier(0);   // four row tiles: without the fence the scheduler keeps the MFMA results of all of them alive (256 registers + 192 bytes of scratch)
         }
         if (ch == nc - 1) {
             const int n0 = t * 16 + g * 4;

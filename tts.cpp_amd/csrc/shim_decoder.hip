@@ -430,7 +430,7 @@ int launch_qstream(tts_hip_ctx *c, int kclass, const W &w, int R, float *out, in
     qa.aq = c->aq; qa.ad = c->ad;
     const StreamMap sm{ks, (int) w.K / ks};
     const int tiles = ((int) w.N + 15) / 16, items = tiles * ks;
-    const int nwv = tiles >= 256 ? 8 : 4, rt = qstream_slab_rows(R) / 16;
+    const int rt = qstream_slab_rows(R) / 16, nwv = (tiles >= 256 && rt < 4) ? 8 : 4;   // four row tiles: the eight-wave form (256 registers per wave at most) spills
     int grid = ((items + nwv - 1) / nwv + ks - 1) / ks * ks;
     grid = std::min(grid, 1024 / ks * ks);   // beyond four workgroups per CU the waves walk several tiles (the LM head)
     const size_t lds = qstream_lds(R, sm.kslice);
