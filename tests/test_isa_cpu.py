@@ -151,3 +151,42 @@ def test_one_sequence_kernels_request_their_staging_inputs_before_the_weights(tm
             out = subprocess.run([sys.executable, tool, str(asm), "gemm16_kernelILi1ELi6E", "--first-use=v_exp_f32"], capture_output=True, text=True,
                                  check=True).stdout
             assert "gemm16_kernel" not in out, out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_streaming_kernels_prefetch_overlaps_the_current_chunk(tmp_path):
+    """Round 6 (profiles/r06/stream_loop_waits.txt): with the next chunk's loads under `if (next chunk exists)` the compiler's waits for the CURRENT chunk counted
+    down to vmcnt(0) — the chunk just requested had to land before the current one was finished, no overlap.  The loops now issue unconditionally in the block
+    in front of the MFMAs: every run of >= 8 weight loads that is followed by the MFMAs of a chunk must leave those MFMAs waiting with vmcnt >= 8 (eight loads =
+    the newer chunk may still be in flight), in the fp16 and in the integer streaming kernel."""
+    asm, remarks = _compile(tmp_path, "stream_ov", STREAM_TU)
+    text = open(asm).read()
+    checked = 0
+    for sym in ("_Z18gemv_stream_kernelILi4ELi0ELi0ELi8EE", "_Z18gemv_stream_kernelILi16ELi0ELi0ELi8EE", "_Z19qgemv_stream_kernelILi4ELi2ELi1ELb0EE", "_Z19qgemv_stream_kernelILi8ELi2ELi1ELb0EE"):
+        m = re.search(r"^" + sym + r"[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)   # (a kernel has several s_endpgm: waves without a tile leave early)
+        assert m, sym
+        lines = m.group(1).splitlines()
+        i, blocks = 0, 0
+        while i < len(lines):
+            if "global_load_dwordx4" in lines[i]:
+                j, loads = i, 0
+                while j < len(lines) and ("global_load_dwordx4" in lines[j] or not re.search(r"v_mfma|s_waitcnt vmcnt|s_cbranch|s_barrier|ds_write", lines[j])):
+                    loads += "global_load_dwordx4" in lines[j]
+                    j += 1
+                if loads >= 8 and j < len(lines):   # what follows the run: MFMAs of a chunk (the loop) or LDS writes / a barrier (the staging prologue)
+                    waits, mf, k = [], 0, j
+                    while k < len(lines) and mf < 8 and not re.search(r"s_cbranch|s_barrier|ds_write|global_load", lines[k]):
+                        w = re.search(r"s_waitcnt vmcnt\((\d+)\)", lines[k])
+                        if w:
+                            waits.append(int(w.group(1)))
+                        mf += "v_mfma" in lines[k]
+                        k += 1
+                    if mf >= 4 and waits:
+                        assert min(waits) >= 8, f"{sym}: MFMAs behind a prefetch wait with vmcnt({min(waits)}): the prefetched chunk is waited for"
+                        blocks += 1
+                i = max(j, i + 1)
+            else:
+                i += 1
+        assert blocks >= 2, (sym, blocks)
+        checked += blocks
+    assert checked >= 8
