@@ -129,6 +129,24 @@ def test_kokoro_82m_shapes_match_oracle(tune):
     eng.close()
 
 
+def test_kokoro_albert_attention_through_lds_equals_the_row_walking_kernel():
+    """kk_albert_attn64_kernel (round 6: a chunk of 64 keys staged through LDS, four rows per workgroup) keeps kk_albert_attn_kernel's arithmetic term for
+    term: the duration states of 75 phoneme ids (two key chunks, a ragged last workgroup) are bit-identical with tune("kokoro_attn_lds") = 0 and 1, and
+    the predicted lengths are the oracle's."""
+    model = synth.build_kokoro(synth.kokoro_82m())
+    cfg = model.cfg
+    rng = np.random.default_rng(75)
+    toks = np.concatenate([[0], rng.integers(1, cfg.vocab, 75), [0]]).astype(np.uint32)
+    res = {}
+    for v in (0, 1):
+        eng = hip.KokoroEngine(model, tune={"kokoro_attn_lds": v})
+        res[v] = eng.durations(toks, cfg.voices[0])
+        eng.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    ref_lens, ref_hid = orc.KokoroOracle(model).durations(toks, cfg.voices[0])
+    assert np.array_equal(res[1][0], ref_lens) and relerr(res[1][1], ref_hid) < 2e-3
+
+
 def test_kokoro_82m_projections_over_a_long_sequence():
     """40 phoneme ids at the 82M widths: from 32 rows on, ALBERT's and the predictor's projections run on kk_linear_mfma_kernel (64 x 64
     tiles of the exact-fp32 MFMA) instead of one wave per output — durations identical, duration states against the oracle"""

@@ -126,6 +126,50 @@ static __global__ __launch_bounds__(64) void kk_albert_attn_kernel(const float *
     }
 }
 
+// The same attention for head size 64 with the keys staged through LDS (round 6).  kk_albert_attn_kernel's lanes walk a K row each (256 bytes per lane, 64
+// separate lines per load instruction: 270 us per launch at 402 positions, 9 % of a synthesis); here a workgroup owns four rows of one head, a chunk of 64
+// keys is copied to LDS with coalesced loads ([64][65] floats: a lane's key row is conflict-free) and every wave takes its row's dot products from there.
+// The arithmetic is kk_albert_attn_kernel's, term for term (sequential 64-term dots, lane-strided max / sum, the value sum in key order): same results.
+static __global__ __launch_bounds__(256) void kk_albert_attn64_kernel(const float *q, const float *k, const float *v, int n, int H, float scale, float *out) {
+    extern __shared__ float kk_sm[];
+    constexpr int HS = 64, LD = 65;
+    float *ks = kk_sm;                        // [64][65] the chunk's keys
+    float *qs = ks + 64 * LD;                 // [4][64] the rows' queries
+    float *sc = qs + 4 * HS;                  // [4][n] scores -> probabilities
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.y * 4 + wave;
+    const bool live = t < n;
+    qs[wave * HS + lane] = live ? q[(int64_t) t * H + h * HS + lane] : 0.0f;
+    float *scw = sc + (size_t) wave * n;
+    float mx = -INFINITY;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        __syncthreads();                      // the previous chunk is consumed (and, first time, the queries are in place)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int idx = tid + i * 256, key = idx >> 6, e = idx & 63;
+            ks[key * LD + e] = k[(int64_t) min(j0 + key, n - 1) * H + h * HS + e];
+        }
+        __syncthreads();
+        if (live && j0 + lane < n) {
+            const float *qr = qs + wave * HS, *kr = ks + lane * LD;
+            float d = 0.0f;
+            for (int e = 0; e < HS; e++) d = __builtin_fmaf(qr[e], kr[e], d);   // explicit: the unrolled form otherwise gets some products as v_pk_mul + v_add (no contraction), kk_albert_attn_kernel's loop is all fma
+            d *= scale;
+            scw[j0 + lane] = d;
+            mx = fmaxf(mx, d);
+        }
+    }
+    if (!live) return;                        // (no barrier below)
+    mx = wave_max(mx);
+    float sum = 0.0f;
+    for (int j = lane; j < n; j += 64) { const float p = expf(scw[j] - mx); scw[j] = p; sum += p; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    float a = 0.0f;
+    for (int j = 0; j < n; j++) a = __builtin_fmaf(scw[j] * inv, v[(int64_t) j * H + h * HS + lane], a);
+    out[(int64_t) t * H + h * HS + lane] = a;
+}
+
 // ggml_gelu as the reference's CPU path evaluates it (kokoro/model.cpp:1000): tanh form through the table indexed by the fp16 bits of x,
 // i.e. x rounded to fp16 and the result rounded to fp16, 0 / x outside (-10, 10) — the same arithmetic as gelu_apply(mode 1), parler_kernels.h
 static __global__ void kk_gelu_kernel(float *x, int64_t n) {

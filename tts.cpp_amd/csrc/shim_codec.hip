@@ -1145,8 +1145,12 @@ extern "C" int tts_hip_kokoro_durations(tts_hip_ctx *c, const uint32_t *tokens, 
         k.linear(k.w(L0 + "q"), k.w(L0 + "q_bias"), x, H, N, H, H, q, H);
         k.linear(k.w(L0 + "k"), k.w(L0 + "k_bias"), x, H, N, H, H, kk, H);
         k.linear(k.w(L0 + "v"), k.w(L0 + "v_bias"), x, H, N, H, H, v, H);
-        hipLaunchKernelGGL(kk_albert_attn_kernel, dim3(NH, N), dim3(64), (size_t) N * 4, c->stream, (const float *) q, (const float *) kk, (const float *) v, N, H, hs,
-                           c->ko.attn_scale, att);
+        if (hs == 64 && c->kk_attn_lds && (size_t) (64 * 65 + 4 * 64 + 4 * N) * 4 <= 64 * 1024)   // keys staged through LDS, four rows per workgroup (tune("kokoro_attn_lds") = 0: one wave per row)
+            hipLaunchKernelGGL(kk_albert_attn64_kernel, dim3(NH, (N + 3) / 4), dim3(256), (size_t) (64 * 65 + 4 * 64 + 4 * N) * 4, c->stream, (const float *) q, (const float *) kk,
+                               (const float *) v, N, H, c->ko.attn_scale, att);
+        else
+            hipLaunchKernelGGL(kk_albert_attn_kernel, dim3(NH, N), dim3(64), (size_t) N * 4, c->stream, (const float *) q, (const float *) kk, (const float *) v, N, H, hs,
+                               c->ko.attn_scale, att);
         k.linear(k.w(L0 + "o"), k.w(L0 + "o_bias"), att, H, N, H, H, o, H);
         hipLaunchKernelGGL(kk_add_kernel, kgrid((int64_t) N * H), dim3(256), 0, c->stream, (const float *) o, (const float *) x, o, (int64_t) N * H, 1.0f);
         k.norm_rows(o, H, N, H, 1e-12f, k.w(L0 + "ffn_norm"), k.w(L0 + "ffn_norm_bias"), 0, x, H);

@@ -164,6 +164,7 @@ extern "C" int tts_hip_tune(tts_hip_ctx *c, const char *key, int v) {
     else if (k == "dac_conv1_direct") c->dac_conv1_direct = v != 0;
     else if (k == "kokoro_mfma") c->kk_mfma = v != 0;
     else if (k == "kokoro_b3") c->kk_b3 = v != 0;
+    else if (k == "kokoro_attn_lds") c->kk_attn_lds = v != 0;
     else if (k == "kokoro_split") {   // the packed planes belong to a scheme: drop them, the next convolution packs again
         if (c->kk_split != (v != 0)) { (void) hipDeviceSynchronize(); for (auto &pw : c->packed_b3) free_dev(pw.second); c->packed_b3.clear(); }
         c->kk_split = v != 0;

@@ -278,6 +278,7 @@ struct tts_hip_ctx {
     size_t kk_pool_cap = 0, kk_pool_next = 0;
     int *kk_stuck = nullptr;    // set by kk_lstm_split_kernel when a granule never arrives (bounded spin)
     bool kk_b3 = true;          // tune("kokoro_b3") = 0: Kokoro's k = 3 / 5 / 7 / 11 same-convolutions stay on the exact-fp32 MFMA kernel instead of bf16 x 3 split products
+    bool kk_attn_lds = true;    // tune("kokoro_attn_lds") = 0: ALBERT's attention as one wave per (head, row) walking the K rows from memory (kk_albert_attn_kernel)
     int kk_split = 1;           // tune("kokoro_split"): the operand split of those convolutions — 1 = fp16 hi + lo, three products (round 6), 0 = three bf16 planes, six products
     bool kk_mfma = true;        // tune("kokoro_mfma")=0: every Kokoro convolution through the one-thread-per-output kernel
     bool attn_short = true;     // tune("attn_short")=0: cross-attention through the general kernel
