@@ -77,6 +77,35 @@ def _f16_bits(x):
     return x.astype("<f2").view("<u2")
 
 
+class _Pool:
+    """Full-depth models at the real widths (tests/test_gpu_full_depth.py): minting 1.6-3.3 G fresh normals (and quantising them) costs minutes of box time, so
+    `pooled` models cut every matrix out of one buffer of 2^25 standard normals at a random offset (tiled when the matrix is longer), and quantised matrices are
+    minted as random blocks directly (codes uniform, one fp16 scale per block around std / rms(code)).  Small tensors (norms) stay fresh draws."""
+
+    def __init__(self, rng):
+        self.rng = rng
+        self.buf = rng.standard_normal(1 << 25, dtype=np.float32)
+
+    def normal(self, shape, std):
+        n = int(np.prod(shape))
+        if n <= self.buf.size:
+            off = int(self.rng.integers(0, self.buf.size - n + 1))
+            return (self.buf[off:off + n] * np.float32(std)).reshape(shape)
+        off = int(self.rng.integers(0, self.buf.size))
+        return (np.tile(self.buf, -(-(n + off) // self.buf.size))[off:off + n] * np.float32(std)).reshape(shape)
+
+    def blocks(self, shape, std, ttype):
+        nb = int(np.prod(shape)) // 32
+        width, rms = {gguf.Q4_0: (18, 4.63), gguf.Q5_0: (22, 9.24), gguf.Q8_0: (34, 73.9)}[ttype]
+        out = self.rng.integers(0, 256, size=(nb, width), dtype=np.uint8)
+        d = (np.float32(std / rms) * (0.75 + 0.5 * self.rng.random(nb, dtype=np.float32))).astype(np.float16)
+        out[:, 0:2] = d.reshape(-1, 1).view(np.uint8)
+        if ttype == gguf.Q8_0:   # -128 is not a code quantize_row_q8_0 produces
+            body = out[:, 2:]
+            body[body == 0x80] = 0x81
+        return out.reshape(-1)
+
+
 def quantize(arr, ttype):
     a = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1, 32)
     nb = a.shape[0]
@@ -561,17 +590,37 @@ def llama3_rope_factors(head_dim, base=500000.0, factor=8.0, low=1.0, high=4.0, 
     return np.array(out, dtype=np.float32)
 
 
+class _Lazy:
+    """a matrix of a pooled model: shape + std, minted by add() in the tensor's own type"""
+
+    def __init__(self, shape, std):
+        self.shape, self.std = tuple(shape), std
+
+
+def _add_pooled(tensors, pool, name, lazy, ttype):
+    ne = list(reversed(lazy.shape))
+    if ttype in (gguf.Q4_0, gguf.Q5_0, gguf.Q8_0):
+        tensors.append(gguf.Tensor(name, ttype, ne, pool.blocks(lazy.shape, lazy.std, ttype)))
+    else:
+        tensors.append(gguf.Tensor.from_array(name, pool.normal(lazy.shape, lazy.std), ttype))
+
+
 class SynthOrpheus:
-    def __init__(self, cfg: OrpheusConfig):
+    def __init__(self, cfg: OrpheusConfig, pooled=False):
         self.cfg = cfg
         rng = np.random.Generator(np.random.Philox(cfg.seed))
+        pool = _Pool(rng) if pooled else None
         self.tensors = []
         H, F, kvH = cfg.hidden, cfg.ffn, cfg.kv_heads * cfg.head_dim
 
         def normal(shape, std):
+            if pooled and len(shape) == 2:
+                return _Lazy(shape, std)
             return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
 
         def add(name, arr, quantizable=True):
+            if isinstance(arr, _Lazy):
+                return _add_pooled(self.tensors, pool, "orpheus." + name, arr, cfg.weight_type if quantizable else gguf.F32)
             arr = np.ascontiguousarray(arr, dtype=np.float32)
             ttype = cfg.weight_type if quantizable else gguf.F32
             ne = list(reversed(arr.shape))
@@ -606,8 +655,8 @@ class SynthOrpheus:
         return path
 
 
-def build_orpheus(cfg: OrpheusConfig) -> SynthOrpheus:
-    return SynthOrpheus(cfg)
+def build_orpheus(cfg: OrpheusConfig, pooled=False) -> SynthOrpheus:
+    return SynthOrpheus(cfg, pooled=pooled)
 
 
 class SynthOrpheusFull:
@@ -724,14 +773,18 @@ def dia_1_6b(**kw):
 
 
 class SynthDia:
-    def __init__(self, cfg: DiaConfig, suppress_special=False):
+    def __init__(self, cfg: DiaConfig, suppress_special=False, pooled=False):
         self.cfg = cfg
         assert cfg.enc_heads * cfg.head_dim == cfg.dec_hidden and cfg.dec_heads * cfg.head_dim == cfg.dec_hidden
         rng = np.random.Generator(np.random.Philox(cfg.seed))
+        pool = _Pool(rng) if pooled else None   # full-depth models: matrices cut out of one buffer of normals (unquantised types only)
+        assert not pooled or cfg.weight_type in (gguf.F32, gguf.F16)
         self.tensors = []
         EH, DH, A, kvH = cfg.enc_hidden, cfg.dec_hidden, cfg.dec_heads * cfg.head_dim, cfg.dec_kv_heads * cfg.head_dim
 
         def normal(shape, std):
+            if pooled and len(shape) == 2:
+                return pool.normal(shape, std)
             return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
 
         def add(name, arr, quantizable=True):
