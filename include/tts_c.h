@@ -143,6 +143,9 @@ int tts_c_single_pass_tokenize(const char *const *vocab, int n_vocab, const char
 /* the clause / chunk split of kokoro_runner::generate (:1420-1446) for a phoneme string: out receives, per chunk, its length
  * followed by its ids (bos ... eos); returns the number of uint32 written (or needed, when larger than cap) */
 int tts_c_kokoro_chunks(const char *const *vocab, int n_vocab, const char *phonemes, uint32_t max_ctx, uint32_t space_token_id, uint32_t *out, int cap);
+/* the state of the reference's noise engine (random_uniform_gen, src/util.cpp:65-71: std::default_random_engine = minstd_rand0) after k more draws:
+ * kokoro_runner::generate_batch hands every clause its stretch of the one stream this way (host/kokoro_runner.h) */
+uint32_t tts_c_minstd0_jump(uint32_t state, uint64_t k);
 
 /* ---- the quantize tool (examples/quantize/quantize_impl.h:5-15: quantization_params + quantize_gguf) ------------
  * Host only.  quantize_type is the ggml type number (F16 1, Q4_0 2, Q5_0 6, Q8_0 8; quantize.cpp:11-20). */

@@ -676,6 +676,26 @@ def test_noise_stream_restatement_matches_the_local_standard_library(tmp_path):
     assert np.array_equal(np.concatenate([a, b]), want)
 
 
+def test_noise_stream_jump_ahead_equals_drawing():
+    """kokoro_runner::generate_batch (host/kokoro_runner.cpp) gives every clause its stretch of the ONE minstd stream the reference draws source noise from
+    (util.cpp:65-71) by jumping the engine ahead: x -> 16807^k x mod 2^31 - 1.  The jump equals k draws, composes, and k = 0 is the identity."""
+    from rng_oracle import minstd0_uniform
+    L = runner.load_lib()
+    L.tts_c_minstd0_jump.restype = C.c_uint32
+    L.tts_c_minstd0_jump.argtypes = [C.c_uint32, C.c_uint64]
+    for start in (1, 48271, 2147483646):
+        assert L.tts_c_minstd0_jump(start, 0) == start
+        for k in (1, 2, 999, 5400):
+            _, st = minstd0_uniform(k, start)
+            assert L.tts_c_minstd0_jump(start, k) == st
+    big = 7 * 600 * 9 * 1200 + 13                                  # a long clause's noise: frames x 600 samples x 9 harmonics
+    x = 1
+    for _ in range(3):
+        x = L.tts_c_minstd0_jump(x, big)
+    assert x == L.tts_c_minstd0_jump(1, 3 * big) == pow(16807, 3 * big, 2147483647)
+    assert L.tts_c_minstd0_jump(1, 2147483646) == 1               # the multiplicative group's order
+
+
 @pytest.mark.parametrize("kind", ["dia", "kokoro", "orpheus"])
 def test_cpp_gguf_reader_on_the_other_architectures(tmp_path, kind):
     """the C++ reader sees every tensor (name, type, shape, bytes) and key of the Dia / Kokoro / Orpheus files the generators mint"""

@@ -942,7 +942,10 @@ static __global__ void pack_resunit_t7_kernel(const float *w7, const float *w1, 
 }
 
 // SP: the operand split (dac_kernels.h: SplitB3 = bf16 x 3 / six products, SplitH2 = fp16 hi + lo / three products, SplitH1 = fp16 / one product)
-template <int MI, int KS2, typename SP = SplitB3>
+// WDMA: the weight stages (already LDS images in memory) go memory -> LDS by global_load_lds_dwordx4 (1 KiB per wave instruction, lane-linear) instead
+// of through 16-byte registers + ds_write_b128 (13 LDS-path cycles per wave instruction, 5 per thread and stage): no staging registers, no store phase.
+__device__ __forceinline__ void dac_wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int MI, int KS2, typename SP = SplitB3, bool WDMA = false>
 __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
     constexpr int NPL = SP::NPL;
     using G = ResT7<MI>;
@@ -981,22 +984,40 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[i][e] = 0.0f;
 
-    uint4d wreg[WV];
+    constexpr int NPIECE = WST * 2 / 1024;                    // 1-KiB pieces per stage (WDMA): piece wn + 8 j is wave wn's
+    static_assert(!WDMA || (WST * 2) % 1024 == 0, "stage = whole 1-KiB pieces");
+    uint4d wreg[WDMA ? 1 : WV];
     float xreg[2][8];                                         // (group, position) units u = tid, tid + 512 of the 2 * xw <= 620 of a chunk
     auto prefetch_w = [&](int g) __attribute__((always_inline)) {
-        const uint4d *wp = wg + (int64_t) g * (WST / 8);
+        if constexpr (WDMA) {                                 // stage g lands in buffer g & 1 (free since the barrier that ended stage g - 1)
+            const char *wp = (const char *) a.w + (int64_t) g * (WST * 2) + lane * 16;
+            char *wd = (char *) (wsb + (g & 1) * WST);
 #pragma unroll
-        for (int j = 0; j < WV; j++) {
-            const int i = tid + j * NT;
-            if (i < WST / 8) wreg[j] = wp[i];
+            for (int j = 0; j < (NPIECE + 7) / 8; j++) {
+                const int pc = wn + 8 * j;
+                if (NPIECE % 8 == 0 || pc < NPIECE)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (wp + pc * 1024),
+                                                     (__attribute__((address_space(3))) void *) (wd + pc * 1024), 16, 0, 0);
+            }
+        } else {
+            const uint4d *wp = wg + (int64_t) g * (WST / 8);
+#pragma unroll
+            for (int j = 0; j < WV; j++) {
+                const int i = tid + j * NT;
+                if (i < WST / 8) wreg[j] = wp[i];
+            }
         }
     };
     auto commit_w = [&](int buf) __attribute__((always_inline)) {
-        uint4d *wd = (uint4d *) (wsb + buf * WST);
+        if constexpr (WDMA) {
+            dac_wait_vmcnt0();                                // this wave's pieces have landed; the barrier that follows publishes every wave's
+        } else {
+            uint4d *wd = (uint4d *) (wsb + buf * WST);
 #pragma unroll
-        for (int j = 0; j < WV; j++) {
-            const int i = tid + j * NT;
-            if (i < WST / 8) wd[i] = wreg[j];
+            for (int j = 0; j < WV; j++) {
+                const int i = tid + j * NT;
+                if (i < WST / 8) wd[i] = wreg[j];
+            }
         }
     };
     auto prefetch_x = [&](int c) __attribute__((always_inline)) {

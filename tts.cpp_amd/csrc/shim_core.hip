@@ -160,6 +160,7 @@ extern "C" int tts_hip_tune(tts_hip_ctx *c, const char *key, int v) {
     else if (k == "dac_split") c->dac_split = v ? 1 : 0;         // 1: fp16 hi + lo split (three products) instead of bf16 x 3 (six)
     else if (k == "dac_f16_planes") c->dac_f16_planes = v;       // 0: F16 codec tensors on the fp16 tile kernels of round 2
     else if (k == "dac_tap7") c->dac_tap7 = v;                   // 0: tap-pair k-steps in the k = 7 planes convs
+    else if (k == "dac_wdma") c->dac_wdma = v;                   // 0: weight stages through registers (rounds 3-6a)
     else if (k == "dac_b3") c->dac_b3 = std::max(0, v);
     else if (k == "dac_conv1_direct") c->dac_conv1_direct = v != 0;
     else if (k == "kokoro_mfma") c->kk_mfma = v != 0;

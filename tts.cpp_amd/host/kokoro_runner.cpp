@@ -1,8 +1,13 @@
 #include "kokoro_runner.h"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
+#include <type_traits>
 
 #include "gguf.h"
 
@@ -157,9 +162,20 @@ std::unique_ptr<tts_generation_runner> kokoro_model_loader::from_file(gguf_file 
     return std::make_unique<kokoro_runner>(hp, new single_pass_tokenizer(toks->arr_s), device, config.voice);
 }
 
-kokoro_runner::kokoro_runner(const kokoro_hparams & hp_, single_pass_tokenizer * tok, int device, const std::string & voice_)
-    : tts_generation_runner{kokoro_loader}, hp(hp_), tokenizer(tok), voice(voice_) {
-    tts_hip_kokoro_desc d{};
+kokoro_runner::kokoro_runner(const kokoro_hparams & hp_, single_pass_tokenizer * tok, int device_, const std::string & voice_)
+    : tts_generation_runner{kokoro_loader}, hp(hp_), tokenizer(tok), voice(voice_), device(device_) {
+    {
+        const tts_load_options & lo = tts_thread_load_options();
+        if (lo.share_with) {
+            share_ctx = (tts_hip_ctx *) lo.share_with->device_context();
+            if (!share_ctx) TTS_ABORT("load: share_with names a runner that cannot share its weights\n");
+        }
+        declare_only = lo.declare_only || share_ctx != nullptr;
+        const uint32_t ms = tts_load_max_seqs();
+        if (ms > 1) lanes_max = std::min<uint32_t>(ms, 16);
+        if (const char * e = getenv("TTS_KOKORO_LANES")) lanes_max = (uint32_t) std::clamp(atoi(e), 1, 16);
+    }
+    tts_hip_kokoro_desc & d = desc;
     d.struct_size = sizeof(d);
     d.n_attn_heads = hp.n_attn_heads; d.n_recurrence = hp.n_recurrence; d.n_dp_layers = hp.n_duration_prediction_layers; d.f0_n_blocks = hp.f0_n_blocks;
     d.n_conv_layers = hp.n_conv_layers; d.n_decoder_blocks = hp.n_decoder_blocks; d.n_upsamples = hp.n_upsamples; d.n_kernels = hp.n_kernels;
@@ -173,21 +189,47 @@ kokoro_runner::kokoro_runner(const kokoro_hparams & hp_, single_pass_tokenizer *
     memcpy(d.noise_res_padding, hp.noise_res_padding, sizeof(d.noise_res_padding)); memcpy(d.noise_res_dilation, hp.noise_res_dilation, sizeof(d.noise_res_dilation));
     ctx = tts_hip_kokoro_create(device, &d);
     if (!ctx) TTS_ABORT("tts_hip_kokoro_create failed: %s\n", tts_hip_last_error());
+    lanes.push_back(ctx);
     sampling_rate = 24000.0f;      // model.h:424
     supports_voices = true;
 }
 
-kokoro_runner::~kokoro_runner() { tts_hip_destroy(ctx); }
+kokoro_runner::~kokoro_runner() {
+    for (size_t i = lanes.size(); i-- > 1;) tts_hip_destroy(lanes[i]);   // arenas are reference counted: the order does not matter
+    tts_hip_destroy(ctx);
+}
+
+// lane i > 0: a further device context (own stream and scratch) declared with the same tensors and finalized on lane 0's arena
+tts_hip_ctx * kokoro_runner::lane(size_t i) {
+    while (lanes.size() <= i) {
+        tts_hip_ctx * c = tts_hip_kokoro_create(device, &desc);
+        if (!c) TTS_ABORT("tts_hip_kokoro_create (lane %zu) failed: %s\n", lanes.size(), tts_hip_last_error());
+        for (const auto & t : decls) hip_check(tts_hip_upload(c, t.name.c_str(), t.type, t.n_dims, t.ne, nullptr), t.name.c_str());
+        if (tts_hip_arena_bytes(c) != tts_hip_arena_bytes(ctx)) TTS_ABORT("kokoro lane: arena layout differs from the loaded runner's\n");
+        hip_check(tts_hip_finalize(c, tts_hip_arena_ptr(ctx)), "tts_hip_finalize(kokoro lane)");
+        hip_check(tts_hip_arena_filled(c), "tts_hip_arena_filled(kokoro lane)");
+        lanes.push_back(c);
+    }
+    return lanes[i];
+}
 
 void kokoro_runner::assign_weight(const char * name, const gguf_tensor_view & t) {
     if (strncmp(name, "kokoro.", 7) != 0) TTS_ABORT("GGML_ASSERT(name_sv.starts_with(\"kokoro.\")) failed for tensor '%s'\n", name);   // model.cpp:1329
     if (!strncmp(name, "kokoro.voice_tensors.", 21)) uploaded_voices.insert(name + 21);
     if (!strcmp(name, "kokoro.duration_predictor.encode")) duration_hidden = (uint32_t) t.ne[1];
     if (!strcmp(name, "kokoro.duration_predictor.layers.1.gamma_weight")) style_half = (uint32_t) t.ne[0];
-    hip_check(tts_hip_upload(ctx, name, t.type, t.n_dims, t.ne, t.data), name);
+    tensor_decl dcl{name, t.type, t.n_dims, {t.ne[0], t.ne[1], t.ne[2], t.ne[3]}};
+    decls.push_back(std::move(dcl));
+    // declare-only: the shape is all the device needs to lay its arena out; the bytes are another runner's (share_with) or arrive by broadcast
+    hip_check(tts_hip_upload(ctx, name, t.type, t.n_dims, t.ne, declare_only ? nullptr : t.data), name);
 }
 
 void kokoro_runner::prepare_post_load() {
+    if (share_ctx) {
+        if (tts_hip_arena_bytes(ctx) != tts_hip_arena_bytes(share_ctx)) TTS_ABORT("load: the runner to share weights with holds a different model\n");
+        hip_check(tts_hip_finalize(ctx, tts_hip_arena_ptr(share_ctx)), "tts_hip_finalize(kokoro, shared arena)");
+        hip_check(tts_hip_arena_filled(ctx), "tts_hip_arena_filled");
+    } else
     hip_check(tts_hip_finalize(ctx, nullptr), "tts_hip_finalize(kokoro)");
     if (duration_hidden == 0 || style_half == 0) TTS_ABORT("the Kokoro duration predictor tensors are missing from the GGUF file\n");
     if (voice.empty()) voice = "af_heart";   // propagate_voice_setting :1390-1396
@@ -271,4 +313,114 @@ void kokoro_runner::generate(const char * prompt, tts_response & output, const g
     if (pcm.empty()) return;
     output.data = pcm.data();
     output.n_outputs = pcm.size();
+}
+
+// ---- generate_batch: clauses of n utterances through `lanes_max` contexts on one weight arena -------------------------------------
+uint32_t minstd0_jump(uint32_t state, uint64_t k) {
+    const uint64_t m = 2147483647ull;
+    uint64_t a = 16807ull, f = 1;
+    for (; k; k >>= 1) {
+        if (k & 1) f = f * a % m;
+        a = a * a % m;
+    }
+    return (uint32_t) ((uint64_t) state * f % m);
+}
+
+static_assert(std::is_same<std::default_random_engine, std::minstd_rand0>::value, "random_uniform_gen's engine is minstd_rand0 here (util.cpp:65-71)");
+
+static uint32_t engine_state(const std::default_random_engine & e) {
+    std::default_random_engine c = e;
+    const uint32_t next = (uint32_t) c();                                   // x1 = a x0 mod m  ->  x0 = x1 a^-1 mod m  (a^-1 = a^(m - 2))
+    return minstd0_jump(next, 2147483647ull - 2);
+}
+
+void kokoro_runner::generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs, const generation_configuration & config) {
+    const size_t n = sentences.size();
+    if (n <= 1 || lanes_max <= 1) { tts_generation_runner::generate_batch(sentences, outputs, config); return; }
+    voice = config.voice.empty() ? std::string("af_heart") : config.voice;
+    if (!uploaded_voices.count(voice)) TTS_ABORT("Failed to find Kokoro voice '%s' aborting.\n", voice.c_str());
+    if (!phoneme_notice_given && !getenv("TTS_KOKORO_INPUT_IS_PHONEMES")) {
+        phoneme_notice_given = true;
+        fprintf(stderr, "kokoro: NOTE this engine has no phonemizer: the prompts are read as IPA phonemes (the reference phonemizes text first, "
+                        "kokoro/model.cpp:1415-1417).  Set TTS_KOKORO_INPUT_IS_PHONEMES=1 to silence this notice.\n");
+    }
+    // clauses in the order sequential generate() calls would run them (the cut of over-long chunks as in generate)
+    struct piece { size_t utt = 0; std::vector<uint32_t> tokens; std::vector<float> lens, hidden, pcm; size_t frames = 0; };
+    std::vector<piece> work;
+    const size_t inner_max = hp.max_context_length - 2;
+    for (size_t u = 0; u < n; u++)
+        for (const auto & tokens : kokoro_clause_chunks(hp, *tokenizer, sentences[u])) {
+            auto add = [&](std::vector<uint32_t> t) { work.emplace_back(); work.back().utt = u; work.back().tokens = std::move(t); };
+            if (tokens.size() <= hp.max_context_length) { add(tokens); continue; }
+            for (size_t at = 1; at + 1 < tokens.size(); at += inner_max) {
+                std::vector<uint32_t> p{hp.bos_token_id};
+                p.insert(p.end(), tokens.begin() + (long) at, tokens.begin() + (long) std::min(at + inner_max, tokens.size() - 1));
+                p.push_back(hp.eos_token_id);
+                add(std::move(p));
+            }
+        }
+    const size_t n_lanes = std::min<size_t>(lanes_max, work.size());
+    for (size_t i = 0; i < n_lanes; i++) lane(i);
+    // the noise stream: clause i's stretch starts where clause i - 1's ends; a lane takes its start state when every earlier clause's length is known
+    std::mutex              mu;
+    std::condition_variable cv;
+    size_t                  turn = 0;                      // clauses whose stretch has been reserved
+    uint32_t                state = engine_state(noise_engine);
+    std::atomic<size_t>     next{0};
+    std::atomic<bool>       failed{false};
+    std::string             error;
+    const size_t            per_frame = (size_t) hp.up_sampling_factor * (hp.harmonic_num + 1);
+    auto worker = [&](size_t li) {
+        tts_hip_ctx * c = lanes[li];
+        std::vector<float> noise;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= work.size()) return;
+            piece & w = work[i];
+            const uint32_t nt = (uint32_t) w.tokens.size();
+            w.lens.resize(nt);
+            w.hidden.resize((size_t) nt * (duration_hidden + style_half));
+            int rc = failed ? 1 : tts_hip_kokoro_durations(c, w.tokens.data(), nt, voice.c_str(), w.lens.data(), w.hidden.data());
+            std::string err = rc ? tts_hip_last_error() : "";
+            for (float l : w.lens) w.frames += rc ? 0 : (size_t) l;
+            uint32_t start;
+            {   // reserve the stretch in clause order, also when this clause failed (the others must not wait forever)
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return turn == i; });
+                start = state;
+                state = minstd0_jump(state, (uint64_t) w.frames * per_frame);
+                turn++;
+                if (rc && !failed.exchange(true)) error = "tts_hip_kokoro_durations failed: " + err;
+            }
+            cv.notify_all();
+            if (rc || failed) continue;
+            noise.resize(w.frames * per_frame);
+            std::default_random_engine            eng(start);
+            std::uniform_real_distribution<float> dist{0.0f, 1.0f};
+            for (auto & v : noise) v = dist(eng);
+            w.pcm.resize(w.frames * hp.up_sampling_factor);
+            rc = tts_hip_kokoro_generate(c, w.tokens.data(), nt, w.lens.data(), w.hidden.data(), voice.c_str(), noise.data(), w.pcm.data(), nullptr, nullptr);
+            if (rc) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!failed.exchange(true)) error = std::string("tts_hip_kokoro_generate failed: ") + tts_hip_last_error();
+            }
+        }
+    };
+    std::vector<std::thread> threads;
+    for (size_t li = 1; li < n_lanes; li++) threads.emplace_back(worker, li);
+    worker(0);
+    for (auto & t : threads) t.join();
+    if (failed) TTS_ABORT("%s\n", error.c_str());
+    noise_engine.seed(state);                               // as after the same utterances through generate()
+    batch_store_.assign(n, {});
+    outputs.assign(n, tts_response{});
+    last_prompt_tokens.clear();
+    last_lengths.clear();
+    for (const auto & w : work) {
+        batch_store_[w.utt].insert(batch_store_[w.utt].end(), w.pcm.begin(), w.pcm.end());
+        last_prompt_tokens.insert(last_prompt_tokens.end(), w.tokens.begin(), w.tokens.end());
+        last_lengths.insert(last_lengths.end(), w.lens.begin(), w.lens.end());
+    }
+    for (size_t u = 0; u < n; u++)
+        if (!batch_store_[u].empty()) { outputs[u].data = batch_store_[u].data(); outputs[u].n_outputs = batch_store_[u].size(); }
 }

@@ -58,6 +58,17 @@ struct kokoro_runner final : tts_generation_runner {
     void generate(const char * phonemes, tts_response & output, const generation_configuration & config) override;
     std::vector<std::string_view> list_voices() override;
 
+    // ---- extension: utterance-level concurrency inside one GPU --------------------------------------------------------------------
+    // A Kokoro synthesis is a chain of short launches (LSTM recurrences, AdaIN, iSTFT): one context leaves most of the GPU idle.  The
+    // reference's answer is N workers with a model each (examples/server/server.cpp:225-321); here generate_batch runs the clauses of
+    // n utterances through up to `lanes_max` device contexts on their own streams (a host thread each) that all read ONE weight
+    // arena.  Every utterance's audio is bit for bit that of the same utterances given to generate() one after the other: the source
+    // noise is one minstd stream in the reference (random_uniform_gen, util.cpp:65-71), so clause i takes the stretch of the stream that
+    // follows clause i - 1's (the engine is jumped ahead, x -> a^k x mod m, once the earlier clauses' durations are known).
+    void     generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs, const generation_configuration & config) override;
+    void *   device_context() const override { return ctx; }
+    uint32_t lanes_max = 4;   // tts_load_options::max_seqs / TTS_HIP_MAX_SEQS (> 1), TTS_KOKORO_LANES; 1: generate_batch = generate in a loop
+
     std::vector<uint32_t> last_prompt_tokens;   // every clause's ids of the last generate, concatenated
     std::vector<float>    last_lengths;
     bool                  phoneme_notice_given = false;
@@ -73,5 +84,16 @@ struct kokoro_runner final : tts_generation_runner {
     std::uniform_real_distribution<float>  noise_dist{0.0f, 1.0f};
 
   private:
+    struct tensor_decl { std::string name; int type, n_dims; int64_t ne[4]; };
+    std::vector<tensor_decl>   decls;               // what assign_weight saw: a further lane declares the same tensors on the same arena
+    std::vector<tts_hip_ctx *> lanes;               // lanes[0] == ctx; the others are created by the first generate_batch that needs them
+    tts_hip_kokoro_desc        desc{};
+    int                        device = 0;
+    tts_hip_ctx *              share_ctx = nullptr; // tts_load_options::share_with: this runner reads another runner's arena
+    bool                       declare_only = false;
+    tts_hip_ctx * lane(size_t i);
     void run(const std::vector<uint32_t> & tokens);
 };
+
+// the state of std::minstd_rand0 after k more draws (x -> 16807^k x mod 2^31 - 1)
+uint32_t minstd0_jump(uint32_t state, uint64_t k);

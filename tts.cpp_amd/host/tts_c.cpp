@@ -305,6 +305,8 @@ extern "C" int tts_c_kokoro_chunks(const char * const * vocab, int n_vocab, cons
     return (int) flat.size();
 }
 
+extern "C" uint32_t tts_c_minstd0_jump(uint32_t state, uint64_t k) { return minstd0_jump(state, k); }
+
 // ---- quantize tool (host/quantize.h) -------------------------------------------------------------------------
 #include "quantize.h"
 
