@@ -449,7 +449,7 @@ class TimeBudget:
     `--steps 20 --warmup 5` line (25 steps of ~11 s = 280 s before any extra) dropped the round's own feature.  Round 5: the long parts warm up on a
     48-step run of the same row count, the request stream is 2 x the rows instead of 3 x, the costs are the measured ones, and the order inside
     long_utterances is uniform, ragged_stream, ragged, uniform_same_mix (most wanted first).  With 25 steps of 11.3 s the whole line takes 519-525 s (profiles/r05/bench_driver_flags.json).  `--time-budget-s 0` = no limit."""
-    COST = {"decode_step_batch1": 5, "generate_batch1_end_to_end": 8, "secondary.kokoro": 2, "secondary.dia": 8, "secondary.orpheus": 5,
+    COST = {"decode_step_batch1": 5, "generate_batch1_end_to_end": 8, "secondary.kokoro": 15, "secondary.dia": 8, "secondary.orpheus": 5,
             "long_utterances.uniform": 60, "long_utterances.ragged_stream": 69, "long_utterances.ragged": 36, "long_utterances.uniform_same_mix": 30}
     RESERVED = 12   # the CPU baseline that still has to run after the extras of the main context
 

@@ -447,6 +447,31 @@ def run_kokoro(args):
             dt = time.perf_counter() - t0
         out["concurrent_contexts"][str(n_ctx)] = {"audio_seconds_per_sec": round(sum(box) / dt, 1), "syntheses": n_ctx * max(2, args.steps), "seconds": round(dt, 3)}
         for e in engs: e.close()
+    # the product's form of the same thing: kokoro_runner::generate_batch (host/kokoro_runner.cpp) — runner_from_file on a GGUF file, n phoneme strings in one
+    # call, their clauses through `max_seqs` device contexts on ONE weight arena, the source noise drawn on the host as the reference does (one minstd stream,
+    # handed out by jump-ahead): audio bit-equal to generate() calls in a row (tests/test_gpu_kokoro.py).  16 utterances of 400 ids x 3 frames (a duration head
+    # that predicts 3 frames per id: synth forced_frames) = 30.15 s of audio each; max_seqs = 1 is the reference's shape (one generate() after the other).
+    import tempfile
+    from tts_cpp_amd import runner as _runner
+    fmodel = synth.build_kokoro(synth.kokoro_82m(forced_frames=3))
+    with tempfile.TemporaryDirectory() as td:
+        gpath = fmodel.write_gguf(os.path.join(td, "kokoro82m.gguf"))
+        texts = ["".join(chr(0x61 + int(v)) for v in rng.integers(0, 26, 398)) for _ in range(16)]
+        os.environ["TTS_KOKORO_INPUT_IS_PHONEMES"] = "1"
+        out["runner_generate_batch"] = {}
+        first = None
+        for lanes in tuple(int(x) for x in os.environ.get("TTS_BENCH_KOKORO_LANES", "1,2,4,8").split(",") if x):
+            r = _runner.Runner(gpath, voice=cfg.voices[0].encode(), max_seqs=lanes, share_with=first)
+            first = first or r
+            r.generate_batch_sizes(texts[:max(2, lanes)], voice=cfg.voices[0].encode())      # warm-up: lanes created, planes packed
+            t0 = time.perf_counter()
+            sizes = r.generate_batch_sizes(texts, voice=cfg.voices[0].encode())
+            dt = time.perf_counter() - t0
+            out["runner_generate_batch"][str(lanes)] = {"audio_seconds_per_sec": round(sum(sizes) / 24000.0 / dt, 1), "utterances": len(texts), "seconds": round(dt, 3),
+                                                        "audio_s_per_utterance": round(sizes[0] / 24000.0, 2)}
+            if r is not first:
+                r.close()
+        first.close()
     if not args.no_cpu_baseline:
         orc = _oracle()
         o = orc.KokoroOracle(model)

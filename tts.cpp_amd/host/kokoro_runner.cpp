@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <chrono>
 #include <thread>
 #include <type_traits>
 
@@ -171,8 +172,7 @@ kokoro_runner::kokoro_runner(const kokoro_hparams & hp_, single_pass_tokenizer *
             if (!share_ctx) TTS_ABORT("load: share_with names a runner that cannot share its weights\n");
         }
         declare_only = lo.declare_only || share_ctx != nullptr;
-        const uint32_t ms = tts_load_max_seqs();
-        if (ms > 1) lanes_max = std::min<uint32_t>(ms, 16);
+        if (lo.max_seqs > 0 || getenv("TTS_HIP_MAX_SEQS")) lanes_max = std::min<uint32_t>(tts_load_max_seqs(), 16);   // an explicit 1: one context, as the reference
         if (const char * e = getenv("TTS_KOKORO_LANES")) lanes_max = (uint32_t) std::clamp(atoi(e), 1, 16);
     }
     tts_hip_kokoro_desc & d = desc;
@@ -243,6 +243,49 @@ std::vector<std::string_view> kokoro_runner::list_voices() {
     return out;
 }
 
+// ---- the source noise: ONE minstd stream (random_uniform_gen, util.cpp:65-71), drawn in parallel stretches ---------------------------
+uint32_t minstd0_jump(uint32_t state, uint64_t k) {
+    const uint64_t m = 2147483647ull;
+    uint64_t a = 16807ull, f = 1;
+    for (; k; k >>= 1) {
+        if (k & 1) f = f * a % m;
+        a = a * a % m;
+    }
+    return (uint32_t) ((uint64_t) state * f % m);
+}
+
+static_assert(std::is_same<std::default_random_engine, std::minstd_rand0>::value, "random_uniform_gen's engine is minstd_rand0 here (util.cpp:65-71)");
+
+static uint32_t engine_state(const std::default_random_engine & e) {
+    std::default_random_engine c = e;
+    const uint32_t next = (uint32_t) c();                                   // x1 = a x0 mod m  ->  x0 = x1 a^-1 mod m  (a^-1 = a^(m - 2))
+    return minstd0_jump(next, 2147483647ull - 2);
+}
+
+// out[0 .. n) = the draws an engine in `state` would give through uniform_real_distribution<float>(0, 1), by `threads` host threads: stretch j starts
+// from the state jumped ahead to its first draw and uses the standard library's own engine and distribution, so the values are the sequential ones
+// (a 400-id clause needs 6.5 M draws = 18 ms on one core, a third of a synthesis)
+static void draw_uniform(uint32_t state, size_t n, float * out, unsigned threads) {
+    auto stretch = [=](size_t a, size_t b) {
+        std::default_random_engine            eng(minstd0_jump(state, a));
+        std::uniform_real_distribution<float> dist{0.0f, 1.0f};
+        for (size_t i = a; i < b; i++) out[i] = dist(eng);
+    };
+    threads = (unsigned) std::min<size_t>(std::max(1u, threads), n / 65536 + 1);
+    if (threads <= 1) { stretch(0, n); return; }
+    const size_t per = (n + threads - 1) / threads;
+    std::vector<std::thread> th;
+    for (unsigned j = 1; j < threads; j++) th.emplace_back(stretch, std::min(n, j * per), std::min(n, (j + 1) * per));
+    stretch(0, std::min(n, per));
+    for (auto & t : th) t.join();
+}
+
+static unsigned noise_threads(unsigned lanes) {
+    if (const char * e = getenv("TTS_KOKORO_NOISE_THREADS")) return (unsigned) std::clamp(atoi(e), 1, 64);
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return std::clamp(hw / std::max(1u, lanes), 1u, 8u);
+}
+
 void kokoro_runner::run(const std::vector<uint32_t> & tokens) {
     const uint32_t n = (uint32_t) tokens.size();
     // the hidden states come back to the host and go in again, as in the reference (:1112-1113, :1261)
@@ -251,7 +294,9 @@ void kokoro_runner::run(const std::vector<uint32_t> & tokens) {
     size_t total = 0;
     for (float l : lens) total += (size_t) l;
     std::vector<float> noise(total * hp.up_sampling_factor * (hp.harmonic_num + 1));   // set_inputs :1255
-    for (auto & v : noise) v = noise_dist(noise_engine);
+    const uint32_t st = engine_state(noise_engine);
+    draw_uniform(st, noise.size(), noise.data(), noise_threads(1));
+    noise_engine.seed(minstd0_jump(st, noise.size()));                                  // the engine after noise.size() draws
     const size_t at = pcm.size();
     pcm.resize(at + total * hp.up_sampling_factor);
     hip_check(tts_hip_kokoro_generate(ctx, tokens.data(), n, lens.data(), hidden.data(), voice.c_str(), noise.data(), pcm.data() + at, nullptr, nullptr), "tts_hip_kokoro_generate");
@@ -316,23 +361,6 @@ void kokoro_runner::generate(const char * prompt, tts_response & output, const g
 }
 
 // ---- generate_batch: clauses of n utterances through `lanes_max` contexts on one weight arena -------------------------------------
-uint32_t minstd0_jump(uint32_t state, uint64_t k) {
-    const uint64_t m = 2147483647ull;
-    uint64_t a = 16807ull, f = 1;
-    for (; k; k >>= 1) {
-        if (k & 1) f = f * a % m;
-        a = a * a % m;
-    }
-    return (uint32_t) ((uint64_t) state * f % m);
-}
-
-static_assert(std::is_same<std::default_random_engine, std::minstd_rand0>::value, "random_uniform_gen's engine is minstd_rand0 here (util.cpp:65-71)");
-
-static uint32_t engine_state(const std::default_random_engine & e) {
-    std::default_random_engine c = e;
-    const uint32_t next = (uint32_t) c();                                   // x1 = a x0 mod m  ->  x0 = x1 a^-1 mod m  (a^-1 = a^(m - 2))
-    return minstd0_jump(next, 2147483647ull - 2);
-}
 
 void kokoro_runner::generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs, const generation_configuration & config) {
     const size_t n = sentences.size();
@@ -370,6 +398,10 @@ void kokoro_runner::generate_batch(const std::vector<std::string> & sentences, s
     std::atomic<bool>       failed{false};
     std::string             error;
     const size_t            per_frame = (size_t) hp.up_sampling_factor * (hp.harmonic_num + 1);
+    const unsigned n_noise_threads = noise_threads((unsigned) n_lanes);
+    const bool trace = getenv("TTS_KOKORO_BATCH_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     auto worker = [&](size_t li) {
         tts_hip_ctx * c = lanes[li];
         std::vector<float> noise;
@@ -380,7 +412,9 @@ void kokoro_runner::generate_batch(const std::vector<std::string> & sentences, s
             const uint32_t nt = (uint32_t) w.tokens.size();
             w.lens.resize(nt);
             w.hidden.resize((size_t) nt * (duration_hidden + style_half));
+            const double t0 = now();
             int rc = failed ? 1 : tts_hip_kokoro_durations(c, w.tokens.data(), nt, voice.c_str(), w.lens.data(), w.hidden.data());
+            const double t1 = now();
             std::string err = rc ? tts_hip_last_error() : "";
             for (float l : w.lens) w.frames += rc ? 0 : (size_t) l;
             uint32_t start;
@@ -394,12 +428,13 @@ void kokoro_runner::generate_batch(const std::vector<std::string> & sentences, s
             }
             cv.notify_all();
             if (rc || failed) continue;
+            const double t2 = now();
             noise.resize(w.frames * per_frame);
-            std::default_random_engine            eng(start);
-            std::uniform_real_distribution<float> dist{0.0f, 1.0f};
-            for (auto & v : noise) v = dist(eng);
+            draw_uniform(start, noise.size(), noise.data(), n_noise_threads);
             w.pcm.resize(w.frames * hp.up_sampling_factor);
+            const double t3 = now();
             rc = tts_hip_kokoro_generate(c, w.tokens.data(), nt, w.lens.data(), w.hidden.data(), voice.c_str(), noise.data(), w.pcm.data(), nullptr, nullptr);
+            if (trace) fprintf(stderr, "kokoro batch: clause %zu lane %zu  start %.1f  durations %.1f  turn %.1f  noise %.1f  generate %.1f ms\n", i, li, t0 - t_begin, t1 - t0, t2 - t1, t3 - t2, now() - t3);
             if (rc) {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!failed.exchange(true)) error = std::string("tts_hip_kokoro_generate failed: ") + tts_hip_last_error();

@@ -67,7 +67,7 @@ struct kokoro_runner final : tts_generation_runner {
     // follows clause i - 1's (the engine is jumped ahead, x -> a^k x mod m, once the earlier clauses' durations are known).
     void     generate_batch(const std::vector<std::string> & sentences, std::vector<tts_response> & outputs, const generation_configuration & config) override;
     void *   device_context() const override { return ctx; }
-    uint32_t lanes_max = 4;   // tts_load_options::max_seqs / TTS_HIP_MAX_SEQS (> 1), TTS_KOKORO_LANES; 1: generate_batch = generate in a loop
+    uint32_t lanes_max = 4;   // tts_load_options::max_seqs / TTS_HIP_MAX_SEQS when given, TTS_KOKORO_LANES; 1: generate_batch = generate in a loop
 
     std::vector<uint32_t> last_prompt_tokens;   // every clause's ids of the last generate, concatenated
     std::vector<float>    last_lengths;
@@ -81,7 +81,6 @@ struct kokoro_runner final : tts_generation_runner {
     uint32_t                               duration_hidden = 0, style_half = 0;   // from the tensor shapes (model.h:197,206 defaults 512 / 128)
     std::vector<float>                     pcm;
     std::default_random_engine             noise_engine;   // random_uniform_gen's engine (util.cpp:65-71): default seed, never reseeded
-    std::uniform_real_distribution<float>  noise_dist{0.0f, 1.0f};
 
   private:
     struct tensor_decl { std::string name; int type, n_dims; int64_t ne[4]; };

@@ -898,6 +898,7 @@ class KokoroConfig:
     harmonic_num: int = 8
     voices: tuple = ("af_test", "bm_test")
     seed: int = 0xC0C0
+    forced_frames: int = 0       # > 0 (bench models): the duration head ignores its input and predicts exactly this many frames per token (biases +-20, weights 0)
 
     @property
     def up_sampling_factor(self):
@@ -992,7 +993,11 @@ class SynthKokoro:
                 add(f"{dp}layers.{2 * l + 1}.{gb}_weight", normal((D, S), 0.3 / math.sqrt(S)))
                 add(f"{dp}layers.{2 * l + 1}.{gb}_bias", normal((D,), 0.1))
         lstm(dp + "duration_lstm", D + S, D // 2)
-        lin(dp + "duration_proj", cfg.n_durations, D, std=8.0)   # wide: the tiny model then predicts a spread of lengths
+        if cfg.forced_frames > 0:
+            add(dp + "duration_proj", np.zeros((cfg.n_durations, D), dtype=np.float32))
+            add(dp + "duration_proj_bias", np.where(np.arange(cfg.n_durations) < cfg.forced_frames, 20.0, -20.0).astype(np.float32))
+        else:
+            lin(dp + "duration_proj", cfg.n_durations, D, std=8.0)   # wide: the tiny model then predicts a spread of lengths
         lstm(dp + "shared_lstm", D + S, D // 2)
         dims = [(D, D, False), (D, D // 2, True), (D // 2, D // 2, False)][:cfg.f0_blocks]
         for br in ("f0", "n"):
