@@ -43,6 +43,7 @@ from tts_cpp_amd import dist as tdist  # noqa: E402
 from tts_cpp_amd import gguf, hip, runner, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+I8_PEAK_TOPS = 5033.6     # dense int8 MFMA = 2 x the fp16 rate (MI355X_MICROARCH.md: >= 3944 TOPS measured on 16x16x64)
 F32_PEAK_TFLOPS = 157.3   # fp32 vector == fp32-input MFMA peak
 F16_PEAK_TFLOPS = 2516.8  # dense fp16 / bf16 MFMA = 16 x the fp32 matrix rate (MI355X_MICROARCH.md); with random operands the chip sustains
                           # 1830 TFLOP/s of v_mfma_f32_32x32x16_bf16 (power-limited clock, profiles/r03/mfma_rate.txt)
@@ -387,8 +388,8 @@ def family_stats(stats):
 
 def roof_of(name, st, src, tot, arith, dac_wtype, wtype="f16"):
     """one family against the roofline that bounds it; bf16 x 3 families are priced with the flops they ISSUE against the bf16 pipe,
-    the fp32-equivalent (algorithmic) rate beside it.  With quantised decoder matrices (--wtype q*) the decoder GEMMs are qgemm16_kernel's
-    integer block dots over Q8_0-quantised rows (at most 256 rows per forward): a weight stream, priced against HBM, not the fp16 matrix pipe."""
+    the fp32-equivalent (algorithmic) rate beside it.  With quantised decoder matrices (--wtype q*) the decoder GEMMs are qgemm_tile_kernel's
+    int8 MFMA blocks over Q8_0-quantised rows, priced against the dense int8 matrix peak."""
     per_launch_ms = st["ms_total"] / max(st["launches"], 1)
     tf = st["flops_total"] / max(st["ms_total"], 1e-9) / 1e9
     gb = st["bytes_total"] / max(st["ms_total"], 1e-9) / 1e6
@@ -404,8 +405,12 @@ def roof_of(name, st, src, tot, arith, dac_wtype, wtype="f16"):
                       f"fp32 operands as three bf16 terms, six bf16 MFMAs per product, fp32 accumulate: achieved = issued bf16 flops ({mult:.2f} x "
                       "algorithmic) against the dense bf16 peak; with random operands the pipe sustains 1830 TFLOP/s (power-limited clock, profiles/r03/mfma_rate.txt)")}
     elif name in MFMA_FP16 and wtype.startswith("q"):
-        r = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 4), "int8_dot_TOPs": round(tf, 3)}
-        name = f"qgemm16_kernel (decoder GEMMs with {wtype} matrices: Q8_0-quantised rows, integer block dots)"
+        # round 6: from 65 rows on the decoder GEMMs are qgemm_tile_kernel — one v_mfma_i32_32x32x32_i8 per 32-wide quantisation block, every block's 16 i32
+        # results per lane scaled by d_w * d_a in ggml's order on the vector pipe (~48 VALU instructions per MFMA: the measured bound, profiles/r06/valu_rate.txt)
+        r = {"bound": "mfma", "achieved": round(tf, 3), "peak": I8_PEAK_TOPS, "unit": "TFLOP/s", "frac": round(tf / I8_PEAK_TOPS, 4),
+             "hbm_GBps": round(gb, 1), "hbm_frac": round(gb / HBM_PEAK_GBS, 4),
+             "note": "int8 ops against the dense int8 MFMA peak (TOP/s); the kernel is bound by the per-block fp32 scaling on the vector pipe, not by the matrix pipe"}
+        name = f"qgemm_tile_kernel (decoder GEMMs with {wtype} matrices: Q8_0-quantised rows x int8 weight codes on v_mfma_i32_32x32x32_i8, block scales on the vector pipe)"
     elif name in MFMA_FP32 or name in MFMA_FP16 or name in B3_ISSUE:
         peak = F16_PEAK_TFLOPS if (name in MFMA_FP16 or dac_wtype == "f16") else F32_PEAK_TFLOPS
         r = {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
