@@ -945,7 +945,12 @@ static __global__ void pack_resunit_t7_kernel(const float *w7, const float *w1, 
 // WDMA: the weight stages (already LDS images in memory) go memory -> LDS by global_load_lds_dwordx4 (1 KiB per wave instruction, lane-linear) instead
 // of through 16-byte registers + ds_write_b128 (13 LDS-path cycles per wave instruction, 5 per thread and stage): no staging registers, no store phase.
 __device__ __forceinline__ void dac_wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-template <int MI, int KS2, typename SP = SplitB3, bool WDMA = false>
+// VAR (bit mask):
+//   1  the waves that share a SIMD run a chunk's last stage in opposite orders — waves 0-3: MFMAs, then snake + split of the next chunk's input image;
+//      waves 4-7: the staging first, then the MFMAs (wave w and w + 4 sit on one SIMD) — so that one wave's vector work runs under the other's MFMAs
+//   2  the k = 7 accumulators are turned into the k = 1 conv's B operand ONCE (bias, snake, split; hi | lo << 16 in place) instead of once per 96-channel
+//      pass of the k = 1 conv (two passes at 192 channels); planes of 16 bits only (fp16 hi + lo, fp16)
+template <int MI, int KS2, typename SP = SplitB3, bool WDMA = false, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
     constexpr int NPL = SP::NPL;
     using G = ResT7<MI>;
@@ -1056,12 +1061,16 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
         }
     };
 
+    constexpr bool SHIFT = (VAR & 1) != 0, ONCE = (VAR & 2) != 0 && NPL <= 2;
+    const bool early = SHIFT && __builtin_amdgcn_readfirstlane(wn) >= 4;
+    RU_STAMP(0);
     prefetch_w(0);
     prefetch_x(0);
     __syncthreads();   // tables visible
     commit_w(0);
     commit_x(0, 0);
     __syncthreads();
+    RU_STAMP(1);
 
     // ---- k = 7 conv: NCH chunks of 16 input channels, SPC stages each -----------------------------------------------------------------
     for (int c = 0; c < NCH; c++) {
@@ -1072,6 +1081,7 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
             prefetch_w(g + 1);                                   // the stream continues into the k = 1 stages
             if (sub == 0 && c + 1 < NCH) prefetch_x(c + 1);
             const __bf16 *ws = wsb + (g & 1) * WST;
+            if (sub == SPC - 1 && c + 1 < NCH && early) commit_x(c + 1, (c + 1) & 1);   // the buffer was last read in chunk c - 1
             static_for<CNT>([&](auto S) __attribute__((always_inline)) {
                 constexpr int s = decltype(S)::value;
                 bf16x8d bf[NPL];
@@ -1093,10 +1103,36 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
                 }
             });
             commit_w((g + 1) & 1);
-            if (sub == SPC - 1 && c + 1 < NCH) commit_x(c + 1, (c + 1) & 1);
+            if (sub == SPC - 1 && c + 1 < NCH && !early) commit_x(c + 1, (c + 1) & 1);
             __syncthreads();
         });
     }
+    RU_STAMP(2);
+    uint32_t bop[ONCE ? MI : 1][16];   // ONCE: the k = 1 conv's B operand, planes packed hi | lo << 16 (takes the accumulators' registers over)
+    if constexpr (ONCE) {
+#pragma unroll
+        for (int i = 0; i < MI; i++)
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                float hv[8], al[8], ral[8];
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const int e = 8 * hf + m;
+                    const float4 tb = tab[32 * i + (e & 3) + 8 * (e >> 2) + 4 * hi];
+                    hv[m] = acc[i][e] + tb.x; al[m] = tb.y; ral[m] = tb.z;
+                }
+                snake_vec<8>(hv, al, ral);
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    __bf16 pv[NPL];
+                    SP::split(hv[m], pv);
+                    uint32_t w = __builtin_bit_cast(uint16_t, pv[0]);
+                    if constexpr (NPL == 2) w |= (uint32_t) __builtin_bit_cast(uint16_t, pv[NPL - 1]) << 16;
+                    bop[i][8 * hf + m] = w;
+                }
+            }
+    }
+    RU_STAMP(3);
 
     // ---- k = 1 conv: the accumulators (bias, snake, split) are its B fragments; 96 output channels per pass --------------------------
     const int t = t0 + wn * 32 + l31;
@@ -1114,21 +1150,30 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
         static_for<KS2>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value, ks = q * KS2 + s, ib = ks / 2, qq = ks % 2;
             bf16x8d bf[NPL];
-            float hv[8], al[8], ral[8];
+            if constexpr (ONCE) {
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                const int e = 8 * qq + m;
-                const int ch = 32 * ib + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                const float4 tb = tab[ch];
-                hv[m] = acc[ib][e] + tb.x; al[m] = tb.y; ral[m] = tb.z;
-            }
-            snake_vec<8>(hv, al, ral);
+                for (int m = 0; m < 8; m++) {
+                    const uint32_t w = bop[ib][8 * qq + m];
+                    bf[0][m] = __builtin_bit_cast(__bf16, (uint16_t) (w & 0xffffu));
+                    if constexpr (NPL == 2) bf[NPL - 1][m] = __builtin_bit_cast(__bf16, (uint16_t) (w >> 16));
+                }
+            } else {
+                float hv[8], al[8], ral[8];
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                __bf16 pv[NPL];
-                SP::split(hv[m], pv);
+                for (int m = 0; m < 8; m++) {
+                    const int e = 8 * qq + m;
+                    const int ch = 32 * ib + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    const float4 tb = tab[ch];
+                    hv[m] = acc[ib][e] + tb.x; al[m] = tb.y; ral[m] = tb.z;
+                }
+                snake_vec<8>(hv, al, ral);
 #pragma unroll
-                for (int pl = 0; pl < NPL; pl++) bf[pl][m] = pv[pl];
+                for (int m = 0; m < 8; m++) {
+                    __bf16 pv[NPL];
+                    SP::split(hv[m], pv);
+#pragma unroll
+                    for (int pl = 0; pl < NPL; pl++) bf[pl][m] = pv[pl];
+                }
             }
             bf16x8d af[3][NPL];
 #pragma unroll
@@ -1165,4 +1210,5 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
             }
         }
     });
+    RU_STAMP(4);
 }

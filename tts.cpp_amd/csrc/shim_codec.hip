@@ -544,7 +544,7 @@ static int launch_resunit_t(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
     HIPCHK(hipGetLastError());
     return 0;
 }
-template <int MI, int KS2, typename SP, bool WDMA>
+template <int MI, int KS2, typename SP, bool WDMA, int VAR>
 static int launch_resunit_t7_s(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
     constexpr int C = 32 * MI;
     const int xw = 256 + 6 * a.dil;
@@ -552,18 +552,19 @@ static int launch_resunit_t7_s(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
     const size_t lds = 2 * WST * 2 + (size_t) 2 * SP::NPL * 2 * xw * 8 * 2 + (size_t) C * 24;
     static std::atomic<uint64_t> attr{0};
     if (attr_needed(attr, c->device)) {
-        HIPCHK(hipFuncSetAttribute((const void *) resunit_t7_kernel<MI, KS2, SP, WDMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) resunit_t7_kernel<MI, KS2, SP, WDMA, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    hipLaunchKernelGGL((resunit_t7_kernel<MI, KS2, SP, WDMA>), dim3((a.L + 255) / 256, 1, nz), dim3(512), lds, c->stream, a);
+    hipLaunchKernelGGL((resunit_t7_kernel<MI, KS2, SP, WDMA, VAR>), dim3((a.L + 255) / 256, 1, nz), dim3(512), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
+// round 6 default: weight stages by global_load_lds, the k = 1 conv's B operand made once (dac_wdma = 1, VAR 2); tune("dac_wdma") = 0: the round-5 form
 template <int MI, int KS2>
 static int launch_resunit_t7(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
     const int sc = dac_scheme(c);
     if (c->dac_wdma)
-        return sc == 0 ? launch_resunit_t7_s<MI, KS2, SplitB3, true>(c, a, nz) : sc == 1 ? launch_resunit_t7_s<MI, KS2, SplitH2, true>(c, a, nz) : launch_resunit_t7_s<MI, KS2, SplitH1, true>(c, a, nz);
-    return sc == 0 ? launch_resunit_t7_s<MI, KS2, SplitB3, false>(c, a, nz) : sc == 1 ? launch_resunit_t7_s<MI, KS2, SplitH2, false>(c, a, nz) : launch_resunit_t7_s<MI, KS2, SplitH1, false>(c, a, nz);
+        return sc == 0 ? launch_resunit_t7_s<MI, KS2, SplitB3, true, 0>(c, a, nz) : sc == 1 ? launch_resunit_t7_s<MI, KS2, SplitH2, true, 2>(c, a, nz) : launch_resunit_t7_s<MI, KS2, SplitH1, true, 2>(c, a, nz);
+    return sc == 0 ? launch_resunit_t7_s<MI, KS2, SplitB3, false, 0>(c, a, nz) : sc == 1 ? launch_resunit_t7_s<MI, KS2, SplitH2, false, 0>(c, a, nz) : launch_resunit_t7_s<MI, KS2, SplitH1, false, 0>(c, a, nz);
 }
 static bool resunit_fused(const tts_hip_ctx *c, const DRes &r, int dil) {
     return c->dac_fuse && !(c->d.flags & TTS_HIP_FLAG_VALU_GEMM) && dil <= 9 && c->packed_ru.count(r.in_w);

@@ -266,7 +266,7 @@ struct tts_hip_ctx {
                                 // products; 0 = bf16 x 3, six products (rounds 3 - 5).  64 x 248-frame pass 132.4 -> 84.6 ms, every DAC bar held (profiles/r06/dac_split_call1.txt)
     int dac_f16_planes = 1;     // tune("dac_f16_planes")=0: F16 codec tensors stay on round 2's fp16 tile kernels (conv1d_mfma16_kernel / convt1d_mfma16_kernel) instead of the plane kernels with one fp16 plane
     int dac_tap7 = 1;           // tune("dac_tap7")=0: the k = 7 convs on planes keep the tap-pair k-steps (8 slots for 7 taps) instead of one tap per k-step
-    int dac_wdma = 1;           // tune("dac_wdma")=0: weight stages of the fused units through registers + ds_write_b128 instead of global_load_lds
+    int dac_wdma = 1;           // tune("dac_wdma")=0: the fused units as in round 5 (weight stages through registers + ds_write_b128, the k = 1 operand rebuilt per pass)
     int dac_planes = 1;         // tune("dac_planes")=0: the wide classes (channels % 128 == 0, no fused unit) keep fp32 activations and stage snake + split per tile
     bool dac_buf_user = false;  // counted in g_dac_buffers[device].users
     std::map<size_t, __bf16 *> packed_ct;   // transposed conv weight -> bf16 planes of convt_b3_kernel
