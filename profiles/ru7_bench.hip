@@ -82,9 +82,7 @@ static void bench(int n, int frames, int mult, int dil) {
         CK(hipMemset(st, 0, nwg * 5 * 8)); a.stamps = st; run<MI, KS2, WD, V>(a, n, 1); a.stamps = nullptr; stamps(); } while (0)
     VARIANT("regs", false, 0, true);
     VARIANT("wdma", true, 0, false);
-    VARIANT("wdma shift", true, 1, false);
     VARIANT("wdma once", true, 2, false);
-    VARIANT("wdma shift once", true, 3, false);
     CK(hipFree(x)); CK(hipFree(y)); CK(hipFree(y0)); CK(hipFree(w7)); CK(hipFree(w1)); CK(hipFree(b)); CK(hipFree(wp)); CK(hipFree(st));
 }
 

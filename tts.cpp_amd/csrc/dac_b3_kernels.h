@@ -946,10 +946,12 @@ static __global__ void pack_resunit_t7_kernel(const float *w7, const float *w1, 
 // of through 16-byte registers + ds_write_b128 (13 LDS-path cycles per wave instruction, 5 per thread and stage): no staging registers, no store phase.
 __device__ __forceinline__ void dac_wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // VAR (bit mask):
-//   1  the waves that share a SIMD run a chunk's last stage in opposite orders — waves 0-3: MFMAs, then snake + split of the next chunk's input image;
-//      waves 4-7: the staging first, then the MFMAs (wave w and w + 4 sit on one SIMD) — so that one wave's vector work runs under the other's MFMAs
-//   2  the k = 7 accumulators are turned into the k = 1 conv's B operand ONCE (bias, snake, split; hi | lo << 16 in place) instead of once per 96-channel
-//      pass of the k = 1 conv (two passes at 192 channels); planes of 16 bits only (fp16 hi + lo, fp16)
+//   2  the k = 7 accumulators are turned into the k = 1 conv's B operand ONCE (bias, snake, split; hi | lo << 16) instead of once per k-step and 96-channel
+//      pass of the k = 1 conv; planes of 16 bits only (fp16 hi + lo, fp16).  (Kept as its own array: the same bits stored back into the float accumulators
+//      were miscompiled.)
+//   Measured and removed (profiles/r06/ru7_bench_variants.txt): 1 = waves that share a SIMD run the chunk's last stage in opposite orders (staging first /
+//   MFMAs first): -4.5 % at 96 channels alone, nothing on top of 2; 4 = the staging's snake + split as straight-line code pinned between the MFMAs with
+//   sched_group_barrier (range test collected, not branched on): k = 7 phase 152.5 K -> 179.9 K cycles, slower.
 template <int MI, int KS2, typename SP = SplitB3, bool WDMA = false, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
     constexpr int NPL = SP::NPL;
@@ -1036,9 +1038,8 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
             for (int e = 0; e < 8; e++) xreg[q][e] = ok ? xg[(int64_t) (c * 16 + g * 8 + e) * LS + t] : 0.0f;
         }
     };
-    auto commit_x = [&](int c, int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
+    auto commit_x_q = [&](int c, int buf, int q) __attribute__((always_inline)) {
+        {
             const int u = tid + q * NT;
             if (u < 2 * xw) {
                 const int g = u >= xw ? 1 : 0;
@@ -1060,9 +1061,12 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
             }
         }
     };
+    auto commit_x = [&](int c, int buf) __attribute__((always_inline)) {
+        commit_x_q(c, buf, 0);
+        commit_x_q(c, buf, 1);
+    };
 
-    constexpr bool SHIFT = (VAR & 1) != 0, ONCE = (VAR & 2) != 0 && NPL <= 2;
-    const bool early = SHIFT && __builtin_amdgcn_readfirstlane(wn) >= 4;
+    constexpr bool ONCE = (VAR & 2) != 0 && NPL <= 2;
     RU_STAMP(0);
     prefetch_w(0);
     prefetch_x(0);
@@ -1081,7 +1085,6 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
             prefetch_w(g + 1);                                   // the stream continues into the k = 1 stages
             if (sub == 0 && c + 1 < NCH) prefetch_x(c + 1);
             const __bf16 *ws = wsb + (g & 1) * WST;
-            if (sub == SPC - 1 && c + 1 < NCH && early) commit_x(c + 1, (c + 1) & 1);   // the buffer was last read in chunk c - 1
             static_for<CNT>([&](auto S) __attribute__((always_inline)) {
                 constexpr int s = decltype(S)::value;
                 bf16x8d bf[NPL];
@@ -1103,7 +1106,7 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
                 }
             });
             commit_w((g + 1) & 1);
-            if (sub == SPC - 1 && c + 1 < NCH && !early) commit_x(c + 1, (c + 1) & 1);
+            if (sub == SPC - 1 && c + 1 < NCH) commit_x(c + 1, (c + 1) & 1);
             __syncthreads();
         });
     }
