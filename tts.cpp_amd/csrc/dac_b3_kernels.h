@@ -952,6 +952,8 @@ __device__ __forceinline__ void dac_wait_vmcnt0() { asm volatile("s_waitcnt vmcn
 //   Measured and removed (profiles/r06/ru7_bench_variants.txt): 1 = waves that share a SIMD run the chunk's last stage in opposite orders (staging first /
 //   MFMAs first): -4.5 % at 96 channels alone, nothing on top of 2; 4 = the staging's snake + split as straight-line code pinned between the MFMAs with
 //   sched_group_barrier (range test collected, not branched on): k = 7 phase 152.5 K -> 179.9 K cycles, slower.
+//   8 = the operand built tile by tile between the first pass's MFMAs, the SIMD's two waves one tile apart: 6.95 -> 7.41 ms at 192 channels; 16 = the 12 .. 108
+//   halo units beyond 512 as one element per lane: -0.5 % at dilation 1, +1-2 % at dilation 9.  Whatever mixes vector work into the MFMA stream loses here.
 template <int MI, int KS2, typename SP = SplitB3, bool WDMA = false, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
     constexpr int NPL = SP::NPL;
