@@ -83,9 +83,6 @@ static void bench(int n, int frames, int mult, int dil) {
     VARIANT("regs", false, 0, true);
     VARIANT("wdma", true, 0, false);
     VARIANT("wdma once", true, 2, false);
-    VARIANT("wdma once lazy", true, 10, false);
-    VARIANT("wdma once halo1", true, 18, false);
-    VARIANT("wdma once lazy halo1", true, 26, false);
     CK(hipFree(x)); CK(hipFree(y)); CK(hipFree(y0)); CK(hipFree(w7)); CK(hipFree(w1)); CK(hipFree(b)); CK(hipFree(wp)); CK(hipFree(st));
 }
 

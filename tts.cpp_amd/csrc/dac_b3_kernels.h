@@ -997,7 +997,6 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
     static_assert(!WDMA || (WST * 2) % 1024 == 0, "stage = whole 1-KiB pieces");
     uint4d wreg[WDMA ? 1 : WV];
     float xreg[2][8];                                         // (group, position) units u = tid, tid + 512 of the 2 * xw <= 620 of a chunk
-    constexpr bool HALO1 = (VAR & 16) != 0;
     auto prefetch_w = [&](int g) __attribute__((always_inline)) {
         if constexpr (WDMA) {                                 // stage g lands in buffer g & 1 (free since the barrier that ended stage g - 1)
             const char *wp = (const char *) a.w + (int64_t) g * (WST * 2) + lane * 16;
@@ -1033,15 +1032,6 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
     auto prefetch_x = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            if (HALO1 && q == 1) {   // the 12 .. 108 units beyond 512: one ELEMENT per lane (elements tid, tid + 512 of the (2 xw - 512) * 8)
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const int j = tid + k * NT, uh = NT + (j >> 3), e = j & 7;
-                    const int g = uh >= xw ? 1 : 0, t = t0 + (uh - g * xw) - a.pad;
-                    xreg[1][k] = (uh < 2 * xw && t >= 0 && t < L) ? xg[(int64_t) (c * 16 + g * 8 + e) * LS + t] : 0.0f;
-                }
-                continue;
-            }
             const int u = tid + q * NT;
             const int g = u >= xw ? 1 : 0, p = u - g * xw;   // lanes run along positions: coalesced rows
             const int t = t0 + p - a.pad;
@@ -1051,20 +1041,7 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
         }
     };
     auto commit_x_q = [&](int c, int buf, int q) __attribute__((always_inline)) {
-        if (HALO1 && q == 1) {
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int j = tid + k * NT, uh = NT + (j >> 3), e = j & 7;
-                if (uh < 2 * xw) {
-                    const float2 t2 = tin[c * 16 + (uh >= xw ? 8 : 0) + e];
-                    __bf16 pv[NPL];
-                    SP::split(snake_f(xreg[1][k], t2.x, t2.y), pv);
-                    __bf16 *xd = xsb + buf * NPL * xpl + uh * 8 + e;
-#pragma unroll
-                    for (int pl = 0; pl < NPL; pl++) xd[pl * xpl] = pv[pl];
-                }
-            }
-        } else {
+        {
             const int u = tid + q * NT;
             if (u < 2 * xw) {
                 const int g = u >= xw ? 1 : 0;
@@ -1137,36 +1114,28 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
     }
     RU_STAMP(2);
     uint32_t bop[ONCE ? MI : 1][16];   // ONCE: the k = 1 conv's B operand, planes packed hi | lo << 16 (takes the accumulators' registers over)
-    auto make_bop = [&](auto TI) __attribute__((always_inline)) {   // tile i of the accumulators -> bias, snake, split
-        constexpr int i = decltype(TI)::value;
+    if constexpr (ONCE) {
 #pragma unroll
-        for (int hf = 0; hf < 2; hf++) {
-            float hv[8], al[8], ral[8];
+        for (int i = 0; i < MI; i++)
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                const int e = 8 * hf + m;
-                const float4 tb = tab[32 * i + (e & 3) + 8 * (e >> 2) + 4 * hi];
-                hv[m] = acc[i][e] + tb.x; al[m] = tb.y; ral[m] = tb.z;
+            for (int hf = 0; hf < 2; hf++) {
+                float hv[8], al[8], ral[8];
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const int e = 8 * hf + m;
+                    const float4 tb = tab[32 * i + (e & 3) + 8 * (e >> 2) + 4 * hi];
+                    hv[m] = acc[i][e] + tb.x; al[m] = tb.y; ral[m] = tb.z;
+                }
+                snake_vec<8>(hv, al, ral);
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    __bf16 pv[NPL];
+                    SP::split(hv[m], pv);
+                    uint32_t w = __builtin_bit_cast(uint16_t, pv[0]);
+                    if constexpr (NPL == 2) w |= (uint32_t) __builtin_bit_cast(uint16_t, pv[NPL - 1]) << 16;
+                    bop[i][8 * hf + m] = w;
+                }
             }
-            snake_vec<8>(hv, al, ral);
-#pragma unroll
-            for (int m = 0; m < 8; m++) {
-                __bf16 pv[NPL];
-                SP::split(hv[m], pv);
-                uint32_t w = __builtin_bit_cast(uint16_t, pv[0]);
-                if constexpr (NPL == 2) w |= (uint32_t) __builtin_bit_cast(uint16_t, pv[NPL - 1]) << 16;
-                bop[i][8 * hf + m] = w;
-            }
-        }
-    };
-    // LAZY: tile i + 1 (waves 0-3) or i + 2 (waves 4-7, which start with two tiles) is turned into the operand after the first pass's MFMAs on tile i,
-    // so that on a SIMD one wave's vector work meets the other wave's MFMAs instead of both doing the same thing at the same time
-    constexpr bool LAZY = ONCE && (VAR & 8) != 0;
-    const bool lead = LAZY && __builtin_amdgcn_readfirstlane(wn) >= 4;
-    if constexpr (ONCE && !LAZY) static_for<MI>([&](auto TI) __attribute__((always_inline)) { make_bop(TI); });
-    if constexpr (LAZY) {
-        make_bop(std::integral_constant<int, 0>{});
-        if (lead) make_bop(std::integral_constant<int, 1>{});
     }
     RU_STAMP(3);
 
@@ -1222,10 +1191,6 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
 #pragma unroll
                 for (int ii = 0; ii < 3; ii++)
                     acc2[ii] = SP::mfma(af[ii][SP::ta(tm)], bf[SP::tb(tm)], acc2[ii]);
-            if constexpr (LAZY && p == 0 && qq == 1) {
-                if (lead) { if constexpr (ib + 2 < MI) make_bop(std::integral_constant<int, ib + 2 < MI ? ib + 2 : 0>{}); }
-                else { if constexpr (ib + 1 < MI) make_bop(std::integral_constant<int, ib + 1 < MI ? ib + 1 : 0>{}); }
-            }
         });
         if constexpr (g2 + 1 < N1) {
             commit_w((N7 + g2 + 1) & 1);
