@@ -146,6 +146,9 @@ int tts_c_kokoro_chunks(const char *const *vocab, int n_vocab, const char *phone
 /* the state of the reference's noise engine (random_uniform_gen, src/util.cpp:65-71: std::default_random_engine = minstd_rand0) after k more draws:
  * kokoro_runner::generate_batch hands every clause its stretch of the one stream this way (host/kokoro_runner.h) */
 uint32_t tts_c_minstd0_jump(uint32_t state, uint64_t k);
+/* n draws of that engine through std::uniform_real_distribution<float>(0, 1) from `state`, drawn as `threads` parallel stretches (what the runner does for a
+ * clause's source noise); returns the state afterwards */
+uint32_t tts_c_minstd0_uniform(uint32_t state, uint64_t n, float *out, uint32_t threads);
 
 /* ---- the quantize tool (examples/quantize/quantize_impl.h:5-15: quantization_params + quantize_gguf) ------------
  * Host only.  quantize_type is the ggml type number (F16 1, Q4_0 2, Q5_0 6, Q8_0 8; quantize.cpp:11-20). */

@@ -694,6 +694,19 @@ def test_noise_stream_jump_ahead_equals_drawing():
         x = L.tts_c_minstd0_jump(x, big)
     assert x == L.tts_c_minstd0_jump(1, 3 * big) == pow(16807, 3 * big, 2147483647)
     assert L.tts_c_minstd0_jump(1, 2147483646) == 1               # the multiplicative group's order
+    # a clause's noise drawn as parallel stretches (the standard library's own engine and distribution from jumped states) is the sequential stream
+    L.tts_c_minstd0_uniform.restype = C.c_uint32
+    L.tts_c_minstd0_uniform.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_float), C.c_uint32]
+    n = 3 * 65536 + 4321
+    want, st = minstd0_uniform(5000, 12345)
+    for threads in (1, 2, 7):
+        out = np.empty(n, dtype=np.float32)
+        end = L.tts_c_minstd0_uniform(12345, n, out.ctypes.data_as(C.POINTER(C.c_float)), threads)
+        assert np.array_equal(out[:5000], want) and end == L.tts_c_minstd0_jump(12345, n)
+        if threads == 1:
+            ref = out
+        else:
+            assert np.array_equal(out, ref), threads
 
 
 @pytest.mark.parametrize("kind", ["dia", "kokoro", "orpheus"])

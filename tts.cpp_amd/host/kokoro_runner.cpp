@@ -265,7 +265,7 @@ static uint32_t engine_state(const std::default_random_engine & e) {
 // out[0 .. n) = the draws an engine in `state` would give through uniform_real_distribution<float>(0, 1), by `threads` host threads: stretch j starts
 // from the state jumped ahead to its first draw and uses the standard library's own engine and distribution, so the values are the sequential ones
 // (a 400-id clause needs 6.5 M draws = 18 ms on one core, a third of a synthesis)
-static void draw_uniform(uint32_t state, size_t n, float * out, unsigned threads) {
+void minstd0_draw_uniform(uint32_t state, size_t n, float * out, unsigned threads) {
     auto stretch = [=](size_t a, size_t b) {
         std::default_random_engine            eng(minstd0_jump(state, a));
         std::uniform_real_distribution<float> dist{0.0f, 1.0f};
@@ -295,7 +295,7 @@ void kokoro_runner::run(const std::vector<uint32_t> & tokens) {
     for (float l : lens) total += (size_t) l;
     std::vector<float> noise(total * hp.up_sampling_factor * (hp.harmonic_num + 1));   // set_inputs :1255
     const uint32_t st = engine_state(noise_engine);
-    draw_uniform(st, noise.size(), noise.data(), noise_threads(1));
+    minstd0_draw_uniform(st, noise.size(), noise.data(), noise_threads(1));
     noise_engine.seed(minstd0_jump(st, noise.size()));                                  // the engine after noise.size() draws
     const size_t at = pcm.size();
     pcm.resize(at + total * hp.up_sampling_factor);
@@ -430,7 +430,7 @@ void kokoro_runner::generate_batch(const std::vector<std::string> & sentences, s
             if (rc || failed) continue;
             const double t2 = now();
             noise.resize(w.frames * per_frame);
-            draw_uniform(start, noise.size(), noise.data(), n_noise_threads);
+            minstd0_draw_uniform(start, noise.size(), noise.data(), n_noise_threads);
             w.pcm.resize(w.frames * hp.up_sampling_factor);
             const double t3 = now();
             rc = tts_hip_kokoro_generate(c, w.tokens.data(), nt, w.lens.data(), w.hidden.data(), voice.c_str(), noise.data(), w.pcm.data(), nullptr, nullptr);

@@ -96,3 +96,5 @@ struct kokoro_runner final : tts_generation_runner {
 
 // the state of std::minstd_rand0 after k more draws (x -> 16807^k x mod 2^31 - 1)
 uint32_t minstd0_jump(uint32_t state, uint64_t k);
+// out[0 .. n) = the draws an engine in `state` gives through uniform_real_distribution<float>(0, 1), drawn as `threads` parallel stretches
+void minstd0_draw_uniform(uint32_t state, size_t n, float * out, unsigned threads);

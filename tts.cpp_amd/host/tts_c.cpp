@@ -306,6 +306,10 @@ extern "C" int tts_c_kokoro_chunks(const char * const * vocab, int n_vocab, cons
 }
 
 extern "C" uint32_t tts_c_minstd0_jump(uint32_t state, uint64_t k) { return minstd0_jump(state, k); }
+extern "C" uint32_t tts_c_minstd0_uniform(uint32_t state, uint64_t n, float * out, uint32_t threads) {
+    minstd0_draw_uniform(state, (size_t) n, out, threads);
+    return minstd0_jump(state, n);
+}
 
 // ---- quantize tool (host/quantize.h) -------------------------------------------------------------------------
 #include "quantize.h"

@@ -30,7 +30,7 @@ EXPORTS = ["tts_c_default_config", "tts_c_runner_from_file", "tts_c_generate", "
            "tts_c_last_error", "tts_c_update_conditional_prompt", "tts_c_last_tokens", "tts_c_tokenize", "tts_c_sampler_sample", "tts_c_gguf_summary", "tts_c_gguf_tensor",
            "tts_c_pool_create", "tts_c_pool_set_text_encoder", "tts_c_pool_set_continuous", "tts_c_pool_set_continuous_yield_ms", "tts_c_pool_admitted_in_flight", "tts_c_pool_conditional_prompt", "tts_c_pool_submit", "tts_c_pool_wait", "tts_c_pool_release", "tts_c_pool_stats", "tts_c_pool_load_stats", "tts_c_pool_free", "tts_c_set_load_options", "tts_c_set_load_options_ex", "tts_c_runner_device_context", "tts_c_runner_tokenize",
            "tts_c_quantize_gguf", "tts_c_quantize_decision", "tts_c_quantize_rows",
-           "tts_c_dia_tokenize", "tts_c_dia_check_stopping", "tts_c_dia_adjust_output_tokens", "tts_c_single_pass_tokenize", "tts_c_kokoro_chunks", "tts_c_minstd0_jump"]
+           "tts_c_dia_tokenize", "tts_c_dia_check_stopping", "tts_c_dia_adjust_output_tokens", "tts_c_single_pass_tokenize", "tts_c_kokoro_chunks", "tts_c_minstd0_jump", "tts_c_minstd0_uniform"]
 
 _lib = None
 
