@@ -102,6 +102,27 @@ def test_kokoro_runner_from_file(tmp_path):
     r.close()
 
 
+def test_kokoro_device_pool_workers_share_one_weight_arena(tmp_path):
+    """device_pool with two workers on device 0 and a Kokoro file (the reference: every worker loads the whole model, server.cpp:316-321): the file is parsed
+    and uploaded once, the second worker's runner is loaded with share_with (kokoro_runner::device_context, declare-only tensors, finalize on the first
+    worker's arena).  Every request comes back with the number of samples its own generate() gives (the durations are deterministic; the source noise of a
+    worker depends on what that worker synthesised before, as with the reference's process-wide engine)."""
+    from tts_cpp_amd import runner
+    model = synth.build_kokoro(synth.kokoro_tiny())
+    path = model.write_gguf(str(tmp_path / "kokoro.gguf"))
+    texts = ["abc de. fgh", "hgf ed cba", "a", "cab. bac! abc? cba", "de de de de", "fgh abc. de"]
+    r = runner.Runner(path, voice=b"af_test")
+    expect = [r.generate(t, voice=b"af_test").size for t in texts]
+    r.close()
+    pool = runner.Pool(path, n_workers=2, devices=[0], max_batch=2, voice=b"af_test")
+    assert pool.load_stats() == {"weight_broadcasts": 0, "shared_arena_loads": 1}
+    ids = [pool.submit(t, voice=b"af_test") for t in texts]
+    for i, n in zip(ids, expect):
+        audio, bs, wk, err = pool.wait(i, timeout_ms=60000)
+        assert err == "" and audio.size == n and np.isfinite(audio).all() and wk in (0, 1)
+    pool.close()
+
+
 def test_kokoro_runner_generate_batch_equals_generate_calls_in_a_row(tmp_path):
     """kokoro_runner::generate_batch (VERDICT r5 item 3 for Kokoro: utterances batched inside one GPU; the reference's only concurrency is N workers with a
     model each, server.cpp:225-321): the clauses of n utterances run through `max_seqs` device contexts on their own streams, all reading ONE weight arena
