@@ -933,7 +933,9 @@ extern "C" int tts_hip_broadcast_weights_rank(tts_hip_ctx *c, const void *id128,
     if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world) return set_err("tts_hip_broadcast_weights_rank: rank %d / root %d outside world %d", rank, root, world);
     if (!c->finalized || !c->arena) return set_err("tts_hip_broadcast_weights_rank: context is not finalized");
     if (rank == root && !c->weights_present) return set_err("tts_hip_broadcast_weights_rank: the root rank holds no weights");
-    if (world == 1) return 0;
+    // a world of one has nothing to receive; TTS_HIP_RCCL_SINGLE_RANK=1 sends it through RCCL all the same (communicator of one rank, in-place broadcast):
+    // the library path — dlopen, unique id, ncclCommInitRank, ncclBroadcast on the context's stream, destroy — runs on a one-GPU box (tests/test_gpu_runner.py)
+    if (world == 1 && !getenv("TTS_HIP_RCCL_SINGLE_RANK")) return 0;
     RcclApi *api = rccl();
     if (!api) return set_err("tts_hip_broadcast_weights_rank: librccl.so could not be opened");
     HIPCHK(hipSetDevice(c->device));
