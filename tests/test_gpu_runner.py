@@ -221,6 +221,7 @@ def test_rccl_path_runs_with_a_world_of_one(monkeypatch):
     assert ident.any()                                                   # ncclGetUniqueId filled it
     rc = L.tts_hip_broadcast_weights_rank(eng.ctx, ident.ctypes.data_as(C.c_void_p), 0, 1, 0)
     assert rc == 0, L.tts_hip_last_error().decode()
+    hip.HipEngine.broadcast_weights([eng])                               # the one-process form: ncclCommInitAll over one device, grouped broadcast
     snap1 = np.empty(nbytes, dtype=np.uint8)
     assert rt.hipMemcpy(snap1.ctypes.data_as(C.c_void_p), eng.arena_ptr(), nbytes, 2) == 0
     assert np.array_equal(snap0, snap1)

@@ -886,7 +886,7 @@ extern "C" int tts_hip_broadcast_weights(tts_hip_ctx **ctxs, int n, int root) {
         for (int j = i + 1; j < n; j++)
             if (ctxs[i]->device == ctxs[j]->device)
                 return set_err("tts_hip_broadcast_weights: contexts %d and %d share device %d (contexts of one device share the arena: tts_hip_finalize(ctx, tts_hip_arena_ptr(other)))", i, j, ctxs[i]->device);
-    if (n == 1) return 0;
+    if (n == 1 && !getenv("TTS_HIP_RCCL_SINGLE_RANK")) return 0;   // (the env switch: ncclCommInitAll over one device + an in-place broadcast, see _rank below)
     RcclApi *api = rccl();
     if (!api) return set_err("tts_hip_broadcast_weights: librccl.so could not be opened (%s)", dlerror() ? dlerror() : "symbols missing");
     std::vector<int> devs((size_t) n);
