@@ -11,21 +11,21 @@
 
 static float frand(uint32_t &s) { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; }
 
-template <int MI, int KS2, bool WDMA, int VAR>
+template <int MI, int KS2, bool WDMA, int VAR, int NI = 1>
 static float run(const ResUnitArgs &a, int n, int reps) {
     using SP = SplitH2;
     constexpr int C = 32 * MI;
-    const int xw = 256 + 6 * a.dil;
+    const int xw = 256 * NI + 6 * a.dil;
     const size_t WST = (size_t) SP::NPL * ResT7<MI>::MAXCNT * 2 * C * 8;
     const size_t lds = 2 * WST * 2 + (size_t) 2 * SP::NPL * 2 * xw * 8 * 2 + (size_t) C * 24;
-    CK(hipFuncSetAttribute((const void *) resunit_t7_kernel<MI, KS2, SP, WDMA, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void *) resunit_t7_kernel<MI, KS2, SP, WDMA, VAR, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const dim3 grid((a.L + 255) / 256, 1, n);
-    hipLaunchKernelGGL((resunit_t7_kernel<MI, KS2, SP, WDMA, VAR>), grid, dim3(512), lds, 0, a);
+    const dim3 grid((a.L + 256 * NI - 1) / (256 * NI), 1, n);
+    hipLaunchKernelGGL((resunit_t7_kernel<MI, KS2, SP, WDMA, VAR, NI>), grid, dim3(512), lds, 0, a);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int r = 0; r < reps; r++) hipLaunchKernelGGL((resunit_t7_kernel<MI, KS2, SP, WDMA, VAR>), grid, dim3(512), lds, 0, a);
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL((resunit_t7_kernel<MI, KS2, SP, WDMA, VAR, NI>), grid, dim3(512), lds, 0, a);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -78,11 +78,13 @@ static void bench(int n, int frames, int mult, int dil) {
         for (size_t w = 0; w < nwg; w++) for (int k = 0; k < 4; k++) d[k] += (double) (hs[w * 5 + k + 1] - hs[w * 5 + k]);
         printf("   stamps (cycle counter ticks per workgroup, wave 0): prologue %.0f  k7 %.0f  mid-transform %.0f  k1 + epilogue %.0f\n", d[0] / nwg, d[1] / nwg, d[2] / nwg, d[3] / nwg);
     };
-#define VARIANT(name, WD, V, first) do { a.y = first ? y0 : y; a.stamps = nullptr; float ms = run<MI, KS2, WD, V>(a, n, 3); report(name, ms, first); \
-        CK(hipMemset(st, 0, nwg * 5 * 8)); a.stamps = st; run<MI, KS2, WD, V>(a, n, 1); a.stamps = nullptr; stamps(); } while (0)
+#define VARIANT(name, WD, V, first) VARIANT_NI(name, WD, V, 1, first)
+#define VARIANT_NI(name, WD, V, NIv, first) do { a.y = first ? y0 : y; a.stamps = nullptr; float ms = run<MI, KS2, WD, V, NIv>(a, n, 3); report(name, ms, first); \
+        CK(hipMemset(st, 0, nwg * 5 * 8)); a.stamps = st; run<MI, KS2, WD, V, NIv>(a, n, 1); a.stamps = nullptr; stamps(); } while (0)
     VARIANT("regs", false, 0, true);
     VARIANT("wdma", true, 0, false);
     VARIANT("wdma once", true, 2, false);
+    VARIANT_NI("wdma once ni2", true, 2, 2, false);
     CK(hipFree(x)); CK(hipFree(y)); CK(hipFree(y0)); CK(hipFree(w7)); CK(hipFree(w1)); CK(hipFree(b)); CK(hipFree(wp)); CK(hipFree(st));
 }
 

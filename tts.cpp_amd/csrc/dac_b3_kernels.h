@@ -954,17 +954,20 @@ __device__ __forceinline__ void dac_wait_vmcnt0() { asm volatile("s_waitcnt vmcn
 //   sched_group_barrier (range test collected, not branched on): k = 7 phase 152.5 K -> 179.9 K cycles, slower.
 //   8 = the operand built tile by tile between the first pass's MFMAs, the SIMD's two waves one tile apart: 6.95 -> 7.41 ms at 192 channels; 16 = the 12 .. 108
 //   halo units beyond 512 as one element per lane: -0.5 % at dilation 1, +1-2 % at dilation 9.  Whatever mixes vector work into the MFMA stream loses here.
-template <int MI, int KS2, typename SP = SplitB3, bool WDMA = false, int VAR = 0>
+// NI: position tiles of 32 per wave (workgroup = 256 NI positions).  NI = 2: a weight fragment read from LDS feeds two MFMAs instead of one, a stage carries twice
+// the MFMAs per barrier and per weight byte; needs VAR 2 (the k = 1 phase then runs once per position tile, streaming its weight stages again).
+template <int MI, int KS2, typename SP = SplitB3, bool WDMA = false, int VAR = 0, int NI = 1>
 __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
     constexpr int NPL = SP::NPL;
     using G = ResT7<MI>;
-    constexpr int C = 32 * MI, WN = 8, NT = 512, T_T = 32 * WN;
+    constexpr int C = 32 * MI, WN = 8, NT = 512, T_T = 32 * WN * NI, NQ = NI + 1;
     constexpr int SPC = G::SPC, NCH = C / 16, N7 = NCH * SPC;
     constexpr int WPL1 = KS2 * 2 * 96 * 8;
     constexpr int WST = NPL * G::MAXCNT * 2 * C * 8;          // 16-bit values per stage (stream stride and LDS buffer) >= NPL * WPL1
     constexpr int NP = MI / 3, NS1 = (C / 16) / KS2, N1 = NP * NS1;
     constexpr int WV = (WST / 8 + NT - 1) / NT;               // 16-byte vectors per thread per stage
     static_assert(NPL * WPL1 <= WST && (C / 16) % KS2 == 0 && MI % 3 == 0, "stage shapes");
+    static_assert(NI == 1 || ((VAR & 2) != 0 && NPL <= 2 && N1 % 2 == 0), "NI > 1: once-built operand, an even number of k = 1 stages");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int xw = T_T + 6 * a.dil;
     const int xpl = 2 * xw * 8;                               // bf16 per input plane of a chunk: [group 2][position][8]
@@ -987,16 +990,18 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
         tin[i] = make_float2(ai, 1.0f / ai);
     }
 
-    float16d acc[MI];
+    float16d acc[NI][MI];
 #pragma unroll
-    for (int i = 0; i < MI; i++)
+    for (int j = 0; j < NI; j++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[i][e] = 0.0f;
+        for (int i = 0; i < MI; i++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[j][i][e] = 0.0f;
 
     constexpr int NPIECE = WST * 2 / 1024;                    // 1-KiB pieces per stage (WDMA): piece wn + 8 j is wave wn's
     static_assert(!WDMA || (WST * 2) % 1024 == 0, "stage = whole 1-KiB pieces");
     uint4d wreg[WDMA ? 1 : WV];
-    float xreg[2][8];                                         // (group, position) units u = tid, tid + 512 of the 2 * xw <= 620 of a chunk
+    float xreg[NQ][8];                                        // (group, position) units u = tid, tid + 512, .. of the 2 * xw <= 512 NI + 108 of a chunk
     auto prefetch_w = [&](int g) __attribute__((always_inline)) {
         if constexpr (WDMA) {                                 // stage g lands in buffer g & 1 (free since the barrier that ended stage g - 1)
             const char *wp = (const char *) a.w + (int64_t) g * (WST * 2) + lane * 16;
@@ -1031,7 +1036,7 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
     };
     auto prefetch_x = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < NQ; q++) {
             const int u = tid + q * NT;
             const int g = u >= xw ? 1 : 0, p = u - g * xw;   // lanes run along positions: coalesced rows
             const int t = t0 + p - a.pad;
@@ -1064,8 +1069,8 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
         }
     };
     auto commit_x = [&](int c, int buf) __attribute__((always_inline)) {
-        commit_x_q(c, buf, 0);
-        commit_x_q(c, buf, 1);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) commit_x_q(c, buf, q);
     };
 
     constexpr bool ONCE = (VAR & 2) != 0 && NPL <= 2;
@@ -1089,9 +1094,11 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
             const __bf16 *ws = wsb + (g & 1) * WST;
             static_for<CNT>([&](auto S) __attribute__((always_inline)) {
                 constexpr int s = decltype(S)::value;
-                bf16x8d bf[NPL];
+                bf16x8d bf[NI][NPL];
 #pragma unroll
-                for (int pl = 0; pl < NPL; pl++) bf[pl] = *(const bf16x8d *) (xs + pl * xpl + (hi * xw + wn * 32 + l31 + (FIRST + s) * a.dil) * 8);
+                for (int j = 0; j < NI; j++)
+#pragma unroll
+                    for (int pl = 0; pl < NPL; pl++) bf[j][pl] = *(const bf16x8d *) (xs + pl * xpl + (hi * xw + (wn * NI + j) * 32 + l31 + (FIRST + s) * a.dil) * 8);
 #pragma unroll
                 for (int ig = 0; ig < MI; ig += 3) {
                     bf16x8d af[3][NPL];
@@ -1101,10 +1108,12 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
                         for (int pl = 0; pl < NPL; pl++)
                             af[ii][pl] = *(const bf16x8d *) (ws + pl * WPL7 + (((s * 2 + hi) * C) + (ig + ii) * 32 + l31) * 8);
 #pragma unroll
-                    for (int tm = 0; tm < SP::NT; tm++)
+                    for (int j = 0; j < NI; j++)
 #pragma unroll
-                        for (int ii = 0; ii < 3; ii++)
-                            acc[ig + ii] = SP::mfma(af[ii][SP::ta(tm)], bf[SP::tb(tm)], acc[ig + ii]);
+                        for (int tm = 0; tm < SP::NT; tm++)
+#pragma unroll
+                            for (int ii = 0; ii < 3; ii++)
+                                acc[j][ig + ii] = SP::mfma(af[ii][SP::ta(tm)], bf[j][SP::tb(tm)], acc[j][ig + ii]);
                 }
             });
             commit_w((g + 1) & 1);
@@ -1113,8 +1122,10 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
         });
     }
     RU_STAMP(2);
-    uint32_t bop[ONCE ? MI : 1][16];   // ONCE: the k = 1 conv's B operand, planes packed hi | lo << 16 (takes the accumulators' registers over)
+    uint32_t bop[NI][ONCE ? MI : 1][16];   // ONCE: the k = 1 conv's B operand, planes packed hi | lo << 16 (takes the accumulators' registers over)
     if constexpr (ONCE) {
+#pragma unroll
+      for (int j = 0; j < NI; j++)
 #pragma unroll
         for (int i = 0; i < MI; i++)
 #pragma unroll
@@ -1124,7 +1135,7 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
                 for (int m = 0; m < 8; m++) {
                     const int e = 8 * hf + m;
                     const float4 tb = tab[32 * i + (e & 3) + 8 * (e >> 2) + 4 * hi];
-                    hv[m] = acc[i][e] + tb.x; al[m] = tb.y; ral[m] = tb.z;
+                    hv[m] = acc[j][i][e] + tb.x; al[m] = tb.y; ral[m] = tb.z;
                 }
                 snake_vec<8>(hv, al, ral);
 #pragma unroll
@@ -1133,15 +1144,17 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
                     SP::split(hv[m], pv);
                     uint32_t w = __builtin_bit_cast(uint16_t, pv[0]);
                     if constexpr (NPL == 2) w |= (uint32_t) __builtin_bit_cast(uint16_t, pv[NPL - 1]) << 16;
-                    bop[i][8 * hf + m] = w;
+                    bop[j][i][8 * hf + m] = w;
                 }
             }
     }
     RU_STAMP(3);
 
     // ---- k = 1 conv: the accumulators (bias, snake, split) are its B fragments; 96 output channels per pass --------------------------
-    const int t = t0 + wn * 32 + l31;
     float16d acc2[3];
+    static_for<NI>([&](auto JT) __attribute__((always_inline)) {
+    constexpr int jt = decltype(JT)::value;
+    const int t = t0 + (wn * NI + jt) * 32 + l31;
     static_for<N1>([&](auto G2) __attribute__((always_inline)) {
         constexpr int g2 = decltype(G2)::value, p = g2 / NS1, q = g2 % NS1;
         if constexpr (q == 0) {
@@ -1151,6 +1164,7 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
                 for (int e = 0; e < 16; e++) acc2[i][e] = 0.0f;
         }
         if constexpr (g2 + 1 < N1) prefetch_w(N7 + g2 + 1);
+        else if constexpr (jt + 1 < NI) prefetch_w(N7);          // the next position tile streams the k = 1 stages again (N1 even: same buffers)
         const __bf16 *ws = wsb + ((N7 + g2) & 1) * WST;
         static_for<KS2>([&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value, ks = q * KS2 + s, ib = ks / 2, qq = ks % 2;
@@ -1158,7 +1172,7 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
             if constexpr (ONCE) {
 #pragma unroll
                 for (int m = 0; m < 8; m++) {
-                    const uint32_t w = bop[ib][8 * qq + m];
+                    const uint32_t w = bop[jt][ib][8 * qq + m];
                     bf[0][m] = __builtin_bit_cast(__bf16, (uint16_t) (w & 0xffffu));
                     if constexpr (NPL == 2) bf[NPL - 1][m] = __builtin_bit_cast(__bf16, (uint16_t) (w >> 16));
                 }
@@ -1169,7 +1183,7 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
                     const int e = 8 * qq + m;
                     const int ch = 32 * ib + (e & 3) + 8 * (e >> 2) + 4 * hi;
                     const float4 tb = tab[ch];
-                    hv[m] = acc[ib][e] + tb.x; al[m] = tb.y; ral[m] = tb.z;
+                    hv[m] = acc[jt][ib][e] + tb.x; al[m] = tb.y; ral[m] = tb.z;
                 }
                 snake_vec<8>(hv, al, ral);
 #pragma unroll
@@ -1192,7 +1206,7 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
                 for (int ii = 0; ii < 3; ii++)
                     acc2[ii] = SP::mfma(af[ii][SP::ta(tm)], bf[SP::tb(tm)], acc2[ii]);
         });
-        if constexpr (g2 + 1 < N1) {
+        if constexpr (g2 + 1 < N1 || jt + 1 < NI) {
             commit_w((N7 + g2 + 1) & 1);
             __syncthreads();
         }
@@ -1214,6 +1228,7 @@ __global__ __launch_bounds__(512, 2) void resunit_t7_kernel(ResUnitArgs a) {
                 }
             }
         }
+    });
     });
     RU_STAMP(4);
 }

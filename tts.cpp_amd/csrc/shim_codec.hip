@@ -544,26 +544,28 @@ static int launch_resunit_t(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
     HIPCHK(hipGetLastError());
     return 0;
 }
-template <int MI, int KS2, typename SP, bool WDMA, int VAR>
+template <int MI, int KS2, typename SP, bool WDMA, int VAR, int NI = 1>
 static int launch_resunit_t7_s(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
-    constexpr int C = 32 * MI;
-    const int xw = 256 + 6 * a.dil;
+    constexpr int C = 32 * MI, T_T = 256 * NI;
+    const int xw = T_T + 6 * a.dil;
     const size_t WST = (size_t) SP::NPL * ResT7<MI>::MAXCNT * 2 * C * 8;
     const size_t lds = 2 * WST * 2 + (size_t) 2 * SP::NPL * 2 * xw * 8 * 2 + (size_t) C * 24;
     static std::atomic<uint64_t> attr{0};
     if (attr_needed(attr, c->device)) {
-        HIPCHK(hipFuncSetAttribute((const void *) resunit_t7_kernel<MI, KS2, SP, WDMA, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *) resunit_t7_kernel<MI, KS2, SP, WDMA, VAR, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    hipLaunchKernelGGL((resunit_t7_kernel<MI, KS2, SP, WDMA, VAR>), dim3((a.L + 255) / 256, 1, nz), dim3(512), lds, c->stream, a);
+    hipLaunchKernelGGL((resunit_t7_kernel<MI, KS2, SP, WDMA, VAR, NI>), dim3((a.L + T_T - 1) / T_T, 1, nz), dim3(512), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
-// round 6 default: weight stages by global_load_lds, the k = 1 conv's B operand made once (dac_wdma = 1, VAR 2); tune("dac_wdma") = 0: the round-5 form
+// round 6 default: weight stages by global_load_lds, the k = 1 conv's B operand made once (dac_wdma = 1, VAR 2), and at 96 channels two position tiles per
+// wave (NI 2: 4.72 -> 4.47 ms per launch; at 192 channels the accumulators of two tiles do not fit); tune("dac_wdma") = 0: the round-5 form
 template <int MI, int KS2>
 static int launch_resunit_t7(tts_hip_ctx *c, const ResUnitArgs &a, int nz) {
     const int sc = dac_scheme(c);
+    constexpr int NI = MI == 3 ? 2 : 1;
     if (c->dac_wdma)
-        return sc == 0 ? launch_resunit_t7_s<MI, KS2, SplitB3, true, 0>(c, a, nz) : sc == 1 ? launch_resunit_t7_s<MI, KS2, SplitH2, true, 2>(c, a, nz) : launch_resunit_t7_s<MI, KS2, SplitH1, true, 2>(c, a, nz);
+        return sc == 0 ? launch_resunit_t7_s<MI, KS2, SplitB3, true, 0>(c, a, nz) : sc == 1 ? launch_resunit_t7_s<MI, KS2, SplitH2, true, 2, NI>(c, a, nz) : launch_resunit_t7_s<MI, KS2, SplitH1, true, 2, NI>(c, a, nz);
     return sc == 0 ? launch_resunit_t7_s<MI, KS2, SplitB3, false, 0>(c, a, nz) : sc == 1 ? launch_resunit_t7_s<MI, KS2, SplitH2, false, 0>(c, a, nz) : launch_resunit_t7_s<MI, KS2, SplitH1, false, 0>(c, a, nz);
 }
 static bool resunit_fused(const tts_hip_ctx *c, const DRes &r, int dil) {
