@@ -519,6 +519,8 @@ static int launch_conv_planes(tts_hip_ctx *c, const DacBatch &bt, const __bf16 *
         const bool tapk = c->dac_tap7 && cin % 16 == 0;
         // 64 ch x 256 pos, 4 waves.  One tap per k-step: one LDS buffer (73 KB, two workgroups per CU).  Measured and dropped (64-utterance pass,
         // k = 7 family, profiles/r03/tap7_call16.txt): 8 waves 49.9 ms (128 registers, spills), two LDS buffers 53.5 / 48.6 ms against 45.7.
+        // Round 6, fp16 hi + lo planes (48.5 KB of LDS: a third workgroup per CU would fit): compiled for three waves per SIMD (<= 168 registers from 198) the
+        // kernel spills 120 bytes per lane and the family takes 30.6 ms against 26.1 (profiles/CALLS_r06.md 107).
         if (tapk) CHK((launch_conv_b3p_t<7, 2, 2, 1, 4, 7, 2, 1>(c, a, bt.n)));
         else CHK((launch_conv_b3p_t<7, 2, 2, 1, 4, 4, 2>(c, a, bt.n)));                             // tap pairs (dac_tap7 = 0)
     } else if (cout % 256 == 0) {
